@@ -1,0 +1,88 @@
+/* sgx.h — C ABI of the MI355X-native SG-SLAM tracking hot path (libsgx.so).
+ *
+ * The reference (silencht/SG-SLAM) has no FFI layer: its Tracking / LocalMapping threads call
+ * C++ classes directly.  Each entry point below replaces one of those call sites; the C++
+ * adapters in sg_slam_amd/host/ keep the reference class signatures and forward here.
+ * All functions return SGX_OK (0) or a negative sgx_status; no C++ types cross this line.
+ * Pointers named d_* are DEVICE pointers (HBM); all others are host pointers.
+ * `stream` is a hipStream_t passed as void* (NULL = default stream).
+ */
+#ifndef SGX_H
+#define SGX_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum sgx_status {
+    SGX_OK = 0,
+    SGX_ERR_INVALID = -1,      /* bad argument */
+    SGX_ERR_UNSUPPORTED = -2,  /* geometry outside compiled limits */
+    SGX_ERR_NOMEM = -3,
+    SGX_ERR_DEVICE = -4,       /* HIP runtime error */
+    SGX_ERR_OVERFLOW = -5      /* a fixed-capacity device buffer overflowed (result not valid) */
+} sgx_status;
+
+const char *sgx_version(void);
+const char *sgx_status_string(int status);
+
+/* cv::KeyPoint (OpenCV 3.4 layout, 28 bytes) as produced by ORBextractor::operator()
+ * (reference: src/sg-slam/src/ORBextractor.cc:838-848, :1096-1104). */
+typedef struct sgx_keypoint {
+    float x, y;      /* pt, already multiplied by the level scale for octave > 0 */
+    float size;      /* (int)(31 * scale[octave]) */
+    float angle;     /* degrees in [0,360), cv::fastAtan2 of the intensity centroid */
+    float response;  /* FAST score */
+    int32_t octave;
+    int32_t class_id; /* -1 */
+} sgx_keypoint;
+
+/* ---- ORB extractor ------------------------------------------------------------------------
+ * Replaces ORB_SLAM2::ORBextractor (src/sg-slam/include/ORBextractor.h:45-111):
+ *   ctor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)   -> sgx_orb_create
+ *   operator()(image, mask [ignored], keypoints, descriptors)   -> sgx_orb_extract[_batch_dev]
+ *   GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
+ *   GetInverseScaleSigmaSquares / GetLevels / GetnFeatures         -> sgx_orb_get_tables
+ * The image size is fixed per handle (the reference re-derives level sizes per call,
+ * ORBextractor.cc:1112-1113; a Tracking instance only ever feeds one size). */
+typedef struct sgx_orb_config {
+    int32_t nfeatures;      /* ORBextractor.nFeatures  (TUM3.yaml: 1000) */
+    float scale_factor;     /* ORBextractor.scaleFactor (1.2) */
+    int32_t nlevels;        /* ORBextractor.nLevels (8) */
+    int32_t ini_th_fast;    /* ORBextractor.iniThFAST (20) */
+    int32_t min_th_fast;    /* ORBextractor.minThFAST (7) */
+    int32_t width, height;  /* gray image size (640x480) */
+    int32_t max_batch;      /* frames per batched call (device workspace is sized for this) */
+} sgx_orb_config;
+
+typedef struct sgx_orb sgx_orb;
+
+int sgx_orb_create(const sgx_orb_config *cfg, sgx_orb **out);
+void sgx_orb_destroy(sgx_orb *h);
+/* keypoint capacity per frame that callers must provide (sum of per-level quotas + slack;
+ * the octree may return up to 3 more than a level's quota, ORBextractor.cc:670-735). */
+int sgx_orb_keypoint_capacity(const sgx_orb *h);
+/* each array has nlevels entries; any pointer may be NULL */
+int sgx_orb_get_tables(const sgx_orb *h, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2,
+                       int32_t *features_per_level);
+/* Batched, device-resident.  d_gray: batch frames, each height rows of `pitch` bytes.
+ * d_kps: batch*cap keypoints, d_desc: batch*cap*32 bytes, d_count: batch int32.
+ * Asynchronous on `stream`.  cap must be >= sgx_orb_keypoint_capacity(). */
+int sgx_orb_extract_batch_dev(sgx_orb *h, const uint8_t *d_gray, int pitch, int batch,
+                              sgx_keypoint *d_kps, uint8_t *d_desc, int32_t *d_count, int cap, void *stream);
+/* Single host frame == ORBextractor::operator() (ORBextractor.cc:1045-1106).  Synchronous. */
+int sgx_orb_extract(sgx_orb *h, const uint8_t *gray, int stride, sgx_keypoint *kps, uint8_t *desc, int cap, int *n);
+/* device-side overflow/status word of the last batched call (synchronises `stream`) */
+int sgx_orb_last_status(sgx_orb *h, void *stream);
+
+/* test/diagnostic taps (synchronous, host destination) */
+int sgx_orb_debug_level_geometry(const sgx_orb *h, int level, int32_t *w, int32_t *hgt, int32_t *stride);
+int sgx_orb_debug_read_level(sgx_orb *h, int frame, int level, uint8_t *dst /* w*h, tight */);
+/* candidates of (frame, level) after per-cell FAST+NMS, unordered: x,y relative to the
+ * (16,16) border origin exactly as pushed at ORBextractor.cc:823-825; returns count in *n */
+int sgx_orb_debug_read_candidates(sgx_orb *h, int frame, int level, int32_t *x, int32_t *y, int32_t *score, int cap, int *n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

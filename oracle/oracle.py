@@ -1,0 +1,133 @@
+"""ctypes loader for oracle/liboracle.so (the CPU restatement of the reference path).
+TEST INFRASTRUCTURE ONLY — never imported by the product package."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+KP_DTYPE = np.dtype([('x', 'f4'), ('y', 'f4'), ('size', 'f4'), ('angle', 'f4'), ('response', 'f4'),
+                     ('octave', 'i4'), ('class_id', 'i4')])
+assert KP_DTYPE.itemsize == 28
+
+
+def build():
+    subprocess.check_call(['make', '-s', '-C', _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, 'liboracle.so')
+        if not os.path.exists(so):
+            build()
+        _LIB = C.CDLL(so)
+        _LIB.orc_fast_atan2.restype = C.c_float
+        _LIB.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        _LIB.orc_ic_angle.restype = C.c_float
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def orb_params(nfeatures=1000, scale=1.2, nlevels=8):
+    L = lib()
+    sc = np.zeros(nlevels, 'f4'); isc = np.zeros(nlevels, 'f4'); s2 = np.zeros(nlevels, 'f4'); is2 = np.zeros(nlevels, 'f4')
+    per = np.zeros(nlevels, 'i4'); umax = np.zeros(16, 'i4')
+    L.orc_orb_params_flat(C.c_int(nfeatures), C.c_float(scale), C.c_int(nlevels), _p(sc), _p(isc), _p(s2), _p(is2), _p(per), _p(umax))
+    return dict(scale=sc, inv_scale=isc, sigma2=s2, inv_sigma2=is2, per_level=per, umax=umax)
+
+
+def level_sizes(w, h, scale=1.2, nlevels=8):
+    p = orb_params(1000, scale, nlevels)
+    out = []
+    for l in range(nlevels):
+        s = p['inv_scale'][l]
+        out.append((int(np.rint(np.float32(w) * s)), int(np.rint(np.float32(h) * s))))
+    return out
+
+
+def resize_linear(src, dw, dh):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().orc_resize_linear_u8(_p(src), C.c_int(src.shape[1]), C.c_int(src.shape[0]), C.c_int(src.shape[1]),
+                               _p(dst), C.c_int(dw), C.c_int(dh), C.c_int(dw))
+    return dst
+
+
+def gaussian7(src):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros_like(src)
+    h, w = src.shape
+    lib().orc_gaussian7_u8(_p(src), C.c_int(w), C.c_int(h), C.c_int(w), _p(dst), C.c_int(w))
+    return dst
+
+
+def fast(img, threshold, nonmax=True):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    cap = w * h
+    ox = np.zeros(cap, 'i4'); oy = np.zeros(cap, 'i4'); os_ = np.zeros(cap, 'i4')
+    n = lib().orc_fast9_16(_p(img), C.c_int(w), C.c_int(w), C.c_int(h), C.c_int(threshold), C.c_int(int(nonmax)),
+                           _p(ox), _p(oy), _p(os_), C.c_int(cap))
+    return ox[:n].copy(), oy[:n].copy(), os_[:n].copy()
+
+
+def level_candidates(img, ini_th=20, min_th=7):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    cap = w * h // 4 + 16
+    cx = np.zeros(cap, 'f4'); cy = np.zeros(cap, 'f4'); cr = np.zeros(cap, 'f4')
+    n = lib().orc_level_candidates(_p(img), C.c_int(w), C.c_int(w), C.c_int(h), C.c_int(ini_th), C.c_int(min_th),
+                                   _p(cx), _p(cy), _p(cr), C.c_int(cap))
+    return cx[:n].copy(), cy[:n].copy(), cr[:n].copy()
+
+
+def distribute_octree(kx, ky, kr, minX, maxX, minY, maxY, N):
+    kx = np.ascontiguousarray(kx, 'f4'); ky = np.ascontiguousarray(ky, 'f4'); kr = np.ascontiguousarray(kr, 'f4')
+    cap = max(4 * N + 16, 16)
+    out = np.zeros(cap, 'i4')
+    n = lib().orc_distribute_octree(_p(kx), _p(ky), _p(kr), C.c_int(len(kx)), C.c_int(minX), C.c_int(maxX),
+                                    C.c_int(minY), C.c_int(maxY), C.c_int(N), _p(out), C.c_int(cap))
+    return out[:n].copy()
+
+
+def fast_atan2(y, x):
+    return float(lib().orc_fast_atan2(C.c_float(y), C.c_float(x)))
+
+
+def ic_angle(img, x, y, umax):
+    img = np.ascontiguousarray(img, np.uint8)
+    umax = np.ascontiguousarray(umax, 'i4')
+    return float(lib().orc_ic_angle(_p(img), C.c_int(img.shape[1]), C.c_float(x), C.c_float(y), _p(umax)))
+
+
+def descriptor(blur, x, y, angle):
+    blur = np.ascontiguousarray(blur, np.uint8)
+    d = np.zeros(32, np.uint8)
+    lib().orc_descriptor(_p(blur), C.c_int(blur.shape[1]), C.c_float(x), C.c_float(y), C.c_float(angle), _p(d))
+    return d
+
+
+def orb_extract(gray, nfeatures=1000, scale=1.2, nlevels=8, ini_th=20, min_th=7, want_pyr=False):
+    """ORBextractor::operator() restatement. Returns (keypoints[KP_DTYPE], desc[N,32] u8[, pyr, ncand])."""
+    gray = np.ascontiguousarray(gray, np.uint8)
+    h, w = gray.shape
+    cap = 4 * nfeatures + 64
+    kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8)
+    ncand = np.zeros(nlevels, 'i4')
+    pyr = None
+    if want_pyr:
+        tot = sum(a * b for a, b in level_sizes(w, h, scale, nlevels))
+        pyr = np.zeros(tot, np.uint8)
+    n = lib().orc_orb_extract(_p(gray), C.c_int(w), C.c_int(h), C.c_int(w), C.c_int(nfeatures), C.c_float(scale),
+                              C.c_int(nlevels), C.c_int(ini_th), C.c_int(min_th), _p(kps), _p(desc), C.c_int(cap),
+                              _p(pyr) if want_pyr else None, _p(ncand))
+    assert n <= cap
+    if want_pyr:
+        return kps[:n].copy(), desc[:n].copy(), pyr, ncand
+    return kps[:n].copy(), desc[:n].copy()

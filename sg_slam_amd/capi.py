@@ -1,0 +1,66 @@
+"""ctypes binding of the C-ABI declared in include/sgx.h (one Python method per entry point)."""
+import ctypes as C
+import numpy as np
+
+KP_DTYPE = np.dtype([('x', 'f4'), ('y', 'f4'), ('size', 'f4'), ('angle', 'f4'), ('response', 'f4'),
+                     ('octave', 'i4'), ('class_id', 'i4')])   # cv::KeyPoint / sgx_keypoint, 28 B
+
+
+class SgxError(RuntimeError):
+    pass
+
+
+class OrbConfig(C.Structure):
+    _fields_ = [('nfeatures', C.c_int32), ('scale_factor', C.c_float), ('nlevels', C.c_int32),
+                ('ini_th_fast', C.c_int32), ('min_th_fast', C.c_int32), ('width', C.c_int32),
+                ('height', C.c_int32), ('max_batch', C.c_int32)]
+
+
+# every symbol include/sgx.h declares (tests/test_abi.py checks the export table against this list)
+SYMBOLS = [
+    'sgx_version', 'sgx_status_string',
+    'sgx_orb_create', 'sgx_orb_destroy', 'sgx_orb_keypoint_capacity', 'sgx_orb_get_tables',
+    'sgx_orb_extract_batch_dev', 'sgx_orb_extract', 'sgx_orb_last_status',
+    'sgx_orb_debug_level_geometry', 'sgx_orb_debug_read_level', 'sgx_orb_debug_read_candidates',
+]
+
+
+def _vp(x):
+    """device/host pointer from int, numpy array or anything with data_ptr()"""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    if hasattr(x, 'data_ptr'):
+        return C.c_void_p(x.data_ptr())
+    return x.ctypes.data_as(C.c_void_p)
+
+
+class SgxLib:
+    def __init__(self, path):
+        self.path = path
+        self.dll = C.CDLL(path)
+        d = self.dll
+        d.sgx_version.restype = C.c_char_p
+        d.sgx_status_string.restype = C.c_char_p
+        d.sgx_status_string.argtypes = [C.c_int]
+        d.sgx_orb_create.argtypes = [C.POINTER(OrbConfig), C.POINTER(C.c_void_p)]
+        d.sgx_orb_destroy.argtypes = [C.c_void_p]
+        d.sgx_orb_destroy.restype = None
+        d.sgx_orb_keypoint_capacity.argtypes = [C.c_void_p]
+        d.sgx_orb_get_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+        d.sgx_orb_extract_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_int, C.c_void_p]
+        d.sgx_orb_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        d.sgx_orb_last_status.argtypes = [C.c_void_p, C.c_void_p]
+        d.sgx_orb_debug_level_geometry.argtypes = [C.c_void_p, C.c_int] + [C.POINTER(C.c_int32)] * 3
+        d.sgx_orb_debug_read_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        d.sgx_orb_debug_read_candidates.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                    C.c_int, C.POINTER(C.c_int)]
+
+    def version(self):
+        return self.dll.sgx_version().decode()
+
+    def check(self, rc, what=''):
+        if rc != 0:
+            raise SgxError(f'{what}: {self.dll.sgx_status_string(rc).decode()} ({rc})')

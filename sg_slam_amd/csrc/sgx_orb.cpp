@@ -1,0 +1,316 @@
+// sgx_orb.cpp — host side of the ORB extractor C-ABI (include/sgx.h): handle, tables, launches.
+// Compiled as HIP for gfx950 (product) or as plain C++ with -DSGX_EMU (kernel-logic emulator,
+// tests only).  Reference behaviour: src/sg-slam/src/ORBextractor.cc (cited inline).
+#include "sgx_orb_kernels.h"
+#include "../../include/sgx.h"
+#include "../../include/sgx_orb_pattern.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#ifdef SGX_EMU
+thread_local sgx_dim3 blockIdx, blockDim, gridDim;
+#endif
+
+#define SGX_CHECK_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
+    fprintf(stderr, "sgx: HIP error %d (%s) at %s:%d\n", (int)_e, hipGetErrorString(_e), __FILE__, __LINE__); return SGX_ERR_DEVICE; } } while (0)
+
+struct sgx_orb {
+    sgx_orb_config cfg;
+    SgxOrbGeom g;
+    float scale[SGX_MAX_LEVELS], inv_scale[SGX_MAX_LEVELS], sigma2[SGX_MAX_LEVELS], inv_sigma2[SGX_MAX_LEVELS];
+    int umax_h[16];
+    // device tables
+    SgxCell *d_cells = nullptr;
+    SgxXTab *d_xt[SGX_MAX_LEVELS] = {};
+    SgxYTab *d_yt[SGX_MAX_LEVELS] = {};
+    int *d_umax = nullptr;
+    signed char *d_pattern = nullptr;
+    // device workspace (sized for cfg.max_batch)
+    uint8_t *d_pyr = nullptr;
+    uint32_t *d_cand = nullptr;
+    int *d_cand_count = nullptr;
+    uint32_t *d_sel = nullptr;
+    int *d_sel_count = nullptr;
+    uint32_t *d_status = nullptr;
+    // single-frame staging for sgx_orb_extract
+    uint8_t *d_gray1 = nullptr; uint8_t *d_kps1 = nullptr; uint8_t *d_desc1 = nullptr; int *d_count1 = nullptr;
+    int last_batch = 0;
+};
+
+static inline int cvround_f(float v) { return (int)lrintf(v); }
+static inline int cvround_d(double v) { return (int)lrint(v); }
+
+// ORBextractor::ORBextractor, ORBextractor.cc:411-471 (scale tables, per-level quotas, umax)
+static void build_tables(sgx_orb *h)
+{
+    const sgx_orb_config &c = h->cfg;
+    const double sf = (double)c.scale_factor;           // member `double scaleFactor` (ORBextractor.h:99) set from a float
+    const int nl = c.nlevels;
+    h->scale[0] = 1.0f; h->sigma2[0] = 1.0f;
+    for (int i = 1; i < nl; i++) { h->scale[i] = (float)((double)h->scale[i - 1] * sf); h->sigma2[i] = h->scale[i] * h->scale[i]; }
+    for (int i = 0; i < nl; i++) { h->inv_scale[i] = 1.0f / h->scale[i]; h->inv_sigma2[i] = 1.0f / h->sigma2[i]; }
+    const float factor = (float)(1.0f / sf);
+    float want = c.nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nl));
+    int sum = 0;
+    for (int l = 0; l < nl - 1; l++) { h->g.lv[l].quota = cvround_f(want); sum += h->g.lv[l].quota; want *= factor; }
+    h->g.lv[nl - 1].quota = c.nfeatures - sum > 0 ? c.nfeatures - sum : 0;
+    // umax (:455-470)
+    int umax[17] = {0};
+    const int HP = 15;
+    const int vmax = (int)floor(HP * sqrtf(2.f) / 2 + 1), vmin = (int)ceil(HP * sqrtf(2.f) / 2);
+    for (int v = 0; v <= vmax; ++v) umax[v] = cvround_d(sqrt((double)HP * HP - v * v));
+    for (int v = HP, v0 = 0; v >= vmin; --v) { while (umax[v0] == umax[v0 + 1]) ++v0; umax[v] = v0; ++v0; }
+    for (int i = 0; i < 16; i++) h->umax_h[i] = umax[i];
+}
+
+// cv::resize coefficient tables (OpenCV 3.4 imgproc/resize.cpp, INTER_LINEAR, 8U fixed point)
+static void build_resize_tables(int sw, int sh, int dw, int dh, std::vector<SgxXTab> &xt, std::vector<SgxYTab> &yt)
+{
+    const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+    xt.resize(dw); yt.resize(dh);
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        xt[dx].sx = (short)sx; xt[dx].sx1 = (short)(sx + 1 < sw ? sx + 1 : sx);
+        xt[dx].a0 = (short)cvround_f((1.f - fx) * 2048); xt[dx].a1 = (short)cvround_f(fx * 2048);
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= sy;
+        int r0 = sy, r1 = sy + 1;
+        if (r0 < 0) r0 = 0; if (r0 > sh - 1) r0 = sh - 1;
+        if (r1 < 0) r1 = 0; if (r1 > sh - 1) r1 = sh - 1;
+        yt[dy].sy0 = (short)r0; yt[dy].sy1 = (short)r1;
+        yt[dy].b0 = (short)cvround_f((1.f - fy) * 2048); yt[dy].b1 = (short)cvround_f(fy * 2048);
+    }
+}
+
+extern "C" const char *sgx_version(void) {
+#ifdef SGX_EMU
+    return "sgx 0.1 (EMULATOR - tests only)";
+#else
+    return "sgx 0.1 (gfx950)";
+#endif
+}
+
+extern "C" const char *sgx_status_string(int s)
+{
+    switch (s) {
+    case SGX_OK: return "ok";
+    case SGX_ERR_INVALID: return "invalid argument";
+    case SGX_ERR_UNSUPPORTED: return "unsupported geometry";
+    case SGX_ERR_NOMEM: return "out of memory";
+    case SGX_ERR_DEVICE: return "HIP runtime error";
+    case SGX_ERR_OVERFLOW: return "device buffer overflow";
+    default: return "unknown";
+    }
+}
+
+extern "C" void sgx_orb_destroy(sgx_orb *h)
+{
+    if (!h) return;
+    (void)hipFree(h->d_cells); (void)hipFree(h->d_umax); (void)hipFree(h->d_pattern); (void)hipFree(h->d_pyr); (void)hipFree(h->d_cand);
+    (void)hipFree(h->d_cand_count); (void)hipFree(h->d_sel); (void)hipFree(h->d_sel_count); (void)hipFree(h->d_status);
+    (void)hipFree(h->d_gray1); (void)hipFree(h->d_kps1); (void)hipFree(h->d_desc1); (void)hipFree(h->d_count1);
+    for (int l = 0; l < SGX_MAX_LEVELS; l++) { (void)hipFree(h->d_xt[l]); (void)hipFree(h->d_yt[l]); }
+    delete h;
+}
+
+extern "C" int sgx_orb_create(const sgx_orb_config *cfg, sgx_orb **out)
+{
+    if (!cfg || !out) return SGX_ERR_INVALID;
+    if (cfg->nlevels < 1 || cfg->nlevels > SGX_MAX_LEVELS || cfg->nfeatures < 1 || cfg->width < 64 || cfg->height < 64 ||
+        cfg->width > 4000 || cfg->height > 4000 || cfg->max_batch < 1 || !(cfg->scale_factor > 1.0f)) return SGX_ERR_INVALID;
+    sgx_orb *h = new sgx_orb();
+    h->cfg = *cfg;
+    SgxOrbGeom &g = h->g;
+    memset(&g, 0, sizeof g);
+    g.nlevels = cfg->nlevels; g.W = cfg->width; g.H = cfg->height; g.ini_th = cfg->ini_th_fast; g.min_th = cfg->min_th_fast;
+    build_tables(h);
+    std::vector<SgxCell> cells;
+    int off = 0, kp_cap = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+        SgxLevel &L = g.lv[l];
+        L.w = cvround_f((float)cfg->width * h->inv_scale[l]);      // ORBextractor.cc:1112-1113
+        L.h = cvround_f((float)cfg->height * h->inv_scale[l]);
+        L.stride = (L.w + 63) & ~63;
+        L.scale = h->scale[l];
+        L.patch_size = (int)(31 * h->scale[l]);                     // :838
+        if (l > 0) { L.off = off; off += L.stride * L.h; }
+        if (L.w < 2 * SGX_EDGE + 8 || L.h < 2 * SGX_EDGE + 8) { sgx_orb_destroy(h); return SGX_ERR_UNSUPPORTED; }
+        // FAST cell grid, ORBextractor.cc:774-808
+        const float W = 30;
+        const int minBX = SGX_BORDER, minBY = SGX_BORDER, maxBX = L.w - SGX_EDGE + 3, maxBY = L.h - SGX_EDGE + 3;
+        const float width = (float)(maxBX - minBX), height = (float)(maxBY - minBY);
+        L.ncols = (int)(width / W); L.nrows = (int)(height / W);
+        if (L.ncols < 1 || L.nrows < 1) { sgx_orb_destroy(h); return SGX_ERR_UNSUPPORTED; }
+        L.wcell = (int)ceilf(width / L.ncols); L.hcell = (int)ceilf(height / L.nrows);
+        L.cell0 = (int)cells.size();
+        if (L.wcell + 6 > SGX_TILE_MAX || L.hcell + 6 > SGX_TILE_MAX || L.ncols > 1023 || L.nrows > 1023 || L.wcell > 1023 || L.hcell > 1023) {
+            sgx_orb_destroy(h); return SGX_ERR_UNSUPPORTED; }
+        for (int i = 0; i < L.nrows; i++) {
+            const float iniY = (float)(minBY + i * L.hcell);
+            float maxY = iniY + L.hcell + 6;
+            if (iniY >= maxBY - 3) continue;
+            if (maxY > maxBY) maxY = (float)maxBY;
+            for (int j = 0; j < L.ncols; j++) {
+                const float iniX = (float)(minBX + j * L.wcell);
+                float maxX = iniX + L.wcell + 6;
+                if (iniX >= maxBX - 6) continue;
+                if (maxX > maxBX) maxX = (float)maxBX;
+                SgxCell c; c.level = (short)l; c.x0 = (short)iniX; c.y0 = (short)iniY;
+                c.cw = (short)((int)maxX - (int)iniX); c.ch = (short)((int)maxY - (int)iniY);
+                c.ox = (short)(j * L.wcell); c.oy = (short)(i * L.hcell); c.pad = 0;
+                if (c.cw >= 7 && c.ch >= 7) cells.push_back(c);      // cv::FAST yields nothing on tiles < 7 px
+            }
+        }
+        const int nIni = (int)roundf((float)(maxBX - minBX) / (float)(maxBY - minBY));
+        int lim = L.quota + 3; if (lim < 4 * nIni) lim = 4 * nIni;
+        if (lim > SGX_OCT_MAXN) { sgx_orb_destroy(h); return SGX_ERR_UNSUPPORTED; }
+        kp_cap += lim;
+    }
+    g.pyr_pitch = (off + 255) & ~255;
+    g.ncells = (int)cells.size();
+    g.kp_cap = kp_cap;
+
+    const int B = cfg->max_batch, nl = g.nlevels;
+#define SGX_ALLOC(p, bytes) do { if (hipMalloc((void **)&(p), (bytes)) != hipSuccess) { sgx_orb_destroy(h); return SGX_ERR_NOMEM; } } while (0)
+    SGX_ALLOC(h->d_cells, cells.size() * sizeof(SgxCell));
+    SGX_ALLOC(h->d_umax, 16 * sizeof(int));
+    SGX_ALLOC(h->d_pattern, 1024);
+    SGX_ALLOC(h->d_pyr, (size_t)B * g.pyr_pitch + 256);
+    SGX_ALLOC(h->d_cand, (size_t)B * nl * SGX_CAND_CAP * 4);
+    SGX_ALLOC(h->d_cand_count, (size_t)B * nl * 4);
+    SGX_ALLOC(h->d_sel, (size_t)B * nl * SGX_OCT_MAXN * 4);
+    SGX_ALLOC(h->d_sel_count, (size_t)B * nl * 4);
+    SGX_ALLOC(h->d_status, 4);
+    SGX_ALLOC(h->d_gray1, (size_t)g.W * g.H);
+    SGX_ALLOC(h->d_kps1, (size_t)kp_cap * 28);
+    SGX_ALLOC(h->d_desc1, (size_t)kp_cap * 32);
+    SGX_ALLOC(h->d_count1, 4);
+    SGX_CHECK_HIP(hipMemcpyAsync(h->d_cells, cells.data(), cells.size() * sizeof(SgxCell), hipMemcpyHostToDevice, 0));
+    SGX_CHECK_HIP(hipMemcpyAsync(h->d_umax, h->umax_h, 16 * sizeof(int), hipMemcpyHostToDevice, 0));
+    SGX_CHECK_HIP(hipMemcpyAsync(h->d_pattern, sgx_orb_pattern_xy, 1024, hipMemcpyHostToDevice, 0));
+    SGX_CHECK_HIP(hipMemsetAsync(h->d_status, 0, 4, 0));
+    for (int l = 1; l < nl; l++) {
+        std::vector<SgxXTab> xt; std::vector<SgxYTab> yt;
+        build_resize_tables(g.lv[l - 1].w, g.lv[l - 1].h, g.lv[l].w, g.lv[l].h, xt, yt);
+        SGX_ALLOC(h->d_xt[l], xt.size() * sizeof(SgxXTab));
+        SGX_ALLOC(h->d_yt[l], yt.size() * sizeof(SgxYTab));
+        SGX_CHECK_HIP(hipMemcpyAsync(h->d_xt[l], xt.data(), xt.size() * sizeof(SgxXTab), hipMemcpyHostToDevice, 0));
+        SGX_CHECK_HIP(hipMemcpyAsync(h->d_yt[l], yt.data(), yt.size() * sizeof(SgxYTab), hipMemcpyHostToDevice, 0));
+        SGX_CHECK_HIP(hipStreamSynchronize(0));   // xt/yt are stack vectors
+    }
+    SGX_CHECK_HIP(hipStreamSynchronize(0));
+#undef SGX_ALLOC
+    *out = h;
+    return SGX_OK;
+}
+
+extern "C" int sgx_orb_keypoint_capacity(const sgx_orb *h) { return h ? h->g.kp_cap : SGX_ERR_INVALID; }
+
+extern "C" int sgx_orb_get_tables(const sgx_orb *h, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2, int32_t *per_level)
+{
+    if (!h) return SGX_ERR_INVALID;
+    for (int l = 0; l < h->g.nlevels; l++) {
+        if (scale) scale[l] = h->scale[l];
+        if (inv_scale) inv_scale[l] = h->inv_scale[l];
+        if (sigma2) sigma2[l] = h->sigma2[l];
+        if (inv_sigma2) inv_sigma2[l] = h->inv_sigma2[l];
+        if (per_level) per_level[l] = h->g.lv[l].quota;
+    }
+    return SGX_OK;
+}
+
+extern "C" int sgx_orb_extract_batch_dev(sgx_orb *h, const uint8_t *d_gray, int pitch, int batch,
+                                         sgx_keypoint *d_kps, uint8_t *d_desc, int32_t *d_count, int cap, void *stream_)
+{
+    if (!h || !d_gray || !d_kps || !d_desc || !d_count) return SGX_ERR_INVALID;
+    if (batch < 1 || batch > h->cfg.max_batch || pitch < h->g.W || (pitch & 3) || ((uintptr_t)d_gray & 3) || cap < h->g.kp_cap) return SGX_ERR_INVALID;
+    sgx_stream_t stream = (sgx_stream_t)stream_;
+    const SgxOrbGeom &g = h->g;
+    const int nl = g.nlevels;
+    h->last_batch = batch;
+    SGX_CHECK_HIP(hipMemsetAsync(h->d_cand_count, 0, (size_t)batch * nl * 4, stream));
+    for (int l = 1; l < nl; l++) {
+        dim3 grid((g.lv[l].w + 255) / 256, (g.lv[l].h + 3) / 4, batch);
+        SGX_LAUNCH(k_resize, grid, dim3(256), stream, g, l, d_gray, pitch, h->d_pyr, h->d_xt[l], h->d_yt[l]);
+    }
+    SGX_LAUNCH(k_fast_cells, dim3(g.ncells * batch), dim3(256), stream, g, h->d_cells, d_gray, pitch, h->d_pyr, batch,
+               h->d_cand, h->d_cand_count, h->d_status);
+    SGX_LAUNCH(k_octree, dim3(nl, batch), dim3(SGX_OCT_THREADS), stream, g, h->d_cand, h->d_cand_count, h->d_sel, h->d_sel_count, h->d_status);
+    SGX_LAUNCH(k_orient_desc, dim3(g.kp_cap, batch), dim3(64), stream, g, d_gray, pitch, h->d_pyr, h->d_sel, h->d_sel_count,
+               h->d_umax, h->d_pattern, (uint8_t *)d_kps, d_desc, d_count, cap, h->d_status);
+    SGX_CHECK_HIP(hipGetLastError());
+    return SGX_OK;
+}
+
+extern "C" int sgx_orb_last_status(sgx_orb *h, void *stream_)
+{
+    if (!h) return SGX_ERR_INVALID;
+    uint32_t st = 0;
+    SGX_CHECK_HIP(hipMemcpyAsync(&st, h->d_status, 4, hipMemcpyDeviceToHost, (sgx_stream_t)stream_));
+    SGX_CHECK_HIP(hipStreamSynchronize((sgx_stream_t)stream_));
+    if (st) { SGX_CHECK_HIP(hipMemsetAsync(h->d_status, 0, 4, (sgx_stream_t)stream_)); return SGX_ERR_OVERFLOW; }
+    return SGX_OK;
+}
+
+extern "C" int sgx_orb_extract(sgx_orb *h, const uint8_t *gray, int stride, sgx_keypoint *kps, uint8_t *desc, int cap, int *n)
+{
+    if (!h || !gray || !kps || !desc || !n || stride < h->g.W || cap < 0) return SGX_ERR_INVALID;
+    const int W = h->g.W, H = h->g.H, kc = h->g.kp_cap;
+    for (int y = 0; y < H; y++)
+        SGX_CHECK_HIP(hipMemcpyAsync(h->d_gray1 + (size_t)y * W, gray + (size_t)y * stride, W, hipMemcpyHostToDevice, 0));
+    int rc = sgx_orb_extract_batch_dev(h, h->d_gray1, W, 1, (sgx_keypoint *)h->d_kps1, h->d_desc1, h->d_count1, kc, 0);
+    if (rc != SGX_OK) return rc;
+    int cnt = 0;
+    SGX_CHECK_HIP(hipMemcpyAsync(&cnt, h->d_count1, 4, hipMemcpyDeviceToHost, 0));
+    SGX_CHECK_HIP(hipStreamSynchronize(0));
+    rc = sgx_orb_last_status(h, 0);
+    if (rc != SGX_OK) return rc;
+    if (cnt > cap) return SGX_ERR_OVERFLOW;
+    SGX_CHECK_HIP(hipMemcpyAsync(kps, h->d_kps1, (size_t)cnt * 28, hipMemcpyDeviceToHost, 0));
+    SGX_CHECK_HIP(hipMemcpyAsync(desc, h->d_desc1, (size_t)cnt * 32, hipMemcpyDeviceToHost, 0));
+    SGX_CHECK_HIP(hipStreamSynchronize(0));
+    *n = cnt;
+    return SGX_OK;
+}
+
+extern "C" int sgx_orb_debug_level_geometry(const sgx_orb *h, int level, int32_t *w, int32_t *hgt, int32_t *stride)
+{
+    if (!h || level < 0 || level >= h->g.nlevels) return SGX_ERR_INVALID;
+    if (w) *w = h->g.lv[level].w; if (hgt) *hgt = h->g.lv[level].h; if (stride) *stride = h->g.lv[level].stride;
+    return SGX_OK;
+}
+
+extern "C" int sgx_orb_debug_read_level(sgx_orb *h, int frame, int level, uint8_t *dst)
+{
+    if (!h || !dst || level < 1 || level >= h->g.nlevels || frame < 0 || frame >= h->cfg.max_batch) return SGX_ERR_INVALID;
+    const SgxLevel &L = h->g.lv[level];
+    for (int y = 0; y < L.h; y++)
+        SGX_CHECK_HIP(hipMemcpyAsync(dst + (size_t)y * L.w, h->d_pyr + (size_t)frame * h->g.pyr_pitch + L.off + (size_t)y * L.stride, L.w, hipMemcpyDeviceToHost, 0));
+    SGX_CHECK_HIP(hipStreamSynchronize(0));
+    return SGX_OK;
+}
+
+extern "C" int sgx_orb_debug_read_candidates(sgx_orb *h, int frame, int level, int32_t *x, int32_t *y, int32_t *score, int cap, int *n)
+{
+    if (!h || !n || level < 0 || level >= h->g.nlevels || frame < 0 || frame >= h->cfg.max_batch) return SGX_ERR_INVALID;
+    int cnt = 0;
+    SGX_CHECK_HIP(hipMemcpyAsync(&cnt, h->d_cand_count + frame * h->g.nlevels + level, 4, hipMemcpyDeviceToHost, 0));
+    SGX_CHECK_HIP(hipStreamSynchronize(0));
+    if (cnt > SGX_CAND_CAP) cnt = SGX_CAND_CAP;
+    std::vector<uint32_t> buf(cnt > 0 ? cnt : 1);
+    SGX_CHECK_HIP(hipMemcpyAsync(buf.data(), h->d_cand + ((size_t)frame * h->g.nlevels + level) * SGX_CAND_CAP, (size_t)cnt * 4, hipMemcpyDeviceToHost, 0));
+    SGX_CHECK_HIP(hipStreamSynchronize(0));
+    for (int i = 0; i < cnt && i < cap; i++) { x[i] = buf[i] & 0xFFF; y[i] = (buf[i] >> 12) & 0xFFF; score[i] = buf[i] >> 24; }
+    *n = cnt;
+    return SGX_OK;
+}

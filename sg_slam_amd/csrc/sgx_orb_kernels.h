@@ -1,0 +1,734 @@
+// sgx_orb_kernels.h — HIP kernels of the ORB extractor (gfx950), phase-style (see sgx_rt.h).
+//
+// Pipeline for a batch of B frames (each kernel covers all B frames in one launch):
+//   k_resize      x (nlevels-1)  level l <- level l-1     (cv::resize INTER_LINEAR, fixed point)
+//   k_fast_cells  x 1            per-cell FAST-9/16 score + NMS + 20/7 threshold fallback
+//   k_octree      x 1            DistributeOctTree, one workgroup per (frame, level)
+//   k_orient_desc x 1            IC_Angle + on-the-fly 7x7 Gaussian + steered BRIEF, one wave per keypoint
+// Reference behaviour: src/sg-slam/src/ORBextractor.cc (cited per kernel).  All arithmetic is
+// integer or fp32 evaluated exactly as written (-ffp-contract=off; IEEE div/sqrt).
+#pragma once
+#include "sgx_rt.h"
+
+#define SGX_MAX_LEVELS 12
+#define SGX_EDGE 19            /* EDGE_THRESHOLD, ORBextractor.cc:75 */
+#define SGX_BORDER 16          /* EDGE_THRESHOLD-3 = minBorderX/Y, ORBextractor.cc:774 */
+#define SGX_TILE_MAX 68        /* max FAST cell tile edge incl. 3-px aprons */
+#define SGX_TILE_STRIDE 72
+#define SGX_CAND_CAP 8192      /* max FAST candidates per (frame, level) */
+#define SGX_OCT_MAXN 1280      /* max octree list length (per-level quota + 3) */
+#define SGX_OCT_THREADS 256
+
+struct SgxLevel {
+    int w, h, stride;          // level image geometry (stride in bytes)
+    int off;                   // byte offset of the level inside one frame's pyramid buffer (levels >= 1)
+    int quota;                 // mnFeaturesPerLevel[level]
+    int ncols, nrows, wcell, hcell;  // FAST cell grid (ORBextractor.cc:785-788)
+    int cell0;                 // index of this level's first cell in the cell table
+    int patch_size;            // (int)(31*scale)
+    float scale;               // mvScaleFactor[level]
+};
+
+struct SgxOrbGeom {
+    int nlevels, W, H;
+    int pyr_pitch;             // bytes per frame of pyramid storage (levels 1..)
+    int ncells;                // total valid cells over all levels
+    int kp_cap;                // keypoint capacity per frame
+    int ini_th, min_th;
+    SgxLevel lv[SGX_MAX_LEVELS];
+};
+
+struct SgxCell { short level, x0, y0, cw, ch, ox, oy, pad; };  // tile rect in level coords; ox=j*wCell, oy=i*hCell
+
+// status bits written by kernels
+#define SGX_ST_CAND_OVERFLOW 1u
+#define SGX_ST_NODE_OVERFLOW 2u
+#define SGX_ST_KP_OVERFLOW 4u
+
+SGX_DEV const uint8_t *sgx_level_ptr(const SgxOrbGeom &g, const uint8_t *gray, int gray_pitch, const uint8_t *pyr,
+                                     int frame, int level, int *stride)
+{
+    if (level == 0) { *stride = gray_pitch; return gray + (size_t)frame * gray_pitch * g.H; }
+    *stride = g.lv[level].stride;
+    return pyr + (size_t)frame * g.pyr_pitch + g.lv[level].off;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_resize: cv::resize(u8, INTER_LINEAR) level l-1 -> l (ORBextractor.cc:1121).  The per-column
+// {sx, a0, a1} and per-row {sy0, sy1, b0, b1} tables are built on the host with the exact
+// OpenCV float/cvRound sequence (sgx_orb.cpp: build_resize_tables), so the kernel is integer-only:
+//   h0 = S0[sx]*a0 + S0[sx+1]*a1 ; h1 likewise ; dst = (((b0*(h0>>4))>>16) + ((b1*(h1>>4))>>16) + 2) >> 2
+// Each thread produces 4 adjacent pixels and stores one dword.  grid = (ceil(dw/4/64), ceil(dh/4), B).
+// ---------------------------------------------------------------------------------------------
+struct SgxXTab { short sx, sx1, a0, a1; };
+struct SgxYTab { short sy0, sy1, b0, b1; };
+
+SGX_KERNEL(256) k_resize(SgxOrbGeom g, int level, const uint8_t *gray, int gray_pitch, uint8_t *pyr,
+                         const SgxXTab *xt, const SgxYTab *yt)
+{
+    SGX_THREADS_BEGIN(tid)
+    const int dw = g.lv[level].w, dh = g.lv[level].h;
+    const int x4 = ((int)blockIdx.x * 64 + (tid & 63)) * 4;
+    const int y = (int)blockIdx.y * 4 + (tid >> 6);
+    const int frame = (int)blockIdx.z;
+    if (x4 < dw && y < dh) {
+        int sstride, dstride;
+        const uint8_t *src = sgx_level_ptr(g, gray, gray_pitch, pyr, frame, level - 1, &sstride);
+        uint8_t *dst = (uint8_t *)sgx_level_ptr(g, gray, gray_pitch, pyr, frame, level, &dstride);
+        const SgxYTab ty = yt[y];
+        const uint8_t *r0 = src + (size_t)ty.sy0 * sstride, *r1 = src + (size_t)ty.sy1 * sstride;
+        uint32_t out = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int x = x4 + i;
+            if (x < dw) {
+                const SgxXTab tx = xt[x];
+                const int h0 = r0[tx.sx] * tx.a0 + r0[tx.sx1] * tx.a1;
+                const int h1 = r1[tx.sx] * tx.a0 + r1[tx.sx1] * tx.a1;
+                const int v = (((ty.b0 * (h0 >> 4)) >> 16) + ((ty.b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                out |= (uint32_t)(v & 255) << (8 * i);
+            }
+        }
+        *(uint32_t *)(dst + (size_t)y * dstride + x4) = out;   // stride is a multiple of 64 -> in-bounds, aligned
+    }
+    SGX_THREADS_END
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_fast_cells: ORBextractor.cc:790-830 for every cell of every level of every frame.
+// One 256-thread workgroup per (cell, frame).  cv::FAST(cell, 20, nms) with fallback
+// cv::FAST(cell, 7, nms) is evaluated from ONE threshold-free score map S = A-1, where
+// A = max over the 16 nine-pixel arcs of min(v - ring) (bright) / min(ring - v) (dark):
+// a pixel is a corner at threshold t iff S >= t, its OpenCV response is S, NMS is a strict
+// '>' against the 8 neighbours inside the cell interior (everything else scores 0), and the
+// cell keeps {NMS-max, S>=20} unless that set is empty, then {NMS-max, S>=7}.
+// Candidates are appended unordered to the (frame, level) list as packed x | y<<12 | S<<24
+// with x,y relative to the (16,16) border origin (ORBextractor.cc:823-824); k_octree does not
+// depend on their order.
+// ---------------------------------------------------------------------------------------------
+SGX_DEV uint32_t sgx_has9(uint32_t m16)
+{
+    uint32_t m = m16 | (m16 << 16);
+    uint32_t a = m & (m >> 1);
+    uint32_t b = a & (a >> 2);
+    uint32_t c = b & (b >> 4);
+    return (c & (m >> 8)) & 0xFFFFu;
+}
+
+SGX_KERNEL(256) k_fast_cells(SgxOrbGeom g, const SgxCell *cells, const uint8_t *gray, int gray_pitch, const uint8_t *pyr,
+                             int batch, uint32_t *cand, int *cand_count, uint32_t *status)
+{
+    SGX_LDS uint8_t tile[SGX_TILE_MAX * SGX_TILE_STRIDE];
+    SGX_LDS uint8_t score[SGX_TILE_MAX * SGX_TILE_STRIDE];
+    SGX_LDS uint16_t clist[(SGX_TILE_MAX - 6) * (SGX_TILE_MAX - 6)];
+    SGX_LDS uint32_t outbuf[((SGX_TILE_MAX - 5) / 2) * ((SGX_TILE_MAX - 5) / 2)];
+    SGX_LDS int n_corner, n_hi, n_lo, out_base;
+
+    // block -> (cell, frame): frame fastest so that frame f stays on XCD f%8 (block b -> XCD b%8)
+    const int bid = (int)blockIdx.x;
+    const int frame = bid % batch, cid = bid / batch;
+    const SgxCell c = cells[cid];
+    const int cw = c.cw, ch = c.ch, level = c.level;
+    int stride;
+    const uint8_t *img = sgx_level_ptr(g, gray, gray_pitch, pyr, frame, level, &stride);
+    const int thr_lo = g.min_th, thr_hi = g.ini_th;
+
+    SGX_THREADS_BEGIN(tid)
+    if (tid == 0) { n_corner = 0; n_hi = 0; n_lo = 0; }
+    // stage tile rows as aligned dwords; zero the score map
+    const int xa = c.x0 & ~3, lead = c.x0 - xa, ndw = (lead + cw + 3) >> 2;
+    for (int i = tid; i < ch * ndw; i += (int)blockDim.x) {
+        const int r = i / ndw, q = i - r * ndw;
+        const uint32_t v = *(const uint32_t *)(img + (size_t)(c.y0 + r) * stride + xa + 4 * q);
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int x = 4 * q + b - lead;
+            if (x >= 0 && x < cw) tile[r * SGX_TILE_STRIDE + x] = (uint8_t)(v >> (8 * b));
+        }
+    }
+    for (int i = tid; i < ch * SGX_TILE_STRIDE; i += (int)blockDim.x) score[i] = 0;
+    SGX_THREADS_END
+    SGX_SYNC();
+
+    // phase B: corner test at the LOW threshold for every interior pixel, compact positives
+    const int iw = cw - 6, ih = ch - 6;
+    SGX_THREADS_BEGIN(tid)
+    for (int i = tid; i < iw * ih; i += (int)blockDim.x) {
+        const int y = 3 + i / iw, x = 3 + i % iw;
+        const uint8_t *p = tile + y * SGX_TILE_STRIDE + x;
+        const int v = p[0], lo = v - thr_lo, hi = v + thr_lo;
+        uint32_t mb = 0, md = 0;
+#define SGX_RING(k, dx, dy) { const int r_ = p[(dy) * SGX_TILE_STRIDE + (dx)]; mb |= (uint32_t)(r_ > hi) << (k); md |= (uint32_t)(r_ < lo) << (k); }
+        SGX_RING(0, 0, 3) SGX_RING(1, 1, 3) SGX_RING(2, 2, 2) SGX_RING(3, 3, 1) SGX_RING(4, 3, 0) SGX_RING(5, 3, -1)
+        SGX_RING(6, 2, -2) SGX_RING(7, 1, -3) SGX_RING(8, 0, -3) SGX_RING(9, -1, -3) SGX_RING(10, -2, -2) SGX_RING(11, -3, -1)
+        SGX_RING(12, -3, 0) SGX_RING(13, -3, 1) SGX_RING(14, -2, 2) SGX_RING(15, -1, 3)
+#undef SGX_RING
+        if (sgx_has9(mb) | sgx_has9(md)) {
+            const int slot = sgx_atomic_add(&n_corner, 1);
+            clist[slot] = (uint16_t)(y * SGX_TILE_STRIDE + x);
+        }
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+
+    // phase C: threshold-free score for the compacted corners
+    SGX_THREADS_BEGIN(tid)
+    for (int i = tid; i < n_corner; i += (int)blockDim.x) {
+        const int pos = clist[i];
+        const uint8_t *p = tile + pos;
+        const int v = p[0];
+        int d[16];
+        d[0] = v - p[3 * SGX_TILE_STRIDE];       d[1] = v - p[3 * SGX_TILE_STRIDE + 1];  d[2] = v - p[2 * SGX_TILE_STRIDE + 2];
+        d[3] = v - p[SGX_TILE_STRIDE + 3];       d[4] = v - p[3];                        d[5] = v - p[-SGX_TILE_STRIDE + 3];
+        d[6] = v - p[-2 * SGX_TILE_STRIDE + 2];  d[7] = v - p[-3 * SGX_TILE_STRIDE + 1]; d[8] = v - p[-3 * SGX_TILE_STRIDE];
+        d[9] = v - p[-3 * SGX_TILE_STRIDE - 1];  d[10] = v - p[-2 * SGX_TILE_STRIDE - 2]; d[11] = v - p[-SGX_TILE_STRIDE - 3];
+        d[12] = v - p[-3];                       d[13] = v - p[SGX_TILE_STRIDE - 3];     d[14] = v - p[2 * SGX_TILE_STRIDE - 2];
+        d[15] = v - p[3 * SGX_TILE_STRIDE - 1];
+        int mn2[16], mx2[16], mn4[16], mx4[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+        for (int k = 0; k < 16; k++) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
+        int A = -512, Bm = 512;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int mn9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
+            const int mx9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
+            A = max(A, mn9); Bm = min(Bm, mx9);
+        }
+        const int s = max(A, -Bm) - 1;
+        score[pos] = (uint8_t)s;
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+
+    // phase D: NMS (strict > over the 8 neighbours; apron and non-corners are 0), count survivors
+    SGX_THREADS_BEGIN(tid)
+    for (int i = tid; i < n_corner; i += (int)blockDim.x) {
+        const int pos = clist[i];
+        const uint8_t *s = score + pos;
+        const int v = s[0];
+        const bool mx = v > s[-1] && v > s[1] && v > s[-SGX_TILE_STRIDE - 1] && v > s[-SGX_TILE_STRIDE] && v > s[-SGX_TILE_STRIDE + 1] &&
+                        v > s[SGX_TILE_STRIDE - 1] && v > s[SGX_TILE_STRIDE] && v > s[SGX_TILE_STRIDE + 1];
+        if (mx && v >= thr_lo) {
+            if (v >= thr_hi) sgx_atomic_add(&n_hi, 1);
+            const int slot = sgx_atomic_add(&n_lo, 1);
+            const int y = pos / SGX_TILE_STRIDE, x = pos - y * SGX_TILE_STRIDE;
+            outbuf[slot] = (uint32_t)(x + c.ox) | ((uint32_t)(y + c.oy) << 12) | ((uint32_t)v << 24);
+        }
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+
+    // phase E: pick the threshold, reserve space in the (frame, level) list, emit
+    const int use_thr = n_hi > 0 ? thr_hi : thr_lo;
+    const int n_emit = n_hi > 0 ? n_hi : n_lo;
+    SGX_THREADS_BEGIN(tid)
+    if (tid == 0 && n_emit > 0) out_base = sgx_atomic_add(&cand_count[frame * g.nlevels + level], n_emit);
+    if (tid == 0) n_corner = 0;       // reuse as emit cursor
+    SGX_THREADS_END
+    SGX_SYNC();
+    if (n_emit > 0) {
+        uint32_t *dst = cand + ((size_t)frame * g.nlevels + level) * SGX_CAND_CAP;
+        SGX_THREADS_BEGIN(tid)
+        for (int i = tid; i < n_lo; i += (int)blockDim.x) {
+            const uint32_t e = outbuf[i];
+            if ((int)(e >> 24) >= use_thr) {
+                const int slot = out_base + sgx_atomic_add(&n_corner, 1);
+                if (slot < SGX_CAND_CAP) dst[slot] = e;
+                else sgx_atomic_or(status, SGX_ST_CAND_OVERFLOW);
+            }
+        }
+        SGX_THREADS_END
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_octree: ORBextractor::DistributeOctTree (ORBextractor.cc:540-764) + the coordinate shift,
+// octave and size assignment of ComputeKeyPointsOctTree (:838-848).  One workgroup per
+// (frame, level); candidates and the node list live in LDS.
+//
+// Data-parallel restatement of the reference's std::list algorithm.  The list is an array in
+// list order; node id == list position.  One "pass" splits a set of nodes at once:
+//   phase 1 (reference :607-666): every node with >1 key splits; children are push_front'ed in
+//     creation order, so the new list is reverse(children in creation order) ++ kept nodes.
+//   phase 2 (reference :677-738): the children created by the previous pass that hold >1 key are
+//     processed in descending (size, creation order) [the reference sorts (size, node address),
+//     :685; address ties are allocator dependent there — see oracle/orb_oracle.c], stopping at the
+//     first split that makes the list reach N; same reverse-prepend rule for the list.
+// Keys never move: key k carries node_of[k]; a split recomputes the quadrant of each key of a
+// splitting node (DivideNode :482-538) and remaps node_of through the new positions.
+// The final pick per node is the max response, first-in-candidate-order on ties (:745-761);
+// candidate order in the reference is cell-raster, row-major inside a cell, which is encoded
+// in a rank key so the unordered candidate list of k_fast_cells gives the same pick.
+// ---------------------------------------------------------------------------------------------
+SGX_DEV void sgx_block_exclusive_scan_i32(int *a, int n, int *total, int tid);
+
+struct SgxOctNode { uint16_t ulx, uly, urx, bry; };   // UL.x, UL.y, UR.x, BR.y — all DivideNode needs
+
+// quadrant of key e inside node b (DivideNode :484-527): n1=0 (left/top) n2=1 (right/top) n3=2 n4=3
+SGX_DEV int sgx_oct_quadrant(const SgxOctNode b, uint32_t e)
+{
+    const int halfX = (int)ceilf((float)(b.urx - b.ulx) / 2), halfY = (int)ceilf((float)(b.bry - b.uly) / 2);
+    const float x = (float)(e & 0xFFF), y = (float)((e >> 12) & 0xFFF);
+    const float sx = (float)(b.ulx + halfX), sy = (float)(b.uly + halfY);
+    return (x < sx) ? ((y < sy) ? 0 : 2) : ((y < sy) ? 1 : 3);
+}
+
+// (response desc, candidate order asc) as one sortable 48-bit key; candidate order in the
+// reference is cell-raster, row-major inside a cell (ORBextractor.cc:790-827)
+SGX_DEV unsigned long long sgx_oct_pick_key(uint32_t e, int wcell, int hcell)
+{
+    const int x = (int)(e & 0xFFF), y = (int)((e >> 12) & 0xFFF);
+    const int cj = (x - 3) / wcell, ci = (y - 3) / hcell;          // owning FAST cell (interiors tile the level)
+    const unsigned long long rank = ((unsigned long long)ci << 30) | ((unsigned long long)cj << 20) |
+                                    ((unsigned long long)(y - ci * hcell) << 10) | (unsigned long long)(x - cj * wcell);
+    return ((unsigned long long)(e >> 24) << 40) | (0xFFFFFFFFFFull - rank);
+}
+
+SGX_KERNEL(SGX_OCT_THREADS) k_octree(SgxOrbGeom g, const uint32_t *cand, const int *cand_count,
+                                     uint32_t *sel, int *sel_count, uint32_t *status)
+{
+    // keys
+    SGX_LDS uint32_t kxy[SGX_CAND_CAP];          // packed x | y<<12 | S<<24
+    SGX_LDS uint16_t node_of[SGX_CAND_CAP];
+    // node list (array in list order), ping-pong
+    SGX_LDS SgxOctNode nb[2][SGX_OCT_MAXN];
+    SGX_LDS uint16_t ncnt[2][SGX_OCT_MAXN];      // keys per node
+    SGX_LDS uint16_t nseq[2][SGX_OCT_MAXN];      // creation index within the pass that created it
+    SGX_LDS uint8_t nflag[2][SGX_OCT_MAXN];      // 1: created by the last pass with >1 key (the reference's vSizeAndPointerToNode)
+    // per-pass scratch indexed by OLD list position
+    SGX_LDS int quad[SGX_OCT_MAXN][4];           // keys per quadrant; later the children's new positions ([0] for kept nodes)
+    SGX_LDS int scanA[SGX_OCT_MAXN];             // children created before (in creation order)
+    SGX_LDS int scanB[SGX_OCT_MAXN];             // kept nodes before (in list order)
+    SGX_LDS uint8_t splitting[SGX_OCT_MAXN];
+    SGX_LDS uint16_t order[SGX_OCT_MAXN];        // phase 2: processing rank -> old position
+    SGX_LDS uint16_t rank_of[SGX_OCT_MAXN];
+    SGX_LDS unsigned long long best[SGX_OCT_MAXN];
+    SGX_LDS int s_size, s_C, s_kept, s_ntoexpand, s_stop, s_m, s_overflow;
+
+    const int level = (int)blockIdx.x, frame = (int)blockIdx.y;
+    const SgxLevel L = g.lv[level];
+    const int N = L.quota;
+    int nk = cand_count[frame * g.nlevels + level];
+    if (nk > SGX_CAND_CAP) nk = SGX_CAND_CAP;
+    const uint32_t *src = cand + ((size_t)frame * g.nlevels + level) * SGX_CAND_CAP;
+    uint32_t *out = sel + ((size_t)frame * g.nlevels + level) * SGX_OCT_MAXN;
+    const int NT = (int)blockDim.x;
+
+    const int minX = SGX_BORDER, maxX = L.w - SGX_EDGE + 3, minY = SGX_BORDER, maxY = L.h - SGX_EDGE + 3;
+    const int nIni = (int)roundf((float)(maxX - minX) / (float)(maxY - minY));       // :544
+    const float hX = nIni > 0 ? (float)(maxX - minX) / (float)nIni : 1.f;             // :546
+
+    if (nk == 0 || nIni < 1 || nIni > 64) {
+        SGX_THREADS_BEGIN(tid) if (tid == 0) sel_count[frame * g.nlevels + level] = 0; SGX_THREADS_END
+        return;
+    }
+
+    // ---- roots (:553-571); empty roots are dropped (:573-586)
+    SGX_THREADS_BEGIN(tid)
+    for (int i = tid; i < nIni; i += NT) scanA[i] = 0;
+    if (tid == 0) s_overflow = 0;
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    for (int k = tid; k < nk; k += NT) {
+        const uint32_t e = src[k];
+        kxy[k] = e;
+        const int r = (int)((float)(e & 0xFFF) / hX);       // vpIniNodes[kp.pt.x/hX] :570
+        node_of[k] = (uint16_t)r;
+        sgx_atomic_add(&scanA[r], 1);
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    if (tid == 0) {     // nIni is tiny: compact the non-empty roots serially
+        int n = 0;
+        for (int i = 0; i < nIni; i++) {
+            const int c = scanA[i];
+            if (c == 0) { scanB[i] = -1; continue; }
+            nb[0][n].ulx = (uint16_t)(int)(hX * (float)i); nb[0][n].uly = 0;
+            nb[0][n].urx = (uint16_t)(int)(hX * (float)(i + 1)); nb[0][n].bry = (uint16_t)(maxY - minY);
+            ncnt[0][n] = (uint16_t)c; nseq[0][n] = (uint16_t)i; nflag[0][n] = 0;
+            scanB[i] = n; n++;
+        }
+        s_size = n;
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    for (int k = tid; k < nk; k += NT) node_of[k] = (uint16_t)scanB[node_of[k]];
+    SGX_THREADS_END
+    SGX_SYNC();
+
+    int cur = 0;            // ping-pong index of the live node arrays
+    int phase2 = 0;
+    for (int guard = 0; guard < 4096; guard++) {
+        const int size = s_size;
+        const int nxt = cur ^ 1;
+        // ---- choose the (provisional) splitting set
+        if (!phase2) {
+            SGX_THREADS_BEGIN(tid)
+            for (int i = tid; i < size; i += NT) splitting[i] = ncnt[cur][i] > 1;       // !bNoMore
+            if (tid == 0) { s_stop = 0x7FFFFFFF; s_m = 0; }
+            SGX_THREADS_END
+        } else {
+            // processing rank by (count, creation order) descending (:685-686)
+            SGX_THREADS_BEGIN(tid)
+            for (int i = tid; i < size; i += NT) {
+                int r = -1;
+                if (nflag[cur][i]) {
+                    const uint32_t ki = ((uint32_t)ncnt[cur][i] << 16) | nseq[cur][i];
+                    r = 0;
+                    for (int j = 0; j < size; j++)
+                        if (nflag[cur][j]) { const uint32_t kj = ((uint32_t)ncnt[cur][j] << 16) | nseq[cur][j]; r += kj > ki; }
+                    order[r] = (uint16_t)i;
+                }
+                rank_of[i] = (uint16_t)r;
+                splitting[i] = r >= 0;
+            }
+            SGX_THREADS_END
+        }
+        SGX_SYNC();
+        // ---- quadrant populations of the splitting nodes
+        SGX_THREADS_BEGIN(tid)
+        for (int i = tid; i < size; i += NT) { quad[i][0] = 0; quad[i][1] = 0; quad[i][2] = 0; quad[i][3] = 0; }
+        SGX_THREADS_END
+        SGX_SYNC();
+        SGX_THREADS_BEGIN(tid)
+        for (int k = tid; k < nk; k += NT) {
+            const int p = node_of[k];
+            if (splitting[p]) sgx_atomic_add(&quad[p][sgx_oct_quadrant(nb[cur][p], kxy[k])], 1);
+        }
+        SGX_THREADS_END
+        SGX_SYNC();
+        // ---- phase 2: stop at the first split that makes the list reach N (:731-732)
+        if (phase2) {
+            SGX_THREADS_BEGIN(tid)
+            if (tid == 0) {
+                int m = 0;
+                for (int i = 0; i < size; i++) m += nflag[cur][i];
+                int sz = size, stop = 0x7FFFFFFF;
+                for (int r = 0; r < m; r++) {
+                    const int i = order[r];
+                    sz += (quad[i][0] > 0) + (quad[i][1] > 0) + (quad[i][2] > 0) + (quad[i][3] > 0) - 1;
+                    if (sz >= N) { stop = r; break; }
+                }
+                s_stop = stop; s_m = m;
+            }
+            SGX_THREADS_END
+            SGX_SYNC();
+            SGX_THREADS_BEGIN(tid)
+            for (int i = tid; i < size; i += NT) if (splitting[i] && (int)rank_of[i] > s_stop) splitting[i] = 0;
+            SGX_THREADS_END
+            SGX_SYNC();
+        }
+        // ---- children per creation slot (phase 1: list order, phase 2: processing rank) and kept flags
+        SGX_THREADS_BEGIN(tid)
+        for (int s = tid; s < size; s += NT) {
+            int i = s;
+            bool on = splitting[s];
+            if (phase2) { on = s < s_m && s <= s_stop; i = on ? (int)order[s] : 0; }
+            scanA[s] = on ? (quad[i][0] > 0) + (quad[i][1] > 0) + (quad[i][2] > 0) + (quad[i][3] > 0) : 0;
+            scanB[s] = splitting[s] ? 0 : 1;
+        }
+        SGX_THREADS_END
+        SGX_SYNC();
+        SGX_THREADS_BEGIN(tid)
+        sgx_block_exclusive_scan_i32(scanA, size, &s_C, tid);
+        SGX_THREADS_END
+        SGX_SYNC();
+        SGX_THREADS_BEGIN(tid)
+        sgx_block_exclusive_scan_i32(scanB, size, &s_kept, tid);
+        if (tid == 0) s_ntoexpand = 0;
+        SGX_THREADS_END
+        SGX_SYNC();
+        const int C = s_C;
+        const int new_size = C + s_kept;
+        if (new_size > SGX_OCT_MAXN) {
+            SGX_THREADS_BEGIN(tid) if (tid == 0) { sgx_atomic_or(status, SGX_ST_NODE_OVERFLOW); s_overflow = 1; } SGX_THREADS_END
+            SGX_SYNC();
+            break;
+        }
+        // ---- build the new list: reverse(children in creation order) ++ kept nodes in old order
+        SGX_THREADS_BEGIN(tid)
+        for (int i = tid; i < size; i += NT) {
+            if (splitting[i]) {
+                const SgxOctNode b = nb[cur][i];
+                const int halfX = (int)ceilf((float)(b.urx - b.ulx) / 2), halfY = (int)ceilf((float)(b.bry - b.uly) / 2);
+                int ci = scanA[phase2 ? (int)rank_of[i] : i];
+                for (int q = 0; q < 4; q++) {
+                    const int c = quad[i][q];
+                    if (c == 0) continue;
+                    const int pos = C - 1 - ci;
+                    SgxOctNode nn;
+                    nn.ulx = (q & 1) ? (uint16_t)(b.ulx + halfX) : b.ulx;
+                    nn.urx = (q & 1) ? b.urx : (uint16_t)(b.ulx + halfX);
+                    nn.uly = (q & 2) ? (uint16_t)(b.uly + halfY) : b.uly;
+                    nn.bry = (q & 2) ? b.bry : (uint16_t)(b.uly + halfY);
+                    nb[nxt][pos] = nn; ncnt[nxt][pos] = (uint16_t)c; nseq[nxt][pos] = (uint16_t)ci;
+                    nflag[nxt][pos] = c > 1;
+                    if (c > 1) sgx_atomic_add(&s_ntoexpand, 1);
+                    quad[i][q] = pos;
+                    ci++;
+                }
+            } else {
+                const int pos = C + scanB[i];
+                nb[nxt][pos] = nb[cur][i]; ncnt[nxt][pos] = ncnt[cur][i]; nseq[nxt][pos] = nseq[cur][i];
+                nflag[nxt][pos] = 0;
+                quad[i][0] = pos;
+            }
+        }
+        SGX_THREADS_END
+        SGX_SYNC();
+        SGX_THREADS_BEGIN(tid)
+        for (int k = tid; k < nk; k += NT) {
+            const int p = node_of[k];
+            node_of[k] = (uint16_t)(splitting[p] ? quad[p][sgx_oct_quadrant(nb[cur][p], kxy[k])] : quad[p][0]);
+        }
+        if (tid == 0) s_size = new_size;
+        SGX_THREADS_END
+        SGX_SYNC();
+        cur = nxt;
+        // ---- termination (:670-675, :735-736)
+        if (new_size >= N || new_size == size) break;
+        if (!phase2 && new_size + s_ntoexpand * 3 > N) phase2 = 1;
+    }
+
+    // ---- retain the best key of every node (:745-761) and emit in list order
+    const int fsize = s_size;
+    SGX_THREADS_BEGIN(tid)
+    for (int i = tid; i < fsize; i += NT) best[i] = 0ull;
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    for (int k = tid; k < nk; k += NT) sgx_atomic_max(&best[node_of[k]], sgx_oct_pick_key(kxy[k], L.wcell, L.hcell));
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    for (int k = tid; k < nk; k += NT)
+        if (best[node_of[k]] == sgx_oct_pick_key(kxy[k], L.wcell, L.hcell)) out[node_of[k]] = kxy[k];   // the key is unique per pixel
+    if (tid == 0) sel_count[frame * g.nlevels + level] = s_overflow ? 0 : fsize;
+    SGX_THREADS_END
+}
+
+// Block-wide exclusive scan of a[0..n) (int32), total written to *total.  Called by all threads
+// inside one SGX_THREADS region and followed by SGX_SYNC().
+#ifdef SGX_EMU
+SGX_DEV void sgx_block_exclusive_scan_i32(int *a, int n, int *total, int tid)
+{
+    if (tid != 0) return;
+    int run = 0;
+    for (int i = 0; i < n; i++) { const int v = a[i]; a[i] = run; run += v; }
+    *total = run;
+}
+#else
+SGX_DEV void sgx_block_exclusive_scan_i32(int *a, int n, int *total, int tid)
+{
+    // wave 0 scans the array in 64-wide chunks with shuffles (n <= 1280 -> <= 20 chunks)
+    if (tid >= 64) return;
+    int carry = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + tid;
+        const int v = i < n ? a[i] : 0;
+        int inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (tid >= o) inc += t; }
+        if (i < n) a[i] = carry + inc - v;
+        carry += __shfl(inc, 63, 64);
+    }
+    if (tid == 0) *total = carry;
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// sinf/cosf exactly as the host libm computes them for the reference (`cos(float)` / `sin(float)`
+// at ORBextractor.cc:114 resolve to glibc cosf/sinf).  Restatement of glibc >= 2.28
+// sysdeps/ieee754/flt-32/{s_sinf.c,s_cosf.c,sincosf.h} (double-precision polynomial, 2^24-scaled
+// quadrant reduction); checked bit-for-bit against glibc 2.35 on every float in [0, 2*pi*1.001]
+// (tests/test_sincosf.py samples it).  Valid for |x| < 120, which covers angle*pi/180, angle in [0,360).
+// ---------------------------------------------------------------------------------------------
+SGX_DEV float sgx_sincos_poly(double x, double x2, int neg_cos, int n)
+{
+    const double c0 = neg_cos ? -0x1p0 : 0x1p0, c1 = neg_cos ? 0x1.ffffffd0c621cp-2 : -0x1.ffffffd0c621cp-2;
+    const double c2 = neg_cos ? -0x1.55553e1068f19p-5 : 0x1.55553e1068f19p-5, c3 = neg_cos ? 0x1.6c087e89a359dp-10 : -0x1.6c087e89a359dp-10;
+    const double c4 = neg_cos ? -0x1.99343027bf8c3p-16 : 0x1.99343027bf8c3p-16;
+    const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+    if ((n & 1) == 0) {
+        const double x3 = x * x2, sp = s2 + x2 * s3, x7 = x3 * x2, s = x + x3 * s1;
+        return (float)(s + x7 * sp);
+    }
+    const double x4 = x2 * x2, cp2 = c3 + x2 * c4, cp1 = c0 + x2 * c1, x6 = x4 * x2, c = cp1 + x4 * c2;
+    return (float)(c + x6 * cp2);
+}
+
+SGX_DEV void sgx_sincosf(float y, float *sn, float *cs)
+{
+    const double hpi_inv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
+    double x = (double)y;
+    uint32_t u; memcpy(&u, &y, 4);
+    const uint32_t top = (u >> 20) & 0x7ff;
+    if (top < 0x3f4u) {                        // |y| < pi/4   (abstop12(0x1.921FB6p-1f) = 0x3f4)
+        const double x2 = x * x;
+        if (top < 0x398u) { *sn = y; *cs = 1.0f; return; }      // |y| < 2^-12
+        *sn = sgx_sincos_poly(x, x2, 0, 0);
+        *cs = sgx_sincos_poly(x, x2, 0, 1);
+        return;
+    }
+    const double r = x * hpi_inv;
+    const int n = ((int32_t)r + 0x800000) >> 24;
+    x = x - n * hpi;
+    const double sgn = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+    const int neg = (n & 2) != 0;
+    *sn = sgx_sincos_poly(x * sgn, x * x, neg, n);
+    *cs = sgx_sincos_poly(x * sgn, x * x, neg, n ^ 1);
+}
+
+// cv::fastAtan2 (degrees) — OpenCV 3.4 atan_f32 polynomial; see oracle/orb_oracle.c orc_fast_atan2
+SGX_DEV float sgx_fast_atan2(float y, float x)
+{
+    const float k = (float)(180 / 3.1415926535897932384626433832795);
+    const float p1 = 0.9997878412794807f * k, p3 = -0.3258083974640975f * k;
+    const float p5 = 0.1555786518463281f * k, p7 = -0.04432655554792128f * k;
+    const float eps = (float)2.2204460492503131e-16;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) { c = ay / (ax + eps); c2 = c * c; a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    else { c = ax / (ay + eps); c2 = c * c; a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+SGX_DEV int sgx_reflect101(int i, int n)
+{
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) { if (i < 0) i = -i; else i = 2 * (n - 1) - i; }
+    return i;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_orient_desc: one 64-lane wave per output keypoint.
+//   IC_Angle (ORBextractor.cc:78-105) on the un-blurred level,
+//   GaussianBlur 7x7 sigma 2 REFLECT_101 (:1086-1087; OpenCV 3.4.15 fixed-point: taps
+//   {18,34,48,56,48,34,18}/256, 8.8 horizontal, 16.16 vertical, +0.5 round) evaluated only on the
+//   37x37 window the steered pattern can reach (|offset| <= round(18.38)),
+//   computeOrbDescriptor (:109-148), keypoint scaling/packing (:838-848, :1096-1104).
+// Output keypoints of a frame are ordered level 0..nlevels-1, inside a level in octree list order.
+// ---------------------------------------------------------------------------------------------
+#define SGX_PR 21                  /* source patch radius: 18 (pattern reach) + 3 (blur) */
+#define SGX_PW (2 * SGX_PR + 1)    /* 43 */
+#define SGX_BR 18
+#define SGX_BW (2 * SGX_BR + 1)    /* 37 */
+
+SGX_KERNEL(64) k_orient_desc(SgxOrbGeom g, const uint8_t *gray, int gray_pitch, const uint8_t *pyr,
+                             const uint32_t *sel, const int *sel_count, const int *umax, const signed char *pattern,
+                             uint8_t *kps_raw, uint8_t *desc, int *count, int cap, uint32_t *status)
+{
+    SGX_LDS uint8_t patch[SGX_PW * (SGX_PW + 1)];
+    SGX_LDS uint16_t hbuf[SGX_PW * SGX_BW];
+    SGX_LDS uint8_t blur[SGX_BW * (SGX_BW + 1)];
+    SGX_LDS uint8_t bits[256];
+    SGX_LDS int s_m01, s_m10;
+    SGX_LDS float s_a, s_b;
+    const int GK0 = 18, GK1 = 34, GK2 = 48, GK3 = 56;
+
+    const int slot = (int)blockIdx.x, frame = (int)blockIdx.y;
+    int level = -1, base = 0, total = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+        const int n = sel_count[frame * g.nlevels + l];
+        if (level < 0 && slot < total + n) { level = l; base = total; }
+        total += n;
+    }
+    if (slot == 0) {
+        SGX_THREADS_BEGIN(tid)
+        if (tid == 0) { count[frame] = total < cap ? total : cap; if (total > cap) sgx_atomic_or(status, SGX_ST_KP_OVERFLOW); }
+        SGX_THREADS_END
+    }
+    if (level < 0 || slot >= cap) return;
+
+    const SgxLevel L = g.lv[level];
+    const uint32_t e = sel[((size_t)frame * g.nlevels + level) * SGX_OCT_MAXN + (slot - base)];
+    const int kx = (int)(e & 0xFFF) + SGX_BORDER, ky = (int)((e >> 12) & 0xFFF) + SGX_BORDER;   // :844-845
+    int stride;
+    const uint8_t *img = sgx_level_ptr(g, gray, gray_pitch, pyr, frame, level, &stride);
+
+    SGX_THREADS_BEGIN(tid)
+    if (tid == 0) { s_m01 = 0; s_m10 = 0; }
+    for (int i = tid; i < SGX_PW * SGX_PW; i += 64) {
+        const int r = i / SGX_PW, c = i - r * SGX_PW;
+        const int yy = sgx_reflect101(ky + r - SGX_PR, L.h), xx = sgx_reflect101(kx + c - SGX_PR, L.w);
+        patch[r * (SGX_PW + 1) + c] = img[(size_t)yy * stride + xx];
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+
+    // intensity-centroid moments over the radius-15 disc (umax rows), integer exact in any order
+    SGX_THREADS_BEGIN(tid)
+    int m10 = 0, m01 = 0;
+    for (int i = tid; i < 31 * 31; i += 64) {
+        const int v = i / 31 - 15, u = i - (v + 15) * 31 - 15;
+        const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
+        if (au <= umax[av]) {
+            const int I = patch[(SGX_PR + v) * (SGX_PW + 1) + SGX_PR + u];
+            m10 += u * I; m01 += v * I;
+        }
+    }
+    sgx_atomic_add(&s_m10, m10); sgx_atomic_add(&s_m01, m01);
+    // horizontal blur pass (8.8 fixed point)
+    for (int i = tid; i < SGX_PW * SGX_BW; i += 64) {
+        const int r = i / SGX_BW, c = i - r * SGX_BW;
+        const uint8_t *p = patch + r * (SGX_PW + 1) + c;        // window columns c..c+6 <-> blurred column c
+        hbuf[i] = (uint16_t)(GK0 * (p[0] + p[6]) + GK1 * (p[1] + p[5]) + GK2 * (p[2] + p[4]) + GK3 * p[3]);
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+
+    SGX_THREADS_BEGIN(tid)
+    if (tid == 0) {
+        const float angle = sgx_fast_atan2((float)s_m01, (float)s_m10);
+        const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+        float sn, cs;
+        sgx_sincosf(angle * factorPI, &sn, &cs);
+        s_a = cs; s_b = sn;
+        // keypoint record (cv::KeyPoint layout)
+        float *kp = (float *)(kps_raw + ((size_t)frame * cap + slot) * 28);
+        float fx = (float)kx, fy = (float)ky;
+        if (level != 0) { fx = fx * L.scale; fy = fy * L.scale; }
+        kp[0] = fx; kp[1] = fy; kp[2] = (float)L.patch_size; kp[3] = angle; kp[4] = (float)(e >> 24);
+        ((int *)kp)[5] = level; ((int *)kp)[6] = -1;
+    }
+    // vertical blur pass (16.16) + rounding
+    for (int i = tid; i < SGX_BW * SGX_BW; i += 64) {
+        const int r = i / SGX_BW, c = i - r * SGX_BW;
+        const uint16_t *h = hbuf + r * SGX_BW + c;
+        const uint32_t acc = (uint32_t)GK0 * (h[0] + h[6 * SGX_BW]) + (uint32_t)GK1 * (h[SGX_BW] + h[5 * SGX_BW]) +
+                             (uint32_t)GK2 * (h[2 * SGX_BW] + h[4 * SGX_BW]) + (uint32_t)GK3 * h[3 * SGX_BW];
+        blur[r * (SGX_BW + 1) + c] = (uint8_t)((acc + 32768u) >> 16);
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+
+    SGX_THREADS_BEGIN(tid)
+    const float a = s_a, b = s_b;
+    for (int t = tid; t < 256; t += 64) {
+        const signed char *pt = pattern + 4 * t;
+        const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
+        const int r0 = sgx_cvround(x0 * b + y0 * a), c0 = sgx_cvround(x0 * a - y0 * b);
+        const int r1 = sgx_cvround(x1 * b + y1 * a), c1 = sgx_cvround(x1 * a - y1 * b);
+        const int t0 = blur[(SGX_BR + r0) * (SGX_BW + 1) + SGX_BR + c0];
+        const int t1 = blur[(SGX_BR + r1) * (SGX_BW + 1) + SGX_BR + c1];
+        bits[t] = (uint8_t)(t0 < t1);
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+
+    SGX_THREADS_BEGIN(tid)
+    if (tid < 32) {
+        int v = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) v |= bits[8 * tid + j] << j;
+        desc[((size_t)frame * cap + slot) * 32 + tid] = (uint8_t)v;
+    }
+    SGX_THREADS_END
+}
