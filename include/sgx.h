@@ -82,6 +82,15 @@ int sgx_orb_debug_read_level(sgx_orb *h, int frame, int level, uint8_t *dst /* w
  * (16,16) border origin exactly as pushed at ORBextractor.cc:823-825; returns count in *n */
 int sgx_orb_debug_read_candidates(sgx_orb *h, int frame, int level, int32_t *x, int32_t *y, int32_t *score, int cap, int *n);
 
+/* run the octree-distribution kernel alone on packed candidates (x | y<<12 | score<<24, coordinates
+ * relative to the (16,16) border origin) for `level`; returns the selected packed entries in list order */
+int sgx_orb_debug_run_octree(sgx_orb *h, int level, const uint32_t *packed, int n, uint32_t *out_sel, int cap, int *nsel);
+
+/* per-kernel HIP-event timing of the batched call (classes: 0 pyramid resize, 1 FAST cells, 2 octree,
+ * 3 orientation+descriptor).  Events are recorded on the caller's stream around each launch. */
+int sgx_orb_profile_enable(sgx_orb *h, int on);
+int sgx_orb_profile_read(sgx_orb *h, float ms[4], int32_t launches[4], int reset);
+
 #ifdef __cplusplus
 }
 #endif

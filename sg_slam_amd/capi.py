@@ -22,6 +22,7 @@ SYMBOLS = [
     'sgx_orb_create', 'sgx_orb_destroy', 'sgx_orb_keypoint_capacity', 'sgx_orb_get_tables',
     'sgx_orb_extract_batch_dev', 'sgx_orb_extract', 'sgx_orb_last_status',
     'sgx_orb_debug_level_geometry', 'sgx_orb_debug_read_level', 'sgx_orb_debug_read_candidates',
+    'sgx_orb_debug_run_octree', 'sgx_orb_profile_enable', 'sgx_orb_profile_read',
 ]
 
 
@@ -57,6 +58,10 @@ class SgxLib:
         d.sgx_orb_debug_read_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         d.sgx_orb_debug_read_candidates.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                     C.c_int, C.POINTER(C.c_int)]
+
+        d.sgx_orb_debug_run_octree.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        d.sgx_orb_profile_enable.argtypes = [C.c_void_p, C.c_int]
+        d.sgx_orb_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
 
     def version(self):
         return self.dll.sgx_version().decode()

@@ -32,13 +32,41 @@ struct sgx_orb {
     uint8_t *d_pyr = nullptr;
     uint32_t *d_cand = nullptr;
     int *d_cand_count = nullptr;
+    uint16_t *d_node_scratch = nullptr;
     uint32_t *d_sel = nullptr;
     int *d_sel_count = nullptr;
     uint32_t *d_status = nullptr;
     // single-frame staging for sgx_orb_extract
     uint8_t *d_gray1 = nullptr; uint8_t *d_kps1 = nullptr; uint8_t *d_desc1 = nullptr; int *d_count1 = nullptr;
     int last_batch = 0;
+    // optional per-kernel HIP-event profiling (sgx_orb_profile_*)
+    int prof_on = 0;
+#ifndef SGX_EMU
+    std::vector<hipEvent_t> ev_a[4], ev_b[4];   // kernel classes: 0 resize (all levels), 1 fast_cells, 2 octree, 3 orient_desc
+    int ev_used[4] = {0, 0, 0, 0};
+#endif
 };
+
+#ifndef SGX_EMU
+static void prof_begin(sgx_orb *h, int k, hipStream_t st)
+{
+    if (!h->prof_on) return;
+    if (h->ev_used[k] == (int)h->ev_a[k].size()) {
+        hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+        h->ev_a[k].push_back(a); h->ev_b[k].push_back(b);
+    }
+    (void)hipEventRecord(h->ev_a[k][h->ev_used[k]], st);
+}
+static void prof_end(sgx_orb *h, int k, hipStream_t st)
+{
+    if (!h->prof_on) return;
+    (void)hipEventRecord(h->ev_b[k][h->ev_used[k]], st);
+    h->ev_used[k]++;
+}
+#else
+static void prof_begin(sgx_orb *, int, sgx_stream_t) {}
+static void prof_end(sgx_orb *, int, sgx_stream_t) {}
+#endif
 
 static inline int cvround_f(float v) { return (int)lrintf(v); }
 static inline int cvround_d(double v) { return (int)lrint(v); }
@@ -117,7 +145,7 @@ extern "C" void sgx_orb_destroy(sgx_orb *h)
 {
     if (!h) return;
     (void)hipFree(h->d_cells); (void)hipFree(h->d_umax); (void)hipFree(h->d_pattern); (void)hipFree(h->d_pyr); (void)hipFree(h->d_cand);
-    (void)hipFree(h->d_cand_count); (void)hipFree(h->d_sel); (void)hipFree(h->d_sel_count); (void)hipFree(h->d_status);
+    (void)hipFree(h->d_cand_count); (void)hipFree(h->d_node_scratch); (void)hipFree(h->d_sel); (void)hipFree(h->d_sel_count); (void)hipFree(h->d_status);
     (void)hipFree(h->d_gray1); (void)hipFree(h->d_kps1); (void)hipFree(h->d_desc1); (void)hipFree(h->d_count1);
     for (int l = 0; l < SGX_MAX_LEVELS; l++) { (void)hipFree(h->d_xt[l]); (void)hipFree(h->d_yt[l]); }
     delete h;
@@ -135,7 +163,7 @@ extern "C" int sgx_orb_create(const sgx_orb_config *cfg, sgx_orb **out)
     g.nlevels = cfg->nlevels; g.W = cfg->width; g.H = cfg->height; g.ini_th = cfg->ini_th_fast; g.min_th = cfg->min_th_fast;
     build_tables(h);
     std::vector<SgxCell> cells;
-    int off = 0, kp_cap = 0;
+    int off = 0, kp_cap = 0, cand_off = 0;
     for (int l = 0; l < g.nlevels; l++) {
         SgxLevel &L = g.lv[l];
         L.w = cvround_f((float)cfg->width * h->inv_scale[l]);      // ORBextractor.cc:1112-1113
@@ -153,6 +181,7 @@ extern "C" int sgx_orb_create(const sgx_orb_config *cfg, sgx_orb **out)
         if (L.ncols < 1 || L.nrows < 1) { sgx_orb_destroy(h); return SGX_ERR_UNSUPPORTED; }
         L.wcell = (int)ceilf(width / L.ncols); L.hcell = (int)ceilf(height / L.nrows);
         L.cell0 = (int)cells.size();
+        L.cand_off = cand_off; L.cand_cap = 0;
         if (L.wcell + 6 > SGX_TILE_MAX || L.hcell + 6 > SGX_TILE_MAX || L.ncols > 1023 || L.nrows > 1023 || L.wcell > 1023 || L.hcell > 1023) {
             sgx_orb_destroy(h); return SGX_ERR_UNSUPPORTED; }
         for (int i = 0; i < L.nrows; i++) {
@@ -168,14 +197,20 @@ extern "C" int sgx_orb_create(const sgx_orb_config *cfg, sgx_orb **out)
                 SgxCell c; c.level = (short)l; c.x0 = (short)iniX; c.y0 = (short)iniY;
                 c.cw = (short)((int)maxX - (int)iniX); c.ch = (short)((int)maxY - (int)iniY);
                 c.ox = (short)(j * L.wcell); c.oy = (short)(i * L.hcell); c.pad = 0;
-                if (c.cw >= 7 && c.ch >= 7) cells.push_back(c);      // cv::FAST yields nothing on tiles < 7 px
+                if (c.cw >= 7 && c.ch >= 7) {                        // cv::FAST yields nothing on tiles < 7 px
+                    cells.push_back(c);
+                    L.cand_cap += ((c.cw - 6 + 1) / 2) * ((c.ch - 6 + 1) / 2);   // strict-'>' NMS: no two survivors are 8-adjacent
+                }
             }
         }
         const int nIni = (int)roundf((float)(maxBX - minBX) / (float)(maxBY - minBY));
         int lim = L.quota + 3; if (lim < 4 * nIni) lim = 4 * nIni;
         if (lim > SGX_OCT_MAXN) { sgx_orb_destroy(h); return SGX_ERR_UNSUPPORTED; }
         kp_cap += lim;
+        L.cand_cap = (L.cand_cap + 63) & ~63;
+        cand_off += L.cand_cap;
     }
+    g.cand_pitch = cand_off;
     g.pyr_pitch = (off + 255) & ~255;
     g.ncells = (int)cells.size();
     g.kp_cap = kp_cap;
@@ -186,7 +221,8 @@ extern "C" int sgx_orb_create(const sgx_orb_config *cfg, sgx_orb **out)
     SGX_ALLOC(h->d_umax, 16 * sizeof(int));
     SGX_ALLOC(h->d_pattern, 1024);
     SGX_ALLOC(h->d_pyr, (size_t)B * g.pyr_pitch + 256);
-    SGX_ALLOC(h->d_cand, (size_t)B * nl * SGX_CAND_CAP * 4);
+    SGX_ALLOC(h->d_cand, (size_t)B * g.cand_pitch * 4);
+    SGX_ALLOC(h->d_node_scratch, (size_t)B * g.cand_pitch * 2);
     SGX_ALLOC(h->d_cand_count, (size_t)B * nl * 4);
     SGX_ALLOC(h->d_sel, (size_t)B * nl * SGX_OCT_MAXN * 4);
     SGX_ALLOC(h->d_sel_count, (size_t)B * nl * 4);
@@ -239,15 +275,24 @@ extern "C" int sgx_orb_extract_batch_dev(sgx_orb *h, const uint8_t *d_gray, int 
     const int nl = g.nlevels;
     h->last_batch = batch;
     SGX_CHECK_HIP(hipMemsetAsync(h->d_cand_count, 0, (size_t)batch * nl * 4, stream));
+    prof_begin(h, 0, stream);
     for (int l = 1; l < nl; l++) {
         dim3 grid((g.lv[l].w + 255) / 256, (g.lv[l].h + 3) / 4, batch);
         SGX_LAUNCH(k_resize, grid, dim3(256), stream, g, l, d_gray, pitch, h->d_pyr, h->d_xt[l], h->d_yt[l]);
     }
+    prof_end(h, 0, stream);
+    prof_begin(h, 1, stream);
     SGX_LAUNCH(k_fast_cells, dim3(g.ncells * batch), dim3(256), stream, g, h->d_cells, d_gray, pitch, h->d_pyr, batch,
                h->d_cand, h->d_cand_count, h->d_status);
-    SGX_LAUNCH(k_octree, dim3(nl, batch), dim3(SGX_OCT_THREADS), stream, g, h->d_cand, h->d_cand_count, h->d_sel, h->d_sel_count, h->d_status);
+    prof_end(h, 1, stream);
+    prof_begin(h, 2, stream);
+    SGX_LAUNCH(k_octree<true>, dim3(nl, batch), dim3(SGX_OCT_THREADS), stream, g, h->d_cand, h->d_cand_count, h->d_node_scratch, h->d_sel, h->d_sel_count, h->d_status);
+    SGX_LAUNCH(k_octree<false>, dim3(nl, batch), dim3(SGX_OCT_THREADS), stream, g, h->d_cand, h->d_cand_count, h->d_node_scratch, h->d_sel, h->d_sel_count, h->d_status);
+    prof_end(h, 2, stream);
+    prof_begin(h, 3, stream);
     SGX_LAUNCH(k_orient_desc, dim3(g.kp_cap, batch), dim3(64), stream, g, d_gray, pitch, h->d_pyr, h->d_sel, h->d_sel_count,
                h->d_umax, h->d_pattern, (uint8_t *)d_kps, d_desc, d_count, cap, h->d_status);
+    prof_end(h, 3, stream);
     SGX_CHECK_HIP(hipGetLastError());
     return SGX_OK;
 }
@@ -306,11 +351,54 @@ extern "C" int sgx_orb_debug_read_candidates(sgx_orb *h, int frame, int level, i
     int cnt = 0;
     SGX_CHECK_HIP(hipMemcpyAsync(&cnt, h->d_cand_count + frame * h->g.nlevels + level, 4, hipMemcpyDeviceToHost, 0));
     SGX_CHECK_HIP(hipStreamSynchronize(0));
-    if (cnt > SGX_CAND_CAP) cnt = SGX_CAND_CAP;
+    if (cnt > h->g.lv[level].cand_cap) cnt = h->g.lv[level].cand_cap;
     std::vector<uint32_t> buf(cnt > 0 ? cnt : 1);
-    SGX_CHECK_HIP(hipMemcpyAsync(buf.data(), h->d_cand + ((size_t)frame * h->g.nlevels + level) * SGX_CAND_CAP, (size_t)cnt * 4, hipMemcpyDeviceToHost, 0));
+    SGX_CHECK_HIP(hipMemcpyAsync(buf.data(), h->d_cand + (size_t)frame * h->g.cand_pitch + h->g.lv[level].cand_off, (size_t)cnt * 4, hipMemcpyDeviceToHost, 0));
     SGX_CHECK_HIP(hipStreamSynchronize(0));
     for (int i = 0; i < cnt && i < cap; i++) { x[i] = buf[i] & 0xFFF; y[i] = (buf[i] >> 12) & 0xFFF; score[i] = buf[i] >> 24; }
     *n = cnt;
     return SGX_OK;
+}
+
+extern "C" int sgx_orb_profile_enable(sgx_orb *h, int on)
+{
+    if (!h) return SGX_ERR_INVALID;
+    h->prof_on = on ? 1 : 0;
+    return SGX_OK;
+}
+
+// ms[4] = summed duration per kernel class since the last reset, launches[4] = number of timed launches
+extern "C" int sgx_orb_profile_read(sgx_orb *h, float *ms, int32_t *launches, int reset)
+{
+    if (!h || !ms || !launches) return SGX_ERR_INVALID;
+    for (int k = 0; k < 4; k++) { ms[k] = 0.f; launches[k] = 0; }
+#ifndef SGX_EMU
+    SGX_CHECK_HIP(hipDeviceSynchronize());
+    for (int k = 0; k < 4; k++) {
+        for (int i = 0; i < h->ev_used[k]; i++) { float t = 0.f; SGX_CHECK_HIP(hipEventElapsedTime(&t, h->ev_a[k][i], h->ev_b[k][i])); ms[k] += t; }
+        launches[k] = h->ev_used[k];
+        if (reset) h->ev_used[k] = 0;
+    }
+#endif
+    return SGX_OK;
+}
+
+// test tap: run k_octree alone on a caller-supplied candidate list for `level` (frame slot 0)
+extern "C" int sgx_orb_debug_run_octree(sgx_orb *h, int level, const uint32_t *packed, int n, uint32_t *out_sel, int cap, int *nsel)
+{
+    if (!h || !packed || !out_sel || !nsel || level < 0 || level >= h->g.nlevels || n < 0 || n > h->g.lv[level].cand_cap) return SGX_ERR_INVALID;
+    const int nl = h->g.nlevels;
+    std::vector<int> cnt(nl, 0); cnt[level] = n;
+    SGX_CHECK_HIP(hipMemcpyAsync(h->d_cand_count, cnt.data(), nl * 4, hipMemcpyHostToDevice, 0));
+    SGX_CHECK_HIP(hipMemcpyAsync(h->d_cand + h->g.lv[level].cand_off, packed, (size_t)n * 4, hipMemcpyHostToDevice, 0));
+    SGX_LAUNCH(k_octree<true>, dim3(nl, 1), dim3(SGX_OCT_THREADS), (sgx_stream_t)0, h->g, h->d_cand, h->d_cand_count, h->d_node_scratch, h->d_sel, h->d_sel_count, h->d_status);
+    SGX_LAUNCH(k_octree<false>, dim3(nl, 1), dim3(SGX_OCT_THREADS), (sgx_stream_t)0, h->g, h->d_cand, h->d_cand_count, h->d_node_scratch, h->d_sel, h->d_sel_count, h->d_status);
+    int ns = 0;
+    SGX_CHECK_HIP(hipMemcpyAsync(&ns, h->d_sel_count + level, 4, hipMemcpyDeviceToHost, 0));
+    SGX_CHECK_HIP(hipStreamSynchronize(0));
+    if (ns > cap) return SGX_ERR_OVERFLOW;
+    SGX_CHECK_HIP(hipMemcpyAsync(out_sel, h->d_sel + (size_t)level * SGX_OCT_MAXN, (size_t)ns * 4, hipMemcpyDeviceToHost, 0));
+    SGX_CHECK_HIP(hipStreamSynchronize(0));
+    *nsel = ns;
+    return sgx_orb_last_status(h, 0);
 }

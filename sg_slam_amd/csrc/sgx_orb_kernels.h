@@ -15,7 +15,7 @@
 #define SGX_BORDER 16          /* EDGE_THRESHOLD-3 = minBorderX/Y, ORBextractor.cc:774 */
 #define SGX_TILE_MAX 68        /* max FAST cell tile edge incl. 3-px aprons */
 #define SGX_TILE_STRIDE 72
-#define SGX_CAND_CAP 8192      /* max FAST candidates per (frame, level) */
+#define SGX_CAND_LDS 8192      /* k_octree keeps up to this many keys of a (frame, level) in LDS; more -> global-memory variant */
 #define SGX_OCT_MAXN 1280      /* max octree list length (per-level quota + 3) */
 #define SGX_OCT_THREADS 256
 
@@ -26,6 +26,7 @@ struct SgxLevel {
     int ncols, nrows, wcell, hcell;  // FAST cell grid (ORBextractor.cc:785-788)
     int cell0;                 // index of this level's first cell in the cell table
     int patch_size;            // (int)(31*scale)
+    int cand_off, cand_cap;    // slice of one frame's candidate buffer (cap = exact upper bound of NMS survivors)
     float scale;               // mvScaleFactor[level]
 };
 
@@ -34,6 +35,7 @@ struct SgxOrbGeom {
     int pyr_pitch;             // bytes per frame of pyramid storage (levels 1..)
     int ncells;                // total valid cells over all levels
     int kp_cap;                // keypoint capacity per frame
+    int cand_pitch;            // candidate entries per frame (all levels)
     int ini_th, min_th;
     SgxLevel lv[SGX_MAX_LEVELS];
 };
@@ -229,13 +231,14 @@ SGX_KERNEL(256) k_fast_cells(SgxOrbGeom g, const SgxCell *cells, const uint8_t *
     SGX_THREADS_END
     SGX_SYNC();
     if (n_emit > 0) {
-        uint32_t *dst = cand + ((size_t)frame * g.nlevels + level) * SGX_CAND_CAP;
+        uint32_t *dst = cand + (size_t)frame * g.cand_pitch + g.lv[level].cand_off;
+        const int dcap = g.lv[level].cand_cap;
         SGX_THREADS_BEGIN(tid)
         for (int i = tid; i < n_lo; i += (int)blockDim.x) {
             const uint32_t e = outbuf[i];
             if ((int)(e >> 24) >= use_thr) {
                 const int slot = out_base + sgx_atomic_add(&n_corner, 1);
-                if (slot < SGX_CAND_CAP) dst[slot] = e;
+                if (slot < dcap) dst[slot] = e;
                 else sgx_atomic_or(status, SGX_ST_CAND_OVERFLOW);
             }
         }
@@ -286,12 +289,16 @@ SGX_DEV unsigned long long sgx_oct_pick_key(uint32_t e, int wcell, int hcell)
     return ((unsigned long long)(e >> 24) << 40) | (0xFFFFFFFFFFull - rank);
 }
 
-SGX_KERNEL(SGX_OCT_THREADS) k_octree(SgxOrbGeom g, const uint32_t *cand, const int *cand_count,
+template <bool KEYS_IN_LDS>
+SGX_KERNEL(SGX_OCT_THREADS) k_octree(SgxOrbGeom g, const uint32_t *cand, const int *cand_count, uint16_t *node_scratch,
                                      uint32_t *sel, int *sel_count, uint32_t *status)
 {
-    // keys
-    SGX_LDS uint32_t kxy[SGX_CAND_CAP];          // packed x | y<<12 | S<<24
-    SGX_LDS uint16_t node_of[SGX_CAND_CAP];
+    // keys: packed x | y<<12 | S<<24 and the list position of the node that owns each key.
+    // Normal case: both in LDS.  A (frame, level) with more than SGX_CAND_LDS candidates (e.g. pure
+    // noise) is handled by the KEYS_IN_LDS=false instantiation, which reads the keys from the
+    // candidate buffer and keeps node_of in a global scratch slice; each block runs in exactly one.
+    SGX_LDS uint32_t kxy_lds[KEYS_IN_LDS ? SGX_CAND_LDS : 1];
+    SGX_LDS uint16_t node_lds[KEYS_IN_LDS ? SGX_CAND_LDS : 1];
     // node list (array in list order), ping-pong
     SGX_LDS SgxOctNode nb[2][SGX_OCT_MAXN];
     SGX_LDS uint16_t ncnt[2][SGX_OCT_MAXN];      // keys per node
@@ -311,8 +318,11 @@ SGX_KERNEL(SGX_OCT_THREADS) k_octree(SgxOrbGeom g, const uint32_t *cand, const i
     const SgxLevel L = g.lv[level];
     const int N = L.quota;
     int nk = cand_count[frame * g.nlevels + level];
-    if (nk > SGX_CAND_CAP) nk = SGX_CAND_CAP;
-    const uint32_t *src = cand + ((size_t)frame * g.nlevels + level) * SGX_CAND_CAP;
+    if (nk > L.cand_cap) nk = L.cand_cap;
+    if ((nk <= SGX_CAND_LDS) != KEYS_IN_LDS) return;
+    const uint32_t *src = cand + (size_t)frame * g.cand_pitch + L.cand_off;
+    uint32_t *kxy = KEYS_IN_LDS ? kxy_lds : (uint32_t *)src;
+    uint16_t *node_of = KEYS_IN_LDS ? node_lds : node_scratch + (size_t)frame * g.cand_pitch + L.cand_off;
     uint32_t *out = sel + ((size_t)frame * g.nlevels + level) * SGX_OCT_MAXN;
     const int NT = (int)blockDim.x;
 
@@ -334,7 +344,7 @@ SGX_KERNEL(SGX_OCT_THREADS) k_octree(SgxOrbGeom g, const uint32_t *cand, const i
     SGX_THREADS_BEGIN(tid)
     for (int k = tid; k < nk; k += NT) {
         const uint32_t e = src[k];
-        kxy[k] = e;
+        if (KEYS_IN_LDS) kxy[k] = e;
         const int r = (int)((float)(e & 0xFFF) / hX);       // vpIniNodes[kp.pt.x/hX] :570
         node_of[k] = (uint16_t)r;
         sgx_atomic_add(&scanA[r], 1);

@@ -19,13 +19,13 @@
 #define SGX_THREADS_END }
 #define SGX_SYNC() __syncthreads()
 #define SGX_LDS __shared__
-#define SGX_KERNEL(bounds) extern "C" __global__ void __launch_bounds__(bounds)
+#define SGX_KERNEL(bounds) __global__ void __launch_bounds__(bounds)
 #define SGX_DEV __device__ __forceinline__
 #define SGX_CONST __constant__
 #define sgx_atomic_add(p, v) atomicAdd((p), (v))
 #define sgx_atomic_max(p, v) atomicMax((p), (v))
 #define sgx_atomic_or(p, v) atomicOr((p), (v))
-#define SGX_LAUNCH(kern, grid, block, stream, ...) hipLaunchKernelGGL(kern, grid, block, 0, stream, __VA_ARGS__)
+#define SGX_LAUNCH(kern, grid, block, stream, ...) hipLaunchKernelGGL((kern), grid, block, 0, stream, __VA_ARGS__)
 #define SGX_POPCLL(x) __popcll(x)
 typedef hipStream_t sgx_stream_t;
 #else
@@ -50,7 +50,7 @@ template <class T, class U> static inline T sgx_atomic_or(T *p, U v) { T o = *p;
 #define SGX_LAUNCH(kern, grid, block, stream, ...)                                        \
     do { sgx_dim3 _g = (grid), _b = (block); gridDim = _g; blockDim = _b;                  \
          for (unsigned _z = 0; _z < _g.z; ++_z) for (unsigned _y = 0; _y < _g.y; ++_y)     \
-         for (unsigned _x = 0; _x < _g.x; ++_x) { blockIdx = sgx_dim3(_x, _y, _z); kern(__VA_ARGS__); } } while (0)
+         for (unsigned _x = 0; _x < _g.x; ++_x) { blockIdx = sgx_dim3(_x, _y, _z); (kern)(__VA_ARGS__); } } while (0)
 #define SGX_POPCLL(x) __builtin_popcountll(x)
 typedef void *sgx_stream_t;
 using std::min; using std::max;

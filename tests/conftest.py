@@ -1,0 +1,59 @@
+import os
+import subprocess
+import sys
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def _have_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+HAVE_GPU = _have_gpu()
+
+
+@pytest.fixture(scope='session')
+def oracle():
+    from oracle import oracle as orc
+    orc.lib()
+    return orc
+
+
+@pytest.fixture(scope='session')
+def emu():
+    """Kernel-logic emulator: the product kernels compiled with -DSGX_EMU for the host (tests only)."""
+    from sg_slam_amd.capi import SgxLib
+    so = os.path.join(ROOT, 'tests', 'emu', 'libsgx_emu.so')
+    subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'sg_slam_amd', 'csrc'), 'emu'])
+    lib = SgxLib(so)
+    assert 'EMULATOR' in lib.version()
+    return lib
+
+
+@pytest.fixture(scope='session')
+def gpulib():
+    """The product library on a real GPU; must be the HIP build."""
+    if not HAVE_GPU:
+        pytest.skip('no GPU')
+    import sg_slam_amd
+    lib = sg_slam_amd.load()
+    assert 'gfx950' in lib.version()
+    return lib
+
+
+@pytest.fixture(scope='session')
+def stream_frames():
+    from sg_slam_amd import synth
+    S = synth.PlaneStream(seed=1234)
+    return S

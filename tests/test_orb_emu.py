@@ -1,0 +1,113 @@
+"""Kernel LOGIC parity without a GPU: the product's HIP kernel sources compiled with -DSGX_EMU
+(tests/emu/libsgx_emu.so, sequential workgroup emulation) against the CPU oracle, bit-exact.
+The same assertions run on the real device in tests/test_orb_gpu.py."""
+import numpy as np
+import pytest
+from sg_slam_amd import synth
+from sg_slam_amd.orb import ORBextractor
+
+
+@pytest.fixture(scope='module')
+def ex(emu):
+    e = ORBextractor(lib=emu, max_batch=2)
+    yield e
+    e.close()
+
+
+def _same(ka, da, kb, db):
+    return len(ka) == len(kb) and (ka == kb).all() and da.shape == db.shape and (da == db).all()
+
+
+@pytest.mark.parametrize('t', [0, 1, 7, 23])
+def test_extract_matches_oracle(ex, oracle, stream_frames, t):
+    g, _, _ = stream_frames.frame(t)
+    k, d = ex(g)
+    ko, do = oracle.orb_extract(g)
+    assert _same(k, d, ko, do)
+
+
+def test_stage_taps_match_oracle(ex, oracle, stream_frames):
+    g, _, _ = stream_frames.frame(5)
+    ex(g)
+    _, _, pyr, nc = oracle.orb_extract(g, want_pyr=True)
+    off = 640 * 480
+    for l, (w, h) in enumerate(oracle.level_sizes(640, 480)):
+        if l == 0:
+            lvl = g
+        else:
+            lvl = pyr[off:off + w * h].reshape(h, w); off += w * h
+            assert (ex.debug_level(0, l) == lvl).all()
+        x, y, s = ex.debug_candidates(0, l)
+        cx, cy, cr = oracle.level_candidates(lvl)
+        assert len(x) == nc[l] == len(cx)
+        assert sorted(zip(x, y, s)) == sorted(zip(cx.astype(int), cy.astype(int), cr.astype(int)))
+
+
+def test_degenerate_images(ex, oracle):
+    k, d = ex(synth.constant_image())
+    assert len(k) == 0 and d.shape == (0, 32)
+    img = synth.low_contrast_image()
+    k, d = ex(img)
+    ko, do = oracle.orb_extract(img)
+    assert _same(k, d, ko, do) and len(k) > 100
+
+
+def test_random_noise_image(ex, oracle):
+    # pure noise: ~every cell saturated with corners, stresses candidate volume and octree phase 2
+    rng = np.random.RandomState(3)
+    img = rng.randint(0, 256, (480, 640)).astype(np.uint8)
+    k, d = ex(img)
+    ko, do = oracle.orb_extract(img)
+    assert _same(k, d, ko, do)
+
+
+def test_batched_call_equals_single(ex, oracle, stream_frames, emu):
+    g0, _, _ = stream_frames.frame(2); g1, _, _ = stream_frames.frame(3)
+    batch = np.stack([g0, g1])
+    cap = ex.capacity
+    from sg_slam_amd.capi import KP_DTYPE
+    kps = np.zeros((2, cap), KP_DTYPE); desc = np.zeros((2, cap, 32), np.uint8); cnt = np.zeros(2, 'i4')
+    ex.extract_batch_dev(batch, 640, 2, kps, desc, cnt)
+    ex.last_status()
+    for b, g in enumerate((g0, g1)):
+        ko, do = oracle.orb_extract(g)
+        assert _same(kps[b, :cnt[b]], desc[b, :cnt[b]], ko, do)
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_octree_kernel_random_candidates(ex, oracle, seed):
+    """k_octree alone vs the oracle's list-based DistributeOctTree on random candidate sets,
+    including heavy response ties and clustered points (phase-2 ordering, early-stop rule)."""
+    rng = np.random.RandomState(100 + seed)
+    level = seed % 8
+    w, h = oracle.level_sizes(640, 480)[level]
+    p = oracle.orb_params()
+    N = int(p['per_level'][level])
+    W, H = w - 32, h - 32                      # candidate coordinate range (relative to the border origin)
+    n = int(rng.choice([1, 2, 5, N // 2, N, 3 * N, 8 * N, min(8000, 30 * N)]))
+    # cell-interior coordinates start at 3 (a FAST candidate never sits in the 3-px apron)
+    if seed % 3 == 0:      # clustered
+        cx = rng.randint(3, W - 3, 6); cy = rng.randint(3, H - 3, 6)
+        k = rng.randint(0, 6, n * 2)
+        xs = np.clip(cx[k] + rng.randint(-25, 26, n * 2), 3, W - 4); ys = np.clip(cy[k] + rng.randint(-25, 26, n * 2), 3, H - 4)
+    else:
+        xs = rng.randint(3, W - 3, n * 2); ys = rng.randint(3, H - 3, n * 2)
+    pts = np.unique(np.stack([ys, xs], 1), axis=0)[:n]          # distinct pixels
+    rng.shuffle(pts)
+    ys, xs = pts[:, 0], pts[:, 1]
+    resp = rng.randint(7, 12 if seed % 2 else 200, len(xs))     # many ties when the range is narrow
+    # oracle consumes candidates in the reference's cell-raster order
+    lv = [l for l in range(8)][level]
+    geomN = oracle.orb_params()
+    # order by (cell row, cell col, y, x) as ComputeKeyPointsOctTree produces them
+    width = float(w - 32); height = float(h - 32)
+    ncols = int(width / 30); nrows = int(height / 30)
+    wcell = int(np.ceil(width / ncols)); hcell = int(np.ceil(height / nrows))
+    order = np.lexsort((xs, ys, (xs - 3) // wcell, (ys - 3) // hcell))
+    xo, yo, ro = xs[order], ys[order], resp[order]
+    sel = oracle.distribute_octree(xo.astype('f4'), yo.astype('f4'), ro.astype('f4'), 16, w - 16, 16, h - 16, N)
+    exp = list(zip(xo[sel], yo[sel], ro[sel]))
+    # kernel gets them shuffled (k_fast_cells appends unordered)
+    perm = rng.permutation(len(xs))
+    gx, gy, gs = ex.debug_run_octree(level, xs[perm], ys[perm], resp[perm])
+    assert list(zip(gx, gy, gs)) == exp
