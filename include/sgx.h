@@ -82,6 +82,47 @@ int sgx_orb_debug_read_level(sgx_orb *h, int frame, int level, uint8_t *dst /* w
  * (16,16) border origin exactly as pushed at ORBextractor.cc:823-825; returns count in *n */
 int sgx_orb_debug_read_candidates(sgx_orb *h, int frame, int level, int32_t *x, int32_t *y, int32_t *score, int cap, int *n);
 
+/* ---- ORB matcher ----------------------------------------------------------------------------
+ * Replaces ORB_SLAM2::ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame,
+ * const float th, const bool bMono)  (src/sg-slam/include/ORBmatcher.h:56, src/sg-slam/src/ORBmatcher.cc:1332-1472),
+ * the motion-model tracker's matcher (Tracking.cc:924-931), including Frame::GetFeaturesInArea's
+ * 64x48-grid candidate semantics (Frame.cc:354-419), the greedy "observed map point keeps its
+ * keypoint" rule (:1407-1409) and the rotation-histogram filter (:1436-1469).
+ * Frames are passed flattened: per keypoint arrays with a common per-frame
+ * pitch `cap`.  l_* arrays describe LastFrame.mvpMapPoints[i]: has_mp (non-NULL), outlier
+ * (mvbOutlier), xw (GetWorldPos, 3 floats), obs (Observations()), mpdesc (GetDescriptor(), 32 B).
+ * cur_match[k] (out) = index i of the last-frame map point assigned to current keypoint k, or -1;
+ * the current frame starts with no map points, as at Tracking.cc:919. */
+typedef struct sgx_camera {
+    float fx, fy, cx, cy, bf;                  /* Frame::fx.. and mbf */
+    float min_x, max_x, min_y, max_y;          /* Frame::mnMinX.. (0,cols,0,rows for zero distortion, Frame.cc:707-713) */
+} sgx_camera;
+
+int sgx_match_project_frame_batch_dev(
+    int batch, int cap,
+    const sgx_keypoint *d_ckeys, const uint8_t *d_cdesc, const float *d_curight, const int32_t *d_cn, const float *d_cTcw,
+    const sgx_keypoint *d_lkeys, const int32_t *d_ln, const uint8_t *d_l_has_mp, const uint8_t *d_l_outlier, const float *d_l_xw,
+    const int32_t *d_l_obs, const uint8_t *d_l_mpdesc, const float *d_lTcw,
+    const sgx_camera *cam, const float *scale_factors, int nlevels, float th, int b_mono, int check_orientation,
+    int32_t *d_cur_match, int32_t *d_nmatches, void *stream);
+/* host pointers, one frame pair, synchronous */
+int sgx_match_project_frame(
+    int nc, const sgx_keypoint *ckeys, const uint8_t *cdesc, const float *curight, const float *cTcw,
+    int nl, const sgx_keypoint *lkeys, const uint8_t *l_has_mp, const uint8_t *l_outlier, const float *l_xw,
+    const int32_t *l_obs, const uint8_t *l_mpdesc, const float *lTcw,
+    const sgx_camera *cam, const float *scale_factors, int nlevels, float th, int b_mono, int check_orientation,
+    int32_t *cur_match, int32_t *nmatches);
+
+/* ---- per-frame glue between the accelerated stages (device resident) -----------------------------
+ * Frame::ComputeStereoFromRGBD (Frame.cc:893-914) fused with the u16 -> metres conversion
+ * (Tracking.cc:229-230): uright[i] = x - bf/d, zdepth[i] = d, or -1 when depth is 0. */
+int sgx_frame_stereo_from_rgbd_batch_dev(int batch, int cap, const sgx_keypoint *d_keys, const int32_t *d_n,
+                                         const uint16_t *d_depth, int width, int height, float depth_map_factor,
+                                         float bf, float *d_uright, float *d_zdepth, void *stream);
+/* Frame::UnprojectStereo (Frame.cc:916-930) for every keypoint: xw = Rwc*x3Dc + Ow, has = depth>0 */
+int sgx_frame_unproject_batch_dev(int batch, int cap, const sgx_keypoint *d_keys, const int32_t *d_n, const float *d_zdepth,
+                                  const float *d_Tcw, const sgx_camera *cam, float *d_xw, uint8_t *d_has, void *stream);
+
 /* run the octree-distribution kernel alone on packed candidates (x | y<<12 | score<<24, coordinates
  * relative to the (16,16) border origin) for `level`; returns the selected packed entries in list order */
 int sgx_orb_debug_run_octree(sgx_orb *h, int level, const uint32_t *packed, int n, uint32_t *out_sel, int cap, int *nsel);

@@ -1,0 +1,236 @@
+/* oracle/match_oracle.c — CPU ORACLE for the ORB matcher stage.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Restates, with the reference's own sequential/greedy semantics:
+ *   ORBmatcher::DescriptorDistance            src/sg-slam/src/ORBmatcher.cc:1649-1665
+ *   ORBmatcher::SearchByProjection(cur,last)  src/sg-slam/src/ORBmatcher.cc:1332-1472
+ *   ORBmatcher::ComputeThreeMaxima            src/sg-slam/src/ORBmatcher.cc:1603-1644
+ *   Frame::AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea   src/sg-slam/src/Frame.cc:257-272,409-419,354-407
+ *   Frame::ComputeStereoFromRGBD / UnprojectStereo                src/sg-slam/src/Frame.cc:893-932
+ * The 3x3 float cv::Mat products the reference uses (Rcw*x3Dw+tcw etc.) go through OpenCV's
+ * cv::gemm small-matrix path (not in the reference tree): t = a0*b0+a1*b1+a2*b2 in float, then
+ * (float)(t*alpha + beta*c) in double.   ==> PARITY UNPINNED at that boundary <==
+ * Only tests/, smoke() and bench.py's cpu_baseline leg may load this.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct { float x, y, size, angle, response; int octave, class_id; } orc_keypoint;
+
+#define GRID_COLS 64
+#define GRID_ROWS 48
+#define TH_HIGH 100
+#define HISTO_LENGTH 30
+
+int orc_descriptor_distance(const uint8_t *a, const uint8_t *b)
+{
+    const uint32_t *pa = (const uint32_t *)a, *pb = (const uint32_t *)b;
+    int dist = 0;
+    for (int i = 0; i < 8; i++) {
+        uint32_t v = pa[i] ^ pb[i];
+        v = v - ((v >> 1) & 0x55555555);
+        v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+        dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+    }
+    return dist;
+}
+
+/* cv::gemm small path: d = (float)((a_row . b)*alpha + beta*c), dot in float left-to-right */
+static float gemm3(const float *arow, const float *b, double alpha, double beta, float c)
+{
+    float t = arow[0] * b[0] + arow[1] * b[1] + arow[2] * b[2];
+    return (float)(t * alpha + beta * c);
+}
+
+typedef struct { int *idx; int n, cap; } cellvec;
+
+typedef struct {
+    cellvec cell[GRID_COLS][GRID_ROWS];
+    float minX, maxX, minY, maxY, invW, invH;
+} grid_t;
+
+static void grid_build(grid_t *g, int N, const orc_keypoint *keys, float minX, float maxX, float minY, float maxY)
+{
+    memset(g, 0, sizeof *g);
+    g->minX = minX; g->maxX = maxX; g->minY = minY; g->maxY = maxY;
+    g->invW = (float)GRID_COLS / (maxX - minX);      /* Frame.cc:184-185 */
+    g->invH = (float)GRID_ROWS / (maxY - minY);
+    for (int i = 0; i < N; i++) {
+        int px = (int)round((keys[i].x - minX) * g->invW);     /* PosInGrid: round(), Frame.cc:411-412 */
+        int py = (int)round((keys[i].y - minY) * g->invH);
+        if (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) continue;
+        cellvec *c = &g->cell[px][py];
+        if (c->n == c->cap) { c->cap = c->cap ? 2 * c->cap : 8; c->idx = (int *)realloc(c->idx, sizeof(int) * c->cap); }
+        c->idx[c->n++] = i;
+    }
+}
+static void grid_free(grid_t *g) { for (int i = 0; i < GRID_COLS; i++) for (int j = 0; j < GRID_ROWS; j++) free(g->cell[i][j].idx); }
+
+/* Frame::GetFeaturesInArea, Frame.cc:354-407; returns count, indices in the reference's scan order */
+static int features_in_area(const grid_t *g, const orc_keypoint *keys, float x, float y, float r, int minLevel, int maxLevel, int *out)
+{
+    int n = 0;
+    int nMinCellX = (int)floorf((x - g->minX - r) * g->invW); if (nMinCellX < 0) nMinCellX = 0;
+    if (nMinCellX >= GRID_COLS) return 0;
+    int nMaxCellX = (int)ceilf((x - g->minX + r) * g->invW); if (nMaxCellX > GRID_COLS - 1) nMaxCellX = GRID_COLS - 1;
+    if (nMaxCellX < 0) return 0;
+    int nMinCellY = (int)floorf((y - g->minY - r) * g->invH); if (nMinCellY < 0) nMinCellY = 0;
+    if (nMinCellY >= GRID_ROWS) return 0;
+    int nMaxCellY = (int)ceilf((y - g->minY + r) * g->invH); if (nMaxCellY > GRID_ROWS - 1) nMaxCellY = GRID_ROWS - 1;
+    if (nMaxCellY < 0) return 0;
+    const int bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+        for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+            const cellvec *c = &g->cell[ix][iy];
+            for (int j = 0; j < c->n; j++) {
+                const orc_keypoint *kp = &keys[c->idx[j]];
+                if (bCheckLevels) {
+                    if (kp->octave < minLevel) continue;
+                    if (maxLevel >= 0 && kp->octave > maxLevel) continue;
+                }
+                const float dx = kp->x - x, dy = kp->y - y;
+                if (fabsf(dx) < r && fabsf(dy) < r) out[n++] = c->idx[j];
+            }
+        }
+    return n;
+}
+
+static void three_maxima(const int *cnt, int L, int *i1, int *i2, int *i3)
+{
+    int m1 = 0, m2 = 0, m3 = 0; *i1 = *i2 = *i3 = -1;
+    for (int i = 0; i < L; i++) {
+        const int s = cnt[i];
+        if (s > m1) { m3 = m2; m2 = m1; m1 = s; *i3 = *i2; *i2 = *i1; *i1 = i; }
+        else if (s > m2) { m3 = m2; m2 = s; *i3 = *i2; *i2 = i; }
+        else if (s > m3) { m3 = s; *i3 = i; }
+    }
+    if (m2 < 0.1f * (float)m1) { *i2 = -1; *i3 = -1; }
+    else if (m3 < 0.1f * (float)m1) { *i3 = -1; }
+}
+
+/* ORBmatcher::SearchByProjection(Frame &Cur, const Frame &Last, th, bMono), ORBmatcher.cc:1332-1472.
+ * cur_match[k] (in/out): index of the last-frame map point held by current keypoint k, -1 = NULL.
+ * l_obs[i] = MapPoint::Observations() of the last frame's i-th map point. Returns nmatches. */
+int orc_search_by_projection_frame(
+    int Nc, const orc_keypoint *ckeys, const uint8_t *cdesc, const float *curight, const float *cTcw,
+    int Nl, const orc_keypoint *lkeys, const uint8_t *l_has_mp, const uint8_t *l_outlier, const float *l_xw,
+    const int *l_obs, const uint8_t *l_mpdesc, const float *lTcw,
+    float fx, float fy, float cx, float cy, float bf, float minX, float maxX, float minY, float maxY,
+    const float *scale_factors, float th, int bMono, int check_ori, int *cur_match)
+{
+    int nmatches = 0;
+    grid_t *g = (grid_t *)malloc(sizeof(grid_t));
+    grid_build(g, Nc, ckeys, minX, maxX, minY, maxY);
+    int *hist[HISTO_LENGTH], hn[HISTO_LENGTH], hc[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) { hist[i] = NULL; hn[i] = 0; hc[i] = 0; }
+    const float factor = HISTO_LENGTH / 360.0f;
+    const float mb = bf / fx;                                   /* Frame.cc:196 */
+
+    /* Rcw, tcw (row-major 4x4) */
+    float Rcw[3][3], tcw[3], Rlw[3][3], tlw[3];
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) { Rcw[r][c] = cTcw[4 * r + c]; Rlw[r][c] = lTcw[4 * r + c]; } tcw[r] = cTcw[4 * r + 3]; tlw[r] = lTcw[4 * r + 3]; }
+    /* twc = -Rcw.t()*tcw : gemm with a transpose flag -> generic path, double accumulation, alpha=-1 */
+    float twc[3];
+    for (int i = 0; i < 3; i++) {
+        double s = 0; for (int k = 0; k < 3; k++) s += (double)Rcw[k][i] * (double)tcw[k];
+        twc[i] = (float)(s * -1.0);
+    }
+    /* tlc = Rlw*twc+tlw */
+    const float tlc2 = gemm3(Rlw[2], twc, 1.0, 1.0, tlw[2]);
+    const int bForward = tlc2 > mb && !bMono;
+    const int bBackward = -tlc2 > mb && !bMono;
+
+    int *vind = (int *)malloc(sizeof(int) * (Nc > 0 ? Nc : 1));
+    for (int i = 0; i < Nl; i++) {
+        if (!l_has_mp[i] || l_outlier[i]) continue;
+        const float *xw = l_xw + 3 * i;
+        const float x3[3] = { gemm3(Rcw[0], xw, 1.0, 1.0, tcw[0]), gemm3(Rcw[1], xw, 1.0, 1.0, tcw[1]), gemm3(Rcw[2], xw, 1.0, 1.0, tcw[2]) };
+        const float xc = x3[0], yc = x3[1];
+        const float invzc = (float)(1.0 / x3[2]);
+        if (invzc < 0) continue;
+        float u = fx * xc * invzc + cx;
+        float v = fy * yc * invzc + cy;
+        if (u < minX || u > maxX) continue;
+        if (v < minY || v > maxY) continue;
+        const int nLastOctave = lkeys[i].octave;
+        const float radius = th * scale_factors[nLastOctave];
+        int nv;
+        if (bForward) nv = features_in_area(g, ckeys, u, v, radius, nLastOctave, -1, vind);
+        else if (bBackward) nv = features_in_area(g, ckeys, u, v, radius, 0, nLastOctave, vind);
+        else nv = features_in_area(g, ckeys, u, v, radius, nLastOctave - 1, nLastOctave + 1, vind);
+        if (nv == 0) continue;
+        const uint8_t *dMP = l_mpdesc + 32 * (size_t)i;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int q = 0; q < nv; q++) {
+            const int i2 = vind[q];
+            if (cur_match[i2] >= 0 && l_obs[cur_match[i2]] > 0) continue;
+            if (curight[i2] > 0) {
+                const float ur = u - bf * invzc;
+                const float er = fabsf(ur - curight[i2]);
+                if (er > radius) continue;
+            }
+            const int dist = orc_descriptor_distance(dMP, cdesc + 32 * (size_t)i2);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= TH_HIGH) {
+            cur_match[bestIdx2] = i;
+            nmatches++;
+            if (check_ori) {
+                float rot = lkeys[i].angle - ckeys[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                if (hn[bin] == hc[bin]) { hc[bin] = hc[bin] ? 2 * hc[bin] : 64; hist[bin] = (int *)realloc(hist[bin], sizeof(int) * hc[bin]); }
+                hist[bin][hn[bin]++] = bestIdx2;
+            }
+        }
+    }
+    if (check_ori) {
+        int i1, i2, i3;
+        three_maxima(hn, HISTO_LENGTH, &i1, &i2, &i3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != i1 && i != i2 && i != i3)
+                for (int j = 0; j < hn[i]; j++) { cur_match[hist[i][j]] = -1; nmatches--; }
+    }
+    for (int i = 0; i < HISTO_LENGTH; i++) free(hist[i]);
+    free(vind); grid_free(g); free(g);
+    return nmatches;
+}
+
+/* Frame::ComputeStereoFromRGBD, Frame.cc:893-914.  depth is the CV_32F image after
+ * imDepth.convertTo(CV_32F, mDepthMapFactor) with mDepthMapFactor = 1/DepthMapFactor (Tracking.cc:229-230, :139-142);
+ * cv::Mat::at<float>(v,u) with float arguments truncates them to int. */
+void orc_compute_stereo_from_rgbd(int N, const orc_keypoint *keys, const orc_keypoint *keys_un, const float *depth, int w,
+                                  float bf, float *uright, float *zdepth)
+{
+    for (int i = 0; i < N; i++) {
+        uright[i] = -1; zdepth[i] = -1;
+        const float d = depth[(size_t)(int)keys[i].y * w + (int)keys[i].x];
+        if (d > 0) { zdepth[i] = d; uright[i] = keys_un[i].x - bf / d; }
+    }
+}
+
+/* Tracking.cc:229-230: imDepth.convertTo(imDepth, CV_32F, mDepthMapFactor): u16 -> float via
+ * saturate_cast<float>(src*alpha) with alpha a double (cv::convertScale 16u->32f computes in float: src*(float)alpha). */
+void orc_depth_convert(const uint16_t *raw, size_t n, float depth_map_factor_inv, float *out)
+{
+    for (size_t i = 0; i < n; i++) out[i] = (float)raw[i] * depth_map_factor_inv;
+}
+
+/* Frame::UnprojectStereo, Frame.cc:916-930, with mRwc = Rcw^T (cv::Mat::t() copy) and mOw = -Rcw^T*tcw (Frame.cc:288-294) */
+int orc_unproject_stereo(const orc_keypoint *kp_un, float z, const float *Tcw, float fx, float fy, float cx, float cy, float *xw)
+{
+    if (!(z > 0)) return 0;
+    const float invfx = 1.0f / fx, invfy = 1.0f / fy;
+    const float x = (kp_un->x - cx) * z * invfx, y = (kp_un->y - cy) * z * invfy;
+    float Rwc[3][3], tcw[3], Ow[3];
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Rwc[r][c] = Tcw[4 * c + r]; tcw[r] = Tcw[4 * r + 3]; }
+    for (int i = 0; i < 3; i++) {              /* mOw = -mRcw.t()*mtcw : transpose flag -> generic gemm path */
+        double s = 0; for (int k = 0; k < 3; k++) s += (double)Tcw[4 * k + i] * (double)tcw[k];
+        Ow[i] = (float)(s * -1.0);
+    }
+    const float xc[3] = { x, y, z };
+    for (int i = 0; i < 3; i++) xw[i] = gemm3(Rwc[i], xc, 1.0, 1.0, Ow[i]);
+    return 1;
+}

@@ -131,3 +131,55 @@ def orb_extract(gray, nfeatures=1000, scale=1.2, nlevels=8, ini_th=20, min_th=7,
     if want_pyr:
         return kps[:n].copy(), desc[:n].copy(), pyr, ncand
     return kps[:n].copy(), desc[:n].copy()
+
+
+# ---- matcher stage (oracle/match_oracle.c) ---------------------------------------------------
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return int(lib().orc_descriptor_distance(_p(a), _p(b)))
+
+
+def compute_stereo_from_rgbd(keys, depth_u16, bf=40.0, depth_factor=5000.0):
+    """Tracking.cc:229-230 + Frame::ComputeStereoFromRGBD; returns (uright, zdepth)"""
+    keys = np.ascontiguousarray(keys)
+    raw = np.ascontiguousarray(depth_u16, np.uint16)
+    h, w = raw.shape
+    dep = np.zeros((h, w), 'f4')
+    lib().orc_depth_convert(_p(raw), C.c_size_t(raw.size), C.c_float(np.float32(1.0) / np.float32(depth_factor)), _p(dep))
+    n = len(keys)
+    ur = np.zeros(n, 'f4'); z = np.zeros(n, 'f4')
+    lib().orc_compute_stereo_from_rgbd(C.c_int(n), _p(keys), _p(keys), _p(dep), C.c_int(w), C.c_float(bf), _p(ur), _p(z))
+    return ur, z
+
+
+def unproject_stereo(keys, zdepth, Tcw, cam):
+    keys = np.ascontiguousarray(keys); T = np.ascontiguousarray(Tcw, 'f4').reshape(16)
+    n = len(keys)
+    xw = np.zeros((n, 3), 'f4'); has = np.zeros(n, np.uint8)
+    for i in range(n):
+        o = np.zeros(3, 'f4')
+        has[i] = lib().orc_unproject_stereo(_p(keys[i:i + 1]), C.c_float(zdepth[i]), _p(T), C.c_float(cam['fx']), C.c_float(cam['fy']),
+                                            C.c_float(cam['cx']), C.c_float(cam['cy']), _p(o))
+        xw[i] = o
+    return xw, has
+
+
+def search_by_projection_frame(cur, last, cam, scale_factors, th=15.0, mono=False, check_ori=True):
+    """ORBmatcher::SearchByProjection(Cur, Last, th, bMono). cur/last: dicts of flattened frame arrays
+    (keys, desc, uright, Tcw; last additionally has_mp, outlier, xw, obs, mpdesc). Returns (cur_match, nmatches)."""
+    ck = np.ascontiguousarray(cur['keys']); cd = np.ascontiguousarray(cur['desc'], np.uint8); cu = np.ascontiguousarray(cur['uright'], 'f4')
+    cT = np.ascontiguousarray(cur['Tcw'], 'f4').reshape(16)
+    lk = np.ascontiguousarray(last['keys']); lh = np.ascontiguousarray(last['has_mp'], np.uint8); lo = np.ascontiguousarray(last['outlier'], np.uint8)
+    lx = np.ascontiguousarray(last['xw'], 'f4'); lb = np.ascontiguousarray(last['obs'], 'i4'); lm = np.ascontiguousarray(last['mpdesc'], np.uint8)
+    lT = np.ascontiguousarray(last['Tcw'], 'f4').reshape(16)
+    sf = np.ascontiguousarray(scale_factors, 'f4')
+    match = np.full(len(ck), -1, 'i4')
+    L = lib()
+    L.orc_search_by_projection_frame.restype = C.c_int
+    n = L.orc_search_by_projection_frame(
+        C.c_int(len(ck)), _p(ck), _p(cd), _p(cu), _p(cT),
+        C.c_int(len(lk)), _p(lk), _p(lh), _p(lo), _p(lx), _p(lb), _p(lm), _p(lT),
+        C.c_float(cam['fx']), C.c_float(cam['fy']), C.c_float(cam['cx']), C.c_float(cam['cy']), C.c_float(cam['bf']),
+        C.c_float(cam.get('min_x', 0.0)), C.c_float(cam.get('max_x', 640.0)), C.c_float(cam.get('min_y', 0.0)), C.c_float(cam.get('max_y', 480.0)),
+        _p(sf), C.c_float(th), C.c_int(int(mono)), C.c_int(int(check_ori)), _p(match))
+    return match, int(n)

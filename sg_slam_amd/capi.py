@@ -10,6 +10,11 @@ class SgxError(RuntimeError):
     pass
 
 
+class Camera(C.Structure):
+    _fields_ = [('fx', C.c_float), ('fy', C.c_float), ('cx', C.c_float), ('cy', C.c_float), ('bf', C.c_float),
+                ('min_x', C.c_float), ('max_x', C.c_float), ('min_y', C.c_float), ('max_y', C.c_float)]
+
+
 class OrbConfig(C.Structure):
     _fields_ = [('nfeatures', C.c_int32), ('scale_factor', C.c_float), ('nlevels', C.c_int32),
                 ('ini_th_fast', C.c_int32), ('min_th_fast', C.c_int32), ('width', C.c_int32),
@@ -23,6 +28,8 @@ SYMBOLS = [
     'sgx_orb_extract_batch_dev', 'sgx_orb_extract', 'sgx_orb_last_status',
     'sgx_orb_debug_level_geometry', 'sgx_orb_debug_read_level', 'sgx_orb_debug_read_candidates',
     'sgx_orb_debug_run_octree', 'sgx_orb_profile_enable', 'sgx_orb_profile_read',
+    'sgx_match_project_frame_batch_dev', 'sgx_match_project_frame',
+    'sgx_frame_stereo_from_rgbd_batch_dev', 'sgx_frame_unproject_batch_dev',
 ]
 
 
@@ -62,6 +69,12 @@ class SgxLib:
         d.sgx_orb_debug_run_octree.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         d.sgx_orb_profile_enable.argtypes = [C.c_void_p, C.c_int]
         d.sgx_orb_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+
+        vp = C.c_void_p
+        d.sgx_match_project_frame_batch_dev.argtypes = [C.c_int, C.c_int] + [vp] * 13 + [C.POINTER(Camera), vp, C.c_int, C.c_float, C.c_int, C.c_int, vp, vp, vp]
+        d.sgx_match_project_frame.argtypes = [C.c_int] + [vp] * 4 + [C.c_int] + [vp] * 7 + [C.POINTER(Camera), vp, C.c_int, C.c_float, C.c_int, C.c_int, vp, vp]
+        d.sgx_frame_stereo_from_rgbd_batch_dev.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_float, vp, vp, vp]
+        d.sgx_frame_unproject_batch_dev.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, C.POINTER(Camera), vp, vp, vp]
 
     def version(self):
         return self.dll.sgx_version().decode()

@@ -1,0 +1,105 @@
+// sgx_match.cpp — host side of the matcher / frame-glue C-ABI (include/sgx.h).
+// Reference behaviour: src/sg-slam/src/ORBmatcher.cc:1332-1472, src/sg-slam/src/Frame.cc:893-932.
+#include "sgx_match_kernels.h"
+#include "../../include/sgx.h"
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+#define SGX_CHECK_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
+    fprintf(stderr, "sgx: HIP error %d (%s) at %s:%d\n", (int)_e, hipGetErrorString(_e), __FILE__, __LINE__); return SGX_ERR_DEVICE; } } while (0)
+
+static SgxCam to_cam(const sgx_camera *c) { SgxCam k; k.fx = c->fx; k.fy = c->fy; k.cx = c->cx; k.cy = c->cy; k.bf = c->bf; k.minX = c->min_x; k.maxX = c->max_x; k.minY = c->min_y; k.maxY = c->max_y; return k; }
+
+extern "C" int sgx_match_project_frame_batch_dev(
+    int batch, int cap,
+    const sgx_keypoint *d_ckeys, const uint8_t *d_cdesc, const float *d_curight, const int32_t *d_cn, const float *d_cTcw,
+    const sgx_keypoint *d_lkeys, const int32_t *d_ln, const uint8_t *d_l_has_mp, const uint8_t *d_l_outlier, const float *d_l_xw,
+    const int32_t *d_l_obs, const uint8_t *d_l_mpdesc, const float *d_lTcw,
+    const sgx_camera *cam, const float *scale_factors, int nlevels, float th, int b_mono, int check_orientation,
+    int32_t *d_cur_match, int32_t *d_nmatches, void *stream)
+{
+    if (batch < 1 || cap < 1 || cap > SGX_MATCH_CAP || !cam || !scale_factors || nlevels < 1 || nlevels > 12) return SGX_ERR_INVALID;
+    if (!d_ckeys || !d_cdesc || !d_curight || !d_cn || !d_cTcw || !d_lkeys || !d_ln || !d_l_has_mp || !d_l_outlier || !d_l_xw ||
+        !d_l_obs || !d_l_mpdesc || !d_lTcw || !d_cur_match || !d_nmatches) return SGX_ERR_INVALID;
+    SgxScales sc; memset(&sc, 0, sizeof sc);
+    for (int i = 0; i < nlevels; i++) sc.s[i] = scale_factors[i];
+    SGX_LAUNCH(k_match_project_frame, dim3(batch), dim3(SGX_MATCH_THREADS), (sgx_stream_t)stream, cap,
+               (const uint8_t *)d_ckeys, d_cdesc, d_curight, d_cn, d_cTcw, (const uint8_t *)d_lkeys, d_ln, d_l_has_mp, d_l_outlier,
+               d_l_xw, d_l_obs, d_l_mpdesc, d_lTcw, to_cam(cam), sc, th, b_mono, check_orientation, d_cur_match, d_nmatches);
+    SGX_CHECK_HIP(hipGetLastError());
+    return SGX_OK;
+}
+
+extern "C" int sgx_frame_stereo_from_rgbd_batch_dev(int batch, int cap, const sgx_keypoint *d_keys, const int32_t *d_n,
+                                                     const uint16_t *d_depth, int width, int height, float depth_map_factor,
+                                                     float bf, float *d_uright, float *d_zdepth, void *stream)
+{
+    if (batch < 1 || cap < 1 || !d_keys || !d_n || !d_depth || !d_uright || !d_zdepth || !(depth_map_factor > 0)) return SGX_ERR_INVALID;
+    const float inv = 1.0f / depth_map_factor;           // mDepthMapFactor = 1.0f/mDepthMapFactor, Tracking.cc:139-142
+    SGX_LAUNCH(k_stereo_from_rgbd, dim3((cap + 255) / 256, batch), dim3(256), (sgx_stream_t)stream, cap, (const uint8_t *)d_keys, d_n,
+               d_depth, width, height, inv, bf, d_uright, d_zdepth);
+    SGX_CHECK_HIP(hipGetLastError());
+    return SGX_OK;
+}
+
+extern "C" int sgx_frame_unproject_batch_dev(int batch, int cap, const sgx_keypoint *d_keys, const int32_t *d_n, const float *d_zdepth,
+                                              const float *d_Tcw, const sgx_camera *cam, float *d_xw, uint8_t *d_has, void *stream)
+{
+    if (batch < 1 || cap < 1 || !d_keys || !d_n || !d_zdepth || !d_Tcw || !cam || !d_xw || !d_has) return SGX_ERR_INVALID;
+    SGX_LAUNCH(k_unproject, dim3((cap + 255) / 256, batch), dim3(256), (sgx_stream_t)stream, cap, (const uint8_t *)d_keys, d_n, d_zdepth,
+               d_Tcw, to_cam(cam), d_xw, d_has);
+    SGX_CHECK_HIP(hipGetLastError());
+    return SGX_OK;
+}
+
+// Host-pointer, single pair: the drop-in for ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono).
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int put(const void *src, size_t n) { if (hipMalloc(&p, n ? n : 1) != hipSuccess) return SGX_ERR_NOMEM; if (src && n) { if (hipMemcpyAsync(p, src, n, hipMemcpyHostToDevice, 0) != hipSuccess) return SGX_ERR_DEVICE; } return SGX_OK; }
+};
+}
+
+extern "C" int sgx_match_project_frame(
+    int nc, const sgx_keypoint *ckeys, const uint8_t *cdesc, const float *curight, const float *cTcw,
+    int nl, const sgx_keypoint *lkeys, const uint8_t *l_has_mp, const uint8_t *l_outlier, const float *l_xw,
+    const int32_t *l_obs, const uint8_t *l_mpdesc, const float *lTcw,
+    const sgx_camera *cam, const float *scale_factors, int nlevels, float th, int b_mono, int check_orientation,
+    int32_t *cur_match, int32_t *nmatches)
+{
+    if (nc < 0 || nl < 0 || nc > SGX_MATCH_CAP || nl > SGX_MATCH_CAP || !cur_match || !nmatches) return SGX_ERR_INVALID;
+    int cap = nc > nl ? nc : nl; if (cap < 1) cap = 1;
+    DevBuf b[16];
+    std::vector<uint8_t> pad;
+    auto up = [&](int k, const void *src, size_t elem, int n) -> int {
+        pad.assign((size_t)cap * elem, 0);
+        if (n > 0 && src) memcpy(pad.data(), src, (size_t)n * elem);
+        int rc = b[k].put(pad.data(), pad.size());
+        if (rc == SGX_OK && hipStreamSynchronize(0) != hipSuccess) rc = SGX_ERR_DEVICE;
+        return rc;
+    };
+    int rc;
+#define UP(k, src, elem, n) if ((rc = up(k, src, elem, n)) != SGX_OK) return rc
+    UP(0, ckeys, 28, nc); UP(1, cdesc, 32, nc); UP(2, curight, 4, nc); UP(3, lkeys, 28, nl); UP(4, l_has_mp, 1, nl); UP(5, l_outlier, 1, nl);
+    UP(6, l_xw, 12, nl); UP(7, l_obs, 4, nl); UP(8, l_mpdesc, 32, nl);
+#undef UP
+    if ((rc = b[9].put(&nc, 4)) != SGX_OK) return rc;
+    if ((rc = b[10].put(&nl, 4)) != SGX_OK) return rc;
+    if ((rc = b[11].put(cTcw, 64)) != SGX_OK) return rc;
+    if ((rc = b[12].put(lTcw, 64)) != SGX_OK) return rc;
+    if ((rc = b[13].put(nullptr, (size_t)cap * 4)) != SGX_OK) return rc;
+    if ((rc = b[14].put(nullptr, 4)) != SGX_OK) return rc;
+    SGX_CHECK_HIP(hipStreamSynchronize(0));
+    rc = sgx_match_project_frame_batch_dev(1, cap, (const sgx_keypoint *)b[0].p, (const uint8_t *)b[1].p, (const float *)b[2].p, (const int32_t *)b[9].p,
+                                           (const float *)b[11].p, (const sgx_keypoint *)b[3].p, (const int32_t *)b[10].p, (const uint8_t *)b[4].p,
+                                           (const uint8_t *)b[5].p, (const float *)b[6].p, (const int32_t *)b[7].p, (const uint8_t *)b[8].p,
+                                           (const float *)b[12].p, cam, scale_factors, nlevels, th, b_mono, check_orientation,
+                                           (int32_t *)b[13].p, (int32_t *)b[14].p, nullptr);
+    if (rc != SGX_OK) return rc;
+    SGX_CHECK_HIP(hipMemcpyAsync(cur_match, b[13].p, (size_t)nc * 4, hipMemcpyDeviceToHost, 0));
+    SGX_CHECK_HIP(hipMemcpyAsync(nmatches, b[14].p, 4, hipMemcpyDeviceToHost, 0));
+    SGX_CHECK_HIP(hipStreamSynchronize(0));
+    return SGX_OK;
+}

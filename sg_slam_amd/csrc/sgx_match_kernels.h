@@ -1,0 +1,280 @@
+// sgx_match_kernels.h — HIP kernels of the ORB matcher + the per-frame glue the matcher needs
+// (stereo-from-RGBD, unprojection).  Phase style, see sgx_rt.h.
+// Reference behaviour: src/sg-slam/src/ORBmatcher.cc, src/sg-slam/src/Frame.cc (cited per kernel).
+#pragma once
+#include "sgx_rt.h"
+
+#define SGX_GRID_COLS 64          /* FRAME_GRID_COLS, Frame.h:40 */
+#define SGX_GRID_ROWS 48          /* FRAME_GRID_ROWS, Frame.h:39 */
+#define SGX_TH_HIGH 100           /* ORBmatcher::TH_HIGH, ORBmatcher.cc:37 */
+#define SGX_HISTO 30              /* ORBmatcher::HISTO_LENGTH, ORBmatcher.cc:39 */
+#define SGX_MATCH_CAP 1280        /* max keypoints per frame handled in LDS */
+#define SGX_MATCH_THREADS 1024
+
+struct SgxCam { float fx, fy, cx, cy, bf, minX, maxX, minY, maxY; };
+struct SgxScales { float s[12]; };
+
+// 256-bit Hamming distance == ORBmatcher::DescriptorDistance (ORBmatcher.cc:1649-1665; SWAR popcount == popcount)
+SGX_DEV int sgx_hamming256(const uint32_t *a, const uint32_t *b)
+{
+    int d = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        const unsigned long long x = ((unsigned long long)(a[i] ^ b[i])) | ((unsigned long long)(a[i + 1] ^ b[i + 1]) << 32);
+        d += (int)SGX_POPCLL(x);
+    }
+    return d;
+}
+
+// cv::gemm small-matrix path for 3x3 * 3x1 (+ c): float dot left-to-right, then (float)(t*alpha + beta*c) in double
+SGX_DEV float sgx_gemm3(const float *arow, const float *b, float c)
+{
+    const float t = arow[0] * b[0] + arow[1] * b[1] + arow[2] * b[2];
+    return (float)((double)t * 1.0 + 1.0 * (double)c);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_match_project_frame: ORBmatcher::SearchByProjection(Frame &Cur, const Frame &Last, th, bMono)
+// (ORBmatcher.cc:1332-1472), one 1024-thread workgroup per frame pair, thread i <-> last-frame
+// map point i.
+//
+// The reference walks the map points in index order; a current keypoint already holding a map
+// point with Observations()>0 is skipped by later map points (:1407-1409), otherwise it may be
+// re-assigned (the later map point wins).  Parallel restatement:
+//   * candidate set of map point i = exactly the keypoints Frame::GetFeaturesInArea (Frame.cc:354-407)
+//     would return: valid grid cell (PosInGrid uses round(), :411-418) inside the floor/ceil cell
+//     window, level gate, |dx|<r and |dy|<r; evaluated against all keypoints (the 64x48 grid is only
+//     an index in the reference; its scan order is encoded in the preference key).
+//   * preference = min over unlocked candidates of (distance, cell x, cell y, keypoint index) ==
+//     "first strictly smaller distance in scan order" (:1423).
+//   * locks: lock[k] = smallest i with Observations()>0 whose choice is k; k is unavailable to i'
+//     iff lock[k] < i'.  The sequential greedy result is the unique fixpoint of
+//     choice_i = best unlocked under the locks of {choice_j, j<i}; Jacobi iteration reaches it
+//     (map point i is exact after i+1 sweeps; in practice 1-3 sweeps) and stops when the lock
+//     table no longer changes.
+//   * rotation histogram (:1436-1469): bins from all assignments (overwritten ones included, as in
+//     the reference), three maxima, keypoints that received ANY assignment from a rejected bin are
+//     cleared, nmatches = assignments - rejected assignments.
+// ---------------------------------------------------------------------------------------------
+SGX_KERNEL(SGX_MATCH_THREADS) k_match_project_frame(
+    int cap, const uint8_t *ckeys_raw, const uint8_t *cdesc, const float *curight, const int *cn, const float *cTcw,
+    const uint8_t *lkeys_raw, const int *ln, const uint8_t *l_has_mp, const uint8_t *l_outlier, const float *l_xw,
+    const int *l_obs, const uint8_t *l_mpdesc, const float *lTcw,
+    SgxCam cam, SgxScales sc, float th, int bMono, int check_ori, int *cur_match, int *nmatches_out)
+{
+    SGX_LDS float kx[SGX_MATCH_CAP], ky[SGX_MATCH_CAP], kur[SGX_MATCH_CAP], kang[SGX_MATCH_CAP];
+    SGX_LDS uint32_t kinfo[SGX_MATCH_CAP];           // octave | cellx<<8 | celly<<16 | valid<<31
+    SGX_LDS uint32_t kdesc[SGX_MATCH_CAP * 8];
+    SGX_LDS int lock_a[SGX_MATCH_CAP], lock_b[SGX_MATCH_CAP];
+    SGX_LDS int choice[SGX_MATCH_CAP];
+    SGX_LDS int owner[SGX_MATCH_CAP];
+    SGX_LDS int hist[SGX_HISTO], bad[SGX_HISTO];
+    SGX_LDS int s_changed, s_total, s_rejected;
+
+    const int f = (int)blockIdx.x;
+    const int Nc = min(cn[f], cap), Nl = min(ln[f], cap);
+    const int NT = (int)blockDim.x;
+    const float *Tc = cTcw + 16 * f, *Tl = lTcw + 16 * f;
+    const float invW = (float)SGX_GRID_COLS / (cam.maxX - cam.minX), invH = (float)SGX_GRID_ROWS / (cam.maxY - cam.minY);
+
+    // ---- stage the current frame
+    SGX_THREADS_BEGIN(tid)
+    for (int k = tid; k < Nc; k += NT) {
+        const float *kp = (const float *)(ckeys_raw + ((size_t)f * cap + k) * 28);
+        const float x = kp[0], y = kp[1];
+        kx[k] = x; ky[k] = y; kang[k] = kp[3]; kur[k] = curight[(size_t)f * cap + k];
+        const int oct = ((const int *)kp)[5];
+        const int px = (int)round((double)((x - cam.minX) * invW)), py = (int)round((double)((y - cam.minY) * invH));
+        const bool valid = !(px < 0 || px >= SGX_GRID_COLS || py < 0 || py >= SGX_GRID_ROWS);
+        kinfo[k] = (uint32_t)(oct & 0xFF) | ((uint32_t)(px & 0xFF) << 8) | ((uint32_t)(py & 0xFF) << 16) | (valid ? 0x80000000u : 0u);
+        const uint32_t *d = (const uint32_t *)(cdesc + ((size_t)f * cap + k) * 32);
+#pragma unroll
+        for (int w = 0; w < 8; w++) kdesc[k * 8 + w] = d[w];
+        lock_a[k] = 0x7FFFFFFF; owner[k] = -1;
+    }
+    for (int i = tid; i < SGX_HISTO; i += NT) { hist[i] = 0; bad[i] = 0; }
+    if (tid == 0) { s_total = 0; s_rejected = 0; }
+    SGX_THREADS_END
+    SGX_SYNC();
+
+    // ---- frame-level quantities (:1342-1353), uniform
+    float Rcw[3][3], tcw[3];
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Rcw[r][c] = Tc[4 * r + c]; tcw[r] = Tc[4 * r + 3]; }
+    float twc[3];
+    for (int i = 0; i < 3; i++) {              // -Rcw.t()*tcw: transpose flag -> generic gemm, double accumulation, alpha = -1
+        double s = 0; for (int k = 0; k < 3; k++) s += (double)Rcw[k][i] * (double)tcw[k];
+        twc[i] = (float)(s * -1.0);
+    }
+    const float Rl2[3] = { Tl[8], Tl[9], Tl[10] };
+    const float tlc2 = sgx_gemm3(Rl2, twc, Tl[11]);
+    const float mb = cam.bf / cam.fx;
+    const bool bForward = tlc2 > mb && !bMono, bBackward = -tlc2 > mb && !bMono;
+
+    int *lock_cur = lock_a, *lock_new = lock_b;
+    for (int sweep = 0; sweep < SGX_MATCH_CAP + 2; sweep++) {
+        SGX_THREADS_BEGIN(tid)
+        if (tid == 0) s_changed = 0;
+        for (int k = tid; k < Nc; k += NT) lock_new[k] = 0x7FFFFFFF;
+        SGX_THREADS_END
+        SGX_SYNC();
+        SGX_THREADS_BEGIN(tid)
+        for (int i = tid; i < Nl; i += NT) {
+            int best = -1;
+            const size_t li = (size_t)f * cap + i;
+            if (l_has_mp[li] && !l_outlier[li]) {
+                const float *xw = l_xw + 3 * li;
+                const float x3x = sgx_gemm3(Rcw[0], xw, tcw[0]), x3y = sgx_gemm3(Rcw[1], xw, tcw[1]), x3z = sgx_gemm3(Rcw[2], xw, tcw[2]);
+                const float invzc = (float)(1.0 / (double)x3z);
+                const float u = cam.fx * x3x * invzc + cam.cx, v = cam.fy * x3y * invzc + cam.cy;
+                if (!(invzc < 0) && !(u < cam.minX || u > cam.maxX) && !(v < cam.minY || v > cam.maxY)) {
+                    const int lo = ((const int *)(lkeys_raw + li * 28))[5];
+                    const float radius = th * sc.s[lo];
+                    int minLevel, maxLevel;
+                    if (bForward) { minLevel = lo; maxLevel = -1; } else if (bBackward) { minLevel = 0; maxLevel = lo; } else { minLevel = lo - 1; maxLevel = lo + 1; }
+                    // GetFeaturesInArea cell window (Frame.cc:359-373)
+                    const int c0x = max(0, (int)floorf((u - cam.minX - radius) * invW)), c1x = min(SGX_GRID_COLS - 1, (int)ceilf((u - cam.minX + radius) * invW));
+                    const int c0y = max(0, (int)floorf((v - cam.minY - radius) * invH)), c1y = min(SGX_GRID_ROWS - 1, (int)ceilf((v - cam.minY + radius) * invH));
+                    if (!(c0x >= SGX_GRID_COLS || c1x < 0 || c0y >= SGX_GRID_ROWS || c1y < 0)) {
+                        const bool chk = (minLevel > 0) || (maxLevel >= 0);
+                        const float ur = u - cam.bf * invzc;
+                        const uint32_t *dmp = (const uint32_t *)(l_mpdesc + li * 32);
+                        uint32_t dm[8];
+#pragma unroll
+                        for (int w = 0; w < 8; w++) dm[w] = dmp[w];
+                        unsigned long long bestKey = ~0ull;
+                        for (int k = 0; k < Nc; k++) {
+                            const uint32_t inf = kinfo[k];
+                            if (!(inf & 0x80000000u)) continue;
+                            const int px = (inf >> 8) & 0xFF, py = (inf >> 16) & 0xFF, oct = inf & 0xFF;
+                            if (px < c0x || px > c1x || py < c0y || py > c1y) continue;
+                            if (chk) { if (oct < minLevel) continue; if (maxLevel >= 0 && oct > maxLevel) continue; }
+                            if (!(fabsf(kx[k] - u) < radius && fabsf(ky[k] - v) < radius)) continue;
+                            if (lock_cur[k] < i) continue;                                   // holds an observed map point (:1407-1409)
+                            if (kur[k] > 0) { if (fabsf(ur - kur[k]) > radius) continue; }    // :1411-1417
+                            const int dist = sgx_hamming256(dm, &kdesc[k * 8]);
+                            const unsigned long long key = ((unsigned long long)dist << 28) | ((unsigned long long)px << 22) | ((unsigned long long)py << 16) | (unsigned long long)k;
+                            if (key < bestKey) bestKey = key;
+                        }
+                        if (bestKey != ~0ull && (int)(bestKey >> 28) <= SGX_TH_HIGH) best = (int)(bestKey & 0xFFFF);   // :1430
+                    }
+                }
+            }
+            choice[i] = best;
+            if (best >= 0 && l_obs[li] > 0) sgx_atomic_min_i32(&lock_new[best], i);
+        }
+        SGX_THREADS_END
+        SGX_SYNC();
+        SGX_THREADS_BEGIN(tid)
+        for (int k = tid; k < Nc; k += NT) if (lock_new[k] != lock_cur[k]) s_changed = 1;
+        SGX_THREADS_END
+        SGX_SYNC();
+        int *t = lock_cur; lock_cur = lock_new; lock_new = t;
+        if (!s_changed) break;
+    }
+
+    // ---- assignments, rotation histogram
+    SGX_THREADS_BEGIN(tid)
+    for (int i = tid; i < Nl; i += NT) {
+        const int k = choice[i];
+        if (k < 0) continue;
+        sgx_atomic_max(&owner[k], i);
+        sgx_atomic_add(&s_total, 1);
+        if (check_ori) {
+            const float la = ((const float *)(lkeys_raw + ((size_t)f * cap + i) * 28))[3];
+            float rot = la - kang[k];
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)round((double)(rot * (SGX_HISTO / 360.0f)));
+            if (bin == SGX_HISTO) bin = 0;
+            sgx_atomic_add(&hist[bin], 1);
+            lock_new[i] = bin;                  // lock_new is free now: reuse as per-map-point bin
+        }
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+    if (check_ori) {
+        SGX_THREADS_BEGIN(tid)
+        if (tid == 0) {                         // ComputeThreeMaxima, ORBmatcher.cc:1603-1644
+            int m1 = 0, m2 = 0, m3 = 0, i1 = -1, i2 = -1, i3 = -1;
+            for (int i = 0; i < SGX_HISTO; i++) {
+                const int s = hist[i];
+                if (s > m1) { m3 = m2; m2 = m1; m1 = s; i3 = i2; i2 = i1; i1 = i; }
+                else if (s > m2) { m3 = m2; m2 = s; i3 = i2; i2 = i; }
+                else if (s > m3) { m3 = s; i3 = i; }
+            }
+            if ((float)m2 < 0.1f * (float)m1) { i2 = -1; i3 = -1; }
+            else if ((float)m3 < 0.1f * (float)m1) { i3 = -1; }
+            for (int i = 0; i < SGX_HISTO; i++) bad[i] = (i != i1 && i != i2 && i != i3);
+        }
+        SGX_THREADS_END
+        SGX_SYNC();
+        SGX_THREADS_BEGIN(tid)
+        for (int i = tid; i < Nl; i += NT) {
+            const int k = choice[i];
+            if (k >= 0 && bad[lock_new[i]]) { sgx_atomic_add(&s_rejected, 1); lock_cur[k] = -2; }   // lock_cur reused as kill flag (-2)
+        }
+        SGX_THREADS_END
+        SGX_SYNC();
+    }
+    SGX_THREADS_BEGIN(tid)
+    for (int k = tid; k < Nc; k += NT) cur_match[(size_t)f * cap + k] = (check_ori && lock_cur[k] == -2) ? -1 : owner[k];
+    for (int k = Nc + tid; k < cap; k += NT) cur_match[(size_t)f * cap + k] = -1;
+    if (tid == 0) nmatches_out[f] = s_total - s_rejected;
+    SGX_THREADS_END
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_stereo_from_rgbd: Frame::ComputeStereoFromRGBD (Frame.cc:893-914) fused with the depth
+// conversion imDepth.convertTo(CV_32F, 1/DepthMapFactor) (Tracking.cc:229-230) evaluated only at
+// the keypoints.  grid = (ceil(cap/256), batch)
+// ---------------------------------------------------------------------------------------------
+SGX_KERNEL(256) k_stereo_from_rgbd(int cap, const uint8_t *keys_raw, const int *n, const uint16_t *depth, int W, int H,
+                                   float depth_factor_inv, float bf, float *uright, float *zdepth)
+{
+    SGX_THREADS_BEGIN(tid)
+    const int f = (int)blockIdx.y, i = (int)blockIdx.x * 256 + tid;
+    if (i < cap) {
+        float ur = -1.f, z = -1.f;
+        if (i < n[f]) {
+            const float *kp = (const float *)(keys_raw + ((size_t)f * cap + i) * 28);
+            const int u = (int)kp[0], v = (int)kp[1];                    // cv::Mat::at<float>(float,float) truncates
+            const float d = (float)depth[((size_t)f * H + v) * W + u] * depth_factor_inv;
+            if (d > 0) { z = d; ur = kp[0] - bf / d; }
+        }
+        uright[(size_t)f * cap + i] = ur; zdepth[(size_t)f * cap + i] = z;
+    }
+    SGX_THREADS_END
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_unproject: Frame::UnprojectStereo (Frame.cc:916-930) for every keypoint with depth > 0:
+// x3Dw = mRwc*x3Dc + mOw, mRwc = Rcw^T, mOw = -Rcw^T tcw (Frame.cc:288-294).  has[i] = depth>0.
+// ---------------------------------------------------------------------------------------------
+SGX_KERNEL(256) k_unproject(int cap, const uint8_t *keys_raw, const int *n, const float *zdepth, const float *Tcw, SgxCam cam,
+                            float *xw, uint8_t *has)
+{
+    SGX_THREADS_BEGIN(tid)
+    const int f = (int)blockIdx.y, i = (int)blockIdx.x * 256 + tid;
+    if (i < cap) {
+        const size_t o = (size_t)f * cap + i;
+        uint8_t h = 0;
+        float X[3] = {0.f, 0.f, 0.f};
+        if (i < n[f]) {
+            const float z = zdepth[o];
+            if (z > 0) {
+                const float *T = Tcw + 16 * f;
+                const float *kp = (const float *)(keys_raw + o * 28);
+                const float invfx = 1.0f / cam.fx, invfy = 1.0f / cam.fy;
+                const float xc[3] = { (kp[0] - cam.cx) * z * invfx, (kp[1] - cam.cy) * z * invfy, z };
+                for (int r = 0; r < 3; r++) {
+                    double s = 0; for (int k = 0; k < 3; k++) s += (double)T[4 * k + r] * (double)T[4 * k + 3];
+                    const float Ow = (float)(s * -1.0);
+                    const float Rrow[3] = { T[r], T[4 + r], T[8 + r] };
+                    X[r] = sgx_gemm3(Rrow, xc, Ow);
+                }
+                h = 1;
+            }
+        }
+        xw[3 * o] = X[0]; xw[3 * o + 1] = X[1]; xw[3 * o + 2] = X[2]; has[o] = h;
+    }
+    SGX_THREADS_END
+}

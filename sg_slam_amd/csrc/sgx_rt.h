@@ -24,6 +24,7 @@
 #define SGX_CONST __constant__
 #define sgx_atomic_add(p, v) atomicAdd((p), (v))
 #define sgx_atomic_max(p, v) atomicMax((p), (v))
+#define sgx_atomic_min_i32(p, v) atomicMin((p), (v))
 #define sgx_atomic_or(p, v) atomicOr((p), (v))
 #define SGX_LAUNCH(kern, grid, block, stream, ...) hipLaunchKernelGGL((kern), grid, block, 0, stream, __VA_ARGS__)
 #define SGX_POPCLL(x) __popcll(x)
@@ -47,6 +48,7 @@ extern thread_local sgx_dim3 blockIdx, blockDim, gridDim;
 template <class T, class U> static inline T sgx_atomic_add(T *p, U v) { T o = *p; *p = (T)(o + (T)v); return o; }
 template <class T, class U> static inline T sgx_atomic_max(T *p, U v) { T o = *p; if ((T)v > o) *p = (T)v; return o; }
 template <class T, class U> static inline T sgx_atomic_or(T *p, U v) { T o = *p; *p = (T)(o | (T)v); return o; }
+static inline int sgx_atomic_min_i32(int *p, int v) { int o = *p; if (v < o) *p = v; return o; }
 #define SGX_LAUNCH(kern, grid, block, stream, ...)                                        \
     do { sgx_dim3 _g = (grid), _b = (block); gridDim = _g; blockDim = _b;                  \
          for (unsigned _z = 0; _z < _g.z; ++_z) for (unsigned _y = 0; _y < _g.y; ++_y)     \
