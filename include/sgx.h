@@ -123,6 +123,25 @@ int sgx_frame_stereo_from_rgbd_batch_dev(int batch, int cap, const sgx_keypoint 
 int sgx_frame_unproject_batch_dev(int batch, int cap, const sgx_keypoint *d_keys, const int32_t *d_n, const float *d_zdepth,
                                   const float *d_Tcw, const sgx_camera *cam, float *d_xw, uint8_t *d_has, void *stream);
 
+/* ---- pose-only optimisation -------------------------------------------------------------------
+ * Replaces `static int Optimizer::PoseOptimization(Frame *pFrame)` (src/sg-slam/include/Optimizer.h:50,
+ * src/sg-slam/src/Optimizer.cc:239-451): g2o Levenberg-Marquardt over the frame pose with one
+ * mono (mvuRight<0) or stereo reprojection edge per keypoint that holds a map point, Huber kernel,
+ * 4 rounds x 10 iterations with chi2 inlier classification between rounds.  fp64 inside, fp32 at the
+ * boundary exactly like the reference (Converter.cc:37-71).
+ * Flattened Frame: keys_un = mvKeysUn, uright = mvuRight, inv_level_sigma2 = mvInvLevelSigma2;
+ * mvpMapPoints[i] is given either per keypoint (has_mp[i], mp_xw[3*i..]) or through mp_index[i]
+ * (row of mp_xw, -1 = NULL) so the matcher's output can be consumed without a gather.
+ * In/out: Tcw (4x4 row-major float, pFrame->mTcw).  Out: outlier = mvbOutlier, return value in
+ * n_inliers (nInitialCorrespondences - nBad; 0 when fewer than 3 correspondences). */
+int sgx_pose_optimization_batch_dev(int batch, int cap, const sgx_keypoint *d_keys_un, const float *d_uright, const int32_t *d_n,
+                                    const int32_t *d_mp_index, const uint8_t *d_has_mp, const float *d_mp_xw, int xw_pitch,
+                                    const float *inv_level_sigma2, int nlevels, const sgx_camera *cam,
+                                    float *d_Tcw, uint8_t *d_outlier, int32_t *d_n_inliers, void *stream);
+int sgx_pose_optimization(int n, const sgx_keypoint *keys_un, const float *uright, const uint8_t *has_mp, const float *mp_xw,
+                          const float *inv_level_sigma2, int nlevels, const sgx_camera *cam,
+                          float *Tcw, uint8_t *outlier, int32_t *n_inliers);
+
 /* run the octree-distribution kernel alone on packed candidates (x | y<<12 | score<<24, coordinates
  * relative to the (16,16) border origin) for `level`; returns the selected packed entries in list order */
 int sgx_orb_debug_run_octree(sgx_orb *h, int level, const uint32_t *packed, int n, uint32_t *out_sel, int cap, int *nsel);

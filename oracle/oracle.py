@@ -183,3 +183,21 @@ def search_by_projection_frame(cur, last, cam, scale_factors, th=15.0, mono=Fals
         C.c_float(cam.get('min_x', 0.0)), C.c_float(cam.get('max_x', 640.0)), C.c_float(cam.get('min_y', 0.0)), C.c_float(cam.get('max_y', 480.0)),
         _p(sf), C.c_float(th), C.c_int(int(mono)), C.c_int(int(check_ori)), _p(match))
     return match, int(n)
+
+
+# ---- pose optimisation (oracle/poseopt_oracle.c) ---------------------------------------------
+def pose_optimization(frame, cam, inv_level_sigma2, want_trace=False):
+    """Optimizer::PoseOptimization restatement.  Returns (n_inliers, Tcw[4,4] f32, outlier[N][, trace, trace_n])."""
+    k = np.ascontiguousarray(frame['keys']); ur = np.ascontiguousarray(frame['uright'], 'f4')
+    has = np.ascontiguousarray(frame['has_mp'], np.uint8); xw = np.ascontiguousarray(frame['xw'], 'f4')
+    T = np.ascontiguousarray(frame['Tcw'], 'f4').reshape(16).copy()
+    is2 = np.ascontiguousarray(inv_level_sigma2, 'f4')
+    n = len(k)
+    out = np.zeros(max(n, 1), np.uint8)
+    trace = np.zeros(4 * 11 * 3, 'f8'); tn = np.zeros(4, 'i4')
+    L = lib(); L.orc_pose_optimization.restype = C.c_int
+    r = L.orc_pose_optimization(C.c_int(n), _p(k), _p(ur), _p(is2), _p(has), _p(xw), C.c_float(cam['fx']), C.c_float(cam['fy']),
+                                C.c_float(cam['cx']), C.c_float(cam['cy']), C.c_float(cam['bf']), _p(T), _p(out), _p(trace), _p(tn))
+    if want_trace:
+        return int(r), T.reshape(4, 4), out[:n], trace.reshape(4, 11, 3), tn
+    return int(r), T.reshape(4, 4), out[:n]

@@ -30,6 +30,7 @@ SYMBOLS = [
     'sgx_orb_debug_run_octree', 'sgx_orb_profile_enable', 'sgx_orb_profile_read',
     'sgx_match_project_frame_batch_dev', 'sgx_match_project_frame',
     'sgx_frame_stereo_from_rgbd_batch_dev', 'sgx_frame_unproject_batch_dev',
+    'sgx_pose_optimization_batch_dev', 'sgx_pose_optimization',
 ]
 
 
@@ -75,6 +76,8 @@ class SgxLib:
         d.sgx_match_project_frame.argtypes = [C.c_int] + [vp] * 4 + [C.c_int] + [vp] * 7 + [C.POINTER(Camera), vp, C.c_int, C.c_float, C.c_int, C.c_int, vp, vp]
         d.sgx_frame_stereo_from_rgbd_batch_dev.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_float, vp, vp, vp]
         d.sgx_frame_unproject_batch_dev.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, C.POINTER(Camera), vp, vp, vp]
+        d.sgx_pose_optimization_batch_dev.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, C.POINTER(Camera), vp, vp, vp, vp]
+        d.sgx_pose_optimization.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.c_int, C.POINTER(Camera), vp, vp, vp]
 
     def version(self):
         return self.dll.sgx_version().decode()

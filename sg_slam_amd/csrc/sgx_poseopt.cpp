@@ -1,0 +1,55 @@
+// sgx_poseopt.cpp — host side of the PoseOptimization C-ABI (include/sgx.h).
+// Reference behaviour: src/sg-slam/src/Optimizer.cc:239-451.
+#include "sgx_poseopt_kernels.h"
+#include "../../include/sgx.h"
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+#define SGX_CHECK_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
+    fprintf(stderr, "sgx: HIP error %d (%s) at %s:%d\n", (int)_e, hipGetErrorString(_e), __FILE__, __LINE__); return SGX_ERR_DEVICE; } } while (0)
+
+static SgxCam po_cam(const sgx_camera *c) { SgxCam k; k.fx = c->fx; k.fy = c->fy; k.cx = c->cx; k.cy = c->cy; k.bf = c->bf; k.minX = c->min_x; k.maxX = c->max_x; k.minY = c->min_y; k.maxY = c->max_y; return k; }
+
+extern "C" int sgx_pose_optimization_batch_dev(int batch, int cap, const sgx_keypoint *d_keys_un, const float *d_uright, const int32_t *d_n,
+                                                const int32_t *d_mp_index, const uint8_t *d_has_mp, const float *d_mp_xw, int xw_pitch,
+                                                const float *inv_level_sigma2, int nlevels, const sgx_camera *cam,
+                                                float *d_Tcw, uint8_t *d_outlier, int32_t *d_n_inliers, void *stream)
+{
+    if (batch < 1 || cap < 1 || cap > SGX_PO_CAP || !d_keys_un || !d_uright || !d_n || (!d_mp_index && !d_has_mp) || !d_mp_xw || xw_pitch < 1 ||
+        !inv_level_sigma2 || nlevels < 1 || nlevels > 12 || !cam || !d_Tcw || !d_outlier || !d_n_inliers) return SGX_ERR_INVALID;
+    SgxScales is2; memset(&is2, 0, sizeof is2);
+    for (int i = 0; i < nlevels; i++) is2.s[i] = inv_level_sigma2[i];
+    SGX_LAUNCH(k_pose_opt, dim3(batch), dim3(SGX_PO_THREADS), (sgx_stream_t)stream, cap, (const uint8_t *)d_keys_un, d_uright, d_n,
+               d_mp_index, d_has_mp, d_mp_xw, xw_pitch, is2, po_cam(cam), d_Tcw, d_outlier, d_n_inliers);
+    SGX_CHECK_HIP(hipGetLastError());
+    return SGX_OK;
+}
+
+// Host pointers, one frame: the drop-in for `int Optimizer::PoseOptimization(Frame *pFrame)`.
+extern "C" int sgx_pose_optimization(int n, const sgx_keypoint *keys_un, const float *uright, const uint8_t *has_mp, const float *mp_xw,
+                                      const float *inv_level_sigma2, int nlevels, const sgx_camera *cam,
+                                      float *Tcw, uint8_t *outlier, int32_t *n_inliers)
+{
+    if (n < 0 || n > SGX_PO_CAP || !Tcw || !outlier || !n_inliers) return SGX_ERR_INVALID;
+    const int cap = n > 0 ? n : 1;
+    void *d[8] = {0};
+    const size_t sz[8] = { (size_t)cap * 28, (size_t)cap * 4, 4, (size_t)cap, (size_t)cap * 12, 64, (size_t)cap, 4 };
+    const void *src[8] = { keys_un, uright, &n, has_mp, mp_xw, Tcw, nullptr, nullptr };
+    int rc = SGX_OK;
+    for (int i = 0; i < 8 && rc == SGX_OK; i++) {
+        if (hipMalloc(&d[i], sz[i]) != hipSuccess) { rc = SGX_ERR_NOMEM; break; }
+        if (src[i] && n > 0 && hipMemcpyAsync(d[i], src[i], i == 2 || i == 5 ? sz[i] : (size_t)n * (sz[i] / cap), hipMemcpyHostToDevice, 0) != hipSuccess) rc = SGX_ERR_DEVICE;
+    }
+    if (rc == SGX_OK && n == 0) { (void)hipMemcpyAsync(d[2], &n, 4, hipMemcpyHostToDevice, 0); (void)hipMemcpyAsync(d[5], Tcw, 64, hipMemcpyHostToDevice, 0); }
+    if (rc == SGX_OK && hipStreamSynchronize(0) != hipSuccess) rc = SGX_ERR_DEVICE;
+    if (rc == SGX_OK)
+        rc = sgx_pose_optimization_batch_dev(1, cap, (const sgx_keypoint *)d[0], (const float *)d[1], (const int32_t *)d[2], nullptr, (const uint8_t *)d[3],
+                                             (const float *)d[4], cap, inv_level_sigma2, nlevels, cam, (float *)d[5], (uint8_t *)d[6], (int32_t *)d[7], nullptr);
+    if (rc == SGX_OK) {
+        if (hipMemcpyAsync(Tcw, d[5], 64, hipMemcpyDeviceToHost, 0) != hipSuccess || hipMemcpyAsync(outlier, d[6], (size_t)n, hipMemcpyDeviceToHost, 0) != hipSuccess ||
+            hipMemcpyAsync(n_inliers, d[7], 4, hipMemcpyDeviceToHost, 0) != hipSuccess || hipStreamSynchronize(0) != hipSuccess) rc = SGX_ERR_DEVICE;
+    }
+    for (int i = 0; i < 8; i++) if (d[i]) (void)hipFree(d[i]);
+    return rc;
+}

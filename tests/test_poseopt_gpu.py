@@ -1,0 +1,29 @@
+"""GPU parity (MI355X) for PoseOptimization: pose within 1e-5 relative of the oracle, identical
+inlier/outlier classification and inlier count."""
+import numpy as np
+import pytest
+from scenes import make_pose_problem, CAM
+from sg_slam_amd.optimizer import Optimizer
+from test_poseopt import pose_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('n,seed', [(200, 42), (400, 43), (800, 44), (1000, 47), (60, 45), (9, 46), (2, 48)])
+def test_gpu_matches_oracle(gpulib, oracle, n, seed):
+    frame, _, _ = make_pose_problem(oracle, n=n, seed=seed)
+    is2 = oracle.orb_params()['inv_sigma2']
+    en, eT, eout = oracle.pose_optimization(frame, CAM, is2)
+    f2 = dict(frame)
+    gn = Optimizer.PoseOptimization(f2, CAM, is2, lib=gpulib)
+    assert gn == en and (f2['outlier'] == eout).all() and pose_close(f2['Tcw'], eT)
+
+
+def test_gpu_mono_stereo(gpulib, oracle):
+    is2 = oracle.orb_params()['inv_sigma2']
+    for mono_frac in (0.0, 1.0):
+        frame, _, _ = make_pose_problem(oracle, n=300, seed=7, mono_frac=mono_frac)
+        en, eT, eout = oracle.pose_optimization(frame, CAM, is2)
+        f2 = dict(frame)
+        gn = Optimizer.PoseOptimization(f2, CAM, is2, lib=gpulib)
+        assert gn == en and (f2['outlier'] == eout).all() and pose_close(f2['Tcw'], eT)
