@@ -11,8 +11,7 @@
 #define SGX_MATCH_CAP 1280        /* max keypoints per frame handled in LDS */
 #define SGX_MATCH_THREADS 1024
 
-struct SgxCam { float fx, fy, cx, cy, bf, minX, maxX, minY, maxY; };
-struct SgxScales { float s[12]; };
+#include "sgx_types.h"
 
 // 256-bit Hamming distance == ORBmatcher::DescriptorDistance (ORBmatcher.cc:1649-1665; SWAR popcount == popcount)
 SGX_DEV int sgx_hamming256(const uint32_t *a, const uint32_t *b)

@@ -4,7 +4,7 @@
 // (G = src/sg-slam/Thirdparty/g2o/g2o; cited inline; the CPU restatement is oracle/poseopt_oracle.c).
 #pragma once
 #include "sgx_rt.h"
-#include "sgx_match_kernels.h"   // SgxCam
+#include "sgx_types.h"
 
 #define SGX_PO_CAP 1280
 #define SGX_PO_THREADS 64
