@@ -1,13 +1,16 @@
 #!/usr/bin/env python3
 """bench.py — tracked frames/s of the MI355X tracking hot path on synthetic 640x480 RGB-D streams.
 
-One "step" = one frame from each of S independent streams on this GPU, pushed through the hot path
-(stages implemented so far are listed in config.stages).  Frames are resident in HBM before the
-timed region.  N>1: one process per GPU (torch.distributed / RCCL), streams are sharded across
-ranks (weak scaling, no data-path collective); value = all ranks' frames / max-over-ranks time.
+One "step" = one frame from each of S independent streams on this GPU pushed through the whole
+per-frame path (sg_slam_amd/tracker.py): ORB extract -> stereo-from-RGBD -> motion model ->
+SearchByProjection(cur,last) -> PoseOptimization -> unproject.  Frames are resident in HBM before the
+timed region.  N>1: one process per GPU (torch.distributed over RCCL); streams are sharded across ranks
+(weak scaling, no data-path collective); after the timed region the per-frame records (pose + counts) are
+gathered to rank 0 with one RCCL all_gather (BASELINE config 5), outside the timing.
+value = all ranks' frames / max-over-ranks time.
 
-Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel,
-HIP-event timed inside the timed region) and `cpu_baseline` (the oracle timed on host cores).
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel by summed HIP-event time inside the timed
+region) and `cpu_baseline` (the oracle — CPU restatement of the reference path — timed on host cores).
 """
 import argparse
 import json
@@ -21,31 +24,38 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
-
-# level geometry of the 640x480 / 1.2 / 8-level pyramid
 LEVELS = [(640, 480), (533, 400), (444, 333), (370, 278), (309, 231), (257, 193), (214, 161), (179, 134)]
 PIX = [w * h for w, h in LEVELS]
 
 
-def algorithmic_bytes_per_frame(nkp=1000, ncand=6000):
+def algorithmic_bytes_per_frame(nkp=1000, ncand=6000, nmatch=600):
     """Compulsory HBM bytes per frame per kernel class."""
     return {
         'pyramid_resize': sum(PIX[:-1]) + sum(PIX[1:]),            # read levels 0..6 once, write levels 1..7
         'fast_cells': sum(PIX) + 4 * ncand,                        # read every level once, write packed candidates
         'octree': 4 * ncand + 4 * nkp,                             # read candidates, write selected
         'orient_desc': sum(PIX) + nkp * (28 + 32),                 # read every level at most once, write kp + desc
+        'stereo_from_rgbd': nkp * (28 + 2 + 8),                    # keypoint + one depth texel in, uright/z out
+        'motion_model': 3 * 64,
+        'match_project_frame': 2 * nkp * (28 + 32) + nkp * (4 + 12 + 1 + 1 + 4) + nkp * 4,   # both frames' kp+desc, uright/xw/flags, match out
+        'pose_opt': nkp * (28 + 4 + 4) + nmatch * 12 + nkp + 64,   # keypoints, uright, match index, matched map points, outlier flags, pose
+        'unproject': nkp * (28 + 4 + 12 + 1),
     }
+
+
+def ping_pong(T):
+    return list(range(T)) + list(range(T - 2, 0, -1)) if T > 1 else [0]
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=4)
     ap.add_argument('--streams', type=int, default=64, help='independent streams per GPU (frames per step)')
-    ap.add_argument('--frames', type=int, default=4, help='distinct frames kept per stream (ping-pong replay)')
+    ap.add_argument('--frames', type=int, default=6, help='distinct frames kept per stream (ping-pong replay)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=120, help='frames timed on the CPU oracle')
+    ap.add_argument('--cpu-sample', type=int, default=100, help='frames timed on the CPU oracle')
     args = ap.parse_args()
 
     import torch
@@ -64,38 +74,38 @@ def main():
 
     import sg_slam_amd
     from sg_slam_amd import synth
-    from sg_slam_amd.orb import ORBextractor
+    from sg_slam_amd.tracker import TrackerBatch
     lib = sg_slam_amd.load()
+    cam = dict(synth.TUM3)
 
     S, T = args.streams, args.frames
     # synthetic streams: stream s of rank r = the plane stream starting at time offset 37*(r*S+s)
     gen = synth.PlaneStream(seed=1234)
     host = np.empty((T, S, 480, 640), np.uint8)
+    t0s = [37 * (rank * S + s) for s in range(S)]
     for s in range(S):
-        t0 = 37 * (rank * S + s)
         for t in range(T):
-            host[t, s] = gen.frame(t0 + t)[0]
+            host[t, s] = gen.frame(t0s[s] + t)[0]
     d_frames = torch.from_numpy(host).cuda()
-    order = list(range(T)) + list(range(T - 2, 0, -1)) if T > 1 else [0]      # ping-pong: motion stays continuous
+    depth_val = int(round(gen.z0 * cam['depth_factor']))
+    d_depth = torch.full((S, 480, 640), depth_val, dtype=torch.int16, device='cuda')      # the plane: constant raw depth (u16 bits)
+    order = ping_pong(T)
 
-    ex = ORBextractor(lib=lib, max_batch=S)
-    cap = ex.capacity
-    d_kps = torch.zeros((S, cap, 28), dtype=torch.uint8, device='cuda')
-    d_desc = torch.zeros((S, cap, 32), dtype=torch.uint8, device='cuda')
-    d_cnt = torch.zeros(S, dtype=torch.int32, device='cuda')
+    tr = TrackerBatch(lib, S, cam, xp='torch')
+    tr.set_initial_pose(np.stack([gen.Tcw(t0) for t0 in t0s]))
     stream = torch.cuda.current_stream().cuda_stream
 
     def step(i):
-        fr = d_frames[order[i % len(order)]]
-        ex.extract_batch_dev(fr, 640, S, d_kps, d_desc, d_cnt, stream=stream)
+        tr.step(d_frames[order[i % len(order)]], d_depth, stream=stream)
 
     for i in range(args.warmup):
         step(i)
-    ex.last_status(stream=stream)
+    tr.ex.last_status(stream=stream)
     torch.cuda.synchronize()
     if dist: dist.barrier()
     torch.cuda.synchronize()
-    ex.profile_enable(True)
+    lib.profile_read(reset=True)
+    lib.profile_enable(True)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
@@ -103,14 +113,30 @@ def main():
     if dist: dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    ex.profile_enable(False)
-    prof = ex.profile_read()
-    ex.last_status(stream=stream)
-    nkp_mean = float(d_cnt.float().mean().item())
+    lib.profile_enable(False)
+    prof = lib.profile_read()
+    tr.ex.last_status(stream=stream)
+    nkp, nmatch, ninl = tr.last_counts()
+    poses = tr.last_pose()
+    # accuracy vs the synthetic ground truth of the last tracked frame (translation of the camera centre)
+    last_i = args.warmup + args.steps - 1
+    gt = np.stack([gen.Tcw(t0 + order[last_i % len(order)]) for t0 in t0s])
+    def centre(Tm): return -np.einsum('sij,sj->si', np.transpose(Tm[:, :3, :3], (0, 2, 1)), Tm[:, :3, 3])
+    err = np.linalg.norm(centre(poses.astype('f8')) - centre(gt), axis=1)
+    ate_rmse = float(np.sqrt((err ** 2).mean()))
+    tracked = int((ninl >= 10).sum())
+
     if dist:
         tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # BASELINE config 5: gather per-frame records (pose + counts) to rank 0 over RCCL/xGMI (outside the timed region)
+        rec = torch.cat([tr.Tcw[1].reshape(S, 16), tr.ninl.float().reshape(S, 1), tr.nmatch.float().reshape(S, 1)], 1).contiguous()
+        allrec = [torch.empty_like(rec) for _ in range(world)]
+        dist.all_gather(allrec, rec)
+        sq = torch.tensor([float((err ** 2).sum()), float(len(err)), float(tracked)], dtype=torch.float64, device='cuda')
+        dist.all_reduce(sq)
+        ate_rmse = float(torch.sqrt(sq[0] / sq[1]).item()); tracked = int(sq[2].item())
 
     if rank != 0:
         if dist: dist.destroy_process_group()
@@ -118,15 +144,14 @@ def main():
     frames_total = S * args.steps * world
     fps = frames_total / dt
 
-    # dominant kernel (largest summed HIP-event time in the timed region)
-    alg = algorithmic_bytes_per_frame(nkp=int(round(nkp_mean)))
-    dom = max(prof, key=lambda k: prof[k][0])
+    alg = algorithmic_bytes_per_frame(nkp=int(round(float(nkp.mean()))), nmatch=int(round(float(nmatch.mean()))))
     per_kernel = {}
     for k, (ms, n) in prof.items():
         if n == 0: continue
         avg_ms = ms / n
-        per_kernel[k] = {'avg_ms_per_launch': avg_ms, 'launches': n, 'alg_bytes_per_launch': alg[k] * S,
-                         'achieved_GBs': alg[k] * S / (avg_ms * 1e-3) / 1e9}
+        per_kernel[k] = {'avg_ms_per_launch': round(avg_ms, 5), 'launches': n, 'total_ms': round(ms, 3), 'alg_bytes_per_launch': alg[k] * S,
+                         'achieved_GBs': round(alg[k] * S / (avg_ms * 1e-3) / 1e9, 3)}
+    dom = max(per_kernel, key=lambda k: per_kernel[k]['total_ms'])
     dk = per_kernel[dom]
     roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': dk['achieved_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': dk['achieved_GBs'] / HBM_PEAK_GBS, 'traffic': None,
@@ -136,23 +161,47 @@ def main():
 
     cpu = None
     if not args.no_cpu_baseline and world == 1:
-        from oracle import oracle as orc            # checker/baseline leg only — never the measured product path
+        # the oracle chained exactly like the tracker (checker/baseline leg only — never the measured product path)
+        from oracle import oracle as orc
+        sf = orc.orb_params()['scale']; is2 = orc.orb_params()['inv_sigma2']
         n = args.cpu_sample
+        depth_img = np.full((480, 640), depth_val, np.uint16)
         orc.orb_extract(host[0, 0])
         c0 = time.perf_counter()
-        for i in range(n):
-            orc.orb_extract(host[i % T, (i // T) % S])
+        last = None; done = 0; s = 0
+        while done < n:
+            Tcur = gen.Tcw(t0s[s]).astype('f4')
+            for i in range(min(len(order) * 2, n - done)):
+                g = host[order[i % len(order)], s]
+                k, d = orc.orb_extract(g)
+                ur, z = orc.compute_stereo_from_rgbd(k, depth_img, cam['bf'], cam['depth_factor'])
+                if last is not None and i > 0:
+                    cur = dict(keys=k, desc=d, uright=ur, Tcw=Tcur)
+                    m, nm = orc.search_by_projection_frame(cur, last, cam, sf, th=15)
+                    fr2 = dict(keys=k, uright=ur, has_mp=(m >= 0).astype(np.uint8), Tcw=Tcur,
+                               xw=np.where((m >= 0)[:, None], last['xw'][np.maximum(m, 0)], 0).astype('f4'))
+                    _, Tcur, _ = orc.pose_optimization(fr2, cam, is2)
+                xw, has = orc.unproject_stereo(k, z, Tcur, cam)
+                last = dict(keys=k, desc=d, uright=ur, Tcw=Tcur, has_mp=has, outlier=np.zeros(len(k), np.uint8), xw=xw,
+                            obs=np.zeros(len(k), 'i4'), mpdesc=d)
+                done += 1
+            s = (s + 1) % S; last = None
         cdt = time.perf_counter() - c0
         cpu = {'value': n / cdt, 'unit': 'frames/s', 'cores': 1, 'kind': 'port',
-               'sample': f'{n} frames of the same synthetic stream through oracle.orb_extract (ORB stage), 1 thread, host has {os.cpu_count()} cores'}
+               'sample': f'{n} frames of the same synthetic streams through the oracle chain (orb_extract + stereo + SearchByProjection + '
+                         f'PoseOptimization + unproject), 1 thread; host has {os.cpu_count()} cores'}
 
     out = {
         'metric': 'tracked frames/sec (640x480 RGB-D)', 'value': fps, 'unit': 'frames/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
         'config': {'workload': 'Single MI355X: ORB extract+match HIP kernels, 640x480 synthetic stream, 1000 feats/frame',
-                   'stages': ['orb_extract'], 'streams_per_gpu': S, 'frames_per_step': S, 'mean_keypoints': nkp_mean,
-                   'nfeatures': 1000, 'nlevels': 8, 'scale_factor': 1.2, 'parallelism': f'streams-sharded x{world}'},
+                   'stages': ['orb_extract', 'stereo_from_rgbd', 'motion_model', 'search_by_projection(cur,last)', 'pose_optimization', 'unproject'],
+                   'streams_per_gpu': S, 'frames_per_step': S, 'distinct_frames_per_stream': T,
+                   'mean_keypoints': float(nkp.mean()), 'mean_matches': float(nmatch.mean()), 'mean_inliers': float(ninl.mean()),
+                   'tracked_streams_last_frame': tracked, 'ate_rmse_m_vs_synthetic_gt': ate_rmse,
+                   'nfeatures': 1000, 'nlevels': 8, 'scale_factor': 1.2, 'parallelism': f'streams-sharded x{world}',
+                   'pose_dtype': 'f64 LM, f32 boundary'},
         'roofline': roofline, 'cpu_baseline': cpu,
     }
     print(json.dumps(out))

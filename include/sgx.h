@@ -123,6 +123,11 @@ int sgx_frame_stereo_from_rgbd_batch_dev(int batch, int cap, const sgx_keypoint 
 int sgx_frame_unproject_batch_dev(int batch, int cap, const sgx_keypoint *d_keys, const int32_t *d_n, const float *d_zdepth,
                                   const float *d_Tcw, const sgx_camera *cam, float *d_xw, uint8_t *d_has, void *stream);
 
+/* Tracking's constant-velocity prediction (Tracking.cc:463-470, :914): pred = Tcur * inv(Tprev) * Tcur;
+ * frames with valid[f]==0 (optional array) copy Tcur. */
+int sgx_frame_motion_model_batch_dev(int batch, const float *d_Tcw_cur, const float *d_Tcw_prev, const uint8_t *d_valid,
+                                     float *d_Tcw_pred, void *stream);
+
 /* ---- pose-only optimisation -------------------------------------------------------------------
  * Replaces `static int Optimizer::PoseOptimization(Frame *pFrame)` (src/sg-slam/include/Optimizer.h:50,
  * src/sg-slam/src/Optimizer.cc:239-451): g2o Levenberg-Marquardt over the frame pose with one
@@ -146,10 +151,14 @@ int sgx_pose_optimization(int n, const sgx_keypoint *keys_un, const float *urigh
  * relative to the (16,16) border origin) for `level`; returns the selected packed entries in list order */
 int sgx_orb_debug_run_octree(sgx_orb *h, int level, const uint32_t *packed, int n, uint32_t *out_sel, int cap, int *nsel);
 
-/* per-kernel HIP-event timing of the batched call (classes: 0 pyramid resize, 1 FAST cells, 2 octree,
- * 3 orientation+descriptor).  Events are recorded on the caller's stream around each launch. */
-int sgx_orb_profile_enable(sgx_orb *h, int on);
-int sgx_orb_profile_read(sgx_orb *h, float ms[4], int32_t launches[4], int reset);
+/* ---- per-kernel HIP-event timing (process-wide) ---------------------------------------------------
+ * When enabled, every batched entry point records a hipEvent pair on the caller's stream around each
+ * kernel launch.  sgx_profile_read sums the elapsed times per kernel class since the last reset
+ * (ms[k], launches[k] for k < sgx_profile_num_classes(); it synchronises the device). */
+int sgx_profile_enable(int on);
+int sgx_profile_num_classes(void);
+const char *sgx_profile_class_name(int k);
+int sgx_profile_read(float *ms, int32_t *launches, int reset);
 
 #ifdef __cplusplus
 }

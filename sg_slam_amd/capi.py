@@ -27,10 +27,10 @@ SYMBOLS = [
     'sgx_orb_create', 'sgx_orb_destroy', 'sgx_orb_keypoint_capacity', 'sgx_orb_get_tables',
     'sgx_orb_extract_batch_dev', 'sgx_orb_extract', 'sgx_orb_last_status',
     'sgx_orb_debug_level_geometry', 'sgx_orb_debug_read_level', 'sgx_orb_debug_read_candidates',
-    'sgx_orb_debug_run_octree', 'sgx_orb_profile_enable', 'sgx_orb_profile_read',
+    'sgx_orb_debug_run_octree', 'sgx_profile_enable', 'sgx_profile_num_classes', 'sgx_profile_class_name', 'sgx_profile_read',
     'sgx_match_project_frame_batch_dev', 'sgx_match_project_frame',
     'sgx_frame_stereo_from_rgbd_batch_dev', 'sgx_frame_unproject_batch_dev',
-    'sgx_pose_optimization_batch_dev', 'sgx_pose_optimization',
+    'sgx_pose_optimization_batch_dev', 'sgx_pose_optimization', 'sgx_frame_motion_model_batch_dev',
 ]
 
 
@@ -68,8 +68,10 @@ class SgxLib:
                                                     C.c_int, C.POINTER(C.c_int)]
 
         d.sgx_orb_debug_run_octree.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
-        d.sgx_orb_profile_enable.argtypes = [C.c_void_p, C.c_int]
-        d.sgx_orb_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        d.sgx_profile_enable.argtypes = [C.c_int]
+        d.sgx_profile_class_name.restype = C.c_char_p
+        d.sgx_profile_class_name.argtypes = [C.c_int]
+        d.sgx_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 
         vp = C.c_void_p
         d.sgx_match_project_frame_batch_dev.argtypes = [C.c_int, C.c_int] + [vp] * 13 + [C.POINTER(Camera), vp, C.c_int, C.c_float, C.c_int, C.c_int, vp, vp, vp]
@@ -78,6 +80,7 @@ class SgxLib:
         d.sgx_frame_unproject_batch_dev.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, C.POINTER(Camera), vp, vp, vp]
         d.sgx_pose_optimization_batch_dev.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, C.POINTER(Camera), vp, vp, vp, vp]
         d.sgx_pose_optimization.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.c_int, C.POINTER(Camera), vp, vp, vp]
+        d.sgx_frame_motion_model_batch_dev.argtypes = [C.c_int, vp, vp, vp, vp, vp]
 
     def version(self):
         return self.dll.sgx_version().decode()
@@ -85,3 +88,13 @@ class SgxLib:
     def check(self, rc, what=''):
         if rc != 0:
             raise SgxError(f'{what}: {self.dll.sgx_status_string(rc).decode()} ({rc})')
+
+    # per-kernel HIP-event timing (process-wide)
+    def profile_enable(self, on=True):
+        self.check(self.dll.sgx_profile_enable(int(on)))
+
+    def profile_read(self, reset=True):
+        n = self.dll.sgx_profile_num_classes()
+        ms = np.zeros(n, 'f4'); cnt = np.zeros(n, 'i4')
+        self.check(self.dll.sgx_profile_read(_vp(ms), _vp(cnt), int(reset)), 'sgx_profile_read')
+        return {self.dll.sgx_profile_class_name(k).decode(): (float(ms[k]), int(cnt[k])) for k in range(n)}

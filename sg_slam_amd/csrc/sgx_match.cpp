@@ -1,6 +1,7 @@
 // sgx_match.cpp — host side of the matcher / frame-glue C-ABI (include/sgx.h).
 // Reference behaviour: src/sg-slam/src/ORBmatcher.cc:1332-1472, src/sg-slam/src/Frame.cc:893-932.
 #include "sgx_match_kernels.h"
+#include "sgx_prof.h"
 #include "../../include/sgx.h"
 #include <stdio.h>
 #include <string.h>
@@ -24,9 +25,11 @@ extern "C" int sgx_match_project_frame_batch_dev(
         !d_l_obs || !d_l_mpdesc || !d_lTcw || !d_cur_match || !d_nmatches) return SGX_ERR_INVALID;
     SgxScales sc; memset(&sc, 0, sizeof sc);
     for (int i = 0; i < nlevels; i++) sc.s[i] = scale_factors[i];
+    sgx_prof_begin(SGX_K_MATCH, (sgx_stream_t)stream);
     SGX_LAUNCH(k_match_project_frame, dim3(batch), dim3(SGX_MATCH_THREADS), (sgx_stream_t)stream, cap,
                (const uint8_t *)d_ckeys, d_cdesc, d_curight, d_cn, d_cTcw, (const uint8_t *)d_lkeys, d_ln, d_l_has_mp, d_l_outlier,
                d_l_xw, d_l_obs, d_l_mpdesc, d_lTcw, to_cam(cam), sc, th, b_mono, check_orientation, d_cur_match, d_nmatches);
+    sgx_prof_end(SGX_K_MATCH, (sgx_stream_t)stream);
     SGX_CHECK_HIP(hipGetLastError());
     return SGX_OK;
 }
@@ -37,8 +40,10 @@ extern "C" int sgx_frame_stereo_from_rgbd_batch_dev(int batch, int cap, const sg
 {
     if (batch < 1 || cap < 1 || !d_keys || !d_n || !d_depth || !d_uright || !d_zdepth || !(depth_map_factor > 0)) return SGX_ERR_INVALID;
     const float inv = 1.0f / depth_map_factor;           // mDepthMapFactor = 1.0f/mDepthMapFactor, Tracking.cc:139-142
+    sgx_prof_begin(SGX_K_STEREO, (sgx_stream_t)stream);
     SGX_LAUNCH(k_stereo_from_rgbd, dim3((cap + 255) / 256, batch), dim3(256), (sgx_stream_t)stream, cap, (const uint8_t *)d_keys, d_n,
                d_depth, width, height, inv, bf, d_uright, d_zdepth);
+    sgx_prof_end(SGX_K_STEREO, (sgx_stream_t)stream);
     SGX_CHECK_HIP(hipGetLastError());
     return SGX_OK;
 }
@@ -47,8 +52,20 @@ extern "C" int sgx_frame_unproject_batch_dev(int batch, int cap, const sgx_keypo
                                               const float *d_Tcw, const sgx_camera *cam, float *d_xw, uint8_t *d_has, void *stream)
 {
     if (batch < 1 || cap < 1 || !d_keys || !d_n || !d_zdepth || !d_Tcw || !cam || !d_xw || !d_has) return SGX_ERR_INVALID;
+    sgx_prof_begin(SGX_K_UNPROJECT, (sgx_stream_t)stream);
     SGX_LAUNCH(k_unproject, dim3((cap + 255) / 256, batch), dim3(256), (sgx_stream_t)stream, cap, (const uint8_t *)d_keys, d_n, d_zdepth,
                d_Tcw, to_cam(cam), d_xw, d_has);
+    sgx_prof_end(SGX_K_UNPROJECT, (sgx_stream_t)stream);
+    SGX_CHECK_HIP(hipGetLastError());
+    return SGX_OK;
+}
+
+extern "C" int sgx_frame_motion_model_batch_dev(int batch, const float *d_Tcw_cur, const float *d_Tcw_prev, const uint8_t *d_valid, float *d_Tcw_pred, void *stream)
+{
+    if (batch < 1 || !d_Tcw_cur || !d_Tcw_prev || !d_Tcw_pred) return SGX_ERR_INVALID;
+    sgx_prof_begin(SGX_K_MOTION, (sgx_stream_t)stream);
+    SGX_LAUNCH(k_motion_model, dim3((batch + 63) / 64), dim3(64), (sgx_stream_t)stream, batch, d_Tcw_cur, d_Tcw_prev, d_valid, d_Tcw_pred);
+    sgx_prof_end(SGX_K_MOTION, (sgx_stream_t)stream);
     SGX_CHECK_HIP(hipGetLastError());
     return SGX_OK;
 }

@@ -277,3 +277,41 @@ SGX_KERNEL(256) k_unproject(int cap, const uint8_t *keys_raw, const int *n, cons
     }
     SGX_THREADS_END
 }
+
+// ---------------------------------------------------------------------------------------------
+// k_motion_model: the caller-side constant-velocity prediction of Tracking (Tracking.cc:463-470, :914):
+//   LastTwc = [Rlw^T | -Rlw^T tlw],  mVelocity = Tcw_cur * LastTwc,  predicted = mVelocity * Tcw_cur
+// i.e. pred = Tcur * inv(Tprev) * Tcur for the next frame.  4x4 float products as cv::gemm's 4x4 path
+// (float dot, left to right).  One thread per frame.
+// ---------------------------------------------------------------------------------------------
+SGX_DEV void sgx_mat4_mul(const float *A, const float *B, float *C)
+{
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) {
+        const float t = A[4 * i] * B[j] + A[4 * i + 1] * B[4 + j] + A[4 * i + 2] * B[8 + j] + A[4 * i + 3] * B[12 + j];
+        C[4 * i + j] = (float)((double)t * 1.0);
+    }
+}
+
+SGX_KERNEL(64) k_motion_model(int batch, const float *Tcur, const float *Tprev, const uint8_t *valid, float *Tpred)
+{
+    SGX_THREADS_BEGIN(tid)
+    const int f = (int)blockIdx.x * 64 + tid;
+    if (f < batch) {
+        const float *Tc = Tcur + 16 * f, *Tp = Tprev + 16 * f;
+        float out[16];
+        if (valid && !valid[f]) { for (int i = 0; i < 16; i++) out[i] = Tc[i]; }
+        else {
+            float Twc[16];
+            for (int r = 0; r < 3; r++) {
+                for (int c = 0; c < 3; c++) Twc[4 * r + c] = Tp[4 * c + r];
+                double s = 0; for (int k = 0; k < 3; k++) s += (double)Tp[4 * k + r] * (double)Tp[4 * k + 3];   // mOw = -Rcw^T tcw (Frame.cc:288-294)
+                Twc[4 * r + 3] = (float)(s * -1.0);
+            }
+            Twc[12] = 0.f; Twc[13] = 0.f; Twc[14] = 0.f; Twc[15] = 1.f;
+            float V[16]; sgx_mat4_mul(Tc, Twc, V);
+            sgx_mat4_mul(V, Tc, out);
+        }
+        for (int i = 0; i < 16; i++) Tpred[16 * f + i] = out[i];
+    }
+    SGX_THREADS_END
+}

@@ -2,6 +2,7 @@
 // Compiled as HIP for gfx950 (product) or as plain C++ with -DSGX_EMU (kernel-logic emulator,
 // tests only).  Reference behaviour: src/sg-slam/src/ORBextractor.cc (cited inline).
 #include "sgx_orb_kernels.h"
+#include "sgx_prof.h"
 #include "../../include/sgx.h"
 #include "../../include/sgx_orb_pattern.h"
 #include <math.h>
@@ -39,34 +40,7 @@ struct sgx_orb {
     // single-frame staging for sgx_orb_extract
     uint8_t *d_gray1 = nullptr; uint8_t *d_kps1 = nullptr; uint8_t *d_desc1 = nullptr; int *d_count1 = nullptr;
     int last_batch = 0;
-    // optional per-kernel HIP-event profiling (sgx_orb_profile_*)
-    int prof_on = 0;
-#ifndef SGX_EMU
-    std::vector<hipEvent_t> ev_a[4], ev_b[4];   // kernel classes: 0 resize (all levels), 1 fast_cells, 2 octree, 3 orient_desc
-    int ev_used[4] = {0, 0, 0, 0};
-#endif
 };
-
-#ifndef SGX_EMU
-static void prof_begin(sgx_orb *h, int k, hipStream_t st)
-{
-    if (!h->prof_on) return;
-    if (h->ev_used[k] == (int)h->ev_a[k].size()) {
-        hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-        h->ev_a[k].push_back(a); h->ev_b[k].push_back(b);
-    }
-    (void)hipEventRecord(h->ev_a[k][h->ev_used[k]], st);
-}
-static void prof_end(sgx_orb *h, int k, hipStream_t st)
-{
-    if (!h->prof_on) return;
-    (void)hipEventRecord(h->ev_b[k][h->ev_used[k]], st);
-    h->ev_used[k]++;
-}
-#else
-static void prof_begin(sgx_orb *, int, sgx_stream_t) {}
-static void prof_end(sgx_orb *, int, sgx_stream_t) {}
-#endif
 
 static inline int cvround_f(float v) { return (int)lrintf(v); }
 static inline int cvround_d(double v) { return (int)lrint(v); }
@@ -275,24 +249,24 @@ extern "C" int sgx_orb_extract_batch_dev(sgx_orb *h, const uint8_t *d_gray, int 
     const int nl = g.nlevels;
     h->last_batch = batch;
     SGX_CHECK_HIP(hipMemsetAsync(h->d_cand_count, 0, (size_t)batch * nl * 4, stream));
-    prof_begin(h, 0, stream);
+    sgx_prof_begin(SGX_K_RESIZE, stream);
     for (int l = 1; l < nl; l++) {
         dim3 grid((g.lv[l].w + 255) / 256, (g.lv[l].h + 3) / 4, batch);
         SGX_LAUNCH(k_resize, grid, dim3(256), stream, g, l, d_gray, pitch, h->d_pyr, h->d_xt[l], h->d_yt[l]);
     }
-    prof_end(h, 0, stream);
-    prof_begin(h, 1, stream);
+    sgx_prof_end(SGX_K_RESIZE, stream);
+    sgx_prof_begin(SGX_K_FAST, stream);
     SGX_LAUNCH(k_fast_cells, dim3(g.ncells * batch), dim3(256), stream, g, h->d_cells, d_gray, pitch, h->d_pyr, batch,
                h->d_cand, h->d_cand_count, h->d_status);
-    prof_end(h, 1, stream);
-    prof_begin(h, 2, stream);
+    sgx_prof_end(SGX_K_FAST, stream);
+    sgx_prof_begin(SGX_K_OCTREE, stream);
     SGX_LAUNCH(k_octree<true>, dim3(nl, batch), dim3(SGX_OCT_THREADS), stream, g, h->d_cand, h->d_cand_count, h->d_node_scratch, h->d_sel, h->d_sel_count, h->d_status);
     SGX_LAUNCH(k_octree<false>, dim3(nl, batch), dim3(SGX_OCT_THREADS), stream, g, h->d_cand, h->d_cand_count, h->d_node_scratch, h->d_sel, h->d_sel_count, h->d_status);
-    prof_end(h, 2, stream);
-    prof_begin(h, 3, stream);
+    sgx_prof_end(SGX_K_OCTREE, stream);
+    sgx_prof_begin(SGX_K_ORIENT_DESC, stream);
     SGX_LAUNCH(k_orient_desc, dim3(g.kp_cap, batch), dim3(64), stream, g, d_gray, pitch, h->d_pyr, h->d_sel, h->d_sel_count,
                h->d_umax, h->d_pattern, (uint8_t *)d_kps, d_desc, d_count, cap, h->d_status);
-    prof_end(h, 3, stream);
+    sgx_prof_end(SGX_K_ORIENT_DESC, stream);
     SGX_CHECK_HIP(hipGetLastError());
     return SGX_OK;
 }
@@ -357,29 +331,6 @@ extern "C" int sgx_orb_debug_read_candidates(sgx_orb *h, int frame, int level, i
     SGX_CHECK_HIP(hipStreamSynchronize(0));
     for (int i = 0; i < cnt && i < cap; i++) { x[i] = buf[i] & 0xFFF; y[i] = (buf[i] >> 12) & 0xFFF; score[i] = buf[i] >> 24; }
     *n = cnt;
-    return SGX_OK;
-}
-
-extern "C" int sgx_orb_profile_enable(sgx_orb *h, int on)
-{
-    if (!h) return SGX_ERR_INVALID;
-    h->prof_on = on ? 1 : 0;
-    return SGX_OK;
-}
-
-// ms[4] = summed duration per kernel class since the last reset, launches[4] = number of timed launches
-extern "C" int sgx_orb_profile_read(sgx_orb *h, float *ms, int32_t *launches, int reset)
-{
-    if (!h || !ms || !launches) return SGX_ERR_INVALID;
-    for (int k = 0; k < 4; k++) { ms[k] = 0.f; launches[k] = 0; }
-#ifndef SGX_EMU
-    SGX_CHECK_HIP(hipDeviceSynchronize());
-    for (int k = 0; k < 4; k++) {
-        for (int i = 0; i < h->ev_used[k]; i++) { float t = 0.f; SGX_CHECK_HIP(hipEventElapsedTime(&t, h->ev_a[k][i], h->ev_b[k][i])); ms[k] += t; }
-        launches[k] = h->ev_used[k];
-        if (reset) h->ev_used[k] = 0;
-    }
-#endif
     return SGX_OK;
 }
 

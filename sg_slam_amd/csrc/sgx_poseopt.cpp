@@ -1,6 +1,7 @@
 // sgx_poseopt.cpp — host side of the PoseOptimization C-ABI (include/sgx.h).
 // Reference behaviour: src/sg-slam/src/Optimizer.cc:239-451.
 #include "sgx_poseopt_kernels.h"
+#include "sgx_prof.h"
 #include "../../include/sgx.h"
 #include <stdio.h>
 #include <string.h>
@@ -20,8 +21,10 @@ extern "C" int sgx_pose_optimization_batch_dev(int batch, int cap, const sgx_key
         !inv_level_sigma2 || nlevels < 1 || nlevels > 12 || !cam || !d_Tcw || !d_outlier || !d_n_inliers) return SGX_ERR_INVALID;
     SgxScales is2; memset(&is2, 0, sizeof is2);
     for (int i = 0; i < nlevels; i++) is2.s[i] = inv_level_sigma2[i];
+    sgx_prof_begin(SGX_K_POSEOPT, (sgx_stream_t)stream);
     SGX_LAUNCH(k_pose_opt, dim3(batch), dim3(SGX_PO_THREADS), (sgx_stream_t)stream, cap, (const uint8_t *)d_keys_un, d_uright, d_n,
                d_mp_index, d_has_mp, d_mp_xw, xw_pitch, is2, po_cam(cam), d_Tcw, d_outlier, d_n_inliers);
+    sgx_prof_end(SGX_K_POSEOPT, (sgx_stream_t)stream);
     SGX_CHECK_HIP(hipGetLastError());
     return SGX_OK;
 }

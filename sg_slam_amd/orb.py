@@ -82,13 +82,3 @@ class ORBextractor:
         self.lib.check(self.lib.dll.sgx_orb_debug_run_octree(self.h, level, _vp(packed), len(packed), _vp(out), 2048, C.byref(n)), 'debug_run_octree')
         o = out[:n.value]
         return (o & 0xFFF).astype('i4'), ((o >> 12) & 0xFFF).astype('i4'), (o >> 24).astype('i4')
-
-    PROFILE_CLASSES = ('pyramid_resize', 'fast_cells', 'octree', 'orient_desc')
-
-    def profile_enable(self, on=True):
-        self.lib.check(self.lib.dll.sgx_orb_profile_enable(self.h, int(on)))
-
-    def profile_read(self, reset=True):
-        ms = np.zeros(4, 'f4'); n = np.zeros(4, 'i4')
-        self.lib.check(self.lib.dll.sgx_orb_profile_read(self.h, _vp(ms), _vp(n), int(reset)), 'profile_read')
-        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(self.PROFILE_CLASSES)}

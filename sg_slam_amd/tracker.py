@@ -1,0 +1,107 @@
+"""TrackerBatch — S independent RGB-D streams tracked in lock-step on one GPU, one frame per stream per
+step, every stage device-resident and asynchronous on one HIP stream:
+
+  ORBextractor::operator()          -> sgx_orb_extract_batch_dev           (ORBextractor.cc:1045-1106)
+  Frame::ComputeStereoFromRGBD      -> sgx_frame_stereo_from_rgbd_batch_dev (Frame.cc:893-914)
+  constant-velocity prediction      -> sgx_frame_motion_model_batch_dev     (Tracking.cc:463-470, :914)
+  ORBmatcher::SearchByProjection    -> sgx_match_project_frame_batch_dev    (ORBmatcher.cc:1332-1472, th=15)
+  Optimizer::PoseOptimization       -> sgx_pose_optimization_batch_dev      (Optimizer.cc:239-451)
+  Frame::UnprojectStereo            -> sgx_frame_unproject_batch_dev        (Frame.cc:916-930)
+
+This mirrors the call order of Tracking::GrabImageRGBD -> Frame() -> TrackWithMotionModel
+(Tracking.cc:206-251, :906-967) in "visual odometry" form: the map points a frame is tracked against
+are the previous frame's keypoints unprojected with their measured depth (UpdateLastFrame, :840-904),
+Observations()==0.  It is the bench / integration harness, not a re-implementation of Tracking.
+Arrays are torch CUDA tensors (product) or numpy arrays (kernel-logic emulator in tests).
+"""
+import ctypes as C
+import numpy as np
+from .capi import _vp
+from .matcher import camera_struct
+from .orb import ORBextractor
+
+
+class TrackerBatch:
+    def __init__(self, lib, streams, cam, width=640, height=480, nfeatures=1000, xp='torch', th=15.0):
+        self.lib, self.S, self.cam, self.W, self.H, self.th = lib, streams, dict(cam), width, height, th
+        self.ex = ORBextractor(nfeatures=nfeatures, width=width, height=height, max_batch=streams, lib=lib)
+        self.cap = self.ex.capacity
+        self.cs = camera_struct(cam, width, height)
+        self.scale = np.ascontiguousarray(self.ex.mvScaleFactor, 'f4')
+        self.inv_sigma2 = np.ascontiguousarray(self.ex.mvInvLevelSigma2, 'f4')
+        self.xp = xp
+        S, cap = streams, self.cap
+        z = self._zeros
+        # double-buffered per-frame state: [0]/[1] alternate as current/last
+        self.keys = [z((S, cap, 28), 'u1') for _ in range(2)]
+        self.desc = [z((S, cap, 32), 'u1') for _ in range(2)]
+        self.n = [z((S,), 'i4') for _ in range(2)]
+        self.uright = [z((S, cap), 'f4') for _ in range(2)]
+        self.zdepth = [z((S, cap), 'f4') for _ in range(2)]
+        self.xw = [z((S, cap, 3), 'f4') for _ in range(2)]
+        self.has = [z((S, cap), 'u1') for _ in range(2)]
+        self.Tcw = [z((S, 16), 'f4') for _ in range(3)]          # cur, last, last-last (rotating)
+        self.match = z((S, cap), 'i4')
+        self.nmatch = z((S,), 'i4')
+        self.outlier = z((S, cap), 'u1')
+        self.ninl = z((S,), 'i4')
+        self.zero_u8 = z((S, cap), 'u1')
+        self.zero_i4 = z((S, cap), 'i4')
+        self.vel_valid = z((S,), 'u1')
+        self.cur = 0
+        self.frame_idx = 0
+
+    def _zeros(self, shape, dt):
+        if self.xp == 'torch':
+            import torch
+            tdt = {'u1': torch.uint8, 'i4': torch.int32, 'f4': torch.float32}[dt]
+            return torch.zeros(shape, dtype=tdt, device='cuda')
+        return np.zeros(shape, {'u1': np.uint8, 'i4': np.int32, 'f4': np.float32}[dt])
+
+    def set_initial_pose(self, Tcw_host):
+        """Tcw of the first frame of every stream (S,4,4) — the reference starts at identity
+        (Tracking::StereoInitialization, Tracking.cc:547-603); synthetic streams start at ground truth."""
+        T = np.ascontiguousarray(Tcw_host, 'f4').reshape(self.S, 16)
+        for b in self.Tcw:
+            if self.xp == 'torch':
+                import torch
+                b.copy_(torch.from_numpy(T))
+            else:
+                b[...] = T
+
+    def step(self, d_gray, d_depth, stream=None, gray_pitch=None):
+        """Track the next frame of every stream.  d_gray: S x H x W u8, d_depth: S x H x W u16 (raw, DepthMapFactor 5000)."""
+        L, S, cap, cam = self.lib, self.S, self.cap, self.cam
+        c, l = self.cur, self.cur ^ 1
+        Tc, Tl, Tll = self.Tcw[0], self.Tcw[1], self.Tcw[2]
+        st = _vp(stream)
+        self.ex.extract_batch_dev(d_gray, gray_pitch or self.W, S, self.keys[c], self.desc[c], self.n[c], stream=stream)
+        L.check(L.dll.sgx_frame_stereo_from_rgbd_batch_dev(S, cap, _vp(self.keys[c]), _vp(self.n[c]), _vp(d_depth), self.W, self.H,
+                                                           float(cam['depth_factor']), float(cam['bf']), _vp(self.uright[c]), _vp(self.zdepth[c]), st), 'stereo')
+        if self.frame_idx > 0:
+            # Tc <- predicted pose from (Tl, Tll); frame 1 has no velocity yet -> uses the last pose
+            L.check(L.dll.sgx_frame_motion_model_batch_dev(S, _vp(Tl), _vp(Tll), _vp(self.vel_valid), _vp(Tc), st), 'motion model')
+            L.check(L.dll.sgx_match_project_frame_batch_dev(
+                S, cap, _vp(self.keys[c]), _vp(self.desc[c]), _vp(self.uright[c]), _vp(self.n[c]), _vp(Tc),
+                _vp(self.keys[l]), _vp(self.n[l]), _vp(self.has[l]), _vp(self.zero_u8), _vp(self.xw[l]), _vp(self.zero_i4), _vp(self.desc[l]), _vp(Tl),
+                C.byref(self.cs), _vp(self.scale), len(self.scale), float(self.th), 0, 1, _vp(self.match), _vp(self.nmatch), st), 'match')
+            L.check(L.dll.sgx_pose_optimization_batch_dev(
+                S, cap, _vp(self.keys[c]), _vp(self.uright[c]), _vp(self.n[c]), _vp(self.match), None, _vp(self.xw[l]), cap,
+                _vp(self.inv_sigma2), len(self.inv_sigma2), C.byref(self.cs), _vp(Tc), _vp(self.outlier), _vp(self.ninl), st), 'pose opt')
+            if self.frame_idx == 1:
+                self.vel_valid[...] = 1
+        L.check(L.dll.sgx_frame_unproject_batch_dev(S, cap, _vp(self.keys[c]), _vp(self.n[c]), _vp(self.zdepth[c]), _vp(Tc), C.byref(self.cs),
+                                                    _vp(self.xw[c]), _vp(self.has[c]), st), 'unproject')
+        # rotate: cur -> last, last -> last-last
+        self.Tcw = [Tll, Tc, Tl]
+        self.cur ^= 1
+        self.frame_idx += 1
+
+    def last_pose(self):
+        """(S,4,4) float32 Tcw of the most recently tracked frame (synchronises)."""
+        T = self.Tcw[1]
+        return (T.cpu().numpy() if self.xp == 'torch' else T.copy()).reshape(self.S, 4, 4)
+
+    def last_counts(self):
+        g = (lambda a: a.cpu().numpy()) if self.xp == 'torch' else (lambda a: a.copy())
+        return g(self.n[self.cur ^ 1]), g(self.nmatch), g(self.ninl)
