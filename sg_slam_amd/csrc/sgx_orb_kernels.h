@@ -9,6 +9,7 @@
 // integer or fp32 evaluated exactly as written (-ffp-contract=off; IEEE div/sqrt).
 #pragma once
 #include "sgx_rt.h"
+#include "sgx_block.h"
 
 #define SGX_MAX_LEVELS 12
 #define SGX_EDGE 19            /* EDGE_THRESHOLD, ORBextractor.cc:75 */
@@ -265,7 +266,6 @@ SGX_KERNEL(256) k_fast_cells(SgxOrbGeom g, const SgxCell *cells, const uint8_t *
 // candidate order in the reference is cell-raster, row-major inside a cell, which is encoded
 // in a rank key so the unordered candidate list of k_fast_cells gives the same pick.
 // ---------------------------------------------------------------------------------------------
-SGX_DEV void sgx_block_exclusive_scan_i32(int *a, int n, int *total, int tid);
 
 struct SgxOctNode { uint16_t ulx, uly, urx, bry; };   // UL.x, UL.y, UR.x, BR.y — all DivideNode needs
 
@@ -521,35 +521,6 @@ SGX_KERNEL(SGX_OCT_THREADS) k_octree(SgxOrbGeom g, const uint32_t *cand, const i
     if (tid == 0) sel_count[frame * g.nlevels + level] = s_overflow ? 0 : fsize;
     SGX_THREADS_END
 }
-
-// Block-wide exclusive scan of a[0..n) (int32), total written to *total.  Called by all threads
-// inside one SGX_THREADS region and followed by SGX_SYNC().
-#ifdef SGX_EMU
-SGX_DEV void sgx_block_exclusive_scan_i32(int *a, int n, int *total, int tid)
-{
-    if (tid != 0) return;
-    int run = 0;
-    for (int i = 0; i < n; i++) { const int v = a[i]; a[i] = run; run += v; }
-    *total = run;
-}
-#else
-SGX_DEV void sgx_block_exclusive_scan_i32(int *a, int n, int *total, int tid)
-{
-    // wave 0 scans the array in 64-wide chunks with shuffles (n <= 1280 -> <= 20 chunks)
-    if (tid >= 64) return;
-    int carry = 0;
-    for (int base = 0; base < n; base += 64) {
-        const int i = base + tid;
-        const int v = i < n ? a[i] : 0;
-        int inc = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (tid >= o) inc += t; }
-        if (i < n) a[i] = carry + inc - v;
-        carry += __shfl(inc, 63, 64);
-    }
-    if (tid == 0) *total = carry;
-}
-#endif
 
 // ---------------------------------------------------------------------------------------------
 // sinf/cosf exactly as the host libm computes them for the reference (`cos(float)` / `sin(float)`

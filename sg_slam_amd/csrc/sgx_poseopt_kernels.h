@@ -5,9 +5,10 @@
 #pragma once
 #include "sgx_rt.h"
 #include "sgx_types.h"
+#include "sgx_block.h"
 
 #define SGX_PO_CAP 1280
-#define SGX_PO_THREADS 64
+#define SGX_PO_THREADS 256
 #define SGX_PO_NRED 28            /* 21 upper-triangular H entries + 6 b entries + chi */
 
 struct SgxSE3 { double q[4]; double t[3]; };   // quaternion x,y,z,w + translation (g2o::SE3Quat)
@@ -168,13 +169,13 @@ SGX_DEV double sgx_po_chi2(const double *err, double info, int stereo)
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_pose_opt: one wave per frame.  Edge e <-> keypoint i with a map point (ascending i, as the
-// reference inserts them, Optimizer.cc:280-360).  Lanes own edges e = lane, lane+64, ...; the
+// k_pose_opt: one 256-thread workgroup per frame.  Edge e <-> keypoint i with a map point (ascending i, as the
+// reference inserts them, Optimizer.cc:280-360).  Threads own edges e = tid, tid+256, ...; the
 // 6x6 system, the chi2 sums and the LM control flow are wave-uniform (each lane evaluates the same
 // scalar code on values reduced through LDS), so the kernel follows the reference's accept/reject,
 // lambda schedule and stop rules statement for statement (levenberg.cpp:61-164).
-// Sums over edges are reduced in a fixed order (lane-strided partials, then 64 partials in lane
-// order): deterministic, and within ~1e-15 relative of the reference's sequential order.
+// Sums over edges are reduced in a fixed order (thread-strided partials, 8 groups of 32, then 8):
+// deterministic, and within ~1e-15 relative of the reference's sequential order.
 // mp_index (optional): map point of keypoint i is table row mp_index[i] (-1 = none); otherwise has_mp/xw are per keypoint.
 // ---------------------------------------------------------------------------------------------
 SGX_KERNEL(SGX_PO_THREADS) k_pose_opt(int cap, const uint8_t *keys_raw, const float *uright, const int *n_kp,
@@ -186,7 +187,9 @@ SGX_KERNEL(SGX_PO_THREADS) k_pose_opt(int cap, const uint8_t *keys_raw, const fl
     SGX_LDS uint16_t e_kp[SGX_PO_CAP];
     SGX_LDS uint8_t e_flags[SGX_PO_CAP];          // bit0 stereo, bit1 level==1 (excluded), bit2 robust kernel on, bit3 outlier flag
     SGX_LDS double part[SGX_PO_THREADS * SGX_PO_NRED];
+    SGX_LDS double part2[SGX_PO_NRED * 8];
     SGX_LDS double red[SGX_PO_NRED];
+    SGX_LDS int scan[SGX_PO_THREADS];
     SGX_LDS int s_ne, s_nbad;
 
     const int f = (int)blockIdx.x;
@@ -195,29 +198,40 @@ SGX_KERNEL(SGX_PO_THREADS) k_pose_opt(int cap, const uint8_t *keys_raw, const fl
     const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);   // Optimizer.cc:272-273 (float)
     const double fx = cam.fx, fy = cam.fy, cx = cam.cx, cy = cam.cy, bf = cam.bf;
 
-    // ---- build the edge list in ascending keypoint order (serial compaction by lane 0: N <= 1280)
+    // ---- build the edge list in ascending keypoint order: per-thread contiguous chunks + block scan
+    const int CH = (N + NT - 1) / NT;
     SGX_THREADS_BEGIN(tid)
-    if (tid == 0) {
-        int ne = 0;
-        for (int i = 0; i < N; i++) {
-            const size_t o = (size_t)f * cap + i;
-            int src = -1;
-            if (mp_index) { const int m = mp_index[o]; if (m >= 0) src = m; }
-            else if (has_mp[o]) src = i;
-            if (src < 0) continue;
-            const float *kp = (const float *)(keys_raw + o * 28);
-            const float ur = uright[o];
-            e_obs[3 * ne] = kp[0]; e_obs[3 * ne + 1] = kp[1]; e_obs[3 * ne + 2] = ur;
-            const float *X = xw + ((size_t)f * xw_pitch + src) * 3;
-            e_xw[3 * ne] = X[0]; e_xw[3 * ne + 1] = X[1]; e_xw[3 * ne + 2] = X[2];
-            e_info[ne] = inv_sigma2.s[((const int *)kp)[5]];
-            e_kp[ne] = (uint16_t)i;
-            e_flags[ne] = (uint8_t)((ur < 0 ? 0 : 1) | 4);        // mono iff mvuRight<0 (Optimizer.cc:286); Huber on
-            ne++;
-        }
-        s_ne = ne;
+    int c = 0;
+    for (int i = tid * CH; i < min(N, (tid + 1) * CH); i++) {
+        const size_t o = (size_t)f * cap + i;
+        c += mp_index ? (mp_index[o] >= 0) : (has_mp[o] != 0);
     }
+    scan[tid] = c;
     for (int i = tid; i < cap; i += NT) outlier[(size_t)f * cap + i] = 0;
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    sgx_block_exclusive_scan_i32(scan, NT, &s_ne, tid);
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    int ne_ = scan[tid];
+    for (int i = tid * CH; i < min(N, (tid + 1) * CH); i++) {
+        const size_t o = (size_t)f * cap + i;
+        int src = -1;
+        if (mp_index) { const int m = mp_index[o]; if (m >= 0) src = m; }
+        else if (has_mp[o]) src = i;
+        if (src < 0) continue;
+        const float *kp = (const float *)(keys_raw + o * 28);
+        const float ur = uright[o];
+        e_obs[3 * ne_] = kp[0]; e_obs[3 * ne_ + 1] = kp[1]; e_obs[3 * ne_ + 2] = ur;
+        const float *X = xw + ((size_t)f * xw_pitch + src) * 3;
+        e_xw[3 * ne_] = X[0]; e_xw[3 * ne_ + 1] = X[1]; e_xw[3 * ne_ + 2] = X[2];
+        e_info[ne_] = inv_sigma2.s[((const int *)kp)[5]];
+        e_kp[ne_] = (uint16_t)i;
+        e_flags[ne_] = (uint8_t)((ur < 0 ? 0 : 1) | 4);        // mono iff mvuRight<0 (Optimizer.cc:286); Huber on
+        ne_++;
+    }
     SGX_THREADS_END
     SGX_SYNC();
     const int ne = s_ne;
@@ -247,16 +261,21 @@ SGX_KERNEL(SGX_PO_THREADS) k_pose_opt(int cap, const uint8_t *keys_raw, const fl
     SGX_THREADS_END                                                                                         \
     SGX_SYNC();                                                                                             \
     SGX_THREADS_BEGIN(tid)                                                                                  \
-    if (tid == 0) { double s = 0; for (int l = 0; l < NT; l++) s += part[l * SGX_PO_NRED + 27]; red[27] = s; } \
+    if (tid < 8) { double s = 0; for (int l = 0; l < 32; l++) s += part[(tid * 32 + l) * SGX_PO_NRED + 27]; part2[27 * 8 + tid] = s; } \
+    SGX_THREADS_END                                                                                         \
+    SGX_SYNC();                                                                                             \
+    SGX_THREADS_BEGIN(tid)                                                                                  \
+    if (tid == 0) { double s = 0; for (int l = 0; l < 8; l++) s += part2[27 * 8 + l]; red[27] = s; }        \
     SGX_THREADS_END                                                                                         \
     SGX_SYNC();
 
     for (int round = 0; round < 4; round++) {
         sgx_se3_from_cv(T0, est);                                   // Optimizer.cc:377: every round restarts from pFrame->mTcw
         double lambda = -1, ni = 2; int nBadLM = 0;
+        bool fresh = false; double freshChi = 0;        // e_err / chi already evaluated at `est` by an accepted trial
         for (int it = 0; it < 10; it++) {
-            SGX_PO_ERRORS()
-            double currentChi = red[27];
+            if (!fresh) { SGX_PO_ERRORS() freshChi = red[27]; }    // computeActiveErrors + activeRobustChi2 (levenberg.cpp:73-80)
+            double currentChi = freshChi;
             double tempChi = currentChi;
             const double iniChi = currentChi;
             // ---- buildSystem: b -= rho1 * J^T (Omega e), H += J^T (rho1 Omega) J   (base_unary_edge.hpp:43-72)
@@ -294,7 +313,11 @@ SGX_KERNEL(SGX_PO_THREADS) k_pose_opt(int cap, const uint8_t *keys_raw, const fl
             SGX_THREADS_END
             SGX_SYNC();
             SGX_THREADS_BEGIN(tid)
-            if (tid < 27) { double s = 0; for (int l = 0; l < NT; l++) s += part[l * SGX_PO_NRED + tid]; red[tid] = s; }
+            if (tid < 27 * 8) { const int c = tid >> 3, j = tid & 7; double s = 0; for (int l = 0; l < 32; l++) s += part[(j * 32 + l) * SGX_PO_NRED + c]; part2[c * 8 + j] = s; }
+            SGX_THREADS_END
+            SGX_SYNC();
+            SGX_THREADS_BEGIN(tid)
+            if (tid < 27) { double s = 0; for (int l = 0; l < 8; l++) s += part2[tid * 8 + l]; red[tid] = s; }
             SGX_THREADS_END
             SGX_SYNC();
             double H[6][6], b[6];
@@ -323,8 +346,8 @@ SGX_KERNEL(SGX_PO_THREADS) k_pose_opt(int cap, const uint8_t *keys_raw, const fl
                     double alpha = 1. - pow((2 * rho - 1), 3.0);
                     alpha = alpha < 2. / 3. ? alpha : 2. / 3.;
                     const double sf = alpha > 1. / 3. ? alpha : 1. / 3.;
-                    lambda *= sf; ni = 2; currentChi = tempChi;
-                } else { lambda *= ni; ni *= 2; est = backup; }       // pop: the edges keep the rejected trial's errors
+                    lambda *= sf; ni = 2; currentChi = tempChi; fresh = true; freshChi = tempChi;
+                } else { lambda *= ni; ni *= 2; est = backup; fresh = false; }   // pop: the edges keep the rejected trial's errors
                 qmax++;
             } while (rho < 0 && qmax < 10);
             if (qmax == 10 || rho == 0) break;                       // Terminate
