@@ -14,19 +14,25 @@
 struct SgxSE3 { double q[4]; double t[3]; };   // quaternion x,y,z,w + translation (g2o::SE3Quat)
 
 SGX_DEV void sgx_quat_from_R(const double R[3][3], double q[4])
-{   // Eigen Quaterniond(Matrix3d)
+{   // Eigen Quaterniond(Matrix3d) (Shepperd branches); written with static indices only (no scratch)
     double t = R[0][0] + R[1][1] + R[2][2];
     if (t > 0) {
         t = sqrt(t + 1.0); q[3] = 0.5 * t; t = 0.5 / t;
         q[0] = (R[2][1] - R[1][2]) * t; q[1] = (R[0][2] - R[2][0]) * t; q[2] = (R[1][0] - R[0][1]) * t;
     } else {
-        int i = 0; if (R[1][1] > R[0][0]) i = 1; if (R[2][2] > R[i][i]) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = sqrt(R[i][i] - R[j][j] - R[k][k] + 1.0);
-        double qq[4];
-        qq[i] = 0.5 * t; t = 0.5 / t;
-        qq[3] = (R[k][j] - R[j][k]) * t; qq[j] = (R[j][i] + R[i][j]) * t; qq[k] = (R[k][i] + R[i][k]) * t;
-        q[0] = qq[0]; q[1] = qq[1]; q[2] = qq[2]; q[3] = qq[3];
+        int i = 0; if (R[1][1] > R[0][0]) i = 1;
+        const double rii = i == 0 ? R[0][0] : R[1][1];
+        if (R[2][2] > rii) i = 2;
+        if (i == 0) {            // j = 1, k = 2
+            t = sqrt(R[0][0] - R[1][1] - R[2][2] + 1.0); q[0] = 0.5 * t; t = 0.5 / t;
+            q[3] = (R[2][1] - R[1][2]) * t; q[1] = (R[1][0] + R[0][1]) * t; q[2] = (R[2][0] + R[0][2]) * t;
+        } else if (i == 1) {     // j = 2, k = 0
+            t = sqrt(R[1][1] - R[2][2] - R[0][0] + 1.0); q[1] = 0.5 * t; t = 0.5 / t;
+            q[3] = (R[0][2] - R[2][0]) * t; q[2] = (R[2][1] + R[1][2]) * t; q[0] = (R[0][1] + R[1][0]) * t;
+        } else {                 // j = 0, k = 1
+            t = sqrt(R[2][2] - R[0][0] - R[1][1] + 1.0); q[2] = 0.5 * t; t = 0.5 / t;
+            q[3] = (R[1][0] - R[0][1]) * t; q[0] = (R[0][2] + R[2][0]) * t; q[1] = (R[1][2] + R[2][1]) * t;
+        }
     }
 }
 SGX_DEV void sgx_quat_normalize_rot(double q[4])
@@ -59,18 +65,31 @@ SGX_DEV void sgx_se3_exp(const double u[6], SgxSE3 &out)
     const double theta = sqrt(w0 * w0 + w1 * w1 + w2 * w2);
     const double O[3][3] = { { 0, -w2, w1 }, { w2, 0, -w0 }, { -w1, w0, 0 } };
     double O2[3][3];
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += O[i][k] * O[k][j]; O2[i][j] = s; }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) O2[i][j] = O[i][0] * O[0][j] + O[i][1] * O[1][j] + O[i][2] * O[2][j];
+    }
     double R[3][3], V[3][3];
     if (theta < 0.00001) {
-        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { R[i][j] = (i == j) + O[i][j] + O2[i][j]; V[i][j] = R[i][j]; }
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) { R[i][j] = (i == j) + O[i][j] + O2[i][j]; V[i][j] = R[i][j]; }
+        }
     } else {
-        const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta), c = (theta - sin(theta)) / pow(theta, 3.0);
-        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
-            R[i][j] = (i == j) + a * O[i][j] + b * O2[i][j];
-            V[i][j] = (i == j) + b * O[i][j] + c * O2[i][j];
+        const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta), c = (theta - sin(theta)) / (theta * theta * theta);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                R[i][j] = (i == j) + a * O[i][j] + b * O2[i][j];
+                V[i][j] = (i == j) + b * O[i][j] + c * O2[i][j];
+            }
         }
     }
     sgx_quat_from_R(R, out.q);
+#pragma unroll
     for (int i = 0; i < 3; i++) out.t[i] = V[i][0] * u[3] + V[i][1] * u[4] + V[i][2] * u[5];
     sgx_quat_normalize_rot(out.q);
 }
@@ -85,7 +104,12 @@ SGX_DEV void sgx_se3_mul(const SgxSE3 &a, const SgxSE3 &b, SgxSE3 &o)
 SGX_DEV void sgx_se3_from_cv(const float *T, SgxSE3 &o)
 {   // Converter::toSE3Quat, src/sg-slam/src/Converter.cc:37-47
     double R[3][3];
-    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) R[i][j] = (double)T[4 * i + j]; o.t[i] = (double)T[4 * i + 3]; }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) R[i][j] = (double)T[4 * i + j];
+        o.t[i] = (double)T[4 * i + 3];
+    }
     sgx_quat_from_R(R, o.q); sgx_quat_normalize_rot(o.q);
 }
 SGX_DEV void sgx_se3_to_cv(const SgxSE3 &s, float *T)
@@ -108,38 +132,48 @@ SGX_DEV void sgx_huber(double e, double delta, double *rho0, double *rho1)
     else { const double sq = sqrt(e); *rho0 = 2 * sq * delta - dsqr; *rho1 = delta / sq; }
 }
 
-// LinearSolverDense: Eigen LDLT with diagonal pivoting on the 6x6 (G/solvers/linear_solver_dense.h:105-111);
-// returns false when the factorisation is "not positive" (step is then rejected, levenberg.cpp:126-127)
+// LinearSolverDense (G/solvers/linear_solver_dense.h:105-111) factorises H with Eigen's LDLT and rejects the step
+// when the factorisation is not positive (levenberg.cpp:126-127).  Here: LDL^T of the 6x6 in natural order, fully
+// unrolled (registers only).  H + lambda*I is symmetric positive definite whenever the reference's pivoted LDLT
+// reports "positive", and then both give the same solution to ~1e-15 relative; a non-positive or NaN pivot
+// returns false (step rejected) like !isPositive().
 SGX_DEV bool sgx_ldlt6_solve(const double Hin[6][6], const double b[6], double x[6])
 {
-    double A[6][6]; int perm[6];
-    for (int i = 0; i < 6; i++) { perm[i] = i; for (int j = 0; j < 6; j++) A[i][j] = Hin[i][j]; }
-    int sign = 0;
-    for (int k = 0; k < 6; k++) {
-        int p = k; double big = fabs(A[k][k]);
-        for (int i = k + 1; i < 6; i++) if (fabs(A[i][i]) > big) { big = fabs(A[i][i]); p = i; }
-        if (k == 0) sign = A[p][p] > 0 ? 1 : -1;
-        if (p != k) {
-            for (int j = 0; j < 6; j++) { const double t = A[k][j]; A[k][j] = A[p][j]; A[p][j] = t; }
-            for (int i = 0; i < 6; i++) { const double t = A[i][k]; A[i][k] = A[i][p]; A[i][p] = t; }
-            const int t = perm[k]; perm[k] = perm[p]; perm[p] = t;
-        }
-        const double d = A[k][k];
-        if (!(d == d)) return false;
-        if (d == 0) continue;
-        for (int i = k + 1; i < 6; i++) {
-            const double l = A[i][k] / d;
-            for (int j = k + 1; j < 6; j++) A[i][j] -= l * A[k][j];
-            A[i][k] = l;
+    double L[6][6], D[6];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        double d = Hin[j][j];
+#pragma unroll
+        for (int k = 0; k < 6; k++) if (k < j) d -= L[j][k] * L[j][k] * D[k];
+        D[j] = d;
+        if (!(d > 0)) ok = false;
+#pragma unroll
+        for (int i = 0; i < 6; i++) if (i > j) {
+            double v = Hin[i][j];
+#pragma unroll
+            for (int k = 0; k < 6; k++) if (k < j) v -= L[i][k] * L[j][k] * D[k];
+            L[i][j] = v / d;
         }
     }
-    if (sign != 1) return false;
+    if (!ok) return false;
     double y[6];
-    for (int i = 0; i < 6; i++) y[i] = b[perm[i]];
-    for (int i = 0; i < 6; i++) for (int j = 0; j < i; j++) y[i] -= A[i][j] * y[j];
-    for (int i = 0; i < 6; i++) y[i] = A[i][i] != 0 ? y[i] / A[i][i] : 0;
-    for (int i = 5; i >= 0; i--) for (int j = i + 1; j < 6; j++) y[i] -= A[j][i] * y[j];
-    for (int i = 0; i < 6; i++) x[perm[i]] = y[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        double v = b[i];
+#pragma unroll
+        for (int k = 0; k < 6; k++) if (k < i) v -= L[i][k] * y[k];
+        y[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) y[i] /= D[i];
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+        double v = y[i];
+#pragma unroll
+        for (int k = 0; k < 6; k++) if (k > i) v -= L[k][i] * x[k];
+        x[i] = v;
+    }
     return true;
 }
 
@@ -162,9 +196,9 @@ SGX_DEV void sgx_po_edge_error(const SgxSE3 &T, const float *X, const float *obs
 // BaseEdge::chi2 = e . (Omega e), Omega = invSigma2 * I   (G/core/base_edge.h:58-61)
 SGX_DEV double sgx_po_chi2(const double *err, double info, int stereo)
 {
-    double s = 0;
-    const int D = stereo ? 3 : 2;
-    for (int i = 0; i < D; i++) s += err[i] * (info * err[i]);
+    double s = err[0] * (info * err[0]);
+    s += err[1] * (info * err[1]);
+    if (stereo) s += err[2] * (info * err[2]);
     return s;
 }
 
@@ -281,6 +315,7 @@ SGX_KERNEL(SGX_PO_THREADS) k_pose_opt(int cap, const uint8_t *keys_raw, const fl
             // ---- buildSystem: b -= rho1 * J^T (Omega e), H += J^T (rho1 Omega) J   (base_unary_edge.hpp:43-72)
             SGX_THREADS_BEGIN(tid)
             double acc[27];
+#pragma unroll
             for (int k = 0; k < 27; k++) acc[k] = 0;
             for (int e = tid; e < ne; e += NT) {
                 const int fl = e_flags[e];
@@ -296,19 +331,27 @@ SGX_KERNEL(SGX_PO_THREADS) k_pose_opt(int cap, const uint8_t *keys_raw, const fl
                 J[1][3] = 0; J[1][4] = -invz * fy; J[1][5] = y * invz_2 * fy;
                 J[2][0] = J[0][0] - bf * y * invz_2; J[2][1] = J[0][1] + bf * x * invz_2; J[2][2] = J[0][2];
                 J[2][3] = J[0][3]; J[2][4] = 0; J[2][5] = J[0][5] - bf * invz_2;
-                const int D = stereo ? 3 : 2;
                 const double info = (double)e_info[e];
-                const double *er = e_err + 3 * e;
+                const double er[3] = { e_err[3 * e], e_err[3 * e + 1], stereo ? e_err[3 * e + 2] : 0.0 };
+                if (!stereo) {            // mono edge: the third row does not exist (adds exact zeros below)
+#pragma unroll
+                    for (int a = 0; a < 6; a++) J[2][a] = 0;
+                }
                 double rho1 = 1.0;
                 if (fl & 4) { double r0; sgx_huber(sgx_po_chi2(er, info, stereo), stereo ? deltaStereo : deltaMono, &r0, &rho1); }
                 const double w = rho1 * info;
-                int q = 0;
+#pragma unroll
                 for (int a = 0; a < 6; a++) {
-                    double s = 0; for (int d = 0; d < D; d++) s += J[d][a] * (info * er[d]);
+                    const double s = J[0][a] * (info * er[0]) + J[1][a] * (info * er[1]) + J[2][a] * (info * er[2]);
                     acc[21 + a] -= rho1 * s;
-                    for (int c = a; c < 6; c++) { double h = 0; for (int d = 0; d < D; d++) h += J[d][a] * w * J[d][c]; acc[q++] += h; }
+#pragma unroll
+                    for (int c = 0; c < 6; c++) if (c >= a) {
+                        const double h = J[0][a] * w * J[0][c] + J[1][a] * w * J[1][c] + J[2][a] * w * J[2][c];
+                        acc[a * 6 - (a * (a - 1)) / 2 + (c - a)] += h;
+                    }
                 }
             }
+#pragma unroll
             for (int k = 0; k < 27; k++) part[tid * SGX_PO_NRED + k] = acc[k];
             SGX_THREADS_END
             SGX_SYNC();
@@ -321,16 +364,27 @@ SGX_KERNEL(SGX_PO_THREADS) k_pose_opt(int cap, const uint8_t *keys_raw, const fl
             SGX_THREADS_END
             SGX_SYNC();
             double H[6][6], b[6];
-            { int q = 0; for (int a = 0; a < 6; a++) { for (int c = a; c < 6; c++) { H[a][c] = red[q]; H[c][a] = red[q]; q++; } b[a] = red[21 + a]; } }
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+#pragma unroll
+                for (int c = 0; c < 6; c++) if (c >= a) { const double v = red[a * 6 - (a * (a - 1)) / 2 + (c - a)]; H[a][c] = v; H[c][a] = v; }
+                b[a] = red[21 + a];
+            }
             if (it == 0) {                                           // computeLambdaInit, levenberg.cpp:166-180 (tau = 1e-5)
-                double maxd = 0; for (int j = 0; j < 6; j++) if (fabs(H[j][j]) > maxd) maxd = fabs(H[j][j]);
+                double maxd = 0;
+#pragma unroll
+                for (int j = 0; j < 6; j++) if (fabs(H[j][j]) > maxd) maxd = fabs(H[j][j]);
                 lambda = 1e-5 * maxd; ni = 2; nBadLM = 0;
             }
             double rho = 0; int qmax = 0;
             do {
                 const SgxSE3 backup = est;                           // push
                 double Hl[6][6];
-                for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++) Hl[a][c] = H[a][c] + (a == c ? lambda : 0.0);
+#pragma unroll
+                for (int a = 0; a < 6; a++) {
+#pragma unroll
+                    for (int c = 0; c < 6; c++) Hl[a][c] = H[a][c] + (a == c ? lambda : 0.0);
+                }
                 double x[6] = { 0, 0, 0, 0, 0, 0 };
                 const bool ok2 = sgx_ldlt6_solve(Hl, b, x);
                 SgxSE3 ex; sgx_se3_exp(x, ex);
@@ -339,11 +393,14 @@ SGX_KERNEL(SGX_PO_THREADS) k_pose_opt(int cap, const uint8_t *keys_raw, const fl
                 tempChi = red[27];
                 if (!ok2) tempChi = 1.7976931348623157e308;
                 rho = currentChi - tempChi;
-                double scale = 0; for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + b[j]);
+                double scale = 0;
+#pragma unroll
+                for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + b[j]);
                 scale += 1e-3;
                 rho /= scale;
                 if (rho > 0 && isfinite(tempChi)) {
-                    double alpha = 1. - pow((2 * rho - 1), 3.0);
+                    const double r21 = 2 * rho - 1;
+                    double alpha = 1. - r21 * r21 * r21;
                     alpha = alpha < 2. / 3. ? alpha : 2. / 3.;
                     const double sf = alpha > 1. / 3. ? alpha : 1. / 3.;
                     lambda *= sf; ni = 2; currentChi = tempChi; fresh = true; freshChi = tempChi;
