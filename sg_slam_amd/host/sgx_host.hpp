@@ -1,0 +1,131 @@
+// sgx_host.hpp — C++ host-side mirror of the reference operator interfaces over the C-ABI (include/sgx.h).
+//
+// Same class names, method names, argument meaning and error behaviour as the reference
+// (src/sg-slam/include/{ORBextractor,ORBmatcher,Optimizer}.h), expressed on plain views instead of
+// cv::Mat / Frame* so this header has no OpenCV dependency.  INTEGRATION.md shows the three-line glue that
+// adapts cv::Mat / Frame to these views inside the reference tree.  Header-only; link with -lsgx.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/sgx.h"
+
+namespace sgx {
+
+struct GrayView { const uint8_t *data; int rows, cols, step; bool empty() const { return !data || rows <= 0 || cols <= 0; } };
+
+// flattened ORB_SLAM2::Frame: what the matcher / optimiser read and write
+struct FrameView {
+    int N = 0;
+    std::vector<sgx_keypoint> mvKeysUn;     // == mvKeys when the camera has no distortion (Frame.cc:656-660)
+    std::vector<uint8_t> mDescriptors;      // N x 32
+    std::vector<float> mvuRight, mvDepth;   // -1 when no depth
+    std::vector<int32_t> mvpMapPoints;      // index into the owner of the map points (e.g. last frame), -1 = NULL
+    std::vector<uint8_t> mvbOutlier;
+    float mTcw[16] = {1,0,0,0, 0,1,0,0, 0,0,1,0, 0,0,0,1};
+    // map points held by this frame's keypoints (used when this frame is the "LastFrame" of the matcher)
+    std::vector<uint8_t> mpValid;           // mvpMapPoints[i] != NULL
+    std::vector<float> mpWorldPos;          // N x 3   MapPoint::GetWorldPos()
+    std::vector<int32_t> mpObservations;    // MapPoint::Observations()
+    std::vector<uint8_t> mpDescriptor;      // N x 32  MapPoint::GetDescriptor()
+};
+
+inline void check(int rc, const char *what) { if (rc != SGX_OK) throw std::runtime_error(std::string(what) + ": " + sgx_status_string(rc)); }
+
+// ORB_SLAM2::ORBextractor (ORBextractor.h:45-111)
+class ORBextractor {
+public:
+    ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int width = 640, int height = 480)
+        : nfeatures_(nfeatures), scaleFactor_(scaleFactor), nlevels_(nlevels)
+    {
+        sgx_orb_config c{nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, width, height, 1};
+        check(sgx_orb_create(&c, &h_), "sgx_orb_create");
+        mvScaleFactor.resize(nlevels); mvInvScaleFactor.resize(nlevels); mvLevelSigma2.resize(nlevels); mvInvLevelSigma2.resize(nlevels);
+        check(sgx_orb_get_tables(h_, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(), mvInvLevelSigma2.data(), nullptr), "sgx_orb_get_tables");
+    }
+    ~ORBextractor() { sgx_orb_destroy(h_); }
+    ORBextractor(const ORBextractor &) = delete;
+    ORBextractor &operator=(const ORBextractor &) = delete;
+
+    // operator()(image, mask, keypoints, descriptors): mask is ignored, as in the reference (Frame.cc:277 passes cv::Mat())
+    void operator()(const GrayView &image, const void * /*mask*/, std::vector<sgx_keypoint> &keypoints, std::vector<uint8_t> &descriptors)
+    {
+        keypoints.clear(); descriptors.clear();
+        if (image.empty()) return;                                   // ORBextractor.cc:1048
+        const int cap = sgx_orb_keypoint_capacity(h_);
+        keypoints.resize(cap); descriptors.resize((size_t)cap * 32);
+        int n = 0;
+        check(sgx_orb_extract(h_, image.data, image.step, keypoints.data(), descriptors.data(), cap, &n), "sgx_orb_extract");
+        keypoints.resize(n); descriptors.resize((size_t)n * 32);
+    }
+    int GetLevels() { return nlevels_; }
+    float GetScaleFactor() { return scaleFactor_; }
+    std::vector<float> GetScaleFactors() { return mvScaleFactor; }
+    std::vector<float> GetInverseScaleFactors() { return mvInvScaleFactor; }
+    std::vector<float> GetScaleSigmaSquares() { return mvLevelSigma2; }
+    std::vector<float> GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
+    int GetnFeatures() { return nfeatures_; }
+    sgx_orb *handle() { return h_; }
+
+private:
+    sgx_orb *h_ = nullptr;
+    int nfeatures_; float scaleFactor_; int nlevels_;
+    std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+};
+
+// ORB_SLAM2::ORBmatcher (ORBmatcher.h:41-89) — SearchByProjection(CurrentFrame, LastFrame, th, bMono)
+class ORBmatcher {
+public:
+    static const int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 30;
+    ORBmatcher(float nnratio = 0.6f, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+
+    static int DescriptorDistance(const uint8_t *a, const uint8_t *b)
+    {
+        int d = 0;
+        for (int i = 0; i < 32; i++) d += __builtin_popcount((unsigned)(a[i] ^ b[i]));
+        return d;
+    }
+
+    // fills CurrentFrame.mvpMapPoints with indices of LastFrame map points; returns nmatches (ORBmatcher.cc:1332-1472)
+    int SearchByProjection(FrameView &CurrentFrame, const FrameView &LastFrame, float th, bool bMono,
+                           const sgx_camera &cam, const std::vector<float> &scaleFactors)
+    {
+        CurrentFrame.mvpMapPoints.assign(CurrentFrame.N, -1);
+        std::vector<uint8_t> no_outlier(LastFrame.N, 0);
+        const uint8_t *outl = LastFrame.mvbOutlier.size() == (size_t)LastFrame.N ? LastFrame.mvbOutlier.data() : no_outlier.data();
+        int32_t n = 0;
+        check(sgx_match_project_frame(CurrentFrame.N, CurrentFrame.mvKeysUn.data(), CurrentFrame.mDescriptors.data(), CurrentFrame.mvuRight.data(), CurrentFrame.mTcw,
+                                      LastFrame.N, LastFrame.mvKeysUn.data(), LastFrame.mpValid.data(), outl, LastFrame.mpWorldPos.data(),
+                                      LastFrame.mpObservations.data(), LastFrame.mpDescriptor.data(), LastFrame.mTcw,
+                                      &cam, scaleFactors.data(), (int)scaleFactors.size(), th, bMono ? 1 : 0, mbCheckOrientation ? 1 : 0,
+                                      CurrentFrame.mvpMapPoints.data(), &n), "sgx_match_project_frame");
+        return n;
+    }
+
+protected:
+    float mfNNratio; bool mbCheckOrientation;
+};
+
+// ORB_SLAM2::Optimizer (Optimizer.h:40-58) — static int PoseOptimization(Frame *pFrame)
+class Optimizer {
+public:
+    // map points of pFrame->mvpMapPoints[i] live in `owner` (the frame the matcher matched against)
+    static int PoseOptimization(FrameView *pFrame, const FrameView &owner, const sgx_camera &cam, const std::vector<float> &invLevelSigma2)
+    {
+        const int N = pFrame->N;
+        std::vector<uint8_t> has(N, 0); std::vector<float> xw((size_t)N * 3, 0.f);
+        for (int i = 0; i < N; i++) {
+            const int m = pFrame->mvpMapPoints[i];
+            if (m >= 0) { has[i] = 1; std::memcpy(&xw[3 * (size_t)i], &owner.mpWorldPos[3 * (size_t)m], 12); }
+        }
+        pFrame->mvbOutlier.assign(N, 0);
+        int32_t ninl = 0;
+        check(sgx_pose_optimization(N, pFrame->mvKeysUn.data(), pFrame->mvuRight.data(), has.data(), xw.data(), invLevelSigma2.data(),
+                                    (int)invLevelSigma2.size(), &cam, pFrame->mTcw, pFrame->mvbOutlier.data(), &ninl), "sgx_pose_optimization");
+        return ninl;
+    }
+};
+
+}  // namespace sgx
