@@ -82,7 +82,8 @@ def main():
     # synthetic streams: stream s of rank r = the plane stream starting at time offset 37*(r*S+s)
     gen = synth.PlaneStream(seed=1234)
     host = np.empty((T, S, 480, 640), np.uint8)
-    t0s = [37 * (rank * S + s) for s in range(S)]
+    from sg_slam_amd import dist as sdist
+    t0s = sdist.stream_offsets(rank, S)
     for s in range(S):
         for t in range(T):
             host[t, s] = gen.frame(t0s[s] + t)[0]
@@ -127,16 +128,12 @@ def main():
     tracked = int((ninl >= 10).sum())
 
     if dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        # BASELINE config 5: gather per-frame records (pose + counts) to rank 0 over RCCL/xGMI (outside the timed region)
-        rec = torch.cat([tr.Tcw[1].reshape(S, 16), tr.ninl.float().reshape(S, 1), tr.nmatch.float().reshape(S, 1)], 1).contiguous()
-        allrec = [torch.empty_like(rec) for _ in range(world)]
-        dist.all_gather(allrec, rec)
-        sq = torch.tensor([float((err ** 2).sum()), float(len(err)), float(tracked)], dtype=torch.float64, device='cuda')
-        dist.all_reduce(sq)
-        ate_rmse = float(torch.sqrt(sq[0] / sq[1]).item()); tracked = int(sq[2].item())
+        dt = sdist.max_over_ranks(dist, dt, 'cuda')
+        # BASELINE config 5: gather per-frame records (pose + counts) over RCCL/xGMI (outside the timed region)
+        allrec = sdist.gather_frame_records(dist, tr.Tcw[1], tr.ninl, tr.nmatch)
+        assert allrec.shape == (world, S, 18)
+        sq = sdist.sum_over_ranks(dist, [float((err ** 2).sum()), float(len(err)), float(tracked)], 'cuda')
+        ate_rmse = float(np.sqrt(sq[0] / sq[1])); tracked = int(sq[2])
 
     if rank != 0:
         if dist: dist.destroy_process_group()
