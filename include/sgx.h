@@ -147,6 +147,30 @@ int sgx_pose_optimization(int n, const sgx_keypoint *keys_un, const float *urigh
                           const float *inv_level_sigma2, int nlevels, const sgx_camera *cam,
                           float *Tcw, uint8_t *outlier, int32_t *n_inliers);
 
+/* ---- local bundle adjustment -------------------------------------------------------------------
+ * Replaces `static void Optimizer::LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Map *pMap)`
+ * (src/sg-slam/include/Optimizer.h:52, src/sg-slam/src/Optimizer.cc:453-778) from the point where the local
+ * graph is known: the caller flattens lLocalKeyFrames + lFixedCameras into `poses` (KeyFrame::mnId order, as g2o
+ * orders vertices), lLocalMapPoints into `points`, and the observation edges in insertion order (outer loop over
+ * points, Optimizer.cc:572-653).  optimize(5) with Huber -> chi2/depth classification -> optimize(10) without the
+ * outliers -> per-edge erase flags (the (KeyFrame, MapPoint) pairs of vToErase, :709-757).  fp64 inside.
+ * pose_fixed: 0 = local keyframe (optimised), 1 = fixed camera (lFixedCameras, never rewritten),
+ *             2 = local keyframe with mnId==0 (fixed vertex, still rewritten through SE3Quat like :762-768).
+ * edge_obs: (u, v, uR) per edge, uR < 0 => monocular edge.  stop_flag mirrors pbStopFlag (polled between trials). */
+typedef struct sgx_ba_problem {
+    int32_t n_poses, n_points, n_edges;
+    float *poses;                 /* n_poses x 16 (Tcw row-major), in/out */
+    const uint8_t *pose_fixed;    /* n_poses */
+    float *points;                /* n_points x 3, in/out */
+    const int32_t *edge_pose;     /* n_edges */
+    const int32_t *edge_point;    /* n_edges */
+    const float *edge_obs;        /* n_edges x 3 */
+    const float *edge_info;       /* n_edges: mvInvLevelSigma2[octave] */
+} sgx_ba_problem;
+typedef struct sgx_ba_stats { int32_t iterations_first, iterations_second, free_poses, reserved; double chi2_first, chi2_second; } sgx_ba_stats;
+int sgx_local_bundle_adjustment(const sgx_ba_problem *problem, const sgx_camera *cam, const volatile int32_t *stop_flag,
+                                uint8_t *edge_erase, sgx_ba_stats *stats);
+
 /* run the octree-distribution kernel alone on packed candidates (x | y<<12 | score<<24, coordinates
  * relative to the (16,16) border origin) for `level`; returns the selected packed entries in list order */
 int sgx_orb_debug_run_octree(sgx_orb *h, int level, const uint32_t *packed, int n, uint32_t *out_sel, int cap, int *nsel);

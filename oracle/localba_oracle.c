@@ -1,0 +1,281 @@
+/* oracle/localba_oracle.c — CPU ORACLE for Optimizer::LocalBundleAdjustment.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Restates (fp64, fp32 at the cv::Mat boundary):
+ *   Optimizer::LocalBundleAdjustment             src/sg-slam/src/Optimizer.cc:453-778 (graph already flattened by the caller)
+ * and the vendored g2o it drives (G = src/sg-slam/Thirdparty/g2o/g2o):
+ *   OptimizationAlgorithmLevenberg::solve        G/core/optimization_algorithm_levenberg.cpp:61-189
+ *   BlockSolver<6,3> buildSystem/setLambda/solve G/core/block_solver.hpp:354-486,502-604 (Schur complement)
+ *   BaseBinaryEdge::constructQuadraticForm       G/core/base_binary_edge.hpp:55-120
+ *   Edge(Stereo)SE3ProjectXYZ                    G/types/types_six_dof_expmap.h:80-140, .cpp:103-157,188-234
+ *   VertexSBAPointXYZ::oplusImpl                 G/types/types_sba.h:52-56
+ *   SparseOptimizer::buildIndexMapping           G/core/sparse_optimizer.cpp:166-190 (free poses first, then points)
+ * The reduced camera system is solved by the reference with Eigen SimplicialLDLT (G/solvers/linear_solver_eigen.h);
+ * here by a dense LDL^T — same solution up to rounding.   ==> PARITY UNPINNED at the Eigen boundary <==
+ *
+ * Flattened problem: poses[np] (Tcw 4x4 float, fixed flag; KeyFrame::mnId order), points[nl] (float3; MapPoint order),
+ * edges[ne] in insertion order (outer loop over points, Optimizer.cc:572-653): pose index, point index,
+ * obs (u, v, uR; uR < 0 => monocular edge), invSigma2.
+ */
+#include <math.h>
+#include <float.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "orc_se3.h"
+
+typedef struct { double fx, fy, cx, cy, bf; } bcam;
+typedef struct { int pose, point, stereo, level, robust; double obs[3], info, err[3]; } bedge;
+
+static void bhuber(double e, double delta, double rho[3])
+{
+    const double dsqr = delta * delta;
+    if (e <= dsqr) { rho[0] = e; rho[1] = 1.; rho[2] = 0.; }
+    else { const double sq = sqrt(e); rho[0] = 2 * sq * delta - dsqr; rho[1] = delta / sq; rho[2] = -0.5 * rho[1] / e; }
+}
+static void bedge_error(bedge *e, const se3q *T, const double *X, const bcam *c)
+{
+    double p[3]; se3_map(T, X, p);
+    if (!e->stereo) { e->err[0] = e->obs[0] - (p[0] / p[2] * c->fx + c->cx); e->err[1] = e->obs[1] - (p[1] / p[2] * c->fy + c->cy); e->err[2] = 0; }
+    else {
+        const float invz = 1.0f / p[2];                    /* types_six_dof_expmap.cpp:150-157 — float */
+        const double r0 = p[0] * invz * c->fx + c->cx, r1 = p[1] * invz * c->fy + c->cy, r2 = r0 - c->bf * invz;
+        e->err[0] = e->obs[0] - r0; e->err[1] = e->obs[1] - r1; e->err[2] = e->obs[2] - r2;
+    }
+}
+static double bedge_chi2(const bedge *e) { const int D = e->stereo ? 3 : 2; double s = 0; for (int i = 0; i < D; i++) s += e->err[i] * (e->info * e->err[i]); return s; }
+
+/* dense LDL^T solve (n x n, row-major, symmetric); returns 0 when a pivot is not positive */
+static int dense_ldlt_solve(double *A, int n, const double *b, double *x)
+{
+    double *d = (double *)malloc(sizeof(double) * n);
+    for (int j = 0; j < n; j++) {
+        double v = A[(size_t)j * n + j];
+        for (int k = 0; k < j; k++) v -= A[(size_t)j * n + k] * A[(size_t)j * n + k] * d[k];
+        d[j] = v;
+        if (!(v > 0)) { free(d); return 0; }
+        for (int i = j + 1; i < n; i++) {
+            double w = A[(size_t)i * n + j];
+            for (int k = 0; k < j; k++) w -= A[(size_t)i * n + k] * A[(size_t)j * n + k] * d[k];
+            A[(size_t)i * n + j] = w / v;
+        }
+    }
+    for (int i = 0; i < n; i++) { double v = b[i]; for (int k = 0; k < i; k++) v -= A[(size_t)i * n + k] * x[k]; x[i] = v; }
+    for (int i = 0; i < n; i++) x[i] /= d[i];
+    for (int i = n - 1; i >= 0; i--) { double v = x[i]; for (int k = i + 1; k < n; k++) v -= A[(size_t)k * n + i] * x[k]; x[i] = v; }
+    free(d);
+    return 1;
+}
+
+typedef struct {
+    int np, nl, ne, nfree;
+    se3q *T; double *X; int *hidx;          /* hidx[pose] = index among free poses or -1 */
+    bedge *E; bcam cam;
+    float dMono, dStereo;
+    const volatile int *stop;
+} ba_t;
+
+static double ba_active_chi2(ba_t *B, int recompute)
+{
+    double chi = 0;
+    for (int k = 0; k < B->ne; k++) {
+        bedge *e = &B->E[k]; if (e->level != 0) continue;
+        if (recompute) bedge_error(e, &B->T[e->pose], &B->X[3 * e->point], &B->cam);
+        const double c2 = bedge_chi2(e);
+        if (e->robust) { double r[3]; bhuber(c2, e->stereo ? B->dStereo : B->dMono, r); chi += r[0]; } else chi += c2;
+    }
+    return chi;
+}
+
+/* one optimizer.optimize(iterations) call on the level-0 edges; trace rows: {chi2, lambda, trials} */
+static int ba_optimize(ba_t *B, int iterations, double *trace)
+{
+    const int nf = B->nfree, nl = B->nl, NP = 6 * nf;
+    /* active vertices: a point takes part only if it has an active edge (initializeOptimization, sparse_optimizer.cpp:218-245) */
+    uint8_t *pt_active = (uint8_t *)calloc(nl > 0 ? nl : 1, 1);
+    for (int k = 0; k < B->ne; k++) if (B->E[k].level == 0) pt_active[B->E[k].point] = 1;
+    double *Hpp = (double *)malloc(sizeof(double) * (size_t)(nf > 0 ? nf : 1) * 36), *bp = (double *)malloc(sizeof(double) * (NP > 0 ? NP : 1));
+    double *Hll = (double *)malloc(sizeof(double) * (size_t)(nl > 0 ? nl : 1) * 9), *bl = (double *)malloc(sizeof(double) * (size_t)(nl > 0 ? nl : 1) * 3);
+    double *Hpl = (double *)malloc(sizeof(double) * (size_t)(B->ne > 0 ? B->ne : 1) * 18);
+    double *S = (double *)malloc(sizeof(double) * (size_t)(NP > 0 ? NP : 1) * (NP > 0 ? NP : 1));
+    double *xp = (double *)calloc(NP > 0 ? NP : 1, sizeof(double)), *xl = (double *)calloc((size_t)(nl > 0 ? nl : 1) * 3, sizeof(double));
+    double *Dinv = (double *)malloc(sizeof(double) * (size_t)(nl > 0 ? nl : 1) * 9), *coef = (double *)malloc(sizeof(double) * (NP > 0 ? NP : 1));
+    se3q *Tb = (se3q *)malloc(sizeof(se3q) * B->np); double *Xb = (double *)malloc(sizeof(double) * (size_t)(nl > 0 ? nl : 1) * 3);
+    double lambda = -1, ni = 2; int nBadLM = 0, iters = 0;
+    for (int it = 0; it < iterations; it++) {
+        if (B->stop && *B->stop) break;                                   /* SparseOptimizer::terminate() */
+        double currentChi = ba_active_chi2(B, 1), tempChi = currentChi; const double iniChi = currentChi;
+        /* ---- buildSystem */
+        memset(Hpp, 0, sizeof(double) * (size_t)nf * 36); memset(bp, 0, sizeof(double) * NP);
+        memset(Hll, 0, sizeof(double) * (size_t)nl * 9); memset(bl, 0, sizeof(double) * (size_t)nl * 3);
+        for (int k = 0; k < B->ne; k++) {
+            bedge *e = &B->E[k]; double *hpl = Hpl + (size_t)k * 18; memset(hpl, 0, sizeof(double) * 18);
+            if (e->level != 0) continue;
+            const se3q *T = &B->T[e->pose]; const double *X = &B->X[3 * e->point];
+            double p[3]; se3_map(T, X, p);
+            double R[3][3]; quat_to_R(T->q, R);
+            const double x = p[0], y = p[1], z = p[2], z_2 = z * z, fx = B->cam.fx, fy = B->cam.fy, bf = B->cam.bf;
+            double A[3][3], Bj[3][6];
+            if (e->stereo) {                                                 /* .cpp:188-234 */
+                for (int c = 0; c < 3; c++) {
+                    A[0][c] = -fx * R[0][c] / z + fx * x * R[2][c] / z_2;
+                    A[1][c] = -fy * R[1][c] / z + fy * y * R[2][c] / z_2;
+                    A[2][c] = A[0][c] - bf * R[2][c] / z_2;
+                }
+            } else {                                                          /* .cpp:103-139: -1/z * tmp * R */
+                const double tmp[2][3] = { { fx, 0, -x / z * fx }, { 0, fy, -y / z * fy } };
+                for (int r = 0; r < 2; r++) for (int c = 0; c < 3; c++) { double s = 0; for (int q = 0; q < 3; q++) s += tmp[r][q] * R[q][c]; A[r][c] = -1. / z * s; }
+                for (int c = 0; c < 3; c++) A[2][c] = 0;
+            }
+            Bj[0][0] = x * y / z_2 * fx; Bj[0][1] = -(1 + (x * x / z_2)) * fx; Bj[0][2] = y / z * fx; Bj[0][3] = -1. / z * fx; Bj[0][4] = 0; Bj[0][5] = x / z_2 * fx;
+            Bj[1][0] = (1 + y * y / z_2) * fy; Bj[1][1] = -x * y / z_2 * fy; Bj[1][2] = -x / z * fy; Bj[1][3] = 0; Bj[1][4] = -1. / z * fy; Bj[1][5] = y / z_2 * fy;
+            if (e->stereo) { Bj[2][0] = Bj[0][0] - bf * y / z_2; Bj[2][1] = Bj[0][1] + bf * x / z_2; Bj[2][2] = Bj[0][2]; Bj[2][3] = Bj[0][3]; Bj[2][4] = 0; Bj[2][5] = Bj[0][5] - bf / z_2; }
+            else for (int c = 0; c < 6; c++) Bj[2][c] = 0;
+            const int D = e->stereo ? 3 : 2;
+            double rho1 = 1.0;
+            if (e->robust) { double r[3]; bhuber(bedge_chi2(e), e->stereo ? B->dStereo : B->dMono, r); rho1 = r[1]; }
+            const double w = rho1 * e->info;
+            double om_r[3]; for (int d = 0; d < 3; d++) om_r[d] = -(e->info * e->err[d]) * rho1;
+            double *hl = Hll + (size_t)e->point * 9, *bL = bl + (size_t)e->point * 3;
+            for (int a = 0; a < 3; a++) {
+                double s = 0; for (int d = 0; d < D; d++) s += A[d][a] * om_r[d]; bL[a] += s;
+                for (int c = 0; c < 3; c++) { double h = 0; for (int d = 0; d < D; d++) h += A[d][a] * w * A[d][c]; hl[3 * a + c] += h; }
+            }
+            const int hp = B->hidx[e->pose];
+            if (hp >= 0) {
+                double *hP = Hpp + (size_t)hp * 36, *bP = bp + 6 * hp;
+                for (int a = 0; a < 6; a++) {
+                    double s = 0; for (int d = 0; d < D; d++) s += Bj[d][a] * om_r[d]; bP[a] += s;
+                    for (int c = 0; c < 6; c++) { double h = 0; for (int d = 0; d < D; d++) h += Bj[d][a] * w * Bj[d][c]; hP[6 * a + c] += h; }
+                    for (int c = 0; c < 3; c++) { double h = 0; for (int d = 0; d < D; d++) h += Bj[d][a] * w * A[d][c]; hpl[3 * a + c] = h; }
+                }
+            }
+        }
+        if (it == 0) {                                                       /* computeLambdaInit over all active vertices */
+            double maxd = 0;
+            for (int i = 0; i < nf; i++) for (int j = 0; j < 6; j++) { const double v = fabs(Hpp[(size_t)i * 36 + 7 * j]); if (v > maxd) maxd = v; }
+            for (int i = 0; i < nl; i++) if (pt_active[i]) for (int j = 0; j < 3; j++) { const double v = fabs(Hll[(size_t)i * 9 + 4 * j]); if (v > maxd) maxd = v; }
+            lambda = 1e-5 * maxd; ni = 2; nBadLM = 0;
+        }
+        double rho = 0; int qmax = 0;
+        do {
+            memcpy(Tb, B->T, sizeof(se3q) * B->np); memcpy(Xb, B->X, sizeof(double) * (size_t)nl * 3);      /* push */
+            /* ---- solve with Schur complement (block_solver.hpp:367-486); lambda on both diagonals (:573-587) */
+            int ok2 = 1;
+            memset(S, 0, sizeof(double) * (size_t)NP * NP); memset(coef, 0, sizeof(double) * NP);
+            for (int i = 0; i < nf; i++) for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++)
+                S[(size_t)(6 * i + a) * NP + 6 * i + c] = Hpp[(size_t)i * 36 + 6 * a + c] + (a == c ? lambda : 0);
+            for (int l = 0; l < nl; l++) {
+                double *Di = Dinv + (size_t)l * 9;
+                if (!pt_active[l]) { memset(Di, 0, sizeof(double) * 9); continue; }
+                double M[9]; memcpy(M, Hll + (size_t)l * 9, sizeof M); M[0] += lambda; M[4] += lambda; M[8] += lambda;
+                const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
+                const double det = M[0] * c00 + M[1] * c01 + M[2] * c02, id = 1.0 / det;          /* Eigen Matrix3d::inverse(): cofactors / det */
+                Di[0] = c00 * id; Di[1] = (M[2] * M[7] - M[1] * M[8]) * id; Di[2] = (M[1] * M[5] - M[2] * M[4]) * id;
+                Di[3] = c01 * id; Di[4] = (M[0] * M[8] - M[2] * M[6]) * id; Di[5] = (M[2] * M[3] - M[0] * M[5]) * id;
+                Di[6] = c02 * id; Di[7] = (M[1] * M[6] - M[0] * M[7]) * id; Di[8] = (M[0] * M[4] - M[1] * M[3]) * id;
+            }
+            /* edges of one point are contiguous or not — handle generally with per-point edge lists */
+            {
+                int *head = (int *)malloc(sizeof(int) * (nl + 1)); int *lst = (int *)malloc(sizeof(int) * (B->ne > 0 ? B->ne : 1));
+                memset(head, 0, sizeof(int) * (nl + 1));
+                for (int k = 0; k < B->ne; k++) if (B->E[k].level == 0 && B->hidx[B->E[k].pose] >= 0) head[B->E[k].point + 1]++;
+                for (int l = 0; l < nl; l++) head[l + 1] += head[l];
+                int *fill = (int *)calloc(nl > 0 ? nl : 1, sizeof(int));
+                for (int k = 0; k < B->ne; k++) if (B->E[k].level == 0 && B->hidx[B->E[k].pose] >= 0) { const int l = B->E[k].point; lst[head[l] + fill[l]++] = k; }
+                for (int l = 0; l < nl; l++) {
+                    const double *Di = Dinv + (size_t)l * 9;
+                    double db[3]; for (int a = 0; a < 3; a++) db[a] = Di[3 * a] * bl[3 * l] + Di[3 * a + 1] * bl[3 * l + 1] + Di[3 * a + 2] * bl[3 * l + 2];
+                    for (int q1 = head[l]; q1 < head[l + 1]; q1++) {
+                        const int k1 = lst[q1], i1 = B->hidx[B->E[k1].pose]; const double *B1 = Hpl + (size_t)k1 * 18;
+                        double BD[18];
+                        for (int a = 0; a < 6; a++) for (int c = 0; c < 3; c++) BD[3 * a + c] = B1[3 * a] * Di[c] + B1[3 * a + 1] * Di[3 + c] + B1[3 * a + 2] * Di[6 + c];
+                        for (int a = 0; a < 6; a++) coef[6 * i1 + a] += B1[3 * a] * db[0] + B1[3 * a + 1] * db[1] + B1[3 * a + 2] * db[2];
+                        for (int q2 = head[l]; q2 < head[l + 1]; q2++) {
+                            const int k2 = lst[q2], i2 = B->hidx[B->E[k2].pose]; const double *B2 = Hpl + (size_t)k2 * 18;
+                            for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++)
+                                S[(size_t)(6 * i1 + a) * NP + 6 * i2 + c] -= BD[3 * a] * B2[3 * c] + BD[3 * a + 1] * B2[3 * c + 1] + BD[3 * a + 2] * B2[3 * c + 2];
+                        }
+                    }
+                }
+                free(head); free(lst); free(fill);
+            }
+            double *bs = (double *)malloc(sizeof(double) * (NP > 0 ? NP : 1));
+            for (int i = 0; i < NP; i++) bs[i] = bp[i] - coef[i];
+            if (NP > 0) ok2 = dense_ldlt_solve(S, NP, bs, xp);
+            free(bs);
+            if (ok2) {                                                       /* xl = Dinv (bl - Hpl^T xp) */
+                double *cl = (double *)malloc(sizeof(double) * (size_t)(nl > 0 ? nl : 1) * 3); memcpy(cl, bl, sizeof(double) * (size_t)nl * 3);
+                for (int k = 0; k < B->ne; k++) {
+                    const bedge *e = &B->E[k]; const int hp = B->hidx[e->pose];
+                    if (e->level != 0 || hp < 0) continue;
+                    const double *Bk = Hpl + (size_t)k * 18;
+                    for (int c = 0; c < 3; c++) { double s = 0; for (int a = 0; a < 6; a++) s += Bk[3 * a + c] * xp[6 * hp + a]; cl[3 * e->point + c] -= s; }
+                }
+                for (int l = 0; l < nl; l++) { const double *Di = Dinv + (size_t)l * 9; for (int a = 0; a < 3; a++) xl[3 * l + a] = Di[3 * a] * cl[3 * l] + Di[3 * a + 1] * cl[3 * l + 1] + Di[3 * a + 2] * cl[3 * l + 2]; }
+                free(cl);
+            }
+            /* ---- update (oplus); g2o applies _x even when the solve failed — _x then holds the previous solution */
+            for (int i = 0; i < B->np; i++) { const int hp = B->hidx[i]; if (hp < 0) continue; se3q ex, up; se3_exp(xp + 6 * hp, &ex); se3_mul(&ex, &B->T[i], &up); B->T[i] = up; }
+            for (int l = 0; l < nl; l++) if (pt_active[l]) for (int a = 0; a < 3; a++) B->X[3 * l + a] += xl[3 * l + a];
+            tempChi = ba_active_chi2(B, 1);
+            if (!ok2) tempChi = DBL_MAX;
+            rho = currentChi - tempChi;
+            double scale = 0;
+            for (int i = 0; i < NP; i++) scale += xp[i] * (lambda * xp[i] + bp[i]);
+            for (int l = 0; l < nl; l++) if (pt_active[l]) for (int a = 0; a < 3; a++) scale += xl[3 * l + a] * (lambda * xl[3 * l + a] + bl[3 * l + a]);
+            scale += 1e-3; rho /= scale;
+            if (rho > 0 && isfinite(tempChi)) {
+                double alpha = 1. - pow((2 * rho - 1), 3); alpha = alpha < 2. / 3. ? alpha : 2. / 3.;
+                lambda *= (alpha > 1. / 3. ? alpha : 1. / 3.); ni = 2; currentChi = tempChi;
+            } else { lambda *= ni; ni *= 2; memcpy(B->T, Tb, sizeof(se3q) * B->np); memcpy(B->X, Xb, sizeof(double) * (size_t)nl * 3); }
+            qmax++;
+        } while (rho < 0 && qmax < 10 && !(B->stop && *B->stop));
+        iters = it + 1;
+        if (trace) { trace[3 * it] = currentChi; trace[3 * it + 1] = lambda; trace[3 * it + 2] = qmax; }
+        if (qmax == 10 || rho == 0) break;
+        if ((iniChi - currentChi) * 1e3 < iniChi) nBadLM++; else nBadLM = 0;
+        if (nBadLM >= 3) break;
+    }
+    free(pt_active); free(Hpp); free(bp); free(Hll); free(bl); free(Hpl); free(S); free(xp); free(xl); free(Dinv); free(coef); free(Tb); free(Xb);
+    return iters;
+}
+
+int orc_local_ba(int np, float *poses, const uint8_t *pose_fixed, int nl, float *points,
+                 int ne, const int *e_pose, const int *e_point, const float *e_obs, const float *e_info,
+                 float fx, float fy, float cx, float cy, float bf, const int *stop_flag,
+                 uint8_t *e_erase, double *trace /* 15*3 or NULL */, int *iters_out /* 2 or NULL */)
+{
+    ba_t B; memset(&B, 0, sizeof B);
+    B.np = np; B.nl = nl; B.ne = ne; B.cam.fx = fx; B.cam.fy = fy; B.cam.cx = cx; B.cam.cy = cy; B.cam.bf = bf;
+    B.dMono = (float)sqrt(5.991); B.dStereo = (float)sqrt(7.815); B.stop = (const volatile int *)stop_flag;
+    B.T = (se3q *)malloc(sizeof(se3q) * (np > 0 ? np : 1)); B.X = (double *)malloc(sizeof(double) * (size_t)(nl > 0 ? nl : 1) * 3);
+    B.hidx = (int *)malloc(sizeof(int) * (np > 0 ? np : 1)); B.E = (bedge *)calloc(ne > 0 ? ne : 1, sizeof(bedge));
+    for (int i = 0; i < np; i++) { se3_from_cv(poses + 16 * i, &B.T[i]); B.hidx[i] = pose_fixed[i] ? -1 : B.nfree++; }
+    for (int i = 0; i < 3 * nl; i++) B.X[i] = points[i];
+    for (int k = 0; k < ne; k++) {
+        bedge *e = &B.E[k]; e->pose = e_pose[k]; e->point = e_point[k]; e->stereo = !(e_obs[3 * k + 2] < 0); e->level = 0; e->robust = 1;
+        e->obs[0] = e_obs[3 * k]; e->obs[1] = e_obs[3 * k + 1]; e->obs[2] = e->stereo ? e_obs[3 * k + 2] : 0; e->info = e_info[k];
+    }
+    memset(e_erase, 0, ne);
+    if (stop_flag && *stop_flag) goto done;                                   /* Optimizer.cc:655-657 */
+    { const int it1 = ba_optimize(&B, 5, trace); if (iters_out) iters_out[0] = it1; }
+    if (!(stop_flag && *stop_flag)) {                                         /* :662-707 */
+        for (int k = 0; k < ne; k++) {
+            bedge *e = &B.E[k];
+            double p[3]; se3_map(&B.T[e->pose], &B.X[3 * e->point], p);
+            if (bedge_chi2(e) > (e->stereo ? 7.815 : 5.991) || !(p[2] > 0.0)) e->level = 1;
+            e->robust = 0;
+        }
+        const int it2 = ba_optimize(&B, 10, trace ? trace + 45 : NULL); if (iters_out) iters_out[1] = it2;
+    }
+    for (int k = 0; k < ne; k++) {                                            /* :709-742 */
+        bedge *e = &B.E[k];
+        double p[3]; se3_map(&B.T[e->pose], &B.X[3 * e->point], p);
+        if (bedge_chi2(e) > (e->stereo ? 7.815 : 5.991) || !(p[2] > 0.0)) e_erase[k] = 1;
+    }
+    for (int i = 0; i < np; i++) if (pose_fixed[i] != 1) se3_to_cv(&B.T[i], poses + 16 * i);   /* :762-768: every LOCAL KF is rewritten (pose_fixed 2 = local KF with mnId 0: fixed vertex, still rewritten) */
+    for (int i = 0; i < 3 * nl; i++) points[i] = (float)B.X[i];                                  /* :771-777 */
+done:
+    free(B.T); free(B.X); free(B.hidx); free(B.E);
+    return 0;
+}

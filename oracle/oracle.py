@@ -201,3 +201,18 @@ def pose_optimization(frame, cam, inv_level_sigma2, want_trace=False):
     if want_trace:
         return int(r), T.reshape(4, 4), out[:n], trace.reshape(4, 11, 3), tn
     return int(r), T.reshape(4, 4), out[:n]
+
+
+# ---- local bundle adjustment (oracle/localba_oracle.c) -----------------------------------------
+def local_ba(problem, cam, stop_flag=None):
+    """Optimizer::LocalBundleAdjustment restatement on the flattened graph.  Returns (poses[np,4,4], points[nl,3], erase[ne], trace[2,15,3], iters[2])."""
+    poses = np.ascontiguousarray(problem['poses'], 'f4').reshape(-1, 16).copy(); fixed = np.ascontiguousarray(problem['pose_fixed'], np.uint8)
+    pts = np.ascontiguousarray(problem['points'], 'f4').copy()
+    ep = np.ascontiguousarray(problem['edge_pose'], 'i4'); el = np.ascontiguousarray(problem['edge_point'], 'i4')
+    eo = np.ascontiguousarray(problem['edge_obs'], 'f4'); ei = np.ascontiguousarray(problem['edge_info'], 'f4')
+    erase = np.zeros(len(ep), np.uint8); trace = np.zeros(2 * 15 * 3, 'f8'); iters = np.zeros(2, 'i4')
+    st = None if stop_flag is None else _p(np.ascontiguousarray(stop_flag, 'i4'))
+    lib().orc_local_ba(C.c_int(len(poses)), _p(poses), _p(fixed), C.c_int(len(pts)), _p(pts), C.c_int(len(ep)), _p(ep), _p(el), _p(eo), _p(ei),
+                       C.c_float(cam['fx']), C.c_float(cam['fy']), C.c_float(cam['cx']), C.c_float(cam['cy']), C.c_float(cam['bf']), st,
+                       _p(erase), _p(trace), _p(iters))
+    return poses.reshape(-1, 4, 4), pts, erase, trace.reshape(2, 15, 3), iters

@@ -15,6 +15,16 @@ class Camera(C.Structure):
                 ('min_x', C.c_float), ('max_x', C.c_float), ('min_y', C.c_float), ('max_y', C.c_float)]
 
 
+class BaProblem(C.Structure):
+    _fields_ = [('n_poses', C.c_int32), ('n_points', C.c_int32), ('n_edges', C.c_int32), ('poses', C.c_void_p), ('pose_fixed', C.c_void_p),
+                ('points', C.c_void_p), ('edge_pose', C.c_void_p), ('edge_point', C.c_void_p), ('edge_obs', C.c_void_p), ('edge_info', C.c_void_p)]
+
+
+class BaStats(C.Structure):
+    _fields_ = [('iterations_first', C.c_int32), ('iterations_second', C.c_int32), ('free_poses', C.c_int32), ('reserved', C.c_int32),
+                ('chi2_first', C.c_double), ('chi2_second', C.c_double)]
+
+
 class OrbConfig(C.Structure):
     _fields_ = [('nfeatures', C.c_int32), ('scale_factor', C.c_float), ('nlevels', C.c_int32),
                 ('ini_th_fast', C.c_int32), ('min_th_fast', C.c_int32), ('width', C.c_int32),
@@ -31,6 +41,7 @@ SYMBOLS = [
     'sgx_match_project_frame_batch_dev', 'sgx_match_project_frame',
     'sgx_frame_stereo_from_rgbd_batch_dev', 'sgx_frame_unproject_batch_dev',
     'sgx_pose_optimization_batch_dev', 'sgx_pose_optimization', 'sgx_frame_motion_model_batch_dev',
+    'sgx_local_bundle_adjustment',
 ]
 
 
@@ -81,6 +92,7 @@ class SgxLib:
         d.sgx_pose_optimization_batch_dev.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, C.POINTER(Camera), vp, vp, vp, vp]
         d.sgx_pose_optimization.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.c_int, C.POINTER(Camera), vp, vp, vp]
         d.sgx_frame_motion_model_batch_dev.argtypes = [C.c_int, vp, vp, vp, vp, vp]
+        d.sgx_local_bundle_adjustment.argtypes = [C.POINTER(BaProblem), C.POINTER(Camera), vp, vp, C.POINTER(BaStats)]
 
     def version(self):
         return self.dll.sgx_version().decode()

@@ -1,0 +1,454 @@
+// sgx_ba_kernels.h — HIP kernels for Optimizer::LocalBundleAdjustment (fp64): edge errors, J^T J / J^T r block
+// accumulation, Schur complement on the 3x3 landmark blocks, dense LDL^T of the reduced camera system,
+// landmark back-substitution, manifold update.  Phase style (sgx_rt.h).
+// Reference behaviour: src/sg-slam/src/Optimizer.cc:453-778 and vendored g2o (G = src/sg-slam/Thirdparty/g2o/g2o):
+// block_solver.hpp:354-604, base_binary_edge.hpp:55-120, types_six_dof_expmap.{h,cpp}; CPU restatement: oracle/localba_oracle.c.
+#pragma once
+#include "sgx_rt.h"
+#include "sgx_types.h"
+#include "sgx_se3.h"                 // SgxSE3 helpers (SE3Quat restatement), sgx_huber, sgx_po_chi2
+
+#define SGX_BA_THREADS 256
+#define SGX_BA_MAX_DENSE 1536        /* largest reduced camera system (6 * free poses) the single-workgroup LDL^T handles */
+
+// edge record: pose index, point index, flags (bit0 stereo, bit1 level==1, bit2 Huber on)
+struct SgxBaEdge { int pose, point, flags; float obs[3]; float info; };
+
+// EdgeSE3ProjectXYZ / EdgeStereoSE3ProjectXYZ::computeError (types_six_dof_expmap.h:90-94,122-126; .cpp:141-157): stereo invz is a float
+SGX_DEV void sgx_ba_edge_error(const SgxSE3 &T, const double *X, const SgxBaEdge &e, double fx, double fy, double cx, double cy, double bf, double err[3])
+{
+    double p[3]; sgx_se3_map(T, X, p);
+    if (!(e.flags & 1)) { err[0] = (double)e.obs[0] - (p[0] / p[2] * fx + cx); err[1] = (double)e.obs[1] - (p[1] / p[2] * fy + cy); err[2] = 0; }
+    else {
+        const float invz = (float)(1.0 / p[2]);
+        const double r0 = p[0] * invz * fx + cx, r1 = p[1] * invz * fy + cy, r2 = r0 - bf * invz;
+        err[0] = (double)e.obs[0] - r0; err[1] = (double)e.obs[1] - r1; err[2] = (double)e.obs[2] - r2;
+    }
+}
+
+// k_ba_errors: computeActiveErrors + activeRobustChi2 (sparse_optimizer.cpp:61-114).  Per-block partial sums in
+// partial[blockIdx.x] (summed in block order by the host: deterministic).
+SGX_KERNEL(SGX_BA_THREADS) k_ba_errors(int ne, const SgxBaEdge *E, const SgxSE3 *T, const double *X, SgxCam cam, double dMono, double dStereo,
+                                       double *err, double *partial)
+{
+    SGX_LDS double red[SGX_BA_THREADS];
+    SGX_THREADS_BEGIN(tid)
+    const int k = (int)blockIdx.x * SGX_BA_THREADS + tid;
+    double chi = 0;
+    if (k < ne) {
+        const SgxBaEdge e = E[k];
+        if (!(e.flags & 2)) {
+            double er[3];
+            sgx_ba_edge_error(T[e.pose], X + 3 * (size_t)e.point, e, cam.fx, cam.fy, cam.cx, cam.cy, cam.bf, er);
+            err[3 * (size_t)k] = er[0]; err[3 * (size_t)k + 1] = er[1]; err[3 * (size_t)k + 2] = er[2];
+            const double c2 = sgx_po_chi2(er, (double)e.info, e.flags & 1);
+            if (e.flags & 4) { double r0, r1; sgx_huber(c2, (e.flags & 1) ? dStereo : dMono, &r0, &r1); chi = r0; } else chi = c2;
+        }
+    }
+    red[tid] = chi;
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    if (tid == 0) { double s = 0; for (int i = 0; i < SGX_BA_THREADS; i++) s += red[i]; partial[blockIdx.x] = s; }
+    SGX_THREADS_END
+}
+
+// Jacobians of one edge at the current estimates (EdgeSE3ProjectXYZ::linearizeOplus .cpp:103-139, stereo :188-234):
+// A = d e / d point (3x3, row 2 zero for mono), Bj = d e / d pose (3x6)
+SGX_DEV void sgx_ba_jacobians(const SgxSE3 &T, const double *X, int stereo, double fx, double fy, double bf, double A[3][3], double Bj[3][6])
+{
+    double p[3]; sgx_se3_map(T, X, p);
+    const double *q = T.q;
+    const double tx = 2 * q[0], ty = 2 * q[1], tz = 2 * q[2];
+    const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
+    const double txx = tx * q[0], txy = ty * q[0], txz = tz * q[0], tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+    const double R[3][3] = { { 1 - (tyy + tzz), txy - twz, txz + twy }, { txy + twz, 1 - (txx + tzz), tyz - twx }, { txz - twy, tyz + twx, 1 - (txx + tyy) } };
+    const double x = p[0], y = p[1], z = p[2], z_2 = z * z;
+    if (stereo) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            A[0][c] = -fx * R[0][c] / z + fx * x * R[2][c] / z_2;
+            A[1][c] = -fy * R[1][c] / z + fy * y * R[2][c] / z_2;
+            A[2][c] = A[0][c] - bf * R[2][c] / z_2;
+        }
+    } else {
+        const double t02 = -x / z * fx, t12 = -y / z * fy;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            A[0][c] = -1. / z * (fx * R[0][c] + 0 * R[1][c] + t02 * R[2][c]);
+            A[1][c] = -1. / z * (0 * R[0][c] + fy * R[1][c] + t12 * R[2][c]);
+            A[2][c] = 0;
+        }
+    }
+    Bj[0][0] = x * y / z_2 * fx; Bj[0][1] = -(1 + (x * x / z_2)) * fx; Bj[0][2] = y / z * fx; Bj[0][3] = -1. / z * fx; Bj[0][4] = 0; Bj[0][5] = x / z_2 * fx;
+    Bj[1][0] = (1 + y * y / z_2) * fy; Bj[1][1] = -x * y / z_2 * fy; Bj[1][2] = -x / z * fy; Bj[1][3] = 0; Bj[1][4] = -1. / z * fy; Bj[1][5] = y / z_2 * fy;
+    if (stereo) { Bj[2][0] = Bj[0][0] - bf * y / z_2; Bj[2][1] = Bj[0][1] + bf * x / z_2; Bj[2][2] = Bj[0][2]; Bj[2][3] = Bj[0][3]; Bj[2][4] = 0; Bj[2][5] = Bj[0][5] - bf / z_2; }
+    else {
+#pragma unroll
+        for (int c = 0; c < 6; c++) Bj[2][c] = 0;
+    }
+}
+
+// k_ba_linearize_points: one thread per landmark walks the landmark's edges (CSR by point, insertion order) and builds
+// Hll (3x3), bl (3) and, per edge with a free pose, the off-diagonal block Hpl_e = B^T W A (6x3)
+// (BaseBinaryEdge::constructQuadraticForm, base_binary_edge.hpp:55-120).
+SGX_KERNEL(SGX_BA_THREADS) k_ba_linearize_points(int nl, const int *pt_start, const int *pt_edges, const SgxBaEdge *E, const SgxSE3 *T, const double *X,
+                                                 const int *hidx, const double *err, SgxCam cam, double dMono, double dStereo,
+                                                 double *Hll, double *bl, double *Hpl, uint8_t *pt_active)
+{
+    SGX_THREADS_BEGIN(tid)
+    const int l = (int)blockIdx.x * SGX_BA_THREADS + tid;
+    if (l < nl) {
+        double H[9], b[3]; int active = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) H[i] = 0;
+        b[0] = b[1] = b[2] = 0;
+        const double Xl[3] = { X[3 * (size_t)l], X[3 * (size_t)l + 1], X[3 * (size_t)l + 2] };
+        for (int q = pt_start[l]; q < pt_start[l + 1]; q++) {
+            const int k = pt_edges[q];
+            const SgxBaEdge e = E[k];
+            double *hpl = Hpl + (size_t)k * 18;
+            if (e.flags & 2) continue;
+            active = 1;
+            const int stereo = e.flags & 1;
+            double A[3][3], Bj[3][6];
+            sgx_ba_jacobians(T[e.pose], Xl, stereo, cam.fx, cam.fy, cam.bf, A, Bj);
+            const double info = (double)e.info;
+            const double er[3] = { err[3 * (size_t)k], err[3 * (size_t)k + 1], stereo ? err[3 * (size_t)k + 2] : 0.0 };
+            double rho1 = 1.0;
+            if (e.flags & 4) { double r0; sgx_huber(sgx_po_chi2(er, info, stereo), stereo ? dStereo : dMono, &r0, &rho1); }
+            const double w = rho1 * info;
+            const double om[3] = { -(info * er[0]) * rho1, -(info * er[1]) * rho1, -(info * er[2]) * rho1 };
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                b[a] += A[0][a] * om[0] + A[1][a] * om[1] + A[2][a] * om[2];
+#pragma unroll
+                for (int c = 0; c < 3; c++) H[3 * a + c] += A[0][a] * w * A[0][c] + A[1][a] * w * A[1][c] + A[2][a] * w * A[2][c];
+            }
+            if (hidx[e.pose] >= 0) {
+#pragma unroll
+                for (int a = 0; a < 6; a++) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) hpl[3 * a + c] = Bj[0][a] * w * A[0][c] + Bj[1][a] * w * A[1][c] + Bj[2][a] * w * A[2][c];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 9; i++) Hll[(size_t)l * 9 + i] = H[i];
+        bl[3 * (size_t)l] = b[0]; bl[3 * (size_t)l + 1] = b[1]; bl[3 * (size_t)l + 2] = b[2];
+        pt_active[l] = (uint8_t)active;
+    }
+    SGX_THREADS_END
+}
+
+// k_ba_linearize_poses: one workgroup per FREE pose; its threads stride over the pose's edges (CSR by pose), stage the
+// per-edge contributions B^T W B (21 upper entries) and B^T omega_r (6) in registers, then reduce the Jacobian tiles
+// through LDS in a fixed order -> Hpp (6x6) and bp (6).  No atomics: deterministic.
+SGX_KERNEL(SGX_BA_THREADS) k_ba_linearize_poses(int np, const int *free_pose, const int *pose_start, const int *pose_edges, const SgxBaEdge *E, const SgxSE3 *T,
+                                                const double *X, const double *err, SgxCam cam, double dMono, double dStereo, double *Hpp, double *bp)
+{
+    SGX_LDS double part[SGX_BA_THREADS * 27];
+    SGX_LDS double part2[27 * 8];
+    const int hp = (int)blockIdx.x;
+    const int pose = free_pose[hp];
+    SGX_THREADS_BEGIN(tid)
+    double acc[27];
+#pragma unroll
+    for (int i = 0; i < 27; i++) acc[i] = 0;
+    const SgxSE3 Tp = T[pose];
+    for (int q = pose_start[pose] + tid; q < pose_start[pose + 1]; q += SGX_BA_THREADS) {
+        const int k = pose_edges[q];
+        const SgxBaEdge e = E[k];
+        if (e.flags & 2) continue;
+        const int stereo = e.flags & 1;
+        const double Xl[3] = { X[3 * (size_t)e.point], X[3 * (size_t)e.point + 1], X[3 * (size_t)e.point + 2] };
+        double A[3][3], Bj[3][6];
+        sgx_ba_jacobians(Tp, Xl, stereo, cam.fx, cam.fy, cam.bf, A, Bj);
+        const double info = (double)e.info;
+        const double er[3] = { err[3 * (size_t)k], err[3 * (size_t)k + 1], stereo ? err[3 * (size_t)k + 2] : 0.0 };
+        double rho1 = 1.0;
+        if (e.flags & 4) { double r0; sgx_huber(sgx_po_chi2(er, info, stereo), stereo ? dStereo : dMono, &r0, &rho1); }
+        const double w = rho1 * info;
+        const double om[3] = { -(info * er[0]) * rho1, -(info * er[1]) * rho1, -(info * er[2]) * rho1 };
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+            acc[21 + a] += Bj[0][a] * om[0] + Bj[1][a] * om[1] + Bj[2][a] * om[2];
+#pragma unroll
+            for (int c = 0; c < 6; c++) if (c >= a) acc[a * 6 - (a * (a - 1)) / 2 + (c - a)] += Bj[0][a] * w * Bj[0][c] + Bj[1][a] * w * Bj[1][c] + Bj[2][a] * w * Bj[2][c];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 27; i++) part[tid * 27 + i] = acc[i];
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    if (tid < 27 * 8) { const int c = tid >> 3, j = tid & 7; double s = 0; for (int l = 0; l < 32; l++) s += part[(j * 32 + l) * 27 + c]; part2[c * 8 + j] = s; }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    if (tid < 27) {
+        double s = 0; for (int l = 0; l < 8; l++) s += part2[tid * 8 + l];
+        if (tid >= 21) bp[6 * (size_t)hp + (tid - 21)] = s;
+        else {      // unpack upper-triangular index -> (a, c)
+            int a = 0, rem = tid; while (rem >= 6 - a) { rem -= 6 - a; a++; }
+            const int c = a + rem;
+            Hpp[(size_t)hp * 36 + 6 * a + c] = s; Hpp[(size_t)hp * 36 + 6 * c + a] = s;
+        }
+    }
+    SGX_THREADS_END
+}
+
+// k_ba_schur_init: S = blockdiag(Hpp) + lambda*I (setLambda block_solver.hpp:564-589, then "_Hschur = _Hpp" :372-373), coef = 0
+SGX_KERNEL(SGX_BA_THREADS) k_ba_schur_init(int nf, const double *Hpp, double lambda, double *S, double *coef)
+{
+    SGX_THREADS_BEGIN(tid)
+    const int NP = 6 * nf;
+    const size_t total = (size_t)NP * NP;
+    for (size_t i = (size_t)blockIdx.x * SGX_BA_THREADS + tid; i < total; i += (size_t)gridDim.x * SGX_BA_THREADS) {
+        const int r = (int)(i / NP), c = (int)(i % NP);
+        double v = 0;
+        if (r / 6 == c / 6) v = Hpp[(size_t)(r / 6) * 36 + 6 * (r % 6) + (c % 6)] + (r == c ? lambda : 0.0);
+        S[i] = v;
+    }
+    for (int i = (int)blockIdx.x * SGX_BA_THREADS + tid; i < NP; i += (int)gridDim.x * SGX_BA_THREADS) coef[i] = 0;
+    SGX_THREADS_END
+}
+
+// k_ba_schur: one thread per landmark (block_solver.hpp:380-433): Dinv = (Hll + lambda I)^-1 (closed form, Eigen Matrix3d::inverse),
+// db = Dinv bl, and for every pair of the landmark's edges with free poses: S(i1,i2) -= Hpl_1 Dinv Hpl_2^T, coef(i1) += Hpl_1 db.
+// fp64 atomics into the reduced system (several landmarks touch the same pose pair; summation order differs from the
+// reference's by rounding only).
+SGX_KERNEL(SGX_BA_THREADS) k_ba_schur(int nl, int nf, const int *pt_start, const int *pt_edges, const SgxBaEdge *E, const int *hidx, const uint8_t *pt_active,
+                                      const double *Hll, const double *bl, const double *Hpl, double lambda, double *Dinv, double *S, double *coef)
+{
+    SGX_THREADS_BEGIN(tid)
+    const int l = (int)blockIdx.x * SGX_BA_THREADS + tid;
+    if (l < nl) {
+        double Di[9];
+        if (!pt_active[l]) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) Di[i] = 0;
+        } else {
+            double M[9];
+#pragma unroll
+            for (int i = 0; i < 9; i++) M[i] = Hll[(size_t)l * 9 + i];
+            M[0] += lambda; M[4] += lambda; M[8] += lambda;
+            const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
+            const double det = M[0] * c00 + M[1] * c01 + M[2] * c02, id = 1.0 / det;
+            Di[0] = c00 * id; Di[1] = (M[2] * M[7] - M[1] * M[8]) * id; Di[2] = (M[1] * M[5] - M[2] * M[4]) * id;
+            Di[3] = c01 * id; Di[4] = (M[0] * M[8] - M[2] * M[6]) * id; Di[5] = (M[2] * M[3] - M[0] * M[5]) * id;
+            Di[6] = c02 * id; Di[7] = (M[1] * M[6] - M[0] * M[7]) * id; Di[8] = (M[0] * M[4] - M[1] * M[3]) * id;
+        }
+#pragma unroll
+        for (int i = 0; i < 9; i++) Dinv[(size_t)l * 9 + i] = Di[i];
+        if (pt_active[l]) {
+            const int NP = 6 * nf;
+            const double b0 = bl[3 * (size_t)l], b1 = bl[3 * (size_t)l + 1], b2 = bl[3 * (size_t)l + 2];
+            const double db[3] = { Di[0] * b0 + Di[1] * b1 + Di[2] * b2, Di[3] * b0 + Di[4] * b1 + Di[5] * b2, Di[6] * b0 + Di[7] * b1 + Di[8] * b2 };
+            for (int q1 = pt_start[l]; q1 < pt_start[l + 1]; q1++) {
+                const int k1 = pt_edges[q1];
+                const SgxBaEdge e1 = E[k1];
+                const int i1 = hidx[e1.pose];
+                if ((e1.flags & 2) || i1 < 0) continue;
+                const double *B1 = Hpl + (size_t)k1 * 18;
+                double BD[18];
+#pragma unroll
+                for (int a = 0; a < 6; a++) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) BD[3 * a + c] = B1[3 * a] * Di[c] + B1[3 * a + 1] * Di[3 + c] + B1[3 * a + 2] * Di[6 + c];
+                    sgx_atomic_add(&coef[6 * i1 + a], B1[3 * a] * db[0] + B1[3 * a + 1] * db[1] + B1[3 * a + 2] * db[2]);
+                }
+                for (int q2 = pt_start[l]; q2 < pt_start[l + 1]; q2++) {
+                    const int k2 = pt_edges[q2];
+                    const SgxBaEdge e2 = E[k2];
+                    const int i2 = hidx[e2.pose];
+                    if ((e2.flags & 2) || i2 < 0) continue;
+                    const double *B2 = Hpl + (size_t)k2 * 18;
+#pragma unroll
+                    for (int a = 0; a < 6; a++) {
+#pragma unroll
+                        for (int c = 0; c < 6; c++)
+                            sgx_atomic_add(&S[(size_t)(6 * i1 + a) * NP + 6 * i2 + c], -(BD[3 * a] * B2[3 * c] + BD[3 * a + 1] * B2[3 * c + 1] + BD[3 * a + 2] * B2[3 * c + 2]));
+                    }
+                }
+            }
+        }
+    }
+    SGX_THREADS_END
+}
+
+// k_ba_solve_dense: reduced camera system S xp = bp - coef by LDL^T (right-looking, in place in global memory) in ONE
+// 1024-thread workgroup; ok = 0 when a pivot is not positive (the LM step is then rejected, levenberg.cpp:126-127).
+// The reference uses Eigen SimplicialLDLT (linear_solver_eigen.h:94-124); the solution is unique.
+SGX_KERNEL(1024) k_ba_solve_dense(int n, double *S, const double *bp, const double *coef, double *x, double *dwork, int *ok)
+{
+    SGX_LDS int s_ok;
+    const int NT = (int)blockDim.x;
+    SGX_THREADS_BEGIN(tid)
+    if (tid == 0) s_ok = 1;
+    for (int i = tid; i < n; i += NT) x[i] = bp[i] - coef[i];
+    SGX_THREADS_END
+    SGX_SYNC();
+    for (int j = 0; j < n; j++) {
+        const double d = S[(size_t)j * n + j];
+        if (!(d > 0)) { SGX_THREADS_BEGIN(tid) if (tid == 0) s_ok = 0; SGX_THREADS_END SGX_SYNC(); break; }
+        // column j of L (stored below the diagonal), keep the unscaled column in dwork for the rank-1 update
+        SGX_THREADS_BEGIN(tid)
+        for (int i = j + 1 + tid; i < n; i += NT) { const double v = S[(size_t)i * n + j]; dwork[i] = v; S[(size_t)i * n + j] = v / d; }
+        if (tid == 0) dwork[j] = d;
+        SGX_THREADS_END
+        SGX_SYNC();
+        // trailing update of the lower triangle: S[i][k] -= L[i][j] * d * L[k][j] = dwork[i] * S[k][j]
+        SGX_THREADS_BEGIN(tid)
+        const int m = n - j - 1;
+        for (int t = tid; t < m * m; t += NT) {
+            const int i = j + 1 + t / m, k = j + 1 + t % m;
+            if (k <= i) S[(size_t)i * n + k] -= dwork[i] * S[(size_t)k * n + j];
+        }
+        SGX_THREADS_END
+        SGX_SYNC();
+    }
+    if (s_ok) {
+        // forward: L y = b (column-oriented so each step is parallel over rows)
+        for (int j = 0; j < n; j++) {
+            SGX_THREADS_BEGIN(tid)
+            const double yj = x[j];
+            for (int i = j + 1 + tid; i < n; i += NT) x[i] -= S[(size_t)i * n + j] * yj;
+            SGX_THREADS_END
+            SGX_SYNC();
+        }
+        SGX_THREADS_BEGIN(tid)
+        for (int i = tid; i < n; i += NT) x[i] /= S[(size_t)i * n + i];
+        SGX_THREADS_END
+        SGX_SYNC();
+        // backward: L^T x = y
+        for (int j = n - 1; j >= 0; j--) {
+            SGX_THREADS_BEGIN(tid)
+            const double xj = x[j];
+            for (int i = tid; i < j; i += NT) x[i] -= S[(size_t)j * n + i] * xj;
+            SGX_THREADS_END
+            SGX_SYNC();
+        }
+    }
+    SGX_THREADS_BEGIN(tid)
+    if (tid == 0) *ok = s_ok;
+    SGX_THREADS_END
+}
+
+// k_ba_backsub: xl = Dinv (bl - Hpl^T xp) per landmark (block_solver.hpp:461-481)
+SGX_KERNEL(SGX_BA_THREADS) k_ba_backsub(int nl, const int *pt_start, const int *pt_edges, const SgxBaEdge *E, const int *hidx, const uint8_t *pt_active,
+                                        const double *bl, const double *Hpl, const double *Dinv, const double *xp, double *xl)
+{
+    SGX_THREADS_BEGIN(tid)
+    const int l = (int)blockIdx.x * SGX_BA_THREADS + tid;
+    if (l < nl) {
+        double c[3] = { bl[3 * (size_t)l], bl[3 * (size_t)l + 1], bl[3 * (size_t)l + 2] };
+        for (int q = pt_start[l]; q < pt_start[l + 1]; q++) {
+            const int k = pt_edges[q];
+            const SgxBaEdge e = E[k];
+            const int hp = hidx[e.pose];
+            if ((e.flags & 2) || hp < 0) continue;
+            const double *Bk = Hpl + (size_t)k * 18;
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) {
+                double s = 0;
+#pragma unroll
+                for (int a = 0; a < 6; a++) s += Bk[3 * a + cc] * xp[6 * hp + a];
+                c[cc] -= s;
+            }
+        }
+        const double *Di = Dinv + (size_t)l * 9;
+#pragma unroll
+        for (int a = 0; a < 3; a++) xl[3 * (size_t)l + a] = pt_active[l] ? Di[3 * a] * c[0] + Di[3 * a + 1] * c[1] + Di[3 * a + 2] * c[2] : 0.0;
+    }
+    SGX_THREADS_END
+}
+
+// k_ba_update: push (backup) + oplus: T <- exp(xp) T for free poses (types_six_dof_expmap.h:73-76), X += xl (types_sba.h:52-56);
+// also the per-block partial sums of computeScale (levenberg.cpp:182-189): sum x (lambda x + b)
+SGX_KERNEL(SGX_BA_THREADS) k_ba_update(int np, int nl, const int *hidx, const uint8_t *pt_active, const double *xp, const double *xl, const double *bp, const double *bl,
+                                       double lambda, SgxSE3 *T, double *X, SgxSE3 *Tb, double *Xb, double *partial)
+{
+    SGX_LDS double red[SGX_BA_THREADS];
+    SGX_THREADS_BEGIN(tid)
+    const int i = (int)blockIdx.x * SGX_BA_THREADS + tid;
+    double sc = 0;
+    if (i < np) {
+        Tb[i] = T[i];
+        const int hp = hidx[i];
+        if (hp >= 0) {
+            double u[6];
+#pragma unroll
+            for (int a = 0; a < 6; a++) { u[a] = xp[6 * hp + a]; sc += u[a] * (lambda * u[a] + bp[6 * hp + a]); }
+            SgxSE3 ex, up; sgx_se3_exp(u, ex); sgx_se3_mul(ex, T[i], up); T[i] = up;
+        }
+    }
+    if (i < nl) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const double v = X[3 * (size_t)i + a];
+            Xb[3 * (size_t)i + a] = v;
+            if (pt_active[i]) { const double d = xl[3 * (size_t)i + a]; X[3 * (size_t)i + a] = v + d; sc += d * (lambda * d + bl[3 * (size_t)i + a]); }
+        }
+    }
+    red[tid] = sc;
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    if (tid == 0) { double s = 0; for (int k = 0; k < SGX_BA_THREADS; k++) s += red[k]; partial[blockIdx.x] = s; }
+    SGX_THREADS_END
+}
+
+// k_ba_classify: chi2 > th or depth <= 0 per edge (Optimizer.cc:672-702, :713-742) from the edge's CURRENT stored error
+// (errors of excluded / rejected-trial edges are deliberately stale, as in the reference); mode 0: set level + drop Huber, mode 1: erase flags
+SGX_KERNEL(SGX_BA_THREADS) k_ba_classify(int ne, SgxBaEdge *E, const SgxSE3 *T, const double *X, const double *err, int mode, uint8_t *erase)
+{
+    SGX_THREADS_BEGIN(tid)
+    const int k = (int)blockIdx.x * SGX_BA_THREADS + tid;
+    if (k < ne) {
+        SgxBaEdge e = E[k];
+        const int stereo = e.flags & 1;
+        const double er[3] = { err[3 * (size_t)k], err[3 * (size_t)k + 1], stereo ? err[3 * (size_t)k + 2] : 0.0 };
+        const double c2 = sgx_po_chi2(er, (double)e.info, stereo);
+        const double Xl[3] = { X[3 * (size_t)e.point], X[3 * (size_t)e.point + 1], X[3 * (size_t)e.point + 2] };
+        double p[3]; sgx_se3_map(T[e.pose], Xl, p);
+        const bool bad = c2 > (stereo ? 7.815 : 5.991) || !(p[2] > 0.0);
+        if (mode == 0) { if (bad) e.flags |= 2; e.flags &= ~4; E[k].flags = e.flags; }
+        else erase[k] = bad ? 1 : 0;
+    }
+    SGX_THREADS_END
+}
+
+// float 4x4 <-> SE3Quat at the boundary (Converter.cc:37-71)
+SGX_KERNEL(SGX_BA_THREADS) k_ba_poses_in(int np, const float *Tcw, SgxSE3 *T)
+{
+    SGX_THREADS_BEGIN(tid)
+    const int i = (int)blockIdx.x * SGX_BA_THREADS + tid;
+    if (i < np) { SgxSE3 s; sgx_se3_from_cv(Tcw + 16 * (size_t)i, s); T[i] = s; }
+    SGX_THREADS_END
+}
+SGX_KERNEL(SGX_BA_THREADS) k_ba_poses_out(int np, const uint8_t *fixed, const SgxSE3 *T, float *Tcw)
+{
+    SGX_THREADS_BEGIN(tid)
+    const int i = (int)blockIdx.x * SGX_BA_THREADS + tid;
+    if (i < np && fixed[i] != 1) { float o[16]; sgx_se3_to_cv(T[i], o); for (int a = 0; a < 16; a++) Tcw[16 * (size_t)i + a] = o[a]; }
+    SGX_THREADS_END
+}
+
+// k_ba_maxdiag: per-block max |diag| over the free poses' Hpp blocks and the active landmarks' Hll blocks
+// (computeLambdaInit, levenberg.cpp:166-180)
+SGX_KERNEL(SGX_BA_THREADS) k_ba_maxdiag(int nf, int nl, const double *Hpp, const double *Hll, const uint8_t *pt_active, double *partial)
+{
+    SGX_LDS double red[SGX_BA_THREADS];
+    SGX_THREADS_BEGIN(tid)
+    const int i = (int)blockIdx.x * SGX_BA_THREADS + tid;
+    double m = 0;
+    if (i < nf) { for (int j = 0; j < 6; j++) m = fmax(m, fabs(Hpp[(size_t)i * 36 + 7 * j])); }
+    if (i < nl && pt_active[i]) { for (int j = 0; j < 3; j++) m = fmax(m, fabs(Hll[(size_t)i * 9 + 4 * j])); }
+    red[tid] = m;
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    if (tid == 0) { double s = 0; for (int k = 0; k < SGX_BA_THREADS; k++) s = fmax(s, red[k]); partial[blockIdx.x] = s; }
+    SGX_THREADS_END
+}

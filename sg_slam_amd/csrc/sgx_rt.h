@@ -64,6 +64,9 @@ static inline hipError_t hipFree(void *p) { free(p); return 0; }
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, sgx_stream_t) { memmove(d, s, n); return 0; }
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, sgx_stream_t) { memset(d, v, n); return 0; }
 static inline hipError_t hipStreamSynchronize(sgx_stream_t) { return 0; }
+static inline hipError_t hipDeviceSynchronize() { return 0; }
+static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int) { memmove(d, s, n); return 0; }
+static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return 0; }
 static inline hipError_t hipGetLastError() { return 0; }
 static inline const char *hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipMemcpyToSymbolEmu(void *d, const void *s, size_t n) { memcpy(d, s, n); return 0; }

@@ -6,7 +6,7 @@ positions per keypoint), Tcw (4x4 f32).  PoseOptimization updates frame['Tcw'] a
 in place and returns the inlier count, like the reference mutates pFrame."""
 import ctypes as C
 import numpy as np
-from .capi import _vp
+from .capi import _vp, BaProblem, BaStats
 from .matcher import camera_struct
 from ._lib import load
 
@@ -27,3 +27,23 @@ class Optimizer:
         frame['Tcw'] = T.reshape(4, 4)
         frame['outlier'] = out[:n]
         return int(ninl[0])
+
+    @staticmethod
+    def LocalBundleAdjustment(problem, cam, stop_flag=None, lib=None):
+        """Optimizer::LocalBundleAdjustment on a flattened local graph (see include/sgx.h sgx_ba_problem).
+        problem: dict(poses[np,4,4] f32, pose_fixed[np] u8, points[nl,3] f32, edge_pose, edge_point [ne] i4,
+        edge_obs[ne,3] f32, edge_info[ne] f32).  Updates problem['poses'] / ['points'] in place (like the reference
+        mutates KeyFrames / MapPoints) and returns (erase[ne] u8, stats)."""
+        lib = lib if lib is not None else load()
+        poses = np.ascontiguousarray(problem['poses'], 'f4').reshape(-1, 16).copy(); fixed = np.ascontiguousarray(problem['pose_fixed'], np.uint8)
+        pts = np.ascontiguousarray(problem['points'], 'f4').copy()
+        ep = np.ascontiguousarray(problem['edge_pose'], 'i4'); el = np.ascontiguousarray(problem['edge_point'], 'i4')
+        eo = np.ascontiguousarray(problem['edge_obs'], 'f4'); ei = np.ascontiguousarray(problem['edge_info'], 'f4')
+        P = BaProblem(len(poses), len(pts), len(ep), poses.ctypes.data, fixed.ctypes.data, pts.ctypes.data, ep.ctypes.data, el.ctypes.data,
+                      eo.ctypes.data, ei.ctypes.data)
+        erase = np.zeros(len(ep), np.uint8); st = BaStats()
+        cs = camera_struct(cam)
+        stop = None if stop_flag is None else _vp(stop_flag)
+        lib.check(lib.dll.sgx_local_bundle_adjustment(C.byref(P), C.byref(cs), stop, _vp(erase), C.byref(st)), 'sgx_local_bundle_adjustment')
+        problem['poses'] = poses.reshape(-1, 4, 4); problem['points'] = pts
+        return erase, dict(iterations=(st.iterations_first, st.iterations_second), chi2=(st.chi2_first, st.chi2_second), free_poses=st.free_poses)

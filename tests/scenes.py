@@ -72,3 +72,50 @@ def make_pose_problem(orc, n=400, seed=42, outlier_frac=0.2, noise_px=1.0, mono_
     T0 = np.eye(4); T0[:3, :3] = dR @ R; T0[:3, 3] = dR @ t + d[3:]
     frame = dict(keys=keys, uright=ur.astype('f4'), has_mp=has, xw=Xw.astype('f4'), Tcw=T0.astype('f4'))
     return frame, Ttrue, gross
+
+
+def make_ba_problem(orc, n_free=8, n_fixed=5, n_points=400, seed=11, outlier_frac=0.08, noise_px=0.8, mono_frac=0.2, pose_sigma=0.01, point_sigma=0.03):
+    """SURVEY.md §8(d) input 4, LocalBA-sized: keyframes on a short arc looking at a point cloud, every point seen by 3..8
+    keyframes, pixel noise sigma*level scale, gross outliers, initial poses/points perturbed.  poses[0] is the
+    mnId==0 keyframe (pose_fixed 2), then n_free local keyframes (0), then n_fixed fixed cameras (1)."""
+    rng = np.random.RandomState(seed)
+    p = orc.orb_params()
+    npose = 1 + n_free + n_fixed
+    Ts = []
+    for i in range(npose):
+        a = 0.04 * i
+        R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        C = np.array([0.15 * i, 0.02 * np.sin(i), 0.01 * i])
+        T = np.eye(4); T[:3, :3] = R; T[:3, 3] = -R @ C
+        Ts.append(T)
+    Ts = np.stack(Ts)
+    pts = np.stack([rng.uniform(-1.5, 3.0, n_points), rng.uniform(-1.2, 1.2, n_points), rng.uniform(2.0, 6.0, n_points)], 1)
+    fixed = np.array([2] + [0] * n_free + [1] * n_fixed, np.uint8)
+    ep, el, eo, ei = [], [], [], []
+    for l in range(n_points):
+        seen = rng.choice(npose, size=min(rng.randint(3, 9), npose), replace=False)
+        for i in sorted(seen):                      # std::map<KeyFrame*,size_t> order stand-in
+            Xc = Ts[i, :3, :3] @ pts[l] + Ts[i, :3, 3]
+            if Xc[2] < 0.3:
+                continue
+            u = CAM['fx'] * Xc[0] / Xc[2] + CAM['cx']; v = CAM['fy'] * Xc[1] / Xc[2] + CAM['cy']
+            if not (0 < u < 640 and 0 < v < 480):
+                continue
+            octv = rng.randint(0, 8); sig = noise_px * p['scale'][octv]
+            uo = u + rng.randn() * sig; vo = v + rng.randn() * sig
+            ur = uo - CAM['bf'] / Xc[2] + rng.randn() * sig * 0.5
+            if rng.rand() < outlier_frac:
+                uo += rng.uniform(-50, 50); vo += rng.uniform(-50, 50)
+            if rng.rand() < mono_frac:
+                ur = -1.0
+            ep.append(i); el.append(l); eo.append([uo, vo, ur]); ei.append(p['inv_sigma2'][octv])
+    poses0 = Ts.copy()
+    for i in range(npose):
+        if fixed[i] == 0:
+            d = rng.randn(6) * pose_sigma
+            dR = np.eye(3) + np.array([[0, -d[2], d[1]], [d[2], 0, -d[0]], [-d[1], d[0], 0]])
+            uu, _, vv = np.linalg.svd(dR); dR = uu @ vv
+            poses0[i, :3, :3] = dR @ Ts[i, :3, :3]; poses0[i, :3, 3] = dR @ Ts[i, :3, 3] + d[3:]
+    pts0 = pts + rng.randn(*pts.shape) * point_sigma
+    return dict(poses=poses0.astype('f4'), pose_fixed=fixed, points=pts0.astype('f4'), edge_pose=np.array(ep, 'i4'), edge_point=np.array(el, 'i4'),
+                edge_obs=np.array(eo, 'f4'), edge_info=np.array(ei, 'f4')), Ts, pts
