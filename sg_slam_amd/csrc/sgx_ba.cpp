@@ -76,8 +76,19 @@ static int optimize(BA &B, int iterations, int *iters_done, double *final_chi)
             }
             SGX_LAUNCH(k_ba_schur, dim3((B.nl + SGX_BA_THREADS - 1) / SGX_BA_THREADS), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.nl, B.nf, B.pt_start, B.pt_edges, B.E,
                        B.hidx, B.pt_active, B.Hll, B.bl, B.Hpl, lambda, B.Dinv, B.S, B.coef);
-            if (B.NP > 0) {
-                SGX_LAUNCH(k_ba_solve_dense, dim3(1), dim3(1024), (sgx_stream_t)0, B.NP, B.S, B.bp, B.coef, B.xp, B.dwork, B.ok);
+            if (B.NP > 0) {                                          // blocked Cholesky of the reduced camera system
+                const int one = 1;
+                SGX_CHECK_HIP(hipMemcpy(B.ok, &one, 4, hipMemcpyHostToDevice));
+                const int nt = (B.NP + SGX_NB - 1) / SGX_NB;
+                for (int kb = 0; kb < nt; kb++) {
+                    const int k0 = kb * SGX_NB, rem = nt - kb - 1;
+                    SGX_LAUNCH(k_chol_diag, dim3(1), dim3(SGX_NB * SGX_NB / 4), (sgx_stream_t)0, B.NP, k0, B.S, B.ok);
+                    if (rem > 0) {
+                        SGX_LAUNCH(k_chol_panel, dim3(rem), dim3(256), (sgx_stream_t)0, B.NP, k0, B.S, B.ok);
+                        SGX_LAUNCH(k_chol_update, dim3(rem * (rem + 1) / 2), dim3(256), (sgx_stream_t)0, B.NP, k0, B.S, B.ok);
+                    }
+                }
+                SGX_LAUNCH(k_chol_solve, dim3(1), dim3(1024), (sgx_stream_t)0, B.NP, B.S, B.bp, B.coef, B.xp, B.ok);
                 SGX_CHECK_HIP(hipMemcpy(&ok2, B.ok, 4, hipMemcpyDeviceToHost));
             }
             if (ok2)

@@ -9,7 +9,7 @@
 #include "sgx_se3.h"                 // SgxSE3 helpers (SE3Quat restatement), sgx_huber, sgx_po_chi2
 
 #define SGX_BA_THREADS 256
-#define SGX_BA_MAX_DENSE 1536        /* largest reduced camera system (6 * free poses) the single-workgroup LDL^T handles */
+#define SGX_BA_MAX_DENSE 24576       /* largest reduced camera system (6 * free poses) factorised densely (4.8 GB of fp64) */
 
 // edge record: pose index, point index, flags (bit0 stereo, bit1 level==1, bit2 Huber on)
 struct SgxBaEdge { int pose, point, flags; float obs[3]; float info; };
@@ -277,62 +277,139 @@ SGX_KERNEL(SGX_BA_THREADS) k_ba_schur(int nl, int nf, const int *pt_start, const
     SGX_THREADS_END
 }
 
-// k_ba_solve_dense: reduced camera system S xp = bp - coef by LDL^T (right-looking, in place in global memory) in ONE
-// 1024-thread workgroup; ok = 0 when a pivot is not positive (the LM step is then rejected, levenberg.cpp:126-127).
-// The reference uses Eigen SimplicialLDLT (linear_solver_eigen.h:94-124); the solution is unique.
-SGX_KERNEL(1024) k_ba_solve_dense(int n, double *S, const double *bp, const double *coef, double *x, double *dwork, int *ok)
+// ---------------------------------------------------------------------------------------------
+// Reduced camera system  S xp = bp - coef  (S symmetric positive definite, n = 6 * free poses, row-major, full storage).
+// The reference factorises it with Eigen SimplicialLDLT (G/solvers/linear_solver_eigen.h:94-124); the solution is
+// unique, so a blocked right-looking Cholesky (L L^T, 32x32 tiles staged in LDS) is used here:
+//   per panel k:  k_chol_diag (1 workgroup)  ->  k_chol_panel (one workgroup per row tile below)  ->
+//                 k_chol_update (one workgroup per lower-triangular tile pair: A_ij -= L_ik L_jk^T)
+// then k_chol_solve (one workgroup, blocked forward/backward substitution).  *ok is cleared when a pivot is not
+// positive (or NaN): the LM step is then rejected exactly like !isPositive / solve()==false (levenberg.cpp:126-127).
+// ---------------------------------------------------------------------------------------------
+#define SGX_NB 32
+
+SGX_KERNEL(SGX_NB * SGX_NB / 4) k_chol_diag(int n, int k0, double *S, int *ok)
 {
+    SGX_LDS double A[SGX_NB][SGX_NB + 1];
     SGX_LDS int s_ok;
+    const int nb = min(SGX_NB, n - k0);
     const int NT = (int)blockDim.x;
     SGX_THREADS_BEGIN(tid)
     if (tid == 0) s_ok = 1;
+    for (int t = tid; t < nb * nb; t += NT) { const int r = t / nb, c = t % nb; A[r][c] = S[(size_t)(k0 + r) * n + k0 + c]; }
+    SGX_THREADS_END
+    SGX_SYNC();
+    for (int j = 0; j < nb; j++) {
+        const double d = A[j][j];
+        if (!(d > 0)) { SGX_THREADS_BEGIN(tid) if (tid == 0) s_ok = 0; SGX_THREADS_END SGX_SYNC(); break; }
+        const double sd = sqrt(d);
+        SGX_THREADS_BEGIN(tid)
+        for (int i = j + tid; i < nb; i += NT) A[i][j] = A[i][j] / sd;      // includes the diagonal: A[j][j] = sqrt(d)
+        SGX_THREADS_END
+        SGX_SYNC();
+        SGX_THREADS_BEGIN(tid)
+        const int m = nb - j - 1;
+        for (int t = tid; t < m * m; t += NT) { const int i = j + 1 + t / m, c = j + 1 + t % m; if (c <= i) A[i][c] -= A[i][j] * A[c][j]; }
+        SGX_THREADS_END
+        SGX_SYNC();
+    }
+    SGX_THREADS_BEGIN(tid)
+    for (int t = tid; t < nb * nb; t += NT) { const int r = t / nb, c = t % nb; if (c <= r) S[(size_t)(k0 + r) * n + k0 + c] = A[r][c]; }
+    if (tid == 0 && !s_ok) *ok = 0;
+    SGX_THREADS_END
+}
+
+// L_ik = A_ik L_kk^-T for the row tile i = k0/NB + 1 + blockIdx.x
+SGX_KERNEL(256) k_chol_panel(int n, int k0, double *S, const int *ok)
+{
+    SGX_LDS double Lk[SGX_NB][SGX_NB + 1];
+    SGX_LDS double A[SGX_NB][SGX_NB + 1];
+    if (!*ok) return;
+    const int nb = min(SGX_NB, n - k0);
+    const int r0 = k0 + SGX_NB * (1 + (int)blockIdx.x);
+    const int nr = min(SGX_NB, n - r0);
+    const int NT = (int)blockDim.x;
+    SGX_THREADS_BEGIN(tid)
+    for (int t = tid; t < nb * nb; t += NT) { const int r = t / nb, c = t % nb; Lk[r][c] = S[(size_t)(k0 + r) * n + k0 + c]; }
+    for (int t = tid; t < nr * nb; t += NT) { const int r = t / nb, c = t % nb; A[r][c] = S[(size_t)(r0 + r) * n + k0 + c]; }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    if (tid < nr) {                          // one thread per row: x L^T = a  (forward over columns)
+        for (int c = 0; c < nb; c++) {
+            double v = A[tid][c];
+            for (int q = 0; q < c; q++) v -= A[tid][q] * Lk[c][q];
+            A[tid][c] = v / Lk[c][c];
+        }
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    for (int t = tid; t < nr * nb; t += NT) { const int r = t / nb, c = t % nb; S[(size_t)(r0 + r) * n + k0 + c] = A[r][c]; }
+    SGX_THREADS_END
+}
+
+// A_ij -= L_ik L_jk^T for the lower-triangular tile pairs (i >= j) of the trailing matrix; blockIdx.x enumerates pairs
+SGX_KERNEL(256) k_chol_update(int n, int k0, double *S, const int *ok)
+{
+    SGX_LDS double Li[SGX_NB][SGX_NB + 1];
+    SGX_LDS double Lj[SGX_NB][SGX_NB + 1];
+    if (!*ok) return;
+    const int nb = min(SGX_NB, n - k0);
+    // unrank blockIdx.x -> (bi >= bj) within the trailing tiles
+    int bi = 0, rem = (int)blockIdx.x;
+    while (rem > bi) { rem -= bi + 1; bi++; }
+    const int bj = rem;
+    const int r0 = k0 + SGX_NB * (1 + bi), c0 = k0 + SGX_NB * (1 + bj);
+    const int nr = min(SGX_NB, n - r0), nc = min(SGX_NB, n - c0);
+    const int NT = (int)blockDim.x;
+    SGX_THREADS_BEGIN(tid)
+    for (int t = tid; t < nr * nb; t += NT) { const int r = t / nb, c = t % nb; Li[r][c] = S[(size_t)(r0 + r) * n + k0 + c]; }
+    for (int t = tid; t < nc * nb; t += NT) { const int r = t / nb, c = t % nb; Lj[r][c] = S[(size_t)(c0 + r) * n + k0 + c]; }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    for (int t = tid; t < nr * nc; t += NT) {
+        const int r = t / nc, c = t % nc;
+        if (bi == bj && c > r) continue;
+        double s = 0;
+        for (int q = 0; q < nb; q++) s += Li[r][q] * Lj[c][q];
+        S[(size_t)(r0 + r) * n + c0 + c] -= s;
+    }
+    SGX_THREADS_END
+}
+
+// x = (bp - coef); L y = x; L^T x = y — blocked, one 1024-thread workgroup
+SGX_KERNEL(1024) k_chol_solve(int n, const double *S, const double *bp, const double *coef, double *x, const int *ok)
+{
+    if (!*ok) return;
+    const int NT = (int)blockDim.x;
+    SGX_THREADS_BEGIN(tid)
     for (int i = tid; i < n; i += NT) x[i] = bp[i] - coef[i];
     SGX_THREADS_END
     SGX_SYNC();
-    for (int j = 0; j < n; j++) {
-        const double d = S[(size_t)j * n + j];
-        if (!(d > 0)) { SGX_THREADS_BEGIN(tid) if (tid == 0) s_ok = 0; SGX_THREADS_END SGX_SYNC(); break; }
-        // column j of L (stored below the diagonal), keep the unscaled column in dwork for the rank-1 update
+    for (int k0 = 0; k0 < n; k0 += SGX_NB) {
+        const int nb = min(SGX_NB, n - k0);
         SGX_THREADS_BEGIN(tid)
-        for (int i = j + 1 + tid; i < n; i += NT) { const double v = S[(size_t)i * n + j]; dwork[i] = v; S[(size_t)i * n + j] = v / d; }
-        if (tid == 0) dwork[j] = d;
+        if (tid == 0) for (int r = 0; r < nb; r++) { double v = x[k0 + r]; for (int q = 0; q < r; q++) v -= S[(size_t)(k0 + r) * n + k0 + q] * x[k0 + q]; x[k0 + r] = v / S[(size_t)(k0 + r) * n + k0 + r]; }
         SGX_THREADS_END
         SGX_SYNC();
-        // trailing update of the lower triangle: S[i][k] -= L[i][j] * d * L[k][j] = dwork[i] * S[k][j]
         SGX_THREADS_BEGIN(tid)
-        const int m = n - j - 1;
-        for (int t = tid; t < m * m; t += NT) {
-            const int i = j + 1 + t / m, k = j + 1 + t % m;
-            if (k <= i) S[(size_t)i * n + k] -= dwork[i] * S[(size_t)k * n + j];
-        }
+        for (int i = k0 + nb + tid; i < n; i += NT) { double v = x[i]; for (int q = 0; q < nb; q++) v -= S[(size_t)i * n + k0 + q] * x[k0 + q]; x[i] = v; }
         SGX_THREADS_END
         SGX_SYNC();
     }
-    if (s_ok) {
-        // forward: L y = b (column-oriented so each step is parallel over rows)
-        for (int j = 0; j < n; j++) {
-            SGX_THREADS_BEGIN(tid)
-            const double yj = x[j];
-            for (int i = j + 1 + tid; i < n; i += NT) x[i] -= S[(size_t)i * n + j] * yj;
-            SGX_THREADS_END
-            SGX_SYNC();
-        }
+    for (int k0 = ((n - 1) / SGX_NB) * SGX_NB; k0 >= 0; k0 -= SGX_NB) {
+        const int nb = min(SGX_NB, n - k0);
         SGX_THREADS_BEGIN(tid)
-        for (int i = tid; i < n; i += NT) x[i] /= S[(size_t)i * n + i];
+        if (tid == 0) for (int r = nb - 1; r >= 0; r--) { double v = x[k0 + r]; for (int q = r + 1; q < nb; q++) v -= S[(size_t)(k0 + q) * n + k0 + r] * x[k0 + q]; x[k0 + r] = v / S[(size_t)(k0 + r) * n + k0 + r]; }
         SGX_THREADS_END
         SGX_SYNC();
-        // backward: L^T x = y
-        for (int j = n - 1; j >= 0; j--) {
-            SGX_THREADS_BEGIN(tid)
-            const double xj = x[j];
-            for (int i = tid; i < j; i += NT) x[i] -= S[(size_t)j * n + i] * xj;
-            SGX_THREADS_END
-            SGX_SYNC();
-        }
+        SGX_THREADS_BEGIN(tid)
+        for (int i = tid; i < k0; i += NT) { double v = x[i]; for (int q = 0; q < nb; q++) v -= S[(size_t)(k0 + q) * n + i] * x[k0 + q]; x[i] = v; }
+        SGX_THREADS_END
+        SGX_SYNC();
     }
-    SGX_THREADS_BEGIN(tid)
-    if (tid == 0) *ok = s_ok;
-    SGX_THREADS_END
 }
 
 // k_ba_backsub: xl = Dinv (bl - Hpl^T xp) per landmark (block_solver.hpp:461-481)
