@@ -13,11 +13,21 @@
     fprintf(stderr, "sgx: HIP error %d (%s) at %s:%d\n", (int)_e, hipGetErrorString(_e), __FILE__, __LINE__); return SGX_ERR_DEVICE; } } while (0)
 
 namespace {
-struct Dev {
-    std::vector<void *> all;
-    ~Dev() { for (void *p : all) (void)hipFree(p); }
-    template <class T> int alloc(T **p, size_t n) { void *q = nullptr; if (hipMalloc(&q, (n ? n : 1) * sizeof(T)) != hipSuccess) return SGX_ERR_NOMEM; all.push_back(q); *p = (T *)q; return SGX_OK; }
+// One grow-only device arena per process (LocalBundleAdjustment runs on the single LocalMapping thread, LocalMapping.cc:81):
+// avoids ~30 hipMalloc/hipFree pairs per call.  Layout is computed twice: first pass sizes, second pass assigns.
+struct Arena {
+    char *base = nullptr; size_t cap = 0, off = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return SGX_OK;
+        if (base) (void)hipFree(base);
+        base = nullptr; cap = 0;
+        const size_t want = bytes + bytes / 4;
+        if (hipMalloc((void **)&base, want) != hipSuccess) return SGX_ERR_NOMEM;
+        cap = want; return SGX_OK;
+    }
+    template <class T> void take(T **p, size_t n) { off = (off + 255) & ~(size_t)255; if (base) *p = (T *)(base + off); off += (n ? n : 1) * sizeof(T); }
 };
+static Arena g_arena;
 
 struct BA {
     int np, nl, ne, nf, NP;
@@ -26,6 +36,7 @@ struct BA {
     // device
     SgxBaEdge *E; SgxSE3 *T, *Tb; double *X, *Xb, *err, *Hll, *bl, *Hpl, *Hpp, *bp, *S, *coef, *xp, *xl, *Dinv, *dwork, *partial;
     int *pt_start, *pt_edges, *pose_start, *pose_edges, *hidx, *free_pose, *ok; uint8_t *pt_active;
+    double *part_chi, *part_scale;      // device scalars block: [ok | part_scale[nblk_v] | part_chi[nblk_e]] read back with ONE copy per trial
     int nblk_e, nblk_v;
     std::vector<double> hpart;
 };
@@ -44,8 +55,24 @@ static int sum_partials(BA &B, int n, double *out, bool is_max = false)
 
 static int active_chi2(BA &B, double *chi)
 {
-    SGX_LAUNCH(k_ba_errors, dim3(B.nblk_e), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.ne, B.E, B.T, B.X, B.cam, B.dMono, B.dStereo, B.err, B.partial);
-    return sum_partials(B, B.nblk_e, chi);
+    SGX_LAUNCH(k_ba_errors, dim3(B.nblk_e), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.ne, B.E, B.T, B.X, B.cam, B.dMono, B.dStereo, B.err, B.part_chi);
+    B.hpart.resize(B.nblk_e);
+    SGX_CHECK_HIP(hipMemcpy(B.hpart.data(), B.part_chi, sizeof(double) * B.nblk_e, hipMemcpyDeviceToHost));
+    double s = 0; for (int i = 0; i < B.nblk_e; i++) s += B.hpart[i];
+    *chi = s;
+    return SGX_OK;
+}
+
+// after a trial: ok flag, computeScale partials and the new chi2 partials in one device->host copy
+static int read_trial(BA &B, int *ok, double *scale, double *chi)
+{
+    const int nd = 1 + B.nblk_v + B.nblk_e;
+    B.hpart.resize(nd);
+    SGX_CHECK_HIP(hipMemcpy(B.hpart.data(), (const double *)B.ok, sizeof(double) * nd, hipMemcpyDeviceToHost));
+    int okv; memcpy(&okv, &B.hpart[0], 4); *ok = okv;
+    double s = 0; for (int i = 0; i < B.nblk_v; i++) s += B.hpart[1 + i]; *scale = s;
+    double c = 0; for (int i = 0; i < B.nblk_e; i++) c += B.hpart[1 + B.nblk_v + i]; *chi = c;
+    return SGX_OK;
 }
 
 // one optimizer.optimize(iterations) call
@@ -70,6 +97,7 @@ static int optimize(BA &B, int iterations, int *iters_done, double *final_chi)
         double rho = 0; int qmax = 0;
         do {
             int ok2 = 1;
+            { const int one = 1; SGX_CHECK_HIP(hipMemcpyAsync(B.ok, &one, 4, hipMemcpyHostToDevice, 0)); }
             if (B.NP > 0) {
                 const int g = (int)(((size_t)B.NP * B.NP + SGX_BA_THREADS - 1) / SGX_BA_THREADS);
                 SGX_LAUNCH(k_ba_schur_init, dim3(g > 4096 ? 4096 : g), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.nf, B.Hpp, lambda, B.S, B.coef);
@@ -77,8 +105,6 @@ static int optimize(BA &B, int iterations, int *iters_done, double *final_chi)
             SGX_LAUNCH(k_ba_schur, dim3((B.nl + SGX_BA_THREADS - 1) / SGX_BA_THREADS), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.nl, B.nf, B.pt_start, B.pt_edges, B.E,
                        B.hidx, B.pt_active, B.Hll, B.bl, B.Hpl, lambda, B.Dinv, B.S, B.coef);
             if (B.NP > 0) {                                          // blocked Cholesky of the reduced camera system
-                const int one = 1;
-                SGX_CHECK_HIP(hipMemcpy(B.ok, &one, 4, hipMemcpyHostToDevice));
                 const int nt = (B.NP + SGX_NB - 1) / SGX_NB;
                 for (int kb = 0; kb < nt; kb++) {
                     const int k0 = kb * SGX_NB, rem = nt - kb - 1;
@@ -89,16 +115,15 @@ static int optimize(BA &B, int iterations, int *iters_done, double *final_chi)
                     }
                 }
                 SGX_LAUNCH(k_chol_solve, dim3(1), dim3(1024), (sgx_stream_t)0, B.NP, B.S, B.bp, B.coef, B.xp, B.ok);
-                SGX_CHECK_HIP(hipMemcpy(&ok2, B.ok, 4, hipMemcpyDeviceToHost));
             }
-            if (ok2)
-                SGX_LAUNCH(k_ba_backsub, dim3((B.nl + SGX_BA_THREADS - 1) / SGX_BA_THREADS), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.nl, B.pt_start, B.pt_edges, B.E, B.hidx,
-                           B.pt_active, B.bl, B.Hpl, B.Dinv, B.xp, B.xl);
+            // when the factorisation failed, xp/xl keep the previous solution (as g2o's _x does) and the step is rejected below
+            SGX_LAUNCH(k_ba_backsub, dim3((B.nl + SGX_BA_THREADS - 1) / SGX_BA_THREADS), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.nl, B.pt_start, B.pt_edges, B.E, B.hidx,
+                           B.pt_active, B.bl, B.Hpl, B.Dinv, B.xp, B.xl, B.ok);
             // push + update + computeScale
             SGX_LAUNCH(k_ba_update, dim3(B.nblk_v), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.np, B.nl, B.hidx, B.pt_active, B.xp, B.xl, B.bp, B.bl, lambda,
-                       B.T, B.X, B.Tb, B.Xb, B.partial);
-            double scale = 0; rc = sum_partials(B, B.nblk_v, &scale); if (rc != SGX_OK) return rc;
-            rc = active_chi2(B, &tempChi); if (rc != SGX_OK) return rc;
+                       B.T, B.X, B.Tb, B.Xb, B.part_scale);
+            SGX_LAUNCH(k_ba_errors, dim3(B.nblk_e), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.ne, B.E, B.T, B.X, B.cam, B.dMono, B.dStereo, B.err, B.part_chi);
+            double scale = 0; rc = read_trial(B, &ok2, &scale, &tempChi); if (rc != SGX_OK) return rc;
             if (!ok2) tempChi = DBL_MAX;
             rho = currentChi - tempChi;
             scale += 1e-3; rho /= scale;
@@ -154,33 +179,44 @@ extern "C" int sgx_local_bundle_adjustment(const sgx_ba_problem *P, const sgx_ca
       for (int k = 0; k < B.ne; k++) { pt_edges[pt_start[E[k].point] + f1[E[k].point]++] = k; pose_edges[pose_start[E[k].pose] + f2[E[k].pose]++] = k; } }
     std::vector<double> Xd(3 * (size_t)B.nl);
     for (size_t i = 0; i < Xd.size(); i++) Xd[i] = (double)P->points[i];
-    // ---- device state
-    Dev D; float *dTcw = nullptr; uint8_t *dfixed = nullptr, *derase = nullptr;
+    // ---- device state: one arena; the host->device inputs are packed contiguously and uploaded with one copy
+    float *dTcw = nullptr; uint8_t *dfixed = nullptr, *derase = nullptr;
     const int nv = B.np > B.nl ? B.np : B.nl;
     B.nblk_e = (B.ne + SGX_BA_THREADS - 1) / SGX_BA_THREADS; B.nblk_v = (nv + SGX_BA_THREADS - 1) / SGX_BA_THREADS;
-    const int npart = B.nblk_e > B.nblk_v ? B.nblk_e : B.nblk_v;
     int rc = SGX_OK;
-#define A(p, n) if ((rc = D.alloc(&(p), (n))) != SGX_OK) return rc
-    A(B.E, B.ne); A(B.T, B.np); A(B.Tb, B.np); A(B.X, 3 * (size_t)B.nl); A(B.Xb, 3 * (size_t)B.nl); A(B.err, 3 * (size_t)B.ne);
-    A(B.Hll, 9 * (size_t)B.nl); A(B.bl, 3 * (size_t)B.nl); A(B.Hpl, 18 * (size_t)B.ne); A(B.Hpp, 36 * (size_t)B.nf); A(B.bp, B.NP);
-    A(B.S, (size_t)B.NP * B.NP); A(B.coef, B.NP); A(B.xp, B.NP); A(B.xl, 3 * (size_t)B.nl); A(B.Dinv, 9 * (size_t)B.nl); A(B.dwork, B.NP);
-    A(B.partial, npart); A(B.pt_start, B.nl + 1); A(B.pt_edges, B.ne); A(B.pose_start, B.np + 1); A(B.pose_edges, B.ne); A(B.hidx, B.np);
-    A(B.free_pose, B.nf); A(B.ok, 1); A(B.pt_active, B.nl); A(dTcw, 16 * (size_t)B.np); A(dfixed, B.np); A(derase, B.ne);
-#undef A
-    SGX_CHECK_HIP(hipMemcpy(B.E, E.data(), sizeof(SgxBaEdge) * B.ne, hipMemcpyHostToDevice));
-    SGX_CHECK_HIP(hipMemcpy(B.X, Xd.data(), sizeof(double) * Xd.size(), hipMemcpyHostToDevice));
-    SGX_CHECK_HIP(hipMemcpy(B.pt_start, pt_start.data(), 4 * (size_t)(B.nl + 1), hipMemcpyHostToDevice));
-    SGX_CHECK_HIP(hipMemcpy(B.pt_edges, pt_edges.data(), 4 * (size_t)B.ne, hipMemcpyHostToDevice));
-    SGX_CHECK_HIP(hipMemcpy(B.pose_start, pose_start.data(), 4 * (size_t)(B.np + 1), hipMemcpyHostToDevice));
-    SGX_CHECK_HIP(hipMemcpy(B.pose_edges, pose_edges.data(), 4 * (size_t)B.ne, hipMemcpyHostToDevice));
-    SGX_CHECK_HIP(hipMemcpy(B.hidx, hidx.data(), 4 * (size_t)B.np, hipMemcpyHostToDevice));
-    if (B.nf) SGX_CHECK_HIP(hipMemcpy(B.free_pose, free_pose.data(), 4 * (size_t)B.nf, hipMemcpyHostToDevice));
-    SGX_CHECK_HIP(hipMemcpy(dTcw, P->poses, 64 * (size_t)B.np, hipMemcpyHostToDevice));
-    SGX_CHECK_HIP(hipMemcpy(dfixed, P->pose_fixed, B.np, hipMemcpyHostToDevice));
-    SGX_CHECK_HIP(hipMemset(B.xp, 0, sizeof(double) * (B.NP ? B.NP : 1)));
-    SGX_CHECK_HIP(hipMemset(B.xl, 0, sizeof(double) * 3 * (size_t)B.nl));
-    SGX_CHECK_HIP(hipMemset(B.err, 0, sizeof(double) * 3 * (size_t)B.ne));
-    SGX_CHECK_HIP(hipMemset(B.Hpl, 0, sizeof(double) * 18 * (size_t)B.ne));
+    size_t in_bytes = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        Arena &A = g_arena; A.off = 0;
+        char *save = A.base; if (pass == 0) A.base = nullptr;             // sizing pass: no pointers handed out
+        A.take(&B.E, B.ne); A.take(&B.X, 3 * (size_t)B.nl); A.take(&B.pt_start, B.nl + 1); A.take(&B.pt_edges, B.ne);
+        A.take(&B.pose_start, B.np + 1); A.take(&B.pose_edges, B.ne); A.take(&B.hidx, B.np); A.take(&B.free_pose, B.nf);
+        A.take(&dTcw, 16 * (size_t)B.np); A.take(&dfixed, B.np);
+        in_bytes = A.off;
+        A.take(&B.T, B.np); A.take(&B.Tb, B.np); A.take(&B.Xb, 3 * (size_t)B.nl); A.take(&B.err, 3 * (size_t)B.ne);
+        A.take(&B.Hll, 9 * (size_t)B.nl); A.take(&B.bl, 3 * (size_t)B.nl); A.take(&B.Hpl, 18 * (size_t)B.ne); A.take(&B.Hpp, 36 * (size_t)B.nf);
+        A.take(&B.bp, B.NP); A.take(&B.S, (size_t)B.NP * B.NP); A.take(&B.coef, B.NP); A.take(&B.xp, B.NP); A.take(&B.xl, 3 * (size_t)B.nl);
+        A.take(&B.Dinv, 9 * (size_t)B.nl); A.take(&B.dwork, B.NP); A.take(&B.partial, B.nblk_v);
+        { double *blk = nullptr; A.take(&blk, 1 + (size_t)B.nblk_v + B.nblk_e); B.ok = (int *)blk; B.part_scale = blk ? blk + 1 : nullptr; B.part_chi = blk ? blk + 1 + B.nblk_v : nullptr; }
+        A.take(&B.pt_active, B.nl); A.take(&derase, B.ne);
+        const size_t total = A.off;
+        A.base = save;
+        if (pass == 0) { if ((rc = A.reserve(total)) != SGX_OK) return rc; }
+    }
+    {
+        std::vector<char> stage(in_bytes, 0);
+        char *base = g_arena.base;
+        auto put = [&](const void *dst_dev, const void *src, size_t bytes) { memcpy(stage.data() + ((const char *)dst_dev - base), src, bytes); };
+        put(B.E, E.data(), sizeof(SgxBaEdge) * B.ne); put(B.X, Xd.data(), sizeof(double) * Xd.size());
+        put(B.pt_start, pt_start.data(), 4 * (size_t)(B.nl + 1)); put(B.pt_edges, pt_edges.data(), 4 * (size_t)B.ne);
+        put(B.pose_start, pose_start.data(), 4 * (size_t)(B.np + 1)); put(B.pose_edges, pose_edges.data(), 4 * (size_t)B.ne);
+        put(B.hidx, hidx.data(), 4 * (size_t)B.np); if (B.nf) put(B.free_pose, free_pose.data(), 4 * (size_t)B.nf);
+        put(dTcw, P->poses, 64 * (size_t)B.np); put(dfixed, P->pose_fixed, B.np);
+        SGX_CHECK_HIP(hipMemcpy(base, stage.data(), in_bytes, hipMemcpyHostToDevice));
+    }
+    SGX_CHECK_HIP(hipMemsetAsync(B.xp, 0, sizeof(double) * (B.NP ? B.NP : 1), 0));
+    SGX_CHECK_HIP(hipMemsetAsync(B.xl, 0, sizeof(double) * 3 * (size_t)B.nl, 0));
+    SGX_CHECK_HIP(hipMemsetAsync(B.err, 0, sizeof(double) * 3 * (size_t)B.ne, 0));
+    SGX_CHECK_HIP(hipMemsetAsync(B.Hpl, 0, sizeof(double) * 18 * (size_t)B.ne, 0));
     SGX_LAUNCH(k_ba_poses_in, dim3((B.np + SGX_BA_THREADS - 1) / SGX_BA_THREADS), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.np, dTcw, B.T);
 
     int it1 = 0, it2 = 0; double chi1 = 0, chi2 = 0;

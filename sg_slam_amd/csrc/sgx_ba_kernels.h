@@ -414,8 +414,9 @@ SGX_KERNEL(1024) k_chol_solve(int n, const double *S, const double *bp, const do
 
 // k_ba_backsub: xl = Dinv (bl - Hpl^T xp) per landmark (block_solver.hpp:461-481)
 SGX_KERNEL(SGX_BA_THREADS) k_ba_backsub(int nl, const int *pt_start, const int *pt_edges, const SgxBaEdge *E, const int *hidx, const uint8_t *pt_active,
-                                        const double *bl, const double *Hpl, const double *Dinv, const double *xp, double *xl)
+                                        const double *bl, const double *Hpl, const double *Dinv, const double *xp, double *xl, const int *ok)
 {
+    if (!*ok) return;            // failed factorisation: keep the previous xl (g2o returns before the landmark update, block_solver.hpp:455-456)
     SGX_THREADS_BEGIN(tid)
     const int l = (int)blockIdx.x * SGX_BA_THREADS + tid;
     if (l < nl) {
