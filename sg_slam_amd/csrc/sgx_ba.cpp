@@ -36,6 +36,7 @@ struct BA {
     // device
     SgxBaEdge *E; SgxSE3 *T, *Tb; double *X, *Xb, *err, *Hll, *bl, *Hpl, *Hpp, *bp, *S, *coef, *xp, *xl, *Dinv, *dwork, *partial;
     int *pt_start, *pt_edges, *pose_start, *pose_edges, *hidx, *free_pose, *ok; uint8_t *pt_active;
+    SgxBaJob *jobs; double *Linv; long long njobs; size_t jobs_cap;
     double *part_chi, *part_scale;      // device scalars block: [ok | part_scale[nblk_v] | part_chi[nblk_e]] read back with ONE copy per trial
     int nblk_e, nblk_v;
     std::vector<double> hpart;
@@ -75,6 +76,23 @@ static int read_trial(BA &B, int *ok, double *scale, double *chi)
     return SGX_OK;
 }
 
+// Schur job list for the current active edge set: all ordered pairs (k1, k2) of active free-pose edges of one landmark
+static int build_jobs(BA &B, const std::vector<int> &pt_start, const std::vector<int> &pt_edges, const std::vector<SgxBaEdge> &E,
+                      const std::vector<uint8_t> &level1, const std::vector<int> &hidx)
+{
+    std::vector<SgxBaJob> jobs;
+    std::vector<int> act;
+    for (int l = 0; l < B.nl; l++) {
+        act.clear();
+        for (int q = pt_start[l]; q < pt_start[l + 1]; q++) { const int k = pt_edges[q]; if (!level1[k] && hidx[E[k].pose] >= 0) act.push_back(k); }
+        for (int k1 : act) for (int k2 : act) jobs.push_back(SgxBaJob{k1, k2});
+    }
+    B.njobs = (long long)jobs.size();
+    if (jobs.size() > B.jobs_cap) return SGX_ERR_NOMEM;
+    if (!jobs.empty()) SGX_CHECK_HIP(hipMemcpy(B.jobs, jobs.data(), sizeof(SgxBaJob) * jobs.size(), hipMemcpyHostToDevice));
+    return SGX_OK;
+}
+
 // one optimizer.optimize(iterations) call
 static int optimize(BA &B, int iterations, int *iters_done, double *final_chi)
 {
@@ -102,19 +120,25 @@ static int optimize(BA &B, int iterations, int *iters_done, double *final_chi)
                 const int g = (int)(((size_t)B.NP * B.NP + SGX_BA_THREADS - 1) / SGX_BA_THREADS);
                 SGX_LAUNCH(k_ba_schur_init, dim3(g > 4096 ? 4096 : g), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.nf, B.Hpp, lambda, B.S, B.coef);
             }
-            SGX_LAUNCH(k_ba_schur, dim3((B.nl + SGX_BA_THREADS - 1) / SGX_BA_THREADS), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.nl, B.nf, B.pt_start, B.pt_edges, B.E,
-                       B.hidx, B.pt_active, B.Hll, B.bl, B.Hpl, lambda, B.Dinv, B.S, B.coef);
-            if (B.NP > 0) {                                          // blocked Cholesky of the reduced camera system
+            SGX_LAUNCH(k_ba_dinv, dim3((B.nl + SGX_BA_THREADS - 1) / SGX_BA_THREADS), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.nl, B.pt_active, B.Hll, lambda, B.Dinv);
+            if (B.njobs > 0) {
+                const long long n36 = B.njobs * 36;
+                SGX_LAUNCH(k_ba_schur_pairs, dim3((unsigned)((n36 + SGX_BA_THREADS - 1) / SGX_BA_THREADS)), dim3(SGX_BA_THREADS), (sgx_stream_t)0, n36, B.nf, B.jobs, B.E,
+                           B.hidx, B.bl, B.Hpl, B.Dinv, B.S, B.coef);
+            }
+            if (B.NP > 0 && B.NP <= SGX_CHOL_SMALL) {
+                SGX_LAUNCH(k_chol_small, dim3(1), dim3(256), (sgx_stream_t)0, B.NP, B.S, B.bp, B.coef, B.xp, B.ok);
+            } else if (B.NP > 0) {                                   // blocked Cholesky of the reduced camera system
                 const int nt = (B.NP + SGX_NB - 1) / SGX_NB;
                 for (int kb = 0; kb < nt; kb++) {
                     const int k0 = kb * SGX_NB, rem = nt - kb - 1;
-                    SGX_LAUNCH(k_chol_diag, dim3(1), dim3(SGX_NB * SGX_NB / 4), (sgx_stream_t)0, B.NP, k0, B.S, B.ok);
+                    SGX_LAUNCH(k_chol_diag, dim3(1), dim3(256), (sgx_stream_t)0, B.NP, k0, B.S, B.Linv, B.ok);
                     if (rem > 0) {
-                        SGX_LAUNCH(k_chol_panel, dim3(rem), dim3(256), (sgx_stream_t)0, B.NP, k0, B.S, B.ok);
+                        SGX_LAUNCH(k_chol_panel, dim3(rem), dim3(256), (sgx_stream_t)0, B.NP, k0, B.S, B.Linv, B.ok);
                         SGX_LAUNCH(k_chol_update, dim3(rem * (rem + 1) / 2), dim3(256), (sgx_stream_t)0, B.NP, k0, B.S, B.ok);
                     }
                 }
-                SGX_LAUNCH(k_chol_solve, dim3(1), dim3(1024), (sgx_stream_t)0, B.NP, B.S, B.bp, B.coef, B.xp, B.ok);
+                SGX_LAUNCH(k_chol_solve, dim3(1), dim3(256), (sgx_stream_t)0, B.NP, B.S, B.Linv, B.bp, B.coef, B.xp, B.ok);
             }
             // when the factorisation failed, xp/xl keep the previous solution (as g2o's _x does) and the step is rejected below
             SGX_LAUNCH(k_ba_backsub, dim3((B.nl + SGX_BA_THREADS - 1) / SGX_BA_THREADS), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.nl, B.pt_start, B.pt_edges, B.E, B.hidx,
@@ -179,6 +203,10 @@ extern "C" int sgx_local_bundle_adjustment(const sgx_ba_problem *P, const sgx_ca
       for (int k = 0; k < B.ne; k++) { pt_edges[pt_start[E[k].point] + f1[E[k].point]++] = k; pose_edges[pose_start[E[k].pose] + f2[E[k].pose]++] = k; } }
     std::vector<double> Xd(3 * (size_t)B.nl);
     for (size_t i = 0; i < Xd.size(); i++) Xd[i] = (double)P->points[i];
+    // upper bound of the Schur job list: sum over landmarks of (edges with a free pose)^2
+    size_t jobs_cap = 0;
+    for (int l = 0; l < B.nl; l++) { size_t c = 0; for (int q = pt_start[l]; q < pt_start[l + 1]; q++) if (hidx[E[pt_edges[q]].pose] >= 0) c++; jobs_cap += c * c; }
+    B.jobs_cap = jobs_cap;
     // ---- device state: one arena; the host->device inputs are packed contiguously and uploaded with one copy
     float *dTcw = nullptr; uint8_t *dfixed = nullptr, *derase = nullptr;
     const int nv = B.np > B.nl ? B.np : B.nl;
@@ -198,6 +226,7 @@ extern "C" int sgx_local_bundle_adjustment(const sgx_ba_problem *P, const sgx_ca
         A.take(&B.Dinv, 9 * (size_t)B.nl); A.take(&B.dwork, B.NP); A.take(&B.partial, B.nblk_v);
         { double *blk = nullptr; A.take(&blk, 1 + (size_t)B.nblk_v + B.nblk_e); B.ok = (int *)blk; B.part_scale = blk ? blk + 1 : nullptr; B.part_chi = blk ? blk + 1 + B.nblk_v : nullptr; }
         A.take(&B.pt_active, B.nl); A.take(&derase, B.ne);
+        A.take(&B.jobs, jobs_cap); A.take(&B.Linv, (size_t)((B.NP + SGX_NB - 1) / SGX_NB) * SGX_NB * SGX_NB);
         const size_t total = A.off;
         A.base = save;
         if (pass == 0) { if ((rc = A.reserve(total)) != SGX_OK) return rc; }
@@ -220,9 +249,17 @@ extern "C" int sgx_local_bundle_adjustment(const sgx_ba_problem *P, const sgx_ca
     SGX_LAUNCH(k_ba_poses_in, dim3((B.np + SGX_BA_THREADS - 1) / SGX_BA_THREADS), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.np, dTcw, B.T);
 
     int it1 = 0, it2 = 0; double chi1 = 0, chi2 = 0;
+    std::vector<uint8_t> level1(B.ne, 0);
+    rc = build_jobs(B, pt_start, pt_edges, E, level1, hidx); if (rc != SGX_OK) return rc;
     rc = optimize(B, 5, &it1, &chi1); if (rc != SGX_OK) return rc;                          // Optimizer.cc:659-660
     if (!stopped(B)) {                                                                      // :662-707
         SGX_LAUNCH(k_ba_classify, dim3(B.nblk_e), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.ne, B.E, B.T, B.X, B.err, 0, derase);
+        {   // mirror the new levels on the host to rebuild the Schur job list (the active edge set changed)
+            std::vector<SgxBaEdge> Eh(B.ne);
+            SGX_CHECK_HIP(hipMemcpy(Eh.data(), B.E, sizeof(SgxBaEdge) * B.ne, hipMemcpyDeviceToHost));
+            for (int k = 0; k < B.ne; k++) level1[k] = (Eh[k].flags & 2) ? 1 : 0;
+            rc = build_jobs(B, pt_start, pt_edges, E, level1, hidx); if (rc != SGX_OK) return rc;
+        }
         rc = optimize(B, 10, &it2, &chi2); if (rc != SGX_OK) return rc;
     }
     SGX_LAUNCH(k_ba_classify, dim3(B.nblk_e), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.ne, B.E, B.T, B.X, B.err, 1, derase);   // :709-742

@@ -214,12 +214,235 @@ SGX_KERNEL(SGX_BA_THREADS) k_ba_schur_init(int nf, const double *Hpp, double lam
     SGX_THREADS_END
 }
 
-// k_ba_schur: one thread per landmark (block_solver.hpp:380-433): Dinv = (Hll + lambda I)^-1 (closed form, Eigen Matrix3d::inverse),
-// db = Dinv bl, and for every pair of the landmark's edges with free poses: S(i1,i2) -= Hpl_1 Dinv Hpl_2^T, coef(i1) += Hpl_1 db.
-// fp64 atomics into the reduced system (several landmarks touch the same pose pair; summation order differs from the
-// reference's by rounding only).
-SGX_KERNEL(SGX_BA_THREADS) k_ba_schur(int nl, int nf, const int *pt_start, const int *pt_edges, const SgxBaEdge *E, const int *hidx, const uint8_t *pt_active,
-                                      const double *Hll, const double *bl, const double *Hpl, double lambda, double *Dinv, double *S, double *coef)
+// ---------------------------------------------------------------------------------------------
+// Reduced camera system  S xp = bp - coef  (S symmetric positive definite, n = 6 * free poses, row-major, full storage).
+// The reference factorises it with Eigen SimplicialLDLT (G/solvers/linear_solver_eigen.h:94-124); the solution is unique,
+// so a Cholesky L L^T is used here.  *ok is cleared when a pivot is not positive (or NaN): the LM step is then rejected
+// exactly like solve()==false (levenberg.cpp:126-127).
+//   n <= 128 : k_chol_small — the whole matrix lives in LDS (128 KB), one 256-thread workgroup factorises and solves.
+//   n  > 128 : blocked right-looking factorisation on 32x32 tiles staged in LDS, per panel k:
+//                k_chol_diag   (1 workgroup: factor L_kk and its explicit inverse Linv_kk)
+//                k_chol_panel  (one workgroup per row tile below:  L_ik = A_ik Linv_kk^T   — a tile GEMM)
+//                k_chol_update (one workgroup per lower-triangular tile pair: A_ij -= L_ik L_jk^T)
+//              then k_chol_solve (one workgroup, blocked substitution with the stored Linv_kk: mat-vec + tile updates).
+// ---------------------------------------------------------------------------------------------
+#define SGX_NB 32
+#define SGX_CHOL_SMALL 128
+
+SGX_KERNEL(256) k_chol_small(int n, const double *S, const double *bp, const double *coef, double *x, int *ok)
+{
+    SGX_LDS double A[SGX_CHOL_SMALL * SGX_CHOL_SMALL];
+    SGX_LDS double v[SGX_CHOL_SMALL];
+    SGX_LDS int s_ok;
+    const int NT = (int)blockDim.x;
+    SGX_THREADS_BEGIN(tid)
+    if (tid == 0) s_ok = 1;
+    for (int t = tid; t < n * n; t += NT) A[t] = S[t];
+    for (int i = tid; i < n; i += NT) v[i] = bp[i] - coef[i];
+    SGX_THREADS_END
+    SGX_SYNC();
+    for (int j = 0; j < n; j++) {
+        const double d = A[j * n + j];
+        if (!(d > 0)) { SGX_THREADS_BEGIN(tid) if (tid == 0) s_ok = 0; SGX_THREADS_END SGX_SYNC(); break; }
+        const double sd = sqrt(d);
+        SGX_THREADS_BEGIN(tid)
+        for (int i = j + tid; i < n; i += NT) A[i * n + j] = A[i * n + j] / sd;
+        SGX_THREADS_END
+        SGX_SYNC();
+        SGX_THREADS_BEGIN(tid)
+        const int m = n - j - 1;
+        for (int t = tid; t < m * m; t += NT) { const int i = j + 1 + t / m, c = j + 1 + t % m; if (c <= i) A[i * n + c] -= A[i * n + j] * A[c * n + j]; }
+        SGX_THREADS_END
+        SGX_SYNC();
+    }
+    if (s_ok) {
+        for (int j = 0; j < n; j++) {                    // L y = v (column oriented)
+            SGX_THREADS_BEGIN(tid)
+            if (tid == 0) v[j] = v[j] / A[j * n + j];
+            SGX_THREADS_END
+            SGX_SYNC();
+            SGX_THREADS_BEGIN(tid)
+            const double yj = v[j];
+            for (int i = j + 1 + tid; i < n; i += NT) v[i] -= A[i * n + j] * yj;
+            SGX_THREADS_END
+            SGX_SYNC();
+        }
+        for (int j = n - 1; j >= 0; j--) {               // L^T x = y
+            SGX_THREADS_BEGIN(tid)
+            if (tid == 0) v[j] = v[j] / A[j * n + j];
+            SGX_THREADS_END
+            SGX_SYNC();
+            SGX_THREADS_BEGIN(tid)
+            const double xj = v[j];
+            for (int i = tid; i < j; i += NT) v[i] -= A[j * n + i] * xj;
+            SGX_THREADS_END
+            SGX_SYNC();
+        }
+        SGX_THREADS_BEGIN(tid)
+        for (int i = tid; i < n; i += NT) x[i] = v[i];
+        SGX_THREADS_END
+    }
+    SGX_THREADS_BEGIN(tid)
+    if (tid == 0 && !s_ok) *ok = 0;
+    SGX_THREADS_END
+}
+
+// factor the diagonal tile (lower part of S overwritten with L_kk) and store Linv_kk (32x32, row-major, zero-padded) in Linv[k0/NB]
+SGX_KERNEL(256) k_chol_diag(int n, int k0, double *S, double *Linv, int *ok)
+{
+    SGX_LDS double A[SGX_NB][SGX_NB + 1];
+    SGX_LDS double X[SGX_NB][SGX_NB + 1];
+    SGX_LDS int s_ok;
+    const int nb = min(SGX_NB, n - k0);
+    const int NT = (int)blockDim.x;
+    SGX_THREADS_BEGIN(tid)
+    if (tid == 0) s_ok = 1;
+    for (int t = tid; t < nb * nb; t += NT) { const int r = t / nb, c = t % nb; A[r][c] = S[(size_t)(k0 + r) * n + k0 + c]; }
+    for (int t = tid; t < SGX_NB * SGX_NB; t += NT) X[t / SGX_NB][t % SGX_NB] = 0;
+    SGX_THREADS_END
+    SGX_SYNC();
+    for (int j = 0; j < nb; j++) {
+        const double d = A[j][j];
+        if (!(d > 0)) { SGX_THREADS_BEGIN(tid) if (tid == 0) s_ok = 0; SGX_THREADS_END SGX_SYNC(); break; }
+        const double sd = sqrt(d);
+        SGX_THREADS_BEGIN(tid)
+        for (int i = j + tid; i < nb; i += NT) A[i][j] = A[i][j] / sd;      // includes the diagonal: A[j][j] = sqrt(d)
+        SGX_THREADS_END
+        SGX_SYNC();
+        SGX_THREADS_BEGIN(tid)
+        const int m = nb - j - 1;
+        for (int t = tid; t < m * m; t += NT) { const int i = j + 1 + t / m, c = j + 1 + t % m; if (c <= i) A[i][c] -= A[i][j] * A[c][j]; }
+        SGX_THREADS_END
+        SGX_SYNC();
+    }
+    if (s_ok) {
+        SGX_THREADS_BEGIN(tid)
+        if (tid < nb) {                      // column tid of L^-1 by forward substitution (independent per column)
+            const int c = tid;
+            for (int r = c; r < nb; r++) {
+                double sacc = (r == c) ? 1.0 : 0.0;
+                for (int q = c; q < r; q++) sacc -= A[r][q] * X[q][c];
+                X[r][c] = sacc / A[r][r];
+            }
+        }
+        SGX_THREADS_END
+        SGX_SYNC();
+    }
+    SGX_THREADS_BEGIN(tid)
+    for (int t = tid; t < nb * nb; t += NT) { const int r = t / nb, c = t % nb; if (c <= r) S[(size_t)(k0 + r) * n + k0 + c] = A[r][c]; }
+    double *Lo = Linv + (size_t)(k0 / SGX_NB) * SGX_NB * SGX_NB;
+    for (int t = tid; t < SGX_NB * SGX_NB; t += NT) Lo[t] = X[t / SGX_NB][t % SGX_NB];
+    if (tid == 0 && !s_ok) *ok = 0;
+    SGX_THREADS_END
+}
+
+// L_ik = A_ik Linv_kk^T for the row tile i = k0/NB + 1 + blockIdx.x
+SGX_KERNEL(256) k_chol_panel(int n, int k0, double *S, const double *Linv, const int *ok)
+{
+    SGX_LDS double Li[SGX_NB][SGX_NB + 1];
+    SGX_LDS double A[SGX_NB][SGX_NB + 1];
+    if (!*ok) return;
+    const int nb = min(SGX_NB, n - k0);
+    const int r0 = k0 + SGX_NB * (1 + (int)blockIdx.x);
+    const int nr = min(SGX_NB, n - r0);
+    const int NT = (int)blockDim.x;
+    const double *Lk = Linv + (size_t)(k0 / SGX_NB) * SGX_NB * SGX_NB;
+    SGX_THREADS_BEGIN(tid)
+    for (int t = tid; t < SGX_NB * SGX_NB; t += NT) Li[t / SGX_NB][t % SGX_NB] = Lk[t];
+    for (int t = tid; t < nr * nb; t += NT) { const int r = t / nb, c = t % nb; A[r][c] = S[(size_t)(r0 + r) * n + k0 + c]; }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    for (int t = tid; t < nr * nb; t += NT) {
+        const int r = t / nb, c = t % nb;
+        double sacc = 0;
+        for (int q = 0; q <= c; q++) sacc += A[r][q] * Li[c][q];          // (A Linv^T)[r][c] = sum_q A[r][q] Linv[c][q], Linv lower triangular
+        S[(size_t)(r0 + r) * n + k0 + c] = sacc;
+    }
+    SGX_THREADS_END
+}
+
+// A_ij -= L_ik L_jk^T for the lower-triangular tile pairs (i >= j) of the trailing matrix; blockIdx.x enumerates pairs
+SGX_KERNEL(256) k_chol_update(int n, int k0, double *S, const int *ok)
+{
+    SGX_LDS double Li[SGX_NB][SGX_NB + 1];
+    SGX_LDS double Lj[SGX_NB][SGX_NB + 1];
+    if (!*ok) return;
+    const int nb = min(SGX_NB, n - k0);
+    int bi = 0, rem = (int)blockIdx.x;               // unrank blockIdx.x -> (bi >= bj) within the trailing tiles
+    while (rem > bi) { rem -= bi + 1; bi++; }
+    const int bj = rem;
+    const int r0 = k0 + SGX_NB * (1 + bi), c0 = k0 + SGX_NB * (1 + bj);
+    const int nr = min(SGX_NB, n - r0), nc = min(SGX_NB, n - c0);
+    const int NT = (int)blockDim.x;
+    SGX_THREADS_BEGIN(tid)
+    for (int t = tid; t < nr * nb; t += NT) { const int r = t / nb, c = t % nb; Li[r][c] = S[(size_t)(r0 + r) * n + k0 + c]; }
+    for (int t = tid; t < nc * nb; t += NT) { const int r = t / nb, c = t % nb; Lj[r][c] = S[(size_t)(c0 + r) * n + k0 + c]; }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    for (int t = tid; t < nr * nc; t += NT) {
+        const int r = t / nc, c = t % nc;
+        if (bi == bj && c > r) continue;
+        double sacc = 0;
+        for (int q = 0; q < nb; q++) sacc += Li[r][q] * Lj[c][q];
+        S[(size_t)(r0 + r) * n + c0 + c] -= sacc;
+    }
+    SGX_THREADS_END
+}
+
+// x = (bp - coef); L y = x; L^T x = y — blocked with the stored diagonal inverses, one 256-thread workgroup
+SGX_KERNEL(256) k_chol_solve(int n, const double *S, const double *Linv, const double *bp, const double *coef, double *x, const int *ok)
+{
+    SGX_LDS double xs[SGX_NB], ys[SGX_NB];
+    if (!*ok) return;
+    const int NT = (int)blockDim.x;
+    SGX_THREADS_BEGIN(tid)
+    for (int i = tid; i < n; i += NT) x[i] = bp[i] - coef[i];
+    SGX_THREADS_END
+    SGX_SYNC();
+    for (int k0 = 0; k0 < n; k0 += SGX_NB) {
+        const int nb = min(SGX_NB, n - k0);
+        const double *Lk = Linv + (size_t)(k0 / SGX_NB) * SGX_NB * SGX_NB;
+        SGX_THREADS_BEGIN(tid)
+        if (tid < nb) xs[tid] = x[k0 + tid];
+        SGX_THREADS_END
+        SGX_SYNC();
+        SGX_THREADS_BEGIN(tid)
+        if (tid < nb) { double sacc = 0; for (int q = 0; q <= tid; q++) sacc += Lk[tid * SGX_NB + q] * xs[q]; ys[tid] = sacc; x[k0 + tid] = sacc; }   // y_k = Linv_kk x_k
+        SGX_THREADS_END
+        SGX_SYNC();
+        SGX_THREADS_BEGIN(tid)
+        for (int i = k0 + nb + tid; i < n; i += NT) { double vv = x[i]; for (int q = 0; q < nb; q++) vv -= S[(size_t)i * n + k0 + q] * ys[q]; x[i] = vv; }
+        SGX_THREADS_END
+        SGX_SYNC();
+    }
+    for (int k0 = ((n - 1) / SGX_NB) * SGX_NB; k0 >= 0; k0 -= SGX_NB) {
+        const int nb = min(SGX_NB, n - k0);
+        const double *Lk = Linv + (size_t)(k0 / SGX_NB) * SGX_NB * SGX_NB;
+        SGX_THREADS_BEGIN(tid)
+        if (tid < nb) xs[tid] = x[k0 + tid];
+        SGX_THREADS_END
+        SGX_SYNC();
+        SGX_THREADS_BEGIN(tid)
+        if (tid < nb) { double sacc = 0; for (int q = tid; q < nb; q++) sacc += Lk[q * SGX_NB + tid] * xs[q]; ys[tid] = sacc; x[k0 + tid] = sacc; }    // x_k = Linv_kk^T y_k
+        SGX_THREADS_END
+        SGX_SYNC();
+        SGX_THREADS_BEGIN(tid)
+        for (int i = tid; i < k0; i += NT) { double vv = x[i]; for (int q = 0; q < nb; q++) vv -= S[(size_t)(k0 + q) * n + i] * ys[q]; x[i] = vv; }
+        SGX_THREADS_END
+        SGX_SYNC();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_ba_schur_pairs: the Schur complement (block_solver.hpp:380-433) as one thread per (job, entry): a job is a pair of
+// active free-pose edges (k1, k2) of one landmark (host-built list, static during one optimize() call); the 36 threads of a
+// job each produce one entry of  Hpl_1 Dinv Hpl_2^T  and subtract it from S(i1,i2) with an fp64 atomic; the diagonal jobs'
+// first 6 threads also add coef(i1) += Hpl_1 (Dinv bl).  (Summation order differs from the reference by rounding only.)
+// k_ba_dinv (one thread per landmark) computes Dinv = (Hll + lambda I)^-1 first (closed form = Eigen Matrix3d::inverse()).
+// ---------------------------------------------------------------------------------------------
+SGX_KERNEL(SGX_BA_THREADS) k_ba_dinv(int nl, const uint8_t *pt_active, const double *Hll, double lambda, double *Dinv)
 {
     SGX_THREADS_BEGIN(tid)
     const int l = (int)blockIdx.x * SGX_BA_THREADS + tid;
@@ -241,175 +464,35 @@ SGX_KERNEL(SGX_BA_THREADS) k_ba_schur(int nl, int nf, const int *pt_start, const
         }
 #pragma unroll
         for (int i = 0; i < 9; i++) Dinv[(size_t)l * 9 + i] = Di[i];
-        if (pt_active[l]) {
-            const int NP = 6 * nf;
+    }
+    SGX_THREADS_END
+}
+
+struct SgxBaJob { int k1, k2; };
+
+SGX_KERNEL(SGX_BA_THREADS) k_ba_schur_pairs(long long njobs36, int nf, const SgxBaJob *jobs, const SgxBaEdge *E, const int *hidx,
+                                            const double *bl, const double *Hpl, const double *Dinv, double *S, double *coef)
+{
+    SGX_THREADS_BEGIN(tid)
+    const long long g = (long long)blockIdx.x * SGX_BA_THREADS + tid;
+    if (g < njobs36) {
+        const int job = (int)(g / 36), ent = (int)(g % 36), a = ent / 6, c = ent % 6;
+        const SgxBaJob jb = jobs[job];
+        const SgxBaEdge e1 = E[jb.k1], e2 = E[jb.k2];
+        const int i1 = hidx[e1.pose], i2 = hidx[e2.pose], l = e1.point;
+        const double *Di = Dinv + (size_t)l * 9;
+        const double *B1 = Hpl + (size_t)jb.k1 * 18 + 3 * a, *B2 = Hpl + (size_t)jb.k2 * 18 + 3 * c;
+        const double bd0 = B1[0] * Di[0] + B1[1] * Di[3] + B1[2] * Di[6];
+        const double bd1 = B1[0] * Di[1] + B1[1] * Di[4] + B1[2] * Di[7];
+        const double bd2 = B1[0] * Di[2] + B1[1] * Di[5] + B1[2] * Di[8];
+        const int NP = 6 * nf;
+        sgx_atomic_add(&S[(size_t)(6 * i1 + a) * NP + 6 * i2 + c], -(bd0 * B2[0] + bd1 * B2[1] + bd2 * B2[2]));
+        if (jb.k1 == jb.k2 && c == 0) {
             const double b0 = bl[3 * (size_t)l], b1 = bl[3 * (size_t)l + 1], b2 = bl[3 * (size_t)l + 2];
-            const double db[3] = { Di[0] * b0 + Di[1] * b1 + Di[2] * b2, Di[3] * b0 + Di[4] * b1 + Di[5] * b2, Di[6] * b0 + Di[7] * b1 + Di[8] * b2 };
-            for (int q1 = pt_start[l]; q1 < pt_start[l + 1]; q1++) {
-                const int k1 = pt_edges[q1];
-                const SgxBaEdge e1 = E[k1];
-                const int i1 = hidx[e1.pose];
-                if ((e1.flags & 2) || i1 < 0) continue;
-                const double *B1 = Hpl + (size_t)k1 * 18;
-                double BD[18];
-#pragma unroll
-                for (int a = 0; a < 6; a++) {
-#pragma unroll
-                    for (int c = 0; c < 3; c++) BD[3 * a + c] = B1[3 * a] * Di[c] + B1[3 * a + 1] * Di[3 + c] + B1[3 * a + 2] * Di[6 + c];
-                    sgx_atomic_add(&coef[6 * i1 + a], B1[3 * a] * db[0] + B1[3 * a + 1] * db[1] + B1[3 * a + 2] * db[2]);
-                }
-                for (int q2 = pt_start[l]; q2 < pt_start[l + 1]; q2++) {
-                    const int k2 = pt_edges[q2];
-                    const SgxBaEdge e2 = E[k2];
-                    const int i2 = hidx[e2.pose];
-                    if ((e2.flags & 2) || i2 < 0) continue;
-                    const double *B2 = Hpl + (size_t)k2 * 18;
-#pragma unroll
-                    for (int a = 0; a < 6; a++) {
-#pragma unroll
-                        for (int c = 0; c < 6; c++)
-                            sgx_atomic_add(&S[(size_t)(6 * i1 + a) * NP + 6 * i2 + c], -(BD[3 * a] * B2[3 * c] + BD[3 * a + 1] * B2[3 * c + 1] + BD[3 * a + 2] * B2[3 * c + 2]));
-                    }
-                }
-            }
+            sgx_atomic_add(&coef[6 * i1 + a], bd0 * b0 + bd1 * b1 + bd2 * b2);        // Hpl_1 Dinv bl
         }
     }
     SGX_THREADS_END
-}
-
-// ---------------------------------------------------------------------------------------------
-// Reduced camera system  S xp = bp - coef  (S symmetric positive definite, n = 6 * free poses, row-major, full storage).
-// The reference factorises it with Eigen SimplicialLDLT (G/solvers/linear_solver_eigen.h:94-124); the solution is
-// unique, so a blocked right-looking Cholesky (L L^T, 32x32 tiles staged in LDS) is used here:
-//   per panel k:  k_chol_diag (1 workgroup)  ->  k_chol_panel (one workgroup per row tile below)  ->
-//                 k_chol_update (one workgroup per lower-triangular tile pair: A_ij -= L_ik L_jk^T)
-// then k_chol_solve (one workgroup, blocked forward/backward substitution).  *ok is cleared when a pivot is not
-// positive (or NaN): the LM step is then rejected exactly like !isPositive / solve()==false (levenberg.cpp:126-127).
-// ---------------------------------------------------------------------------------------------
-#define SGX_NB 32
-
-SGX_KERNEL(SGX_NB * SGX_NB / 4) k_chol_diag(int n, int k0, double *S, int *ok)
-{
-    SGX_LDS double A[SGX_NB][SGX_NB + 1];
-    SGX_LDS int s_ok;
-    const int nb = min(SGX_NB, n - k0);
-    const int NT = (int)blockDim.x;
-    SGX_THREADS_BEGIN(tid)
-    if (tid == 0) s_ok = 1;
-    for (int t = tid; t < nb * nb; t += NT) { const int r = t / nb, c = t % nb; A[r][c] = S[(size_t)(k0 + r) * n + k0 + c]; }
-    SGX_THREADS_END
-    SGX_SYNC();
-    for (int j = 0; j < nb; j++) {
-        const double d = A[j][j];
-        if (!(d > 0)) { SGX_THREADS_BEGIN(tid) if (tid == 0) s_ok = 0; SGX_THREADS_END SGX_SYNC(); break; }
-        const double sd = sqrt(d);
-        SGX_THREADS_BEGIN(tid)
-        for (int i = j + tid; i < nb; i += NT) A[i][j] = A[i][j] / sd;      // includes the diagonal: A[j][j] = sqrt(d)
-        SGX_THREADS_END
-        SGX_SYNC();
-        SGX_THREADS_BEGIN(tid)
-        const int m = nb - j - 1;
-        for (int t = tid; t < m * m; t += NT) { const int i = j + 1 + t / m, c = j + 1 + t % m; if (c <= i) A[i][c] -= A[i][j] * A[c][j]; }
-        SGX_THREADS_END
-        SGX_SYNC();
-    }
-    SGX_THREADS_BEGIN(tid)
-    for (int t = tid; t < nb * nb; t += NT) { const int r = t / nb, c = t % nb; if (c <= r) S[(size_t)(k0 + r) * n + k0 + c] = A[r][c]; }
-    if (tid == 0 && !s_ok) *ok = 0;
-    SGX_THREADS_END
-}
-
-// L_ik = A_ik L_kk^-T for the row tile i = k0/NB + 1 + blockIdx.x
-SGX_KERNEL(256) k_chol_panel(int n, int k0, double *S, const int *ok)
-{
-    SGX_LDS double Lk[SGX_NB][SGX_NB + 1];
-    SGX_LDS double A[SGX_NB][SGX_NB + 1];
-    if (!*ok) return;
-    const int nb = min(SGX_NB, n - k0);
-    const int r0 = k0 + SGX_NB * (1 + (int)blockIdx.x);
-    const int nr = min(SGX_NB, n - r0);
-    const int NT = (int)blockDim.x;
-    SGX_THREADS_BEGIN(tid)
-    for (int t = tid; t < nb * nb; t += NT) { const int r = t / nb, c = t % nb; Lk[r][c] = S[(size_t)(k0 + r) * n + k0 + c]; }
-    for (int t = tid; t < nr * nb; t += NT) { const int r = t / nb, c = t % nb; A[r][c] = S[(size_t)(r0 + r) * n + k0 + c]; }
-    SGX_THREADS_END
-    SGX_SYNC();
-    SGX_THREADS_BEGIN(tid)
-    if (tid < nr) {                          // one thread per row: x L^T = a  (forward over columns)
-        for (int c = 0; c < nb; c++) {
-            double v = A[tid][c];
-            for (int q = 0; q < c; q++) v -= A[tid][q] * Lk[c][q];
-            A[tid][c] = v / Lk[c][c];
-        }
-    }
-    SGX_THREADS_END
-    SGX_SYNC();
-    SGX_THREADS_BEGIN(tid)
-    for (int t = tid; t < nr * nb; t += NT) { const int r = t / nb, c = t % nb; S[(size_t)(r0 + r) * n + k0 + c] = A[r][c]; }
-    SGX_THREADS_END
-}
-
-// A_ij -= L_ik L_jk^T for the lower-triangular tile pairs (i >= j) of the trailing matrix; blockIdx.x enumerates pairs
-SGX_KERNEL(256) k_chol_update(int n, int k0, double *S, const int *ok)
-{
-    SGX_LDS double Li[SGX_NB][SGX_NB + 1];
-    SGX_LDS double Lj[SGX_NB][SGX_NB + 1];
-    if (!*ok) return;
-    const int nb = min(SGX_NB, n - k0);
-    // unrank blockIdx.x -> (bi >= bj) within the trailing tiles
-    int bi = 0, rem = (int)blockIdx.x;
-    while (rem > bi) { rem -= bi + 1; bi++; }
-    const int bj = rem;
-    const int r0 = k0 + SGX_NB * (1 + bi), c0 = k0 + SGX_NB * (1 + bj);
-    const int nr = min(SGX_NB, n - r0), nc = min(SGX_NB, n - c0);
-    const int NT = (int)blockDim.x;
-    SGX_THREADS_BEGIN(tid)
-    for (int t = tid; t < nr * nb; t += NT) { const int r = t / nb, c = t % nb; Li[r][c] = S[(size_t)(r0 + r) * n + k0 + c]; }
-    for (int t = tid; t < nc * nb; t += NT) { const int r = t / nb, c = t % nb; Lj[r][c] = S[(size_t)(c0 + r) * n + k0 + c]; }
-    SGX_THREADS_END
-    SGX_SYNC();
-    SGX_THREADS_BEGIN(tid)
-    for (int t = tid; t < nr * nc; t += NT) {
-        const int r = t / nc, c = t % nc;
-        if (bi == bj && c > r) continue;
-        double s = 0;
-        for (int q = 0; q < nb; q++) s += Li[r][q] * Lj[c][q];
-        S[(size_t)(r0 + r) * n + c0 + c] -= s;
-    }
-    SGX_THREADS_END
-}
-
-// x = (bp - coef); L y = x; L^T x = y — blocked, one 1024-thread workgroup
-SGX_KERNEL(1024) k_chol_solve(int n, const double *S, const double *bp, const double *coef, double *x, const int *ok)
-{
-    if (!*ok) return;
-    const int NT = (int)blockDim.x;
-    SGX_THREADS_BEGIN(tid)
-    for (int i = tid; i < n; i += NT) x[i] = bp[i] - coef[i];
-    SGX_THREADS_END
-    SGX_SYNC();
-    for (int k0 = 0; k0 < n; k0 += SGX_NB) {
-        const int nb = min(SGX_NB, n - k0);
-        SGX_THREADS_BEGIN(tid)
-        if (tid == 0) for (int r = 0; r < nb; r++) { double v = x[k0 + r]; for (int q = 0; q < r; q++) v -= S[(size_t)(k0 + r) * n + k0 + q] * x[k0 + q]; x[k0 + r] = v / S[(size_t)(k0 + r) * n + k0 + r]; }
-        SGX_THREADS_END
-        SGX_SYNC();
-        SGX_THREADS_BEGIN(tid)
-        for (int i = k0 + nb + tid; i < n; i += NT) { double v = x[i]; for (int q = 0; q < nb; q++) v -= S[(size_t)i * n + k0 + q] * x[k0 + q]; x[i] = v; }
-        SGX_THREADS_END
-        SGX_SYNC();
-    }
-    for (int k0 = ((n - 1) / SGX_NB) * SGX_NB; k0 >= 0; k0 -= SGX_NB) {
-        const int nb = min(SGX_NB, n - k0);
-        SGX_THREADS_BEGIN(tid)
-        if (tid == 0) for (int r = nb - 1; r >= 0; r--) { double v = x[k0 + r]; for (int q = r + 1; q < nb; q++) v -= S[(size_t)(k0 + q) * n + k0 + r] * x[k0 + q]; x[k0 + r] = v / S[(size_t)(k0 + r) * n + k0 + r]; }
-        SGX_THREADS_END
-        SGX_SYNC();
-        SGX_THREADS_BEGIN(tid)
-        for (int i = tid; i < k0; i += NT) { double v = x[i]; for (int q = 0; q < nb; q++) v -= S[(size_t)(k0 + q) * n + i] * x[k0 + q]; x[i] = v; }
-        SGX_THREADS_END
-        SGX_SYNC();
-    }
 }
 
 // k_ba_backsub: xl = Dinv (bl - Hpl^T xp) per landmark (block_solver.hpp:461-481)
