@@ -109,6 +109,10 @@ def make_ba_problem(orc, n_free=8, n_fixed=5, n_points=400, seed=11, outlier_fra
             if rng.rand() < mono_frac:
                 ur = -1.0
             ep.append(i); el.append(l); eo.append([uo, vo, ur]); ei.append(p['inv_sigma2'][octv])
+    # a map point enters the local graph with at least two observations (single-view points have unobservable depth)
+    cnt = np.bincount(np.array(el, 'i8'), minlength=n_points)
+    keep = [k for k in range(len(el)) if cnt[el[k]] >= 2]
+    ep = [ep[k] for k in keep]; el = [el[k] for k in keep]; eo = [eo[k] for k in keep]; ei = [ei[k] for k in keep]
     poses0 = Ts.copy()
     for i in range(npose):
         if fixed[i] == 0:

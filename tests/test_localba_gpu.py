@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 from scenes import make_ba_problem, CAM
 from sg_slam_amd.optimizer import Optimizer
-from test_localba import close
+from test_localba import close, points_close
 
 pytestmark = pytest.mark.gpu
 
@@ -17,7 +17,7 @@ def test_gpu_matches_oracle(gpulib, oracle, seed, n_free, n_fixed, n_points):
     erase, stats = Optimizer.LocalBundleAdjustment(p2, CAM, lib=gpulib)
     assert stats['iterations'] == tuple(eiters)
     assert (erase == eerase).all()
-    assert close(p2['poses'], eposes) and close(p2['points'], epoints)
+    assert close(p2['poses'], eposes) and points_close(p2['points'], epoints)
     ref = etrace[1, eiters[1] - 1, 0]
     assert abs(stats['chi2'][1] - ref) <= 1e-5 * max(1.0, ref)
 
