@@ -10,6 +10,7 @@
 #ifndef SGX_H
 #define SGX_H
 #include <stdint.h>
+#include <stddef.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -170,6 +171,40 @@ typedef struct sgx_ba_problem {
 typedef struct sgx_ba_stats { int32_t iterations_first, iterations_second, free_poses, reserved; double chi2_first, chi2_second; } sgx_ba_stats;
 int sgx_local_bundle_adjustment(const sgx_ba_problem *problem, const sgx_camera *cam, const volatile int32_t *stop_flag,
                                 uint8_t *edge_erase, sgx_ba_stats *stats);
+
+/* ---- 2-D detector + dynamic-feature mask --------------------------------------------------------
+ * Replaces ORB_SLAM2::Detector2D (src/sg-slam/include/Detector2D.h:45-67, src/sg-slam/src/Detector2D.cc:16-89): the ncnn
+ * forward pass of the shipped MobileNetV3-SSDLite graph (Thirdparty/ncnn_model/mobilenetv3_ssdlite_voc.param + .bin) on 300x300,
+ * DetectionOutput, and detect()'s filtering into mvObjects2D / mvPotentialDynamicBorderForMapping / ...ForRmDynamicFeature.
+ * sgx_det_create takes the .param TEXT and the .bin BYTES (the caller reads the two files Detector2D.cc:24-25 names);
+ * pointwise convolutions run as fp32-MFMA GEMMs.  The Run()/isNewImageArrived()/ImageDetectFinished() thread handshake
+ * (Detector2D.cc:122-149) becomes stream ordering: the caller launches detect on its own HIP stream / thread. */
+#define SGX_DET_MAX 100
+typedef struct sgx_detection { float label, score, xmin, ymin, xmax, ymax; } sgx_detection;        /* ncnn DetectionOutput row (normalised coords) */
+typedef struct sgx_object2d { int32_t id; float prob, x, y, w, h; } sgx_object2d;                   /* Object2D: class id, prob, cv::Rect_<float> in pixels */
+typedef struct sgx_det_result {
+    int32_t n_raw; sgx_detection raw[SGX_DET_MAX];
+    int32_t n_objects; sgx_object2d objects[SGX_DET_MAX];            /* mvObjects2D (non-person) */
+    int32_t have_dynamic_for_mapping, have_dynamic_for_rm_feature;   /* mbHaveDynamicObjectFor{Mapping,RmDynamicFeature} */
+    int32_t n_map_boxes; sgx_object2d map_boxes[SGX_DET_MAX];        /* mvPotentialDynamicBorderForMapping */
+    int32_t n_rm_boxes; sgx_object2d rm_boxes[SGX_DET_MAX];          /* mvPotentialDynamicBorderForRmDynamicFeature (prob > 0.2) */
+} sgx_det_result;
+typedef struct sgx_det sgx_det;
+int sgx_det_create(const char *param_text, const void *bin, size_t bin_bytes, int width, int height, int max_batch,
+                   float detection_confidence_threshold, float dynamic_detection_confidence_threshold, sgx_det **out);
+void sgx_det_destroy(sgx_det *h);
+int sgx_det_info(const sgx_det *h, int32_t *num_priors, int32_t *num_class, int32_t *num_kernels, double *gmac);
+/* Detector2D::detect(const cv::Mat &bgr) for `batch` host images (interleaved 3-channel u8, row pitch in bytes); synchronous */
+int sgx_det_detect(sgx_det *h, const uint8_t *images, int pitch, int batch, sgx_det_result *results);
+/* device-resident batched forward only: leaves mbox_loc (num_priors*4) and softmax conf (num_priors*num_class) per image in HBM */
+int sgx_det_forward_batch_dev(sgx_det *h, const uint8_t *d_img, int pitch, int batch, const float **d_loc, const float **d_conf, void *stream);
+int sgx_det_debug_read_blob(sgx_det *h, const char *blob_name, int image, float *dst, int cap, int *n);
+/* Frame::RmDynamicPointWithSemanticAndGeometry's keep/erase predicate (src/sg-slam/src/Frame.cc:556-597, :613-652): keep[i] = 1 when the
+ * epipolar distance of (keypoint i, its LK-tracked previous position) under F (3x3 row-major fp64, cv::findFundamentalMat) is below
+ * 0.2 px inside a person box / 1.0 px elsewhere.  boxes: max_boxes x (x, y, w, h) per frame.  The caller applies the
+ * "restore everything when fewer than 0.1*nFeatures survive" rule (:599-604) and compacts keypoints + descriptor rows. */
+int sgx_dynamic_mask_batch_dev(int batch, int cap, const sgx_keypoint *d_keys, const int32_t *d_n, const float *d_prev_xy, const double *d_F,
+                               const float *d_boxes, const int32_t *d_nboxes, int max_boxes, uint8_t *d_keep, void *stream);
 
 /* run the octree-distribution kernel alone on packed candidates (x | y<<12 | score<<24, coordinates
  * relative to the (16,16) border origin) for `level`; returns the selected packed entries in list order */

@@ -1,0 +1,254 @@
+"""oracle/detector_oracle.py — CPU ORACLE (numpy, fp32) for Detector2D::detect.  TEST INFRASTRUCTURE ONLY.
+
+Restates  src/sg-slam/src/Detector2D.cc:34-89  (pre-processing, ncnn forward of the shipped graph
+src/sg-slam/Thirdparty/ncnn_model/mobilenetv3_ssdlite_voc.param, box post-processing) and
+Frame::RmDynamicPointWithSemanticAndGeometry's keep/erase predicate (src/sg-slam/src/Frame.cc:563-627).
+
+ncnn is NOT vendored in the reference tree (un-pinned git master, README.md:144-152) and the weight blob is absent:
+==> PARITY UNPINNED at the ncnn boundary <==  The layer semantics below follow ncnn's published layer definitions
+(SURVEY.md Appendix A.7): Convolution / ConvolutionDepthWise (0=outc 1=k 3=stride 4=pad 5=bias 6=weights 7=group),
+BinaryOp (0 add, 2 mul, 3 div), Clip, ReLU, Permute(order 3 = HWC), Flatten, Concat, Reshape, Softmax, PriorBox (Caffe-SSD
+style; the mmdetection flags 14/15 of the shipped graph are NOT modelled — noted in DESIGN.md), DetectionOutput.
+Weights are synthetic (the .bin is missing): N(0, 2/fan_in), seed 7, in ncnn .bin order.
+"""
+import numpy as np
+
+MEAN = np.array([123.675, 116.28, 103.53], np.float32)
+TARGET = 300
+
+
+# ---------------------------------------------------------------- param parsing
+def parse_param(path):
+    lines = [l.split() for l in open(path).read().strip().split('\n')]
+    assert lines[0][0] == '7767517'
+    layers = []
+    for tok in lines[2:]:
+        typ, name, nin, nout = tok[0], tok[1], int(tok[2]), int(tok[3])
+        ins = tok[4:4 + nin]; outs = tok[4 + nin:4 + nin + nout]
+        params = {}
+        for kv in tok[4 + nin + nout:]:
+            k, v = kv.split('=')
+            k = int(k)
+            if k <= -23300:
+                vals = v.split(','); params[-k - 23300] = [float(x) for x in vals[1:]]
+            else:
+                params[k] = float(v) if ('.' in v or 'e' in v) else int(v)
+        layers.append(dict(type=typ, name=name, ins=ins, outs=outs, p=params))
+    return layers
+
+
+def synth_weights(layers, seed=7):
+    """dict layer-name -> arrays, and the ncnn .bin byte string (flag word 0 + raw fp32 per conv weight, raw bias, raw MemoryData)."""
+    rng = np.random.RandomState(seed)
+    W = {}; blob = []
+    for L in layers:
+        p = L['p']
+        if L['type'] == 'MemoryData':
+            n = p.get(0, 0) * max(p.get(1, 1), 1) * max(p.get(2, 1), 1)
+            # scalars of the h-swish / h-sigmoid chains: +3 and /6 in the original network; keep those semantics
+            W[L['name']] = None
+        elif L['type'] in ('Convolution', 'ConvolutionDepthWise'):
+            outc, k = p[0], p[1]; wsize = p[6]; group = p.get(7, 1)
+            inc = wsize // (outc * k * k) * group
+            fan_in = (inc // group) * k * k
+            w = (rng.randn(wsize) * np.sqrt(2.0 / fan_in)).astype(np.float32)
+            b = (rng.randn(outc) * 0.05).astype(np.float32) if p.get(5, 0) else np.zeros(outc, np.float32)
+            W[L['name']] = (w, b)
+    # MemoryData constants: consumers tell whether it is the "+3" or the "/6" (BinaryOp add vs div)
+    use = {}
+    for L in layers:
+        if L['type'] == 'BinaryOp':
+            for i in L['ins']:
+                if i in W and W[i] is None:
+                    use[i] = L['p'].get(0, 0)
+    for L in layers:
+        if L['type'] == 'MemoryData':
+            W[L['name']] = np.array([3.0 if use.get(L['name'], 0) == 0 else 6.0], np.float32)
+    for L in layers:     # .bin order = layer order
+        if L['type'] == 'MemoryData':
+            blob.append(W[L['name']].tobytes())
+        elif L['type'] in ('Convolution', 'ConvolutionDepthWise'):
+            w, b = W[L['name']]
+            blob.append(np.zeros(1, np.uint32).tobytes()); blob.append(w.tobytes())
+            if L['p'].get(5, 0): blob.append(b.tobytes())
+    return W, b''.join(blob)
+
+
+# ---------------------------------------------------------------- pre-processing
+def resize_bilinear_c3(src, dw, dh):
+    """ncnn resize_bilinear_c3 (src/mat_pixel_resize.cpp): 11-bit fixed point, like OpenCV's but clamping to (n-2, 1.0)."""
+    sh, sw, _ = src.shape
+    def tabs(s, d):
+        scale = float(s) / d
+        ofs = np.zeros(d, np.int32); a = np.zeros((d, 2), np.int32)
+        for i in range(d):
+            f = np.float32((i + 0.5) * scale - 0.5)
+            si = int(np.floor(f)); f = np.float32(f - si)
+            if si < 0: si, f = 0, np.float32(0)
+            if si >= s - 1: si, f = s - 2, np.float32(1)
+            ofs[i] = si
+            a[i, 0] = int(np.rint(np.float32(np.float32(1) - f) * np.float32(2048))); a[i, 1] = int(np.rint(f * np.float32(2048)))
+        return ofs, a
+    xo, xa = tabs(sw, dw); yo, ya = tabs(sh, dh)
+    s = src.astype(np.int32)
+    rows = s[:, xo, :] * xa[None, :, 0, None] + s[:, xo + 1, :] * xa[None, :, 1, None]            # (sh, dw, 3)
+    r0 = rows[yo]; r1 = rows[yo + 1]
+    out = (((ya[:, 0, None, None] * (r0 >> 4)) >> 16) + ((ya[:, 1, None, None] * (r1 >> 4)) >> 16) + 2) >> 2
+    return out.astype(np.uint8)
+
+
+def preprocess(img_u8):
+    """from_pixels_resize(..., PIXEL_RGB, w, h, 300, 300) + substract_mean_normalize(mean, norm=1): -> float32 CHW"""
+    r = resize_bilinear_c3(img_u8, TARGET, TARGET)
+    x = r.astype(np.float32).transpose(2, 0, 1)
+    return (x - MEAN[:, None, None]) * np.float32(1.0)
+
+
+# ---------------------------------------------------------------- forward
+def conv2d(x, w, b, outc, k, stride, pad, group, dt=np.float32):
+    x = x.astype(dt); w = w.astype(dt); b = b.astype(dt)
+    inc, H, W = x.shape
+    Ho = (H + 2 * pad - k) // stride + 1; Wo = (W + 2 * pad - k) // stride + 1
+    xp = np.zeros((inc, H + 2 * pad, W + 2 * pad), dt); xp[:, pad:pad + H, pad:pad + W] = x
+    if group == 1:
+        w = w.reshape(outc, inc, k, k)
+        if k == 1:
+            y = w.reshape(outc, inc) @ xp[:, ::stride, ::stride].reshape(inc, -1)
+        else:
+            cols = np.stack([xp[:, i:i + stride * Ho:stride, j:j + stride * Wo:stride] for i in range(k) for j in range(k)], 1)   # (inc, k*k, Ho, Wo)
+            y = w.reshape(outc, inc * k * k) @ cols.reshape(inc * k * k, -1)
+        y = y.reshape(outc, Ho, Wo).astype(dt)
+    else:
+        assert group == inc == outc
+        w = w.reshape(outc, k, k)
+        y = np.zeros((outc, Ho, Wo), dt)
+        for i in range(k):
+            for j in range(k):
+                y += w[:, i, j, None, None] * xp[:, i:i + stride * Ho:stride, j:j + stride * Wo:stride]
+    return (y + b[:, None, None]).astype(dt)
+
+
+def prior_box(fh, fw, img, p):
+    mins, maxs, ars = p.get(0, []), p.get(1, []), p.get(2, [])
+    flip, clip, offset = p.get(7, 1), p.get(8, 0), np.float32(p.get(13, 0.0))
+    step_w = np.float32(img) / np.float32(fw); step_h = np.float32(img) / np.float32(fh)
+    boxes = []
+    for i in range(fh):
+        for j in range(fw):
+            cx = np.float32((np.float32(j) + offset) * step_w); cy = np.float32((np.float32(i) + offset) * step_h)
+            def add(bw, bh):
+                boxes.append([(cx - bw * np.float32(0.5)) / img, (cy - bh * np.float32(0.5)) / img, (cx + bw * np.float32(0.5)) / img, (cy + bh * np.float32(0.5)) / img])
+            for kk, ms in enumerate(mins):
+                ms = np.float32(ms); add(ms, ms)
+                if maxs:
+                    s = np.float32(np.sqrt(ms * np.float32(maxs[kk]))); add(s, s)
+                for ar in ars:
+                    sq = np.float32(np.sqrt(np.float32(ar)))
+                    add(ms * sq, ms / sq)
+                    if flip: add(ms / sq, ms * sq)
+    b = np.array(boxes, np.float32)
+    if clip: b = np.clip(b, 0, 1)
+    var = np.tile(np.array([p.get(3, .1), p.get(4, .1), p.get(5, .2), p.get(6, .2)], np.float32), len(b))
+    return np.stack([b.reshape(-1), var])
+
+
+def detection_output(loc, conf, priors, p):
+    ncls, nms_th, nms_topk, keep_topk, conf_th = p[0], np.float32(p[1]), p[2], p[3], np.float32(p[4])
+    var = np.array([p.get(5, .1), p.get(6, .1), p.get(7, .2), p.get(8, .2)], np.float32)
+    pb = priors[0].reshape(-1, 4); n = len(pb); loc = loc.reshape(n, 4); conf = conf.reshape(n, ncls)
+    pw = pb[:, 2] - pb[:, 0]; ph = pb[:, 3] - pb[:, 1]; pcx = (pb[:, 0] + pb[:, 2]) * np.float32(0.5); pcy = (pb[:, 1] + pb[:, 3]) * np.float32(0.5)
+    cx = var[0] * loc[:, 0] * pw + pcx; cy = var[1] * loc[:, 1] * ph + pcy
+    w = np.exp(var[2] * loc[:, 2]).astype(np.float32) * pw; h = np.exp(var[3] * loc[:, 3]).astype(np.float32) * ph
+    boxes = np.stack([cx - w * np.float32(0.5), cy - h * np.float32(0.5), cx + w * np.float32(0.5), cy + h * np.float32(0.5)], 1).astype(np.float32)
+    allr = []
+    for c in range(1, ncls):
+        sc = conf[:, c]; idx = np.nonzero(sc > conf_th)[0]
+        idx = idx[np.argsort(-sc[idx], kind='stable')][:nms_topk]
+        keep = []
+        for i in idx:
+            ok = True
+            for k in keep:
+                a, b = boxes[i], boxes[k]
+                iw = min(a[2], b[2]) - max(a[0], b[0]); ih = min(a[3], b[3]) - max(a[1], b[1])
+                inter = np.float32(iw * ih) if (iw > 0 and ih > 0) else np.float32(0)
+                union = (a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - inter
+                if inter / union > nms_th: ok = False; break
+            if ok: keep.append(i)
+        allr += [(c, sc[i], *boxes[i]) for i in keep]
+    allr.sort(key=lambda r: -r[1])
+    return np.array(allr[:keep_topk], np.float32).reshape(-1, 6)
+
+
+def forward(layers, W, x, dt=np.float32):
+    """x: CHW input blob. dt = np.float32 (the reference's precision) or np.float64 (error yardstick for the fp32 tolerance).
+    Returns (detection_out rows[n,6], blobs dict)."""
+    blobs = {'input': x.astype(dt)}
+    for L in layers:
+        t, p, ins, outs = L['type'], L['p'], L['ins'], L['outs']
+        if t == 'Input': continue
+        if t == 'MemoryData': blobs[outs[0]] = W[L['name']].astype(dt); continue
+        if t == 'Split':
+            for o in outs: blobs[o] = blobs[ins[0]]
+            continue
+        a = blobs[ins[0]]
+        if t in ('Convolution', 'ConvolutionDepthWise'):
+            w, b = W[L['name']]
+            y = conv2d(a, w, b, p[0], p[1], p.get(3, 1), p.get(4, 0), p.get(7, 1), dt)
+        elif t == 'BinaryOp':
+            b = blobs[ins[1]]; op = p.get(0, 0)
+            if b.size == 1: b = b.reshape(())
+            y = (a + b if op == 0 else a * b if op == 2 else a / b if op == 3 else None).astype(dt)
+        elif t == 'Clip': y = np.clip(a, dt(p[0]), dt(p[1]))
+        elif t == 'ReLU': y = np.maximum(a, dt(0))
+        elif t == 'Permute': assert p[0] == 3; y = np.ascontiguousarray(a.transpose(1, 2, 0))
+        elif t == 'Flatten': y = a.reshape(-1)
+        elif t == 'Concat':
+            xs = [blobs[i] for i in ins]
+            y = np.concatenate(xs, 0) if p.get(0, 0) == 0 else np.concatenate(xs, 1)
+        elif t == 'Reshape': y = a.reshape(-1, p[0])
+        elif t == 'Softmax':
+            e = np.exp(a - a.max(1, keepdims=True)).astype(dt); y = (e / e.sum(1, keepdims=True)).astype(dt)
+        elif t == 'PriorBox':
+            y = prior_box(a.shape[1], a.shape[2], TARGET, p)
+        elif t == 'DetectionOutput':
+            y = detection_output(blobs[ins[0]].astype(np.float32), blobs[ins[1]].astype(np.float32), blobs[ins[2]], p)
+        else:
+            raise NotImplementedError(t)
+        blobs[outs[0]] = y
+    return blobs['detection_out'], blobs
+
+
+def detect(layers, W, img_u8, det_th=0.90, dyn_th=0.01):
+    """Detector2D::detect: returns (objects [(id, prob, x, y, w, h)], person boxes for mapping, person boxes for the dynamic-feature mask)."""
+    img_h, img_w = img_u8.shape[:2]
+    out, _ = forward(layers, W, preprocess(img_u8))
+    objs, map_boxes, rm_boxes = [], [], []
+    T = np.float32(TARGET)
+    def cl(v): return min(max(np.float32(v * T), np.float32(0)), np.float32(TARGET - 1)) / T
+    for v in out:
+        if v[1] > np.float32(det_th) or (v[1] > np.float32(dyn_th) and int(v[0]) == 15):
+            x1 = cl(v[2]) * img_w; y1 = cl(v[3]) * img_h; x2 = cl(v[4]) * img_w; y2 = cl(v[5]) * img_h
+            rect = (np.float32(x1), np.float32(y1), np.float32(x2 - x1), np.float32(y2 - y1))
+            if int(v[0]) == 15:
+                map_boxes.append(rect)
+                if v[1] > np.float32(0.2): rm_boxes.append(rect)
+            else:
+                objs.append((int(v[0]), float(v[1]), *rect))
+    return objs, map_boxes, rm_boxes
+
+
+# ---------------------------------------------------------------- dynamic-feature mask predicate
+def dynamic_mask(kps_xy, prev_xy, F, boxes, have_dynamic, nfeatures=1000):
+    """Frame.cc:556-604 keep/erase decision per keypoint.  Returns (keep[N] bool, restored flag).
+    CheckEpiLineDistToRmDynamicPoint (:613-627, fp64) with threshold 0.2 inside a person box (isInDynamicRegion :629-652, strict),
+    1.0 elsewhere; if a person is present and fewer than 0.1*nFeatures survive, all keypoints are restored (:599-604)."""
+    F = np.asarray(F, np.float64)
+    keep = np.zeros(len(kps_xy), bool)
+    for i, ((x, y), (px, py)) in enumerate(zip(kps_xy, prev_xy)):
+        x = np.float32(x); y = np.float32(y)
+        a = x * F[0, 0] + y * F[0, 1] + F[0, 2]; b = x * F[1, 0] + y * F[1, 1] + F[1, 2]; c = x * F[2, 0] + y * F[2, 1] + F[2, 2]
+        dist = abs(a * np.float32(px) + b * np.float32(py) + c) / np.sqrt(a * a + b * b)
+        inbox = have_dynamic and any((x > bx and x < bx + bw and y > by and y < by + bh) for (bx, by, bw, bh) in boxes)
+        keep[i] = dist < (0.2 if inbox else 1.0)
+    restored = bool(have_dynamic and keep.sum() < nfeatures * 0.1)
+    return keep, restored

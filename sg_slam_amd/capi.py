@@ -25,6 +25,23 @@ class BaStats(C.Structure):
                 ('chi2_first', C.c_double), ('chi2_second', C.c_double)]
 
 
+SGX_DET_MAX = 100
+
+
+class Detection(C.Structure):
+    _fields_ = [(k, C.c_float) for k in ('label', 'score', 'xmin', 'ymin', 'xmax', 'ymax')]
+
+
+class Object2D(C.Structure):
+    _fields_ = [('id', C.c_int32)] + [(k, C.c_float) for k in ('prob', 'x', 'y', 'w', 'h')]
+
+
+class DetResult(C.Structure):
+    _fields_ = [('n_raw', C.c_int32), ('raw', Detection * SGX_DET_MAX), ('n_objects', C.c_int32), ('objects', Object2D * SGX_DET_MAX),
+                ('have_dynamic_for_mapping', C.c_int32), ('have_dynamic_for_rm_feature', C.c_int32),
+                ('n_map_boxes', C.c_int32), ('map_boxes', Object2D * SGX_DET_MAX), ('n_rm_boxes', C.c_int32), ('rm_boxes', Object2D * SGX_DET_MAX)]
+
+
 class OrbConfig(C.Structure):
     _fields_ = [('nfeatures', C.c_int32), ('scale_factor', C.c_float), ('nlevels', C.c_int32),
                 ('ini_th_fast', C.c_int32), ('min_th_fast', C.c_int32), ('width', C.c_int32),
@@ -42,6 +59,8 @@ SYMBOLS = [
     'sgx_frame_stereo_from_rgbd_batch_dev', 'sgx_frame_unproject_batch_dev',
     'sgx_pose_optimization_batch_dev', 'sgx_pose_optimization', 'sgx_frame_motion_model_batch_dev',
     'sgx_local_bundle_adjustment',
+    'sgx_det_create', 'sgx_det_destroy', 'sgx_det_info', 'sgx_det_detect', 'sgx_det_forward_batch_dev', 'sgx_det_debug_read_blob',
+    'sgx_dynamic_mask_batch_dev',
 ]
 
 
@@ -93,6 +112,13 @@ class SgxLib:
         d.sgx_pose_optimization.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.c_int, C.POINTER(Camera), vp, vp, vp]
         d.sgx_frame_motion_model_batch_dev.argtypes = [C.c_int, vp, vp, vp, vp, vp]
         d.sgx_local_bundle_adjustment.argtypes = [C.POINTER(BaProblem), C.POINTER(Camera), vp, vp, C.POINTER(BaStats)]
+        d.sgx_det_create.argtypes = [C.c_char_p, vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.POINTER(vp)]
+        d.sgx_det_destroy.argtypes = [vp]; d.sgx_det_destroy.restype = None
+        d.sgx_det_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+        d.sgx_det_detect.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(DetResult)]
+        d.sgx_det_forward_batch_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp), vp]
+        d.sgx_det_debug_read_blob.argtypes = [vp, C.c_char_p, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
+        d.sgx_dynamic_mask_batch_dev.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp]
 
     def version(self):
         return self.dll.sgx_version().decode()

@@ -1,0 +1,380 @@
+// sgx_det.cpp — host side of the 2-D detector C-ABI: ncnn .param/.bin loader, shape inference, execution plan
+// (with conv+activation and Permute/Flatten/Concat fusion), batched forward, DetectionOutput + Detector2D::detect
+// post-processing, dynamic-feature mask.  Reference: src/sg-slam/src/Detector2D.cc:16-89, src/sg-slam/src/Frame.cc:556-604.
+#include "sgx_det_kernels.h"
+#include "sgx_prof.h"
+#include "../../include/sgx.h"
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#define SGX_CHECK_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
+    fprintf(stderr, "sgx: HIP error %d (%s) at %s:%d\n", (int)_e, hipGetErrorString(_e), __FILE__, __LINE__); return SGX_ERR_DEVICE; } } while (0)
+
+namespace {
+struct Layer {
+    std::string type, name;
+    std::vector<std::string> ins, outs;
+    std::map<int, double> p;
+    std::map<int, std::vector<float>> pa;
+    int geti(int k, int d) const { auto it = p.find(k); return it == p.end() ? d : (int)it->second; }
+    float getf(int k, float d) const { auto it = p.find(k); return it == p.end() ? d : (float)it->second; }
+};
+struct Blob { int c = 0, h = 0, w = 0; size_t n = 0; float *d = nullptr; bool scalar = false; float sval = 0.f; int alias = -1; };
+enum OpKind { OP_PW, OP_KXK, OP_BINARY, OP_UNARY, OP_PERMUTE_INTO, OP_COPY_INTO, OP_SOFTMAX };
+struct Op {
+    OpKind kind; int in0 = -1, in1 = -1, out = -1;
+    int inc = 0, outc = 0, H = 0, W = 0, Ho = 0, Wo = 0, k = 1, stride = 1, pad = 0, depthwise = 0, act = 0; float lo = 0, hi = 0;
+    float *wt = nullptr, *bias = nullptr; int bop = 0; int off = 0; int rows = 0, C = 0;
+};
+}  // namespace
+
+struct sgx_det {
+    int T = 300, max_batch = 1, W = 0, H = 0;
+    float det_th = 0.9f, dyn_th = 0.01f;
+    std::vector<Layer> layers;
+    std::map<std::string, int> blob_id;
+    std::vector<Blob> blobs;
+    std::vector<Op> ops;
+    std::vector<void *> dev;
+    std::vector<float> priors;          // 2 x (num_priors*4): boxes, variances (PriorBox is input-independent: host constant)
+    int num_priors = 0, num_class = 21, nms_top_k = 300, keep_top_k = 100; float nms_th = 0.45f, conf_th = 0.01f, dvar[4] = {0.1f, 0.1f, 0.2f, 0.2f};
+    int loc_blob = -1, conf_blob = -1;
+    SgxDetTab *d_xt = nullptr, *d_yt = nullptr; uint8_t *d_img = nullptr;
+    double gmac = 0;
+    ~sgx_det() { for (void *p : dev) (void)hipFree(p); }
+    template <class Tp> int alloc(Tp **p, size_t n) { void *q = nullptr; if (hipMalloc(&q, (n ? n : 1) * sizeof(Tp)) != hipSuccess) return SGX_ERR_NOMEM; dev.push_back(q); *p = (Tp *)q; return SGX_OK; }
+};
+
+static int parse_param(const char *text, std::vector<Layer> &layers)
+{
+    std::istringstream is(text);
+    std::string line;
+    if (!std::getline(is, line) || atoi(line.c_str()) != 7767517) return SGX_ERR_INVALID;
+    if (!std::getline(is, line)) return SGX_ERR_INVALID;
+    while (std::getline(is, line)) {
+        std::istringstream ls(line);
+        Layer L; int nin = 0, nout = 0;
+        if (!(ls >> L.type >> L.name >> nin >> nout)) continue;
+        for (int i = 0; i < nin; i++) { std::string s; ls >> s; L.ins.push_back(s); }
+        for (int i = 0; i < nout; i++) { std::string s; ls >> s; L.outs.push_back(s); }
+        std::string kv;
+        while (ls >> kv) {
+            const size_t eq = kv.find('=');
+            if (eq == std::string::npos) continue;
+            const int k = atoi(kv.substr(0, eq).c_str());
+            const std::string v = kv.substr(eq + 1);
+            if (k <= -23300) {
+                std::vector<float> arr; std::istringstream vs(v); std::string tok; bool first = true;
+                while (std::getline(vs, tok, ',')) { if (first) { first = false; continue; } arr.push_back((float)atof(tok.c_str())); }
+                L.pa[-k - 23300] = arr;
+            } else L.p[k] = atof(v.c_str());
+        }
+        layers.push_back(L);
+    }
+    return layers.empty() ? SGX_ERR_INVALID : SGX_OK;
+}
+
+static void build_tab(int s, int d, std::vector<SgxDetTab> &t)
+{   // ncnn resize_bilinear (mat_pixel_resize.cpp): clamp to (s-2, 1.0) at the far edge
+    t.resize(d);
+    const double scale = (double)s / d;
+    for (int i = 0; i < d; i++) {
+        float f = (float)((i + 0.5) * scale - 0.5);
+        int si = (int)floorf(f); f -= si;
+        if (si < 0) { si = 0; f = 0.f; }
+        if (si >= s - 1) { si = s - 2; f = 1.f; }
+        t[i].o = (short)si; t[i].a0 = (short)lrintf((1.f - f) * 2048); t[i].a1 = (short)lrintf(f * 2048); t[i].pad = 0;
+    }
+}
+
+extern "C" void sgx_det_destroy(sgx_det *h) { delete h; }
+
+extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bin_bytes, int width, int height, int max_batch,
+                              float detection_confidence_threshold, float dynamic_detection_confidence_threshold, sgx_det **out)
+{
+    if (!param_text || !bin || !out || width < 8 || height < 8 || max_batch < 1) return SGX_ERR_INVALID;
+    sgx_det *h = new sgx_det();
+    h->W = width; h->H = height; h->max_batch = max_batch; h->det_th = detection_confidence_threshold; h->dyn_th = dynamic_detection_confidence_threshold;
+    int rc = parse_param(param_text, h->layers);
+    if (rc != SGX_OK) { delete h; return rc; }
+    const int B = max_batch, T = h->T;
+    const uint8_t *bp = (const uint8_t *)bin; size_t bo = 0;
+    auto blob = [&](const std::string &n) -> int { auto it = h->blob_id.find(n); if (it != h->blob_id.end()) return it->second; h->blob_id[n] = (int)h->blobs.size(); h->blobs.push_back(Blob()); return (int)h->blobs.size() - 1; };
+    auto resolve = [&](int id) { while (h->blobs[id].alias >= 0) id = h->blobs[id].alias; return id; };
+    auto consumers = [&](const std::string &name, std::vector<const Layer *> &outv) { outv.clear(); for (const Layer &L : h->layers) for (const std::string &i : L.ins) if (i == name) outv.push_back(&L); };
+#define FAIL(code) do { delete h; return (code); } while (0)
+    std::map<std::string, std::pair<int, int>> into;       // conv output name -> (concat blob id, offset): fused Permute+Flatten+Concat
+    std::map<std::string, int> concat_off;                 // flatten output name -> offset inside its concat
+    std::vector<float> prior_boxes, prior_vars;
+    for (size_t li = 0; li < h->layers.size(); li++) {
+        const Layer &L = h->layers[li];
+        if (L.type == "Input") { Blob &b = h->blobs[blob(L.outs[0])]; b.c = 3; b.h = T; b.w = T; b.n = (size_t)3 * T * T; if (h->alloc(&b.d, b.n * B)) FAIL(SGX_ERR_NOMEM); continue; }
+        if (L.type == "MemoryData") {
+            const int n = L.geti(0, 0) * std::max(L.geti(1, 1), 1) * std::max(L.geti(2, 1), 1);
+            if (n != 1 || bo + 4 > bin_bytes) FAIL(SGX_ERR_UNSUPPORTED);
+            Blob &b = h->blobs[blob(L.outs[0])]; b.scalar = true; memcpy(&b.sval, bp + bo, 4); bo += 4; b.n = 1; continue;
+        }
+        if (L.type == "Split") { const int src = blob(L.ins[0]); for (const std::string &o : L.outs) { const int id = blob(o); h->blobs[id] = h->blobs[resolve(src)]; h->blobs[id].alias = resolve(src); } continue; }
+        const int in0 = resolve(blob(L.ins[0]));
+        const Blob A = h->blobs[in0];
+        if (L.type == "Convolution" || L.type == "ConvolutionDepthWise") {
+            Op op; const int outc = L.geti(0, 0), k = L.geti(1, 1), stride = L.geti(3, 1), pad = L.geti(4, 0), wsize = L.geti(6, 0), group = L.geti(7, 1);
+            const int inc = A.c;
+            if (L.geti(2, 1) != 1 || (group != 1 && group != inc) || wsize != outc * (inc / group) * k * k) FAIL(SGX_ERR_UNSUPPORTED);
+            if (bo + 4 + (size_t)wsize * 4 + (L.geti(5, 0) ? (size_t)outc * 4 : 0) > bin_bytes) FAIL(SGX_ERR_INVALID);
+            uint32_t flag; memcpy(&flag, bp + bo, 4); bo += 4;
+            if (flag != 0) FAIL(SGX_ERR_UNSUPPORTED);                       // raw fp32 weights only
+            if (h->alloc(&op.wt, wsize) || h->alloc(&op.bias, outc)) FAIL(SGX_ERR_NOMEM);
+            if (hipMemcpy(op.wt, bp + bo, (size_t)wsize * 4, hipMemcpyHostToDevice) != hipSuccess) FAIL(SGX_ERR_DEVICE);
+            bo += (size_t)wsize * 4;
+            std::vector<float> bz(outc, 0.f);
+            if (L.geti(5, 0)) { memcpy(bz.data(), bp + bo, (size_t)outc * 4); bo += (size_t)outc * 4; }
+            if (hipMemcpy(op.bias, bz.data(), (size_t)outc * 4, hipMemcpyHostToDevice) != hipSuccess) FAIL(SGX_ERR_DEVICE);
+            op.inc = inc; op.outc = outc; op.H = A.h; op.W = A.w; op.k = k; op.stride = stride; op.pad = pad; op.depthwise = group != 1;
+            op.Ho = (A.h + 2 * pad - k) / stride + 1; op.Wo = (A.w + 2 * pad - k) / stride + 1;
+            op.kind = (k == 1 && group == 1 && stride == 1 && pad == 0) ? OP_PW : OP_KXK;
+            op.in0 = in0;
+            h->gmac += (double)op.Ho * op.Wo * wsize * 1e-9;
+            // peephole: a ReLU / Clip that is the only consumer of this convolution is folded into its epilogue
+            std::string outname = L.outs[0];
+            std::vector<const Layer *> cons; consumers(outname, cons);
+            if (cons.size() == 1 && (cons[0]->type == "ReLU" || cons[0]->type == "Clip")) {
+                op.act = cons[0]->type == "ReLU" ? SGX_ACT_RELU : SGX_ACT_CLIP; op.lo = cons[0]->getf(0, 0.f); op.hi = cons[0]->getf(1, 0.f);
+                const int oid = blob(cons[0]->outs[0]); Blob &ob = h->blobs[oid]; ob.c = outc; ob.h = op.Ho; ob.w = op.Wo; ob.n = (size_t)outc * op.Ho * op.Wo;
+                if (h->alloc(&ob.d, ob.n * B)) FAIL(SGX_ERR_NOMEM);
+                op.out = oid;
+                const int cid = blob(outname); h->blobs[cid] = ob; h->blobs[cid].alias = oid;
+            } else {
+                const int oid = blob(outname); Blob &ob = h->blobs[oid]; ob.c = outc; ob.h = op.Ho; ob.w = op.Wo; ob.n = (size_t)outc * op.Ho * op.Wo;
+                if (h->alloc(&ob.d, ob.n * B)) FAIL(SGX_ERR_NOMEM);
+                op.out = oid;
+            }
+            h->ops.push_back(op);
+            continue;
+        }
+        if (L.type == "ReLU" || L.type == "Clip") {
+            const int oid = blob(L.outs[0]);
+            if (h->blobs[oid].alias >= 0 || h->blobs[oid].d) continue;        // already produced by a fused convolution epilogue
+            Op op; op.kind = OP_UNARY; op.in0 = in0; op.act = L.type == "ReLU" ? SGX_ACT_RELU : SGX_ACT_CLIP; op.lo = L.getf(0, 0.f); op.hi = L.getf(1, 0.f);
+            Blob &ob = h->blobs[oid]; ob = A; ob.alias = -1; if (h->alloc(&ob.d, ob.n * B)) FAIL(SGX_ERR_NOMEM);
+            op.out = oid; h->ops.push_back(op); continue;
+        }
+        if (L.type == "BinaryOp") {
+            const int in1 = resolve(blob(L.ins[1]));
+            Op op; op.kind = OP_BINARY; op.in0 = in0; op.in1 = in1; op.bop = L.geti(0, 0);
+            if (op.bop != 0 && op.bop != 2 && op.bop != 3) FAIL(SGX_ERR_UNSUPPORTED);
+            if (!h->blobs[in1].scalar && h->blobs[in1].n != A.n) FAIL(SGX_ERR_UNSUPPORTED);
+            const int oid = blob(L.outs[0]); Blob &ob = h->blobs[oid]; ob = A; ob.alias = -1; if (h->alloc(&ob.d, ob.n * B)) FAIL(SGX_ERR_NOMEM);
+            op.out = oid; h->ops.push_back(op); continue;
+        }
+        const int raw_in = blob(L.ins[0]);                                    // unresolved: keeps view layers (Permute) visible in the alias chain
+        if (L.type == "Permute") { if (L.geti(0, 0) != 3) FAIL(SGX_ERR_UNSUPPORTED); const int oid = blob(L.outs[0]); h->blobs[oid] = A; h->blobs[oid].alias = raw_in; h->blobs[oid].sval = 1.f; /* marks "HWC view of" */ continue; }
+        if (L.type == "Flatten") { const int oid = blob(L.outs[0]); h->blobs[oid] = A; h->blobs[oid].sval = 0.f; h->blobs[oid].alias = raw_in; continue; }
+        if (L.type == "PriorBox") {
+            const std::vector<float> mins = L.pa.count(0) ? L.pa.at(0) : std::vector<float>(), maxs = L.pa.count(1) ? L.pa.at(1) : std::vector<float>(), ars = L.pa.count(2) ? L.pa.at(2) : std::vector<float>();
+            const int flip = L.geti(7, 1), clip = L.geti(8, 0); const float offset = L.getf(13, 0.f);
+            const float step_w = (float)T / (float)A.w, step_h = (float)T / (float)A.h;
+            const float var[4] = { L.getf(3, .1f), L.getf(4, .1f), L.getf(5, .2f), L.getf(6, .2f) };
+            auto add = [&](float cx, float cy, float bw, float bh) {
+                float bx[4] = { (cx - bw * 0.5f) / T, (cy - bh * 0.5f) / T, (cx + bw * 0.5f) / T, (cy + bh * 0.5f) / T };
+                for (int q = 0; q < 4; q++) { prior_boxes.push_back(clip ? std::min(std::max(bx[q], 0.f), 1.f) : bx[q]); prior_vars.push_back(var[q]); }
+            };
+            for (int i = 0; i < A.h; i++) for (int j = 0; j < A.w; j++) {
+                const float cx = ((float)j + offset) * step_w, cy = ((float)i + offset) * step_h;
+                for (size_t kk = 0; kk < mins.size(); kk++) {
+                    const float ms = mins[kk]; add(cx, cy, ms, ms);
+                    if (!maxs.empty()) { const float s = sqrtf(ms * maxs[kk]); add(cx, cy, s, s); }
+                    for (float ar : ars) { const float sq = sqrtf(ar); add(cx, cy, ms * sq, ms / sq); if (flip) add(cx, cy, ms / sq, ms * sq); }
+                }
+            }
+            blob(L.outs[0]); continue;
+        }
+        if (L.type == "Concat") {
+            if (L.name == "mbox_priorbox") { blob(L.outs[0]); continue; }
+            size_t total = 0; for (const std::string &i : L.ins) total += h->blobs[resolve(blob(i))].n;
+            const int oid = blob(L.outs[0]); Blob &ob = h->blobs[oid]; ob.c = 1; ob.h = 1; ob.w = (int)total; ob.n = total; if (h->alloc(&ob.d, ob.n * B)) FAIL(SGX_ERR_NOMEM);
+            int off = 0;
+            for (const std::string &i : L.ins) {
+                // input is Flatten(Permute(conv)) : find whether a Permute sits in the alias chain
+                int id = blob(i); bool hwc = false; while (h->blobs[id].alias >= 0) { if (h->blobs[id].sval == 1.f) hwc = true; id = h->blobs[id].alias; }
+                Op op; op.kind = hwc ? OP_PERMUTE_INTO : OP_COPY_INTO; op.in0 = id; op.out = oid; op.off = off; op.C = h->blobs[id].c; op.rows = h->blobs[id].h * h->blobs[id].w;
+                h->ops.push_back(op); off += (int)h->blobs[id].n;
+            }
+            continue;
+        }
+        if (L.type == "Reshape") { const int oid = blob(L.outs[0]); h->blobs[oid] = A; h->blobs[oid].alias = raw_in; h->blobs[oid].w = L.geti(0, 1); h->blobs[oid].h = (int)(A.n / L.geti(0, 1)); continue; }
+        if (L.type == "Softmax") {
+            Op op; op.kind = OP_SOFTMAX; op.in0 = in0; op.C = h->blobs[blob(L.ins[0])].w; op.rows = (int)(A.n / op.C);
+            const int oid = blob(L.outs[0]); Blob &ob = h->blobs[oid]; ob = A; ob.alias = -1; if (h->alloc(&ob.d, ob.n * B)) FAIL(SGX_ERR_NOMEM);
+            op.out = oid; h->ops.push_back(op); continue;
+        }
+        if (L.type == "DetectionOutput") {
+            h->loc_blob = resolve(blob(L.ins[0])); h->conf_blob = resolve(blob(L.ins[1]));
+            h->num_class = L.geti(0, 21); h->nms_th = L.getf(1, 0.45f); h->nms_top_k = L.geti(2, 300); h->keep_top_k = L.geti(3, 100); h->conf_th = L.getf(4, 0.01f);
+            h->dvar[0] = L.getf(5, .1f); h->dvar[1] = L.getf(6, .1f); h->dvar[2] = L.getf(7, .2f); h->dvar[3] = L.getf(8, .2f);
+            continue;
+        }
+        FAIL(SGX_ERR_UNSUPPORTED);
+    }
+#undef FAIL
+    if (h->loc_blob < 0 || h->conf_blob < 0) { delete h; return SGX_ERR_INVALID; }
+    h->num_priors = (int)prior_boxes.size() / 4;
+    h->priors = prior_boxes; h->priors.insert(h->priors.end(), prior_vars.begin(), prior_vars.end());
+    if ((size_t)h->num_priors * 4 != h->blobs[h->loc_blob].n || (size_t)h->num_priors * h->num_class != h->blobs[h->conf_blob].n) { delete h; return SGX_ERR_INVALID; }
+    std::vector<SgxDetTab> xt, yt; build_tab(width, T, xt); build_tab(height, T, yt);
+    if (h->alloc(&h->d_xt, T) || h->alloc(&h->d_yt, T) || h->alloc(&h->d_img, (size_t)B * width * height * 3)) { delete h; return SGX_ERR_NOMEM; }
+    if (hipMemcpy(h->d_xt, xt.data(), sizeof(SgxDetTab) * T, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(h->d_yt, yt.data(), sizeof(SgxDetTab) * T, hipMemcpyHostToDevice) != hipSuccess) { delete h; return SGX_ERR_DEVICE; }
+    *out = h;
+    return SGX_OK;
+}
+
+// Batched forward from device-resident interleaved 3-channel u8 images (B x H x W x 3, row pitch in bytes).
+// Leaves loc (num_priors*4) and softmax conf (num_priors*num_class) per image in device memory; returns their pointers.
+extern "C" int sgx_det_forward_batch_dev(sgx_det *h, const uint8_t *d_img, int pitch, int batch, const float **d_loc, const float **d_conf, void *stream_)
+{
+    if (!h || !d_img || batch < 1 || batch > h->max_batch || pitch < 3 * h->W) return SGX_ERR_INVALID;
+    sgx_stream_t st = (sgx_stream_t)stream_;
+    const int T = h->T;
+    const int in_id = h->blob_id.at("input");
+    SGX_LAUNCH(k_det_preprocess, dim3((T * T + 255) / 256, batch), dim3(256), st, batch, d_img, h->W, h->H, pitch, h->d_xt, h->d_yt, T, 123.675f, 116.28f, 103.53f, h->blobs[in_id].d);
+    for (const Op &op : h->ops) {
+        const Blob &A = h->blobs[op.in0]; const Blob &O = h->blobs[op.out];
+        switch (op.kind) {
+        case OP_PW: {
+            const int N = op.H * op.W;
+            SGX_LAUNCH(k_conv_pw, dim3((N + 63) / 64, (op.outc + 63) / 64, batch), dim3(256), st, op.inc, op.outc, N, A.d, A.n, op.wt, op.bias, O.d, O.n, op.act, op.lo, op.hi, 0, 0);
+            break; }
+        case OP_KXK:
+            SGX_LAUNCH(k_conv_kxk, dim3((op.Ho * op.Wo + 255) / 256, op.outc, batch), dim3(256), st, op.inc, op.outc, op.H, op.W, op.Ho, op.Wo, op.k, op.stride, op.pad, op.depthwise,
+                       A.d, A.n, op.wt, op.bias, O.d, O.n, op.act, op.lo, op.hi);
+            break;
+        case OP_BINARY: {
+            const Blob &Bb = h->blobs[op.in1];
+            if (batch == h->max_batch || true) {
+                // per-image pitch equals blob size (dense), so the batch is one flat range
+                const size_t n = A.n * batch; const int g = (int)std::min<size_t>((n + 255) / 256, 8192);
+                SGX_LAUNCH(k_binary, dim3(g), dim3(256), st, n, op.bop, A.d, Bb.scalar ? A.d : Bb.d, Bb.scalar ? 1 : 0, Bb.sval, O.d);
+            }
+            break; }
+        case OP_UNARY: { const size_t n = A.n * batch; const int g = (int)std::min<size_t>((n + 255) / 256, 8192); SGX_LAUNCH(k_unary, dim3(g), dim3(256), st, n, op.act, op.lo, op.hi, A.d, O.d); break; }
+        case OP_PERMUTE_INTO: SGX_LAUNCH(k_permute_hwc_into, dim3((op.C * op.rows + 255) / 256, batch), dim3(256), st, op.C, op.rows, A.d, A.n, O.d, O.n, op.off); break;
+        case OP_COPY_INTO: SGX_LAUNCH(k_copy_into, dim3(((int)A.n + 255) / 256, batch), dim3(256), st, (int)A.n, A.d, A.n, O.d, O.n, op.off); break;
+        case OP_SOFTMAX: SGX_LAUNCH(k_softmax_rows, dim3((op.rows + 255) / 256, batch), dim3(256), st, op.rows, op.C, A.d, A.n, O.d, O.n); break;
+        }
+    }
+    SGX_CHECK_HIP(hipGetLastError());
+    if (d_loc) *d_loc = h->blobs[h->loc_blob].d;
+    if (d_conf) *d_conf = h->blobs[h->conf_blob].d;
+    return SGX_OK;
+}
+
+extern "C" int sgx_det_info(const sgx_det *h, int32_t *num_priors, int32_t *num_class, int32_t *num_kernels, double *gmac)
+{
+    if (!h) return SGX_ERR_INVALID;
+    if (num_priors) *num_priors = h->num_priors; if (num_class) *num_class = h->num_class; if (num_kernels) *num_kernels = (int)h->ops.size() + 1; if (gmac) *gmac = h->gmac;
+    return SGX_OK;
+}
+
+// test tap: copy one image's blob (by ncnn blob name) to the host; returns element count in *n
+extern "C" int sgx_det_debug_read_blob(sgx_det *h, const char *name, int image, float *dst, int cap, int *n)
+{
+    if (!h || !name || !n) return SGX_ERR_INVALID;
+    auto it = h->blob_id.find(name); if (it == h->blob_id.end()) return SGX_ERR_INVALID;
+    int id = it->second; while (h->blobs[id].alias >= 0) id = h->blobs[id].alias;
+    const Blob &b = h->blobs[id];
+    if (!b.d || image < 0 || image >= h->max_batch) return SGX_ERR_INVALID;
+    *n = (int)b.n;
+    if (dst && cap >= (int)b.n) SGX_CHECK_HIP(hipMemcpy(dst, b.d + (size_t)image * b.n, b.n * 4, hipMemcpyDeviceToHost));
+    return SGX_OK;
+}
+
+namespace { struct Cand { float score; int idx; }; }
+
+// ncnn DetectionOutput (decode + per-class NMS + keep_top_k) on the host, then Detector2D::detect's filtering (Detector2D.cc:53-88)
+static void detection_output(const sgx_det *h, const float *loc, const float *conf, std::vector<sgx_detection> &rows)
+{
+    const int n = h->num_priors, nc = h->num_class;
+    const float *pb = h->priors.data();
+    std::vector<float> box((size_t)n * 4);
+    for (int i = 0; i < n; i++) {
+        const float *p = pb + 4 * i, *l = loc + 4 * i;
+        const float pw = p[2] - p[0], ph = p[3] - p[1], pcx = (p[0] + p[2]) * 0.5f, pcy = (p[1] + p[3]) * 0.5f;
+        const float cx = h->dvar[0] * l[0] * pw + pcx, cy = h->dvar[1] * l[1] * ph + pcy;
+        const float w = expf(h->dvar[2] * l[2]) * pw, hh = expf(h->dvar[3] * l[3]) * ph;
+        box[4 * i] = cx - w * 0.5f; box[4 * i + 1] = cy - hh * 0.5f; box[4 * i + 2] = cx + w * 0.5f; box[4 * i + 3] = cy + hh * 0.5f;
+    }
+    std::vector<sgx_detection> all;
+    std::vector<Cand> cand; std::vector<int> keep;
+    for (int c = 1; c < nc; c++) {
+        cand.clear();
+        for (int i = 0; i < n; i++) { const float s = conf[(size_t)i * nc + c]; if (s > h->conf_th) cand.push_back(Cand{s, i}); }
+        std::stable_sort(cand.begin(), cand.end(), [](const Cand &a, const Cand &b) { return a.score > b.score; });
+        if ((int)cand.size() > h->nms_top_k) cand.resize(h->nms_top_k);
+        keep.clear();
+        for (const Cand &cd : cand) {
+            const float *a = &box[4 * (size_t)cd.idx]; bool ok = true;
+            for (int kidx : keep) {
+                const float *b = &box[4 * (size_t)kidx];
+                const float iw = std::min(a[2], b[2]) - std::max(a[0], b[0]), ih = std::min(a[3], b[3]) - std::max(a[1], b[1]);
+                const float inter = (iw > 0 && ih > 0) ? iw * ih : 0.f;
+                const float uni = (a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - inter;
+                if (inter / uni > h->nms_th) { ok = false; break; }
+            }
+            if (ok) { keep.push_back(cd.idx); sgx_detection d; d.label = (float)c; d.score = cd.score; memcpy(&d.xmin, &box[4 * (size_t)cd.idx], 16); all.push_back(d); }
+        }
+    }
+    std::stable_sort(all.begin(), all.end(), [](const sgx_detection &a, const sgx_detection &b) { return a.score > b.score; });
+    if ((int)all.size() > h->keep_top_k) all.resize(h->keep_top_k);
+    rows = all;
+}
+
+// Detector2D::detect for `batch` host images (interleaved 3-channel u8, as cv::Mat bgr.data).  Per image: raw detection_out
+// rows (<= keep_top_k), the filtered objects and the "person" rectangles for mapping / for the dynamic-feature mask.
+extern "C" int sgx_det_detect(sgx_det *h, const uint8_t *images, int pitch, int batch, sgx_det_result *results)
+{
+    if (!h || !images || !results || batch < 1 || batch > h->max_batch || pitch < 3 * h->W) return SGX_ERR_INVALID;
+    for (int b = 0; b < batch; b++)
+        for (int y = 0; y < h->H; y++)
+            SGX_CHECK_HIP(hipMemcpyAsync(h->d_img + ((size_t)b * h->H + y) * 3 * h->W, images + ((size_t)b * h->H + y) * pitch, (size_t)3 * h->W, hipMemcpyHostToDevice, 0));
+    const float *dl = nullptr, *dc = nullptr;
+    int rc = sgx_det_forward_batch_dev(h, h->d_img, 3 * h->W, batch, &dl, &dc, nullptr);
+    if (rc != SGX_OK) return rc;
+    const size_t nl = (size_t)h->num_priors * 4, ncf = (size_t)h->num_priors * h->num_class;
+    std::vector<float> loc(nl * batch), conf(ncf * batch);
+    SGX_CHECK_HIP(hipMemcpy(loc.data(), dl, nl * batch * 4, hipMemcpyDeviceToHost));
+    SGX_CHECK_HIP(hipMemcpy(conf.data(), dc, ncf * batch * 4, hipMemcpyDeviceToHost));
+    const float T = (float)h->T;
+    for (int b = 0; b < batch; b++) {
+        sgx_det_result &R = results[b]; memset(&R, 0, sizeof R);
+        std::vector<sgx_detection> rows; detection_output(h, loc.data() + nl * b, conf.data() + ncf * b, rows);
+        R.n_raw = (int)rows.size();
+        for (int i = 0; i < R.n_raw && i < SGX_DET_MAX; i++) R.raw[i] = rows[i];
+        auto cl = [&](float v) { return std::min(std::max(v * T, 0.f), (float)(h->T - 1)) / T; };
+        for (const sgx_detection &v : rows) {
+            if (v.score > h->det_th || (v.score > h->dyn_th && (int)v.label == 15)) {
+                const float x1 = cl(v.xmin) * h->W, y1 = cl(v.ymin) * h->H, x2 = cl(v.xmax) * h->W, y2 = cl(v.ymax) * h->H;
+                sgx_object2d o; o.id = (int)v.label; o.prob = v.score; o.x = x1; o.y = y1; o.w = x2 - x1; o.h = y2 - y1;
+                if (o.id == 15) {
+                    R.have_dynamic_for_mapping = 1; if (R.n_map_boxes < SGX_DET_MAX) R.map_boxes[R.n_map_boxes++] = o;
+                    if (o.prob > 0.2f) { R.have_dynamic_for_rm_feature = 1; if (R.n_rm_boxes < SGX_DET_MAX) R.rm_boxes[R.n_rm_boxes++] = o; }
+                } else if (R.n_objects < SGX_DET_MAX) R.objects[R.n_objects++] = o;
+            }
+        }
+    }
+    return SGX_OK;
+}
+
+extern "C" int sgx_dynamic_mask_batch_dev(int batch, int cap, const sgx_keypoint *d_keys, const int32_t *d_n, const float *d_prev_xy, const double *d_F,
+                                          const float *d_boxes, const int32_t *d_nboxes, int max_boxes, uint8_t *d_keep, void *stream)
+{
+    if (batch < 1 || cap < 1 || !d_keys || !d_n || !d_prev_xy || !d_F || !d_boxes || !d_nboxes || !d_keep || max_boxes < 0) return SGX_ERR_INVALID;
+    SGX_LAUNCH(k_dynamic_mask, dim3((cap + 255) / 256, batch), dim3(256), (sgx_stream_t)stream, cap, (const uint8_t *)d_keys, d_n, d_prev_xy, d_F, d_boxes, d_nboxes, max_boxes, d_keep);
+    SGX_CHECK_HIP(hipGetLastError());
+    return SGX_OK;
+}

@@ -1,0 +1,64 @@
+"""Detector2D — host-side mirror of ORB_SLAM2::Detector2D (reference: src/sg-slam/include/Detector2D.h:45-67,
+src/sg-slam/src/Detector2D.cc:16-89) over the C-ABI.  detect(bgr) fills the same public members the reference's
+Frame reads (Frame.cc:482-500): mvObjects2D, mbHaveDynamicObjectFor{Mapping,RmDynamicFeature},
+mvPotentialDynamicBorderFor{Mapping,RmDynamicFeature}."""
+import ctypes as C
+import numpy as np
+from .capi import DetResult, _vp
+from ._lib import load
+
+CLASS_NAMES = ["background", "aeroplane", "bicycle", "bird", "boat", "bottle", "bus", "car", "cat", "chair", "cow", "diningtable",
+               "dog", "horse", "motorbike", "person", "pottedplant", "sheep", "sofa", "train", "tvmonitor"]        # Detector2D.cc:8-14
+
+
+class Detector2D:
+    def __init__(self, detection_confidence_threshold, dynamic_detection_confidence_threshold, param_path=None, bin_path=None,
+                 param_text=None, bin_bytes=None, width=640, height=480, max_batch=1, lib=None):
+        self.lib = lib if lib is not None else load()
+        if param_text is None:
+            param_text = open(param_path or './Thirdparty/ncnn_model/mobilenetv3_ssdlite_voc.param').read()      # Detector2D.cc:24
+        if bin_bytes is None:
+            bin_bytes = open(bin_path or './Thirdparty/ncnn_model/mobilenetv3_ssdlite_voc.bin', 'rb').read()      # Detector2D.cc:25
+        self._bin = bin_bytes
+        h = C.c_void_p()
+        self.lib.check(self.lib.dll.sgx_det_create(param_text.encode(), bin_bytes, len(bin_bytes), width, height, max_batch,
+                                                   float(detection_confidence_threshold), float(dynamic_detection_confidence_threshold), C.byref(h)), 'sgx_det_create')
+        self.h = h; self.width, self.height, self.max_batch = width, height, max_batch
+        npri, ncls, nk = C.c_int32(), C.c_int32(), C.c_int32(); g = C.c_double()
+        self.lib.check(self.lib.dll.sgx_det_info(self.h, C.byref(npri), C.byref(ncls), C.byref(nk), C.byref(g)))
+        self.num_priors, self.num_class, self.num_kernels, self.gmac = npri.value, ncls.value, nk.value, g.value
+        self.mvObjects2D = []; self.mbHaveDynamicObjectForMapping = False; self.mbHaveDynamicObjectForRmDynamicFeature = False
+        self.mvPotentialDynamicBorderForMapping = []; self.mvPotentialDynamicBorderForRmDynamicFeature = []
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.dll.sgx_det_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try: self.close()
+        except Exception: pass
+
+    def detect_batch(self, images):
+        imgs = np.ascontiguousarray(images, np.uint8)
+        if imgs.ndim == 3: imgs = imgs[None]
+        B = imgs.shape[0]
+        res = (DetResult * B)()
+        self.lib.check(self.lib.dll.sgx_det_detect(self.h, _vp(imgs), imgs.shape[2] * 3, B, res), 'sgx_det_detect')
+        return res
+
+    def detect(self, bgr):
+        r = self.detect_batch(bgr)[0]
+        rect = lambda o: (o.x, o.y, o.w, o.h)
+        self.raw = np.array([[d.label, d.score, d.xmin, d.ymin, d.xmax, d.ymax] for d in r.raw[:r.n_raw]], np.float32).reshape(-1, 6)
+        self.mvObjects2D = [(o.id, CLASS_NAMES[o.id], o.prob, rect(o)) for o in r.objects[:r.n_objects]]
+        self.mbHaveDynamicObjectForMapping = bool(r.have_dynamic_for_mapping)
+        self.mbHaveDynamicObjectForRmDynamicFeature = bool(r.have_dynamic_for_rm_feature)
+        self.mvPotentialDynamicBorderForMapping = [rect(o) for o in r.map_boxes[:r.n_map_boxes]]
+        self.mvPotentialDynamicBorderForRmDynamicFeature = [rect(o) for o in r.rm_boxes[:r.n_rm_boxes]]
+
+    def debug_blob(self, name, image=0):
+        n = C.c_int(0)
+        self.lib.check(self.lib.dll.sgx_det_debug_read_blob(self.h, name.encode(), image, None, 0, C.byref(n)))
+        out = np.zeros(n.value, 'f4')
+        self.lib.check(self.lib.dll.sgx_det_debug_read_blob(self.h, name.encode(), image, _vp(out), n.value, C.byref(n)))
+        return out

@@ -1,0 +1,90 @@
+"""Detector2D forward + post-processing + dynamic-feature mask: emulator vs the numpy oracle on the shipped graph with
+synthetic weights (the reference's .bin is absent).
+
+fp32 tolerance.  The reference computes in fp32 with ncnn's (unknowable) summation order; with synthetic weights the
+activations reach ~1e4 and pass through ~100 layers with clips and gates, so two correct fp32 implementations drift apart by far
+more than 1 ulp.  The yardstick is therefore a float64 run of the oracle: the device result must be as close to it as the
+oracle's own fp32 run is (within a factor 4), per tapped blob; the first layers (little accumulated drift) must agree to 1e-5."""
+import os
+import numpy as np
+import pytest
+from oracle import detector_oracle as D
+from sg_slam_amd.detector import Detector2D
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PARAM = os.path.join(ROOT, 'tests', 'golden', 'mobilenetv3_ssdlite_voc.param')
+RTOL = 1e-4
+
+
+def rel_err(a, b):
+    return float(np.abs(a - b).max() / max(1e-6, np.abs(b).max()))
+
+
+@pytest.fixture(scope='module')
+def model():
+    layers = D.parse_param(PARAM)
+    W, blob = D.synth_weights(layers, seed=7)
+    return layers, W, blob
+
+
+def make_image(seed, person=False):
+    rng = np.random.RandomState(seed)
+    img = rng.randint(0, 256, (480, 640, 3)).astype(np.uint8)
+    img[100:300, 200:400] = (img[100:300, 200:400] // 4 + 150).astype(np.uint8)
+    return img
+
+
+def run_compare(lib, model, seeds=(0, 1)):
+    layers, W, blob = model
+    det = Detector2D(0.90, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=2, lib=lib)
+    assert det.num_priors == 2268 and det.num_class == 21 and abs(det.gmac - 0.5574) < 1e-3
+    imgs = np.stack([make_image(s) for s in seeds])
+    res = det.detect_batch(imgs)
+    for b, s in enumerate(seeds):
+        x = D.preprocess(imgs[b])
+        out, blobs = D.forward(layers, W, x)
+        _, blobs64 = D.forward(layers, W, x, dt=np.float64)
+        assert (det.debug_blob('input', b).reshape(3, 300, 300) == x).all()                 # integer resize + exact fp32 subtract
+        for name in ('580', '587', '603'):
+            assert rel_err(det.debug_blob(name, b), np.asarray(blobs[name], np.float32).reshape(-1)) < 1e-5, name
+        for name in ('620', '672', '849', '908', '944', 'mbox_loc', 'mbox_conf_softmax'):
+            got = det.debug_blob(name, b); ref = np.asarray(blobs64[name]).reshape(-1); np32 = np.asarray(blobs[name], np.float64).reshape(-1)
+            e_dev, e_np = rel_err(got.astype(np.float64), ref), rel_err(np32, ref)
+            assert got.shape == ref.shape and e_dev <= max(4 * e_np, 1e-5), (name, e_dev, e_np)
+        r = res[b]
+        got_rows = np.array([[d.label, d.score, d.xmin, d.ymin, d.xmax, d.ymax] for d in r.raw[:r.n_raw]], np.float32).reshape(-1, 6)
+        # post-processing (DetectionOutput + Detector2D::detect filtering) checked exactly on the DEVICE's own loc/conf
+        p = [L for L in layers if L['type'] == 'DetectionOutput'][0]['p']
+        exp_rows = D.detection_output(det.debug_blob('mbox_loc', b), det.debug_blob('mbox_conf_softmax', b), blobs['mbox_priorbox'], p)
+        assert got_rows.shape == exp_rows.shape and (got_rows[:, 0] == exp_rows[:, 0]).all()
+        assert np.abs(got_rows[:, 1:] - exp_rows[:, 1:]).max() < 1e-5
+        keep = [v for v in exp_rows if v[1] > np.float32(0.90) or (v[1] > np.float32(0.01) and int(v[0]) == 15)]
+        assert r.n_objects == sum(int(v[0]) != 15 for v in keep) and r.n_map_boxes == sum(int(v[0]) == 15 for v in keep)
+        assert r.n_rm_boxes == sum(int(v[0]) == 15 and v[1] > np.float32(0.2) for v in keep)
+        assert bool(r.have_dynamic_for_mapping) == (r.n_map_boxes > 0) and bool(r.have_dynamic_for_rm_feature) == (r.n_rm_boxes > 0)
+    det.close()
+
+
+def test_detector_emu_matches_oracle(emu, model):
+    run_compare(emu, model)
+
+
+def run_mask(lib, to_dev=lambda a: a, to_host=lambda a: a):
+    from sg_slam_amd.capi import KP_DTYPE, _vp
+    rng = np.random.RandomState(2)
+    cap, n = 1024, 900
+    keys = np.zeros((1, cap), KP_DTYPE); keys['x'][0, :n] = rng.uniform(0, 640, n); keys['y'][0, :n] = rng.uniform(0, 480, n)
+    prev = np.zeros((1, cap, 2), 'f4'); prev[0, :n, 0] = keys['x'][0, :n] + 3 + rng.randn(n) * 0.6; prev[0, :n, 1] = keys['y'][0, :n] + rng.randn(n) * 0.6
+    F = np.array([[0, 0, 0], [0, 0, -1.0], [0, 1.0, 0]], 'f8')                               # pure x-translation: epipolar lines are rows
+    boxes = np.zeros((1, 4, 4), 'f4'); boxes[0, 0] = (200, 100, 150, 250); boxes[0, 1] = (400, 50, 60, 60)
+    nb = np.array([2], 'i4'); cnt = np.array([n], 'i4'); keep = np.zeros((1, cap), np.uint8)
+    dk, dc, dp, dF, db, dn, dkeep = map(to_dev, (keys, cnt, prev, F.reshape(1, 9).copy(), boxes, nb, keep))
+    lib.check(lib.dll.sgx_dynamic_mask_batch_dev(1, cap, _vp(dk), _vp(dc), _vp(dp), _vp(dF), _vp(db), _vp(dn), 4, _vp(dkeep), None))
+    got = to_host(dkeep)[0, :n].astype(bool)
+    exp, restored = D.dynamic_mask(list(zip(keys['x'][0, :n], keys['y'][0, :n])), prev[0, :n], F, [tuple(b) for b in boxes[0, :2]], True)
+    assert (got == exp).all() and 0.2 < exp.mean() < 0.95 and not restored
+    assert (to_host(dkeep)[0, n:] == 0).all()
+
+
+def test_dynamic_mask_emu(emu):
+    run_mask(emu)
