@@ -55,6 +55,7 @@ def main():
     ap.add_argument('--streams', type=int, default=64, help='independent streams per GPU (frames per step)')
     ap.add_argument('--frames', type=int, default=6, help='distinct frames kept per stream (ping-pong replay)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-pipeline', action='store_true', help='single HIP stream (no overlap of extraction with match/pose-opt)')
     ap.add_argument('--cpu-sample', type=int, default=100, help='frames timed on the CPU oracle')
     args = ap.parse_args()
 
@@ -92,7 +93,7 @@ def main():
     d_depth = torch.full((S, 480, 640), depth_val, dtype=torch.int16, device='cuda')      # the plane: constant raw depth (u16 bits)
     order = ping_pong(T)
 
-    tr = TrackerBatch(lib, S, cam, xp='torch')
+    tr = TrackerBatch(lib, S, cam, xp='torch', pipelined=not args.no_pipeline)
     tr.set_initial_pose(np.stack([gen.Tcw(t0) for t0 in t0s]))
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -101,6 +102,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    tr.synchronize()
     tr.ex.last_status(stream=stream)
     torch.cuda.synchronize()
     if dist: dist.barrier()
@@ -110,6 +112,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    tr.synchronize()
     torch.cuda.synchronize()
     if dist: dist.barrier()
     torch.cuda.synchronize()
@@ -197,7 +200,7 @@ def main():
                    'streams_per_gpu': S, 'frames_per_step': S, 'distinct_frames_per_stream': T,
                    'mean_keypoints': float(nkp.mean()), 'mean_matches': float(nmatch.mean()), 'mean_inliers': float(ninl.mean()),
                    'tracked_streams_last_frame': tracked, 'ate_rmse_m_vs_synthetic_gt': ate_rmse,
-                   'nfeatures': 1000, 'nlevels': 8, 'scale_factor': 1.2, 'parallelism': f'streams-sharded x{world}',
+                   'nfeatures': 1000, 'nlevels': 8, 'scale_factor': 1.2, 'parallelism': f'streams-sharded x{world}', 'hip_streams': 1 if args.no_pipeline else 2,
                    'pose_dtype': 'f64 LM, f32 boundary'},
         'roofline': roofline, 'cpu_baseline': cpu,
     }

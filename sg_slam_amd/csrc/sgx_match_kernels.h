@@ -12,6 +12,7 @@
 #define SGX_MATCH_THREADS 1024
 
 #include "sgx_types.h"
+#include "sgx_block.h"
 
 // 256-bit Hamming distance == ORBmatcher::DescriptorDistance (ORBmatcher.cc:1649-1665; SWAR popcount == popcount)
 SGX_DEV int sgx_hamming256(const uint32_t *a, const uint32_t *b)
@@ -42,8 +43,8 @@ SGX_DEV float sgx_gemm3(const float *arow, const float *b, float c)
 // re-assigned (the later map point wins).  Parallel restatement:
 //   * candidate set of map point i = exactly the keypoints Frame::GetFeaturesInArea (Frame.cc:354-407)
 //     would return: valid grid cell (PosInGrid uses round(), :411-418) inside the floor/ceil cell
-//     window, level gate, |dx|<r and |dy|<r; evaluated against all keypoints (the 64x48 grid is only
-//     an index in the reference; its scan order is encoded in the preference key).
+//     window, level gate, |dx|<r and |dy|<r; the 64x48 grid is rebuilt in LDS as a CSR index (its
+//     per-cell order is irrelevant: the reference's scan order is encoded in the preference key).
 //   * preference = min over unlocked candidates of (distance, cell x, cell y, keypoint index) ==
 //     "first strictly smaller distance in scan order" (:1423).
 //   * locks: lock[k] = smallest i with Observations()>0 whose choice is k; k is unavailable to i'
@@ -68,7 +69,10 @@ SGX_KERNEL(SGX_MATCH_THREADS) k_match_project_frame(
     SGX_LDS int choice[SGX_MATCH_CAP];
     SGX_LDS int owner[SGX_MATCH_CAP];
     SGX_LDS int hist[SGX_HISTO], bad[SGX_HISTO];
-    SGX_LDS int s_changed, s_total, s_rejected;
+    SGX_LDS int cell_start[SGX_GRID_COLS * SGX_GRID_ROWS + 1];   // Frame::mGrid as CSR: cell = ix*48 + iy (AssignFeaturesToGrid, Frame.cc:257-272)
+    SGX_LDS int cell_fill[SGX_GRID_COLS * SGX_GRID_ROWS];
+    SGX_LDS uint16_t cell_list[SGX_MATCH_CAP];
+    SGX_LDS int s_changed, s_total, s_rejected, s_ngrid;
 
     const int f = (int)blockIdx.x;
     const int Nc = min(cn[f], cap), Nl = min(ln[f], cap);
@@ -92,7 +96,25 @@ SGX_KERNEL(SGX_MATCH_THREADS) k_match_project_frame(
         lock_a[k] = 0x7FFFFFFF; owner[k] = -1;
     }
     for (int i = tid; i < SGX_HISTO; i += NT) { hist[i] = 0; bad[i] = 0; }
+    for (int i = tid; i < SGX_GRID_COLS * SGX_GRID_ROWS; i += NT) { cell_start[i] = 0; cell_fill[i] = 0; }
     if (tid == 0) { s_total = 0; s_rejected = 0; }
+    SGX_THREADS_END
+    SGX_SYNC();
+    // ---- the 64x48 grid index (only an accelerator here: candidate order is carried by the preference key)
+    SGX_THREADS_BEGIN(tid)
+    for (int k = tid; k < Nc; k += NT) { const uint32_t inf = kinfo[k]; if (inf & 0x80000000u) sgx_atomic_add(&cell_start[((inf >> 8) & 0xFF) * SGX_GRID_ROWS + ((inf >> 16) & 0xFF)], 1); }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    sgx_block_exclusive_scan_i32(cell_start, SGX_GRID_COLS * SGX_GRID_ROWS, &s_ngrid, tid);
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    if (tid == 0) cell_start[SGX_GRID_COLS * SGX_GRID_ROWS] = s_ngrid;
+    for (int k = tid; k < Nc; k += NT) {
+        const uint32_t inf = kinfo[k];
+        if (inf & 0x80000000u) { const int c = ((inf >> 8) & 0xFF) * SGX_GRID_ROWS + ((inf >> 16) & 0xFF); cell_list[cell_start[c] + sgx_atomic_add(&cell_fill[c], 1)] = (uint16_t)k; }
+    }
     SGX_THREADS_END
     SGX_SYNC();
 
@@ -141,11 +163,10 @@ SGX_KERNEL(SGX_MATCH_THREADS) k_match_project_frame(
 #pragma unroll
                         for (int w = 0; w < 8; w++) dm[w] = dmp[w];
                         unsigned long long bestKey = ~0ull;
-                        for (int k = 0; k < Nc; k++) {
-                            const uint32_t inf = kinfo[k];
-                            if (!(inf & 0x80000000u)) continue;
-                            const int px = (inf >> 8) & 0xFF, py = (inf >> 16) & 0xFF, oct = inf & 0xFF;
-                            if (px < c0x || px > c1x || py < c0y || py > c1y) continue;
+                        for (int px = c0x; px <= c1x; px++) for (int py = c0y; py <= c1y; py++)
+                        for (int q = cell_start[px * SGX_GRID_ROWS + py]; q < cell_start[px * SGX_GRID_ROWS + py + 1]; q++) {
+                            const int k = cell_list[q];
+                            const int oct = kinfo[k] & 0xFF;
                             if (chk) { if (oct < minLevel) continue; if (maxLevel >= 0 && oct > maxLevel) continue; }
                             if (!(fabsf(kx[k] - u) < radius && fabsf(ky[k] - v) < radius)) continue;
                             if (lock_cur[k] < i) continue;                                   // holds an observed map point (:1407-1409)

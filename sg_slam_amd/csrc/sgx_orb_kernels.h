@@ -601,12 +601,14 @@ SGX_DEV int sgx_reflect101(int i, int n)
 #define SGX_PW (2 * SGX_PR + 1)    /* 43 */
 #define SGX_BR 18
 #define SGX_BW (2 * SGX_BR + 1)    /* 37 */
+#define SGX_PS 48                  /* LDS row stride of the staged patch (bytes) */
 
 SGX_KERNEL(64) k_orient_desc(SgxOrbGeom g, const uint8_t *gray, int gray_pitch, const uint8_t *pyr,
                              const uint32_t *sel, const int *sel_count, const int *umax, const signed char *pattern,
                              uint8_t *kps_raw, uint8_t *desc, int *count, int cap, uint32_t *status)
 {
-    SGX_LDS uint8_t patch[SGX_PW * (SGX_PW + 1)];
+    SGX_LDS uint32_t patch_dw[SGX_PW * SGX_PS / 4];      // 43 rows x 48 bytes; column c of the patch sits at byte lead + c
+    uint8_t *patch = (uint8_t *)patch_dw;
     SGX_LDS uint16_t hbuf[SGX_PW * SGX_BW];
     SGX_LDS uint8_t blur[SGX_BW * (SGX_BW + 1)];
     SGX_LDS uint8_t bits[256];
@@ -634,12 +636,25 @@ SGX_KERNEL(64) k_orient_desc(SgxOrbGeom g, const uint8_t *gray, int gray_pitch, 
     int stride;
     const uint8_t *img = sgx_level_ptr(g, gray, gray_pitch, pyr, frame, level, &stride);
 
+    // stage the 43x43 source patch.  Fast path (patch inside the image): aligned dword loads, one LDS dword store each;
+    // near the border: byte loads with BORDER_REFLECT_101 indices.
+    const int px0 = kx - SGX_PR, py0 = ky - SGX_PR;
+    const bool inside = px0 >= 0 && py0 >= 0 && ky + SGX_PR < L.h && kx + SGX_PR < L.w && kx + SGX_PR + 4 < stride;
+    const int lead = inside ? (px0 & 3) : 0;
     SGX_THREADS_BEGIN(tid)
     if (tid == 0) { s_m01 = 0; s_m10 = 0; }
-    for (int i = tid; i < SGX_PW * SGX_PW; i += 64) {
-        const int r = i / SGX_PW, c = i - r * SGX_PW;
-        const int yy = sgx_reflect101(ky + r - SGX_PR, L.h), xx = sgx_reflect101(kx + c - SGX_PR, L.w);
-        patch[r * (SGX_PW + 1) + c] = img[(size_t)yy * stride + xx];
+    if (inside) {
+        const int xa = px0 - lead;
+        for (int i = tid; i < SGX_PW * (SGX_PS / 4); i += 64) {
+            const int r = i / (SGX_PS / 4), q = i - r * (SGX_PS / 4);
+            if (4 * q < lead + SGX_PW) patch_dw[i] = *(const uint32_t *)(img + (size_t)(py0 + r) * stride + xa + 4 * q);
+        }
+    } else {
+        for (int i = tid; i < SGX_PW * SGX_PW; i += 64) {
+            const int r = i / SGX_PW, c = i - r * SGX_PW;
+            const int yy = sgx_reflect101(py0 + r, L.h), xx = sgx_reflect101(px0 + c, L.w);
+            patch[r * SGX_PS + c] = img[(size_t)yy * stride + xx];
+        }
     }
     SGX_THREADS_END
     SGX_SYNC();
@@ -651,7 +666,7 @@ SGX_KERNEL(64) k_orient_desc(SgxOrbGeom g, const uint8_t *gray, int gray_pitch, 
         const int v = i / 31 - 15, u = i - (v + 15) * 31 - 15;
         const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
         if (au <= umax[av]) {
-            const int I = patch[(SGX_PR + v) * (SGX_PW + 1) + SGX_PR + u];
+            const int I = patch[(SGX_PR + v) * SGX_PS + lead + SGX_PR + u];
             m10 += u * I; m01 += v * I;
         }
     }
@@ -659,7 +674,7 @@ SGX_KERNEL(64) k_orient_desc(SgxOrbGeom g, const uint8_t *gray, int gray_pitch, 
     // horizontal blur pass (8.8 fixed point)
     for (int i = tid; i < SGX_PW * SGX_BW; i += 64) {
         const int r = i / SGX_BW, c = i - r * SGX_BW;
-        const uint8_t *p = patch + r * (SGX_PW + 1) + c;        // window columns c..c+6 <-> blurred column c
+        const uint8_t *p = patch + r * SGX_PS + lead + c;       // window columns c..c+6 <-> blurred column c
         hbuf[i] = (uint16_t)(GK0 * (p[0] + p[6]) + GK1 * (p[1] + p[5]) + GK2 * (p[2] + p[4]) + GK3 * p[3]);
     }
     SGX_THREADS_END

@@ -22,7 +22,7 @@ from .orb import ORBextractor
 
 
 class TrackerBatch:
-    def __init__(self, lib, streams, cam, width=640, height=480, nfeatures=1000, xp='torch', th=15.0):
+    def __init__(self, lib, streams, cam, width=640, height=480, nfeatures=1000, xp='torch', th=15.0, pipelined=True):
         self.lib, self.S, self.cam, self.W, self.H, self.th = lib, streams, dict(cam), width, height, th
         self.ex = ORBextractor(nfeatures=nfeatures, width=width, height=height, max_batch=streams, lib=lib)
         self.cap = self.ex.capacity
@@ -32,14 +32,15 @@ class TrackerBatch:
         self.xp = xp
         S, cap = streams, self.cap
         z = self._zeros
-        # double-buffered per-frame state: [0]/[1] alternate as current/last
-        self.keys = [z((S, cap, 28), 'u1') for _ in range(2)]
-        self.desc = [z((S, cap, 32), 'u1') for _ in range(2)]
-        self.n = [z((S,), 'i4') for _ in range(2)]
-        self.uright = [z((S, cap), 'f4') for _ in range(2)]
-        self.zdepth = [z((S, cap), 'f4') for _ in range(2)]
-        self.xw = [z((S, cap, 3), 'f4') for _ in range(2)]
-        self.has = [z((S, cap), 'u1') for _ in range(2)]
+        # triple-buffered per-frame state: frame t lives in slot t % 3 (current / last / being overwritten by the next extract)
+        NB = 3
+        self.keys = [z((S, cap, 28), 'u1') for _ in range(NB)]
+        self.desc = [z((S, cap, 32), 'u1') for _ in range(NB)]
+        self.n = [z((S,), 'i4') for _ in range(NB)]
+        self.uright = [z((S, cap), 'f4') for _ in range(NB)]
+        self.zdepth = [z((S, cap), 'f4') for _ in range(NB)]
+        self.xw = [z((S, cap, 3), 'f4') for _ in range(NB)]
+        self.has = [z((S, cap), 'u1') for _ in range(NB)]
         self.Tcw = [z((S, 16), 'f4') for _ in range(3)]          # cur, last, last-last (rotating)
         self.match = z((S, cap), 'i4')
         self.nmatch = z((S,), 'i4')
@@ -50,6 +51,14 @@ class TrackerBatch:
         self.vel_valid = z((S,), 'u1')
         self.cur = 0
         self.frame_idx = 0
+        # Two HIP streams: E = extraction (+stereo) of frame t+1 overlaps T = match / pose-opt / unproject of frame t.  The wide
+        # kernels (FAST, descriptors) fill the chip while the one-workgroup-per-frame kernels (matcher, LM) run beside them.
+        self.pipelined = bool(pipelined and xp == 'torch')
+        if self.pipelined:
+            import torch
+            self.sE, self.sT = torch.cuda.Stream(), torch.cuda.Stream()
+            self.ev_extract = [torch.cuda.Event() for _ in range(NB)]
+            self.ev_track = [torch.cuda.Event() for _ in range(NB)]
 
     def _zeros(self, shape, dt):
         if self.xp == 'torch':
@@ -70,15 +79,31 @@ class TrackerBatch:
                 b[...] = T
 
     def step(self, d_gray, d_depth, stream=None, gray_pitch=None):
-        """Track the next frame of every stream.  d_gray: S x H x W u8, d_depth: S x H x W u16 (raw, DepthMapFactor 5000)."""
+        """Track the next frame of every stream.  d_gray: S x H x W u8, d_depth: S x H x W u16 (raw, DepthMapFactor 5000).
+        Asynchronous; with pipelined=True the extraction runs on its own stream (call synchronize() before reading results)."""
         L, S, cap, cam = self.lib, self.S, self.cap, self.cam
-        c, l = self.cur, self.cur ^ 1
+        t = self.frame_idx
+        c, l = t % 3, (t - 1) % 3
         Tc, Tl, Tll = self.Tcw[0], self.Tcw[1], self.Tcw[2]
-        st = _vp(stream)
-        self.ex.extract_batch_dev(d_gray, gray_pitch or self.W, S, self.keys[c], self.desc[c], self.n[c], stream=stream)
+        if self.pipelined:
+            import torch
+            cur_stream = torch.cuda.current_stream()
+            sE, sT = self.sE, self.sT
+            if t == 0:
+                sE.wait_stream(cur_stream); sT.wait_stream(cur_stream)
+            if t >= 2:
+                sE.wait_event(self.ev_track[(t - 2) % 3])            # slot c was "last" of step t-2+1: its readers must be done
+            stE, stT = sE.cuda_stream, sT.cuda_stream
+        else:
+            stE = stT = stream
+        self.ex.extract_batch_dev(d_gray, gray_pitch or self.W, S, self.keys[c], self.desc[c], self.n[c], stream=stE)
         L.check(L.dll.sgx_frame_stereo_from_rgbd_batch_dev(S, cap, _vp(self.keys[c]), _vp(self.n[c]), _vp(d_depth), self.W, self.H,
-                                                           float(cam['depth_factor']), float(cam['bf']), _vp(self.uright[c]), _vp(self.zdepth[c]), st), 'stereo')
-        if self.frame_idx > 0:
+                                                           float(cam['depth_factor']), float(cam['bf']), _vp(self.uright[c]), _vp(self.zdepth[c]), _vp(stE)), 'stereo')
+        if self.pipelined:
+            self.ev_extract[c].record(self.sE)
+            self.sT.wait_event(self.ev_extract[c])
+        st = _vp(stT)
+        if t > 0:
             # Tc <- predicted pose from (Tl, Tll); frame 1 has no velocity yet -> uses the last pose
             L.check(L.dll.sgx_frame_motion_model_batch_dev(S, _vp(Tl), _vp(Tll), _vp(self.vel_valid), _vp(Tc), st), 'motion model')
             L.check(L.dll.sgx_match_project_frame_batch_dev(
@@ -88,20 +113,35 @@ class TrackerBatch:
             L.check(L.dll.sgx_pose_optimization_batch_dev(
                 S, cap, _vp(self.keys[c]), _vp(self.uright[c]), _vp(self.n[c]), _vp(self.match), None, _vp(self.xw[l]), cap,
                 _vp(self.inv_sigma2), len(self.inv_sigma2), C.byref(self.cs), _vp(Tc), _vp(self.outlier), _vp(self.ninl), st), 'pose opt')
-            if self.frame_idx == 1:
-                self.vel_valid[...] = 1
+            if t == 1:
+                if self.pipelined:
+                    import torch
+                    with torch.cuda.stream(self.sT):
+                        self.vel_valid.fill_(1)
+                else:
+                    self.vel_valid[...] = 1
         L.check(L.dll.sgx_frame_unproject_batch_dev(S, cap, _vp(self.keys[c]), _vp(self.n[c]), _vp(self.zdepth[c]), _vp(Tc), C.byref(self.cs),
                                                     _vp(self.xw[c]), _vp(self.has[c]), st), 'unproject')
-        # rotate: cur -> last, last -> last-last
+        if self.pipelined:
+            self.ev_track[c].record(self.sT)
+        # rotate poses: cur -> last, last -> last-last
         self.Tcw = [Tll, Tc, Tl]
-        self.cur ^= 1
+        self.cur = c
         self.frame_idx += 1
+
+    def synchronize(self):
+        if self.pipelined:
+            import torch
+            self.sE.synchronize(); self.sT.synchronize()
+            torch.cuda.current_stream().wait_stream(self.sT)
 
     def last_pose(self):
         """(S,4,4) float32 Tcw of the most recently tracked frame (synchronises)."""
+        self.synchronize()
         T = self.Tcw[1]
         return (T.cpu().numpy() if self.xp == 'torch' else T.copy()).reshape(self.S, 4, 4)
 
     def last_counts(self):
+        self.synchronize()
         g = (lambda a: a.cpu().numpy()) if self.xp == 'torch' else (lambda a: a.copy())
-        return g(self.n[self.cur ^ 1]), g(self.nmatch), g(self.ninl)
+        return g(self.n[self.cur]), g(self.nmatch), g(self.ninl)
