@@ -163,10 +163,12 @@ SGX_KERNEL(SGX_MATCH_THREADS) k_match_project_frame(
 #pragma unroll
                         for (int w = 0; w < 8; w++) dm[w] = dmp[w];
                         unsigned long long bestKey = ~0ull;
-                        for (int px = c0x; px <= c1x; px++) for (int py = c0y; py <= c1y; py++)
-                        for (int q = cell_start[px * SGX_GRID_ROWS + py]; q < cell_start[px * SGX_GRID_ROWS + py + 1]; q++) {
+                        // cells (px, c0y..c1y) of one grid column are contiguous in the CSR index: one key range per column
+                        for (int px = c0x; px <= c1x; px++)
+                        for (int q = cell_start[px * SGX_GRID_ROWS + c0y], qe = cell_start[px * SGX_GRID_ROWS + c1y + 1]; q < qe; q++) {
                             const int k = cell_list[q];
-                            const int oct = kinfo[k] & 0xFF;
+                            const uint32_t inf = kinfo[k];
+                            const int oct = inf & 0xFF, py = (inf >> 16) & 0xFF;
                             if (chk) { if (oct < minLevel) continue; if (maxLevel >= 0 && oct > maxLevel) continue; }
                             if (!(fabsf(kx[k] - u) < radius && fabsf(ky[k] - v) < radius)) continue;
                             if (lock_cur[k] < i) continue;                                   // holds an observed map point (:1407-1409)

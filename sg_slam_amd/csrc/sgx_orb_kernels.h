@@ -121,11 +121,12 @@ SGX_DEV uint32_t sgx_has9(uint32_t m16)
 SGX_KERNEL(256) k_fast_cells(SgxOrbGeom g, const SgxCell *cells, const uint8_t *gray, int gray_pitch, const uint8_t *pyr,
                              int batch, uint32_t *cand, int *cand_count, uint32_t *status)
 {
-    SGX_LDS uint8_t tile[SGX_TILE_MAX * SGX_TILE_STRIDE];
+    SGX_LDS uint32_t tile_dw[SGX_TILE_MAX * SGX_TILE_STRIDE / 4];   // staged rows, 72 B stride; tile column x sits at byte lead + x
     SGX_LDS uint8_t score[SGX_TILE_MAX * SGX_TILE_STRIDE];
     SGX_LDS uint16_t clist[(SGX_TILE_MAX - 6) * (SGX_TILE_MAX - 6)];
     SGX_LDS uint32_t outbuf[((SGX_TILE_MAX - 5) / 2) * ((SGX_TILE_MAX - 5) / 2)];
     SGX_LDS int n_corner, n_hi, n_lo, out_base;
+    const uint8_t *tile = (const uint8_t *)tile_dw;
 
     // block -> (cell, frame): frame fastest so that frame f stays on XCD f%8 (block b -> XCD b%8)
     const int bid = (int)blockIdx.x;
@@ -135,41 +136,52 @@ SGX_KERNEL(256) k_fast_cells(SgxOrbGeom g, const SgxCell *cells, const uint8_t *
     int stride;
     const uint8_t *img = sgx_level_ptr(g, gray, gray_pitch, pyr, frame, level, &stride);
     const int thr_lo = g.min_th, thr_hi = g.ini_th;
+    const int xa = c.x0 & ~3, lead = c.x0 - xa, ndw = (lead + cw + 3) >> 2;
+    const int SD = SGX_TILE_STRIDE / 4;
 
+    // phase A: stage the tile rows as aligned dwords (coalesced global loads, one LDS dword store each); zero the score map
     SGX_THREADS_BEGIN(tid)
     if (tid == 0) { n_corner = 0; n_hi = 0; n_lo = 0; }
-    // stage tile rows as aligned dwords; zero the score map
-    const int xa = c.x0 & ~3, lead = c.x0 - xa, ndw = (lead + cw + 3) >> 2;
-    for (int i = tid; i < ch * ndw; i += (int)blockDim.x) {
-        const int r = i / ndw, q = i - r * ndw;
-        const uint32_t v = *(const uint32_t *)(img + (size_t)(c.y0 + r) * stride + xa + 4 * q);
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const int x = 4 * q + b - lead;
-            if (x >= 0 && x < cw) tile[r * SGX_TILE_STRIDE + x] = (uint8_t)(v >> (8 * b));
-        }
+    for (int i = tid; i < ch * SD; i += (int)blockDim.x) {
+        const int r = i / SD, q = i - r * SD;
+        tile_dw[i] = q < ndw ? *(const uint32_t *)(img + (size_t)(c.y0 + r) * stride + xa + 4 * q) : 0u;
     }
     for (int i = tid; i < ch * SGX_TILE_STRIDE; i += (int)blockDim.x) score[i] = 0;
     SGX_THREADS_END
     SGX_SYNC();
 
-    // phase B: corner test at the LOW threshold for every interior pixel, compact positives
-    const int iw = cw - 6, ih = ch - 6;
+    // phase B: FAST-9 segment test at the LOW threshold.  A task = 4 horizontally adjacent pixels whose 10-byte-wide,
+    // 7-row neighbourhood is exactly 3 aligned dwords per row: 21 LDS dword reads per 4 pixels (instead of 68 byte reads);
+    // ring bytes are picked with static shifts.  Positives are compacted.
+    const int ih = ch - 6, ng = (lead + cw + 3) >> 2;
     SGX_THREADS_BEGIN(tid)
-    for (int i = tid; i < iw * ih; i += (int)blockDim.x) {
-        const int y = 3 + i / iw, x = 3 + i % iw;
-        const uint8_t *p = tile + y * SGX_TILE_STRIDE + x;
-        const int v = p[0], lo = v - thr_lo, hi = v + thr_lo;
-        uint32_t mb = 0, md = 0;
-#define SGX_RING(k, dx, dy) { const int r_ = p[(dy) * SGX_TILE_STRIDE + (dx)]; mb |= (uint32_t)(r_ > hi) << (k); md |= (uint32_t)(r_ < lo) << (k); }
-        SGX_RING(0, 0, 3) SGX_RING(1, 1, 3) SGX_RING(2, 2, 2) SGX_RING(3, 3, 1) SGX_RING(4, 3, 0) SGX_RING(5, 3, -1)
-        SGX_RING(6, 2, -2) SGX_RING(7, 1, -3) SGX_RING(8, 0, -3) SGX_RING(9, -1, -3) SGX_RING(10, -2, -2) SGX_RING(11, -3, -1)
-        SGX_RING(12, -3, 0) SGX_RING(13, -3, 1) SGX_RING(14, -2, 2) SGX_RING(15, -1, 3)
-#undef SGX_RING
-        if (sgx_has9(mb) | sgx_has9(md)) {
-            const int slot = sgx_atomic_add(&n_corner, 1);
-            clist[slot] = (uint16_t)(y * SGX_TILE_STRIDE + x);
+    for (int t = tid; t < ih * ng; t += (int)blockDim.x) {
+        const int y = 3 + t / ng, gq = t % ng;
+        const int x0 = 4 * gq + 3 - lead;                                   // tile column of the first pixel of the group
+        if (x0 + 3 < 3 || x0 >= cw - 3) continue;
+        uint32_t R[7][3];
+#pragma unroll
+        for (int d = 0; d < 7; d++) {
+            const uint32_t *row = tile_dw + (y + d - 3) * SD + gq;
+            R[d][0] = row[0]; R[d][1] = gq + 1 < SD ? row[1] : 0u; R[d][2] = gq + 2 < SD ? row[2] : 0u;
         }
+#define SGX_PX(d, idx) ((int)((R[(d)][(idx) >> 2] >> (8 * ((idx) & 3))) & 255u))
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int x = x0 + i;
+            const int v = SGX_PX(3, 3 + i), lo = v - thr_lo, hi = v + thr_lo;
+            uint32_t mb = 0, md = 0;
+#define SGX_RING(k, dx, dy) { const int r_ = SGX_PX(3 + (dy), 3 + i + (dx)); mb |= (uint32_t)(r_ > hi) << (k); md |= (uint32_t)(r_ < lo) << (k); }
+            SGX_RING(0, 0, 3) SGX_RING(1, 1, 3) SGX_RING(2, 2, 2) SGX_RING(3, 3, 1) SGX_RING(4, 3, 0) SGX_RING(5, 3, -1)
+            SGX_RING(6, 2, -2) SGX_RING(7, 1, -3) SGX_RING(8, 0, -3) SGX_RING(9, -1, -3) SGX_RING(10, -2, -2) SGX_RING(11, -3, -1)
+            SGX_RING(12, -3, 0) SGX_RING(13, -3, 1) SGX_RING(14, -2, 2) SGX_RING(15, -1, 3)
+#undef SGX_RING
+            if (x >= 3 && x < cw - 3 && (sgx_has9(mb) | sgx_has9(md))) {
+                const int slot = sgx_atomic_add(&n_corner, 1);
+                clist[slot] = (uint16_t)(y * SGX_TILE_STRIDE + lead + x);
+            }
+        }
+#undef SGX_PX
     }
     SGX_THREADS_END
     SGX_SYNC();
@@ -216,7 +228,7 @@ SGX_KERNEL(256) k_fast_cells(SgxOrbGeom g, const SgxCell *cells, const uint8_t *
         if (mx && v >= thr_lo) {
             if (v >= thr_hi) sgx_atomic_add(&n_hi, 1);
             const int slot = sgx_atomic_add(&n_lo, 1);
-            const int y = pos / SGX_TILE_STRIDE, x = pos - y * SGX_TILE_STRIDE;
+            const int y = pos / SGX_TILE_STRIDE, x = pos - y * SGX_TILE_STRIDE - lead;
             outbuf[slot] = (uint32_t)(x + c.ox) | ((uint32_t)(y + c.oy) << 12) | ((uint32_t)v << 24);
         }
     }
@@ -581,6 +593,12 @@ SGX_DEV float sgx_fast_atan2(float y, float x)
     return a;
 }
 
+// (hi:lo) >> (8*sh) as 32 bits, sh in 0..3 (v_alignbyte_b32)
+SGX_DEV uint32_t sgx_alignbyte(uint32_t hi, uint32_t lo, int sh)
+{
+    return (uint32_t)((((unsigned long long)hi << 32) | lo) >> (8 * sh));
+}
+
 SGX_DEV int sgx_reflect101(int i, int n)
 {
     if (n == 1) return 0;
@@ -602,6 +620,7 @@ SGX_DEV int sgx_reflect101(int i, int n)
 #define SGX_BR 18
 #define SGX_BW (2 * SGX_BR + 1)    /* 37 */
 #define SGX_PS 48                  /* LDS row stride of the staged patch (bytes) */
+#define SGX_HS 40                  /* LDS row stride of the horizontal-pass buffer (u16) */
 
 SGX_KERNEL(64) k_orient_desc(SgxOrbGeom g, const uint8_t *gray, int gray_pitch, const uint8_t *pyr,
                              const uint32_t *sel, const int *sel_count, const int *umax, const signed char *pattern,
@@ -609,7 +628,8 @@ SGX_KERNEL(64) k_orient_desc(SgxOrbGeom g, const uint8_t *gray, int gray_pitch, 
 {
     SGX_LDS uint32_t patch_dw[SGX_PW * SGX_PS / 4];      // 43 rows x 48 bytes; column c of the patch sits at byte lead + c
     uint8_t *patch = (uint8_t *)patch_dw;
-    SGX_LDS uint16_t hbuf[SGX_PW * SGX_BW];
+    SGX_LDS uint32_t hbuf_dw[SGX_PW * SGX_HS / 2];       // horizontal pass, 8.8 fixed point, row stride SGX_HS u16
+    uint16_t *hbuf = (uint16_t *)hbuf_dw;
     SGX_LDS uint8_t blur[SGX_BW * (SGX_BW + 1)];
     SGX_LDS uint8_t bits[256];
     SGX_LDS int s_m01, s_m10;
@@ -671,11 +691,25 @@ SGX_KERNEL(64) k_orient_desc(SgxOrbGeom g, const uint8_t *gray, int gray_pitch, 
         }
     }
     sgx_atomic_add(&s_m10, m10); sgx_atomic_add(&s_m01, m01);
-    // horizontal blur pass (8.8 fixed point)
-    for (int i = tid; i < SGX_PW * SGX_BW; i += 64) {
-        const int r = i / SGX_BW, c = i - r * SGX_BW;
-        const uint8_t *p = patch + r * SGX_PS + lead + c;       // window columns c..c+6 <-> blurred column c
-        hbuf[i] = (uint16_t)(GK0 * (p[0] + p[6]) + GK1 * (p[1] + p[5]) + GK2 * (p[2] + p[4]) + GK3 * p[3]);
+    // horizontal blur pass (8.8 fixed point): task = (row, 8-column segment); the 14 source bytes come from 5 aligned dword
+    // reads realigned with v_alignbyte, every byte is read once (sliding window in registers)
+    for (int t = tid; t < SGX_PW * 5; t += 64) {
+        const int r = t / 5, sg = t - r * 5;
+        const uint32_t *w = patch_dw + (r * SGX_PS + 8 * sg) / 4;
+        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = (8 * sg + 16 < SGX_PS) ? w[4] : 0u;
+        const uint32_t v0 = sgx_alignbyte(w1, w0, lead), v1 = sgx_alignbyte(w2, w1, lead), v2 = sgx_alignbyte(w3, w2, lead), v3 = sgx_alignbyte(w4, w3, lead);
+        int b[16];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { b[j] = (v0 >> (8 * j)) & 255; b[4 + j] = (v1 >> (8 * j)) & 255; b[8 + j] = (v2 >> (8 * j)) & 255; b[12 + j] = (v3 >> (8 * j)) & 255; }
+        uint32_t o[4];
+#pragma unroll
+        for (int c = 0; c < 8; c += 2) {
+            const uint32_t h0 = (uint32_t)(GK0 * (b[c] + b[c + 6]) + GK1 * (b[c + 1] + b[c + 5]) + GK2 * (b[c + 2] + b[c + 4]) + GK3 * b[c + 3]);
+            const uint32_t h1 = (uint32_t)(GK0 * (b[c + 1] + b[c + 7]) + GK1 * (b[c + 2] + b[c + 6]) + GK2 * (b[c + 3] + b[c + 5]) + GK3 * b[c + 4]);
+            o[c >> 1] = h0 | (h1 << 16);
+        }
+        uint32_t *dst = hbuf_dw + (r * SGX_HS + 8 * sg) / 2;          // columns >= 37 of the last segment are never read
+        dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3];
     }
     SGX_THREADS_END
     SGX_SYNC();
@@ -694,13 +728,20 @@ SGX_KERNEL(64) k_orient_desc(SgxOrbGeom g, const uint8_t *gray, int gray_pitch, 
         kp[0] = fx; kp[1] = fy; kp[2] = (float)L.patch_size; kp[3] = angle; kp[4] = (float)(e >> 24);
         ((int *)kp)[5] = level; ((int *)kp)[6] = -1;
     }
-    // vertical blur pass (16.16) + rounding
-    for (int i = tid; i < SGX_BW * SGX_BW; i += 64) {
-        const int r = i / SGX_BW, c = i - r * SGX_BW;
-        const uint16_t *h = hbuf + r * SGX_BW + c;
-        const uint32_t acc = (uint32_t)GK0 * (h[0] + h[6 * SGX_BW]) + (uint32_t)GK1 * (h[SGX_BW] + h[5 * SGX_BW]) +
-                             (uint32_t)GK2 * (h[2 * SGX_BW] + h[4 * SGX_BW]) + (uint32_t)GK3 * h[3 * SGX_BW];
-        blur[r * (SGX_BW + 1) + c] = (uint8_t)((acc + 32768u) >> 16);
+    // vertical blur pass (16.16) + rounding: task = (column, 8-row segment), 14 sliding reads per 8 outputs
+    for (int t = tid; t < SGX_BW * 5; t += 64) {
+        const int sg = t / SGX_BW, c = t - sg * SGX_BW;
+        const int r0 = 8 * sg, nr = (SGX_BW - r0) < 8 ? (SGX_BW - r0) : 8;
+        uint32_t h[14];
+#pragma unroll
+        for (int j = 0; j < 14; j++) h[j] = (r0 + j < SGX_PW) ? (uint32_t)hbuf[(r0 + j) * SGX_HS + c] : 0u;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (j < nr) {
+                const uint32_t acc = (uint32_t)GK0 * (h[j] + h[j + 6]) + (uint32_t)GK1 * (h[j + 1] + h[j + 5]) + (uint32_t)GK2 * (h[j + 2] + h[j + 4]) + (uint32_t)GK3 * h[j + 3];
+                blur[(r0 + j) * (SGX_BW + 1) + c] = (uint8_t)((acc + 32768u) >> 16);
+            }
+        }
     }
     SGX_THREADS_END
     SGX_SYNC();
