@@ -109,6 +109,12 @@ SGX_KERNEL(256) k_resize(SgxOrbGeom g, int level, const uint8_t *gray, int gray_
 // with x,y relative to the (16,16) border origin (ORBextractor.cc:823-824); k_octree does not
 // depend on their order.
 // ---------------------------------------------------------------------------------------------
+// ((hi:lo) >> sh) as 32 bits (v_alignbit_b32); with sh = 31 it shifts the sign bit of lo into hi from the right
+SGX_DEV uint32_t sgx_alignbit(uint32_t hi, uint32_t lo, int sh)
+{
+    return (uint32_t)((((unsigned long long)hi << 32) | lo) >> sh);
+}
+
 SGX_DEV uint32_t sgx_has9(uint32_t m16)
 {
     uint32_t m = m16 | (m16 << 16);
@@ -125,7 +131,8 @@ SGX_KERNEL(256) k_fast_cells(SgxOrbGeom g, const SgxCell *cells, const uint8_t *
     SGX_LDS uint8_t score[SGX_TILE_MAX * SGX_TILE_STRIDE];
     SGX_LDS uint16_t clist[(SGX_TILE_MAX - 6) * (SGX_TILE_MAX - 6)];
     SGX_LDS uint32_t outbuf[((SGX_TILE_MAX - 5) / 2) * ((SGX_TILE_MAX - 5) / 2)];
-    SGX_LDS int n_corner, n_hi, n_lo, out_base;
+    SGX_LDS uint16_t qlist[(SGX_TILE_MAX - 6) * (SGX_TILE_MAX - 6)];
+    SGX_LDS int n_corner, n_hi, n_lo, out_base, n_quick;
     const uint8_t *tile = (const uint8_t *)tile_dw;
 
     // block -> (cell, frame): frame fastest so that frame f stays on XCD f%8 (block b -> XCD b%8)
@@ -141,7 +148,7 @@ SGX_KERNEL(256) k_fast_cells(SgxOrbGeom g, const SgxCell *cells, const uint8_t *
 
     // phase A: stage the tile rows as aligned dwords (coalesced global loads, one LDS dword store each); zero the score map
     SGX_THREADS_BEGIN(tid)
-    if (tid == 0) { n_corner = 0; n_hi = 0; n_lo = 0; }
+    if (tid == 0) { n_corner = 0; n_hi = 0; n_lo = 0; n_quick = 0; }
     for (int i = tid; i < ch * SD; i += (int)blockDim.x) {
         const int r = i / SD, q = i - r * SD;
         tile_dw[i] = q < ndw ? *(const uint32_t *)(img + (size_t)(c.y0 + r) * stride + xa + 4 * q) : 0u;
@@ -150,38 +157,53 @@ SGX_KERNEL(256) k_fast_cells(SgxOrbGeom g, const SgxCell *cells, const uint8_t *
     SGX_THREADS_END
     SGX_SYNC();
 
-    // phase B: FAST-9 segment test at the LOW threshold.  A task = 4 horizontally adjacent pixels whose 10-byte-wide,
-    // 7-row neighbourhood is exactly 3 aligned dwords per row: 21 LDS dword reads per 4 pixels (instead of 68 byte reads);
-    // ring bytes are picked with static shifts.  Positives are compacted.
+    // phase B1: necessary condition on every interior pixel.  A 9-pixel arc of the 16-ring contains one pixel of every antipodal
+    // pair, so a corner needs (p0|p8) & (p4|p12) all-brighter or all-darker (the high-speed test cv::FAST itself starts with).
+    // A task = 4 horizontally adjacent pixels: the compass pixels come from 7 aligned LDS dwords.  Survivors are compacted.
     const int ih = ch - 6, ng = (lead + cw + 3) >> 2;
     SGX_THREADS_BEGIN(tid)
     for (int t = tid; t < ih * ng; t += (int)blockDim.x) {
         const int y = 3 + t / ng, gq = t % ng;
         const int x0 = 4 * gq + 3 - lead;                                   // tile column of the first pixel of the group
         if (x0 + 3 < 3 || x0 >= cw - 3) continue;
-        uint32_t R[7][3];
-#pragma unroll
-        for (int d = 0; d < 7; d++) {
-            const uint32_t *row = tile_dw + (y + d - 3) * SD + gq;
-            R[d][0] = row[0]; R[d][1] = gq + 1 < SD ? row[1] : 0u; R[d][2] = gq + 2 < SD ? row[2] : 0u;
-        }
-#define SGX_PX(d, idx) ((int)((R[(d)][(idx) >> 2] >> (8 * ((idx) & 3))) & 255u))
+        const uint32_t *rc = tile_dw + y * SD + gq, *rp = rc + 3 * SD, *rm = rc - 3 * SD;
+        const bool has1 = gq + 1 < SD, has2 = gq + 2 < SD;
+        const uint32_t C0 = rc[0], C1 = has1 ? rc[1] : 0u, C2 = has2 ? rc[2] : 0u;
+        const uint32_t P0 = rp[0], P1 = has1 ? rp[1] : 0u, M0 = rm[0], M1 = has1 ? rm[1] : 0u;
+#define SGX_B3(w0, w1, w2, idx) ((int)((((idx) < 4 ? (w0) : ((idx) < 8 ? (w1) : (w2))) >> (8 * ((idx) & 3))) & 255u))
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int x = x0 + i;
-            const int v = SGX_PX(3, 3 + i), lo = v - thr_lo, hi = v + thr_lo;
-            uint32_t mb = 0, md = 0;
-#define SGX_RING(k, dx, dy) { const int r_ = SGX_PX(3 + (dy), 3 + i + (dx)); mb |= (uint32_t)(r_ > hi) << (k); md |= (uint32_t)(r_ < lo) << (k); }
-            SGX_RING(0, 0, 3) SGX_RING(1, 1, 3) SGX_RING(2, 2, 2) SGX_RING(3, 3, 1) SGX_RING(4, 3, 0) SGX_RING(5, 3, -1)
-            SGX_RING(6, 2, -2) SGX_RING(7, 1, -3) SGX_RING(8, 0, -3) SGX_RING(9, -1, -3) SGX_RING(10, -2, -2) SGX_RING(11, -3, -1)
-            SGX_RING(12, -3, 0) SGX_RING(13, -3, 1) SGX_RING(14, -2, 2) SGX_RING(15, -1, 3)
-#undef SGX_RING
-            if (x >= 3 && x < cw - 3 && (sgx_has9(mb) | sgx_has9(md))) {
-                const int slot = sgx_atomic_add(&n_corner, 1);
-                clist[slot] = (uint16_t)(y * SGX_TILE_STRIDE + lead + x);
+            const int v = SGX_B3(C0, C1, C2, 3 + i), lo = v - thr_lo, hi = v + thr_lo;
+            const int r0 = SGX_B3(P0, P1, 0u, 3 + i), r8 = SGX_B3(M0, M1, 0u, 3 + i), r4 = SGX_B3(C0, C1, C2, 6 + i), r12 = SGX_B3(C0, C1, C2, i);
+            const bool br = ((r0 > hi) | (r8 > hi)) & ((r4 > hi) | (r12 > hi));
+            const bool dk = ((r0 < lo) | (r8 < lo)) & ((r4 < lo) | (r12 < lo));
+            if (x >= 3 && x < cw - 3 && (br | dk)) {
+                const int slot = sgx_atomic_add(&n_quick, 1);
+                qlist[slot] = (uint16_t)(y * SGX_TILE_STRIDE + lead + x);
             }
         }
-#undef SGX_PX
+#undef SGX_B3
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+
+    // phase B2: full segment test (>= 9 contiguous ring pixels brighter than v+t or darker than v-t) on the survivors.
+    // The two 16-bit ring masks are shifted in from sign bits with v_alignbit (2 VALU per ring pixel and polarity).
+    SGX_THREADS_BEGIN(tid)
+    for (int t = tid; t < n_quick; t += (int)blockDim.x) {
+        const int pos = qlist[t];
+        const uint8_t *p = tile + pos;
+        const int v = p[0], lo = v - thr_lo, hi = v + thr_lo;
+        uint32_t mb = 0, md = 0;
+#define SGX_RING(dx, dy) { const int r_ = p[(dy) * SGX_TILE_STRIDE + (dx)]; mb = sgx_alignbit(mb, (uint32_t)(hi - r_), 31); md = sgx_alignbit(md, (uint32_t)(r_ - lo), 31); }
+        SGX_RING(0, 3) SGX_RING(1, 3) SGX_RING(2, 2) SGX_RING(3, 1) SGX_RING(3, 0) SGX_RING(3, -1) SGX_RING(2, -2) SGX_RING(1, -3)
+        SGX_RING(0, -3) SGX_RING(-1, -3) SGX_RING(-2, -2) SGX_RING(-3, -1) SGX_RING(-3, 0) SGX_RING(-3, 1) SGX_RING(-2, 2) SGX_RING(-1, 3)
+#undef SGX_RING
+        if (sgx_has9(mb & 0xFFFFu) | sgx_has9(md & 0xFFFFu)) {
+            const int slot = sgx_atomic_add(&n_corner, 1);
+            clist[slot] = (uint16_t)pos;
+        }
     }
     SGX_THREADS_END
     SGX_SYNC();
