@@ -185,6 +185,12 @@ extern "C" int sgx_orb_create(const sgx_orb_config *cfg, sgx_orb **out)
         cand_off += L.cand_cap;
     }
     g.cand_pitch = cand_off;
+    {   // k_fast_cells LDS carve for the largest tile of this geometry
+        int mw = 7, mh = 7;
+        for (const SgxCell &cc : cells) { if (cc.cw > mw) mw = cc.cw; if (cc.ch > mh) mh = cc.ch; }
+        const int tile_b = mh * SGX_TILE_STRIDE, q_b = ((mw - 6) * (mh - 6) * 2 + 15) & ~15, o_b = (((mw - 5) / 2) * ((mh - 5) / 2) * 4 + 15) & ~15;
+        g.fast_off_score = tile_b; g.fast_off_qlist = 2 * tile_b; g.fast_off_out = 2 * tile_b + q_b; g.fast_lds_bytes = 2 * tile_b + q_b + o_b;
+    }
     g.pyr_pitch = (off + 255) & ~255;
     g.ncells = (int)cells.size();
     g.kp_cap = kp_cap;
@@ -256,7 +262,7 @@ extern "C" int sgx_orb_extract_batch_dev(sgx_orb *h, const uint8_t *d_gray, int 
     }
     sgx_prof_end(SGX_K_RESIZE, stream);
     sgx_prof_begin(SGX_K_FAST, stream);
-    SGX_LAUNCH(k_fast_cells, dim3(g.ncells * batch), dim3(256), stream, g, h->d_cells, d_gray, pitch, h->d_pyr, batch,
+    SGX_LAUNCH_DYN(k_fast_cells, dim3(g.ncells * batch), dim3(256), g.fast_lds_bytes, stream, g, h->d_cells, d_gray, pitch, h->d_pyr, batch,
                h->d_cand, h->d_cand_count, h->d_status);
     sgx_prof_end(SGX_K_FAST, stream);
     sgx_prof_begin(SGX_K_OCTREE, stream);

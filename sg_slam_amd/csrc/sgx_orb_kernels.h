@@ -36,6 +36,7 @@ struct SgxOrbGeom {
     int pyr_pitch;             // bytes per frame of pyramid storage (levels 1..)
     int ncells;                // total valid cells over all levels
     int kp_cap;                // keypoint capacity per frame
+    int fast_off_score, fast_off_qlist, fast_off_out, fast_lds_bytes;   // k_fast_cells dynamic-LDS carve (bytes)
     int cand_pitch;            // candidate entries per frame (all levels)
     int ini_th, min_th;
     SgxLevel lv[SGX_MAX_LEVELS];
@@ -112,7 +113,11 @@ SGX_KERNEL(256) k_resize(SgxOrbGeom g, int level, const uint8_t *gray, int gray_
 // ((hi:lo) >> sh) as 32 bits (v_alignbit_b32); with sh = 31 it shifts the sign bit of lo into hi from the right
 SGX_DEV uint32_t sgx_alignbit(uint32_t hi, uint32_t lo, int sh)
 {
+#ifndef SGX_EMU
+    return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)sh);
+#else
     return (uint32_t)((((unsigned long long)hi << 32) | lo) >> sh);
+#endif
 }
 
 SGX_DEV uint32_t sgx_has9(uint32_t m16)
@@ -127,11 +132,13 @@ SGX_DEV uint32_t sgx_has9(uint32_t m16)
 SGX_KERNEL(256) k_fast_cells(SgxOrbGeom g, const SgxCell *cells, const uint8_t *gray, int gray_pitch, const uint8_t *pyr,
                              int batch, uint32_t *cand, int *cand_count, uint32_t *status)
 {
-    SGX_LDS uint32_t tile_dw[SGX_TILE_MAX * SGX_TILE_STRIDE / 4];   // staged rows, 72 B stride; tile column x sits at byte lead + x
-    SGX_LDS uint8_t score[SGX_TILE_MAX * SGX_TILE_STRIDE];
-    SGX_LDS uint16_t clist[(SGX_TILE_MAX - 6) * (SGX_TILE_MAX - 6)];
-    SGX_LDS uint32_t outbuf[((SGX_TILE_MAX - 5) / 2) * ((SGX_TILE_MAX - 5) / 2)];
-    SGX_LDS uint16_t qlist[(SGX_TILE_MAX - 6) * (SGX_TILE_MAX - 6)];
+    // LDS: carved from one dynamic pool sized on the host from the largest tile of this geometry (g.fast_* fields), so that
+    // the common 640x480 case (tiles <= 43x40) runs 8 workgroups per CU instead of the 5 a worst-case static layout allows.
+    SGX_DYN_LDS(pool);
+    uint32_t *tile_dw = (uint32_t *)pool;                                   // staged rows, 72 B stride; tile column x at byte lead + x
+    uint8_t *score = (uint8_t *)pool + g.fast_off_score;                    // threshold-free FAST score map, same layout
+    uint16_t *qlist = (uint16_t *)((uint8_t *)pool + g.fast_off_qlist);     // survivors of the quick test; bit 15 = is a corner
+    uint32_t *outbuf = (uint32_t *)((uint8_t *)pool + g.fast_off_out);      // NMS survivors (packed candidates)
     SGX_LDS int n_corner, n_hi, n_lo, out_base, n_quick;
     const uint8_t *tile = (const uint8_t *)tile_dw;
 
@@ -200,18 +207,16 @@ SGX_KERNEL(256) k_fast_cells(SgxOrbGeom g, const SgxCell *cells, const uint8_t *
         SGX_RING(0, 3) SGX_RING(1, 3) SGX_RING(2, 2) SGX_RING(3, 1) SGX_RING(3, 0) SGX_RING(3, -1) SGX_RING(2, -2) SGX_RING(1, -3)
         SGX_RING(0, -3) SGX_RING(-1, -3) SGX_RING(-2, -2) SGX_RING(-3, -1) SGX_RING(-3, 0) SGX_RING(-3, 1) SGX_RING(-2, 2) SGX_RING(-1, 3)
 #undef SGX_RING
-        if (sgx_has9(mb & 0xFFFFu) | sgx_has9(md & 0xFFFFu)) {
-            const int slot = sgx_atomic_add(&n_corner, 1);
-            clist[slot] = (uint16_t)pos;
-        }
+        if (sgx_has9(mb & 0xFFFFu) | sgx_has9(md & 0xFFFFu)) qlist[t] = (uint16_t)(pos | 0x8000);     // pos < 68*72 < 2^15
     }
     SGX_THREADS_END
     SGX_SYNC();
 
     // phase C: threshold-free score for the compacted corners
     SGX_THREADS_BEGIN(tid)
-    for (int i = tid; i < n_corner; i += (int)blockDim.x) {
-        const int pos = clist[i];
+    for (int i = tid; i < n_quick; i += (int)blockDim.x) {
+        if (!(qlist[i] & 0x8000)) continue;
+        const int pos = qlist[i] & 0x7FFF;
         const uint8_t *p = tile + pos;
         const int v = p[0];
         int d[16];
@@ -241,8 +246,9 @@ SGX_KERNEL(256) k_fast_cells(SgxOrbGeom g, const SgxCell *cells, const uint8_t *
 
     // phase D: NMS (strict > over the 8 neighbours; apron and non-corners are 0), count survivors
     SGX_THREADS_BEGIN(tid)
-    for (int i = tid; i < n_corner; i += (int)blockDim.x) {
-        const int pos = clist[i];
+    for (int i = tid; i < n_quick; i += (int)blockDim.x) {
+        if (!(qlist[i] & 0x8000)) continue;
+        const int pos = qlist[i] & 0x7FFF;
         const uint8_t *s = score + pos;
         const int v = s[0];
         const bool mx = v > s[-1] && v > s[1] && v > s[-SGX_TILE_STRIDE - 1] && v > s[-SGX_TILE_STRIDE] && v > s[-SGX_TILE_STRIDE + 1] &&
@@ -618,7 +624,11 @@ SGX_DEV float sgx_fast_atan2(float y, float x)
 // (hi:lo) >> (8*sh) as 32 bits, sh in 0..3 (v_alignbyte_b32)
 SGX_DEV uint32_t sgx_alignbyte(uint32_t hi, uint32_t lo, int sh)
 {
+#ifndef SGX_EMU
+    return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)sh);
+#else
     return (uint32_t)((((unsigned long long)hi << 32) | lo) >> (8 * sh));
+#endif
 }
 
 SGX_DEV int sgx_reflect101(int i, int n)

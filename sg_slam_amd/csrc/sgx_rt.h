@@ -19,6 +19,8 @@
 #define SGX_THREADS_END }
 #define SGX_SYNC() __syncthreads()
 #define SGX_LDS __shared__
+#define SGX_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#define SGX_LAUNCH_DYN(kern, grid, block, lds, stream, ...) hipLaunchKernelGGL((kern), grid, block, (lds), stream, __VA_ARGS__)
 #define SGX_KERNEL(bounds) __global__ void __launch_bounds__(bounds)
 #define SGX_DEV __device__ __forceinline__
 #define SGX_CONST __constant__
@@ -42,6 +44,8 @@ extern thread_local sgx_dim3 blockIdx, blockDim, gridDim;
 #define SGX_THREADS_END }
 #define SGX_SYNC() ((void)0)
 #define SGX_LDS static thread_local
+#define SGX_DYN_LDS(name) static thread_local unsigned char name[163840] __attribute__((aligned(16)))
+#define SGX_LAUNCH_DYN(kern, grid, block, lds, stream, ...) SGX_LAUNCH(kern, grid, block, stream, __VA_ARGS__)
 #define SGX_KERNEL(bounds) static void
 #define SGX_DEV static inline
 #define SGX_CONST static
