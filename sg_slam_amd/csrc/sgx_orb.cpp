@@ -270,8 +270,8 @@ extern "C" int sgx_orb_extract_batch_dev(sgx_orb *h, const uint8_t *d_gray, int 
     SGX_LAUNCH(k_octree<false>, dim3(nl, batch), dim3(SGX_OCT_THREADS), stream, g, h->d_cand, h->d_cand_count, h->d_node_scratch, h->d_sel, h->d_sel_count, h->d_status);
     sgx_prof_end(SGX_K_OCTREE, stream);
     sgx_prof_begin(SGX_K_ORIENT_DESC, stream);
-    SGX_LAUNCH(k_orient_desc, dim3(g.kp_cap, batch), dim3(64), stream, g, d_gray, pitch, h->d_pyr, h->d_sel, h->d_sel_count,
-               h->d_umax, h->d_pattern, (uint8_t *)d_kps, d_desc, d_count, cap, h->d_status);
+    SGX_LAUNCH(k_orient_desc, dim3(g.kp_cap * batch), dim3(64), stream, g, d_gray, pitch, h->d_pyr, h->d_sel, h->d_sel_count,
+               h->d_umax, h->d_pattern, (uint8_t *)d_kps, d_desc, d_count, cap, batch, h->d_status);
     sgx_prof_end(SGX_K_ORIENT_DESC, stream);
     SGX_CHECK_HIP(hipGetLastError());
     return SGX_OK;

@@ -656,7 +656,7 @@ SGX_DEV int sgx_reflect101(int i, int n)
 
 SGX_KERNEL(64) k_orient_desc(SgxOrbGeom g, const uint8_t *gray, int gray_pitch, const uint8_t *pyr,
                              const uint32_t *sel, const int *sel_count, const int *umax, const signed char *pattern,
-                             uint8_t *kps_raw, uint8_t *desc, int *count, int cap, uint32_t *status)
+                             uint8_t *kps_raw, uint8_t *desc, int *count, int cap, int batch, uint32_t *status)
 {
     SGX_LDS uint32_t patch_dw[SGX_PW * SGX_PS / 4];      // 43 rows x 48 bytes; column c of the patch sits at byte lead + c
     uint8_t *patch = (uint8_t *)patch_dw;
@@ -668,7 +668,15 @@ SGX_KERNEL(64) k_orient_desc(SgxOrbGeom g, const uint8_t *gray, int gray_pitch, 
     SGX_LDS float s_a, s_b;
     const int GK0 = 18, GK1 = 34, GK2 = 48, GK3 = 56;
 
-    const int slot = (int)blockIdx.x, frame = (int)blockIdx.y;
+    // block -> (slot, frame).  1-D grid of kp_cap * batch blocks; the hardware places block n on XCD n % 8, so frames are dealt
+    // to XCDs (frame f -> XCD f % 8) and each XCD walks its frames one after the other: a frame's pyramid (1.2 MB) stays in
+    // that XCD's 4 MB L2 while its ~1000 patches are read (speed only; any placement is correct).
+    int slot, frame;
+    {
+        const int n = (int)blockIdx.x, kc = g.kp_cap;
+        if ((batch & 7) == 0) { const int xcd = n & 7, j = n >> 3; frame = xcd + 8 * (j / kc); slot = j % kc; }
+        else { frame = n / kc; slot = n % kc; }
+    }
     int level = -1, base = 0, total = 0;
     for (int l = 0; l < g.nlevels; l++) {
         const int n = sel_count[frame * g.nlevels + l];
