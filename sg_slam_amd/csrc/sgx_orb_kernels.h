@@ -705,7 +705,8 @@ SGX_KERNEL(64) k_orient_desc(SgxOrbGeom g, const uint8_t *gray, int gray_pitch, 
     if (tid == 0) { s_m01 = 0; s_m10 = 0; }
     if (inside) {
         const int xa = px0 - lead;
-        for (int i = tid; i < SGX_PW * (SGX_PS / 4); i += 64) {
+#pragma unroll
+        for (int it_ = 0; it_ < (SGX_PW * (SGX_PS / 4) + 63) / 64; it_++) { const int i = tid + 64 * it_; if (i >= SGX_PW * (SGX_PS / 4)) break;
             const int r = i / (SGX_PS / 4), q = i - r * (SGX_PS / 4);
             if (4 * q < lead + SGX_PW) patch_dw[i] = *(const uint32_t *)(img + (size_t)(py0 + r) * stride + xa + 4 * q);
         }
@@ -722,7 +723,8 @@ SGX_KERNEL(64) k_orient_desc(SgxOrbGeom g, const uint8_t *gray, int gray_pitch, 
     // intensity-centroid moments over the radius-15 disc (umax rows), integer exact in any order
     SGX_THREADS_BEGIN(tid)
     int m10 = 0, m01 = 0;
-    for (int i = tid; i < 31 * 31; i += 64) {
+#pragma unroll
+    for (int it_ = 0; it_ < (31 * 31 + 63) / 64; it_++) { const int i = tid + 64 * it_; if (i >= 31 * 31) break;
         const int v = i / 31 - 15, u = i - (v + 15) * 31 - 15;
         const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
         if (au <= umax[av]) {
@@ -733,7 +735,8 @@ SGX_KERNEL(64) k_orient_desc(SgxOrbGeom g, const uint8_t *gray, int gray_pitch, 
     sgx_atomic_add(&s_m10, m10); sgx_atomic_add(&s_m01, m01);
     // horizontal blur pass (8.8 fixed point): task = (row, 8-column segment); the 14 source bytes come from 5 aligned dword
     // reads realigned with v_alignbyte, every byte is read once (sliding window in registers)
-    for (int t = tid; t < SGX_PW * 5; t += 64) {
+#pragma unroll
+    for (int it_ = 0; it_ < (SGX_PW * 5 + 63) / 64; it_++) { const int t = tid + 64 * it_; if (t >= SGX_PW * 5) break;
         const int r = t / 5, sg = t - r * 5;
         const uint32_t *w = patch_dw + (r * SGX_PS + 8 * sg) / 4;
         const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = (8 * sg + 16 < SGX_PS) ? w[4] : 0u;
@@ -769,7 +772,8 @@ SGX_KERNEL(64) k_orient_desc(SgxOrbGeom g, const uint8_t *gray, int gray_pitch, 
         ((int *)kp)[5] = level; ((int *)kp)[6] = -1;
     }
     // vertical blur pass (16.16) + rounding: task = (column, 8-row segment), 14 sliding reads per 8 outputs
-    for (int t = tid; t < SGX_BW * 5; t += 64) {
+#pragma unroll
+    for (int it_ = 0; it_ < (SGX_BW * 5 + 63) / 64; it_++) { const int t = tid + 64 * it_; if (t >= SGX_BW * 5) break;
         const int sg = t / SGX_BW, c = t - sg * SGX_BW;
         const int r0 = 8 * sg, nr = (SGX_BW - r0) < 8 ? (SGX_BW - r0) : 8;
         uint32_t h[14];
@@ -788,7 +792,8 @@ SGX_KERNEL(64) k_orient_desc(SgxOrbGeom g, const uint8_t *gray, int gray_pitch, 
 
     SGX_THREADS_BEGIN(tid)
     const float a = s_a, b = s_b;
-    for (int t = tid; t < 256; t += 64) {
+#pragma unroll
+    for (int it_ = 0; it_ < 4; it_++) { const int t = tid + 64 * it_;
         const signed char *pt = pattern + 4 * t;
         const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
         const int r0 = sgx_cvround(x0 * b + y0 * a), c0 = sgx_cvround(x0 * a - y0 * b);
