@@ -153,8 +153,15 @@ def main():
                          'achieved_GBs': round(alg[k] * S / (avg_ms * 1e-3) / 1e9, 3)}
     dom = max(per_kernel, key=lambda k: per_kernel[k]['total_ms'])
     dk = per_kernel[dom]
+    traffic = None
+    try:        # HBM traffic of the same kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/)
+        tj = json.load(open(os.path.join(ROOT, 'profiles', 'r1_traffic.json')))
+        if tj['frames_per_launch'] == S and dom in tj['bytes_per_launch']:
+            traffic = tj['bytes_per_launch'][dom]
+    except Exception:
+        traffic = None
     roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': dk['achieved_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': dk['achieved_GBs'] / HBM_PEAK_GBS, 'traffic': None,
+                'frac': dk['achieved_GBs'] / HBM_PEAK_GBS, 'traffic': traffic,
                 'avg_launch_ms': dk['avg_ms_per_launch'], 'alg_bytes_per_launch': dk['alg_bytes_per_launch'],
                 'per_kernel': per_kernel,
                 'orb_stage_frac': 1.96e6 * (fps / world) / 1e9 / HBM_PEAK_GBS}
