@@ -114,6 +114,20 @@ int sgx_match_project_frame(
     const sgx_camera *cam, const float *scale_factors, int nlevels, float th, int b_mono, int check_orientation,
     int32_t *cur_match, int32_t *nmatches);
 
+/* Tracking::SearchLocalPoints' inner work (src/sg-slam/src/Tracking.cc:1284-1311): Frame::isInFrustum(pMP, viewing_cos_limit = 0.5)
+ * (Frame.cc:296-352, MapPoint::PredictScale MapPoint.cc:402-417) for every local map point, then
+ * ORBmatcher(nnratio = 0.8).SearchByProjection(Frame &F, const std::vector<MapPoint*> &vpMapPoints, th) (ORBmatcher.cc:45-129).
+ * Local map point i: m_xw (GetWorldPos), m_normal (GetNormal), m_min_dist / m_max_dist (mfMinDistance / mfMaxDistance), m_desc,
+ * m_obs (Observations()), m_skip (isBad() or mnLastFrameSeen == current frame, Tracking.cc:1288-1291); per-frame pitch mcap (<= 4096).
+ * cur_mp_obs[k] = Observations() of the map point keypoint k already holds (-1 = none; NULL = no keypoint holds one).
+ * Out: cur_match[k] = local map point newly assigned to keypoint k or -1, nmatches, in_view[i] = mbTrackInView (for IncreaseVisible). */
+int sgx_match_project_local_batch_dev(
+    int batch, int cap, const sgx_keypoint *d_ckeys, const uint8_t *d_cdesc, const float *d_curight, const int32_t *d_cn, const float *d_cTcw, const int32_t *d_cur_mp_obs,
+    int mcap, const int32_t *d_mn, const float *d_m_xw, const float *d_m_normal, const float *d_m_min_dist, const float *d_m_max_dist, const uint8_t *d_m_desc,
+    const int32_t *d_m_obs, const uint8_t *d_m_skip,
+    const sgx_camera *cam, const float *scale_factors, int nlevels, float log_scale_factor, float th, float nnratio, float viewing_cos_limit,
+    int32_t *d_cur_match, int32_t *d_nmatches, uint8_t *d_in_view, void *stream);
+
 /* ---- per-frame glue between the accelerated stages (device resident) -----------------------------
  * Frame::ComputeStereoFromRGBD (Frame.cc:893-914) fused with the u16 -> metres conversion
  * (Tracking.cc:229-230): uright[i] = x - bf/d, zdepth[i] = d, or -1 when depth is 0. */

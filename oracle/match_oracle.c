@@ -234,3 +234,79 @@ int orc_unproject_stereo(const orc_keypoint *kp_un, float z, const float *Tcw, f
     for (int i = 0; i < 3; i++) xw[i] = gemm3(Rwc[i], xc, 1.0, 1.0, Ow[i]);
     return 1;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Local-map matcher: Frame::isInFrustum (Frame.cc:296-352), MapPoint::PredictScale (MapPoint.cc:402-417),
+ * ORBmatcher::RadiusByViewingCos (ORBmatcher.cc:131-137) and
+ * ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, const float th)  (ORBmatcher.cc:45-129),
+ * driven as Tracking::SearchLocalPoints does (Tracking.cc:1262-1312).
+ * Local map point i: xw, normal (GetNormal), min_dist / max_dist (mfMinDistance / mfMaxDistance; the invariance bounds are
+ * 0.8*min and 1.2*max, MapPoint.cc:372-383), descriptor, obs, skip (isBad() or mnLastFrameSeen == current frame id).
+ * cur_mp_obs[k]: Observations() of the map point keypoint k already holds (-1 = NULL) — from the motion-model stage.
+ * Output: cur_match[k] = index of the local map point newly assigned to keypoint k, or -1 (unchanged); in_view[i] = mbTrackInView.
+ * ---------------------------------------------------------------------------------------- */
+int orc_search_by_projection_local(
+    int Nc, const orc_keypoint *ckeys, const uint8_t *cdesc, const float *curight, const float *cTcw, const int *cur_mp_obs,
+    int Nm, const float *m_xw, const float *m_normal, const float *m_min_dist, const float *m_max_dist, const uint8_t *m_desc,
+    const int *m_obs, const uint8_t *m_skip,
+    float fx, float fy, float cx, float cy, float bf, float minX, float maxX, float minY, float maxY,
+    const float *scale_factors, int nlevels, float log_scale_factor, float th, float nnratio, float viewing_cos_limit,
+    int *cur_match, uint8_t *in_view)
+{
+    int nmatches = 0;
+    grid_t *g = (grid_t *)malloc(sizeof(grid_t));
+    grid_build(g, Nc, ckeys, minX, maxX, minY, maxY);
+    float Rcw[3][3], tcw[3], Ow[3];
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Rcw[r][c] = cTcw[4 * r + c]; tcw[r] = cTcw[4 * r + 3]; }
+    for (int i = 0; i < 3; i++) { double s = 0; for (int k = 0; k < 3; k++) s += (double)Rcw[k][i] * (double)tcw[k]; Ow[i] = (float)(s * -1.0); }   /* mOw, Frame.cc:288-294 */
+    int *owner_obs = (int *)malloc(sizeof(int) * (Nc > 0 ? Nc : 1));
+    for (int k = 0; k < Nc; k++) { owner_obs[k] = cur_mp_obs ? cur_mp_obs[k] : -1; cur_match[k] = -1; }
+    int *vind = (int *)malloc(sizeof(int) * (Nc > 0 ? Nc : 1));
+    const int bFactor = th != 1.0f;
+    for (int i = 0; i < Nm; i++) {
+        in_view[i] = 0;
+        if (m_skip[i]) continue;
+        /* ---- isInFrustum */
+        const float *P = m_xw + 3 * i;
+        const float Pc[3] = { gemm3(Rcw[0], P, 1.0, 1.0, tcw[0]), gemm3(Rcw[1], P, 1.0, 1.0, tcw[1]), gemm3(Rcw[2], P, 1.0, 1.0, tcw[2]) };
+        if (Pc[2] < 0.0f) continue;
+        const float invz = 1.0f / Pc[2];
+        const float u = fx * Pc[0] * invz + cx, v = fy * Pc[1] * invz + cy;
+        if (u < minX || u > maxX) continue;
+        if (v < minY || v > maxY) continue;
+        const float maxDistance = 1.2f * m_max_dist[i], minDistance = 0.8f * m_min_dist[i];
+        const float PO[3] = { P[0] - Ow[0], P[1] - Ow[1], P[2] - Ow[2] };
+        const float dist = (float)sqrt((double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2]);   /* cv::norm: double accumulation */
+        if (dist < minDistance || dist > maxDistance) continue;
+        const float *Pn = m_normal + 3 * i;
+        const float viewCos = (float)(((double)PO[0] * Pn[0] + (double)PO[1] * Pn[1] + (double)PO[2] * Pn[2]) / (double)dist);   /* Mat::dot returns double */
+        if (viewCos < viewing_cos_limit) continue;
+        const float ratio = m_max_dist[i] / dist;
+        int nPredictedLevel = (int)ceilf(logf(ratio) / log_scale_factor);      /* std::log(float)/std::ceil(float): `using namespace std` reaches MapPoint.cc via TemplatedVocabulary.h:36 */
+        if (nPredictedLevel < 0) nPredictedLevel = 0; else if (nPredictedLevel >= nlevels) nPredictedLevel = nlevels - 1;
+        in_view[i] = 1;
+        const float projXR = u - bf * invz;
+        /* ---- SearchByProjection body */
+        float r = viewCos > 0.998 ? 2.5f : 4.0f;
+        if (bFactor) r *= th;
+        const float rad = r * scale_factors[nPredictedLevel];
+        const int nv = features_in_area(g, ckeys, u, v, rad, nPredictedLevel - 1, nPredictedLevel, vind);
+        if (nv == 0) continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int q = 0; q < nv; q++) {
+            const int idx = vind[q];
+            if (owner_obs[idx] > 0) continue;                                     /* holds a map point with observations */
+            if (curight[idx] > 0) { const float er = fabsf(projXR - curight[idx]); if (er > rad) continue; }
+            const int d = orc_descriptor_distance(m_desc + 32 * (size_t)i, cdesc + 32 * (size_t)idx);
+            if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = ckeys[idx].octave; bestIdx = idx; }
+            else if (d < bestDist2) { bestLevel2 = ckeys[idx].octave; bestDist2 = d; }
+        }
+        if (bestDist <= TH_HIGH) {
+            if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+            cur_match[bestIdx] = i; owner_obs[bestIdx] = m_obs[i];
+            nmatches++;
+        }
+    }
+    free(vind); free(owner_obs); grid_free(g); free(g);
+    return nmatches;
+}

@@ -216,3 +216,24 @@ def local_ba(problem, cam, stop_flag=None):
                        C.c_float(cam['fx']), C.c_float(cam['fy']), C.c_float(cam['cx']), C.c_float(cam['cy']), C.c_float(cam['bf']), st,
                        _p(erase), _p(trace), _p(iters))
     return poses.reshape(-1, 4, 4), pts, erase, trace.reshape(2, 15, 3), iters
+
+
+def search_by_projection_local(cur, lm, cam, scale_factors, th=3.0, nnratio=0.8, viewing_cos_limit=0.5):
+    """Tracking::SearchLocalPoints inner work: isInFrustum + ORBmatcher(0.8).SearchByProjection(F, vpMapPoints, th).
+    cur: keys, desc, uright, Tcw [, mp_obs]; lm (local map): xw, normal, min_dist, max_dist, desc, obs, skip.
+    Returns (cur_match[Nc], nmatches, in_view[Nm])."""
+    ck = np.ascontiguousarray(cur['keys']); cd = np.ascontiguousarray(cur['desc'], np.uint8); cu = np.ascontiguousarray(cur['uright'], 'f4')
+    cT = np.ascontiguousarray(cur['Tcw'], 'f4').reshape(16)
+    co = np.ascontiguousarray(cur.get('mp_obs', np.full(len(ck), -1)), 'i4')
+    xw = np.ascontiguousarray(lm['xw'], 'f4'); nr = np.ascontiguousarray(lm['normal'], 'f4'); mnd = np.ascontiguousarray(lm['min_dist'], 'f4'); mxd = np.ascontiguousarray(lm['max_dist'], 'f4')
+    md = np.ascontiguousarray(lm['desc'], np.uint8); mo = np.ascontiguousarray(lm['obs'], 'i4'); ms = np.ascontiguousarray(lm['skip'], np.uint8)
+    sf = np.ascontiguousarray(scale_factors, 'f4')
+    match = np.full(max(len(ck), 1), -1, 'i4'); inview = np.zeros(max(len(xw), 1), np.uint8)
+    L = lib(); L.orc_search_by_projection_local.restype = C.c_int
+    n = L.orc_search_by_projection_local(
+        C.c_int(len(ck)), _p(ck), _p(cd), _p(cu), _p(cT), _p(co),
+        C.c_int(len(xw)), _p(xw), _p(nr), _p(mnd), _p(mxd), _p(md), _p(mo), _p(ms),
+        C.c_float(cam['fx']), C.c_float(cam['fy']), C.c_float(cam['cx']), C.c_float(cam['cy']), C.c_float(cam['bf']),
+        C.c_float(cam.get('min_x', 0.0)), C.c_float(cam.get('max_x', 640.0)), C.c_float(cam.get('min_y', 0.0)), C.c_float(cam.get('max_y', 480.0)),
+        _p(sf), C.c_int(len(sf)), C.c_float(np.log(np.float32(sf[1]))), C.c_float(th), C.c_float(nnratio), C.c_float(viewing_cos_limit), _p(match), _p(inview))
+    return match[:len(ck)], int(n), inview[:len(xw)]

@@ -60,6 +60,25 @@ extern "C" int sgx_frame_unproject_batch_dev(int batch, int cap, const sgx_keypo
     return SGX_OK;
 }
 
+extern "C" int sgx_match_project_local_batch_dev(
+    int batch, int cap, const sgx_keypoint *d_ckeys, const uint8_t *d_cdesc, const float *d_curight, const int32_t *d_cn, const float *d_cTcw, const int32_t *d_cur_mp_obs,
+    int mcap, const int32_t *d_mn, const float *d_m_xw, const float *d_m_normal, const float *d_m_min_dist, const float *d_m_max_dist, const uint8_t *d_m_desc,
+    const int32_t *d_m_obs, const uint8_t *d_m_skip,
+    const sgx_camera *cam, const float *scale_factors, int nlevels, float log_scale_factor, float th, float nnratio, float viewing_cos_limit,
+    int32_t *d_cur_match, int32_t *d_nmatches, uint8_t *d_in_view, void *stream)
+{
+    if (batch < 1 || cap < 1 || cap > SGX_MATCH_CAP || mcap < 1 || mcap > SGX_LOCAL_CAP || !cam || !scale_factors || nlevels < 1 || nlevels > 12) return SGX_ERR_INVALID;
+    if (!d_ckeys || !d_cdesc || !d_curight || !d_cn || !d_cTcw || !d_mn || !d_m_xw || !d_m_normal || !d_m_min_dist || !d_m_max_dist || !d_m_desc || !d_m_obs ||
+        !d_m_skip || !d_cur_match || !d_nmatches || !d_in_view) return SGX_ERR_INVALID;
+    SgxScales sc; memset(&sc, 0, sizeof sc);
+    for (int i = 0; i < nlevels; i++) sc.s[i] = scale_factors[i];
+    SGX_LAUNCH(k_match_project_local, dim3(batch), dim3(SGX_MATCH_THREADS), (sgx_stream_t)stream, cap, (const uint8_t *)d_ckeys, d_cdesc, d_curight, d_cn, d_cTcw,
+               d_cur_mp_obs, mcap, d_mn, d_m_xw, d_m_normal, d_m_min_dist, d_m_max_dist, d_m_desc, d_m_obs, d_m_skip, to_cam(cam), sc, nlevels, log_scale_factor,
+               th, nnratio, viewing_cos_limit, d_cur_match, d_nmatches, d_in_view);
+    SGX_CHECK_HIP(hipGetLastError());
+    return SGX_OK;
+}
+
 extern "C" int sgx_frame_motion_model_batch_dev(int batch, const float *d_Tcw_cur, const float *d_Tcw_prev, const uint8_t *d_valid, float *d_Tcw_pred, void *stream)
 {
     if (batch < 1 || !d_Tcw_cur || !d_Tcw_prev || !d_Tcw_pred) return SGX_ERR_INVALID;

@@ -338,3 +338,171 @@ SGX_KERNEL(64) k_motion_model(int batch, const float *Tcur, const float *Tprev, 
     }
     SGX_THREADS_END
 }
+
+// ---------------------------------------------------------------------------------------------
+// k_match_project_local: Tracking::SearchLocalPoints' inner work (Tracking.cc:1284-1311) for one frame:
+//   Frame::isInFrustum(pMP, 0.5)            Frame.cc:296-352   (incl. MapPoint::PredictScale, MapPoint.cc:402-417)
+//   ORBmatcher(0.8).SearchByProjection(F, vpMapPoints, th)   ORBmatcher.cc:45-129 (RadiusByViewingCos :131-137)
+// One 1024-thread workgroup per frame, thread i <-> local map point i (strided).  Same ingredients as
+// k_match_project_frame: LDS-staged frame + CSR grid, preference keys, lock table + Jacobi sweeps for the greedy
+// "a keypoint that holds an observed map point is skipped" rule (:87-89).  Here the best AND the second-best available
+// candidates matter (ratio test :120-121): second = 2nd smallest (distance, scan order) key among the available candidates.
+// cur_mp_obs[k] > 0 marks keypoints already holding an observed map point (motion-model stage): locked from the start.
+// Outputs: cur_match[k] = local map point newly assigned to keypoint k (last writer in index order) or -1; in_view = mbTrackInView.
+// ---------------------------------------------------------------------------------------------
+#define SGX_LOCAL_CAP 4096
+
+SGX_KERNEL(SGX_MATCH_THREADS) k_match_project_local(
+    int cap, const uint8_t *ckeys_raw, const uint8_t *cdesc, const float *curight, const int *cn, const float *cTcw, const int *cur_mp_obs,
+    int mcap, const int *mn, const float *m_xw, const float *m_normal, const float *m_min_dist, const float *m_max_dist, const uint8_t *m_desc,
+    const int *m_obs, const uint8_t *m_skip,
+    SgxCam cam, SgxScales sc, int nlevels, float log_scale_factor, float th, float nnratio, float viewing_cos_limit,
+    int *cur_match, int *nmatches_out, uint8_t *in_view)
+{
+    SGX_LDS float kx[SGX_MATCH_CAP], ky[SGX_MATCH_CAP], kur[SGX_MATCH_CAP];
+    SGX_LDS uint32_t kinfo[SGX_MATCH_CAP];
+    SGX_LDS uint32_t kdesc[SGX_MATCH_CAP * 8];
+    SGX_LDS int lock_a[SGX_MATCH_CAP], lock_b[SGX_MATCH_CAP];
+    SGX_LDS int owner[SGX_MATCH_CAP];
+    SGX_LDS int cell_start[SGX_GRID_COLS * SGX_GRID_ROWS + 1];
+    SGX_LDS int cell_fill[SGX_GRID_COLS * SGX_GRID_ROWS];
+    SGX_LDS uint16_t cell_list[SGX_MATCH_CAP];
+    SGX_LDS uint16_t choice[SGX_LOCAL_CAP];           // 0xFFFF = none
+    SGX_LDS int s_changed, s_total, s_ngrid;
+
+    const int f = (int)blockIdx.x;
+    const int Nc = min(cn[f], cap), Nm = min(min(mn[f], mcap), SGX_LOCAL_CAP);
+    const int NT = (int)blockDim.x;
+    const float *Tc = cTcw + 16 * f;
+    const float invW = (float)SGX_GRID_COLS / (cam.maxX - cam.minX), invH = (float)SGX_GRID_ROWS / (cam.maxY - cam.minY);
+
+    SGX_THREADS_BEGIN(tid)
+    for (int k = tid; k < Nc; k += NT) {
+        const float *kp = (const float *)(ckeys_raw + ((size_t)f * cap + k) * 28);
+        const float x = kp[0], y = kp[1];
+        kx[k] = x; ky[k] = y; kur[k] = curight[(size_t)f * cap + k];
+        const int oct = ((const int *)kp)[5];
+        const int px = (int)round((double)((x - cam.minX) * invW)), py = (int)round((double)((y - cam.minY) * invH));
+        const bool valid = !(px < 0 || px >= SGX_GRID_COLS || py < 0 || py >= SGX_GRID_ROWS);
+        kinfo[k] = (uint32_t)(oct & 0xFF) | ((uint32_t)(px & 0xFF) << 8) | ((uint32_t)(py & 0xFF) << 16) | (valid ? 0x80000000u : 0u);
+        const uint32_t *d = (const uint32_t *)(cdesc + ((size_t)f * cap + k) * 32);
+#pragma unroll
+        for (int w = 0; w < 8; w++) kdesc[k * 8 + w] = d[w];
+        // a keypoint holding an observed map point is unavailable to every local map point: lock index -1
+        lock_a[k] = (cur_mp_obs && cur_mp_obs[(size_t)f * cap + k] > 0) ? -1 : 0x7FFFFFFF;
+        owner[k] = -1;
+    }
+    for (int i = tid; i < SGX_GRID_COLS * SGX_GRID_ROWS; i += NT) { cell_start[i] = 0; cell_fill[i] = 0; }
+    if (tid == 0) s_total = 0;
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    for (int k = tid; k < Nc; k += NT) { const uint32_t inf = kinfo[k]; if (inf & 0x80000000u) sgx_atomic_add(&cell_start[((inf >> 8) & 0xFF) * SGX_GRID_ROWS + ((inf >> 16) & 0xFF)], 1); }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    sgx_block_exclusive_scan_i32(cell_start, SGX_GRID_COLS * SGX_GRID_ROWS, &s_ngrid, tid);
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    if (tid == 0) cell_start[SGX_GRID_COLS * SGX_GRID_ROWS] = s_ngrid;
+    for (int k = tid; k < Nc; k += NT) {
+        const uint32_t inf = kinfo[k];
+        if (inf & 0x80000000u) { const int c = ((inf >> 8) & 0xFF) * SGX_GRID_ROWS + ((inf >> 16) & 0xFF); cell_list[cell_start[c] + sgx_atomic_add(&cell_fill[c], 1)] = (uint16_t)k; }
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+
+    float Rcw[3][3], tcw[3], Ow[3];
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Rcw[r][c] = Tc[4 * r + c]; tcw[r] = Tc[4 * r + 3]; }
+    for (int i = 0; i < 3; i++) { double s = 0; for (int k = 0; k < 3; k++) s += (double)Rcw[k][i] * (double)tcw[k]; Ow[i] = (float)(s * -1.0); }   // mOw, Frame.cc:288-294
+    const bool bFactor = th != 1.0f;
+
+    int *lock_cur = lock_a, *lock_new = lock_b;
+    for (int sweep = 0; sweep < SGX_LOCAL_CAP + 2; sweep++) {
+        SGX_THREADS_BEGIN(tid)
+        if (tid == 0) s_changed = 0;
+        for (int k = tid; k < Nc; k += NT) lock_new[k] = (cur_mp_obs && cur_mp_obs[(size_t)f * cap + k] > 0) ? -1 : 0x7FFFFFFF;
+        SGX_THREADS_END
+        SGX_SYNC();
+        SGX_THREADS_BEGIN(tid)
+        for (int i = tid; i < Nm; i += NT) {
+            int best = -1; uint8_t vis = 0;
+            const size_t mi = (size_t)f * mcap + i;
+            if (!m_skip[mi]) {
+                // ---- Frame::isInFrustum
+                const float *P = m_xw + 3 * mi;
+                const float pcx = sgx_gemm3(Rcw[0], P, tcw[0]), pcy = sgx_gemm3(Rcw[1], P, tcw[1]), pcz = sgx_gemm3(Rcw[2], P, tcw[2]);
+                bool ok = !(pcz < 0.0f);
+                const float invz = 1.0f / pcz;
+                const float u = cam.fx * pcx * invz + cam.cx, v = cam.fy * pcy * invz + cam.cy;
+                ok = ok && !(u < cam.minX || u > cam.maxX) && !(v < cam.minY || v > cam.maxY);
+                const float maxDistance = 1.2f * m_max_dist[mi], minDistance = 0.8f * m_min_dist[mi];       // MapPoint.cc:372-383
+                const float po0 = P[0] - Ow[0], po1 = P[1] - Ow[1], po2 = P[2] - Ow[2];
+                const float dist = (float)sqrt((double)po0 * po0 + (double)po1 * po1 + (double)po2 * po2);   // cv::norm accumulates in double
+                ok = ok && !(dist < minDistance || dist > maxDistance);
+                const float *Pn = m_normal + 3 * mi;
+                const float viewCos = (float)(((double)po0 * Pn[0] + (double)po1 * Pn[1] + (double)po2 * Pn[2]) / (double)dist);
+                ok = ok && !(viewCos < viewing_cos_limit);
+                if (ok) {
+                    vis = 1;
+                    int lvl = (int)ceilf((float)log((double)(m_max_dist[mi] / dist)) / log_scale_factor);   // MapPoint::PredictScale (logf in the reference)
+                    if (lvl < 0) lvl = 0; else if (lvl >= nlevels) lvl = nlevels - 1;
+                    const float projXR = u - cam.bf * invz;
+                    float r = viewCos > 0.998 ? 2.5f : 4.0f;                    // RadiusByViewingCos
+                    if (bFactor) r *= th;
+                    const float radius = r * sc.s[lvl];
+                    const int minLevel = lvl - 1, maxLevel = lvl;
+                    const int c0x = max(0, (int)floorf((u - cam.minX - radius) * invW)), c1x = min(SGX_GRID_COLS - 1, (int)ceilf((u - cam.minX + radius) * invW));
+                    const int c0y = max(0, (int)floorf((v - cam.minY - radius) * invH)), c1y = min(SGX_GRID_ROWS - 1, (int)ceilf((v - cam.minY + radius) * invH));
+                    if (!(c0x >= SGX_GRID_COLS || c1x < 0 || c0y >= SGX_GRID_ROWS || c1y < 0)) {
+                        const uint32_t *dmp = (const uint32_t *)(m_desc + mi * 32);
+                        uint32_t dm[8];
+#pragma unroll
+                        for (int w = 0; w < 8; w++) dm[w] = dmp[w];
+                        unsigned long long k1 = ~0ull, k2 = ~0ull;       // best / second-best (distance, scan order) keys
+                        for (int px = c0x; px <= c1x; px++)
+                        for (int q = cell_start[px * SGX_GRID_ROWS + c0y], qe = cell_start[px * SGX_GRID_ROWS + c1y + 1]; q < qe; q++) {
+                            const int k = cell_list[q];
+                            const uint32_t inf = kinfo[k];
+                            const int oct = inf & 0xFF, py = (inf >> 16) & 0xFF;
+                            if (oct < minLevel || oct > maxLevel) continue;        // bCheckLevels holds (maxLevel >= 0)
+                            if (!(fabsf(kx[k] - u) < radius && fabsf(ky[k] - v) < radius)) continue;
+                            if (lock_cur[k] < i) continue;
+                            if (kur[k] > 0) { if (fabsf(projXR - kur[k]) > radius) continue; }
+                            const int dd = sgx_hamming256(dm, &kdesc[k * 8]);
+                            const unsigned long long key = ((unsigned long long)dd << 36) | ((unsigned long long)px << 30) | ((unsigned long long)py << 24) |
+                                                           ((unsigned long long)k << 8) | (unsigned long long)oct;
+                            if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
+                        }
+                        if (k1 != ~0ull) {
+                            const int bestDist = (int)(k1 >> 36), bestLevel = (int)(k1 & 0xFF);
+                            const int bestDist2 = k2 != ~0ull ? (int)(k2 >> 36) : 256, bestLevel2 = k2 != ~0ull ? (int)(k2 & 0xFF) : -1;
+                            if (bestDist <= SGX_TH_HIGH && !(bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2)) best = (int)((k1 >> 8) & 0xFFFF);
+                        }
+                    }
+                }
+            }
+            in_view[mi] = vis;
+            choice[i] = best >= 0 ? (uint16_t)best : (uint16_t)0xFFFF;
+            if (best >= 0 && m_obs[mi] > 0) sgx_atomic_min_i32(&lock_new[best], i);
+        }
+        SGX_THREADS_END
+        SGX_SYNC();
+        SGX_THREADS_BEGIN(tid)
+        for (int k = tid; k < Nc; k += NT) if (lock_new[k] != lock_cur[k]) s_changed = 1;
+        SGX_THREADS_END
+        SGX_SYNC();
+        int *t = lock_cur; lock_cur = lock_new; lock_new = t;
+        if (!s_changed) break;
+    }
+
+    SGX_THREADS_BEGIN(tid)
+    for (int i = tid; i < Nm; i += NT) { const int k = choice[i]; if (k != 0xFFFF) { sgx_atomic_max(&owner[k], i); sgx_atomic_add(&s_total, 1); } }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    for (int k = tid; k < cap; k += NT) cur_match[(size_t)f * cap + k] = k < Nc ? owner[k] : -1;
+    if (tid == 0) nmatches_out[f] = s_total;
+    SGX_THREADS_END
+}

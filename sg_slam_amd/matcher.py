@@ -46,3 +46,40 @@ class ORBmatcher:
         self.lib.check(rc, 'sgx_match_project_frame')
         cur['match'] = match[:len(ck)]
         return int(n[0])
+
+    def SearchByProjectionLocal(self, F, local_map, th, cam, scale_factors, viewing_cos_limit=0.5):
+        """Tracking::SearchLocalPoints' inner work: Frame::isInFrustum(pMP, 0.5) for every local map point followed by
+        ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th) (ORBmatcher.cc:45-129) with this matcher's
+        nnratio.  F: keys, desc, uright, Tcw [, mp_obs]; local_map: xw, normal, min_dist, max_dist, desc, obs, skip.
+        Sets F['match_local'] (index into local_map or -1) and local_map['in_view']; returns nmatches."""
+        ck = np.ascontiguousarray(F['keys']); cd = np.ascontiguousarray(F['desc'], np.uint8); cu = np.ascontiguousarray(F['uright'], 'f4')
+        cT = np.ascontiguousarray(F['Tcw'], 'f4').reshape(16); co = np.ascontiguousarray(F.get('mp_obs', np.full(len(ck), -1)), 'i4')
+        lm = local_map
+        xw = np.ascontiguousarray(lm['xw'], 'f4'); nr = np.ascontiguousarray(lm['normal'], 'f4')
+        mnd = np.ascontiguousarray(lm['min_dist'], 'f4'); mxd = np.ascontiguousarray(lm['max_dist'], 'f4')
+        md = np.ascontiguousarray(lm['desc'], np.uint8); mo = np.ascontiguousarray(lm['obs'], 'i4'); ms = np.ascontiguousarray(lm['skip'], np.uint8)
+        sf = np.ascontiguousarray(scale_factors, 'f4')
+        nc, nm = len(ck), len(xw)
+        cnt = np.array([nc], 'i4'); mcnt = np.array([nm], 'i4')
+        match = np.full(max(nc, 1), -1, 'i4'); n = np.zeros(1, 'i4'); inview = np.zeros(max(nm, 1), np.uint8)
+        cs = camera_struct(cam)
+        arrs = [ck, cd, cu, cnt, cT, co, mcnt, xw, nr, mnd, mxd, md, mo, ms, match, n, inview]
+        dev, back = self._to_device(arrs)
+        d = dev
+        rc = self.lib.dll.sgx_match_project_local_batch_dev(1, max(nc, 1), _vp(d[0]), _vp(d[1]), _vp(d[2]), _vp(d[3]), _vp(d[4]), _vp(d[5]),
+                                                            max(nm, 1), _vp(d[6]), _vp(d[7]), _vp(d[8]), _vp(d[9]), _vp(d[10]), _vp(d[11]), _vp(d[12]), _vp(d[13]),
+                                                            C.byref(cs), _vp(sf), len(sf), float(np.log(np.float32(sf[1]))), float(th), float(self.mfNNratio),
+                                                            float(viewing_cos_limit), _vp(d[14]), _vp(d[15]), _vp(d[16]), None)
+        self.lib.check(rc, 'sgx_match_project_local_batch_dev')
+        match, n, inview = back(d[14]), back(d[15]), back(d[16])
+        F['match_local'] = match[:nc]; local_map['in_view'] = inview[:nm]
+        return int(n[0])
+
+    def _to_device(self, arrs):
+        """numpy arrays -> device buffers for the *_batch_dev entry points: torch CUDA tensors with the product library,
+        the arrays themselves under the kernel-logic emulator (host memory)."""
+        if 'EMULATOR' in self.lib.version():
+            return arrs, (lambda a: a)
+        import torch
+        dev = [torch.from_numpy(a.view(np.uint8) if a.dtype.fields else a).cuda() for a in arrs]
+        return dev, (lambda t: t.cpu().numpy())

@@ -123,3 +123,32 @@ def make_ba_problem(orc, n_free=8, n_fixed=5, n_points=400, seed=11, outlier_fra
     pts0 = pts + rng.randn(*pts.shape) * point_sigma
     return dict(poses=poses0.astype('f4'), pose_fixed=fixed, points=pts0.astype('f4'), edge_pose=np.array(ep, 'i4'), edge_point=np.array(el, 'i4'),
                 edge_obs=np.array(eo, 'f4'), edge_info=np.array(ei, 'f4')), Ts, pts
+
+
+def make_local_map(orc, S, t, seed=0, n_prev=2):
+    """cur = frame t; local map = keypoints of frames t-1..t-n_prev unprojected with their true poses (MapPoint ctor,
+    MapPoint.cc:44-67: normal = unit vector from the camera centre, max_dist = dist*scale[octave], min_dist = max_dist/scale[nlevels-1]).
+    Some keypoints of cur already hold observed map points (cur['mp_obs'] > 0), some local points are skipped / unobserved."""
+    rng = np.random.RandomState(seed)
+    p = orc.orb_params(); sf = p['scale']
+    g, d, T = S.frame(t)
+    k, desc = orc.orb_extract(g)
+    ur, z = orc.compute_stereo_from_rgbd(k, d, CAM['bf'], CAM['depth_factor'])
+    cur = dict(keys=k, desc=desc, uright=ur, Tcw=T.astype('f4'))
+    xs, ns, mind, maxd, ds = [], [], [], [], []
+    for j in range(1, n_prev + 1):
+        gj, dj, Tj = S.frame(t - j)
+        kj, dsj = orc.orb_extract(gj)
+        urj, zj = orc.compute_stereo_from_rgbd(kj, dj, CAM['bf'], CAM['depth_factor'])
+        xw, has = orc.unproject_stereo(kj, zj, Tj.astype('f4'), CAM)
+        Ow = -(Tj[:3, :3].T @ Tj[:3, 3])
+        sel = has > 0
+        PO = xw[sel] - Ow.astype('f4')
+        dist = np.linalg.norm(PO.astype('f8'), axis=1).astype('f4')
+        xs.append(xw[sel]); ns.append((PO / dist[:, None]).astype('f4'))
+        mx = (dist * sf[kj['octave'][sel]]).astype('f4'); maxd.append(mx); mind.append((mx / sf[7]).astype('f4')); ds.append(dsj[sel])
+    xw = np.concatenate(xs); n = len(xw)
+    lm = dict(xw=xw, normal=np.concatenate(ns), min_dist=np.concatenate(mind), max_dist=np.concatenate(maxd), desc=np.concatenate(ds),
+              obs=(rng.rand(n) < 0.7).astype('i4') * rng.randint(1, 5, n), skip=(rng.rand(n) < 0.1).astype(np.uint8))
+    cur['mp_obs'] = np.where(rng.rand(len(k)) < 0.25, rng.randint(0, 3, len(k)), -1).astype('i4')
+    return cur, lm
