@@ -3,7 +3,8 @@
 
 One "step" = one frame from each of S independent streams on this GPU pushed through the whole
 per-frame path (sg_slam_amd/tracker.py): ORB extract -> stereo-from-RGBD -> motion model ->
-SearchByProjection(cur,last) -> PoseOptimization -> unproject.  Frames are resident in HBM before the
+SearchByProjection(cur,last) -> PoseOptimization -> [TrackLocalMap: SearchByProjection(cur, local points) ->
+PoseOptimization] -> unproject -> new map points.  Frames are resident in HBM before the
 timed region.  N>1: one process per GPU (torch.distributed over RCCL); streams are sharded across ranks
 (weak scaling, no data-path collective); after the timed region the per-frame records (pose + counts) are
 gathered to rank 0 with one RCCL all_gather (BASELINE config 5), outside the timing.
@@ -40,6 +41,8 @@ def algorithmic_bytes_per_frame(nkp=1000, ncand=6000, nmatch=600):
         'match_project_frame': 2 * nkp * (28 + 32) + nkp * (4 + 12 + 1 + 1 + 4) + nkp * 4,   # both frames' kp+desc, uright/xw/flags, match out
         'pose_opt': nkp * (28 + 4 + 4) + nmatch * 12 + nkp + 64,   # keypoints, uright, match index, matched map points, outlier flags, pose
         'unproject': nkp * (28 + 4 + 12 + 1),
+        'match_project_local': nkp * (28 + 32 + 4 + 4) + 2 * nkp * (12 + 12 + 4 + 4 + 32 + 4 + 1) + nkp * 4 + 2 * nkp,   # cur kp/desc/uright/obs, 2 frames of map points, match + in_view out
+        'map_point_glue': nkp * (28 + 12 + 1 + 32 + 12 + 12 + 8 + 32 + 1) / 4 + nkp * (4 + 1 + 4 + 4 + 4) / 2 + 3 * nkp * 24 / 4,   # per launch: make_map_points | merge (x2) | gather
     }
 
 
@@ -56,6 +59,7 @@ def main():
     ap.add_argument('--frames', type=int, default=6, help='distinct frames kept per stream (ping-pong replay)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-pipeline', action='store_true', help='single HIP stream (no overlap of extraction with match/pose-opt)')
+    ap.add_argument('--no-local-map', action='store_true', help='skip the TrackLocalMap stage (local-map SearchByProjection + second PoseOptimization)')
     ap.add_argument('--cpu-sample', type=int, default=100, help='frames timed on the CPU oracle')
     args = ap.parse_args()
 
@@ -93,7 +97,7 @@ def main():
     d_depth = torch.full((S, 480, 640), depth_val, dtype=torch.int16, device='cuda')      # the plane: constant raw depth (u16 bits)
     order = ping_pong(T)
 
-    tr = TrackerBatch(lib, S, cam, xp='torch', pipelined=not args.no_pipeline)
+    tr = TrackerBatch(lib, S, cam, xp='torch', pipelined=not args.no_pipeline, local_map=not args.no_local_map)
     tr.set_initial_pose(np.stack([gen.Tcw(t0) for t0 in t0s]))
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -121,6 +125,9 @@ def main():
     prof = lib.profile_read()
     tr.ex.last_status(stream=stream)
     nkp, nmatch, ninl = tr.last_counts()
+    nmatch_local, ninl2 = tr.last_local_counts()
+    if not args.no_local_map:
+        ninl = ninl2
     poses = tr.last_pose()
     # accuracy vs the synthetic ground truth of the last tracked frame (translation of the camera centre)
     last_i = args.warmup + args.steps - 1
@@ -176,8 +183,16 @@ def main():
         orc.orb_extract(host[0, 0])
         c0 = time.perf_counter()
         last = None; done = 0; s = 0
+        use_lm = not args.no_local_map
+        def cpu_map_points(fr):        # MapPoint(Pos, pMap, pFrame, idx) glue of the oracle chain (numpy)
+            Tm = fr['Tcw'].astype('f8'); Ow = (-(Tm[:3, :3].T @ Tm[:3, 3])).astype('f4')
+            PO = fr['xw'] - Ow[None]; nrm = np.sqrt((PO.astype('f8') ** 2).sum(1)); nrm[nrm == 0] = 1
+            mx = (nrm * sf[fr['keys']['octave']]).astype('f4')
+            return dict(xw=fr['xw'], normal=(PO / nrm[:, None]).astype('f4'), min_dist=(mx / sf[-1]).astype('f4'), max_dist=mx, desc=fr['desc'],
+                        skip=(fr['has_mp'] == 0).astype(np.uint8), obs=np.ones(len(mx), 'i4'))
+        def cat(ds): return {k2: np.concatenate([d_[k2] for d_ in ds]) for k2 in ds[0]}
         while done < n:
-            Tcur = gen.Tcw(t0s[s]).astype('f4')
+            Tcur = gen.Tcw(t0s[s]).astype('f4'); ring = []
             for i in range(min(len(order) * 2, n - done)):
                 g = host[order[i % len(order)], s]
                 k, d = orc.orb_extract(g)
@@ -187,7 +202,17 @@ def main():
                     m, nm = orc.search_by_projection_frame(cur, last, cam, sf, th=15)
                     fr2 = dict(keys=k, uright=ur, has_mp=(m >= 0).astype(np.uint8), Tcw=Tcur,
                                xw=np.where((m >= 0)[:, None], last['xw'][np.maximum(m, 0)], 0).astype('f4'))
-                    _, Tcur, _ = orc.pose_optimization(fr2, cam, is2)
+                    _, Tcur, out1 = orc.pose_optimization(fr2, cam, is2)
+                    if use_lm:
+                        keep = (m >= 0) & (out1 == 0)
+                        merged_xw = np.where(keep[:, None], fr2['xw'], 0).astype('f4'); has2 = keep.copy()
+                        if ring:
+                            lm = cat(ring[-2:])
+                            ml, _, _ = orc.search_by_projection_local(dict(keys=k, desc=d, uright=ur, Tcw=Tcur, mp_obs=np.where(keep, 0, -1).astype('i4')),
+                                                                      lm, cam, sf, th=3.0, nnratio=0.8, viewing_cos_limit=0.5)
+                            merged_xw = np.where((ml >= 0)[:, None], lm['xw'][np.maximum(ml, 0)], merged_xw).astype('f4'); has2 |= ml >= 0
+                        _, Tcur, _ = orc.pose_optimization(dict(keys=k, uright=ur, has_mp=has2.astype(np.uint8), Tcw=Tcur, xw=merged_xw), cam, is2)
+                        ring.append(cpu_map_points(last))
                 xw, has = orc.unproject_stereo(k, z, Tcur, cam)
                 last = dict(keys=k, desc=d, uright=ur, Tcw=Tcur, has_mp=has, outlier=np.zeros(len(k), np.uint8), xw=xw,
                             obs=np.zeros(len(k), 'i4'), mpdesc=d)
@@ -196,14 +221,17 @@ def main():
         cdt = time.perf_counter() - c0
         cpu = {'value': n / cdt, 'unit': 'frames/s', 'cores': 1, 'kind': 'port',
                'sample': f'{n} frames of the same synthetic streams through the oracle chain (orb_extract + stereo + SearchByProjection + '
-                         f'PoseOptimization + unproject), 1 thread; host has {os.cpu_count()} cores'}
+                         f'PoseOptimization + {"local-map SearchByProjection + PoseOptimization + " if use_lm else ""}unproject), 1 thread; host has {os.cpu_count()} cores'}
 
     out = {
         'metric': 'tracked frames/sec (640x480 RGB-D)', 'value': fps, 'unit': 'frames/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
         'config': {'workload': 'Single MI355X: ORB extract+match HIP kernels, 640x480 synthetic stream, 1000 feats/frame',
-                   'stages': ['orb_extract', 'stereo_from_rgbd', 'motion_model', 'search_by_projection(cur,last)', 'pose_optimization', 'unproject'],
+                   'stages': ['orb_extract', 'stereo_from_rgbd', 'motion_model', 'search_by_projection(cur,last)', 'pose_optimization'] +
+                             ([] if args.no_local_map else ['search_by_projection(cur,local_map th=3)', 'pose_optimization#2']) + ['unproject'] +
+                             ([] if args.no_local_map else ['make_map_points']),
+                   'local_map_points': 0 if args.no_local_map else 2 * tr.cap, 'mean_local_map_matches': None if args.no_local_map else float(nmatch_local.mean()),
                    'streams_per_gpu': S, 'frames_per_step': S, 'distinct_frames_per_stream': T,
                    'mean_keypoints': float(nkp.mean()), 'mean_matches': float(nmatch.mean()), 'mean_inliers': float(ninl.mean()),
                    'tracked_streams_last_frame': tracked, 'ate_rmse_m_vs_synthetic_gt': ate_rmse,

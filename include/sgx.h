@@ -143,6 +143,19 @@ int sgx_frame_unproject_batch_dev(int batch, int cap, const sgx_keypoint *d_keys
 int sgx_frame_motion_model_batch_dev(int batch, const float *d_Tcw_cur, const float *d_Tcw_prev, const uint8_t *d_valid,
                                      float *d_Tcw_pred, void *stream);
 
+/* MapPoint::MapPoint(Pos, pMap, pFrame, idxF) (src/sg-slam/src/MapPoint.cc:45-67) for every keypoint with depth — the temporal points of
+ * Tracking::UpdateLastFrame (Tracking.cc:840-904): normal, mfMin/MaxDistance, descriptor; written to slice `half` (0/1) of a
+ * per-frame ring of 2*cap local-map records (the layout sgx_match_project_local_batch_dev consumes with mcap = 2*cap). */
+int sgx_frame_make_map_points_batch_dev(int batch, int cap, int half, const sgx_keypoint *d_keys, const int32_t *d_n, const float *d_xw, const uint8_t *d_has,
+                                        const uint8_t *d_desc, const float *d_Tcw, const float *scale_factors, int nlevels,
+                                        float *d_m_xw, float *d_m_normal, float *d_m_min_dist, float *d_m_max_dist, uint8_t *d_m_desc, uint8_t *d_m_skip, void *stream);
+/* mvpMapPoints after TrackWithMotionModel (+ SearchLocalPoints): merged[k] indexes the combined table xw_all = [last frame's points (cap) |
+ * local-map ring (2*cap)]; motion-model outliers are dropped (Tracking.cc:941-956); a local-map match replaces an unobserved point.
+ * cur_mp_obs[k] (optional out) = 0 for keypoints holding a visual-odometry point, -1 otherwise (input of the local-map matcher).
+ * d_match_local / d_merged / d_xw_all may be NULL (first call of a frame only needs cur_mp_obs). */
+int sgx_frame_merge_matches_batch_dev(int batch, int cap, const int32_t *d_n, const int32_t *d_match_last, const uint8_t *d_outlier_last, const int32_t *d_match_local,
+                                      const float *d_xw_last, const float *d_m_xw, int32_t *d_merged, int32_t *d_cur_mp_obs, float *d_xw_all, void *stream);
+
 /* ---- pose-only optimisation -------------------------------------------------------------------
  * Replaces `static int Optimizer::PoseOptimization(Frame *pFrame)` (src/sg-slam/include/Optimizer.h:50,
  * src/sg-slam/src/Optimizer.cc:239-451): g2o Levenberg-Marquardt over the frame pose with one

@@ -56,7 +56,7 @@ SYMBOLS = [
     'sgx_orb_debug_level_geometry', 'sgx_orb_debug_read_level', 'sgx_orb_debug_read_candidates',
     'sgx_orb_debug_run_octree', 'sgx_profile_enable', 'sgx_profile_num_classes', 'sgx_profile_class_name', 'sgx_profile_read',
     'sgx_match_project_frame_batch_dev', 'sgx_match_project_frame', 'sgx_match_project_local_batch_dev',
-    'sgx_frame_stereo_from_rgbd_batch_dev', 'sgx_frame_unproject_batch_dev',
+    'sgx_frame_stereo_from_rgbd_batch_dev', 'sgx_frame_unproject_batch_dev', 'sgx_frame_make_map_points_batch_dev', 'sgx_frame_merge_matches_batch_dev',
     'sgx_pose_optimization_batch_dev', 'sgx_pose_optimization', 'sgx_frame_motion_model_batch_dev',
     'sgx_local_bundle_adjustment',
     'sgx_det_create', 'sgx_det_destroy', 'sgx_det_info', 'sgx_det_detect', 'sgx_det_forward_batch_dev', 'sgx_det_debug_read_blob',
@@ -120,6 +120,8 @@ class SgxLib:
         d.sgx_det_debug_read_blob.argtypes = [vp, C.c_char_p, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
         d.sgx_dynamic_mask_batch_dev.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp]
         d.sgx_match_project_local_batch_dev.argtypes = [C.c_int, C.c_int] + [vp] * 6 + [C.c_int] + [vp] * 8 + [C.POINTER(Camera), vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp, vp, vp]
+        d.sgx_frame_make_map_points_batch_dev.argtypes = [C.c_int, C.c_int, C.c_int] + [vp] * 7 + [C.c_int] + [vp] * 7
+        d.sgx_frame_merge_matches_batch_dev.argtypes = [C.c_int, C.c_int] + [vp] * 10
 
     def version(self):
         return self.dll.sgx_version().decode()

@@ -72,9 +72,40 @@ extern "C" int sgx_match_project_local_batch_dev(
         !d_m_skip || !d_cur_match || !d_nmatches || !d_in_view) return SGX_ERR_INVALID;
     SgxScales sc; memset(&sc, 0, sizeof sc);
     for (int i = 0; i < nlevels; i++) sc.s[i] = scale_factors[i];
+    sgx_prof_begin(SGX_K_MATCH_LOCAL, (sgx_stream_t)stream);
     SGX_LAUNCH(k_match_project_local, dim3(batch), dim3(SGX_MATCH_THREADS), (sgx_stream_t)stream, cap, (const uint8_t *)d_ckeys, d_cdesc, d_curight, d_cn, d_cTcw,
                d_cur_mp_obs, mcap, d_mn, d_m_xw, d_m_normal, d_m_min_dist, d_m_max_dist, d_m_desc, d_m_obs, d_m_skip, to_cam(cam), sc, nlevels, log_scale_factor,
                th, nnratio, viewing_cos_limit, d_cur_match, d_nmatches, d_in_view);
+    sgx_prof_end(SGX_K_MATCH_LOCAL, (sgx_stream_t)stream);
+    SGX_CHECK_HIP(hipGetLastError());
+    return SGX_OK;
+}
+
+extern "C" int sgx_frame_make_map_points_batch_dev(int batch, int cap, int half, const sgx_keypoint *d_keys, const int32_t *d_n, const float *d_xw, const uint8_t *d_has,
+                                                    const uint8_t *d_desc, const float *d_Tcw, const float *scale_factors, int nlevels,
+                                                    float *d_m_xw, float *d_m_normal, float *d_m_min_dist, float *d_m_max_dist, uint8_t *d_m_desc, uint8_t *d_m_skip, void *stream)
+{
+    if (batch < 1 || cap < 1 || half < 0 || half > 1 || !d_keys || !d_n || !d_xw || !d_has || !d_desc || !d_Tcw || !scale_factors || nlevels < 1 || nlevels > 12 ||
+        !d_m_xw || !d_m_normal || !d_m_min_dist || !d_m_max_dist || !d_m_desc || !d_m_skip) return SGX_ERR_INVALID;
+    SgxScales sc; memset(&sc, 0, sizeof sc);
+    for (int i = 0; i < nlevels; i++) sc.s[i] = scale_factors[i];
+    sgx_prof_begin(SGX_K_MAPGLUE, (sgx_stream_t)stream);
+    SGX_LAUNCH(k_make_map_points, dim3((cap + 255) / 256, batch), dim3(256), (sgx_stream_t)stream, cap, half, (const uint8_t *)d_keys, d_n, d_xw, d_has, d_desc, d_Tcw, sc, nlevels,
+               d_m_xw, d_m_normal, d_m_min_dist, d_m_max_dist, d_m_desc, d_m_skip);
+    sgx_prof_end(SGX_K_MAPGLUE, (sgx_stream_t)stream);
+    SGX_CHECK_HIP(hipGetLastError());
+    return SGX_OK;
+}
+
+extern "C" int sgx_frame_merge_matches_batch_dev(int batch, int cap, const int32_t *d_n, const int32_t *d_match_last, const uint8_t *d_outlier_last, const int32_t *d_match_local,
+                                                  const float *d_xw_last, const float *d_m_xw, int32_t *d_merged, int32_t *d_cur_mp_obs, float *d_xw_all, void *stream)
+{
+    if (batch < 1 || cap < 1 || !d_n || !d_match_last || !d_outlier_last) return SGX_ERR_INVALID;
+    sgx_prof_begin(SGX_K_MAPGLUE, (sgx_stream_t)stream);
+    SGX_LAUNCH(k_merge_matches, dim3((cap + 255) / 256, batch), dim3(256), (sgx_stream_t)stream, cap, d_n, d_match_last, d_outlier_last, d_match_local, d_merged, d_cur_mp_obs);
+    if (d_xw_all && d_xw_last && d_m_xw)
+        SGX_LAUNCH(k_gather_xw, dim3((3 * cap + 255) / 256, batch), dim3(256), (sgx_stream_t)stream, cap, d_xw_last, d_m_xw, d_xw_all);
+    sgx_prof_end(SGX_K_MAPGLUE, (sgx_stream_t)stream);
     SGX_CHECK_HIP(hipGetLastError());
     return SGX_OK;
 }

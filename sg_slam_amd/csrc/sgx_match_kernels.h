@@ -506,3 +506,72 @@ SGX_KERNEL(SGX_MATCH_THREADS) k_match_project_local(
     if (tid == 0) nmatches_out[f] = s_total;
     SGX_THREADS_END
 }
+
+// ---------------------------------------------------------------------------------------------
+// k_make_map_points: MapPoint::MapPoint(Pos, pMap, pFrame, idxF) (MapPoint.cc:45-67) for every keypoint of a frame that has
+// depth — the "visual odometry" points Tracking::UpdateLastFrame creates (Tracking.cc:840-904): normal = (P - Ow)/|P - Ow|,
+// mfMaxDistance = dist * scale[octave], mfMinDistance = mfMaxDistance / scale[nlevels-1], descriptor = the keypoint's.
+// Records go to slice `half` of a per-frame local-map ring of 2*cap entries; entries without depth are marked skip.
+// ---------------------------------------------------------------------------------------------
+SGX_KERNEL(256) k_make_map_points(int cap, int half, const uint8_t *keys_raw, const int *n, const float *xw, const uint8_t *has, const uint8_t *desc,
+                                  const float *Tcw, SgxScales sc, int nlevels, float *m_xw, float *m_normal, float *m_min, float *m_max, uint8_t *m_desc, uint8_t *m_skip)
+{
+    SGX_THREADS_BEGIN(tid)
+    const int f = (int)blockIdx.y, i = (int)blockIdx.x * 256 + tid;
+    if (i < cap) {
+        const size_t o = (size_t)f * cap + i, m = (size_t)f * 2 * cap + (size_t)half * cap + i;
+        const bool ok = i < n[f] && has[o];
+        m_skip[m] = ok ? 0 : 1;
+        if (ok) {
+            const float *T = Tcw + 16 * f;
+            float P[3], PO[3];
+            for (int r = 0; r < 3; r++) {
+                double s = 0; for (int k = 0; k < 3; k++) s += (double)T[4 * k + r] * (double)T[4 * k + 3];
+                P[r] = xw[3 * o + r]; PO[r] = P[r] - (float)(s * -1.0);
+            }
+            const double nrm = sqrt((double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2]);
+            const float dist = (float)nrm, inv = (float)(1.0 / nrm);
+            const int oct = ((const int *)(keys_raw + o * 28))[5];
+            const float mx = dist * sc.s[oct];
+            for (int r = 0; r < 3; r++) { m_xw[3 * m + r] = P[r]; m_normal[3 * m + r] = PO[r] * inv; }
+            m_max[m] = mx; m_min[m] = mx / sc.s[nlevels - 1];
+            const uint32_t *d = (const uint32_t *)(desc + o * 32); uint32_t *dd = (uint32_t *)(m_desc + m * 32);
+#pragma unroll
+            for (int w = 0; w < 8; w++) dd[w] = d[w];
+        }
+    }
+    SGX_THREADS_END
+}
+
+// k_merge_matches: the frame's mvpMapPoints after TrackWithMotionModel + SearchLocalPoints as ONE index into a combined
+// map-point table [last frame's points (cap) | local-map ring (2*cap)]: a local-map match replaces a visual-odometry point
+// (Observations()==0 points are overwritten, ORBmatcher.cc:87-89,123); motion-model outliers were dropped (Tracking.cc:941-956).
+SGX_KERNEL(256) k_merge_matches(int cap, const int *n, const int *match_last, const uint8_t *outlier_last, const int *match_local, int *merged, int *cur_mp_obs)
+{
+    SGX_THREADS_BEGIN(tid)
+    const int f = (int)blockIdx.y, i = (int)blockIdx.x * 256 + tid;
+    if (i < cap) {
+        const size_t o = (size_t)f * cap + i;
+        int idx = -1;
+        if (i < n[f]) {
+            if (match_local && match_local[o] >= 0) idx = cap + match_local[o];
+            else if (match_last[o] >= 0 && !outlier_last[o]) idx = match_last[o];
+        }
+        if (merged) merged[o] = idx;
+        if (cur_mp_obs) cur_mp_obs[o] = (i < n[f] && match_last[o] >= 0 && !outlier_last[o]) ? 0 : -1;    // VO points: Observations() == 0
+    }
+    SGX_THREADS_END
+}
+
+// k_gather_xw: combined map-point position table for pose optimisation #2: [last.xw (cap) | local-map xw (2*cap)] per frame
+SGX_KERNEL(256) k_gather_xw(int cap, const float *xw_last, const float *m_xw, float *xw_all)
+{
+    SGX_THREADS_BEGIN(tid)
+    const int f = (int)blockIdx.y, i = (int)blockIdx.x * 256 + tid;
+    if (i < 3 * cap) {
+        const float *src = i < cap ? xw_last + 3 * ((size_t)f * cap + i) : m_xw + 3 * ((size_t)f * 2 * cap + (i - cap));
+        float *dst = xw_all + 3 * ((size_t)f * 3 * cap + i);
+        dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+    }
+    SGX_THREADS_END
+}

@@ -16,3 +16,21 @@ def unproject_batch(lib, batch, cap, d_keys, d_n, d_zdepth, d_Tcw, cam, d_xw, d_
     cs = camera_struct(cam)
     lib.check(lib.dll.sgx_frame_unproject_batch_dev(batch, cap, _vp(d_keys), _vp(d_n), _vp(d_zdepth), _vp(d_Tcw), C.byref(cs), _vp(d_xw),
                                                     _vp(d_has), _vp(stream)), 'sgx_frame_unproject_batch_dev')
+
+
+def make_map_points_batch(lib, batch, cap, half, d_keys, d_n, d_xw, d_has, d_desc, d_Tcw, scale_factors, d_m_xw, d_m_normal, d_m_min, d_m_max,
+                          d_m_desc, d_m_skip, stream=None):
+    """MapPoint::MapPoint(Pos, pMap, pFrame, idxF) (MapPoint.cc:45-67) for every keypoint with depth -> slice `half` of a 2*cap ring."""
+    import numpy as np
+    sf = np.ascontiguousarray(scale_factors, 'f4')
+    lib.check(lib.dll.sgx_frame_make_map_points_batch_dev(batch, cap, int(half), _vp(d_keys), _vp(d_n), _vp(d_xw), _vp(d_has), _vp(d_desc), _vp(d_Tcw),
+                                                          _vp(sf), len(sf), _vp(d_m_xw), _vp(d_m_normal), _vp(d_m_min), _vp(d_m_max), _vp(d_m_desc),
+                                                          _vp(d_m_skip), _vp(stream)), 'sgx_frame_make_map_points_batch_dev')
+
+
+def merge_matches_batch(lib, batch, cap, d_n, d_match_last, d_outlier_last, d_match_local=None, d_xw_last=None, d_m_xw=None, d_merged=None,
+                        d_cur_mp_obs=None, d_xw_all=None, stream=None):
+    """mvpMapPoints after TrackWithMotionModel (+ SearchLocalPoints) as one index into [last.xw | local-map ring] (Tracking.cc:941-956)."""
+    lib.check(lib.dll.sgx_frame_merge_matches_batch_dev(batch, cap, _vp(d_n), _vp(d_match_last), _vp(d_outlier_last), _vp(d_match_local), _vp(d_xw_last),
+                                                        _vp(d_m_xw), _vp(d_merged), _vp(d_cur_mp_obs), _vp(d_xw_all), _vp(stream)),
+              'sgx_frame_merge_matches_batch_dev')

@@ -6,7 +6,10 @@ step, every stage device-resident and asynchronous on one HIP stream:
   constant-velocity prediction      -> sgx_frame_motion_model_batch_dev     (Tracking.cc:463-470, :914)
   ORBmatcher::SearchByProjection    -> sgx_match_project_frame_batch_dev    (ORBmatcher.cc:1332-1472, th=15)
   Optimizer::PoseOptimization       -> sgx_pose_optimization_batch_dev      (Optimizer.cc:239-451)
+  Tracking::TrackLocalMap           -> sgx_match_project_local_batch_dev    (isInFrustum + SearchByProjection(F, local points, th=3), Tracking.cc:1262-1312)
+                                       + sgx_pose_optimization_batch_dev    (second PoseOptimization, Tracking.cc:979)
   Frame::UnprojectStereo            -> sgx_frame_unproject_batch_dev        (Frame.cc:916-930)
+  MapPoint(Pos, pMap, pFrame, idx)  -> sgx_frame_make_map_points_batch_dev  (MapPoint.cc:45-67; the local map is the points of frames t-2, t-3)
 
 This mirrors the call order of Tracking::GrabImageRGBD -> Frame() -> TrackWithMotionModel
 (Tracking.cc:206-251, :906-967) in "visual odometry" form: the map points a frame is tracked against
@@ -22,7 +25,7 @@ from .orb import ORBextractor
 
 
 class TrackerBatch:
-    def __init__(self, lib, streams, cam, width=640, height=480, nfeatures=1000, xp='torch', th=15.0, pipelined=True):
+    def __init__(self, lib, streams, cam, width=640, height=480, nfeatures=1000, xp='torch', th=15.0, pipelined=True, local_map=True, debug_taps=False):
         self.lib, self.S, self.cam, self.W, self.H, self.th = lib, streams, dict(cam), width, height, th
         self.ex = ORBextractor(nfeatures=nfeatures, width=width, height=height, max_batch=streams, lib=lib)
         self.cap = self.ex.capacity
@@ -49,6 +52,19 @@ class TrackerBatch:
         self.zero_u8 = z((S, cap), 'u1')
         self.zero_i4 = z((S, cap), 'i4')
         self.vel_valid = z((S,), 'u1')
+        # TrackLocalMap stage (Tracking.cc:969-1013): local map = the visual-odometry points of frames t-2 and t-3 (ring of 2*cap records)
+        self.local_map = bool(local_map)
+        self.debug_taps = bool(debug_taps)          # tests: keep the pose between the two PoseOptimization calls
+        self.Tcw_mm = z((S, 16), 'f4')
+        self.log_scale = float(np.log(np.float32(self.scale[1])))
+        self.lm_xw = z((S, 2 * cap, 3), 'f4'); self.lm_normal = z((S, 2 * cap, 3), 'f4')
+        self.lm_min = z((S, 2 * cap), 'f4'); self.lm_max = z((S, 2 * cap), 'f4')
+        self.lm_desc = z((S, 2 * cap, 32), 'u1'); self.lm_skip = z((S, 2 * cap), 'u1')
+        self.lm_obs = z((S, 2 * cap), 'i4'); self.lm_n = z((S,), 'i4')
+        self.lm_skip[...] = 1; self.lm_obs[...] = 1; self.lm_n[...] = 2 * cap
+        self.match_local = z((S, cap), 'i4'); self.nmatch_local = z((S,), 'i4'); self.in_view = z((S, 2 * cap), 'u1')
+        self.merged = z((S, cap), 'i4'); self.cur_mp_obs = z((S, cap), 'i4'); self.xw_all = z((S, 3 * cap, 3), 'f4')
+        self.outlier2 = z((S, cap), 'u1'); self.ninl2 = z((S,), 'i4')
         self.cur = 0
         self.frame_idx = 0
         # Two HIP streams: E = extraction (+stereo) of frame t+1 overlaps T = match / pose-opt / unproject of frame t.  The wide
@@ -120,8 +136,33 @@ class TrackerBatch:
                         self.vel_valid.fill_(1)
                 else:
                     self.vel_valid[...] = 1
+        if t > 0 and self.debug_taps:
+            if self.pipelined:
+                import torch
+                with torch.cuda.stream(self.sT):
+                    self.Tcw_mm.copy_(Tc)
+            else:
+                self.Tcw_mm[...] = Tc
+        if t > 0 and self.local_map:
+            # ---- TrackLocalMap: SearchLocalPoints (isInFrustum + SearchByProjection th=3) and the second PoseOptimization
+            L.check(L.dll.sgx_frame_merge_matches_batch_dev(S, cap, _vp(self.n[c]), _vp(self.match), _vp(self.outlier), None, None, None,
+                                                            None, _vp(self.cur_mp_obs), None, st), 'mp_obs')
+            L.check(L.dll.sgx_match_project_local_batch_dev(
+                S, cap, _vp(self.keys[c]), _vp(self.desc[c]), _vp(self.uright[c]), _vp(self.n[c]), _vp(Tc), _vp(self.cur_mp_obs),
+                2 * cap, _vp(self.lm_n), _vp(self.lm_xw), _vp(self.lm_normal), _vp(self.lm_min), _vp(self.lm_max), _vp(self.lm_desc), _vp(self.lm_obs), _vp(self.lm_skip),
+                C.byref(self.cs), _vp(self.scale), len(self.scale), self.log_scale, 3.0, 0.8, 0.5, _vp(self.match_local), _vp(self.nmatch_local), _vp(self.in_view), st), 'match local')
+            L.check(L.dll.sgx_frame_merge_matches_batch_dev(S, cap, _vp(self.n[c]), _vp(self.match), _vp(self.outlier), _vp(self.match_local),
+                                                            _vp(self.xw[l]), _vp(self.lm_xw), _vp(self.merged), None, _vp(self.xw_all), st), 'merge')
+            L.check(L.dll.sgx_pose_optimization_batch_dev(
+                S, cap, _vp(self.keys[c]), _vp(self.uright[c]), _vp(self.n[c]), _vp(self.merged), None, _vp(self.xw_all), 3 * cap,
+                _vp(self.inv_sigma2), len(self.inv_sigma2), C.byref(self.cs), _vp(Tc), _vp(self.outlier2), _vp(self.ninl2), st), 'pose opt 2')
         L.check(L.dll.sgx_frame_unproject_batch_dev(S, cap, _vp(self.keys[c]), _vp(self.n[c]), _vp(self.zdepth[c]), _vp(Tc), C.byref(self.cs),
                                                     _vp(self.xw[c]), _vp(self.has[c]), st), 'unproject')
+        if t > 0 and self.local_map:
+            # the last frame's points join the local map for the NEXT frames (ring slice (t-1) % 2 <- frame t-1, i.e. at step t+1 the ring holds t-1 and t-2)
+            L.check(L.dll.sgx_frame_make_map_points_batch_dev(S, cap, (t - 1) % 2, _vp(self.keys[l]), _vp(self.n[l]), _vp(self.xw[l]), _vp(self.has[l]), _vp(self.desc[l]),
+                                                              _vp(Tl), _vp(self.scale), len(self.scale), _vp(self.lm_xw), _vp(self.lm_normal), _vp(self.lm_min),
+                                                              _vp(self.lm_max), _vp(self.lm_desc), _vp(self.lm_skip), st), 'make map points')
         if self.pipelined:
             self.ev_track[c].record(self.sT)
         # rotate poses: cur -> last, last -> last-last
@@ -145,3 +186,9 @@ class TrackerBatch:
         self.synchronize()
         g = (lambda a: a.cpu().numpy()) if self.xp == 'torch' else (lambda a: a.copy())
         return g(self.n[self.cur]), g(self.nmatch), g(self.ninl)
+
+    def last_local_counts(self):
+        """(local-map matches, inliers of the second PoseOptimization) of the last tracked frame"""
+        self.synchronize()
+        g = (lambda a: a.cpu().numpy()) if self.xp == 'torch' else (lambda a: a.copy())
+        return g(self.nmatch_local), g(self.ninl2)

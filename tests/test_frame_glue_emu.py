@@ -30,5 +30,55 @@ def run_glue(lib, oracle, S, to_dev=lambda a: a, to_host=lambda a: a):
     assert (has[0, :n] == ehas).all() and (xw[0, :n][ehas > 0] == exw[ehas > 0]).all() and (has[0, n:] == 0).all()
 
 
+def run_map_glue(lib, oracle, S, to_dev=lambda a: a, to_host=lambda a: a):
+    """make_map_points (MapPoint.cc:45-67) and merge_matches (Tracking.cc:941-956) vs numpy restatements, bit-exact."""
+    from test_tracker_emu import make_map_points
+    g, d, T = S.frame(7)
+    d = d.copy(); d[60:200, 300:420] = 0
+    k, desc = oracle.orb_extract(g)
+    _, z = oracle.compute_stereo_from_rgbd(k, d, CAM['bf'], CAM['depth_factor'])
+    T32 = T.astype('f4')
+    xw, has = oracle.unproject_stereo(k, z, T32, CAM)
+    sf = np.asarray(oracle.orb_params()['scale'], 'f4')
+    cap = 1024; n = len(k)
+    keys = np.zeros((2, cap), KP_DTYPE); keys[1, :n] = k
+    X = np.zeros((2, cap, 3), 'f4'); X[1, :n] = xw
+    Hs = np.zeros((2, cap), np.uint8); Hs[1, :n] = has; Hs[1, n:] = 1            # rows beyond n must be ignored
+    De = np.zeros((2, cap, 32), np.uint8); De[1, :n] = desc
+    cnt = np.array([0, n], 'i4'); Tb = np.stack([np.eye(4, dtype='f4'), T32]).reshape(2, 16)
+    ring = dict(xw=np.full((2, 2 * cap, 3), 7, 'f4'), normal=np.full((2, 2 * cap, 3), 7, 'f4'), mn=np.full((2, 2 * cap), 7, 'f4'), mx=np.full((2, 2 * cap), 7, 'f4'),
+                desc=np.full((2, 2 * cap, 32), 7, np.uint8), skip=np.zeros((2, 2 * cap), np.uint8))
+    dv = {k2: to_dev(v) for k2, v in ring.items()}
+    fr.make_map_points_batch(lib, 2, cap, 1, to_dev(keys), to_dev(cnt), to_dev(X), to_dev(Hs), to_dev(De), to_dev(Tb), sf,
+                             dv['xw'], dv['normal'], dv['mn'], dv['mx'], dv['desc'], dv['skip'])
+    out = {k2: to_host(v) for k2, v in dv.items()}
+    e = make_map_points(k, xw, has, desc, T32, sf)
+    ok = has > 0
+    assert ok.sum() > 300 and (~ok).sum() > 20
+    assert (out['skip'][1, cap:cap + n] == e['skip']).all() and (out['skip'][1, cap + n:] == 1).all() and (out['skip'][0, cap:] == 1).all()
+    assert (out['skip'][:, :cap] == 0).all() and (out['xw'][:, :cap] == 7).all()                      # the other half is untouched
+    for name, key in (('xw', 'xw'), ('normal', 'normal'), ('mn', 'min_dist'), ('mx', 'max_dist'), ('desc', 'desc')):
+        assert (out[name][1, cap:cap + n][ok] == e[key][ok]).all(), name
+    # merge
+    rng = np.random.RandomState(3)
+    ml = np.where(rng.rand(2, cap) < 0.6, rng.randint(0, cap, (2, cap)), -1).astype('i4')
+    ol = (rng.rand(2, cap) < 0.2).astype(np.uint8)
+    mloc = np.where(rng.rand(2, cap) < 0.3, rng.randint(0, 2 * cap, (2, cap)), -1).astype('i4')
+    cnt2 = np.array([700, 1000], 'i4')
+    merged = to_dev(np.zeros((2, cap), 'i4')); obs = to_dev(np.zeros((2, cap), 'i4')); xall = to_dev(np.zeros((2, 3 * cap, 3), 'f4'))
+    xl = rng.rand(2, cap, 3).astype('f4'); xm = rng.rand(2, 2 * cap, 3).astype('f4')
+    fr.merge_matches_batch(lib, 2, cap, to_dev(cnt2), to_dev(ml), to_dev(ol), to_dev(mloc), to_dev(xl), to_dev(xm), merged, obs, xall)
+    merged, obs, xall = map(to_host, (merged, obs, xall))
+    live = np.arange(cap)[None, :] < cnt2[:, None]
+    keep = live & (ml >= 0) & (ol == 0)
+    em = np.where(live & (mloc >= 0), cap + mloc, np.where(keep, ml, -1))
+    assert (merged == em).all() and (obs == np.where(keep, 0, -1)).all()
+    assert (xall[:, :cap] == xl).all() and (xall[:, cap:] == xm).all()
+
+
+def test_map_glue_emu(emu, oracle, stream_frames):
+    run_map_glue(emu, oracle, stream_frames)
+
+
 def test_glue_emu(emu, oracle, stream_frames):
     run_glue(emu, oracle, stream_frames)

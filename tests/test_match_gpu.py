@@ -32,3 +32,11 @@ def test_glue_gpu(gpulib, oracle, stream_frames):
     run_glue(gpulib, oracle, stream_frames,
              to_dev=lambda a: torch.from_numpy(a.view(np.uint8) if a.dtype.fields else (a.view(np.int16) if a.dtype == np.uint16 else a)).cuda(),
              to_host=lambda t: t.cpu().numpy())
+
+
+def test_map_glue_gpu(gpulib, oracle, stream_frames):
+    import torch
+    from test_frame_glue_emu import run_map_glue
+    run_map_glue(gpulib, oracle, stream_frames,
+                 to_dev=lambda a: torch.from_numpy(a.view(np.uint8) if a.dtype.fields else (a.view(np.int16) if a.dtype == np.uint16 else a)).cuda(),
+                 to_host=lambda t: t.cpu().numpy())

@@ -1,4 +1,4 @@
-"""End-to-end tracking harness on the kernel-logic emulator: 2 streams x 5 frames.  Each stage's
+"""End-to-end tracking harness on the kernel-logic emulator: 2 streams x 5 frames (TrackWithMotionModel + TrackLocalMap).  Each stage's
 output is checked against the oracle chained the same way (bit-exact where the stage is integer /
 fp32, 1e-5 relative for the optimised pose), and the pose follows the synthetic ground truth."""
 import numpy as np
@@ -7,10 +7,43 @@ from sg_slam_amd import synth
 from sg_slam_amd.tracker import TrackerBatch
 
 
+def make_map_points(k, xw, has, d, Tcw, sf):
+    """MapPoint::MapPoint(Pos, pMap, pFrame, idxF) (MapPoint.cc:45-67) for every keypoint with depth (numpy restatement of the glue)."""
+    n = len(k)
+    R = Tcw[:3, :3].astype('f8'); tt = Tcw[:3, 3].astype('f8')
+    Ow = np.array([-(R[0, r] * tt[0] + R[1, r] * tt[1] + R[2, r] * tt[2]) for r in range(3)]).astype('f4')
+    PO = (xw.astype('f4') - Ow[None, :]).astype('f4')
+    nrm = np.sqrt((PO.astype('f8') ** 2)[:, 0] + (PO.astype('f8') ** 2)[:, 1] + (PO.astype('f8') ** 2)[:, 2])
+    with np.errstate(divide='ignore', invalid='ignore'):
+        inv = (1.0 / nrm).astype('f4')
+        normal = (PO * inv[:, None]).astype('f4')
+    mx = (nrm.astype('f4') * sf[k['octave']].astype('f4')).astype('f4')
+    mn = (mx / np.float32(sf[-1])).astype('f4')
+    skip = (has == 0).astype(np.uint8)
+    for a in (normal, mx, mn):
+        a[skip == 1] = 0
+    return dict(xw=np.where(skip[:, None] == 1, 0, xw).astype('f4'), normal=normal, min_dist=mn, max_dist=mx, desc=d.copy(), skip=skip, obs=np.ones(n, 'i4'))
+
+
+def ring_concat(ring, cap):
+    """[half 0 | half 1] padded to cap records each, like the device ring"""
+    out = {}
+    for key, shp, dt, fill in (('xw', (3,), 'f4', 0), ('normal', (3,), 'f4', 0), ('min_dist', (), 'f4', 0), ('max_dist', (), 'f4', 0),
+                               ('desc', (32,), 'u1', 0), ('skip', (), 'u1', 1), ('obs', (), 'i4', 1)):
+        a = np.full((2 * cap,) + shp, fill, dt)
+        for h in range(2):
+            if ring[h] is not None:
+                m = len(ring[h][key]); a[h * cap:h * cap + m] = ring[h][key]
+        out[key] = a
+    return out
+
+
 def run_tracker(lib, oracle, xp):
     S = synth.PlaneStream(seed=1234)
     offs = [0, 41]
-    tr = TrackerBatch(lib, 2, CAM, xp=xp)
+    tr = TrackerBatch(lib, 2, CAM, xp=xp, debug_taps=True)
+    cap = tr.cap
+    rings = [[None, None], [None, None]]; prev = [None, None]
     H = (lambda a: a.cpu().numpy()) if xp == 'torch' else (lambda a: a)
     def D(a):
         if xp != 'torch':
@@ -25,7 +58,9 @@ def run_tracker(lib, oracle, xp):
         gray = np.stack([f[0] for f in fr]); depth = np.stack([f[1] for f in fr])
         tr.step(D(gray), D(depth))
         n, nm, ninl = tr.last_counts()
+        nml, ninl2 = tr.last_local_counts()
         Tg = tr.last_pose()
+        Tmm = H(tr.Tcw_mm).reshape(2, 4, 4)
         for s in range(2):
             k, d = oracle.orb_extract(fr[s][0])
             ur, z = oracle.compute_stereo_from_rgbd(k, fr[s][1], CAM['bf'], CAM['depth_factor'])
@@ -37,7 +72,7 @@ def run_tracker(lib, oracle, xp):
                     Tpred = Tl[s].copy()
                 else:                      # pred = Tl * inv(Tll) * Tl in float32 (the oracle of this glue is numpy fp32 here)
                     Tpred = None
-                cur = dict(keys=k, desc=d, uright=ur, Tcw=Tpred if Tpred is not None else Tg[s])   # matching pose: see below
+                cur = dict(keys=k, desc=d, uright=ur, Tcw=Tpred)   # matching pose: see below
                 if Tpred is None:
                     # recompute the prediction exactly as the kernel does (float32, left-to-right)
                     A = Tl[s]; P = Tll[s]
@@ -60,10 +95,29 @@ def run_tracker(lib, oracle, xp):
                            xw=np.where((exp_match >= 0)[:, None], last[s]['xw'][np.maximum(exp_match, 0)], 0).astype('f4'))
                 en, eT, eout = oracle.pose_optimization(fr2, CAM, is2)
                 assert ninl[s] == en and (H(tr.outlier)[s, :len(k)] == eout).all()
-                assert np.abs(Tg[s] - eT).max() <= 1e-5 * max(1.0, np.abs(eT).max())
+                assert np.abs(Tmm[s] - eT).max() <= 1e-5 * max(1.0, np.abs(eT).max())
+                # ---- TrackLocalMap (Tracking.cc:969-1013): local points = VO points of frames t-2, t-3; chained from the DEVICE pose of stage 1
+                keep = (exp_match >= 0) & (eout == 0)
+                lm = ring_concat(rings[s], cap)
+                cur2 = dict(keys=k, desc=d, uright=ur, Tcw=Tmm[s], mp_obs=np.where(keep, 0, -1).astype('i4'))
+                eml, enl, einview = oracle.search_by_projection_local(cur2, lm, CAM, sf, th=3.0, nnratio=0.8, viewing_cos_limit=0.5)
+                assert nml[s] == enl and (H(tr.match_local)[s, :len(k)] == eml).all()
+                assert (H(tr.in_view)[s] == einview).all()
+                merged = np.where(eml >= 0, cap + eml, np.where(keep, exp_match, -1))
+                assert (H(tr.merged)[s, :len(k)] == merged).all()
+                xw_all = np.concatenate([np.pad(last[s]['xw'], ((0, cap - len(last[s]['xw'])), (0, 0))), lm['xw']]).astype('f4')
+                fr3 = dict(keys=k, uright=ur, has_mp=(merged >= 0).astype(np.uint8), Tcw=Tmm[s],
+                           xw=np.where((merged >= 0)[:, None], xw_all[np.maximum(merged, 0)], 0).astype('f4'))
+                en2, eT2, eout2 = oracle.pose_optimization(fr3, CAM, is2)
+                assert ninl2[s] == en2 and (H(tr.outlier2)[s, :len(k)] == eout2).all()
+                assert np.abs(Tg[s] - eT2).max() <= 1e-5 * max(1.0, np.abs(eT2).max())
+                if t >= 3:
+                    assert enl > 50                       # the local map really contributes once the ring is filled
                 Tc = Tg[s].copy()
                 # tracking follows the synthetic ground truth
                 assert np.abs(Tc - S.Tcw(offs[s] + t)).max() < 0.02 and en > 150
+            if t > 0:          # frame t-1's points join the local map after frame t was tracked (ring slice (t-1) % 2)
+                rings[s][(t - 1) % 2] = make_map_points(last[s]['keys'], last[s]['xw'], last[s]['has_mp'], last[s]['desc'], Tl[s], np.asarray(sf, 'f4'))
             xw, has = oracle.unproject_stereo(k, z, Tc, CAM)
             last[s] = dict(keys=k, desc=d, uright=ur, Tcw=Tc, has_mp=has, outlier=np.zeros(len(k), np.uint8), xw=xw,
                            obs=np.zeros(len(k), 'i4'), mpdesc=d)
