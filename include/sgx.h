@@ -226,6 +226,11 @@ int sgx_det_detect(sgx_det *h, const uint8_t *images, int pitch, int batch, sgx_
 /* device-resident batched forward only: leaves mbox_loc (num_priors*4) and softmax conf (num_priors*num_class) per image in HBM */
 int sgx_det_forward_batch_dev(sgx_det *h, const uint8_t *d_img, int pitch, int batch, const float **d_loc, const float **d_conf, void *stream);
 int sgx_det_debug_read_blob(sgx_det *h, const char *blob_name, int image, float *dst, int cap, int *n);
+/* test / tuning taps.  set_fusion(0) makes the NEXT sgx_det_create build the unfused plan (one kernel per ncnn layer, every blob
+ * materialised) — the fused plan (default) must reproduce it bit for bit.  time_ops: HIP-event time per plan step (ms[0] = pre-processing). */
+int sgx_det_debug_set_fusion(int on);
+int sgx_det_debug_time_ops(sgx_det *h, const uint8_t *d_img, int pitch, int batch, int reps, float *ms, int cap, int *nops);
+int sgx_det_debug_op_desc(const sgx_det *h, int i, char *buf, int cap);
 /* Frame::RmDynamicPointWithSemanticAndGeometry's keep/erase predicate (src/sg-slam/src/Frame.cc:556-597, :613-652): keep[i] = 1 when the
  * epipolar distance of (keypoint i, its LK-tracked previous position) under F (3x3 row-major fp64, cv::findFundamentalMat) is below
  * 0.2 px inside a person box / 1.0 px elsewhere.  boxes: max_boxes x (x, y, w, h) per frame.  The caller applies the

@@ -27,8 +27,10 @@ struct Layer {
 };
 struct Blob { int c = 0, h = 0, w = 0; size_t n = 0; float *d = nullptr; bool scalar = false; float sval = 0.f; int alias = -1; };
 enum OpKind { OP_PW, OP_KXK, OP_BINARY, OP_UNARY, OP_PERMUTE_INTO, OP_COPY_INTO, OP_SOFTMAX };
+struct EpiStep { int op, src; float a, b; int tensor; };
 struct Op {
     OpKind kind; int in0 = -1, in1 = -1, out = -1;
+    std::vector<EpiStep> epi; int hwc = 0, hwc_off = 0; bool dead = false; std::string name;
     int inc = 0, outc = 0, H = 0, W = 0, Ho = 0, Wo = 0, k = 1, stride = 1, pad = 0, depthwise = 0, act = 0; float lo = 0, hi = 0;
     float *wt = nullptr, *bias = nullptr; int bop = 0; int off = 0; int rows = 0, C = 0;
 };
@@ -50,6 +52,9 @@ struct sgx_det {
     ~sgx_det() { for (void *p : dev) (void)hipFree(p); }
     template <class Tp> int alloc(Tp **p, size_t n) { void *q = nullptr; if (hipMalloc(&q, (n ? n : 1) * sizeof(Tp)) != hipSuccess) return SGX_ERR_NOMEM; dev.push_back(q); *p = (Tp *)q; return SGX_OK; }
 };
+
+static int g_det_fuse = 1;
+extern "C" int sgx_det_debug_set_fusion(int on) { g_det_fuse = on ? 1 : 0; return SGX_OK; }
 
 static int parse_param(const char *text, std::vector<Layer> &layers)
 {
@@ -107,7 +112,6 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
     const uint8_t *bp = (const uint8_t *)bin; size_t bo = 0;
     auto blob = [&](const std::string &n) -> int { auto it = h->blob_id.find(n); if (it != h->blob_id.end()) return it->second; h->blob_id[n] = (int)h->blobs.size(); h->blobs.push_back(Blob()); return (int)h->blobs.size() - 1; };
     auto resolve = [&](int id) { while (h->blobs[id].alias >= 0) id = h->blobs[id].alias; return id; };
-    auto consumers = [&](const std::string &name, std::vector<const Layer *> &outv) { outv.clear(); for (const Layer &L : h->layers) for (const std::string &i : L.ins) if (i == name) outv.push_back(&L); };
 #define FAIL(code) do { delete h; return (code); } while (0)
     std::map<std::string, std::pair<int, int>> into;       // conv output name -> (concat blob id, offset): fused Permute+Flatten+Concat
     std::map<std::string, int> concat_off;                 // flatten output name -> offset inside its concat
@@ -141,37 +145,24 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
             op.kind = (k == 1 && group == 1 && stride == 1 && pad == 0) ? OP_PW : OP_KXK;
             op.in0 = in0;
             h->gmac += (double)op.Ho * op.Wo * wsize * 1e-9;
-            // peephole: a ReLU / Clip that is the only consumer of this convolution is folded into its epilogue
-            std::string outname = L.outs[0];
-            std::vector<const Layer *> cons; consumers(outname, cons);
-            if (cons.size() == 1 && (cons[0]->type == "ReLU" || cons[0]->type == "Clip")) {
-                op.act = cons[0]->type == "ReLU" ? SGX_ACT_RELU : SGX_ACT_CLIP; op.lo = cons[0]->getf(0, 0.f); op.hi = cons[0]->getf(1, 0.f);
-                const int oid = blob(cons[0]->outs[0]); Blob &ob = h->blobs[oid]; ob.c = outc; ob.h = op.Ho; ob.w = op.Wo; ob.n = (size_t)outc * op.Ho * op.Wo;
-                if (h->alloc(&ob.d, ob.n * B)) FAIL(SGX_ERR_NOMEM);
-                op.out = oid;
-                const int cid = blob(outname); h->blobs[cid] = ob; h->blobs[cid].alias = oid;
-            } else {
-                const int oid = blob(outname); Blob &ob = h->blobs[oid]; ob.c = outc; ob.h = op.Ho; ob.w = op.Wo; ob.n = (size_t)outc * op.Ho * op.Wo;
-                if (h->alloc(&ob.d, ob.n * B)) FAIL(SGX_ERR_NOMEM);
-                op.out = oid;
-            }
+            const int oid = blob(L.outs[0]); Blob &ob = h->blobs[oid]; ob = Blob(); ob.c = outc; ob.h = op.Ho; ob.w = op.Wo; ob.n = (size_t)outc * op.Ho * op.Wo;
+            op.out = oid; op.name = L.name;
             h->ops.push_back(op);
             continue;
         }
         if (L.type == "ReLU" || L.type == "Clip") {
             const int oid = blob(L.outs[0]);
-            if (h->blobs[oid].alias >= 0 || h->blobs[oid].d) continue;        // already produced by a fused convolution epilogue
             Op op; op.kind = OP_UNARY; op.in0 = in0; op.act = L.type == "ReLU" ? SGX_ACT_RELU : SGX_ACT_CLIP; op.lo = L.getf(0, 0.f); op.hi = L.getf(1, 0.f);
-            Blob &ob = h->blobs[oid]; ob = A; ob.alias = -1; if (h->alloc(&ob.d, ob.n * B)) FAIL(SGX_ERR_NOMEM);
-            op.out = oid; h->ops.push_back(op); continue;
+            Blob &ob = h->blobs[oid]; ob = A; ob.alias = -1; ob.d = nullptr;
+            op.out = oid; op.name = L.name; h->ops.push_back(op); continue;
         }
         if (L.type == "BinaryOp") {
             const int in1 = resolve(blob(L.ins[1]));
             Op op; op.kind = OP_BINARY; op.in0 = in0; op.in1 = in1; op.bop = L.geti(0, 0);
             if (op.bop != 0 && op.bop != 2 && op.bop != 3) FAIL(SGX_ERR_UNSUPPORTED);
             if (!h->blobs[in1].scalar && h->blobs[in1].n != A.n) FAIL(SGX_ERR_UNSUPPORTED);
-            const int oid = blob(L.outs[0]); Blob &ob = h->blobs[oid]; ob = A; ob.alias = -1; if (h->alloc(&ob.d, ob.n * B)) FAIL(SGX_ERR_NOMEM);
-            op.out = oid; h->ops.push_back(op); continue;
+            const int oid = blob(L.outs[0]); Blob &ob = h->blobs[oid]; ob = A; ob.alias = -1; ob.d = nullptr;
+            op.out = oid; op.name = L.name; h->ops.push_back(op); continue;
         }
         const int raw_in = blob(L.ins[0]);                                    // unresolved: keeps view layers (Permute) visible in the alias chain
         if (L.type == "Permute") { if (L.geti(0, 0) != 3) FAIL(SGX_ERR_UNSUPPORTED); const int oid = blob(L.outs[0]); h->blobs[oid] = A; h->blobs[oid].alias = raw_in; h->blobs[oid].sval = 1.f; /* marks "HWC view of" */ continue; }
@@ -198,21 +189,21 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
         if (L.type == "Concat") {
             if (L.name == "mbox_priorbox") { blob(L.outs[0]); continue; }
             size_t total = 0; for (const std::string &i : L.ins) total += h->blobs[resolve(blob(i))].n;
-            const int oid = blob(L.outs[0]); Blob &ob = h->blobs[oid]; ob.c = 1; ob.h = 1; ob.w = (int)total; ob.n = total; if (h->alloc(&ob.d, ob.n * B)) FAIL(SGX_ERR_NOMEM);
+            const int oid = blob(L.outs[0]); Blob &ob = h->blobs[oid]; ob.c = 1; ob.h = 1; ob.w = (int)total; ob.n = total;
             int off = 0;
             for (const std::string &i : L.ins) {
                 // input is Flatten(Permute(conv)) : find whether a Permute sits in the alias chain
                 int id = blob(i); bool hwc = false; while (h->blobs[id].alias >= 0) { if (h->blobs[id].sval == 1.f) hwc = true; id = h->blobs[id].alias; }
                 Op op; op.kind = hwc ? OP_PERMUTE_INTO : OP_COPY_INTO; op.in0 = id; op.out = oid; op.off = off; op.C = h->blobs[id].c; op.rows = h->blobs[id].h * h->blobs[id].w;
-                h->ops.push_back(op); off += (int)h->blobs[id].n;
+                op.name = L.name; h->ops.push_back(op); off += (int)h->blobs[id].n;
             }
             continue;
         }
         if (L.type == "Reshape") { const int oid = blob(L.outs[0]); h->blobs[oid] = A; h->blobs[oid].alias = raw_in; h->blobs[oid].w = L.geti(0, 1); h->blobs[oid].h = (int)(A.n / L.geti(0, 1)); continue; }
         if (L.type == "Softmax") {
             Op op; op.kind = OP_SOFTMAX; op.in0 = in0; op.C = h->blobs[blob(L.ins[0])].w; op.rows = (int)(A.n / op.C);
-            const int oid = blob(L.outs[0]); Blob &ob = h->blobs[oid]; ob = A; ob.alias = -1; if (h->alloc(&ob.d, ob.n * B)) FAIL(SGX_ERR_NOMEM);
-            op.out = oid; h->ops.push_back(op); continue;
+            const int oid = blob(L.outs[0]); Blob &ob = h->blobs[oid]; ob = A; ob.alias = -1; ob.d = nullptr;
+            op.out = oid; op.name = L.name; h->ops.push_back(op); continue;
         }
         if (L.type == "DetectionOutput") {
             h->loc_blob = resolve(blob(L.ins[0])); h->conf_blob = resolve(blob(L.ins[1]));
@@ -222,8 +213,75 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
         }
         FAIL(SGX_ERR_UNSUPPORTED);
     }
+    if (h->loc_blob < 0 || h->conf_blob < 0) FAIL(SGX_ERR_INVALID);
+    // ---- fusion pass: fold the elementwise chain behind every convolution into its epilogue, and the Permute+Flatten+Concat copy of
+    // the head convolutions into an HWC store.  Same fp32 operations in the same order: the fused plan is bit-identical to the unfused one.
+    if (g_det_fuse) {
+        std::vector<Op> &ops = h->ops;
+        const int nops = (int)ops.size();
+        std::vector<int> producer(h->blobs.size(), -2);
+        producer[resolve(h->blob_id.at("input"))] = -1;
+        for (int i = 0; i < nops; i++) if (ops[i].kind != OP_PERMUTE_INTO && ops[i].kind != OP_COPY_INTO) producer[ops[i].out] = i;
+        auto readers = [&](int id, std::vector<int> &r) {
+            r.clear();
+            for (int i = 0; i < nops; i++) {
+                if (ops[i].dead) continue;
+                const bool r0 = ops[i].in0 == id, r1 = ops[i].kind == OP_BINARY && ops[i].in1 == id && !h->blobs[id].scalar;
+                if (r0 || r1) r.push_back(i);
+            }
+        };
+        std::vector<int> R;
+        for (int ci = 0; ci < nops; ci++) {
+            Op &cv = ops[ci];
+            if (cv.kind != OP_PW && cv.kind != OP_KXK) continue;
+            const int root = cv.out;
+            int cur = root, root_extra = -1;
+            std::vector<EpiStep> steps; std::vector<int> absorbed;
+            while ((int)steps.size() < SGX_EPI_MAX) {
+                if (cur == h->loc_blob || cur == h->conf_blob) break;
+                readers(cur, R);
+                int next = -1;
+                if (R.size() == 1) next = R[0];
+                else if (cur == root && R.size() == 2 && steps.empty()) { next = std::min(R[0], R[1]); root_extra = std::max(R[0], R[1]); }
+                else break;
+                if (next == root_extra && cur != root) { /* handled below as the ROOT operand */ }
+                const Op &e = ops[next];
+                EpiStep st; st.a = 0; st.b = 0; st.tensor = -1; st.src = SGX_ESRC_CONST;
+                if (e.kind == OP_UNARY) { st.op = e.act == SGX_ACT_RELU ? SGX_EOP_RELU : SGX_EOP_CLIP; st.a = e.lo; st.b = e.hi; }
+                else if (e.kind == OP_BINARY) {
+                    if (e.in0 == cur && e.in1 == cur) break;
+                    const bool first = e.in0 == cur;                     // chain value is the left operand
+                    const int other = first ? e.in1 : e.in0;
+                    const int fwd = e.bop == 0 ? SGX_EOP_ADD : e.bop == 2 ? SGX_EOP_MUL : SGX_EOP_DIV;
+                    st.op = first ? fwd : (e.bop == 3 ? SGX_EOP_RDIV : fwd);
+                    if (h->blobs[other].scalar) { st.src = SGX_ESRC_CONST; st.a = h->blobs[other].sval; }
+                    else if (other == root && cur != root) { st.src = SGX_ESRC_ROOT; }
+                    else if (producer[other] >= -1 && producer[other] < ci && h->blobs[other].n == h->blobs[root].n) { st.src = SGX_ESRC_TENSOR; st.tensor = other; }
+                    else break;
+                } else break;
+                steps.push_back(st); absorbed.push_back(next); cur = e.out;
+            }
+            // the convolution's raw output stays in registers: every reader of it must have been absorbed
+            if (root_extra >= 0 && std::find(absorbed.begin(), absorbed.end(), root_extra) == absorbed.end()) { steps.clear(); absorbed.clear(); cur = root; }
+            // ... and a ROOT operand may only be used when the raw output has no reader left outside the chain
+            if (!steps.empty()) {
+                cv.epi = steps; cv.out = cur;
+                for (int a : absorbed) ops[a].dead = true;
+                producer[cur] = ci;
+            }
+            if (cv.kind == OP_PW) {                                      // head convolution -> HWC store into the concat buffer
+                bool tens = false; for (const EpiStep &st : cv.epi) tens = tens || st.src == SGX_ESRC_TENSOR;
+                readers(cv.out, R);
+                if (!tens && R.size() == 1 && ops[R[0]].kind == OP_PERMUTE_INTO && cv.out != h->loc_blob && cv.out != h->conf_blob) {
+                    cv.hwc = 1; cv.hwc_off = ops[R[0]].off; cv.out = ops[R[0]].out; ops[R[0]].dead = true;
+                }
+            }
+        }
+        std::vector<Op> live; for (const Op &o : ops) if (!o.dead) live.push_back(o);
+        ops.swap(live);
+    }
+    for (const Op &o : h->ops) { Blob &ob = h->blobs[o.out]; if (!ob.d && ob.n) { if (h->alloc(&ob.d, ob.n * B)) FAIL(SGX_ERR_NOMEM); } }
 #undef FAIL
-    if (h->loc_blob < 0 || h->conf_blob < 0) { delete h; return SGX_ERR_INVALID; }
     h->num_priors = (int)prior_boxes.size() / 4;
     h->priors = prior_boxes; h->priors.insert(h->priors.end(), prior_vars.begin(), prior_vars.end());
     if ((size_t)h->num_priors * 4 != h->blobs[h->loc_blob].n || (size_t)h->num_priors * h->num_class != h->blobs[h->conf_blob].n) { delete h; return SGX_ERR_INVALID; }
@@ -234,43 +292,101 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
     return SGX_OK;
 }
 
+static SgxEpi make_epi(const sgx_det *h, const Op &op, size_t tpitch)
+{
+    SgxEpi e; memset(&e, 0, sizeof e);
+    e.tpitch = tpitch;
+    if (op.act == SGX_ACT_RELU) { e.s[e.n].op = SGX_EOP_RELU; e.n++; }
+    else if (op.act == SGX_ACT_CLIP) { e.s[e.n].op = SGX_EOP_CLIP; e.s[e.n].a = op.lo; e.s[e.n].b = op.hi; e.n++; }
+    for (const EpiStep &st : op.epi) {
+        SgxEpiStep &d = e.s[e.n++];
+        d.op = st.op; d.src = st.src; d.a = st.a; d.b = st.b; d.t = st.tensor >= 0 ? h->blobs[st.tensor].d : nullptr;
+    }
+    return e;
+}
+
+static void run_op(sgx_det *h, const Op &op, int batch, sgx_stream_t st)
+{
+    const Blob &A = h->blobs[op.in0]; const Blob &O = h->blobs[op.out];
+    switch (op.kind) {
+    case OP_PW: {
+        const int N = op.H * op.W;
+        SGX_LAUNCH(k_conv_pw, dim3((N + 63) / 64, (op.outc + 63) / 64, batch), dim3(256), st, op.inc, op.outc, N, A.d, A.n, op.wt, op.bias, O.d, O.n,
+                   make_epi(h, op, (size_t)op.outc * N), op.hwc, op.hwc_off);
+        break; }
+    case OP_KXK:
+        SGX_LAUNCH(k_conv_kxk, dim3((op.Ho * op.Wo + 255) / 256, op.outc, batch), dim3(256), st, op.inc, op.outc, op.H, op.W, op.Ho, op.Wo, op.k, op.stride, op.pad, op.depthwise,
+                   A.d, A.n, op.wt, op.bias, O.d, O.n, make_epi(h, op, (size_t)op.outc * op.Ho * op.Wo));
+        break;
+    case OP_BINARY: {
+        const Blob &Bb = h->blobs[op.in1];
+        // per-image pitch equals blob size (dense), so the batch is one flat range
+        const size_t n = A.n * batch; const int g = (int)std::min<size_t>((n + 255) / 256, 8192);
+        SGX_LAUNCH(k_binary, dim3(g), dim3(256), st, n, op.bop, A.d, Bb.scalar ? A.d : Bb.d, Bb.scalar ? 1 : 0, Bb.sval, O.d);
+        break; }
+    case OP_UNARY: { const size_t n = A.n * batch; const int g = (int)std::min<size_t>((n + 255) / 256, 8192); SGX_LAUNCH(k_unary, dim3(g), dim3(256), st, n, op.act, op.lo, op.hi, A.d, O.d); break; }
+    case OP_PERMUTE_INTO: SGX_LAUNCH(k_permute_hwc_into, dim3((op.C * op.rows + 255) / 256, batch), dim3(256), st, op.C, op.rows, A.d, A.n, O.d, O.n, op.off); break;
+    case OP_COPY_INTO: SGX_LAUNCH(k_copy_into, dim3(((int)A.n + 255) / 256, batch), dim3(256), st, (int)A.n, A.d, A.n, O.d, O.n, op.off); break;
+    case OP_SOFTMAX: SGX_LAUNCH(k_softmax_rows, dim3((op.rows + 255) / 256, batch), dim3(256), st, op.rows, op.C, A.d, A.n, O.d, O.n); break;
+    }
+}
+
+static void run_preprocess(sgx_det *h, const uint8_t *d_img, int pitch, int batch, sgx_stream_t st)
+{
+    const int T = h->T;
+    SGX_LAUNCH(k_det_preprocess, dim3((T * T + 255) / 256, batch), dim3(256), st, batch, d_img, h->W, h->H, pitch, h->d_xt, h->d_yt, T, 123.675f, 116.28f, 103.53f,
+               h->blobs[h->blob_id.at("input")].d);
+}
+
 // Batched forward from device-resident interleaved 3-channel u8 images (B x H x W x 3, row pitch in bytes).
 // Leaves loc (num_priors*4) and softmax conf (num_priors*num_class) per image in device memory; returns their pointers.
 extern "C" int sgx_det_forward_batch_dev(sgx_det *h, const uint8_t *d_img, int pitch, int batch, const float **d_loc, const float **d_conf, void *stream_)
 {
     if (!h || !d_img || batch < 1 || batch > h->max_batch || pitch < 3 * h->W) return SGX_ERR_INVALID;
     sgx_stream_t st = (sgx_stream_t)stream_;
-    const int T = h->T;
-    const int in_id = h->blob_id.at("input");
-    SGX_LAUNCH(k_det_preprocess, dim3((T * T + 255) / 256, batch), dim3(256), st, batch, d_img, h->W, h->H, pitch, h->d_xt, h->d_yt, T, 123.675f, 116.28f, 103.53f, h->blobs[in_id].d);
-    for (const Op &op : h->ops) {
-        const Blob &A = h->blobs[op.in0]; const Blob &O = h->blobs[op.out];
-        switch (op.kind) {
-        case OP_PW: {
-            const int N = op.H * op.W;
-            SGX_LAUNCH(k_conv_pw, dim3((N + 63) / 64, (op.outc + 63) / 64, batch), dim3(256), st, op.inc, op.outc, N, A.d, A.n, op.wt, op.bias, O.d, O.n, op.act, op.lo, op.hi, 0, 0);
-            break; }
-        case OP_KXK:
-            SGX_LAUNCH(k_conv_kxk, dim3((op.Ho * op.Wo + 255) / 256, op.outc, batch), dim3(256), st, op.inc, op.outc, op.H, op.W, op.Ho, op.Wo, op.k, op.stride, op.pad, op.depthwise,
-                       A.d, A.n, op.wt, op.bias, O.d, O.n, op.act, op.lo, op.hi);
-            break;
-        case OP_BINARY: {
-            const Blob &Bb = h->blobs[op.in1];
-            if (batch == h->max_batch || true) {
-                // per-image pitch equals blob size (dense), so the batch is one flat range
-                const size_t n = A.n * batch; const int g = (int)std::min<size_t>((n + 255) / 256, 8192);
-                SGX_LAUNCH(k_binary, dim3(g), dim3(256), st, n, op.bop, A.d, Bb.scalar ? A.d : Bb.d, Bb.scalar ? 1 : 0, Bb.sval, O.d);
-            }
-            break; }
-        case OP_UNARY: { const size_t n = A.n * batch; const int g = (int)std::min<size_t>((n + 255) / 256, 8192); SGX_LAUNCH(k_unary, dim3(g), dim3(256), st, n, op.act, op.lo, op.hi, A.d, O.d); break; }
-        case OP_PERMUTE_INTO: SGX_LAUNCH(k_permute_hwc_into, dim3((op.C * op.rows + 255) / 256, batch), dim3(256), st, op.C, op.rows, A.d, A.n, O.d, O.n, op.off); break;
-        case OP_COPY_INTO: SGX_LAUNCH(k_copy_into, dim3(((int)A.n + 255) / 256, batch), dim3(256), st, (int)A.n, A.d, A.n, O.d, O.n, op.off); break;
-        case OP_SOFTMAX: SGX_LAUNCH(k_softmax_rows, dim3((op.rows + 255) / 256, batch), dim3(256), st, op.rows, op.C, A.d, A.n, O.d, O.n); break;
-        }
-    }
+    run_preprocess(h, d_img, pitch, batch, st);
+    for (const Op &op : h->ops) run_op(h, op, batch, st);
     SGX_CHECK_HIP(hipGetLastError());
     if (d_loc) *d_loc = h->blobs[h->loc_blob].d;
     if (d_conf) *d_conf = h->blobs[h->conf_blob].d;
+    return SGX_OK;
+}
+
+// test / tuning taps: per-launch HIP-event time of every step of the plan (ms[0] = pre-processing, ms[1 + i] = op i), and a description of op i
+extern "C" int sgx_det_debug_time_ops(sgx_det *h, const uint8_t *d_img, int pitch, int batch, int reps, float *ms, int cap, int *nops)
+{
+    if (!h || !d_img || !ms || !nops || batch < 1 || batch > h->max_batch || reps < 1) return SGX_ERR_INVALID;
+    *nops = (int)h->ops.size() + 1;
+    if (cap < *nops) return SGX_ERR_INVALID;
+#ifndef SGX_EMU
+    hipEvent_t a, b; SGX_CHECK_HIP(hipEventCreate(&a)); SGX_CHECK_HIP(hipEventCreate(&b));
+    for (int i = 0; i < *nops; i++) {
+        float tot = 0.f;
+        for (int r = 0; r < reps + 1; r++) {
+            SGX_CHECK_HIP(hipEventRecord(a, 0));
+            if (i == 0) run_preprocess(h, d_img, pitch, batch, 0); else run_op(h, h->ops[i - 1], batch, 0);
+            SGX_CHECK_HIP(hipEventRecord(b, 0)); SGX_CHECK_HIP(hipEventSynchronize(b));
+            float t = 0.f; SGX_CHECK_HIP(hipEventElapsedTime(&t, a, b)); if (r) tot += t;
+        }
+        ms[i] = tot / reps;
+    }
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    return SGX_OK;
+#else
+    return SGX_ERR_UNSUPPORTED;
+#endif
+}
+
+extern "C" int sgx_det_debug_op_desc(const sgx_det *h, int i, char *buf, int cap)
+{
+    if (!h || !buf || cap < 16 || i < 0 || i > (int)h->ops.size()) return SGX_ERR_INVALID;
+    if (i == 0) { snprintf(buf, cap, "preprocess %dx%d->%d", h->W, h->H, h->T); return SGX_OK; }
+    const Op &o = h->ops[i - 1];
+    static const char *kn[] = { "pw", "kxk", "binary", "unary", "permute_into", "copy_into", "softmax" };
+    if (o.kind == OP_PW || o.kind == OP_KXK)
+        snprintf(buf, cap, "%s %s c%d->%d k%d s%d %s%dx%d->%dx%d epi%d%s", kn[o.kind], o.name.c_str(), o.inc, o.outc, o.k, o.stride, o.depthwise ? "dw " : "", o.H, o.W,
+                 o.kind == OP_PW ? o.H : o.Ho, o.kind == OP_PW ? o.W : o.Wo, (int)o.epi.size() + (o.act ? 1 : 0), o.hwc ? " hwc" : "");
+    else snprintf(buf, cap, "%s %s n=%zu", kn[o.kind], o.name.c_str(), h->blobs[o.in0].n);
     return SGX_OK;
 }
 

@@ -16,6 +16,31 @@ SGX_DEV float sgx_act(float v, int act, float lo, float hi)
     return v;
 }
 
+// Epilogue program of a convolution: the chain of ncnn elementwise layers (BinaryOp / Clip / ReLU) that consumes its output, applied
+// in registers in the graph's order with the graph's fp32 operations (so a fused plan is bit-identical to the unfused one).
+// h-swish   x * clip(x + 3, 0, 6) / 6   = [ADD c] [CLIP] [MUL root] [DIV c];   SE gate + residual = [ADD c] [CLIP] [DIV c] [MUL t0] [ADD t1]
+#define SGX_EPI_MAX 6
+enum { SGX_EOP_ADD = 0, SGX_EOP_SUB, SGX_EOP_MUL, SGX_EOP_DIV, SGX_EOP_RSUB, SGX_EOP_RDIV, SGX_EOP_CLIP, SGX_EOP_RELU };
+enum { SGX_ESRC_CONST = 0, SGX_ESRC_TENSOR, SGX_ESRC_ROOT };
+struct SgxEpiStep { int op, src; float a, b; const float *t; };
+struct SgxEpi { int n; int pad; size_t tpitch; SgxEpiStep s[SGX_EPI_MAX]; };     // tensor operands have the output's shape; per-image pitch tpitch
+
+SGX_DEV float sgx_epi(const SgxEpi &e, float v, size_t toff)
+{
+    const float root = v;
+    for (int i = 0; i < e.n; i++) {
+        const int op = e.s[i].op;
+        if (op == SGX_EOP_CLIP) v = fminf(fmaxf(v, e.s[i].a), e.s[i].b);
+        else if (op == SGX_EOP_RELU) v = fmaxf(v, 0.f);
+        else {
+            const int src = e.s[i].src;
+            const float o = src == SGX_ESRC_CONST ? e.s[i].a : (src == SGX_ESRC_ROOT ? root : e.s[i].t[toff]);
+            v = op == SGX_EOP_ADD ? v + o : op == SGX_EOP_MUL ? v * o : op == SGX_EOP_DIV ? v / o : op == SGX_EOP_SUB ? v - o : op == SGX_EOP_RSUB ? o - v : o / v;
+        }
+    }
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_det_preprocess: ncnn::Mat::from_pixels_resize(PIXEL_RGB, w, h, 300, 300) + substract_mean_normalize (Detector2D.cc:39-40).
 // ncnn resize_bilinear_c3: 11-bit fixed-point coefficients (host-built tables, clamp to (n-2, 1.0)), then u8 -> f32 - mean.
@@ -49,7 +74,7 @@ SGX_KERNEL(256) k_det_preprocess(int B, const uint8_t *img, int W, int H, int pi
 // Workgroup = 4 waves = 64 (oc) x 64 (pixels) output tile, each wave one 32x32 accumulator (16 VGPR/lane); K staged
 // through LDS in steps of 16 (8 MFMAs per wave per step).  A operand: lane l holds Wt[oc0 + (l&31)][k + (l>>5)],
 // B operand: In[k + (l>>5)][n0 + (l&31)]; C/D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5).
-// Epilogue: bias + activation, optional HWC store into a concat buffer (fuses ncnn Permute(3)+Flatten+Concat).
+// Epilogue: bias + the fused elementwise program, optional HWC store into a concat buffer (fuses ncnn Permute(3)+Flatten+Concat).
 // grid = (ceil(N/64), ceil(outc/64), B)
 // ---------------------------------------------------------------------------------------------
 #define SGX_PW_KT 16
@@ -58,7 +83,7 @@ typedef float sgx_f32x16 __attribute__((ext_vector_type(16)));
 #endif
 
 SGX_KERNEL(256) k_conv_pw(int inc, int outc, int N, const float *in, size_t in_pitch, const float *Wt, const float *bias,
-                          float *out, size_t out_pitch, int act, float lo, float hi, int hwc, int hwc_off)
+                          float *out, size_t out_pitch, SgxEpi epi, int hwc, int hwc_off)
 {
     SGX_LDS float As[SGX_PW_KT][64 + 1];      // [k][oc]
     SGX_LDS float Bs[SGX_PW_KT][64 + 1];      // [k][pixel]
@@ -93,7 +118,7 @@ SGX_KERNEL(256) k_conv_pw(int inc, int outc, int N, const float *in, size_t in_p
     for (int r = 0; r < 16; r++) {
         const int row = oc0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row < outc && col < N) {
-            const float v = sgx_act(acc[r] + bias[row], act, lo, hi);
+            const float v = sgx_epi(epi, acc[r] + bias[row], (size_t)b * epi.tpitch + (size_t)row * N + col);
             if (hwc) Y[(size_t)hwc_off + (size_t)col * outc + row] = v; else Y[(size_t)row * N + col] = v;
         }
     }
@@ -106,7 +131,7 @@ SGX_KERNEL(256) k_conv_pw(int inc, int outc, int N, const float *in, size_t in_p
         if (row < outc && col < N) {
             float s = 0.f;
             for (int k = 0; k < inc; k++) s = fmaf(Wt[(size_t)row * inc + k], X[(size_t)k * N + col], s);
-            const float v = sgx_act(s + bias[row], act, lo, hi);
+            const float v = sgx_epi(epi, s + bias[row], (size_t)b * epi.tpitch + (size_t)row * N + col);
             if (hwc) Y[(size_t)hwc_off + (size_t)col * outc + row] = v; else Y[(size_t)row * N + col] = v;
         }
     }
@@ -120,8 +145,7 @@ SGX_KERNEL(256) k_conv_pw(int inc, int outc, int N, const float *in, size_t in_p
 // grid = (ceil(Ho*Wo/256), outc, B)
 // ---------------------------------------------------------------------------------------------
 SGX_KERNEL(256) k_conv_kxk(int inc, int outc, int H, int W, int Ho, int Wo, int k, int stride, int pad, int depthwise,
-                           const float *in, size_t in_pitch, const float *Wt, const float *bias, float *out, size_t out_pitch,
-                           int act, float lo, float hi)
+                           const float *in, size_t in_pitch, const float *Wt, const float *bias, float *out, size_t out_pitch, SgxEpi epi)
 {
     SGX_THREADS_BEGIN(tid)
     const int idx = (int)blockIdx.x * 256 + tid, oc = (int)blockIdx.y, b = (int)blockIdx.z;
@@ -143,7 +167,7 @@ SGX_KERNEL(256) k_conv_kxk(int inc, int outc, int H, int W, int Ho, int Wo, int 
                 }
             }
         }
-        out[(size_t)b * out_pitch + (size_t)oc * Ho * Wo + idx] = sgx_act(s + bias[oc], act, lo, hi);
+        out[(size_t)b * out_pitch + (size_t)oc * Ho * Wo + idx] = sgx_epi(epi, s + bias[oc], (size_t)b * epi.tpitch + (size_t)oc * Ho * Wo + idx);
     }
     SGX_THREADS_END
 }

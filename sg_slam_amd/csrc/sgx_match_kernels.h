@@ -351,6 +351,43 @@ SGX_KERNEL(64) k_motion_model(int batch, const float *Tcur, const float *Tprev, 
 // Outputs: cur_match[k] = local map point newly assigned to keypoint k (last writer in index order) or -1; in_view = mbTrackInView.
 // ---------------------------------------------------------------------------------------------
 #define SGX_LOCAL_CAP 4096
+#define SGX_LOCAL_SLOTS (SGX_LOCAL_CAP / SGX_MATCH_THREADS)      /* local map points per thread */
+#define SGX_LOCAL_KEEP 4                                          /* smallest candidate keys kept per map point */
+
+struct SgxLocalProj { float u, v, radius, projXR; int lvl; bool ok; };
+
+// Frame::isInFrustum + MapPoint::PredictScale + the search radius of SearchByProjection for one local map point
+SGX_DEV SgxLocalProj sgx_local_project(const float *P, const float *Pn, float max_dist, float min_dist, const float (*Rcw)[3], const float *tcw, const float *Ow,
+                                       const SgxCam &cam, const SgxScales &sc, int nlevels, float log_scale_factor, float th, float viewing_cos_limit)
+{
+    SgxLocalProj r; r.lvl = 0; r.radius = 0.f; r.projXR = 0.f;
+    const float pcx = sgx_gemm3(Rcw[0], P, tcw[0]), pcy = sgx_gemm3(Rcw[1], P, tcw[1]), pcz = sgx_gemm3(Rcw[2], P, tcw[2]);
+    bool ok = !(pcz < 0.0f);
+    const float invz = 1.0f / pcz;
+    r.u = cam.fx * pcx * invz + cam.cx; r.v = cam.fy * pcy * invz + cam.cy;
+    ok = ok && !(r.u < cam.minX || r.u > cam.maxX) && !(r.v < cam.minY || r.v > cam.maxY);
+    const float maxDistance = 1.2f * max_dist, minDistance = 0.8f * min_dist;                     // MapPoint.cc:372-383
+    const float po0 = P[0] - Ow[0], po1 = P[1] - Ow[1], po2 = P[2] - Ow[2];
+    const float dist = (float)sqrt((double)po0 * po0 + (double)po1 * po1 + (double)po2 * po2);   // cv::norm accumulates in double
+    ok = ok && !(dist < minDistance || dist > maxDistance);
+    const float viewCos = (float)(((double)po0 * Pn[0] + (double)po1 * Pn[1] + (double)po2 * Pn[2]) / (double)dist);
+    ok = ok && !(viewCos < viewing_cos_limit);
+    r.ok = ok;
+    if (ok) {
+        int lvl = (int)ceilf((float)log((double)(max_dist / dist)) / log_scale_factor);           // MapPoint::PredictScale (logf in the reference)
+        if (lvl < 0) lvl = 0; else if (lvl >= nlevels) lvl = nlevels - 1;
+        r.lvl = lvl;
+        r.projXR = r.u - cam.bf * invz;
+        float rad = viewCos > 0.998 ? 2.5f : 4.0f;                                                // RadiusByViewingCos
+        if (th != 1.0f) rad *= th;
+        r.radius = rad * sc.s[lvl];
+    }
+    return r;
+}
+
+// candidate key: (Hamming distance, scan order = grid column, grid row, keypoint index) — smaller = preferred / earlier in the reference's scan
+#define SGX_LKEY(dd, px, py, k) (((uint32_t)(dd) << 23) | ((uint32_t)(px) << 17) | ((uint32_t)(py) << 11) | (uint32_t)(k))
+#define SGX_LKEY_NONE 0xFFFFFFFFu
 
 SGX_KERNEL(SGX_MATCH_THREADS) k_match_project_local(
     int cap, const uint8_t *ckeys_raw, const uint8_t *cdesc, const float *curight, const int *cn, const float *cTcw, const int *cur_mp_obs,
@@ -369,6 +406,10 @@ SGX_KERNEL(SGX_MATCH_THREADS) k_match_project_local(
     SGX_LDS uint16_t cell_list[SGX_MATCH_CAP];
     SGX_LDS uint16_t choice[SGX_LOCAL_CAP];           // 0xFFFF = none
     SGX_LDS int s_changed, s_total, s_ngrid;
+    // per-thread state that lives across the sweeps: the SGX_LOCAL_KEEP smallest candidate keys of each of the thread's map points
+    // (lock-independent: the locks only ever REMOVE candidates), + bit 0 = list truncated, bit 1 = the point's Observations() > 0
+    SGX_PRIV_DECL(uint32_t, ckey, SGX_LOCAL_SLOTS * SGX_LOCAL_KEEP, SGX_MATCH_THREADS);
+    SGX_PRIV_DECL(uint32_t, cflag, SGX_LOCAL_SLOTS, SGX_MATCH_THREADS);
 
     const int f = (int)blockIdx.x;
     const int Nc = min(cn[f], cap), Nm = min(min(mn[f], mcap), SGX_LOCAL_CAP);
@@ -416,8 +457,64 @@ SGX_KERNEL(SGX_MATCH_THREADS) k_match_project_local(
     float Rcw[3][3], tcw[3], Ow[3];
     for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Rcw[r][c] = Tc[4 * r + c]; tcw[r] = Tc[4 * r + 3]; }
     for (int i = 0; i < 3; i++) { double s = 0; for (int k = 0; k < 3; k++) s += (double)Rcw[k][i] * (double)tcw[k]; Ow[i] = (float)(s * -1.0); }   // mOw, Frame.cc:288-294
-    const bool bFactor = th != 1.0f;
 
+    // ---- build: project every local map point once, keep its smallest candidate keys (no lock filter)
+    SGX_THREADS_BEGIN(tid)
+    SGX_PRIV_BIND(ckey, tid); SGX_PRIV_BIND(cflag, tid);
+#pragma unroll
+    for (int j = 0; j < SGX_LOCAL_SLOTS; j++) {
+        const int i = tid + j * SGX_MATCH_THREADS;
+        uint32_t c0 = SGX_LKEY_NONE, c1 = SGX_LKEY_NONE, c2 = SGX_LKEY_NONE, c3 = SGX_LKEY_NONE, flag = 0;
+        if (i < Nm) {
+            const size_t mi = (size_t)f * mcap + i;
+            uint8_t vis = 0;
+            if (!m_skip[mi]) {
+                const SgxLocalProj pr = sgx_local_project(m_xw + 3 * mi, m_normal + 3 * mi, m_max_dist[mi], m_min_dist[mi], Rcw, tcw, Ow, cam, sc, nlevels,
+                                                          log_scale_factor, th, viewing_cos_limit);
+                if (pr.ok) {
+                    vis = 1;
+                    if (m_obs[mi] > 0) flag |= 2u;
+                    const float u = pr.u, v = pr.v, radius = pr.radius;
+                    const int minLevel = pr.lvl - 1, maxLevel = pr.lvl;
+                    const int c0x = max(0, (int)floorf((u - cam.minX - radius) * invW)), c1x = min(SGX_GRID_COLS - 1, (int)ceilf((u - cam.minX + radius) * invW));
+                    const int c0y = max(0, (int)floorf((v - cam.minY - radius) * invH)), c1y = min(SGX_GRID_ROWS - 1, (int)ceilf((v - cam.minY + radius) * invH));
+                    if (!(c0x >= SGX_GRID_COLS || c1x < 0 || c0y >= SGX_GRID_ROWS || c1y < 0)) {
+                        const uint32_t *dmp = (const uint32_t *)(m_desc + mi * 32);
+                        uint32_t dm[8];
+#pragma unroll
+                        for (int w = 0; w < 8; w++) dm[w] = dmp[w];
+                        int cnt = 0;
+                        for (int px = c0x; px <= c1x; px++)
+                        for (int q = cell_start[px * SGX_GRID_ROWS + c0y], qe = cell_start[px * SGX_GRID_ROWS + c1y + 1]; q < qe; q++) {
+                            const int k = cell_list[q];
+                            const uint32_t inf = kinfo[k];
+                            const int oct = inf & 0xFF, py = (inf >> 16) & 0xFF;
+                            if (oct < minLevel || oct > maxLevel) continue;        // bCheckLevels holds (maxLevel >= 0)
+                            if (!(fabsf(kx[k] - u) < radius && fabsf(ky[k] - v) < radius)) continue;
+                            if (kur[k] > 0) { if (fabsf(pr.projXR - kur[k]) > radius) continue; }
+                            const int dd = sgx_hamming256(dm, &kdesc[k * 8]);
+                            uint32_t key = SGX_LKEY(dd, px, py, k);
+                            cnt++;
+                            if (key < c3) {                                            // sorted insertion, static registers
+                                c3 = key;
+                                if (c3 < c2) { const uint32_t t = c2; c2 = c3; c3 = t; }
+                                if (c2 < c1) { const uint32_t t = c1; c1 = c2; c2 = t; }
+                                if (c1 < c0) { const uint32_t t = c0; c0 = c1; c1 = t; }
+                            }
+                        }
+                        if (cnt > SGX_LOCAL_KEEP) flag |= 1u;
+                    }
+                }
+            }
+            in_view[mi] = vis;
+        }
+        ckey[j * SGX_LOCAL_KEEP + 0] = c0; ckey[j * SGX_LOCAL_KEEP + 1] = c1; ckey[j * SGX_LOCAL_KEEP + 2] = c2; ckey[j * SGX_LOCAL_KEEP + 3] = c3;
+        cflag[j] = flag;
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+
+    // ---- Jacobi sweeps over the lock table: each map point takes its two smallest keys whose keypoint is not locked by a smaller index
     int *lock_cur = lock_a, *lock_new = lock_b;
     for (int sweep = 0; sweep < SGX_LOCAL_CAP + 2; sweep++) {
         SGX_THREADS_BEGIN(tid)
@@ -426,66 +523,50 @@ SGX_KERNEL(SGX_MATCH_THREADS) k_match_project_local(
         SGX_THREADS_END
         SGX_SYNC();
         SGX_THREADS_BEGIN(tid)
-        for (int i = tid; i < Nm; i += NT) {
-            int best = -1; uint8_t vis = 0;
-            const size_t mi = (size_t)f * mcap + i;
-            if (!m_skip[mi]) {
-                // ---- Frame::isInFrustum
-                const float *P = m_xw + 3 * mi;
-                const float pcx = sgx_gemm3(Rcw[0], P, tcw[0]), pcy = sgx_gemm3(Rcw[1], P, tcw[1]), pcz = sgx_gemm3(Rcw[2], P, tcw[2]);
-                bool ok = !(pcz < 0.0f);
-                const float invz = 1.0f / pcz;
-                const float u = cam.fx * pcx * invz + cam.cx, v = cam.fy * pcy * invz + cam.cy;
-                ok = ok && !(u < cam.minX || u > cam.maxX) && !(v < cam.minY || v > cam.maxY);
-                const float maxDistance = 1.2f * m_max_dist[mi], minDistance = 0.8f * m_min_dist[mi];       // MapPoint.cc:372-383
-                const float po0 = P[0] - Ow[0], po1 = P[1] - Ow[1], po2 = P[2] - Ow[2];
-                const float dist = (float)sqrt((double)po0 * po0 + (double)po1 * po1 + (double)po2 * po2);   // cv::norm accumulates in double
-                ok = ok && !(dist < minDistance || dist > maxDistance);
-                const float *Pn = m_normal + 3 * mi;
-                const float viewCos = (float)(((double)po0 * Pn[0] + (double)po1 * Pn[1] + (double)po2 * Pn[2]) / (double)dist);
-                ok = ok && !(viewCos < viewing_cos_limit);
-                if (ok) {
-                    vis = 1;
-                    int lvl = (int)ceilf((float)log((double)(m_max_dist[mi] / dist)) / log_scale_factor);   // MapPoint::PredictScale (logf in the reference)
-                    if (lvl < 0) lvl = 0; else if (lvl >= nlevels) lvl = nlevels - 1;
-                    const float projXR = u - cam.bf * invz;
-                    float r = viewCos > 0.998 ? 2.5f : 4.0f;                    // RadiusByViewingCos
-                    if (bFactor) r *= th;
-                    const float radius = r * sc.s[lvl];
-                    const int minLevel = lvl - 1, maxLevel = lvl;
+        SGX_PRIV_BIND(ckey, tid); SGX_PRIV_BIND(cflag, tid);
+#pragma unroll
+        for (int j = 0; j < SGX_LOCAL_SLOTS; j++) {
+            const int i = tid + j * SGX_MATCH_THREADS;
+            if (i < Nm) {
+                uint32_t k1 = SGX_LKEY_NONE, k2 = SGX_LKEY_NONE;
+#pragma unroll
+                for (int q = 0; q < SGX_LOCAL_KEEP; q++) {
+                    const uint32_t key = ckey[j * SGX_LOCAL_KEEP + q];
+                    if (key != SGX_LKEY_NONE && !(lock_cur[key & 0x7FF] < i)) { if (k1 == SGX_LKEY_NONE) k1 = key; else if (k2 == SGX_LKEY_NONE) k2 = key; }
+                }
+                if ((cflag[j] & 1u) && k2 == SGX_LKEY_NONE) {
+                    // rare: the kept list was truncated and fewer than two of its keypoints are still available -> full rescan with the lock filter
+                    const size_t mi = (size_t)f * mcap + i;
+                    const SgxLocalProj pr = sgx_local_project(m_xw + 3 * mi, m_normal + 3 * mi, m_max_dist[mi], m_min_dist[mi], Rcw, tcw, Ow, cam, sc, nlevels,
+                                                              log_scale_factor, th, viewing_cos_limit);
+                    const float u = pr.u, v = pr.v, radius = pr.radius;
+                    const int minLevel = pr.lvl - 1, maxLevel = pr.lvl;
                     const int c0x = max(0, (int)floorf((u - cam.minX - radius) * invW)), c1x = min(SGX_GRID_COLS - 1, (int)ceilf((u - cam.minX + radius) * invW));
                     const int c0y = max(0, (int)floorf((v - cam.minY - radius) * invH)), c1y = min(SGX_GRID_ROWS - 1, (int)ceilf((v - cam.minY + radius) * invH));
-                    if (!(c0x >= SGX_GRID_COLS || c1x < 0 || c0y >= SGX_GRID_ROWS || c1y < 0)) {
-                        const uint32_t *dmp = (const uint32_t *)(m_desc + mi * 32);
-                        uint32_t dm[8];
-#pragma unroll
-                        for (int w = 0; w < 8; w++) dm[w] = dmp[w];
-                        unsigned long long k1 = ~0ull, k2 = ~0ull;       // best / second-best (distance, scan order) keys
-                        for (int px = c0x; px <= c1x; px++)
-                        for (int q = cell_start[px * SGX_GRID_ROWS + c0y], qe = cell_start[px * SGX_GRID_ROWS + c1y + 1]; q < qe; q++) {
-                            const int k = cell_list[q];
-                            const uint32_t inf = kinfo[k];
-                            const int oct = inf & 0xFF, py = (inf >> 16) & 0xFF;
-                            if (oct < minLevel || oct > maxLevel) continue;        // bCheckLevels holds (maxLevel >= 0)
-                            if (!(fabsf(kx[k] - u) < radius && fabsf(ky[k] - v) < radius)) continue;
-                            if (lock_cur[k] < i) continue;
-                            if (kur[k] > 0) { if (fabsf(projXR - kur[k]) > radius) continue; }
-                            const int dd = sgx_hamming256(dm, &kdesc[k * 8]);
-                            const unsigned long long key = ((unsigned long long)dd << 36) | ((unsigned long long)px << 30) | ((unsigned long long)py << 24) |
-                                                           ((unsigned long long)k << 8) | (unsigned long long)oct;
-                            if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
-                        }
-                        if (k1 != ~0ull) {
-                            const int bestDist = (int)(k1 >> 36), bestLevel = (int)(k1 & 0xFF);
-                            const int bestDist2 = k2 != ~0ull ? (int)(k2 >> 36) : 256, bestLevel2 = k2 != ~0ull ? (int)(k2 & 0xFF) : -1;
-                            if (bestDist <= SGX_TH_HIGH && !(bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2)) best = (int)((k1 >> 8) & 0xFFFF);
-                        }
+                    const uint32_t *dm = (const uint32_t *)(m_desc + mi * 32);
+                    k1 = SGX_LKEY_NONE; k2 = SGX_LKEY_NONE;
+                    for (int px = c0x; px <= c1x; px++)
+                    for (int q = cell_start[px * SGX_GRID_ROWS + c0y], qe = cell_start[px * SGX_GRID_ROWS + c1y + 1]; q < qe; q++) {
+                        const int k = cell_list[q];
+                        const uint32_t inf = kinfo[k];
+                        const int oct = inf & 0xFF, py = (inf >> 16) & 0xFF;
+                        if (oct < minLevel || oct > maxLevel) continue;
+                        if (!(fabsf(kx[k] - u) < radius && fabsf(ky[k] - v) < radius)) continue;
+                        if (lock_cur[k] < i) continue;
+                        if (kur[k] > 0) { if (fabsf(pr.projXR - kur[k]) > radius) continue; }
+                        const uint32_t key = SGX_LKEY(sgx_hamming256(dm, &kdesc[k * 8]), px, py, k);
+                        if (key < k1) { k2 = k1; k1 = key; } else if (key < k2) k2 = key;
                     }
                 }
+                int best = -1;
+                if (k1 != SGX_LKEY_NONE) {
+                    const int bestDist = (int)(k1 >> 23), bestLevel = (int)(kinfo[k1 & 0x7FF] & 0xFF);
+                    const int bestDist2 = k2 != SGX_LKEY_NONE ? (int)(k2 >> 23) : 256, bestLevel2 = k2 != SGX_LKEY_NONE ? (int)(kinfo[k2 & 0x7FF] & 0xFF) : -1;
+                    if (bestDist <= SGX_TH_HIGH && !(bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2)) best = (int)(k1 & 0x7FF);
+                }
+                choice[i] = best >= 0 ? (uint16_t)best : (uint16_t)0xFFFF;
+                if (best >= 0 && (cflag[j] & 2u)) sgx_atomic_min_i32(&lock_new[best], i);
             }
-            in_view[mi] = vis;
-            choice[i] = best >= 0 ? (uint16_t)best : (uint16_t)0xFFFF;
-            if (best >= 0 && m_obs[mi] > 0) sgx_atomic_min_i32(&lock_new[best], i);
         }
         SGX_THREADS_END
         SGX_SYNC();

@@ -13,7 +13,7 @@ CLASS_NAMES = ["background", "aeroplane", "bicycle", "bird", "boat", "bottle", "
 
 class Detector2D:
     def __init__(self, detection_confidence_threshold, dynamic_detection_confidence_threshold, param_path=None, bin_path=None,
-                 param_text=None, bin_bytes=None, width=640, height=480, max_batch=1, lib=None):
+                 param_text=None, bin_bytes=None, width=640, height=480, max_batch=1, lib=None, fuse=True):
         self.lib = lib if lib is not None else load()
         if param_text is None:
             param_text = open(param_path or './Thirdparty/ncnn_model/mobilenetv3_ssdlite_voc.param').read()      # Detector2D.cc:24
@@ -21,8 +21,10 @@ class Detector2D:
             bin_bytes = open(bin_path or './Thirdparty/ncnn_model/mobilenetv3_ssdlite_voc.bin', 'rb').read()      # Detector2D.cc:25
         self._bin = bin_bytes
         h = C.c_void_p()
+        self.lib.dll.sgx_det_debug_set_fusion(1 if fuse else 0)      # fuse=False: one kernel per ncnn layer, every blob kept (tests)
         self.lib.check(self.lib.dll.sgx_det_create(param_text.encode(), bin_bytes, len(bin_bytes), width, height, max_batch,
                                                    float(detection_confidence_threshold), float(dynamic_detection_confidence_threshold), C.byref(h)), 'sgx_det_create')
+        self.lib.dll.sgx_det_debug_set_fusion(1)
         self.h = h; self.width, self.height, self.max_batch = width, height, max_batch
         npri, ncls, nk = C.c_int32(), C.c_int32(), C.c_int32(); g = C.c_double()
         self.lib.check(self.lib.dll.sgx_det_info(self.h, C.byref(npri), C.byref(ncls), C.byref(nk), C.byref(g)))
@@ -55,6 +57,19 @@ class Detector2D:
         self.mbHaveDynamicObjectForRmDynamicFeature = bool(r.have_dynamic_for_rm_feature)
         self.mvPotentialDynamicBorderForMapping = [rect(o) for o in r.map_boxes[:r.n_map_boxes]]
         self.mvPotentialDynamicBorderForRmDynamicFeature = [rect(o) for o in r.rm_boxes[:r.n_rm_boxes]]
+
+    def has_blob(self, name):
+        n = C.c_int(0)
+        return self.lib.dll.sgx_det_debug_read_blob(self.h, name.encode(), 0, None, 0, C.byref(n)) == 0
+
+    def time_ops(self, d_img, batch, reps=5):
+        """[(description, ms per launch)] of every plan step on device images (tuning tap)"""
+        ms = np.zeros(self.num_kernels, 'f4'); n = C.c_int(0)
+        self.lib.check(self.lib.dll.sgx_det_debug_time_ops(self.h, _vp(d_img), self.width * 3, batch, reps, _vp(ms), len(ms), C.byref(n)))
+        out = []
+        for i in range(n.value):
+            buf = C.create_string_buffer(256); self.lib.check(self.lib.dll.sgx_det_debug_op_desc(self.h, i, buf, 256)); out.append((buf.value.decode(), float(ms[i])))
+        return out
 
     def debug_blob(self, name, image=0):
         n = C.c_int(0)

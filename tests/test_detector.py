@@ -34,9 +34,10 @@ def make_image(seed, person=False):
     return img
 
 
-def run_compare(lib, model, seeds=(0, 1)):
+def run_compare(lib, model, seeds=(0, 1), fuse=False):
     layers, W, blob = model
-    det = Detector2D(0.90, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=2, lib=lib)
+    det = Detector2D(0.90, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=2, lib=lib, fuse=fuse)
+    assert det.num_kernels == (282 if not fuse else 103), det.num_kernels
     assert det.num_priors == 2268 and det.num_class == 21 and abs(det.gmac - 0.5574) < 1e-3
     imgs = np.stack([make_image(s) for s in seeds])
     res = det.detect_batch(imgs)
@@ -46,6 +47,9 @@ def run_compare(lib, model, seeds=(0, 1)):
         _, blobs64 = D.forward(layers, W, x, dt=np.float64)
         assert (det.debug_blob('input', b).reshape(3, 300, 300) == x).all()                 # integer resize + exact fp32 subtract
         for name in ('580', '587', '603'):
+            if fuse and not det.has_blob(name):
+                assert name == '580'                              # the stem's raw output lives only in registers of the fused h-swish epilogue
+                continue
             assert rel_err(det.debug_blob(name, b), np.asarray(blobs[name], np.float32).reshape(-1)) < 1e-5, name
         for name in ('620', '672', '849', '908', '944', 'mbox_loc', 'mbox_conf_softmax'):
             got = det.debug_blob(name, b); ref = np.asarray(blobs64[name]).reshape(-1); np32 = np.asarray(blobs[name], np.float64).reshape(-1)
@@ -67,6 +71,28 @@ def run_compare(lib, model, seeds=(0, 1)):
 
 def test_detector_emu_matches_oracle(emu, model):
     run_compare(emu, model)
+
+
+def test_detector_emu_fused_matches_oracle(emu, model):
+    run_compare(emu, model, seeds=(0,), fuse=True)
+
+
+def run_fused_equals_unfused(lib, model):
+    """The fused plan (conv epilogue programs, HWC head stores) applies the same fp32 operations in the same order: bit-identical outputs."""
+    layers, W, blob = model
+    imgs = np.stack([make_image(3), make_image(4)])
+    outs = []
+    for fuse in (False, True):
+        det = Detector2D(0.90, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=2, lib=lib, fuse=fuse)
+        det.detect_batch(imgs)
+        outs.append([np.stack([det.debug_blob(nm, b) for b in range(2)]) for nm in ('587', '632', '672', '849', '908', '944', 'mbox_loc', 'mbox_conf_softmax')])
+        det.close()
+    for a, b in zip(*outs):
+        assert (a == b).all()
+
+
+def test_detector_emu_fused_equals_unfused(emu, model):
+    run_fused_equals_unfused(emu, model)
 
 
 def run_mask(lib, to_dev=lambda a: a, to_host=lambda a: a):

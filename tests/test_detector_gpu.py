@@ -13,3 +13,12 @@ def test_detector_gpu_matches_oracle(gpulib, model):
 def test_dynamic_mask_gpu(gpulib):
     import torch
     run_mask(gpulib, to_dev=lambda a: torch.from_numpy(a.view(np.uint8) if a.dtype.fields else a).cuda(), to_host=lambda t: t.cpu().numpy())
+
+
+def test_detector_gpu_fused_matches_oracle(gpulib, model):
+    run_compare(gpulib, model, seeds=(0,), fuse=True)
+
+
+def test_detector_gpu_fused_equals_unfused(gpulib, model):
+    from test_detector import run_fused_equals_unfused
+    run_fused_equals_unfused(gpulib, model)

@@ -19,3 +19,46 @@ def run_local(lib, oracle, S, t, seed, th):
 @pytest.mark.parametrize('t,seed,th', [(5, 0, 3.0), (12, 1, 3.0), (30, 2, 5.0), (44, 3, 1.0)])
 def test_local_emu(emu, oracle, stream_frames, t, seed, th):
     run_local(emu, oracle, stream_frames, t, seed, th)
+
+
+def crowded_scene(seed=0, nk=90, nm=70):
+    """Many keypoints crowded into one search window, graded in descriptor distance, and many observed map points projecting
+    there: every point's kept candidate list is exhausted by the locks of the points before it (truncated-list rescan path)."""
+    from sg_slam_amd.capi import KP_DTYPE
+    rng = np.random.RandomState(seed)
+    base = rng.randint(0, 256, 32).astype(np.uint8)
+    def flipped(bits):
+        d = base.copy()
+        for b in bits:
+            d[b // 8] ^= np.uint8(1 << (b % 8))
+        return d
+    order = rng.permutation(256)
+    rank = rng.permutation(nk)                                    # keypoint r differs from base in 3*rank[r] bits
+    k = np.zeros(nk, KP_DTYPE)
+    k['x'] = 320 + rng.uniform(-7, 7, nk).astype('f4'); k['y'] = 240 + rng.uniform(-7, 7, nk).astype('f4')
+    k['octave'] = 1 + (rank % 2); k['size'] = 31; k['angle'] = 0        # neighbours in distance sit on different levels: ratio test never rejects
+    kd = np.stack([flipped(order[:min(3 * rank[r], 256)]) for r in range(nk)])
+    z0 = 2.0
+    cur = dict(keys=k, desc=kd, uright=np.full(nk, -1, 'f4'), Tcw=np.eye(4, dtype='f4'), mp_obs=np.where(rng.rand(nk) < 0.15, 2, -1).astype('i4'))
+    fx, fy, cx, cy = CAM['fx'], CAM['fy'], CAM['cx'], CAM['cy']
+    u = 320 + rng.uniform(-2, 2, nm); v = 240 + rng.uniform(-2, 2, nm)
+    xw = np.stack([(u - cx) / fx * z0, (v - cy) / fy * z0, np.full(nm, z0)], 1).astype('f4')
+    dist = np.linalg.norm(xw.astype('f8'), axis=1).astype('f4')
+    md = np.stack([flipped(order[256 - rng.randint(0, 3):]) for _ in range(nm)])
+    lm = dict(xw=xw, normal=(xw / dist[:, None]).astype('f4'), min_dist=np.full(nm, 0.1, 'f4'), max_dist=(dist * np.float32(1.2 ** 1.5)).astype('f4'),
+              desc=md, obs=(rng.rand(nm) < 0.85).astype('i4'), skip=np.zeros(nm, np.uint8))
+    return cur, lm
+
+
+def run_crowded(lib, oracle, seed):
+    cur, lm = crowded_scene(seed)
+    sf = oracle.orb_params()['scale']
+    exp_match, exp_n, exp_view = oracle.search_by_projection_local(cur, lm, CAM, sf, th=3.0, nnratio=0.8)
+    n = ORBmatcher(0.8, True, lib=lib).SearchByProjectionLocal(cur, lm, 3.0, CAM, sf)
+    assert exp_n >= 8 and exp_view.all()
+    assert n == exp_n and (cur['match_local'] == exp_match).all() and (lm['in_view'] == exp_view).all()
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2, 3])
+def test_local_crowded_emu(emu, oracle, seed):
+    run_crowded(emu, oracle, seed)

@@ -15,7 +15,8 @@ PARAM = os.path.join(ROOT, 'tests', 'golden', 'mobilenetv3_ssdlite_voc.param')
 lib = sg_slam_amd.load()
 layers = D.parse_param(PARAM); W, blob = D.synth_weights(layers)
 out = []
-for B in (1, 16, 64):
+BATCHES = [int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else [1, 16, 64]
+for B in BATCHES:
     det = Detector2D(0.9, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=B, lib=lib)
     img = torch.randint(0, 256, (B, 480, 640, 3), dtype=torch.uint8, device='cuda')
     st = torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,32 @@
+"""Per-plan-step HIP-event timing of the detector forward against each step's own roofline (max(bytes / HBM peak, flops / fp32-MFMA peak)).
+usage: python tools/prof_det_ops.py [batch] > profiles/<name>.txt"""
+import os, re, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import sg_slam_amd
+from sg_slam_amd.detector import Detector2D
+from oracle import detector_oracle as D          # only to synthesise the weight blob (the reference's .bin is absent)
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+PARAM = os.path.join(ROOT, 'tests', 'golden', 'mobilenetv3_ssdlite_voc.param')
+lib = sg_slam_amd.load()
+layers = D.parse_param(PARAM); W, blob = D.synth_weights(layers)
+det = Detector2D(0.9, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=B, lib=lib)
+img = torch.randint(0, 256, (B, 480, 640, 3), dtype=torch.uint8, device='cuda')
+rows = det.time_ops(img, B, reps=10)
+tot = sum(ms for _, ms in rows); troof = 0.0
+print(f'detector plan, batch {B}: {len(rows)} launches, sum of per-launch times {tot:.3f} ms  ({B / tot * 1e3:.0f} frames/s)')
+print(f'{"ms":>8} {"roof_ms":>8} {"frac":>6}  step')
+for desc, ms in rows:
+    m = re.match(r'(pw|kxk) \S+ c(\d+)->(\d+) k(\d+) s(\d+) (dw )?(\d+)x(\d+)->(\d+)x(\d+)', desc)
+    roof = 0.0
+    if m:
+        c, oc, k, s = int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5)); dw = m.group(6) is not None
+        h, w, ho, wo = (int(m.group(i)) for i in (7, 8, 9, 10))
+        by = 4.0 * (c * h * w + oc * ho * wo) * B; fl = 2.0 * ho * wo * oc * (1 if dw else c) * k * k * B
+        roof = max(by / 8e12, fl / 157.3e12) * 1e3
+    troof += roof
+    print(f'{ms:8.4f} {roof:8.4f} {roof / ms if ms else 0:6.2f}  {desc}')
+print(f'sum of step rooflines {troof:.3f} ms -> plan at {troof / tot:.2f} of its roofline')
