@@ -32,12 +32,12 @@ struct Op {
     OpKind kind; int in0 = -1, in1 = -1, out = -1;
     std::vector<EpiStep> epi; int hwc = 0, hwc_off = 0; bool dead = false; std::string name;
     int inc = 0, outc = 0, H = 0, W = 0, Ho = 0, Wo = 0, k = 1, stride = 1, pad = 0, depthwise = 0, act = 0; float lo = 0, hi = 0;
-    float *wt = nullptr, *bias = nullptr; int bop = 0; int off = 0; int rows = 0, C = 0;
+    float *wt = nullptr, *bias = nullptr, *wtT = nullptr; int bop = 0; int off = 0; int rows = 0, C = 0;
 };
 }  // namespace
 
 struct sgx_det {
-    int T = 300, max_batch = 1, W = 0, H = 0;
+    int T = 300, max_batch = 1, W = 0, H = 0, legacy = 0;
     float det_th = 0.9f, dyn_th = 0.01f;
     std::vector<Layer> layers;
     std::map<std::string, int> blob_id;
@@ -54,7 +54,9 @@ struct sgx_det {
 };
 
 static int g_det_fuse = 1;
+static int g_det_legacy = 0;             // test tap (read at sgx_det_create): run the simple reference kernels (k_conv_pw / k_conv_kxk) instead of the tuned ones
 extern "C" int sgx_det_debug_set_fusion(int on) { g_det_fuse = on ? 1 : 0; return SGX_OK; }
+extern "C" int sgx_det_debug_set_legacy_kernels(int on) { g_det_legacy = on ? 1 : 0; return SGX_OK; }
 
 static int parse_param(const char *text, std::vector<Layer> &layers)
 {
@@ -105,7 +107,7 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
 {
     if (!param_text || !bin || !out || width < 8 || height < 8 || max_batch < 1) return SGX_ERR_INVALID;
     sgx_det *h = new sgx_det();
-    h->W = width; h->H = height; h->max_batch = max_batch; h->det_th = detection_confidence_threshold; h->dyn_th = dynamic_detection_confidence_threshold;
+    h->W = width; h->H = height; h->max_batch = max_batch; h->legacy = g_det_legacy; h->det_th = detection_confidence_threshold; h->dyn_th = dynamic_detection_confidence_threshold;
     int rc = parse_param(param_text, h->layers);
     if (rc != SGX_OK) { delete h; return rc; }
     const int B = max_batch, T = h->T;
@@ -136,6 +138,17 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
             if (flag != 0) FAIL(SGX_ERR_UNSUPPORTED);                       // raw fp32 weights only
             if (h->alloc(&op.wt, wsize) || h->alloc(&op.bias, outc)) FAIL(SGX_ERR_NOMEM);
             if (hipMemcpy(op.wt, bp + bo, (size_t)wsize * 4, hipMemcpyHostToDevice) != hipSuccess) FAIL(SGX_ERR_DEVICE);
+            {   // host-transposed copies for the tuned kernels: pointwise [k][oc]; stem [(c,i,j)][16]
+                const float *wsrc = (const float *)(bp + bo);
+                const bool pw = (k == 1 && group == 1 && stride == 1 && pad == 0), stem = (group == 1 && k > 1 && outc <= 16);
+                if (pw || stem) {
+                    const int kk = inc * k * k, ldo = pw ? outc : 16;
+                    std::vector<float> wT((size_t)kk * ldo, 0.f);
+                    for (int o = 0; o < outc; o++) for (int q = 0; q < kk; q++) { float v; memcpy(&v, wsrc + (size_t)o * kk + q, 4); wT[(size_t)q * ldo + o] = v; }
+                    if (h->alloc(&op.wtT, wT.size())) FAIL(SGX_ERR_NOMEM);
+                    if (hipMemcpy(op.wtT, wT.data(), wT.size() * 4, hipMemcpyHostToDevice) != hipSuccess) FAIL(SGX_ERR_DEVICE);
+                }
+            }
             bo += (size_t)wsize * 4;
             std::vector<float> bz(outc, 0.f);
             if (L.geti(5, 0)) { memcpy(bz.data(), bp + bo, (size_t)outc * 4); bo += (size_t)outc * 4; }
@@ -311,13 +324,67 @@ static void run_op(sgx_det *h, const Op &op, int batch, sgx_stream_t st)
     switch (op.kind) {
     case OP_PW: {
         const int N = op.H * op.W;
-        SGX_LAUNCH(k_conv_pw, dim3((N + 63) / 64, (op.outc + 63) / 64, batch), dim3(256), st, op.inc, op.outc, N, A.d, A.n, op.wt, op.bias, O.d, O.n,
-                   make_epi(h, op, (size_t)op.outc * N), op.hwc, op.hwc_off);
+        if (h->legacy || !op.wtT) {
+            SGX_LAUNCH(k_conv_pw, dim3((N + 63) / 64, (op.outc + 63) / 64, batch), dim3(256), st, op.inc, op.outc, N, A.d, A.n, op.wt, op.bias, O.d, O.n,
+                       make_epi(h, op, (size_t)op.outc * N), op.hwc, op.hwc_off);
+            break;
+        }
+        // Tile choice.  oc block = OCB sub-tiles of 32 channels, wave tile = PXB sub-tiles of 32 pixels, workgroup = 4 waves along pixels.
+        // Largest tile (most operand reuse) whose grid still gives every CU >= 2 workgroups, among those with the least oc padding;
+        // if no candidate fills the chip, the one with the most workgroups.
+        const int sub = (op.outc + 31) / 32, total = batch * N;
+        static const int cand[7][2] = { {4, 2}, {3, 2}, {2, 2}, {1, 4}, {2, 1}, {1, 2}, {1, 1} };
+        int ocb = 1, pxb = 1; long best_score = -1;
+        for (int c = 0; c < 7; c++) {
+            const int cb = cand[c][0], cp = cand[c][1];
+            const long nwg = (long)((total + 128 * cp - 1) / (128 * cp)) * ((sub + cb - 1) / cb);
+            const int padded = ((sub + cb - 1) / cb) * cb;
+            // score: filling the chip first (capped), then little padding, then tile size
+            const long fill = std::min(nwg, 512L);
+            const long score = fill * 1000000L + (long)(1000 - (padded - sub) * 100) * 100L + cb * cp;
+            if (score > best_score) { best_score = score; ocb = cb; pxb = cp; }
+        }
+        const int nxt = (total + 128 * pxb - 1) / (128 * pxb), noc = (sub + ocb - 1) / ocb;
+        const int grid = ((nxt + 7) / 8) * 8 * noc;
+        const SgxEpi e = make_epi(h, op, (size_t)op.outc * N);
+#define SGX_PW2(OCB_, PXB_) do { auto kfn = k_conv_pw2<OCB_, PXB_>; SGX_LAUNCH(kfn, dim3(grid), dim3(256), st, op.inc, op.outc, N, total, A.d, A.n, op.wtT, op.bias, \
+                                                                               O.d, O.n, e, op.hwc, op.hwc_off, nxt, noc); } while (0)
+        switch (ocb * 10 + pxb) {
+        case 42: SGX_PW2(4, 2); break; case 32: SGX_PW2(3, 2); break; case 22: SGX_PW2(2, 2); break; case 14: SGX_PW2(1, 4); break;
+        case 21: SGX_PW2(2, 1); break; case 12: SGX_PW2(1, 2); break; default: SGX_PW2(1, 1); break;
+        }
+#undef SGX_PW2
         break; }
-    case OP_KXK:
-        SGX_LAUNCH(k_conv_kxk, dim3((op.Ho * op.Wo + 255) / 256, op.outc, batch), dim3(256), st, op.inc, op.outc, op.H, op.W, op.Ho, op.Wo, op.k, op.stride, op.pad, op.depthwise,
-                   A.d, A.n, op.wt, op.bias, O.d, O.n, make_epi(h, op, (size_t)op.outc * op.Ho * op.Wo));
-        break;
+    case OP_KXK: {
+        const SgxEpi e = make_epi(h, op, (size_t)op.outc * op.Ho * op.Wo);
+        const int budget = 8192;                                        // floats of LDS per workgroup for the staged input
+        const int Wp = (op.Wo - 1) * op.stride + op.k;
+        auto magic = [](int d) -> unsigned { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
+        if (!h->legacy && op.depthwise && (op.k == 3 || op.k == 5) && Wp * op.k <= budget) {
+            const int nplanes = batch * op.outc, rin_full = (op.Ho - 1) * op.stride + op.k;
+            int P = 1, RB = op.Ho;
+            if (rin_full * Wp <= budget) P = std::max(1, std::min(std::min(budget / (rin_full * Wp), 16), nplanes / 2048));
+            else {
+                const int rbmax = std::max(1, (budget / Wp - op.k) / op.stride + 1);
+                int nb = (op.Ho + rbmax - 1) / rbmax;
+                nb = std::max(nb, std::min((2048 + nplanes - 1) / nplanes, std::max(1, op.Ho / 4)));
+                RB = (op.Ho + nb - 1) / nb;
+            }
+            const int nbands = (op.Ho + RB - 1) / RB, ngroups = (nplanes + P - 1) / P;
+            const size_t lds = ((size_t)P * ((RB - 1) * op.stride + op.k) * Wp + (size_t)P * (op.k * op.k + 1)) * 4;
+            if (op.k == 3) { auto kfn = k_conv_dw<3>; SGX_LAUNCH_DYN(kfn, dim3(ngroups * nbands), dim3(256), lds, st, op.outc, op.H, op.W, op.Ho, op.Wo, op.stride, op.pad, P, RB, nbands, nplanes,
+                                                                     magic(Wp), magic(op.Wo), A.d, op.wt, op.bias, O.d, e); }
+            else { auto kfn = k_conv_dw<5>; SGX_LAUNCH_DYN(kfn, dim3(ngroups * nbands), dim3(256), lds, st, op.outc, op.H, op.W, op.Ho, op.Wo, op.stride, op.pad, P, RB, nbands, nplanes,
+                                                           magic(Wp), magic(op.Wo), A.d, op.wt, op.bias, O.d, e); }
+        } else if (!h->legacy && !op.depthwise && op.wtT && op.outc <= 16 && op.inc * Wp * op.k <= budget) {
+            const int RB = std::min(op.Ho, std::max(1, (budget / (op.inc * Wp) - op.k) / op.stride + 1)), nbands = (op.Ho + RB - 1) / RB;
+            const size_t lds = (size_t)op.inc * ((RB - 1) * op.stride + op.k) * Wp * 4;
+            SGX_LAUNCH_DYN(k_conv_stem, dim3(nbands, batch), dim3(256), lds, st, op.inc, op.outc, op.H, op.W, op.Ho, op.Wo, op.k, op.stride, op.pad, RB, magic(Wp), magic(op.Wo),
+                           A.d, A.n, op.wtT, op.bias, O.d, O.n, e);
+        } else
+            SGX_LAUNCH(k_conv_kxk, dim3((op.Ho * op.Wo + 255) / 256, op.outc, batch), dim3(256), st, op.inc, op.outc, op.H, op.W, op.Ho, op.Wo, op.k, op.stride, op.pad, op.depthwise,
+                       A.d, A.n, op.wt, op.bias, O.d, O.n, e);
+        break; }
     case OP_BINARY: {
         const Blob &Bb = h->blobs[op.in1];
         // per-image pitch equals blob size (dense), so the batch is one flat range

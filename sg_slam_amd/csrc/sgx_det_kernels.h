@@ -27,15 +27,20 @@ struct SgxEpi { int n; int pad; size_t tpitch; SgxEpiStep s[SGX_EPI_MAX]; };    
 
 SGX_DEV float sgx_epi(const SgxEpi &e, float v, size_t toff)
 {
+    // fully unrolled over the (at most SGX_EPI_MAX) steps: every field is a wave-uniform kernel argument at a constant offset, so the
+    // scalar loads are hoisted out of the callers' loops and a step costs a few scalar branches + one or two VALU operations
     const float root = v;
-    for (int i = 0; i < e.n; i++) {
-        const int op = e.s[i].op;
-        if (op == SGX_EOP_CLIP) v = fminf(fmaxf(v, e.s[i].a), e.s[i].b);
-        else if (op == SGX_EOP_RELU) v = fmaxf(v, 0.f);
-        else {
-            const int src = e.s[i].src;
-            const float o = src == SGX_ESRC_CONST ? e.s[i].a : (src == SGX_ESRC_ROOT ? root : e.s[i].t[toff]);
-            v = op == SGX_EOP_ADD ? v + o : op == SGX_EOP_MUL ? v * o : op == SGX_EOP_DIV ? v / o : op == SGX_EOP_SUB ? v - o : op == SGX_EOP_RSUB ? o - v : o / v;
+#pragma unroll
+    for (int i = 0; i < SGX_EPI_MAX; i++) {
+        if (i < e.n) {
+            const int op = e.s[i].op;
+            if (op == SGX_EOP_CLIP) v = fminf(fmaxf(v, e.s[i].a), e.s[i].b);
+            else if (op == SGX_EOP_RELU) v = fmaxf(v, 0.f);
+            else {
+                const int src = e.s[i].src;
+                const float o = src == SGX_ESRC_CONST ? e.s[i].a : (src == SGX_ESRC_ROOT ? root : e.s[i].t[toff]);
+                v = op == SGX_EOP_ADD ? v + o : op == SGX_EOP_MUL ? v * o : op == SGX_EOP_DIV ? v / o : op == SGX_EOP_SUB ? v - o : op == SGX_EOP_RSUB ? o - v : o / v;
+            }
         }
     }
     return v;
@@ -93,9 +98,9 @@ SGX_KERNEL(256) k_conv_pw(int inc, int outc, int N, const float *in, size_t in_p
 #ifndef SGX_EMU
     const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-    sgx_f32x16 acc;
+    sgx_f32x16 acc;                                   // sum = bias, then the products in ascending k (ncnn's order)
 #pragma unroll
-    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    for (int r = 0; r < 16; r++) { const int row = oc0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); acc[r] = row < outc ? bias[row] : 0.f; }
     for (int k0 = 0; k0 < inc; k0 += SGX_PW_KT) {
         for (int t = tid; t < SGX_PW_KT * 64; t += 256) {
             const int kk = t >> 6, c = t & 63;                 // B tile: consecutive threads -> consecutive pixels (coalesced)
@@ -118,7 +123,7 @@ SGX_KERNEL(256) k_conv_pw(int inc, int outc, int N, const float *in, size_t in_p
     for (int r = 0; r < 16; r++) {
         const int row = oc0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row < outc && col < N) {
-            const float v = sgx_epi(epi, acc[r] + bias[row], (size_t)b * epi.tpitch + (size_t)row * N + col);
+            const float v = sgx_epi(epi, acc[r], (size_t)b * epi.tpitch + (size_t)row * N + col);
             if (hwc) Y[(size_t)hwc_off + (size_t)col * outc + row] = v; else Y[(size_t)row * N + col] = v;
         }
     }
@@ -129,9 +134,9 @@ SGX_KERNEL(256) k_conv_pw(int inc, int outc, int N, const float *in, size_t in_p
     for (int t = tid; t < 64 * 64; t += 256) {
         const int row = oc0 + (t >> 6), col = n0 + (t & 63);
         if (row < outc && col < N) {
-            float s = 0.f;
+            float s = bias[row];
             for (int k = 0; k < inc; k++) s = fmaf(Wt[(size_t)row * inc + k], X[(size_t)k * N + col], s);
-            const float v = sgx_epi(epi, s + bias[row], (size_t)b * epi.tpitch + (size_t)row * N + col);
+            const float v = sgx_epi(epi, s, (size_t)b * epi.tpitch + (size_t)row * N + col);
             if (hwc) Y[(size_t)hwc_off + (size_t)col * outc + row] = v; else Y[(size_t)row * N + col] = v;
         }
     }
@@ -152,7 +157,7 @@ SGX_KERNEL(256) k_conv_kxk(int inc, int outc, int H, int W, int Ho, int Wo, int 
     if (idx < Ho * Wo) {
         const int oy = idx / Wo, ox = idx - oy * Wo;
         const float *X = in + (size_t)b * in_pitch;
-        float s = 0.f;
+        float s = bias[oc];
         const int c0 = depthwise ? oc : 0, c1 = depthwise ? oc + 1 : inc;
         for (int c = c0; c < c1; c++) {
             const float *w = Wt + ((size_t)oc * (depthwise ? 1 : inc) + (depthwise ? 0 : c)) * k * k;
@@ -167,7 +172,276 @@ SGX_KERNEL(256) k_conv_kxk(int inc, int outc, int H, int W, int Ho, int Wo, int 
                 }
             }
         }
-        out[(size_t)b * out_pitch + (size_t)oc * Ho * Wo + idx] = sgx_epi(epi, s + bias[oc], (size_t)b * epi.tpitch + (size_t)oc * Ho * Wo + idx);
+        out[(size_t)b * out_pitch + (size_t)oc * Ho * Wo + idx] = sgx_epi(epi, s, (size_t)b * epi.tpitch + (size_t)oc * Ho * Wo + idx);
+    }
+    SGX_THREADS_END
+}
+
+// exact n / d for n < 2^20, d < 2^12 with m = ceil(2^32 / d) (host-computed): one mul-hi instead of an integer division
+// (m == 0 encodes d == 1)
+SGX_DEV unsigned sgx_fastdiv(unsigned n, unsigned m)
+{
+#ifndef SGX_EMU
+    return m ? __umulhi(n, m) : n;
+#else
+    return m ? (unsigned)(((unsigned long long)n * m) >> 32) : n;
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_conv_pw2: 1x1 convolution as a weights-stationary streaming GEMM on the fp32 matrix cores.
+//   Out[b][oc][n] = sum_k WtT[k][oc] * In[b][k][n] + bias[oc]          (WtT = weights transposed on the host at load time)
+// The pixel axis is flattened over the batch (g = b*N + n), so small feature maps (10x10 ... 1x1) still fill whole tiles.
+// Workgroup = 4 waves; every wave owns PXB sub-tiles of 32 pixels and all OCB sub-tiles of 32 output channels of the block:
+// its B operands (input) go global -> registers in the MFMA layout (lane l: In[k + (l>>5)][pixel l&31], two coalesced 128 B
+// rows per load, prefetched 4 k-steps ahead) and are each used for OCB MFMAs; the A operands (weights) are staged through
+// double-buffered LDS chunks of SGX_PW2_KC input channels, shared by the 4 waves, each used for PXB MFMAs.  Every input element
+// is read once per oc block.  Rows of a chunk past `inc` hold zero weights, so a chunk is always processed in whole groups of 8 k.
+// sum = bias, then the products in ascending k, as in k_conv_pw.  Epilogue: bias + fused elementwise program; CHW or HWC store.
+// 1-D grid, XCD-aware: the oc blocks of one pixel tile run on the same XCD (shared L2) back to back.
+// ---------------------------------------------------------------------------------------------
+#define SGX_PW2_KC 32
+
+template <int OCB, int PXB>
+SGX_KERNEL_OCC(256, (OCB * PXB <= 4 ? 4 : (OCB * PXB <= 6 ? 3 : 2))) k_conv_pw2(int inc, int outc, int N, int total, const float *in, size_t in_pitch, const float *WtT, const float *bias,
+                           float *out, size_t out_pitch, SgxEpi epi, int hwc, int hwc_off, int nxt, int noc)
+{
+    constexpr int OCT = 32 * OCB;
+    SGX_LDS float Ws[2][SGX_PW2_KC][OCT + 1];       // weight chunks, double-buffered
+    SGX_LDS float Es[4][32][33];                    // per-wave epilogue staging tile
+    const int id = (int)blockIdx.x;
+    const int grp = id / (8 * noc), rem = id - grp * (8 * noc);
+    const int xt = grp * 8 + (rem & 7), yt = rem >> 3;                  // XCD = id % 8 = xt % 8
+    if (xt >= nxt) return;                                               // uniform per workgroup
+    const int oc0 = yt * OCT;
+#ifndef SGX_EMU
+    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int g0 = (xt * 4 + wave) * (32 * PXB);
+    // lanes past the end of the pixel axis (and rows past outc / k past inc) work on clamped addresses: finite values that meet zero
+    // weights or are never stored.  No divergent control flow anywhere in the main loop.
+    const float *px[PXB];
+#pragma unroll
+    for (int m = 0; m < PXB; m++) {
+        const unsigned gg = (unsigned)min(g0 + 32 * m + l31, total - 1), b = gg / (unsigned)N, n = gg - b * (unsigned)N;
+        px[m] = in + (size_t)b * in_pitch + n;
+    }
+    constexpr int D = 4;                                   // B-operand prefetch ring: D k-steps (of 2 input channels) ahead of the MFMAs
+    constexpr int WR = SGX_PW2_KC * OCT / 256;             // weight-chunk elements per thread
+    float bq[D][PXB];
+#pragma unroll
+    for (int d = 0; d < D; d++)
+#pragma unroll
+        for (int m = 0; m < PXB; m++) bq[d][m] = px[m][(size_t)min(2 * d + half, inc - 1) * N];
+    float wr[WR];
+#pragma unroll
+    for (int i = 0; i < WR; i++) {
+        const int t = tid + 256 * i, kk = t / OCT, oc = t - kk * OCT;
+        wr[i] = (kk < inc && oc0 + oc < outc) ? WtT[(size_t)kk * outc + oc0 + oc] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < WR; i++) { const int t = tid + 256 * i, kk = t / OCT, oc = t - kk * OCT; Ws[0][kk][oc] = wr[i]; }
+    sgx_f32x16 acc[OCB][PXB];
+#pragma unroll
+    for (int t = 0; t < OCB; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float bz = bias[min(oc0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half, outc - 1)];
+#pragma unroll
+            for (int m = 0; m < PXB; m++) acc[t][m][r] = bz;
+        }
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < inc; k0 += SGX_PW2_KC, buf ^= 1) {
+        const bool more = k0 + SGX_PW2_KC < inc;
+        if (more) {                                        // next weight chunk: global -> registers now, -> LDS after this chunk's MFMAs
+#pragma unroll
+            for (int i = 0; i < WR; i++) {
+                const int t = tid + 256 * i, kk = k0 + SGX_PW2_KC + t / OCT, oc = t % OCT;
+                wr[i] = (kk < inc && oc0 + oc < outc) ? WtT[(size_t)kk * outc + oc0 + oc] : 0.f;
+            }
+        }
+        const int kend = min(SGX_PW2_KC, inc - k0);
+        for (int kk = 0; kk < kend; kk += 2 * D) {
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                float bv[PXB];
+#pragma unroll
+                for (int m = 0; m < PXB; m++) { bv[m] = bq[d][m]; bq[d][m] = px[m][(size_t)min(k0 + kk + 2 * (d + D) + half, inc - 1) * N]; }
+#pragma unroll
+                for (int t = 0; t < OCB; t++) {
+                    const float a = Ws[buf][kk + 2 * d + half][32 * t + l31];
+#pragma unroll
+                    for (int m = 0; m < PXB; m++) acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[m], acc[t][m], 0, 0, 0);
+                }
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < WR; i++) { const int t = tid + 256 * i, kk = t / OCT, oc = t - kk * OCT; Ws[buf ^ 1][kk][oc] = wr[i]; }
+        }
+        __syncthreads();
+    }
+    // ---- epilogue, one 32x32 tile at a time through a wave-private LDS tile: a compact run-time loop applies the elementwise program
+    // (64 inlined copies of it cost hundreds of VGPRs), and the read-back order is chosen per store layout so stores stay contiguous
+    // (CHW: lanes along pixels; HWC: lanes along channels).
+    float (*E)[33] = Es[wave];
+#pragma unroll
+    for (int m = 0; m < PXB; m++)
+#pragma unroll
+        for (int t = 0; t < OCB; t++) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; r++) E[(r & 3) + 8 * (r >> 2) + 4 * half][l31] = acc[t][m][r];
+            __syncthreads();
+            const int gt = g0 + 32 * m, rt = oc0 + 32 * t;
+            if (!hwc) {
+                const int g = gt + l31;
+                const unsigned gg = (unsigned)min(g, total - 1), b = gg / (unsigned)N, n = gg - b * (unsigned)N;
+                float *Y = out + (size_t)b * out_pitch + n;
+                const size_t tb = (size_t)b * epi.tpitch + n;
+#pragma unroll 1
+                for (int j = 0; j < 16; j++) {
+                    const int rr = 2 * j + half, row = rt + rr;
+                    if (g < total && row < outc) Y[(size_t)row * N] = sgx_epi(epi, E[rr][l31], tb + (size_t)row * N);
+                }
+            } else {
+                const int row = rt + l31;
+#pragma unroll 1
+                for (int j = 0; j < 16; j++) {
+                    const int cc = 2 * j + half, g = gt + cc;
+                    const unsigned gg = (unsigned)min(g, total - 1), b = gg / (unsigned)N, n = gg - b * (unsigned)N;
+                    if (g < total && row < outc)
+                        out[(size_t)b * out_pitch + (size_t)hwc_off + (size_t)n * outc + row] = sgx_epi(epi, E[l31][cc], (size_t)b * epi.tpitch + (size_t)row * N + n);
+                }
+            }
+        }
+#else
+    (void)Ws; (void)Es;
+    SGX_THREADS_BEGIN(tid)
+    for (int t = tid; t < OCT * 128 * PXB; t += 256) {
+        const int row = oc0 + t / (128 * PXB), g = xt * 128 * PXB + t % (128 * PXB);
+        if (row < outc && g < total) {
+            const int b = g / N, n = g - b * N;
+            const float *X = in + (size_t)b * in_pitch;
+            float s = bias[row];
+            for (int k = 0; k < inc; k++) s = fmaf(WtT[(size_t)k * outc + row], X[(size_t)k * N + n], s);
+            const float v = sgx_epi(epi, s, (size_t)b * epi.tpitch + (size_t)row * N + n);
+            float *Y = out + (size_t)b * out_pitch;
+            if (hwc) Y[(size_t)hwc_off + (size_t)n * outc + row] = v; else Y[(size_t)row * N + n] = v;
+        }
+    }
+    SGX_THREADS_END
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_conv_dw: depthwise K x K convolution (ncnn ConvolutionDepthWise, group == channels), stride s, zero padding.
+// Planes are indexed p = b*C + c over the dense [B][C][H][W] blob.  A workgroup owns P consecutive planes x one band of RB output
+// rows: the zero-padded input band is staged in LDS with coalesced row loads (each input element read once), every thread then
+// produces outputs o = tid, tid+256, ... of the band (consecutive threads -> consecutive x: conflict-free LDS reads at stride 1,
+// coalesced stores).  Small planes (19x19 ... 1x1) are grouped P per workgroup, large ones (150x150) are cut into row bands.
+// Tap order (i, j) ascending with fmaf, as k_conv_kxk; taps that fall into the padding add an exact zero.
+// grid = (ceil(B*C / P) * nbands)
+// ---------------------------------------------------------------------------------------------
+template <int K>
+SGX_KERNEL(256) k_conv_dw(int C, int H, int W, int Ho, int Wo, int stride, int pad, int P, int RB, int nbands, int nplanes,
+                          unsigned wp_magic, unsigned wo_magic, const float *in, const float *Wt, const float *bias, float *out, SgxEpi epi)
+{
+    SGX_DYN_LDS(smem);
+    float *tile = (float *)smem;
+    const int grp = (int)blockIdx.x / nbands, band = (int)blockIdx.x - grp * nbands;
+    const int p0 = grp * P, np = min(P, nplanes - p0);
+    const int r0 = band * RB, nrows = min(RB, Ho - r0);
+    const int Wp = (Wo - 1) * stride + K, Rin = (nrows - 1) * stride + K, iy0 = r0 * stride - pad;
+    float *wl = tile + (size_t)P * ((RB - 1) * stride + K) * Wp;          // [P][K*K] weights + [P] bias
+    SGX_THREADS_BEGIN(tid)
+    const int per = Rin * Wp;
+    for (int q = 0; q < np; q++) {
+        const float *src = in + (size_t)(p0 + q) * H * W;
+        for (int t = tid; t < per; t += 256) {
+            const int ry = (int)sgx_fastdiv((unsigned)t, wp_magic), cx = t - ry * Wp;
+            const int iy = iy0 + ry, ix = cx - pad;
+            tile[q * per + t] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? src[(size_t)iy * W + ix] : 0.f;
+        }
+    }
+    for (int t = tid; t < np * (K * K + 1); t += 256) {
+        const int q = t / (K * K + 1), j = t - q * (K * K + 1), c = (p0 + q) % C;
+        wl[t] = j < K * K ? Wt[(size_t)c * K * K + j] : bias[c];
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    const int per = Rin * Wp, nout = nrows * Wo;
+    for (int q = 0; q < np; q++) {
+        const float *w = wl + q * (K * K + 1);
+        float wr[K * K];
+#pragma unroll
+        for (int j = 0; j < K * K; j++) wr[j] = w[j];
+        const float bz = w[K * K];
+        const size_t obase = (size_t)(p0 + q) * Ho * Wo + (size_t)r0 * Wo;
+        for (int o = tid; o < nout; o += 256) {
+            const int oy = (int)sgx_fastdiv((unsigned)o, wo_magic), ox = o - oy * Wo;
+            const float *base = tile + q * per + (oy * stride) * Wp + ox * stride;
+            float s = bz;
+#pragma unroll
+            for (int i = 0; i < K; i++)
+#pragma unroll
+                for (int j = 0; j < K; j++) s = fmaf(wr[i * K + j], base[i * Wp + j], s);
+            out[obase + o] = sgx_epi(epi, s, obase + o);
+        }
+    }
+    SGX_THREADS_END
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_conv_stem: dense K x K convolution with few input channels and <= 16 output channels (the 3 -> 16, 3x3, stride-2 stem).
+// A workgroup owns a band of RB output rows of one image: the inc zero-padded input bands are staged in LDS once, every thread
+// computes ALL output channels of its pixels (16 accumulators), weights are read with wave-uniform addresses from the
+// host-transposed table WtT[(c*K*K + i*K + j)][16].  Accumulation order per output: c, i, j ascending (as k_conv_kxk).
+// grid = (nbands, B)
+// ---------------------------------------------------------------------------------------------
+SGX_KERNEL(256) k_conv_stem(int inc, int outc, int H, int W, int Ho, int Wo, int K, int stride, int pad, int RB, unsigned wp_magic, unsigned wo_magic,
+                            const float *in, size_t in_pitch, const float *WtT, const float *bias, float *out, size_t out_pitch, SgxEpi epi)
+{
+    SGX_DYN_LDS(smem);
+    float *tile = (float *)smem;
+    const int b = (int)blockIdx.y, r0 = (int)blockIdx.x * RB, nrows = min(RB, Ho - r0);
+    const int Wp = (Wo - 1) * stride + K, Rin = (nrows - 1) * stride + K, iy0 = r0 * stride - pad, per = Rin * Wp;
+    SGX_THREADS_BEGIN(tid)
+    for (int c = 0; c < inc; c++) {
+        const float *src = in + (size_t)b * in_pitch + (size_t)c * H * W;
+        for (int t = tid; t < per; t += 256) {
+            const int ry = (int)sgx_fastdiv((unsigned)t, wp_magic), cx = t - ry * Wp;
+            const int iy = iy0 + ry, ix = cx - pad;
+            tile[c * per + t] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? src[(size_t)iy * W + ix] : 0.f;
+        }
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    const int nout = nrows * Wo;
+    for (int o = tid; o < nout; o += 256) {
+        const int oy = (int)sgx_fastdiv((unsigned)o, wo_magic), ox = o - oy * Wo;
+        float acc[16];
+#pragma unroll
+        for (int oc = 0; oc < 16; oc++) acc[oc] = oc < outc ? bias[oc] : 0.f;
+        for (int c = 0; c < inc; c++) {
+            const float *base = tile + c * per + (oy * stride) * Wp + ox * stride;
+            for (int i = 0; i < K; i++)
+                for (int j = 0; j < K; j++) {
+                    const float x = base[i * Wp + j];
+                    const float *w = WtT + (size_t)((c * K + i) * K + j) * 16;
+#pragma unroll
+                    for (int oc = 0; oc < 16; oc++) acc[oc] = fmaf(w[oc], x, acc[oc]);
+                }
+        }
+        const size_t pix = (size_t)(r0 + oy) * Wo + ox;
+#pragma unroll
+        for (int oc = 0; oc < 16; oc++)
+            if (oc < outc) {
+                const size_t idx = (size_t)oc * Ho * Wo + pix;
+                out[(size_t)b * out_pitch + idx] = sgx_epi(epi, acc[oc], (size_t)b * epi.tpitch + idx);
+            }
     }
     SGX_THREADS_END
 }

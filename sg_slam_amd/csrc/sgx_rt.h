@@ -22,6 +22,7 @@
 #define SGX_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #define SGX_LAUNCH_DYN(kern, grid, block, lds, stream, ...) hipLaunchKernelGGL((kern), grid, block, (lds), stream, __VA_ARGS__)
 #define SGX_KERNEL(bounds) __global__ void __launch_bounds__(bounds)
+#define SGX_KERNEL_OCC(bounds, waves_per_simd) __global__ void __launch_bounds__(bounds) __attribute__((amdgpu_waves_per_eu(waves_per_simd, waves_per_simd)))
 #define SGX_DEV __device__ __forceinline__
 #define SGX_CONST __constant__
 #define sgx_atomic_add(p, v) atomicAdd((p), (v))
@@ -50,6 +51,7 @@ extern thread_local sgx_dim3 blockIdx, blockDim, gridDim;
 #define SGX_DYN_LDS(name) static thread_local unsigned char name[163840] __attribute__((aligned(16)))
 #define SGX_LAUNCH_DYN(kern, grid, block, lds, stream, ...) SGX_LAUNCH(kern, grid, block, stream, __VA_ARGS__)
 #define SGX_KERNEL(bounds) static void
+#define SGX_KERNEL_OCC(bounds, waves_per_simd) static void
 #define SGX_DEV static inline
 #define SGX_CONST static
 template <class T, class U> static inline T sgx_atomic_add(T *p, U v) { T o = *p; *p = (T)(o + (T)v); return o; }

@@ -78,17 +78,19 @@ def test_detector_emu_fused_matches_oracle(emu, model):
 
 
 def run_fused_equals_unfused(lib, model):
-    """The fused plan (conv epilogue programs, HWC head stores) applies the same fp32 operations in the same order: bit-identical outputs."""
+    """The fused plan (conv epilogue programs, HWC head stores) and the tuned kernels (streaming MFMA GEMM, LDS-tiled depthwise, stem)
+    apply the same fp32 operations in the same order as the one-kernel-per-layer reference plan: bit-identical outputs."""
     layers, W, blob = model
     imgs = np.stack([make_image(3), make_image(4)])
     outs = []
-    for fuse in (False, True):
-        det = Detector2D(0.90, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=2, lib=lib, fuse=fuse)
+    for fuse, legacy in ((False, True), (True, True), (True, False), (False, False)):
+        det = Detector2D(0.90, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=2, lib=lib, fuse=fuse, legacy_kernels=legacy)
         det.detect_batch(imgs)
         outs.append([np.stack([det.debug_blob(nm, b) for b in range(2)]) for nm in ('587', '632', '672', '849', '908', '944', 'mbox_loc', 'mbox_conf_softmax')])
         det.close()
-    for a, b in zip(*outs):
-        assert (a == b).all()
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert (a == b).all()
 
 
 def test_detector_emu_fused_equals_unfused(emu, model):
