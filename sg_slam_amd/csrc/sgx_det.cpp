@@ -315,6 +315,20 @@ static SgxEpi make_epi(const sgx_det *h, const Op &op, size_t tpitch)
         SgxEpiStep &d = e.s[e.n++];
         d.op = st.op; d.src = st.src; d.a = st.a; d.b = st.b; d.t = st.tensor >= 0 ? h->blobs[st.tensor].d : nullptr;
     }
+    // recognise the recurring programs (straight-line code in the kernels); anything else runs through the generic interpreter
+    auto is = [&](int i, int opc, int src) { return i < e.n && e.s[i].op == opc && (opc == SGX_EOP_CLIP || opc == SGX_EOP_RELU || e.s[i].src == src); };
+    const float inf = INFINITY;
+    e.mode = SGX_EMODE_GENERIC;
+    if (e.n == 0) e.mode = SGX_EMODE_NONE;
+    else if (e.n == 1 && is(0, SGX_EOP_RELU, 0)) { e.mode = SGX_EMODE_ACT; e.lo = 0.f; e.hi = inf; }
+    else if (e.n == 1 && is(0, SGX_EOP_CLIP, 0)) { e.mode = SGX_EMODE_ACT; e.lo = e.s[0].a; e.hi = e.s[0].b; }
+    else if (e.n == 1 && is(0, SGX_EOP_ADD, SGX_ESRC_TENSOR)) { e.mode = SGX_EMODE_ADD_T; e.t1 = e.s[0].t; }
+    else if (e.n == 4 && is(0, SGX_EOP_ADD, SGX_ESRC_CONST) && is(1, SGX_EOP_CLIP, 0) && is(2, SGX_EOP_MUL, SGX_ESRC_ROOT) && is(3, SGX_EOP_DIV, SGX_ESRC_CONST)) {
+        e.mode = SGX_EMODE_HSWISH; e.c1 = e.s[0].a; e.lo = e.s[1].a; e.hi = e.s[1].b; e.c2 = e.s[3].a;
+    } else if ((e.n == 4 || e.n == 5) && is(0, SGX_EOP_ADD, SGX_ESRC_CONST) && is(1, SGX_EOP_CLIP, 0) && is(2, SGX_EOP_DIV, SGX_ESRC_CONST) && is(3, SGX_EOP_MUL, SGX_ESRC_TENSOR) &&
+               (e.n == 4 || is(4, SGX_EOP_ADD, SGX_ESRC_TENSOR))) {
+        e.mode = e.n == 4 ? SGX_EMODE_GATE : SGX_EMODE_GATE_ADD; e.c1 = e.s[0].a; e.lo = e.s[1].a; e.hi = e.s[1].b; e.c2 = e.s[2].a; e.t0 = e.s[3].t; if (e.n == 5) e.t1 = e.s[4].t;
+    }
     return e;
 }
 

@@ -23,12 +23,24 @@ SGX_DEV float sgx_act(float v, int act, float lo, float hi)
 enum { SGX_EOP_ADD = 0, SGX_EOP_SUB, SGX_EOP_MUL, SGX_EOP_DIV, SGX_EOP_RSUB, SGX_EOP_RDIV, SGX_EOP_CLIP, SGX_EOP_RELU };
 enum { SGX_ESRC_CONST = 0, SGX_ESRC_TENSOR, SGX_ESRC_ROOT };
 struct SgxEpiStep { int op, src; float a, b; const float *t; };
-struct SgxEpi { int n; int pad; size_t tpitch; SgxEpiStep s[SGX_EPI_MAX]; };     // tensor operands have the output's shape; per-image pitch tpitch
+// mode: the planner recognises the graph's recurring programs so the kernels run them as straight-line code (one uniform switch) instead
+// of interpreting the step list; every mode performs exactly the steps' operations in the steps' order.
+enum { SGX_EMODE_GENERIC = 0, SGX_EMODE_NONE, SGX_EMODE_ACT, SGX_EMODE_HSWISH, SGX_EMODE_GATE, SGX_EMODE_GATE_ADD, SGX_EMODE_ADD_T };
+struct SgxEpi { int n; int mode; size_t tpitch; float c1, lo, hi, c2; const float *t0, *t1; SgxEpiStep s[SGX_EPI_MAX]; };   // tensor operands: output's shape, per-image pitch tpitch
 
 SGX_DEV float sgx_epi(const SgxEpi &e, float v, size_t toff)
 {
-    // fully unrolled over the (at most SGX_EPI_MAX) steps: every field is a wave-uniform kernel argument at a constant offset, so the
-    // scalar loads are hoisted out of the callers' loops and a step costs a few scalar branches + one or two VALU operations
+    switch (e.mode) {
+    case SGX_EMODE_NONE: return v;
+    case SGX_EMODE_ACT: return fminf(fmaxf(v, e.lo), e.hi);                                                       // [RELU] (hi = +inf) / [CLIP]
+    case SGX_EMODE_HSWISH: { float u = v + e.c1; u = fminf(fmaxf(u, e.lo), e.hi); u = u * v; return u / e.c2; }      // [ADD c][CLIP][MUL root][DIV c]
+    case SGX_EMODE_GATE: { float u = v + e.c1; u = fminf(fmaxf(u, e.lo), e.hi); u = u / e.c2; return u * e.t0[toff]; }   // [ADD c][CLIP][DIV c][MUL t]
+    case SGX_EMODE_GATE_ADD: { float u = v + e.c1; u = fminf(fmaxf(u, e.lo), e.hi); u = u / e.c2; u = u * e.t0[toff]; return u + e.t1[toff]; }
+    case SGX_EMODE_ADD_T: return v + e.t1[toff];                                                                   // [ADD t]
+    default: break;
+    }
+    // generic interpreter, fully unrolled over the (at most SGX_EPI_MAX) steps: every field is a wave-uniform kernel argument at a
+    // constant offset, so the scalar loads are hoisted out of the callers' loops
     const float root = v;
 #pragma unroll
     for (int i = 0; i < SGX_EPI_MAX; i++) {
@@ -225,7 +237,7 @@ SGX_KERNEL_OCC(256, (OCB * PXB <= 4 ? 4 : (OCB * PXB <= 6 ? 3 : 2))) k_conv_pw2(
         const unsigned gg = (unsigned)min(g0 + 32 * m + l31, total - 1), b = gg / (unsigned)N, n = gg - b * (unsigned)N;
         px[m] = in + (size_t)b * in_pitch + n;
     }
-    constexpr int D = 4;                                   // B-operand prefetch ring: D k-steps (of 2 input channels) ahead of the MFMAs
+    constexpr int D = OCB * PXB >= 4 ? 4 : (OCB * PXB == 2 ? 8 : 16);   // B-operand prefetch ring: D k-steps (of 2 input channels) ahead of the MFMAs, ~1000+ MFMA cycles
     constexpr int WR = SGX_PW2_KC * OCT / 256;             // weight-chunk elements per thread
     float bq[D][PXB];
 #pragma unroll
@@ -267,11 +279,13 @@ SGX_KERNEL_OCC(256, (OCB * PXB <= 4 ? 4 : (OCB * PXB <= 6 ? 3 : 2))) k_conv_pw2(
                 float bv[PXB];
 #pragma unroll
                 for (int m = 0; m < PXB; m++) { bv[m] = bq[d][m]; bq[d][m] = px[m][(size_t)min(k0 + kk + 2 * (d + D) + half, inc - 1) * N]; }
+                if (kk + 2 * d < kend) {                     // (uniform) rows past the end of the chunk hold zero weights: skip their MFMAs
 #pragma unroll
-                for (int t = 0; t < OCB; t++) {
-                    const float a = Ws[buf][kk + 2 * d + half][32 * t + l31];
+                    for (int t = 0; t < OCB; t++) {
+                        const float a = Ws[buf][kk + 2 * d + half][32 * t + l31];
 #pragma unroll
-                    for (int m = 0; m < PXB; m++) acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[m], acc[t][m], 0, 0, 0);
+                        for (int m = 0; m < PXB; m++) acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[m], acc[t][m], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -297,12 +311,13 @@ SGX_KERNEL_OCC(256, (OCB * PXB <= 4 ? 4 : (OCB * PXB <= 6 ? 3 : 2))) k_conv_pw2(
             if (!hwc) {
                 const int g = gt + l31;
                 const unsigned gg = (unsigned)min(g, total - 1), b = gg / (unsigned)N, n = gg - b * (unsigned)N;
-                float *Y = out + (size_t)b * out_pitch + n;
-                const size_t tb = (size_t)b * epi.tpitch + n;
-#pragma unroll 1
-                for (int j = 0; j < 16; j++) {
-                    const int rr = 2 * j + half, row = rt + rr;
-                    if (g < total && row < outc) Y[(size_t)row * N] = sgx_epi(epi, E[rr][l31], tb + (size_t)row * N);
+                float *Y = out + (size_t)b * out_pitch + n + (size_t)(rt + half) * N;
+                size_t tb = (size_t)b * epi.tpitch + n + (size_t)(rt + half) * N;
+                const int nj = g < total ? min(16, (outc - rt - half + 1) / 2) : 0;          // rows rt + half + 2j < outc
+#pragma unroll 4
+                for (int j = 0; j < nj; j++) {
+                    *Y = sgx_epi(epi, E[2 * j + half][l31], tb);
+                    Y += 2 * (size_t)N; tb += 2 * (size_t)N;
                 }
             } else {
                 const int row = rt + l31;
