@@ -32,7 +32,7 @@ struct Op {
     OpKind kind; int in0 = -1, in1 = -1, out = -1;
     std::vector<EpiStep> epi; int hwc = 0, hwc_off = 0; bool dead = false; std::string name;
     int inc = 0, outc = 0, H = 0, W = 0, Ho = 0, Wo = 0, k = 1, stride = 1, pad = 0, depthwise = 0, act = 0; float lo = 0, hi = 0;
-    float *wt = nullptr, *bias = nullptr, *wtT = nullptr; int bop = 0; int off = 0; int rows = 0, C = 0;
+    float *wt = nullptr, *bias = nullptr, *wtT = nullptr; int ldw = 0; int bop = 0; int off = 0; int rows = 0, C = 0;
 };
 }  // namespace
 
@@ -142,8 +142,9 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                 const float *wsrc = (const float *)(bp + bo);
                 const bool pw = (k == 1 && group == 1 && stride == 1 && pad == 0), stem = (group == 1 && k > 1 && outc <= 16);
                 if (pw || stem) {
-                    const int kk = inc * k * k, ldo = pw ? outc : 16;
-                    std::vector<float> wT((size_t)kk * ldo, 0.f);
+                    const int kk = inc * k * k, ldo = pw ? ((outc + 31) / 32) * 32 + 96 : 16;          // pointwise: zero-padded to [ceil32(inc)][ldo]
+                    op.ldw = ldo;
+                    std::vector<float> wT((size_t)(pw ? ((kk + 31) / 32) * 32 : kk) * ldo, 0.f);
                     for (int o = 0; o < outc; o++) for (int q = 0; q < kk; q++) { float v; memcpy(&v, wsrc + (size_t)o * kk + q, 4); wT[(size_t)q * ldo + o] = v; }
                     if (h->alloc(&op.wtT, wT.size())) FAIL(SGX_ERR_NOMEM);
                     if (hipMemcpy(op.wtT, wT.data(), wT.size() * 4, hipMemcpyHostToDevice) != hipSuccess) FAIL(SGX_ERR_DEVICE);
@@ -338,7 +339,8 @@ static void run_op(sgx_det *h, const Op &op, int batch, sgx_stream_t st)
     switch (op.kind) {
     case OP_PW: {
         const int N = op.H * op.W;
-        if (h->legacy || !op.wtT) {
+        const size_t big = (size_t)batch * std::max(std::max(A.n, O.n), (size_t)op.outc * N) * 4;      // k_conv_pw2 uses 32-bit byte offsets per lane
+        if (h->legacy || !op.wtT || (op.inc & 1) || big >= 0xFFFFFFFFull) {
             SGX_LAUNCH(k_conv_pw, dim3((N + 63) / 64, (op.outc + 63) / 64, batch), dim3(256), st, op.inc, op.outc, N, A.d, A.n, op.wt, op.bias, O.d, O.n,
                        make_epi(h, op, (size_t)op.outc * N), op.hwc, op.hwc_off);
             break;
@@ -362,7 +364,7 @@ static void run_op(sgx_det *h, const Op &op, int batch, sgx_stream_t st)
         const int grid = ((nxt + 7) / 8) * 8 * noc;
         const SgxEpi e = make_epi(h, op, (size_t)op.outc * N);
 #define SGX_PW2(OCB_, PXB_) do { auto kfn = k_conv_pw2<OCB_, PXB_>; SGX_LAUNCH(kfn, dim3(grid), dim3(256), st, op.inc, op.outc, N, total, A.d, A.n, op.wtT, op.bias, \
-                                                                               O.d, O.n, e, op.hwc, op.hwc_off, nxt, noc); } while (0)
+                                                                               O.d, O.n, e, op.hwc, op.hwc_off, nxt, noc, op.ldw); } while (0)
         switch (ocb * 10 + pxb) {
         case 42: SGX_PW2(4, 2); break; case 32: SGX_PW2(3, 2); break; case 22: SGX_PW2(2, 2); break; case 14: SGX_PW2(1, 4); break;
         case 21: SGX_PW2(2, 1); break; case 12: SGX_PW2(1, 2); break; default: SGX_PW2(1, 1); break;
@@ -387,13 +389,13 @@ static void run_op(sgx_det *h, const Op &op, int batch, sgx_stream_t st)
             const int nbands = (op.Ho + RB - 1) / RB, ngroups = (nplanes + P - 1) / P;
             const size_t lds = ((size_t)P * ((RB - 1) * op.stride + op.k) * Wp + (size_t)P * (op.k * op.k + 1)) * 4;
             if (op.k == 3) { auto kfn = k_conv_dw<3>; SGX_LAUNCH_DYN(kfn, dim3(ngroups * nbands), dim3(256), lds, st, op.outc, op.H, op.W, op.Ho, op.Wo, op.stride, op.pad, P, RB, nbands, nplanes,
-                                                                     magic(Wp), magic(op.Wo), A.d, op.wt, op.bias, O.d, e); }
+                                                                     magic(((std::min(RB, op.Ho) - 1) * op.stride + op.k) * Wp), magic(Wp), magic(op.Wo), A.d, op.wt, op.bias, O.d, e); }
             else { auto kfn = k_conv_dw<5>; SGX_LAUNCH_DYN(kfn, dim3(ngroups * nbands), dim3(256), lds, st, op.outc, op.H, op.W, op.Ho, op.Wo, op.stride, op.pad, P, RB, nbands, nplanes,
-                                                           magic(Wp), magic(op.Wo), A.d, op.wt, op.bias, O.d, e); }
+                                                           magic(((std::min(RB, op.Ho) - 1) * op.stride + op.k) * Wp), magic(Wp), magic(op.Wo), A.d, op.wt, op.bias, O.d, e); }
         } else if (!h->legacy && !op.depthwise && op.wtT && op.outc <= 16 && op.inc * Wp * op.k <= budget) {
             const int RB = std::min(op.Ho, std::max(1, (budget / (op.inc * Wp) - op.k) / op.stride + 1)), nbands = (op.Ho + RB - 1) / RB;
             const size_t lds = (size_t)op.inc * ((RB - 1) * op.stride + op.k) * Wp * 4;
-            SGX_LAUNCH_DYN(k_conv_stem, dim3(nbands, batch), dim3(256), lds, st, op.inc, op.outc, op.H, op.W, op.Ho, op.Wo, op.k, op.stride, op.pad, RB, magic(Wp), magic(op.Wo),
+            SGX_LAUNCH_DYN(k_conv_stem, dim3(nbands, batch), dim3(256), lds, st, op.inc, op.outc, op.H, op.W, op.Ho, op.Wo, op.k, op.stride, op.pad, RB, magic(((RB - 1) * op.stride + op.k) * Wp), magic(Wp), magic(op.Wo),
                            A.d, A.n, op.wtT, op.bias, O.d, O.n, e);
         } else
             SGX_LAUNCH(k_conv_kxk, dim3((op.Ho * op.Wo + 255) / 256, op.outc, batch), dim3(256), st, op.inc, op.outc, op.H, op.W, op.Ho, op.Wo, op.k, op.stride, op.pad, op.depthwise,

@@ -28,17 +28,18 @@ struct SgxEpiStep { int op, src; float a, b; const float *t; };
 enum { SGX_EMODE_GENERIC = 0, SGX_EMODE_NONE, SGX_EMODE_ACT, SGX_EMODE_HSWISH, SGX_EMODE_GATE, SGX_EMODE_GATE_ADD, SGX_EMODE_ADD_T };
 struct SgxEpi { int n; int mode; size_t tpitch; float c1, lo, hi, c2; const float *t0, *t1; SgxEpiStep s[SGX_EPI_MAX]; };   // tensor operands: output's shape, per-image pitch tpitch
 
-SGX_DEV float sgx_epi(const SgxEpi &e, float v, size_t toff)
+// tensor operand address = t + uoff (elements; wave-uniform in the tuned kernels -> scalar base register) + voff4 (bytes, 32-bit lane offset)
+SGX_DEV float sgx_ldoff(const float *ubase, unsigned voff4) { return *(const float *)((const char *)ubase + voff4); }
+
+template <int MODE>
+SGX_DEV float sgx_epi_mode(const SgxEpi &e, float v, size_t uoff, unsigned voff4)
 {
-    switch (e.mode) {
-    case SGX_EMODE_NONE: return v;
-    case SGX_EMODE_ACT: return fminf(fmaxf(v, e.lo), e.hi);                                                       // [RELU] (hi = +inf) / [CLIP]
-    case SGX_EMODE_HSWISH: { float u = v + e.c1; u = fminf(fmaxf(u, e.lo), e.hi); u = u * v; return u / e.c2; }      // [ADD c][CLIP][MUL root][DIV c]
-    case SGX_EMODE_GATE: { float u = v + e.c1; u = fminf(fmaxf(u, e.lo), e.hi); u = u / e.c2; return u * e.t0[toff]; }   // [ADD c][CLIP][DIV c][MUL t]
-    case SGX_EMODE_GATE_ADD: { float u = v + e.c1; u = fminf(fmaxf(u, e.lo), e.hi); u = u / e.c2; u = u * e.t0[toff]; return u + e.t1[toff]; }
-    case SGX_EMODE_ADD_T: return v + e.t1[toff];                                                                   // [ADD t]
-    default: break;
-    }
+    if (MODE == SGX_EMODE_NONE) return v;
+    if (MODE == SGX_EMODE_ACT) return fminf(fmaxf(v, e.lo), e.hi);                                                       // [RELU] (hi = +inf) / [CLIP]
+    if (MODE == SGX_EMODE_HSWISH) { float u = v + e.c1; u = fminf(fmaxf(u, e.lo), e.hi); u = u * v; return u / e.c2; }      // [ADD c][CLIP][MUL root][DIV c]
+    if (MODE == SGX_EMODE_GATE) { float u = v + e.c1; u = fminf(fmaxf(u, e.lo), e.hi); u = u / e.c2; return u * sgx_ldoff(e.t0 + uoff, voff4); }   // [ADD c][CLIP][DIV c][MUL t]
+    if (MODE == SGX_EMODE_GATE_ADD) { float u = v + e.c1; u = fminf(fmaxf(u, e.lo), e.hi); u = u / e.c2; u = u * sgx_ldoff(e.t0 + uoff, voff4); return u + sgx_ldoff(e.t1 + uoff, voff4); }
+    if (MODE == SGX_EMODE_ADD_T) return v + sgx_ldoff(e.t1 + uoff, voff4);                                                // [ADD t]
     // generic interpreter, fully unrolled over the (at most SGX_EPI_MAX) steps: every field is a wave-uniform kernel argument at a
     // constant offset, so the scalar loads are hoisted out of the callers' loops
     const float root = v;
@@ -50,12 +51,25 @@ SGX_DEV float sgx_epi(const SgxEpi &e, float v, size_t toff)
             else if (op == SGX_EOP_RELU) v = fmaxf(v, 0.f);
             else {
                 const int src = e.s[i].src;
-                const float o = src == SGX_ESRC_CONST ? e.s[i].a : (src == SGX_ESRC_ROOT ? root : e.s[i].t[toff]);
+                const float o = src == SGX_ESRC_CONST ? e.s[i].a : (src == SGX_ESRC_ROOT ? root : sgx_ldoff(e.s[i].t + uoff, voff4));
                 v = op == SGX_EOP_ADD ? v + o : op == SGX_EOP_MUL ? v * o : op == SGX_EOP_DIV ? v / o : op == SGX_EOP_SUB ? v - o : op == SGX_EOP_RSUB ? o - v : o / v;
             }
         }
     }
     return v;
+}
+
+SGX_DEV float sgx_epi(const SgxEpi &e, float v, size_t uoff, unsigned voff4 = 0)
+{
+    switch (e.mode) {
+    case SGX_EMODE_NONE: return sgx_epi_mode<SGX_EMODE_NONE>(e, v, uoff, voff4);
+    case SGX_EMODE_ACT: return sgx_epi_mode<SGX_EMODE_ACT>(e, v, uoff, voff4);
+    case SGX_EMODE_HSWISH: return sgx_epi_mode<SGX_EMODE_HSWISH>(e, v, uoff, voff4);
+    case SGX_EMODE_GATE: return sgx_epi_mode<SGX_EMODE_GATE>(e, v, uoff, voff4);
+    case SGX_EMODE_GATE_ADD: return sgx_epi_mode<SGX_EMODE_GATE_ADD>(e, v, uoff, voff4);
+    case SGX_EMODE_ADD_T: return sgx_epi_mode<SGX_EMODE_ADD_T>(e, v, uoff, voff4);
+    default: return sgx_epi_mode<SGX_EMODE_GENERIC>(e, v, uoff, voff4);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -202,7 +216,7 @@ SGX_DEV unsigned sgx_fastdiv(unsigned n, unsigned m)
 
 // ---------------------------------------------------------------------------------------------
 // k_conv_pw2: 1x1 convolution as a weights-stationary streaming GEMM on the fp32 matrix cores.
-//   Out[b][oc][n] = sum_k WtT[k][oc] * In[b][k][n] + bias[oc]          (WtT = weights transposed on the host at load time)
+//   Out[b][oc][n] = sum_k WtT[k][oc] * In[b][k][n] + bias[oc]          (WtT = weights transposed + zero-padded to [ceil32(inc)][ldw] on the host at load time)
 // The pixel axis is flattened over the batch (g = b*N + n), so small feature maps (10x10 ... 1x1) still fill whole tiles.
 // Workgroup = 4 waves; every wave owns PXB sub-tiles of 32 pixels and all OCB sub-tiles of 32 output channels of the block:
 // its B operands (input) go global -> registers in the MFMA layout (lane l: In[k + (l>>5)][pixel l&31], two coalesced 128 B
@@ -214,13 +228,27 @@ SGX_DEV unsigned sgx_fastdiv(unsigned n, unsigned m)
 // ---------------------------------------------------------------------------------------------
 #define SGX_PW2_KC 32
 
+#ifndef SGX_EMU
+// read-back of one staged 32x32 tile, CHW store: lane = pixel (l31) of row 2j + half; scalar row base + 32-bit lane offsets
+template <int MODE>
+SGX_DEV void sgx_pw2_readback(const SgxEpi &epi, const float (*E)[33], int nj, int rt, int N, int half, int l31, float *out, unsigned ooff4, unsigned toff4)
+{
+#pragma unroll 4
+    for (int j = 0; j < nj; j++) {
+        const unsigned ubyte = (unsigned)(rt + 2 * j) * (unsigned)N * 4u;                             // wave-uniform row offset (blobs < 4 GB)
+        *(float *)((char *)out + ubyte + ooff4) = sgx_epi_mode<MODE>(epi, E[2 * j + half][l31], (size_t)(ubyte >> 2), toff4);
+    }
+}
+#endif
+
 template <int OCB, int PXB>
 SGX_KERNEL_OCC(256, (OCB * PXB <= 4 ? 4 : (OCB * PXB <= 6 ? 3 : 2))) k_conv_pw2(int inc, int outc, int N, int total, const float *in, size_t in_pitch, const float *WtT, const float *bias,
-                           float *out, size_t out_pitch, SgxEpi epi, int hwc, int hwc_off, int nxt, int noc)
+                           float *out, size_t out_pitch, SgxEpi epi, int hwc, int hwc_off, int nxt, int noc, int ldw)
 {
     constexpr int OCT = 32 * OCB;
     SGX_LDS float Ws[2][SGX_PW2_KC][OCT + 1];       // weight chunks, double-buffered
     SGX_LDS float Es[4][32][33];                    // per-wave epilogue staging tile
+    SGX_LDS float Bs[OCT];                          // bias of the oc block
     const int id = (int)blockIdx.x;
     const int grp = id / (8 * noc), rem = id - grp * (8 * noc);
     const int xt = grp * 8 + (rem & 7), yt = rem >> 3;                  // XCD = id % 8 = xt % 8
@@ -229,56 +257,60 @@ SGX_KERNEL_OCC(256, (OCB * PXB <= 4 ? 4 : (OCB * PXB <= 6 ? 3 : 2))) k_conv_pw2(
 #ifndef SGX_EMU
     const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int g0 = (xt * 4 + wave) * (32 * PXB);
-    // lanes past the end of the pixel axis (and rows past outc / k past inc) work on clamped addresses: finite values that meet zero
+    // Addressing: every global access is (wave-uniform base: channel row / weight row) + (32-bit per-lane byte offset: image, pixel, k parity),
+    // i.e. scalar-base + vector-offset loads/stores with no per-access address arithmetic (host guarantees blobs < 4 GB and an even `inc`).
+    // Lanes past the end of the pixel axis (and rows past outc, k past inc) work on clamped addresses: finite values that meet zero
     // weights or are never stored.  No divergent control flow anywhere in the main loop.
-    const float *px[PXB];
+    unsigned ioff4[PXB], ooff4[PXB], toff4[PXB];
 #pragma unroll
     for (int m = 0; m < PXB; m++) {
-        const unsigned gg = (unsigned)min(g0 + 32 * m + l31, total - 1), b = gg / (unsigned)N, n = gg - b * (unsigned)N;
-        px[m] = in + (size_t)b * in_pitch + n;
+        const unsigned gg = (unsigned)min(g0 + 32 * m + l31, total - 1), b = gg / (unsigned)N, n = gg - b * (unsigned)N, hn = n + (unsigned)half * (unsigned)N;
+        ioff4[m] = (b * (unsigned)in_pitch + hn) * 4u; ooff4[m] = (b * (unsigned)out_pitch + hn) * 4u; toff4[m] = (b * (unsigned)epi.tpitch + hn) * 4u;
     }
     constexpr int D = OCB * PXB >= 4 ? 4 : (OCB * PXB == 2 ? 8 : 16);   // B-operand prefetch ring: D k-steps (of 2 input channels) ahead of the MFMAs, ~1000+ MFMA cycles
     constexpr int WR = SGX_PW2_KC * OCT / 256;             // weight-chunk elements per thread
     float bq[D][PXB];
 #pragma unroll
-    for (int d = 0; d < D; d++)
+    for (int d = 0; d < D; d++) {
+        const float *rowp = (const float *)((const char *)in + (unsigned)min(2 * d, inc - 2) * (unsigned)N * 4u);
 #pragma unroll
-        for (int m = 0; m < PXB; m++) bq[d][m] = px[m][(size_t)min(2 * d + half, inc - 1) * N];
-    float wr[WR];
-#pragma unroll
-    for (int i = 0; i < WR; i++) {
-        const int t = tid + 256 * i, kk = t / OCT, oc = t - kk * OCT;
-        wr[i] = (kk < inc && oc0 + oc < outc) ? WtT[(size_t)kk * outc + oc0 + oc] : 0.f;
+        for (int m = 0; m < PXB; m++) bq[d][m] = sgx_ldoff(rowp, ioff4[m]);
     }
+    // weights: host-padded with zeros to [ceil32(inc)][ldw] (ldw >= any oc block end), so chunk loads are unconditional: uniform base + lane offset
+    float wr[WR]; unsigned woff4[WR];
+#pragma unroll
+    for (int i = 0; i < WR; i++) { const int t = tid + 256 * i, kk = t / OCT, oc = t - kk * OCT; woff4[i] = (unsigned)(kk * ldw + oc) * 4u; }
+#pragma unroll
+    for (int i = 0; i < WR; i++) wr[i] = sgx_ldoff(WtT + oc0, woff4[i]);
 #pragma unroll
     for (int i = 0; i < WR; i++) { const int t = tid + 256 * i, kk = t / OCT, oc = t - kk * OCT; Ws[0][kk][oc] = wr[i]; }
+    if (tid < OCT) Bs[tid] = bias[min(oc0 + tid, outc - 1)];
+    __syncthreads();
     sgx_f32x16 acc[OCB][PXB];
 #pragma unroll
     for (int t = 0; t < OCB; t++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const float bz = bias[min(oc0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half, outc - 1)];
+            const float bz = Bs[32 * t + (r & 3) + 8 * (r >> 2) + 4 * half];
 #pragma unroll
             for (int m = 0; m < PXB; m++) acc[t][m][r] = bz;
         }
-    __syncthreads();
     int buf = 0;
     for (int k0 = 0; k0 < inc; k0 += SGX_PW2_KC, buf ^= 1) {
         const bool more = k0 + SGX_PW2_KC < inc;
         if (more) {                                        // next weight chunk: global -> registers now, -> LDS after this chunk's MFMAs
+            const float *wb = WtT + (size_t)(k0 + SGX_PW2_KC) * ldw + oc0;
 #pragma unroll
-            for (int i = 0; i < WR; i++) {
-                const int t = tid + 256 * i, kk = k0 + SGX_PW2_KC + t / OCT, oc = t % OCT;
-                wr[i] = (kk < inc && oc0 + oc < outc) ? WtT[(size_t)kk * outc + oc0 + oc] : 0.f;
-            }
+            for (int i = 0; i < WR; i++) wr[i] = sgx_ldoff(wb, woff4[i]);
         }
         const int kend = min(SGX_PW2_KC, inc - k0);
         for (int kk = 0; kk < kend; kk += 2 * D) {
 #pragma unroll
             for (int d = 0; d < D; d++) {
                 float bv[PXB];
+                const float *rowp = (const float *)((const char *)in + (unsigned)min(k0 + kk + 2 * (d + D), inc - 2) * (unsigned)N * 4u);   // wave-uniform row base
 #pragma unroll
-                for (int m = 0; m < PXB; m++) { bv[m] = bq[d][m]; bq[d][m] = px[m][(size_t)min(k0 + kk + 2 * (d + D) + half, inc - 1) * N]; }
+                for (int m = 0; m < PXB; m++) { bv[m] = bq[d][m]; bq[d][m] = sgx_ldoff(rowp, ioff4[m]); }
                 if (kk + 2 * d < kend) {                     // (uniform) rows past the end of the chunk hold zero weights: skip their MFMAs
 #pragma unroll
                     for (int t = 0; t < OCB; t++) {
@@ -299,39 +331,45 @@ SGX_KERNEL_OCC(256, (OCB * PXB <= 4 ? 4 : (OCB * PXB <= 6 ? 3 : 2))) k_conv_pw2(
     // (64 inlined copies of it cost hundreds of VGPRs), and the read-back order is chosen per store layout so stores stay contiguous
     // (CHW: lanes along pixels; HWC: lanes along channels).
     float (*E)[33] = Es[wave];
-#pragma unroll
-    for (int m = 0; m < PXB; m++)
-#pragma unroll
-        for (int t = 0; t < OCB; t++) {
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < 16; r++) E[(r & 3) + 8 * (r >> 2) + 4 * half][l31] = acc[t][m][r];
-            __syncthreads();
-            const int gt = g0 + 32 * m, rt = oc0 + 32 * t;
-            if (!hwc) {
-                const int g = gt + l31;
-                const unsigned gg = (unsigned)min(g, total - 1), b = gg / (unsigned)N, n = gg - b * (unsigned)N;
-                float *Y = out + (size_t)b * out_pitch + n + (size_t)(rt + half) * N;
-                size_t tb = (size_t)b * epi.tpitch + n + (size_t)(rt + half) * N;
-                const int nj = g < total ? min(16, (outc - rt - half + 1) / 2) : 0;          // rows rt + half + 2j < outc
-#pragma unroll 4
-                for (int j = 0; j < nj; j++) {
-                    *Y = sgx_epi(epi, E[2 * j + half][l31], tb);
-                    Y += 2 * (size_t)N; tb += 2 * (size_t)N;
-                }
-            } else {
-                const int row = rt + l31;
 #pragma unroll 1
-                for (int j = 0; j < 16; j++) {
-                    const int cc = 2 * j + half, g = gt + cc;
-                    const unsigned gg = (unsigned)min(g, total - 1), b = gg / (unsigned)N, n = gg - b * (unsigned)N;
-                    if (g < total && row < outc)
-                        out[(size_t)b * out_pitch + (size_t)hwc_off + (size_t)n * outc + row] = sgx_epi(epi, E[l31][cc], (size_t)b * epi.tpitch + (size_t)row * N + n);
-                }
+    for (int tile = 0; tile < OCB * PXB; tile++) {
+        const int m = tile / OCB, t = tile - m * OCB;
+        __syncthreads();
+#pragma unroll
+        for (int tt = 0; tt < OCB * PXB; tt++)
+            if (tt == tile) {                                // static register indices, one uniform branch per tile
+#pragma unroll
+                for (int r = 0; r < 16; r++) E[(r & 3) + 8 * (r >> 2) + 4 * half][l31] = acc[tt % OCB][tt / OCB][r];
+            }
+        __syncthreads();
+        unsigned oo = ooff4[0], to = toff4[0];
+#pragma unroll
+        for (int q = 1; q < PXB; q++) if (m == q) { oo = ooff4[q]; to = toff4[q]; }
+        const int gt = g0 + 32 * m, rt = oc0 + 32 * t;
+        if (!hwc) {
+            const int nj = gt + l31 < total ? min(16, (outc - rt - half + 1) / 2) : 0;              // rows rt + half + 2j < outc
+            switch (epi.mode) {
+            case SGX_EMODE_NONE: sgx_pw2_readback<SGX_EMODE_NONE>(epi, E, nj, rt, N, half, l31, out, oo, to); break;
+            case SGX_EMODE_ACT: sgx_pw2_readback<SGX_EMODE_ACT>(epi, E, nj, rt, N, half, l31, out, oo, to); break;
+            case SGX_EMODE_HSWISH: sgx_pw2_readback<SGX_EMODE_HSWISH>(epi, E, nj, rt, N, half, l31, out, oo, to); break;
+            case SGX_EMODE_GATE: sgx_pw2_readback<SGX_EMODE_GATE>(epi, E, nj, rt, N, half, l31, out, oo, to); break;
+            case SGX_EMODE_GATE_ADD: sgx_pw2_readback<SGX_EMODE_GATE_ADD>(epi, E, nj, rt, N, half, l31, out, oo, to); break;
+            case SGX_EMODE_ADD_T: sgx_pw2_readback<SGX_EMODE_ADD_T>(epi, E, nj, rt, N, half, l31, out, oo, to); break;
+            default: sgx_pw2_readback<SGX_EMODE_GENERIC>(epi, E, nj, rt, N, half, l31, out, oo, to); break;
+            }
+        } else {
+            const int row = rt + l31;
+#pragma unroll 1
+            for (int j = 0; j < 16; j++) {
+                const int cc = 2 * j + half, g = gt + cc;
+                const unsigned gg = (unsigned)min(g, total - 1), b = gg / (unsigned)N, n = gg - b * (unsigned)N;
+                if (g < total && row < outc)
+                    out[(size_t)b * out_pitch + (size_t)hwc_off + (size_t)n * outc + row] = sgx_epi(epi, E[l31][cc], (size_t)b * epi.tpitch + (size_t)row * N + n, 0);
             }
         }
+    }
 #else
-    (void)Ws; (void)Es;
+    (void)Ws; (void)Es; (void)Bs;
     SGX_THREADS_BEGIN(tid)
     for (int t = tid; t < OCT * 128 * PXB; t += 256) {
         const int row = oc0 + t / (128 * PXB), g = xt * 128 * PXB + t % (128 * PXB);
@@ -339,7 +377,7 @@ SGX_KERNEL_OCC(256, (OCB * PXB <= 4 ? 4 : (OCB * PXB <= 6 ? 3 : 2))) k_conv_pw2(
             const int b = g / N, n = g - b * N;
             const float *X = in + (size_t)b * in_pitch;
             float s = bias[row];
-            for (int k = 0; k < inc; k++) s = fmaf(WtT[(size_t)k * outc + row], X[(size_t)k * N + n], s);
+            for (int k = 0; k < inc; k++) s = fmaf(WtT[(size_t)k * ldw + row], X[(size_t)k * N + n], s);
             const float v = sgx_epi(epi, s, (size_t)b * epi.tpitch + (size_t)row * N + n);
             float *Y = out + (size_t)b * out_pitch;
             if (hwc) Y[(size_t)hwc_off + (size_t)n * outc + row] = v; else Y[(size_t)row * N + n] = v;
@@ -360,7 +398,7 @@ SGX_KERNEL_OCC(256, (OCB * PXB <= 4 ? 4 : (OCB * PXB <= 6 ? 3 : 2))) k_conv_pw2(
 // ---------------------------------------------------------------------------------------------
 template <int K>
 SGX_KERNEL(256) k_conv_dw(int C, int H, int W, int Ho, int Wo, int stride, int pad, int P, int RB, int nbands, int nplanes,
-                          unsigned wp_magic, unsigned wo_magic, const float *in, const float *Wt, const float *bias, float *out, SgxEpi epi)
+                          unsigned per_magic, unsigned wp_magic, unsigned wo_magic, const float *in, const float *Wt, const float *bias, float *out, SgxEpi epi)
 {
     SGX_DYN_LDS(smem);
     float *tile = (float *)smem;
@@ -370,14 +408,23 @@ SGX_KERNEL(256) k_conv_dw(int C, int H, int W, int Ho, int Wo, int stride, int p
     const int Wp = (Wo - 1) * stride + K, Rin = (nrows - 1) * stride + K, iy0 = r0 * stride - pad;
     float *wl = tile + (size_t)P * ((RB - 1) * stride + K) * Wp;          // [P][K*K] weights + [P] bias
     SGX_THREADS_BEGIN(tid)
-    const int per = Rin * Wp;
-    for (int q = 0; q < np; q++) {
-        const float *src = in + (size_t)(p0 + q) * H * W;
-        for (int t = tid; t < per; t += 256) {
-            const int ry = (int)sgx_fastdiv((unsigned)t, wp_magic), cx = t - ry * Wp;
+    // staging: linear index over the P padded bands, 8 independent loads in flight per thread before the LDS stores (latency, not
+    // instruction count, bounds this phase); consecutive threads -> consecutive x: coalesced row segments
+    const int per = Rin * Wp, tot = np * per;
+    for (int t0 = tid; t0 < tot; t0 += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int t = min(t0 + 256 * u, tot - 1);
+            const int q = P == 1 ? 0 : (int)sgx_fastdiv((unsigned)t, per_magic), r = t - q * per;
+            const int ry = (int)sgx_fastdiv((unsigned)r, wp_magic), cx = r - ry * Wp;
             const int iy = iy0 + ry, ix = cx - pad;
-            tile[q * per + t] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? src[(size_t)iy * W + ix] : 0.f;
+            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            v[u] = in[((size_t)(p0 + q) * H + (ok ? iy : 0)) * W + (ok ? ix : 0)];
+            v[u] = ok ? v[u] : 0.f;
         }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int t = t0 + 256 * u; if (t < tot) tile[t] = v[u]; }
     }
     for (int t = tid; t < np * (K * K + 1); t += 256) {
         const int q = t / (K * K + 1), j = t - q * (K * K + 1), c = (p0 + q) % C;
@@ -415,21 +462,29 @@ SGX_KERNEL(256) k_conv_dw(int C, int H, int W, int Ho, int Wo, int stride, int p
 // host-transposed table WtT[(c*K*K + i*K + j)][16].  Accumulation order per output: c, i, j ascending (as k_conv_kxk).
 // grid = (nbands, B)
 // ---------------------------------------------------------------------------------------------
-SGX_KERNEL(256) k_conv_stem(int inc, int outc, int H, int W, int Ho, int Wo, int K, int stride, int pad, int RB, unsigned wp_magic, unsigned wo_magic,
+SGX_KERNEL(256) k_conv_stem(int inc, int outc, int H, int W, int Ho, int Wo, int K, int stride, int pad, int RB, unsigned per_magic, unsigned wp_magic, unsigned wo_magic,
                             const float *in, size_t in_pitch, const float *WtT, const float *bias, float *out, size_t out_pitch, SgxEpi epi)
 {
     SGX_DYN_LDS(smem);
     float *tile = (float *)smem;
     const int b = (int)blockIdx.y, r0 = (int)blockIdx.x * RB, nrows = min(RB, Ho - r0);
-    const int Wp = (Wo - 1) * stride + K, Rin = (nrows - 1) * stride + K, iy0 = r0 * stride - pad, per = Rin * Wp;
+    const int Wp = (Wo - 1) * stride + K, iy0 = r0 * stride - pad, per = ((RB - 1) * stride + K) * Wp;      // full-band plane stride in LDS (also for the last, shorter band)
     SGX_THREADS_BEGIN(tid)
-    for (int c = 0; c < inc; c++) {
-        const float *src = in + (size_t)b * in_pitch + (size_t)c * H * W;
-        for (int t = tid; t < per; t += 256) {
-            const int ry = (int)sgx_fastdiv((unsigned)t, wp_magic), cx = t - ry * Wp;
+    const int tot = inc * per;
+    for (int t0 = tid; t0 < tot; t0 += 256 * 8) {              // 8 independent loads in flight per thread, as k_conv_dw
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int t = min(t0 + 256 * u, tot - 1);
+            const int c = (int)sgx_fastdiv((unsigned)t, per_magic), r = t - c * per;
+            const int ry = (int)sgx_fastdiv((unsigned)r, wp_magic), cx = r - ry * Wp;
             const int iy = iy0 + ry, ix = cx - pad;
-            tile[c * per + t] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? src[(size_t)iy * W + ix] : 0.f;
+            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            v[u] = in[(size_t)b * in_pitch + ((size_t)c * H + (ok ? iy : 0)) * W + (ok ? ix : 0)];
+            v[u] = ok ? v[u] : 0.f;
         }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int t = t0 + 256 * u; if (t < tot) tile[t] = v[u]; }
     }
     SGX_THREADS_END
     SGX_SYNC();

@@ -15,7 +15,8 @@ lib = sg_slam_amd.load()
 layers = D.parse_param(PARAM); W, blob = D.synth_weights(layers)
 det = Detector2D(0.9, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=B, lib=lib)
 img = torch.randint(0, 256, (B, 480, 640, 3), dtype=torch.uint8, device='cuda')
-rows = det.time_ops(img, B, reps=10)
+REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+rows = det.time_ops(img, B, reps=REPS)
 tot = sum(ms for _, ms in rows); troof = 0.0
 print(f'detector plan, batch {B}: {len(rows)} launches, sum of per-launch times {tot:.3f} ms  ({B / tot * 1e3:.0f} frames/s)')
 print(f'{"ms":>8} {"roof_ms":>8} {"frac":>6}  step')
