@@ -42,6 +42,7 @@ def algorithmic_bytes_per_frame(nkp=1000, ncand=6000, nmatch=600):
         'pose_opt': nkp * (28 + 4 + 4) + nmatch * 12 + nkp + 64,   # keypoints, uright, match index, matched map points, outlier flags, pose
         'unproject': nkp * (28 + 4 + 12 + 1),
         'match_project_local': nkp * (28 + 32 + 4 + 4) + 2 * nkp * (12 + 12 + 4 + 4 + 32 + 4 + 1) + nkp * 4 + 2 * nkp,   # cur kp/desc/uright/obs, 2 frames of map points, match + in_view out
+        'dynamic_mask': nkp * (28 + 8 + 1) / 2 + nkp * (1 + 2 * (28 + 32)) / 2,      # per launch: mask (keypoint + prev point in, flag out) | compaction (records in and out)
         'map_point_glue': nkp * (28 + 12 + 1 + 32 + 12 + 12 + 8 + 32 + 1) / 4 + nkp * (4 + 1 + 4 + 4 + 4) / 2 + 3 * nkp * 24 / 4,   # per launch: make_map_points | merge (x2) | gather
     }
 
@@ -60,6 +61,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-pipeline', action='store_true', help='single HIP stream (no overlap of extraction with match/pose-opt)')
     ap.add_argument('--no-local-map', action='store_true', help='skip the TrackLocalMap stage (local-map SearchByProjection + second PoseOptimization)')
+    ap.add_argument('--no-mask', action='store_true', help='skip the dynamic-feature mask + erase stage (Frame::RmDynamicPointWithSemanticAndGeometry)')
     ap.add_argument('--cpu-sample', type=int, default=100, help='frames timed on the CPU oracle')
     args = ap.parse_args()
 
@@ -101,8 +103,26 @@ def main():
     tr.set_initial_pose(np.stack([gen.Tcw(t0) for t0 in t0s]))
     stream = torch.cuda.current_stream().cuda_stream
 
+    # Inputs of the dynamic-feature mask.  The reference obtains them on the host (LK flow + RANSAC F, Frame.cc:445-472; person boxes from
+    # Detector2D): here they come from the synthetic ground truth (synth.flow_affine / synth.fundamental), with one "person" box per stream whose
+    # content moves 6 px across the epipolar lines, so the erase path does real work (~8 % of the keypoints go).
+    masks = {}
+    if not args.no_mask:
+        boxes = torch.zeros((S, tr.max_boxes, 4), dtype=torch.float32, device='cuda'); boxes[:, 0] = torch.tensor([200.0, 120.0, 160.0, 240.0])
+        nboxes = torch.ones((S,), dtype=torch.int32, device='cuda'); have_dyn = torch.ones((S,), dtype=torch.int32, device='cuda')
+        for i in range(1, len(order) + 1):
+            a, b = order[(i - 1) % len(order)], order[i % len(order)]
+            if (a, b) in masks: continue
+            A = np.stack([synth.flow_affine(gen, t0 + b, t0 + a).reshape(6) for t0 in t0s]).astype('f4')
+            F = np.stack([synth.fundamental(gen, t0 + b, t0 + a).reshape(9) for t0 in t0s])
+            d = np.stack([A[:, 0] * 280 + A[:, 1] * 240 + A[:, 2] - 280, A[:, 3] * 280 + A[:, 4] * 240 + A[:, 5] - 240], 1)
+            sh = 6.0 * np.stack([-d[:, 1], d[:, 0]], 1) / np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-9)
+            masks[(a, b)] = dict(A=torch.from_numpy(A).cuda(), F=torch.from_numpy(F).cuda(), boxes=boxes, nboxes=nboxes, have_dynamic=have_dyn,
+                                 shift=torch.from_numpy(sh.astype('f4')).cuda())
+
     def step(i):
-        tr.step(d_frames[order[i % len(order)]], d_depth, stream=stream)
+        m = masks.get((order[(i - 1) % len(order)], order[i % len(order)])) if (i > 0 and masks) else None
+        tr.step(d_frames[order[i % len(order)]], d_depth, stream=stream, mask=m)
 
     for i in range(args.warmup):
         step(i)
@@ -126,6 +146,7 @@ def main():
     tr.ex.last_status(stream=stream)
     nkp, nmatch, ninl = tr.last_counts()
     nmatch_local, ninl2 = tr.last_local_counts()
+    n_raw = tr.rn.cpu().numpy() if not args.no_mask else nkp
     if not args.no_local_map:
         ninl = ninl2
     poses = tr.last_pose()
@@ -151,7 +172,7 @@ def main():
     frames_total = S * args.steps * world
     fps = frames_total / dt
 
-    alg = algorithmic_bytes_per_frame(nkp=int(round(float(nkp.mean()))), nmatch=int(round(float(nmatch.mean()))))
+    alg = algorithmic_bytes_per_frame(nkp=int(round(float(n_raw.mean()))), nmatch=int(round(float(nmatch.mean()))))
     per_kernel = {}
     for k, (ms, n) in prof.items():
         if n == 0: continue
@@ -228,12 +249,12 @@ def main():
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
         'config': {'workload': 'Single MI355X: ORB extract+match HIP kernels, 640x480 synthetic stream, 1000 feats/frame',
-                   'stages': ['orb_extract', 'stereo_from_rgbd', 'motion_model', 'search_by_projection(cur,last)', 'pose_optimization'] +
+                   'stages': ['orb_extract'] + ([] if args.no_mask else ['dynamic_mask+erase (LK/F inputs from synthetic ground truth)']) + ['stereo_from_rgbd', 'motion_model', 'search_by_projection(cur,last)', 'pose_optimization'] +
                              ([] if args.no_local_map else ['search_by_projection(cur,local_map th=3)', 'pose_optimization#2']) + ['unproject'] +
                              ([] if args.no_local_map else ['make_map_points']),
                    'local_map_points': 0 if args.no_local_map else 2 * tr.cap, 'mean_local_map_matches': None if args.no_local_map else float(nmatch_local.mean()),
                    'streams_per_gpu': S, 'frames_per_step': S, 'distinct_frames_per_stream': T,
-                   'mean_keypoints': float(nkp.mean()), 'mean_matches': float(nmatch.mean()), 'mean_inliers': float(ninl.mean()),
+                   'mean_keypoints': float(nkp.mean()), 'mean_keypoints_before_mask': float(n_raw.mean()), 'mean_matches': float(nmatch.mean()), 'mean_inliers': float(ninl.mean()),
                    'tracked_streams_last_frame': tracked, 'ate_rmse_m_vs_synthetic_gt': ate_rmse,
                    'nfeatures': 1000, 'nlevels': 8, 'scale_factor': 1.2, 'parallelism': f'streams-sharded x{world}', 'hip_streams': 1 if args.no_pipeline else 2,
                    'pose_dtype': 'f64 LM, f32 boundary'},

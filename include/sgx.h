@@ -238,6 +238,11 @@ int sgx_det_debug_op_desc(const sgx_det *h, int i, char *buf, int cap);
  * "restore everything when fewer than 0.1*nFeatures survive" rule (:599-604) and compacts keypoints + descriptor rows. */
 int sgx_dynamic_mask_batch_dev(int batch, int cap, const sgx_keypoint *d_keys, const int32_t *d_n, const float *d_prev_xy, const double *d_F,
                                const float *d_boxes, const int32_t *d_nboxes, int max_boxes, uint8_t *d_keep, void *stream);
+/* The erase step that follows the mask (Frame.cc:556-604): keypoints with keep == 0 and their descriptor rows are removed, order preserved;
+ * when have_dynamic[f] != 0 (a person box with prob > 0.2 exists, Detector2D.cc:80-84) and fewer than 0.1 * nfeatures keypoints survive, all
+ * keypoints of the frame are restored (:599-604).  Out of place; d_have_dynamic may be NULL (no dynamic object in any frame). */
+int sgx_frame_compact_keys_batch_dev(int batch, int cap, const sgx_keypoint *d_keys, const uint8_t *d_desc, const int32_t *d_n, const uint8_t *d_keep,
+                                     const int32_t *d_have_dynamic, int nfeatures, sgx_keypoint *d_keys_out, uint8_t *d_desc_out, int32_t *d_n_out, void *stream);
 
 /* run the octree-distribution kernel alone on packed candidates (x | y<<12 | score<<24, coordinates
  * relative to the (16,16) border origin) for `level`; returns the selected packed entries in list order */

@@ -1,6 +1,7 @@
 // sgx_det.cpp — host side of the 2-D detector C-ABI: ncnn .param/.bin loader, shape inference, execution plan
 // (with conv+activation and Permute/Flatten/Concat fusion), batched forward, DetectionOutput + Detector2D::detect
 // post-processing, dynamic-feature mask.  Reference: src/sg-slam/src/Detector2D.cc:16-89, src/sg-slam/src/Frame.cc:556-604.
+#include "sgx_block.h"
 #include "sgx_det_kernels.h"
 #include "sgx_prof.h"
 #include "../../include/sgx.h"
@@ -573,7 +574,21 @@ extern "C" int sgx_dynamic_mask_batch_dev(int batch, int cap, const sgx_keypoint
                                           const float *d_boxes, const int32_t *d_nboxes, int max_boxes, uint8_t *d_keep, void *stream)
 {
     if (batch < 1 || cap < 1 || !d_keys || !d_n || !d_prev_xy || !d_F || !d_boxes || !d_nboxes || !d_keep || max_boxes < 0) return SGX_ERR_INVALID;
+    sgx_prof_begin(SGX_K_MASK, (sgx_stream_t)stream);
     SGX_LAUNCH(k_dynamic_mask, dim3((cap + 255) / 256, batch), dim3(256), (sgx_stream_t)stream, cap, (const uint8_t *)d_keys, d_n, d_prev_xy, d_F, d_boxes, d_nboxes, max_boxes, d_keep);
+    sgx_prof_end(SGX_K_MASK, (sgx_stream_t)stream);
+    SGX_CHECK_HIP(hipGetLastError());
+    return SGX_OK;
+}
+
+extern "C" int sgx_frame_compact_keys_batch_dev(int batch, int cap, const sgx_keypoint *d_keys, const uint8_t *d_desc, const int32_t *d_n, const uint8_t *d_keep,
+                                                const int32_t *d_have_dynamic, int nfeatures, sgx_keypoint *d_keys_out, uint8_t *d_desc_out, int32_t *d_n_out, void *stream)
+{
+    if (batch < 1 || cap < 1 || !d_keys || !d_desc || !d_n || !d_keep || !d_keys_out || !d_desc_out || !d_n_out || (const void *)d_keys == (const void *)d_keys_out) return SGX_ERR_INVALID;
+    sgx_prof_begin(SGX_K_MASK, (sgx_stream_t)stream);
+    SGX_LAUNCH(k_compact_keys, dim3(batch), dim3(256), (sgx_stream_t)stream, cap, (const uint8_t *)d_keys, d_desc, d_n, d_keep, d_have_dynamic, (float)nfeatures * 0.1f,
+               (uint8_t *)d_keys_out, d_desc_out, d_n_out);
+    sgx_prof_end(SGX_K_MASK, (sgx_stream_t)stream);
     SGX_CHECK_HIP(hipGetLastError());
     return SGX_OK;
 }

@@ -601,3 +601,42 @@ SGX_KERNEL(256) k_dynamic_mask(int cap, const uint8_t *keys_raw, const int *n, c
     }
     SGX_THREADS_END
 }
+
+// ---------------------------------------------------------------------------------------------
+// k_compact_keys: the erase step of Frame::RmDynamicPointWithSemanticAndGeometry (Frame.cc:556-604): keypoints with keep == 0 and their
+// descriptor rows are removed, order preserved (the reference erases from mvKeys / rebuilds mDescriptors row by row); when a dynamic
+// object is present and fewer than 0.1 * nFeatures keypoints survive, everything is restored (:599-604).  One workgroup per frame:
+// block scan of the keep flags, then each record (28 B keypoint + 32 B descriptor) moves as dwords.  Out of place.
+// ---------------------------------------------------------------------------------------------
+SGX_KERNEL(256) k_compact_keys(int cap, const uint8_t *keys, const uint8_t *desc, const int *n, const uint8_t *keep, const int *have_dynamic, float restore_below,
+                               uint8_t *keys_out, uint8_t *desc_out, int *n_out)
+{
+    SGX_LDS int scan[256];
+    SGX_LDS int s_total;
+    const int f = (int)blockIdx.x, N = min(n[f], cap), CH = (N + 255) / 256;
+    SGX_THREADS_BEGIN(tid)
+    int c = 0;
+    for (int i = tid * CH; i < min(N, (tid + 1) * CH); i++) c += keep[(size_t)f * cap + i] ? 1 : 0;
+    scan[tid] = c;
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    sgx_block_exclusive_scan_i32(scan, 256, &s_total, tid);
+    SGX_THREADS_END
+    SGX_SYNC();
+    const bool restore = (have_dynamic && have_dynamic[f]) && (float)s_total < restore_below;       // Cur_keypoint_sum < GetnFeatures()*0.1 (int vs float compare)
+    SGX_THREADS_BEGIN(tid)
+    int pos = restore ? tid * CH : scan[tid];
+    for (int i = tid * CH; i < min(N, (tid + 1) * CH); i++) {
+        if (!restore && !keep[(size_t)f * cap + i]) continue;
+        const uint32_t *ks = (const uint32_t *)(keys + ((size_t)f * cap + i) * 28), *ds = (const uint32_t *)(desc + ((size_t)f * cap + i) * 32);
+        uint32_t *kd = (uint32_t *)(keys_out + ((size_t)f * cap + pos) * 28), *dd = (uint32_t *)(desc_out + ((size_t)f * cap + pos) * 32);
+#pragma unroll
+        for (int w = 0; w < 7; w++) kd[w] = ks[w];
+#pragma unroll
+        for (int w = 0; w < 8; w++) dd[w] = ds[w];
+        pos++;
+    }
+    if (tid == 0) n_out[f] = restore ? N : s_total;
+    SGX_THREADS_END
+}

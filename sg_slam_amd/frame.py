@@ -34,3 +34,10 @@ def merge_matches_batch(lib, batch, cap, d_n, d_match_last, d_outlier_last, d_ma
     lib.check(lib.dll.sgx_frame_merge_matches_batch_dev(batch, cap, _vp(d_n), _vp(d_match_last), _vp(d_outlier_last), _vp(d_match_local), _vp(d_xw_last),
                                                         _vp(d_m_xw), _vp(d_merged), _vp(d_cur_mp_obs), _vp(d_xw_all), _vp(stream)),
               'sgx_frame_merge_matches_batch_dev')
+
+
+def compact_keys_batch(lib, batch, cap, d_keys, d_desc, d_n, d_keep, d_have_dynamic, nfeatures, d_keys_out, d_desc_out, d_n_out, stream=None):
+    """The erase step of Frame::RmDynamicPointWithSemanticAndGeometry (Frame.cc:556-604): order-preserving removal of masked keypoints and
+    their descriptor rows, with the "restore all when < 0.1*nFeatures survive and a dynamic object is present" rule."""
+    lib.check(lib.dll.sgx_frame_compact_keys_batch_dev(batch, cap, _vp(d_keys), _vp(d_desc), _vp(d_n), _vp(d_keep), _vp(d_have_dynamic), int(nfeatures),
+                                                       _vp(d_keys_out), _vp(d_desc_out), _vp(d_n_out), _vp(stream)), 'sgx_frame_compact_keys_batch_dev')

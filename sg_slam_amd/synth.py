@@ -98,6 +98,36 @@ class PlaneStream:
         return gray, depth, self.Tcw(t)
 
 
+def _texel_map(stream, t):
+    """3x3 homogeneous map pixel (u, v) of frame t -> texel of the world texture (the float form of PlaneStream.frame's Q16 warp)."""
+    cam, z0, ts = stream.cam, stream.z0, stream.ts
+    fx, fy, cx, cy = cam['fx'], cam['fy'], cam['cx'], cam['cy']
+    cxm, cym, th = stream.pose(t)
+    c, s = math.cos(th), math.sin(th)
+    return np.array([[c, s * (fx / fy), ts / 2 + fx / z0 * cxm - c * cx - s * (fx / fy) * cy],
+                     [-s * (fy / fx), c, ts / 2 + fy / z0 * cym + s * (fy / fx) * cx - c * cy],
+                     [0.0, 0.0, 1.0]])
+
+
+def flow_affine(stream, t_cur, t_prev):
+    """2x3 affine map: pixel of frame t_cur -> pixel of the same scene point in frame t_prev.  Stands in for cv::calcOpticalFlowPyrLK
+    (Frame.cc:445, SURVEY.md §8(f) N1: not built) when the dynamic-feature mask is exercised on synthetic streams."""
+    M = np.linalg.inv(_texel_map(stream, t_prev)) @ _texel_map(stream, t_cur)
+    return M[:2, :]
+
+
+def fundamental(stream, t_cur, t_prev):
+    """3x3 F with x_prev^T F x_cur = 0 from the ground-truth poses (stands in for cv::findFundamentalMat, Frame.cc:469-472)."""
+    cam = stream.cam
+    K = np.array([[cam['fx'], 0, cam['cx']], [0, cam['fy'], cam['cy']], [0, 0, 1.0]])
+    T = stream.Tcw(t_prev) @ np.linalg.inv(stream.Tcw(t_cur))              # X_prev = R X_cur + t
+    R, t = T[:3, :3], T[:3, 3]
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    F = np.linalg.inv(K).T @ tx @ R @ np.linalg.inv(K)
+    nrm = np.abs(F).max()
+    return F / nrm if nrm > 0 else F
+
+
 def constant_image(value=128, width=640, height=480):
     """Degenerate case: no corners anywhere -> 0 keypoints (ORBextractor.cc:1065-1066)."""
     return np.full((height, width), value, np.uint8)

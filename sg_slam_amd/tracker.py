@@ -2,6 +2,7 @@
 step, every stage device-resident and asynchronous on one HIP stream:
 
   ORBextractor::operator()          -> sgx_orb_extract_batch_dev           (ORBextractor.cc:1045-1106)
+  Frame::RmDynamicPoint... (mask)   -> sgx_dynamic_mask_batch_dev + sgx_frame_compact_keys_batch_dev (Frame.cc:556-604; LK / F are inputs)
   Frame::ComputeStereoFromRGBD      -> sgx_frame_stereo_from_rgbd_batch_dev (Frame.cc:893-914)
   constant-velocity prediction      -> sgx_frame_motion_model_batch_dev     (Tracking.cc:463-470, :914)
   ORBmatcher::SearchByProjection    -> sgx_match_project_frame_batch_dev    (ORBmatcher.cc:1332-1472, th=15)
@@ -65,6 +66,12 @@ class TrackerBatch:
         self.match_local = z((S, cap), 'i4'); self.nmatch_local = z((S,), 'i4'); self.in_view = z((S, 2 * cap), 'u1')
         self.merged = z((S, cap), 'i4'); self.cur_mp_obs = z((S, cap), 'i4'); self.xw_all = z((S, 3 * cap, 3), 'f4')
         self.outlier2 = z((S, cap), 'u1'); self.ninl2 = z((S,), 'i4')
+        # dynamic-feature mask stage (Frame::RmDynamicPointWithSemanticAndGeometry): raw extraction buffers, keep flags, previous positions
+        self.rkeys = z((S, cap, 28), 'u1'); self.rdesc = z((S, cap, 32), 'u1'); self.rn = z((S,), 'i4')
+        self.keep = z((S, cap), 'u1'); self.prev_xy = z((S, cap, 2), 'f4')
+        self.max_boxes = 8
+        self.no_boxes = z((S, self.max_boxes, 4), 'f4'); self.no_nboxes = z((S,), 'i4')
+        self.nfeatures = int(nfeatures)
         self.cur = 0
         self.frame_idx = 0
         # Two HIP streams: E = extraction (+stereo) of frame t+1 overlaps T = match / pose-opt / unproject of frame t.  The wide
@@ -94,9 +101,36 @@ class TrackerBatch:
             else:
                 b[...] = T
 
-    def step(self, d_gray, d_depth, stream=None, gray_pitch=None):
+    def _prev_points(self, keys_raw, A, shift=None, boxes=None):
+        """prev_xy[s, i] = A[s] * (x, y, 1) of keypoint i: the stand-in for the LK tracker on synthetic streams (see synth.flow_affine);
+        `shift` (S,2) moves the previous position of keypoints inside the first box of `boxes` (an independently moving object)."""
+        S, cap = self.S, self.cap
+        if self.xp == 'torch':
+            import torch
+            kf = keys_raw.view(torch.float32).view(S, cap, 7)
+            x, y = kf[..., 0], kf[..., 1]
+            px = A[:, 0:1] * x + A[:, 1:2] * y + A[:, 2:3]; py = A[:, 3:4] * x + A[:, 4:5] * y + A[:, 5:6]
+            if shift is not None:
+                bx = boxes[:, 0, :]
+                inside = (x > bx[:, 0:1]) & (x < bx[:, 0:1] + bx[:, 2:3]) & (y > bx[:, 1:2]) & (y < bx[:, 1:2] + bx[:, 3:4])
+                px = px + inside * shift[:, 0:1]; py = py + inside * shift[:, 1:2]
+            self.prev_xy.copy_(torch.stack([px, py], -1))
+        else:
+            kf = keys_raw.view(np.float32).reshape(S, cap, 7)
+            x, y = kf[..., 0], kf[..., 1]
+            px = A[:, 0:1] * x + A[:, 1:2] * y + A[:, 2:3]; py = A[:, 3:4] * x + A[:, 4:5] * y + A[:, 5:6]
+            if shift is not None:
+                bx = boxes[:, 0, :]
+                inside = (x > bx[:, 0:1]) & (x < bx[:, 0:1] + bx[:, 2:3]) & (y > bx[:, 1:2]) & (y < bx[:, 1:2] + bx[:, 3:4])
+                px = px + inside * shift[:, 0:1]; py = py + inside * shift[:, 1:2]
+            self.prev_xy[...] = np.stack([px, py], -1).astype(np.float32)
+
+    def step(self, d_gray, d_depth, stream=None, gray_pitch=None, mask=None):
         """Track the next frame of every stream.  d_gray: S x H x W u8, d_depth: S x H x W u16 (raw, DepthMapFactor 5000).
-        Asynchronous; with pipelined=True the extraction runs on its own stream (call synchronize() before reading results)."""
+        Asynchronous; with pipelined=True the extraction runs on its own stream (call synchronize() before reading results).
+        mask (optional, frames t > 0): dict with 'A' (S,6) f32 flow map and 'F' (S,9) f64 fundamental matrices [the LK / RANSAC outputs the
+        reference computes on the host, Frame.cc:445-472], optionally 'boxes' (S,max_boxes,4) f32, 'nboxes' (S,) i32, 'have_dynamic' (S,) i32
+        [Detector2D results] and 'shift' (S,2): runs the dynamic-feature mask + erase step between extraction and ComputeStereoFromRGBD."""
         L, S, cap, cam = self.lib, self.S, self.cap, self.cam
         t = self.frame_idx
         c, l = t % 3, (t - 1) % 3
@@ -112,7 +146,22 @@ class TrackerBatch:
             stE, stT = sE.cuda_stream, sT.cuda_stream
         else:
             stE = stT = stream
-        self.ex.extract_batch_dev(d_gray, gray_pitch or self.W, S, self.keys[c], self.desc[c], self.n[c], stream=stE)
+        use_mask = mask is not None and t > 0
+        if not use_mask:
+            self.ex.extract_batch_dev(d_gray, gray_pitch or self.W, S, self.keys[c], self.desc[c], self.n[c], stream=stE)
+        else:
+            self.ex.extract_batch_dev(d_gray, gray_pitch or self.W, S, self.rkeys, self.rdesc, self.rn, stream=stE)
+            boxes = mask.get('boxes', self.no_boxes); nboxes = mask.get('nboxes', self.no_nboxes)
+            if self.pipelined:
+                import torch
+                with torch.cuda.stream(self.sE):
+                    self._prev_points(self.rkeys, mask['A'], mask.get('shift'), boxes)
+            else:
+                self._prev_points(self.rkeys, mask['A'], mask.get('shift'), boxes)
+            L.check(L.dll.sgx_dynamic_mask_batch_dev(S, cap, _vp(self.rkeys), _vp(self.rn), _vp(self.prev_xy), _vp(mask['F']), _vp(boxes), _vp(nboxes),
+                                                     self.max_boxes, _vp(self.keep), _vp(stE)), 'dynamic mask')
+            L.check(L.dll.sgx_frame_compact_keys_batch_dev(S, cap, _vp(self.rkeys), _vp(self.rdesc), _vp(self.rn), _vp(self.keep), _vp(mask.get('have_dynamic')),
+                                                           self.nfeatures, _vp(self.keys[c]), _vp(self.desc[c]), _vp(self.n[c]), _vp(stE)), 'compact keys')
         L.check(L.dll.sgx_frame_stereo_from_rgbd_batch_dev(S, cap, _vp(self.keys[c]), _vp(self.n[c]), _vp(d_depth), self.W, self.H,
                                                            float(cam['depth_factor']), float(cam['bf']), _vp(self.uright[c]), _vp(self.zdepth[c]), _vp(stE)), 'stereo')
         if self.pipelined:

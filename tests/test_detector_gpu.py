@@ -22,3 +22,9 @@ def test_detector_gpu_fused_matches_oracle(gpulib, model):
 def test_detector_gpu_fused_equals_unfused(gpulib, model):
     from test_detector import run_fused_equals_unfused
     run_fused_equals_unfused(gpulib, model)
+
+
+def test_compact_gpu(gpulib):
+    import torch
+    from test_detector import run_compact
+    run_compact(gpulib, to_dev=lambda a: torch.from_numpy(a.view(np.uint8) if a.dtype.fields else a).cuda(), to_host=lambda t: t.cpu().numpy())

@@ -126,3 +126,57 @@ def run_tracker(lib, oracle, xp):
 
 def test_tracker_two_streams(emu, oracle):
     run_tracker(emu, oracle, 'numpy')
+
+
+def run_tracker_mask(lib, xp):
+    """Mask + erase stage inside the harness: LK / F stand-ins from the synthetic ground truth; an 'independently moving' box whose keypoints
+    must be erased; the rest survive (epipolar distance ~ 0) and tracking still follows the ground truth."""
+    S = synth.PlaneStream(seed=1234)
+    offs = [3, 57]
+    tr = TrackerBatch(lib, 2, CAM, xp=xp)
+    H = (lambda a: a.cpu().numpy()) if xp == 'torch' else (lambda a: a)
+    def D(a):
+        if xp != 'torch':
+            return a
+        import torch
+        return torch.from_numpy(a.view(np.int16) if a.dtype == np.uint16 else a).cuda()
+    tr.set_initial_pose(np.stack([S.Tcw(o) for o in offs]))
+    box = np.zeros((2, tr.max_boxes, 4), 'f4'); box[:, 0] = (200, 120, 160, 240)
+    for t in range(4):
+        fr = [S.frame(o + t) for o in offs]
+        gray = np.stack([f[0] for f in fr]); depth = np.stack([f[1] for f in fr])
+        m = None
+        if t > 0:
+            A = np.stack([synth.flow_affine(S, o + t, o + t - 1).reshape(6) for o in offs]).astype('f4')
+            F = np.stack([synth.fundamental(S, o + t, o + t - 1).reshape(9) for o in offs])
+            # the object moves ACROSS the epipolar lines (perpendicular to the camera-induced flow at the box centre), 6 px
+            sh = []
+            for a in A:
+                d = np.array([a[0] * 280 + a[1] * 240 + a[2] - 280, a[3] * 280 + a[4] * 240 + a[5] - 240])
+                sh.append(6.0 * np.array([-d[1], d[0]]) / np.linalg.norm(d))
+            m = dict(A=D(A), F=D(F), boxes=D(box), nboxes=D(np.array([1, 0], 'i4')), have_dynamic=D(np.array([1, 0], 'i4')),
+                     shift=D(np.array(sh, 'f4')))
+        tr.step(D(gray), D(depth), mask=m)
+        n, nm, ninl = tr.last_counts()
+        if t > 0:
+            rn, keep = H(tr.rn), H(tr.keep)
+            rk = H(tr.rkeys).view(np.float32).reshape(2, tr.cap, 7)
+            for s in range(2):
+                k = keep[s, :rn[s]].astype(bool)
+                x, y = rk[s, :rn[s], 0], rk[s, :rn[s], 1]
+                inside = (x > 200) & (x < 360) & (y > 120) & (y < 360)
+                if s == 0:          # stream 0 has the moving box: its keypoints are erased (0.2 px threshold, 5 px displacement), the others stay
+                    assert inside.sum() > 30 and k[inside].sum() == 0 and k[~inside].mean() > 0.97
+                else:               # stream 1: nboxes = 0 -> the shift is applied to prev_xy inside box 0 anyway, threshold 1.0 px -> erased as well
+                    assert k[~inside].mean() > 0.97
+                assert n[s] == k.sum()
+                kc = H(tr.keys[tr.cur]).reshape(2, tr.cap, 28); rb = H(tr.rkeys).reshape(2, tr.cap, 28)       # bytes (class_id = -1 is a NaN pattern as float)
+                assert (kc[s, :n[s]] == rb[s, :rn[s]][k]).all()
+                assert (H(tr.desc[tr.cur])[s, :n[s]] == H(tr.rdesc)[s, :rn[s]][k]).all()
+            Tg = tr.last_pose()
+            for s in range(2):
+                assert np.abs(Tg[s] - S.Tcw(offs[s] + t)).max() < 0.02 and ninl[s] > 120
+
+
+def test_tracker_mask_emu(emu):
+    run_tracker_mask(emu, 'numpy')
