@@ -78,6 +78,7 @@ int sgx_orb_last_status(sgx_orb *h, void *stream);
 
 /* test/diagnostic taps (synchronous, host destination) */
 int sgx_orb_debug_level_geometry(const sgx_orb *h, int level, int32_t *w, int32_t *hgt, int32_t *stride);
+int sgx_orb_debug_set_unfused_pyramid(int on);   /* test tap: 1 = per-level k_resize launches instead of the fused pyramid kernel (must give identical bytes) */
 int sgx_orb_debug_read_level(sgx_orb *h, int frame, int level, uint8_t *dst /* w*h, tight */);
 /* candidates of (frame, level) after per-cell FAST+NMS, unordered: x,y relative to the
  * (16,16) border origin exactly as pushed at ORBextractor.cc:823-825; returns count in *n */

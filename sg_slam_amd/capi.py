@@ -53,7 +53,7 @@ SYMBOLS = [
     'sgx_version', 'sgx_status_string',
     'sgx_orb_create', 'sgx_orb_destroy', 'sgx_orb_keypoint_capacity', 'sgx_orb_get_tables',
     'sgx_orb_extract_batch_dev', 'sgx_orb_extract', 'sgx_orb_last_status',
-    'sgx_orb_debug_level_geometry', 'sgx_orb_debug_read_level', 'sgx_orb_debug_read_candidates',
+    'sgx_orb_debug_level_geometry', 'sgx_orb_debug_set_unfused_pyramid', 'sgx_orb_debug_read_level', 'sgx_orb_debug_read_candidates',
     'sgx_orb_debug_run_octree', 'sgx_profile_enable', 'sgx_profile_num_classes', 'sgx_profile_class_name', 'sgx_profile_read',
     'sgx_match_project_frame_batch_dev', 'sgx_match_project_frame', 'sgx_match_project_local_batch_dev',
     'sgx_frame_stereo_from_rgbd_batch_dev', 'sgx_frame_unproject_batch_dev', 'sgx_frame_make_map_points_batch_dev', 'sgx_frame_merge_matches_batch_dev',

@@ -27,6 +27,8 @@ struct sgx_orb {
     SgxCell *d_cells = nullptr;
     SgxXTab *d_xt[SGX_MAX_LEVELS] = {};
     SgxYTab *d_yt[SGX_MAX_LEVELS] = {};
+    // fused pyramid (k_pyramid): concatenated tables, per (tile, level) rects
+    SgxXTab *d_xt_all = nullptr; SgxYTab *d_yt_all = nullptr; SgxPyrRect *d_pyr_rects = nullptr; SgxPyrTabs pyr_tabs; int pyr_tiles = 0, pyr_lds = 0;
     int *d_umax = nullptr;
     signed char *d_pattern = nullptr;
     // device workspace (sized for cfg.max_batch)
@@ -41,6 +43,9 @@ struct sgx_orb {
     uint8_t *d_gray1 = nullptr; uint8_t *d_kps1 = nullptr; uint8_t *d_desc1 = nullptr; int *d_count1 = nullptr;
     int last_batch = 0;
 };
+
+static int g_orb_unfused_pyramid = 0;      // test tap: 1 = one k_resize launch per level instead of the fused k_pyramid
+extern "C" int sgx_orb_debug_set_unfused_pyramid(int on) { g_orb_unfused_pyramid = on ? 1 : 0; return SGX_OK; }
 
 static inline int cvround_f(float v) { return (int)lrintf(v); }
 static inline int cvround_d(double v) { return (int)lrint(v); }
@@ -122,6 +127,7 @@ extern "C" void sgx_orb_destroy(sgx_orb *h)
     (void)hipFree(h->d_cand_count); (void)hipFree(h->d_node_scratch); (void)hipFree(h->d_sel); (void)hipFree(h->d_sel_count); (void)hipFree(h->d_status);
     (void)hipFree(h->d_gray1); (void)hipFree(h->d_kps1); (void)hipFree(h->d_desc1); (void)hipFree(h->d_count1);
     for (int l = 0; l < SGX_MAX_LEVELS; l++) { (void)hipFree(h->d_xt[l]); (void)hipFree(h->d_yt[l]); }
+    (void)hipFree(h->d_xt_all); (void)hipFree(h->d_yt_all); (void)hipFree(h->d_pyr_rects);
     delete h;
 }
 
@@ -225,6 +231,51 @@ extern "C" int sgx_orb_create(const sgx_orb_config *cfg, sgx_orb **out)
         SGX_CHECK_HIP(hipStreamSynchronize(0));   // xt/yt are stack vectors
     }
     SGX_CHECK_HIP(hipStreamSynchronize(0));
+    if (nl > 1) {   // ---- k_pyramid plan: tiles are a fixed partition of every level; needed regions are propagated from the coarsest level up
+        std::vector<std::vector<SgxXTab>> xts(nl); std::vector<std::vector<SgxYTab>> yts(nl);
+        std::vector<SgxXTab> xall; std::vector<SgxYTab> yall;
+        memset(&h->pyr_tabs, 0, sizeof h->pyr_tabs);
+        for (int l = 1; l < nl; l++) {
+            build_resize_tables(g.lv[l - 1].w, g.lv[l - 1].h, g.lv[l].w, g.lv[l].h, xts[l], yts[l]);
+            h->pyr_tabs.xoff[l] = (int)xall.size(); h->pyr_tabs.yoff[l] = (int)yall.size();
+            xall.insert(xall.end(), xts[l].begin(), xts[l].end()); yall.insert(yall.end(), yts[l].begin(), yts[l].end());
+        }
+        const int T = 32, ntx = (g.lv[nl - 1].w + T - 1) / T, nty = (g.lv[nl - 1].h + T - 1) / T;
+        std::vector<SgxPyrRect> rects((size_t)ntx * nty * nl);
+        int max_a = 0, max_b = 0;
+        for (int j = 0; j < nty; j++) for (int i = 0; i < ntx; i++) {
+            SgxPyrRect *R = &rects[((size_t)j * ntx + i) * nl];
+            int nx0 = 0, nx1 = 0, ny0 = 0, ny1 = 0;                 // needed region of level l+1 (exclusive ends)
+            for (int l = nl - 1; l >= 0; l--) {
+                const int Wl = g.lv[l].w, Hl = g.lv[l].h;
+                int ax0 = Wl, ax1 = 0, ay0 = Hl, ay1 = 0;
+                if (l >= 1) {                                        // owned part of this level
+                    ax0 = i == 0 ? 0 : (int)(((long)i * Wl / ntx) & ~3L); ax1 = i == ntx - 1 ? Wl : (int)(((long)(i + 1) * Wl / ntx) & ~3L);
+                    ay0 = (int)((long)j * Hl / nty); ay1 = j == nty - 1 ? Hl : (int)((long)(j + 1) * Hl / nty);
+                }
+                SgxPyrRect &r = R[l];
+                r.ox0 = (short)ax0; r.ox1 = (short)ax1; r.oy0 = (short)ay0; r.oy1 = (short)ay1;
+                if (l < nl - 1) {                                    // sources of the next level's needed region
+                    for (int x = nx0; x < std::min(nx1, g.lv[l + 1].w); x++) { ax0 = std::min(ax0, (int)xts[l + 1][x].sx); ax1 = std::max(ax1, (int)xts[l + 1][x].sx1 + 1); }
+                    for (int y = ny0; y < ny1; y++) { ay0 = std::min(ay0, (int)yts[l + 1][y].sy0); ay1 = std::max(ay1, (int)yts[l + 1][y].sy1 + 1); }
+                }
+                ax0 &= ~3; ax1 = (ax1 + 3) & ~3;                     // dword groups; groups past the image width are computed as zeros / read inside the row pitch
+                r.nx0 = (short)ax0; r.ny0 = (short)ay0; r.nw = (short)(ax1 - ax0); r.nh = (short)(ay1 - ay0);
+                const int q = r.nw / 4; r.qmagic = q <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)q - 1) / (unsigned)q); r.pad = 0;
+                const int bytes = (int)r.nw * r.nh;
+                if (l & 1) max_b = std::max(max_b, bytes); else max_a = std::max(max_a, bytes);
+                nx0 = ax0; nx1 = ax1; ny0 = ay0; ny1 = ay1;
+            }
+        }
+        h->pyr_tabs.lds_a = (max_a + 15) & ~15;
+        h->pyr_lds = h->pyr_tabs.lds_a + ((max_b + 15) & ~15);
+        h->pyr_tiles = ntx * nty;
+        if (h->pyr_lds > 64 * 1024) h->pyr_tiles = 0;               // geometry too large for the fused plan: per-level k_resize launches
+        SGX_ALLOC(h->d_xt_all, xall.size() * sizeof(SgxXTab)); SGX_ALLOC(h->d_yt_all, yall.size() * sizeof(SgxYTab)); SGX_ALLOC(h->d_pyr_rects, rects.size() * sizeof(SgxPyrRect));
+        SGX_CHECK_HIP(hipMemcpy(h->d_xt_all, xall.data(), xall.size() * sizeof(SgxXTab), hipMemcpyHostToDevice));
+        SGX_CHECK_HIP(hipMemcpy(h->d_yt_all, yall.data(), yall.size() * sizeof(SgxYTab), hipMemcpyHostToDevice));
+        SGX_CHECK_HIP(hipMemcpy(h->d_pyr_rects, rects.data(), rects.size() * sizeof(SgxPyrRect), hipMemcpyHostToDevice));
+    }
 #undef SGX_ALLOC
     *out = h;
     return SGX_OK;
@@ -256,10 +307,13 @@ extern "C" int sgx_orb_extract_batch_dev(sgx_orb *h, const uint8_t *d_gray, int 
     h->last_batch = batch;
     SGX_CHECK_HIP(hipMemsetAsync(h->d_cand_count, 0, (size_t)batch * nl * 4, stream));
     sgx_prof_begin(SGX_K_RESIZE, stream);
-    for (int l = 1; l < nl; l++) {
-        dim3 grid((g.lv[l].w + 255) / 256, (g.lv[l].h + 3) / 4, batch);
-        SGX_LAUNCH(k_resize, grid, dim3(256), stream, g, l, d_gray, pitch, h->d_pyr, h->d_xt[l], h->d_yt[l]);
-    }
+    if (h->pyr_tiles > 0 && !g_orb_unfused_pyramid)
+        SGX_LAUNCH_DYN(k_pyramid, dim3(h->pyr_tiles, batch), dim3(256), h->pyr_lds, stream, g, h->pyr_tabs, d_gray, pitch, h->d_pyr, h->d_xt_all, h->d_yt_all, h->d_pyr_rects);
+    else
+        for (int l = 1; l < nl; l++) {
+            dim3 grid((g.lv[l].w + 255) / 256, (g.lv[l].h + 3) / 4, batch);
+            SGX_LAUNCH(k_resize, grid, dim3(256), stream, g, l, d_gray, pitch, h->d_pyr, h->d_xt[l], h->d_yt[l]);
+        }
     sgx_prof_end(SGX_K_RESIZE, stream);
     sgx_prof_begin(SGX_K_FAST, stream);
     SGX_LAUNCH_DYN(k_fast_cells, dim3(g.ncells * batch), dim3(256), g.fast_lds_bytes, stream, g, h->d_cells, d_gray, pitch, h->d_pyr, batch,

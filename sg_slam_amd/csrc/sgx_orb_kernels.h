@@ -99,6 +99,79 @@ SGX_KERNEL(256) k_resize(SgxOrbGeom g, int level, const uint8_t *gray, int gray_
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_pyramid: ORBextractor::ComputePyramid (ORBextractor.cc:1108-1133) for all levels in ONE launch.  The chained resizes
+// level l-1 -> l are evaluated tile by tile: a workgroup owns one tile of every level (a fixed 1/(ntx*nty) partition of each
+// level, x boundaries multiples of 4), stages the level-0 footprint of its tiles in LDS, and walks down the chain with two
+// ping-pong LDS buffers, computing at each level the region the next level needs plus the part it owns (a few halo columns /
+// rows are recomputed by neighbouring workgroups), and writing only the owned part to HBM as dwords.  Same tables and integer
+// formula as k_resize, so the pyramid is byte-identical; level l-1 is never re-read from HBM.
+// Host-built per (tile, level) rects: needed region (x0 and width multiples of 4) and owned region.  grid = (ntiles, B).
+// ---------------------------------------------------------------------------------------------
+struct SgxPyrRect { short nx0, ny0, nw, nh, ox0, oy0, ox1, oy1; unsigned qmagic; int pad; };   // qmagic = ceil(2^32 / (nw/4))
+struct SgxPyrTabs { int xoff[SGX_MAX_LEVELS], yoff[SGX_MAX_LEVELS]; int lds_a; };
+
+SGX_DEV unsigned sgx_udiv_magic(unsigned n, unsigned m)
+{
+#ifndef SGX_EMU
+    return m ? __umulhi(n, m) : n;
+#else
+    return m ? (unsigned)(((unsigned long long)n * m) >> 32) : n;
+#endif
+}
+
+SGX_KERNEL(256) k_pyramid(SgxOrbGeom g, SgxPyrTabs tb, const uint8_t *gray, int gray_pitch, uint8_t *pyr, const SgxXTab *xt, const SgxYTab *yt,
+                          const SgxPyrRect *rects)
+{
+    SGX_DYN_LDS(smem);
+    const int tile = (int)blockIdx.x, frame = (int)blockIdx.y, nl = g.nlevels;
+    const SgxPyrRect *R = rects + (size_t)tile * nl;
+    uint8_t *cur = smem, *nxt = smem + tb.lds_a;
+    {   // level-0 footprint, dword loads (x0 and width are multiples of 4; the row pitch is a multiple of 4)
+        const SgxPyrRect r0 = R[0];
+        const uint8_t *src = gray + (size_t)frame * gray_pitch * g.H;
+        const int q = r0.nw >> 2, groups = q * r0.nh;
+        SGX_THREADS_BEGIN(tid)
+        for (int idx = tid; idx < groups; idx += 256) {
+            const int y = (int)sgx_udiv_magic((unsigned)idx, r0.qmagic), x4 = (idx - y * q) * 4;
+            *(uint32_t *)(cur + y * r0.nw + x4) = *(const uint32_t *)(src + (size_t)(r0.ny0 + y) * gray_pitch + r0.nx0 + x4);
+        }
+        SGX_THREADS_END
+    }
+    SGX_SYNC();
+    for (int l = 1; l < nl; l++) {
+        const SgxPyrRect rp = R[l - 1], r = R[l];
+        const int W = g.lv[l].w, dstride = g.lv[l].stride;
+        uint8_t *dst = pyr + (size_t)frame * g.pyr_pitch + g.lv[l].off;
+        const SgxXTab *xtl = xt + tb.xoff[l]; const SgxYTab *ytl = yt + tb.yoff[l];
+        const int q = r.nw >> 2, groups = q * r.nh;
+        SGX_THREADS_BEGIN(tid)
+        for (int idx = tid; idx < groups; idx += 256) {
+            const int y = (int)sgx_udiv_magic((unsigned)idx, r.qmagic), x4 = (idx - y * q) * 4;
+            const int gy = r.ny0 + y, gx4 = r.nx0 + x4;
+            const SgxYTab ty = ytl[gy];
+            const uint8_t *r0 = cur + (ty.sy0 - rp.ny0) * rp.nw - rp.nx0, *r1 = cur + (ty.sy1 - rp.ny0) * rp.nw - rp.nx0;
+            uint32_t out = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int x = gx4 + i;
+                if (x < W) {
+                    const SgxXTab tx = xtl[x];
+                    const int h0 = r0[tx.sx] * tx.a0 + r0[tx.sx1] * tx.a1;
+                    const int h1 = r1[tx.sx] * tx.a0 + r1[tx.sx1] * tx.a1;
+                    const int v = (((ty.b0 * (h0 >> 4)) >> 16) + ((ty.b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                    out |= (uint32_t)(v & 255) << (8 * i);
+                }
+            }
+            *(uint32_t *)(nxt + y * r.nw + x4) = out;
+            if (gy >= r.oy0 && gy < r.oy1 && gx4 >= r.ox0 && gx4 < r.ox1) *(uint32_t *)(dst + (size_t)gy * dstride + gx4) = out;   // stride is a multiple of 64: in-bounds, aligned
+        }
+        SGX_THREADS_END
+        SGX_SYNC();
+        uint8_t *t = cur; cur = nxt; nxt = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_fast_cells: ORBextractor.cc:790-830 for every cell of every level of every frame.
 // One 256-thread workgroup per (cell, frame).  cv::FAST(cell, 20, nms) with fallback
 // cv::FAST(cell, 7, nms) is evaluated from ONE threshold-free score map S = A-1, where

@@ -111,3 +111,28 @@ def test_octree_kernel_random_candidates(ex, oracle, seed):
     perm = rng.permutation(len(xs))
     gx, gy, gs = ex.debug_run_octree(level, xs[perm], ys[perm], resp[perm])
     assert list(zip(gx, gy, gs)) == exp
+
+
+def run_fused_pyramid_equals_per_level(lib, to_dev=lambda a: a):
+    """k_pyramid (all levels in one launch, tiles chained through LDS) writes the same bytes as the per-level k_resize launches."""
+    for (w, h, nl, sf) in ((640, 480, 8, 1.2), (752, 480, 8, 1.2), (512, 384, 6, 1.3), (644, 484, 4, 1.5)):
+        rng = np.random.RandomState(w + h)
+        imgs = rng.randint(0, 256, (2, h, w)).astype(np.uint8)
+        e = ORBextractor(lib=lib, width=w, height=h, nlevels=nl, scaleFactor=sf, max_batch=2)
+        levels = []
+        from sg_slam_amd.capi import KP_DTYPE
+        cap = e.capacity
+        kps = to_dev(np.zeros((2, cap * 28), np.uint8)); desc = to_dev(np.zeros((2, cap, 32), np.uint8)); cnt = to_dev(np.zeros(2, 'i4')); dimg = to_dev(imgs)
+        for unfused in (1, 0):
+            lib.dll.sgx_orb_debug_set_unfused_pyramid(unfused)
+            e.extract_batch_dev(dimg, w, 2, kps, desc, cnt)
+            e.last_status()
+            levels.append([[e.debug_level(f, l) for l in range(1, nl)] for f in range(2)])
+        e.close()
+        for f in range(2):
+            for a, b in zip(levels[0][f], levels[1][f]):
+                assert a.shape == b.shape and (a == b).all(), (w, h)
+
+
+def test_fused_pyramid_equals_per_level(emu):
+    run_fused_pyramid_equals_per_level(emu)

@@ -88,3 +88,9 @@ def test_full_size_properties(ex, stream_frames):
     cnt = np.bincount(k1['octave'], minlength=8)
     assert (cnt <= ex.mnFeaturesPerLevel + 3).all()
     assert (k1['angle'] >= 0).all() and (k1['angle'] < 360).all()
+
+
+def test_fused_pyramid_equals_per_level_gpu(gpulib):
+    import torch
+    from test_orb_emu import run_fused_pyramid_equals_per_level
+    run_fused_pyramid_equals_per_level(gpulib, to_dev=lambda a: torch.from_numpy(a).cuda())
