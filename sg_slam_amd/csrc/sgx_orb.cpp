@@ -42,6 +42,7 @@ struct sgx_orb {
     // single-frame staging for sgx_orb_extract
     uint8_t *d_gray1 = nullptr; uint8_t *d_kps1 = nullptr; uint8_t *d_desc1 = nullptr; int *d_count1 = nullptr;
     int last_batch = 0;
+    int oct_maxlim = 0;            // largest octree list capacity over the levels (quota + 3 or 4*nIni)
 };
 
 static int g_orb_unfused_pyramid = 0;      // test tap: 1 = one k_resize launch per level instead of the fused k_pyramid
@@ -187,6 +188,7 @@ extern "C" int sgx_orb_create(const sgx_orb_config *cfg, sgx_orb **out)
         int lim = L.quota + 3; if (lim < 4 * nIni) lim = 4 * nIni;
         if (lim > SGX_OCT_MAXN) { sgx_orb_destroy(h); return SGX_ERR_UNSUPPORTED; }
         kp_cap += lim;
+        if (lim > h->oct_maxlim) h->oct_maxlim = lim;
         L.cand_cap = (L.cand_cap + 63) & ~63;
         cand_off += L.cand_cap;
     }
@@ -242,7 +244,7 @@ extern "C" int sgx_orb_create(const sgx_orb_config *cfg, sgx_orb **out)
         }
         const int T = 32, ntx = (g.lv[nl - 1].w + T - 1) / T, nty = (g.lv[nl - 1].h + T - 1) / T;
         std::vector<SgxPyrRect> rects((size_t)ntx * nty * nl);
-        int max_a = 0, max_b = 0;
+        int max_a = 0, max_b = 0, max_x = 0, max_y = 0;
         for (int j = 0; j < nty; j++) for (int i = 0; i < ntx; i++) {
             SgxPyrRect *R = &rects[((size_t)j * ntx + i) * nl];
             int nx0 = 0, nx1 = 0, ny0 = 0, ny1 = 0;                 // needed region of level l+1 (exclusive ends)
@@ -266,9 +268,13 @@ extern "C" int sgx_orb_create(const sgx_orb_config *cfg, sgx_orb **out)
                 if (l & 1) max_b = std::max(max_b, bytes); else max_a = std::max(max_a, bytes);
                 nx0 = ax0; nx1 = ax1; ny0 = ay0; ny1 = ay1;
             }
+            int xo = 0, yo = 0;
+            for (int l = 1; l < nl; l++) { R[l].xo = xo; R[l].yo = yo; xo += R[l].nw; yo += R[l].nh; }
+            R[0].xo = R[0].yo = 0;
+            max_x = std::max(max_x, xo); max_y = std::max(max_y, yo);
         }
-        h->pyr_tabs.lds_a = (max_a + 15) & ~15;
-        h->pyr_lds = h->pyr_tabs.lds_a + ((max_b + 15) & ~15);
+        h->pyr_tabs.lds_a = (max_a + 15) & ~15; h->pyr_tabs.lds_b = (max_b + 15) & ~15; h->pyr_tabs.lds_x = max_x * (int)sizeof(SgxXTab);
+        h->pyr_lds = h->pyr_tabs.lds_a + h->pyr_tabs.lds_b + h->pyr_tabs.lds_x + max_y * (int)sizeof(SgxYTab);
         h->pyr_tiles = ntx * nty;
         if (h->pyr_lds > 64 * 1024) h->pyr_tiles = 0;               // geometry too large for the fused plan: per-level k_resize launches
         SGX_ALLOC(h->d_xt_all, xall.size() * sizeof(SgxXTab)); SGX_ALLOC(h->d_yt_all, yall.size() * sizeof(SgxYTab)); SGX_ALLOC(h->d_pyr_rects, rects.size() * sizeof(SgxPyrRect));
@@ -296,6 +302,22 @@ extern "C" int sgx_orb_get_tables(const sgx_orb *h, float *scale, float *inv_sca
     return SGX_OK;
 }
 
+// k_octree launches.  Candidate-count classes: small LDS footprints let several (frame, level) workgroups share a CU; each block runs in exactly one launch.
+static void launch_octree(sgx_orb *h, int batch, sgx_stream_t stream)
+{
+    const SgxOrbGeom &g = h->g; const int nl = g.nlevels;
+    if (h->oct_maxlim <= 256) {
+        auto ka = k_octree<true, 256, 2048>; auto kb = k_octree<true, 256, SGX_CAND_LDS>; auto kc = k_octree<false, 256, 1>;
+        SGX_LAUNCH(ka, dim3(nl, batch), dim3(SGX_OCT_THREADS), stream, g, h->d_cand, h->d_cand_count, h->d_node_scratch, h->d_sel, h->d_sel_count, h->d_status, -1);
+        SGX_LAUNCH(kb, dim3(nl, batch), dim3(SGX_OCT_THREADS), stream, g, h->d_cand, h->d_cand_count, h->d_node_scratch, h->d_sel, h->d_sel_count, h->d_status, 2048);
+        SGX_LAUNCH(kc, dim3(nl, batch), dim3(SGX_OCT_THREADS), stream, g, h->d_cand, h->d_cand_count, h->d_node_scratch, h->d_sel, h->d_sel_count, h->d_status, SGX_CAND_LDS);
+    } else {
+        auto kb = k_octree<true, SGX_OCT_MAXN, SGX_CAND_LDS>; auto kc = k_octree<false, SGX_OCT_MAXN, 1>;
+        SGX_LAUNCH(kb, dim3(nl, batch), dim3(SGX_OCT_THREADS), stream, g, h->d_cand, h->d_cand_count, h->d_node_scratch, h->d_sel, h->d_sel_count, h->d_status, -1);
+        SGX_LAUNCH(kc, dim3(nl, batch), dim3(SGX_OCT_THREADS), stream, g, h->d_cand, h->d_cand_count, h->d_node_scratch, h->d_sel, h->d_sel_count, h->d_status, SGX_CAND_LDS);
+    }
+}
+
 extern "C" int sgx_orb_extract_batch_dev(sgx_orb *h, const uint8_t *d_gray, int pitch, int batch,
                                          sgx_keypoint *d_kps, uint8_t *d_desc, int32_t *d_count, int cap, void *stream_)
 {
@@ -320,8 +342,7 @@ extern "C" int sgx_orb_extract_batch_dev(sgx_orb *h, const uint8_t *d_gray, int 
                h->d_cand, h->d_cand_count, h->d_status);
     sgx_prof_end(SGX_K_FAST, stream);
     sgx_prof_begin(SGX_K_OCTREE, stream);
-    SGX_LAUNCH(k_octree<true>, dim3(nl, batch), dim3(SGX_OCT_THREADS), stream, g, h->d_cand, h->d_cand_count, h->d_node_scratch, h->d_sel, h->d_sel_count, h->d_status);
-    SGX_LAUNCH(k_octree<false>, dim3(nl, batch), dim3(SGX_OCT_THREADS), stream, g, h->d_cand, h->d_cand_count, h->d_node_scratch, h->d_sel, h->d_sel_count, h->d_status);
+    launch_octree(h, batch, stream);
     sgx_prof_end(SGX_K_OCTREE, stream);
     sgx_prof_begin(SGX_K_ORIENT_DESC, stream);
     SGX_LAUNCH(k_orient_desc, dim3(g.kp_cap * batch), dim3(64), stream, g, d_gray, pitch, h->d_pyr, h->d_sel, h->d_sel_count,
@@ -402,8 +423,7 @@ extern "C" int sgx_orb_debug_run_octree(sgx_orb *h, int level, const uint32_t *p
     std::vector<int> cnt(nl, 0); cnt[level] = n;
     SGX_CHECK_HIP(hipMemcpyAsync(h->d_cand_count, cnt.data(), nl * 4, hipMemcpyHostToDevice, 0));
     SGX_CHECK_HIP(hipMemcpyAsync(h->d_cand + h->g.lv[level].cand_off, packed, (size_t)n * 4, hipMemcpyHostToDevice, 0));
-    SGX_LAUNCH(k_octree<true>, dim3(nl, 1), dim3(SGX_OCT_THREADS), (sgx_stream_t)0, h->g, h->d_cand, h->d_cand_count, h->d_node_scratch, h->d_sel, h->d_sel_count, h->d_status);
-    SGX_LAUNCH(k_octree<false>, dim3(nl, 1), dim3(SGX_OCT_THREADS), (sgx_stream_t)0, h->g, h->d_cand, h->d_cand_count, h->d_node_scratch, h->d_sel, h->d_sel_count, h->d_status);
+    launch_octree(h, 1, (sgx_stream_t)0);
     int ns = 0;
     SGX_CHECK_HIP(hipMemcpyAsync(&ns, h->d_sel_count + level, 4, hipMemcpyDeviceToHost, 0));
     SGX_CHECK_HIP(hipStreamSynchronize(0));

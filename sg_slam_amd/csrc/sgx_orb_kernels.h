@@ -107,8 +107,8 @@ SGX_KERNEL(256) k_resize(SgxOrbGeom g, int level, const uint8_t *gray, int gray_
 // formula as k_resize, so the pyramid is byte-identical; level l-1 is never re-read from HBM.
 // Host-built per (tile, level) rects: needed region (x0 and width multiples of 4) and owned region.  grid = (ntiles, B).
 // ---------------------------------------------------------------------------------------------
-struct SgxPyrRect { short nx0, ny0, nw, nh, ox0, oy0, ox1, oy1; unsigned qmagic; int pad; };   // qmagic = ceil(2^32 / (nw/4))
-struct SgxPyrTabs { int xoff[SGX_MAX_LEVELS], yoff[SGX_MAX_LEVELS]; int lds_a; };
+struct SgxPyrRect { short nx0, ny0, nw, nh, ox0, oy0, ox1, oy1; unsigned qmagic; int xo, yo, pad; };   // qmagic = ceil(2^32 / (nw/4)); xo / yo: slots of this level's table slices in LDS
+struct SgxPyrTabs { int xoff[SGX_MAX_LEVELS], yoff[SGX_MAX_LEVELS]; int lds_a, lds_b, lds_x; };        // LDS carve: [buffer A | buffer B | x-table slices | y-table slices]
 
 SGX_DEV unsigned sgx_udiv_magic(unsigned n, unsigned m)
 {
@@ -126,7 +126,8 @@ SGX_KERNEL(256) k_pyramid(SgxOrbGeom g, SgxPyrTabs tb, const uint8_t *gray, int 
     const int tile = (int)blockIdx.x, frame = (int)blockIdx.y, nl = g.nlevels;
     const SgxPyrRect *R = rects + (size_t)tile * nl;
     uint8_t *cur = smem, *nxt = smem + tb.lds_a;
-    {   // level-0 footprint, dword loads (x0 and width are multiples of 4; the row pitch is a multiple of 4)
+    SgxXTab *xtl_lds = (SgxXTab *)(smem + tb.lds_a + tb.lds_b); SgxYTab *ytl_lds = (SgxYTab *)(smem + tb.lds_a + tb.lds_b + tb.lds_x);
+    {   // level-0 footprint, dword loads (x0 and width are multiples of 4; the row pitch is a multiple of 4) + this tile's slices of every level's tables
         const SgxPyrRect r0 = R[0];
         const uint8_t *src = gray + (size_t)frame * gray_pitch * g.H;
         const int q = r0.nw >> 2, groups = q * r0.nh;
@@ -135,6 +136,12 @@ SGX_KERNEL(256) k_pyramid(SgxOrbGeom g, SgxPyrTabs tb, const uint8_t *gray, int 
             const int y = (int)sgx_udiv_magic((unsigned)idx, r0.qmagic), x4 = (idx - y * q) * 4;
             *(uint32_t *)(cur + y * r0.nw + x4) = *(const uint32_t *)(src + (size_t)(r0.ny0 + y) * gray_pitch + r0.nx0 + x4);
         }
+        for (int l = 1; l < nl; l++) {
+            const SgxPyrRect r = R[l];
+            const int nx = min((int)r.nw, g.lv[l].w - r.nx0);
+            for (int i = tid; i < nx; i += 256) xtl_lds[r.xo + i] = xt[tb.xoff[l] + r.nx0 + i];
+            for (int i = tid; i < r.nh; i += 256) ytl_lds[r.yo + i] = yt[tb.yoff[l] + r.ny0 + i];
+        }
         SGX_THREADS_END
     }
     SGX_SYNC();
@@ -142,7 +149,7 @@ SGX_KERNEL(256) k_pyramid(SgxOrbGeom g, SgxPyrTabs tb, const uint8_t *gray, int 
         const SgxPyrRect rp = R[l - 1], r = R[l];
         const int W = g.lv[l].w, dstride = g.lv[l].stride;
         uint8_t *dst = pyr + (size_t)frame * g.pyr_pitch + g.lv[l].off;
-        const SgxXTab *xtl = xt + tb.xoff[l]; const SgxYTab *ytl = yt + tb.yoff[l];
+        const SgxXTab *xtl = xtl_lds + r.xo - r.nx0; const SgxYTab *ytl = ytl_lds + r.yo - r.ny0;
         const int q = r.nw >> 2, groups = q * r.nh;
         SGX_THREADS_BEGIN(tid)
         for (int idx = tid; idx < groups; idx += 256) {
@@ -402,29 +409,31 @@ SGX_DEV unsigned long long sgx_oct_pick_key(uint32_t e, int wcell, int hcell)
     return ((unsigned long long)(e >> 24) << 40) | (0xFFFFFFFFFFull - rank);
 }
 
-template <bool KEYS_IN_LDS>
+// MAXN = node-list capacity (>= the largest per-level quota + 3), CL = keys kept in LDS; a block handles its (frame, level) iff the candidate
+// count nk lies in its class: nk_lo < nk <= CL (KEYS_IN_LDS) or nk > nk_lo (global keys).  Small classes leave room for several workgroups per CU.
+template <bool KEYS_IN_LDS, int MAXN, int CL>
 SGX_KERNEL(SGX_OCT_THREADS) k_octree(SgxOrbGeom g, const uint32_t *cand, const int *cand_count, uint16_t *node_scratch,
-                                     uint32_t *sel, int *sel_count, uint32_t *status)
+                                     uint32_t *sel, int *sel_count, uint32_t *status, int nk_lo)
 {
     // keys: packed x | y<<12 | S<<24 and the list position of the node that owns each key.
     // Normal case: both in LDS.  A (frame, level) with more than SGX_CAND_LDS candidates (e.g. pure
     // noise) is handled by the KEYS_IN_LDS=false instantiation, which reads the keys from the
     // candidate buffer and keeps node_of in a global scratch slice; each block runs in exactly one.
-    SGX_LDS uint32_t kxy_lds[KEYS_IN_LDS ? SGX_CAND_LDS : 1];
-    SGX_LDS uint16_t node_lds[KEYS_IN_LDS ? SGX_CAND_LDS : 1];
+    SGX_LDS uint32_t kxy_lds[KEYS_IN_LDS ? CL : 1];
+    SGX_LDS uint16_t node_lds[KEYS_IN_LDS ? CL : 1];
     // node list (array in list order), ping-pong
-    SGX_LDS SgxOctNode nb[2][SGX_OCT_MAXN];
-    SGX_LDS uint16_t ncnt[2][SGX_OCT_MAXN];      // keys per node
-    SGX_LDS uint16_t nseq[2][SGX_OCT_MAXN];      // creation index within the pass that created it
-    SGX_LDS uint8_t nflag[2][SGX_OCT_MAXN];      // 1: created by the last pass with >1 key (the reference's vSizeAndPointerToNode)
+    SGX_LDS SgxOctNode nb[2][MAXN];
+    SGX_LDS uint16_t ncnt[2][MAXN];      // keys per node
+    SGX_LDS uint16_t nseq[2][MAXN];      // creation index within the pass that created it
+    SGX_LDS uint8_t nflag[2][MAXN];      // 1: created by the last pass with >1 key (the reference's vSizeAndPointerToNode)
     // per-pass scratch indexed by OLD list position
-    SGX_LDS int quad[SGX_OCT_MAXN][4];           // keys per quadrant; later the children's new positions ([0] for kept nodes)
-    SGX_LDS int scanA[SGX_OCT_MAXN];             // children created before (in creation order)
-    SGX_LDS int scanB[SGX_OCT_MAXN];             // kept nodes before (in list order)
-    SGX_LDS uint8_t splitting[SGX_OCT_MAXN];
-    SGX_LDS uint16_t order[SGX_OCT_MAXN];        // phase 2: processing rank -> old position
-    SGX_LDS uint16_t rank_of[SGX_OCT_MAXN];
-    SGX_LDS unsigned long long best[SGX_OCT_MAXN];
+    SGX_LDS int quad[MAXN][4];           // keys per quadrant; later the children's new positions ([0] for kept nodes)
+    SGX_LDS int scanA[MAXN];             // children created before (in creation order)
+    SGX_LDS int scanB[MAXN];             // kept nodes before (in list order)
+    SGX_LDS uint8_t splitting[MAXN];
+    SGX_LDS uint16_t order[MAXN];        // phase 2: processing rank -> old position
+    SGX_LDS uint16_t rank_of[MAXN];
+    SGX_LDS unsigned long long best[MAXN];
     SGX_LDS int s_size, s_C, s_kept, s_ntoexpand, s_stop, s_m, s_overflow;
 
     const int level = (int)blockIdx.x, frame = (int)blockIdx.y;
@@ -432,7 +441,7 @@ SGX_KERNEL(SGX_OCT_THREADS) k_octree(SgxOrbGeom g, const uint32_t *cand, const i
     const int N = L.quota;
     int nk = cand_count[frame * g.nlevels + level];
     if (nk > L.cand_cap) nk = L.cand_cap;
-    if ((nk <= SGX_CAND_LDS) != KEYS_IN_LDS) return;
+    if (nk <= nk_lo || (KEYS_IN_LDS && nk > CL)) return;
     const uint32_t *src = cand + (size_t)frame * g.cand_pitch + L.cand_off;
     uint32_t *kxy = KEYS_IN_LDS ? kxy_lds : (uint32_t *)src;
     uint16_t *node_of = KEYS_IN_LDS ? node_lds : node_scratch + (size_t)frame * g.cand_pitch + L.cand_off;
@@ -568,7 +577,7 @@ SGX_KERNEL(SGX_OCT_THREADS) k_octree(SgxOrbGeom g, const uint32_t *cand, const i
         SGX_SYNC();
         const int C = s_C;
         const int new_size = C + s_kept;
-        if (new_size > SGX_OCT_MAXN) {
+        if (new_size > MAXN) {
             SGX_THREADS_BEGIN(tid) if (tid == 0) { sgx_atomic_or(status, SGX_ST_NODE_OVERFLOW); s_overflow = 1; } SGX_THREADS_END
             SGX_SYNC();
             break;
