@@ -172,6 +172,7 @@ int sgx_pose_optimization_batch_dev(int batch, int cap, const sgx_keypoint *d_ke
                                     const int32_t *d_mp_index, const uint8_t *d_has_mp, const float *d_mp_xw, int xw_pitch,
                                     const float *inv_level_sigma2, int nlevels, const sgx_camera *cam,
                                     float *d_Tcw, uint8_t *d_outlier, int32_t *d_n_inliers, void *stream);
+int sgx_pose_opt_debug_set_threads(int threads_per_frame);   /* tuning / test tap: 0 = default (256 threads = four waves per frame), 64 = one wave per frame, 256 */
 int sgx_pose_optimization(int n, const sgx_keypoint *keys_un, const float *uright, const uint8_t *has_mp, const float *mp_xw,
                           const float *inv_level_sigma2, int nlevels, const sgx_camera *cam,
                           float *Tcw, uint8_t *outlier, int32_t *n_inliers);

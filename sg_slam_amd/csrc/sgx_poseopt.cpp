@@ -12,6 +12,9 @@
 
 static SgxCam po_cam(const sgx_camera *c) { SgxCam k; k.fx = c->fx; k.fy = c->fy; k.cx = c->cx; k.cy = c->cy; k.bf = c->bf; k.minX = c->min_x; k.maxX = c->max_x; k.minY = c->min_y; k.maxY = c->max_y; return k; }
 
+static int g_po_threads = 0;      // tuning / test tap: 0 = default (256), 64 or 256 = force
+extern "C" int sgx_pose_opt_debug_set_threads(int t) { if (t != 0 && t != 64 && t != 256) return SGX_ERR_INVALID; g_po_threads = t; return SGX_OK; }
+
 extern "C" int sgx_pose_optimization_batch_dev(int batch, int cap, const sgx_keypoint *d_keys_un, const float *d_uright, const int32_t *d_n,
                                                 const int32_t *d_mp_index, const uint8_t *d_has_mp, const float *d_mp_xw, int xw_pitch,
                                                 const float *inv_level_sigma2, int nlevels, const sgx_camera *cam,
@@ -22,8 +25,13 @@ extern "C" int sgx_pose_optimization_batch_dev(int batch, int cap, const sgx_key
     SgxScales is2; memset(&is2, 0, sizeof is2);
     for (int i = 0; i < nlevels; i++) is2.s[i] = inv_level_sigma2[i];
     sgx_prof_begin(SGX_K_POSEOPT, (sgx_stream_t)stream);
-    SGX_LAUNCH(k_pose_opt, dim3(batch), dim3(SGX_PO_THREADS), (sgx_stream_t)stream, cap, (const uint8_t *)d_keys_un, d_uright, d_n,
-               d_mp_index, d_has_mp, d_mp_xw, xw_pitch, is2, po_cam(cam), d_Tcw, d_outlier, d_n_inliers);
+    // threads per frame: four waves.  The one-wave variant (tap below) is kept for tuning: measured on MI355X it is 2x slower per launch at every
+    // batch size (0.67 vs 0.35 ms at 64-256 frames, tools/bench_poseopt.py) because its 85 KB of LDS still limits a CU to one frame at a time.
+    const int wide = g_po_threads ? (g_po_threads == 256) : 1;
+    if (wide) { auto kfn = k_pose_opt<256>; SGX_LAUNCH(kfn, dim3(batch), dim3(256), (sgx_stream_t)stream, cap, (const uint8_t *)d_keys_un, d_uright, d_n,
+                                                       d_mp_index, d_has_mp, d_mp_xw, xw_pitch, is2, po_cam(cam), d_Tcw, d_outlier, d_n_inliers); }
+    else { auto kfn = k_pose_opt<64>; SGX_LAUNCH(kfn, dim3(batch), dim3(64), (sgx_stream_t)stream, cap, (const uint8_t *)d_keys_un, d_uright, d_n,
+                                                 d_mp_index, d_has_mp, d_mp_xw, xw_pitch, is2, po_cam(cam), d_Tcw, d_outlier, d_n_inliers); }
     sgx_prof_end(SGX_K_POSEOPT, (sgx_stream_t)stream);
     SGX_CHECK_HIP(hipGetLastError());
     return SGX_OK;

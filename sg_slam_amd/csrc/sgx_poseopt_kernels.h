@@ -23,7 +23,11 @@
 // deterministic, and within ~1e-15 relative of the reference's sequential order.
 // mp_index (optional): map point of keypoint i is table row mp_index[i] (-1 = none); otherwise has_mp/xw are per keypoint.
 // ---------------------------------------------------------------------------------------------
-SGX_KERNEL(SGX_PO_THREADS) k_pose_opt(int cap, const uint8_t *keys_raw, const float *uright, const int *n_kp,
+// NTT = threads per frame: 256 (4 waves: lowest latency per frame) or 64 (one wave per frame: no inter-wave barriers to wait on and 4x fewer
+// waves for the redundant serial part, so large batches of frames pack four to a CU and finish sooner in aggregate).  Same arithmetic order
+// within a thread; the partial sums are regrouped (NTT/32 groups of 32), i.e. results differ only in the last bits of the reductions.
+template <int NTT>
+SGX_KERNEL(NTT) k_pose_opt(int cap, const uint8_t *keys_raw, const float *uright, const int *n_kp,
                                       const int *mp_index, const uint8_t *has_mp, const float *xw, int xw_pitch,
                                       SgxScales inv_sigma2, SgxCam cam, float *Tcw, uint8_t *outlier, int *n_inliers)
 {
@@ -31,15 +35,16 @@ SGX_KERNEL(SGX_PO_THREADS) k_pose_opt(int cap, const uint8_t *keys_raw, const fl
     SGX_LDS double e_err[SGX_PO_CAP * 3];
     SGX_LDS uint16_t e_kp[SGX_PO_CAP];
     SGX_LDS uint8_t e_flags[SGX_PO_CAP];          // bit0 stereo, bit1 level==1 (excluded), bit2 robust kernel on, bit3 outlier flag
-    SGX_LDS double part[SGX_PO_THREADS * SGX_PO_NRED];
-    SGX_LDS double part2[SGX_PO_NRED * 8];
+    constexpr int NG = NTT / 32;                   // reduction groups of 32 threads
+    SGX_LDS double part[NTT * SGX_PO_NRED];
+    SGX_LDS double part2[SGX_PO_NRED * NG];
     SGX_LDS double red[SGX_PO_NRED];
-    SGX_LDS int scan[SGX_PO_THREADS];
+    SGX_LDS int scan[NTT];
     SGX_LDS int s_ne, s_nbad;
 
     const int f = (int)blockIdx.x;
     const int N = min(n_kp[f], cap);
-    const int NT = SGX_PO_THREADS;
+    const int NT = NTT;
     const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);   // Optimizer.cc:272-273 (float)
     const double fx = cam.fx, fy = cam.fy, cx = cam.cx, cy = cam.cy, bf = cam.bf;
 
@@ -106,11 +111,11 @@ SGX_KERNEL(SGX_PO_THREADS) k_pose_opt(int cap, const uint8_t *keys_raw, const fl
     SGX_THREADS_END                                                                                         \
     SGX_SYNC();                                                                                             \
     SGX_THREADS_BEGIN(tid)                                                                                  \
-    if (tid < 8) { double s = 0; for (int l = 0; l < 32; l++) s += part[(tid * 32 + l) * SGX_PO_NRED + 27]; part2[27 * 8 + tid] = s; } \
+    if (tid < NG) { double s = 0; for (int l = 0; l < 32; l++) s += part[(tid * 32 + l) * SGX_PO_NRED + 27]; part2[27 * NG + tid] = s; } \
     SGX_THREADS_END                                                                                         \
     SGX_SYNC();                                                                                             \
     SGX_THREADS_BEGIN(tid)                                                                                  \
-    if (tid == 0) { double s = 0; for (int l = 0; l < 8; l++) s += part2[27 * 8 + l]; red[27] = s; }        \
+    if (tid == 0) { double s = 0; for (int l = 0; l < NG; l++) s += part2[27 * NG + l]; red[27] = s; }      \
     SGX_THREADS_END                                                                                         \
     SGX_SYNC();
 
@@ -167,11 +172,11 @@ SGX_KERNEL(SGX_PO_THREADS) k_pose_opt(int cap, const uint8_t *keys_raw, const fl
             SGX_THREADS_END
             SGX_SYNC();
             SGX_THREADS_BEGIN(tid)
-            if (tid < 27 * 8) { const int c = tid >> 3, j = tid & 7; double s = 0; for (int l = 0; l < 32; l++) s += part[(j * 32 + l) * SGX_PO_NRED + c]; part2[c * 8 + j] = s; }
+            if (tid < 27 * NG) { const int c = tid / NG, j = tid - c * NG; double s = 0; for (int l = 0; l < 32; l++) s += part[(j * 32 + l) * SGX_PO_NRED + c]; part2[c * NG + j] = s; }
             SGX_THREADS_END
             SGX_SYNC();
             SGX_THREADS_BEGIN(tid)
-            if (tid < 27) { double s = 0; for (int l = 0; l < 8; l++) s += part2[tid * 8 + l]; red[tid] = s; }
+            if (tid < 27) { double s = 0; for (int l = 0; l < NG; l++) s += part2[tid * NG + l]; red[tid] = s; }
             SGX_THREADS_END
             SGX_SYNC();
             double H[6][6], b[6];
