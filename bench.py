@@ -56,13 +56,13 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=40)
     ap.add_argument('--warmup', type=int, default=4)
-    ap.add_argument('--streams', type=int, default=64, help='independent streams per GPU (frames per step)')
+    ap.add_argument('--streams', type=int, default=256, help='independent streams per GPU (frames per step)')
     ap.add_argument('--frames', type=int, default=6, help='distinct frames kept per stream (ping-pong replay)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-pipeline', action='store_true', help='single HIP stream (no overlap of extraction with match/pose-opt)')
     ap.add_argument('--no-local-map', action='store_true', help='skip the TrackLocalMap stage (local-map SearchByProjection + second PoseOptimization)')
     ap.add_argument('--no-mask', action='store_true', help='skip the dynamic-feature mask + erase stage (Frame::RmDynamicPointWithSemanticAndGeometry)')
-    ap.add_argument('--cpu-sample', type=int, default=100, help='frames timed on the CPU oracle')
+    ap.add_argument('--cpu-sample', type=int, default=400, help='frames timed on the CPU oracle')
     args = ap.parse_args()
 
     import torch

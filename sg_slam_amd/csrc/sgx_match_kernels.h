@@ -75,6 +75,7 @@ SGX_KERNEL(SGX_MATCH_THREADS) k_match_project_frame(
     SGX_LDS int s_changed, s_total, s_rejected, s_ngrid;
 
     const int f = (int)blockIdx.x;
+    SGX_WAVE_PRIORITY(3);          // latency-critical one-workgroup-per-frame kernel (see k_pose_opt)
     const int Nc = min(cn[f], cap), Nl = min(ln[f], cap);
     const int NT = (int)blockDim.x;
     const float *Tc = cTcw + 16 * f, *Tl = lTcw + 16 * f;
@@ -412,6 +413,7 @@ SGX_KERNEL(SGX_MATCH_THREADS) k_match_project_local(
     SGX_PRIV_DECL(uint32_t, cflag, SGX_LOCAL_SLOTS, SGX_MATCH_THREADS);
 
     const int f = (int)blockIdx.x;
+    SGX_WAVE_PRIORITY(3);          // latency-critical one-workgroup-per-frame kernel (see k_pose_opt)
     const int Nc = min(cn[f], cap), Nm = min(min(mn[f], mcap), SGX_LOCAL_CAP);
     const int NT = (int)blockDim.x;
     const float *Tc = cTcw + 16 * f;

@@ -42,6 +42,9 @@ SGX_KERNEL(NTT) k_pose_opt(int cap, const uint8_t *keys_raw, const float *uright
     SGX_LDS int scan[NTT];
     SGX_LDS int s_ne, s_nbad;
 
+    // one workgroup per frame on the latency-critical tracking stream: out-prioritise the throughput kernels (extraction of the next frame)
+    // that share the CU, whose thousands of waves do not care about a few lost issue slots
+    SGX_WAVE_PRIORITY(3);
     const int f = (int)blockIdx.x;
     const int N = min(n_kp[f], cap);
     const int NT = NTT;

@@ -31,6 +31,7 @@
 #define sgx_atomic_or(p, v) atomicOr((p), (v))
 #define SGX_LAUNCH(kern, grid, block, stream, ...) hipLaunchKernelGGL((kern), grid, block, 0, stream, __VA_ARGS__)
 #define SGX_POPCLL(x) __popcll(x)
+#define SGX_WAVE_PRIORITY(p) __builtin_amdgcn_s_setprio(p)   /* issue priority of this wave against co-resident waves (0..3) */
 #define SGX_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)      /* value known to be equal across the wave: keep it in a scalar register */
 // per-thread state that must survive SGX_SYNC(): registers on the device, a [threads][count] table in the emulator
 #define SGX_PRIV_DECL(type, name, count, threads) type name[count]
@@ -65,6 +66,7 @@ static inline int sgx_atomic_min_i32(int *p, int v) { int o = *p; if (v < o) *p 
          for (unsigned _x = 0; _x < _g.x; ++_x) { blockIdx = sgx_dim3(_x, _y, _z); (kern)(__VA_ARGS__); } } while (0)
 #define SGX_POPCLL(x) __builtin_popcountll(x)
 #define SGX_UNIFORM(x) (x)
+#define SGX_WAVE_PRIORITY(p) ((void)0)
 #define SGX_PRIV_DECL(type, name, count, threads) static thread_local type name##_store[threads][count]
 #define SGX_PRIV_BIND(name, tid) auto *name = name##_store[tid]
 typedef void *sgx_stream_t;

@@ -79,7 +79,7 @@ class TrackerBatch:
         self.pipelined = bool(pipelined and xp == 'torch')
         if self.pipelined:
             import torch
-            self.sE, self.sT = torch.cuda.Stream(), torch.cuda.Stream()
+            self.sE, self.sT = torch.cuda.Stream(), torch.cuda.Stream(priority=-1)      # the tracking stream is the latency-critical one: dispatch it first
             self.ev_extract = [torch.cuda.Event() for _ in range(NB)]
             self.ev_track = [torch.cuda.Event() for _ in range(NB)]
 
