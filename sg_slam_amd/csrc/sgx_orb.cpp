@@ -338,7 +338,8 @@ extern "C" int sgx_orb_extract_batch_dev(sgx_orb *h, const uint8_t *d_gray, int 
         }
     sgx_prof_end(SGX_K_RESIZE, stream);
     sgx_prof_begin(SGX_K_FAST, stream);
-    SGX_LAUNCH_DYN(k_fast_cells, dim3(g.ncells * batch), dim3(256), g.fast_lds_bytes, stream, g, h->d_cells, d_gray, pitch, h->d_pyr, batch,
+    static const int fast_threads = getenv("SGX_TUNE_FAST_THREADS") ? atoi(getenv("SGX_TUNE_FAST_THREADS")) : 128;      // workgroup size; env = tuning tap (64..SGX_FAST_THREADS)
+    SGX_LAUNCH_DYN(k_fast_cells, dim3(g.ncells * batch), dim3(fast_threads), g.fast_lds_bytes, stream, g, h->d_cells, d_gray, pitch, h->d_pyr, batch,
                h->d_cand, h->d_cand_count, h->d_status);
     sgx_prof_end(SGX_K_FAST, stream);
     sgx_prof_begin(SGX_K_OCTREE, stream);
