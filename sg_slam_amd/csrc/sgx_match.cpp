@@ -4,6 +4,7 @@
 #include "sgx_prof.h"
 #include "../../include/sgx.h"
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -26,7 +27,8 @@ extern "C" int sgx_match_project_frame_batch_dev(
     SgxScales sc; memset(&sc, 0, sizeof sc);
     for (int i = 0; i < nlevels; i++) sc.s[i] = scale_factors[i];
     sgx_prof_begin(SGX_K_MATCH, (sgx_stream_t)stream);
-    SGX_LAUNCH(k_match_project_frame, dim3(batch), dim3(SGX_MATCH_THREADS), (sgx_stream_t)stream, cap,
+    static const int mthreads = getenv("SGX_TUNE_MATCH_THREADS") ? atoi(getenv("SGX_TUNE_MATCH_THREADS")) : SGX_MATCH_THREADS;   // env = tuning tap (64..1024)
+    SGX_LAUNCH(k_match_project_frame, dim3(batch), dim3(mthreads), (sgx_stream_t)stream, cap,
                (const uint8_t *)d_ckeys, d_cdesc, d_curight, d_cn, d_cTcw, (const uint8_t *)d_lkeys, d_ln, d_l_has_mp, d_l_outlier,
                d_l_xw, d_l_obs, d_l_mpdesc, d_lTcw, to_cam(cam), sc, th, b_mono, check_orientation, d_cur_match, d_nmatches);
     sgx_prof_end(SGX_K_MATCH, (sgx_stream_t)stream);
