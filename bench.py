@@ -59,6 +59,7 @@ def main():
     ap.add_argument('--streams', type=int, default=256, help='independent streams per GPU (frames per step)')
     ap.add_argument('--frames', type=int, default=6, help='distinct frames kept per stream (ping-pong replay)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-cpu-all-cores', action='store_true', help='skip the frames-parallel all-host-cores CPU baseline (keeps the 1-core figure)')
     ap.add_argument('--no-pipeline', action='store_true', help='single HIP stream (no overlap of extraction with match/pose-opt)')
     ap.add_argument('--no-local-map', action='store_true', help='skip the TrackLocalMap stage (local-map SearchByProjection + second PoseOptimization)')
     ap.add_argument('--no-mask', action='store_true', help='skip the dynamic-feature mask + erase stage (Frame::RmDynamicPointWithSemanticAndGeometry)')
@@ -196,53 +197,41 @@ def main():
 
     cpu = None
     if not args.no_cpu_baseline and world == 1:
-        # the oracle chained exactly like the tracker (checker/baseline leg only — never the measured product path)
-        from oracle import oracle as orc
-        sf = orc.orb_params()['scale']; is2 = orc.orb_params()['inv_sigma2']
+        # the oracle chained exactly like the tracker (checker/baseline leg only — never the measured product path): 1 core in-process, then
+        # frames-parallel on all host cores (one worker process per core, each its own stream), as SURVEY.md §8(d) asks
+        from oracle import cpu_chain
         n = args.cpu_sample
         depth_img = np.full((480, 640), depth_val, np.uint16)
-        orc.orb_extract(host[0, 0])
-        c0 = time.perf_counter()
-        last = None; done = 0; s = 0
         use_lm = not args.no_local_map
-        def cpu_map_points(fr):        # MapPoint(Pos, pMap, pFrame, idx) glue of the oracle chain (numpy)
-            Tm = fr['Tcw'].astype('f8'); Ow = (-(Tm[:3, :3].T @ Tm[:3, 3])).astype('f4')
-            PO = fr['xw'] - Ow[None]; nrm = np.sqrt((PO.astype('f8') ** 2).sum(1)); nrm[nrm == 0] = 1
-            mx = (nrm * sf[fr['keys']['octave']]).astype('f4')
-            return dict(xw=fr['xw'], normal=(PO / nrm[:, None]).astype('f4'), min_dist=(mx / sf[-1]).astype('f4'), max_dist=mx, desc=fr['desc'],
-                        skip=(fr['has_mp'] == 0).astype(np.uint8), obs=np.ones(len(mx), 'i4'))
-        def cat(ds): return {k2: np.concatenate([d_[k2] for d_ in ds]) for k2 in ds[0]}
-        while done < n:
-            Tcur = gen.Tcw(t0s[s]).astype('f4'); ring = []
-            for i in range(min(len(order) * 2, n - done)):
-                g = host[order[i % len(order)], s]
-                k, d = orc.orb_extract(g)
-                ur, z = orc.compute_stereo_from_rgbd(k, depth_img, cam['bf'], cam['depth_factor'])
-                if last is not None and i > 0:
-                    cur = dict(keys=k, desc=d, uright=ur, Tcw=Tcur)
-                    m, nm = orc.search_by_projection_frame(cur, last, cam, sf, th=15)
-                    fr2 = dict(keys=k, uright=ur, has_mp=(m >= 0).astype(np.uint8), Tcw=Tcur,
-                               xw=np.where((m >= 0)[:, None], last['xw'][np.maximum(m, 0)], 0).astype('f4'))
-                    _, Tcur, out1 = orc.pose_optimization(fr2, cam, is2)
-                    if use_lm:
-                        keep = (m >= 0) & (out1 == 0)
-                        merged_xw = np.where(keep[:, None], fr2['xw'], 0).astype('f4'); has2 = keep.copy()
-                        if ring:
-                            lm = cat(ring[-2:])
-                            ml, _, _ = orc.search_by_projection_local(dict(keys=k, desc=d, uright=ur, Tcw=Tcur, mp_obs=np.where(keep, 0, -1).astype('i4')),
-                                                                      lm, cam, sf, th=3.0, nnratio=0.8, viewing_cos_limit=0.5)
-                            merged_xw = np.where((ml >= 0)[:, None], lm['xw'][np.maximum(ml, 0)], merged_xw).astype('f4'); has2 |= ml >= 0
-                        _, Tcur, _ = orc.pose_optimization(dict(keys=k, uright=ur, has_mp=has2.astype(np.uint8), Tcw=Tcur, xw=merged_xw), cam, is2)
-                        ring.append(cpu_map_points(last))
-                xw, has = orc.unproject_stereo(k, z, Tcur, cam)
-                last = dict(keys=k, desc=d, uright=ur, Tcw=Tcur, has_mp=has, outlier=np.zeros(len(k), np.uint8), xw=xw,
-                            obs=np.zeros(len(k), 'i4'), mpdesc=d)
-                done += 1
-            s = (s + 1) % S; last = None
-        cdt = time.perf_counter() - c0
+        cdt = cpu_chain.run_chain([host[t, 0] for t in range(T)], depth_img, cam, gen.Tcw(t0s[0]), order, n, use_lm)
         cpu = {'value': n / cdt, 'unit': 'frames/s', 'cores': 1, 'kind': 'port',
-               'sample': f'{n} frames of the same synthetic streams through the oracle chain (orb_extract + stereo + SearchByProjection + '
-                         f'PoseOptimization + {"local-map SearchByProjection + PoseOptimization + " if use_lm else ""}unproject), 1 thread; host has {os.cpu_count()} cores'}
+               'sample': f'{n} frames of one synthetic stream through the oracle chain (orb_extract + stereo + SearchByProjection + '
+                         f'PoseOptimization + {"local-map SearchByProjection + PoseOptimization + " if use_lm else ""}unproject; the mask stage and the '
+                         f'LK / RANSAC of the reference are not included), 1 thread; host has {os.cpu_count()} cores'}
+        if not args.no_cpu_all_cores:
+            import subprocess, tempfile
+            P = max(1, min(os.cpu_count() or 1, 128)); n_per = max(12, args.cpu_sample // 10)
+            start = os.path.join(tempfile.mkdtemp(prefix='sgx_cpu_'), 'go')
+            env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
+            procs = [subprocess.Popen([sys.executable, '-m', 'oracle.cpu_chain', '--index', str(k), '--frames', str(T), '--n', str(n_per), '--start-file', start] +
+                                      (['--no-local-map'] if not use_lm else []), cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for k in range(P)]
+            try:
+                for pr in procs:
+                    pr.stdout.readline()                                 # READY (frames synthesised, library loaded)
+                open(start, 'w').close()
+                w0 = time.perf_counter()
+                secs = []
+                for pr in procs:
+                    line = pr.stdout.readline().split()
+                    if len(line) == 3 and line[0] == 'SECONDS': secs.append(float(line[1]))
+                wall = time.perf_counter() - w0
+                if len(secs) == P:
+                    cpu.update({'value_all_cores': P * n_per / wall, 'cores_all': P,
+                                'sample_all_cores': f'{P} worker processes (one per core, each its own stream) x {n_per} frames, started together; {P * n_per} frames / wall time'})
+            finally:
+                for pr in procs:
+                    try: pr.wait(timeout=5)
+                    except Exception: pr.kill()
 
     out = {
         'metric': 'tracked frames/sec (640x480 RGB-D)', 'value': fps, 'unit': 'frames/s', 'n_gpus': world,
