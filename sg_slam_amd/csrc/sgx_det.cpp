@@ -7,6 +7,7 @@
 #include "../../include/sgx.h"
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <map>
@@ -50,7 +51,15 @@ struct sgx_det {
     int loc_blob = -1, conf_blob = -1;
     SgxDetTab *d_xt = nullptr, *d_yt = nullptr; uint8_t *d_img = nullptr;
     double gmac = 0;
-    ~sgx_det() { for (void *p : dev) (void)hipFree(p); }
+#ifndef SGX_EMU
+    std::map<int, hipGraphExec_t> graphs;     // captured plan per batch size (launch-bound tail of ~100 small kernels -> one graph launch)
+#endif
+    ~sgx_det() {
+#ifndef SGX_EMU
+        for (auto &g : graphs) (void)hipGraphExecDestroy(g.second);
+#endif
+        for (void *p : dev) (void)hipFree(p);
+    }
     template <class Tp> int alloc(Tp **p, size_t n) { void *q = nullptr; if (hipMalloc(&q, (n ? n : 1) * sizeof(Tp)) != hipSuccess) return SGX_ERR_NOMEM; dev.push_back(q); *p = (Tp *)q; return SGX_OK; }
 };
 
@@ -429,6 +438,24 @@ extern "C" int sgx_det_forward_batch_dev(sgx_det *h, const uint8_t *d_img, int p
     if (!h || !d_img || batch < 1 || batch > h->max_batch || pitch < 3 * h->W) return SGX_ERR_INVALID;
     sgx_stream_t st = (sgx_stream_t)stream_;
     run_preprocess(h, d_img, pitch, batch, st);
+#ifndef SGX_EMU
+    // The plan after pre-processing only touches the handle's own blobs, so it is captured once per batch size into a hipGraph and replayed
+    // (needs a non-default stream; SGX_DET_NO_GRAPH=1 or the legacy stream falls back to individual launches).
+    static const bool no_graph = getenv("SGX_DET_NO_GRAPH") != nullptr;
+    if (st != nullptr && !no_graph) {
+        auto it = h->graphs.find(batch);
+        if (it == h->graphs.end()) {
+            hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+            SGX_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            for (const Op &op : h->ops) run_op(h, op, batch, st);
+            SGX_CHECK_HIP(hipStreamEndCapture(st, &graph));
+            SGX_CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(graph);
+            it = h->graphs.emplace(batch, exec).first;
+        }
+        SGX_CHECK_HIP(hipGraphLaunch(it->second, st));
+    } else
+#endif
     for (const Op &op : h->ops) run_op(h, op, batch, st);
     SGX_CHECK_HIP(hipGetLastError());
     if (d_loc) *d_loc = h->blobs[h->loc_blob].d;

@@ -28,3 +28,35 @@ def test_compact_gpu(gpulib):
     import torch
     from test_detector import run_compact
     run_compact(gpulib, to_dev=lambda a: torch.from_numpy(a.view(np.uint8) if a.dtype.fields else a).cuda(), to_host=lambda t: t.cpu().numpy())
+
+
+def test_forward_graph_replay_equals_plain_launches(gpulib, model):
+    """sgx_det_forward_batch_dev on a non-default stream captures the plan into a hipGraph and replays it: same loc / conf as individual launches."""
+    import ctypes as C
+    import torch
+    from sg_slam_amd.capi import _vp
+    from sg_slam_amd.detector import Detector2D
+    from test_detector import PARAM, make_image
+    layers, W, blob = model
+    det = Detector2D(0.9, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=2, lib=gpulib)
+    imgs = torch.from_numpy(np.stack([make_image(5), make_image(6)])).cuda()
+    dl, dc = C.c_void_p(), C.c_void_p()
+    nl, nc = det.num_priors * 4, det.num_priors * det.num_class
+    def grab():
+        torch.cuda.synchronize()
+        out = []
+        for ptr, n in ((dl, nl), (dc, nc)):
+            host = np.zeros(2 * n, 'f4'); t = torch.zeros(2 * n, dtype=torch.float32, device='cuda')
+            C.cdll.LoadLibrary('libamdhip64.so').hipMemcpy(C.c_void_p(t.data_ptr()), ptr, C.c_size_t(8 * n), 3)
+            out.append(t.cpu().numpy())
+        return out
+    gpulib.check(gpulib.dll.sgx_det_forward_batch_dev(det.h, _vp(imgs), 640 * 3, 2, C.byref(dl), C.byref(dc), None))
+    plain = grab()
+    s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+    for _ in range(2):       # first call captures + launches, second replays
+        gpulib.check(gpulib.dll.sgx_det_forward_batch_dev(det.h, _vp(imgs), 640 * 3, 2, C.byref(dl), C.byref(dc), C.c_void_p(s.cuda_stream)))
+    s.synchronize()
+    graph = grab()
+    for a, b in zip(plain, graph):
+        assert (a == b).all()
+    det.close()

@@ -19,7 +19,8 @@ BATCHES = [int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else [1,
 for B in BATCHES:
     det = Detector2D(0.9, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=B, lib=lib)
     img = torch.randint(0, 256, (B, 480, 640, 3), dtype=torch.uint8, device='cuda')
-    st = torch.cuda.current_stream().cuda_stream
+    ts = torch.cuda.Stream(); st = ts.cuda_stream          # a non-default stream: the plan is replayed as a hipGraph
+    ts.wait_stream(torch.cuda.current_stream())
     dl = C.c_void_p(); dc = C.c_void_p()
     def fwd(): lib.check(lib.dll.sgx_det_forward_batch_dev(det.h, _vp(img), 640 * 3, B, C.byref(dl), C.byref(dc), _vp(st)))
     for _ in range(3): fwd()
