@@ -4,7 +4,6 @@
 #include "sgx_prof.h"
 #include "../../include/sgx.h"
 #include <stdio.h>
-#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -29,33 +28,10 @@ extern "C" int sgx_pose_optimization_batch_dev(int batch, int cap, const sgx_key
     // threads per frame: four waves.  The one-wave variant (tap below) is kept for tuning: measured on MI355X it is 2x slower per launch at every
     // batch size (0.67 vs 0.35 ms at 64-256 frames, tools/bench_poseopt.py) because its 85 KB of LDS still limits a CU to one frame at a time.
     const int wide = g_po_threads ? (g_po_threads == 256) : 1;
-    const int ecap = cap < SGX_PO_CAP ? cap : SGX_PO_CAP;
-    size_t lds = (size_t)ecap * (24 + 12 + 12 + 4 + 2 + 1) + 16;                  // per-edge arrays (fp64 error, obs, point, info, keypoint index, flags)
-    // Tuning tap (off by default): from SGX_TUNE_PO_SCRATCH_FROM frames per call the per-edge arrays go to a global scratch slice, so the workgroup's LDS
-    // footprint drops from ~90 KB to ~34 KB.  Measured on MI355X it does not pay: 0.47 vs 0.37 ms alone at 256 frames, and 88 k vs 91 k frames/s in the
-    // two-stream bench — the co-resident extraction kernels are not LDS-starved.  Grow-only scratch, one per process; calls must be stream-ordered.
-    uint8_t *scratch = nullptr;
-    static const int scratch_from = getenv("SGX_TUNE_PO_SCRATCH_FROM") ? atoi(getenv("SGX_TUNE_PO_SCRATCH_FROM")) : 0x7FFFFFFF;
-    if (batch >= scratch_from) {
-        static uint8_t *g_scratch = nullptr; static size_t g_scratch_bytes = 0;
-        const size_t per = ((size_t)ecap * 55 + 63) & ~(size_t)63, need = per * (size_t)batch;
-        if (need > g_scratch_bytes) {
-            SGX_CHECK_HIP(hipStreamSynchronize((sgx_stream_t)stream));
-            if (g_scratch) (void)hipFree(g_scratch);
-            void *p = nullptr; if (hipMalloc(&p, need) != hipSuccess) { g_scratch = nullptr; g_scratch_bytes = 0; return SGX_ERR_NOMEM; }
-            g_scratch = (uint8_t *)p; g_scratch_bytes = need;
-        }
-        scratch = g_scratch; lds = 16;
-    }
-#ifndef SGX_EMU
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_pose_opt<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-                     (void)hipFuncSetAttribute((const void *)k_pose_opt<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr_set = true; }
-#endif
-    if (wide) { auto kfn = k_pose_opt<256>; SGX_LAUNCH_DYN(kfn, dim3(batch), dim3(256), lds, (sgx_stream_t)stream, cap, (const uint8_t *)d_keys_un, d_uright, d_n,
-                                                       d_mp_index, d_has_mp, d_mp_xw, xw_pitch, is2, po_cam(cam), d_Tcw, d_outlier, d_n_inliers, scratch); }
-    else { auto kfn = k_pose_opt<64>; SGX_LAUNCH_DYN(kfn, dim3(batch), dim3(64), lds, (sgx_stream_t)stream, cap, (const uint8_t *)d_keys_un, d_uright, d_n,
-                                                 d_mp_index, d_has_mp, d_mp_xw, xw_pitch, is2, po_cam(cam), d_Tcw, d_outlier, d_n_inliers, scratch); }
+    if (wide) { auto kfn = k_pose_opt<256>; SGX_LAUNCH(kfn, dim3(batch), dim3(256), (sgx_stream_t)stream, cap, (const uint8_t *)d_keys_un, d_uright, d_n,
+                                                       d_mp_index, d_has_mp, d_mp_xw, xw_pitch, is2, po_cam(cam), d_Tcw, d_outlier, d_n_inliers); }
+    else { auto kfn = k_pose_opt<64>; SGX_LAUNCH(kfn, dim3(batch), dim3(64), (sgx_stream_t)stream, cap, (const uint8_t *)d_keys_un, d_uright, d_n,
+                                                 d_mp_index, d_has_mp, d_mp_xw, xw_pitch, is2, po_cam(cam), d_Tcw, d_outlier, d_n_inliers); }
     sgx_prof_end(SGX_K_POSEOPT, (sgx_stream_t)stream);
     SGX_CHECK_HIP(hipGetLastError());
     return SGX_OK;

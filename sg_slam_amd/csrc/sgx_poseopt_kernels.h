@@ -29,23 +29,14 @@
 template <int NTT>
 SGX_KERNEL(NTT) k_pose_opt(int cap, const uint8_t *keys_raw, const float *uright, const int *n_kp,
                                       const int *mp_index, const uint8_t *has_mp, const float *xw, int xw_pitch,
-                                      SgxScales inv_sigma2, SgxCam cam, float *Tcw, uint8_t *outlier, int *n_inliers, uint8_t *edge_scratch)
+                                      SgxScales inv_sigma2, SgxCam cam, float *Tcw, uint8_t *outlier, int *n_inliers)
 {
-    // LDS.  The per-edge arrays are carved from a dynamic pool sized by the caller's keypoint capacity (55 B per edge), and only NB threads build
-    // the normal equations (their 27 partial sums are what needs LDS rows): 85 KB at cap 1024 instead of 130 KB, so the extraction kernels that
-    // share the CU keep half of its LDS (a CU hosts one of these workgroups per stream batch for most of a step).
-    SGX_DYN_LDS(pool);
-    const int ecap = min(cap, SGX_PO_CAP);
-    // edge_scratch != nullptr: the per-edge arrays live in a global scratch slice of this frame (L2-resident, read coalesced once per pass) and the
-    // workgroup keeps only ~34 KB of LDS; nullptr: they are carved from the dynamic LDS pool (lowest latency for small batches)
-    double *e_err = edge_scratch ? (double *)(edge_scratch + (size_t)blockIdx.x * (((size_t)ecap * 55 + 63) & ~(size_t)63)) : (double *)pool;   // [3 * ecap]
-    float *e_obs = (float *)(e_err + 3 * (size_t)ecap), *e_xw = e_obs + 3 * (size_t)ecap, *e_info = e_xw + 3 * (size_t)ecap;
-    uint16_t *e_kp = (uint16_t *)(e_info + ecap);
-    uint8_t *e_flags = (uint8_t *)(e_kp + ecap);          // bit0 stereo, bit1 level==1 (excluded), bit2 robust kernel on, bit3 outlier flag
-    constexpr int NB = NTT < 128 ? NTT : 128;      // threads that linearise (buildSystem)
-    constexpr int NG = NTT / 32, NGB = NB / 32;    // reduction groups of 32 threads (chi2 pass / buildSystem pass)
-    SGX_LDS double part[NB * SGX_PO_NRED];
-    SGX_LDS double cpart[NTT];
+    SGX_LDS float e_obs[SGX_PO_CAP * 3], e_xw[SGX_PO_CAP * 3], e_info[SGX_PO_CAP];
+    SGX_LDS double e_err[SGX_PO_CAP * 3];
+    SGX_LDS uint16_t e_kp[SGX_PO_CAP];
+    SGX_LDS uint8_t e_flags[SGX_PO_CAP];          // bit0 stereo, bit1 level==1 (excluded), bit2 robust kernel on, bit3 outlier flag
+    constexpr int NG = NTT / 32;                   // reduction groups of 32 threads
+    SGX_LDS double part[NTT * SGX_PO_NRED];
     SGX_LDS double part2[SGX_PO_NRED * NG];
     SGX_LDS double red[SGX_PO_NRED];
     SGX_LDS int scan[NTT];
@@ -119,11 +110,11 @@ SGX_KERNEL(NTT) k_pose_opt(int cap, const uint8_t *keys_raw, const float *uright
         if (fl & 4) { double r0, r1; sgx_huber(c2, (fl & 1) ? deltaStereo : deltaMono, &r0, &r1); chi += r0; } \
         else chi += c2;                                                                                     \
     }                                                                                                       \
-    cpart[tid] = chi;                                                                                       \
+    part[tid * SGX_PO_NRED + 27] = chi;                                                                     \
     SGX_THREADS_END                                                                                         \
     SGX_SYNC();                                                                                             \
     SGX_THREADS_BEGIN(tid)                                                                                  \
-    if (tid < NG) { double s = 0; for (int l = 0; l < 32; l++) s += cpart[tid * 32 + l]; part2[27 * NG + tid] = s; }                     \
+    if (tid < NG) { double s = 0; for (int l = 0; l < 32; l++) s += part[(tid * 32 + l) * SGX_PO_NRED + 27]; part2[27 * NG + tid] = s; } \
     SGX_THREADS_END                                                                                         \
     SGX_SYNC();                                                                                             \
     SGX_THREADS_BEGIN(tid)                                                                                  \
@@ -145,7 +136,7 @@ SGX_KERNEL(NTT) k_pose_opt(int cap, const uint8_t *keys_raw, const float *uright
             double acc[27];
 #pragma unroll
             for (int k = 0; k < 27; k++) acc[k] = 0;
-            for (int e = tid; e < ne && tid < NB; e += NB) {
+            for (int e = tid; e < ne; e += NT) {
                 const int fl = e_flags[e];
                 if (fl & 2) continue;
                 const int stereo = fl & 1;
@@ -179,18 +170,16 @@ SGX_KERNEL(NTT) k_pose_opt(int cap, const uint8_t *keys_raw, const float *uright
                     }
                 }
             }
-            if (tid < NB) {
 #pragma unroll
-                for (int k = 0; k < 27; k++) part[tid * SGX_PO_NRED + k] = acc[k];
-            }
+            for (int k = 0; k < 27; k++) part[tid * SGX_PO_NRED + k] = acc[k];
             SGX_THREADS_END
             SGX_SYNC();
             SGX_THREADS_BEGIN(tid)
-            if (tid < 27 * NGB) { const int c = tid / NGB, j = tid - c * NGB; double s = 0; for (int l = 0; l < 32; l++) s += part[(j * 32 + l) * SGX_PO_NRED + c]; part2[c * NG + j] = s; }
+            if (tid < 27 * NG) { const int c = tid / NG, j = tid - c * NG; double s = 0; for (int l = 0; l < 32; l++) s += part[(j * 32 + l) * SGX_PO_NRED + c]; part2[c * NG + j] = s; }
             SGX_THREADS_END
             SGX_SYNC();
             SGX_THREADS_BEGIN(tid)
-            if (tid < 27) { double s = 0; for (int l = 0; l < NGB; l++) s += part2[tid * NG + l]; red[tid] = s; }
+            if (tid < 27) { double s = 0; for (int l = 0; l < NG; l++) s += part2[tid * NG + l]; red[tid] = s; }
             SGX_THREADS_END
             SGX_SYNC();
             double H[6][6], b[6];
