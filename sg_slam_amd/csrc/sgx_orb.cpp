@@ -341,7 +341,8 @@ extern "C" int sgx_orb_extract_batch_dev(sgx_orb *h, const uint8_t *d_gray, int 
     sgx_prof_end(SGX_K_RESIZE, stream);
     sgx_prof_begin(SGX_K_FAST, stream);
     static const int fast_threads = getenv("SGX_TUNE_FAST_THREADS") ? atoi(getenv("SGX_TUNE_FAST_THREADS")) : 128;      // workgroup size; env = tuning tap (64..SGX_FAST_THREADS)
-    SGX_LAUNCH_DYN(k_fast_cells, dim3(g.ncells * batch), dim3(fast_threads), g.fast_lds_bytes, stream, g, h->d_cells, d_gray, pitch, h->d_pyr, batch,
+    static const int e_extra = getenv("SGX_TUNE_E_EXTRA_LDS") ? atoi(getenv("SGX_TUNE_E_EXTRA_LDS")) : 0;   // tuning tap: pad the extraction kernels' LDS to cap their occupancy
+    SGX_LAUNCH_DYN(k_fast_cells, dim3(g.ncells * batch), dim3(fast_threads), g.fast_lds_bytes + e_extra, stream, g, h->d_cells, d_gray, pitch, h->d_pyr, batch,
                h->d_cand, h->d_cand_count, h->d_status);
     sgx_prof_end(SGX_K_FAST, stream);
     sgx_prof_begin(SGX_K_OCTREE, stream);
@@ -350,7 +351,7 @@ extern "C" int sgx_orb_extract_batch_dev(sgx_orb *h, const uint8_t *d_gray, int 
     sgx_prof_begin(SGX_K_ORIENT_DESC, stream);
     unsigned long long umax_packed = 0;
     for (int i = 0; i < 16; i++) umax_packed |= (unsigned long long)(h->umax_h[i] & 15) << (4 * i);
-    SGX_LAUNCH(k_orient_desc, dim3(g.kp_cap * batch), dim3(64), stream, g, d_gray, pitch, h->d_pyr, h->d_sel, h->d_sel_count,
+    SGX_LAUNCH_DYN(k_orient_desc, dim3(g.kp_cap * batch), dim3(64), e_extra / 2, stream, g, d_gray, pitch, h->d_pyr, h->d_sel, h->d_sel_count,
                umax_packed, h->d_pattern, (uint8_t *)d_kps, d_desc, d_count, cap, batch, h->d_status);
     sgx_prof_end(SGX_K_ORIENT_DESC, stream);
     SGX_CHECK_HIP(hipGetLastError());
