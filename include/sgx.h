@@ -129,6 +129,10 @@ int sgx_match_project_local_batch_dev(
     const sgx_camera *cam, const float *scale_factors, int nlevels, float log_scale_factor, float th, float nnratio, float viewing_cos_limit,
     int32_t *d_cur_match, int32_t *d_nmatches, uint8_t *d_in_view, void *stream);
 
+/* The colour conversion at the top of Tracking::GrabImageRGBD (src/sg-slam/src/Tracking.cc:214-227): cvtColor(CV_RGB2GRAY / CV_BGR2GRAY / CV_RGBA2GRAY / CV_BGRA2GRAY) on
+ * 8-bit images, OpenCV's fixed point (R*4899 + G*9617 + B*1868 + 8192) >> 14.  blue_first = !mbRGB.  Pitches in bytes, multiples of 4; pointers 4-byte aligned. */
+int sgx_frame_gray_from_color_batch_dev(int batch, int width, int height, const uint8_t *d_src, int src_pitch, int channels, int blue_first,
+                                        uint8_t *d_gray, int gray_pitch, void *stream);
 /* ---- per-frame glue between the accelerated stages (device resident) -----------------------------
  * Frame::ComputeStereoFromRGBD (Frame.cc:893-914) fused with the u16 -> metres conversion
  * (Tracking.cc:229-230): uright[i] = x - bf/d, zdepth[i] = d, or -1 when depth is 0. */

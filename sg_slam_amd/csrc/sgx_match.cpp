@@ -172,3 +172,13 @@ extern "C" int sgx_match_project_frame(
     SGX_CHECK_HIP(hipStreamSynchronize(0));
     return SGX_OK;
 }
+
+extern "C" int sgx_frame_gray_from_color_batch_dev(int batch, int width, int height, const uint8_t *d_src, int src_pitch, int channels, int blue_first,
+                                                   uint8_t *d_gray, int gray_pitch, void *stream)
+{
+    if (batch < 1 || width < 1 || height < 1 || !d_src || !d_gray || (channels != 3 && channels != 4) || src_pitch < width * channels || gray_pitch < width ||
+        (src_pitch & 3) || (gray_pitch & 3) || ((uintptr_t)d_src & 3) || ((uintptr_t)d_gray & 3)) return SGX_ERR_INVALID;
+    SGX_LAUNCH(k_gray_from_color, dim3((width + 255) / 256, height, batch), dim3(64), (sgx_stream_t)stream, width, height, d_src, src_pitch, channels, blue_first ? 1 : 0, d_gray, gray_pitch);
+    SGX_CHECK_HIP(hipGetLastError());
+    return SGX_OK;
+}

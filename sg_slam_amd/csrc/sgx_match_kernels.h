@@ -658,3 +658,39 @@ SGX_KERNEL(256) k_gather_xw(int cap, const float *xw_last, const float *m_xw, fl
     }
     SGX_THREADS_END
 }
+
+// ---------------------------------------------------------------------------------------------
+// k_gray_from_color: the cvtColor at the top of Tracking::GrabImageRGBD (Tracking.cc:214-227): CV_RGB2GRAY / CV_BGR2GRAY (3 channels) or
+// CV_RGBA2GRAY / CV_BGRA2GRAY (4 channels) on 8-bit images, OpenCV's fixed-point form
+//   gray = (R*4899 + G*9617 + B*1868 + (1 << 13)) >> 14            (R2Y, G2Y, B2Y at yuv_shift 14, rounding CV_DESCALE)
+// One thread per 4 output pixels: 3 (or 4) aligned dword loads, one dword store.  grid = (ceil(W/4/64), H, B), block 64.
+// ---------------------------------------------------------------------------------------------
+SGX_KERNEL(64) k_gray_from_color(int W, int H, const uint8_t *src, int src_pitch, int channels, int blue_first, uint8_t *dst, int dst_pitch)
+{
+    SGX_THREADS_BEGIN(tid)
+    const int x4 = ((int)blockIdx.x * 64 + tid) * 4, y = (int)blockIdx.y, b = (int)blockIdx.z;
+    if (x4 < W) {
+        const uint8_t *row = src + ((size_t)b * H + y) * src_pitch + (size_t)x4 * channels;
+        uint32_t out = 0;
+        const int c0 = blue_first ? 1868 : 4899, c2 = blue_first ? 4899 : 1868;
+        uint32_t w[4];
+        const int nd = channels;                               // 4 pixels = `channels` dwords
+        for (int i = 0; i < 4; i++) w[i] = (i < nd && x4 + 4 <= W) ? ((const uint32_t *)row)[i] : 0u;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (x4 + i < W) {
+                int p0, p1, p2;
+                if (x4 + 4 <= W) {
+                    const int o = i * channels;                // byte offset of the pixel inside the 4-pixel group
+                    p0 = (w[o >> 2] >> (8 * (o & 3))) & 255; p1 = (w[(o + 1) >> 2] >> (8 * ((o + 1) & 3))) & 255; p2 = (w[(o + 2) >> 2] >> (8 * ((o + 2) & 3))) & 255;
+                } else { p0 = row[i * channels]; p1 = row[i * channels + 1]; p2 = row[i * channels + 2]; }     // ragged row end: byte loads
+                const int v = (p0 * c0 + p1 * 9617 + p2 * c2 + (1 << 13)) >> 14;
+                out |= (uint32_t)v << (8 * i);
+            }
+        }
+        uint8_t *d = dst + ((size_t)b * H + y) * dst_pitch + x4;
+        if (x4 + 4 <= W) *(uint32_t *)d = out;
+        else for (int i = 0; x4 + i < W; i++) d[i] = (uint8_t)(out >> (8 * i));
+    }
+    SGX_THREADS_END
+}

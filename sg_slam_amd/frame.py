@@ -41,3 +41,9 @@ def compact_keys_batch(lib, batch, cap, d_keys, d_desc, d_n, d_keep, d_have_dyna
     their descriptor rows, with the "restore all when < 0.1*nFeatures survive and a dynamic object is present" rule."""
     lib.check(lib.dll.sgx_frame_compact_keys_batch_dev(batch, cap, _vp(d_keys), _vp(d_desc), _vp(d_n), _vp(d_keep), _vp(d_have_dynamic), int(nfeatures),
                                                        _vp(d_keys_out), _vp(d_desc_out), _vp(d_n_out), _vp(stream)), 'sgx_frame_compact_keys_batch_dev')
+
+
+def gray_from_color_batch(lib, batch, width, height, d_src, src_pitch, channels, blue_first, d_gray, gray_pitch, stream=None):
+    """cvtColor(..., CV_{RGB,BGR,RGBA,BGRA}2GRAY) of Tracking::GrabImageRGBD (Tracking.cc:214-227) on device images."""
+    lib.check(lib.dll.sgx_frame_gray_from_color_batch_dev(batch, width, height, _vp(d_src), src_pitch, channels, 1 if blue_first else 0, _vp(d_gray), gray_pitch, _vp(stream)),
+              'sgx_frame_gray_from_color_batch_dev')

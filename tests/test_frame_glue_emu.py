@@ -82,3 +82,25 @@ def test_map_glue_emu(emu, oracle, stream_frames):
 
 def test_glue_emu(emu, oracle, stream_frames):
     run_glue(emu, oracle, stream_frames)
+
+
+def run_gray(lib, to_dev=lambda a: a, to_host=lambda a: a):
+    """cvtColor to gray (Tracking.cc:214-227): OpenCV's fixed-point formula, every channel order, ragged widths."""
+    rng = np.random.RandomState(2)
+    for (w, h, ch) in ((640, 480, 3), (644, 7, 4), (61, 5, 3), (3, 2, 4)):
+        pitch = (w * ch + 3) & ~3; gp = (w + 3) & ~3
+        src = np.zeros((2, h, pitch), np.uint8); src[:, :, :w * ch] = rng.randint(0, 256, (2, h, w * ch))
+        src[0, 0, :ch] = 255; src[0, 0, ch:2 * ch] = 0
+        for blue_first in (0, 1):
+            dst = to_dev(np.full((2, h, gp), 7, np.uint8))
+            fr.gray_from_color_batch(lib, 2, w, h, to_dev(src), pitch, ch, blue_first, dst, gp)
+            got = to_host(dst)
+            px = src[:, :, :w * ch].reshape(2, h, w, ch).astype(np.int64)
+            r, g, b = (px[..., 2], px[..., 1], px[..., 0]) if blue_first else (px[..., 0], px[..., 1], px[..., 2])
+            exp = (r * 4899 + g * 9617 + b * 1868 + 8192) >> 14
+            assert (got[:, :, :w] == exp).all() and (got[:, :, w:] == 7).all(), (w, h, ch, blue_first)
+            assert got[0, 0, 0] == 255 and got[0, 0, 1] == 0
+
+
+def test_gray_emu(emu):
+    run_gray(emu)

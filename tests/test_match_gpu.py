@@ -40,3 +40,9 @@ def test_map_glue_gpu(gpulib, oracle, stream_frames):
     run_map_glue(gpulib, oracle, stream_frames,
                  to_dev=lambda a: torch.from_numpy(a.view(np.uint8) if a.dtype.fields else (a.view(np.int16) if a.dtype == np.uint16 else a)).cuda(),
                  to_host=lambda t: t.cpu().numpy())
+
+
+def test_gray_gpu(gpulib):
+    import torch
+    from test_frame_glue_emu import run_gray
+    run_gray(gpulib, to_dev=lambda a: torch.from_numpy(a).cuda(), to_host=lambda t: t.cpu().numpy())
