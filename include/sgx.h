@@ -129,6 +129,11 @@ int sgx_match_project_local_batch_dev(
     const sgx_camera *cam, const float *scale_factors, int nlevels, float log_scale_factor, float th, float nnratio, float viewing_cos_limit,
     int32_t *d_cur_match, int32_t *d_nmatches, uint8_t *d_in_view, void *stream);
 
+/* Harness helper (bench.py / tests), NOT a reference entry point: the previous-frame position of every keypoint under a per-frame affine flow
+ * (prev = A * (x, y, 1), A = 6 floats), optionally displaced by shift[2] inside the frame's first box.  Stands in for cv::calcOpticalFlowPyrLK
+ * (Frame.cc:445, tier N1) when the dynamic-feature mask is exercised on synthetic streams whose flow is known exactly. */
+int sgx_debug_flow_affine_batch_dev(int batch, int cap, const sgx_keypoint *d_keys, const int32_t *d_n, const float *d_A, const float *d_shift, const float *d_boxes,
+                                    int max_boxes, float *d_prev_xy, void *stream);
 /* The colour conversion at the top of Tracking::GrabImageRGBD (src/sg-slam/src/Tracking.cc:214-227): cvtColor(CV_RGB2GRAY / CV_BGR2GRAY / CV_RGBA2GRAY / CV_BGRA2GRAY) on
  * 8-bit images, OpenCV's fixed point (R*4899 + G*9617 + B*1868 + 8192) >> 14.  blue_first = !mbRGB.  Pitches in bytes, multiples of 4; pointers 4-byte aligned. */
 int sgx_frame_gray_from_color_batch_dev(int batch, int width, int height, const uint8_t *d_src, int src_pitch, int channels, int blue_first,

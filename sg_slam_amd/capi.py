@@ -60,7 +60,7 @@ SYMBOLS = [
     'sgx_pose_optimization_batch_dev', 'sgx_pose_opt_debug_set_threads', 'sgx_pose_optimization', 'sgx_frame_motion_model_batch_dev',
     'sgx_local_bundle_adjustment',
     'sgx_det_create', 'sgx_det_destroy', 'sgx_det_info', 'sgx_det_detect', 'sgx_det_forward_batch_dev', 'sgx_det_debug_read_blob',
-    'sgx_frame_compact_keys_batch_dev', 'sgx_frame_gray_from_color_batch_dev', 'sgx_det_debug_set_fusion', 'sgx_det_debug_set_legacy_kernels', 'sgx_det_debug_time_ops', 'sgx_det_debug_op_desc',
+    'sgx_frame_compact_keys_batch_dev', 'sgx_frame_gray_from_color_batch_dev', 'sgx_debug_flow_affine_batch_dev', 'sgx_det_debug_set_fusion', 'sgx_det_debug_set_legacy_kernels', 'sgx_det_debug_time_ops', 'sgx_det_debug_op_desc',
     'sgx_dynamic_mask_batch_dev',
 ]
 
@@ -125,6 +125,7 @@ class SgxLib:
         d.sgx_det_debug_op_desc.argtypes = [vp, C.c_int, C.c_char_p, C.c_int]
         d.sgx_dynamic_mask_batch_dev.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp]
         d.sgx_frame_gray_from_color_batch_dev.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]
+        d.sgx_debug_flow_affine_batch_dev.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, vp]
         d.sgx_frame_compact_keys_batch_dev.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]
         d.sgx_match_project_local_batch_dev.argtypes = [C.c_int, C.c_int] + [vp] * 6 + [C.c_int] + [vp] * 8 + [C.POINTER(Camera), vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp, vp, vp]
         d.sgx_frame_make_map_points_batch_dev.argtypes = [C.c_int, C.c_int, C.c_int] + [vp] * 7 + [C.c_int] + [vp] * 7

@@ -182,3 +182,12 @@ extern "C" int sgx_frame_gray_from_color_batch_dev(int batch, int width, int hei
     SGX_CHECK_HIP(hipGetLastError());
     return SGX_OK;
 }
+
+extern "C" int sgx_debug_flow_affine_batch_dev(int batch, int cap, const sgx_keypoint *d_keys, const int32_t *d_n, const float *d_A, const float *d_shift, const float *d_boxes,
+                                               int max_boxes, float *d_prev_xy, void *stream)
+{
+    if (batch < 1 || cap < 1 || !d_keys || !d_n || !d_A || !d_prev_xy) return SGX_ERR_INVALID;
+    SGX_LAUNCH(k_flow_affine, dim3((cap + 255) / 256, batch), dim3(256), (sgx_stream_t)stream, cap, (const uint8_t *)d_keys, d_n, d_A, d_shift, d_boxes, max_boxes, d_prev_xy);
+    SGX_CHECK_HIP(hipGetLastError());
+    return SGX_OK;
+}

@@ -694,3 +694,23 @@ SGX_KERNEL(64) k_gray_from_color(int W, int H, const uint8_t *src, int src_pitch
     }
     SGX_THREADS_END
 }
+
+// k_flow_affine: harness stand-in for the LK tracker on synthetic streams (bench.py / tests; see sg_slam_amd/synth.py flow_affine): prev = A * (x, y, 1) per
+// keypoint, optionally displaced by `shift` inside the frame's first box (an independently moving object).  Not part of the reference path.
+SGX_KERNEL(256) k_flow_affine(int cap, const uint8_t *keys_raw, const int *n, const float *A, const float *shift, const float *boxes, int max_boxes, float *prev_xy)
+{
+    SGX_THREADS_BEGIN(tid)
+    const int f = (int)blockIdx.y, i = (int)blockIdx.x * 256 + tid;
+    if (i < cap) {
+        const float *kp = (const float *)(keys_raw + ((size_t)f * cap + i) * 28);
+        const float x = kp[0], y = kp[1];
+        const float *a = A + 6 * f;
+        float px = a[0] * x + a[1] * y + a[2], py = a[3] * x + a[4] * y + a[5];
+        if (shift && boxes) {
+            const float *bx = boxes + 4 * (size_t)f * max_boxes;
+            if (x > bx[0] && x < bx[0] + bx[2] && y > bx[1] && y < bx[1] + bx[3]) { px += shift[2 * f]; py += shift[2 * f + 1]; }
+        }
+        prev_xy[2 * ((size_t)f * cap + i)] = px; prev_xy[2 * ((size_t)f * cap + i) + 1] = py;
+    }
+    SGX_THREADS_END
+}

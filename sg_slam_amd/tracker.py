@@ -101,29 +101,12 @@ class TrackerBatch:
             else:
                 b[...] = T
 
-    def _prev_points(self, keys_raw, A, shift=None, boxes=None):
+    def _prev_points(self, keys_raw, A, shift, boxes, st):
         """prev_xy[s, i] = A[s] * (x, y, 1) of keypoint i: the stand-in for the LK tracker on synthetic streams (see synth.flow_affine);
         `shift` (S,2) moves the previous position of keypoints inside the first box of `boxes` (an independently moving object)."""
-        S, cap = self.S, self.cap
-        if self.xp == 'torch':
-            import torch
-            kf = keys_raw.view(torch.float32).view(S, cap, 7)
-            x, y = kf[..., 0], kf[..., 1]
-            px = A[:, 0:1] * x + A[:, 1:2] * y + A[:, 2:3]; py = A[:, 3:4] * x + A[:, 4:5] * y + A[:, 5:6]
-            if shift is not None:
-                bx = boxes[:, 0, :]
-                inside = (x > bx[:, 0:1]) & (x < bx[:, 0:1] + bx[:, 2:3]) & (y > bx[:, 1:2]) & (y < bx[:, 1:2] + bx[:, 3:4])
-                px = px + inside * shift[:, 0:1]; py = py + inside * shift[:, 1:2]
-            self.prev_xy.copy_(torch.stack([px, py], -1))
-        else:
-            kf = keys_raw.view(np.float32).reshape(S, cap, 7)
-            x, y = kf[..., 0], kf[..., 1]
-            px = A[:, 0:1] * x + A[:, 1:2] * y + A[:, 2:3]; py = A[:, 3:4] * x + A[:, 4:5] * y + A[:, 5:6]
-            if shift is not None:
-                bx = boxes[:, 0, :]
-                inside = (x > bx[:, 0:1]) & (x < bx[:, 0:1] + bx[:, 2:3]) & (y > bx[:, 1:2]) & (y < bx[:, 1:2] + bx[:, 3:4])
-                px = px + inside * shift[:, 0:1]; py = py + inside * shift[:, 1:2]
-            self.prev_xy[...] = np.stack([px, py], -1).astype(np.float32)
+        L = self.lib
+        L.check(L.dll.sgx_debug_flow_affine_batch_dev(self.S, self.cap, _vp(keys_raw), _vp(self.rn), _vp(A), _vp(shift), _vp(boxes if shift is not None else None),
+                                                      self.max_boxes, _vp(self.prev_xy), st), 'flow affine')
 
     def step(self, d_gray, d_depth, stream=None, gray_pitch=None, mask=None):
         """Track the next frame of every stream.  d_gray: S x H x W u8, d_depth: S x H x W u16 (raw, DepthMapFactor 5000).
@@ -152,12 +135,7 @@ class TrackerBatch:
         else:
             self.ex.extract_batch_dev(d_gray, gray_pitch or self.W, S, self.rkeys, self.rdesc, self.rn, stream=stE)
             boxes = mask.get('boxes', self.no_boxes); nboxes = mask.get('nboxes', self.no_nboxes)
-            if self.pipelined:
-                import torch
-                with torch.cuda.stream(self.sE):
-                    self._prev_points(self.rkeys, mask['A'], mask.get('shift'), boxes)
-            else:
-                self._prev_points(self.rkeys, mask['A'], mask.get('shift'), boxes)
+            self._prev_points(self.rkeys, mask['A'], mask.get('shift'), boxes, _vp(stE))
             L.check(L.dll.sgx_dynamic_mask_batch_dev(S, cap, _vp(self.rkeys), _vp(self.rn), _vp(self.prev_xy), _vp(mask['F']), _vp(boxes), _vp(nboxes),
                                                      self.max_boxes, _vp(self.keep), _vp(stE)), 'dynamic mask')
             L.check(L.dll.sgx_frame_compact_keys_batch_dev(S, cap, _vp(self.rkeys), _vp(self.rdesc), _vp(self.rn), _vp(self.keep), _vp(mask.get('have_dynamic')),
