@@ -231,60 +231,49 @@ SGX_KERNEL(SGX_BA_THREADS) k_ba_schur_init(int nf, const double *Hpp, double lam
 
 SGX_KERNEL(256) k_chol_small(int n, const double *S, const double *bp, const double *coef, double *x, int *ok)
 {
-    SGX_LDS double A[SGX_CHOL_SMALL * SGX_CHOL_SMALL];
+    // L D L^T in "unscaled column" form: column j keeps u_ij = L_ij * d_j, so no square roots and no separate column-scaling phase; the right-hand side
+    // rides along as an extra column (forward substitution folded into the factorisation).  One barrier per column for the factorisation, one per
+    // column for the back substitution  x_j = (v_j - sum_{i>j} u_ij x_i) / d_j.  Rows are padded to an odd stride (bank-conflict-free column walks);
+    // the trailing update maps the 256 threads as 16 x 16 over (row, column) residues — no integer divisions in the loops.
+    constexpr int LD = SGX_CHOL_SMALL + 1;
+    SGX_LDS double A[SGX_CHOL_SMALL * LD];
     SGX_LDS double v[SGX_CHOL_SMALL];
     SGX_LDS int s_ok;
     const int NT = (int)blockDim.x;
     SGX_THREADS_BEGIN(tid)
     if (tid == 0) s_ok = 1;
-    for (int t = tid; t < n * n; t += NT) A[t] = S[t];
+    for (int r = tid >> 4; r < n; r += NT >> 4)
+        for (int c = tid & 15; c < n; c += 16) A[r * LD + c] = S[(size_t)r * n + c];
     for (int i = tid; i < n; i += NT) v[i] = bp[i] - coef[i];
     SGX_THREADS_END
     SGX_SYNC();
+    int jfail = n;
     for (int j = 0; j < n; j++) {
-        const double d = A[j * n + j];
-        if (!(d > 0)) { SGX_THREADS_BEGIN(tid) if (tid == 0) s_ok = 0; SGX_THREADS_END SGX_SYNC(); break; }
-        const double sd = sqrt(d);
+        const double d = A[j * LD + j];                  // final pivot: every update from the columns before j has been applied
+        if (!(d > 0)) { jfail = j; break; }
+        const double rd = 1.0 / d, vj = v[j];
         SGX_THREADS_BEGIN(tid)
-        for (int i = j + tid; i < n; i += NT) A[i * n + j] = A[i * n + j] / sd;
-        SGX_THREADS_END
-        SGX_SYNC();
-        SGX_THREADS_BEGIN(tid)
-        const int m = n - j - 1;
-        for (int t = tid; t < m * m; t += NT) { const int i = j + 1 + t / m, c = j + 1 + t % m; if (c <= i) A[i * n + c] -= A[i * n + j] * A[c * n + j]; }
+        const int ty = tid >> 4, tx = tid & 15;
+        for (int i = j + 1 + ty; i < n; i += NT >> 4) {
+            const double f = A[i * LD + j] * rd;         // L_ij
+            for (int c = j + 1 + tx; c <= i; c += 16) A[i * LD + c] -= f * A[c * LD + j];
+            if (tx == 0) v[i] -= f * vj;
+        }
         SGX_THREADS_END
         SGX_SYNC();
     }
-    if (s_ok) {
-        for (int j = 0; j < n; j++) {                    // L y = v (column oriented)
-            SGX_THREADS_BEGIN(tid)
-            if (tid == 0) v[j] = v[j] / A[j * n + j];
-            SGX_THREADS_END
-            SGX_SYNC();
-            SGX_THREADS_BEGIN(tid)
-            const double yj = v[j];
-            for (int i = j + 1 + tid; i < n; i += NT) v[i] -= A[i * n + j] * yj;
-            SGX_THREADS_END
-            SGX_SYNC();
-        }
-        for (int j = n - 1; j >= 0; j--) {               // L^T x = y
-            SGX_THREADS_BEGIN(tid)
-            if (tid == 0) v[j] = v[j] / A[j * n + j];
-            SGX_THREADS_END
-            SGX_SYNC();
-            SGX_THREADS_BEGIN(tid)
-            const double xj = v[j];
-            for (int i = tid; i < j; i += NT) v[i] -= A[j * n + i] * xj;
-            SGX_THREADS_END
-            SGX_SYNC();
-        }
-        SGX_THREADS_BEGIN(tid)
-        for (int i = tid; i < n; i += NT) x[i] = v[i];
-        SGX_THREADS_END
+    if (jfail < n) {
+        SGX_THREADS_BEGIN(tid) if (tid == 0) { s_ok = 0; *ok = 0; } SGX_THREADS_END
+        return;
     }
-    SGX_THREADS_BEGIN(tid)
-    if (tid == 0 && !s_ok) *ok = 0;
-    SGX_THREADS_END
+    for (int j = n - 1; j >= 0; j--) {
+        const double xj = v[j] / A[j * LD + j];
+        SGX_THREADS_BEGIN(tid)
+        for (int i = tid; i < j; i += NT) v[i] -= A[j * LD + i] * xj;
+        if (tid == 0) x[j] = xj;
+        SGX_THREADS_END
+        SGX_SYNC();
+    }
 }
 
 // factor the diagonal tile (lower part of S overwritten with L_kk) and store Linv_kk (32x32, row-major, zero-padded) in Linv[k0/NB]
