@@ -6,6 +6,7 @@
 #include <float.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -126,19 +127,23 @@ static int optimize(BA &B, int iterations, int *iters_done, double *final_chi)
                 SGX_LAUNCH(k_ba_schur_pairs, dim3((unsigned)((n36 + SGX_BA_THREADS - 1) / SGX_BA_THREADS)), dim3(SGX_BA_THREADS), (sgx_stream_t)0, n36, B.nf, B.jobs, B.E,
                            B.hidx, B.bl, B.Hpl, B.Dinv, B.S, B.coef);
             }
+            // workgroup sizes of the single-workgroup solver kernels (env = tuning taps): their phases are short, so fewer waves mean cheaper barriers
+            static const int t_small = getenv("SGX_TUNE_CHOL_SMALL_THREADS") ? atoi(getenv("SGX_TUNE_CHOL_SMALL_THREADS")) : 256;
+            static const int t_diag = getenv("SGX_TUNE_CHOL_DIAG_THREADS") ? atoi(getenv("SGX_TUNE_CHOL_DIAG_THREADS")) : 256;
+            static const int t_solve = getenv("SGX_TUNE_CHOL_SOLVE_THREADS") ? atoi(getenv("SGX_TUNE_CHOL_SOLVE_THREADS")) : 256;
             if (B.NP > 0 && B.NP <= SGX_CHOL_SMALL) {
-                SGX_LAUNCH(k_chol_small, dim3(1), dim3(256), (sgx_stream_t)0, B.NP, B.S, B.bp, B.coef, B.xp, B.ok);
+                SGX_LAUNCH(k_chol_small, dim3(1), dim3(t_small), (sgx_stream_t)0, B.NP, B.S, B.bp, B.coef, B.xp, B.ok);
             } else if (B.NP > 0) {                                   // blocked Cholesky of the reduced camera system
                 const int nt = (B.NP + SGX_NB - 1) / SGX_NB;
                 for (int kb = 0; kb < nt; kb++) {
                     const int k0 = kb * SGX_NB, rem = nt - kb - 1;
-                    SGX_LAUNCH(k_chol_diag, dim3(1), dim3(256), (sgx_stream_t)0, B.NP, k0, B.S, B.Linv, B.ok);
+                    SGX_LAUNCH(k_chol_diag, dim3(1), dim3(t_diag), (sgx_stream_t)0, B.NP, k0, B.S, B.Linv, B.ok);
                     if (rem > 0) {
                         SGX_LAUNCH(k_chol_panel, dim3(rem), dim3(256), (sgx_stream_t)0, B.NP, k0, B.S, B.Linv, B.ok);
                         SGX_LAUNCH(k_chol_update, dim3(rem * (rem + 1) / 2), dim3(256), (sgx_stream_t)0, B.NP, k0, B.S, B.ok);
                     }
                 }
-                SGX_LAUNCH(k_chol_solve, dim3(1), dim3(256), (sgx_stream_t)0, B.NP, B.S, B.Linv, B.bp, B.coef, B.xp, B.ok);
+                SGX_LAUNCH(k_chol_solve, dim3(1), dim3(t_solve), (sgx_stream_t)0, B.NP, B.S, B.Linv, B.bp, B.coef, B.xp, B.ok);
             }
             // when the factorisation failed, xp/xl keep the previous solution (as g2o's _x does) and the step is rejected below
             SGX_LAUNCH(k_ba_backsub, dim3((B.nl + SGX_BA_THREADS - 1) / SGX_BA_THREADS), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.nl, B.pt_start, B.pt_edges, B.E, B.hidx,

@@ -279,49 +279,72 @@ SGX_KERNEL(256) k_chol_small(int n, const double *S, const double *bp, const dou
 // factor the diagonal tile (lower part of S overwritten with L_kk) and store Linv_kk (32x32, row-major, zero-padded) in Linv[k0/NB]
 SGX_KERNEL(256) k_chol_diag(int n, int k0, double *S, double *Linv, int *ok)
 {
+    // Factorised in the same unscaled L D L^T form as k_chol_small (one barrier per column, 16 x 16 thread map, no integer divisions in the loops);
+    // the Cholesky factor the panel / update kernels expect is recovered at the end: L_ij = u_ij / sqrt(d_j), L_jj = sqrt(d_j).
     SGX_LDS double A[SGX_NB][SGX_NB + 1];
     SGX_LDS double X[SGX_NB][SGX_NB + 1];
-    SGX_LDS int s_ok;
+    SGX_LDS double sd[SGX_NB];
     const int nb = min(SGX_NB, n - k0);
     const int NT = (int)blockDim.x;
     SGX_THREADS_BEGIN(tid)
-    if (tid == 0) s_ok = 1;
-    for (int t = tid; t < nb * nb; t += NT) { const int r = t / nb, c = t % nb; A[r][c] = S[(size_t)(k0 + r) * n + k0 + c]; }
-    for (int t = tid; t < SGX_NB * SGX_NB; t += NT) X[t / SGX_NB][t % SGX_NB] = 0;
+    for (int t = tid; t < SGX_NB * SGX_NB; t += NT) {
+        const int r = t >> 5, c = t & 31;
+        A[r][c] = (r < nb && c < nb) ? S[(size_t)(k0 + r) * n + k0 + c] : 0.0;
+        X[r][c] = 0;
+    }
     SGX_THREADS_END
     SGX_SYNC();
+    int jfail = nb;
     for (int j = 0; j < nb; j++) {
         const double d = A[j][j];
-        if (!(d > 0)) { SGX_THREADS_BEGIN(tid) if (tid == 0) s_ok = 0; SGX_THREADS_END SGX_SYNC(); break; }
-        const double sd = sqrt(d);
+        if (!(d > 0)) { jfail = j; break; }
+        const double rd = 1.0 / d;
         SGX_THREADS_BEGIN(tid)
-        for (int i = j + tid; i < nb; i += NT) A[i][j] = A[i][j] / sd;      // includes the diagonal: A[j][j] = sqrt(d)
-        SGX_THREADS_END
-        SGX_SYNC();
-        SGX_THREADS_BEGIN(tid)
-        const int m = nb - j - 1;
-        for (int t = tid; t < m * m; t += NT) { const int i = j + 1 + t / m, c = j + 1 + t % m; if (c <= i) A[i][c] -= A[i][j] * A[c][j]; }
-        SGX_THREADS_END
-        SGX_SYNC();
-    }
-    if (s_ok) {
-        SGX_THREADS_BEGIN(tid)
-        if (tid < nb) {                      // column tid of L^-1 by forward substitution (independent per column)
-            const int c = tid;
-            for (int r = c; r < nb; r++) {
-                double sacc = (r == c) ? 1.0 : 0.0;
-                for (int q = c; q < r; q++) sacc -= A[r][q] * X[q][c];
-                X[r][c] = sacc / A[r][r];
-            }
+        const int ty = tid >> 4, tx = tid & 15;
+        for (int i = j + 1 + ty; i < nb; i += NT >> 4) {
+            const double f = A[i][j] * rd;
+            for (int c = j + 1 + tx; c <= i; c += 16) A[i][c] -= f * A[c][j];
         }
         SGX_THREADS_END
         SGX_SYNC();
     }
+    if (jfail < nb) {
+        SGX_THREADS_BEGIN(tid) if (tid == 0) *ok = 0; SGX_THREADS_END
+        return;
+    }
     SGX_THREADS_BEGIN(tid)
-    for (int t = tid; t < nb * nb; t += NT) { const int r = t / nb, c = t % nb; if (c <= r) S[(size_t)(k0 + r) * n + k0 + c] = A[r][c]; }
+    if (tid < nb) sd[tid] = sqrt(A[tid][tid]);
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    for (int t = tid; t < SGX_NB * SGX_NB; t += NT) {
+        const int r = t >> 5, c = t & 31;
+        if (r < nb && c < r) A[r][c] = A[r][c] / sd[c];
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    if (tid < nb) A[tid][tid] = sd[tid];
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    if (tid < nb) {                      // column tid of L^-1 by forward substitution (independent per column)
+        const int c = tid;
+        for (int r = c; r < nb; r++) {
+            double sacc = (r == c) ? 1.0 : 0.0;
+            for (int q = c; q < r; q++) sacc -= A[r][q] * X[q][c];
+            X[r][c] = sacc / sd[r];
+        }
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
     double *Lo = Linv + (size_t)(k0 / SGX_NB) * SGX_NB * SGX_NB;
-    for (int t = tid; t < SGX_NB * SGX_NB; t += NT) Lo[t] = X[t / SGX_NB][t % SGX_NB];
-    if (tid == 0 && !s_ok) *ok = 0;
+    for (int t = tid; t < SGX_NB * SGX_NB; t += NT) {
+        const int r = t >> 5, c = t & 31;
+        if (r < nb && c <= r) S[(size_t)(k0 + r) * n + k0 + c] = A[r][c];
+        Lo[t] = X[r][c];
+    }
     SGX_THREADS_END
 }
 
@@ -383,7 +406,7 @@ SGX_KERNEL(256) k_chol_update(int n, int k0, double *S, const int *ok)
 // x = (bp - coef); L y = x; L^T x = y — blocked with the stored diagonal inverses, one 256-thread workgroup
 SGX_KERNEL(256) k_chol_solve(int n, const double *S, const double *Linv, const double *bp, const double *coef, double *x, const int *ok)
 {
-    SGX_LDS double xs[SGX_NB], ys[SGX_NB];
+    SGX_LDS double ys[SGX_NB];
     if (!*ok) return;
     const int NT = (int)blockDim.x;
     SGX_THREADS_BEGIN(tid)
@@ -394,14 +417,11 @@ SGX_KERNEL(256) k_chol_solve(int n, const double *S, const double *Linv, const d
         const int nb = min(SGX_NB, n - k0);
         const double *Lk = Linv + (size_t)(k0 / SGX_NB) * SGX_NB * SGX_NB;
         SGX_THREADS_BEGIN(tid)
-        if (tid < nb) xs[tid] = x[k0 + tid];
+        if (tid < nb) { double sacc = 0; for (int q = 0; q <= tid; q++) sacc += Lk[tid * SGX_NB + q] * x[k0 + q]; ys[tid] = sacc; }   // y_k = Linv_kk x_k (x_k: previous phase, same workgroup)
         SGX_THREADS_END
         SGX_SYNC();
         SGX_THREADS_BEGIN(tid)
-        if (tid < nb) { double sacc = 0; for (int q = 0; q <= tid; q++) sacc += Lk[tid * SGX_NB + q] * xs[q]; ys[tid] = sacc; x[k0 + tid] = sacc; }   // y_k = Linv_kk x_k
-        SGX_THREADS_END
-        SGX_SYNC();
-        SGX_THREADS_BEGIN(tid)
+        if (tid < nb) x[k0 + tid] = ys[tid];
         for (int i = k0 + nb + tid; i < n; i += NT) { double vv = x[i]; for (int q = 0; q < nb; q++) vv -= S[(size_t)i * n + k0 + q] * ys[q]; x[i] = vv; }
         SGX_THREADS_END
         SGX_SYNC();
@@ -410,14 +430,11 @@ SGX_KERNEL(256) k_chol_solve(int n, const double *S, const double *Linv, const d
         const int nb = min(SGX_NB, n - k0);
         const double *Lk = Linv + (size_t)(k0 / SGX_NB) * SGX_NB * SGX_NB;
         SGX_THREADS_BEGIN(tid)
-        if (tid < nb) xs[tid] = x[k0 + tid];
+        if (tid < nb) { double sacc = 0; for (int q = tid; q < nb; q++) sacc += Lk[q * SGX_NB + tid] * x[k0 + q]; ys[tid] = sacc; }    // x_k = Linv_kk^T y_k
         SGX_THREADS_END
         SGX_SYNC();
         SGX_THREADS_BEGIN(tid)
-        if (tid < nb) { double sacc = 0; for (int q = tid; q < nb; q++) sacc += Lk[q * SGX_NB + tid] * xs[q]; ys[tid] = sacc; x[k0 + tid] = sacc; }    // x_k = Linv_kk^T y_k
-        SGX_THREADS_END
-        SGX_SYNC();
-        SGX_THREADS_BEGIN(tid)
+        if (tid < nb) x[k0 + tid] = ys[tid];
         for (int i = tid; i < k0; i += NT) { double vv = x[i]; for (int q = 0; q < nb; q++) vv -= S[(size_t)(k0 + q) * n + i] * ys[q]; x[i] = vv; }
         SGX_THREADS_END
         SGX_SYNC();

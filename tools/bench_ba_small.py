@@ -6,7 +6,7 @@ from sg_slam_amd.optimizer import Optimizer
 from oracle import oracle as orc
 from scenes import make_ba_problem, CAM
 lib = sg_slam_amd.load()
-prob, _, _ = make_ba_problem(orc, n_free=20, n_fixed=40, n_points=2000, seed=21)
+prob, _, _ = make_ba_problem(orc, n_free=int(sys.argv[1]) if len(sys.argv) > 1 else 20, n_fixed=int(sys.argv[2]) if len(sys.argv) > 2 else 40, n_points=int(sys.argv[3]) if len(sys.argv) > 3 else 2000, seed=21)
 def run():
     p2 = {k: (v.copy() if hasattr(v, 'copy') else v) for k, v in prob.items()}
     t = time.perf_counter(); er, st = Optimizer.LocalBundleAdjustment(p2, CAM, lib=lib); return time.perf_counter() - t, st
