@@ -137,9 +137,9 @@ static int optimize(BA &B, int iterations, int *iters_done, double *final_chi)
                 const int nt = (B.NP + SGX_NB - 1) / SGX_NB;
                 for (int kb = 0; kb < nt; kb++) {
                     const int k0 = kb * SGX_NB, rem = nt - kb - 1;
-                    SGX_LAUNCH(k_chol_diag, dim3(1), dim3(t_diag), (sgx_stream_t)0, B.NP, k0, B.S, B.Linv, B.ok);
+                    SGX_LAUNCH(k_chol_diag, dim3(1), dim3(t_diag), (sgx_stream_t)0, B.NP, k0, B.S, B.Linv, B.ok, B.bp, B.coef, B.xp);
                     if (rem > 0) {
-                        SGX_LAUNCH(k_chol_panel, dim3(rem), dim3(256), (sgx_stream_t)0, B.NP, k0, B.S, B.Linv, B.ok);
+                        SGX_LAUNCH(k_chol_panel, dim3(rem), dim3(256), (sgx_stream_t)0, B.NP, k0, B.S, B.Linv, B.ok, B.xp);
                         SGX_LAUNCH(k_chol_update, dim3(rem * (rem + 1) / 2), dim3(256), (sgx_stream_t)0, B.NP, k0, B.S, B.ok);
                     }
                 }

@@ -226,7 +226,10 @@ SGX_KERNEL(SGX_BA_THREADS) k_ba_schur_init(int nf, const double *Hpp, double lam
 //                k_chol_update (one workgroup per lower-triangular tile pair: A_ij -= L_ik L_jk^T)
 //              then k_chol_solve (one workgroup, blocked substitution with the stored Linv_kk: mat-vec + tile updates).
 // ---------------------------------------------------------------------------------------------
-#define SGX_NB 32
+#define SGX_NB 32            /* tile edge of the blocked factorisation.  Measured: 64 halves the launches and runs the 2000-keyframe BA 8 % faster, but its
+                                diagonal-tile kernel (64 serial steps + a 64-long register inverse) makes LocalBA-sized systems 20 % slower */
+#define SGX_NB_SHIFT 5
+#define SGX_TB (SGX_NB / 16)  /* register block edge of the tile GEMMs (16 x 16 thread map) */
 #define SGX_CHOL_SMALL 128
 
 SGX_KERNEL(256) k_chol_small(int n, const double *S, const double *bp, const double *coef, double *x, int *ok)
@@ -277,18 +280,19 @@ SGX_KERNEL(256) k_chol_small(int n, const double *S, const double *bp, const dou
 }
 
 // factor the diagonal tile (lower part of S overwritten with L_kk) and store Linv_kk (32x32, row-major, zero-padded) in Linv[k0/NB]
-SGX_KERNEL(256) k_chol_diag(int n, int k0, double *S, double *Linv, int *ok)
+SGX_KERNEL(256) k_chol_diag(int n, int k0, double *S, double *Linv, int *ok, const double *bp, const double *coef, double *x)
 {
     // Factorised in the same unscaled L D L^T form as k_chol_small (one barrier per column, 16 x 16 thread map, no integer divisions in the loops);
     // the Cholesky factor the panel / update kernels expect is recovered at the end: L_ij = u_ij / sqrt(d_j), L_jj = sqrt(d_j).
     SGX_LDS double A[SGX_NB][SGX_NB + 1];
     SGX_LDS double X[SGX_NB][SGX_NB + 1];
-    SGX_LDS double sd[SGX_NB];
+    SGX_LDS double sd[SGX_NB], rsd[SGX_NB];
     const int nb = min(SGX_NB, n - k0);
     const int NT = (int)blockDim.x;
     SGX_THREADS_BEGIN(tid)
+    if (k0 == 0) for (int i = tid; i < n; i += NT) x[i] = bp[i] - coef[i];            // right-hand side of the reduced system (first panel only)
     for (int t = tid; t < SGX_NB * SGX_NB; t += NT) {
-        const int r = t >> 5, c = t & 31;
+        const int r = t >> SGX_NB_SHIFT, c = t & (SGX_NB - 1);
         A[r][c] = (r < nb && c < nb) ? S[(size_t)(k0 + r) * n + k0 + c] : 0.0;
         X[r][c] = 0;
     }
@@ -313,12 +317,12 @@ SGX_KERNEL(256) k_chol_diag(int n, int k0, double *S, double *Linv, int *ok)
         return;
     }
     SGX_THREADS_BEGIN(tid)
-    if (tid < nb) sd[tid] = sqrt(A[tid][tid]);
+    if (tid < SGX_NB) { const double r_ = tid < nb ? sqrt(A[tid][tid]) : 1.0; sd[tid] = r_; rsd[tid] = 1.0 / r_; }
     SGX_THREADS_END
     SGX_SYNC();
     SGX_THREADS_BEGIN(tid)
     for (int t = tid; t < SGX_NB * SGX_NB; t += NT) {
-        const int r = t >> 5, c = t & 31;
+        const int r = t >> SGX_NB_SHIFT, c = t & (SGX_NB - 1);
         if (r < nb && c < r) A[r][c] = A[r][c] / sd[c];
     }
     SGX_THREADS_END
@@ -328,31 +332,65 @@ SGX_KERNEL(256) k_chol_diag(int n, int k0, double *S, double *Linv, int *ok)
     SGX_THREADS_END
     SGX_SYNC();
     SGX_THREADS_BEGIN(tid)
-    if (tid < nb) {                      // column tid of L^-1 by forward substitution (independent per column)
-        const int c = tid;
-        for (int r = c; r < nb; r++) {
-            double sacc = (r == c) ? 1.0 : 0.0;
-            for (int q = c; q < r; q++) sacc -= A[r][q] * X[q][c];
-            X[r][c] = sacc / sd[r];
+    if (tid < SGX_NB) {
+        // column tid of L^-1 by forward substitution, the column in registers and every index static: entries above the diagonal come out as exact
+        // zeros by themselves (x_q = 0 for q < tid), so no thread-dependent loop bounds; the tile reads are broadcasts the compiler can hoist.
+        // (A run-time-bounded loop over LDS here cost ~20 us per tile: ~500 dependent LDS round trips.)
+        double xc[SGX_NB];
+#pragma unroll
+        for (int r = 0; r < SGX_NB; r++) {
+            double sacc = (r == tid) ? 1.0 : 0.0;
+#pragma unroll
+            for (int q = 0; q < r; q++) sacc -= A[r][q] * xc[q];
+            xc[r] = sacc * rsd[r];
         }
+#pragma unroll
+        for (int r = 0; r < SGX_NB; r++) X[r][tid] = (tid < nb && r < nb) ? xc[r] : 0.0;
     }
     SGX_THREADS_END
     SGX_SYNC();
+    // forward substitution rides along with the factorisation (right-looking): y_k = Linv_kk x_k here, x_i -= L_ik y_k in k_chol_panel
     SGX_THREADS_BEGIN(tid)
+    if (tid < nb) { double sacc = 0; for (int q = 0; q <= tid; q++) sacc += X[tid][q] * x[k0 + q]; sd[tid] = sacc; }      // sd reused as y_k
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    if (tid < nb) x[k0 + tid] = sd[tid];
     double *Lo = Linv + (size_t)(k0 / SGX_NB) * SGX_NB * SGX_NB;
     for (int t = tid; t < SGX_NB * SGX_NB; t += NT) {
-        const int r = t >> 5, c = t & 31;
+        const int r = t >> SGX_NB_SHIFT, c = t & (SGX_NB - 1);
         if (r < nb && c <= r) S[(size_t)(k0 + r) * n + k0 + c] = A[r][c];
         Lo[t] = X[r][c];
     }
     SGX_THREADS_END
 }
 
-// L_ik = A_ik Linv_kk^T for the row tile i = k0/NB + 1 + blockIdx.x
-SGX_KERNEL(256) k_chol_panel(int n, int k0, double *S, const double *Linv, const int *ok)
+// C(NB x NB) = P * Q^T for two LDS tiles stored TRANSPOSED ([q][row], zero-padded): thread (ty, tx) of the 16 x 16 map owns the TB x TB block rows TB*ty.., cols TB*tx..;
+// per q it reads TB + TB contiguous doubles and issues TB*TB FMAs (1 LDS read per FMA at TB = 2, 0.5 at TB = 4, instead of 2 for the one-output-per-thread form).
+SGX_DEV void sgx_tile_gemm_nt(const double (*PT)[SGX_NB + 4], const double (*QT)[SGX_NB + 4], int ty, int tx, double acc[SGX_TB][SGX_TB])
 {
-    SGX_LDS double Li[SGX_NB][SGX_NB + 1];
-    SGX_LDS double A[SGX_NB][SGX_NB + 1];
+#pragma unroll
+    for (int i = 0; i < SGX_TB; i++)
+#pragma unroll
+        for (int j = 0; j < SGX_TB; j++) acc[i][j] = 0;
+#pragma unroll 8
+    for (int q = 0; q < SGX_NB; q++) {
+        double a[SGX_TB], b[SGX_TB];
+#pragma unroll
+        for (int i = 0; i < SGX_TB; i++) { a[i] = PT[q][SGX_TB * ty + i]; b[i] = QT[q][SGX_TB * tx + i]; }
+#pragma unroll
+        for (int i = 0; i < SGX_TB; i++)
+#pragma unroll
+            for (int j = 0; j < SGX_TB; j++) acc[i][j] += a[i] * b[j];
+    }
+}
+
+// L_ik = A_ik Linv_kk^T for the row tile i = k0/NB + 1 + blockIdx.x, then the forward-substitution update x_i -= L_ik y_k
+SGX_KERNEL(256) k_chol_panel(int n, int k0, double *S, const double *Linv, const int *ok, double *x)
+{
+    SGX_LDS double LiT[SGX_NB][SGX_NB + 4];      // Linv_kk transposed: [q][c]
+    SGX_LDS double AT[SGX_NB][SGX_NB + 4];       // A_ik transposed: [q][r]
+    SGX_LDS double LoT[SGX_NB][SGX_NB + 4];      // L_ik transposed: [c][r]
     if (!*ok) return;
     const int nb = min(SGX_NB, n - k0);
     const int r0 = k0 + SGX_NB * (1 + (int)blockIdx.x);
@@ -360,25 +398,37 @@ SGX_KERNEL(256) k_chol_panel(int n, int k0, double *S, const double *Linv, const
     const int NT = (int)blockDim.x;
     const double *Lk = Linv + (size_t)(k0 / SGX_NB) * SGX_NB * SGX_NB;
     SGX_THREADS_BEGIN(tid)
-    for (int t = tid; t < SGX_NB * SGX_NB; t += NT) Li[t / SGX_NB][t % SGX_NB] = Lk[t];
-    for (int t = tid; t < nr * nb; t += NT) { const int r = t / nb, c = t % nb; A[r][c] = S[(size_t)(r0 + r) * n + k0 + c]; }
+    for (int t = tid; t < SGX_NB * SGX_NB; t += NT) {
+        const int r = t >> SGX_NB_SHIFT, c = t & (SGX_NB - 1);
+        LiT[c][r] = Lk[t];                                                            // Linv[r][c] (zero above the diagonal and past nb)
+        AT[c][r] = (r < nr && c < nb) ? S[(size_t)(r0 + r) * n + k0 + c] : 0.0;
+    }
     SGX_THREADS_END
     SGX_SYNC();
     SGX_THREADS_BEGIN(tid)
-    for (int t = tid; t < nr * nb; t += NT) {
-        const int r = t / nb, c = t % nb;
-        double sacc = 0;
-        for (int q = 0; q <= c; q++) sacc += A[r][q] * Li[c][q];          // (A Linv^T)[r][c] = sum_q A[r][q] Linv[c][q], Linv lower triangular
-        S[(size_t)(r0 + r) * n + k0 + c] = sacc;
-    }
+    const int ty = tid >> 4, tx = tid & 15;
+    double acc[SGX_TB][SGX_TB];
+    sgx_tile_gemm_nt(AT, LiT, ty, tx, acc);                                            // out[r][c] = sum_q A[r][q] Linv[c][q]
+#pragma unroll
+    for (int i = 0; i < SGX_TB; i++)
+#pragma unroll
+        for (int j = 0; j < SGX_TB; j++) {
+            const int r = SGX_TB * ty + i, c = SGX_TB * tx + j;
+            LoT[c][r] = acc[i][j];                                                     // L_ik (transposed) for the substitution below
+            if (r < nr && c < nb) S[(size_t)(r0 + r) * n + k0 + c] = acc[i][j];
+        }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    if (tid < nr) { double vv = x[r0 + tid]; for (int q = 0; q < nb; q++) vv -= LoT[q][tid] * x[k0 + q]; x[r0 + tid] = vv; }      // forward substitution: x_i -= L_ik y_k
     SGX_THREADS_END
 }
 
 // A_ij -= L_ik L_jk^T for the lower-triangular tile pairs (i >= j) of the trailing matrix; blockIdx.x enumerates pairs
 SGX_KERNEL(256) k_chol_update(int n, int k0, double *S, const int *ok)
 {
-    SGX_LDS double Li[SGX_NB][SGX_NB + 1];
-    SGX_LDS double Lj[SGX_NB][SGX_NB + 1];
+    SGX_LDS double LiT[SGX_NB][SGX_NB + 4];
+    SGX_LDS double LjT[SGX_NB][SGX_NB + 4];
     if (!*ok) return;
     const int nb = min(SGX_NB, n - k0);
     int bi = 0, rem = (int)blockIdx.x;               // unrank blockIdx.x -> (bi >= bj) within the trailing tiles
@@ -388,18 +438,24 @@ SGX_KERNEL(256) k_chol_update(int n, int k0, double *S, const int *ok)
     const int nr = min(SGX_NB, n - r0), nc = min(SGX_NB, n - c0);
     const int NT = (int)blockDim.x;
     SGX_THREADS_BEGIN(tid)
-    for (int t = tid; t < nr * nb; t += NT) { const int r = t / nb, c = t % nb; Li[r][c] = S[(size_t)(r0 + r) * n + k0 + c]; }
-    for (int t = tid; t < nc * nb; t += NT) { const int r = t / nb, c = t % nb; Lj[r][c] = S[(size_t)(c0 + r) * n + k0 + c]; }
+    for (int t = tid; t < SGX_NB * SGX_NB; t += NT) {
+        const int r = t >> SGX_NB_SHIFT, c = t & (SGX_NB - 1);
+        LiT[c][r] = (r < nr && c < nb) ? S[(size_t)(r0 + r) * n + k0 + c] : 0.0;
+        LjT[c][r] = (r < nc && c < nb) ? S[(size_t)(c0 + r) * n + k0 + c] : 0.0;
+    }
     SGX_THREADS_END
     SGX_SYNC();
     SGX_THREADS_BEGIN(tid)
-    for (int t = tid; t < nr * nc; t += NT) {
-        const int r = t / nc, c = t % nc;
-        if (bi == bj && c > r) continue;
-        double sacc = 0;
-        for (int q = 0; q < nb; q++) sacc += Li[r][q] * Lj[c][q];
-        S[(size_t)(r0 + r) * n + c0 + c] -= sacc;
-    }
+    const int ty = tid >> 4, tx = tid & 15;
+    double acc[SGX_TB][SGX_TB];
+    sgx_tile_gemm_nt(LiT, LjT, ty, tx, acc);
+#pragma unroll
+    for (int i = 0; i < SGX_TB; i++)
+#pragma unroll
+        for (int j = 0; j < SGX_TB; j++) {
+            const int r = SGX_TB * ty + i, c = SGX_TB * tx + j;
+            if (r < nr && c < nc && !(bi == bj && c > r)) S[(size_t)(r0 + r) * n + c0 + c] -= acc[i][j];
+        }
     SGX_THREADS_END
 }
 
@@ -409,23 +465,7 @@ SGX_KERNEL(256) k_chol_solve(int n, const double *S, const double *Linv, const d
     SGX_LDS double ys[SGX_NB];
     if (!*ok) return;
     const int NT = (int)blockDim.x;
-    SGX_THREADS_BEGIN(tid)
-    for (int i = tid; i < n; i += NT) x[i] = bp[i] - coef[i];
-    SGX_THREADS_END
-    SGX_SYNC();
-    for (int k0 = 0; k0 < n; k0 += SGX_NB) {
-        const int nb = min(SGX_NB, n - k0);
-        const double *Lk = Linv + (size_t)(k0 / SGX_NB) * SGX_NB * SGX_NB;
-        SGX_THREADS_BEGIN(tid)
-        if (tid < nb) { double sacc = 0; for (int q = 0; q <= tid; q++) sacc += Lk[tid * SGX_NB + q] * x[k0 + q]; ys[tid] = sacc; }   // y_k = Linv_kk x_k (x_k: previous phase, same workgroup)
-        SGX_THREADS_END
-        SGX_SYNC();
-        SGX_THREADS_BEGIN(tid)
-        if (tid < nb) x[k0 + tid] = ys[tid];
-        for (int i = k0 + nb + tid; i < n; i += NT) { double vv = x[i]; for (int q = 0; q < nb; q++) vv -= S[(size_t)i * n + k0 + q] * ys[q]; x[i] = vv; }
-        SGX_THREADS_END
-        SGX_SYNC();
-    }
+    // x already holds y = L^-1 (bp - coef): the forward substitution ran inside k_chol_diag / k_chol_panel.  Backward pass:
     for (int k0 = ((n - 1) / SGX_NB) * SGX_NB; k0 >= 0; k0 -= SGX_NB) {
         const int nb = min(SGX_NB, n - k0);
         const double *Lk = Linv + (size_t)(k0 / SGX_NB) * SGX_NB * SGX_NB;
