@@ -126,6 +126,56 @@ public:
                                     (int)invLevelSigma2.size(), &cam, pFrame->mTcw, pFrame->mvbOutlier.data(), &ninl), "sgx_pose_optimization");
         return ninl;
     }
+
+    // static void LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Map *pMap) (Optimizer.cc:453-778) on the flattened local graph the caller
+    // collects at Optimizer.cc:455-653: poses / points are updated in place, the return value lists the erased observations.
+    struct LocalGraph {
+        std::vector<float> poses;            // n_poses x 16 (Tcw)
+        std::vector<uint8_t> pose_fixed;     // 0 local keyframe, 1 fixed camera, 2 local keyframe with mnId == 0
+        std::vector<float> points;           // n_points x 3
+        std::vector<int32_t> edge_pose, edge_point;
+        std::vector<float> edge_obs;         // n_edges x 3 (u, v, uR; uR < 0 = monocular)
+        std::vector<float> edge_info;        // mvInvLevelSigma2[octave]
+    };
+    static std::vector<uint8_t> LocalBundleAdjustment(LocalGraph &g, const sgx_camera &cam, const volatile int32_t *pbStopFlag = nullptr, sgx_ba_stats *stats = nullptr)
+    {
+        sgx_ba_problem P{(int32_t)g.pose_fixed.size(), (int32_t)(g.points.size() / 3), (int32_t)g.edge_pose.size(), g.poses.data(), g.pose_fixed.data(), g.points.data(),
+                         g.edge_pose.data(), g.edge_point.data(), g.edge_obs.data(), g.edge_info.data()};
+        std::vector<uint8_t> erase(g.edge_pose.size(), 0);
+        check(sgx_local_bundle_adjustment(&P, &cam, pbStopFlag, erase.data(), stats), "sgx_local_bundle_adjustment");
+        return erase;
+    }
+};
+
+// ORB_SLAM2::Detector2D (Detector2D.h:45-67): same public result members as the reference (read by Frame.cc:482-500)
+struct Object2D { float x, y, w, h; float prob; int id; };          // cv::Rect_<float> rect; float prob; int id (name = class_names[id])
+class Detector2D {
+public:
+    // param_text / bin: the contents of ./Thirdparty/ncnn_model/mobilenetv3_ssdlite_voc.{param,bin} (Detector2D.cc:24-25 reads them from the CWD)
+    Detector2D(float detection_confidence_threshold, float dynamic_detection_confidence_threshold, const std::string &param_text, const std::vector<uint8_t> &bin,
+               int width = 640, int height = 480)
+    {
+        check(sgx_det_create(param_text.c_str(), bin.data(), bin.size(), width, height, 1, detection_confidence_threshold, dynamic_detection_confidence_threshold, &h_), "sgx_det_create");
+    }
+    ~Detector2D() { if (h_) sgx_det_destroy(h_); }
+    Detector2D(const Detector2D &) = delete; Detector2D &operator=(const Detector2D &) = delete;
+
+    void detect(const uint8_t *bgr, int step)                       // void detect(const cv::Mat &bgr) (Detector2D.cc:34-89)
+    {
+        sgx_det_result r;
+        check(sgx_det_detect(h_, bgr, step, 1, &r), "sgx_det_detect");
+        auto conv = [](const sgx_object2d &o) { return Object2D{o.x, o.y, o.w, o.h, o.prob, o.id}; };
+        mvObjects2D.clear(); mvPotentialDynamicBorderForMapping.clear(); mvPotentialDynamicBorderForRmDynamicFeature.clear(); raw.assign(r.raw, r.raw + r.n_raw);
+        for (int i = 0; i < r.n_objects; i++) mvObjects2D.push_back(conv(r.objects[i]));
+        for (int i = 0; i < r.n_map_boxes; i++) mvPotentialDynamicBorderForMapping.push_back(conv(r.map_boxes[i]));
+        for (int i = 0; i < r.n_rm_boxes; i++) mvPotentialDynamicBorderForRmDynamicFeature.push_back(conv(r.rm_boxes[i]));
+        mbHaveDynamicObjectForMapping = r.have_dynamic_for_mapping != 0; mbHaveDynamicObjectForRmDynamicFeature = r.have_dynamic_for_rm_feature != 0;
+    }
+    std::vector<Object2D> mvObjects2D, mvPotentialDynamicBorderForMapping, mvPotentialDynamicBorderForRmDynamicFeature;
+    bool mbHaveDynamicObjectForMapping = false, mbHaveDynamicObjectForRmDynamicFeature = false;
+    std::vector<sgx_detection> raw;                                  // ncnn detection_out rows (test tap)
+private:
+    sgx_det *h_ = nullptr;
 };
 
 }  // namespace sgx

@@ -39,3 +39,52 @@ def test_cpp_example_matches_oracle(gpulib, oracle, stream_frames, tmp_path):
     einl, eT, _ = oracle.pose_optimization(fr, CAM, is2)
     assert (n0, n1, nm, ninl) == (len(k0), len(k1), en, einl)
     assert np.abs(T - eT).max() <= 1e-5 * max(1.0, np.abs(eT).max())
+
+
+def _exe(name):
+    exe = os.path.join(ROOT, 'sg_slam_amd', 'host', name)
+    if not os.path.exists(exe):
+        import __graft_entry__
+        __graft_entry__.build()
+    return exe
+
+
+def test_cpp_local_bundle_adjustment_matches_oracle(gpulib, oracle, tmp_path):
+    """sgx::Optimizer::LocalBundleAdjustment (C++ mirror) on a flattened local graph: same LM iteration counts, erase count, chi2 and poses as the oracle."""
+    from scenes import make_ba_problem
+    prob, _, _ = make_ba_problem(oracle, n_free=12, n_fixed=6, n_points=700, seed=31)
+    eposes, epoints, eerase, etrace, eiters = oracle.local_ba(prob, CAM)
+    f = tmp_path / 'graph.bin'
+    with open(f, 'wb') as fh:
+        fh.write(np.array([len(prob['poses']), len(prob['points']), len(prob['edge_pose'])], 'i4').tobytes())
+        for k, dt in (('poses', 'f4'), ('pose_fixed', 'u1'), ('points', 'f4'), ('edge_pose', 'i4'), ('edge_point', 'i4'), ('edge_obs', 'f4'), ('edge_info', 'f4')):
+            fh.write(np.ascontiguousarray(prob[k], dt).tobytes())
+    out = subprocess.check_output([_exe('example_backend'), 'ba', str(f)], text=True).splitlines()
+    v = out[0].split()
+    assert (int(v[1]), int(v[2])) == tuple(eiters) and int(v[6]) == int(eerase.sum())
+    chi = etrace[1, eiters[1] - 1, 0]
+    assert abs(float(v[4]) - chi) <= 1e-5 * max(1.0, chi)
+    T1 = np.array([float(x) for x in out[1].split()[1:]], 'f4').reshape(4, 4)
+    assert np.abs(T1 - eposes[1]).max() <= 1e-5 * max(1.0, np.abs(eposes[1]).max())
+
+
+def test_cpp_detector_matches_python_mirror(gpulib, tmp_path):
+    """sgx::Detector2D::detect (C++ mirror) gives the same detection rows and dynamic-object flags as the Python mirror of the same C ABI."""
+    from oracle import detector_oracle as D
+    from sg_slam_amd.detector import Detector2D
+    param = os.path.join(ROOT, 'tests', 'golden', 'mobilenetv3_ssdlite_voc.param')
+    layers = D.parse_param(param); W, blob = D.synth_weights(layers, seed=7)
+    rng = np.random.RandomState(9)
+    img = rng.randint(0, 256, (480, 640, 3)).astype(np.uint8)
+    fb = tmp_path / 'model.bin'; fi = tmp_path / 'frame.raw'
+    fb.write_bytes(blob); img.tofile(fi)
+    out = subprocess.check_output([_exe('example_backend'), 'det', param, str(fb), str(fi)], text=True).splitlines()
+    det = Detector2D(0.9, 0.01, param_text=open(param).read(), bin_bytes=blob, lib=gpulib)
+    r = det.detect_batch(img)[0]
+    v = out[0].split()
+    assert (int(v[1]), int(v[3]), int(v[5]), int(v[7]), int(v[9]), int(v[11])) == (r.n_raw, r.n_objects, r.n_map_boxes, r.n_rm_boxes, r.have_dynamic_for_mapping, r.have_dynamic_for_rm_feature)
+    for i, line in enumerate(out[1:]):
+        x = [float(t) for t in line.split()[1:]]
+        d = r.raw[i]
+        assert np.allclose(x, [d.label, d.score, d.xmin, d.ymin, d.xmax, d.ymax], rtol=1e-6, atol=1e-7)
+    det.close()
