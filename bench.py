@@ -62,6 +62,8 @@ def main():
     ap.add_argument('--no-cpu-all-cores', action='store_true', help='skip the frames-parallel all-host-cores CPU baseline (keeps the 1-core figure)')
     ap.add_argument('--no-pipeline', action='store_true', help='single HIP stream (no overlap of extraction with match/pose-opt)')
     ap.add_argument('--no-local-map', action='store_true', help='skip the TrackLocalMap stage (local-map SearchByProjection + second PoseOptimization)')
+    ap.add_argument('--detector', action='store_true', help='also run the detector forward (MobileNetV3-SSDLite, synthetic weights) on every frame, on a third HIP stream; '
+                    'its host-side DetectionOutput post-processing is not included and the mask keeps using the synthetic person box')
     ap.add_argument('--no-mask', action='store_true', help='skip the dynamic-feature mask + erase stage (Frame::RmDynamicPointWithSemanticAndGeometry)')
     ap.add_argument('--cpu-sample', type=int, default=400, help='frames timed on the CPU oracle')
     args = ap.parse_args()
@@ -121,7 +123,24 @@ def main():
             masks[(a, b)] = dict(A=torch.from_numpy(A).cuda(), F=torch.from_numpy(F).cuda(), boxes=boxes, nboxes=nboxes, have_dynamic=have_dyn,
                                  shift=torch.from_numpy(sh.astype('f4')).cuda())
 
+    det = None
+    if args.detector:
+        # BASELINE config 3: the detector forward of every frame runs beside extraction and tracking (the reference runs Detector2D::detect on its own thread).
+        from sg_slam_amd.detector import Detector2D
+        from oracle import detector_oracle as D_                  # only to synthesise the weight blob (the reference's .bin is absent)
+        import ctypes as C_
+        from sg_slam_amd.capi import _vp as _vp_
+        param = os.path.join(ROOT, 'tests', 'golden', 'mobilenetv3_ssdlite_voc.param')
+        _, blob = D_.synth_weights(D_.parse_param(param))
+        det = Detector2D(0.9, 0.01, param_text=open(param).read(), bin_bytes=blob, max_batch=S, lib=lib)
+        d_bgr = d_frames.unsqueeze(-1).expand(T, S, 480, 640, 3).contiguous()          # gray replicated to 3 channels (SURVEY §8(d) input 2)
+        sD = torch.cuda.Stream(); sD.wait_stream(torch.cuda.current_stream())
+        dl_, dc_ = C_.c_void_p(), C_.c_void_p()
+        def det_step(i):
+            lib.check(lib.dll.sgx_det_forward_batch_dev(det.h, _vp_(d_bgr[order[i % len(order)]]), 640 * 3, S, C_.byref(dl_), C_.byref(dc_), C_.c_void_p(sD.cuda_stream)), 'detector forward')
+
     def step(i):
+        if det is not None: det_step(i)
         m = masks.get((order[(i - 1) % len(order)], order[i % len(order)])) if (i > 0 and masks) else None
         tr.step(d_frames[order[i % len(order)]], d_depth, stream=stream, mask=m)
 
@@ -138,6 +157,7 @@ def main():
     for i in range(args.steps):
         step(args.warmup + i)
     tr.synchronize()
+    if det is not None: sD.synchronize()
     torch.cuda.synchronize()
     if dist: dist.barrier()
     torch.cuda.synchronize()
@@ -238,6 +258,7 @@ def main():
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
         'config': {'workload': 'Single MI355X: ORB extract+match HIP kernels, 640x480 synthetic stream, 1000 feats/frame',
+                   'detector_forward_concurrent': bool(args.detector),
                    'stages': ['orb_extract'] + ([] if args.no_mask else ['dynamic_mask+erase (LK/F inputs from synthetic ground truth)']) + ['stereo_from_rgbd', 'motion_model', 'search_by_projection(cur,last)', 'pose_optimization'] +
                              ([] if args.no_local_map else ['search_by_projection(cur,local_map th=3)', 'pose_optimization#2']) + ['unproject'] +
                              ([] if args.no_local_map else ['make_map_points']),
