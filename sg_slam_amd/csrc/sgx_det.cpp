@@ -115,7 +115,7 @@ extern "C" void sgx_det_destroy(sgx_det *h) { delete h; }
 extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bin_bytes, int width, int height, int max_batch,
                               float detection_confidence_threshold, float dynamic_detection_confidence_threshold, sgx_det **out)
 {
-    if (!param_text || !bin || !out || width < 8 || height < 8 || max_batch < 1) return SGX_ERR_INVALID;
+    if (!param_text || !bin || !out || width < 8 || height < 8 || width > SGX_PRE_MAXW || max_batch < 1) return SGX_ERR_INVALID;
     sgx_det *h = new sgx_det();
     h->W = width; h->H = height; h->max_batch = max_batch; h->legacy = g_det_legacy; h->det_th = detection_confidence_threshold; h->dyn_th = dynamic_detection_confidence_threshold;
     int rc = parse_param(param_text, h->layers);
@@ -226,6 +226,7 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
         if (L.type == "Reshape") { const int oid = blob(L.outs[0]); h->blobs[oid] = A; h->blobs[oid].alias = raw_in; h->blobs[oid].w = L.geti(0, 1); h->blobs[oid].h = (int)(A.n / L.geti(0, 1)); continue; }
         if (L.type == "Softmax") {
             Op op; op.kind = OP_SOFTMAX; op.in0 = in0; op.C = h->blobs[blob(L.ins[0])].w; op.rows = (int)(A.n / op.C);
+            if (op.C < 1 || op.C > SGX_SOFTMAX_MAXC) FAIL(SGX_ERR_UNSUPPORTED);
             const int oid = blob(L.outs[0]); Blob &ob = h->blobs[oid]; ob = A; ob.alias = -1; ob.d = nullptr;
             op.out = oid; op.name = L.name; h->ops.push_back(op); continue;
         }
@@ -310,7 +311,7 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
     h->priors = prior_boxes; h->priors.insert(h->priors.end(), prior_vars.begin(), prior_vars.end());
     if ((size_t)h->num_priors * 4 != h->blobs[h->loc_blob].n || (size_t)h->num_priors * h->num_class != h->blobs[h->conf_blob].n) { delete h; return SGX_ERR_INVALID; }
     std::vector<SgxDetTab> xt, yt; build_tab(width, T, xt); build_tab(height, T, yt);
-    if (h->alloc(&h->d_xt, T) || h->alloc(&h->d_yt, T) || h->alloc(&h->d_img, (size_t)B * width * height * 3)) { delete h; return SGX_ERR_NOMEM; }
+    if (h->alloc(&h->d_xt, T) || h->alloc(&h->d_yt, T) || h->alloc(&h->d_img, (size_t)B * height * ((3 * width + 3) & ~3) + 4)) { delete h; return SGX_ERR_NOMEM; }
     if (hipMemcpy(h->d_xt, xt.data(), sizeof(SgxDetTab) * T, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(h->d_yt, yt.data(), sizeof(SgxDetTab) * T, hipMemcpyHostToDevice) != hipSuccess) { delete h; return SGX_ERR_DEVICE; }
     *out = h;
     return SGX_OK;
@@ -427,7 +428,7 @@ static void run_op(sgx_det *h, const Op &op, int batch, sgx_stream_t st)
 static void run_preprocess(sgx_det *h, const uint8_t *d_img, int pitch, int batch, sgx_stream_t st)
 {
     const int T = h->T;
-    SGX_LAUNCH(k_det_preprocess, dim3((T * T + 255) / 256, batch), dim3(256), st, batch, d_img, h->W, h->H, pitch, h->d_xt, h->d_yt, T, 123.675f, 116.28f, 103.53f,
+    SGX_LAUNCH(k_det_preprocess, dim3(T, batch), dim3(256), st, batch, d_img, h->W, h->H, pitch, h->d_xt, h->d_yt, T, 123.675f, 116.28f, 103.53f,
                h->blobs[h->blob_id.at("input")].d);
 }
 
@@ -435,7 +436,7 @@ static void run_preprocess(sgx_det *h, const uint8_t *d_img, int pitch, int batc
 // Leaves loc (num_priors*4) and softmax conf (num_priors*num_class) per image in device memory; returns their pointers.
 extern "C" int sgx_det_forward_batch_dev(sgx_det *h, const uint8_t *d_img, int pitch, int batch, const float **d_loc, const float **d_conf, void *stream_)
 {
-    if (!h || !d_img || batch < 1 || batch > h->max_batch || pitch < 3 * h->W) return SGX_ERR_INVALID;
+    if (!h || !d_img || batch < 1 || batch > h->max_batch || pitch < ((3 * h->W + 3) & ~3) || (pitch & 3) || ((uintptr_t)d_img & 3)) return SGX_ERR_INVALID;   // rows are read as aligned dwords
     sgx_stream_t st = (sgx_stream_t)stream_;
     run_preprocess(h, d_img, pitch, batch, st);
 #ifndef SGX_EMU
@@ -566,11 +567,12 @@ static void detection_output(const sgx_det *h, const float *loc, const float *co
 extern "C" int sgx_det_detect(sgx_det *h, const uint8_t *images, int pitch, int batch, sgx_det_result *results)
 {
     if (!h || !images || !results || batch < 1 || batch > h->max_batch || pitch < 3 * h->W) return SGX_ERR_INVALID;
+    const int ipitch = (3 * h->W + 3) & ~3;                      // device copy: rows padded to whole dwords
     for (int b = 0; b < batch; b++)
         for (int y = 0; y < h->H; y++)
-            SGX_CHECK_HIP(hipMemcpyAsync(h->d_img + ((size_t)b * h->H + y) * 3 * h->W, images + ((size_t)b * h->H + y) * pitch, (size_t)3 * h->W, hipMemcpyHostToDevice, 0));
+            SGX_CHECK_HIP(hipMemcpyAsync(h->d_img + ((size_t)b * h->H + y) * ipitch, images + ((size_t)b * h->H + y) * pitch, (size_t)3 * h->W, hipMemcpyHostToDevice, 0));
     const float *dl = nullptr, *dc = nullptr;
-    int rc = sgx_det_forward_batch_dev(h, h->d_img, 3 * h->W, batch, &dl, &dc, nullptr);
+    int rc = sgx_det_forward_batch_dev(h, h->d_img, ipitch, batch, &dl, &dc, nullptr);
     if (rc != SGX_OK) return rc;
     const size_t nl = (size_t)h->num_priors * 4, ncf = (size_t)h->num_priors * h->num_class;
     std::vector<float> loc(nl * batch), conf(ncf * batch);

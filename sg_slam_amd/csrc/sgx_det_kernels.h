@@ -79,19 +79,30 @@ SGX_DEV float sgx_epi(const SgxEpi &e, float v, size_t uoff, unsigned voff4 = 0)
 // ---------------------------------------------------------------------------------------------
 struct SgxDetTab { short o, a0, a1, pad; };
 
+// One workgroup per (output row, image): the two source rows the row needs are staged in LDS as aligned dwords (coalesced), the T outputs x 3 channels
+// are computed from LDS bytes and stored as three coalesced plane rows.  grid = (T, B); the row pitch and the image base are multiples of 4.
+#define SGX_PRE_MAXW 2048
 SGX_KERNEL(256) k_det_preprocess(int B, const uint8_t *img, int W, int H, int pitch, const SgxDetTab *xt, const SgxDetTab *yt, int T,
                                  float m0, float m1, float m2, float *out)
 {
+    SGX_LDS uint32_t rows[2][SGX_PRE_MAXW * 3 / 4 + 2];
+    const int y = (int)blockIdx.x, b = (int)blockIdx.y;
+    const SgxDetTab ty = yt[y];
+    const int ndw = (3 * W + 3) >> 2;
     SGX_THREADS_BEGIN(tid)
-    const int idx = (int)blockIdx.x * 256 + tid, b = (int)blockIdx.y;
-    if (idx < T * T) {
-        const int y = idx / T, x = idx - y * T;
-        const SgxDetTab tx = xt[x], ty = yt[y];
-        const uint8_t *r0 = img + ((size_t)b * H + ty.o) * pitch + 3 * tx.o, *r1 = r0 + pitch;
-        const float mean[3] = { m0, m1, m2 };
+    const uint32_t *s0 = (const uint32_t *)(img + ((size_t)b * H + ty.o) * pitch), *s1 = (const uint32_t *)(img + ((size_t)b * H + ty.o + 1) * pitch);
+    for (int t = tid; t < ndw; t += 256) { rows[0][t] = s0[t]; rows[1][t] = s1[t]; }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    const uint8_t *r0 = (const uint8_t *)rows[0], *r1 = (const uint8_t *)rows[1];
+    const float mean[3] = { m0, m1, m2 };
+    for (int x = tid; x < T; x += 256) {
+        const SgxDetTab tx = xt[x];
+        const uint8_t *p0 = r0 + 3 * tx.o, *p1 = r1 + 3 * tx.o;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            const int h0 = r0[c] * tx.a0 + r0[3 + c] * tx.a1, h1 = r1[c] * tx.a0 + r1[3 + c] * tx.a1;
+            const int h0 = p0[c] * tx.a0 + p0[3 + c] * tx.a1, h1 = p1[c] * tx.a0 + p1[3 + c] * tx.a1;
             const int v = (((ty.a0 * (h0 >> 4)) >> 16) + ((ty.a1 * (h1 >> 4)) >> 16) + 2) >> 2;
             out[(((size_t)b * 3 + c) * T + y) * T + x] = ((float)(v & 255) - mean[c]) * 1.0f;
         }
@@ -553,20 +564,34 @@ SGX_KERNEL(256) k_copy_into(int n, const float *src, size_t src_pitch, float *ds
     SGX_THREADS_END
 }
 
-// k_softmax_rows: ncnn Softmax over the innermost axis of a (rows x C) blob (mbox_conf_reshape: 2268 x 21): exp(x - max) / sum
+// k_softmax_rows: ncnn Softmax over the innermost axis of a (rows x C) blob (mbox_conf_reshape: 2268 x 21): exp(x - max) / sum.
+// A workgroup owns 256 consecutive rows: the 256*C floats are staged in LDS with coalesced loads (row stride C is odd -> conflict-free
+// per-row walks), every thread normalises its row in LDS, and the block is written back coalesced.  C <= SGX_SOFTMAX_MAXC.
+#define SGX_SOFTMAX_MAXC 32
 SGX_KERNEL(256) k_softmax_rows(int rows, int C, const float *in, size_t in_pitch, float *out, size_t out_pitch)
 {
+    SGX_LDS float buf[256 * SGX_SOFTMAX_MAXC + 1];
+    const int r0 = (int)blockIdx.x * 256, b = (int)blockIdx.y;
+    const int nr = min(256, rows - r0), tot = nr * C;
+    const float *src = in + (size_t)b * in_pitch + (size_t)r0 * C;
+    float *dst = out + (size_t)b * out_pitch + (size_t)r0 * C;
     SGX_THREADS_BEGIN(tid)
-    const int r = (int)blockIdx.x * 256 + tid, b = (int)blockIdx.y;
-    if (r < rows) {
-        const float *x = in + (size_t)b * in_pitch + (size_t)r * C;
-        float *y = out + (size_t)b * out_pitch + (size_t)r * C;
+    for (int t = tid; t < tot; t += 256) buf[t] = src[t];
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    if (tid < nr) {
+        float *x = buf + tid * C;
         float m = x[0];
         for (int c = 1; c < C; c++) m = fmaxf(m, x[c]);
         float s = 0.f;
-        for (int c = 0; c < C; c++) { const float e = expf(x[c] - m); y[c] = e; s += e; }
-        for (int c = 0; c < C; c++) y[c] = y[c] / s;
+        for (int c = 0; c < C; c++) { const float e = expf(x[c] - m); x[c] = e; s += e; }
+        for (int c = 0; c < C; c++) x[c] = x[c] / s;
     }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    for (int t = tid; t < tot; t += 256) dst[t] = buf[t];
     SGX_THREADS_END
 }
 
