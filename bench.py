@@ -62,6 +62,8 @@ def main():
     ap.add_argument('--no-cpu-all-cores', action='store_true', help='skip the frames-parallel all-host-cores CPU baseline (keeps the 1-core figure)')
     ap.add_argument('--no-pipeline', action='store_true', help='single HIP stream (no overlap of extraction with match/pose-opt)')
     ap.add_argument('--no-local-map', action='store_true', help='skip the TrackLocalMap stage (local-map SearchByProjection + second PoseOptimization)')
+    ap.add_argument('--groups', type=int, default=1, help='split the streams of this GPU into G independently pipelined groups (own extraction / tracking HIP streams each): '
+                    'the drain of one group between kernels overlaps the body of another')
     ap.add_argument('--detector', action='store_true', help='also run the detector forward (MobileNetV3-SSDLite, synthetic weights) on every frame, on a third HIP stream; '
                     'its host-side DetectionOutput post-processing is not included and the mask keeps using the synthetic person box')
     ap.add_argument('--no-mask', action='store_true', help='skip the dynamic-feature mask + erase stage (Frame::RmDynamicPointWithSemanticAndGeometry)')
@@ -102,7 +104,33 @@ def main():
     d_depth = torch.full((S, 480, 640), depth_val, dtype=torch.int16, device='cuda')      # the plane: constant raw depth (u16 bits)
     order = ping_pong(T)
 
-    tr = TrackerBatch(lib, S, cam, xp='torch', pipelined=not args.no_pipeline, local_map=not args.no_local_map)
+    class TrackerGroups:
+        """G TrackerBatch instances over contiguous slices of the S streams, stepped together (same interface as one TrackerBatch for what bench.py reads)"""
+        def __init__(self, G):
+            self.bounds = [(g * S // G, (g + 1) * S // G) for g in range(G)]
+            self.trs = [TrackerBatch(lib, b - a, cam, xp='torch', pipelined=not args.no_pipeline, local_map=not args.no_local_map) for a, b in self.bounds]
+            self.max_boxes, self.cap, self.ex = self.trs[0].max_boxes, self.trs[0].cap, self.trs[0].ex
+        def set_initial_pose(self, T0):
+            for (a, b), t in zip(self.bounds, self.trs): t.set_initial_pose(T0[a:b])
+        def step(self, gray, depth, stream=None, mask=None):
+            for (a, b), t in zip(self.bounds, self.trs):
+                t.step(gray[a:b], depth[a:b], stream=stream, mask=None if mask is None else {k: v[a:b] for k, v in mask.items()})
+        def synchronize(self):
+            for t in self.trs: t.synchronize()
+        def _cat(self, parts): return tuple(np.concatenate(x) for x in zip(*parts))
+        def last_counts(self): return self._cat([t.last_counts() for t in self.trs])
+        def last_local_counts(self): return self._cat([t.last_local_counts() for t in self.trs])
+        def last_pose(self): return np.concatenate([t.last_pose() for t in self.trs])
+        @property
+        def rn(self): return torch.cat([t.rn for t in self.trs])
+        @property
+        def ninl(self): return torch.cat([t.ninl for t in self.trs])
+        @property
+        def nmatch(self): return torch.cat([t.nmatch for t in self.trs])
+        @property
+        def Tcw(self): return [torch.cat([t.Tcw[i] for t in self.trs]) for i in range(3)]
+
+    tr = TrackerGroups(max(1, min(args.groups, S)))
     tr.set_initial_pose(np.stack([gen.Tcw(t0) for t0 in t0s]))
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -194,18 +222,19 @@ def main():
     fps = frames_total / dt
 
     alg = algorithmic_bytes_per_frame(nkp=int(round(float(n_raw.mean()))), nmatch=int(round(float(nmatch.mean()))))
+    SL = S / len(tr.trs)                 # frames per launch (streams of one group)
     per_kernel = {}
     for k, (ms, n) in prof.items():
         if n == 0: continue
         avg_ms = ms / n
-        per_kernel[k] = {'avg_ms_per_launch': round(avg_ms, 5), 'launches': n, 'total_ms': round(ms, 3), 'alg_bytes_per_launch': alg[k] * S,
-                         'achieved_GBs': round(alg[k] * S / (avg_ms * 1e-3) / 1e9, 3)}
+        per_kernel[k] = {'avg_ms_per_launch': round(avg_ms, 5), 'launches': n, 'total_ms': round(ms, 3), 'alg_bytes_per_launch': alg[k] * SL,
+                         'achieved_GBs': round(alg[k] * SL / (avg_ms * 1e-3) / 1e9, 3)}
     dom = max(per_kernel, key=lambda k: per_kernel[k]['total_ms'])
     dk = per_kernel[dom]
     traffic = None
     try:        # HBM traffic of the same kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/)
         tj = json.load(open(os.path.join(ROOT, 'profiles', 'r1_traffic.json')))
-        if tj['frames_per_launch'] == S and dom in tj['bytes_per_launch']:
+        if tj['frames_per_launch'] == SL and dom in tj['bytes_per_launch']:
             traffic = tj['bytes_per_launch'][dom]
     except Exception:
         traffic = None
@@ -258,7 +287,7 @@ def main():
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
         'config': {'workload': 'Single MI355X: ORB extract+match HIP kernels, 640x480 synthetic stream, 1000 feats/frame',
-                   'detector_forward_concurrent': bool(args.detector),
+                   'detector_forward_concurrent': bool(args.detector), 'stream_groups': len(tr.trs),
                    'stages': ['orb_extract'] + ([] if args.no_mask else ['dynamic_mask+erase (LK/F inputs from synthetic ground truth)']) + ['stereo_from_rgbd', 'motion_model', 'search_by_projection(cur,last)', 'pose_optimization'] +
                              ([] if args.no_local_map else ['search_by_projection(cur,local_map th=3)', 'pose_optimization#2']) + ['unproject'] +
                              ([] if args.no_local_map else ['make_map_points']),
