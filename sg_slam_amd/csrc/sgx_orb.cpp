@@ -33,6 +33,7 @@ struct sgx_orb {
     signed char *d_pattern = nullptr;
     // device workspace (sized for cfg.max_batch)
     uint8_t *d_pyr = nullptr;
+    uint8_t *d_blur = nullptr; SgxBlurTile *d_blur_tiles = nullptr;     // blurred copy of every level (k_blur_levels) and its tile table
     uint32_t *d_cand = nullptr;
     int *d_cand_count = nullptr;
     uint16_t *d_node_scratch = nullptr;
@@ -128,7 +129,7 @@ extern "C" void sgx_orb_destroy(sgx_orb *h)
     (void)hipFree(h->d_cand_count); (void)hipFree(h->d_node_scratch); (void)hipFree(h->d_sel); (void)hipFree(h->d_sel_count); (void)hipFree(h->d_status);
     (void)hipFree(h->d_gray1); (void)hipFree(h->d_kps1); (void)hipFree(h->d_desc1); (void)hipFree(h->d_count1);
     for (int l = 0; l < SGX_MAX_LEVELS; l++) { (void)hipFree(h->d_xt[l]); (void)hipFree(h->d_yt[l]); }
-    (void)hipFree(h->d_xt_all); (void)hipFree(h->d_yt_all); (void)hipFree(h->d_pyr_rects);
+    (void)hipFree(h->d_xt_all); (void)hipFree(h->d_yt_all); (void)hipFree(h->d_pyr_rects); (void)hipFree(h->d_blur); (void)hipFree(h->d_blur_tiles);
     delete h;
 }
 
@@ -200,6 +201,20 @@ extern "C" int sgx_orb_create(const sgx_orb_config *cfg, sgx_orb **out)
         g.fast_off_score = tile_b; g.fast_off_qlist = 2 * tile_b; g.fast_off_out = 2 * tile_b + q_b; g.fast_lds_bytes = 2 * tile_b + q_b + o_b;
     }
     g.pyr_pitch = (off + 255) & ~255;
+    std::vector<SgxBlurTile> btiles;
+    {
+        int boff = 0;
+        for (int l = 0; l < g.nlevels; l++) {
+            SgxLevel &L = g.lv[l];
+            L.bstride = (L.w + 63) & ~63; L.boff = boff; boff += L.bstride * L.h;
+            for (int y0 = 0; y0 < L.h; y0 += SGX_BT_H) for (int x0 = 0; x0 < L.w; x0 += SGX_BT_W) {
+                SgxBlurTile t; memset(&t, 0, sizeof t);
+                t.level = (short)l; t.x0 = (short)x0; t.y0 = (short)y0; t.w = (short)std::min(SGX_BT_W, L.w - x0); t.h = (short)std::min(SGX_BT_H, L.h - y0);
+                btiles.push_back(t);
+            }
+        }
+        g.blur_pitch = (boff + 255) & ~255; g.nblur_tiles = (int)btiles.size();
+    }
     g.ncells = (int)cells.size();
     g.kp_cap = kp_cap;
 
@@ -209,6 +224,9 @@ extern "C" int sgx_orb_create(const sgx_orb_config *cfg, sgx_orb **out)
     SGX_ALLOC(h->d_umax, 16 * sizeof(int));
     SGX_ALLOC(h->d_pattern, 1024);
     SGX_ALLOC(h->d_pyr, (size_t)B * g.pyr_pitch + 256);
+    SGX_ALLOC(h->d_blur, (size_t)B * g.blur_pitch + 256);
+    SGX_ALLOC(h->d_blur_tiles, btiles.size() * sizeof(SgxBlurTile));
+    SGX_CHECK_HIP(hipMemcpy(h->d_blur_tiles, btiles.data(), btiles.size() * sizeof(SgxBlurTile), hipMemcpyHostToDevice));
     SGX_ALLOC(h->d_cand, (size_t)B * g.cand_pitch * 4);
     SGX_ALLOC(h->d_node_scratch, (size_t)B * g.cand_pitch * 2);
     SGX_ALLOC(h->d_cand_count, (size_t)B * nl * 4);
@@ -351,8 +369,17 @@ extern "C" int sgx_orb_extract_batch_dev(sgx_orb *h, const uint8_t *d_gray, int 
     sgx_prof_begin(SGX_K_ORIENT_DESC, stream);
     unsigned long long umax_packed = 0;
     for (int i = 0; i < 16; i++) umax_packed |= (unsigned long long)(h->umax_h[i] & 15) << (4 * i);
-    SGX_LAUNCH_DYN(k_orient_desc, dim3(g.kp_cap * batch), dim3(64), e_extra / 2, stream, g, d_gray, pitch, h->d_pyr, h->d_sel, h->d_sel_count,
-               umax_packed, h->d_pattern, (uint8_t *)d_kps, d_desc, d_count, cap, batch, h->d_status);
+    // default: blur whole levels once (k_blur_levels), then a light per-keypoint kernel; SGX_TUNE_ORB_PATCH_BLUR=1 selects the first design (blur of a
+    // 37x37 window per keypoint inside k_orient_desc) — identical bytes (tests), ~45 vs ~20+ VALU operations per pixel-equivalent
+    static const bool patch_blur = getenv("SGX_TUNE_ORB_PATCH_BLUR") != nullptr;
+    if (patch_blur) {
+        SGX_LAUNCH_DYN(k_orient_desc, dim3(g.kp_cap * batch), dim3(64), e_extra / 2, stream, g, d_gray, pitch, h->d_pyr, h->d_sel, h->d_sel_count,
+                       umax_packed, h->d_pattern, (uint8_t *)d_kps, d_desc, d_count, cap, batch, h->d_status);
+    } else {
+        SGX_LAUNCH(k_blur_levels, dim3(g.nblur_tiles * batch), dim3(256), stream, g, h->d_blur_tiles, d_gray, pitch, h->d_pyr, h->d_blur, batch);
+        SGX_LAUNCH(k_orient_desc2, dim3(g.kp_cap * batch), dim3(64), stream, g, d_gray, pitch, h->d_pyr, h->d_blur, h->d_sel, h->d_sel_count,
+                   umax_packed, h->d_pattern, (uint8_t *)d_kps, d_desc, d_count, cap, batch, h->d_status);
+    }
     sgx_prof_end(SGX_K_ORIENT_DESC, stream);
     SGX_CHECK_HIP(hipGetLastError());
     return SGX_OK;

@@ -28,6 +28,7 @@ struct SgxLevel {
     int cell0;                 // index of this level's first cell in the cell table
     int patch_size;            // (int)(31*scale)
     int cand_off, cand_cap;    // slice of one frame's candidate buffer (cap = exact upper bound of NMS survivors)
+    int boff, bstride;         // blurred copy of the level (all levels incl. 0): byte offset inside one frame's blur buffer, row stride
     float scale;               // mvScaleFactor[level]
 };
 
@@ -38,6 +39,7 @@ struct SgxOrbGeom {
     int kp_cap;                // keypoint capacity per frame
     int fast_off_score, fast_off_qlist, fast_off_out, fast_lds_bytes;   // k_fast_cells dynamic-LDS carve (bytes)
     int cand_pitch;            // candidate entries per frame (all levels)
+    int blur_pitch, nblur_tiles;   // bytes per frame of blurred-level storage; tiles of k_blur_levels over all levels
     int ini_th, min_th;
     SgxLevel lv[SGX_MAX_LEVELS];
 };
@@ -888,6 +890,208 @@ SGX_KERNEL(64) k_orient_desc(SgxOrbGeom g, const uint8_t *gray, int gray_pitch, 
     SGX_THREADS_END
     SGX_SYNC();
 
+    SGX_THREADS_BEGIN(tid)
+    if (tid < 32) {
+        int v = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) v |= bits[8 * tid + j] << j;
+        desc[((size_t)frame * cap + slot) * 32 + tid] = (uint8_t)v;
+    }
+    SGX_THREADS_END
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_blur_levels: GaussianBlur(level, 7x7, sigma 2, BORDER_REFLECT_101) of every pyramid level (ORBextractor.cc:1086-1087), whole levels like the
+// reference, as one launch over 64 x 32 tiles: the tile + 3-px halo is staged in LDS (aligned dwords inside the image, reflected byte loads on
+// border tiles), horizontal pass in 8.8 fixed point and vertical pass in 16.16 with sliding windows (every staged value is read once per pass), exact
+// OpenCV taps {18,34,48,56,48,34,18}/256 and rounding.  It costs ~20 VALU operations per pixel, less than half of blurring a 37x37 window per
+// keypoint, and leaves k_orient_desc2 with plain gathers.  block -> (tile, frame), frame fastest (XCD-aware like k_fast_cells).
+// ---------------------------------------------------------------------------------------------
+struct SgxBlurTile { short level, x0, y0, w, h, pad0, pad1, pad2; };
+#define SGX_BT_W 64
+#define SGX_BT_H 58            /* + 6 halo rows = 64 staged rows: the horizontal pass is exactly two rounds of 256 (row, 8-column) tasks */
+#define SGX_BT_IS 80            /* LDS row stride of the staged input (bytes): 3 lead + 3 + 64 + 3, dword aligned */
+#define SGX_BT_HS 72            /* row stride of the horizontal-pass buffer (u16) */
+
+SGX_KERNEL(256) k_blur_levels(SgxOrbGeom g, const SgxBlurTile *tiles, const uint8_t *gray, int gray_pitch, const uint8_t *pyr, uint8_t *blur, int batch)
+{
+    SGX_LDS uint32_t in_dw[(SGX_BT_H + 6) * SGX_BT_IS / 4];
+    SGX_LDS uint32_t h_dw[(SGX_BT_H + 6) * SGX_BT_HS / 2];
+    SGX_LDS uint32_t o_dw[SGX_BT_H * SGX_BT_W / 4];
+    uint8_t *in = (uint8_t *)in_dw; uint16_t *hb = (uint16_t *)h_dw; uint8_t *ob = (uint8_t *)o_dw;
+    const int GK0 = 18, GK1 = 34, GK2 = 48, GK3 = 56;
+    const int bid = (int)blockIdx.x, frame = bid % batch;
+    const SgxBlurTile t = tiles[bid / batch];
+    const SgxLevel L = g.lv[t.level];
+    int stride;
+    const uint8_t *img = sgx_level_ptr(g, gray, gray_pitch, pyr, frame, t.level, &stride);
+    const int rows = t.h + 6, xs = t.x0 - 3, ys = t.y0 - 3;
+    // staging: always aligned dwords.  Rows outside the level are fetched from their BORDER_REFLECT_101 source row; dwords that would start outside the row
+    // are clamped into it (their bytes are garbage) and the at most 3 + 3 halo columns that lie outside the level are then copied from their reflected
+    // columns, which are always staged.  (A per-byte reflected loader for border tiles — 30 % of the tiles — cost more than the two blur passes.)
+    const int lead = xs & 3, xa = xs - lead, maxq = (stride >> 2) - 1;
+    SGX_THREADS_BEGIN(tid)
+    for (int i = tid; i < rows * (SGX_BT_IS / 4); i += 256) {
+        const int r = i / (SGX_BT_IS / 4), q = i - r * (SGX_BT_IS / 4);
+        int yy = ys + r; yy = yy < 0 ? -yy : (yy >= L.h ? 2 * (L.h - 1) - yy : yy);
+        const int dq = min(max((xa >> 2) + q, 0), maxq);
+        in_dw[i] = ((const uint32_t *)(img + (size_t)yy * stride))[dq];
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+    if (xs < 0 || t.x0 + t.w + 3 > L.w) {
+        SGX_THREADS_BEGIN(tid)
+        for (int k = tid; k < rows * 6; k += 256) {
+            const int r = k / 6, hc = k - r * 6;
+            const int x = hc < 3 ? xs + hc : t.x0 + t.w + (hc - 3);               // level column of this halo slot
+            if (x < 0 || x >= L.w) {
+                const int xr = x < 0 ? -x : 2 * (L.w - 1) - x;
+                in[r * SGX_BT_IS + lead + (x - xs)] = in[r * SGX_BT_IS + lead + (xr - xs)];
+            }
+        }
+        SGX_THREADS_END
+        SGX_SYNC();
+    }
+    // horizontal pass: task = (row, 8-column segment); 14 source bytes from 5 aligned dwords realigned with v_alignbyte
+    SGX_THREADS_BEGIN(tid)
+    for (int k = tid; k < rows * (SGX_BT_W / 8); k += 256) {
+        const int r = k >> 3, sg = k & 7;
+        if (8 * sg >= t.w) continue;
+        const uint32_t *w = in_dw + (r * SGX_BT_IS + 8 * sg) / 4;
+        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
+        const uint32_t v0 = sgx_alignbyte(w1, w0, lead), v1 = sgx_alignbyte(w2, w1, lead), v2 = sgx_alignbyte(w3, w2, lead), v3 = sgx_alignbyte(w4, w3, lead);
+        int b[16];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { b[j] = (v0 >> (8 * j)) & 255; b[4 + j] = (v1 >> (8 * j)) & 255; b[8 + j] = (v2 >> (8 * j)) & 255; b[12 + j] = (v3 >> (8 * j)) & 255; }
+        uint32_t o[4];
+#pragma unroll
+        for (int c = 0; c < 8; c += 2) {
+            const uint32_t h0 = (uint32_t)(GK0 * (b[c] + b[c + 6]) + GK1 * (b[c + 1] + b[c + 5]) + GK2 * (b[c + 2] + b[c + 4]) + GK3 * b[c + 3]);
+            const uint32_t h1 = (uint32_t)(GK0 * (b[c + 1] + b[c + 7]) + GK1 * (b[c + 2] + b[c + 6]) + GK2 * (b[c + 3] + b[c + 5]) + GK3 * b[c + 4]);
+            o[c >> 1] = h0 | (h1 << 16);
+        }
+        uint32_t *dst = h_dw + (r * SGX_BT_HS + 8 * sg) / 2;
+        dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3];
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+    // vertical pass: task = (column, 8-row segment), 14 sliding reads per 8 outputs
+    SGX_THREADS_BEGIN(tid)
+    for (int k = tid; k < 64 * ((SGX_BT_H + 7) / 8); k += 256) {
+        const int c = k & 63, sg = k >> 6, r0 = 8 * sg;
+        if (c < t.w && r0 < t.h) {
+            uint32_t h[14];
+#pragma unroll
+            for (int j = 0; j < 14; j++) h[j] = (r0 + j < SGX_BT_H + 6) ? (uint32_t)hb[(r0 + j) * SGX_BT_HS + c] : 0u;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t acc = (uint32_t)GK0 * (h[j] + h[j + 6]) + (uint32_t)GK1 * (h[j + 1] + h[j + 5]) + (uint32_t)GK2 * (h[j + 2] + h[j + 4]) + (uint32_t)GK3 * h[j + 3];
+                ob[(r0 + j) * SGX_BT_W + c] = (uint8_t)((acc + 32768u) >> 16);
+            }
+        }
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    uint8_t *dst = blur + (size_t)frame * g.blur_pitch + L.boff;
+    for (int i = tid; i < t.h * (SGX_BT_W / 4); i += 256) {
+        const int r = i >> 4, q = i & 15;
+        if (4 * q < t.w) *(uint32_t *)(dst + (size_t)(t.y0 + r) * L.bstride + t.x0 + 4 * q) = o_dw[i];        // rows are padded to 64 bytes: the last dword may spill into the padding
+    }
+    SGX_THREADS_END
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_orient_desc2: IC_Angle (ORBextractor.cc:78-105) on the raw level + steered BRIEF (:109-148) sampled from the blurred level written by k_blur_levels.
+// One wave per keypoint slot, XCD-aware block order as k_orient_desc.  Keypoints sit >= 19 px from the border (EDGE_THRESHOLD) and the rotated pattern
+// reaches 18 px, so neither the 31x31 moment patch nor the samples ever leave the level: no border path.
+// ---------------------------------------------------------------------------------------------
+#define SGX_MS 36              /* LDS row stride of the staged 31x31 moment patch (bytes) */
+SGX_KERNEL(64) k_orient_desc2(SgxOrbGeom g, const uint8_t *gray, int gray_pitch, const uint8_t *pyr, const uint8_t *blur,
+                              const uint32_t *sel, const int *sel_count, unsigned long long umax_packed, const signed char *pattern,
+                              uint8_t *kps_raw, uint8_t *desc, int *count, int cap, int batch, uint32_t *status)
+{
+    SGX_LDS uint32_t patch_dw[31 * SGX_MS / 4];
+    SGX_LDS uint8_t bits[256];
+    SGX_LDS int s_m01, s_m10;
+    SGX_LDS float s_a, s_b;
+    const uint8_t *patch = (const uint8_t *)patch_dw;
+    int slot, frame;
+    {
+        const int n = (int)blockIdx.x, kc = g.kp_cap;
+        if ((batch & 7) == 0) { const int xcd = n & 7, j = n >> 3; frame = xcd + 8 * (j / kc); slot = j % kc; }
+        else { frame = n / kc; slot = n % kc; }
+    }
+    int level = -1, base = 0, total = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+        const int n = sel_count[frame * g.nlevels + l];
+        if (level < 0 && slot < total + n) { level = l; base = total; }
+        total += n;
+    }
+    if (slot == 0) {
+        SGX_THREADS_BEGIN(tid)
+        if (tid == 0) { count[frame] = total < cap ? total : cap; if (total > cap) sgx_atomic_or(status, SGX_ST_KP_OVERFLOW); }
+        SGX_THREADS_END
+    }
+    if (level < 0 || slot >= cap) return;
+    const SgxLevel L = g.lv[level];
+    const uint32_t e = sel[((size_t)frame * g.nlevels + level) * SGX_OCT_MAXN + (slot - base)];
+    const int kx = (int)(e & 0xFFF) + SGX_BORDER, ky = (int)((e >> 12) & 0xFFF) + SGX_BORDER;   // :844-845
+    int stride;
+    const uint8_t *img = sgx_level_ptr(g, gray, gray_pitch, pyr, frame, level, &stride);
+    const int px0 = kx - 15, py0 = ky - 15, lead = px0 & 3, xa = px0 - lead;
+    SGX_THREADS_BEGIN(tid)
+    if (tid == 0) { s_m01 = 0; s_m10 = 0; }
+#pragma unroll
+    for (int it_ = 0; it_ < (31 * (SGX_MS / 4) + 63) / 64; it_++) { const int i = tid + 64 * it_; if (i >= 31 * (SGX_MS / 4)) break;
+        const int r = i / (SGX_MS / 4), q = i - r * (SGX_MS / 4);
+        patch_dw[i] = *(const uint32_t *)(img + (size_t)(py0 + r) * stride + xa + 4 * q);              // 36 bytes per row from an aligned start: inside the padded row
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    int m10 = 0, m01 = 0;
+#pragma unroll
+    for (int it_ = 0; it_ < (31 * 31 + 63) / 64; it_++) { const int i = tid + 64 * it_; if (i >= 31 * 31) break;
+        const int v = i / 31 - 15, u = i - (v + 15) * 31 - 15;
+        const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
+        if (au <= (int)((umax_packed >> (4 * av)) & 15ull)) {
+            const int I = patch[(15 + v) * SGX_MS + lead + 15 + u];
+            m10 += u * I; m01 += v * I;
+        }
+    }
+    sgx_atomic_add(&s_m10, m10); sgx_atomic_add(&s_m01, m01);
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    if (tid == 0) {
+        const float angle = sgx_fast_atan2((float)s_m01, (float)s_m10);
+        const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+        float sn, cs;
+        sgx_sincosf(angle * factorPI, &sn, &cs);
+        s_a = cs; s_b = sn;
+        float *kp = (float *)(kps_raw + ((size_t)frame * cap + slot) * 28);
+        float fx = (float)kx, fy = (float)ky;
+        if (level != 0) { fx = fx * L.scale; fy = fy * L.scale; }
+        kp[0] = fx; kp[1] = fy; kp[2] = (float)L.patch_size; kp[3] = angle; kp[4] = (float)(e >> 24);
+        ((int *)kp)[5] = level; ((int *)kp)[6] = -1;
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    const float a = s_a, b = s_b;
+    const uint8_t *bl = blur + (size_t)frame * g.blur_pitch + L.boff + (size_t)ky * L.bstride + kx;
+#pragma unroll
+    for (int it_ = 0; it_ < 4; it_++) { const int t = tid + 64 * it_;
+        const uint32_t pw = *(const uint32_t *)(pattern + 4 * t);
+        const float x0 = (float)(signed char)(pw & 255u), y0 = (float)(signed char)((pw >> 8) & 255u), x1 = (float)(signed char)((pw >> 16) & 255u), y1 = (float)(signed char)(pw >> 24);
+        const int r0 = sgx_cvround(x0 * b + y0 * a), c0 = sgx_cvround(x0 * a - y0 * b);
+        const int r1 = sgx_cvround(x1 * b + y1 * a), c1 = sgx_cvround(x1 * a - y1 * b);
+        const int t0 = bl[r0 * L.bstride + c0], t1 = bl[r1 * L.bstride + c1];
+        bits[t] = (uint8_t)(t0 < t1);
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
     SGX_THREADS_BEGIN(tid)
     if (tid < 32) {
         int v = 0;

@@ -136,3 +136,19 @@ def run_fused_pyramid_equals_per_level(lib, to_dev=lambda a: a):
 
 def test_fused_pyramid_equals_per_level(emu):
     run_fused_pyramid_equals_per_level(emu)
+
+
+def run_other_geometries(lib, oracle):
+    """full extraction parity at image sizes other than 640x480 (level widths that are not multiples of the tile sizes, narrow last tiles)"""
+    tex = synth.world_texture(7, 1024, 900)
+    for (w, h) in ((752, 480), (516, 388), (320, 240)):
+        img = np.ascontiguousarray(tex[100:100 + h, 50:50 + w])
+        ko, do = oracle.orb_extract(img)
+        e = ORBextractor(lib=lib, width=w, height=h)
+        k, d = e(img)
+        e.close()
+        assert len(ko) > 500 and _same(k, d, ko, do), (w, h)
+
+
+def test_other_geometries_emu(emu, oracle):
+    run_other_geometries(emu, oracle)

@@ -94,3 +94,8 @@ def test_fused_pyramid_equals_per_level_gpu(gpulib):
     import torch
     from test_orb_emu import run_fused_pyramid_equals_per_level
     run_fused_pyramid_equals_per_level(gpulib, to_dev=lambda a: torch.from_numpy(a).cuda())
+
+
+def test_other_geometries_gpu(gpulib, oracle):
+    from test_orb_emu import run_other_geometries
+    run_other_geometries(gpulib, oracle)
