@@ -913,7 +913,7 @@ struct SgxBlurTile { short level, x0, y0, w, h, pad0, pad1, pad2; };
 #define SGX_BT_IS 80            /* LDS row stride of the staged input (bytes): 3 lead + 3 + 64 + 3, dword aligned */
 #define SGX_BT_HS 72            /* row stride of the horizontal-pass buffer (u16) */
 
-SGX_KERNEL(256) k_blur_levels(SgxOrbGeom g, const SgxBlurTile *tiles, const uint8_t *gray, int gray_pitch, const uint8_t *pyr, uint8_t *blur, int batch)
+SGX_KERNEL(512) k_blur_levels(SgxOrbGeom g, const SgxBlurTile *tiles, const uint8_t *gray, int gray_pitch, const uint8_t *pyr, uint8_t *blur, int batch)
 {
     SGX_LDS uint32_t in_dw[(SGX_BT_H + 6) * SGX_BT_IS / 4];
     SGX_LDS uint32_t h_dw[(SGX_BT_H + 6) * SGX_BT_HS / 2];
@@ -931,7 +931,7 @@ SGX_KERNEL(256) k_blur_levels(SgxOrbGeom g, const SgxBlurTile *tiles, const uint
     // columns, which are always staged.  (A per-byte reflected loader for border tiles — 30 % of the tiles — cost more than the two blur passes.)
     const int lead = xs & 3, xa = xs - lead, maxq = (stride >> 2) - 1;
     SGX_THREADS_BEGIN(tid)
-    for (int i = tid; i < rows * (SGX_BT_IS / 4); i += 256) {
+    for (int i = tid; i < rows * (SGX_BT_IS / 4); i += (int)blockDim.x) {
         const int r = i / (SGX_BT_IS / 4), q = i - r * (SGX_BT_IS / 4);
         int yy = ys + r; yy = yy < 0 ? -yy : (yy >= L.h ? 2 * (L.h - 1) - yy : yy);
         const int dq = min(max((xa >> 2) + q, 0), maxq);
@@ -941,7 +941,7 @@ SGX_KERNEL(256) k_blur_levels(SgxOrbGeom g, const SgxBlurTile *tiles, const uint
     SGX_SYNC();
     if (xs < 0 || t.x0 + t.w + 3 > L.w) {
         SGX_THREADS_BEGIN(tid)
-        for (int k = tid; k < rows * 6; k += 256) {
+        for (int k = tid; k < rows * 6; k += (int)blockDim.x) {
             const int r = k / 6, hc = k - r * 6;
             const int x = hc < 3 ? xs + hc : t.x0 + t.w + (hc - 3);               // level column of this halo slot
             if (x < 0 || x >= L.w) {
@@ -954,7 +954,7 @@ SGX_KERNEL(256) k_blur_levels(SgxOrbGeom g, const SgxBlurTile *tiles, const uint
     }
     // horizontal pass: task = (row, 8-column segment); 14 source bytes from 5 aligned dwords realigned with v_alignbyte
     SGX_THREADS_BEGIN(tid)
-    for (int k = tid; k < rows * (SGX_BT_W / 8); k += 256) {
+    for (int k = tid; k < rows * (SGX_BT_W / 8); k += (int)blockDim.x) {
         const int r = k >> 3, sg = k & 7;
         if (8 * sg >= t.w) continue;
         const uint32_t *w = in_dw + (r * SGX_BT_IS + 8 * sg) / 4;
@@ -977,7 +977,7 @@ SGX_KERNEL(256) k_blur_levels(SgxOrbGeom g, const SgxBlurTile *tiles, const uint
     SGX_SYNC();
     // vertical pass: task = (column, 8-row segment), 14 sliding reads per 8 outputs
     SGX_THREADS_BEGIN(tid)
-    for (int k = tid; k < 64 * ((SGX_BT_H + 7) / 8); k += 256) {
+    for (int k = tid; k < 64 * ((SGX_BT_H + 7) / 8); k += (int)blockDim.x) {
         const int c = k & 63, sg = k >> 6, r0 = 8 * sg;
         if (c < t.w && r0 < t.h) {
             uint32_t h[14];
@@ -994,7 +994,7 @@ SGX_KERNEL(256) k_blur_levels(SgxOrbGeom g, const SgxBlurTile *tiles, const uint
     SGX_SYNC();
     SGX_THREADS_BEGIN(tid)
     uint8_t *dst = blur + (size_t)frame * g.blur_pitch + L.boff;
-    for (int i = tid; i < t.h * (SGX_BT_W / 4); i += 256) {
+    for (int i = tid; i < t.h * (SGX_BT_W / 4); i += (int)blockDim.x) {
         const int r = i >> 4, q = i & 15;
         if (4 * q < t.w) *(uint32_t *)(dst + (size_t)(t.y0 + r) * L.bstride + t.x0 + 4 * q) = o_dw[i];        // rows are padded to 64 bytes: the last dword may spill into the padding
     }
