@@ -60,6 +60,9 @@ class ORBmatcher:
         md = np.ascontiguousarray(lm['desc'], np.uint8); mo = np.ascontiguousarray(lm['obs'], 'i4'); ms = np.ascontiguousarray(lm['skip'], np.uint8)
         sf = np.ascontiguousarray(scale_factors, 'f4')
         nc, nm = len(ck), len(xw)
+        if nc == 0 or nm == 0:              # nothing to project / nothing to match against: the reference's loops do not execute (ORBmatcher.cc:52-127)
+            F['match_local'] = np.full(nc, -1, 'i4'); local_map['in_view'] = np.zeros(nm, np.uint8)
+            return 0
         cnt = np.array([nc], 'i4'); mcnt = np.array([nm], 'i4')
         match = np.full(max(nc, 1), -1, 'i4'); n = np.zeros(1, 'i4'); inview = np.zeros(max(nm, 1), np.uint8)
         cs = camera_struct(cam)
