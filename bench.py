@@ -35,7 +35,7 @@ def algorithmic_bytes_per_frame(nkp=1000, ncand=6000, nmatch=600):
         'pyramid_resize': sum(PIX[:-1]) + sum(PIX[1:]),            # read levels 0..6 once, write levels 1..7
         'fast_cells': sum(PIX) + 4 * ncand,                        # read every level once, write packed candidates
         'octree': 4 * ncand + 4 * nkp,                             # read candidates, write selected
-        'orient_desc': sum(PIX) + nkp * (28 + 32),                 # read every level at most once, write kp + desc
+        'orient_desc': sum(PIX) + nkp * (28 + 32),                 # fused bound: read every level at most once, write kp + desc (the whole-level blur design moves ~1.9x)
         'stereo_from_rgbd': nkp * (28 + 2 + 8),                    # keypoint + one depth texel in, uright/z out
         'motion_model': 3 * 64,
         'match_project_frame': 2 * nkp * (28 + 32) + nkp * (4 + 12 + 1 + 1 + 4) + nkp * 4,   # both frames' kp+desc, uright/xw/flags, match out
