@@ -378,8 +378,13 @@ extern "C" int sgx_orb_extract_batch_dev(sgx_orb *h, const uint8_t *d_gray, int 
     } else {
         static const int blur_threads = getenv("SGX_TUNE_BLUR_THREADS") ? atoi(getenv("SGX_TUNE_BLUR_THREADS")) : 256;   // env = tuning tap (64..512)
         SGX_LAUNCH(k_blur_levels, dim3(g.nblur_tiles * batch), dim3(blur_threads), stream, g, h->d_blur_tiles, d_gray, pitch, h->d_pyr, h->d_blur, batch);
-        SGX_LAUNCH(k_orient_desc2, dim3(g.kp_cap * batch), dim3(64), stream, g, d_gray, pitch, h->d_pyr, h->d_blur, h->d_sel, h->d_sel_count,
-                   umax_packed, h->d_pattern, (uint8_t *)d_kps, d_desc, d_count, cap, batch, h->d_status);
+        static const bool one_per_wave = getenv("SGX_TUNE_ORB_DESC_ONE_PER_WAVE") != nullptr;       // tuning tap: k_orient_desc2 (one keypoint per wave)
+        if (one_per_wave)
+            SGX_LAUNCH(k_orient_desc2, dim3(g.kp_cap * batch), dim3(64), stream, g, d_gray, pitch, h->d_pyr, h->d_blur, h->d_sel, h->d_sel_count,
+                       umax_packed, h->d_pattern, (uint8_t *)d_kps, d_desc, d_count, cap, batch, h->d_status);
+        else
+            SGX_LAUNCH(k_orient_desc4, dim3(((g.kp_cap + 3) / 4) * batch), dim3(64), stream, g, d_gray, pitch, h->d_pyr, h->d_blur, h->d_sel, h->d_sel_count,
+                       umax_packed, h->d_pattern, (uint8_t *)d_kps, d_desc, d_count, cap, batch, h->d_status);
     }
     sgx_prof_end(SGX_K_ORIENT_DESC, stream);
     SGX_CHECK_HIP(hipGetLastError());

@@ -1101,3 +1101,150 @@ SGX_KERNEL(64) k_orient_desc2(SgxOrbGeom g, const uint8_t *gray, int gray_pitch,
     }
     SGX_THREADS_END
 }
+
+// ---------------------------------------------------------------------------------------------
+// k_orient_desc4: k_orient_desc2 with FOUR keypoints per wave (16 lanes each).  The serial part of a keypoint (fastAtan2 + the bit-exact sincosf, ~250
+// wave instructions executed for one active lane) is then shared by four keypoints, and the moment sums walk the staged patch as dwords (4 pixels per
+// lane step).  Same arithmetic per keypoint, so identical bytes.  block -> (group of 4 slots, frame), XCD-aware like k_orient_desc.
+// ---------------------------------------------------------------------------------------------
+SGX_KERNEL(64) k_orient_desc4(SgxOrbGeom g, const uint8_t *gray, int gray_pitch, const uint8_t *pyr, const uint8_t *blur,
+                              const uint32_t *sel, const int *sel_count, unsigned long long umax_packed, const signed char *pattern,
+                              uint8_t *kps_raw, uint8_t *desc, int *count, int cap, int batch, uint32_t *status)
+{
+    SGX_LDS uint32_t patch_dw[4][31 * SGX_MS / 4];
+    SGX_LDS uint8_t bits[4][256];
+    SGX_LDS int s_m01[4], s_m10[4];
+    SGX_LDS float s_a[4], s_b[4];
+    int slot4, frame;
+    {
+        const int n = (int)blockIdx.x, kc = (g.kp_cap + 3) >> 2;
+        if ((batch & 7) == 0) { const int xcd = n & 7, j = n >> 3; frame = xcd + 8 * (j / kc); slot4 = j % kc; }
+        else { frame = n / kc; slot4 = n % kc; }
+    }
+    // per-level counts of this frame (wave-uniform)
+    int total = 0;
+    for (int l = 0; l < g.nlevels; l++) total += sel_count[frame * g.nlevels + l];
+    if (slot4 == 0) {
+        SGX_THREADS_BEGIN(tid)
+        if (tid == 0) { count[frame] = total < cap ? total : cap; if (total > cap) sgx_atomic_or(status, SGX_ST_KP_OVERFLOW); }
+        SGX_THREADS_END
+    }
+    if (4 * slot4 >= total || 4 * slot4 >= cap) return;
+
+    SGX_THREADS_BEGIN(tid)
+    if (tid < 4) { s_m01[tid] = 0; s_m10[tid] = 0; }
+    // stage the four 31x31 moment patches (aligned dwords, 36 bytes per row)
+    const int grp = tid >> 4, l16 = tid & 15, slot = 4 * slot4 + grp;
+    int level = -1, base = 0, acc_ = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+        const int n = sel_count[frame * g.nlevels + l];
+        if (level < 0 && slot < acc_ + n) { level = l; base = acc_; }
+        acc_ += n;
+    }
+    if (level >= 0 && slot < cap) {
+        const uint32_t e = sel[((size_t)frame * g.nlevels + level) * SGX_OCT_MAXN + (slot - base)];
+        const int kx = (int)(e & 0xFFF) + SGX_BORDER, ky = (int)((e >> 12) & 0xFFF) + SGX_BORDER;
+        int stride;
+        const uint8_t *img = sgx_level_ptr(g, gray, gray_pitch, pyr, frame, level, &stride);
+        const int px0 = kx - 15, py0 = ky - 15, lead = px0 & 3, xa = px0 - lead;
+        for (int i = l16; i < 31 * (SGX_MS / 4); i += 16) {
+            const int r = i / (SGX_MS / 4), q = i - r * (SGX_MS / 4);
+            patch_dw[grp][i] = *(const uint32_t *)(img + (size_t)(py0 + r) * stride + xa + 4 * q);
+        }
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    const int grp = tid >> 4, l16 = tid & 15, slot = 4 * slot4 + grp;
+    int level = -1, base = 0, acc_ = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+        const int n = sel_count[frame * g.nlevels + l];
+        if (level < 0 && slot < acc_ + n) { level = l; base = acc_; }
+        acc_ += n;
+    }
+    if (level >= 0 && slot < cap) {
+        const uint32_t e = sel[((size_t)frame * g.nlevels + level) * SGX_OCT_MAXN + (slot - base)];
+        const int lead = ((int)(e & 0xFFF) + SGX_BORDER - 15) & 3;
+        int m10 = 0, m01 = 0;
+        for (int i = l16; i < 31 * (SGX_MS / 4); i += 16) {
+            const int r = i / (SGX_MS / 4), q = i - r * (SGX_MS / 4);
+            const int v = r - 15, av = v < 0 ? -v : v, um = (int)((umax_packed >> (4 * av)) & 15ull);
+            const uint32_t w = patch_dw[grp][i];
+            int rowsum = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int u = 4 * q + j - lead - 15, au = u < 0 ? -u : u;
+                const int I = au <= um ? (int)((w >> (8 * j)) & 255u) : 0;           // columns outside the disc (incl. the dword padding) weigh 0
+                m10 += u * I; rowsum += I;
+            }
+            m01 += v * rowsum;
+        }
+        sgx_atomic_add(&s_m10[grp], m10); sgx_atomic_add(&s_m01[grp], m01);
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    const int grp = tid >> 4, l16 = tid & 15, slot = 4 * slot4 + grp;
+    int level = -1, base = 0, acc_ = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+        const int n = sel_count[frame * g.nlevels + l];
+        if (level < 0 && slot < acc_ + n) { level = l; base = acc_; }
+        acc_ += n;
+    }
+    if (level >= 0 && slot < cap && l16 == 0) {
+        const SgxLevel L = g.lv[level];
+        const uint32_t e = sel[((size_t)frame * g.nlevels + level) * SGX_OCT_MAXN + (slot - base)];
+        const int kx = (int)(e & 0xFFF) + SGX_BORDER, ky = (int)((e >> 12) & 0xFFF) + SGX_BORDER;
+        const float angle = sgx_fast_atan2((float)s_m01[grp], (float)s_m10[grp]);
+        const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+        float sn, cs;
+        sgx_sincosf(angle * factorPI, &sn, &cs);
+        s_a[grp] = cs; s_b[grp] = sn;
+        float *kp = (float *)(kps_raw + ((size_t)frame * cap + slot) * 28);
+        float fx = (float)kx, fy = (float)ky;
+        if (level != 0) { fx = fx * L.scale; fy = fy * L.scale; }
+        kp[0] = fx; kp[1] = fy; kp[2] = (float)L.patch_size; kp[3] = angle; kp[4] = (float)(e >> 24);
+        ((int *)kp)[5] = level; ((int *)kp)[6] = -1;
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    const int grp = tid >> 4, l16 = tid & 15, slot = 4 * slot4 + grp;
+    int level = -1, base = 0, acc_ = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+        const int n = sel_count[frame * g.nlevels + l];
+        if (level < 0 && slot < acc_ + n) { level = l; base = acc_; }
+        acc_ += n;
+    }
+    if (level >= 0 && slot < cap) {
+        const SgxLevel L = g.lv[level];
+        const uint32_t e = sel[((size_t)frame * g.nlevels + level) * SGX_OCT_MAXN + (slot - base)];
+        const int kx = (int)(e & 0xFFF) + SGX_BORDER, ky = (int)((e >> 12) & 0xFFF) + SGX_BORDER;
+        const float a = s_a[grp], b = s_b[grp];
+        const uint8_t *bl = blur + (size_t)frame * g.blur_pitch + L.boff + (size_t)ky * L.bstride + kx;
+#pragma unroll 4
+        for (int it_ = 0; it_ < 16; it_++) { const int t = l16 + 16 * it_;
+            const uint32_t pw = *(const uint32_t *)(pattern + 4 * t);
+            const float x0 = (float)(signed char)(pw & 255u), y0 = (float)(signed char)((pw >> 8) & 255u), x1 = (float)(signed char)((pw >> 16) & 255u), y1 = (float)(signed char)(pw >> 24);
+            const int r0 = sgx_cvround(x0 * b + y0 * a), c0 = sgx_cvround(x0 * a - y0 * b);
+            const int r1 = sgx_cvround(x1 * b + y1 * a), c1 = sgx_cvround(x1 * a - y1 * b);
+            const int t0 = bl[r0 * L.bstride + c0], t1 = bl[r1 * L.bstride + c1];
+            bits[grp][t] = (uint8_t)(t0 < t1);
+        }
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    const int grp = tid >> 4, l16 = tid & 15, slot = 4 * slot4 + grp;
+    if (slot < total && slot < cap) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; h2++) {
+            const int byte = 2 * l16 + h2;
+            int v = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) v |= bits[grp][8 * byte + j] << j;
+            desc[((size_t)frame * cap + slot) * 32 + byte] = (uint8_t)v;
+        }
+    }
+    SGX_THREADS_END
+}
