@@ -192,6 +192,42 @@ SGX_KERNEL(1024) k_pyramid(SgxOrbGeom g, SgxPyrTabs tb, const uint8_t *gray, int
 // with x,y relative to the (16,16) border origin (ORBextractor.cc:823-824); k_octree does not
 // depend on their order.
 // ---------------------------------------------------------------------------------------------
+// ((hi:lo) >> 8*sh) as 32 bits (v_alignbyte_b32)
+SGX_DEV uint32_t sgx_alignbyte(uint32_t hi, uint32_t lo, int sh)
+{
+#ifndef SGX_EMU
+    return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)sh);
+#else
+    return (uint32_t)((((unsigned long long)hi << 32) | lo) >> (8 * sh));
+#endif
+}
+
+// packed 2 x u16 helpers (v_pk_sub_u16 clamp / v_pk_min_u16 on the device)
+#ifndef SGX_EMU
+typedef unsigned short sgx_u16x2 __attribute__((ext_vector_type(2)));
+SGX_DEV uint32_t sgx_pk_usubsat_u16(uint32_t a, uint32_t b)
+{
+    const sgx_u16x2 r = __builtin_elementwise_sub_sat(__builtin_bit_cast(sgx_u16x2, a), __builtin_bit_cast(sgx_u16x2, b));
+    return __builtin_bit_cast(uint32_t, r);
+}
+SGX_DEV uint32_t sgx_pk_min_u16(uint32_t a, uint32_t b)
+{
+    const sgx_u16x2 r = __builtin_elementwise_min(__builtin_bit_cast(sgx_u16x2, a), __builtin_bit_cast(sgx_u16x2, b));
+    return __builtin_bit_cast(uint32_t, r);
+}
+#else
+SGX_DEV uint32_t sgx_pk_usubsat_u16(uint32_t a, uint32_t b)
+{
+    const uint32_t al = a & 0xFFFFu, ah = a >> 16, bl = b & 0xFFFFu, bh = b >> 16;
+    return (al > bl ? al - bl : 0u) | ((ah > bh ? ah - bh : 0u) << 16);
+}
+SGX_DEV uint32_t sgx_pk_min_u16(uint32_t a, uint32_t b)
+{
+    const uint32_t al = a & 0xFFFFu, ah = a >> 16, bl = b & 0xFFFFu, bh = b >> 16;
+    return (al < bl ? al : bl) | ((ah < bh ? ah : bh) << 16);
+}
+#endif
+
 // ((hi:lo) >> sh) as 32 bits (v_alignbit_b32); with sh = 31 it shifts the sign bit of lo into hi from the right
 SGX_DEV uint32_t sgx_alignbit(uint32_t hi, uint32_t lo, int sh)
 {
@@ -260,20 +296,30 @@ SGX_KERNEL(SGX_FAST_THREADS) k_fast_cells(SgxOrbGeom g, const SgxCell *cells, co
         const bool has1 = gq + 1 < SD, has2 = gq + 2 < SD;
         const uint32_t C0 = rc[0], C1 = has1 ? rc[1] : 0u, C2 = has2 ? rc[2] : 0u;
         const uint32_t P0 = rp[0], P1 = has1 ? rp[1] : 0u, M0 = rm[0], M1 = has1 ? rm[1] : 0u;
-#define SGX_B3(w0, w1, w2, idx) ((int)((((idx) < 4 ? (w0) : ((idx) < 8 ? (w1) : (w2))) >> (8 * ((idx) & 3))) & 255u))
+        // the 4 pixels of the task as packed bytes: centre v (tile bytes 3..6 of the group), the compass pixels below / above (same columns of rows
+        // y+3 / y-3) and right / left (bytes 6..9 / 0..3), then as two sets of 2 x u16 (even / odd pixels) for the packed saturating compares:
+        //   brighter  <=>  usubsat(r, v + t) != 0      darker  <=>  usubsat(usubsat(v, t), r) != 0
+        const uint32_t V = sgx_alignbyte(C1, C0, 3), R4 = sgx_alignbyte(C2, C1, 2), R12 = C0, R0 = sgx_alignbyte(P1, P0, 3), R8 = sgx_alignbyte(M1, M0, 3);
+        const uint32_t T2 = (uint32_t)thr_lo * 0x00010001u;
+        uint32_t any[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+            const int sh = 8 * s2;
+            const uint32_t v = (V >> sh) & 0x00FF00FFu, r0 = (R0 >> sh) & 0x00FF00FFu, r8 = (R8 >> sh) & 0x00FF00FFu, r4 = (R4 >> sh) & 0x00FF00FFu, r12 = (R12 >> sh) & 0x00FF00FFu;
+            const uint32_t hi = v + T2, lo = sgx_pk_usubsat_u16(v, T2);
+            const uint32_t br = sgx_pk_min_u16(sgx_pk_usubsat_u16(r0, hi) | sgx_pk_usubsat_u16(r8, hi), sgx_pk_usubsat_u16(r4, hi) | sgx_pk_usubsat_u16(r12, hi));
+            const uint32_t dk = sgx_pk_min_u16(sgx_pk_usubsat_u16(lo, r0) | sgx_pk_usubsat_u16(lo, r8), sgx_pk_usubsat_u16(lo, r4) | sgx_pk_usubsat_u16(lo, r12));
+            any[s2] = br | dk;
+        }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int x = x0 + i;
-            const int v = SGX_B3(C0, C1, C2, 3 + i), lo = v - thr_lo, hi = v + thr_lo;
-            const int r0 = SGX_B3(P0, P1, 0u, 3 + i), r8 = SGX_B3(M0, M1, 0u, 3 + i), r4 = SGX_B3(C0, C1, C2, 6 + i), r12 = SGX_B3(C0, C1, C2, i);
-            const bool br = ((r0 > hi) | (r8 > hi)) & ((r4 > hi) | (r12 > hi));
-            const bool dk = ((r0 < lo) | (r8 < lo)) & ((r4 < lo) | (r12 < lo));
-            if (x >= 3 && x < cw - 3 && (br | dk)) {
+            const uint32_t f = (any[i & 1] >> (16 * (i >> 1))) & 0xFFFFu;          // pixel i = half (i>>1) of set (i&1)
+            if (x >= 3 && x < cw - 3 && f) {
                 const int slot = sgx_atomic_add(&n_quick, 1);
                 qlist[slot] = (uint16_t)(y * SGX_TILE_STRIDE + lead + x);
             }
         }
-#undef SGX_B3
     }
     SGX_THREADS_END
     SGX_SYNC();
@@ -285,30 +331,22 @@ SGX_KERNEL(SGX_FAST_THREADS) k_fast_cells(SgxOrbGeom g, const SgxCell *cells, co
         const int pos = qlist[t];
         const uint8_t *p = tile + pos;
         const int v = p[0], lo = v - thr_lo, hi = v + thr_lo;
+        int r[16];                                                    // the 16 ring pixels, clockwise from (0, +3) — loaded once for the mask test and the score
+        r[0] = p[3 * SGX_TILE_STRIDE];       r[1] = p[3 * SGX_TILE_STRIDE + 1];  r[2] = p[2 * SGX_TILE_STRIDE + 2];
+        r[3] = p[SGX_TILE_STRIDE + 3];       r[4] = p[3];                        r[5] = p[-SGX_TILE_STRIDE + 3];
+        r[6] = p[-2 * SGX_TILE_STRIDE + 2];  r[7] = p[-3 * SGX_TILE_STRIDE + 1]; r[8] = p[-3 * SGX_TILE_STRIDE];
+        r[9] = p[-3 * SGX_TILE_STRIDE - 1];  r[10] = p[-2 * SGX_TILE_STRIDE - 2]; r[11] = p[-SGX_TILE_STRIDE - 3];
+        r[12] = p[-3];                       r[13] = p[SGX_TILE_STRIDE - 3];     r[14] = p[2 * SGX_TILE_STRIDE - 2];
+        r[15] = p[3 * SGX_TILE_STRIDE - 1];
         uint32_t mb = 0, md = 0;
-#define SGX_RING(dx, dy) { const int r_ = p[(dy) * SGX_TILE_STRIDE + (dx)]; mb = sgx_alignbit(mb, (uint32_t)(hi - r_), 31); md = sgx_alignbit(md, (uint32_t)(r_ - lo), 31); }
-        SGX_RING(0, 3) SGX_RING(1, 3) SGX_RING(2, 2) SGX_RING(3, 1) SGX_RING(3, 0) SGX_RING(3, -1) SGX_RING(2, -2) SGX_RING(1, -3)
-        SGX_RING(0, -3) SGX_RING(-1, -3) SGX_RING(-2, -2) SGX_RING(-3, -1) SGX_RING(-3, 0) SGX_RING(-3, 1) SGX_RING(-2, 2) SGX_RING(-1, 3)
-#undef SGX_RING
-        if (sgx_has9(mb & 0xFFFFu) | sgx_has9(md & 0xFFFFu)) qlist[t] = (uint16_t)(pos | 0x8000);     // pos < 68*72 < 2^15
-    }
-    SGX_THREADS_END
-    SGX_SYNC();
-
-    // phase C: threshold-free score for the compacted corners
-    SGX_THREADS_BEGIN(tid)
-    for (int i = tid; i < n_quick; i += (int)blockDim.x) {
-        if (!(qlist[i] & 0x8000)) continue;
-        const int pos = qlist[i] & 0x7FFF;
-        const uint8_t *p = tile + pos;
-        const int v = p[0];
+#pragma unroll
+        for (int k = 0; k < 16; k++) { mb = sgx_alignbit(mb, (uint32_t)(hi - r[k]), 31); md = sgx_alignbit(md, (uint32_t)(r[k] - lo), 31); }
+        if (!(sgx_has9(mb & 0xFFFFu) | sgx_has9(md & 0xFFFFu))) continue;
+        qlist[t] = (uint16_t)(pos | 0x8000);                          // pos < 68*72 < 2^15
+        // threshold-free score of the corner, in the same pass (phase C of the first version cost one more barrier and one more walk of the list)
         int d[16];
-        d[0] = v - p[3 * SGX_TILE_STRIDE];       d[1] = v - p[3 * SGX_TILE_STRIDE + 1];  d[2] = v - p[2 * SGX_TILE_STRIDE + 2];
-        d[3] = v - p[SGX_TILE_STRIDE + 3];       d[4] = v - p[3];                        d[5] = v - p[-SGX_TILE_STRIDE + 3];
-        d[6] = v - p[-2 * SGX_TILE_STRIDE + 2];  d[7] = v - p[-3 * SGX_TILE_STRIDE + 1]; d[8] = v - p[-3 * SGX_TILE_STRIDE];
-        d[9] = v - p[-3 * SGX_TILE_STRIDE - 1];  d[10] = v - p[-2 * SGX_TILE_STRIDE - 2]; d[11] = v - p[-SGX_TILE_STRIDE - 3];
-        d[12] = v - p[-3];                       d[13] = v - p[SGX_TILE_STRIDE - 3];     d[14] = v - p[2 * SGX_TILE_STRIDE - 2];
-        d[15] = v - p[3 * SGX_TILE_STRIDE - 1];
+#pragma unroll
+        for (int k = 0; k < 16; k++) d[k] = v - r[k];
         int mn2[16], mx2[16], mn4[16], mx4[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
@@ -707,14 +745,6 @@ SGX_DEV float sgx_fast_atan2(float y, float x)
 }
 
 // (hi:lo) >> (8*sh) as 32 bits, sh in 0..3 (v_alignbyte_b32)
-SGX_DEV uint32_t sgx_alignbyte(uint32_t hi, uint32_t lo, int sh)
-{
-#ifndef SGX_EMU
-    return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)sh);
-#else
-    return (uint32_t)((((unsigned long long)hi << 32) | lo) >> (8 * sh));
-#endif
-}
 
 SGX_DEV int sgx_reflect101(int i, int n)
 {
