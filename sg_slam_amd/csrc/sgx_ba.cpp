@@ -1,6 +1,9 @@
 // sgx_ba.cpp — host side of the LocalBundleAdjustment C-ABI: flattening helpers (CSR by landmark / by pose), the
 // Levenberg-Marquardt control loop (statement-for-statement OptimizationAlgorithmLevenberg::solve,
 // G/core/optimization_algorithm_levenberg.cpp:61-164) and the kernel launches.  Reference: src/sg-slam/src/Optimizer.cc:453-778.
+// fp64 solver arithmetic: multiply-adds may fuse (the reference g2o is built -O3 -march=native, where GCC contracts to FMA as well; the
+// parity bar for poses / landmarks is 1e-5 relative, not bit equality).  The bit-exact integer / fp32 feature kernels keep -ffp-contract=off.
+#pragma clang fp contract(fast)
 #include "sgx_ba_kernels.h"
 #include "../../include/sgx.h"
 #include <float.h>

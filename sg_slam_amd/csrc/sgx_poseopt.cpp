@@ -1,5 +1,8 @@
 // sgx_poseopt.cpp — host side of the PoseOptimization C-ABI (include/sgx.h).
 // Reference behaviour: src/sg-slam/src/Optimizer.cc:239-451.
+// fp64 solver arithmetic: multiply-adds may fuse (the reference g2o is built -O3 -march=native, where GCC contracts to FMA as well; the
+// parity bar for poses / landmarks is 1e-5 relative, not bit equality).  The bit-exact integer / fp32 feature kernels keep -ffp-contract=off.
+#pragma clang fp contract(fast)
 #include "sgx_poseopt_kernels.h"
 #include "sgx_prof.h"
 #include "../../include/sgx.h"
@@ -64,3 +67,4 @@ extern "C" int sgx_pose_optimization(int n, const sgx_keypoint *keys_un, const f
     for (int i = 0; i < 8; i++) if (d[i]) (void)hipFree(d[i]);
     return rc;
 }
+

@@ -9,7 +9,8 @@
 
 #define SGX_PO_CAP 1280
 #define SGX_PO_THREADS 256
-#define SGX_PO_NRED 28            /* 21 upper-triangular H entries + 6 b entries + chi */
+#define SGX_PO_NRED 27            /* 21 upper-triangular H entries + 6 b entries (odd row stride: conflict-free LDS writes) */
+#define SGX_PO_CG 16              /* groups of the chi2 reduction */
 
 #include "sgx_se3.h"
 
@@ -19,8 +20,14 @@
 // 6x6 system, the chi2 sums and the LM control flow are wave-uniform (each lane evaluates the same
 // scalar code on values reduced through LDS), so the kernel follows the reference's accept/reject,
 // lambda schedule and stop rules statement for statement (levenberg.cpp:61-164).
-// Sums over edges are reduced in a fixed order (thread-strided partials, 8 groups of 32, then 8):
+// Sums over edges are reduced in a fixed order (thread-strided partials, interleaved groups of rows, then the groups):
 // deterministic, and within ~1e-15 relative of the reference's sequential order.
+// Measured with clock64 on MI355X (tools/ubench/f64_issue.hip): a wave issues a dependent fp64 FMA every 7.3 cycles and, with eight
+// independent chains, still only every 5.2; unrolling the edge loops four-fold bought 15 % per edge but paid it back in idle tail slots, and a
+// 512-thread variant (two waves per SIMD) was slower at every phase.  So the kernel's time is its fp64 instruction count: the per-edge code is
+// branch-free with a single division (mono / stereo, excluded edges and the Huber kernel are selects), multiply-adds fuse (sgx_poseopt.cpp)
+// and the wave-uniform solver multiplies by reciprocals.  Phase split of one launch (800 points, 54 LM trials): residuals 45 %, solver +
+// exp 25 %, linearisation 21 %, classification and set-up 9 %.
 // mp_index (optional): map point of keypoint i is table row mp_index[i] (-1 = none); otherwise has_mp/xw are per keypoint.
 // ---------------------------------------------------------------------------------------------
 // NTT = threads per frame: 256 (4 waves: lowest latency per frame) or 64 (one wave per frame: no inter-wave barriers to wait on and 4x fewer
@@ -34,11 +41,12 @@ SGX_KERNEL(NTT) k_pose_opt(int cap, const uint8_t *keys_raw, const float *uright
     SGX_LDS float e_obs[SGX_PO_CAP * 3], e_xw[SGX_PO_CAP * 3], e_info[SGX_PO_CAP];
     SGX_LDS double e_err[SGX_PO_CAP * 3];
     SGX_LDS uint16_t e_kp[SGX_PO_CAP];
-    SGX_LDS uint8_t e_flags[SGX_PO_CAP];          // bit0 stereo, bit1 level==1 (excluded), bit2 robust kernel on, bit3 outlier flag
-    constexpr int NG = NTT / 32;                   // reduction groups of 32 threads
+    SGX_LDS uint8_t e_flags[SGX_PO_CAP];          // bit0 stereo, bit1 level==1 (excluded), bit3 outlier flag
+    constexpr int NG = NTT / 32;                   // reduction groups (rows j, j+NG, j+2NG, ... of `part`)
     SGX_LDS double part[NTT * SGX_PO_NRED];
     SGX_LDS double part2[SGX_PO_NRED * NG];
     SGX_LDS double red[SGX_PO_NRED];
+    SGX_LDS double chi_part[NTT], chi_grp[SGX_PO_CG];
     SGX_LDS int scan[NTT];
     SGX_LDS int s_ne, s_nbad;
 
@@ -82,7 +90,7 @@ SGX_KERNEL(NTT) k_pose_opt(int cap, const uint8_t *keys_raw, const float *uright
         e_xw[3 * ne_] = X[0]; e_xw[3 * ne_ + 1] = X[1]; e_xw[3 * ne_ + 2] = X[2];
         e_info[ne_] = inv_sigma2.s[((const int *)kp)[5]];
         e_kp[ne_] = (uint16_t)i;
-        e_flags[ne_] = (uint8_t)((ur < 0 ? 0 : 1) | 4);        // mono iff mvuRight<0 (Optimizer.cc:286); Huber on
+        e_flags[ne_] = (uint8_t)(ur < 0 ? 0 : 1);              // mono iff mvuRight<0 (Optimizer.cc:286)
         ne_++;
     }
     SGX_THREADS_END
@@ -98,36 +106,38 @@ SGX_KERNEL(NTT) k_pose_opt(int cap, const uint8_t *keys_raw, const float *uright
     for (int i = 0; i < 16; i++) T0[i] = Tcw[16 * f + i];
     int nBad = 0;
 
-// evaluates errors of the active (level-0) edges at `est`, accumulates the robust chi2 into part[lane][27]
+// evaluates the errors of the edges at `est` and the robust chi2 of the active (level-0) ones -> chiTot.  Excluded edges are evaluated too
+// (their e_err is recomputed by the classification below before it is next read) but add an exact zero.
 #define SGX_PO_ERRORS()                                                                                     \
     SGX_THREADS_BEGIN(tid)                                                                                  \
     double chi = 0;                                                                                         \
     for (int e = tid; e < ne; e += NT) {                                                                    \
         const int fl = e_flags[e];                                                                          \
-        if (fl & 2) continue;                                                                               \
-        sgx_po_edge_error(est, e_xw + 3 * e, e_obs + 3 * e, fl & 1, fx, fy, cx, cy, bf, e_err + 3 * e);      \
-        const double c2 = sgx_po_chi2(e_err + 3 * e, (double)e_info[e], fl & 1);                            \
-        if (fl & 4) { double r0, r1; sgx_huber(c2, (fl & 1) ? deltaStereo : deltaMono, &r0, &r1); chi += r0; } \
-        else chi += c2;                                                                                     \
+        double er[3];                                                                                       \
+        sgx_po_residual(est, e_xw + 3 * e, e_obs + 3 * e, (fl & 1) != 0, fx, fy, cx, cy, bf, er);            \
+        e_err[3 * e] = er[0]; e_err[3 * e + 1] = er[1]; e_err[3 * e + 2] = er[2];                           \
+        const double c2 = sgx_po_chi2(er, (double)e_info[e], 1);                                            \
+        double r0 = c2;                                                                                     \
+        if (robust) r0 = sgx_huber_rho0(c2, (fl & 1) ? deltaStereo : deltaMono);                            \
+        chi += (fl & 2) ? 0.0 : r0;                                                                         \
     }                                                                                                       \
-    part[tid * SGX_PO_NRED + 27] = chi;                                                                     \
+    chi_part[tid] = chi;                                                                                    \
     SGX_THREADS_END                                                                                         \
     SGX_SYNC();                                                                                             \
     SGX_THREADS_BEGIN(tid)                                                                                  \
-    if (tid < NG) { double s = 0; for (int l = 0; l < 32; l++) s += part[(tid * 32 + l) * SGX_PO_NRED + 27]; part2[27 * NG + tid] = s; } \
+    if (tid < SGX_PO_CG) { double s = 0; for (int l = 0; l < NTT / SGX_PO_CG; l++) s += chi_part[l * SGX_PO_CG + tid]; chi_grp[tid] = s; } \
     SGX_THREADS_END                                                                                         \
     SGX_SYNC();                                                                                             \
-    SGX_THREADS_BEGIN(tid)                                                                                  \
-    if (tid == 0) { double s = 0; for (int l = 0; l < NG; l++) s += part2[27 * NG + l]; red[27] = s; }      \
-    SGX_THREADS_END                                                                                         \
-    SGX_SYNC();
+    { double s = 0; for (int l = 0; l < SGX_PO_CG; l++) s += chi_grp[l]; chiTot = s; }
 
     for (int round = 0; round < 4; round++) {
         sgx_se3_from_cv(T0, est);                                   // Optimizer.cc:377: every round restarts from pFrame->mTcw
         double lambda = -1, ni = 2; int nBadLM = 0;
+        const bool robust = round < 3;                  // every edge carries the Huber kernel until the third classification drops it (Optimizer.cc:436)
+        double chiTot = 0;
         bool fresh = false; double freshChi = 0;        // e_err / chi already evaluated at `est` by an accepted trial
         for (int it = 0; it < 10; it++) {
-            if (!fresh) { SGX_PO_ERRORS() freshChi = red[27]; }    // computeActiveErrors + activeRobustChi2 (levenberg.cpp:73-80)
+            if (!fresh) { SGX_PO_ERRORS() freshChi = chiTot; }    // computeActiveErrors + activeRobustChi2 (levenberg.cpp:73-80)
             double currentChi = freshChi;
             double tempChi = currentChi;
             const double iniChi = currentChi;
@@ -138,26 +148,23 @@ SGX_KERNEL(NTT) k_pose_opt(int cap, const uint8_t *keys_raw, const float *uright
             for (int k = 0; k < 27; k++) acc[k] = 0;
             for (int e = tid; e < ne; e += NT) {
                 const int fl = e_flags[e];
-                if (fl & 2) continue;
-                const int stereo = fl & 1;
+                const bool stereo = (fl & 1) != 0, active = !(fl & 2);
                 const double Xd[3] = { (double)e_xw[3 * e], (double)e_xw[3 * e + 1], (double)e_xw[3 * e + 2] };
                 double p[3]; sgx_se3_map(est, Xd, p);
-                const double x = p[0], y = p[1], invz = 1.0 / p[2], invz_2 = invz * invz;
+                // an excluded edge contributes exact zeros: zero weight and residual on a harmless point, so that no inf / NaN can leak in
+                const double x = active ? p[0] : 0.0, y = active ? p[1] : 0.0, invz = 1.0 / (active ? p[2] : 1.0), invz_2 = invz * invz;
                 double J[3][6];                                      // types_six_dof_expmap.cpp:266-288, 335-364
                 J[0][0] = x * y * invz_2 * fx; J[0][1] = -(1 + (x * x * invz_2)) * fx; J[0][2] = y * invz * fx;
                 J[0][3] = -invz * fx; J[0][4] = 0; J[0][5] = x * invz_2 * fx;
                 J[1][0] = (1 + y * y * invz_2) * fy; J[1][1] = -x * y * invz_2 * fy; J[1][2] = -x * invz * fy;
                 J[1][3] = 0; J[1][4] = -invz * fy; J[1][5] = y * invz_2 * fy;
-                J[2][0] = J[0][0] - bf * y * invz_2; J[2][1] = J[0][1] + bf * x * invz_2; J[2][2] = J[0][2];
-                J[2][3] = J[0][3]; J[2][4] = 0; J[2][5] = J[0][5] - bf * invz_2;
-                const double info = (double)e_info[e];
-                const double er[3] = { e_err[3 * e], e_err[3 * e + 1], stereo ? e_err[3 * e + 2] : 0.0 };
-                if (!stereo) {            // mono edge: the third row does not exist (adds exact zeros below)
-#pragma unroll
-                    for (int a = 0; a < 6; a++) J[2][a] = 0;
-                }
+                // mono edge: the third row does not exist (adds exact zeros below)
+                J[2][0] = stereo ? J[0][0] - bf * y * invz_2 : 0.0; J[2][1] = stereo ? J[0][1] + bf * x * invz_2 : 0.0; J[2][2] = stereo ? J[0][2] : 0.0;
+                J[2][3] = stereo ? J[0][3] : 0.0; J[2][4] = 0; J[2][5] = stereo ? J[0][5] - bf * invz_2 : 0.0;
+                const double info = active ? (double)e_info[e] : 0.0;
+                const double er[3] = { active ? e_err[3 * e] : 0.0, active ? e_err[3 * e + 1] : 0.0, (active && stereo) ? e_err[3 * e + 2] : 0.0 };
                 double rho1 = 1.0;
-                if (fl & 4) { double r0; sgx_huber(sgx_po_chi2(er, info, stereo), stereo ? deltaStereo : deltaMono, &r0, &rho1); }
+                if (robust) rho1 = sgx_huber_rho1(sgx_po_chi2(er, info, 1), stereo ? deltaStereo : deltaMono);
                 const double w = rho1 * info;
 #pragma unroll
                 for (int a = 0; a < 6; a++) {
@@ -175,7 +182,7 @@ SGX_KERNEL(NTT) k_pose_opt(int cap, const uint8_t *keys_raw, const float *uright
             SGX_THREADS_END
             SGX_SYNC();
             SGX_THREADS_BEGIN(tid)
-            if (tid < 27 * NG) { const int c = tid / NG, j = tid - c * NG; double s = 0; for (int l = 0; l < 32; l++) s += part[(j * 32 + l) * SGX_PO_NRED + c]; part2[c * NG + j] = s; }
+            if (tid < 27 * NG) { const int c = tid / NG, j = tid - c * NG; double s = 0; for (int l = 0; l < 32; l++) s += part[(l * NG + j) * SGX_PO_NRED + c]; part2[c * NG + j] = s; }
             SGX_THREADS_END
             SGX_SYNC();
             SGX_THREADS_BEGIN(tid)
@@ -186,8 +193,8 @@ SGX_KERNEL(NTT) k_pose_opt(int cap, const uint8_t *keys_raw, const float *uright
 #pragma unroll
             for (int a = 0; a < 6; a++) {
 #pragma unroll
-                for (int c = 0; c < 6; c++) if (c >= a) { const double v = red[a * 6 - (a * (a - 1)) / 2 + (c - a)]; H[a][c] = v; H[c][a] = v; }
-                b[a] = red[21 + a];
+                for (int c = 0; c < 6; c++) if (c >= a) { const double v = sgx_uniform_f64(red[a * 6 - (a * (a - 1)) / 2 + (c - a)]); H[a][c] = v; H[c][a] = v; }
+                b[a] = sgx_uniform_f64(red[21 + a]);
             }
             if (it == 0) {                                           // computeLambdaInit, levenberg.cpp:166-180 (tau = 1e-5)
                 double maxd = 0;
@@ -209,7 +216,7 @@ SGX_KERNEL(NTT) k_pose_opt(int cap, const uint8_t *keys_raw, const float *uright
                 SgxSE3 ex; sgx_se3_exp(x, ex);
                 SgxSE3 upd; sgx_se3_mul(ex, est, upd); est = upd;     // VertexSE3Expmap::oplusImpl
                 SGX_PO_ERRORS()
-                tempChi = red[27];
+                tempChi = chiTot;
                 if (!ok2) tempChi = 1.7976931348623157e308;
                 rho = currentChi - tempChi;
                 double scale = 0;
@@ -243,7 +250,6 @@ SGX_KERNEL(NTT) k_pose_opt(int cap, const uint8_t *keys_raw, const float *uright
             if (fl & 8) sgx_po_edge_error(est, e_xw + 3 * e, e_obs + 3 * e, stereo, fx, fy, cx, cy, bf, e_err + 3 * e);
             const float chi2 = (float)sgx_po_chi2(e_err + 3 * e, (double)e_info[e], stereo);
             if (chi2 > (stereo ? 7.815f : 5.991f)) { fl |= (8 | 2); bad++; } else { fl &= ~(8 | 2); }
-            if (round == 2) fl &= ~4;
             e_flags[e] = (uint8_t)fl;
         }
         if (bad) sgx_atomic_add(&s_nbad, bad);

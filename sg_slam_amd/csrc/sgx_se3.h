@@ -6,6 +6,17 @@
 
 struct SgxSE3 { double q[4]; double t[3]; };   // quaternion x,y,z,w + translation (g2o::SE3Quat)
 
+// a / b, correctly rounded, from r = RN(1 / b): one multiply and two fused multiply-adds (Markstein's theorem: with the correctly rounded
+// reciprocal and a faithful first quotient, the corrected quotient is the correctly rounded one).  Zero / infinite / NaN operands make the
+// remainder non-finite and keep the first quotient a * r, which is then already the IEEE result (+-inf, 0 or NaN); a zero remainder keeps
+// it too (it is exact, and adding +0 would lose the sign of a -0 quotient).
+SGX_DEV double sgx_div_by_recip(double a, double b, double r)
+{
+    const double q = a * r;
+    const double rem = fma(-b, q, a);
+    return (fabs(rem) <= 1.7976931348623157e308 && rem != 0.0) ? fma(rem, r, q) : q;
+}
+
 SGX_DEV void sgx_quat_from_R(const double R[3][3], double q[4])
 {   // Eigen Quaterniond(Matrix3d) (Shepperd branches); written with static indices only (no scratch)
     double t = R[0][0] + R[1][1] + R[2][2];
@@ -32,7 +43,8 @@ SGX_DEV void sgx_quat_normalize_rot(double q[4])
 {   // SE3Quat::normalizeRotation, G/types/se3quat.h:280-285
     if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
     const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+    const double rn = 1.0 / n;                    // four correctly rounded quotients q[i] / n from one division
+    q[0] = sgx_div_by_recip(q[0], n, rn); q[1] = sgx_div_by_recip(q[1], n, rn); q[2] = sgx_div_by_recip(q[2], n, rn); q[3] = sgx_div_by_recip(q[3], n, rn);
 }
 SGX_DEV void sgx_quat_rotate(const double q[4], const double v[3], double o[3])
 {   // Eigen QuaternionBase::_transformVector
@@ -71,7 +83,8 @@ SGX_DEV void sgx_se3_exp(const double u[6], SgxSE3 &out)
             for (int j = 0; j < 3; j++) { R[i][j] = (i == j) + O[i][j] + O2[i][j]; V[i][j] = R[i][j]; }
         }
     } else {
-        const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta), c = (theta - sin(theta)) / (theta * theta * theta);
+        double st, ct; sincos(theta, &st, &ct);
+        const double a = st / theta, b = (1 - ct) / (theta * theta), c = (theta - st) / (theta * theta * theta);
 #pragma unroll
         for (int i = 0; i < 3; i++) {
 #pragma unroll
@@ -125,28 +138,34 @@ SGX_DEV void sgx_huber(double e, double delta, double *rho0, double *rho1)
     else { const double sq = sqrt(e); *rho0 = 2 * sq * delta - dsqr; *rho1 = delta / sq; }
 }
 
+// the two values separately, without a branch (e = 0 selects the first form)
+SGX_DEV double sgx_huber_rho0(double e, double delta)
+{ const double dsqr = delta * delta; return e <= dsqr ? e : 2 * sqrt(e) * delta - dsqr; }
+SGX_DEV double sgx_huber_rho1(double e, double delta)
+{ const double dsqr = delta * delta; return e <= dsqr ? 1. : delta / sqrt(e); }
+
 // LinearSolverDense (G/solvers/linear_solver_dense.h:105-111) factorises H with Eigen's LDLT and rejects the step
 // when the factorisation is not positive (levenberg.cpp:126-127).  Here: LDL^T of the 6x6 in natural order, fully
 // unrolled (registers only).  H + lambda*I is symmetric positive definite whenever the reference's pivoted LDLT
 // reports "positive", and then both give the same solution to ~1e-15 relative; a non-positive or NaN pivot
-// returns false (step rejected) like !isPositive().
+// returns false (step rejected) like !isPositive().  Quotients by a pivot are products with its reciprocal (six divisions instead of 21).
 SGX_DEV bool sgx_ldlt6_solve(const double Hin[6][6], const double b[6], double x[6])
 {
-    double L[6][6], D[6];
+    double L[6][6], D[6], rD[6];
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < 6; j++) {
         double d = Hin[j][j];
 #pragma unroll
         for (int k = 0; k < 6; k++) if (k < j) d -= L[j][k] * L[j][k] * D[k];
-        D[j] = d;
+        D[j] = d; rD[j] = 1.0 / d;
         if (!(d > 0)) ok = false;
 #pragma unroll
         for (int i = 0; i < 6; i++) if (i > j) {
             double v = Hin[i][j];
 #pragma unroll
             for (int k = 0; k < 6; k++) if (k < j) v -= L[i][k] * L[j][k] * D[k];
-            L[i][j] = v / d;
+            L[i][j] = v * rD[j];
         }
     }
     if (!ok) return false;
@@ -159,7 +178,7 @@ SGX_DEV bool sgx_ldlt6_solve(const double Hin[6][6], const double b[6], double x
         y[i] = v;
     }
 #pragma unroll
-    for (int i = 0; i < 6; i++) y[i] /= D[i];
+    for (int i = 0; i < 6; i++) y[i] *= rD[i];
 #pragma unroll
     for (int i = 5; i >= 0; i--) {
         double v = y[i];
@@ -185,6 +204,18 @@ SGX_DEV void sgx_po_edge_error(const SgxSE3 &T, const float *X, const float *obs
         const double r0 = p[0] * invz * fx + cx, r1 = p[1] * invz * fy + cy, r2 = r0 - bf * invz;
         err[0] = (double)obs[0] - r0; err[1] = (double)obs[1] - r1; err[2] = (double)obs[2] - r2;
     }
+}
+// the same residual, branch-free for both edge kinds (one division: the mono quotients p/z come from the reciprocal the stereo form needs anyway)
+SGX_DEV void sgx_po_residual(const SgxSE3 &T, const float *X, const float *obs, bool stereo,
+                             double fx, double fy, double cx, double cy, double bf, double *err)
+{
+    const double Xd[3] = { (double)X[0], (double)X[1], (double)X[2] };
+    double p[3]; sgx_se3_map(T, Xd, p);
+    const double rz = 1.0 / p[2];
+    const float invz = (float)rz;
+    const double s0 = p[0] * invz * fx + cx, s1 = p[1] * invz * fy + cy, s2 = s0 - bf * invz;
+    const double m0 = sgx_div_by_recip(p[0], p[2], rz) * fx + cx, m1 = sgx_div_by_recip(p[1], p[2], rz) * fy + cy;
+    err[0] = (double)obs[0] - (stereo ? s0 : m0); err[1] = (double)obs[1] - (stereo ? s1 : m1); err[2] = stereo ? (double)obs[2] - s2 : 0.0;
 }
 // BaseEdge::chi2 = e . (Omega e), Omega = invSigma2 * I   (G/core/base_edge.h:58-61)
 SGX_DEV double sgx_po_chi2(const double *err, double info, int stereo)
