@@ -118,7 +118,7 @@ SGX_KERNEL(NTT) k_pose_opt(int cap, const uint8_t *keys_raw, const float *uright
         e_err[3 * e] = er[0]; e_err[3 * e + 1] = er[1]; e_err[3 * e + 2] = er[2];                           \
         const double c2 = sgx_po_chi2(er, (double)e_info[e], 1);                                            \
         double r0 = c2;                                                                                     \
-        if (robust) r0 = sgx_huber_rho0(c2, (fl & 1) ? deltaStereo : deltaMono);                            \
+        if (robust) r0 = sgx_huber_rho0((fl & 2) ? 0.0 : c2, (fl & 1) ? deltaStereo : deltaMono);           \
         chi += (fl & 2) ? 0.0 : r0;                                                                         \
     }                                                                                                       \
     chi_part[tid] = chi;                                                                                    \

@@ -33,6 +33,9 @@
 #define SGX_POPCLL(x) __popcll(x)
 #define SGX_WAVE_PRIORITY(p) __builtin_amdgcn_s_setprio(p)   /* issue priority of this wave against co-resident waves (0..3) */
 #define SGX_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)      /* value known to be equal across the wave: keep it in a scalar register */
+/* true if the predicate holds in any lane of the wave: a scalar branch around work whose result only those lanes select (the emulator always
+   takes the branch: same results by construction) */
+#define SGX_WAVE_ANY(pred) (__builtin_amdgcn_ballot_w64(pred) != 0)
 static __device__ __forceinline__ double sgx_uniform_f64(double x)   /* the same for a double (two scalar registers) */
 { return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x))); }
 // per-thread state that must survive SGX_SYNC(): registers on the device, a [threads][count] table in the emulator
@@ -68,6 +71,7 @@ static inline int sgx_atomic_min_i32(int *p, int v) { int o = *p; if (v < o) *p 
          for (unsigned _x = 0; _x < _g.x; ++_x) { blockIdx = sgx_dim3(_x, _y, _z); (kern)(__VA_ARGS__); } } while (0)
 #define SGX_POPCLL(x) __builtin_popcountll(x)
 #define SGX_UNIFORM(x) (x)
+#define SGX_WAVE_ANY(pred) ((void)(pred), true)
 static inline double sgx_uniform_f64(double x) { return x; }
 #define SGX_WAVE_PRIORITY(p) ((void)0)
 #define SGX_PRIV_DECL(type, name, count, threads) static thread_local type name##_store[threads][count]

@@ -138,11 +138,21 @@ SGX_DEV void sgx_huber(double e, double delta, double *rho0, double *rho1)
     else { const double sq = sqrt(e); *rho0 = 2 * sq * delta - dsqr; *rho1 = delta / sq; }
 }
 
-// the two values separately, without a branch (e = 0 selects the first form)
+// the two values separately: the square root (and quotient) are evaluated only if some lane of the wave is beyond delta, and selected per lane
 SGX_DEV double sgx_huber_rho0(double e, double delta)
-{ const double dsqr = delta * delta; return e <= dsqr ? e : 2 * sqrt(e) * delta - dsqr; }
+{
+    const double dsqr = delta * delta;
+    double r = e;
+    if (SGX_WAVE_ANY(!(e <= dsqr))) r = e <= dsqr ? e : 2 * sqrt(e) * delta - dsqr;
+    return r;
+}
 SGX_DEV double sgx_huber_rho1(double e, double delta)
-{ const double dsqr = delta * delta; return e <= dsqr ? 1. : delta / sqrt(e); }
+{
+    const double dsqr = delta * delta;
+    double r = 1.;
+    if (SGX_WAVE_ANY(!(e <= dsqr))) r = e <= dsqr ? 1. : delta / sqrt(e);
+    return r;
+}
 
 // LinearSolverDense (G/solvers/linear_solver_dense.h:105-111) factorises H with Eigen's LDLT and rejects the step
 // when the factorisation is not positive (levenberg.cpp:126-127).  Here: LDL^T of the 6x6 in natural order, fully
@@ -214,7 +224,8 @@ SGX_DEV void sgx_po_residual(const SgxSE3 &T, const float *X, const float *obs, 
     const double rz = 1.0 / p[2];
     const float invz = (float)rz;
     const double s0 = p[0] * invz * fx + cx, s1 = p[1] * invz * fy + cy, s2 = s0 - bf * invz;
-    const double m0 = sgx_div_by_recip(p[0], p[2], rz) * fx + cx, m1 = sgx_div_by_recip(p[1], p[2], rz) * fy + cy;
+    double m0 = s0, m1 = s1;
+    if (SGX_WAVE_ANY(!stereo)) { m0 = sgx_div_by_recip(p[0], p[2], rz) * fx + cx; m1 = sgx_div_by_recip(p[1], p[2], rz) * fy + cy; }
     err[0] = (double)obs[0] - (stereo ? s0 : m0); err[1] = (double)obs[1] - (stereo ? s1 : m1); err[2] = stereo ? (double)obs[2] - s2 : 0.0;
 }
 // BaseEdge::chi2 = e . (Omega e), Omega = invSigma2 * I   (G/core/base_edge.h:58-61)
