@@ -152,3 +152,47 @@ def make_local_map(orc, S, t, seed=0, n_prev=2):
               obs=(rng.rand(n) < 0.7).astype('i4') * rng.randint(1, 5, n), skip=(rng.rand(n) < 0.1).astype(np.uint8))
     cur['mp_obs'] = np.where(rng.rand(len(k)) < 0.25, rng.randint(0, 3, len(k)), -1).astype('i4')
     return cur, lm
+
+
+def make_big_ba_problem(nkf=2000, npt=50000, seed=4):
+    """BASELINE config 4 generator (SURVEY.md §8(d) input 4): `nkf` keyframes on three loops of a 15 m circle looking outward, `npt` landmarks on walls
+    3..8 m away, each seen from 5..11 consecutive keyframes; pixel noise per octave, 5 % gross outliers, 20 % mono observations, perturbed initial poses
+    (the first one fixed) and points.  Returns (problem dict for Optimizer.LocalBundleAdjustment, true poses [nkf,4,4] f64, initial poses f64)."""
+    NKF, NPT = nkf, npt
+    rng = np.random.RandomState(seed)
+    # 3 loops of a 15 m circle, cameras looking outward (+z = radial direction), walls of landmarks 3..8 m away
+    th = 3 * 2 * np.pi * np.arange(NKF) / NKF
+    C = np.stack([15 * np.cos(th), 0.05 * np.sin(5 * th), 15 * np.sin(th)], 1) * (1 + 0.02 * np.arange(NKF)[:, None] / NKF)
+    zc = np.stack([np.cos(th), np.zeros(NKF), np.sin(th)], 1); yc = np.tile([0.0, 1.0, 0.0], (NKF, 1)); xc = np.cross(yc, zc)
+    R = np.stack([xc, yc, zc], 1)                                   # rows = camera axes in world coords: Xc = R (Xw - C)
+    Ts = np.tile(np.eye(4), (NKF, 1, 1)); Ts[:, :3, :3] = R; Ts[:, :3, 3] = -np.einsum('nij,nj->ni', R, C)
+    base = rng.randint(0, NKF, NPT); k = rng.randint(5, 12, NPT)
+    mid = (base + k // 2) % NKF
+    depth = rng.uniform(3.0, 8.0, NPT); lat = rng.uniform(-0.45, 0.45, NPT) * depth; up = rng.uniform(-0.3, 0.3, NPT) * depth
+    pts = C[mid] + zc[mid] * depth[:, None] + xc[mid] * lat[:, None] + yc[mid] * up[:, None]
+    sig = np.array([1.2 ** i for i in range(8)]); inv_sigma2 = 1.0 / sig ** 2
+    ep, el = [], []
+    for j in range(11):
+        sel = np.nonzero(k > j)[0]; ep.append((base[sel] + j) % NKF); el.append(sel)
+    ep = np.concatenate(ep); el = np.concatenate(el)
+    o = np.lexsort((ep, el)); ep, el = ep[o], el[o]
+    Xc = np.einsum('nij,nj->ni', Ts[ep, :3, :3], pts[el]) + Ts[ep, :3, 3]
+    u = CAM['fx'] * Xc[:, 0] / Xc[:, 2] + CAM['cx']; v = CAM['fy'] * Xc[:, 1] / Xc[:, 2] + CAM['cy']
+    ok = (Xc[:, 2] > 0.3) & (u > 0) & (u < 640) & (v > 0) & (v < 480)
+    ep, el, Xc, u, v = ep[ok], el[ok], Xc[ok], u[ok], v[ok]
+    cnt = np.bincount(el, minlength=NPT); ok = cnt[el] >= 2
+    ep, el, Xc, u, v = ep[ok], el[ok], Xc[ok], u[ok], v[ok]
+    ne = len(ep)
+    octv = rng.randint(0, 8, ne); s = 0.8 * sig[octv]
+    uo = u + rng.randn(ne) * s; vo = v + rng.randn(ne) * s; ur = uo - CAM['bf'] / Xc[:, 2] + rng.randn(ne) * s * 0.5
+    out = rng.rand(ne) < 0.05; uo[out] += rng.uniform(-50, 50, out.sum()); vo[out] += rng.uniform(-50, 50, out.sum())
+    ur[rng.rand(ne) < 0.2] = -1.0
+    poses0 = Ts.copy()
+    d = rng.randn(NKF, 6) * 0.01; d[0] = 0
+    for i in range(1, NKF):
+        w = d[i, :3]; dR = np.eye(3) + np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]); uu, _, vv = np.linalg.svd(dR); dR = uu @ vv
+        poses0[i, :3, :3] = dR @ Ts[i, :3, :3]; poses0[i, :3, 3] = dR @ Ts[i, :3, 3] + d[i, 3:]
+    fixed = np.zeros(NKF, np.uint8); fixed[0] = 2
+    prob = dict(poses=poses0.astype('f4'), pose_fixed=fixed, points=(pts + rng.randn(NPT, 3) * 0.03).astype('f4'), edge_pose=ep.astype('i4'), edge_point=el.astype('i4'),
+                edge_obs=np.stack([uo, vo, ur], 1).astype('f4'), edge_info=inv_sigma2[octv].astype('f4'))
+    return prob, Ts, poses0
