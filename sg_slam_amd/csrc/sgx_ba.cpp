@@ -40,7 +40,7 @@ struct BA {
     // device
     SgxBaEdge *E; SgxSE3 *T, *Tb; double *X, *Xb, *err, *Hll, *bl, *Hpl, *Hpp, *bp, *S, *coef, *xp, *xl, *Dinv, *dwork, *partial;
     int *pt_start, *pt_edges, *pose_start, *pose_edges, *hidx, *free_pose, *ok; uint8_t *pt_active;
-    SgxBaJob *jobs; double *Linv; long long njobs; size_t jobs_cap;
+    SgxBaJob *jobs; double *Linv, *xsol; long long njobs; size_t jobs_cap;
     double *part_chi, *part_scale;      // device scalars block: [ok | part_scale[nblk_v] | part_chi[nblk_e]] read back with ONE copy per trial
     int nblk_e, nblk_v;
     std::vector<double> hpart;
@@ -119,6 +119,7 @@ static int optimize(BA &B, int iterations, int *iters_done, double *final_chi)
         double rho = 0; int qmax = 0;
         do {
             int ok2 = 1;
+            const double *xsol = B.xp;                               // where the solver leaves the pose increments
             { const int one = 1; SGX_CHECK_HIP(hipMemcpyAsync(B.ok, &one, 4, hipMemcpyHostToDevice, 0)); }
             if (B.NP > 0) {
                 const int g = (int)(((size_t)B.NP * B.NP + SGX_BA_THREADS - 1) / SGX_BA_THREADS);
@@ -146,13 +147,22 @@ static int optimize(BA &B, int iterations, int *iters_done, double *final_chi)
                         SGX_LAUNCH(k_chol_update, dim3(rem * (rem + 1) / 2), dim3(256), (sgx_stream_t)0, B.NP, k0, B.S, B.ok);
                     }
                 }
-                SGX_LAUNCH(k_chol_solve, dim3(1), dim3(t_solve), (sgx_stream_t)0, B.NP, B.S, B.Linv, B.bp, B.coef, B.xp, B.ok);
+                static const int back_min = getenv("SGX_TUNE_CHOL_BACK_MIN") ? atoi(getenv("SGX_TUNE_CHOL_BACK_MIN")) : 0;     // measured: the per-block launches win at every blocked size (360 unknowns: 9.9 -> 9.5 ms per LocalBA, 12 000: 2.5 -> 1.1 s)
+                if (B.NP < back_min) {
+                    SGX_LAUNCH(k_chol_solve, dim3(1), dim3(t_solve), (sgx_stream_t)0, B.NP, B.S, B.Linv, B.bp, B.coef, B.xp, B.ok);
+                } else {                                            // one launch per diagonal block, all CUs on the row panel (k_chol_back_step)
+                    for (int kb = nt - 1; kb >= 0; kb--) {
+                        const int k0 = kb * SGX_NB;
+                        SGX_LAUNCH(k_chol_back_step, dim3(k0 > 0 ? (k0 + 255) / 256 : 1), dim3(256), (sgx_stream_t)0, B.NP, k0, B.S, B.Linv, B.xp, B.xsol, B.ok);
+                    }
+                    xsol = B.xsol;
+                }
             }
             // when the factorisation failed, xp/xl keep the previous solution (as g2o's _x does) and the step is rejected below
             SGX_LAUNCH(k_ba_backsub, dim3((B.nl + SGX_BA_THREADS - 1) / SGX_BA_THREADS), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.nl, B.pt_start, B.pt_edges, B.E, B.hidx,
-                           B.pt_active, B.bl, B.Hpl, B.Dinv, B.xp, B.xl, B.ok);
+                           B.pt_active, B.bl, B.Hpl, B.Dinv, xsol, B.xl, B.ok);
             // push + update + computeScale
-            SGX_LAUNCH(k_ba_update, dim3(B.nblk_v), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.np, B.nl, B.hidx, B.pt_active, B.xp, B.xl, B.bp, B.bl, lambda,
+            SGX_LAUNCH(k_ba_update, dim3(B.nblk_v), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.np, B.nl, B.hidx, B.pt_active, xsol, B.xl, B.bp, B.bl, lambda,
                        B.T, B.X, B.Tb, B.Xb, B.part_scale);
             SGX_LAUNCH(k_ba_errors, dim3(B.nblk_e), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.ne, B.E, B.T, B.X, B.cam, B.dMono, B.dStereo, B.err, B.part_chi);
             double scale = 0; rc = read_trial(B, &ok2, &scale, &tempChi); if (rc != SGX_OK) return rc;
@@ -230,7 +240,7 @@ extern "C" int sgx_local_bundle_adjustment(const sgx_ba_problem *P, const sgx_ca
         in_bytes = A.off;
         A.take(&B.T, B.np); A.take(&B.Tb, B.np); A.take(&B.Xb, 3 * (size_t)B.nl); A.take(&B.err, 3 * (size_t)B.ne);
         A.take(&B.Hll, 9 * (size_t)B.nl); A.take(&B.bl, 3 * (size_t)B.nl); A.take(&B.Hpl, 18 * (size_t)B.ne); A.take(&B.Hpp, 36 * (size_t)B.nf);
-        A.take(&B.bp, B.NP); A.take(&B.S, (size_t)B.NP * B.NP); A.take(&B.coef, B.NP); A.take(&B.xp, B.NP); A.take(&B.xl, 3 * (size_t)B.nl);
+        A.take(&B.bp, B.NP); A.take(&B.S, (size_t)B.NP * B.NP); A.take(&B.coef, B.NP); A.take(&B.xp, B.NP); A.take(&B.xsol, B.NP); A.take(&B.xl, 3 * (size_t)B.nl);
         A.take(&B.Dinv, 9 * (size_t)B.nl); A.take(&B.dwork, B.NP); A.take(&B.partial, B.nblk_v);
         { double *blk = nullptr; A.take(&blk, 1 + (size_t)B.nblk_v + B.nblk_e); B.ok = (int *)blk; B.part_scale = blk ? blk + 1 : nullptr; B.part_chi = blk ? blk + 1 + B.nblk_v : nullptr; }
         A.take(&B.pt_active, B.nl); A.take(&derase, B.ne);
@@ -251,6 +261,7 @@ extern "C" int sgx_local_bundle_adjustment(const sgx_ba_problem *P, const sgx_ca
         SGX_CHECK_HIP(hipMemcpy(base, stage.data(), in_bytes, hipMemcpyHostToDevice));
     }
     SGX_CHECK_HIP(hipMemsetAsync(B.xp, 0, sizeof(double) * (B.NP ? B.NP : 1), 0));
+    SGX_CHECK_HIP(hipMemsetAsync(B.xsol, 0, sizeof(double) * (B.NP ? B.NP : 1), 0));
     SGX_CHECK_HIP(hipMemsetAsync(B.xl, 0, sizeof(double) * 3 * (size_t)B.nl, 0));
     SGX_CHECK_HIP(hipMemsetAsync(B.err, 0, sizeof(double) * 3 * (size_t)B.ne, 0));
     SGX_CHECK_HIP(hipMemsetAsync(B.Hpl, 0, sizeof(double) * 18 * (size_t)B.ne, 0));

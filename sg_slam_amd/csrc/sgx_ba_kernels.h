@@ -481,6 +481,32 @@ SGX_KERNEL(256) k_chol_solve(int n, const double *S, const double *Linv, const d
     }
 }
 
+// One step of the same backward pass spread over the chip (large systems: the single workgroup above would stream the whole factor, n^2/2 doubles,
+// through one CU).  Launched once per diagonal block, last block first: every workgroup recomputes x_k = Linv_kk^T y_k (a 32 x 32 mat-vec) from the
+// working vector y, workgroup 0 stores it to `xsol`, and workgroup w applies the update y_i -= sum_q L[k0+q][i] x_k[q] to its 256 columns i < k0
+// (32 coalesced row segments).  y[k0..] is only read during the launch and `xsol` only written, so the workgroups need no ordering among themselves.
+SGX_KERNEL(256) k_chol_back_step(int n, int k0, const double *S, const double *Linv, double *y, double *xsol, const int *ok)
+{
+    SGX_LDS double ys[SGX_NB];
+    if (!*ok) return;
+    const int nb = min(SGX_NB, n - k0);
+    const double *Lk = Linv + (size_t)(k0 / SGX_NB) * SGX_NB * SGX_NB;
+    SGX_THREADS_BEGIN(tid)
+    if (tid < nb) { double sacc = 0; for (int q = tid; q < nb; q++) sacc += Lk[q * SGX_NB + tid] * y[k0 + q]; ys[tid] = sacc; }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    if (blockIdx.x == 0 && tid < nb) xsol[k0 + tid] = ys[tid];
+    const int i = (int)blockIdx.x * 256 + tid;
+    if (i < k0) {
+        double vv = y[i];
+#pragma unroll 8
+        for (int q = 0; q < nb; q++) vv -= S[(size_t)(k0 + q) * n + i] * ys[q];
+        y[i] = vv;
+    }
+    SGX_THREADS_END
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_ba_schur_pairs: the Schur complement (block_solver.hpp:380-433) as one thread per (job, entry): a job is a pair of
 // active free-pose edges (k1, k2) of one landmark (host-built list, static during one optimize() call); the 36 threads of a
