@@ -139,12 +139,22 @@ static int optimize(BA &B, int iterations, int *iters_done, double *final_chi)
                 SGX_LAUNCH(k_chol_small, dim3(1), dim3(t_small), (sgx_stream_t)0, B.NP, B.S, B.bp, B.coef, B.xp, B.ok);
             } else if (B.NP > 0) {                                   // blocked Cholesky of the reduced camera system
                 const int nt = (B.NP + SGX_NB - 1) / SGX_NB;
+                // tiles per outer panel; small systems keep one level (a rank-256 launch on the critical path costs them more than its eight rank-32 shares)
+                static const int wide_min = getenv("SGX_TUNE_CHOL_WIDE_MIN") ? atoi(getenv("SGX_TUNE_CHOL_WIDE_MIN")) : 1024;
+                const int OT = B.NP > wide_min ? SGX_OB / SGX_NB : (1 << 24);
                 for (int kb = 0; kb < nt; kb++) {
                     const int k0 = kb * SGX_NB, rem = nt - kb - 1;
+                    const int in_panel = OT - 1 - kb % OT;           // column tiles right of this one that still belong to the outer panel
                     SGX_LAUNCH(k_chol_diag, dim3(1), dim3(t_diag), (sgx_stream_t)0, B.NP, k0, B.S, B.Linv, B.ok, B.bp, B.coef, B.xp);
                     if (rem > 0) {
                         SGX_LAUNCH(k_chol_panel, dim3(rem), dim3(256), (sgx_stream_t)0, B.NP, k0, B.S, B.Linv, B.ok, B.xp);
-                        SGX_LAUNCH(k_chol_update, dim3(rem * (rem + 1) / 2), dim3(256), (sgx_stream_t)0, B.NP, k0, B.S, B.ok);
+                        const int pc = in_panel < rem ? in_panel : rem;
+                        if (pc > 0) SGX_LAUNCH(k_chol_update, dim3(rem, pc), dim3(256), (sgx_stream_t)0, B.NP, k0, B.S, B.ok);
+                        if (in_panel == 0) {                         // panel finished: one rank-256 update of the rest on the matrix cores
+                            const int p0 = (kb / OT) * SGX_OB, q0 = p0 + SGX_OB;
+                            const int wt = (B.NP - q0 + SGX_WT - 1) / SGX_WT;
+                            if (wt > 0) SGX_LAUNCH(k_chol_update_wide, dim3(wt, wt), dim3(256), (sgx_stream_t)0, B.NP, p0, SGX_OB, B.S, B.ok);
+                        }
                     }
                 }
                 static const int back_min = getenv("SGX_TUNE_CHOL_BACK_MIN") ? atoi(getenv("SGX_TUNE_CHOL_BACK_MIN")) : 0;     // measured: the per-block launches win at every blocked size (360 unknowns: 9.9 -> 9.5 ms per LocalBA, 12 000: 2.5 -> 1.1 s)

@@ -223,8 +223,9 @@ SGX_KERNEL(SGX_BA_THREADS) k_ba_schur_init(int nf, const double *Hpp, double lam
 //   n  > 128 : blocked right-looking factorisation on 32x32 tiles staged in LDS, per panel k:
 //                k_chol_diag   (1 workgroup: factor L_kk and its explicit inverse Linv_kk)
 //                k_chol_panel  (one workgroup per row tile below:  L_ik = A_ik Linv_kk^T   — a tile GEMM)
-//                k_chol_update (one workgroup per lower-triangular tile pair: A_ij -= L_ik L_jk^T)
-//              then k_chol_solve (one workgroup, blocked substitution with the stored Linv_kk: mat-vec + tile updates).
+//                k_chol_update (one workgroup per lower-triangular tile pair inside the current 256-column outer panel: A_ij -= L_ik L_jk^T)
+//              per outer panel: k_chol_update_wide (fp64 MFMA rank-256 update of everything right of the panel, 64 x 64 tiles)
+//              then the backward pass: k_chol_back_step per diagonal block (all CUs), or k_chol_solve (one workgroup) via the tuning tap.
 // ---------------------------------------------------------------------------------------------
 #define SGX_NB 32            /* tile edge of the blocked factorisation.  Measured: 64 halves the launches and runs the 2000-keyframe BA 8 % faster, but its
                                 diagonal-tile kernel (64 serial steps + a 64-long register inverse) makes LocalBA-sized systems 20 % slower */
@@ -424,16 +425,16 @@ SGX_KERNEL(256) k_chol_panel(int n, int k0, double *S, const double *Linv, const
     SGX_THREADS_END
 }
 
-// A_ij -= L_ik L_jk^T for the lower-triangular tile pairs (i >= j) of the trailing matrix; blockIdx.x enumerates pairs
+// A_ij -= L_ik L_jk^T for the lower-triangular tile pairs (i >= j) of the trailing matrix, column tiles j < gridDim.y only (the rest of the current
+// 256-column outer panel; everything right of the panel is updated once per panel by k_chol_update_wide).  grid = (row tiles, column tiles).
 SGX_KERNEL(256) k_chol_update(int n, int k0, double *S, const int *ok)
 {
     SGX_LDS double LiT[SGX_NB][SGX_NB + 4];
     SGX_LDS double LjT[SGX_NB][SGX_NB + 4];
     if (!*ok) return;
     const int nb = min(SGX_NB, n - k0);
-    int bi = 0, rem = (int)blockIdx.x;               // unrank blockIdx.x -> (bi >= bj) within the trailing tiles
-    while (rem > bi) { rem -= bi + 1; bi++; }
-    const int bj = rem;
+    const int bi = (int)blockIdx.x, bj = (int)blockIdx.y;
+    if (bi < bj) return;
     const int r0 = k0 + SGX_NB * (1 + bi), c0 = k0 + SGX_NB * (1 + bj);
     const int nr = min(SGX_NB, n - r0), nc = min(SGX_NB, n - c0);
     const int NT = (int)blockDim.x;
@@ -457,6 +458,92 @@ SGX_KERNEL(256) k_chol_update(int n, int k0, double *S, const int *ok)
             if (r < nr && c < nc && !(bi == bj && c > r)) S[(size_t)(r0 + r) * n + c0 + c] -= acc[i][j];
         }
     SGX_THREADS_END
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_chol_update_wide: the rank-PW update of everything right of a finished outer panel (columns p0 .. p0+pw of L, pw <= SGX_OB):
+//   A[r][c] -= sum_{k in panel} L[r][k] L[c][k]      for the lower-triangular 64 x 64 tile pairs (r-tile >= c-tile) starting at row / column q0 = p0 + pw.
+// This is the one dense fp64 contraction of the solver (n^3/3 multiply-adds for an n x n system) and runs on the matrix cores:
+// v_mfma_f64_16x16x4_f64, A operand lane l = L[r0 + (l&15)][k + (l>>4)], B operand lane l = L[c0 + (l&15)][k + (l>>4)], C/D lane l, register i =
+// row (l>>4) + 4 i, column l&15 (cdna guide: the f64 shape has its own C/D map).  A workgroup = 4 waves = one 64 x 64 tile, each wave a 32 x 32 quadrant
+// (2 x 2 MFMA blocks, 16 accumulator doubles per lane); the two 64 x 32 operand slabs of a K-chunk are staged TRANSPOSED in LDS with a row stride of
+// 80 doubles, which spreads the 16 rows x 4 k of an operand read over all 64 banks.  With rank-32 updates the trailing matrix made a round trip
+// through L2 / HBM per 32 columns (560 GB per factorisation at n = 12 000, 0.74 s of 1.08 s); here it makes one per 256 columns and the
+// multiply-adds leave the VALU.  grid = (tiles, tiles), upper-triangle workgroups exit.
+// ---------------------------------------------------------------------------------------------
+#define SGX_OB 256           /* outer panel width of the two-level blocked factorisation (8 tiles of SGX_NB) */
+#define SGX_WT 64            /* output tile edge of the wide update */
+#define SGX_WLD 80           /* LDS row stride (doubles) of the transposed operand slabs */
+#ifndef SGX_EMU
+typedef double sgx_f64x4 __attribute__((ext_vector_type(4)));
+#endif
+SGX_KERNEL(256) k_chol_update_wide(int n, int p0, int pw, double *S, const int *ok)
+{
+    if (!*ok) return;
+    const int bi = (int)blockIdx.x, bj = (int)blockIdx.y;
+    if (bi < bj) return;
+    const int q0 = p0 + pw;
+    const int r0 = q0 + SGX_WT * bi, c0 = q0 + SGX_WT * bj;
+#ifndef SGX_EMU
+    SGX_LDS double LiT[SGX_NB][SGX_WLD];          // [k][row] of the row tile
+    SGX_LDS double LjT[SGX_NB][SGX_WLD];          // [k][row] of the column tile
+    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    sgx_f64x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = sgx_f64x4{0.0, 0.0, 0.0, 0.0};
+    // a thread stages 8 consecutive k of one row (64 B) of each slab, 4 threads cover a row's K-chunk; the next chunk is fetched into registers
+    // while the matrix cores work on the current one
+    const int srow = tid >> 2, skq = (tid & 3) * 8;
+    const bool vi = r0 + srow < n, vj = c0 + srow < n;
+    const double *gi = S + (size_t)(vi ? r0 + srow : 0) * n + p0 + skq, *gj = S + (size_t)(vj ? c0 + srow : 0) * n + p0 + skq;
+    double pi[8], pj[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { const bool vk = skq + u < pw; pi[u] = (vi && vk) ? gi[u] : 0.0; pj[u] = (vj && vk) ? gj[u] : 0.0; }
+    for (int kc = 0; kc < pw; kc += SGX_NB) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) { LiT[skq + u][srow] = pi[u]; LjT[skq + u][srow] = pj[u]; }
+        __syncthreads();
+        if (kc + SGX_NB < pw) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const bool vk = kc + SGX_NB + skq + u < pw; pi[u] = (vi && vk) ? gi[kc + SGX_NB + u] : 0.0; pj[u] = (vj && vk) ? gj[kc + SGX_NB + u] : 0.0; }
+        }
+#pragma unroll
+        for (int k4 = 0; k4 < SGX_NB; k4 += 4) {
+            const int kk = k4 + (lane >> 4), rr = lane & 15;
+            const double a0 = LiT[kk][wm + rr], a1 = LiT[kk][wm + 16 + rr];
+            const double b0 = LjT[kk][wn + rr], b1 = LjT[kk][wn + 16 + rr];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int r = r0 + wm + 16 * a + (lane >> 4) + 4 * i, c = c0 + wn + 16 * b + (lane & 15);
+                if (r < n && c < n && c <= r) S[(size_t)r * n + c] -= acc[a][b][i];
+            }
+#else
+    // kernel-logic emulator: the same tile decomposition with a plain k-ordered sum (the matrix core's internal order differs in the last bits)
+    SGX_THREADS_BEGIN(tid)
+    for (int t = tid; t < SGX_WT * SGX_WT; t += 256) {
+        const int r = r0 + (t >> 6), c = c0 + (t & 63);
+        if (r < n && c < n && c <= r) {
+            double sacc = 0;
+            for (int k = 0; k < pw; k++) sacc += S[(size_t)r * n + p0 + k] * S[(size_t)c * n + p0 + k];
+            S[(size_t)r * n + c] -= sacc;
+        }
+    }
+    SGX_THREADS_END
+#endif
 }
 
 // x = (bp - coef); L y = x; L^T x = y — blocked with the stored diagonal inverses, one 256-thread workgroup

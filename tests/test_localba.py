@@ -47,7 +47,7 @@ def test_oracle_stop_flag(oracle):
     assert (poses == prob['poses']).all() and (points == prob['points']).all() and erase.sum() == 0    # Optimizer.cc:655-657
 
 
-@pytest.mark.parametrize('seed,n_free,n_fixed,n_points', [(11, 8, 5, 400), (12, 3, 0, 120), (13, 16, 10, 900), (15, 30, 8, 1500)])
+@pytest.mark.parametrize('seed,n_free,n_fixed,n_points', [(11, 8, 5, 400), (12, 3, 0, 120), (13, 16, 10, 900), (15, 30, 8, 1500), (17, 56, 10, 2500)])
 def test_emu_matches_oracle(emu, oracle, seed, n_free, n_fixed, n_points):
     prob, _, _ = make_ba_problem(oracle, n_free=n_free, n_fixed=n_fixed, n_points=n_points, seed=seed)
     eposes, epoints, eerase, etrace, eiters = oracle.local_ba(prob, CAM)

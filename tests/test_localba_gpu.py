@@ -9,7 +9,7 @@ from test_localba import close, points_close
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('seed,n_free,n_fixed,n_points', [(11, 8, 5, 400), (12, 3, 0, 120), (13, 16, 10, 900), (14, 20, 40, 2000), (15, 30, 8, 1500), (16, 70, 30, 5000)])
+@pytest.mark.parametrize('seed,n_free,n_fixed,n_points', [(11, 8, 5, 400), (12, 3, 0, 120), (13, 16, 10, 900), (14, 20, 40, 2000), (15, 30, 8, 1500), (16, 70, 30, 5000), (17, 56, 10, 2500), (18, 130, 20, 7000)])
 def test_gpu_matches_oracle(gpulib, oracle, seed, n_free, n_fixed, n_points):
     prob, _, _ = make_ba_problem(oracle, n_free=n_free, n_fixed=n_fixed, n_points=n_points, seed=seed)
     eposes, epoints, eerase, etrace, eiters = oracle.local_ba(prob, CAM)
