@@ -497,18 +497,18 @@ SGX_KERNEL(256) k_chol_update_wide(int n, int p0, int pw, double *S, const int *
     // a thread stages 8 consecutive k of one row (64 B) of each slab, 4 threads cover a row's K-chunk; the next chunk is fetched into registers
     // while the matrix cores work on the current one
     const int srow = tid >> 2, skq = (tid & 3) * 8;
-    const bool vi = r0 + srow < n, vj = c0 + srow < n;
-    const double *gi = S + (size_t)(vi ? r0 + srow : 0) * n + p0 + skq, *gj = S + (size_t)(vj ? c0 + srow : 0) * n + p0 + skq;
+    const bool vi = r0 + srow < n, vj = c0 + srow < n;                 // rows past the matrix edge: fetched from the last row (no branch around the loads), zeroed on the way to LDS
+    const double *gi = S + (size_t)min(r0 + srow, n - 1) * n + p0 + skq, *gj = S + (size_t)min(c0 + srow, n - 1) * n + p0 + skq;
     double pi[8], pj[8];
 #pragma unroll
-    for (int u = 0; u < 8; u++) { const bool vk = skq + u < pw; pi[u] = (vi && vk) ? gi[u] : 0.0; pj[u] = (vj && vk) ? gj[u] : 0.0; }
-    for (int kc = 0; kc < pw; kc += SGX_NB) {
+    for (int u = 0; u < 8; u++) { pi[u] = gi[u]; pj[u] = gj[u]; }
+    for (int kc = 0; kc < pw; kc += SGX_NB) {                          // pw is a multiple of SGX_NB (whole outer panels only)
 #pragma unroll
-        for (int u = 0; u < 8; u++) { LiT[skq + u][srow] = pi[u]; LjT[skq + u][srow] = pj[u]; }
+        for (int u = 0; u < 8; u++) { LiT[skq + u][srow] = vi ? pi[u] : 0.0; LjT[skq + u][srow] = vj ? pj[u] : 0.0; }
         __syncthreads();
         if (kc + SGX_NB < pw) {
 #pragma unroll
-            for (int u = 0; u < 8; u++) { const bool vk = kc + SGX_NB + skq + u < pw; pi[u] = (vi && vk) ? gi[kc + SGX_NB + u] : 0.0; pj[u] = (vj && vk) ? gj[kc + SGX_NB + u] : 0.0; }
+            for (int u = 0; u < 8; u++) { pi[u] = gi[kc + SGX_NB + u]; pj[u] = gj[kc + SGX_NB + u]; }
         }
 #pragma unroll
         for (int k4 = 0; k4 < SGX_NB; k4 += 4) {
