@@ -136,7 +136,9 @@ static int optimize(BA &B, int iterations, int *iters_done, double *final_chi)
             static const int t_diag = getenv("SGX_TUNE_CHOL_DIAG_THREADS") ? atoi(getenv("SGX_TUNE_CHOL_DIAG_THREADS")) : 256;
             static const int t_solve = getenv("SGX_TUNE_CHOL_SOLVE_THREADS") ? atoi(getenv("SGX_TUNE_CHOL_SOLVE_THREADS")) : 256;
             if (B.NP > 0 && B.NP <= SGX_CHOL_SMALL) {
-                SGX_LAUNCH(k_chol_small, dim3(1), dim3(t_small), (sgx_stream_t)0, B.NP, B.S, B.bp, B.coef, B.xp, B.ok);
+                static const int small_lds = getenv("SGX_TUNE_CHOL_SMALL_LDS") ? atoi(getenv("SGX_TUNE_CHOL_SMALL_LDS")) : 0;     // 1 = the LDS-resident version (comparison tap)
+                if (small_lds) SGX_LAUNCH(k_chol_small, dim3(1), dim3(t_small), (sgx_stream_t)0, B.NP, B.S, B.bp, B.coef, B.xp, B.ok);
+                else SGX_LAUNCH(k_chol_small_reg, dim3(1), dim3(256), (sgx_stream_t)0, B.NP, B.S, B.bp, B.coef, B.xp, B.ok);
             } else if (B.NP > 0) {                                   // blocked Cholesky of the reduced camera system
                 const int nt = (B.NP + SGX_NB - 1) / SGX_NB;
                 // tiles per outer panel; small systems keep one level (a rank-256 launch on the critical path costs them more than its eight rank-32 shares)

@@ -280,6 +280,114 @@ SGX_KERNEL(256) k_chol_small(int n, const double *S, const double *bp, const dou
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_chol_small_reg: the same factorisation and solve (n <= 128, unscaled L D L^T, right-hand side riding along) with the working matrix in REGISTERS.
+// Thread (ty, tx) of the 16 x 16 map owns A[ty + 16 a][tx + 16 c], a, c = 0..7 (64 doubles) and a copy of the right-hand side entries v[tx + 16 c].
+// Column j: its owners (tx == j mod 16) publish the finished column, unscaled, as row j of LmT in LDS (+ v_j in slot 128) — one barrier — and every thread
+// applies the rank-1 update to its own registers from 2 x 8 broadcast reads of that row.  The 8 x 16 column steps are unrolled over the column group jb so
+// that every register index is static and the row / column groups already eliminated (a, c < jb; c > a) are pruned at compile time: 120 multiply-add
+// statements in total instead of 64 per column.  The LDS-resident version (k_chol_small) spends ~1.8 us per column on dependent LDS read-modify-writes;
+// LmT doubles as the factor for the back substitution, done 16 unknowns at a time: every thread solves the 16 x 16 triangle redundantly in registers
+// (no barriers inside), then threads 0..j0-1 push the block into their pending right-hand sides — 8 barriers instead of 128.
+// ---------------------------------------------------------------------------------------------
+SGX_KERNEL(256) k_chol_small_reg(int n, const double *S, const double *bp, const double *coef, double *x, int *ok)
+{
+    constexpr int N = SGX_CHOL_SMALL, LD = SGX_CHOL_SMALL + 1, G = SGX_CHOL_SMALL / 16;
+    SGX_LDS double LmT[N * LD];                       // LmT[j * LD + i] = u_ij = L_ij d_j (i >= j);  LmT[j * LD + N] = y_j (forward-substituted right-hand side)
+    SGX_LDS double rdiag[N];                          // 1 / d_j
+    SGX_LDS double w[N];                              // pending right-hand sides of the back substitution, then the solution
+    SGX_PRIV_DECL(double, a, G * G, 256);
+    SGX_PRIV_DECL(double, vr, G, 256);
+    SGX_THREADS_BEGIN(tid)
+    SGX_PRIV_BIND(a, tid); SGX_PRIV_BIND(vr, tid);
+    const int ty = tid >> 4, tx = tid & 15;
+#pragma unroll
+    for (int ai = 0; ai < G; ai++)
+#pragma unroll
+        for (int ci = 0; ci < G; ci++) { const int i = ty + 16 * ai, c = tx + 16 * ci; a[G * ai + ci] = (i < n && c < n) ? S[(size_t)i * n + c] : 0.0; }
+#pragma unroll
+    for (int ci = 0; ci < G; ci++) { const int c = tx + 16 * ci; vr[ci] = c < n ? bp[c] - coef[c] : 0.0; }
+    SGX_THREADS_END
+    bool failed = false;
+#pragma unroll
+    for (int jb = 0; jb < G; jb++) {
+        for (int jj = 0; jj < 16; jj++) {
+            const int j = 16 * jb + jj;
+            if (j >= n || failed) break;
+            SGX_THREADS_BEGIN(tid)
+            SGX_PRIV_BIND(a, tid); SGX_PRIV_BIND(vr, tid);
+            const int ty = tid >> 4, tx = tid & 15;
+            if (tx == jj) {
+#pragma unroll
+                for (int ai = jb; ai < G; ai++) LmT[j * LD + ty + 16 * ai] = a[G * ai + jb];
+                if (ty == 0) LmT[j * LD + N] = vr[jb];
+            }
+            SGX_THREADS_END
+            SGX_SYNC();
+            const double d = LmT[j * LD + j];            // final pivot: every update from the columns before j has been applied
+            if (!(d > 0)) { failed = true; break; }
+            const double rd = 1.0 / d, fv = LmT[j * LD + N] * rd;
+            SGX_THREADS_BEGIN(tid)
+            SGX_PRIV_BIND(a, tid); SGX_PRIV_BIND(vr, tid);
+            const int ty = tid >> 4, tx = tid & 15;
+            if (tid == 0) rdiag[j] = rd;
+            double f[G], u[G];
+#pragma unroll
+            for (int g = jb; g < G; g++) {
+                const double ui = LmT[j * LD + ty + 16 * g], uc = LmT[j * LD + tx + 16 * g];
+                f[g] = (ty + 16 * g > j) ? ui * rd : 0.0;      // L_ij for the rows below the pivot, 0 for finished rows (their update is an exact no-op)
+                u[g] = (tx + 16 * g > j) ? uc : 0.0;
+            }
+#pragma unroll
+            for (int ai = jb; ai < G; ai++)
+#pragma unroll
+                for (int ci = jb; ci <= ai; ci++) {
+                    const double t = f[ai] * u[ci];
+                    a[G * ai + ci] -= (ci < ai || tx <= ty) ? t : 0.0;      // lower triangle only (the diagonal groups hold both halves)
+                }
+#pragma unroll
+            for (int ci = jb; ci < G; ci++) vr[ci] -= fv * u[ci];
+            SGX_THREADS_END
+        }
+    }
+    if (failed) {
+        SGX_THREADS_BEGIN(tid) if (tid == 0) *ok = 0; SGX_THREADS_END
+        return;
+    }
+    // ---- back substitution  x_j = (y_j - sum_{i>j} u_ij x_i) / d_j, 16 unknowns per barrier
+    SGX_THREADS_BEGIN(tid)
+    if (tid < n) w[tid] = LmT[tid * LD + N];
+    SGX_THREADS_END
+    SGX_SYNC();
+    for (int jb = (n - 1) / 16; jb >= 0; jb--) {
+        const int j0 = 16 * jb;
+        SGX_THREADS_BEGIN(tid)
+        double xs[16];
+#pragma unroll
+        for (int q = 15; q >= 0; q--) {                  // every thread solves the 16 x 16 triangle (broadcast reads, static indices)
+            const int j = j0 + q;
+            double sacc = j < n ? w[j] : 0.0;
+#pragma unroll
+            for (int r = q + 1; r < 16; r++) sacc -= ((j0 + r < n && j < n) ? LmT[j * LD + j0 + r] : 0.0) * xs[r];
+            xs[q] = j < n ? sacc * rdiag[j] : 0.0;
+        }
+        if (tid < j0) {                                  // push the block into the rows above it
+            double sacc = w[tid];
+#pragma unroll
+            for (int r = 0; r < 16; r++) sacc -= (j0 + r < n ? LmT[tid * LD + j0 + r] : 0.0) * xs[r];
+            w[tid] = sacc;
+        }
+        if (tid < 16 && j0 + tid < n) {
+            double v = 0;
+#pragma unroll
+            for (int r = 0; r < 16; r++) v = (r == tid) ? xs[r] : v;
+            x[j0 + tid] = v;
+        }
+        SGX_THREADS_END
+        SGX_SYNC();
+    }
+}
+
 // factor the diagonal tile (lower part of S overwritten with L_kk) and store Linv_kk (32x32, row-major, zero-padded) in Linv[k0/NB]
 SGX_KERNEL(256) k_chol_diag(int n, int k0, double *S, double *Linv, int *ok, const double *bp, const double *coef, double *x)
 {
