@@ -147,6 +147,11 @@ static int optimize(BA &B, int iterations, int *iters_done, double *final_chi)
                 for (int kb = 0; kb < nt; kb++) {
                     const int k0 = kb * SGX_NB, rem = nt - kb - 1;
                     const int in_panel = OT - 1 - kb % OT;           // column tiles right of this one that still belong to the outer panel
+#ifndef SGX_EMU
+                    static const int diag_lds = getenv("SGX_TUNE_CHOL_DIAG_LDS") ? atoi(getenv("SGX_TUNE_CHOL_DIAG_LDS")) : 0;      // 1 = the workgroup / LDS version (comparison tap)
+                    if (!diag_lds) SGX_LAUNCH(k_chol_diag_wave, dim3(1), dim3(64), (sgx_stream_t)0, B.NP, k0, B.S, B.Linv, B.ok, B.bp, B.coef, B.xp);
+                    else
+#endif
                     SGX_LAUNCH(k_chol_diag, dim3(1), dim3(t_diag), (sgx_stream_t)0, B.NP, k0, B.S, B.Linv, B.ok, B.bp, B.coef, B.xp);
                     if (rem > 0) {
                         SGX_LAUNCH(k_chol_panel, dim3(rem), dim3(256), (sgx_stream_t)0, B.NP, k0, B.S, B.Linv, B.ok, B.xp);

@@ -474,6 +474,84 @@ SGX_KERNEL(256) k_chol_diag(int n, int k0, double *S, double *Linv, int *ok, con
     SGX_THREADS_END
 }
 
+#ifndef SGX_EMU
+// ---------------------------------------------------------------------------------------------
+// k_chol_diag_wave: k_chol_diag as ONE wave with the tile in registers (device only; the emulator keeps the LDS version, same arithmetic).
+// Lane r < 32 holds row r of the tile (32 doubles) — the factorisation's column step j needs the pivot and u_cj = A[c][j] of every row c > j, which are
+// lane c's register j: a v_readlane with a compile-time lane (the j and c loops are fully unrolled), i.e. a scalar operand of the multiply-add, no LDS
+// and no barrier.  ~500 (readlane pair + FMA) triples for the factorisation and again for the explicit inverse (column t of L^-1 in lane t), against
+// 32 barrier-separated LDS read-modify-write phases in the workgroup version: 23 -> ~10 us per tile, which is the sequential spine of every blocked solve.
+// Same operations in the same order as k_chol_diag for L and L^-1 (bit-identical tiles); y_k comes from an in-lane forward substitution.
+// ---------------------------------------------------------------------------------------------
+static __device__ __forceinline__ double sgx_readlane_f64(double v, int lane)
+{ return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane)); }
+
+__global__ void __launch_bounds__(64) k_chol_diag_wave(int n, int k0, double *S, double *Linv, int *ok, const double *bp, const double *coef, double *x)
+{
+    const int lane = (int)threadIdx.x, row = lane & 31;
+    const int nb = min(SGX_NB, n - k0);
+    if (k0 == 0) for (int i = lane; i < n; i += 64) x[i] = bp[i] - coef[i];          // right-hand side of the reduced system (first panel only)
+    double a[SGX_NB];
+    {
+        const double *src = S + (size_t)(k0 + min(row, nb - 1)) * n + k0;
+#pragma unroll
+        for (int c = 0; c < SGX_NB; c++) a[c] = (row < nb && c < nb) ? src[min(c, nb - 1)] : 0.0;
+    }
+    // ---- unscaled L D L^T: a[j] of lane i becomes u_ij = L_ij d_j
+#pragma unroll
+    for (int j = 0; j < SGX_NB; j++) {
+        if (j < nb) {
+            const double d = sgx_readlane_f64(a[j], j);
+            if (!(d > 0)) { if (lane == 0) *ok = 0; return; }
+            const double rd = 1.0 / d;
+            const double f = a[j] * rd;
+#pragma unroll
+            for (int c = j + 1; c < SGX_NB; c++) a[c] -= f * sgx_readlane_f64(a[j], c);
+        }
+    }
+    // ---- Cholesky factor: L_ij = u_ij / sqrt(d_j), L_jj = sqrt(d_j)
+    double dv = 1.0;                                     // lane j: d_j
+#pragma unroll
+    for (int j = 0; j < SGX_NB; j++) dv = (row == j && j < nb) ? a[j] : dv;
+    const double sdv = sqrt(dv), rsdv = 1.0 / sdv;
+#pragma unroll
+    for (int j = 0; j < SGX_NB; j++) {
+        const double sdj = sgx_readlane_f64(sdv, j), rj = sgx_readlane_f64(rsdv, j);
+        a[j] = (row == j) ? (j < nb ? sdj : 0.0) : sgx_div_by_recip(a[j], sdj, rj);
+    }
+    // ---- explicit inverse: lane t computes column t of L^-1 by forward substitution (same order as k_chol_diag)
+    double xc[SGX_NB];
+#pragma unroll
+    for (int r = 0; r < SGX_NB; r++) {
+        double sacc = (r == row) ? 1.0 : 0.0;
+#pragma unroll
+        for (int q = 0; q < r; q++) sacc -= sgx_readlane_f64(a[q], r) * xc[q];
+        xc[r] = (r < nb && row < nb) ? sacc * sgx_readlane_f64(rsdv, r) : 0.0;
+    }
+    // ---- y_k = L_kk^-1 x_k by forward substitution (lane r holds entry r); x_i -= L_ik y_k follows in k_chol_panel
+    double b = (row < nb) ? x[k0 + row] : 0.0;
+#pragma unroll
+    for (int q = 0; q < SGX_NB; q++) {
+        if (q < nb) {
+            const double yq = sgx_readlane_f64(b, q) * sgx_readlane_f64(rsdv, q);        // entry q has received every update from the entries before it
+            b = (row == q) ? yq : ((row > q) ? b - a[q] * yq : b);
+        }
+    }
+    if (lane < nb) x[k0 + lane] = b;
+    // ---- stores: the lower triangle of L_kk over S, L_kk^-1 (zero-padded 32 x 32, row-major) into its slot
+    if (lane < nb) {
+        double *dst = S + (size_t)(k0 + lane) * n + k0;
+#pragma unroll
+        for (int c = 0; c < SGX_NB; c++) if (c <= lane) dst[c] = a[c];
+    }
+    double *Lo = Linv + (size_t)(k0 / SGX_NB) * SGX_NB * SGX_NB;
+    if (lane < SGX_NB) {
+#pragma unroll
+        for (int r = 0; r < SGX_NB; r++) Lo[r * SGX_NB + lane] = xc[r];
+    }
+}
+#endif
+
 // C(NB x NB) = P * Q^T for two LDS tiles stored TRANSPOSED ([q][row], zero-padded): thread (ty, tx) of the 16 x 16 map owns the TB x TB block rows TB*ty.., cols TB*tx..;
 // per q it reads TB + TB contiguous doubles and issues TB*TB FMAs (1 LDS read per FMA at TB = 2, 0.5 at TB = 4, instead of 2 for the one-output-per-thread form).
 SGX_DEV void sgx_tile_gemm_nt(const double (*PT)[SGX_NB + 4], const double (*QT)[SGX_NB + 4], int ty, int tx, double acc[SGX_TB][SGX_TB])
