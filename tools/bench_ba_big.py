@@ -20,9 +20,13 @@ if os.environ.get('SGX_TOOL_EMU'):          # generator / plumbing check without
     lib = SgxLib(os.path.join(ROOT, 'tests', 'emu', 'libsgx_emu.so'))
 else:
     lib = sg_slam_amd.load()
+# two calls on the same input: the first one also pays for loading the code objects and growing the process-wide device arena (a LocalMapping thread pays
+# that once), the second is the steady state reported as `seconds`
+p1 = {k: (v.copy() if hasattr(v, 'copy') else v) for k, v in prob.items()}
+t = time.perf_counter(); Optimizer.LocalBundleAdjustment(p1, CAM, lib=lib); dt_first = time.perf_counter() - t
 t = time.perf_counter(); er, st = Optimizer.LocalBundleAdjustment(prob, CAM, lib=lib); dt = time.perf_counter() - t
 err_before = np.abs(poses0[:, :3, 3] - Ts[:, :3, 3]).max(); err_after = np.abs(prob['poses'].astype('f8')[:, :3, 3] - Ts[:, :3, 3]).max()
 its = int(sum(st['iterations']))
-print(json.dumps(dict(bench='bundle_adjustment_big', keyframes=NKF, landmarks=NPT, edges=int(ne), reduced_system=6 * (NKF - 1), lm_iterations=its, seconds=dt,
+print(json.dumps(dict(bench='bundle_adjustment_big', keyframes=NKF, landmarks=NPT, edges=int(ne), reduced_system=6 * (NKF - 1), lm_iterations=its, seconds=dt, seconds_first_call=dt_first,
                       edges_per_s=ne * its / dt, stats={k2: (list(map(float, v2)) if hasattr(v2, '__len__') else float(v2)) for k2, v2 in st.items()},
                       max_abs_translation_error_before=float(err_before), max_abs_translation_error_after=float(err_after))))
