@@ -325,15 +325,19 @@ static void launch_octree(sgx_orb *h, int batch, sgx_stream_t stream)
 {
     const SgxOrbGeom &g = h->g; const int nl = g.nlevels;
     static const int oct_threads = getenv("SGX_TUNE_OCT_THREADS") ? atoi(getenv("SGX_TUNE_OCT_THREADS")) : SGX_OCT_THREADS;   // env = tuning tap (64..SGX_OCT_THREADS)
+    // (levels, frames) dispatch order.  The (frames, levels) order — all level-0 workgroups first, small levels in the tail; tap below — runs the kernel itself
+    // 30 % faster at 256 frames (0.33 -> 0.22 ms) but the two-stream pipeline 1.5 % slower (A/B on one box: 112.5 k vs 114.1 k frames/s), so it is not the default
+    static const bool frame_fast = getenv("SGX_TUNE_OCT_FRAME_FAST") != nullptr;
+    const dim3 ogrid = frame_fast ? dim3(batch, nl) : dim3(nl, batch);
     if (h->oct_maxlim <= 256) {
         auto ka = k_octree<true, 256, 2048>; auto kb = k_octree<true, 256, SGX_CAND_LDS>; auto kc = k_octree<false, 256, 1>;
-        SGX_LAUNCH(ka, dim3(nl, batch), dim3(oct_threads), stream, g, h->d_cand, h->d_cand_count, h->d_node_scratch, h->d_sel, h->d_sel_count, h->d_status, -1);
-        SGX_LAUNCH(kb, dim3(nl, batch), dim3(oct_threads), stream, g, h->d_cand, h->d_cand_count, h->d_node_scratch, h->d_sel, h->d_sel_count, h->d_status, 2048);
-        SGX_LAUNCH(kc, dim3(nl, batch), dim3(oct_threads), stream, g, h->d_cand, h->d_cand_count, h->d_node_scratch, h->d_sel, h->d_sel_count, h->d_status, SGX_CAND_LDS);
+        SGX_LAUNCH(ka, ogrid, dim3(oct_threads), stream, g, h->d_cand, h->d_cand_count, h->d_node_scratch, h->d_sel, h->d_sel_count, h->d_status, -1);
+        SGX_LAUNCH(kb, ogrid, dim3(oct_threads), stream, g, h->d_cand, h->d_cand_count, h->d_node_scratch, h->d_sel, h->d_sel_count, h->d_status, 2048);
+        SGX_LAUNCH(kc, ogrid, dim3(oct_threads), stream, g, h->d_cand, h->d_cand_count, h->d_node_scratch, h->d_sel, h->d_sel_count, h->d_status, SGX_CAND_LDS);
     } else {
         auto kb = k_octree<true, SGX_OCT_MAXN, SGX_CAND_LDS>; auto kc = k_octree<false, SGX_OCT_MAXN, 1>;
-        SGX_LAUNCH(kb, dim3(nl, batch), dim3(oct_threads), stream, g, h->d_cand, h->d_cand_count, h->d_node_scratch, h->d_sel, h->d_sel_count, h->d_status, -1);
-        SGX_LAUNCH(kc, dim3(nl, batch), dim3(oct_threads), stream, g, h->d_cand, h->d_cand_count, h->d_node_scratch, h->d_sel, h->d_sel_count, h->d_status, SGX_CAND_LDS);
+        SGX_LAUNCH(kb, ogrid, dim3(oct_threads), stream, g, h->d_cand, h->d_cand_count, h->d_node_scratch, h->d_sel, h->d_sel_count, h->d_status, -1);
+        SGX_LAUNCH(kc, ogrid, dim3(oct_threads), stream, g, h->d_cand, h->d_cand_count, h->d_node_scratch, h->d_sel, h->d_sel_count, h->d_status, SGX_CAND_LDS);
     }
 }
 

@@ -477,7 +477,9 @@ SGX_KERNEL(512) k_octree(SgxOrbGeom g, const uint32_t *cand, const int *cand_cou
     SGX_LDS unsigned long long best[MAXN];
     SGX_LDS int s_size, s_C, s_kept, s_ntoexpand, s_stop, s_m, s_overflow;
 
-    const int level = (int)blockIdx.x, frame = (int)blockIdx.y;
+    // grid = (levels, frames) by default; (frames, levels) — level 0, the longest-running, dispatched first — is a tuning tap (sgx_orb.cpp)
+    const bool frames_fast = (int)gridDim.y == g.nlevels;            // the two grid shapes are told apart by their extent
+    const int frame = (int)(frames_fast ? blockIdx.x : blockIdx.y), level = (int)(frames_fast ? blockIdx.y : blockIdx.x);
     const SgxLevel L = g.lv[level];
     const int N = L.quota;
     int nk = cand_count[frame * g.nlevels + level];
