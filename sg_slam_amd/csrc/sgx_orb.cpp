@@ -233,7 +233,7 @@ extern "C" int sgx_orb_create(const sgx_orb_config *cfg, sgx_orb **out)
     SGX_ALLOC(h->d_sel, (size_t)B * nl * SGX_OCT_MAXN * 4);
     SGX_ALLOC(h->d_sel_count, (size_t)B * nl * 4);
     SGX_ALLOC(h->d_status, 4);
-    SGX_ALLOC(h->d_gray1, (size_t)g.W * g.H);
+    SGX_ALLOC(h->d_gray1, (size_t)((g.W + 3) & ~3) * g.H);             // staging copy of a host frame, rows padded to dwords (the kernels stage aligned dwords)
     SGX_ALLOC(h->d_kps1, (size_t)kp_cap * 28);
     SGX_ALLOC(h->d_desc1, (size_t)kp_cap * 32);
     SGX_ALLOC(h->d_count1, 4);
@@ -408,10 +408,11 @@ extern "C" int sgx_orb_last_status(sgx_orb *h, void *stream_)
 extern "C" int sgx_orb_extract(sgx_orb *h, const uint8_t *gray, int stride, sgx_keypoint *kps, uint8_t *desc, int cap, int *n)
 {
     if (!h || !gray || !kps || !desc || !n || stride < h->g.W || cap < 0) return SGX_ERR_INVALID;
-    const int W = h->g.W, H = h->g.H, kc = h->g.kp_cap;
-    for (int y = 0; y < H; y++)
-        SGX_CHECK_HIP(hipMemcpyAsync(h->d_gray1 + (size_t)y * W, gray + (size_t)y * stride, W, hipMemcpyHostToDevice, 0));
-    int rc = sgx_orb_extract_batch_dev(h, h->d_gray1, W, 1, (sgx_keypoint *)h->d_kps1, h->d_desc1, h->d_count1, kc, 0);
+    const int W = h->g.W, H = h->g.H, kc = h->g.kp_cap, P = (W + 3) & ~3;      // any image width (KITTI: 1241): the device copy is pitched to dwords
+    if (stride == P) SGX_CHECK_HIP(hipMemcpyAsync(h->d_gray1, gray, (size_t)P * (H - 1) + W, hipMemcpyHostToDevice, 0));
+    else for (int y = 0; y < H; y++)
+        SGX_CHECK_HIP(hipMemcpyAsync(h->d_gray1 + (size_t)y * P, gray + (size_t)y * stride, W, hipMemcpyHostToDevice, 0));
+    int rc = sgx_orb_extract_batch_dev(h, h->d_gray1, P, 1, (sgx_keypoint *)h->d_kps1, h->d_desc1, h->d_count1, kc, 0);
     if (rc != SGX_OK) return rc;
     int cnt = 0;
     SGX_CHECK_HIP(hipMemcpyAsync(&cnt, h->d_count1, 4, hipMemcpyDeviceToHost, 0));

@@ -152,3 +152,20 @@ def run_other_geometries(lib, oracle):
 
 def test_other_geometries_emu(emu, oracle):
     run_other_geometries(emu, oracle)
+
+
+def run_other_parameters(lib, oracle):
+    """the reference's other shipped settings and a few off-grid ones: KITTI.yaml (1241x376 — a width that is not a multiple of 4 — 2000 features), a coarser / finer
+    pyramid, other FAST thresholds; full extraction parity each"""
+    tex = synth.world_texture(7, 1400, 1100)
+    for (w, h, nf, sf, nl, ini, mn) in ((1241, 376, 2000, 1.2, 8, 20, 7), (800, 600, 3000, 1.3, 6, 30, 10), (640, 480, 1000, 1.1, 10, 12, 5)):
+        img = np.ascontiguousarray(tex[40:40 + h, 60:60 + w])
+        ko, do = oracle.orb_extract(img, nfeatures=nf, scale=sf, nlevels=nl, ini_th=ini, min_th=mn)
+        e = ORBextractor(lib=lib, nfeatures=nf, scaleFactor=sf, nlevels=nl, iniThFAST=ini, minThFAST=mn, width=w, height=h)
+        k, d = e(img)
+        e.close()
+        assert len(ko) > nf // 2 and _same(k, d, ko, do), (w, h, nf, sf, nl)
+
+
+def test_other_parameters_emu(emu, oracle):
+    run_other_parameters(emu, oracle)

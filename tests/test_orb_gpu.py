@@ -99,3 +99,8 @@ def test_fused_pyramid_equals_per_level_gpu(gpulib):
 def test_other_geometries_gpu(gpulib, oracle):
     from test_orb_emu import run_other_geometries
     run_other_geometries(gpulib, oracle)
+
+
+def test_other_parameters_gpu(gpulib, oracle):
+    from test_orb_emu import run_other_parameters
+    run_other_parameters(gpulib, oracle)
