@@ -66,7 +66,8 @@ int sgx_orb_keypoint_capacity(const sgx_orb *h);
 /* each array has nlevels entries; any pointer may be NULL */
 int sgx_orb_get_tables(const sgx_orb *h, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2,
                        int32_t *features_per_level);
-/* Batched, device-resident.  d_gray: batch frames, each height rows of `pitch` bytes.
+/* Batched, device-resident.  d_gray: batch frames, each height rows of `pitch` bytes; d_gray and pitch must be multiples of 4
+ * (the kernels stage aligned dwords; any image WIDTH is fine — sgx_orb_extract pads its staging copy itself), else SGX_ERR_INVALID.
  * d_kps: batch*cap keypoints, d_desc: batch*cap*32 bytes, d_count: batch int32.
  * Asynchronous on `stream`.  cap must be >= sgx_orb_keypoint_capacity(). */
 int sgx_orb_extract_batch_dev(sgx_orb *h, const uint8_t *d_gray, int pitch, int batch,
