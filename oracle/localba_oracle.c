@@ -44,6 +44,29 @@ static void bedge_error(bedge *e, const se3q *T, const double *X, const bcam *c)
 }
 static double bedge_chi2(const bedge *e) { const int D = e->stereo ? 3 : 2; double s = 0; for (int i = 0; i < D; i++) s += e->err[i] * (e->info * e->err[i]); return s; }
 
+/* linearizeOplus of Edge(Stereo)SE3ProjectXYZ: A = d err / d point (3x3), Bj = d err / d pose increment (3x6); rows of a monocular edge's third component are 0 */
+static void bedge_jacobians(int stereo, const se3q *T, const double *X, const bcam *cam, double A[3][3], double Bj[3][6])
+{
+    double p[3]; se3_map(T, X, p);
+    double R[3][3]; quat_to_R(T->q, R);
+    const double x = p[0], y = p[1], z = p[2], z_2 = z * z, fx = cam->fx, fy = cam->fy, bf = cam->bf;
+    if (stereo) {                                                    /* .cpp:188-234 */
+        for (int c = 0; c < 3; c++) {
+            A[0][c] = -fx * R[0][c] / z + fx * x * R[2][c] / z_2;
+            A[1][c] = -fy * R[1][c] / z + fy * y * R[2][c] / z_2;
+            A[2][c] = A[0][c] - bf * R[2][c] / z_2;
+        }
+    } else {                                                         /* .cpp:103-139: -1/z * tmp * R */
+        const double tmp[2][3] = { { fx, 0, -x / z * fx }, { 0, fy, -y / z * fy } };
+        for (int r = 0; r < 2; r++) for (int c = 0; c < 3; c++) { double s = 0; for (int q = 0; q < 3; q++) s += tmp[r][q] * R[q][c]; A[r][c] = -1. / z * s; }
+        for (int c = 0; c < 3; c++) A[2][c] = 0;
+    }
+    Bj[0][0] = x * y / z_2 * fx; Bj[0][1] = -(1 + (x * x / z_2)) * fx; Bj[0][2] = y / z * fx; Bj[0][3] = -1. / z * fx; Bj[0][4] = 0; Bj[0][5] = x / z_2 * fx;
+    Bj[1][0] = (1 + y * y / z_2) * fy; Bj[1][1] = -x * y / z_2 * fy; Bj[1][2] = -x / z * fy; Bj[1][3] = 0; Bj[1][4] = -1. / z * fy; Bj[1][5] = y / z_2 * fy;
+    if (stereo) { Bj[2][0] = Bj[0][0] - bf * y / z_2; Bj[2][1] = Bj[0][1] + bf * x / z_2; Bj[2][2] = Bj[0][2]; Bj[2][3] = Bj[0][3]; Bj[2][4] = 0; Bj[2][5] = Bj[0][5] - bf / z_2; }
+    else for (int c = 0; c < 6; c++) Bj[2][c] = 0;
+}
+
 /* dense LDL^T solve (n x n, row-major, symmetric); returns 0 when a pivot is not positive */
 static int dense_ldlt_solve(double *A, int n, const double *b, double *x)
 {
@@ -86,6 +109,111 @@ static double ba_active_chi2(ba_t *B, int recompute)
     return chi;
 }
 
+typedef struct { double *Hpp, *bp, *Hll, *bl, *Hpl, *S, *xp, *xl, *Dinv, *coef; uint8_t *pt_active; } ba_buf;
+
+/* buildSystem (block_solver.hpp:502-560) on the level-0 edges, at the current estimate and the errors last computed */
+static void ba_build(ba_t *B, ba_buf *W)
+{
+    const int nf = B->nfree, nl = B->nl, NP = 6 * nf;
+    double *Hpp = W->Hpp, *bp = W->bp, *Hll = W->Hll, *bl = W->bl, *Hpl = W->Hpl, *S = W->S, *xp = W->xp, *xl = W->xl, *Dinv = W->Dinv, *coef = W->coef;
+    const uint8_t *pt_active = W->pt_active;
+    (void)nf; (void)nl; (void)NP; (void)Hpp; (void)bp; (void)Hll; (void)bl; (void)Hpl; (void)S; (void)xp; (void)xl; (void)Dinv; (void)coef; (void)pt_active;
+    /* ---- buildSystem */
+    memset(Hpp, 0, sizeof(double) * (size_t)nf * 36); memset(bp, 0, sizeof(double) * NP);
+    memset(Hll, 0, sizeof(double) * (size_t)nl * 9); memset(bl, 0, sizeof(double) * (size_t)nl * 3);
+    for (int k = 0; k < B->ne; k++) {
+        bedge *e = &B->E[k]; double *hpl = Hpl + (size_t)k * 18; memset(hpl, 0, sizeof(double) * 18);
+        if (e->level != 0) continue;
+        const se3q *T = &B->T[e->pose]; const double *X = &B->X[3 * e->point];
+        double A[3][3], Bj[3][6];
+        bedge_jacobians(e->stereo, T, X, &B->cam, A, Bj);
+        const int D = e->stereo ? 3 : 2;
+        double rho1 = 1.0;
+        if (e->robust) { double r[3]; bhuber(bedge_chi2(e), e->stereo ? B->dStereo : B->dMono, r); rho1 = r[1]; }
+        const double w = rho1 * e->info;
+        double om_r[3]; for (int d = 0; d < 3; d++) om_r[d] = -(e->info * e->err[d]) * rho1;
+        double *hl = Hll + (size_t)e->point * 9, *bL = bl + (size_t)e->point * 3;
+        for (int a = 0; a < 3; a++) {
+            double s = 0; for (int d = 0; d < D; d++) s += A[d][a] * om_r[d]; bL[a] += s;
+            for (int c = 0; c < 3; c++) { double h = 0; for (int d = 0; d < D; d++) h += A[d][a] * w * A[d][c]; hl[3 * a + c] += h; }
+        }
+        const int hp = B->hidx[e->pose];
+        if (hp >= 0) {
+            double *hP = Hpp + (size_t)hp * 36, *bP = bp + 6 * hp;
+            for (int a = 0; a < 6; a++) {
+                double s = 0; for (int d = 0; d < D; d++) s += Bj[d][a] * om_r[d]; bP[a] += s;
+                for (int c = 0; c < 6; c++) { double h = 0; for (int d = 0; d < D; d++) h += Bj[d][a] * w * Bj[d][c]; hP[6 * a + c] += h; }
+                for (int c = 0; c < 3; c++) { double h = 0; for (int d = 0; d < D; d++) h += Bj[d][a] * w * A[d][c]; hpl[3 * a + c] = h; }
+            }
+        }
+    }
+}
+
+/* one linear solve of the damped normal equations through the Schur complement; returns 0 when the reduced system is not positive definite */
+static int ba_solve(ba_t *B, ba_buf *W, double lambda)
+{
+    const int nf = B->nfree, nl = B->nl, NP = 6 * nf;
+    double *Hpp = W->Hpp, *bp = W->bp, *Hll = W->Hll, *bl = W->bl, *Hpl = W->Hpl, *S = W->S, *xp = W->xp, *xl = W->xl, *Dinv = W->Dinv, *coef = W->coef;
+    const uint8_t *pt_active = W->pt_active;
+    (void)nf; (void)nl; (void)NP; (void)Hpp; (void)bp; (void)Hll; (void)bl; (void)Hpl; (void)S; (void)xp; (void)xl; (void)Dinv; (void)coef; (void)pt_active;
+    /* ---- solve with Schur complement (block_solver.hpp:367-486); lambda on both diagonals (:573-587) */
+    int ok2 = 1;
+    memset(S, 0, sizeof(double) * (size_t)NP * NP); memset(coef, 0, sizeof(double) * NP);
+    for (int i = 0; i < nf; i++) for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++)
+        S[(size_t)(6 * i + a) * NP + 6 * i + c] = Hpp[(size_t)i * 36 + 6 * a + c] + (a == c ? lambda : 0);
+    for (int l = 0; l < nl; l++) {
+        double *Di = Dinv + (size_t)l * 9;
+        if (!pt_active[l]) { memset(Di, 0, sizeof(double) * 9); continue; }
+        double M[9]; memcpy(M, Hll + (size_t)l * 9, sizeof M); M[0] += lambda; M[4] += lambda; M[8] += lambda;
+        const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
+        const double det = M[0] * c00 + M[1] * c01 + M[2] * c02, id = 1.0 / det;          /* Eigen Matrix3d::inverse(): cofactors / det */
+        Di[0] = c00 * id; Di[1] = (M[2] * M[7] - M[1] * M[8]) * id; Di[2] = (M[1] * M[5] - M[2] * M[4]) * id;
+        Di[3] = c01 * id; Di[4] = (M[0] * M[8] - M[2] * M[6]) * id; Di[5] = (M[2] * M[3] - M[0] * M[5]) * id;
+        Di[6] = c02 * id; Di[7] = (M[1] * M[6] - M[0] * M[7]) * id; Di[8] = (M[0] * M[4] - M[1] * M[3]) * id;
+    }
+    /* edges of one point are contiguous or not — handle generally with per-point edge lists */
+    {
+        int *head = (int *)malloc(sizeof(int) * (nl + 1)); int *lst = (int *)malloc(sizeof(int) * (B->ne > 0 ? B->ne : 1));
+        memset(head, 0, sizeof(int) * (nl + 1));
+        for (int k = 0; k < B->ne; k++) if (B->E[k].level == 0 && B->hidx[B->E[k].pose] >= 0) head[B->E[k].point + 1]++;
+        for (int l = 0; l < nl; l++) head[l + 1] += head[l];
+        int *fill = (int *)calloc(nl > 0 ? nl : 1, sizeof(int));
+        for (int k = 0; k < B->ne; k++) if (B->E[k].level == 0 && B->hidx[B->E[k].pose] >= 0) { const int l = B->E[k].point; lst[head[l] + fill[l]++] = k; }
+        for (int l = 0; l < nl; l++) {
+            const double *Di = Dinv + (size_t)l * 9;
+            double db[3]; for (int a = 0; a < 3; a++) db[a] = Di[3 * a] * bl[3 * l] + Di[3 * a + 1] * bl[3 * l + 1] + Di[3 * a + 2] * bl[3 * l + 2];
+            for (int q1 = head[l]; q1 < head[l + 1]; q1++) {
+                const int k1 = lst[q1], i1 = B->hidx[B->E[k1].pose]; const double *B1 = Hpl + (size_t)k1 * 18;
+                double BD[18];
+                for (int a = 0; a < 6; a++) for (int c = 0; c < 3; c++) BD[3 * a + c] = B1[3 * a] * Di[c] + B1[3 * a + 1] * Di[3 + c] + B1[3 * a + 2] * Di[6 + c];
+                for (int a = 0; a < 6; a++) coef[6 * i1 + a] += B1[3 * a] * db[0] + B1[3 * a + 1] * db[1] + B1[3 * a + 2] * db[2];
+                for (int q2 = head[l]; q2 < head[l + 1]; q2++) {
+                    const int k2 = lst[q2], i2 = B->hidx[B->E[k2].pose]; const double *B2 = Hpl + (size_t)k2 * 18;
+                    for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++)
+                        S[(size_t)(6 * i1 + a) * NP + 6 * i2 + c] -= BD[3 * a] * B2[3 * c] + BD[3 * a + 1] * B2[3 * c + 1] + BD[3 * a + 2] * B2[3 * c + 2];
+                }
+            }
+        }
+        free(head); free(lst); free(fill);
+    }
+    double *bs = (double *)malloc(sizeof(double) * (NP > 0 ? NP : 1));
+    for (int i = 0; i < NP; i++) bs[i] = bp[i] - coef[i];
+    if (NP > 0) ok2 = dense_ldlt_solve(S, NP, bs, xp);
+    free(bs);
+    if (ok2) {                                                       /* xl = Dinv (bl - Hpl^T xp) */
+        double *cl = (double *)malloc(sizeof(double) * (size_t)(nl > 0 ? nl : 1) * 3); memcpy(cl, bl, sizeof(double) * (size_t)nl * 3);
+        for (int k = 0; k < B->ne; k++) {
+            const bedge *e = &B->E[k]; const int hp = B->hidx[e->pose];
+            if (e->level != 0 || hp < 0) continue;
+            const double *Bk = Hpl + (size_t)k * 18;
+            for (int c = 0; c < 3; c++) { double s = 0; for (int a = 0; a < 6; a++) s += Bk[3 * a + c] * xp[6 * hp + a]; cl[3 * e->point + c] -= s; }
+        }
+        for (int l = 0; l < nl; l++) { const double *Di = Dinv + (size_t)l * 9; for (int a = 0; a < 3; a++) xl[3 * l + a] = Di[3 * a] * cl[3 * l] + Di[3 * a + 1] * cl[3 * l + 1] + Di[3 * a + 2] * cl[3 * l + 2]; }
+        free(cl);
+    }
+    return ok2;
+}
+
 /* one optimizer.optimize(iterations) call on the level-0 edges; trace rows: {chi2, lambda, trials} */
 static int ba_optimize(ba_t *B, int iterations, double *trace)
 {
@@ -100,56 +228,12 @@ static int ba_optimize(ba_t *B, int iterations, double *trace)
     double *xp = (double *)calloc(NP > 0 ? NP : 1, sizeof(double)), *xl = (double *)calloc((size_t)(nl > 0 ? nl : 1) * 3, sizeof(double));
     double *Dinv = (double *)malloc(sizeof(double) * (size_t)(nl > 0 ? nl : 1) * 9), *coef = (double *)malloc(sizeof(double) * (NP > 0 ? NP : 1));
     se3q *Tb = (se3q *)malloc(sizeof(se3q) * B->np); double *Xb = (double *)malloc(sizeof(double) * (size_t)(nl > 0 ? nl : 1) * 3);
+    ba_buf W = { Hpp, bp, Hll, bl, Hpl, S, xp, xl, Dinv, coef, pt_active };
     double lambda = -1, ni = 2; int nBadLM = 0, iters = 0;
     for (int it = 0; it < iterations; it++) {
         if (B->stop && *B->stop) break;                                   /* SparseOptimizer::terminate() */
         double currentChi = ba_active_chi2(B, 1), tempChi = currentChi; const double iniChi = currentChi;
-        /* ---- buildSystem */
-        memset(Hpp, 0, sizeof(double) * (size_t)nf * 36); memset(bp, 0, sizeof(double) * NP);
-        memset(Hll, 0, sizeof(double) * (size_t)nl * 9); memset(bl, 0, sizeof(double) * (size_t)nl * 3);
-        for (int k = 0; k < B->ne; k++) {
-            bedge *e = &B->E[k]; double *hpl = Hpl + (size_t)k * 18; memset(hpl, 0, sizeof(double) * 18);
-            if (e->level != 0) continue;
-            const se3q *T = &B->T[e->pose]; const double *X = &B->X[3 * e->point];
-            double p[3]; se3_map(T, X, p);
-            double R[3][3]; quat_to_R(T->q, R);
-            const double x = p[0], y = p[1], z = p[2], z_2 = z * z, fx = B->cam.fx, fy = B->cam.fy, bf = B->cam.bf;
-            double A[3][3], Bj[3][6];
-            if (e->stereo) {                                                 /* .cpp:188-234 */
-                for (int c = 0; c < 3; c++) {
-                    A[0][c] = -fx * R[0][c] / z + fx * x * R[2][c] / z_2;
-                    A[1][c] = -fy * R[1][c] / z + fy * y * R[2][c] / z_2;
-                    A[2][c] = A[0][c] - bf * R[2][c] / z_2;
-                }
-            } else {                                                          /* .cpp:103-139: -1/z * tmp * R */
-                const double tmp[2][3] = { { fx, 0, -x / z * fx }, { 0, fy, -y / z * fy } };
-                for (int r = 0; r < 2; r++) for (int c = 0; c < 3; c++) { double s = 0; for (int q = 0; q < 3; q++) s += tmp[r][q] * R[q][c]; A[r][c] = -1. / z * s; }
-                for (int c = 0; c < 3; c++) A[2][c] = 0;
-            }
-            Bj[0][0] = x * y / z_2 * fx; Bj[0][1] = -(1 + (x * x / z_2)) * fx; Bj[0][2] = y / z * fx; Bj[0][3] = -1. / z * fx; Bj[0][4] = 0; Bj[0][5] = x / z_2 * fx;
-            Bj[1][0] = (1 + y * y / z_2) * fy; Bj[1][1] = -x * y / z_2 * fy; Bj[1][2] = -x / z * fy; Bj[1][3] = 0; Bj[1][4] = -1. / z * fy; Bj[1][5] = y / z_2 * fy;
-            if (e->stereo) { Bj[2][0] = Bj[0][0] - bf * y / z_2; Bj[2][1] = Bj[0][1] + bf * x / z_2; Bj[2][2] = Bj[0][2]; Bj[2][3] = Bj[0][3]; Bj[2][4] = 0; Bj[2][5] = Bj[0][5] - bf / z_2; }
-            else for (int c = 0; c < 6; c++) Bj[2][c] = 0;
-            const int D = e->stereo ? 3 : 2;
-            double rho1 = 1.0;
-            if (e->robust) { double r[3]; bhuber(bedge_chi2(e), e->stereo ? B->dStereo : B->dMono, r); rho1 = r[1]; }
-            const double w = rho1 * e->info;
-            double om_r[3]; for (int d = 0; d < 3; d++) om_r[d] = -(e->info * e->err[d]) * rho1;
-            double *hl = Hll + (size_t)e->point * 9, *bL = bl + (size_t)e->point * 3;
-            for (int a = 0; a < 3; a++) {
-                double s = 0; for (int d = 0; d < D; d++) s += A[d][a] * om_r[d]; bL[a] += s;
-                for (int c = 0; c < 3; c++) { double h = 0; for (int d = 0; d < D; d++) h += A[d][a] * w * A[d][c]; hl[3 * a + c] += h; }
-            }
-            const int hp = B->hidx[e->pose];
-            if (hp >= 0) {
-                double *hP = Hpp + (size_t)hp * 36, *bP = bp + 6 * hp;
-                for (int a = 0; a < 6; a++) {
-                    double s = 0; for (int d = 0; d < D; d++) s += Bj[d][a] * om_r[d]; bP[a] += s;
-                    for (int c = 0; c < 6; c++) { double h = 0; for (int d = 0; d < D; d++) h += Bj[d][a] * w * Bj[d][c]; hP[6 * a + c] += h; }
-                    for (int c = 0; c < 3; c++) { double h = 0; for (int d = 0; d < D; d++) h += Bj[d][a] * w * A[d][c]; hpl[3 * a + c] = h; }
-                }
-            }
-        }
+        ba_build(B, &W);
         if (it == 0) {                                                       /* computeLambdaInit over all active vertices */
             double maxd = 0;
             for (int i = 0; i < nf; i++) for (int j = 0; j < 6; j++) { const double v = fabs(Hpp[(size_t)i * 36 + 7 * j]); if (v > maxd) maxd = v; }
@@ -159,61 +243,7 @@ static int ba_optimize(ba_t *B, int iterations, double *trace)
         double rho = 0; int qmax = 0;
         do {
             memcpy(Tb, B->T, sizeof(se3q) * B->np); memcpy(Xb, B->X, sizeof(double) * (size_t)nl * 3);      /* push */
-            /* ---- solve with Schur complement (block_solver.hpp:367-486); lambda on both diagonals (:573-587) */
-            int ok2 = 1;
-            memset(S, 0, sizeof(double) * (size_t)NP * NP); memset(coef, 0, sizeof(double) * NP);
-            for (int i = 0; i < nf; i++) for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++)
-                S[(size_t)(6 * i + a) * NP + 6 * i + c] = Hpp[(size_t)i * 36 + 6 * a + c] + (a == c ? lambda : 0);
-            for (int l = 0; l < nl; l++) {
-                double *Di = Dinv + (size_t)l * 9;
-                if (!pt_active[l]) { memset(Di, 0, sizeof(double) * 9); continue; }
-                double M[9]; memcpy(M, Hll + (size_t)l * 9, sizeof M); M[0] += lambda; M[4] += lambda; M[8] += lambda;
-                const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
-                const double det = M[0] * c00 + M[1] * c01 + M[2] * c02, id = 1.0 / det;          /* Eigen Matrix3d::inverse(): cofactors / det */
-                Di[0] = c00 * id; Di[1] = (M[2] * M[7] - M[1] * M[8]) * id; Di[2] = (M[1] * M[5] - M[2] * M[4]) * id;
-                Di[3] = c01 * id; Di[4] = (M[0] * M[8] - M[2] * M[6]) * id; Di[5] = (M[2] * M[3] - M[0] * M[5]) * id;
-                Di[6] = c02 * id; Di[7] = (M[1] * M[6] - M[0] * M[7]) * id; Di[8] = (M[0] * M[4] - M[1] * M[3]) * id;
-            }
-            /* edges of one point are contiguous or not — handle generally with per-point edge lists */
-            {
-                int *head = (int *)malloc(sizeof(int) * (nl + 1)); int *lst = (int *)malloc(sizeof(int) * (B->ne > 0 ? B->ne : 1));
-                memset(head, 0, sizeof(int) * (nl + 1));
-                for (int k = 0; k < B->ne; k++) if (B->E[k].level == 0 && B->hidx[B->E[k].pose] >= 0) head[B->E[k].point + 1]++;
-                for (int l = 0; l < nl; l++) head[l + 1] += head[l];
-                int *fill = (int *)calloc(nl > 0 ? nl : 1, sizeof(int));
-                for (int k = 0; k < B->ne; k++) if (B->E[k].level == 0 && B->hidx[B->E[k].pose] >= 0) { const int l = B->E[k].point; lst[head[l] + fill[l]++] = k; }
-                for (int l = 0; l < nl; l++) {
-                    const double *Di = Dinv + (size_t)l * 9;
-                    double db[3]; for (int a = 0; a < 3; a++) db[a] = Di[3 * a] * bl[3 * l] + Di[3 * a + 1] * bl[3 * l + 1] + Di[3 * a + 2] * bl[3 * l + 2];
-                    for (int q1 = head[l]; q1 < head[l + 1]; q1++) {
-                        const int k1 = lst[q1], i1 = B->hidx[B->E[k1].pose]; const double *B1 = Hpl + (size_t)k1 * 18;
-                        double BD[18];
-                        for (int a = 0; a < 6; a++) for (int c = 0; c < 3; c++) BD[3 * a + c] = B1[3 * a] * Di[c] + B1[3 * a + 1] * Di[3 + c] + B1[3 * a + 2] * Di[6 + c];
-                        for (int a = 0; a < 6; a++) coef[6 * i1 + a] += B1[3 * a] * db[0] + B1[3 * a + 1] * db[1] + B1[3 * a + 2] * db[2];
-                        for (int q2 = head[l]; q2 < head[l + 1]; q2++) {
-                            const int k2 = lst[q2], i2 = B->hidx[B->E[k2].pose]; const double *B2 = Hpl + (size_t)k2 * 18;
-                            for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++)
-                                S[(size_t)(6 * i1 + a) * NP + 6 * i2 + c] -= BD[3 * a] * B2[3 * c] + BD[3 * a + 1] * B2[3 * c + 1] + BD[3 * a + 2] * B2[3 * c + 2];
-                        }
-                    }
-                }
-                free(head); free(lst); free(fill);
-            }
-            double *bs = (double *)malloc(sizeof(double) * (NP > 0 ? NP : 1));
-            for (int i = 0; i < NP; i++) bs[i] = bp[i] - coef[i];
-            if (NP > 0) ok2 = dense_ldlt_solve(S, NP, bs, xp);
-            free(bs);
-            if (ok2) {                                                       /* xl = Dinv (bl - Hpl^T xp) */
-                double *cl = (double *)malloc(sizeof(double) * (size_t)(nl > 0 ? nl : 1) * 3); memcpy(cl, bl, sizeof(double) * (size_t)nl * 3);
-                for (int k = 0; k < B->ne; k++) {
-                    const bedge *e = &B->E[k]; const int hp = B->hidx[e->pose];
-                    if (e->level != 0 || hp < 0) continue;
-                    const double *Bk = Hpl + (size_t)k * 18;
-                    for (int c = 0; c < 3; c++) { double s = 0; for (int a = 0; a < 6; a++) s += Bk[3 * a + c] * xp[6 * hp + a]; cl[3 * e->point + c] -= s; }
-                }
-                for (int l = 0; l < nl; l++) { const double *Di = Dinv + (size_t)l * 9; for (int a = 0; a < 3; a++) xl[3 * l + a] = Di[3 * a] * cl[3 * l] + Di[3 * a + 1] * cl[3 * l + 1] + Di[3 * a + 2] * cl[3 * l + 2]; }
-                free(cl);
-            }
+            const int ok2 = ba_solve(B, &W, lambda);
             /* ---- update (oplus); g2o applies _x even when the solve failed — _x then holds the previous solution */
             for (int i = 0; i < B->np; i++) { const int hp = B->hidx[i]; if (hp < 0) continue; se3q ex, up; se3_exp(xp + 6 * hp, &ex); se3_mul(&ex, &B->T[i], &up); B->T[i] = up; }
             for (int l = 0; l < nl; l++) if (pt_active[l]) for (int a = 0; a < 3; a++) B->X[3 * l + a] += xl[3 * l + a];
@@ -240,10 +270,10 @@ static int ba_optimize(ba_t *B, int iterations, double *trace)
     return iters;
 }
 
-int orc_local_ba(int np, float *poses, const uint8_t *pose_fixed, int nl, float *points,
-                 int ne, const int *e_pose, const int *e_point, const float *e_obs, const float *e_info,
-                 float fx, float fy, float cx, float cy, float bf, const int *stop_flag,
-                 uint8_t *e_erase, double *trace /* 15*3 or NULL */, int *iters_out /* 2 or NULL */)
+/* flattened problem -> internal state (vertices in fp64, every edge active with the Huber kernel on) */
+static void ba_setup(ba_t *Bp, int np, const float *poses, const uint8_t *pose_fixed, int nl, const float *points,
+                     int ne, const int *e_pose, const int *e_point, const float *e_obs, const float *e_info,
+                     float fx, float fy, float cx, float cy, float bf, const int *stop_flag)
 {
     ba_t B; memset(&B, 0, sizeof B);
     B.np = np; B.nl = nl; B.ne = ne; B.cam.fx = fx; B.cam.fy = fy; B.cam.cx = cx; B.cam.cy = cy; B.cam.bf = bf;
@@ -256,6 +286,16 @@ int orc_local_ba(int np, float *poses, const uint8_t *pose_fixed, int nl, float 
         bedge *e = &B.E[k]; e->pose = e_pose[k]; e->point = e_point[k]; e->stereo = !(e_obs[3 * k + 2] < 0); e->level = 0; e->robust = 1;
         e->obs[0] = e_obs[3 * k]; e->obs[1] = e_obs[3 * k + 1]; e->obs[2] = e->stereo ? e_obs[3 * k + 2] : 0; e->info = e_info[k];
     }
+    *Bp = B;
+}
+
+int orc_local_ba(int np, float *poses, const uint8_t *pose_fixed, int nl, float *points,
+                 int ne, const int *e_pose, const int *e_point, const float *e_obs, const float *e_info,
+                 float fx, float fy, float cx, float cy, float bf, const int *stop_flag,
+                 uint8_t *e_erase, double *trace /* 15*3 or NULL */, int *iters_out /* 2 or NULL */)
+{
+    ba_t B;
+    ba_setup(&B, np, poses, pose_fixed, nl, points, ne, e_pose, e_point, e_obs, e_info, fx, fy, cx, cy, bf, stop_flag);
     memset(e_erase, 0, ne);
     if (stop_flag && *stop_flag) goto done;                                   /* Optimizer.cc:655-657 */
     { const int it1 = ba_optimize(&B, 5, trace); if (iters_out) iters_out[0] = it1; }
@@ -278,4 +318,43 @@ int orc_local_ba(int np, float *poses, const uint8_t *pose_fixed, int nl, float 
 done:
     free(B.T); free(B.X); free(B.hidx); free(B.E);
     return 0;
+}
+
+/* ---- known-answer taps (tests/test_oracle_kat.py): the pieces above exposed one at a time, so that the tests can pin them against independent
+ * arithmetic (central differences for the Jacobians, a dense solve of the full normal equations for the Schur path) ---- */
+int orc_kat_ba_edge(const float *Tcw, const double *X, const double *obs, int stereo, double fx, double fy, double cx, double cy, double bf,
+                    const double *dpose, const double *dpoint, double *err, double *Jpose, double *Jpoint)
+{
+    se3q T, ex, Tp; se3_from_cv(Tcw, &T); se3_exp(dpose, &ex); se3_mul(&ex, &T, &Tp);             /* VertexSE3Expmap::oplusImpl */
+    const double Xp[3] = { X[0] + dpoint[0], X[1] + dpoint[1], X[2] + dpoint[2] };                 /* VertexSBAPointXYZ::oplusImpl */
+    bcam cam = { fx, fy, cx, cy, bf };
+    bedge e; memset(&e, 0, sizeof e); e.stereo = stereo; e.obs[0] = obs[0]; e.obs[1] = obs[1]; e.obs[2] = obs[2]; e.info = 1;
+    bedge_error(&e, &Tp, Xp, &cam);
+    double A[3][3], Bj[3][6]; bedge_jacobians(stereo, &Tp, Xp, &cam, A, Bj);
+    for (int d = 0; d < 3; d++) { err[d] = e.err[d]; for (int c = 0; c < 3; c++) Jpoint[3 * d + c] = A[d][c]; for (int c = 0; c < 6; c++) Jpose[6 * d + c] = Bj[d][c]; }
+    return 0;
+}
+
+int orc_kat_ba_step(int np, const float *poses, const uint8_t *pose_fixed, int nl, const float *points,
+                    int ne, const int *e_pose, const int *e_point, const float *e_obs, const float *e_info,
+                    float fx, float fy, float cx, float cy, float bf, double lambda, int robust,
+                    double *Hpp, double *bp, double *Hll, double *bl, double *Hpl, double *xp, double *xl, int *hidx_out)
+{
+    ba_t B;
+    ba_setup(&B, np, poses, pose_fixed, nl, points, ne, e_pose, e_point, e_obs, e_info, fx, fy, cx, cy, bf, NULL);
+    for (int k = 0; k < ne; k++) B.E[k].robust = robust;
+    const int nf = B.nfree, NP = 6 * nf;
+    ba_buf W; memset(&W, 0, sizeof W);
+    W.pt_active = (uint8_t *)calloc(nl > 0 ? nl : 1, 1);
+    for (int k = 0; k < ne; k++) W.pt_active[B.E[k].point] = 1;
+    W.Hpp = Hpp; W.bp = bp; W.Hll = Hll; W.bl = bl; W.Hpl = Hpl; W.xp = xp; W.xl = xl;
+    W.S = (double *)malloc(sizeof(double) * (size_t)(NP > 0 ? NP : 1) * (NP > 0 ? NP : 1));
+    W.Dinv = (double *)malloc(sizeof(double) * (size_t)(nl > 0 ? nl : 1) * 9); W.coef = (double *)malloc(sizeof(double) * (NP > 0 ? NP : 1));
+    (void)ba_active_chi2(&B, 1);                                              /* computeActiveErrors */
+    ba_build(&B, &W);
+    const int ok = ba_solve(&B, &W, lambda);
+    for (int i = 0; i < np; i++) hidx_out[i] = B.hidx[i];
+    free(W.pt_active); free(W.S); free(W.Dinv); free(W.coef);
+    free(B.T); free(B.X); free(B.hidx); free(B.E);
+    return ok;
 }

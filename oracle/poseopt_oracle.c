@@ -53,6 +53,21 @@ static void huber(double e, double delta, double rho[3])
     else { const double sq = sqrt(e); rho[0] = 2 * sq * delta - dsqr; rho[1] = delta / sq; rho[2] = -0.5 * rho[1] / e; }
 }
 
+/* linearizeOplus of Edge(Stereo)SE3ProjectXYZOnlyPose, types_six_dof_expmap.cpp:266-288, 335-364 (a mono edge has no third row: left untouched) */
+static void pedge_jacobian(int stereo, const se3q *T, const double *Xw, const pcam *cam, double J[3][6])
+{
+    double p[3]; se3_map(T, Xw, p);
+    const double x = p[0], y = p[1], invz = 1.0 / p[2], invz_2 = invz * invz;
+    J[0][0] = x * y * invz_2 * cam->fx; J[0][1] = -(1 + (x * x * invz_2)) * cam->fx; J[0][2] = y * invz * cam->fx;
+    J[0][3] = -invz * cam->fx; J[0][4] = 0; J[0][5] = x * invz_2 * cam->fx;
+    J[1][0] = (1 + y * y * invz_2) * cam->fy; J[1][1] = -x * y * invz_2 * cam->fy; J[1][2] = -x * invz * cam->fy;
+    J[1][3] = 0; J[1][4] = -invz * cam->fy; J[1][5] = y * invz_2 * cam->fy;
+    if (stereo) {
+        J[2][0] = J[0][0] - cam->bf * y * invz_2; J[2][1] = J[0][1] + cam->bf * x * invz_2; J[2][2] = J[0][2];
+        J[2][3] = J[0][3]; J[2][4] = 0; J[2][5] = J[0][5] - cam->bf * invz_2;
+    }
+}
+
 /* Eigen::LDLT-style factorisation with diagonal pivoting of a 6x6; returns 0 when "not positive" */
 static int ldlt6_solve(const double Hin[6][6], const double b[6], double x[6])
 {
@@ -134,18 +149,9 @@ int orc_pose_optimization(int N, const orc_keypoint *keys, const float *uright, 
             memset(H, 0, sizeof H); memset(b, 0, sizeof b);
             for (int k = 0; k < ne; k++) {
                 pedge *e = &E[k]; if (e->level != 0) continue;
-                double p[3]; se3_map(&est, e->Xw, p);
-                const double x = p[0], y = p[1], invz = 1.0 / p[2], invz_2 = invz * invz;
                 double J[3][6];
-                J[0][0] = x * y * invz_2 * cam.fx; J[0][1] = -(1 + (x * x * invz_2)) * cam.fx; J[0][2] = y * invz * cam.fx;
-                J[0][3] = -invz * cam.fx; J[0][4] = 0; J[0][5] = x * invz_2 * cam.fx;
-                J[1][0] = (1 + y * y * invz_2) * cam.fy; J[1][1] = -x * y * invz_2 * cam.fy; J[1][2] = -x * invz * cam.fy;
-                J[1][3] = 0; J[1][4] = -invz * cam.fy; J[1][5] = y * invz_2 * cam.fy;
+                pedge_jacobian(e->stereo, &est, e->Xw, &cam, J);
                 const int D = e->stereo ? 3 : 2;
-                if (e->stereo) {
-                    J[2][0] = J[0][0] - cam.bf * y * invz_2; J[2][1] = J[0][1] + cam.bf * x * invz_2; J[2][2] = J[0][2];
-                    J[2][3] = J[0][3]; J[2][4] = 0; J[2][5] = J[0][5] - cam.bf * invz_2;
-                }
                 double rho1 = 1.0;
                 if (e->robust) { double rho[3]; huber(edge_chi2(e), e->stereo ? deltaStereo : deltaMono, rho); rho1 = rho[1]; }
                 const double w = rho1 * e->info;               /* weightedOmega = rho[1]*information */
@@ -211,4 +217,19 @@ int orc_pose_optimization(int N, const orc_keypoint *keys, const float *uright, 
     se3_to_cv(&est, Tcw);
     free(E);
     return nInitial - nBad;
+}
+
+/* ---- known-answer tap (tests/test_oracle_kat.py): error and analytic Jacobian of one pose-only edge at exp(delta) * Tcw ---- */
+int orc_kat_pose_edge(const float *Tcw, const double *Xw, const double *obs, int stereo, double fx, double fy, double cx, double cy, double bf,
+                      const double *delta, double *err, double *Jout)
+{
+    se3q T, ex, Tp; se3_from_cv(Tcw, &T); se3_exp(delta, &ex); se3_mul(&ex, &T, &Tp);
+    pcam cam = { fx, fy, cx, cy, bf };
+    pedge e; memset(&e, 0, sizeof e); e.stereo = stereo; e.info = 1;
+    for (int d = 0; d < 3; d++) { e.obs[d] = obs[d]; e.Xw[d] = Xw[d]; }
+    edge_error(&e, &Tp, &cam);
+    double J[3][6]; memset(J, 0, sizeof J);
+    pedge_jacobian(stereo, &Tp, e.Xw, &cam, J);
+    for (int d = 0; d < 3; d++) { err[d] = e.err[d]; for (int c = 0; c < 6; c++) Jout[6 * d + c] = J[d][c]; }
+    return 0;
 }
