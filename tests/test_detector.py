@@ -147,3 +147,35 @@ def run_compact(lib, to_dev=lambda a: a, to_host=lambda a: a):
 
 def test_compact_emu(emu):
     run_compact(emu)
+
+
+def test_oracle_convolutions_match_torch(model):
+    """pins the ORACLE's convolution semantics (padding, stride, depthwise grouping, ncnn weight order [outc][inc/group][kh][kw]) to an independent
+    implementation: the whole shipped graph is run twice in float64, once with the oracle's numpy convolution and once with torch.nn.functional.conv2d
+    substituted for it; every convolution output must agree to 1e-6 relative (float64 summation-order differences, amplified through ~100 gated layers, reach
+    3e-8 at the deepest blobs; a wrong stride / pad / weight order is off by O(1))."""
+    import torch
+    import torch.nn.functional as F
+    layers, W, _ = model
+    x = D.preprocess(make_image(4))
+    _, ref = D.forward(layers, W, x, dt=np.float64)
+
+    def conv_torch(x, w, b, outc, k, stride, pad, group, dt=np.float64):
+        inc = x.shape[0]
+        wt = torch.from_numpy(np.ascontiguousarray(w, np.float64).reshape(outc, inc // group, k, k))
+        y = F.conv2d(torch.from_numpy(np.ascontiguousarray(x, np.float64))[None], wt, torch.from_numpy(np.ascontiguousarray(b, np.float64)), stride=stride, padding=pad, groups=group)
+        return y[0].numpy().astype(dt)
+
+    orig = D.conv2d
+    D.conv2d = conv_torch
+    try:
+        _, alt = D.forward(layers, W, x, dt=np.float64)
+    finally:
+        D.conv2d = orig
+    nconv = 0
+    for L in layers:
+        if L['type'] in ('Convolution', 'ConvolutionDepthWise'):
+            a, b = ref[L['outs'][0]], alt[L['outs'][0]]
+            assert a.shape == b.shape and rel_err(b, a) <= 1e-6, L['name']
+            nconv += 1
+    assert nconv > 90 and np.allclose(ref['detection_out'], alt['detection_out'], rtol=1e-5, atol=1e-8)
