@@ -242,10 +242,8 @@ SGX_KERNEL(256) k_chol_small(int n, const double *S, const double *bp, const dou
     constexpr int LD = SGX_CHOL_SMALL + 1;
     SGX_LDS double A[SGX_CHOL_SMALL * LD];
     SGX_LDS double v[SGX_CHOL_SMALL];
-    SGX_LDS int s_ok;
     const int NT = (int)blockDim.x;
     SGX_THREADS_BEGIN(tid)
-    if (tid == 0) s_ok = 1;
     for (int r = tid >> 4; r < n; r += NT >> 4)
         for (int c = tid & 15; c < n; c += 16) A[r * LD + c] = S[(size_t)r * n + c];
     for (int i = tid; i < n; i += NT) v[i] = bp[i] - coef[i];
@@ -267,7 +265,7 @@ SGX_KERNEL(256) k_chol_small(int n, const double *S, const double *bp, const dou
         SGX_SYNC();
     }
     if (jfail < n) {
-        SGX_THREADS_BEGIN(tid) if (tid == 0) { s_ok = 0; *ok = 0; } SGX_THREADS_END
+        SGX_THREADS_BEGIN(tid) if (tid == 0) *ok = 0; SGX_THREADS_END
         return;
     }
     for (int j = n - 1; j >= 0; j--) {
