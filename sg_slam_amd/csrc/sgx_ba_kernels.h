@@ -287,6 +287,8 @@ SGX_KERNEL(256) k_chol_small(int n, const double *S, const double *bp, const dou
 // statements in total instead of 64 per column.  The LDS-resident version (k_chol_small) spends ~1.8 us per column on dependent LDS read-modify-writes;
 // LmT doubles as the factor for the back substitution, done 16 unknowns at a time: every thread solves the 16 x 16 triangle redundantly in registers
 // (no barriers inside), then threads 0..j0-1 push the block into their pending right-hand sides — 8 barriers instead of 128.
+// (Measured and dropped: two columns per barrier, every thread correcting the second published column itself — 3.30 vs 3.05 ms per LocalBA of 20 + 40
+// keyframes: the barrier is not what a column step waits for, the extra reads and corrections cost more than it saves.)
 // ---------------------------------------------------------------------------------------------
 SGX_KERNEL(256) k_chol_small_reg(int n, const double *S, const double *bp, const double *coef, double *x, int *ok)
 {
