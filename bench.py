@@ -64,8 +64,9 @@ def main():
     ap.add_argument('--no-local-map', action='store_true', help='skip the TrackLocalMap stage (local-map SearchByProjection + second PoseOptimization)')
     ap.add_argument('--groups', type=int, default=1, help='split the streams of this GPU into G independently pipelined groups (own extraction / tracking HIP streams each): '
                     'the drain of one group between kernels overlaps the body of another')
-    ap.add_argument('--detector', action='store_true', help='also run the detector forward (MobileNetV3-SSDLite, synthetic weights) on every frame, on a third HIP stream; '
-                    'its host-side DetectionOutput post-processing is not included and the mask keeps using the synthetic person box')
+    ap.add_argument('--detector', action='store_true', help='also run Detector2D::detect (MobileNetV3-SSDLite forward + DetectionOutput + filtering, all on the device; synthetic weights) on '
+                    'every frame, on a third HIP stream; its boxes land in device arrays of the mask stage\'s layout, but the mask keeps using the synthetic person box '
+                    '(random-weight detections would erase random features)')
     ap.add_argument('--no-mask', action='store_true', help='skip the dynamic-feature mask + erase stage (Frame::RmDynamicPointWithSemanticAndGeometry)')
     ap.add_argument('--cpu-sample', type=int, default=400, help='frames timed on the CPU oracle')
     args = ap.parse_args()
@@ -163,9 +164,11 @@ def main():
         det = Detector2D(0.9, 0.01, param_text=open(param).read(), bin_bytes=blob, max_batch=S, lib=lib)
         d_bgr = d_frames.unsqueeze(-1).expand(T, S, 480, 640, 3).contiguous()          # gray replicated to 3 channels (SURVEY §8(d) input 2)
         sD = torch.cuda.Stream(); sD.wait_stream(torch.cuda.current_stream())
-        dl_, dc_ = C_.c_void_p(), C_.c_void_p()
+        from sg_slam_amd.capi import DetResult as DetResult_
+        d_det_res = torch.zeros((S, C_.sizeof(DetResult_)), dtype=torch.uint8, device='cuda')
+        d_det_boxes = torch.zeros((S, 4, 4), dtype=torch.float32, device='cuda'); d_det_nb = torch.zeros(S, dtype=torch.int32, device='cuda'); d_det_have = torch.zeros(S, dtype=torch.int32, device='cuda')
         def det_step(i):
-            lib.check(lib.dll.sgx_det_forward_batch_dev(det.h, _vp_(d_bgr[order[i % len(order)]]), 640 * 3, S, C_.byref(dl_), C_.byref(dc_), C_.c_void_p(sD.cuda_stream)), 'detector forward')
+            det.detect_batch_dev(d_bgr[order[i % len(order)]], 640 * 3, S, d_det_res, d_det_boxes, d_det_nb, 4, d_det_have, stream=sD.cuda_stream)
 
     def step(i):
         if det is not None: det_step(i)
@@ -287,7 +290,7 @@ def main():
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
         'config': {'workload': 'Single MI355X: ORB extract+match HIP kernels, 640x480 synthetic stream, 1000 feats/frame',
-                   'detector_forward_concurrent': bool(args.detector), 'stream_groups': len(tr.trs),
+                   'detector_detect_concurrent': bool(args.detector), 'stream_groups': len(tr.trs),
                    'stages': ['orb_extract'] + ([] if args.no_mask else ['dynamic_mask+erase (LK/F inputs from synthetic ground truth)']) + ['stereo_from_rgbd', 'motion_model', 'search_by_projection(cur,last)', 'pose_optimization'] +
                              ([] if args.no_local_map else ['search_by_projection(cur,local_map th=3)', 'pose_optimization#2']) + ['unproject'] +
                              ([] if args.no_local_map else ['make_map_points']),

@@ -235,9 +235,17 @@ void sgx_det_destroy(sgx_det *h);
 int sgx_det_info(const sgx_det *h, int32_t *num_priors, int32_t *num_class, int32_t *num_kernels, double *gmac);
 /* Detector2D::detect(const cv::Mat &bgr) for `batch` host images (interleaved 3-channel u8, row pitch in bytes); synchronous */
 int sgx_det_detect(sgx_det *h, const uint8_t *images, int pitch, int batch, sgx_det_result *results);
+/* Detector2D::detect, device-resident and asynchronous on `stream`: forward + ncnn DetectionOutput (decode, per-class NMS, keep_top_k) + detect()'s
+ * filtering, all on the GPU.  d_results: batch structs in device memory (same layout as the host entry fills).  d_boxes / d_nboxes / d_have_dynamic
+ * (optional, may be NULL): the person rectangles (max_boxes x (x, y, w, h) per image), their count and mbHaveDynamicObjectForRmDynamicFeature, laid out
+ * as sgx_dynamic_mask_batch_dev / sgx_frame_compact_keys_batch_dev take them — Detector2D.cc:53-88 feeding Frame.cc:482-500 without a host round trip. */
+int sgx_det_detect_batch_dev(sgx_det *h, const uint8_t *d_img, int pitch, int batch, sgx_det_result *d_results,
+                             float *d_boxes, int32_t *d_nboxes, int max_boxes, int32_t *d_have_dynamic, void *stream);
 /* device-resident batched forward only: leaves mbox_loc (num_priors*4) and softmax conf (num_priors*num_class) per image in HBM */
 int sgx_det_forward_batch_dev(sgx_det *h, const uint8_t *d_img, int pitch, int batch, const float **d_loc, const float **d_conf, void *stream);
 int sgx_det_debug_read_blob(sgx_det *h, const char *blob_name, int image, float *dst, int cap, int *n);
+/* test tap: DetectionOutput + detect() filtering alone on caller-supplied head outputs (host arrays: loc batch x num_priors x 4, conf batch x num_priors x num_class) */
+int sgx_det_debug_detection_output(sgx_det *h, const float *loc, const float *conf, int batch, sgx_det_result *results);
 /* test / tuning taps.  set_fusion(0) makes the NEXT sgx_det_create build the unfused plan (one kernel per ncnn layer, every blob
  * materialised) — the fused plan (default) must reproduce it bit for bit.  time_ops: HIP-event time per plan step (ms[0] = pre-processing). */
 int sgx_det_debug_set_fusion(int on);

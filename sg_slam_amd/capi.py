@@ -59,7 +59,7 @@ SYMBOLS = [
     'sgx_frame_stereo_from_rgbd_batch_dev', 'sgx_frame_unproject_batch_dev', 'sgx_frame_make_map_points_batch_dev', 'sgx_frame_merge_matches_batch_dev',
     'sgx_pose_optimization_batch_dev', 'sgx_pose_opt_debug_set_threads', 'sgx_pose_optimization', 'sgx_frame_motion_model_batch_dev',
     'sgx_local_bundle_adjustment',
-    'sgx_det_create', 'sgx_det_destroy', 'sgx_det_info', 'sgx_det_detect', 'sgx_det_forward_batch_dev', 'sgx_det_debug_read_blob',
+    'sgx_det_create', 'sgx_det_destroy', 'sgx_det_info', 'sgx_det_detect', 'sgx_det_detect_batch_dev', 'sgx_det_forward_batch_dev', 'sgx_det_debug_read_blob', 'sgx_det_debug_detection_output',
     'sgx_frame_compact_keys_batch_dev', 'sgx_frame_gray_from_color_batch_dev', 'sgx_debug_flow_affine_batch_dev', 'sgx_det_debug_set_fusion', 'sgx_det_debug_set_legacy_kernels', 'sgx_det_debug_time_ops', 'sgx_det_debug_op_desc',
     'sgx_dynamic_mask_batch_dev',
 ]
@@ -117,6 +117,8 @@ class SgxLib:
         d.sgx_det_destroy.argtypes = [vp]; d.sgx_det_destroy.restype = None
         d.sgx_det_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
         d.sgx_det_detect.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(DetResult)]
+        d.sgx_det_debug_detection_output.argtypes = [vp, vp, vp, C.c_int, C.POINTER(DetResult)]
+        d.sgx_det_detect_batch_dev.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp]
         d.sgx_det_forward_batch_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp), vp]
         d.sgx_det_debug_read_blob.argtypes = [vp, C.c_char_p, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
         d.sgx_det_debug_set_fusion.argtypes = [C.c_int]

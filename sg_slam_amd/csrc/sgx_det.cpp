@@ -50,6 +50,7 @@ struct sgx_det {
     int num_priors = 0, num_class = 21, nms_top_k = 300, keep_top_k = 100; float nms_th = 0.45f, conf_th = 0.01f, dvar[4] = {0.1f, 0.1f, 0.2f, 0.2f};
     int loc_blob = -1, conf_blob = -1;
     SgxDetTab *d_xt = nullptr, *d_yt = nullptr; uint8_t *d_img = nullptr;
+    float *d_priors = nullptr, *d_cls_rows = nullptr; int *d_cls_count = nullptr; sgx_det_result *d_results = nullptr;      // DetectionOutput on the device
     double gmac = 0;
 #ifndef SGX_EMU
     std::map<int, hipGraphExec_t> graphs;     // captured plan per batch size (launch-bound tail of ~100 small kernels -> one graph launch)
@@ -310,6 +311,11 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
     h->num_priors = (int)prior_boxes.size() / 4;
     h->priors = prior_boxes; h->priors.insert(h->priors.end(), prior_vars.begin(), prior_vars.end());
     if ((size_t)h->num_priors * 4 != h->blobs[h->loc_blob].n || (size_t)h->num_priors * h->num_class != h->blobs[h->conf_blob].n) { delete h; return SGX_ERR_INVALID; }
+    if (h->num_priors > SGX_DO_SORT || h->nms_top_k > SGX_DO_TOPK || (h->num_class - 1) * h->nms_top_k > SGX_DO_MERGE || h->num_class - 1 > 63 || h->num_class < 2 ||
+        h->keep_top_k > SGX_DET_MAX) { delete h; return SGX_ERR_UNSUPPORTED; }
+    if (h->alloc(&h->d_priors, (size_t)h->num_priors * 4) || h->alloc(&h->d_cls_rows, (size_t)B * (h->num_class - 1) * SGX_DO_TOPK * 6) ||
+        h->alloc(&h->d_cls_count, (size_t)B * (h->num_class - 1)) || h->alloc(&h->d_results, (size_t)B)) { delete h; return SGX_ERR_NOMEM; }
+    if (hipMemcpy(h->d_priors, prior_boxes.data(), sizeof(float) * 4 * h->num_priors, hipMemcpyHostToDevice) != hipSuccess) { delete h; return SGX_ERR_DEVICE; }
     std::vector<SgxDetTab> xt, yt; build_tab(width, T, xt); build_tab(height, T, yt);
     if (h->alloc(&h->d_xt, T) || h->alloc(&h->d_yt, T) || h->alloc(&h->d_img, (size_t)B * height * ((3 * width + 3) & ~3) + 4)) { delete h; return SGX_ERR_NOMEM; }
     if (hipMemcpy(h->d_xt, xt.data(), sizeof(SgxDetTab) * T, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(h->d_yt, yt.data(), sizeof(SgxDetTab) * T, hipMemcpyHostToDevice) != hipSuccess) { delete h; return SGX_ERR_DEVICE; }
@@ -522,44 +528,41 @@ extern "C" int sgx_det_debug_read_blob(sgx_det *h, const char *name, int image, 
     return SGX_OK;
 }
 
-namespace { struct Cand { float score; int idx; }; }
+static int run_detection_output(sgx_det *h, int batch, sgx_det_result *d_results, float *d_boxes, int32_t *d_nboxes, int max_boxes, int32_t *d_have_dynamic, sgx_stream_t st);
 
-// ncnn DetectionOutput (decode + per-class NMS + keep_top_k) on the host, then Detector2D::detect's filtering (Detector2D.cc:53-88)
-static void detection_output(const sgx_det *h, const float *loc, const float *conf, std::vector<sgx_detection> &rows)
+// Detector2D::detect, device-resident: forward, then ncnn DetectionOutput (decode + per-class NMS + keep_top_k) and the detect() filtering as two kernels
+// (k_det_class_nms, k_det_merge).  d_results[batch] receives the same struct the host entry returns; d_boxes / d_nboxes / d_have_dynamic (optional) are
+// the person rectangles, their count and the have-dynamic flag in the layout sgx_dynamic_mask_batch_dev and sgx_frame_compact_keys_batch_dev take.
+extern "C" int sgx_det_detect_batch_dev(sgx_det *h, const uint8_t *d_img, int pitch, int batch, sgx_det_result *d_results,
+                                        float *d_boxes, int32_t *d_nboxes, int max_boxes, int32_t *d_have_dynamic, void *stream_)
 {
-    const int n = h->num_priors, nc = h->num_class;
-    const float *pb = h->priors.data();
-    std::vector<float> box((size_t)n * 4);
-    for (int i = 0; i < n; i++) {
-        const float *p = pb + 4 * i, *l = loc + 4 * i;
-        const float pw = p[2] - p[0], ph = p[3] - p[1], pcx = (p[0] + p[2]) * 0.5f, pcy = (p[1] + p[3]) * 0.5f;
-        const float cx = h->dvar[0] * l[0] * pw + pcx, cy = h->dvar[1] * l[1] * ph + pcy;
-        const float w = expf(h->dvar[2] * l[2]) * pw, hh = expf(h->dvar[3] * l[3]) * ph;
-        box[4 * i] = cx - w * 0.5f; box[4 * i + 1] = cy - hh * 0.5f; box[4 * i + 2] = cx + w * 0.5f; box[4 * i + 3] = cy + hh * 0.5f;
-    }
-    std::vector<sgx_detection> all;
-    std::vector<Cand> cand; std::vector<int> keep;
-    for (int c = 1; c < nc; c++) {
-        cand.clear();
-        for (int i = 0; i < n; i++) { const float s = conf[(size_t)i * nc + c]; if (s > h->conf_th) cand.push_back(Cand{s, i}); }
-        std::stable_sort(cand.begin(), cand.end(), [](const Cand &a, const Cand &b) { return a.score > b.score; });
-        if ((int)cand.size() > h->nms_top_k) cand.resize(h->nms_top_k);
-        keep.clear();
-        for (const Cand &cd : cand) {
-            const float *a = &box[4 * (size_t)cd.idx]; bool ok = true;
-            for (int kidx : keep) {
-                const float *b = &box[4 * (size_t)kidx];
-                const float iw = std::min(a[2], b[2]) - std::max(a[0], b[0]), ih = std::min(a[3], b[3]) - std::max(a[1], b[1]);
-                const float inter = (iw > 0 && ih > 0) ? iw * ih : 0.f;
-                const float uni = (a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - inter;
-                if (inter / uni > h->nms_th) { ok = false; break; }
-            }
-            if (ok) { keep.push_back(cd.idx); sgx_detection d; d.label = (float)c; d.score = cd.score; memcpy(&d.xmin, &box[4 * (size_t)cd.idx], 16); all.push_back(d); }
-        }
-    }
-    std::stable_sort(all.begin(), all.end(), [](const sgx_detection &a, const sgx_detection &b) { return a.score > b.score; });
-    if ((int)all.size() > h->keep_top_k) all.resize(h->keep_top_k);
-    rows = all;
+    if (!h || !d_results || ((d_boxes != nullptr) != (d_nboxes != nullptr)) || (d_boxes && max_boxes < 1)) return SGX_ERR_INVALID;
+    const float *dl = nullptr, *dc = nullptr;
+    int rc = sgx_det_forward_batch_dev(h, d_img, pitch, batch, &dl, &dc, stream_);
+    if (rc != SGX_OK) return rc;
+    return run_detection_output(h, batch, d_results, d_boxes, d_nboxes, max_boxes, d_have_dynamic, (sgx_stream_t)stream_);
+}
+
+static int run_detection_output(sgx_det *h, int batch, sgx_det_result *d_results, float *d_boxes, int32_t *d_nboxes, int max_boxes, int32_t *d_have_dynamic, sgx_stream_t st)
+{
+    SgxDetOut P; P.n = h->num_priors; P.nc = h->num_class; P.nms_top_k = h->nms_top_k; P.keep_top_k = h->keep_top_k; P.nms_th = h->nms_th; P.conf_th = h->conf_th;
+    P.var0 = h->dvar[0]; P.var1 = h->dvar[1]; P.var2 = h->dvar[2]; P.var3 = h->dvar[3];
+    SGX_LAUNCH(k_det_class_nms, dim3(h->num_class - 1, batch), dim3(256), st, P, h->blobs[h->loc_blob].d, h->blobs[h->conf_blob].d, h->d_priors, h->d_cls_rows, h->d_cls_count);
+    SGX_LAUNCH(k_det_merge, dim3(batch), dim3(256), st, P, h->d_cls_rows, h->d_cls_count, h->det_th, h->dyn_th, h->W, h->H, h->T, d_results, d_boxes, d_nboxes, max_boxes, d_have_dynamic);
+    SGX_CHECK_HIP(hipGetLastError());
+    return SGX_OK;
+}
+
+// test tap: DetectionOutput + detect() filtering alone on caller-supplied head outputs (loc: batch x num_priors x 4, conf: batch x num_priors x num_class)
+extern "C" int sgx_det_debug_detection_output(sgx_det *h, const float *loc, const float *conf, int batch, sgx_det_result *results)
+{
+    if (!h || !loc || !conf || !results || batch < 1 || batch > h->max_batch) return SGX_ERR_INVALID;
+    SGX_CHECK_HIP(hipMemcpy(h->blobs[h->loc_blob].d, loc, sizeof(float) * 4 * (size_t)h->num_priors * batch, hipMemcpyHostToDevice));
+    SGX_CHECK_HIP(hipMemcpy(h->blobs[h->conf_blob].d, conf, sizeof(float) * (size_t)h->num_priors * h->num_class * batch, hipMemcpyHostToDevice));
+    int rc = run_detection_output(h, batch, h->d_results, nullptr, nullptr, 0, nullptr, (sgx_stream_t)0);
+    if (rc != SGX_OK) return rc;
+    SGX_CHECK_HIP(hipMemcpy(results, h->d_results, sizeof(sgx_det_result) * batch, hipMemcpyDeviceToHost));
+    return SGX_OK;
 }
 
 // Detector2D::detect for `batch` host images (interleaved 3-channel u8, as cv::Mat bgr.data).  Per image: raw detection_out
@@ -571,31 +574,9 @@ extern "C" int sgx_det_detect(sgx_det *h, const uint8_t *images, int pitch, int 
     for (int b = 0; b < batch; b++)
         for (int y = 0; y < h->H; y++)
             SGX_CHECK_HIP(hipMemcpyAsync(h->d_img + ((size_t)b * h->H + y) * ipitch, images + ((size_t)b * h->H + y) * pitch, (size_t)3 * h->W, hipMemcpyHostToDevice, 0));
-    const float *dl = nullptr, *dc = nullptr;
-    int rc = sgx_det_forward_batch_dev(h, h->d_img, ipitch, batch, &dl, &dc, nullptr);
+    int rc = sgx_det_detect_batch_dev(h, h->d_img, ipitch, batch, h->d_results, nullptr, nullptr, 0, nullptr, nullptr);
     if (rc != SGX_OK) return rc;
-    const size_t nl = (size_t)h->num_priors * 4, ncf = (size_t)h->num_priors * h->num_class;
-    std::vector<float> loc(nl * batch), conf(ncf * batch);
-    SGX_CHECK_HIP(hipMemcpy(loc.data(), dl, nl * batch * 4, hipMemcpyDeviceToHost));
-    SGX_CHECK_HIP(hipMemcpy(conf.data(), dc, ncf * batch * 4, hipMemcpyDeviceToHost));
-    const float T = (float)h->T;
-    for (int b = 0; b < batch; b++) {
-        sgx_det_result &R = results[b]; memset(&R, 0, sizeof R);
-        std::vector<sgx_detection> rows; detection_output(h, loc.data() + nl * b, conf.data() + ncf * b, rows);
-        R.n_raw = (int)rows.size();
-        for (int i = 0; i < R.n_raw && i < SGX_DET_MAX; i++) R.raw[i] = rows[i];
-        auto cl = [&](float v) { return std::min(std::max(v * T, 0.f), (float)(h->T - 1)) / T; };
-        for (const sgx_detection &v : rows) {
-            if (v.score > h->det_th || (v.score > h->dyn_th && (int)v.label == 15)) {
-                const float x1 = cl(v.xmin) * h->W, y1 = cl(v.ymin) * h->H, x2 = cl(v.xmax) * h->W, y2 = cl(v.ymax) * h->H;
-                sgx_object2d o; o.id = (int)v.label; o.prob = v.score; o.x = x1; o.y = y1; o.w = x2 - x1; o.h = y2 - y1;
-                if (o.id == 15) {
-                    R.have_dynamic_for_mapping = 1; if (R.n_map_boxes < SGX_DET_MAX) R.map_boxes[R.n_map_boxes++] = o;
-                    if (o.prob > 0.2f) { R.have_dynamic_for_rm_feature = 1; if (R.n_rm_boxes < SGX_DET_MAX) R.rm_boxes[R.n_rm_boxes++] = o; }
-                } else if (R.n_objects < SGX_DET_MAX) R.objects[R.n_objects++] = o;
-            }
-        }
-    }
+    SGX_CHECK_HIP(hipMemcpy(results, h->d_results, sizeof(sgx_det_result) * batch, hipMemcpyDeviceToHost));
     return SGX_OK;
 }
 

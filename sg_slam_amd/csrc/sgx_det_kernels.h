@@ -4,6 +4,7 @@
 // src/sg-slam/Thirdparty/ncnn_model/mobilenetv3_ssdlite_voc.param (layer semantics: oracle/detector_oracle.py).
 #pragma once
 #include "sgx_rt.h"
+#include "../../include/sgx.h"
 
 #define SGX_ACT_NONE 0
 #define SGX_ACT_RELU 1
@@ -663,5 +664,197 @@ SGX_KERNEL(256) k_compact_keys(int cap, const uint8_t *keys, const uint8_t *desc
         pos++;
     }
     if (tid == 0) n_out[f] = restore ? N : s_total;
+    SGX_THREADS_END
+}
+
+// ---------------------------------------------------------------------------------------------
+// ncnn DetectionOutput (decode + per-class NMS + keep_top_k) and Detector2D::detect's filtering (Detector2D.cc:53-88) on the device.
+//   k_det_class_nms  (grid: classes-1 x frames, 256 threads): one (frame, class): candidates = priors with conf > conf_th, sorted by score (descending,
+//     ties by prior index — std::stable_sort of the candidate list built in index order), cut to nms_top_k; their boxes are decoded from prior + loc;
+//     greedy NMS "keep i unless a kept, higher-ranked box overlaps it by more than nms_th" is resolved exactly: the overlap relation with all higher-ranked
+//     candidates is one bit matrix (computed in parallel), the greedy scan then runs 64 candidates at a time (suppression by earlier chunks is a parallel
+//     AND with the final kept words; inside a chunk one thread walks 64 rows).  The kept rows are written in rank order.
+//   k_det_merge      (grid: frames, 256 threads): the rows of all classes in class-major order, stable-sorted by score, cut to keep_top_k, then the
+//     detect() filter (score > det_th, or class 15 "person" above dyn_th; clamp to the 300 x 300 net input, scale to the image) fills the same
+//     sgx_det_result the host entry returns and, optionally, the (boxes, count, have-dynamic) arrays sgx_dynamic_mask_batch_dev / compact_keys take.
+// Sorting = bitonic network over 64-bit keys (score bits << 32 | ~sequence number) in LDS: score > 0, so its bit pattern orders like the value.
+// ---------------------------------------------------------------------------------------------
+#define SGX_DO_SORT 4096                   /* per-class sort capacity: num_priors <= this */
+#define SGX_DO_TOPK 320                    /* nms_top_k <= this (5 words of 64 candidates) */
+#define SGX_DO_WORDS (SGX_DO_TOPK / 64)
+#define SGX_DO_MERGE 8192                  /* (classes - 1) * nms_top_k <= this */
+struct SgxDetOut { int n, nc, nms_top_k, keep_top_k; float nms_th, conf_th, var0, var1, var2, var3; };
+
+// descending bitonic sort of `size` (power of two) 64-bit keys in LDS by `NT` threads
+#define SGX_BITONIC_DESC(keys, size, NT)                                                                             \
+    for (int k_ = 2; k_ <= (size); k_ <<= 1)                                                                         \
+        for (int j_ = k_ >> 1; j_ > 0; j_ >>= 1) {                                                                   \
+            SGX_THREADS_BEGIN(tid)                                                                                   \
+            for (int t_ = tid; t_ < (size) / 2; t_ += (NT)) {                                                        \
+                const int lo_ = ((t_ & ~(j_ - 1)) << 1) | (t_ & (j_ - 1)), hi_ = lo_ | j_;                           \
+                const unsigned long long a_ = keys[lo_], b_ = keys[hi_];                                             \
+                const bool desc_ = (lo_ & k_) == 0;                                                                  \
+                if (desc_ ? a_ < b_ : a_ > b_) { keys[lo_] = b_; keys[hi_] = a_; }                                   \
+            }                                                                                                        \
+            SGX_THREADS_END                                                                                          \
+            SGX_SYNC();                                                                                              \
+        }
+
+SGX_KERNEL(256) k_det_class_nms(SgxDetOut P, const float *loc, const float *conf, const float *priors, float *cls_rows, int *cls_count)
+{
+    SGX_LDS unsigned long long keys[SGX_DO_SORT];
+    SGX_LDS float box[SGX_DO_TOPK][4];
+    SGX_LDS unsigned long long over[SGX_DO_TOPK][SGX_DO_WORDS];
+    SGX_LDS unsigned long long kept[SGX_DO_WORDS];
+    SGX_LDS uint8_t pre[64];
+    SGX_LDS int s_m;
+    const int c = 1 + (int)blockIdx.x, f = (int)blockIdx.y, n = P.n, nc = P.nc;
+    const float *L = loc + (size_t)f * n * 4, *C = conf + (size_t)f * n * nc;
+    int size = 64; while (size < n) size <<= 1;               // <= SGX_DO_SORT (checked at create)
+    SGX_THREADS_BEGIN(tid)
+    if (tid == 0) s_m = 0;
+    for (int i = tid; i < size; i += 256) {
+        unsigned long long key = 0;
+        if (i < n) { const float s = C[(size_t)i * nc + c]; if (s > P.conf_th) { uint32_t b; memcpy(&b, &s, 4); key = ((unsigned long long)b << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i); } }
+        keys[i] = key;
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_BITONIC_DESC(keys, size, 256)
+    SGX_THREADS_BEGIN(tid)
+    int cnt = 0;
+    for (int r = tid; r < P.nms_top_k && r < size; r += 256) cnt += keys[r] != 0;
+    if (cnt) sgx_atomic_add(&s_m, cnt);
+    SGX_THREADS_END
+    SGX_SYNC();
+    const int m = s_m;                                           // candidates that enter the NMS (sorted: the non-zero keys come first)
+    SGX_THREADS_BEGIN(tid)
+    for (int r = tid; r < m; r += 256) {                        // decode (ncnn detectionoutput.cpp; the host code this replaces used the same expressions)
+        const int i = (int)(0xFFFFFFFFu - (uint32_t)keys[r]);
+        const float *p = priors + 4 * i, *l = L + 4 * i;
+        const float pw = p[2] - p[0], ph = p[3] - p[1], pcx = (p[0] + p[2]) * 0.5f, pcy = (p[1] + p[3]) * 0.5f;
+        const float cx = P.var0 * l[0] * pw + pcx, cy = P.var1 * l[1] * ph + pcy;
+        const float w = expf(P.var2 * l[2]) * pw, hh = expf(P.var3 * l[3]) * ph;
+        box[r][0] = cx - w * 0.5f; box[r][1] = cy - hh * 0.5f; box[r][2] = cx + w * 0.5f; box[r][3] = cy + hh * 0.5f;
+    }
+    for (int w = tid; w < SGX_DO_WORDS; w += 256) kept[w] = 0;
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    for (int t = tid; t < m * SGX_DO_WORDS; t += 256) {         // over[r] bit q: candidate r overlaps the higher-ranked candidate q by more than nms_th
+        const int r = t / SGX_DO_WORDS, w = t - r * SGX_DO_WORDS;
+        unsigned long long bits = 0;
+        const float a0 = box[r][0], a1 = box[r][1], a2 = box[r][2], a3 = box[r][3];
+        for (int b = 0; b < 64; b++) {
+            const int q = 64 * w + b;
+            if (q >= r) break;
+            const float iw = fminf(a2, box[q][2]) - fmaxf(a0, box[q][0]), ih = fminf(a3, box[q][3]) - fmaxf(a1, box[q][1]);
+            const float inter = (iw > 0 && ih > 0) ? iw * ih : 0.f;
+            const float uni = (a2 - a0) * (a3 - a1) + (box[q][2] - box[q][0]) * (box[q][3] - box[q][1]) - inter;
+            if (inter / uni > P.nms_th) bits |= 1ull << b;
+        }
+        over[r][w] = bits;
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+    for (int ch = 0; ch * 64 < m; ch++) {
+        SGX_THREADS_BEGIN(tid)
+        if (tid < 64) {
+            const int r = 64 * ch + tid;
+            bool s = false;
+            if (r < m) for (int w = 0; w < ch; w++) s = s || (over[r][w] & kept[w]) != 0;
+            pre[tid] = s ? 1 : 0;
+        }
+        SGX_THREADS_END
+        SGX_SYNC();
+        SGX_THREADS_BEGIN(tid)
+        if (tid == 0) {
+            unsigned long long word = 0;
+            for (int t = 0; t < 64 && 64 * ch + t < m; t++) if (!pre[t] && (over[64 * ch + t][ch] & word) == 0) word |= 1ull << t;
+            kept[ch] = word;
+        }
+        SGX_THREADS_END
+        SGX_SYNC();
+    }
+    SGX_THREADS_BEGIN(tid)
+    float *out = cls_rows + ((size_t)f * (nc - 1) + (c - 1)) * SGX_DO_TOPK * 6;
+    for (int r = tid; r < m; r += 256) {
+        const int w = r >> 6, b = r & 63;
+        if (!((kept[w] >> b) & 1)) continue;
+        int pos = SGX_POPCLL(kept[w] & ((1ull << b) - 1));
+        for (int q = 0; q < w; q++) pos += SGX_POPCLL(kept[q]);
+        const uint32_t sb = (uint32_t)(keys[r] >> 32); float s; memcpy(&s, &sb, 4);
+        float *o = out + 6 * pos;
+        o[0] = (float)c; o[1] = s; o[2] = box[r][0]; o[3] = box[r][1]; o[4] = box[r][2]; o[5] = box[r][3];
+    }
+    if (tid == 0) { int tot = 0; for (int q = 0; q < SGX_DO_WORDS; q++) tot += SGX_POPCLL(kept[q]); cls_count[f * (nc - 1) + (c - 1)] = tot; }
+    SGX_THREADS_END
+}
+
+SGX_KERNEL(256) k_det_merge(SgxDetOut P, const float *cls_rows, const int *cls_count, float det_th, float dyn_th, int W, int H, int T,
+                            sgx_det_result *results, float *boxes, int *nboxes, int max_boxes, int *have_dynamic)
+{
+    SGX_LDS unsigned long long keys[SGX_DO_MERGE];
+    SGX_LDS int off[64];
+    SGX_LDS int s_total;
+    const int f = (int)blockIdx.x, ncl = P.nc - 1;
+    SGX_THREADS_BEGIN(tid)
+    if (tid == 0) { int run = 0; for (int q = 0; q < ncl; q++) { off[q] = run; run += cls_count[f * ncl + q]; } off[ncl] = run; s_total = run; }
+    SGX_THREADS_END
+    SGX_SYNC();
+    const int total = s_total;
+    int size = 64; while (size < total) size <<= 1;              // <= SGX_DO_MERGE (checked at create)
+    SGX_THREADS_BEGIN(tid)
+    for (int i = tid; i < size; i += 256) keys[i] = 0;
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    for (int q = 0; q < ncl; q++) {
+        const int cnt = off[q + 1] - off[q];
+        const float *rows = cls_rows + ((size_t)f * ncl + q) * SGX_DO_TOPK * 6;
+        for (int p = tid; p < cnt; p += 256) {
+            const float s = rows[6 * p + 1]; uint32_t b; memcpy(&b, &s, 4);
+            const int seq = off[q] + p;                          // position in the class-major list the reference sorts (stable: ties keep this order)
+            keys[seq] = ((unsigned long long)b << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)seq);
+        }
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_BITONIC_DESC(keys, size, 256)
+    const int K = min(min(total, P.keep_top_k), SGX_DET_MAX);
+    sgx_det_result *R = results + f;
+    SGX_THREADS_BEGIN(tid)
+    for (int r = tid; r < K; r += 256) {
+        const int seq = (int)(0xFFFFFFFFu - (uint32_t)keys[r]);
+        int q = 0; while (q + 1 < ncl && off[q + 1] <= seq) q++;
+        const float *row = cls_rows + (((size_t)f * ncl + q) * SGX_DO_TOPK + (seq - off[q])) * 6;
+        sgx_detection d; d.label = row[0]; d.score = row[1]; d.xmin = row[2]; d.ymin = row[3]; d.xmax = row[4]; d.ymax = row[5];
+        R->raw[r] = d;
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    if (tid == 0) {                                              // Detector2D::detect, Detector2D.cc:53-88 (sequential: it appends to four lists in row order)
+        R->n_raw = K; R->n_objects = 0; R->n_map_boxes = 0; R->n_rm_boxes = 0; R->have_dynamic_for_mapping = 0; R->have_dynamic_for_rm_feature = 0;
+        const float Tf = (float)T;
+        for (int r = 0; r < K; r++) {
+            const sgx_detection v = R->raw[r];
+            if (v.score > det_th || (v.score > dyn_th && (int)v.label == 15)) {
+                const float x1 = fminf(fmaxf(v.xmin * Tf, 0.f), (float)(T - 1)) / Tf * W, y1 = fminf(fmaxf(v.ymin * Tf, 0.f), (float)(T - 1)) / Tf * H;
+                const float x2 = fminf(fmaxf(v.xmax * Tf, 0.f), (float)(T - 1)) / Tf * W, y2 = fminf(fmaxf(v.ymax * Tf, 0.f), (float)(T - 1)) / Tf * H;
+                sgx_object2d o; o.id = (int)v.label; o.prob = v.score; o.x = x1; o.y = y1; o.w = x2 - x1; o.h = y2 - y1;
+                if (o.id == 15) {
+                    R->have_dynamic_for_mapping = 1; if (R->n_map_boxes < SGX_DET_MAX) R->map_boxes[R->n_map_boxes++] = o;
+                    if (o.prob > 0.2f) { R->have_dynamic_for_rm_feature = 1; if (R->n_rm_boxes < SGX_DET_MAX) R->rm_boxes[R->n_rm_boxes++] = o; }
+                } else if (R->n_objects < SGX_DET_MAX) R->objects[R->n_objects++] = o;
+            }
+        }
+        if (boxes && nboxes) {                                   // the mask stage's inputs: person rectangles (x, y, w, h), their count, the have-dynamic flag
+            const int nb = min(R->n_rm_boxes, max_boxes);
+            for (int q = 0; q < nb; q++) { float *b = boxes + 4 * ((size_t)f * max_boxes + q); b[0] = R->rm_boxes[q].x; b[1] = R->rm_boxes[q].y; b[2] = R->rm_boxes[q].w; b[3] = R->rm_boxes[q].h; }
+            nboxes[f] = nb;
+        }
+        if (have_dynamic) have_dynamic[f] = R->have_dynamic_for_rm_feature;
+    }
     SGX_THREADS_END
 }

@@ -49,6 +49,13 @@ class Detector2D:
         self.lib.check(self.lib.dll.sgx_det_detect(self.h, _vp(imgs), imgs.shape[2] * 3, B, res), 'sgx_det_detect')
         return res
 
+    def detect_batch_dev(self, d_img, pitch, batch, d_results, d_boxes=None, d_nboxes=None, max_boxes=0, d_have_dynamic=None, stream=None):
+        """device-resident detect(): forward + DetectionOutput + filtering, asynchronous on `stream`; d_results = batch DetResult structs in device memory;
+        d_boxes / d_nboxes / d_have_dynamic (optional) are the mask stage's inputs (sgx_dynamic_mask_batch_dev / sgx_frame_compact_keys_batch_dev layout)"""
+        self.lib.check(self.lib.dll.sgx_det_detect_batch_dev(self.h, _vp(d_img), pitch, batch, _vp(d_results), None if d_boxes is None else _vp(d_boxes),
+                                                             None if d_nboxes is None else _vp(d_nboxes), max_boxes, None if d_have_dynamic is None else _vp(d_have_dynamic),
+                                                             None if stream is None else C.c_void_p(stream)), 'sgx_det_detect_batch_dev')
+
     def detect(self, bgr):
         r = self.detect_batch(bgr)[0]
         rect = lambda o: (o.x, o.y, o.w, o.h)

@@ -149,6 +149,71 @@ def test_compact_emu(emu):
     run_compact(emu)
 
 
+def run_detect_dev(lib, model, to_dev=lambda a: a, to_host=lambda a: a):
+    """sgx_det_detect_batch_dev: results struct and the mask-stage arrays it fills on the device (person rectangles, count, have-dynamic flag) against the
+    host entry (which copies the same device results back; its rows are checked against the oracle in run_compare)"""
+    from sg_slam_amd.capi import DetResult
+    import ctypes as C
+    layers, W, blob = model
+    det = Detector2D(0.90, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=2, lib=lib)
+    imgs = np.stack([make_image(5), make_image(6)])
+    host = det.detect_batch(imgs)
+    MB = 4
+    d_img = to_dev(np.ascontiguousarray(imgs)); d_res = to_dev(np.zeros((2, C.sizeof(DetResult)), np.uint8))
+    d_boxes = to_dev(np.full((2, MB, 4), -1, 'f4')); d_nb = to_dev(np.full(2, -1, 'i4')); d_have = to_dev(np.full(2, -1, 'i4'))
+    det.detect_batch_dev(d_img, 640 * 3, 2, d_res, d_boxes, d_nb, MB, d_have)
+    res = (DetResult * 2).from_buffer_copy(np.ascontiguousarray(to_host(d_res)).tobytes())
+    boxes, nb, have = to_host(d_boxes), to_host(d_nb), to_host(d_have)
+    for b in range(2):
+        assert bytes(res[b]) == bytes(host[b])
+        r = res[b]
+        assert nb[b] == min(r.n_rm_boxes, MB) and have[b] == r.have_dynamic_for_rm_feature
+        for q in range(nb[b]):
+            o = r.rm_boxes[q]
+            assert (boxes[b, q] == np.array([o.x, o.y, o.w, o.h], 'f4')).all()
+        assert r.n_raw > 0 and r.n_map_boxes >= r.n_rm_boxes
+    det.close()
+
+
+def test_detect_dev_emu(emu, model):
+    run_detect_dev(emu, model)
+
+
+def run_detection_output_stress(lib, model):
+    """DetectionOutput alone on adversarial head outputs: clusters of heavily overlapping boxes (long suppression chains across the 64-candidate chunks of the
+    device scan), exactly tied scores (stable order = prior index, then class), more than nms_top_k candidates per class, classes with none"""
+    from sg_slam_amd.capi import DetResult
+    layers, W, blob = model
+    det = Detector2D(0.90, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=2, lib=lib)
+    n, nc = det.num_priors, det.num_class
+    _, blobs = D.forward(layers, W, D.preprocess(make_image(0)))
+    priors = blobs['mbox_priorbox']
+    p = [L for L in layers if L['type'] == 'DetectionOutput'][0]['p']
+    rng = np.random.RandomState(11)
+    loc = np.zeros((2, n, 4), 'f4'); conf = np.zeros((2, n, nc), 'f4')
+    for b in range(2):
+        loc[b] = rng.randn(n, 4).astype('f4') * (0.3 if b == 0 else 2.0)           # small offsets: neighbouring priors overlap heavily
+        raw = rng.rand(n, nc).astype('f4') ** 3
+        raw[:, 3] = 0.0                                                               # a class without candidates
+        raw[:, 5] = np.round(raw[:, 5] * 8) / 8                                       # heavy score ties
+        raw[:, 15] = np.maximum(raw[:, 15], 0.02)                                     # every prior is a "person" candidate (> nms_top_k)
+        if b == 1: raw[rng.rand(n) < 0.7] *= 0.001
+        conf[b] = raw
+    res = (DetResult * 2)()
+    lib.check(lib.dll.sgx_det_debug_detection_output(det.h, loc.ctypes.data, conf.ctypes.data, 2, res), 'detection_output')
+    for b in range(2):
+        exp = D.detection_output(loc[b].reshape(-1), conf[b].reshape(-1), priors, p)
+        r = res[b]
+        got = np.array([[d.label, d.score, d.xmin, d.ymin, d.xmax, d.ymax] for d in r.raw[:r.n_raw]], np.float32).reshape(-1, 6)
+        assert got.shape == exp.shape and len(exp) == 100
+        assert (got[:, :2] == exp[:, :2]).all() and np.abs(got[:, 2:] - exp[:, 2:]).max() < 1e-5
+    det.close()
+
+
+def test_detection_output_stress_emu(emu, model):
+    run_detection_output_stress(emu, model)
+
+
 def test_oracle_convolutions_match_torch(model):
     """pins the ORACLE's convolution semantics (padding, stride, depthwise grouping, ncnn weight order [outc][inc/group][kh][kw]) to an independent
     implementation: every convolution of the shipped graph is evaluated in float64 on the oracle's own input blob, once with the oracle's numpy routine and

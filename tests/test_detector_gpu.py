@@ -60,3 +60,14 @@ def test_forward_graph_replay_equals_plain_launches(gpulib, model):
     for a, b in zip(plain, graph):
         assert (a == b).all()
     det.close()
+
+
+def test_detect_dev_gpu(gpulib, model):
+    import torch
+    from test_detector import run_detect_dev
+    run_detect_dev(gpulib, model, to_dev=lambda a: torch.from_numpy(a).cuda(), to_host=lambda t: t.cpu().numpy())
+
+
+def test_detection_output_stress_gpu(gpulib, model):
+    from test_detector import run_detection_output_stress
+    run_detection_output_stress(gpulib, model)
