@@ -682,6 +682,7 @@ SGX_KERNEL(256) k_compact_keys(int cap, const uint8_t *keys, const uint8_t *desc
 #define SGX_DO_SORT 4096                   /* per-class sort capacity: num_priors <= this */
 #define SGX_DO_TOPK 320                    /* nms_top_k <= this (5 words of 64 candidates) */
 #define SGX_DO_WORDS (SGX_DO_TOPK / 64)
+#define SGX_DO_COMPACT 1024                /* up to this many candidates are gathered and sorted on their own (fits the suppression matrix: TOPK * WORDS entries) */
 #define SGX_DO_MERGE 8192                  /* (classes - 1) * nms_top_k <= this */
 struct SgxDetOut { int n, nc, nms_top_k, keep_top_k; float nms_th, conf_th, var0, var1, var2, var3; };
 
@@ -707,27 +708,51 @@ SGX_KERNEL(256) k_det_class_nms(SgxDetOut P, const float *loc, const float *conf
     SGX_LDS unsigned long long over[SGX_DO_TOPK][SGX_DO_WORDS];
     SGX_LDS unsigned long long kept[SGX_DO_WORDS];
     SGX_LDS uint8_t pre[64];
-    SGX_LDS int s_m;
+    SGX_LDS int s_m, s_pos;
     const int c = 1 + (int)blockIdx.x, f = (int)blockIdx.y, n = P.n, nc = P.nc;
     const float *L = loc + (size_t)f * n * 4, *C = conf + (size_t)f * n * nc;
     int size = 64; while (size < n) size <<= 1;               // <= SGX_DO_SORT (checked at create)
     SGX_THREADS_BEGIN(tid)
-    if (tid == 0) s_m = 0;
-    for (int i = tid; i < size; i += 256) {
-        unsigned long long key = 0;
-        if (i < n) { const float s = C[(size_t)i * nc + c]; if (s > P.conf_th) { uint32_t b; memcpy(&b, &s, 4); key = ((unsigned long long)b << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i); } }
-        keys[i] = key;
-    }
+    if (tid == 0) { s_m = 0; s_pos = 0; }
     SGX_THREADS_END
     SGX_SYNC();
-    SGX_BITONIC_DESC(keys, size, 256)
     SGX_THREADS_BEGIN(tid)
     int cnt = 0;
-    for (int r = tid; r < P.nms_top_k && r < size; r += 256) cnt += keys[r] != 0;
+    for (int i = tid; i < size; i += 256) {
+        unsigned long long key = 0;
+        if (i < n) { const float s = C[(size_t)i * nc + c]; if (s > P.conf_th) { uint32_t b; memcpy(&b, &s, 4); key = ((unsigned long long)b << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i); cnt++; } }
+        keys[i] = key;
+    }
     if (cnt) sgx_atomic_add(&s_m, cnt);
     SGX_THREADS_END
     SGX_SYNC();
-    const int m = s_m;                                           // candidates that enter the NMS (sorted: the non-zero keys come first)
+    const int ncand = s_m;
+    if (ncand == 0) {                                            // a class nobody scored above the threshold (the common case with trained weights): nothing to do
+        SGX_THREADS_BEGIN(tid) if (tid == 0) cls_count[f * (nc - 1) + (c - 1)] = 0; SGX_THREADS_END
+        return;
+    }
+    if (ncand <= SGX_DO_COMPACT) {
+        // few candidates: gather them (any order — the keys are distinct, the sort decides) into the not-yet-used suppression matrix, sort only
+        // the next power of two, and hand the head of the list back
+        unsigned long long *ck = &over[0][0];
+        int csize = 64; while (csize < ncand) csize <<= 1;
+        SGX_THREADS_BEGIN(tid)
+        for (int i = tid; i < csize; i += 256) ck[i] = 0;
+        SGX_THREADS_END
+        SGX_SYNC();
+        SGX_THREADS_BEGIN(tid)
+        for (int i = tid; i < size; i += 256) { const unsigned long long key = keys[i]; if (key) ck[sgx_atomic_add(&s_pos, 1)] = key; }
+        SGX_THREADS_END
+        SGX_SYNC();
+        SGX_BITONIC_DESC(ck, csize, 256)
+        SGX_THREADS_BEGIN(tid)
+        for (int r = tid; r < SGX_DO_TOPK; r += 256) keys[r] = r < csize ? ck[r] : 0;
+        SGX_THREADS_END
+        SGX_SYNC();
+    } else {
+        SGX_BITONIC_DESC(keys, size, 256)
+    }
+    const int m = min(ncand, P.nms_top_k);                       // candidates that enter the NMS: the head of the sorted list
     SGX_THREADS_BEGIN(tid)
     for (int r = tid; r < m; r += 256) {                        // decode (ncnn detectionoutput.cpp; the host code this replaces used the same expressions)
         const int i = (int)(0xFFFFFFFFu - (uint32_t)keys[r]);
