@@ -219,9 +219,10 @@ SGX_KERNEL(SGX_BA_THREADS) k_ba_schur_init(int nf, const double *Hpp, double lam
 // The reference factorises it with Eigen SimplicialLDLT (G/solvers/linear_solver_eigen.h:94-124); the solution is unique,
 // so a Cholesky L L^T is used here.  *ok is cleared when a pivot is not positive (or NaN): the LM step is then rejected
 // exactly like solve()==false (levenberg.cpp:126-127).
-//   n <= 128 : k_chol_small — the whole matrix lives in LDS (128 KB), one 256-thread workgroup factorises and solves.
+//   n <= 128 : k_chol_small_reg — one 256-thread workgroup, the working matrix in registers, finished columns in LDS (k_chol_small, the LDS-resident
+//              first version, stays as a comparison tap).
 //   n  > 128 : blocked right-looking factorisation on 32x32 tiles staged in LDS, per panel k:
-//                k_chol_diag   (1 workgroup: factor L_kk and its explicit inverse Linv_kk)
+//                k_chol_diag_wave (ONE wave, tile in registers: factor L_kk and its explicit inverse Linv_kk; k_chol_diag = workgroup / LDS version, emulator + tap)
 //                k_chol_panel  (one workgroup per row tile below:  L_ik = A_ik Linv_kk^T   — a tile GEMM)
 //                k_chol_update (one workgroup per lower-triangular tile pair inside the current 256-column outer panel: A_ij -= L_ik L_jk^T)
 //              per outer panel: k_chol_update_wide (fp64 MFMA rank-256 update of everything right of the panel, 64 x 64 tiles)
