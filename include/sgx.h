@@ -130,6 +130,13 @@ int sgx_match_project_local_batch_dev(
     const sgx_camera *cam, const float *scale_factors, int nlevels, float log_scale_factor, float th, float nnratio, float viewing_cos_limit,
     int32_t *d_cur_match, int32_t *d_nmatches, uint8_t *d_in_view, void *stream);
 
+/* host pointers, one frame, synchronous (cur_mp_obs and in_view may be NULL) */
+int sgx_match_project_local(
+    int nc, const sgx_keypoint *ckeys, const uint8_t *cdesc, const float *curight, const float *cTcw, const int32_t *cur_mp_obs,
+    int nm, const float *m_xw, const float *m_normal, const float *m_min_dist, const float *m_max_dist, const uint8_t *m_desc, const int32_t *m_obs, const uint8_t *m_skip,
+    const sgx_camera *cam, const float *scale_factors, int nlevels, float log_scale_factor, float th, float nnratio, float viewing_cos_limit,
+    int32_t *cur_match, int32_t *nmatches, uint8_t *in_view);
+
 /* Harness helper (bench.py / tests), NOT a reference entry point: the previous-frame position of every keypoint under a per-frame affine flow
  * (prev = A * (x, y, 1), A = 6 floats), optionally displaced by shift[2] inside the frame's first box.  Stands in for cv::calcOpticalFlowPyrLK
  * (Frame.cc:445, tier N1) when the dynamic-feature mask is exercised on synthetic streams whose flow is known exactly. */

@@ -55,7 +55,7 @@ SYMBOLS = [
     'sgx_orb_extract_batch_dev', 'sgx_orb_extract', 'sgx_orb_last_status',
     'sgx_orb_debug_level_geometry', 'sgx_orb_debug_set_unfused_pyramid', 'sgx_orb_debug_read_level', 'sgx_orb_debug_read_candidates',
     'sgx_orb_debug_run_octree', 'sgx_profile_enable', 'sgx_profile_num_classes', 'sgx_profile_class_name', 'sgx_profile_read',
-    'sgx_match_project_frame_batch_dev', 'sgx_match_project_frame', 'sgx_match_project_local_batch_dev',
+    'sgx_match_project_frame_batch_dev', 'sgx_match_project_frame', 'sgx_match_project_local_batch_dev', 'sgx_match_project_local',
     'sgx_frame_stereo_from_rgbd_batch_dev', 'sgx_frame_unproject_batch_dev', 'sgx_frame_make_map_points_batch_dev', 'sgx_frame_merge_matches_batch_dev',
     'sgx_pose_optimization_batch_dev', 'sgx_pose_opt_debug_set_threads', 'sgx_pose_optimization', 'sgx_frame_motion_model_batch_dev',
     'sgx_local_bundle_adjustment',
@@ -129,6 +129,7 @@ class SgxLib:
         d.sgx_frame_gray_from_color_batch_dev.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]
         d.sgx_debug_flow_affine_batch_dev.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, vp]
         d.sgx_frame_compact_keys_batch_dev.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]
+        d.sgx_match_project_local.argtypes = [C.c_int] + [vp] * 5 + [C.c_int] + [vp] * 7 + [C.POINTER(Camera), vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp, vp]
         d.sgx_match_project_local_batch_dev.argtypes = [C.c_int, C.c_int] + [vp] * 6 + [C.c_int] + [vp] * 8 + [C.POINTER(Camera), vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp, vp, vp]
         d.sgx_frame_make_map_points_batch_dev.argtypes = [C.c_int, C.c_int, C.c_int] + [vp] * 7 + [C.c_int] + [vp] * 7
         d.sgx_frame_merge_matches_batch_dev.argtypes = [C.c_int, C.c_int] + [vp] * 10

@@ -173,6 +173,42 @@ extern "C" int sgx_match_project_frame(
     return SGX_OK;
 }
 
+// Host pointers, one frame: the drop-in for Tracking::SearchLocalPoints' isInFrustum loop + ORBmatcher::SearchByProjection(Frame &F, vpMapPoints, th).
+extern "C" int sgx_match_project_local(
+    int nc, const sgx_keypoint *ckeys, const uint8_t *cdesc, const float *curight, const float *cTcw, const int32_t *cur_mp_obs,
+    int nm, const float *m_xw, const float *m_normal, const float *m_min_dist, const float *m_max_dist, const uint8_t *m_desc, const int32_t *m_obs, const uint8_t *m_skip,
+    const sgx_camera *cam, const float *scale_factors, int nlevels, float log_scale_factor, float th, float nnratio, float viewing_cos_limit,
+    int32_t *cur_match, int32_t *nmatches, uint8_t *in_view)
+{
+    if (nc < 0 || nm < 0 || nc > SGX_MATCH_CAP || nm > SGX_LOCAL_CAP || !cur_match || !nmatches || !cTcw || !cam || !scale_factors) return SGX_ERR_INVALID;
+    for (int i = 0; i < nc; i++) cur_match[i] = -1;
+    if (in_view) memset(in_view, 0, (size_t)nm);
+    *nmatches = 0;
+    if (nc == 0 || nm == 0) return SGX_OK;                       // the reference's loops do not execute (ORBmatcher.cc:52-127)
+    DevBuf b[18];
+    int rc;
+    std::vector<int32_t> no_obs;
+    if (!cur_mp_obs) { no_obs.assign((size_t)nc, -1); cur_mp_obs = no_obs.data(); }
+#define UP(k, src, bytes) if ((rc = b[k].put(src, (size_t)(bytes))) != SGX_OK) return rc
+    UP(0, ckeys, (size_t)nc * 28); UP(1, cdesc, (size_t)nc * 32); UP(2, curight, (size_t)nc * 4); UP(3, &nc, 4); UP(4, cTcw, 64); UP(5, cur_mp_obs, (size_t)nc * 4);
+    UP(6, &nm, 4); UP(7, m_xw, (size_t)nm * 12); UP(8, m_normal, (size_t)nm * 12); UP(9, m_min_dist, (size_t)nm * 4); UP(10, m_max_dist, (size_t)nm * 4);
+    UP(11, m_desc, (size_t)nm * 32); UP(12, m_obs, (size_t)nm * 4); UP(13, m_skip, (size_t)nm);
+    UP(14, nullptr, (size_t)nc * 4); UP(15, nullptr, 4); UP(16, nullptr, (size_t)nm);
+#undef UP
+    SGX_CHECK_HIP(hipStreamSynchronize(0));
+    rc = sgx_match_project_local_batch_dev(1, nc, (const sgx_keypoint *)b[0].p, (const uint8_t *)b[1].p, (const float *)b[2].p, (const int32_t *)b[3].p, (const float *)b[4].p,
+                                           (const int32_t *)b[5].p, nm, (const int32_t *)b[6].p, (const float *)b[7].p, (const float *)b[8].p, (const float *)b[9].p,
+                                           (const float *)b[10].p, (const uint8_t *)b[11].p, (const int32_t *)b[12].p, (const uint8_t *)b[13].p,
+                                           cam, scale_factors, nlevels, log_scale_factor, th, nnratio, viewing_cos_limit,
+                                           (int32_t *)b[14].p, (int32_t *)b[15].p, (uint8_t *)b[16].p, nullptr);
+    if (rc != SGX_OK) return rc;
+    SGX_CHECK_HIP(hipMemcpyAsync(cur_match, b[14].p, (size_t)nc * 4, hipMemcpyDeviceToHost, 0));
+    SGX_CHECK_HIP(hipMemcpyAsync(nmatches, b[15].p, 4, hipMemcpyDeviceToHost, 0));
+    if (in_view) SGX_CHECK_HIP(hipMemcpyAsync(in_view, b[16].p, (size_t)nm, hipMemcpyDeviceToHost, 0));
+    SGX_CHECK_HIP(hipStreamSynchronize(0));
+    return SGX_OK;
+}
+
 extern "C" int sgx_frame_gray_from_color_batch_dev(int batch, int width, int height, const uint8_t *d_src, int src_pitch, int channels, int blue_first,
                                                    uint8_t *d_gray, int gray_pitch, void *stream)
 {

@@ -2,6 +2,7 @@
 // written against the C++ mirror classes.  Reads two raw 640x480 gray frames (+ a constant depth) from files given
 // on the command line and prints keypoints / matches / inliers / pose; tests/test_host_cpp_gpu.py feeds it
 // synthetic frames and compares the printed numbers with the oracle.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include "sgx_host.hpp"
@@ -45,7 +46,24 @@ int main(int argc, char **argv)
     int nmatches = matcher.SearchByProjection(cur, last, 15, false, cam, ex.GetScaleFactors());
     if (nmatches < 20) nmatches = matcher.SearchByProjection(cur, last, 30, false, cam, ex.GetScaleFactors());   // Tracking.cc:927-931
     const int ninl = sgx::Optimizer::PoseOptimization(&cur, last, cam, ex.GetInverseScaleSigmaSquares());
-    printf("N0 %d N1 %d matches %d inliers %d\n", last.N, cur.N, nmatches, ninl);
+    // TrackLocalMap-style second search (Tracking.cc:969-1013): the local map = the last frame's points as MapPoints created from that frame
+    // (MapPoint.cc:45-67: normal from the camera centre, mfMaxDistance = dist * scale[octave], mfMinDistance = mfMaxDistance / scale[nlevels - 1])
+    sgx::LocalMapView lm; lm.N = last.N;
+    const std::vector<float> sf = ex.GetScaleFactors();
+    lm.mWorldPos = last.mpWorldPos; lm.mDescriptor = last.mDescriptors; lm.nObs.assign(lm.N, 1); lm.skip.assign(lm.N, 0);
+    lm.mNormalVector.resize((size_t)lm.N * 3); lm.mfMinDistance.resize(lm.N); lm.mfMaxDistance.resize(lm.N);
+    for (int i = 0; i < lm.N; i++) {
+        const float *X = &lm.mWorldPos[3 * (size_t)i];
+        const float d = std::sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2]);       // camera centre of the last frame = origin
+        for (int a = 0; a < 3; a++) lm.mNormalVector[3 * (size_t)i + a] = X[a] / d;
+        lm.mfMaxDistance[i] = d * sf[last.mvKeysUn[i].octave]; lm.mfMinDistance[i] = lm.mfMaxDistance[i] / sf[sf.size() - 1];
+    }
+    std::vector<int32_t> held(cur.N, -1), local;
+    for (int k = 0; k < cur.N; k++) if (cur.mvpMapPoints[k] >= 0 && !cur.mvbOutlier[k]) held[k] = 1;     // keypoints that kept their point from the first stage
+    sgx::ORBmatcher lmatcher(0.8f);
+    const int nlocal = lmatcher.SearchByProjection(cur, lm, 3, cam, sf, local, &held);
+    int inview = 0; for (uint8_t v : lm.mbTrackInView) inview += v;
+    printf("N0 %d N1 %d matches %d inliers %d local %d inview %d\n", last.N, cur.N, nmatches, ninl, nlocal, inview);
     printf("Tcw");
     for (int i = 0; i < 16; i++) printf(" %.9g", cur.mTcw[i]);
     printf("\n");

@@ -7,6 +7,7 @@
 #pragma once
 #include <cstdint>
 #include <cstring>
+#include <cmath>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -30,6 +31,17 @@ struct FrameView {
     std::vector<float> mpWorldPos;          // N x 3   MapPoint::GetWorldPos()
     std::vector<int32_t> mpObservations;    // MapPoint::Observations()
     std::vector<uint8_t> mpDescriptor;      // N x 32  MapPoint::GetDescriptor()
+};
+
+// flattened local map (Tracking::mvpLocalMapPoints): what isInFrustum / SearchByProjection(F, vpMapPoints, th) read from each MapPoint
+struct LocalMapView {
+    int N = 0;
+    std::vector<float> mWorldPos, mNormalVector;    // N x 3   GetWorldPos(), GetNormal()
+    std::vector<float> mfMinDistance, mfMaxDistance;
+    std::vector<uint8_t> mDescriptor;               // N x 32  GetDescriptor()
+    std::vector<int32_t> nObs;                      // Observations()
+    std::vector<uint8_t> skip;                      // isBad() || mnLastFrameSeen == F.mnId (Tracking.cc:1288-1291)
+    std::vector<uint8_t> mbTrackInView;             // out: isInFrustum result (for IncreaseVisible)
 };
 
 inline void check(int rc, const char *what) { if (rc != SGX_OK) throw std::runtime_error(std::string(what) + ": " + sgx_status_string(rc)); }
@@ -101,6 +113,20 @@ public:
                                       LastFrame.mpObservations.data(), LastFrame.mpDescriptor.data(), LastFrame.mTcw,
                                       &cam, scaleFactors.data(), (int)scaleFactors.size(), th, bMono ? 1 : 0, mbCheckOrientation ? 1 : 0,
                                       CurrentFrame.mvpMapPoints.data(), &n), "sgx_match_project_frame");
+        return n;
+    }
+
+    // Tracking::SearchLocalPoints' body (Tracking.cc:1284-1311): isInFrustum(pMP, 0.5) for every local point, then SearchByProjection(F, vpMapPoints, th)
+    // (ORBmatcher.cc:45-129).  matched[k] = local point newly assigned to keypoint k of F (or -1); F.mvpMapPoints (>= 0 = holds a point) is only read.
+    int SearchByProjection(FrameView &F, LocalMapView &M, float th, const sgx_camera &cam, const std::vector<float> &scaleFactors, std::vector<int32_t> &matched,
+                           const std::vector<int32_t> *heldObservations = nullptr)
+    {
+        matched.assign(F.N, -1); M.mbTrackInView.assign(M.N, 0);
+        int32_t n = 0;
+        check(sgx_match_project_local(F.N, F.mvKeysUn.data(), F.mDescriptors.data(), F.mvuRight.data(), F.mTcw, heldObservations ? heldObservations->data() : nullptr,
+                                      M.N, M.mWorldPos.data(), M.mNormalVector.data(), M.mfMinDistance.data(), M.mfMaxDistance.data(), M.mDescriptor.data(), M.nObs.data(), M.skip.data(),
+                                      &cam, scaleFactors.data(), (int)scaleFactors.size(), std::log(scaleFactors[1]), th, mfNNratio, 0.5f,
+                                      matched.data(), &n, M.mbTrackInView.data()), "sgx_match_project_local");
         return n;
     }
 

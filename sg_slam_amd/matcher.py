@@ -63,26 +63,11 @@ class ORBmatcher:
         if nc == 0 or nm == 0:              # nothing to project / nothing to match against: the reference's loops do not execute (ORBmatcher.cc:52-127)
             F['match_local'] = np.full(nc, -1, 'i4'); local_map['in_view'] = np.zeros(nm, np.uint8)
             return 0
-        cnt = np.array([nc], 'i4'); mcnt = np.array([nm], 'i4')
-        match = np.full(max(nc, 1), -1, 'i4'); n = np.zeros(1, 'i4'); inview = np.zeros(max(nm, 1), np.uint8)
+        match = np.full(nc, -1, 'i4'); n = np.zeros(1, 'i4'); inview = np.zeros(nm, np.uint8)
         cs = camera_struct(cam)
-        arrs = [ck, cd, cu, cnt, cT, co, mcnt, xw, nr, mnd, mxd, md, mo, ms, match, n, inview]
-        dev, back = self._to_device(arrs)
-        d = dev
-        rc = self.lib.dll.sgx_match_project_local_batch_dev(1, max(nc, 1), _vp(d[0]), _vp(d[1]), _vp(d[2]), _vp(d[3]), _vp(d[4]), _vp(d[5]),
-                                                            max(nm, 1), _vp(d[6]), _vp(d[7]), _vp(d[8]), _vp(d[9]), _vp(d[10]), _vp(d[11]), _vp(d[12]), _vp(d[13]),
-                                                            C.byref(cs), _vp(sf), len(sf), float(np.log(np.float32(sf[1]))), float(th), float(self.mfNNratio),
-                                                            float(viewing_cos_limit), _vp(d[14]), _vp(d[15]), _vp(d[16]), None)
-        self.lib.check(rc, 'sgx_match_project_local_batch_dev')
-        match, n, inview = back(d[14]), back(d[15]), back(d[16])
-        F['match_local'] = match[:nc]; local_map['in_view'] = inview[:nm]
+        rc = self.lib.dll.sgx_match_project_local(nc, _vp(ck), _vp(cd), _vp(cu), _vp(cT), _vp(co), nm, _vp(xw), _vp(nr), _vp(mnd), _vp(mxd), _vp(md), _vp(mo), _vp(ms),
+                                                  C.byref(cs), _vp(sf), len(sf), float(np.log(np.float32(sf[1]))), float(th), float(self.mfNNratio),
+                                                  float(viewing_cos_limit), _vp(match), _vp(n), _vp(inview))
+        self.lib.check(rc, 'sgx_match_project_local')
+        F['match_local'] = match; local_map['in_view'] = inview
         return int(n[0])
-
-    def _to_device(self, arrs):
-        """numpy arrays -> device buffers for the *_batch_dev entry points: torch CUDA tensors with the product library,
-        the arrays themselves under the kernel-logic emulator (host memory)."""
-        if 'EMULATOR' in self.lib.version():
-            return arrs, (lambda a: a)
-        import torch
-        dev = [torch.from_numpy(a.view(np.uint8) if a.dtype.fields else a).cuda() for a in arrs]
-        return dev, (lambda t: t.cpu().numpy())

@@ -39,6 +39,16 @@ def test_cpp_example_matches_oracle(gpulib, oracle, stream_frames, tmp_path):
     einl, eT, _ = oracle.pose_optimization(fr, CAM, is2)
     assert (n0, n1, nm, ninl) == (len(k0), len(k1), en, einl)
     assert np.abs(T - eT).max() <= 1e-5 * max(1.0, np.abs(eT).max())
+    # TrackLocalMap-style second search through ORBmatcher::SearchByProjection(F, vpMapPoints, th): chained from the pose the C++ run printed
+    nlocal, ninview = int(vals[9]), int(vals[11])
+    _, _, eout = oracle.pose_optimization(fr, CAM, is2)
+    dist = np.sqrt(xw[:, 0] * xw[:, 0] + xw[:, 1] * xw[:, 1] + xw[:, 2] * xw[:, 2]).astype('f4')
+    sf32 = np.asarray(sf, 'f4')
+    mx = (dist * sf32[k0['octave']]).astype('f4')
+    lm = dict(xw=xw, normal=(xw / dist[:, None]).astype('f4'), max_dist=mx, min_dist=(mx / sf32[-1]).astype('f4'), desc=d0, obs=np.ones(len(k0), 'i4'), skip=np.zeros(len(k0), np.uint8))
+    cur2 = dict(keys=k1, desc=d1, uright=ur1, Tcw=T, mp_obs=np.where((m >= 0) & (eout == 0), 1, -1).astype('i4'))
+    res = oracle.search_by_projection_local(cur2, lm, CAM, sf, th=3.0, nnratio=0.8)
+    assert nlocal == res[1] and ninview == int(np.asarray(res[2]).sum())
 
 
 def _exe(name):
