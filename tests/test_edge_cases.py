@@ -42,6 +42,20 @@ def run_edge_cases(lib, oracle, S):
     g3 = Optimizer.PoseOptimization(f3, CAM, is2, lib=lib)
     assert g3 == en3 and (f3['outlier'] == eo3).all() and np.abs(f3['Tcw'] - eT3).max() <= 1e-5 * max(1.0, np.abs(eT3).max())
 
+    # argument validation of the C ABI: bad arguments are reported (SGX_ERR_INVALID = -1), never dereferenced
+    import ctypes as C
+    d = lib.dll
+    one = np.zeros(64, 'f4'); i1 = np.zeros(4, 'i4')
+    assert d.sgx_match_project_local(-1, None, None, None, one.ctypes.data, None, 0, None, None, None, None, None, None, None, None, None, 8, 0.18, 3.0, 0.8, 0.5,
+                                     i1.ctypes.data, i1.ctypes.data, None) == -1
+    assert d.sgx_match_project_local(0, None, None, None, one.ctypes.data, None, 0, None, None, None, None, None, None, None, None, None, 8, 0.18, 3.0, 0.8, 0.5,
+                                     None, i1.ctypes.data, None) == -1
+    assert d.sgx_pose_optimization(5000, None, None, None, None, None, 8, None, one.ctypes.data, i1.ctypes.data, i1.ctypes.data) == -1
+    assert d.sgx_det_detect_batch_dev(None, None, 0, 1, None, None, None, 0, None, None) == -1
+    assert d.sgx_det_detect(None, None, 0, 1, None) == -1
+    assert d.sgx_local_bundle_adjustment(None, None, None, None, None) == -1
+    assert d.sgx_orb_extract_batch_dev(None, None, 640, 1, None, None, None, 1024, None) == -1
+
 
 def test_edge_cases_emu(emu, oracle, stream_frames):
     run_edge_cases(emu, oracle, stream_frames)
