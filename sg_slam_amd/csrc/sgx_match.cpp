@@ -2,6 +2,7 @@
 // Reference behaviour: src/sg-slam/src/ORBmatcher.cc:1332-1472, src/sg-slam/src/Frame.cc:893-932.
 #include "sgx_match_kernels.h"
 #include "sgx_prof.h"
+#include "sgx_stage.h"
 #include "../../include/sgx.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -124,10 +125,10 @@ extern "C" int sgx_frame_motion_model_batch_dev(int batch, const float *d_Tcw_cu
 
 // Host-pointer, single pair: the drop-in for ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono).
 namespace {
+// device staging of the host-pointer entries: per-thread slots that persist from call to call (sgx_stage.h); slot ranges: frame matcher 0.., local matcher 20..
 struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int put(const void *src, size_t n) { if (hipMalloc(&p, n ? n : 1) != hipSuccess) return SGX_ERR_NOMEM; if (src && n) { if (hipMemcpyAsync(p, src, n, hipMemcpyHostToDevice, 0) != hipSuccess) return SGX_ERR_DEVICE; } return SGX_OK; }
+    void *p = nullptr; int slot = 0;
+    int put(const void *src, size_t n) { SgxStaged s; const int rc = s.put(slot, src, n); p = s.p; return rc; }
 };
 }
 
@@ -140,7 +141,7 @@ extern "C" int sgx_match_project_frame(
 {
     if (nc < 0 || nl < 0 || nc > SGX_MATCH_CAP || nl > SGX_MATCH_CAP || !cur_match || !nmatches) return SGX_ERR_INVALID;
     int cap = nc > nl ? nc : nl; if (cap < 1) cap = 1;
-    DevBuf b[16];
+    DevBuf b[16]; for (int i = 0; i < 16; i++) b[i].slot = i;
     std::vector<uint8_t> pad;
     auto up = [&](int k, const void *src, size_t elem, int n) -> int {
         pad.assign((size_t)cap * elem, 0);
@@ -185,7 +186,7 @@ extern "C" int sgx_match_project_local(
     if (in_view) memset(in_view, 0, (size_t)nm);
     *nmatches = 0;
     if (nc == 0 || nm == 0) return SGX_OK;                       // the reference's loops do not execute (ORBmatcher.cc:52-127)
-    DevBuf b[18];
+    DevBuf b[18]; for (int i = 0; i < 18; i++) b[i].slot = 20 + i;
     int rc;
     std::vector<int32_t> no_obs;
     if (!cur_mp_obs) { no_obs.assign((size_t)nc, -1); cur_mp_obs = no_obs.data(); }

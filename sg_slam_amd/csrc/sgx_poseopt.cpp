@@ -5,6 +5,7 @@
 #pragma clang fp contract(fast)
 #include "sgx_poseopt_kernels.h"
 #include "sgx_prof.h"
+#include "sgx_stage.h"
 #include "../../include/sgx.h"
 #include <stdio.h>
 #include <string.h>
@@ -52,7 +53,7 @@ extern "C" int sgx_pose_optimization(int n, const sgx_keypoint *keys_un, const f
     const void *src[8] = { keys_un, uright, &n, has_mp, mp_xw, Tcw, nullptr, nullptr };
     int rc = SGX_OK;
     for (int i = 0; i < 8 && rc == SGX_OK; i++) {
-        if (hipMalloc(&d[i], sz[i]) != hipSuccess) { rc = SGX_ERR_NOMEM; break; }
+        if ((rc = sgx_stage().get(40 + i, sz[i], &d[i])) != SGX_OK) break;           // per-thread staging slots, kept from call to call (sgx_stage.h)
         if (src[i] && n > 0 && hipMemcpyAsync(d[i], src[i], i == 2 || i == 5 ? sz[i] : (size_t)n * (sz[i] / cap), hipMemcpyHostToDevice, 0) != hipSuccess) rc = SGX_ERR_DEVICE;
     }
     if (rc == SGX_OK && n == 0) { (void)hipMemcpyAsync(d[2], &n, 4, hipMemcpyHostToDevice, 0); (void)hipMemcpyAsync(d[5], Tcw, 64, hipMemcpyHostToDevice, 0); }
@@ -64,7 +65,6 @@ extern "C" int sgx_pose_optimization(int n, const sgx_keypoint *keys_un, const f
         if (hipMemcpyAsync(Tcw, d[5], 64, hipMemcpyDeviceToHost, 0) != hipSuccess || hipMemcpyAsync(outlier, d[6], (size_t)n, hipMemcpyDeviceToHost, 0) != hipSuccess ||
             hipMemcpyAsync(n_inliers, d[7], 4, hipMemcpyDeviceToHost, 0) != hipSuccess || hipStreamSynchronize(0) != hipSuccess) rc = SGX_ERR_DEVICE;
     }
-    for (int i = 0; i < 8; i++) if (d[i]) (void)hipFree(d[i]);
     return rc;
 }
 
