@@ -38,9 +38,9 @@ def ring_concat(ring, cap):
     return out
 
 
-def run_tracker(lib, oracle, xp):
-    S = synth.PlaneStream(seed=1234)
-    offs = [0, 41]
+def run_tracker(lib, oracle, xp, stream_seed=1234, offs=(0, 41), nframes=5):
+    S = synth.PlaneStream(seed=stream_seed)
+    offs = list(offs)
     tr = TrackerBatch(lib, 2, CAM, xp=xp, debug_taps=True)
     cap = tr.cap
     rings = [[None, None], [None, None]]; prev = [None, None]
@@ -53,7 +53,7 @@ def run_tracker(lib, oracle, xp):
     tr.set_initial_pose(np.stack([S.Tcw(o) for o in offs]))
     sf = oracle.orb_params()['scale']; is2 = oracle.orb_params()['inv_sigma2']
     last = [None, None]; Tl = [S.Tcw(o).astype('f4') for o in offs]; Tll = [t.copy() for t in Tl]
-    for t in range(5):
+    for t in range(nframes):
         fr = [S.frame(o + t) for o in offs]
         gray = np.stack([f[0] for f in fr]); depth = np.stack([f[1] for f in fr])
         tr.step(D(gray), D(depth))
