@@ -127,7 +127,9 @@ def orb_extract(gray, nfeatures=1000, scale=1.2, nlevels=8, ini_th=20, min_th=7,
     n = lib().orc_orb_extract(_p(gray), C.c_int(w), C.c_int(h), C.c_int(w), C.c_int(nfeatures), C.c_float(scale),
                               C.c_int(nlevels), C.c_int(ini_th), C.c_int(min_th), _p(kps), _p(desc), C.c_int(cap),
                               _p(pyr) if want_pyr else None, _p(ncand))
-    assert n <= cap
+    if n == -2:
+        raise ValueError('a pyramid level is more than twice as tall as wide: DistributeOctTree is undefined there in the reference (nIni = 0)')
+    assert 0 <= n <= cap
     if want_pyr:
         return kps[:n].copy(), desc[:n].copy(), pyr, ncand
     return kps[:n].copy(), desc[:n].copy()

@@ -373,6 +373,7 @@ int orc_distribute_octree(const float *kx, const float *ky, const float *kresp, 
 {
     olist L; memset(&L, 0, sizeof L); L.head = L.tail = -1;
     const int nIni = (int)roundf((float)(maxX - minX) / (maxY - minY));
+    if (nIni < 1) return -2;                                  /* the reference divides by nIni and indexes an empty vector here (:544-566): undefined, reported */
     const float hX = (float)(maxX - minX) / nIni;
     int *ini = (int *)malloc(sizeof(int) * (nIni > 0 ? nIni : 1));
     for (int i = 0; i < nIni; i++) {
@@ -514,6 +515,11 @@ int orc_orb_extract(const uint8_t *gray, int w, int h, int stride,
     orc_params P; orc_orb_params(&P, nfeatures, scaleFactor, nlevels, iniTh, minTh);
     uint8_t *lv[ORC_MAX_LEVELS]; int lw[ORC_MAX_LEVELS], lh[ORC_MAX_LEVELS];
     size_t pyr_off = 0;
+    for (int l = 0; l < nlevels; l++) {           /* geometries on which the reference's DistributeOctTree is undefined (nIni = 0, :544-566): reported, like the product's create */
+        int lw_, lh_; orc_level_size(&P, w, h, l, &lw_, &lh_);
+        const int bw = lw_ - 2 * (EDGE_TH - 3), bh = lh_ - 2 * (EDGE_TH - 3);
+        if (bw < 1 || bh < 1 || (int)roundf((float)bw / (float)bh) < 1) return -2;
+    }
     for (int l = 0; l < nlevels; l++) {
         orc_level_size(&P, w, h, l, &lw[l], &lh[l]);
         lv[l] = (uint8_t *)malloc((size_t)lw[l] * lh[l]);

@@ -186,6 +186,9 @@ extern "C" int sgx_orb_create(const sgx_orb_config *cfg, sgx_orb **out)
             }
         }
         const int nIni = (int)roundf((float)(maxBX - minBX) / (float)(maxBY - minBY));
+        // a level whose bordered area is more than twice as tall as wide has nIni = 0 root nodes: the reference divides by it and indexes an empty vector
+        // (ORBextractor.cc:544-566, undefined behaviour) — refuse such geometries instead of returning a level without keypoints
+        if (nIni < 1 || nIni > 64) { sgx_orb_destroy(h); return SGX_ERR_UNSUPPORTED; }
         int lim = L.quota + 3; if (lim < 4 * nIni) lim = 4 * nIni;
         if (lim > SGX_OCT_MAXN) { sgx_orb_destroy(h); return SGX_ERR_UNSUPPORTED; }
         kp_cap += lim;

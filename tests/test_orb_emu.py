@@ -169,3 +169,14 @@ def run_other_parameters(lib, oracle):
 
 def test_other_parameters_emu(emu, oracle):
     run_other_parameters(emu, oracle)
+
+
+def test_portrait_geometry_is_refused(emu, oracle):
+    """a pyramid level more than twice as tall as wide gives DistributeOctTree nIni = round(w / h) = 0 root nodes; the reference then divides by zero and indexes an
+    empty vector (ORBextractor.cc:544-566).  Product and oracle report the geometry instead of returning a level without keypoints / crashing."""
+    with pytest.raises(Exception, match='unsupported'):
+        ORBextractor(lib=emu, width=264, height=579)
+    with pytest.raises(ValueError):
+        oracle.orb_extract(np.zeros((579, 264), np.uint8))
+    e = ORBextractor(lib=emu, width=300, height=560, nlevels=4)          # (300 - 32) / (560 - 32) = 0.51 -> one root node: still fine
+    e.close()
