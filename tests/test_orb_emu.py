@@ -178,5 +178,5 @@ def test_portrait_geometry_is_refused(emu, oracle):
         ORBextractor(lib=emu, width=264, height=579)
     with pytest.raises(ValueError):
         oracle.orb_extract(np.zeros((579, 264), np.uint8))
-    e = ORBextractor(lib=emu, width=300, height=560, nlevels=4)          # (300 - 32) / (560 - 32) = 0.51 -> one root node: still fine
+    e = ORBextractor(lib=emu, width=300, height=560, nlevels=2)          # (300 - 32) / (560 - 32) = 0.51, (250 - 32) / (467 - 32) = 0.50 -> one root node per level: fine
     e.close()
