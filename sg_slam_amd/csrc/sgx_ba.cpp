@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include <vector>
 
 #define SGX_CHECK_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
@@ -211,6 +212,9 @@ extern "C" int sgx_local_bundle_adjustment(const sgx_ba_problem *P, const sgx_ca
 {
     if (!P || !cam || !edge_erase || P->n_poses < 1 || P->n_points < 1 || P->n_edges < 1 || !P->poses || !P->pose_fixed || !P->points ||
         !P->edge_pose || !P->edge_point || !P->edge_obs || !P->edge_info) return SGX_ERR_INVALID;
+    // the device arena is one per process: calls from several threads (the reference has one LocalMapping thread, plus GlobalBundleAdjustment from LoopClosing) take turns
+    static std::mutex arena_mutex;
+    std::lock_guard<std::mutex> arena_lock(arena_mutex);
     BA B; memset((void *)&B, 0, offsetof(BA, hpart));
     B.np = P->n_poses; B.nl = P->n_points; B.ne = P->n_edges; B.stop = stop_flag;
     B.cam.fx = cam->fx; B.cam.fy = cam->fy; B.cam.cx = cam->cx; B.cam.cy = cam->cy; B.cam.bf = cam->bf;
