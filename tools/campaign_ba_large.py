@@ -13,7 +13,8 @@ from scenes import make_ba_problem, CAM
 from test_localba import close, points_close
 lib = SgxLib(os.path.join(ROOT, 'tests', 'emu', 'libsgx_emu.so'))
 rng = np.random.RandomState(int(sys.argv[1])); t0 = time.time(); n = bad = 0
-while time.time() - t0 < float(sys.argv[2]):
+MAXC = int(sys.argv[3]) if len(sys.argv) > 3 else None          # optional: stop after this many cases (deterministic runs)
+while time.time() - t0 < float(sys.argv[2]) and (MAXC is None or n < MAXC):
     nfree = int(rng.choice([23, 30, 44, 50, 64, 90])); nfix = int(rng.choice([3, 10, 25])); npts = int(rng.choice([1500, 3000, 5000]))
     seed = int(rng.randint(0, 1 << 30)); bo = float(rng.choice([0.0, 0.08, 0.2])); bm = float(rng.choice([0.0, 0.2, 0.6]))
     prob, _, _ = make_ba_problem(orc, n_free=nfree, n_fixed=nfix, n_points=npts, seed=seed, outlier_frac=bo, mono_frac=bm)

@@ -12,7 +12,8 @@ lib = SgxLib(os.path.join(ROOT, 'tests', 'emu', 'libsgx_emu.so'))
 seed0 = int(sys.argv[1]); rng = np.random.RandomState(seed0)
 sf = orc.orb_params()['scale']
 t0 = time.time(); n = 0; bad = 0
-while time.time() - t0 < float(sys.argv[2]):
+MAXC = int(sys.argv[3]) if len(sys.argv) > 3 else None          # optional: stop after this many cases (deterministic runs)
+while time.time() - t0 < float(sys.argv[2]) and (MAXC is None or n < MAXC):
     S = synth.PlaneStream(seed=int(rng.randint(0, 100000)))
     t = int(rng.randint(0, 60))
     mode = ['zero', 'mixed', 'all'][rng.randint(0, 3)]

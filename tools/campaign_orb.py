@@ -11,7 +11,8 @@ lib = SgxLib(os.path.join(ROOT, 'tests', 'emu', 'libsgx_emu.so'))
 ex = ORBextractor(lib=lib, max_batch=1)
 rng = np.random.RandomState(int(sys.argv[1]))
 t0 = time.time(); n = 0; bad = 0
-while time.time() - t0 < float(sys.argv[2]):
+MAXC = int(sys.argv[3]) if len(sys.argv) > 3 else None          # optional: stop after this many cases (deterministic runs)
+while time.time() - t0 < float(sys.argv[2]) and (MAXC is None or n < MAXC):
     kind = rng.randint(0, 6)
     tex = synth.world_texture(int(rng.randint(0, 10000)), 1000, 800)
     y0, x0 = rng.randint(0, 300), rng.randint(0, 300)

@@ -14,7 +14,8 @@ from oracle import oracle as orc
 lib = SgxLib(os.path.join(ROOT, 'tests', 'emu', 'libsgx_emu.so'))
 rng = np.random.RandomState(int(sys.argv[1])); t0 = time.time(); n = bad = refused = 0
 tex = synth.world_texture(int(sys.argv[1]), 1500, 1000)
-while time.time() - t0 < float(sys.argv[2]):
+MAXC = int(sys.argv[3]) if len(sys.argv) > 3 else None          # optional: stop after this many cases (deterministic runs)
+while time.time() - t0 < float(sys.argv[2]) and (MAXC is None or n < MAXC):
     w = int(rng.randint(160, 1301)); h = int(rng.randint(120, 801))
     nf = int(rng.choice([300, 500, 1000, 1200, 2000, 3000])); sf = float(rng.choice([1.1, 1.2, 1.3, 1.5])); nl = int(rng.randint(3, 11))
     ini = int(rng.choice([10, 20, 30])); mn = int(rng.choice([3, 7, 10]))

@@ -16,7 +16,8 @@ lib = SgxLib(os.path.join(ROOT, 'tests', 'emu', 'libsgx_emu.so'))
 is2 = orc.orb_params()['inv_sigma2']
 seed0 = int(sys.argv[1]); rng = np.random.RandomState(seed0)
 t0 = time.time(); npo = nba = bad = 0
-while time.time() - t0 < float(sys.argv[2]):
+MAXC = int(sys.argv[3]) if len(sys.argv) > 3 else None          # optional: stop after this many cases (deterministic runs)
+while time.time() - t0 < float(sys.argv[2]) and (MAXC is None or npo < MAXC):
     n = int(rng.choice([3, 5, 12, 40, 150, 400, 900, 1200])); mono = float(rng.choice([0.0, 0.15, 0.5, 1.0])); outl = float(rng.choice([0.0, 0.2, 0.5]))
     fr, _, _ = make_pose_problem(orc, n=n, seed=int(rng.randint(0, 1 << 30)), outlier_frac=outl, noise_px=float(rng.choice([0.0, 1.0, 3.0])), mono_frac=mono, init_sigma=float(rng.choice([0.005, 0.02, 0.08])))
     en, eT, eout = orc.pose_optimization(fr, CAM, is2)

@@ -10,7 +10,8 @@ from oracle import oracle as orc
 from test_tracker_emu import run_tracker
 lib = SgxLib(os.path.join(ROOT, 'tests', 'emu', 'libsgx_emu.so'))
 rng = np.random.RandomState(int(sys.argv[1])); t0 = time.time(); n = bad = 0
-while time.time() - t0 < float(sys.argv[2]):
+MAXC = int(sys.argv[3]) if len(sys.argv) > 3 else None          # optional: stop after this many cases (deterministic runs)
+while time.time() - t0 < float(sys.argv[2]) and (MAXC is None or n < MAXC):
     ss = int(rng.randint(0, 100000)); offs = (int(rng.randint(0, 80)), int(rng.randint(0, 80))); nf = int(rng.randint(4, 8))
     try:
         run_tracker(lib, orc, 'numpy', stream_seed=ss, offs=offs, nframes=nf)
