@@ -1,7 +1,7 @@
 """Differential campaign (CPU): ncnn DetectionOutput + detect() filtering alone (k_det_class_nms, k_det_merge through sgx_det_debug_detection_output) on random head
 outputs — box offsets of three spreads, score distributions with heavy ties, sparse and dense candidate sets, empty classes — through the kernel-logic emulator against
 the oracle: identical rows, labels, scores and order; boxes within 1e-5.  usage: python tools/campaign_detection_output.py <seed> <seconds>
-Round 1: 2 seeds x 900 s = 2 312 cases, 0 mismatches."""
+Round 1: 2 seeds x 900 s + 1 x 3000 s = 7 067 cases, 0 mismatches."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
