@@ -261,7 +261,7 @@ int sgx_det_debug_time_ops(sgx_det *h, const uint8_t *d_img, int pitch, int batc
 int sgx_det_debug_op_desc(const sgx_det *h, int i, char *buf, int cap);
 /* Frame::RmDynamicPointWithSemanticAndGeometry's keep/erase predicate (src/sg-slam/src/Frame.cc:556-597, :613-652): keep[i] = 1 when the
  * epipolar distance of (keypoint i, its LK-tracked previous position) under F (3x3 row-major fp64, cv::findFundamentalMat) is below
- * 0.2 px inside a person box / 1.0 px elsewhere.  boxes: max_boxes x (x, y, w, h) per frame.  The caller applies the
+ * 0.2 px inside a person box / 1.0 px elsewhere (an all-zero F = "no fundamental matrix": the frame keeps every keypoint).  boxes: max_boxes x (x, y, w, h) per frame.  The caller applies the
  * "restore everything when fewer than 0.1*nFeatures survive" rule (:599-604) and compacts keypoints + descriptor rows. */
 int sgx_dynamic_mask_batch_dev(int batch, int cap, const sgx_keypoint *d_keys, const int32_t *d_n, const float *d_prev_xy, const double *d_F,
                                const float *d_boxes, const int32_t *d_nboxes, int max_boxes, uint8_t *d_keep, void *stream);
@@ -270,6 +270,51 @@ int sgx_dynamic_mask_batch_dev(int batch, int cap, const sgx_keypoint *d_keys, c
  * keypoints of the frame are restored (:599-604).  Out of place; d_have_dynamic may be NULL (no dynamic object in any frame). */
 int sgx_frame_compact_keys_batch_dev(int batch, int cap, const sgx_keypoint *d_keys, const uint8_t *d_desc, const int32_t *d_n, const uint8_t *d_keep,
                                      const int32_t *d_have_dynamic, int nfeatures, sgx_keypoint *d_keys_out, uint8_t *d_desc_out, int32_t *d_n_out, void *stream);
+
+
+/* ---- inputs of the dynamic-feature mask: optical flow + fundamental matrix ------------------------
+ * What Frame::RmDynamicPointWithSemanticAndGeometry computes before its erase loop (src/sg-slam/src/Frame.cc:430-472):
+ *   :445     cv::calcOpticalFlowPyrLK(imGray, imGrayPre, Curpoint, Prepoint, State, Err, Size(21,21), 3, TermCriteria(ITER|EPS, 30, 0.01))
+ *            — every keypoint of the current frame tracked into the PREVIOUS frame (State / Err are ignored by the caller)
+ *   :454-467 the pairs whose previous position lies outside the previous frame's person boxes (vPreFramePotentialDynamicBorder)
+ *   :469-472 cv::findFundamentalMat(cur, prev, FM_RANSAC, 1.0, 0.99) on that selection when more than 20 pairs remain, else on all pairs
+ * A sgx_flow handle owns the two image pyramids (current / previous) like the file-scope `imGrayPre` of Frame.cc:31,155-163: each
+ * sgx_flow_lk_batch_dev call builds the pyramid (+ Scharr derivatives) of the new frames, tracks into the pyramid kept from the previous call,
+ * and swaps.  OpenCV 3.4 semantics (lkpyramid.cpp, pyramids.cpp); sums are accumulated exactly (the library's int64 `acctype` variant). */
+typedef struct sgx_flow_config {
+    int32_t width, height, max_batch;
+    int32_t win_size;       /* 21 (only value supported) */
+    int32_t max_level;      /* 3  (0..3) */
+    int32_t max_count;      /* 30 */
+    double epsilon;         /* 0.01 */
+} sgx_flow_config;
+typedef struct sgx_flow sgx_flow;
+int sgx_flow_create(const sgx_flow_config *cfg, sgx_flow **out);
+void sgx_flow_destroy(sgx_flow *h);
+int sgx_flow_reset(sgx_flow *h);                 /* forget the previous frame (imGrayPre.data == NULL) */
+int sgx_flow_levels(const sgx_flow *h);          /* pyramid levels actually used (buildOpticalFlowPyramid stops when a level is not larger than the window) */
+/* d_gray: batch frames of height rows x pitch bytes (pitch and pointer multiples of 4).  When the handle holds a previous batch of the same size:
+ * d_prev_xy[f*cap + i] = (x, y) of keypoint i of frame f in the previous frame (nextPts), d_status (optional) = State; *have_prev (host, optional) = 1.
+ * First call after create / reset: only the pyramid is built, *have_prev = 0 (the reference skips the whole mask step, Frame.cc:155-163).
+ * Asynchronous on `stream`. */
+int sgx_flow_lk_batch_dev(sgx_flow *h, const uint8_t *d_gray, int pitch, int batch, const sgx_keypoint *d_keys, const int32_t *d_n, int cap,
+                          float *d_prev_xy, uint8_t *d_status, int32_t *have_prev, void *stream);
+/* cv::calcOpticalFlowPyrLK(gray_from, gray_to, pts, next_pts, status, ...) on one host image pair (n points, 2 floats each).  Synchronous; resets the streaming state. */
+int sgx_flow_lk(sgx_flow *h, const uint8_t *gray_from, const uint8_t *gray_to, int stride, const float *pts, int n, float *next_pts, uint8_t *status);
+int sgx_flow_debug_read_level(sgx_flow *h, int slot, int frame, int level, uint8_t *img, int16_t *der);     /* test tap */
+int sgx_flow_debug_level_size(const sgx_flow *h, int level, int32_t *w, int32_t *hgt);
+/* Frame.cc:454-472 for `batch` frames: pair selection against the PREVIOUS frame's person boxes (d_pre_have_dynamic = bPreFrameHavePotentialDynamicObj,
+ * d_pre_boxes / d_pre_nboxes = vPreFramePotentialDynamicBorder in the layout sgx_det_detect_batch_dev writes; all three may be NULL) and
+ * cv::findFundamentalMat(FM_RANSAC, threshold, confidence): cv::RNG(-1) sampling, 7-point solver, symmetric epipolar error, adaptive iteration count,
+ * no refit (fundam.cpp, ptsetreg.cpp).  d_F: 9 doubles per frame, row-major, x_prev^T F x_cur = 0 (what sgx_dynamic_mask_batch_dev takes);
+ * d_ok[f] = 0 when OpenCV would return an empty Mat (fewer than 7 pairs, or no model) — F is then all zeros and the mask keeps every keypoint of
+ * that frame (the reference indexes the empty Mat: undefined behaviour).  8..14 pairs (OpenCV switches to LMedS) also give d_ok = 0.
+ * d_stats (optional): 4 ints per frame — RANSAC iterations run, iteration and root index of the returned model, its inlier count. */
+int sgx_fundamental_ransac_batch_dev(int batch, int cap, const sgx_keypoint *d_keys, const int32_t *d_n, const float *d_prev_xy,
+                                     const int32_t *d_pre_have_dynamic, const float *d_pre_boxes, const int32_t *d_pre_nboxes, int max_boxes,
+                                     double threshold, double confidence, double *d_F, int32_t *d_ok, int32_t *d_stats, void *stream);
+/* cv::findFundamentalMat(pts1, pts2, FM_RANSAC, threshold, confidence) on host points.  Synchronous. */
+int sgx_find_fundamental_mat(const float *pts1, const float *pts2, int n, double threshold, double confidence, double *F, int32_t *ok, int32_t *stats);
 
 /* run the octree-distribution kernel alone on packed candidates (x | y<<12 | score<<24, coordinates
  * relative to the (16,16) border origin) for `level`; returns the selected packed entries in list order */

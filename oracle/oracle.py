@@ -239,3 +239,61 @@ def search_by_projection_local(cur, lm, cam, scale_factors, th=3.0, nnratio=0.8,
         C.c_float(cam.get('min_x', 0.0)), C.c_float(cam.get('max_x', 640.0)), C.c_float(cam.get('min_y', 0.0)), C.c_float(cam.get('max_y', 480.0)),
         _p(sf), C.c_int(len(sf)), C.c_float(np.log(np.float32(sf[1]))), C.c_float(th), C.c_float(nnratio), C.c_float(viewing_cos_limit), _p(match), _p(inview))
     return match[:len(ck)], int(n), inview[:len(xw)]
+
+
+# ---- mask inputs: pyramidal LK + RANSAC fundamental matrix (oracle/flow_oracle.c) ---------------
+def pyr_down(img):
+    img = np.ascontiguousarray(img, np.uint8); h, w = img.shape
+    dw, dh = (w + 1) // 2, (h + 1) // 2
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().orc_pyrdown_u8(_p(img), C.c_int(w), C.c_int(h), C.c_int(w), _p(dst), C.c_int(dw), C.c_int(dh), C.c_int(dw))
+    return dst
+
+
+def scharr_deriv(img):
+    img = np.ascontiguousarray(img, np.uint8); h, w = img.shape
+    d = np.zeros((h, w, 2), np.int16)
+    lib().orc_scharr_deriv(_p(img), C.c_int(w), C.c_int(h), C.c_int(w), _p(d))
+    return d
+
+
+def lk_pyr(I, J, pts, win=21, max_level=3, max_count=30, epsilon=0.01, acc_mode=1, want_iters=False):
+    """cv::calcOpticalFlowPyrLK(I, J, pts, ...) restatement: (next_pts[n,2] f32, status[n] u8 [, iters[n,levels]])."""
+    I = np.ascontiguousarray(I, np.uint8); J = np.ascontiguousarray(J, np.uint8); h, w = I.shape
+    pts = np.ascontiguousarray(pts, 'f4').reshape(-1, 2); n = len(pts)
+    out = np.zeros((max(n, 1), 2), 'f4'); st = np.zeros(max(n, 1), np.uint8); it = np.zeros((max(n, 1), 8), 'i4')
+    itl = np.zeros((max(n, 1) * 8,), 'i4')
+    nl = lib().orc_lk_pyr(_p(I), _p(J), C.c_int(w), C.c_int(h), C.c_int(w), _p(pts), C.c_int(n), _p(out), _p(st), C.c_int(win), C.c_int(max_level),
+                          C.c_int(max_count), C.c_double(epsilon), C.c_int(acc_mode), _p(itl))
+    if want_iters:
+        return out[:n], st[:n], itl[:n * nl].reshape(n, nl)
+    return out[:n], st[:n]
+
+
+def fm_select(cur, prev, pre_have_dynamic, boxes):
+    cur = np.ascontiguousarray(cur, 'f4').reshape(-1, 2); prev = np.ascontiguousarray(prev, 'f4').reshape(-1, 2); n = len(cur)
+    boxes = np.ascontiguousarray(boxes, 'f4').reshape(-1, 4)
+    co = np.zeros((max(n, 1), 2), 'f4'); po = np.zeros((max(n, 1), 2), 'f4')
+    m = lib().orc_fm_select(_p(cur), _p(prev), C.c_int(n), C.c_int(int(pre_have_dynamic)), _p(boxes), C.c_int(len(boxes)), _p(co), _p(po))
+    return co[:m], po[:m]
+
+
+def fm_run7point(m1, m2):
+    m1 = np.ascontiguousarray(m1, 'f4').reshape(7, 2); m2 = np.ascontiguousarray(m2, 'f4').reshape(7, 2)
+    f = np.zeros((3, 9), 'f8')
+    n = lib().orc_fm_run7point(_p(m1), _p(m2), _p(f))
+    return f[:max(n, 0)].reshape(-1, 3, 3)
+
+
+def find_fundamental_ransac(m1, m2, threshold=1.0, confidence=0.99):
+    """cv::findFundamentalMat(m1, m2, FM_RANSAC, threshold, confidence): (ok, F[3,3] f64, inlier mask, stats[iters, best_iter, best_root, inliers])."""
+    m1 = np.ascontiguousarray(m1, 'f4').reshape(-1, 2); m2 = np.ascontiguousarray(m2, 'f4').reshape(-1, 2); n = len(m1)
+    F = np.zeros(9, 'f8'); mask = np.zeros(max(n, 1), np.uint8); stats = np.zeros(4, 'i4')
+    ok = lib().orc_find_fundamental_ransac(_p(m1), _p(m2), C.c_int(n), C.c_double(threshold), C.c_double(confidence), _p(F), _p(mask), _p(stats))
+    return int(ok), F.reshape(3, 3), mask[:n], stats
+
+
+def solve_cubic(c):
+    c = np.ascontiguousarray(c, 'f8'); r = np.zeros(3, 'f8')
+    n = lib().orc_solve_cubic(_p(c), _p(r))
+    return int(n), r

@@ -42,6 +42,11 @@ class DetResult(C.Structure):
                 ('n_map_boxes', C.c_int32), ('map_boxes', Object2D * SGX_DET_MAX), ('n_rm_boxes', C.c_int32), ('rm_boxes', Object2D * SGX_DET_MAX)]
 
 
+class FlowConfig(C.Structure):
+    _fields_ = [('width', C.c_int32), ('height', C.c_int32), ('max_batch', C.c_int32), ('win_size', C.c_int32), ('max_level', C.c_int32),
+                ('max_count', C.c_int32), ('epsilon', C.c_double)]
+
+
 class OrbConfig(C.Structure):
     _fields_ = [('nfeatures', C.c_int32), ('scale_factor', C.c_float), ('nlevels', C.c_int32),
                 ('ini_th_fast', C.c_int32), ('min_th_fast', C.c_int32), ('width', C.c_int32),
@@ -62,6 +67,8 @@ SYMBOLS = [
     'sgx_det_create', 'sgx_det_destroy', 'sgx_det_info', 'sgx_det_detect', 'sgx_det_detect_batch_dev', 'sgx_det_forward_batch_dev', 'sgx_det_debug_read_blob', 'sgx_det_debug_detection_output',
     'sgx_frame_compact_keys_batch_dev', 'sgx_frame_gray_from_color_batch_dev', 'sgx_debug_flow_affine_batch_dev', 'sgx_det_debug_set_fusion', 'sgx_det_debug_set_legacy_kernels', 'sgx_det_debug_time_ops', 'sgx_det_debug_op_desc',
     'sgx_dynamic_mask_batch_dev',
+    'sgx_flow_create', 'sgx_flow_destroy', 'sgx_flow_reset', 'sgx_flow_levels', 'sgx_flow_lk_batch_dev', 'sgx_flow_lk', 'sgx_flow_debug_read_level', 'sgx_flow_debug_level_size',
+    'sgx_fundamental_ransac_batch_dev', 'sgx_find_fundamental_mat',
 ]
 
 
@@ -133,6 +140,16 @@ class SgxLib:
         d.sgx_match_project_local_batch_dev.argtypes = [C.c_int, C.c_int] + [vp] * 6 + [C.c_int] + [vp] * 8 + [C.POINTER(Camera), vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp, vp, vp]
         d.sgx_frame_make_map_points_batch_dev.argtypes = [C.c_int, C.c_int, C.c_int] + [vp] * 7 + [C.c_int] + [vp] * 7
         d.sgx_frame_merge_matches_batch_dev.argtypes = [C.c_int, C.c_int] + [vp] * 10
+        d.sgx_flow_create.argtypes = [C.POINTER(FlowConfig), C.POINTER(vp)]
+        d.sgx_flow_destroy.argtypes = [vp]; d.sgx_flow_destroy.restype = None
+        d.sgx_flow_reset.argtypes = [vp]
+        d.sgx_flow_levels.argtypes = [vp]
+        d.sgx_flow_lk_batch_dev.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, C.POINTER(C.c_int32), vp]
+        d.sgx_flow_lk.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, vp, vp]
+        d.sgx_flow_debug_read_level.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
+        d.sgx_flow_debug_level_size.argtypes = [vp, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        d.sgx_fundamental_ransac_batch_dev.argtypes = [C.c_int, C.c_int] + [vp] * 6 + [C.c_int, C.c_double, C.c_double, vp, vp, vp, vp]
+        d.sgx_find_fundamental_mat.argtypes = [vp, vp, C.c_int, C.c_double, C.c_double, vp, vp, vp]
 
     def version(self):
         return self.dll.sgx_version().decode()

@@ -615,13 +615,16 @@ SGX_KERNEL(256) k_dynamic_mask(int cap, const uint8_t *keys_raw, const int *n, c
             const double a = x * Fm[0] + y * Fm[1] + Fm[2], b = x * Fm[3] + y * Fm[4] + Fm[5], c = x * Fm[6] + y * Fm[7] + Fm[8];
             const float px = prev_xy[2 * ((size_t)f * cap + i)], py = prev_xy[2 * ((size_t)f * cap + i) + 1];
             const double dist = fabs(a * px + b * py + c) / sqrt(a * a + b * b);
+            // an all-zero F is how sgx_fundamental_ransac_batch_dev reports "cv::findFundamentalMat returned an empty Mat" (fewer than 7 pairs / no
+            // model): the reference then reads F12.at<double>() of an empty matrix (undefined behaviour); here such a frame keeps all its keypoints
+            const bool noF = Fm[0] == 0. && Fm[1] == 0. && Fm[2] == 0. && Fm[3] == 0. && Fm[4] == 0. && Fm[5] == 0. && Fm[6] == 0. && Fm[7] == 0. && Fm[8] == 0.;
             bool inbox = false;
             const int nb = nboxes[f];
             for (int q = 0; q < nb && q < max_boxes; q++) {
                 const float *r = boxes + 4 * ((size_t)f * max_boxes + q);
                 if (x > r[0] && x < r[0] + r[2] && y > r[1] && y < r[1] + r[3]) { inbox = true; break; }
             }
-            k = dist < (inbox ? 0.2 : 1.0) ? 1 : 0;
+            k = (noF || dist < (inbox ? 0.2 : 1.0)) ? 1 : 0;
         }
         keep[(size_t)f * cap + i] = k;
     }

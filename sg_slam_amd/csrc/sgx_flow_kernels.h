@@ -1,0 +1,736 @@
+// sgx_flow_kernels.h — the inputs of the dynamic-feature mask on the device (tier N1 of SURVEY.md §8):
+//   cv::calcOpticalFlowPyrLK(imGray, imGrayPre, Curpoint, Prepoint, State, Err, Size(21,21), 3, TermCriteria(ITER|EPS, 30, 0.01))
+//                                                                                   src/sg-slam/src/Frame.cc:445
+//   point selection outside the previous frame's person boxes                       src/sg-slam/src/Frame.cc:454-467
+//   cv::findFundamentalMat(cur, prev, FM_RANSAC, 1.0, 0.99)                         src/sg-slam/src/Frame.cc:469-472
+// OpenCV 3.4 algorithms as restated in oracle/flow_oracle.c (lkpyramid.cpp, pyramids.cpp, fundam.cpp, ptsetreg.cpp).
+//
+// Kernels
+//   k_lk_copy       level 0 of the LK pyramid = a pitch-aligned copy of the frame (it becomes "imGrayPre" of the next call)
+//   k_lk_pyrdown    cv::pyrDown: 5x5 [1 4 6 4 1]^2, (sum + 128) >> 8, REFLECT_101 — four outputs per thread from aligned dwords
+//   k_lk_scharr     calcSharrDeriv: interleaved int16 (dI/dx, dI/dy), REFLECT_101 inside, four pixels per thread, one 16-byte store
+//   k_lk_track      LKTrackerInvoker: ONE WAVE PER KEYPOINT, all pyramid levels chained in one launch.  Lane (r, s) owns window row r and the seven
+//                   columns 7s..7s+6 (63 lanes = 21 x 21 samples): its window intensities and derivatives stay in registers for all iterations; the
+//                   tracked-to image patch sits in a per-wave LDS tile (32 rows x 36 B, re-staged only when the window walks out of it).  Every sum
+//                   (2x2 gradient matrix, mismatch vector) is accumulated as EXACT integers — per lane in 32 bits, across the wave as two 16-bit
+//                   halves through DPP row reductions — and converted to float once: the order-free variant of OpenCV's accumulation
+//                   (`typedef int64 acctype`), bit-identical to oracle acc_mode 1.  The per-iteration float arithmetic follows lkpyramid.cpp operation
+//                   by operation (-ffp-contract=off).
+//   k_fm_ransac     one workgroup per frame: pair selection (block scan), then RANSAC in chunks: thread 0 advances cv::RNG and forms the 7-index
+//                   groups, a thread per group runs checkSubset + run7Point (Householder null space, cv::solveCubic) in fp64, all threads score the
+//                   models (FMEstimatorCallback::computeError), thread 0 replays the sequential accept / RANSACUpdateNumIters rule in iteration
+//                   order — same samples, same winner as the sequential library loop.
+#pragma once
+#include "sgx_rt.h"
+#include "sgx_block.h"
+#include <float.h>
+#include <math.h>
+
+#define SGX_LK_MAXL 4                 /* pyramid levels (maxLevel <= 3, Frame.cc:445 passes 3) */
+#define SGX_LK_WIN 21                 /* winSize (the lane mapping of k_lk_track is built for 21 x 21) */
+#define SGX_LK_TILE_ROWS 32
+#define SGX_LK_TILE_PITCH 36          /* bytes per LDS tile row: 9 dwords (odd dword stride) */
+struct SgxLkGeom {
+    int nl;
+    int w[SGX_LK_MAXL], h[SGX_LK_MAXL], pitch[SGX_LK_MAXL];
+    unsigned ioff[SGX_LK_MAXL];       /* byte offset of level l inside a frame's image block */
+    unsigned doff[SGX_LK_MAXL];       /* byte offset of level l inside a frame's derivative block (row pitch = 4 * w) */
+    unsigned img_stride, der_stride;  /* bytes per frame */
+};
+
+SGX_DEV int sgx_reflect101(int p, int len)      /* cv::borderInterpolate(p, len, BORDER_REFLECT_101), any p */
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) { if (p < 0) p = -p; else p = 2 * len - 2 - p; }
+    return p;
+}
+SGX_DEV int sgx_floor_f(float v) { return (int)floorf(v); }
+/* exact int64 -> float (round to nearest even), |v| < 2^47: (v >> 24) and the 24-bit remainder are both exact floats, one rounding in the add */
+SGX_DEV float sgx_i64_to_f32(long long v)
+{
+    const long long hi = v >> 24; const int lo = (int)(v - (hi << 24));
+    return (float)(int)hi * 16777216.0f + (float)lo;
+}
+
+// ---------------------------------------------------------------------------------------------
+SGX_KERNEL(256) k_lk_copy(const uint8_t *src, int w, int h, int spitch, uint8_t *dst, int dpitch, unsigned dstride)
+{
+    SGX_THREADS_BEGIN(tid)
+    const int f = (int)blockIdx.y, qw = dpitch >> 2, q = (int)blockIdx.x * 256 + tid;
+    if (q < qw * h) {
+        const int y = q / qw, x = (q - y * qw) * 4;
+        const uint8_t *s = src + ((size_t)f * h + y) * spitch;
+        uint32_t v;
+        if (x + 4 <= w) v = *(const uint32_t *)(s + x);
+        else { v = 0; for (int i = 0; x + i < w; i++) v |= (uint32_t)s[x + i] << (8 * i); }
+        *(uint32_t *)(dst + (size_t)f * dstride + (size_t)y * dpitch + x) = v;
+    }
+    SGX_THREADS_END
+}
+
+// cv::pyrDown (pyramids.cpp, pyrDown_<FixPtCast<uchar,8>>): dst(x, y) = (sum_{i,j} k_i k_j src(2x-2+i, 2y-2+j) + 128) >> 8, k = [1 4 6 4 1]
+SGX_KERNEL(256) k_lk_pyrdown(const uint8_t *src, int sw, int sh, int spitch, unsigned sstride, uint8_t *dst, int dw, int dh, int dpitch, unsigned dstride)
+{
+    SGX_THREADS_BEGIN(tid)
+    const int f = (int)blockIdx.y, qw = dpitch >> 2, q = (int)blockIdx.x * 256 + tid;
+    if (q < qw * dh) {
+        const int y = q / qw, X = (q - y * qw) * 4;
+        const uint8_t *S = src + (size_t)f * sstride;
+        int acc[4] = { 0, 0, 0, 0 };
+        const bool fast = X >= 2 && 2 * X + 11 < spitch && 2 * X + 8 <= sw - 1;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int wk = k == 0 || k == 4 ? 1 : k == 2 ? 6 : 4;
+            const uint8_t *row = S + (size_t)sgx_reflect101(2 * y - 2 + k, sh) * spitch;
+            int p[11];
+            if (fast) {
+                const uint32_t *r4 = (const uint32_t *)(row + 2 * X - 4);
+                const uint32_t a = r4[0], b = r4[1], c = r4[2], d = r4[3];
+                p[0] = (a >> 16) & 255; p[1] = a >> 24;
+                p[2] = b & 255; p[3] = (b >> 8) & 255; p[4] = (b >> 16) & 255; p[5] = b >> 24;
+                p[6] = c & 255; p[7] = (c >> 8) & 255; p[8] = (c >> 16) & 255; p[9] = c >> 24;
+                p[10] = d & 255;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 11; i++) p[i] = row[sgx_reflect101(2 * X - 2 + i, sw)];
+            }
+#pragma unroll
+            for (int o = 0; o < 4; o++) acc[o] += wk * (p[2 * o + 2] * 6 + (p[2 * o + 1] + p[2 * o + 3]) * 4 + p[2 * o] + p[2 * o + 4]);
+        }
+        uint32_t out = 0;
+#pragma unroll
+        for (int o = 0; o < 4; o++) out |= (uint32_t)((acc[o] + 128) >> 8) << (8 * o);       /* columns >= dw of the last quad are padding */
+        *(uint32_t *)(dst + (size_t)f * dstride + (size_t)y * dpitch + X) = out;
+    }
+    SGX_THREADS_END
+}
+
+// calcSharrDeriv (lkpyramid.cpp): dx = [3 10 3]^T (rows) x [-1 0 1] (cols), dy = [-1 0 1]^T x [3 10 3]; neighbours outside the image are REFLECT_101
+SGX_KERNEL(256) k_lk_scharr(const uint8_t *img, int w, int h, int pitch, unsigned istride, int16_t *der, unsigned dstride)
+{
+    SGX_THREADS_BEGIN(tid)
+    const int f = (int)blockIdx.y, qw = (w + 3) >> 2, q = (int)blockIdx.x * 256 + tid;
+    if (q < qw * h) {
+        const int y = q / qw, X = (q - y * qw) * 4;
+        const uint8_t *S = img + (size_t)f * istride;
+        const uint8_t *r0 = S + (size_t)(y > 0 ? y - 1 : h > 1 ? 1 : 0) * pitch, *r1 = S + (size_t)y * pitch, *r2 = S + (size_t)(y < h - 1 ? y + 1 : h > 1 ? h - 2 : 0) * pitch;
+        int t0[6], t1[6];                       /* columns X-1 .. X+4: smoothed (3,10,3) and differenced (-1,0,1) column sums */
+        if (X >= 4 && X + 4 <= w - 1 && X + 8 <= pitch) {
+            const uint32_t a0 = *(const uint32_t *)(r0 + X - 4), b0 = *(const uint32_t *)(r0 + X), c0 = *(const uint32_t *)(r0 + X + 4);
+            const uint32_t a1 = *(const uint32_t *)(r1 + X - 4), b1 = *(const uint32_t *)(r1 + X), c1 = *(const uint32_t *)(r1 + X + 4);
+            const uint32_t a2 = *(const uint32_t *)(r2 + X - 4), b2 = *(const uint32_t *)(r2 + X), c2 = *(const uint32_t *)(r2 + X + 4);
+            const int p0[6] = { (int)(a0 >> 24), (int)(b0 & 255), (int)((b0 >> 8) & 255), (int)((b0 >> 16) & 255), (int)(b0 >> 24), (int)(c0 & 255) };
+            const int p1[6] = { (int)(a1 >> 24), (int)(b1 & 255), (int)((b1 >> 8) & 255), (int)((b1 >> 16) & 255), (int)(b1 >> 24), (int)(c1 & 255) };
+            const int p2[6] = { (int)(a2 >> 24), (int)(b2 & 255), (int)((b2 >> 8) & 255), (int)((b2 >> 16) & 255), (int)(b2 >> 24), (int)(c2 & 255) };
+#pragma unroll
+            for (int i = 0; i < 6; i++) { t0[i] = (p0[i] + p2[i]) * 3 + p1[i] * 10; t1[i] = p2[i] - p0[i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                int c = X - 1 + i;
+                c = c < 0 ? (w > 1 ? 1 : 0) : c >= w ? (c == w ? (w > 1 ? w - 2 : 0) : w - 1) : c;        /* only columns -1 and w are ever used beyond the image */
+                t0[i] = (r0[c] + r2[c]) * 3 + r1[c] * 10; t1[i] = r2[c] - r0[c];
+            }
+        }
+        uint32_t o[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int dx = t0[i + 2] - t0[i], dy = (t1[i + 2] + t1[i]) * 3 + t1[i + 1] * 10;
+            o[i] = (uint32_t)(dx & 0xFFFF) | ((uint32_t)(dy & 0xFFFF) << 16);
+        }
+        uint32_t *d = (uint32_t *)((uint8_t *)der + (size_t)f * dstride) + (size_t)y * w + X;
+        for (int i = 0; i < 4 && X + i < w; i++) d[i] = o[i];
+    }
+    SGX_THREADS_END
+}
+
+// ---------------------------------------------------------------------------------------------
+// LKTrackerInvoker
+// ---------------------------------------------------------------------------------------------
+struct SgxLkWeights { int w00, w01, w10, w11; };
+SGX_DEV SgxLkWeights sgx_lk_weights(float a, float b)            /* lkpyramid.cpp: W_BITS = 14, iw11 is the remainder */
+{
+    SgxLkWeights k;
+    k.w00 = sgx_cvround((1.f - a) * (1.f - b) * (float)(1 << 14));
+    k.w01 = sgx_cvround(a * (1.f - b) * (float)(1 << 14));
+    k.w10 = sgx_cvround((1.f - a) * b * (float)(1 << 14));
+    k.w11 = (1 << 14) - k.w00 - k.w01 - k.w10;
+    return k;
+}
+#define SGX_LK_DESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
+
+#ifndef SGX_EMU
+/* sum over the 64 lanes of a wave of a non-negative-or-small int (no overflow by construction at the call sites); the result is wave-uniform.
+ * Four DPP adds give every lane its 16-lane row total (xor 1, xor 2 inside quads, rotate by 4 and by 8 inside the row); the four row totals meet in
+ * scalar registers. */
+SGX_DEV int sgx_wave_sum_i32(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);      /* quad_perm [1,0,3,2] */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);      /* quad_perm [2,3,0,1] */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, true);     /* row_ror:4 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, true);     /* row_ror:8 */
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+/* exact wave sum of per-lane int32 partials (|v| < 2^31) as int64: low 16 bits and the signed high part are reduced separately (each fits 32 bits) */
+SGX_DEV long long sgx_wave_sum_i64(int v)
+{
+    const int lo = sgx_wave_sum_i32(v & 0xFFFF), hi = sgx_wave_sum_i32(v >> 16);
+    return (long long)hi * 65536 + lo;
+}
+#endif
+
+/* the part of one level that is the same on every lane: OpenCV's float arithmetic, operation by operation */
+struct SgxLkStep { float dx, dy; };
+SGX_DEV SgxLkStep sgx_lk_step(float A11, float A12, float A22, float D, long long sb1, long long sb2)
+{
+    const float FLT_SCALE = 1.f / (1 << 20);
+    const float b1 = sgx_i64_to_f32(sb1) * FLT_SCALE, b2 = sgx_i64_to_f32(sb2) * FLT_SCALE;
+    SgxLkStep s;
+    s.dx = (A12 * b2 - A22 * b1) * D;
+    s.dy = (A12 * b1 - A11 * b2) * D;
+    return s;
+}
+
+struct SgxLkArgs {
+    const uint8_t *cur_img, *prev_img;       /* per-frame image blocks (SgxLkGeom offsets) */
+    const int16_t *cur_der;
+    const uint8_t *keys; const int *n; int cap;
+    float *prev_xy; uint8_t *status;
+    int max_count; double eps2; float min_eig;
+};
+
+#ifdef SGX_EMU
+// scalar twin of the wave kernel (kernel-logic emulator only): same integer sums, same float steps
+static void sgx_lk_track_point(const SgxLkGeom &g, const uint8_t *I0, const int16_t *D0, const uint8_t *J0, float kx, float ky, int max_count, double eps2, float min_eig,
+                               float *ox, float *oy, uint8_t *ost)
+{
+    const int W = SGX_LK_WIN; const float half = (W - 1) * 0.5f, FLT_SCALE = 1.f / (1 << 20);
+    float outx = 0.f, outy = 0.f; uint8_t status = 1;
+    static thread_local short Iw[SGX_LK_WIN * SGX_LK_WIN], dIw[SGX_LK_WIN * SGX_LK_WIN * 2];
+    for (int level = g.nl - 1; level >= 0; level--) {
+        const int w = g.w[level], h = g.h[level], pitch = g.pitch[level];
+        const uint8_t *I = I0 + g.ioff[level], *J = J0 + g.ioff[level];
+        const int16_t *Dv = (const int16_t *)((const uint8_t *)D0 + g.doff[level]);
+        const float sc = 1.0f / (float)(1 << level);
+        float prevx = kx * sc, prevy = ky * sc, nextx, nexty;
+        if (level == g.nl - 1) { nextx = prevx; nexty = prevy; } else { nextx = outx * 2.f; nexty = outy * 2.f; }
+        outx = nextx; outy = nexty;
+        prevx -= half; prevy -= half;
+        const int ipx = sgx_floor_f(prevx), ipy = sgx_floor_f(prevy);
+        if (ipx < -W || ipx >= w || ipy < -W || ipy >= h) { if (level == 0) status = 0; continue; }
+        SgxLkWeights k = sgx_lk_weights(prevx - ipx, prevy - ipy);
+        long long s11 = 0, s12 = 0, s22 = 0;
+        for (int y = 0; y < W; y++) for (int x = 0; x < W; x++) {
+            int pv[4], dx[4], dy[4];
+            for (int c = 0; c < 4; c++) {
+                const int gx = ipx + x + (c & 1), gy = ipy + y + (c >> 1);
+                pv[c] = I[(size_t)sgx_reflect101(gy, h) * pitch + sgx_reflect101(gx, w)];
+                if (gx < 0 || gy < 0 || gx >= w || gy >= h) { dx[c] = dy[c] = 0; } else { dx[c] = Dv[((size_t)gy * w + gx) * 2]; dy[c] = Dv[((size_t)gy * w + gx) * 2 + 1]; }
+            }
+            const int iv = SGX_LK_DESCALE(pv[0] * k.w00 + pv[1] * k.w01 + pv[2] * k.w10 + pv[3] * k.w11, 9);
+            const int ix = SGX_LK_DESCALE(dx[0] * k.w00 + dx[1] * k.w01 + dx[2] * k.w10 + dx[3] * k.w11, 14);
+            const int iy = SGX_LK_DESCALE(dy[0] * k.w00 + dy[1] * k.w01 + dy[2] * k.w10 + dy[3] * k.w11, 14);
+            Iw[y * W + x] = (short)iv; dIw[(y * W + x) * 2] = (short)ix; dIw[(y * W + x) * 2 + 1] = (short)iy;
+            s11 += (long long)ix * ix; s12 += (long long)ix * iy; s22 += (long long)iy * iy;
+        }
+        const float A11 = sgx_i64_to_f32(s11) * FLT_SCALE, A12 = sgx_i64_to_f32(s12) * FLT_SCALE, A22 = sgx_i64_to_f32(s22) * FLT_SCALE;
+        float D = A11 * A22 - A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * W * W);
+        if (minEig < min_eig || D < FLT_EPSILON) { if (level == 0) status = 0; continue; }
+        D = 1.f / D;
+        nextx -= half; nexty -= half;
+        float pdx = 0.f, pdy = 0.f;
+        for (int j = 0; j < max_count; j++) {
+            const int inx = sgx_floor_f(nextx), iny = sgx_floor_f(nexty);
+            if (inx < -W || inx >= w || iny < -W || iny >= h) { if (level == 0) status = 0; break; }
+            k = sgx_lk_weights(nextx - inx, nexty - iny);
+            long long sb1 = 0, sb2 = 0;
+            for (int y = 0; y < W; y++) for (int x = 0; x < W; x++) {
+                int pv[4];
+                for (int c = 0; c < 4; c++) pv[c] = J[(size_t)sgx_reflect101(iny + y + (c >> 1), h) * pitch + sgx_reflect101(inx + x + (c & 1), w)];
+                const int diff = SGX_LK_DESCALE(pv[0] * k.w00 + pv[1] * k.w01 + pv[2] * k.w10 + pv[3] * k.w11, 9) - Iw[y * W + x];
+                sb1 += (long long)diff * dIw[(y * W + x) * 2]; sb2 += (long long)diff * dIw[(y * W + x) * 2 + 1];
+            }
+            const SgxLkStep st = sgx_lk_step(A11, A12, A22, D, sb1, sb2);
+            nextx += st.dx; nexty += st.dy;
+            outx = nextx + half; outy = nexty + half;
+            if ((double)st.dx * st.dx + (double)st.dy * st.dy <= eps2) break;
+            if (j > 0 && fabs((double)(st.dx + pdx)) < 0.01 && fabs((double)(st.dy + pdy)) < 0.01) { outx -= st.dx * 0.5f; outy -= st.dy * 0.5f; break; }
+            pdx = st.dx; pdy = st.dy;
+        }
+        if (status && level == 0) {
+            const int ix = sgx_floor_f(outx - half), iy = sgx_floor_f(outy - half);
+            if (ix < -W || ix >= w || iy < -W || iy >= h) status = 0;
+        }
+    }
+    *ox = outx; *oy = outy; *ost = status;
+}
+SGX_KERNEL(256) k_lk_track(SgxLkGeom g, SgxLkArgs A)
+{
+    SGX_THREADS_BEGIN(tid)
+    const int f = (int)blockIdx.y, kp = (int)blockIdx.x * 4 + (tid >> 6);
+    if ((tid & 63) == 0 && kp < A.n[f] && kp < A.cap) {
+        const float *kpt = (const float *)(A.keys + ((size_t)f * A.cap + kp) * 28);
+        float ox, oy; uint8_t st;
+        sgx_lk_track_point(g, A.cur_img + (size_t)f * g.img_stride, (const int16_t *)((const uint8_t *)A.cur_der + (size_t)f * g.der_stride), A.prev_img + (size_t)f * g.img_stride,
+                           kpt[0], kpt[1], A.max_count, A.eps2, A.min_eig, &ox, &oy, &st);
+        A.prev_xy[2 * ((size_t)f * A.cap + kp)] = ox; A.prev_xy[2 * ((size_t)f * A.cap + kp) + 1] = oy;
+        if (A.status) A.status[(size_t)f * A.cap + kp] = st;
+    }
+    SGX_THREADS_END
+}
+#else
+/* the eight bytes starting at byte offset `b` of an LDS tile, from three aligned dwords */
+SGX_DEV void sgx_lk_lds8(const uint32_t *tile, int b, uint32_t &lo, uint32_t &hi)
+{
+    const uint32_t *p = tile + (b >> 2); const uint32_t s = (uint32_t)b & 3u;
+    const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+    lo = __builtin_amdgcn_alignbyte(w1, w0, s); hi = __builtin_amdgcn_alignbyte(w2, w1, s);
+}
+#define SGX_LK_BYTE(lo, hi, k) ((int)(((k) < 4 ? (lo) >> (8 * (k)) : (hi) >> (8 * ((k) - 4))) & 255u))
+
+SGX_KERNEL(256) k_lk_track(SgxLkGeom g, SgxLkArgs A)
+{
+    __shared__ uint32_t tiles[4][SGX_LK_TILE_ROWS * SGX_LK_TILE_PITCH / 4 + 4];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int f = (int)blockIdx.y, kp = (int)blockIdx.x * 4 + wv;
+    if (kp >= A.n[f] || kp >= A.cap) return;                       /* wave-uniform: no workgroup barrier is used below */
+    uint32_t *tile = tiles[wv];
+    const int W = SGX_LK_WIN; const float half = 10.0f, FLT_SCALE = 1.f / (1 << 20);
+    const float *kpt = (const float *)(A.keys + ((size_t)f * A.cap + kp) * 28);
+    const float kx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, kpt[0])));
+    const float ky = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, kpt[1])));
+    const uint8_t *I0 = A.cur_img + (size_t)f * g.img_stride, *J0 = A.prev_img + (size_t)f * g.img_stride;
+    const uint8_t *D0 = (const uint8_t *)A.cur_der + (size_t)f * g.der_stride;
+    const int r = lane / 3, s7 = (lane - 3 * r) * 7;               /* window row, first of the lane's seven columns */
+    const bool active = lane < 63;
+    float outx = 0.f, outy = 0.f; int status = 1;
+
+    for (int level = g.nl - 1; level >= 0; level--) {
+        const int w = g.w[level], h = g.h[level], pitch = g.pitch[level];
+        const uint8_t *I = I0 + g.ioff[level], *J = J0 + g.ioff[level];
+        const uint32_t *Dv = (const uint32_t *)(D0 + g.doff[level]);
+        const float sc = 1.0f / (float)(1 << level);
+        float prevx = kx * sc, prevy = ky * sc, nextx, nexty;
+        if (level == g.nl - 1) { nextx = prevx; nexty = prevy; } else { nextx = outx * 2.f; nexty = outy * 2.f; }
+        outx = nextx; outy = nexty;
+        prevx -= half; prevy -= half;
+        const int ipx = sgx_floor_f(prevx), ipy = sgx_floor_f(prevy);
+        if (ipx < -W || ipx >= w || ipy < -W || ipy >= h) { if (level == 0) status = 0; continue; }
+        SgxLkWeights k = sgx_lk_weights(prevx - ipx, prevy - ipy);
+
+        // ---- this lane's seven window samples of I and its derivatives (kept in registers for every iteration of the level)
+        int iv[7], ix[7], iy[7];
+        int s11 = 0, s12 = 0, s22 = 0;
+        {
+            const int gy0 = ipy + r, gx0 = ipx + s7;
+            const uint8_t *ra = I + (size_t)sgx_reflect101(gy0, h) * pitch, *rb = I + (size_t)sgx_reflect101(gy0 + 1, h) * pitch;
+            const bool ya = gy0 >= 0 && gy0 < h, yb = gy0 + 1 >= 0 && gy0 + 1 < h;
+            int pa[8], pb[8]; uint32_t da[8], db[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const int gx = gx0 + c, rx = sgx_reflect101(gx, w);
+                const bool xin = gx >= 0 && gx < w;
+                pa[c] = ra[rx]; pb[c] = rb[rx];
+                da[c] = (xin && ya) ? Dv[(size_t)gy0 * w + gx] : 0u;
+                db[c] = (xin && yb) ? Dv[(size_t)(gy0 + 1) * w + gx] : 0u;
+            }
+#pragma unroll
+            for (int c = 0; c < 7; c++) {
+                iv[c] = SGX_LK_DESCALE(pa[c] * k.w00 + pa[c + 1] * k.w01 + pb[c] * k.w10 + pb[c + 1] * k.w11, 9);
+                const int x00 = (int)(short)(da[c] & 0xFFFF), x01 = (int)(short)(da[c + 1] & 0xFFFF), x10 = (int)(short)(db[c] & 0xFFFF), x11 = (int)(short)(db[c + 1] & 0xFFFF);
+                const int y00 = (int)da[c] >> 16, y01 = (int)da[c + 1] >> 16, y10 = (int)db[c] >> 16, y11 = (int)db[c + 1] >> 16;
+                ix[c] = SGX_LK_DESCALE(x00 * k.w00 + x01 * k.w01 + x10 * k.w10 + x11 * k.w11, 14);
+                iy[c] = SGX_LK_DESCALE(y00 * k.w00 + y01 * k.w01 + y10 * k.w10 + y11 * k.w11, 14);
+                if (!active) { iv[c] = 0; ix[c] = 0; iy[c] = 0; }
+                s11 += ix[c] * ix[c]; s12 += ix[c] * iy[c]; s22 += iy[c] * iy[c];
+            }
+        }
+        const float A11 = sgx_i64_to_f32(sgx_wave_sum_i64(s11)) * FLT_SCALE, A12 = sgx_i64_to_f32(sgx_wave_sum_i64(s12)) * FLT_SCALE,
+                    A22 = sgx_i64_to_f32(sgx_wave_sum_i64(s22)) * FLT_SCALE;
+        float D = A11 * A22 - A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * W * W);
+        if (minEig < A.min_eig || D < FLT_EPSILON) { if (level == 0) status = 0; continue; }
+        D = 1.f / D;
+        nextx -= half; nexty -= half;
+        float pdx = 0.f, pdy = 0.f;
+        int ox = 0, oy = 0; bool staged = false;
+        for (int j = 0; j < A.max_count; j++) {
+            const int inx = sgx_floor_f(nextx), iny = sgx_floor_f(nexty);
+            if (inx < -W || inx >= w || iny < -W || iny >= h) { if (level == 0) status = 0; break; }
+            k = sgx_lk_weights(nextx - inx, nexty - iny);
+            if (!staged || inx < ox || inx - ox > SGX_LK_TILE_PITCH - 22 || iny < oy || iny - oy > SGX_LK_TILE_ROWS - 22) {
+                // ---- stage the 32 x 36-byte patch of J around the window (REFLECT_101 outside the image), aligned dwords where the image allows
+                ox = ((inx - 5) >> 2) << 2; oy = iny - 5;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+                for (int i = lane; i < SGX_LK_TILE_ROWS * (SGX_LK_TILE_PITCH / 4); i += 64) {
+                    const int row = i / (SGX_LK_TILE_PITCH / 4), c4 = (i - row * (SGX_LK_TILE_PITCH / 4)) * 4;
+                    const uint8_t *src = J + (size_t)sgx_reflect101(oy + row, h) * pitch;
+                    const int gx = ox + c4;
+                    uint32_t v;
+                    if (gx >= 0 && gx + 4 <= w) v = *(const uint32_t *)(src + gx);
+                    else v = (uint32_t)src[sgx_reflect101(gx, w)] | ((uint32_t)src[sgx_reflect101(gx + 1, w)] << 8) | ((uint32_t)src[sgx_reflect101(gx + 2, w)] << 16) |
+                             ((uint32_t)src[sgx_reflect101(gx + 3, w)] << 24);
+                    tile[i] = v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+                staged = true;
+            }
+            int sb1 = 0, sb2 = 0;
+            {
+                const int b = (iny - oy + r) * SGX_LK_TILE_PITCH + (inx - ox) + s7;
+                uint32_t alo, ahi, blo, bhi;
+                sgx_lk_lds8(tile, active ? b : 0, alo, ahi); sgx_lk_lds8(tile, active ? b + SGX_LK_TILE_PITCH : 0, blo, bhi);
+#pragma unroll
+                for (int c = 0; c < 7; c++) {
+                    const int diff = SGX_LK_DESCALE(SGX_LK_BYTE(alo, ahi, c) * k.w00 + SGX_LK_BYTE(alo, ahi, c + 1) * k.w01 + SGX_LK_BYTE(blo, bhi, c) * k.w10 +
+                                                    SGX_LK_BYTE(blo, bhi, c + 1) * k.w11, 9) - iv[c];
+                    sb1 += diff * ix[c]; sb2 += diff * iy[c];          /* ix = iy = 0 on the idle lane */
+                }
+            }
+            const SgxLkStep st = sgx_lk_step(A11, A12, A22, D, sgx_wave_sum_i64(sb1), sgx_wave_sum_i64(sb2));
+            nextx += st.dx; nexty += st.dy;
+            outx = nextx + half; outy = nexty + half;
+            if ((double)st.dx * st.dx + (double)st.dy * st.dy <= A.eps2) break;
+            if (j > 0 && fabs((double)(st.dx + pdx)) < 0.01 && fabs((double)(st.dy + pdy)) < 0.01) { outx -= st.dx * 0.5f; outy -= st.dy * 0.5f; break; }
+            pdx = st.dx; pdy = st.dy;
+        }
+        if (status && level == 0) {
+            const int qx = sgx_floor_f(outx - half), qy = sgx_floor_f(outy - half);
+            if (qx < -W || qx >= w || qy < -W || qy >= h) status = 0;
+        }
+    }
+    if (lane == 0) {
+        A.prev_xy[2 * ((size_t)f * A.cap + kp)] = outx; A.prev_xy[2 * ((size_t)f * A.cap + kp) + 1] = outy;
+        if (A.status) A.status[(size_t)f * A.cap + kp] = (uint8_t)status;
+    }
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// findFundamentalMat(FM_RANSAC)
+// ---------------------------------------------------------------------------------------------
+#define SGX_FM_CHUNK 32               /* 7-index groups drawn per round */
+#define SGX_FM_MAXPTS 2048
+
+/* cv::solveCubic (mathfuncs.cpp) */
+SGX_DEV int sgx_solve_cubic(const double *c, double *roots)
+{
+    double a0 = c[0], a1 = c[1], a2 = c[2], a3 = c[3];
+    double x0 = 0., x1 = 0., x2 = 0.;
+    int n = 0;
+    if (a0 == 0) {
+        if (a1 == 0) {
+            if (a2 == 0) n = a3 == 0 ? -1 : 0;
+            else { x0 = -a3 / a2; n = 1; }
+        } else {
+            double d = a2 * a2 - 4 * a1 * a3;
+            if (d >= 0) {
+                d = sqrt(d);
+                double q1 = (-a2 + d) * 0.5, q2 = (a2 + d) * -0.5;
+                if (fabs(q1) > fabs(q2)) { x0 = q1 / a1; x1 = a3 / q1; }
+                else { x0 = q2 / a1; x1 = a3 / q2; }
+                n = d > 0 ? 2 : 1;
+            }
+        }
+    } else {
+        a0 = 1. / a0; a1 *= a0; a2 *= a0; a3 *= a0;
+        double Q = (a1 * a1 - 3 * a2) * (1. / 9);
+        double R = (2 * a1 * a1 * a1 - 9 * a1 * a2 + 27 * a3) * (1. / 54);
+        double Qcubed = Q * Q * Q;
+        double d = Qcubed - R * R;
+        if (d > 0) {
+            double theta = acos(R / sqrt(Qcubed));
+            double sqrtQ = sqrt(Q);
+            double t0 = -2 * sqrtQ, t1 = theta * (1. / 3), t2 = a1 * (1. / 3);
+            x0 = t0 * cos(t1) - t2;
+            x1 = t0 * cos(t1 + (2. * 3.1415926535897932384626433832795 / 3)) - t2;
+            x2 = t0 * cos(t1 + (4. * 3.1415926535897932384626433832795 / 3)) - t2;
+            n = 3;
+        } else if (d == 0) {
+            if (R >= 0) { x0 = -2 * pow(R, 1. / 3) - a1 / 3; x1 = pow(R, 1. / 3) - a1 / 3; }
+            else { x0 = 2 * pow(-R, 1. / 3) - a1 / 3; x1 = -pow(-R, 1. / 3) - a1 / 3; }
+            x2 = 0;
+            n = x0 == x1 ? 1 : 2;
+            x1 = x0 == x1 ? 0 : x1;
+        } else {
+            double e;
+            d = sqrt(-d);
+            e = pow(d + fabs(R), 1. / 3);
+            if (R > 0) e = -e;
+            x0 = (e + Q / e) - a1 * (1. / 3);
+            n = 1;
+        }
+    }
+    roots[0] = x0; roots[1] = x1; roots[2] = x2;
+    return n;
+}
+
+/* run7Point (fundam.cpp).  M = 63-double work area (A^T, 9 x 7, overwritten by the Householder vectors).  Null space of the 7 x 9 system =
+ * the last two columns of Q in A^T = QR: q_j = H_0 H_1 ... H_6 e_j (same arithmetic as oracle/flow_oracle.c null_space_7x9). */
+SGX_DEV int sgx_fm_run7point(const float *m1, const float *m2, double *M, double *fmatrix)
+{
+    double beta[7], f1[9], f2[9], c[4], r[3];
+    for (int i = 0; i < 7; i++) {
+        const double x0 = m1[2 * i], y0 = m1[2 * i + 1], x1 = m2[2 * i], y1 = m2[2 * i + 1];
+        M[0 * 7 + i] = x1 * x0; M[1 * 7 + i] = x1 * y0; M[2 * 7 + i] = x1;
+        M[3 * 7 + i] = y1 * x0; M[4 * 7 + i] = y1 * y0; M[5 * 7 + i] = y1;
+        M[6 * 7 + i] = x0; M[7 * 7 + i] = y0; M[8 * 7 + i] = 1;
+    }
+    for (int k = 0; k < 7; k++) {
+        double nrm = 0; for (int i = k; i < 9; i++) nrm += M[i * 7 + k] * M[i * 7 + k];
+        nrm = sqrt(nrm);
+        beta[k] = 0;
+        if (nrm == 0) continue;
+        M[k * 7 + k] += M[k * 7 + k] >= 0 ? nrm : -nrm;                 /* column k, rows k..8 now hold v_k */
+        double vv = 0; for (int i = k; i < 9; i++) vv += M[i * 7 + k] * M[i * 7 + k];
+        if (vv == 0) continue;
+        beta[k] = 2. / vv;
+        for (int j = k + 1; j < 7; j++) {
+            double s = 0; for (int i = k; i < 9; i++) s += M[i * 7 + k] * M[i * 7 + j];
+            s *= beta[k];
+            for (int i = k; i < 9; i++) M[i * 7 + j] -= s * M[i * 7 + k];
+        }
+    }
+    for (int i = 0; i < 9; i++) { f1[i] = i == 7; f2[i] = i == 8; }
+    for (int k = 6; k >= 0; k--) {
+        double s1 = 0, s2 = 0;
+        for (int i = k; i < 9; i++) { s1 += M[i * 7 + k] * f1[i]; s2 += M[i * 7 + k] * f2[i]; }
+        s1 *= beta[k]; s2 *= beta[k];
+        for (int i = k; i < 9; i++) { f1[i] -= s1 * M[i * 7 + k]; f2[i] -= s2 * M[i * 7 + k]; }
+    }
+    for (int i = 0; i < 9; i++) f1[i] -= f2[i];
+    double t0 = f2[4] * f2[8] - f2[5] * f2[7], t1 = f2[3] * f2[8] - f2[5] * f2[6], t2 = f2[3] * f2[7] - f2[4] * f2[6];
+    c[3] = f2[0] * t0 - f2[1] * t1 + f2[2] * t2;
+    c[2] = f1[0] * t0 - f1[1] * t1 + f1[2] * t2 -
+           f1[3] * (f2[1] * f2[8] - f2[2] * f2[7]) + f1[4] * (f2[0] * f2[8] - f2[2] * f2[6]) - f1[5] * (f2[0] * f2[7] - f2[1] * f2[6]) +
+           f1[6] * (f2[1] * f2[5] - f2[2] * f2[4]) - f1[7] * (f2[0] * f2[5] - f2[2] * f2[3]) + f1[8] * (f2[0] * f2[4] - f2[1] * f2[3]);
+    t0 = f1[4] * f1[8] - f1[5] * f1[7]; t1 = f1[3] * f1[8] - f1[5] * f1[6]; t2 = f1[3] * f1[7] - f1[4] * f1[6];
+    c[0] = f1[0] * t0 - f1[1] * t1 + f1[2] * t2;
+    c[1] = f2[0] * t0 - f2[1] * t1 + f2[2] * t2 -
+           f2[3] * (f1[1] * f1[8] - f1[2] * f1[7]) + f2[4] * (f1[0] * f1[8] - f1[2] * f1[6]) - f2[5] * (f1[0] * f1[7] - f1[1] * f1[6]) +
+           f2[6] * (f1[1] * f1[5] - f1[2] * f1[4]) - f2[7] * (f1[0] * f1[5] - f1[2] * f1[3]) + f2[8] * (f1[0] * f1[4] - f1[1] * f1[3]);
+    const int n = sgx_solve_cubic(c, r);
+    if (n < 1 || n > 3) return n;
+    for (int k = 0; k < n; k++, fmatrix += 9) {
+        double lambda = r[k], mu = 1.;
+        const double s = f1[8] * r[k] + f2[8];
+        if (fabs(s) > DBL_EPSILON) { mu = 1. / s; lambda *= mu; fmatrix[8] = 1.; }
+        else fmatrix[8] = 0.;
+        for (int i = 0; i < 8; i++) fmatrix[i] = f1[i] * lambda + f2[i] * mu;
+    }
+    return n;
+}
+
+/* FMEstimatorCallback::computeError for one pair, as float */
+SGX_DEV float sgx_fm_error(const double *F, float m1x, float m1y, float m2x, float m2y)
+{
+    double a, b, c, d1, d2, s1, s2;
+    a = F[0] * m1x + F[1] * m1y + F[2];
+    b = F[3] * m1x + F[4] * m1y + F[5];
+    c = F[6] * m1x + F[7] * m1y + F[8];
+    s2 = 1. / (a * a + b * b);
+    d2 = m2x * a + m2y * b + c;
+    a = F[0] * m2x + F[3] * m2y + F[6];
+    b = F[1] * m2x + F[4] * m2y + F[7];
+    c = F[2] * m2x + F[5] * m2y + F[8];
+    s1 = 1. / (a * a + b * b);
+    d1 = m1x * a + m1y * b + c;
+    const double e1 = d1 * d1 * s1, e2 = d2 * d2 * s2;
+    return (float)(e1 < e2 ? e2 : e1);                               /* std::max(e1, e2) */
+}
+
+/* haveCollinearPoints(m, 7): does the LAST point lie on a line through two earlier ones (ptsetreg.cpp) */
+SGX_DEV bool sgx_fm_collinear7(const float *p)
+{
+    const int i = 6;
+    for (int j = 0; j < i; j++) {
+        const double dx1 = p[2 * j] - p[2 * i], dy1 = p[2 * j + 1] - p[2 * i + 1];
+        for (int k = 0; k < j; k++) {
+            const double dx2 = p[2 * k] - p[2 * i], dy2 = p[2 * k + 1] - p[2 * i + 1];
+            if (fabs(dx2 * dy1 - dy2 * dx1) <= FLT_EPSILON * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2))) return true;
+        }
+    }
+    return false;
+}
+
+/* RANSACUpdateNumIters (ptsetreg.cpp) */
+SGX_DEV int sgx_ransac_update_num_iters(double p, double ep, int model_points, int max_iters)
+{
+    p = p > 0. ? p : 0.; p = p < 1. ? p : 1.;
+    ep = ep > 0. ? ep : 0.; ep = ep < 1. ? ep : 1.;
+    double num = 1. - p > DBL_MIN ? 1. - p : DBL_MIN;
+    double denom = 1. - pow(1. - ep, (double)model_points);
+    if (denom < DBL_MIN) return 0;
+    num = log(num); denom = log(denom);
+    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
+}
+
+struct SgxFmArgs {
+    const uint8_t *keys; const int *n; int cap; const float *prev_xy;
+    const int *pre_have; const float *pre_boxes; const int *pre_nboxes; int max_boxes;       /* previous frame's person boxes (may be NULL) */
+    double threshold, confidence; int max_iters;
+    double *F; int *ok; int *stats;          /* F: 9 doubles per frame; ok: 1 / 0 (no model; F zeroed); stats (optional): 4 ints per frame */
+};
+
+SGX_KERNEL(256) k_fm_ransac(SgxFmArgs A)
+{
+    SGX_DYN_LDS(lds_raw);
+    // layout: m1 (cap float2) | m2 (cap float2) | scan (256 int) | flags (cap u8, padded)
+    const int f = (int)blockIdx.x, cap = A.cap;
+    float *m1 = (float *)lds_raw, *m2 = m1 + 2 * cap;
+    int *scan = (int *)(m2 + 2 * cap);
+    uint8_t *flag = (uint8_t *)(scan + 256);
+    SGX_LDS int s_total, s_count, s_done, s_niters, s_iter, s_maxgood, s_best_iter, s_best_root, s_attempts;
+    SGX_LDS unsigned long long s_rng;
+    SGX_LDS int g_idx[SGX_FM_CHUNK][7];
+    SGX_LDS int g_nmodels[SGX_FM_CHUNK];            /* -1 = group rejected by checkSubset */
+    SGX_LDS double g_model[SGX_FM_CHUNK][27];
+    SGX_LDS int g_good[SGX_FM_CHUNK][3];
+    SGX_LDS double g_work[SGX_FM_CHUNK][63];
+    SGX_LDS double s_best[9];
+    const int N = min(A.n[f], cap), CH = (N + 255) / 256;
+    const bool pre = A.pre_have && A.pre_have[f] && A.pre_boxes && A.pre_nboxes;
+
+    // ---- Frame.cc:454-467: pairs whose previous position is outside every person box of the previous frame
+    SGX_THREADS_BEGIN(tid)
+    int c = 0;
+    for (int i = tid * CH; i < min(N, (tid + 1) * CH); i++) {
+        uint8_t keep = 1;
+        if (pre) {
+            const float x = A.prev_xy[2 * ((size_t)f * cap + i)], y = A.prev_xy[2 * ((size_t)f * cap + i) + 1];
+            const int nb = min(A.pre_nboxes[f], A.max_boxes);
+            for (int q = 0; q < nb; q++) {
+                const float *r = A.pre_boxes + 4 * ((size_t)f * A.max_boxes + q);
+                if (x > r[0] && x < r[0] + r[2] && y > r[1] && y < r[1] + r[3]) { keep = 0; break; }
+            }
+        }
+        flag[i] = keep; c += keep;
+    }
+    scan[tid] = c;
+    if (tid == 0) { s_done = 0; s_niters = A.max_iters > 1 ? A.max_iters : 1; s_iter = 0; s_maxgood = 0; s_best_iter = 0; s_best_root = 0; s_attempts = 0; s_rng = ~0ull; }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    sgx_block_exclusive_scan_i32(scan, 256, &s_total, tid);
+    SGX_THREADS_END
+    SGX_SYNC();
+    const bool use_sel = pre && s_total > 20;                       /* :469 */
+    SGX_THREADS_BEGIN(tid)
+    int pos = use_sel ? scan[tid] : tid * CH;
+    for (int i = tid * CH; i < min(N, (tid + 1) * CH); i++) {
+        if (use_sel && !flag[i]) continue;
+        const float *kp = (const float *)(A.keys + ((size_t)f * cap + i) * 28);
+        m1[2 * pos] = kp[0]; m1[2 * pos + 1] = kp[1];
+        m2[2 * pos] = A.prev_xy[2 * ((size_t)f * cap + i)]; m2[2 * pos + 1] = A.prev_xy[2 * ((size_t)f * cap + i) + 1];
+        pos++;
+    }
+    if (tid == 0) s_count = use_sel ? s_total : N;
+    SGX_THREADS_END
+    SGX_SYNC();
+    const int count = s_count;
+    const float t = (float)(A.threshold * A.threshold);
+
+    if (count < 7 || (count > 7 && count < 15)) {                   /* < 7: empty Mat; 8..14: LMedS in OpenCV (not built): no model */
+        SGX_THREADS_BEGIN(tid)
+        if (tid < 9) A.F[9 * (size_t)f + tid] = 0.;
+        if (tid == 0) { A.ok[f] = 0; if (A.stats) { A.stats[4 * f] = 0; A.stats[4 * f + 1] = 0; A.stats[4 * f + 2] = 0; A.stats[4 * f + 3] = 0; } }
+        SGX_THREADS_END
+        return;
+    }
+    if (count == 7) {                                                /* run7Point on the seven pairs; a 3x3 read of the 9x3 result sees the first root */
+        SGX_THREADS_BEGIN(tid)
+        if (tid == 0) {
+            const int k = sgx_fm_run7point(m1, m2, g_work[0], g_model[0]);
+            for (int i = 0; i < 9; i++) A.F[9 * (size_t)f + i] = k > 0 ? g_model[0][i] : 0.;
+            A.ok[f] = k > 0;
+            if (A.stats) { A.stats[4 * f] = 0; A.stats[4 * f + 1] = 0; A.stats[4 * f + 2] = 0; A.stats[4 * f + 3] = 0; }
+        }
+        SGX_THREADS_END
+        return;
+    }
+
+    // ---- RANSACPointSetRegistrator::run, SGX_FM_CHUNK candidate groups per round
+    for (;;) {
+        SGX_THREADS_BEGIN(tid)
+        if (tid == 0) {
+            // cv::RNG::uniform(0, count) draws: seven distinct indices per group (getSubset's inner loops; the group is checked below)
+            unsigned long long st = s_rng;
+            for (int gI = 0; gI < SGX_FM_CHUNK; gI++)
+                for (int i = 0; i < 7; i++) {
+                    int idx_i, j;
+                    for (;;) {
+                        st = (unsigned long long)(unsigned)st * 4164903690ull + (unsigned)(st >> 32);
+                        idx_i = (int)((unsigned)st % (unsigned)count);
+                        for (j = 0; j < i; j++) if (idx_i == g_idx[gI][j]) break;
+                        if (j == i) break;
+                    }
+                    g_idx[gI][i] = idx_i;
+                }
+            s_rng = st;
+        }
+        SGX_THREADS_END
+        SGX_SYNC();
+        SGX_THREADS_BEGIN(tid)
+        if (tid < SGX_FM_CHUNK) {
+            float a[14], b[14];
+            for (int i = 0; i < 7; i++) { const int id = g_idx[tid][i]; a[2 * i] = m1[2 * id]; a[2 * i + 1] = m1[2 * id + 1]; b[2 * i] = m2[2 * id]; b[2 * i + 1] = m2[2 * id + 1]; }
+            int nm = -1;
+            if (!sgx_fm_collinear7(a) && !sgx_fm_collinear7(b)) { nm = sgx_fm_run7point(a, b, g_work[tid], g_model[tid]); if (nm < 0 || nm > 3) nm = 0; }
+            g_nmodels[tid] = nm;
+            g_good[tid][0] = g_good[tid][1] = g_good[tid][2] = 0;
+        }
+        SGX_THREADS_END
+        SGX_SYNC();
+        // ---- findInliers for every model of the round
+        for (int gI = 0; gI < SGX_FM_CHUNK; gI++) {
+            const int nm = g_nmodels[gI];
+            for (int k = 0; k < nm; k++) {
+                SGX_THREADS_BEGIN(tid)
+                double Fm[9];
+                for (int i = 0; i < 9; i++) Fm[i] = g_model[gI][9 * k + i];
+                int cnt = 0;
+                for (int p = tid; p < count; p += 256) cnt += sgx_fm_error(Fm, m1[2 * p], m1[2 * p + 1], m2[2 * p], m2[2 * p + 1]) <= t ? 1 : 0;
+                if (cnt) sgx_atomic_add(&g_good[gI][k], cnt);
+                SGX_THREADS_END
+            }
+        }
+        SGX_SYNC();
+        // ---- the sequential accept rule, replayed in iteration order (ptsetreg.cpp run())
+        SGX_THREADS_BEGIN(tid)
+        if (tid == 0) {
+            int iter = s_iter, niters = s_niters, maxgood = s_maxgood, attempts = s_attempts;
+            bool done = false;
+            for (int gI = 0; gI < SGX_FM_CHUNK && !done; gI++) {
+                if (iter >= niters) { done = true; break; }
+                if (g_nmodels[gI] < 0) {                                       /* getSubset repeats the draw (`continue` of its attempt loop), 10000 attempts at most */
+                    if (++attempts >= 10000) done = true;                      /* getSubset fails: `return false` at iter 0 (nothing found yet), `break` later */
+                    continue;
+                }
+                attempts = 0;
+                for (int k = 0; k < g_nmodels[gI]; k++) {
+                    const int good = g_good[gI][k];
+                    if (good > (maxgood > 6 ? maxgood : 6)) {
+                        for (int i = 0; i < 9; i++) s_best[i] = g_model[gI][9 * k + i];
+                        maxgood = good; s_best_iter = iter; s_best_root = k;
+                        niters = sgx_ransac_update_num_iters(A.confidence, (double)(count - good) / count, 7, niters);
+                    }
+                }
+                iter++;
+            }
+            if (iter >= niters) done = true;
+            s_iter = iter; s_niters = niters; s_maxgood = maxgood; s_attempts = attempts; s_done = done ? 1 : 0;
+        }
+        SGX_THREADS_END
+        SGX_SYNC();
+        if (s_done) break;
+    }
+    SGX_THREADS_BEGIN(tid)
+    const bool ok = s_maxgood > 0;
+    if (tid < 9) A.F[9 * (size_t)f + tid] = ok ? s_best[tid] : 0.;
+    if (tid == 0) {
+        A.ok[f] = ok ? 1 : 0;
+        if (A.stats) { A.stats[4 * f] = s_iter; A.stats[4 * f + 1] = s_best_iter; A.stats[4 * f + 2] = s_best_root; A.stats[4 * f + 3] = s_maxgood; }
+    }
+    SGX_THREADS_END
+}
