@@ -279,8 +279,8 @@ int sgx_frame_compact_keys_batch_dev(int batch, int cap, const sgx_keypoint *d_k
  *   :454-467 the pairs whose previous position lies outside the previous frame's person boxes (vPreFramePotentialDynamicBorder)
  *   :469-472 cv::findFundamentalMat(cur, prev, FM_RANSAC, 1.0, 0.99) on that selection when more than 20 pairs remain, else on all pairs
  * A sgx_flow handle owns the two image pyramids (current / previous) like the file-scope `imGrayPre` of Frame.cc:31,155-163: each
- * sgx_flow_lk_batch_dev call builds the pyramid (+ Scharr derivatives) of the new frames, tracks into the pyramid kept from the previous call,
- * and swaps.  OpenCV 3.4 semantics (lkpyramid.cpp, pyramids.cpp); sums are accumulated exactly (the library's int64 `acctype` variant). */
+ * sgx_flow_lk_batch_dev call builds the pyramid of the new frames, tracks into the pyramid kept from the previous call, and swaps (the Scharr
+ * derivatives are evaluated inside the tracker from the image itself).  OpenCV 3.4 semantics (lkpyramid.cpp, pyramids.cpp); sums are accumulated exactly (the library's int64 `acctype` variant). */
 typedef struct sgx_flow_config {
     int32_t width, height, max_batch;
     int32_t win_size;       /* 21 (only value supported) */
@@ -301,7 +301,7 @@ int sgx_flow_lk_batch_dev(sgx_flow *h, const uint8_t *d_gray, int pitch, int bat
                           float *d_prev_xy, uint8_t *d_status, int32_t *have_prev, void *stream);
 /* cv::calcOpticalFlowPyrLK(gray_from, gray_to, pts, next_pts, status, ...) on one host image pair (n points, 2 floats each).  Synchronous; resets the streaming state. */
 int sgx_flow_lk(sgx_flow *h, const uint8_t *gray_from, const uint8_t *gray_to, int stride, const float *pts, int n, float *next_pts, uint8_t *status);
-int sgx_flow_debug_read_level(sgx_flow *h, int slot, int frame, int level, uint8_t *img, int16_t *der);     /* test tap */
+int sgx_flow_debug_read_level(sgx_flow *h, int slot, int frame, int level, uint8_t *img);     /* test tap: pyramid level, w*h tight */
 int sgx_flow_debug_level_size(const sgx_flow *h, int level, int32_t *w, int32_t *hgt);
 /* Frame.cc:454-472 for `batch` frames: pair selection against the PREVIOUS frame's person boxes (d_pre_have_dynamic = bPreFrameHavePotentialDynamicObj,
  * d_pre_boxes / d_pre_nboxes = vPreFramePotentialDynamicBorder in the layout sgx_det_detect_batch_dev writes; all three may be NULL) and

@@ -146,7 +146,7 @@ class SgxLib:
         d.sgx_flow_levels.argtypes = [vp]
         d.sgx_flow_lk_batch_dev.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, C.POINTER(C.c_int32), vp]
         d.sgx_flow_lk.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, vp, vp]
-        d.sgx_flow_debug_read_level.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
+        d.sgx_flow_debug_read_level.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
         d.sgx_flow_debug_level_size.argtypes = [vp, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         d.sgx_fundamental_ransac_batch_dev.argtypes = [C.c_int, C.c_int] + [vp] * 6 + [C.c_int, C.c_double, C.c_double, vp, vp, vp, vp]
         d.sgx_find_fundamental_mat.argtypes = [vp, vp, C.c_int, C.c_double, C.c_double, vp, vp, vp]

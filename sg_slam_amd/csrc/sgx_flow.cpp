@@ -17,7 +17,6 @@ struct sgx_flow {
     sgx_flow_config cfg;
     SgxLkGeom g;
     uint8_t *img[2] = { nullptr, nullptr };     // two pyramid slots (current / previous), max_batch frames each
-    int16_t *der = nullptr;                     // Scharr derivatives of the current frames
     int cur = 0;                                // slot the NEXT call writes
     int prev_batch = 0;                         // frames held by the other slot (0 = no previous frame: `if(imGrayPre.data)` false, Frame.cc:155)
 };
@@ -35,10 +34,10 @@ extern "C" int sgx_flow_create(const sgx_flow_config *cfg, sgx_flow **out)
     SgxLkGeom &g = h->g;
     memset(&g, 0, sizeof g);
     // buildOpticalFlowPyramid (lkpyramid.cpp): halve until a level would not be larger than the window
-    int w = cfg->width, hh = cfg->height; unsigned io = 0, dof = 0;
+    int w = cfg->width, hh = cfg->height; unsigned io = 0;
     for (int l = 0;; l++) {
-        g.w[l] = w; g.h[l] = hh; g.pitch[l] = (w + 3) & ~3; g.ioff[l] = io; g.doff[l] = dof;
-        io += (unsigned)g.pitch[l] * (unsigned)hh; dof += (unsigned)w * (unsigned)hh * 4u;
+        g.w[l] = w; g.h[l] = hh; g.pitch[l] = (w + 3) & ~3; g.ioff[l] = io;
+        io += (unsigned)g.pitch[l] * (unsigned)hh;
         g.nl = l + 1;
         if (l == cfg->max_level) break;
         const int nw = (w + 1) / 2, nh = (hh + 1) / 2;
@@ -46,10 +45,8 @@ extern "C" int sgx_flow_create(const sgx_flow_config *cfg, sgx_flow **out)
         w = nw; hh = nh;
     }
     g.img_stride = (io + 15u + 64u) & ~15u;       // + slack: the 4-dword row loads of k_lk_pyrdown may run a few bytes past a level's last row
-    g.der_stride = (dof + 15u) & ~15u;
     for (int s = 0; s < 2; s++)
         if (hipMalloc((void **)&h->img[s], (size_t)g.img_stride * cfg->max_batch) != hipSuccess) { sgx_flow_destroy(h); return SGX_ERR_NOMEM; }
-    if (hipMalloc((void **)&h->der, (size_t)g.der_stride * cfg->max_batch) != hipSuccess) { sgx_flow_destroy(h); return SGX_ERR_NOMEM; }
     *out = h;
     return SGX_OK;
 }
@@ -58,15 +55,14 @@ extern "C" void sgx_flow_destroy(sgx_flow *h)
 {
     if (!h) return;
     for (int s = 0; s < 2; s++) if (h->img[s]) (void)hipFree(h->img[s]);
-    if (h->der) (void)hipFree(h->der);
     delete h;
 }
 
 extern "C" int sgx_flow_reset(sgx_flow *h) { if (!h) return SGX_ERR_INVALID; h->prev_batch = 0; return SGX_OK; }
 extern "C" int sgx_flow_levels(const sgx_flow *h) { return h ? h->g.nl : SGX_ERR_INVALID; }
 
-// pyramid (+ derivatives when `with_der`) of `batch` frames into slot `slot`
-static int build_pyramid(sgx_flow *h, int slot, const uint8_t *d_gray, int pitch, int batch, bool with_der, sgx_stream_t st)
+// pyramid of `batch` frames into slot `slot`
+static int build_pyramid(sgx_flow *h, int slot, const uint8_t *d_gray, int pitch, int batch, sgx_stream_t st)
 {
     const SgxLkGeom &g = h->g;
     uint8_t *base = h->img[slot];
@@ -75,10 +71,6 @@ static int build_pyramid(sgx_flow *h, int slot, const uint8_t *d_gray, int pitch
     for (int l = 1; l < g.nl; l++)
         SGX_LAUNCH(k_lk_pyrdown, dim3(((g.pitch[l] >> 2) * g.h[l] + 255) / 256, batch), dim3(256), st, (const uint8_t *)(base + g.ioff[l - 1]), g.w[l - 1], g.h[l - 1], g.pitch[l - 1],
                    g.img_stride, base + g.ioff[l], g.w[l], g.h[l], g.pitch[l], g.img_stride);
-    if (with_der)
-        for (int l = 0; l < g.nl; l++)
-            SGX_LAUNCH(k_lk_scharr, dim3((((g.w[l] + 3) >> 2) * g.h[l] + 255) / 256, batch), dim3(256), st, (const uint8_t *)(base + g.ioff[l]), g.w[l], g.h[l], g.pitch[l], g.img_stride,
-                       (int16_t *)((uint8_t *)h->der + g.doff[l]), g.der_stride);
     sgx_prof_end(SGX_K_LK_PYR, st);
     SGX_CHECK_HIP(hipGetLastError());
     return SGX_OK;
@@ -87,13 +79,14 @@ static int build_pyramid(sgx_flow *h, int slot, const uint8_t *d_gray, int pitch
 static int track(sgx_flow *h, int cur_slot, int prev_slot, int batch, const sgx_keypoint *d_keys, const int32_t *d_n, int cap, float *d_prev_xy, uint8_t *d_status, sgx_stream_t st)
 {
     SgxLkArgs A;
-    A.cur_img = h->img[cur_slot]; A.prev_img = h->img[prev_slot]; A.cur_der = h->der;
+    A.cur_img = h->img[cur_slot]; A.prev_img = h->img[prev_slot];
     A.keys = (const uint8_t *)d_keys; A.n = d_n; A.cap = cap; A.prev_xy = d_prev_xy; A.status = d_status;
     A.max_count = h->cfg.max_count > 100 ? 100 : h->cfg.max_count;                        // SparsePyrLKOpticalFlowImpl::calc clamps the criteria
     double eps = h->cfg.epsilon > 10. ? 10. : h->cfg.epsilon;
     A.eps2 = eps * eps; A.min_eig = (float)1e-4;
     sgx_prof_begin(SGX_K_LK_TRACK, st);
-    SGX_LAUNCH(k_lk_track, dim3((cap + 3) / 4, batch), dim3(256), st, h->g, A);
+    A.batch = batch; A.kblocks = (cap + 3) / 4;
+    SGX_LAUNCH(k_lk_track, dim3((unsigned)A.kblocks * (unsigned)batch), dim3(256), st, h->g, A);
     sgx_prof_end(SGX_K_LK_TRACK, st);
     SGX_CHECK_HIP(hipGetLastError());
     return SGX_OK;
@@ -108,7 +101,7 @@ extern "C" int sgx_flow_lk_batch_dev(sgx_flow *h, const uint8_t *d_gray, int pit
     const int cur = h->cur, prev = cur ^ 1;
     const bool tracked = h->prev_batch == batch;
     if (tracked && (!d_keys || !d_n || !d_prev_xy || cap < 1)) return SGX_ERR_INVALID;
-    int rc = build_pyramid(h, cur, d_gray, pitch, batch, tracked, st);
+    int rc = build_pyramid(h, cur, d_gray, pitch, batch, st);
     if (rc != SGX_OK) return rc;
     if (tracked) { rc = track(h, cur, prev, batch, d_keys, d_n, cap, d_prev_xy, d_status, st); if (rc != SGX_OK) return rc; }
     if (have_prev) *have_prev = tracked ? 1 : 0;
@@ -131,8 +124,8 @@ extern "C" int sgx_flow_lk(sgx_flow *h, const uint8_t *gray_from, const uint8_t 
     if ((rc = dI.put(0, pack.data(), pack.size())) != SGX_OK || (rc = dK.put(1, kp.data(), kp.size() * sizeof(sgx_keypoint))) != SGX_OK ||
         (rc = dN.put(2, &n, sizeof n)) != SGX_OK || (rc = dO.put(3, nullptr, (size_t)n * 8)) != SGX_OK || (rc = dS.put(4, nullptr, (size_t)n)) != SGX_OK) return rc;
     const int keep_cur = h->cur, keep_prev = h->prev_batch;
-    if ((rc = build_pyramid(h, 1, (const uint8_t *)dI.p, P, 1, false, 0)) != SGX_OK) return rc;                        // to-image ("nextImg") -> slot 1
-    if ((rc = build_pyramid(h, 0, (const uint8_t *)dI.p + (size_t)P * H, P, 1, true, 0)) != SGX_OK) return rc;          // from-image -> slot 0 (+ derivatives)
+    if ((rc = build_pyramid(h, 1, (const uint8_t *)dI.p, P, 1, 0)) != SGX_OK) return rc;                        // to-image ("nextImg") -> slot 1
+    if ((rc = build_pyramid(h, 0, (const uint8_t *)dI.p + (size_t)P * H, P, 1, 0)) != SGX_OK) return rc;          // from-image -> slot 0
     if ((rc = track(h, 0, 1, 1, (const sgx_keypoint *)dK.p, (const int32_t *)dN.p, n, (float *)dO.p, (uint8_t *)dS.p, 0)) != SGX_OK) return rc;
     SGX_CHECK_HIP(hipMemcpy(next_pts, dO.p, (size_t)n * 8, hipMemcpyDeviceToHost));
     if (status) SGX_CHECK_HIP(hipMemcpy(status, dS.p, (size_t)n, hipMemcpyDeviceToHost));
@@ -140,17 +133,17 @@ extern "C" int sgx_flow_lk(sgx_flow *h, const uint8_t *gray_from, const uint8_t 
     return SGX_OK;
 }
 
-extern "C" int sgx_flow_debug_read_level(sgx_flow *h, int slot, int frame, int level, uint8_t *img /* w*h tight, may be NULL */, int16_t *der /* w*h*2, slot must be the last built, may be NULL */)
+extern "C" int sgx_flow_debug_read_level(sgx_flow *h, int slot, int frame, int level, uint8_t *img /* w*h tight */)
 {
     if (!h || slot < 0 || slot > 1 || frame < 0 || frame >= h->cfg.max_batch || level < 0 || level >= h->g.nl) return SGX_ERR_INVALID;
     const SgxLkGeom &g = h->g;
     SGX_CHECK_HIP(hipDeviceSynchronize());
-    if (img) {
+    if (!img) return SGX_ERR_INVALID;
+    {
         std::vector<uint8_t> t((size_t)g.pitch[level] * g.h[level]);
         SGX_CHECK_HIP(hipMemcpy(t.data(), h->img[slot] + (size_t)frame * g.img_stride + g.ioff[level], t.size(), hipMemcpyDeviceToHost));
         for (int y = 0; y < g.h[level]; y++) memcpy(img + (size_t)y * g.w[level], &t[(size_t)y * g.pitch[level]], (size_t)g.w[level]);
     }
-    if (der) SGX_CHECK_HIP(hipMemcpy(der, (uint8_t *)h->der + (size_t)frame * g.der_stride + g.doff[level], (size_t)g.w[level] * g.h[level] * 4, hipMemcpyDeviceToHost));
     return SGX_OK;
 }
 extern "C" int sgx_flow_debug_level_size(const sgx_flow *h, int level, int32_t *w, int32_t *hh)

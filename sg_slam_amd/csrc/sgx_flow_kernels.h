@@ -8,9 +8,9 @@
 // Kernels
 //   k_lk_copy       level 0 of the LK pyramid = a pitch-aligned copy of the frame (it becomes "imGrayPre" of the next call)
 //   k_lk_pyrdown    cv::pyrDown: 5x5 [1 4 6 4 1]^2, (sum + 128) >> 8, REFLECT_101 — four outputs per thread from aligned dwords
-//   k_lk_scharr     calcSharrDeriv: interleaved int16 (dI/dx, dI/dy), REFLECT_101 inside, four pixels per thread, one 16-byte store
 //   k_lk_track      LKTrackerInvoker: ONE WAVE PER KEYPOINT, all pyramid levels chained in one launch.  Lane (r, s) owns window row r and the seven
-//                   columns 7s..7s+6 (63 lanes = 21 x 21 samples): its window intensities and derivatives stay in registers for all iterations; the
+//                   columns 7s..7s+6 (63 lanes = 21 x 21 samples): its window intensities and Scharr derivatives (calcSharrDeriv evaluated on the fly from an
+//                   LDS-staged patch of the image — no derivative plane ever exists in HBM) stay in registers for all iterations; the
 //                   tracked-to image patch sits in a per-wave LDS tile (32 rows x 36 B, re-staged only when the window walks out of it).  Every sum
 //                   (2x2 gradient matrix, mismatch vector) is accumulated as EXACT integers — per lane in 32 bits, across the wave as two 16-bit
 //                   halves through DPP row reductions — and converted to float once: the order-free variant of OpenCV's accumulation
@@ -28,14 +28,12 @@
 
 #define SGX_LK_MAXL 4                 /* pyramid levels (maxLevel <= 3, Frame.cc:445 passes 3) */
 #define SGX_LK_WIN 21                 /* winSize (the lane mapping of k_lk_track is built for 21 x 21) */
-#define SGX_LK_TILE_ROWS 32
 #define SGX_LK_TILE_PITCH 36          /* bytes per LDS tile row: 9 dwords (odd dword stride) */
 struct SgxLkGeom {
     int nl;
     int w[SGX_LK_MAXL], h[SGX_LK_MAXL], pitch[SGX_LK_MAXL];
     unsigned ioff[SGX_LK_MAXL];       /* byte offset of level l inside a frame's image block */
-    unsigned doff[SGX_LK_MAXL];       /* byte offset of level l inside a frame's derivative block (row pitch = 4 * w) */
-    unsigned img_stride, der_stride;  /* bytes per frame */
+    unsigned img_stride;              /* bytes per frame */
 };
 
 SGX_DEV int sgx_reflect101(int p, int len)      /* cv::borderInterpolate(p, len, BORDER_REFLECT_101), any p */
@@ -105,45 +103,6 @@ SGX_KERNEL(256) k_lk_pyrdown(const uint8_t *src, int sw, int sh, int spitch, uns
     SGX_THREADS_END
 }
 
-// calcSharrDeriv (lkpyramid.cpp): dx = [3 10 3]^T (rows) x [-1 0 1] (cols), dy = [-1 0 1]^T x [3 10 3]; neighbours outside the image are REFLECT_101
-SGX_KERNEL(256) k_lk_scharr(const uint8_t *img, int w, int h, int pitch, unsigned istride, int16_t *der, unsigned dstride)
-{
-    SGX_THREADS_BEGIN(tid)
-    const int f = (int)blockIdx.y, qw = (w + 3) >> 2, q = (int)blockIdx.x * 256 + tid;
-    if (q < qw * h) {
-        const int y = q / qw, X = (q - y * qw) * 4;
-        const uint8_t *S = img + (size_t)f * istride;
-        const uint8_t *r0 = S + (size_t)(y > 0 ? y - 1 : h > 1 ? 1 : 0) * pitch, *r1 = S + (size_t)y * pitch, *r2 = S + (size_t)(y < h - 1 ? y + 1 : h > 1 ? h - 2 : 0) * pitch;
-        int t0[6], t1[6];                       /* columns X-1 .. X+4: smoothed (3,10,3) and differenced (-1,0,1) column sums */
-        if (X >= 4 && X + 4 <= w - 1 && X + 8 <= pitch) {
-            const uint32_t a0 = *(const uint32_t *)(r0 + X - 4), b0 = *(const uint32_t *)(r0 + X), c0 = *(const uint32_t *)(r0 + X + 4);
-            const uint32_t a1 = *(const uint32_t *)(r1 + X - 4), b1 = *(const uint32_t *)(r1 + X), c1 = *(const uint32_t *)(r1 + X + 4);
-            const uint32_t a2 = *(const uint32_t *)(r2 + X - 4), b2 = *(const uint32_t *)(r2 + X), c2 = *(const uint32_t *)(r2 + X + 4);
-            const int p0[6] = { (int)(a0 >> 24), (int)(b0 & 255), (int)((b0 >> 8) & 255), (int)((b0 >> 16) & 255), (int)(b0 >> 24), (int)(c0 & 255) };
-            const int p1[6] = { (int)(a1 >> 24), (int)(b1 & 255), (int)((b1 >> 8) & 255), (int)((b1 >> 16) & 255), (int)(b1 >> 24), (int)(c1 & 255) };
-            const int p2[6] = { (int)(a2 >> 24), (int)(b2 & 255), (int)((b2 >> 8) & 255), (int)((b2 >> 16) & 255), (int)(b2 >> 24), (int)(c2 & 255) };
-#pragma unroll
-            for (int i = 0; i < 6; i++) { t0[i] = (p0[i] + p2[i]) * 3 + p1[i] * 10; t1[i] = p2[i] - p0[i]; }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 6; i++) {
-                int c = X - 1 + i;
-                c = c < 0 ? (w > 1 ? 1 : 0) : c >= w ? (c == w ? (w > 1 ? w - 2 : 0) : w - 1) : c;        /* only columns -1 and w are ever used beyond the image */
-                t0[i] = (r0[c] + r2[c]) * 3 + r1[c] * 10; t1[i] = r2[c] - r0[c];
-            }
-        }
-        uint32_t o[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int dx = t0[i + 2] - t0[i], dy = (t1[i + 2] + t1[i]) * 3 + t1[i + 1] * 10;
-            o[i] = (uint32_t)(dx & 0xFFFF) | ((uint32_t)(dy & 0xFFFF) << 16);
-        }
-        uint32_t *d = (uint32_t *)((uint8_t *)der + (size_t)f * dstride) + (size_t)y * w + X;
-        for (int i = 0; i < 4 && X + i < w; i++) d[i] = o[i];
-    }
-    SGX_THREADS_END
-}
-
 // ---------------------------------------------------------------------------------------------
 // LKTrackerInvoker
 // ---------------------------------------------------------------------------------------------
@@ -159,27 +118,7 @@ SGX_DEV SgxLkWeights sgx_lk_weights(float a, float b)            /* lkpyramid.cp
 }
 #define SGX_LK_DESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
 
-#ifndef SGX_EMU
-/* sum over the 64 lanes of a wave of a non-negative-or-small int (no overflow by construction at the call sites); the result is wave-uniform.
- * Four DPP adds give every lane its 16-lane row total (xor 1, xor 2 inside quads, rotate by 4 and by 8 inside the row); the four row totals meet in
- * scalar registers. */
-SGX_DEV int sgx_wave_sum_i32(int v)
-{
-    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);      /* quad_perm [1,0,3,2] */
-    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);      /* quad_perm [2,3,0,1] */
-    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, true);     /* row_ror:4 */
-    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, true);     /* row_ror:8 */
-    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
-}
-/* exact wave sum of per-lane int32 partials (|v| < 2^31) as int64: low 16 bits and the signed high part are reduced separately (each fits 32 bits) */
-SGX_DEV long long sgx_wave_sum_i64(int v)
-{
-    const int lo = sgx_wave_sum_i32(v & 0xFFFF), hi = sgx_wave_sum_i32(v >> 16);
-    return (long long)hi * 65536 + lo;
-}
-#endif
-
-/* the part of one level that is the same on every lane: OpenCV's float arithmetic, operation by operation */
+/* the part of one iteration that is the same on every lane: OpenCV's float arithmetic, operation by operation */
 struct SgxLkStep { float dx, dy; };
 SGX_DEV SgxLkStep sgx_lk_step(float A11, float A12, float A22, float D, long long sb1, long long sb2)
 {
@@ -193,15 +132,25 @@ SGX_DEV SgxLkStep sgx_lk_step(float A11, float A12, float A22, float D, long lon
 
 struct SgxLkArgs {
     const uint8_t *cur_img, *prev_img;       /* per-frame image blocks (SgxLkGeom offsets) */
-    const int16_t *cur_der;
     const uint8_t *keys; const int *n; int cap;
     float *prev_xy; uint8_t *status;
     int max_count; double eps2; float min_eig;
+    int batch, kblocks;                      /* frames, keypoint blocks (4 keypoints each) per frame */
 };
+/* block -> (frame, keypoint block): blocks are dealt to the 8 XCDs round-robin (observed dispatch order, speed only), so block i works for frame
+ * (i % 8) + 8 * slot and walks through ALL keypoint blocks of that frame before the XCD moves to its next frame: the two pyramids of a frame
+ * (0.8 MB) stay in one XCD's 4 MB L2 while its ~1000 windows are gathered from them. */
+SGX_DEV void sgx_lk_decode_block(int i, int batch, int kblocks, int &f, int &kb)
+{
+    const int full = (batch / 8) * 8;                              /* frames that fill whole groups of eight */
+    if (i < full * kblocks) { const int x = i & 7, j = i >> 3; kb = j % kblocks; f = x + 8 * (j / kblocks); }
+    else { const int j = i - full * kblocks; f = full + j / kblocks; kb = j % kblocks; }
+}
 
 #ifdef SGX_EMU
 // scalar twin of the wave kernel (kernel-logic emulator only): same integer sums, same float steps
-static void sgx_lk_track_point(const SgxLkGeom &g, const uint8_t *I0, const int16_t *D0, const uint8_t *J0, float kx, float ky, int max_count, double eps2, float min_eig,
+static inline int sgx_lk_px(const uint8_t *I, int w, int h, int pitch, int x, int y) { return I[(size_t)sgx_reflect101(y, h) * pitch + sgx_reflect101(x, w)]; }
+static void sgx_lk_track_point(const SgxLkGeom &g, const uint8_t *I0, const uint8_t *J0, float kx, float ky, int max_count, double eps2, float min_eig,
                                float *ox, float *oy, uint8_t *ost)
 {
     const int W = SGX_LK_WIN; const float half = (W - 1) * 0.5f, FLT_SCALE = 1.f / (1 << 20);
@@ -210,7 +159,6 @@ static void sgx_lk_track_point(const SgxLkGeom &g, const uint8_t *I0, const int1
     for (int level = g.nl - 1; level >= 0; level--) {
         const int w = g.w[level], h = g.h[level], pitch = g.pitch[level];
         const uint8_t *I = I0 + g.ioff[level], *J = J0 + g.ioff[level];
-        const int16_t *Dv = (const int16_t *)((const uint8_t *)D0 + g.doff[level]);
         const float sc = 1.0f / (float)(1 << level);
         float prevx = kx * sc, prevy = ky * sc, nextx, nexty;
         if (level == g.nl - 1) { nextx = prevx; nexty = prevy; } else { nextx = outx * 2.f; nexty = outy * 2.f; }
@@ -224,8 +172,16 @@ static void sgx_lk_track_point(const SgxLkGeom &g, const uint8_t *I0, const int1
             int pv[4], dx[4], dy[4];
             for (int c = 0; c < 4; c++) {
                 const int gx = ipx + x + (c & 1), gy = ipy + y + (c >> 1);
-                pv[c] = I[(size_t)sgx_reflect101(gy, h) * pitch + sgx_reflect101(gx, w)];
-                if (gx < 0 || gy < 0 || gx >= w || gy >= h) { dx[c] = dy[c] = 0; } else { dx[c] = Dv[((size_t)gy * w + gx) * 2]; dy[c] = Dv[((size_t)gy * w + gx) * 2 + 1]; }
+                pv[c] = sgx_lk_px(I, w, h, pitch, gx, gy);
+                if (gx < 0 || gy < 0 || gx >= w || gy >= h) { dx[c] = dy[c] = 0; }
+                else {          /* calcSharrDeriv on the REFLECT_101-extended image; outside the image the derivative plane is 0 (copyMakeBorder CONSTANT) */
+                    int t0[3], t1[3];
+                    for (int q = 0; q < 3; q++) {
+                        const int a = sgx_lk_px(I, w, h, pitch, gx - 1 + q, gy - 1), b = sgx_lk_px(I, w, h, pitch, gx - 1 + q, gy), cc = sgx_lk_px(I, w, h, pitch, gx - 1 + q, gy + 1);
+                        t0[q] = (a + cc) * 3 + b * 10; t1[q] = cc - a;
+                    }
+                    dx[c] = t0[2] - t0[0]; dy[c] = (t1[0] + t1[2]) * 3 + t1[1] * 10;
+                }
             }
             const int iv = SGX_LK_DESCALE(pv[0] * k.w00 + pv[1] * k.w01 + pv[2] * k.w10 + pv[3] * k.w11, 9);
             const int ix = SGX_LK_DESCALE(dx[0] * k.w00 + dx[1] * k.w01 + dx[2] * k.w10 + dx[3] * k.w11, 14);
@@ -247,7 +203,7 @@ static void sgx_lk_track_point(const SgxLkGeom &g, const uint8_t *I0, const int1
             long long sb1 = 0, sb2 = 0;
             for (int y = 0; y < W; y++) for (int x = 0; x < W; x++) {
                 int pv[4];
-                for (int c = 0; c < 4; c++) pv[c] = J[(size_t)sgx_reflect101(iny + y + (c >> 1), h) * pitch + sgx_reflect101(inx + x + (c & 1), w)];
+                for (int c = 0; c < 4; c++) pv[c] = sgx_lk_px(J, w, h, pitch, inx + x + (c & 1), iny + y + (c >> 1));
                 const int diff = SGX_LK_DESCALE(pv[0] * k.w00 + pv[1] * k.w01 + pv[2] * k.w10 + pv[3] * k.w11, 9) - Iw[y * W + x];
                 sb1 += (long long)diff * dIw[(y * W + x) * 2]; sb2 += (long long)diff * dIw[(y * W + x) * 2 + 1];
             }
@@ -268,48 +224,100 @@ static void sgx_lk_track_point(const SgxLkGeom &g, const uint8_t *I0, const int1
 SGX_KERNEL(256) k_lk_track(SgxLkGeom g, SgxLkArgs A)
 {
     SGX_THREADS_BEGIN(tid)
-    const int f = (int)blockIdx.y, kp = (int)blockIdx.x * 4 + (tid >> 6);
+    int f, kb;
+    sgx_lk_decode_block((int)blockIdx.x, A.batch, A.kblocks, f, kb);
+    const int kp = kb * 4 + (tid >> 6);
     if ((tid & 63) == 0 && kp < A.n[f] && kp < A.cap) {
         const float *kpt = (const float *)(A.keys + ((size_t)f * A.cap + kp) * 28);
         float ox, oy; uint8_t st;
-        sgx_lk_track_point(g, A.cur_img + (size_t)f * g.img_stride, (const int16_t *)((const uint8_t *)A.cur_der + (size_t)f * g.der_stride), A.prev_img + (size_t)f * g.img_stride,
-                           kpt[0], kpt[1], A.max_count, A.eps2, A.min_eig, &ox, &oy, &st);
+        sgx_lk_track_point(g, A.cur_img + (size_t)f * g.img_stride, A.prev_img + (size_t)f * g.img_stride, kpt[0], kpt[1], A.max_count, A.eps2, A.min_eig, &ox, &oy, &st);
         A.prev_xy[2 * ((size_t)f * A.cap + kp)] = ox; A.prev_xy[2 * ((size_t)f * A.cap + kp) + 1] = oy;
         if (A.status) A.status[(size_t)f * A.cap + kp] = st;
     }
     SGX_THREADS_END
 }
 #else
-/* the eight bytes starting at byte offset `b` of an LDS tile, from three aligned dwords */
-SGX_DEV void sgx_lk_lds8(const uint32_t *tile, int b, uint32_t &lo, uint32_t &hi)
+/* sum over the 64 lanes of a wave (no overflow by construction at the call sites); the result is wave-uniform.  Four DPP adds give every lane its
+ * 16-lane row total (xor 1, xor 2 inside quads, rotate by 4 and by 8 inside the row); two row broadcasts carry the totals into lane 63. */
+SGX_DEV int sgx_wave_sum_i32(int v)
 {
-    const uint32_t *p = tile + (b >> 2); const uint32_t s = (uint32_t)b & 3u;
-    const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
-    lo = __builtin_amdgcn_alignbyte(w1, w0, s); hi = __builtin_amdgcn_alignbyte(w2, w1, s);
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);      /* quad_perm [1,0,3,2] */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);      /* quad_perm [2,3,0,1] */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, true);     /* row_ror:4 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, true);     /* row_ror:8 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);    /* row_bcast:15 into rows 1 and 3 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);    /* row_bcast:31 into rows 2 and 3 */
+    return __builtin_amdgcn_readlane(v, 63);
 }
-#define SGX_LK_BYTE(lo, hi, k) ((int)(((k) < 4 ? (lo) >> (8 * (k)) : (hi) >> (8 * ((k) - 4))) & 255u))
+/* exact wave sum of per-lane int32 partials, returned as the correctly rounded float of the exact integer: the low 16 bits and the signed high
+ * part are reduced separately (each fits 32 bits); hi * 65536 + lo is exact in fp64 (< 2^53), one rounding in the conversion to float —
+ * identical to (float)(int64) of the oracle */
+SGX_DEV float sgx_wave_sum_f32(int v)
+{
+    const int lo = sgx_wave_sum_i32(v & 0xFFFF), hi = sgx_wave_sum_i32(v >> 16);
+    return (float)((double)hi * 65536.0 + (double)lo);
+}
+SGX_DEV int sgx_mul24(int a, int b) { return __mul24(a, b); }          /* both operands fit 24 bits at every call site */
+/* REFLECT_101 for indices at most one image length outside, clamped (the clamp only ever acts on tile bytes no window uses) */
+SGX_DEV int sgx_reflect1(int p, int len) { p = p < 0 ? -p : p; p = p >= len ? 2 * len - 2 - p : p; return min(max(p, 0), len - 1); }
+
+typedef short sgx_i16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short sgx_u16x2 __attribute__((ext_vector_type(2)));
+SGX_DEV sgx_i16x2 sgx_as_i16x2(uint32_t v) { return __builtin_bit_cast(sgx_i16x2, v); }
+SGX_DEV uint32_t sgx_as_u32(sgx_i16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+/* (byte a of {hi:lo}, 0, byte b of {hi:lo}, 0): two pixels widened to a 16-bit pair in one v_perm_b32 */
+#define SGX_LK_PAIR(hi, lo, a, b) sgx_as_i16x2(__builtin_amdgcn_perm((hi), (lo), (uint32_t)(a) | 0x0c00u | ((uint32_t)(b) << 16) | 0x0c000000u))
+/* (high half of p, low half of q): the pair one 16-bit element further along a row of pairs */
+SGX_DEV sgx_i16x2 sgx_lk_next(sgx_i16x2 p, sgx_i16x2 q) { return sgx_as_i16x2(__builtin_amdgcn_alignbit(sgx_as_u32(q), sgx_as_u32(p), 16)); }
+#define SGX_LK_DOT2(a, b, c) __builtin_amdgcn_sdot2((a), (b), (c), false)
+
+/* stage the ROWS x 36-byte patch of `img` whose top-left corner is (ox, oy) (ox a multiple of 4) into the wave's LDS tile: REFLECT_101 outside the
+ * image, aligned dwords wherever the image allows.  Lane -> (row within a group of seven, dword column): 63 lanes move seven tile rows per pass. */
+template <int PASSES>
+SGX_DEV void sgx_lk_stage(uint32_t *tile, const uint8_t *img, int w, int h, int pitch, int ox, int oy, int rl, int cl)
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+    const int gx = ox + 4 * cl;
+    const bool inside = gx >= 0 && gx + 4 <= w;
+    const int x0 = sgx_reflect1(gx, w), x1 = sgx_reflect1(gx + 1, w), x2 = sgx_reflect1(gx + 2, w), x3 = sgx_reflect1(gx + 3, w);
+    if (rl < 7) {
+#pragma unroll
+        for (int p = 0; p < PASSES; p++) {
+            const int row = p * 7 + rl;
+            const uint8_t *src = img + (size_t)sgx_reflect1(oy + row, h) * pitch;
+            uint32_t v;
+            if (inside) v = *(const uint32_t *)(src + gx);
+            else v = (uint32_t)src[x0] | ((uint32_t)src[x1] << 8) | ((uint32_t)src[x2] << 16) | ((uint32_t)src[x3] << 24);
+            tile[row * (SGX_LK_TILE_PITCH / 4) + cl] = v;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+}
 
 SGX_KERNEL(256) k_lk_track(SgxLkGeom g, SgxLkArgs A)
 {
-    __shared__ uint32_t tiles[4][SGX_LK_TILE_ROWS * SGX_LK_TILE_PITCH / 4 + 4];
+    __shared__ uint32_t tiles[4][35 * SGX_LK_TILE_PITCH / 4 + 5];
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int f = (int)blockIdx.y, kp = (int)blockIdx.x * 4 + wv;
+    int f, kb;
+    sgx_lk_decode_block((int)blockIdx.x, A.batch, A.kblocks, f, kb);
+    const int kp = kb * 4 + wv;
     if (kp >= A.n[f] || kp >= A.cap) return;                       /* wave-uniform: no workgroup barrier is used below */
     uint32_t *tile = tiles[wv];
+    const uint8_t *tile8 = (const uint8_t *)tile;
     const int W = SGX_LK_WIN; const float half = 10.0f, FLT_SCALE = 1.f / (1 << 20);
     const float *kpt = (const float *)(A.keys + ((size_t)f * A.cap + kp) * 28);
     const float kx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, kpt[0])));
     const float ky = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, kpt[1])));
     const uint8_t *I0 = A.cur_img + (size_t)f * g.img_stride, *J0 = A.prev_img + (size_t)f * g.img_stride;
-    const uint8_t *D0 = (const uint8_t *)A.cur_der + (size_t)f * g.der_stride;
     const int r = lane / 3, s7 = (lane - 3 * r) * 7;               /* window row, first of the lane's seven columns */
+    const int rl = lane / 9, cl = lane - 9 * rl;                   /* staging role: tile row within a pass, dword column */
     const bool active = lane < 63;
+    const int lane_off = active ? r * SGX_LK_TILE_PITCH + s7 : 0;
     float outx = 0.f, outy = 0.f; int status = 1;
 
     for (int level = g.nl - 1; level >= 0; level--) {
         const int w = g.w[level], h = g.h[level], pitch = g.pitch[level];
         const uint8_t *I = I0 + g.ioff[level], *J = J0 + g.ioff[level];
-        const uint32_t *Dv = (const uint32_t *)(D0 + g.doff[level]);
         const float sc = 1.0f / (float)(1 << level);
         float prevx = kx * sc, prevy = ky * sc, nextx, nexty;
         if (level == g.nl - 1) { nextx = prevx; nexty = prevy; } else { nextx = outx * 2.f; nexty = outy * 2.f; }
@@ -318,36 +326,69 @@ SGX_KERNEL(256) k_lk_track(SgxLkGeom g, SgxLkArgs A)
         const int ipx = sgx_floor_f(prevx), ipy = sgx_floor_f(prevy);
         if (ipx < -W || ipx >= w || ipy < -W || ipy >= h) { if (level == 0) status = 0; continue; }
         SgxLkWeights k = sgx_lk_weights(prevx - ipx, prevy - ipy);
+        sgx_i16x2 W0 = sgx_as_i16x2((uint32_t)k.w00 | ((uint32_t)k.w01 << 16)), W1 = sgx_as_i16x2((uint32_t)k.w10 | ((uint32_t)k.w11 << 16));
 
-        // ---- this lane's seven window samples of I and its derivatives (kept in registers for every iteration of the level)
-        int iv[7], ix[7], iy[7];
+        // ---- this lane's seven window samples of I and of its Scharr derivatives (kept in registers for every iteration of the level).  The 24 x 24
+        //      patch (window + bilinear neighbour + one-pixel derivative apron) is staged once; calcSharrDeriv is evaluated from it on the fly in packed
+        //      16-bit arithmetic: tile rows gy0-1 .. gy0+2, columns gx0-1 .. gx0+8 give the derivatives at the 2 x 8 positions the lane interpolates between.
+        int ivb[7]; int ix[7], iy[7];                              /* ivb = 256 - (I sample << 9): the accumulator the J interpolation starts from */
         int s11 = 0, s12 = 0, s22 = 0;
         {
+            const int tx = ((ipx - 1) >> 2) << 2, ty = ipy - 1;
+            sgx_lk_stage<4>(tile, I, w, h, pitch, tx, ty, rl, cl);
             const int gy0 = ipy + r, gx0 = ipx + s7;
-            const uint8_t *ra = I + (size_t)sgx_reflect101(gy0, h) * pitch, *rb = I + (size_t)sgx_reflect101(gy0 + 1, h) * pitch;
-            const bool ya = gy0 >= 0 && gy0 < h, yb = gy0 + 1 >= 0 && gy0 + 1 < h;
-            int pa[8], pb[8]; uint32_t da[8], db[8];
+            const uint8_t *tb = tile8 + lane_off + (ipx - 1 - tx);                /* tile row gy0-1, column gx0-1 */
+            sgx_i16x2 P[4][5];                                     /* rows gy0-1 .. gy0+2, column pairs (0,1) (2,3) .. (8,9) */
 #pragma unroll
-            for (int c = 0; c < 8; c++) {
-                const int gx = gx0 + c, rx = sgx_reflect101(gx, w);
-                const bool xin = gx >= 0 && gx < w;
-                pa[c] = ra[rx]; pb[c] = rb[rx];
-                da[c] = (xin && ya) ? Dv[(size_t)gy0 * w + gx] : 0u;
-                db[c] = (xin && yb) ? Dv[(size_t)(gy0 + 1) * w + gx] : 0u;
+            for (int j = 0; j < 4; j++) {
+                uint32_t q[3];
+                __builtin_memcpy(q, tb + j * SGX_LK_TILE_PITCH, 12);
+                P[j][0] = SGX_LK_PAIR(q[0], q[0], 0, 1); P[j][1] = SGX_LK_PAIR(q[0], q[0], 2, 3);
+                P[j][2] = SGX_LK_PAIR(q[1], q[1], 0, 1); P[j][3] = SGX_LK_PAIR(q[1], q[1], 2, 3);
+                P[j][4] = SGX_LK_PAIR(q[2], q[2], 0, 1);
+            }
+            const sgx_i16x2 c3 = { 3, 3 }, c10 = { 10, 10 };
+            sgx_i16x2 S0[5], S1[5], D0[5], D1[5];                  /* column sums (3,10,3) and differences (-1,0,1) for derivative rows gy0 and gy0+1 */
+#pragma unroll
+            for (int q = 0; q < 5; q++) {
+                S0[q] = (P[0][q] + P[2][q]) * c3 + P[1][q] * c10; D0[q] = P[2][q] - P[0][q];
+                S1[q] = (P[1][q] + P[3][q]) * c3 + P[2][q] * c10; D1[q] = P[3][q] - P[1][q];
+            }
+            // derivative pairs at positions (gx0 + 2q, gx0 + 2q + 1), q = 0..3, rows gy0 (a) and gy0+1 (b)
+            sgx_i16x2 xa[5], ya[5], xb[5], yb[5];
+            const bool whole = ipx >= 0 && ipx + W < w && ipy >= 0 && ipy + W < h;       /* every position the window touches is inside the image (wave-uniform) */
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                xa[q] = S0[q + 1] - S0[q]; ya[q] = (D0[q] + D0[q + 1]) * c3 + sgx_lk_next(D0[q], D0[q + 1]) * c10;
+                xb[q] = S1[q + 1] - S1[q]; yb[q] = (D1[q] + D1[q + 1]) * c3 + sgx_lk_next(D1[q], D1[q + 1]) * c10;
+            }
+            if (!whole) {                                           /* the derivative plane is 0 outside the image (copyMakeBorder CONSTANT) */
+                const bool rowa = gy0 >= 0 && gy0 < h, rowb = gy0 + 1 >= 0 && gy0 + 1 < h;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int x = gx0 + 2 * q;
+                    const uint32_t m = ((x >= 0 && x < w) ? 0xFFFFu : 0u) | ((x + 1 >= 0 && x + 1 < w) ? 0xFFFF0000u : 0u);
+                    const uint32_t ma = rowa ? m : 0u, mb = rowb ? m : 0u;
+                    xa[q] = sgx_as_i16x2(sgx_as_u32(xa[q]) & ma); ya[q] = sgx_as_i16x2(sgx_as_u32(ya[q]) & ma);
+                    xb[q] = sgx_as_i16x2(sgx_as_u32(xb[q]) & mb); yb[q] = sgx_as_i16x2(sgx_as_u32(yb[q]) & mb);
+                }
             }
 #pragma unroll
             for (int c = 0; c < 7; c++) {
-                iv[c] = SGX_LK_DESCALE(pa[c] * k.w00 + pa[c + 1] * k.w01 + pb[c] * k.w10 + pb[c + 1] * k.w11, 9);
-                const int x00 = (int)(short)(da[c] & 0xFFFF), x01 = (int)(short)(da[c + 1] & 0xFFFF), x10 = (int)(short)(db[c] & 0xFFFF), x11 = (int)(short)(db[c + 1] & 0xFFFF);
-                const int y00 = (int)da[c] >> 16, y01 = (int)da[c + 1] >> 16, y10 = (int)db[c] >> 16, y11 = (int)db[c + 1] >> 16;
-                ix[c] = SGX_LK_DESCALE(x00 * k.w00 + x01 * k.w01 + x10 * k.w10 + x11 * k.w11, 14);
-                iy[c] = SGX_LK_DESCALE(y00 * k.w00 + y01 * k.w01 + y10 * k.w10 + y11 * k.w11, 14);
-                if (!active) { iv[c] = 0; ix[c] = 0; iy[c] = 0; }
-                s11 += ix[c] * ix[c]; s12 += ix[c] * iy[c]; s22 += iy[c] * iy[c];
+                // pairs (c, c+1): even c are the stored pairs, odd c straddle two of them
+                const sgx_i16x2 pxa = (c & 1) ? sgx_lk_next(xa[c >> 1], xa[(c >> 1) + 1]) : xa[c >> 1], pxb = (c & 1) ? sgx_lk_next(xb[c >> 1], xb[(c >> 1) + 1]) : xb[c >> 1];
+                const sgx_i16x2 pya = (c & 1) ? sgx_lk_next(ya[c >> 1], ya[(c >> 1) + 1]) : ya[c >> 1], pyb = (c & 1) ? sgx_lk_next(yb[c >> 1], yb[(c >> 1) + 1]) : yb[c >> 1];
+                // image pair at columns (c+1, c+2) of the 10-column rows 1 and 2: odd-aligned for even c
+                const sgx_i16x2 pia = (c & 1) ? P[1][(c + 1) >> 1] : sgx_lk_next(P[1][c >> 1], P[1][(c >> 1) + 1]), pib = (c & 1) ? P[2][(c + 1) >> 1] : sgx_lk_next(P[2][c >> 1], P[2][(c >> 1) + 1]);
+                int v = SGX_LK_DOT2(pib, W1, SGX_LK_DOT2(pia, W0, 256)) >> 9;
+                int vx = SGX_LK_DOT2(pxb, W1, SGX_LK_DOT2(pxa, W0, 8192)) >> 14;
+                int vy = SGX_LK_DOT2(pyb, W1, SGX_LK_DOT2(pya, W0, 8192)) >> 14;
+                if (!active) { v = 0; vx = 0; vy = 0; }
+                ivb[c] = 256 - (v << 9); ix[c] = vx; iy[c] = vy;
+                s11 += sgx_mul24(vx, vx); s12 += sgx_mul24(vx, vy); s22 += sgx_mul24(vy, vy);
             }
         }
-        const float A11 = sgx_i64_to_f32(sgx_wave_sum_i64(s11)) * FLT_SCALE, A12 = sgx_i64_to_f32(sgx_wave_sum_i64(s12)) * FLT_SCALE,
-                    A22 = sgx_i64_to_f32(sgx_wave_sum_i64(s22)) * FLT_SCALE;
+        const float A11 = sgx_wave_sum_f32(s11) * FLT_SCALE, A12 = sgx_wave_sum_f32(s12) * FLT_SCALE, A22 = sgx_wave_sum_f32(s22) * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * W * W);
         if (minEig < A.min_eig || D < FLT_EPSILON) { if (level == 0) status = 0; continue; }
@@ -359,41 +400,30 @@ SGX_KERNEL(256) k_lk_track(SgxLkGeom g, SgxLkArgs A)
             const int inx = sgx_floor_f(nextx), iny = sgx_floor_f(nexty);
             if (inx < -W || inx >= w || iny < -W || iny >= h) { if (level == 0) status = 0; break; }
             k = sgx_lk_weights(nextx - inx, nexty - iny);
-            if (!staged || inx < ox || inx - ox > SGX_LK_TILE_PITCH - 22 || iny < oy || iny - oy > SGX_LK_TILE_ROWS - 22) {
-                // ---- stage the 32 x 36-byte patch of J around the window (REFLECT_101 outside the image), aligned dwords where the image allows
-                ox = ((inx - 5) >> 2) << 2; oy = iny - 5;
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
-                for (int i = lane; i < SGX_LK_TILE_ROWS * (SGX_LK_TILE_PITCH / 4); i += 64) {
-                    const int row = i / (SGX_LK_TILE_PITCH / 4), c4 = (i - row * (SGX_LK_TILE_PITCH / 4)) * 4;
-                    const uint8_t *src = J + (size_t)sgx_reflect101(oy + row, h) * pitch;
-                    const int gx = ox + c4;
-                    uint32_t v;
-                    if (gx >= 0 && gx + 4 <= w) v = *(const uint32_t *)(src + gx);
-                    else v = (uint32_t)src[sgx_reflect101(gx, w)] | ((uint32_t)src[sgx_reflect101(gx + 1, w)] << 8) | ((uint32_t)src[sgx_reflect101(gx + 2, w)] << 16) |
-                             ((uint32_t)src[sgx_reflect101(gx + 3, w)] << 24);
-                    tile[i] = v;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+            W0 = sgx_as_i16x2((uint32_t)k.w00 | ((uint32_t)k.w01 << 16)); W1 = sgx_as_i16x2((uint32_t)k.w10 | ((uint32_t)k.w11 << 16));
+            if (!staged || inx < ox || inx - ox > SGX_LK_TILE_PITCH - 22 || iny < oy || iny - oy > 35 - 22) {
+                ox = ((inx - 5) >> 2) << 2; oy = iny - 6;           /* five to eight pixels of room on every side before the window leaves the tile */
+                sgx_lk_stage<5>(tile, J, w, h, pitch, ox, oy, rl, cl);
                 staged = true;
             }
             int sb1 = 0, sb2 = 0;
             {
-                const int b = (iny - oy + r) * SGX_LK_TILE_PITCH + (inx - ox) + s7;
-                uint32_t alo, ahi, blo, bhi;
-                sgx_lk_lds8(tile, active ? b : 0, alo, ahi); sgx_lk_lds8(tile, active ? b + SGX_LK_TILE_PITCH : 0, blo, bhi);
+                const uint8_t *tb = tile8 + lane_off + (iny - oy) * SGX_LK_TILE_PITCH + (inx - ox);
+                uint32_t a[2], b[2];
+                __builtin_memcpy(a, tb, 8); __builtin_memcpy(b, tb + SGX_LK_TILE_PITCH, 8);
 #pragma unroll
                 for (int c = 0; c < 7; c++) {
-                    const int diff = SGX_LK_DESCALE(SGX_LK_BYTE(alo, ahi, c) * k.w00 + SGX_LK_BYTE(alo, ahi, c + 1) * k.w01 + SGX_LK_BYTE(blo, bhi, c) * k.w10 +
-                                                    SGX_LK_BYTE(blo, bhi, c + 1) * k.w11, 9) - iv[c];
-                    sb1 += diff * ix[c]; sb2 += diff * iy[c];          /* ix = iy = 0 on the idle lane */
+                    const int diff = SGX_LK_DOT2(SGX_LK_PAIR(b[1], b[0], c, c + 1), W1, SGX_LK_DOT2(SGX_LK_PAIR(a[1], a[0], c, c + 1), W0, ivb[c])) >> 9;
+                    sb1 += sgx_mul24(diff, ix[c]); sb2 += sgx_mul24(diff, iy[c]);          /* ix = iy = 0 on the idle lane */
                 }
             }
-            const SgxLkStep st = sgx_lk_step(A11, A12, A22, D, sgx_wave_sum_i64(sb1), sgx_wave_sum_i64(sb2));
-            nextx += st.dx; nexty += st.dy;
+            const float b1 = sgx_wave_sum_f32(sb1) * FLT_SCALE, b2 = sgx_wave_sum_f32(sb2) * FLT_SCALE;
+            const float dx = (A12 * b2 - A22 * b1) * D, dy = (A12 * b1 - A11 * b2) * D;
+            nextx += dx; nexty += dy;
             outx = nextx + half; outy = nexty + half;
-            if ((double)st.dx * st.dx + (double)st.dy * st.dy <= A.eps2) break;
-            if (j > 0 && fabs((double)(st.dx + pdx)) < 0.01 && fabs((double)(st.dy + pdy)) < 0.01) { outx -= st.dx * 0.5f; outy -= st.dy * 0.5f; break; }
-            pdx = st.dx; pdy = st.dy;
+            if ((double)dx * dx + (double)dy * dy <= A.eps2) break;
+            if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) { outx -= dx * 0.5f; outy -= dy * 0.5f; break; }
+            pdx = dx; pdy = dy;
         }
         if (status && level == 0) {
             const int qx = sgx_floor_f(outx - half), qy = sgx_floor_f(outy - half);

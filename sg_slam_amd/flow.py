@@ -52,13 +52,12 @@ class OpticalFlowLK:
                                                           C.byref(have), _vp(stream)), 'sgx_flow_lk_batch_dev')
         return bool(have.value)
 
-    def debug_level(self, slot, frame, level, want_der=False):
+    def debug_level(self, slot, frame, level):
         w, h = C.c_int32(), C.c_int32()
         self.lib.check(self.lib.dll.sgx_flow_debug_level_size(self.h, level, C.byref(w), C.byref(h)))
         img = np.zeros((h.value, w.value), np.uint8)
-        der = np.zeros((h.value, w.value, 2), np.int16) if want_der else None
-        self.lib.check(self.lib.dll.sgx_flow_debug_read_level(self.h, slot, frame, level, _vp(img), _vp(der)), 'flow debug_read_level')
-        return (img, der) if want_der else img
+        self.lib.check(self.lib.dll.sgx_flow_debug_read_level(self.h, slot, frame, level, _vp(img)), 'flow debug_read_level')
+        return img
 
 
 def find_fundamental_mat(pts1, pts2, threshold=1.0, confidence=0.99, lib=None):
