@@ -1,17 +1,18 @@
 #!/usr/bin/env python3
-"""bench.py — tracked frames/s of the MI355X tracking hot path on synthetic 640x480 RGB-D streams.
+"""bench.py — tracked frames/s of the MI355X tracking hot path on 640x480 RGB-D streams.
 
-One "step" = one frame from each of S independent streams on this GPU pushed through the whole
-per-frame path (sg_slam_amd/tracker.py): ORB extract -> stereo-from-RGBD -> motion model ->
-SearchByProjection(cur,last) -> PoseOptimization -> [TrackLocalMap: SearchByProjection(cur, local points) ->
-PoseOptimization] -> unproject -> new map points.  Frames are resident in HBM before the
-timed region.  N>1: one process per GPU (torch.distributed over RCCL); streams are sharded across ranks
-(weak scaling, no data-path collective); after the timed region the per-frame records (pose + counts) are
-gathered to rank 0 with one RCCL all_gather (BASELINE config 5), outside the timing.
-value = all ranks' frames / max-over-ranks time.
+One "step" = one frame from each of S independent streams on this GPU pushed through the whole per-frame path (sg_slam_amd/tracker.py):
+  Detector2D::detect (MobileNetV3-SSDLite forward on the fp32 matrix cores + DetectionOutput + filtering, own HIP stream)   [--no-detector to drop]
+  ORB extract -> pyramidal LK flow into the previous frame -> RANSAC fundamental matrix -> wait for the detector -> dynamic-feature mask + erase
+  -> stereo-from-RGBD -> motion model -> SearchByProjection(cur,last) -> PoseOptimization -> [TrackLocalMap: SearchByProjection(cur, local points)
+  -> PoseOptimization] -> unproject -> new map points.
+Frames are resident in HBM before the timed region.  N>1: one process per GPU (torch.distributed over RCCL); streams are sharded across ranks
+(weak scaling, no data-path collective); the per-frame records {n, keypoints, descriptors, pose} of every step are gathered to all ranks with one
+RCCL all_gather per step on a side stream inside the timed region (BASELINE config 5).  value = all ranks' frames / max-over-ranks time.
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel by summed HIP-event time inside the timed
-region) and `cpu_baseline` (the oracle — CPU restatement of the reference path — timed on host cores).
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel class by summed HIP-event time inside the timed region), `cpu_baseline` (the oracle —
+CPU restatement of the reference path — timed on host cores) and `config2` (the ORB extract + match + pose-opt chain without detector / LK / RANSAC:
+BASELINE configs[1], last round's headline, for continuity).
 """
 import argparse
 import json
@@ -25,8 +26,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F32_PEAK_TFS = 157.3        # fp32-input MFMA = fp32 vector peak
+FP64_PEAK_TFS = 78.6
 LEVELS = [(640, 480), (533, 400), (444, 333), (370, 278), (309, 231), (257, 193), (214, 161), (179, 134)]
 PIX = [w * h for w, h in LEVELS]
+LKPIX = [640 * 480, 320 * 240, 160 * 120, 80 * 60]
 
 
 def algorithmic_bytes_per_frame(nkp=1000, ncand=6000, nmatch=600):
@@ -35,15 +39,19 @@ def algorithmic_bytes_per_frame(nkp=1000, ncand=6000, nmatch=600):
         'pyramid_resize': sum(PIX[:-1]) + sum(PIX[1:]),            # read levels 0..6 once, write levels 1..7
         'fast_cells': sum(PIX) + 4 * ncand,                        # read every level once, write packed candidates
         'octree': 4 * ncand + 4 * nkp,                             # read candidates, write selected
-        'orient_desc': sum(PIX) + nkp * (28 + 32),                 # fused bound: read every level at most once, write kp + desc (the whole-level blur design moves ~1.9x)
+        'orient_desc': sum(PIX) + nkp * (28 + 32),                 # fused bound: read every level at most once, write kp + desc
         'stereo_from_rgbd': nkp * (28 + 2 + 8),                    # keypoint + one depth texel in, uright/z out
         'motion_model': 3 * 64,
         'match_project_frame': 2 * nkp * (28 + 32) + nkp * (4 + 12 + 1 + 1 + 4) + nkp * 4,   # both frames' kp+desc, uright/xw/flags, match out
         'pose_opt': nkp * (28 + 4 + 4) + nmatch * 12 + nkp + 64,   # keypoints, uright, match index, matched map points, outlier flags, pose
         'unproject': nkp * (28 + 4 + 12 + 1),
-        'match_project_local': nkp * (28 + 32 + 4 + 4) + 2 * nkp * (12 + 12 + 4 + 4 + 32 + 4 + 1) + nkp * 4 + 2 * nkp,   # cur kp/desc/uright/obs, 2 frames of map points, match + in_view out
-        'dynamic_mask': nkp * (28 + 8 + 1) / 2 + nkp * (1 + 2 * (28 + 32)) / 2,      # per launch: mask (keypoint + prev point in, flag out) | compaction (records in and out)
-        'map_point_glue': nkp * (28 + 12 + 1 + 32 + 12 + 12 + 8 + 32 + 1) / 4 + nkp * (4 + 1 + 4 + 4 + 4) / 2 + 3 * nkp * 24 / 4,   # per launch: make_map_points | merge (x2) | gather
+        'match_project_local': nkp * (28 + 32 + 4 + 4) + 2 * nkp * (12 + 12 + 4 + 4 + 32 + 4 + 1) + nkp * 4 + 2 * nkp,
+        'dynamic_mask': nkp * (28 + 8 + 1) / 2 + nkp * (1 + 2 * (28 + 32)) / 2,      # per launch: mask | compaction
+        'map_point_glue': nkp * (28 + 12 + 1 + 32 + 12 + 12 + 8 + 32 + 1) / 4 + nkp * (4 + 1 + 4 + 4 + 4) / 2 + 3 * nkp * 24 / 4,
+        'lk_pyramid': LKPIX[0] + sum(LKPIX),                       # read the frame once, write the four LK levels (incl. the kept copy of level 0)
+        'lk_track': 2 * sum(LKPIX) + nkp * (28 + 9),               # both pyramids read once, keypoints in, tracked position + status out
+        'fm_ransac': nkp * (28 + 8) + 80,                          # point pairs in, F + flag out
+        'det_output': 2268 * (4 + 21) * 4 + 4852,                  # loc + softmax conf of every prior in, result struct out
     }
 
 
@@ -51,10 +59,21 @@ def ping_pong(T):
     return list(range(T)) + list(range(T - 2, 0, -1)) if T > 1 else [0]
 
 
+def ate_pooled(est, ref):
+    """est, ref: (N, S, 4, 4) Tcw; per-stream Horn alignment, pooled translational RMSE over all streams and frames"""
+    from sg_slam_amd import tum
+    sq = 0.0; cnt = 0
+    for s in range(est.shape[1]):
+        a, b = tum.camera_centres(est[:, s]), tum.camera_centres(ref[:, s])
+        r = tum.ate_rmse(a, b)
+        sq += r * r * len(a); cnt += len(a)
+    return float(np.sqrt(sq / max(cnt, 1))), sq, cnt
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--steps', type=int, default=24)
     ap.add_argument('--warmup', type=int, default=4)
     ap.add_argument('--streams', type=int, default=256, help='independent streams per GPU (frames per step)')
     ap.add_argument('--frames', type=int, default=6, help='distinct frames kept per stream (ping-pong replay)')
@@ -62,13 +81,17 @@ def main():
     ap.add_argument('--no-cpu-all-cores', action='store_true', help='skip the frames-parallel all-host-cores CPU baseline (keeps the 1-core figure)')
     ap.add_argument('--no-pipeline', action='store_true', help='single HIP stream (no overlap of extraction with match/pose-opt)')
     ap.add_argument('--no-local-map', action='store_true', help='skip the TrackLocalMap stage (local-map SearchByProjection + second PoseOptimization)')
-    ap.add_argument('--groups', type=int, default=1, help='split the streams of this GPU into G independently pipelined groups (own extraction / tracking HIP streams each): '
-                    'the drain of one group between kernels overlaps the body of another')
-    ap.add_argument('--detector', action='store_true', help='also run Detector2D::detect (MobileNetV3-SSDLite forward + DetectionOutput + filtering, all on the device; synthetic weights) on '
-                    'every frame, on a third HIP stream; its boxes land in device arrays of the mask stage\'s layout, but the mask keeps using the synthetic person box '
-                    '(random-weight detections would erase random features)')
-    ap.add_argument('--no-mask', action='store_true', help='skip the dynamic-feature mask + erase stage (Frame::RmDynamicPointWithSemanticAndGeometry)')
-    ap.add_argument('--cpu-sample', type=int, default=400, help='frames timed on the CPU oracle')
+    ap.add_argument('--no-detector', action='store_true', help='drop Detector2D::detect (the mask then sees no person boxes)')
+    ap.add_argument('--no-config2', action='store_true', help='skip the secondary ORB extract + match + pose-opt measurement (BASELINE configs[1])')
+    ap.add_argument('--config2-only', action='store_true', help='measure only the configs[1] chain (no detector, no LK / RANSAC; mask inputs from the synthetic ground truth)')
+    ap.add_argument('--param', default=os.path.join(ROOT, 'tests', 'golden', 'mobilenetv3_ssdlite_voc.param'), help='ncnn .param of the detector (the graph the reference ships)')
+    ap.add_argument('--bin', default='', help='ncnn .bin weights of the detector (absent from the reference tree; default: synthetic weights in .bin order)')
+    ap.add_argument('--person-logit', type=float, default=-4.0, help='synthetic detector weights only: offset of the person-class logit.  Random weights report large random "person" boxes; '
+                    'the mask then erases most static keypoints inside them (0.2 px rule) and streams get lost.  -4 (default): practically no person detections, the mask works with its '
+                    '1.0 px rule; +2: ~7 random boxes per frame (tests/test_detector_mask_gpu.py checks that data flow)')
+    ap.add_argument('--tum', default='', help='TUM RGB-D sequence directory (rgb/ depth/ associations.txt [groundtruth.txt]): the streams are consecutive chunks of the sequence')
+    ap.add_argument('--save-trajectory', default='', help='write stream 0 of rank 0 as a TUM trajectory file (System::SaveTrajectoryTUM format)')
+    ap.add_argument('--cpu-sample', type=int, default=120, help='frames timed on the CPU oracle')
     args = ap.parse_args()
 
     import torch
@@ -86,109 +109,152 @@ def main():
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
 
     import sg_slam_amd
-    from sg_slam_amd import synth
+    from sg_slam_amd import synth, tum
+    from sg_slam_amd import dist as sdist
     from sg_slam_amd.tracker import TrackerBatch
+    from sg_slam_amd.capi import _vp
     lib = sg_slam_amd.load()
     cam = dict(synth.TUM3)
 
     S, T = args.streams, args.frames
-    # synthetic streams: stream s of rank r = the plane stream starting at time offset 37*(r*S+s)
-    gen = synth.PlaneStream(seed=1234)
-    host = np.empty((T, S, 480, 640), np.uint8)
-    from sg_slam_amd import dist as sdist
+    # synthetic scene: a textured background plane with a second textured layer in front of it (parallax, occlusion boundaries); ground-truth poses known
+    gen = synth.LayeredStream(seed=1234)
     t0s = sdist.stream_offsets(rank, S)
-    for s in range(S):
-        for t in range(T):
-            host[t, s] = gen.frame(t0s[s] + t)[0]
-    d_frames = torch.from_numpy(host).cuda()
-    depth_val = int(round(gen.z0 * cam['depth_factor']))
-    d_depth = torch.full((S, 480, 640), depth_val, dtype=torch.int16, device='cuda')      # the plane: constant raw depth (u16 bits)
     order = ping_pong(T)
-
-    class TrackerGroups:
-        """G TrackerBatch instances over contiguous slices of the S streams, stepped together (same interface as one TrackerBatch for what bench.py reads)"""
-        def __init__(self, G):
-            self.bounds = [(g * S // G, (g + 1) * S // G) for g in range(G)]
-            self.trs = [TrackerBatch(lib, b - a, cam, xp='torch', pipelined=not args.no_pipeline, local_map=not args.no_local_map) for a, b in self.bounds]
-            self.max_boxes, self.cap, self.ex = self.trs[0].max_boxes, self.trs[0].cap, self.trs[0].ex
-        def set_initial_pose(self, T0):
-            for (a, b), t in zip(self.bounds, self.trs): t.set_initial_pose(T0[a:b])
-        def step(self, gray, depth, stream=None, mask=None):
-            for (a, b), t in zip(self.bounds, self.trs):
-                t.step(gray[a:b], depth[a:b], stream=stream, mask=None if mask is None else {k: v[a:b] for k, v in mask.items()})
-        def synchronize(self):
-            for t in self.trs: t.synchronize()
-        def _cat(self, parts): return tuple(np.concatenate(x) for x in zip(*parts))
-        def last_counts(self): return self._cat([t.last_counts() for t in self.trs])
-        def last_local_counts(self): return self._cat([t.last_local_counts() for t in self.trs])
-        def last_pose(self): return np.concatenate([t.last_pose() for t in self.trs])
-        @property
-        def rn(self): return torch.cat([t.rn for t in self.trs])
-        @property
-        def ninl(self): return torch.cat([t.ninl for t in self.trs])
-        @property
-        def nmatch(self): return torch.cat([t.nmatch for t in self.trs])
-        @property
-        def Tcw(self): return [torch.cat([t.Tcw[i] for t in self.trs]) for i in range(3)]
-
-    tr = TrackerGroups(max(1, min(args.groups, S)))
-    tr.set_initial_pose(np.stack([gen.Tcw(t0) for t0 in t0s]))
+    stamps = None; gt_tum = None
+    if args.tum:
+        # BASELINE configs 1 / 3: a real TUM sequence.  Stream s = frames [s*T, (s+1)*T) of the sequence (consecutive chunks), replayed ping-pong like the synthetic ones.
+        st_all, rgbf, depf = tum.load_associations(os.path.join(args.tum, 'associations.txt'))
+        S = min(S, max(1, len(st_all) // T)); t0s = [s * T for s in range(S)]
+        bgr = np.empty((T, S, 480, 640, 3), np.uint8); dep = np.empty((T, S, 480, 640), np.uint16)
+        for s in range(S):
+            for t in range(T):
+                bgr[t, s], dep[t, s] = tum.load_frame(args.tum, rgbf[s * T + t], depf[s * T + t])
+        stamps = np.array(st_all[:S * T]).reshape(S, T)
+        d_bgr = torch.from_numpy(bgr).cuda()
+        d_frames = torch.empty((T, S, 480, 640), dtype=torch.uint8, device='cuda')
+        for t in range(T):      # Tracking::GrabImageRGBD's cvtColor: Camera.RGB = 1 in TUM3.yaml applies the RGB weights to imread's BGR data (Tracking.cc:216-217)
+            lib.check(lib.dll.sgx_frame_gray_from_color_batch_dev(S, 640, 480, _vp(d_bgr[t]), 640 * 3, 3, 0, _vp(d_frames[t]), 640, None), 'gray')
+        torch.cuda.synchronize()
+        host = d_frames.cpu().numpy()
+        d_depth_t = torch.from_numpy(dep.view(np.int16)).cuda()
+        gtp = os.path.join(args.tum, 'groundtruth.txt')
+        if os.path.exists(gtp):
+            gt_tum = tum.load_trajectory_tum(gtp)
+    else:
+        host, host_depth = synth.synth_streams('LayeredStream', 1234, t0s, T)
+        d_frames = torch.from_numpy(host).cuda()
+        d_depth_t = torch.from_numpy(host_depth.view(np.int16)).cuda()          # raw u16 depth (DepthMapFactor 5000) as int16 bits
+        d_bgr = None
+    def depth_of(fi): return d_depth_t[fi if d_depth_t.shape[0] > 1 else 0]
     stream = torch.cuda.current_stream().cuda_stream
+    MB = 100                                                                                      # SGX_DET_MAX person boxes per frame
 
-    # Inputs of the dynamic-feature mask.  The reference obtains them on the host (LK flow + RANSAC F, Frame.cc:445-472; person boxes from
-    # Detector2D): here they come from the synthetic ground truth (synth.flow_affine / synth.fundamental), with one "person" box per stream whose
-    # content moves 6 px across the epipolar lines, so the erase path does real work (~8 % of the keypoints go).
-    masks = {}
-    if not args.no_mask:
-        boxes = torch.zeros((S, tr.max_boxes, 4), dtype=torch.float32, device='cuda'); boxes[:, 0] = torch.tensor([200.0, 120.0, 160.0, 240.0])
-        nboxes = torch.ones((S,), dtype=torch.int32, device='cuda'); have_dyn = torch.ones((S,), dtype=torch.int32, device='cuda')
-        for i in range(1, len(order) + 1):
-            a, b = order[(i - 1) % len(order)], order[i % len(order)]
-            if (a, b) in masks: continue
-            A = np.stack([synth.flow_affine(gen, t0 + b, t0 + a).reshape(6) for t0 in t0s]).astype('f4')
-            F = np.stack([synth.fundamental(gen, t0 + b, t0 + a).reshape(9) for t0 in t0s])
-            d = np.stack([A[:, 0] * 280 + A[:, 1] * 240 + A[:, 2] - 280, A[:, 3] * 280 + A[:, 4] * 240 + A[:, 5] - 240], 1)
-            sh = 6.0 * np.stack([-d[:, 1], d[:, 0]], 1) / np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-9)
-            masks[(a, b)] = dict(A=torch.from_numpy(A).cuda(), F=torch.from_numpy(F).cuda(), boxes=boxes, nboxes=nboxes, have_dynamic=have_dyn,
-                                 shift=torch.from_numpy(sh.astype('f4')).cuda())
+    def initial_poses():
+        return np.stack([np.eye(4) for _ in t0s]) if args.tum else np.stack([gen.Tcw(t0) for t0 in t0s])
 
+    # ------------------------------------------------------------------------------------------------ secondary: BASELINE configs[1] chain
+    def run_config2(steps, warmup):
+        """ORB extract -> stereo -> motion model -> match -> pose-opt (-> local map) -> unproject: BASELINE configs[1], last round's headline chain (that one also ran the
+        mask + erase kernels on ground-truth flow; they are part of the full path now)"""
+        tr2 = TrackerBatch(lib, S, cam, xp='torch', pipelined=not args.no_pipeline, local_map=not args.no_local_map)
+        tr2.set_initial_pose(initial_poses())
+        def st2(i):
+            tr2.step(d_frames[order[i % len(order)]], depth_of(order[i % len(order)]), stream=stream, mask=None)
+        for i in range(warmup): st2(i)
+        tr2.synchronize(); torch.cuda.synchronize()
+        if dist: dist.barrier()
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        for i in range(steps): st2(warmup + i)
+        tr2.synchronize(); torch.cuda.synchronize()
+        if dist: dist.barrier()
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - c0
+        if dist: dt2 = sdist.max_over_ranks(dist, dt2, 'cuda')
+        nk, nm, ni = tr2.last_counts()
+        return {'workload': 'Single MI355X: ORB extract+match HIP kernels, 640x480 synthetic stream, 1000 feats/frame', 'value': S * steps * world / dt2, 'unit': 'frames/s',
+                'ms_per_step': dt2 / steps * 1e3, 'steps': steps, 'warmup': warmup, 'mean_keypoints': float(nk.mean()), 'mean_matches': float(nm.mean()),
+                'stages': 'orb_extract, stereo, motion model, SearchByProjection, PoseOptimization, local-map SearchByProjection, PoseOptimization, unproject, make_map_points; '
+                          'no detector, no LK / RANSAC / mask'}
+
+    if args.config2_only:
+        c2 = run_config2(args.steps, args.warmup)
+        if rank == 0:
+            print(json.dumps({'metric': 'tracked frames/sec (640x480 RGB-D)', 'value': c2['value'], 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                              'ms_per_step': c2['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
+                              'config': c2, 'roofline': None, 'cpu_baseline': None}))
+        if dist: dist.destroy_process_group()
+        return
+
+    # ------------------------------------------------------------------------------------------------ the full per-frame path
+    tr = TrackerBatch(lib, S, cam, xp='torch', pipelined=not args.no_pipeline, local_map=not args.no_local_map, lk=True, max_boxes=MB)
+    tr.set_initial_pose(initial_poses())
     det = None
-    if args.detector:
-        # BASELINE config 3: the detector forward of every frame runs beside extraction and tracking (the reference runs Detector2D::detect on its own thread).
-        from sg_slam_amd.detector import Detector2D
-        from oracle import detector_oracle as D_                  # only to synthesise the weight blob (the reference's .bin is absent)
+    if not args.no_detector:
+        # Detector2D::detect of every frame on its own HIP stream (the reference runs it on its own thread, Detector2D::Run); its person boxes are read by the mask
+        # stage of the SAME frame after an event wait (Frame.cc:478-500) and by the RANSAC pair selection of the NEXT frame (Frame.cc:454-467).
         import ctypes as C_
-        from sg_slam_amd.capi import _vp as _vp_
-        param = os.path.join(ROOT, 'tests', 'golden', 'mobilenetv3_ssdlite_voc.param')
-        _, blob = D_.synth_weights(D_.parse_param(param))
-        det = Detector2D(0.9, 0.01, param_text=open(param).read(), bin_bytes=blob, max_batch=S, lib=lib)
-        d_bgr = d_frames.unsqueeze(-1).expand(T, S, 480, 640, 3).contiguous()          # gray replicated to 3 channels (SURVEY §8(d) input 2)
+        from sg_slam_amd.detector import Detector2D
+        from sg_slam_amd.capi import DetResult
+        layers = synth.parse_ncnn_param(args.param)
+        if args.bin:
+            blob = open(args.bin, 'rb').read(); weights_note = f'weights from {os.path.basename(args.bin)}'
+        else:
+            _, blob = synth.synth_ncnn_weights(layers, seed=7, person_logit=args.person_logit)
+            weights_note = f'synthetic weights N(0, 2/fan_in) seed 7 in ncnn .bin order, person-class logit {args.person_logit:+g} (the reference tree does not contain the .bin)'
+        det = Detector2D(0.9, 0.01, param_text=open(args.param).read(), bin_bytes=blob, max_batch=S, lib=lib)
+        if d_bgr is None:
+            d_bgr = d_frames.unsqueeze(-1).expand(T, S, 480, 640, 3).contiguous()          # gray replicated to 3 channels (SURVEY §8(d) input 2)
         sD = torch.cuda.Stream(); sD.wait_stream(torch.cuda.current_stream())
-        from sg_slam_amd.capi import DetResult as DetResult_
-        d_det_res = torch.zeros((S, C_.sizeof(DetResult_)), dtype=torch.uint8, device='cuda')
-        d_det_boxes = torch.zeros((S, 4, 4), dtype=torch.float32, device='cuda'); d_det_nb = torch.zeros(S, dtype=torch.int32, device='cuda'); d_det_have = torch.zeros(S, dtype=torch.int32, device='cuda')
-        def det_step(i):
-            det.detect_batch_dev(d_bgr[order[i % len(order)]], 640 * 3, S, d_det_res, d_det_boxes, d_det_nb, 4, d_det_have, stream=sD.cuda_stream)
+        det_res = [torch.zeros((S, C_.sizeof(DetResult)), dtype=torch.uint8, device='cuda') for _ in range(2)]
+        det_boxes = [torch.zeros((S, MB, 4), dtype=torch.float32, device='cuda') for _ in range(2)]
+        det_nb = [torch.zeros(S, dtype=torch.int32, device='cuda') for _ in range(2)]
+        det_have = [torch.zeros(S, dtype=torch.int32, device='cuda') for _ in range(2)]
+        det_ev = [torch.cuda.Event() for _ in range(2)]
+        det_gflop = 2.0 * det.gmac
+
+    gather = sdist.FrameRecordGather(dist, S, tr.cap, 'cuda') if dist else None
+    traj = []; box_log = []                       # device pose snapshots per step; (boxes, nboxes) of stream 0 per step for the oracle-chain comparison
 
     def step(i):
-        if det is not None: det_step(i)
-        m = masks.get((order[(i - 1) % len(order)], order[i % len(order)])) if (i > 0 and masks) else None
-        tr.step(d_frames[order[i % len(order)]], d_depth, stream=stream, mask=m)
+        fi = order[i % len(order)]
+        m = {}
+        if det is not None:
+            b = i & 1
+            if i >= 2 and tr.pipelined:
+                sD.wait_event(tr.ev_extract[(i - 2) % 3])       # buffer set b was last read by the mask / pre-box copy of step i-2 (extraction stream)
+            det.detect_batch_dev(d_bgr[fi], 640 * 3, S, det_res[b], det_boxes[b], det_nb[b], MB, det_have[b], stream=sD.cuda_stream)
+            det_ev[b].record(sD)
+            m = dict(boxes=det_boxes[b], nboxes=det_nb[b], have_dynamic=det_have[b], event=det_ev[b])
+            if len(box_log) < 64:
+                with torch.cuda.stream(sD):
+                    box_log.append((det_boxes[b][0].clone(), det_nb[b][0:1].clone()))
+        if gather is not None and i >= 3 and tr.pipelined:
+            tr.sE.wait_event(gather.packed[(i - 3) & 1])    # the frame slot about to be overwritten was packed into a send buffer three steps ago
+        tr.step(d_frames[fi], depth_of(fi), stream=stream, mask=m)
+        traj.append(tr.snapshot_pose())
+        if gather is not None:
+            c = tr.cur
+            gather.submit(tr.n[c], tr.keys[c], tr.desc[c], tr.Tcw[1], after_event=tr.ev_track[c] if tr.pipelined else None)
 
     for i in range(args.warmup):
         step(i)
     tr.synchronize()
+    if gather is not None: gather.wait()
     tr.ex.last_status(stream=stream)
     torch.cuda.synchronize()
     if dist: dist.barrier()
     torch.cuda.synchronize()
     lib.profile_read(reset=True)
     lib.profile_enable(True)
+    gather_bytes0 = gather.bytes_moved if gather else 0
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
     tr.synchronize()
     if det is not None: sD.synchronize()
+    if gather is not None: gather.wait()
     torch.cuda.synchronize()
     if dist: dist.barrier()
     torch.cuda.synchronize()
@@ -198,25 +264,44 @@ def main():
     tr.ex.last_status(stream=stream)
     nkp, nmatch, ninl = tr.last_counts()
     nmatch_local, ninl2 = tr.last_local_counts()
-    n_raw = tr.rn.cpu().numpy() if not args.no_mask else nkp
+    n_raw = tr.rn.cpu().numpy()
     if not args.no_local_map:
         ninl = ninl2
-    poses = tr.last_pose()
-    # accuracy vs the synthetic ground truth of the last tracked frame (translation of the camera centre)
-    last_i = args.warmup + args.steps - 1
-    gt = np.stack([gen.Tcw(t0 + order[last_i % len(order)]) for t0 in t0s])
-    def centre(Tm): return -np.einsum('sij,sj->si', np.transpose(Tm[:, :3, :3], (0, 2, 1)), Tm[:, :3, 3])
-    err = np.linalg.norm(centre(poses.astype('f8')) - centre(gt), axis=1)
-    ate_rmse = float(np.sqrt((err ** 2).mean()))
     tracked = int((ninl >= 10).sum())
+    f_ok = tr.f_ok.cpu().numpy(); f_stats = tr.f_stats.cpu().numpy()
+    nbx = det_nb[(args.warmup + args.steps - 1) & 1].cpu().numpy() if det is not None else np.zeros(S, 'i4')
+
+    # ---- accuracy over the WHOLE run (warm-up + timed steps): per-stream Horn-aligned ATE against the synthetic ground truth (or groundtruth.txt)
+    N = len(traj)
+    est = torch.stack(traj).cpu().numpy().reshape(N, S, 4, 4).astype('f8')
+    ate_gt = None; ate_sq = 0.0; ate_cnt = 0
+    if not args.tum:
+        gt = np.stack([np.stack([gen.Tcw(t0 + order[i % len(order)]) for t0 in t0s]) for i in range(N)])
+        ate_gt, ate_sq, ate_cnt = ate_pooled(est, gt)
+    elif gt_tum is not None:
+        gst, gxyz, _ = gt_tum
+        for s in range(S):
+            st_s = np.array([stamps[s, order[i % len(order)]] for i in range(N)])
+            pairs = tum.associate(st_s, gst)
+            if len(pairs) >= 3:
+                a = tum.camera_centres(est[[i for i, _ in pairs], s]); b = gxyz[[j for _, j in pairs]]
+                r = tum.ate_rmse(a, b); ate_sq += r * r * len(a); ate_cnt += len(a)
+        ate_gt = float(np.sqrt(ate_sq / ate_cnt)) if ate_cnt else None
 
     if dist:
         dt = sdist.max_over_ranks(dist, dt, 'cuda')
-        # BASELINE config 5: gather per-frame records (pose + counts) over RCCL/xGMI (outside the timed region)
-        allrec = sdist.gather_frame_records(dist, tr.Tcw[1], tr.ninl, tr.nmatch)
-        assert allrec.shape == (world, S, 18)
-        sq = sdist.sum_over_ranks(dist, [float((err ** 2).sum()), float(len(err)), float(tracked)], 'cuda')
-        ate_rmse = float(np.sqrt(sq[0] / sq[1])); tracked = int(sq[2])
+        sq = sdist.sum_over_ranks(dist, [ate_sq, float(ate_cnt), float(tracked)], 'cuda')
+        ate_gt = float(np.sqrt(sq[0] / sq[1])) if sq[1] else None; tracked = int(sq[2])
+        last_rec = gather.unpack(gather.recv[(gather.step_idx - 1) & 1])
+        assert last_rec['n'].shape == (world, S) and (last_rec['n'][rank] == tr.n[tr.cur].cpu().numpy()).all()
+    if args.save_trajectory and rank == 0:
+        st0 = [stamps[0, order[i % len(order)]] if stamps is not None else float(i) / 30.0 for i in range(N)]
+        tum.save_trajectory_tum(args.save_trajectory, st0, [est[i, 0] for i in range(N)])
+
+    c2 = None
+    if not args.no_config2 and not args.tum:
+        del traj
+        c2 = run_config2(8, 2)
 
     if rank != 0:
         if dist: dist.destroy_process_group()
@@ -225,41 +310,73 @@ def main():
     fps = frames_total / dt
 
     alg = algorithmic_bytes_per_frame(nkp=int(round(float(n_raw.mean()))), nmatch=int(round(float(nmatch.mean()))))
-    SL = S / len(tr.trs)                 # frames per launch (streams of one group)
+    insts = {}
+    try:        # wave-level instruction counts per frame from the committed PMC passes (tools/collect_profiles.sh -> profiles/r2_pmc_insts.json)
+        insts = json.load(open(os.path.join(ROOT, 'profiles', 'r2_pmc_insts.json')))
+    except Exception:
+        insts = {}
     per_kernel = {}
     for k, (ms, n) in prof.items():
         if n == 0: continue
         avg_ms = ms / n
-        per_kernel[k] = {'avg_ms_per_launch': round(avg_ms, 5), 'launches': n, 'total_ms': round(ms, 3), 'alg_bytes_per_launch': alg[k] * SL,
-                         'achieved_GBs': round(alg[k] * SL / (avg_ms * 1e-3) / 1e9, 3)}
+        e = {'avg_ms_per_launch': round(avg_ms, 5), 'launches': n, 'total_ms': round(ms, 3)}
+        if k == 'det_forward':
+            e.update({'bound': 'mfma', 'alg_gflop_per_launch': det_gflop * S, 'achieved_TFLOPs': round(det_gflop * S / (avg_ms * 1e-3) / 1e3, 3)})
+        else:
+            e.update({'bound': 'hbm', 'alg_bytes_per_launch': alg[k] * S, 'achieved_GBs': round(alg[k] * S / (avg_ms * 1e-3) / 1e9, 3)})
+        ik = insts.get('kernels', {}).get(k)
+        if ik:   # share of the chip's VALU issue capacity this class used while it ran: wave-VALU instructions x measured cycles per instruction / (SIMDs x clock x time)
+            e['valu_frac'] = round(ik['valu_insts_per_frame'] * S * insts['cycles_per_valu_inst'] / (1024 * insts['clock_ghz'] * 1e9 * avg_ms * 1e-3), 3)
+            if 'fp64_gflop_per_frame' in ik:
+                e['fp64_frac'] = round(ik['fp64_gflop_per_frame'] * S / (avg_ms * 1e-3) / 1e3 / FP64_PEAK_TFS, 4)
+        per_kernel[k] = e
     dom = max(per_kernel, key=lambda k: per_kernel[k]['total_ms'])
     dk = per_kernel[dom]
     traffic = None
-    try:        # HBM traffic of the same kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/)
-        tj = json.load(open(os.path.join(ROOT, 'profiles', 'r1_traffic.json')))
-        if tj['frames_per_launch'] == SL and dom in tj['bytes_per_launch']:
+    try:        # HBM traffic of the same kernel class from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), not measured in this run
+        tj = json.load(open(os.path.join(ROOT, 'profiles', 'r2_traffic.json')))
+        if tj['frames_per_launch'] == S and dom in tj['bytes_per_launch']:
             traffic = tj['bytes_per_launch'][dom]
     except Exception:
         traffic = None
-    roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': dk['achieved_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': dk['achieved_GBs'] / HBM_PEAK_GBS, 'traffic': traffic,
-                'avg_launch_ms': dk['avg_ms_per_launch'], 'alg_bytes_per_launch': dk['alg_bytes_per_launch'],
-                'per_kernel': per_kernel,
-                'orb_stage_frac': 1.96e6 * (fps / world) / 1e9 / HBM_PEAK_GBS}
+    if dk['bound'] == 'mfma':
+        roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': dk['achieved_TFLOPs'], 'peak': MFMA_F32_PEAK_TFS, 'unit': 'TFLOP/s', 'frac': dk['achieved_TFLOPs'] / MFMA_F32_PEAK_TFS,
+                    'traffic': traffic, 'avg_launch_ms': dk['avg_ms_per_launch'], 'alg_gflop_per_launch': dk['alg_gflop_per_launch'],
+                    'note': 'det_forward = pre-processing + the 103-launch hipGraph of the MobileNetV3-SSDLite plan (69 pointwise convolutions on v_mfma_f32_32x32x2_f32 carry 0.50 of its '
+                            '0.557 GMAC); flops = 2 x MACs of the whole graph, priced against the fp32 matrix peak; per-launch rocprof table in profiles/'}
+    else:
+        roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': dk['achieved_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': dk['achieved_GBs'] / HBM_PEAK_GBS, 'traffic': traffic,
+                    'avg_launch_ms': dk['avg_ms_per_launch'], 'alg_bytes_per_launch': dk['alg_bytes_per_launch']}
+    roofline['traffic_source'] = 'profiles/r2_traffic.json (separate rocprofv3 --pmc passes of this command)' if traffic is not None else None
+    roofline['per_kernel'] = per_kernel
+    orb_ms = sum(per_kernel[k]['avg_ms_per_launch'] * per_kernel[k]['launches'] / args.steps for k in ('pyramid_resize', 'fast_cells', 'octree', 'orient_desc') if k in per_kernel)
+    roofline['orb_stage'] = {'ms_per_step_standalone_sum': round(orb_ms, 4), 'alg_bytes_per_frame': 1.96e6,
+                             'frac_of_hbm_peak': (1.96e6 * S / (orb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if orb_ms > 0 else None}
 
-    cpu = None
-    if not args.no_cpu_baseline and world == 1:
+    cpu = None; ate_oracle = None
+    if not args.no_cpu_baseline and world == 1 and not args.tum:
         # the oracle chained exactly like the tracker (checker/baseline leg only — never the measured product path): 1 core in-process, then
         # frames-parallel on all host cores (one worker process per core, each its own stream), as SURVEY.md §8(d) asks
         from oracle import cpu_chain
         n = args.cpu_sample
-        depth_img = np.full((480, 640), depth_val, np.uint16)
+        depth_img = [host_depth[t, 0] for t in range(T)]
         use_lm = not args.no_local_map
-        cdt = cpu_chain.run_chain([host[t, 0] for t in range(T)], depth_img, cam, gen.Tcw(t0s[0]), order, n, use_lm)
+        stage = {}
+        cdt = cpu_chain.run_chain([host[t, 0] for t in range(T)], depth_img, cam, gen.Tcw(t0s[0]), order, n, use_lm, stage_times=stage)
         cpu = {'value': n / cdt, 'unit': 'frames/s', 'cores': 1, 'kind': 'port',
-               'sample': f'{n} frames of one synthetic stream through the oracle chain (orb_extract + stereo + SearchByProjection + '
-                         f'PoseOptimization + {"local-map SearchByProjection + PoseOptimization + " if use_lm else ""}unproject; the mask stage and the '
-                         f'LK / RANSAC of the reference are not included), 1 thread; host has {os.cpu_count()} cores'}
+               'sample': f'{n} frames of one synthetic stream through the oracle chain (orb_extract + calcOpticalFlowPyrLK + findFundamentalMat RANSAC + dynamic mask + stereo + '
+                         f'SearchByProjection + PoseOptimization + {"local-map SearchByProjection + PoseOptimization + " if use_lm else ""}unproject), 1 thread; the detector forward is NOT '
+                         f'in this figure (the oracle detector is a numpy port, ~3 s per frame, not representative of ncnn; the reference runs it on a second thread); host has {os.cpu_count()} cores',
+               'ms_per_frame_by_stage': {k: round(v / n * 1e3, 3) for k, v in stage.items()}}
+        # trajectory of the device path against the oracle chain on the same frames and the same detector boxes ("ATE vs ref"): stream 0, first M frames
+        M = min(N, 32, len(box_log) if det is not None else N)
+        if M >= 3:
+            bxs = [bl[0].cpu().numpy()[:int(bl[1].cpu().numpy()[0])] for bl in box_log[:M]] if det is not None else None
+            _, otraj = cpu_chain.run_chain([host[t, 0] for t in range(T)], depth_img, cam, gen.Tcw(t0s[0]), order, M, use_lm, boxes=bxs, want_traj=True, restart=False)
+            oc = tum.camera_centres(np.stack(otraj)); dc = tum.camera_centres(est[:M, 0])
+            ate_oracle = {'frames': M, 'ate_rmse_m': tum.ate_rmse(dc, oc), 'max_abs_pose_entry_diff': float(np.abs(np.stack(otraj).astype('f8') - est[:M, 0]).max()),
+                          'note': 'stream 0: device trajectory vs the oracle chain run on the same frames with the same detector boxes (the oracle uses OpenCV\'s float accumulation '
+                                  'order in LK, the device the exact-sum variant; RANSAC / mask decisions can differ on knife-edge points)'}
         if not args.no_cpu_all_cores:
             import subprocess, tempfile
             P = max(1, min(os.cpu_count() or 1, 128)); n_per = max(12, args.cpu_sample // 10)
@@ -285,23 +402,32 @@ def main():
                     try: pr.wait(timeout=5)
                     except Exception: pr.kill()
 
+    workload = ('Single MI355X: + NCNN detector fwd (MFMA convs) and dynamic-feature mask' if det is not None else 'Single MI355X: ORB extract+match HIP kernels + LK / RANSAC mask inputs') + \
+               (f', TUM sequence {os.path.basename(os.path.normpath(args.tum))}' if args.tum else ', 640x480 synthetic streams') + ', 1000 feats/frame'
     out = {
         'metric': 'tracked frames/sec (640x480 RGB-D)', 'value': fps, 'unit': 'frames/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
-        'config': {'workload': 'Single MI355X: ORB extract+match HIP kernels, 640x480 synthetic stream, 1000 feats/frame',
-                   'detector_detect_concurrent': bool(args.detector), 'stream_groups': len(tr.trs),
-                   'stages': ['orb_extract'] + ([] if args.no_mask else ['dynamic_mask+erase (LK/F inputs from synthetic ground truth)']) + ['stereo_from_rgbd', 'motion_model', 'search_by_projection(cur,last)', 'pose_optimization'] +
-                             ([] if args.no_local_map else ['search_by_projection(cur,local_map th=3)', 'pose_optimization#2']) + ['unproject'] +
-                             ([] if args.no_local_map else ['make_map_points']),
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u8', 'data': 'tum' if args.tum else 'synthetic',
+        'config': {'workload': workload,
+                   'timed_region': ['detector_detect (forward + DetectionOutput + filtering, own stream)' if det is not None else None, 'orb_extract', 'lk_pyramid + lk_track (calcOpticalFlowPyrLK)',
+                                    'fm_ransac (pair selection + findFundamentalMat)', 'wait for detector boxes', 'dynamic_mask + erase', 'stereo_from_rgbd', 'motion_model',
+                                    'search_by_projection(cur,last)', 'pose_optimization'] + ([] if args.no_local_map else ['search_by_projection(cur,local_map th=3)', 'pose_optimization#2']) +
+                                   ['unproject'] + ([] if args.no_local_map else ['make_map_points']) + (['all_gather of frame records'] if dist else []),
+                   'detector': None if det is None else {'graph': os.path.basename(args.param), 'weights': weights_note, 'gflop_per_frame': det_gflop, 'mean_person_boxes_last_step': float(nbx.mean()),
+                                                         'boxes_feed_mask_of_same_frame_and_ransac_selection_of_next': True},
                    'local_map_points': 0 if args.no_local_map else 2 * tr.cap, 'mean_local_map_matches': None if args.no_local_map else float(nmatch_local.mean()),
                    'streams_per_gpu': S, 'frames_per_step': S, 'distinct_frames_per_stream': T,
                    'mean_keypoints': float(nkp.mean()), 'mean_keypoints_before_mask': float(n_raw.mean()), 'mean_matches': float(nmatch.mean()), 'mean_inliers': float(ninl.mean()),
-                   'tracked_streams_last_frame': tracked, 'ate_rmse_m_vs_synthetic_gt': ate_rmse,
-                   'nfeatures': 1000, 'nlevels': 8, 'scale_factor': 1.2, 'parallelism': f'streams-sharded x{world}', 'hip_streams': 1 if args.no_pipeline else 2,
+                   'fundamental_ok_frac': float(f_ok.mean()), 'mean_ransac_iterations': float(f_stats[:, 0].mean()),
+                   'tracked_streams_last_frame': tracked, 'trajectory_frames_per_stream': N,
+                   'ate_rmse_m_vs_ground_truth': ate_gt, 'ate_vs_oracle_chain': ate_oracle,
+                   'frame_record_gather': None if gather is None else {'bytes_per_step': gather.world * S * gather.rec_bytes, 'record_bytes': gather.rec_bytes,
+                                                                       'GBs': (gather.bytes_moved - gather_bytes0) / dt / 1e9, 'inside_timed_region': True},
+                   'nfeatures': 1000, 'nlevels': 8, 'scale_factor': 1.2, 'parallelism': f'streams-sharded x{world}', 'hip_streams': 1 if args.no_pipeline else (3 if det is not None else 2),
                    'pose_dtype': 'f64 LM, f32 boundary'},
-        'roofline': roofline, 'cpu_baseline': cpu,
+        'roofline': roofline, 'cpu_baseline': cpu, 'config2': c2,
     }
+    out['config']['timed_region'] = [x for x in out['config']['timed_region'] if x]
     print(json.dumps(out))
     if dist: dist.destroy_process_group()
 

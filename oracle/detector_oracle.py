@@ -17,61 +17,9 @@ MEAN = np.array([123.675, 116.28, 103.53], np.float32)
 TARGET = 300
 
 
-# ---------------------------------------------------------------- param parsing
-def parse_param(path):
-    lines = [l.split() for l in open(path).read().strip().split('\n')]
-    assert lines[0][0] == '7767517'
-    layers = []
-    for tok in lines[2:]:
-        typ, name, nin, nout = tok[0], tok[1], int(tok[2]), int(tok[3])
-        ins = tok[4:4 + nin]; outs = tok[4 + nin:4 + nin + nout]
-        params = {}
-        for kv in tok[4 + nin + nout:]:
-            k, v = kv.split('=')
-            k = int(k)
-            if k <= -23300:
-                vals = v.split(','); params[-k - 23300] = [float(x) for x in vals[1:]]
-            else:
-                params[k] = float(v) if ('.' in v or 'e' in v) else int(v)
-        layers.append(dict(type=typ, name=name, ins=ins, outs=outs, p=params))
-    return layers
-
-
-def synth_weights(layers, seed=7):
-    """dict layer-name -> arrays, and the ncnn .bin byte string (flag word 0 + raw fp32 per conv weight, raw bias, raw MemoryData)."""
-    rng = np.random.RandomState(seed)
-    W = {}; blob = []
-    for L in layers:
-        p = L['p']
-        if L['type'] == 'MemoryData':
-            n = p.get(0, 0) * max(p.get(1, 1), 1) * max(p.get(2, 1), 1)
-            # scalars of the h-swish / h-sigmoid chains: +3 and /6 in the original network; keep those semantics
-            W[L['name']] = None
-        elif L['type'] in ('Convolution', 'ConvolutionDepthWise'):
-            outc, k = p[0], p[1]; wsize = p[6]; group = p.get(7, 1)
-            inc = wsize // (outc * k * k) * group
-            fan_in = (inc // group) * k * k
-            w = (rng.randn(wsize) * np.sqrt(2.0 / fan_in)).astype(np.float32)
-            b = (rng.randn(outc) * 0.05).astype(np.float32) if p.get(5, 0) else np.zeros(outc, np.float32)
-            W[L['name']] = (w, b)
-    # MemoryData constants: consumers tell whether it is the "+3" or the "/6" (BinaryOp add vs div)
-    use = {}
-    for L in layers:
-        if L['type'] == 'BinaryOp':
-            for i in L['ins']:
-                if i in W and W[i] is None:
-                    use[i] = L['p'].get(0, 0)
-    for L in layers:
-        if L['type'] == 'MemoryData':
-            W[L['name']] = np.array([3.0 if use.get(L['name'], 0) == 0 else 6.0], np.float32)
-    for L in layers:     # .bin order = layer order
-        if L['type'] == 'MemoryData':
-            blob.append(W[L['name']].tobytes())
-        elif L['type'] in ('Convolution', 'ConvolutionDepthWise'):
-            w, b = W[L['name']]
-            blob.append(np.zeros(1, np.uint32).tobytes()); blob.append(w.tobytes())
-            if L['p'].get(5, 0): blob.append(b.tobytes())
-    return W, b''.join(blob)
+# ---------------------------------------------------------------- param parsing / synthetic weights
+# (shared with the harness: the graph description is data, the synthetic blob is an input, neither is oracle arithmetic)
+from sg_slam_amd.synth import parse_ncnn_param as parse_param, synth_ncnn_weights as synth_weights  # noqa: E402,F401
 
 
 # ---------------------------------------------------------------- pre-processing

@@ -512,3 +512,24 @@ unsigned orc_rng_sequence(uint64_t seed, int count, int modulo, int32_t *out)
     for (int i = 0; i < count; i++) out[i] = orc_rng_uniform(&r, 0, modulo);
     return (unsigned)r.state;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Frame.cc:556-604: keep[i] = epipolar distance of (cur_i, prev_i) under F (CheckEpiLineDistToRmDynamicPoint :613-627, fp64) below 0.2 inside a
+ * person box of THIS frame (isInDynamicRegion, strict) / 1.0 elsewhere.  Returns 1 when the restore rule fires (a person present and fewer than
+ * 0.1 * nFeatures survivors: mvKeys is restored, :599-604) — keep[] still holds the per-point decisions.
+ * ---------------------------------------------------------------------------------------------------------------- */
+int orc_dynamic_mask(const float *cur, const float *prev, int n, const double *F, const float *boxes, int nboxes, int have_dynamic, int nfeatures, uint8_t *keep)
+{
+    int sum = 0;
+    for (int i = 0; i < n; i++) {
+        const float x = cur[2 * i], y = cur[2 * i + 1];
+        const double a = x * F[0] + y * F[1] + F[2], b = x * F[3] + y * F[4] + F[5], c = x * F[6] + y * F[7] + F[8];
+        const double dist = fabs(a * prev[2 * i] + b * prev[2 * i + 1] + c) / sqrt(a * a + b * b);
+        int in = 0;
+        if (have_dynamic)
+            for (int k = 0; k < nboxes; k++) { const float *r = boxes + 4 * k; if (x > r[0] && x < r[0] + r[2] && y > r[1] && y < r[1] + r[3]) { in = 1; break; } }
+        keep[i] = (uint8_t)(dist < (in ? 0.2 : 1.0));
+        sum += keep[i];
+    }
+    return have_dynamic && (float)sum < (float)nfeatures * 0.1f;
+}

@@ -297,3 +297,12 @@ def solve_cubic(c):
     c = np.ascontiguousarray(c, 'f8'); r = np.zeros(3, 'f8')
     n = lib().orc_solve_cubic(_p(c), _p(r))
     return int(n), r
+
+
+def dynamic_mask(cur, prev, F, boxes, have_dynamic, nfeatures=1000):
+    """Frame.cc:556-604 keep flags + restore rule (C twin of detector_oracle.dynamic_mask): (keep[n] bool, restored)"""
+    cur = np.ascontiguousarray(cur, 'f4').reshape(-1, 2); prev = np.ascontiguousarray(prev, 'f4').reshape(-1, 2)
+    F = np.ascontiguousarray(F, 'f8').reshape(9); boxes = np.ascontiguousarray(boxes, 'f4').reshape(-1, 4)
+    keep = np.zeros(max(len(cur), 1), np.uint8)
+    r = lib().orc_dynamic_mask(_p(cur), _p(prev), C.c_int(len(cur)), _p(F), _p(boxes), C.c_int(len(boxes)), C.c_int(int(bool(have_dynamic))), C.c_int(nfeatures), _p(keep))
+    return keep[:len(cur)].astype(bool), bool(r)

@@ -444,6 +444,7 @@ extern "C" int sgx_det_forward_batch_dev(sgx_det *h, const uint8_t *d_img, int p
 {
     if (!h || !d_img || batch < 1 || batch > h->max_batch || pitch < ((3 * h->W + 3) & ~3) || (pitch & 3) || ((uintptr_t)d_img & 3)) return SGX_ERR_INVALID;   // rows are read as aligned dwords
     sgx_stream_t st = (sgx_stream_t)stream_;
+    sgx_prof_begin(SGX_K_DET_FWD, st);
     run_preprocess(h, d_img, pitch, batch, st);
 #ifndef SGX_EMU
     // The plan after pre-processing only touches the handle's own blobs, so it is captured once per batch size into a hipGraph and replayed
@@ -464,6 +465,7 @@ extern "C" int sgx_det_forward_batch_dev(sgx_det *h, const uint8_t *d_img, int p
     } else
 #endif
     for (const Op &op : h->ops) run_op(h, op, batch, st);
+    sgx_prof_end(SGX_K_DET_FWD, st);
     SGX_CHECK_HIP(hipGetLastError());
     if (d_loc) *d_loc = h->blobs[h->loc_blob].d;
     if (d_conf) *d_conf = h->blobs[h->conf_blob].d;
@@ -547,8 +549,10 @@ static int run_detection_output(sgx_det *h, int batch, sgx_det_result *d_results
 {
     SgxDetOut P; P.n = h->num_priors; P.nc = h->num_class; P.nms_top_k = h->nms_top_k; P.keep_top_k = h->keep_top_k; P.nms_th = h->nms_th; P.conf_th = h->conf_th;
     P.var0 = h->dvar[0]; P.var1 = h->dvar[1]; P.var2 = h->dvar[2]; P.var3 = h->dvar[3];
+    sgx_prof_begin(SGX_K_DET_OUT, st);
     SGX_LAUNCH(k_det_class_nms, dim3(h->num_class - 1, batch), dim3(256), st, P, h->blobs[h->loc_blob].d, h->blobs[h->conf_blob].d, h->d_priors, h->d_cls_rows, h->d_cls_count);
     SGX_LAUNCH(k_det_merge, dim3(batch), dim3(256), st, P, h->d_cls_rows, h->d_cls_count, h->det_th, h->dyn_th, h->W, h->H, h->T, d_results, d_boxes, d_nboxes, max_boxes, d_have_dynamic);
+    sgx_prof_end(SGX_K_DET_OUT, st);
     SGX_CHECK_HIP(hipGetLastError());
     return SGX_OK;
 }

@@ -279,17 +279,21 @@ SGX_DEV void sgx_lk_stage(uint32_t *tile, const uint8_t *img, int w, int h, int 
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
     const int gx = ox + 4 * cl;
     const bool inside = gx >= 0 && gx + 4 <= w;
-    const int x0 = sgx_reflect1(gx, w), x1 = sgx_reflect1(gx + 1, w), x2 = sgx_reflect1(gx + 2, w), x3 = sgx_reflect1(gx + 3, w);
     if (rl < 7) {
+        uint32_t v[PASSES];
+        if (inside) {                                               /* all loads of the patch are in flight together */
 #pragma unroll
-        for (int p = 0; p < PASSES; p++) {
-            const int row = p * 7 + rl;
-            const uint8_t *src = img + (size_t)sgx_reflect1(oy + row, h) * pitch;
-            uint32_t v;
-            if (inside) v = *(const uint32_t *)(src + gx);
-            else v = (uint32_t)src[x0] | ((uint32_t)src[x1] << 8) | ((uint32_t)src[x2] << 16) | ((uint32_t)src[x3] << 24);
-            tile[row * (SGX_LK_TILE_PITCH / 4) + cl] = v;
+            for (int p = 0; p < PASSES; p++) v[p] = *(const uint32_t *)(img + (size_t)sgx_reflect1(oy + p * 7 + rl, h) * pitch + gx);
+        } else {
+            const int x0 = sgx_reflect1(gx, w), x1 = sgx_reflect1(gx + 1, w), x2 = sgx_reflect1(gx + 2, w), x3 = sgx_reflect1(gx + 3, w);
+#pragma unroll
+            for (int p = 0; p < PASSES; p++) {
+                const uint8_t *src = img + (size_t)sgx_reflect1(oy + p * 7 + rl, h) * pitch;
+                v[p] = (uint32_t)src[x0] | ((uint32_t)src[x1] << 8) | ((uint32_t)src[x2] << 16) | ((uint32_t)src[x3] << 24);
+            }
         }
+#pragma unroll
+        for (int p = 0; p < PASSES; p++) tile[(p * 7 + rl) * (SGX_LK_TILE_PITCH / 4) + cl] = v[p];
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
 }
@@ -334,18 +338,31 @@ SGX_KERNEL(256) k_lk_track(SgxLkGeom g, SgxLkArgs A)
         int ivb[7]; int ix[7], iy[7];                              /* ivb = 256 - (I sample << 9): the accumulator the J interpolation starts from */
         int s11 = 0, s12 = 0, s22 = 0;
         {
-            const int tx = ((ipx - 1) >> 2) << 2, ty = ipy - 1;
-            sgx_lk_stage<4>(tile, I, w, h, pitch, tx, ty, rl, cl);
             const int gy0 = ipy + r, gx0 = ipx + s7;
-            const uint8_t *tb = tile8 + lane_off + (ipx - 1 - tx);                /* tile row gy0-1, column gx0-1 */
-            sgx_i16x2 P[4][5];                                     /* rows gy0-1 .. gy0+2, column pairs (0,1) (2,3) .. (8,9) */
+            sgx_i16x2 P[4][5];                                     /* rows gy0-1 .. gy0+2, column pairs (0,1) (2,3) .. (8,9) of columns gx0-1 .. gx0+8 */
+            const bool direct = ipx >= 1 && ipx + 25 < w && ipy >= 1 && ipy + 22 < h;      /* patch + apron inside the image (wave-uniform): no reflection anywhere */
+            if (direct) {                                          /* the lane's 4 x 12 bytes straight from the image (unaligned loads through L1) */
+                const uint8_t *gb = I + (size_t)(active ? gy0 - 1 : ipy) * pitch + (active ? gx0 - 1 : ipx);
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                uint32_t q[3];
-                __builtin_memcpy(q, tb + j * SGX_LK_TILE_PITCH, 12);
-                P[j][0] = SGX_LK_PAIR(q[0], q[0], 0, 1); P[j][1] = SGX_LK_PAIR(q[0], q[0], 2, 3);
-                P[j][2] = SGX_LK_PAIR(q[1], q[1], 0, 1); P[j][3] = SGX_LK_PAIR(q[1], q[1], 2, 3);
-                P[j][4] = SGX_LK_PAIR(q[2], q[2], 0, 1);
+                for (int j = 0; j < 4; j++) {
+                    uint32_t q[3];
+                    __builtin_memcpy(q, gb + (size_t)j * pitch, 12);
+                    P[j][0] = SGX_LK_PAIR(q[0], q[0], 0, 1); P[j][1] = SGX_LK_PAIR(q[0], q[0], 2, 3);
+                    P[j][2] = SGX_LK_PAIR(q[1], q[1], 0, 1); P[j][3] = SGX_LK_PAIR(q[1], q[1], 2, 3);
+                    P[j][4] = SGX_LK_PAIR(q[2], q[2], 0, 1);
+                }
+            } else {                                               /* near the border: REFLECT_101 patch through the LDS tile */
+                const int tx = ((ipx - 1) >> 2) << 2, ty = ipy - 1;
+                sgx_lk_stage<4>(tile, I, w, h, pitch, tx, ty, rl, cl);
+                const uint8_t *tb = tile8 + lane_off + (ipx - 1 - tx);                /* tile row gy0-1, column gx0-1 */
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    uint32_t q[3];
+                    __builtin_memcpy(q, tb + j * SGX_LK_TILE_PITCH, 12);
+                    P[j][0] = SGX_LK_PAIR(q[0], q[0], 0, 1); P[j][1] = SGX_LK_PAIR(q[0], q[0], 2, 3);
+                    P[j][2] = SGX_LK_PAIR(q[1], q[1], 0, 1); P[j][3] = SGX_LK_PAIR(q[1], q[1], 2, 3);
+                    P[j][4] = SGX_LK_PAIR(q[2], q[2], 0, 1);
+                }
             }
             const sgx_i16x2 c3 = { 3, 3 }, c10 = { 10, 10 };
             sgx_i16x2 S0[5], S1[5], D0[5], D1[5];                  /* column sums (3,10,3) and differences (-1,0,1) for derivative rows gy0 and gy0+1 */

@@ -67,34 +67,73 @@ class PlaneStream:
         T[:3, 3] = -R @ C
         return T
 
-    def frame(self, t):
+    def _warp_coords(self, t, z):
+        """Q16 texel coordinates of every pixel for the plane at depth z (texels are pixels at depth z0): texel = (z/z0) * S(u - cx, v - cy) + centre"""
         cam, z0, ts = self.cam, self.z0, self.ts
         fx, fy, cx, cy = cam['fx'], cam['fy'], cam['cx'], cam['cy']
         cxm, cym, th = self.pose(t)
         c, s = math.cos(th), math.sin(th)
         Q = 1 << 16
-        # texel = A * (u,v) + b   (Q16), derived from Pw = R^T Pc + C on the plane z = z0
-        a00 = int(round(c * Q)); a01 = int(round(s * (fx / fy) * Q))
-        a10 = int(round(-s * (fy / fx) * Q)); a11 = int(round(c * Q))
-        b0 = int(round((ts / 2 + fx / z0 * cxm - c * cx - s * (fx / fy) * cy) * Q))
-        b1 = int(round((ts / 2 + fy / z0 * cym + s * (fy / fx) * cx - c * cy) * Q))
+        k = z / z0
+        # texel = A * (u,v) + b   (Q16), derived from Pw = R^T Pc + C on the plane at depth z
+        a00 = int(round(k * c * Q)); a01 = int(round(k * s * (fx / fy) * Q))
+        a10 = int(round(-k * s * (fy / fx) * Q)); a11 = int(round(k * c * Q))
+        b0 = int(round((ts / 2 + fx / z0 * cxm - k * (c * cx + s * (fx / fy) * cy)) * Q))
+        b1 = int(round((ts / 2 + fy / z0 * cym + k * (s * (fy / fx) * cx - c * cy)) * Q))
         u = np.arange(self.w, dtype=np.int64)[None, :]
         v = np.arange(self.h, dtype=np.int64)[:, None]
-        X = a00 * u + a01 * v + b0
-        Y = a10 * u + a11 * v + b1
+        return a00 * u + a01 * v + b0, a10 * u + a11 * v + b1
+
+    def _warp(self, tex, t, z):
+        """bilinear (Q8 fractions, integer arithmetic) sample of `tex` under the warp of the plane at depth z"""
+        ts = self.ts
+        X, Y = self._warp_coords(t, z)
         xi = X >> 16; yi = Y >> 16
         xf = (X & 0xFFFF) >> 8; yf = (Y & 0xFFFF) >> 8             # Q8 fractions
         xi = np.clip(xi, 0, ts - 2); yi = np.clip(yi, 0, ts - 2)
-        T = self.tex.astype(np.int64)
+        T = tex.astype(np.int64)
         p00 = T[yi, xi]; p01 = T[yi, xi + 1]; p10 = T[yi + 1, xi]; p11 = T[yi + 1, xi + 1]
         top = p00 * (256 - xf) + p01 * xf
         bot = p10 * (256 - xf) + p11 * xf
-        img = (top * (256 - yf) + bot * yf + 32768) >> 16
+        return (top * (256 - yf) + bot * yf + 32768) >> 16
+
+    def _noise(self, img, t):
         if self.noise:
             rng = np.random.RandomState((self.seed * 100003 + t) & 0x7FFFFFFF)
             img = img + rng.randint(-self.noise, self.noise + 1, img.shape)
-        gray = np.clip(img, 0, 255).astype(np.uint8)
-        depth = np.full((self.h, self.w), int(round(z0 * cam['depth_factor'])), np.uint16)
+        return np.clip(img, 0, 255).astype(np.uint8)
+
+    def frame(self, t):
+        gray = self._noise(self._warp(self.tex, t, self.z0), t)
+        depth = np.full((self.h, self.w), int(round(self.z0 * self.cam['depth_factor'])), np.uint16)
+        return gray, depth, self.Tcw(t)
+
+
+class LayeredStream(PlaneStream):
+    """PlaneStream plus a second fronto-parallel layer in front of it: textured rectangles at depth z1 < z0 occlude the background plane, so the scene
+    has parallax (the epipolar geometry between frames is well determined — a single plane leaves cv::findFundamentalMat degenerate), depth
+    discontinuities and occlusion boundaries.  Same camera motion and ground-truth poses as PlaneStream; the depth image holds z1 / z0 per pixel."""
+
+    def __init__(self, seed=1234, z1=1.3, coverage=0.35, **kw):
+        super().__init__(seed=seed, **kw)
+        self.z1 = z1
+        self.tex_fg = world_texture(seed + 7919, self.ts, n_rect=2400)
+        rng = np.random.RandomState(seed + 104729)
+        m = np.zeros((self.ts, self.ts), np.uint8)
+        while m.mean() < coverage:
+            w = int(rng.randint(90, 260)); h = int(rng.randint(90, 260))
+            x = int(rng.randint(0, self.ts - w)); y = int(rng.randint(0, self.ts - h))
+            m[y:y + h, x:x + w] = 1
+        self.fg_mask = m
+
+    def frame(self, t):
+        X, Y = self._warp_coords(t, self.z1)
+        xi = np.clip((X + 32768) >> 16, 0, self.ts - 1); yi = np.clip((Y + 32768) >> 16, 0, self.ts - 1)
+        fg = self.fg_mask[yi, xi].astype(bool)                      # nearest texel of the foreground layer's footprint
+        img = np.where(fg, self._warp(self.tex_fg, t, self.z1), self._warp(self.tex, t, self.z0))
+        gray = self._noise(img, t)
+        f = self.cam['depth_factor']
+        depth = np.where(fg, int(round(self.z1 * f)), int(round(self.z0 * f))).astype(np.uint16)
         return gray, depth, self.Tcw(t)
 
 
@@ -139,3 +178,122 @@ def low_contrast_image(seed=5, width=640, height=480):
     tex = world_texture(seed, 1024, n_rect=600).astype(np.int64)
     img = 118 + ((tex[:height, :width] - 128) * 22 >> 7)
     return np.clip(img, 0, 255).astype(np.uint8)
+
+
+class MovingObject:
+    """An independently moving textured rectangle composited over a stream's frames — the "person" of the dynamic-feature mask tests.  Integer
+    positions, so frames stay byte-exact; box(t) is the rectangle (x, y, w, h) a detector would report for frame t."""
+
+    def __init__(self, seed=77, w=120, h=200, x0=250, y0=140, vx=5, vy=-3):
+        self.w, self.h, self.x0, self.y0, self.vx, self.vy = w, h, x0, y0, vx, vy
+        self.tex = world_texture(seed, 512, n_rect=400)[100:100 + h, 60:60 + w].copy()
+
+    def box(self, t):
+        return (float(self.x0 + self.vx * t), float(self.y0 + self.vy * t), float(self.w), float(self.h))
+
+    def paste(self, gray, t):
+        out = gray.copy()
+        x, y = self.x0 + self.vx * t, self.y0 + self.vy * t
+        out[y:y + self.h, x:x + self.w] = self.tex
+        return out
+
+
+# ---- detector weights: the reference's mobilenetv3_ssdlite_voc.bin is not in its tree, so harness and tests synthesise a blob in ncnn .bin order
+def parse_ncnn_param(path):
+    """ncnn .param text -> list of layers (type, name, ins, outs, params) — the graph the reference loads at Detector2D.cc:24 (layer_count / blob_count
+    header, `id=value` and `-233xx=n,v,...` array parameters)."""
+    lines = [l.split() for l in open(path).read().strip().split('\n')]
+    assert lines[0][0] == '7767517'
+    layers = []
+    for tok in lines[2:]:
+        typ, name, nin, nout = tok[0], tok[1], int(tok[2]), int(tok[3])
+        ins = tok[4:4 + nin]; outs = tok[4 + nin:4 + nin + nout]
+        params = {}
+        for kv in tok[4 + nin + nout:]:
+            k, v = kv.split('=')
+            k = int(k)
+            if k <= -23300:
+                vals = v.split(','); params[-k - 23300] = [float(x) for x in vals[1:]]
+            else:
+                params[k] = float(v) if ('.' in v or 'e' in v) else int(v)
+        layers.append(dict(type=typ, name=name, ins=ins, outs=outs, p=params))
+    return layers
+
+
+def synth_ncnn_weights(layers, seed=7, person_logit=0.0):
+    """dict layer-name -> arrays, and the ncnn .bin byte string (flag word 0 + raw fp32 per conv weight, raw bias, raw MemoryData).
+    person_logit: added to the bias of every class-15 ("person") channel of the six confidence heads (the convolutions feeding mbox_conf): with purely
+    random weights no prior ever ranks a person among the 100 kept detections; +2 yields a handful of person boxes per frame, so the dynamic-feature
+    mask downstream receives real detector output."""
+    rng = np.random.RandomState(seed)
+    W = {}; blob = []
+    for L in layers:
+        p = L['p']
+        if L['type'] == 'MemoryData':
+            n = p.get(0, 0) * max(p.get(1, 1), 1) * max(p.get(2, 1), 1)
+            # scalars of the h-swish / h-sigmoid chains: +3 and /6 in the original network; keep those semantics
+            W[L['name']] = None
+        elif L['type'] in ('Convolution', 'ConvolutionDepthWise'):
+            outc, k = p[0], p[1]; wsize = p[6]; group = p.get(7, 1)
+            inc = wsize // (outc * k * k) * group
+            fan_in = (inc // group) * k * k
+            w = (rng.randn(wsize) * np.sqrt(2.0 / fan_in)).astype(np.float32)
+            b = (rng.randn(outc) * 0.05).astype(np.float32) if p.get(5, 0) else np.zeros(outc, np.float32)
+            W[L['name']] = (w, b)
+    if person_logit:
+        producer = {o: L for L in layers for o in L['outs']}
+        conf_in = next(L for L in layers if L['name'] == 'mbox_conf')['ins']
+        for blob_name in conf_in:                                # F{i}_conf <- Flatten <- Permute <- Convolution
+            L = producer[blob_name]
+            while L['type'] in ('Flatten', 'Permute'):
+                L = producer[L['ins'][0]]
+            w, b = W[L['name']]
+            b = b.copy(); b[15::21] += np.float32(person_logit); W[L['name']] = (w, b)
+    # MemoryData constants: consumers tell whether it is the "+3" or the "/6" (BinaryOp add vs div)
+    use = {}
+    for L in layers:
+        if L['type'] == 'BinaryOp':
+            for i in L['ins']:
+                if i in W and W[i] is None:
+                    use[i] = L['p'].get(0, 0)
+    for L in layers:
+        if L['type'] == 'MemoryData':
+            W[L['name']] = np.array([3.0 if use.get(L['name'], 0) == 0 else 6.0], np.float32)
+    for L in layers:     # .bin order = layer order
+        if L['type'] == 'MemoryData':
+            blob.append(W[L['name']].tobytes())
+        elif L['type'] in ('Convolution', 'ConvolutionDepthWise'):
+            w, b = W[L['name']]
+            blob.append(np.zeros(1, np.uint32).tobytes()); blob.append(w.tobytes())
+            if L['p'].get(5, 0): blob.append(b.tobytes())
+    return W, b''.join(blob)
+
+
+# ---- parallel synthesis of many streams (bench harness): one generator per worker process
+_POOL_GEN = None
+
+
+def _pool_init(cls_name, seed):
+    global _POOL_GEN
+    _POOL_GEN = globals()[cls_name](seed=seed)
+
+
+def _pool_frame(t):
+    g, d, _ = _POOL_GEN.frame(t)
+    return g, d
+
+
+def synth_streams(cls_name, seed, offsets, T, workers=None):
+    """(gray[T, S, H, W] u8, depth[T, S, H, W] u16) of the streams starting at time offsets `offsets`, synthesised by a process pool"""
+    import os
+    from concurrent.futures import ProcessPoolExecutor
+    S = len(offsets)
+    ts = [o + t for o in offsets for t in range(T)]
+    workers = workers or max(1, min(32, (os.cpu_count() or 2) // 2))
+    gray = None; depth = None
+    with ProcessPoolExecutor(workers, initializer=_pool_init, initargs=(cls_name, seed)) as ex:
+        for i, (g, d) in enumerate(ex.map(_pool_frame, ts, chunksize=8)):
+            if gray is None:
+                gray = np.empty((T, S) + g.shape, np.uint8); depth = np.empty((T, S) + d.shape, np.uint16)
+            gray[i % T, i // T] = g; depth[i % T, i // T] = d
+    return gray, depth

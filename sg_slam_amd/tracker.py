@@ -2,7 +2,9 @@
 step, every stage device-resident and asynchronous on one HIP stream:
 
   ORBextractor::operator()          -> sgx_orb_extract_batch_dev           (ORBextractor.cc:1045-1106)
-  Frame::RmDynamicPoint... (mask)   -> sgx_dynamic_mask_batch_dev + sgx_frame_compact_keys_batch_dev (Frame.cc:556-604; LK / F are inputs)
+  Frame::RmDynamicPoint... (mask)   -> sgx_flow_lk_batch_dev (calcOpticalFlowPyrLK, Frame.cc:445) + sgx_fundamental_ransac_batch_dev (pair selection +
+                                       findFundamentalMat, :454-472) + wait for the detector (:478-500) + sgx_dynamic_mask_batch_dev +
+                                       sgx_frame_compact_keys_batch_dev (:556-604)          [lk=True; with lk=False the LK / F inputs are given by the caller]
   Frame::ComputeStereoFromRGBD      -> sgx_frame_stereo_from_rgbd_batch_dev (Frame.cc:893-914)
   constant-velocity prediction      -> sgx_frame_motion_model_batch_dev     (Tracking.cc:463-470, :914)
   ORBmatcher::SearchByProjection    -> sgx_match_project_frame_batch_dev    (ORBmatcher.cc:1332-1472, th=15)
@@ -23,10 +25,11 @@ import numpy as np
 from .capi import _vp
 from .matcher import camera_struct
 from .orb import ORBextractor
+from .flow import OpticalFlowLK, fundamental_ransac_batch_dev
 
 
 class TrackerBatch:
-    def __init__(self, lib, streams, cam, width=640, height=480, nfeatures=1000, xp='torch', th=15.0, pipelined=True, local_map=True, debug_taps=False):
+    def __init__(self, lib, streams, cam, width=640, height=480, nfeatures=1000, xp='torch', th=15.0, pipelined=True, local_map=True, debug_taps=False, lk=False, max_boxes=8):
         self.lib, self.S, self.cam, self.W, self.H, self.th = lib, streams, dict(cam), width, height, th
         self.ex = ORBextractor(nfeatures=nfeatures, width=width, height=height, max_batch=streams, lib=lib)
         self.cap = self.ex.capacity
@@ -69,9 +72,17 @@ class TrackerBatch:
         # dynamic-feature mask stage (Frame::RmDynamicPointWithSemanticAndGeometry): raw extraction buffers, keep flags, previous positions
         self.rkeys = z((S, cap, 28), 'u1'); self.rdesc = z((S, cap, 32), 'u1'); self.rn = z((S,), 'i4')
         self.keep = z((S, cap), 'u1'); self.prev_xy = z((S, cap, 2), 'f4')
-        self.max_boxes = 8
+        self.max_boxes = int(max_boxes)
         self.no_boxes = z((S, self.max_boxes, 4), 'f4'); self.no_nboxes = z((S,), 'i4')
         self.nfeatures = int(nfeatures)
+        # the mask's real inputs (lk=True): LK flow into the previous frame's pyramid, RANSAC F, the previous frame's person boxes (Frame.cc:31-33 globals)
+        self.lk = bool(lk)
+        if self.lk:
+            self.flow = OpticalFlowLK(width=width, height=height, max_batch=S, lib=lib)
+            self.F = z((S, 9), 'f8'); self.f_ok = z((S,), 'i4'); self.f_stats = z((S, 4), 'i4'); self.lk_status = z((S, cap), 'u1')
+            self.pre_boxes = z((S, self.max_boxes, 4), 'f4'); self.pre_nboxes = z((S,), 'i4'); self.pre_have = z((S,), 'i4')     # vPreFramePotentialDynamicBorder, bPreFrameHavePotentialDynamicObj
+            self.no_have = z((S,), 'i4')
+        self._held = [None] * NB                     # inputs of the last NB steps stay referenced until their slot is reused (their readers run on other streams)
         self.cur = 0
         self.frame_idx = 0
         # Two HIP streams: E = extraction (+stereo) of frame t+1 overlaps T = match / pose-opt / unproject of frame t.  The wide
@@ -86,9 +97,9 @@ class TrackerBatch:
     def _zeros(self, shape, dt):
         if self.xp == 'torch':
             import torch
-            tdt = {'u1': torch.uint8, 'i4': torch.int32, 'f4': torch.float32}[dt]
+            tdt = {'u1': torch.uint8, 'i4': torch.int32, 'f4': torch.float32, 'f8': torch.float64}[dt]
             return torch.zeros(shape, dtype=tdt, device='cuda')
-        return np.zeros(shape, {'u1': np.uint8, 'i4': np.int32, 'f4': np.float32}[dt])
+        return np.zeros(shape, {'u1': np.uint8, 'i4': np.int32, 'f4': np.float32, 'f8': np.float64}[dt])
 
     def set_initial_pose(self, Tcw_host):
         """Tcw of the first frame of every stream (S,4,4) — the reference starts at identity
@@ -113,7 +124,12 @@ class TrackerBatch:
         Asynchronous; with pipelined=True the extraction runs on its own stream (call synchronize() before reading results).
         mask (optional, frames t > 0): dict with 'A' (S,6) f32 flow map and 'F' (S,9) f64 fundamental matrices [the LK / RANSAC outputs the
         reference computes on the host, Frame.cc:445-472], optionally 'boxes' (S,max_boxes,4) f32, 'nboxes' (S,) i32, 'have_dynamic' (S,) i32
-        [Detector2D results] and 'shift' (S,2): runs the dynamic-feature mask + erase step between extraction and ComputeStereoFromRGBD."""
+        [Detector2D results] and 'shift' (S,2): runs the dynamic-feature mask + erase step between extraction and ComputeStereoFromRGBD.
+        With lk=True (constructor) the flow and F are computed here (every keypoint tracked into the previous frame, RANSAC F) and `mask` only carries the
+        detector's results for THIS frame: 'boxes', 'nboxes', 'have_dynamic' (device arrays in sgx_det_detect_batch_dev's layout) and optionally 'event' —
+        a torch event recorded after the detector launch, which the mask stage waits for (Frame.cc:478 `while(!isDetectImageFinished())`).
+        Input lifetime: the tensors passed to step() are read asynchronously on the tracker's streams; the tracker keeps references to them for three
+        steps, so callers may drop (but must not overwrite) them earlier."""
         L, S, cap, cam = self.lib, self.S, self.cap, self.cam
         t = self.frame_idx
         c, l = t % 3, (t - 1) % 3
@@ -122,15 +138,42 @@ class TrackerBatch:
             import torch
             cur_stream = torch.cuda.current_stream()
             sE, sT = self.sE, self.sT
+            sE.wait_stream(cur_stream)                                # the frames (and mask inputs) may have been produced on the caller's stream
             if t == 0:
-                sE.wait_stream(cur_stream); sT.wait_stream(cur_stream)
+                sT.wait_stream(cur_stream)
             if t >= 2:
                 sE.wait_event(self.ev_track[(t - 2) % 3])            # slot c was "last" of step t-2+1: its readers must be done
             stE, stT = sE.cuda_stream, sT.cuda_stream
         else:
             stE = stT = stream
-        use_mask = mask is not None and t > 0
-        if not use_mask:
+        self._held[c] = (d_gray, d_depth, mask)
+        use_mask = (mask is not None or self.lk) and t > 0
+        if self.lk:
+            mask = mask or {}
+            have_boxes = 'boxes' in mask
+            boxes = mask.get('boxes', self.no_boxes); nboxes = mask.get('nboxes', self.no_nboxes); have_dyn = mask.get('have_dynamic', self.no_have)
+            if t == 0:
+                self.ex.extract_batch_dev(d_gray, gray_pitch or self.W, S, self.keys[c], self.desc[c], self.n[c], stream=stE)
+                self.flow.lk_batch_dev(d_gray, gray_pitch or self.W, S, None, None, cap, None, None, stream=stE)       # first frame: pyramid only (imGrayPre empty, Frame.cc:155-163)
+            else:
+                self.ex.extract_batch_dev(d_gray, gray_pitch or self.W, S, self.rkeys, self.rdesc, self.rn, stream=stE)
+                self.flow.lk_batch_dev(d_gray, gray_pitch or self.W, S, self.rkeys, self.rn, cap, self.prev_xy, self.lk_status, stream=stE)
+                fundamental_ransac_batch_dev(L, S, cap, self.rkeys, self.rn, self.prev_xy, self.F, self.f_ok, self.f_stats, pre_have=self.pre_have, pre_boxes=self.pre_boxes,
+                                             pre_nboxes=self.pre_nboxes, max_boxes=self.max_boxes, stream=stE)
+                if self.pipelined and mask.get('event') is not None:
+                    self.sE.wait_event(mask['event'])               # Frame.cc:478: the detector thread must have finished this image
+                L.check(L.dll.sgx_dynamic_mask_batch_dev(S, cap, _vp(self.rkeys), _vp(self.rn), _vp(self.prev_xy), _vp(self.F), _vp(boxes), _vp(nboxes),
+                                                         self.max_boxes, _vp(self.keep), _vp(stE)), 'dynamic mask')
+                L.check(L.dll.sgx_frame_compact_keys_batch_dev(S, cap, _vp(self.rkeys), _vp(self.rdesc), _vp(self.rn), _vp(self.keep), _vp(have_dyn),
+                                                               self.nfeatures, _vp(self.keys[c]), _vp(self.desc[c]), _vp(self.n[c]), _vp(stE)), 'compact keys')
+                # Frame.cc:482-499: this frame's detector results become the "previous frame" state of the next call (frame 0 never gets here, like the reference)
+                if self.xp == 'torch':
+                    import torch
+                    with torch.cuda.stream(self.sE) if self.pipelined else torch.cuda.stream(torch.cuda.current_stream()):
+                        self.pre_boxes.copy_(boxes); self.pre_nboxes.copy_(nboxes); self.pre_have.copy_(have_dyn)
+                else:
+                    self.pre_boxes[...] = boxes; self.pre_nboxes[...] = nboxes; self.pre_have[...] = have_dyn
+        elif not use_mask:
             self.ex.extract_batch_dev(d_gray, gray_pitch or self.W, S, self.keys[c], self.desc[c], self.n[c], stream=stE)
         else:
             self.ex.extract_batch_dev(d_gray, gray_pitch or self.W, S, self.rkeys, self.rdesc, self.rn, stream=stE)
@@ -196,6 +239,17 @@ class TrackerBatch:
         self.Tcw = [Tll, Tc, Tl]
         self.cur = c
         self.frame_idx += 1
+
+    def snapshot_pose(self):
+        """device copy of the pose of the frame just tracked (S,16), ordered on the tracking stream — for trajectory files / ATE without a host sync per frame"""
+        T = self.Tcw[1]
+        if self.xp != 'torch':
+            return T.copy()
+        if self.pipelined:
+            import torch
+            with torch.cuda.stream(self.sT):
+                return T.clone()
+        return T.clone()
 
     def synchronize(self):
         if self.pipelined:

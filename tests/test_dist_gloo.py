@@ -29,9 +29,15 @@ def _worker(rank, world, port, q):
         tr.step(np.stack([f[0] for f in fr]), np.stack([f[1] for f in fr]))
     n, nm, ninl = tr.last_counts()
     rec = sdist.gather_frame_records(dist, torch.from_numpy(tr.Tcw[1].copy()), torch.from_numpy(ninl.copy()), torch.from_numpy(nm.copy()))
+    # config-5 record gather as specified: keypoints + descriptors + pose of the last frame, one all_gather per step batch
+    G = sdist.FrameRecordGather(dist, S, tr.cap, 'cpu', async_stream=False)
+    c = tr.cur
+    got = G.unpack(G.submit(torch.from_numpy(tr.n[c].copy()), torch.from_numpy(tr.keys[c].copy()), torch.from_numpy(tr.desc[c].copy()), torch.from_numpy(tr.Tcw[1].copy())))
+    G.wait()
+    mine = dict(n=tr.n[c].copy(), keys=tr.keys[c].copy(), desc=tr.desc[c].copy(), Tcw=tr.Tcw[1].copy())
     tmax = sdist.max_over_ranks(dist, float(rank + 1), 'cpu')
     tot = sdist.sum_over_ranks(dist, [1.0, float(ninl.sum())], 'cpu')
-    q.put((rank, offs, rec.numpy(), tmax, tot))
+    q.put((rank, offs, rec.numpy(), tmax, tot, got, mine))
     dist.destroy_process_group()
 
 
@@ -44,9 +50,16 @@ def test_two_rank_sharded_tracking(emu):
     for p in ps: p.start()
     res = sorted([q.get(timeout=300) for _ in ps], key=lambda r: r[0])
     for p in ps: p.join(60)
-    (r0, o0, rec0, tm0, tot0), (r1, o1, rec1, tm1, tot1) = res
+    (r0, o0, rec0, tm0, tot0, got0, mine0), (r1, o1, rec1, tm1, tot1, got1, mine1) = res
     assert set(o0).isdisjoint(o1)                         # weak scaling: different streams per rank
     assert rec0.shape == (2, 1, 18) and (rec0 == rec1).all()    # every rank holds every rank's records
     assert tm0 == tm1 == 2.0 and tot0[0] == 2.0
     assert not np.allclose(rec0[0], rec0[1])              # the two shards really tracked different streams
     assert (rec0[:, :, 16] > 100).all()                   # inliers: both shards tracked
+    # the gathered frame records: every rank holds every rank's keypoints / descriptors / pose of the step, bit for bit
+    for got in (got0, got1):
+        for r, mine in enumerate((mine0, mine1)):
+            n = int(mine['n'][0])
+            assert got['n'][r, 0] == n and n > 500
+            assert (got['keys'][r, 0, :n] == mine['keys'][0, :n]).all() and (got['desc'][r, 0, :n] == mine['desc'][0, :n]).all()
+            assert (got['Tcw'][r, 0].view(np.uint32) == mine['Tcw'][0].view(np.uint32)).all()

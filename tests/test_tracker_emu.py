@@ -180,3 +180,65 @@ def run_tracker_mask(lib, xp):
 
 def test_tracker_mask_emu(emu):
     run_tracker_mask(emu, 'numpy')
+
+
+def run_tracker_lk(lib, oracle, xp, nframes=4):
+    """The mask stage with its REAL inputs (tier N1): every raw keypoint tracked into the previous frame by the LK kernel, F from the RANSAC kernel (pair
+    selection against the previous frame's boxes), person boxes handed over like detector results.  Stream 0 carries an independently moving textured
+    rectangle (reported as its person box), stream 1 is static.  Every intermediate is checked against the oracle chained the same way."""
+    from oracle import detector_oracle as DO
+    S = synth.PlaneStream(seed=1234)
+    obj = synth.MovingObject()
+    offs = [3, 57]
+    tr = TrackerBatch(lib, 2, CAM, xp=xp, lk=True)
+    H = (lambda a: a.cpu().numpy()) if xp == 'torch' else (lambda a: a)
+    def D(a):
+        if xp != 'torch':
+            return a
+        import torch
+        return torch.from_numpy(a.view(np.int16) if a.dtype == np.uint16 else a).cuda()
+    tr.set_initial_pose(np.stack([S.Tcw(o) for o in offs]))
+    prev_gray = None; pre_boxes = [[], []]; pre_have = [0, 0]
+    for t in range(nframes):
+        fr = [S.frame(o + t) for o in offs]
+        gray = np.stack([obj.paste(fr[0][0], t), fr[1][0]]); depth = np.stack([f[1] for f in fr])
+        box = np.zeros((2, tr.max_boxes, 4), 'f4'); box[0, 0] = obj.box(t)
+        nb = np.array([1, 0], 'i4'); have = np.array([1, 0], 'i4')
+        tr.step(D(gray), D(depth), mask=dict(boxes=D(box), nboxes=D(nb), have_dynamic=D(have)))
+        n, nm, ninl = tr.last_counts()
+        if t > 0:
+            rn, keep, pxy, F, fok = H(tr.rn), H(tr.keep), H(tr.prev_xy), H(tr.F), H(tr.f_ok)
+            rk = H(tr.rkeys).view(np.float32).reshape(2, tr.cap, 7)
+            for s in range(2):
+                ko, _ = oracle.orb_extract(gray[s])
+                assert rn[s] == len(ko)
+                pts = np.stack([ko['x'], ko['y']], 1)
+                ref, _ = oracle.lk_pyr(gray[s], prev_gray[s], pts)
+                assert (pxy[s, :rn[s]].view(np.uint32) == ref.view(np.uint32)).all()
+                c, p = oracle.fm_select(pts, ref, pre_have[s], np.array(pre_boxes[s], 'f4').reshape(-1, 4))
+                if s == 0 and t > 1:
+                    assert len(c) < len(pts)                   # the previous frame's box removed the pairs that landed inside it
+                rok, rF, _, _ = oracle.find_fundamental_ransac(c, p)
+                assert fok[s] == rok == 1
+                assert np.abs(F[s].reshape(3, 3) - rF).max() <= 1e-9 * np.abs(rF).max()
+                bx = [tuple(box[s, 0])] if nb[s] else []
+                ek, restored = DO.dynamic_mask(pts, ref, F[s].reshape(3, 3), bx, bool(have[s]), 1000)
+                k = keep[s, :rn[s]].astype(bool)
+                assert (k == ek).all() and not restored
+                assert n[s] == k.sum()
+                x, y = rk[s, :rn[s], 0], rk[s, :rn[s], 1]
+                if s == 0:
+                    b = obj.box(t)
+                    inside = (x > b[0] + 12) & (x < b[0] + b[2] - 12) & (y > b[1] + 12) & (y < b[1] + b[3] - 12)
+                    assert inside.sum() > 20 and k[inside].mean() < 0.35 and k[~inside].mean() > 0.9
+                else:
+                    assert k.mean() > 0.97
+            Tg = tr.last_pose()
+            for s in range(2):
+                assert np.abs(Tg[s] - S.Tcw(offs[s] + t)).max() < 0.03 and ninl[s] > 120
+            pre_boxes = [[tuple(box[0, 0])], []]; pre_have = [1, 0]
+        prev_gray = gray
+
+
+def test_tracker_lk_emu(emu, oracle):
+    run_tracker_lk(emu, oracle, 'numpy')

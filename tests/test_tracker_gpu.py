@@ -59,3 +59,8 @@ def test_tracker_full_batch_properties(gpulib):
         Tgt = gen.Tcw(offs[d] + NF - 1)
         assert np.abs(full[NF - 1][5][d].reshape(4, 4)[:3, 3] - Tgt[:3, 3]).max() < 0.02
         assert full[NF - 1][2][d] > 100
+
+
+def test_tracker_lk_gpu(gpulib, oracle):
+    from test_tracker_emu import run_tracker_lk
+    run_tracker_lk(gpulib, oracle, 'torch', nframes=5)
