@@ -1,0 +1,15 @@
+"""Which library the differential campaigns drive: the kernel-logic emulator (default, CPU) or — SGX_CAMPAIGN_LIB=device — the product library on the GPU
+(tests/test_campaign_gpu.py runs a fixed-seed slice of every campaign that way, so the random inputs also reach the hipcc build)."""
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def campaign_lib():
+    """(library, array flavour for the tracker harness)"""
+    if os.environ.get('SGX_CAMPAIGN_LIB', '') == 'device':
+        import sg_slam_amd
+        lib = sg_slam_amd.load()
+        assert 'gfx950' in lib.version()
+        return lib, 'torch'
+    from sg_slam_amd.capi import SgxLib
+    return SgxLib(os.path.join(ROOT, 'tests', 'emu', 'libsgx_emu.so')), 'numpy'

@@ -11,7 +11,8 @@ from sg_slam_amd.optimizer import Optimizer
 from oracle import oracle as orc
 from scenes import make_ba_problem, CAM
 from test_localba import close, points_close
-lib = SgxLib(os.path.join(ROOT, 'tests', 'emu', 'libsgx_emu.so'))
+from _campaign_lib import campaign_lib
+lib, XP = campaign_lib()
 rng = np.random.RandomState(int(sys.argv[1])); t0 = time.time(); n = bad = 0
 MAXC = int(sys.argv[3]) if len(sys.argv) > 3 else None          # optional: stop after this many cases (deterministic runs)
 while time.time() - t0 < float(sys.argv[2]) and (MAXC is None or n < MAXC):

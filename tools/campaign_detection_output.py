@@ -8,7 +8,8 @@ import numpy as np
 from oracle import detector_oracle as D
 from sg_slam_amd.detector import Detector2D
 from sg_slam_amd.capi import SgxLib, DetResult
-lib = SgxLib(ROOT + '/tests/emu/libsgx_emu.so')
+from _campaign_lib import campaign_lib
+lib, XP = campaign_lib()
 PARAM = ROOT + '/tests/golden/mobilenetv3_ssdlite_voc.param'
 layers = D.parse_param(PARAM); W, blob = D.synth_weights(layers, seed=7)
 det = Detector2D(0.90, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=1, lib=lib)
@@ -18,7 +19,8 @@ img = rng0.randint(0, 256, (480, 640, 3)).astype(np.uint8)
 _, blobs = D.forward(layers, W, D.preprocess(img)); priors = blobs['mbox_priorbox']
 p = [L for L in layers if L['type'] == 'DetectionOutput'][0]['p']
 seed0 = int(sys.argv[1]); rng = np.random.RandomState(seed0); t0 = time.time(); cases = bad = 0
-while time.time() - t0 < float(sys.argv[2]):
+MAXC = int(sys.argv[3]) if len(sys.argv) > 3 else None          # optional: stop after this many cases (deterministic runs)
+while time.time() - t0 < float(sys.argv[2]) and (MAXC is None or cases < MAXC):
     loc = (rng.randn(1, n, 4) * rng.choice([0.1, 0.5, 2.0])).astype('f4')
     raw = (rng.rand(n, nc) ** rng.choice([1, 3, 8])).astype('f4')
     if rng.rand() < 0.5: raw = np.round(raw * 16) / np.float32(16)                       # heavy score ties

@@ -10,7 +10,8 @@ import numpy as np
 from oracle import detector_oracle as D
 from sg_slam_amd.capi import SgxLib
 import test_detector as T
-lib = SgxLib(os.path.join(ROOT, 'tests', 'emu', 'libsgx_emu.so'))
+from _campaign_lib import campaign_lib
+lib, XP = campaign_lib()
 layers = D.parse_param(T.PARAM)
 seed0 = int(sys.argv[1]); t0 = time.time(); n = bad = 0
 rng = np.random.RandomState(seed0)

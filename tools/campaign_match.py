@@ -1,14 +1,15 @@
 """Differential campaign (CPU): random frame pairs / local maps, thresholds, ratio tests and observation patterns through both matchers of the kernel-logic
 emulator and the oracle; match indices and in-view flags must be identical.  usage: python tools/campaign_match.py <seed> <seconds>
 Round 1: 2 seeds x 1100 s + 2 x 3000 s = 8 133 cases, 0 mismatches."""
-import sys, time; import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import sys, time; import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
 from sg_slam_amd import synth
 from sg_slam_amd.matcher import ORBmatcher
 from sg_slam_amd.capi import SgxLib
 from oracle import oracle as orc
 from scenes import make_pair, make_local_map, CAM
-lib = SgxLib(os.path.join(ROOT, 'tests', 'emu', 'libsgx_emu.so'))
+from _campaign_lib import campaign_lib
+lib, XP = campaign_lib()
 seed0 = int(sys.argv[1]); rng = np.random.RandomState(seed0)
 sf = orc.orb_params()['scale']
 t0 = time.time(); n = 0; bad = 0

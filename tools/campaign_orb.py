@@ -1,13 +1,14 @@
 """Differential campaign (CPU, minutes to hours): random images of six kinds (texture crops, low contrast, noise, half-flat, salt & pepper, blocky) through
 the kernel-logic emulator and the oracle; full extraction must agree bit for bit.  usage: python tools/campaign_orb.py <seed> <seconds>
 Round 1: 4 seeds x 1200 s + 3 seeds x 2400 s = 34 649 images, 0 mismatches."""
-import sys, time; import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import sys, time; import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
 from sg_slam_amd import synth
 from sg_slam_amd.orb import ORBextractor
 from sg_slam_amd.capi import SgxLib
 from oracle import oracle as orc
-lib = SgxLib(os.path.join(ROOT, 'tests', 'emu', 'libsgx_emu.so'))
+from _campaign_lib import campaign_lib
+lib, XP = campaign_lib()
 ex = ORBextractor(lib=lib, max_batch=1)
 rng = np.random.RandomState(int(sys.argv[1]))
 t0 = time.time(); n = 0; bad = 0

@@ -11,7 +11,8 @@ from sg_slam_amd import synth
 from sg_slam_amd.orb import ORBextractor
 from sg_slam_amd.capi import SgxLib
 from oracle import oracle as orc
-lib = SgxLib(os.path.join(ROOT, 'tests', 'emu', 'libsgx_emu.so'))
+from _campaign_lib import campaign_lib
+lib, XP = campaign_lib()
 rng = np.random.RandomState(int(sys.argv[1])); t0 = time.time(); n = bad = refused = 0
 tex = synth.world_texture(int(sys.argv[1]), 1500, 1000)
 MAXC = int(sys.argv[3]) if len(sys.argv) > 3 else None          # optional: stop after this many cases (deterministic runs)

@@ -12,7 +12,8 @@ from sg_slam_amd.optimizer import Optimizer
 from oracle import oracle as orc
 from scenes import make_pose_problem, make_ba_problem, CAM
 from test_localba import close, points_close
-lib = SgxLib(os.path.join(ROOT, 'tests', 'emu', 'libsgx_emu.so'))
+from _campaign_lib import campaign_lib
+lib, XP = campaign_lib()
 is2 = orc.orb_params()['inv_sigma2']
 seed0 = int(sys.argv[1]); rng = np.random.RandomState(seed0)
 t0 = time.time(); npo = nba = bad = 0

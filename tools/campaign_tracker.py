@@ -8,13 +8,14 @@ import numpy as np
 from sg_slam_amd.capi import SgxLib
 from oracle import oracle as orc
 from test_tracker_emu import run_tracker
-lib = SgxLib(os.path.join(ROOT, 'tests', 'emu', 'libsgx_emu.so'))
+from _campaign_lib import campaign_lib
+lib, XP = campaign_lib()
 rng = np.random.RandomState(int(sys.argv[1])); t0 = time.time(); n = bad = 0
 MAXC = int(sys.argv[3]) if len(sys.argv) > 3 else None          # optional: stop after this many cases (deterministic runs)
 while time.time() - t0 < float(sys.argv[2]) and (MAXC is None or n < MAXC):
     ss = int(rng.randint(0, 100000)); offs = (int(rng.randint(0, 80)), int(rng.randint(0, 80))); nf = int(rng.randint(4, 8))
     try:
-        run_tracker(lib, orc, 'numpy', stream_seed=ss, offs=offs, nframes=nf)
+        run_tracker(lib, orc, XP, stream_seed=ss, offs=offs, nframes=nf)
     except AssertionError as e:
         bad += 1; print('MISMATCH stream_seed', ss, 'offs', offs, 'frames', nf, repr(e)[:200], flush=True)
     n += 1
