@@ -217,6 +217,13 @@ typedef struct sgx_ba_problem {
 typedef struct sgx_ba_stats { int32_t iterations_first, iterations_second, free_poses, reserved; double chi2_first, chi2_second; } sgx_ba_stats;
 int sgx_local_bundle_adjustment(const sgx_ba_problem *problem, const sgx_camera *cam, const volatile int32_t *stop_flag,
                                 uint8_t *edge_erase, sgx_ba_stats *stats);
+/* Replaces `static void Optimizer::BundleAdjustment(const vector<KeyFrame*> &vpKFs, const vector<MapPoint*> &vpMP, int nIterations, bool *pbStopFlag,
+ * const unsigned long nLoopKF, const bool bRobust)` (src/sg-slam/include/Optimizer.h:44-46, src/sg-slam/src/Optimizer.cc:49-237; GlobalBundleAdjustemnt :40-47 is
+ * the same call on all keyframes / map points of the Map): every non-bad keyframe is a pose (pose_fixed != 0 exactly for mnId == 0), every non-bad map point a
+ * landmark, one edge per observation in a keyframe of the problem; ONE optimizer.optimize(nIterations) with Huber kernels sqrt(5.99) / sqrt(7.815) when bRobust, no
+ * outlier classification.  Out: every pose (the fixed one included, :200-214) and every point that has at least one edge (:216-236; the others are
+ * vbNotIncludedMP) — the caller stores them with SetPose / SetWorldPos (nLoopKF == 0) or in mTcwGBA / mPosGBA.  stats: iterations_first, chi2_first. */
+int sgx_bundle_adjustment(const sgx_ba_problem *problem, const sgx_camera *cam, int n_iterations, const volatile int32_t *stop_flag, int robust, sgx_ba_stats *stats);
 
 /* ---- 2-D detector + dynamic-feature mask --------------------------------------------------------
  * Replaces ORB_SLAM2::Detector2D (src/sg-slam/include/Detector2D.h:45-67, src/sg-slam/src/Detector2D.cc:16-89): the ncnn

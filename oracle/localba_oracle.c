@@ -320,6 +320,30 @@ done:
     return 0;
 }
 
+/* Optimizer::BundleAdjustment (Optimizer.cc:49-237) on the flattened graph: every keyframe is a vertex (fixed iff mnId == 0: pose_fixed != 0), every map point with
+ * at least one edge is a marginalised vertex, ONE optimize(nIterations) over all edges (level 0), Huber deltas sqrt(5.99) / sqrt(7.815) as floats when bRobust
+ * (:83-84; note 5.99, not LocalBA's 5.991), no outlier classification.  Every keyframe pose is rewritten through SE3Quat (:200-214, the fixed one included), every
+ * included point through Vector3d -> float (:216-236).  Points without edges are "not included" (vbNotIncludedMP): untouched. */
+int orc_bundle_adjustment(int np, float *poses, const uint8_t *pose_fixed, int nl, float *points,
+                          int ne, const int *e_pose, const int *e_point, const float *e_obs, const float *e_info,
+                          float fx, float fy, float cx, float cy, float bf, int n_iterations, int robust, const int *stop_flag,
+                          double *trace /* n_iterations*3 or NULL */, int *iters_out /* 1 or NULL */)
+{
+    ba_t B;
+    ba_setup(&B, np, poses, pose_fixed, nl, points, ne, e_pose, e_point, e_obs, e_info, fx, fy, cx, cy, bf, stop_flag);
+    B.dMono = (float)sqrt(5.99); B.dStereo = (float)sqrt(7.815);
+    for (int k = 0; k < ne; k++) B.E[k].robust = robust ? 1 : 0;
+    uint8_t *included = (uint8_t *)calloc(nl > 0 ? nl : 1, 1);
+    for (int k = 0; k < ne; k++) included[e_point[k]] = 1;
+    const int it = ba_optimize(&B, n_iterations, trace);
+    if (iters_out) iters_out[0] = it;
+    for (int i = 0; i < np; i++) se3_to_cv(&B.T[i], poses + 16 * i);
+    for (int i = 0; i < nl; i++) if (included[i]) for (int c = 0; c < 3; c++) points[3 * i + c] = (float)B.X[3 * i + c];
+    free(included);
+    free(B.T); free(B.X); free(B.hidx); free(B.E);
+    return 0;
+}
+
 /* ---- known-answer taps (tests/test_oracle_kat.py): the pieces above exposed one at a time, so that the tests can pin them against independent
  * arithmetic (central differences for the Jacobians, a dense solve of the full normal equations for the Schur path) ---- */
 int orc_kat_ba_edge(const float *Tcw, const double *X, const double *obs, int stereo, double fx, double fy, double cx, double cy, double bf,

@@ -306,3 +306,17 @@ def dynamic_mask(cur, prev, F, boxes, have_dynamic, nfeatures=1000):
     keep = np.zeros(max(len(cur), 1), np.uint8)
     r = lib().orc_dynamic_mask(_p(cur), _p(prev), C.c_int(len(cur)), _p(F), _p(boxes), C.c_int(len(boxes)), C.c_int(int(bool(have_dynamic))), C.c_int(nfeatures), _p(keep))
     return keep[:len(cur)].astype(bool), bool(r)
+
+
+def bundle_adjustment(problem, cam, n_iterations=5, robust=True, stop_flag=None):
+    """Optimizer::BundleAdjustment restatement on the flattened graph.  Returns (poses[np,4,4], points[nl,3], trace[n_iterations,3], iterations)."""
+    poses = np.ascontiguousarray(problem['poses'], 'f4').reshape(-1, 16).copy(); fixed = np.ascontiguousarray(problem['pose_fixed'], np.uint8)
+    pts = np.ascontiguousarray(problem['points'], 'f4').copy()
+    ep = np.ascontiguousarray(problem['edge_pose'], 'i4'); el = np.ascontiguousarray(problem['edge_point'], 'i4')
+    eo = np.ascontiguousarray(problem['edge_obs'], 'f4'); ei = np.ascontiguousarray(problem['edge_info'], 'f4')
+    trace = np.zeros(max(n_iterations, 1) * 3, 'f8'); iters = np.zeros(1, 'i4')
+    st = None if stop_flag is None else _p(np.ascontiguousarray(stop_flag, 'i4'))
+    lib().orc_bundle_adjustment(C.c_int(len(poses)), _p(poses), _p(fixed), C.c_int(len(pts)), _p(pts), C.c_int(len(ep)), _p(ep), _p(el), _p(eo), _p(ei),
+                                C.c_float(cam['fx']), C.c_float(cam['fy']), C.c_float(cam['cx']), C.c_float(cam['cy']), C.c_float(cam['bf']),
+                                C.c_int(n_iterations), C.c_int(int(bool(robust))), st, _p(trace), _p(iters))
+    return poses.reshape(-1, 4, 4), pts, trace.reshape(-1, 3), int(iters[0])

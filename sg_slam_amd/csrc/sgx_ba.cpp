@@ -207,10 +207,11 @@ static int optimize(BA &B, int iterations, int *iters_done, double *final_chi)
 }
 }  // namespace
 
-extern "C" int sgx_local_bundle_adjustment(const sgx_ba_problem *P, const sgx_camera *cam, const volatile int32_t *stop_flag,
-                                           uint8_t *edge_erase, sgx_ba_stats *stats)
+// mode 0: Optimizer::LocalBundleAdjustment (Optimizer.cc:453-778); mode 1: Optimizer::BundleAdjustment (Optimizer.cc:49-237): one optimize(n_iterations) over
+// all edges, Huber deltas sqrt(5.99) / sqrt(7.815) only when `robust`, no classification, every pose rewritten
+static int ba_run(const sgx_ba_problem *P, const sgx_camera *cam, const volatile int32_t *stop_flag, uint8_t *edge_erase, sgx_ba_stats *stats, int mode, int n_iterations, int robust)
 {
-    if (!P || !cam || !edge_erase || P->n_poses < 1 || P->n_points < 1 || P->n_edges < 1 || !P->poses || !P->pose_fixed || !P->points ||
+    if (!P || !cam || (mode == 0 && !edge_erase) || P->n_poses < 1 || P->n_points < 1 || P->n_edges < 1 || !P->poses || !P->pose_fixed || !P->points ||
         !P->edge_pose || !P->edge_point || !P->edge_obs || !P->edge_info) return SGX_ERR_INVALID;
     // the device arena is one per process: calls from several threads (the reference has one LocalMapping thread, plus GlobalBundleAdjustment from LoopClosing) take turns
     static std::mutex arena_mutex;
@@ -219,9 +220,10 @@ extern "C" int sgx_local_bundle_adjustment(const sgx_ba_problem *P, const sgx_ca
     B.np = P->n_poses; B.nl = P->n_points; B.ne = P->n_edges; B.stop = stop_flag;
     B.cam.fx = cam->fx; B.cam.fy = cam->fy; B.cam.cx = cam->cx; B.cam.cy = cam->cy; B.cam.bf = cam->bf;
     B.dMono = (double)(float)sqrt(5.991); B.dStereo = (double)(float)sqrt(7.815);          // Optimizer.cc:569-570 (float)
+    if (mode == 1) { B.dMono = robust ? (double)(float)sqrt(5.99) : 1e150; B.dStereo = robust ? (double)(float)sqrt(7.815) : 1e150; }   // :83-84; no kernel = Huber that never leaves its quadratic zone
     if (stats) memset(stats, 0, sizeof *stats);
-    memset(edge_erase, 0, B.ne);
-    if (stop_flag && *stop_flag) return SGX_OK;                                              // Optimizer.cc:655-657
+    if (edge_erase) memset(edge_erase, 0, B.ne);
+    if (mode == 0 && stop_flag && *stop_flag) return SGX_OK;                                 // Optimizer.cc:655-657
     // ---- index structures
     std::vector<int> hidx(B.np), free_pose;
     for (int i = 0; i < B.np; i++) { if (P->pose_fixed[i]) hidx[i] = -1; else { hidx[i] = (int)free_pose.size(); free_pose.push_back(i); } }
@@ -278,7 +280,8 @@ extern "C" int sgx_local_bundle_adjustment(const sgx_ba_problem *P, const sgx_ca
         put(B.pt_start, pt_start.data(), 4 * (size_t)(B.nl + 1)); put(B.pt_edges, pt_edges.data(), 4 * (size_t)B.ne);
         put(B.pose_start, pose_start.data(), 4 * (size_t)(B.np + 1)); put(B.pose_edges, pose_edges.data(), 4 * (size_t)B.ne);
         put(B.hidx, hidx.data(), 4 * (size_t)B.np); if (B.nf) put(B.free_pose, free_pose.data(), 4 * (size_t)B.nf);
-        put(dTcw, P->poses, 64 * (size_t)B.np); put(dfixed, P->pose_fixed, B.np);
+        put(dTcw, P->poses, 64 * (size_t)B.np);
+        if (mode == 0) put(dfixed, P->pose_fixed, B.np);           // mode 1: every keyframe is rewritten from its vertex (Optimizer.cc:200-214) -> flags stay 0
         SGX_CHECK_HIP(hipMemcpy(base, stage.data(), in_bytes, hipMemcpyHostToDevice));
     }
     SGX_CHECK_HIP(hipMemsetAsync(B.xp, 0, sizeof(double) * (B.NP ? B.NP : 1), 0));
@@ -291,8 +294,8 @@ extern "C" int sgx_local_bundle_adjustment(const sgx_ba_problem *P, const sgx_ca
     int it1 = 0, it2 = 0; double chi1 = 0, chi2 = 0;
     std::vector<uint8_t> level1(B.ne, 0);
     rc = build_jobs(B, pt_start, pt_edges, E, level1, hidx); if (rc != SGX_OK) return rc;
-    rc = optimize(B, 5, &it1, &chi1); if (rc != SGX_OK) return rc;                          // Optimizer.cc:659-660
-    if (!stopped(B)) {                                                                      // :662-707
+    rc = optimize(B, mode == 1 ? n_iterations : 5, &it1, &chi1); if (rc != SGX_OK) return rc;   // Optimizer.cc:659-660 / :187-188
+    if (mode == 0 && !stopped(B)) {                                                                      // :662-707
         SGX_LAUNCH(k_ba_classify, dim3(B.nblk_e), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.ne, B.E, B.T, B.X, B.err, 0, derase);
         {   // mirror the new levels on the host to rebuild the Schur job list (the active edge set changed)
             std::vector<SgxBaEdge> Eh(B.ne);
@@ -302,13 +305,27 @@ extern "C" int sgx_local_bundle_adjustment(const sgx_ba_problem *P, const sgx_ca
         }
         rc = optimize(B, 10, &it2, &chi2); if (rc != SGX_OK) return rc;
     }
-    SGX_LAUNCH(k_ba_classify, dim3(B.nblk_e), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.ne, B.E, B.T, B.X, B.err, 1, derase);   // :709-742
+    if (mode == 0) SGX_LAUNCH(k_ba_classify, dim3(B.nblk_e), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.ne, B.E, B.T, B.X, B.err, 1, derase);   // :709-742
     SGX_LAUNCH(k_ba_poses_out, dim3((B.np + SGX_BA_THREADS - 1) / SGX_BA_THREADS), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.np, dfixed, B.T, dTcw);
     SGX_CHECK_HIP(hipGetLastError());
-    SGX_CHECK_HIP(hipMemcpy(edge_erase, derase, B.ne, hipMemcpyDeviceToHost));
+    if (mode == 0) SGX_CHECK_HIP(hipMemcpy(edge_erase, derase, B.ne, hipMemcpyDeviceToHost));
     SGX_CHECK_HIP(hipMemcpy(P->poses, dTcw, 64 * (size_t)B.np, hipMemcpyDeviceToHost));
     SGX_CHECK_HIP(hipMemcpy(Xd.data(), B.X, sizeof(double) * Xd.size(), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < Xd.size(); i++) P->points[i] = (float)Xd[i];                      // Converter::toCvMat(Vector3d), Optimizer.cc:771-777
+    for (int l = 0; l < B.nl; l++)                                                           // Converter::toCvMat(Vector3d), Optimizer.cc:771-777 / :216-236
+        if (mode == 0 || pt_start[l + 1] > pt_start[l])                                      // BundleAdjustment: points without edges were removed from the graph (vbNotIncludedMP)
+            for (int c = 0; c < 3; c++) P->points[3 * (size_t)l + c] = (float)Xd[3 * (size_t)l + c];
     if (stats) { stats->iterations_first = it1; stats->iterations_second = it2; stats->chi2_first = chi1; stats->chi2_second = chi2; stats->free_poses = B.nf; }
     return SGX_OK;
+}
+
+extern "C" int sgx_local_bundle_adjustment(const sgx_ba_problem *P, const sgx_camera *cam, const volatile int32_t *stop_flag,
+                                           uint8_t *edge_erase, sgx_ba_stats *stats)
+{
+    return ba_run(P, cam, stop_flag, edge_erase, stats, 0, 0, 1);
+}
+
+extern "C" int sgx_bundle_adjustment(const sgx_ba_problem *P, const sgx_camera *cam, int n_iterations, const volatile int32_t *stop_flag, int robust, sgx_ba_stats *stats)
+{
+    if (n_iterations < 0) return SGX_ERR_INVALID;
+    return ba_run(P, cam, stop_flag, nullptr, stats, 1, n_iterations, robust);
 }

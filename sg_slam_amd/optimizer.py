@@ -47,3 +47,24 @@ class Optimizer:
         lib.check(lib.dll.sgx_local_bundle_adjustment(C.byref(P), C.byref(cs), stop, _vp(erase), C.byref(st)), 'sgx_local_bundle_adjustment')
         problem['poses'] = poses.reshape(-1, 4, 4); problem['points'] = pts
         return erase, dict(iterations=(st.iterations_first, st.iterations_second), chi2=(st.chi2_first, st.chi2_second), free_poses=st.free_poses)
+
+    @staticmethod
+    def BundleAdjustment(problem, cam, nIterations=5, stop_flag=None, nLoopKF=0, bRobust=True, lib=None):
+        """Optimizer::BundleAdjustment(vpKFs, vpMP, nIterations, pbStopFlag, nLoopKF, bRobust) on the flattened graph (pose_fixed != 0 exactly for the keyframe
+        with mnId == 0).  nLoopKF == 0: problem['poses'] / ['points'] are updated in place (SetPose / SetWorldPos); otherwise the results are returned under
+        'poses_gba' / 'points_gba' (mTcwGBA / mPosGBA, mnBAGlobalForKF = nLoopKF) and the problem is left untouched.  Returns stats."""
+        lib = lib if lib is not None else load()
+        poses = np.ascontiguousarray(problem['poses'], 'f4').reshape(-1, 16).copy(); fixed = np.ascontiguousarray(problem['pose_fixed'], np.uint8)
+        pts = np.ascontiguousarray(problem['points'], 'f4').copy()
+        ep = np.ascontiguousarray(problem['edge_pose'], 'i4'); el = np.ascontiguousarray(problem['edge_point'], 'i4')
+        eo = np.ascontiguousarray(problem['edge_obs'], 'f4'); ei = np.ascontiguousarray(problem['edge_info'], 'f4')
+        P = BaProblem(len(poses), len(pts), len(ep), poses.ctypes.data, fixed.ctypes.data, pts.ctypes.data, ep.ctypes.data, el.ctypes.data,
+                      eo.ctypes.data, ei.ctypes.data)
+        st = BaStats(); cs = camera_struct(cam)
+        stop = None if stop_flag is None else _vp(stop_flag)
+        lib.check(lib.dll.sgx_bundle_adjustment(C.byref(P), C.byref(cs), int(nIterations), stop, int(bool(bRobust)), C.byref(st)), 'sgx_bundle_adjustment')
+        if nLoopKF == 0:
+            problem['poses'] = poses.reshape(-1, 4, 4); problem['points'] = pts
+        else:
+            problem['poses_gba'] = poses.reshape(-1, 4, 4); problem['points_gba'] = pts; problem['mnBAGlobalForKF'] = nLoopKF
+        return dict(iterations=st.iterations_first, chi2=st.chi2_first, free_poses=st.free_poses)
