@@ -137,6 +137,23 @@ int sgx_match_project_local(
     const sgx_camera *cam, const float *scale_factors, int nlevels, float log_scale_factor, float th, float nnratio, float viewing_cos_limit,
     int32_t *cur_match, int32_t *nmatches, uint8_t *in_view);
 
+/* ---- ORBmatcher gates of the LocalMapping thread (tier N2) --------------------------------------------------------------------
+ * static int ORBmatcher::DescriptorDistance(const cv::Mat &a, const cv::Mat &b) (src/sg-slam/include/ORBmatcher.h:45, ORBmatcher.cc:1649-1665) for every pair of two
+ * descriptor sets (rows of 32 bytes): out[i * nb + j]. */
+int sgx_hamming_matrix(const uint8_t *desc_a, int na, const uint8_t *desc_b, int nb, uint16_t *out);
+int sgx_hamming_matrix_dev(const uint8_t *d_desc_a, int na, const uint8_t *d_desc_b, int nb, uint16_t *d_out, void *stream);
+/* int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, vector<pair<size_t,size_t>> &vMatchedPairs, const bool bOnlyStereo)
+ * (src/sg-slam/include/ORBmatcher.h:72-73, src/sg-slam/src/ORBmatcher.cc:659-827; caller LocalMapping::CreateNewMapPoints, LocalMapping.cc:268).  Flattened keyframes:
+ * keys*_un = mvKeysUn, desc* = mDescriptors, uright* = mvuRight, has_mp*[i] = GetMapPoint(i) != NULL, feat_node*[i] = the key under which keypoint i sits in mFeatVec
+ * (DBoW2 FeatureVector: vocabulary node 4 levels up; -1 = not in the map), cam_center1 = pKF1->GetCameraCenter() (3 floats), Tcw2 = pKF2->GetPose() (4x4 row-major),
+ * F12 = 3x3 row-major float, cam2 / scale_factors2 / level_sigma2_2 = pKF2's fx.., mvScaleFactors, mvLevelSigma2.  pairs (out, capacity n1 pairs) = vMatchedPairs as
+ * (idx1, idx2) in ascending idx1; *npairs = return value.  Host pointers, synchronous. */
+int sgx_match_search_for_triangulation(
+    int n1, const sgx_keypoint *keys1_un, const uint8_t *desc1, const float *uright1, const uint8_t *has_mp1, const int32_t *feat_node1, const float *cam_center1,
+    int n2, const sgx_keypoint *keys2_un, const uint8_t *desc2, const float *uright2, const uint8_t *has_mp2, const int32_t *feat_node2, const float *Tcw2,
+    const float *F12, const sgx_camera *cam2, const float *scale_factors2, const float *level_sigma2_2, int nlevels, int only_stereo, int check_orientation,
+    int32_t *pairs, int32_t *npairs);
+
 /* Harness helper (bench.py / tests), NOT a reference entry point: the previous-frame position of every keypoint under a per-frame affine flow
  * (prev = A * (x, y, 1), A = 6 floats), optionally displaced by shift[2] inside the frame's first box.  Stands in for cv::calcOpticalFlowPyrLK
  * (Frame.cc:445, tier N1) when the dynamic-feature mask is exercised on synthetic streams whose flow is known exactly. */

@@ -22,6 +22,7 @@ typedef struct { float x, y, size, angle, response; int octave, class_id; } orc_
 #define GRID_ROWS 48
 #define TH_HIGH 100
 #define HISTO_LENGTH 30
+#define TH_LOW 50                  /* ORBmatcher::TH_LOW, ORBmatcher.cc:38 */
 
 int orc_descriptor_distance(const uint8_t *a, const uint8_t *b)
 {
@@ -308,5 +309,102 @@ int orc_search_by_projection_local(
         }
     }
     free(vind); free(owner_obs); grid_free(g); free(g);
+    return nmatches;
+}
+
+
+/* ---- LocalMapping gates (tier N2) --------------------------------------------------------------------------------------------------------------- */
+void orc_hamming_matrix(const uint8_t *a, int na, const uint8_t *b, int nb, uint16_t *out)
+{
+    for (int i = 0; i < na; i++) for (int j = 0; j < nb; j++) out[(size_t)i * nb + j] = (uint16_t)orc_descriptor_distance(a + 32 * (size_t)i, b + 32 * (size_t)j);
+}
+
+/* ORBmatcher::CheckDistEpipolarLine, ORBmatcher.cc:140-158 (F12 row-major float) */
+static int check_dist_epipolar(const orc_keypoint *kp1, const orc_keypoint *kp2, const float *F12, const float *sigma2_2)
+{
+    const float a = kp1->x * F12[0] + kp1->y * F12[3] + F12[6];
+    const float b = kp1->x * F12[1] + kp1->y * F12[4] + F12[7];
+    const float c = kp1->x * F12[2] + kp1->y * F12[5] + F12[8];
+    const float num = a * kp2->x + b * kp2->y + c;
+    const float den = a * a + b * b;
+    if (den == 0) return 0;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84 * sigma2_2[kp2->octave];
+}
+
+static int cmp_int(const void *x, const void *y) { const int a = *(const int *)x, b = *(const int *)y; return (a > b) - (a < b); }
+
+/* ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo), ORBmatcher.cc:659-827.
+ * feat_node[i] = vocabulary node (DBoW2 FeatureVector key, levelsup 4) of keypoint i, -1 = none: mFeatVec is a std::map<NodeId, vector<index>> whose vectors hold the
+ * indices in ascending order (TemplatedVocabulary::transform pushes them in feature order).  cam_center1 = pKF1->GetCameraCenter(), Tcw2 = pKF2 pose.
+ * pairs (out): (idx1, idx2) in ascending idx1; returns nmatches. */
+int orc_search_for_triangulation(int n1, const orc_keypoint *k1, const uint8_t *d1, const float *ur1, const uint8_t *has1, const int *node1, const float *cam_center1,
+                                 int n2, const orc_keypoint *k2, const uint8_t *d2, const float *ur2, const uint8_t *has2, const int *node2, const float *Tcw2,
+                                 const float *F12, float fx, float fy, float cx, float cy, const float *scale2, const float *sigma2_2,
+                                 int only_stereo, int check_ori, int *pairs)
+{
+    float C2[3];
+    for (int r = 0; r < 3; r++) C2[r] = gemm3(Tcw2 + 4 * r, cam_center1, 1.0, 1.0, Tcw2[4 * r + 3]);       /* C2 = R2w*Cw + t2w (:666-670) */
+    const float invz = 1.0f / C2[2];
+    const float ex = fx * C2[0] * invz + cx, ey = fy * C2[1] * invz + cy;
+    int nmatches = 0;
+    uint8_t *matched2 = (uint8_t *)calloc(n2 > 0 ? n2 : 1, 1);
+    int *m12 = (int *)malloc(sizeof(int) * (n1 > 0 ? n1 : 1));
+    for (int i = 0; i < n1; i++) m12[i] = -1;
+    int *hist[HISTO_LENGTH], hn[HISTO_LENGTH], hc[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) { hist[i] = NULL; hn[i] = hc[i] = 0; }
+    const float factor = HISTO_LENGTH / 360.0f;
+    /* the ordered set of nodes both keyframes have */
+    int *u1 = (int *)malloc(sizeof(int) * (n1 > 0 ? n1 : 1)), nu1 = 0;
+    for (int i = 0; i < n1; i++) if (node1[i] >= 0) u1[nu1++] = node1[i];
+    qsort(u1, nu1, sizeof(int), cmp_int);
+    for (int q = 0; q < nu1; q++) {
+        if (q > 0 && u1[q] == u1[q - 1]) continue;
+        const int nid = u1[q];
+        int any2 = 0; for (int j = 0; j < n2; j++) if (node2[j] == nid) { any2 = 1; break; }
+        if (!any2) continue;
+        for (int idx1 = 0; idx1 < n1; idx1++) {                                                           /* f1it->second in index order */
+            if (node1[idx1] != nid) continue;
+            if (has1[idx1]) continue;
+            const int stereo1 = ur1[idx1] >= 0;
+            if (only_stereo && !stereo1) continue;
+            int bestDist = TH_LOW, bestIdx2 = -1;
+            for (int idx2 = 0; idx2 < n2; idx2++) {
+                if (node2[idx2] != nid) continue;
+                if (matched2[idx2] || has2[idx2]) continue;
+                const int stereo2 = ur2[idx2] >= 0;
+                if (only_stereo && !stereo2) continue;
+                const int dist = orc_descriptor_distance(d1 + 32 * (size_t)idx1, d2 + 32 * (size_t)idx2);
+                if (dist > TH_LOW || dist > bestDist) continue;
+                if (!stereo1 && !stereo2) {
+                    const float distex = ex - k2[idx2].x, distey = ey - k2[idx2].y;
+                    if (distex * distex + distey * distey < 100 * scale2[k2[idx2].octave]) continue;
+                }
+                if (check_dist_epipolar(&k1[idx1], &k2[idx2], F12, sigma2_2)) { bestIdx2 = idx2; bestDist = dist; }
+            }
+            if (bestIdx2 >= 0) {
+                m12[idx1] = bestIdx2; matched2[bestIdx2] = 1; nmatches++;
+                if (check_ori) {
+                    float rot = k1[idx1].angle - k2[bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)round(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    if (hn[bin] == hc[bin]) { hc[bin] = hc[bin] ? 2 * hc[bin] : 64; hist[bin] = (int *)realloc(hist[bin], sizeof(int) * hc[bin]); }
+                    hist[bin][hn[bin]++] = idx1;
+                }
+            }
+        }
+    }
+    if (check_ori) {
+        int i1, i2, i3; three_maxima(hn, HISTO_LENGTH, &i1, &i2, &i3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == i1 || i == i2 || i == i3) continue;
+            for (int j = 0; j < hn[i]; j++) { matched2[m12[hist[i][j]]] = 0; m12[hist[i][j]] = -1; nmatches--; }
+        }
+    }
+    int n = 0;
+    for (int i = 0; i < n1; i++) if (m12[i] >= 0) { pairs[2 * n] = i; pairs[2 * n + 1] = m12[i]; n++; }
+    for (int i = 0; i < HISTO_LENGTH; i++) free(hist[i]);
+    free(matched2); free(m12); free(u1);
     return nmatches;
 }

@@ -320,3 +320,26 @@ def bundle_adjustment(problem, cam, n_iterations=5, robust=True, stop_flag=None)
                                 C.c_float(cam['fx']), C.c_float(cam['fy']), C.c_float(cam['cx']), C.c_float(cam['cy']), C.c_float(cam['bf']),
                                 C.c_int(n_iterations), C.c_int(int(bool(robust))), st, _p(trace), _p(iters))
     return poses.reshape(-1, 4, 4), pts, trace.reshape(-1, 3), int(iters[0])
+
+
+# ---- LocalMapping gates (oracle/match_oracle.c) ----------------------------------------------------
+def hamming_matrix(a, b):
+    a = np.ascontiguousarray(a, np.uint8).reshape(-1, 32); b = np.ascontiguousarray(b, np.uint8).reshape(-1, 32)
+    out = np.zeros((len(a), len(b)), np.uint16)
+    lib().orc_hamming_matrix(_p(a), C.c_int(len(a)), _p(b), C.c_int(len(b)), _p(out))
+    return out
+
+
+def search_for_triangulation(kf1, kf2, F12, only_stereo, cam2, scale2, sigma2_2, check_ori=True):
+    """ORBmatcher::SearchForTriangulation restatement: (nmatches, pairs[n,2])"""
+    k1 = np.ascontiguousarray(kf1['keys']); d1 = np.ascontiguousarray(kf1['desc'], np.uint8); u1 = np.ascontiguousarray(kf1['uright'], 'f4')
+    h1 = np.ascontiguousarray(kf1['has_mp'], np.uint8); n1 = np.ascontiguousarray(kf1['feat_node'], 'i4'); c1 = np.ascontiguousarray(kf1['cam_center'], 'f4')
+    k2 = np.ascontiguousarray(kf2['keys']); d2 = np.ascontiguousarray(kf2['desc'], np.uint8); u2 = np.ascontiguousarray(kf2['uright'], 'f4')
+    h2 = np.ascontiguousarray(kf2['has_mp'], np.uint8); n2 = np.ascontiguousarray(kf2['feat_node'], 'i4'); T2 = np.ascontiguousarray(kf2['Tcw'], 'f4').reshape(16)
+    F = np.ascontiguousarray(F12, 'f4').reshape(9); sf = np.ascontiguousarray(scale2, 'f4'); sg = np.ascontiguousarray(sigma2_2, 'f4')
+    pairs = np.zeros((max(len(k1), 1), 2), 'i4')
+    L = lib(); L.orc_search_for_triangulation.restype = C.c_int
+    n = L.orc_search_for_triangulation(C.c_int(len(k1)), _p(k1), _p(d1), _p(u1), _p(h1), _p(n1), _p(c1), C.c_int(len(k2)), _p(k2), _p(d2), _p(u2), _p(h2), _p(n2), _p(T2),
+                                       _p(F), C.c_float(cam2['fx']), C.c_float(cam2['fy']), C.c_float(cam2['cx']), C.c_float(cam2['cy']), _p(sf), _p(sg),
+                                       C.c_int(int(bool(only_stereo))), C.c_int(int(bool(check_ori))), _p(pairs))
+    return int(n), pairs[:n].copy()

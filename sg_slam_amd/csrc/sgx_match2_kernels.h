@@ -1,0 +1,141 @@
+// sgx_match2_kernels.h — ORBmatcher gates used by LocalMapping (tier N2 of SURVEY.md §8):
+//   k_hamming_matrix            ORBmatcher::DescriptorDistance for every pair of two descriptor sets        src/sg-slam/src/ORBmatcher.cc:1649-1665
+//   k_search_triangulation      ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo)   src/sg-slam/src/ORBmatcher.cc:659-827
+// SearchForTriangulation walks the two DBoW2 FeatureVectors (std::map<NodeId, vector<feature index>>) in lock step and, inside every COMMON vocabulary node,
+// gives each unmatched keypoint of KF1 (index order) its best still-unmatched keypoint of KF2 of that node (Hamming <= TH_LOW, epipolar gate).  The greedy
+// "vbMatched2" lock only couples keypoints of the SAME node, so nodes are independent: one thread runs one node's loops exactly as written, all nodes in
+// parallel; the rotation histogram (ComputeThreeMaxima) is resolved by the workgroup afterwards.
+#pragma once
+#include "sgx_match_common.h"
+
+#define SGX_TH_LOW 50             /* ORBmatcher::TH_LOW, ORBmatcher.cc:38 */
+
+// out[i * nb + j] = Hamming distance of row i of A and row j of B (32-byte rows); 16 x 16 pairs per workgroup from LDS-staged rows
+SGX_KERNEL(256) k_hamming_matrix(const uint32_t *A, int na, const uint32_t *B, int nb, uint16_t *out)
+{
+    SGX_LDS uint32_t sa[16][9], sb[16][9];
+    const int i0 = (int)blockIdx.y * 16, j0 = (int)blockIdx.x * 16;
+    SGX_THREADS_BEGIN(tid)
+    const int r = tid >> 4, w = tid & 15;
+    if (w < 8) sa[r][w] = i0 + r < na ? A[(size_t)(i0 + r) * 8 + w] : 0u;
+    else sb[r][w - 8] = j0 + r < nb ? B[(size_t)(j0 + r) * 8 + (w - 8)] : 0u;
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    const int i = tid >> 4, j = tid & 15;
+    if (i0 + i < na && j0 + j < nb) out[(size_t)(i0 + i) * nb + j0 + j] = (uint16_t)sgx_hamming256(sa[i], sb[j]);
+    SGX_THREADS_END
+}
+
+struct SgxTriArgs {
+    int n1, n2, nnodes;                      /* keypoints of KF1 / KF2, common vocabulary nodes */
+    const uint8_t *keys1, *keys2;            /* mvKeysUn (28-byte cv::KeyPoint) */
+    const uint32_t *desc1, *desc2;
+    const float *uright1, *uright2;
+    const uint8_t *has_mp1, *has_mp2;        /* GetMapPoint(idx) != NULL */
+    const int *items1, *items2;              /* feature indices grouped by node (FeatureVector order) */
+    const int *job;                          /* per common node: start1, end1, start2, end2 into items1 / items2 */
+    float F12[9];                            /* row-major */
+    float ex, ey;                            /* epipole of KF1's centre in KF2 */
+    SgxScales scale2, sigma2_2;              /* pKF2->mvScaleFactors, pKF2->mvLevelSigma2 */
+    int only_stereo, check_ori;
+    int *match12;                            /* out: n1 entries, index in KF2 or -1 */
+    uint8_t *matched2;                       /* work: n2 flags */
+    int *nmatches;
+};
+
+SGX_KERNEL(256) k_search_triangulation(SgxTriArgs A)
+{
+    SGX_LDS int hist[SGX_HISTO], bad[SGX_HISTO];
+    SGX_LDS int s_total, s_rejected;
+    SGX_THREADS_BEGIN(tid)
+    for (int i = tid; i < A.n1; i += 256) A.match12[i] = -1;
+    for (int i = tid; i < A.n2; i += 256) A.matched2[i] = 0;
+    for (int i = tid; i < SGX_HISTO; i += 256) { hist[i] = 0; bad[i] = 0; }
+    if (tid == 0) { s_total = 0; s_rejected = 0; }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    for (int nd = tid; nd < A.nnodes; nd += 256) {
+        const int s1 = A.job[4 * nd], e1 = A.job[4 * nd + 1], s2 = A.job[4 * nd + 2], e2 = A.job[4 * nd + 3];
+        for (int q1 = s1; q1 < e1; q1++) {
+            const int idx1 = A.items1[q1];
+            if (A.has_mp1[idx1]) continue;                                       // :704-705
+            const bool stereo1 = A.uright1[idx1] >= 0;
+            if (A.only_stereo && !stereo1) continue;
+            const float *kp1 = (const float *)(A.keys1 + (size_t)idx1 * 28);
+            const uint32_t *d1 = A.desc1 + (size_t)idx1 * 8;
+            // CheckDistEpipolarLine: l = x1' F12 (ORBmatcher.cc:140-143), float arithmetic left to right
+            const float a = kp1[0] * A.F12[0] + kp1[1] * A.F12[3] + A.F12[6];
+            const float b = kp1[0] * A.F12[1] + kp1[1] * A.F12[4] + A.F12[7];
+            const float c = kp1[0] * A.F12[2] + kp1[1] * A.F12[5] + A.F12[8];
+            const float den = a * a + b * b;
+            int bestDist = SGX_TH_LOW, bestIdx2 = -1;
+            for (int q2 = s2; q2 < e2; q2++) {
+                const int idx2 = A.items2[q2];
+                if (A.matched2[idx2] || A.has_mp2[idx2]) continue;               // :728-729
+                const bool stereo2 = A.uright2[idx2] >= 0;
+                if (A.only_stereo && !stereo2) continue;
+                const int dist = sgx_hamming256(d1, A.desc2 + (size_t)idx2 * 8);
+                if (dist > SGX_TH_LOW || dist > bestDist) continue;
+                const float *kp2 = (const float *)(A.keys2 + (size_t)idx2 * 28);
+                const int oct2 = ((const int *)kp2)[5];
+                if (!stereo1 && !stereo2) {                                      // too close to the epipole: :746-752
+                    const float dx = A.ex - kp2[0], dy = A.ey - kp2[1];
+                    if (dx * dx + dy * dy < 100 * A.scale2.s[oct2]) continue;
+                }
+                const float num = a * kp2[0] + b * kp2[1] + c;
+                if (den == 0) continue;
+                const float dsqr = num * num / den;
+                if ((double)dsqr < 3.84 * (double)A.sigma2_2.s[oct2]) { bestIdx2 = idx2; bestDist = dist; }      // :157 compares in double (3.84 is a double literal)
+            }
+            if (bestIdx2 >= 0) {
+                A.match12[idx1] = bestIdx2; A.matched2[bestIdx2] = 1;
+                sgx_atomic_add(&s_total, 1);
+                if (A.check_ori) {
+                    const float *kp2 = (const float *)(A.keys2 + (size_t)bestIdx2 * 28);
+                    float rot = kp1[3] - kp2[3];
+                    if (rot < 0.0f) rot += 360.0f;
+                    int bin = (int)round((double)(rot * (SGX_HISTO / 360.0f)));
+                    if (bin == SGX_HISTO) bin = 0;
+                    sgx_atomic_add(&hist[bin], 1);
+                }
+            }
+        }
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+    if (A.check_ori) {
+        SGX_THREADS_BEGIN(tid)
+        if (tid == 0) {                         // ComputeThreeMaxima, ORBmatcher.cc:1603-1644
+            int m1 = 0, m2 = 0, m3 = 0, i1 = -1, i2 = -1, i3 = -1;
+            for (int i = 0; i < SGX_HISTO; i++) {
+                const int s = hist[i];
+                if (s > m1) { m3 = m2; m2 = m1; m1 = s; i3 = i2; i2 = i1; i1 = i; }
+                else if (s > m2) { m3 = m2; m2 = s; i3 = i2; i2 = i; }
+                else if (s > m3) { m3 = s; i3 = i; }
+            }
+            if ((float)m2 < 0.1f * (float)m1) { i2 = -1; i3 = -1; }
+            else if ((float)m3 < 0.1f * (float)m1) { i3 = -1; }
+            for (int i = 0; i < SGX_HISTO; i++) bad[i] = (i != i1 && i != i2 && i != i3);
+        }
+        SGX_THREADS_END
+        SGX_SYNC();
+        SGX_THREADS_BEGIN(tid)
+        for (int i = tid; i < A.n1; i += 256) {
+            const int j = A.match12[i];
+            if (j < 0) continue;
+            const float *kp1 = (const float *)(A.keys1 + (size_t)i * 28), *kp2 = (const float *)(A.keys2 + (size_t)j * 28);
+            float rot = kp1[3] - kp2[3];
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)round((double)(rot * (SGX_HISTO / 360.0f)));
+            if (bin == SGX_HISTO) bin = 0;
+            if (bad[bin]) { A.match12[i] = -1; A.matched2[j] = 0; sgx_atomic_add(&s_rejected, 1); }
+        }
+        SGX_THREADS_END
+        SGX_SYNC();
+    }
+    SGX_THREADS_BEGIN(tid)
+    if (tid == 0) A.nmatches[0] = s_total - s_rejected;
+    SGX_THREADS_END
+}

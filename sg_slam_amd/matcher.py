@@ -71,3 +71,25 @@ class ORBmatcher:
         self.lib.check(rc, 'sgx_match_project_local')
         F['match_local'] = match; local_map['in_view'] = inview
         return int(n[0])
+
+    def HammingMatrix(self, desc_a, desc_b):
+        """DescriptorDistance of every row pair (na x nb uint16)"""
+        a = np.ascontiguousarray(desc_a, np.uint8).reshape(-1, 32); b = np.ascontiguousarray(desc_b, np.uint8).reshape(-1, 32)
+        out = np.zeros((len(a), len(b)), np.uint16)
+        self.lib.check(self.lib.dll.sgx_hamming_matrix(_vp(a), len(a), _vp(b), len(b), _vp(out)), 'sgx_hamming_matrix')
+        return out
+
+    def SearchForTriangulation(self, kf1, kf2, F12, bOnlyStereo, cam2, scale_factors2, level_sigma2_2):
+        """ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo) (ORBmatcher.cc:659-827).  kf*: dicts keys (mvKeysUn), desc, uright, has_mp,
+        feat_node (mFeatVec key per keypoint), kf1 additionally cam_center (GetCameraCenter), kf2 Tcw.  Returns (nmatches, vMatchedPairs[n,2])."""
+        k1 = np.ascontiguousarray(kf1['keys']); d1 = np.ascontiguousarray(kf1['desc'], np.uint8); u1 = np.ascontiguousarray(kf1['uright'], 'f4')
+        h1 = np.ascontiguousarray(kf1['has_mp'], np.uint8); n1 = np.ascontiguousarray(kf1['feat_node'], 'i4'); c1 = np.ascontiguousarray(kf1['cam_center'], 'f4')
+        k2 = np.ascontiguousarray(kf2['keys']); d2 = np.ascontiguousarray(kf2['desc'], np.uint8); u2 = np.ascontiguousarray(kf2['uright'], 'f4')
+        h2 = np.ascontiguousarray(kf2['has_mp'], np.uint8); n2 = np.ascontiguousarray(kf2['feat_node'], 'i4'); T2 = np.ascontiguousarray(kf2['Tcw'], 'f4').reshape(16)
+        F = np.ascontiguousarray(F12, 'f4').reshape(9); sf = np.ascontiguousarray(scale_factors2, 'f4'); sg = np.ascontiguousarray(level_sigma2_2, 'f4')
+        pairs = np.zeros((max(len(k1), 1), 2), 'i4'); n = np.zeros(1, 'i4')
+        cs = camera_struct(cam2)
+        self.lib.check(self.lib.dll.sgx_match_search_for_triangulation(len(k1), _vp(k1), _vp(d1), _vp(u1), _vp(h1), _vp(n1), _vp(c1), len(k2), _vp(k2), _vp(d2), _vp(u2), _vp(h2),
+                                                                       _vp(n2), _vp(T2), _vp(F), C.byref(cs), _vp(sf), _vp(sg), len(sf), int(bool(bOnlyStereo)),
+                                                                       int(self.mbCheckOrientation), _vp(pairs), _vp(n)), 'sgx_match_search_for_triangulation')
+        return int(n[0]), pairs[:n[0]].copy()

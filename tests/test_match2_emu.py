@@ -1,0 +1,10 @@
+"""LocalMapping matcher gates (tier N2) on the kernel-logic emulator against the oracle."""
+import match2_cases as mc
+
+
+def test_hamming_matrix_emu(emu, oracle):
+    mc.check_hamming(emu, oracle)
+
+
+def test_search_for_triangulation_emu(emu, oracle):
+    mc.check_triangulation(emu, oracle, n_cases=4)
