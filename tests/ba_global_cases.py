@@ -26,11 +26,11 @@ def check_gba(lib, oracle, n_kf, n_points, seed, n_iter, robust, outlier_frac=0.
     assert (p2['points'][-5:] == prob['points'][-5:]).all()                 # points without observations are not part of the graph
     assert not (p2['poses'][1:] == prob['poses'][1:]).all()                 # the free keyframes moved
     # the fixed keyframe is rewritten through SE3Quat (a normalised copy of itself)
-    assert np.abs(p2['poses'][0] - prob['poses'][0]).max() < 1e-6
+    assert np.abs(p2['poses'][0] - prob['poses'][0]).max() < 1e-5 * max(1.0, np.abs(prob['poses'][0]).max())
     # nLoopKF != 0: results go to mTcwGBA / mPosGBA, the map is left alone
     p3 = {k: (v.copy() if hasattr(v, 'copy') else v) for k, v in prob.items()}
     Optimizer.BundleAdjustment(p3, CAM, nIterations=n_iter, nLoopKF=17, bRobust=robust, lib=lib)
-    assert (p3['poses'] == prob['poses']).all() and (p3['poses_gba'] == p2['poses']).all() and p3['mnBAGlobalForKF'] == 17
+    assert (p3['poses'] == prob['poses']).all() and close(p3['poses_gba'], p2['poses']) and p3['mnBAGlobalForKF'] == 17     # two runs agree to rounding (the Schur complement is accumulated with fp64 atomics)
 
 
 def check_gba_robust_matters(oracle):
