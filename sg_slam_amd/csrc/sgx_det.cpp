@@ -2,7 +2,7 @@
 // (with conv+activation and Permute/Flatten/Concat fusion), batched forward, DetectionOutput + Detector2D::detect
 // post-processing, dynamic-feature mask.  Reference: src/sg-slam/src/Detector2D.cc:16-89, src/sg-slam/src/Frame.cc:556-604.
 #include "sgx_block.h"
-#include "sgx_det_kernels.h"
+#include "sgx_det_block.h"
 #include "sgx_prof.h"
 #include "../../include/sgx.h"
 #include <math.h>
@@ -28,13 +28,14 @@ struct Layer {
     float getf(int k, float d) const { auto it = p.find(k); return it == p.end() ? d : (float)it->second; }
 };
 struct Blob { int c = 0, h = 0, w = 0; size_t n = 0; float *d = nullptr; bool scalar = false; float sval = 0.f; int alias = -1; };
-enum OpKind { OP_PW, OP_KXK, OP_BINARY, OP_UNARY, OP_PERMUTE_INTO, OP_COPY_INTO, OP_SOFTMAX };
+enum OpKind { OP_PW, OP_KXK, OP_BINARY, OP_UNARY, OP_PERMUTE_INTO, OP_COPY_INTO, OP_SOFTMAX, OP_FUSED_BLOCK };
 struct EpiStep { int op, src; float a, b; int tensor; };
 struct Op {
     OpKind kind; int in0 = -1, in1 = -1, out = -1;
     std::vector<EpiStep> epi; int hwc = 0, hwc_off = 0; bool dead = false; std::string name;
     int inc = 0, outc = 0, H = 0, W = 0, Ho = 0, Wo = 0, k = 1, stride = 1, pad = 0, depthwise = 0, act = 0; float lo = 0, hi = 0;
     float *wt = nullptr, *bias = nullptr, *wtT = nullptr; int ldw = 0; int bop = 0; int off = 0; int rows = 0, C = 0;
+    SgxFusedBlk fb; int fb_res_blob = -1;      // OP_FUSED_BLOCK: expand -> depthwise -> project (+ residual) in one kernel (sgx_det_block.h)
 };
 }  // namespace
 
@@ -65,9 +66,11 @@ struct sgx_det {
 };
 
 static int g_det_fuse = 1;
+static int g_det_block_fusion = 0;       // test / tuning tap (read at sgx_det_create): fuse expand -> depthwise -> project triples into k_fused_block
 static int g_det_legacy = 0;             // test tap (read at sgx_det_create): run the simple reference kernels (k_conv_pw / k_conv_kxk) instead of the tuned ones
 extern "C" int sgx_det_debug_set_fusion(int on) { g_det_fuse = on ? 1 : 0; return SGX_OK; }
 extern "C" int sgx_det_debug_set_legacy_kernels(int on) { g_det_legacy = on ? 1 : 0; return SGX_OK; }
+extern "C" int sgx_det_debug_set_block_fusion(int on) { g_det_block_fusion = on ? 1 : 0; return SGX_OK; }
 
 static int parse_param(const char *text, std::vector<Layer> &layers)
 {
@@ -303,6 +306,61 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                 }
             }
         }
+        // ---- block fusion: pointwise expand (ReLU / Clip) -> depthwise (ReLU / Clip) -> pointwise project (nothing / + tensor) with no other reader of the two
+        // intermediates becomes one OP_FUSED_BLOCK (sgx_det_block.h): the expanded tensor never reaches HBM.  OPT-IN (SGX_DET_BLOCK_FUSION=1 or
+        // sgx_det_debug_set_block_fusion): bit-identical, but measured SLOWER than the three tuned kernels on MI355X at batch 256 (13.7 vs 10.9 ms per forward: 30-60 k small
+        // workgroups, each re-staging its weights and running five barrier-separated phases at 3 waves per SIMD) — see DESIGN.md §6.
+        if ((g_det_block_fusion || getenv("SGX_DET_BLOCK_FUSION")) && !g_det_legacy) {
+            auto act_only = [&](const Op &o, float *lo, float *hi) -> bool {
+                if (o.epi.size() != 1) return false;
+                const EpiStep &st = o.epi[0];
+                if (st.op == SGX_EOP_RELU) { *lo = 0.f; *hi = INFINITY; return true; }
+                if (st.op == SGX_EOP_CLIP) { *lo = st.a; *hi = st.b; return true; }
+                return false;
+            };
+            for (int ai = 0; ai < nops; ai++) {
+                Op &a = ops[ai];
+                if (a.dead || a.kind != OP_PW || a.hwc) continue;
+                float lo1, hi1, lo2, hi2;
+                if (!act_only(a, &lo1, &hi1)) continue;
+                readers(a.out, R); if (R.size() != 1) continue;
+                const int bi = R[0]; Op &bq = ops[bi];
+                if (bq.kind != OP_KXK || !bq.depthwise || (bq.k != 3 && bq.k != 5) || !act_only(bq, &lo2, &hi2)) continue;
+                readers(bq.out, R); if (R.size() != 1) continue;
+                const int ci = R[0]; Op &c = ops[ci];
+                if (c.kind != OP_PW || c.hwc || c.in0 != bq.out) continue;
+                int res = -1;
+                if (c.epi.size() == 1 && c.epi[0].op == SGX_EOP_ADD && c.epi[0].src == SGX_ESRC_TENSOR) res = c.epi[0].tensor;
+                else if (!c.epi.empty()) continue;
+                if ((a.inc & 1) || (a.outc & 1) || a.outc != bq.outc || c.inc != bq.outc || a.inc > 64 || c.outc > 64) continue;       // k_fused_block stages <= 2048 weights per array and chunk
+                if (a.out == h->loc_blob || a.out == h->conf_blob || bq.out == h->loc_blob || bq.out == h->conf_blob) continue;
+                // tile choice: least matrix-core work per output pixel among the tiles that fit the LDS budget and the accumulator registers
+                SgxFusedBlk fb; memset(&fb, 0, sizeof fb);
+                fb.Cin = a.inc; fb.Cmid = a.outc; fb.Cout = c.outc; fb.K = bq.k; fb.stride = bq.stride; fb.pad = bq.pad; fb.H = a.H; fb.W = a.W; fb.Ho = bq.Ho; fb.Wo = bq.Wo;
+                fb.lo1 = lo1; fb.hi1 = hi1; fb.lo2 = lo2; fb.hi2 = hi2;
+                const int ncb = (fb.Cout + 31) / 32, nch = (fb.Cmid + 31) / 32;
+                double best = 1e30; int bth = 0, btw = 0;
+                for (int th = 1; th <= 16; th++) for (int tw = 4; tw <= 40; tw++) {
+                    SgxFusedBlk t = fb; t.TOH = th; t.TOW = tw; t.TIH = (th - 1) * fb.stride + fb.K; t.TIW = (tw - 1) * fb.stride + fb.K;
+                    t.NPI = ((t.TIH * t.TIW + 31) / 32) * 32; t.NPO = ((th * tw + 31) / 32) * 32; t.CMR = std::min(32, fb.Cmid); t.ES = t.NPI + 4;
+                    if (ncb * (t.NPO / 32) > 8 || sgx_fb_lds_floats(t) * 4 > 52 * 1024 || fb.Cout * th * tw > 64 * 1024 || t.NPI >= (1 << 12) || th * tw >= (1 << 12)) continue;
+                    const int txn = (fb.Wo + tw - 1) / tw, tyn = (fb.Ho + th - 1) / th;
+                    // MFMAs per tile: expand NBI * Cin/2 per chunk, project NBO * ncb * 16 per chunk; VALU depthwise ~ K*K per output per channel (weighted); fixed per-tile cost
+                    const double cost = (double)txn * tyn * (nch * ((t.NPI / 32) * (fb.Cin / 2.0) + (t.NPO / 32) * ncb * 16.0) * 64.0 / 4.0 + (double)fb.Cmid * th * tw * fb.K * fb.K * 4.0 / 256.0 * 2.0 + 3000.0);
+                    if (cost < best) { best = cost; bth = th; btw = tw; }
+                }
+                if (!bth) continue;
+                fb.TOH = bth; fb.TOW = btw; fb.TIH = (bth - 1) * fb.stride + fb.K; fb.TIW = (btw - 1) * fb.stride + fb.K;
+                fb.NPI = ((fb.TIH * fb.TIW + 31) / 32) * 32; fb.NPO = ((bth * btw + 31) / 32) * 32; fb.CMR = std::min(32, fb.Cmid); fb.ES = fb.NPI + 4;
+                { auto magic = [](int d) -> unsigned { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
+                  fb.m_tiw = magic(fb.TIW); fb.m_tow = magic(btw); fb.m_npo = magic(bth * btw); fb.m_kk = magic(fb.K * fb.K); }
+                fb.tiles_x = (fb.Wo + btw - 1) / btw; fb.tiles_y = (fb.Ho + bth - 1) / bth; fb.dbg = getenv("SGX_FB_DBG") ? atoi(getenv("SGX_FB_DBG")) : 0;
+                fb.w1 = a.wt; fb.b1 = a.bias; fb.wd = bq.wt; fb.bd = bq.bias; fb.w2 = c.wt; fb.b2 = c.bias;
+                Op f; f.kind = OP_FUSED_BLOCK; f.in0 = a.in0; f.out = c.out; f.name = a.name + "+" + bq.name + "+" + c.name; f.fb = fb; f.fb_res_blob = res;
+                f.inc = a.inc; f.outc = c.outc; f.H = a.H; f.W = a.W; f.Ho = bq.Ho; f.Wo = bq.Wo; f.k = bq.k; f.stride = bq.stride;
+                ops[ci] = f; a.dead = true; bq.dead = true;           // the block takes the project convolution's place in the plan (its residual operand is older)
+            }
+        }
         std::vector<Op> live; for (const Op &o : ops) if (!o.dead) live.push_back(o);
         ops.swap(live);
     }
@@ -387,6 +445,12 @@ static void run_op(sgx_det *h, const Op &op, int batch, sgx_stream_t st)
         case 21: SGX_PW2(2, 1); break; case 12: SGX_PW2(1, 2); break; default: SGX_PW2(1, 1); break;
         }
 #undef SGX_PW2
+        break; }
+    case OP_FUSED_BLOCK: {
+        SgxFusedBlk fb = op.fb;
+        fb.in = A.d; fb.in_pitch = A.n; fb.out = O.d; fb.out_pitch = O.n;
+        fb.res = op.fb_res_blob >= 0 ? h->blobs[op.fb_res_blob].d : nullptr; fb.res_pitch = op.fb_res_blob >= 0 ? h->blobs[op.fb_res_blob].n : 0;
+        SGX_LAUNCH_DYN(k_fused_block, dim3((unsigned)(fb.tiles_x * fb.tiles_y * batch)), dim3(256), sgx_fb_lds_floats(fb) * 4, st, fb);
         break; }
     case OP_KXK: {
         const SgxEpi e = make_epi(h, op, (size_t)op.outc * op.Ho * op.Wo);
@@ -502,10 +566,13 @@ extern "C" int sgx_det_debug_op_desc(const sgx_det *h, int i, char *buf, int cap
     if (!h || !buf || cap < 16 || i < 0 || i > (int)h->ops.size()) return SGX_ERR_INVALID;
     if (i == 0) { snprintf(buf, cap, "preprocess %dx%d->%d", h->W, h->H, h->T); return SGX_OK; }
     const Op &o = h->ops[i - 1];
-    static const char *kn[] = { "pw", "kxk", "binary", "unary", "permute_into", "copy_into", "softmax" };
+    static const char *kn[] = { "pw", "kxk", "binary", "unary", "permute_into", "copy_into", "softmax", "block" };
     if (o.kind == OP_PW || o.kind == OP_KXK)
         snprintf(buf, cap, "%s %s c%d->%d k%d s%d %s%dx%d->%dx%d epi%d%s", kn[o.kind], o.name.c_str(), o.inc, o.outc, o.k, o.stride, o.depthwise ? "dw " : "", o.H, o.W,
                  o.kind == OP_PW ? o.H : o.Ho, o.kind == OP_PW ? o.W : o.Wo, (int)o.epi.size() + (o.act ? 1 : 0), o.hwc ? " hwc" : "");
+    else if (o.kind == OP_FUSED_BLOCK)
+        snprintf(buf, cap, "block %s c%d->%d->%d k%d s%d %dx%d->%dx%d tile %dx%d%s", o.name.c_str(), o.fb.Cin, o.fb.Cmid, o.fb.Cout, o.fb.K, o.fb.stride, o.H, o.W, o.Ho, o.Wo, o.fb.TOH, o.fb.TOW,
+                 o.fb_res_blob >= 0 ? " +res" : "");
     else snprintf(buf, cap, "%s %s n=%zu", kn[o.kind], o.name.c_str(), h->blobs[o.in0].n);
     return SGX_OK;
 }

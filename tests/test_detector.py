@@ -83,8 +83,10 @@ def run_fused_equals_unfused(lib, model):
     layers, W, blob = model
     imgs = np.stack([make_image(3), make_image(4)])
     outs = []
-    for fuse, legacy in ((False, True), (True, True), (True, False), (False, False)):
-        det = Detector2D(0.90, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=2, lib=lib, fuse=fuse, legacy_kernels=legacy)
+    for fuse, legacy, blocks in ((False, True, False), (True, True, False), (True, False, False), (False, False, False), (True, False, True)):
+        # the last plan additionally runs the six expand -> depthwise -> project triples as one k_fused_block each (opt-in: correct but slower at batch 256)
+        det = Detector2D(0.90, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=2, lib=lib, fuse=fuse, legacy_kernels=legacy, block_fusion=blocks)
+        assert det.num_kernels == (91 if blocks else 103 if fuse else 282)
         det.detect_batch(imgs)
         outs.append([np.stack([det.debug_blob(nm, b) for b in range(2)]) for nm in ('587', '632', '672', '849', '908', '944', 'mbox_loc', 'mbox_conf_softmax')])
         det.close()
