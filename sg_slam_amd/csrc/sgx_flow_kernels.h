@@ -365,6 +365,7 @@ SGX_KERNEL(256) k_lk_track(SgxLkGeom g, SgxLkArgs A)
                 }
             }
             const sgx_i16x2 c3 = { 3, 3 }, c10 = { 10, 10 };
+            const sgx_i16x2 Wd0 = active ? W0 : sgx_as_i16x2(0u), Wd1 = active ? W1 : sgx_as_i16x2(0u);
             sgx_i16x2 S0[5], S1[5], D0[5], D1[5];                  /* column sums (3,10,3) and differences (-1,0,1) for derivative rows gy0 and gy0+1 */
 #pragma unroll
             for (int q = 0; q < 5; q++) {
@@ -397,10 +398,9 @@ SGX_KERNEL(256) k_lk_track(SgxLkGeom g, SgxLkArgs A)
                 const sgx_i16x2 pya = (c & 1) ? sgx_lk_next(ya[c >> 1], ya[(c >> 1) + 1]) : ya[c >> 1], pyb = (c & 1) ? sgx_lk_next(yb[c >> 1], yb[(c >> 1) + 1]) : yb[c >> 1];
                 // image pair at columns (c+1, c+2) of the 10-column rows 1 and 2: odd-aligned for even c
                 const sgx_i16x2 pia = (c & 1) ? P[1][(c + 1) >> 1] : sgx_lk_next(P[1][c >> 1], P[1][(c >> 1) + 1]), pib = (c & 1) ? P[2][(c + 1) >> 1] : sgx_lk_next(P[2][c >> 1], P[2][(c >> 1) + 1]);
-                int v = SGX_LK_DOT2(pib, W1, SGX_LK_DOT2(pia, W0, 256)) >> 9;
-                int vx = SGX_LK_DOT2(pxb, W1, SGX_LK_DOT2(pxa, W0, 8192)) >> 14;
-                int vy = SGX_LK_DOT2(pyb, W1, SGX_LK_DOT2(pya, W0, 8192)) >> 14;
-                if (!active) { v = 0; vx = 0; vy = 0; }
+                const int v = SGX_LK_DOT2(pib, W1, SGX_LK_DOT2(pia, W0, 256)) >> 9;               /* the idle lane's intensity sample is never used: its ix = iy = 0 */
+                const int vx = SGX_LK_DOT2(pxb, Wd1, SGX_LK_DOT2(pxa, Wd0, 8192)) >> 14;          /* idle lane: zero weights -> (0 + 8192) >> 14 = 0 */
+                const int vy = SGX_LK_DOT2(pyb, Wd1, SGX_LK_DOT2(pya, Wd0, 8192)) >> 14;
                 ivb[c] = 256 - (v << 9); ix[c] = vx; iy[c] = vy;
                 s11 += sgx_mul24(vx, vx); s12 += sgx_mul24(vx, vy); s22 += sgx_mul24(vy, vy);
             }
@@ -697,13 +697,15 @@ SGX_KERNEL(256) k_fm_ransac(SgxFmArgs A)
         return;
     }
 
-    // ---- RANSACPointSetRegistrator::run, SGX_FM_CHUNK candidate groups per round
-    for (;;) {
+    // ---- RANSACPointSetRegistrator::run, up to SGX_FM_CHUNK candidate groups per round (the first round draws only 8: on mostly static scenes the adaptive
+    //      iteration count ends the loop after ~5-15 iterations, so scoring 32 x 3 models up front is wasted work)
+    for (int round = 0;; round++) {
+        const int G = round == 0 ? 8 : SGX_FM_CHUNK;
         SGX_THREADS_BEGIN(tid)
         if (tid == 0) {
             // cv::RNG::uniform(0, count) draws: seven distinct indices per group (getSubset's inner loops; the group is checked below)
             unsigned long long st = s_rng;
-            for (int gI = 0; gI < SGX_FM_CHUNK; gI++)
+            for (int gI = 0; gI < G; gI++)
                 for (int i = 0; i < 7; i++) {
                     int idx_i, j;
                     for (;;) {
@@ -719,7 +721,7 @@ SGX_KERNEL(256) k_fm_ransac(SgxFmArgs A)
         SGX_THREADS_END
         SGX_SYNC();
         SGX_THREADS_BEGIN(tid)
-        if (tid < SGX_FM_CHUNK) {
+        if (tid < G) {
             float a[14], b[14];
             for (int i = 0; i < 7; i++) { const int id = g_idx[tid][i]; a[2 * i] = m1[2 * id]; a[2 * i + 1] = m1[2 * id + 1]; b[2 * i] = m2[2 * id]; b[2 * i + 1] = m2[2 * id + 1]; }
             int nm = -1;
@@ -730,7 +732,7 @@ SGX_KERNEL(256) k_fm_ransac(SgxFmArgs A)
         SGX_THREADS_END
         SGX_SYNC();
         // ---- findInliers for every model of the round
-        for (int gI = 0; gI < SGX_FM_CHUNK; gI++) {
+        for (int gI = 0; gI < G; gI++) {
             const int nm = g_nmodels[gI];
             for (int k = 0; k < nm; k++) {
                 SGX_THREADS_BEGIN(tid)
@@ -748,7 +750,7 @@ SGX_KERNEL(256) k_fm_ransac(SgxFmArgs A)
         if (tid == 0) {
             int iter = s_iter, niters = s_niters, maxgood = s_maxgood, attempts = s_attempts;
             bool done = false;
-            for (int gI = 0; gI < SGX_FM_CHUNK && !done; gI++) {
+            for (int gI = 0; gI < G && !done; gI++) {
                 if (iter >= niters) { done = true; break; }
                 if (g_nmodels[gI] < 0) {                                       /* getSubset repeats the draw (`continue` of its attempt loop), 10000 attempts at most */
                     if (++attempts >= 10000) done = true;                      /* getSubset fails: `return false` at iter 0 (nothing found yet), `break` later */

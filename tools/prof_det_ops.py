@@ -7,13 +7,14 @@ sys.path.insert(0, ROOT)
 import torch
 import sg_slam_amd
 from sg_slam_amd.detector import Detector2D
-from oracle import detector_oracle as D          # only to synthesise the weight blob (the reference's .bin is absent)
+from sg_slam_amd import synth
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 PARAM = os.path.join(ROOT, 'tests', 'golden', 'mobilenetv3_ssdlite_voc.param')
 lib = sg_slam_amd.load()
-layers = D.parse_param(PARAM); W, blob = D.synth_weights(layers)
-det = Detector2D(0.9, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=B, lib=lib)
+layers = synth.parse_ncnn_param(PARAM); W, blob = synth.synth_ncnn_weights(layers)
+det = Detector2D(0.9, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=B, lib=lib, legacy_kernels=bool(int(os.environ.get('SGX_PROF_LEGACY', '0'))),
+                 block_fusion=bool(int(os.environ.get('SGX_PROF_BLOCKS', '0'))))
 img = torch.randint(0, 256, (B, 480, 640, 3), dtype=torch.uint8, device='cuda')
 REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 rows = det.time_ops(img, B, reps=REPS)
