@@ -153,6 +153,24 @@ int sgx_match_search_for_triangulation(
     int n2, const sgx_keypoint *keys2_un, const uint8_t *desc2, const float *uright2, const uint8_t *has_mp2, const int32_t *feat_node2, const float *Tcw2,
     const float *F12, const sgx_camera *cam2, const float *scale_factors2, const float *level_sigma2_2, int nlevels, int only_stereo, int check_orientation,
     int32_t *pairs, int32_t *npairs);
+/* int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches) (src/sg-slam/include/ORBmatcher.h:64, src/sg-slam/src/ORBmatcher.cc:159-290;
+ * callers Tracking::TrackReferenceKeyFrame Tracking.cc:806, Relocalization :1496): kf_good_mp[i] = the keyframe's keypoint i holds a map point that is not bad,
+ * feat_node_* = mFeatVec keys per keypoint (the vocabulary transform itself — DBoW2 + ORBvoc — stays with the caller).  match_f[j] = index of the keyframe keypoint whose
+ * map point the frame's keypoint j receives (vpMapPointMatches[j] = vpMapPointsKF[match_f[j]]), -1 = NULL; *nmatches = return value.  Host pointers, synchronous. */
+int sgx_match_search_by_bow(
+    int nk, const sgx_keypoint *keys_kf_un, const uint8_t *desc_kf, const uint8_t *kf_good_mp, const int32_t *feat_node_kf,
+    int nf, const sgx_keypoint *keys_f_un, const uint8_t *desc_f, const int32_t *feat_node_f, float nnratio, int check_orientation,
+    int32_t *match_f, int32_t *nmatches);
+/* The search of int ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, const float th = 3.0) (src/sg-slam/include/ORBmatcher.h:83,
+ * src/sg-slam/src/ORBmatcher.cc:829-979; caller LocalMapping::SearchInNeighbors, LocalMapping.cc:489,514): for every candidate map point i (m_skip[i] = NULL / isBad() /
+ * IsInKeyFrame(pKF); m_min_dist / m_max_dist = mfMinDistance / mfMaxDistance) the keyframe keypoint best_idx[i] it fuses with (-1: none within TH_LOW) and the Hamming
+ * distance best_dist[i].  *nfused = return value (number of best_idx >= 0).  The map mutations that follow in the reference (Replace / AddObservation / AddMapPoint,
+ * :950-969) are applied by the caller in index order: they do not influence the search.  Host pointers, synchronous. */
+int sgx_match_fuse_search(
+    int nk, const sgx_keypoint *keys_un, const uint8_t *desc, const float *uright, const float *Tcw,
+    int nm, const float *m_xw, const float *m_normal, const float *m_min_dist, const float *m_max_dist, const uint8_t *m_desc, const uint8_t *m_skip,
+    const sgx_camera *cam, const float *scale_factors, const float *inv_level_sigma2, int nlevels, float log_scale_factor, float th,
+    int32_t *best_idx, int32_t *best_dist, int32_t *nfused);
 
 /* Harness helper (bench.py / tests), NOT a reference entry point: the previous-frame position of every keypoint under a per-frame affine flow
  * (prev = A * (x, y, 1), A = 6 floats), optionally displaced by shift[2] inside the frame's first box.  Stands in for cv::calcOpticalFlowPyrLK

@@ -408,3 +408,114 @@ int orc_search_for_triangulation(int n1, const orc_keypoint *k1, const uint8_t *
     free(matched2); free(m12); free(u1);
     return nmatches;
 }
+
+
+/* ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches), ORBmatcher.cc:159-290.  kf_good_mp[i] = the keyframe's keypoint i holds a map
+ * point that is not bad; node_* = FeatureVector key per keypoint (-1 = none).  match_f[j] (out) = index of the keyframe keypoint whose map point keypoint j of the
+ * frame receives, or -1.  Returns nmatches. */
+int orc_search_by_bow(int nk, const orc_keypoint *kk, const uint8_t *dk, const uint8_t *kf_good_mp, const int *node_k,
+                      int nf, const orc_keypoint *kf, const uint8_t *df, const int *node_f, float nnratio, int check_ori, int *match_f)
+{
+    int nmatches = 0;
+    for (int j = 0; j < nf; j++) match_f[j] = -1;
+    int *hist[HISTO_LENGTH], hn[HISTO_LENGTH], hc[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) { hist[i] = NULL; hn[i] = hc[i] = 0; }
+    const float factor = HISTO_LENGTH / 360.0f;
+    int *u1 = (int *)malloc(sizeof(int) * (nk > 0 ? nk : 1)), nu1 = 0;
+    for (int i = 0; i < nk; i++) if (node_k[i] >= 0) u1[nu1++] = node_k[i];
+    qsort(u1, nu1, sizeof(int), cmp_int);
+    for (int q = 0; q < nu1; q++) {
+        if (q > 0 && u1[q] == u1[q - 1]) continue;
+        const int nid = u1[q];
+        for (int ik = 0; ik < nk; ik++) {
+            if (node_k[ik] != nid || !kf_good_mp[ik]) continue;
+            int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+            for (int jf = 0; jf < nf; jf++) {
+                if (node_f[jf] != nid || match_f[jf] >= 0) continue;
+                const int dist = orc_descriptor_distance(dk + 32 * (size_t)ik, df + 32 * (size_t)jf);
+                if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = jf; }
+                else if (dist < bestDist2) bestDist2 = dist;
+            }
+            if (bestDist1 <= TH_LOW && (float)bestDist1 < nnratio * (float)bestDist2) {
+                match_f[bestIdxF] = ik;
+                if (check_ori) {
+                    float rot = kk[ik].angle - kf[bestIdxF].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)round(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    if (hn[bin] == hc[bin]) { hc[bin] = hc[bin] ? 2 * hc[bin] : 64; hist[bin] = (int *)realloc(hist[bin], sizeof(int) * hc[bin]); }
+                    hist[bin][hn[bin]++] = bestIdxF;
+                }
+                nmatches++;
+            }
+        }
+    }
+    if (check_ori) {
+        int i1, i2, i3; three_maxima(hn, HISTO_LENGTH, &i1, &i2, &i3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == i1 || i == i2 || i == i3) continue;
+            for (int j = 0; j < hn[i]; j++) { match_f[hist[i][j]] = -1; nmatches--; }
+        }
+    }
+    for (int i = 0; i < HISTO_LENGTH; i++) free(hist[i]);
+    free(u1);
+    return nmatches;
+}
+
+/* The search of ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, const float th), ORBmatcher.cc:829-979: for every candidate map point the keyframe
+ * keypoint it would be fused with (best_idx, -1 = none within TH_LOW) and its descriptor distance.  m_skip[i] = !pMP || isBad() || IsInKeyFrame(pKF).  The map mutations
+ * that follow (Replace / AddObservation / AddMapPoint, :950-969) stay with the caller; nFused = number of best_idx >= 0. */
+int orc_fuse_search(int Nk, const orc_keypoint *keys, const uint8_t *desc, const float *uright, const float *Tcw,
+                    int Nm, const float *m_xw, const float *m_normal, const float *m_min_dist, const float *m_max_dist, const uint8_t *m_desc, const uint8_t *m_skip,
+                    float fx, float fy, float cx, float cy, float bf, float minX, float maxX, float minY, float maxY,
+                    const float *scale_factors, const float *inv_level_sigma2, int nlevels, float log_scale_factor, float th, int *best_idx, int *best_dist)
+{
+    grid_t *g = (grid_t *)malloc(sizeof(grid_t));
+    grid_build(g, Nk, keys, minX, maxX, minY, maxY);
+    int *cand = (int *)malloc(sizeof(int) * (Nk > 0 ? Nk : 1));
+    float Rcw[3][3], tcw[3], Ow[3];
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Rcw[r][c] = Tcw[4 * r + c]; tcw[r] = Tcw[4 * r + 3]; }
+    for (int r = 0; r < 3; r++) Ow[r] = -(Rcw[0][r] * tcw[0] + Rcw[1][r] * tcw[1] + Rcw[2][r] * tcw[2]);       /* GetCameraCenter: -Rcw^T tcw (cv::Mat product) */
+    int nFused = 0;
+    for (int i = 0; i < Nm; i++) {
+        best_idx[i] = -1; best_dist[i] = 256;
+        if (m_skip[i]) continue;
+        const float *P = m_xw + 3 * i;
+        const float pcx = gemm3(Rcw[0], P, 1.0, 1.0, tcw[0]), pcy = gemm3(Rcw[1], P, 1.0, 1.0, tcw[1]), pcz = gemm3(Rcw[2], P, 1.0, 1.0, tcw[2]);
+        if (pcz < 0.0f) continue;
+        const float invz = 1 / pcz, x = pcx * invz, y = pcy * invz;
+        const float u = fx * x + cx, v = fy * y + cy;
+        if (!(u >= minX && u < maxX && v >= minY && v < maxY)) continue;                      /* KeyFrame::IsInImage */
+        const float ur = u - bf * invz;
+        const float maxDistance = 1.2f * m_max_dist[i], minDistance = 0.8f * m_min_dist[i];
+        const float po0 = P[0] - Ow[0], po1 = P[1] - Ow[1], po2 = P[2] - Ow[2];
+        const float dist3D = (float)sqrt((double)po0 * po0 + (double)po1 * po1 + (double)po2 * po2);
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        const double dot = (double)po0 * m_normal[3 * i] + (double)po1 * m_normal[3 * i + 1] + (double)po2 * m_normal[3 * i + 2];
+        if (dot < 0.5 * dist3D) continue;
+        int lvl = (int)ceilf(logf(m_max_dist[i] / dist3D) / log_scale_factor);
+        if (lvl < 0) lvl = 0; else if (lvl >= nlevels) lvl = nlevels - 1;
+        const float radius = th * scale_factors[lvl];
+        const int nc = features_in_area(g, keys, u, v, radius, -1, -1, cand);
+        int bestDist = 256, bestIdx = -1;
+        for (int q = 0; q < nc; q++) {
+            const int idx = cand[q]; const orc_keypoint *kp = &keys[idx];
+            const int kpLevel = kp->octave;
+            if (kpLevel < lvl - 1 || kpLevel > lvl) continue;
+            if (uright[idx] >= 0) {
+                const float ex = u - kp->x, ey = v - kp->y, er = ur - uright[idx];
+                const float e2 = ex * ex + ey * ey + er * er;
+                if (e2 * inv_level_sigma2[kpLevel] > 7.8) continue;
+            } else {
+                const float ex = u - kp->x, ey = v - kp->y;
+                const float e2 = ex * ex + ey * ey;
+                if (e2 * inv_level_sigma2[kpLevel] > 5.99) continue;
+            }
+            const int dist = orc_descriptor_distance(m_desc + 32 * (size_t)i, desc + 32 * (size_t)idx);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestDist <= TH_LOW) { best_idx[i] = bestIdx; best_dist[i] = bestDist; nFused++; }
+    }
+    grid_free(g); free(g); free(cand);
+    return nFused;
+}

@@ -343,3 +343,26 @@ def search_for_triangulation(kf1, kf2, F12, only_stereo, cam2, scale2, sigma2_2,
                                        _p(F), C.c_float(cam2['fx']), C.c_float(cam2['fy']), C.c_float(cam2['cx']), C.c_float(cam2['cy']), _p(sf), _p(sg),
                                        C.c_int(int(bool(only_stereo))), C.c_int(int(bool(check_ori))), _p(pairs))
     return int(n), pairs[:n].copy()
+
+
+def search_by_bow(kf, F, nnratio=0.7, check_ori=True):
+    kk = np.ascontiguousarray(kf['keys']); dk = np.ascontiguousarray(kf['desc'], np.uint8); gk = np.ascontiguousarray(kf['good_mp'], np.uint8); nk = np.ascontiguousarray(kf['feat_node'], 'i4')
+    kq = np.ascontiguousarray(F['keys']); dq = np.ascontiguousarray(F['desc'], np.uint8); nq = np.ascontiguousarray(F['feat_node'], 'i4')
+    match = np.full(max(len(kq), 1), -1, 'i4')
+    L = lib(); L.orc_search_by_bow.restype = C.c_int
+    n = L.orc_search_by_bow(C.c_int(len(kk)), _p(kk), _p(dk), _p(gk), _p(nk), C.c_int(len(kq)), _p(kq), _p(dq), _p(nq), C.c_float(nnratio), C.c_int(int(bool(check_ori))), _p(match))
+    return int(n), match[:len(kq)].copy()
+
+
+def fuse_search(kf, m, cam, scale_factors, inv_level_sigma2, th=3.0):
+    k = np.ascontiguousarray(kf['keys']); d = np.ascontiguousarray(kf['desc'], np.uint8); u = np.ascontiguousarray(kf['uright'], 'f4'); T = np.ascontiguousarray(kf['Tcw'], 'f4').reshape(16)
+    xw = np.ascontiguousarray(m['xw'], 'f4'); nr = np.ascontiguousarray(m['normal'], 'f4'); mn = np.ascontiguousarray(m['min_dist'], 'f4'); mx = np.ascontiguousarray(m['max_dist'], 'f4')
+    md = np.ascontiguousarray(m['desc'], np.uint8); sk = np.ascontiguousarray(m['skip'], np.uint8)
+    sf = np.ascontiguousarray(scale_factors, 'f4'); is2 = np.ascontiguousarray(inv_level_sigma2, 'f4')
+    bi = np.full(max(len(xw), 1), -1, 'i4'); bd = np.full(max(len(xw), 1), 256, 'i4')
+    L = lib(); L.orc_fuse_search.restype = C.c_int
+    n = L.orc_fuse_search(C.c_int(len(k)), _p(k), _p(d), _p(u), _p(T), C.c_int(len(xw)), _p(xw), _p(nr), _p(mn), _p(mx), _p(md), _p(sk),
+                          C.c_float(cam['fx']), C.c_float(cam['fy']), C.c_float(cam['cx']), C.c_float(cam['cy']), C.c_float(cam['bf']),
+                          C.c_float(cam.get('min_x', 0.0)), C.c_float(cam.get('max_x', 640.0)), C.c_float(cam.get('min_y', 0.0)), C.c_float(cam.get('max_y', 480.0)),
+                          _p(sf), _p(is2), C.c_int(len(sf)), C.c_float(np.log(np.float32(sf[1]))), C.c_float(th), _p(bi), _p(bd))
+    return int(n), bi[:len(xw)].copy(), bd[:len(xw)].copy()

@@ -94,3 +94,86 @@ extern "C" int sgx_match_search_for_triangulation(
     *npairs = n;
     return SGX_OK;
 }
+
+extern "C" int sgx_match_search_by_bow(
+    int nk, const sgx_keypoint *keys_kf_un, const uint8_t *desc_kf, const uint8_t *kf_good_mp, const int32_t *feat_node_kf,
+    int nf, const sgx_keypoint *keys_f_un, const uint8_t *desc_f, const int32_t *feat_node_f, float nnratio, int check_orientation,
+    int32_t *match_f, int32_t *nmatches)
+{
+    if (nk < 0 || nf < 0 || !nmatches || (nf > 0 && !match_f)) return SGX_ERR_INVALID;
+    *nmatches = 0;
+    for (int j = 0; j < nf; j++) match_f[j] = -1;
+    if (nk == 0 || nf == 0) return SGX_OK;
+    if (!keys_kf_un || !desc_kf || !kf_good_mp || !feat_node_kf || !keys_f_un || !desc_f || !feat_node_f) return SGX_ERR_INVALID;
+    std::vector<int> it1, id1, st1, it2, id2, st2, job;
+    group_by_node(feat_node_kf, nk, it1, id1, st1); group_by_node(feat_node_f, nf, it2, id2, st2);
+    for (size_t a = 0, b = 0; a < id1.size() && b < id2.size();) {
+        if (id1[a] == id2[b]) { job.push_back(st1[a]); job.push_back(st1[a + 1]); job.push_back(st2[b]); job.push_back(st2[b + 1]); a++; b++; }
+        else if (id1[a] < id2[b]) a++; else b++;
+    }
+    SgxBowArgs A; memset(&A, 0, sizeof A);
+    A.nk = nk; A.nf = nf; A.nnodes = (int)(job.size() / 4); A.nnratio = nnratio; A.check_ori = check_orientation;
+    SgxStaged b[12]; int rc; const int dummy = 0;
+#define PUT(k, src, bytes) if ((rc = b[k].put(k, src, bytes)) != SGX_OK) return rc
+    PUT(0, keys_kf_un, (size_t)nk * 28); PUT(1, desc_kf, (size_t)nk * 32); PUT(2, kf_good_mp, (size_t)nk);
+    PUT(3, keys_f_un, (size_t)nf * 28); PUT(4, desc_f, (size_t)nf * 32);
+    PUT(5, it1.empty() ? &dummy : it1.data(), it1.empty() ? 4 : it1.size() * 4); PUT(6, it2.empty() ? &dummy : it2.data(), it2.empty() ? 4 : it2.size() * 4);
+    PUT(7, job.empty() ? &dummy : job.data(), job.empty() ? 4 : job.size() * 4);
+    PUT(8, nullptr, (size_t)nf * 4); PUT(9, nullptr, 4);
+#undef PUT
+    A.keys_k = (const uint8_t *)b[0].p; A.desc_k = (const uint32_t *)b[1].p; A.good_k = (const uint8_t *)b[2].p;
+    A.keys_f = (const uint8_t *)b[3].p; A.desc_f = (const uint32_t *)b[4].p;
+    A.items_k = (const int *)b[5].p; A.items_f = (const int *)b[6].p; A.job = (const int *)b[7].p; A.match_f = (int *)b[8].p; A.nmatches = (int *)b[9].p;
+    SGX_LAUNCH(k_search_bow, dim3(1), dim3(256), (sgx_stream_t)0, A);
+    SGX_CHECK_HIP(hipGetLastError());
+    SGX_CHECK_HIP(hipMemcpy(match_f, A.match_f, (size_t)nf * 4, hipMemcpyDeviceToHost));
+    SGX_CHECK_HIP(hipMemcpy(nmatches, A.nmatches, 4, hipMemcpyDeviceToHost));
+    return SGX_OK;
+}
+
+extern "C" int sgx_match_fuse_search(
+    int nk, const sgx_keypoint *keys_un, const uint8_t *desc, const float *uright, const float *Tcw,
+    int nm, const float *m_xw, const float *m_normal, const float *m_min_dist, const float *m_max_dist, const uint8_t *m_desc, const uint8_t *m_skip,
+    const sgx_camera *cam, const float *scale_factors, const float *inv_level_sigma2, int nlevels, float log_scale_factor, float th,
+    int32_t *best_idx, int32_t *best_dist, int32_t *nfused)
+{
+    if (nk < 0 || nm < 0 || !cam || !Tcw || !scale_factors || !inv_level_sigma2 || nlevels < 1 || nlevels > 12 || !nfused || (nm > 0 && (!best_idx || !best_dist))) return SGX_ERR_INVALID;
+    *nfused = 0;
+    for (int i = 0; i < nm; i++) { best_idx[i] = -1; best_dist[i] = 256; }
+    if (nk == 0 || nm == 0) return SGX_OK;
+    if (!keys_un || !desc || !uright || !m_xw || !m_normal || !m_min_dist || !m_max_dist || !m_desc || !m_skip) return SGX_ERR_INVALID;
+    // the keyframe's mGrid (Frame::AssignFeaturesToGrid / PosInGrid: round(), Frame.cc:257-272, :409-419) as CSR, cell (ix, iy) -> ix * 48 + iy, insertion (index) order inside a cell
+    const float invW = 64.0f / (cam->max_x - cam->min_x), invH = 48.0f / (cam->max_y - cam->min_y);
+    std::vector<int> cell((size_t)nk, -1), start(64 * 48 + 1, 0), items;
+    for (int i = 0; i < nk; i++) {
+        const int px = (int)round((keys_un[i].x - cam->min_x) * invW), py = (int)round((keys_un[i].y - cam->min_y) * invH);
+        if (px < 0 || px >= 64 || py < 0 || py >= 48) continue;
+        cell[(size_t)i] = px * 48 + py; start[(size_t)cell[(size_t)i] + 1]++;
+    }
+    for (int c = 0; c < 64 * 48; c++) start[(size_t)c + 1] += start[(size_t)c];
+    items.resize((size_t)start[64 * 48] > 0 ? (size_t)start[64 * 48] : 1);
+    { std::vector<int> fill(64 * 48, 0); for (int i = 0; i < nk; i++) if (cell[(size_t)i] >= 0) items[(size_t)start[(size_t)cell[(size_t)i]] + fill[(size_t)cell[(size_t)i]]++] = i; }
+    SgxFuseArgs A; memset(&A, 0, sizeof A);
+    A.nk = nk; A.nm = nm; A.nlevels = nlevels; A.log_scale_factor = log_scale_factor; A.th = th;
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) A.Rcw[r][c] = Tcw[4 * r + c]; A.tcw[r] = Tcw[4 * r + 3]; }
+    for (int r = 0; r < 3; r++) A.Ow[r] = -(A.Rcw[0][r] * A.tcw[0] + A.Rcw[1][r] * A.tcw[1] + A.Rcw[2][r] * A.tcw[2]);
+    A.cam.fx = cam->fx; A.cam.fy = cam->fy; A.cam.cx = cam->cx; A.cam.cy = cam->cy; A.cam.bf = cam->bf; A.cam.minX = cam->min_x; A.cam.maxX = cam->max_x; A.cam.minY = cam->min_y; A.cam.maxY = cam->max_y;
+    for (int i = 0; i < nlevels; i++) { A.scale.s[i] = scale_factors[i]; A.inv_sigma2.s[i] = inv_level_sigma2[i]; }
+    SgxStaged b[14]; int rc;
+#define PUT(k, src, bytes) if ((rc = b[k].put(k, src, bytes)) != SGX_OK) return rc
+    PUT(0, keys_un, (size_t)nk * 28); PUT(1, desc, (size_t)nk * 32); PUT(2, uright, (size_t)nk * 4);
+    PUT(3, start.data(), start.size() * 4); PUT(4, items.data(), items.size() * 4);
+    PUT(5, m_xw, (size_t)nm * 12); PUT(6, m_normal, (size_t)nm * 12); PUT(7, m_min_dist, (size_t)nm * 4); PUT(8, m_max_dist, (size_t)nm * 4); PUT(9, m_desc, (size_t)nm * 32); PUT(10, m_skip, (size_t)nm);
+    PUT(11, nullptr, (size_t)nm * 4); PUT(12, nullptr, (size_t)nm * 4);
+#undef PUT
+    A.keys = (const uint8_t *)b[0].p; A.desc = (const uint32_t *)b[1].p; A.uright = (const float *)b[2].p; A.cell_start = (const int *)b[3].p; A.cell_items = (const int *)b[4].p;
+    A.m_xw = (const float *)b[5].p; A.m_normal = (const float *)b[6].p; A.m_min_dist = (const float *)b[7].p; A.m_max_dist = (const float *)b[8].p;
+    A.m_desc = (const uint32_t *)b[9].p; A.m_skip = (const uint8_t *)b[10].p; A.best_idx = (int *)b[11].p; A.best_dist = (int *)b[12].p;
+    SGX_LAUNCH(k_fuse_search, dim3((nm + 255) / 256), dim3(256), (sgx_stream_t)0, A);
+    SGX_CHECK_HIP(hipGetLastError());
+    SGX_CHECK_HIP(hipMemcpy(best_idx, A.best_idx, (size_t)nm * 4, hipMemcpyDeviceToHost));
+    SGX_CHECK_HIP(hipMemcpy(best_dist, A.best_dist, (size_t)nm * 4, hipMemcpyDeviceToHost));
+    int n = 0; for (int i = 0; i < nm; i++) n += best_idx[i] >= 0;
+    *nfused = n;
+    return SGX_OK;
+}

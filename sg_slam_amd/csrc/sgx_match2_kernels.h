@@ -139,3 +139,164 @@ SGX_KERNEL(256) k_search_triangulation(SgxTriArgs A)
     if (tid == 0) A.nmatches[0] = s_total - s_rejected;
     SGX_THREADS_END
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// k_search_bow: ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vpMapPointMatches)   src/sg-slam/src/ORBmatcher.cc:159-290.  Same node-by-node walk as
+// SearchForTriangulation: inside a common vocabulary node every keyframe keypoint that holds a good map point (index order) takes the closest still-free frame
+// keypoint of the node when it passes TH_LOW and the nearest-neighbour ratio; one thread per node, rotation histogram by the workgroup.
+// ---------------------------------------------------------------------------------------------
+struct SgxBowArgs {
+    int nk, nf, nnodes;
+    const uint8_t *keys_k, *keys_f; const uint32_t *desc_k, *desc_f; const uint8_t *good_k;
+    const int *items_k, *items_f, *job;
+    float nnratio; int check_ori;
+    int *match_f; int *nmatches;
+};
+SGX_KERNEL(256) k_search_bow(SgxBowArgs A)
+{
+    SGX_LDS int hist[SGX_HISTO], bad[SGX_HISTO];
+    SGX_LDS int s_total, s_rejected;
+    SGX_THREADS_BEGIN(tid)
+    for (int i = tid; i < A.nf; i += 256) A.match_f[i] = -1;
+    for (int i = tid; i < SGX_HISTO; i += 256) { hist[i] = 0; bad[i] = 0; }
+    if (tid == 0) { s_total = 0; s_rejected = 0; }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    for (int nd = tid; nd < A.nnodes; nd += 256) {
+        const int s1 = A.job[4 * nd], e1 = A.job[4 * nd + 1], s2 = A.job[4 * nd + 2], e2 = A.job[4 * nd + 3];
+        for (int q1 = s1; q1 < e1; q1++) {
+            const int ik = A.items_k[q1];
+            if (!A.good_k[ik]) continue;                                          // :195-199
+            const uint32_t *d1 = A.desc_k + (size_t)ik * 8;
+            int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+            for (int q2 = s2; q2 < e2; q2++) {
+                const int jf = A.items_f[q2];
+                if (A.match_f[jf] >= 0) continue;                                  // :212
+                const int dist = sgx_hamming256(d1, A.desc_f + (size_t)jf * 8);
+                if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = jf; }
+                else if (dist < bestDist2) bestDist2 = dist;
+            }
+            if (bestDist1 <= SGX_TH_LOW && (float)bestDist1 < A.nnratio * (float)bestDist2) {
+                A.match_f[bestIdxF] = ik;
+                sgx_atomic_add(&s_total, 1);
+                if (A.check_ori) {
+                    const float ka = ((const float *)(A.keys_k + (size_t)ik * 28))[3], fa = ((const float *)(A.keys_f + (size_t)bestIdxF * 28))[3];
+                    float rot = ka - fa;
+                    if (rot < 0.0f) rot += 360.0f;
+                    int bin = (int)round((double)(rot * (SGX_HISTO / 360.0f)));
+                    if (bin == SGX_HISTO) bin = 0;
+                    sgx_atomic_add(&hist[bin], 1);
+                }
+            }
+        }
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+    if (A.check_ori) {
+        SGX_THREADS_BEGIN(tid)
+        if (tid == 0) {                         // ComputeThreeMaxima, ORBmatcher.cc:1603-1644
+            int m1 = 0, m2 = 0, m3 = 0, i1 = -1, i2 = -1, i3 = -1;
+            for (int i = 0; i < SGX_HISTO; i++) {
+                const int s = hist[i];
+                if (s > m1) { m3 = m2; m2 = m1; m1 = s; i3 = i2; i2 = i1; i1 = i; }
+                else if (s > m2) { m3 = m2; m2 = s; i3 = i2; i2 = i; }
+                else if (s > m3) { m3 = s; i3 = i; }
+            }
+            if ((float)m2 < 0.1f * (float)m1) { i2 = -1; i3 = -1; }
+            else if ((float)m3 < 0.1f * (float)m1) { i3 = -1; }
+            for (int i = 0; i < SGX_HISTO; i++) bad[i] = (i != i1 && i != i2 && i != i3);
+        }
+        SGX_THREADS_END
+        SGX_SYNC();
+        SGX_THREADS_BEGIN(tid)
+        for (int j = tid; j < A.nf; j += 256) {
+            const int ik = A.match_f[j];
+            if (ik < 0) continue;
+            const float ka = ((const float *)(A.keys_k + (size_t)ik * 28))[3], fa = ((const float *)(A.keys_f + (size_t)j * 28))[3];
+            float rot = ka - fa;
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)round((double)(rot * (SGX_HISTO / 360.0f)));
+            if (bin == SGX_HISTO) bin = 0;
+            if (bad[bin]) { A.match_f[j] = -1; sgx_atomic_add(&s_rejected, 1); }
+        }
+        SGX_THREADS_END
+        SGX_SYNC();
+    }
+    SGX_THREADS_BEGIN(tid)
+    if (tid == 0) A.nmatches[0] = s_total - s_rejected;
+    SGX_THREADS_END
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_fuse_search: the search of ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, const float th)   src/sg-slam/src/ORBmatcher.cc:829-979
+// One thread per candidate map point: projection + gates (:855-897), KeyFrame::GetFeaturesInArea over the keyframe's 64 x 48 grid in the reference's scan order
+// (KeyFrame.cc:570-609), level / chi2 gates (:909-941), best Hamming distance with first-wins ties (:947-951).  No locks: candidates do not depend on earlier fusions.
+// ---------------------------------------------------------------------------------------------
+struct SgxFuseArgs {
+    int nk, nm, nlevels;
+    const uint8_t *keys; const uint32_t *desc; const float *uright;
+    const int *cell_start, *cell_items;                 // CSR of the keyframe grid: cell (ix, iy) -> ix * 48 + iy
+    const float *m_xw, *m_normal, *m_min_dist, *m_max_dist; const uint32_t *m_desc; const uint8_t *m_skip;
+    float Rcw[3][3], tcw[3], Ow[3];
+    SgxCam cam; SgxScales scale, inv_sigma2; float log_scale_factor, th;
+    int *best_idx, *best_dist;
+};
+SGX_KERNEL(256) k_fuse_search(SgxFuseArgs A)
+{
+    SGX_THREADS_BEGIN(tid)
+    const int i = (int)blockIdx.x * 256 + tid;
+    if (i < A.nm) {
+        int bestDist = 256, bestIdx = -1;
+        const float *P = A.m_xw + 3 * (size_t)i;
+        bool ok = !A.m_skip[i];
+        const float pcx = sgx_gemm3(A.Rcw[0], P, A.tcw[0]), pcy = sgx_gemm3(A.Rcw[1], P, A.tcw[1]), pcz = sgx_gemm3(A.Rcw[2], P, A.tcw[2]);
+        ok = ok && !(pcz < 0.0f);
+        const float invz = 1 / pcz, x = pcx * invz, y = pcy * invz;
+        const float u = A.cam.fx * x + A.cam.cx, v = A.cam.fy * y + A.cam.cy;
+        ok = ok && (u >= A.cam.minX && u < A.cam.maxX && v >= A.cam.minY && v < A.cam.maxY);
+        const float ur = u - A.cam.bf * invz;
+        const float maxDistance = 1.2f * A.m_max_dist[i], minDistance = 0.8f * A.m_min_dist[i];
+        const float po0 = P[0] - A.Ow[0], po1 = P[1] - A.Ow[1], po2 = P[2] - A.Ow[2];
+        const float dist3D = (float)sqrt((double)po0 * po0 + (double)po1 * po1 + (double)po2 * po2);
+        ok = ok && !(dist3D < minDistance || dist3D > maxDistance);
+        const double dot = (double)po0 * A.m_normal[3 * (size_t)i] + (double)po1 * A.m_normal[3 * (size_t)i + 1] + (double)po2 * A.m_normal[3 * (size_t)i + 2];
+        ok = ok && !(dot < 0.5 * (double)dist3D);
+        if (ok) {
+            int lvl = (int)ceilf((float)log((double)(A.m_max_dist[i] / dist3D)) / A.log_scale_factor);       // MapPoint::PredictScale(dist, pKF), logf in the reference
+            if (lvl < 0) lvl = 0; else if (lvl >= A.nlevels) lvl = A.nlevels - 1;
+            const float r = A.th * A.scale.s[lvl];
+            const float invW = 64.0f / (A.cam.maxX - A.cam.minX), invH = 48.0f / (A.cam.maxY - A.cam.minY);
+            int x0 = (int)floorf((u - A.cam.minX - r) * invW), x1 = (int)ceilf((u - A.cam.minX + r) * invW);
+            int y0 = (int)floorf((v - A.cam.minY - r) * invH), y1 = (int)ceilf((v - A.cam.minY + r) * invH);
+            x0 = max(x0, 0); y0 = max(y0, 0); x1 = min(x1, 63); y1 = min(y1, 47);
+            const uint32_t *dm = A.m_desc + (size_t)i * 8;
+            if (x0 < 64 && y0 < 48)
+                for (int ix = x0; ix <= x1; ix++) for (int iy = y0; iy <= y1; iy++) {
+                    const int c = ix * 48 + iy;
+                    for (int q = A.cell_start[c]; q < A.cell_start[c + 1]; q++) {
+                        const int idx = A.cell_items[q];
+                        const float *kp = (const float *)(A.keys + (size_t)idx * 28);
+                        if (!(fabsf(kp[0] - u) < r && fabsf(kp[1] - v) < r)) continue;
+                        const int kpLevel = ((const int *)kp)[5];
+                        if (kpLevel < lvl - 1 || kpLevel > lvl) continue;
+                        const float ex = u - kp[0], ey = v - kp[1];
+                        if (A.uright[idx] >= 0) {
+                            const float er = ur - A.uright[idx];
+                            const float e2 = ex * ex + ey * ey + er * er;
+                            if ((double)(e2 * A.inv_sigma2.s[kpLevel]) > 7.8) continue;
+                        } else {
+                            const float e2 = ex * ex + ey * ey;
+                            if ((double)(e2 * A.inv_sigma2.s[kpLevel]) > 5.99) continue;
+                        }
+                        const int dist = sgx_hamming256(dm, A.desc + (size_t)idx * 8);
+                        if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+                    }
+                }
+        }
+        const bool fused = bestDist <= SGX_TH_LOW;
+        A.best_idx[i] = fused ? bestIdx : -1; A.best_dist[i] = fused ? bestDist : 256;
+    }
+    SGX_THREADS_END
+}

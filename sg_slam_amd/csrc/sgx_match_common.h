@@ -18,3 +18,9 @@ SGX_DEV int sgx_hamming256(const uint32_t *a, const uint32_t *b)
     return d;
 }
 
+// cv::gemm small-matrix path for 3x3 * 3x1 (+ c): float dot left-to-right, then (float)(t*alpha + beta*c) in double
+SGX_DEV float sgx_gemm3(const float *arow, const float *b, float c)
+{
+    const float t = arow[0] * b[0] + arow[1] * b[1] + arow[2] * b[2];
+    return (float)((double)t * 1.0 + 1.0 * (double)c);
+}

@@ -93,3 +93,27 @@ class ORBmatcher:
                                                                        _vp(n2), _vp(T2), _vp(F), C.byref(cs), _vp(sf), _vp(sg), len(sf), int(bool(bOnlyStereo)),
                                                                        int(self.mbCheckOrientation), _vp(pairs), _vp(n)), 'sgx_match_search_for_triangulation')
         return int(n[0]), pairs[:n[0]].copy()
+
+    def SearchByBoW(self, kf, F):
+        """ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches) (ORBmatcher.cc:159-290).  kf: keys (mvKeysUn), desc, good_mp, feat_node; F: keys, desc, feat_node.
+        Returns (nmatches, match_f[nf]): match_f[j] = keyframe keypoint whose map point frame keypoint j gets, or -1."""
+        kk = np.ascontiguousarray(kf['keys']); dk = np.ascontiguousarray(kf['desc'], np.uint8); gk = np.ascontiguousarray(kf['good_mp'], np.uint8); nk = np.ascontiguousarray(kf['feat_node'], 'i4')
+        kq = np.ascontiguousarray(F['keys']); dq = np.ascontiguousarray(F['desc'], np.uint8); nq = np.ascontiguousarray(F['feat_node'], 'i4')
+        match = np.full(max(len(kq), 1), -1, 'i4'); n = np.zeros(1, 'i4')
+        self.lib.check(self.lib.dll.sgx_match_search_by_bow(len(kk), _vp(kk), _vp(dk), _vp(gk), _vp(nk), len(kq), _vp(kq), _vp(dq), _vp(nq), float(self.mfNNratio),
+                                                            int(self.mbCheckOrientation), _vp(match), _vp(n)), 'sgx_match_search_by_bow')
+        return int(n[0]), match[:len(kq)].copy()
+
+    def FuseSearch(self, kf, map_points, th, cam, scale_factors, inv_level_sigma2):
+        """the search of ORBmatcher::Fuse(pKF, vpMapPoints, th) (ORBmatcher.cc:829-979): (nFused, best_idx[nm], best_dist[nm]).  kf: keys, desc, uright, Tcw;
+        map_points: xw, normal, min_dist, max_dist, desc, skip."""
+        k = np.ascontiguousarray(kf['keys']); d = np.ascontiguousarray(kf['desc'], np.uint8); u = np.ascontiguousarray(kf['uright'], 'f4'); T = np.ascontiguousarray(kf['Tcw'], 'f4').reshape(16)
+        m = map_points
+        xw = np.ascontiguousarray(m['xw'], 'f4'); nr = np.ascontiguousarray(m['normal'], 'f4'); mn = np.ascontiguousarray(m['min_dist'], 'f4'); mx = np.ascontiguousarray(m['max_dist'], 'f4')
+        md = np.ascontiguousarray(m['desc'], np.uint8); sk = np.ascontiguousarray(m['skip'], np.uint8)
+        sf = np.ascontiguousarray(scale_factors, 'f4'); is2 = np.ascontiguousarray(inv_level_sigma2, 'f4')
+        bi = np.full(max(len(xw), 1), -1, 'i4'); bd = np.full(max(len(xw), 1), 256, 'i4'); n = np.zeros(1, 'i4')
+        cs = camera_struct(cam)
+        self.lib.check(self.lib.dll.sgx_match_fuse_search(len(k), _vp(k), _vp(d), _vp(u), _vp(T), len(xw), _vp(xw), _vp(nr), _vp(mn), _vp(mx), _vp(md), _vp(sk), C.byref(cs), _vp(sf), _vp(is2),
+                                                          len(sf), float(np.log(np.float32(sf[1]))), float(th), _vp(bi), _vp(bd), _vp(n)), 'sgx_match_fuse_search')
+        return int(n[0]), bi[:len(xw)].copy(), bd[:len(xw)].copy()

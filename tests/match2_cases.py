@@ -66,3 +66,44 @@ def check_triangulation(lib, orc, n_cases=6):
     assert ORBmatcher(lib=lib).SearchForTriangulation(kf1, e, fundamental_12(kf1, kf2), False, CAM, sf, sg)[0] == 0
     kf2b = dict(kf2); kf2b['feat_node'] = kf2['feat_node'] + 100000
     assert ORBmatcher(lib=lib).SearchForTriangulation(kf1, kf2b, fundamental_12(kf1, kf2), False, CAM, sf, sg)[0] == 0
+
+
+def check_bow(lib, orc, n_cases=5):
+    total = 0
+    for c in range(n_cases):
+        _, kf, F = make_keyframes(orc, 40 + c, 8 + 2 * c, 10 + 2 * c)
+        kf = dict(kf); kf['good_mp'] = kf['has_mp']                        # the keyframe's map points (60 % of its keypoints when only_some_mp)
+        if c % 2 == 1: kf['good_mp'] = np.ones(len(kf['keys']), np.uint8)
+        for ratio in (0.7, 0.9):
+            for ori in (True, False):
+                en, em = orc.search_by_bow(kf, F, ratio, ori)
+                gn, gm = ORBmatcher(ratio, ori, lib=lib).SearchByBoW(kf, F)
+                assert gn == en == (em >= 0).sum() and (gm == em).all(), (c, ratio, ori, gn, en)
+                total += en
+                sel = em >= 0
+                assert kf['good_mp'][em[sel]].all() and (kf['feat_node'][em[sel]] == F['feat_node'][sel]).all() and len(set(em[sel])) <= sel.sum()
+    assert total > 300
+
+
+def check_fuse(lib, orc, n_cases=5):
+    sf = orc.orb_params()['scale']; is2 = orc.orb_params()['inv_sigma2']
+    from test_tracker_emu import make_map_points
+    total = 0
+    for c in range(n_cases):
+        gen = synth.LayeredStream(seed=1234 + c)
+        rng = np.random.RandomState(c)
+        g0, d0, T0 = gen.frame(20 + c); g1, d1, T1 = gen.frame(23 + c)
+        k0, dd0 = orc.orb_extract(g0); ur0, z0 = orc.compute_stereo_from_rgbd(k0, d0, CAM['bf'], CAM['depth_factor'])
+        k1, dd1 = orc.orb_extract(g1); ur1, z1 = orc.compute_stereo_from_rgbd(k1, d1, CAM['bf'], CAM['depth_factor'])
+        xw, has = orc.unproject_stereo(k1, z1, T1.astype('f4'), CAM)
+        mp = make_map_points(k1, xw, has, dd1, T1.astype('f4'), np.asarray(sf, 'f4'))      # candidate map points = the other keyframe's points
+        mp['skip'] = (mp['skip'] | (rng.rand(len(k1)) < 0.2)).astype(np.uint8)             # some already in pKF / bad
+        ur0 = ur0.copy(); ur0[rng.rand(len(k0)) < 0.3] = -1                                # monocular keypoints take the 5.99 gate
+        kf = dict(keys=k0, desc=dd0, uright=ur0, Tcw=T0.astype('f4'))
+        for th in (3.0, 5.0):
+            en, ei, ed = orc.fuse_search(kf, mp, CAM, sf, is2, th)
+            gn, gi, gd = ORBmatcher(lib=lib).FuseSearch(kf, mp, th, CAM, sf, is2)
+            assert gn == en and (gi == ei).all() and (gd == ed).all(), (c, th, gn, en)
+            total += en
+            assert (ed[ei >= 0] <= 50).all() and not mp['skip'][ei >= 0].any()
+    assert total > 500

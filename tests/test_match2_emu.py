@@ -8,3 +8,11 @@ def test_hamming_matrix_emu(emu, oracle):
 
 def test_search_for_triangulation_emu(emu, oracle):
     mc.check_triangulation(emu, oracle, n_cases=4)
+
+
+def test_search_by_bow_emu(emu, oracle):
+    mc.check_bow(emu, oracle, n_cases=3)
+
+
+def test_fuse_search_emu(emu, oracle):
+    mc.check_fuse(emu, oracle, n_cases=3)

@@ -11,3 +11,11 @@ def test_hamming_matrix_gpu(gpulib, oracle):
 
 def test_search_for_triangulation_gpu(gpulib, oracle):
     mc.check_triangulation(gpulib, oracle, n_cases=8)
+
+
+def test_search_by_bow_gpu(gpulib, oracle):
+    mc.check_bow(gpulib, oracle, n_cases=6)
+
+
+def test_fuse_search_gpu(gpulib, oracle):
+    mc.check_fuse(gpulib, oracle, n_cases=6)
