@@ -287,7 +287,13 @@ int sgx_det_detect(sgx_det *h, const uint8_t *images, int pitch, int batch, sgx_
 /* Detector2D::detect, device-resident and asynchronous on `stream`: forward + ncnn DetectionOutput (decode, per-class NMS, keep_top_k) + detect()'s
  * filtering, all on the GPU.  d_results: batch structs in device memory (same layout as the host entry fills).  d_boxes / d_nboxes / d_have_dynamic
  * (optional, may be NULL): the person rectangles (max_boxes x (x, y, w, h) per image), their count and mbHaveDynamicObjectForRmDynamicFeature, laid out
- * as sgx_dynamic_mask_batch_dev / sgx_frame_compact_keys_batch_dev take them — Detector2D.cc:53-88 feeding Frame.cc:482-500 without a host round trip. */
+ * as sgx_dynamic_mask_batch_dev / sgx_frame_compact_keys_batch_dev take them — Detector2D.cc:53-88 feeding Frame.cc:482-500 without a host round trip.
+ * Two documented differences from the reference, both where the reference's own result is not defined:
+ *   - Frame.cc:482-491 copies the detector's flags into the Frame only when mvObjects2D (the NON-person list) is not empty; otherwise the Frame's
+ *     mbHaveDynamicObjectForRmDynamicFeature (Frame.h:112, never initialised by the constructor) is read indeterminate at :493/:512/:565/:599.  d_have_dynamic[f]
+ *     here is always Detector2D's own flag (a person with prob > 0.2 exists), i.e. the value the reference reads whenever it is defined.
+ *   - ncnn's DetectionOutput orders candidates with an unstable quicksort (qsort_descent_inplace); rows with EXACTLY equal scores may come out in either order
+ *     there.  Here (and in oracle/detector_oracle.py) ties keep class-major, then prior-index order (a stable sort); with distinct scores the outputs agree. */
 int sgx_det_detect_batch_dev(sgx_det *h, const uint8_t *d_img, int pitch, int batch, sgx_det_result *d_results,
                              float *d_boxes, int32_t *d_nboxes, int max_boxes, int32_t *d_have_dynamic, void *stream);
 /* device-resident batched forward only: leaves mbox_loc (num_priors*4) and softmax conf (num_priors*num_class) per image in HBM */

@@ -21,8 +21,17 @@ namespace {
 // One grow-only device arena per process (LocalBundleAdjustment runs on the single LocalMapping thread, LocalMapping.cc:81):
 // avoids ~30 hipMalloc/hipFree pairs per call.  Layout is computed twice: first pass sizes, second pass assigns.
 struct Arena {
-    char *base = nullptr; size_t cap = 0, off = 0;
+    char *base = nullptr; size_t cap = 0, off = 0; int device = -1;
     int reserve(size_t bytes) {
+#ifndef SGX_EMU
+        int cur = 0;
+        if (hipGetDevice(&cur) != hipSuccess) return SGX_ERR_DEVICE;
+        if (base && cur != device) {                      // the arena lives on the device that was current when it was allocated: a caller on another device gets a fresh one
+            const int keep = cur; (void)hipSetDevice(device); (void)hipFree(base); (void)hipSetDevice(keep);
+            base = nullptr; cap = 0;
+        }
+        device = cur;
+#endif
         if (bytes <= cap) return SGX_OK;
         if (base) (void)hipFree(base);
         base = nullptr; cap = 0;

@@ -438,8 +438,9 @@ static void run_op(sgx_det *h, const Op &op, int batch, sgx_stream_t st)
         const int nxt = (total + 128 * pxb - 1) / (128 * pxb), noc = (sub + ocb - 1) / ocb;
         const int grid = ((nxt + 7) / 8) * 8 * noc;
         const SgxEpi e = make_epi(h, op, (size_t)op.outc * N);
+        static const int pw2_direct = getenv("SGX_PW2_DIRECT") ? atoi(getenv("SGX_PW2_DIRECT")) : 1;
 #define SGX_PW2(OCB_, PXB_) do { auto kfn = k_conv_pw2<OCB_, PXB_>; SGX_LAUNCH(kfn, dim3(grid), dim3(256), st, op.inc, op.outc, N, total, A.d, A.n, op.wtT, op.bias, \
-                                                                               O.d, O.n, e, op.hwc, op.hwc_off, nxt, noc, op.ldw); } while (0)
+                                                                               O.d, O.n, e, op.hwc, op.hwc_off, nxt, noc, op.ldw, pw2_direct); } while (0)
         switch (ocb * 10 + pxb) {
         case 42: SGX_PW2(4, 2); break; case 32: SGX_PW2(3, 2); break; case 22: SGX_PW2(2, 2); break; case 14: SGX_PW2(1, 4); break;
         case 21: SGX_PW2(2, 1); break; case 12: SGX_PW2(1, 2); break; default: SGX_PW2(1, 1); break;

@@ -251,11 +251,32 @@ SGX_DEV void sgx_pw2_readback(const SgxEpi &epi, const float (*E)[33], int nj, i
         *(float *)((char *)out + ubyte + ooff4) = sgx_epi_mode<MODE>(epi, E[2 * j + half][l31], (size_t)(ubyte >> 2), toff4);
     }
 }
+
+// CHW store straight from the accumulators: in the MFMA C layout a register already holds one output row segment per half-wave (lanes along pixels), so
+// every store writes two whole 128 B lines; no LDS round trip, no barrier.  Row base wave-uniform, lane offset 32-bit.
+template <int MODE, int OCB, int PXB>
+SGX_DEV void sgx_pw2_store_direct(const SgxEpi &epi, const sgx_f32x16 (&acc)[OCB][PXB], int oc0, int outc, int N, int half, const bool (&pv)[PXB], float *out,
+                                  const unsigned (&od)[PXB], const unsigned (&td)[PXB])
+{
+#pragma unroll
+    for (int t = 0; t < OCB; t++) {
+        if (oc0 + 32 * t >= outc) break;                                 // uniform: oc padding of the last block
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int rowu = oc0 + 32 * t + (r & 3) + 8 * (r >> 2);
+            const unsigned ubyte = (unsigned)rowu * (unsigned)N * 4u;
+            const bool rv = rowu + 4 * half < outc;
+#pragma unroll
+            for (int m = 0; m < PXB; m++)
+                if (rv && pv[m]) *(float *)((char *)out + ubyte + od[m]) = sgx_epi_mode<MODE>(epi, acc[t][m][r], (size_t)(ubyte >> 2), td[m]);
+        }
+    }
+}
 #endif
 
 template <int OCB, int PXB>
 SGX_KERNEL_OCC(256, (OCB * PXB <= 4 ? 4 : (OCB * PXB <= 6 ? 3 : 2))) k_conv_pw2(int inc, int outc, int N, int total, const float *in, size_t in_pitch, const float *WtT, const float *bias,
-                           float *out, size_t out_pitch, SgxEpi epi, int hwc, int hwc_off, int nxt, int noc, int ldw)
+                           float *out, size_t out_pitch, SgxEpi epi, int hwc, int hwc_off, int nxt, int noc, int ldw, int direct)
 {
     constexpr int OCT = 32 * OCB;
     SGX_LDS float Ws[2][SGX_PW2_KC][OCT + 1];       // weight chunks, double-buffered
@@ -342,6 +363,23 @@ SGX_KERNEL_OCC(256, (OCB * PXB <= 4 ? 4 : (OCB * PXB <= 6 ? 3 : 2))) k_conv_pw2(
     // ---- epilogue, one 32x32 tile at a time through a wave-private LDS tile: a compact run-time loop applies the elementwise program
     // (64 inlined copies of it cost hundreds of VGPRs), and the read-back order is chosen per store layout so stores stay contiguous
     // (CHW: lanes along pixels; HWC: lanes along channels).
+    if (!hwc && direct && epi.mode != SGX_EMODE_GENERIC) {
+        unsigned od[PXB], td[PXB]; bool pv[PXB];
+#pragma unroll
+        for (int m = 0; m < PXB; m++) {
+            const unsigned h3 = 3u * (unsigned)half * (unsigned)N * 4u;     // ooff4 already carries half * N: rows of the upper half-wave are 4 further down
+            od[m] = ooff4[m] + h3; td[m] = toff4[m] + h3; pv[m] = g0 + 32 * m + l31 < total;
+        }
+        switch (epi.mode) {
+        case SGX_EMODE_NONE: sgx_pw2_store_direct<SGX_EMODE_NONE, OCB, PXB>(epi, acc, oc0, outc, N, half, pv, out, od, td); break;
+        case SGX_EMODE_ACT: sgx_pw2_store_direct<SGX_EMODE_ACT, OCB, PXB>(epi, acc, oc0, outc, N, half, pv, out, od, td); break;
+        case SGX_EMODE_HSWISH: sgx_pw2_store_direct<SGX_EMODE_HSWISH, OCB, PXB>(epi, acc, oc0, outc, N, half, pv, out, od, td); break;
+        case SGX_EMODE_GATE: sgx_pw2_store_direct<SGX_EMODE_GATE, OCB, PXB>(epi, acc, oc0, outc, N, half, pv, out, od, td); break;
+        case SGX_EMODE_GATE_ADD: sgx_pw2_store_direct<SGX_EMODE_GATE_ADD, OCB, PXB>(epi, acc, oc0, outc, N, half, pv, out, od, td); break;
+        default: sgx_pw2_store_direct<SGX_EMODE_ADD_T, OCB, PXB>(epi, acc, oc0, outc, N, half, pv, out, od, td); break;
+        }
+        return;
+    }
     float (*E)[33] = Es[wave];
 #pragma unroll 1
     for (int tile = 0; tile < OCB * PXB; tile++) {

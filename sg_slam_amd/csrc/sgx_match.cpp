@@ -139,7 +139,9 @@ extern "C" int sgx_match_project_frame(
     const sgx_camera *cam, const float *scale_factors, int nlevels, float th, int b_mono, int check_orientation,
     int32_t *cur_match, int32_t *nmatches)
 {
-    if (nc < 0 || nl < 0 || nc > SGX_MATCH_CAP || nl > SGX_MATCH_CAP || !cur_match || !nmatches) return SGX_ERR_INVALID;
+    if (nc < 0 || nl < 0 || nc > SGX_MATCH_CAP || nl > SGX_MATCH_CAP || !cur_match || !nmatches || !cTcw || !lTcw || !cam || !scale_factors || nlevels < 1) return SGX_ERR_INVALID;
+    if (nc > 0 && (!ckeys || !cdesc || !curight)) return SGX_ERR_INVALID;
+    if (nl > 0 && (!lkeys || !l_has_mp || !l_outlier || !l_xw || !l_obs || !l_mpdesc)) return SGX_ERR_INVALID;
     int cap = nc > nl ? nc : nl; if (cap < 1) cap = 1;
     DevBuf b[16]; for (int i = 0; i < 16; i++) b[i].slot = i;
     std::vector<uint8_t> pad;

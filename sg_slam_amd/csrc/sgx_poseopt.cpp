@@ -46,7 +46,8 @@ extern "C" int sgx_pose_optimization(int n, const sgx_keypoint *keys_un, const f
                                       const float *inv_level_sigma2, int nlevels, const sgx_camera *cam,
                                       float *Tcw, uint8_t *outlier, int32_t *n_inliers)
 {
-    if (n < 0 || n > SGX_PO_CAP || !Tcw || !outlier || !n_inliers) return SGX_ERR_INVALID;
+    if (n < 0 || n > SGX_PO_CAP || !Tcw || !outlier || !n_inliers || !cam || !inv_level_sigma2 || nlevels < 1) return SGX_ERR_INVALID;
+    if (n > 0 && (!keys_un || !uright || !has_mp || !mp_xw)) return SGX_ERR_INVALID;      // a NULL source would leave the staging slot's previous contents in place
     const int cap = n > 0 ? n : 1;
     void *d[8] = {0};
     const size_t sz[8] = { (size_t)cap * 28, (size_t)cap * 4, 4, (size_t)cap, (size_t)cap * 12, 64, (size_t)cap, 4 };

@@ -2,6 +2,7 @@
 #include "sgx_prof.h"
 #include "../../include/sgx.h"
 #include <vector>
+#include <mutex>
 
 static int g_on = 0;
 static const char *g_names[SGX_K_COUNT] = { "pyramid_resize", "fast_cells", "octree", "orient_desc", "stereo_from_rgbd",
@@ -9,15 +10,21 @@ static const char *g_names[SGX_K_COUNT] = { "pyramid_resize", "fast_cells", "oct
 #ifndef SGX_EMU
 static std::vector<hipEvent_t> g_a[SGX_K_COUNT], g_b[SGX_K_COUNT];
 static int g_used[SGX_K_COUNT];
+// the entry points are called from the Tracking, Detector2D and LocalMapping threads: the event lists are process-wide, so every access takes this
+// lock.  A begin/end pair of one class must not interleave with another thread's pair of the SAME class (each class belongs to one pipeline stage, hence one thread).
+static std::mutex g_mu;
 void sgx_prof_begin(int k, sgx_stream_t st)
 {
     if (!g_on) return;
+    std::lock_guard<std::mutex> lk(g_mu);
     if (g_used[k] == (int)g_a[k].size()) { hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); g_a[k].push_back(a); g_b[k].push_back(b); }
     (void)hipEventRecord(g_a[k][g_used[k]], st);
 }
 void sgx_prof_end(int k, sgx_stream_t st)
 {
     if (!g_on) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_used[k] >= (int)g_a[k].size()) return;                      // end without a begin (profiling switched on in between)
     (void)hipEventRecord(g_b[k][g_used[k]], st);
     g_used[k]++;
 }
@@ -36,6 +43,7 @@ extern "C" int sgx_profile_read(float *ms, int32_t *launches, int reset)
     for (int k = 0; k < SGX_K_COUNT; k++) { ms[k] = 0.f; launches[k] = 0; }
 #ifndef SGX_EMU
     if (hipDeviceSynchronize() != hipSuccess) return SGX_ERR_DEVICE;
+    std::lock_guard<std::mutex> lk(g_mu);
     for (int k = 0; k < SGX_K_COUNT; k++) {
         for (int i = 0; i < g_used[k]; i++) { float t = 0.f; if (hipEventElapsedTime(&t, g_a[k][i], g_b[k][i]) != hipSuccess) return SGX_ERR_DEVICE; ms[k] += t; }
         launches[k] = g_used[k];

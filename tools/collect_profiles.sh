@@ -1,33 +1,43 @@
 #!/bin/bash
-# Re-collects the measurement artefacts kept under profiles/ on a 1-GPU MI355X box (run from the repo root; ~4 minutes of GPU time):
+# Re-collects the measurement artefacts kept under profiles/ on a 1-GPU MI355X box (run from the repo root; ~6 minutes of GPU time):
 #   tools/collect_profiles.sh <tag>        e.g.  /usr/local/graft/bin/gpurun --timeout 1500 -- 'tools/collect_profiles.sh r2_a'
-# Writes into gpurun_out/<tag>/; copy what should be judged into profiles/ afterwards.  Counter passes follow MI355X_MICROARCH.md: one counter per pass
-# (FETCH_SIZE and WRITE_SIZE together made rocprofv3 abort on this pool), --kernel-trace only (no sys / runtime trace domains), each under a hard timeout.
+# Writes into gpurun_out/<tag>/; copy what should be judged into profiles/ afterwards.  Counter passes follow MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE in
+# separate passes, --kernel-trace only (no sys / runtime trace domains), each under a hard timeout.  The SQ / TCC passes run the chain without the detector
+# (its 103-launch graph is profiled per step by tools/prof_det_ops.py instead) on 4 steps (1 warm-up + 3 timed).
 set -u
 TAG=${1:-run}
 R=$PWD; O=$R/gpurun_out/$TAG; mkdir -p $O
-# 1. the default bench line (with the CPU baseline) and the smaller / larger stream counts
-timeout 400 python bench.py > $O/bench_default.json 2> $O/bench_default.err
-timeout 200 python bench.py --no-cpu-baseline --streams 64  > $O/bench_s64.json 2>/dev/null
-timeout 200 python bench.py --no-cpu-baseline --streams 512 > $O/bench_s512.json 2>/dev/null
-timeout 300 python bench.py --no-cpu-baseline --detector   > $O/bench_with_detector.json 2>/dev/null
+PB="python $R/bench.py --no-cpu-baseline --no-config2 --no-detector --steps 3 --warmup 1"
+# 1. the default bench line (full chain, detector on, CPU baseline, config-2 secondary)
+timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 # 2. kernel statistics of the same command (rocprofv3 wants a writable cwd / TMPDIR)
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o b -- python $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2>/dev/null
-# 3. HBM traffic: separate passes, 8 steps each (2 warm-up + 6 timed), joined per bench kernel class by tools/pmc_traffic.py
-timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -o p -- python $R/bench.py --no-cpu-baseline --steps 6 --warmup 2 > /dev/null 2>&1
-timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o p -- python $R/bench.py --no-cpu-baseline --steps 6 --warmup 2 > /dev/null 2>&1
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o b -- python $R/bench.py --no-cpu-baseline --no-config2 > $O/bench_under_rocprof.json 2>/dev/null
+# 3. SQ instruction counters (two passes) and HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes)
+timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace --output-format csv -d $O/sq_a -o p -- $PB > /dev/null 2>&1
+timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $O/sq_b -o p -- $PB > /dev/null 2>&1
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -o p -- $PB > /dev/null 2>&1
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o p -- $PB > /dev/null 2>&1
+# 4. detector: per-step table, then the same SQ counters over its launches (batch 256, 2 repetitions, steps launched one by one)
+timeout 200 python $R/tools/prof_det_ops.py 256 5 > $O/detector_ops_b256.txt 2>/dev/null
+timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace --output-format csv -d $O/det_sq -o p -- python $R/tools/prof_det_ops.py 256 2 > /dev/null 2>&1
+timeout -s KILL 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/det_mfma -o p -- python $R/tools/prof_det_ops.py 256 2 > /dev/null 2>&1
 cd $R
-python tools/pmc_traffic.py $O/fetch/p_counter_collection.csv $O/write/p_counter_collection.csv 256 8 $O/traffic.json
-# 4. bundle adjustment: LocalBA sizes, 500 and 2000 keyframes, kernel statistics of the big one
+f() { find $O/$1 -name "*counter_collection.csv" | head -1; }
+python tools/pmc_traffic.py $(f fetch) $(f write) 256 4 $O/traffic.json $O/bench_under_rocprof.json > /dev/null
+python tools/pmc_insts.py $O/pmc_insts.json 256 4 $(f sq_a) $(f sq_b) --det $(f det_sq) 256 $(python - <<PY
+import csv
+n = sum(1 for r in csv.DictReader(open("$(f det_sq)")) if r['Counter_Name'] == 'SQ_WAVES' and 'k_det_preprocess' in r['Kernel_Name'])
+print(max(n, 1))
+PY
+) > $O/pmc_insts.txt
+for d in sq_a sq_b fetch write det_sq det_mfma; do python tools/pmc_summary.py $(f $d) > $O/pmc_$d.txt 2>/dev/null; done
+# 5. standalone stage benches
+timeout 100 python tools/bench_flow.py > $O/flow.txt 2>/dev/null
 timeout 100 python tools/bench_ba.py > $O/localba.json 2>/dev/null
 timeout 100 python tools/bench_ba_big.py 500 12000 > $O/ba_500.json 2>/dev/null
 timeout 100 python tools/bench_ba_big.py > $O/ba_2000.json 2>/dev/null
-cd /tmp
-timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ba_stats -o b -- python $R/tools/bench_ba_big.py > /dev/null 2>&1
-cd $R
-# 5. detector forward alone (frames/s per batch size, per-step table)
-timeout 200 python tools/bench_det.py > $O/detector_bench.json 2>/dev/null
+find $O -name "*.csv" -size +4M -delete      # raw traces stay on the box; the summaries above are what gets committed
 python - <<PY
 import json
 j = json.load(open("$O/bench_default.json"))
