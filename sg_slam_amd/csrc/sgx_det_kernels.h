@@ -723,7 +723,6 @@ SGX_KERNEL(256) k_compact_keys(int cap, const uint8_t *keys, const uint8_t *desc
 #define SGX_DO_SORT 4096                   /* per-class sort capacity: num_priors <= this */
 #define SGX_DO_TOPK 320                    /* nms_top_k <= this (5 words of 64 candidates) */
 #define SGX_DO_WORDS (SGX_DO_TOPK / 64)
-#define SGX_DO_COMPACT 1024                /* up to this many candidates are gathered and sorted on their own (fits the suppression matrix: TOPK * WORDS entries) */
 #define SGX_DO_MERGE 8192                  /* (classes - 1) * nms_top_k <= this */
 struct SgxDetOut { int n, nc, nms_top_k, keep_top_k; float nms_th, conf_th, var0, var1, var2, var3; };
 
@@ -742,27 +741,140 @@ struct SgxDetOut { int n, nc, nms_top_k, keep_top_k; float nms_th, conf_th, var0
             SGX_SYNC();                                                                                              \
         }
 
+// Radix select over the score half of the keys (4 passes of 8 bits, most significant first): finds the score S of the K-th largest key among the non-zero
+// keys[0..size) (precondition: at least K of them).  hist/cum: int[256] in LDS; sel: int[4] in LDS = { score bits found so far, keys still needed among the
+// current bucket, bucket of this pass, size of the last bucket }.  Afterwards sel[0] = S and "sel[1] == sel[3]" says that exactly K keys have a score >= S
+// (no tie across the cut); otherwise the caller falls back to the full sort.  Runs as phases inside a kernel body (256 threads).
+#define SGX_TOPK_SELECT(keys, size, K, hist, cum, sel, s_tot)                                                        \
+    SGX_THREADS_BEGIN(tid) if (tid == 0) { sel[0] = 0; sel[1] = (K); sel[2] = 0; sel[3] = 0; } SGX_THREADS_END       \
+    SGX_SYNC();                                                                                                      \
+    for (int sh_ = 24; sh_ >= 0; sh_ -= 8) {                                                                         \
+        SGX_THREADS_BEGIN(tid) hist[tid] = 0; SGX_THREADS_END                                                        \
+        SGX_SYNC();                                                                                                  \
+        SGX_THREADS_BEGIN(tid)                                                                                       \
+        const uint32_t pre_ = (uint32_t)sel[0];                                                                      \
+        for (int i_ = tid; i_ < (size); i_ += 256) {                                                                 \
+            const unsigned long long k_ = keys[i_]; const uint32_t h_ = (uint32_t)(k_ >> 32);                        \
+            if (k_ != 0 && (sh_ == 24 || ((h_ ^ pre_) >> ((sh_ + 8) & 31)) == 0)) sgx_atomic_add(&hist[255 - (int)((h_ >> sh_) & 255u)], 1); \
+        }                                                                                                            \
+        SGX_THREADS_END                                                                                              \
+        SGX_SYNC();                                                                                                  \
+        SGX_THREADS_BEGIN(tid) cum[tid] = hist[tid]; SGX_THREADS_END                                                 \
+        SGX_SYNC();                                                                                                  \
+        SGX_THREADS_BEGIN(tid) sgx_block_exclusive_scan_i32(cum, 256, &s_tot, tid); SGX_THREADS_END                  \
+        SGX_SYNC();                                                                                                  \
+        SGX_THREADS_BEGIN(tid) { const int need_ = sel[1]; if (cum[tid] < need_ && need_ <= cum[tid] + hist[tid]) sel[2] = tid; } SGX_THREADS_END \
+        SGX_SYNC();                                                                                                  \
+        SGX_THREADS_BEGIN(tid) if (tid == 0) { const int b_ = sel[2]; sel[1] -= cum[b_]; sel[3] = hist[b_]; sel[0] = (int)((uint32_t)sel[0] | ((uint32_t)(255 - b_) << sh_)); } SGX_THREADS_END \
+        SGX_SYNC();                                                                                                  \
+    }
+
+// rank sort (descending) of the n distinct keys src[0..n) into dst[0..n): rank = number of larger keys.  One pass, no barriers inside; src reads are broadcasts.
+#define SGX_RANK_SORT_DESC(src, n, dst)                                                                              \
+    SGX_THREADS_BEGIN(tid)                                                                                           \
+    for (int r_ = tid; r_ < (n); r_ += 256) {                                                                        \
+        const unsigned long long k_ = src[r_]; int rank_ = 0;                                                        \
+        _Pragma("unroll 8")                                                                                          \
+        for (int q_ = 0; q_ < (n); q_++) rank_ += src[q_] > k_ ? 1 : 0;                                              \
+        dst[rank_] = k_;                                                                                             \
+    }                                                                                                                \
+    SGX_THREADS_END                                                                                                  \
+    SGX_SYNC();
+
+// one radix-select pass, resolve step: hist[rb] = keys of the current bucket whose byte is 255 - rb (descending order).  Finds the byte bucket that holds the
+// sel[1]-th largest key, updates sel (see SGX_TOPK_SELECT) and clears hist for the next pass.  Called by all threads in one phase; wave 0 works.
+#ifdef SGX_EMU
+SGX_DEV void sgx_topk_resolve(int *hist, int *sel, int sh, int tid)
+{
+    if (tid != 0) return;
+    int run = 0; const int need = sel[1];
+    for (int rb = 0; rb < 256; rb++) {
+        const int hcur = hist[rb];
+        if (run < need && need <= run + hcur) { sel[1] = need - run; sel[3] = hcur; sel[0] = (int)((uint32_t)sel[0] | ((uint32_t)(255 - rb) << sh)); }
+        run += hcur;
+    }
+    for (int rb = 0; rb < 256; rb++) hist[rb] = 0;
+}
+#else
+SGX_DEV void sgx_topk_resolve(int *hist, int *sel, int sh, int tid)
+{
+    if (tid >= 64) return;
+    const int need = sel[1]; const uint32_t pre = (uint32_t)sel[0];
+    int hv[4]; int sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { hv[j] = hist[4 * tid + j]; sum += hv[j]; }
+    int inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (tid >= o) inc += t; }
+    int run = inc - sum;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (run < need && need <= run + hv[j]) { sel[1] = need - run; sel[3] = hv[j]; sel[0] = (int)(pre | ((uint32_t)(255 - (4 * tid + j)) << sh)); }
+        run += hv[j];
+        hist[4 * tid + j] = 0;
+    }
+}
+#endif
+
+// Radix select over 32-bit score patterns sc[0..n) (0 = not a candidate; scores are positive floats, so the bit pattern orders like the value): 4 passes of
+// 8 bits, most significant first.  Afterwards sel[0] = the K-th largest pattern S, sel[1] = how many of the sel[3] entries equal to S belong to the K largest.
+// Precondition: at least K non-zero entries, hist[] all zero (left zero again).  Phases inside a kernel body (256 threads); 2 barriers per pass.
+#define SGX_TOPK_SELECT32(sc, n, K, hist, sel)                                                                       \
+    SGX_THREADS_BEGIN(tid) if (tid == 0) { sel[0] = 0; sel[1] = (K); sel[2] = 0; sel[3] = 0; } SGX_THREADS_END       \
+    SGX_SYNC();                                                                                                      \
+    for (int sh_ = 24; sh_ >= 0; sh_ -= 8) {                                                                         \
+        SGX_THREADS_BEGIN(tid)                                                                                       \
+        const uint32_t pre_ = (uint32_t)sel[0];                                                                      \
+        for (int i_ = tid; i_ < (n); i_ += 256) {                                                                    \
+            const uint32_t h_ = sc[i_];                                                                              \
+            if (h_ != 0 && (sh_ == 24 || ((h_ ^ pre_) >> ((sh_ + 8) & 31)) == 0)) sgx_atomic_add(&hist[255 - (int)((h_ >> sh_) & 255u)], 1); \
+        }                                                                                                            \
+        SGX_THREADS_END                                                                                              \
+        SGX_SYNC();                                                                                                  \
+        SGX_THREADS_BEGIN(tid) sgx_topk_resolve(hist, sel, sh_, tid); SGX_THREADS_END                                \
+        SGX_SYNC();                                                                                                  \
+    }
+
+// "IoU(a, b) > th" exactly as `inter / uni > th` evaluates in fp32, without dividing in the clear cases: th * uni is within 2^-23 (relative) of the real
+// product, so an `inter` more than 1e-6 (relative) away from it is on the same side as the correctly rounded quotient; inside that band (and for degenerate
+// unions) the division itself decides.
+SGX_DEV bool sgx_iou_gt(float a0, float a1, float a2, float a3, float area_a, float b0, float b1, float b2, float b3, float area_b, float th)
+{
+    const float iw = fminf(a2, b2) - fmaxf(a0, b0), ih = fminf(a3, b3) - fmaxf(a1, b1);
+    const float inter = (iw > 0 && ih > 0) ? iw * ih : 0.f;
+    const float uni = area_a + area_b - inter;
+    if (th > 0.f && uni > 1e-30f && uni < 3e38f) {
+        const float pth = th * uni;
+        if (inter > pth * 1.000001f) return true;
+        if (inter < pth * 0.999999f) return false;
+    }
+    return inter / uni > th;
+}
+
 SGX_KERNEL(256) k_det_class_nms(SgxDetOut P, const float *loc, const float *conf, const float *priors, float *cls_rows, int *cls_count)
 {
-    SGX_LDS unsigned long long keys[SGX_DO_SORT];
+    SGX_LDS uint32_t sc[SGX_DO_SORT];                            // score pattern per prior, 0 = below the confidence threshold
+    SGX_LDS unsigned long long keys[SGX_DO_TOPK];
     SGX_LDS float box[SGX_DO_TOPK][4];
+    SGX_LDS float area[SGX_DO_TOPK];
     SGX_LDS unsigned long long over[SGX_DO_TOPK][SGX_DO_WORDS];
     SGX_LDS unsigned long long kept[SGX_DO_WORDS];
-    SGX_LDS uint8_t pre[64];
-    SGX_LDS int s_m, s_pos;
+    SGX_LDS int hist[256], eqc[256], sel[4];
+    SGX_LDS int s_m, s_pos, s_tot;
+    unsigned long long *ck = &over[0][0];                        // the unsorted selection lives in the not-yet-used suppression matrix
     const int c = 1 + (int)blockIdx.x, f = (int)blockIdx.y, n = P.n, nc = P.nc;
     const float *L = loc + (size_t)f * n * 4, *C = conf + (size_t)f * n * nc;
-    int size = 64; while (size < n) size <<= 1;               // <= SGX_DO_SORT (checked at create)
     SGX_THREADS_BEGIN(tid)
     if (tid == 0) { s_m = 0; s_pos = 0; }
+    hist[tid] = 0;
     SGX_THREADS_END
     SGX_SYNC();
     SGX_THREADS_BEGIN(tid)
     int cnt = 0;
-    for (int i = tid; i < size; i += 256) {
-        unsigned long long key = 0;
-        if (i < n) { const float s = C[(size_t)i * nc + c]; if (s > P.conf_th) { uint32_t b; memcpy(&b, &s, 4); key = ((unsigned long long)b << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i); cnt++; } }
-        keys[i] = key;
+    for (int i = tid; i < n; i += 256) {
+        const float s = C[(size_t)i * nc + c]; uint32_t b = 0;
+        if (s > P.conf_th) { memcpy(&b, &s, 4); cnt++; }
+        sc[i] = b;
     }
     if (cnt) sgx_atomic_add(&s_m, cnt);
     SGX_THREADS_END
@@ -772,28 +884,34 @@ SGX_KERNEL(256) k_det_class_nms(SgxDetOut P, const float *loc, const float *conf
         SGX_THREADS_BEGIN(tid) if (tid == 0) cls_count[f * (nc - 1) + (c - 1)] = 0; SGX_THREADS_END
         return;
     }
-    if (ncand <= SGX_DO_COMPACT) {
-        // few candidates: gather them (any order — the keys are distinct, the sort decides) into the not-yet-used suppression matrix, sort only
-        // the next power of two, and hand the head of the list back
-        unsigned long long *ck = &over[0][0];
-        int csize = 64; while (csize < ncand) csize <<= 1;
+    // The NMS only ever looks at the nms_top_k best candidates (ordered by score, ties by prior index — the stable sort of the list built in index order).
+    // Select them first (score of rank nms_top_k by radix select; a tie across the cut takes the lowest prior indices), then order just those.
+    const int m = min(ncand, P.nms_top_k);
+    const int CH = (n + 255) / 256;
+    if (ncand > P.nms_top_k) {
+        SGX_TOPK_SELECT32(sc, n, P.nms_top_k, hist, sel)
         SGX_THREADS_BEGIN(tid)
-        for (int i = tid; i < csize; i += 256) ck[i] = 0;
+        const uint32_t S = (uint32_t)sel[0]; int e = 0;
+        for (int i = tid * CH; i < min(n, (tid + 1) * CH); i++) e += sc[i] == S ? 1 : 0;
+        eqc[tid] = e;
         SGX_THREADS_END
         SGX_SYNC();
-        SGX_THREADS_BEGIN(tid)
-        for (int i = tid; i < size; i += 256) { const unsigned long long key = keys[i]; if (key) ck[sgx_atomic_add(&s_pos, 1)] = key; }
-        SGX_THREADS_END
+        SGX_THREADS_BEGIN(tid) sgx_block_exclusive_scan_i32(eqc, 256, &s_tot, tid); SGX_THREADS_END
         SGX_SYNC();
-        SGX_BITONIC_DESC(ck, csize, 256)
-        SGX_THREADS_BEGIN(tid)
-        for (int r = tid; r < SGX_DO_TOPK; r += 256) keys[r] = r < csize ? ck[r] : 0;
-        SGX_THREADS_END
-        SGX_SYNC();
-    } else {
-        SGX_BITONIC_DESC(keys, size, 256)
     }
-    const int m = min(ncand, P.nms_top_k);                       // candidates that enter the NMS: the head of the sorted list
+    SGX_THREADS_BEGIN(tid)
+    const bool cut = ncand > P.nms_top_k;
+    const uint32_t S = cut ? (uint32_t)sel[0] : 1u; const int need = cut ? sel[1] : n;
+    int run = cut ? eqc[tid] : 0;
+    for (int i = tid * CH; i < min(n, (tid + 1) * CH); i++) {
+        const uint32_t b = sc[i];
+        bool take = b > S || (!cut && b != 0);
+        if (cut && b == S) { take = run < need; run++; }
+        if (take) ck[sgx_atomic_add(&s_pos, 1)] = ((unsigned long long)b << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i);
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_RANK_SORT_DESC(ck, m, keys)
     SGX_THREADS_BEGIN(tid)
     for (int r = tid; r < m; r += 256) {                        // decode (ncnn detectionoutput.cpp; the host code this replaces used the same expressions)
         const int i = (int)(0xFFFFFFFFu - (uint32_t)keys[r]);
@@ -801,47 +919,91 @@ SGX_KERNEL(256) k_det_class_nms(SgxDetOut P, const float *loc, const float *conf
         const float pw = p[2] - p[0], ph = p[3] - p[1], pcx = (p[0] + p[2]) * 0.5f, pcy = (p[1] + p[3]) * 0.5f;
         const float cx = P.var0 * l[0] * pw + pcx, cy = P.var1 * l[1] * ph + pcy;
         const float w = expf(P.var2 * l[2]) * pw, hh = expf(P.var3 * l[3]) * ph;
-        box[r][0] = cx - w * 0.5f; box[r][1] = cy - hh * 0.5f; box[r][2] = cx + w * 0.5f; box[r][3] = cy + hh * 0.5f;
+        const float x0 = cx - w * 0.5f, y0 = cy - hh * 0.5f, x1 = cx + w * 0.5f, y1 = cy + hh * 0.5f;
+        box[r][0] = x0; box[r][1] = y0; box[r][2] = x1; box[r][3] = y1; area[r] = (x1 - x0) * (y1 - y0);
     }
     for (int w = tid; w < SGX_DO_WORDS; w += 256) kept[w] = 0;
     SGX_THREADS_END
     SGX_SYNC();
+    // over[r] bit q: candidate r overlaps the higher-ranked candidate q by more than nms_th (only words up to r / 64 are ever read)
+#ifndef SGX_EMU
+    {
+        const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
+        // lanes along the higher-ranked candidates q = 64 w + lane: their boxes do not depend on the row, so every wave keeps them in registers; a row then
+        // costs one broadcast read of its own box and one independent compare chain + ballot per word
+        float qb[SGX_DO_WORDS][4], qa[SGX_DO_WORDS];
+#pragma unroll
+        for (int w = 0; w < SGX_DO_WORDS; w++) {
+            const int qq = min(64 * w + lane, m - 1);
+            qb[w][0] = box[qq][0]; qb[w][1] = box[qq][1]; qb[w][2] = box[qq][2]; qb[w][3] = box[qq][3]; qa[w] = area[qq];
+        }
+        for (int r = wave; r < m; r += 4) {
+            const float a0 = box[r][0], a1 = box[r][1], a2 = box[r][2], a3 = box[r][3], aa = area[r];
+#pragma unroll
+            for (int w = 0; w < SGX_DO_WORDS; w++) {
+                if (64 * w < r) {                                // uniform
+                    const bool o = 64 * w + lane < r && sgx_iou_gt(a0, a1, a2, a3, aa, qb[w][0], qb[w][1], qb[w][2], qb[w][3], qa[w], P.nms_th);
+                    const unsigned long long bits = __ballot(o);
+                    if (lane == 0) over[r][w] = bits;
+                }
+            }
+            if (lane == 0 && (r & 63) == 0) over[r][r >> 6] = 0;    // first row of a chunk: its own word has no higher-ranked member
+        }
+    }
+#else
     SGX_THREADS_BEGIN(tid)
-    for (int t = tid; t < m * SGX_DO_WORDS; t += 256) {         // over[r] bit q: candidate r overlaps the higher-ranked candidate q by more than nms_th
+    for (int t = tid; t < m * SGX_DO_WORDS; t += 256) {
         const int r = t / SGX_DO_WORDS, w = t - r * SGX_DO_WORDS;
         unsigned long long bits = 0;
-        const float a0 = box[r][0], a1 = box[r][1], a2 = box[r][2], a3 = box[r][3];
         for (int b = 0; b < 64; b++) {
             const int q = 64 * w + b;
             if (q >= r) break;
-            const float iw = fminf(a2, box[q][2]) - fmaxf(a0, box[q][0]), ih = fminf(a3, box[q][3]) - fmaxf(a1, box[q][1]);
-            const float inter = (iw > 0 && ih > 0) ? iw * ih : 0.f;
-            const float uni = (a2 - a0) * (a3 - a1) + (box[q][2] - box[q][0]) * (box[q][3] - box[q][1]) - inter;
-            if (inter / uni > P.nms_th) bits |= 1ull << b;
+            if (sgx_iou_gt(box[r][0], box[r][1], box[r][2], box[r][3], area[r], box[q][0], box[q][1], box[q][2], box[q][3], area[q], P.nms_th)) bits |= 1ull << b;
         }
         over[r][w] = bits;
     }
     SGX_THREADS_END
+#endif
     SGX_SYNC();
-    for (int ch = 0; ch * 64 < m; ch++) {
-        SGX_THREADS_BEGIN(tid)
-        if (tid < 64) {
-            const int r = 64 * ch + tid;
-            bool s = false;
+    // greedy scan in rank order, 64 candidates (one word) at a time: suppression by earlier words is a parallel AND with their final kept bits, inside the
+    // word the decision chain is sequential
+#ifndef SGX_EMU
+    if ((int)threadIdx.x < 64) {                                 // wave 0: row bits and the "suppressed by an earlier word" flag sit in lanes, the chain runs on the scalar unit
+        const int lane = (int)threadIdx.x;
+        for (int ch = 0; ch * 64 < m; ch++) {
+            const int r = 64 * ch + lane;
+            bool s = r >= m;
             if (r < m) for (int w = 0; w < ch; w++) s = s || (over[r][w] & kept[w]) != 0;
-            pre[tid] = s ? 1 : 0;
+            const unsigned long long row = r < m ? over[r][ch] : 0ull;
+            const unsigned long long blocked = __ballot(s);
+            const uint32_t rlo = (uint32_t)row, rhi = (uint32_t)(row >> 32);
+            unsigned long long word = 0;
+#pragma unroll
+            for (int t = 0; t < 64; t++) {
+                const unsigned long long rt = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)rhi, t) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)rlo, t);
+                if (!((blocked >> t) & 1) && (rt & word) == 0) word |= 1ull << t;
+            }
+            if (lane == 0) kept[ch] = word;
+            __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): the next word's lanes read kept[ch]
+            __builtin_amdgcn_wave_barrier();
         }
-        SGX_THREADS_END
-        SGX_SYNC();
+    }
+    SGX_SYNC();
+#else
+    for (int ch = 0; ch * 64 < m; ch++) {
         SGX_THREADS_BEGIN(tid)
         if (tid == 0) {
             unsigned long long word = 0;
-            for (int t = 0; t < 64 && 64 * ch + t < m; t++) if (!pre[t] && (over[64 * ch + t][ch] & word) == 0) word |= 1ull << t;
+            for (int t = 0; t < 64 && 64 * ch + t < m; t++) {
+                const int r = 64 * ch + t; bool s = false;
+                for (int w = 0; w < ch; w++) s = s || (over[r][w] & kept[w]) != 0;
+                if (!s && (over[r][ch] & word) == 0) word |= 1ull << t;
+            }
             kept[ch] = word;
         }
         SGX_THREADS_END
-        SGX_SYNC();
     }
+#endif
     SGX_THREADS_BEGIN(tid)
     float *out = cls_rows + ((size_t)f * (nc - 1) + (c - 1)) * SGX_DO_TOPK * 6;
     for (int r = tid; r < m; r += 256) {
@@ -861,8 +1023,10 @@ SGX_KERNEL(256) k_det_merge(SgxDetOut P, const float *cls_rows, const int *cls_c
                             sgx_det_result *results, float *boxes, int *nboxes, int max_boxes, int *have_dynamic)
 {
     SGX_LDS unsigned long long keys[SGX_DO_MERGE];
+    SGX_LDS unsigned long long top[128];
     SGX_LDS int off[64];
-    SGX_LDS int s_total;
+    SGX_LDS int s_total, s_tot, s_pos;
+    SGX_LDS int hist[256], cum[256], sel[4];
     const int f = (int)blockIdx.x, ncl = P.nc - 1;
     SGX_THREADS_BEGIN(tid)
     if (tid == 0) { int run = 0; for (int q = 0; q < ncl; q++) { off[q] = run; run += cls_count[f * ncl + q]; } off[ncl] = run; s_total = run; }
@@ -886,8 +1050,24 @@ SGX_KERNEL(256) k_det_merge(SgxDetOut P, const float *cls_rows, const int *cls_c
     }
     SGX_THREADS_END
     SGX_SYNC();
-    SGX_BITONIC_DESC(keys, size, 256)
     const int K = min(min(total, P.keep_top_k), SGX_DET_MAX);
+    // only the K (<= 100) best rows leave the kernel: select them by score, then rank-sort those; a score tie across the cut goes to the full sort
+    bool sorted = K == 0;
+    if (K > 0 && K <= 128) {
+        if (total > K) { SGX_TOPK_SELECT(keys, size, K, hist, cum, sel, s_tot) }
+        if (total <= K || sel[1] == sel[3]) {
+            SGX_THREADS_BEGIN(tid) if (tid == 0) s_pos = 0; SGX_THREADS_END
+            SGX_SYNC();
+            SGX_THREADS_BEGIN(tid)
+            const uint32_t S = total > K ? (uint32_t)sel[0] : 0u;
+            for (int i = tid; i < size; i += 256) { const unsigned long long key = keys[i]; if (key != 0 && (uint32_t)(key >> 32) >= S) top[sgx_atomic_add(&s_pos, 1)] = key; }
+            SGX_THREADS_END
+            SGX_SYNC();
+            SGX_RANK_SORT_DESC(top, K, keys)
+            sorted = true;
+        }
+    }
+    if (!sorted) { SGX_BITONIC_DESC(keys, size, 256) }
     sgx_det_result *R = results + f;
     SGX_THREADS_BEGIN(tid)
     for (int r = tid; r < K; r += 256) {
