@@ -458,7 +458,26 @@ static void run_op(sgx_det *h, const Op &op, int batch, sgx_stream_t st)
         const int budget = 8192;                                        // floats of LDS per workgroup for the staged input
         const int Wp = (op.Wo - 1) * op.stride + op.k;
         auto magic = [](int d) -> unsigned { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
-        if (!h->legacy && op.depthwise && (op.k == 3 || op.k == 5) && Wp * op.k <= budget) {
+        const int nbx4 = (op.Wo + 3) / 4, pitch4 = ((nbx4 - 1) * 4 * op.stride + 3 * op.stride + op.k + 3) & ~3;
+        static const int dw2_on = getenv("SGX_DW2") ? atoi(getenv("SGX_DW2")) : 1;
+        if (dw2_on && !h->legacy && op.depthwise && (op.k == 3 || op.k == 5) && (op.stride == 1 || op.stride == 2) && pitch4 * op.k <= budget) {
+            // k_conv_dw2: P planes x a band of RB output rows per workgroup, LDS tile [P][(RB - 1) s + k][pitch4]
+            const int nplanes = batch * op.outc, rin_full = (op.Ho - 1) * op.stride + op.k, KW = (op.k * op.k + 1 + 3) & ~3;
+            int P = 1, RB = op.Ho;
+            if (rin_full * pitch4 <= budget) P = std::max(1, std::min(std::min(budget / (rin_full * pitch4), 16), nplanes / 2048));
+            else {
+                const int rbmax = std::max(1, (budget / pitch4 - op.k) / op.stride + 1);
+                int nb = (op.Ho + rbmax - 1) / rbmax;
+                nb = std::max(nb, std::min((2048 + nplanes - 1) / nplanes, std::max(1, op.Ho / 4)));
+                RB = (op.Ho + nb - 1) / nb;
+            }
+            const int nbands = (op.Ho + RB - 1) / RB, ngroups = (nplanes + P - 1) / P;
+            const size_t lds = ((size_t)P * ((RB - 1) * op.stride + op.k) * pitch4 + (size_t)P * KW) * 4;
+#define SGX_DW2(K_, S_) do { auto kfn = k_conv_dw2<K_, S_>; SGX_LAUNCH_DYN(kfn, dim3(ngroups * nbands), dim3(256), lds, st, op.outc, op.H, op.W, op.Ho, op.Wo, op.pad, P, RB, nbands, nplanes, pitch4, \
+                                                                          magic(std::min(RB, op.Ho) * nbx4), magic(nbx4), A.d, op.wt, op.bias, O.d, e); } while (0)
+            if (op.k == 3 && op.stride == 1) SGX_DW2(3, 1); else if (op.k == 3) SGX_DW2(3, 2); else if (op.stride == 1) SGX_DW2(5, 1); else SGX_DW2(5, 2);
+#undef SGX_DW2
+        } else if (!h->legacy && op.depthwise && (op.k == 3 || op.k == 5) && Wp * op.k <= budget) {
             const int nplanes = batch * op.outc, rin_full = (op.Ho - 1) * op.stride + op.k;
             int P = 1, RB = op.Ho;
             if (rin_full * Wp <= budget) P = std::max(1, std::min(std::min(budget / (rin_full * Wp), 16), nplanes / 2048));

@@ -260,7 +260,7 @@ SGX_DEV void sgx_pw2_store_direct(const SgxEpi &epi, const sgx_f32x16 (&acc)[OCB
 {
 #pragma unroll
     for (int t = 0; t < OCB; t++) {
-        if (oc0 + 32 * t >= outc) break;                                 // uniform: oc padding of the last block
+        if (oc0 + 32 * t < outc)                                         // uniform: oc padding of the last block
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int rowu = oc0 + 32 * t + (r & 3) + 8 * (r >> 2);
@@ -502,6 +502,117 @@ SGX_KERNEL(256) k_conv_dw(int C, int H, int W, int Ho, int Wo, int stride, int p
             out[obase + o] = sgx_epi(epi, s, obase + o);
         }
     }
+    SGX_THREADS_END
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_conv_dw2<K, S>: depthwise K x K convolution, stride S — the lean version of k_conv_dw (same decomposition: a workgroup owns P consecutive planes x one band of
+// RB output rows, the zero-padded input band staged once in LDS), with both phases register-blocked 4 wide:
+//   staging  one group of 4 consecutive padded columns per thread and step (4 scalar global loads, ONE ds_write_b128); the (plane, row, group) counters advance
+//            incrementally — no division per element;
+//   compute  one task = 4 consecutive outputs of a row: the (3 S + K) inputs of each of the K rows come in as aligned ds_read_b128 (LDS row pitch a multiple of 4, block origin
+//            4 bx S), weights + bias of the plane as K*K + 1 floats padded to whole float4s; 4 K^2 fmaf in tap order (i, j) ascending per output, as k_conv_kxk; the
+//            epilogue program is selected once per kernel, not per output; a full block leaves as one 16-byte store (consecutive lanes -> consecutive 16 B).
+// LDS: [P][Rmax][pitch] floats + [P][KW] weights, Rmax = (RB - 1) S + K, pitch = roundup4((ceil(Wo / 4) - 1) 4 S + 3 S + K), KW = roundup4(K K + 1).
+// grid = ceil(B C / P) * nbands.
+// ---------------------------------------------------------------------------------------------
+struct alignas(16) sgx_f4 { float v[4]; };
+
+template <int K, int S, int MODE>
+SGX_DEV void sgx_dw2_tasks(int tid, int np, int nrows, int nbx, int Wo, int Ho, int r0, int p0, int pitch, int plane_stride, unsigned task_magic, unsigned nbx_magic,
+                           const float *tile, const float *wl, float *out, const SgxEpi &epi)
+{
+    constexpr int KW = (K * K + 1 + 3) & ~3, NV = (3 * S + K + 3) / 4;
+    const int per_plane = nrows * nbx, ntask = np * per_plane;
+    for (int t = tid; t < ntask; t += 256) {
+        const int q = np == 1 ? 0 : (int)sgx_fastdiv((unsigned)t, task_magic), rem = t - q * per_plane;
+        const int oy = (int)sgx_fastdiv((unsigned)rem, nbx_magic), bx = rem - oy * nbx;
+        float w[KW];
+        const sgx_f4 *wq = (const sgx_f4 *)(wl + q * KW);
+#pragma unroll
+        for (int g = 0; g < KW / 4; g++) { const sgx_f4 x = wq[g]; w[4 * g] = x.v[0]; w[4 * g + 1] = x.v[1]; w[4 * g + 2] = x.v[2]; w[4 * g + 3] = x.v[3]; }
+        float acc[4] = { w[K * K], w[K * K], w[K * K], w[K * K] };
+        const float *base = tile + q * plane_stride + (oy * S) * pitch + bx * (4 * S);
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            float v[4 * NV];
+            const sgx_f4 *row = (const sgx_f4 *)(base + i * pitch);
+#pragma unroll
+            for (int g = 0; g < NV; g++) { const sgx_f4 x = row[g]; v[4 * g] = x.v[0]; v[4 * g + 1] = x.v[1]; v[4 * g + 2] = x.v[2]; v[4 * g + 3] = x.v[3]; }
+#pragma unroll
+            for (int j = 0; j < K; j++)
+#pragma unroll
+                for (int x = 0; x < 4; x++) acc[x] = fmaf(w[i * K + j], v[x * S + j], acc[x]);
+        }
+        const size_t o = ((size_t)(p0 + q) * Ho + (size_t)(r0 + oy)) * Wo + (size_t)(4 * bx);
+        const int nx = min(4, Wo - 4 * bx);
+        float res[4];
+#pragma unroll
+        for (int x = 0; x < 4; x++) res[x] = sgx_epi_mode<MODE>(epi, acc[x], o + (size_t)min(x, nx - 1), 0);
+        if (nx == 4) { sgx_f4 pk; pk.v[0] = res[0]; pk.v[1] = res[1]; pk.v[2] = res[2]; pk.v[3] = res[3]; memcpy(out + o, &pk, 16); }
+        else for (int x = 0; x < nx; x++) out[o + x] = res[x];
+    }
+}
+
+template <int K, int S>
+SGX_KERNEL(256) k_conv_dw2(int C, int H, int W, int Ho, int Wo, int pad, int P, int RB, int nbands, int nplanes, int pitch, unsigned task_magic, unsigned nbx_magic,
+                           const float *in, const float *Wt, const float *bias, float *out, SgxEpi epi)
+{
+    SGX_DYN_LDS(smem);
+    constexpr int KW = (K * K + 1 + 3) & ~3;
+    float *tile = (float *)smem;
+    const int grp = (int)blockIdx.x / nbands, band = (int)blockIdx.x - grp * nbands;
+    const int p0 = grp * P, np = min(P, nplanes - p0);
+    const int r0 = band * RB, nrows = min(RB, Ho - r0);
+    const int Rmax = (RB - 1) * S + K, Rin = (nrows - 1) * S + K, iy0 = r0 * S - pad;
+    const int plane_stride = Rmax * pitch, G = pitch >> 2;                // G groups of 4 columns per staged row
+    float *wl = tile + (size_t)P * plane_stride;
+    SGX_THREADS_BEGIN(tid)
+    // ---- staging.  Group index g = tid + 256 k over (plane q, row ry, column group cg), cg fastest; counters advance by the constant step 256 = (dq, dry, dcg)
+    const int rows256 = 256 / G, dcg = 256 - rows256 * G, dq = rows256 / Rin, dry = rows256 - dq * Rin;
+    const int ngrp = np * Rin * G;
+    int ry = tid / G, cg = tid - ry * G, q = ry / Rin; ry -= q * Rin;
+    for (int g0 = tid; g0 < ngrp; g0 += 512) {
+        float v[2][4]; int dst[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {                               // 8 independent loads in flight per thread before the LDS stores
+            const int qq = min(q, np - 1), iy = iy0 + ry;
+            const bool rowok = (unsigned)iy < (unsigned)H;
+            const float *src = in + ((size_t)(p0 + qq) * H + (size_t)(rowok ? iy : 0)) * W;
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                const int ix = 4 * cg + x - pad;
+                const bool ok = rowok && (unsigned)ix < (unsigned)W;
+                const float ld = src[ok ? ix : 0];
+                v[u][x] = ok ? ld : 0.f;
+            }
+            dst[u] = g0 + 256 * u < ngrp ? qq * plane_stride + ry * pitch + 4 * cg : -1;
+            cg += dcg; const int carry = cg >= G ? 1 : 0; cg -= carry ? G : 0;
+            ry += dry + carry; q += dq; if (ry >= Rin) { ry -= Rin; q++; }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+            if (dst[u] >= 0) { sgx_f4 pk; pk.v[0] = v[u][0]; pk.v[1] = v[u][1]; pk.v[2] = v[u][2]; pk.v[3] = v[u][3]; *(sgx_f4 *)(tile + dst[u]) = pk; }
+    }
+    for (int t = tid; t < np * KW; t += 256) {
+        const int qw = t / KW, j = t - qw * KW, c = (p0 + qw) % C;
+        wl[t] = j < K * K ? Wt[(size_t)c * K * K + j] : (j == K * K ? bias[c] : 0.f);
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+    const int nbx = (Wo + 3) >> 2;
+    SGX_THREADS_BEGIN(tid)
+#define SGX_DW2_RUN(M) sgx_dw2_tasks<K, S, M>(tid, np, nrows, nbx, Wo, Ho, r0, p0, pitch, plane_stride, task_magic, nbx_magic, tile, wl, out, epi)
+    switch (epi.mode) {
+    case SGX_EMODE_NONE: SGX_DW2_RUN(SGX_EMODE_NONE); break;
+    case SGX_EMODE_ACT: SGX_DW2_RUN(SGX_EMODE_ACT); break;
+    case SGX_EMODE_HSWISH: SGX_DW2_RUN(SGX_EMODE_HSWISH); break;
+    case SGX_EMODE_GATE: SGX_DW2_RUN(SGX_EMODE_GATE); break;
+    case SGX_EMODE_GATE_ADD: SGX_DW2_RUN(SGX_EMODE_GATE_ADD); break;
+    case SGX_EMODE_ADD_T: SGX_DW2_RUN(SGX_EMODE_ADD_T); break;
+    default: SGX_DW2_RUN(SGX_EMODE_GENERIC); break;
+    }
+#undef SGX_DW2_RUN
     SGX_THREADS_END
 }
 
