@@ -493,6 +493,14 @@ static void run_op(sgx_det *h, const Op &op, int batch, sgx_stream_t st)
                                                                      magic(((std::min(RB, op.Ho) - 1) * op.stride + op.k) * Wp), magic(Wp), magic(op.Wo), A.d, op.wt, op.bias, O.d, e); }
             else { auto kfn = k_conv_dw<5>; SGX_LAUNCH_DYN(kfn, dim3(ngroups * nbands), dim3(256), lds, st, op.outc, op.H, op.W, op.Ho, op.Wo, op.stride, op.pad, P, RB, nbands, nplanes,
                                                            magic(((std::min(RB, op.Ho) - 1) * op.stride + op.k) * Wp), magic(Wp), magic(op.Wo), A.d, op.wt, op.bias, O.d, e); }
+        } else if (dw2_on && !h->legacy && !op.depthwise && op.wtT && op.outc <= 16 && op.inc == 3 && op.k == 3 && op.stride == 2 && 3 * 5 * pitch4 * 4 <= 65536 &&
+                   (e.mode == SGX_EMODE_NONE || e.mode == SGX_EMODE_ACT || e.mode == SGX_EMODE_HSWISH)) {
+            // k_conv_stem2: bands of RB output rows; LDS = 3 x ((RB - 1) 2 + 3) x pitch4 floats, about 40 KB (3-4 workgroups per CU); RB*ceil(Wo/4) tasks for 256 threads
+            int RB = std::max(1, std::min(op.Ho, ((10240 / (3 * pitch4)) - 3) / 2 + 1));
+            const int nbands = (op.Ho + RB - 1) / RB;
+            const size_t lds = (size_t)3 * ((RB - 1) * 2 + 3) * pitch4 * 4;
+            auto kfn = k_conv_stem2<3>;
+            SGX_LAUNCH_DYN(kfn, dim3(nbands, batch), dim3(256), lds, st, op.outc, op.H, op.W, op.Ho, op.Wo, op.pad, RB, pitch4, magic(nbx4), A.d, A.n, op.wtT, op.bias, O.d, O.n, e);
         } else if (!h->legacy && !op.depthwise && op.wtT && op.outc <= 16 && op.inc * Wp * op.k <= budget) {
             const int RB = std::min(op.Ho, std::max(1, (budget / (op.inc * Wp) - op.k) / op.stride + 1)), nbands = (op.Ho + RB - 1) / RB;
             const size_t lds = (size_t)op.inc * ((RB - 1) * op.stride + op.k) * Wp * 4;

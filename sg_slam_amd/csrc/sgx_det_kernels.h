@@ -518,6 +518,39 @@ SGX_KERNEL(256) k_conv_dw(int C, int H, int W, int Ho, int Wo, int stride, int p
 // ---------------------------------------------------------------------------------------------
 struct alignas(16) sgx_f4 { float v[4]; };
 
+// LDS staging shared by k_conv_dw2 / k_conv_stem2: np planes (plane q at in + q * H * W), rows iy0 .. iy0 + Rin - 1, padded columns 0 .. pitch - 1 (column cx = input
+// column cx - pad), zeros outside the image; tile[q][ry][cx] with plane stride plane_stride.  One group of 4 columns per thread and step (4 scalar global loads, one
+// ds_write_b128); the group index g = tid + 256 k runs over (q, ry, column group cg), cg fastest, and the counters advance by the constant step 256 = (dq, dry, dcg).
+SGX_DEV void sgx_stage_planes4(int tid, const float *in, int np, int H, int W, int iy0, int Rin, int pad, int pitch, int plane_stride, float *tile)
+{
+    const int G = pitch >> 2;
+    const int rows256 = 256 / G, dcg = 256 - rows256 * G, dq = rows256 / Rin, dry = rows256 - dq * Rin;
+    const int ngrp = np * Rin * G;
+    int ry = tid / G, cg = tid - ry * G, q = ry / Rin; ry -= q * Rin;
+    for (int g0 = tid; g0 < ngrp; g0 += 512) {
+        float v[2][4]; int dst[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {                               // 8 independent loads in flight per thread before the LDS stores
+            const int qq = min(q, np - 1), iy = iy0 + ry;
+            const bool rowok = (unsigned)iy < (unsigned)H;
+            const float *src = in + ((size_t)qq * H + (size_t)(rowok ? iy : 0)) * W;
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                const int ix = 4 * cg + x - pad;
+                const bool ok = rowok && (unsigned)ix < (unsigned)W;
+                const float ld = src[ok ? ix : 0];
+                v[u][x] = ok ? ld : 0.f;
+            }
+            dst[u] = g0 + 256 * u < ngrp ? qq * plane_stride + ry * pitch + 4 * cg : -1;
+            cg += dcg; const int carry = cg >= G ? 1 : 0; cg -= carry ? G : 0;
+            ry += dry + carry; q += dq; if (ry >= Rin) { ry -= Rin; q++; }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+            if (dst[u] >= 0) { sgx_f4 pk; pk.v[0] = v[u][0]; pk.v[1] = v[u][1]; pk.v[2] = v[u][2]; pk.v[3] = v[u][3]; *(sgx_f4 *)(tile + dst[u]) = pk; }
+    }
+}
+
 template <int K, int S, int MODE>
 SGX_DEV void sgx_dw2_tasks(int tid, int np, int nrows, int nbx, int Wo, int Ho, int r0, int p0, int pitch, int plane_stride, unsigned task_magic, unsigned nbx_magic,
                            const float *tile, const float *wl, float *out, const SgxEpi &epi)
@@ -565,35 +598,10 @@ SGX_KERNEL(256) k_conv_dw2(int C, int H, int W, int Ho, int Wo, int pad, int P, 
     const int p0 = grp * P, np = min(P, nplanes - p0);
     const int r0 = band * RB, nrows = min(RB, Ho - r0);
     const int Rmax = (RB - 1) * S + K, Rin = (nrows - 1) * S + K, iy0 = r0 * S - pad;
-    const int plane_stride = Rmax * pitch, G = pitch >> 2;                // G groups of 4 columns per staged row
+    const int plane_stride = Rmax * pitch;
     float *wl = tile + (size_t)P * plane_stride;
     SGX_THREADS_BEGIN(tid)
-    // ---- staging.  Group index g = tid + 256 k over (plane q, row ry, column group cg), cg fastest; counters advance by the constant step 256 = (dq, dry, dcg)
-    const int rows256 = 256 / G, dcg = 256 - rows256 * G, dq = rows256 / Rin, dry = rows256 - dq * Rin;
-    const int ngrp = np * Rin * G;
-    int ry = tid / G, cg = tid - ry * G, q = ry / Rin; ry -= q * Rin;
-    for (int g0 = tid; g0 < ngrp; g0 += 512) {
-        float v[2][4]; int dst[2];
-#pragma unroll
-        for (int u = 0; u < 2; u++) {                               // 8 independent loads in flight per thread before the LDS stores
-            const int qq = min(q, np - 1), iy = iy0 + ry;
-            const bool rowok = (unsigned)iy < (unsigned)H;
-            const float *src = in + ((size_t)(p0 + qq) * H + (size_t)(rowok ? iy : 0)) * W;
-#pragma unroll
-            for (int x = 0; x < 4; x++) {
-                const int ix = 4 * cg + x - pad;
-                const bool ok = rowok && (unsigned)ix < (unsigned)W;
-                const float ld = src[ok ? ix : 0];
-                v[u][x] = ok ? ld : 0.f;
-            }
-            dst[u] = g0 + 256 * u < ngrp ? qq * plane_stride + ry * pitch + 4 * cg : -1;
-            cg += dcg; const int carry = cg >= G ? 1 : 0; cg -= carry ? G : 0;
-            ry += dry + carry; q += dq; if (ry >= Rin) { ry -= Rin; q++; }
-        }
-#pragma unroll
-        for (int u = 0; u < 2; u++)
-            if (dst[u] >= 0) { sgx_f4 pk; pk.v[0] = v[u][0]; pk.v[1] = v[u][1]; pk.v[2] = v[u][2]; pk.v[3] = v[u][3]; *(sgx_f4 *)(tile + dst[u]) = pk; }
-    }
+    sgx_stage_planes4(tid, in + (size_t)p0 * H * W, np, H, W, iy0, Rin, pad, pitch, plane_stride, tile);
     for (int t = tid; t < np * KW; t += 256) {
         const int qw = t / KW, j = t - qw * KW, c = (p0 + qw) % C;
         wl[t] = j < K * K ? Wt[(size_t)c * K * K + j] : (j == K * K ? bias[c] : 0.f);
@@ -613,6 +621,82 @@ SGX_KERNEL(256) k_conv_dw2(int C, int H, int W, int Ho, int Wo, int pad, int P, 
     default: SGX_DW2_RUN(SGX_EMODE_GENERIC); break;
     }
 #undef SGX_DW2_RUN
+    SGX_THREADS_END
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_conv_stem2<INC>: the 3 x 3, stride-2 stem (INC input channels -> up to 16 output channels), lean version of k_conv_stem: a workgroup owns a band of RB output rows of
+// one image, the INC padded input bands staged by sgx_stage_planes4; one task = 4 consecutive output pixels x ALL output channels (64 accumulators): per (c, i) row three
+// aligned ds_read_b128 bring the 9 inputs, the 16 weights of a tap are wave-uniform (scalar loads from the host-transposed table WtT[(c*9 + i*3 + j)][16]) and feed 64 fmaf.
+// Accumulation order per output: c, i, j ascending (as k_conv_kxk).  Every channel's 4 results leave as one 16-byte store.  grid = (nbands, B)
+// ---------------------------------------------------------------------------------------------
+template <int INC, int MODE>
+SGX_DEV void sgx_stem2_tasks(int tid, int outc, int nrows, int nbx, int Wo, int Ho, int r0, int pitch, int plane_stride, unsigned nbx_magic,
+                             const float *tile, const float *__restrict__ WtT, const float *__restrict__ bias, float *__restrict__ out, size_t tbase, const SgxEpi &epi)
+{
+    const int ntask = nrows * nbx;
+    for (int t = tid; t < ntask; t += 256) {
+        const int oy = (int)sgx_fastdiv((unsigned)t, nbx_magic), bx = t - oy * nbx;
+        int zoff = 0;
+#ifndef SGX_EMU
+        asm volatile("" : "+s"(zoff));                            // opaque (but scalar) zero: keeps the 27 x 16 weight loads inside the task loop as scalar loads instead of 432 hoisted VGPRs
+#endif
+        float acc[16][4];
+#pragma unroll
+        for (int oc = 0; oc < 16; oc++) { const float bz = bias[min(oc, outc - 1)]; acc[oc][0] = bz; acc[oc][1] = bz; acc[oc][2] = bz; acc[oc][3] = bz; }
+#pragma unroll 1
+        for (int c = 0; c < INC; c++)                               // run-time loops over (c, i): 3 taps x 16 scalar weights live at a time
+#pragma unroll 1
+            for (int i = 0; i < 3; i++) {
+                float v[12];
+                const sgx_f4 *row = (const sgx_f4 *)(tile + c * plane_stride + (2 * oy + i) * pitch + 8 * bx);
+#pragma unroll
+                for (int g = 0; g < 3; g++) { const sgx_f4 x = row[g]; v[4 * g] = x.v[0]; v[4 * g + 1] = x.v[1]; v[4 * g + 2] = x.v[2]; v[4 * g + 3] = x.v[3]; }
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const float *w = WtT + zoff + ((c * 3 + i) * 3 + j) * 16;
+#pragma unroll
+                    for (int oc = 0; oc < 16; oc++)
+#pragma unroll
+                        for (int x = 0; x < 4; x++) acc[oc][x] = fmaf(w[oc], v[2 * x + j], acc[oc][x]);
+                }
+            }
+        const size_t pix = (size_t)(r0 + oy) * Wo + (size_t)(4 * bx);
+        const int nx = min(4, Wo - 4 * bx);
+#pragma unroll
+        for (int oc = 0; oc < 16; oc++)
+            if (oc < outc) {
+                const size_t idx = (size_t)oc * Ho * Wo + pix;
+                float res[4];
+#pragma unroll
+                for (int x = 0; x < 4; x++) res[x] = sgx_epi_mode<MODE>(epi, acc[oc][x], tbase + idx + (size_t)min(x, nx - 1), 0);
+                if (nx == 4) { sgx_f4 pk; pk.v[0] = res[0]; pk.v[1] = res[1]; pk.v[2] = res[2]; pk.v[3] = res[3]; memcpy(out + idx, &pk, 16); }
+                else for (int x = 0; x < nx; x++) out[idx + x] = res[x];
+            }
+    }
+}
+
+template <int INC>
+SGX_KERNEL(256) k_conv_stem2(int outc, int H, int W, int Ho, int Wo, int pad, int RB, int pitch, unsigned nbx_magic,
+                             const float *__restrict__ in, size_t in_pitch, const float *__restrict__ WtT, const float *__restrict__ bias, float *__restrict__ out, size_t out_pitch, SgxEpi epi)
+{
+    SGX_DYN_LDS(smem);
+    float *tile = (float *)smem;
+    const int b = (int)blockIdx.y, r0 = (int)blockIdx.x * RB, nrows = min(RB, Ho - r0);
+    const int Rmax = (RB - 1) * 2 + 3, Rin = (nrows - 1) * 2 + 3, iy0 = r0 * 2 - pad, plane_stride = Rmax * pitch;
+    SGX_THREADS_BEGIN(tid)
+    sgx_stage_planes4(tid, in + (size_t)b * in_pitch, INC, H, W, iy0, Rin, pad, pitch, plane_stride, tile);
+    SGX_THREADS_END
+    SGX_SYNC();
+    const int nbx = (Wo + 3) >> 2;
+    SGX_THREADS_BEGIN(tid)
+#define SGX_STEM2_RUN(M) sgx_stem2_tasks<INC, M>(tid, outc, nrows, nbx, Wo, Ho, r0, pitch, plane_stride, nbx_magic, tile, WtT, bias, out + (size_t)b * out_pitch, (size_t)b * epi.tpitch, epi)
+    switch (epi.mode) {
+    case SGX_EMODE_NONE: SGX_STEM2_RUN(SGX_EMODE_NONE); break;
+    case SGX_EMODE_ACT: SGX_STEM2_RUN(SGX_EMODE_ACT); break;
+    default: SGX_STEM2_RUN(SGX_EMODE_HSWISH); break;             // the host launches this kernel for these three programs only
+    }
+#undef SGX_STEM2_RUN
     SGX_THREADS_END
 }
 
