@@ -258,7 +258,7 @@ SGX_KERNEL(SGX_FAST_THREADS) k_fast_cells(SgxOrbGeom g, const SgxCell *cells, co
     uint8_t *score = (uint8_t *)pool + g.fast_off_score;                    // threshold-free FAST score map, same layout
     uint16_t *qlist = (uint16_t *)((uint8_t *)pool + g.fast_off_qlist);     // survivors of the quick test; bit 15 = is a corner
     uint32_t *outbuf = (uint32_t *)((uint8_t *)pool + g.fast_off_out);      // NMS survivors (packed candidates)
-    SGX_LDS int n_corner, n_hi, n_lo, out_base, n_quick;
+    SGX_LDS int n_lo, out_base, n_quick;
     const uint8_t *tile = (const uint8_t *)tile_dw;
 
     // block -> (cell, frame): frame fastest so that frame f stays on XCD f%8 (block b -> XCD b%8)
@@ -274,7 +274,7 @@ SGX_KERNEL(SGX_FAST_THREADS) k_fast_cells(SgxOrbGeom g, const SgxCell *cells, co
 
     // phase A: stage the tile rows as aligned dwords (coalesced global loads, one LDS dword store each); zero the score map
     SGX_THREADS_BEGIN(tid)
-    if (tid == 0) { n_corner = 0; n_hi = 0; n_lo = 0; n_quick = 0; }
+    if (tid == 0) { n_lo = 0; n_quick = 0; }
     for (int i = tid; i < ch * SD; i += (int)blockDim.x) {
         const int r = i / SD, q = i - r * SD;
         tile_dw[i] = q < ndw ? *(const uint32_t *)(img + (size_t)(c.y0 + r) * stride + xa + 4 * q) : 0u;
@@ -283,126 +283,131 @@ SGX_KERNEL(SGX_FAST_THREADS) k_fast_cells(SgxOrbGeom g, const SgxCell *cells, co
     SGX_THREADS_END
     SGX_SYNC();
 
-    // phase B1: necessary condition on every interior pixel.  A 9-pixel arc of the 16-ring contains one pixel of every antipodal
-    // pair, so a corner needs (p0|p8) & (p4|p12) all-brighter or all-darker (the high-speed test cv::FAST itself starts with).
-    // A task = 4 horizontally adjacent pixels: the compass pixels come from 7 aligned LDS dwords.  Survivors are compacted.
+    // Two passes, as the reference: FAST at iniThFAST first; only a cell that yields no corner is searched again at minThFAST (ORBextractor.cc:806-817).  The
+    // segment test, the threshold-free score and the 3x3 NMS of a pass see exactly the corners cv::FAST(threshold) sees: a pixel is a corner at threshold t iff its
+    // score >= t, and a neighbour that is not a corner at t has a score below t, so it cannot suppress one that is (cv::FAST scores it 0).  Textured cells — the
+    // common case — never pay for the low-threshold pass, whose quick test lets several times more pixels through.
     const int ih = ch - 6, ng = (lead + cw + 3) >> 2;
-    SGX_THREADS_BEGIN(tid)
-    for (int t = tid; t < ih * ng; t += (int)blockDim.x) {
-        const int y = 3 + t / ng, gq = t % ng;
-        const int x0 = 4 * gq + 3 - lead;                                   // tile column of the first pixel of the group
-        if (x0 + 3 < 3 || x0 >= cw - 3) continue;
-        const uint32_t *rc = tile_dw + y * SD + gq, *rp = rc + 3 * SD, *rm = rc - 3 * SD;
-        const bool has1 = gq + 1 < SD, has2 = gq + 2 < SD;
-        const uint32_t C0 = rc[0], C1 = has1 ? rc[1] : 0u, C2 = has2 ? rc[2] : 0u;
-        const uint32_t P0 = rp[0], P1 = has1 ? rp[1] : 0u, M0 = rm[0], M1 = has1 ? rm[1] : 0u;
-        // the 4 pixels of the task as packed bytes: centre v (tile bytes 3..6 of the group), the compass pixels below / above (same columns of rows
-        // y+3 / y-3) and right / left (bytes 6..9 / 0..3), then as two sets of 2 x u16 (even / odd pixels) for the packed saturating compares:
-        //   brighter  <=>  usubsat(r, v + t) != 0      darker  <=>  usubsat(usubsat(v, t), r) != 0
-        const uint32_t V = sgx_alignbyte(C1, C0, 3), R4 = sgx_alignbyte(C2, C1, 2), R12 = C0, R0 = sgx_alignbyte(P1, P0, 3), R8 = sgx_alignbyte(M1, M0, 3);
-        const uint32_t T2 = (uint32_t)thr_lo * 0x00010001u;
-        uint32_t any[2];
-#pragma unroll
-        for (int s2 = 0; s2 < 2; s2++) {
-            const int sh = 8 * s2;
-            const uint32_t v = (V >> sh) & 0x00FF00FFu, r0 = (R0 >> sh) & 0x00FF00FFu, r8 = (R8 >> sh) & 0x00FF00FFu, r4 = (R4 >> sh) & 0x00FF00FFu, r12 = (R12 >> sh) & 0x00FF00FFu;
-            const uint32_t hi = v + T2, lo = sgx_pk_usubsat_u16(v, T2);
-            const uint32_t br = sgx_pk_min_u16(sgx_pk_usubsat_u16(r0, hi) | sgx_pk_usubsat_u16(r8, hi), sgx_pk_usubsat_u16(r4, hi) | sgx_pk_usubsat_u16(r12, hi));
-            const uint32_t dk = sgx_pk_min_u16(sgx_pk_usubsat_u16(lo, r0) | sgx_pk_usubsat_u16(lo, r8), sgx_pk_usubsat_u16(lo, r4) | sgx_pk_usubsat_u16(lo, r12));
-            any[s2] = br | dk;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int x = x0 + i;
-            const uint32_t f = (any[i & 1] >> (16 * (i >> 1))) & 0xFFFFu;          // pixel i = half (i>>1) of set (i&1)
-            if (x >= 3 && x < cw - 3 && f) {
-                const int slot = sgx_atomic_add(&n_quick, 1);
-                qlist[slot] = (uint16_t)(y * SGX_TILE_STRIDE + lead + x);
+    for (int pass = 0; pass < 2; pass++) {
+        const int thr = pass == 0 ? thr_hi : thr_lo;
+        // phase B1: necessary condition on every interior pixel.  A 9-pixel arc of the 16-ring contains one pixel of every antipodal
+        // pair, so a corner needs (p0|p8) & (p4|p12) all-brighter or all-darker (the high-speed test cv::FAST itself starts with).
+        // A task = 4 horizontally adjacent pixels: the compass pixels come from 7 aligned LDS dwords.  Survivors are compacted.
+        SGX_THREADS_BEGIN(tid)
+        for (int t = tid; t < ih * ng; t += (int)blockDim.x) {
+            const int y = 3 + t / ng, gq = t % ng;
+            const int x0 = 4 * gq + 3 - lead;                                   // tile column of the first pixel of the group
+            if (x0 + 3 < 3 || x0 >= cw - 3) continue;
+            const uint32_t *rc = tile_dw + y * SD + gq, *rp = rc + 3 * SD, *rm = rc - 3 * SD;
+            const bool has1 = gq + 1 < SD, has2 = gq + 2 < SD;
+            const uint32_t C0 = rc[0], C1 = has1 ? rc[1] : 0u, C2 = has2 ? rc[2] : 0u;
+            const uint32_t P0 = rp[0], P1 = has1 ? rp[1] : 0u, M0 = rm[0], M1 = has1 ? rm[1] : 0u;
+            // the 4 pixels of the task as packed bytes: centre v (tile bytes 3..6 of the group), the compass pixels below / above (same columns of rows
+            // y+3 / y-3) and right / left (bytes 6..9 / 0..3), then as two sets of 2 x u16 (even / odd pixels) for the packed saturating compares:
+            //   brighter  <=>  usubsat(r, v + t) != 0      darker  <=>  usubsat(usubsat(v, t), r) != 0
+            const uint32_t V = sgx_alignbyte(C1, C0, 3), R4 = sgx_alignbyte(C2, C1, 2), R12 = C0, R0 = sgx_alignbyte(P1, P0, 3), R8 = sgx_alignbyte(M1, M0, 3);
+            const uint32_t T2 = (uint32_t)thr * 0x00010001u;
+            uint32_t any[2];
+    #pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) {
+                const int sh = 8 * s2;
+                const uint32_t v = (V >> sh) & 0x00FF00FFu, r0 = (R0 >> sh) & 0x00FF00FFu, r8 = (R8 >> sh) & 0x00FF00FFu, r4 = (R4 >> sh) & 0x00FF00FFu, r12 = (R12 >> sh) & 0x00FF00FFu;
+                const uint32_t hi = v + T2, lo = sgx_pk_usubsat_u16(v, T2);
+                const uint32_t br = sgx_pk_min_u16(sgx_pk_usubsat_u16(r0, hi) | sgx_pk_usubsat_u16(r8, hi), sgx_pk_usubsat_u16(r4, hi) | sgx_pk_usubsat_u16(r12, hi));
+                const uint32_t dk = sgx_pk_min_u16(sgx_pk_usubsat_u16(lo, r0) | sgx_pk_usubsat_u16(lo, r8), sgx_pk_usubsat_u16(lo, r4) | sgx_pk_usubsat_u16(lo, r12));
+                any[s2] = br | dk;
+            }
+    #pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int x = x0 + i;
+                const uint32_t f = (any[i & 1] >> (16 * (i >> 1))) & 0xFFFFu;          // pixel i = half (i>>1) of set (i&1)
+                if (x >= 3 && x < cw - 3 && f) {
+                    const int slot = sgx_atomic_add(&n_quick, 1);
+                    qlist[slot] = (uint16_t)(y * SGX_TILE_STRIDE + lead + x);
+                }
             }
         }
-    }
-    SGX_THREADS_END
-    SGX_SYNC();
+        SGX_THREADS_END
+        SGX_SYNC();
 
-    // phase B2: full segment test (>= 9 contiguous ring pixels brighter than v+t or darker than v-t) on the survivors.
-    // The two 16-bit ring masks are shifted in from sign bits with v_alignbit (2 VALU per ring pixel and polarity).
-    SGX_THREADS_BEGIN(tid)
-    for (int t = tid; t < n_quick; t += (int)blockDim.x) {
-        const int pos = qlist[t];
-        const uint8_t *p = tile + pos;
-        const int v = p[0], lo = v - thr_lo, hi = v + thr_lo;
-        int r[16];                                                    // the 16 ring pixels, clockwise from (0, +3) — loaded once for the mask test and the score
-        r[0] = p[3 * SGX_TILE_STRIDE];       r[1] = p[3 * SGX_TILE_STRIDE + 1];  r[2] = p[2 * SGX_TILE_STRIDE + 2];
-        r[3] = p[SGX_TILE_STRIDE + 3];       r[4] = p[3];                        r[5] = p[-SGX_TILE_STRIDE + 3];
-        r[6] = p[-2 * SGX_TILE_STRIDE + 2];  r[7] = p[-3 * SGX_TILE_STRIDE + 1]; r[8] = p[-3 * SGX_TILE_STRIDE];
-        r[9] = p[-3 * SGX_TILE_STRIDE - 1];  r[10] = p[-2 * SGX_TILE_STRIDE - 2]; r[11] = p[-SGX_TILE_STRIDE - 3];
-        r[12] = p[-3];                       r[13] = p[SGX_TILE_STRIDE - 3];     r[14] = p[2 * SGX_TILE_STRIDE - 2];
-        r[15] = p[3 * SGX_TILE_STRIDE - 1];
-        uint32_t mb = 0, md = 0;
-#pragma unroll
-        for (int k = 0; k < 16; k++) { mb = sgx_alignbit(mb, (uint32_t)(hi - r[k]), 31); md = sgx_alignbit(md, (uint32_t)(r[k] - lo), 31); }
-        if (!(sgx_has9(mb & 0xFFFFu) | sgx_has9(md & 0xFFFFu))) continue;
-        qlist[t] = (uint16_t)(pos | 0x8000);                          // pos < 68*72 < 2^15
-        // threshold-free score of the corner, in the same pass (phase C of the first version cost one more barrier and one more walk of the list)
-        int d[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) d[k] = v - r[k];
-        int mn2[16], mx2[16], mn4[16], mx4[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
-#pragma unroll
-        for (int k = 0; k < 16; k++) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
-        int A = -512, Bm = 512;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int mn9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
-            const int mx9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
-            A = max(A, mn9); Bm = min(Bm, mx9);
+        // phase B2: full segment test (>= 9 contiguous ring pixels brighter than v+t or darker than v-t) on the survivors.
+        // The two 16-bit ring masks are shifted in from sign bits with v_alignbit (2 VALU per ring pixel and polarity).
+        SGX_THREADS_BEGIN(tid)
+        for (int t = tid; t < n_quick; t += (int)blockDim.x) {
+            const int pos = qlist[t];
+            const uint8_t *p = tile + pos;
+            const int v = p[0], lo = v - thr, hi = v + thr;
+            int r[16];                                                    // the 16 ring pixels, clockwise from (0, +3) — loaded once for the mask test and the score
+            r[0] = p[3 * SGX_TILE_STRIDE];       r[1] = p[3 * SGX_TILE_STRIDE + 1];  r[2] = p[2 * SGX_TILE_STRIDE + 2];
+            r[3] = p[SGX_TILE_STRIDE + 3];       r[4] = p[3];                        r[5] = p[-SGX_TILE_STRIDE + 3];
+            r[6] = p[-2 * SGX_TILE_STRIDE + 2];  r[7] = p[-3 * SGX_TILE_STRIDE + 1]; r[8] = p[-3 * SGX_TILE_STRIDE];
+            r[9] = p[-3 * SGX_TILE_STRIDE - 1];  r[10] = p[-2 * SGX_TILE_STRIDE - 2]; r[11] = p[-SGX_TILE_STRIDE - 3];
+            r[12] = p[-3];                       r[13] = p[SGX_TILE_STRIDE - 3];     r[14] = p[2 * SGX_TILE_STRIDE - 2];
+            r[15] = p[3 * SGX_TILE_STRIDE - 1];
+            uint32_t mb = 0, md = 0;
+    #pragma unroll
+            for (int k = 0; k < 16; k++) { mb = sgx_alignbit(mb, (uint32_t)(hi - r[k]), 31); md = sgx_alignbit(md, (uint32_t)(r[k] - lo), 31); }
+            if (!(sgx_has9(mb & 0xFFFFu) | sgx_has9(md & 0xFFFFu))) continue;
+            qlist[t] = (uint16_t)(pos | 0x8000);                          // pos < 68*72 < 2^15
+            // threshold-free score of the corner, in the same pass (phase C of the first version cost one more barrier and one more walk of the list)
+            int d[16];
+    #pragma unroll
+            for (int k = 0; k < 16; k++) d[k] = v - r[k];
+            int mn2[16], mx2[16], mn4[16], mx4[16];
+    #pragma unroll
+            for (int k = 0; k < 16; k++) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
+    #pragma unroll
+            for (int k = 0; k < 16; k++) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
+            int A = -512, Bm = 512;
+    #pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int mn9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
+                const int mx9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
+                A = max(A, mn9); Bm = min(Bm, mx9);
+            }
+            const int s = max(A, -Bm) - 1;
+            score[pos] = (uint8_t)s;
         }
-        const int s = max(A, -Bm) - 1;
-        score[pos] = (uint8_t)s;
-    }
-    SGX_THREADS_END
-    SGX_SYNC();
+        SGX_THREADS_END
+        SGX_SYNC();
 
-    // phase D: NMS (strict > over the 8 neighbours; apron and non-corners are 0), count survivors
-    SGX_THREADS_BEGIN(tid)
-    for (int i = tid; i < n_quick; i += (int)blockDim.x) {
-        if (!(qlist[i] & 0x8000)) continue;
-        const int pos = qlist[i] & 0x7FFF;
-        const uint8_t *s = score + pos;
-        const int v = s[0];
-        const bool mx = v > s[-1] && v > s[1] && v > s[-SGX_TILE_STRIDE - 1] && v > s[-SGX_TILE_STRIDE] && v > s[-SGX_TILE_STRIDE + 1] &&
-                        v > s[SGX_TILE_STRIDE - 1] && v > s[SGX_TILE_STRIDE] && v > s[SGX_TILE_STRIDE + 1];
-        if (mx && v >= thr_lo) {
-            if (v >= thr_hi) sgx_atomic_add(&n_hi, 1);
-            const int slot = sgx_atomic_add(&n_lo, 1);
-            const int y = pos / SGX_TILE_STRIDE, x = pos - y * SGX_TILE_STRIDE - lead;
-            outbuf[slot] = (uint32_t)(x + c.ox) | ((uint32_t)(y + c.oy) << 12) | ((uint32_t)v << 24);
+        // phase D: NMS (strict > over the 8 neighbours; apron and non-corners are 0), count survivors
+        SGX_THREADS_BEGIN(tid)
+        for (int i = tid; i < n_quick; i += (int)blockDim.x) {
+            if (!(qlist[i] & 0x8000)) continue;
+            const int pos = qlist[i] & 0x7FFF;
+            const uint8_t *s = score + pos;
+            const int v = s[0];
+            const bool mx = v > s[-1] && v > s[1] && v > s[-SGX_TILE_STRIDE - 1] && v > s[-SGX_TILE_STRIDE] && v > s[-SGX_TILE_STRIDE + 1] &&
+                            v > s[SGX_TILE_STRIDE - 1] && v > s[SGX_TILE_STRIDE] && v > s[SGX_TILE_STRIDE + 1];
+            if (mx && v >= thr) {
+                const int slot = sgx_atomic_add(&n_lo, 1);
+                const int y = pos / SGX_TILE_STRIDE, x = pos - y * SGX_TILE_STRIDE - lead;
+                outbuf[slot] = (uint32_t)(x + c.ox) | ((uint32_t)(y + c.oy) << 12) | ((uint32_t)v << 24);
+            }
         }
-    }
-    SGX_THREADS_END
-    SGX_SYNC();
+        SGX_THREADS_END
+        SGX_SYNC();
 
-    // phase E: pick the threshold, reserve space in the (frame, level) list, emit
-    const int use_thr = n_hi > 0 ? thr_hi : thr_lo;
-    const int n_emit = n_hi > 0 ? n_hi : n_lo;
+        if (n_lo > 0 || thr_hi == thr_lo) break;                      // uniform: n_lo is final after the barrier above
+        SGX_THREADS_BEGIN(tid) if (tid == 0) n_quick = 0; SGX_THREADS_END
+        SGX_SYNC();
+    }
+
+    // phase E: reserve space in the (frame, level) list, emit the NMS survivors of the pass that found corners
+    const int n_emit = n_lo;
     SGX_THREADS_BEGIN(tid)
     if (tid == 0 && n_emit > 0) out_base = sgx_atomic_add(&cand_count[frame * g.nlevels + level], n_emit);
-    if (tid == 0) n_corner = 0;       // reuse as emit cursor
     SGX_THREADS_END
     SGX_SYNC();
     if (n_emit > 0) {
         uint32_t *dst = cand + (size_t)frame * g.cand_pitch + g.lv[level].cand_off;
         const int dcap = g.lv[level].cand_cap;
         SGX_THREADS_BEGIN(tid)
-        for (int i = tid; i < n_lo; i += (int)blockDim.x) {
-            const uint32_t e = outbuf[i];
-            if ((int)(e >> 24) >= use_thr) {
-                const int slot = out_base + sgx_atomic_add(&n_corner, 1);
-                if (slot < dcap) dst[slot] = e;
-                else sgx_atomic_or(status, SGX_ST_CAND_OVERFLOW);
-            }
+        for (int i = tid; i < n_emit; i += (int)blockDim.x) {
+            const int slot = out_base + i;
+            if (slot < dcap) dst[slot] = outbuf[i];
+            else sgx_atomic_or(status, SGX_ST_CAND_OVERFLOW);
         }
         SGX_THREADS_END
     }
