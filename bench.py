@@ -330,6 +330,13 @@ def main():
             if 'fp64_gflop_per_frame' in ik:
                 e['fp64_frac'] = round(ik['fp64_gflop_per_frame'] * S / (avg_ms * 1e-3) / 1e3 / FP64_PEAK_TFS, 4)
         per_kernel[k] = e
+    try:        # launch durations with nothing else on the GPU (the timed region above runs three streams at once: every kernel there shares CUs with the detector graph)
+        sj = json.load(open(os.path.join(ROOT, 'profiles', 'r2_standalone.json')))
+        if sj['frames_per_launch'] == S:
+            for k, v in sj['avg_ms_per_launch'].items():
+                if k in per_kernel: per_kernel[k]['standalone_avg_ms_per_launch'] = round(v, 5)
+    except Exception:
+        pass
     dom = max(per_kernel, key=lambda k: per_kernel[k]['total_ms'])
     dk = per_kernel[dom]
     traffic = None

@@ -22,17 +22,32 @@ timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format cs
 timeout 200 python $R/tools/prof_det_ops.py 256 5 > $O/detector_ops_b256.txt 2>/dev/null
 timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace --output-format csv -d $O/det_sq -o p -- python $R/tools/prof_det_ops.py 256 2 > /dev/null 2>&1
 timeout -s KILL 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/det_mfma -o p -- python $R/tools/prof_det_ops.py 256 2 > /dev/null 2>&1
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/det_fetch -o p -- python $R/tools/prof_det_ops.py 256 2 > /dev/null 2>&1
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/det_write -o p -- python $R/tools/prof_det_ops.py 256 2 > /dev/null 2>&1
 cd $R
 f() { find $O/$1 -name "*counter_collection.csv" | head -1; }
-python tools/pmc_traffic.py $(f fetch) $(f write) 256 4 $O/traffic.json $O/bench_under_rocprof.json > /dev/null
+python tools/pmc_traffic.py --det $(f det_fetch) $(f det_write) 3 $(f fetch) $(f write) 256 4 $O/traffic.json $O/bench_under_rocprof.json > /dev/null
 python tools/pmc_insts.py $O/pmc_insts.json 256 4 $(f sq_a) $(f sq_b) --det $(f det_sq) 256 $(python - <<PY
 import csv
 n = sum(1 for r in csv.DictReader(open("$(f det_sq)")) if r['Counter_Name'] == 'SQ_WAVES' and 'k_det_preprocess' in r['Kernel_Name'])
 print(max(n, 1))
 PY
 ) > $O/pmc_insts.txt
-for d in sq_a sq_b fetch write det_sq det_mfma; do python tools/pmc_summary.py $(f $d) > $O/pmc_$d.txt 2>/dev/null; done
-# 5. standalone stage benches
+for d in sq_a sq_b fetch write det_sq det_mfma det_fetch det_write; do python tools/pmc_summary.py $(f $d) > $O/pmc_$d.txt 2>/dev/null; done
+# 5. standalone kernel times: the chain on ONE stream without the detector (no kernel shares the GPU with another), the detector on its own
+timeout 300 python bench.py --no-cpu-baseline --no-detector --no-config2 --no-pipeline > $O/bench_serial.json 2>/dev/null
+timeout 200 python tools/prof_det_output.py 256 10 > $O/det_standalone.txt 2>/dev/null
+python - <<PY
+import json, re
+j = json.load(open("$O/bench_serial.json")); pk = j["roofline"]["per_kernel"]
+res = {k: pk[k]["avg_ms_per_launch"] for k in pk}
+for l in open("$O/det_standalone.txt"):
+    m = re.match(r"(det_\w+)\s+([\d.]+) ms per launch", l)
+    if m: res[m.group(1)] = float(m.group(2))
+json.dump({"note": "average launch duration with nothing else on the GPU: bench.py --no-detector --no-pipeline (one stream) for the chain, tools/prof_det_output.py for the detector; 256 frames per launch",
+           "frames_per_launch": 256, "avg_ms_per_launch": res}, open("$O/standalone.json", "w"), indent=1)
+PY
+# 6. standalone stage benches
 timeout 100 python tools/bench_flow.py > $O/flow.txt 2>/dev/null
 timeout 100 python tools/bench_ba.py > $O/localba.json 2>/dev/null
 timeout 100 python tools/bench_ba_big.py 500 12000 > $O/ba_500.json 2>/dev/null
