@@ -455,7 +455,8 @@ static void run_op(sgx_det *h, const Op &op, int batch, sgx_stream_t st)
         break; }
     case OP_KXK: {
         const SgxEpi e = make_epi(h, op, (size_t)op.outc * op.Ho * op.Wo);
-        const int budget = 8192;                                        // floats of LDS per workgroup for the staged input
+        static const int budget_env = getenv("SGX_DW_BUDGET") ? atoi(getenv("SGX_DW_BUDGET")) : 8192;
+        const int budget = budget_env;                                  // floats of LDS per workgroup for the staged input
         const int Wp = (op.Wo - 1) * op.stride + op.k;
         auto magic = [](int d) -> unsigned { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
         const int nbx4 = (op.Wo + 3) / 4, pitch4 = ((nbx4 - 1) * 4 * op.stride + 3 * op.stride + op.k + 3) & ~3;

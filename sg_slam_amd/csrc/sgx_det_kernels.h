@@ -518,6 +518,9 @@ SGX_KERNEL(256) k_conv_dw(int C, int H, int W, int Ho, int Wo, int stride, int p
 // ---------------------------------------------------------------------------------------------
 struct alignas(16) sgx_f4 { float v[4]; };
 
+#ifndef SGX_STAGE_U
+#define SGX_STAGE_U 4
+#endif
 // LDS staging shared by k_conv_dw2 / k_conv_stem2: np planes (plane q at in + q * H * W), rows iy0 .. iy0 + Rin - 1, padded columns 0 .. pitch - 1 (column cx = input
 // column cx - pad), zeros outside the image; tile[q][ry][cx] with plane stride plane_stride.  One group of 4 columns per thread and step (4 scalar global loads, one
 // ds_write_b128); the group index g = tid + 256 k runs over (q, ry, column group cg), cg fastest, and the counters advance by the constant step 256 = (dq, dry, dcg).
@@ -527,10 +530,10 @@ SGX_DEV void sgx_stage_planes4(int tid, const float *in, int np, int H, int W, i
     const int rows256 = 256 / G, dcg = 256 - rows256 * G, dq = rows256 / Rin, dry = rows256 - dq * Rin;
     const int ngrp = np * Rin * G;
     int ry = tid / G, cg = tid - ry * G, q = ry / Rin; ry -= q * Rin;
-    for (int g0 = tid; g0 < ngrp; g0 += 512) {
-        float v[2][4]; int dst[2];
+    for (int g0 = tid; g0 < ngrp; g0 += 256 * SGX_STAGE_U) {
+        float v[SGX_STAGE_U][4]; int dst[SGX_STAGE_U];
 #pragma unroll
-        for (int u = 0; u < 2; u++) {                               // 8 independent loads in flight per thread before the LDS stores
+        for (int u = 0; u < SGX_STAGE_U; u++) {                     // 4 SGX_STAGE_U independent loads in flight per thread before the LDS stores
             const int qq = min(q, np - 1), iy = iy0 + ry;
             const bool rowok = (unsigned)iy < (unsigned)H;
             const float *src = in + ((size_t)qq * H + (size_t)(rowok ? iy : 0)) * W;
@@ -546,7 +549,7 @@ SGX_DEV void sgx_stage_planes4(int tid, const float *in, int np, int H, int W, i
             ry += dry + carry; q += dq; if (ry >= Rin) { ry -= Rin; q++; }
         }
 #pragma unroll
-        for (int u = 0; u < 2; u++)
+        for (int u = 0; u < SGX_STAGE_U; u++)
             if (dst[u] >= 0) { sgx_f4 pk; pk.v[0] = v[u][0]; pk.v[1] = v[u][1]; pk.v[2] = v[u][2]; pk.v[3] = v[u][3]; *(sgx_f4 *)(tile + dst[u]) = pk; }
     }
 }
