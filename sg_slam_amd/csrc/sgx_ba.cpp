@@ -50,7 +50,7 @@ struct BA {
     // device
     SgxBaEdge *E; SgxSE3 *T, *Tb; double *X, *Xb, *err, *Hll, *bl, *Hpl, *Hpp, *bp, *S, *coef, *xp, *xl, *Dinv, *dwork, *partial;
     int *pt_start, *pt_edges, *pose_start, *pose_edges, *hidx, *free_pose, *ok; uint8_t *pt_active;
-    SgxBaJob *jobs; double *Linv, *xsol; long long njobs; size_t jobs_cap;
+    SgxBaJob *jobs; int *blk_start; double *Linv, *xsol; long long njobs, nblk; size_t jobs_cap;
     double *part_chi, *part_scale;      // device scalars block: [ok | part_scale[nblk_v] | part_chi[nblk_e]] read back with ONE copy per trial
     int nblk_e, nblk_v;
     std::vector<double> hpart;
@@ -101,9 +101,22 @@ static int build_jobs(BA &B, const std::vector<int> &pt_start, const std::vector
         for (int q = pt_start[l]; q < pt_start[l + 1]; q++) { const int k = pt_edges[q]; if (!level1[k] && hidx[E[k].pose] >= 0) act.push_back(k); }
         for (int k1 : act) for (int k2 : act) jobs.push_back(SgxBaJob{k1, k2});
     }
-    B.njobs = (long long)jobs.size();
+    B.njobs = (long long)jobs.size(); B.nblk = 0;
     if (jobs.size() > B.jobs_cap) return SGX_ERR_NOMEM;
-    if (!jobs.empty()) SGX_CHECK_HIP(hipMemcpy(B.jobs, jobs.data(), sizeof(SgxBaJob) * jobs.size(), hipMemcpyHostToDevice));
+    if (jobs.empty()) return SGX_OK;
+    // stable counting sort by destination block (i1, i2) of the reduced system: inside a block the jobs keep landmark order, the order in which the reference
+    // subtracts them (block_solver.hpp:380-433); k_ba_schur_pairs then sums every block sequentially, without atomics
+    const size_t nkeys = (size_t)B.nf * B.nf;
+    std::vector<int> count(nkeys + 1, 0);
+    auto key = [&](const SgxBaJob &j) { return (size_t)hidx[E[j.k1].pose] * B.nf + hidx[E[j.k2].pose]; };
+    for (const SgxBaJob &j : jobs) count[key(j) + 1]++;
+    std::vector<int> blk_start; blk_start.reserve(jobs.size() + 1);
+    { int run = 0; for (size_t k = 0; k < nkeys; k++) { const int c = count[k + 1]; count[k] = run; if (c) blk_start.push_back(run); run += c; } blk_start.push_back(run); }
+    std::vector<SgxBaJob> sorted(jobs.size());
+    for (const SgxBaJob &j : jobs) sorted[(size_t)count[key(j)]++] = j;
+    B.nblk = (long long)blk_start.size() - 1;
+    SGX_CHECK_HIP(hipMemcpy(B.jobs, sorted.data(), sizeof(SgxBaJob) * sorted.size(), hipMemcpyHostToDevice));
+    SGX_CHECK_HIP(hipMemcpy(B.blk_start, blk_start.data(), sizeof(int) * blk_start.size(), hipMemcpyHostToDevice));
     return SGX_OK;
 }
 
@@ -137,8 +150,8 @@ static int optimize(BA &B, int iterations, int *iters_done, double *final_chi)
             }
             SGX_LAUNCH(k_ba_dinv, dim3((B.nl + SGX_BA_THREADS - 1) / SGX_BA_THREADS), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.nl, B.pt_active, B.Hll, lambda, B.Dinv);
             if (B.njobs > 0) {
-                const long long n36 = B.njobs * 36;
-                SGX_LAUNCH(k_ba_schur_pairs, dim3((unsigned)((n36 + SGX_BA_THREADS - 1) / SGX_BA_THREADS)), dim3(SGX_BA_THREADS), (sgx_stream_t)0, n36, B.nf, B.jobs, B.E,
+                const long long n36 = B.nblk * 36;
+                SGX_LAUNCH(k_ba_schur_pairs, dim3((unsigned)((n36 + SGX_BA_THREADS - 1) / SGX_BA_THREADS)), dim3(SGX_BA_THREADS), (sgx_stream_t)0, n36, B.nf, B.blk_start, B.jobs, B.E,
                            B.hidx, B.bl, B.Hpl, B.Dinv, B.S, B.coef);
             }
             // workgroup sizes of the single-workgroup solver kernels (env = tuning taps): their phases are short, so fewer waves mean cheaper barriers
@@ -276,7 +289,7 @@ static int ba_run(const sgx_ba_problem *P, const sgx_camera *cam, const volatile
         A.take(&B.Dinv, 9 * (size_t)B.nl); A.take(&B.dwork, B.NP); A.take(&B.partial, B.nblk_v);
         { double *blk = nullptr; A.take(&blk, 1 + (size_t)B.nblk_v + B.nblk_e); B.ok = (int *)blk; B.part_scale = blk ? blk + 1 : nullptr; B.part_chi = blk ? blk + 1 + B.nblk_v : nullptr; }
         A.take(&B.pt_active, B.nl); A.take(&derase, B.ne);
-        A.take(&B.jobs, jobs_cap); A.take(&B.Linv, (size_t)((B.NP + SGX_NB - 1) / SGX_NB) * SGX_NB * SGX_NB);
+        A.take(&B.jobs, jobs_cap); A.take(&B.blk_start, jobs_cap + 1); A.take(&B.Linv, (size_t)((B.NP + SGX_NB - 1) / SGX_NB) * SGX_NB * SGX_NB);
         const size_t total = A.off;
         A.base = save;
         if (pass == 0) { if ((rc = A.reserve(total)) != SGX_OK) return rc; }

@@ -784,8 +784,7 @@ SGX_KERNEL(256) k_chol_back_step(int n, int k0, const double *S, const double *L
 // ---------------------------------------------------------------------------------------------
 // k_ba_schur_pairs: the Schur complement (block_solver.hpp:380-433) as one thread per (job, entry): a job is a pair of
 // active free-pose edges (k1, k2) of one landmark (host-built list, static during one optimize() call); the 36 threads of a
-// job each produce one entry of  Hpl_1 Dinv Hpl_2^T  and subtract it from S(i1,i2) with an fp64 atomic; the diagonal jobs'
-// first 6 threads also add coef(i1) += Hpl_1 (Dinv bl).  (Summation order differs from the reference by rounding only.)
+// job produce the 36 entries of  Hpl_1 Dinv Hpl_2^T,  which are subtracted from S(i1,i2); the diagonal jobs also add coef(i1) += Hpl_1 (Dinv bl).
 // k_ba_dinv (one thread per landmark) computes Dinv = (Hll + lambda I)^-1 first (closed form = Eigen Matrix3d::inverse()).
 // ---------------------------------------------------------------------------------------------
 SGX_KERNEL(SGX_BA_THREADS) k_ba_dinv(int nl, const uint8_t *pt_active, const double *Hll, double lambda, double *Dinv)
@@ -816,27 +815,38 @@ SGX_KERNEL(SGX_BA_THREADS) k_ba_dinv(int nl, const uint8_t *pt_active, const dou
 
 struct SgxBaJob { int k1, k2; };
 
-SGX_KERNEL(SGX_BA_THREADS) k_ba_schur_pairs(long long njobs36, int nf, const SgxBaJob *jobs, const SgxBaEdge *E, const int *hidx,
+// Jobs arrive sorted by destination block (i1, i2) of the reduced system, landmark order inside a block (host: stable counting sort, once per active edge set).
+// One thread per (destination block, entry): it starts from the value k_ba_schur_init left in S and subtracts the block's contributions ONE BY ONE IN LANDMARK
+// ORDER — the order in which block_solver.hpp:380-433 visits them — and writes the entry once.  No atomics: the reduced system, hence the whole optimisation,
+// is bit-reproducible from run to run.  The diagonal jobs (k1 == k2) of a diagonal block also accumulate coef(i1) += Hpl_1 (Dinv bl), same order.
+SGX_KERNEL(SGX_BA_THREADS) k_ba_schur_pairs(long long nblk36, int nf, const int *blk_start, const SgxBaJob *jobs, const SgxBaEdge *E, const int *hidx,
                                             const double *bl, const double *Hpl, const double *Dinv, double *S, double *coef)
 {
     SGX_THREADS_BEGIN(tid)
     const long long g = (long long)blockIdx.x * SGX_BA_THREADS + tid;
-    if (g < njobs36) {
-        const int job = (int)(g / 36), ent = (int)(g % 36), a = ent / 6, c = ent % 6;
-        const SgxBaJob jb = jobs[job];
-        const SgxBaEdge e1 = E[jb.k1], e2 = E[jb.k2];
-        const int i1 = hidx[e1.pose], i2 = hidx[e2.pose], l = e1.point;
-        const double *Di = Dinv + (size_t)l * 9;
-        const double *B1 = Hpl + (size_t)jb.k1 * 18 + 3 * a, *B2 = Hpl + (size_t)jb.k2 * 18 + 3 * c;
-        const double bd0 = B1[0] * Di[0] + B1[1] * Di[3] + B1[2] * Di[6];
-        const double bd1 = B1[0] * Di[1] + B1[1] * Di[4] + B1[2] * Di[7];
-        const double bd2 = B1[0] * Di[2] + B1[1] * Di[5] + B1[2] * Di[8];
-        const int NP = 6 * nf;
-        sgx_atomic_add(&S[(size_t)(6 * i1 + a) * NP + 6 * i2 + c], -(bd0 * B2[0] + bd1 * B2[1] + bd2 * B2[2]));
-        if (jb.k1 == jb.k2 && c == 0) {
-            const double b0 = bl[3 * (size_t)l], b1 = bl[3 * (size_t)l + 1], b2 = bl[3 * (size_t)l + 2];
-            sgx_atomic_add(&coef[6 * i1 + a], bd0 * b0 + bd1 * b1 + bd2 * b2);        // Hpl_1 Dinv bl
+    if (g < nblk36) {
+        const int blk = (int)(g / 36), ent = (int)(g % 36), a = ent / 6, c = ent % 6;
+        const int q0 = blk_start[blk], q1 = blk_start[blk + 1];
+        const SgxBaJob j0 = jobs[q0];
+        const int i1 = hidx[E[j0.k1].pose], i2 = hidx[E[j0.k2].pose], NP = 6 * nf;
+        double acc = S[(size_t)(6 * i1 + a) * NP + 6 * i2 + c];
+        double cacc = (i1 == i2 && c == 0) ? coef[6 * i1 + a] : 0.0;
+        for (int q = q0; q < q1; q++) {
+            const SgxBaJob jb = jobs[q];
+            const int l = E[jb.k1].point;
+            const double *Di = Dinv + (size_t)l * 9;
+            const double *B1 = Hpl + (size_t)jb.k1 * 18 + 3 * a, *B2 = Hpl + (size_t)jb.k2 * 18 + 3 * c;
+            const double bd0 = B1[0] * Di[0] + B1[1] * Di[3] + B1[2] * Di[6];
+            const double bd1 = B1[0] * Di[1] + B1[1] * Di[4] + B1[2] * Di[7];
+            const double bd2 = B1[0] * Di[2] + B1[1] * Di[5] + B1[2] * Di[8];
+            acc += -(bd0 * B2[0] + bd1 * B2[1] + bd2 * B2[2]);
+            if (jb.k1 == jb.k2 && c == 0) {
+                const double b0 = bl[3 * (size_t)l], b1 = bl[3 * (size_t)l + 1], b2 = bl[3 * (size_t)l + 2];
+                cacc += bd0 * b0 + bd1 * b1 + bd2 * b2;               // Hpl_1 Dinv bl
+            }
         }
+        S[(size_t)(6 * i1 + a) * NP + 6 * i2 + c] = acc;
+        if (i1 == i2 && c == 0) coef[6 * i1 + a] = cacc;
     }
     SGX_THREADS_END
 }

@@ -50,4 +50,5 @@ def test_ba_full_size_properties(gpulib):
     e0 = np.abs(T0[:, :3, 3] - Ttrue[:, :3, 3]); e1 = np.abs(poses.astype('f8')[:, :3, 3] - Ttrue[:, :3, 3])
     assert e1.mean() < 0.5 * e0.mean() and e1.max() < e0.max()
     assert 0.02 < erase.mean() < 0.12                       # 5 % gross outliers were planted
-    assert close(runs[1][0], poses) and points_close(runs[1][1], points) and (runs[1][2] != erase).mean() < 1e-4 and runs[1][3]['iterations'] == stats['iterations']
+    # run-to-run: bit-identical (the Schur complement is summed per destination block in landmark order, no atomics)
+    assert (runs[1][0] == poses).all() and (runs[1][1] == points).all() and (runs[1][2] == erase).all() and runs[1][3]['iterations'] == stats['iterations']
