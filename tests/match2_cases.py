@@ -83,6 +83,17 @@ def check_bow(lib, orc, n_cases=5):
                 sel = em >= 0
                 assert kf['good_mp'][em[sel]].all() and (kf['feat_node'][em[sel]] == F['feat_node'][sel]).all() and len(set(em[sel])) <= sel.sum()
     assert total > 300
+    # degenerate inputs: empty keyframe / empty frame / no map point in the keyframe / disjoint vocabulary nodes
+    _, kf, F = make_keyframes(orc, 77, 9, 12)
+    kf = dict(kf); kf['good_mp'] = np.ones(len(kf['keys']), np.uint8)
+    empty = dict(keys=kf['keys'][:0], desc=kf['desc'][:0], good_mp=kf['good_mp'][:0], feat_node=kf['feat_node'][:0])
+    m = ORBmatcher(0.7, True, lib=lib)
+    assert m.SearchByBoW(empty, F)[0] == 0 and (m.SearchByBoW(empty, F)[1] == -1).all()
+    assert m.SearchByBoW(kf, dict(keys=F['keys'][:0], desc=F['desc'][:0], feat_node=F['feat_node'][:0]))[0] == 0
+    none = dict(kf); none['good_mp'] = np.zeros(len(kf['keys']), np.uint8)
+    assert m.SearchByBoW(none, F)[0] == 0 == orc.search_by_bow(none, F)[0]
+    far = dict(F); far['feat_node'] = F['feat_node'] + 100000
+    assert m.SearchByBoW(kf, far)[0] == 0 == orc.search_by_bow(kf, far)[0]
 
 
 def check_fuse(lib, orc, n_cases=5):
@@ -107,3 +118,14 @@ def check_fuse(lib, orc, n_cases=5):
             total += en
             assert (ed[ei >= 0] <= 50).all() and not mp['skip'][ei >= 0].any()
     assert total > 500
+    # degenerate inputs: no candidate, every candidate skipped, empty keyframe, every point behind the camera
+    none = {k: v[:0] for k, v in mp.items()}
+    assert ORBmatcher(lib=lib).FuseSearch(kf, none, 3.0, CAM, sf, is2)[0] == 0
+    allskip = dict(mp); allskip['skip'] = np.ones(len(mp['skip']), np.uint8)
+    n, bi, bd = ORBmatcher(lib=lib).FuseSearch(kf, allskip, 3.0, CAM, sf, is2)
+    assert n == 0 and (bi == -1).all() and (bd == 256).all()
+    ekf = dict(keys=k0[:0], desc=dd0[:0], uright=ur0[:0], Tcw=T0.astype('f4'))
+    assert ORBmatcher(lib=lib).FuseSearch(ekf, mp, 3.0, CAM, sf, is2)[0] == 0
+    behind = dict(mp); behind['xw'] = mp['xw'].copy(); behind['xw'][:, 2] -= 1000.0
+    en, ei, ed = orc.fuse_search(kf, behind, CAM, sf, is2, 3.0); gn, gi, gd = ORBmatcher(lib=lib).FuseSearch(kf, behind, 3.0, CAM, sf, is2)
+    assert gn == en == 0 and (gi == ei).all()
