@@ -103,7 +103,7 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get('SGX_BENCH_FORCE_DIST'):       # SGX_BENCH_FORCE_DIST=1: run the RCCL gather path with one rank too (smoke test of the multi-GPU code on a 1-GPU box)
         import torch.distributed as dist_
         dist = dist_
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
