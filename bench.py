@@ -142,7 +142,7 @@ def main():
         if os.path.exists(gtp):
             gt_tum = tum.load_trajectory_tum(gtp)
     else:
-        host, host_depth = synth.synth_streams('LayeredStream', 1234, t0s, T)
+        host, host_depth = synth.synth_streams('LayeredStream', 1234, t0s, T, workers=max(1, min(32, (os.cpu_count() or 2) // (2 * world))))   # the ranks of a node share its cores
         d_frames = torch.from_numpy(host).cuda()
         d_depth_t = torch.from_numpy(host_depth.view(np.int16)).cuda()          # raw u16 depth (DepthMapFactor 5000) as int16 bits
         d_bgr = None
