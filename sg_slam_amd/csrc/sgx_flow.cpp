@@ -85,8 +85,11 @@ static int track(sgx_flow *h, int cur_slot, int prev_slot, int batch, const sgx_
     double eps = h->cfg.epsilon > 10. ? 10. : h->cfg.epsilon;
     A.eps2 = eps * eps; A.min_eig = (float)1e-4;
     sgx_prof_begin(SGX_K_LK_TRACK, st);
-    A.batch = batch; A.kblocks = (cap + 3) / 4;
-    SGX_LAUNCH(k_lk_track, dim3((unsigned)A.kblocks * (unsigned)batch), dim3(256), st, h->g, A);
+    static const int kpw = getenv("SGX_LK_KPW") ? atoi(getenv("SGX_LK_KPW")) : 2;      // keypoints per wave: 2 (default) / 4 = k_lk_trackN, 1 = k_lk_track; same results
+    A.batch = batch; A.kblocks = (cap + 4 * kpw - 1) / (4 * kpw);
+    if (kpw == 4) { auto kfn = k_lk_trackN<4>; SGX_LAUNCH(kfn, dim3((unsigned)A.kblocks * (unsigned)batch), dim3(256), st, h->g, A); }
+    else if (kpw == 2) { auto kfn = k_lk_trackN<2>; SGX_LAUNCH(kfn, dim3((unsigned)A.kblocks * (unsigned)batch), dim3(256), st, h->g, A); }
+    else { A.kblocks = (cap + 3) / 4; SGX_LAUNCH(k_lk_track, dim3((unsigned)A.kblocks * (unsigned)batch), dim3(256), st, h->g, A); }
     sgx_prof_end(SGX_K_LK_TRACK, st);
     SGX_CHECK_HIP(hipGetLastError());
     return SGX_OK;

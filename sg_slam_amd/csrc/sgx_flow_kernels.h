@@ -455,6 +455,262 @@ SGX_KERNEL(256) k_lk_track(SgxLkGeom g, SgxLkArgs A)
 #endif
 
 // ---------------------------------------------------------------------------------------------
+// k_lk_trackN<KPW>: the same tracker with KPW = 2 or 4 keypoints per wave (one per group of LPK = 64 / KPW lanes: a half-wave, or a 16-lane DPP row).  The 63 seven-sample
+// segments of a window are dealt to the LPK lanes of a group (segments l, l + LPK, ...), so a lane does per keypoint what KPW lanes of k_lk_track do — the per-sample work per keypoint is unchanged — while everything
+// that k_lk_track pays once per wave is now paid once per KPW keypoints: the cross-lane reductions (4 DPP adds inside a row, plus one lane-xor-16 exchange for half-waves, instead of 6 + a readlane),
+// the float step arithmetic, the window / tile bookkeeping.  The groups of a wave iterate together; a finished group idles (its lanes are masked) until the slowest
+// one stops (measured on the bench streams: 13.1 iterations per keypoint on average, 14.6 / 16.1 for the maximum over 2 / 4 neighbours).  KPW = 2 needs half the
+// registers of KPW = 4 (two segments per lane instead of four) and runs at twice the occupancy.  All sums are the same exact integers, so the results are bit-identical to k_lk_track and to the oracle's exact-sum mode.
+// Workgroup = 4 waves = 4 KPW keypoints; LDS: one 36 x 32-byte tile per keypoint.
+// ---------------------------------------------------------------------------------------------
+#ifndef SGX_EMU
+SGX_DEV int sgx_row_sum_i32(int v)                                  /* every lane receives the total of its 16-lane row */
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);      /* quad_perm [1,0,3,2] */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);      /* quad_perm [2,3,0,1] */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, true);     /* row_ror:4 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, true);     /* row_ror:8 */
+    return v;
+}
+template <int LPK>
+SGX_DEV float sgx_group_sum_f32(int v)                              /* exact sum over the LPK lanes of a group -> correctly rounded float, as sgx_wave_sum_f32 */
+{
+    int lo = sgx_row_sum_i32(v & 0xFFFF), hi = sgx_row_sum_i32(v >> 16);
+    if (LPK == 32) { lo += __shfl_xor(lo, 16, 64); hi += __shfl_xor(hi, 16, 64); }      /* the other row of the half-wave */
+    return (float)((double)hi * 65536.0 + (double)lo);
+}
+
+/* stage the NROWS x 32-byte patch of `img` whose top-left corner is (ox, oy) (ox a multiple of 4) into a keypoint's tile with the LPK lanes of its group (LPK / 8 tile rows of
+ * eight dwords per pass): REFLECT_101 outside the image, aligned dwords wherever the image allows. */
+#define SGX_LK4_PITCH 32
+template <int NROWS, int LPK>
+SGX_DEV void sgx_lk_stage_row(uint32_t *tile, const uint8_t *img, int w, int h, int pitch, int ox, int oy, int l16)
+{
+    constexpr int RPP = LPK / 8, G = LPK == 16 ? 6 : 3;              /* tile rows per pass; loads in flight per lane before their LDS stores */
+    const int c = l16 & 7, rs = l16 >> 3, gx = ox + 4 * c;
+    const bool inside = gx >= 0 && gx + 4 <= w;
+    const int x0 = sgx_reflect1(gx, w), x1 = sgx_reflect1(gx + 1, w), x2 = sgx_reflect1(gx + 2, w), x3 = sgx_reflect1(gx + 3, w);
+#pragma unroll 1
+    for (int r0 = rs; r0 < NROWS; r0 += RPP * G) {
+        uint32_t v[G];
+#pragma unroll
+        for (int p = 0; p < G; p++) {
+            const uint8_t *src = img + (size_t)sgx_reflect1(oy + min(r0 + RPP * p, NROWS - 1), h) * pitch;
+            if (inside) v[p] = *(const uint32_t *)(src + gx);
+            else v[p] = (uint32_t)src[x0] | ((uint32_t)src[x1] << 8) | ((uint32_t)src[x2] << 16) | ((uint32_t)src[x3] << 24);
+        }
+#pragma unroll
+        for (int p = 0; p < G; p++) { const int r = r0 + RPP * p; if (r < NROWS) tile[r * (SGX_LK4_PITCH / 4) + c] = v[p]; }
+    }
+}
+
+/* one seven-sample segment of the tracked-from window: the packed pixel pairs P (rows gy0-1 .. gy0+2, columns gx0-1 .. gx0+8) -> window intensities (as the
+ * accumulator start 256 - (I << 9)), Scharr derivatives, and the segment's share of the gradient matrix.  Same arithmetic as k_lk_track. */
+SGX_DEV void sgx_lk_segment_setup(const sgx_i16x2 (&P)[4][5], sgx_i16x2 W0, sgx_i16x2 W1, bool whole, int gx0, int gy0, int w, int h,
+                                  int (&ivb)[7], uint32_t (&ixy)[7], int &s11, int &s12, int &s22)
+{
+    const sgx_i16x2 c3 = { 3, 3 }, c10 = { 10, 10 };
+    sgx_i16x2 S0[5], S1[5], D0[5], D1[5];
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+        S0[q] = (P[0][q] + P[2][q]) * c3 + P[1][q] * c10; D0[q] = P[2][q] - P[0][q];
+        S1[q] = (P[1][q] + P[3][q]) * c3 + P[2][q] * c10; D1[q] = P[3][q] - P[1][q];
+    }
+    sgx_i16x2 xa[5], ya[5], xb[5], yb[5];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        xa[q] = S0[q + 1] - S0[q]; ya[q] = (D0[q] + D0[q + 1]) * c3 + sgx_lk_next(D0[q], D0[q + 1]) * c10;
+        xb[q] = S1[q + 1] - S1[q]; yb[q] = (D1[q] + D1[q + 1]) * c3 + sgx_lk_next(D1[q], D1[q + 1]) * c10;
+    }
+    if (!whole) {                                                   /* the derivative plane is 0 outside the image (copyMakeBorder CONSTANT) */
+        const bool rowa = gy0 >= 0 && gy0 < h, rowb = gy0 + 1 >= 0 && gy0 + 1 < h;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int x = gx0 + 2 * q;
+            const uint32_t m = ((x >= 0 && x < w) ? 0xFFFFu : 0u) | ((x + 1 >= 0 && x + 1 < w) ? 0xFFFF0000u : 0u);
+            const uint32_t ma = rowa ? m : 0u, mb = rowb ? m : 0u;
+            xa[q] = sgx_as_i16x2(sgx_as_u32(xa[q]) & ma); ya[q] = sgx_as_i16x2(sgx_as_u32(ya[q]) & ma);
+            xb[q] = sgx_as_i16x2(sgx_as_u32(xb[q]) & mb); yb[q] = sgx_as_i16x2(sgx_as_u32(yb[q]) & mb);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 7; c++) {
+        const sgx_i16x2 pxa = (c & 1) ? sgx_lk_next(xa[c >> 1], xa[(c >> 1) + 1]) : xa[c >> 1], pxb = (c & 1) ? sgx_lk_next(xb[c >> 1], xb[(c >> 1) + 1]) : xb[c >> 1];
+        const sgx_i16x2 pya = (c & 1) ? sgx_lk_next(ya[c >> 1], ya[(c >> 1) + 1]) : ya[c >> 1], pyb = (c & 1) ? sgx_lk_next(yb[c >> 1], yb[(c >> 1) + 1]) : yb[c >> 1];
+        const sgx_i16x2 pia = (c & 1) ? P[1][(c + 1) >> 1] : sgx_lk_next(P[1][c >> 1], P[1][(c >> 1) + 1]), pib = (c & 1) ? P[2][(c + 1) >> 1] : sgx_lk_next(P[2][c >> 1], P[2][(c >> 1) + 1]);
+        const int v = SGX_LK_DOT2(pib, W1, SGX_LK_DOT2(pia, W0, 256)) >> 9;
+        const int vx = SGX_LK_DOT2(pxb, W1, SGX_LK_DOT2(pxa, W0, 8192)) >> 14;
+        const int vy = SGX_LK_DOT2(pyb, W1, SGX_LK_DOT2(pya, W0, 8192)) >> 14;
+        ivb[c] = 256 - (v << 9); ixy[c] = ((uint32_t)vx & 0xFFFFu) | ((uint32_t)vy << 16);          /* |vx|, |vy| <= 16 * 255: they fit 16 bits */
+        s11 += sgx_mul24(vx, vx); s12 += sgx_mul24(vx, vy); s22 += sgx_mul24(vy, vy);
+    }
+}
+/* acc += diff * (low / high signed half of pair): v_mad_i32_i16 with op_sel picks the half, so the (Ix, Iy) pairs stay packed in one register per sample */
+SGX_DEV int sgx_mad_lo16(int diff, uint32_t pair, int acc) { asm("v_mad_i32_i16 %0, %1, %2, %0 op_sel:[0,0,0,0]" : "+v"(acc) : "v"(diff), "v"(pair)); return acc; }
+SGX_DEV int sgx_mad_hi16(int diff, uint32_t pair, int acc) { asm("v_mad_i32_i16 %0, %1, %2, %0 op_sel:[0,1,0,0]" : "+v"(acc) : "v"(diff), "v"(pair)); return acc; }
+
+template <int KPW>
+SGX_KERNEL_OCC(256, (KPW == 4 ? 3 : 5)) k_lk_trackN(SgxLkGeom g, SgxLkArgs A)
+{
+    constexpr int LPK = 64 / KPW, SPL = KPW;                         /* lanes per keypoint, segments per lane (SPL * LPK = 64 slots for 63 segments) */
+    constexpr int TD = 36 * SGX_LK4_PITCH / 4 + 5;                 /* dwords per keypoint tile: 36 rows of 32 bytes (+ slack for the 8-byte reads past the last row; odd stride between tiles) */
+    __shared__ uint32_t tiles[4 * KPW][TD];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, row = lane / LPK, l16 = lane % LPK;
+    int f, kb;
+    sgx_lk_decode_block((int)blockIdx.x, A.batch, A.kblocks, f, kb);
+    const int nkp = min(A.n[f], A.cap);
+    if (kb * (4 * KPW) + wv * KPW >= nkp) return;                            /* wave-uniform: no workgroup barrier is used below */
+    const int kp = kb * (4 * KPW) + wv * KPW + row;
+    const bool valid = kp < nkp;
+    uint32_t *tile = tiles[wv * KPW + row];
+    const uint8_t *tile8 = (const uint8_t *)tile;
+    const int W = SGX_LK_WIN; const float half = 10.0f, FLT_SCALE = 1.f / (1 << 20);
+    const float *kpt = (const float *)(A.keys + ((size_t)f * A.cap + (valid ? kp : 0)) * 28);
+    const float kx = kpt[0], ky = kpt[1];
+    const uint8_t *I0 = A.cur_img + (size_t)f * g.img_stride, *J0 = A.prev_img + (size_t)f * g.img_stride;
+    // the lane's SPL segments: segment index l16 + LPK q -> (window row, first of seven columns); the 64th slot (last lane, last q) is idle: zero weights
+    int soff[SPL], srow[SPL], scol[SPL];
+#pragma unroll
+    for (int q = 0; q < SPL; q++) { const int si = min(l16 + LPK * q, 62); srow[q] = si / 3; scol[q] = (si - 3 * srow[q]) * 7; soff[q] = srow[q] * SGX_LK4_PITCH + scol[q]; }
+    const bool idle3 = l16 == LPK - 1;                              /* the last slot of the last lane does not exist */
+    float outx = 0.f, outy = 0.f; int status = 1;
+
+    for (int level = g.nl - 1; level >= 0; level--) {
+        const int w = g.w[level], h = g.h[level], pitch = g.pitch[level];
+        const uint8_t *I = I0 + g.ioff[level], *J = J0 + g.ioff[level];
+        const float sc = 1.0f / (float)(1 << level);
+        float prevx = kx * sc, prevy = ky * sc, nextx, nexty;
+        if (level == g.nl - 1) { nextx = prevx; nexty = prevy; } else { nextx = outx * 2.f; nexty = outy * 2.f; }
+        outx = nextx; outy = nexty;
+        prevx -= half; prevy -= half;
+        const int ipx = sgx_floor_f(prevx), ipy = sgx_floor_f(prevy);
+        bool act = valid;                                           /* this row still works on this level */
+        if (ipx < -W || ipx >= w || ipy < -W || ipy >= h) { if (level == 0) status = 0; act = false; }
+        if (!__any(act)) continue;
+        SgxLkWeights k = sgx_lk_weights(prevx - ipx, prevy - ipy);
+        sgx_i16x2 W0 = sgx_as_i16x2((uint32_t)k.w00 | ((uint32_t)k.w01 << 16)), W1 = sgx_as_i16x2((uint32_t)k.w10 | ((uint32_t)k.w11 << 16));
+
+        int ivb[SPL][7]; uint32_t ixy[SPL][7];
+        int s11 = 0, s12 = 0, s22 = 0;
+        {
+            const bool direct = act && ipx >= 1 && ipx + 25 < w && ipy >= 1 && ipy + 22 < h;       /* patch + apron inside the image: no reflection anywhere (per row) */
+            const bool whole = ipx >= 0 && ipx + W < w && ipy >= 0 && ipy + W < h;
+            const int tx = ((ipx - 1) >> 2) << 2, ty = ipy - 1;
+            if (__any(act && !direct)) {                            /* near the border: REFLECT_101 patch through the keypoint's LDS tile */
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+                if (act && !direct) sgx_lk_stage_row<28, LPK>(tile, I, w, h, pitch, tx, ty, l16);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+            }
+#pragma unroll
+            for (int q = 0; q < SPL; q++) {
+                const int gy0 = ipy + srow[q], gx0 = ipx + scol[q];
+                sgx_i16x2 P[4][5];
+                if (direct) {
+                    const uint8_t *gb = I + (size_t)(gy0 - 1) * pitch + (gx0 - 1);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        uint32_t d[3];
+                        __builtin_memcpy(d, gb + (size_t)j * pitch, 12);
+                        P[j][0] = SGX_LK_PAIR(d[0], d[0], 0, 1); P[j][1] = SGX_LK_PAIR(d[0], d[0], 2, 3);
+                        P[j][2] = SGX_LK_PAIR(d[1], d[1], 0, 1); P[j][3] = SGX_LK_PAIR(d[1], d[1], 2, 3);
+                        P[j][4] = SGX_LK_PAIR(d[2], d[2], 0, 1);
+                    }
+                } else {
+                    const uint8_t *tb = tile8 + soff[q] + (ipx - 1 - tx);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        uint32_t d[3];
+                        __builtin_memcpy(d, tb + j * SGX_LK4_PITCH, 12);
+                        P[j][0] = SGX_LK_PAIR(d[0], d[0], 0, 1); P[j][1] = SGX_LK_PAIR(d[0], d[0], 2, 3);
+                        P[j][2] = SGX_LK_PAIR(d[1], d[1], 0, 1); P[j][3] = SGX_LK_PAIR(d[1], d[1], 2, 3);
+                        P[j][4] = SGX_LK_PAIR(d[2], d[2], 0, 1);
+                    }
+                }
+                const bool on = act && !(q == SPL - 1 && idle3);          /* inactive rows and the idle slot: zero weights -> zero samples */
+                const sgx_i16x2 Wq0 = on ? W0 : sgx_as_i16x2(0u), Wq1 = on ? W1 : sgx_as_i16x2(0u);
+                sgx_lk_segment_setup(P, Wq0, Wq1, whole, gx0, gy0, w, h, ivb[q], ixy[q], s11, s12, s22);
+                __builtin_amdgcn_sched_barrier(0);                  /* one segment at a time: keeps the 60 temporaries of a segment from overlapping the next one's */
+            }
+        }
+        const float A11 = sgx_group_sum_f32<LPK>(s11) * FLT_SCALE, A12 = sgx_group_sum_f32<LPK>(s12) * FLT_SCALE, A22 = sgx_group_sum_f32<LPK>(s22) * FLT_SCALE;
+        float D = A11 * A22 - A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * W * W);
+        if (act && (minEig < A.min_eig || D < FLT_EPSILON)) { if (level == 0) status = 0; act = false; }
+        D = 1.f / D;
+        nextx -= half; nexty -= half;
+        float pdx = 0.f, pdy = 0.f;
+        int ox = 0, oy = 0; bool staged = false;
+        for (int j = 0; j < A.max_count; j++) {
+            const int inx = sgx_floor_f(nextx), iny = sgx_floor_f(nexty);
+            if (act && (inx < -W || inx >= w || iny < -W || iny >= h)) { if (level == 0) status = 0; act = false; }
+            if (!__any(act)) break;
+            k = sgx_lk_weights(nextx - inx, nexty - iny);
+            W0 = sgx_as_i16x2((uint32_t)k.w00 | ((uint32_t)k.w01 << 16)); W1 = sgx_as_i16x2((uint32_t)k.w10 | ((uint32_t)k.w11 << 16));
+            const bool need = act && (!staged || inx < ox || inx - ox > SGX_LK4_PITCH - 22 || iny < oy || iny - oy > 36 - 22);
+            if (__any(need)) {
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+                if (need) {
+                    ox = ((inx - 3) >> 2) << 2; oy = iny - 7;       /* three to six pixels of room left and right, seven above and below, before the window leaves the tile */
+                    sgx_lk_stage_row<36, LPK>(tile, J, w, h, pitch, ox, oy, l16);
+                    staged = true;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+            }
+            int sb1 = 0, sb2 = 0;
+            if (act) {
+                const uint8_t *tb0 = tile8 + (iny - oy) * SGX_LK4_PITCH + (inx - ox);
+#pragma unroll
+                for (int q = 0; q < SPL; q++) {
+                    const uint8_t *tb = tb0 + soff[q];
+                    uint32_t a[2], b[2];
+                    __builtin_memcpy(a, tb, 8); __builtin_memcpy(b, tb + SGX_LK4_PITCH, 8);
+#pragma unroll
+                    for (int c = 0; c < 7; c++) {
+                        const int diff = SGX_LK_DOT2(SGX_LK_PAIR(b[1], b[0], c, c + 1), W1, SGX_LK_DOT2(SGX_LK_PAIR(a[1], a[0], c, c + 1), W0, ivb[q][c])) >> 9;
+                        sb1 = sgx_mad_lo16(diff, ixy[q][c], sb1); sb2 = sgx_mad_hi16(diff, ixy[q][c], sb2);      /* |diff| <= 255 * 32 fits 16 bits; ix = iy = 0 on the idle slot */
+                    }
+                }
+            }
+            const float b1 = sgx_group_sum_f32<LPK>(sb1) * FLT_SCALE, b2 = sgx_group_sum_f32<LPK>(sb2) * FLT_SCALE;
+            if (act) {
+                const float dx = (A12 * b2 - A22 * b1) * D, dy = (A12 * b1 - A11 * b2) * D;
+                nextx += dx; nexty += dy;
+                outx = nextx + half; outy = nexty + half;
+                if ((double)dx * dx + (double)dy * dy <= A.eps2) act = false;
+                else if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) { outx -= dx * 0.5f; outy -= dy * 0.5f; act = false; }
+                pdx = dx; pdy = dy;
+            }
+        }
+        if (valid && status && level == 0) {
+            const int qx = sgx_floor_f(outx - half), qy = sgx_floor_f(outy - half);
+            if (qx < -W || qx >= w || qy < -W || qy >= h) status = 0;
+        }
+    }
+    if (l16 == 0 && valid) {
+        A.prev_xy[2 * ((size_t)f * A.cap + kp)] = outx; A.prev_xy[2 * ((size_t)f * A.cap + kp) + 1] = outy;
+        if (A.status) A.status[(size_t)f * A.cap + kp] = (uint8_t)status;
+    }
+}
+#else
+template <int KPW>
+SGX_KERNEL(256) k_lk_trackN(SgxLkGeom g, SgxLkArgs A)
+{
+    SGX_THREADS_BEGIN(tid)
+    int f, kb;
+    sgx_lk_decode_block((int)blockIdx.x, A.batch, A.kblocks, f, kb);
+    const int kp = kb * (4 * KPW) + tid / (64 / KPW);
+    if (tid % (64 / KPW) == 0 && kp < A.n[f] && kp < A.cap) {
+        const float *kpt = (const float *)(A.keys + ((size_t)f * A.cap + kp) * 28);
+        float ox, oy; uint8_t st;
+        sgx_lk_track_point(g, A.cur_img + (size_t)f * g.img_stride, A.prev_img + (size_t)f * g.img_stride, kpt[0], kpt[1], A.max_count, A.eps2, A.min_eig, &ox, &oy, &st);
+        A.prev_xy[2 * ((size_t)f * A.cap + kp)] = ox; A.prev_xy[2 * ((size_t)f * A.cap + kp) + 1] = oy;
+        if (A.status) A.status[(size_t)f * A.cap + kp] = st;
+    }
+    SGX_THREADS_END
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------
 // findFundamentalMat(FM_RANSAC)
 // ---------------------------------------------------------------------------------------------
 #define SGX_FM_CHUNK 32               /* 7-index groups drawn per round */
