@@ -19,3 +19,25 @@ def classify(kernel_name):
         if base.startswith(pre):
             return cls
     return None
+
+
+# dispatches per bench step of the kernels that run more than once per step (everything else: once); used to find out in how many of the profiled steps a class
+# ran at all — the first step of a run has no previous frame, so the tracking-stage kernels (LK, RANSAC, matchers, pose optimisation ...) run in one step fewer
+DISPATCHES_PER_STEP = {'k_pose_opt': 2, 'k_merge_matches': 2, 'k_lk_pyrdown': 3, 'k_resize': 7}
+
+
+def steps_ran(dispatch_counts):
+    """dispatch_counts: {kernel base name: dispatches} of ONE class -> number of steps in which the class ran"""
+    best = 0.0
+    for name, n in dispatch_counts.items():
+        per = 1
+        for pre, k in DISPATCHES_PER_STEP.items():
+            if name.startswith(pre): per = k
+        best = max(best, n / per)
+    return max(1, int(round(best)))
+
+
+def base_name(kernel_name):
+    base = kernel_name.split('(')[0]
+    if base.startswith('void '): base = base[5:]
+    return base.split('<')[0].strip()

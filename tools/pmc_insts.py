@@ -3,15 +3,17 @@ usage: pmc_insts.py out.json frames_per_launch steps_profiled sq_pass.csv [more.
 Every CSV is a counter_collection.csv; counters are summed over all dispatches of a class and divided by frames x steps.  SQ_INSTS_* are
 wave-level instruction counts (one per wave64 instruction issued).  fp64 flops per frame assume all 64 lanes active: 64 x (ADD + MUL + 2 FMA)."""
 import csv, json, sys, collections
-from pmc_classes import classify
+from pmc_classes import classify, steps_ran, base_name
 
 def collect(path):
-    acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(lambda: collections.defaultdict(int))
+    """per class: counter totals over all dispatches, and the number of steps in which the class ran (from the dispatch counts of its kernels)"""
+    acc = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.defaultdict(lambda: collections.defaultdict(set))
     for r in csv.DictReader(open(path)):
         cls = classify(r['Kernel_Name'])
         if cls is None: continue
-        acc[cls][r['Counter_Name']] += float(r['Counter_Value']); n[cls][r['Counter_Name']] += 1
-    return acc, n
+        acc[cls][r['Counter_Name']] += float(r['Counter_Value']); disp[cls][base_name(r['Kernel_Name'])].add(r['Dispatch_Id'])
+    ran = {cls: steps_ran({k: len(v) for k, v in d.items()}) for cls, d in disp.items()}
+    return acc, ran
 
 args = sys.argv[1:]
 det = None
@@ -20,10 +22,10 @@ if '--det' in args:
 out, S, steps = args[0], int(args[1]), int(args[2])
 tot = collections.defaultdict(dict)
 for p in args[3:]:
-    acc, _ = collect(p)
+    acc, ran = collect(p)
     for cls, cs in acc.items():
         if cls.startswith('det_') and det: continue
-        for c, v in cs.items(): tot[cls][c] = v / (S * steps)
+        for c, v in cs.items(): tot[cls][c] = v / (S * min(steps, ran[cls]))
 if det:
     acc, _ = collect(det[0])
     for cls, cs in acc.items():

@@ -3,16 +3,18 @@ MI355X guide prescribes).  Per bench kernel class: mean HBM-side bytes per bench
 FETCH_SIZE (KB) is doubled (gfx950 reports half of a wide coalesced read stream) and WRITE_SIZE (KB) is taken as is.
 usage: pmc_traffic.py [--det det_fetch.csv det_write.csv launches_per_step] fetch.csv write.csv frames_per_launch steps_profiled out.json [bench.json: launches per step per class are taken from its per_kernel table]"""
 import csv, json, sys, collections
-from pmc_classes import classify
+from pmc_classes import classify, steps_ran, base_name
 # bench launches per step of each class (a "launch" in bench.py's per_kernel table = one sgx_* call / one prof begin-end bracket)
 PER_STEP = dict(pyramid_resize=1, fast_cells=1, octree=1, orient_desc=1, stereo_from_rgbd=1, motion_model=1, match_project_frame=1, match_project_local=1,
                 pose_opt=2, unproject=1, map_point_glue=3, dynamic_mask=2, lk_pyramid=1, lk_track=1, fm_ransac=1, det_forward=1, det_output=1)
+RAN = {}
 def total(path, counter):
-    acc = collections.defaultdict(float)
+    acc = collections.defaultdict(float); disp = collections.defaultdict(lambda: collections.defaultdict(set))
     for r in csv.DictReader(open(path)):
         if r['Counter_Name'] != counter: continue
         cls = classify(r['Kernel_Name'])
-        if cls is not None: acc[cls] += float(r['Counter_Value'])
+        if cls is not None: acc[cls] += float(r['Counter_Value']); disp[cls][base_name(r['Kernel_Name'])].add(r['Dispatch_Id'])
+    for cls, d in disp.items(): RAN[cls] = steps_ran({k: len(v) for k, v in d.items()})
     return acc
 det = None
 if '--det' in sys.argv:
@@ -24,7 +26,7 @@ if len(sys.argv) > 6:
 f = total(fetch, 'FETCH_SIZE'); w = total(write, 'WRITE_SIZE')
 res = {}
 for cls in sorted(set(f) | set(w)):
-    launches = PER_STEP[cls] * steps
+    launches = PER_STEP[cls] * min(steps, RAN.get(cls, steps))          # the tracking-stage classes do not run in the first step of a run
     res[cls] = int(round((2.0 * f.get(cls, 0.0) + w.get(cls, 0.0)) * 1024.0 / launches))
 if det:            # detector classes from the per-step profile (tools/prof_det_ops.py: every plan step launched det[2] times on its own)
     fd = total(det[0], 'FETCH_SIZE'); wd = total(det[1], 'WRITE_SIZE')
