@@ -466,10 +466,12 @@ SGX_KERNEL(256) k_lk_track(SgxLkGeom g, SgxLkArgs A)
 #ifndef SGX_EMU
 SGX_DEV int sgx_row_sum_i32(int v)                                  /* every lane receives the total of its 16-lane row */
 {
-    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);      /* quad_perm [1,0,3,2] */
-    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);      /* quad_perm [2,3,0,1] */
-    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, true);     /* row_ror:4 */
-    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, true);     /* row_ror:8 */
+    /* quad permutes and row rotations read a valid lane everywhere, so the `old` operand is never used: passing v itself spares the v_mov 0 the compiler
+     * would otherwise emit in front of every DPP add */
+    v += __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, true);      /* quad_perm [1,0,3,2] */
+    v += __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, true);      /* quad_perm [2,3,0,1] */
+    v += __builtin_amdgcn_update_dpp(v, v, 0x124, 0xF, 0xF, true);     /* row_ror:4 */
+    v += __builtin_amdgcn_update_dpp(v, v, 0x128, 0xF, 0xF, true);     /* row_ror:8 */
     return v;
 }
 template <int LPK>
@@ -594,7 +596,7 @@ SGX_KERNEL_OCC(256, (KPW == 4 ? 3 : 5)) k_lk_trackN(SgxLkGeom g, SgxLkArgs A)
         int s11 = 0, s12 = 0, s22 = 0;
         {
             const bool direct = act && ipx >= 1 && ipx + 25 < w && ipy >= 1 && ipy + 22 < h;       /* patch + apron inside the image: no reflection anywhere (per row) */
-            const bool whole = ipx >= 0 && ipx + W < w && ipy >= 0 && ipy + W < h;
+            const bool whole = !__any(act && !(ipx >= 0 && ipx + W < w && ipy >= 0 && ipy + W < h));      /* wave-uniform: no active window of this wave touches the border -> the masking code is skipped, not predicated */
             const int tx = ((ipx - 1) >> 2) << 2, ty = ipy - 1;
             if (__any(act && !direct)) {                            /* near the border: REFLECT_101 patch through the keypoint's LDS tile */
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
