@@ -354,6 +354,10 @@ def main():
     else:
         roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': dk['achieved_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': dk['achieved_GBs'] / HBM_PEAK_GBS, 'traffic': traffic,
                     'avg_launch_ms': dk['avg_ms_per_launch'], 'alg_bytes_per_launch': dk['alg_bytes_per_launch']}
+    if 'standalone_avg_ms_per_launch' in dk:      # the same kernel class with nothing else on the GPU (committed profile, not measured in this run)
+        sa = dk['standalone_avg_ms_per_launch']
+        ach = (dk['alg_gflop_per_launch'] / (sa * 1e-3) / 1e3) if dk['bound'] == 'mfma' else (dk['alg_bytes_per_launch'] / (sa * 1e-3) / 1e9)
+        roofline['standalone'] = {'avg_launch_ms': sa, 'achieved': round(ach, 3), 'frac': ach / roofline['peak'], 'source': 'profiles/r2_standalone.json'}
     roofline['traffic_source'] = 'profiles/r2_traffic.json (separate rocprofv3 --pmc passes of this command)' if traffic is not None else None
     roofline['per_kernel'] = per_kernel
     orb_ms = sum(per_kernel[k]['avg_ms_per_launch'] * per_kernel[k]['launches'] / args.steps for k in ('pyramid_resize', 'fast_cells', 'octree', 'orient_desc') if k in per_kernel)
