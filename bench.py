@@ -75,7 +75,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=24)
     ap.add_argument('--warmup', type=int, default=4)
-    ap.add_argument('--streams', type=int, default=256, help='independent streams per GPU (frames per step)')
+    ap.add_argument('--streams', type=int, default=512, help='independent streams per GPU (frames per step)')
     ap.add_argument('--frames', type=int, default=6, help='distinct frames kept per stream (ping-pong replay)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-cpu-all-cores', action='store_true', help='skip the frames-parallel all-host-cores CPU baseline (keeps the 1-core figure)')
