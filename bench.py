@@ -358,6 +358,22 @@ def main():
         sa = dk['standalone_avg_ms_per_launch']
         ach = (dk['alg_gflop_per_launch'] / (sa * 1e-3) / 1e3) if dk['bound'] == 'mfma' else (dk['alg_bytes_per_launch'] / (sa * 1e-3) / 1e9)
         roofline['standalone'] = {'avg_launch_ms': sa, 'achieved': round(ach, 3), 'frac': ach / roofline['peak'], 'source': 'profiles/r2_standalone.json'}
+    if dom == 'det_forward':
+        # det_forward is a 103-node hipGraph: the HIP-event span of a launch also contains the gaps in which kernels of the other two streams run between its nodes.  The sum of the
+        # node kernels' own durations comes from the committed rocprofv3 kernel statistics of this same command (profiles/r2_bench_kernel_stats.csv).
+        try:
+            import csv
+            sys.path.insert(0, os.path.join(ROOT, 'tools'))
+            from pmc_classes import classify
+            rows = list(csv.DictReader(open(os.path.join(ROOT, 'profiles', 'r2_bench_kernel_stats.csv'))))
+            tot_ns = sum(float(r['TotalDurationNs']) for r in rows if classify(r['Name']) == 'det_forward')
+            nl = max([int(r['Calls']) for r in rows if r['Name'].startswith('k_det_preprocess')] or [0])
+            if nl and S == 512:
+                kms = tot_ns / nl / 1e6
+                roofline['graph_kernel_time'] = {'sum_of_node_kernel_ms_per_launch': round(kms, 3), 'achieved': round(dk['alg_gflop_per_launch'] / (kms * 1e-3) / 1e3, 3),
+                                                 'frac': dk['alg_gflop_per_launch'] / (kms * 1e-3) / 1e3 / MFMA_F32_PEAK_TFS, 'source': 'profiles/r2_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command at 512 streams)'}
+        except Exception:
+            pass
     roofline['traffic_source'] = 'profiles/r2_traffic.json (separate rocprofv3 --pmc passes of this command)' if traffic is not None else None
     roofline['per_kernel'] = per_kernel
     orb_ms = sum(per_kernel[k]['avg_ms_per_launch'] * per_kernel[k]['launches'] / args.steps for k in ('pyramid_resize', 'fast_cells', 'octree', 'orient_desc') if k in per_kernel)
