@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SEED = '4321'
 SLICES = [('campaign_orb.py', 150), ('campaign_orb_geometry.py', 150), ('campaign_match.py', 120), ('campaign_solvers.py', 1200), ('campaign_ba_large.py', 30),
-          ('campaign_detection_output.py', 200)]
+          ('campaign_detection_output.py', 200), ('campaign_flow.py', 60)]
 
 
 def test_campaign_slices_on_device(gpulib, oracle):

@@ -10,7 +10,7 @@ SEED = '1234'
 
 
 @pytest.mark.parametrize('tool,cases', [('campaign_orb.py', 12), ('campaign_orb_geometry.py', 12), ('campaign_match.py', 4), ('campaign_solvers.py', 120),
-                                        ('campaign_ba_large.py', 5), ('campaign_tracker.py', 1)])
+                                        ('campaign_ba_large.py', 5), ('campaign_tracker.py', 1), ('campaign_flow.py', 4)])
 def test_campaign_tool_runs_clean(emu, oracle, tool, cases):
     # a fixed number of cases from a fixed seed: the same inputs on every machine
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', tool), SEED, '120', str(cases)], capture_output=True, text=True, timeout=300)

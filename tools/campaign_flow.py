@@ -1,0 +1,49 @@
+"""Differential campaign: the mask-input stage — calcOpticalFlowPyrLK and findFundamentalMat(FM_RANSAC) — on random synthetic frame pairs (two scene generators with or without an independently moving patch, random seeds and frame
+gaps 1..3, random brightness / contrast changes between the frames, keypoints = the oracle's ORB keypoints plus random points inside, on and outside the border) through the kernel-logic
+emulator (default) or the device (SGX_CAMPAIGN_LIB=device) against the oracle: tracked positions and status bit-identical to the oracle's exact-sum mode, RANSAC with the same iteration
+count / winning sample / inlier count and F within 1e-9, also on random point pairs with 0..60 % gross outliers and on degenerate sets (n < 7, n = 7, 8..14).
+usage: python tools/campaign_flow.py <seed> <seconds> [max cases]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np
+from oracle import oracle as orc
+from sg_slam_amd import synth
+from sg_slam_amd.flow import OpticalFlowLK, find_fundamental_mat
+from flow_cases import two_view
+from _campaign_lib import campaign_lib
+lib, XP = campaign_lib()
+seed0 = int(sys.argv[1]); rng = np.random.RandomState(seed0); t0 = time.time(); cases = bad = 0
+MAXC = int(sys.argv[3]) if len(sys.argv) > 3 else None
+fl = OpticalFlowLK(lib=lib)
+while time.time() - t0 < float(sys.argv[2]) and (MAXC is None or cases < MAXC):
+    gen = [synth.PlaneStream, synth.LayeredStream][rng.randint(2)](seed=int(rng.randint(1 << 30)))
+    t = int(rng.randint(3, 60)); gap = int(rng.randint(1, 4))
+    prev, cur = gen.frame(t - gap)[0], gen.frame(t)[0]
+    if rng.rand() < 0.4:                                         # an independently moving patch (the "person" of the mask tests)
+        mo = synth.MovingObject(seed=int(rng.randint(1 << 30)), x0=int(rng.randint(40, 460)), y0=int(rng.randint(40, 240)), vx=int(rng.randint(-8, 9)), vy=int(rng.randint(-6, 7)))
+        prev, cur = mo.paste(prev, 0), mo.paste(cur, gap)
+    if rng.rand() < 0.3:                                         # photometric change between the frames
+        a, b = rng.uniform(0.8, 1.2), rng.uniform(-15, 15)
+        prev = np.clip(prev.astype('f4') * a + b, 0, 255).astype(np.uint8)
+    k, _ = orc.orb_extract(cur)
+    pts = np.stack([k['x'], k['y']], 1).astype('f4')
+    if len(pts) > 300: pts = pts[rng.choice(len(pts), 300, replace=False)]
+    extra = np.c_[rng.uniform(-40, 680, 30), rng.uniform(-40, 520, 30)].astype('f4')
+    edge = np.array([[0, 0], [639, 479], [0.5, 478.5], [10.0, 10.0], [629.0, 469.0], [-21.5, 100], [320, -22.0], [660.9, 240], [320, 500.9]], 'f4')
+    pts = np.concatenate([pts, extra, edge])
+    got, st = fl(cur, prev, pts)
+    ref, rst = orc.lk_pyr(cur, prev, pts, acc_mode=1)
+    ok = (st == rst).all() and (got.view(np.uint32) == ref.view(np.uint32)).all()
+    sel = st > 0
+    if ok and sel.sum() >= 15:
+        o1, F, s1 = find_fundamental_mat(pts[sel], got[sel], lib=lib)
+        o2, rF, _, s2 = orc.find_fundamental_ransac(pts[sel], got[sel])
+        ok = o1 == (1 if o2 == 1 else 0) and (o1 == 0 or ((s1 == s2).all() and np.abs(F - rF).max() <= 1e-9 * max(np.abs(rF).max(), 1e-300)))
+    n = int(rng.choice([0, 3, 6, 7, 8, 11, 14, 15, 16, 40, 200, 1000])); x1, x2 = two_view(max(n, 1), int(rng.randint(1 << 30)), int(rng.choice([0, 2, 3, 5])), float(rng.choice([0.0, 0.3, 1.5])))
+    o1, F, s1 = find_fundamental_mat(x1[:n], x2[:n], lib=lib)
+    o2, rF, _, s2 = orc.find_fundamental_ransac(x1[:n], x2[:n])
+    ok2 = o1 == (1 if o2 == 1 else 0) and (o1 == 0 or ((s1 == s2).all() and np.abs(F - rF).max() <= 1e-9 * max(np.abs(rF).max(), 1e-300)))
+    cases += 1
+    if not (ok and ok2): bad += 1; print('MISMATCH case', cases, type(gen).__name__, t, gap, 'lk', ok, 'ransac', ok2, n, flush=True)
+fl.close()
+print('seed', seed0, 'cases', cases, 'bad', bad, flush=True)
