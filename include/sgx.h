@@ -172,6 +172,17 @@ int sgx_match_fuse_search(
     const sgx_camera *cam, const float *scale_factors, const float *inv_level_sigma2, int nlevels, float log_scale_factor, float th,
     int32_t *best_idx, int32_t *best_dist, int32_t *nfused);
 
+/* int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, const float th, const int ORBdist)
+ * (src/sg-slam/include/ORBmatcher.h:56, src/sg-slam/src/ORBmatcher.cc:1474-1601; caller Tracking::Relocalization, Tracking.cc:1571,1584): projection of the keyframe's map
+ * points into the frame.  kf_ok[i] = vpMPs[i] && !isBad() && !sAlreadyFound.count(vpMPs[i]); c_has_mp[k] = CurrentFrame.mvpMapPoints[k] != NULL on entry (such keypoints are
+ * never taken); m_min_dist / m_max_dist = mfMinDistance / mfMaxDistance.  cur_match[k] (out) = index i of the keyframe map point keypoint k receives
+ * (CurrentFrame.mvpMapPoints[k] = vpMPs[i]), -1 = left alone; *nmatches = return value.  Host pointers, synchronous. */
+int sgx_match_project_keyframe(
+    int nc, const sgx_keypoint *ckeys_un, const uint8_t *cdesc, const uint8_t *c_has_mp, const float *cTcw,
+    int nk, const sgx_keypoint *kf_keys_un, const uint8_t *kf_ok, const float *m_xw, const float *m_min_dist, const float *m_max_dist, const uint8_t *m_desc,
+    const sgx_camera *cam, const float *scale_factors, int nlevels, float log_scale_factor, float th, int orb_dist, int check_orientation,
+    int32_t *cur_match, int32_t *nmatches);
+
 /* Harness helper (bench.py / tests), NOT a reference entry point: the previous-frame position of every keypoint under a per-frame affine flow
  * (prev = A * (x, y, 1), A = 6 floats), optionally displaced by shift[2] inside the frame's first box.  Stands in for cv::calcOpticalFlowPyrLK
  * (Frame.cc:445, tier N1) when the dynamic-feature mask is exercised on synthetic streams whose flow is known exactly. */

@@ -519,3 +519,78 @@ int orc_fuse_search(int Nk, const orc_keypoint *keys, const uint8_t *desc, const
     grid_free(g); free(g); free(cand);
     return nFused;
 }
+
+/* int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, const float th, const int ORBdist)
+ * (ORBmatcher.cc:1474-1601; caller Tracking::Relocalization, Tracking.cc:1571,1584).  kf_ok[i] = vpMPs[i] && !isBad() && !sAlreadyFound.count();
+ * c_has_mp[k] = CurrentFrame.mvpMapPoints[k] != NULL on entry.  cur_match[k] (out) = index i of the keyframe map point the frame's keypoint k receives, -1 = untouched. */
+int orc_search_by_projection_kf(
+    int Nc, const orc_keypoint *ckeys, const uint8_t *cdesc, const uint8_t *c_has_mp, const float *cTcw,
+    int Nk, const orc_keypoint *kf_keys, const uint8_t *kf_ok, const float *m_xw, const float *m_min_dist, const float *m_max_dist, const uint8_t *m_desc,
+    float fx, float fy, float cx, float cy, float minX, float maxX, float minY, float maxY,
+    const float *scale_factors, int nlevels, float log_scale_factor, float th, int orb_dist, int check_ori, int *cur_match)
+{
+    int nmatches = 0;
+    grid_t *g = (grid_t *)malloc(sizeof(grid_t));
+    grid_build(g, Nc, ckeys, minX, maxX, minY, maxY);
+    int *hist[HISTO_LENGTH], hn[HISTO_LENGTH], hc[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) { hist[i] = NULL; hn[i] = 0; hc[i] = 0; }
+    const float factor = HISTO_LENGTH / 360.0f;
+    float Rcw[3][3], tcw[3], Ow[3];
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Rcw[r][c] = cTcw[4 * r + c]; tcw[r] = cTcw[4 * r + 3]; }
+    for (int i = 0; i < 3; i++) {                       /* Ow = -Rcw.t()*tcw : gemm with a transpose flag -> generic path, double accumulation, alpha = -1 */
+        double s = 0; for (int k = 0; k < 3; k++) s += (double)Rcw[k][i] * (double)tcw[k];
+        Ow[i] = (float)(s * -1.0);
+    }
+    for (int k = 0; k < Nc; k++) cur_match[k] = -1;
+    uint8_t *taken = (uint8_t *)malloc(Nc > 0 ? Nc : 1);
+    for (int k = 0; k < Nc; k++) taken[k] = c_has_mp[k] ? 1 : 0;
+    int *vind = (int *)malloc(sizeof(int) * (Nc > 0 ? Nc : 1));
+    for (int i = 0; i < Nk; i++) {
+        if (!kf_ok[i]) continue;
+        const float *xw = m_xw + 3 * i;
+        const float xc = gemm3(Rcw[0], xw, 1.0, 1.0, tcw[0]), yc = gemm3(Rcw[1], xw, 1.0, 1.0, tcw[1]), zc = gemm3(Rcw[2], xw, 1.0, 1.0, tcw[2]);
+        const float invzc = (float)(1.0 / zc);
+        const float u = fx * xc * invzc + cx, v = fy * yc * invzc + cy;
+        if (u < minX || u > maxX) continue;
+        if (v < minY || v > maxY) continue;
+        const float po0 = xw[0] - Ow[0], po1 = xw[1] - Ow[1], po2 = xw[2] - Ow[2];
+        const float dist3D = (float)sqrt((double)po0 * po0 + (double)po1 * po1 + (double)po2 * po2);      /* cv::norm: double accumulation */
+        const float maxDistance = 1.2f * m_max_dist[i], minDistance = 0.8f * m_min_dist[i];             /* Get{Max,Min}DistanceInvariance */
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        int lvl = (int)ceilf(logf(m_max_dist[i] / dist3D) / log_scale_factor);                             /* MapPoint::PredictScale(dist, &CurrentFrame) */
+        if (lvl < 0) lvl = 0; else if (lvl >= nlevels) lvl = nlevels - 1;
+        const float radius = th * scale_factors[lvl];
+        const int nv = features_in_area(g, ckeys, u, v, radius, lvl - 1, lvl + 1, vind);
+        if (nv == 0) continue;
+        const uint8_t *dMP = m_desc + 32 * (size_t)i;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int q = 0; q < nv; q++) {
+            const int i2 = vind[q];
+            if (taken[i2]) continue;                                                                       /* CurrentFrame.mvpMapPoints[i2] != NULL */
+            const int dist = orc_descriptor_distance(dMP, cdesc + 32 * (size_t)i2);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= orb_dist) {
+            cur_match[bestIdx2] = i; taken[bestIdx2] = 1;
+            nmatches++;
+            if (check_ori) {
+                float rot = kf_keys[i].angle - ckeys[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                if (hn[bin] == hc[bin]) { hc[bin] = hc[bin] ? 2 * hc[bin] : 64; hist[bin] = (int *)realloc(hist[bin], sizeof(int) * hc[bin]); }
+                hist[bin][hn[bin]++] = bestIdx2;
+            }
+        }
+    }
+    if (check_ori) {
+        int i1, i2, i3;
+        three_maxima(hn, HISTO_LENGTH, &i1, &i2, &i3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != i1 && i != i2 && i != i3)
+                for (int j = 0; j < hn[i]; j++) { cur_match[hist[i][j]] = -1; nmatches--; }
+    }
+    for (int i = 0; i < HISTO_LENGTH; i++) free(hist[i]);
+    free(vind); free(taken); grid_free(g); free(g);
+    return nmatches;
+}

@@ -366,3 +366,17 @@ def fuse_search(kf, m, cam, scale_factors, inv_level_sigma2, th=3.0):
                           C.c_float(cam.get('min_x', 0.0)), C.c_float(cam.get('max_x', 640.0)), C.c_float(cam.get('min_y', 0.0)), C.c_float(cam.get('max_y', 480.0)),
                           _p(sf), _p(is2), C.c_int(len(sf)), C.c_float(np.log(np.float32(sf[1]))), C.c_float(th), _p(bi), _p(bd))
     return int(n), bi[:len(xw)].copy(), bd[:len(xw)].copy()
+
+
+def search_by_projection_kf(F, kf, cam, scale_factors, th, orb_dist, check_ori=True):
+    ck = np.ascontiguousarray(F['keys']); cd = np.ascontiguousarray(F['desc'], np.uint8); ch = np.ascontiguousarray(F['has_mp'], np.uint8); T = np.ascontiguousarray(F['Tcw'], 'f4').reshape(16)
+    kk = np.ascontiguousarray(kf['keys']); ok = np.ascontiguousarray(kf['ok'], np.uint8); xw = np.ascontiguousarray(kf['xw'], 'f4')
+    mn = np.ascontiguousarray(kf['min_dist'], 'f4'); mx = np.ascontiguousarray(kf['max_dist'], 'f4'); md = np.ascontiguousarray(kf['desc'], np.uint8)
+    sf = np.ascontiguousarray(scale_factors, 'f4')
+    match = np.full(max(len(ck), 1), -1, 'i4')
+    L = lib(); L.orc_search_by_projection_kf.restype = C.c_int
+    n = L.orc_search_by_projection_kf(C.c_int(len(ck)), _p(ck), _p(cd), _p(ch), _p(T), C.c_int(len(kk)), _p(kk), _p(ok), _p(xw), _p(mn), _p(mx), _p(md),
+                                      C.c_float(cam['fx']), C.c_float(cam['fy']), C.c_float(cam['cx']), C.c_float(cam['cy']),
+                                      C.c_float(cam.get('min_x', 0.0)), C.c_float(cam.get('max_x', 640.0)), C.c_float(cam.get('min_y', 0.0)), C.c_float(cam.get('max_y', 480.0)),
+                                      _p(sf), C.c_int(len(sf)), C.c_float(np.log(np.float32(sf[1]))), C.c_float(th), C.c_int(orb_dist), C.c_int(int(bool(check_ori))), _p(match))
+    return int(n), match[:len(ck)].copy()

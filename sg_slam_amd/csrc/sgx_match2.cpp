@@ -177,3 +177,50 @@ extern "C" int sgx_match_fuse_search(
     *nfused = n;
     return SGX_OK;
 }
+
+extern "C" int sgx_match_project_keyframe(
+    int nc, const sgx_keypoint *ckeys_un, const uint8_t *cdesc, const uint8_t *c_has_mp, const float *cTcw,
+    int nk, const sgx_keypoint *kf_keys_un, const uint8_t *kf_ok, const float *m_xw, const float *m_min_dist, const float *m_max_dist, const uint8_t *m_desc,
+    const sgx_camera *cam, const float *scale_factors, int nlevels, float log_scale_factor, float th, int orb_dist, int check_orientation,
+    int32_t *cur_match, int32_t *nmatches)
+{
+    if (nc < 0 || nk < 0 || !cam || !cTcw || !scale_factors || nlevels < 1 || nlevels > 12 || !nmatches || (nc > 0 && !cur_match)) return SGX_ERR_INVALID;
+    *nmatches = 0;
+    for (int k = 0; k < nc; k++) cur_match[k] = -1;
+    if (nc == 0 || nk == 0) return SGX_OK;
+    if (!ckeys_un || !cdesc || !c_has_mp || !kf_keys_un || !kf_ok || !m_xw || !m_min_dist || !m_max_dist || !m_desc) return SGX_ERR_INVALID;
+    // CurrentFrame.mGrid (AssignFeaturesToGrid / PosInGrid: round(), Frame.cc:257-272, :409-419) as CSR, cell (ix, iy) -> ix * 48 + iy, index order inside a cell
+    const float invW = 64.0f / (cam->max_x - cam->min_x), invH = 48.0f / (cam->max_y - cam->min_y);
+    std::vector<int> cell((size_t)nc, -1), start(64 * 48 + 1, 0), items;
+    for (int i = 0; i < nc; i++) {
+        const int px = (int)round((ckeys_un[i].x - cam->min_x) * invW), py = (int)round((ckeys_un[i].y - cam->min_y) * invH);
+        if (px < 0 || px >= 64 || py < 0 || py >= 48) continue;
+        cell[(size_t)i] = px * 48 + py; start[(size_t)cell[(size_t)i] + 1]++;
+    }
+    for (int c = 0; c < 64 * 48; c++) start[(size_t)c + 1] += start[(size_t)c];
+    items.resize((size_t)start[64 * 48] > 0 ? (size_t)start[64 * 48] : 1);
+    { std::vector<int> fill(64 * 48, 0); for (int i = 0; i < nc; i++) if (cell[(size_t)i] >= 0) items[(size_t)start[(size_t)cell[(size_t)i]] + fill[(size_t)cell[(size_t)i]]++] = i; }
+    SgxKfProjArgs A; memset(&A, 0, sizeof A);
+    A.nc = nc; A.nk = nk; A.nlevels = nlevels; A.orb_dist = orb_dist; A.check_ori = check_orientation; A.log_scale_factor = log_scale_factor; A.th = th;
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) A.Rcw[r][c] = cTcw[4 * r + c]; A.tcw[r] = cTcw[4 * r + 3]; }
+    for (int i = 0; i < 3; i++) {                       // Ow = -Rcw.t()*tcw: transpose flag -> generic gemm, double accumulation, alpha = -1
+        double s = 0; for (int k = 0; k < 3; k++) s += (double)A.Rcw[k][i] * (double)A.tcw[k];
+        A.Ow[i] = (float)(s * -1.0);
+    }
+    A.cam.fx = cam->fx; A.cam.fy = cam->fy; A.cam.cx = cam->cx; A.cam.cy = cam->cy; A.cam.bf = cam->bf; A.cam.minX = cam->min_x; A.cam.maxX = cam->max_x; A.cam.minY = cam->min_y; A.cam.maxY = cam->max_y;
+    for (int i = 0; i < nlevels; i++) A.scale.s[i] = scale_factors[i];
+    SgxStaged b[18]; int rc;
+#define PUT(k, src, bytes) if ((rc = b[k].put(k, src, bytes)) != SGX_OK) return rc
+    PUT(0, ckeys_un, (size_t)nc * 28); PUT(1, cdesc, (size_t)nc * 32); PUT(2, c_has_mp, (size_t)nc); PUT(3, start.data(), start.size() * 4); PUT(4, items.data(), items.size() * 4);
+    PUT(5, kf_keys_un, (size_t)nk * 28); PUT(6, kf_ok, (size_t)nk); PUT(7, m_xw, (size_t)nk * 12); PUT(8, m_min_dist, (size_t)nk * 4); PUT(9, m_max_dist, (size_t)nk * 4); PUT(10, m_desc, (size_t)nk * 32);
+    PUT(11, nullptr, (size_t)nc * 4); PUT(12, nullptr, (size_t)nc * 4); PUT(13, nullptr, (size_t)nk * 4); PUT(14, nullptr, (size_t)nc * 4); PUT(15, nullptr, 4);
+#undef PUT
+    A.ckeys = (const uint8_t *)b[0].p; A.cdesc = (const uint32_t *)b[1].p; A.c_has_mp = (const uint8_t *)b[2].p; A.cell_start = (const int *)b[3].p; A.cell_items = (const int *)b[4].p;
+    A.kf_keys = (const uint8_t *)b[5].p; A.kf_ok = (const uint8_t *)b[6].p; A.m_xw = (const float *)b[7].p; A.m_min_dist = (const float *)b[8].p; A.m_max_dist = (const float *)b[9].p;
+    A.m_desc = (const uint32_t *)b[10].p; A.lock_a = (int *)b[11].p; A.lock_b = (int *)b[12].p; A.choice = (int *)b[13].p; A.cur_match = (int *)b[14].p; A.nmatches = (int *)b[15].p;
+    SGX_LAUNCH(k_match_project_kf, dim3(1), dim3(1024), (sgx_stream_t)0, A);
+    SGX_CHECK_HIP(hipGetLastError());
+    SGX_CHECK_HIP(hipMemcpy(cur_match, A.cur_match, (size_t)nc * 4, hipMemcpyDeviceToHost));
+    SGX_CHECK_HIP(hipMemcpy(nmatches, A.nmatches, 4, hipMemcpyDeviceToHost));
+    return SGX_OK;
+}

@@ -300,3 +300,145 @@ SGX_KERNEL(256) k_fuse_search(SgxFuseArgs A)
     }
     SGX_THREADS_END
 }
+
+// ---------------------------------------------------------------------------------------------
+// k_match_project_kf: ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1474-1601),
+// the relocalisation matcher.  The reference walks the keyframe's map points in index order; a point takes the best still-free keypoint of its window ("free" = no map
+// point on entry and not taken by an earlier point of this loop).  That greedy order is resolved exactly as in k_match_project_frame: lock[k] = smallest point index that
+// took keypoint k; every sweep lets all points choose in parallel against the previous sweep's locks; point i is final after i + 1 sweeps, the loop stops at the first
+// sweep that changes no lock.  Candidates are scanned in GetFeaturesInArea order (grid column, grid row, insertion order) with a strict '<', so ties fall as in the reference.
+// One workgroup (a single frame per call: relocalisation is a rare, sequential event); CSR grid built on the host.
+// ---------------------------------------------------------------------------------------------
+struct SgxKfProjArgs {
+    int nc, nk, nlevels, orb_dist, check_ori;
+    float log_scale_factor, th;
+    float Rcw[3][3], tcw[3], Ow[3];
+    SgxCam cam; SgxScales scale;
+    const uint8_t *ckeys; const uint32_t *cdesc; const uint8_t *c_has_mp; const int *cell_start; const int *cell_items;
+    const uint8_t *kf_keys; const uint8_t *kf_ok; const float *m_xw, *m_min_dist, *m_max_dist; const uint32_t *m_desc;
+    int *lock_a, *lock_b, *choice, *cur_match, *nmatches;
+};
+
+SGX_KERNEL(1024) k_match_project_kf(SgxKfProjArgs A)
+{
+    SGX_LDS int hist[SGX_HISTO], bad[SGX_HISTO];
+    SGX_LDS int s_changed, s_total, s_rejected;
+    const int NT = (int)blockDim.x;
+    SGX_THREADS_BEGIN(tid)
+    for (int k = tid; k < A.nc; k += NT) { A.lock_a[k] = A.c_has_mp[k] ? -1 : 0x7FFFFFFF; A.cur_match[k] = -1; }
+    for (int i = tid; i < SGX_HISTO; i += NT) { hist[i] = 0; bad[i] = 0; }
+    if (tid == 0) { s_total = 0; s_rejected = 0; }
+    SGX_THREADS_END
+    SGX_SYNC();
+    int *lock_cur = A.lock_a, *lock_new = A.lock_b;
+    const float invW = 64.0f / (A.cam.maxX - A.cam.minX), invH = 48.0f / (A.cam.maxY - A.cam.minY);
+    for (int sweep = 0; sweep < A.nk + 2; sweep++) {
+        SGX_THREADS_BEGIN(tid)
+        if (tid == 0) s_changed = 0;
+        for (int k = tid; k < A.nc; k += NT) lock_new[k] = A.c_has_mp[k] ? -1 : 0x7FFFFFFF;
+        SGX_THREADS_END
+        SGX_SYNC();
+        SGX_THREADS_BEGIN(tid)
+        for (int i = tid; i < A.nk; i += NT) {
+            int best = -1;
+            if (A.kf_ok[i]) {
+                const float *xw = A.m_xw + 3 * (size_t)i;
+                const float xc = sgx_gemm3(A.Rcw[0], xw, A.tcw[0]), yc = sgx_gemm3(A.Rcw[1], xw, A.tcw[1]), zc = sgx_gemm3(A.Rcw[2], xw, A.tcw[2]);
+                const float invzc = (float)(1.0 / (double)zc);
+                const float u = A.cam.fx * xc * invzc + A.cam.cx, v = A.cam.fy * yc * invzc + A.cam.cy;
+                bool ok = !(u < A.cam.minX || u > A.cam.maxX) && !(v < A.cam.minY || v > A.cam.maxY);
+                const float po0 = xw[0] - A.Ow[0], po1 = xw[1] - A.Ow[1], po2 = xw[2] - A.Ow[2];
+                const float dist3D = (float)sqrt((double)po0 * po0 + (double)po1 * po1 + (double)po2 * po2);
+                ok = ok && !(dist3D < 0.8f * A.m_min_dist[i] || dist3D > 1.2f * A.m_max_dist[i]);
+                if (ok) {
+                    int lvl = (int)ceilf((float)log((double)(A.m_max_dist[i] / dist3D)) / A.log_scale_factor);      // MapPoint::PredictScale(dist, &CurrentFrame)
+                    if (lvl < 0) lvl = 0; else if (lvl >= A.nlevels) lvl = A.nlevels - 1;
+                    const float r = A.th * A.scale.s[lvl];
+                    const int minLevel = lvl - 1, maxLevel = lvl + 1;
+                    int x0 = (int)floorf((u - A.cam.minX - r) * invW), x1 = (int)ceilf((u - A.cam.minX + r) * invW);
+                    int y0 = (int)floorf((v - A.cam.minY - r) * invH), y1 = (int)ceilf((v - A.cam.minY + r) * invH);
+                    x0 = max(x0, 0); y0 = max(y0, 0); x1 = min(x1, 63); y1 = min(y1, 47);
+                    const uint32_t *dm = A.m_desc + (size_t)i * 8;
+                    int bestDist = 256;
+                    if (x0 < 64 && y0 < 48)
+                        for (int ix = x0; ix <= x1; ix++) for (int iy = y0; iy <= y1; iy++) {
+                            const int c = ix * 48 + iy;
+                            for (int q = A.cell_start[c]; q < A.cell_start[c + 1]; q++) {
+                                const int k = A.cell_items[q];
+                                const float *kp = (const float *)(A.ckeys + (size_t)k * 28);
+                                const int oct = ((const int *)kp)[5];
+                                if (oct < minLevel) continue;                       // bCheckLevels: minLevel > 0 || maxLevel >= 0 always holds here (maxLevel >= 1)
+                                if (oct > maxLevel) continue;
+                                if (!(fabsf(kp[0] - u) < r && fabsf(kp[1] - v) < r)) continue;
+                                if (lock_cur[k] < i) continue;                     // holds a map point: on entry (-1) or taken by an earlier point of this loop
+                                const int dist = sgx_hamming256(dm, A.cdesc + (size_t)k * 8);
+                                if (dist < bestDist) { bestDist = dist; best = k; }
+                            }
+                        }
+                    if (bestDist > A.orb_dist) best = -1;
+                }
+            }
+            A.choice[i] = best;
+            if (best >= 0) sgx_atomic_min_i32(&lock_new[best], i);
+        }
+        SGX_THREADS_END
+        SGX_SYNC();
+        SGX_THREADS_BEGIN(tid)
+        for (int k = tid; k < A.nc; k += NT) if (lock_new[k] != lock_cur[k]) s_changed = 1;
+        SGX_THREADS_END
+        SGX_SYNC();
+        int *t = lock_cur; lock_cur = lock_new; lock_new = t;
+        if (!s_changed) break;
+    }
+    // assignments (at the fixpoint a keypoint is chosen by exactly one point: the one that holds its lock) and the rotation histogram
+    SGX_THREADS_BEGIN(tid)
+    for (int i = tid; i < A.nk; i += NT) {
+        const int k = A.choice[i];
+        if (k < 0) continue;
+        A.cur_match[k] = i;
+        sgx_atomic_add(&s_total, 1);
+        if (A.check_ori) {
+            const float ka = ((const float *)(A.kf_keys + (size_t)i * 28))[3], ca = ((const float *)(A.ckeys + (size_t)k * 28))[3];
+            float rot = ka - ca;
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)round((double)(rot * (SGX_HISTO / 360.0f)));
+            if (bin == SGX_HISTO) bin = 0;
+            sgx_atomic_add(&hist[bin], 1);
+        }
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+    if (A.check_ori) {
+        SGX_THREADS_BEGIN(tid)
+        if (tid == 0) {                                         // ComputeThreeMaxima, ORBmatcher.cc:1603-1644
+            int m1 = 0, m2 = 0, m3 = 0, i1 = -1, i2 = -1, i3 = -1;
+            for (int i = 0; i < SGX_HISTO; i++) {
+                const int s = hist[i];
+                if (s > m1) { m3 = m2; m2 = m1; m1 = s; i3 = i2; i2 = i1; i1 = i; }
+                else if (s > m2) { m3 = m2; m2 = s; i3 = i2; i2 = i; }
+                else if (s > m3) { m3 = s; i3 = i; }
+            }
+            if ((float)m2 < 0.1f * (float)m1) { i2 = -1; i3 = -1; }
+            else if ((float)m3 < 0.1f * (float)m1) { i3 = -1; }
+            for (int i = 0; i < SGX_HISTO; i++) bad[i] = (i != i1 && i != i2 && i != i3);
+        }
+        SGX_THREADS_END
+        SGX_SYNC();
+        SGX_THREADS_BEGIN(tid)
+        for (int i = tid; i < A.nk; i += NT) {
+            const int k = A.choice[i];
+            if (k < 0) continue;
+            const float ka = ((const float *)(A.kf_keys + (size_t)i * 28))[3], ca = ((const float *)(A.ckeys + (size_t)k * 28))[3];
+            float rot = ka - ca;
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)round((double)(rot * (SGX_HISTO / 360.0f)));
+            if (bin == SGX_HISTO) bin = 0;
+            if (bad[bin]) { A.cur_match[k] = -1; sgx_atomic_add(&s_rejected, 1); }
+        }
+        SGX_THREADS_END
+        SGX_SYNC();
+    }
+    SGX_THREADS_BEGIN(tid)
+    if (tid == 0) *A.nmatches = s_total - s_rejected;
+    SGX_THREADS_END
+}

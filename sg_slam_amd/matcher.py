@@ -117,3 +117,15 @@ class ORBmatcher:
         self.lib.check(self.lib.dll.sgx_match_fuse_search(len(k), _vp(k), _vp(d), _vp(u), _vp(T), len(xw), _vp(xw), _vp(nr), _vp(mn), _vp(mx), _vp(md), _vp(sk), C.byref(cs), _vp(sf), _vp(is2),
                                                           len(sf), float(np.log(np.float32(sf[1]))), float(th), _vp(bi), _vp(bd), _vp(n)), 'sgx_match_fuse_search')
         return int(n[0]), bi[:len(xw)].copy(), bd[:len(xw)].copy()
+
+    def SearchByProjectionKF(self, F, kf, th, ORBdist, cam, scale_factors):
+        """ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1474-1601).  F: keys, desc, has_mp, Tcw; kf: keys, ok (map point present,
+        not bad, not already found), xw, min_dist, max_dist, desc.  Returns (nmatches, cur_match[nc]): cur_match[k] = keyframe map point index given to keypoint k, or -1."""
+        ck = np.ascontiguousarray(F['keys']); cd = np.ascontiguousarray(F['desc'], np.uint8); ch = np.ascontiguousarray(F['has_mp'], np.uint8); T = np.ascontiguousarray(F['Tcw'], 'f4').reshape(16)
+        kk = np.ascontiguousarray(kf['keys']); ok = np.ascontiguousarray(kf['ok'], np.uint8); xw = np.ascontiguousarray(kf['xw'], 'f4')
+        mn = np.ascontiguousarray(kf['min_dist'], 'f4'); mx = np.ascontiguousarray(kf['max_dist'], 'f4'); md = np.ascontiguousarray(kf['desc'], np.uint8)
+        sf = np.ascontiguousarray(scale_factors, 'f4'); cs = camera_struct(cam)
+        match = np.full(max(len(ck), 1), -1, 'i4'); n = np.zeros(1, 'i4')
+        self.lib.check(self.lib.dll.sgx_match_project_keyframe(len(ck), _vp(ck), _vp(cd), _vp(ch), _vp(T), len(kk), _vp(kk), _vp(ok), _vp(xw), _vp(mn), _vp(mx), _vp(md), C.byref(cs), _vp(sf), len(sf),
+                                                               float(np.log(np.float32(sf[1]))), float(th), int(ORBdist), int(self.mbCheckOrientation), _vp(match), _vp(n)), 'sgx_match_project_keyframe')
+        return int(n[0]), match[:len(ck)].copy()

@@ -129,3 +129,53 @@ def check_fuse(lib, orc, n_cases=5):
     behind = dict(mp); behind['xw'] = mp['xw'].copy(); behind['xw'][:, 2] -= 1000.0
     en, ei, ed = orc.fuse_search(kf, behind, CAM, sf, is2, 3.0); gn, gi, gd = ORBmatcher(lib=lib).FuseSearch(kf, behind, 3.0, CAM, sf, is2)
     assert gn == en == 0 and (gi == ei).all()
+
+
+def check_project_kf(lib, orc, n_cases=5):
+    """ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist): the relocalisation matcher — same keypoint -> map point assignment as the oracle's
+    sequential loop (greedy "first point takes the keypoint" order, keypoints that hold a map point on entry, already-found points, both call shapes of Tracking::Relocalization)."""
+    sf = orc.orb_params()['scale']
+    from test_tracker_emu import make_map_points
+    total = 0
+    for c in range(n_cases):
+        gen = synth.LayeredStream(seed=4321 + c)
+        rng = np.random.RandomState(100 + c)
+        g0, d0, T0 = gen.frame(30 + c); g1, d1, T1 = gen.frame(32 + c)          # keyframe = frame 30, current frame = frame 32
+        k0, dd0 = orc.orb_extract(g0); ur0, z0 = orc.compute_stereo_from_rgbd(k0, d0, CAM['bf'], CAM['depth_factor'])
+        k1, dd1 = orc.orb_extract(g1)
+        xw, has = orc.unproject_stereo(k0, z0, T0.astype('f4'), CAM)
+        mp = make_map_points(k0, xw, has, dd0, T0.astype('f4'), np.asarray(sf, 'f4'))
+        ok = ((~mp['skip'].astype(bool)) & (rng.rand(len(k0)) > 0.15)).astype(np.uint8)            # some map points bad / already found
+        kf = dict(keys=k0, ok=ok, xw=mp['xw'], min_dist=mp['min_dist'], max_dist=mp['max_dist'], desc=mp['desc'])
+        Tc = T1.astype('f4').copy(); Tc[:3, 3] += rng.normal(0, 0.01, 3).astype('f4')               # a slightly wrong pose, as after the PnP step
+        for th, od, frac in ((10.0, 100, 0.0), (3.0, 64, 0.3), (10.0, 100, 0.6)):
+            has_mp = (rng.rand(len(k1)) < frac).astype(np.uint8)                                       # keypoints that already hold a map point
+            F = dict(keys=k1, desc=dd1, has_mp=has_mp, Tcw=Tc)
+            for ori in (True, False):
+                en, em = orc.search_by_projection_kf(F, kf, CAM, sf, th, od, ori)
+                gn, gm = ORBmatcher(0.9, ori, lib=lib).SearchByProjectionKF(F, kf, th, od, CAM, sf)
+                assert gn == en == (em >= 0).sum() and (gm == em).all(), (c, th, od, ori, gn, en, int((gm != em).sum()))
+                sel = em >= 0
+                assert not has_mp[sel].any() and ok[em[sel]].all() and len(set(em[sel])) == sel.sum()   # only free keypoints, only valid points, a point used once
+                total += en
+    assert total > 1500
+    # an adversarial lock chain: many identical map points compete for a few keypoints, so almost every point depends on the choices of the points before it
+    k, dd = orc.orb_extract(synth.LayeredStream(seed=9).frame(5)[0])
+    n = 200
+    T = np.eye(4, dtype='f4')
+    u, v = k['x'][:8].astype('f4'), k['y'][:8].astype('f4')
+    z = 2.0
+    xw = np.stack([(np.tile(u, n // 8) - CAM['cx']) / CAM['fx'] * z, (np.tile(v, n // 8) - CAM['cy']) / CAM['fy'] * z, np.full(n, z)], 1).astype('f4')
+    kfk = np.zeros(n, k.dtype); kfk['angle'] = np.tile(k['angle'][:8], n // 8); kfk['octave'] = 0
+    kf = dict(keys=kfk, ok=np.ones(n, np.uint8), xw=xw, min_dist=np.full(n, 0.5, 'f4'), max_dist=np.full(n, 2.2, 'f4'), desc=np.tile(dd[:8], (n // 8, 1)))      # predicted level 1: window levels 0..2
+    F = dict(keys=k, desc=dd, has_mp=np.zeros(len(k), np.uint8), Tcw=T)
+    en, em = orc.search_by_projection_kf(F, kf, CAM, sf, 10.0, 255, False)                     # ORBdist 255: every free keypoint of the window is acceptable -> long chains (256 would accept "no candidate": UB in the reference)
+    gn, gm = ORBmatcher(0.9, False, lib=lib).SearchByProjectionKF(F, kf, 10.0, 255, CAM, sf)
+    assert gn == en and (gm == em).all() and en >= 10, (gn, en)                 # 200 points compete for the handful of keypoints of 8 windows
+    # degenerate inputs
+    e = dict(keys=k[:0], desc=dd[:0], has_mp=np.zeros(0, np.uint8), Tcw=T)
+    assert ORBmatcher(lib=lib).SearchByProjectionKF(e, kf, 10.0, 100, CAM, sf)[0] == 0
+    ekf = {kk: vv[:0] for kk, vv in kf.items()}
+    assert ORBmatcher(lib=lib).SearchByProjectionKF(F, ekf, 10.0, 100, CAM, sf)[0] == 0
+    allt = dict(F); allt['has_mp'] = np.ones(len(k), np.uint8)
+    assert ORBmatcher(lib=lib).SearchByProjectionKF(allt, kf, 10.0, 100, CAM, sf)[0] == 0 == orc.search_by_projection_kf(allt, kf, CAM, sf, 10.0, 100)[0]

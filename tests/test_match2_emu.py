@@ -16,3 +16,7 @@ def test_search_by_bow_emu(emu, oracle):
 
 def test_fuse_search_emu(emu, oracle):
     mc.check_fuse(emu, oracle, n_cases=3)
+
+
+def test_project_keyframe_emu(emu, oracle):
+    mc.check_project_kf(emu, oracle, n_cases=2)

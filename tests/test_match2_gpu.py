@@ -19,3 +19,7 @@ def test_search_by_bow_gpu(gpulib, oracle):
 
 def test_fuse_search_gpu(gpulib, oracle):
     mc.check_fuse(gpulib, oracle, n_cases=6)
+
+
+def test_project_keyframe_gpu(gpulib, oracle):
+    mc.check_project_kf(gpulib, oracle, n_cases=5)
