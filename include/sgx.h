@@ -271,6 +271,15 @@ int sgx_local_bundle_adjustment(const sgx_ba_problem *problem, const sgx_camera 
  * vbNotIncludedMP) — the caller stores them with SetPose / SetWorldPos (nLoopKF == 0) or in mTcwGBA / mPosGBA.  stats: iterations_first, chi2_first. */
 int sgx_bundle_adjustment(const sgx_ba_problem *problem, const sgx_camera *cam, int n_iterations, const volatile int32_t *stop_flag, int robust, sgx_ba_stats *stats);
 
+/* int Optimizer::OptimizeSim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches1, g2o::Sim3 &g2oS12, const float th2, const bool bFixScale)
+ * (src/sg-slam/include/Optimizer.h:56-57, src/sg-slam/src/Optimizer.cc:1046-1257; caller LoopClosing::ComputeSim3, LoopClosing.cc:326).  The caller lists the n correspondences the
+ * reference turns into edge pairs (vpMatches1[i] && both map points good && pMP2 observed in pKF2, :1107-1133) in index order: p1c / p2c = the two map points in their own
+ * keyframe's camera frame (R1w*P3D1w + t1w, R2w*P3D2w + t2w), obs1 / obs2 = kpUn.pt, info1 / info2 = mvInvLevelSigma2[octave], K1 / K2 = (fx, fy, cx, cy).
+ * S12 in/out = (qx, qy, qz, qw, tx, ty, tz, s) of g2o::Sim3; inlier[i] = 0 where the reference sets vpMatches1[idx] = NULL; iterations (optional) = LM iterations of the two
+ * optimize() calls; *n_inliers = return value (0 with S12 untouched when fewer than 10 correspondences survive the first check).  Host pointers, synchronous. */
+int sgx_optimize_sim3(int n, const float *p1c, const float *p2c, const float *obs1, const float *obs2, const float *info1, const float *info2,
+                      const float *K1, const float *K2, double *S12, float th2, int fix_scale, uint8_t *inlier, int32_t *iterations, int32_t *n_inliers);
+
 /* ---- 2-D detector + dynamic-feature mask --------------------------------------------------------
  * Replaces ORB_SLAM2::Detector2D (src/sg-slam/include/Detector2D.h:45-67, src/sg-slam/src/Detector2D.cc:16-89): the ncnn
  * forward pass of the shipped MobileNetV3-SSDLite graph (Thirdparty/ncnn_model/mobilenetv3_ssdlite_voc.param + .bin) on 300x300,

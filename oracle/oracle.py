@@ -380,3 +380,15 @@ def search_by_projection_kf(F, kf, cam, scale_factors, th, orb_dist, check_ori=T
                                       C.c_float(cam.get('min_x', 0.0)), C.c_float(cam.get('max_x', 640.0)), C.c_float(cam.get('min_y', 0.0)), C.c_float(cam.get('max_y', 480.0)),
                                       _p(sf), C.c_int(len(sf)), C.c_float(np.log(np.float32(sf[1]))), C.c_float(th), C.c_int(orb_dist), C.c_int(int(bool(check_ori))), _p(match))
     return int(n), match[:len(ck)].copy()
+
+
+def optimize_sim3(p1c, p2c, obs1, obs2, info1, info2, K1, K2, S12, th2=10.0, fix_scale=False):
+    """Optimizer::OptimizeSim3 on flattened correspondences: (nIn, S12[8] = (qx,qy,qz,qw,tx,ty,tz,s), inlier[n], iterations[2])."""
+    p1c = np.ascontiguousarray(p1c, 'f4').reshape(-1, 3); p2c = np.ascontiguousarray(p2c, 'f4').reshape(-1, 3); n = len(p1c)
+    o1 = np.ascontiguousarray(obs1, 'f4').reshape(-1, 2); o2 = np.ascontiguousarray(obs2, 'f4').reshape(-1, 2)
+    i1 = np.ascontiguousarray(info1, 'f4'); i2 = np.ascontiguousarray(info2, 'f4')
+    k1 = np.ascontiguousarray(K1, 'f4'); k2 = np.ascontiguousarray(K2, 'f4')
+    S = np.ascontiguousarray(S12, 'f8').copy(); inl = np.zeros(max(n, 1), np.uint8); it = np.zeros(2, 'i4')
+    L = lib(); L.orc_optimize_sim3.restype = C.c_int
+    nin = L.orc_optimize_sim3(C.c_int(n), _p(p1c), _p(p2c), _p(o1), _p(o2), _p(i1), _p(i2), _p(k1), _p(k2), _p(S), C.c_float(th2), C.c_int(int(bool(fix_scale))), _p(inl), _p(it))
+    return int(nin), S, inl[:n].copy(), it

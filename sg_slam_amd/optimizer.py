@@ -68,3 +68,17 @@ class Optimizer:
         else:
             problem['poses_gba'] = poses.reshape(-1, 4, 4); problem['points_gba'] = pts; problem['mnBAGlobalForKF'] = nLoopKF
         return dict(iterations=st.iterations_first, chi2=st.chi2_first, free_poses=st.free_poses)
+
+    @staticmethod
+    def OptimizeSim3(p1c, p2c, obs1, obs2, info1, info2, K1, K2, S12, th2=10.0, bFixScale=False, lib=None):
+        """Optimizer::OptimizeSim3(pKF1, pKF2, vpMatches1, g2oS12, th2, bFixScale) (Optimizer.cc:1046-1257) on the flattened correspondences (see include/sgx.h):
+        returns (nIn, S12[8] = (qx, qy, qz, qw, tx, ty, tz, s), inlier[n], iterations[2])."""
+        lib = lib if lib is not None else load()
+        p1c = np.ascontiguousarray(p1c, 'f4').reshape(-1, 3); p2c = np.ascontiguousarray(p2c, 'f4').reshape(-1, 3); n = len(p1c)
+        o1 = np.ascontiguousarray(obs1, 'f4').reshape(-1, 2); o2 = np.ascontiguousarray(obs2, 'f4').reshape(-1, 2)
+        i1 = np.ascontiguousarray(info1, 'f4'); i2 = np.ascontiguousarray(info2, 'f4')
+        k1 = np.ascontiguousarray(K1, 'f4'); k2 = np.ascontiguousarray(K2, 'f4')
+        S = np.ascontiguousarray(S12, 'f8').copy(); inl = np.zeros(max(n, 1), np.uint8); it = np.zeros(2, 'i4'); nin = np.zeros(1, 'i4')
+        lib.check(lib.dll.sgx_optimize_sim3(n, _vp(p1c), _vp(p2c), _vp(o1), _vp(o2), _vp(i1), _vp(i2), _vp(k1), _vp(k2), _vp(S), float(th2), int(bool(bFixScale)), _vp(inl), _vp(it), _vp(nin)),
+                  'sgx_optimize_sim3')
+        return int(nin[0]), S, inl[:n].copy(), it
