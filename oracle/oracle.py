@@ -392,3 +392,21 @@ def optimize_sim3(p1c, p2c, obs1, obs2, info1, info2, K1, K2, S12, th2=10.0, fix
     L = lib(); L.orc_optimize_sim3.restype = C.c_int
     nin = L.orc_optimize_sim3(C.c_int(n), _p(p1c), _p(p2c), _p(o1), _p(o2), _p(i1), _p(i2), _p(k1), _p(k2), _p(S), C.c_float(th2), C.c_int(int(bool(fix_scale))), _p(inl), _p(it))
     return int(nin), S, inl[:n].copy(), it
+
+
+def optimize_essential_graph(S, fixed, e_i, e_j, e_meas, fix_scale=True, iterations=20):
+    """the optimisation of Optimizer::OptimizeEssentialGraph on a flattened pose graph: (S_out[nv,8], stats[iterations, chi2 before, chi2 after])"""
+    S = np.ascontiguousarray(S, 'f8').reshape(-1, 8).copy(); fx = np.ascontiguousarray(fixed, np.uint8)
+    ei = np.ascontiguousarray(e_i, 'i4'); ej = np.ascontiguousarray(e_j, 'i4'); em = np.ascontiguousarray(e_meas, 'f8').reshape(-1, 8)
+    st = np.zeros(3, 'f8')
+    L = lib(); L.orc_optimize_essential_graph.restype = C.c_int
+    L.orc_optimize_essential_graph(C.c_int(len(S)), _p(S), _p(fx), C.c_int(len(ei)), _p(ei), _p(ej), _p(em), C.c_int(int(bool(fix_scale))), C.c_int(iterations), _p(st))
+    return S, st
+
+
+def correct_map_points(xw, ref, Srw, corrected_Swr):
+    xw = np.ascontiguousarray(xw, 'f4').reshape(-1, 3); ref = np.ascontiguousarray(ref, 'i4')
+    a = np.ascontiguousarray(Srw, 'f8').reshape(-1, 8); c = np.ascontiguousarray(corrected_Swr, 'f8').reshape(-1, 8)
+    out = np.zeros_like(xw)
+    lib().orc_correct_map_points(C.c_int(len(xw)), _p(xw), _p(ref), _p(a), _p(c), _p(out))
+    return out

@@ -235,3 +235,185 @@ int orc_optimize_sim3(int n, const float *p1c, const float *p2c, const float *ob
     free(E);
     return nIn;
 }
+
+/* ===================================================================================================================
+ * Optimizer::OptimizeEssentialGraph (src/sg-slam/src/Optimizer.cc:781-1042; caller LoopClosing::CorrectLoop, LoopClosing.cc:567): the pose-graph optimisation itself.
+ * The graph construction (:807-958 — which keyframes are connected and the measurements Sji = Sjw * Swi) walks the map's covisibility / spanning-tree / loop-edge containers and
+ * stays with the caller; this function takes the vertices (initial Sim3 estimates, the fixed loop keyframe) and the EdgeSim3 list in insertion order and runs
+ *   solver->setUserLambdaInit(1e-16); optimizer.initializeOptimization(); optimizer.optimize(20);                                  (:794, :961-962)
+ * EdgeSim3::computeError: _error = (C * v1 * v2^-1).log() (G/types/types_seven_dof_expmap.h:100-108), information = identity, no robust kernel, numeric Jacobians for both
+ * vertices (G/core/base_binary_edge.hpp:131-205); Sim3::log G/types/sim3.h:145-226 (deltaR: G/types/se3_ops.hpp; W.lu().solve(t): Eigen PartialPivLU, restated).
+ * The reference solves the sparse normal equations with Eigen's sparse Cholesky (LinearSolverEigen); here they are dense (same solution up to rounding).
+ * =================================================================================================================== */
+static void lu3_solve(const double Ain[3][3], const double b[3], double x[3])
+{   /* Eigen PartialPivLU of a 3x3 and solve */
+    double A[3][3]; int p[3] = { 0, 1, 2 };
+    memcpy(A, Ain, sizeof A);
+    for (int k = 0; k < 3; k++) {
+        int piv = k; double big = fabs(A[k][k]);
+        for (int i = k + 1; i < 3; i++) if (fabs(A[i][k]) > big) { big = fabs(A[i][k]); piv = i; }
+        if (piv != k) { for (int j = 0; j < 3; j++) { double t = A[k][j]; A[k][j] = A[piv][j]; A[piv][j] = t; } int t = p[k]; p[k] = p[piv]; p[piv] = t; }
+        for (int i = k + 1; i < 3; i++) { A[i][k] /= A[k][k]; for (int j = k + 1; j < 3; j++) A[i][j] -= A[i][k] * A[k][j]; }
+    }
+    double y[3];
+    for (int i = 0; i < 3; i++) { y[i] = b[p[i]]; for (int j = 0; j < i; j++) y[i] -= A[i][j] * y[j]; }
+    for (int i = 2; i >= 0; i--) { double v = y[i]; for (int j = i + 1; j < 3; j++) v -= A[i][j] * x[j]; x[i] = v / A[i][i]; }
+}
+static void sim3_log(const sim3 *S, double res[7])
+{   /* Sim3::log, sim3.h:145-226 */
+    const double sigma = log(S->s);
+    double R[3][3]; quat_to_R(S->q, R);
+    const double d = 0.5 * (R[0][0] + R[1][1] + R[2][2] - 1);
+    const double dR[3] = { R[2][1] - R[1][2], R[0][2] - R[2][0], R[1][0] - R[0][1] };
+    const double eps = 0.00001;
+    double omega[3], A, B, C;
+    if (fabs(sigma) < eps) {
+        C = 1;
+        if (d > 1 - eps) { for (int i = 0; i < 3; i++) omega[i] = 0.5 * dR[i]; A = 1. / 2.; B = 1. / 6.; }
+        else {
+            const double theta = acos(d), theta2 = theta * theta, f = theta / (2 * sqrt(1 - d * d));
+            for (int i = 0; i < 3; i++) omega[i] = f * dR[i];
+            A = (1 - cos(theta)) / theta2; B = (theta - sin(theta)) / (theta2 * theta);
+        }
+    } else {
+        C = (S->s - 1) / sigma;
+        if (d > 1 - eps) {
+            const double sigma2 = sigma * sigma;
+            for (int i = 0; i < 3; i++) omega[i] = 0.5 * dR[i];
+            A = ((sigma - 1) * S->s + 1) / sigma2; B = ((0.5 * sigma2 - sigma + 1) * S->s) / (sigma2 * sigma);
+        } else {
+            const double theta = acos(d), f = theta / (2 * sqrt(1 - d * d));
+            for (int i = 0; i < 3; i++) omega[i] = f * dR[i];
+            const double theta2 = theta * theta, a = S->s * sin(theta), b = S->s * cos(theta), c = theta2 + sigma * sigma;
+            A = (a * sigma + (1 - b) * theta) / (theta * c);
+            B = (C - ((b - 1) * sigma + a * theta) / c) * 1. / theta2;
+        }
+    }
+    const double O[3][3] = { { 0, -omega[2], omega[1] }, { omega[2], 0, -omega[0] }, { -omega[1], omega[0], 0 } };
+    double O2[3][3], W[3][3], ups[3];
+    mat3_mul(O, O, O2);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) W[i][j] = (A * O[i][j] + B * O2[i][j]) + C * (i == j);
+    lu3_solve(W, S->t, ups);
+    for (int i = 0; i < 3; i++) { res[i] = omega[i]; res[3 + i] = ups[i]; }
+    res[6] = sigma;
+}
+static void eg_error(const sim3 *C, const sim3 *vi, const sim3 *vj, double e[7])
+{
+    sim3 a, inv, b; sim3_mul(C, vi, &a); sim3_inverse(vj, &inv); sim3_mul(&a, &inv, &b); sim3_log(&b, e);
+}
+static void load_sim3(const double *p, sim3 *s) { memcpy(s->q, p, 32); memcpy(s->t, p + 4, 24); s->s = p[7]; }
+static void store_sim3(const sim3 *s, double *p) { memcpy(p, s->q, 32); memcpy(p + 4, s->t, 24); p[7] = s->s; }
+
+/* dense Cholesky solve of the n x n system (row-major, only the full symmetric matrix is read); returns 0 when a pivot is not positive */
+static int chol_solve_dense(int n, double *A, const double *b, double *x)
+{
+    for (int j = 0; j < n; j++) {
+        double d = A[(size_t)j * n + j];
+        for (int k = 0; k < j; k++) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
+        if (!(d > 0)) return 0;
+        d = sqrt(d); A[(size_t)j * n + j] = d;
+        for (int i = j + 1; i < n; i++) {
+            double v = A[(size_t)i * n + j];
+            for (int k = 0; k < j; k++) v -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
+            A[(size_t)i * n + j] = v / d;
+        }
+    }
+    for (int i = 0; i < n; i++) { double v = b[i]; for (int k = 0; k < i; k++) v -= A[(size_t)i * n + k] * x[k]; x[i] = v / A[(size_t)i * n + i]; }
+    for (int i = n - 1; i >= 0; i--) { double v = x[i]; for (int k = i + 1; k < n; k++) v -= A[(size_t)k * n + i] * x[k]; x[i] = v / A[(size_t)i * n + i]; }
+    return 1;
+}
+
+/* S (nv x 8, in/out): vertex estimates (qx,qy,qz,qw,tx,ty,tz,s); fixed[v] != 0: setFixed(true); edges e: vertex 0 = e_i, vertex 1 = e_j, measurement e_meas (ne x 8).
+ * stats (optional, 3 doubles): iterations run, chi2 before, chi2 after.  Returns the number of LM iterations. */
+int orc_optimize_essential_graph(int nv, double *S, const uint8_t *fixed, int ne, const int *e_i, const int *e_j, const double *e_meas, int fix_scale, int iterations, double *stats)
+{
+    sim3 *V = (sim3 *)malloc(sizeof(sim3) * (size_t)(nv > 0 ? nv : 1)), *Bk = (sim3 *)malloc(sizeof(sim3) * (size_t)(nv > 0 ? nv : 1));
+    int *hidx = (int *)malloc(sizeof(int) * (size_t)(nv > 0 ? nv : 1));
+    int nf = 0;
+    for (int v = 0; v < nv; v++) { load_sim3(S + 8 * v, &V[v]); hidx[v] = fixed[v] ? -1 : nf++; }
+    const int n = 7 * nf;
+    double *H = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1) * (size_t)(n > 0 ? n : 1)), *Hl = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1) * (size_t)(n > 0 ? n : 1));
+    double *b = (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double)), *x = (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double));
+    double (*err)[7] = (double (*)[7])malloc(sizeof(double) * 7 * (size_t)(ne > 0 ? ne : 1));
+    sim3 *M = (sim3 *)malloc(sizeof(sim3) * (size_t)(ne > 0 ? ne : 1));
+    for (int k = 0; k < ne; k++) load_sim3(e_meas + 8 * k, &M[k]);
+    double lambda = -1, ni = 2; int nBadLM = 0, iters = 0; double chi_first = 0, chi_last = 0;
+    for (int it = 0; it < iterations && n > 0; it++) {
+        double currentChi = 0;
+        for (int k = 0; k < ne; k++) { eg_error(&M[k], &V[e_i[k]], &V[e_j[k]], err[k]); for (int c = 0; c < 7; c++) currentChi += err[k][c] * err[k][c]; }
+        if (it == 0) chi_first = currentChi;
+        double tempChi = currentChi; const double iniChi = currentChi;
+        memset(H, 0, sizeof(double) * (size_t)n * n); memset(b, 0, sizeof(double) * (size_t)n);
+        const double dl = 1e-9, scalar = 1.0 / (2 * dl);
+        for (int k = 0; k < ne; k++) {
+            const int vi = e_i[k], vj = e_j[k], hi = hidx[vi], hj = hidx[vj];
+            double J[2][7][7];                                     /* J[side][row][col] */
+            for (int side = 0; side < 2; side++) {
+                const int hv = side ? hj : hi; if (hv < 0) continue;
+                for (int d = 0; d < 7; d++) {
+                    double add[7] = { 0, 0, 0, 0, 0, 0, 0 }, ep[7], em[7]; sim3 pp, pm;
+                    add[d] = dl; oplus(side ? &V[vj] : &V[vi], add, fix_scale, &pp);
+                    add[d] = -dl; oplus(side ? &V[vj] : &V[vi], add, fix_scale, &pm);
+                    if (!side) { eg_error(&M[k], &pp, &V[vj], ep); eg_error(&M[k], &pm, &V[vj], em); } else { eg_error(&M[k], &V[vi], &pp, ep); eg_error(&M[k], &V[vi], &pm, em); }
+                    for (int r = 0; r < 7; r++) J[side][r][d] = scalar * (ep[r] - em[r]);
+                }
+            }
+            for (int sa = 0; sa < 2; sa++) {
+                const int ha = sa ? hj : hi; if (ha < 0) continue;
+                for (int a = 0; a < 7; a++) {
+                    double s = 0; for (int r = 0; r < 7; r++) s += J[sa][r][a] * err[k][r];
+                    b[7 * ha + a] -= s;
+                    for (int sb = 0; sb < 2; sb++) {
+                        const int hb = sb ? hj : hi; if (hb < 0) continue;
+                        for (int c = 0; c < 7; c++) { double h = 0; for (int r = 0; r < 7; r++) h += J[sa][r][a] * J[sb][r][c]; H[(size_t)(7 * ha + a) * n + 7 * hb + c] += h; }
+                    }
+                }
+            }
+        }
+        if (it == 0) { lambda = 1e-16; ni = 2; nBadLM = 0; }          /* computeLambdaInit: _userLambdaInit > 0 */
+        double rho = 0; int qmax = 0;
+        do {
+            memcpy(Bk, V, sizeof(sim3) * (size_t)nv);
+            memcpy(Hl, H, sizeof(double) * (size_t)n * n);
+            for (int j = 0; j < n; j++) Hl[(size_t)j * n + j] += lambda;
+            const int ok2 = chol_solve_dense(n, Hl, b, x);           /* a failed factorisation leaves x from the previous solve, as g2o's _x */
+            for (int v = 0; v < nv; v++) if (hidx[v] >= 0) { sim3 u; oplus(&V[v], x + 7 * hidx[v], fix_scale, &u); V[v] = u; }
+            tempChi = 0;
+            for (int k = 0; k < ne; k++) { eg_error(&M[k], &V[e_i[k]], &V[e_j[k]], err[k]); for (int c = 0; c < 7; c++) tempChi += err[k][c] * err[k][c]; }
+            if (!ok2) tempChi = DBL_MAX;
+            rho = currentChi - tempChi;
+            double scale = 0; for (int j = 0; j < n; j++) scale += x[j] * (lambda * x[j] + b[j]);
+            scale += 1e-3; rho /= scale;
+            if (rho > 0 && isfinite(tempChi)) {
+                double alpha = 1. - pow((2 * rho - 1), 3);
+                alpha = alpha < 2. / 3. ? alpha : 2. / 3.;
+                const double sf = alpha > 1. / 3. ? alpha : 1. / 3.;
+                lambda *= sf; ni = 2; currentChi = tempChi;
+            } else { lambda *= ni; ni *= 2; memcpy(V, Bk, sizeof(sim3) * (size_t)nv); }
+            qmax++;
+        } while (rho < 0 && qmax < 10);
+        iters = it + 1; chi_last = currentChi;
+        if (qmax == 10 || rho == 0) break;
+        if ((iniChi - currentChi) * 1e3 < iniChi) nBadLM++; else nBadLM = 0;
+        if (nBadLM >= 3) break;
+    }
+    for (int v = 0; v < nv; v++) store_sim3(&V[v], S + 8 * v);
+    if (stats) { stats[0] = iters; stats[1] = chi_first; stats[2] = chi_last; }
+    free(V); free(Bk); free(hidx); free(H); free(Hl); free(b); free(x); free(err); free(M);
+    return iters;
+}
+
+/* the map-point correction that follows (Optimizer.cc:1004-1041): P' = correctedSwr.map(Srw.map(P)) with the point's reference keyframe r; fp64 inside, float at the cv::Mat boundary */
+void orc_correct_map_points(int n, const float *xw, const int *ref, const double *Srw, const double *corrected_Swr, float *out)
+{
+    for (int i = 0; i < n; i++) {
+        sim3 a, c; load_sim3(Srw + 8 * ref[i], &a); load_sim3(corrected_Swr + 8 * ref[i], &c);
+        const double p[3] = { xw[3 * i], xw[3 * i + 1], xw[3 * i + 2] }; double m[3], o[3];
+        sim3_map(&a, p, m); sim3_map(&c, m, o);
+        out[3 * i] = (float)o[0]; out[3 * i + 1] = (float)o[1]; out[3 * i + 2] = (float)o[2];
+    }
+}
+
+/* known-answer taps (tests/test_sim3.py): Sim3 exp / log / product / inverse on (qx,qy,qz,qw,tx,ty,tz,s) */
+void orc_kat_sim3_exp(const double *u, double *out8) { sim3 s; sim3_exp(u, &s); store_sim3(&s, out8); }
+void orc_kat_sim3_log(const double *s8, double *out7) { sim3 s; load_sim3(s8, &s); sim3_log(&s, out7); }

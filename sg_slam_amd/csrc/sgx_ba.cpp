@@ -120,6 +120,60 @@ static int build_jobs(BA &B, const std::vector<int> &pt_start, const std::vector
     return SGX_OK;
 }
 
+// Dense symmetric positive definite solve  S x = bp - coef  on the device (in place: S is overwritten by its factor): register / LDS kernels for small systems, the blocked
+// right-looking Cholesky with the fp64-MFMA trailing update above SGX_CHOL_SMALL unknowns.  *ok (device) is cleared when a pivot is not positive; x then keeps its previous
+// content.  *xout = where the solution was left (xp or xsol).  Shared by the bundle adjustments (reduced camera system) and the essential-graph optimisation.
+struct Chol { int NP; double *S, *Linv, *bp, *coef, *xp, *xsol; int *ok; };
+static int chol_factor_solve(const Chol &C, const double **xout)
+{
+    *xout = C.xp;
+    // workgroup sizes of the single-workgroup solver kernels (env = tuning taps): their phases are short, so fewer waves mean cheaper barriers
+    static const int t_small = getenv("SGX_TUNE_CHOL_SMALL_THREADS") ? atoi(getenv("SGX_TUNE_CHOL_SMALL_THREADS")) : 256;
+    static const int t_diag = getenv("SGX_TUNE_CHOL_DIAG_THREADS") ? atoi(getenv("SGX_TUNE_CHOL_DIAG_THREADS")) : 256;
+    static const int t_solve = getenv("SGX_TUNE_CHOL_SOLVE_THREADS") ? atoi(getenv("SGX_TUNE_CHOL_SOLVE_THREADS")) : 256;
+    if (C.NP > 0 && C.NP <= SGX_CHOL_SMALL) {
+        static const int small_lds = getenv("SGX_TUNE_CHOL_SMALL_LDS") ? atoi(getenv("SGX_TUNE_CHOL_SMALL_LDS")) : 0;     // 1 = the LDS-resident version (comparison tap)
+        if (small_lds) SGX_LAUNCH(k_chol_small, dim3(1), dim3(t_small), (sgx_stream_t)0, C.NP, C.S, C.bp, C.coef, C.xp, C.ok);
+        else SGX_LAUNCH(k_chol_small_reg, dim3(1), dim3(256), (sgx_stream_t)0, C.NP, C.S, C.bp, C.coef, C.xp, C.ok);
+    } else if (C.NP > 0) {                                   // blocked Cholesky of the reduced camera system
+        const int nt = (C.NP + SGX_NB - 1) / SGX_NB;
+        // tiles per outer panel; small systems keep one level (a rank-256 launch on the critical path costs them more than its eight rank-32 shares)
+        static const int wide_min = getenv("SGX_TUNE_CHOL_WIDE_MIN") ? atoi(getenv("SGX_TUNE_CHOL_WIDE_MIN")) : 1024;
+        const int OT = C.NP > wide_min ? SGX_OB / SGX_NB : (1 << 24);
+        for (int kb = 0; kb < nt; kb++) {
+            const int k0 = kb * SGX_NB, rem = nt - kb - 1;
+            const int in_panel = OT - 1 - kb % OT;           // column tiles right of this one that still belong to the outer panel
+#ifndef SGX_EMU
+            static const int diag_lds = getenv("SGX_TUNE_CHOL_DIAG_LDS") ? atoi(getenv("SGX_TUNE_CHOL_DIAG_LDS")) : 0;      // 1 = the workgroup / LDS version (comparison tap)
+            if (!diag_lds) SGX_LAUNCH(k_chol_diag_wave, dim3(1), dim3(64), (sgx_stream_t)0, C.NP, k0, C.S, C.Linv, C.ok, C.bp, C.coef, C.xp);
+            else
+#endif
+            SGX_LAUNCH(k_chol_diag, dim3(1), dim3(t_diag), (sgx_stream_t)0, C.NP, k0, C.S, C.Linv, C.ok, C.bp, C.coef, C.xp);
+            if (rem > 0) {
+                SGX_LAUNCH(k_chol_panel, dim3(rem), dim3(256), (sgx_stream_t)0, C.NP, k0, C.S, C.Linv, C.ok, C.xp);
+                const int pc = in_panel < rem ? in_panel : rem;
+                if (pc > 0) SGX_LAUNCH(k_chol_update, dim3(rem, pc), dim3(256), (sgx_stream_t)0, C.NP, k0, C.S, C.ok);
+                if (in_panel == 0) {                         // panel finished: one rank-256 update of the rest on the matrix cores
+                    const int p0 = (kb / OT) * SGX_OB, q0 = p0 + SGX_OB;
+                    const int wt = (C.NP - q0 + SGX_WT - 1) / SGX_WT;
+                    if (wt > 0) SGX_LAUNCH(k_chol_update_wide, dim3(wt, wt), dim3(256), (sgx_stream_t)0, C.NP, p0, SGX_OB, C.S, C.ok);
+                }
+            }
+        }
+        static const int back_min = getenv("SGX_TUNE_CHOL_BACK_MIN") ? atoi(getenv("SGX_TUNE_CHOL_BACK_MIN")) : 0;     // measured: the per-block launches win at every blocked size (360 unknowns: 9.9 -> 9.5 ms per LocalBA, 12 000: 2.5 -> 1.1 s)
+        if (C.NP < back_min) {
+            SGX_LAUNCH(k_chol_solve, dim3(1), dim3(t_solve), (sgx_stream_t)0, C.NP, C.S, C.Linv, C.bp, C.coef, C.xp, C.ok);
+        } else {                                            // one launch per diagonal block, all CUs on the row panel (k_chol_back_step)
+            for (int kb = nt - 1; kb >= 0; kb--) {
+                const int k0 = kb * SGX_NB;
+                SGX_LAUNCH(k_chol_back_step, dim3(k0 > 0 ? (k0 + 255) / 256 : 1), dim3(256), (sgx_stream_t)0, C.NP, k0, C.S, C.Linv, C.xp, C.xsol, C.ok);
+            }
+            *xout = C.xsol;
+        }
+    }
+    return SGX_OK;
+}
+
 // one optimizer.optimize(iterations) call
 static int optimize(BA &B, int iterations, int *iters_done, double *final_chi)
 {
@@ -154,50 +208,7 @@ static int optimize(BA &B, int iterations, int *iters_done, double *final_chi)
                 SGX_LAUNCH(k_ba_schur_pairs, dim3((unsigned)((n36 + SGX_BA_THREADS - 1) / SGX_BA_THREADS)), dim3(SGX_BA_THREADS), (sgx_stream_t)0, n36, B.nf, B.blk_start, B.jobs, B.E,
                            B.hidx, B.bl, B.Hpl, B.Dinv, B.S, B.coef);
             }
-            // workgroup sizes of the single-workgroup solver kernels (env = tuning taps): their phases are short, so fewer waves mean cheaper barriers
-            static const int t_small = getenv("SGX_TUNE_CHOL_SMALL_THREADS") ? atoi(getenv("SGX_TUNE_CHOL_SMALL_THREADS")) : 256;
-            static const int t_diag = getenv("SGX_TUNE_CHOL_DIAG_THREADS") ? atoi(getenv("SGX_TUNE_CHOL_DIAG_THREADS")) : 256;
-            static const int t_solve = getenv("SGX_TUNE_CHOL_SOLVE_THREADS") ? atoi(getenv("SGX_TUNE_CHOL_SOLVE_THREADS")) : 256;
-            if (B.NP > 0 && B.NP <= SGX_CHOL_SMALL) {
-                static const int small_lds = getenv("SGX_TUNE_CHOL_SMALL_LDS") ? atoi(getenv("SGX_TUNE_CHOL_SMALL_LDS")) : 0;     // 1 = the LDS-resident version (comparison tap)
-                if (small_lds) SGX_LAUNCH(k_chol_small, dim3(1), dim3(t_small), (sgx_stream_t)0, B.NP, B.S, B.bp, B.coef, B.xp, B.ok);
-                else SGX_LAUNCH(k_chol_small_reg, dim3(1), dim3(256), (sgx_stream_t)0, B.NP, B.S, B.bp, B.coef, B.xp, B.ok);
-            } else if (B.NP > 0) {                                   // blocked Cholesky of the reduced camera system
-                const int nt = (B.NP + SGX_NB - 1) / SGX_NB;
-                // tiles per outer panel; small systems keep one level (a rank-256 launch on the critical path costs them more than its eight rank-32 shares)
-                static const int wide_min = getenv("SGX_TUNE_CHOL_WIDE_MIN") ? atoi(getenv("SGX_TUNE_CHOL_WIDE_MIN")) : 1024;
-                const int OT = B.NP > wide_min ? SGX_OB / SGX_NB : (1 << 24);
-                for (int kb = 0; kb < nt; kb++) {
-                    const int k0 = kb * SGX_NB, rem = nt - kb - 1;
-                    const int in_panel = OT - 1 - kb % OT;           // column tiles right of this one that still belong to the outer panel
-#ifndef SGX_EMU
-                    static const int diag_lds = getenv("SGX_TUNE_CHOL_DIAG_LDS") ? atoi(getenv("SGX_TUNE_CHOL_DIAG_LDS")) : 0;      // 1 = the workgroup / LDS version (comparison tap)
-                    if (!diag_lds) SGX_LAUNCH(k_chol_diag_wave, dim3(1), dim3(64), (sgx_stream_t)0, B.NP, k0, B.S, B.Linv, B.ok, B.bp, B.coef, B.xp);
-                    else
-#endif
-                    SGX_LAUNCH(k_chol_diag, dim3(1), dim3(t_diag), (sgx_stream_t)0, B.NP, k0, B.S, B.Linv, B.ok, B.bp, B.coef, B.xp);
-                    if (rem > 0) {
-                        SGX_LAUNCH(k_chol_panel, dim3(rem), dim3(256), (sgx_stream_t)0, B.NP, k0, B.S, B.Linv, B.ok, B.xp);
-                        const int pc = in_panel < rem ? in_panel : rem;
-                        if (pc > 0) SGX_LAUNCH(k_chol_update, dim3(rem, pc), dim3(256), (sgx_stream_t)0, B.NP, k0, B.S, B.ok);
-                        if (in_panel == 0) {                         // panel finished: one rank-256 update of the rest on the matrix cores
-                            const int p0 = (kb / OT) * SGX_OB, q0 = p0 + SGX_OB;
-                            const int wt = (B.NP - q0 + SGX_WT - 1) / SGX_WT;
-                            if (wt > 0) SGX_LAUNCH(k_chol_update_wide, dim3(wt, wt), dim3(256), (sgx_stream_t)0, B.NP, p0, SGX_OB, B.S, B.ok);
-                        }
-                    }
-                }
-                static const int back_min = getenv("SGX_TUNE_CHOL_BACK_MIN") ? atoi(getenv("SGX_TUNE_CHOL_BACK_MIN")) : 0;     // measured: the per-block launches win at every blocked size (360 unknowns: 9.9 -> 9.5 ms per LocalBA, 12 000: 2.5 -> 1.1 s)
-                if (B.NP < back_min) {
-                    SGX_LAUNCH(k_chol_solve, dim3(1), dim3(t_solve), (sgx_stream_t)0, B.NP, B.S, B.Linv, B.bp, B.coef, B.xp, B.ok);
-                } else {                                            // one launch per diagonal block, all CUs on the row panel (k_chol_back_step)
-                    for (int kb = nt - 1; kb >= 0; kb--) {
-                        const int k0 = kb * SGX_NB;
-                        SGX_LAUNCH(k_chol_back_step, dim3(k0 > 0 ? (k0 + 255) / 256 : 1), dim3(256), (sgx_stream_t)0, B.NP, k0, B.S, B.Linv, B.xp, B.xsol, B.ok);
-                    }
-                    xsol = B.xsol;
-                }
-            }
+            { const Chol C = { B.NP, B.S, B.Linv, B.bp, B.coef, B.xp, B.xsol, B.ok }; if ((rc = chol_factor_solve(C, &xsol)) != SGX_OK) return rc; }
             // when the factorisation failed, xp/xl keep the previous solution (as g2o's _x does) and the step is rejected below
             SGX_LAUNCH(k_ba_backsub, dim3((B.nl + SGX_BA_THREADS - 1) / SGX_BA_THREADS), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.nl, B.pt_start, B.pt_edges, B.E, B.hidx,
                            B.pt_active, B.bl, B.Hpl, B.Dinv, xsol, B.xl, B.ok);

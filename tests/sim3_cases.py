@@ -77,3 +77,81 @@ def check_sim3(lib, orc, n_cases=6):
     assert Optimizer.OptimizeSim3(pr['p1c'][:0], pr['p2c'][:0], pr['obs1'][:0], pr['obs2'][:0], pr['info1'][:0], pr['info2'][:0], K, K, pr['S0'], 10.0, False, lib=lib)[0] == 0
     gn, gS, ginl, git = Optimizer.OptimizeSim3(pr['p1c'][:8], pr['p2c'][:8], pr['obs1'][:8], pr['obs2'][:8], pr['info1'][:8], pr['info2'][:8], K, K, pr['S0'], 10.0, False, lib=lib)
     assert gn == 0 and (gS == pr['S0']).all()
+
+
+# ---- essential graph (pose graph over keyframes, EdgeSim3) -----------------------------------------------------------------------
+def qmul(a, b):
+    return np.r_[a[3] * b[:3] + b[3] * a[:3] + np.cross(a[:3], b[:3]), a[3] * b[3] - a[:3] @ b[:3]]
+
+
+def s_mul(A, B):       # Sim3 product on (q, t, s) rows
+    return np.r_[qmul(A[:4], B[:4]), A[7] * quat_rot(A[:4], B[4:7]) + A[4:7], A[7] * B[7]]
+
+
+def s_inv(A):
+    qc = np.r_[-A[:3], A[3]]
+    return np.r_[qc, quat_rot(qc, (-1.0 / A[7]) * A[4:7]), 1.0 / A[7]]
+
+
+def make_graph(seed, nv=40, noise=0.02, scale_drift=0.0):
+    """keyframes on a loop; exact relative measurements (spanning chain + covisibility shortcuts + one loop edge); initial estimates = the truth with accumulated drift, vertex 0 fixed"""
+    rng = np.random.RandomState(seed)
+    truth = []
+    for i in range(nv):
+        a = 2 * np.pi * i / nv
+        q = quat_from_rotvec(np.array([0.0, a, 0.0]) + rng.normal(0, 0.02, 3)); t = np.array([2 * np.cos(a), 0.1 * rng.randn(), 2 * np.sin(a)])
+        truth.append(np.r_[q, t, 1.0])
+    truth = np.array(truth)
+    ei, ej = [], []
+    for i in range(1, nv): ei.append(i); ej.append(i - 1)                        # spanning tree: child -> parent
+    for i in range(3, nv, 2): ei.append(i); ej.append(i - 3)                      # covisibility
+    ei.append(nv - 1); ej.append(0)                                              # the loop
+    for i in range(10, nv, 7): ei.append(i); ej.append(i - 10)
+    ei, ej = np.array(ei, 'i4'), np.array(ej, 'i4')
+    meas = np.array([s_mul(truth[j], s_inv(truth[i])) for i, j in zip(ei, ej)])    # Sji = Sjw * Swi
+    S0 = truth.copy()
+    drift = np.zeros(6)
+    for i in range(1, nv):                                                        # accumulated drift along the chain
+        drift = drift + rng.normal(0, noise, 6)
+        d = np.r_[quat_from_rotvec(drift[:3] * 0.3), drift[3:], np.exp(scale_drift * i / nv)]
+        S0[i] = s_mul(d, truth[i])
+    fixed = np.zeros(nv, np.uint8); fixed[0] = 1
+    return dict(S0=S0, truth=truth, fixed=fixed, ei=ei, ej=ej, meas=meas)
+
+
+def check_eg_oracle_recovers(orc):
+    """known answer: exact relative measurements -> chi2 collapses and every keyframe returns to the generating pose (bFixScale = true, the RGB-D setting, Tracking / LoopClosing
+    pass mSensor != MONOCULAR).  With a free scale the vendored g2o stalls once the rotation part of a step falls below 1e-5 while its scale part is above it: that branch of
+    Sim3's exponential map carries B = ((sigma^2/2 - sigma + 1) s) / sigma^3 (sim3.h:110), which diverges like 1/sigma^3 instead of tending to 1/6 — restated as written, so the
+    oracle stalls the same way; the test then only asks for a decrease."""
+    for seed, (fix, sd) in enumerate(((True, 0.0), (True, 0.0), (False, 0.0), (False, 0.15))):
+        g = make_graph(seed, 30, scale_drift=sd)
+        S, st = orc.optimize_essential_graph(g['S0'], g['fixed'], g['ei'], g['ej'], g['meas'], fix, 20)
+        assert (S[0] == g['S0'][0]).all()                                          # the fixed vertex is not touched
+        if fix:
+            assert st[1] > 1e-3 and st[2] < 1e-9 * st[1] and st[0] >= 3
+            for v in range(len(S)):
+                assert sim3_close(S[v], g['truth'][v], 1e-6), (seed, v)
+        else:
+            assert st[2] < 0.05 * st[1]
+    pts = np.random.RandomState(3).uniform(-3, 3, (50, 3)).astype('f4'); ref = np.random.RandomState(4).randint(0, 30, 50).astype('i4')
+    inv = np.array([s_inv(s) for s in S])
+    out = orc.correct_map_points(pts, ref, g['S0'], inv)
+    exp = np.array([inv[r][7] * quat_rot(inv[r][:4], g['S0'][r][7] * quat_rot(g['S0'][r][:4], p) + g['S0'][r][4:7]) + inv[r][4:7] for p, r in zip(pts.astype('f8'), ref)])
+    assert np.abs(out - exp).max() < 1e-5
+
+
+def check_eg(lib, orc, n_cases=4):
+    from sg_slam_amd.optimizer import Optimizer
+    for seed in range(n_cases):
+        g = make_graph(50 + seed, [20, 60, 150, 400][seed % 4], noise=[0.02, 0.01, 0.03, 0.005][seed % 4], scale_drift=[0.0, 0.1, 0.0, 0.05][seed % 4])
+        for fix in (True, False):
+            eS, est = orc.optimize_essential_graph(g['S0'], g['fixed'], g['ei'], g['ej'], g['meas'], fix, 20)
+            gS, gst = Optimizer.OptimizeEssentialGraph(g['S0'], g['fixed'], g['ei'], g['ej'], g['meas'], fix, 20, lib=lib)
+            assert abs(gst[0] - est[0]) <= 1, (seed, fix, gst, est)                 # numeric-Jacobian noise floor: see check_sim3
+            assert abs(gst[1] - est[1]) <= 1e-9 * est[1]
+            for v in range(len(eS)):
+                assert sim3_close(gS[v], eS[v], 1e-5), (seed, fix, v, gS[v], eS[v])
+    pts = np.random.RandomState(5).uniform(-3, 3, (300, 3)).astype('f4'); ref = np.random.RandomState(6).randint(0, len(eS), 300).astype('i4')
+    inv = np.array([s_inv(s) for s in eS])
+    assert np.abs(Optimizer.CorrectMapPoints(pts, ref, g['S0'], inv, lib=lib) - orc.correct_map_points(pts, ref, g['S0'], inv)).max() <= 1e-6

@@ -8,3 +8,7 @@ def test_sim3_oracle_recovers(oracle):
 
 def test_sim3_emu(emu, oracle):
     sc.check_sim3(emu, oracle, n_cases=4)
+
+
+def test_essential_graph_oracle_recovers(oracle):
+    sc.check_eg_oracle_recovers(oracle)
