@@ -280,6 +280,18 @@ int sgx_bundle_adjustment(const sgx_ba_problem *problem, const sgx_camera *cam, 
 int sgx_optimize_sim3(int n, const float *p1c, const float *p2c, const float *obs1, const float *obs2, const float *info1, const float *info2,
                       const float *K1, const float *K2, double *S12, float th2, int fix_scale, uint8_t *inlier, int32_t *iterations, int32_t *n_inliers);
 
+/* The optimisation of void Optimizer::OptimizeEssentialGraph(Map*, KeyFrame *pLoopKF, KeyFrame *pCurKF, const KeyFrameAndPose &NonCorrectedSim3, const KeyFrameAndPose &CorrectedSim3,
+ * const map<KeyFrame*, set<KeyFrame*>> &LoopConnections, const bool &bFixScale) (src/sg-slam/include/Optimizer.h:49-52, src/sg-slam/src/Optimizer.cc:781-1042; caller
+ * LoopClosing::CorrectLoop, LoopClosing.cc:567): solver->setUserLambdaInit(1e-16); optimize(20) on the pose graph the reference builds at :807-958.  The caller flattens that graph:
+ * S_in[v] = the vertex estimate (vScw: the corrected Sim3 where CorrectedSim3 holds the keyframe, Sim3(Rcw, tcw, 1) otherwise) as (qx, qy, qz, qw, tx, ty, tz, s); fixed[v] != 0 for
+ * pLoopKF; one row per g2o::EdgeSim3 in insertion order: e_i = vertex 0, e_j = vertex 1, e_meas = the measurement Sji.  S_out[v] = the optimised estimates (CorrectedSiw, :970-973);
+ * stats (optional, 3 doubles): LM iterations, chi2 before, chi2 after.  EdgeSim3 has no analytic Jacobian in the vendored g2o: numeric differences, as the reference.  Host pointers. */
+int sgx_optimize_essential_graph(int nv, const double *S_in, const uint8_t *fixed, int ne, const int32_t *e_i, const int32_t *e_j, const double *e_meas,
+                                 int fix_scale, int iterations, double *S_out, double *stats);
+/* The map-point correction that follows (Optimizer.cc:1004-1041): xw_out[i] = correctedSwr.map(Srw.map(xw[i])) with r = ref[i], the point's reference keyframe (or mnCorrectedReference);
+ * Srw = vScw, corrected_Swr = vCorrectedSwc (nv x 8 each).  The pose recovery [R t/s; 0 1] (:975-985) is three divisions on the host. */
+int sgx_correct_map_points(int n, const float *xw, const int32_t *ref, int nv, const double *Srw, const double *corrected_Swr, float *xw_out);
+
 /* ---- 2-D detector + dynamic-feature mask --------------------------------------------------------
  * Replaces ORB_SLAM2::Detector2D (src/sg-slam/include/Detector2D.h:45-67, src/sg-slam/src/Detector2D.cc:16-89): the ncnn
  * forward pass of the shipped MobileNetV3-SSDLite graph (Thirdparty/ncnn_model/mobilenetv3_ssdlite_voc.param + .bin) on 300x300,

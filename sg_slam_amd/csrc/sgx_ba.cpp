@@ -5,12 +5,15 @@
 // parity bar for poses / landmarks is 1e-5 relative, not bit equality).  The bit-exact integer / fp32 feature kernels keep -ffp-contract=off.
 #pragma clang fp contract(fast)
 #include "sgx_ba_kernels.h"
+#include "sgx_eg_kernels.h"
 #include "../../include/sgx.h"
 #include <float.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
+#include <cmath>
 #include <mutex>
 #include <vector>
 
@@ -361,4 +364,133 @@ extern "C" int sgx_bundle_adjustment(const sgx_ba_problem *P, const sgx_camera *
 {
     if (n_iterations < 0) return SGX_ERR_INVALID;
     return ba_run(P, cam, stop_flag, nullptr, stats, 1, n_iterations, robust);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------------------
+// Optimizer::OptimizeEssentialGraph: the optimisation (Optimizer.cc:794, :961-962) on a flattened pose graph; kernels in sgx_eg_kernels.h
+// ---------------------------------------------------------------------------------------------------------------------------------------------------------
+namespace {
+struct DevBufs {                                       // plain hipMalloc'ed buffers of one call (loop closing is rare: no arena)
+    std::vector<void *> p;
+    ~DevBufs() { for (void *q : p) (void)hipFree(q); }
+    template <class T> int get(T **out, size_t n) { void *q = nullptr; if (hipMalloc(&q, (n ? n : 1) * sizeof(T)) != hipSuccess) return SGX_ERR_NOMEM; p.push_back(q); *out = (T *)q; return SGX_OK; }
+    template <class T> int put(T **out, const T *src, size_t n) { int rc = get(out, n); if (rc != SGX_OK) return rc; if (n && hipMemcpy(*out, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return SGX_ERR_DEVICE; return SGX_OK; }
+};
+}
+
+extern "C" int sgx_optimize_essential_graph(int nv, const double *S_in, const uint8_t *fixed, int ne, const int32_t *e_i, const int32_t *e_j, const double *e_meas,
+                                            int fix_scale, int iterations, double *S_out, double *stats)
+{
+    if (nv < 0 || ne < 0 || iterations < 0 || (nv > 0 && (!S_in || !fixed || !S_out)) || (ne > 0 && (!e_i || !e_j || !e_meas))) return SGX_ERR_INVALID;
+    if (stats) { stats[0] = 0; stats[1] = 0; stats[2] = 0; }
+    for (int k = 0; k < ne; k++) if (e_i[k] < 0 || e_i[k] >= nv || e_j[k] < 0 || e_j[k] >= nv || e_i[k] == e_j[k]) return SGX_ERR_INVALID;
+    if (nv > 0 && S_out != S_in) memcpy(S_out, S_in, sizeof(double) * 8 * (size_t)nv);
+    std::vector<int> hidx((size_t)(nv > 0 ? nv : 1), -1);
+    int nf = 0;
+    for (int v = 0; v < nv; v++) hidx[(size_t)v] = fixed[v] ? -1 : nf++;
+    const int NP = 7 * nf;
+    if (NP == 0 || ne == 0 || iterations == 0) return SGX_OK;
+    if (NP > SGX_BA_MAX_DENSE) return SGX_ERR_UNSUPPORTED;
+    // incidence lists of the free vertices and the groups of edges that share an unordered vertex pair, both in edge order
+    std::vector<int> inc_start((size_t)nf + 1, 0), inc_edge; std::vector<uint8_t> inc_side;
+    for (int k = 0; k < ne; k++) { if (hidx[(size_t)e_i[k]] >= 0) inc_start[(size_t)hidx[(size_t)e_i[k]] + 1]++; if (hidx[(size_t)e_j[k]] >= 0) inc_start[(size_t)hidx[(size_t)e_j[k]] + 1]++; }
+    for (int h = 0; h < nf; h++) inc_start[(size_t)h + 1] += inc_start[(size_t)h];
+    inc_edge.resize((size_t)inc_start[(size_t)nf] > 0 ? (size_t)inc_start[(size_t)nf] : 1); inc_side.resize(inc_edge.size());
+    { std::vector<int> fill((size_t)nf, 0);
+      for (int k = 0; k < ne; k++) for (int side = 0; side < 2; side++) { const int h = hidx[(size_t)(side ? e_j[k] : e_i[k])]; if (h < 0) continue;
+          const size_t q = (size_t)inc_start[(size_t)h] + (size_t)fill[(size_t)h]++; inc_edge[q] = k; inc_side[q] = (uint8_t)side; } }
+    std::vector<int> order; order.reserve((size_t)ne);
+    for (int k = 0; k < ne; k++) if (hidx[(size_t)e_i[k]] >= 0 && hidx[(size_t)e_j[k]] >= 0) order.push_back(k);
+    auto lo_of = [&](int k) { return std::min(hidx[(size_t)e_i[k]], hidx[(size_t)e_j[k]]); };
+    auto hi_of = [&](int k) { return std::max(hidx[(size_t)e_i[k]], hidx[(size_t)e_j[k]]); };
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return lo_of(x) != lo_of(y) ? lo_of(x) < lo_of(y) : hi_of(x) < hi_of(y); });
+    std::vector<int> pair_start, pair_lo, pair_hi, pair_edge; std::vector<uint8_t> pair_flip;
+    for (size_t q = 0; q < order.size(); q++) {
+        const int k = order[q];
+        if (q == 0 || lo_of(k) != lo_of(order[q - 1]) || hi_of(k) != hi_of(order[q - 1])) { pair_start.push_back((int)q); pair_lo.push_back(lo_of(k)); pair_hi.push_back(hi_of(k)); }
+        pair_edge.push_back(k); pair_flip.push_back((uint8_t)(hidx[(size_t)e_i[k]] > hidx[(size_t)e_j[k]]));
+    }
+    pair_start.push_back((int)order.size());
+    const int npair = (int)pair_lo.size();
+    if (pair_edge.empty()) { pair_edge.push_back(0); pair_flip.push_back(0); }
+    if (pair_lo.empty()) { pair_lo.push_back(0); pair_hi.push_back(0); }
+
+    DevBufs D; int rc;
+    double *dV, *dVb, *dM, *derr, *dblk, *dH, *dS, *db, *dbp, *dcoef, *dxp, *dxsol, *dLinv, *dpart; int *dei, *dej, *dhidx, *dok, *dis, *die, *dps, *dpl, *dph, *dpe; uint8_t *dside, *dflip;
+    const int nblk_e = (ne + SGX_EG_THREADS - 1) / SGX_EG_THREADS, nblk_v = (nv + SGX_EG_THREADS - 1) / SGX_EG_THREADS, npart = std::max(nblk_e, nblk_v);
+#define TRY(x) if ((rc = (x)) != SGX_OK) return rc
+    TRY(D.put(&dV, S_in, 8 * (size_t)nv)); TRY(D.get(&dVb, 8 * (size_t)nv)); TRY(D.put(&dM, e_meas, 8 * (size_t)ne)); TRY(D.put(&dei, e_i, (size_t)ne)); TRY(D.put(&dej, e_j, (size_t)ne));
+    TRY(D.put(&dhidx, hidx.data(), (size_t)nv)); TRY(D.get(&derr, 7 * (size_t)ne)); TRY(D.get(&dblk, (size_t)SGX_EG_BLK * ne));
+    TRY(D.get(&dH, (size_t)NP * NP)); TRY(D.get(&dS, (size_t)NP * NP)); TRY(D.get(&db, (size_t)NP)); TRY(D.get(&dbp, (size_t)NP)); TRY(D.get(&dcoef, (size_t)NP)); TRY(D.get(&dxp, (size_t)NP)); TRY(D.get(&dxsol, (size_t)NP));
+    TRY(D.get(&dLinv, (size_t)((NP + SGX_NB - 1) / SGX_NB) * SGX_NB * SGX_NB)); TRY(D.get(&dok, 4)); TRY(D.get(&dpart, (size_t)npart));
+    TRY(D.put(&dis, inc_start.data(), inc_start.size())); TRY(D.put(&die, inc_edge.data(), inc_edge.size())); TRY(D.put(&dside, inc_side.data(), inc_side.size()));
+    TRY(D.put(&dps, pair_start.data(), pair_start.size())); TRY(D.put(&dpl, pair_lo.data(), pair_lo.size())); TRY(D.put(&dph, pair_hi.data(), pair_hi.size()));
+    TRY(D.put(&dpe, pair_edge.data(), pair_edge.size())); TRY(D.put(&dflip, pair_flip.data(), pair_flip.size()));
+#undef TRY
+    SGX_CHECK_HIP(hipMemset(dxp, 0, sizeof(double) * (size_t)NP)); SGX_CHECK_HIP(hipMemset(dxsol, 0, sizeof(double) * (size_t)NP));
+    std::vector<double> hp((size_t)npart);
+    auto chi2_at = [&](const double *V, double *chi) -> int {
+        SGX_LAUNCH(k_eg_errors, dim3(nblk_e), dim3(SGX_EG_THREADS), (sgx_stream_t)0, ne, dei, dej, dM, V, derr, dpart);
+        SGX_CHECK_HIP(hipMemcpy(hp.data(), dpart, sizeof(double) * (size_t)nblk_e, hipMemcpyDeviceToHost));
+        double s = 0; for (int i = 0; i < nblk_e; i++) s += hp[(size_t)i]; *chi = s; return SGX_OK;
+    };
+    double lambda = -1, ni = 2; int nBadLM = 0, iters = 0; double chi_first = 0, chi_last = 0;
+    for (int it = 0; it < iterations; it++) {
+        double currentChi = 0; if ((rc = chi2_at(dV, &currentChi)) != SGX_OK) return rc;
+        if (it == 0) chi_first = currentChi;
+        double tempChi = currentChi; const double iniChi = currentChi;
+        SGX_LAUNCH(k_eg_linearize, dim3(nblk_e), dim3(SGX_EG_THREADS), (sgx_stream_t)0, ne, dei, dej, dM, dV, dhidx, fix_scale, derr, dblk);
+        SGX_CHECK_HIP(hipMemsetAsync(dH, 0, sizeof(double) * (size_t)NP * NP, 0));
+        SGX_LAUNCH(k_eg_assemble_diag, dim3(nf), dim3(64), (sgx_stream_t)0, NP, dis, die, dside, dblk, dH, db);
+        if (npair > 0) SGX_LAUNCH(k_eg_assemble_pairs, dim3(npair), dim3(64), (sgx_stream_t)0, NP, dps, dpl, dph, dpe, dflip, dblk, dH);
+        if (it == 0) { lambda = 1e-16; ni = 2; nBadLM = 0; }                  // computeLambdaInit with setUserLambdaInit(1e-16)
+        double rho = 0; int qmax = 0;
+        do {
+            SGX_CHECK_HIP(hipMemcpyAsync(dVb, dV, sizeof(double) * 8 * (size_t)nv, hipMemcpyDeviceToDevice, 0));       // push
+            { const int one = 1; SGX_CHECK_HIP(hipMemcpyAsync(dok, &one, 4, hipMemcpyHostToDevice, 0)); }
+            const size_t n2 = (size_t)NP * NP; const int g = (int)std::min<size_t>((n2 + SGX_EG_THREADS - 1) / SGX_EG_THREADS, 8192);
+            SGX_LAUNCH(k_eg_damp, dim3(g), dim3(SGX_EG_THREADS), (sgx_stream_t)0, NP, dH, db, lambda, dS, dbp, dcoef);
+            const double *xsol = dxp;
+            { const Chol C = { NP, dS, dLinv, dbp, dcoef, dxp, dxsol, dok }; if ((rc = chol_factor_solve(C, &xsol)) != SGX_OK) return rc; }
+            SGX_LAUNCH(k_eg_update, dim3(nblk_v), dim3(SGX_EG_THREADS), (sgx_stream_t)0, nv, dhidx, xsol, db, lambda, fix_scale, dok, dVb, dV, dpart);
+            SGX_CHECK_HIP(hipMemcpy(hp.data(), dpart, sizeof(double) * (size_t)nblk_v, hipMemcpyDeviceToHost));
+            double scale = 0; for (int i = 0; i < nblk_v; i++) scale += hp[(size_t)i];
+            int ok2 = 1; SGX_CHECK_HIP(hipMemcpy(&ok2, dok, 4, hipMemcpyDeviceToHost));
+            if ((rc = chi2_at(dV, &tempChi)) != SGX_OK) return rc;
+            if (!ok2) tempChi = DBL_MAX;
+            rho = currentChi - tempChi;
+            scale += 1e-3; rho /= scale;
+            if (rho > 0 && std::isfinite(tempChi)) {
+                const double r21 = 2 * rho - 1;
+                double alpha = 1. - r21 * r21 * r21; alpha = alpha < 2. / 3. ? alpha : 2. / 3.;
+                lambda *= (alpha > 1. / 3. ? alpha : 1. / 3.); ni = 2; currentChi = tempChi;
+            } else {
+                lambda *= ni; ni *= 2;
+                SGX_CHECK_HIP(hipMemcpyAsync(dV, dVb, sizeof(double) * 8 * (size_t)nv, hipMemcpyDeviceToDevice, 0));   // pop
+            }
+            qmax++;
+        } while (rho < 0 && qmax < 10);
+        iters = it + 1; chi_last = currentChi;
+        if (qmax == 10 || rho == 0) break;
+        if ((iniChi - currentChi) * 1e3 < iniChi) nBadLM++; else nBadLM = 0;
+        if (nBadLM >= 3) break;
+    }
+    SGX_CHECK_HIP(hipMemcpy(S_out, dV, sizeof(double) * 8 * (size_t)nv, hipMemcpyDeviceToHost));
+    if (stats) { stats[0] = iters; stats[1] = chi_first; stats[2] = chi_last; }
+    return SGX_OK;
+}
+
+extern "C" int sgx_correct_map_points(int n, const float *xw, const int32_t *ref, int nv, const double *Srw, const double *corrected_Swr, float *xw_out)
+{
+    if (n < 0 || nv < 0 || (n > 0 && (!xw || !ref || !Srw || !corrected_Swr || !xw_out))) return SGX_ERR_INVALID;
+    if (n == 0) return SGX_OK;
+    for (int i = 0; i < n; i++) if (ref[i] < 0 || ref[i] >= nv) return SGX_ERR_INVALID;
+    DevBufs D; int rc; float *dx, *dout; int *dref; double *da, *dc;
+    if ((rc = D.put(&dx, xw, 3 * (size_t)n)) != SGX_OK || (rc = D.put(&dref, ref, (size_t)n)) != SGX_OK || (rc = D.put(&da, Srw, 8 * (size_t)nv)) != SGX_OK ||
+        (rc = D.put(&dc, corrected_Swr, 8 * (size_t)nv)) != SGX_OK || (rc = D.get(&dout, 3 * (size_t)n)) != SGX_OK) return rc;
+    SGX_LAUNCH(k_eg_correct_points, dim3((n + SGX_EG_THREADS - 1) / SGX_EG_THREADS), dim3(SGX_EG_THREADS), (sgx_stream_t)0, n, dx, dref, da, dc, dout);
+    SGX_CHECK_HIP(hipGetLastError());
+    SGX_CHECK_HIP(hipMemcpy(xw_out, dout, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost));
+    return SGX_OK;
 }

@@ -82,3 +82,23 @@ class Optimizer:
         lib.check(lib.dll.sgx_optimize_sim3(n, _vp(p1c), _vp(p2c), _vp(o1), _vp(o2), _vp(i1), _vp(i2), _vp(k1), _vp(k2), _vp(S), float(th2), int(bool(bFixScale)), _vp(inl), _vp(it), _vp(nin)),
                   'sgx_optimize_sim3')
         return int(nin[0]), S, inl[:n].copy(), it
+
+    @staticmethod
+    def OptimizeEssentialGraph(S, fixed, e_i, e_j, e_meas, bFixScale=True, iterations=20, lib=None):
+        """the optimisation of Optimizer::OptimizeEssentialGraph (Optimizer.cc:781-1042) on a flattened pose graph (see include/sgx.h): (S_out[nv, 8], stats[iterations, chi2 before, after])"""
+        lib = lib if lib is not None else load()
+        S = np.ascontiguousarray(S, 'f8').reshape(-1, 8); fx = np.ascontiguousarray(fixed, np.uint8)
+        ei = np.ascontiguousarray(e_i, 'i4'); ej = np.ascontiguousarray(e_j, 'i4'); em = np.ascontiguousarray(e_meas, 'f8').reshape(-1, 8)
+        out = np.zeros_like(S); st = np.zeros(3, 'f8')
+        lib.check(lib.dll.sgx_optimize_essential_graph(len(S), _vp(S), _vp(fx), len(ei), _vp(ei), _vp(ej), _vp(em), int(bool(bFixScale)), int(iterations), _vp(out), _vp(st)), 'sgx_optimize_essential_graph')
+        return out, st
+
+    @staticmethod
+    def CorrectMapPoints(xw, ref, Srw, corrected_Swr, lib=None):
+        """Optimizer.cc:1004-1041: P' = correctedSwr.map(Srw.map(P)) for every map point (ref = its reference keyframe's vertex index)"""
+        lib = lib if lib is not None else load()
+        xw = np.ascontiguousarray(xw, 'f4').reshape(-1, 3); ref = np.ascontiguousarray(ref, 'i4')
+        a = np.ascontiguousarray(Srw, 'f8').reshape(-1, 8); c = np.ascontiguousarray(corrected_Swr, 'f8').reshape(-1, 8)
+        out = np.zeros_like(xw)
+        lib.check(lib.dll.sgx_correct_map_points(len(xw), _vp(xw), _vp(ref), len(a), _vp(a), _vp(c), _vp(out)), 'sgx_correct_map_points')
+        return out

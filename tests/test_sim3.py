@@ -12,3 +12,7 @@ def test_sim3_emu(emu, oracle):
 
 def test_essential_graph_oracle_recovers(oracle):
     sc.check_eg_oracle_recovers(oracle)
+
+
+def test_essential_graph_emu(emu, oracle):
+    sc.check_eg(emu, oracle, n_cases=3)
