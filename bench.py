@@ -359,8 +359,8 @@ def main():
         ach = (dk['alg_gflop_per_launch'] / (sa * 1e-3) / 1e3) if dk['bound'] == 'mfma' else (dk['alg_bytes_per_launch'] / (sa * 1e-3) / 1e9)
         roofline['standalone'] = {'avg_launch_ms': sa, 'achieved': round(ach, 3), 'frac': ach / roofline['peak'], 'source': 'profiles/r2_standalone.json'}
     if dom == 'det_forward':
-        # det_forward is a 103-node hipGraph: the HIP-event span of a launch also contains the gaps in which kernels of the other two streams run between its nodes.  The sum of the
-        # node kernels' own durations comes from the committed rocprofv3 kernel statistics of this same command (profiles/r2_bench_kernel_stats.csv).
+        # det_forward is a 103-node hipGraph, timed as one HIP-event span; the sum of its node kernels' own durations from the committed rocprofv3 kernel statistics of this same
+        # command (profiles/r2_bench_kernel_stats.csv) is reported next to it (the two agree when the graph's nodes run back to back).
         try:
             import csv
             sys.path.insert(0, os.path.join(ROOT, 'tools'))
