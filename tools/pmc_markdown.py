@@ -62,7 +62,7 @@ for k in ds:
 try: tj = json.load(open(O + '/traffic.json'))['bytes_per_launch']
 except Exception: tj = {}
 out.append('\nWhole forward (pre-processing + 102 plan steps), %d frames: %.1f GB of HBM-side traffic (`traffic.json`) against %.1f GB of algorithmic activation + weight bytes summed over the steps '
-           '(`detector_ops.txt`): every step's input comes from HBM again (at this batch size nothing survives in the Infinity Cache from one step to the next), nothing is re-read.  Standalone: forward %.2f ms, DetectionOutput + filtering %.2f ms '
+           '(`detector_ops.txt`): the input of every step comes from HBM again (at this batch size nothing survives in the Infinity Cache from one step to the next), nothing is re-read.  Standalone: forward %.2f ms, DetectionOutput + filtering %.2f ms '
            '(`standalone.json`).\n' % (S, tj.get('det_forward', 0) / 1e9, 27.2 * S / 256, st.get('det_forward', 0), st.get('det_output', 0)))
 out.append('''Reading.  The pointwise kernels keep the fp32 matrix pipes 30–60 % busy (the deep-K 19 × 19 / 10 × 10 layers most), the depthwise and stem kernels are VALU / LDS work.  The per-step
 table prices every step against max(bytes / 8 TB/s, flops / 157.3 TFLOP/s); `tools/ubench/stream_bw.hip` shows that the pointwise access shape (a wave reads two 128-byte row segments per
