@@ -2,6 +2,8 @@
 // graph and Detector2D::detect, driven from files so tests/test_host_cpp_gpu.py can compare against the oracle / the Python mirror.
 //   example_backend ba  graph.bin                       graph.bin = int32 np, nl, ne | poses f32 | fixed u8 | points f32 | edge_pose i32 | edge_point i32 | obs f32 | info f32
 //   example_backend det model.param model.bin frame.raw   frame.raw = 480 x 640 x 3 u8 (BGR)
+//   example_backend flow cur.raw prev.raw pts.bin          two 480 x 640 u8 frames, pts.bin = int32 n | n x 2 f32: calcOpticalFlowPyrLK + findFundamentalMat (Frame.cc:445, :469-472)
+//   example_backend sim3 pairs.bin                        int32 n, fix_scale | p1c p2c (n x 3 f32) obs1 obs2 (n x 2 f32) info1 info2 (n f32) | K1 K2 (4 f32) | S12 (8 f64): OptimizeSim3
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -45,6 +47,36 @@ int main(int argc, char **argv)
         for (size_t i = 0; i < det.raw.size() && i < 5; i++) printf("row %g %.9g %.9g %.9g %.9g %.9g\n", det.raw[i].label, det.raw[i].score, det.raw[i].xmin, det.raw[i].ymin, det.raw[i].xmax, det.raw[i].ymax);
         return 0;
     }
-    fprintf(stderr, "usage: %s ba graph.bin | det model.param model.bin frame.raw\n", argv[0]);
+    if (argc >= 5 && !strcmp(argv[1], "flow")) {
+        const std::vector<uint8_t> cur = slurp(argv[2]), prev = slurp(argv[3]), pb = slurp(argv[4]);
+        const int n = *(const int32_t *)pb.data();
+        std::vector<float> pts((size_t)2 * n), next; std::vector<uint8_t> st;
+        memcpy(pts.data(), pb.data() + 4, sizeof(float) * 2 * (size_t)n);
+        sgx::OpticalFlowLK lk(640, 480);
+        lk(cur.data(), prev.data(), pts, next, st);
+        std::vector<float> a, b; int ntr = 0;
+        for (int i = 0; i < n; i++) if (st[(size_t)i]) { ntr++; a.push_back(pts[2 * (size_t)i]); a.push_back(pts[2 * (size_t)i + 1]); b.push_back(next[2 * (size_t)i]); b.push_back(next[2 * (size_t)i + 1]); }
+        double F[9]; const bool ok = sgx::findFundamentalMat(a, b, F);
+        printf("tracked %d ok %d\n", ntr, (int)ok);
+        printf("first"); for (int i = 0; i < 8 && i < 2 * n; i++) printf(" %.9g", next[(size_t)i]); printf("\n");
+        printf("F"); for (int i = 0; i < 9; i++) printf(" %.17g", F[i]); printf("\n");
+        return 0;
+    }
+    if (argc >= 3 && !strcmp(argv[1], "sim3")) {
+        const std::vector<uint8_t> b = slurp(argv[2]);
+        const int32_t *hdr = (const int32_t *)b.data(); const int n = hdr[0], fix = hdr[1];
+        const uint8_t *p = b.data() + 8;
+        sgx::Optimizer::Sim3Pairs c; float K1[4], K2[4]; sgx::Optimizer::Sim3 S;
+        auto take = [&](std::vector<float> &v, size_t m) { v.resize(m); memcpy(v.data(), p, m * 4); p += m * 4; };
+        take(c.p1c, (size_t)n * 3); take(c.p2c, (size_t)n * 3); take(c.obs1, (size_t)n * 2); take(c.obs2, (size_t)n * 2); take(c.info1, (size_t)n); take(c.info2, (size_t)n);
+        memcpy(K1, p, 16); p += 16; memcpy(K2, p, 16); p += 16; memcpy(S.v, p, 64);
+        std::vector<uint8_t> inl;
+        const int nin = sgx::Optimizer::OptimizeSim3(c, K1, K2, S, 10.0f, fix != 0, inl);
+        int kept = 0; for (uint8_t e : inl) kept += e;
+        printf("nin %d kept %d\n", nin, kept);
+        printf("S12"); for (int i = 0; i < 8; i++) printf(" %.17g", S.v[i]); printf("\n");
+        return 0;
+    }
+    fprintf(stderr, "usage: %s ba graph.bin | det model.param model.bin frame.raw | flow cur.raw prev.raw pts.bin | sim3 pairs.bin\n", argv[0]);
     return 2;
 }

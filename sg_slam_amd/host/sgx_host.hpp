@@ -10,6 +10,7 @@
 #include <cmath>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 #include "../../include/sgx.h"
 
@@ -130,9 +131,91 @@ public:
         return n;
     }
 
+    // ---- LocalMapping / relocalisation gates (tier N2).  KeyFrameView: the flattened keyframe fields the reference reads.
+    struct KeyFrameView {
+        int N = 0;
+        std::vector<sgx_keypoint> mvKeysUn; std::vector<uint8_t> mDescriptors; std::vector<float> mvuRight;
+        std::vector<uint8_t> hasMapPoint;        // GetMapPoint(i) != NULL (for SearchByBoW: ... && !isBad())
+        std::vector<int32_t> featNode;           // key of mFeatVec under which keypoint i sits (-1: none)
+        float Tcw[16]; float Ow[3];
+    };
+    // int SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, vector<pair<size_t,size_t>> &vMatchedPairs, const bool bOnlyStereo) (ORBmatcher.cc:659-827)
+    int SearchForTriangulation(const KeyFrameView &KF1, const KeyFrameView &KF2, const float F12[9], const sgx_camera &cam2, const std::vector<float> &scaleFactors2,
+                               const std::vector<float> &levelSigma2_2, std::vector<std::pair<size_t, size_t>> &vMatchedPairs, bool bOnlyStereo)
+    {
+        std::vector<int32_t> pairs((size_t)2 * (KF1.N > 0 ? KF1.N : 1)); int32_t np = 0;
+        check(sgx_match_search_for_triangulation(KF1.N, KF1.mvKeysUn.data(), KF1.mDescriptors.data(), KF1.mvuRight.data(), KF1.hasMapPoint.data(), KF1.featNode.data(), KF1.Ow,
+                                                 KF2.N, KF2.mvKeysUn.data(), KF2.mDescriptors.data(), KF2.mvuRight.data(), KF2.hasMapPoint.data(), KF2.featNode.data(), KF2.Tcw,
+                                                 F12, &cam2, scaleFactors2.data(), levelSigma2_2.data(), (int)scaleFactors2.size(), bOnlyStereo ? 1 : 0, mbCheckOrientation ? 1 : 0,
+                                                 pairs.data(), &np), "sgx_match_search_for_triangulation");
+        vMatchedPairs.clear();
+        for (int i = 0; i < np; i++) vMatchedPairs.emplace_back((size_t)pairs[2 * i], (size_t)pairs[2 * i + 1]);
+        return np;
+    }
+    // int SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches) (ORBmatcher.cc:159-290): matches[j] = keyframe keypoint whose map point keypoint j of F receives
+    int SearchByBoW(const KeyFrameView &KF, const FrameView &F, const std::vector<int32_t> &featNodeF, std::vector<int32_t> &matches)
+    {
+        matches.assign((size_t)(F.N > 0 ? F.N : 1), -1); int32_t n = 0;
+        check(sgx_match_search_by_bow(KF.N, KF.mvKeysUn.data(), KF.mDescriptors.data(), KF.hasMapPoint.data(), KF.featNode.data(),
+                                      F.N, F.mvKeysUn.data(), F.mDescriptors.data(), featNodeF.data(), mfNNratio, mbCheckOrientation ? 1 : 0, matches.data(), &n), "sgx_match_search_by_bow");
+        matches.resize((size_t)F.N);
+        return n;
+    }
+    // the search of int Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, const float th) (ORBmatcher.cc:829-979): bestIdx[i] = keypoint of pKF map point i fuses with (-1: none)
+    int Fuse(const KeyFrameView &KF, LocalMapView &M, float th, const sgx_camera &cam, const std::vector<float> &scaleFactors, const std::vector<float> &invLevelSigma2,
+             std::vector<int32_t> &bestIdx, std::vector<int32_t> &bestDist)
+    {
+        bestIdx.assign((size_t)(M.N > 0 ? M.N : 1), -1); bestDist.assign((size_t)(M.N > 0 ? M.N : 1), 256); int32_t n = 0;
+        check(sgx_match_fuse_search(KF.N, KF.mvKeysUn.data(), KF.mDescriptors.data(), KF.mvuRight.data(), KF.Tcw, M.N, M.mWorldPos.data(), M.mNormalVector.data(), M.mfMinDistance.data(),
+                                    M.mfMaxDistance.data(), M.mDescriptor.data(), M.skip.data(), &cam, scaleFactors.data(), invLevelSigma2.data(), (int)scaleFactors.size(),
+                                    std::log(scaleFactors[1]), th, bestIdx.data(), bestDist.data(), &n), "sgx_match_fuse_search");
+        bestIdx.resize((size_t)M.N); bestDist.resize((size_t)M.N);
+        return n;
+    }
+    // int SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, const float th, const int ORBdist) (ORBmatcher.cc:1474-1601): M = pKF's map points
+    // (M.skip[i] = NULL / isBad() / already found), kfKeysUn = pKF->mvKeysUn; CurrentFrame.mvpMapPoints (>= 0 = holds a point) is read; matched[k] = index into M or -1
+    int SearchByProjection(FrameView &CurrentFrame, const std::vector<sgx_keypoint> &kfKeysUn, LocalMapView &M, float th, int ORBdist, const sgx_camera &cam,
+                           const std::vector<float> &scaleFactors, std::vector<int32_t> &matched)
+    {
+        std::vector<uint8_t> held((size_t)(CurrentFrame.N > 0 ? CurrentFrame.N : 1), 0), ok((size_t)(M.N > 0 ? M.N : 1), 0);
+        for (int k = 0; k < CurrentFrame.N; k++) held[(size_t)k] = CurrentFrame.mvpMapPoints.size() == (size_t)CurrentFrame.N && CurrentFrame.mvpMapPoints[(size_t)k] >= 0;
+        for (int i = 0; i < M.N; i++) ok[(size_t)i] = !M.skip[(size_t)i];
+        matched.assign((size_t)(CurrentFrame.N > 0 ? CurrentFrame.N : 1), -1); int32_t n = 0;
+        check(sgx_match_project_keyframe(CurrentFrame.N, CurrentFrame.mvKeysUn.data(), CurrentFrame.mDescriptors.data(), held.data(), CurrentFrame.mTcw,
+                                         M.N, kfKeysUn.data(), ok.data(), M.mWorldPos.data(), M.mfMinDistance.data(), M.mfMaxDistance.data(), M.mDescriptor.data(),
+                                         &cam, scaleFactors.data(), (int)scaleFactors.size(), std::log(scaleFactors[1]), th, ORBdist, mbCheckOrientation ? 1 : 0, matched.data(), &n),
+              "sgx_match_project_keyframe");
+        matched.resize((size_t)CurrentFrame.N);
+        return n;
+    }
+
 protected:
     float mfNNratio; bool mbCheckOrientation;
 };
+
+// the two OpenCV calls of Frame::RmDynamicPointWithSemanticAndGeometry (Frame.cc:445, :469-472)
+class OpticalFlowLK {                                                // cv::calcOpticalFlowPyrLK(cur, prev, pts, nextPts, status, err, Size(21,21), 3, TermCriteria(ITER|EPS, 30, 0.01))
+public:
+    OpticalFlowLK(int width, int height) : w_(width) { sgx_flow_config c{width, height, 1, 21, 3, 30, 0.01}; check(sgx_flow_create(&c, &h_), "sgx_flow_create"); }
+    ~OpticalFlowLK() { if (h_) sgx_flow_destroy(h_); }
+    OpticalFlowLK(const OpticalFlowLK &) = delete; OpticalFlowLK &operator=(const OpticalFlowLK &) = delete;
+    void operator()(const uint8_t *imFrom, const uint8_t *imTo, const std::vector<float> &pts /* x0 y0 x1 y1 .. */, std::vector<float> &nextPts, std::vector<uint8_t> &status)
+    {
+        const int n = (int)(pts.size() / 2);
+        nextPts.assign(pts.size() ? pts.size() : 2, 0.f); status.assign((size_t)(n > 0 ? n : 1), 0);
+        check(sgx_flow_lk(h_, imFrom, imTo, w_, pts.data(), n, nextPts.data(), status.data()), "sgx_flow_lk");
+        nextPts.resize(pts.size()); status.resize((size_t)n);
+    }
+private:
+    sgx_flow *h_ = nullptr; int w_;
+};
+// cv::findFundamentalMat(points1, points2, cv::FM_RANSAC, 1.0, 0.99): returns false for OpenCV's empty Mat
+inline bool findFundamentalMat(const std::vector<float> &points1, const std::vector<float> &points2, double F[9], double param1 = 1.0, double param2 = 0.99)
+{
+    int32_t ok = 0;
+    check(sgx_find_fundamental_mat(points1.data(), points2.data(), (int)(points1.size() / 2), param1, param2, F, &ok, nullptr), "sgx_find_fundamental_mat");
+    return ok != 0;
+}
 
 // ORB_SLAM2::Optimizer (Optimizer.h:40-58) — static int PoseOptimization(Frame *pFrame)
 class Optimizer {
@@ -170,6 +253,37 @@ public:
         std::vector<uint8_t> erase(g.edge_pose.size(), 0);
         check(sgx_local_bundle_adjustment(&P, &cam, pbStopFlag, erase.data(), stats), "sgx_local_bundle_adjustment");
         return erase;
+    }
+    // static void BundleAdjustment(const vector<KeyFrame*> &vpKFs, const vector<MapPoint*> &vpMP, int nIterations, bool *pbStopFlag, const unsigned long nLoopKF, const bool bRobust)
+    // (Optimizer.cc:49-237) on the flattened graph (pose_fixed != 0 for mnId == 0): poses / points updated in place
+    static void BundleAdjustment(LocalGraph &g, const sgx_camera &cam, int nIterations = 5, const volatile int32_t *pbStopFlag = nullptr, bool bRobust = true, sgx_ba_stats *stats = nullptr)
+    {
+        sgx_ba_problem P{(int32_t)g.pose_fixed.size(), (int32_t)(g.points.size() / 3), (int32_t)g.edge_pose.size(), g.poses.data(), g.pose_fixed.data(), g.points.data(),
+                         g.edge_pose.data(), g.edge_point.data(), g.edge_obs.data(), g.edge_info.data()};
+        check(sgx_bundle_adjustment(&P, &cam, nIterations, pbStopFlag, bRobust ? 1 : 0, stats), "sgx_bundle_adjustment");
+    }
+    // g2o::Sim3 as (qx, qy, qz, qw, tx, ty, tz, s)
+    struct Sim3 { double v[8]; };
+    // static int OptimizeSim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches1, g2o::Sim3 &g2oS12, const float th2, const bool bFixScale) (Optimizer.cc:1046-1257)
+    // on the correspondences the reference turns into edge pairs (include/sgx.h); inlier[i] == 0 <=> vpMatches1[idx] = NULL
+    struct Sim3Pairs { std::vector<float> p1c, p2c, obs1, obs2, info1, info2; };
+    static int OptimizeSim3(const Sim3Pairs &c, const float K1[4], const float K2[4], Sim3 &g2oS12, float th2, bool bFixScale, std::vector<uint8_t> &inlier)
+    {
+        const int n = (int)c.info1.size();
+        inlier.assign((size_t)(n > 0 ? n : 1), 0); int32_t nin = 0;
+        check(sgx_optimize_sim3(n, c.p1c.data(), c.p2c.data(), c.obs1.data(), c.obs2.data(), c.info1.data(), c.info2.data(), K1, K2, g2oS12.v, th2, bFixScale ? 1 : 0, inlier.data(), nullptr, &nin),
+              "sgx_optimize_sim3");
+        inlier.resize((size_t)n);
+        return nin;
+    }
+    // the optimisation of static void OptimizeEssentialGraph(...) (Optimizer.cc:781-1042) on the flattened pose graph; vertices are updated in place
+    struct PoseGraph { std::vector<Sim3> vScw; std::vector<uint8_t> fixed; std::vector<int32_t> e_i, e_j; std::vector<Sim3> e_meas; };
+    static void OptimizeEssentialGraph(PoseGraph &g, bool bFixScale, int iterations = 20, double stats[3] = nullptr)
+    {
+        std::vector<Sim3> out(g.vScw.size() ? g.vScw.size() : 1);
+        check(sgx_optimize_essential_graph((int)g.vScw.size(), g.vScw.empty() ? nullptr : g.vScw[0].v, g.fixed.data(), (int)g.e_i.size(), g.e_i.data(), g.e_j.data(),
+                                           g.e_meas.empty() ? nullptr : g.e_meas[0].v, bFixScale ? 1 : 0, iterations, out[0].v, stats), "sgx_optimize_essential_graph");
+        out.resize(g.vScw.size()); g.vScw = out;
     }
 };
 

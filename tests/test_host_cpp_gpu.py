@@ -98,3 +98,40 @@ def test_cpp_detector_matches_python_mirror(gpulib, tmp_path):
         d = r.raw[i]
         assert np.allclose(x, [d.label, d.score, d.xmin, d.ymin, d.xmax, d.ymax], rtol=1e-6, atol=1e-7)
     det.close()
+
+
+def test_cpp_flow_and_fundamental_match_python_mirror(gpulib, oracle, tmp_path):
+    """sgx::OpticalFlowLK / sgx::findFundamentalMat (C++ mirror of Frame.cc:445, :469-472): the same tracks and F as the Python mirror of the same C ABI (which the parity tests pin to the oracle)."""
+    from sg_slam_amd import synth
+    from sg_slam_amd.flow import OpticalFlowLK, find_fundamental_mat
+    L = synth.LayeredStream(seed=1234)
+    prev, cur = L.frame(20)[0], L.frame(21)[0]
+    k, _ = oracle.orb_extract(cur)
+    pts = np.stack([k['x'], k['y']], 1).astype('f4')[:400]
+    fc = tmp_path / 'cur.raw'; fp = tmp_path / 'prev.raw'; fb = tmp_path / 'pts.bin'
+    cur.tofile(fc); prev.tofile(fp)
+    with open(fb, 'wb') as fh: fh.write(np.array([len(pts)], 'i4').tobytes()); fh.write(pts.tobytes())
+    out = subprocess.check_output([_exe('example_backend'), 'flow', str(fc), str(fp), str(fb)], text=True).splitlines()
+    fl = OpticalFlowLK(lib=gpulib); nxt, st = fl(cur, prev, pts); fl.close()
+    sel = st > 0
+    ok, F, _ = find_fundamental_mat(pts[sel], nxt[sel], lib=gpulib)
+    v = out[0].split()
+    assert int(v[1]) == int(sel.sum()) and int(v[3]) == ok
+    assert np.allclose([float(x) for x in out[1].split()[1:]], nxt.reshape(-1)[:8], rtol=0, atol=1e-6)
+    assert np.allclose([float(x) for x in out[2].split()[1:]], F.reshape(-1), rtol=1e-12, atol=0)
+
+
+def test_cpp_optimize_sim3_matches_oracle(gpulib, oracle, tmp_path):
+    """sgx::Optimizer::OptimizeSim3 (C++ mirror): same return value, inlier count and similarity as the oracle."""
+    import sim3_cases as sc
+    pr = sc.make_problem(21, n=150, outliers=0.15)
+    f = tmp_path / 'pairs.bin'
+    with open(f, 'wb') as fh:
+        fh.write(np.array([len(pr['p1c']), 0], 'i4').tobytes())
+        for key in ('p1c', 'p2c', 'obs1', 'obs2', 'info1', 'info2'): fh.write(np.ascontiguousarray(pr[key], 'f4').tobytes())
+        fh.write(sc.K.tobytes()); fh.write(sc.K.tobytes()); fh.write(np.ascontiguousarray(pr['S0'], 'f8').tobytes())
+    out = subprocess.check_output([_exe('example_backend'), 'sim3', str(f)], text=True).splitlines()
+    en, eS, einl, _ = oracle.optimize_sim3(pr['p1c'], pr['p2c'], pr['obs1'], pr['obs2'], pr['info1'], pr['info2'], sc.K, sc.K, pr['S0'], 10.0, False)
+    v = out[0].split()
+    assert int(v[1]) == en and int(v[3]) == int(einl.sum())
+    assert sc.sim3_close([float(x) for x in out[1].split()[1:]], eS, 1e-5)
