@@ -161,6 +161,14 @@ int sgx_match_search_by_bow(
     int nk, const sgx_keypoint *keys_kf_un, const uint8_t *desc_kf, const uint8_t *kf_good_mp, const int32_t *feat_node_kf,
     int nf, const sgx_keypoint *keys_f_un, const uint8_t *desc_f, const int32_t *feat_node_f, float nnratio, int check_orientation,
     int32_t *match_f, int32_t *nmatches);
+/* int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12) (src/sg-slam/include/ORBmatcher.h:65, src/sg-slam/src/ORBmatcher.cc:524-655;
+ * caller LoopClosing::ComputeSim3, LoopClosing.cc:265): good*[i] = keypoint i of that keyframe holds a map point that is not bad; match12[i1] (out, n1 entries) = keypoint of
+ * pKF2 whose map point is vpMatches12[i1], -1 = NULL; *nmatches = return value.  Differs from the KeyFrame-Frame overload in the strict `< TH_LOW` gate (:597) and in requiring a
+ * map point on both sides (:581-587).  Host pointers, synchronous. */
+int sgx_match_search_by_bow_kf(
+    int n1, const sgx_keypoint *keys1_un, const uint8_t *desc1, const uint8_t *good1, const int32_t *feat_node1,
+    int n2, const sgx_keypoint *keys2_un, const uint8_t *desc2, const uint8_t *good2, const int32_t *feat_node2, float nnratio, int check_orientation,
+    int32_t *match12, int32_t *nmatches);
 /* The search of int ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, const float th = 3.0) (src/sg-slam/include/ORBmatcher.h:83,
  * src/sg-slam/src/ORBmatcher.cc:829-979; caller LocalMapping::SearchInNeighbors, LocalMapping.cc:489,514): for every candidate map point i (m_skip[i] = NULL / isBad() /
  * IsInKeyFrame(pKF); m_min_dist / m_max_dist = mfMinDistance / mfMaxDistance) the keyframe keypoint best_idx[i] it fuses with (-1: none within TH_LOW) and the Hamming

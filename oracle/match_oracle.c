@@ -413,8 +413,9 @@ int orc_search_for_triangulation(int n1, const orc_keypoint *k1, const uint8_t *
 /* ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches), ORBmatcher.cc:159-290.  kf_good_mp[i] = the keyframe's keypoint i holds a map
  * point that is not bad; node_* = FeatureVector key per keypoint (-1 = none).  match_f[j] (out) = index of the keyframe keypoint whose map point keypoint j of the
  * frame receives, or -1.  Returns nmatches. */
-int orc_search_by_bow(int nk, const orc_keypoint *kk, const uint8_t *dk, const uint8_t *kf_good_mp, const int *node_k,
-                      int nf, const orc_keypoint *kf, const uint8_t *df, const int *node_f, float nnratio, int check_ori, int *match_f)
+/* shared body of the two SearchByBoW overloads: good_f (may be NULL) filters side 2, strict selects `bestDist1 < TH_LOW` (KeyFrame-KeyFrame, :597) over `<= TH_LOW` (KeyFrame-Frame, :234) */
+static int search_by_bow_core(int nk, const orc_keypoint *kk, const uint8_t *dk, const uint8_t *kf_good_mp, const int *node_k,
+                              int nf, const orc_keypoint *kf, const uint8_t *df, const uint8_t *good_f, const int *node_f, float nnratio, int check_ori, int strict, int *match_f)
 {
     int nmatches = 0;
     for (int j = 0; j < nf; j++) match_f[j] = -1;
@@ -432,11 +433,12 @@ int orc_search_by_bow(int nk, const orc_keypoint *kk, const uint8_t *dk, const u
             int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
             for (int jf = 0; jf < nf; jf++) {
                 if (node_f[jf] != nid || match_f[jf] >= 0) continue;
+                if (good_f && !good_f[jf]) continue;
                 const int dist = orc_descriptor_distance(dk + 32 * (size_t)ik, df + 32 * (size_t)jf);
                 if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = jf; }
                 else if (dist < bestDist2) bestDist2 = dist;
             }
-            if (bestDist1 <= TH_LOW && (float)bestDist1 < nnratio * (float)bestDist2) {
+            if ((strict ? bestDist1 < TH_LOW : bestDist1 <= TH_LOW) && (float)bestDist1 < nnratio * (float)bestDist2) {
                 match_f[bestIdxF] = ik;
                 if (check_ori) {
                     float rot = kk[ik].angle - kf[bestIdxF].angle;
@@ -460,6 +462,23 @@ int orc_search_by_bow(int nk, const orc_keypoint *kk, const uint8_t *dk, const u
     for (int i = 0; i < HISTO_LENGTH; i++) free(hist[i]);
     free(u1);
     return nmatches;
+}
+int orc_search_by_bow(int nk, const orc_keypoint *kk, const uint8_t *dk, const uint8_t *kf_good_mp, const int *node_k,
+                      int nf, const orc_keypoint *kf, const uint8_t *df, const int *node_f, float nnratio, int check_ori, int *match_f)
+{
+    return search_by_bow_core(nk, kk, dk, kf_good_mp, node_k, nf, kf, df, NULL, node_f, nnratio, check_ori, 0, match_f);
+}
+/* int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12) (ORBmatcher.cc:524-655; caller LoopClosing::ComputeSim3, LoopClosing.cc:259):
+ * good1 / good2 = the keypoint holds a map point that is not bad; match12[i1] (out) = keypoint of pKF2 whose map point pKF1's keypoint i1 is matched with, -1 = NULL. */
+int orc_search_by_bow_kf(int n1, const orc_keypoint *k1, const uint8_t *d1, const uint8_t *good1, const int *node1,
+                         int n2, const orc_keypoint *k2, const uint8_t *d2, const uint8_t *good2, const int *node2, float nnratio, int check_ori, int *match12)
+{
+    int *m2 = (int *)malloc(sizeof(int) * (size_t)(n2 > 0 ? n2 : 1));
+    const int n = search_by_bow_core(n1, k1, d1, good1, node1, n2, k2, d2, good2, node2, nnratio, check_ori, 1, m2);
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    for (int j = 0; j < n2; j++) if (m2[j] >= 0) match12[m2[j]] = j;
+    free(m2);
+    return n;
 }
 
 /* The search of ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, const float th), ORBmatcher.cc:829-979: for every candidate map point the keyframe

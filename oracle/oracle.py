@@ -354,6 +354,15 @@ def search_by_bow(kf, F, nnratio=0.7, check_ori=True):
     return int(n), match[:len(kq)].copy()
 
 
+def search_by_bow_kf(kf1, kf2, nnratio=0.75, check_ori=True):
+    a = [np.ascontiguousarray(kf1['keys']), np.ascontiguousarray(kf1['desc'], np.uint8), np.ascontiguousarray(kf1['good_mp'], np.uint8), np.ascontiguousarray(kf1['feat_node'], 'i4')]
+    b = [np.ascontiguousarray(kf2['keys']), np.ascontiguousarray(kf2['desc'], np.uint8), np.ascontiguousarray(kf2['good_mp'], np.uint8), np.ascontiguousarray(kf2['feat_node'], 'i4')]
+    match = np.full(max(len(a[0]), 1), -1, 'i4')
+    L = lib(); L.orc_search_by_bow_kf.restype = C.c_int
+    n = L.orc_search_by_bow_kf(C.c_int(len(a[0])), *[_p(x) for x in a], C.c_int(len(b[0])), *[_p(x) for x in b], C.c_float(nnratio), C.c_int(int(bool(check_ori))), _p(match))
+    return int(n), match[:len(a[0])].copy()
+
+
 def fuse_search(kf, m, cam, scale_factors, inv_level_sigma2, th=3.0):
     k = np.ascontiguousarray(kf['keys']); d = np.ascontiguousarray(kf['desc'], np.uint8); u = np.ascontiguousarray(kf['uright'], 'f4'); T = np.ascontiguousarray(kf['Tcw'], 'f4').reshape(16)
     xw = np.ascontiguousarray(m['xw'], 'f4'); nr = np.ascontiguousarray(m['normal'], 'f4'); mn = np.ascontiguousarray(m['min_dist'], 'f4'); mx = np.ascontiguousarray(m['max_dist'], 'f4')

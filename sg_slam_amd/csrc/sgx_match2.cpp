@@ -95,6 +95,39 @@ extern "C" int sgx_match_search_for_triangulation(
     return SGX_OK;
 }
 
+// shared body of the two SearchByBoW overloads (ORBmatcher.cc:167-290 KeyFrame-Frame, :524-655 KeyFrame-KeyFrame)
+static int search_by_bow_impl(
+    int nk, const sgx_keypoint *keys_kf_un, const uint8_t *desc_kf, const uint8_t *kf_good_mp, const int32_t *feat_node_kf,
+    int nf, const sgx_keypoint *keys_f_un, const uint8_t *desc_f, const uint8_t *good_f, const int32_t *feat_node_f, float nnratio, int check_orientation, int th_low,
+    int32_t *match_f, int32_t *nmatches)
+{
+    std::vector<int> it1, id1, st1, it2, id2, st2, job;
+    group_by_node(feat_node_kf, nk, it1, id1, st1); group_by_node(feat_node_f, nf, it2, id2, st2);
+    for (size_t a = 0, b = 0; a < id1.size() && b < id2.size();) {
+        if (id1[a] == id2[b]) { job.push_back(st1[a]); job.push_back(st1[a + 1]); job.push_back(st2[b]); job.push_back(st2[b + 1]); a++; b++; }
+        else if (id1[a] < id2[b]) a++; else b++;
+    }
+    SgxBowArgs A; memset(&A, 0, sizeof A);
+    A.nk = nk; A.nf = nf; A.nnodes = (int)(job.size() / 4); A.nnratio = nnratio; A.check_ori = check_orientation; A.th_low = th_low;
+    SgxStaged b[12]; int rc; const int dummy = 0;
+#define PUT(k, src, bytes) if ((rc = b[k].put(k, src, bytes)) != SGX_OK) return rc
+    PUT(0, keys_kf_un, (size_t)nk * 28); PUT(1, desc_kf, (size_t)nk * 32); PUT(2, kf_good_mp, (size_t)nk);
+    PUT(3, keys_f_un, (size_t)nf * 28); PUT(4, desc_f, (size_t)nf * 32);
+    PUT(5, it1.empty() ? &dummy : it1.data(), it1.empty() ? 4 : it1.size() * 4); PUT(6, it2.empty() ? &dummy : it2.data(), it2.empty() ? 4 : it2.size() * 4);
+    PUT(7, job.empty() ? &dummy : job.data(), job.empty() ? 4 : job.size() * 4);
+    PUT(8, nullptr, (size_t)nf * 4); PUT(9, nullptr, 4);
+    if (good_f) { PUT(10, good_f, (size_t)nf); A.good_f = (const uint8_t *)b[10].p; }
+#undef PUT
+    A.keys_k = (const uint8_t *)b[0].p; A.desc_k = (const uint32_t *)b[1].p; A.good_k = (const uint8_t *)b[2].p;
+    A.keys_f = (const uint8_t *)b[3].p; A.desc_f = (const uint32_t *)b[4].p;
+    A.items_k = (const int *)b[5].p; A.items_f = (const int *)b[6].p; A.job = (const int *)b[7].p; A.match_f = (int *)b[8].p; A.nmatches = (int *)b[9].p;
+    SGX_LAUNCH(k_search_bow, dim3(1), dim3(256), (sgx_stream_t)0, A);
+    SGX_CHECK_HIP(hipGetLastError());
+    SGX_CHECK_HIP(hipMemcpy(match_f, A.match_f, (size_t)nf * 4, hipMemcpyDeviceToHost));
+    SGX_CHECK_HIP(hipMemcpy(nmatches, A.nmatches, 4, hipMemcpyDeviceToHost));
+    return SGX_OK;
+}
+
 extern "C" int sgx_match_search_by_bow(
     int nk, const sgx_keypoint *keys_kf_un, const uint8_t *desc_kf, const uint8_t *kf_good_mp, const int32_t *feat_node_kf,
     int nf, const sgx_keypoint *keys_f_un, const uint8_t *desc_f, const int32_t *feat_node_f, float nnratio, int check_orientation,
@@ -105,29 +138,23 @@ extern "C" int sgx_match_search_by_bow(
     for (int j = 0; j < nf; j++) match_f[j] = -1;
     if (nk == 0 || nf == 0) return SGX_OK;
     if (!keys_kf_un || !desc_kf || !kf_good_mp || !feat_node_kf || !keys_f_un || !desc_f || !feat_node_f) return SGX_ERR_INVALID;
-    std::vector<int> it1, id1, st1, it2, id2, st2, job;
-    group_by_node(feat_node_kf, nk, it1, id1, st1); group_by_node(feat_node_f, nf, it2, id2, st2);
-    for (size_t a = 0, b = 0; a < id1.size() && b < id2.size();) {
-        if (id1[a] == id2[b]) { job.push_back(st1[a]); job.push_back(st1[a + 1]); job.push_back(st2[b]); job.push_back(st2[b + 1]); a++; b++; }
-        else if (id1[a] < id2[b]) a++; else b++;
-    }
-    SgxBowArgs A; memset(&A, 0, sizeof A);
-    A.nk = nk; A.nf = nf; A.nnodes = (int)(job.size() / 4); A.nnratio = nnratio; A.check_ori = check_orientation;
-    SgxStaged b[12]; int rc; const int dummy = 0;
-#define PUT(k, src, bytes) if ((rc = b[k].put(k, src, bytes)) != SGX_OK) return rc
-    PUT(0, keys_kf_un, (size_t)nk * 28); PUT(1, desc_kf, (size_t)nk * 32); PUT(2, kf_good_mp, (size_t)nk);
-    PUT(3, keys_f_un, (size_t)nf * 28); PUT(4, desc_f, (size_t)nf * 32);
-    PUT(5, it1.empty() ? &dummy : it1.data(), it1.empty() ? 4 : it1.size() * 4); PUT(6, it2.empty() ? &dummy : it2.data(), it2.empty() ? 4 : it2.size() * 4);
-    PUT(7, job.empty() ? &dummy : job.data(), job.empty() ? 4 : job.size() * 4);
-    PUT(8, nullptr, (size_t)nf * 4); PUT(9, nullptr, 4);
-#undef PUT
-    A.keys_k = (const uint8_t *)b[0].p; A.desc_k = (const uint32_t *)b[1].p; A.good_k = (const uint8_t *)b[2].p;
-    A.keys_f = (const uint8_t *)b[3].p; A.desc_f = (const uint32_t *)b[4].p;
-    A.items_k = (const int *)b[5].p; A.items_f = (const int *)b[6].p; A.job = (const int *)b[7].p; A.match_f = (int *)b[8].p; A.nmatches = (int *)b[9].p;
-    SGX_LAUNCH(k_search_bow, dim3(1), dim3(256), (sgx_stream_t)0, A);
-    SGX_CHECK_HIP(hipGetLastError());
-    SGX_CHECK_HIP(hipMemcpy(match_f, A.match_f, (size_t)nf * 4, hipMemcpyDeviceToHost));
-    SGX_CHECK_HIP(hipMemcpy(nmatches, A.nmatches, 4, hipMemcpyDeviceToHost));
+    return search_by_bow_impl(nk, keys_kf_un, desc_kf, kf_good_mp, feat_node_kf, nf, keys_f_un, desc_f, nullptr, feat_node_f, nnratio, check_orientation, SGX_TH_LOW, match_f, nmatches);
+}
+
+extern "C" int sgx_match_search_by_bow_kf(
+    int n1, const sgx_keypoint *keys1_un, const uint8_t *desc1, const uint8_t *good1, const int32_t *feat_node1,
+    int n2, const sgx_keypoint *keys2_un, const uint8_t *desc2, const uint8_t *good2, const int32_t *feat_node2, float nnratio, int check_orientation,
+    int32_t *match12, int32_t *nmatches)
+{
+    if (n1 < 0 || n2 < 0 || !nmatches || (n1 > 0 && !match12)) return SGX_ERR_INVALID;
+    *nmatches = 0;
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    if (n1 == 0 || n2 == 0) return SGX_OK;
+    if (!keys1_un || !desc1 || !good1 || !feat_node1 || !keys2_un || !desc2 || !good2 || !feat_node2) return SGX_ERR_INVALID;
+    std::vector<int32_t> m2((size_t)n2, -1);
+    const int rc = search_by_bow_impl(n1, keys1_un, desc1, good1, feat_node1, n2, keys2_un, desc2, good2, feat_node2, nnratio, check_orientation, SGX_TH_LOW - 1, m2.data(), nmatches);
+    if (rc != SGX_OK) return rc;
+    for (int j = 0; j < n2; j++) if (m2[(size_t)j] >= 0) match12[m2[(size_t)j]] = j;     // vbMatched2 makes the relation one-to-one, so the inverse is vpMatches12 (:600)
     return SGX_OK;
 }
 

@@ -149,8 +149,10 @@ SGX_KERNEL(256) k_search_triangulation(SgxTriArgs A)
 struct SgxBowArgs {
     int nk, nf, nnodes;
     const uint8_t *keys_k, *keys_f; const uint32_t *desc_k, *desc_f; const uint8_t *good_k;
+    const uint8_t *good_f;      // KeyFrame-KeyFrame overload: side 2 must hold a good map point too (ORBmatcher.cc:581-587); NULL = KeyFrame-Frame overload
     const int *items_k, *items_f, *job;
     float nnratio; int check_ori;
+    int th_low;                 // accept bestDist1 <= th_low: TH_LOW for KeyFrame-Frame (:234), TH_LOW - 1 for KeyFrame-KeyFrame (`< TH_LOW`, :597)
     int *match_f; int *nmatches;
 };
 SGX_KERNEL(256) k_search_bow(SgxBowArgs A)
@@ -173,12 +175,13 @@ SGX_KERNEL(256) k_search_bow(SgxBowArgs A)
             int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
             for (int q2 = s2; q2 < e2; q2++) {
                 const int jf = A.items_f[q2];
-                if (A.match_f[jf] >= 0) continue;                                  // :212
+                if (A.match_f[jf] >= 0) continue;                                  // :212 / vbMatched2 :578
+                if (A.good_f && !A.good_f[jf]) continue;                           // :581-587
                 const int dist = sgx_hamming256(d1, A.desc_f + (size_t)jf * 8);
                 if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = jf; }
                 else if (dist < bestDist2) bestDist2 = dist;
             }
-            if (bestDist1 <= SGX_TH_LOW && (float)bestDist1 < A.nnratio * (float)bestDist2) {
+            if (bestDist1 <= A.th_low && (float)bestDist1 < A.nnratio * (float)bestDist2) {
                 A.match_f[bestIdxF] = ik;
                 sgx_atomic_add(&s_total, 1);
                 if (A.check_ori) {

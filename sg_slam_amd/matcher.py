@@ -104,6 +104,16 @@ class ORBmatcher:
                                                             int(self.mbCheckOrientation), _vp(match), _vp(n)), 'sgx_match_search_by_bow')
         return int(n[0]), match[:len(kq)].copy()
 
+    def SearchByBoWKF(self, kf1, kf2):
+        """ORBmatcher::SearchByBoW(pKF1, pKF2, vpMatches12) (ORBmatcher.cc:524-655; LoopClosing::ComputeSim3).  kf*: keys, desc, good_mp, feat_node.
+        Returns (nmatches, match12[n1]): match12[i1] = keypoint of pKF2 whose map point pKF1's keypoint i1 is matched with, or -1."""
+        a = [np.ascontiguousarray(kf1['keys']), np.ascontiguousarray(kf1['desc'], np.uint8), np.ascontiguousarray(kf1['good_mp'], np.uint8), np.ascontiguousarray(kf1['feat_node'], 'i4')]
+        b = [np.ascontiguousarray(kf2['keys']), np.ascontiguousarray(kf2['desc'], np.uint8), np.ascontiguousarray(kf2['good_mp'], np.uint8), np.ascontiguousarray(kf2['feat_node'], 'i4')]
+        match = np.full(max(len(a[0]), 1), -1, 'i4'); n = np.zeros(1, 'i4')
+        self.lib.check(self.lib.dll.sgx_match_search_by_bow_kf(len(a[0]), *[_vp(x) for x in a], len(b[0]), *[_vp(x) for x in b], float(self.mfNNratio),
+                                                               int(self.mbCheckOrientation), _vp(match), _vp(n)), 'sgx_match_search_by_bow_kf')
+        return int(n[0]), match[:len(a[0])].copy()
+
     def FuseSearch(self, kf, map_points, th, cam, scale_factors, inv_level_sigma2):
         """the search of ORBmatcher::Fuse(pKF, vpMapPoints, th) (ORBmatcher.cc:829-979): (nFused, best_idx[nm], best_dist[nm]).  kf: keys, desc, uright, Tcw;
         map_points: xw, normal, min_dist, max_dist, desc, skip."""

@@ -96,6 +96,48 @@ def check_bow(lib, orc, n_cases=5):
     assert m.SearchByBoW(kf, far)[0] == 0 == orc.search_by_bow(kf, far)[0]
 
 
+def check_bow_kf(lib, orc, n_cases=5):
+    """SearchByBoW(pKF1, pKF2, vpMatches12) (LoopClosing::ComputeSim3): strict TH_LOW, map points required on both sides, output indexed by pKF1's keypoints."""
+    total = 0; strict_seen = 0
+    for c in range(n_cases):
+        _, kf1, kf2 = make_keyframes(orc, 140 + c, 8 + 2 * c, 10 + 2 * c)
+        rng = np.random.default_rng(900 + c)
+        kf1 = dict(kf1); kf2 = dict(kf2)
+        kf1['good_mp'] = (rng.random(len(kf1['keys'])) < 0.8).astype(np.uint8); kf2['good_mp'] = (rng.random(len(kf2['keys'])) < 0.8).astype(np.uint8)
+        for ratio in (0.75, 0.95):
+            for ori in (True, False):
+                en, em = orc.search_by_bow_kf(kf1, kf2, ratio, ori)
+                gn, gm = ORBmatcher(ratio, ori, lib=lib).SearchByBoWKF(kf1, kf2)
+                assert gn == en == (em >= 0).sum() and (gm == em).all(), (c, ratio, ori, gn, en)
+                total += en
+                sel = em >= 0
+                assert kf1['good_mp'][sel].all() and kf2['good_mp'][em[sel]].all() and (kf1['feat_node'][sel] == kf2['feat_node'][em[sel]]).all()
+                assert len(set(em[sel])) == sel.sum()                                    # vbMatched2: every keypoint of pKF2 used once
+                d = np.array([np.unpackbits(kf1['desc'][i] ^ kf2['desc'][j]).sum() for i, j in zip(np.nonzero(sel)[0], em[sel])])
+                assert (d < 50).all()                                                    # strict `< TH_LOW`
+        # the KeyFrame-Frame overload accepts distance == TH_LOW, this one must not: plant one pair at exactly 50 bits in a node of its own
+        k1 = dict(kf1); k2 = dict(kf2)
+        k1['desc'] = kf1['desc'].copy(); k2['desc'] = kf2['desc'].copy(); k1['feat_node'] = kf1['feat_node'].copy(); k2['feat_node'] = kf2['feat_node'].copy()
+        k1['good_mp'] = kf1['good_mp'].copy(); k2['good_mp'] = kf2['good_mp'].copy()
+        flip = np.zeros(256, np.uint8); flip[rng.choice(256, 50, replace=False)] = 1
+        k2['desc'][0] = k1['desc'][0] ^ np.packbits(flip); k1['feat_node'][0] = k2['feat_node'][0] = 777777; k1['good_mp'][0] = k2['good_mp'][0] = 1
+        en, em = orc.search_by_bow_kf(k1, k2, 0.75, False); gn, gm = ORBmatcher(0.75, False, lib=lib).SearchByBoWKF(k1, k2)
+        assert gn == en and (gm == em).all() and em[0] == -1
+        f2 = dict(keys=k2['keys'], desc=k2['desc'], feat_node=k2['feat_node']); a = dict(k1)
+        assert ORBmatcher(0.75, False, lib=lib).SearchByBoW(a, f2)[1][0] == 0             # same pair, KeyFrame-Frame overload: accepted at == TH_LOW
+        strict_seen += 1
+    assert total > 300 and strict_seen == n_cases
+    _, kf1, kf2 = make_keyframes(orc, 177, 9, 12)
+    kf1 = dict(kf1); kf2 = dict(kf2); kf1['good_mp'] = np.ones(len(kf1['keys']), np.uint8); kf2['good_mp'] = np.ones(len(kf2['keys']), np.uint8)
+    m = ORBmatcher(0.75, True, lib=lib)
+    empty = dict(keys=kf1['keys'][:0], desc=kf1['desc'][:0], good_mp=kf1['good_mp'][:0], feat_node=kf1['feat_node'][:0])
+    assert m.SearchByBoWKF(empty, kf2)[0] == 0 and m.SearchByBoWKF(kf1, empty)[0] == 0 and (m.SearchByBoWKF(kf1, empty)[1] == -1).all()
+    none2 = dict(kf2); none2['good_mp'] = np.zeros(len(kf2['keys']), np.uint8)
+    assert m.SearchByBoWKF(kf1, none2)[0] == 0 == orc.search_by_bow_kf(kf1, none2)[0]
+    far = dict(kf2); far['feat_node'] = kf2['feat_node'] + 100000
+    assert m.SearchByBoWKF(kf1, far)[0] == 0 == orc.search_by_bow_kf(kf1, far)[0]
+
+
 def check_fuse(lib, orc, n_cases=5):
     sf = orc.orb_params()['scale']; is2 = orc.orb_params()['inv_sigma2']
     from test_tracker_emu import make_map_points

@@ -14,6 +14,10 @@ def test_search_by_bow_emu(emu, oracle):
     mc.check_bow(emu, oracle, n_cases=3)
 
 
+def test_search_by_bow_kf_emu(emu, oracle):
+    mc.check_bow_kf(emu, oracle, n_cases=3)
+
+
 def test_fuse_search_emu(emu, oracle):
     mc.check_fuse(emu, oracle, n_cases=3)
 

@@ -17,6 +17,10 @@ def test_search_by_bow_gpu(gpulib, oracle):
     mc.check_bow(gpulib, oracle, n_cases=6)
 
 
+def test_search_by_bow_kf_gpu(gpulib, oracle):
+    mc.check_bow_kf(gpulib, oracle, n_cases=6)
+
+
 def test_fuse_search_gpu(gpulib, oracle):
     mc.check_fuse(gpulib, oracle, n_cases=6)
 
