@@ -153,7 +153,7 @@ int sgx_match_search_for_triangulation(
     int n2, const sgx_keypoint *keys2_un, const uint8_t *desc2, const float *uright2, const uint8_t *has_mp2, const int32_t *feat_node2, const float *Tcw2,
     const float *F12, const sgx_camera *cam2, const float *scale_factors2, const float *level_sigma2_2, int nlevels, int only_stereo, int check_orientation,
     int32_t *pairs, int32_t *npairs);
-/* int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches) (src/sg-slam/include/ORBmatcher.h:64, src/sg-slam/src/ORBmatcher.cc:159-290;
+/* int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches) (src/sg-slam/include/ORBmatcher.h:65, src/sg-slam/src/ORBmatcher.cc:159-290;
  * callers Tracking::TrackReferenceKeyFrame Tracking.cc:806, Relocalization :1496): kf_good_mp[i] = the keyframe's keypoint i holds a map point that is not bad,
  * feat_node_* = mFeatVec keys per keypoint (the vocabulary transform itself — DBoW2 + ORBvoc — stays with the caller).  match_f[j] = index of the keyframe keypoint whose
  * map point the frame's keypoint j receives (vpMapPointMatches[j] = vpMapPointsKF[match_f[j]]), -1 = NULL; *nmatches = return value.  Host pointers, synchronous. */
@@ -161,7 +161,7 @@ int sgx_match_search_by_bow(
     int nk, const sgx_keypoint *keys_kf_un, const uint8_t *desc_kf, const uint8_t *kf_good_mp, const int32_t *feat_node_kf,
     int nf, const sgx_keypoint *keys_f_un, const uint8_t *desc_f, const int32_t *feat_node_f, float nnratio, int check_orientation,
     int32_t *match_f, int32_t *nmatches);
-/* int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12) (src/sg-slam/include/ORBmatcher.h:65, src/sg-slam/src/ORBmatcher.cc:524-655;
+/* int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12) (src/sg-slam/include/ORBmatcher.h:66, src/sg-slam/src/ORBmatcher.cc:524-655;
  * caller LoopClosing::ComputeSim3, LoopClosing.cc:265): good*[i] = keypoint i of that keyframe holds a map point that is not bad; match12[i1] (out, n1 entries) = keypoint of
  * pKF2 whose map point is vpMatches12[i1], -1 = NULL; *nmatches = return value.  Differs from the KeyFrame-Frame overload in the strict `< TH_LOW` gate (:597) and in requiring a
  * map point on both sides (:581-587).  Host pointers, synchronous. */
@@ -169,7 +169,7 @@ int sgx_match_search_by_bow_kf(
     int n1, const sgx_keypoint *keys1_un, const uint8_t *desc1, const uint8_t *good1, const int32_t *feat_node1,
     int n2, const sgx_keypoint *keys2_un, const uint8_t *desc2, const uint8_t *good2, const int32_t *feat_node2, float nnratio, int check_orientation,
     int32_t *match12, int32_t *nmatches);
-/* The search of int ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, const float th = 3.0) (src/sg-slam/include/ORBmatcher.h:83,
+/* The search of int ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, const float th = 3.0) (src/sg-slam/include/ORBmatcher.h:80,
  * src/sg-slam/src/ORBmatcher.cc:829-979; caller LocalMapping::SearchInNeighbors, LocalMapping.cc:489,514): for every candidate map point i (m_skip[i] = NULL / isBad() /
  * IsInKeyFrame(pKF); m_min_dist / m_max_dist = mfMinDistance / mfMaxDistance) the keyframe keypoint best_idx[i] it fuses with (-1: none within TH_LOW) and the Hamming
  * distance best_dist[i].  *nfused = return value (number of best_idx >= 0).  The map mutations that follow in the reference (Replace / AddObservation / AddMapPoint,
@@ -190,6 +190,41 @@ int sgx_match_project_keyframe(
     int nk, const sgx_keypoint *kf_keys_un, const uint8_t *kf_ok, const float *m_xw, const float *m_min_dist, const float *m_max_dist, const uint8_t *m_desc,
     const sgx_camera *cam, const float *scale_factors, int nlevels, float log_scale_factor, float th, int orb_dist, int check_orientation,
     int32_t *cur_match, int32_t *nmatches);
+
+/* ---- ORBmatcher gates of the LoopClosing thread that project map points through a similarity (tier N2) ----------------------------------------------------------
+ * Shared conventions: keys_un / desc = the target keyframe's mvKeysUn / mDescriptors; Scw = 4x4 row-major float (sRcw | tcw), decomposed as the reference does
+ * (:301-306, :990-995); m_xw / m_normal / m_min_dist / m_max_dist / m_desc = GetWorldPos, GetNormal, mfMinDistance, mfMaxDistance, GetDescriptor of every candidate;
+ * cam supplies fx, fy, cx, cy and the image bounds (KeyFrame::IsInImage), scale_factors = mvScaleFactors, log_scale_factor = mfLogScaleFactor.  Host pointers, synchronous.
+ *
+ * The search of int ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, float th, vector<MapPoint*> &vpReplacePoint)
+ * (src/sg-slam/include/ORBmatcher.h:83, src/sg-slam/src/ORBmatcher.cc:981-1101; caller LoopClosing::SearchAndFuse, LoopClosing.cc:599): m_skip[i] = isBad() ||
+ * pKF->GetMapPoints().count(pMP).  best_idx[i] = keyframe keypoint candidate i lands on (-1: none within TH_LOW), best_dist[i] its Hamming distance (256: none); the caller
+ * reads pKF->GetMapPoint(best_idx[i]) to fill vpReplacePoint[i] or to add the observation (:1084-1097).  *nfused = return value. */
+int sgx_match_fuse_search_sim3(
+    int nk, const sgx_keypoint *keys_un, const uint8_t *desc, const float *Scw,
+    int nm, const float *m_xw, const float *m_normal, const float *m_min_dist, const float *m_max_dist, const uint8_t *m_desc, const uint8_t *m_skip,
+    const sgx_camera *cam, const float *scale_factors, int nlevels, float log_scale_factor, float th,
+    int32_t *best_idx, int32_t *best_dist, int32_t *nfused);
+/* int ORBmatcher::SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, vector<MapPoint*> &vpMatched, int th)
+ * (src/sg-slam/include/ORBmatcher.h:60, src/sg-slam/src/ORBmatcher.cc:292-407; caller LoopClosing::ComputeSim3, LoopClosing.cc:375): matched_in[k] = vpMatched[k] != NULL on
+ * entry, m_skip[i] = isBad() || the point is already in vpMatched.  matched_out[k] = index i of the candidate this call stores in vpMatched[k], -1 = unchanged; the
+ * reference's in-order greedy assignment (a point skips keypoints filled by earlier points, :381) is reproduced exactly.  *nmatches = return value. */
+int sgx_match_project_sim3(
+    int nk, const sgx_keypoint *keys_un, const uint8_t *desc, const uint8_t *matched_in, const float *Scw,
+    int nm, const float *m_xw, const float *m_normal, const float *m_min_dist, const float *m_max_dist, const uint8_t *m_desc, const uint8_t *m_skip,
+    const sgx_camera *cam, const float *scale_factors, int nlevels, float log_scale_factor, int th,
+    int32_t *matched_out, int32_t *nmatches);
+/* int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12, const float &s12, const cv::Mat &R12, const cv::Mat &t12, const float th)
+ * (src/sg-slam/include/ORBmatcher.h:77, src/sg-slam/src/ORBmatcher.cc:1106-1330; caller LoopClosing::ComputeSim3, LoopClosing.cc:323).  Per keyframe, indexed by keypoint:
+ * Tcw = GetPose() (4x4 row-major), mp_ok[i] = GetMapPointMatches()[i] is neither NULL nor bad, m_* = that map point's fields.  R12 = 3x3 row-major, t12 = 3 floats.
+ * match12 (in/out, n1 entries): -1 = vpMatches12[i1] is NULL; >= 0 = the keypoint of pKF2 its map point sits on (GetIndexInKeyFrame(pKF2)); -2 = non-NULL but not observed by
+ * pKF2.  Pairs that agree in both directions are written as keypoint indices of pKF2 (vpMatches12[i1] = vpMapPoints2[match12[i1]]); *nfound = return value.  Both keyframes
+ * share cam / scale_factors (one sensor, one ORB pyramid). */
+int sgx_match_search_by_sim3(
+    int n1, const sgx_keypoint *keys1_un, const uint8_t *desc1, const float *Tcw1, const uint8_t *mp_ok1, const float *m_xw1, const float *m_min_dist1, const float *m_max_dist1, const uint8_t *m_desc1,
+    int n2, const sgx_keypoint *keys2_un, const uint8_t *desc2, const float *Tcw2, const uint8_t *mp_ok2, const float *m_xw2, const float *m_min_dist2, const float *m_max_dist2, const uint8_t *m_desc2,
+    const sgx_camera *cam, const float *scale_factors, int nlevels, float log_scale_factor, float s12, const float *R12, const float *t12, float th,
+    int32_t *match12, int32_t *nfound);
 
 /* Harness helper (bench.py / tests), NOT a reference entry point: the previous-frame position of every keypoint under a per-frame affine flow
  * (prev = A * (x, y, 1), A = 6 floats), optionally displaced by shift[2] inside the frame's first box.  Stands in for cv::calcOpticalFlowPyrLK

@@ -15,6 +15,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <limits.h>
 
 typedef struct { float x, y, size, angle, response; int octave, class_id; } orc_keypoint;
 
@@ -612,4 +613,186 @@ int orc_search_by_projection_kf(
     for (int i = 0; i < HISTO_LENGTH; i++) free(hist[i]);
     free(vind); free(taken); grid_free(g); free(g);
     return nmatches;
+}
+
+/* ---- loop-closing matchers that project through a Sim3 (LoopClosing::ComputeSim3 / SearchAndFuse) ---------------------------------------------------------------- */
+
+/* "Decompose Scw" (ORBmatcher.cc:301-306, :990-995): scw = sqrt(row0 . row0) (Mat::dot: double accumulation), Rcw = sRcw / scw and tcw = Scw.col(3) / scw
+ * (Mat / double -> convertTo with the float of 1/scw), Ow = -Rcw.t() * tcw (gemm with a transpose flag: double accumulation, alpha = -1). */
+static void decompose_scw(const float *Scw, float Rcw[3][3], float tcw[3], float Ow[3])
+{
+    double s = 0; for (int c = 0; c < 3; c++) s += (double)Scw[c] * (double)Scw[c];
+    const float scw = (float)sqrt(s);
+    const float inv = (float)(1.0 / (double)scw);
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Rcw[r][c] = Scw[4 * r + c] * inv; tcw[r] = Scw[4 * r + 3] * inv; }
+    for (int i = 0; i < 3; i++) {
+        double a = 0; for (int k = 0; k < 3; k++) a += (double)Rcw[k][i] * (double)tcw[k];
+        Ow[i] = (float)(a * -1.0);
+    }
+}
+
+/* The search of int ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, float th, vector<MapPoint*> &vpReplacePoint) (ORBmatcher.cc:981-1101;
+ * caller LoopClosing::SearchAndFuse, LoopClosing.cc:599).  m_skip[i] = isBad() || pKF->GetMapPoints().count(pMP).  best_idx[i] = keyframe keypoint the point lands on
+ * (-1: none within TH_LOW); the caller then reads pKF->GetMapPoint(best_idx[i]) to fill vpReplacePoint or to add the observation (:1084-1097). */
+int orc_fuse_search_sim3(int Nk, const orc_keypoint *keys, const uint8_t *desc, const float *Scw,
+                         int Nm, const float *m_xw, const float *m_normal, const float *m_min_dist, const float *m_max_dist, const uint8_t *m_desc, const uint8_t *m_skip,
+                         float fx, float fy, float cx, float cy, float minX, float maxX, float minY, float maxY,
+                         const float *scale_factors, int nlevels, float log_scale_factor, float th, int *best_idx, int *best_dist)
+{
+    grid_t *g = (grid_t *)malloc(sizeof(grid_t));
+    grid_build(g, Nk, keys, minX, maxX, minY, maxY);
+    int *cand = (int *)malloc(sizeof(int) * (Nk > 0 ? Nk : 1));
+    float Rcw[3][3], tcw[3], Ow[3];
+    decompose_scw(Scw, Rcw, tcw, Ow);
+    int nFused = 0;
+    for (int i = 0; i < Nm; i++) {
+        best_idx[i] = -1; best_dist[i] = 256;
+        if (m_skip[i]) continue;
+        const float *P = m_xw + 3 * i;
+        const float pcx = gemm3(Rcw[0], P, 1.0, 1.0, tcw[0]), pcy = gemm3(Rcw[1], P, 1.0, 1.0, tcw[1]), pcz = gemm3(Rcw[2], P, 1.0, 1.0, tcw[2]);
+        if (pcz < 0.0f) continue;
+        const float invz = (float)(1.0 / pcz), x = pcx * invz, y = pcy * invz;                 /* :1022 `1.0/` : double division */
+        const float u = fx * x + cx, v = fy * y + cy;
+        if (!(u >= minX && u < maxX && v >= minY && v < maxY)) continue;
+        const float maxDistance = 1.2f * m_max_dist[i], minDistance = 0.8f * m_min_dist[i];
+        const float po0 = P[0] - Ow[0], po1 = P[1] - Ow[1], po2 = P[2] - Ow[2];
+        const float dist3D = (float)sqrt((double)po0 * po0 + (double)po1 * po1 + (double)po2 * po2);
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        const double dot = (double)po0 * m_normal[3 * i] + (double)po1 * m_normal[3 * i + 1] + (double)po2 * m_normal[3 * i + 2];
+        if (dot < 0.5 * dist3D) continue;
+        int lvl = (int)ceilf(logf(m_max_dist[i] / dist3D) / log_scale_factor);
+        if (lvl < 0) lvl = 0; else if (lvl >= nlevels) lvl = nlevels - 1;
+        const float radius = th * scale_factors[lvl];
+        const int nc = features_in_area(g, keys, u, v, radius, -1, -1, cand);
+        int bestDist = INT_MAX, bestIdx = -1;
+        for (int q = 0; q < nc; q++) {
+            const int idx = cand[q];
+            const int kpLevel = keys[idx].octave;
+            if (kpLevel < lvl - 1 || kpLevel > lvl) continue;
+            const int dist = orc_descriptor_distance(m_desc + 32 * (size_t)i, desc + 32 * (size_t)idx);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestDist <= TH_LOW) { best_idx[i] = bestIdx; best_dist[i] = bestDist; nFused++; }
+    }
+    grid_free(g); free(g); free(cand);
+    return nFused;
+}
+
+/* int ORBmatcher::SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, vector<MapPoint*> &vpMatched, int th) (ORBmatcher.cc:292-407;
+ * caller LoopClosing::ComputeSim3, LoopClosing.cc:375).  matched_in[k] = vpMatched[k] != NULL on entry; m_skip[i] = isBad() || the point is already in vpMatched;
+ * matched_out[k] = index i of the candidate that this call put into vpMatched[k], -1 = unchanged. */
+int orc_search_by_projection_sim3(int Nk, const orc_keypoint *keys, const uint8_t *desc, const uint8_t *matched_in, const float *Scw,
+                                  int Nm, const float *m_xw, const float *m_normal, const float *m_min_dist, const float *m_max_dist, const uint8_t *m_desc, const uint8_t *m_skip,
+                                  float fx, float fy, float cx, float cy, float minX, float maxX, float minY, float maxY,
+                                  const float *scale_factors, int nlevels, float log_scale_factor, int th, int *matched_out)
+{
+    grid_t *g = (grid_t *)malloc(sizeof(grid_t));
+    grid_build(g, Nk, keys, minX, maxX, minY, maxY);
+    int *cand = (int *)malloc(sizeof(int) * (Nk > 0 ? Nk : 1));
+    uint8_t *taken = (uint8_t *)malloc((size_t)(Nk > 0 ? Nk : 1));
+    for (int k = 0; k < Nk; k++) { taken[k] = matched_in[k] != 0; matched_out[k] = -1; }
+    float Rcw[3][3], tcw[3], Ow[3];
+    decompose_scw(Scw, Rcw, tcw, Ow);
+    int nmatches = 0;
+    for (int i = 0; i < Nm; i++) {
+        if (m_skip[i]) continue;
+        const float *P = m_xw + 3 * i;
+        const float pcx = gemm3(Rcw[0], P, 1.0, 1.0, tcw[0]), pcy = gemm3(Rcw[1], P, 1.0, 1.0, tcw[1]), pcz = gemm3(Rcw[2], P, 1.0, 1.0, tcw[2]);
+        if (pcz < 0.0f) continue;
+        const float invz = 1 / pcz, x = pcx * invz, y = pcy * invz;                            /* :333 `1/` : float division */
+        const float u = fx * x + cx, v = fy * y + cy;
+        if (!(u >= minX && u < maxX && v >= minY && v < maxY)) continue;
+        const float maxDistance = 1.2f * m_max_dist[i], minDistance = 0.8f * m_min_dist[i];
+        const float po0 = P[0] - Ow[0], po1 = P[1] - Ow[1], po2 = P[2] - Ow[2];
+        const float dist = (float)sqrt((double)po0 * po0 + (double)po1 * po1 + (double)po2 * po2);
+        if (dist < minDistance || dist > maxDistance) continue;
+        const double dot = (double)po0 * m_normal[3 * i] + (double)po1 * m_normal[3 * i + 1] + (double)po2 * m_normal[3 * i + 2];
+        if (dot < 0.5 * dist) continue;
+        int lvl = (int)ceilf(logf(m_max_dist[i] / dist) / log_scale_factor);
+        if (lvl < 0) lvl = 0; else if (lvl >= nlevels) lvl = nlevels - 1;
+        const float radius = th * scale_factors[lvl];
+        const int nc = features_in_area(g, keys, u, v, radius, -1, -1, cand);
+        int bestDist = 256, bestIdx = -1;
+        for (int q = 0; q < nc; q++) {
+            const int idx = cand[q];
+            if (taken[idx]) continue;                                                          /* vpMatched[idx] */
+            const int kpLevel = keys[idx].octave;
+            if (kpLevel < lvl - 1 || kpLevel > lvl) continue;
+            const int d = orc_descriptor_distance(m_desc + 32 * (size_t)i, desc + 32 * (size_t)idx);
+            if (d < bestDist) { bestDist = d; bestIdx = idx; }
+        }
+        if (bestDist <= TH_LOW) { taken[bestIdx] = 1; matched_out[bestIdx] = i; nmatches++; }
+    }
+    grid_free(g); free(g); free(cand); free(taken);
+    return nmatches;
+}
+
+/* one direction of SearchBySim3 (:1150-1224 / :1227-1301): map points of the source keyframe (indexed by its keypoints) through Rsw, tsw and then sR, t into the
+ * target keyframe; match[i] = best target keypoint within TH_HIGH, -1 otherwise */
+static void sim3_direction(int Ns, const uint8_t *src_ok, const uint8_t *src_already, const float *xw, const float *mind, const float *maxd, const uint8_t *mdesc,
+                           const float Rsw[3][3], const float *tsw, const float sR[3][3], const float *t,
+                           const grid_t *g, const orc_keypoint *tkeys, const uint8_t *tdesc, int *cand,
+                           float fx, float fy, float cx, float cy, float minX, float maxX, float minY, float maxY,
+                           const float *scale_factors, int nlevels, float log_scale_factor, float th, int *match)
+{
+    for (int i = 0; i < Ns; i++) {
+        match[i] = -1;
+        if (!src_ok[i] || src_already[i]) continue;
+        const float *P = xw + 3 * i;
+        const float c1[3] = { gemm3(Rsw[0], P, 1.0, 1.0, tsw[0]), gemm3(Rsw[1], P, 1.0, 1.0, tsw[1]), gemm3(Rsw[2], P, 1.0, 1.0, tsw[2]) };
+        const float c2[3] = { gemm3(sR[0], c1, 1.0, 1.0, t[0]), gemm3(sR[1], c1, 1.0, 1.0, t[1]), gemm3(sR[2], c1, 1.0, 1.0, t[2]) };
+        if (c2[2] < 0.0) continue;
+        const float invz = (float)(1.0 / c2[2]), x = c2[0] * invz, y = c2[1] * invz;
+        const float u = fx * x + cx, v = fy * y + cy;
+        if (!(u >= minX && u < maxX && v >= minY && v < maxY)) continue;
+        const float maxDistance = 1.2f * maxd[i], minDistance = 0.8f * mind[i];
+        const float dist3D = (float)sqrt((double)c2[0] * c2[0] + (double)c2[1] * c2[1] + (double)c2[2] * c2[2]);       /* cv::norm(p3Dc2) */
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        int lvl = (int)ceilf(logf(maxd[i] / dist3D) / log_scale_factor);
+        if (lvl < 0) lvl = 0; else if (lvl >= nlevels) lvl = nlevels - 1;
+        const float radius = th * scale_factors[lvl];
+        const int nc = features_in_area(g, tkeys, u, v, radius, -1, -1, cand);
+        int bestDist = INT_MAX, bestIdx = -1;
+        for (int q = 0; q < nc; q++) {
+            const int idx = cand[q];
+            if (tkeys[idx].octave < lvl - 1 || tkeys[idx].octave > lvl) continue;
+            const int d = orc_descriptor_distance(mdesc + 32 * (size_t)i, tdesc + 32 * (size_t)idx);
+            if (d < bestDist) { bestDist = d; bestIdx = idx; }
+        }
+        if (bestDist <= TH_HIGH) match[i] = bestIdx;
+    }
+}
+
+/* int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12, const float &s12, const cv::Mat &R12, const cv::Mat &t12, const float th)
+ * (ORBmatcher.cc:1106-1330; caller LoopClosing::ComputeSim3, LoopClosing.cc:323).  Per keyframe, indexed by keypoint: ok = holds a map point that is not bad, xw / min_dist /
+ * max_dist / mdesc = that map point's position, mfMinDistance, mfMaxDistance and descriptor.  match12 (in/out): -1 = vpMatches12[i1] is NULL, >= 0 = the keypoint of pKF2
+ * its map point sits on (GetIndexInKeyFrame), -2 = non-NULL but not observed by pKF2.  New matches are written as keypoint indices of pKF2; returns nFound. */
+int orc_search_by_sim3(int N1, const orc_keypoint *keys1, const uint8_t *desc1, const float *Tcw1, const uint8_t *ok1, const float *xw1, const float *min1, const float *max1, const uint8_t *mdesc1,
+                       int N2, const orc_keypoint *keys2, const uint8_t *desc2, const float *Tcw2, const uint8_t *ok2, const float *xw2, const float *min2, const float *max2, const uint8_t *mdesc2,
+                       float fx, float fy, float cx, float cy, float minX, float maxX, float minY, float maxY,
+                       const float *scale_factors, int nlevels, float log_scale_factor, float s12, const float *R12, const float *t12, float th, int *match12)
+{
+    float R1w[3][3], t1w[3], R2w[3][3], t2w[3], sR12[3][3], sR21[3][3], t21[3];
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) { R1w[r][c] = Tcw1[4 * r + c]; R2w[r][c] = Tcw2[4 * r + c]; } t1w[r] = Tcw1[4 * r + 3]; t2w[r] = Tcw2[4 * r + 3]; }
+    const float inv_s = (float)(1.0 / (double)s12);
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { sR12[r][c] = R12[3 * r + c] * s12; sR21[r][c] = R12[3 * c + r] * inv_s; }     /* s12*R12, (1.0/s12)*R12.t() */
+    for (int r = 0; r < 3; r++) t21[r] = gemm3(sR21[r], t12, -1.0, 0.0, 0.0f);                                                             /* -sR21*t12 */
+    uint8_t *already1 = (uint8_t *)calloc((size_t)(N1 > 0 ? N1 : 1), 1), *already2 = (uint8_t *)calloc((size_t)(N2 > 0 ? N2 : 1), 1);
+    for (int i = 0; i < N1; i++) if (match12[i] != -1) { already1[i] = 1; if (match12[i] >= 0 && match12[i] < N2) already2[match12[i]] = 1; }
+    int *m1 = (int *)malloc(sizeof(int) * (size_t)(N1 > 0 ? N1 : 1)), *m2 = (int *)malloc(sizeof(int) * (size_t)(N2 > 0 ? N2 : 1));
+    int *cand = (int *)malloc(sizeof(int) * (size_t)((N1 > N2 ? N1 : N2) + 1));
+    grid_t *g = (grid_t *)malloc(sizeof(grid_t));
+    grid_build(g, N2, keys2, minX, maxX, minY, maxY);
+    sim3_direction(N1, ok1, already1, xw1, min1, max1, mdesc1, R1w, t1w, sR21, t21, g, keys2, desc2, cand, fx, fy, cx, cy, minX, maxX, minY, maxY, scale_factors, nlevels, log_scale_factor, th, m1);
+    grid_free(g);
+    grid_build(g, N1, keys1, minX, maxX, minY, maxY);
+    sim3_direction(N2, ok2, already2, xw2, min2, max2, mdesc2, R2w, t2w, sR12, t12, g, keys1, desc1, cand, fx, fy, cx, cy, minX, maxX, minY, maxY, scale_factors, nlevels, log_scale_factor, th, m2);
+    grid_free(g); free(g);
+    int nFound = 0;
+    for (int i1 = 0; i1 < N1; i1++) {                                                   /* check agreement, :1305-1320 */
+        const int idx2 = m1[i1];
+        if (idx2 >= 0 && m2[idx2] == i1) { match12[i1] = idx2; nFound++; }
+    }
+    free(already1); free(already2); free(m1); free(m2); free(cand);
+    return nFound;
 }

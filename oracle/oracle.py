@@ -391,6 +391,49 @@ def search_by_projection_kf(F, kf, cam, scale_factors, th, orb_dist, check_ori=T
     return int(n), match[:len(ck)].copy()
 
 
+def _cam_args(cam):
+    return [C.c_float(cam['fx']), C.c_float(cam['fy']), C.c_float(cam['cx']), C.c_float(cam['cy']),
+            C.c_float(cam.get('min_x', 0.0)), C.c_float(cam.get('max_x', 640.0)), C.c_float(cam.get('min_y', 0.0)), C.c_float(cam.get('max_y', 480.0))]
+
+
+def _points(m):
+    return [np.ascontiguousarray(m['xw'], 'f4'), np.ascontiguousarray(m['normal'], 'f4'), np.ascontiguousarray(m['min_dist'], 'f4'), np.ascontiguousarray(m['max_dist'], 'f4'),
+            np.ascontiguousarray(m['desc'], np.uint8), np.ascontiguousarray(m['skip'], np.uint8)]
+
+
+def fuse_search_sim3(kf, Scw, m, cam, scale_factors, th):
+    k = np.ascontiguousarray(kf['keys']); d = np.ascontiguousarray(kf['desc'], np.uint8); S = np.ascontiguousarray(Scw, 'f4').reshape(16)
+    pts = _points(m); nm = len(pts[0]); sf = np.ascontiguousarray(scale_factors, 'f4')
+    bi = np.full(max(nm, 1), -1, 'i4'); bd = np.full(max(nm, 1), 256, 'i4')
+    L = lib(); L.orc_fuse_search_sim3.restype = C.c_int
+    n = L.orc_fuse_search_sim3(C.c_int(len(k)), _p(k), _p(d), _p(S), C.c_int(nm), *[_p(x) for x in pts], *_cam_args(cam), _p(sf), C.c_int(len(sf)),
+                               C.c_float(np.log(np.float32(sf[1]))), C.c_float(th), _p(bi), _p(bd))
+    return int(n), bi[:nm].copy(), bd[:nm].copy()
+
+
+def search_by_projection_sim3(kf, Scw, m, cam, scale_factors, th):
+    k = np.ascontiguousarray(kf['keys']); d = np.ascontiguousarray(kf['desc'], np.uint8); mi = np.ascontiguousarray(kf['matched'], np.uint8); S = np.ascontiguousarray(Scw, 'f4').reshape(16)
+    pts = _points(m); nm = len(pts[0]); sf = np.ascontiguousarray(scale_factors, 'f4')
+    mo = np.full(max(len(k), 1), -1, 'i4')
+    L = lib(); L.orc_search_by_projection_sim3.restype = C.c_int
+    n = L.orc_search_by_projection_sim3(C.c_int(len(k)), _p(k), _p(d), _p(mi), _p(S), C.c_int(nm), *[_p(x) for x in pts], *_cam_args(cam), _p(sf), C.c_int(len(sf)),
+                                        C.c_float(np.log(np.float32(sf[1]))), C.c_int(int(th)), _p(mo))
+    return int(n), mo[:len(k)].copy()
+
+
+def search_by_sim3(kf1, kf2, match12, s12, R12, t12, th, cam, scale_factors):
+    def flat(kf):
+        return [np.ascontiguousarray(kf['keys']), np.ascontiguousarray(kf['desc'], np.uint8), np.ascontiguousarray(kf['Tcw'], 'f4').reshape(16), np.ascontiguousarray(kf['mp_ok'], np.uint8),
+                np.ascontiguousarray(kf['xw'], 'f4'), np.ascontiguousarray(kf['min_dist'], 'f4'), np.ascontiguousarray(kf['max_dist'], 'f4'), np.ascontiguousarray(kf['mp_desc'], np.uint8)]
+    a = flat(kf1); b = flat(kf2); sf = np.ascontiguousarray(scale_factors, 'f4')
+    R = np.ascontiguousarray(R12, 'f4').reshape(9); t = np.ascontiguousarray(t12, 'f4').reshape(3)
+    m = np.full(max(len(a[0]), 1), -1, 'i4'); m[:len(a[0])] = np.asarray(match12, 'i4')
+    L = lib(); L.orc_search_by_sim3.restype = C.c_int
+    n = L.orc_search_by_sim3(C.c_int(len(a[0])), *[_p(x) for x in a], C.c_int(len(b[0])), *[_p(x) for x in b], *_cam_args(cam), _p(sf), C.c_int(len(sf)),
+                             C.c_float(np.log(np.float32(sf[1]))), C.c_float(s12), _p(R), _p(t), C.c_float(th), _p(m))
+    return int(n), m[:len(a[0])].copy()
+
+
 def optimize_sim3(p1c, p2c, obs1, obs2, info1, info2, K1, K2, S12, th2=10.0, fix_scale=False):
     """Optimizer::OptimizeSim3 on flattened correspondences: (nIn, S12[8] = (qx,qy,qz,qw,tx,ty,tz,s), inlier[n], iterations[2])."""
     p1c = np.ascontiguousarray(p1c, 'f4').reshape(-1, 3); p2c = np.ascontiguousarray(p2c, 'f4').reshape(-1, 3); n = len(p1c)

@@ -69,7 +69,7 @@ SYMBOLS = [
     'sgx_dynamic_mask_batch_dev',
     'sgx_flow_create', 'sgx_flow_destroy', 'sgx_flow_reset', 'sgx_flow_levels', 'sgx_flow_lk_batch_dev', 'sgx_flow_lk', 'sgx_flow_debug_read_level', 'sgx_flow_debug_level_size',
     'sgx_fundamental_ransac_batch_dev', 'sgx_find_fundamental_mat',
-    'sgx_hamming_matrix', 'sgx_hamming_matrix_dev', 'sgx_match_search_for_triangulation', 'sgx_match_search_by_bow', 'sgx_match_search_by_bow_kf', 'sgx_match_fuse_search', 'sgx_match_project_keyframe', 'sgx_optimize_sim3', 'sgx_optimize_essential_graph', 'sgx_correct_map_points',
+    'sgx_hamming_matrix', 'sgx_hamming_matrix_dev', 'sgx_match_search_for_triangulation', 'sgx_match_search_by_bow', 'sgx_match_search_by_bow_kf', 'sgx_match_fuse_search', 'sgx_match_project_keyframe', 'sgx_match_fuse_search_sim3', 'sgx_match_project_sim3', 'sgx_match_search_by_sim3', 'sgx_optimize_sim3', 'sgx_optimize_essential_graph', 'sgx_correct_map_points',
 ]
 
 
@@ -159,6 +159,9 @@ class SgxLib:
         d.sgx_optimize_sim3.argtypes = [C.c_int] + [vp] * 9 + [C.c_float, C.c_int, vp, vp, vp]
         d.sgx_match_project_keyframe.argtypes = [C.c_int] + [vp] * 4 + [C.c_int] + [vp] * 6 + [C.POINTER(Camera), vp, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, vp, vp]
         d.sgx_match_search_by_bow.argtypes = [C.c_int] + [vp] * 4 + [C.c_int] + [vp] * 3 + [C.c_float, C.c_int, vp, vp]
+        d.sgx_match_fuse_search_sim3.argtypes = [C.c_int, vp, vp, vp, C.c_int] + [vp] * 6 + [vp, vp, C.c_int, C.c_float, C.c_float, vp, vp, vp]
+        d.sgx_match_project_sim3.argtypes = [C.c_int, vp, vp, vp, vp, C.c_int] + [vp] * 6 + [vp, vp, C.c_int, C.c_float, C.c_int, vp, vp]
+        d.sgx_match_search_by_sim3.argtypes = ([C.c_int] + [vp] * 8) * 2 + [vp, vp, C.c_int, C.c_float, C.c_float, vp, vp, C.c_float, vp, vp]
         d.sgx_match_search_by_bow_kf.argtypes = [C.c_int] + [vp] * 4 + [C.c_int] + [vp] * 4 + [C.c_float, C.c_int, vp, vp]
         d.sgx_match_fuse_search.argtypes = [C.c_int] + [vp] * 4 + [C.c_int] + [vp] * 6 + [C.POINTER(Camera), vp, vp, C.c_int, C.c_float, C.c_float, vp, vp, vp]
         d.sgx_hamming_matrix_dev.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]

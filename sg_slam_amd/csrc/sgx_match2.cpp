@@ -251,3 +251,177 @@ extern "C" int sgx_match_project_keyframe(
     SGX_CHECK_HIP(hipMemcpy(nmatches, A.nmatches, 4, hipMemcpyDeviceToHost));
     return SGX_OK;
 }
+
+// ---- loop-closing matchers that project through a Sim3 -------------------------------------------------------------------------------------------------------------
+
+// KeyFrame::mGrid (KeyFrame.cc:39-47 copies Frame::mGrid, built by AssignFeaturesToGrid / PosInGrid with round(), Frame.cc:257-272, :409-419) as CSR:
+// cell (ix, iy) -> ix * 48 + iy, index order inside a cell
+static void build_kf_grid(int n, const sgx_keypoint *keys, const sgx_camera *cam, std::vector<int> &start, std::vector<int> &items)
+{
+    const float invW = 64.0f / (cam->max_x - cam->min_x), invH = 48.0f / (cam->max_y - cam->min_y);
+    std::vector<int> cell((size_t)n, -1);
+    start.assign(64 * 48 + 1, 0);
+    for (int i = 0; i < n; i++) {
+        const int px = (int)round((keys[i].x - cam->min_x) * invW), py = (int)round((keys[i].y - cam->min_y) * invH);
+        if (px < 0 || px >= 64 || py < 0 || py >= 48) continue;
+        cell[(size_t)i] = px * 48 + py; start[(size_t)cell[(size_t)i] + 1]++;
+    }
+    for (int c = 0; c < 64 * 48; c++) start[(size_t)c + 1] += start[(size_t)c];
+    items.assign((size_t)start[64 * 48] > 0 ? (size_t)start[64 * 48] : 1, 0);
+    std::vector<int> fill(64 * 48, 0);
+    for (int i = 0; i < n; i++) if (cell[(size_t)i] >= 0) items[(size_t)start[(size_t)cell[(size_t)i]] + fill[(size_t)cell[(size_t)i]]++] = i;
+}
+
+// "Decompose Scw" (ORBmatcher.cc:301-306, :990-995).  cv::Mat arithmetic: Mat::dot accumulates in double; Mat / double is a convertTo by the float of 1/scw;
+// -Rcw.t() * tcw is a gemm with a transpose flag (double accumulation, alpha = -1).
+static void decompose_scw(const float *Scw, float R[3][3], float t[3], float Ow[3])
+{
+    double s = 0; for (int c = 0; c < 3; c++) s += (double)Scw[c] * (double)Scw[c];
+    const float scw = (float)sqrt(s), inv = (float)(1.0 / (double)scw);
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) R[r][c] = Scw[4 * r + c] * inv; t[r] = Scw[4 * r + 3] * inv; }
+    for (int i = 0; i < 3; i++) {
+        double a = 0; for (int k = 0; k < 3; k++) a += (double)R[k][i] * (double)t[k];
+        Ow[i] = (float)(a * -1.0);
+    }
+}
+
+static void sim3_fill_common(SgxSim3ProjArgs &A, const sgx_camera *cam, const float *scale_factors, int nlevels, float log_scale_factor, float th)
+{
+    A.nlevels = nlevels; A.log_scale_factor = log_scale_factor; A.th = th;
+    A.cam.fx = cam->fx; A.cam.fy = cam->fy; A.cam.cx = cam->cx; A.cam.cy = cam->cy; A.cam.bf = cam->bf; A.cam.minX = cam->min_x; A.cam.maxX = cam->max_x; A.cam.minY = cam->min_y; A.cam.maxY = cam->max_y;
+    for (int i = 0; i < nlevels; i++) A.scale.s[i] = scale_factors[i];
+}
+
+extern "C" int sgx_match_fuse_search_sim3(
+    int nk, const sgx_keypoint *keys_un, const uint8_t *desc, const float *Scw,
+    int nm, const float *m_xw, const float *m_normal, const float *m_min_dist, const float *m_max_dist, const uint8_t *m_desc, const uint8_t *m_skip,
+    const sgx_camera *cam, const float *scale_factors, int nlevels, float log_scale_factor, float th,
+    int32_t *best_idx, int32_t *best_dist, int32_t *nfused)
+{
+    if (nk < 0 || nm < 0 || !cam || !Scw || !scale_factors || nlevels < 1 || nlevels > 12 || !nfused || (nm > 0 && (!best_idx || !best_dist))) return SGX_ERR_INVALID;
+    *nfused = 0;
+    for (int i = 0; i < nm; i++) { best_idx[i] = -1; best_dist[i] = 256; }
+    if (nk == 0 || nm == 0) return SGX_OK;
+    if (!keys_un || !desc || !m_xw || !m_normal || !m_min_dist || !m_max_dist || !m_desc || !m_skip) return SGX_ERR_INVALID;
+    std::vector<int> start, items;
+    build_kf_grid(nk, keys_un, cam, start, items);
+    SgxSim3ProjArgs A; memset(&A, 0, sizeof A);
+    A.nk = nk; A.nm = nm; A.flags = SGX_S3_NORMAL; A.th_accept = SGX_TH_LOW;
+    sim3_fill_common(A, cam, scale_factors, nlevels, log_scale_factor, th);
+    decompose_scw(Scw, A.R1, A.t1, A.Ow);
+    SgxStaged b[12]; int rc;
+#define PUT(k, src, bytes) if ((rc = b[k].put(k, src, bytes)) != SGX_OK) return rc
+    PUT(0, keys_un, (size_t)nk * 28); PUT(1, desc, (size_t)nk * 32); PUT(2, start.data(), start.size() * 4); PUT(3, items.data(), items.size() * 4);
+    PUT(4, m_xw, (size_t)nm * 12); PUT(5, m_normal, (size_t)nm * 12); PUT(6, m_min_dist, (size_t)nm * 4); PUT(7, m_max_dist, (size_t)nm * 4); PUT(8, m_desc, (size_t)nm * 32); PUT(9, m_skip, (size_t)nm);
+    PUT(10, nullptr, (size_t)nm * 4); PUT(11, nullptr, (size_t)nm * 4);
+#undef PUT
+    A.keys = (const uint8_t *)b[0].p; A.desc = (const uint32_t *)b[1].p; A.cell_start = (const int *)b[2].p; A.cell_items = (const int *)b[3].p;
+    A.m_xw = (const float *)b[4].p; A.m_normal = (const float *)b[5].p; A.m_min_dist = (const float *)b[6].p; A.m_max_dist = (const float *)b[7].p;
+    A.m_desc = (const uint32_t *)b[8].p; A.m_skip = (const uint8_t *)b[9].p; A.best_idx = (int *)b[10].p; A.best_dist = (int *)b[11].p;
+    SGX_LAUNCH(k_sim3_search, dim3((nm + 255) / 256), dim3(256), (sgx_stream_t)0, A);
+    SGX_CHECK_HIP(hipGetLastError());
+    SGX_CHECK_HIP(hipMemcpy(best_idx, A.best_idx, (size_t)nm * 4, hipMemcpyDeviceToHost));
+    SGX_CHECK_HIP(hipMemcpy(best_dist, A.best_dist, (size_t)nm * 4, hipMemcpyDeviceToHost));
+    int n = 0; for (int i = 0; i < nm; i++) n += best_idx[i] >= 0;
+    *nfused = n;
+    return SGX_OK;
+}
+
+extern "C" int sgx_match_project_sim3(
+    int nk, const sgx_keypoint *keys_un, const uint8_t *desc, const uint8_t *matched_in, const float *Scw,
+    int nm, const float *m_xw, const float *m_normal, const float *m_min_dist, const float *m_max_dist, const uint8_t *m_desc, const uint8_t *m_skip,
+    const sgx_camera *cam, const float *scale_factors, int nlevels, float log_scale_factor, int th,
+    int32_t *matched_out, int32_t *nmatches)
+{
+    if (nk < 0 || nm < 0 || !cam || !Scw || !scale_factors || nlevels < 1 || nlevels > 12 || !nmatches || (nk > 0 && !matched_out)) return SGX_ERR_INVALID;
+    *nmatches = 0;
+    for (int k = 0; k < nk; k++) matched_out[k] = -1;
+    if (nk == 0 || nm == 0) return SGX_OK;
+    if (!keys_un || !desc || !matched_in || !m_xw || !m_normal || !m_min_dist || !m_max_dist || !m_desc || !m_skip) return SGX_ERR_INVALID;
+    std::vector<int> start, items;
+    build_kf_grid(nk, keys_un, cam, start, items);
+    SgxSim3ProjArgs A; memset(&A, 0, sizeof A);
+    A.nk = nk; A.nm = nm; A.flags = SGX_S3_NORMAL | SGX_S3_FLOAT_INVZ; A.th_accept = SGX_TH_LOW;
+    sim3_fill_common(A, cam, scale_factors, nlevels, log_scale_factor, (float)th);
+    decompose_scw(Scw, A.R1, A.t1, A.Ow);
+    SgxStaged b[17]; int rc;
+#define PUT(k, src, bytes) if ((rc = b[k].put(k, src, bytes)) != SGX_OK) return rc
+    PUT(0, keys_un, (size_t)nk * 28); PUT(1, desc, (size_t)nk * 32); PUT(2, start.data(), start.size() * 4); PUT(3, items.data(), items.size() * 4);
+    PUT(4, m_xw, (size_t)nm * 12); PUT(5, m_normal, (size_t)nm * 12); PUT(6, m_min_dist, (size_t)nm * 4); PUT(7, m_max_dist, (size_t)nm * 4); PUT(8, m_desc, (size_t)nm * 32); PUT(9, m_skip, (size_t)nm);
+    PUT(10, nullptr, (size_t)nm * 4); PUT(11, nullptr, (size_t)nm * 4);
+    PUT(12, matched_in, (size_t)nk); PUT(13, nullptr, (size_t)nk * 4); PUT(14, nullptr, (size_t)nk * 4); PUT(15, nullptr, (size_t)nk * 4); PUT(16, nullptr, 4);
+#undef PUT
+    A.keys = (const uint8_t *)b[0].p; A.desc = (const uint32_t *)b[1].p; A.cell_start = (const int *)b[2].p; A.cell_items = (const int *)b[3].p;
+    A.m_xw = (const float *)b[4].p; A.m_normal = (const float *)b[5].p; A.m_min_dist = (const float *)b[6].p; A.m_max_dist = (const float *)b[7].p;
+    A.m_desc = (const uint32_t *)b[8].p; A.m_skip = (const uint8_t *)b[9].p; A.best_idx = (int *)b[10].p; A.best_dist = (int *)b[11].p;
+    A.taken_in = (const uint8_t *)b[12].p; A.lock_a = (int *)b[13].p; A.lock_b = (int *)b[14].p; A.matched_out = (int *)b[15].p; A.nmatches = (int *)b[16].p;
+    SGX_LAUNCH(k_sim3_search_locked, dim3(1), dim3(1024), (sgx_stream_t)0, A);
+    SGX_CHECK_HIP(hipGetLastError());
+    SGX_CHECK_HIP(hipMemcpy(matched_out, A.matched_out, (size_t)nk * 4, hipMemcpyDeviceToHost));
+    SGX_CHECK_HIP(hipMemcpy(nmatches, A.nmatches, 4, hipMemcpyDeviceToHost));
+    return SGX_OK;
+}
+
+extern "C" int sgx_match_search_by_sim3(
+    int n1, const sgx_keypoint *keys1_un, const uint8_t *desc1, const float *Tcw1, const uint8_t *mp_ok1, const float *m_xw1, const float *m_min_dist1, const float *m_max_dist1, const uint8_t *m_desc1,
+    int n2, const sgx_keypoint *keys2_un, const uint8_t *desc2, const float *Tcw2, const uint8_t *mp_ok2, const float *m_xw2, const float *m_min_dist2, const float *m_max_dist2, const uint8_t *m_desc2,
+    const sgx_camera *cam, const float *scale_factors, int nlevels, float log_scale_factor, float s12, const float *R12, const float *t12, float th,
+    int32_t *match12, int32_t *nfound)
+{
+    if (n1 < 0 || n2 < 0 || !cam || !scale_factors || nlevels < 1 || nlevels > 12 || !nfound || !R12 || !t12 || !Tcw1 || !Tcw2 || (n1 > 0 && !match12)) return SGX_ERR_INVALID;
+    *nfound = 0;
+    if (n1 == 0 || n2 == 0) return SGX_OK;
+    if (!keys1_un || !desc1 || !mp_ok1 || !m_xw1 || !m_min_dist1 || !m_max_dist1 || !m_desc1 || !keys2_un || !desc2 || !mp_ok2 || !m_xw2 || !m_min_dist2 || !m_max_dist2 || !m_desc2) return SGX_ERR_INVALID;
+    // vbAlreadyMatched1 / vbAlreadyMatched2 (:1136-1147) folded into the per-point skip flags
+    std::vector<uint8_t> skip1((size_t)n1), skip2((size_t)n2);
+    for (int i = 0; i < n2; i++) skip2[(size_t)i] = !mp_ok2[i];
+    for (int i = 0; i < n1; i++) {
+        skip1[(size_t)i] = !mp_ok1[i] || match12[i] != -1;
+        if (match12[i] >= 0 && match12[i] < n2) skip2[(size_t)match12[i]] = 1;
+    }
+    // s12*R12, (1.0/s12)*R12.t(), -sR21*t12 (:1124-1126): float scaling by the float of the factor; the 3x3 * 3x1 product goes through cv::gemm's small path
+    float sR12[3][3], sR21[3][3], t21[3];
+    const float inv_s = (float)(1.0 / (double)s12);
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { sR12[r][c] = R12[3 * r + c] * s12; sR21[r][c] = R12[3 * c + r] * inv_s; }
+    for (int r = 0; r < 3; r++) { const float t = sR21[r][0] * t12[0] + sR21[r][1] * t12[1] + sR21[r][2] * t12[2]; t21[r] = (float)((double)t * -1.0 + 0.0); }
+    std::vector<int> start1, items1, start2, items2;
+    build_kf_grid(n1, keys1_un, cam, start1, items1); build_kf_grid(n2, keys2_un, cam, start2, items2);
+    SgxStaged b[24]; int rc;
+#define PUT(k, src, bytes) if ((rc = b[k].put(k, src, bytes)) != SGX_OK) return rc
+    PUT(0, keys1_un, (size_t)n1 * 28); PUT(1, desc1, (size_t)n1 * 32); PUT(2, start1.data(), start1.size() * 4); PUT(3, items1.data(), items1.size() * 4);
+    PUT(4, m_xw1, (size_t)n1 * 12); PUT(5, m_min_dist1, (size_t)n1 * 4); PUT(6, m_max_dist1, (size_t)n1 * 4); PUT(7, m_desc1, (size_t)n1 * 32); PUT(8, skip1.data(), (size_t)n1);
+    PUT(9, nullptr, (size_t)n1 * 4); PUT(10, nullptr, (size_t)n1 * 4);
+    PUT(11, keys2_un, (size_t)n2 * 28); PUT(12, desc2, (size_t)n2 * 32); PUT(13, start2.data(), start2.size() * 4); PUT(14, items2.data(), items2.size() * 4);
+    PUT(15, m_xw2, (size_t)n2 * 12); PUT(16, m_min_dist2, (size_t)n2 * 4); PUT(17, m_max_dist2, (size_t)n2 * 4); PUT(18, m_desc2, (size_t)n2 * 32); PUT(19, skip2.data(), (size_t)n2);
+    PUT(20, nullptr, (size_t)n2 * 4); PUT(21, nullptr, (size_t)n2 * 4);
+#undef PUT
+    SgxSim3ProjArgs A; memset(&A, 0, sizeof A);
+    A.flags = SGX_S3_TWO_STEP | SGX_S3_CAM_DIST; A.th_accept = SGX_TH_HIGH;
+    sim3_fill_common(A, cam, scale_factors, nlevels, log_scale_factor, th);
+    SgxSim3ProjArgs B = A;
+    // KF1's points into KF2 (:1150-1224)
+    A.nk = n2; A.nm = n1;
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) { A.R1[r][c] = Tcw1[4 * r + c]; A.R2[r][c] = sR21[r][c]; } A.t1[r] = Tcw1[4 * r + 3]; A.t2[r] = t21[r]; }
+    A.keys = (const uint8_t *)b[11].p; A.desc = (const uint32_t *)b[12].p; A.cell_start = (const int *)b[13].p; A.cell_items = (const int *)b[14].p;
+    A.m_xw = (const float *)b[4].p; A.m_min_dist = (const float *)b[5].p; A.m_max_dist = (const float *)b[6].p; A.m_desc = (const uint32_t *)b[7].p; A.m_skip = (const uint8_t *)b[8].p;
+    A.best_idx = (int *)b[9].p; A.best_dist = (int *)b[10].p;
+    SGX_LAUNCH(k_sim3_search, dim3((n1 + 255) / 256), dim3(256), (sgx_stream_t)0, A);
+    // KF2's points into KF1 (:1227-1301)
+    B.nk = n1; B.nm = n2;
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) { B.R1[r][c] = Tcw2[4 * r + c]; B.R2[r][c] = sR12[r][c]; } B.t1[r] = Tcw2[4 * r + 3]; B.t2[r] = t12[r]; }
+    B.keys = (const uint8_t *)b[0].p; B.desc = (const uint32_t *)b[1].p; B.cell_start = (const int *)b[2].p; B.cell_items = (const int *)b[3].p;
+    B.m_xw = (const float *)b[15].p; B.m_min_dist = (const float *)b[16].p; B.m_max_dist = (const float *)b[17].p; B.m_desc = (const uint32_t *)b[18].p; B.m_skip = (const uint8_t *)b[19].p;
+    B.best_idx = (int *)b[20].p; B.best_dist = (int *)b[21].p;
+    SGX_LAUNCH(k_sim3_search, dim3((n2 + 255) / 256), dim3(256), (sgx_stream_t)0, B);
+    SGX_CHECK_HIP(hipGetLastError());
+    std::vector<int> m1((size_t)n1), m2((size_t)n2);
+    SGX_CHECK_HIP(hipMemcpy(m1.data(), A.best_idx, (size_t)n1 * 4, hipMemcpyDeviceToHost));
+    SGX_CHECK_HIP(hipMemcpy(m2.data(), B.best_idx, (size_t)n2 * 4, hipMemcpyDeviceToHost));
+    int n = 0;
+    for (int i1 = 0; i1 < n1; i1++) {                                   // check agreement (:1305-1320)
+        const int idx2 = m1[(size_t)i1];
+        if (idx2 >= 0 && m2[(size_t)idx2] == i1) { match12[i1] = idx2; n++; }
+    }
+    *nfound = n;
+    return SGX_OK;
+}

@@ -445,3 +445,142 @@ SGX_KERNEL(1024) k_match_project_kf(SgxKfProjArgs A)
     if (tid == 0) *A.nmatches = s_total - s_rejected;
     SGX_THREADS_END
 }
+
+// ---------------------------------------------------------------------------------------------
+// Loop-closing matchers that project map points through a similarity into a keyframe (LoopClosing::ComputeSim3 / SearchAndFuse):
+//   ORBmatcher::Fuse(pKF, Scw, vpPoints, th, vpReplacePoint)            ORBmatcher.cc:981-1101   k_sim3_search, SGX_S3_NORMAL
+//   ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) ORBmatcher.cc:1106-1330  k_sim3_search twice (SGX_S3_TWO_STEP | SGX_S3_CAM_DIST), then the agreement check
+//   ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th)    ORBmatcher.cc:292-407    k_sim3_search_locked, SGX_S3_NORMAL | SGX_S3_FLOAT_INVZ
+// All three share one body: transform, depth / image / distance (/ viewing-angle) gates, MapPoint::PredictScale, KeyFrame::GetFeaturesInArea in the reference's scan order
+// (KeyFrame.cc:570-609) with the octave gate [level - 1, level], best Hamming distance with first-wins ties.
+// ---------------------------------------------------------------------------------------------
+#define SGX_S3_TWO_STEP   1     // p = R2 * (R1 * xw + t1) + t2   (SearchBySim3: world -> source camera -> target camera)
+#define SGX_S3_CAM_DIST   2     // dist3D = |p|  (SearchBySim3) instead of |xw - Ow|
+#define SGX_S3_NORMAL     4     // viewing-angle gate PO . Pn >= 0.5 dist
+#define SGX_S3_FLOAT_INVZ 8     // invz = 1 / z in float (:333); otherwise (float)(1.0 / z) (:1022, :1170)
+struct SgxSim3ProjArgs {
+    int nk, nm, nlevels, flags, th_accept;
+    const uint8_t *keys; const uint32_t *desc;          // target keyframe: mvKeysUn, mDescriptors
+    const int *cell_start, *cell_items;                 // CSR of its grid: cell (ix, iy) -> ix * 48 + iy
+    const float *m_xw, *m_normal, *m_min_dist, *m_max_dist; const uint32_t *m_desc; const uint8_t *m_skip;
+    float R1[3][3], t1[3], R2[3][3], t2[3], Ow[3];
+    SgxCam cam; SgxScales scale; float log_scale_factor, th;
+    const uint8_t *taken_in;                            // locked variant: vpMatched[k] != NULL on entry
+    int *lock_a, *lock_b;
+    int *best_idx, *best_dist;                          // per candidate
+    int *matched_out, *nmatches;                        // locked variant: per keypoint, total
+};
+
+// best keypoint for candidate i (-1: none); lock (may be NULL): keypoints with lock[k] < i are held by an earlier candidate (or on entry: -1)
+SGX_DEV int sgx_sim3_project_one(const SgxSim3ProjArgs &A, int i, const int *lock, int *dist_out)
+{
+    int bestDist = 0x7FFFFFFF, bestIdx = -1;
+    const float *P = A.m_xw + 3 * (size_t)i;
+    bool ok = !A.m_skip[i];
+    float pc[3] = { sgx_gemm3(A.R1[0], P, A.t1[0]), sgx_gemm3(A.R1[1], P, A.t1[1]), sgx_gemm3(A.R1[2], P, A.t1[2]) };
+    if (A.flags & SGX_S3_TWO_STEP) {
+        const float q[3] = { sgx_gemm3(A.R2[0], pc, A.t2[0]), sgx_gemm3(A.R2[1], pc, A.t2[1]), sgx_gemm3(A.R2[2], pc, A.t2[2]) };
+        pc[0] = q[0]; pc[1] = q[1]; pc[2] = q[2];
+    }
+    ok = ok && !(pc[2] < 0.0f);
+    const float invz = (A.flags & SGX_S3_FLOAT_INVZ) ? 1 / pc[2] : (float)(1.0 / (double)pc[2]);
+    const float x = pc[0] * invz, y = pc[1] * invz;
+    const float u = A.cam.fx * x + A.cam.cx, v = A.cam.fy * y + A.cam.cy;
+    ok = ok && (u >= A.cam.minX && u < A.cam.maxX && v >= A.cam.minY && v < A.cam.maxY);                    // KeyFrame::IsInImage
+    const float maxDistance = 1.2f * A.m_max_dist[i], minDistance = 0.8f * A.m_min_dist[i];
+    float d0, d1, d2;
+    if (A.flags & SGX_S3_CAM_DIST) { d0 = pc[0]; d1 = pc[1]; d2 = pc[2]; } else { d0 = P[0] - A.Ow[0]; d1 = P[1] - A.Ow[1]; d2 = P[2] - A.Ow[2]; }
+    const float dist3D = (float)sqrt((double)d0 * d0 + (double)d1 * d1 + (double)d2 * d2);
+    ok = ok && !(dist3D < minDistance || dist3D > maxDistance);
+    if (A.flags & SGX_S3_NORMAL) {
+        const double dot = (double)d0 * A.m_normal[3 * (size_t)i] + (double)d1 * A.m_normal[3 * (size_t)i + 1] + (double)d2 * A.m_normal[3 * (size_t)i + 2];
+        ok = ok && !(dot < 0.5 * (double)dist3D);
+    }
+    if (ok) {
+        int lvl = (int)ceilf((float)log((double)(A.m_max_dist[i] / dist3D)) / A.log_scale_factor);           // MapPoint::PredictScale(dist, pKF), logf in the reference
+        if (lvl < 0) lvl = 0; else if (lvl >= A.nlevels) lvl = A.nlevels - 1;
+        const float r = A.th * A.scale.s[lvl];
+        const float invW = 64.0f / (A.cam.maxX - A.cam.minX), invH = 48.0f / (A.cam.maxY - A.cam.minY);
+        int x0 = (int)floorf((u - A.cam.minX - r) * invW), x1 = (int)ceilf((u - A.cam.minX + r) * invW);
+        int y0 = (int)floorf((v - A.cam.minY - r) * invH), y1 = (int)ceilf((v - A.cam.minY + r) * invH);
+        x0 = max(x0, 0); y0 = max(y0, 0); x1 = min(x1, 63); y1 = min(y1, 47);
+        const uint32_t *dm = A.m_desc + (size_t)i * 8;
+        if (x0 < 64 && y0 < 48)
+            for (int ix = x0; ix <= x1; ix++) for (int iy = y0; iy <= y1; iy++) {
+                const int c = ix * 48 + iy;
+                for (int q = A.cell_start[c]; q < A.cell_start[c + 1]; q++) {
+                    const int idx = A.cell_items[q];
+                    const float *kp = (const float *)(A.keys + (size_t)idx * 28);
+                    if (!(fabsf(kp[0] - u) < r && fabsf(kp[1] - v) < r)) continue;
+                    if (lock && lock[idx] < i) continue;
+                    const int kpLevel = ((const int *)kp)[5];
+                    if (kpLevel < lvl - 1 || kpLevel > lvl) continue;
+                    const int dist = sgx_hamming256(dm, A.desc + (size_t)idx * 8);
+                    if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+                }
+            }
+    }
+    if (bestDist > A.th_accept) bestIdx = -1;
+    *dist_out = bestIdx >= 0 ? bestDist : 256;
+    return bestIdx;
+}
+
+SGX_KERNEL(256) k_sim3_search(SgxSim3ProjArgs A)
+{
+    SGX_THREADS_BEGIN(tid)
+    const int i = (int)blockIdx.x * 256 + tid;
+    if (i < A.nm) {
+        int d;
+        const int b = sgx_sim3_project_one(A, i, nullptr, &d);
+        A.best_idx[i] = b; A.best_dist[i] = d;
+    }
+    SGX_THREADS_END
+}
+
+// The reference walks vpPoints in order and a point skips keypoints whose vpMatched slot is already filled (:381), by the caller or by an earlier point of the loop.
+// Resolved exactly as in k_match_project_kf: lock[k] = smallest candidate index that took keypoint k (-1: filled on entry); sweeps until no lock changes.
+SGX_KERNEL(1024) k_sim3_search_locked(SgxSim3ProjArgs A)
+{
+    SGX_LDS int s_changed, s_total;
+    const int NT = (int)blockDim.x;
+    SGX_THREADS_BEGIN(tid)
+    for (int k = tid; k < A.nk; k += NT) { A.lock_a[k] = A.taken_in[k] ? -1 : 0x7FFFFFFF; A.matched_out[k] = -1; }
+    if (tid == 0) s_total = 0;
+    SGX_THREADS_END
+    SGX_SYNC();
+    int *lock_cur = A.lock_a, *lock_new = A.lock_b;
+    for (int sweep = 0; sweep < A.nm + 2; sweep++) {
+        SGX_THREADS_BEGIN(tid)
+        if (tid == 0) s_changed = 0;
+        for (int k = tid; k < A.nk; k += NT) lock_new[k] = A.taken_in[k] ? -1 : 0x7FFFFFFF;
+        SGX_THREADS_END
+        SGX_SYNC();
+        SGX_THREADS_BEGIN(tid)
+        for (int i = tid; i < A.nm; i += NT) {
+            int d;
+            const int b = sgx_sim3_project_one(A, i, lock_cur, &d);
+            A.best_idx[i] = b; A.best_dist[i] = d;
+            if (b >= 0) sgx_atomic_min_i32(&lock_new[b], i);
+        }
+        SGX_THREADS_END
+        SGX_SYNC();
+        SGX_THREADS_BEGIN(tid)
+        for (int k = tid; k < A.nk; k += NT) if (lock_new[k] != lock_cur[k]) s_changed = 1;
+        SGX_THREADS_END
+        SGX_SYNC();
+        int *t = lock_cur; lock_cur = lock_new; lock_new = t;
+        if (!s_changed) break;
+    }
+    SGX_THREADS_BEGIN(tid)
+    for (int i = tid; i < A.nm; i += NT) {
+        const int k = A.best_idx[i];
+        if (k < 0) continue;
+        A.matched_out[k] = i;                       // at the fixpoint a keypoint is chosen by exactly one candidate
+        sgx_atomic_add(&s_total, 1);
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    if (tid == 0) *A.nmatches = s_total;
+    SGX_THREADS_END
+}

@@ -189,6 +189,59 @@ public:
         return n;
     }
 
+    // ---- LoopClosing gates (tier N2).  M = candidate map points (M.skip[i] = isBad() / already found / already in pKF); Scw = 4x4 row-major (sRcw | tcw).
+    // int SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12) (ORBmatcher.cc:524-655): hasMapPoint = holds a map point that is not bad;
+    // vpMatches12[i1] = keypoint of pKF2 whose map point keypoint i1 of pKF1 is matched with (-1: NULL)
+    int SearchByBoW(const KeyFrameView &KF1, const KeyFrameView &KF2, std::vector<int32_t> &vpMatches12)
+    {
+        vpMatches12.assign((size_t)(KF1.N > 0 ? KF1.N : 1), -1); int32_t n = 0;
+        check(sgx_match_search_by_bow_kf(KF1.N, KF1.mvKeysUn.data(), KF1.mDescriptors.data(), KF1.hasMapPoint.data(), KF1.featNode.data(),
+                                         KF2.N, KF2.mvKeysUn.data(), KF2.mDescriptors.data(), KF2.hasMapPoint.data(), KF2.featNode.data(), mfNNratio, mbCheckOrientation ? 1 : 0,
+                                         vpMatches12.data(), &n), "sgx_match_search_by_bow_kf");
+        vpMatches12.resize((size_t)KF1.N);
+        return n;
+    }
+    // int SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12, const float &s12, const cv::Mat &R12, const cv::Mat &t12, const float th)
+    // (ORBmatcher.cc:1106-1330).  M1 / M2 = the keyframes' own map points, indexed by keypoint (skip = NULL or bad); vpMatches12 as in include/sgx.h (-1 / >= 0 / -2)
+    int SearchBySim3(const KeyFrameView &KF1, LocalMapView &M1, const KeyFrameView &KF2, LocalMapView &M2, std::vector<int32_t> &vpMatches12, float s12, const float R12[9],
+                     const float t12[3], float th, const sgx_camera &cam, const std::vector<float> &scaleFactors)
+    {
+        std::vector<uint8_t> ok1((size_t)(KF1.N > 0 ? KF1.N : 1), 0), ok2((size_t)(KF2.N > 0 ? KF2.N : 1), 0);
+        for (int i = 0; i < KF1.N; i++) ok1[(size_t)i] = !M1.skip[(size_t)i];
+        for (int i = 0; i < KF2.N; i++) ok2[(size_t)i] = !M2.skip[(size_t)i];
+        vpMatches12.resize((size_t)(KF1.N > 0 ? KF1.N : 1), -1); int32_t n = 0;
+        check(sgx_match_search_by_sim3(KF1.N, KF1.mvKeysUn.data(), KF1.mDescriptors.data(), KF1.Tcw, ok1.data(), M1.mWorldPos.data(), M1.mfMinDistance.data(), M1.mfMaxDistance.data(), M1.mDescriptor.data(),
+                                       KF2.N, KF2.mvKeysUn.data(), KF2.mDescriptors.data(), KF2.Tcw, ok2.data(), M2.mWorldPos.data(), M2.mfMinDistance.data(), M2.mfMaxDistance.data(), M2.mDescriptor.data(),
+                                       &cam, scaleFactors.data(), (int)scaleFactors.size(), std::log(scaleFactors[1]), s12, R12, t12, th, vpMatches12.data(), &n), "sgx_match_search_by_sim3");
+        vpMatches12.resize((size_t)KF1.N);
+        return n;
+    }
+    // int SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, vector<MapPoint*> &vpMatched, int th) (ORBmatcher.cc:292-407):
+    // vpMatched[k] >= 0 on entry = slot filled; newly filled slots receive the index into M
+    int SearchByProjection(const KeyFrameView &KF, const float Scw[16], LocalMapView &M, std::vector<int32_t> &vpMatched, int th, const sgx_camera &cam, const std::vector<float> &scaleFactors)
+    {
+        std::vector<uint8_t> held((size_t)(KF.N > 0 ? KF.N : 1), 0);
+        for (int k = 0; k < KF.N; k++) held[(size_t)k] = vpMatched.size() == (size_t)KF.N && vpMatched[(size_t)k] >= 0;
+        std::vector<int32_t> out((size_t)(KF.N > 0 ? KF.N : 1), -1); int32_t n = 0;
+        check(sgx_match_project_sim3(KF.N, KF.mvKeysUn.data(), KF.mDescriptors.data(), held.data(), Scw, M.N, M.mWorldPos.data(), M.mNormalVector.data(), M.mfMinDistance.data(),
+                                     M.mfMaxDistance.data(), M.mDescriptor.data(), M.skip.data(), &cam, scaleFactors.data(), (int)scaleFactors.size(), std::log(scaleFactors[1]), th,
+                                     out.data(), &n), "sgx_match_project_sim3");
+        vpMatched.resize((size_t)KF.N, -1);
+        for (int k = 0; k < KF.N; k++) if (out[(size_t)k] >= 0) vpMatched[(size_t)k] = out[(size_t)k];
+        return n;
+    }
+    // the search of int Fuse(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, float th, vector<MapPoint*> &vpReplacePoint) (ORBmatcher.cc:981-1101)
+    int Fuse(const KeyFrameView &KF, const float Scw[16], LocalMapView &M, float th, const sgx_camera &cam, const std::vector<float> &scaleFactors,
+             std::vector<int32_t> &bestIdx, std::vector<int32_t> &bestDist)
+    {
+        bestIdx.assign((size_t)(M.N > 0 ? M.N : 1), -1); bestDist.assign((size_t)(M.N > 0 ? M.N : 1), 256); int32_t n = 0;
+        check(sgx_match_fuse_search_sim3(KF.N, KF.mvKeysUn.data(), KF.mDescriptors.data(), Scw, M.N, M.mWorldPos.data(), M.mNormalVector.data(), M.mfMinDistance.data(),
+                                         M.mfMaxDistance.data(), M.mDescriptor.data(), M.skip.data(), &cam, scaleFactors.data(), (int)scaleFactors.size(), std::log(scaleFactors[1]), th,
+                                         bestIdx.data(), bestDist.data(), &n), "sgx_match_fuse_search_sim3");
+        bestIdx.resize((size_t)M.N); bestDist.resize((size_t)M.N);
+        return n;
+    }
+
 protected:
     float mfNNratio; bool mbCheckOrientation;
 };

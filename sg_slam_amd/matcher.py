@@ -128,6 +128,47 @@ class ORBmatcher:
                                                           len(sf), float(np.log(np.float32(sf[1]))), float(th), _vp(bi), _vp(bd), _vp(n)), 'sgx_match_fuse_search')
         return int(n[0]), bi[:len(xw)].copy(), bd[:len(xw)].copy()
 
+    @staticmethod
+    def _points(m):
+        return [np.ascontiguousarray(m['xw'], 'f4'), np.ascontiguousarray(m['normal'], 'f4'), np.ascontiguousarray(m['min_dist'], 'f4'), np.ascontiguousarray(m['max_dist'], 'f4'),
+                np.ascontiguousarray(m['desc'], np.uint8), np.ascontiguousarray(m['skip'], np.uint8)]
+
+    def FuseSearchSim3(self, kf, Scw, map_points, th, cam, scale_factors):
+        """the search of ORBmatcher::Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (ORBmatcher.cc:981-1101): (nFused, best_idx[nm], best_dist[nm]).  kf: keys, desc;
+        map_points: xw, normal, min_dist, max_dist, desc, skip."""
+        k = np.ascontiguousarray(kf['keys']); d = np.ascontiguousarray(kf['desc'], np.uint8); S = np.ascontiguousarray(Scw, 'f4').reshape(16)
+        pts = self._points(map_points); nm = len(pts[0])
+        sf = np.ascontiguousarray(scale_factors, 'f4'); cs = camera_struct(cam)
+        bi = np.full(max(nm, 1), -1, 'i4'); bd = np.full(max(nm, 1), 256, 'i4'); n = np.zeros(1, 'i4')
+        self.lib.check(self.lib.dll.sgx_match_fuse_search_sim3(len(k), _vp(k), _vp(d), _vp(S), nm, *[_vp(x) for x in pts], C.byref(cs), _vp(sf), len(sf),
+                                                               float(np.log(np.float32(sf[1]))), float(th), _vp(bi), _vp(bd), _vp(n)), 'sgx_match_fuse_search_sim3')
+        return int(n[0]), bi[:nm].copy(), bd[:nm].copy()
+
+    def SearchByProjectionSim3(self, kf, Scw, map_points, th, cam, scale_factors):
+        """ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:292-407).  kf: keys, desc, matched (vpMatched[k] != NULL on entry).
+        Returns (nmatches, matched_out[nk]): matched_out[k] = candidate index newly stored in vpMatched[k], or -1."""
+        k = np.ascontiguousarray(kf['keys']); d = np.ascontiguousarray(kf['desc'], np.uint8); mi = np.ascontiguousarray(kf['matched'], np.uint8); S = np.ascontiguousarray(Scw, 'f4').reshape(16)
+        pts = self._points(map_points); nm = len(pts[0])
+        sf = np.ascontiguousarray(scale_factors, 'f4'); cs = camera_struct(cam)
+        mo = np.full(max(len(k), 1), -1, 'i4'); n = np.zeros(1, 'i4')
+        self.lib.check(self.lib.dll.sgx_match_project_sim3(len(k), _vp(k), _vp(d), _vp(mi), _vp(S), nm, *[_vp(x) for x in pts], C.byref(cs), _vp(sf), len(sf),
+                                                           float(np.log(np.float32(sf[1]))), int(th), _vp(mo), _vp(n)), 'sgx_match_project_sim3')
+        return int(n[0]), mo[:len(k)].copy()
+
+    def SearchBySim3(self, kf1, kf2, match12, s12, R12, t12, th, cam, scale_factors):
+        """ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) (ORBmatcher.cc:1106-1330).  kf*: keys, desc, Tcw, mp_ok, xw, min_dist, max_dist, mp_desc
+        (all per keypoint).  match12: -1 NULL, >= 0 keypoint of pKF2, -2 matched to a point pKF2 does not observe.  Returns (nFound, match12 updated)."""
+        def flat(kf):
+            return [np.ascontiguousarray(kf['keys']), np.ascontiguousarray(kf['desc'], np.uint8), np.ascontiguousarray(kf['Tcw'], 'f4').reshape(16), np.ascontiguousarray(kf['mp_ok'], np.uint8),
+                    np.ascontiguousarray(kf['xw'], 'f4'), np.ascontiguousarray(kf['min_dist'], 'f4'), np.ascontiguousarray(kf['max_dist'], 'f4'), np.ascontiguousarray(kf['mp_desc'], np.uint8)]
+        a = flat(kf1); b = flat(kf2)
+        sf = np.ascontiguousarray(scale_factors, 'f4'); cs = camera_struct(cam)
+        R = np.ascontiguousarray(R12, 'f4').reshape(9); t = np.ascontiguousarray(t12, 'f4').reshape(3)
+        m = np.full(max(len(a[0]), 1), -1, 'i4'); m[:len(a[0])] = np.asarray(match12, 'i4'); n = np.zeros(1, 'i4')
+        self.lib.check(self.lib.dll.sgx_match_search_by_sim3(len(a[0]), *[_vp(x) for x in a], len(b[0]), *[_vp(x) for x in b], C.byref(cs), _vp(sf), len(sf),
+                                                             float(np.log(np.float32(sf[1]))), float(s12), _vp(R), _vp(t), float(th), _vp(m), _vp(n)), 'sgx_match_search_by_sim3')
+        return int(n[0]), m[:len(a[0])].copy()
+
     def SearchByProjectionKF(self, F, kf, th, ORBdist, cam, scale_factors):
         """ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1474-1601).  F: keys, desc, has_mp, Tcw; kf: keys, ok (map point present,
         not bad, not already found), xw, min_dist, max_dist, desc.  Returns (nmatches, cur_match[nc]): cur_match[k] = keyframe map point index given to keypoint k, or -1."""

@@ -221,3 +221,133 @@ def check_project_kf(lib, orc, n_cases=5):
     assert ORBmatcher(lib=lib).SearchByProjectionKF(F, ekf, 10.0, 100, CAM, sf)[0] == 0
     allt = dict(F); allt['has_mp'] = np.ones(len(k), np.uint8)
     assert ORBmatcher(lib=lib).SearchByProjectionKF(allt, kf, 10.0, 100, CAM, sf)[0] == 0 == orc.search_by_projection_kf(allt, kf, CAM, sf, 10.0, 100)[0]
+
+
+def _kf_with_points(orc, gen, t, sf, rng, bad_frac=0.15):
+    """a keyframe whose keypoints carry their own RGB-D map points (per-keypoint arrays, as GetMapPointMatches() is indexed)"""
+    from test_tracker_emu import make_map_points
+    g, dep, T = gen.frame(t)
+    k, d = orc.orb_extract(g)
+    ur, z = orc.compute_stereo_from_rgbd(k, dep, CAM['bf'], CAM['depth_factor'])
+    Tf = T.astype('f4')
+    xw, has = orc.unproject_stereo(k, z, Tf, CAM)
+    mp = make_map_points(k, xw, has, d, Tf, np.asarray(sf, 'f4'))
+    mp['skip'] = (mp['skip'] | (rng.rand(len(k)) < bad_frac)).astype(np.uint8)
+    return dict(keys=k, desc=d, Tcw=Tf, mp=mp)
+
+
+def _scaled(T, s, rng, noise=0.0):
+    """Scw = s * [Rcw | tcw] (a similarity that projects like Tcw), with a little pose noise as after the Sim3 optimisation"""
+    S = T.astype('f4').copy()
+    S[:3, 3] += rng.normal(0, noise, 3).astype('f4')
+    S[:3, :] = (S[:3, :] * np.float32(s)).astype('f4')
+    return S
+
+
+def check_fuse_sim3(lib, orc, n_cases=5):
+    """the search of Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (LoopClosing::SearchAndFuse): loop map points into a keyframe of the current covisibility group"""
+    sf = orc.orb_params()['scale']
+    total = 0
+    for c in range(n_cases):
+        gen = synth.LayeredStream(seed=2234 + c); rng = np.random.RandomState(300 + c)
+        a = _kf_with_points(orc, gen, 20 + c, sf, rng); b = _kf_with_points(orc, gen, 23 + c, sf, rng)
+        kf = dict(keys=a['keys'], desc=a['desc'])
+        for s, noise in ((1.0, 0.0), (0.9, 0.004), (1.13, 0.01)):
+            Scw = _scaled(a['Tcw'], s, rng, noise)
+            for th in (4.0, 7.5):
+                en, ei, ed = orc.fuse_search_sim3(kf, Scw, b['mp'], CAM, sf, th)
+                gn, gi, gd = ORBmatcher(lib=lib).FuseSearchSim3(kf, Scw, b['mp'], th, CAM, sf)
+                assert gn == en == (ei >= 0).sum() and (gi == ei).all() and (gd == ed).all(), (c, s, th, gn, en)
+                assert (ed[ei >= 0] <= 50).all() and (ed[ei < 0] == 256).all() and not b['mp']['skip'][ei >= 0].any()
+                total += en
+    assert total > 1500, total
+    none = {k: v[:0] for k, v in b['mp'].items()}
+    assert ORBmatcher(lib=lib).FuseSearchSim3(kf, Scw, none, 4.0, CAM, sf)[0] == 0
+    allskip = dict(b['mp']); allskip['skip'] = np.ones(len(b['mp']['skip']), np.uint8)
+    n, bi, bd = ORBmatcher(lib=lib).FuseSearchSim3(kf, Scw, allskip, 4.0, CAM, sf)
+    assert n == 0 and (bi == -1).all() and (bd == 256).all()
+    ekf = dict(keys=a['keys'][:0], desc=a['desc'][:0])
+    assert ORBmatcher(lib=lib).FuseSearchSim3(ekf, Scw, b['mp'], 4.0, CAM, sf)[0] == 0
+    behind = dict(b['mp']); behind['xw'] = b['mp']['xw'].copy(); behind['xw'][:, 2] -= 1000.0
+    en, ei, ed = orc.fuse_search_sim3(kf, Scw, behind, CAM, sf, 4.0); gn, gi, gd = ORBmatcher(lib=lib).FuseSearchSim3(kf, Scw, behind, 4.0, CAM, sf)
+    assert gn == en == 0 and (gi == ei).all()
+
+
+def check_project_sim3(lib, orc, n_cases=5):
+    """SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (LoopClosing::ComputeSim3): same keypoint <- candidate assignment as the oracle's sequential loop"""
+    sf = orc.orb_params()['scale']
+    total = 0
+    for c in range(n_cases):
+        gen = synth.LayeredStream(seed=3234 + c); rng = np.random.RandomState(400 + c)
+        a = _kf_with_points(orc, gen, 30 + c, sf, rng); b = _kf_with_points(orc, gen, 32 + c, sf, rng); b2 = _kf_with_points(orc, gen, 33 + c, sf, rng)
+        pts = {k: np.concatenate([b['mp'][k], b2['mp'][k]]) for k in b['mp']}                   # mvpLoopMapPoints: the loop keyframe's and its neighbours' points -> competition
+        for s, noise, frac in ((1.0, 0.0, 0.0), (0.95, 0.005, 0.3), (1.2, 0.01, 0.6)):
+            Scw = _scaled(a['Tcw'], s, rng, noise)
+            kf = dict(keys=a['keys'], desc=a['desc'], matched=(rng.rand(len(a['keys'])) < frac).astype(np.uint8))
+            for th in (10, 4):
+                en, em = orc.search_by_projection_sim3(kf, Scw, pts, CAM, sf, th)
+                gn, gm = ORBmatcher(lib=lib).SearchByProjectionSim3(kf, Scw, pts, th, CAM, sf)
+                assert gn == en == (em >= 0).sum() and (gm == em).all(), (c, s, th, gn, en, int((gm != em).sum()))
+                sel = em >= 0
+                assert not kf['matched'][sel].any() and not pts['skip'][em[sel]].any() and len(set(em[sel])) == sel.sum()
+                total += en
+    assert total > 3000, total
+    # an adversarial lock chain: 200 copies of 8 points compete for the keypoints of 8 windows
+    k, dd = orc.orb_extract(synth.LayeredStream(seed=9).frame(5)[0])
+    n = 200; z = 2.0
+    u, v = k['x'][:8].astype('f4'), k['y'][:8].astype('f4')
+    xw = np.stack([(np.tile(u, n // 8) - CAM['cx']) / CAM['fx'] * z, (np.tile(v, n // 8) - CAM['cy']) / CAM['fy'] * z, np.full(n, z)], 1).astype('f4')
+    nrm = (xw / np.linalg.norm(xw, axis=1, keepdims=True)).astype('f4')
+    pts = dict(xw=xw, normal=nrm, min_dist=np.full(n, 0.5, 'f4'), max_dist=np.full(n, 2.2, 'f4'), desc=np.tile(dd[:8], (n // 8, 1)), skip=np.zeros(n, np.uint8))
+    kf = dict(keys=k, desc=dd, matched=np.zeros(len(k), np.uint8))
+    S = np.eye(4, dtype='f4')
+    en, em = orc.search_by_projection_sim3(kf, S, pts, CAM, sf, 10)
+    gn, gm = ORBmatcher(lib=lib).SearchByProjectionSim3(kf, S, pts, 10, CAM, sf)
+    assert gn == en and (gm == em).all() and en >= 8, (gn, en)
+    # TH_LOW bounds the chain above (only close descriptors are accepted); with every pair at distance 0 the assignment is the pure index-order greedy
+    same = dict(kf); same['desc'] = np.tile(dd[:1], (len(k), 1)); pts2 = dict(pts); pts2['desc'] = np.tile(dd[:1], (n, 1))
+    en, em = orc.search_by_projection_sim3(same, S, pts2, CAM, sf, 10)
+    gn, gm = ORBmatcher(lib=lib).SearchByProjectionSim3(same, S, pts2, 10, CAM, sf)
+    assert gn == en and (gm == em).all() and en >= 10, (gn, en)
+    # degenerate inputs
+    assert ORBmatcher(lib=lib).SearchByProjectionSim3(dict(keys=k[:0], desc=dd[:0], matched=np.zeros(0, np.uint8)), S, pts, 10, CAM, sf)[0] == 0
+    assert ORBmatcher(lib=lib).SearchByProjectionSim3(kf, S, {kk: vv[:0] for kk, vv in pts.items()}, 10, CAM, sf)[0] == 0
+    full = dict(kf); full['matched'] = np.ones(len(k), np.uint8)
+    assert ORBmatcher(lib=lib).SearchByProjectionSim3(full, S, pts, 10, CAM, sf)[0] == 0 == orc.search_by_projection_sim3(full, S, pts, CAM, sf, 10)[0]
+
+
+def check_search_by_sim3(lib, orc, n_cases=5):
+    """SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th): two directed searches + agreement, with pre-matched pairs excluded on both sides"""
+    sf = orc.orb_params()['scale']
+    total = 0
+    for c in range(n_cases):
+        gen = synth.LayeredStream(seed=5234 + c); rng = np.random.RandomState(500 + c)
+        a = _kf_with_points(orc, gen, 40 + c, sf, rng); b = _kf_with_points(orc, gen, 42 + c, sf, rng)
+        def flat(x):
+            return dict(keys=x['keys'], desc=x['desc'], Tcw=x['Tcw'], mp_ok=(1 - x['mp']['skip']).astype(np.uint8), xw=x['mp']['xw'], min_dist=x['mp']['min_dist'],
+                        max_dist=x['mp']['max_dist'], mp_desc=x['mp']['desc'])
+        k1, k2 = flat(a), flat(b)
+        T1 = a['Tcw'].astype('f8'); T2 = b['Tcw'].astype('f8')
+        R12 = T1[:3, :3] @ T2[:3, :3].T; t12 = T1[:3, 3] - R12 @ T2[:3, 3]
+        for s12, noise, pre in ((1.0, 0.0, 0.0), (1.02, 0.004, 0.2), (0.97, 0.01, 0.5)):
+            t = (t12 + rng.normal(0, noise, 3)).astype('f4')
+            m0 = np.full(len(k1['keys']), -1, 'i4')
+            pm = np.nonzero((rng.rand(len(m0)) < pre) & (k1['mp_ok'] == 1))[0]
+            m0[pm] = rng.randint(0, len(k2['keys']), len(pm)); m0[pm[::7]] = -2                    # BoW matches found before; a few on points pKF2 does not observe
+            for th in (7.5, 3.0):
+                en, em = orc.search_by_sim3(k1, k2, m0, s12, R12, t, th, CAM, sf)
+                gn, gm = ORBmatcher(lib=lib).SearchBySim3(k1, k2, m0, s12, R12, t, th, CAM, sf)
+                assert gn == en and (gm == em).all(), (c, s12, th, gn, en, int((gm != em).sum()))
+                new = (em != m0)
+                assert new.sum() == en and (m0[new] == -1).all() and k1['mp_ok'][new].all() and k2['mp_ok'][em[new]].all()
+                assert not set(em[new]) & set(m0[m0 >= 0]) and len(set(em[new])) == en               # never a keypoint of pKF2 that a prior match occupies; one-to-one
+                total += en
+    assert total > 1000, total
+    e = {k: (v[:0] if k != 'Tcw' else v) for k, v in k1.items()}
+    assert ORBmatcher(lib=lib).SearchBySim3(e, k2, np.zeros(0, 'i4'), 1.0, R12, t12, 7.5, CAM, sf)[0] == 0
+    e2 = {k: (v[:0] if k != 'Tcw' else v) for k, v in k2.items()}
+    n, m = ORBmatcher(lib=lib).SearchBySim3(k1, e2, m0, 1.0, R12, t12, 7.5, CAM, sf)
+    assert n == 0 and (m == m0).all()
+    allm = np.zeros(len(k1['keys']), 'i4')
+    n, m = ORBmatcher(lib=lib).SearchBySim3(k1, k2, allm, 1.0, R12, t12, 7.5, CAM, sf)
+    assert n == 0 == orc.search_by_sim3(k1, k2, allm, 1.0, R12, t12, 7.5, CAM, sf)[0] and (m == allm).all()

@@ -24,3 +24,15 @@ def test_fuse_search_emu(emu, oracle):
 
 def test_project_keyframe_emu(emu, oracle):
     mc.check_project_kf(emu, oracle, n_cases=2)
+
+
+def test_fuse_search_sim3_emu(emu, oracle):
+    mc.check_fuse_sim3(emu, oracle, n_cases=2)
+
+
+def test_project_sim3_emu(emu, oracle):
+    mc.check_project_sim3(emu, oracle, n_cases=2)
+
+
+def test_search_by_sim3_emu(emu, oracle):
+    mc.check_search_by_sim3(emu, oracle, n_cases=2)

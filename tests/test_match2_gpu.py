@@ -27,3 +27,15 @@ def test_fuse_search_gpu(gpulib, oracle):
 
 def test_project_keyframe_gpu(gpulib, oracle):
     mc.check_project_kf(gpulib, oracle, n_cases=5)
+
+
+def test_fuse_search_sim3_gpu(gpulib, oracle):
+    mc.check_fuse_sim3(gpulib, oracle, n_cases=6)
+
+
+def test_project_sim3_gpu(gpulib, oracle):
+    mc.check_project_sim3(gpulib, oracle, n_cases=6)
+
+
+def test_search_by_sim3_gpu(gpulib, oracle):
+    mc.check_search_by_sim3(gpulib, oracle, n_cases=6)
