@@ -92,6 +92,7 @@ def main():
     ap.add_argument('--tum', default='', help='TUM RGB-D sequence directory (rgb/ depth/ associations.txt [groundtruth.txt]): the streams are consecutive chunks of the sequence')
     ap.add_argument('--save-trajectory', default='', help='write stream 0 of rank 0 as a TUM trajectory file (System::SaveTrajectoryTUM format)')
     ap.add_argument('--cpu-sample', type=int, default=120, help='frames timed on the CPU oracle')
+    ap.add_argument('--det-cus', type=int, default=int(os.environ.get('SGX_BENCH_DET_CUS', '0')), help='give the detector stream this many CUs (mask bits from the top) and the tracking streams the rest; 0 = no CU masks')
     args = ap.parse_args()
 
     import torch
@@ -206,7 +207,13 @@ def main():
         det = Detector2D(0.9, 0.01, param_text=open(args.param).read(), bin_bytes=blob, max_batch=S, lib=lib)
         if d_bgr is None:
             d_bgr = d_frames.unsqueeze(-1).expand(T, S, 480, 640, 3).contiguous()          # gray replicated to 3 channels (SURVEY §8(d) input 2)
-        sD = torch.cuda.Stream(); sD.wait_stream(torch.cuda.current_stream())
+        if args.det_cus > 0:
+            from sg_slam_amd.streams import masked_stream
+            sD = masked_stream(256 - args.det_cus, args.det_cus)
+            if tr.pipelined: tr.sE, tr.sT = masked_stream(0, 256 - args.det_cus), masked_stream(0, 256 - args.det_cus)
+        else:
+            sD = torch.cuda.Stream()
+        sD.wait_stream(torch.cuda.current_stream())
         det_res = [torch.zeros((S, C_.sizeof(DetResult)), dtype=torch.uint8, device='cuda') for _ in range(2)]
         det_boxes = [torch.zeros((S, MB, 4), dtype=torch.float32, device='cuda') for _ in range(2)]
         det_nb = [torch.zeros(S, dtype=torch.int32, device='cuda') for _ in range(2)]
