@@ -310,7 +310,11 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
         // intermediates becomes one OP_FUSED_BLOCK (sgx_det_block.h): the expanded tensor never reaches HBM.  OPT-IN (SGX_DET_BLOCK_FUSION=1 or
         // sgx_det_debug_set_block_fusion): bit-identical, but measured SLOWER than the three tuned kernels on MI355X at batch 256 (13.7 vs 10.9 ms per forward: 30-60 k small
         // workgroups, each re-staging its weights and running five barrier-separated phases at 3 waves per SIMD) — see DESIGN.md §6.
-        if ((g_det_block_fusion || getenv("SGX_DET_BLOCK_FUSION")) && !g_det_legacy) {
+        // k_fused_block2 (VALU-only, thread per pixel) takes the high-resolution few-channel blocks by default (SGX_DET_BLOCK2=0 turns it off); faster than the three kernels there.
+        static const int fb2_env = getenv("SGX_DET_BLOCK2") ? atoi(getenv("SGX_DET_BLOCK2")) : 1;
+        const bool fb2_on = fb2_env != 0 && !g_det_legacy && g_det_fuse;
+        const bool fb1_on = (g_det_block_fusion || getenv("SGX_DET_BLOCK_FUSION")) && !g_det_legacy;
+        if (fb1_on || fb2_on) {
             auto act_only = [&](const Op &o, float *lo, float *hi) -> bool {
                 if (o.epi.size() != 1) return false;
                 const EpiStep &st = o.epi[0];
@@ -332,8 +336,31 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                 int res = -1;
                 if (c.epi.size() == 1 && c.epi[0].op == SGX_EOP_ADD && c.epi[0].src == SGX_ESRC_TENSOR) res = c.epi[0].tensor;
                 else if (!c.epi.empty()) continue;
-                if ((a.inc & 1) || (a.outc & 1) || a.outc != bq.outc || c.inc != bq.outc || a.inc > 64 || c.outc > 64) continue;       // k_fused_block stages <= 2048 weights per array and chunk
+                if (a.outc != bq.outc || c.inc != bq.outc) continue;
                 if (a.out == h->loc_blob || a.out == h->conf_blob || bq.out == h->loc_blob || bq.out == h->conf_blob) continue;
+                const int v2 = sgx_fb2_variant(a.inc, c.outc, bq.k, bq.stride);
+                if (fb2_on && v2 && (a.outc % SGX_FB2_CM) == 0 && c.wtT && bq.pad == bq.k / 2) {
+                    SgxFusedBlk fb; memset(&fb, 0, sizeof fb);
+                    fb.Cin = a.inc; fb.Cmid = a.outc; fb.Cout = c.outc; fb.K = bq.k; fb.stride = bq.stride; fb.pad = bq.pad; fb.H = a.H; fb.W = a.W; fb.Ho = bq.Ho; fb.Wo = bq.Wo;
+                    fb.lo1 = lo1; fb.hi1 = hi1; fb.lo2 = lo2; fb.hi2 = hi2; fb.v2 = v2;
+                    sgx_fb2_tile(v2, &fb.TOH, &fb.TOW);
+                    fb.tiles_x = (fb.Wo + fb.TOW - 1) / fb.TOW; fb.tiles_y = (fb.Ho + fb.TOH - 1) / fb.TOH;
+                    fb.w1 = a.wt; fb.b1 = a.bias; fb.wd = bq.wt; fb.bd = bq.bias; fb.w2 = c.wt; fb.b2 = c.bias; fb.w2t = c.wtT; fb.ldw2 = c.ldw;
+                    {   // depthwise weights with the channels of a pair interleaved
+                        const int kk = bq.k * bq.k; std::vector<float> wh((size_t)fb.Cmid * kk), w2((size_t)fb.Cmid * kk);
+                        if (hipMemcpy(wh.data(), bq.wt, wh.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) FAIL(SGX_ERR_DEVICE);
+                        for (int m = 0; m < fb.Cmid; m++) for (int t = 0; t < kk; t++) w2[((size_t)(m >> 1) * kk + t) * 2 + (m & 1)] = wh[(size_t)m * kk + t];
+                        float *dw2 = nullptr; if (h->alloc(&dw2, w2.size())) FAIL(SGX_ERR_NOMEM);
+                        if (hipMemcpy(dw2, w2.data(), w2.size() * 4, hipMemcpyHostToDevice) != hipSuccess) FAIL(SGX_ERR_DEVICE);
+                        fb.wd2 = dw2;
+                    }
+                    Op f; f.kind = OP_FUSED_BLOCK; f.in0 = a.in0; f.out = c.out; f.name = a.name + "+" + bq.name + "+" + c.name; f.fb = fb; f.fb_res_blob = res;
+                    f.inc = a.inc; f.outc = c.outc; f.H = a.H; f.W = a.W; f.Ho = bq.Ho; f.Wo = bq.Wo; f.k = bq.k; f.stride = bq.stride;
+                    ops[ci] = f; a.dead = true; bq.dead = true;
+                    continue;
+                }
+                if (!fb1_on) continue;
+                if ((a.inc & 1) || (a.outc & 1) || a.inc > 64 || c.outc > 64) continue;       // k_fused_block stages <= 2048 weights per array and chunk
                 // tile choice: least matrix-core work per output pixel among the tiles that fit the LDS budget and the accumulator registers
                 SgxFusedBlk fb; memset(&fb, 0, sizeof fb);
                 fb.Cin = a.inc; fb.Cmid = a.outc; fb.Cout = c.outc; fb.K = bq.k; fb.stride = bq.stride; fb.pad = bq.pad; fb.H = a.H; fb.W = a.W; fb.Ho = bq.Ho; fb.Wo = bq.Wo;
@@ -451,6 +478,7 @@ static void run_op(sgx_det *h, const Op &op, int batch, sgx_stream_t st)
         SgxFusedBlk fb = op.fb;
         fb.in = A.d; fb.in_pitch = A.n; fb.out = O.d; fb.out_pitch = O.n;
         fb.res = op.fb_res_blob >= 0 ? h->blobs[op.fb_res_blob].d : nullptr; fb.res_pitch = op.fb_res_blob >= 0 ? h->blobs[op.fb_res_blob].n : 0;
+        if (fb.v2) { (void)sgx_fb2_launch(fb, batch, st); break; }                      // the variant was validated when the plan was built
         SGX_LAUNCH_DYN(k_fused_block, dim3((unsigned)(fb.tiles_x * fb.tiles_y * batch)), dim3(256), sgx_fb_lds_floats(fb) * 4, st, fb);
         break; }
     case OP_KXK: {

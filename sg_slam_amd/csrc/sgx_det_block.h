@@ -20,6 +20,9 @@ struct SgxFusedBlk {
     const float *w1, *b1, *wd, *bd, *w2, *b2;                 // original ncnn layouts: w1 [Cmid][Cin], wd [Cmid][K*K], w2 [Cout][Cmid]
     float *out; size_t out_pitch;
     const float *res; size_t res_pitch;                        // residual (BinaryOp add behind the project convolution) or NULL
+    int v2;                                                    // != 0: k_fused_block2 instantiation (VALU-only, high-resolution blocks), tile variant in the low bits
+    const float *w2t; int ldw2;                                // project weights transposed [Cmid][ldw2] (the pointwise kernel's copy)
+    const float *wd2;                                          // depthwise weights, channel pairs interleaved [Cmid / 2][K * K][2]
 };
 #define SGX_FB_CM 32                                           /* expanded channels per chunk = one MFMA row block */
 static inline size_t sgx_fb_lds_floats(const SgxFusedBlk &p)
@@ -216,4 +219,220 @@ SGX_KERNEL(256) k_fused_block(SgxFusedBlk p)
     }
     SGX_THREADS_END
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_fused_block2 — the same inverted-residual block for the HIGH-RESOLUTION, FEW-CHANNEL blocks at the head of the backbone (150 x 150 and 75 x 75, Cin / Cout <= 24),
+// where the one-kernel-per-layer plan is pure activation traffic (the expanded tensor of the 16 -> 64 block is 5.8 MB per image, written once and read once)
+// and the matrix cores have nothing to amortise (K = 16).  Everything is VALU fmaf in the unfused kernels' order, so the result is bit-identical to them:
+//   once      x[slot][k]      the thread's input pixels (tile + halo dealt round-robin over 128 threads), all Cin channels, straight from global memory into registers
+//   per chunk of CM expanded channels:
+//     phase A  E[m][pixel] = act1(b1 + sum_k w1[m][k] x[k])   k ascending; zero outside the image (the depthwise convolution pads ITS input)        -> LDS, one chunk only
+//     phase B  d = act2(bd + sum_taps wd[m][t] E[m][tap])      taps (i, j) ascending; one output pixel per thread and slot
+//     phase C  acc[co] = fmaf(w2[co][m], d, acc[co])           accumulators start from b2 and persist over the chunks (m keeps ascending)
+//   store      acc (+ residual tensor)
+// Weights are read with scalar loads (uniform addresses, __restrict__): w1 [Cmid][CIN], wd [Cmid][K*K], w2t [Cmid][ldw2] (the transposed copy the pointwise kernel uses).
+// For stride 2 the E tile is stored with its columns split by parity, so the 16 lanes of an output row read consecutive words for every tap.
+// ---------------------------------------------------------------------------------------------
+#define SGX_FB2_THREADS 128
+// Two fp32 lanes of one v_pk_fma_f32: a wave64 v_fma_f32 occupies the SIMD for 4 cycles, the packed form does two FMAs in the same slot (that is how gfx950 reaches its
+// 157 TFLOP/s fp32 vector peak).  Each half is an ordinary fused multiply-add, so results equal the scalar chain bit for bit.  The weights stay in SCALAR registers:
+// gfx950 reads an SGPR pair as a packed source with full pair and op_sel semantics (checked on hardware, tools/ubench/pk_fma_sgpr.hip); the compiler never emits that form
+// (it copies scalars into VGPRs first, one v_mov per use), hence the inline assembly.
+#ifndef SGX_EMU
+typedef float sgx_f2 __attribute__((ext_vector_type(2)));
+SGX_DEV sgx_f2 sgx_mk2(float a, float b) { sgx_f2 r; r.x = a; r.y = b; return r; }
+// c + (w.x, w.x) * b   and   c + (w.y, w.y) * b, w in scalar registers
+SGX_DEV sgx_f2 sgx_fma2_wlo(sgx_f2 w, sgx_f2 b, sgx_f2 c) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(c) : "s"(w), "v"(b)); return c; }
+SGX_DEV sgx_f2 sgx_fma2_whi(sgx_f2 w, sgx_f2 b, sgx_f2 c) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(c) : "s"(w), "v"(b)); return c; }
+// c + w * b, w a scalar-register pair
+SGX_DEV sgx_f2 sgx_fma2_w(sgx_f2 w, sgx_f2 b, sgx_f2 c) { asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(c) : "s"(w), "v"(b)); return c; }
+// c + w * (d.x, d.x)   and   c + w * (d.y, d.y), w a scalar-register pair
+SGX_DEV sgx_f2 sgx_fma2_w_dlo(sgx_f2 w, sgx_f2 d, sgx_f2 c) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(c) : "s"(w), "v"(d)); return c; }
+SGX_DEV sgx_f2 sgx_fma2_w_dhi(sgx_f2 w, sgx_f2 d, sgx_f2 c) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(c) : "s"(w), "v"(d)); return c; }
+#else
+struct sgx_f2 { float x, y; };
+static inline sgx_f2 sgx_mk2(float a, float b) { sgx_f2 r; r.x = a; r.y = b; return r; }
+static inline sgx_f2 sgx_fma2_w(sgx_f2 a, sgx_f2 b, sgx_f2 c) { sgx_f2 r; r.x = fmaf(a.x, b.x, c.x); r.y = fmaf(a.y, b.y, c.y); return r; }
+static inline sgx_f2 sgx_fma2_wlo(sgx_f2 w, sgx_f2 b, sgx_f2 c) { return sgx_fma2_w(sgx_mk2(w.x, w.x), b, c); }
+static inline sgx_f2 sgx_fma2_whi(sgx_f2 w, sgx_f2 b, sgx_f2 c) { return sgx_fma2_w(sgx_mk2(w.y, w.y), b, c); }
+static inline sgx_f2 sgx_fma2_w_dlo(sgx_f2 w, sgx_f2 d, sgx_f2 c) { return sgx_fma2_w(w, sgx_mk2(d.x, d.x), c); }
+static inline sgx_f2 sgx_fma2_w_dhi(sgx_f2 w, sgx_f2 d, sgx_f2 c) { return sgx_fma2_w(w, sgx_mk2(d.y, d.y), c); }
+#endif
+template <int CIN, int COUT, int K, int S, int TOH, int TOW, int CM> struct SgxFb2Geom {
+    static constexpr int TIH = (TOH - 1) * S + K, TIW = (TOW - 1) * S + K, NPI = TIH * TIW, NPO = TOH * TOW;
+    static constexpr int SLOTS_IN = (NPI + SGX_FB2_THREADS - 1) / SGX_FB2_THREADS, SLOTS_OUT = (NPO + SGX_FB2_THREADS - 1) / SGX_FB2_THREADS;
+    static constexpr int PAIRS_IN = SLOTS_IN / 2, ODD_IN = SLOTS_IN & 1;
+    static constexpr int HALF = (TIW + 1) / 2;
+    static constexpr int TIWP = S == 2 ? 2 * HALF + 1 : TIW + 1;          // row pitch of the E tile in channel-pair words (stride 2: two half rows)
+    static constexpr int ES = TIH * TIWP;                                  // pixels per channel pair
+    static_assert((CM & 1) == 0 && (COUT & 1) == 0 && (CIN & 1) == 0, "channels are processed in pairs");
+};
+
+// wd2: depthwise weights with the two channels of a pair interleaved, [Cmid / 2][K * K][2] (built once per plan, sgx_det.cpp)
+template <int CIN, int COUT, int K, int S, int TOH, int TOW, int CM>
+SGX_KERNEL(SGX_FB2_THREADS) k_fused_block2(int Cmid, int H, int W, int Ho, int Wo, int pad, int tiles_x, int tiles_y, float lo1, float hi1, float lo2, float hi2,
+                                           const float *__restrict__ in, size_t in_pitch, const float *__restrict__ w1, const float *__restrict__ b1,
+                                           const float *__restrict__ wd2, const float *__restrict__ bd, const float *__restrict__ w2t, int ldw2, const float *__restrict__ b2,
+                                           float *__restrict__ out, size_t out_pitch, const float *__restrict__ res, size_t res_pitch)
+{
+    typedef SgxFb2Geom<CIN, COUT, K, S, TOH, TOW, CM> G;
+    SGX_LDS sgx_f2 Es[(CM / 2) * G::ES];                                                       // E tile of the chunk: [channel pair][pixel] -> (E[2p][pixel], E[2p + 1][pixel])
+    SGX_PRIV_DECL(sgx_f2, x2, (G::PAIRS_IN ? G::PAIRS_IN : 1) * CIN, SGX_FB2_THREADS);        // input pixels of slots (2p, 2p + 1), all Cin channels
+    SGX_PRIV_DECL(float, x1, CIN, SGX_FB2_THREADS);                                            // the odd last slot
+    SGX_PRIV_DECL(sgx_f2, acc, G::SLOTS_OUT * (COUT / 2), SGX_FB2_THREADS);                    // output channels (2c, 2c + 1)
+    SGX_PRIV_DECL(int, eidx, G::SLOTS_IN, SGX_FB2_THREADS);                    // pixel index inside the E tile (-1: slot beyond the tile); bit 30 set = pixel outside the image
+    const int tile = (int)blockIdx.x % (tiles_x * tiles_y), b = (int)blockIdx.x / (tiles_x * tiles_y);
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int oy0 = ty * TOH, ox0 = tx * TOW, iy0 = oy0 * S - pad, ix0 = ox0 * S - pad;
+    const float *X = in + (size_t)b * in_pitch;
+    const size_t plane = (size_t)H * W;
+
+    SGX_THREADS_BEGIN(tid)
+    SGX_PRIV_BIND(x2, tid); SGX_PRIV_BIND(x1, tid); SGX_PRIV_BIND(acc, tid); SGX_PRIV_BIND(eidx, tid);
+#pragma unroll
+    for (int j = 0; j < G::SLOTS_IN; j++) {
+        const int q = tid + SGX_FB2_THREADS * j, ry = q / G::TIW, rx = q - ry * G::TIW, iy = iy0 + ry, ix = ix0 + rx;
+        const bool inside = q < G::NPI && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const float *src = X + (size_t)(inside ? iy : 0) * W + (inside ? ix : 0);          // every lane loads (a valid address), the select follows: no divergent branches
+#pragma unroll
+        for (int k = 0; k < CIN; k++) {
+            const float ld = src[(size_t)k * plane];
+            const float v = inside ? ld : 0.f;
+            if (j < 2 * G::PAIRS_IN) { if (j & 1) x2[(j >> 1) * CIN + k].y = v; else x2[(j >> 1) * CIN + k].x = v; }
+            else x1[k] = v;
+        }
+        const int li = S == 2 ? ry * G::TIWP + (rx & 1) * G::HALF + (rx >> 1) : ry * G::TIWP + rx;
+        eidx[j] = q < G::NPI ? (li | (inside ? 0 : (1 << 30))) : -1;
+    }
+#pragma unroll
+    for (int jo = 0; jo < G::SLOTS_OUT; jo++) {
+#pragma unroll
+        for (int cp = 0; cp < COUT / 2; cp++) acc[jo * (COUT / 2) + cp] = sgx_mk2(b2[2 * cp], b2[2 * cp + 1]);
+    }
+    SGX_THREADS_END
+
+    for (int cm0 = 0; cm0 < Cmid; cm0 += CM) {
+        // ---- phase A: expand this chunk for the thread's input pixels (two pixels per packed FMA, the weight broadcast to both halves)
+        SGX_THREADS_BEGIN(tid)
+        SGX_PRIV_BIND(x2, tid); SGX_PRIV_BIND(x1, tid); SGX_PRIV_BIND(eidx, tid);
+        float *Ef = (float *)Es;
+#pragma unroll 1
+        for (int m = 0; m < CM; m++) {
+            const sgx_f2 *wr = (const sgx_f2 *)(w1 + (size_t)(cm0 + m) * CIN);
+            const float bias = b1[cm0 + m];
+            sgx_f2 wk[CIN / 2];
+#pragma unroll
+            for (int k = 0; k < CIN / 2; k++) wk[k] = wr[k];
+            float *Em = Ef + (size_t)(m >> 1) * G::ES * 2 + (m & 1);
+#pragma unroll
+            for (int jp = 0; jp < G::PAIRS_IN; jp++) {
+                sgx_f2 s = sgx_mk2(bias, bias);
+#pragma unroll
+                for (int k = 0; k < CIN / 2; k++) { s = sgx_fma2_wlo(wk[k], x2[jp * CIN + 2 * k], s); s = sgx_fma2_whi(wk[k], x2[jp * CIN + 2 * k + 1], s); }
+                const int e0 = eidx[2 * jp], e1 = eidx[2 * jp + 1];
+                if (e0 >= 0) Em[(e0 & 0xFFFFFF) * 2] = (e0 & (1 << 30)) ? 0.f : fminf(fmaxf(s.x, lo1), hi1);
+                if (e1 >= 0) Em[(e1 & 0xFFFFFF) * 2] = (e1 & (1 << 30)) ? 0.f : fminf(fmaxf(s.y, lo1), hi1);
+            }
+            if (G::ODD_IN) {
+                float s = bias;
+#pragma unroll
+                for (int k = 0; k < CIN / 2; k++) { s = fmaf(wk[k].x, x1[2 * k], s); s = fmaf(wk[k].y, x1[2 * k + 1], s); }
+                const int e = eidx[G::SLOTS_IN - 1];
+                if (e >= 0) Em[(e & 0xFFFFFF) * 2] = (e & (1 << 30)) ? 0.f : fminf(fmaxf(s, lo1), hi1);
+            }
+        }
+        SGX_THREADS_END
+        SGX_SYNC();
+        // ---- phases B + C: depthwise on two channels of the chunk at a time, then the project accumulation; one output pixel per thread and slot
+        SGX_THREADS_BEGIN(tid)
+        SGX_PRIV_BIND(acc, tid);
+#pragma unroll 1
+        for (int m = 0; m < CM; m += 2) {
+            const sgx_f2 *wt = (const sgx_f2 *)(wd2 + (size_t)(cm0 + m) * (K * K));                  // pair (cm0 + m) / 2: K * K interleaved weight pairs
+            const sgx_f2 *wp0 = (const sgx_f2 *)(w2t + (size_t)(cm0 + m) * ldw2), *wp1 = (const sgx_f2 *)(w2t + (size_t)(cm0 + m + 1) * ldw2);
+            const sgx_f2 bias = sgx_mk2(bd[cm0 + m], bd[cm0 + m + 1]);
+            sgx_f2 wk[K * K], wc0[COUT / 2], wc1[COUT / 2];
+#pragma unroll
+            for (int t = 0; t < K * K; t++) wk[t] = wt[t];
+#pragma unroll
+            for (int cp = 0; cp < COUT / 2; cp++) { wc0[cp] = wp0[cp]; wc1[cp] = wp1[cp]; }
+#pragma unroll
+            for (int jo = 0; jo < G::SLOTS_OUT; jo++) {
+                const int o = min(tid + SGX_FB2_THREADS * jo, G::NPO - 1), oy = o / TOW, ox = o - oy * TOW;
+                const sgx_f2 *e = Es + (size_t)(m >> 1) * G::ES + (oy * S) * G::TIWP + (S == 2 ? ox : ox * S);
+                sgx_f2 s = bias;
+#pragma unroll
+                for (int a = 0; a < K; a++) {
+#pragma unroll
+                    for (int c = 0; c < K; c++) s = sgx_fma2_w(wk[a * K + c], e[a * G::TIWP + (S == 2 ? (c & 1) * G::HALF + (c >> 1) : c)], s);
+                }
+                const sgx_f2 d = sgx_mk2(fminf(fmaxf(s.x, lo2), hi2), fminf(fmaxf(s.y, lo2), hi2));
+#pragma unroll
+                for (int cp = 0; cp < COUT / 2; cp++) acc[jo * (COUT / 2) + cp] = sgx_fma2_w_dlo(wc0[cp], d, acc[jo * (COUT / 2) + cp]);
+#pragma unroll
+                for (int cp = 0; cp < COUT / 2; cp++) acc[jo * (COUT / 2) + cp] = sgx_fma2_w_dhi(wc1[cp], d, acc[jo * (COUT / 2) + cp]);
+            }
+        }
+        SGX_THREADS_END
+        SGX_SYNC();
+    }
+
+    // ---- store (+ residual): all residual loads first, then the adds and the stores
+    SGX_THREADS_BEGIN(tid)
+    SGX_PRIV_BIND(acc, tid);
+    const size_t cs = (size_t)Ho * Wo;
+#pragma unroll
+    for (int jo = 0; jo < G::SLOTS_OUT; jo++) {
+        const int o = tid + SGX_FB2_THREADS * jo, oy = o / TOW, ox = o - oy * TOW, gy = oy0 + oy, gx = ox0 + ox;
+        if (o < G::NPO && gy < Ho && gx < Wo) {
+            const size_t off0 = (size_t)gy * Wo + gx;
+            float v[COUT];
+#pragma unroll
+            for (int co = 0; co < COUT; co++) v[co] = (co & 1) ? acc[jo * (COUT / 2) + (co >> 1)].y : acc[jo * (COUT / 2) + (co >> 1)].x;
+            if (res) {
+                const float *rp = res + (size_t)b * res_pitch + off0;
+                float r[COUT];
+#pragma unroll
+                for (int co = 0; co < COUT; co++) r[co] = rp[(size_t)co * cs];
+#pragma unroll
+                for (int co = 0; co < COUT; co++) v[co] = v[co] + r[co];
+            }
+            float *op = out + (size_t)b * out_pitch + off0;
+#pragma unroll
+            for (int co = 0; co < COUT; co++) op[(size_t)co * cs] = v[co];
+        }
+    }
+    SGX_THREADS_END
+}
+
+// ---- k_fused_block2 dispatch: (Cin, Cout, K, stride) -> instantiation; the tile variant comes from SGX_FB2_TILE (tuning tap) --------------------------------------
+#define SGX_FB2_CM 8
+static inline int sgx_fb2_variant(int cin, int cout, int k, int stride)
+{
+    static const int tile = getenv("SGX_FB2_TILE") ? atoi(getenv("SGX_FB2_TILE")) : 0;
+    int shape = 0;
+    if (cin == 16 && cout == 16 && k == 3 && stride == 1) shape = 1;
+    else if (cin == 16 && cout == 24 && k == 3 && stride == 2) shape = 2;
+    else if (cin == 24 && cout == 24 && k == 3 && stride == 1) shape = 3;
+    if (!shape) return 0;
+    return shape * 16 + ((shape == 2) ? 0 : (tile & 1));                       // stride 1: tile 0 = 8 x 16, tile 1 = 16 x 16; stride 2: 8 x 16 only (input pixels live in registers)
+}
+static inline void sgx_fb2_tile(int v2, int *toh, int *tow) { *toh = (v2 >> 4) == 2 ? 7 : (v2 & 1) ? 16 : 8; *tow = 16; }       // stride 2: 7 x 16 outputs = 15 x 33 inputs = 4 full slots
+static inline int sgx_fb2_launch(const SgxFusedBlk &fb, int batch, sgx_stream_t st)
+{
+    const unsigned grid = (unsigned)(fb.tiles_x * fb.tiles_y * batch);
+#define SGX_FB2(CIN_, COUT_, K_, S_, TOH_, TOW_) do { auto kfn = k_fused_block2<CIN_, COUT_, K_, S_, TOH_, TOW_, SGX_FB2_CM>;                                        \
+        SGX_LAUNCH(kfn, dim3(grid), dim3(SGX_FB2_THREADS), st, fb.Cmid, fb.H, fb.W, fb.Ho, fb.Wo, fb.pad, fb.tiles_x, fb.tiles_y, fb.lo1, fb.hi1, fb.lo2, fb.hi2,     \
+                   fb.in, fb.in_pitch, fb.w1, fb.b1, fb.wd2, fb.bd, fb.w2t, fb.ldw2, fb.b2, fb.out, fb.out_pitch, fb.res, fb.res_pitch); } while (0)
+    switch (fb.v2) {
+    case 16: SGX_FB2(16, 16, 3, 1, 8, 16); break;
+    case 17: SGX_FB2(16, 16, 3, 1, 16, 16); break;
+    case 32: SGX_FB2(16, 24, 3, 2, 7, 16); break;
+    case 48: SGX_FB2(24, 24, 3, 1, 8, 16); break;
+    case 49: SGX_FB2(24, 24, 3, 1, 16, 16); break;
+    default: return SGX_ERR_INVALID;
+    }
+#undef SGX_FB2
+    return SGX_OK;
 }

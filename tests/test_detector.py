@@ -37,7 +37,7 @@ def make_image(seed, person=False):
 def run_compare(lib, model, seeds=(0, 1), fuse=False):
     layers, W, blob = model
     det = Detector2D(0.90, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=2, lib=lib, fuse=fuse)
-    assert det.num_kernels == (282 if not fuse else 103), det.num_kernels
+    assert det.num_kernels == (282 if not fuse else 97), det.num_kernels
     assert det.num_priors == 2268 and det.num_class == 21 and abs(det.gmac - 0.5574) < 1e-3
     imgs = np.stack([make_image(s) for s in seeds])
     res = det.detect_batch(imgs)
@@ -86,7 +86,7 @@ def run_fused_equals_unfused(lib, model):
     for fuse, legacy, blocks in ((False, True, False), (True, True, False), (True, False, False), (False, False, False), (True, False, True)):
         # the last plan additionally runs the six expand -> depthwise -> project triples as one k_fused_block each (opt-in: correct but slower at batch 256)
         det = Detector2D(0.90, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=2, lib=lib, fuse=fuse, legacy_kernels=legacy, block_fusion=blocks)
-        assert det.num_kernels == (91 if blocks else 103 if fuse else 282)
+        assert det.num_kernels == (91 if blocks else 97 if (fuse and not legacy) else 103 if fuse else 282)     # 97: the three high-resolution blocks run as k_fused_block2 by default
         det.detect_batch(imgs)
         outs.append([np.stack([det.debug_blob(nm, b) for b in range(2)]) for nm in ('587', '632', '672', '849', '908', '944', 'mbox_loc', 'mbox_conf_softmax')])
         det.close()
