@@ -339,7 +339,7 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                 if (a.outc != bq.outc || c.inc != bq.outc) continue;
                 if (a.out == h->loc_blob || a.out == h->conf_blob || bq.out == h->loc_blob || bq.out == h->conf_blob) continue;
                 const int v2 = sgx_fb2_variant(a.inc, c.outc, bq.k, bq.stride);
-                if (fb2_on && v2 && (a.outc % SGX_FB2_CM) == 0 && c.wtT && bq.pad == bq.k / 2) {
+                if (fb2_on && v2 && (a.outc % sgx_fb2_cm(v2)) == 0 && c.wtT && bq.pad == bq.k / 2) {
                     SgxFusedBlk fb; memset(&fb, 0, sizeof fb);
                     fb.Cin = a.inc; fb.Cmid = a.outc; fb.Cout = c.outc; fb.K = bq.k; fb.stride = bq.stride; fb.pad = bq.pad; fb.H = a.H; fb.W = a.W; fb.Ho = bq.Ho; fb.Wo = bq.Wo;
                     fb.lo1 = lo1; fb.hi1 = hi1; fb.lo2 = lo2; fb.hi2 = hi2; fb.v2 = v2;

@@ -270,7 +270,8 @@ template <int CIN, int COUT, int K, int S, int TOH, int TOW, int CM> struct SgxF
 };
 
 // wd2: depthwise weights with the two channels of a pair interleaved, [Cmid / 2][K * K][2] (built once per plan, sgx_det.cpp)
-template <int CIN, int COUT, int K, int S, int TOH, int TOW, int CM>
+// RES: 0 = no residual operand, 1 = fetched before the chunk loop (hides its latency, costs COUT registers), 2 = fetched before the store; UA = phase A unroll
+template <int CIN, int COUT, int K, int S, int TOH, int TOW, int CM, int RES, int UA>
 SGX_KERNEL(SGX_FB2_THREADS) k_fused_block2(int Cmid, int H, int W, int Ho, int Wo, int pad, int tiles_x, int tiles_y, float lo1, float hi1, float lo2, float hi2,
                                            const float *__restrict__ in, size_t in_pitch, const float *__restrict__ w1, const float *__restrict__ b1,
                                            const float *__restrict__ wd2, const float *__restrict__ bd, const float *__restrict__ w2t, int ldw2, const float *__restrict__ b2,
@@ -282,6 +283,7 @@ SGX_KERNEL(SGX_FB2_THREADS) k_fused_block2(int Cmid, int H, int W, int Ho, int W
     SGX_PRIV_DECL(float, x1, CIN, SGX_FB2_THREADS);                                            // the odd last slot
     SGX_PRIV_DECL(sgx_f2, acc, G::SLOTS_OUT * (COUT / 2), SGX_FB2_THREADS);                    // output channels (2c, 2c + 1)
     SGX_PRIV_DECL(int, eidx, G::SLOTS_IN, SGX_FB2_THREADS);                    // pixel index inside the E tile (-1: slot beyond the tile); bit 30 set = pixel outside the image
+    SGX_PRIV_DECL(float, rsd, RES == 1 ? G::SLOTS_OUT * COUT : 1, SGX_FB2_THREADS);           // residual operand of the thread's output pixels, fetched up front (its latency hides behind the whole block)
     const int tile = (int)blockIdx.x % (tiles_x * tiles_y), b = (int)blockIdx.x / (tiles_x * tiles_y);
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int oy0 = ty * TOH, ox0 = tx * TOW, iy0 = oy0 * S - pad, ix0 = ox0 * S - pad;
@@ -289,7 +291,17 @@ SGX_KERNEL(SGX_FB2_THREADS) k_fused_block2(int Cmid, int H, int W, int Ho, int W
     const size_t plane = (size_t)H * W;
 
     SGX_THREADS_BEGIN(tid)
-    SGX_PRIV_BIND(x2, tid); SGX_PRIV_BIND(x1, tid); SGX_PRIV_BIND(acc, tid); SGX_PRIV_BIND(eidx, tid);
+    SGX_PRIV_BIND(x2, tid); SGX_PRIV_BIND(x1, tid); SGX_PRIV_BIND(acc, tid); SGX_PRIV_BIND(eidx, tid); SGX_PRIV_BIND(rsd, tid);
+    if (RES == 1) {
+#pragma unroll
+        for (int jo = 0; jo < G::SLOTS_OUT; jo++) {
+            const int o = tid + SGX_FB2_THREADS * jo, oy = o / TOW, ox = o - oy * TOW, gy = oy0 + oy, gx = ox0 + ox;
+            const bool live = o < G::NPO && gy < Ho && gx < Wo;
+            const float *rp = res + (live ? (size_t)b * res_pitch + (size_t)gy * Wo + gx : 0);
+#pragma unroll
+            for (int co = 0; co < COUT; co++) { const float ld = rp[live ? (size_t)co * Ho * Wo : 0]; rsd[jo * COUT + co] = live ? ld : 0.f; }
+        }
+    }
 #pragma unroll
     for (int j = 0; j < G::SLOTS_IN; j++) {
         const int q = tid + SGX_FB2_THREADS * j, ry = q / G::TIW, rx = q - ry * G::TIW, iy = iy0 + ry, ix = ix0 + rx;
@@ -317,7 +329,7 @@ SGX_KERNEL(SGX_FB2_THREADS) k_fused_block2(int Cmid, int H, int W, int Ho, int W
         SGX_THREADS_BEGIN(tid)
         SGX_PRIV_BIND(x2, tid); SGX_PRIV_BIND(x1, tid); SGX_PRIV_BIND(eidx, tid);
         float *Ef = (float *)Es;
-#pragma unroll 1
+#pragma unroll UA
         for (int m = 0; m < CM; m++) {
             const sgx_f2 *wr = (const sgx_f2 *)(w1 + (size_t)(cm0 + m) * CIN);
             const float bias = b1[cm0 + m];
@@ -325,11 +337,19 @@ SGX_KERNEL(SGX_FB2_THREADS) k_fused_block2(int Cmid, int H, int W, int Ho, int W
 #pragma unroll
             for (int k = 0; k < CIN / 2; k++) wk[k] = wr[k];
             float *Em = Ef + (size_t)(m >> 1) * G::ES * 2 + (m & 1);
+            sgx_f2 sp[G::PAIRS_IN ? G::PAIRS_IN : 1];
+#pragma unroll
+            for (int jp = 0; jp < G::PAIRS_IN; jp++) sp[jp] = sgx_mk2(bias, bias);
+#pragma unroll
+            for (int k = 0; k < CIN / 2; k++) {                      // the pixel pairs' chains interleaved: independent packed FMAs back to back
+#pragma unroll
+                for (int jp = 0; jp < G::PAIRS_IN; jp++) sp[jp] = sgx_fma2_wlo(wk[k], x2[jp * CIN + 2 * k], sp[jp]);
+#pragma unroll
+                for (int jp = 0; jp < G::PAIRS_IN; jp++) sp[jp] = sgx_fma2_whi(wk[k], x2[jp * CIN + 2 * k + 1], sp[jp]);
+            }
 #pragma unroll
             for (int jp = 0; jp < G::PAIRS_IN; jp++) {
-                sgx_f2 s = sgx_mk2(bias, bias);
-#pragma unroll
-                for (int k = 0; k < CIN / 2; k++) { s = sgx_fma2_wlo(wk[k], x2[jp * CIN + 2 * k], s); s = sgx_fma2_whi(wk[k], x2[jp * CIN + 2 * k + 1], s); }
+                const sgx_f2 s = sp[jp];
                 const int e0 = eidx[2 * jp], e1 = eidx[2 * jp + 1];
                 if (e0 >= 0) Em[(e0 & 0xFFFFFF) * 2] = (e0 & (1 << 30)) ? 0.f : fminf(fmaxf(s.x, lo1), hi1);
                 if (e1 >= 0) Em[(e1 & 0xFFFFFF) * 2] = (e1 & (1 << 30)) ? 0.f : fminf(fmaxf(s.y, lo1), hi1);
@@ -380,7 +400,7 @@ SGX_KERNEL(SGX_FB2_THREADS) k_fused_block2(int Cmid, int H, int W, int Ho, int W
 
     // ---- store (+ residual): all residual loads first, then the adds and the stores
     SGX_THREADS_BEGIN(tid)
-    SGX_PRIV_BIND(acc, tid);
+    SGX_PRIV_BIND(acc, tid); SGX_PRIV_BIND(rsd, tid);
     const size_t cs = (size_t)Ho * Wo;
 #pragma unroll
     for (int jo = 0; jo < G::SLOTS_OUT; jo++) {
@@ -390,7 +410,10 @@ SGX_KERNEL(SGX_FB2_THREADS) k_fused_block2(int Cmid, int H, int W, int Ho, int W
             float v[COUT];
 #pragma unroll
             for (int co = 0; co < COUT; co++) v[co] = (co & 1) ? acc[jo * (COUT / 2) + (co >> 1)].y : acc[jo * (COUT / 2) + (co >> 1)].x;
-            if (res) {
+            if (RES == 1) {
+#pragma unroll
+                for (int co = 0; co < COUT; co++) v[co] = v[co] + rsd[jo * COUT + co];
+            } else if (RES == 2) {                                   // all loads first, then the adds
                 const float *rp = res + (size_t)b * res_pitch + off0;
                 float r[COUT];
 #pragma unroll
@@ -407,30 +430,31 @@ SGX_KERNEL(SGX_FB2_THREADS) k_fused_block2(int Cmid, int H, int W, int Ho, int W
 }
 
 // ---- k_fused_block2 dispatch: (Cin, Cout, K, stride) -> instantiation; the tile variant comes from SGX_FB2_TILE (tuning tap) --------------------------------------
-#define SGX_FB2_CM 8
+static inline int sgx_fb2_cm(int v2) { return (v2 >> 4) == 1 ? 16 : 8; }       /* expanded channels per chunk of the instantiation (Cmid must be a multiple) */
 static inline int sgx_fb2_variant(int cin, int cout, int k, int stride)
 {
-    static const int tile = getenv("SGX_FB2_TILE") ? atoi(getenv("SGX_FB2_TILE")) : 0;
+    static const int tile_env = getenv("SGX_FB2_TILE") ? atoi(getenv("SGX_FB2_TILE")) : -1;          // tuning tap: force 8 x 16 (0) or 16 x 16 (1) output tiles on the stride-1 blocks
     int shape = 0;
     if (cin == 16 && cout == 16 && k == 3 && stride == 1) shape = 1;
     else if (cin == 16 && cout == 24 && k == 3 && stride == 2) shape = 2;
     else if (cin == 24 && cout == 24 && k == 3 && stride == 1) shape = 3;
     if (!shape) return 0;
+    const int tile = tile_env >= 0 ? tile_env : (shape == 1 ? 1 : 0);           // measured at 512 frames: 16 -> 16 -> 16 at 150 x 150 is best with 16 x 16 tiles (0.76 ms against 0.79), 24 -> 72 -> 24 with 8 x 16 (0.61 against 0.68)
     return shape * 16 + ((shape == 2) ? 0 : (tile & 1));                       // stride 1: tile 0 = 8 x 16, tile 1 = 16 x 16; stride 2: 8 x 16 only (input pixels live in registers)
 }
 static inline void sgx_fb2_tile(int v2, int *toh, int *tow) { *toh = (v2 >> 4) == 2 ? 7 : (v2 & 1) ? 16 : 8; *tow = 16; }       // stride 2: 7 x 16 outputs = 15 x 33 inputs = 4 full slots
 static inline int sgx_fb2_launch(const SgxFusedBlk &fb, int batch, sgx_stream_t st)
 {
     const unsigned grid = (unsigned)(fb.tiles_x * fb.tiles_y * batch);
-#define SGX_FB2(CIN_, COUT_, K_, S_, TOH_, TOW_) do { auto kfn = k_fused_block2<CIN_, COUT_, K_, S_, TOH_, TOW_, SGX_FB2_CM>;                                        \
+#define SGX_FB2(CIN_, COUT_, K_, S_, TOH_, TOW_, CM_, RES_, UA_) do { auto kfn = fb.res ? k_fused_block2<CIN_, COUT_, K_, S_, TOH_, TOW_, CM_, RES_, UA_> : k_fused_block2<CIN_, COUT_, K_, S_, TOH_, TOW_, CM_, 0, UA_>;                                        \
         SGX_LAUNCH(kfn, dim3(grid), dim3(SGX_FB2_THREADS), st, fb.Cmid, fb.H, fb.W, fb.Ho, fb.Wo, fb.pad, fb.tiles_x, fb.tiles_y, fb.lo1, fb.hi1, fb.lo2, fb.hi2,     \
                    fb.in, fb.in_pitch, fb.w1, fb.b1, fb.wd2, fb.bd, fb.w2t, fb.ldw2, fb.b2, fb.out, fb.out_pitch, fb.res, fb.res_pitch); } while (0)
     switch (fb.v2) {
-    case 16: SGX_FB2(16, 16, 3, 1, 8, 16); break;
-    case 17: SGX_FB2(16, 16, 3, 1, 16, 16); break;
-    case 32: SGX_FB2(16, 24, 3, 2, 7, 16); break;
-    case 48: SGX_FB2(24, 24, 3, 1, 8, 16); break;
-    case 49: SGX_FB2(24, 24, 3, 1, 16, 16); break;
+    case 16: SGX_FB2(16, 16, 3, 1, 8, 16, 16, 1, 2); break;           // Cmid = 16: one chunk
+    case 17: SGX_FB2(16, 16, 3, 1, 16, 16, 16, 1, 2); break;
+    case 32: SGX_FB2(16, 24, 3, 2, 7, 16, 8, 2, 1); break;
+    case 48: SGX_FB2(24, 24, 3, 1, 8, 16, 8, 2, 1); break;
+    case 49: SGX_FB2(24, 24, 3, 1, 16, 16, 8, 2, 1); break;
     default: return SGX_ERR_INVALID;
     }
 #undef SGX_FB2
