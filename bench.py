@@ -356,7 +356,7 @@ def main():
     if dk['bound'] == 'mfma':
         roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': dk['achieved_TFLOPs'], 'peak': MFMA_F32_PEAK_TFS, 'unit': 'TFLOP/s', 'frac': dk['achieved_TFLOPs'] / MFMA_F32_PEAK_TFS,
                     'traffic': traffic, 'avg_launch_ms': dk['avg_ms_per_launch'], 'alg_gflop_per_launch': dk['alg_gflop_per_launch'],
-                    'note': 'det_forward = pre-processing + the 103-launch hipGraph of the MobileNetV3-SSDLite plan (69 pointwise convolutions on v_mfma_f32_32x32x2_f32 carry 0.50 of its '
+                    'note': f'det_forward = pre-processing + the {det.num_kernels}-launch hipGraph of the MobileNetV3-SSDLite plan (the pointwise convolutions on v_mfma_f32_32x32x2_f32 carry 0.50 of its '
                             '0.557 GMAC); flops = 2 x MACs of the whole graph, priced against the fp32 matrix peak; per-launch rocprof table in profiles/'}
     else:
         roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': dk['achieved_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': dk['achieved_GBs'] / HBM_PEAK_GBS, 'traffic': traffic,
@@ -366,7 +366,7 @@ def main():
         ach = (dk['alg_gflop_per_launch'] / (sa * 1e-3) / 1e3) if dk['bound'] == 'mfma' else (dk['alg_bytes_per_launch'] / (sa * 1e-3) / 1e9)
         roofline['standalone'] = {'avg_launch_ms': sa, 'achieved': round(ach, 3), 'frac': ach / roofline['peak'], 'source': 'profiles/r2_standalone.json'}
     if dom == 'det_forward':
-        # det_forward is a 103-node hipGraph, timed as one HIP-event span; the sum of its node kernels' own durations from the committed rocprofv3 kernel statistics of this same
+        # det_forward is a ~100-node hipGraph, timed as one HIP-event span; the sum of its node kernels' own durations from the committed rocprofv3 kernel statistics of this same
         # command (profiles/r2_bench_kernel_stats.csv) is reported next to it (the two agree when the graph's nodes run back to back).
         try:
             import csv

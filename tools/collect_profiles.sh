@@ -3,7 +3,7 @@
 #   tools/collect_profiles.sh <tag>        e.g.  /usr/local/graft/bin/gpurun --timeout 1500 -- 'tools/collect_profiles.sh r2_a'
 # Writes into gpurun_out/<tag>/; copy what should be judged into profiles/ afterwards.  Counter passes follow MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE in
 # separate passes, --kernel-trace only (no sys / runtime trace domains), each under a hard timeout.  The SQ / TCC passes run the chain without the detector
-# (its 103-launch graph is profiled per step by tools/prof_det_ops.py instead) on 4 steps (1 warm-up + 3 timed).
+# (its ~100-launch graph is profiled per step by tools/prof_det_ops.py instead) on 4 steps (1 warm-up + 3 timed).
 set -u
 TAG=${1:-run}
 S=${STREAMS:-512}          # frames per launch = bench.py's default --streams

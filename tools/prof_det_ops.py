@@ -4,6 +4,43 @@ import os, re, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+def step_roof_ms(desc, B):
+    """max(bytes / HBM peak, flops / fp32 peak) of one plan step; fused blocks: the block's input (+ residual) and output tensors, the MACs of its three convolutions"""
+    m = re.match(r'(pw|kxk) \S+ c(\d+)->(\d+) k(\d+) s(\d+) (dw )?(\d+)x(\d+)->(\d+)x(\d+)', desc)
+    if m:
+        c, oc, k, s = int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5)); dw = m.group(6) is not None
+        h, w, ho, wo = (int(m.group(i)) for i in (7, 8, 9, 10))
+        by = 4.0 * (c * h * w + oc * ho * wo) * B; fl = 2.0 * ho * wo * oc * (1 if dw else c) * k * k * B
+        return max(by / 8e12, fl / 157.3e12) * 1e3
+    m = re.match(r'block \S+ c(\d+)->(\d+)->(\d+) k(\d+) s(\d+) (\d+)x(\d+)->(\d+)x(\d+)', desc)
+    if m:
+        c, cm, oc, k, s, h, w, ho, wo = (int(m.group(i)) for i in range(1, 10))
+        by = 4.0 * (c * h * w * (2 if '+res' in desc else 1) + oc * ho * wo) * B
+        fl = 2.0 * (h * w * c * cm + ho * wo * cm * k * k + ho * wo * cm * oc) * B
+        return max(by / 8e12, fl / 157.3e12) * 1e3
+    return 0.0
+
+
+def report(B, rows):
+    tot = sum(ms for _, ms in rows); troof = 0.0
+    print(f'detector plan, batch {B}: {len(rows)} launches, sum of per-launch times {tot:.3f} ms  ({B / tot * 1e3:.0f} frames/s)')
+    print(f'{"ms":>8} {"roof_ms":>8} {"frac":>6}  step')
+    for desc, ms in rows:
+        roof = step_roof_ms(desc, B); troof += roof
+        print(f'{ms:8.4f} {roof:8.4f} {roof / ms if ms else 0:6.2f}  {desc}')
+    print(f'sum of step rooflines {troof:.3f} ms -> plan at {troof / tot:.2f} of its roofline')
+
+
+if len(sys.argv) > 2 and sys.argv[1] == '--reprice':          # re-derive the roofline columns of an existing table (no GPU): prof_det_ops.py --reprice table.txt
+    lines = open(sys.argv[2]).read().splitlines()
+    B = int(re.search(r'batch (\d+)', lines[0]).group(1))
+    rows = []
+    for l in lines[2:]:
+        m = re.match(r'\s*([\d.]+)\s+[\d.]+\s+[\d.]+\s+(\S.*)', l)
+        if m: rows.append((m.group(2), float(m.group(1))))
+    report(B, rows)
+    sys.exit(0)
+
 import torch
 import sg_slam_amd
 from sg_slam_amd.detector import Detector2D
@@ -17,18 +54,4 @@ det = Detector2D(0.9, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_b
                  block_fusion=bool(int(os.environ.get('SGX_PROF_BLOCKS', '0'))))
 img = torch.randint(0, 256, (B, 480, 640, 3), dtype=torch.uint8, device='cuda')
 REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-rows = det.time_ops(img, B, reps=REPS)
-tot = sum(ms for _, ms in rows); troof = 0.0
-print(f'detector plan, batch {B}: {len(rows)} launches, sum of per-launch times {tot:.3f} ms  ({B / tot * 1e3:.0f} frames/s)')
-print(f'{"ms":>8} {"roof_ms":>8} {"frac":>6}  step')
-for desc, ms in rows:
-    m = re.match(r'(pw|kxk) \S+ c(\d+)->(\d+) k(\d+) s(\d+) (dw )?(\d+)x(\d+)->(\d+)x(\d+)', desc)
-    roof = 0.0
-    if m:
-        c, oc, k, s = int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5)); dw = m.group(6) is not None
-        h, w, ho, wo = (int(m.group(i)) for i in (7, 8, 9, 10))
-        by = 4.0 * (c * h * w + oc * ho * wo) * B; fl = 2.0 * ho * wo * oc * (1 if dw else c) * k * k * B
-        roof = max(by / 8e12, fl / 157.3e12) * 1e3
-    troof += roof
-    print(f'{ms:8.4f} {roof:8.4f} {roof / ms if ms else 0:6.2f}  {desc}')
-print(f'sum of step rooflines {troof:.3f} ms -> plan at {troof / tot:.2f} of its roofline')
+report(B, det.time_ops(img, B, reps=REPS))
