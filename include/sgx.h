@@ -226,6 +226,31 @@ int sgx_match_search_by_sim3(
     const sgx_camera *cam, const float *scale_factors, int nlevels, float log_scale_factor, float s12, const float *R12, const float *t12, float th,
     int32_t *match12, int32_t *nfound);
 
+/* ---- ORBVocabulary = DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> (src/sg-slam/include/ORBVocabulary.h:31-32) ----------------------------------------------
+ * The bag-of-words transform behind Frame::ComputeBoW (src/sg-slam/src/Frame.cc:422-429) and KeyFrame::ComputeBoW (src/sg-slam/src/KeyFrame.cc:60-69):
+ *     mpORBvocabulary->transform(vCurrentDesc, mBowVec, mFeatVec, 4)          src/sg-slam/Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1139-1206
+ * The per-feature tree descent (:1231-1273, FORB::distance FORB.cpp:81-101) runs on the device; BowVector / FeatureVector assembly and scoring are host work.
+ *
+ * sgx_voc_load: loadFromTextFile (:1351-1438) for a path ending in ".txt", loadFromBinaryFile (:1467-1510) otherwise — System::System's rule (System.cc:69-73).
+ * sgx_voc_create: the same tree from flat arrays: node 0 is the root, parent[i] < i for i >= 1, desc32 = nnodes x 32 bytes, is_leaf[i] gives node i the next word id. */
+typedef struct sgx_voc sgx_voc;
+int sgx_voc_load(const char *path, sgx_voc **out);
+int sgx_voc_create(int k, int L, int scoring, int weighting, int nnodes, const int32_t *parent, const uint8_t *desc32, const double *weight, const uint8_t *is_leaf, sgx_voc **out);
+int sgx_voc_info(const sgx_voc *v, int32_t *k, int32_t *L, int32_t *scoring, int32_t *weighting, int32_t *nnodes, int32_t *nwords);
+void sgx_voc_destroy(sgx_voc *v);
+/* transform(features, v, fv, levelsup) for one frame (host pointers, synchronous): desc = n x 32 bytes (mDescriptors rows).  bow_ids / bow_weights (capacity n) = the
+ * BowVector in std::map order (word ids ascending; weights accumulated in feature order and normalised as the vocabulary's scoring demands), *nbow its size;
+ * feat_node[i] = key of mFeatVec under which feature i sits (the node levelsup levels above its word), -1 when the word is stopped (weight <= 0, :1170) — exactly the
+ * feat_node_* input of the sgx_match_search_by_bow* and sgx_match_search_for_triangulation entries; feat_word (optional) = word id per feature.
+ * Divergence: when a descent reaches a leaf above level L - levelsup the reference leaves the node id unassigned (uninitialised variable); this build reports the leaf. */
+int sgx_voc_transform(sgx_voc *v, int n, const uint8_t *desc, int levelsup, int32_t *bow_ids, double *bow_weights, int32_t *nbow, int32_t *feat_node, int32_t *feat_word);
+/* the per-feature part for B frames resident on the device (frame b: d_n[b] descriptors at d_desc + b * desc_pitch; outputs with row pitch cap); asynchronous on `stream` */
+int sgx_voc_transform_batch_dev(sgx_voc *v, const uint8_t *d_desc, size_t desc_pitch, const int32_t *d_n, int batch, int cap, int levelsup,
+                                int32_t *d_word_id, double *d_weight, int32_t *d_feat_node, void *stream);
+/* double TemplatedVocabulary::score(const BowVector&, const BowVector&) (:1210-1215) for the L1 scoring the ORB vocabulary files select (L1Scoring::score,
+ * src/sg-slam/Thirdparty/DBoW2/DBoW2/ScoringObject.cpp:23-67; callers KeyFrameDatabase.cc:133,249, LoopClosing.cc:134); SGX_ERR_UNSUPPORTED for the other scoring types */
+int sgx_voc_score(const sgx_voc *v, int n1, const int32_t *ids1, const double *w1, int n2, const int32_t *ids2, const double *w2, double *score);
+
 /* Harness helper (bench.py / tests), NOT a reference entry point: the previous-frame position of every keypoint under a per-frame affine flow
  * (prev = A * (x, y, 1), A = 6 floats), optionally displaced by shift[2] inside the frame's first box.  Stands in for cv::calcOpticalFlowPyrLK
  * (Frame.cc:445, tier N1) when the dynamic-feature mask is exercised on synthetic streams whose flow is known exactly. */

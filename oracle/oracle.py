@@ -462,3 +462,37 @@ def correct_map_points(xw, ref, Srw, corrected_Swr):
     out = np.zeros_like(xw)
     lib().orc_correct_map_points(C.c_int(len(xw)), _p(xw), _p(ref), _p(a), _p(c), _p(out))
     return out
+
+
+# ---- DBoW2 vocabulary transform (bow_oracle.c) -------------------------------------------------------------------------------------------------------------------
+class Vocabulary:
+    """oracle-side ORBVocabulary: create from flat arrays or load a text / binary vocabulary file"""
+
+    def __init__(self, k=None, L=None, parent=None, desc=None, weight=None, is_leaf=None, scoring=0, weighting=0, path=None):
+        Lb = lib(); Lb.orc_voc_create.restype = C.c_void_p; Lb.orc_voc_load.restype = C.c_void_p
+        if path is not None:
+            self.h = Lb.orc_voc_load(path.encode())
+            if not self.h: raise IOError(path)
+        else:
+            parent = np.ascontiguousarray(parent, 'i4'); desc = np.ascontiguousarray(desc, np.uint8); weight = np.ascontiguousarray(weight, 'f8'); is_leaf = np.ascontiguousarray(is_leaf, np.uint8)
+            self.h = Lb.orc_voc_create(C.c_int(k), C.c_int(L), C.c_int(scoring), C.c_int(weighting), C.c_int(len(parent)), _p(parent), _p(desc), _p(weight), _p(is_leaf))
+        info = np.zeros(6, 'i4'); Lb.orc_voc_info(C.c_void_p(self.h), _p(info))
+        self.k, self.L, self.scoring, self.weighting, self.nnodes, self.nwords = (int(x) for x in info)
+
+    def transform(self, descriptors, levelsup=4):
+        d = np.ascontiguousarray(descriptors, np.uint8).reshape(-1, 32); n = len(d)
+        word = np.full(max(n, 1), -1, 'i4'); w = np.zeros(max(n, 1), 'f8'); fn = np.full(max(n, 1), -1, 'i4')
+        Lb = lib(); Lb.orc_voc_transform_features(C.c_void_p(self.h), C.c_int(n), _p(d), C.c_int(levelsup), _p(word), _p(w), _p(fn))
+        ids = np.zeros(max(n, 1), 'i4'); bw = np.zeros(max(n, 1), 'f8')
+        Lb.orc_voc_bow_vector.restype = C.c_int
+        m = Lb.orc_voc_bow_vector(C.c_void_p(self.h), C.c_int(n), _p(word), _p(w), _p(ids), _p(bw))
+        return ids[:m].copy(), bw[:m].copy(), fn[:n].copy(), word[:n].copy()
+
+    def close(self):
+        if self.h: lib().orc_voc_destroy(C.c_void_p(self.h)); self.h = None
+
+
+def bow_score_l1(v1, v2):
+    i1 = np.ascontiguousarray(v1[0], 'i4'); w1 = np.ascontiguousarray(v1[1], 'f8'); i2 = np.ascontiguousarray(v2[0], 'i4'); w2 = np.ascontiguousarray(v2[1], 'f8')
+    Lb = lib(); Lb.orc_bow_score_l1.restype = C.c_double
+    return float(Lb.orc_bow_score_l1(C.c_int(len(i1)), _p(i1), _p(w1), C.c_int(len(i2)), _p(i2), _p(w2)))

@@ -77,6 +77,18 @@ int main(int argc, char **argv)
         printf("S12"); for (int i = 0; i < 8; i++) printf(" %.17g", S.v[i]); printf("\n");
         return 0;
     }
-    fprintf(stderr, "usage: %s ba graph.bin | det model.param model.bin frame.raw | flow cur.raw prev.raw pts.bin | sim3 pairs.bin\n", argv[0]);
+    if (argc >= 4 && !strcmp(argv[1], "voc")) {                     // Frame::ComputeBoW: vocabulary file (.txt = text, else binary), descriptors (N x 32 bytes)
+        sgx::ORBVocabulary voc;
+        const std::string vf(argv[2]);
+        const bool okload = vf.size() >= 4 && vf.compare(vf.size() - 4, 4, ".txt") == 0 ? voc.loadFromTextFile(vf) : voc.loadFromBinaryFile(vf);
+        if (!okload) { fprintf(stderr, "Wrong path to vocabulary.\n"); return 1; }        // System.cc:74-79
+        const std::vector<uint8_t> d = slurp(argv[3]);
+        sgx::ORBVocabulary::BowVector v; std::vector<int32_t> fn;
+        voc.transform(d, v, fn, 4);
+        double wsum = 0; long long idsum = 0, nodesum = 0; for (auto &e : v) { wsum += e.second; idsum += e.first; } for (int32_t x : fn) nodesum += x;
+        printf("words %u bow %zu idsum %lld nodesum %lld wsum %.17g self %.17g\n", voc.size(), v.size(), idsum, nodesum, wsum, voc.score(v, v));
+        return 0;
+    }
+    fprintf(stderr, "usage: %s ba graph.bin | det model.param model.bin frame.raw | flow cur.raw prev.raw pts.bin | sim3 pairs.bin | voc voc.txt desc.bin\n", argv[0]);
     return 2;
 }

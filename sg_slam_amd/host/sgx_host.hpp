@@ -246,6 +246,44 @@ protected:
     float mfNNratio; bool mbCheckOrientation;
 };
 
+// ORBVocabulary = DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> (src/sg-slam/include/ORBVocabulary.h:31-32): the members the reference calls
+class ORBVocabulary {
+public:
+    typedef std::vector<std::pair<int32_t, double>> BowVector;       // DBoW2::BowVector (std::map<WordId, WordValue>) in key order
+    ORBVocabulary() {}
+    ~ORBVocabulary() { if (h_) sgx_voc_destroy(h_); }
+    ORBVocabulary(const ORBVocabulary &) = delete; ORBVocabulary &operator=(const ORBVocabulary &) = delete;
+    bool loadFromTextFile(const std::string &filename) { return filename.size() >= 4 && filename.compare(filename.size() - 4, 4, ".txt") == 0 && load(filename); }
+    bool loadFromBinaryFile(const std::string &filename) { return !(filename.size() >= 4 && filename.compare(filename.size() - 4, 4, ".txt") == 0) && load(filename); }
+    bool empty() const { return size() == 0; }
+    unsigned size() const { int32_t nw = 0; if (h_) sgx_voc_info(h_, nullptr, nullptr, nullptr, nullptr, nullptr, &nw); return (unsigned)nw; }
+    // void transform(const vector<TDescriptor>& features, BowVector &v, FeatureVector &fv, int levelsup) (TemplatedVocabulary.h:1139-1206); descriptors = N x 32 bytes;
+    // featNode[i] = the key of fv under which feature i sits (-1: stopped word) — KeyFrameView::featNode / the featNodeF argument of SearchByBoW
+    void transform(const std::vector<uint8_t> &descriptors, BowVector &v, std::vector<int32_t> &featNode, int levelsup) const
+    {
+        const int n = (int)(descriptors.size() / 32);
+        std::vector<int32_t> ids((size_t)(n > 0 ? n : 1)); std::vector<double> w((size_t)(n > 0 ? n : 1)); int32_t nb = 0;
+        featNode.assign((size_t)(n > 0 ? n : 1), -1);
+        check(sgx_voc_transform(h_, n, descriptors.data(), levelsup, ids.data(), w.data(), &nb, featNode.data(), nullptr), "sgx_voc_transform");
+        featNode.resize((size_t)n); v.clear();
+        for (int i = 0; i < nb; i++) v.emplace_back(ids[(size_t)i], w[(size_t)i]);
+    }
+    // double score(const BowVector &a, const BowVector &b) (:1210-1215)
+    double score(const BowVector &a, const BowVector &b) const
+    {
+        std::vector<int32_t> ia, ib; std::vector<double> wa, wb;
+        for (auto &e : a) { ia.push_back(e.first); wa.push_back(e.second); }
+        for (auto &e : b) { ib.push_back(e.first); wb.push_back(e.second); }
+        double s = 0;
+        check(sgx_voc_score(h_, (int)ia.size(), ia.data(), wa.data(), (int)ib.size(), ib.data(), wb.data(), &s), "sgx_voc_score");
+        return s;
+    }
+    sgx_voc *handle() const { return h_; }
+private:
+    bool load(const std::string &f) { sgx_voc *h = nullptr; if (sgx_voc_load(f.c_str(), &h) != SGX_OK) return false; if (h_) sgx_voc_destroy(h_); h_ = h; return true; }
+    sgx_voc *h_ = nullptr;
+};
+
 // the two OpenCV calls of Frame::RmDynamicPointWithSemanticAndGeometry (Frame.cc:445, :469-472)
 class OpticalFlowLK {                                                // cv::calcOpticalFlowPyrLK(cur, prev, pts, nextPts, status, err, Size(21,21), 3, TermCriteria(ITER|EPS, 30, 0.01))
 public:

@@ -135,3 +135,21 @@ def test_cpp_optimize_sim3_matches_oracle(gpulib, oracle, tmp_path):
     v = out[0].split()
     assert int(v[1]) == en and int(v[3]) == int(einl.sum())
     assert sc.sim3_close([float(x) for x in out[1].split()[1:]], eS, 1e-5)
+
+
+def test_cpp_vocabulary_matches_python_mirror(gpulib, oracle, tmp_path):
+    """sgx::ORBVocabulary (C++ mirror): load a text vocabulary, transform(features, BowVector, FeatureVector, 4), score — same numbers as the Python mirror and the oracle."""
+    import voc_cases as vc
+    from sg_slam_amd.vocabulary import ORBVocabulary
+    voc = vc.make_vocabulary(17, k=6, L=5)
+    f = tmp_path / 'voc.txt'; vc.write_text(voc, str(f))
+    d = vc.make_features(voc, 3, 900)
+    fd = tmp_path / 'desc.bin'; d.tofile(fd)
+    out = subprocess.check_output([_exe('example_backend'), 'voc', str(f), str(fd)], text=True).split()
+    V = ORBVocabulary(gpulib); assert V.loadFromTextFile(str(f))
+    ids, w, fn, _ = V.transform(d, 4)
+    O = oracle.Vocabulary(path=str(f)); oi, ow, ofn, _ = O.transform(d, 4)
+    assert (ids == oi).all() and (w == ow).all() and (fn == ofn).all()
+    assert int(out[1]) == V.size() and int(out[3]) == len(ids) and int(out[5]) == int(ids.astype('i8').sum()) and int(out[7]) == int(fn.astype('i8').sum())
+    assert float(out[9]) == float(np.sum(w[np.arange(len(w))].tolist())) or abs(float(out[9]) - 1.0) < 1e-12
+    assert abs(float(out[11]) - 1.0) < 1e-12

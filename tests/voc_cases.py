@@ -1,0 +1,152 @@
+"""Shared cases for the DBoW2 vocabulary transform (Frame::ComputeBoW): device (or emulator) against the oracle on synthetic vocabularies; the vocabulary FILE of the
+reference (ORBvoc) is absent, so the trees are synthesised and also written in the two file formats the loaders read."""
+import os
+import struct
+import numpy as np
+from sg_slam_amd import synth
+from sg_slam_amd.vocabulary import ORBVocabulary
+from sg_slam_amd.matcher import ORBmatcher
+
+
+def make_vocabulary(seed, k=10, L=3, early_leaf=0.03, stop=0.05):
+    """a k-ary tree of depth L over 256-bit descriptors: every child = its parent's descriptor with a level-dependent number of flipped bits (so descents are meaningful);
+    a few nodes above the last level are childless leaves (a k-means tree runs out of points), a few words carry weight 0 (stopped), weights are idf-like positives"""
+    rng = np.random.RandomState(seed)
+    parent = [0]; desc = [np.zeros(32, np.uint8)]; weight = [0.0]; leaf = [0]; level = [0]
+    frontier = [0]
+    for lv in range(1, L + 1):
+        nxt = []
+        for p in frontier:
+            for c in range(k):
+                base = rng.randint(0, 256, 32).astype(np.uint8) if lv == 1 else desc[p].copy()
+                if lv > 1:
+                    flips = rng.choice(256, max(2, 64 >> (lv - 1)), replace=False)
+                    bits = np.unpackbits(base); bits[flips] ^= 1; base = np.packbits(bits)
+                nid = len(parent); parent.append(p); desc.append(base); level.append(lv)
+                is_leaf = lv == L or (lv >= 2 and rng.rand() < early_leaf)
+                leaf.append(1 if is_leaf else 0)
+                weight.append((0.0 if rng.rand() < stop else float(rng.uniform(0.5, 9.0))) if is_leaf else 0.0)
+                if not is_leaf: nxt.append(nid)
+        frontier = nxt
+    return dict(k=k, L=L, parent=np.array(parent, 'i4'), desc=np.stack(desc), weight=np.array(weight, 'f8'), is_leaf=np.array(leaf, np.uint8), level=np.array(level))
+
+
+def make_features(voc, seed, n=1000):
+    """descriptors near words of the vocabulary (a few flipped bits) mixed with unrelated ones; ORB rows of a synthetic frame would do as well"""
+    rng = np.random.RandomState(seed)
+    leaves = np.nonzero(voc['is_leaf'])[0]
+    pick = leaves[rng.randint(0, len(leaves), n)]
+    d = voc['desc'][pick].copy()
+    for i in range(n):
+        if rng.rand() < 0.25: d[i] = rng.randint(0, 256, 32)
+        else:
+            bits = np.unpackbits(d[i]); bits[rng.choice(256, rng.randint(0, 12), replace=False)] ^= 1; d[i] = np.packbits(bits)
+    return d
+
+
+def write_text(voc, path, scoring=0, weighting=0):
+    """saveToTextFile's layout (TemplatedVocabulary.h:1442-1464): header, then per node `parent is_leaf b0 .. b31 weight`"""
+    with open(path, 'w') as f:
+        f.write(f"{voc['k']} {voc['L']}  {scoring} {weighting}\n")
+        for i in range(1, len(voc['parent'])):
+            f.write(f"{voc['parent'][i]} {int(voc['is_leaf'][i])} " + ' '.join(str(int(b)) for b in voc['desc'][i]) + f" {float(voc['weight'][i])!r}\n")
+
+
+def write_binary(voc, path, scoring=0, weighting=0):
+    """saveToBinaryFile's layout (:1514-1540): nb_nodes, size_node, k, L, scoring, weighting, then records of int parent, 32 bytes, float weight, uchar is_leaf"""
+    n = len(voc['parent']) - 1
+    with open(path, 'wb') as f:
+        f.write(struct.pack('<IIiiii', n, 41, voc['k'], voc['L'], scoring, weighting))
+        for i in range(1, n + 1):
+            f.write(struct.pack('<i', int(voc['parent'][i])) + voc['desc'][i].tobytes() + struct.pack('<f', float(voc['weight'][i])) + bytes([int(voc['is_leaf'][i])]))
+
+
+def check_transform(lib, orc, n_cases=4):
+    total_stopped = 0; early = 0
+    for c in range(n_cases):
+        L = 3 + (c % 2)                                                    # depth 3 and 4 (k = 10 -> 1 110 / 11 110 nodes); levelsup 4 then maps to the root / level 0
+        voc = make_vocabulary(100 + c, k=10 if L == 3 else 6, L=L)
+        for scoring, weighting in ((0, 0), (0, 1), (0, 2), (0, 3), (1, 0), (3, 0)):
+            V = ORBVocabulary(lib).create(voc['k'], voc['L'], voc['parent'], voc['desc'], voc['weight'], voc['is_leaf'], scoring, weighting)
+            O = orc.Vocabulary(voc['k'], voc['L'], voc['parent'], voc['desc'], voc['weight'], voc['is_leaf'], scoring, weighting)
+            assert V.nwords == O.nwords == int(voc['is_leaf'].sum()) and V.nnodes == len(voc['parent'])
+            d = make_features(voc, 7 * c + scoring + weighting, 1000)
+            for levelsup in (1, 2, 4):
+                gi, gw, gn, gword = V.transform(d, levelsup)
+                ei, ew, en, eword = O.transform(d, levelsup)
+                assert (gword == eword).all() and (gn == en).all(), (c, scoring, weighting, levelsup)
+                assert (gi == ei).all() and (gw == ew).all(), (c, scoring, weighting, levelsup, np.abs(gw - ew).max() if len(gw) == len(ew) else None)
+                assert (np.diff(ei) > 0).all()                                 # std::map order
+                stopped = voc['weight'][np.nonzero(voc['is_leaf'])[0]][eword] <= 0
+                assert ((en == -1) == stopped).all()
+                total_stopped += int(stopped.sum())
+                if scoring == 0: assert abs(ew.sum() - 1.0) < 1e-12            # L1-normalised
+                if levelsup < L:
+                    # the node levelsup levels above the word, or the word's own node when the leaf sits higher than that (documented divergence from the reference's uninitialised value)
+                    leaf_nodes = np.nonzero(voc['is_leaf'])[0][eword]
+                    want = leaf_nodes.copy()
+                    for i, nd in enumerate(leaf_nodes):
+                        a = nd
+                        while voc['level'][a] > L - levelsup: a = voc['parent'][a]
+                        want[i] = a
+                    early += int((voc['level'][leaf_nodes] < L - levelsup).sum())
+                    assert (en[~stopped] == want[~stopped]).all()
+                else:
+                    assert (en[~stopped] == 0).all()                           # nid_level <= 0: the root
+            V.close(); O.close()
+    assert total_stopped > 50 and early > 0
+    # degenerate inputs: no features; a vocabulary that is only a root
+    V = ORBVocabulary(lib).create(voc['k'], voc['L'], voc['parent'], voc['desc'], voc['weight'], voc['is_leaf'])
+    gi, gw, gn, gword = V.transform(np.zeros((0, 32), np.uint8))
+    assert len(gi) == 0 and len(gn) == 0
+    E = ORBVocabulary(lib).create(10, 3, [0], np.zeros((1, 32), np.uint8), [0.0], [0])
+    gi, gw, gn, gword = E.transform(make_features(voc, 1, 10))
+    assert E.empty() and len(gi) == 0 and (gn == -1).all()
+
+
+def check_files_and_score(lib, orc, tmpdir):
+    voc = make_vocabulary(321, k=8, L=3)
+    txt = os.path.join(tmpdir, 'voc.txt'); binf = os.path.join(tmpdir, 'voc.bin')
+    write_text(voc, txt); write_binary(voc, binf)
+    A = ORBVocabulary(lib).create(voc['k'], voc['L'], voc['parent'], voc['desc'], voc['weight'], voc['is_leaf'])
+    T = ORBVocabulary(lib); assert T.loadFromTextFile(txt)
+    B = ORBVocabulary(lib); assert B.loadFromBinaryFile(binf)
+    OT = orc.Vocabulary(path=txt); OB = orc.Vocabulary(path=binf)
+    assert (T.k, T.L, T.nnodes, T.nwords) == (A.k, A.L, A.nnodes, A.nwords) == (B.k, B.L, B.nnodes, B.nwords) == (OT.k, OT.L, OT.nnodes, OT.nwords)
+    d1 = make_features(voc, 5, 800); d2 = make_features(voc, 6, 900)
+    a1 = A.transform(d1); t1 = T.transform(d1); b1 = B.transform(d1); ot1 = OT.transform(d1); ob1 = OB.transform(d1)
+    assert all((x == y).all() for x, y in zip(a1, t1))                         # the text file keeps the doubles (repr round trip)
+    assert all((x == y).all() for x, y in zip(t1, ot1)) and all((x == y).all() for x, y in zip(b1, ob1))
+    assert (b1[0] == a1[0]).all() and np.abs(b1[1] - a1[1]).max() < 1e-7       # the binary file stores float weights
+    # L1 score: product against oracle, self-score 1, symmetry, disjoint vectors 0
+    a2 = A.transform(d2)
+    s12 = A.score(a1[:2], a2[:2])
+    assert s12 == orc.bow_score_l1(a1[:2], a2[:2]) == A.score(a2[:2], a1[:2]) and 0.0 <= s12 <= 1.0
+    assert abs(A.score(a1[:2], a1[:2]) - 1.0) < 1e-12
+    far = (a1[0] + 10 ** 6, a1[1])
+    assert A.score(a1[:2], far) == 0.0
+    assert not ORBVocabulary(lib).loadFromTextFile(os.path.join(tmpdir, 'missing.txt'))
+    for v in (A, T, B): v.close()
+    for v in (OT, OB): v.close()
+
+
+def check_bow_chain(lib, orc):
+    """ComputeBoW feeding SearchByBoW: node ids from the vocabulary on real ORB descriptors of two frames, product chain against oracle chain"""
+    from scenes import CAM
+    gen = synth.LayeredStream(seed=77)
+    g0, _, _ = gen.frame(10); g1, _, _ = gen.frame(12)
+    k0, d0 = orc.orb_extract(g0); k1, d1 = orc.orb_extract(g1)
+    # a vocabulary whose first level is built from this scene's descriptors, so that matching features meet in the same nodes
+    rng = np.random.RandomState(3)
+    voc = make_vocabulary(55, k=10, L=3, early_leaf=0.0, stop=0.0)
+    seeds = d0[rng.choice(len(d0), 10, replace=False)]
+    for c in range(10): voc['desc'][1 + c] = seeds[c]
+    V = ORBVocabulary(lib).create(voc['k'], voc['L'], voc['parent'], voc['desc'], voc['weight'], voc['is_leaf'])
+    O = orc.Vocabulary(voc['k'], voc['L'], voc['parent'], voc['desc'], voc['weight'], voc['is_leaf'])
+    n0 = V.transform(d0, 2)[2]; n1 = V.transform(d1, 2)[2]
+    assert (n0 == O.transform(d0, 2)[2]).all() and (n1 == O.transform(d1, 2)[2]).all()
+    kf = dict(keys=k0, desc=d0, good_mp=np.ones(len(k0), np.uint8), feat_node=n0); F = dict(keys=k1, desc=d1, feat_node=n1)
+    gn, gm = ORBmatcher(0.7, True, lib=lib).SearchByBoW(kf, F)
+    en, em = orc.search_by_bow(kf, F, 0.7, True)
+    assert gn == en and (gm == em).all() and en > 50, (gn, en)
+    V.close(); O.close()
