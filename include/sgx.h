@@ -457,7 +457,8 @@ int sgx_flow_debug_level_size(const sgx_flow *h, int level, int32_t *w, int32_t 
  * cv::findFundamentalMat(FM_RANSAC, threshold, confidence): cv::RNG(-1) sampling, 7-point solver, symmetric epipolar error, adaptive iteration count,
  * no refit (fundam.cpp, ptsetreg.cpp).  d_F: 9 doubles per frame, row-major, x_prev^T F x_cur = 0 (what sgx_dynamic_mask_batch_dev takes);
  * d_ok[f] = 0 when OpenCV would return an empty Mat (fewer than 7 pairs, or no model) — F is then all zeros and the mask keeps every keypoint of
- * that frame (the reference indexes the empty Mat: undefined behaviour).  8..14 pairs (OpenCV switches to LMedS) also give d_ok = 0.
+ * that frame (the reference indexes the empty Mat: undefined behaviour).  For 8..14 pairs OpenCV switches to LMeDSPointSetRegistrator::run and so does this entry
+ * (same subsets from the same RNG, smallest median error, sigma-based inlier count, success = at least 7 inliers).
  * d_stats (optional): 4 ints per frame — RANSAC iterations run, iteration and root index of the returned model, its inlier count. */
 int sgx_fundamental_ransac_batch_dev(int batch, int cap, const sgx_keypoint *d_keys, const int32_t *d_n, const float *d_prev_xy,
                                      const int32_t *d_pre_have_dynamic, const float *d_pre_boxes, const int32_t *d_pre_nboxes, int max_boxes,

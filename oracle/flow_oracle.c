@@ -461,19 +461,54 @@ int orc_fm_sample_sequence(const float *m1, const float *m2, int n, int iters, i
     for (k = 0; k < iters; k++) { int id[7]; if (!fm_get_subset(m1, m2, n, &rng, a, b, id, g_partial_subsets)) break; for (int j = 0; j < 7; j++) idx_out[7 * k + j] = id[j]; }
     return k;
 }
+/* LMeDSPointSetRegistrator::run (OpenCV ptsetreg.cpp) for the fundamental-matrix callback, modelPoints = 7, maxIters = 1000: niters = max(RANSACUpdateNumIters(confidence,
+ * 0.45, 7, 1000), 3) subsets from cv::RNG(-1); per model the median = element count/2 of the sorted float errors (std::nth_element over their bit patterns, equal to float
+ * order for the non-negative errors); the smallest median wins (strict '<', first wins); sigma = max(2.5 * 1.4826 * (1 + 5 / (count - 7)) * sqrt(minMedian), 0.001),
+ * inliers = err <= (float)(sigma^2); the call succeeds when at least 7 inliers remain.  stats: iterations run, winning iteration, winning root, inliers. */
+static int fm_lmeds(const float *m1, const float *m2, int n, double confidence, double *F, uint8_t *mask, int32_t *stats)
+{
+    orc_rng rng; rng.state = (uint64_t)-1;
+    int niters = orc_ransac_update_num_iters(confidence, 0.45, 7, 1000); if (niters < 3) niters = 3;
+    double minMedian = DBL_MAX, best[9]; memset(best, 0, sizeof best);
+    float ms1[14], ms2[14], err[16]; int iter;
+    for (iter = 0; iter < niters; iter++) {
+        if (!fm_get_subset(m1, m2, n, &rng, ms1, ms2, NULL, g_partial_subsets)) { if (iter == 0) return 0; break; }
+        double model[27];
+        const int nmodels = orc_fm_run7point(ms1, ms2, model);
+        if (nmodels <= 0) continue;
+        for (int i = 0; i < nmodels; i++) {
+            const double *Fi = model + 9 * i;
+            for (int p = 0; p < n; p++) err[p] = fm_error(Fi, m1[2 * p], m1[2 * p + 1], m2[2 * p], m2[2 * p + 1]);
+            for (int a = 1; a < n; a++) { const float v = err[a]; int b = a - 1; while (b >= 0 && err[b] > v) { err[b + 1] = err[b]; b--; } err[b + 1] = v; }     /* nth_element(count/2): the sorted order has the same element there */
+            const double median = (double)err[n / 2];
+            if (median < minMedian) { minMedian = median; memcpy(best, Fi, sizeof best); if (stats) { stats[1] = iter; stats[2] = i; } }
+        }
+    }
+    if (stats) stats[0] = iter;
+    if (!(minMedian < DBL_MAX)) return 0;
+    double sigma = 2.5 * 1.4826 * (1 + 5. / (n - 7)) * sqrt(minMedian);
+    if (sigma < 0.001) sigma = 0.001;
+    const float t = (float)(sigma * sigma);
+    int good = 0;
+    for (int p = 0; p < n; p++) { const int f = fm_error(best, m1[2 * p], m1[2 * p + 1], m2[2 * p], m2[2 * p + 1]) <= t; if (mask) mask[p] = (uint8_t)f; good += f; }
+    if (stats) stats[3] = good;
+    if (good < 7) return 0;
+    memcpy(F, best, sizeof best);
+    return 1;
+}
 /* findFundamentalMat(m1, m2, FM_RANSAC, threshold, confidence): returns 1 and F (3x3 row-major, F[8] = 1 or 0) or 0 (empty Mat).
  * mask (optional, n bytes) = inliers of the returned model.  stats (optional, 4 ints): iterations run, index of the winning iteration,
  * root index of the winning model, inlier count.
- * n < 7 -> empty; n == 7 -> run7Point directly (first solution is what a 3x3 read of the 9x3 result sees); 8..14 points use LMedS in
- * OpenCV (`npoints >= 15` gate in fundam.cpp) — NOT restated: returns -1 (callers treat it as "no F"). */
+ * n < 7 -> empty; n == 7 -> run7Point directly (first solution is what a 3x3 read of the 9x3 result sees); 8..14 points: OpenCV switches to
+ * LMedS (`(method & ~3) == FM_RANSAC && npoints >= 15` gate in fundam.cpp): fm_lmeds above. */
 int orc_find_fundamental_ransac(const float *m1, const float *m2, int n, double threshold, double confidence, double *F, uint8_t *mask, int32_t *stats)
 {
     if (stats) stats[0] = stats[1] = stats[2] = stats[3] = 0;
     if (n < 7) return 0;
     if (n == 7) { double f[27]; const int k = orc_fm_run7point(m1, m2, f); if (k <= 0) return 0; memcpy(F, f, sizeof(double) * 9); return 1; }
-    if (n < 15) return -1;
     if (threshold <= 0) threshold = 3;
     if (confidence < DBL_EPSILON || confidence > 1 - DBL_EPSILON) confidence = 0.99;
+    if (n < 15) return fm_lmeds(m1, m2, n, confidence, F, mask, stats);
     const float thr2 = (float)(threshold * threshold);      /* findInliers: float t = (float)(thresh*thresh) */
     orc_rng rng; rng.state = (uint64_t)-1;
     int niters = 1000, max_good = 0, iter;

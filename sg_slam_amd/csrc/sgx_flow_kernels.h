@@ -16,7 +16,7 @@
 //                   halves through DPP row reductions — and converted to float once: the order-free variant of OpenCV's accumulation
 //                   (`typedef int64 acctype`), bit-identical to oracle acc_mode 1.  The per-iteration float arithmetic follows lkpyramid.cpp operation
 //                   by operation (-ffp-contract=off).
-//   k_fm_ransac     one workgroup per frame: pair selection (block scan), then RANSAC in chunks: thread 0 advances cv::RNG and forms the 7-index
+//   k_fm_ransac     one workgroup per frame: pair selection (block scan), then RANSAC (LMedS for 8 .. 14 pairs, as OpenCV) in chunks: thread 0 advances cv::RNG and forms the 7-index
 //                   groups, a thread per group runs checkSubset + run7Point (Householder null space, cv::solveCubic) in fp64, all threads score the
 //                   models (FMEstimatorCallback::computeError), thread 0 replays the sequential accept / RANSACUpdateNumIters rule in iteration
 //                   order — same samples, same winner as the sequential library loop.
@@ -894,6 +894,8 @@ SGX_KERNEL(256) k_fm_ransac(SgxFmArgs A)
     SGX_LDS int g_good[SGX_FM_CHUNK][3];
     SGX_LDS double g_work[SGX_FM_CHUNK][63];
     SGX_LDS double s_best[9];
+    SGX_LDS float g_med[SGX_FM_CHUNK][3];           /* LMedS: median error of every model of the round */
+    SGX_LDS double s_minmed;
     const int N = min(A.n[f], cap), CH = (N + 255) / 256;
     const bool pre = A.pre_have && A.pre_have[f] && A.pre_boxes && A.pre_nboxes;
 
@@ -936,7 +938,7 @@ SGX_KERNEL(256) k_fm_ransac(SgxFmArgs A)
     const int count = s_count;
     const float t = (float)(A.threshold * A.threshold);
 
-    if (count < 7 || (count > 7 && count < 15)) {                   /* < 7: empty Mat; 8..14: LMedS in OpenCV (not built): no model */
+    if (count < 7) {                                                 /* empty Mat */
         SGX_THREADS_BEGIN(tid)
         if (tid < 9) A.F[9 * (size_t)f + tid] = 0.;
         if (tid == 0) { A.ok[f] = 0; if (A.stats) { A.stats[4 * f] = 0; A.stats[4 * f + 1] = 0; A.stats[4 * f + 2] = 0; A.stats[4 * f + 3] = 0; } }
@@ -955,10 +957,19 @@ SGX_KERNEL(256) k_fm_ransac(SgxFmArgs A)
         return;
     }
 
+    // ---- 8 .. 14 pairs: cv::findFundamentalMat switches to LMeDSPointSetRegistrator::run (`npoints >= 15` gate in fundam.cpp): same subsets from the same RNG, a model is
+    //      ranked by the median of its errors (element count / 2 of the sorted errors), niters = max(RANSACUpdateNumIters(confidence, 0.45, 7, 1000), 3), no early exit
+    const bool lmeds = count < 15;
+    if (lmeds) {
+        SGX_THREADS_BEGIN(tid)
+        if (tid == 0) { const int ni = sgx_ransac_update_num_iters(A.confidence, 0.45, 7, 1000); s_niters = ni > 3 ? ni : 3; s_minmed = DBL_MAX; }
+        SGX_THREADS_END
+        SGX_SYNC();
+    }
     // ---- RANSACPointSetRegistrator::run, up to SGX_FM_CHUNK candidate groups per round (the first round draws only 8: on mostly static scenes the adaptive
     //      iteration count ends the loop after ~5-15 iterations, so scoring 32 x 3 models up front is wasted work)
     for (int round = 0;; round++) {
-        const int G = round == 0 ? 8 : SGX_FM_CHUNK;
+        const int G = round == 0 && !lmeds ? 8 : SGX_FM_CHUNK;
         SGX_THREADS_BEGIN(tid)
         if (tid == 0) {
             // cv::RNG::uniform(0, count) draws: seven distinct indices per group (getSubset's inner loops; the group is checked below)
@@ -989,6 +1000,46 @@ SGX_KERNEL(256) k_fm_ransac(SgxFmArgs A)
         }
         SGX_THREADS_END
         SGX_SYNC();
+        if (lmeds) {
+            // ---- the median error of every model of the round (one thread per model; at most 14 pairs)
+            SGX_THREADS_BEGIN(tid)
+            if (tid < 3 * G) {
+                const int gI = tid / 3, k = tid - 3 * gI;
+                if (k < g_nmodels[gI]) {
+                    double Fm[9]; float err[16];
+                    for (int i = 0; i < 9; i++) Fm[i] = g_model[gI][9 * k + i];
+                    for (int p = 0; p < count; p++) {
+                        const float v = sgx_fm_error(Fm, m1[2 * p], m1[2 * p + 1], m2[2 * p], m2[2 * p + 1]);
+                        int b = p - 1; while (b >= 0 && err[b] > v) { err[b + 1] = err[b]; b--; }          /* insertion sort: nth_element(count / 2) leaves the same element there */
+                        err[b + 1] = v;
+                    }
+                    g_med[gI][k] = err[count / 2];
+                }
+            }
+            SGX_THREADS_END
+            SGX_SYNC();
+            SGX_THREADS_BEGIN(tid)
+            if (tid == 0) {
+                int iter = s_iter, attempts = s_attempts; const int niters = s_niters; double minmed = s_minmed;
+                bool done = false;
+                for (int gI = 0; gI < G && !done; gI++) {
+                    if (iter >= niters) { done = true; break; }
+                    if (g_nmodels[gI] < 0) { if (++attempts >= 10000) done = true; continue; }
+                    attempts = 0;
+                    for (int k = 0; k < g_nmodels[gI]; k++) {
+                        const double med = (double)g_med[gI][k];
+                        if (med < minmed) { minmed = med; for (int i = 0; i < 9; i++) s_best[i] = g_model[gI][9 * k + i]; s_best_iter = iter; s_best_root = k; }
+                    }
+                    iter++;
+                }
+                if (iter >= niters) done = true;
+                s_iter = iter; s_attempts = attempts; s_minmed = minmed; s_done = done ? 1 : 0;
+            }
+            SGX_THREADS_END
+            SGX_SYNC();
+            if (s_done) break;
+            continue;
+        }
         // ---- findInliers for every model of the round
         for (int gI = 0; gI < G; gI++) {
             const int nm = g_nmodels[gI];
@@ -1032,12 +1083,28 @@ SGX_KERNEL(256) k_fm_ransac(SgxFmArgs A)
         SGX_SYNC();
         if (s_done) break;
     }
+    if (lmeds) {                                                     /* sigma from the best median, inliers of the best model, success = at least 7 of them */
+        SGX_THREADS_BEGIN(tid)
+        if (tid == 0) {
+            int good = 0;
+            if (s_minmed < DBL_MAX) {
+                double sigma = 2.5 * 1.4826 * (1 + 5. / (count - 7)) * sqrt(s_minmed);
+                if (sigma < 0.001) sigma = 0.001;
+                const float ts = (float)(sigma * sigma);
+                for (int p = 0; p < count; p++) good += sgx_fm_error(s_best, m1[2 * p], m1[2 * p + 1], m2[2 * p], m2[2 * p + 1]) <= ts ? 1 : 0;
+            }
+            s_maxgood = good >= 7 ? good : 0;
+            if (A.stats) A.stats[4 * f + 3] = good;
+        }
+        SGX_THREADS_END
+        SGX_SYNC();
+    }
     SGX_THREADS_BEGIN(tid)
     const bool ok = s_maxgood > 0;
     if (tid < 9) A.F[9 * (size_t)f + tid] = ok ? s_best[tid] : 0.;
     if (tid == 0) {
         A.ok[f] = ok ? 1 : 0;
-        if (A.stats) { A.stats[4 * f] = s_iter; A.stats[4 * f + 1] = s_best_iter; A.stats[4 * f + 2] = s_best_root; A.stats[4 * f + 3] = s_maxgood; }
+        if (A.stats) { A.stats[4 * f] = s_iter; A.stats[4 * f + 1] = s_best_iter; A.stats[4 * f + 2] = s_best_root; if (!lmeds) A.stats[4 * f + 3] = s_maxgood; }
     }
     SGX_THREADS_END
 }

@@ -118,15 +118,20 @@ def check_ransac_host(lib, orc):
         l = (F @ np.c_[x1, np.ones(n)].T).T
         d = np.abs((l * np.c_[x2, np.ones(n)]).sum(1)) / np.hypot(l[:, 0], l[:, 1])
         assert np.median(d[rmask > 0]) < 0.6
-    for n in (0, 5, 7, 10):                                  # < 7: empty; 7: 7-point directly; 8..14: LMedS in OpenCV — not built, reported as "no F"
-        x1, x2 = two_view(max(n, 1), 9, 0)
-        ok, F, st = find_fundamental_mat(x1[:n], x2[:n], lib=lib)
-        rok, rF, _, _ = orc.find_fundamental_ransac(x1[:n], x2[:n])
-        assert ok == (1 if rok == 1 else 0)
-        if ok:
-            assert np.abs(F - rF).max() <= 1e-9 * np.abs(rF).max()
-        else:
-            assert (F == 0).all()
+    lmeds_ok = 0
+    for n in (0, 5, 7, 8, 9, 10, 12, 14):                    # < 7: empty; 7: 7-point directly; 8..14: OpenCV's LMedS branch
+        for seed, every in ((9, 0), (10, 5), (11, 3)):              # no outliers / every fifth / every third pair an outlier
+            x1, x2 = two_view(max(n, 1), seed, every)
+            ok, F, st = find_fundamental_mat(x1[:n], x2[:n], lib=lib)
+            rok, rF, rmask, rst = orc.find_fundamental_ransac(x1[:n], x2[:n])
+            assert ok == rok, (n, seed, ok, rok)
+            if n >= 8: assert (st == rst).all(), (n, seed, st, rst)           # iterations (300 at confidence 0.99), winning iteration / root, inliers
+            if ok:
+                assert np.abs(F - rF).max() <= 1e-9 * np.abs(rF).max()
+                if n >= 8: lmeds_ok += 1; assert rst[0] == 300 and rst[3] >= 7
+            else:
+                assert (F == 0).all()
+    assert lmeds_ok >= 8
 
 
 def check_ransac_batch(lib, orc, xp):
