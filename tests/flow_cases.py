@@ -105,7 +105,7 @@ def check_lk_stream(lib, orc, xp, S=2, T=4):
     fl.close()
 
 
-def check_ransac_host(lib, orc):
+def check_ransac_host(lib, orc, exact_lmeds=True):
     """findFundamentalMat: same RANSAC trajectory (iterations, winning sample / root, inlier count) and F within 1e-9 of the oracle"""
     for seed, (n, oe) in enumerate(((400, 4), (1000, 3), (60, 2), (15, 0), (500, 0))):
         x1, x2 = two_view(n, seed, oe)
@@ -125,10 +125,19 @@ def check_ransac_host(lib, orc):
             ok, F, st = find_fundamental_mat(x1[:n], x2[:n], lib=lib)
             rok, rF, rmask, rst = orc.find_fundamental_ransac(x1[:n], x2[:n])
             assert ok == rok, (n, seed, ok, rok)
-            if n >= 8: assert (st == rst).all(), (n, seed, st, rst)           # iterations (300 at confidence 0.99), winning iteration / root, inliers
+            # 8..13 pairs: the median (element n / 2 < 7 of the sorted errors) is one of the ~1e-20 residuals of the seven SAMPLE points themselves, so which subset wins is
+            # decided by rounding noise of the 7-point solver (libm) — in OpenCV too.  With the oracle's libm (emulator) the choice is identical; on the device only what
+            # is well defined is compared: success, 300 iterations, and that the returned matrix is an exact 7-point model of the data (>= 7 pairs at ~zero error).
+            exact = exact_lmeds or n < 8 or n >= 14
+            if n >= 8 and exact: assert (st == rst).all(), (n, seed, st, rst)           # iterations (300 at confidence 0.99), winning iteration / root, inliers
             if ok:
-                assert np.abs(F - rF).max() <= 1e-9 * np.abs(rF).max()
-                if n >= 8: lmeds_ok += 1; assert rst[0] == 300 and rst[3] >= 7
+                if exact: assert np.abs(F - rF).max() <= 1e-9 * np.abs(rF).max()
+                if n >= 8:
+                    lmeds_ok += 1; assert st[0] == rst[0] == 300 and st[3] >= 7 and rst[3] >= 7
+                    a = np.c_[x1[:n], np.ones(n)].astype('f8'); b = np.c_[x2[:n], np.ones(n)].astype('f8')
+                    l2 = (F @ a.T).T; l1 = (F.T @ b.T).T; e = (b * l2).sum(1) ** 2
+                    err = np.maximum(e / (l2[:, 0] ** 2 + l2[:, 1] ** 2), e / (l1[:, 0] ** 2 + l1[:, 1] ** 2))      # FMEstimatorCallback::computeError
+                    assert (err <= max(1e-6, 1e-3 * np.median(err) if n >= 14 else 1e-6)).sum() >= 7 or n >= 14
             else:
                 assert (F == 0).all()
     assert lmeds_ok >= 8
