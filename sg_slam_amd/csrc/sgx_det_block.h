@@ -270,7 +270,7 @@ template <int CIN, int COUT, int K, int S, int TOH, int TOW, int CM> struct SgxF
 };
 
 // wd2: depthwise weights with the two channels of a pair interleaved, [Cmid / 2][K * K][2] (built once per plan, sgx_det.cpp)
-// RES: 0 = no residual operand, 1 = fetched before the chunk loop (hides its latency, costs COUT registers), 2 = fetched before the store; UA = phase A unroll
+// RES: 0 = no residual operand, 1 = fetched before the chunk loop (hides its latency, costs COUT registers), 2 = fetched before the store; UA: 2 = phase A on channel pairs (8-byte LDS stores), 1 = one channel per step, 3 = one channel per step unrolled by two
 template <int CIN, int COUT, int K, int S, int TOH, int TOW, int CM, int RES, int UA>
 SGX_KERNEL(SGX_FB2_THREADS) k_fused_block2(int Cmid, int H, int W, int Ho, int Wo, int pad, int tiles_x, int tiles_y, float lo1, float hi1, float lo2, float hi2,
                                            const float *__restrict__ in, size_t in_pitch, const float *__restrict__ w1, const float *__restrict__ b1,
@@ -278,6 +278,7 @@ SGX_KERNEL(SGX_FB2_THREADS) k_fused_block2(int Cmid, int H, int W, int Ho, int W
                                            float *__restrict__ out, size_t out_pitch, const float *__restrict__ res, size_t res_pitch)
 {
     typedef SgxFb2Geom<CIN, COUT, K, S, TOH, TOW, CM> G;
+    constexpr int UNR_A = UA == 3 ? 2 : 1;
     SGX_LDS sgx_f2 Es[(CM / 2) * G::ES];                                                       // E tile of the chunk: [channel pair][pixel] -> (E[2p][pixel], E[2p + 1][pixel])
     SGX_PRIV_DECL(sgx_f2, x2, (G::PAIRS_IN ? G::PAIRS_IN : 1) * CIN, SGX_FB2_THREADS);        // input pixels of slots (2p, 2p + 1), all Cin channels
     SGX_PRIV_DECL(float, x1, CIN, SGX_FB2_THREADS);                                            // the odd last slot
@@ -325,11 +326,49 @@ SGX_KERNEL(SGX_FB2_THREADS) k_fused_block2(int Cmid, int H, int W, int Ho, int W
     SGX_THREADS_END
 
     for (int cm0 = 0; cm0 < Cmid; cm0 += CM) {
-        // ---- phase A: expand this chunk for the thread's input pixels (two pixels per packed FMA, the weight broadcast to both halves)
+        // ---- phase A: expand this chunk for the thread's input pixels: two pixels per packed FMA (the weight broadcast to both halves), two expanded channels per step so
+        //      that a pixel's pair (E[m], E[m + 1]) leaves as one 8-byte LDS store into the pair-interleaved tile
+        if (UA == 2) {
+        SGX_THREADS_BEGIN(tid)
+        SGX_PRIV_BIND(x2, tid); SGX_PRIV_BIND(x1, tid); SGX_PRIV_BIND(eidx, tid);
+#pragma unroll 1
+        for (int m = 0; m < CM; m += 2) {
+            const sgx_f2 *wr0 = (const sgx_f2 *)(w1 + (size_t)(cm0 + m) * CIN), *wr1 = (const sgx_f2 *)(w1 + (size_t)(cm0 + m + 1) * CIN);
+            const float bias0 = b1[cm0 + m], bias1 = b1[cm0 + m + 1];
+            sgx_f2 wk0[CIN / 2], wk1[CIN / 2];
+#pragma unroll
+            for (int k = 0; k < CIN / 2; k++) { wk0[k] = wr0[k]; wk1[k] = wr1[k]; }
+            sgx_f2 *Em = Es + (size_t)(m >> 1) * G::ES;
+            sgx_f2 sp0[G::PAIRS_IN ? G::PAIRS_IN : 1], sp1[G::PAIRS_IN ? G::PAIRS_IN : 1];
+#pragma unroll
+            for (int jp = 0; jp < G::PAIRS_IN; jp++) { sp0[jp] = sgx_mk2(bias0, bias0); sp1[jp] = sgx_mk2(bias1, bias1); }
+#pragma unroll
+            for (int k = 0; k < CIN / 2; k++) {                      // independent chains (pixel pairs x two channels) interleaved
+#pragma unroll
+                for (int jp = 0; jp < G::PAIRS_IN; jp++) { sp0[jp] = sgx_fma2_wlo(wk0[k], x2[jp * CIN + 2 * k], sp0[jp]); sp1[jp] = sgx_fma2_wlo(wk1[k], x2[jp * CIN + 2 * k], sp1[jp]); }
+#pragma unroll
+                for (int jp = 0; jp < G::PAIRS_IN; jp++) { sp0[jp] = sgx_fma2_whi(wk0[k], x2[jp * CIN + 2 * k + 1], sp0[jp]); sp1[jp] = sgx_fma2_whi(wk1[k], x2[jp * CIN + 2 * k + 1], sp1[jp]); }
+            }
+#pragma unroll
+            for (int jp = 0; jp < G::PAIRS_IN; jp++) {
+                const int e0 = eidx[2 * jp], e1 = eidx[2 * jp + 1];
+                if (e0 >= 0) Em[e0 & 0xFFFFFF] = (e0 & (1 << 30)) ? sgx_mk2(0.f, 0.f) : sgx_mk2(fminf(fmaxf(sp0[jp].x, lo1), hi1), fminf(fmaxf(sp1[jp].x, lo1), hi1));
+                if (e1 >= 0) Em[e1 & 0xFFFFFF] = (e1 & (1 << 30)) ? sgx_mk2(0.f, 0.f) : sgx_mk2(fminf(fmaxf(sp0[jp].y, lo1), hi1), fminf(fmaxf(sp1[jp].y, lo1), hi1));
+            }
+            if (G::ODD_IN) {
+                float s0 = bias0, s1 = bias1;
+#pragma unroll
+                for (int k = 0; k < CIN / 2; k++) { s0 = fmaf(wk0[k].x, x1[2 * k], s0); s1 = fmaf(wk1[k].x, x1[2 * k], s1); s0 = fmaf(wk0[k].y, x1[2 * k + 1], s0); s1 = fmaf(wk1[k].y, x1[2 * k + 1], s1); }
+                const int e = eidx[G::SLOTS_IN - 1];
+                if (e >= 0) Em[e & 0xFFFFFF] = (e & (1 << 30)) ? sgx_mk2(0.f, 0.f) : sgx_mk2(fminf(fmaxf(s0, lo1), hi1), fminf(fmaxf(s1, lo1), hi1));
+            }
+        }
+        SGX_THREADS_END
+        } else {                                                     // one channel per step (scalar 4-byte stores): better where the register budget is tight
         SGX_THREADS_BEGIN(tid)
         SGX_PRIV_BIND(x2, tid); SGX_PRIV_BIND(x1, tid); SGX_PRIV_BIND(eidx, tid);
         float *Ef = (float *)Es;
-#pragma unroll UA
+#pragma unroll UNR_A
         for (int m = 0; m < CM; m++) {
             const sgx_f2 *wr = (const sgx_f2 *)(w1 + (size_t)(cm0 + m) * CIN);
             const float bias = b1[cm0 + m];
@@ -363,6 +402,7 @@ SGX_KERNEL(SGX_FB2_THREADS) k_fused_block2(int Cmid, int H, int W, int Ho, int W
             }
         }
         SGX_THREADS_END
+        }
         SGX_SYNC();
         // ---- phases B + C: depthwise on two channels of the chunk at a time, then the project accumulation; one output pixel per thread and slot
         SGX_THREADS_BEGIN(tid)
@@ -450,9 +490,9 @@ static inline int sgx_fb2_launch(const SgxFusedBlk &fb, int batch, sgx_stream_t 
         SGX_LAUNCH(kfn, dim3(grid), dim3(SGX_FB2_THREADS), st, fb.Cmid, fb.H, fb.W, fb.Ho, fb.Wo, fb.pad, fb.tiles_x, fb.tiles_y, fb.lo1, fb.hi1, fb.lo2, fb.hi2,     \
                    fb.in, fb.in_pitch, fb.w1, fb.b1, fb.wd2, fb.bd, fb.w2t, fb.ldw2, fb.b2, fb.out, fb.out_pitch, fb.res, fb.res_pitch); } while (0)
     switch (fb.v2) {
-    case 16: SGX_FB2(16, 16, 3, 1, 8, 16, 16, 1, 2); break;           // Cmid = 16: one chunk
-    case 17: SGX_FB2(16, 16, 3, 1, 16, 16, 16, 1, 2); break;
-    case 32: SGX_FB2(16, 24, 3, 2, 7, 16, 8, 2, 1); break;
+    case 16: SGX_FB2(16, 16, 3, 1, 8, 16, 16, 1, 3); break;           // Cmid = 16: one chunk
+    case 17: SGX_FB2(16, 16, 3, 1, 16, 16, 16, 1, 3); break;
+    case 32: SGX_FB2(16, 24, 3, 2, 7, 16, 8, 2, 2); break;           // phase A on channel pairs: 0.83 -> 0.70 ms (the other two shapes lose: 0.71 -> 0.76, 0.61 -> 0.72)
     case 48: SGX_FB2(24, 24, 3, 1, 8, 16, 8, 2, 1); break;
     case 49: SGX_FB2(24, 24, 3, 1, 16, 16, 8, 2, 1); break;
     default: return SGX_ERR_INVALID;
