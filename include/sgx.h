@@ -226,6 +226,15 @@ int sgx_match_search_by_sim3(
     const sgx_camera *cam, const float *scale_factors, int nlevels, float log_scale_factor, float s12, const float *R12, const float *t12, float th,
     int32_t *match12, int32_t *nfound);
 
+/* int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f> &vbPrevMatched, vector<int> &vnMatches12, int windowSize = 10)
+ * (src/sg-slam/include/ORBmatcher.h:69, src/sg-slam/src/ORBmatcher.cc:407-522; caller Tracking::MonocularInitialization, Tracking.cc:639, windowSize 100): the monocular
+ * initialiser's matcher (the RGB-D system never reaches it; built so that every ORBmatcher method has a device form).  prev_matched (in/out, n1 x 2 floats) = vbPrevMatched,
+ * matches12 (out, n1) = vnMatches12; cam supplies the image bounds of F2's grid.  The reference's order-dependent stealing rule (a later keypoint takes a match only with a
+ * strictly smaller distance) is reproduced exactly.  Host pointers, synchronous. */
+int sgx_match_search_for_initialization(
+    int n1, const sgx_keypoint *keys1_un, const uint8_t *desc1, int n2, const sgx_keypoint *keys2_un, const uint8_t *desc2,
+    float *prev_matched, int window_size, float nnratio, int check_orientation, const sgx_camera *cam, int32_t *matches12, int32_t *nmatches);
+
 /* ---- ORBVocabulary = DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> (src/sg-slam/include/ORBVocabulary.h:31-32) ----------------------------------------------
  * The bag-of-words transform behind Frame::ComputeBoW (src/sg-slam/src/Frame.cc:422-429) and KeyFrame::ComputeBoW (src/sg-slam/src/KeyFrame.cc:60-69):
  *     mpORBvocabulary->transform(vCurrentDesc, mBowVec, mFeatVec, 4)          src/sg-slam/Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1139-1206

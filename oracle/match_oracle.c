@@ -796,3 +796,61 @@ int orc_search_by_sim3(int N1, const orc_keypoint *keys1, const uint8_t *desc1, 
     free(already1); free(already2); free(m1); free(m2); free(cand);
     return nFound;
 }
+
+/* int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f> &vbPrevMatched, vector<int> &vnMatches12, int windowSize)
+ * (ORBmatcher.cc:407-522; caller Tracking::MonocularInitialization, Tracking.cc:639 — the monocular initialiser, never reached by the RGB-D system).
+ * prev_matched (in/out, N1 x 2 floats) = vbPrevMatched; matches12 (out, N1) = vnMatches12.  A histogram entry stays in its bin when a later keypoint steals the match
+ * (the three maxima count it; the removal loop skips it because vnMatches12 is already -1), as in the reference. */
+int orc_search_for_initialization(int N1, const orc_keypoint *k1, const uint8_t *d1, int N2, const orc_keypoint *k2, const uint8_t *d2, float *prev_matched, int windowSize,
+                                  float nnratio, int check_ori, float minX, float maxX, float minY, float maxY, int *matches12)
+{
+    int nmatches = 0;
+    grid_t *g = (grid_t *)malloc(sizeof(grid_t));
+    grid_build(g, N2, k2, minX, maxX, minY, maxY);
+    int *vind = (int *)malloc(sizeof(int) * (size_t)(N2 > 0 ? N2 : 1)), *dist2 = (int *)malloc(sizeof(int) * (size_t)(N2 > 0 ? N2 : 1)), *m21 = (int *)malloc(sizeof(int) * (size_t)(N2 > 0 ? N2 : 1));
+    int *hist[HISTO_LENGTH], hn[HISTO_LENGTH], hc[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) { hist[i] = NULL; hn[i] = 0; hc[i] = 0; }
+    const float factor = HISTO_LENGTH / 360.0f;
+    for (int i = 0; i < N1; i++) matches12[i] = -1;
+    for (int i = 0; i < N2; i++) { dist2[i] = INT_MAX; m21[i] = -1; }
+    for (int i1 = 0; i1 < N1; i1++) {
+        const int level1 = k1[i1].octave;
+        if (level1 > 0) continue;
+        const int nv = features_in_area(g, k2, prev_matched[2 * i1], prev_matched[2 * i1 + 1], (float)windowSize, level1, level1, vind);
+        if (nv == 0) continue;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int q = 0; q < nv; q++) {
+            const int i2 = vind[q];
+            const int dist = orc_descriptor_distance(d1 + 32 * (size_t)i1, d2 + 32 * (size_t)i2);
+            if (dist2[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= TH_LOW) {
+            if (bestDist < (float)bestDist2 * nnratio) {
+                if (m21[bestIdx2] >= 0) { matches12[m21[bestIdx2]] = -1; nmatches--; }
+                matches12[i1] = bestIdx2; m21[bestIdx2] = i1; dist2[bestIdx2] = bestDist; nmatches++;
+                if (check_ori) {
+                    float rot = k1[i1].angle - k2[bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)round(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    if (hn[bin] == hc[bin]) { hc[bin] = hc[bin] ? 2 * hc[bin] : 64; hist[bin] = (int *)realloc(hist[bin], sizeof(int) * hc[bin]); }
+                    hist[bin][hn[bin]++] = i1;
+                }
+            }
+        }
+    }
+    if (check_ori) {
+        int i1, i2, i3;
+        three_maxima(hn, HISTO_LENGTH, &i1, &i2, &i3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == i1 || i == i2 || i == i3) continue;
+            for (int j = 0; j < hn[i]; j++) { const int idx1 = hist[i][j]; if (matches12[idx1] >= 0) { matches12[idx1] = -1; nmatches--; } }
+        }
+    }
+    for (int i = 0; i < N1; i++) if (matches12[i] >= 0) { prev_matched[2 * i] = k2[matches12[i]].x; prev_matched[2 * i + 1] = k2[matches12[i]].y; }
+    for (int i = 0; i < HISTO_LENGTH; i++) free(hist[i]);
+    grid_free(g); free(g); free(vind); free(dist2); free(m21);
+    return nmatches;
+}

@@ -354,6 +354,15 @@ def search_by_bow(kf, F, nnratio=0.7, check_ori=True):
     return int(n), match[:len(kq)].copy()
 
 
+def search_for_initialization(F1, F2, prev_matched, window, cam, nnratio=0.9, check_ori=True):
+    a = np.ascontiguousarray(F1['keys']); da = np.ascontiguousarray(F1['desc'], np.uint8); b = np.ascontiguousarray(F2['keys']); db = np.ascontiguousarray(F2['desc'], np.uint8)
+    pm = np.ascontiguousarray(prev_matched, 'f4').reshape(-1, 2).copy(); m = np.full(max(len(a), 1), -1, 'i4')
+    L = lib(); L.orc_search_for_initialization.restype = C.c_int
+    n = L.orc_search_for_initialization(C.c_int(len(a)), _p(a), _p(da), C.c_int(len(b)), _p(b), _p(db), _p(pm), C.c_int(int(window)), C.c_float(nnratio), C.c_int(int(bool(check_ori))),
+                                        C.c_float(cam.get('min_x', 0.0)), C.c_float(cam.get('max_x', 640.0)), C.c_float(cam.get('min_y', 0.0)), C.c_float(cam.get('max_y', 480.0)), _p(m))
+    return int(n), m[:len(a)].copy(), pm
+
+
 def search_by_bow_kf(kf1, kf2, nnratio=0.75, check_ori=True):
     a = [np.ascontiguousarray(kf1['keys']), np.ascontiguousarray(kf1['desc'], np.uint8), np.ascontiguousarray(kf1['good_mp'], np.uint8), np.ascontiguousarray(kf1['feat_node'], 'i4')]
     b = [np.ascontiguousarray(kf2['keys']), np.ascontiguousarray(kf2['desc'], np.uint8), np.ascontiguousarray(kf2['good_mp'], np.uint8), np.ascontiguousarray(kf2['feat_node'], 'i4')]

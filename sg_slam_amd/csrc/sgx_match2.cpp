@@ -425,3 +425,34 @@ extern "C" int sgx_match_search_by_sim3(
     *nfound = n;
     return SGX_OK;
 }
+
+extern "C" int sgx_match_search_for_initialization(
+    int n1, const sgx_keypoint *keys1_un, const uint8_t *desc1, int n2, const sgx_keypoint *keys2_un, const uint8_t *desc2,
+    float *prev_matched, int window_size, float nnratio, int check_orientation, const sgx_camera *cam, int32_t *matches12, int32_t *nmatches)
+{
+    if (n1 < 0 || n2 < 0 || !cam || !nmatches || window_size < 0 || (n1 > 0 && (!matches12 || !prev_matched))) return SGX_ERR_INVALID;
+    *nmatches = 0;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    if (n1 == 0 || n2 == 0) return SGX_OK;
+    if (!keys1_un || !desc1 || !keys2_un || !desc2 || n2 >= (1 << 22)) return SGX_ERR_INVALID;
+    std::vector<int> start, items;
+    build_kf_grid(n2, keys2_un, cam, start, items);              // F2.mGrid (Frame::AssignFeaturesToGrid, same round() cell rule)
+    SgxInitSearchArgs A; memset(&A, 0, sizeof A);
+    A.n1 = n1; A.n2 = n2; A.window = window_size; A.check_ori = check_orientation; A.nnratio = nnratio;
+    A.cam.fx = cam->fx; A.cam.fy = cam->fy; A.cam.cx = cam->cx; A.cam.cy = cam->cy; A.cam.bf = cam->bf; A.cam.minX = cam->min_x; A.cam.maxX = cam->max_x; A.cam.minY = cam->min_y; A.cam.maxY = cam->max_y;
+    SgxStaged b[12]; int rc;
+#define PUT(k, src, bytes) if ((rc = b[k].put(k, src, bytes)) != SGX_OK) return rc
+    PUT(0, keys1_un, (size_t)n1 * 28); PUT(1, desc1, (size_t)n1 * 32); PUT(2, keys2_un, (size_t)n2 * 28); PUT(3, desc2, (size_t)n2 * 32);
+    PUT(4, start.data(), start.size() * 4); PUT(5, items.data(), items.size() * 4); PUT(6, prev_matched, (size_t)n1 * 8);
+    PUT(7, nullptr, (size_t)n1 * 4); PUT(8, nullptr, (size_t)n2 * 4); PUT(9, nullptr, (size_t)n2 * 4); PUT(10, nullptr, 4);
+#undef PUT
+    A.keys1 = (const uint8_t *)b[0].p; A.desc1 = (const uint32_t *)b[1].p; A.keys2 = (const uint8_t *)b[2].p; A.desc2 = (const uint32_t *)b[3].p;
+    A.cell_start = (const int *)b[4].p; A.cell_items = (const int *)b[5].p; A.prev_matched = (float *)b[6].p;
+    A.matches12 = (int *)b[7].p; A.matches21 = (int *)b[8].p; A.dist21 = (int *)b[9].p; A.nmatches = (int *)b[10].p;
+    SGX_LAUNCH(k_search_initialization, dim3(1), dim3(256), (sgx_stream_t)0, A);
+    SGX_CHECK_HIP(hipGetLastError());
+    SGX_CHECK_HIP(hipMemcpy(matches12, A.matches12, (size_t)n1 * 4, hipMemcpyDeviceToHost));
+    SGX_CHECK_HIP(hipMemcpy(prev_matched, A.prev_matched, (size_t)n1 * 8, hipMemcpyDeviceToHost));
+    SGX_CHECK_HIP(hipMemcpy(nmatches, A.nmatches, 4, hipMemcpyDeviceToHost));
+    return SGX_OK;
+}

@@ -584,3 +584,122 @@ SGX_KERNEL(1024) k_sim3_search_locked(SgxSim3ProjArgs A)
     if (tid == 0) *A.nmatches = s_total;
     SGX_THREADS_END
 }
+
+// ---------------------------------------------------------------------------------------------
+// k_search_initialization: ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (ORBmatcher.cc:407-522), the monocular initialiser's
+// matcher.  The reference walks F1's level-0 keypoints in order; a keypoint may take a keypoint of F2 from an earlier one when its distance is strictly smaller
+// (vMatchedDistance), so the outer loop is inherently sequential.  One workgroup: the outer loop runs in order, the window search of a keypoint is spread over the
+// threads (the cells of one grid column are contiguous in the CSR grid): pass A finds (smallest distance, first in GetFeaturesInArea order) with one LDS atomic min on
+// distance << 22 | ordinal, pass B the second smallest distance among the others; thread 0 applies the accept / steal rules.  A rare, one-frame-pair event: latency over throughput.
+// ---------------------------------------------------------------------------------------------
+struct SgxInitSearchArgs {
+    int n1, n2, window, check_ori; float nnratio;
+    SgxCam cam;
+    const uint8_t *keys1, *keys2; const uint32_t *desc1, *desc2;
+    const int *cell_start, *cell_items;                 // CSR grid of F2: cell (ix, iy) -> ix * 48 + iy
+    float *prev_matched;                                // in / out
+    int *matches12, *matches21, *dist21, *nmatches;
+};
+
+SGX_KERNEL(256) k_search_initialization(SgxInitSearchArgs A)
+{
+    SGX_LDS int hist[SGX_HISTO], bad[SGX_HISTO];
+    SGX_LDS int s_key, s_second, s_best_idx, s_total;
+    SGX_THREADS_BEGIN(tid)
+    for (int i = tid; i < A.n1; i += 256) A.matches12[i] = -1;
+    for (int i = tid; i < A.n2; i += 256) { A.matches21[i] = -1; A.dist21[i] = 0x7FFFFFFF; }
+    for (int i = tid; i < SGX_HISTO; i += 256) { hist[i] = 0; bad[i] = 0; }
+    if (tid == 0) s_total = 0;
+    SGX_THREADS_END
+    SGX_SYNC();
+    const float invW = 64.0f / (A.cam.maxX - A.cam.minX), invH = 48.0f / (A.cam.maxY - A.cam.minY), r = (float)A.window;
+    for (int i1 = 0; i1 < A.n1; i1++) {
+        const float *kp1 = (const float *)(A.keys1 + (size_t)i1 * 28);
+        if (((const int *)kp1)[5] > 0) continue;                                   // level1 > 0 (:424-426); uniform
+        const float x = A.prev_matched[2 * i1], y = A.prev_matched[2 * i1 + 1];
+        int x0 = (int)floorf((x - A.cam.minX - r) * invW), x1 = (int)ceilf((x - A.cam.minX + r) * invW);
+        int y0 = (int)floorf((y - A.cam.minY - r) * invH), y1 = (int)ceilf((y - A.cam.minY + r) * invH);
+        x0 = max(x0, 0); y0 = max(y0, 0); x1 = min(x1, 63); y1 = min(y1, 47);
+        if (x0 >= 64 || y0 >= 48 || x1 < 0 || y1 < 0) continue;                    // Frame::GetFeaturesInArea early returns
+        const uint32_t *da = A.desc1 + (size_t)i1 * 8;
+        SGX_THREADS_BEGIN(tid)
+        if (tid == 0) { s_key = 0x7FFFFFFF; s_second = 0x7FFFFFFF; s_best_idx = -1; }
+        SGX_THREADS_END
+        SGX_SYNC();
+        for (int pass = 0; pass < 2; pass++) {
+            SGX_THREADS_BEGIN(tid)
+            int ordinal = 0;
+            for (int ix = x0; ix <= x1; ix++) {
+                const int s = A.cell_start[ix * 48 + y0], e = A.cell_start[ix * 48 + y1 + 1];
+                for (int q = s + tid; q < e; q += 256) {
+                    const int i2 = A.cell_items[q];
+                    const float *kp2 = (const float *)(A.keys2 + (size_t)i2 * 28);
+                    if (((const int *)kp2)[5] != 0) continue;                                       // minLevel = maxLevel = level1 = 0
+                    if (!(fabsf(kp2[0] - x) < r && fabsf(kp2[1] - y) < r)) continue;
+                    const int dist = sgx_hamming256(da, A.desc2 + (size_t)i2 * 8);
+                    if (A.dist21[i2] <= dist) continue;                                             // vMatchedDistance (:444-445)
+                    const int key = (dist << 22) | (ordinal + (q - s));
+                    if (pass == 0) sgx_atomic_min_i32(&s_key, key);
+                    else if (key == s_key) s_best_idx = i2;
+                    else sgx_atomic_min_i32(&s_second, dist);
+                }
+                ordinal += e - s;
+            }
+            SGX_THREADS_END
+            SGX_SYNC();
+        }
+        SGX_THREADS_BEGIN(tid)
+        if (tid == 0 && s_best_idx >= 0) {
+            const int bestDist = s_key >> 22, bestDist2 = s_second, bestIdx2 = s_best_idx;
+            if (bestDist <= SGX_TH_LOW && (float)bestDist < (float)bestDist2 * A.nnratio) {
+                if (A.matches21[bestIdx2] >= 0) { A.matches12[A.matches21[bestIdx2]] = -1; s_total--; }
+                A.matches12[i1] = bestIdx2; A.matches21[bestIdx2] = i1; A.dist21[bestIdx2] = bestDist; s_total++;
+                if (A.check_ori) {
+                    float rot = kp1[3] - ((const float *)(A.keys2 + (size_t)bestIdx2 * 28))[3];
+                    if (rot < 0.0f) rot += 360.0f;
+                    int bin = (int)round((double)(rot * (SGX_HISTO / 360.0f)));
+                    if (bin == SGX_HISTO) bin = 0;
+                    hist[bin]++;                                                                    // stays counted when the match is stolen later, as rotHist does
+                }
+            }
+        }
+        SGX_THREADS_END
+        SGX_SYNC();
+    }
+    if (A.check_ori) {
+        SGX_THREADS_BEGIN(tid)
+        if (tid == 0) {
+            int m1 = 0, m2 = 0, m3 = 0, i1 = -1, i2 = -1, i3 = -1;
+            for (int i = 0; i < SGX_HISTO; i++) {
+                const int s = hist[i];
+                if (s > m1) { m3 = m2; m2 = m1; m1 = s; i3 = i2; i2 = i1; i1 = i; }
+                else if (s > m2) { m3 = m2; m2 = s; i3 = i2; i2 = i; }
+                else if (s > m3) { m3 = s; i3 = i; }
+            }
+            if ((float)m2 < 0.1f * (float)m1) { i2 = -1; i3 = -1; }
+            else if ((float)m3 < 0.1f * (float)m1) { i3 = -1; }
+            for (int i = 0; i < SGX_HISTO; i++) bad[i] = (i != i1 && i != i2 && i != i3);
+        }
+        SGX_THREADS_END
+        SGX_SYNC();
+        SGX_THREADS_BEGIN(tid)
+        for (int i = tid; i < A.n1; i += 256) {
+            const int j = A.matches12[i];
+            if (j < 0) continue;
+            float rot = ((const float *)(A.keys1 + (size_t)i * 28))[3] - ((const float *)(A.keys2 + (size_t)j * 28))[3];
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)round((double)(rot * (SGX_HISTO / 360.0f)));
+            if (bin == SGX_HISTO) bin = 0;
+            if (bad[bin]) { A.matches12[i] = -1; sgx_atomic_add(&s_total, -1); }
+        }
+        SGX_THREADS_END
+        SGX_SYNC();
+    }
+    SGX_THREADS_BEGIN(tid)
+    for (int i = tid; i < A.n1; i += 256) {                                         // update vbPrevMatched (:516-519)
+        const int j = A.matches12[i];
+        if (j >= 0) { const float *kp2 = (const float *)(A.keys2 + (size_t)j * 28); A.prev_matched[2 * i] = kp2[0]; A.prev_matched[2 * i + 1] = kp2[1]; }
+    }
+    if (tid == 0) *A.nmatches = s_total;
+    SGX_THREADS_END
+}

@@ -242,6 +242,18 @@ public:
         return n;
     }
 
+    // int SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f> &vbPrevMatched, vector<int> &vnMatches12, int windowSize = 10) (ORBmatcher.cc:407-522);
+    // vbPrevMatched = N1 x (x, y)
+    int SearchForInitialization(const FrameView &F1, const FrameView &F2, std::vector<float> &vbPrevMatched, std::vector<int32_t> &vnMatches12, int windowSize, const sgx_camera &cam)
+    {
+        vnMatches12.assign((size_t)(F1.N > 0 ? F1.N : 1), -1); int32_t n = 0;
+        vbPrevMatched.resize((size_t)2 * (F1.N > 0 ? F1.N : 1));
+        check(sgx_match_search_for_initialization(F1.N, F1.mvKeysUn.data(), F1.mDescriptors.data(), F2.N, F2.mvKeysUn.data(), F2.mDescriptors.data(), vbPrevMatched.data(), windowSize,
+                                                  mfNNratio, mbCheckOrientation ? 1 : 0, &cam, vnMatches12.data(), &n), "sgx_match_search_for_initialization");
+        vnMatches12.resize((size_t)F1.N); vbPrevMatched.resize((size_t)2 * F1.N);
+        return n;
+    }
+
 protected:
     float mfNNratio; bool mbCheckOrientation;
 };

@@ -104,6 +104,16 @@ class ORBmatcher:
                                                             int(self.mbCheckOrientation), _vp(match), _vp(n)), 'sgx_match_search_by_bow')
         return int(n[0]), match[:len(kq)].copy()
 
+    def SearchForInitialization(self, F1, F2, vbPrevMatched, windowSize=10, cam=None):
+        """ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (ORBmatcher.cc:407-522).  F*: keys (mvKeysUn), desc.
+        Returns (nmatches, vnMatches12[n1], vbPrevMatched updated)."""
+        a = np.ascontiguousarray(F1['keys']); da = np.ascontiguousarray(F1['desc'], np.uint8); b = np.ascontiguousarray(F2['keys']); db = np.ascontiguousarray(F2['desc'], np.uint8)
+        pm = np.ascontiguousarray(vbPrevMatched, 'f4').reshape(-1, 2).copy()
+        m = np.full(max(len(a), 1), -1, 'i4'); n = np.zeros(1, 'i4'); cs = camera_struct(cam)
+        self.lib.check(self.lib.dll.sgx_match_search_for_initialization(len(a), _vp(a), _vp(da), len(b), _vp(b), _vp(db), _vp(pm), int(windowSize), float(self.mfNNratio),
+                                                                        int(self.mbCheckOrientation), C.byref(cs), _vp(m), _vp(n)), 'sgx_match_search_for_initialization')
+        return int(n[0]), m[:len(a)].copy(), pm
+
     def SearchByBoWKF(self, kf1, kf2):
         """ORBmatcher::SearchByBoW(pKF1, pKF2, vpMatches12) (ORBmatcher.cc:524-655; LoopClosing::ComputeSim3).  kf*: keys, desc, good_mp, feat_node.
         Returns (nmatches, match12[n1]): match12[i1] = keypoint of pKF2 whose map point pKF1's keypoint i1 is matched with, or -1."""

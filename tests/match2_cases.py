@@ -351,3 +351,40 @@ def check_search_by_sim3(lib, orc, n_cases=5):
     allm = np.zeros(len(k1['keys']), 'i4')
     n, m = ORBmatcher(lib=lib).SearchBySim3(k1, k2, allm, 1.0, R12, t12, 7.5, CAM, sf)
     assert n == 0 == orc.search_by_sim3(k1, k2, allm, 1.0, R12, t12, 7.5, CAM, sf)[0] and (m == allm).all()
+
+
+def check_search_for_initialization(lib, orc, n_cases=4):
+    """SearchForInitialization (monocular initialiser): same vnMatches12 / vbPrevMatched / count as the oracle's sequential loop, incl. matches stolen by later keypoints"""
+    total = 0; stolen_seen = 0
+    for c in range(n_cases):
+        gen = synth.LayeredStream(seed=6234 + c)
+        g0, _, _ = gen.frame(10 + c); g1, _, _ = gen.frame(12 + c)
+        k0, d0 = orc.orb_extract(g0); k1, d1 = orc.orb_extract(g1)
+        F1 = dict(keys=k0, desc=d0); F2 = dict(keys=k1, desc=d1)
+        pm0 = np.stack([k0['x'], k0['y']], 1).astype('f4')                        # mvbPrevMatched starts as F1's keypoint positions (Tracking.cc:607-609)
+        for window, ratio, ori in ((100, 0.9, True), (100, 0.9, False), (30, 0.7, True), (250, 1.5, False)):
+            en, em, epm = orc.search_for_initialization(F1, F2, pm0, window, CAM, ratio, ori)
+            gn, gm, gpm = ORBmatcher(ratio, ori, lib=lib).SearchForInitialization(F1, F2, pm0, window, CAM)
+            assert gn == en == (em >= 0).sum() and (gm == em).all() and (gpm == epm).all(), (c, window, ratio, ori, gn, en, int((gm != em).sum()))
+            sel = em >= 0
+            assert (k0['octave'][sel] == 0).all() and (k1['octave'][em[sel]] == 0).all() and len(set(em[sel])) == sel.sum()
+            assert (epm[sel] == np.stack([k1['x'][em[sel]], k1['y'][em[sel]]], 1)).all() and (epm[~sel] == pm0[~sel]).all()
+            total += en
+        # many level-0 keypoints of F1 with the same descriptor compete for one keypoint of F2: later ones steal it only with a strictly smaller distance
+        kk = k0.copy(); dd = d0.copy(); lv0 = np.nonzero(k0['octave'] == 0)[0][:40]
+        tgt = np.nonzero(k1['octave'] == 0)[0][0]
+        for r, i in enumerate(lv0):
+            bits = np.unpackbits(d1[tgt]); bits[:max(0, 30 - r)] ^= 1; dd[i] = np.packbits(bits)           # distances 30, 29, ..., decreasing along the order: every one steals
+        pmx = pm0.copy(); pmx[lv0] = [k1['x'][tgt], k1['y'][tgt]]
+        en, em, epm = orc.search_for_initialization(dict(keys=kk, desc=dd), F2, pmx, 5, CAM, 2.0, False)
+        gn, gm, gpm = ORBmatcher(2.0, False, lib=lib).SearchForInitialization(dict(keys=kk, desc=dd), F2, pmx, 5, CAM)
+        assert gn == en and (gm == em).all() and (gpm == epm).all()
+        stolen_seen += int((em[lv0] == tgt).sum() == 1 and en >= 1)
+    assert total > 300 * n_cases and stolen_seen == n_cases, (total, stolen_seen)
+    m = ORBmatcher(0.9, True, lib=lib)
+    e = dict(keys=k0[:0], desc=d0[:0])
+    assert m.SearchForInitialization(e, F2, np.zeros((0, 2), 'f4'), 100, CAM)[0] == 0
+    n, mm, pp = m.SearchForInitialization(F1, dict(keys=k1[:0], desc=d1[:0]), pm0, 100, CAM)
+    assert n == 0 and (mm == -1).all() and (pp == pm0).all()
+    far = pm0 + 5000.0                                                           # every window outside the image
+    assert m.SearchForInitialization(F1, F2, far, 100, CAM)[0] == 0 == orc.search_for_initialization(F1, F2, far, 100, CAM)[0]

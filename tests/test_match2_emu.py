@@ -36,3 +36,7 @@ def test_project_sim3_emu(emu, oracle):
 
 def test_search_by_sim3_emu(emu, oracle):
     mc.check_search_by_sim3(emu, oracle, n_cases=2)
+
+
+def test_search_for_initialization_emu(emu, oracle):
+    mc.check_search_for_initialization(emu, oracle, n_cases=2)

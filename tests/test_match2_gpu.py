@@ -39,3 +39,7 @@ def test_project_sim3_gpu(gpulib, oracle):
 
 def test_search_by_sim3_gpu(gpulib, oracle):
     mc.check_search_by_sim3(gpulib, oracle, n_cases=6)
+
+
+def test_search_for_initialization_gpu(gpulib, oracle):
+    mc.check_search_for_initialization(gpulib, oracle, n_cases=4)
