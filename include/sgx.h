@@ -235,6 +235,27 @@ int sgx_match_search_for_initialization(
     int n1, const sgx_keypoint *keys1_un, const uint8_t *desc1, int n2, const sgx_keypoint *keys2_un, const uint8_t *desc2,
     float *prev_matched, int window_size, float nnratio, int check_orientation, const sgx_camera *cam, int32_t *matches12, int32_t *nmatches);
 
+/* ---- Sim3Solver (src/sg-slam/include/Sim3Solver.h:36-130, src/sg-slam/src/Sim3Solver.cc), the RANSAC initialiser of LoopClosing::ComputeSim3 (LoopClosing.cc:274-301) ----
+ * The constructor's flattening stays with the caller (:40-111): for every usable pair (vpMatched12[i1] set, both map points good and indexed in their keyframes)
+ * x3dc1 = Rcw1 * X3D1w + tcw1, x3dc2 = Rcw2 * X3D2w + tcw2 (n x 3 floats), max_err1/2 = 9.210 * mvLevelSigma2[octave] (n floats), K1 / K2 = fx, fy, cx, cy.
+ * create runs FromCameraToImage (:407-425) and SetRansacParameters() with the class defaults (0.99, 6, 300).
+ * iterate(nIterations, bNoMore, vbInliers, nInliers) (:140-208): every iteration of the call is a hypothesis evaluated on the device (three correspondences, Horn's
+ * closed form ComputeSim3 :228-337 in the reference's cv::Mat arithmetic incl. cv::eigen's Jacobi and cv::Rodrigues, CheckInliers :340-365); the sequential accept rule
+ * (>= best so far, return at the first model with more than minInliers inliers) is replayed in iteration order, iterations after a success are not consumed.
+ * Random numbers: the reference calls the process-global rand() (DUtils::Random::RandomInt, Random.cpp:71-74), three times per iteration.  rand_draws = those raw rand()
+ * values (3 x n_iterations; only the first 3 x *iterations_run are consumed — a caller sharing the global stream passes one iteration per call), or NULL: the solver then
+ * uses its own replica of glibc's rand() seeded with rand_seed at creation (srand(rand_seed)).
+ * Outputs: *found = a model was returned (T12 = 4x4 row-major mBestT12, inliers[n] over the n pairs — the caller maps them through mvnIndices1 — *n_inliers);
+ * *no_more = bNoMore.  get_estimate = GetEstimatedRotation / Translation / Scale of the best model so far, and the effective mRansacMaxIts. */
+typedef struct sgx_sim3_solver sgx_sim3_solver;
+int sgx_sim3_solver_create(int n, const float *x3dc1, const float *x3dc2, const float *max_err1, const float *max_err2, const float *K1, const float *K2, int fix_scale,
+                           unsigned rand_seed, sgx_sim3_solver **out);
+int sgx_sim3_solver_set_ransac_parameters(sgx_sim3_solver *s, double probability, int min_inliers, int max_iterations);
+int sgx_sim3_solver_iterate(sgx_sim3_solver *s, int n_iterations, const int32_t *rand_draws, float *T12, int32_t *no_more, uint8_t *inliers, int32_t *n_inliers,
+                            int32_t *found, int32_t *iterations_run);
+int sgx_sim3_solver_get_estimate(const sgx_sim3_solver *s, float *R12, float *t12, float *scale, int32_t *max_iterations);
+void sgx_sim3_solver_destroy(sgx_sim3_solver *s);
+
 /* ---- ORBVocabulary = DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> (src/sg-slam/include/ORBVocabulary.h:31-32) ----------------------------------------------
  * The bag-of-words transform behind Frame::ComputeBoW (src/sg-slam/src/Frame.cc:422-429) and KeyFrame::ComputeBoW (src/sg-slam/src/KeyFrame.cc:60-69):
  *     mpORBvocabulary->transform(vCurrentDesc, mBowVec, mFeatVec, 4)          src/sg-slam/Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1139-1206

@@ -505,3 +505,41 @@ def bow_score_l1(v1, v2):
     i1 = np.ascontiguousarray(v1[0], 'i4'); w1 = np.ascontiguousarray(v1[1], 'f8'); i2 = np.ascontiguousarray(v2[0], 'i4'); w2 = np.ascontiguousarray(v2[1], 'f8')
     Lb = lib(); Lb.orc_bow_score_l1.restype = C.c_double
     return float(Lb.orc_bow_score_l1(C.c_int(len(i1)), _p(i1), _p(w1), C.c_int(len(i2)), _p(i2), _p(w2)))
+
+
+# ---- Sim3Solver (sim3solver_oracle.c) ---------------------------------------------------------------------------------------------------------------------------------
+class Sim3SolverOracle:
+    def __init__(self, x3dc1, x3dc2, max_err1, max_err2, K1, K2, fix_scale=True):
+        a = np.ascontiguousarray(x3dc1, 'f4').reshape(-1, 3); b = np.ascontiguousarray(x3dc2, 'f4').reshape(-1, 3)
+        e1 = np.ascontiguousarray(max_err1, 'f4'); e2 = np.ascontiguousarray(max_err2, 'f4'); k1 = np.ascontiguousarray(K1, 'f4'); k2 = np.ascontiguousarray(K2, 'f4')
+        L = lib(); L.orc_s3_create.restype = C.c_void_p
+        self.N = len(a); self.h = L.orc_s3_create(C.c_int(self.N), _p(a), _p(b), _p(e1), _p(e2), _p(k1), _p(k2), C.c_int(int(bool(fix_scale))))
+
+    def set_ransac_parameters(self, probability=0.99, min_inliers=6, max_iterations=300):
+        lib().orc_s3_set_ransac_parameters(C.c_void_p(self.h), C.c_double(probability), C.c_int(min_inliers), C.c_int(max_iterations))
+
+    def max_iterations(self):
+        L = lib(); L.orc_s3_max_iterations.restype = C.c_int; return int(L.orc_s3_max_iterations(C.c_void_p(self.h)))
+
+    def iterate(self, n_iterations, rand_draws):
+        d = np.ascontiguousarray(rand_draws, 'i4'); T = np.zeros(16, 'f4'); nm = C.c_int(); inl = np.zeros(max(self.N, 1), np.uint8); ni = C.c_int(); run = C.c_int()
+        L = lib(); L.orc_s3_iterate.restype = C.c_int
+        f = L.orc_s3_iterate(C.c_void_p(self.h), C.c_int(n_iterations), _p(d), _p(T), C.byref(nm), _p(inl), C.byref(ni), C.byref(run))
+        return (T.reshape(4, 4) if f else None), bool(nm.value), inl[:self.N].astype(bool), int(ni.value), int(run.value)
+
+    def estimate(self):
+        R = np.zeros(9, 'f4'); t = np.zeros(3, 'f4'); s = C.c_float()
+        lib().orc_s3_best(C.c_void_p(self.h), _p(R), _p(t), C.byref(s)); return R.reshape(3, 3), t, float(s.value)
+
+    def close(self):
+        if self.h: lib().orc_s3_destroy(C.c_void_p(self.h)); self.h = None
+
+
+def glibc_rand_sequence(seed, n):
+    out = np.zeros(max(n, 1), 'i4'); lib().orc_glibc_rand_sequence(C.c_uint(seed), C.c_int(n), _p(out)); return out[:n]
+
+
+def sim3_horn(P1, P2, fix_scale=False):
+    """ComputeSim3 on one triple: P1, P2 = 3 x 3 (column i = point i) -> (R, t, s)"""
+    a = np.ascontiguousarray(P1, 'f4').reshape(9); b = np.ascontiguousarray(P2, 'f4').reshape(9); R = np.zeros(9, 'f4'); t = np.zeros(3, 'f4'); s = C.c_float()
+    lib().orc_s3_compute(_p(a), _p(b), C.c_int(int(bool(fix_scale))), _p(R), _p(t), C.byref(s)); return R.reshape(3, 3), t, float(s.value)

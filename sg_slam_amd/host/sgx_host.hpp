@@ -258,6 +258,31 @@ protected:
     float mfNNratio; bool mbCheckOrientation;
 };
 
+// Sim3Solver (src/sg-slam/include/Sim3Solver.h:36-130): constructed from the flattened usable correspondences (what Sim3Solver.cc:40-111 gathers), then the reference's calls
+class Sim3Solver {
+public:
+    // x3dc1 / x3dc2: n x 3 camera-frame points, maxErr1 / maxErr2: 9.210 * mvLevelSigma2[octave], K = (fx, fy, cx, cy), indices1[i] = the i1 of pair i (mvnIndices1), N1 = vpMatched12.size()
+    Sim3Solver(const std::vector<float> &x3dc1, const std::vector<float> &x3dc2, const std::vector<float> &maxErr1, const std::vector<float> &maxErr2, const float K1[4], const float K2[4],
+               const std::vector<int32_t> &indices1, int N1, bool bFixScale, unsigned randSeed = 0) : idx1_(indices1), N1_(N1), n_((int)maxErr1.size())
+    { check(sgx_sim3_solver_create(n_, x3dc1.data(), x3dc2.data(), maxErr1.data(), maxErr2.data(), K1, K2, bFixScale ? 1 : 0, randSeed, &h_), "sgx_sim3_solver_create"); }
+    ~Sim3Solver() { if (h_) sgx_sim3_solver_destroy(h_); }
+    Sim3Solver(const Sim3Solver &) = delete; Sim3Solver &operator=(const Sim3Solver &) = delete;
+    void SetRansacParameters(double probability = 0.99, int minInliers = 6, int maxIterations = 300) { check(sgx_sim3_solver_set_ransac_parameters(h_, probability, minInliers, maxIterations), "sgx_sim3_solver_set_ransac_parameters"); }
+    // cv::Mat iterate(int nIterations, bool &bNoMore, vector<bool> &vbInliers, int &nInliers): returns true and fills T12 (4x4 row-major) when a model is found.
+    // randDraws (optional): 3 raw rand() values per iteration for callers that share the process-global stream; otherwise the solver's glibc-compatible replica is used.
+    bool iterate(int nIterations, bool &bNoMore, std::vector<bool> &vbInliers, int &nInliers, float T12[16], const std::vector<int32_t> *randDraws = nullptr)
+    {
+        std::vector<uint8_t> inl((size_t)(n_ > 0 ? n_ : 1), 0); int32_t nm = 0, ni = 0, fnd = 0;
+        check(sgx_sim3_solver_iterate(h_, nIterations, randDraws ? randDraws->data() : nullptr, T12, &nm, inl.data(), &ni, &fnd, nullptr), "sgx_sim3_solver_iterate");
+        bNoMore = nm != 0; nInliers = ni; vbInliers.assign((size_t)N1_, false);
+        if (fnd) for (int i = 0; i < n_; i++) if (inl[(size_t)i]) vbInliers[(size_t)idx1_[(size_t)i]] = true;           // vbInliers[mvnIndices1[i]] = true (:196-198)
+        return fnd != 0;
+    }
+    void GetEstimate(float R12[9], float t12[3], float &scale) const { check(sgx_sim3_solver_get_estimate(h_, R12, t12, &scale, nullptr), "sgx_sim3_solver_get_estimate"); }
+private:
+    sgx_sim3_solver *h_ = nullptr; std::vector<int32_t> idx1_; int N1_, n_;
+};
+
 // ORBVocabulary = DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> (src/sg-slam/include/ORBVocabulary.h:31-32): the members the reference calls
 class ORBVocabulary {
 public:
