@@ -32,7 +32,10 @@ struct sgx_sim3_solver {
 extern "C" int sgx_sim3_solver_set_ransac_parameters(sgx_sim3_solver *s, double probability, int min_inliers, int max_iterations)
 {
     if (!s) return SGX_ERR_INVALID;
+    if (!(probability > 0 && probability < 1) || min_inliers < 1 || max_iterations < 1) return SGX_ERR_INVALID;
     s->prob = probability; s->minInliers = min_inliers; s->maxIts = max_iterations;                 // Sim3Solver.cc:113-138
+    s->nIterations = 0;
+    if (s->N <= 0) return SGX_OK;                                 // no correspondences: iterate() reports bNoMore at once (N < minInliers); the reference divides by N here
     const float epsilon = (float)s->minInliers / s->N;
     int nIterations;
     if (s->minInliers == s->N) nIterations = 1;
