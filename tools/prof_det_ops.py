@@ -33,6 +33,7 @@ def report(B, rows):
 
 if len(sys.argv) > 2 and sys.argv[1] == '--reprice':          # re-derive the roofline columns of an existing table (no GPU): prof_det_ops.py --reprice table.txt
     lines = open(sys.argv[2]).read().splitlines()
+    while lines and not lines[0].startswith('detector plan'): lines.pop(0)          # stderr noise of the GPU box ahead of the table
     B = int(re.search(r'batch (\d+)', lines[0]).group(1))
     rows = []
     for l in lines[2:]:
