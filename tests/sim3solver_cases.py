@@ -59,9 +59,10 @@ def check_solver(lib, orc, n_cases=4, exact=True):
                     if exact: assert (gT == eT).all() and (ginl == einl).all() and gni == eni
                     else: assert np.abs(gT - eT).max() <= 2e-5 * max(1.0, np.abs(eT).max()) and (ginl != einl).sum() <= 1 and abs(gni - eni) <= 1
                     assert eni > 20 and einl.sum() == eni
-                    # the model is the generating similarity up to the noise
-                    sR = eT[:3, :3]; assert np.abs(sR - s * R).max() < 0.05 and np.abs(eT[:3, 3] - t).max() < 0.15
-                    assert einl[~bad].mean() > 0.8 and einl[bad].mean() < 0.3
+                    # the model is near the generating similarity (iterate returns at the FIRST model with more than minInliers inliers, so it can be a mediocre one) and its
+                    # inliers are true correspondences
+                    sR = eT[:3, :3]; assert np.abs(sR - s * R).max() < 0.25 and np.abs(eT[:3, 3] - t).max() < 0.6
+                    assert einl[bad].sum() <= 0.1 * eni
                     gR, gt, gs = S.estimate(); eR, et, es = O.estimate()
                     tol = 0 if exact else 2e-5
                     assert np.abs(gR - eR).max() <= tol and np.abs(gt - et).max() <= tol * 10 and abs(gs - es) <= tol
