@@ -89,6 +89,23 @@ int main(int argc, char **argv)
         printf("words %u bow %zu idsum %lld nodesum %lld wsum %.17g self %.17g\n", voc.size(), v.size(), idsum, nodesum, wsum, voc.score(v, v));
         return 0;
     }
-    fprintf(stderr, "usage: %s ba graph.bin | det model.param model.bin frame.raw | flow cur.raw prev.raw pts.bin | sim3 pairs.bin | voc voc.txt desc.bin\n", argv[0]);
+    if (argc >= 3 && !strcmp(argv[1], "s3solver")) {               // Sim3Solver: n, fix, then x3dc1, x3dc2 (n x 3), maxErr1, maxErr2 (n), K1, K2 (4 floats each)
+        const std::vector<uint8_t> b = slurp(argv[2]);
+        const int32_t *hdr = (const int32_t *)b.data(); const int n = hdr[0], fix = hdr[1];
+        const uint8_t *p = b.data() + 8;
+        std::vector<float> x1, x2, e1, e2; float K1[4], K2[4];
+        auto take = [&](std::vector<float> &v, size_t m) { v.resize(m); memcpy(v.data(), p, m * 4); p += m * 4; };
+        take(x1, (size_t)n * 3); take(x2, (size_t)n * 3); take(e1, (size_t)n); take(e2, (size_t)n); memcpy(K1, p, 16); p += 16; memcpy(K2, p, 16);
+        std::vector<int32_t> idx((size_t)n); for (int i = 0; i < n; i++) idx[(size_t)i] = 2 * i;          // pretend every second keypoint of pKF1 carries a usable pair
+        sgx::Sim3Solver solver(x1, x2, e1, e2, K1, K2, idx, 2 * n, fix != 0, 7);
+        solver.SetRansacParameters(0.99, 20, 300);
+        bool bNoMore = false; std::vector<bool> vbInliers; int nInliers = 0, calls = 0; float T12[16]; bool found = false;
+        while (!found && !bNoMore) { found = solver.iterate(5, bNoMore, vbInliers, nInliers, T12); calls++; }     // the loop of LoopClosing::ComputeSim3 (:296-335) for one candidate
+        int marked = 0, odd = 0; for (size_t i = 0; i < vbInliers.size(); i++) { marked += vbInliers[i]; if ((i & 1) && vbInliers[i]) odd++; }
+        printf("found %d calls %d inliers %d marked %d odd %d\n", (int)found, calls, nInliers, marked, odd);
+        printf("T12"); for (int i = 0; i < 16; i++) printf(" %.9g", found ? T12[i] : 0.f); printf("\n");
+        return 0;
+    }
+    fprintf(stderr, "usage: %s ba graph.bin | det model.param model.bin frame.raw | flow cur.raw prev.raw pts.bin | sim3 pairs.bin | voc voc.txt desc.bin | s3solver pairs.bin\n", argv[0]);
     return 2;
 }

@@ -153,3 +153,23 @@ def test_cpp_vocabulary_matches_python_mirror(gpulib, oracle, tmp_path):
     assert int(out[1]) == V.size() and int(out[3]) == len(ids) and int(out[5]) == int(ids.astype('i8').sum()) and int(out[7]) == int(fn.astype('i8').sum())
     assert float(out[9]) == float(np.sum(w[np.arange(len(w))].tolist())) or abs(float(out[9]) - 1.0) < 1e-12
     assert abs(float(out[11]) - 1.0) < 1e-12
+
+
+def test_cpp_sim3_solver_matches_python_mirror(gpulib, oracle, tmp_path):
+    """sgx::Sim3Solver (C++ mirror): the iterate(5) loop of LoopClosing::ComputeSim3 with the solver's own rand() replica — same call count, inliers and T12 as the Python mirror."""
+    import sim3solver_cases as sc
+    from sg_slam_amd.sim3solver import Sim3Solver
+    X1, X2, e1, e2, R, t, s, bad = sc.make_pairs(41, 180, 0.35)
+    f = tmp_path / 'pairs.bin'
+    with open(f, 'wb') as fh:
+        fh.write(np.array([len(X1), 1], 'i4').tobytes())
+        for a in (X1, X2, e1, e2, sc.K, sc.K): fh.write(np.ascontiguousarray(a, 'f4').tobytes())
+    out = subprocess.check_output([_exe('example_backend'), 's3solver', str(f)], text=True).splitlines()
+    S = Sim3Solver(X1, X2, e1, e2, sc.K, sc.K, True, rand_seed=7, lib=gpulib); S.SetRansacParameters(0.99, 20, 300)
+    calls = 0; T = None; nm = False
+    while T is None and not nm:
+        T, nm, inl, ni, run = S.iterate(5); calls += 1
+    v = out[0].split()
+    assert int(v[1]) == int(T is not None) and int(v[3]) == calls and int(v[5]) == ni and int(v[7]) == int(inl.sum()) and int(v[9]) == 0
+    if T is not None:
+        assert np.abs(np.array([float(x) for x in out[1].split()[1:]], 'f4').reshape(4, 4) - T).max() == 0
