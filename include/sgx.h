@@ -235,6 +235,19 @@ int sgx_match_search_for_initialization(
     int n1, const sgx_keypoint *keys1_un, const uint8_t *desc1, int n2, const sgx_keypoint *keys2_un, const uint8_t *desc2,
     float *prev_matched, int window_size, float nnratio, int check_orientation, const sgx_camera *cam, int32_t *matches12, int32_t *nmatches);
 
+/* ---- MapPoint post-steps of the optimisers and of map-point creation, batched over points (host pointers, synchronous) -----------------------------------------------
+ * Observations of point p = entries obs_start[p] .. obs_start[p + 1] - 1, IN THE ORDER THE REFERENCE WALKS mObservations (a std::map keyed by KeyFrame*: the float sums
+ * below depend on it; the caller flattens in that order).
+ * void MapPoint::UpdateNormalAndDepth() (src/sg-slam/src/MapPoint.cc:330-371; callers Optimizer.cc:227,776,1042 — the last statement of BundleAdjustment / LocalBundleAdjustment /
+ * OptimizeEssentialGraph per point — LocalMapping.cc:152,444,527, Tracking.cc:572,708,1234): obs_center = GetCameraCenter() of every observing keyframe, ref_center /
+ * ref_level = mpRefKF's camera centre and the octave of the point's keypoint in it.  normal / min_dist / max_dist (in/out) = mNormalVector, mfMinDistance, mfMaxDistance;
+ * a point without observations keeps its values (:345-346). */
+int sgx_mappoint_update_normal_and_depth(int n, const float *xw, const int32_t *obs_start, const float *obs_center, const float *ref_center, const int32_t *ref_level,
+                                         const float *scale_factors, int nlevels, float *normal, float *min_dist, float *max_dist);
+/* void MapPoint::ComputeDistinctiveDescriptors() (MapPoint.cc:242-307): obs_desc = the observed descriptor rows (keyframes that are not bad).  best[p] = index within the
+ * point's list of the descriptor with the least median Hamming distance to the others (first on ties), -1 for an empty list; desc_out (optional, n x 32) = that row. */
+int sgx_mappoint_distinctive_descriptors(int n, const int32_t *obs_start, const uint8_t *obs_desc, int32_t *best, uint8_t *desc_out);
+
 /* ---- Sim3Solver (src/sg-slam/include/Sim3Solver.h:36-130, src/sg-slam/src/Sim3Solver.cc), the RANSAC initialiser of LoopClosing::ComputeSim3 (LoopClosing.cc:274-301) ----
  * The constructor's flattening stays with the caller (:40-111): for every usable pair (vpMatched12[i1] set, both map points good and indexed in their keyframes)
  * x3dc1 = Rcw1 * X3D1w + tcw1, x3dc2 = Rcw2 * X3D2w + tcw2 (n x 3 floats), max_err1/2 = 9.210 * mvLevelSigma2[octave] (n floats), K1 / K2 = fx, fy, cx, cy.

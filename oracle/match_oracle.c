@@ -854,3 +854,52 @@ int orc_search_for_initialization(int N1, const orc_keypoint *k1, const uint8_t 
     grid_free(g); free(g); free(vind); free(dist2); free(m21);
     return nmatches;
 }
+
+/* ---- MapPoint post-steps of the optimisers and of map-point creation ---------------------------------------------------------------------------------------------
+ * void MapPoint::UpdateNormalAndDepth() (src/sg-slam/src/MapPoint.cc:330-371; callers Optimizer.cc:227,776,1042, LocalMapping.cc:152,444,527, Tracking.cc:572,708,1234) for n
+ * points: obs_start = CSR over the observations of every point IN THE ORDER THE REFERENCE WALKS mObservations (a std::map keyed by KeyFrame*: pointer order — the caller
+ * supplies it), obs_center = GetCameraCenter() of each observing keyframe, ref_center / ref_level = the reference keyframe's camera centre and the octave of the point's
+ * keypoint in it.  A point without observations keeps its values (the function returns early, :345-346). */
+void orc_update_normal_and_depth(int n, const float *xw, const int *obs_start, const float *obs_center, const float *ref_center, const int *ref_level,
+                                 const float *scale_factors, int nlevels, float *normal, float *min_dist, float *max_dist)
+{
+    for (int p = 0; p < n; p++) {
+        const int s = obs_start[p], e = obs_start[p + 1];
+        if (e <= s) continue;
+        const float *P = xw + 3 * p;
+        float nrm[3] = { 0.f, 0.f, 0.f };
+        for (int q = s; q < e; q++) {
+            const float d[3] = { P[0] - obs_center[3 * q], P[1] - obs_center[3 * q + 1], P[2] - obs_center[3 * q + 2] };          /* normali = mWorldPos - Owi */
+            const double len = sqrt((double)d[0] * d[0] + (double)d[1] * d[1] + (double)d[2] * d[2]);                                /* cv::norm */
+            const float inv = (float)(1.0 / len);                                                                                   /* normali / norm: convertTo by the float of 1/norm */
+            for (int k = 0; k < 3; k++) nrm[k] = nrm[k] + d[k] * inv;
+        }
+        const float pc[3] = { P[0] - ref_center[3 * p], P[1] - ref_center[3 * p + 1], P[2] - ref_center[3 * p + 2] };
+        const float dist = (float)sqrt((double)pc[0] * pc[0] + (double)pc[1] * pc[1] + (double)pc[2] * pc[2]);
+        max_dist[p] = dist * scale_factors[ref_level[p]];
+        min_dist[p] = max_dist[p] / scale_factors[nlevels - 1];
+        const float invn = (float)(1.0 / (double)(e - s));                                                                          /* normal / n */
+        for (int k = 0; k < 3; k++) normal[3 * p + k] = nrm[k] * invn;
+    }
+}
+
+/* void MapPoint::ComputeDistinctiveDescriptors() (MapPoint.cc:242-307) for n points: obs_desc = the observed descriptor rows (keyframes that are not bad), in mObservations
+ * order.  best[p] = index (within the point's list) of the descriptor with the least median distance to the others, -1 for an empty list (early return, :269-270). */
+void orc_distinctive_descriptors(int n, const int *obs_start, const uint8_t *obs_desc, int *best)
+{
+    for (int p = 0; p < n; p++) {
+        const int s = obs_start[p], N = obs_start[p + 1] - s;
+        best[p] = -1;
+        if (N <= 0) continue;
+        int *row = (int *)malloc(sizeof(int) * (size_t)N);
+        int BestMedian = INT_MAX, BestIdx = 0;
+        for (int i = 0; i < N; i++) {
+            for (int j = 0; j < N; j++) row[j] = i == j ? 0 : orc_descriptor_distance(obs_desc + 32 * (size_t)(s + i), obs_desc + 32 * (size_t)(s + j));
+            for (int a = 1; a < N; a++) { const int v = row[a]; int b = a - 1; while (b >= 0 && row[b] > v) { row[b + 1] = row[b]; b--; } row[b + 1] = v; }        /* sort */
+            const int median = row[(int)(0.5 * (N - 1))];
+            if (median < BestMedian) { BestMedian = median; BestIdx = i; }
+        }
+        best[p] = BestIdx;
+        free(row);
+    }
+}

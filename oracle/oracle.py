@@ -543,3 +543,19 @@ def sim3_horn(P1, P2, fix_scale=False):
     """ComputeSim3 on one triple: P1, P2 = 3 x 3 (column i = point i) -> (R, t, s)"""
     a = np.ascontiguousarray(P1, 'f4').reshape(9); b = np.ascontiguousarray(P2, 'f4').reshape(9); R = np.zeros(9, 'f4'); t = np.zeros(3, 'f4'); s = C.c_float()
     lib().orc_s3_compute(_p(a), _p(b), C.c_int(int(bool(fix_scale))), _p(R), _p(t), C.byref(s)); return R.reshape(3, 3), t, float(s.value)
+
+
+def update_normal_and_depth(xw, obs_start, obs_center, ref_center, ref_level, scale_factors, normal, min_dist, max_dist):
+    xw = np.ascontiguousarray(xw, 'f4').reshape(-1, 3); n = len(xw)
+    st = np.ascontiguousarray(obs_start, 'i4'); oc = np.ascontiguousarray(obs_center, 'f4').reshape(-1, 3); rc = np.ascontiguousarray(ref_center, 'f4').reshape(-1, 3)
+    rl = np.ascontiguousarray(ref_level, 'i4'); sf = np.ascontiguousarray(scale_factors, 'f4')
+    nr = np.ascontiguousarray(normal, 'f4').reshape(-1, 3).copy(); mn = np.ascontiguousarray(min_dist, 'f4').copy(); mx = np.ascontiguousarray(max_dist, 'f4').copy()
+    lib().orc_update_normal_and_depth(C.c_int(n), _p(xw), _p(st), _p(oc), _p(rc), _p(rl), _p(sf), C.c_int(len(sf)), _p(nr), _p(mn), _p(mx))
+    return nr, mn, mx
+
+
+def distinctive_descriptors(obs_start, obs_desc):
+    st = np.ascontiguousarray(obs_start, 'i4'); n = len(st) - 1; d = np.ascontiguousarray(obs_desc, np.uint8).reshape(-1, 32)
+    best = np.full(max(n, 1), -1, 'i4')
+    lib().orc_distinctive_descriptors(C.c_int(n), _p(st), _p(d), _p(best))
+    return best[:n].copy()

@@ -456,3 +456,43 @@ extern "C" int sgx_match_search_for_initialization(
     SGX_CHECK_HIP(hipMemcpy(nmatches, A.nmatches, 4, hipMemcpyDeviceToHost));
     return SGX_OK;
 }
+
+// ---- MapPoint post-steps (MapPoint.cc:242-307, :330-371), batched over points; host pointers, synchronous ------------------------------------------------------------
+extern "C" int sgx_mappoint_update_normal_and_depth(int n, const float *xw, const int32_t *obs_start, const float *obs_center, const float *ref_center, const int32_t *ref_level,
+                                                    const float *scale_factors, int nlevels, float *normal, float *min_dist, float *max_dist)
+{
+    if (n < 0 || nlevels < 1 || nlevels > 12 || !scale_factors || (n > 0 && (!xw || !obs_start || !ref_center || !ref_level || !normal || !min_dist || !max_dist))) return SGX_ERR_INVALID;
+    if (n == 0) return SGX_OK;
+    const int total = obs_start[n];
+    if (total < 0 || (total > 0 && !obs_center)) return SGX_ERR_INVALID;
+    for (int p = 0; p < n; p++) if (obs_start[p] > obs_start[p + 1] || ref_level[p] < 0 || ref_level[p] >= nlevels) return SGX_ERR_INVALID;
+    SgxScales sc; memset(&sc, 0, sizeof sc); for (int i = 0; i < nlevels; i++) sc.s[i] = scale_factors[i];
+    SgxStaged b[8]; int rc;
+#define PUT(k, src, bytes) if ((rc = b[k].put(k, src, bytes)) != SGX_OK) return rc
+    PUT(0, xw, (size_t)n * 12); PUT(1, obs_start, ((size_t)n + 1) * 4); PUT(2, obs_center, (size_t)total * 12); PUT(3, ref_center, (size_t)n * 12); PUT(4, ref_level, (size_t)n * 4);
+    PUT(5, normal, (size_t)n * 12); PUT(6, min_dist, (size_t)n * 4); PUT(7, max_dist, (size_t)n * 4);          // points without observations keep the caller's values
+#undef PUT
+    SGX_LAUNCH(k_mappoint_normal_depth, dim3((n + 255) / 256), dim3(256), (sgx_stream_t)0, n, (const float *)b[0].p, (const int *)b[1].p, (const float *)b[2].p, (const float *)b[3].p,
+               (const int *)b[4].p, sc, nlevels, (float *)b[5].p, (float *)b[6].p, (float *)b[7].p);
+    SGX_CHECK_HIP(hipGetLastError());
+    SGX_CHECK_HIP(hipMemcpy(normal, b[5].p, (size_t)n * 12, hipMemcpyDeviceToHost));
+    SGX_CHECK_HIP(hipMemcpy(min_dist, b[6].p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    SGX_CHECK_HIP(hipMemcpy(max_dist, b[7].p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return SGX_OK;
+}
+
+extern "C" int sgx_mappoint_distinctive_descriptors(int n, const int32_t *obs_start, const uint8_t *obs_desc, int32_t *best, uint8_t *desc_out)
+{
+    if (n < 0 || (n > 0 && (!obs_start || !best))) return SGX_ERR_INVALID;
+    if (n == 0) return SGX_OK;
+    const int total = obs_start[n];
+    if (total < 0 || (total > 0 && !obs_desc)) return SGX_ERR_INVALID;
+    for (int p = 0; p < n; p++) if (obs_start[p] > obs_start[p + 1] || obs_start[p + 1] - obs_start[p] > 65535) return SGX_ERR_INVALID;
+    SgxStaged b[3]; int rc;
+    if ((rc = b[0].put(0, obs_start, ((size_t)n + 1) * 4)) != SGX_OK || (rc = b[1].put(1, obs_desc, (size_t)total * 32)) != SGX_OK || (rc = b[2].put(2, nullptr, (size_t)n * 4)) != SGX_OK) return rc;
+    SGX_LAUNCH(k_mappoint_distinctive, dim3(n), dim3(64), (sgx_stream_t)0, n, (const int *)b[0].p, (const uint32_t *)b[1].p, (int *)b[2].p);
+    SGX_CHECK_HIP(hipGetLastError());
+    SGX_CHECK_HIP(hipMemcpy(best, b[2].p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (desc_out) for (int p = 0; p < n; p++) if (best[p] >= 0) memcpy(desc_out + 32 * (size_t)p, obs_desc + 32 * (size_t)(obs_start[p] + best[p]), 32);      // mDescriptor = vDescriptors[BestIdx].clone()
+    return SGX_OK;
+}

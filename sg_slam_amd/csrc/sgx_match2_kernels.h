@@ -703,3 +703,70 @@ SGX_KERNEL(256) k_search_initialization(SgxInitSearchArgs A)
     if (tid == 0) *A.nmatches = s_total;
     SGX_THREADS_END
 }
+
+// ---------------------------------------------------------------------------------------------
+// MapPoint post-steps of the optimisers and of map-point creation, batched over points:
+//   k_mappoint_normal_depth   MapPoint::UpdateNormalAndDepth  (src/sg-slam/src/MapPoint.cc:330-371; Optimizer.cc:227,776,1042, LocalMapping.cc:152,444,527, Tracking.cc:1234)
+//   k_mappoint_distinctive    MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:242-307)
+// Observations arrive as CSR in the order the reference walks mObservations (its float sums are order dependent).
+// ---------------------------------------------------------------------------------------------
+SGX_KERNEL(256) k_mappoint_normal_depth(int n, const float *xw, const int *obs_start, const float *obs_center, const float *ref_center, const int *ref_level,
+                                        SgxScales scale, int nlevels, float *normal, float *min_dist, float *max_dist)
+{
+    SGX_THREADS_BEGIN(tid)
+    const int p = (int)blockIdx.x * 256 + tid;
+    if (p < n) {
+        const int s = obs_start[p], e = obs_start[p + 1];
+        if (e > s) {
+            const float *P = xw + 3 * (size_t)p;
+            float n0 = 0.f, n1 = 0.f, n2 = 0.f;
+            for (int q = s; q < e; q++) {
+                const float d0 = P[0] - obs_center[3 * (size_t)q], d1 = P[1] - obs_center[3 * (size_t)q + 1], d2 = P[2] - obs_center[3 * (size_t)q + 2];
+                const double len = sqrt((double)d0 * d0 + (double)d1 * d1 + (double)d2 * d2);
+                const float inv = (float)(1.0 / len);
+                n0 = n0 + d0 * inv; n1 = n1 + d1 * inv; n2 = n2 + d2 * inv;
+            }
+            const float c0 = P[0] - ref_center[3 * (size_t)p], c1 = P[1] - ref_center[3 * (size_t)p + 1], c2 = P[2] - ref_center[3 * (size_t)p + 2];
+            const float dist = (float)sqrt((double)c0 * c0 + (double)c1 * c1 + (double)c2 * c2);
+            const float mx = dist * scale.s[ref_level[p]];
+            max_dist[p] = mx; min_dist[p] = mx / scale.s[nlevels - 1];
+            const float invn = (float)(1.0 / (double)(e - s));
+            normal[3 * (size_t)p] = n0 * invn; normal[3 * (size_t)p + 1] = n1 * invn; normal[3 * (size_t)p + 2] = n2 * invn;
+        }
+    }
+    SGX_THREADS_END
+}
+
+// One workgroup (64 threads) per point; thread i owns row i of the N x N distance matrix (rows beyond 64 in further rounds).  The median of a row = element
+// (int)(0.5 * (N - 1)) of the sorted row = the smallest v with count(d <= v) > k: nine bisection steps over the 257 possible distances, distances recomputed
+// (no N x N storage).  The row with the least median wins, the first one on ties (strict '<' in row order): LDS atomic min on median << 16 | row.
+SGX_KERNEL(64) k_mappoint_distinctive(int n, const int *obs_start, const uint32_t *obs_desc, int *best)
+{
+    SGX_LDS int s_key;
+    const int p = (int)blockIdx.x;
+    const int s = obs_start[p], N = obs_start[p + 1] - s;
+    SGX_THREADS_BEGIN(tid)
+    if (tid == 0) s_key = 0x7FFFFFFF;
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    const int k = (int)(0.5 * (double)(N - 1));
+    for (int i = tid; i < N; i += 64) {
+        uint32_t di[8];
+#pragma unroll
+        for (int w = 0; w < 8; w++) di[w] = obs_desc[(size_t)(s + i) * 8 + w];
+        int lo = 0, hi = 256;                                          // smallest v in [0, 256] with count(d <= v) >= k + 1
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            int cnt = 0;
+            for (int j = 0; j < N; j++) cnt += (i == j ? 0 : sgx_hamming256(di, obs_desc + (size_t)(s + j) * 8)) <= mid ? 1 : 0;
+            if (cnt >= k + 1) hi = mid; else lo = mid + 1;
+        }
+        sgx_atomic_min_i32(&s_key, (lo << 16) | i);
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    if (tid == 0) best[p] = N > 0 ? (s_key & 0xFFFF) : -1;
+    SGX_THREADS_END
+}
