@@ -235,6 +235,19 @@ int sgx_match_search_for_initialization(
     int n1, const sgx_keypoint *keys1_un, const uint8_t *desc1, int n2, const sgx_keypoint *keys2_un, const uint8_t *desc2,
     float *prev_matched, int window_size, float nnratio, int check_orientation, const sgx_camera *cam, int32_t *matches12, int32_t *nmatches);
 
+/* The per-pair body of void LocalMapping::CreateNewMapPoints() (src/sg-slam/src/LocalMapping.cc:283-421) for the pairs sgx_match_search_for_triangulation returned for
+ * (mpCurrentKeyFrame, pKF2): parallax test (:300-317), linear triangulation by cv::SVD::compute on the 4 x 4 system (:320-338) or the stereo unprojection of the side with
+ * the larger parallax (:340-349), positive depth in both keyframes (:353-360), the chi-square reprojection gates (:362-406: 5.991 mono, 7.8 stereo, times mvLevelSigma2) and
+ * the scale-consistency gate (:408-423).  keys*_un = mvKeysUn, keys* = mvKeys (KeyFrame::UnprojectStereo reads those, KeyFrame.cc:621-622; the same array when the camera
+ * has no distortion), uright* = mvuRight, depth* = mvDepth, Tcw* = GetPose() (4x4 row-major); cam: fx, fy, cx, cy, bf.  ok[q] = 1 and x3d[q] = the new map point of pair q;
+ * the map mutations (:425-442: new MapPoint, AddObservation, ComputeDistinctiveDescriptors, UpdateNormalAndDepth ...) stay with the caller.  *nnew = number of ok pairs.
+ * Divergence: where the reference would dereference the empty Mat of UnprojectStereo (depth <= 0 on the chosen stereo side) the pair is rejected. */
+int sgx_triangulate_new_map_points(
+    int npairs, const int32_t *pairs,
+    int n1, const sgx_keypoint *keys1_un, const sgx_keypoint *keys1, const float *uright1, const float *depth1, const float *Tcw1,
+    int n2, const sgx_keypoint *keys2_un, const sgx_keypoint *keys2, const float *uright2, const float *depth2, const float *Tcw2,
+    const sgx_camera *cam, const float *scale_factors, const float *level_sigma2, int nlevels, uint8_t *ok, float *x3d, int32_t *nnew);
+
 /* ---- MapPoint post-steps of the optimisers and of map-point creation, batched over points (host pointers, synchronous) -----------------------------------------------
  * Observations of point p = entries obs_start[p] .. obs_start[p + 1] - 1, IN THE ORDER THE REFERENCE WALKS mObservations (a std::map keyed by KeyFrame*: the float sums
  * below depend on it; the caller flattens in that order).

@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <limits.h>
+#include <float.h>
 
 typedef struct { float x, y, size, angle, response; int octave, class_id; } orc_keypoint;
 
@@ -902,4 +903,127 @@ void orc_distinctive_descriptors(int n, const int *obs_start, const uint8_t *obs
         best[p] = BestIdx;
         free(row);
     }
+}
+
+/* ---- the triangulation step of LocalMapping::CreateNewMapPoints (src/sg-slam/src/LocalMapping.cc:283-421) for the pairs SearchForTriangulation returned -----------
+ * cv::SVD::compute(A, w, u, vt, MODIFY_A | FULL_UV) on the 4 x 4 float matrix = OpenCV's one-sided Jacobi (JacobiSVDImpl_<float> on A^T, lapack.cpp) when OpenCV is built
+ * without LAPACK: rows of A^T are rotated pairwise until orthogonal, singular values sorted descending, vt.row(3) = the direction of the smallest one. */
+static void jacobi_svd4_vt(const float *A /* 4x4 row-major */, float *vt_row3)
+{
+    const int n = 4, m = 4; const float eps = FLT_EPSILON * 2;       /* JacobiSVD(float*): JacobiSVDImpl_(..., FLT_MIN, FLT_EPSILON * 2) */
+    float At[16], Vt[16]; double W[4];
+    for (int i = 0; i < 4; i++) for (int k = 0; k < 4; k++) At[4 * i + k] = A[4 * k + i];
+    for (int i = 0; i < n; i++) { double sd = 0; for (int k = 0; k < m; k++) { const float t = At[4 * i + k]; sd += (double)t * t; } W[i] = sd; for (int k = 0; k < n; k++) Vt[4 * i + k] = i == k ? 1.f : 0.f; }
+    const int max_iter = 30;                                         /* max(m, 30) */
+    for (int iter = 0; iter < max_iter; iter++) {
+        int changed = 0;
+        for (int i = 0; i < n - 1; i++)
+            for (int j = i + 1; j < n; j++) {
+                float *Ai = At + 4 * i, *Aj = At + 4 * j;
+                double a = W[i], p = 0, b = W[j];
+                for (int k = 0; k < m; k++) p += (double)Ai[k] * Aj[k];
+                if (fabs(p) <= eps * sqrt(a * b)) continue;
+                p *= 2;
+                const double beta = a - b, gamma = hypot(p, beta);
+                float c, s;
+                if (beta < 0) { const double delta = (gamma - beta) * 0.5; s = (float)sqrt(delta / gamma); c = (float)(p / (gamma * s * 2)); }
+                else { c = (float)sqrt((gamma + beta) / (gamma * 2)); s = (float)(p / (gamma * c * 2)); }
+                a = b = 0;
+                for (int k = 0; k < m; k++) { const float t0 = c * Ai[k] + s * Aj[k], t1 = -s * Ai[k] + c * Aj[k]; Ai[k] = t0; Aj[k] = t1; a += (double)t0 * t0; b += (double)t1 * t1; }
+                W[i] = a; W[j] = b; changed = 1;
+                float *Vi = Vt + 4 * i, *Vj = Vt + 4 * j;
+                for (int k = 0; k < n; k++) { const float t0 = c * Vi[k] + s * Vj[k], t1 = -s * Vi[k] + c * Vj[k]; Vi[k] = t0; Vj[k] = t1; }
+            }
+        if (!changed) break;
+    }
+    for (int i = 0; i < n; i++) { double sd = 0; for (int k = 0; k < m; k++) { const float t = At[4 * i + k]; sd += (double)t * t; } W[i] = sqrt(sd); }
+    for (int i = 0; i < n - 1; i++) {
+        int j = i;
+        for (int k = i + 1; k < n; k++) if (W[j] < W[k]) j = k;
+        if (i != j) { const double tw = W[i]; W[i] = W[j]; W[j] = tw; for (int k = 0; k < 4; k++) { float t = At[4 * i + k]; At[4 * i + k] = At[4 * j + k]; At[4 * j + k] = t; t = Vt[4 * i + k]; Vt[4 * i + k] = Vt[4 * j + k]; Vt[4 * j + k] = t; } }
+    }
+    for (int k = 0; k < 4; k++) vt_row3[k] = Vt[12 + k];
+}
+
+static double dot3d(const float *a, const float *b) { double r = 0; for (int i = 0; i < 3; i++) r += (double)a[i] * b[i]; return r; }      /* Mat::dot, 3 elements */
+
+/* keys*_un = mvKeysUn, keys* = mvKeys (KeyFrame::UnprojectStereo reads the distorted ones, KeyFrame.cc:621-622), uright = mvuRight, depth = mvDepth; cam = fx, fy, cx, cy, mbf
+ * (invfx = 1.0f / fx, mb = mbf / fx as Frame.cc:117-123 sets them).  ok[i] = 1 and x3d[i] = the new map point's position when pair i passes every gate. */
+int orc_triangulate_pairs(int npairs, const int *pairs, const orc_keypoint *k1un, const orc_keypoint *k1, const float *ur1, const float *dp1, const float *Tcw1,
+                          const orc_keypoint *k2un, const orc_keypoint *k2, const float *ur2, const float *dp2, const float *Tcw2,
+                          float fx, float fy, float cx, float cy, float mbf, const float *scale_factors, const float *level_sigma2, float scale_factor, uint8_t *ok, float *x3d)
+{
+    const float invfx = 1.0f / fx, invfy = 1.0f / fy, mb = mbf / fx;
+    float Rcw1[3][3], tcw1[3], Rwc1[3][3], Ow1[3], Rcw2[3][3], tcw2[3], Rwc2[3][3], Ow2[3];
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) { Rcw1[r][c] = Tcw1[4 * r + c]; Rcw2[r][c] = Tcw2[4 * r + c]; Rwc1[c][r] = Tcw1[4 * r + c]; Rwc2[c][r] = Tcw2[4 * r + c]; } tcw1[r] = Tcw1[4 * r + 3]; tcw2[r] = Tcw2[4 * r + 3]; }
+    for (int i = 0; i < 3; i++) {                                    /* Ow = -Rcw.t() * tcw (KeyFrame::SetPose): transpose flag -> double accumulation, alpha = -1 */
+        double a = 0, b = 0; for (int k = 0; k < 3; k++) { a += (double)Rcw1[k][i] * tcw1[k]; b += (double)Rcw2[k][i] * tcw2[k]; }
+        Ow1[i] = (float)(a * -1.0); Ow2[i] = (float)(b * -1.0);
+    }
+    const float ratioFactor = 1.5f * scale_factor;
+    int nnew = 0;
+    for (int q = 0; q < npairs; q++) {
+        ok[q] = 0; x3d[3 * q] = x3d[3 * q + 1] = x3d[3 * q + 2] = 0;
+        const int idx1 = pairs[2 * q], idx2 = pairs[2 * q + 1];
+        const orc_keypoint *kp1 = &k1un[idx1], *kp2 = &k2un[idx2];
+        const float kp1_ur = ur1[idx1], kp2_ur = ur2[idx2];
+        const int bStereo1 = kp1_ur >= 0, bStereo2 = kp2_ur >= 0;
+        const float xn1[3] = { (kp1->x - cx) * invfx, (kp1->y - cy) * invfy, 1.0f }, xn2[3] = { (kp2->x - cx) * invfx, (kp2->y - cy) * invfy, 1.0f };
+        const float ray1[3] = { gemm3(Rwc1[0], xn1, 1.0, 0.0, 0.f), gemm3(Rwc1[1], xn1, 1.0, 0.0, 0.f), gemm3(Rwc1[2], xn1, 1.0, 0.0, 0.f) };
+        const float ray2[3] = { gemm3(Rwc2[0], xn2, 1.0, 0.0, 0.f), gemm3(Rwc2[1], xn2, 1.0, 0.0, 0.f), gemm3(Rwc2[2], xn2, 1.0, 0.0, 0.f) };
+        const float cosParallaxRays = (float)(dot3d(ray1, ray2) / (sqrt(dot3d(ray1, ray1)) * sqrt(dot3d(ray2, ray2))));
+        float cosParallaxStereo = cosParallaxRays + 1, cosParallaxStereo1 = cosParallaxStereo, cosParallaxStereo2 = cosParallaxStereo;
+        if (bStereo1) cosParallaxStereo1 = cosf(2 * atan2f(mb / 2, dp1[idx1]));
+        else if (bStereo2) cosParallaxStereo2 = cosf(2 * atan2f(mb / 2, dp2[idx2]));
+        cosParallaxStereo = cosParallaxStereo1 < cosParallaxStereo2 ? cosParallaxStereo1 : cosParallaxStereo2;
+        float X[3];
+        if (cosParallaxRays < cosParallaxStereo && cosParallaxRays > 0 && (bStereo1 || bStereo2 || cosParallaxRays < 0.9998)) {
+            float A[16], v[4];
+            for (int k = 0; k < 4; k++) {
+                A[k] = xn1[0] * Tcw1[8 + k] - Tcw1[k]; A[4 + k] = xn1[1] * Tcw1[8 + k] - Tcw1[4 + k];
+                A[8 + k] = xn2[0] * Tcw2[8 + k] - Tcw2[k]; A[12 + k] = xn2[1] * Tcw2[8 + k] - Tcw2[4 + k];
+            }
+            jacobi_svd4_vt(A, v);
+            if (v[3] == 0) continue;
+            const float inv = (float)(1.0 / (double)v[3]);
+            X[0] = v[0] * inv; X[1] = v[1] * inv; X[2] = v[2] * inv;
+        } else if (bStereo1 && cosParallaxStereo1 < cosParallaxStereo2) {
+            const float z = dp1[idx1];
+            if (!(z > 0)) continue;                                  /* UnprojectStereo returns an empty Mat: the reference would fault on x3D.t(); treated as rejected */
+            const float xc[3] = { (k1[idx1].x - cx) * z * invfx, (k1[idx1].y - cy) * z * invfy, z };
+            for (int i = 0; i < 3; i++) X[i] = gemm3(Rwc1[i], xc, 1.0, 1.0, Ow1[i]);
+        } else if (bStereo2 && cosParallaxStereo2 < cosParallaxStereo1) {
+            const float z = dp2[idx2];
+            if (!(z > 0)) continue;
+            const float xc[3] = { (k2[idx2].x - cx) * z * invfx, (k2[idx2].y - cy) * z * invfy, z };
+            for (int i = 0; i < 3; i++) X[i] = gemm3(Rwc2[i], xc, 1.0, 1.0, Ow2[i]);
+        } else continue;
+        const float z1 = (float)(dot3d(Rcw1[2], X) + tcw1[2]);
+        if (z1 <= 0) continue;
+        const float z2 = (float)(dot3d(Rcw2[2], X) + tcw2[2]);
+        if (z2 <= 0) continue;
+        const float s1 = level_sigma2[kp1->octave];
+        const float x1 = (float)(dot3d(Rcw1[0], X) + tcw1[0]), y1 = (float)(dot3d(Rcw1[1], X) + tcw1[1]);
+        const float invz1 = (float)(1.0 / z1);
+        {
+            const float u1 = fx * x1 * invz1 + cx, v1 = fy * y1 * invz1 + cy, eX = u1 - kp1->x, eY = v1 - kp1->y;
+            if (!bStereo1) { if ((eX * eX + eY * eY) > 5.991 * s1) continue; }
+            else { const float u1r = u1 - mbf * invz1, eR = u1r - kp1_ur; if ((eX * eX + eY * eY + eR * eR) > 7.8 * s1) continue; }
+        }
+        const float s2 = level_sigma2[kp2->octave];
+        const float x2 = (float)(dot3d(Rcw2[0], X) + tcw2[0]), y2 = (float)(dot3d(Rcw2[1], X) + tcw2[1]);
+        const float invz2 = (float)(1.0 / z2);
+        {
+            const float u2 = fx * x2 * invz2 + cx, v2 = fy * y2 * invz2 + cy, eX = u2 - kp2->x, eY = v2 - kp2->y;
+            if (!bStereo2) { if ((eX * eX + eY * eY) > 5.991 * s2) continue; }
+            else { const float u2r = u2 - mbf * invz2, eR = u2r - kp2_ur; if ((eX * eX + eY * eY + eR * eR) > 7.8 * s2) continue; }
+        }
+        const float n1[3] = { X[0] - Ow1[0], X[1] - Ow1[1], X[2] - Ow1[2] }, n2[3] = { X[0] - Ow2[0], X[1] - Ow2[1], X[2] - Ow2[2] };
+        const float dist1 = (float)sqrt(dot3d(n1, n1)), dist2 = (float)sqrt(dot3d(n2, n2));
+        if (dist1 == 0 || dist2 == 0) continue;
+        const float ratioDist = dist2 / dist1, ratioOctave = scale_factors[kp1->octave] / scale_factors[kp2->octave];
+        if (ratioDist * ratioFactor < ratioOctave || ratioDist > ratioOctave * ratioFactor) continue;
+        ok[q] = 1; x3d[3 * q] = X[0]; x3d[3 * q + 1] = X[1]; x3d[3 * q + 2] = X[2]; nnew++;
+    }
+    return nnew;
 }

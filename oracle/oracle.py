@@ -559,3 +559,16 @@ def distinctive_descriptors(obs_start, obs_desc):
     best = np.full(max(n, 1), -1, 'i4')
     lib().orc_distinctive_descriptors(C.c_int(n), _p(st), _p(d), _p(best))
     return best[:n].copy()
+
+
+def triangulate_pairs(pairs, kf1, kf2, cam, scale_factors, level_sigma2):
+    pr = np.ascontiguousarray(pairs, 'i4').reshape(-1, 2); npairs = len(pr)
+    def flat(k):
+        return (np.ascontiguousarray(k['keys_un']), np.ascontiguousarray(k.get('keys', k['keys_un'])), np.ascontiguousarray(k['uright'], 'f4'), np.ascontiguousarray(k['depth'], 'f4'),
+                np.ascontiguousarray(k['Tcw'], 'f4').reshape(16))
+    a = flat(kf1); b = flat(kf2); sf = np.ascontiguousarray(scale_factors, 'f4'); sg = np.ascontiguousarray(level_sigma2, 'f4')
+    ok = np.zeros(max(npairs, 1), np.uint8); x = np.zeros((max(npairs, 1), 3), 'f4')
+    L = lib(); L.orc_triangulate_pairs.restype = C.c_int
+    n = L.orc_triangulate_pairs(C.c_int(npairs), _p(pr), *[_p(v) for v in a], *[_p(v) for v in b], C.c_float(cam['fx']), C.c_float(cam['fy']), C.c_float(cam['cx']), C.c_float(cam['cy']),
+                                C.c_float(cam['bf']), _p(sf), _p(sg), C.c_float(sf[1]), _p(ok), _p(x))
+    return int(n), ok[:npairs].astype(bool), x[:npairs].copy()

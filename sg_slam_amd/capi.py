@@ -69,7 +69,7 @@ SYMBOLS = [
     'sgx_dynamic_mask_batch_dev',
     'sgx_flow_create', 'sgx_flow_destroy', 'sgx_flow_reset', 'sgx_flow_levels', 'sgx_flow_lk_batch_dev', 'sgx_flow_lk', 'sgx_flow_debug_read_level', 'sgx_flow_debug_level_size',
     'sgx_fundamental_ransac_batch_dev', 'sgx_find_fundamental_mat',
-    'sgx_hamming_matrix', 'sgx_hamming_matrix_dev', 'sgx_match_search_for_triangulation', 'sgx_match_search_by_bow', 'sgx_match_search_by_bow_kf', 'sgx_match_fuse_search', 'sgx_match_project_keyframe', 'sgx_match_fuse_search_sim3', 'sgx_mappoint_update_normal_and_depth', 'sgx_mappoint_distinctive_descriptors', 'sgx_sim3_solver_create', 'sgx_sim3_solver_set_ransac_parameters', 'sgx_sim3_solver_iterate', 'sgx_sim3_solver_get_estimate', 'sgx_sim3_solver_destroy', 'sgx_match_search_for_initialization', 'sgx_voc_load', 'sgx_voc_create', 'sgx_voc_info', 'sgx_voc_destroy', 'sgx_voc_transform', 'sgx_voc_transform_batch_dev', 'sgx_voc_score', 'sgx_match_project_sim3', 'sgx_match_search_by_sim3', 'sgx_optimize_sim3', 'sgx_optimize_essential_graph', 'sgx_correct_map_points',
+    'sgx_hamming_matrix', 'sgx_hamming_matrix_dev', 'sgx_match_search_for_triangulation', 'sgx_match_search_by_bow', 'sgx_match_search_by_bow_kf', 'sgx_match_fuse_search', 'sgx_match_project_keyframe', 'sgx_match_fuse_search_sim3', 'sgx_triangulate_new_map_points', 'sgx_mappoint_update_normal_and_depth', 'sgx_mappoint_distinctive_descriptors', 'sgx_sim3_solver_create', 'sgx_sim3_solver_set_ransac_parameters', 'sgx_sim3_solver_iterate', 'sgx_sim3_solver_get_estimate', 'sgx_sim3_solver_destroy', 'sgx_match_search_for_initialization', 'sgx_voc_load', 'sgx_voc_create', 'sgx_voc_info', 'sgx_voc_destroy', 'sgx_voc_transform', 'sgx_voc_transform_batch_dev', 'sgx_voc_score', 'sgx_match_project_sim3', 'sgx_match_search_by_sim3', 'sgx_optimize_sim3', 'sgx_optimize_essential_graph', 'sgx_correct_map_points',
 ]
 
 
@@ -170,6 +170,7 @@ class SgxLib:
         d.sgx_sim3_solver_destroy.argtypes = [vp]; d.sgx_sim3_solver_destroy.restype = None
         d.sgx_mappoint_update_normal_and_depth.argtypes = [C.c_int] + [vp] * 6 + [C.c_int, vp, vp, vp]
         d.sgx_mappoint_distinctive_descriptors.argtypes = [C.c_int, vp, vp, vp, vp]
+        d.sgx_triangulate_new_map_points.argtypes = [C.c_int, vp] + [C.c_int] + [vp] * 5 + [C.c_int] + [vp] * 5 + [vp, vp, vp, C.c_int, vp, vp, vp]
         d.sgx_voc_load.argtypes = [C.c_char_p, vp]
         d.sgx_voc_create.argtypes = [C.c_int] * 5 + [vp] * 5
         d.sgx_voc_info.argtypes = [vp] * 7

@@ -496,3 +496,39 @@ extern "C" int sgx_mappoint_distinctive_descriptors(int n, const int32_t *obs_st
     if (desc_out) for (int p = 0; p < n; p++) if (best[p] >= 0) memcpy(desc_out + 32 * (size_t)p, obs_desc + 32 * (size_t)(obs_start[p] + best[p]), 32);      // mDescriptor = vDescriptors[BestIdx].clone()
     return SGX_OK;
 }
+
+extern "C" int sgx_triangulate_new_map_points(
+    int npairs, const int32_t *pairs,
+    int n1, const sgx_keypoint *keys1_un, const sgx_keypoint *keys1, const float *uright1, const float *depth1, const float *Tcw1,
+    int n2, const sgx_keypoint *keys2_un, const sgx_keypoint *keys2, const float *uright2, const float *depth2, const float *Tcw2,
+    const sgx_camera *cam, const float *scale_factors, const float *level_sigma2, int nlevels, uint8_t *ok, float *x3d, int32_t *nnew)
+{
+    if (npairs < 0 || n1 < 0 || n2 < 0 || !cam || !scale_factors || !level_sigma2 || nlevels < 2 || nlevels > 12 || !Tcw1 || !Tcw2 || !nnew || (npairs > 0 && (!pairs || !ok || !x3d))) return SGX_ERR_INVALID;
+    *nnew = 0;
+    if (npairs == 0) return SGX_OK;
+    if (!keys1_un || !keys1 || !uright1 || !depth1 || !keys2_un || !keys2 || !uright2 || !depth2) return SGX_ERR_INVALID;
+    for (int q = 0; q < npairs; q++) if (pairs[2 * q] < 0 || pairs[2 * q] >= n1 || pairs[2 * q + 1] < 0 || pairs[2 * q + 1] >= n2) return SGX_ERR_INVALID;
+    SgxNewPointArgs A; memset(&A, 0, sizeof A);
+    A.npairs = npairs; memcpy(A.Tcw1, Tcw1, 64); memcpy(A.Tcw2, Tcw2, 64);
+    for (int i = 0; i < 3; i++) {                                 // Ow = -Rcw.t() * tcw (KeyFrame::SetPose, KeyFrame.cc:64-66): transpose flag -> double accumulation, alpha = -1
+        double a = 0, b = 0; for (int k = 0; k < 3; k++) { a += (double)Tcw1[4 * k + i] * (double)Tcw1[4 * k + 3]; b += (double)Tcw2[4 * k + i] * (double)Tcw2[4 * k + 3]; }
+        A.Ow1[i] = (float)(a * -1.0); A.Ow2[i] = (float)(b * -1.0);
+    }
+    A.fx = cam->fx; A.fy = cam->fy; A.cx = cam->cx; A.cy = cam->cy; A.mbf = cam->bf; A.ratio_factor = 1.5f * scale_factors[1];       // ratioFactor = 1.5f * mfScaleFactor (:233)
+    for (int i = 0; i < nlevels; i++) { A.scale.s[i] = scale_factors[i]; A.sigma2.s[i] = level_sigma2[i]; }
+    SgxStaged b[12]; int rc;
+#define PUT(k, src, bytes) if ((rc = b[k].put(k, src, bytes)) != SGX_OK) return rc
+    PUT(0, pairs, (size_t)npairs * 8); PUT(1, keys1_un, (size_t)n1 * 28); PUT(2, keys1, (size_t)n1 * 28); PUT(3, uright1, (size_t)n1 * 4); PUT(4, depth1, (size_t)n1 * 4);
+    PUT(5, keys2_un, (size_t)n2 * 28); PUT(6, keys2, (size_t)n2 * 28); PUT(7, uright2, (size_t)n2 * 4); PUT(8, depth2, (size_t)n2 * 4);
+    PUT(9, nullptr, (size_t)npairs); PUT(10, nullptr, (size_t)npairs * 12);
+#undef PUT
+    A.pairs = (const int *)b[0].p; A.keys1_un = (const uint8_t *)b[1].p; A.keys1 = (const uint8_t *)b[2].p; A.ur1 = (const float *)b[3].p; A.dp1 = (const float *)b[4].p;
+    A.keys2_un = (const uint8_t *)b[5].p; A.keys2 = (const uint8_t *)b[6].p; A.ur2 = (const float *)b[7].p; A.dp2 = (const float *)b[8].p; A.ok = (uint8_t *)b[9].p; A.x3d = (float *)b[10].p;
+    SGX_LAUNCH(k_triangulate_pairs, dim3((npairs + 255) / 256), dim3(256), (sgx_stream_t)0, A);
+    SGX_CHECK_HIP(hipGetLastError());
+    SGX_CHECK_HIP(hipMemcpy(ok, A.ok, (size_t)npairs, hipMemcpyDeviceToHost));
+    SGX_CHECK_HIP(hipMemcpy(x3d, A.x3d, (size_t)npairs * 12, hipMemcpyDeviceToHost));
+    int n = 0; for (int q = 0; q < npairs; q++) n += ok[q];
+    *nnew = n;
+    return SGX_OK;
+}

@@ -7,6 +7,7 @@
 // parallel; the rotation histogram (ComputeThreeMaxima) is resolved by the workgroup afterwards.
 #pragma once
 #include "sgx_match_common.h"
+#include <float.h>
 
 #define SGX_TH_LOW 50             /* ORBmatcher::TH_LOW, ORBmatcher.cc:38 */
 
@@ -768,5 +769,141 @@ SGX_KERNEL(64) k_mappoint_distinctive(int n, const int *obs_start, const uint32_
     SGX_SYNC();
     SGX_THREADS_BEGIN(tid)
     if (tid == 0) best[p] = N > 0 ? (s_key & 0xFFFF) : -1;
+    SGX_THREADS_END
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_triangulate_pairs: the per-pair body of LocalMapping::CreateNewMapPoints (src/sg-slam/src/LocalMapping.cc:283-421) for the pairs SearchForTriangulation returned:
+// parallax test, linear triangulation (cv::SVD::compute on the 4 x 4 system = OpenCV's one-sided Jacobi, JacobiSVDImpl_<float>) or the stereo unprojection of the better
+// side, positive depth in both keyframes, the chi-square reprojection gates (mono 5.991 / stereo 7.8), the scale-consistency gate.  Pairs are independent: one thread each.
+// The map mutations that follow (:402-419) stay with the caller.
+// ---------------------------------------------------------------------------------------------
+struct SgxNewPointArgs {
+    int npairs;
+    const int *pairs;
+    const uint8_t *keys1_un, *keys1, *keys2_un, *keys2; const float *ur1, *dp1, *ur2, *dp2;
+    float Tcw1[16], Tcw2[16], Ow1[3], Ow2[3];
+    float fx, fy, cx, cy, mbf, ratio_factor;
+    SgxScales scale, sigma2;
+    uint8_t *ok; float *x3d;
+};
+
+SGX_DEV void sgx_jacobi_svd4_vt3(const float *A, float *v)
+{
+    const int n = 4, m = 4; const float eps = FLT_EPSILON * 2;
+    float At[16], Vt[16]; double W[4];
+    for (int i = 0; i < 4; i++) for (int k = 0; k < 4; k++) At[4 * i + k] = A[4 * k + i];
+    for (int i = 0; i < n; i++) { double sd = 0; for (int k = 0; k < m; k++) { const float t = At[4 * i + k]; sd += (double)t * t; } W[i] = sd; for (int k = 0; k < n; k++) Vt[4 * i + k] = i == k ? 1.f : 0.f; }
+    for (int iter = 0; iter < 30; iter++) {
+        bool changed = false;
+        for (int i = 0; i < n - 1; i++)
+            for (int j = i + 1; j < n; j++) {
+                float *Ai = At + 4 * i, *Aj = At + 4 * j;
+                double a = W[i], p = 0, b = W[j];
+                for (int k = 0; k < m; k++) p += (double)Ai[k] * Aj[k];
+                if (fabs(p) <= (double)eps * sqrt(a * b)) continue;
+                p *= 2;
+                const double beta = a - b, gamma = hypot(p, beta);
+                float c, s;
+                if (beta < 0) { const double delta = (gamma - beta) * 0.5; s = (float)sqrt(delta / gamma); c = (float)(p / (gamma * (double)s * 2)); }
+                else { c = (float)sqrt((gamma + beta) / (gamma * 2)); s = (float)(p / (gamma * (double)c * 2)); }
+                a = b = 0;
+                for (int k = 0; k < m; k++) { const float t0 = c * Ai[k] + s * Aj[k], t1 = -s * Ai[k] + c * Aj[k]; Ai[k] = t0; Aj[k] = t1; a += (double)t0 * t0; b += (double)t1 * t1; }
+                W[i] = a; W[j] = b; changed = true;
+                float *Vi = Vt + 4 * i, *Vj = Vt + 4 * j;
+                for (int k = 0; k < n; k++) { const float t0 = c * Vi[k] + s * Vj[k], t1 = -s * Vi[k] + c * Vj[k]; Vi[k] = t0; Vj[k] = t1; }
+            }
+        if (!changed) break;
+    }
+    for (int i = 0; i < n; i++) { double sd = 0; for (int k = 0; k < m; k++) { const float t = At[4 * i + k]; sd += (double)t * t; } W[i] = sqrt(sd); }
+    for (int i = 0; i < n - 1; i++) {
+        int j = i;
+        for (int k = i + 1; k < n; k++) if (W[j] < W[k]) j = k;
+        if (i != j) { const double tw = W[i]; W[i] = W[j]; W[j] = tw; for (int k = 0; k < 4; k++) { float t = At[4 * i + k]; At[4 * i + k] = At[4 * j + k]; At[4 * j + k] = t; t = Vt[4 * i + k]; Vt[4 * i + k] = Vt[4 * j + k]; Vt[4 * j + k] = t; } }
+    }
+    for (int k = 0; k < 4; k++) v[k] = Vt[12 + k];
+}
+
+SGX_DEV double sgx_dot3d(const float *a, const float *b) { double r = 0; for (int i = 0; i < 3; i++) r += (double)a[i] * (double)b[i]; return r; }
+SGX_DEV float sgx_gemm3_t(const float *T, int col, const float *b, float c, double beta)      // row `col` of the TRANSPOSE of the 3 x 3 block of T (4-float rows) times b, + beta * c
+{
+    const float t = T[col] * b[0] + T[4 + col] * b[1] + T[8 + col] * b[2];
+    return (float)((double)t * 1.0 + beta * (double)c);
+}
+
+SGX_KERNEL(256) k_triangulate_pairs(SgxNewPointArgs A)
+{
+    SGX_THREADS_BEGIN(tid)
+    const int q = (int)blockIdx.x * 256 + tid;
+    if (q < A.npairs) {
+        uint8_t okq = 0; float X[3] = { 0.f, 0.f, 0.f };
+        do {
+            const int idx1 = A.pairs[2 * q], idx2 = A.pairs[2 * q + 1];
+            const float *kp1 = (const float *)(A.keys1_un + (size_t)idx1 * 28), *kp2 = (const float *)(A.keys2_un + (size_t)idx2 * 28);
+            const int oct1 = ((const int *)kp1)[5], oct2 = ((const int *)kp2)[5];
+            const float invfx = 1.0f / A.fx, invfy = 1.0f / A.fy, mb = A.mbf / A.fx;
+            const float kp1_ur = A.ur1[idx1], kp2_ur = A.ur2[idx2];
+            const bool bStereo1 = kp1_ur >= 0, bStereo2 = kp2_ur >= 0;
+            const float xn1[3] = { (kp1[0] - A.cx) * invfx, (kp1[1] - A.cy) * invfy, 1.0f }, xn2[3] = { (kp2[0] - A.cx) * invfx, (kp2[1] - A.cy) * invfy, 1.0f };
+            const float ray1[3] = { sgx_gemm3_t(A.Tcw1, 0, xn1, 0.f, 0.0), sgx_gemm3_t(A.Tcw1, 1, xn1, 0.f, 0.0), sgx_gemm3_t(A.Tcw1, 2, xn1, 0.f, 0.0) };
+            const float ray2[3] = { sgx_gemm3_t(A.Tcw2, 0, xn2, 0.f, 0.0), sgx_gemm3_t(A.Tcw2, 1, xn2, 0.f, 0.0), sgx_gemm3_t(A.Tcw2, 2, xn2, 0.f, 0.0) };
+            const float cosParallaxRays = (float)(sgx_dot3d(ray1, ray2) / (sqrt(sgx_dot3d(ray1, ray1)) * sqrt(sgx_dot3d(ray2, ray2))));
+            float cosParallaxStereo = cosParallaxRays + 1, cs1 = cosParallaxStereo, cs2 = cosParallaxStereo;
+            if (bStereo1) cs1 = cosf(2 * atan2f(mb / 2, A.dp1[idx1]));
+            else if (bStereo2) cs2 = cosf(2 * atan2f(mb / 2, A.dp2[idx2]));
+            cosParallaxStereo = cs1 < cs2 ? cs1 : cs2;
+            if (cosParallaxRays < cosParallaxStereo && cosParallaxRays > 0 && (bStereo1 || bStereo2 || (double)cosParallaxRays < 0.9998)) {
+                float M[16], v[4];
+                for (int k = 0; k < 4; k++) {
+                    M[k] = xn1[0] * A.Tcw1[8 + k] - A.Tcw1[k]; M[4 + k] = xn1[1] * A.Tcw1[8 + k] - A.Tcw1[4 + k];
+                    M[8 + k] = xn2[0] * A.Tcw2[8 + k] - A.Tcw2[k]; M[12 + k] = xn2[1] * A.Tcw2[8 + k] - A.Tcw2[4 + k];
+                }
+                sgx_jacobi_svd4_vt3(M, v);
+                if (v[3] == 0) break;
+                const float inv = (float)(1.0 / (double)v[3]);
+                X[0] = v[0] * inv; X[1] = v[1] * inv; X[2] = v[2] * inv;
+            } else if (bStereo1 && cs1 < cs2) {
+                const float z = A.dp1[idx1];
+                if (!(z > 0)) break;
+                const float *kd = (const float *)(A.keys1 + (size_t)idx1 * 28);
+                const float xc[3] = { (kd[0] - A.cx) * z * invfx, (kd[1] - A.cy) * z * invfy, z };
+                for (int i = 0; i < 3; i++) X[i] = sgx_gemm3_t(A.Tcw1, i, xc, A.Ow1[i], 1.0);
+            } else if (bStereo2 && cs2 < cs1) {
+                const float z = A.dp2[idx2];
+                if (!(z > 0)) break;
+                const float *kd = (const float *)(A.keys2 + (size_t)idx2 * 28);
+                const float xc[3] = { (kd[0] - A.cx) * z * invfx, (kd[1] - A.cy) * z * invfy, z };
+                for (int i = 0; i < 3; i++) X[i] = sgx_gemm3_t(A.Tcw2, i, xc, A.Ow2[i], 1.0);
+            } else break;
+            const float z1 = (float)(sgx_dot3d(A.Tcw1 + 8, X) + (double)A.Tcw1[11]);
+            if (z1 <= 0) break;
+            const float z2 = (float)(sgx_dot3d(A.Tcw2 + 8, X) + (double)A.Tcw2[11]);
+            if (z2 <= 0) break;
+            const float s1 = A.sigma2.s[oct1];
+            const float x1 = (float)(sgx_dot3d(A.Tcw1, X) + (double)A.Tcw1[3]), y1 = (float)(sgx_dot3d(A.Tcw1 + 4, X) + (double)A.Tcw1[7]);
+            const float invz1 = (float)(1.0 / (double)z1);
+            {
+                const float u1 = A.fx * x1 * invz1 + A.cx, v1 = A.fy * y1 * invz1 + A.cy, eX = u1 - kp1[0], eY = v1 - kp1[1];
+                if (!bStereo1) { if ((double)(eX * eX + eY * eY) > 5.991 * (double)s1) break; }
+                else { const float u1r = u1 - A.mbf * invz1, eR = u1r - kp1_ur; if ((double)(eX * eX + eY * eY + eR * eR) > 7.8 * (double)s1) break; }
+            }
+            const float s2 = A.sigma2.s[oct2];
+            const float x2 = (float)(sgx_dot3d(A.Tcw2, X) + (double)A.Tcw2[3]), y2 = (float)(sgx_dot3d(A.Tcw2 + 4, X) + (double)A.Tcw2[7]);
+            const float invz2 = (float)(1.0 / (double)z2);
+            {
+                const float u2 = A.fx * x2 * invz2 + A.cx, v2 = A.fy * y2 * invz2 + A.cy, eX = u2 - kp2[0], eY = v2 - kp2[1];
+                if (!bStereo2) { if ((double)(eX * eX + eY * eY) > 5.991 * (double)s2) break; }
+                else { const float u2r = u2 - A.mbf * invz2, eR = u2r - kp2_ur; if ((double)(eX * eX + eY * eY + eR * eR) > 7.8 * (double)s2) break; }
+            }
+            const float n1[3] = { X[0] - A.Ow1[0], X[1] - A.Ow1[1], X[2] - A.Ow1[2] }, n2[3] = { X[0] - A.Ow2[0], X[1] - A.Ow2[1], X[2] - A.Ow2[2] };
+            const float dist1 = (float)sqrt(sgx_dot3d(n1, n1)), dist2 = (float)sqrt(sgx_dot3d(n2, n2));
+            if (dist1 == 0 || dist2 == 0) break;
+            const float ratioDist = dist2 / dist1, ratioOctave = A.scale.s[oct1] / A.scale.s[oct2];
+            if (ratioDist * A.ratio_factor < ratioOctave || ratioDist > ratioOctave * A.ratio_factor) break;
+            okq = 1;
+        } while (0);
+        A.ok[q] = okq;
+        A.x3d[3 * (size_t)q] = okq ? X[0] : 0.f; A.x3d[3 * (size_t)q + 1] = okq ? X[1] : 0.f; A.x3d[3 * (size_t)q + 2] = okq ? X[2] : 0.f;
+    }
     SGX_THREADS_END
 }

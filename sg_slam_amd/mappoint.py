@@ -23,3 +23,21 @@ def ComputeDistinctiveDescriptors(obs_start, obs_desc, lib=None):
     best = np.full(max(n, 1), -1, 'i4'); out = np.zeros((max(n, 1), 32), np.uint8)
     lib.check(lib.dll.sgx_mappoint_distinctive_descriptors(n, _vp(st), _vp(d), _vp(best), _vp(out)), 'sgx_mappoint_distinctive_descriptors')
     return best[:n].copy(), out[:n].copy()
+
+
+def TriangulateNewMapPoints(pairs, kf1, kf2, cam, scale_factors, level_sigma2, lib=None):
+    """the per-pair body of LocalMapping::CreateNewMapPoints (LocalMapping.cc:283-421).  kf*: keys_un, keys (mvKeys; defaults to keys_un), uright, depth, Tcw.
+    Returns (nnew, ok[npairs], x3d[npairs, 3])."""
+    import ctypes as C
+    from .matcher import camera_struct
+    lib = lib or load()
+    pr = np.ascontiguousarray(pairs, 'i4').reshape(-1, 2); npairs = len(pr)
+    def flat(k):
+        ku = np.ascontiguousarray(k['keys_un']); kd = np.ascontiguousarray(k.get('keys', k['keys_un']))
+        return len(ku), ku, kd, np.ascontiguousarray(k['uright'], 'f4'), np.ascontiguousarray(k['depth'], 'f4'), np.ascontiguousarray(k['Tcw'], 'f4').reshape(16)
+    n1, a0, a1, a2, a3, a4 = flat(kf1); n2, b0, b1, b2, b3, b4 = flat(kf2)
+    sf = np.ascontiguousarray(scale_factors, 'f4'); sg = np.ascontiguousarray(level_sigma2, 'f4'); cs = camera_struct(cam)
+    ok = np.zeros(max(npairs, 1), np.uint8); x = np.zeros((max(npairs, 1), 3), 'f4'); n = np.zeros(1, 'i4')
+    lib.check(lib.dll.sgx_triangulate_new_map_points(npairs, _vp(pr), n1, _vp(a0), _vp(a1), _vp(a2), _vp(a3), _vp(a4), n2, _vp(b0), _vp(b1), _vp(b2), _vp(b3), _vp(b4),
+                                                     C.byref(cs), _vp(sf), _vp(sg), len(sf), _vp(ok), _vp(x), _vp(n)), 'sgx_triangulate_new_map_points')
+    return int(n[0]), ok[:npairs].astype(bool), x[:npairs].copy()
