@@ -258,6 +258,40 @@ protected:
     float mfNNratio; bool mbCheckOrientation;
 };
 
+// The numeric steps of LocalMapping / MapPoint that surround the matcher gates and the optimisers, on flattened data
+namespace LocalMappingSteps {
+    // the per-pair body of LocalMapping::CreateNewMapPoints (LocalMapping.cc:283-421); mvKeys / mvDepth per keyframe; returns nnew, ok[q], x3D[q]
+    inline int CreateNewMapPoints(const std::vector<std::pair<size_t, size_t>> &vMatchedIndices,
+                                  const ORBmatcher::KeyFrameView &KF1, const std::vector<sgx_keypoint> &mvKeys1, const std::vector<float> &mvDepth1,
+                                  const ORBmatcher::KeyFrameView &KF2, const std::vector<sgx_keypoint> &mvKeys2, const std::vector<float> &mvDepth2,
+                                  const sgx_camera &cam, const std::vector<float> &scaleFactors, const std::vector<float> &levelSigma2, std::vector<uint8_t> &ok, std::vector<float> &x3D)
+    {
+        const int np = (int)vMatchedIndices.size();
+        std::vector<int32_t> pairs((size_t)2 * (np > 0 ? np : 1));
+        for (int i = 0; i < np; i++) { pairs[(size_t)2 * i] = (int32_t)vMatchedIndices[(size_t)i].first; pairs[(size_t)2 * i + 1] = (int32_t)vMatchedIndices[(size_t)i].second; }
+        ok.assign((size_t)(np > 0 ? np : 1), 0); x3D.assign((size_t)3 * (np > 0 ? np : 1), 0.f); int32_t nnew = 0;
+        check(sgx_triangulate_new_map_points(np, pairs.data(), KF1.N, KF1.mvKeysUn.data(), mvKeys1.data(), KF1.mvuRight.data(), mvDepth1.data(), KF1.Tcw,
+                                             KF2.N, KF2.mvKeysUn.data(), mvKeys2.data(), KF2.mvuRight.data(), mvDepth2.data(), KF2.Tcw, &cam, scaleFactors.data(), levelSigma2.data(),
+                                             (int)scaleFactors.size(), ok.data(), x3D.data(), &nnew), "sgx_triangulate_new_map_points");
+        ok.resize((size_t)np); x3D.resize((size_t)3 * np);
+        return nnew;
+    }
+    // MapPoint::UpdateNormalAndDepth / ComputeDistinctiveDescriptors for a batch of points (MapPoint.cc:330-371, :242-307); observations as CSR in mObservations order
+    inline void UpdateNormalAndDepth(const std::vector<float> &xw, const std::vector<int32_t> &obsStart, const std::vector<float> &obsCenter, const std::vector<float> &refCenter,
+                                     const std::vector<int32_t> &refLevel, const std::vector<float> &scaleFactors, std::vector<float> &normal, std::vector<float> &minDist, std::vector<float> &maxDist)
+    {
+        check(sgx_mappoint_update_normal_and_depth((int)refLevel.size(), xw.data(), obsStart.data(), obsCenter.data(), refCenter.data(), refLevel.data(), scaleFactors.data(),
+                                                   (int)scaleFactors.size(), normal.data(), minDist.data(), maxDist.data()), "sgx_mappoint_update_normal_and_depth");
+    }
+    inline void ComputeDistinctiveDescriptors(const std::vector<int32_t> &obsStart, const std::vector<uint8_t> &obsDesc, std::vector<int32_t> &best, std::vector<uint8_t> &mDescriptor)
+    {
+        const int n = (int)obsStart.size() - 1;
+        best.assign((size_t)(n > 0 ? n : 1), -1); mDescriptor.assign((size_t)32 * (n > 0 ? n : 1), 0);
+        check(sgx_mappoint_distinctive_descriptors(n, obsStart.data(), obsDesc.data(), best.data(), mDescriptor.data()), "sgx_mappoint_distinctive_descriptors");
+        best.resize((size_t)(n > 0 ? n : 0)); mDescriptor.resize((size_t)32 * (n > 0 ? n : 0));
+    }
+}
+
 // Sim3Solver (src/sg-slam/include/Sim3Solver.h:36-130): constructed from the flattened usable correspondences (what Sim3Solver.cc:40-111 gathers), then the reference's calls
 class Sim3Solver {
 public:
