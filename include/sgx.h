@@ -460,6 +460,7 @@ int sgx_det_debug_detection_output(sgx_det *h, const float *loc, const float *co
 /* test / tuning taps.  set_fusion(0) makes the NEXT sgx_det_create build the unfused plan (one kernel per ncnn layer, every blob
  * materialised) — the fused plan (default) must reproduce it bit for bit.  time_ops: HIP-event time per plan step (ms[0] = pre-processing). */
 int sgx_det_debug_set_fusion(int on);
+int sgx_det_debug_set_irb(int on);                 /* the NEXT sgx_det_create: 1 / 0 force the matrix-core inverted-residual block kernels (sgx_det_irb.h) on / off, -1 = default (on unless SGX_DET_IRB=0); bit-identical either way */
 int sgx_det_debug_set_block_fusion(int on);        /* 1: the NEXT sgx_det_create also fuses every expand -> depthwise -> project triple into one kernel (bit-identical; opt-in: slower at batch 256) */
 int sgx_det_debug_set_legacy_kernels(int on);      /* 1: run the simple reference kernels (one thread per output / 64x64 GEMM tile) instead of the tuned ones */
 int sgx_det_debug_time_ops(sgx_det *h, const uint8_t *d_img, int pitch, int batch, int reps, float *ms, int cap, int *nops);

@@ -65,7 +65,7 @@ SYMBOLS = [
     'sgx_pose_optimization_batch_dev', 'sgx_pose_opt_debug_set_threads', 'sgx_pose_optimization', 'sgx_frame_motion_model_batch_dev',
     'sgx_local_bundle_adjustment', 'sgx_bundle_adjustment',
     'sgx_det_create', 'sgx_det_destroy', 'sgx_det_info', 'sgx_det_detect', 'sgx_det_detect_batch_dev', 'sgx_det_forward_batch_dev', 'sgx_det_debug_read_blob', 'sgx_det_debug_detection_output',
-    'sgx_frame_compact_keys_batch_dev', 'sgx_frame_gray_from_color_batch_dev', 'sgx_debug_flow_affine_batch_dev', 'sgx_det_debug_set_fusion', 'sgx_det_debug_set_legacy_kernels', 'sgx_det_debug_set_block_fusion', 'sgx_det_debug_time_ops', 'sgx_det_debug_op_desc',
+    'sgx_frame_compact_keys_batch_dev', 'sgx_frame_gray_from_color_batch_dev', 'sgx_debug_flow_affine_batch_dev', 'sgx_det_debug_set_fusion', 'sgx_det_debug_set_legacy_kernels', 'sgx_det_debug_set_block_fusion', 'sgx_det_debug_set_irb', 'sgx_det_debug_time_ops', 'sgx_det_debug_op_desc',
     'sgx_dynamic_mask_batch_dev',
     'sgx_flow_create', 'sgx_flow_destroy', 'sgx_flow_reset', 'sgx_flow_levels', 'sgx_flow_lk_batch_dev', 'sgx_flow_lk', 'sgx_flow_debug_read_level', 'sgx_flow_debug_level_size',
     'sgx_fundamental_ransac_batch_dev', 'sgx_find_fundamental_mat',
@@ -133,6 +133,7 @@ class SgxLib:
         d.sgx_det_debug_set_fusion.argtypes = [C.c_int]
         d.sgx_det_debug_set_legacy_kernels.argtypes = [C.c_int]
         d.sgx_det_debug_set_block_fusion.argtypes = [C.c_int]
+        d.sgx_det_debug_set_irb.argtypes = [C.c_int]
         d.sgx_det_debug_time_ops.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
         d.sgx_det_debug_op_desc.argtypes = [vp, C.c_int, C.c_char_p, C.c_int]
         d.sgx_dynamic_mask_batch_dev.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp]

@@ -3,6 +3,7 @@
 // post-processing, dynamic-feature mask.  Reference: src/sg-slam/src/Detector2D.cc:16-89, src/sg-slam/src/Frame.cc:556-604.
 #include "sgx_block.h"
 #include "sgx_det_block.h"
+#include "sgx_det_irb.h"
 #include "sgx_prof.h"
 #include "../../include/sgx.h"
 #include <math.h>
@@ -28,7 +29,7 @@ struct Layer {
     float getf(int k, float d) const { auto it = p.find(k); return it == p.end() ? d : (float)it->second; }
 };
 struct Blob { int c = 0, h = 0, w = 0; size_t n = 0; float *d = nullptr; bool scalar = false; float sval = 0.f; int alias = -1; };
-enum OpKind { OP_PW, OP_KXK, OP_BINARY, OP_UNARY, OP_PERMUTE_INTO, OP_COPY_INTO, OP_SOFTMAX, OP_FUSED_BLOCK };
+enum OpKind { OP_PW, OP_KXK, OP_BINARY, OP_UNARY, OP_PERMUTE_INTO, OP_COPY_INTO, OP_SOFTMAX, OP_FUSED_BLOCK, OP_IRB };
 struct EpiStep { int op, src; float a, b; int tensor; };
 struct Op {
     OpKind kind; int in0 = -1, in1 = -1, out = -1;
@@ -36,6 +37,7 @@ struct Op {
     int inc = 0, outc = 0, H = 0, W = 0, Ho = 0, Wo = 0, k = 1, stride = 1, pad = 0, depthwise = 0, act = 0; float lo = 0, hi = 0;
     float *wt = nullptr, *bias = nullptr, *wtT = nullptr; int ldw = 0; int bop = 0; int off = 0; int rows = 0, C = 0;
     SgxFusedBlk fb; int fb_res_blob = -1;      // OP_FUSED_BLOCK: expand -> depthwise -> project (+ residual) in one kernel (sgx_det_block.h)
+    SgxIrb irb; int irb_res_blob = -1;         // OP_IRB: [expand ->] depthwise -> project [-> squeeze-excite gate] [+ residual] on the matrix cores (sgx_det_irb.h)
 };
 }  // namespace
 
@@ -71,6 +73,8 @@ static int g_det_legacy = 0;             // test tap (read at sgx_det_create): r
 extern "C" int sgx_det_debug_set_fusion(int on) { g_det_fuse = on ? 1 : 0; return SGX_OK; }
 extern "C" int sgx_det_debug_set_legacy_kernels(int on) { g_det_legacy = on ? 1 : 0; return SGX_OK; }
 extern "C" int sgx_det_debug_set_block_fusion(int on) { g_det_block_fusion = on ? 1 : 0; return SGX_OK; }
+static int g_det_irb = -1;               // test / tuning tap: inverted-residual blocks and SSD heads as one matrix-core kernel each (sgx_det_irb.h); default on, SGX_DET_IRB=0 turns it off
+extern "C" int sgx_det_debug_set_irb(int on) { g_det_irb = on < 0 ? -1 : (on ? 1 : 0); return SGX_OK; }
 
 static int parse_param(const char *text, std::vector<Layer> &layers)
 {
@@ -388,6 +392,135 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                 ops[ci] = f; a.dead = true; bq.dead = true;           // the block takes the project convolution's place in the plan (its residual operand is older)
             }
         }
+        // ---- inverted-residual blocks on the matrix cores (sgx_det_irb.h): [pointwise expand + act ->] depthwise + act -> pointwise project
+        // [-> squeeze (ReLU) -> excite -> hard-sigmoid gate x project output] [+ residual], one kernel, nothing but the block's input and output in HBM.
+        // SGX_DET_IRB=0 keeps the per-layer plan (bit-identical either way).
+        static const int irb_env = getenv("SGX_DET_IRB") ? atoi(getenv("SGX_DET_IRB")) : 0;      // default off until the kernel beats the per-layer plan
+        if ((g_det_irb < 0 ? irb_env != 0 : g_det_irb != 0) && !g_det_legacy) {
+            struct EpiClass { int mode; float c1, lo, hi, c2; int t0, t1; };
+            auto classify = [&](const std::vector<EpiStep> &e) -> EpiClass {
+                EpiClass r; r.mode = SGX_EMODE_GENERIC; r.c1 = 0; r.lo = 0; r.hi = INFINITY; r.c2 = 1; r.t0 = -1; r.t1 = -1;
+                auto is = [&](size_t i, int opc, int src) { return i < e.size() && e[i].op == opc && (opc == SGX_EOP_CLIP || opc == SGX_EOP_RELU || e[i].src == src); };
+                if (e.empty()) r.mode = SGX_EMODE_NONE;
+                else if (e.size() == 1 && is(0, SGX_EOP_RELU, 0)) { r.mode = SGX_EMODE_ACT; r.lo = 0.f; r.hi = INFINITY; }
+                else if (e.size() == 1 && is(0, SGX_EOP_CLIP, 0)) { r.mode = SGX_EMODE_ACT; r.lo = e[0].a; r.hi = e[0].b; }
+                else if (e.size() == 1 && is(0, SGX_EOP_ADD, SGX_ESRC_TENSOR)) { r.mode = SGX_EMODE_ADD_T; r.t1 = e[0].tensor; }
+                else if (e.size() == 4 && is(0, SGX_EOP_ADD, SGX_ESRC_CONST) && is(1, SGX_EOP_CLIP, 0) && is(2, SGX_EOP_MUL, SGX_ESRC_ROOT) && is(3, SGX_EOP_DIV, SGX_ESRC_CONST)) {
+                    r.mode = SGX_EMODE_HSWISH; r.c1 = e[0].a; r.lo = e[1].a; r.hi = e[1].b; r.c2 = e[3].a;
+                } else if ((e.size() == 4 || e.size() == 5) && is(0, SGX_EOP_ADD, SGX_ESRC_CONST) && is(1, SGX_EOP_CLIP, 0) && is(2, SGX_EOP_DIV, SGX_ESRC_CONST) && is(3, SGX_EOP_MUL, SGX_ESRC_TENSOR) &&
+                           (e.size() == 4 || is(4, SGX_EOP_ADD, SGX_ESRC_TENSOR))) {
+                    r.mode = e.size() == 4 ? SGX_EMODE_GATE : SGX_EMODE_GATE_ADD; r.c1 = e[0].a; r.lo = e[1].a; r.hi = e[1].b; r.c2 = e[2].a; r.t0 = e[3].tensor; if (e.size() == 5) r.t1 = e[4].tensor;
+                }
+                return r;
+            };
+            // readers of a blob among the live ops, INCLUDING epilogue tensor operands
+            auto readers_all = [&](int id, std::vector<int> &r) {
+                r.clear();
+                for (int i = 0; i < nops; i++) {
+                    if (ops[i].dead) continue;
+                    bool rd = ops[i].in0 == id || (ops[i].kind == OP_BINARY && ops[i].in1 == id && !h->blobs[id].scalar) || (ops[i].kind == OP_FUSED_BLOCK && ops[i].fb_res_blob == id) ||
+                              (ops[i].kind == OP_IRB && ops[i].irb_res_blob == id);
+                    for (const EpiStep &st : ops[i].epi) rd = rd || st.tensor == id;
+                    if (rd) r.push_back(i);
+                }
+            };
+            static const int irb_mask = getenv("SGX_DET_IRB_MASK") ? atoi(getenv("SGX_DET_IRB_MASK")) : 0xff;      // tuning tap: 1 stride-1 blocks, 2 stride-2 blocks, 4 no-expand blocks, 8 heads
+            for (int bi = 0; bi < nops; bi++) {
+                Op &bq = ops[bi];
+                if (bq.dead || bq.kind != OP_KXK || !bq.depthwise || (bq.k != 3 && bq.k != 5) || (bq.stride != 1 && bq.stride != 2) || bq.pad != bq.k / 2 || bq.inc != bq.outc) continue;
+                const EpiClass cb = classify(bq.epi);
+                if (cb.mode != SGX_EMODE_ACT && cb.mode != SGX_EMODE_HSWISH) continue;
+                if (bq.out == h->loc_blob || bq.out == h->conf_blob) continue;
+                // project: the only reader of the depthwise output
+                readers_all(bq.out, R); if (R.size() != 1) continue;
+                const int ci = R[0]; Op &c = ops[ci];
+                if (c.kind != OP_PW || c.in0 != bq.out || !c.wtT || c.inc != bq.outc || (c.inc & 1)) continue;
+                const EpiClass cc = classify(c.epi);
+                if (cc.mode != SGX_EMODE_NONE && cc.mode != SGX_EMODE_ADD_T) continue;
+                if (c.hwc && cc.mode != SGX_EMODE_NONE) continue;
+                // expand: pointwise producer of the depthwise input whose only reader is the depthwise convolution
+                int ai = -1; EpiClass ca; ca.mode = SGX_EMODE_NONE;
+                for (int i = 0; i < nops; i++) if (!ops[i].dead && ops[i].kind == OP_PW && ops[i].out == bq.in0 && !ops[i].hwc) ai = i;
+                if (ai >= 0) {
+                    readers_all(bq.in0, R);
+                    ca = classify(ops[ai].epi);
+                    if (R.size() != 1 || !ops[ai].wtT || (ops[ai].inc & 1) || (ca.mode != SGX_EMODE_ACT && ca.mode != SGX_EMODE_HSWISH) || bq.in0 == h->loc_blob || bq.in0 == h->conf_blob) ai = -1;
+                }
+                // squeeze-excite behind the project convolution: readers of its output = { squeeze conv, excite conv's gate operand }
+                int di = -1, ei = -1; EpiClass cd, ce; int out_blob = c.out, res_blob = cc.mode == SGX_EMODE_ADD_T ? cc.t1 : -1;
+                if (!c.hwc && cc.mode == SGX_EMODE_NONE && c.out != h->loc_blob && c.out != h->conf_blob) {
+                    readers_all(c.out, R);
+                    if (R.size() == 2) {
+                        for (int q = 0; q < 2; q++) {
+                            const Op &d = ops[R[q]], &e = ops[R[1 - q]];
+                            if (d.kind != OP_PW || e.kind != OP_PW || d.in0 != c.out || d.hwc || e.hwc || !d.wtT || !e.wtT || e.in0 != d.out || (d.outc & 1) || (d.inc & 1)) continue;
+                            cd = classify(d.epi); ce = classify(e.epi);
+                            if (cd.mode != SGX_EMODE_ACT || (ce.mode != SGX_EMODE_GATE && ce.mode != SGX_EMODE_GATE_ADD) || ce.t0 != c.out || e.outc != c.outc) continue;
+                            std::vector<int> R2; readers_all(d.out, R2); if (R2.size() != 1) continue;
+                            di = R[q]; ei = R[1 - q]; out_blob = e.out; res_blob = ce.mode == SGX_EMODE_GATE_ADD ? ce.t1 : -1;
+                        }
+                    }
+                }
+                const bool head = c.hwc != 0;
+                const int kind_bit = head ? 8 : (ai < 0 ? 4 : (bq.stride == 2 ? 2 : 1));
+                if (!(irb_mask & kind_bit)) continue;
+                const int NT = (c.outc + 31) / 32, NQ = di >= 0 ? (ops[di].outc + 31) / 32 : 0;
+                if (!sgx_irb_supported(bq.k, bq.stride, NT, NQ, ai >= 0)) continue;
+                if (ai >= 0 && (ops[ai].inc % 8)) continue;                       // the expand operand ring advances four k-steps at a time
+                // geometry: whole images (G per workgroup) or bands of output rows; two plane buffers when they fit
+                SgxIrb ib; memset(&ib, 0, sizeof ib);
+                ib.Cin = ai >= 0 ? ops[ai].inc : bq.inc; ib.Cexp = bq.outc; ib.Cout = c.outc; ib.Cq = di >= 0 ? ops[di].outc : 0;
+                ib.H = bq.H; ib.W = bq.W; ib.Ho = bq.Ho; ib.Wo = bq.Wo; ib.K = bq.k; ib.S = bq.stride; ib.pad = bq.pad;
+                ib.Wp = bq.W + 2 * bq.pad;
+                const size_t lds_max = 160 * 1024; const int kkp = SGX_IRB_KKP(bq.k), max_px = 384;
+                auto lds_of = [&](int g, int oh, int nb) { const int planeT = ((g * ((oh - 1) * bq.stride + bq.k) * ib.Wp + 3) / 4) * 4; return (size_t)nb * 32 * (planeT + kkp) * 4; };
+                int G = 0, OH = bq.Ho, nbands = 1, nbuf = 2;
+                if (bq.Ho * bq.Wo <= max_px && lds_of(1, bq.Ho, 1) <= lds_max) {
+                    G = std::max(1, max_px / (bq.Ho * bq.Wo));
+                    while (G > 1 && lds_of(G, bq.Ho, 2) > lds_max) G--;
+                    nbuf = lds_of(G, bq.Ho, 2) <= lds_max ? 2 : 1;
+                } else {
+                    G = 1; OH = std::max(1, std::min(bq.Ho, max_px / bq.Wo));
+                    while (OH > 1 && lds_of(1, OH, 1) > lds_max) OH--;
+                    if (lds_of(1, OH, 1) > lds_max || OH * bq.Wo > 1024) continue;
+                    nbands = (bq.Ho + OH - 1) / OH; OH = (bq.Ho + nbands - 1) / nbands;              // even bands
+                    nbuf = lds_of(1, OH, 2) <= lds_max ? 2 : 1;
+                }
+                ib.G = G; ib.OH = OH; ib.nbands = nbands; ib.nbuf = nbuf;
+                ib.HpWp = ((OH - 1) * bq.stride + bq.k) * ib.Wp; ib.planeT = ((G * ib.HpWp + 3) / 4) * 4;
+                {   // 32-bit offsets inside the kernel
+                    const size_t big = (size_t)B * std::max(std::max(h->blobs[ai >= 0 ? ops[ai].in0 : bq.in0].n, h->blobs[out_blob].n), (size_t)1) * 4;
+                    if (big >= 0xFFFFFFFFull) continue;
+                }
+                ib.has_expand = ai >= 0;
+                if (ai >= 0) { ib.act1 = ca.mode; ib.a1c1 = ca.c1; ib.a1lo = ca.lo; ib.a1hi = ca.hi; ib.a1c2 = ca.c2; ib.w1T = ops[ai].wtT; ib.b1 = ops[ai].bias; ib.ld1 = ops[ai].ldw; ib.w1 = ops[ai].wt; }
+                ib.act2 = cb.mode; ib.a2c1 = cb.c1; ib.a2lo = cb.lo; ib.a2hi = cb.hi; ib.a2c2 = cb.c2;
+                ib.w2T = c.wtT; ib.b2 = c.bias; ib.ld2 = c.ldw; ib.w2 = c.wt; ib.wd = bq.wt; ib.bd = bq.bias;
+                if (di >= 0) {
+                    ib.qlo = cd.lo; ib.qhi = cd.hi; ib.gc1 = ce.c1; ib.glo = ce.lo; ib.ghi = ce.hi; ib.gc2 = ce.c2;
+                    ib.wq1T = ops[di].wtT; ib.bq1 = ops[di].bias; ib.ldq1 = ops[di].ldw; ib.wq1 = ops[di].wt;
+                    ib.wq2T = ops[ei].wtT; ib.bq2 = ops[ei].bias; ib.ldq2 = ops[ei].ldw; ib.wq2 = ops[ei].wt;
+                }
+                ib.has_res = res_blob >= 0; ib.hwc = c.hwc; ib.hwc_off = c.hwc_off;
+                {   // depthwise taps + bias, one padded row per channel
+                    const int kk = bq.k * bq.k, rows = ((bq.outc + 31) / 32) * 32;
+                    std::vector<float> wh((size_t)bq.outc * kk), bh(bq.outc), wp((size_t)rows * kkp, 0.f);
+                    if (hipMemcpy(wh.data(), bq.wt, wh.size() * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(bh.data(), bq.bias, bh.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) FAIL(SGX_ERR_DEVICE);
+                    for (int m = 0; m < bq.outc; m++) { for (int t = 0; t < kk; t++) wp[(size_t)m * kkp + t] = wh[(size_t)m * kk + t]; wp[(size_t)m * kkp + kk] = bh[m]; }
+                    float *dwp = nullptr; if (h->alloc(&dwp, wp.size())) FAIL(SGX_ERR_NOMEM);
+                    if (hipMemcpy(dwp, wp.data(), wp.size() * 4, hipMemcpyHostToDevice) != hipSuccess) FAIL(SGX_ERR_DEVICE);
+                    ib.wdp = dwp;
+                }
+                Op f; f.kind = OP_IRB; f.in0 = ai >= 0 ? ops[ai].in0 : bq.in0; f.out = out_blob; f.irb = ib; f.irb_res_blob = res_blob;
+                f.name = (ai >= 0 ? ops[ai].name + "+" : std::string()) + bq.name + "+" + c.name + (di >= 0 ? "+" + ops[di].name + "+" + ops[ei].name : std::string());
+                f.inc = ib.Cin; f.outc = ib.Cout; f.H = bq.H; f.W = bq.W; f.Ho = bq.Ho; f.Wo = bq.Wo; f.k = bq.k; f.stride = bq.stride; f.hwc = c.hwc; f.hwc_off = c.hwc_off;
+                // the block takes the place of its LAST convolution in the plan (every operand is older)
+                const int last = di >= 0 ? ei : ci;
+                if (ai >= 0) ops[ai].dead = true;
+                bq.dead = true; if (last != ci) ops[ci].dead = true; if (di >= 0 && di != last) ops[di].dead = true;
+                ops[last] = f;
+            }
+        }
         std::vector<Op> live; for (const Op &o : ops) if (!o.dead) live.push_back(o);
         ops.swap(live);
     }
@@ -480,6 +613,12 @@ static void run_op(sgx_det *h, const Op &op, int batch, sgx_stream_t st)
         fb.res = op.fb_res_blob >= 0 ? h->blobs[op.fb_res_blob].d : nullptr; fb.res_pitch = op.fb_res_blob >= 0 ? h->blobs[op.fb_res_blob].n : 0;
         if (fb.v2) { (void)sgx_fb2_launch(fb, batch, st); break; }                      // the variant was validated when the plan was built
         SGX_LAUNCH_DYN(k_fused_block, dim3((unsigned)(fb.tiles_x * fb.tiles_y * batch)), dim3(256), sgx_fb_lds_floats(fb) * 4, st, fb);
+        break; }
+    case OP_IRB: {
+        SgxIrb ib = op.irb;
+        ib.in = A.d; ib.in_pitch = A.n; ib.out = O.d; ib.out_pitch = O.n;
+        ib.res = op.irb_res_blob >= 0 ? h->blobs[op.irb_res_blob].d : nullptr; ib.res_pitch = op.irb_res_blob >= 0 ? h->blobs[op.irb_res_blob].n : 0;
+        (void)sgx_irb_launch(ib, batch, st);                                             // the instantiation was validated when the plan was built
         break; }
     case OP_KXK: {
         const SgxEpi e = make_epi(h, op, (size_t)op.outc * op.Ho * op.Wo);
@@ -623,13 +762,16 @@ extern "C" int sgx_det_debug_op_desc(const sgx_det *h, int i, char *buf, int cap
     if (!h || !buf || cap < 16 || i < 0 || i > (int)h->ops.size()) return SGX_ERR_INVALID;
     if (i == 0) { snprintf(buf, cap, "preprocess %dx%d->%d", h->W, h->H, h->T); return SGX_OK; }
     const Op &o = h->ops[i - 1];
-    static const char *kn[] = { "pw", "kxk", "binary", "unary", "permute_into", "copy_into", "softmax", "block" };
+    static const char *kn[] = { "pw", "kxk", "binary", "unary", "permute_into", "copy_into", "softmax", "block", "irb" };
     if (o.kind == OP_PW || o.kind == OP_KXK)
         snprintf(buf, cap, "%s %s c%d->%d k%d s%d %s%dx%d->%dx%d epi%d%s", kn[o.kind], o.name.c_str(), o.inc, o.outc, o.k, o.stride, o.depthwise ? "dw " : "", o.H, o.W,
                  o.kind == OP_PW ? o.H : o.Ho, o.kind == OP_PW ? o.W : o.Wo, (int)o.epi.size() + (o.act ? 1 : 0), o.hwc ? " hwc" : "");
     else if (o.kind == OP_FUSED_BLOCK)
         snprintf(buf, cap, "block %s c%d->%d->%d k%d s%d %dx%d->%dx%d tile %dx%d%s", o.name.c_str(), o.fb.Cin, o.fb.Cmid, o.fb.Cout, o.fb.K, o.fb.stride, o.H, o.W, o.Ho, o.Wo, o.fb.TOH, o.fb.TOW,
                  o.fb_res_blob >= 0 ? " +res" : "");
+    else if (o.kind == OP_IRB)
+        snprintf(buf, cap, "irb %s c%d->%d->%d q%d k%d s%d %dx%d->%dx%d G%d bands%d buf%d%s%s%s", o.name.c_str(), o.irb.Cin, o.irb.Cexp, o.irb.Cout, o.irb.Cq, o.irb.K, o.irb.S, o.H, o.W, o.Ho, o.Wo,
+                 o.irb.G, o.irb.nbands, o.irb.nbuf, o.irb.has_expand ? "" : " noexp", o.irb_res_blob >= 0 ? " +res" : "", o.hwc ? " hwc" : "");
     else snprintf(buf, cap, "%s %s n=%zu", kn[o.kind], o.name.c_str(), h->blobs[o.in0].n);
     return SGX_OK;
 }

@@ -1,0 +1,389 @@
+// sgx_det_irb.h — inverted-residual block of the detector backbone (MobileNetV3: ncnn graph mobilenetv3_ssdlite_voc.param, caller Detector2D.cc:34-45)
+// as ONE kernel on the fp32 matrix cores:
+//     [pointwise expand Cin -> Cexp + act]  ->  depthwise K x K stride S + act  ->  pointwise project Cexp -> Cout
+//     [-> squeeze Cout -> Cq + ReLU -> excite Cq -> Cout -> hard-sigmoid gate x project output]  [+ residual]
+// (this graph's squeeze-excite has NO pooling: it is a per-pixel 1x1 chain).  The SSD heads (depthwise 3x3 -> pointwise, HWC store) and blocks whose
+// expanded tensor has other readers run the same kernel without the expand stage (the depthwise input is then read from HBM).
+//
+// Work decomposition.  A workgroup owns G whole images (small maps) or one band of output rows of one image; wave w owns output-pixel group w
+// (32 pixels: the N side of v_mfma_f32_32x32x2_f32) for the WHOLE block, so everything behind the depthwise stage is wave-private:
+//   expand   E[32 ch][in pixels] = act1(b1 + W1 x X): one 32 x 32 MFMA tile per (chunk of 32 expanded channels, input-pixel group), tiles dealt round-robin
+//            to the waves; A = weights (host-transposed, zero-padded), B = input straight from global memory in the MFMA lane layout; the activated tile is
+//            written to a zero-bordered LDS plane buffer (the depthwise convolution's zero padding) — the ONLY cross-wave hand-off (one barrier per chunk
+//            with two plane buffers, two with one)
+//   dw       lane (half h, pixel j) of wave w computes channel 2s + h of the chunk at ITS output pixel from the LDS planes (K*K taps, fmaf in tap order):
+//            the result IS the B operand of k-step s of the project GEMM in the MFMA lane layout — the depthwise output never exists in memory
+//   project  acc[t] (Cout / 32 tiles x 32 pixels, 16 registers each) += W2[:, 2s..2s+1] x that operand; accumulators persist over the chunks
+//   squeeze-excite  the accumulator (C/D) layout is turned into the B layout with eight v_permlane32_swap per tile (rows 8m+{0..3} live in the lower,
+//            8m+4+{0..3} in the upper half-wave: swapping register pairs across the halves yields the (k, k+1) row pairs in ascending k), so both
+//            1x1 convolutions of the gate chain run on the matrix cores out of registers; gate, residual add and the store (CHW or HWC) finish per lane.
+// Arithmetic: accumulators start from the bias, products in ascending k (the MFMA is an exact fp32 fmaf chain), depthwise taps (i, j) ascending with fmaf,
+// elementwise programs as the per-layer kernels apply them — the block is bit-identical to the per-layer plan (tests: *_fused_equals_unfused).
+#pragma once
+#include "sgx_det_kernels.h"
+#ifdef SGX_EMU
+#include <vector>
+#endif
+
+struct SgxIrb {
+    int Cin, Cexp, Cout, Cq;                    // Cq = 0: no squeeze-excite
+    int H, W, Ho, Wo, K, S, pad;
+    int G, nbands, OH, batch;                   // images per workgroup (nbands == 1) or bands of OH output rows per image (G == 1)
+    int Wp, HpWp, planeT, nbuf;                 // LDS plane geometry in floats: row pitch, per-image plane, per-channel plane (G images); 1 or 2 plane buffers
+    int has_expand;
+    int act1, act2;                             // SGX_EMODE_ACT / SGX_EMODE_HSWISH
+    float a1c1, a1lo, a1hi, a1c2, a2c1, a2lo, a2hi, a2c2;
+    float qlo, qhi;                             // squeeze activation
+    float gc1, glo, ghi, gc2;                   // gate: clip(v + gc1, glo, ghi) / gc2
+    int has_res, hwc, hwc_off;
+    const float *in; size_t in_pitch; float *out; size_t out_pitch; const float *res; size_t res_pitch;
+    const float *w1T, *b1; int ld1;             // [ceil32(Cin)][ld1]
+    const float *wdp;                           // [ceil32(Cexp)][KKP]: K*K taps, bias, zero padding
+    const float *w2T, *b2; int ld2;             // [ceil32(Cexp)][ld2]
+    const float *wq1T, *bq1; int ldq1;          // [ceil32(Cout)][ldq1]
+    const float *wq2T, *bq2; int ldq2;          // [ceil32(Cq)][ldq2]
+    // original ncnn layouts (emulator build)
+    const float *w1, *wd, *bd, *w2, *wq1, *wq2;
+};
+#define SGX_IRB_KKP(K) (((K) * (K) + 1 + 3) & ~3)
+static inline size_t sgx_irb_lds_bytes(const SgxIrb &p) { return (size_t)p.nbuf * 32 * ((size_t)p.planeT + SGX_IRB_KKP(p.K)) * 4; }
+
+SGX_DEV float sgx_irb_act(int mode, float v, float c1, float lo, float hi, float c2)
+{
+    if (mode == SGX_EMODE_HSWISH) { float u = v + c1; u = fminf(fmaxf(u, lo), hi); u = u * v; return u / c2; }
+    return fminf(fmaxf(v, lo), hi);
+}
+
+#ifndef SGX_EMU
+// accumulator layout (lane l: pixel l & 31, rows (r & 3) + 8 (r >> 2) + 4 (l >> 5)) -> B-operand layout of the 16 k-steps over the tile's 32 rows
+// (k-step j: lower half-wave row 2j, upper half-wave row 2j + 1).  v_permlane32_swap(x, y): x.hi <-> y.lo.
+SGX_DEV void sgx_irb_d2b(const sgx_f32x16 &d, float (&b)[16])
+{
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const auto r01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(d[4 * m]), __float_as_uint(d[4 * m + 1]), false, false);
+        const auto r23 = __builtin_amdgcn_permlane32_swap(__float_as_uint(d[4 * m + 2]), __float_as_uint(d[4 * m + 3]), false, false);
+        b[4 * m + 0] = __uint_as_float(r01[0]); b[4 * m + 1] = __uint_as_float(r23[0]);
+        b[4 * m + 2] = __uint_as_float(r01[1]); b[4 * m + 3] = __uint_as_float(r23[1]);
+    }
+}
+// operand streams are buffer loads: 128-bit descriptor (wave-uniform) + 32-bit lane byte offset + scalar byte offset: no per-load address arithmetic
+typedef __amdgpu_buffer_rsrc_t sgx_rsrc;
+SGX_DEV sgx_rsrc sgx_mkrsrc(const void *ptr) { return __builtin_amdgcn_make_buffer_rsrc((void *)ptr, 0, 0x7fffffff, 0x00020000); }
+SGX_DEV float sgx_bld(sgx_rsrc r, unsigned voff, unsigned soff) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0)); }
+
+template <int K, int S, int NT, int NQ, bool EXPAND>
+__global__ void __launch_bounds__(768) k_irb(SgxIrb p)
+{
+    extern __shared__ __attribute__((aligned(16))) float sgx_irb_smem[];
+    constexpr int KK = K * K, KKP = SGX_IRB_KKP(K);
+    float *Eb = sgx_irb_smem;                                         // [nbuf][32][planeT]
+    float *Wds = sgx_irb_smem + (size_t)p.nbuf * 32 * p.planeT;       // [nbuf][32][KKP]
+    const int tid = (int)threadIdx.x, nthreads = (int)blockDim.x, wave = tid >> 6, nwaves = nthreads >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int HW = p.H * p.W, HWo = p.Ho * p.Wo;
+    int b0, nimg, oy0, OH;
+    if (p.nbands > 1) { b0 = (int)blockIdx.x / p.nbands; nimg = 1; oy0 = ((int)blockIdx.x - b0 * p.nbands) * p.OH; OH = min(p.OH, p.Ho - oy0); }
+    else { b0 = (int)blockIdx.x * p.G; nimg = min(p.G, p.batch - b0); oy0 = 0; OH = p.Ho; }
+    const int ypA = oy0 * S;                                          // first padded input row held in the planes
+    const int iyA = max(0, ypA - p.pad), iyB = min(p.H, (oy0 + OH - 1) * S + K - p.pad), IH = iyB - iyA;      // real input rows [iyA, iyB)
+    const int PI = nimg * IH * p.W, PO = nimg * OH * p.Wo, ngi = (PI + 31) >> 5;
+    // my output pixel
+    const int og = wave * 32 + l31; const bool ovalid = og < PO;
+    const int oc_ = min(og, PO - 1), og_img = oc_ / (OH * p.Wo), orem = oc_ - og_img * (OH * p.Wo), oyl = orem / p.Wo, ox = orem - oyl * p.Wo;
+    const int e_r = half * p.planeT + og_img * p.HpWp + oyl * S * p.Wp + ox * S;                // depthwise read base (tap (i, j): + i Wp + j; k-step s: + 2 s planeT)
+    const unsigned opix = (unsigned)((oy0 + oyl) * p.Wo + ox);
+    const sgx_rsrc r_in = sgx_mkrsrc(p.in), r_w1 = sgx_mkrsrc(EXPAND ? p.w1T : p.w2T), r_w2 = sgx_mkrsrc(p.w2T);
+
+    {   // zero the plane buffers once: borders and rows outside the image stay zero, the interior is rewritten per chunk
+        float4 *z = (float4 *)Eb; const int nz = p.nbuf * 8 * p.planeT;
+        for (int i = tid; i < nz; i += nthreads) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    sgx_f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) { const int row = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half; const float bv = p.b2[min(row, p.Cout - 1)]; acc[t][r] = row < p.Cout ? bv : 0.f; }
+
+    const int nchunks = (p.Cexp + 31) >> 5, bmask = p.nbuf - 1;
+    const unsigned aoff1 = (unsigned)(half * p.ld1 + l31) * 4u, aoff2 = (unsigned)(half * p.ld2 + l31) * 4u;
+
+    for (int c = -1; c < nchunks; c++) {
+        // ---- stage B of chunk c: depthwise into the B operand, project on the matrix cores
+        if (c >= 0) {
+            const int ch0 = c * 32, nks = min(16, (p.Cexp - ch0) >> 1), buf = c & bmask;
+            const float *E = Eb + (size_t)buf * 32 * p.planeT + e_r;
+            const float *Wc = Wds + (size_t)buf * 32 * KKP + half * KKP;
+            const unsigned sB = (unsigned)(ch0 * p.ld2) * 4u, sstep = (unsigned)(2 * p.ld2) * 4u;
+            float an[NT];
+#pragma unroll
+            for (int t = 0; t < NT; t++) an[t] = sgx_bld(r_w2, aoff2 + 128u * t, sB);
+            for (int s = 0; s < nks; s++) {
+                float a[NT];
+#pragma unroll
+                for (int t = 0; t < NT; t++) a[t] = an[t];
+                {
+                    const unsigned sn = sB + (unsigned)min(s + 1, nks - 1) * sstep;
+#pragma unroll
+                    for (int t = 0; t < NT; t++) an[t] = sgx_bld(r_w2, aoff2 + 128u * t, sn);
+                }
+                float w[KKP];
+#pragma unroll
+                for (int i = 0; i < KKP / 4; i++) { const float4 q4 = ((const float4 *)(Wc + 2 * s * KKP))[i]; w[4 * i] = q4.x; w[4 * i + 1] = q4.y; w[4 * i + 2] = q4.z; w[4 * i + 3] = q4.w; }
+                const float *ep = E + (size_t)2 * s * p.planeT;
+                float v = w[KK];
+#pragma unroll
+                for (int i = 0; i < K; i++)
+#pragma unroll
+                    for (int j = 0; j < K; j++) v = fmaf(w[i * K + j], ep[i * p.Wp + j], v);
+                v = sgx_irb_act(p.act2, v, p.a2c1, p.a2lo, p.a2hi, p.a2c2);
+#pragma unroll
+                for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], v, acc[t], 0, 0, 0);
+            }
+        }
+        if (p.nbuf == 1) __syncthreads();
+        // ---- stage A of chunk c + 1 into its plane buffer: expand on the matrix cores (or a plain load), activation, LDS write; the chunk's depthwise weights
+        if (c + 1 < nchunks) {
+            const int ch0 = (c + 1) * 32, buf = (c + 1) & bmask;
+            float *E = Eb + (size_t)buf * 32 * p.planeT;
+            for (int i = tid; i < 8 * KKP; i += nthreads) ((float4 *)(Wds + (size_t)buf * 32 * KKP))[i] = ((const float4 *)(p.wdp + (size_t)ch0 * KKP))[i];
+            for (int tile = wave; tile < ngi; tile += nwaves) {
+                const int q = tile * 32 + l31; const bool ivalid = q < PI;
+                const int qc = min(q, PI - 1), qi = qc / (IH * p.W), qrem = qc - qi * (IH * p.W), ry = qrem / p.W, ix = qrem - ry * p.W, iy = iyA + ry;
+                float *Ew = E + qi * p.HpWp + (iy + p.pad - ypA) * p.Wp + ix + p.pad;
+                const unsigned xoff = (unsigned)((size_t)(b0 + qi) * p.in_pitch + (size_t)iy * p.W + ix + (size_t)half * HW) * 4u;
+                if (EXPAND) {
+                    sgx_f32x16 e;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) { const int row = ch0 + (r & 3) + 8 * (r >> 2) + 4 * half; const float bv = p.b1[min(row, p.Cexp - 1)]; e[r] = row < p.Cexp ? bv : 0.f; }
+                    constexpr int D = 4;                                  // operand ring: D k-steps in flight (Cin / 2 is a multiple of D: planner)
+                    const int nks = p.Cin >> 1;
+                    const unsigned sA = (unsigned)ch0 * 4u, sAstep = (unsigned)(2 * p.ld1) * 4u, sXstep = (unsigned)(2 * HW) * 4u;
+                    float ar[D], br[D];
+#pragma unroll
+                    for (int d = 0; d < D; d++) { ar[d] = sgx_bld(r_w1, aoff1, sA + d * sAstep); br[d] = sgx_bld(r_in, xoff, d * sXstep); }
+                    for (int s0 = 0; s0 < nks; s0 += D) {
+#pragma unroll
+                        for (int d = 0; d < D; d++) {
+                            const float a = ar[d], bb = br[d];
+                            const unsigned sn = (unsigned)min(s0 + d + D, nks - 1);
+                            ar[d] = sgx_bld(r_w1, aoff1, sA + sn * sAstep); br[d] = sgx_bld(r_in, xoff, sn * sXstep);
+                            e = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, e, 0, 0, 0);
+                        }
+                    }
+                    if (p.act1 == SGX_EMODE_HSWISH) {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) e[r] = sgx_irb_act(SGX_EMODE_HSWISH, e[r], p.a1c1, p.a1lo, p.a1hi, p.a1c2);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) e[r] = fminf(fmaxf(e[r], p.a1lo), p.a1hi);
+                    }
+                    if (ivalid) {                                         // rows past Cexp of the last chunk are written but never read (stage B stops at Cexp)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) Ew[(size_t)((r & 3) + 8 * (r >> 2) + 4 * half) * p.planeT] = e[r];
+                    }
+                } else {
+                    // depthwise input from global memory: lane (half, pixel) loads channels ch0 + 2 r + half, r = 0..15 (two coalesced rows per load)
+                    float v[16];
+                    const unsigned sXstep = (unsigned)(2 * HW) * 4u;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) v[r] = sgx_bld(r_in, xoff, (unsigned)min(ch0 + 2 * r, p.Cexp - 2) / 2u * sXstep);
+                    if (ivalid) {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) Ew[(size_t)(2 * r + half) * p.planeT] = v[r];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: [squeeze-excite gate] [+ residual], store
+    const unsigned obase = (unsigned)((size_t)(b0 + og_img) * p.out_pitch), rbase = (unsigned)((size_t)(b0 + og_img) * p.res_pitch);
+    if (NQ > 0) {
+        // Both 1x1 convolutions of the gate run out of registers in groups of four k-steps (one register quad of a tile = 8 rows); the A operands of the
+        // next group are in flight while the current group's MFMAs issue, and a scheduling barrier per group keeps the compiler from hoisting every load
+        // of the unrolled chain to the top (hundreds of live registers).
+        const sgx_rsrc r_q1 = sgx_mkrsrc(p.wq1T), r_q2 = sgx_mkrsrc(p.wq2T);
+        constexpr int NQ1 = NQ > 0 ? NQ : 1;
+        sgx_f32x16 qa[NQ1];
+#pragma unroll
+        for (int u = 0; u < NQ; u++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) { const int row = 32 * u + (r & 3) + 8 * (r >> 2) + 4 * half; const float bv = p.bq1[min(row, p.Cq - 1)]; qa[u][r] = row < p.Cq ? bv : 0.f; }
+        const unsigned aoffq1 = (unsigned)(half * p.ldq1 + l31) * 4u, aoffq2 = (unsigned)(half * p.ldq2 + l31) * 4u;
+        const unsigned sq1 = (unsigned)(2 * p.ldq1) * 4u, sq2 = (unsigned)(2 * p.ldq2) * 4u;          // byte step of one k-step (two weight rows)
+        {
+            float an[4][NQ1];
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int u = 0; u < NQ; u++) an[j][u] = sgx_bld(r_q1, aoffq1 + 128u * u, (unsigned)j * sq1);
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const int g = 4 * t + m;                              // k-steps 4 g .. 4 g + 3 = rows 8 g .. 8 g + 7 (Cout is a multiple of 8: planner)
+                    if (8 * g < p.Cout) {
+                        float cur[4][NQ1];
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+#pragma unroll
+                            for (int u = 0; u < NQ; u++) cur[j][u] = an[j][u];
+                        if (8 * (g + 1) < p.Cout) {
+#pragma unroll
+                            for (int j = 0; j < 4; j++)
+#pragma unroll
+                                for (int u = 0; u < NQ; u++) an[j][u] = sgx_bld(r_q1, aoffq1 + 128u * u, (unsigned)(4 * (g + 1) + j) * sq1);
+                        }
+                        const auto r01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[t][4 * m]), __float_as_uint(acc[t][4 * m + 1]), false, false);
+                        const auto r23 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[t][4 * m + 2]), __float_as_uint(acc[t][4 * m + 3]), false, false);
+                        const float bv[4] = { __uint_as_float(r01[0]), __uint_as_float(r23[0]), __uint_as_float(r01[1]), __uint_as_float(r23[1]) };
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+#pragma unroll
+                            for (int u = 0; u < NQ; u++) qa[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[j][u], bv[j], qa[u], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        float qb[NQ1][16];
+#pragma unroll
+        for (int u = 0; u < NQ; u++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) qa[u][r] = fminf(fmaxf(qa[u][r], p.qlo), p.qhi);
+            sgx_irb_d2b(qa[u], qb[u]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            sgx_f32x16 ga;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { const int row = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half; const float bv = p.bq2[min(row, p.Cout - 1)]; ga[r] = row < p.Cout ? bv : 0.f; }
+            float an[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) an[j] = sgx_bld(r_q2, aoffq2 + 128u * t, (unsigned)j * sq2);
+#pragma unroll
+            for (int g = 0; g < 4 * NQ; g++) {
+                if (8 * g < p.Cq) {
+                    float cur[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) cur[j] = an[j];
+                    if (8 * (g + 1) < p.Cq) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) an[j] = sgx_bld(r_q2, aoffq2 + 128u * t, (unsigned)(4 * (g + 1) + j) * sq2);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (2 * (4 * g + j) < p.Cq) ga = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[j], qb[g >> 2][4 * (g & 3) + j], ga, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) { float u_ = ga[r] + p.gc1; u_ = fminf(fmaxf(u_, p.glo), p.ghi); u_ = u_ / p.gc2; acc[t][r] = u_ * acc[t][r]; }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (ovalid) {
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < p.Cout) {
+                    float v = acc[t][r];
+                    if (p.has_res) v = v + p.res[(size_t)rbase + (size_t)row * HWo + opix];
+                    if (p.hwc) p.out[(size_t)obase + (size_t)p.hwc_off + (size_t)opix * p.Cout + row] = v;
+                    else p.out[(size_t)obase + (size_t)row * HWo + opix] = v;
+                }
+            }
+        }
+    }
+}
+#endif
+
+#ifdef SGX_EMU
+// kernel-logic emulator: the block as scalar fmaf chains in the device kernel's order (bias first, k ascending, taps (i, j) ascending; taps in the zero
+// padding add an exact zero), one call per image.
+static void sgx_irb_emu(const SgxIrb &p, int b)
+{
+    const int HW = p.H * p.W, HWo = p.Ho * p.Wo, KK = p.K * p.K;
+    const float *X = p.in + (size_t)b * p.in_pitch;
+    std::vector<float> E((size_t)p.Cexp * HW), Dw((size_t)p.Cexp * HWo), Y((size_t)p.Cout * HWo), Q((size_t)std::max(p.Cq, 1) * HWo);
+    for (int m = 0; m < p.Cexp; m++) for (int q = 0; q < HW; q++) {
+        if (!p.has_expand) { E[(size_t)m * HW + q] = X[(size_t)m * HW + q]; continue; }
+        float s = p.b1[m];
+        for (int k = 0; k < p.Cin; k++) s = fmaf(p.w1[(size_t)m * p.Cin + k], X[(size_t)k * HW + q], s);
+        E[(size_t)m * HW + q] = sgx_irb_act(p.act1, s, p.a1c1, p.a1lo, p.a1hi, p.a1c2);
+    }
+    for (int m = 0; m < p.Cexp; m++) for (int oy = 0; oy < p.Ho; oy++) for (int ox = 0; ox < p.Wo; ox++) {
+        float s = p.bd[m];
+        for (int i = 0; i < p.K; i++) for (int j = 0; j < p.K; j++) {
+            const int iy = oy * p.S - p.pad + i, ix = ox * p.S - p.pad + j;
+            const float x = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? E[(size_t)m * HW + iy * p.W + ix] : 0.f;
+            s = fmaf(p.wd[(size_t)m * KK + i * p.K + j], x, s);
+        }
+        Dw[(size_t)m * HWo + oy * p.Wo + ox] = sgx_irb_act(p.act2, s, p.a2c1, p.a2lo, p.a2hi, p.a2c2);
+    }
+    for (int o = 0; o < p.Cout; o++) for (int q = 0; q < HWo; q++) {
+        float s = p.b2[o];
+        for (int k = 0; k < p.Cexp; k++) s = fmaf(p.w2[(size_t)o * p.Cexp + k], Dw[(size_t)k * HWo + q], s);
+        Y[(size_t)o * HWo + q] = s;
+    }
+    if (p.Cq > 0) {
+        for (int u = 0; u < p.Cq; u++) for (int q = 0; q < HWo; q++) {
+            float s = p.bq1[u];
+            for (int k = 0; k < p.Cout; k++) s = fmaf(p.wq1[(size_t)u * p.Cout + k], Y[(size_t)k * HWo + q], s);
+            Q[(size_t)u * HWo + q] = fminf(fmaxf(s, p.qlo), p.qhi);
+        }
+        for (int o = 0; o < p.Cout; o++) for (int q = 0; q < HWo; q++) {
+            float s = p.bq2[o];
+            for (int k = 0; k < p.Cq; k++) s = fmaf(p.wq2[(size_t)o * p.Cq + k], Q[(size_t)k * HWo + q], s);
+            float u = s + p.gc1; u = fminf(fmaxf(u, p.glo), p.ghi); u = u / p.gc2;
+            Y[(size_t)o * HWo + q] = u * Y[(size_t)o * HWo + q];
+        }
+    }
+    for (int o = 0; o < p.Cout; o++) for (int q = 0; q < HWo; q++) {
+        float v = Y[(size_t)o * HWo + q];
+        if (p.has_res) v = v + p.res[(size_t)b * p.res_pitch + (size_t)o * HWo + q];
+        if (p.hwc) p.out[(size_t)b * p.out_pitch + (size_t)p.hwc_off + (size_t)q * p.Cout + o] = v;
+        else p.out[(size_t)b * p.out_pitch + (size_t)o * HWo + q] = v;
+    }
+}
+#endif
+
+// instantiations the planner may pick: (K, S, NT = ceil(Cout / 32), NQ = ceil(Cq / 32), with / without the expand stage)
+#define SGX_IRB_INSTANCES(X) \
+    X(3, 1, 3, 0, true) X(3, 1, 4, 1, true) X(5, 1, 5, 2, true) X(5, 1, 2, 1, true) X(3, 2, 3, 0, true) X(5, 2, 2, 1, true) \
+    X(5, 2, 5, 2, false) X(3, 1, 1, 0, false) X(3, 1, 3, 0, false) X(3, 1, 4, 0, false)
+static inline bool sgx_irb_supported(int K, int S, int NT, int NQ, bool expand)
+{
+#define SGX_IRB_X(K_, S_, NT_, NQ_, E_) if (K == K_ && S == S_ && NT == NT_ && NQ == NQ_ && expand == E_) return true;
+    SGX_IRB_INSTANCES(SGX_IRB_X)
+#undef SGX_IRB_X
+    return false;
+}
+
+#ifndef SGX_IRB_NO_LAUNCH
+static inline int sgx_irb_launch(const SgxIrb &p, int batch, sgx_stream_t st)
+{
+#ifdef SGX_EMU
+    for (int b = 0; b < batch; b++) sgx_irb_emu(p, b);
+    return SGX_OK;
+#else
+    const int NT = (p.Cout + 31) / 32, NQ = (p.Cq + 31) / 32;
+    const int maxPO = p.nbands > 1 ? p.OH * p.Wo : p.G * p.Ho * p.Wo, nw = (maxPO + 31) / 32;
+    const unsigned grid = p.nbands > 1 ? (unsigned)(batch * p.nbands) : (unsigned)((batch + p.G - 1) / p.G);
+    const size_t lds = sgx_irb_lds_bytes(p);
+    if (nw > 12 || lds > 160 * 1024) return SGX_ERR_UNSUPPORTED;
+    SgxIrb q = p; q.batch = batch;
+#define SGX_IRB_X(K_, S_, NT_, NQ_, E_) if (p.K == K_ && p.S == S_ && NT == NT_ && NQ == NQ_ && (p.has_expand != 0) == E_) { \
+        auto kfn = k_irb<K_, S_, NT_, NQ_, E_>; static bool attr = false; \
+        if (!attr) { (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * nw), lds, st, q); return SGX_OK; }
+    SGX_IRB_INSTANCES(SGX_IRB_X)
+#undef SGX_IRB_X
+    return SGX_ERR_UNSUPPORTED;
+#endif
+}
+#endif

@@ -36,8 +36,8 @@ def make_image(seed, person=False):
 
 def run_compare(lib, model, seeds=(0, 1), fuse=False):
     layers, W, blob = model
-    det = Detector2D(0.90, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=2, lib=lib, fuse=fuse)
-    assert det.num_kernels == (282 if not fuse else 97), det.num_kernels
+    det = Detector2D(0.90, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=2, lib=lib, fuse=fuse, irb=fuse)
+    assert det.num_kernels == (282 if not fuse else 46), det.num_kernels      # 46: the inverted-residual blocks and the SSD heads run as one k_irb each
     assert det.num_priors == 2268 and det.num_class == 21 and abs(det.gmac - 0.5574) < 1e-3
     imgs = np.stack([make_image(s) for s in seeds])
     res = det.detect_batch(imgs)
@@ -51,7 +51,10 @@ def run_compare(lib, model, seeds=(0, 1), fuse=False):
                 assert name == '580'                              # the stem's raw output lives only in registers of the fused h-swish epilogue
                 continue
             assert rel_err(det.debug_blob(name, b), np.asarray(blobs[name], np.float32).reshape(-1)) < 1e-5, name
-        for name in ('620', '672', '849', '908', '944', 'mbox_loc', 'mbox_conf_softmax'):
+        for name in ('620', '632', '672', '849', '908', '944', 'mbox_loc', 'mbox_conf_softmax'):
+            if fuse and not det.has_blob(name):
+                assert name == '620'                              # project output ahead of the squeeze-excite gate: lives only in the accumulators of k_irb
+                continue
             got = det.debug_blob(name, b); ref = np.asarray(blobs64[name]).reshape(-1); np32 = np.asarray(blobs[name], np.float64).reshape(-1)
             e_dev, e_np = rel_err(got.astype(np.float64), ref), rel_err(np32, ref)
             assert got.shape == ref.shape and e_dev <= max(4 * e_np, 1e-5), (name, e_dev, e_np)
@@ -83,10 +86,11 @@ def run_fused_equals_unfused(lib, model):
     layers, W, blob = model
     imgs = np.stack([make_image(3), make_image(4)])
     outs = []
-    for fuse, legacy, blocks in ((False, True, False), (True, True, False), (True, False, False), (False, False, False), (True, False, True)):
-        # the last plan additionally runs the six expand -> depthwise -> project triples as one k_fused_block each (opt-in: correct but slower at batch 256)
-        det = Detector2D(0.90, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=2, lib=lib, fuse=fuse, legacy_kernels=legacy, block_fusion=blocks)
-        assert det.num_kernels == (91 if blocks else 97 if (fuse and not legacy) else 103 if fuse else 282)     # 97: the three high-resolution blocks run as k_fused_block2 by default
+    for fuse, legacy, blocks, irb in ((False, True, False, False), (True, True, False, False), (True, False, False, False), (False, False, False, False), (True, False, True, False), (True, False, False, True)):
+        # the fifth plan additionally runs the six expand -> depthwise -> project triples as one k_fused_block each (opt-in: correct but slower at batch 256);
+        # the last one is the default plan: inverted-residual blocks (with their squeeze-excite gates) and SSD heads as one matrix-core kernel each (k_irb)
+        det = Detector2D(0.90, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=2, lib=lib, fuse=fuse, legacy_kernels=legacy, block_fusion=blocks, irb=irb)
+        assert det.num_kernels == (46 if irb else 91 if blocks else 97 if (fuse and not legacy) else 103 if fuse else 282), det.num_kernels     # 97: the three high-resolution blocks run as k_fused_block2
         det.detect_batch(imgs)
         outs.append([np.stack([det.debug_blob(nm, b) for b in range(2)]) for nm in ('587', '632', '672', '849', '908', '944', 'mbox_loc', 'mbox_conf_softmax')])
         det.close()

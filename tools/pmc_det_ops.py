@@ -8,7 +8,7 @@ table = collections.defaultdict(dict)
 for path in sys.argv[3:]:
     per = collections.OrderedDict()
     for r in csv.DictReader(open(path)):
-        if not r['Kernel_Name'].startswith(KN) and 'k_conv' not in r['Kernel_Name'] and 'k_fused_block' not in r['Kernel_Name']: continue
+        if not r['Kernel_Name'].startswith(KN) and 'k_conv' not in r['Kernel_Name'] and 'k_fused_block' not in r['Kernel_Name'] and 'k_irb' not in r['Kernel_Name']: continue
         per.setdefault(int(r['Dispatch_Id']), {})[r['Counter_Name']] = float(r['Counter_Value'])
     ids = sorted(per)
     assert len(ids) == reps * len(ops), (len(ids), reps, len(ops))
