@@ -460,7 +460,7 @@ int sgx_det_debug_detection_output(sgx_det *h, const float *loc, const float *co
 /* test / tuning taps.  set_fusion(0) makes the NEXT sgx_det_create build the unfused plan (one kernel per ncnn layer, every blob
  * materialised) — the fused plan (default) must reproduce it bit for bit.  time_ops: HIP-event time per plan step (ms[0] = pre-processing). */
 int sgx_det_debug_set_fusion(int on);
-int sgx_det_debug_set_irb(int on);                 /* the NEXT sgx_det_create: 1 / 0 force the matrix-core inverted-residual block kernels (sgx_det_irb.h) on / off, -1 = default (on unless SGX_DET_IRB=0); bit-identical either way */
+int sgx_det_debug_set_irb(int on);                 /* the NEXT sgx_det_create: matrix-core inverted-residual block kernels (sgx_det_irb.h) 0 off, 1 on the shapes where they beat the per-layer kernels, 2 on every supported shape, -1 = default (1, or SGX_DET_IRB); bit-identical either way */
 int sgx_det_debug_set_block_fusion(int on);        /* 1: the NEXT sgx_det_create also fuses every expand -> depthwise -> project triple into one kernel (bit-identical; opt-in: slower at batch 256) */
 int sgx_det_debug_set_legacy_kernels(int on);      /* 1: run the simple reference kernels (one thread per output / 64x64 GEMM tile) instead of the tuned ones */
 int sgx_det_debug_time_ops(sgx_det *h, const uint8_t *d_img, int pitch, int batch, int reps, float *ms, int cap, int *nops);
@@ -522,6 +522,50 @@ int sgx_fundamental_ransac_batch_dev(int batch, int cap, const sgx_keypoint *d_k
                                      double threshold, double confidence, double *d_F, int32_t *d_ok, int32_t *d_stats, void *stream);
 /* cv::findFundamentalMat(pts1, pts2, FM_RANSAC, threshold, confidence) on host points.  Synchronous. */
 int sgx_find_fundamental_mat(const float *pts1, const float *pts2, int n, double threshold, double confidence, double *F, int32_t *ok, int32_t *stats);
+
+/* ---- the pipelined per-frame host (C++ behind this C ABI: sg_slam_amd/csrc/sgx_tracker.cpp) ---------------------------------
+ * S independent RGB-D streams tracked in lock-step on one GPU, one frame per stream per step, in the call order of the reference's tracking thread:
+ * Tracking::GrabImageRGBD (src/sg-slam/src/Tracking.cc:206-251) -> Frame::Frame (src/sg-slam/src/Frame.cc:100-200: ExtractORB, detector hand-shake :170-176 / :478,
+ * RmDynamicPointWithSemanticAndGeometry :430-610, ComputeStereoFromRGBD :893-914) -> Tracking::TrackWithMotionModel / TrackLocalMap (Tracking.cc:906-1013), in
+ * visual-odometry form (Tracking::UpdateLastFrame :840-904 points; local map = the points of frames t-2, t-3).  Three HIP streams (detector | extraction + mask |
+ * tracking) chained by events, triple-buffered frame state, no host synchronisation inside a step; an optional fourth stream uploads host frames.
+ * It is the harness host of bench.py / example_track.cpp / the tests — keyframe decisions, relocalisation and the map stay with ORB_SLAM2::Tracking. */
+typedef struct sgx_tracker_config {
+    int32_t streams, width, height;
+    int32_t nfeatures; float scale_factor; int32_t nlevels, ini_th_fast, min_th_fast;      /* ORBextractor.* of the settings file (TUM3.yaml: 1000, 1.2, 8, 20, 7) */
+    sgx_camera cam; float depth_map_factor;                                                 /* Camera.*, DepthMapFactor (5000) */
+    float th_projection;                                                                    /* SearchByProjection(cur, last, th): 15 (Tracking.cc:924) */
+    int32_t local_map;                                                                      /* 1: TrackLocalMap stage (SearchLocalPoints + second PoseOptimization) */
+    int32_t dynamic_mask;                                                                   /* 1: calcOpticalFlowPyrLK + findFundamentalMat + mask + erase (Frame.cc:430-610) */
+    int32_t max_boxes;                                                                      /* person rectangles kept per frame (<= SGX_DET_MAX) */
+    int32_t pipelined;                                                                      /* 1: own HIP streams; 0: everything on the caller's stream (tests) */
+} sgx_tracker_config;
+typedef struct sgx_tracker sgx_tracker;
+int sgx_tracker_create(const sgx_tracker_config *cfg, sgx_det *detector /* NULL: no Detector2D::detect; not owned */, sgx_tracker **out);
+void sgx_tracker_destroy(sgx_tracker *t);
+int sgx_tracker_keypoint_capacity(const sgx_tracker *t);
+int sgx_tracker_record_bytes(const sgx_tracker *t);                   /* 16 + cap * 28 + cap * 32 + 64: the per-frame record of BASELINE config 5 */
+int sgx_tracker_set_initial_pose(sgx_tracker *t, const float *Tcw /* streams x 16, host */);
+/* one frame of every stream from device memory: d_gray streams x height x gray_pitch u8, d_depth streams x height x width raw u16, d_bgr (optional, detector
+ * input) streams x height x bgr_pitch interleaved 3-channel u8.  Asynchronous; the inputs must stay untouched until three more steps were issued or
+ * sgx_tracker_sync returned. */
+int sgx_tracker_step_dev(sgx_tracker *t, const uint8_t *d_gray, int gray_pitch, const uint16_t *d_depth, const uint8_t *d_bgr, int bgr_pitch, void *caller_stream);
+/* host input (cv::imread's BGR image + the 16-bit depth map, rgbd_tum.cc:114-115): fill the pinned staging buffers of slot 0 / 1, then step; the tracker uploads
+ * them on its own stream and converts to gray on the device (Tracking.cc:214-227; rgb_order = Camera.RGB).  A slot may be refilled once two further steps were issued. */
+int sgx_tracker_host_buffers(sgx_tracker *t, int slot, uint8_t **bgr, int *bgr_pitch, uint16_t **depth);
+int sgx_tracker_step_host(sgx_tracker *t, int slot, int rgb_order);
+int sgx_tracker_sync(sgx_tracker *t);
+/* results of the frame tracked last (synchronises; any pointer may be NULL): Tcw streams x 16, keypoints after the mask, motion-model matches / inliers, local-map
+ * matches / inliers of the second PoseOptimization, keypoints before the mask, findFundamentalMat success, its 4 statistics per stream */
+int sgx_tracker_read(sgx_tracker *t, float *Tcw, int32_t *nkeys, int32_t *nmatches, int32_t *ninliers, int32_t *nmatches_local, int32_t *ninliers2, int32_t *nkeys_raw,
+                     int32_t *f_ok, int32_t *f_stats);
+int sgx_tracker_snapshot_pose_dev(sgx_tracker *t, float *d_out /* streams x 16 */);                               /* async copy on the tracking stream */
+int sgx_tracker_snapshot_boxes_dev(sgx_tracker *t, int stream_index, float *d_boxes /* max_boxes x 4 */, int32_t *d_nboxes);   /* async copy on the detector stream */
+/* the frame records {n, cv::KeyPoint[cap], descriptors[cap][32], Tcw} of the frame tracked last, packed by one kernel into d_records (streams x record_bytes) on
+ * `stream` after the frame's tracking event: what the RCCL gather of BASELINE config 5 sends */
+int sgx_tracker_pack_records_dev(sgx_tracker *t, uint8_t *d_records, void *stream);
+int sgx_tracker_frame_dev(sgx_tracker *t, const int32_t **d_n, const sgx_keypoint **d_keys, const uint8_t **d_desc, const float **d_Tcw, const float **d_xw, const uint8_t **d_has);
+sgx_orb *sgx_tracker_extractor(sgx_tracker *t);
 
 /* run the octree-distribution kernel alone on packed candidates (x | y<<12 | score<<24, coordinates
  * relative to the (16,16) border origin) for `level`; returns the selected packed entries in list order */

@@ -47,6 +47,12 @@ class FlowConfig(C.Structure):
                 ('max_count', C.c_int32), ('epsilon', C.c_double)]
 
 
+class TrackerConfig(C.Structure):
+    _fields_ = [('streams', C.c_int32), ('width', C.c_int32), ('height', C.c_int32), ('nfeatures', C.c_int32), ('scale_factor', C.c_float), ('nlevels', C.c_int32),
+                ('ini_th_fast', C.c_int32), ('min_th_fast', C.c_int32), ('cam', Camera), ('depth_map_factor', C.c_float), ('th_projection', C.c_float),
+                ('local_map', C.c_int32), ('dynamic_mask', C.c_int32), ('max_boxes', C.c_int32), ('pipelined', C.c_int32)]
+
+
 class OrbConfig(C.Structure):
     _fields_ = [('nfeatures', C.c_int32), ('scale_factor', C.c_float), ('nlevels', C.c_int32),
                 ('ini_th_fast', C.c_int32), ('min_th_fast', C.c_int32), ('width', C.c_int32),
@@ -67,6 +73,9 @@ SYMBOLS = [
     'sgx_det_create', 'sgx_det_destroy', 'sgx_det_info', 'sgx_det_detect', 'sgx_det_detect_batch_dev', 'sgx_det_forward_batch_dev', 'sgx_det_debug_read_blob', 'sgx_det_debug_detection_output',
     'sgx_frame_compact_keys_batch_dev', 'sgx_frame_gray_from_color_batch_dev', 'sgx_debug_flow_affine_batch_dev', 'sgx_det_debug_set_fusion', 'sgx_det_debug_set_legacy_kernels', 'sgx_det_debug_set_block_fusion', 'sgx_det_debug_set_irb', 'sgx_det_debug_time_ops', 'sgx_det_debug_op_desc',
     'sgx_dynamic_mask_batch_dev',
+    'sgx_tracker_create', 'sgx_tracker_destroy', 'sgx_tracker_keypoint_capacity', 'sgx_tracker_record_bytes', 'sgx_tracker_set_initial_pose', 'sgx_tracker_step_dev',
+    'sgx_tracker_host_buffers', 'sgx_tracker_step_host', 'sgx_tracker_sync', 'sgx_tracker_read', 'sgx_tracker_snapshot_pose_dev', 'sgx_tracker_snapshot_boxes_dev',
+    'sgx_tracker_pack_records_dev', 'sgx_tracker_frame_dev', 'sgx_tracker_extractor',
     'sgx_flow_create', 'sgx_flow_destroy', 'sgx_flow_reset', 'sgx_flow_levels', 'sgx_flow_lk_batch_dev', 'sgx_flow_lk', 'sgx_flow_debug_read_level', 'sgx_flow_debug_level_size',
     'sgx_fundamental_ransac_batch_dev', 'sgx_find_fundamental_mat',
     'sgx_hamming_matrix', 'sgx_hamming_matrix_dev', 'sgx_match_search_for_triangulation', 'sgx_match_search_by_bow', 'sgx_match_search_by_bow_kf', 'sgx_match_fuse_search', 'sgx_match_project_keyframe', 'sgx_match_fuse_search_sim3', 'sgx_triangulate_new_map_points', 'sgx_mappoint_update_normal_and_depth', 'sgx_mappoint_distinctive_descriptors', 'sgx_sim3_solver_create', 'sgx_sim3_solver_set_ransac_parameters', 'sgx_sim3_solver_iterate', 'sgx_sim3_solver_get_estimate', 'sgx_sim3_solver_destroy', 'sgx_match_search_for_initialization', 'sgx_voc_load', 'sgx_voc_create', 'sgx_voc_info', 'sgx_voc_destroy', 'sgx_voc_transform', 'sgx_voc_transform_batch_dev', 'sgx_voc_score', 'sgx_match_project_sim3', 'sgx_match_search_by_sim3', 'sgx_optimize_sim3', 'sgx_optimize_essential_graph', 'sgx_correct_map_points',
@@ -134,6 +143,21 @@ class SgxLib:
         d.sgx_det_debug_set_legacy_kernels.argtypes = [C.c_int]
         d.sgx_det_debug_set_block_fusion.argtypes = [C.c_int]
         d.sgx_det_debug_set_irb.argtypes = [C.c_int]
+        d.sgx_tracker_create.argtypes = [C.POINTER(TrackerConfig), vp, C.POINTER(vp)]
+        d.sgx_tracker_destroy.argtypes = [vp]; d.sgx_tracker_destroy.restype = None
+        d.sgx_tracker_keypoint_capacity.argtypes = [vp]
+        d.sgx_tracker_record_bytes.argtypes = [vp]
+        d.sgx_tracker_set_initial_pose.argtypes = [vp, vp]
+        d.sgx_tracker_step_dev.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, vp]
+        d.sgx_tracker_host_buffers.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(vp)]
+        d.sgx_tracker_step_host.argtypes = [vp, C.c_int, C.c_int]
+        d.sgx_tracker_sync.argtypes = [vp]
+        d.sgx_tracker_read.argtypes = [vp] * 10
+        d.sgx_tracker_snapshot_pose_dev.argtypes = [vp, vp]
+        d.sgx_tracker_snapshot_boxes_dev.argtypes = [vp, C.c_int, vp, vp]
+        d.sgx_tracker_pack_records_dev.argtypes = [vp, vp, vp]
+        d.sgx_tracker_frame_dev.argtypes = [vp] + [C.POINTER(vp)] * 6
+        d.sgx_tracker_extractor.argtypes = [vp]; d.sgx_tracker_extractor.restype = vp
         d.sgx_det_debug_time_ops.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
         d.sgx_det_debug_op_desc.argtypes = [vp, C.c_int, C.c_char_p, C.c_int]
         d.sgx_dynamic_mask_batch_dev.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp]

@@ -73,8 +73,9 @@ static int g_det_legacy = 0;             // test tap (read at sgx_det_create): r
 extern "C" int sgx_det_debug_set_fusion(int on) { g_det_fuse = on ? 1 : 0; return SGX_OK; }
 extern "C" int sgx_det_debug_set_legacy_kernels(int on) { g_det_legacy = on ? 1 : 0; return SGX_OK; }
 extern "C" int sgx_det_debug_set_block_fusion(int on) { g_det_block_fusion = on ? 1 : 0; return SGX_OK; }
-static int g_det_irb = -1;               // test / tuning tap: inverted-residual blocks and SSD heads as one matrix-core kernel each (sgx_det_irb.h); default on, SGX_DET_IRB=0 turns it off
-extern "C" int sgx_det_debug_set_irb(int on) { g_det_irb = on < 0 ? -1 : (on ? 1 : 0); return SGX_OK; }
+static int g_det_irb = -1;               // test / tuning tap: inverted-residual blocks and SSD heads as one matrix-core kernel each (sgx_det_irb.h): 0 off, 1 the shapes where it beats
+                                         // the per-layer kernels on MI355X (default), 2 every shape it supports (tests); -1 = SGX_DET_IRB or the default
+extern "C" int sgx_det_debug_set_irb(int on) { g_det_irb = on < 0 ? -1 : (on > 2 ? 2 : on); return SGX_OK; }
 
 static int parse_param(const char *text, std::vector<Layer> &layers)
 {
@@ -395,8 +396,9 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
         // ---- inverted-residual blocks on the matrix cores (sgx_det_irb.h): [pointwise expand + act ->] depthwise + act -> pointwise project
         // [-> squeeze (ReLU) -> excite -> hard-sigmoid gate x project output] [+ residual], one kernel, nothing but the block's input and output in HBM.
         // SGX_DET_IRB=0 keeps the per-layer plan (bit-identical either way).
-        static const int irb_env = getenv("SGX_DET_IRB") ? atoi(getenv("SGX_DET_IRB")) : 0;      // default off until the kernel beats the per-layer plan
-        if ((g_det_irb < 0 ? irb_env != 0 : g_det_irb != 0) && !g_det_legacy) {
+        static const int irb_env = getenv("SGX_DET_IRB") ? atoi(getenv("SGX_DET_IRB")) : 1;
+        const int irb_mode = g_det_irb < 0 ? irb_env : g_det_irb;
+        if (irb_mode != 0 && !g_det_legacy) {
             struct EpiClass { int mode; float c1, lo, hi, c2; int t0, t1; };
             auto classify = [&](const std::vector<EpiStep> &e) -> EpiClass {
                 EpiClass r; r.mode = SGX_EMODE_GENERIC; r.c1 = 0; r.lo = 0; r.hi = INFINITY; r.c2 = 1; r.t0 = -1; r.t1 = -1;
@@ -464,9 +466,18 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                 const bool head = c.hwc != 0;
                 const int kind_bit = head ? 8 : (ai < 0 ? 4 : (bq.stride == 2 ? 2 : 1));
                 if (!(irb_mask & kind_bit)) continue;
+                if (irb_mode == 1) {
+                    // measured at 512 frames (profiles/r3_detector_ops.txt against profiles/r2_detector_ops.txt): the kernel wins on the 19 x 19 blocks, on the 38 -> 19
+                    // stride-2 block and on every SSD head; the high-resolution few-channel blocks (short k loops), the stride-2 block without an expand stage and
+                    // the 10 x 10 block stay on the per-layer kernels
+                    const int px = bq.Ho * bq.Wo;
+                    const bool win = head || (ai >= 0 && ops[ai].inc >= 40 && px >= 256 && px <= 400);
+                    if (!win) continue;
+                }
                 const int NT = (c.outc + 31) / 32, NQ = di >= 0 ? (ops[di].outc + 31) / 32 : 0;
-                if (!sgx_irb_supported(bq.k, bq.stride, NT, NQ, ai >= 0)) continue;
-                if (ai >= 0 && (ops[ai].inc % 8)) continue;                       // the expand operand ring advances four k-steps at a time
+                if (!sgx_irb_supported(bq.k, bq.stride, NT, NQ, ai >= 0, cb.mode == SGX_EMODE_HSWISH)) continue;
+                if (ai >= 0 && ca.mode != cb.mode) continue;                      // one activation kind per instantiation
+                if (bq.outc % 8) continue;                                        // stage B advances four k-steps per trip
                 // geometry: whole images (G per workgroup) or bands of output rows; two plane buffers when they fit
                 SgxIrb ib; memset(&ib, 0, sizeof ib);
                 ib.Cin = ai >= 0 ? ops[ai].inc : bq.inc; ib.Cexp = bq.outc; ib.Cout = c.outc; ib.Cq = di >= 0 ? ops[di].outc : 0;
@@ -475,17 +486,25 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                 const size_t lds_max = 160 * 1024; const int kkp = SGX_IRB_KKP(bq.k), max_px = 384;
                 auto lds_of = [&](int g, int oh, int nb) { const int planeT = ((g * ((oh - 1) * bq.stride + bq.k) * ib.Wp + 3) / 4) * 4; return (size_t)nb * 32 * (planeT + kkp) * 4; };
                 int G = 0, OH = bq.Ho, nbands = 1, nbuf = 2;
-                if (bq.Ho * bq.Wo <= max_px && lds_of(1, bq.Ho, 1) <= lds_max) {
-                    G = std::max(1, max_px / (bq.Ho * bq.Wo));
+                static const int env_g = getenv("SGX_IRB_G") ? atoi(getenv("SGX_IRB_G")) : 0, env_nbuf = getenv("SGX_IRB_NBUF") ? atoi(getenv("SGX_IRB_NBUF")) : 0,
+                                 env_split = getenv("SGX_IRB_SPLIT") ? atoi(getenv("SGX_IRB_SPLIT")) : 0, env_minhw = getenv("SGX_IRB_MINHW") ? atoi(getenv("SGX_IRB_MINHW")) : 0;      // tuning taps
+                if (bq.Ho * bq.Wo < env_minhw) continue;
+                const bool split = env_split > 0 && bq.Ho * bq.Wo >= env_split;          // force bands of about half the image
+                if (!split && bq.Ho * bq.Wo <= max_px && lds_of(1, bq.Ho, 1) <= lds_max) {
+                    // one image per workgroup (two of the tiny maps): many small workgroups fill the chip and overlap each other's barriers better than a few
+                    // large ones (measured at 512 frames: 10 x 10 maps 0.91 -> 0.78 ms, 5 x 5 heads 0.15 -> 0.08 ms against three / twelve images per workgroup)
+                    G = std::min(std::max(1, max_px / (bq.Ho * bq.Wo)), bq.Ho * bq.Wo >= 64 ? 1 : 2);
+                    if (env_g > 0) G = std::min(std::max(1, max_px / (bq.Ho * bq.Wo)), env_g);
                     while (G > 1 && lds_of(G, bq.Ho, 2) > lds_max) G--;
                     nbuf = lds_of(G, bq.Ho, 2) <= lds_max ? 2 : 1;
                 } else {
-                    G = 1; OH = std::max(1, std::min(bq.Ho, max_px / bq.Wo));
+                    G = 1; OH = std::max(1, std::min(split ? (bq.Ho + 1) / 2 : bq.Ho, max_px / bq.Wo));
                     while (OH > 1 && lds_of(1, OH, 1) > lds_max) OH--;
                     if (lds_of(1, OH, 1) > lds_max || OH * bq.Wo > 1024) continue;
                     nbands = (bq.Ho + OH - 1) / OH; OH = (bq.Ho + nbands - 1) / nbands;              // even bands
                     nbuf = lds_of(1, OH, 2) <= lds_max ? 2 : 1;
                 }
+                if (env_nbuf == 1) nbuf = 1;
                 ib.G = G; ib.OH = OH; ib.nbands = nbands; ib.nbuf = nbuf;
                 ib.HpWp = ((OH - 1) * bq.stride + bq.k) * ib.Wp; ib.planeT = ((G * ib.HpWp + 3) / 4) * 4;
                 {   // 32-bit offsets inside the kernel
@@ -493,6 +512,7 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                     if (big >= 0xFFFFFFFFull) continue;
                 }
                 ib.has_expand = ai >= 0;
+                { static const int env_stagger = getenv("SGX_IRB_STAGGER") ? atoi(getenv("SGX_IRB_STAGGER")) : 1; ib.stagger = env_stagger; }
                 if (ai >= 0) { ib.act1 = ca.mode; ib.a1c1 = ca.c1; ib.a1lo = ca.lo; ib.a1hi = ca.hi; ib.a1c2 = ca.c2; ib.w1T = ops[ai].wtT; ib.b1 = ops[ai].bias; ib.ld1 = ops[ai].ldw; ib.w1 = ops[ai].wt; }
                 ib.act2 = cb.mode; ib.a2c1 = cb.c1; ib.a2lo = cb.lo; ib.a2hi = cb.hi; ib.a2c2 = cb.c2;
                 ib.w2T = c.wtT; ib.b2 = c.bias; ib.ld2 = c.ldw; ib.w2 = c.wt; ib.wd = bq.wt; ib.bd = bq.bias;
@@ -534,6 +554,7 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
     if (h->alloc(&h->d_priors, (size_t)h->num_priors * 4) || h->alloc(&h->d_cls_rows, (size_t)B * (h->num_class - 1) * SGX_DO_TOPK * 6) ||
         h->alloc(&h->d_cls_count, (size_t)B * (h->num_class - 1)) || h->alloc(&h->d_results, (size_t)B)) { delete h; return SGX_ERR_NOMEM; }
     if (hipMemcpy(h->d_priors, prior_boxes.data(), sizeof(float) * 4 * h->num_priors, hipMemcpyHostToDevice) != hipSuccess) { delete h; return SGX_ERR_DEVICE; }
+    if (hipMemset(h->d_results, 0, sizeof(sgx_det_result) * (size_t)B) != hipSuccess) { delete h; return SGX_ERR_DEVICE; }      // entries past the counts are never written: keep them defined
     std::vector<SgxDetTab> xt, yt; build_tab(width, T, xt); build_tab(height, T, yt);
     if (h->alloc(&h->d_xt, T) || h->alloc(&h->d_yt, T) || h->alloc(&h->d_img, (size_t)B * height * ((3 * width + 3) & ~3) + 4)) { delete h; return SGX_ERR_NOMEM; }
     if (hipMemcpy(h->d_xt, xt.data(), sizeof(SgxDetTab) * T, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(h->d_yt, yt.data(), sizeof(SgxDetTab) * T, hipMemcpyHostToDevice) != hipSuccess) { delete h; return SGX_ERR_DEVICE; }

@@ -30,7 +30,7 @@ struct SgxIrb {
     int H, W, Ho, Wo, K, S, pad;
     int G, nbands, OH, batch;                   // images per workgroup (nbands == 1) or bands of OH output rows per image (G == 1)
     int Wp, HpWp, planeT, nbuf;                 // LDS plane geometry in floats: row pitch, per-image plane, per-channel plane (G images); 1 or 2 plane buffers
-    int has_expand;
+    int has_expand, stagger;
     int act1, act2;                             // SGX_EMODE_ACT / SGX_EMODE_HSWISH
     float a1c1, a1lo, a1hi, a1c2, a2c1, a2lo, a2hi, a2c2;
     float qlo, qhi;                             // squeeze activation
@@ -70,13 +70,18 @@ SGX_DEV void sgx_irb_d2b(const sgx_f32x16 &d, float (&b)[16])
 // operand streams are buffer loads: 128-bit descriptor (wave-uniform) + 32-bit lane byte offset + scalar byte offset: no per-load address arithmetic
 typedef __amdgpu_buffer_rsrc_t sgx_rsrc;
 SGX_DEV sgx_rsrc sgx_mkrsrc(const void *ptr) { return __builtin_amdgcn_make_buffer_rsrc((void *)ptr, 0, 0x7fffffff, 0x00020000); }
+SGX_DEV sgx_rsrc sgx_mkrsrc_n(const void *ptr, int bytes) { return __builtin_amdgcn_make_buffer_rsrc((void *)ptr, 0, bytes, 0x00020000); }      // loads past `bytes` return 0
 SGX_DEV float sgx_bld(sgx_rsrc r, unsigned voff, unsigned soff) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0)); }
+SGX_DEV void sgx_bst(sgx_rsrc r, unsigned voff, unsigned soff, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)voff, (int)soff, 0); }
+// bias of accumulator register r of 32-row tile t: row = 32 t + (r & 3) + 8 (r >> 2) + 4 half; the descriptor ends at the last channel, so padded rows read 0
+#define SGX_IRB_BIAS(rs, t, r, half) sgx_bld(rs, (unsigned)(half) * 16u, (unsigned)(32 * (t) + ((r) & 3) + 8 * ((r) >> 2)) * 4u)
 
-template <int K, int S, int NT, int NQ, bool EXPAND>
+template <int K, int S, int NT, int NQ, bool EXPAND, bool HS>
 __global__ void __launch_bounds__(768) k_irb(SgxIrb p)
 {
     extern __shared__ __attribute__((aligned(16))) float sgx_irb_smem[];
     constexpr int KK = K * K, KKP = SGX_IRB_KKP(K);
+    constexpr int AMODE = HS ? SGX_EMODE_HSWISH : SGX_EMODE_ACT;      // both activations of a block are of one kind in this graph (planner checks)
     float *Eb = sgx_irb_smem;                                         // [nbuf][32][planeT]
     float *Wds = sgx_irb_smem + (size_t)p.nbuf * 32 * p.planeT;       // [nbuf][32][KKP]
     const int tid = (int)threadIdx.x, nthreads = (int)blockDim.x, wave = tid >> 6, nwaves = nthreads >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
@@ -86,107 +91,148 @@ __global__ void __launch_bounds__(768) k_irb(SgxIrb p)
     else { b0 = (int)blockIdx.x * p.G; nimg = min(p.G, p.batch - b0); oy0 = 0; OH = p.Ho; }
     const int ypA = oy0 * S;                                          // first padded input row held in the planes
     const int iyA = max(0, ypA - p.pad), iyB = min(p.H, (oy0 + OH - 1) * S + K - p.pad), IH = iyB - iyA;      // real input rows [iyA, iyB)
-    const int PI = nimg * IH * p.W, PO = nimg * OH * p.Wo, ngi = (PI + 31) >> 5;
-    // my output pixel
+    const int PI = nimg * IH * p.W, PO = nimg * OH * p.Wo, ngi = (PI + 31) >> 5, ngo = (PO + 31) >> 5;
+    // my output pixel (waves past the last output group only help with stage A)
+    const bool owner = wave < ngo;
     const int og = wave * 32 + l31; const bool ovalid = og < PO;
     const int oc_ = min(og, PO - 1), og_img = oc_ / (OH * p.Wo), orem = oc_ - og_img * (OH * p.Wo), oyl = orem / p.Wo, ox = orem - oyl * p.Wo;
     const int e_r = half * p.planeT + og_img * p.HpWp + oyl * S * p.Wp + ox * S;                // depthwise read base (tap (i, j): + i Wp + j; k-step s: + 2 s planeT)
     const unsigned opix = (unsigned)((oy0 + oyl) * p.Wo + ox);
-    const sgx_rsrc r_in = sgx_mkrsrc(p.in), r_w1 = sgx_mkrsrc(EXPAND ? p.w1T : p.w2T), r_w2 = sgx_mkrsrc(p.w2T);
+    const sgx_rsrc r_in = sgx_mkrsrc(p.in), r_w1 = sgx_mkrsrc(EXPAND ? p.w1T : p.w2T), r_w2 = sgx_mkrsrc(p.w2T), r_b1 = sgx_mkrsrc_n(EXPAND ? p.b1 : p.b2, (EXPAND ? p.Cexp : p.Cout) * 4);
 
     {   // zero the plane buffers once: borders and rows outside the image stay zero, the interior is rewritten per chunk
         float4 *z = (float4 *)Eb; const int nz = p.nbuf * 8 * p.planeT;
         for (int i = tid; i < nz; i += nthreads) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     sgx_f32x16 acc[NT];
+    {
+        const sgx_rsrc r_b2 = sgx_mkrsrc_n(p.b2, p.Cout * 4);
 #pragma unroll
-    for (int t = 0; t < NT; t++)
+        for (int t = 0; t < NT; t++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) { const int row = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half; const float bv = p.b2[min(row, p.Cout - 1)]; acc[t][r] = row < p.Cout ? bv : 0.f; }
+            for (int r = 0; r < 16; r++) acc[t][r] = SGX_IRB_BIAS(r_b2, t, r, half);
+    }
 
     const int nchunks = (p.Cexp + 31) >> 5, bmask = p.nbuf - 1;
     const unsigned aoff1 = (unsigned)(half * p.ld1 + l31) * 4u, aoff2 = (unsigned)(half * p.ld2 + l31) * 4u;
+    const unsigned sXstep = (unsigned)(2 * HW) * 4u;
+
+    // first stage-A tile of this wave (tile = wave): geometry is chunk-independent
+    const int q0 = wave * 32 + l31; const bool ivalid0 = q0 < PI && wave < ngi;
+    const int qc0 = min(q0, PI - 1), qi0 = qc0 / (IH * p.W), qrem0 = qc0 - qi0 * (IH * p.W), ry0 = qrem0 / p.W, ix0 = qrem0 - ry0 * p.W, iy0 = iyA + ry0;
+    const int ew0 = qi0 * p.HpWp + (iy0 + p.pad - ypA) * p.Wp + ix0 + p.pad;
+    const unsigned xoff0 = (unsigned)((size_t)(b0 + qi0) * p.in_pitch + (size_t)iy0 * p.W + ix0 + (size_t)half * HW) * 4u;
+
+    // depthwise convolution of k-step s of a chunk at this lane's output pixel = B operand of the project GEMM
+    auto dw = [&](const float *E, const float *Wc, int s) -> float {
+        float w[KKP];
+#pragma unroll
+        for (int i = 0; i < KKP / 4; i++) { const float4 q4 = ((const float4 *)(Wc + 2 * s * KKP))[i]; w[4 * i] = q4.x; w[4 * i + 1] = q4.y; w[4 * i + 2] = q4.z; w[4 * i + 3] = q4.w; }
+        const float *ep = E + (size_t)2 * s * p.planeT;
+        float v = w[KK];
+#pragma unroll
+        for (int i = 0; i < K; i++)
+#pragma unroll
+            for (int j = 0; j < K; j++) v = fmaf(w[i * K + j], ep[i * p.Wp + j], v);
+        return sgx_irb_act(AMODE, v, p.a2c1, p.a2lo, p.a2hi, p.a2c2);
+    };
 
     for (int c = -1; c < nchunks; c++) {
-        // ---- stage B of chunk c: depthwise into the B operand, project on the matrix cores
-        if (c >= 0) {
+        const int ch1 = (c + 1) * 32, buf1 = (c + 1) & bmask;
+        const bool more = c + 1 < nchunks;
+        // ---- no expand stage: the next chunk's depthwise input (first tile of this wave) is requested before this chunk's stage B and parked in registers
+        float pre[EXPAND ? 1 : 16];
+        if (!EXPAND && more && p.nbuf == 2) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) pre[r] = sgx_bld(r_in, xoff0, (unsigned)min(ch1 + 2 * r, p.Cexp - 2) / 2u * sXstep);
+        }
+        // ---- stage B of chunk c: depthwise into the B operand, project on the matrix cores; the depthwise value of step s + 1 is computed beside the
+        // MFMAs of step s (independent instruction streams for the scheduler), the project weights are requested two steps ahead
+        // With two plane buffers stage B of chunk c and stage A of chunk c + 1 touch different buffers between the same two barriers, so their order inside a
+        // wave is free: waves 4..7 run A first, the others B first — at any time part of the workgroup is in the MFMA + load heavy stage A while the rest is
+        // in the VALU / LDS / MFMA mix of stage B, instead of all twelve waves hitting the same phase (and its VALU-only activation tail) together.
+        const int a_first = (p.nbuf == 2 && p.stagger) ? ((wave >> 2) & 1) : 0;
+#pragma unroll 1
+        for (int hp = 0; hp < 2; hp++) {
+        if (hp == a_first && c >= 0 && owner) {
             const int ch0 = c * 32, nks = min(16, (p.Cexp - ch0) >> 1), buf = c & bmask;
             const float *E = Eb + (size_t)buf * 32 * p.planeT + e_r;
             const float *Wc = Wds + (size_t)buf * 32 * KKP + half * KKP;
             const unsigned sB = (unsigned)(ch0 * p.ld2) * 4u, sstep = (unsigned)(2 * p.ld2) * 4u;
-            float an[NT];
+            // project weights: a ring of R k-steps in flight, statically indexed (the loop advances R steps per trip; Cexp is a multiple of 8: planner), so a
+            // load is only waited for R steps after it was issued
+            constexpr int R = 4;
+            float ar[R][NT];
 #pragma unroll
-            for (int t = 0; t < NT; t++) an[t] = sgx_bld(r_w2, aoff2 + 128u * t, sB);
-            for (int s = 0; s < nks; s++) {
-                float a[NT];
+            for (int d = 0; d < R; d++)
 #pragma unroll
-                for (int t = 0; t < NT; t++) a[t] = an[t];
-                {
-                    const unsigned sn = sB + (unsigned)min(s + 1, nks - 1) * sstep;
+                for (int t = 0; t < NT; t++) ar[d][t] = sgx_bld(r_w2, aoff2 + 128u * t, sB + (unsigned)min(d, nks - 1) * sstep);
+            float v = dw(E, Wc, 0);
+            for (int s0 = 0; s0 < nks; s0 += R) {
 #pragma unroll
-                    for (int t = 0; t < NT; t++) an[t] = sgx_bld(r_w2, aoff2 + 128u * t, sn);
+                for (int d = 0; d < R; d++) {
+                    const int s = s0 + d;
+#pragma unroll
+                    for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[d][t], v, acc[t], 0, 0, 0);
+                    const unsigned sn = sB + (unsigned)min(s + R, nks - 1) * sstep;
+#pragma unroll
+                    for (int t = 0; t < NT; t++) ar[d][t] = sgx_bld(r_w2, aoff2 + 128u * t, sn);
+                    v = dw(E, Wc, min(s + 1, nks - 1));
                 }
-                float w[KKP];
-#pragma unroll
-                for (int i = 0; i < KKP / 4; i++) { const float4 q4 = ((const float4 *)(Wc + 2 * s * KKP))[i]; w[4 * i] = q4.x; w[4 * i + 1] = q4.y; w[4 * i + 2] = q4.z; w[4 * i + 3] = q4.w; }
-                const float *ep = E + (size_t)2 * s * p.planeT;
-                float v = w[KK];
-#pragma unroll
-                for (int i = 0; i < K; i++)
-#pragma unroll
-                    for (int j = 0; j < K; j++) v = fmaf(w[i * K + j], ep[i * p.Wp + j], v);
-                v = sgx_irb_act(p.act2, v, p.a2c1, p.a2lo, p.a2hi, p.a2c2);
-#pragma unroll
-                for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], v, acc[t], 0, 0, 0);
             }
         }
-        if (p.nbuf == 1) __syncthreads();
+        if (p.nbuf == 1 && hp == 0) __syncthreads();
         // ---- stage A of chunk c + 1 into its plane buffer: expand on the matrix cores (or a plain load), activation, LDS write; the chunk's depthwise weights
-        if (c + 1 < nchunks) {
-            const int ch0 = (c + 1) * 32, buf = (c + 1) & bmask;
-            float *E = Eb + (size_t)buf * 32 * p.planeT;
-            for (int i = tid; i < 8 * KKP; i += nthreads) ((float4 *)(Wds + (size_t)buf * 32 * KKP))[i] = ((const float4 *)(p.wdp + (size_t)ch0 * KKP))[i];
+        if (hp != a_first && more) {
+            float *E = Eb + (size_t)buf1 * 32 * p.planeT;
+            for (int i = tid; i < 8 * KKP; i += nthreads) ((float4 *)(Wds + (size_t)buf1 * 32 * KKP))[i] = ((const float4 *)(p.wdp + (size_t)ch1 * KKP))[i];
             for (int tile = wave; tile < ngi; tile += nwaves) {
-                const int q = tile * 32 + l31; const bool ivalid = q < PI;
-                const int qc = min(q, PI - 1), qi = qc / (IH * p.W), qrem = qc - qi * (IH * p.W), ry = qrem / p.W, ix = qrem - ry * p.W, iy = iyA + ry;
-                float *Ew = E + qi * p.HpWp + (iy + p.pad - ypA) * p.Wp + ix + p.pad;
-                const unsigned xoff = (unsigned)((size_t)(b0 + qi) * p.in_pitch + (size_t)iy * p.W + ix + (size_t)half * HW) * 4u;
+                const bool first = tile == wave;
+                int ew; unsigned xoff; bool ivalid;
+                if (first) { ew = ew0; xoff = xoff0; ivalid = ivalid0; }
+                else {
+                    const int q = tile * 32 + l31; ivalid = q < PI;
+                    const int qc = min(q, PI - 1), qi = qc / (IH * p.W), qrem = qc - qi * (IH * p.W), ry = qrem / p.W, ix = qrem - ry * p.W, iy = iyA + ry;
+                    ew = qi * p.HpWp + (iy + p.pad - ypA) * p.Wp + ix + p.pad;
+                    xoff = (unsigned)((size_t)(b0 + qi) * p.in_pitch + (size_t)iy * p.W + ix + (size_t)half * HW) * 4u;
+                }
+                float *Ew = E + ew;
                 if (EXPAND) {
                     sgx_f32x16 e;
 #pragma unroll
-                    for (int r = 0; r < 16; r++) { const int row = ch0 + (r & 3) + 8 * (r >> 2) + 4 * half; const float bv = p.b1[min(row, p.Cexp - 1)]; e[r] = row < p.Cexp ? bv : 0.f; }
-                    constexpr int D = 4;                                  // operand ring: D k-steps in flight (Cin / 2 is a multiple of D: planner)
-                    const int nks = p.Cin >> 1;
-                    const unsigned sA = (unsigned)ch0 * 4u, sAstep = (unsigned)(2 * p.ld1) * 4u, sXstep = (unsigned)(2 * HW) * 4u;
+                    for (int r = 0; r < 16; r++) e[r] = sgx_bld(r_b1, (unsigned)half * 16u, (unsigned)(ch1 + (r & 3) + 8 * (r >> 2)) * 4u);
+                    // operand ring: D k-steps in flight.  The k loop runs over whole groups of D steps: steps past Cin / 2 meet zero weight rows (the host pads the
+                    // transposed weights to a multiple of 32 rows) and a clamped, finite input row — the per-layer kernel k_conv_pw2 pads the same way
+                    constexpr int D = 8;
+                    const int nks = p.Cin >> 1, nkp = (nks + D - 1) & ~(D - 1);
+                    const unsigned sA = (unsigned)ch1 * 4u, sAstep = (unsigned)(2 * p.ld1) * 4u;
                     float ar[D], br[D];
 #pragma unroll
-                    for (int d = 0; d < D; d++) { ar[d] = sgx_bld(r_w1, aoff1, sA + d * sAstep); br[d] = sgx_bld(r_in, xoff, d * sXstep); }
-                    for (int s0 = 0; s0 < nks; s0 += D) {
+                    for (int d = 0; d < D; d++) { ar[d] = sgx_bld(r_w1, aoff1, sA + d * sAstep); br[d] = sgx_bld(r_in, xoff, (unsigned)min(d, nks - 1) * sXstep); }
+                    for (int s0 = 0; s0 < nkp; s0 += D) {
 #pragma unroll
                         for (int d = 0; d < D; d++) {
-                            const float a = ar[d], bb = br[d];
-                            const unsigned sn = (unsigned)min(s0 + d + D, nks - 1);
-                            ar[d] = sgx_bld(r_w1, aoff1, sA + sn * sAstep); br[d] = sgx_bld(r_in, xoff, sn * sXstep);
-                            e = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, e, 0, 0, 0);
+                            e = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[d], br[d], e, 0, 0, 0);       // the MFMA reads its operands at issue: the slot is reloaded right behind it
+                            const int sn = min(s0 + d + D, nkp - 1);
+                            ar[d] = sgx_bld(r_w1, aoff1, sA + (unsigned)sn * sAstep); br[d] = sgx_bld(r_in, xoff, (unsigned)min(sn, nks - 1) * sXstep);
                         }
                     }
-                    if (p.act1 == SGX_EMODE_HSWISH) {
 #pragma unroll
-                        for (int r = 0; r < 16; r++) e[r] = sgx_irb_act(SGX_EMODE_HSWISH, e[r], p.a1c1, p.a1lo, p.a1hi, p.a1c2);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 16; r++) e[r] = fminf(fmaxf(e[r], p.a1lo), p.a1hi);
-                    }
+                    for (int r = 0; r < 16; r++) e[r] = sgx_irb_act(AMODE, e[r], p.a1c1, p.a1lo, p.a1hi, p.a1c2);
                     if (ivalid) {                                         // rows past Cexp of the last chunk are written but never read (stage B stops at Cexp)
 #pragma unroll
                         for (int r = 0; r < 16; r++) Ew[(size_t)((r & 3) + 8 * (r >> 2) + 4 * half) * p.planeT] = e[r];
                     }
                 } else {
-                    // depthwise input from global memory: lane (half, pixel) loads channels ch0 + 2 r + half, r = 0..15 (two coalesced rows per load)
+                    // depthwise input from global memory: lane (half, pixel) loads channels ch1 + 2 r + half, r = 0..15 (two coalesced rows per load)
                     float v[16];
-                    const unsigned sXstep = (unsigned)(2 * HW) * 4u;
+                    if (first && p.nbuf == 2) {
 #pragma unroll
-                    for (int r = 0; r < 16; r++) v[r] = sgx_bld(r_in, xoff, (unsigned)min(ch0 + 2 * r, p.Cexp - 2) / 2u * sXstep);
+                        for (int r = 0; r < 16; r++) v[r] = pre[r];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) v[r] = sgx_bld(r_in, xoff, (unsigned)min(ch1 + 2 * r, p.Cexp - 2) / 2u * sXstep);
+                    }
                     if (ivalid) {
 #pragma unroll
                         for (int r = 0; r < 16; r++) Ew[(size_t)(2 * r + half) * p.planeT] = v[r];
@@ -194,22 +240,23 @@ __global__ void __launch_bounds__(768) k_irb(SgxIrb p)
                 }
             }
         }
+        }
         __syncthreads();
     }
 
     // ---- epilogue: [squeeze-excite gate] [+ residual], store
-    const unsigned obase = (unsigned)((size_t)(b0 + og_img) * p.out_pitch), rbase = (unsigned)((size_t)(b0 + og_img) * p.res_pitch);
+    if (!owner) return;
     if (NQ > 0) {
         // Both 1x1 convolutions of the gate run out of registers in groups of four k-steps (one register quad of a tile = 8 rows); the A operands of the
         // next group are in flight while the current group's MFMAs issue, and a scheduling barrier per group keeps the compiler from hoisting every load
         // of the unrolled chain to the top (hundreds of live registers).
-        const sgx_rsrc r_q1 = sgx_mkrsrc(p.wq1T), r_q2 = sgx_mkrsrc(p.wq2T);
+        const sgx_rsrc r_q1 = sgx_mkrsrc(p.wq1T), r_q2 = sgx_mkrsrc(p.wq2T), r_bq1 = sgx_mkrsrc_n(p.bq1, p.Cq * 4), r_bq2 = sgx_mkrsrc_n(p.bq2, p.Cout * 4);
         constexpr int NQ1 = NQ > 0 ? NQ : 1;
         sgx_f32x16 qa[NQ1];
 #pragma unroll
         for (int u = 0; u < NQ; u++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) { const int row = 32 * u + (r & 3) + 8 * (r >> 2) + 4 * half; const float bv = p.bq1[min(row, p.Cq - 1)]; qa[u][r] = row < p.Cq ? bv : 0.f; }
+            for (int r = 0; r < 16; r++) qa[u][r] = SGX_IRB_BIAS(r_bq1, u, r, half);
         const unsigned aoffq1 = (unsigned)(half * p.ldq1 + l31) * 4u, aoffq2 = (unsigned)(half * p.ldq2 + l31) * 4u;
         const unsigned sq1 = (unsigned)(2 * p.ldq1) * 4u, sq2 = (unsigned)(2 * p.ldq2) * 4u;          // byte step of one k-step (two weight rows)
         {
@@ -259,7 +306,7 @@ __global__ void __launch_bounds__(768) k_irb(SgxIrb p)
         for (int t = 0; t < NT; t++) {
             sgx_f32x16 ga;
 #pragma unroll
-            for (int r = 0; r < 16; r++) { const int row = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half; const float bv = p.bq2[min(row, p.Cout - 1)]; ga[r] = row < p.Cout ? bv : 0.f; }
+            for (int r = 0; r < 16; r++) ga[r] = SGX_IRB_BIAS(r_bq2, t, r, half);
             float an[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) an[j] = sgx_bld(r_q2, aoffq2 + 128u * t, (unsigned)j * sq2);
@@ -284,17 +331,22 @@ __global__ void __launch_bounds__(768) k_irb(SgxIrb p)
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    // store (+ residual): buffer addressing = lane offset (image, pixel, half-wave row offset) + per-register scalar / immediate row offset
     if (ovalid) {
+        const sgx_rsrc r_out = sgx_mkrsrc(p.out), r_res = sgx_mkrsrc(p.has_res ? (const void *)p.res : (const void *)p.out);
+        const unsigned rvo = (unsigned)((size_t)(b0 + og_img) * p.res_pitch + opix + (size_t)4 * half * HWo) * 4u;
+        const unsigned ovo = p.hwc ? (unsigned)((size_t)(b0 + og_img) * p.out_pitch + (size_t)p.hwc_off + (size_t)opix * p.Cout + 4 * half) * 4u
+                                   : (unsigned)((size_t)(b0 + og_img) * p.out_pitch + opix + (size_t)4 * half * HWo) * 4u;
+        const unsigned rowstep = p.hwc ? 4u : (unsigned)HWo * 4u;
 #pragma unroll
         for (int t = 0; t < NT; t++) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int row = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row < p.Cout) {
+                const int rb = 32 * t + (r & 3) + 8 * (r >> 2);
+                if (rb + 4 * half < p.Cout) {
                     float v = acc[t][r];
-                    if (p.has_res) v = v + p.res[(size_t)rbase + (size_t)row * HWo + opix];
-                    if (p.hwc) p.out[(size_t)obase + (size_t)p.hwc_off + (size_t)opix * p.Cout + row] = v;
-                    else p.out[(size_t)obase + (size_t)row * HWo + opix] = v;
+                    if (p.has_res) v = v + sgx_bld(r_res, rvo, (unsigned)rb * (unsigned)HWo * 4u);
+                    sgx_bst(r_out, ovo, (unsigned)rb * rowstep, v);
                 }
             }
         }
@@ -354,11 +406,11 @@ static void sgx_irb_emu(const SgxIrb &p, int b)
 
 // instantiations the planner may pick: (K, S, NT = ceil(Cout / 32), NQ = ceil(Cq / 32), with / without the expand stage)
 #define SGX_IRB_INSTANCES(X) \
-    X(3, 1, 3, 0, true) X(3, 1, 4, 1, true) X(5, 1, 5, 2, true) X(5, 1, 2, 1, true) X(3, 2, 3, 0, true) X(5, 2, 2, 1, true) \
-    X(5, 2, 5, 2, false) X(3, 1, 1, 0, false) X(3, 1, 3, 0, false) X(3, 1, 4, 0, false)
-static inline bool sgx_irb_supported(int K, int S, int NT, int NQ, bool expand)
+    X(3, 1, 3, 0, true, true) X(3, 1, 4, 1, true, true) X(5, 1, 5, 2, true, true) X(5, 1, 2, 1, true, false) X(3, 2, 3, 0, true, true) X(5, 2, 2, 1, true, false) \
+    X(5, 2, 5, 2, false, true) X(3, 1, 1, 0, false, false) X(3, 1, 3, 0, false, false) X(3, 1, 4, 0, false, false)
+static inline bool sgx_irb_supported(int K, int S, int NT, int NQ, bool expand, bool hswish)
 {
-#define SGX_IRB_X(K_, S_, NT_, NQ_, E_) if (K == K_ && S == S_ && NT == NT_ && NQ == NQ_ && expand == E_) return true;
+#define SGX_IRB_X(K_, S_, NT_, NQ_, E_, H_) if (K == K_ && S == S_ && NT == NT_ && NQ == NQ_ && expand == E_ && hswish == H_) return true;
     SGX_IRB_INSTANCES(SGX_IRB_X)
 #undef SGX_IRB_X
     return false;
@@ -372,13 +424,15 @@ static inline int sgx_irb_launch(const SgxIrb &p, int batch, sgx_stream_t st)
     return SGX_OK;
 #else
     const int NT = (p.Cout + 31) / 32, NQ = (p.Cq + 31) / 32;
-    const int maxPO = p.nbands > 1 ? p.OH * p.Wo : p.G * p.Ho * p.Wo, nw = (maxPO + 31) / 32;
+    const int maxPO = p.nbands > 1 ? p.OH * p.Wo : p.G * p.Ho * p.Wo, ngo = (maxPO + 31) / 32;
+    const int maxPI = p.nbands > 1 ? std::min(p.H, (p.OH - 1) * p.S + p.K) * p.W : p.G * p.H * p.W;
+    const int nw = std::max(ngo, std::min(12, (maxPI + 31) / 32));               // one wave per output-pixel group; up to 12 waves share the stage-A tiles
     const unsigned grid = p.nbands > 1 ? (unsigned)(batch * p.nbands) : (unsigned)((batch + p.G - 1) / p.G);
     const size_t lds = sgx_irb_lds_bytes(p);
     if (nw > 12 || lds > 160 * 1024) return SGX_ERR_UNSUPPORTED;
     SgxIrb q = p; q.batch = batch;
-#define SGX_IRB_X(K_, S_, NT_, NQ_, E_) if (p.K == K_ && p.S == S_ && NT == NT_ && NQ == NQ_ && (p.has_expand != 0) == E_) { \
-        auto kfn = k_irb<K_, S_, NT_, NQ_, E_>; static bool attr = false; \
+#define SGX_IRB_X(K_, S_, NT_, NQ_, E_, H_) if (p.K == K_ && p.S == S_ && NT == NT_ && NQ == NQ_ && (p.has_expand != 0) == E_ && (p.act2 == SGX_EMODE_HSWISH) == H_) { \
+        auto kfn = k_irb<K_, S_, NT_, NQ_, E_, H_>; static bool attr = false; \
         if (!attr) { (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * nw), lds, st, q); return SGX_OK; }
     SGX_IRB_INSTANCES(SGX_IRB_X)

@@ -24,7 +24,7 @@ class Detector2D:
         self.lib.dll.sgx_det_debug_set_fusion(1 if fuse else 0)      # fuse=False: one kernel per ncnn layer, every blob kept (tests)
         self.lib.dll.sgx_det_debug_set_legacy_kernels(1 if legacy_kernels else 0)      # simple reference kernels instead of the tuned ones (tests)
         self.lib.dll.sgx_det_debug_set_block_fusion(1 if block_fusion else 0)          # opt-in: expand -> depthwise -> project as one kernel (tests / tuning)
-        self.lib.dll.sgx_det_debug_set_irb(-1 if irb is None else (1 if irb else 0))    # inverted-residual blocks / heads as one matrix-core kernel each (default on; tests compare both plans)
+        self.lib.dll.sgx_det_debug_set_irb(-1 if irb is None else (2 if irb is True else int(irb)))    # inverted-residual blocks / heads as one matrix-core kernel each: None = default (the shapes where it wins), True / 2 = every supported shape, False / 0 = off
         self.lib.check(self.lib.dll.sgx_det_create(param_text.encode(), bin_bytes, len(bin_bytes), width, height, max_batch,
                                                    float(detection_confidence_threshold), float(dynamic_detection_confidence_threshold), C.byref(h)), 'sgx_det_create')
         self.lib.dll.sgx_det_debug_set_fusion(1); self.lib.dll.sgx_det_debug_set_legacy_kernels(0); self.lib.dll.sgx_det_debug_set_block_fusion(0); self.lib.dll.sgx_det_debug_set_irb(-1)
