@@ -1,18 +1,20 @@
 #!/usr/bin/env python3
 """bench.py — tracked frames/s of the MI355X tracking hot path on 640x480 RGB-D streams.
 
-One "step" = one frame from each of S independent streams on this GPU pushed through the whole per-frame path (sg_slam_amd/tracker.py):
+One "step" = one frame from each of S independent streams on this GPU pushed through the whole per-frame path by the C++ pipelined host behind the C-ABI
+(sgx_tracker_step_dev, sg_slam_amd/csrc/sgx_tracker.cpp — one ctypes call per step; Python only indexes the resident frame tensors):
   Detector2D::detect (MobileNetV3-SSDLite forward on the fp32 matrix cores + DetectionOutput + filtering, own HIP stream)   [--no-detector to drop]
   ORB extract -> pyramidal LK flow into the previous frame -> RANSAC fundamental matrix -> wait for the detector -> dynamic-feature mask + erase
   -> stereo-from-RGBD -> motion model -> SearchByProjection(cur,last) -> PoseOptimization -> [TrackLocalMap: SearchByProjection(cur, local points)
   -> PoseOptimization] -> unproject -> new map points.
 Frames are resident in HBM before the timed region.  N>1: one process per GPU (torch.distributed over RCCL); streams are sharded across ranks
-(weak scaling, no data-path collective); the per-frame records {n, keypoints, descriptors, pose} of every step are gathered to all ranks with one
-RCCL all_gather per step on a side stream inside the timed region (BASELINE config 5).  value = all ranks' frames / max-over-ranks time.
+(weak scaling, no data-path collective); the per-frame records {n, keypoints, descriptors, pose} of every step are packed by one kernel and gathered to
+rank 0 with one RCCL gather per step on a side stream inside the timed region (BASELINE config 5).  value = all ranks' frames / max-over-ranks time.
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel class by summed HIP-event time inside the timed region), `cpu_baseline` (the oracle —
 CPU restatement of the reference path — timed on host cores) and `config2` (the ORB extract + match + pose-opt chain without detector / LK / RANSAC:
-BASELINE configs[1], last round's headline, for continuity).
+BASELINE configs[1]), `host_input` (the same full chain fed from pinned host buffers: BGR + depth uploaded over PCIe and converted to gray inside the timed region)
+and `config4` (BASELINE configs[3]: bundle adjustment of 2 000 keyframes / 50 000 landmarks, seconds per call with a per-kernel-class roofline table).
 """
 import argparse
 import json
@@ -73,8 +75,8 @@ def ate_pooled(est, ref):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=24)
-    ap.add_argument('--warmup', type=int, default=4)
+    ap.add_argument('--steps', type=int, default=240)
+    ap.add_argument('--warmup', type=int, default=8)
     ap.add_argument('--streams', type=int, default=512, help='independent streams per GPU (frames per step)')
     ap.add_argument('--frames', type=int, default=6, help='distinct frames kept per stream (ping-pong replay)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -83,6 +85,10 @@ def main():
     ap.add_argument('--no-local-map', action='store_true', help='skip the TrackLocalMap stage (local-map SearchByProjection + second PoseOptimization)')
     ap.add_argument('--no-detector', action='store_true', help='drop Detector2D::detect (the mask then sees no person boxes)')
     ap.add_argument('--no-config2', action='store_true', help='skip the secondary ORB extract + match + pose-opt measurement (BASELINE configs[1])')
+    ap.add_argument('--no-config4', action='store_true', help='skip the bundle-adjustment measurement (BASELINE configs[3]: 2 000 keyframes / 50 000 landmarks)')
+    ap.add_argument('--no-host-input', action='store_true', help='skip the host-input measurement (frames uploaded from pinned host memory inside the timed region)')
+    ap.add_argument('--host-steps', type=int, default=40, help='timed steps of the host-input measurement')
+    ap.add_argument('--config2-steps', type=int, default=200, help='timed steps of the configs[1] measurement')
     ap.add_argument('--config2-only', action='store_true', help='measure only the configs[1] chain (no detector, no LK / RANSAC; mask inputs from the synthetic ground truth)')
     ap.add_argument('--param', default=os.path.join(ROOT, 'tests', 'golden', 'mobilenetv3_ssdlite_voc.param'), help='ncnn .param of the detector (the graph the reference ships)')
     ap.add_argument('--bin', default='', help='ncnn .bin weights of the detector (absent from the reference tree; default: synthetic weights in .bin order)')
@@ -92,7 +98,6 @@ def main():
     ap.add_argument('--tum', default='', help='TUM RGB-D sequence directory (rgb/ depth/ associations.txt [groundtruth.txt]): the streams are consecutive chunks of the sequence')
     ap.add_argument('--save-trajectory', default='', help='write stream 0 of rank 0 as a TUM trajectory file (System::SaveTrajectoryTUM format)')
     ap.add_argument('--cpu-sample', type=int, default=120, help='frames timed on the CPU oracle')
-    ap.add_argument('--det-cus', type=int, default=int(os.environ.get('SGX_BENCH_DET_CUS', '0')), help='give the detector stream this many CUs (mask bits from the top) and the tracking streams the rest; 0 = no CU masks')
     args = ap.parse_args()
 
     import torch
@@ -112,7 +117,7 @@ def main():
     import sg_slam_amd
     from sg_slam_amd import synth, tum
     from sg_slam_amd import dist as sdist
-    from sg_slam_amd.tracker import TrackerBatch
+    from sg_slam_amd.tracker_native import TrackerNative
     from sg_slam_amd.capi import _vp
     lib = sg_slam_amd.load()
     cam = dict(synth.TUM3)
@@ -158,10 +163,10 @@ def main():
     def run_config2(steps, warmup):
         """ORB extract -> stereo -> motion model -> match -> pose-opt (-> local map) -> unproject: BASELINE configs[1], last round's headline chain (that one also ran the
         mask + erase kernels on ground-truth flow; they are part of the full path now)"""
-        tr2 = TrackerBatch(lib, S, cam, xp='torch', pipelined=not args.no_pipeline, local_map=not args.no_local_map)
+        tr2 = TrackerNative(lib, S, cam, pipelined=not args.no_pipeline, local_map=not args.no_local_map, dynamic_mask=False)
         tr2.set_initial_pose(initial_poses())
         def st2(i):
-            tr2.step(d_frames[order[i % len(order)]], depth_of(order[i % len(order)]), stream=stream, mask=None)
+            tr2.step(d_frames[order[i % len(order)]], depth_of(order[i % len(order)]), stream=stream)
         for i in range(warmup): st2(i)
         tr2.synchronize(); torch.cuda.synchronize()
         if dist: dist.barrier()
@@ -173,7 +178,8 @@ def main():
         torch.cuda.synchronize()
         dt2 = time.perf_counter() - c0
         if dist: dt2 = sdist.max_over_ranks(dist, dt2, 'cuda')
-        nk, nm, ni = tr2.last_counts()
+        r2 = tr2.read(); nk, nm = r2['nkeys'], r2['nmatch']
+        tr2.close()
         return {'workload': 'Single MI355X: ORB extract+match HIP kernels, 640x480 synthetic stream, 1000 feats/frame', 'value': S * steps * world / dt2, 'unit': 'frames/s',
                 'ms_per_step': dt2 / steps * 1e3, 'steps': steps, 'warmup': warmup, 'mean_keypoints': float(nk.mean()), 'mean_matches': float(nm.mean()),
                 'stages': 'orb_extract, stereo, motion model, SearchByProjection, PoseOptimization, local-map SearchByProjection, PoseOptimization, unproject, make_map_points; '
@@ -189,15 +195,11 @@ def main():
         return
 
     # ------------------------------------------------------------------------------------------------ the full per-frame path
-    tr = TrackerBatch(lib, S, cam, xp='torch', pipelined=not args.no_pipeline, local_map=not args.no_local_map, lk=True, max_boxes=MB)
-    tr.set_initial_pose(initial_poses())
     det = None
     if not args.no_detector:
-        # Detector2D::detect of every frame on its own HIP stream (the reference runs it on its own thread, Detector2D::Run); its person boxes are read by the mask
-        # stage of the SAME frame after an event wait (Frame.cc:478-500) and by the RANSAC pair selection of the NEXT frame (Frame.cc:454-467).
-        import ctypes as C_
+        # Detector2D::detect of every frame on its own HIP stream inside the tracker (the reference runs it on its own thread, Detector2D::Run); its person boxes are read by the
+        # mask stage of the SAME frame after an event wait (Frame.cc:478-500) and by the RANSAC pair selection of the NEXT frame (Frame.cc:454-467).
         from sg_slam_amd.detector import Detector2D
-        from sg_slam_amd.capi import DetResult
         layers = synth.parse_ncnn_param(args.param)
         if args.bin:
             blob = open(args.bin, 'rb').read(); weights_note = f'weights from {os.path.basename(args.bin)}'
@@ -207,49 +209,30 @@ def main():
         det = Detector2D(0.9, 0.01, param_text=open(args.param).read(), bin_bytes=blob, max_batch=S, lib=lib)
         if d_bgr is None:
             d_bgr = d_frames.unsqueeze(-1).expand(T, S, 480, 640, 3).contiguous()          # gray replicated to 3 channels (SURVEY §8(d) input 2)
-        if args.det_cus > 0:
-            from sg_slam_amd.streams import masked_stream
-            sD = masked_stream(256 - args.det_cus, args.det_cus)
-            if tr.pipelined: tr.sE, tr.sT = masked_stream(0, 256 - args.det_cus), masked_stream(0, 256 - args.det_cus)
-        else:
-            sD = torch.cuda.Stream()
-        sD.wait_stream(torch.cuda.current_stream())
-        det_res = [torch.zeros((S, C_.sizeof(DetResult)), dtype=torch.uint8, device='cuda') for _ in range(2)]
-        det_boxes = [torch.zeros((S, MB, 4), dtype=torch.float32, device='cuda') for _ in range(2)]
-        det_nb = [torch.zeros(S, dtype=torch.int32, device='cuda') for _ in range(2)]
-        det_have = [torch.zeros(S, dtype=torch.int32, device='cuda') for _ in range(2)]
-        det_ev = [torch.cuda.Event() for _ in range(2)]
         det_gflop = 2.0 * det.gmac
+    tr = TrackerNative(lib, S, cam, pipelined=not args.no_pipeline, local_map=not args.no_local_map, dynamic_mask=True, max_boxes=MB, detector=det)
+    tr.set_initial_pose(initial_poses())
 
     gather = sdist.FrameRecordGather(dist, S, tr.cap, 'cuda') if dist else None
-    traj = []; box_log = []                       # device pose snapshots per step; (boxes, nboxes) of stream 0 per step for the oracle-chain comparison
+    NSTEP = args.warmup + args.steps
+    traj = torch.zeros((NSTEP, S, 16), dtype=torch.float32, device='cuda')                     # pose snapshots per step (device copies on the tracking stream)
+    NBOX = min(64, NSTEP)
+    box_log = torch.zeros((NBOX, MB, 4), dtype=torch.float32, device='cuda'); nbox_log = torch.zeros((NBOX, 1), dtype=torch.int32, device='cuda')      # stream 0, for the oracle-chain comparison
 
     def step(i):
         fi = order[i % len(order)]
-        m = {}
-        if det is not None:
-            b = i & 1
-            if i >= 2 and tr.pipelined:
-                sD.wait_event(tr.ev_extract[(i - 2) % 3])       # buffer set b was last read by the mask / pre-box copy of step i-2 (extraction stream)
-            det.detect_batch_dev(d_bgr[fi], 640 * 3, S, det_res[b], det_boxes[b], det_nb[b], MB, det_have[b], stream=sD.cuda_stream)
-            det_ev[b].record(sD)
-            m = dict(boxes=det_boxes[b], nboxes=det_nb[b], have_dynamic=det_have[b], event=det_ev[b])
-            if len(box_log) < 64:
-                with torch.cuda.stream(sD):
-                    box_log.append((det_boxes[b][0].clone(), det_nb[b][0:1].clone()))
-        if gather is not None and i >= 3 and tr.pipelined:
-            tr.sE.wait_event(gather.packed[(i - 3) & 1])    # the frame slot about to be overwritten was packed into a send buffer three steps ago
-        tr.step(d_frames[fi], depth_of(fi), stream=stream, mask=m)
-        traj.append(tr.snapshot_pose())
+        tr.step(d_frames[fi], depth_of(fi), d_bgr=d_bgr[fi] if det is not None else None, stream=stream)
+        tr.snapshot_pose(traj[i])
+        if det is not None and i < NBOX:
+            tr.snapshot_boxes(0, box_log[i], nbox_log[i])
         if gather is not None:
-            c = tr.cur
-            gather.submit(tr.n[c], tr.keys[c], tr.desc[c], tr.Tcw[1], after_event=tr.ev_track[c] if tr.pipelined else None)
+            gather.submit_tracker(tr)
 
     for i in range(args.warmup):
         step(i)
     tr.synchronize()
     if gather is not None: gather.wait()
-    tr.ex.last_status(stream=stream)
+    tr.last_status(stream=stream)
     torch.cuda.synchronize()
     if dist: dist.barrier()
     torch.cuda.synchronize()
@@ -260,7 +243,6 @@ def main():
     for i in range(args.steps):
         step(args.warmup + i)
     tr.synchronize()
-    if det is not None: sD.synchronize()
     if gather is not None: gather.wait()
     torch.cuda.synchronize()
     if dist: dist.barrier()
@@ -268,19 +250,24 @@ def main():
     dt = time.perf_counter() - t0
     lib.profile_enable(False)
     prof = lib.profile_read()
-    tr.ex.last_status(stream=stream)
-    nkp, nmatch, ninl = tr.last_counts()
-    nmatch_local, ninl2 = tr.last_local_counts()
-    n_raw = tr.rn.cpu().numpy()
+    tr.last_status(stream=stream)
+    res = tr.read()
+    nkp, nmatch, ninl, nmatch_local, ninl2, n_raw, f_ok, f_stats = (res[k] for k in ('nkeys', 'nmatch', 'ninl', 'nmatch_local', 'ninl2', 'nkeys_raw', 'f_ok', 'f_stats'))
     if not args.no_local_map:
         ninl = ninl2
     tracked = int((ninl >= 10).sum())
-    f_ok = tr.f_ok.cpu().numpy(); f_stats = tr.f_stats.cpu().numpy()
-    nbx = det_nb[(args.warmup + args.steps - 1) & 1].cpu().numpy() if det is not None else np.zeros(S, 'i4')
+    if det is not None:
+        bx_last = torch.zeros((MB, 4), dtype=torch.float32, device='cuda'); nb_all = torch.zeros(S, dtype=torch.int32, device='cuda')
+        for s_ in range(0, S, max(1, S // 64)):                                                   # person-box count of a sample of streams in the last step
+            tr.snapshot_boxes(s_, bx_last, nb_all[s_:s_ + 1])
+        tr.synchronize(); torch.cuda.synchronize()
+        nbx = nb_all[::max(1, S // 64)].cpu().numpy()
+    else:
+        nbx = np.zeros(1, 'i4')
 
     # ---- accuracy over the WHOLE run (warm-up + timed steps): per-stream Horn-aligned ATE against the synthetic ground truth (or groundtruth.txt)
-    N = len(traj)
-    est = torch.stack(traj).cpu().numpy().reshape(N, S, 4, 4).astype('f8')
+    N = NSTEP
+    est = traj.cpu().numpy().reshape(N, S, 4, 4).astype('f8')
     ate_gt = None; ate_sq = 0.0; ate_cnt = 0
     if not args.tum:
         gt = np.stack([np.stack([gen.Tcw(t0 + order[i % len(order)]) for t0 in t0s]) for i in range(N)])
@@ -299,8 +286,9 @@ def main():
         dt = sdist.max_over_ranks(dist, dt, 'cuda')
         sq = sdist.sum_over_ranks(dist, [ate_sq, float(ate_cnt), float(tracked)], 'cuda')
         ate_gt = float(np.sqrt(sq[0] / sq[1])) if sq[1] else None; tracked = int(sq[2])
-        last_rec = gather.unpack(gather.recv[(gather.step_idx - 1) & 1])
-        assert last_rec['n'].shape == (world, S) and (last_rec['n'][rank] == tr.n[tr.cur].cpu().numpy()).all()
+        if rank == 0:
+            last_rec = gather.unpack(gather.last())
+            assert last_rec['n'].shape == (world, S) and (last_rec['n'][0] == nkp).all() and (last_rec['Tcw'][0].reshape(S, 16) == res['Tcw']).all()
     if args.save_trajectory and rank == 0:
         st0 = [stamps[0, order[i % len(order)]] if stamps is not None else float(i) / 30.0 for i in range(N)]
         tum.save_trajectory_tum(args.save_trajectory, st0, [est[i, 0] for i in range(N)])
@@ -308,7 +296,67 @@ def main():
     c2 = None
     if not args.no_config2 and not args.tum:
         del traj
-        c2 = run_config2(8, 2)
+        c2 = run_config2(args.config2_steps, 4)
+
+    # ------------------------------------------------------------------------------------------------ host-input mode: the same chain fed from host memory
+    host_in = None
+    if not args.no_host_input and not args.tum and world == 1:
+        # what a caller that holds cv::imread's images does (rgbd_tum.cc:114-115): BGR + 16-bit depth of every stream are uploaded from pinned host buffers on the tracker's
+        # upload stream and converted to gray on the device (Tracking.cc:214-227) INSIDE the timed region.  The two staging slots are filled once (decode / disk are the
+        # caller's); every step moves S x (921 600 + 614 400) bytes over PCIe.
+        th = TrackerNative(lib, S, cam, pipelined=True, local_map=not args.no_local_map, dynamic_mask=True, max_boxes=MB, detector=det)
+        th.set_initial_pose(initial_poses())
+        for slot in range(2):
+            hb, hd = th.host_buffers(slot)
+            f = order[slot % len(order)]
+            hb[:, :, :640 * 3] = np.repeat(host[f][..., None], 3, -1).reshape(S, 480, 640 * 3)
+            hd[...] = host_depth[f if host_depth.shape[0] > 1 else 0]
+        K = max(2, args.host_steps)
+        for i in range(4): th.step_host(i & 1)
+        th.synchronize(); torch.cuda.synchronize()
+        h0 = time.perf_counter()
+        for i in range(K): th.step_host(i & 1)
+        th.synchronize(); torch.cuda.synchronize()
+        dth = time.perf_counter() - h0
+        rh = th.read(); th.close()
+        up_bytes = S * (480 * 640 * 3 + 480 * 640 * 2)
+        host_in = {'value': S * K / dth, 'unit': 'frames/s', 'ms_per_step': dth / K * 1e3, 'steps': K, 'upload_bytes_per_step': up_bytes, 'upload_GBs': up_bytes * K / dth / 1e9,
+                   'pcie_gen5_x16_spec_GBs': 63.0, 'tracked_streams_last_frame': int(((rh['ninl2'] if not args.no_local_map else rh['ninl']) >= 10).sum()),
+                   'note': 'full chain (detector + ORB + LK + RANSAC + mask + matching + 2 x PoseOptimization) with per-step upload of BGR (3 B/px) + depth (2 B/px) from pinned host '
+                           'memory and BGR2GRAY on the device inside the timed region; staging slots pre-filled with two consecutive frames (image decode is the caller\'s)'}
+
+    # ------------------------------------------------------------------------------------------------ BASELINE configs[3]: bundle adjustment, 2 000 keyframes / 50 000 landmarks
+    c4 = None
+    if not args.no_config4 and not args.tum and world == 1:
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        from scenes import make_big_ba_problem, CAM as BA_CAM          # the seeded generator the parity tests use (SURVEY.md §8(d) input 4)
+        from sg_slam_amd.optimizer import Optimizer
+        prob, Ts, poses0 = make_big_ba_problem(2000, 50000)
+        ne = int(len(prob['edge_pose']))
+        p1 = {k: (v.copy() if hasattr(v, 'copy') else v) for k, v in prob.items()}
+        t4 = time.perf_counter(); Optimizer.LocalBundleAdjustment(p1, BA_CAM, lib=lib); dt4_first = time.perf_counter() - t4      # first call: code objects + device arena
+        lib.profile_read(reset=True); lib.profile_enable(True)
+        t4 = time.perf_counter(); er4, st4 = Optimizer.LocalBundleAdjustment(prob, BA_CAM, lib=lib); dt4 = time.perf_counter() - t4
+        lib.profile_enable(False); prof4 = lib.profile_read()
+        its = int(sum(st4['iterations'])); NP4 = 6 * int(st4['free_poses'])
+        pk4 = {}
+        for k in ('ba_linearize', 'ba_schur', 'ba_solve', 'ba_update'):
+            ms, nl = prof4.get(k, (0.0, 0))
+            if nl: pk4[k] = {'launch_groups': nl, 'total_ms': round(ms, 3), 'avg_ms': round(ms / nl, 4)}
+        if 'ba_linearize' in pk4:      # J^T J / J^T r block accumulation (k_ba_linearize_points + k_ba_linearize_poses): SURVEY.md §8(d): ~192 algorithmic bytes per edge
+            e = pk4['ba_linearize']; e.update({'bound': 'hbm', 'alg_bytes_per_launch': 192 * ne, 'achieved_GBs': round(192 * ne / (e['avg_ms'] * 1e-3) / 1e9, 2)})
+            e['frac'] = e['achieved_GBs'] / HBM_PEAK_GBS
+        if 'ba_solve' in pk4:          # reduced camera system: dense-equivalent Cholesky flops NP^3 / 3 against the fp64 matrix peak (the envelope solver does far fewer)
+            e = pk4['ba_solve']; fl = NP4 ** 3 / 3.0
+            e.update({'bound': 'mfma_f64', 'dense_equivalent_gflop': round(fl / 1e9, 1), 'dense_equivalent_TFLOPs': round(fl / (e['avg_ms'] * 1e-3) / 1e12, 2), 'fp64_peak_TFLOPs': FP64_PEAK_TFS,
+                      'solver': os.environ.get('SGX_BA_SOLVER', 'default')})
+        err_before = float(np.abs(poses0[:, :3, 3] - Ts[:, :3, 3]).max()); err_after = float(np.abs(prob['poses'].astype('f8')[:, :3, 3] - Ts[:, :3, 3]).max())
+        c4 = {'workload': 'Single MI355X: g2o PoseOptimization/LocalBA HIP kernels, 2000 keyframes / 50k landmarks synthetic', 'value': dt4, 'unit': 's per bundle adjustment', 'higher_is_better': False,
+              'seconds_first_call': dt4_first, 'keyframes': 2000, 'landmarks': 50000, 'edges': ne, 'reduced_system_unknowns': NP4, 'lm_iterations': its,
+              'chi2_passes': [float(x) for x in st4['chi2']], 'edges_per_s': ne * its / dt4, 'max_abs_translation_error_before': err_before, 'max_abs_translation_error_after': err_after,
+              'erased_edge_frac': float(np.asarray(er4).mean()), 'per_kernel_class': pk4,
+              'note': 'sgx_local_bundle_adjustment (two LM passes + outlier classification, Optimizer.cc:453-778) on the seeded generator of tests/scenes.py; steady-state second call timed, '
+                      'host flattening + upload + LM control included'}
 
     if rank != 0:
         if dist: dist.destroy_process_group()
@@ -319,7 +367,7 @@ def main():
     alg = algorithmic_bytes_per_frame(nkp=int(round(float(n_raw.mean()))), nmatch=int(round(float(nmatch.mean()))))
     insts = {}
     try:        # wave-level instruction counts per frame from the committed PMC passes (tools/collect_profiles.sh -> profiles/r2_pmc_insts.json)
-        insts = json.load(open(os.path.join(ROOT, 'profiles', 'r2_pmc_insts.json')))
+        insts = json.load(open(next(f for f in (os.path.join(ROOT, 'profiles', n) for n in ('r3_pmc_insts.json', 'r2_pmc_insts.json')) if os.path.exists(f))))
     except Exception:
         insts = {}
     per_kernel = {}
@@ -338,7 +386,8 @@ def main():
                 e['fp64_frac'] = round(ik['fp64_gflop_per_frame'] * S / (avg_ms * 1e-3) / 1e3 / FP64_PEAK_TFS, 4)
         per_kernel[k] = e
     try:        # launch durations with nothing else on the GPU (the timed region above runs three streams at once: every kernel there shares CUs with the detector graph)
-        sj = json.load(open(os.path.join(ROOT, 'profiles', 'r2_standalone.json')))
+        sj_path = next(f for f in (os.path.join(ROOT, 'profiles', n) for n in ('r3_standalone.json', 'r2_standalone.json')) if os.path.exists(f))
+        sj = json.load(open(sj_path))
         if sj['frames_per_launch'] == S:
             for k, v in sj['avg_ms_per_launch'].items():
                 if k in per_kernel: per_kernel[k]['standalone_avg_ms_per_launch'] = round(v, 5)
@@ -348,7 +397,8 @@ def main():
     dk = per_kernel[dom]
     traffic = None
     try:        # HBM traffic of the same kernel class from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), not measured in this run
-        tj = json.load(open(os.path.join(ROOT, 'profiles', 'r2_traffic.json')))
+        tj_path = next(f for f in (os.path.join(ROOT, 'profiles', n) for n in ('r3_traffic.json', 'r2_traffic.json')) if os.path.exists(f))
+        tj = json.load(open(tj_path))
         if tj['frames_per_launch'] == S and dom in tj['bytes_per_launch']:
             traffic = tj['bytes_per_launch'][dom]
     except Exception:
@@ -364,7 +414,7 @@ def main():
     if 'standalone_avg_ms_per_launch' in dk:      # the same kernel class with nothing else on the GPU (committed profile, not measured in this run)
         sa = dk['standalone_avg_ms_per_launch']
         ach = (dk['alg_gflop_per_launch'] / (sa * 1e-3) / 1e3) if dk['bound'] == 'mfma' else (dk['alg_bytes_per_launch'] / (sa * 1e-3) / 1e9)
-        roofline['standalone'] = {'avg_launch_ms': sa, 'achieved': round(ach, 3), 'frac': ach / roofline['peak'], 'source': 'profiles/r2_standalone.json'}
+        roofline['standalone'] = {'avg_launch_ms': sa, 'achieved': round(ach, 3), 'frac': ach / roofline['peak'], 'source': 'profiles/' + os.path.basename(sj_path)}
     if dom == 'det_forward':
         # det_forward is a ~100-node hipGraph, timed as one HIP-event span; the sum of its node kernels' own durations from the committed rocprofv3 kernel statistics of this same
         # command (profiles/r2_bench_kernel_stats.csv) is reported next to it (the two agree when the graph's nodes run back to back).
@@ -372,16 +422,17 @@ def main():
             import csv
             sys.path.insert(0, os.path.join(ROOT, 'tools'))
             from pmc_classes import classify
-            rows = list(csv.DictReader(open(os.path.join(ROOT, 'profiles', 'r2_bench_kernel_stats.csv'))))
+            ks_path = next(f for f in (os.path.join(ROOT, 'profiles', n) for n in ('r3_bench_kernel_stats.csv', 'r2_bench_kernel_stats.csv')) if os.path.exists(f))
+            rows = list(csv.DictReader(open(ks_path)))
             tot_ns = sum(float(r['TotalDurationNs']) for r in rows if classify(r['Name']) == 'det_forward')
             nl = max([int(r['Calls']) for r in rows if r['Name'].startswith('k_det_preprocess')] or [0])
             if nl and S == 512:
                 kms = tot_ns / nl / 1e6
                 roofline['graph_kernel_time'] = {'sum_of_node_kernel_ms_per_launch': round(kms, 3), 'achieved': round(dk['alg_gflop_per_launch'] / (kms * 1e-3) / 1e3, 3),
-                                                 'frac': dk['alg_gflop_per_launch'] / (kms * 1e-3) / 1e3 / MFMA_F32_PEAK_TFS, 'source': 'profiles/r2_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command at 512 streams)'}
+                                                 'frac': dk['alg_gflop_per_launch'] / (kms * 1e-3) / 1e3 / MFMA_F32_PEAK_TFS, 'source': 'profiles/' + os.path.basename(ks_path) + ' (rocprofv3 --kernel-trace --stats of this command at 512 streams)'}
         except Exception:
             pass
-    roofline['traffic_source'] = 'profiles/r2_traffic.json (separate rocprofv3 --pmc passes of this command)' if traffic is not None else None
+    roofline['traffic_source'] = ('profiles/' + os.path.basename(tj_path) + ' (separate rocprofv3 --pmc passes of this command)') if traffic is not None else None
     roofline['per_kernel'] = per_kernel
     orb_ms = sum(per_kernel[k]['avg_ms_per_launch'] * per_kernel[k]['launches'] / args.steps for k in ('pyramid_resize', 'fast_cells', 'octree', 'orient_desc') if k in per_kernel)
     roofline['orb_stage'] = {'ms_per_step_standalone_sum': round(orb_ms, 4), 'alg_bytes_per_frame': 1.96e6,
@@ -403,9 +454,10 @@ def main():
                          f'in this figure (the oracle detector is a numpy port, ~3 s per frame, not representative of ncnn; the reference runs it on a second thread); host has {os.cpu_count()} cores',
                'ms_per_frame_by_stage': {k: round(v / n * 1e3, 3) for k, v in stage.items()}}
         # trajectory of the device path against the oracle chain on the same frames and the same detector boxes ("ATE vs ref"): stream 0, first M frames
-        M = min(N, 32, len(box_log) if det is not None else N)
+        M = min(N, 32, NBOX if det is not None else N)
         if M >= 3:
-            bxs = [bl[0].cpu().numpy()[:int(bl[1].cpu().numpy()[0])] for bl in box_log[:M]] if det is not None else None
+            bl_h, nb_h = box_log.cpu().numpy(), nbox_log.cpu().numpy()
+            bxs = [bl_h[i][:int(nb_h[i, 0])] for i in range(M)] if det is not None else None
             _, otraj = cpu_chain.run_chain([host[t, 0] for t in range(T)], depth_img, cam, gen.Tcw(t0s[0]), order, M, use_lm, boxes=bxs, want_traj=True, restart=False)
             oc = tum.camera_centres(np.stack(otraj)); dc = tum.camera_centres(est[:M, 0])
             ate_oracle = {'frames': M, 'ate_rmse_m': tum.ate_rmse(dc, oc), 'max_abs_pose_entry_diff': float(np.abs(np.stack(otraj).astype('f8') - est[:M, 0]).max()),
@@ -446,7 +498,7 @@ def main():
                    'timed_region': ['detector_detect (forward + DetectionOutput + filtering, own stream)' if det is not None else None, 'orb_extract', 'lk_pyramid + lk_track (calcOpticalFlowPyrLK)',
                                     'fm_ransac (pair selection + findFundamentalMat)', 'wait for detector boxes', 'dynamic_mask + erase', 'stereo_from_rgbd', 'motion_model',
                                     'search_by_projection(cur,last)', 'pose_optimization'] + ([] if args.no_local_map else ['search_by_projection(cur,local_map th=3)', 'pose_optimization#2']) +
-                                   ['unproject'] + ([] if args.no_local_map else ['make_map_points']) + (['all_gather of frame records'] if dist else []),
+                                   ['unproject'] + ([] if args.no_local_map else ['make_map_points']) + (['gather of frame records to rank 0'] if dist else []),
                    'detector': None if det is None else {'graph': os.path.basename(args.param), 'weights': weights_note, 'gflop_per_frame': det_gflop, 'mean_person_boxes_last_step': float(nbx.mean()),
                                                          'boxes_feed_mask_of_same_frame_and_ransac_selection_of_next': True},
                    'local_map_points': 0 if args.no_local_map else 2 * tr.cap, 'mean_local_map_matches': None if args.no_local_map else float(nmatch_local.mean()),
@@ -455,11 +507,12 @@ def main():
                    'fundamental_ok_frac': float(f_ok.mean()), 'mean_ransac_iterations': float(f_stats[:, 0].mean()),
                    'tracked_streams_last_frame': tracked, 'trajectory_frames_per_stream': N,
                    'ate_rmse_m_vs_ground_truth': ate_gt, 'ate_vs_oracle_chain': ate_oracle,
-                   'frame_record_gather': None if gather is None else {'bytes_per_step': gather.world * S * gather.rec_bytes, 'record_bytes': gather.rec_bytes,
+                   'frame_record_gather': None if gather is None else {'collective': 'gather to rank 0 (torch.distributed over RCCL), one per step, records packed by one kernel (sgx_tracker_pack_records_dev)',
+                                                                       'bytes_per_step': gather.world * S * gather.rec_bytes, 'record_bytes': gather.rec_bytes,
                                                                        'GBs': (gather.bytes_moved - gather_bytes0) / dt / 1e9, 'inside_timed_region': True},
-                   'nfeatures': 1000, 'nlevels': 8, 'scale_factor': 1.2, 'parallelism': f'streams-sharded x{world}', 'hip_streams': 1 if args.no_pipeline else (3 if det is not None else 2),
+                   'nfeatures': 1000, 'nlevels': 8, 'scale_factor': 1.2, 'parallelism': f'streams-sharded x{world}', 'hip_streams': 1 if args.no_pipeline else (3 if det is not None else 2), 'host': 'C++ pipelined host behind the C-ABI (sgx_tracker_step_dev): one ctypes call per step',
                    'pose_dtype': 'f64 LM, f32 boundary'},
-        'roofline': roofline, 'cpu_baseline': cpu, 'config2': c2,
+        'roofline': roofline, 'cpu_baseline': cpu, 'config2': c2, 'host_input': host_in, 'config4': c4,
     }
     out['config']['timed_region'] = [x for x in out['config']['timed_region'] if x]
     print(json.dumps(out))

@@ -6,7 +6,8 @@
 
 static int g_on = 0;
 static const char *g_names[SGX_K_COUNT] = { "pyramid_resize", "fast_cells", "octree", "orient_desc", "stereo_from_rgbd",
-                                            "motion_model", "match_project_frame", "pose_opt", "unproject", "match_project_local", "map_point_glue", "dynamic_mask", "lk_pyramid", "lk_track", "fm_ransac", "det_forward", "det_output" };
+                                            "motion_model", "match_project_frame", "pose_opt", "unproject", "match_project_local", "map_point_glue", "dynamic_mask", "lk_pyramid", "lk_track", "fm_ransac", "det_forward", "det_output",
+                                            "ba_linearize", "ba_schur", "ba_solve", "ba_update" };
 #ifndef SGX_EMU
 static std::vector<hipEvent_t> g_a[SGX_K_COUNT], g_b[SGX_K_COUNT];
 static int g_used[SGX_K_COUNT];

@@ -1,6 +1,6 @@
 """Multi-GPU plumbing: one process per GPU, streams sharded across ranks, no data-path collective.
-Only two collectives exist, both outside the per-frame path: the max-over-ranks timing reduce and the
-gather of fixed-size per-frame records (pose + counts) to every rank (BASELINE config 5).
+Two collectives exist, neither on the per-frame data path: the max-over-ranks timing reduce and the
+gather of the fixed-size per-frame records to rank 0 (BASELINE config 5).
 Backend 'nccl' (= RCCL over xGMI) on GPUs; the CPU tests run the same code with 'gloo'."""
 import numpy as np
 
@@ -35,35 +35,58 @@ def sum_over_ranks(dist, values, device):
 
 
 class FrameRecordGather:
-    """BASELINE config 5 / SURVEY.md §8(e): after every step batch the per-frame record {n, cv::KeyPoint[cap], desc[cap][32], Tcw} of each stream is
-    gathered from device memory to every rank with ONE all_gather (RCCL over xGMI on GPUs, gloo on CPU), on its own stream so the next step's kernels
-    overlap the transfer.  Record = 16 B header (n, 3 pad) + cap*28 + cap*32 + 64 B pose, packed per stream into one contiguous uint8 buffer
-    (double-buffered: the pack of step t+1 must not overwrite what the collective of step t still reads)."""
+    """BASELINE config 5 / SURVEY.md §8(e): after every step the per-frame record {n, cv::KeyPoint[cap], desc[cap][32], Tcw} of each of the rank's S streams goes to
+    RANK 0 with one `gather` per step (RCCL over xGMI on GPUs — grouped send / recv underneath —, gloo on CPU).  Record = 16 B header (n, 3 pad) + cap*28 + cap*32 +
+    64 B pose; the S records of a step are packed into one contiguous uint8 buffer by ONE kernel of the library (sgx_tracker_pack_records_dev) on a side stream
+    that waits for the frame's tracking event, so the next step's kernels overlap pack and transfer.  Double-buffered: before send[b] is packed again, the
+    collective that read it two steps earlier is waited for (one Work handle per buffer).  Only rank 0 allocates the (world, S, record) receive buffers:
+    8 x 512 x 61.5 KB = 252 MB per step land on rank 0, nothing on the other ranks (an all_gather would deliver the same 252 MB to every rank)."""
 
-    def __init__(self, dist, streams, cap, device, async_stream=True):
+    def __init__(self, dist, streams, cap, device, async_stream=True, dst=0):
         import torch
-        self.dist, self.S, self.cap, self.device = dist, streams, cap, device
+        self.dist, self.S, self.cap, self.device, self.dst = dist, streams, cap, device, dst
         self.rec_bytes = 16 + cap * 28 + cap * 32 + 64
-        self.world = dist.get_world_size()
+        self.world = dist.get_world_size(); self.rank = dist.get_rank()
         self.send = [torch.zeros((streams, self.rec_bytes), dtype=torch.uint8, device=device) for _ in range(2)]
-        self.recv = [torch.zeros((self.world, streams, self.rec_bytes), dtype=torch.uint8, device=device) for _ in range(2)]
+        self.recv = [torch.zeros((self.world, streams, self.rec_bytes), dtype=torch.uint8, device=device) for _ in range(2)] if self.rank == dst else [None, None]
         self.stream = torch.cuda.Stream() if (async_stream and str(device).startswith('cuda')) else None
-        self.packed = [torch.cuda.Event() for _ in range(2)] if self.stream is not None else None
         self.step_idx = 0
         self.bytes_moved = 0
-        self.pending = None
+        self.pending = [None, None]
 
-    def pack(self, buf, n, keys, desc, Tcw):
+    def pack_torch(self, buf, n, keys, desc, Tcw):
+        """reference packer (tests, CPU): the same layout with tensor slice assignments"""
         import torch
         S, cap = self.S, self.cap
+        buf[:, 0:16] = 0
         buf[:, 0:4] = n.reshape(S, 1).to(torch.int32).view(torch.uint8).reshape(S, 4)
         o = 16
         buf[:, o:o + cap * 28] = keys.reshape(S, cap * 28); o += cap * 28
         buf[:, o:o + cap * 32] = desc.reshape(S, cap * 32); o += cap * 32
         buf[:, o:o + 64] = Tcw.reshape(S, 16).to(torch.float32).contiguous().view(torch.uint8).reshape(S, 64)
 
+    def _gather(self, b, async_op):
+        out = list(self.recv[b].unbind(0)) if self.rank == self.dst else None
+        return self.dist.gather(self.send[b], out, dst=self.dst, async_op=async_op)
+
+    def submit_tracker(self, tracker):
+        """pack the records of the frame `tracker` (sg_slam_amd.tracker_native.TrackerNative) tracked last and start the gather; returns immediately"""
+        import torch
+        b = self.step_idx & 1
+        if self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                if self.pending[b] is not None:
+                    self.pending[b].wait(); self.pending[b] = None    # orders this side stream after the collective that read send[b] two steps ago
+                tracker.pack_records(self.send[b], stream=self.stream.cuda_stream)       # waits for the frame's tracking event inside the library
+                self.pending[b] = self._gather(b, True)
+        else:
+            tracker.pack_records(self.send[b]); self._gather(b, False)
+        self.bytes_moved += self.world * self.S * self.rec_bytes
+        self.step_idx += 1
+        return self.recv[b]
+
     def submit(self, n, keys, desc, Tcw, after_event=None):
-        """pack + all_gather of one step's records; returns immediately when an async stream is used (wait() joins)"""
+        """the same from loose tensors (torch packer): CPU tests and callers without the native tracker"""
         import torch
         b = self.step_idx & 1
         if self.stream is not None:
@@ -72,22 +95,28 @@ class FrameRecordGather:
             else:
                 self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
-                self.pack(self.send[b], n, keys, desc, Tcw)
-                self.packed[b].record(self.stream)
-                self.pending = self.dist.all_gather_into_tensor(self.recv[b].view(self.world * self.S, self.rec_bytes), self.send[b], async_op=True)
+                if self.pending[b] is not None:
+                    self.pending[b].wait(); self.pending[b] = None
+                self.pack_torch(self.send[b], n, keys, desc, Tcw)
+                self.pending[b] = self._gather(b, True)
         else:
-            self.pack(self.send[b], n, keys, desc, Tcw)
-            self.dist.all_gather_into_tensor(self.recv[b].view(self.world * self.S, self.rec_bytes), self.send[b])
+            self.pack_torch(self.send[b], n, keys, desc, Tcw)
+            self._gather(b, False)
         self.bytes_moved += self.world * self.S * self.rec_bytes
         self.step_idx += 1
         return self.recv[b]
 
     def wait(self):
         import torch
-        if self.pending is not None:
-            self.pending.wait(); self.pending = None
+        for b in range(2):
+            if self.pending[b] is not None:
+                self.pending[b].wait(); self.pending[b] = None
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
+
+    def last(self):
+        """receive buffer of the most recent step (rank `dst` only)"""
+        return self.recv[(self.step_idx - 1) & 1]
 
     def unpack(self, rec):
         """(world, S, rec_bytes) uint8 -> dict of numpy arrays: n (world,S), keys (world,S,cap,28) u8, desc (world,S,cap,32) u8, Tcw (world,S,16) f32"""

@@ -53,6 +53,20 @@ def gpulib():
 
 
 @pytest.fixture(scope='session')
+def gpulib_nofma():
+    """The product sources built with -DSGX_FP_CONTRACT_OFF (no multiply-add fusion in the fp64 solvers: the reference's rounding); tests only."""
+    if not HAVE_GPU:
+        pytest.skip('no GPU')
+    from sg_slam_amd.capi import SgxLib
+    so = os.path.join(ROOT, 'tests', 'nofma', 'libsgx_nofma.so')
+    if not os.path.exists(so):
+        pytest.skip('tests/nofma/libsgx_nofma.so not built (make -C sg_slam_amd/csrc nofma)')
+    lib = SgxLib(so)
+    assert 'gfx950' in lib.version()
+    return lib
+
+
+@pytest.fixture(scope='session')
 def stream_frames():
     from sg_slam_amd import synth
     S = synth.PlaneStream(seed=1234)

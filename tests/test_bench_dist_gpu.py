@@ -1,0 +1,24 @@
+"""GPU (MI355X): the multi-GPU code path of bench.py on ONE GPU — torch.distributed over RCCL with world_size 1 (SGX_BENCH_FORCE_DIST=1): process-group set-up, the
+one-kernel record pack on the side stream, the per-step gather to rank 0 inside the timed region, the max-over-ranks reduce.  The driver only has 8-GPU nodes now
+and then; this keeps the path exercised every round (the 2-rank semantics are covered on CPU by tests/test_dist_gloo.py)."""
+import json
+import os
+import subprocess
+import sys
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_rccl_gather_path_single_rank(gpulib):
+    env = dict(os.environ, SGX_BENCH_FORCE_DIST='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29600 + os.getpid() % 300), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '6', '--warmup', '3', '--streams', '8', '--no-cpu-baseline', '--no-config2', '--no-config4',
+                          '--no-host-input'], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
+    j = json.loads(line)
+    g = j['config']['frame_record_gather']
+    assert j['n_gpus'] == 1 and j['value'] > 0 and g is not None and g['inside_timed_region'] and g['bytes_per_step'] == 8 * g['record_bytes']
+    assert j['config']['tracked_streams_last_frame'] == 8

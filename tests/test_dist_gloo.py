@@ -1,6 +1,7 @@
 """N>1 path on CPU: two processes (gloo), each tracking its own shard of streams with the kernel-logic
-emulator, then the same collectives bench.py uses (max-over-ranks time, all_gather of per-frame records).
-Checks: shards are disjoint, every rank ends up with every rank's records, values match a single-process run."""
+emulator through the C++ host (sgx_tracker_*), then the same collectives bench.py uses (max-over-ranks time, gather of the
+packed per-frame records to rank 0).  Checks: shards are disjoint, rank 0 ends up with every rank's records bit for bit,
+the library's one-kernel packer equals the tensor-slice packer."""
 import os
 import sys
 import numpy as np
@@ -17,23 +18,29 @@ def _worker(rank, world, port, q):
     from sg_slam_amd import synth, dist as sdist
     from sg_slam_amd.capi import SgxLib
     from sg_slam_amd.tracker import TrackerBatch
+    from sg_slam_amd.tracker_native import TrackerNative
     dist.init_process_group('gloo', rank=rank, world_size=world)
     lib = SgxLib(os.path.join(ROOT, 'tests', 'emu', 'libsgx_emu.so'))
     cam = dict(synth.TUM3); S = 1
     gen = synth.PlaneStream(seed=1234)
     offs = sdist.stream_offsets(rank, S)
-    tr = TrackerBatch(lib, S, cam, xp='numpy')
-    tr.set_initial_pose(np.stack([gen.Tcw(o) for o in offs]))
+    tr = TrackerBatch(lib, S, cam, xp='numpy'); nat = TrackerNative(lib, S, cam, dynamic_mask=False, pipelined=False)
+    tr.set_initial_pose(np.stack([gen.Tcw(o) for o in offs])); nat.set_initial_pose(np.stack([gen.Tcw(o) for o in offs]))
+    held = []
     for t in range(3):
         fr = [gen.frame(o + t) for o in offs]
-        tr.step(np.stack([f[0] for f in fr]), np.stack([f[1] for f in fr]))
+        g, d = np.stack([f[0] for f in fr]), np.stack([f[1] for f in fr]); held.append((g, d))
+        tr.step(g, d); nat.step(g, d)
     n, nm, ninl = tr.last_counts()
     rec = sdist.gather_frame_records(dist, torch.from_numpy(tr.Tcw[1].copy()), torch.from_numpy(ninl.copy()), torch.from_numpy(nm.copy()))
-    # config-5 record gather as specified: keypoints + descriptors + pose of the last frame, one all_gather per step batch
-    G = sdist.FrameRecordGather(dist, S, tr.cap, 'cpu', async_stream=False)
+    # config-5 record gather as specified: keypoints + descriptors + pose of the last frame, one gather to rank 0 per step
+    G = sdist.FrameRecordGather(dist, S, nat.cap, 'cpu', async_stream=False)
     c = tr.cur
-    got = G.unpack(G.submit(torch.from_numpy(tr.n[c].copy()), torch.from_numpy(tr.keys[c].copy()), torch.from_numpy(tr.desc[c].copy()), torch.from_numpy(tr.Tcw[1].copy())))
-    G.wait()
+    r_native = G.submit_tracker(nat); G.wait()                        # the library's packer
+    got = G.unpack(r_native) if rank == 0 else None
+    r_torch = G.submit(torch.from_numpy(tr.n[c].copy()), torch.from_numpy(tr.keys[c].copy()), torch.from_numpy(tr.desc[c].copy()), torch.from_numpy(tr.Tcw[1].copy())); G.wait()
+    assert (r_native is None) == (rank != 0) and (r_torch is None) == (rank != 0)
+    if rank == 0: assert (r_native == r_torch).all()                 # one-kernel packer == tensor-slice packer (and native tracker == Python orchestration)
     mine = dict(n=tr.n[c].copy(), keys=tr.keys[c].copy(), desc=tr.desc[c].copy(), Tcw=tr.Tcw[1].copy())
     tmax = sdist.max_over_ranks(dist, float(rank + 1), 'cpu')
     tot = sdist.sum_over_ranks(dist, [1.0, float(ninl.sum())], 'cpu')
@@ -56,8 +63,9 @@ def test_two_rank_sharded_tracking(emu):
     assert tm0 == tm1 == 2.0 and tot0[0] == 2.0
     assert not np.allclose(rec0[0], rec0[1])              # the two shards really tracked different streams
     assert (rec0[:, :, 16] > 100).all()                   # inliers: both shards tracked
-    # the gathered frame records: every rank holds every rank's keypoints / descriptors / pose of the step, bit for bit
-    for got in (got0, got1):
+    # the gathered frame records: rank 0 holds every rank's keypoints / descriptors / pose of the step, bit for bit; the other rank receives nothing
+    assert got1 is None
+    for got in (got0,):
         for r, mine in enumerate((mine0, mine1)):
             n = int(mine['n'][0])
             assert got['n'][r, 0] == n and n > 500

@@ -19,6 +19,17 @@ def test_gpu_matches_oracle(gpulib, oracle, n, seed):
     assert gn == en and (f2['outlier'] == eout).all() and pose_close(f2['Tcw'], eT)
 
 
+def test_gpu_without_fma_contraction_matches_oracle(gpulib_nofma, oracle):
+    """The product fuses multiply-adds in the fp64 solvers; the reference (g2o, plain -O3 on x86-64) does not.  The same sources built without contraction
+    must reproduce the oracle (-ffp-contract=off as well) at least as closely: same inlier count and flags, pose within the 1e-5 bar."""
+    frame, _, _ = make_pose_problem(oracle, n=800, seed=44)
+    is2 = oracle.orb_params()['inv_sigma2']
+    en, eT, eout = oracle.pose_optimization(frame, CAM, is2)
+    f2 = dict(frame)
+    gn = Optimizer.PoseOptimization(f2, CAM, is2, lib=gpulib_nofma)
+    assert gn == en and (f2['outlier'] == eout).all() and pose_close(f2['Tcw'], eT)
+
+
 def test_gpu_mono_stereo(gpulib, oracle):
     is2 = oracle.orb_params()['inv_sigma2']
     for mono_frac in (0.0, 1.0):
