@@ -51,6 +51,7 @@ struct Arena {
     template <class T> void take(T **p, size_t n) { off = (off + 255) & ~(size_t)255; if (base) *p = (T *)(base + off); off += (n ? n : 1) * sizeof(T); }
 };
 static Arena g_arena;
+static int g_ba_solver = -1;              // test / tuning tap (sgx_ba_debug_set_solver): -1 = SGX_BA_SOLVER or auto, 0 auto, 1 dense blocked Cholesky, 2 envelope solver
 
 struct BA {
     int np, nl, ne, nf, NP;
@@ -62,6 +63,7 @@ struct BA {
     SgxBaJob *jobs; int *blk_start; double *Linv, *xsol; long long njobs, nblk; size_t jobs_cap;
     double *part_chi, *part_scale;      // device scalars block: [ok | part_scale[nblk_v] | part_chi[nblk_e]] read back with ONE copy per trial
     int nblk_e, nblk_v;
+    int *env_rstart, *env_rows;          // narrow-envelope solver: rows of column step k = env_rows[env_rstart[k] .. env_rstart[k+1]) (NULL: dense solver)
     std::vector<double> hpart;
 };
 
@@ -132,10 +134,18 @@ static int build_jobs(BA &B, const std::vector<int> &pt_start, const std::vector
 // Dense symmetric positive definite solve  S x = bp - coef  on the device (in place: S is overwritten by its factor): register / LDS kernels for small systems, the blocked
 // right-looking Cholesky with the fp64-MFMA trailing update above SGX_CHOL_SMALL unknowns.  *ok (device) is cleared when a pivot is not positive; x then keeps its previous
 // content.  *xout = where the solution was left (xp or xsol).  Shared by the bundle adjustments (reduced camera system) and the essential-graph optimisation.
-struct Chol { int NP; double *S, *Linv, *bp, *coef, *xp, *xsol; int *ok; };
+struct Chol { int NP; double *S, *Linv, *bp, *coef, *xp, *xsol; int *ok; const int *env_rstart = nullptr, *env_rows = nullptr; };      // env_*: column-step row lists of a narrow envelope (NULL = dense)
 static int chol_factor_solve(const Chol &C, const double **xout)
 {
     *xout = C.xp;
+    if (C.env_rstart && C.NP > 0) {                      // sparse covisibility: the whole factorisation + forward substitution as one persistent workgroup, then the backward pass
+        const int nt = (C.NP + SGX_NB - 1) / SGX_NB;
+        static const int env_dbg = getenv("SGX_ENV_DBG") ? atoi(getenv("SGX_ENV_DBG")) : 0;      // timing tap: 1 skip the diagonal tiles, 2 skip panel + update, 4 skip the update
+        SGX_LAUNCH(k_chol_env_factor, dim3(1), dim3(SGX_ENV_THREADS), (sgx_stream_t)0, C.NP, nt, C.env_rstart, C.env_rows, C.S, C.Linv, C.ok, C.bp, C.coef, C.xp, env_dbg);
+        SGX_LAUNCH(k_chol_env_back, dim3(1), dim3(1024), (sgx_stream_t)0, C.NP, nt, C.env_rstart, C.env_rows, C.S, C.Linv, C.xp, C.xsol, C.ok);
+        *xout = C.xsol;
+        return SGX_OK;
+    }
     // workgroup sizes of the single-workgroup solver kernels (env = tuning taps): their phases are short, so fewer waves mean cheaper barriers
     static const int t_small = getenv("SGX_TUNE_CHOL_SMALL_THREADS") ? atoi(getenv("SGX_TUNE_CHOL_SMALL_THREADS")) : 256;
     static const int t_diag = getenv("SGX_TUNE_CHOL_DIAG_THREADS") ? atoi(getenv("SGX_TUNE_CHOL_DIAG_THREADS")) : 256;
@@ -222,7 +232,7 @@ static int optimize(BA &B, int iterations, int *iters_done, double *final_chi)
             }
             sgx_prof_end(SGX_K_BA_SCHUR, (sgx_stream_t)0);
             sgx_prof_begin(SGX_K_BA_SOLVE, (sgx_stream_t)0);
-            { const Chol C = { B.NP, B.S, B.Linv, B.bp, B.coef, B.xp, B.xsol, B.ok }; if ((rc = chol_factor_solve(C, &xsol)) != SGX_OK) return rc; }
+            { Chol C = { B.NP, B.S, B.Linv, B.bp, B.coef, B.xp, B.xsol, B.ok }; C.env_rstart = B.env_rstart; C.env_rows = B.env_rows; if ((rc = chol_factor_solve(C, &xsol)) != SGX_OK) return rc; }
             sgx_prof_end(SGX_K_BA_SOLVE, (sgx_stream_t)0);
             sgx_prof_begin(SGX_K_BA_UPDATE, (sgx_stream_t)0);
             // when the factorisation failed, xp/xl keep the previous solution (as g2o's _x does) and the step is rejected below
@@ -256,6 +266,8 @@ static int optimize(BA &B, int iterations, int *iters_done, double *final_chi)
     return SGX_OK;
 }
 }  // namespace
+
+extern "C" int sgx_ba_debug_set_solver(int mode) { g_ba_solver = mode < 0 ? -1 : (mode > 2 ? 2 : mode); return SGX_OK; }
 
 // mode 0: Optimizer::LocalBundleAdjustment (Optimizer.cc:453-778); mode 1: Optimizer::BundleAdjustment (Optimizer.cc:49-237): one optimize(n_iterations) over
 // all edges, Huber deltas sqrt(5.99) / sqrt(7.815) only when `robust`, no classification, every pose rewritten
@@ -298,6 +310,43 @@ static int ba_run(const sgx_ba_problem *P, const sgx_camera *cam, const volatile
     size_t jobs_cap = 0;
     for (int l = 0; l < B.nl; l++) { size_t c = 0; for (int q = pt_start[l]; q < pt_start[l + 1]; q++) if (hidx[E[pt_edges[q]].pose] >= 0) c++; jobs_cap += c * c; }
     B.jobs_cap = jobs_cap;
+    // ---- sparsity of the reduced camera system: free poses i1, i2 are coupled when they share a landmark.  With the free poses in keyframe order (hidx) the tile rows of
+    // the system are non-zero from the first tile column ft[r] on and fill stays inside that envelope; when it is narrow the solver walks it with one persistent workgroup
+    // (k_chol_env_factor) instead of the dense blocked factorisation.  SGX_BA_SOLVER = dense | env | auto (default).
+    std::vector<int> env_rstart, env_rows;
+    {
+        static const char *solver_env = getenv("SGX_BA_SOLVER");
+        const int mode_env = !solver_env ? 0 : (strcmp(solver_env, "dense") == 0 ? 1 : (strcmp(solver_env, "env") == 0 ? 2 : 0));
+        const int smode = g_ba_solver >= 0 ? g_ba_solver : mode_env;
+        const bool want_env = smode != 1, force_env = smode == 2;
+        const int nt = (B.NP + SGX_NB - 1) / SGX_NB;
+        if (want_env && B.NP > (force_env ? 0 : 1024)) {
+            std::vector<int> fblk(B.nf);
+            for (int i = 0; i < B.nf; i++) fblk[i] = i;
+            for (int l = 0; l < B.nl; l++) {
+                int lo = B.nf;
+                for (int q = pt_start[l]; q < pt_start[l + 1]; q++) { const int h = hidx[E[pt_edges[q]].pose]; if (h >= 0 && h < lo) lo = h; }
+                for (int q = pt_start[l]; q < pt_start[l + 1]; q++) { const int h = hidx[E[pt_edges[q]].pose]; if (h >= 0 && lo < fblk[h]) fblk[h] = lo; }
+            }
+            std::vector<int> ft(nt);
+            for (int r = 0; r < nt; r++) {
+                int f = r;
+                for (int u = r * SGX_NB; u < std::min(B.NP, (r + 1) * SGX_NB); u += 1) f = std::min(f, 6 * fblk[u / 6] / SGX_NB);
+                ft[r] = f;
+            }
+            std::vector<int> cnt(nt + 1, 0);
+            size_t total = 0; for (int r = 0; r < nt; r++) { for (int k = ft[r]; k < r; k++) cnt[k + 1]++; total += (size_t)(r - ft[r]); }
+            int maxm = 0; for (int k = 0; k < nt; k++) maxm = std::max(maxm, cnt[k + 1]);
+            // narrow = a step's tile products fit a few rounds of the persistent workgroup's four groups; otherwise the dense two-level path (matrix cores) wins
+            if (maxm <= SGX_ENV_MAXM && (force_env || total <= (size_t)nt * 10)) {
+                env_rstart.assign(nt + 1, 0);
+                for (int k = 0; k < nt; k++) env_rstart[k + 1] = env_rstart[k] + cnt[k + 1];
+                env_rows.resize(total ? total : 1);
+                std::vector<int> fill(env_rstart.begin(), env_rstart.end() - 1);
+                for (int r = 0; r < nt; r++) for (int k = ft[r]; k < r; k++) env_rows[(size_t)fill[k]++] = r;      // rows ascending inside a step
+            }
+        }
+    }
     // ---- device state: one arena; the host->device inputs are packed contiguously and uploaded with one copy
     float *dTcw = nullptr; uint8_t *dfixed = nullptr, *derase = nullptr;
     const int nv = B.np > B.nl ? B.np : B.nl;
@@ -310,6 +359,7 @@ static int ba_run(const sgx_ba_problem *P, const sgx_camera *cam, const volatile
         A.take(&B.E, B.ne); A.take(&B.X, 3 * (size_t)B.nl); A.take(&B.pt_start, B.nl + 1); A.take(&B.pt_edges, B.ne);
         A.take(&B.pose_start, B.np + 1); A.take(&B.pose_edges, B.ne); A.take(&B.hidx, B.np); A.take(&B.free_pose, B.nf);
         A.take(&dTcw, 16 * (size_t)B.np); A.take(&dfixed, B.np);
+        A.take(&B.env_rstart, env_rstart.size()); A.take(&B.env_rows, env_rows.size());
         in_bytes = A.off;
         A.take(&B.T, B.np); A.take(&B.Tb, B.np); A.take(&B.Xb, 3 * (size_t)B.nl); A.take(&B.err, 3 * (size_t)B.ne);
         A.take(&B.Hll, 9 * (size_t)B.nl); A.take(&B.bl, 3 * (size_t)B.nl); A.take(&B.Hpl, 18 * (size_t)B.ne); A.take(&B.Hpp, 36 * (size_t)B.nf);
@@ -331,9 +381,11 @@ static int ba_run(const sgx_ba_problem *P, const sgx_camera *cam, const volatile
         put(B.pose_start, pose_start.data(), 4 * (size_t)(B.np + 1)); put(B.pose_edges, pose_edges.data(), 4 * (size_t)B.ne);
         put(B.hidx, hidx.data(), 4 * (size_t)B.np); if (B.nf) put(B.free_pose, free_pose.data(), 4 * (size_t)B.nf);
         put(dTcw, P->poses, 64 * (size_t)B.np);
+        if (!env_rstart.empty()) { put(B.env_rstart, env_rstart.data(), 4 * env_rstart.size()); put(B.env_rows, env_rows.data(), 4 * env_rows.size()); }
         if (mode == 0) put(dfixed, P->pose_fixed, B.np);           // mode 1: every keyframe is rewritten from its vertex (Optimizer.cc:200-214) -> flags stay 0
         SGX_CHECK_HIP(hipMemcpy(base, stage.data(), in_bytes, hipMemcpyHostToDevice));
     }
+    if (env_rstart.empty()) { B.env_rstart = nullptr; B.env_rows = nullptr; }
     SGX_CHECK_HIP(hipMemsetAsync(B.xp, 0, sizeof(double) * (B.NP ? B.NP : 1), 0));
     SGX_CHECK_HIP(hipMemsetAsync(B.xsol, 0, sizeof(double) * (B.NP ? B.NP : 1), 0));
     SGX_CHECK_HIP(hipMemsetAsync(B.xl, 0, sizeof(double) * 3 * (size_t)B.nl, 0));

@@ -487,9 +487,10 @@ SGX_KERNEL(256) k_chol_diag(int n, int k0, double *S, double *Linv, int *ok, con
 static __device__ __forceinline__ double sgx_readlane_f64(double v, int lane)
 { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane)); }
 
-__global__ void __launch_bounds__(64) k_chol_diag_wave(int n, int k0, double *S, double *Linv, int *ok, const double *bp, const double *coef, double *x)
+// returns false when a pivot is not positive (nothing is stored then)
+static __device__ __forceinline__ bool sgx_chol_diag_wave_body(int lane, int n, int k0, double *S, double *Linv, const double *bp, const double *coef, double *x)
 {
-    const int lane = (int)threadIdx.x, row = lane & 31;
+    const int row = lane & 31;
     const int nb = min(SGX_NB, n - k0);
     if (k0 == 0) for (int i = lane; i < n; i += 64) x[i] = bp[i] - coef[i];          // right-hand side of the reduced system (first panel only)
     double a[SGX_NB];
@@ -503,7 +504,7 @@ __global__ void __launch_bounds__(64) k_chol_diag_wave(int n, int k0, double *S,
     for (int j = 0; j < SGX_NB; j++) {
         if (j < nb) {
             const double d = sgx_readlane_f64(a[j], j);
-            if (!(d > 0)) { if (lane == 0) *ok = 0; return; }
+            if (!(d > 0)) return false;
             const double rd = 1.0 / d;
             const double f = a[j] * rd;
 #pragma unroll
@@ -550,6 +551,13 @@ __global__ void __launch_bounds__(64) k_chol_diag_wave(int n, int k0, double *S,
 #pragma unroll
         for (int r = 0; r < SGX_NB; r++) Lo[r * SGX_NB + lane] = xc[r];
     }
+    return true;
+}
+
+__global__ void __launch_bounds__(64) k_chol_diag_wave(int n, int k0, double *S, double *Linv, int *ok, const double *bp, const double *coef, double *x)
+{
+    const int lane = (int)threadIdx.x;
+    if (!sgx_chol_diag_wave_body(lane, n, k0, S, Linv, bp, coef, x) && lane == 0) *ok = 0;
 }
 #endif
 
@@ -731,6 +739,226 @@ SGX_KERNEL(256) k_chol_update_wide(int n, int p0, int pw, double *S, const int *
     }
     SGX_THREADS_END
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// Envelope (skyline) factorisation for SPARSE reduced camera systems.  The reference hands the reduced system to Eigen's SimplicialLDLT
+// (G/solvers/linear_solver_eigen.h:94-124): what it costs follows the covisibility structure, not n^3.  With keyframes ordered along the trajectory the
+// system is banded (a landmark is seen from a few consecutive keyframes; loop closures add a corner): on 32 x 32 tiles, tile row r is non-zero from its
+// first tile column ft[r] on, fill stays inside that envelope, and column step k of the right-looking factorisation only touches the row tiles
+// R(k) = { r > k : ft[r] <= k } (host-built lists).  For a narrow envelope the work per step is a handful of tile products, so the three launches per
+// step of the dense path (diagonal tile, panel, update: ~45 us of launch latency and ramp per step, 375 steps at 12 000 unknowns) ARE the run time.
+// k_chol_env_factor runs the WHOLE factorisation (and the forward substitution) as ONE persistent workgroup: per step, wave 0 factors and inverts the diagonal tile
+// in registers (sgx_chol_diag_wave_body), then the 256-thread groups of the workgroup take the panel tiles L_rk = A_rk Linv_kk^T (+ x_r -= L_rk y_k) and the
+// update pairs A_rc -= L_rk L_ck^T, r >= c in R(k), with workgroup barriers in between; k_chol_env_back is the backward pass in the same shape.
+// Same tile arithmetic as k_chol_diag / k_chol_panel / k_chol_update (the update of a tile sums over k in ascending order, as the rank-32 path does).
+// The dense two-level path remains for systems whose envelope is not narrow.
+// ---------------------------------------------------------------------------------------------
+#define SGX_ENV_THREADS 512                       /* 8 waves: two per SIMD, so the diagonal-tile wave keeps its 32 x 32 tile + inverse in registers (no scratch) */
+#define SGX_ENV_GROUPS (SGX_ENV_THREADS / 64)     /* one wave per tile product */
+#define SGX_ENV_MAXM 8                            /* row tiles of one column step: one per wave, kept in LDS (8 x 9 KB + the inverse tile) */
+// C(32 x 32) = P Q^T by ONE wave from two LDS tiles stored transposed ([q][row], stride NB + 4): lane (ty = lane >> 3, tx = lane & 7) owns the 4 x 4 block
+// rows 4 ty.., columns 4 tx..; k ascending, one accumulation chain per entry (the order of sgx_tile_gemm_nt)
+SGX_DEV void sgx_wave_gemm_nt(const double (*PT)[SGX_NB + 4], const double (*QT)[SGX_NB + 4], int ty, int tx, double acc[16])
+{
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = 0;
+#pragma unroll 4
+    for (int q = 0; q < SGX_NB; q++) {
+        double a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { a[i] = PT[q][4 * ty + i]; b[i] = QT[q][4 * tx + i]; }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[4 * i + j] += a[i] * b[j];
+    }
+}
+
+SGX_KERNEL(SGX_ENV_THREADS) k_chol_env_factor(int n, int nt, const int *rstart, const int *rows, double *S, double *Linv, int *ok, const double *bp, const double *coef, double *x, int dbg)
+{
+    SGX_LDS double LiT[SGX_NB][SGX_NB + 4];                      // Linv_kk transposed: [q][c]
+    SGX_LDS double yk[SGX_NB];
+    SGX_LDS double pool[SGX_ENV_MAXM][SGX_NB][SGX_NB + 4];       // the row tiles of the step, transposed [q][r]: A_rk on the way in, L_rk on the way out
+    SGX_LDS int s_fail;
+    SGX_PRIV_DECL(double, acc, 16, SGX_ENV_THREADS);
+#ifdef SGX_EMU
+    SGX_LDS double A[SGX_NB][SGX_NB + 1];
+    SGX_LDS double X[SGX_NB][SGX_NB + 1];
+    SGX_LDS double sd[SGX_NB], rsd[SGX_NB];
+#endif
+    SGX_THREADS_BEGIN(tid)
+    if (tid == 0) s_fail = 0;
+    SGX_THREADS_END
+    SGX_SYNC();
+    for (int k = 0; k < nt; k++) {
+        const int k0 = k * SGX_NB, nb = min(SGX_NB, n - k0);
+        // ---- diagonal tile: L_kk over S, Linv_kk, y_k = Linv_kk x_k
+#ifndef SGX_EMU
+        if ((int)threadIdx.x < 64 && !(dbg & 1)) { if (!sgx_chol_diag_wave_body((int)threadIdx.x, n, k0, S, Linv, bp, coef, x) && threadIdx.x == 0) s_fail = 1; }
+#else
+        {   // the workgroup / LDS form of the same factorisation (k_chol_diag), threads 0..255
+            SGX_THREADS_BEGIN(tid)
+            if (tid < 256) {
+                if (k0 == 0) for (int i = tid; i < n; i += 256) x[i] = bp[i] - coef[i];
+                for (int t = tid; t < SGX_NB * SGX_NB; t += 256) { const int r = t >> SGX_NB_SHIFT, c = t & (SGX_NB - 1); A[r][c] = (r < nb && c < nb) ? S[(size_t)(k0 + r) * n + k0 + c] : 0.0; X[r][c] = 0; }
+            }
+            SGX_THREADS_END
+            int jfail = nb;
+            for (int j = 0; j < nb; j++) {
+                const double d = A[j][j];
+                if (!(d > 0)) { jfail = j; break; }
+                const double rd = 1.0 / d;
+                SGX_THREADS_BEGIN(tid)
+                if (tid < 256) {
+                    const int ty = tid >> 4, tx = tid & 15;
+                    for (int i = j + 1 + ty; i < nb; i += 16) { const double f = A[i][j] * rd; for (int c = j + 1 + tx; c <= i; c += 16) A[i][c] -= f * A[c][j]; }
+                }
+                SGX_THREADS_END
+            }
+            if (jfail < nb) s_fail = 1;
+            else {
+                SGX_THREADS_BEGIN(tid)
+                if (tid < SGX_NB) { const double r_ = tid < nb ? sqrt(A[tid][tid]) : 1.0; sd[tid] = r_; rsd[tid] = 1.0 / r_; }
+                SGX_THREADS_END
+                SGX_THREADS_BEGIN(tid)
+                if (tid < 256) for (int t = tid; t < SGX_NB * SGX_NB; t += 256) { const int r = t >> SGX_NB_SHIFT, c = t & (SGX_NB - 1); if (r < nb && c < r) A[r][c] = A[r][c] / sd[c]; }
+                SGX_THREADS_END
+                SGX_THREADS_BEGIN(tid)
+                if (tid < nb) A[tid][tid] = sd[tid];
+                SGX_THREADS_END
+                SGX_THREADS_BEGIN(tid)
+                if (tid < SGX_NB) {
+                    double xc[SGX_NB];
+                    for (int r = 0; r < SGX_NB; r++) { double sacc = (r == tid) ? 1.0 : 0.0; for (int q = 0; q < r; q++) sacc -= A[r][q] * xc[q]; xc[r] = sacc * rsd[r]; }
+                    for (int r = 0; r < SGX_NB; r++) X[r][tid] = (tid < nb && r < nb) ? xc[r] : 0.0;
+                }
+                SGX_THREADS_END
+                SGX_THREADS_BEGIN(tid)
+                if (tid < nb) { double sacc = 0; for (int q = 0; q <= tid; q++) sacc += X[tid][q] * x[k0 + q]; sd[tid] = sacc; }
+                SGX_THREADS_END
+                SGX_THREADS_BEGIN(tid)
+                if (tid < nb) x[k0 + tid] = sd[tid];
+                if (tid < 256) {
+                    double *Lo = Linv + (size_t)k * SGX_NB * SGX_NB;
+                    for (int t = tid; t < SGX_NB * SGX_NB; t += 256) { const int r = t >> SGX_NB_SHIFT, c = t & (SGX_NB - 1); if (r < nb && c <= r) S[(size_t)(k0 + r) * n + k0 + c] = A[r][c]; Lo[t] = X[r][c]; }
+                }
+                SGX_THREADS_END
+            }
+        }
+#endif
+        SGX_SYNC();
+        if (s_fail) {
+            SGX_THREADS_BEGIN(tid) if (tid == 0) *ok = 0; SGX_THREADS_END
+            return;
+        }
+        const int q0 = rstart[k], m = rstart[k + 1] - q0;                   // m <= SGX_ENV_MAXM (host)
+        if (m == 0 || (dbg & 2)) continue;
+        const double *Lk = Linv + (size_t)k * SGX_NB * SGX_NB;
+        // ---- panel: L_rk = A_rk Linv_kk^T for r in R(k) (wave g takes row tile g), then x_r -= L_rk y_k
+        SGX_THREADS_BEGIN(tid)
+        for (int t = tid; t < SGX_NB * SGX_NB; t += SGX_ENV_THREADS) { const int r = t >> SGX_NB_SHIFT, c = t & (SGX_NB - 1); LiT[c][r] = Lk[t]; }
+        if (tid < SGX_NB) yk[tid] = tid < nb ? x[k0 + tid] : 0.0;                                              // y_k for the forward substitution
+        const int g = tid >> 6, lane = tid & 63;
+        if (g < m) {
+            const int r0 = rows[q0 + g] * SGX_NB, nr = min(SGX_NB, n - r0);
+            for (int t = lane; t < SGX_NB * SGX_NB; t += 64) {
+                const int r = t >> SGX_NB_SHIFT, c = t & (SGX_NB - 1);
+                pool[g][c][r] = (r < nr && c < nb) ? S[(size_t)(r0 + r) * n + k0 + c] : 0.0;
+            }
+        }
+        SGX_THREADS_END
+        SGX_SYNC();
+        SGX_THREADS_BEGIN(tid)
+        SGX_PRIV_BIND(acc, tid);
+        const int g = tid >> 6, lane = tid & 63;
+        if (g < m) sgx_wave_gemm_nt(pool[g], LiT, lane >> 3, lane & 7, acc);                                    // out[r][c] = sum_q A[r][q] Linv[c][q]
+        SGX_THREADS_END
+        SGX_SYNC();
+        SGX_THREADS_BEGIN(tid)
+        SGX_PRIV_BIND(acc, tid);
+        const int g = tid >> 6, lane = tid & 63;
+        if (g < m) {
+            const int r0 = rows[q0 + g] * SGX_NB, nr = min(SGX_NB, n - r0), ty = lane >> 3, tx = lane & 7;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int r = 4 * ty + i, c = 4 * tx + j;
+                    pool[g][c][r] = acc[4 * i + j];                                                               // L_rk (transposed) replaces A_rk
+                    if (r < nr && c < nb) S[(size_t)(r0 + r) * n + k0 + c] = acc[4 * i + j];
+                }
+        }
+        SGX_THREADS_END
+        SGX_SYNC();
+        SGX_THREADS_BEGIN(tid)
+        const int g = tid >> 6, lane = tid & 63;
+        if (g < m) {
+            const int r0 = rows[q0 + g] * SGX_NB, nr = min(SGX_NB, n - r0);
+            if (lane < nr) { double vv = x[r0 + lane]; for (int q = 0; q < nb; q++) vv -= pool[g][q][lane] * yk[q]; x[r0 + lane] = vv; }      // forward substitution
+        }
+        SGX_THREADS_END
+        // ---- update: A_rc -= L_rk L_ck^T for the pairs r >= c of R(k), both operands in LDS (pair p <-> (bi, bj), bi >= bj, row-major over the lower triangle)
+        const int npairs = (dbg & 4) ? 0 : m * (m + 1) / 2;
+        for (int it = 0; it * SGX_ENV_GROUPS < npairs; it++) {
+            SGX_THREADS_BEGIN(tid)
+            const int g = tid >> 6, lane = tid & 63, pidx = it * SGX_ENV_GROUPS + g;
+            if (pidx < npairs) {
+                int bi = (int)((sqrt(8.0 * pidx + 1.0) - 1.0) * 0.5); while ((bi + 1) * (bi + 2) / 2 <= pidx) bi++; while (bi * (bi + 1) / 2 > pidx) bi--;
+                const int bj = pidx - bi * (bi + 1) / 2;
+                const int r0 = rows[q0 + bi] * SGX_NB, c0 = rows[q0 + bj] * SGX_NB, nr = min(SGX_NB, n - r0), nc = min(SGX_NB, n - c0);
+                const int ty = lane >> 3, tx = lane & 7;
+                double u[16];
+                sgx_wave_gemm_nt(pool[bi], pool[bj], ty, tx, u);
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int r = 4 * ty + i, c = 4 * tx + j;
+                        if (r < nr && c < nc && !(bi == bj && c > r)) S[(size_t)(r0 + r) * n + c0 + c] -= u[4 * i + j];
+                    }
+            }
+            SGX_THREADS_END
+        }
+        SGX_SYNC();
+    }
+}
+
+// backward pass over the envelope, one persistent workgroup: for k = nt-1 .. 0:  x_k = Linv_kk^T (y_k - sum_{r in R(k)} L_rk^T x_r)
+// (column-oriented form of k_chol_back_step's row updates: the contributions of the finished blocks below are gathered when block k is solved).
+// Thread (row q = tid >> 5, column c = tid & 31) multiplies entry (q, c) of every tile of R(k) with x_r[q] (independent loads), the 32 partial sums of a
+// column meet in LDS; Linv_kk is fetched while they are formed.
+SGX_KERNEL(1024) k_chol_env_back(int n, int nt, const int *rstart, const int *rows, const double *S, const double *Linv, const double *y, double *xsol, const int *ok)
+{
+    SGX_LDS double ys[SGX_NB];
+    SGX_LDS double part[SGX_NB][SGX_NB + 1];
+    SGX_LDS double Li[SGX_NB][SGX_NB + 1];
+    if (!*ok) return;
+    for (int k = nt - 1; k >= 0; k--) {
+        const int k0 = k * SGX_NB, nb = min(SGX_NB, n - k0);
+        const int q0 = rstart[k], m = rstart[k + 1] - q0;
+        const double *Lk = Linv + (size_t)k * SGX_NB * SGX_NB;
+        SGX_THREADS_BEGIN(tid)
+        const int c = tid & 31, q = tid >> 5;
+        double acc = 0;
+        if (c < nb)
+            for (int i = 0; i < m; i++) {
+                const int r0 = rows[q0 + i] * SGX_NB;
+                if (r0 + q < n) acc += S[(size_t)(r0 + q) * n + k0 + c] * xsol[r0 + q];
+            }
+        part[q][c] = acc;
+        Li[q][c] = Lk[tid];
+        SGX_THREADS_END
+        SGX_SYNC();
+        SGX_THREADS_BEGIN(tid)
+        if (tid < SGX_NB) { double t = tid < nb ? y[k0 + tid] : 0.0; for (int s2 = 0; s2 < SGX_NB; s2++) t -= part[s2][tid]; ys[tid] = t; }
+        SGX_THREADS_END
+        SGX_SYNC();
+        SGX_THREADS_BEGIN(tid)
+        if (tid < nb) { double sacc = 0; for (int q = tid; q < nb; q++) sacc += Li[q][tid] * ys[q]; xsol[k0 + tid] = sacc; }
+        SGX_THREADS_END
+        SGX_SYNC();
+    }
 }
 
 // x = (bp - coef); L y = x; L^T x = y — blocked with the stored diagonal inverses, one 256-thread workgroup

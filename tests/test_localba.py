@@ -57,3 +57,28 @@ def test_emu_matches_oracle(emu, oracle, seed, n_free, n_fixed, n_points):
     assert (erase == eerase).all()
     assert close(p2['poses'], eposes) and points_close(p2['points'], epoints)
     assert abs(stats['chi2'][1] - etrace[1, eiters[1] - 1, 0]) <= 1e-5 * max(1.0, etrace[1, eiters[1] - 1, 0])   # residual within 1e-5 relative
+
+
+def run_envelope_solver_equals_dense(lib, nkf, npt, env_mode):
+    """The narrow-envelope solver of the reduced camera system (one persistent workgroup walking the covisibility band, k_chol_env_factor / k_chol_env_back) against the
+    dense blocked Cholesky on the same bundle adjustment: identical iteration counts and erase flags, poses / points / chi2 to rounding."""
+    from scenes import make_big_ba_problem
+    prob, _, _ = make_big_ba_problem(nkf, npt)
+    out = {}
+    try:
+        for mode in (1, env_mode):
+            lib.dll.sgx_ba_debug_set_solver(mode)
+            p = {k: (v.copy() if hasattr(v, 'copy') else v) for k, v in prob.items()}
+            er, st = Optimizer.LocalBundleAdjustment(p, CAM, lib=lib)
+            out[mode] = (p['poses'].astype('f8'), p['points'].astype('f8'), er.copy(), st)
+    finally:
+        lib.dll.sgx_ba_debug_set_solver(-1)
+    a, b = out[1], out[env_mode]
+    assert a[3]['iterations'] == b[3]['iterations'] and (a[2] == b[2]).all()
+    assert np.abs(a[0] - b[0]).max() <= 1e-6 * max(1.0, np.abs(a[0]).max()) and np.abs(a[1] - b[1]).max() <= 1e-5 * max(1.0, np.abs(a[1]).max())
+    for x, y in zip(a[3]['chi2'], b[3]['chi2']):
+        assert abs(x - y) <= 1e-8 * max(1.0, abs(x))
+
+
+def test_envelope_solver_equals_dense_emu(emu):
+    run_envelope_solver_equals_dense(emu, 60, 1500, 2)          # forced (the automatic choice needs more than 1 024 unknowns)

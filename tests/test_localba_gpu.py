@@ -22,6 +22,12 @@ def test_gpu_matches_oracle(gpulib, oracle, seed, n_free, n_fixed, n_points):
     assert abs(stats['chi2'][1] - ref) <= 1e-5 * max(1.0, ref)
 
 
+def test_envelope_solver_equals_dense_gpu(gpulib):
+    from test_localba import run_envelope_solver_equals_dense
+    run_envelope_solver_equals_dense(gpulib, 60, 1500, 2)        # forced on a small system (partial last tile, cyclic corner)
+    run_envelope_solver_equals_dense(gpulib, 600, 15000, 0)      # automatic choice: 3 594 unknowns, narrow covisibility band
+
+
 def test_gpu_stop_flag(gpulib, oracle):
     prob, _, _ = make_ba_problem(oracle, seed=5)
     p2 = {k: (v.copy() if hasattr(v, 'copy') else v) for k, v in prob.items()}
