@@ -487,7 +487,12 @@ int sgx_frame_compact_keys_batch_dev(int batch, int cap, const sgx_keypoint *d_k
  *   :469-472 cv::findFundamentalMat(cur, prev, FM_RANSAC, 1.0, 0.99) on that selection when more than 20 pairs remain, else on all pairs
  * A sgx_flow handle owns the two image pyramids (current / previous) like the file-scope `imGrayPre` of Frame.cc:31,155-163: each
  * sgx_flow_lk_batch_dev call builds the pyramid of the new frames, tracks into the pyramid kept from the previous call, and swaps (the Scharr
- * derivatives are evaluated inside the tracker from the image itself).  OpenCV 3.4 semantics (lkpyramid.cpp, pyramids.cpp); sums are accumulated exactly (the library's int64 `acctype` variant). */
+ * derivatives are evaluated inside the tracker from the image itself).  OpenCV 3.4 semantics (lkpyramid.cpp, pyramids.cpp).
+ * Divergence (stated, with the two undefined reference behaviours documented at sgx_det_detect and sgx_fundamental_ransac_batch_dev): the 2 x 2 gradient matrix and the
+ * mismatch vector of every iteration are summed EXACTLY (int32 partial sums recombined in fp64, rounded once to fp32) — the order-free form of OpenCV's accumulation,
+ * whose own float summation order depends on the SIMD path the build dispatches to (SSE2 / AVX2 / scalar `acctype`).  Against the oracle's OpenCV-order mode
+ * (oracle/flow_oracle.c, acc_mode 0) tracked positions agree to 0.01 px on the test streams; mask decisions of knife-edge keypoints can therefore differ from a
+ * given x86 build of the reference (bench.py reports the resulting trajectory difference as `ate_vs_oracle_chain`). */
 typedef struct sgx_flow_config {
     int32_t width, height, max_batch;
     int32_t win_size;       /* 21 (only value supported) */

@@ -99,9 +99,9 @@ void orc_voc_transform_features(const orc_voc *v, int n, const uint8_t *desc, in
 }
 
 static int must_normalize(int scoring, int *l2)
-{   /* ScoringObject.h:73-92: L1 (true, L1), L2 (true, L2), ChiSquare (true, L1), KL (false, L1), Bhattacharyya (true, L1), DotProduct (false, L1) */
+{   /* ScoringObject.h:73-89: L1 (true, L1), L2 (true, L2), ChiSquare (true, L1), KL (true, L1), Bhattacharyya (true, L1), DotProduct (false, L1) */
     *l2 = scoring == 1;
-    return !(scoring == 3 || scoring == 5);
+    return scoring != 5;
 }
 
 /* the BowVector of transform(features, v, fv, levelsup): ids ascending (std::map order), weights accumulated in feature order, then normalised.  Returns its size. */

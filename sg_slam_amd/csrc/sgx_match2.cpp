@@ -41,6 +41,13 @@ static void group_by_node(const int32_t *node, int n, std::vector<int> &items, s
     start.push_back((int)items.size());
 }
 
+// keypoint octaves index the per-level tables of the kernel arguments (12 entries): reject frames whose octaves fall outside the extractor's levels
+static bool octaves_ok(const sgx_keypoint *k, int n, int nlevels)
+{
+    for (int i = 0; i < n; i++) if (k[i].octave < 0 || k[i].octave >= nlevels) return false;
+    return true;
+}
+
 extern "C" int sgx_match_search_for_triangulation(
     int n1, const sgx_keypoint *keys1_un, const uint8_t *desc1, const float *uright1, const uint8_t *has_mp1, const int32_t *feat_node1, const float *cam_center1,
     int n2, const sgx_keypoint *keys2_un, const uint8_t *desc2, const float *uright2, const uint8_t *has_mp2, const int32_t *feat_node2, const float *Tcw2,
@@ -51,6 +58,7 @@ extern "C" int sgx_match_search_for_triangulation(
     *npairs = 0;
     if (n1 == 0 || n2 == 0) return SGX_OK;
     if (!keys1_un || !desc1 || !uright1 || !has_mp1 || !feat_node1 || !keys2_un || !desc2 || !uright2 || !has_mp2 || !feat_node2 || !pairs) return SGX_ERR_INVALID;
+    if (!octaves_ok(keys1_un, n1, nlevels) || !octaves_ok(keys2_un, n2, nlevels)) return SGX_ERR_INVALID;
     std::vector<int> it1, id1, st1, it2, id2, st2, job;
     group_by_node(feat_node1, n1, it1, id1, st1); group_by_node(feat_node2, n2, it2, id2, st2);
     for (size_t a = 0, b = 0; a < id1.size() && b < id2.size();) {               // the lock-step walk of the two maps (:692-776)
@@ -169,6 +177,7 @@ extern "C" int sgx_match_fuse_search(
     for (int i = 0; i < nm; i++) { best_idx[i] = -1; best_dist[i] = 256; }
     if (nk == 0 || nm == 0) return SGX_OK;
     if (!keys_un || !desc || !uright || !m_xw || !m_normal || !m_min_dist || !m_max_dist || !m_desc || !m_skip) return SGX_ERR_INVALID;
+    if (!octaves_ok(keys_un, nk, nlevels)) return SGX_ERR_INVALID;
     // the keyframe's mGrid (Frame::AssignFeaturesToGrid / PosInGrid: round(), Frame.cc:257-272, :409-419) as CSR, cell (ix, iy) -> ix * 48 + iy, insertion (index) order inside a cell
     const float invW = 64.0f / (cam->max_x - cam->min_x), invH = 48.0f / (cam->max_y - cam->min_y);
     std::vector<int> cell((size_t)nk, -1), start(64 * 48 + 1, 0), items;
@@ -507,6 +516,7 @@ extern "C" int sgx_triangulate_new_map_points(
     *nnew = 0;
     if (npairs == 0) return SGX_OK;
     if (!keys1_un || !keys1 || !uright1 || !depth1 || !keys2_un || !keys2 || !uright2 || !depth2) return SGX_ERR_INVALID;
+    if (!octaves_ok(keys1_un, n1, nlevels) || !octaves_ok(keys2_un, n2, nlevels)) return SGX_ERR_INVALID;
     for (int q = 0; q < npairs; q++) if (pairs[2 * q] < 0 || pairs[2 * q] >= n1 || pairs[2 * q + 1] < 0 || pairs[2 * q + 1] >= n2) return SGX_ERR_INVALID;
     SgxNewPointArgs A; memset(&A, 0, sizeof A);
     A.npairs = npairs; memcpy(A.Tcw1, Tcw1, 64); memcpy(A.Tcw2, Tcw2, 64);

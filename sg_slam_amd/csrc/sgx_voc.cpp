@@ -113,9 +113,9 @@ extern "C" int sgx_voc_transform_batch_dev(sgx_voc *v, const uint8_t *d_desc, si
 }
 
 static bool must_normalize(int scoring, bool *l2)
-{   // ScoringObject.h:73-92
+{   // ScoringObject.h:73-92: every scoring class is declared with mustNormalize = true (KLScoring too: __SCORING_CLASS(KLScoring, true, L1)) except DotProductScoring
     *l2 = scoring == 1;
-    return !(scoring == 3 || scoring == 5);
+    return scoring != 5;
 }
 
 extern "C" int sgx_voc_transform(sgx_voc *v, int n, const uint8_t *desc, int levelsup, int32_t *bow_ids, double *bow_weights, int32_t *nbow, int32_t *feat_node, int32_t *feat_word)

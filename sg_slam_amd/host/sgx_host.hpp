@@ -280,6 +280,8 @@ namespace LocalMappingSteps {
     inline void UpdateNormalAndDepth(const std::vector<float> &xw, const std::vector<int32_t> &obsStart, const std::vector<float> &obsCenter, const std::vector<float> &refCenter,
                                      const std::vector<int32_t> &refLevel, const std::vector<float> &scaleFactors, std::vector<float> &normal, std::vector<float> &minDist, std::vector<float> &maxDist)
     {
+        const size_t np_ = refLevel.size();                          // outputs sized here, seeded with the caller's values (points without observations keep them, MapPoint.cc:335-336)
+        normal.resize(3 * np_, 0.f); minDist.resize(np_, 0.f); maxDist.resize(np_, 0.f);
         check(sgx_mappoint_update_normal_and_depth((int)refLevel.size(), xw.data(), obsStart.data(), obsCenter.data(), refCenter.data(), refLevel.data(), scaleFactors.data(),
                                                    (int)scaleFactors.size(), normal.data(), minDist.data(), maxDist.data()), "sgx_mappoint_update_normal_and_depth");
     }
@@ -478,6 +480,46 @@ public:
     std::vector<sgx_detection> raw;                                  // ncnn detection_out rows (test tap)
 private:
     sgx_det *h_ = nullptr;
+public:
+    sgx_det *handle() { return h_; }
+};
+
+// The pipelined per-frame host (sgx_tracker_*): S RGB-D streams tracked in lock-step with Tracking::GrabImageRGBD's call order (src/sg-slam/src/Tracking.cc:206-251,
+// :906-1013) on three event-chained HIP streams inside the library.  GrabImagesRGBD(slot) = one frame of every stream from the pinned staging buffers of `slot`
+// (imRGB as cv::imread delivers it — interleaved 8-bit BGR — and the raw 16-bit depth map, rgbd_tum.cc:114-115), asynchronous; Pose() synchronises.
+class TrackingPipeline {
+public:
+    TrackingPipeline(int streams, const sgx_camera &cam, float depthMapFactor, Detector2D *detector = nullptr, int width = 640, int height = 480, int nFeatures = 1000,
+                     float scaleFactor = 1.2f, int nLevels = 8, int iniThFAST = 20, int minThFAST = 7, bool localMap = true, bool dynamicMask = true, int maxBoxes = 8)
+        : S_(streams), W_(width), H_(height)
+    {
+        sgx_tracker_config c; std::memset(&c, 0, sizeof c);
+        c.streams = streams; c.width = width; c.height = height; c.nfeatures = nFeatures; c.scale_factor = scaleFactor; c.nlevels = nLevels; c.ini_th_fast = iniThFAST; c.min_th_fast = minThFAST;
+        c.cam = cam; c.depth_map_factor = depthMapFactor; c.th_projection = 15.f; c.local_map = localMap; c.dynamic_mask = dynamicMask; c.max_boxes = maxBoxes; c.pipelined = 1;
+        check(sgx_tracker_create(&c, detector ? detector->handle() : nullptr, &h_), "sgx_tracker_create");
+    }
+    ~TrackingPipeline() { if (h_) sgx_tracker_destroy(h_); }
+    TrackingPipeline(const TrackingPipeline &) = delete;
+    TrackingPipeline &operator=(const TrackingPipeline &) = delete;
+    void SetInitialPose(const std::vector<float> &Tcw) { if ((int)Tcw.size() != 16 * S_) throw std::invalid_argument("SetInitialPose: streams x 16 floats"); check(sgx_tracker_set_initial_pose(h_, Tcw.data()), "sgx_tracker_set_initial_pose"); }
+    // staging buffers of slot 0 / 1: bgr = streams x height rows of `pitch` bytes (3 * width used), depth = streams x height x width uint16
+    void HostBuffers(int slot, uint8_t **bgr, int *pitch, uint16_t **depth) { check(sgx_tracker_host_buffers(h_, slot, bgr, pitch, depth), "sgx_tracker_host_buffers"); }
+    void GrabImagesRGBD(int slot, bool rgbOrder = true) { check(sgx_tracker_step_host(h_, slot, rgbOrder ? 1 : 0), "sgx_tracker_step_host"); }
+    void Synchronize() { check(sgx_tracker_sync(h_), "sgx_tracker_sync"); }
+    // mCurrentFrame.mTcw of every stream (streams x 16) and the tracking counts of the frame tracked last (synchronises)
+    void Pose(std::vector<float> &Tcw, std::vector<int32_t> *nKeys = nullptr, std::vector<int32_t> *nMatches = nullptr, std::vector<int32_t> *nInliers = nullptr)
+    {
+        Tcw.resize((size_t)16 * S_);
+        if (nKeys) nKeys->resize(S_);
+        if (nMatches) nMatches->resize(S_);
+        if (nInliers) nInliers->resize(S_);
+        check(sgx_tracker_read(h_, Tcw.data(), nKeys ? nKeys->data() : nullptr, nMatches ? nMatches->data() : nullptr, nullptr, nullptr, nInliers ? nInliers->data() : nullptr, nullptr, nullptr, nullptr),
+              "sgx_tracker_read");
+    }
+    int streams() const { return S_; }
+    sgx_tracker *handle() { return h_; }
+private:
+    sgx_tracker *h_ = nullptr; int S_, W_, H_;
 };
 
 }  // namespace sgx

@@ -66,7 +66,7 @@ def check_transform(lib, orc, n_cases=4):
     for c in range(n_cases):
         L = 3 + (c % 2)                                                    # depth 3 and 4 (k = 10 -> 1 110 / 11 110 nodes); levelsup 4 then maps to the root / level 0
         voc = make_vocabulary(100 + c, k=10 if L == 3 else 6, L=L)
-        for scoring, weighting in ((0, 0), (0, 1), (0, 2), (0, 3), (1, 0), (3, 0)):
+        for scoring, weighting in ((0, 0), (0, 1), (0, 2), (0, 3), (1, 0), (3, 0), (3, 1), (5, 0)):
             V = ORBVocabulary(lib).create(voc['k'], voc['L'], voc['parent'], voc['desc'], voc['weight'], voc['is_leaf'], scoring, weighting)
             O = orc.Vocabulary(voc['k'], voc['L'], voc['parent'], voc['desc'], voc['weight'], voc['is_leaf'], scoring, weighting)
             assert V.nwords == O.nwords == int(voc['is_leaf'].sum()) and V.nnodes == len(voc['parent'])
@@ -80,7 +80,7 @@ def check_transform(lib, orc, n_cases=4):
                 stopped = voc['weight'][np.nonzero(voc['is_leaf'])[0]][eword] <= 0
                 assert ((en == -1) == stopped).all()
                 total_stopped += int(stopped.sum())
-                if scoring == 0: assert abs(ew.sum() - 1.0) < 1e-12            # L1-normalised
+                if scoring in (0, 3): assert abs(ew.sum() - 1.0) < 1e-12       # L1-normalised (KLScoring is declared mustNormalize = true, ScoringObject.h:83)
                 if levelsup < L:
                     # the node levelsup levels above the word, or the word's own node when the leaf sits higher than that (documented divergence from the reference's uninitialised value)
                     leaf_nodes = np.nonzero(voc['is_leaf'])[0][eword]
