@@ -8,12 +8,12 @@ set -u
 TAG=${1:-run}
 S=${STREAMS:-512}          # frames per launch = bench.py's default --streams
 R=$PWD; O=$R/gpurun_out/$TAG; mkdir -p $O
-PB="python $R/bench.py --streams $S --no-cpu-baseline --no-config2 --no-detector --steps 3 --warmup 1"
+PB="python $R/bench.py --streams $S --no-cpu-baseline --no-config2 --no-config4 --no-host-input --no-detector --steps 3 --warmup 1"
 # 1. the default bench line (full chain, detector on, CPU baseline, config-2 secondary)
 timeout 600 python bench.py --streams $S > $O/bench_default.json 2> $O/bench_default.err
 # 2. kernel statistics of the same command (rocprofv3 wants a writable cwd / TMPDIR)
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o b -- python $R/bench.py --streams $S --no-cpu-baseline --no-config2 > $O/bench_under_rocprof.json 2>/dev/null
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o b -- python $R/bench.py --streams $S --no-cpu-baseline --no-config2 --no-config4 --no-host-input --steps 48 --warmup 4 > $O/bench_under_rocprof.json 2>/dev/null
 # 3. SQ instruction counters (two passes) and HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes)
 timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace --output-format csv -d $O/sq_a -o p -- $PB > /dev/null 2>&1
 timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $O/sq_b -o p -- $PB > /dev/null 2>&1
@@ -36,7 +36,7 @@ PY
 ) > $O/pmc_insts.txt
 for d in sq_a sq_b fetch write det_sq det_mfma det_fetch det_write; do python tools/pmc_summary.py $(f $d) > $O/pmc_$d.txt 2>/dev/null; done
 # 5. standalone kernel times: the chain on ONE stream without the detector (no kernel shares the GPU with another), the detector on its own
-timeout 300 python bench.py --streams $S --no-cpu-baseline --no-detector --no-config2 --no-pipeline > $O/bench_serial.json 2>/dev/null
+timeout 300 python bench.py --streams $S --no-cpu-baseline --no-detector --no-config2 --no-config4 --no-host-input --no-pipeline --steps 48 --warmup 4 > $O/bench_serial.json 2>/dev/null
 timeout 200 python tools/prof_det_output.py $S 10 > $O/det_standalone.txt 2>/dev/null
 python - <<PY
 import json, re
@@ -48,6 +48,12 @@ for l in open("$O/det_standalone.txt"):
 json.dump({"note": "average launch duration with nothing else on the GPU: bench.py --no-detector --no-pipeline (one stream) for the chain, tools/prof_det_output.py for the detector; $S frames per launch",
            "frames_per_launch": $S, "avg_ms_per_launch": res}, open("$O/standalone.json", "w"), indent=1)
 PY
+# 5b. the matrix-core inverted-residual block kernels of the detector: per-step SQ counter table; bundle adjustment (config 4): phases with both solvers + kernel statistics
+bash $R/tools/pmc_irb.sh $TAG > /dev/null 2>&1; cp $R/gpurun_out/pmc_irb_$TAG.txt $O/pmc_irb.txt 2>/dev/null
+timeout 200 python tools/bench_ba_phases.py > $O/ba_phases.json 2>/dev/null
+cd /tmp
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ba_stats -o b -- python $R/tools/bench_ba_phases.py > /dev/null 2>&1
+cd $R
 # 6. standalone stage benches
 timeout 100 python tools/bench_flow.py > $O/flow.txt 2>/dev/null
 timeout 100 python tools/bench_ba.py > $O/localba.json 2>/dev/null

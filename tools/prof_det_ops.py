@@ -18,6 +18,13 @@ def step_roof_ms(desc, B):
         by = 4.0 * (c * h * w * (2 if '+res' in desc else 1) + oc * ho * wo) * B
         fl = 2.0 * (h * w * c * cm + ho * wo * cm * k * k + ho * wo * cm * oc) * B
         return max(by / 8e12, fl / 157.3e12) * 1e3
+    m = re.match(r'irb \S+ c(\d+)->(\d+)->(\d+) q(\d+) k(\d+) s(\d+) (\d+)x(\d+)->(\d+)x(\d+)', desc)
+    if m:      # matrix-core inverted-residual block / SSD head (sgx_det_irb.h): the block's input (+ residual) and output in HBM, the MACs of all its convolutions
+        c, cm, oc, cq, k, s, h, w, ho, wo = (int(m.group(i)) for i in range(1, 11))
+        noexp = ' noexp' in desc
+        by = 4.0 * ((cm if noexp else c) * h * w + oc * ho * wo * (2 if '+res' in desc else 1)) * B
+        fl = 2.0 * ((0 if noexp else h * w * c * cm) + ho * wo * cm * k * k + ho * wo * cm * oc + 2 * ho * wo * oc * cq) * B
+        return max(by / 8e12, fl / 157.3e12) * 1e3
     return 0.0
 
 
