@@ -37,7 +37,7 @@ struct Op {
     int inc = 0, outc = 0, H = 0, W = 0, Ho = 0, Wo = 0, k = 1, stride = 1, pad = 0, depthwise = 0, act = 0; float lo = 0, hi = 0;
     float *wt = nullptr, *bias = nullptr, *wtT = nullptr; int ldw = 0; int bop = 0; int off = 0; int rows = 0, C = 0;
     SgxFusedBlk fb; int fb_res_blob = -1;      // OP_FUSED_BLOCK: expand -> depthwise -> project (+ residual) in one kernel (sgx_det_block.h)
-    SgxIrb irb; int irb_res_blob = -1;         // OP_IRB: [expand ->] depthwise -> project [-> squeeze-excite gate] [+ residual] on the matrix cores (sgx_det_irb.h)
+    SgxIrb irb; int irb_res_blob = -1, irb_out2_blob = -1;         // OP_IRB: [expand ->] depthwise -> project [-> squeeze-excite gate] [+ residual] on the matrix cores (sgx_det_irb.h)
 };
 }  // namespace
 
@@ -541,10 +541,38 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                 ops[last] = f;
             }
         }
+        // ---- the two SSD heads of a feature map (loc and conf: depthwise 3x3 + ReLU -> pointwise, HWC store) read the same planes: one kernel stages them once, reads the
+        // depthwise taps once and runs both heads' weights over them (k_irb with a second accumulator set).  SGX_DET_IRB_DUAL=0 keeps them apart.
+        {
+            static const int dual_env = getenv("SGX_DET_IRB_DUAL") ? atoi(getenv("SGX_DET_IRB_DUAL")) : 1;
+            for (int i = 0; dual_env && i < nops; i++) {
+                Op &a = ops[i];
+                if (a.dead || a.kind != OP_IRB || a.irb.has_expand || !a.irb.hwc || a.irb.Cq || a.irb.Cout2) continue;
+                for (int j = 0; j < nops; j++) {
+                    Op &b = ops[j];
+                    if (j == i || b.dead || b.kind != OP_IRB || b.irb.has_expand || !b.irb.hwc || b.irb.Cq || b.irb.Cout2 || b.in0 != a.in0) continue;
+                    if (b.irb.K != a.irb.K || b.irb.S != a.irb.S || b.irb.Cexp != a.irb.Cexp || b.irb.H != a.irb.H || b.irb.W != a.irb.W || b.irb.act2 != a.irb.act2 ||
+                        b.irb.a2lo != a.irb.a2lo || b.irb.a2hi != a.irb.a2hi || b.irb.G != a.irb.G || b.irb.nbands != a.irb.nbands) continue;
+                    if (b.irb.Cout > 32 || b.irb.Cout > a.irb.Cout) continue;                 // the narrow (loc) head rides along as the second accumulator set
+                    if (!sgx_irb_supported(a.irb.K, a.irb.S, (a.irb.Cout + 31) / 32, 0, false, a.irb.act2 == SGX_EMODE_HSWISH, 1)) continue;
+                    SgxIrb m = a.irb;
+                    m.Cout2 = b.irb.Cout; m.hwc_off2 = b.irb.hwc_off; m.ld2b = b.irb.ld2; m.wdp2 = b.irb.wdp; m.w2Tb = b.irb.w2T; m.b2b = b.irb.b2;
+                    m.wd_b = b.irb.wd; m.bd_b = b.irb.bd; m.w2_b = b.irb.w2;
+                    if (sgx_irb_lds_bytes(m) > 160 * 1024) { m.nbuf = 1; if (sgx_irb_lds_bytes(m) > 160 * 1024) continue; }
+                    Op f = a; f.irb = m; f.irb_out2_blob = b.out; f.name = a.name + "|" + b.name;
+                    const int last = std::max(i, j);
+                    ops[i].dead = true; ops[j].dead = true; ops[last] = f; ops[last].dead = false;
+                    break;
+                }
+            }
+        }
         std::vector<Op> live; for (const Op &o : ops) if (!o.dead) live.push_back(o);
         ops.swap(live);
     }
-    for (const Op &o : h->ops) { Blob &ob = h->blobs[o.out]; if (!ob.d && ob.n) { if (h->alloc(&ob.d, ob.n * B)) FAIL(SGX_ERR_NOMEM); } }
+    for (const Op &o : h->ops) {
+        Blob &ob = h->blobs[o.out]; if (!ob.d && ob.n) { if (h->alloc(&ob.d, ob.n * B)) FAIL(SGX_ERR_NOMEM); }
+        if (o.irb_out2_blob >= 0) { Blob &o2 = h->blobs[o.irb_out2_blob]; if (!o2.d && o2.n) { if (h->alloc(&o2.d, o2.n * B)) FAIL(SGX_ERR_NOMEM); } }
+    }
 #undef FAIL
     h->num_priors = (int)prior_boxes.size() / 4;
     h->priors = prior_boxes; h->priors.insert(h->priors.end(), prior_vars.begin(), prior_vars.end());
@@ -639,6 +667,7 @@ static void run_op(sgx_det *h, const Op &op, int batch, sgx_stream_t st)
         SgxIrb ib = op.irb;
         ib.in = A.d; ib.in_pitch = A.n; ib.out = O.d; ib.out_pitch = O.n;
         ib.res = op.irb_res_blob >= 0 ? h->blobs[op.irb_res_blob].d : nullptr; ib.res_pitch = op.irb_res_blob >= 0 ? h->blobs[op.irb_res_blob].n : 0;
+        if (op.irb_out2_blob >= 0) { ib.out2 = h->blobs[op.irb_out2_blob].d; ib.out2_pitch = h->blobs[op.irb_out2_blob].n; }
         (void)sgx_irb_launch(ib, batch, st);                                             // the instantiation was validated when the plan was built
         break; }
     case OP_KXK: {
@@ -792,7 +821,7 @@ extern "C" int sgx_det_debug_op_desc(const sgx_det *h, int i, char *buf, int cap
                  o.fb_res_blob >= 0 ? " +res" : "");
     else if (o.kind == OP_IRB)
         snprintf(buf, cap, "irb %s c%d->%d->%d q%d k%d s%d %dx%d->%dx%d G%d bands%d buf%d%s%s%s", o.name.c_str(), o.irb.Cin, o.irb.Cexp, o.irb.Cout, o.irb.Cq, o.irb.K, o.irb.S, o.H, o.W, o.Ho, o.Wo,
-                 o.irb.G, o.irb.nbands, o.irb.nbuf, o.irb.has_expand ? "" : " noexp", o.irb_res_blob >= 0 ? " +res" : "", o.hwc ? " hwc" : "");
+                 o.irb.G, o.irb.nbands, o.irb.nbuf, o.irb.has_expand ? "" : " noexp", o.irb_res_blob >= 0 ? " +res" : "", o.hwc ? (o.irb.Cout2 ? " hwc dual" : " hwc") : "");
     else snprintf(buf, cap, "%s %s n=%zu", kn[o.kind], o.name.c_str(), h->blobs[o.in0].n);
     return SGX_OK;
 }

@@ -42,11 +42,13 @@ struct SgxIrb {
     const float *w2T, *b2; int ld2;             // [ceil32(Cexp)][ld2]
     const float *wq1T, *bq1; int ldq1;          // [ceil32(Cout)][ldq1]
     const float *wq2T, *bq2; int ldq2;          // [ceil32(Cq)][ldq2]
+    // second head on the same input (SSD loc + conf heads of one feature map: depthwise -> pointwise twice from ONE staging of the input planes); Cout2 = 0: none
+    int Cout2, hwc_off2, ld2b; const float *wdp2, *w2Tb, *b2b; float *out2; size_t out2_pitch;
     // original ncnn layouts (emulator build)
-    const float *w1, *wd, *bd, *w2, *wq1, *wq2;
+    const float *w1, *wd, *bd, *w2, *wq1, *wq2, *wd_b, *bd_b, *w2_b;
 };
 #define SGX_IRB_KKP(K) (((K) * (K) + 1 + 3) & ~3)
-static inline size_t sgx_irb_lds_bytes(const SgxIrb &p) { return (size_t)p.nbuf * 32 * ((size_t)p.planeT + SGX_IRB_KKP(p.K)) * 4; }
+static inline size_t sgx_irb_lds_bytes(const SgxIrb &p) { return (size_t)p.nbuf * 32 * ((size_t)p.planeT + (p.Cout2 ? 2 : 1) * SGX_IRB_KKP(p.K)) * 4; }
 
 SGX_DEV float sgx_irb_act(int mode, float v, float c1, float lo, float hi, float c2)
 {
@@ -76,7 +78,7 @@ SGX_DEV void sgx_bst(sgx_rsrc r, unsigned voff, unsigned soff, float v) { __buil
 // bias of accumulator register r of 32-row tile t: row = 32 t + (r & 3) + 8 (r >> 2) + 4 half; the descriptor ends at the last channel, so padded rows read 0
 #define SGX_IRB_BIAS(rs, t, r, half) sgx_bld(rs, (unsigned)(half) * 16u, (unsigned)(32 * (t) + ((r) & 3) + 8 * ((r) >> 2)) * 4u)
 
-template <int K, int S, int NT, int NQ, bool EXPAND, bool HS>
+template <int K, int S, int NT, int NQ, bool EXPAND, bool HS, int NT2>
 __global__ void __launch_bounds__(768) k_irb(SgxIrb p)
 {
     extern __shared__ __attribute__((aligned(16))) float sgx_irb_smem[];
@@ -84,6 +86,7 @@ __global__ void __launch_bounds__(768) k_irb(SgxIrb p)
     constexpr int AMODE = HS ? SGX_EMODE_HSWISH : SGX_EMODE_ACT;      // both activations of a block are of one kind in this graph (planner checks)
     float *Eb = sgx_irb_smem;                                         // [nbuf][32][planeT]
     float *Wds = sgx_irb_smem + (size_t)p.nbuf * 32 * p.planeT;       // [nbuf][32][KKP]
+    float *Wds2 = Wds + (size_t)p.nbuf * 32 * KKP;                    // second head's depthwise weights (NT2 > 0)
     const int tid = (int)threadIdx.x, nthreads = (int)blockDim.x, wave = tid >> 6, nwaves = nthreads >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int HW = p.H * p.W, HWo = p.Ho * p.Wo;
     int b0, nimg, oy0, OH;
@@ -112,6 +115,17 @@ __global__ void __launch_bounds__(768) k_irb(SgxIrb p)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[t][r] = SGX_IRB_BIAS(r_b2, t, r, half);
     }
+    constexpr int NT2A = NT2 > 0 ? NT2 : 1;
+    sgx_f32x16 acc2[NT2A];
+    if (NT2 > 0) {
+        const sgx_rsrc r_b2b = sgx_mkrsrc_n(p.b2b, p.Cout2 * 4);
+#pragma unroll
+        for (int t = 0; t < NT2; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc2[t][r] = SGX_IRB_BIAS(r_b2b, t, r, half);
+    }
+    const sgx_rsrc r_w2b = sgx_mkrsrc(NT2 > 0 ? p.w2Tb : p.w2T);
+    const unsigned aoff2b = (unsigned)(half * (NT2 > 0 ? p.ld2b : p.ld2) + l31) * 4u;
 
     const int nchunks = (p.Cexp + 31) >> 5, bmask = p.nbuf - 1;
     const unsigned aoff1 = (unsigned)(half * p.ld1 + l31) * 4u, aoff2 = (unsigned)(half * p.ld2 + l31) * 4u;
@@ -123,17 +137,29 @@ __global__ void __launch_bounds__(768) k_irb(SgxIrb p)
     const int ew0 = qi0 * p.HpWp + (iy0 + p.pad - ypA) * p.Wp + ix0 + p.pad;
     const unsigned xoff0 = (unsigned)((size_t)(b0 + qi0) * p.in_pitch + (size_t)iy0 * p.W + ix0 + (size_t)half * HW) * 4u;
 
-    // depthwise convolution of k-step s of a chunk at this lane's output pixel = B operand of the project GEMM
-    auto dw = [&](const float *E, const float *Wc, int s) -> float {
-        float w[KKP];
+    // depthwise convolution of k-step s of a chunk at this lane's output pixel = B operand of the project GEMM; with a second head the taps are read once and
+    // convolved with both heads' weights
+    auto dw = [&](const float *E, const float *Wc, const float *Wc2, int s, float &v2out) -> float {
+        float w[KKP], tp[KK];
 #pragma unroll
         for (int i = 0; i < KKP / 4; i++) { const float4 q4 = ((const float4 *)(Wc + 2 * s * KKP))[i]; w[4 * i] = q4.x; w[4 * i + 1] = q4.y; w[4 * i + 2] = q4.z; w[4 * i + 3] = q4.w; }
         const float *ep = E + (size_t)2 * s * p.planeT;
-        float v = w[KK];
 #pragma unroll
         for (int i = 0; i < K; i++)
 #pragma unroll
-            for (int j = 0; j < K; j++) v = fmaf(w[i * K + j], ep[i * p.Wp + j], v);
+            for (int j = 0; j < K; j++) tp[i * K + j] = ep[i * p.Wp + j];
+        float v = w[KK];
+#pragma unroll
+        for (int t = 0; t < KK; t++) v = fmaf(w[t], tp[t], v);
+        if (NT2 > 0) {
+            float w2[KKP];
+#pragma unroll
+            for (int i = 0; i < KKP / 4; i++) { const float4 q4 = ((const float4 *)(Wc2 + 2 * s * KKP))[i]; w2[4 * i] = q4.x; w2[4 * i + 1] = q4.y; w2[4 * i + 2] = q4.z; w2[4 * i + 3] = q4.w; }
+            float u = w2[KK];
+#pragma unroll
+            for (int t = 0; t < KK; t++) u = fmaf(w2[t], tp[t], u);
+            v2out = sgx_irb_act(AMODE, u, p.a2c1, p.a2lo, p.a2hi, p.a2c2);
+        }
         return sgx_irb_act(AMODE, v, p.a2c1, p.a2lo, p.a2hi, p.a2c2);
     };
 
@@ -157,27 +183,36 @@ __global__ void __launch_bounds__(768) k_irb(SgxIrb p)
         if (hp == a_first && c >= 0 && owner) {
             const int ch0 = c * 32, nks = min(16, (p.Cexp - ch0) >> 1), buf = c & bmask;
             const float *E = Eb + (size_t)buf * 32 * p.planeT + e_r;
-            const float *Wc = Wds + (size_t)buf * 32 * KKP + half * KKP;
+            const float *Wc = Wds + (size_t)buf * 32 * KKP + half * KKP, *Wc2 = Wds2 + (size_t)buf * 32 * KKP + half * KKP;
             const unsigned sB = (unsigned)(ch0 * p.ld2) * 4u, sstep = (unsigned)(2 * p.ld2) * 4u;
+            const unsigned sBb = (unsigned)(ch0 * p.ld2b) * 4u, sstepb = (unsigned)(2 * p.ld2b) * 4u;
             // project weights: a ring of R k-steps in flight, statically indexed (the loop advances R steps per trip; Cexp is a multiple of 8: planner), so a
             // load is only waited for R steps after it was issued
             constexpr int R = 4;
-            float ar[R][NT];
+            float ar[R][NT], ar2[R][NT2A];
 #pragma unroll
-            for (int d = 0; d < R; d++)
+            for (int d = 0; d < R; d++) {
 #pragma unroll
                 for (int t = 0; t < NT; t++) ar[d][t] = sgx_bld(r_w2, aoff2 + 128u * t, sB + (unsigned)min(d, nks - 1) * sstep);
-            float v = dw(E, Wc, 0);
+#pragma unroll
+                for (int t = 0; t < NT2; t++) ar2[d][t] = sgx_bld(r_w2b, aoff2b + 128u * t, sBb + (unsigned)min(d, nks - 1) * sstepb);
+            }
+            float v2 = 0.f;
+            float v = dw(E, Wc, Wc2, 0, v2);
             for (int s0 = 0; s0 < nks; s0 += R) {
 #pragma unroll
                 for (int d = 0; d < R; d++) {
                     const int s = s0 + d;
 #pragma unroll
                     for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[d][t], v, acc[t], 0, 0, 0);
-                    const unsigned sn = sB + (unsigned)min(s + R, nks - 1) * sstep;
 #pragma unroll
-                    for (int t = 0; t < NT; t++) ar[d][t] = sgx_bld(r_w2, aoff2 + 128u * t, sn);
-                    v = dw(E, Wc, min(s + 1, nks - 1));
+                    for (int t = 0; t < NT2; t++) acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar2[d][t], v2, acc2[t], 0, 0, 0);
+                    const int sn_ = min(s + R, nks - 1);
+#pragma unroll
+                    for (int t = 0; t < NT; t++) ar[d][t] = sgx_bld(r_w2, aoff2 + 128u * t, sB + (unsigned)sn_ * sstep);
+#pragma unroll
+                    for (int t = 0; t < NT2; t++) ar2[d][t] = sgx_bld(r_w2b, aoff2b + 128u * t, sBb + (unsigned)sn_ * sstepb);
+                    v = dw(E, Wc, Wc2, min(s + 1, nks - 1), v2);
                 }
             }
         }
@@ -186,6 +221,7 @@ __global__ void __launch_bounds__(768) k_irb(SgxIrb p)
         if (hp != a_first && more) {
             float *E = Eb + (size_t)buf1 * 32 * p.planeT;
             for (int i = tid; i < 8 * KKP; i += nthreads) ((float4 *)(Wds + (size_t)buf1 * 32 * KKP))[i] = ((const float4 *)(p.wdp + (size_t)ch1 * KKP))[i];
+            if (NT2 > 0) for (int i = tid; i < 8 * KKP; i += nthreads) ((float4 *)(Wds2 + (size_t)buf1 * 32 * KKP))[i] = ((const float4 *)(p.wdp2 + (size_t)ch1 * KKP))[i];
             for (int tile = wave; tile < ngi; tile += nwaves) {
                 const bool first = tile == wave;
                 int ew; unsigned xoff; bool ivalid;
@@ -351,6 +387,18 @@ __global__ void __launch_bounds__(768) k_irb(SgxIrb p)
             }
         }
     }
+    if (NT2 > 0 && ovalid) {                          // second head: HWC store into its own concat buffer
+        const sgx_rsrc r_o2 = sgx_mkrsrc(p.out2);
+        const unsigned ovo2 = (unsigned)((size_t)(b0 + og_img) * p.out2_pitch + (size_t)p.hwc_off2 + (size_t)opix * p.Cout2 + 4 * half) * 4u;
+#pragma unroll
+        for (int t = 0; t < NT2; t++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int rb = 32 * t + (r & 3) + 8 * (r >> 2);
+                if (rb + 4 * half < p.Cout2) sgx_bst(r_o2, ovo2, (unsigned)rb * 4u, acc2[t][r]);
+            }
+        }
+    }
 }
 #endif
 
@@ -401,16 +449,33 @@ static void sgx_irb_emu(const SgxIrb &p, int b)
         if (p.hwc) p.out[(size_t)b * p.out_pitch + (size_t)p.hwc_off + (size_t)q * p.Cout + o] = v;
         else p.out[(size_t)b * p.out_pitch + (size_t)o * HWo + q] = v;
     }
+    if (p.Cout2 > 0) {                                // second head on the same (un-expanded) input: its own depthwise + pointwise, HWC store
+        for (int m = 0; m < p.Cexp; m++) for (int oy = 0; oy < p.Ho; oy++) for (int ox = 0; ox < p.Wo; ox++) {
+            float s = p.bd_b[m];
+            for (int i = 0; i < p.K; i++) for (int j = 0; j < p.K; j++) {
+                const int iy = oy * p.S - p.pad + i, ix = ox * p.S - p.pad + j;
+                const float x = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? E[(size_t)m * HW + iy * p.W + ix] : 0.f;
+                s = fmaf(p.wd_b[(size_t)m * KK + i * p.K + j], x, s);
+            }
+            Dw[(size_t)m * HWo + oy * p.Wo + ox] = sgx_irb_act(p.act2, s, p.a2c1, p.a2lo, p.a2hi, p.a2c2);
+        }
+        for (int o = 0; o < p.Cout2; o++) for (int q = 0; q < HWo; q++) {
+            float s = p.b2b[o];
+            for (int k = 0; k < p.Cexp; k++) s = fmaf(p.w2_b[(size_t)o * p.Cexp + k], Dw[(size_t)k * HWo + q], s);
+            p.out2[(size_t)b * p.out2_pitch + (size_t)p.hwc_off2 + (size_t)q * p.Cout2 + o] = s;
+        }
+    }
 }
 #endif
 
 // instantiations the planner may pick: (K, S, NT = ceil(Cout / 32), NQ = ceil(Cq / 32), with / without the expand stage)
 #define SGX_IRB_INSTANCES(X) \
-    X(3, 1, 3, 0, true, true) X(3, 1, 4, 1, true, true) X(5, 1, 5, 2, true, true) X(5, 1, 2, 1, true, false) X(3, 2, 3, 0, true, true) X(5, 2, 2, 1, true, false) \
-    X(5, 2, 5, 2, false, true) X(3, 1, 1, 0, false, false) X(3, 1, 3, 0, false, false) X(3, 1, 4, 0, false, false)
-static inline bool sgx_irb_supported(int K, int S, int NT, int NQ, bool expand, bool hswish)
+    X(3, 1, 3, 0, true, true, 0) X(3, 1, 4, 1, true, true, 0) X(5, 1, 5, 2, true, true, 0) X(5, 1, 2, 1, true, false, 0) X(3, 2, 3, 0, true, true, 0) X(5, 2, 2, 1, true, false, 0) \
+    X(5, 2, 5, 2, false, true, 0) X(3, 1, 1, 0, false, false, 0) X(3, 1, 3, 0, false, false, 0) X(3, 1, 4, 0, false, false, 0) \
+    X(3, 1, 3, 0, false, false, 1) X(3, 1, 4, 0, false, false, 1)
+static inline bool sgx_irb_supported(int K, int S, int NT, int NQ, bool expand, bool hswish, int NT2 = 0)
 {
-#define SGX_IRB_X(K_, S_, NT_, NQ_, E_, H_) if (K == K_ && S == S_ && NT == NT_ && NQ == NQ_ && expand == E_ && hswish == H_) return true;
+#define SGX_IRB_X(K_, S_, NT_, NQ_, E_, H_, N2_) if (K == K_ && S == S_ && NT == NT_ && NQ == NQ_ && expand == E_ && hswish == H_ && NT2 == N2_) return true;
     SGX_IRB_INSTANCES(SGX_IRB_X)
 #undef SGX_IRB_X
     return false;
@@ -423,7 +488,7 @@ static inline int sgx_irb_launch(const SgxIrb &p, int batch, sgx_stream_t st)
     for (int b = 0; b < batch; b++) sgx_irb_emu(p, b);
     return SGX_OK;
 #else
-    const int NT = (p.Cout + 31) / 32, NQ = (p.Cq + 31) / 32;
+    const int NT = (p.Cout + 31) / 32, NQ = (p.Cq + 31) / 32, NT2 = (p.Cout2 + 31) / 32;
     const int maxPO = p.nbands > 1 ? p.OH * p.Wo : p.G * p.Ho * p.Wo, ngo = (maxPO + 31) / 32;
     const int maxPI = p.nbands > 1 ? std::min(p.H, (p.OH - 1) * p.S + p.K) * p.W : p.G * p.H * p.W;
     const int nw = std::max(ngo, std::min(12, (maxPI + 31) / 32));               // one wave per output-pixel group; up to 12 waves share the stage-A tiles
@@ -431,8 +496,8 @@ static inline int sgx_irb_launch(const SgxIrb &p, int batch, sgx_stream_t st)
     const size_t lds = sgx_irb_lds_bytes(p);
     if (nw > 12 || lds > 160 * 1024) return SGX_ERR_UNSUPPORTED;
     SgxIrb q = p; q.batch = batch;
-#define SGX_IRB_X(K_, S_, NT_, NQ_, E_, H_) if (p.K == K_ && p.S == S_ && NT == NT_ && NQ == NQ_ && (p.has_expand != 0) == E_ && (p.act2 == SGX_EMODE_HSWISH) == H_) { \
-        auto kfn = k_irb<K_, S_, NT_, NQ_, E_, H_>; static bool attr = false; \
+#define SGX_IRB_X(K_, S_, NT_, NQ_, E_, H_, N2_) if (p.K == K_ && p.S == S_ && NT == NT_ && NQ == NQ_ && (p.has_expand != 0) == E_ && (p.act2 == SGX_EMODE_HSWISH) == H_ && NT2 == N2_) { \
+        auto kfn = k_irb<K_, S_, NT_, NQ_, E_, H_, N2_>; static bool attr = false; \
         if (!attr) { (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * nw), lds, st, q); return SGX_OK; }
     SGX_IRB_INSTANCES(SGX_IRB_X)
