@@ -425,7 +425,7 @@ def main():
             ks_path = next(f for f in (os.path.join(ROOT, 'profiles', n) for n in ('r3_bench_kernel_stats.csv', 'r2_bench_kernel_stats.csv')) if os.path.exists(f))
             rows = list(csv.DictReader(open(ks_path)))
             tot_ns = sum(float(r['TotalDurationNs']) for r in rows if classify(r['Name']) == 'det_forward')
-            nl = max([int(r['Calls']) for r in rows if r['Name'].startswith('k_det_preprocess')] or [0])
+            nl = max([int(r['Calls']) for r in rows if r['Name'].startswith(('k_det_preprocess', 'k_stem_pre'))] or [0])
             if nl and S == 512:
                 kms = tot_ns / nl / 1e6
                 roofline['graph_kernel_time'] = {'sum_of_node_kernel_ms_per_launch': round(kms, 3), 'achieved': round(dk['alg_gflop_per_launch'] / (kms * 1e-3) / 1e3, 3),

@@ -43,6 +43,7 @@ struct Op {
 
 struct sgx_det {
     int T = 300, max_batch = 1, W = 0, H = 0, legacy = 0;
+    int pre_fused = 0;                  // 1: ops[0] is the stem convolution and runs as k_stem_pre straight from the u8 images (no "input" blob, no k_det_preprocess launch)
     float det_th = 0.9f, dyn_th = 0.01f;
     std::vector<Layer> layers;
     std::map<std::string, int> blob_id;
@@ -76,6 +77,26 @@ extern "C" int sgx_det_debug_set_block_fusion(int on) { g_det_block_fusion = on 
 static int g_det_irb = -1;               // test / tuning tap: inverted-residual blocks and SSD heads as one matrix-core kernel each (sgx_det_irb.h): 0 off, 1 the shapes where it beats
                                          // the per-layer kernels on MI355X (default), 2 every shape it supports (tests); -1 = SGX_DET_IRB or the default
 extern "C" int sgx_det_debug_set_irb(int on) { g_det_irb = on < 0 ? -1 : (on > 2 ? 2 : on); return SGX_OK; }
+
+// the 3 x 3 stride-2 stem on the k_conv_stem2 path (run_op) — also the condition for fusing the pre-processing into it (k_stem_pre)
+struct Stem2Geom { int nbx4, pitch4, RB, nbands; size_t lds; };
+static Stem2Geom stem2_geom(const Op &op)
+{
+    Stem2Geom g;
+    g.nbx4 = (op.Wo + 3) / 4; g.pitch4 = ((g.nbx4 - 1) * 4 * op.stride + 3 * op.stride + op.k + 3) & ~3;
+    g.RB = std::max(1, std::min(op.Ho, ((10240 / (3 * g.pitch4)) - 3) / 2 + 1));       // LDS = 3 x ((RB - 1) 2 + 3) x pitch4 floats, about 40 KB (3-4 workgroups per CU)
+    g.nbands = (op.Ho + g.RB - 1) / g.RB;
+    g.lds = (size_t)3 * ((g.RB - 1) * 2 + 3) * g.pitch4 * 4;
+    return g;
+}
+static bool stem2_epi_ok(const sgx_det *h, const Op &op);
+static bool stem2_ok(const sgx_det *h, const Op &op)
+{
+    static const int dw2_on = getenv("SGX_DW2") ? atoi(getenv("SGX_DW2")) : 1;
+    if (op.kind != OP_KXK || !dw2_on || h->legacy || op.depthwise || !op.wtT || op.outc > 16 || op.inc != 3 || op.k != 3 || op.stride != 2) return false;
+    const Stem2Geom g = stem2_geom(op);
+    return 3 * 5 * g.pitch4 * 4 <= 65536 && g.pitch4 < 4096 && stem2_epi_ok(h, op);
+}
 
 static int parse_param(const char *text, std::vector<Layer> &layers)
 {
@@ -573,6 +594,16 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
         Blob &ob = h->blobs[o.out]; if (!ob.d && ob.n) { if (h->alloc(&ob.d, ob.n * B)) FAIL(SGX_ERR_NOMEM); }
         if (o.irb_out2_blob >= 0) { Blob &o2 = h->blobs[o.irb_out2_blob]; if (!o2.d && o2.n) { if (h->alloc(&o2.d, o2.n * B)) FAIL(SGX_ERR_NOMEM); } }
     }
+    {   // pre-processing fused into the stem (k_stem_pre) when the stem is the only reader of the network input and takes the k_conv_stem2 path (see run_op)
+        static const int prefuse_env = getenv("SGX_DET_PREFUSE") ? atoi(getenv("SGX_DET_PREFUSE")) : 1;
+        const int in_id = h->blob_id.at("input");
+        int readers = 0; for (const Op &o : h->ops) readers += (o.in0 == in_id) + (o.in1 == in_id);
+        if (prefuse_env && g_det_fuse && !h->legacy && !h->ops.empty() && readers == 1 && stem2_ok(h, h->ops[0]) && h->ops[0].in0 == in_id) {
+            Blob &ib = h->blobs[in_id];
+            auto it = std::find(h->dev.begin(), h->dev.end(), (void *)ib.d);
+            if (it != h->dev.end()) { (void)hipFree(ib.d); h->dev.erase(it); ib.d = nullptr; h->pre_fused = 1; }
+        }
+    }
 #undef FAIL
     h->num_priors = (int)prior_boxes.size() / 4;
     h->priors = prior_boxes; h->priors.insert(h->priors.end(), prior_vars.begin(), prior_vars.end());
@@ -582,6 +613,14 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
     if (h->alloc(&h->d_priors, (size_t)h->num_priors * 4) || h->alloc(&h->d_cls_rows, (size_t)B * (h->num_class - 1) * SGX_DO_TOPK * 6) ||
         h->alloc(&h->d_cls_count, (size_t)B * (h->num_class - 1)) || h->alloc(&h->d_results, (size_t)B)) { delete h; return SGX_ERR_NOMEM; }
     if (hipMemcpy(h->d_priors, prior_boxes.data(), sizeof(float) * 4 * h->num_priors, hipMemcpyHostToDevice) != hipSuccess) { delete h; return SGX_ERR_DEVICE; }
+    {   // A/B switch of the XCD-aware work order (sgx_xcd_order); on by default
+        const int xo = getenv("SGX_DET_XCD") ? atoi(getenv("SGX_DET_XCD")) : 1;
+#ifndef SGX_EMU
+        if (hipMemcpyToSymbol(HIP_SYMBOL(sgx_det_xcd_order), &xo, sizeof(int)) != hipSuccess) { delete h; return SGX_ERR_DEVICE; }
+#else
+        sgx_det_xcd_order = xo;
+#endif
+    }
     if (hipMemset(h->d_results, 0, sizeof(sgx_det_result) * (size_t)B) != hipSuccess) { delete h; return SGX_ERR_DEVICE; }      // entries past the counts are never written: keep them defined
     std::vector<SgxDetTab> xt, yt; build_tab(width, T, xt); build_tab(height, T, yt);
     if (h->alloc(&h->d_xt, T) || h->alloc(&h->d_yt, T) || h->alloc(&h->d_img, (size_t)B * height * ((3 * width + 3) & ~3) + 4)) { delete h; return SGX_ERR_NOMEM; }
@@ -711,14 +750,11 @@ static void run_op(sgx_det *h, const Op &op, int batch, sgx_stream_t st)
                                                                      magic(((std::min(RB, op.Ho) - 1) * op.stride + op.k) * Wp), magic(Wp), magic(op.Wo), A.d, op.wt, op.bias, O.d, e); }
             else { auto kfn = k_conv_dw<5>; SGX_LAUNCH_DYN(kfn, dim3(ngroups * nbands), dim3(256), lds, st, op.outc, op.H, op.W, op.Ho, op.Wo, op.stride, op.pad, P, RB, nbands, nplanes,
                                                            magic(((std::min(RB, op.Ho) - 1) * op.stride + op.k) * Wp), magic(Wp), magic(op.Wo), A.d, op.wt, op.bias, O.d, e); }
-        } else if (dw2_on && !h->legacy && !op.depthwise && op.wtT && op.outc <= 16 && op.inc == 3 && op.k == 3 && op.stride == 2 && 3 * 5 * pitch4 * 4 <= 65536 &&
-                   (e.mode == SGX_EMODE_NONE || e.mode == SGX_EMODE_ACT || e.mode == SGX_EMODE_HSWISH)) {
-            // k_conv_stem2: bands of RB output rows; LDS = 3 x ((RB - 1) 2 + 3) x pitch4 floats, about 40 KB (3-4 workgroups per CU); RB*ceil(Wo/4) tasks for 256 threads
-            int RB = std::max(1, std::min(op.Ho, ((10240 / (3 * pitch4)) - 3) / 2 + 1));
-            const int nbands = (op.Ho + RB - 1) / RB;
-            const size_t lds = (size_t)3 * ((RB - 1) * 2 + 3) * pitch4 * 4;
+        } else if (stem2_ok(h, op)) {
+            // k_conv_stem2: bands of RB output rows; RB*ceil(Wo/4) tasks for 256 threads
+            const Stem2Geom g = stem2_geom(op);
             auto kfn = k_conv_stem2<3>;
-            SGX_LAUNCH_DYN(kfn, dim3(nbands, batch), dim3(256), lds, st, op.outc, op.H, op.W, op.Ho, op.Wo, op.pad, RB, pitch4, magic(nbx4), A.d, A.n, op.wtT, op.bias, O.d, O.n, e);
+            SGX_LAUNCH_DYN(kfn, dim3(g.nbands, batch), dim3(256), g.lds, st, op.outc, op.H, op.W, op.Ho, op.Wo, op.pad, g.RB, g.pitch4, magic(g.nbx4), A.d, A.n, op.wtT, op.bias, O.d, O.n, e);
         } else if (!h->legacy && !op.depthwise && op.wtT && op.outc <= 16 && op.inc * Wp * op.k <= budget) {
             const int RB = std::min(op.Ho, std::max(1, (budget / (op.inc * Wp) - op.k) / op.stride + 1)), nbands = (op.Ho + RB - 1) / RB;
             const size_t lds = (size_t)op.inc * ((RB - 1) * op.stride + op.k) * Wp * 4;
@@ -748,6 +784,25 @@ static void run_preprocess(sgx_det *h, const uint8_t *d_img, int pitch, int batc
                h->blobs[h->blob_id.at("input")].d);
 }
 
+static bool stem2_epi_ok(const sgx_det *h, const Op &op)
+{
+    const SgxEpi e = make_epi(h, op, 0);
+    return e.mode == SGX_EMODE_NONE || e.mode == SGX_EMODE_ACT || e.mode == SGX_EMODE_HSWISH;
+}
+
+// first step of the plan: k_det_preprocess into the "input" blob, or (pre_fused) the stem convolution straight from the images.  Launched outside the captured
+// graph: the image pointer changes from call to call.
+static void run_first_step(sgx_det *h, const uint8_t *d_img, int pitch, int batch, sgx_stream_t st)
+{
+    if (!h->pre_fused) { run_preprocess(h, d_img, pitch, batch, st); return; }
+    const Op &op = h->ops[0]; const Blob &O = h->blobs[op.out];
+    const SgxEpi e = make_epi(h, op, (size_t)op.outc * op.Ho * op.Wo);
+    const Stem2Geom g = stem2_geom(op);
+    auto magic = [](int d) -> unsigned { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
+    SGX_LAUNCH_DYN(k_stem_pre, dim3(g.nbands * batch), dim3(256), g.lds + (size_t)(h->T + (g.RB - 1) * 2 + 3) * sizeof(SgxDetTab), st, d_img, h->H, pitch, h->d_xt, h->d_yt, h->T, 123.675f, 116.28f, 103.53f, g.nbands, batch,
+                   op.outc, op.Ho, op.Wo, op.pad, g.RB, g.pitch4, magic(g.pitch4), magic(g.nbx4), op.wtT, op.bias, O.d, O.n, e);
+}
+
 // Batched forward from device-resident interleaved 3-channel u8 images (B x H x W x 3, row pitch in bytes).
 // Leaves loc (num_priors*4) and softmax conf (num_priors*num_class) per image in device memory; returns their pointers.
 extern "C" int sgx_det_forward_batch_dev(sgx_det *h, const uint8_t *d_img, int pitch, int batch, const float **d_loc, const float **d_conf, void *stream_)
@@ -755,7 +810,8 @@ extern "C" int sgx_det_forward_batch_dev(sgx_det *h, const uint8_t *d_img, int p
     if (!h || !d_img || batch < 1 || batch > h->max_batch || pitch < ((3 * h->W + 3) & ~3) || (pitch & 3) || ((uintptr_t)d_img & 3)) return SGX_ERR_INVALID;   // rows are read as aligned dwords
     sgx_stream_t st = (sgx_stream_t)stream_;
     sgx_prof_begin(SGX_K_DET_FWD, st);
-    run_preprocess(h, d_img, pitch, batch, st);
+    run_first_step(h, d_img, pitch, batch, st);
+    const size_t first = h->pre_fused ? 1 : 0;
 #ifndef SGX_EMU
     // The plan after pre-processing only touches the handle's own blobs, so it is captured once per batch size into a hipGraph and replayed
     // (needs a non-default stream; SGX_DET_NO_GRAPH=1 or the legacy stream falls back to individual launches).
@@ -765,7 +821,7 @@ extern "C" int sgx_det_forward_batch_dev(sgx_det *h, const uint8_t *d_img, int p
         if (it == h->graphs.end()) {
             hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
             SGX_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            for (const Op &op : h->ops) run_op(h, op, batch, st);
+            for (size_t i = first; i < h->ops.size(); i++) run_op(h, h->ops[i], batch, st);
             SGX_CHECK_HIP(hipStreamEndCapture(st, &graph));
             SGX_CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
             (void)hipGraphDestroy(graph);
@@ -774,7 +830,7 @@ extern "C" int sgx_det_forward_batch_dev(sgx_det *h, const uint8_t *d_img, int p
         SGX_CHECK_HIP(hipGraphLaunch(it->second, st));
     } else
 #endif
-    for (const Op &op : h->ops) run_op(h, op, batch, st);
+    for (size_t i = first; i < h->ops.size(); i++) run_op(h, h->ops[i], batch, st);
     sgx_prof_end(SGX_K_DET_FWD, st);
     SGX_CHECK_HIP(hipGetLastError());
     if (d_loc) *d_loc = h->blobs[h->loc_blob].d;
@@ -786,7 +842,8 @@ extern "C" int sgx_det_forward_batch_dev(sgx_det *h, const uint8_t *d_img, int p
 extern "C" int sgx_det_debug_time_ops(sgx_det *h, const uint8_t *d_img, int pitch, int batch, int reps, float *ms, int cap, int *nops)
 {
     if (!h || !d_img || !ms || !nops || batch < 1 || batch > h->max_batch || reps < 1) return SGX_ERR_INVALID;
-    *nops = (int)h->ops.size() + 1;
+    const int skip = h->pre_fused;                                  // step 0 is then the stem itself; step i >= 1 is ops[i]
+    *nops = (int)h->ops.size() + 1 - skip;
     if (cap < *nops) return SGX_ERR_INVALID;
 #ifndef SGX_EMU
     hipEvent_t a, b; SGX_CHECK_HIP(hipEventCreate(&a)); SGX_CHECK_HIP(hipEventCreate(&b));
@@ -794,7 +851,7 @@ extern "C" int sgx_det_debug_time_ops(sgx_det *h, const uint8_t *d_img, int pitc
         float tot = 0.f;
         for (int r = 0; r < reps + 1; r++) {
             SGX_CHECK_HIP(hipEventRecord(a, 0));
-            if (i == 0) run_preprocess(h, d_img, pitch, batch, 0); else run_op(h, h->ops[i - 1], batch, 0);
+            if (i == 0) run_first_step(h, d_img, pitch, batch, 0); else run_op(h, h->ops[i - 1 + skip], batch, 0);
             SGX_CHECK_HIP(hipEventRecord(b, 0)); SGX_CHECK_HIP(hipEventSynchronize(b));
             float t = 0.f; SGX_CHECK_HIP(hipEventElapsedTime(&t, a, b)); if (r) tot += t;
         }
@@ -809,9 +866,11 @@ extern "C" int sgx_det_debug_time_ops(sgx_det *h, const uint8_t *d_img, int pitc
 
 extern "C" int sgx_det_debug_op_desc(const sgx_det *h, int i, char *buf, int cap)
 {
-    if (!h || !buf || cap < 16 || i < 0 || i > (int)h->ops.size()) return SGX_ERR_INVALID;
-    if (i == 0) { snprintf(buf, cap, "preprocess %dx%d->%d", h->W, h->H, h->T); return SGX_OK; }
-    const Op &o = h->ops[i - 1];
+    if (!h || !buf || cap < 16 || i < 0 || i > (int)h->ops.size() - h->pre_fused) return SGX_ERR_INVALID;
+    if (i == 0 && !h->pre_fused) { snprintf(buf, cap, "preprocess %dx%d->%d", h->W, h->H, h->T); return SGX_OK; }
+    if (i == 0) { const Op &s0 = h->ops[0]; snprintf(buf, cap, "kxk %s c%d->%d k%d s%d %dx%d->%dx%d epi%d pre %dx%d->%d", s0.name.c_str(), s0.inc, s0.outc, s0.k, s0.stride, s0.H, s0.W, s0.Ho, s0.Wo,
+                                                     (int)s0.epi.size() + (s0.act ? 1 : 0), h->W, h->H, h->T); return SGX_OK; }
+    const Op &o = h->ops[i - 1 + h->pre_fused];
     static const char *kn[] = { "pw", "kxk", "binary", "unary", "permute_into", "copy_into", "softmax", "block", "irb" };
     if (o.kind == OP_PW || o.kind == OP_KXK)
         snprintf(buf, cap, "%s %s c%d->%d k%d s%d %s%dx%d->%dx%d epi%d%s", kn[o.kind], o.name.c_str(), o.inc, o.outc, o.k, o.stride, o.depthwise ? "dw " : "", o.H, o.W,
@@ -829,7 +888,7 @@ extern "C" int sgx_det_debug_op_desc(const sgx_det *h, int i, char *buf, int cap
 extern "C" int sgx_det_info(const sgx_det *h, int32_t *num_priors, int32_t *num_class, int32_t *num_kernels, double *gmac)
 {
     if (!h) return SGX_ERR_INVALID;
-    if (num_priors) *num_priors = h->num_priors; if (num_class) *num_class = h->num_class; if (num_kernels) *num_kernels = (int)h->ops.size() + 1; if (gmac) *gmac = h->gmac;
+    if (num_priors) *num_priors = h->num_priors; if (num_class) *num_class = h->num_class; if (num_kernels) *num_kernels = (int)h->ops.size() + 1 - h->pre_fused; if (gmac) *gmac = h->gmac;
     return SGX_OK;
 }
 

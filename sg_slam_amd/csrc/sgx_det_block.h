@@ -285,7 +285,8 @@ SGX_KERNEL(SGX_FB2_THREADS) k_fused_block2(int Cmid, int H, int W, int Ho, int W
     SGX_PRIV_DECL(sgx_f2, acc, G::SLOTS_OUT * (COUT / 2), SGX_FB2_THREADS);                    // output channels (2c, 2c + 1)
     SGX_PRIV_DECL(int, eidx, G::SLOTS_IN, SGX_FB2_THREADS);                    // pixel index inside the E tile (-1: slot beyond the tile); bit 30 set = pixel outside the image
     SGX_PRIV_DECL(float, rsd, RES == 1 ? G::SLOTS_OUT * COUT : 1, SGX_FB2_THREADS);           // residual operand of the thread's output pixels, fetched up front (its latency hides behind the whole block)
-    const int tile = (int)blockIdx.x % (tiles_x * tiles_y), b = (int)blockIdx.x / (tiles_x * tiles_y);
+    int tile, b;
+    sgx_xcd_order((int)blockIdx.x, tiles_x * tiles_y, (int)gridDim.x / (tiles_x * tiles_y), &b, &tile);      // a frame's tiles share halo rows and cache lines: one XCD (one L2) per frame
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int oy0 = ty * TOH, ox0 = tx * TOW, iy0 = oy0 * S - pad, ix0 = ox0 * S - pad;
     const float *X = in + (size_t)b * in_pitch;

@@ -6,6 +6,25 @@
 #include "sgx_rt.h"
 #include "../../include/sgx.h"
 
+// XCD-aware work order.  Workgroup w of a launch (linear id, x fastest) is dispatched to XCD w % 8, and every XCD has its own 4 MB L2: with the plain order
+// (work items of a frame on consecutive ids) neighbouring tiles of a frame land on eight different L2s and every halo / partial cache line they share is
+// fetched from HBM once per XCD.  sgx_xcd_order deals the frames out to the XCDs instead: id -> (frame, item) such that all items of a frame run on the XCD
+// frame % 8, consecutively (frames 8q .. 8q + 7 proceed in lock step, one per XCD).  A bijection of [0, per_frame * batch) for every batch: the frames past
+// the last multiple of eight keep the plain order.  sgx_det_xcd_order = 0 restores the plain order everywhere (A/B switch, SGX_DET_XCD=0).
+#ifndef SGX_EMU
+__device__ int sgx_det_xcd_order = 1;
+#else
+static int sgx_det_xcd_order = 1;
+#endif
+SGX_DEV void sgx_xcd_order(int id, int per_frame, int batch, int *frame, int *item)
+{
+    const int b8 = batch & ~7;
+    if (sgx_det_xcd_order && id < b8 * per_frame) {
+        const int x = id & 7, i = id >> 3, q = i / per_frame;
+        *item = i - q * per_frame; *frame = q * 8 + x;
+    } else { const int f = id / per_frame; *frame = f; *item = id - f * per_frame; }
+}
+
 #define SGX_ACT_NONE 0
 #define SGX_ACT_RELU 1
 #define SGX_ACT_CLIP 2
@@ -694,6 +713,79 @@ SGX_KERNEL(256) k_conv_stem2(int outc, int H, int W, int Ho, int Wo, int pad, in
     const int nbx = (Wo + 3) >> 2;
     SGX_THREADS_BEGIN(tid)
 #define SGX_STEM2_RUN(M) sgx_stem2_tasks<INC, M>(tid, outc, nrows, nbx, Wo, Ho, r0, pitch, plane_stride, nbx_magic, tile, WtT, bias, out + (size_t)b * out_pitch, (size_t)b * epi.tpitch, epi)
+    switch (epi.mode) {
+    case SGX_EMODE_NONE: SGX_STEM2_RUN(SGX_EMODE_NONE); break;
+    case SGX_EMODE_ACT: SGX_STEM2_RUN(SGX_EMODE_ACT); break;
+    default: SGX_STEM2_RUN(SGX_EMODE_HSWISH); break;             // the host launches this kernel for these three programs only
+    }
+#undef SGX_STEM2_RUN
+    SGX_THREADS_END
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_stem_pre: k_det_preprocess + k_conv_stem2<3> in one kernel — the 3 x T x T fp32 network input never exists in HBM (1.08 MB written and read back per frame
+// otherwise).  A workgroup owns a band of RB output rows of one image, as k_conv_stem2; instead of copying the three padded input planes of the band from HBM it
+// COMPUTES them into the same LDS tile from the interleaved u8 image: every tile element (row, column) is one resized pixel — the integer bilinear resize of
+// k_det_preprocess (same tables, same arithmetic) on 6 + 6 source bytes read straight from the image (neighbouring lanes read neighbouring bytes: the rows stay in
+// L1 / L2), minus the channel mean — or the convolution's zero padding.  The rows of the band's halo (2 of 2 RB + 1) are resized twice; everything after the barrier
+// is k_conv_stem2.  grid = nbands * B in the XCD-aware order.
+// ---------------------------------------------------------------------------------------------
+SGX_KERNEL(256) k_stem_pre(const uint8_t *__restrict__ img, int H, int ipitch, const SgxDetTab *__restrict__ xt, const SgxDetTab *__restrict__ yt, int T, float m0, float m1, float m2,
+                           int nbands, int batch, int outc, int Ho, int Wo, int pad, int RB, int pitch, unsigned pitch_magic, unsigned nbx_magic,
+                           const float *__restrict__ WtT, const float *__restrict__ bias, float *__restrict__ out, size_t out_pitch, SgxEpi epi)
+{
+    SGX_DYN_LDS(smem);
+    float *tile = (float *)smem;
+    int b, band;
+    sgx_xcd_order((int)blockIdx.x, nbands, batch, &b, &band);
+    const int r0 = band * RB, nrows = min(RB, Ho - r0);
+    const int Rmax = (RB - 1) * 2 + 3, Rin = (nrows - 1) * 2 + 3, iy0 = r0 * 2 - pad, plane_stride = Rmax * pitch;
+    // the resize tables of the band in LDS (all T columns, the band's rows): a tile element then needs ONE round of global loads (its 12 source bytes)
+    SgxDetTab *xs = (SgxDetTab *)(tile + 3 * plane_stride), *ys = xs + T;
+    SGX_THREADS_BEGIN(tid)
+    for (int i = tid; i < T; i += 256) xs[i] = xt[i];
+    if (tid < Rin) ys[tid] = yt[min(max(iy0 + tid, 0), T - 1)];
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    const uint8_t *base = img + (size_t)b * H * ipitch;
+    const float mean[3] = { m0, m1, m2 };
+    constexpr int U = 4;                                            // independent elements per thread and round: their loads are in flight together (no divergent control flow)
+    const int total = Rin * pitch;
+    for (int t0 = tid; t0 < total; t0 += 256 * U) {
+        unsigned long long ra[U], rb[U]; SgxDetTab tx[U], ty[U]; int dst[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int t = min(t0 + 256 * u, total - 1);
+            const int ry = (int)sgx_fastdiv((unsigned)t, pitch_magic), col = t - ry * pitch;
+            const int iy = iy0 + ry, ix = col - pad;
+            const bool inside = (unsigned)iy < (unsigned)T && (unsigned)ix < (unsigned)T;
+            ty[u] = ys[ry]; tx[u] = xs[inside ? ix : 0];
+            const uint8_t *p0 = base + (size_t)ty[u].o * ipitch + 3 * tx[u].o, *p1 = p0 + ipitch;
+            uint32_t a4, b4; uint16_t a2, b2;                      // source pixels tx.o and tx.o + 1 of rows ty.o and ty.o + 1: 6 bytes each (never past the row: tx.o <= W - 2)
+            memcpy(&a4, p0, 4); memcpy(&a2, p0 + 4, 2); memcpy(&b4, p1, 4); memcpy(&b2, p1 + 4, 2);
+            ra[u] = (unsigned long long)a4 | ((unsigned long long)a2 << 32); rb[u] = (unsigned long long)b4 | ((unsigned long long)b2 << 32);
+            dst[u] = t0 + 256 * u < total ? (inside ? ry * pitch + col : -1 - (ry * pitch + col)) : (int)0x80000000;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (dst[u] == (int)0x80000000) continue;
+            const bool inside = dst[u] >= 0;
+            float *d = tile + (inside ? dst[u] : -1 - dst[u]);
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const int q00 = (int)((ra[u] >> (8 * c)) & 255u), q01 = (int)((ra[u] >> (8 * c + 24)) & 255u), q10 = (int)((rb[u] >> (8 * c)) & 255u), q11 = (int)((rb[u] >> (8 * c + 24)) & 255u);
+                const int h0 = q00 * tx[u].a0 + q01 * tx[u].a1, h1 = q10 * tx[u].a0 + q11 * tx[u].a1;
+                const int r = (((ty[u].a0 * (h0 >> 4)) >> 16) + ((ty[u].a1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                d[c * plane_stride] = inside ? ((float)(r & 255) - mean[c]) * 1.0f : 0.f;        // outside the T x T input: the convolution's zero padding
+            }
+        }
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+    const int nbx = (Wo + 3) >> 2;
+    SGX_THREADS_BEGIN(tid)
+#define SGX_STEM2_RUN(M) sgx_stem2_tasks<3, M>(tid, outc, nrows, nbx, Wo, Ho, r0, pitch, plane_stride, nbx_magic, tile, WtT, bias, out + (size_t)b * out_pitch, (size_t)b * epi.tpitch, epi)
     switch (epi.mode) {
     case SGX_EMODE_NONE: SGX_STEM2_RUN(SGX_EMODE_NONE); break;
     case SGX_EMODE_ACT: SGX_STEM2_RUN(SGX_EMODE_ACT); break;

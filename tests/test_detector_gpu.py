@@ -71,3 +71,36 @@ def test_detect_dev_gpu(gpulib, model):
 def test_detection_output_stress_gpu(gpulib, model):
     from test_detector import run_detection_output_stress
     run_detection_output_stress(gpulib, model)
+
+
+def test_xcd_work_order_is_a_permutation_of_the_work(gpulib, model):
+    """The tuned kernels deal frames out to the eight XCDs (sgx_xcd_order): a batch of 19 frames (two full groups of eight + three frames in the plain order)
+    gives, frame by frame, the bytes the batch-of-two plan gives (which run_compare pins to the oracle), and the same with the plain order (SGX_DET_XCD=0)."""
+    import os
+    from sg_slam_amd.detector import Detector2D
+    from test_detector import PARAM, make_image
+    layers, W, blob = model
+    imgs = np.stack([make_image(s) for s in range(19)])
+
+    def run(batch, env):
+        old = os.environ.get('SGX_DET_XCD')
+        if env is None: os.environ.pop('SGX_DET_XCD', None)
+        else: os.environ['SGX_DET_XCD'] = env
+        try:
+            det = Detector2D(0.90, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=batch, lib=gpulib, fuse=True)
+        finally:
+            if old is None: os.environ.pop('SGX_DET_XCD', None)
+            else: os.environ['SGX_DET_XCD'] = old
+        outs = []
+        for i in range(0, 19, batch):
+            n = min(batch, 19 - i)
+            det.detect_batch(imgs[i:i + n])
+            outs += [(det.debug_blob('mbox_loc', b).copy(), det.debug_blob('mbox_conf_softmax', b).copy()) for b in range(n)]
+        det.close()
+        return outs
+
+    ref = run(2, None)
+    for env in (None, '0'):
+        got = run(19, env)
+        for f in range(19):
+            assert (got[f][0] == ref[f][0]).all() and (got[f][1] == ref[f][1]).all(), (env, f)

@@ -30,7 +30,7 @@ f() { find $O/$1 -name "*counter_collection.csv" | head -1; }
 python tools/pmc_traffic.py --det $(f det_fetch) $(f det_write) 3 $(f fetch) $(f write) $S 4 $O/traffic.json $O/bench_under_rocprof.json > /dev/null
 python tools/pmc_insts.py $O/pmc_insts.json $S 4 $(f sq_a) $(f sq_b) --det $(f det_sq) $S $(python - <<PY
 import csv
-n = sum(1 for r in csv.DictReader(open("$(f det_sq)")) if r['Counter_Name'] == 'SQ_WAVES' and 'k_det_preprocess' in r['Kernel_Name'])
+n = sum(1 for r in csv.DictReader(open("$(f det_sq)")) if r['Counter_Name'] == 'SQ_WAVES' and ('k_det_preprocess' in r['Kernel_Name'] or 'k_stem_pre' in r['Kernel_Name']))
 print(max(n, 1))
 PY
 ) > $O/pmc_insts.txt

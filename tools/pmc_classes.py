@@ -6,7 +6,7 @@ CLASS = [('k_pyramid', 'pyramid_resize'), ('k_resize', 'pyramid_resize'), ('k_gr
          ('k_make_map_points', 'map_point_glue'), ('k_merge_matches', 'map_point_glue'), ('k_gather_xw', 'map_point_glue'),
          ('k_dynamic_mask', 'dynamic_mask'), ('k_compact_keys', 'dynamic_mask'),
          ('k_lk_copy', 'lk_pyramid'), ('k_lk_pyrdown', 'lk_pyramid'), ('k_lk_track', 'lk_track'), ('k_fm_ransac', 'fm_ransac'),
-         ('k_det_preprocess', 'det_forward'), ('k_conv_pw', 'det_forward'), ('k_conv_kxk', 'det_forward'), ('k_conv_dw', 'det_forward'), ('k_conv_stem', 'det_forward'), ('k_binary', 'det_forward'), ('k_unary', 'det_forward'),
+         ('k_det_preprocess', 'det_forward'), ('k_stem_pre', 'det_forward'), ('k_conv_pw', 'det_forward'), ('k_conv_kxk', 'det_forward'), ('k_conv_dw', 'det_forward'), ('k_conv_stem', 'det_forward'), ('k_binary', 'det_forward'), ('k_unary', 'det_forward'),
          ('k_copy_into', 'det_forward'), ('k_permute_hwc_into', 'det_forward'), ('k_softmax_rows', 'det_forward'), ('k_fused_block', 'det_forward'),
          ('k_det_class_nms', 'det_output'), ('k_det_merge', 'det_output')]
 

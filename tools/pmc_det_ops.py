@@ -3,7 +3,7 @@ with the plan order (every step is dispatched REPS+1 times in plan order).  usag
 import csv, sys, collections, re
 ops = [l.rstrip('\n') for l in open(sys.argv[1]) if re.match(r'\s*[\d.]+\s+[\d.]+\s+[\d.]+\s+\S', l)]
 reps = int(sys.argv[2]) + 1
-KN = ('k_conv_pw', 'k_conv_kxk', 'k_conv_dw', 'k_conv_stem', 'k_det_preprocess', 'k_softmax_rows', 'k_binary', 'k_unary', 'k_permute', 'k_copy_into')
+KN = ('k_conv_pw', 'k_conv_kxk', 'k_conv_dw', 'k_conv_stem', 'k_stem_pre', 'k_det_preprocess', 'k_softmax_rows', 'k_binary', 'k_unary', 'k_permute', 'k_copy_into')
 table = collections.defaultdict(dict)
 for path in sys.argv[3:]:
     per = collections.OrderedDict()
