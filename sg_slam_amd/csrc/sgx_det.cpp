@@ -484,6 +484,43 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                         }
                     }
                 }
+                // the 75 -> 38 block (24 -> 72 -> 40, 5 x 5 depthwise stride 2, squeeze-excite tail): a k loop of 24 is too short for the matrix-core kernel and the per-layer plan
+                // moves the 72-channel expansion through HBM twice; k_fused_block2 with the squeeze-excite tail in registers takes it
+                // (SGX_DET_BLOCK2_SE=0: per-layer kernels; irb mode 2 keeps k_irb on these shapes for its tests)
+                static const int fb2se_env = getenv("SGX_DET_BLOCK2_SE") ? atoi(getenv("SGX_DET_BLOCK2_SE")) : 1;
+                if (fb2_on && fb2se_env && irb_mode == 1 && ai >= 0 && di >= 0 && !c.hwc && ca.mode == SGX_EMODE_ACT && cb.mode == SGX_EMODE_ACT) {
+                    Op &a = ops[ai]; const Op &d = ops[di], &e = ops[ei];
+                    const int v2 = sgx_fb2_variant(a.inc, c.outc, bq.k, bq.stride, d.outc);
+                    if (v2 && (a.outc % sgx_fb2_cm(v2)) == 0 && a.outc == bq.outc && d.inc == c.outc && e.inc == d.outc) {
+                        SgxFusedBlk fb; memset(&fb, 0, sizeof fb);
+                        fb.Cin = a.inc; fb.Cmid = a.outc; fb.Cout = c.outc; fb.K = bq.k; fb.stride = bq.stride; fb.pad = bq.pad; fb.H = a.H; fb.W = a.W; fb.Ho = bq.Ho; fb.Wo = bq.Wo;
+                        fb.lo1 = ca.lo; fb.hi1 = ca.hi; fb.lo2 = cb.lo; fb.hi2 = cb.hi; fb.v2 = v2;
+                        sgx_fb2_tile(v2, &fb.TOH, &fb.TOW);
+                        fb.tiles_x = (fb.Wo + fb.TOW - 1) / fb.TOW; fb.tiles_y = (fb.Ho + fb.TOH - 1) / fb.TOH;
+                        fb.w1 = a.wt; fb.b1 = a.bias; fb.wd = bq.wt; fb.bd = bq.bias; fb.w2 = c.wt; fb.b2 = c.bias; fb.w2t = c.wtT; fb.ldw2 = c.ldw;
+                        fb.Cq = d.outc; fb.qlo = cd.lo; fb.qhi = cd.hi; fb.gc1 = ce.c1; fb.glo = ce.lo; fb.ghi = ce.hi; fb.gc2 = ce.c2;
+                        fb.wq1 = d.wt; fb.bq1 = d.bias; fb.wq2 = e.wt; fb.bq2 = e.bias;
+                        {   // depthwise weights with the channels of a pair interleaved; squeeze / excite weights with the output pairs interleaved
+                            const int kk = bq.k * bq.k, Cq = d.outc, Co = c.outc;
+                            std::vector<float> wh((size_t)fb.Cmid * kk), w2((size_t)fb.Cmid * kk), q1((size_t)Cq * Co), q2((size_t)Co * Cq), p1((size_t)Cq * Co), p2((size_t)Co * Cq);
+                            if (hipMemcpy(wh.data(), bq.wt, wh.size() * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(q1.data(), d.wt, q1.size() * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                                hipMemcpy(q2.data(), e.wt, q2.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) FAIL(SGX_ERR_DEVICE);
+                            for (int m = 0; m < fb.Cmid; m++) for (int t = 0; t < kk; t++) w2[((size_t)(m >> 1) * kk + t) * 2 + (m & 1)] = wh[(size_t)m * kk + t];
+                            for (int j = 0; j < Cq; j++) for (int k = 0; k < Co; k++) p1[((size_t)(j >> 1) * Co + k) * 2 + (j & 1)] = q1[(size_t)j * Co + k];
+                            for (int co = 0; co < Co; co++) for (int j = 0; j < Cq; j++) p2[((size_t)j * (Co / 2) + (co >> 1)) * 2 + (co & 1)] = q2[(size_t)co * Cq + j];
+                            float *dw2 = nullptr, *dp1 = nullptr, *dp2 = nullptr;
+                            if (h->alloc(&dw2, w2.size()) || h->alloc(&dp1, p1.size()) || h->alloc(&dp2, p2.size())) FAIL(SGX_ERR_NOMEM);
+                            if (hipMemcpy(dw2, w2.data(), w2.size() * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dp1, p1.data(), p1.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                                hipMemcpy(dp2, p2.data(), p2.size() * 4, hipMemcpyHostToDevice) != hipSuccess) FAIL(SGX_ERR_DEVICE);
+                            fb.wd2 = dw2; fb.wq1p = dp1; fb.wq2p = dp2;
+                        }
+                        Op f; f.kind = OP_FUSED_BLOCK; f.in0 = a.in0; f.out = out_blob; f.fb = fb; f.fb_res_blob = res_blob;
+                        f.name = a.name + "+" + bq.name + "+" + c.name + "+" + d.name + "+" + e.name;
+                        f.inc = a.inc; f.outc = c.outc; f.H = a.H; f.W = a.W; f.Ho = bq.Ho; f.Wo = bq.Wo; f.k = bq.k; f.stride = bq.stride;
+                        ops[ai].dead = true; ops[bi].dead = true; ops[ci].dead = true; ops[di].dead = true; ops[ei] = f;      // the block takes the place of its LAST convolution in the plan
+                        continue;
+                    }
+                }
                 const bool head = c.hwc != 0;
                 const int kind_bit = head ? 8 : (ai < 0 ? 4 : (bq.stride == 2 ? 2 : 1));
                 if (!(irb_mask & kind_bit)) continue;
@@ -876,8 +913,8 @@ extern "C" int sgx_det_debug_op_desc(const sgx_det *h, int i, char *buf, int cap
         snprintf(buf, cap, "%s %s c%d->%d k%d s%d %s%dx%d->%dx%d epi%d%s", kn[o.kind], o.name.c_str(), o.inc, o.outc, o.k, o.stride, o.depthwise ? "dw " : "", o.H, o.W,
                  o.kind == OP_PW ? o.H : o.Ho, o.kind == OP_PW ? o.W : o.Wo, (int)o.epi.size() + (o.act ? 1 : 0), o.hwc ? " hwc" : "");
     else if (o.kind == OP_FUSED_BLOCK)
-        snprintf(buf, cap, "block %s c%d->%d->%d k%d s%d %dx%d->%dx%d tile %dx%d%s", o.name.c_str(), o.fb.Cin, o.fb.Cmid, o.fb.Cout, o.fb.K, o.fb.stride, o.H, o.W, o.Ho, o.Wo, o.fb.TOH, o.fb.TOW,
-                 o.fb_res_blob >= 0 ? " +res" : "");
+        snprintf(buf, cap, "block %s c%d->%d->%d k%d s%d %dx%d->%dx%d tile %dx%d%s%s", o.name.c_str(), o.fb.Cin, o.fb.Cmid, o.fb.Cout, o.fb.K, o.fb.stride, o.H, o.W, o.Ho, o.Wo, o.fb.TOH, o.fb.TOW,
+                 o.fb.Cq ? " se" : "", o.fb_res_blob >= 0 ? " +res" : "");
     else if (o.kind == OP_IRB)
         snprintf(buf, cap, "irb %s c%d->%d->%d q%d k%d s%d %dx%d->%dx%d G%d bands%d buf%d%s%s%s", o.name.c_str(), o.irb.Cin, o.irb.Cexp, o.irb.Cout, o.irb.Cq, o.irb.K, o.irb.S, o.H, o.W, o.Ho, o.Wo,
                  o.irb.G, o.irb.nbands, o.irb.nbuf, o.irb.has_expand ? "" : " noexp", o.irb_res_blob >= 0 ? " +res" : "", o.hwc ? (o.irb.Cout2 ? " hwc dual" : " hwc") : "");

@@ -23,7 +23,12 @@ struct SgxFusedBlk {
     int v2;                                                    // != 0: k_fused_block2 instantiation (VALU-only, high-resolution blocks), tile variant in the low bits
     const float *w2t; int ldw2;                                // project weights transposed [Cmid][ldw2] (the pointwise kernel's copy)
     const float *wd2;                                          // depthwise weights, channel pairs interleaved [Cmid / 2][K * K][2]
+    // squeeze-excite tail (k_fused_block2 only, Cq != 0): gate = clip(bq2 + Wq2 x clip(bq1 + Wq1 x y, qlo, qhi) + gc1, glo, ghi) / gc2, output = gate * y [+ residual]
+    int Cq; float qlo, qhi, gc1, glo, ghi, gc2;
+    const float *wq1, *bq1, *wq2, *bq2;                        // original layouts: wq1 [Cq][Cout], wq2 [Cout][Cq]
+    const float *wq1p, *wq2p;                                  // pair-interleaved copies: wq1p [Cq / 2][Cout][2] = (wq1[2j][k], wq1[2j + 1][k]), wq2p [Cq][Cout / 2][2] = (wq2[2c][j], wq2[2c + 1][j])
 };
+struct SgxFb2Se { const float *wq1p, *bq1, *wq2p, *bq2; float qlo, qhi, gc1, glo, ghi, gc2; };
 #define SGX_FB_CM 32                                           /* expanded channels per chunk = one MFMA row block */
 static inline size_t sgx_fb_lds_floats(const SgxFusedBlk &p)
 {
@@ -235,6 +240,11 @@ SGX_KERNEL(256) k_fused_block(SgxFusedBlk p)
 // For stride 2 the E tile is stored with its columns split by parity, so the 16 lanes of an output row read consecutive words for every tap.
 // ---------------------------------------------------------------------------------------------
 #define SGX_FB2_THREADS 128
+#ifndef SGX_EMU
+#define SGX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SGX_SCHED_FENCE() do { } while (0)
+#endif
 // Two fp32 lanes of one v_pk_fma_f32: a wave64 v_fma_f32 occupies the SIMD for 4 cycles, the packed form does two FMAs in the same slot (that is how gfx950 reaches its
 // 157 TFLOP/s fp32 vector peak).  Each half is an ordinary fused multiply-add, so results equal the scalar chain bit for bit.  The weights stay in SCALAR registers:
 // gfx950 reads an SGPR pair as a packed source with full pair and op_sel semantics (checked on hardware, tools/ubench/pk_fma_sgpr.hip); the compiler never emits that form
@@ -271,11 +281,19 @@ template <int CIN, int COUT, int K, int S, int TOH, int TOW, int CM> struct SgxF
 
 // wd2: depthwise weights with the two channels of a pair interleaved, [Cmid / 2][K * K][2] (built once per plan, sgx_det.cpp)
 // RES: 0 = no residual operand, 1 = fetched before the chunk loop (hides its latency, costs COUT registers), 2 = fetched before the store; UA: 2 = phase A on channel pairs (8-byte LDS stores), 1 = one channel per step, 3 = one channel per step unrolled by two
-template <int CIN, int COUT, int K, int S, int TOH, int TOW, int CM, int RES, int UA>
+// NQ: channels of the squeeze-excite tail behind the project convolution (0 = none).  The block's output pixel has all COUT channels in one thread's accumulators, and this
+// network's squeeze-excite has no pooling (1 x 1 convolutions on the feature map itself), so the tail is two small matrix-vector products per thread on wave-uniform weights:
+// the same fmaf chains, k ascending from the bias, as the pointwise kernels of the per-layer plan.
+// PIPE = 1: software-pipelined weight fetch.  The weights of a step are scalar loads (SMEM returns out of order, so the only wait is "all of them"), and a block with 40 output
+// channels and a 5 x 5 depthwise needs 130 weight registers per channel pair — more than the scalar file holds, the compiler then parks them in VGPR lanes (v_writelane /
+// v_readlane: 108 extra VALU instructions around 65 FMAs, measured).  With PIPE the loop body is cut into regions by scheduling fences; every region first issues the loads the
+// NEXT region needs and then computes on registers loaded one region earlier, so at most one region's weights plus the next one's are live and the load latency sits behind
+// a region's FMAs.
+template <int CIN, int COUT, int K, int S, int TOH, int TOW, int CM, int RES, int UA, int NQ = 0, int PIPE = 0>
 SGX_KERNEL(SGX_FB2_THREADS) k_fused_block2(int Cmid, int H, int W, int Ho, int Wo, int pad, int tiles_x, int tiles_y, float lo1, float hi1, float lo2, float hi2,
                                            const float *__restrict__ in, size_t in_pitch, const float *__restrict__ w1, const float *__restrict__ b1,
                                            const float *__restrict__ wd2, const float *__restrict__ bd, const float *__restrict__ w2t, int ldw2, const float *__restrict__ b2,
-                                           float *__restrict__ out, size_t out_pitch, const float *__restrict__ res, size_t res_pitch)
+                                           float *__restrict__ out, size_t out_pitch, const float *__restrict__ res, size_t res_pitch, SgxFb2Se se)
 {
     typedef SgxFb2Geom<CIN, COUT, K, S, TOH, TOW, CM> G;
     constexpr int UNR_A = UA == 3 ? 2 : 1;
@@ -329,7 +347,59 @@ SGX_KERNEL(SGX_FB2_THREADS) k_fused_block2(int Cmid, int H, int W, int Ho, int W
     for (int cm0 = 0; cm0 < Cmid; cm0 += CM) {
         // ---- phase A: expand this chunk for the thread's input pixels: two pixels per packed FMA (the weight broadcast to both halves), two expanded channels per step so
         //      that a pixel's pair (E[m], E[m + 1]) leaves as one 8-byte LDS store into the pair-interleaved tile
-        if (UA == 2) {
+        if (PIPE) {
+        SGX_THREADS_BEGIN(tid)
+        SGX_PRIV_BIND(x2, tid); SGX_PRIV_BIND(x1, tid); SGX_PRIV_BIND(eidx, tid);
+        float *Ef = (float *)Es;
+        sgx_f2 wk[CIN / 2], wn[CIN / 2]; float bias, biasn;
+        {
+            const sgx_f2 *wr = (const sgx_f2 *)(w1 + (size_t)cm0 * CIN);
+#pragma unroll
+            for (int k = 0; k < CIN / 2; k++) wk[k] = wr[k];
+            bias = b1[cm0];
+        }
+#pragma unroll 1
+        for (int m = 0; m < CM; m++) {
+            {   // the next channel's weights (the last step reloads its own: harmless)
+                const int mn = cm0 + (m + 1 < CM ? m + 1 : m);
+                const sgx_f2 *wr = (const sgx_f2 *)(w1 + (size_t)mn * CIN);
+#pragma unroll
+                for (int k = 0; k < CIN / 2; k++) wn[k] = wr[k];
+                biasn = b1[mn];
+            }
+            SGX_SCHED_FENCE();
+            float *Em = Ef + (size_t)(m >> 1) * G::ES * 2 + (m & 1);
+            sgx_f2 sp[G::PAIRS_IN ? G::PAIRS_IN : 1];
+#pragma unroll
+            for (int jp = 0; jp < G::PAIRS_IN; jp++) sp[jp] = sgx_mk2(bias, bias);
+            float s1 = bias;
+#pragma unroll
+            for (int k = 0; k < CIN / 2; k++) {
+#pragma unroll
+                for (int jp = 0; jp < G::PAIRS_IN; jp++) sp[jp] = sgx_fma2_wlo(wk[k], x2[jp * CIN + 2 * k], sp[jp]);
+                if (G::ODD_IN) s1 = fmaf(wk[k].x, x1[2 * k], s1);
+#pragma unroll
+                for (int jp = 0; jp < G::PAIRS_IN; jp++) sp[jp] = sgx_fma2_whi(wk[k], x2[jp * CIN + 2 * k + 1], sp[jp]);
+                if (G::ODD_IN) s1 = fmaf(wk[k].y, x1[2 * k + 1], s1);
+            }
+#pragma unroll
+            for (int jp = 0; jp < G::PAIRS_IN; jp++) {
+                const sgx_f2 sv = sp[jp];
+                const int e0 = eidx[2 * jp], e1 = eidx[2 * jp + 1];
+                if (e0 >= 0) Em[(e0 & 0xFFFFFF) * 2] = (e0 & (1 << 30)) ? 0.f : fminf(fmaxf(sv.x, lo1), hi1);
+                if (e1 >= 0) Em[(e1 & 0xFFFFFF) * 2] = (e1 & (1 << 30)) ? 0.f : fminf(fmaxf(sv.y, lo1), hi1);
+            }
+            if (G::ODD_IN) {
+                const int e = eidx[G::SLOTS_IN - 1];
+                if (e >= 0) Em[(e & 0xFFFFFF) * 2] = (e & (1 << 30)) ? 0.f : fminf(fmaxf(s1, lo1), hi1);
+            }
+            SGX_SCHED_FENCE();
+#pragma unroll
+            for (int k = 0; k < CIN / 2; k++) wk[k] = wn[k];
+            bias = biasn;
+        }
+        SGX_THREADS_END
+        } else if (UA == 2) {
         SGX_THREADS_BEGIN(tid)
         SGX_PRIV_BIND(x2, tid); SGX_PRIV_BIND(x1, tid); SGX_PRIV_BIND(eidx, tid);
 #pragma unroll 1
@@ -406,6 +476,67 @@ SGX_KERNEL(SGX_FB2_THREADS) k_fused_block2(int Cmid, int H, int W, int Ho, int W
         }
         SGX_SYNC();
         // ---- phases B + C: depthwise on two channels of the chunk at a time, then the project accumulation; one output pixel per thread and slot
+        if (PIPE) {
+        SGX_THREADS_BEGIN(tid)
+        SGX_PRIV_BIND(acc, tid);
+        sgx_f2 wk[K * K], bias;
+        {
+            const sgx_f2 *wt = (const sgx_f2 *)(wd2 + (size_t)cm0 * (K * K));
+#pragma unroll
+            for (int t = 0; t < K * K; t++) wk[t] = wt[t];
+            bias = sgx_mk2(bd[cm0], bd[cm0 + 1]);
+        }
+#pragma unroll 1
+        for (int m = 0; m < CM; m += 2) {
+            sgx_f2 wc0[COUT / 2], wc1[COUT / 2], d[G::SLOTS_OUT];
+            {   // region 1: fetch the project weights of channel m, run the depthwise taps of the pair
+                const sgx_f2 *wp0 = (const sgx_f2 *)(w2t + (size_t)(cm0 + m) * ldw2);
+#pragma unroll
+                for (int cp = 0; cp < COUT / 2; cp++) wc0[cp] = wp0[cp];
+            }
+            SGX_SCHED_FENCE();
+#pragma unroll
+            for (int jo = 0; jo < G::SLOTS_OUT; jo++) {
+                const int o = min(tid + SGX_FB2_THREADS * jo, G::NPO - 1), oy = o / TOW, ox = o - oy * TOW;
+                const sgx_f2 *e = Es + (size_t)(m >> 1) * G::ES + (oy * S) * G::TIWP + (S == 2 ? ox : ox * S);
+                sgx_f2 sv = bias;
+#pragma unroll
+                for (int a = 0; a < K; a++) {
+#pragma unroll
+                    for (int c = 0; c < K; c++) sv = sgx_fma2_w(wk[a * K + c], e[a * G::TIWP + (S == 2 ? (c & 1) * G::HALF + (c >> 1) : c)], sv);
+                }
+                d[jo] = sgx_mk2(fminf(fmaxf(sv.x, lo2), hi2), fminf(fmaxf(sv.y, lo2), hi2));
+            }
+            SGX_SCHED_FENCE();
+            {   // region 2: fetch the project weights of channel m + 1, accumulate channel m
+                const sgx_f2 *wp1 = (const sgx_f2 *)(w2t + (size_t)(cm0 + m + 1) * ldw2);
+#pragma unroll
+                for (int cp = 0; cp < COUT / 2; cp++) wc1[cp] = wp1[cp];
+            }
+            SGX_SCHED_FENCE();
+#pragma unroll
+            for (int jo = 0; jo < G::SLOTS_OUT; jo++) {
+#pragma unroll
+                for (int cp = 0; cp < COUT / 2; cp++) acc[jo * (COUT / 2) + cp] = sgx_fma2_w_dlo(wc0[cp], d[jo], acc[jo * (COUT / 2) + cp]);
+            }
+            SGX_SCHED_FENCE();
+            {   // region 3: fetch the depthwise weights of the next pair (the last step reloads its own), accumulate channel m + 1
+                const int mn = cm0 + (m + 2 < CM ? m + 2 : m);
+                const sgx_f2 *wt = (const sgx_f2 *)(wd2 + (size_t)mn * (K * K));
+#pragma unroll
+                for (int t = 0; t < K * K; t++) wk[t] = wt[t];
+                bias = sgx_mk2(bd[mn], bd[mn + 1]);
+            }
+            SGX_SCHED_FENCE();
+#pragma unroll
+            for (int jo = 0; jo < G::SLOTS_OUT; jo++) {
+#pragma unroll
+                for (int cp = 0; cp < COUT / 2; cp++) acc[jo * (COUT / 2) + cp] = sgx_fma2_w_dhi(wc1[cp], d[jo], acc[jo * (COUT / 2) + cp]);
+            }
+            SGX_SCHED_FENCE();
+        }
+        SGX_THREADS_END
+        } else {
         SGX_THREADS_BEGIN(tid)
         SGX_PRIV_BIND(acc, tid);
 #pragma unroll 1
@@ -436,6 +567,7 @@ SGX_KERNEL(SGX_FB2_THREADS) k_fused_block2(int Cmid, int H, int W, int Ho, int W
             }
         }
         SGX_THREADS_END
+        }
         SGX_SYNC();
     }
 
@@ -446,6 +578,37 @@ SGX_KERNEL(SGX_FB2_THREADS) k_fused_block2(int Cmid, int H, int W, int Ho, int W
 #pragma unroll
     for (int jo = 0; jo < G::SLOTS_OUT; jo++) {
         const int o = tid + SGX_FB2_THREADS * jo, oy = o / TOW, ox = o - oy * TOW, gy = oy0 + oy, gx = ox0 + ox;
+        if (NQ > 0) {                                                // squeeze-excite gate on the thread's pixel (all threads: no divergence around the scalar weight loads)
+            static_assert((NQ & 1) == 0, "squeeze channels are processed in pairs");
+            const sgx_f2 *wq1 = (const sgx_f2 *)se.wq1p, *wq2 = (const sgx_f2 *)se.wq2p;
+            sgx_f2 hid[NQ / 2 ? NQ / 2 : 1];
+#pragma unroll
+            for (int jp = 0; jp < NQ / 2; jp++) hid[jp] = sgx_mk2(se.bq1[2 * jp], se.bq1[2 * jp + 1]);
+#pragma unroll
+            for (int cp = 0; cp < COUT / 2; cp++) {                  // k = 2 cp, 2 cp + 1 ascending; two hidden channels per packed FMA
+#pragma unroll
+                for (int jp = 0; jp < NQ / 2; jp++) hid[jp] = sgx_fma2_w_dlo(wq1[jp * COUT + 2 * cp], acc[jo * (COUT / 2) + cp], hid[jp]);
+#pragma unroll
+                for (int jp = 0; jp < NQ / 2; jp++) hid[jp] = sgx_fma2_w_dhi(wq1[jp * COUT + 2 * cp + 1], acc[jo * (COUT / 2) + cp], hid[jp]);
+            }
+#pragma unroll
+            for (int jp = 0; jp < NQ / 2; jp++) hid[jp] = sgx_mk2(fminf(fmaxf(hid[jp].x, se.qlo), se.qhi), fminf(fmaxf(hid[jp].y, se.qlo), se.qhi));
+            sgx_f2 gt[COUT / 2];
+#pragma unroll
+            for (int cp = 0; cp < COUT / 2; cp++) gt[cp] = sgx_mk2(se.bq2[2 * cp], se.bq2[2 * cp + 1]);
+#pragma unroll
+            for (int j = 0; j < NQ; j++) {
+#pragma unroll
+                for (int cp = 0; cp < COUT / 2; cp++) gt[cp] = (j & 1) ? sgx_fma2_w_dhi(wq2[j * (COUT / 2) + cp], hid[j >> 1], gt[cp]) : sgx_fma2_w_dlo(wq2[j * (COUT / 2) + cp], hid[j >> 1], gt[cp]);
+            }
+#pragma unroll
+            for (int cp = 0; cp < COUT / 2; cp++) {                  // [ADD c][CLIP][DIV c][MUL project output], as sgx_epi_mode<SGX_EMODE_GATE>
+                float ux = gt[cp].x + se.gc1, uy = gt[cp].y + se.gc1;
+                ux = fminf(fmaxf(ux, se.glo), se.ghi); uy = fminf(fmaxf(uy, se.glo), se.ghi);
+                ux = ux / se.gc2; uy = uy / se.gc2;
+                acc[jo * (COUT / 2) + cp] = sgx_mk2(ux * acc[jo * (COUT / 2) + cp].x, uy * acc[jo * (COUT / 2) + cp].y);
+            }
+        }
         if (o < G::NPO && gy < Ho && gx < Wo) {
             const size_t off0 = (size_t)gy * Wo + gx;
             float v[COUT];
@@ -472,8 +635,14 @@ SGX_KERNEL(SGX_FB2_THREADS) k_fused_block2(int Cmid, int H, int W, int Ho, int W
 
 // ---- k_fused_block2 dispatch: (Cin, Cout, K, stride) -> instantiation; the tile variant comes from SGX_FB2_TILE (tuning tap) --------------------------------------
 static inline int sgx_fb2_cm(int v2) { return (v2 >> 4) == 1 ? 16 : 8; }       /* expanded channels per chunk of the instantiation (Cmid must be a multiple) */
-static inline int sgx_fb2_variant(int cin, int cout, int k, int stride)
+static inline int sgx_fb2_variant(int cin, int cout, int k, int stride, int cq = 0)
 {
+    if (cq) {                                                                   // block with a squeeze-excite tail: 24 -> 72 -> 40 (5 x 5, stride 2, 75 -> 38): 0.86 -> 0.75 ms per 512 frames.
+        // The two 40 -> 120 -> 40 blocks at 38 x 38 were measured too (8 x 16 tiles): 0.67 ms against 0.61 for the five per-layer kernels — 40 input channels leave one pixel
+        // pair per thread (a single dependent FMA chain in phase A) and the 5 x 5 halo doubles the expand work; they stay on the per-layer plan.
+        if (cin == 24 && cout == 40 && k == 5 && stride == 2 && cq == 10) return 4 * 16;
+        return 0;
+    }
     static const int tile_env = getenv("SGX_FB2_TILE") ? atoi(getenv("SGX_FB2_TILE")) : -1;          // tuning tap: force 8 x 16 (0) or 16 x 16 (1) output tiles on the stride-1 blocks
     int shape = 0;
     if (cin == 16 && cout == 16 && k == 3 && stride == 1) shape = 1;
@@ -483,21 +652,30 @@ static inline int sgx_fb2_variant(int cin, int cout, int k, int stride)
     const int tile = tile_env >= 0 ? tile_env : (shape == 1 ? 1 : 0);           // measured at 512 frames: 16 -> 16 -> 16 at 150 x 150 is best with 16 x 16 tiles (0.76 ms against 0.79), 24 -> 72 -> 24 with 8 x 16 (0.61 against 0.68)
     return shape * 16 + ((shape == 2) ? 0 : (tile & 1));                       // stride 1: tile 0 = 8 x 16, tile 1 = 16 x 16; stride 2: 8 x 16 only (input pixels live in registers)
 }
-static inline void sgx_fb2_tile(int v2, int *toh, int *tow) { *toh = (v2 >> 4) == 2 ? 7 : (v2 & 1) ? 16 : 8; *tow = 16; }       // stride 2: 7 x 16 outputs = 15 x 33 inputs = 4 full slots
+static inline void sgx_fb2_tile(int v2, int *toh, int *tow)
+{
+    *tow = 16;
+    if ((v2 >> 4) == 4) { *toh = 4; *tow = 19; return; }        // 38 = 2 x 19 columns: 20 tiles per image; measured 0.67 ms against 0.75 (5 x 16) and 0.72 (6 x 13)
+    *toh = (v2 >> 4) == 2 ? 7 : (v2 & 1) ? 16 : 8;
+}       // stride 2: 7 x 16 outputs = 15 x 33 inputs = 4 full slots
 static inline int sgx_fb2_launch(const SgxFusedBlk &fb, int batch, sgx_stream_t st)
 {
     const unsigned grid = (unsigned)(fb.tiles_x * fb.tiles_y * batch);
-#define SGX_FB2(CIN_, COUT_, K_, S_, TOH_, TOW_, CM_, RES_, UA_) do { auto kfn = fb.res ? k_fused_block2<CIN_, COUT_, K_, S_, TOH_, TOW_, CM_, RES_, UA_> : k_fused_block2<CIN_, COUT_, K_, S_, TOH_, TOW_, CM_, 0, UA_>;                                        \
+    SgxFb2Se se; se.wq1p = fb.wq1p; se.bq1 = fb.bq1; se.wq2p = fb.wq2p; se.bq2 = fb.bq2; se.qlo = fb.qlo; se.qhi = fb.qhi; se.gc1 = fb.gc1; se.glo = fb.glo; se.ghi = fb.ghi; se.gc2 = fb.gc2;
+#define SGX_FB2Q(CIN_, COUT_, K_, S_, TOH_, TOW_, CM_, RES_, UA_, NQ_, PIPE_) do { auto kfn = fb.res ? k_fused_block2<CIN_, COUT_, K_, S_, TOH_, TOW_, CM_, RES_, UA_, NQ_, PIPE_> : k_fused_block2<CIN_, COUT_, K_, S_, TOH_, TOW_, CM_, 0, UA_, NQ_, PIPE_>;                                        \
         SGX_LAUNCH(kfn, dim3(grid), dim3(SGX_FB2_THREADS), st, fb.Cmid, fb.H, fb.W, fb.Ho, fb.Wo, fb.pad, fb.tiles_x, fb.tiles_y, fb.lo1, fb.hi1, fb.lo2, fb.hi2,     \
-                   fb.in, fb.in_pitch, fb.w1, fb.b1, fb.wd2, fb.bd, fb.w2t, fb.ldw2, fb.b2, fb.out, fb.out_pitch, fb.res, fb.res_pitch); } while (0)
-    switch (fb.v2) {
+                   fb.in, fb.in_pitch, fb.w1, fb.b1, fb.wd2, fb.bd, fb.w2t, fb.ldw2, fb.b2, fb.out, fb.out_pitch, fb.res, fb.res_pitch, se); } while (0)
+#define SGX_FB2(CIN_, COUT_, K_, S_, TOH_, TOW_, CM_, RES_, UA_) SGX_FB2Q(CIN_, COUT_, K_, S_, TOH_, TOW_, CM_, RES_, UA_, 0, 0)
+    switch (fb.v2) {                                                   // pipelined weight fetch (PIPE) measured on every shape: 24 -> 72 -> 40 gains (0.86 -> 0.74 ms), the three 3 x 3 shapes lose 0.04 - 0.08 ms
     case 16: SGX_FB2(16, 16, 3, 1, 8, 16, 16, 1, 3); break;           // Cmid = 16: one chunk
     case 17: SGX_FB2(16, 16, 3, 1, 16, 16, 16, 1, 3); break;
     case 32: SGX_FB2(16, 24, 3, 2, 7, 16, 8, 2, 2); break;           // phase A on channel pairs: 0.83 -> 0.70 ms (the other two shapes lose: 0.71 -> 0.76, 0.61 -> 0.72)
     case 48: SGX_FB2(24, 24, 3, 1, 8, 16, 8, 2, 1); break;
     case 49: SGX_FB2(24, 24, 3, 1, 16, 16, 8, 2, 1); break;
+    case 64: SGX_FB2Q(24, 40, 5, 2, 4, 19, 8, 2, 1, 10, 1); break;     // 4 x 19 outputs = 11 x 41 inputs = 4 slots of 128 threads
     default: return SGX_ERR_INVALID;
     }
 #undef SGX_FB2
+#undef SGX_FB2Q
     return SGX_OK;
 }
