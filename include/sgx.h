@@ -393,6 +393,7 @@ int sgx_local_bundle_adjustment(const sgx_ba_problem *problem, const sgx_camera 
  * landmark, one edge per observation in a keyframe of the problem; ONE optimizer.optimize(nIterations) with Huber kernels sqrt(5.99) / sqrt(7.815) when bRobust, no
  * outlier classification.  Out: every pose (the fixed one included, :200-214) and every point that has at least one edge (:216-236; the others are
  * vbNotIncludedMP) — the caller stores them with SetPose / SetWorldPos (nLoopKF == 0) or in mTcwGBA / mPosGBA.  stats: iterations_first, chi2_first. */
+int sgx_ba_debug_last_plan(int32_t plan[4]);    /* test tap: solver plan of the last bundle adjustment of this process: { 0 dense / 1 envelope, column steps of branch A, of branch B (0 = one branch), unknowns of their separator } */
 int sgx_ba_debug_set_solver(int mode);             /* test / tuning tap: reduced-camera-system solver of the bundle adjustments: -1 default (SGX_BA_SOLVER or auto), 0 auto, 1 dense blocked Cholesky, 2 envelope solver */
 int sgx_bundle_adjustment(const sgx_ba_problem *problem, const sgx_camera *cam, int n_iterations, const volatile int32_t *stop_flag, int robust, sgx_ba_stats *stats);
 

@@ -69,7 +69,7 @@ SYMBOLS = [
     'sgx_match_project_frame_batch_dev', 'sgx_match_project_frame', 'sgx_match_project_local_batch_dev', 'sgx_match_project_local',
     'sgx_frame_stereo_from_rgbd_batch_dev', 'sgx_frame_unproject_batch_dev', 'sgx_frame_make_map_points_batch_dev', 'sgx_frame_merge_matches_batch_dev',
     'sgx_pose_optimization_batch_dev', 'sgx_pose_opt_debug_set_threads', 'sgx_pose_optimization', 'sgx_frame_motion_model_batch_dev',
-    'sgx_local_bundle_adjustment', 'sgx_bundle_adjustment', 'sgx_ba_debug_set_solver',
+    'sgx_local_bundle_adjustment', 'sgx_bundle_adjustment', 'sgx_ba_debug_set_solver', 'sgx_ba_debug_last_plan',
     'sgx_det_create', 'sgx_det_destroy', 'sgx_det_info', 'sgx_det_detect', 'sgx_det_detect_batch_dev', 'sgx_det_forward_batch_dev', 'sgx_det_debug_read_blob', 'sgx_det_debug_detection_output',
     'sgx_frame_compact_keys_batch_dev', 'sgx_frame_gray_from_color_batch_dev', 'sgx_debug_flow_affine_batch_dev', 'sgx_det_debug_set_fusion', 'sgx_det_debug_set_legacy_kernels', 'sgx_det_debug_set_block_fusion', 'sgx_det_debug_set_irb', 'sgx_det_debug_time_ops', 'sgx_det_debug_op_desc',
     'sgx_dynamic_mask_batch_dev',
@@ -131,6 +131,7 @@ class SgxLib:
         d.sgx_frame_motion_model_batch_dev.argtypes = [C.c_int, vp, vp, vp, vp, vp]
         d.sgx_local_bundle_adjustment.argtypes = [C.POINTER(BaProblem), C.POINTER(Camera), vp, vp, C.POINTER(BaStats)]
         d.sgx_ba_debug_set_solver.argtypes = [C.c_int]
+        d.sgx_ba_debug_last_plan.argtypes = [C.c_void_p]
         d.sgx_bundle_adjustment.argtypes = [C.POINTER(BaProblem), C.POINTER(Camera), C.c_int, vp, C.c_int, C.POINTER(BaStats)]
         d.sgx_det_create.argtypes = [C.c_char_p, vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.POINTER(vp)]
         d.sgx_det_destroy.argtypes = [vp]; d.sgx_det_destroy.restype = None

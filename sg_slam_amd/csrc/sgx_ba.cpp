@@ -20,6 +20,7 @@
 #include <string.h>
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <mutex>
 #include <vector>
 
@@ -64,6 +65,8 @@ struct BA {
     double *part_chi, *part_scale;      // device scalars block: [ok | part_scale[nblk_v] | part_chi[nblk_e]] read back with ONE copy per trial
     int nblk_e, nblk_v;
     int *env_rstart, *env_rows;          // narrow-envelope solver: rows of column step k = env_rows[env_rstart[k] .. env_rstart[k+1]) (NULL: dense solver)
+    int env_nA, env_nB;                  // two-branch elimination: column steps [0, nA) and [nA, nA + nB) are independent, the rest is their separator (nB = 0: one branch)
+    double *env_S2, *env_x2;             // the second branch's contributions to the separator (nsep x nsep, nsep)
     std::vector<double> hpart;
 };
 
@@ -101,30 +104,44 @@ static int read_trial(BA &B, int *ok, double *scale, double *chi)
     return SGX_OK;
 }
 
-// Schur job list for the current active edge set: all ordered pairs (k1, k2) of active free-pose edges of one landmark
-static int build_jobs(BA &B, const std::vector<int> &pt_start, const std::vector<int> &pt_edges, const std::vector<SgxBaEdge> &E,
-                      const std::vector<uint8_t> &level1, const std::vector<int> &hidx)
+// Schur job list for the current active edge set: all ordered pairs (k1, k2) of active free-pose edges of one landmark, grouped by destination block (i1, i2) of the reduced
+// system; inside a block the jobs are in landmark order, the order in which the reference subtracts them (block_solver.hpp:380-433); k_ba_schur_pairs then sums every block
+// sequentially, without atomics.  Built block row by block row: the jobs of row i1 come from the edges of that pose (pose_edges_l: ascending landmark) x the active edges of
+// their landmarks, and are dealt to their i2 with a counting sort over the few poses the row touches — everything a row needs sits in L1 / L2 (a sort of the whole list by
+// the nf^2 keys was 30 ms per call at 2 000 keyframes: a third of the bundle adjustment).
+static int build_jobs(BA &B, const std::vector<int> &pt_start, const std::vector<int> &pt_edges, const std::vector<int> &pose_start, const std::vector<int> &pose_edges_l,
+                      const std::vector<SgxBaEdge> &E, const std::vector<uint8_t> &level1, const std::vector<int> &hidx, const std::vector<int> &free_pose)
 {
-    std::vector<SgxBaJob> jobs;
-    std::vector<int> act;
-    for (int l = 0; l < B.nl; l++) {
-        act.clear();
-        for (int q = pt_start[l]; q < pt_start[l + 1]; q++) { const int k = pt_edges[q]; if (!level1[k] && hidx[E[k].pose] >= 0) act.push_back(k); }
-        for (int k1 : act) for (int k2 : act) jobs.push_back(SgxBaJob{k1, k2});
+    static thread_local std::vector<SgxBaJob> sorted, grp;
+    static thread_local std::vector<int> blk_start, grp_h2, touched, cnt, eh;
+    sorted.clear(); blk_start.clear();
+    eh.resize(B.ne);
+    for (int k = 0; k < B.ne; k++) eh[k] = level1[k] ? -1 : hidx[E[k].pose];                    // destination row / column of an active edge, -1 = not in the system
+    cnt.assign(B.nf > 0 ? B.nf : 1, 0);
+    for (int h1 = 0; h1 < B.nf; h1++) {
+        const int p = free_pose[h1];
+        grp.clear(); grp_h2.clear(); touched.clear();
+        for (int q = pose_start[p]; q < pose_start[p + 1]; q++) {
+            const int k1 = pose_edges_l[q]; if (eh[k1] < 0) continue;
+            const int l = E[k1].point;
+            for (int q2 = pt_start[l]; q2 < pt_start[l + 1]; q2++) {
+                const int k2 = pt_edges[q2], h2 = eh[k2]; if (h2 < 0) continue;
+                if (cnt[h2]++ == 0) touched.push_back(h2);
+                grp.push_back(SgxBaJob{k1, k2}); grp_h2.push_back(h2);
+            }
+        }
+        if (grp.empty()) continue;
+        if (sorted.size() + grp.size() > B.jobs_cap) { for (int h2 : touched) cnt[h2] = 0; return SGX_ERR_NOMEM; }
+        std::sort(touched.begin(), touched.end());
+        const size_t base = sorted.size();
+        { int run = 0; for (int h2 : touched) { const int c = cnt[h2]; cnt[h2] = run; blk_start.push_back((int)base + run); run += c; } }
+        sorted.resize(base + grp.size());
+        for (size_t i = 0; i < grp.size(); i++) sorted[base + (size_t)cnt[grp_h2[i]]++] = grp[i];
+        for (int h2 : touched) cnt[h2] = 0;
     }
-    B.njobs = (long long)jobs.size(); B.nblk = 0;
-    if (jobs.size() > B.jobs_cap) return SGX_ERR_NOMEM;
-    if (jobs.empty()) return SGX_OK;
-    // stable counting sort by destination block (i1, i2) of the reduced system: inside a block the jobs keep landmark order, the order in which the reference
-    // subtracts them (block_solver.hpp:380-433); k_ba_schur_pairs then sums every block sequentially, without atomics
-    const size_t nkeys = (size_t)B.nf * B.nf;
-    std::vector<int> count(nkeys + 1, 0);
-    auto key = [&](const SgxBaJob &j) { return (size_t)hidx[E[j.k1].pose] * B.nf + hidx[E[j.k2].pose]; };
-    for (const SgxBaJob &j : jobs) count[key(j) + 1]++;
-    std::vector<int> blk_start; blk_start.reserve(jobs.size() + 1);
-    { int run = 0; for (size_t k = 0; k < nkeys; k++) { const int c = count[k + 1]; count[k] = run; if (c) blk_start.push_back(run); run += c; } blk_start.push_back(run); }
-    std::vector<SgxBaJob> sorted(jobs.size());
-    for (const SgxBaJob &j : jobs) sorted[(size_t)count[key(j)]++] = j;
+    B.njobs = (long long)sorted.size(); B.nblk = 0;
+    if (sorted.empty()) return SGX_OK;
+    blk_start.push_back((int)sorted.size());
     B.nblk = (long long)blk_start.size() - 1;
     SGX_CHECK_HIP(hipMemcpy(B.jobs, sorted.data(), sizeof(SgxBaJob) * sorted.size(), hipMemcpyHostToDevice));
     SGX_CHECK_HIP(hipMemcpy(B.blk_start, blk_start.data(), sizeof(int) * blk_start.size(), hipMemcpyHostToDevice));
@@ -134,15 +151,24 @@ static int build_jobs(BA &B, const std::vector<int> &pt_start, const std::vector
 // Dense symmetric positive definite solve  S x = bp - coef  on the device (in place: S is overwritten by its factor): register / LDS kernels for small systems, the blocked
 // right-looking Cholesky with the fp64-MFMA trailing update above SGX_CHOL_SMALL unknowns.  *ok (device) is cleared when a pivot is not positive; x then keeps its previous
 // content.  *xout = where the solution was left (xp or xsol).  Shared by the bundle adjustments (reduced camera system) and the essential-graph optimisation.
-struct Chol { int NP; double *S, *Linv, *bp, *coef, *xp, *xsol; int *ok; const int *env_rstart = nullptr, *env_rows = nullptr; };      // env_*: column-step row lists of a narrow envelope (NULL = dense)
+struct Chol { int NP; double *S, *Linv, *bp, *coef, *xp, *xsol; int *ok; const int *env_rstart = nullptr, *env_rows = nullptr; int env_nA = 0, env_nB = 0; double *env_S2 = nullptr, *env_x2 = nullptr; };      // env_*: column-step row lists of a narrow envelope (NULL = dense)
 static int chol_factor_solve(const Chol &C, const double **xout)
 {
     *xout = C.xp;
     if (C.env_rstart && C.NP > 0) {                      // sparse covisibility: the whole factorisation + forward substitution as one persistent workgroup, then the backward pass
         const int nt = (C.NP + SGX_NB - 1) / SGX_NB;
         static const int env_dbg = getenv("SGX_ENV_DBG") ? atoi(getenv("SGX_ENV_DBG")) : 0;      // timing tap: 1 skip the diagonal tiles, 2 skip panel + update, 4 skip the update
-        SGX_LAUNCH(k_chol_env_factor, dim3(1), dim3(SGX_ENV_THREADS), (sgx_stream_t)0, C.NP, nt, C.env_rstart, C.env_rows, C.S, C.Linv, C.ok, C.bp, C.coef, C.xp, env_dbg);
-        SGX_LAUNCH(k_chol_env_back, dim3(1), dim3(1024), (sgx_stream_t)0, C.NP, nt, C.env_rstart, C.env_rows, C.S, C.Linv, C.xp, C.xsol, C.ok);
+        const int nA = C.env_nB > 0 ? C.env_nA : nt, nB = C.env_nB > 0 ? C.env_nB : 0;
+        if (nB > 0) {                                    // the second branch's separator contributions start from zero
+            const size_t ns = (size_t)(C.NP - (nA + nB) * SGX_NB);
+            SGX_CHECK_HIP(hipMemsetAsync(C.env_S2, 0, sizeof(double) * (ns * ns + ns), 0));      // x2 follows S2 in the arena
+        }
+        SGX_LAUNCH(k_chol_env_factor, dim3(nB > 0 ? 2 : 1), dim3(SGX_ENV_THREADS), (sgx_stream_t)0, C.NP, nt, C.env_rstart, C.env_rows, C.S, C.Linv, C.ok, C.bp, C.coef, C.xp, env_dbg, 0, nA, nB, C.env_S2, C.env_x2);
+        if (nA + nB < nt) {
+            SGX_LAUNCH(k_chol_env_factor, dim3(1), dim3(SGX_ENV_THREADS), (sgx_stream_t)0, C.NP, nt, C.env_rstart, C.env_rows, C.S, C.Linv, C.ok, C.bp, C.coef, C.xp, env_dbg, 1, nA, nB, C.env_S2, C.env_x2);
+            SGX_LAUNCH(k_chol_env_back, dim3(1), dim3(1024), (sgx_stream_t)0, C.NP, nt, C.env_rstart, C.env_rows, C.S, C.Linv, C.xp, C.xsol, C.ok, 0, nA, nB);
+        }
+        SGX_LAUNCH(k_chol_env_back, dim3(nB > 0 ? 2 : 1), dim3(1024), (sgx_stream_t)0, C.NP, nt, C.env_rstart, C.env_rows, C.S, C.Linv, C.xp, C.xsol, C.ok, 1, nA, nB);
         *xout = C.xsol;
         return SGX_OK;
     }
@@ -232,7 +258,7 @@ static int optimize(BA &B, int iterations, int *iters_done, double *final_chi)
             }
             sgx_prof_end(SGX_K_BA_SCHUR, (sgx_stream_t)0);
             sgx_prof_begin(SGX_K_BA_SOLVE, (sgx_stream_t)0);
-            { Chol C = { B.NP, B.S, B.Linv, B.bp, B.coef, B.xp, B.xsol, B.ok }; C.env_rstart = B.env_rstart; C.env_rows = B.env_rows; if ((rc = chol_factor_solve(C, &xsol)) != SGX_OK) return rc; }
+            { Chol C = { B.NP, B.S, B.Linv, B.bp, B.coef, B.xp, B.xsol, B.ok }; C.env_rstart = B.env_rstart; C.env_rows = B.env_rows; C.env_nA = B.env_nA; C.env_nB = B.env_nB; C.env_S2 = B.env_S2; C.env_x2 = B.env_x2; if ((rc = chol_factor_solve(C, &xsol)) != SGX_OK) return rc; }
             sgx_prof_end(SGX_K_BA_SOLVE, (sgx_stream_t)0);
             sgx_prof_begin(SGX_K_BA_UPDATE, (sgx_stream_t)0);
             // when the factorisation failed, xp/xl keep the previous solution (as g2o's _x does) and the step is rejected below
@@ -267,6 +293,8 @@ static int optimize(BA &B, int iterations, int *iters_done, double *final_chi)
 }
 }  // namespace
 
+static int g_ba_last_plan[4] = { 0, 0, 0, 0 };
+extern "C" int sgx_ba_debug_last_plan(int32_t plan[4]) { if (!plan) return SGX_ERR_INVALID; for (int i = 0; i < 4; i++) plan[i] = g_ba_last_plan[i]; return SGX_OK; }
 extern "C" int sgx_ba_debug_set_solver(int mode) { g_ba_solver = mode < 0 ? -1 : (mode > 2 ? 2 : mode); return SGX_OK; }
 
 // mode 0: Optimizer::LocalBundleAdjustment (Optimizer.cc:453-778); mode 1: Optimizer::BundleAdjustment (Optimizer.cc:49-237): one optimize(n_iterations) over
@@ -278,6 +306,10 @@ static int ba_run(const sgx_ba_problem *P, const sgx_camera *cam, const volatile
     // the device arena is one per process: calls from several threads (the reference has one LocalMapping thread, plus GlobalBundleAdjustment from LoopClosing) take turns
     static std::mutex arena_mutex;
     std::lock_guard<std::mutex> arena_lock(arena_mutex);
+    static const bool timing = getenv("SGX_BA_TIMING") != nullptr;          // tuning tap: wall-clock of the host phases on stderr
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tmark = now();
+    auto lap = [&](const char *what) { if (timing) { (void)hipDeviceSynchronize(); const double t = now(); fprintf(stderr, "[sgx_ba] %-22s %8.3f ms\n", what, t - tmark); tmark = t; } };
     BA B; memset((void *)&B, 0, offsetof(BA, hpart));
     B.np = P->n_poses; B.nl = P->n_points; B.ne = P->n_edges; B.stop = stop_flag;
     B.cam.fx = cam->fx; B.cam.fy = cam->fy; B.cam.cx = cam->cx; B.cam.cy = cam->cy; B.cam.bf = cam->bf;
@@ -304,6 +336,8 @@ static int ba_run(const sgx_ba_problem *P, const sgx_camera *cam, const volatile
     for (int p = 0; p < B.np; p++) pose_start[p + 1] += pose_start[p];
     { std::vector<int> f1(B.nl, 0), f2(B.np, 0);
       for (int k = 0; k < B.ne; k++) { pt_edges[pt_start[E[k].point] + f1[E[k].point]++] = k; pose_edges[pose_start[E[k].pose] + f2[E[k].pose]++] = k; } }
+    std::vector<int> pose_edges_l(pose_edges);                                     // the edges of a pose in ascending landmark order (ties: edge order) for the Schur job list
+    for (int p = 0; p < B.np; p++) std::sort(pose_edges_l.begin() + pose_start[p], pose_edges_l.begin() + pose_start[p + 1], [&](int x, int y) { return E[x].point != E[y].point ? E[x].point < E[y].point : x < y; });
     std::vector<double> Xd(3 * (size_t)B.nl);
     for (size_t i = 0; i < Xd.size(); i++) Xd[i] = (double)P->points[i];
     // upper bound of the Schur job list: sum over landmarks of (edges with a free pose)^2
@@ -314,6 +348,7 @@ static int ba_run(const sgx_ba_problem *P, const sgx_camera *cam, const volatile
     // the system are non-zero from the first tile column ft[r] on and fill stays inside that envelope; when it is narrow the solver walks it with one persistent workgroup
     // (k_chol_env_factor) instead of the dense blocked factorisation.  SGX_BA_SOLVER = dense | env | auto (default).
     std::vector<int> env_rstart, env_rows;
+    int env_nA = 0, env_nB = 0; size_t env_nsep = 0;
     {
         static const char *solver_env = getenv("SGX_BA_SOLVER");
         const int mode_env = !solver_env ? 0 : (strcmp(solver_env, "dense") == 0 ? 1 : (strcmp(solver_env, "env") == 0 ? 2 : 0));
@@ -321,6 +356,7 @@ static int ba_run(const sgx_ba_problem *P, const sgx_camera *cam, const volatile
         const bool want_env = smode != 1, force_env = smode == 2;
         const int nt = (B.NP + SGX_NB - 1) / SGX_NB;
         if (want_env && B.NP > (force_env ? 0 : 1024)) {
+            // free poses of every landmark (natural order = keyframe order), and the lowest pose each pose is coupled with
             std::vector<int> fblk(B.nf);
             for (int i = 0; i < B.nf; i++) fblk[i] = i;
             for (int l = 0; l < B.nl; l++) {
@@ -328,25 +364,72 @@ static int ba_run(const sgx_ba_problem *P, const sgx_camera *cam, const volatile
                 for (int q = pt_start[l]; q < pt_start[l + 1]; q++) { const int h = hidx[E[pt_edges[q]].pose]; if (h >= 0 && h < lo) lo = h; }
                 for (int q = pt_start[l]; q < pt_start[l + 1]; q++) { const int h = hidx[E[pt_edges[q]].pose]; if (h >= 0 && lo < fblk[h]) fblk[h] = lo; }
             }
-            std::vector<int> ft(nt);
-            for (int r = 0; r < nt; r++) {
-                int f = r;
-                for (int u = r * SGX_NB; u < std::min(B.NP, (r + 1) * SGX_NB); u += 1) f = std::min(f, 6 * fblk[u / 6] / SGX_NB);
-                ft[r] = f;
+            // Plan for an ordering pos[natural free-pose index] -> position: tile pattern of the reduced system from the landmarks' pose sets, symbolic tile Cholesky
+            // (the structure of column k is R(k); every pair of R(k) becomes a tile of the factor), narrowness test.  Returns false when a step has too many rows.
+            auto build = [&](const std::vector<int> &pos, std::vector<int> &rstart, std::vector<int> &rws) -> bool {
+                std::vector<uint8_t> pat((size_t)nt * nt, 0);
+                std::vector<int> tl;
+                for (int l = 0; l < B.nl; l++) {
+                    tl.clear();
+                    for (int q = pt_start[l]; q < pt_start[l + 1]; q++) {
+                        const int h = hidx[E[pt_edges[q]].pose]; if (h < 0) continue;
+                        const int u0 = 6 * pos[h], t0 = u0 / SGX_NB, t1 = (u0 + 5) / SGX_NB;
+                        tl.push_back(t0); if (t1 != t0) tl.push_back(t1);
+                    }
+                    for (size_t a = 0; a < tl.size(); a++) for (size_t b = 0; b < tl.size(); b++) if (tl[a] > tl[b]) pat[(size_t)tl[a] * nt + tl[b]] = 1;
+                }
+                // a pose that straddles two tiles couples them even without a landmark
+                for (int h = 0; h < B.nf; h++) { const int u0 = 6 * h, t0 = u0 / SGX_NB, t1 = (u0 + 5) / SGX_NB; if (t1 != t0) pat[(size_t)t1 * nt + t0] = 1; }
+                rstart.assign(nt + 1, 0); rws.clear();
+                std::vector<int> R;
+                size_t total = 0;
+                for (int k = 0; k < nt; k++) {
+                    R.clear();
+                    for (int r = k + 1; r < nt; r++) if (pat[(size_t)r * nt + k]) R.push_back(r);
+                    if ((int)R.size() > SGX_ENV_MAXM) return false;
+                    for (size_t a = 0; a < R.size(); a++) for (size_t b = 0; b < a; b++) pat[(size_t)R[a] * nt + R[b]] = 1;
+                    rws.insert(rws.end(), R.begin(), R.end());                                 // rows ascending inside a step
+                    rstart[k + 1] = (int)rws.size(); total += R.size();
+                }
+                if (rws.empty()) rws.push_back(0);
+                // narrow = a step's tile products fit a few rounds of the persistent workgroup's waves; otherwise the dense two-level path (matrix cores) wins
+                return force_env || total <= (size_t)nt * 10;
+            };
+            // Two-branch ordering: [poses 0 .. a) ascending][poses t0-1 .. bs DEScending][separator: the rest, natural order]: the band is eliminated from both ends at once.
+            // The separator must cut every coupling between the halves (no pose of [bs, t0) shares a landmark with a pose < a): it is the stretch [a, bs) behind the first
+            // half plus — when the trajectory closes on itself — the tail [t0, nf) that sees the start again.  Branch sizes are multiples of 16 poses = 3 tiles.
+            const int twist_env = getenv("SGX_BA_TWIST") ? atoi(getenv("SGX_BA_TWIST")) : 1;          // read per call (tests switch it)
+            bool done = false;
+            if (twist_env && nt >= 24) {
+                const int a = (B.nf / 2 / 16) * 16;
+                int bs = a; while (bs < B.nf && fblk[bs] < a) bs++;                     // behind the first half: coupled with it
+                int t0 = bs; while (t0 < B.nf && fblk[t0] >= a) t0++;                   // the independent stretch ends where the start is seen again
+                const int nb_poses = ((t0 - bs) / 16) * 16; bs = t0 - nb_poses;
+                if (a >= 16 && nb_poses >= 16) {
+                    std::vector<int> pos(B.nf);
+                    int sp = a + nb_poses;
+                    for (int h = 0; h < B.nf; h++) pos[h] = h < a ? h : ((h >= bs && h < t0) ? a + (t0 - 1 - h) : sp++);
+                    const int tA = 6 * a / SGX_NB, tB = 6 * nb_poses / SGX_NB;
+                    bool ok2 = build(pos, env_rstart, env_rows);
+                    // the two branches must not touch each other's tiles: no row of the second branch in a column step of the first (they run concurrently)
+                    for (int k = 0; ok2 && k < tA; k++) for (int q = env_rstart[k]; q < env_rstart[k + 1]; q++) if (env_rows[q] >= tA && env_rows[q] < tA + tB) { ok2 = false; break; }
+                    if (ok2) {
+                        done = true; env_nA = tA; env_nB = tB; env_nsep = (size_t)B.NP - (size_t)(env_nA + env_nB) * SGX_NB;
+                        // the order of the unknowns IS the order of the free poses: renumber them
+                        std::vector<int> fp2(B.nf);
+                        for (int h = 0; h < B.nf; h++) fp2[pos[h]] = free_pose[h];
+                        free_pose.swap(fp2);
+                        for (int h = 0; h < B.nf; h++) hidx[free_pose[h]] = h;
+                    }
+                }
             }
-            std::vector<int> cnt(nt + 1, 0);
-            size_t total = 0; for (int r = 0; r < nt; r++) { for (int k = ft[r]; k < r; k++) cnt[k + 1]++; total += (size_t)(r - ft[r]); }
-            int maxm = 0; for (int k = 0; k < nt; k++) maxm = std::max(maxm, cnt[k + 1]);
-            // narrow = a step's tile products fit a few rounds of the persistent workgroup's four groups; otherwise the dense two-level path (matrix cores) wins
-            if (maxm <= SGX_ENV_MAXM && (force_env || total <= (size_t)nt * 10)) {
-                env_rstart.assign(nt + 1, 0);
-                for (int k = 0; k < nt; k++) env_rstart[k + 1] = env_rstart[k] + cnt[k + 1];
-                env_rows.resize(total ? total : 1);
-                std::vector<int> fill(env_rstart.begin(), env_rstart.end() - 1);
-                for (int r = 0; r < nt; r++) for (int k = ft[r]; k < r; k++) env_rows[(size_t)fill[k]++] = r;      // rows ascending inside a step
+            if (!done) {
+                std::vector<int> pos(B.nf); for (int h = 0; h < B.nf; h++) pos[h] = h;
+                if (!build(pos, env_rstart, env_rows)) { env_rstart.clear(); env_rows.clear(); }
             }
         }
     }
+    lap("index + solver plan");
     // ---- device state: one arena; the host->device inputs are packed contiguously and uploaded with one copy
     float *dTcw = nullptr; uint8_t *dfixed = nullptr, *derase = nullptr;
     const int nv = B.np > B.nl ? B.np : B.nl;
@@ -366,7 +449,7 @@ static int ba_run(const sgx_ba_problem *P, const sgx_camera *cam, const volatile
         A.take(&B.bp, B.NP); A.take(&B.S, (size_t)B.NP * B.NP); A.take(&B.coef, B.NP); A.take(&B.xp, B.NP); A.take(&B.xsol, B.NP); A.take(&B.xl, 3 * (size_t)B.nl);
         A.take(&B.Dinv, 9 * (size_t)B.nl); A.take(&B.dwork, B.NP); A.take(&B.partial, B.nblk_v);
         { double *blk = nullptr; A.take(&blk, 1 + (size_t)B.nblk_v + B.nblk_e); B.ok = (int *)blk; B.part_scale = blk ? blk + 1 : nullptr; B.part_chi = blk ? blk + 1 + B.nblk_v : nullptr; }
-        A.take(&B.pt_active, B.nl); A.take(&derase, B.ne);
+        A.take(&B.pt_active, B.nl); A.take(&derase, B.ne); A.take(&B.env_S2, env_nsep * env_nsep + env_nsep + 1);
         A.take(&B.jobs, jobs_cap); A.take(&B.blk_start, jobs_cap + 1); A.take(&B.Linv, (size_t)((B.NP + SGX_NB - 1) / SGX_NB) * SGX_NB * SGX_NB);
         const size_t total = A.off;
         A.base = save;
@@ -386,6 +469,8 @@ static int ba_run(const sgx_ba_problem *P, const sgx_camera *cam, const volatile
         SGX_CHECK_HIP(hipMemcpy(base, stage.data(), in_bytes, hipMemcpyHostToDevice));
     }
     if (env_rstart.empty()) { B.env_rstart = nullptr; B.env_rows = nullptr; }
+    B.env_nA = env_nA; B.env_nB = env_nB; B.env_x2 = B.env_S2 + env_nsep * env_nsep;
+    g_ba_last_plan[0] = B.env_rstart ? 1 : 0; g_ba_last_plan[1] = env_nB > 0 ? env_nA : (B.env_rstart ? (B.NP + SGX_NB - 1) / SGX_NB : 0); g_ba_last_plan[2] = env_nB; g_ba_last_plan[3] = (int)env_nsep;
     SGX_CHECK_HIP(hipMemsetAsync(B.xp, 0, sizeof(double) * (B.NP ? B.NP : 1), 0));
     SGX_CHECK_HIP(hipMemsetAsync(B.xsol, 0, sizeof(double) * (B.NP ? B.NP : 1), 0));
     SGX_CHECK_HIP(hipMemsetAsync(B.xl, 0, sizeof(double) * 3 * (size_t)B.nl, 0));
@@ -393,19 +478,24 @@ static int ba_run(const sgx_ba_problem *P, const sgx_camera *cam, const volatile
     SGX_CHECK_HIP(hipMemsetAsync(B.Hpl, 0, sizeof(double) * 18 * (size_t)B.ne, 0));
     SGX_LAUNCH(k_ba_poses_in, dim3((B.np + SGX_BA_THREADS - 1) / SGX_BA_THREADS), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.np, dTcw, B.T);
 
+    lap("arena + upload");
     int it1 = 0, it2 = 0; double chi1 = 0, chi2 = 0;
     std::vector<uint8_t> level1(B.ne, 0);
-    rc = build_jobs(B, pt_start, pt_edges, E, level1, hidx); if (rc != SGX_OK) return rc;
+    rc = build_jobs(B, pt_start, pt_edges, pose_start, pose_edges_l, E, level1, hidx, free_pose); if (rc != SGX_OK) return rc;
+    lap("schur job list 1");
     rc = optimize(B, mode == 1 ? n_iterations : 5, &it1, &chi1); if (rc != SGX_OK) return rc;   // Optimizer.cc:659-660 / :187-188
+    lap("optimize 1");
     if (mode == 0 && !stopped(B)) {                                                                      // :662-707
         SGX_LAUNCH(k_ba_classify, dim3(B.nblk_e), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.ne, B.E, B.T, B.X, B.err, 0, derase);
         {   // mirror the new levels on the host to rebuild the Schur job list (the active edge set changed)
             std::vector<SgxBaEdge> Eh(B.ne);
             SGX_CHECK_HIP(hipMemcpy(Eh.data(), B.E, sizeof(SgxBaEdge) * B.ne, hipMemcpyDeviceToHost));
             for (int k = 0; k < B.ne; k++) level1[k] = (Eh[k].flags & 2) ? 1 : 0;
-            rc = build_jobs(B, pt_start, pt_edges, E, level1, hidx); if (rc != SGX_OK) return rc;
+            rc = build_jobs(B, pt_start, pt_edges, pose_start, pose_edges_l, E, level1, hidx, free_pose); if (rc != SGX_OK) return rc;
         }
+        lap("classify + job list 2");
         rc = optimize(B, 10, &it2, &chi2); if (rc != SGX_OK) return rc;
+        lap("optimize 2");
     }
     if (mode == 0) SGX_LAUNCH(k_ba_classify, dim3(B.nblk_e), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.ne, B.E, B.T, B.X, B.err, 1, derase);   // :709-742
     SGX_LAUNCH(k_ba_poses_out, dim3((B.np + SGX_BA_THREADS - 1) / SGX_BA_THREADS), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.np, dfixed, B.T, dTcw);
@@ -417,6 +507,7 @@ static int ba_run(const sgx_ba_problem *P, const sgx_camera *cam, const volatile
         if (mode == 0 || pt_start[l + 1] > pt_start[l])                                      // BundleAdjustment: points without edges were removed from the graph (vbNotIncludedMP)
             for (int c = 0; c < 3; c++) P->points[3 * (size_t)l + c] = (float)Xd[3 * (size_t)l + c];
     if (stats) { stats->iterations_first = it1; stats->iterations_second = it2; stats->chi2_first = chi1; stats->chi2_second = chi2; stats->free_poses = B.nf; }
+    lap("classify + download");
     return SGX_OK;
 }
 

@@ -488,11 +488,11 @@ static __device__ __forceinline__ double sgx_readlane_f64(double v, int lane)
 { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane)); }
 
 // returns false when a pivot is not positive (nothing is stored then)
-static __device__ __forceinline__ bool sgx_chol_diag_wave_body(int lane, int n, int k0, double *S, double *Linv, const double *bp, const double *coef, double *x)
+static __device__ __attribute__((noinline)) bool sgx_chol_diag_wave_body(int lane, int n, int k0, double *S, double *Linv, const double *bp, const double *coef, double *x)
 {
     const int row = lane & 31;
     const int nb = min(SGX_NB, n - k0);
-    if (k0 == 0) for (int i = lane; i < n; i += 64) x[i] = bp[i] - coef[i];          // right-hand side of the reduced system (first panel only)
+    if (k0 == 0 && bp) for (int i = lane; i < n; i += 64) x[i] = bp[i] - coef[i];    // right-hand side of the reduced system (first panel only; the envelope solver sets it up itself: bp == NULL)
     double a[SGX_NB];
     {
         const double *src = S + (size_t)(k0 + min(row, nb - 1)) * n + k0;
@@ -510,6 +510,7 @@ static __device__ __forceinline__ bool sgx_chol_diag_wave_body(int lane, int n, 
 #pragma unroll
             for (int c = j + 1; c < SGX_NB; c++) a[c] -= f * sgx_readlane_f64(a[j], c);
         }
+        __builtin_amdgcn_sched_barrier(0);               // one column at a time: the readlanes of later columns stay behind (hoisted, their scalar results spill into VGPR lanes)
     }
     // ---- Cholesky factor: L_ij = u_ij / sqrt(d_j), L_jj = sqrt(d_j)
     double dv = 1.0;                                     // lane j: d_j
@@ -529,6 +530,7 @@ static __device__ __forceinline__ bool sgx_chol_diag_wave_body(int lane, int n, 
 #pragma unroll
         for (int q = 0; q < r; q++) sacc -= sgx_readlane_f64(a[q], r) * xc[q];
         xc[r] = (r < nb && row < nb) ? sacc * sgx_readlane_f64(rsdv, r) : 0.0;
+        __builtin_amdgcn_sched_barrier(0);
     }
     // ---- y_k = L_kk^-1 x_k by forward substitution (lane r holds entry r); x_i -= L_ik y_k follows in k_chol_panel
     double b = (row < nb) ? x[k0 + row] : 0.0;
@@ -775,8 +777,100 @@ SGX_DEV void sgx_wave_gemm_nt(const double (*PT)[SGX_NB + 4], const double (*QT)
     }
 }
 
-SGX_KERNEL(SGX_ENV_THREADS) k_chol_env_factor(int n, int nt, const int *rstart, const int *rows, double *S, double *Linv, int *ok, const double *bp, const double *coef, double *x, int dbg)
+#ifdef SGX_EMU
+// the workgroup / LDS form of the diagonal-tile factorisation (k_chol_diag) for tile kd: what sgx_chol_diag_wave_body does on the device, same arithmetic.  Sets *fail on a non-positive pivot.
+static void sgx_env_diag_emu(int kd, int n, double *S, double *Linv, const double *bp, const double *coef, double *x, double (*A)[SGX_NB + 1], double (*X)[SGX_NB + 1], double *sd, double *rsd, int *fail)
 {
+    const int k0 = kd * SGX_NB, nb = min(SGX_NB, n - k0);
+    SGX_THREADS_BEGIN(tid)
+    if (tid < 256) {
+        if (k0 == 0 && bp) for (int i = tid; i < n; i += 256) x[i] = bp[i] - coef[i];
+        for (int t = tid; t < SGX_NB * SGX_NB; t += 256) { const int r = t >> SGX_NB_SHIFT, c = t & (SGX_NB - 1); A[r][c] = (r < nb && c < nb) ? S[(size_t)(k0 + r) * n + k0 + c] : 0.0; X[r][c] = 0; }
+    }
+    SGX_THREADS_END
+    int jfail = nb;
+    for (int j = 0; j < nb; j++) {
+        const double d = A[j][j];
+        if (!(d > 0)) { jfail = j; break; }
+        const double rd = 1.0 / d;
+        SGX_THREADS_BEGIN(tid)
+        if (tid < 256) {
+            const int ty = tid >> 4, tx = tid & 15;
+            for (int i = j + 1 + ty; i < nb; i += 16) { const double f = A[i][j] * rd; for (int c = j + 1 + tx; c <= i; c += 16) A[i][c] -= f * A[c][j]; }
+        }
+        SGX_THREADS_END
+    }
+    if (jfail < nb) { *fail = 1; return; }
+    SGX_THREADS_BEGIN(tid)
+    if (tid < SGX_NB) { const double r_ = tid < nb ? sqrt(A[tid][tid]) : 1.0; sd[tid] = r_; rsd[tid] = 1.0 / r_; }
+    SGX_THREADS_END
+    SGX_THREADS_BEGIN(tid)
+    if (tid < 256) for (int t = tid; t < SGX_NB * SGX_NB; t += 256) { const int r = t >> SGX_NB_SHIFT, c = t & (SGX_NB - 1); if (r < nb && c < r) A[r][c] = A[r][c] / sd[c]; }
+    SGX_THREADS_END
+    SGX_THREADS_BEGIN(tid)
+    if (tid < nb) A[tid][tid] = sd[tid];
+    SGX_THREADS_END
+    SGX_THREADS_BEGIN(tid)
+    if (tid < SGX_NB) {
+        double xc[SGX_NB];
+        for (int r = 0; r < SGX_NB; r++) { double sacc = (r == tid) ? 1.0 : 0.0; for (int q = 0; q < r; q++) sacc -= A[r][q] * xc[q]; xc[r] = sacc * rsd[r]; }
+        for (int r = 0; r < SGX_NB; r++) X[r][tid] = (tid < nb && r < nb) ? xc[r] : 0.0;
+    }
+    SGX_THREADS_END
+    SGX_THREADS_BEGIN(tid)
+    if (tid < nb) { double sacc = 0; for (int q = 0; q <= tid; q++) sacc += X[tid][q] * x[k0 + q]; sd[tid] = sacc; }
+    SGX_THREADS_END
+    SGX_THREADS_BEGIN(tid)
+    if (tid < nb) x[k0 + tid] = sd[tid];
+    if (tid < 256) {
+        double *Lo = Linv + (size_t)kd * SGX_NB * SGX_NB;
+        for (int t = tid; t < SGX_NB * SGX_NB; t += 256) { const int r = t >> SGX_NB_SHIFT, c = t & (SGX_NB - 1); if (r < nb && c <= r) S[(size_t)(k0 + r) * n + k0 + c] = A[r][c]; Lo[t] = X[r][c]; }
+    }
+    SGX_THREADS_END
+}
+#endif
+
+// update pair p of column step k: A_rc -= L_rk L_ck^T with (r, c) = the p-th pair (bi >= bj, row-major over the lower triangle) of R(k), both operands in the LDS pool
+// sep0 < n: this workgroup is the SECOND branch of a two-branch elimination — its contributions to the separator x separator tiles go to the side buffer S2 (nsep x nsep),
+// which the separator phase adds to S (the first branch subtracts in S itself; the two never write the same word)
+SGX_DEV void sgx_env_update_pair(int pidx, int lane, int n, int q0, const int *rows, const double (*pool)[SGX_NB][SGX_NB + 4], double *S, int sep0, double *S2)
+{
+    int bi = (int)((sqrt(8.0 * pidx + 1.0) - 1.0) * 0.5); while ((bi + 1) * (bi + 2) / 2 <= pidx) bi++; while (bi * (bi + 1) / 2 > pidx) bi--;
+    const int bj = pidx - bi * (bi + 1) / 2;
+    const int r0 = rows[q0 + bi] * SGX_NB, c0 = rows[q0 + bj] * SGX_NB, nr = min(SGX_NB, n - r0), nc = min(SGX_NB, n - c0);
+    const int ty = lane >> 3, tx = lane & 7;
+    double u[16];
+    sgx_wave_gemm_nt(pool[bi], pool[bj], ty, tx, u);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int r = 4 * ty + i, c = 4 * tx + j;
+            if (r < nr && c < nc && !(bi == bj && c > r)) {
+                if (c0 >= sep0) S2[(size_t)(r0 - sep0 + r) * (n - sep0) + (c0 - sep0 + c)] -= u[4 * i + j];
+                else S[(size_t)(r0 + r) * n + c0 + c] -= u[4 * i + j];
+            }
+        }
+}
+
+// Schedule.  The diagonal tile is the sequential spine (about 10 us on one wave); the updates of a step are up to 36 tile products.  Both run at the same time:
+// after the panel of step k, wave 0 takes the FIRST update pair — rows ascend inside a step, so that is tile (k + 1, k + 1) whenever row k + 1 belongs to R(k) — and then
+// factors and inverts diagonal tile k + 1 (it has received every update: the earlier steps' before their closing barrier, step k's just now, by the same wave), while
+// waves 1 .. 7 work through the remaining pairs.  One barrier later panel k + 1 finds Linv_{k+1} and all of column k + 1 ready.
+//
+// Two branches.  A band can be eliminated from both ends at once: the host orders the unknowns [first half ascending][second half DEScending][separator], so that the two
+// halves are banded blocks that only meet in the separator's rows; their column steps are independent (no tile of one is touched by the other) and run as two workgroups
+// of the same launch (phase 0: workgroup 0 takes steps [0, nA), workgroup 1 takes [nA, nA + nB)).  Both update separator x separator tiles and the separator's share of
+// the right-hand side: workgroup 0 in place, workgroup 1 in S2 / x2 (zeroed by the host), which the separator launch (phase 1: steps [nA + nB, nt), one workgroup) adds in
+// before it starts.  nB = 0: everything is phase 0 of a single workgroup.  The sequential spine is half as long.
+SGX_KERNEL(SGX_ENV_THREADS) k_chol_env_factor(int n, int nt, const int *rstart, const int *rows, double *S, double *Linv, int *ok, const double *bp, const double *coef, double *x, int dbg,
+                                              int phase, int nA, int nB, double *S2, double *x2)
+{
+    const int branch = phase == 0 ? (int)blockIdx.x : 2;                 // 0 / 1: the two independent halves, 2: the separator
+    const int kbeg = branch == 0 ? 0 : (branch == 1 ? nA : nA + nB), kend = branch == 0 ? nA : (branch == 1 ? nA + nB : nt);
+    const int sepu = min(n, (nA + nB) * SGX_NB);                         // first unknown of the separator
+    const int sep0 = branch == 1 ? sepu : n;                             // workgroup 1 diverts its separator contributions
+    double *xs = branch == 1 ? x2 - sepu : x;                            // ... and its share of the separator's right-hand side
     SGX_LDS double LiT[SGX_NB][SGX_NB + 4];                      // Linv_kk transposed: [q][c]
     SGX_LDS double yk[SGX_NB];
     SGX_LDS double pool[SGX_ENV_MAXM][SGX_NB][SGX_NB + 4];       // the row tiles of the step, transposed [q][r]: A_rk on the way in, L_rk on the way out
@@ -787,154 +881,119 @@ SGX_KERNEL(SGX_ENV_THREADS) k_chol_env_factor(int n, int nt, const int *rstart, 
     SGX_LDS double X[SGX_NB][SGX_NB + 1];
     SGX_LDS double sd[SGX_NB], rsd[SGX_NB];
 #endif
+    if (kbeg >= kend) return;
     SGX_THREADS_BEGIN(tid)
     if (tid == 0) s_fail = 0;
+    // right-hand side x = bp - coef of the steps this workgroup owns (workgroup 0 also the separator's); the separator launch folds workgroup 1's contributions in
+    if (branch == 0) { for (int i = tid; i < nA * SGX_NB && i < n; i += SGX_ENV_THREADS) x[i] = bp[i] - coef[i]; for (int i = sepu + tid; i < n; i += SGX_ENV_THREADS) x[i] = bp[i] - coef[i]; }
+    else if (branch == 1) { for (int i = nA * SGX_NB + tid; i < sepu; i += SGX_ENV_THREADS) x[i] = bp[i] - coef[i]; }
+    else if (nB > 0) {
+        const int ns = n - sepu;
+        for (int i = tid; i < ns; i += SGX_ENV_THREADS) x[sepu + i] += x2[i];
+        for (int t = tid; t < ns * ns; t += SGX_ENV_THREADS) { const int r = t / ns, c = t - r * ns; if (c <= (r | (SGX_NB - 1))) S[(size_t)(sepu + r) * n + sepu + c] += S2[t]; }     // lower tiles (the diagonal tiles whole: their upper halves are never read)
+    }
     SGX_THREADS_END
     SGX_SYNC();
-    for (int k = 0; k < nt; k++) {
-        const int k0 = k * SGX_NB, nb = min(SGX_NB, n - k0);
-        // ---- diagonal tile: L_kk over S, Linv_kk, y_k = Linv_kk x_k
+    // ---- first diagonal tile of the range: L_kk over S, Linv_kk, y_k = Linv_kk x_k
 #ifndef SGX_EMU
-        if ((int)threadIdx.x < 64 && !(dbg & 1)) { if (!sgx_chol_diag_wave_body((int)threadIdx.x, n, k0, S, Linv, bp, coef, x) && threadIdx.x == 0) s_fail = 1; }
+    if ((int)threadIdx.x < 64 && !(dbg & 1)) { if (!sgx_chol_diag_wave_body((int)threadIdx.x, n, kbeg * SGX_NB, S, Linv, nullptr, coef, x) && threadIdx.x == 0) s_fail = 1; }
 #else
-        {   // the workgroup / LDS form of the same factorisation (k_chol_diag), threads 0..255
-            SGX_THREADS_BEGIN(tid)
-            if (tid < 256) {
-                if (k0 == 0) for (int i = tid; i < n; i += 256) x[i] = bp[i] - coef[i];
-                for (int t = tid; t < SGX_NB * SGX_NB; t += 256) { const int r = t >> SGX_NB_SHIFT, c = t & (SGX_NB - 1); A[r][c] = (r < nb && c < nb) ? S[(size_t)(k0 + r) * n + k0 + c] : 0.0; X[r][c] = 0; }
-            }
-            SGX_THREADS_END
-            int jfail = nb;
-            for (int j = 0; j < nb; j++) {
-                const double d = A[j][j];
-                if (!(d > 0)) { jfail = j; break; }
-                const double rd = 1.0 / d;
-                SGX_THREADS_BEGIN(tid)
-                if (tid < 256) {
-                    const int ty = tid >> 4, tx = tid & 15;
-                    for (int i = j + 1 + ty; i < nb; i += 16) { const double f = A[i][j] * rd; for (int c = j + 1 + tx; c <= i; c += 16) A[i][c] -= f * A[c][j]; }
-                }
-                SGX_THREADS_END
-            }
-            if (jfail < nb) s_fail = 1;
-            else {
-                SGX_THREADS_BEGIN(tid)
-                if (tid < SGX_NB) { const double r_ = tid < nb ? sqrt(A[tid][tid]) : 1.0; sd[tid] = r_; rsd[tid] = 1.0 / r_; }
-                SGX_THREADS_END
-                SGX_THREADS_BEGIN(tid)
-                if (tid < 256) for (int t = tid; t < SGX_NB * SGX_NB; t += 256) { const int r = t >> SGX_NB_SHIFT, c = t & (SGX_NB - 1); if (r < nb && c < r) A[r][c] = A[r][c] / sd[c]; }
-                SGX_THREADS_END
-                SGX_THREADS_BEGIN(tid)
-                if (tid < nb) A[tid][tid] = sd[tid];
-                SGX_THREADS_END
-                SGX_THREADS_BEGIN(tid)
-                if (tid < SGX_NB) {
-                    double xc[SGX_NB];
-                    for (int r = 0; r < SGX_NB; r++) { double sacc = (r == tid) ? 1.0 : 0.0; for (int q = 0; q < r; q++) sacc -= A[r][q] * xc[q]; xc[r] = sacc * rsd[r]; }
-                    for (int r = 0; r < SGX_NB; r++) X[r][tid] = (tid < nb && r < nb) ? xc[r] : 0.0;
-                }
-                SGX_THREADS_END
-                SGX_THREADS_BEGIN(tid)
-                if (tid < nb) { double sacc = 0; for (int q = 0; q <= tid; q++) sacc += X[tid][q] * x[k0 + q]; sd[tid] = sacc; }
-                SGX_THREADS_END
-                SGX_THREADS_BEGIN(tid)
-                if (tid < nb) x[k0 + tid] = sd[tid];
-                if (tid < 256) {
-                    double *Lo = Linv + (size_t)k * SGX_NB * SGX_NB;
-                    for (int t = tid; t < SGX_NB * SGX_NB; t += 256) { const int r = t >> SGX_NB_SHIFT, c = t & (SGX_NB - 1); if (r < nb && c <= r) S[(size_t)(k0 + r) * n + k0 + c] = A[r][c]; Lo[t] = X[r][c]; }
-                }
-                SGX_THREADS_END
-            }
-        }
+    sgx_env_diag_emu(kbeg, n, S, Linv, nullptr, coef, x, A, X, sd, rsd, &s_fail);
 #endif
-        SGX_SYNC();
+    SGX_SYNC();
+    for (int k = kbeg; k < kend; k++) {
         if (s_fail) {
             SGX_THREADS_BEGIN(tid) if (tid == 0) *ok = 0; SGX_THREADS_END
             return;
         }
-        const int q0 = rstart[k], m = rstart[k + 1] - q0;                   // m <= SGX_ENV_MAXM (host)
-        if (m == 0 || (dbg & 2)) continue;
-        const double *Lk = Linv + (size_t)k * SGX_NB * SGX_NB;
-        // ---- panel: L_rk = A_rk Linv_kk^T for r in R(k) (wave g takes row tile g), then x_r -= L_rk y_k
-        SGX_THREADS_BEGIN(tid)
-        for (int t = tid; t < SGX_NB * SGX_NB; t += SGX_ENV_THREADS) { const int r = t >> SGX_NB_SHIFT, c = t & (SGX_NB - 1); LiT[c][r] = Lk[t]; }
-        if (tid < SGX_NB) yk[tid] = tid < nb ? x[k0 + tid] : 0.0;                                              // y_k for the forward substitution
-        const int g = tid >> 6, lane = tid & 63;
-        if (g < m) {
-            const int r0 = rows[q0 + g] * SGX_NB, nr = min(SGX_NB, n - r0);
-            for (int t = lane; t < SGX_NB * SGX_NB; t += 64) {
-                const int r = t >> SGX_NB_SHIFT, c = t & (SGX_NB - 1);
-                pool[g][c][r] = (r < nr && c < nb) ? S[(size_t)(r0 + r) * n + k0 + c] : 0.0;
-            }
-        }
-        SGX_THREADS_END
-        SGX_SYNC();
-        SGX_THREADS_BEGIN(tid)
-        SGX_PRIV_BIND(acc, tid);
-        const int g = tid >> 6, lane = tid & 63;
-        if (g < m) sgx_wave_gemm_nt(pool[g], LiT, lane >> 3, lane & 7, acc);                                    // out[r][c] = sum_q A[r][q] Linv[c][q]
-        SGX_THREADS_END
-        SGX_SYNC();
-        SGX_THREADS_BEGIN(tid)
-        SGX_PRIV_BIND(acc, tid);
-        const int g = tid >> 6, lane = tid & 63;
-        if (g < m) {
-            const int r0 = rows[q0 + g] * SGX_NB, nr = min(SGX_NB, n - r0), ty = lane >> 3, tx = lane & 7;
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int r = 4 * ty + i, c = 4 * tx + j;
-                    pool[g][c][r] = acc[4 * i + j];                                                               // L_rk (transposed) replaces A_rk
-                    if (r < nr && c < nb) S[(size_t)(r0 + r) * n + k0 + c] = acc[4 * i + j];
-                }
-        }
-        SGX_THREADS_END
-        SGX_SYNC();
-        SGX_THREADS_BEGIN(tid)
-        const int g = tid >> 6, lane = tid & 63;
-        if (g < m) {
-            const int r0 = rows[q0 + g] * SGX_NB, nr = min(SGX_NB, n - r0);
-            if (lane < nr) { double vv = x[r0 + lane]; for (int q = 0; q < nb; q++) vv -= pool[g][q][lane] * yk[q]; x[r0 + lane] = vv; }      // forward substitution
-        }
-        SGX_THREADS_END
-        // ---- update: A_rc -= L_rk L_ck^T for the pairs r >= c of R(k), both operands in LDS (pair p <-> (bi, bj), bi >= bj, row-major over the lower triangle)
-        const int npairs = (dbg & 4) ? 0 : m * (m + 1) / 2;
-        for (int it = 0; it * SGX_ENV_GROUPS < npairs; it++) {
+        const int k0 = k * SGX_NB, nb = min(SGX_NB, n - k0);
+        const int q0 = rstart[k], m = (dbg & 2) ? 0 : rstart[k + 1] - q0;   // m <= SGX_ENV_MAXM (host)
+        if (m > 0) {
+            const double *Lk = Linv + (size_t)k * SGX_NB * SGX_NB;
+            // ---- panel: L_rk = A_rk Linv_kk^T for r in R(k) (wave g takes row tile g), then x_r -= L_rk y_k
             SGX_THREADS_BEGIN(tid)
-            const int g = tid >> 6, lane = tid & 63, pidx = it * SGX_ENV_GROUPS + g;
-            if (pidx < npairs) {
-                int bi = (int)((sqrt(8.0 * pidx + 1.0) - 1.0) * 0.5); while ((bi + 1) * (bi + 2) / 2 <= pidx) bi++; while (bi * (bi + 1) / 2 > pidx) bi--;
-                const int bj = pidx - bi * (bi + 1) / 2;
-                const int r0 = rows[q0 + bi] * SGX_NB, c0 = rows[q0 + bj] * SGX_NB, nr = min(SGX_NB, n - r0), nc = min(SGX_NB, n - c0);
-                const int ty = lane >> 3, tx = lane & 7;
-                double u[16];
-                sgx_wave_gemm_nt(pool[bi], pool[bj], ty, tx, u);
+            for (int t = tid; t < SGX_NB * SGX_NB; t += SGX_ENV_THREADS) { const int r = t >> SGX_NB_SHIFT, c = t & (SGX_NB - 1); LiT[c][r] = Lk[t]; }
+            if (tid < SGX_NB) yk[tid] = tid < nb ? x[k0 + tid] : 0.0;                                              // y_k for the forward substitution
+            const int g = tid >> 6, lane = tid & 63;
+            if (g < m) {
+                const int r0 = rows[q0 + g] * SGX_NB, nr = min(SGX_NB, n - r0);
+                for (int t = lane; t < SGX_NB * SGX_NB; t += 64) {
+                    const int r = t >> SGX_NB_SHIFT, c = t & (SGX_NB - 1);
+                    pool[g][c][r] = (r < nr && c < nb) ? S[(size_t)(r0 + r) * n + k0 + c] : 0.0;
+                }
+            }
+            SGX_THREADS_END
+            SGX_SYNC();
+            SGX_THREADS_BEGIN(tid)
+            SGX_PRIV_BIND(acc, tid);
+            const int g = tid >> 6, lane = tid & 63;
+            if (g < m) sgx_wave_gemm_nt(pool[g], LiT, lane >> 3, lane & 7, acc);                                    // out[r][c] = sum_q A[r][q] Linv[c][q]
+            SGX_THREADS_END
+            SGX_SYNC();
+            SGX_THREADS_BEGIN(tid)
+            SGX_PRIV_BIND(acc, tid);
+            const int g = tid >> 6, lane = tid & 63;
+            if (g < m) {
+                const int r0 = rows[q0 + g] * SGX_NB, nr = min(SGX_NB, n - r0), ty = lane >> 3, tx = lane & 7;
 #pragma unroll
                 for (int i = 0; i < 4; i++)
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const int r = 4 * ty + i, c = 4 * tx + j;
-                        if (r < nr && c < nc && !(bi == bj && c > r)) S[(size_t)(r0 + r) * n + c0 + c] -= u[4 * i + j];
+                        pool[g][c][r] = acc[4 * i + j];                                                               // L_rk (transposed) replaces A_rk
+                        if (r < nr && c < nb) S[(size_t)(r0 + r) * n + k0 + c] = acc[4 * i + j];
                     }
             }
             SGX_THREADS_END
+            SGX_SYNC();
+            SGX_THREADS_BEGIN(tid)
+            const int g = tid >> 6, lane = tid & 63;
+            if (g < m) {
+                const int r0 = rows[q0 + g] * SGX_NB, nr = min(SGX_NB, n - r0);
+                double *xr = r0 >= sep0 ? xs : x;                                                                        // second branch: separator rows accumulate in x2
+                if (lane < nr) { double vv = xr[r0 + lane]; for (int q = 0; q < nb; q++) vv -= pool[g][q][lane] * yk[q]; xr[r0 + lane] = vv; }      // forward substitution
+            }
+            SGX_THREADS_END
+            SGX_SYNC();                                                                                            // x_{k+1} is complete before wave 0 turns it into y_{k+1}
         }
+        // ---- updates A_rc -= L_rk L_ck^T for the pairs r >= c of R(k), and — at the same time, on wave 0 — diagonal tile k + 1
+        const int npairs = (dbg & 4) ? 0 : m * (m + 1) / 2;
+#ifndef SGX_EMU
+        {
+            const int tid = (int)threadIdx.x, g = tid >> 6, lane = tid & 63;
+            if (g == 0) {
+                if (npairs > 0) { sgx_env_update_pair(0, lane, n, q0, rows, pool, S, sep0, S2); __threadfence_block(); }         // tile (k + 1, k + 1) when row k + 1 is in R(k): stored before it is read back
+                if (k + 1 < kend && !(dbg & 1)) { if (!sgx_chol_diag_wave_body(lane, n, (k + 1) * SGX_NB, S, Linv, nullptr, coef, x) && lane == 0) s_fail = 1; }
+            } else {
+                for (int pidx = g; pidx < npairs; pidx += SGX_ENV_GROUPS - 1) sgx_env_update_pair(pidx, lane, n, q0, rows, pool, S, sep0, S2);
+            }
+        }
+#else
+        SGX_THREADS_BEGIN(tid)
+        const int g = tid >> 6, lane = tid & 63;
+        for (int pidx = g; pidx < npairs; pidx += SGX_ENV_GROUPS) sgx_env_update_pair(pidx, lane, n, q0, rows, pool, S, sep0, S2);
+        SGX_THREADS_END
+        if (k + 1 < kend) sgx_env_diag_emu(k + 1, n, S, Linv, nullptr, coef, x, A, X, sd, rsd, &s_fail);
+#endif
         SGX_SYNC();
     }
+    if (s_fail) { SGX_THREADS_BEGIN(tid) if (tid == 0) *ok = 0; SGX_THREADS_END }
 }
 
 // backward pass over the envelope, one persistent workgroup: for k = nt-1 .. 0:  x_k = Linv_kk^T (y_k - sum_{r in R(k)} L_rk^T x_r)
 // (column-oriented form of k_chol_back_step's row updates: the contributions of the finished blocks below are gathered when block k is solved).
 // Thread (row q = tid >> 5, column c = tid & 31) multiplies entry (q, c) of every tile of R(k) with x_r[q] (independent loads), the 32 partial sums of a
 // column meet in LDS; Linv_kk is fetched while they are formed.
-SGX_KERNEL(1024) k_chol_env_back(int n, int nt, const int *rstart, const int *rows, const double *S, const double *Linv, const double *y, double *xsol, const int *ok)
+// Two-branch plans: phase 0 = the separator's steps (one workgroup), phase 1 = the two halves, one workgroup each (they only read the separator's finished solution).
+SGX_KERNEL(1024) k_chol_env_back(int n, int nt, const int *rstart, const int *rows, const double *S, const double *Linv, const double *y, double *xsol, const int *ok, int phase, int nA, int nB)
 {
     SGX_LDS double ys[SGX_NB];
     SGX_LDS double part[SGX_NB][SGX_NB + 1];
     SGX_LDS double Li[SGX_NB][SGX_NB + 1];
     if (!*ok) return;
-    for (int k = nt - 1; k >= 0; k--) {
+    const int branch = phase == 0 ? 2 : (int)blockIdx.x;
+    const int kbeg = branch == 0 ? 0 : (branch == 1 ? nA : nA + nB), kend = branch == 0 ? nA : (branch == 1 ? nA + nB : nt);
+    for (int k = kend - 1; k >= kbeg; k--) {
         const int k0 = k * SGX_NB, nb = min(SGX_NB, n - k0);
         const int q0 = rstart[k], m = rstart[k + 1] - q0;
         const double *Lk = Linv + (size_t)k * SGX_NB * SGX_NB;
