@@ -29,7 +29,7 @@ struct Layer {
     float getf(int k, float d) const { auto it = p.find(k); return it == p.end() ? d : (float)it->second; }
 };
 struct Blob { int c = 0, h = 0, w = 0; size_t n = 0; float *d = nullptr; bool scalar = false; float sval = 0.f; int alias = -1; };
-enum OpKind { OP_PW, OP_KXK, OP_BINARY, OP_UNARY, OP_PERMUTE_INTO, OP_COPY_INTO, OP_SOFTMAX, OP_FUSED_BLOCK, OP_IRB };
+enum OpKind { OP_PW, OP_KXK, OP_BINARY, OP_UNARY, OP_PERMUTE_INTO, OP_COPY_INTO, OP_SOFTMAX, OP_FUSED_BLOCK, OP_IRB, OP_SE_GATE };
 struct EpiStep { int op, src; float a, b; int tensor; };
 struct Op {
     OpKind kind; int in0 = -1, in1 = -1, out = -1;
@@ -37,6 +37,7 @@ struct Op {
     int inc = 0, outc = 0, H = 0, W = 0, Ho = 0, Wo = 0, k = 1, stride = 1, pad = 0, depthwise = 0, act = 0; float lo = 0, hi = 0;
     float *wt = nullptr, *bias = nullptr, *wtT = nullptr; int ldw = 0; int bop = 0; int off = 0; int rows = 0, C = 0;
     SgxFusedBlk fb; int fb_res_blob = -1;      // OP_FUSED_BLOCK: expand -> depthwise -> project (+ residual) in one kernel (sgx_det_block.h)
+    SgxSeGate sg; int sg_res_blob = -1;                            // OP_SE_GATE: squeeze -> excite -> gate x input [+ residual] as one kernel (k_se_gate, sgx_det_block.h)
     SgxIrb irb; int irb_res_blob = -1, irb_out2_blob = -1;         // OP_IRB: [expand ->] depthwise -> project [-> squeeze-excite gate] [+ residual] on the matrix cores (sgx_det_irb.h)
 };
 }  // namespace
@@ -442,7 +443,7 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                 for (int i = 0; i < nops; i++) {
                     if (ops[i].dead) continue;
                     bool rd = ops[i].in0 == id || (ops[i].kind == OP_BINARY && ops[i].in1 == id && !h->blobs[id].scalar) || (ops[i].kind == OP_FUSED_BLOCK && ops[i].fb_res_blob == id) ||
-                              (ops[i].kind == OP_IRB && ops[i].irb_res_blob == id);
+                              (ops[i].kind == OP_IRB && ops[i].irb_res_blob == id) || (ops[i].kind == OP_SE_GATE && ops[i].sg_res_blob == id);
                     for (const EpiStep &st : ops[i].epi) rd = rd || st.tensor == id;
                     if (rd) r.push_back(i);
                 }
@@ -598,6 +599,39 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                 bq.dead = true; if (last != ci) ops[ci].dead = true; if (di >= 0 && di != last) ops[di].dead = true;
                 ops[last] = f;
             }
+        // ---- squeeze-excite tails that are still two pointwise launches (the 38 x 38 blocks: 40 -> 10 -> 40 channels on 1 444 pixels) as one k_se_gate each
+        {
+            static const int seg_env = getenv("SGX_DET_SE_GATE") ? atoi(getenv("SGX_DET_SE_GATE")) : 1;
+            for (int di = 0; seg_env && irb_mode == 1 && g_det_fuse && di < nops; di++) {
+                Op &d = ops[di];
+                if (d.dead || d.kind != OP_PW || d.hwc || d.in0 < 0) continue;
+                const EpiClass cd = classify(d.epi);
+                if (cd.mode != SGX_EMODE_ACT) continue;
+                readers_all(d.out, R); if (R.size() != 1) continue;
+                const int ei = R[0]; Op &e = ops[ei];
+                if (e.kind != OP_PW || e.hwc || e.in0 != d.out || ei < di) continue;
+                const EpiClass ce = classify(e.epi);
+                if ((ce.mode != SGX_EMODE_GATE && ce.mode != SGX_EMODE_GATE_ADD) || ce.t0 != d.in0 || e.outc != d.inc || e.inc != d.outc) continue;
+                if (!sgx_se_gate_supported(d.inc, d.outc) || d.out == h->loc_blob || d.out == h->conf_blob) continue;
+                SgxSeGate sg; memset(&sg, 0, sizeof sg);
+                sg.Cout = d.inc; sg.Cq = d.outc; sg.HW = d.H * d.W;
+                sg.se.bq1 = d.bias; sg.se.bq2 = e.bias; sg.se.qlo = cd.lo; sg.se.qhi = cd.hi; sg.se.gc1 = ce.c1; sg.se.glo = ce.lo; sg.se.ghi = ce.hi; sg.se.gc2 = ce.c2; sg.wq1 = d.wt; sg.wq2 = e.wt;
+                {
+                    const int Cq = d.outc, Co = d.inc;
+                    std::vector<float> q1((size_t)Cq * Co), q2((size_t)Co * Cq), p1((size_t)Cq * Co), p2((size_t)Co * Cq);
+                    if (hipMemcpy(q1.data(), d.wt, q1.size() * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(q2.data(), e.wt, q2.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) FAIL(SGX_ERR_DEVICE);
+                    for (int j = 0; j < Cq; j++) for (int k = 0; k < Co; k++) p1[((size_t)(j >> 1) * Co + k) * 2 + (j & 1)] = q1[(size_t)j * Co + k];
+                    for (int co = 0; co < Co; co++) for (int j = 0; j < Cq; j++) p2[((size_t)j * (Co / 2) + (co >> 1)) * 2 + (co & 1)] = q2[(size_t)co * Cq + j];
+                    float *dp1 = nullptr, *dp2 = nullptr;
+                    if (h->alloc(&dp1, p1.size()) || h->alloc(&dp2, p2.size())) FAIL(SGX_ERR_NOMEM);
+                    if (hipMemcpy(dp1, p1.data(), p1.size() * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dp2, p2.data(), p2.size() * 4, hipMemcpyHostToDevice) != hipSuccess) FAIL(SGX_ERR_DEVICE);
+                    sg.se.wq1p = dp1; sg.se.wq2p = dp2;
+                }
+                Op f; f.kind = OP_SE_GATE; f.in0 = d.in0; f.out = e.out; f.sg = sg; f.sg_res_blob = ce.mode == SGX_EMODE_GATE_ADD ? ce.t1 : -1;
+                f.name = d.name + "+" + e.name; f.inc = d.inc; f.outc = e.outc; f.H = d.H; f.W = d.W; f.Ho = d.H; f.Wo = d.W;
+                d.dead = true; ops[ei] = f;
+            }
+        }
         }
         // ---- the two SSD heads of a feature map (loc and conf: depthwise 3x3 + ReLU -> pointwise, HWC store) read the same planes: one kernel stages them once, reads the
         // depthwise taps once and runs both heads' weights over them (k_irb with a second accumulator set).  SGX_DET_IRB_DUAL=0 keeps them apart.
@@ -738,6 +772,12 @@ static void run_op(sgx_det *h, const Op &op, int batch, sgx_stream_t st)
         fb.res = op.fb_res_blob >= 0 ? h->blobs[op.fb_res_blob].d : nullptr; fb.res_pitch = op.fb_res_blob >= 0 ? h->blobs[op.fb_res_blob].n : 0;
         if (fb.v2) { (void)sgx_fb2_launch(fb, batch, st); break; }                      // the variant was validated when the plan was built
         SGX_LAUNCH_DYN(k_fused_block, dim3((unsigned)(fb.tiles_x * fb.tiles_y * batch)), dim3(256), sgx_fb_lds_floats(fb) * 4, st, fb);
+        break; }
+    case OP_SE_GATE: {
+        SgxSeGate sg = op.sg;
+        sg.y = A.d; sg.y_pitch = A.n; sg.out = O.d; sg.out_pitch = O.n;
+        sg.res = op.sg_res_blob >= 0 ? h->blobs[op.sg_res_blob].d : nullptr; sg.res_pitch = op.sg_res_blob >= 0 ? h->blobs[op.sg_res_blob].n : 0;
+        (void)sgx_se_gate_launch(sg, batch, st);
         break; }
     case OP_IRB: {
         SgxIrb ib = op.irb;
@@ -908,7 +948,8 @@ extern "C" int sgx_det_debug_op_desc(const sgx_det *h, int i, char *buf, int cap
     if (i == 0) { const Op &s0 = h->ops[0]; snprintf(buf, cap, "kxk %s c%d->%d k%d s%d %dx%d->%dx%d epi%d pre %dx%d->%d", s0.name.c_str(), s0.inc, s0.outc, s0.k, s0.stride, s0.H, s0.W, s0.Ho, s0.Wo,
                                                      (int)s0.epi.size() + (s0.act ? 1 : 0), h->W, h->H, h->T); return SGX_OK; }
     const Op &o = h->ops[i - 1 + h->pre_fused];
-    static const char *kn[] = { "pw", "kxk", "binary", "unary", "permute_into", "copy_into", "softmax", "block", "irb" };
+    static const char *kn[] = { "pw", "kxk", "binary", "unary", "permute_into", "copy_into", "softmax", "block", "irb", "se_gate" };
+    if (o.kind == OP_SE_GATE) { snprintf(buf, cap, "se_gate %s c%d->%d->%d %dx%d%s", o.name.c_str(), o.sg.Cout, o.sg.Cq, o.sg.Cout, o.H, o.W, o.sg_res_blob >= 0 ? " +res" : ""); return SGX_OK; }
     if (o.kind == OP_PW || o.kind == OP_KXK)
         snprintf(buf, cap, "%s %s c%d->%d k%d s%d %s%dx%d->%dx%d epi%d%s", kn[o.kind], o.name.c_str(), o.inc, o.outc, o.k, o.stride, o.depthwise ? "dw " : "", o.H, o.W,
                  o.kind == OP_PW ? o.H : o.Ho, o.kind == OP_PW ? o.W : o.Wo, (int)o.epi.size() + (o.act ? 1 : 0), o.hwc ? " hwc" : "");

@@ -633,6 +633,72 @@ SGX_KERNEL(SGX_FB2_THREADS) k_fused_block2(int Cmid, int H, int W, int Ho, int W
     SGX_THREADS_END
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_se_gate<COUT, NQ>: a squeeze-excite tail on its own — out = clip(bq2 + Wq2 x clip(bq1 + Wq1 x y, qlo, qhi) + gc1, glo, ghi) / gc2 * y [+ residual] for every pixel of y.
+// The per-layer plan runs it as two pointwise launches (COUT -> NQ with ReLU, NQ -> COUT with the gate epilogue): with COUT = 40 and NQ = 10 those are 400 + 400 multiply-adds
+// per pixel behind 32-wide matrix-core tiles (a quarter of the rows used) and three passes over y.  Here a thread owns a pixel: COUT loads (coalesced across the wave), the two
+// matrix-vector products on wave-uniform weights exactly as in k_fused_block2's tail (same fmaf chains, k ascending from the bias), COUT stores.  grid = ceil(B * HW / 256).
+// ---------------------------------------------------------------------------------------------
+struct SgxSeGate { int Cout, Cq, HW; const float *y; size_t y_pitch; float *out; size_t out_pitch; const float *res; size_t res_pitch; SgxFb2Se se; const float *wq1, *wq2; };
+template <int COUT, int NQ>
+SGX_KERNEL(256) k_se_gate(int HW, int total, const float *__restrict__ y, size_t y_pitch, float *__restrict__ out, size_t out_pitch, const float *__restrict__ res, size_t res_pitch, SgxFb2Se se)
+{
+    static_assert((NQ & 1) == 0 && (COUT & 1) == 0, "channels are processed in pairs");
+    SGX_THREADS_BEGIN(tid)
+    const int g = min((int)blockIdx.x * 256 + tid, total - 1);            // the lanes past the end recompute the last pixel (no divergence around the scalar weight loads) and do not store
+    const bool live = (int)blockIdx.x * 256 + tid < total;
+    const int b = g / HW, n = g - b * HW;
+    const float *yp = y + (size_t)b * y_pitch + n;
+    sgx_f2 acc[COUT / 2];
+#pragma unroll
+    for (int cp = 0; cp < COUT / 2; cp++) acc[cp] = sgx_mk2(yp[(size_t)(2 * cp) * HW], yp[(size_t)(2 * cp + 1) * HW]);
+    float r[COUT];
+    if (res) {
+        const float *rp = res + (size_t)b * res_pitch + n;
+#pragma unroll
+        for (int co = 0; co < COUT; co++) r[co] = rp[(size_t)co * HW];
+    }
+    const sgx_f2 *wq1 = (const sgx_f2 *)se.wq1p, *wq2 = (const sgx_f2 *)se.wq2p;
+    sgx_f2 hid[NQ / 2];
+#pragma unroll
+    for (int jp = 0; jp < NQ / 2; jp++) hid[jp] = sgx_mk2(se.bq1[2 * jp], se.bq1[2 * jp + 1]);
+#pragma unroll
+    for (int cp = 0; cp < COUT / 2; cp++) {
+#pragma unroll
+        for (int jp = 0; jp < NQ / 2; jp++) hid[jp] = sgx_fma2_w_dlo(wq1[jp * COUT + 2 * cp], acc[cp], hid[jp]);
+#pragma unroll
+        for (int jp = 0; jp < NQ / 2; jp++) hid[jp] = sgx_fma2_w_dhi(wq1[jp * COUT + 2 * cp + 1], acc[cp], hid[jp]);
+    }
+#pragma unroll
+    for (int jp = 0; jp < NQ / 2; jp++) hid[jp] = sgx_mk2(fminf(fmaxf(hid[jp].x, se.qlo), se.qhi), fminf(fmaxf(hid[jp].y, se.qlo), se.qhi));
+    sgx_f2 gt[COUT / 2];
+#pragma unroll
+    for (int cp = 0; cp < COUT / 2; cp++) gt[cp] = sgx_mk2(se.bq2[2 * cp], se.bq2[2 * cp + 1]);
+#pragma unroll
+    for (int j = 0; j < NQ; j++) {
+#pragma unroll
+        for (int cp = 0; cp < COUT / 2; cp++) gt[cp] = (j & 1) ? sgx_fma2_w_dhi(wq2[j * (COUT / 2) + cp], hid[j >> 1], gt[cp]) : sgx_fma2_w_dlo(wq2[j * (COUT / 2) + cp], hid[j >> 1], gt[cp]);
+    }
+    float *op = out + (size_t)b * out_pitch + n;
+#pragma unroll
+    for (int cp = 0; cp < COUT / 2; cp++) {                                // [ADD c][CLIP][DIV c][MUL y] [ADD residual], as sgx_epi_mode<SGX_EMODE_GATE / GATE_ADD>
+        float ux = gt[cp].x + se.gc1, uy = gt[cp].y + se.gc1;
+        ux = fminf(fmaxf(ux, se.glo), se.ghi); uy = fminf(fmaxf(uy, se.glo), se.ghi);
+        ux = ux / se.gc2; uy = uy / se.gc2;
+        ux = ux * acc[cp].x; uy = uy * acc[cp].y;
+        if (res) { ux = ux + r[2 * cp]; uy = uy + r[2 * cp + 1]; }
+        if (live) { op[(size_t)(2 * cp) * HW] = ux; op[(size_t)(2 * cp + 1) * HW] = uy; }
+    }
+    SGX_THREADS_END
+}
+static inline bool sgx_se_gate_supported(int cout, int cq) { return cout == 40 && cq == 10; }
+static inline int sgx_se_gate_launch(const SgxSeGate &p, int batch, sgx_stream_t st)
+{
+    const int total = batch * p.HW;
+    if (p.Cout == 40 && p.Cq == 10) { auto kfn = k_se_gate<40, 10>; SGX_LAUNCH(kfn, dim3((unsigned)((total + 255) / 256)), dim3(256), st, p.HW, total, p.y, p.y_pitch, p.out, p.out_pitch, p.res, p.res_pitch, p.se); return SGX_OK; }
+    return SGX_ERR_INVALID;
+}
+
 // ---- k_fused_block2 dispatch: (Cin, Cout, K, stride) -> instantiation; the tile variant comes from SGX_FB2_TILE (tuning tap) --------------------------------------
 static inline int sgx_fb2_cm(int v2) { return (v2 >> 4) == 1 ? 16 : 8; }       /* expanded channels per chunk of the instantiation (Cmid must be a multiple) */
 static inline int sgx_fb2_variant(int cin, int cout, int k, int stride, int cq = 0)

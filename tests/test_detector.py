@@ -93,7 +93,7 @@ def run_fused_equals_unfused(lib, model):
         # the fifth plan additionally runs the six expand -> depthwise -> project triples as one k_fused_block each (opt-in: correct but slower at batch 256);
         # the last two run inverted-residual blocks (with their squeeze-excite gates) and SSD heads as one matrix-core kernel each (k_irb): every supported shape / the default plan (the shapes where it wins)
         det = Detector2D(0.90, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=2, lib=lib, fuse=fuse, legacy_kernels=legacy, block_fusion=blocks, irb=irb)
-        assert det.num_kernels == (54 if irb == 1 and irb is not True else 39 if irb else 90 if blocks else 96 if (fuse and not legacy) else 103 if fuse else 282), det.num_kernels     # 96: the three high-resolution blocks run as k_fused_block2
+        assert det.num_kernels == (52 if irb == 1 and irb is not True else 39 if irb else 90 if blocks else 96 if (fuse and not legacy) else 103 if fuse else 282), det.num_kernels     # 96: the three high-resolution blocks run as k_fused_block2
         det.detect_batch(imgs)
         outs.append([np.stack([det.debug_blob(nm, b) for b in range(2)]) for nm in ('587', '632', '672', '849', '908', '944', 'mbox_loc', 'mbox_conf_softmax')])
         det.close()

@@ -25,6 +25,11 @@ def step_roof_ms(desc, B):
         by = 4.0 * ((cm if noexp else c) * h * w + oc * ho * wo * (2 if '+res' in desc else 1)) * B
         fl = 2.0 * ((0 if noexp else h * w * c * cm) + ho * wo * cm * k * k + ho * wo * cm * oc + 2 * ho * wo * oc * cq) * B
         return max(by / 8e12, fl / 157.3e12) * 1e3
+    m = re.match(r'se_gate \S+ c(\d+)->(\d+)->(\d+) (\d+)x(\d+)', desc)
+    if m:      # squeeze-excite tail as one kernel: input, output (+ residual) in HBM, 2 x C x Cq multiply-adds per pixel
+        c, cq, _, h, w = (int(m.group(i)) for i in range(1, 6))
+        by = 4.0 * c * h * w * (3 if '+res' in desc else 2) * B; fl = 2.0 * 2 * c * cq * h * w * B
+        return max(by / 8e12, fl / 157.3e12) * 1e3
     return 0.0
 
 
