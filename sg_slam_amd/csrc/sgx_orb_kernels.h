@@ -202,6 +202,26 @@ SGX_DEV uint32_t sgx_alignbyte(uint32_t hi, uint32_t lo, int sh)
 #endif
 }
 
+// exact integer dot products of packed operands: 4 x u8 (v_dot4_u32_u8) and 2 x u16 (v_dot2_u32_u16), 32-bit accumulate, no clamp
+SGX_DEV uint32_t sgx_udot4(uint32_t a, uint32_t b, uint32_t c)
+{
+#ifndef SGX_EMU
+    return __builtin_amdgcn_udot4(a, b, c, false);
+#else
+    for (int i = 0; i < 4; i++) c += ((a >> (8 * i)) & 255u) * ((b >> (8 * i)) & 255u);
+    return c;
+#endif
+}
+SGX_DEV uint32_t sgx_udot2(uint32_t a, uint32_t b, uint32_t c)
+{
+#ifndef SGX_EMU
+    typedef unsigned short sgx_us2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(sgx_us2, a), __builtin_bit_cast(sgx_us2, b), c, false);
+#else
+    return c + (a & 0xFFFFu) * (b & 0xFFFFu) + (a >> 16) * (b >> 16);
+#endif
+}
+
 // packed 2 x u16 helpers (v_pk_sub_u16 clamp / v_pk_min_u16 on the device)
 #ifndef SGX_EMU
 typedef unsigned short sgx_u16x2 __attribute__((ext_vector_type(2)));
@@ -948,12 +968,12 @@ struct SgxBlurTile { short level, x0, y0, w, h, pad0, pad1, pad2; };
 #define SGX_BT_W 64
 #define SGX_BT_H 58            /* + 6 halo rows = 64 staged rows: the horizontal pass is exactly two rounds of 256 (row, 8-column) tasks */
 #define SGX_BT_IS 80            /* LDS row stride of the staged input (bytes): 3 lead + 3 + 64 + 3, dword aligned */
-#define SGX_BT_HS 72            /* row stride of the horizontal-pass buffer (u16) */
+#define SGX_BT_HS 66            /* COLUMN stride of the horizontal-pass buffer (u16): it is stored transposed, [column][row], 64 staged rows + 2 (33 dwords: odd -> the columns of a wave fall on different banks) */
 
 SGX_KERNEL(512) k_blur_levels(SgxOrbGeom g, const SgxBlurTile *tiles, const uint8_t *gray, int gray_pitch, const uint8_t *pyr, uint8_t *blur, int batch)
 {
     SGX_LDS uint32_t in_dw[(SGX_BT_H + 6) * SGX_BT_IS / 4];
-    SGX_LDS uint32_t h_dw[(SGX_BT_H + 6) * SGX_BT_HS / 2];
+    SGX_LDS uint32_t h_dw[SGX_BT_W * SGX_BT_HS / 2 + 8];           // + the 8-dword read of the last column's last segment
     SGX_LDS uint32_t o_dw[SGX_BT_H * SGX_BT_W / 4];
     uint8_t *in = (uint8_t *)in_dw; uint16_t *hb = (uint16_t *)h_dw; uint8_t *ob = (uint8_t *)o_dw;
     const int GK0 = 18, GK1 = 34, GK2 = 48, GK3 = 56;
@@ -989,41 +1009,47 @@ SGX_KERNEL(512) k_blur_levels(SgxOrbGeom g, const SgxBlurTile *tiles, const uint
         SGX_THREADS_END
         SGX_SYNC();
     }
-    // horizontal pass: task = (row, 8-column segment); 14 source bytes from 5 aligned dwords realigned with v_alignbyte
+    // horizontal pass: task = (row, 8-column segment).  The 7 taps (18 34 48 56 48 34 18) / 256 are exact u8 weights: an output is TWO v_dot4_u32_u8 on byte windows
+    // (columns c .. c+3 against 18 34 48 56, columns c+4 .. c+7 against 48 34 18 0) cut out of the 16 staged bytes with v_alignbyte — 9 realignments + 16 dot products
+    // for 8 outputs instead of 16 byte extractions + 56 multiply-adds.  The 8.8 results are stored TRANSPOSED ([column][row], u16) so that the vertical pass finds the
+    // rows of a column as packed pairs.
     SGX_THREADS_BEGIN(tid)
     for (int k = tid; k < rows * (SGX_BT_W / 8); k += (int)blockDim.x) {
         const int r = k >> 3, sg = k & 7;
         if (8 * sg >= t.w) continue;
         const uint32_t *w = in_dw + (r * SGX_BT_IS + 8 * sg) / 4;
         const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
-        const uint32_t v0 = sgx_alignbyte(w1, w0, lead), v1 = sgx_alignbyte(w2, w1, lead), v2 = sgx_alignbyte(w3, w2, lead), v3 = sgx_alignbyte(w4, w3, lead);
-        int b[16];
+        uint32_t A[12];
+        A[0] = sgx_alignbyte(w1, w0, lead); A[4] = sgx_alignbyte(w2, w1, lead); A[8] = sgx_alignbyte(w3, w2, lead);
+        const uint32_t v3 = sgx_alignbyte(w4, w3, lead);
 #pragma unroll
-        for (int j = 0; j < 4; j++) { b[j] = (v0 >> (8 * j)) & 255; b[4 + j] = (v1 >> (8 * j)) & 255; b[8 + j] = (v2 >> (8 * j)) & 255; b[12 + j] = (v3 >> (8 * j)) & 255; }
-        uint32_t o[4];
+        for (int q = 1; q < 4; q++) { A[q] = sgx_alignbyte(A[4], A[0], q); A[4 + q] = sgx_alignbyte(A[8], A[4], q); A[8 + q] = sgx_alignbyte(v3, A[8], q); }
+        const uint32_t WLO = 18u | (34u << 8) | (48u << 16) | (56u << 24), WHI = 48u | (34u << 8) | (18u << 16);
 #pragma unroll
-        for (int c = 0; c < 8; c += 2) {
-            const uint32_t h0 = (uint32_t)(GK0 * (b[c] + b[c + 6]) + GK1 * (b[c + 1] + b[c + 5]) + GK2 * (b[c + 2] + b[c + 4]) + GK3 * b[c + 3]);
-            const uint32_t h1 = (uint32_t)(GK0 * (b[c + 1] + b[c + 7]) + GK1 * (b[c + 2] + b[c + 6]) + GK2 * (b[c + 3] + b[c + 5]) + GK3 * b[c + 4]);
-            o[c >> 1] = h0 | (h1 << 16);
-        }
-        uint32_t *dst = h_dw + (r * SGX_BT_HS + 8 * sg) / 2;
-        dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3];
+        for (int c = 0; c < 8; c++) hb[(8 * sg + c) * SGX_BT_HS + r] = (uint16_t)sgx_udot4(A[c], WLO, sgx_udot4(A[c + 4], WHI, 0u));      // <= 255 * 256: fits 16 bits
     }
     SGX_THREADS_END
     SGX_SYNC();
-    // vertical pass: task = (column, 8-row segment), 14 sliding reads per 8 outputs
+    // vertical pass: task = (column, 8-row segment).  Rows r0 .. r0+15 of the column are 8 aligned dwords = the row pairs starting at even rows; the odd-start pairs come
+    // from v_alignbyte; an output is FOUR v_dot2_u32_u16 (pairs j, j+2, j+4 against (18,34) (48,56) (48,34), pair j+6 against (18,0)) chained through the accumulator that
+    // starts at the rounding constant.  Exact integers: the bytes are those of the multiply-add version.
     SGX_THREADS_BEGIN(tid)
     for (int k = tid; k < 64 * ((SGX_BT_H + 7) / 8); k += (int)blockDim.x) {
         const int c = k & 63, sg = k >> 6, r0 = 8 * sg;
         if (c < t.w && r0 < t.h) {
-            uint32_t h[14];
+            const uint32_t *col = h_dw + (c * SGX_BT_HS + r0) / 2;
+            uint32_t P[14];                                               // P[j] = (h[r0 + j], h[r0 + j + 1])
 #pragma unroll
-            for (int j = 0; j < 14; j++) h[j] = (r0 + j < SGX_BT_H + 6) ? (uint32_t)hb[(r0 + j) * SGX_BT_HS + c] : 0u;
+            for (int q = 0; q < 7; q++) P[2 * q] = col[q];
+            const uint32_t last = col[7];
+#pragma unroll
+            for (int q = 0; q < 6; q++) P[2 * q + 1] = sgx_alignbyte(P[2 * q + 2], P[2 * q], 2);
+            P[13] = sgx_alignbyte(last, P[12], 2);
+            const uint32_t W0 = 18u | (34u << 16), W1 = 48u | (56u << 16), W2 = 48u | (34u << 16), W3 = 18u;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                const uint32_t acc = (uint32_t)GK0 * (h[j] + h[j + 6]) + (uint32_t)GK1 * (h[j + 1] + h[j + 5]) + (uint32_t)GK2 * (h[j + 2] + h[j + 4]) + (uint32_t)GK3 * h[j + 3];
-                ob[(r0 + j) * SGX_BT_W + c] = (uint8_t)((acc + 32768u) >> 16);
+                const uint32_t acc = sgx_udot2(P[j], W0, sgx_udot2(P[j + 2], W1, sgx_udot2(P[j + 4], W2, sgx_udot2(P[j + 6], W3, 32768u))));
+                if (r0 + j < SGX_BT_H) ob[(r0 + j) * SGX_BT_W + c] = (uint8_t)(acc >> 16);
             }
         }
     }
