@@ -970,98 +970,126 @@ struct SgxBlurTile { short level, x0, y0, w, h, pad0, pad1, pad2; };
 #define SGX_BT_IS 80            /* LDS row stride of the staged input (bytes): 3 lead + 3 + 64 + 3, dword aligned */
 #define SGX_BT_HS 66            /* COLUMN stride of the horizontal-pass buffer (u16): it is stored transposed, [column][row], 64 staged rows + 2 (33 dwords: odd -> the columns of a wave fall on different banks) */
 
+// Persistent and software-pipelined: a workgroup walks the work list with stride gridDim.x; the global loads of the NEXT tile are issued into registers right after the
+// horizontal pass (the staged input is dead from then on) and land in LDS after the vertical pass, so a tile costs its two passes and three barriers, not a load round trip
+// on top (the one-tile-per-workgroup form ran at 32 waves per CU that mostly waited: 6.8 us per tile).
+#define SGX_BT_PRE 5            /* staged dwords per thread: 64 rows x 20 dwords / 256 threads (the smallest workgroup the host launches) */
 SGX_KERNEL(512) k_blur_levels(SgxOrbGeom g, const SgxBlurTile *tiles, const uint8_t *gray, int gray_pitch, const uint8_t *pyr, uint8_t *blur, int batch)
 {
     SGX_LDS uint32_t in_dw[(SGX_BT_H + 6) * SGX_BT_IS / 4];
     SGX_LDS uint32_t h_dw[SGX_BT_W * SGX_BT_HS / 2 + 8];           // + the 8-dword read of the last column's last segment
     SGX_LDS uint32_t o_dw[SGX_BT_H * SGX_BT_W / 4];
+    SGX_PRIV_DECL(uint32_t, pre, SGX_BT_PRE, 512);
     uint8_t *in = (uint8_t *)in_dw; uint16_t *hb = (uint16_t *)h_dw; uint8_t *ob = (uint8_t *)o_dw;
-    const int GK0 = 18, GK1 = 34, GK2 = 48, GK3 = 56;
-    const int bid = (int)blockIdx.x, frame = bid % batch;
-    const SgxBlurTile t = tiles[bid / batch];
-    const SgxLevel L = g.lv[t.level];
-    int stride;
-    const uint8_t *img = sgx_level_ptr(g, gray, gray_pitch, pyr, frame, t.level, &stride);
-    const int rows = t.h + 6, xs = t.x0 - 3, ys = t.y0 - 3;
+    const int total = g.nblur_tiles * batch;
     // staging: always aligned dwords.  Rows outside the level are fetched from their BORDER_REFLECT_101 source row; dwords that would start outside the row
     // are clamped into it (their bytes are garbage) and the at most 3 + 3 halo columns that lie outside the level are then copied from their reflected
     // columns, which are always staged.  (A per-byte reflected loader for border tiles — 30 % of the tiles — cost more than the two blur passes.)
-    const int lead = xs & 3, xa = xs - lead, maxq = (stride >> 2) - 1;
-    SGX_THREADS_BEGIN(tid)
-    for (int i = tid; i < rows * (SGX_BT_IS / 4); i += (int)blockDim.x) {
-        const int r = i / (SGX_BT_IS / 4), q = i - r * (SGX_BT_IS / 4);
-        int yy = ys + r; yy = yy < 0 ? -yy : (yy >= L.h ? 2 * (L.h - 1) - yy : yy);
-        const int dq = min(max((xa >> 2) + q, 0), maxq);
-        in_dw[i] = ((const uint32_t *)(img + (size_t)yy * stride))[dq];
+#define SGX_BLUR_FETCH(W_, DST_)                                                                                                           \
+    {                                                                                                                                     \
+        const int f_ = (W_) % batch; const SgxBlurTile t_ = tiles[(W_) / batch]; const SgxLevel L_ = g.lv[t_.level]; int st_;             \
+        const uint8_t *img_ = sgx_level_ptr(g, gray, gray_pitch, pyr, f_, t_.level, &st_);                                                \
+        const int rows_ = t_.h + 6, xs_ = t_.x0 - 3, ys_ = t_.y0 - 3, xa_ = xs_ - (xs_ & 3), maxq_ = (st_ >> 2) - 1;                      \
+        for (int u_ = 0; u_ < SGX_BT_PRE; u_++) {                                                                                         \
+            const int i_ = tid + u_ * (int)blockDim.x;                                                                                    \
+            if (i_ < rows_ * (SGX_BT_IS / 4)) {                                                                                           \
+                const int r_ = i_ / (SGX_BT_IS / 4), q_ = i_ - r_ * (SGX_BT_IS / 4);                                                      \
+                int yy_ = ys_ + r_; yy_ = yy_ < 0 ? -yy_ : (yy_ >= L_.h ? 2 * (L_.h - 1) - yy_ : yy_);                                    \
+                const int dq_ = min(max((xa_ >> 2) + q_, 0), maxq_);                                                                      \
+                DST_[u_] = ((const uint32_t *)(img_ + (size_t)yy_ * st_))[dq_];                                                           \
+            }                                                                                                                             \
+        }                                                                                                                                 \
     }
+    if ((int)blockIdx.x >= total) return;
+    SGX_THREADS_BEGIN(tid)
+    SGX_PRIV_BIND(pre, tid);
+    SGX_BLUR_FETCH((int)blockIdx.x, pre)
+    for (int u = 0; u < SGX_BT_PRE; u++) { const int i = tid + u * (int)blockDim.x; if (i < (SGX_BT_H + 6) * (SGX_BT_IS / 4)) in_dw[i] = pre[u]; }
     SGX_THREADS_END
     SGX_SYNC();
-    if (xs < 0 || t.x0 + t.w + 3 > L.w) {
+    for (int w = (int)blockIdx.x; w < total; w += (int)gridDim.x) {
+        const int frame = w % batch, wn = w + (int)gridDim.x;
+        const SgxBlurTile t = tiles[w / batch];
+        const SgxLevel L = g.lv[t.level];
+        const int rows = t.h + 6, xs = t.x0 - 3;
+        const int lead = xs & 3;
+        if (xs < 0 || t.x0 + t.w + 3 > L.w) {
+            SGX_THREADS_BEGIN(tid)
+            for (int k = tid; k < rows * 6; k += (int)blockDim.x) {
+                const int r = k / 6, hc = k - r * 6;
+                const int x = hc < 3 ? xs + hc : t.x0 + t.w + (hc - 3);               // level column of this halo slot
+                if (x < 0 || x >= L.w) {
+                    const int xr = x < 0 ? -x : 2 * (L.w - 1) - x;
+                    in[r * SGX_BT_IS + lead + (x - xs)] = in[r * SGX_BT_IS + lead + (xr - xs)];
+                }
+            }
+            SGX_THREADS_END
+            SGX_SYNC();
+        }
+        // horizontal pass: task = (row, 8-column segment).  The 7 taps (18 34 48 56 48 34 18) / 256 are exact u8 weights: an output is TWO v_dot4_u32_u8 on byte windows
+        // (columns c .. c+3 against 18 34 48 56, columns c+4 .. c+7 against 48 34 18 0) cut out of the 16 staged bytes with v_alignbyte — 9 realignments + 16 dot products
+        // for 8 outputs instead of 16 byte extractions + 56 multiply-adds.  The 8.8 results are stored TRANSPOSED ([column][row], u16) so that the vertical pass finds the
+        // rows of a column as packed pairs.
         SGX_THREADS_BEGIN(tid)
-        for (int k = tid; k < rows * 6; k += (int)blockDim.x) {
-            const int r = k / 6, hc = k - r * 6;
-            const int x = hc < 3 ? xs + hc : t.x0 + t.w + (hc - 3);               // level column of this halo slot
-            if (x < 0 || x >= L.w) {
-                const int xr = x < 0 ? -x : 2 * (L.w - 1) - x;
-                in[r * SGX_BT_IS + lead + (x - xs)] = in[r * SGX_BT_IS + lead + (xr - xs)];
+        for (int k = tid; k < rows * (SGX_BT_W / 8); k += (int)blockDim.x) {
+            const int r = k >> 3, sg = k & 7;
+            if (8 * sg >= t.w) continue;
+            const uint32_t *w = in_dw + (r * SGX_BT_IS + 8 * sg) / 4;
+            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
+            uint32_t A[12];
+            A[0] = sgx_alignbyte(w1, w0, lead); A[4] = sgx_alignbyte(w2, w1, lead); A[8] = sgx_alignbyte(w3, w2, lead);
+            const uint32_t v3 = sgx_alignbyte(w4, w3, lead);
+    #pragma unroll
+            for (int q = 1; q < 4; q++) { A[q] = sgx_alignbyte(A[4], A[0], q); A[4 + q] = sgx_alignbyte(A[8], A[4], q); A[8 + q] = sgx_alignbyte(v3, A[8], q); }
+            const uint32_t WLO = 18u | (34u << 8) | (48u << 16) | (56u << 24), WHI = 48u | (34u << 8) | (18u << 16);
+    #pragma unroll
+            for (int c = 0; c < 8; c++) hb[(8 * sg + c) * SGX_BT_HS + r] = (uint16_t)sgx_udot4(A[c], WLO, sgx_udot4(A[c + 4], WHI, 0u));      // <= 255 * 256: fits 16 bits
+        }
+        SGX_THREADS_END
+        // the next tile's loads leave now; their latency hides behind the vertical pass
+        SGX_THREADS_BEGIN(tid)
+        SGX_PRIV_BIND(pre, tid);
+        if (wn < total) SGX_BLUR_FETCH(wn, pre)
+        SGX_THREADS_END
+        SGX_SYNC();
+        // vertical pass: task = (column, 8-row segment).  Rows r0 .. r0+15 of the column are 8 aligned dwords = the row pairs starting at even rows; the odd-start pairs come
+        // from v_alignbyte; an output is FOUR v_dot2_u32_u16 (pairs j, j+2, j+4 against (18,34) (48,56) (48,34), pair j+6 against (18,0)) chained through the accumulator that
+        // starts at the rounding constant.  Exact integers: the bytes are those of the multiply-add version.
+        SGX_THREADS_BEGIN(tid)
+        for (int k = tid; k < 64 * ((SGX_BT_H + 7) / 8); k += (int)blockDim.x) {
+            const int c = k & 63, sg = k >> 6, r0 = 8 * sg;
+            if (c < t.w && r0 < t.h) {
+                const uint32_t *col = h_dw + (c * SGX_BT_HS + r0) / 2;
+                uint32_t P[14];                                               // P[j] = (h[r0 + j], h[r0 + j + 1])
+    #pragma unroll
+                for (int q = 0; q < 7; q++) P[2 * q] = col[q];
+                const uint32_t last = col[7];
+    #pragma unroll
+                for (int q = 0; q < 6; q++) P[2 * q + 1] = sgx_alignbyte(P[2 * q + 2], P[2 * q], 2);
+                P[13] = sgx_alignbyte(last, P[12], 2);
+                const uint32_t W0 = 18u | (34u << 16), W1 = 48u | (56u << 16), W2 = 48u | (34u << 16), W3 = 18u;
+    #pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t acc = sgx_udot2(P[j], W0, sgx_udot2(P[j + 2], W1, sgx_udot2(P[j + 4], W2, sgx_udot2(P[j + 6], W3, 32768u))));
+                    if (r0 + j < SGX_BT_H) ob[(r0 + j) * SGX_BT_W + c] = (uint8_t)(acc >> 16);
+                }
             }
         }
         SGX_THREADS_END
+        SGX_THREADS_BEGIN(tid)
+        SGX_PRIV_BIND(pre, tid);
+        if (wn < total) for (int u = 0; u < SGX_BT_PRE; u++) { const int i = tid + u * (int)blockDim.x; if (i < (SGX_BT_H + 6) * (SGX_BT_IS / 4)) in_dw[i] = pre[u]; }
+        SGX_THREADS_END
         SGX_SYNC();
-    }
-    // horizontal pass: task = (row, 8-column segment).  The 7 taps (18 34 48 56 48 34 18) / 256 are exact u8 weights: an output is TWO v_dot4_u32_u8 on byte windows
-    // (columns c .. c+3 against 18 34 48 56, columns c+4 .. c+7 against 48 34 18 0) cut out of the 16 staged bytes with v_alignbyte — 9 realignments + 16 dot products
-    // for 8 outputs instead of 16 byte extractions + 56 multiply-adds.  The 8.8 results are stored TRANSPOSED ([column][row], u16) so that the vertical pass finds the
-    // rows of a column as packed pairs.
-    SGX_THREADS_BEGIN(tid)
-    for (int k = tid; k < rows * (SGX_BT_W / 8); k += (int)blockDim.x) {
-        const int r = k >> 3, sg = k & 7;
-        if (8 * sg >= t.w) continue;
-        const uint32_t *w = in_dw + (r * SGX_BT_IS + 8 * sg) / 4;
-        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
-        uint32_t A[12];
-        A[0] = sgx_alignbyte(w1, w0, lead); A[4] = sgx_alignbyte(w2, w1, lead); A[8] = sgx_alignbyte(w3, w2, lead);
-        const uint32_t v3 = sgx_alignbyte(w4, w3, lead);
-#pragma unroll
-        for (int q = 1; q < 4; q++) { A[q] = sgx_alignbyte(A[4], A[0], q); A[4 + q] = sgx_alignbyte(A[8], A[4], q); A[8 + q] = sgx_alignbyte(v3, A[8], q); }
-        const uint32_t WLO = 18u | (34u << 8) | (48u << 16) | (56u << 24), WHI = 48u | (34u << 8) | (18u << 16);
-#pragma unroll
-        for (int c = 0; c < 8; c++) hb[(8 * sg + c) * SGX_BT_HS + r] = (uint16_t)sgx_udot4(A[c], WLO, sgx_udot4(A[c + 4], WHI, 0u));      // <= 255 * 256: fits 16 bits
-    }
-    SGX_THREADS_END
-    SGX_SYNC();
-    // vertical pass: task = (column, 8-row segment).  Rows r0 .. r0+15 of the column are 8 aligned dwords = the row pairs starting at even rows; the odd-start pairs come
-    // from v_alignbyte; an output is FOUR v_dot2_u32_u16 (pairs j, j+2, j+4 against (18,34) (48,56) (48,34), pair j+6 against (18,0)) chained through the accumulator that
-    // starts at the rounding constant.  Exact integers: the bytes are those of the multiply-add version.
-    SGX_THREADS_BEGIN(tid)
-    for (int k = tid; k < 64 * ((SGX_BT_H + 7) / 8); k += (int)blockDim.x) {
-        const int c = k & 63, sg = k >> 6, r0 = 8 * sg;
-        if (c < t.w && r0 < t.h) {
-            const uint32_t *col = h_dw + (c * SGX_BT_HS + r0) / 2;
-            uint32_t P[14];                                               // P[j] = (h[r0 + j], h[r0 + j + 1])
-#pragma unroll
-            for (int q = 0; q < 7; q++) P[2 * q] = col[q];
-            const uint32_t last = col[7];
-#pragma unroll
-            for (int q = 0; q < 6; q++) P[2 * q + 1] = sgx_alignbyte(P[2 * q + 2], P[2 * q], 2);
-            P[13] = sgx_alignbyte(last, P[12], 2);
-            const uint32_t W0 = 18u | (34u << 16), W1 = 48u | (56u << 16), W2 = 48u | (34u << 16), W3 = 18u;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const uint32_t acc = sgx_udot2(P[j], W0, sgx_udot2(P[j + 2], W1, sgx_udot2(P[j + 4], W2, sgx_udot2(P[j + 6], W3, 32768u))));
-                if (r0 + j < SGX_BT_H) ob[(r0 + j) * SGX_BT_W + c] = (uint8_t)(acc >> 16);
-            }
+        SGX_THREADS_BEGIN(tid)
+        uint8_t *dst = blur + (size_t)frame * g.blur_pitch + L.boff;
+        for (int i = tid; i < t.h * (SGX_BT_W / 4); i += (int)blockDim.x) {
+            const int r = i >> 4, q = i & 15;
+            if (4 * q < t.w) *(uint32_t *)(dst + (size_t)(t.y0 + r) * L.bstride + t.x0 + 4 * q) = o_dw[i];        // rows are padded to 64 bytes: the last dword may spill into the padding
         }
+        SGX_THREADS_END
     }
-    SGX_THREADS_END
-    SGX_SYNC();
-    SGX_THREADS_BEGIN(tid)
-    uint8_t *dst = blur + (size_t)frame * g.blur_pitch + L.boff;
-    for (int i = tid; i < t.h * (SGX_BT_W / 4); i += (int)blockDim.x) {
-        const int r = i >> 4, q = i & 15;
-        if (4 * q < t.w) *(uint32_t *)(dst + (size_t)(t.y0 + r) * L.bstride + t.x0 + 4 * q) = o_dw[i];        // rows are padded to 64 bytes: the last dword may spill into the padding
-    }
-    SGX_THREADS_END
+#undef SGX_BLUR_FETCH
 }
 
 // ---------------------------------------------------------------------------------------------

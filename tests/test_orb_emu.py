@@ -180,3 +180,18 @@ def test_portrait_geometry_is_refused(emu, oracle):
         oracle.orb_extract(np.zeros((579, 264), np.uint8))
     e = ORBextractor(lib=emu, width=300, height=560, nlevels=2)          # (300 - 32) / (560 - 32) = 0.51, (250 - 32) / (467 - 32) = 0.50 -> one root node per level: fine
     e.close()
+
+
+def test_persistent_blur_walks_its_work_list(ex, oracle, stream_frames, monkeypatch):
+    """k_blur_levels is persistent: with fewer workgroups than (tile, frame) work items every workgroup blurs several tiles, fetching the next tile's pixels while it
+    works on the current one.  Eight workgroups for the ~600 tiles of two frames: descriptors still bit-exact."""
+    monkeypatch.setenv('SGX_TUNE_ORB_BLUR_GRID', '8')
+    g0, _, _ = stream_frames.frame(3); g1, _, _ = stream_frames.frame(11)
+    from sg_slam_amd.capi import KP_DTYPE
+    cap = ex.capacity
+    kps = np.zeros((2, cap), KP_DTYPE); desc = np.zeros((2, cap, 32), np.uint8); cnt = np.zeros(2, 'i4')
+    ex.extract_batch_dev(np.stack([g0, g1]), 640, 2, kps, desc, cnt)
+    ex.last_status()
+    for b, g in enumerate((g0, g1)):
+        ko, do = oracle.orb_extract(g)
+        assert _same(kps[b, :cnt[b]], desc[b, :cnt[b]], ko, do)
