@@ -89,3 +89,28 @@ def run_envelope_solver_equals_dense(lib, nkf, npt, env_mode, two_branch=None):
 def test_envelope_solver_equals_dense_emu(emu):
     run_envelope_solver_equals_dense(emu, 60, 1500, 2, two_branch=False)          # forced (the automatic choice needs more than 1 024 unknowns); 12 tiles: one branch
     run_envelope_solver_equals_dense(emu, 150, 3600, 2, two_branch=True)          # 28 tiles: two branches + separator
+
+
+def run_two_branch_matches_oracle(lib, oracle, nkf, npt, solver_mode):
+    """The two-branch envelope solver (band eliminated from both ends by two workgroups + separator) against the ORACLE's dense solve on the same bundle adjustment —
+    not against this library's own dense path: identical LM iteration counts and erase flags, poses / points / chi2 within the parity tolerance."""
+    from scenes import make_big_ba_problem
+    prob, _, _ = make_big_ba_problem(nkf, npt)
+    eposes, epoints, eerase, etrace, eiters = oracle.local_ba(prob, CAM)
+    p2 = {k: (v.copy() if hasattr(v, 'copy') else v) for k, v in prob.items()}
+    lib.dll.sgx_ba_debug_set_solver(solver_mode)
+    try:
+        erase, stats = Optimizer.LocalBundleAdjustment(p2, CAM, lib=lib)
+        pl = (C.c_int32 * 4)(); lib.check(lib.dll.sgx_ba_debug_last_plan(pl))
+    finally:
+        lib.dll.sgx_ba_debug_set_solver(-1)
+    assert pl[0] == 1 and pl[1] > 0 and pl[2] > 0 and pl[3] > 0, tuple(pl)
+    assert stats['iterations'] == tuple(eiters)
+    assert (erase == eerase).all()
+    assert close(p2['poses'], eposes) and points_close(p2['points'], epoints)
+    ref = etrace[1, eiters[1] - 1, 0]
+    assert abs(stats['chi2'][1] - ref) <= 1e-5 * max(1.0, ref)
+
+
+def test_two_branch_solver_matches_oracle_emu(emu, oracle):
+    run_two_branch_matches_oracle(emu, oracle, 160, 4000, 2)          # 954 unknowns = 30 tiles (forced: the automatic choice starts above 1 024 unknowns)

@@ -28,6 +28,11 @@ def test_envelope_solver_equals_dense_gpu(gpulib):
     run_envelope_solver_equals_dense(gpulib, 600, 15000, 0)      # automatic choice: 3 594 unknowns, narrow covisibility band
 
 
+def test_two_branch_solver_matches_oracle_gpu(gpulib, oracle):
+    from test_localba import run_two_branch_matches_oracle
+    run_two_branch_matches_oracle(gpulib, oracle, 400, 10000, -1)    # 2 394 unknowns = 75 tiles, automatic solver choice; the oracle's dense solve takes ~20 s
+
+
 def test_gpu_stop_flag(gpulib, oracle):
     prob, _, _ = make_ba_problem(oracle, seed=5)
     p2 = {k: (v.copy() if hasattr(v, 'copy') else v) for k, v in prob.items()}
