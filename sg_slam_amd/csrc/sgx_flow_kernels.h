@@ -270,6 +270,18 @@ SGX_DEV uint32_t sgx_as_u32(sgx_i16x2 v) { return __builtin_bit_cast(uint32_t, v
 /* (high half of p, low half of q): the pair one 16-bit element further along a row of pairs */
 SGX_DEV sgx_i16x2 sgx_lk_next(sgx_i16x2 p, sgx_i16x2 q) { return sgx_as_i16x2(__builtin_amdgcn_alignbit(sgx_as_u32(q), sgx_as_u32(p), 16)); }
 #define SGX_LK_DOT2(a, b, c) __builtin_amdgcn_sdot2((a), (b), (c), false)
+/* the same dot product with a SEPARATE destination (v_dot2_i32_i16, the VOP3P form): for an accumulator operand that must survive — the compiler picks the two-address
+ * v_dot2c and copies the operand first (one v_mov per window sample and iteration in the tracker's inner loop) */
+SGX_DEV int sgx_lk_dot2_keep(sgx_i16x2 a, sgx_i16x2 b, int c)
+{
+#ifndef SGX_EMU
+    int d;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+#else
+    return SGX_LK_DOT2(a, b, c);
+#endif
+}
 
 /* stage the ROWS x 36-byte patch of `img` whose top-left corner is (ox, oy) (ox a multiple of 4) into the wave's LDS tile: REFLECT_101 outside the
  * image, aligned dwords wherever the image allows.  Lane -> (row within a group of seven, dword column): 63 lanes move seven tile rows per pass. */
@@ -668,7 +680,7 @@ SGX_KERNEL_OCC(256, (KPW == 4 ? 3 : 5)) k_lk_trackN(SgxLkGeom g, SgxLkArgs A)
                     __builtin_memcpy(a, tb, 8); __builtin_memcpy(b, tb + SGX_LK4_PITCH, 8);
 #pragma unroll
                     for (int c = 0; c < 7; c++) {
-                        const int diff = SGX_LK_DOT2(SGX_LK_PAIR(b[1], b[0], c, c + 1), W1, SGX_LK_DOT2(SGX_LK_PAIR(a[1], a[0], c, c + 1), W0, ivb[q][c])) >> 9;
+                        const int diff = SGX_LK_DOT2(SGX_LK_PAIR(b[1], b[0], c, c + 1), W1, sgx_lk_dot2_keep(SGX_LK_PAIR(a[1], a[0], c, c + 1), W0, ivb[q][c])) >> 9;
                         sb1 = sgx_mad_lo16(diff, ixy[q][c], sb1); sb2 = sgx_mad_hi16(diff, ixy[q][c], sb2);      /* |diff| <= 255 * 32 fits 16 bits; ix = iy = 0 on the idle slot */
                     }
                 }
