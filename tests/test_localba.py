@@ -60,11 +60,26 @@ def test_emu_matches_oracle(emu, oracle, seed, n_free, n_fixed, n_points):
     assert abs(stats['chi2'][1] - etrace[1, eiters[1] - 1, 0]) <= 1e-5 * max(1.0, etrace[1, eiters[1] - 1, 0])   # residual within 1e-5 relative
 
 
-def run_envelope_solver_equals_dense(lib, nkf, npt, env_mode, two_branch=None):
+def open_trajectory(prob, nkf, margin=16):
+    """make_big_ba_problem closes the trajectory on itself (landmarks based near the last keyframe are also seen from the first ones); drop those wrap-around observations so
+    that the reduced system is a plain band without the cyclic corner"""
+    ep, el = prob['edge_pose'], prob['edge_point']
+    first = np.full(el.max() + 1, 1 << 30); np.minimum.at(first, el, ep)
+    last = np.full(el.max() + 1, -1); np.maximum.at(last, el, ep)
+    wrap = (last[el] - first[el] > nkf // 2) & (ep < margin)          # a landmark seen from both ends: keep its observations near the end only
+    keep = ~wrap
+    cnt = np.bincount(el[keep], minlength=el.max() + 1); keep &= cnt[el] >= 2
+    out = dict(prob)
+    for k in ('edge_pose', 'edge_point', 'edge_obs', 'edge_info'): out[k] = prob[k][keep]
+    return out
+
+
+def run_envelope_solver_equals_dense(lib, nkf, npt, env_mode, two_branch=None, open_ends=False):
     """The narrow-envelope solver of the reduced camera system (one persistent workgroup walking the covisibility band, k_chol_env_factor / k_chol_env_back) against the
     dense blocked Cholesky on the same bundle adjustment: identical iteration counts and erase flags, poses / points / chi2 to rounding."""
     from scenes import make_big_ba_problem
     prob, _, _ = make_big_ba_problem(nkf, npt)
+    if open_ends: prob = open_trajectory(prob, nkf)
     out = {}; plans = {}
     nkf_free = int((np.asarray(prob['pose_fixed']) == 0).sum())
     try:
@@ -89,6 +104,7 @@ def run_envelope_solver_equals_dense(lib, nkf, npt, env_mode, two_branch=None):
 def test_envelope_solver_equals_dense_emu(emu):
     run_envelope_solver_equals_dense(emu, 60, 1500, 2, two_branch=False)          # forced (the automatic choice needs more than 1 024 unknowns); 12 tiles: one branch
     run_envelope_solver_equals_dense(emu, 150, 3600, 2, two_branch=True)          # 28 tiles: two branches + separator
+    run_envelope_solver_equals_dense(emu, 171, 4000, 2, two_branch=True, open_ends=True)      # an open trajectory (no cyclic corner), a free-pose count that is not a multiple of 16
 
 
 def run_two_branch_matches_oracle(lib, oracle, nkf, npt, solver_mode):
