@@ -22,6 +22,7 @@
 #include <cmath>
 #include <chrono>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #define SGX_CHECK_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
@@ -109,39 +110,70 @@ static int read_trial(BA &B, int *ok, double *scale, double *chi)
 // sequentially, without atomics.  Built block row by block row: the jobs of row i1 come from the edges of that pose (pose_edges_l: ascending landmark) x the active edges of
 // their landmarks, and are dealt to their i2 with a counting sort over the few poses the row touches — everything a row needs sits in L1 / L2 (a sort of the whole list by
 // the nf^2 keys was 30 ms per call at 2 000 keyframes: a third of the bundle adjustment).
+// level1 == nullptr: build from scratch (every edge of a free pose is active).  level1 != nullptr: the list of the SAME problem after the classification pass — the previous list
+// with the jobs of the newly switched-off edges taken out (a stable filter of the sorted list: a few ms instead of a rebuild).
 static int build_jobs(BA &B, const std::vector<int> &pt_start, const std::vector<int> &pt_edges, const std::vector<int> &pose_start, const std::vector<int> &pose_edges_l,
-                      const std::vector<SgxBaEdge> &E, const std::vector<uint8_t> &level1, const std::vector<int> &hidx, const std::vector<int> &free_pose)
+                      const std::vector<SgxBaEdge> &E, const std::vector<uint8_t> *level1, const std::vector<int> &hidx, const std::vector<int> &free_pose)
 {
-    static thread_local std::vector<SgxBaJob> sorted, grp;
-    static thread_local std::vector<int> blk_start, grp_h2, touched, cnt, eh;
-    sorted.clear(); blk_start.clear();
-    eh.resize(B.ne);
-    for (int k = 0; k < B.ne; k++) eh[k] = level1[k] ? -1 : hidx[E[k].pose];                    // destination row / column of an active edge, -1 = not in the system
-    cnt.assign(B.nf > 0 ? B.nf : 1, 0);
-    for (int h1 = 0; h1 < B.nf; h1++) {
-        const int p = free_pose[h1];
-        grp.clear(); grp_h2.clear(); touched.clear();
-        for (int q = pose_start[p]; q < pose_start[p + 1]; q++) {
-            const int k1 = pose_edges_l[q]; if (eh[k1] < 0) continue;
-            const int l = E[k1].point;
-            for (int q2 = pt_start[l]; q2 < pt_start[l + 1]; q2++) {
-                const int k2 = pt_edges[q2], h2 = eh[k2]; if (h2 < 0) continue;
-                if (cnt[h2]++ == 0) touched.push_back(h2);
-                grp.push_back(SgxBaJob{k1, k2}); grp_h2.push_back(h2);
-            }
+    static thread_local std::vector<SgxBaJob> sorted;
+    static thread_local std::vector<int> blk_start;
+    if (level1 && !sorted.empty() && (long long)sorted.size() == B.njobs) {
+        const std::vector<uint8_t> &lv = *level1;
+        size_t w = 0, nb = 0;
+        const size_t nblk = blk_start.size() - 1;
+        for (size_t b = 0; b < nblk; b++) {
+            const size_t beg = (size_t)blk_start[b], end = (size_t)blk_start[b + 1], w0 = w;
+            for (size_t i = beg; i < end; i++) { const SgxBaJob j = sorted[i]; if (!lv[(size_t)j.k1] && !lv[(size_t)j.k2]) sorted[w++] = j; }
+            if (w > w0) blk_start[nb++] = (int)w0;
         }
-        if (grp.empty()) continue;
-        if (sorted.size() + grp.size() > B.jobs_cap) { for (int h2 : touched) cnt[h2] = 0; return SGX_ERR_NOMEM; }
-        std::sort(touched.begin(), touched.end());
-        const size_t base = sorted.size();
-        { int run = 0; for (int h2 : touched) { const int c = cnt[h2]; cnt[h2] = run; blk_start.push_back((int)base + run); run += c; } }
-        sorted.resize(base + grp.size());
-        for (size_t i = 0; i < grp.size(); i++) sorted[base + (size_t)cnt[grp_h2[i]]++] = grp[i];
-        for (int h2 : touched) cnt[h2] = 0;
+        sorted.resize(w); blk_start.resize(nb + 1); blk_start[nb] = (int)w;
+    } else {
+        const int nthreads = std::max(1, std::min(8, B.nf / 64));
+        std::vector<int> eh(B.ne);
+        for (int k = 0; k < B.ne; k++) eh[k] = (level1 && (*level1)[k]) ? -1 : hidx[E[k].pose];      // destination row / column of an active edge, -1 = not in the system
+        // block rows dealt to the threads in contiguous ranges of about equal edge counts
+        std::vector<int> cut(nthreads + 1, B.nf); cut[0] = 0;
+        { long long tot = 0; for (int h = 0; h < B.nf; h++) tot += pose_start[free_pose[h] + 1] - pose_start[free_pose[h]];
+          long long run = 0; int t = 1; for (int h = 0; h < B.nf && t < nthreads; h++) { run += pose_start[free_pose[h] + 1] - pose_start[free_pose[h]]; if (run * nthreads >= tot * t) cut[t++] = h + 1; } }
+        std::vector<std::vector<SgxBaJob>> part((size_t)nthreads); std::vector<std::vector<int>> pblk((size_t)nthreads);
+        auto work = [&](int t) {
+            std::vector<SgxBaJob> &out = part[(size_t)t], grp; std::vector<int> &ob = pblk[(size_t)t], grp_h2, touched, cnt((size_t)(B.nf > 0 ? B.nf : 1), 0);
+            for (int h1 = cut[t]; h1 < cut[t + 1]; h1++) {
+                const int p = free_pose[h1];
+                grp.clear(); grp_h2.clear(); touched.clear();
+                for (int q = pose_start[p]; q < pose_start[p + 1]; q++) {
+                    const int k1 = pose_edges_l[q]; if (eh[k1] < 0) continue;
+                    const int l = E[k1].point;
+                    for (int q2 = pt_start[l]; q2 < pt_start[l + 1]; q2++) {
+                        const int k2 = pt_edges[q2], h2 = eh[k2]; if (h2 < 0) continue;
+                        if (cnt[h2]++ == 0) touched.push_back(h2);
+                        grp.push_back(SgxBaJob{k1, k2}); grp_h2.push_back(h2);
+                    }
+                }
+                if (grp.empty()) continue;
+                std::sort(touched.begin(), touched.end());
+                const size_t base = out.size();
+                { int run = 0; for (int h2 : touched) { const int c = cnt[h2]; cnt[h2] = run; ob.push_back((int)base + run); run += c; } }
+                out.resize(base + grp.size());
+                for (size_t i = 0; i < grp.size(); i++) out[base + (size_t)cnt[grp_h2[i]]++] = grp[i];
+                for (int h2 : touched) cnt[h2] = 0;
+            }
+        };
+        if (nthreads == 1) work(0);
+        else { std::vector<std::thread> th; for (int t = 0; t < nthreads; t++) th.emplace_back(work, t); for (auto &x : th) x.join(); }
+        size_t total = 0; for (auto &v : part) total += v.size();
+        if (total > B.jobs_cap) return SGX_ERR_NOMEM;
+        sorted.resize(total); blk_start.clear();
+        size_t off = 0;
+        for (int t = 0; t < nthreads; t++) {
+            if (!part[(size_t)t].empty()) memcpy(sorted.data() + off, part[(size_t)t].data(), sizeof(SgxBaJob) * part[(size_t)t].size());
+            for (int b : pblk[(size_t)t]) blk_start.push_back((int)off + b);
+            off += part[(size_t)t].size();
+        }
+        blk_start.push_back((int)total);
     }
     B.njobs = (long long)sorted.size(); B.nblk = 0;
     if (sorted.empty()) return SGX_OK;
-    blk_start.push_back((int)sorted.size());
     B.nblk = (long long)blk_start.size() - 1;
     SGX_CHECK_HIP(hipMemcpy(B.jobs, sorted.data(), sizeof(SgxBaJob) * sorted.size(), hipMemcpyHostToDevice));
     SGX_CHECK_HIP(hipMemcpy(B.blk_start, blk_start.data(), sizeof(int) * blk_start.size(), hipMemcpyHostToDevice));
@@ -376,7 +408,8 @@ static int ba_run(const sgx_ba_problem *P, const sgx_camera *cam, const volatile
                         const int u0 = 6 * pos[h], t0 = u0 / SGX_NB, t1 = (u0 + 5) / SGX_NB;
                         tl.push_back(t0); if (t1 != t0) tl.push_back(t1);
                     }
-                    for (size_t a = 0; a < tl.size(); a++) for (size_t b = 0; b < tl.size(); b++) if (tl[a] > tl[b]) pat[(size_t)tl[a] * nt + tl[b]] = 1;
+                    std::sort(tl.begin(), tl.end()); tl.erase(std::unique(tl.begin(), tl.end()), tl.end());      // a landmark's poses sit on a few tiles
+                    for (size_t a = 0; a < tl.size(); a++) for (size_t b = 0; b < a; b++) pat[(size_t)tl[a] * nt + tl[b]] = 1;
                 }
                 // a pose that straddles two tiles couples them even without a landmark
                 for (int h = 0; h < B.nf; h++) { const int u0 = 6 * h, t0 = u0 / SGX_NB, t1 = (u0 + 5) / SGX_NB; if (t1 != t0) pat[(size_t)t1 * nt + t0] = 1; }
@@ -481,7 +514,7 @@ static int ba_run(const sgx_ba_problem *P, const sgx_camera *cam, const volatile
     lap("arena + upload");
     int it1 = 0, it2 = 0; double chi1 = 0, chi2 = 0;
     std::vector<uint8_t> level1(B.ne, 0);
-    rc = build_jobs(B, pt_start, pt_edges, pose_start, pose_edges_l, E, level1, hidx, free_pose); if (rc != SGX_OK) return rc;
+    rc = build_jobs(B, pt_start, pt_edges, pose_start, pose_edges_l, E, nullptr, hidx, free_pose); if (rc != SGX_OK) return rc;
     lap("schur job list 1");
     rc = optimize(B, mode == 1 ? n_iterations : 5, &it1, &chi1); if (rc != SGX_OK) return rc;   // Optimizer.cc:659-660 / :187-188
     lap("optimize 1");
@@ -491,7 +524,7 @@ static int ba_run(const sgx_ba_problem *P, const sgx_camera *cam, const volatile
             std::vector<SgxBaEdge> Eh(B.ne);
             SGX_CHECK_HIP(hipMemcpy(Eh.data(), B.E, sizeof(SgxBaEdge) * B.ne, hipMemcpyDeviceToHost));
             for (int k = 0; k < B.ne; k++) level1[k] = (Eh[k].flags & 2) ? 1 : 0;
-            rc = build_jobs(B, pt_start, pt_edges, pose_start, pose_edges_l, E, level1, hidx, free_pose); if (rc != SGX_OK) return rc;
+            rc = build_jobs(B, pt_start, pt_edges, pose_start, pose_edges_l, E, &level1, hidx, free_pose); if (rc != SGX_OK) return rc;
         }
         lap("classify + job list 2");
         rc = optimize(B, 10, &it2, &chi2); if (rc != SGX_OK) return rc;
