@@ -911,6 +911,39 @@ SGX_KERNEL(SGX_ENV_THREADS) k_chol_env_factor(int n, int nt, const int *rstart, 
         if (m > 0) {
             const double *Lk = Linv + (size_t)k * SGX_NB * SGX_NB;
             // ---- panel: L_rk = A_rk Linv_kk^T for r in R(k) (wave g takes row tile g), then x_r -= L_rk y_k
+#ifndef SGX_EMU
+            {   // a row tile belongs to ONE wave from the load to the forward substitution: only Linv_kk / y_k are shared, so one workgroup barrier (after staging) and wave-level
+                // ordering inside (the emulator keeps the four barrier-separated phases below: it runs the threads of a phase one after the other)
+                const int tid = (int)threadIdx.x, g = tid >> 6, lane = tid & 63;
+                for (int t = tid; t < SGX_NB * SGX_NB; t += SGX_ENV_THREADS) { const int r = t >> SGX_NB_SHIFT, c = t & (SGX_NB - 1); LiT[c][r] = Lk[t]; }
+                if (tid < SGX_NB) yk[tid] = tid < nb ? x[k0 + tid] : 0.0;                                          // y_k for the forward substitution
+                const int r0 = g < m ? rows[q0 + g] * SGX_NB : 0, nr = min(SGX_NB, n - r0);
+                if (g < m) {
+                    for (int t = lane; t < SGX_NB * SGX_NB; t += 64) {
+                        const int r = t >> SGX_NB_SHIFT, c = t & (SGX_NB - 1);
+                        pool[g][c][r] = (r < nr && c < nb) ? S[(size_t)(r0 + r) * n + k0 + c] : 0.0;
+                    }
+                }
+                __syncthreads();
+                if (g < m) {
+                    double a16[16];
+                    sgx_wave_gemm_nt(pool[g], LiT, lane >> 3, lane & 7, a16);                                          // out[r][c] = sum_q A[r][q] Linv[c][q]
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();            // every lane has read A_rk before L_rk replaces it
+                    const int ty = lane >> 3, tx = lane & 7;
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const int r = 4 * ty + i, c = 4 * tx + j;
+                            pool[g][c][r] = a16[4 * i + j];
+                            if (r < nr && c < nb) S[(size_t)(r0 + r) * n + k0 + c] = a16[4 * i + j];
+                        }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+                    double *xr = r0 >= sep0 ? xs : x;                                                                   // second branch: separator rows accumulate in x2
+                    if (lane < nr) { double vv = xr[r0 + lane]; for (int q = 0; q < nb; q++) vv -= pool[g][q][lane] * yk[q]; xr[r0 + lane] = vv; }      // forward substitution
+                }
+            }
+#else
             SGX_THREADS_BEGIN(tid)
             for (int t = tid; t < SGX_NB * SGX_NB; t += SGX_ENV_THREADS) { const int r = t >> SGX_NB_SHIFT, c = t & (SGX_NB - 1); LiT[c][r] = Lk[t]; }
             if (tid < SGX_NB) yk[tid] = tid < nb ? x[k0 + tid] : 0.0;                                              // y_k for the forward substitution
@@ -954,6 +987,7 @@ SGX_KERNEL(SGX_ENV_THREADS) k_chol_env_factor(int n, int nt, const int *rstart, 
                 if (lane < nr) { double vv = xr[r0 + lane]; for (int q = 0; q < nb; q++) vv -= pool[g][q][lane] * yk[q]; xr[r0 + lane] = vv; }      // forward substitution
             }
             SGX_THREADS_END
+#endif
             SGX_SYNC();                                                                                            // x_{k+1} is complete before wave 0 turns it into y_{k+1}
         }
         // ---- updates A_rc -= L_rk L_ck^T for the pairs r >= c of R(k), and — at the same time, on wave 0 — diagonal tile k + 1
