@@ -92,9 +92,10 @@ def main():
     ap.add_argument('--config2-only', action='store_true', help='measure only the configs[1] chain (no detector, no LK / RANSAC; mask inputs from the synthetic ground truth)')
     ap.add_argument('--param', default=os.path.join(ROOT, 'tests', 'golden', 'mobilenetv3_ssdlite_voc.param'), help='ncnn .param of the detector (the graph the reference ships)')
     ap.add_argument('--bin', default='', help='ncnn .bin weights of the detector (absent from the reference tree; default: synthetic weights in .bin order)')
-    ap.add_argument('--person-logit', type=float, default=-4.0, help='synthetic detector weights only: offset of the person-class logit.  Random weights report large random "person" boxes; '
-                    'the mask then erases most static keypoints inside them (0.2 px rule) and streams get lost.  -4 (default): practically no person detections, the mask works with its '
-                    '1.0 px rule; +2: ~7 random boxes per frame (tests/test_detector_mask_gpu.py checks that data flow)')
+    ap.add_argument('--person-logit', type=float, default=-1.5, help='synthetic detector weights only: offset of the person-class logit.  Random weights report large random "person" boxes; '
+                    'the mask then erases most static keypoints inside them (0.2 px rule) and streams get lost.  -1.5 (default since round 3): a person box in every second or third frame, so '
+                    'the 0.2 px person-box branch of the mask runs in the timed region while all streams keep tracking (measured: -1 -> 0.9 boxes per frame, still 512 / 512 tracked; -0.5 -> one '
+                    'stream lost); -4: practically no person detections (rounds 1-2); +2: ~7 random boxes per frame (tests/test_detector_mask_gpu.py checks that data flow)')
     ap.add_argument('--tum', default='', help='TUM RGB-D sequence directory (rgb/ depth/ associations.txt [groundtruth.txt]): the streams are consecutive chunks of the sequence')
     ap.add_argument('--save-trajectory', default='', help='write stream 0 of rank 0 as a TUM trajectory file (System::SaveTrajectoryTUM format)')
     ap.add_argument('--cpu-sample', type=int, default=120, help='frames timed on the CPU oracle')
