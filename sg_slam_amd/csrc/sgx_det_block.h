@@ -386,12 +386,12 @@ SGX_KERNEL(SGX_FB2_THREADS) k_fused_block2(int Cmid, int H, int W, int Ho, int W
             for (int jp = 0; jp < G::PAIRS_IN; jp++) {
                 const sgx_f2 sv = sp[jp];
                 const int e0 = eidx[2 * jp], e1 = eidx[2 * jp + 1];
-                if (e0 >= 0) Em[(e0 & 0xFFFFFF) * 2] = (e0 & (1 << 30)) ? 0.f : fminf(fmaxf(sv.x, lo1), hi1);
-                if (e1 >= 0) Em[(e1 & 0xFFFFFF) * 2] = (e1 & (1 << 30)) ? 0.f : fminf(fmaxf(sv.y, lo1), hi1);
+                if (e0 >= 0) Em[(e0 & 0xFFFFFF) * 2] = (e0 & (1 << 30)) ? 0.f : sgx_clipf(sv.x, lo1, hi1);
+                if (e1 >= 0) Em[(e1 & 0xFFFFFF) * 2] = (e1 & (1 << 30)) ? 0.f : sgx_clipf(sv.y, lo1, hi1);
             }
             if (G::ODD_IN) {
                 const int e = eidx[G::SLOTS_IN - 1];
-                if (e >= 0) Em[(e & 0xFFFFFF) * 2] = (e & (1 << 30)) ? 0.f : fminf(fmaxf(s1, lo1), hi1);
+                if (e >= 0) Em[(e & 0xFFFFFF) * 2] = (e & (1 << 30)) ? 0.f : sgx_clipf(s1, lo1, hi1);
             }
             SGX_SCHED_FENCE();
 #pragma unroll
@@ -423,15 +423,15 @@ SGX_KERNEL(SGX_FB2_THREADS) k_fused_block2(int Cmid, int H, int W, int Ho, int W
 #pragma unroll
             for (int jp = 0; jp < G::PAIRS_IN; jp++) {
                 const int e0 = eidx[2 * jp], e1 = eidx[2 * jp + 1];
-                if (e0 >= 0) Em[e0 & 0xFFFFFF] = (e0 & (1 << 30)) ? sgx_mk2(0.f, 0.f) : sgx_mk2(fminf(fmaxf(sp0[jp].x, lo1), hi1), fminf(fmaxf(sp1[jp].x, lo1), hi1));
-                if (e1 >= 0) Em[e1 & 0xFFFFFF] = (e1 & (1 << 30)) ? sgx_mk2(0.f, 0.f) : sgx_mk2(fminf(fmaxf(sp0[jp].y, lo1), hi1), fminf(fmaxf(sp1[jp].y, lo1), hi1));
+                if (e0 >= 0) Em[e0 & 0xFFFFFF] = (e0 & (1 << 30)) ? sgx_mk2(0.f, 0.f) : sgx_mk2(sgx_clipf(sp0[jp].x, lo1, hi1), sgx_clipf(sp1[jp].x, lo1, hi1));
+                if (e1 >= 0) Em[e1 & 0xFFFFFF] = (e1 & (1 << 30)) ? sgx_mk2(0.f, 0.f) : sgx_mk2(sgx_clipf(sp0[jp].y, lo1, hi1), sgx_clipf(sp1[jp].y, lo1, hi1));
             }
             if (G::ODD_IN) {
                 float s0 = bias0, s1 = bias1;
 #pragma unroll
                 for (int k = 0; k < CIN / 2; k++) { s0 = fmaf(wk0[k].x, x1[2 * k], s0); s1 = fmaf(wk1[k].x, x1[2 * k], s1); s0 = fmaf(wk0[k].y, x1[2 * k + 1], s0); s1 = fmaf(wk1[k].y, x1[2 * k + 1], s1); }
                 const int e = eidx[G::SLOTS_IN - 1];
-                if (e >= 0) Em[e & 0xFFFFFF] = (e & (1 << 30)) ? sgx_mk2(0.f, 0.f) : sgx_mk2(fminf(fmaxf(s0, lo1), hi1), fminf(fmaxf(s1, lo1), hi1));
+                if (e >= 0) Em[e & 0xFFFFFF] = (e & (1 << 30)) ? sgx_mk2(0.f, 0.f) : sgx_mk2(sgx_clipf(s0, lo1, hi1), sgx_clipf(s1, lo1, hi1));
             }
         }
         SGX_THREADS_END
@@ -461,15 +461,15 @@ SGX_KERNEL(SGX_FB2_THREADS) k_fused_block2(int Cmid, int H, int W, int Ho, int W
             for (int jp = 0; jp < G::PAIRS_IN; jp++) {
                 const sgx_f2 s = sp[jp];
                 const int e0 = eidx[2 * jp], e1 = eidx[2 * jp + 1];
-                if (e0 >= 0) Em[(e0 & 0xFFFFFF) * 2] = (e0 & (1 << 30)) ? 0.f : fminf(fmaxf(s.x, lo1), hi1);
-                if (e1 >= 0) Em[(e1 & 0xFFFFFF) * 2] = (e1 & (1 << 30)) ? 0.f : fminf(fmaxf(s.y, lo1), hi1);
+                if (e0 >= 0) Em[(e0 & 0xFFFFFF) * 2] = (e0 & (1 << 30)) ? 0.f : sgx_clipf(s.x, lo1, hi1);
+                if (e1 >= 0) Em[(e1 & 0xFFFFFF) * 2] = (e1 & (1 << 30)) ? 0.f : sgx_clipf(s.y, lo1, hi1);
             }
             if (G::ODD_IN) {
                 float s = bias;
 #pragma unroll
                 for (int k = 0; k < CIN / 2; k++) { s = fmaf(wk[k].x, x1[2 * k], s); s = fmaf(wk[k].y, x1[2 * k + 1], s); }
                 const int e = eidx[G::SLOTS_IN - 1];
-                if (e >= 0) Em[(e & 0xFFFFFF) * 2] = (e & (1 << 30)) ? 0.f : fminf(fmaxf(s, lo1), hi1);
+                if (e >= 0) Em[(e & 0xFFFFFF) * 2] = (e & (1 << 30)) ? 0.f : sgx_clipf(s, lo1, hi1);
             }
         }
         SGX_THREADS_END
@@ -505,7 +505,7 @@ SGX_KERNEL(SGX_FB2_THREADS) k_fused_block2(int Cmid, int H, int W, int Ho, int W
 #pragma unroll
                     for (int c = 0; c < K; c++) sv = sgx_fma2_w(wk[a * K + c], e[a * G::TIWP + (S == 2 ? (c & 1) * G::HALF + (c >> 1) : c)], sv);
                 }
-                d[jo] = sgx_mk2(fminf(fmaxf(sv.x, lo2), hi2), fminf(fmaxf(sv.y, lo2), hi2));
+                d[jo] = sgx_mk2(sgx_clipf(sv.x, lo2, hi2), sgx_clipf(sv.y, lo2, hi2));
             }
             SGX_SCHED_FENCE();
             {   // region 2: fetch the project weights of channel m + 1, accumulate channel m
@@ -559,7 +559,7 @@ SGX_KERNEL(SGX_FB2_THREADS) k_fused_block2(int Cmid, int H, int W, int Ho, int W
 #pragma unroll
                     for (int c = 0; c < K; c++) s = sgx_fma2_w(wk[a * K + c], e[a * G::TIWP + (S == 2 ? (c & 1) * G::HALF + (c >> 1) : c)], s);
                 }
-                const sgx_f2 d = sgx_mk2(fminf(fmaxf(s.x, lo2), hi2), fminf(fmaxf(s.y, lo2), hi2));
+                const sgx_f2 d = sgx_mk2(sgx_clipf(s.x, lo2, hi2), sgx_clipf(s.y, lo2, hi2));
 #pragma unroll
                 for (int cp = 0; cp < COUT / 2; cp++) acc[jo * (COUT / 2) + cp] = sgx_fma2_w_dlo(wc0[cp], d, acc[jo * (COUT / 2) + cp]);
 #pragma unroll
@@ -592,7 +592,7 @@ SGX_KERNEL(SGX_FB2_THREADS) k_fused_block2(int Cmid, int H, int W, int Ho, int W
                 for (int jp = 0; jp < NQ / 2; jp++) hid[jp] = sgx_fma2_w_dhi(wq1[jp * COUT + 2 * cp + 1], acc[jo * (COUT / 2) + cp], hid[jp]);
             }
 #pragma unroll
-            for (int jp = 0; jp < NQ / 2; jp++) hid[jp] = sgx_mk2(fminf(fmaxf(hid[jp].x, se.qlo), se.qhi), fminf(fmaxf(hid[jp].y, se.qlo), se.qhi));
+            for (int jp = 0; jp < NQ / 2; jp++) hid[jp] = sgx_mk2(sgx_clipf(hid[jp].x, se.qlo, se.qhi), sgx_clipf(hid[jp].y, se.qlo, se.qhi));
             sgx_f2 gt[COUT / 2];
 #pragma unroll
             for (int cp = 0; cp < COUT / 2; cp++) gt[cp] = sgx_mk2(se.bq2[2 * cp], se.bq2[2 * cp + 1]);
@@ -604,7 +604,7 @@ SGX_KERNEL(SGX_FB2_THREADS) k_fused_block2(int Cmid, int H, int W, int Ho, int W
 #pragma unroll
             for (int cp = 0; cp < COUT / 2; cp++) {                  // [ADD c][CLIP][DIV c][MUL project output], as sgx_epi_mode<SGX_EMODE_GATE>
                 float ux = gt[cp].x + se.gc1, uy = gt[cp].y + se.gc1;
-                ux = fminf(fmaxf(ux, se.glo), se.ghi); uy = fminf(fmaxf(uy, se.glo), se.ghi);
+                ux = sgx_clipf(ux, se.glo, se.ghi); uy = sgx_clipf(uy, se.glo, se.ghi);
                 ux = ux / se.gc2; uy = uy / se.gc2;
                 acc[jo * (COUT / 2) + cp] = sgx_mk2(ux * acc[jo * (COUT / 2) + cp].x, uy * acc[jo * (COUT / 2) + cp].y);
             }
@@ -670,7 +670,7 @@ SGX_KERNEL(256) k_se_gate(int HW, int total, const float *__restrict__ y, size_t
         for (int jp = 0; jp < NQ / 2; jp++) hid[jp] = sgx_fma2_w_dhi(wq1[jp * COUT + 2 * cp + 1], acc[cp], hid[jp]);
     }
 #pragma unroll
-    for (int jp = 0; jp < NQ / 2; jp++) hid[jp] = sgx_mk2(fminf(fmaxf(hid[jp].x, se.qlo), se.qhi), fminf(fmaxf(hid[jp].y, se.qlo), se.qhi));
+    for (int jp = 0; jp < NQ / 2; jp++) hid[jp] = sgx_mk2(sgx_clipf(hid[jp].x, se.qlo, se.qhi), sgx_clipf(hid[jp].y, se.qlo, se.qhi));
     sgx_f2 gt[COUT / 2];
 #pragma unroll
     for (int cp = 0; cp < COUT / 2; cp++) gt[cp] = sgx_mk2(se.bq2[2 * cp], se.bq2[2 * cp + 1]);
@@ -683,7 +683,7 @@ SGX_KERNEL(256) k_se_gate(int HW, int total, const float *__restrict__ y, size_t
 #pragma unroll
     for (int cp = 0; cp < COUT / 2; cp++) {                                // [ADD c][CLIP][DIV c][MUL y] [ADD residual], as sgx_epi_mode<SGX_EMODE_GATE / GATE_ADD>
         float ux = gt[cp].x + se.gc1, uy = gt[cp].y + se.gc1;
-        ux = fminf(fmaxf(ux, se.glo), se.ghi); uy = fminf(fmaxf(uy, se.glo), se.ghi);
+        ux = sgx_clipf(ux, se.glo, se.ghi); uy = sgx_clipf(uy, se.glo, se.ghi);
         ux = ux / se.gc2; uy = uy / se.gc2;
         ux = ux * acc[cp].x; uy = uy * acc[cp].y;
         if (res) { ux = ux + r[2 * cp]; uy = uy + r[2 * cp + 1]; }

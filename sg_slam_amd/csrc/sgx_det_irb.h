@@ -52,8 +52,8 @@ static inline size_t sgx_irb_lds_bytes(const SgxIrb &p) { return (size_t)p.nbuf 
 
 SGX_DEV float sgx_irb_act(int mode, float v, float c1, float lo, float hi, float c2)
 {
-    if (mode == SGX_EMODE_HSWISH) { float u = v + c1; u = fminf(fmaxf(u, lo), hi); u = u * v; return sgx_div_c2(u, c2); }
-    return fminf(fmaxf(v, lo), hi);
+    if (mode == SGX_EMODE_HSWISH) { float u = v + c1; u = sgx_clipf(u, lo, hi); u = u * v; return sgx_div_c2(u, c2); }
+    return sgx_clipf(v, lo, hi);
 }
 
 #ifndef SGX_EMU
@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(768) k_irb(SgxIrb p)
 #pragma unroll
         for (int u = 0; u < NQ; u++) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) qa[u][r] = fminf(fmaxf(qa[u][r], p.qlo), p.qhi);
+            for (int r = 0; r < 16; r++) qa[u][r] = sgx_clipf(qa[u][r], p.qlo, p.qhi);
             sgx_irb_d2b(qa[u], qb[u]);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -363,7 +363,7 @@ __global__ void __launch_bounds__(768) k_irb(SgxIrb p)
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int r = 0; r < 16; r++) { float u_ = ga[r] + p.gc1; u_ = fminf(fmaxf(u_, p.glo), p.ghi); u_ = sgx_div_c2(u_, p.gc2); acc[t][r] = u_ * acc[t][r]; }
+            for (int r = 0; r < 16; r++) { float u_ = ga[r] + p.gc1; u_ = sgx_clipf(u_, p.glo, p.ghi); u_ = sgx_div_c2(u_, p.gc2); acc[t][r] = u_ * acc[t][r]; }
             __builtin_amdgcn_sched_barrier(0);
         }
     }

@@ -48,6 +48,19 @@ struct SgxEpiStep { int op, src; float a, b; const float *t; };
 enum { SGX_EMODE_GENERIC = 0, SGX_EMODE_NONE, SGX_EMODE_ACT, SGX_EMODE_HSWISH, SGX_EMODE_GATE, SGX_EMODE_GATE_ADD, SGX_EMODE_ADD_T };
 struct SgxEpi { int n; int mode; size_t tpitch; float c1, lo, hi, c2; const float *t0, *t1; SgxEpiStep s[SGX_EPI_MAX]; };   // tensor operands: output's shape, per-image pitch tpitch
 
+// clip(v, lo, hi) = fminf(fmaxf(v, lo), hi) as ONE instruction.  The compiler turns the two calls into three (it canonicalises v in front of the max: IEEE mode) and cannot merge them
+// into v_med3_f32 because lo / hi are run-time values; for lo <= hi the median IS the clip, including -0 against a +0 bound (the hardware orders -0 < +0 in max as in med3) and a NaN
+// quiet-NaN operand (both return lo).  tools/ubench/div6_check.hip compares the two forms for all 2^32 operands with the graph's bounds (0, 6) and (0, +inf): they differ only for
+// signalling NaNs, which no arithmetic instruction produces (an activation is always the result of one).
+SGX_DEV float sgx_clipf(float v, float lo, float hi)
+{
+#ifndef SGX_EMU
+    return __builtin_amdgcn_fmed3f(v, lo, hi);
+#else
+    return fminf(fmaxf(v, lo), hi);
+#endif
+}
+
 // u / c for the divisor the graph uses everywhere (h-swish and h-sigmoid divide by 6): q0 = u r, e = fma(-q0, 6, u), q = fma(e, r, q0) with r = RN(1/6) is the correctly rounded quotient
 // whenever none of the steps leaves the normal range; the sign is u's (a -0 numerator, which the network produces wherever x <= -3, would come out as +0).  Guard: t = u / 8 is
 // subnormal, infinite or NaN  <=>  |u| < 2^-123 (non-zero), |u| = inf or NaN — then (the whole wave, so that no lane pays for both) the IEEE division runs.  Checked against u / 6.0f
@@ -76,10 +89,10 @@ template <int MODE>
 SGX_DEV float sgx_epi_mode(const SgxEpi &e, float v, size_t uoff, unsigned voff4)
 {
     if (MODE == SGX_EMODE_NONE) return v;
-    if (MODE == SGX_EMODE_ACT) return fminf(fmaxf(v, e.lo), e.hi);                                                       // [RELU] (hi = +inf) / [CLIP]
-    if (MODE == SGX_EMODE_HSWISH) { float u = v + e.c1; u = fminf(fmaxf(u, e.lo), e.hi); u = u * v; return sgx_div_c2(u, e.c2); }      // [ADD c][CLIP][MUL root][DIV c]
-    if (MODE == SGX_EMODE_GATE) { float u = v + e.c1; u = fminf(fmaxf(u, e.lo), e.hi); u = sgx_div_c2(u, e.c2); return u * sgx_ldoff(e.t0 + uoff, voff4); }   // [ADD c][CLIP][DIV c][MUL t]
-    if (MODE == SGX_EMODE_GATE_ADD) { float u = v + e.c1; u = fminf(fmaxf(u, e.lo), e.hi); u = sgx_div_c2(u, e.c2); u = u * sgx_ldoff(e.t0 + uoff, voff4); return u + sgx_ldoff(e.t1 + uoff, voff4); }
+    if (MODE == SGX_EMODE_ACT) return sgx_clipf(v, e.lo, e.hi);                                                       // [RELU] (hi = +inf) / [CLIP]
+    if (MODE == SGX_EMODE_HSWISH) { float u = v + e.c1; u = sgx_clipf(u, e.lo, e.hi); u = u * v; return sgx_div_c2(u, e.c2); }      // [ADD c][CLIP][MUL root][DIV c]
+    if (MODE == SGX_EMODE_GATE) { float u = v + e.c1; u = sgx_clipf(u, e.lo, e.hi); u = sgx_div_c2(u, e.c2); return u * sgx_ldoff(e.t0 + uoff, voff4); }   // [ADD c][CLIP][DIV c][MUL t]
+    if (MODE == SGX_EMODE_GATE_ADD) { float u = v + e.c1; u = sgx_clipf(u, e.lo, e.hi); u = sgx_div_c2(u, e.c2); u = u * sgx_ldoff(e.t0 + uoff, voff4); return u + sgx_ldoff(e.t1 + uoff, voff4); }
     if (MODE == SGX_EMODE_ADD_T) return v + sgx_ldoff(e.t1 + uoff, voff4);                                                // [ADD t]
     // generic interpreter, fully unrolled over the (at most SGX_EPI_MAX) steps: every field is a wave-uniform kernel argument at a
     // constant offset, so the scalar loads are hoisted out of the callers' loops
