@@ -68,7 +68,7 @@ SGX_DEV float sgx_clipf(float v, float lo, float hi)
 SGX_DEV float sgx_div_c2(float u, float c2)
 {
 #ifndef SGX_EMU
-    if (c2 == 6.0f) {                                            // wave-uniform: a kernel argument
+    if (__builtin_bit_cast(unsigned, c2) == 0x40C00000u) {        // c2 == 6.0f, wave-uniform (a kernel argument); as an integer compare it runs on the scalar unit (there is no scalar float compare)
         const float t = u * 0.125f;
         unsigned long long bad;                                  // lanes whose t is sNaN | qNaN | -inf | -subnormal | +subnormal | +inf: the compare writes the lane mask straight into a scalar pair
         asm("v_cmp_class_f32_e64 %0, %1, %2" : "=s"(bad) : "v"(t), "v"(0x297));
