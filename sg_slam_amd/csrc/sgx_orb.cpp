@@ -178,7 +178,8 @@ extern "C" int sgx_orb_create(const sgx_orb_config *cfg, sgx_orb **out)
                 if (maxX > maxBX) maxX = (float)maxBX;
                 SgxCell c; c.level = (short)l; c.x0 = (short)iniX; c.y0 = (short)iniY;
                 c.cw = (short)((int)maxX - (int)iniX); c.ch = (short)((int)maxY - (int)iniY);
-                c.ox = (short)(j * L.wcell); c.oy = (short)(i * L.hcell); c.pad = 0;
+                c.ox = (short)(j * L.wcell); c.oy = (short)(i * L.hcell);
+                { const int ng = ((c.x0 & 3) + c.cw + 3) >> 2; c.pad = (short)(unsigned short)((65536 + ng - 1) / ng); }      // ceil(2^16 / ng): k_fast_cells divides its task index by ng (ng >= 2, tasks < 4096: exact)
                 if (c.cw >= 7 && c.ch >= 7) {                        // cv::FAST yields nothing on tiles < 7 px
                     cells.push_back(c);
                     L.cand_cap += ((c.cw - 6 + 1) / 2) * ((c.ch - 6 + 1) / 2);   // strict-'>' NMS: no two survivors are 8-adjacent

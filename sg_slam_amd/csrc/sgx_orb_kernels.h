@@ -44,7 +44,7 @@ struct SgxOrbGeom {
     SgxLevel lv[SGX_MAX_LEVELS];
 };
 
-struct SgxCell { short level, x0, y0, cw, ch, ox, oy, pad; };  // tile rect in level coords; ox=j*wCell, oy=i*hCell
+struct SgxCell { short level, x0, y0, cw, ch, ox, oy, pad; };  // tile rect in level coords; ox=j*wCell, oy=i*hCell; pad = ceil(2^16 / ng), ng = dword groups per tile row (k_fast_cells)
 
 // status bits written by kernels
 #define SGX_ST_CAND_OVERFLOW 1u
@@ -308,6 +308,7 @@ SGX_KERNEL(SGX_FAST_THREADS) k_fast_cells(SgxOrbGeom g, const SgxCell *cells, co
     // score >= t, and a neighbour that is not a corner at t has a score below t, so it cannot suppress one that is (cv::FAST scores it 0).  Textured cells — the
     // common case — never pay for the low-threshold pass, whose quick test lets several times more pixels through.
     const int ih = ch - 6, ng = (lead + cw + 3) >> 2;
+    const unsigned ng_m16 = (unsigned)(unsigned short)c.pad;
     for (int pass = 0; pass < 2; pass++) {
         const int thr = pass == 0 ? thr_hi : thr_lo;
         // phase B1: necessary condition on every interior pixel.  A 9-pixel arc of the 16-ring contains one pixel of every antipodal
@@ -315,7 +316,7 @@ SGX_KERNEL(SGX_FAST_THREADS) k_fast_cells(SgxOrbGeom g, const SgxCell *cells, co
         // A task = 4 horizontally adjacent pixels: the compass pixels come from 7 aligned LDS dwords.  Survivors are compacted.
         SGX_THREADS_BEGIN(tid)
         for (int t = tid; t < ih * ng; t += (int)blockDim.x) {
-            const int y = 3 + t / ng, gq = t % ng;
+            const int yq = (int)(((unsigned)t * ng_m16) >> 16), y = 3 + yq, gq = t - yq * ng;          // t / ng, t % ng with the host's 16-bit reciprocal (exact for t < 4096, ng <= 16)
             const int x0 = 4 * gq + 3 - lead;                                   // tile column of the first pixel of the group
             if (x0 + 3 < 3 || x0 >= cw - 3) continue;
             const uint32_t *rc = tile_dw + y * SD + gq, *rp = rc + 3 * SD, *rm = rc - 3 * SD;
@@ -337,6 +338,7 @@ SGX_KERNEL(SGX_FAST_THREADS) k_fast_cells(SgxOrbGeom g, const SgxCell *cells, co
                 const uint32_t dk = sgx_pk_min_u16(sgx_pk_usubsat_u16(lo, r0) | sgx_pk_usubsat_u16(lo, r8), sgx_pk_usubsat_u16(lo, r4) | sgx_pk_usubsat_u16(lo, r12));
                 any[s2] = br | dk;
             }
+            if ((any[0] | any[1]) == 0u) continue;                                   // three tasks in four hold no survivor
     #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int x = x0 + i;
@@ -985,9 +987,9 @@ SGX_KERNEL(512) k_blur_levels(SgxOrbGeom g, const SgxBlurTile *tiles, const uint
     // staging: always aligned dwords.  Rows outside the level are fetched from their BORDER_REFLECT_101 source row; dwords that would start outside the row
     // are clamped into it (their bytes are garbage) and the at most 3 + 3 halo columns that lie outside the level are then copied from their reflected
     // columns, which are always staged.  (A per-byte reflected loader for border tiles — 30 % of the tiles — cost more than the two blur passes.)
-#define SGX_BLUR_FETCH(W_, DST_)                                                                                                           \
+#define SGX_BLUR_FETCH(F_, T_, DST_)                                                                                                       \
     {                                                                                                                                     \
-        const int f_ = (W_) % batch; const SgxBlurTile t_ = tiles[(W_) / batch]; const SgxLevel L_ = g.lv[t_.level]; int st_;             \
+        const int f_ = (F_); const SgxBlurTile t_ = tiles[(T_)]; const SgxLevel L_ = g.lv[t_.level]; int st_;                             \
         const uint8_t *img_ = sgx_level_ptr(g, gray, gray_pitch, pyr, f_, t_.level, &st_);                                                \
         const int rows_ = t_.h + 6, xs_ = t_.x0 - 3, ys_ = t_.y0 - 3, xa_ = xs_ - (xs_ & 3), maxq_ = (st_ >> 2) - 1;                      \
         for (int u_ = 0; u_ < SGX_BT_PRE; u_++) {                                                                                         \
@@ -1001,15 +1003,20 @@ SGX_KERNEL(512) k_blur_levels(SgxOrbGeom g, const SgxBlurTile *tiles, const uint
         }                                                                                                                                 \
     }
     if ((int)blockIdx.x >= total) return;
+    // work item w = tile * batch + frame (frame fastest); w advances by the grid size: (frame, tile) advance by its remainder / quotient — no division per tile
+    const int step_t = (int)gridDim.x / batch, step_f = (int)gridDim.x - step_t * batch;
+    int cur_t = (int)blockIdx.x / batch, cur_f = (int)blockIdx.x - cur_t * batch;
     SGX_THREADS_BEGIN(tid)
     SGX_PRIV_BIND(pre, tid);
-    SGX_BLUR_FETCH((int)blockIdx.x, pre)
+    SGX_BLUR_FETCH(cur_f, cur_t, pre)
     for (int u = 0; u < SGX_BT_PRE; u++) { const int i = tid + u * (int)blockDim.x; if (i < (SGX_BT_H + 6) * (SGX_BT_IS / 4)) in_dw[i] = pre[u]; }
     SGX_THREADS_END
     SGX_SYNC();
     for (int w = (int)blockIdx.x; w < total; w += (int)gridDim.x) {
-        const int frame = w % batch, wn = w + (int)gridDim.x;
-        const SgxBlurTile t = tiles[w / batch];
+        const int frame = cur_f, wn = w + (int)gridDim.x;
+        const SgxBlurTile t = tiles[cur_t];
+        int nxt_f = cur_f + step_f, nxt_t = cur_t + step_t;
+        if (nxt_f >= batch) { nxt_f -= batch; nxt_t++; }
         const SgxLevel L = g.lv[t.level];
         const int rows = t.h + 6, xs = t.x0 - 3;
         const int lead = xs & 3;
@@ -1049,7 +1056,7 @@ SGX_KERNEL(512) k_blur_levels(SgxOrbGeom g, const SgxBlurTile *tiles, const uint
         // the next tile's loads leave now; their latency hides behind the vertical pass
         SGX_THREADS_BEGIN(tid)
         SGX_PRIV_BIND(pre, tid);
-        if (wn < total) SGX_BLUR_FETCH(wn, pre)
+        if (wn < total) SGX_BLUR_FETCH(nxt_f, nxt_t, pre)
         SGX_THREADS_END
         SGX_SYNC();
         // vertical pass: task = (column, 8-row segment).  Rows r0 .. r0+15 of the column are 8 aligned dwords = the row pairs starting at even rows; the odd-start pairs come
@@ -1088,6 +1095,7 @@ SGX_KERNEL(512) k_blur_levels(SgxOrbGeom g, const SgxBlurTile *tiles, const uint
             if (4 * q < t.w) *(uint32_t *)(dst + (size_t)(t.y0 + r) * L.bstride + t.x0 + 4 * q) = o_dw[i];        // rows are padded to 64 bytes: the last dword may spill into the padding
         }
         SGX_THREADS_END
+        cur_f = nxt_f; cur_t = nxt_t;
     }
 #undef SGX_BLUR_FETCH
 }
