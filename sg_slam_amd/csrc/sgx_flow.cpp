@@ -28,6 +28,7 @@ extern "C" int sgx_flow_create(const sgx_flow_config *cfg, sgx_flow **out)
     if (cfg->width < 1 || cfg->height < 1 || cfg->max_batch < 1 || cfg->max_count < 0 || !(cfg->epsilon >= 0)) return SGX_ERR_INVALID;
     if (cfg->win_size != SGX_LK_WIN || cfg->max_level < 0 || cfg->max_level >= SGX_LK_MAXL) return SGX_ERR_UNSUPPORTED;      // Frame.cc:445 uses 21 and 3
     if (cfg->width <= 1 || cfg->height <= 1) return SGX_ERR_UNSUPPORTED;
+    { const unsigned long long qw = (unsigned long long)((cfg->width + 3) >> 2); if (qw * qw * (unsigned long long)cfg->height >= (1ull << 32)) return SGX_ERR_UNSUPPORTED; }      // the pyramid kernels split their dword index with a 32-bit reciprocal (exact below this size: ~4 k x 4 k)
     sgx_flow *h = new (std::nothrow) sgx_flow();
     if (!h) return SGX_ERR_NOMEM;
     h->cfg = *cfg;
@@ -67,10 +68,11 @@ static int build_pyramid(sgx_flow *h, int slot, const uint8_t *d_gray, int pitch
     const SgxLkGeom &g = h->g;
     uint8_t *base = h->img[slot];
     sgx_prof_begin(SGX_K_LK_PYR, st);
-    SGX_LAUNCH(k_lk_copy, dim3(((g.pitch[0] >> 2) * g.h[0] + 255) / 256, batch), dim3(256), st, d_gray, g.w[0], g.h[0], pitch, base, g.pitch[0], g.img_stride);
+    auto magic = [](int d) -> unsigned { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };      // ceil(2^32 / d): exact quotients for the kernels' index split (index < 2^21, d < 2^11)
+    SGX_LAUNCH(k_lk_copy, dim3(((g.pitch[0] >> 2) * g.h[0] + 255) / 256, batch), dim3(256), st, d_gray, g.w[0], g.h[0], pitch, base, g.pitch[0], g.img_stride, magic(g.pitch[0] >> 2));
     for (int l = 1; l < g.nl; l++)
         SGX_LAUNCH(k_lk_pyrdown, dim3(((g.pitch[l] >> 2) * g.h[l] + 255) / 256, batch), dim3(256), st, (const uint8_t *)(base + g.ioff[l - 1]), g.w[l - 1], g.h[l - 1], g.pitch[l - 1],
-                   g.img_stride, base + g.ioff[l], g.w[l], g.h[l], g.pitch[l], g.img_stride);
+                   g.img_stride, base + g.ioff[l], g.w[l], g.h[l], g.pitch[l], g.img_stride, magic(g.pitch[l] >> 2));
     sgx_prof_end(SGX_K_LK_PYR, st);
     SGX_CHECK_HIP(hipGetLastError());
     return SGX_OK;

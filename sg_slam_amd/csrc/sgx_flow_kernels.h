@@ -51,12 +51,21 @@ SGX_DEV float sgx_i64_to_f32(long long v)
 }
 
 // ---------------------------------------------------------------------------------------------
-SGX_KERNEL(256) k_lk_copy(const uint8_t *src, int w, int h, int spitch, uint8_t *dst, int dpitch, unsigned dstride)
+// exact n / d for n < 2^21, d < 2^11 with m = ceil(2^32 / d) from the host (0 encodes d == 1): one mul-hi instead of the ~25-instruction division sequence — which was most of k_lk_copy
+SGX_DEV unsigned sgx_lk_udiv(unsigned n, unsigned m)
+{
+#ifndef SGX_EMU
+    return m ? __umulhi(n, m) : n;
+#else
+    return m ? (unsigned)(((unsigned long long)n * m) >> 32) : n;
+#endif
+}
+SGX_KERNEL(256) k_lk_copy(const uint8_t *src, int w, int h, int spitch, uint8_t *dst, int dpitch, unsigned dstride, unsigned qw_magic)
 {
     SGX_THREADS_BEGIN(tid)
     const int f = (int)blockIdx.y, qw = dpitch >> 2, q = (int)blockIdx.x * 256 + tid;
     if (q < qw * h) {
-        const int y = q / qw, x = (q - y * qw) * 4;
+        const int y = (int)sgx_lk_udiv((unsigned)q, qw_magic), x = (q - y * qw) * 4;
         const uint8_t *s = src + ((size_t)f * h + y) * spitch;
         uint32_t v;
         if (x + 4 <= w) v = *(const uint32_t *)(s + x);
@@ -67,12 +76,12 @@ SGX_KERNEL(256) k_lk_copy(const uint8_t *src, int w, int h, int spitch, uint8_t 
 }
 
 // cv::pyrDown (pyramids.cpp, pyrDown_<FixPtCast<uchar,8>>): dst(x, y) = (sum_{i,j} k_i k_j src(2x-2+i, 2y-2+j) + 128) >> 8, k = [1 4 6 4 1]
-SGX_KERNEL(256) k_lk_pyrdown(const uint8_t *src, int sw, int sh, int spitch, unsigned sstride, uint8_t *dst, int dw, int dh, int dpitch, unsigned dstride)
+SGX_KERNEL(256) k_lk_pyrdown(const uint8_t *src, int sw, int sh, int spitch, unsigned sstride, uint8_t *dst, int dw, int dh, int dpitch, unsigned dstride, unsigned qw_magic)
 {
     SGX_THREADS_BEGIN(tid)
     const int f = (int)blockIdx.y, qw = dpitch >> 2, q = (int)blockIdx.x * 256 + tid;
     if (q < qw * dh) {
-        const int y = q / qw, X = (q - y * qw) * 4;
+        const int y = (int)sgx_lk_udiv((unsigned)q, qw_magic), X = (q - y * qw) * 4;
         const uint8_t *S = src + (size_t)f * sstride;
         int acc[4] = { 0, 0, 0, 0 };
         const bool fast = X >= 2 && 2 * X + 11 < spitch && 2 * X + 8 <= sw - 1;
