@@ -554,13 +554,17 @@ int sgx_tracker_keypoint_capacity(const sgx_tracker *t);
 int sgx_tracker_record_bytes(const sgx_tracker *t);                   /* 16 + cap * 28 + cap * 32 + 64: the per-frame record of BASELINE config 5 */
 int sgx_tracker_set_initial_pose(sgx_tracker *t, const float *Tcw /* streams x 16, host */);
 /* one frame of every stream from device memory: d_gray streams x height x gray_pitch u8, d_depth streams x height x width raw u16, d_bgr (optional, detector
- * input) streams x height x bgr_pitch interleaved 3-channel u8.  Asynchronous; the inputs must stay untouched until three more steps were issued or
- * sgx_tracker_sync returned. */
+ * input) streams x height x bgr_pitch interleaved 3-channel u8.  Asynchronous — a step only ENQUEUES work.  The inputs of a step may be rewritten
+ * (a) by work enqueued on `caller_stream` after the THIRD following sgx_tracker_step_dev call (that call orders caller_stream behind the step's readers), or
+ * (b) from the host after sgx_tracker_wait_inputs(t, steps_back) or sgx_tracker_sync returned. */
 int sgx_tracker_step_dev(sgx_tracker *t, const uint8_t *d_gray, int gray_pitch, const uint16_t *d_depth, const uint8_t *d_bgr, int bgr_pitch, void *caller_stream);
 /* host input (cv::imread's BGR image + the 16-bit depth map, rgbd_tum.cc:114-115): fill the pinned staging buffers of slot 0 / 1, then step; the tracker uploads
- * them on its own stream and converts to gray on the device (Tracking.cc:214-227; rgb_order = Camera.RGB).  A slot may be refilled once two further steps were issued. */
+ * them on its own stream and converts to gray on the device (Tracking.cc:214-227; rgb_order = Camera.RGB).  The upload is asynchronous: before REFILLING a slot call
+ * sgx_tracker_host_buffers(slot) again — it returns once the slot's pending upload has left the pinned buffers — or sgx_tracker_sync. */
 int sgx_tracker_host_buffers(sgx_tracker *t, int slot, uint8_t **bgr, int *bgr_pitch, uint16_t **depth);
 int sgx_tracker_step_host(sgx_tracker *t, int slot, int rgb_order);
+/* blocks the host until the device has read the input images of the step issued `steps_back` (0..2) calls ago */
+int sgx_tracker_wait_inputs(sgx_tracker *t, int steps_back);
 int sgx_tracker_sync(sgx_tracker *t);
 /* results of the frame tracked last (synchronises; any pointer may be NULL): Tcw streams x 16, keypoints after the mask, motion-model matches / inliers, local-map
  * matches / inliers of the second PoseOptimization, keypoints before the mask, findFundamentalMat success, its 4 statistics per stream */

@@ -74,7 +74,7 @@ SYMBOLS = [
     'sgx_frame_compact_keys_batch_dev', 'sgx_frame_gray_from_color_batch_dev', 'sgx_debug_flow_affine_batch_dev', 'sgx_det_debug_set_fusion', 'sgx_det_debug_set_legacy_kernels', 'sgx_det_debug_set_block_fusion', 'sgx_det_debug_set_irb', 'sgx_det_debug_time_ops', 'sgx_det_debug_op_desc',
     'sgx_dynamic_mask_batch_dev',
     'sgx_tracker_create', 'sgx_tracker_destroy', 'sgx_tracker_keypoint_capacity', 'sgx_tracker_record_bytes', 'sgx_tracker_set_initial_pose', 'sgx_tracker_step_dev',
-    'sgx_tracker_host_buffers', 'sgx_tracker_step_host', 'sgx_tracker_sync', 'sgx_tracker_read', 'sgx_tracker_snapshot_pose_dev', 'sgx_tracker_snapshot_boxes_dev',
+    'sgx_tracker_host_buffers', 'sgx_tracker_step_host', 'sgx_tracker_wait_inputs', 'sgx_tracker_sync', 'sgx_tracker_read', 'sgx_tracker_snapshot_pose_dev', 'sgx_tracker_snapshot_boxes_dev',
     'sgx_tracker_pack_records_dev', 'sgx_tracker_frame_dev', 'sgx_tracker_extractor',
     'sgx_flow_create', 'sgx_flow_destroy', 'sgx_flow_reset', 'sgx_flow_levels', 'sgx_flow_lk_batch_dev', 'sgx_flow_lk', 'sgx_flow_debug_read_level', 'sgx_flow_debug_level_size',
     'sgx_fundamental_ransac_batch_dev', 'sgx_find_fundamental_mat',
@@ -154,6 +154,7 @@ class SgxLib:
         d.sgx_tracker_host_buffers.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(vp)]
         d.sgx_tracker_step_host.argtypes = [vp, C.c_int, C.c_int]
         d.sgx_tracker_sync.argtypes = [vp]
+        d.sgx_tracker_wait_inputs.argtypes = [vp, C.c_int]
         d.sgx_tracker_read.argtypes = [vp] * 10
         d.sgx_tracker_snapshot_pose_dev.argtypes = [vp, vp]
         d.sgx_tracker_snapshot_boxes_dev.argtypes = [vp, C.c_int, vp, vp]

@@ -69,6 +69,9 @@ struct BA {
     int env_nA, env_nB;                  // two-branch elimination: column steps [0, nA) and [nA, nA + nB) are independent, the rest is their separator (nB = 0: one branch)
     double *env_S2, *env_x2;             // the second branch's contributions to the separator (nsep x nsep, nsep)
     std::vector<double> hpart;
+    // host copy of the sorted Schur job list of THIS problem (build_jobs): the classification pass filters it in place instead of rebuilding it.  Owned by the problem, so the
+    // cache can neither be applied to another problem that happens to have the same job count nor outlive the call (it used to be thread_local and never released)
+    std::vector<SgxBaJob> h_jobs; std::vector<int> h_blk_start;
 };
 
 static bool stopped(const BA &B) { return B.stop && *B.stop; }
@@ -115,8 +118,8 @@ static int read_trial(BA &B, int *ok, double *scale, double *chi)
 static int build_jobs(BA &B, const std::vector<int> &pt_start, const std::vector<int> &pt_edges, const std::vector<int> &pose_start, const std::vector<int> &pose_edges_l,
                       const std::vector<SgxBaEdge> &E, const std::vector<uint8_t> *level1, const std::vector<int> &hidx, const std::vector<int> &free_pose)
 {
-    static thread_local std::vector<SgxBaJob> sorted;
-    static thread_local std::vector<int> blk_start;
+    std::vector<SgxBaJob> &sorted = B.h_jobs;
+    std::vector<int> &blk_start = B.h_blk_start;
     if (level1 && !sorted.empty() && (long long)sorted.size() == B.njobs) {
         const std::vector<uint8_t> &lv = *level1;
         size_t w = 0, nb = 0;

@@ -36,6 +36,7 @@ static int st_create(sgx_st *s, int high_priority)
 }
 static void st_destroy(sgx_st s) { if (s) (void)hipStreamDestroy(s); }
 static void st_sync(sgx_st s) { if (s) (void)hipStreamSynchronize(s); }
+static void ev_sync(sgx_ev e) { if (e) (void)hipEventSynchronize(e); }
 static void *host_alloc(size_t n) { void *p = nullptr; return hipHostMalloc(&p, n, hipHostMallocDefault) == hipSuccess ? p : nullptr; }
 static void host_free(void *p) { (void)hipHostFree(p); }
 #else
@@ -48,6 +49,7 @@ static void st_wait(sgx_st, sgx_ev) {}
 static int st_create(sgx_st *s, int) { *s = nullptr; return 0; }
 static void st_destroy(sgx_st) {}
 static void st_sync(sgx_st) {}
+static void ev_sync(sgx_ev) {}
 static void *host_alloc(size_t n) { return calloc(1, n ? n : 1); }
 static void host_free(void *p) { free(p); }
 #endif
@@ -93,6 +95,11 @@ struct sgx_tracker {
     int bgr_pitch = 0;
     sgx_st sE = nullptr, sT = nullptr, sD = nullptr, sU = nullptr;
     sgx_ev ev_extract[3] = {}, ev_track[3] = {}, ev_pack[3] = {}, ev_det[2] = {}, ev_up[2] = {}, ev_in = {};
+    // ev_consumed[c]: every reader of the INPUT images of the step that used frame slot c (extraction stream: ORB, LK pyramid, stereo-from-RGBD; detector stream: the forward) is done.
+    // ev_up[slot]: the H2D copies out of pinned staging slot `slot` are done (the caller may refill it).  ev_step: end of a non-pipelined step on the caller's stream.
+    sgx_ev ev_consumed[3] = {}, ev_step = {};
+    bool consumed_valid[3] = { false, false, false }, up_pending[2] = { false, false };
+    sgx_st last_stream = nullptr;           // non-pipelined mode: the caller stream of the last step (snapshots and the record pack are ordered behind it)
     bool pack_pending[3] = { false, false, false };
     int frame_idx = 0, cur = 0;
     bool pipelined = false;
@@ -115,7 +122,8 @@ extern "C" void sgx_tracker_destroy(sgx_tracker *t)
     if (t->flow) sgx_flow_destroy(t->flow);
     for (void *p : t->dev) (void)hipFree(p);
     for (void *p : t->pinned) host_free(p);
-    for (int i = 0; i < 3; i++) { ev_destroy(t->ev_extract[i]); ev_destroy(t->ev_track[i]); ev_destroy(t->ev_pack[i]); }
+    for (int i = 0; i < 3; i++) { ev_destroy(t->ev_extract[i]); ev_destroy(t->ev_track[i]); ev_destroy(t->ev_pack[i]); ev_destroy(t->ev_consumed[i]); }
+    ev_destroy(t->ev_step);
     for (int i = 0; i < 2; i++) { ev_destroy(t->ev_det[i]); ev_destroy(t->ev_up[i]); }
     ev_destroy(t->ev_in);
     st_destroy(t->sE); st_destroy(t->sT); st_destroy(t->sD); st_destroy(t->sU);
@@ -168,10 +176,10 @@ extern "C" int sgx_tracker_create(const sgx_tracker_config *cfg, sgx_det *detect
     t->pipelined = cfg->pipelined != 0;
     if (t->pipelined) {
         if (st_create(&t->sE, 0) || st_create(&t->sT, 1) || st_create(&t->sD, 0)) FAIL(SGX_ERR_DEVICE);      // the tracking stream is the latency-critical one: dispatch it first
-        for (int i = 0; i < 3; i++) if (ev_create(&t->ev_extract[i]) || ev_create(&t->ev_track[i]) || ev_create(&t->ev_pack[i])) FAIL(SGX_ERR_DEVICE);
+        for (int i = 0; i < 3; i++) if (ev_create(&t->ev_extract[i]) || ev_create(&t->ev_track[i]) || ev_create(&t->ev_pack[i]) || ev_create(&t->ev_consumed[i])) FAIL(SGX_ERR_DEVICE);
         for (int i = 0; i < 2; i++) if (ev_create(&t->ev_det[i]) || ev_create(&t->ev_up[i])) FAIL(SGX_ERR_DEVICE);
         if (ev_create(&t->ev_in)) FAIL(SGX_ERR_DEVICE);
-    }
+    } else if (ev_create(&t->ev_step)) FAIL(SGX_ERR_DEVICE);
 #undef FAIL
     (void)hipDeviceSynchronize();           // the zero-fills above ran on the null stream, which the tracker's non-blocking streams do not wait for
     *out = t;
@@ -190,8 +198,9 @@ extern "C" int sgx_tracker_set_initial_pose(sgx_tracker *t, const float *Tcw)
 
 // One frame of every stream.  d_gray: S x H x gray_pitch u8; d_depth: S x H x W u16 (raw, Tracking.cc:229-230 divides by DepthMapFactor);
 // d_bgr (optional, with a detector): S x H x bgr_pitch interleaved 3-channel u8 — what Detector2D::detect sees.  Asynchronous: the inputs are read on the
-// tracker's streams after everything already enqueued on `caller_stream`; they must stay untouched until three more steps have been issued or
-// sgx_tracker_sync returned.
+// tracker's streams after everything already enqueued on `caller_stream`.  Issuing a step only ENQUEUES work, so "three more steps were issued" says nothing about
+// the device having read the inputs: the inputs of a step may be rewritten (a) by work enqueued on `caller_stream` after the third following
+// sgx_tracker_step_dev call — that call makes `caller_stream` wait for the readers' event —, or (b) from the host after sgx_tracker_wait_inputs / sgx_tracker_sync returned.
 extern "C" int sgx_tracker_step_dev(sgx_tracker *t, const uint8_t *d_gray, int gray_pitch, const uint16_t *d_depth, const uint8_t *d_bgr, int bgr_pitch, void *caller_stream)
 {
     if (!t || !d_gray || !d_depth || gray_pitch < t->cfg.width) return SGX_ERR_INVALID;
@@ -203,6 +212,7 @@ extern "C" int sgx_tracker_step_dev(sgx_tracker *t, const uint8_t *d_gray, int g
         ev_record(t->ev_in, (sgx_st)caller_stream);                       // the frames may have been produced on the caller's stream
         st_wait(sE, t->ev_in); st_wait(sD, t->ev_in);
         if (i == 0) st_wait(sT, t->ev_in);
+        if (t->consumed_valid[c]) st_wait((sgx_st)caller_stream, t->ev_consumed[c]);      // the inputs of step i - 3: later work on the caller's stream may overwrite them
         if (i >= 2) st_wait(sE, t->ev_track[(i - 2) % 3]);                // slot c was "last" of step i - 2 + 1: its readers must be done
         if (t->pack_pending[c]) { st_wait(sE, t->ev_pack[c]); t->pack_pending[c] = false; }      // ... and its record must have been packed for the gather
     }
@@ -235,7 +245,13 @@ extern "C" int sgx_tracker_step_dev(sgx_tracker *t, const uint8_t *d_gray, int g
     } else
         TRK_CHECK(sgx_orb_extract_batch_dev(t->ex, d_gray, gray_pitch, S, t->keys[c], t->desc[c], t->n[c], cap, sE));
     TRK_CHECK(sgx_frame_stereo_from_rgbd_batch_dev(S, cap, t->keys[c], t->n[c], d_depth, cf.width, cf.height, cf.depth_map_factor, cf.cam.bf, t->uright[c], t->zdepth[c], sE));
-    if (t->pipelined) { ev_record(t->ev_extract[c], sE); st_wait(sT, t->ev_extract[c]); }
+    if (t->pipelined) {
+        ev_record(t->ev_extract[c], sE); st_wait(sT, t->ev_extract[c]);
+        // "inputs consumed": the extraction stream's readers are behind us; the detector's forward read d_bgr on its own stream.  With the mask on, sE already waited for
+        // ev_det before the mask; otherwise (first frame, dynamic_mask == 0) the wait is added here, behind ev_extract so that the tracking stream is not held back.
+        if (with_det) st_wait(sE, t->ev_det[b]);
+        ev_record(t->ev_consumed[c], sE); t->consumed_valid[c] = true;
+    }
     // ---- T: Tracking::TrackWithMotionModel (Tracking.cc:906-967)
     if (i > 0) {
         TRK_CHECK(sgx_frame_motion_model_batch_dev(S, Tl, Tll, t->vel_valid, Tc, sT));            // frame 1 has no velocity yet: it starts from the last pose
@@ -257,14 +273,16 @@ extern "C" int sgx_tracker_step_dev(sgx_tracker *t, const uint8_t *d_gray, int g
         TRK_CHECK(sgx_frame_make_map_points_batch_dev(S, cap, (i - 1) % 2, t->keys[l], t->n[l], t->xw[l], t->has[l], t->desc[l], Tl, t->scale, t->nlevels, t->lm_xw, t->lm_normal, t->lm_min,
                                                       t->lm_max, t->lm_desc, t->lm_skip, sT));
     if (t->pipelined) ev_record(t->ev_track[c], sT);
+    else { t->last_stream = (sgx_st)caller_stream; ev_record(t->ev_step, t->last_stream); }
     t->Tcw[0] = Tll; t->Tcw[1] = Tc; t->Tcw[2] = Tl;                     // rotate poses: cur -> last, last -> last-last
     t->cur = c; t->frame_idx = i + 1;
     return SGX_OK;
 }
 
 // ---- host-input path: the caller fills the pinned staging buffers of a slot (as cv::imread + the TUM loader would, rgbd_tum.cc:114-115), the tracker uploads
-// them on its own stream, converts the colour image to gray on the device (Tracking.cc:214-227) and steps.  Two slots: slot s may be refilled after the step
-// issued two calls later has been issued (or after sgx_tracker_sync).
+// them on its own stream, converts the colour image to gray on the device (Tracking.cc:214-227) and steps.  Two slots.  The upload of a slot is asynchronous: before
+// REFILLING a slot the caller asks for it again with sgx_tracker_host_buffers(slot), which returns once the slot's pending H2D copies have completed (or calls
+// sgx_tracker_sync).  Refilling on the strength of "two further steps were issued" was unsafe: issuing is not executing.
 extern "C" int sgx_tracker_host_buffers(sgx_tracker *t, int slot, uint8_t **bgr, int *bgr_pitch, uint16_t **depth)
 {
     if (!t || slot < 0 || slot > 1) return SGX_ERR_INVALID;
@@ -280,6 +298,7 @@ extern "C" int sgx_tracker_host_buffers(sgx_tracker *t, int slot, uint8_t **bgr,
         if (t->pipelined && st_create(&t->sU, 0)) return SGX_ERR_DEVICE;
         (void)hipDeviceSynchronize();       // zero-fills of the new staging buffers (null stream) before the upload stream touches them
     }
+    if (t->up_pending[slot]) { ev_sync(t->ev_up[slot]); t->up_pending[slot] = false; }      // the slot's last upload has left the pinned buffers
     if (bgr) *bgr = t->h_bgr[slot]; if (bgr_pitch) *bgr_pitch = t->bgr_pitch; if (depth) *depth = t->h_depth[slot];
     return SGX_OK;
 }
@@ -289,13 +308,26 @@ extern "C" int sgx_tracker_step_host(sgx_tracker *t, int slot, int rgb_order)
     if (!t || slot < 0 || slot > 1 || !t->h_bgr[0]) return SGX_ERR_INVALID;
     const int S = t->S, W = t->cfg.width, H = t->cfg.height;
     sgx_st sU = t->pipelined ? t->sU : (sgx_st) nullptr;
-    // the device staging slot was read by the step issued two calls ago (extraction + detector streams): its extraction event covers the gray / depth readers,
-    // the detector of that step was waited for by that extraction stream before the mask
-    if (t->pipelined && t->frame_idx >= 2) st_wait(sU, t->ev_extract[(t->frame_idx - 2) % 3]);
+    // the device staging slot was read by the step issued two calls ago, on the extraction AND the detector stream: ev_consumed covers both (ev_extract alone does not
+    // when that step ran without the mask's detector wait — first frame, dynamic_mask == 0)
+    if (t->pipelined && t->frame_idx >= 2) st_wait(sU, t->ev_consumed[(t->frame_idx - 2) % 3]);
     TRK_HIP(hipMemcpyAsync(t->d_bgr[slot], t->h_bgr[slot], (size_t)S * H * t->bgr_pitch, hipMemcpyHostToDevice, sU));
     TRK_HIP(hipMemcpyAsync(t->d_depth[slot], t->h_depth[slot], (size_t)S * H * W * 2, hipMemcpyHostToDevice, sU));
+    if (t->pipelined) { ev_record(t->ev_up[slot], sU); t->up_pending[slot] = true; }
     TRK_CHECK(sgx_frame_gray_from_color_batch_dev(S, W, H, t->d_bgr[slot], t->bgr_pitch, 3, rgb_order ? 0 : 1, t->d_gray[slot], W, sU));
     return sgx_tracker_step_dev(t, t->d_gray[slot], W, t->d_depth[slot], t->det ? t->d_bgr[slot] : nullptr, t->bgr_pitch, sU);
+}
+
+// Blocks the host until the device has read the INPUT images of the step issued `steps_back` calls ago (0 = the last one; at most 2): the caller may then rewrite
+// those buffers from the host.  (Stream-ordered writers need nothing: see sgx_tracker_step_dev.)
+extern "C" int sgx_tracker_wait_inputs(sgx_tracker *t, int steps_back)
+{
+    if (!t || steps_back < 0 || steps_back > 2) return SGX_ERR_INVALID;
+    if (t->frame_idx - 1 - steps_back < 0) return SGX_OK;
+    if (!t->pipelined) { TRK_HIP(hipDeviceSynchronize()); return SGX_OK; }
+    const int c = (t->frame_idx - 1 - steps_back) % 3;
+    if (t->consumed_valid[c]) ev_sync(t->ev_consumed[c]);
+    return SGX_OK;
 }
 
 extern "C" int sgx_tracker_sync(sgx_tracker *t)
@@ -303,6 +335,7 @@ extern "C" int sgx_tracker_sync(sgx_tracker *t)
     if (!t) return SGX_ERR_INVALID;
     if (t->pipelined) { st_sync(t->sE); st_sync(t->sT); st_sync(t->sD); if (t->sU) st_sync(t->sU); }
     else TRK_HIP(hipDeviceSynchronize());
+    t->up_pending[0] = t->up_pending[1] = false;
     return SGX_OK;
 }
 
@@ -330,7 +363,7 @@ extern "C" int sgx_tracker_read(sgx_tracker *t, float *Tcw, int32_t *nkeys, int3
 extern "C" int sgx_tracker_snapshot_pose_dev(sgx_tracker *t, float *d_out)
 {
     if (!t || !d_out) return SGX_ERR_INVALID;
-    TRK_HIP(hipMemcpyAsync(d_out, t->Tcw[1], (size_t)t->S * 64, hipMemcpyDeviceToDevice, t->pipelined ? t->sT : (sgx_st) nullptr));
+    TRK_HIP(hipMemcpyAsync(d_out, t->Tcw[1], (size_t)t->S * 64, hipMemcpyDeviceToDevice, t->pipelined ? t->sT : t->last_stream));      // non-pipelined: the step ran on the caller's stream
     return SGX_OK;
 }
 
@@ -339,7 +372,7 @@ extern "C" int sgx_tracker_snapshot_boxes_dev(sgx_tracker *t, int stream_index, 
 {
     if (!t || !d_boxes || !d_nboxes || stream_index < 0 || stream_index >= t->S || t->frame_idx < 1) return SGX_ERR_INVALID;
     const int b = (t->frame_idx - 1) & 1;
-    sgx_st sD = t->pipelined ? t->sD : (sgx_st) nullptr;
+    sgx_st sD = t->pipelined ? t->sD : t->last_stream;
     TRK_HIP(hipMemcpyAsync(d_boxes, t->det_boxes[b] + (size_t)stream_index * t->MB * 4, (size_t)t->MB * 16, hipMemcpyDeviceToDevice, sD));
     TRK_HIP(hipMemcpyAsync(d_nboxes, t->det_nb[b] + stream_index, 4, hipMemcpyDeviceToDevice, sD));
     return SGX_OK;
@@ -353,6 +386,7 @@ extern "C" int sgx_tracker_pack_records_dev(sgx_tracker *t, uint8_t *d_records, 
     const int c = t->cur, words = sgx_tracker_record_bytes(t) / 4;
     sgx_st st = (sgx_st)stream;
     if (t->pipelined) st_wait(st, t->ev_track[c]);
+    else if (st != t->last_stream) st_wait(st, t->ev_step);               // non-pipelined: the step ran on the caller's stream, `stream` may be another (non-blocking) one
     SGX_LAUNCH(k_pack_frame_records, dim3(t->S), dim3(256), st, t->cap, t->n[c], (const uint32_t *)t->keys[c], (const uint32_t *)t->desc[c], (const uint32_t *)t->Tcw[1], (uint32_t *)d_records, words);
     TRK_HIP(hipGetLastError());
     if (t->pipelined) { ev_record(t->ev_pack[c], st); t->pack_pending[c] = true; }

@@ -65,6 +65,10 @@ class FrameRecordGather:
         buf[:, o:o + cap * 32] = desc.reshape(S, cap * 32); o += cap * 32
         buf[:, o:o + 64] = Tcw.reshape(S, 16).to(torch.float32).contiguous().view(torch.uint8).reshape(S, 64)
 
+    def _step_bytes(self):
+        """bytes this RANK moves per step: a sender ships its S records; the destination receives the other ranks' (its own slice is a local copy)"""
+        return (self.world - 1) * self.S * self.rec_bytes if self.rank == self.dst else self.S * self.rec_bytes
+
     def _gather(self, b, async_op):
         out = list(self.recv[b].unbind(0)) if self.rank == self.dst else None
         return self.dist.gather(self.send[b], out, dst=self.dst, async_op=async_op)
@@ -81,7 +85,7 @@ class FrameRecordGather:
                 self.pending[b] = self._gather(b, True)
         else:
             tracker.pack_records(self.send[b]); self._gather(b, False)
-        self.bytes_moved += self.world * self.S * self.rec_bytes
+        self.bytes_moved += self._step_bytes()
         self.step_idx += 1
         return self.recv[b]
 
@@ -102,7 +106,7 @@ class FrameRecordGather:
         else:
             self.pack_torch(self.send[b], n, keys, desc, Tcw)
             self._gather(b, False)
-        self.bytes_moved += self.world * self.S * self.rec_bytes
+        self.bytes_moved += self._step_bytes()
         self.step_idx += 1
         return self.recv[b]
 

@@ -506,6 +506,8 @@ public:
     void HostBuffers(int slot, uint8_t **bgr, int *pitch, uint16_t **depth) { check(sgx_tracker_host_buffers(h_, slot, bgr, pitch, depth), "sgx_tracker_host_buffers"); }
     void GrabImagesRGBD(int slot, bool rgbOrder = true) { check(sgx_tracker_step_host(h_, slot, rgbOrder ? 1 : 0), "sgx_tracker_step_host"); }
     void Synchronize() { check(sgx_tracker_sync(h_), "sgx_tracker_sync"); }
+    // blocks until the device has read the input images of the step issued stepsBack (0..2) calls ago; HostBuffers(slot) does the same for a pinned staging slot
+    void WaitInputs(int stepsBack = 0) { check(sgx_tracker_wait_inputs(h_, stepsBack), "sgx_tracker_wait_inputs"); }
     // mCurrentFrame.mTcw of every stream (streams x 16) and the tracking counts of the frame tracked last (synchronises)
     void Pose(std::vector<float> &Tcw, std::vector<int32_t> *nKeys = nullptr, std::vector<int32_t> *nMatches = nullptr, std::vector<int32_t> *nInliers = nullptr)
     {

@@ -56,6 +56,10 @@ class TrackerNative:
     def synchronize(self):
         self.lib.check(self.lib.dll.sgx_tracker_sync(self.h))
 
+    def wait_inputs(self, steps_back=0):
+        """host-blocks until the device has read the input images of the step issued `steps_back` calls ago (then they may be rewritten from the host)"""
+        self.lib.check(self.lib.dll.sgx_tracker_wait_inputs(self.h, steps_back), 'sgx_tracker_wait_inputs')
+
     def read(self):
         S = self.S
         out = dict(Tcw=np.zeros((S, 16), 'f4'), nkeys=np.zeros(S, 'i4'), nmatch=np.zeros(S, 'i4'), ninl=np.zeros(S, 'i4'), nmatch_local=np.zeros(S, 'i4'), ninl2=np.zeros(S, 'i4'),

@@ -22,3 +22,21 @@ def test_bench_rccl_gather_path_single_rank(gpulib):
     g = j['config']['frame_record_gather']
     assert j['n_gpus'] == 1 and j['value'] > 0 and g is not None and g['inside_timed_region'] and g['bytes_per_step'] == 8 * g['record_bytes']
     assert j['config']['tracked_streams_last_frame'] == 8
+
+
+def test_bench_gpus_flag_spawns_the_ranks(gpulib):
+    """`python bench.py --gpus N` with no torchrun environment launches N ranks itself (torch.distributed.run, 127.0.0.1 rendezvous).  A 1-GPU box can
+    only run N = 1 through that launcher (SGX_BENCH_FORCE_SPAWN=1 makes --gpus 1 take the same route as --gpus 8); a request for more GPUs than the node has fails loudly."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(SGX_BENCH_FORCE_SPAWN='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '6', '--warmup', '3', '--streams', '8', '--no-cpu-baseline', '--no-config2',
+                          '--no-config4', '--no-host-input'], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert j['n_gpus'] == 1 and j['value'] > 0 and j['config']['frame_record_gather'] is not None       # it ran as a torch.distributed rank
+    import torch
+    n = torch.cuda.device_count() + 1
+    env.pop('SGX_BENCH_FORCE_SPAWN')
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n), '--steps', '2', '--warmup', '1', '--streams', '8', '--no-cpu-baseline', '--no-config2',
+                          '--no-config4', '--no-host-input'], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith('{')]
