@@ -464,6 +464,12 @@ int sgx_det_debug_detection_output(sgx_det *h, const float *loc, const float *co
 int sgx_det_debug_set_fusion(int on);
 int sgx_det_debug_set_irb(int on);                 /* the NEXT sgx_det_create: matrix-core inverted-residual block kernels (sgx_det_irb.h) 0 off, 1 on the shapes where they beat the per-layer kernels, 2 on every supported shape, -1 = default (1, or SGX_DET_IRB); bit-identical either way */
 int sgx_det_debug_set_block_fusion(int on);        /* 1: the NEXT sgx_det_create also fuses every expand -> depthwise -> project triple into one kernel (bit-identical; opt-in: slower at batch 256) */
+/* Matrix-product scheme of the detector's 1x1 convolutions (pointwise / expand / project / squeeze-excite), read by the NEXT sgx_det_create: 0 = exact fp32
+ * (v_mfma_f32_32x32x2_f32, an ascending-k fmaf chain: bit-identical to the per-layer reference kernels), 1 = bf16x3 (each fp32 operand split exactly into three
+ * bf16 terms, the six leading cross products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: fp32-accurate products in another summation order), -1 = the
+ * default (1, or SGX_DET_GEMM=f32|bf16x3).  sgx_det_gemm_mode reports what a detector was built with. */
+int sgx_det_debug_set_gemm(int mode);
+int sgx_det_gemm_mode(const sgx_det *h);
 int sgx_det_debug_set_legacy_kernels(int on);      /* 1: run the simple reference kernels (one thread per output / 64x64 GEMM tile) instead of the tuned ones */
 int sgx_det_debug_time_ops(sgx_det *h, const uint8_t *d_img, int pitch, int batch, int reps, float *ms, int cap, int *nops);
 int sgx_det_debug_op_desc(const sgx_det *h, int i, char *buf, int cap);

@@ -71,7 +71,7 @@ SYMBOLS = [
     'sgx_pose_optimization_batch_dev', 'sgx_pose_opt_debug_set_threads', 'sgx_pose_optimization', 'sgx_frame_motion_model_batch_dev',
     'sgx_local_bundle_adjustment', 'sgx_bundle_adjustment', 'sgx_ba_debug_set_solver', 'sgx_ba_debug_last_plan',
     'sgx_det_create', 'sgx_det_destroy', 'sgx_det_info', 'sgx_det_detect', 'sgx_det_detect_batch_dev', 'sgx_det_forward_batch_dev', 'sgx_det_debug_read_blob', 'sgx_det_debug_detection_output',
-    'sgx_frame_compact_keys_batch_dev', 'sgx_frame_gray_from_color_batch_dev', 'sgx_debug_flow_affine_batch_dev', 'sgx_det_debug_set_fusion', 'sgx_det_debug_set_legacy_kernels', 'sgx_det_debug_set_block_fusion', 'sgx_det_debug_set_irb', 'sgx_det_debug_time_ops', 'sgx_det_debug_op_desc',
+    'sgx_frame_compact_keys_batch_dev', 'sgx_frame_gray_from_color_batch_dev', 'sgx_debug_flow_affine_batch_dev', 'sgx_det_debug_set_fusion', 'sgx_det_debug_set_legacy_kernels', 'sgx_det_debug_set_block_fusion', 'sgx_det_debug_set_irb', 'sgx_det_debug_set_gemm', 'sgx_det_gemm_mode', 'sgx_det_debug_time_ops', 'sgx_det_debug_op_desc',
     'sgx_dynamic_mask_batch_dev',
     'sgx_tracker_create', 'sgx_tracker_destroy', 'sgx_tracker_keypoint_capacity', 'sgx_tracker_record_bytes', 'sgx_tracker_set_initial_pose', 'sgx_tracker_step_dev',
     'sgx_tracker_host_buffers', 'sgx_tracker_step_host', 'sgx_tracker_wait_inputs', 'sgx_tracker_sync', 'sgx_tracker_read', 'sgx_tracker_snapshot_pose_dev', 'sgx_tracker_snapshot_boxes_dev',
@@ -145,6 +145,8 @@ class SgxLib:
         d.sgx_det_debug_set_legacy_kernels.argtypes = [C.c_int]
         d.sgx_det_debug_set_block_fusion.argtypes = [C.c_int]
         d.sgx_det_debug_set_irb.argtypes = [C.c_int]
+        d.sgx_det_debug_set_gemm.argtypes = [C.c_int]
+        d.sgx_det_gemm_mode.argtypes = [vp]
         d.sgx_tracker_create.argtypes = [C.POINTER(TrackerConfig), vp, C.POINTER(vp)]
         d.sgx_tracker_destroy.argtypes = [vp]; d.sgx_tracker_destroy.restype = None
         d.sgx_tracker_keypoint_capacity.argtypes = [vp]

@@ -4,6 +4,7 @@
 #include "sgx_block.h"
 #include "sgx_det_block.h"
 #include "sgx_det_irb.h"
+#include "sgx_det_bf16.h"
 #include "sgx_prof.h"
 #include "../../include/sgx.h"
 #include <math.h>
@@ -36,6 +37,7 @@ struct Op {
     std::vector<EpiStep> epi; int hwc = 0, hwc_off = 0; bool dead = false; std::string name;
     int inc = 0, outc = 0, H = 0, W = 0, Ho = 0, Wo = 0, k = 1, stride = 1, pad = 0, depthwise = 0, act = 0; float lo = 0, hi = 0;
     float *wt = nullptr, *bias = nullptr, *wtT = nullptr; int ldw = 0; int bop = 0; int off = 0; int rows = 0, C = 0;
+    void *wS = nullptr;                         // pointwise weights split into three bf16 terms in the MFMA operand layout (sgx_det_bf16.h), ld = ldw; NULL in the exact-fp32 plan
     SgxFusedBlk fb; int fb_res_blob = -1;      // OP_FUSED_BLOCK: expand -> depthwise -> project (+ residual) in one kernel (sgx_det_block.h)
     SgxSeGate sg; int sg_res_blob = -1;                            // OP_SE_GATE: squeeze -> excite -> gate x input [+ residual] as one kernel (k_se_gate, sgx_det_block.h)
     SgxIrb irb; int irb_res_blob = -1, irb_out2_blob = -1;         // OP_IRB: [expand ->] depthwise -> project [-> squeeze-excite gate] [+ residual] on the matrix cores (sgx_det_irb.h)
@@ -44,6 +46,7 @@ struct Op {
 
 struct sgx_det {
     int T = 300, max_batch = 1, W = 0, H = 0, legacy = 0;
+    int gemm = 0;                       // matrix products of the pointwise convolutions: 0 exact fp32 (v_mfma_f32_32x32x2_f32: an ascending-k fmaf chain), 1 bf16x3 (sgx_det_bf16.h)
     int pre_fused = 0;                  // 1: ops[0] is the stem convolution and runs as k_stem_pre straight from the u8 images (no "input" blob, no k_det_preprocess launch)
     float det_th = 0.9f, dyn_th = 0.01f;
     std::vector<Layer> layers;
@@ -78,6 +81,26 @@ extern "C" int sgx_det_debug_set_block_fusion(int on) { g_det_block_fusion = on 
 static int g_det_irb = -1;               // test / tuning tap: inverted-residual blocks and SSD heads as one matrix-core kernel each (sgx_det_irb.h): 0 off, 1 the shapes where it beats
                                          // the per-layer kernels on MI355X (default), 2 every shape it supports (tests); -1 = SGX_DET_IRB or the default
 extern "C" int sgx_det_debug_set_irb(int on) { g_det_irb = on < 0 ? -1 : (on > 2 ? 2 : on); return SGX_OK; }
+// Matrix-product scheme of the pointwise / expand / project / squeeze-excite convolutions (read at sgx_det_create): 0 = exact fp32 on v_mfma_f32_32x32x2_f32 (bit-identical to the
+// per-layer reference kernels and to the emulator: the anchor of the plan-equality tests), 1 = bf16x3 on v_mfma_f32_32x32x16_bf16 (fp32-accurate products, fp32 accumulation,
+// another summation order; sgx_det_bf16.h), -1 = SGX_DET_GEMM (f32 | bf16x3) or the default.  The emulator build always runs 0.
+static int g_det_gemm = -1;
+#ifndef SGX_DET_GEMM_DEFAULT
+#define SGX_DET_GEMM_DEFAULT 1
+#endif
+extern "C" int sgx_det_debug_set_gemm(int mode) { g_det_gemm = mode < 0 ? -1 : (mode ? 1 : 0); return SGX_OK; }
+extern "C" int sgx_det_gemm_mode(const sgx_det *h) { return h ? h->gemm : -1; }
+static int det_gemm_mode()
+{
+#ifdef SGX_EMU
+    return 0;
+#else
+    if (g_det_gemm >= 0) return g_det_gemm;
+    const char *e = getenv("SGX_DET_GEMM");
+    if (e && *e) return (!strcmp(e, "f32") || !strcmp(e, "0")) ? 0 : 1;
+    return SGX_DET_GEMM_DEFAULT;
+#endif
+}
 
 // the 3 x 3 stride-2 stem on the k_conv_stem2 path (run_op) — also the condition for fusing the pre-processing into it (k_stem_pre)
 struct Stem2Geom { int nbx4, pitch4, RB, nbands; size_t lds; };
@@ -148,7 +171,7 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
 {
     if (!param_text || !bin || !out || width < 8 || height < 8 || width > SGX_PRE_MAXW || max_batch < 1) return SGX_ERR_INVALID;
     sgx_det *h = new sgx_det();
-    h->W = width; h->H = height; h->max_batch = max_batch; h->legacy = g_det_legacy; h->det_th = detection_confidence_threshold; h->dyn_th = dynamic_detection_confidence_threshold;
+    h->W = width; h->H = height; h->max_batch = max_batch; h->legacy = g_det_legacy; h->gemm = g_det_legacy ? 0 : det_gemm_mode(); h->det_th = detection_confidence_threshold; h->dyn_th = dynamic_detection_confidence_threshold;
     int rc = parse_param(param_text, h->layers);
     if (rc != SGX_OK) { delete h; return rc; }
     const int B = max_batch, T = h->T;
@@ -189,6 +212,15 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                     for (int o = 0; o < outc; o++) for (int q = 0; q < kk; q++) { float v; memcpy(&v, wsrc + (size_t)o * kk + q, 4); wT[(size_t)q * ldo + o] = v; }
                     if (h->alloc(&op.wtT, wT.size())) FAIL(SGX_ERR_NOMEM);
                     if (hipMemcpy(op.wtT, wT.data(), wT.size() * 4, hipMemcpyHostToDevice) != hipSuccess) FAIL(SGX_ERR_DEVICE);
+                    if (pw && h->gemm == 1) {                           // bf16x3 plan: the same weights as three bf16 terms in the matrix-core operand layout
+                        std::vector<float> wf((size_t)outc * kk); memcpy(wf.data(), wsrc, wf.size() * 4);
+                        std::vector<unsigned short> ws((size_t)((kk + 15) / 16) * 6 * ldo * 8);
+                        sgx_split_weights_bf16x3(wf.data(), outc, kk, ldo, ws.data());
+                        unsigned short *dws = nullptr;
+                        if (h->alloc(&dws, ws.size())) FAIL(SGX_ERR_NOMEM);
+                        if (hipMemcpy(dws, ws.data(), ws.size() * 2, hipMemcpyHostToDevice) != hipSuccess) FAIL(SGX_ERR_DEVICE);
+                        op.wS = dws;
+                    }
                 }
             }
             bo += (size_t)wsize * 4;
@@ -581,6 +613,12 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                     ib.wq2T = ops[ei].wtT; ib.bq2 = ops[ei].bias; ib.ldq2 = ops[ei].ldw; ib.wq2 = ops[ei].wt;
                 }
                 ib.has_res = res_blob >= 0; ib.hwc = c.hwc; ib.hwc_off = c.hwc_off;
+                {   // bf16x3 plan: every GEMM of the block needs its split weights (and the squeeze width must span the k16 steps the instantiation unrolls)
+                    const int nqs = NQ == 0 ? 1 : (NQ == 2 ? 3 : (NT == 2 ? 1 : 2));
+                    const bool ok3 = h->gemm == 1 && c.wS && (ai < 0 || ops[ai].wS) && (di < 0 || (ops[di].wS && ops[ei].wS && (ops[di].outc + 15) / 16 == nqs));
+                    ib.gemm = ok3 ? 1 : 0;
+                    if (ok3) { ib.w2S = c.wS; ib.w1S = ai >= 0 ? ops[ai].wS : nullptr; ib.wq1S = di >= 0 ? ops[di].wS : nullptr; ib.wq2S = di >= 0 ? ops[ei].wS : nullptr; }
+                }
                 {   // depthwise taps + bias, one padded row per channel
                     const int kk = bq.k * bq.k, rows = ((bq.outc + 31) / 32) * 32;
                     std::vector<float> wh((size_t)bq.outc * kk), bh(bq.outc), wp((size_t)rows * kkp, 0.f);
@@ -645,10 +683,10 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                     if (j == i || b.dead || b.kind != OP_IRB || b.irb.has_expand || !b.irb.hwc || b.irb.Cq || b.irb.Cout2 || b.in0 != a.in0) continue;
                     if (b.irb.K != a.irb.K || b.irb.S != a.irb.S || b.irb.Cexp != a.irb.Cexp || b.irb.H != a.irb.H || b.irb.W != a.irb.W || b.irb.act2 != a.irb.act2 ||
                         b.irb.a2lo != a.irb.a2lo || b.irb.a2hi != a.irb.a2hi || b.irb.G != a.irb.G || b.irb.nbands != a.irb.nbands) continue;
-                    if (b.irb.Cout > 32 || b.irb.Cout > a.irb.Cout) continue;                 // the narrow (loc) head rides along as the second accumulator set
+                    if (b.irb.Cout > 32 || b.irb.Cout > a.irb.Cout || b.irb.gemm != a.irb.gemm) continue;                 // the narrow (loc) head rides along as the second accumulator set
                     if (!sgx_irb_supported(a.irb.K, a.irb.S, (a.irb.Cout + 31) / 32, 0, false, a.irb.act2 == SGX_EMODE_HSWISH, 1)) continue;
                     SgxIrb m = a.irb;
-                    m.Cout2 = b.irb.Cout; m.hwc_off2 = b.irb.hwc_off; m.ld2b = b.irb.ld2; m.wdp2 = b.irb.wdp; m.w2Tb = b.irb.w2T; m.b2b = b.irb.b2;
+                    m.Cout2 = b.irb.Cout; m.hwc_off2 = b.irb.hwc_off; m.ld2b = b.irb.ld2; m.wdp2 = b.irb.wdp; m.w2Tb = b.irb.w2T; m.b2b = b.irb.b2; m.w2Sb = b.irb.w2S;
                     m.wd_b = b.irb.wd; m.bd_b = b.irb.bd; m.w2_b = b.irb.w2;
                     if (sgx_irb_lds_bytes(m) > 160 * 1024) { m.nbuf = 1; if (sgx_irb_lds_bytes(m) > 160 * 1024) continue; }
                     Op f = a; f.irb = m; f.irb_out2_blob = b.out; f.name = a.name + "|" + b.name;
@@ -739,6 +777,35 @@ static void run_op(sgx_det *h, const Op &op, int batch, sgx_stream_t st)
                        make_epi(h, op, (size_t)op.outc * N), op.hwc, op.hwc_off);
             break;
         }
+#ifndef SGX_EMU
+        if (h->gemm == 1 && op.wS) {
+            // bf16x3 (k_conv_pw3): same decomposition; the accumulators + the split operands cap the wave tile at four 32 x 32 sub-tiles
+            const int sub = (op.outc + 31) / 32, total = batch * N;
+            static const int cand3[6][2] = { {2, 2}, {4, 1}, {1, 4}, {2, 1}, {1, 2}, {1, 1} };
+            static const int force3 = getenv("SGX_PW3_FORCE") ? atoi(getenv("SGX_PW3_FORCE")) : 0;      // tuning tap: OCB * 10 + PXB
+            int ocb = 1, pxb = 1; long best_score = -1;
+            for (int c = 0; c < 6; c++) {
+                const int cb = cand3[c][0], cp = cand3[c][1];
+                const long nwg = (long)((total + 128 * cp - 1) / (128 * cp)) * ((sub + cb - 1) / cb);
+                const int padded = ((sub + cb - 1) / cb) * cb;
+                const long fill = std::min(nwg, 512L);
+                const long score = fill * 1000000L + (long)(1000 - (padded - sub) * 100) * 100L + cb * cp * 10 + cb;        // among equals: more oc tiles per split
+                if (score > best_score) { best_score = score; ocb = cb; pxb = cp; }
+            }
+            if (force3) { ocb = force3 / 10; pxb = force3 % 10; }
+            const int nxt = (total + 128 * pxb - 1) / (128 * pxb), noc = (sub + ocb - 1) / ocb;
+            const int grid = ((nxt + 7) / 8) * 8 * noc;
+            const SgxEpi e = make_epi(h, op, (size_t)op.outc * N);
+#define SGX_PW3(OCB_, PXB_) do { auto kfn = k_conv_pw3<OCB_, PXB_>; SGX_LAUNCH(kfn, dim3(grid), dim3(256), st, op.inc, op.outc, N, total, A.d, A.n, (const sgx_u32x4 *)op.wS, op.bias, \
+                                                                               O.d, O.n, e, op.hwc, op.hwc_off, nxt, noc, op.ldw, 1); } while (0)
+            switch (ocb * 10 + pxb) {
+            case 22: SGX_PW3(2, 2); break; case 41: SGX_PW3(4, 1); break; case 14: SGX_PW3(1, 4); break;
+            case 21: SGX_PW3(2, 1); break; case 12: SGX_PW3(1, 2); break; default: SGX_PW3(1, 1); break;
+            }
+#undef SGX_PW3
+            break;
+        }
+#endif
         // Tile choice.  oc block = OCB sub-tiles of 32 channels, wave tile = PXB sub-tiles of 32 pixels, workgroup = 4 waves along pixels.
         // Largest tile (most operand reuse) whose grid still gives every CU >= 2 workgroups, among those with the least oc padding;
         // if no candidate fills the chip, the one with the most workgroups.
@@ -951,14 +1018,14 @@ extern "C" int sgx_det_debug_op_desc(const sgx_det *h, int i, char *buf, int cap
     static const char *kn[] = { "pw", "kxk", "binary", "unary", "permute_into", "copy_into", "softmax", "block", "irb", "se_gate" };
     if (o.kind == OP_SE_GATE) { snprintf(buf, cap, "se_gate %s c%d->%d->%d %dx%d%s", o.name.c_str(), o.sg.Cout, o.sg.Cq, o.sg.Cout, o.H, o.W, o.sg_res_blob >= 0 ? " +res" : ""); return SGX_OK; }
     if (o.kind == OP_PW || o.kind == OP_KXK)
-        snprintf(buf, cap, "%s %s c%d->%d k%d s%d %s%dx%d->%dx%d epi%d%s", kn[o.kind], o.name.c_str(), o.inc, o.outc, o.k, o.stride, o.depthwise ? "dw " : "", o.H, o.W,
-                 o.kind == OP_PW ? o.H : o.Ho, o.kind == OP_PW ? o.W : o.Wo, (int)o.epi.size() + (o.act ? 1 : 0), o.hwc ? " hwc" : "");
+        snprintf(buf, cap, "%s %s c%d->%d k%d s%d %s%dx%d->%dx%d epi%d%s%s", kn[o.kind], o.name.c_str(), o.inc, o.outc, o.k, o.stride, o.depthwise ? "dw " : "", o.H, o.W,
+                 o.kind == OP_PW ? o.H : o.Ho, o.kind == OP_PW ? o.W : o.Wo, (int)o.epi.size() + (o.act ? 1 : 0), o.hwc ? " hwc" : "", (o.kind == OP_PW && h->gemm == 1 && o.wS) ? " bf16x3" : "");
     else if (o.kind == OP_FUSED_BLOCK)
         snprintf(buf, cap, "block %s c%d->%d->%d k%d s%d %dx%d->%dx%d tile %dx%d%s%s", o.name.c_str(), o.fb.Cin, o.fb.Cmid, o.fb.Cout, o.fb.K, o.fb.stride, o.H, o.W, o.Ho, o.Wo, o.fb.TOH, o.fb.TOW,
                  o.fb.Cq ? " se" : "", o.fb_res_blob >= 0 ? " +res" : "");
     else if (o.kind == OP_IRB)
-        snprintf(buf, cap, "irb %s c%d->%d->%d q%d k%d s%d %dx%d->%dx%d G%d bands%d buf%d%s%s%s", o.name.c_str(), o.irb.Cin, o.irb.Cexp, o.irb.Cout, o.irb.Cq, o.irb.K, o.irb.S, o.H, o.W, o.Ho, o.Wo,
-                 o.irb.G, o.irb.nbands, o.irb.nbuf, o.irb.has_expand ? "" : " noexp", o.irb_res_blob >= 0 ? " +res" : "", o.hwc ? (o.irb.Cout2 ? " hwc dual" : " hwc") : "");
+        snprintf(buf, cap, "irb %s c%d->%d->%d q%d k%d s%d %dx%d->%dx%d G%d bands%d buf%d%s%s%s%s", o.name.c_str(), o.irb.Cin, o.irb.Cexp, o.irb.Cout, o.irb.Cq, o.irb.K, o.irb.S, o.H, o.W, o.Ho, o.Wo,
+                 o.irb.G, o.irb.nbands, o.irb.nbuf, o.irb.has_expand ? "" : " noexp", o.irb_res_blob >= 0 ? " +res" : "", o.hwc ? (o.irb.Cout2 ? " hwc dual" : " hwc") : "", o.irb.gemm == 1 ? " bf16x3" : "");
     else snprintf(buf, cap, "%s %s n=%zu", kn[o.kind], o.name.c_str(), h->blobs[o.in0].n);
     return SGX_OK;
 }

@@ -21,6 +21,7 @@
 // elementwise programs as the per-layer kernels apply them — the block is bit-identical to the per-layer plan (tests: *_fused_equals_unfused).
 #pragma once
 #include "sgx_det_kernels.h"
+#include "sgx_det_bf16.h"
 #ifdef SGX_EMU
 #include <vector>
 #endif
@@ -46,6 +47,10 @@ struct SgxIrb {
     int Cout2, hwc_off2, ld2b; const float *wdp2, *w2Tb, *b2b; float *out2; size_t out2_pitch;
     // original ncnn layouts (emulator build)
     const float *w1, *wd, *bd, *w2, *wq1, *wq2, *wd_b, *bd_b, *w2_b;
+    // bf16x3 plan (k_irb3, sgx_det_bf16.h): the same weights split into three bf16 terms in the operand layout of v_mfma_f32_32x32x16_bf16, [k16 step][term][half][ld][8];
+    // ld = the ld of the fp32 copy.  gemm = 1 selects k_irb3
+    int gemm;
+    const void *w1S, *w2S, *wq1S, *wq2S, *w2Sb;
 };
 #define SGX_IRB_KKP(K) (((K) * (K) + 1 + 3) & ~3)
 static inline size_t sgx_irb_lds_bytes(const SgxIrb &p) { return (size_t)p.nbuf * 32 * ((size_t)p.planeT + (p.Cout2 ? 2 : 1) * SGX_IRB_KKP(p.K)) * 4; }
@@ -402,6 +407,354 @@ __global__ void __launch_bounds__(768) k_irb(SgxIrb p)
 }
 #endif
 
+#ifndef SGX_EMU
+// ---------------------------------------------------------------------------------------------
+// k_irb3: the block of k_irb with every matrix product on v_mfma_f32_32x32x16_bf16 (bf16x3, sgx_det_bf16.h).  Same work decomposition, LDS planes, barriers, depthwise
+// arithmetic (fmaf in tap order) and epilogue; what changes is the operand shape of the three GEMMs:
+//   expand   a k16 step = the lane's eight input channels 16 s + 8 half + j of its input pixel (eight row loads), split once, against three dwordx4 weight loads
+//   project  lane (half h, pixel) computes the depthwise outputs of channels 16 s + 8 h + j, j = 0..7, at ITS output pixel (was: one channel per k2 step): after the split
+//            they are the B operand of one k16 step for all NT output tiles
+//   squeeze-excite  accumulator rows -> B layout with FOUR v_permlane32_swap per k16 step (registers 8 q + i <-> 8 q + 4 + i: the lower half-wave ends up with rows
+//            16 q + 0..7, the upper with 16 q + 8..15), then the split
+// NQS = k16 steps of the squeeze width Cq (the launch checks it).
+// ---------------------------------------------------------------------------------------------
+SGX_DEV void sgx_irb_d2b16(const sgx_f32x16 &d, int q, float (&b)[8])
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(d[8 * q + i]), __float_as_uint(d[8 * q + 4 + i]), false, false);
+        b[i] = __uint_as_float(sw[0]); b[4 + i] = __uint_as_float(sw[1]);
+    }
+}
+
+template <int K, int S, int NT, int NQ, bool EXPAND, bool HS, int NT2>
+__global__ void __launch_bounds__(768) k_irb3(SgxIrb p)
+{
+    extern __shared__ __attribute__((aligned(16))) float sgx_irb_smem[];
+    constexpr int KK = K * K, KKP = SGX_IRB_KKP(K);
+    constexpr int AMODE = HS ? SGX_EMODE_HSWISH : SGX_EMODE_ACT;
+    constexpr int NQS = NQ == 0 ? 1 : (NQ == 2 ? 3 : (NT == 2 ? 1 : 2));
+    float *Eb = sgx_irb_smem;                                         // [nbuf][32][planeT]
+    float *Wds = sgx_irb_smem + (size_t)p.nbuf * 32 * p.planeT;       // [nbuf][32][KKP]
+    float *Wds2 = Wds + (size_t)p.nbuf * 32 * KKP;                    // second head's depthwise weights (NT2 > 0)
+    const int tid = (int)threadIdx.x, nthreads = (int)blockDim.x, wave = tid >> 6, nwaves = nthreads >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int HW = p.H * p.W, HWo = p.Ho * p.Wo;
+    int b0, nimg, oy0, OH;
+    if (p.nbands > 1) { b0 = (int)blockIdx.x / p.nbands; nimg = 1; oy0 = ((int)blockIdx.x - b0 * p.nbands) * p.OH; OH = min(p.OH, p.Ho - oy0); }
+    else { b0 = (int)blockIdx.x * p.G; nimg = min(p.G, p.batch - b0); oy0 = 0; OH = p.Ho; }
+    const int ypA = oy0 * S;
+    const int iyA = max(0, ypA - p.pad), iyB = min(p.H, (oy0 + OH - 1) * S + K - p.pad), IH = iyB - iyA;
+    const int PI = nimg * IH * p.W, PO = nimg * OH * p.Wo, ngi = (PI + 31) >> 5, ngo = (PO + 31) >> 5;
+    const bool owner = wave < ngo;
+    const int og = wave * 32 + l31; const bool ovalid = og < PO;
+    const int oc_ = min(og, PO - 1), og_img = oc_ / (OH * p.Wo), orem = oc_ - og_img * (OH * p.Wo), oyl = orem / p.Wo, ox = orem - oyl * p.Wo;
+    const int e_r = 8 * half * p.planeT + og_img * p.HpWp + oyl * S * p.Wp + ox * S;            // depthwise read base of channel 8 half (channel 16 s + j: + (16 s + j) planeT)
+    const unsigned opix = (unsigned)((oy0 + oyl) * p.Wo + ox);
+    const sgx_rsrc r_in = sgx_mkrsrc(p.in), r_b1 = sgx_mkrsrc_n(EXPAND ? p.b1 : p.b2, (EXPAND ? p.Cexp : p.Cout) * 4);
+
+    {
+        float4 *z = (float4 *)Eb; const int nz = p.nbuf * 8 * p.planeT;
+        for (int i = tid; i < nz; i += nthreads) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    sgx_f32x16 acc[NT];
+    {
+        const sgx_rsrc r_b2 = sgx_mkrsrc_n(p.b2, p.Cout * 4);
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[t][r] = SGX_IRB_BIAS(r_b2, t, r, half);
+    }
+    constexpr int NT2A = NT2 > 0 ? NT2 : 1;
+    sgx_f32x16 acc2[NT2A];
+    if (NT2 > 0) {
+        const sgx_rsrc r_b2b = sgx_mkrsrc_n(p.b2b, p.Cout2 * 4);
+#pragma unroll
+        for (int t = 0; t < NT2; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc2[t][r] = SGX_IRB_BIAS(r_b2b, t, r, half);
+    }
+    const int nchunks = (p.Cexp + 31) >> 5, bmask = p.nbuf - 1;
+    // split-weight operand pointers of this lane: + (6 ks + 2 term) ld + 32 tile   (in 16-byte units)
+    const sgx_u32x4 *a1p = (const sgx_u32x4 *)(EXPAND ? p.w1S : p.w2S) + (size_t)half * (EXPAND ? p.ld1 : p.ld2) + l31;
+    const sgx_u32x4 *a2p = (const sgx_u32x4 *)p.w2S + (size_t)half * p.ld2 + l31;
+    const sgx_u32x4 *a2bp = (const sgx_u32x4 *)(NT2 > 0 ? p.w2Sb : p.w2S) + (size_t)half * (NT2 > 0 ? p.ld2b : p.ld2) + l31;
+    const unsigned sXrow = (unsigned)HW * 4u;
+
+    // first stage-A tile of this wave (tile = wave): geometry is chunk-independent
+    const int q0 = wave * 32 + l31; const bool ivalid0 = q0 < PI && wave < ngi;
+    const int qc0 = min(q0, PI - 1), qi0 = qc0 / (IH * p.W), qrem0 = qc0 - qi0 * (IH * p.W), ry0 = qrem0 / p.W, ix0 = qrem0 - ry0 * p.W, iy0 = iyA + ry0;
+    const int ew0 = qi0 * p.HpWp + (iy0 + p.pad - ypA) * p.Wp + ix0 + p.pad;
+    const unsigned xpix0 = (unsigned)((size_t)(b0 + qi0) * p.in_pitch + (size_t)iy0 * p.W + ix0) * 4u;               // channel 0 of the lane's input pixel
+    const unsigned xoff0 = xpix0 + (unsigned)half * sXrow;                                                            // no-expand staging: channel pair layout of k_irb
+
+    // depthwise convolution of the lane's eight channels of k16 step s at its output pixel, split into the three bf16 operands pair by pair (a channel pair is
+    // one register of each term); a scheduling fence per channel (5 x 5) or pair (3 x 3) keeps the live set at one or two channels' taps and weights
+    auto dw8 = [&](const float *E, const float *Wc, const float *Wc2, int s, SgxB3 &bo, SgxB3 &bo2) {
+#pragma unroll
+        for (int jp = 0; jp < 4; jp++) {
+            float vv[2], vv2[2];
+#pragma unroll
+            for (int jh = 0; jh < 2; jh++) {
+                const int j = 2 * jp + jh;
+                float w[KKP], tp[KK];
+                const float *wj = Wc + (16 * s + j) * KKP;
+#pragma unroll
+                for (int i = 0; i < KKP / 4; i++) { const float4 q4 = ((const float4 *)wj)[i]; w[4 * i] = q4.x; w[4 * i + 1] = q4.y; w[4 * i + 2] = q4.z; w[4 * i + 3] = q4.w; }
+                const float *ep = E + (size_t)(16 * s + j) * p.planeT;
+#pragma unroll
+                for (int i = 0; i < K; i++)
+#pragma unroll
+                    for (int jj = 0; jj < K; jj++) tp[i * K + jj] = ep[i * p.Wp + jj];
+                float v = w[KK];
+#pragma unroll
+                for (int t = 0; t < KK; t++) v = fmaf(w[t], tp[t], v);
+                vv[jh] = sgx_irb_act(AMODE, v, p.a2c1, p.a2lo, p.a2hi, p.a2c2);
+                if (NT2 > 0) {
+                    float w2[KKP];
+                    const float *wj2 = Wc2 + (16 * s + j) * KKP;
+#pragma unroll
+                    for (int i = 0; i < KKP / 4; i++) { const float4 q4 = ((const float4 *)wj2)[i]; w2[4 * i] = q4.x; w2[4 * i + 1] = q4.y; w2[4 * i + 2] = q4.z; w2[4 * i + 3] = q4.w; }
+                    float u = w2[KK];
+#pragma unroll
+                    for (int t = 0; t < KK; t++) u = fmaf(w2[t], tp[t], u);
+                    vv2[jh] = sgx_irb_act(AMODE, u, p.a2c1, p.a2lo, p.a2hi, p.a2c2);
+                }
+                if (K == 5) __builtin_amdgcn_sched_barrier(0);
+            }
+            { unsigned a0, a1, a2; sgx_split3(vv[0], vv[1], a0, a1, a2); bo.t0[jp] = a0; bo.t1[jp] = a1; bo.t2[jp] = a2; }
+            if (NT2 > 0) { unsigned a0, a1, a2; sgx_split3(vv2[0], vv2[1], a0, a1, a2); bo2.t0[jp] = a0; bo2.t1[jp] = a1; bo2.t2[jp] = a2; }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    for (int c = -1; c < nchunks; c++) {
+        const int ch1 = (c + 1) * 32, buf1 = (c + 1) & bmask;
+        const bool more = c + 1 < nchunks;
+        float pre[EXPAND ? 1 : 16];
+        if (!EXPAND && more && p.nbuf == 2) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) pre[r] = sgx_bld(r_in, xoff0, (unsigned)min(ch1 + 2 * r, p.Cexp - 2) / 2u * (2u * sXrow));
+        }
+        const int a_first = (p.nbuf == 2 && p.stagger) ? ((wave >> 2) & 1) : 0;
+#pragma unroll 1
+        for (int hp = 0; hp < 2; hp++) {
+        if (hp == a_first && c >= 0 && owner) {
+            // ---- stage B of chunk c: depthwise -> split -> project on the bf16 matrix pipes
+            const int ch0 = c * 32, nks = min(2, (p.Cexp - ch0 + 15) >> 4), buf = c & bmask;
+            const float *E = Eb + (size_t)buf * 32 * p.planeT + e_r;
+            const float *Wc = Wds + (size_t)buf * 32 * KKP + 8 * half * KKP, *Wc2 = Wds2 + (size_t)buf * 32 * KKP + 8 * half * KKP;
+            for (int s = 0; s < nks; s++) {
+                const sgx_u32x4 *wa = a2p + (size_t)(6 * (2 * c + s)) * p.ld2, *wb = a2bp + (size_t)(6 * (2 * c + s)) * (NT2 > 0 ? p.ld2b : p.ld2);
+                // A operands: tile t + 1 is requested while tile t multiplies (two register sets; one for the five-tile blocks, whose accumulators leave no room)
+                constexpr int AR = NT >= 5 ? 1 : 2;
+                sgx_u32x4 ar[AR][3];
+#pragma unroll
+                for (int q = 0; q < 3; q++) ar[0][q] = wa[(size_t)(2 * q) * p.ld2];
+                SgxB3 b, bb;
+                dw8(E, Wc, Wc2, s, b, bb);
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    if (AR == 2) {
+                        if (t + 1 < NT) {
+#pragma unroll
+                            for (int q = 0; q < 3; q++) ar[(t + 1) % AR][q] = wa[(size_t)(2 * q) * p.ld2 + 32 * (t + 1)];
+                        } else if (NT2 > 0) {
+#pragma unroll
+                            for (int q = 0; q < 3; q++) ar[(t + 1) % AR][q] = wb[(size_t)(2 * q) * p.ld2b];
+                        }
+                    } else if (t > 0) {
+#pragma unroll
+                        for (int q = 0; q < 3; q++) ar[0][q] = wa[(size_t)(2 * q) * p.ld2 + 32 * t];
+                    }
+                    acc[t] = sgx_mfma_bf16x3(ar[t % AR][0], ar[t % AR][1], ar[t % AR][2], b, acc[t]);
+                }
+                if (NT2 > 0) {
+#pragma unroll
+                    for (int t = 0; t < NT2; t++) {
+                        if (AR == 1 || t > 0) {
+#pragma unroll
+                            for (int q = 0; q < 3; q++) ar[(NT + t) % AR][q] = wb[(size_t)(2 * q) * p.ld2b + 32 * t];
+                        }
+                        acc2[t] = sgx_mfma_bf16x3(ar[(NT + t) % AR][0], ar[(NT + t) % AR][1], ar[(NT + t) % AR][2], bb, acc2[t]);
+                    }
+                }
+            }
+        }
+        if (p.nbuf == 1 && hp == 0) __syncthreads();
+        // ---- stage A of chunk c + 1 into its plane buffer
+        if (hp != a_first && more) {
+            float *E = Eb + (size_t)buf1 * 32 * p.planeT;
+            for (int i = tid; i < 8 * KKP; i += nthreads) ((float4 *)(Wds + (size_t)buf1 * 32 * KKP))[i] = ((const float4 *)(p.wdp + (size_t)ch1 * KKP))[i];
+            if (NT2 > 0) for (int i = tid; i < 8 * KKP; i += nthreads) ((float4 *)(Wds2 + (size_t)buf1 * 32 * KKP))[i] = ((const float4 *)(p.wdp2 + (size_t)ch1 * KKP))[i];
+            for (int tile = wave; tile < ngi; tile += nwaves) {
+                const bool first = tile == wave;
+                int ew; unsigned xpix; bool ivalid;
+                if (first) { ew = ew0; xpix = xpix0; ivalid = ivalid0; }
+                else {
+                    const int q = tile * 32 + l31; ivalid = q < PI;
+                    const int qc = min(q, PI - 1), qi = qc / (IH * p.W), qrem = qc - qi * (IH * p.W), ry = qrem / p.W, ix = qrem - ry * p.W, iy = iyA + ry;
+                    ew = qi * p.HpWp + (iy + p.pad - ypA) * p.Wp + ix + p.pad;
+                    xpix = (unsigned)((size_t)(b0 + qi) * p.in_pitch + (size_t)iy * p.W + ix) * 4u;
+                }
+                float *Ew = E + ew;
+                if (EXPAND) {
+                    sgx_f32x16 e;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) e[r] = sgx_bld(r_b1, (unsigned)half * 16u, (unsigned)(ch1 + (r & 3) + 8 * (r >> 2)) * 4u);
+                    const int nks1 = (p.Cin + 15) >> 4;
+                    const unsigned xh8 = xpix + (unsigned)(8 * half) * sXrow;
+                    // input channels 16 s + 8 half + j of the lane's input pixel; the last step of a block whose Cin is not a multiple of 16 clamps its rows per lane
+                    // (they meet zero weight rows)
+                    auto loadX = [&](int s, float (&dst)[8]) {
+                        if (16 * s + 16 <= p.Cin) {
+#pragma unroll
+                            for (int j = 0; j < 8; j++) dst[j] = sgx_bld(r_in, xh8, (unsigned)(16 * s + j) * sXrow);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 8; j++) dst[j] = sgx_bld(r_in, xpix + (unsigned)min(16 * s + 8 * half + j, p.Cin - 1) * sXrow, 0u);
+                        }
+                    };
+                    const sgx_u32x4 *w1l = a1p + ch1;
+                    auto loadW = [&](int s, sgx_u32x4 (&dst)[3]) {
+#pragma unroll
+                        for (int q = 0; q < 3; q++) dst[q] = w1l[(size_t)(6 * s + 2 * q) * p.ld1];
+                    };
+                    // input rows one k16 step ahead (two register sets), weights of the step requested in front of the split that precedes their use
+                    float xr[2][8]; sgx_u32x4 wr[3];
+                    loadX(0, xr[0]);
+                    for (int s0 = 0; s0 < nks1; s0 += 2) {
+#pragma unroll
+                        for (int d = 0; d < 2; d++) {
+                            const int s = s0 + d;
+                            if (s < nks1) {
+                                loadW(s, wr);
+                                loadX(min(s + 1, nks1 - 1), xr[d ^ 1]);
+                                const SgxB3 b = sgx_split3x8(xr[d]);
+                                e = sgx_mfma_bf16x3(wr[0], wr[1], wr[2], b, e);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; r++) e[r] = sgx_irb_act(AMODE, e[r], p.a1c1, p.a1lo, p.a1hi, p.a1c2);
+                    if (ivalid) {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) Ew[(size_t)((r & 3) + 8 * (r >> 2) + 4 * half) * p.planeT] = e[r];
+                    }
+                } else {
+                    const unsigned xoff = xpix + (unsigned)half * sXrow;
+                    float v[16];
+                    if (first && p.nbuf == 2) {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) v[r] = pre[r];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) v[r] = sgx_bld(r_in, xoff, (unsigned)min(ch1 + 2 * r, p.Cexp - 2) / 2u * (2u * sXrow));
+                    }
+                    if (ivalid) {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) Ew[(size_t)(2 * r + half) * p.planeT] = v[r];
+                    }
+                }
+            }
+        }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: [squeeze-excite gate] [+ residual], store
+    if (!owner) return;
+    if (NQ > 0) {
+        const sgx_rsrc r_bq1 = sgx_mkrsrc_n(p.bq1, p.Cq * 4), r_bq2 = sgx_mkrsrc_n(p.bq2, p.Cout * 4);
+        constexpr int NQ1 = NQ > 0 ? NQ : 1;
+        const sgx_u32x4 *q1p = (const sgx_u32x4 *)p.wq1S + (size_t)half * p.ldq1 + l31, *q2p = (const sgx_u32x4 *)p.wq2S + (size_t)half * p.ldq2 + l31;
+        sgx_f32x16 qa[NQ1];
+#pragma unroll
+        for (int u = 0; u < NQ; u++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) qa[u][r] = SGX_IRB_BIAS(r_bq1, u, r, half);
+        // squeeze: K = Cout, two k16 steps per accumulator tile
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int ks = 2 * t + q;
+                if (16 * ks < p.Cout) {
+                    sgx_u32x4 aq[NQ1][3];
+#pragma unroll
+                    for (int u = 0; u < NQ; u++)
+#pragma unroll
+                        for (int m = 0; m < 3; m++) aq[u][m] = q1p[(size_t)(6 * ks + 2 * m) * p.ldq1 + 32 * u];
+                    float bv[8];
+                    sgx_irb_d2b16(acc[t], q, bv);
+                    const SgxB3 b = sgx_split3x8(bv);
+#pragma unroll
+                    for (int u = 0; u < NQ; u++) qa[u] = sgx_mfma_bf16x3(aq[u][0], aq[u][1], aq[u][2], b, qa[u]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        SgxB3 qb[NQS];
+#pragma unroll
+        for (int g = 0; g < NQS; g++) {
+            float bv[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) { qa[g >> 1][8 * (g & 1) + r] = sgx_clipf(qa[g >> 1][8 * (g & 1) + r], p.qlo, p.qhi); }
+            sgx_irb_d2b16(qa[g >> 1], g & 1, bv);
+            qb[g] = sgx_split3x8(bv);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // excite: K = Cq (NQS k16 steps), gate, multiply
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            sgx_f32x16 ga;
+#pragma unroll
+            for (int r = 0; r < 16; r++) ga[r] = SGX_IRB_BIAS(r_bq2, t, r, half);
+#pragma unroll
+            for (int g = 0; g < NQS; g++) {
+                sgx_u32x4 ae[3];
+#pragma unroll
+                for (int m = 0; m < 3; m++) ae[m] = q2p[(size_t)(6 * g + 2 * m) * p.ldq2 + 32 * t];
+                ga = sgx_mfma_bf16x3(ae[0], ae[1], ae[2], qb[g], ga);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) { float u_ = ga[r] + p.gc1; u_ = sgx_clipf(u_, p.glo, p.ghi); u_ = sgx_div_c2(u_, p.gc2); acc[t][r] = u_ * acc[t][r]; }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (ovalid) {
+        const sgx_rsrc r_out = sgx_mkrsrc(p.out), r_res = sgx_mkrsrc(p.has_res ? (const void *)p.res : (const void *)p.out);
+        const unsigned rvo = (unsigned)((size_t)(b0 + og_img) * p.res_pitch + opix + (size_t)4 * half * HWo) * 4u;
+        const unsigned ovo = p.hwc ? (unsigned)((size_t)(b0 + og_img) * p.out_pitch + (size_t)p.hwc_off + (size_t)opix * p.Cout + 4 * half) * 4u
+                                   : (unsigned)((size_t)(b0 + og_img) * p.out_pitch + opix + (size_t)4 * half * HWo) * 4u;
+        const unsigned rowstep = p.hwc ? 4u : (unsigned)HWo * 4u;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int rb = 32 * t + (r & 3) + 8 * (r >> 2);
+                if (rb + 4 * half < p.Cout) {
+                    float v = acc[t][r];
+                    if (p.has_res) v = v + sgx_bld(r_res, rvo, (unsigned)rb * (unsigned)HWo * 4u);
+                    sgx_bst(r_out, ovo, (unsigned)rb * rowstep, v);
+                }
+            }
+        }
+    }
+    if (NT2 > 0 && ovalid) {
+        const sgx_rsrc r_o2 = sgx_mkrsrc(p.out2);
+        const unsigned ovo2 = (unsigned)((size_t)(b0 + og_img) * p.out2_pitch + (size_t)p.hwc_off2 + (size_t)opix * p.Cout2 + 4 * half) * 4u;
+#pragma unroll
+        for (int t = 0; t < NT2; t++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int rb = 32 * t + (r & 3) + 8 * (r >> 2);
+                if (rb + 4 * half < p.Cout2) sgx_bst(r_o2, ovo2, (unsigned)rb * 4u, acc2[t][r]);
+            }
+        }
+    }
+}
+#endif
+
 #ifdef SGX_EMU
 // kernel-logic emulator: the block as scalar fmaf chains in the device kernel's order (bias first, k ascending, taps (i, j) ascending; taps in the zero
 // padding add an exact zero), one call per image.
@@ -496,6 +849,17 @@ static inline int sgx_irb_launch(const SgxIrb &p, int batch, sgx_stream_t st)
     const size_t lds = sgx_irb_lds_bytes(p);
     if (nw > 12 || lds > 160 * 1024) return SGX_ERR_UNSUPPORTED;
     SgxIrb q = p; q.batch = batch;
+    if (p.gemm == 1) {
+        const int nqs = NQ == 0 ? 1 : (NQ == 2 ? 3 : (NT == 2 ? 1 : 2));
+        if (NQ > 0 && (p.Cq + 15) / 16 != nqs) return SGX_ERR_UNSUPPORTED;
+#define SGX_IRB_X(K_, S_, NT_, NQ_, E_, H_, N2_) if (p.K == K_ && p.S == S_ && NT == NT_ && NQ == NQ_ && (p.has_expand != 0) == E_ && (p.act2 == SGX_EMODE_HSWISH) == H_ && NT2 == N2_) { \
+        auto kfn = k_irb3<K_, S_, NT_, NQ_, E_, H_, N2_>; static bool attr = false; \
+        if (!attr) { (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * nw), lds, st, q); return SGX_OK; }
+        SGX_IRB_INSTANCES(SGX_IRB_X)
+#undef SGX_IRB_X
+        return SGX_ERR_UNSUPPORTED;
+    }
 #define SGX_IRB_X(K_, S_, NT_, NQ_, E_, H_, N2_) if (p.K == K_ && p.S == S_ && NT == NT_ && NQ == NQ_ && (p.has_expand != 0) == E_ && (p.act2 == SGX_EMODE_HSWISH) == H_ && NT2 == N2_) { \
         auto kfn = k_irb<K_, S_, NT_, NQ_, E_, H_, N2_>; static bool attr = false; \
         if (!attr) { (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \

@@ -327,6 +327,72 @@ SGX_DEV void sgx_pw2_store_direct(const SgxEpi &epi, const sgx_f32x16 (&acc)[OCB
 }
 #endif
 
+#ifndef SGX_EMU
+// Epilogue of the pointwise GEMM kernels (k_conv_pw2: exact fp32 MFMA; k_conv_pw3: bf16x3 MFMA — same accumulator layout): CHW outputs with a recognised program go
+// straight from the accumulators; otherwise one 32x32 tile at a time through a wave-private LDS tile: a compact run-time loop applies the elementwise program
+// (64 inlined copies of it cost hundreds of VGPRs), and the read-back order is chosen per store layout so stores stay contiguous (CHW: lanes along pixels; HWC:
+// lanes along channels).
+template <int OCB, int PXB>
+SGX_DEV void sgx_pw2_epilogue(const SgxEpi &epi, const sgx_f32x16 (&acc)[OCB][PXB], float (*E)[33], int oc0, int outc, int N, int total, int g0, int half, int l31,
+                              float *out, size_t out_pitch, const unsigned (&ooff4)[PXB], const unsigned (&toff4)[PXB], int hwc, int hwc_off, int direct)
+{
+    if (!hwc && direct && epi.mode != SGX_EMODE_GENERIC) {
+        unsigned od[PXB], td[PXB]; bool pv[PXB];
+#pragma unroll
+        for (int m = 0; m < PXB; m++) {
+            const unsigned h3 = 3u * (unsigned)half * (unsigned)N * 4u;     // ooff4 already carries half * N: rows of the upper half-wave are 4 further down
+            od[m] = ooff4[m] + h3; td[m] = toff4[m] + h3; pv[m] = g0 + 32 * m + l31 < total;
+        }
+        switch (epi.mode) {
+        case SGX_EMODE_NONE: sgx_pw2_store_direct<SGX_EMODE_NONE, OCB, PXB>(epi, acc, oc0, outc, N, half, pv, out, od, td); break;
+        case SGX_EMODE_ACT: sgx_pw2_store_direct<SGX_EMODE_ACT, OCB, PXB>(epi, acc, oc0, outc, N, half, pv, out, od, td); break;
+        case SGX_EMODE_HSWISH: sgx_pw2_store_direct<SGX_EMODE_HSWISH, OCB, PXB>(epi, acc, oc0, outc, N, half, pv, out, od, td); break;
+        case SGX_EMODE_GATE: sgx_pw2_store_direct<SGX_EMODE_GATE, OCB, PXB>(epi, acc, oc0, outc, N, half, pv, out, od, td); break;
+        case SGX_EMODE_GATE_ADD: sgx_pw2_store_direct<SGX_EMODE_GATE_ADD, OCB, PXB>(epi, acc, oc0, outc, N, half, pv, out, od, td); break;
+        default: sgx_pw2_store_direct<SGX_EMODE_ADD_T, OCB, PXB>(epi, acc, oc0, outc, N, half, pv, out, od, td); break;
+        }
+        return;
+    }
+#pragma unroll 1
+    for (int tile = 0; tile < OCB * PXB; tile++) {
+        const int m = tile / OCB, t = tile - m * OCB;
+        __syncthreads();
+#pragma unroll
+        for (int tt = 0; tt < OCB * PXB; tt++)
+            if (tt == tile) {                                // static register indices, one uniform branch per tile
+#pragma unroll
+                for (int r = 0; r < 16; r++) E[(r & 3) + 8 * (r >> 2) + 4 * half][l31] = acc[tt % OCB][tt / OCB][r];
+            }
+        __syncthreads();
+        unsigned oo = ooff4[0], to = toff4[0];
+#pragma unroll
+        for (int q = 1; q < PXB; q++) if (m == q) { oo = ooff4[q]; to = toff4[q]; }
+        const int gt = g0 + 32 * m, rt = oc0 + 32 * t;
+        if (!hwc) {
+            const int nj = gt + l31 < total ? min(16, (outc - rt - half + 1) / 2) : 0;              // rows rt + half + 2j < outc
+            switch (epi.mode) {
+            case SGX_EMODE_NONE: sgx_pw2_readback<SGX_EMODE_NONE>(epi, E, nj, rt, N, half, l31, out, oo, to); break;
+            case SGX_EMODE_ACT: sgx_pw2_readback<SGX_EMODE_ACT>(epi, E, nj, rt, N, half, l31, out, oo, to); break;
+            case SGX_EMODE_HSWISH: sgx_pw2_readback<SGX_EMODE_HSWISH>(epi, E, nj, rt, N, half, l31, out, oo, to); break;
+            case SGX_EMODE_GATE: sgx_pw2_readback<SGX_EMODE_GATE>(epi, E, nj, rt, N, half, l31, out, oo, to); break;
+            case SGX_EMODE_GATE_ADD: sgx_pw2_readback<SGX_EMODE_GATE_ADD>(epi, E, nj, rt, N, half, l31, out, oo, to); break;
+            case SGX_EMODE_ADD_T: sgx_pw2_readback<SGX_EMODE_ADD_T>(epi, E, nj, rt, N, half, l31, out, oo, to); break;
+            default: sgx_pw2_readback<SGX_EMODE_GENERIC>(epi, E, nj, rt, N, half, l31, out, oo, to); break;
+            }
+        } else {
+            const int row = rt + l31;
+#pragma unroll 1
+            for (int j = 0; j < 16; j++) {
+                const int cc = 2 * j + half, g = gt + cc;
+                const unsigned gg = (unsigned)min(g, total - 1), b = gg / (unsigned)N, n = gg - b * (unsigned)N;
+                if (g < total && row < outc)
+                    out[(size_t)b * out_pitch + (size_t)hwc_off + (size_t)n * outc + row] = sgx_epi(epi, E[l31][cc], (size_t)b * epi.tpitch + (size_t)row * N + n, 0);
+            }
+        }
+    }
+}
+#endif
+
 template <int OCB, int PXB>
 SGX_KERNEL_OCC(256, (OCB * PXB <= 4 ? 4 : (OCB * PXB <= 6 ? 3 : 2))) k_conv_pw2(int inc, int outc, int N, int total, const float *in, size_t in_pitch, const float *WtT, const float *bias,
                            float *out, size_t out_pitch, SgxEpi epi, int hwc, int hwc_off, int nxt, int noc, int ldw, int direct)
@@ -413,64 +479,7 @@ SGX_KERNEL_OCC(256, (OCB * PXB <= 4 ? 4 : (OCB * PXB <= 6 ? 3 : 2))) k_conv_pw2(
         }
         __syncthreads();
     }
-    // ---- epilogue, one 32x32 tile at a time through a wave-private LDS tile: a compact run-time loop applies the elementwise program
-    // (64 inlined copies of it cost hundreds of VGPRs), and the read-back order is chosen per store layout so stores stay contiguous
-    // (CHW: lanes along pixels; HWC: lanes along channels).
-    if (!hwc && direct && epi.mode != SGX_EMODE_GENERIC) {
-        unsigned od[PXB], td[PXB]; bool pv[PXB];
-#pragma unroll
-        for (int m = 0; m < PXB; m++) {
-            const unsigned h3 = 3u * (unsigned)half * (unsigned)N * 4u;     // ooff4 already carries half * N: rows of the upper half-wave are 4 further down
-            od[m] = ooff4[m] + h3; td[m] = toff4[m] + h3; pv[m] = g0 + 32 * m + l31 < total;
-        }
-        switch (epi.mode) {
-        case SGX_EMODE_NONE: sgx_pw2_store_direct<SGX_EMODE_NONE, OCB, PXB>(epi, acc, oc0, outc, N, half, pv, out, od, td); break;
-        case SGX_EMODE_ACT: sgx_pw2_store_direct<SGX_EMODE_ACT, OCB, PXB>(epi, acc, oc0, outc, N, half, pv, out, od, td); break;
-        case SGX_EMODE_HSWISH: sgx_pw2_store_direct<SGX_EMODE_HSWISH, OCB, PXB>(epi, acc, oc0, outc, N, half, pv, out, od, td); break;
-        case SGX_EMODE_GATE: sgx_pw2_store_direct<SGX_EMODE_GATE, OCB, PXB>(epi, acc, oc0, outc, N, half, pv, out, od, td); break;
-        case SGX_EMODE_GATE_ADD: sgx_pw2_store_direct<SGX_EMODE_GATE_ADD, OCB, PXB>(epi, acc, oc0, outc, N, half, pv, out, od, td); break;
-        default: sgx_pw2_store_direct<SGX_EMODE_ADD_T, OCB, PXB>(epi, acc, oc0, outc, N, half, pv, out, od, td); break;
-        }
-        return;
-    }
-    float (*E)[33] = Es[wave];
-#pragma unroll 1
-    for (int tile = 0; tile < OCB * PXB; tile++) {
-        const int m = tile / OCB, t = tile - m * OCB;
-        __syncthreads();
-#pragma unroll
-        for (int tt = 0; tt < OCB * PXB; tt++)
-            if (tt == tile) {                                // static register indices, one uniform branch per tile
-#pragma unroll
-                for (int r = 0; r < 16; r++) E[(r & 3) + 8 * (r >> 2) + 4 * half][l31] = acc[tt % OCB][tt / OCB][r];
-            }
-        __syncthreads();
-        unsigned oo = ooff4[0], to = toff4[0];
-#pragma unroll
-        for (int q = 1; q < PXB; q++) if (m == q) { oo = ooff4[q]; to = toff4[q]; }
-        const int gt = g0 + 32 * m, rt = oc0 + 32 * t;
-        if (!hwc) {
-            const int nj = gt + l31 < total ? min(16, (outc - rt - half + 1) / 2) : 0;              // rows rt + half + 2j < outc
-            switch (epi.mode) {
-            case SGX_EMODE_NONE: sgx_pw2_readback<SGX_EMODE_NONE>(epi, E, nj, rt, N, half, l31, out, oo, to); break;
-            case SGX_EMODE_ACT: sgx_pw2_readback<SGX_EMODE_ACT>(epi, E, nj, rt, N, half, l31, out, oo, to); break;
-            case SGX_EMODE_HSWISH: sgx_pw2_readback<SGX_EMODE_HSWISH>(epi, E, nj, rt, N, half, l31, out, oo, to); break;
-            case SGX_EMODE_GATE: sgx_pw2_readback<SGX_EMODE_GATE>(epi, E, nj, rt, N, half, l31, out, oo, to); break;
-            case SGX_EMODE_GATE_ADD: sgx_pw2_readback<SGX_EMODE_GATE_ADD>(epi, E, nj, rt, N, half, l31, out, oo, to); break;
-            case SGX_EMODE_ADD_T: sgx_pw2_readback<SGX_EMODE_ADD_T>(epi, E, nj, rt, N, half, l31, out, oo, to); break;
-            default: sgx_pw2_readback<SGX_EMODE_GENERIC>(epi, E, nj, rt, N, half, l31, out, oo, to); break;
-            }
-        } else {
-            const int row = rt + l31;
-#pragma unroll 1
-            for (int j = 0; j < 16; j++) {
-                const int cc = 2 * j + half, g = gt + cc;
-                const unsigned gg = (unsigned)min(g, total - 1), b = gg / (unsigned)N, n = gg - b * (unsigned)N;
-                if (g < total && row < outc)
-                    out[(size_t)b * out_pitch + (size_t)hwc_off + (size_t)n * outc + row] = sgx_epi(epi, E[l31][cc], (size_t)b * epi.tpitch + (size_t)row * N + n, 0);
-            }
-        }
-    }
+    sgx_pw2_epilogue<OCB, PXB>(epi, acc, Es[wave], oc0, outc, N, total, g0, half, l31, out, out_pitch, ooff4, toff4, hwc, hwc_off, direct);
 #else
     (void)Ws; (void)Es; (void)Bs;
     SGX_THREADS_BEGIN(tid)

@@ -13,7 +13,7 @@ CLASS_NAMES = ["background", "aeroplane", "bicycle", "bird", "boat", "bottle", "
 
 class Detector2D:
     def __init__(self, detection_confidence_threshold, dynamic_detection_confidence_threshold, param_path=None, bin_path=None,
-                 param_text=None, bin_bytes=None, width=640, height=480, max_batch=1, lib=None, fuse=True, legacy_kernels=False, block_fusion=False, irb=None):
+                 param_text=None, bin_bytes=None, width=640, height=480, max_batch=1, lib=None, fuse=True, legacy_kernels=False, block_fusion=False, irb=None, gemm=None):
         self.lib = lib if lib is not None else load()
         if param_text is None:
             param_text = open(param_path or './Thirdparty/ncnn_model/mobilenetv3_ssdlite_voc.param').read()      # Detector2D.cc:24
@@ -25,13 +25,16 @@ class Detector2D:
         self.lib.dll.sgx_det_debug_set_legacy_kernels(1 if legacy_kernels else 0)      # simple reference kernels instead of the tuned ones (tests)
         self.lib.dll.sgx_det_debug_set_block_fusion(1 if block_fusion else 0)          # opt-in: expand -> depthwise -> project as one kernel (tests / tuning)
         self.lib.dll.sgx_det_debug_set_irb(-1 if irb is None else (2 if irb is True else int(irb)))    # inverted-residual blocks / heads as one matrix-core kernel each: None = default (the shapes where it wins), True / 2 = every supported shape, False / 0 = off
+        # gemm: None = the library's default, 'f32' = exact fp32 matrix products (bit-identical to the per-layer reference kernels), 'bf16x3' = three-term bf16 split on the bf16 matrix pipes
+        self.lib.dll.sgx_det_debug_set_gemm(-1 if gemm is None else (0 if gemm in (0, 'f32') else 1))
         self.lib.check(self.lib.dll.sgx_det_create(param_text.encode(), bin_bytes, len(bin_bytes), width, height, max_batch,
                                                    float(detection_confidence_threshold), float(dynamic_detection_confidence_threshold), C.byref(h)), 'sgx_det_create')
-        self.lib.dll.sgx_det_debug_set_fusion(1); self.lib.dll.sgx_det_debug_set_legacy_kernels(0); self.lib.dll.sgx_det_debug_set_block_fusion(0); self.lib.dll.sgx_det_debug_set_irb(-1)
+        self.lib.dll.sgx_det_debug_set_fusion(1); self.lib.dll.sgx_det_debug_set_legacy_kernels(0); self.lib.dll.sgx_det_debug_set_block_fusion(0); self.lib.dll.sgx_det_debug_set_irb(-1); self.lib.dll.sgx_det_debug_set_gemm(-1)
         self.h = h; self.width, self.height, self.max_batch = width, height, max_batch
         npri, ncls, nk = C.c_int32(), C.c_int32(), C.c_int32(); g = C.c_double()
         self.lib.check(self.lib.dll.sgx_det_info(self.h, C.byref(npri), C.byref(ncls), C.byref(nk), C.byref(g)))
         self.num_priors, self.num_class, self.num_kernels, self.gmac = npri.value, ncls.value, nk.value, g.value
+        self.gemm = 'bf16x3' if self.lib.dll.sgx_det_gemm_mode(self.h) == 1 else 'f32'
         self.mvObjects2D = []; self.mbHaveDynamicObjectForMapping = False; self.mbHaveDynamicObjectForRmDynamicFeature = False
         self.mvPotentialDynamicBorderForMapping = []; self.mvPotentialDynamicBorderForRmDynamicFeature = []
 

@@ -10,6 +10,24 @@ def test_detector_gpu_matches_oracle(gpulib, model):
     run_compare(gpulib, model)
 
 
+def test_detector_gpu_exact_fp32_plan_matches_oracle(gpulib, model):
+    """the exact-fp32 matrix products (SGX_DET_GEMM=f32): the anchor plan of the plan-equality tests"""
+    run_compare(gpulib, model, seeds=(0,), gemm='f32')
+    run_compare(gpulib, model, seeds=(0,), fuse=True, gemm='f32')
+
+
+def test_detector_gpu_bf16x3_plan_matches_oracle(gpulib, model):
+    """the bf16x3 matrix products (three-term bf16 split, six cross products on v_mfma_f32_32x32x16_bf16): same criterion as the fp32 plan, per-layer and fused"""
+    run_compare(gpulib, model, gemm='bf16x3')
+    run_compare(gpulib, model, fuse=True, gemm='bf16x3')
+
+
+def test_detector_gpu_bf16x3_drift_within_1p5x_of_fp32_and_same_detections(gpulib, model):
+    from test_detector import run_bf16x3_against_f32
+    worst = run_bf16x3_against_f32(gpulib, model)
+    print('bf16x3 drift / fp32 drift, worst over the images:', {k: round(v, 3) for k, v in worst.items()})
+
+
 def test_dynamic_mask_gpu(gpulib):
     import torch
     run_mask(gpulib, to_dev=lambda a: torch.from_numpy(a.view(np.uint8) if a.dtype.fields else a).cuda(), to_host=lambda t: t.cpu().numpy())
