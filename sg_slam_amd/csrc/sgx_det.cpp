@@ -615,7 +615,10 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                 ib.has_res = res_blob >= 0; ib.hwc = c.hwc; ib.hwc_off = c.hwc_off;
                 {   // bf16x3 plan: every GEMM of the block needs its split weights (and the squeeze width must span the k16 steps the instantiation unrolls)
                     const int nqs = NQ == 0 ? 1 : (NQ == 2 ? 3 : (NT == 2 ? 1 : 2));
-                    const bool ok3 = h->gemm == 1 && c.wS && (ai < 0 || ops[ai].wS) && (di < 0 || (ops[di].wS && ops[ei].wS && (ops[di].outc + 15) / 16 == nqs));
+                    // k_irb3 is OPT-IN (SGX_DET_IRB3=1) until its operand streams hide their latency: measured slower than k_irb on every expand block (r4 trips: 0.99 against 0.75 ms on
+                    // 112 -> 672 -> 112), equal on the SSD heads; the pointwise layers take the bf16x3 path by default
+                    static const int irb3_env = getenv("SGX_DET_IRB3") ? atoi(getenv("SGX_DET_IRB3")) : 0;
+                    const bool ok3 = irb3_env != 0 && h->gemm == 1 && c.wS && (ai < 0 || ops[ai].wS) && (di < 0 || (ops[di].wS && ops[ei].wS && (ops[di].outc + 15) / 16 == nqs));
                     ib.gemm = ok3 ? 1 : 0;
                     if (ok3) { ib.w2S = c.wS; ib.w1S = ai >= 0 ? ops[ai].wS : nullptr; ib.wq1S = di >= 0 ? ops[di].wS : nullptr; ib.wq2S = di >= 0 ? ops[ei].wS : nullptr; }
                 }
@@ -778,18 +781,19 @@ static void run_op(sgx_det *h, const Op &op, int batch, sgx_stream_t st)
             break;
         }
 #ifndef SGX_EMU
-        if (h->gemm == 1 && op.wS) {
+        static const int pw3_mink = getenv("SGX_PW3_MINK") ? atoi(getenv("SGX_PW3_MINK")) : 64;      // measured: with fewer than four k16 steps the exact-fp32 kernel's shorter prologue wins (c40 -> 120 / 160: 0.14 against 0.17 ms)
+        if (h->gemm == 1 && op.wS && op.inc >= pw3_mink) {
             // bf16x3 (k_conv_pw3): same decomposition; the accumulators + the split operands cap the wave tile at four 32 x 32 sub-tiles
             const int sub = (op.outc + 31) / 32, total = batch * N;
-            static const int cand3[6][2] = { {2, 2}, {4, 1}, {1, 4}, {2, 1}, {1, 2}, {1, 1} };
+            static const int cand3[8][2] = { {2, 2}, {4, 1}, {3, 1}, {5, 1}, {1, 4}, {2, 1}, {1, 2}, {1, 1} };
             static const int force3 = getenv("SGX_PW3_FORCE") ? atoi(getenv("SGX_PW3_FORCE")) : 0;      // tuning tap: OCB * 10 + PXB
             int ocb = 1, pxb = 1; long best_score = -1;
-            for (int c = 0; c < 6; c++) {
+            for (int c = 0; c < 8; c++) {
                 const int cb = cand3[c][0], cp = cand3[c][1];
                 const long nwg = (long)((total + 128 * cp - 1) / (128 * cp)) * ((sub + cb - 1) / cb);
                 const int padded = ((sub + cb - 1) / cb) * cb;
                 const long fill = std::min(nwg, 512L);
-                const long score = fill * 1000000L + (long)(1000 - (padded - sub) * 100) * 100L + cb * cp * 10 + cb;        // among equals: more oc tiles per split
+                const long score = fill * 1000000L + (long)(1000 - (padded - sub) * 100) * 100L + cb * 20 + cp;        // among equals: more oc tiles per operand split (the split is the vector work of this kernel)
                 if (score > best_score) { best_score = score; ocb = cb; pxb = cp; }
             }
             if (force3) { ocb = force3 / 10; pxb = force3 % 10; }
@@ -799,7 +803,7 @@ static void run_op(sgx_det *h, const Op &op, int batch, sgx_stream_t st)
 #define SGX_PW3(OCB_, PXB_) do { auto kfn = k_conv_pw3<OCB_, PXB_>; SGX_LAUNCH(kfn, dim3(grid), dim3(256), st, op.inc, op.outc, N, total, A.d, A.n, (const sgx_u32x4 *)op.wS, op.bias, \
                                                                                O.d, O.n, e, op.hwc, op.hwc_off, nxt, noc, op.ldw, 1); } while (0)
             switch (ocb * 10 + pxb) {
-            case 22: SGX_PW3(2, 2); break; case 41: SGX_PW3(4, 1); break; case 14: SGX_PW3(1, 4); break;
+            case 22: SGX_PW3(2, 2); break; case 41: SGX_PW3(4, 1); break; case 31: SGX_PW3(3, 1); break; case 51: SGX_PW3(5, 1); break; case 14: SGX_PW3(1, 4); break;
             case 21: SGX_PW3(2, 1); break; case 12: SGX_PW3(1, 2); break; default: SGX_PW3(1, 1); break;
             }
 #undef SGX_PW3
@@ -1019,7 +1023,7 @@ extern "C" int sgx_det_debug_op_desc(const sgx_det *h, int i, char *buf, int cap
     if (o.kind == OP_SE_GATE) { snprintf(buf, cap, "se_gate %s c%d->%d->%d %dx%d%s", o.name.c_str(), o.sg.Cout, o.sg.Cq, o.sg.Cout, o.H, o.W, o.sg_res_blob >= 0 ? " +res" : ""); return SGX_OK; }
     if (o.kind == OP_PW || o.kind == OP_KXK)
         snprintf(buf, cap, "%s %s c%d->%d k%d s%d %s%dx%d->%dx%d epi%d%s%s", kn[o.kind], o.name.c_str(), o.inc, o.outc, o.k, o.stride, o.depthwise ? "dw " : "", o.H, o.W,
-                 o.kind == OP_PW ? o.H : o.Ho, o.kind == OP_PW ? o.W : o.Wo, (int)o.epi.size() + (o.act ? 1 : 0), o.hwc ? " hwc" : "", (o.kind == OP_PW && h->gemm == 1 && o.wS) ? " bf16x3" : "");
+                 o.kind == OP_PW ? o.H : o.Ho, o.kind == OP_PW ? o.W : o.Wo, (int)o.epi.size() + (o.act ? 1 : 0), o.hwc ? " hwc" : "", (o.kind == OP_PW && h->gemm == 1 && o.wS && o.inc >= (getenv("SGX_PW3_MINK") ? atoi(getenv("SGX_PW3_MINK")) : 64)) ? " bf16x3" : "");
     else if (o.kind == OP_FUSED_BLOCK)
         snprintf(buf, cap, "block %s c%d->%d->%d k%d s%d %dx%d->%dx%d tile %dx%d%s%s", o.name.c_str(), o.fb.Cin, o.fb.Cmid, o.fb.Cout, o.fb.K, o.fb.stride, o.H, o.W, o.Ho, o.Wo, o.fb.TOH, o.fb.TOW,
                  o.fb.Cq ? " se" : "", o.fb_res_blob >= 0 ? " +res" : "");

@@ -65,7 +65,7 @@ SGX_DEV sgx_f32x16 sgx_mfma_bf16x3(const sgx_u32x4 &a0, const sgx_u32x4 &a1, con
 // requested two k16 steps ahead, A operands one.  grid / XCD order / tile shapes as k_conv_pw2.
 // ---------------------------------------------------------------------------------------------
 template <int OCB, int PXB>
-SGX_KERNEL_OCC(256, (OCB * PXB == 1 ? 4 : (OCB * PXB == 2 ? 3 : 2))) k_conv_pw3(int inc, int outc, int N, int total, const float *in, size_t in_pitch, const sgx_u32x4 *__restrict__ Ws, const float *bias,
+SGX_KERNEL_OCC(256, (OCB * PXB == 1 ? 4 : (OCB * PXB <= 3 ? 3 : 2))) k_conv_pw3(int inc, int outc, int N, int total, const float *in, size_t in_pitch, const sgx_u32x4 *__restrict__ Ws, const float *bias,
                                                           float *out, size_t out_pitch, SgxEpi epi, int hwc, int hwc_off, int nxt, int noc, int ldw, int direct)
 {
     constexpr int OCT = 32 * OCB;
@@ -118,7 +118,7 @@ SGX_KERNEL_OCC(256, (OCB * PXB == 1 ? 4 : (OCB * PXB == 2 ? 3 : 2))) k_conv_pw3(
             for (int q = 0; q < 3; q++) dst[t][q] = ws[(size_t)(2 * q) * ldw + 32 * t];
     };
     float braw[3][PXB][8];
-    sgx_u32x4 aw[2][OCB][3];
+    sgx_u32x4 aw[2][OCB][3];                                             // weights one k16 step ahead
     loadB(0, braw[0]); loadA(0, aw[0]);
     loadB(min(1, nks - 1), braw[1]);
     __syncthreads();

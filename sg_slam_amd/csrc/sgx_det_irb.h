@@ -49,7 +49,7 @@ struct SgxIrb {
     const float *w1, *wd, *bd, *w2, *wq1, *wq2, *wd_b, *bd_b, *w2_b;
     // bf16x3 plan (k_irb3, sgx_det_bf16.h): the same weights split into three bf16 terms in the operand layout of v_mfma_f32_32x32x16_bf16, [k16 step][term][half][ld][8];
     // ld = the ld of the fp32 copy.  gemm = 1 selects k_irb3
-    int gemm;
+    int gemm, dbg;                              // dbg: timing taps of k_irb3 (SGX_IRB3_DBG, wrong results): 1 no depthwise arithmetic, 2 no stage-B MFMAs, 4 no stage-A MFMAs, 8 no stage-A split, 16 no stage B at all, 32 no stage A tiles
     const void *w1S, *w2S, *wq1S, *wq2S, *w2Sb;
 };
 #define SGX_IRB_KKP(K) (((K) * (K) + 1 + 3) & ~3)
@@ -418,6 +418,15 @@ __global__ void __launch_bounds__(768) k_irb(SgxIrb p)
 //            16 q + 0..7, the upper with 16 q + 8..15), then the split
 // NQS = k16 steps of the squeeze width Cq (the launch checks it).
 // ---------------------------------------------------------------------------------------------
+// Activation of the bf16x3 kernels: the same formula with the division by c2 as q0 = u rc, q = fma(fma(-q0, c2, u), rc, q0) (rc = RN(1 / c2)) WITHOUT the guard + IEEE
+// fall-back of sgx_div_c2: that guard is a wave-uniform branch per activation, which cuts the depthwise stage into one basic block per channel (no overlap of one
+// channel's LDS reads with another's arithmetic).  The unguarded form equals u / c2 unless |u| < 2^-123 (then it is off by a few 2^-149) — irrelevant in a plan that makes
+// no bit-exactness claim; the exact-fp32 plan keeps sgx_div_c2.
+SGX_DEV float sgx_irb_act_fast(int mode, float v, float c1, float lo, float hi, float c2, float rc)
+{
+    if (mode == SGX_EMODE_HSWISH) { float u = v + c1; u = sgx_clipf(u, lo, hi); u = u * v; const float q0 = u * rc; return fmaf(fmaf(-q0, c2, u), rc, q0); }
+    return sgx_clipf(v, lo, hi);
+}
 SGX_DEV void sgx_irb_d2b16(const sgx_f32x16 &d, int q, float (&b)[8])
 {
 #pragma unroll
@@ -479,6 +488,7 @@ __global__ void __launch_bounds__(768) k_irb3(SgxIrb p)
     const sgx_u32x4 *a2p = (const sgx_u32x4 *)p.w2S + (size_t)half * p.ld2 + l31;
     const sgx_u32x4 *a2bp = (const sgx_u32x4 *)(NT2 > 0 ? p.w2Sb : p.w2S) + (size_t)half * (NT2 > 0 ? p.ld2b : p.ld2) + l31;
     const unsigned sXrow = (unsigned)HW * 4u;
+    const float rc1 = 1.0f / p.a1c2, rc2 = 1.0f / p.a2c2, rcg = 1.0f / p.gc2;       // wave-uniform reciprocals of the activation divisors (sgx_irb_act_fast)
 
     // first stage-A tile of this wave (tile = wave): geometry is chunk-independent
     const int q0 = wave * 32 + l31; const bool ivalid0 = q0 < PI && wave < ngi;
@@ -508,7 +518,7 @@ __global__ void __launch_bounds__(768) k_irb3(SgxIrb p)
                 float v = w[KK];
 #pragma unroll
                 for (int t = 0; t < KK; t++) v = fmaf(w[t], tp[t], v);
-                vv[jh] = sgx_irb_act(AMODE, v, p.a2c1, p.a2lo, p.a2hi, p.a2c2);
+                vv[jh] = sgx_irb_act_fast(AMODE, v, p.a2c1, p.a2lo, p.a2hi, p.a2c2, rc2);
                 if (NT2 > 0) {
                     float w2[KKP];
                     const float *wj2 = Wc2 + (16 * s + j) * KKP;
@@ -517,9 +527,8 @@ __global__ void __launch_bounds__(768) k_irb3(SgxIrb p)
                     float u = w2[KK];
 #pragma unroll
                     for (int t = 0; t < KK; t++) u = fmaf(w2[t], tp[t], u);
-                    vv2[jh] = sgx_irb_act(AMODE, u, p.a2c1, p.a2lo, p.a2hi, p.a2c2);
+                    vv2[jh] = sgx_irb_act_fast(AMODE, u, p.a2c1, p.a2lo, p.a2hi, p.a2c2, rc2);
                 }
-                if (K == 5) __builtin_amdgcn_sched_barrier(0);
             }
             { unsigned a0, a1, a2; sgx_split3(vv[0], vv[1], a0, a1, a2); bo.t0[jp] = a0; bo.t1[jp] = a1; bo.t2[jp] = a2; }
             if (NT2 > 0) { unsigned a0, a1, a2; sgx_split3(vv2[0], vv2[1], a0, a1, a2); bo2.t0[jp] = a0; bo2.t1[jp] = a1; bo2.t2[jp] = a2; }
@@ -538,7 +547,7 @@ __global__ void __launch_bounds__(768) k_irb3(SgxIrb p)
         const int a_first = (p.nbuf == 2 && p.stagger) ? ((wave >> 2) & 1) : 0;
 #pragma unroll 1
         for (int hp = 0; hp < 2; hp++) {
-        if (hp == a_first && c >= 0 && owner) {
+        if (hp == a_first && c >= 0 && owner && !(p.dbg & 16)) {
             // ---- stage B of chunk c: depthwise -> split -> project on the bf16 matrix pipes
             const int ch0 = c * 32, nks = min(2, (p.Cexp - ch0 + 15) >> 4), buf = c & bmask;
             const float *E = Eb + (size_t)buf * 32 * p.planeT + e_r;
@@ -551,6 +560,7 @@ __global__ void __launch_bounds__(768) k_irb3(SgxIrb p)
 #pragma unroll
                 for (int q = 0; q < 3; q++) ar[0][q] = wa[(size_t)(2 * q) * p.ld2];
                 SgxB3 b, bb;
+                if (p.dbg & 1) { b.t0 = ar[0][0]; b.t1 = ar[0][1]; b.t2 = ar[0][2]; bb = b; } else
                 dw8(E, Wc, Wc2, s, b, bb);
 #pragma unroll
                 for (int t = 0; t < NT; t++) {
@@ -566,6 +576,7 @@ __global__ void __launch_bounds__(768) k_irb3(SgxIrb p)
 #pragma unroll
                         for (int q = 0; q < 3; q++) ar[0][q] = wa[(size_t)(2 * q) * p.ld2 + 32 * t];
                     }
+                    if (p.dbg & 2) { acc[t][0] += __uint_as_float(ar[t % AR][0][0] ^ b.t0[0] ^ b.t1[1] ^ b.t2[2]); } else
                     acc[t] = sgx_mfma_bf16x3(ar[t % AR][0], ar[t % AR][1], ar[t % AR][2], b, acc[t]);
                 }
                 if (NT2 > 0) {
@@ -586,7 +597,7 @@ __global__ void __launch_bounds__(768) k_irb3(SgxIrb p)
             float *E = Eb + (size_t)buf1 * 32 * p.planeT;
             for (int i = tid; i < 8 * KKP; i += nthreads) ((float4 *)(Wds + (size_t)buf1 * 32 * KKP))[i] = ((const float4 *)(p.wdp + (size_t)ch1 * KKP))[i];
             if (NT2 > 0) for (int i = tid; i < 8 * KKP; i += nthreads) ((float4 *)(Wds2 + (size_t)buf1 * 32 * KKP))[i] = ((const float4 *)(p.wdp2 + (size_t)ch1 * KKP))[i];
-            for (int tile = wave; tile < ngi; tile += nwaves) {
+            for (int tile = wave; tile < ((p.dbg & 32) ? 0 : ngi); tile += nwaves) {
                 const bool first = tile == wave;
                 int ew; unsigned xpix; bool ivalid;
                 if (first) { ew = ew0; xpix = xpix0; ivalid = ivalid0; }
@@ -619,23 +630,26 @@ __global__ void __launch_bounds__(768) k_irb3(SgxIrb p)
 #pragma unroll
                         for (int q = 0; q < 3; q++) dst[q] = w1l[(size_t)(6 * s + 2 * q) * p.ld1];
                     };
-                    // input rows one k16 step ahead (two register sets), weights of the step requested in front of the split that precedes their use
-                    float xr[2][8]; sgx_u32x4 wr[3];
-                    loadX(0, xr[0]);
+                    // input rows and weights one k16 step ahead (two register sets each)
+                    float xr[2][8]; sgx_u32x4 wr[2][3];
+                    loadX(0, xr[0]); loadW(0, wr[0]);
                     for (int s0 = 0; s0 < nks1; s0 += 2) {
 #pragma unroll
                         for (int d = 0; d < 2; d++) {
                             const int s = s0 + d;
                             if (s < nks1) {
-                                loadW(s, wr);
                                 loadX(min(s + 1, nks1 - 1), xr[d ^ 1]);
-                                const SgxB3 b = sgx_split3x8(xr[d]);
-                                e = sgx_mfma_bf16x3(wr[0], wr[1], wr[2], b, e);
+                                loadW(min(s + 1, nks1 - 1), wr[d ^ 1]);
+                                SgxB3 b;
+                                if (p.dbg & 8) { b.t0[0] = __float_as_uint(xr[d][0]); b.t0[1] = __float_as_uint(xr[d][1]); b.t0[2] = __float_as_uint(xr[d][2]); b.t0[3] = __float_as_uint(xr[d][3]); b.t1[0] = __float_as_uint(xr[d][4]); b.t1[1] = __float_as_uint(xr[d][5]); b.t1[2] = __float_as_uint(xr[d][6]); b.t1[3] = __float_as_uint(xr[d][7]); b.t2 = b.t0; }
+                                else b = sgx_split3x8(xr[d]);
+                                if (p.dbg & 4) e[0] += __uint_as_float(wr[d][0][0] ^ wr[d][1][1] ^ wr[d][2][2] ^ b.t0[0] ^ b.t1[1] ^ b.t2[2]);
+                                else e = sgx_mfma_bf16x3(wr[d][0], wr[d][1], wr[d][2], b, e);
                             }
                         }
                     }
 #pragma unroll
-                    for (int r = 0; r < 16; r++) e[r] = sgx_irb_act(AMODE, e[r], p.a1c1, p.a1lo, p.a1hi, p.a1c2);
+                    for (int r = 0; r < 16; r++) e[r] = sgx_irb_act_fast(AMODE, e[r], p.a1c1, p.a1lo, p.a1hi, p.a1c2, rc1);
                     if (ivalid) {
 #pragma unroll
                         for (int r = 0; r < 16; r++) Ew[(size_t)((r & 3) + 8 * (r >> 2) + 4 * half) * p.planeT] = e[r];
@@ -717,7 +731,7 @@ __global__ void __launch_bounds__(768) k_irb3(SgxIrb p)
                 ga = sgx_mfma_bf16x3(ae[0], ae[1], ae[2], qb[g], ga);
             }
 #pragma unroll
-            for (int r = 0; r < 16; r++) { float u_ = ga[r] + p.gc1; u_ = sgx_clipf(u_, p.glo, p.ghi); u_ = sgx_div_c2(u_, p.gc2); acc[t][r] = u_ * acc[t][r]; }
+            for (int r = 0; r < 16; r++) { float u_ = ga[r] + p.gc1; u_ = sgx_clipf(u_, p.glo, p.ghi); const float q0 = u_ * rcg; u_ = fmaf(fmaf(-q0, p.gc2, u_), rcg, q0); acc[t][r] = u_ * acc[t][r]; }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -849,6 +863,7 @@ static inline int sgx_irb_launch(const SgxIrb &p, int batch, sgx_stream_t st)
     const size_t lds = sgx_irb_lds_bytes(p);
     if (nw > 12 || lds > 160 * 1024) return SGX_ERR_UNSUPPORTED;
     SgxIrb q = p; q.batch = batch;
+    { static const int dbg_env = getenv("SGX_IRB3_DBG") ? atoi(getenv("SGX_IRB3_DBG")) : 0; q.dbg = dbg_env; }
     if (p.gemm == 1) {
         const int nqs = NQ == 0 ? 1 : (NQ == 2 ? 3 : (NT == 2 ? 1 : 2));
         if (NQ > 0 && (p.Cq + 15) / 16 != nqs) return SGX_ERR_UNSUPPORTED;
