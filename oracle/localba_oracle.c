@@ -9,8 +9,13 @@
  *   Edge(Stereo)SE3ProjectXYZ                    G/types/types_six_dof_expmap.h:80-140, .cpp:103-157,188-234
  *   VertexSBAPointXYZ::oplusImpl                 G/types/types_sba.h:52-56
  *   SparseOptimizer::buildIndexMapping           G/core/sparse_optimizer.cpp:166-190 (free poses first, then points)
- * The reduced camera system is solved by the reference with Eigen SimplicialLDLT (G/solvers/linear_solver_eigen.h);
- * here by a dense LDL^T — same solution up to rounding.   ==> PARITY UNPINNED at the Eigen boundary <==
+ * The reduced camera system is solved by the reference with Eigen SimplicialLDLT (G/solvers/linear_solver_eigen.h:94-124: a SPARSE LDL^T);
+ * here by an LDL^T in the natural (keyframe) order that stores and touches only the ENVELOPE of the matrix (row i from its first structurally
+ * non-zero column to the diagonal: fill-in of an LDL^T never leaves the envelope).  It performs exactly the operations of the dense row-oriented
+ * LDL^T that this file used until round 3 minus those on structural zeros (which contribute exact zeros), so its results are bit-identical to the
+ * dense solver's (orc_ba_debug_set_dense(1) keeps the dense one for that cross-check, tests/test_localba.py) — and 2 000 keyframes / 50 000
+ * landmarks (BASELINE config 4) take seconds instead of hours, which is what lets tools/make_golden.py pin that size (VERDICT r3 'next round' #5).
+ * Same solution as Eigen's up to rounding / elimination order.   ==> PARITY UNPINNED at the Eigen boundary <==
  *
  * Flattened problem: poses[np] (Tcw 4x4 float, fixed flag; KeyFrame::mnId order), points[nl] (float3; MapPoint order),
  * edges[ne] in insertion order (outer loop over points, Optimizer.cc:572-653): pose index, point index,
@@ -89,6 +94,68 @@ static int dense_ldlt_solve(double *A, int n, const double *b, double *x)
     return 1;
 }
 
+/* envelope (skyline) LDL^T: row i holds columns first[i] .. i at env[ptr[i] .. ptr[i + 1]); same operation order as dense_ldlt_solve */
+typedef struct { int n; int *first; size_t *ptr; double *v; } envmat;
+static double *env_at(const envmat *M, int i, int k) { return M->v + M->ptr[i] + (size_t)(k - M->first[i]); }
+static int env_ldlt_solve(envmat *M, const double *b, double *x)
+{
+    const int n = M->n;
+    double *d = (double *)malloc(sizeof(double) * (n > 0 ? n : 1));
+    /* rows that reach back to column j, for every j: row i > j with first[i] <= j.  A profile is not monotone (the wrap-around keyframes of a loop reach back to
+       column 0), so the candidates are kept as a list of "long" rows plus the band below the diagonal */
+    int bw = 0;                                        /* max width among the rows that are not "long" */
+    int *lng = (int *)malloc(sizeof(int) * (n > 0 ? n : 1)); int nlng = 0;
+    {
+        /* a row is "long" if it is wider than 4 x the median width: it then goes through the explicit list */
+        int *w = (int *)malloc(sizeof(int) * (n > 0 ? n : 1));
+        for (int i = 0; i < n; i++) w[i] = i - M->first[i];
+        int *srt = (int *)malloc(sizeof(int) * (n > 0 ? n : 1)); memcpy(srt, w, sizeof(int) * n);
+        for (int i = 1; i < n; i++) { const int t = srt[i]; int j = i - 1; while (j >= 0 && srt[j] > t) { srt[j + 1] = srt[j]; j--; } srt[j + 1] = t; }      /* insertion sort: widths are nearly sorted */
+        const int med = n ? srt[n / 2] : 0, cut = 4 * med + 64;
+        for (int i = 0; i < n; i++) { if (w[i] > cut) lng[nlng++] = i; else if (w[i] > bw) bw = w[i]; }
+        free(w); free(srt);
+    }
+    int ok = 1;
+    for (int j = 0; j < n && ok; j++) {
+        const double *rj = env_at(M, j, 0);            /* rj[k] = entry (j, k), valid for k >= first[j] */
+        double v = rj[j];
+        for (int k = M->first[j]; k < j; k++) v -= rj[k] * rj[k] * d[k];
+        d[j] = v;
+        if (!(v > 0)) { ok = 0; break; }
+        const int iend = j + bw < n - 1 ? j + bw : n - 1;
+        for (int pass = 0; pass < 2; pass++) {
+            const int cnt = pass == 0 ? iend - j : nlng;
+            for (int q = 0; q < cnt; q++) {
+                int i;
+                if (pass == 0) i = j + 1 + q;                       /* the band below the diagonal (long rows inside it included) */
+                else { i = lng[q]; if (i <= iend) continue; }       /* long rows past it */
+                if (M->first[i] > j) continue;
+                double *ri = env_at(M, i, 0);
+                double wv = ri[j];
+                const int k0 = M->first[i] > M->first[j] ? M->first[i] : M->first[j];
+                for (int k = k0; k < j; k++) wv -= ri[k] * rj[k] * d[k];
+                ri[j] = wv / v;
+            }
+        }
+    }
+    if (ok) {
+        for (int i = 0; i < n; i++) { const double *ri = env_at(M, i, 0); double v = b[i]; for (int k = M->first[i]; k < i; k++) v -= ri[k] * x[k]; x[i] = v; }
+        for (int i = 0; i < n; i++) x[i] /= d[i];
+        /* back substitution x_i -= sum_{k > i} L[k][i] x_k in the dense solver's order (k ascending for every i, i descending) */
+        for (int i = n - 1; i >= 0; i--) {
+            double v = x[i];
+            const int kend = i + bw < n - 1 ? i + bw : n - 1;
+            for (int k = i + 1; k <= kend; k++) if (M->first[k] <= i) v -= *env_at(M, k, i) * x[k];               /* the band (long rows inside it included) */
+            for (int q = 0; q < nlng; q++) { const int k = lng[q]; if (k > kend && M->first[k] <= i) v -= *env_at(M, k, i) * x[k]; }      /* long rows past it, ascending */
+            x[i] = v;
+        }
+    }
+    free(d); free(lng);
+    return ok;
+}
+static int g_ba_dense = 0;
+void orc_ba_debug_set_dense(int on) { g_ba_dense = on ? 1 : 0; }
+
 typedef struct {
     int np, nl, ne, nfree;
     se3q *T; double *X; int *hidx;          /* hidx[pose] = index among free poses or -1 */
@@ -96,6 +163,24 @@ typedef struct {
     float dMono, dStereo;
     const volatile int *stop;
 } ba_t;
+
+/* envelope of the reduced system for the current active edge set: block row i1 starts at the smallest free pose that shares an active landmark with it */
+static void env_build(const ba_t *B, envmat *Sp)
+{
+    const int nf = B->nfree, nl = B->nl, NP = 6 * nf;
+    envmat Senv; memset(&Senv, 0, sizeof Senv);
+    int *minp = (int *)malloc(sizeof(int) * (nf > 0 ? nf : 1)); for (int i = 0; i < nf; i++) minp[i] = i;
+    int *lmin = (int *)malloc(sizeof(int) * (nl > 0 ? nl : 1)); for (int l = 0; l < nl; l++) lmin[l] = nf;
+    for (int k = 0; k < B->ne; k++) { const int hp = B->hidx[B->E[k].pose]; if (B->E[k].level == 0 && hp >= 0 && hp < lmin[B->E[k].point]) lmin[B->E[k].point] = hp; }
+    for (int k = 0; k < B->ne; k++) { const int hp = B->hidx[B->E[k].pose]; if (B->E[k].level == 0 && hp >= 0 && lmin[B->E[k].point] < minp[hp]) minp[hp] = lmin[B->E[k].point]; }
+    Senv.n = NP; Senv.first = (int *)malloc(sizeof(int) * (NP > 0 ? NP : 1)); Senv.ptr = (size_t *)malloc(sizeof(size_t) * (NP + 1));
+    Senv.ptr[0] = 0;
+    for (int r = 0; r < NP; r++) { Senv.first[r] = 6 * minp[r / 6]; Senv.ptr[r + 1] = Senv.ptr[r] + (size_t)(r - Senv.first[r] + 1); }
+    Senv.v = (double *)malloc(sizeof(double) * (Senv.ptr[NP] > 0 ? Senv.ptr[NP] : 1));
+    free(minp); free(lmin);
+    *Sp = Senv;
+}
+static void env_free(envmat *M) { free(M->first); free(M->ptr); free(M->v); }
 
 static double ba_active_chi2(ba_t *B, int recompute)
 {
@@ -109,7 +194,7 @@ static double ba_active_chi2(ba_t *B, int recompute)
     return chi;
 }
 
-typedef struct { double *Hpp, *bp, *Hll, *bl, *Hpl, *S, *xp, *xl, *Dinv, *coef; uint8_t *pt_active; } ba_buf;
+typedef struct { double *Hpp, *bp, *Hll, *bl, *Hpl, *S, *xp, *xl, *Dinv, *coef; uint8_t *pt_active; envmat Senv; } ba_buf;
 
 /* buildSystem (block_solver.hpp:502-560) on the level-0 edges, at the current estimate and the errors last computed */
 static void ba_build(ba_t *B, ba_buf *W)
@@ -158,9 +243,18 @@ static int ba_solve(ba_t *B, ba_buf *W, double lambda)
     (void)nf; (void)nl; (void)NP; (void)Hpp; (void)bp; (void)Hll; (void)bl; (void)Hpl; (void)S; (void)xp; (void)xl; (void)Dinv; (void)coef; (void)pt_active;
     /* ---- solve with Schur complement (block_solver.hpp:367-486); lambda on both diagonals (:573-587) */
     int ok2 = 1;
-    memset(S, 0, sizeof(double) * (size_t)NP * NP); memset(coef, 0, sizeof(double) * NP);
-    for (int i = 0; i < nf; i++) for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++)
-        S[(size_t)(6 * i + a) * NP + 6 * i + c] = Hpp[(size_t)i * 36 + 6 * a + c] + (a == c ? lambda : 0);
+    memset(coef, 0, sizeof(double) * NP);
+    /* S lives in the envelope of its lower triangle (W->Senv; structure from the active edges, W->env_ok = 0 when the edge set changed); the dense copy only for the cross-check */
+    envmat *M = &W->Senv;
+    if (g_ba_dense) {
+        memset(S, 0, sizeof(double) * (size_t)NP * NP);
+        for (int i = 0; i < nf; i++) for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++)
+            S[(size_t)(6 * i + a) * NP + 6 * i + c] = Hpp[(size_t)i * 36 + 6 * a + c] + (a == c ? lambda : 0);
+    } else {
+        memset(M->v, 0, sizeof(double) * M->ptr[NP]);
+        for (int i = 0; i < nf; i++) for (int a = 0; a < 6; a++) for (int c = 0; c <= a; c++)
+            *env_at(M, 6 * i + a, 6 * i + c) = Hpp[(size_t)i * 36 + 6 * a + c] + (a == c ? lambda : 0);
+    }
     for (int l = 0; l < nl; l++) {
         double *Di = Dinv + (size_t)l * 9;
         if (!pt_active[l]) { memset(Di, 0, sizeof(double) * 9); continue; }
@@ -189,8 +283,13 @@ static int ba_solve(ba_t *B, ba_buf *W, double lambda)
                 for (int a = 0; a < 6; a++) coef[6 * i1 + a] += B1[3 * a] * db[0] + B1[3 * a + 1] * db[1] + B1[3 * a + 2] * db[2];
                 for (int q2 = head[l]; q2 < head[l + 1]; q2++) {
                     const int k2 = lst[q2], i2 = B->hidx[B->E[k2].pose]; const double *B2 = Hpl + (size_t)k2 * 18;
-                    for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++)
-                        S[(size_t)(6 * i1 + a) * NP + 6 * i2 + c] -= BD[3 * a] * B2[3 * c] + BD[3 * a + 1] * B2[3 * c + 1] + BD[3 * a + 2] * B2[3 * c + 2];
+                    if (g_ba_dense) {
+                        for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++)
+                            S[(size_t)(6 * i1 + a) * NP + 6 * i2 + c] -= BD[3 * a] * B2[3 * c] + BD[3 * a + 1] * B2[3 * c + 1] + BD[3 * a + 2] * B2[3 * c + 2];
+                    } else if (i2 <= i1) {                         /* the factorisation reads the lower triangle only: the same entries the dense path reads */
+                        for (int a = 0; a < 6; a++) for (int c = 0; c < (i2 < i1 ? 6 : a + 1); c++)
+                            *env_at(M, 6 * i1 + a, 6 * i2 + c) -= BD[3 * a] * B2[3 * c] + BD[3 * a + 1] * B2[3 * c + 1] + BD[3 * a + 2] * B2[3 * c + 2];
+                    }
                 }
             }
         }
@@ -198,7 +297,7 @@ static int ba_solve(ba_t *B, ba_buf *W, double lambda)
     }
     double *bs = (double *)malloc(sizeof(double) * (NP > 0 ? NP : 1));
     for (int i = 0; i < NP; i++) bs[i] = bp[i] - coef[i];
-    if (NP > 0) ok2 = dense_ldlt_solve(S, NP, bs, xp);
+    if (NP > 0) ok2 = g_ba_dense ? dense_ldlt_solve(S, NP, bs, xp) : env_ldlt_solve(M, bs, xp);
     free(bs);
     if (ok2) {                                                       /* xl = Dinv (bl - Hpl^T xp) */
         double *cl = (double *)malloc(sizeof(double) * (size_t)(nl > 0 ? nl : 1) * 3); memcpy(cl, bl, sizeof(double) * (size_t)nl * 3);
@@ -224,11 +323,12 @@ static int ba_optimize(ba_t *B, int iterations, double *trace)
     double *Hpp = (double *)malloc(sizeof(double) * (size_t)(nf > 0 ? nf : 1) * 36), *bp = (double *)malloc(sizeof(double) * (NP > 0 ? NP : 1));
     double *Hll = (double *)malloc(sizeof(double) * (size_t)(nl > 0 ? nl : 1) * 9), *bl = (double *)malloc(sizeof(double) * (size_t)(nl > 0 ? nl : 1) * 3);
     double *Hpl = (double *)malloc(sizeof(double) * (size_t)(B->ne > 0 ? B->ne : 1) * 18);
-    double *S = (double *)malloc(sizeof(double) * (size_t)(NP > 0 ? NP : 1) * (NP > 0 ? NP : 1));
+    double *S = g_ba_dense ? (double *)malloc(sizeof(double) * (size_t)(NP > 0 ? NP : 1) * (NP > 0 ? NP : 1)) : NULL;
+    envmat Senv; env_build(B, &Senv);
     double *xp = (double *)calloc(NP > 0 ? NP : 1, sizeof(double)), *xl = (double *)calloc((size_t)(nl > 0 ? nl : 1) * 3, sizeof(double));
     double *Dinv = (double *)malloc(sizeof(double) * (size_t)(nl > 0 ? nl : 1) * 9), *coef = (double *)malloc(sizeof(double) * (NP > 0 ? NP : 1));
     se3q *Tb = (se3q *)malloc(sizeof(se3q) * B->np); double *Xb = (double *)malloc(sizeof(double) * (size_t)(nl > 0 ? nl : 1) * 3);
-    ba_buf W = { Hpp, bp, Hll, bl, Hpl, S, xp, xl, Dinv, coef, pt_active };
+    ba_buf W = { Hpp, bp, Hll, bl, Hpl, S, xp, xl, Dinv, coef, pt_active, Senv };
     double lambda = -1, ni = 2; int nBadLM = 0, iters = 0;
     for (int it = 0; it < iterations; it++) {
         if (B->stop && *B->stop) break;                                   /* SparseOptimizer::terminate() */
@@ -266,6 +366,7 @@ static int ba_optimize(ba_t *B, int iterations, double *trace)
         if ((iniChi - currentChi) * 1e3 < iniChi) nBadLM++; else nBadLM = 0;
         if (nBadLM >= 3) break;
     }
+    env_free(&Senv);
     free(pt_active); free(Hpp); free(bp); free(Hll); free(bl); free(Hpl); free(S); free(xp); free(xl); free(Dinv); free(coef); free(Tb); free(Xb);
     return iters;
 }
@@ -372,13 +473,14 @@ int orc_kat_ba_step(int np, const float *poses, const uint8_t *pose_fixed, int n
     W.pt_active = (uint8_t *)calloc(nl > 0 ? nl : 1, 1);
     for (int k = 0; k < ne; k++) W.pt_active[B.E[k].point] = 1;
     W.Hpp = Hpp; W.bp = bp; W.Hll = Hll; W.bl = bl; W.Hpl = Hpl; W.xp = xp; W.xl = xl;
-    W.S = (double *)malloc(sizeof(double) * (size_t)(NP > 0 ? NP : 1) * (NP > 0 ? NP : 1));
+    W.S = g_ba_dense ? (double *)malloc(sizeof(double) * (size_t)(NP > 0 ? NP : 1) * (NP > 0 ? NP : 1)) : NULL;
+    env_build(&B, &W.Senv);
     W.Dinv = (double *)malloc(sizeof(double) * (size_t)(nl > 0 ? nl : 1) * 9); W.coef = (double *)malloc(sizeof(double) * (NP > 0 ? NP : 1));
     (void)ba_active_chi2(&B, 1);                                              /* computeActiveErrors */
     ba_build(&B, &W);
     const int ok = ba_solve(&B, &W, lambda);
     for (int i = 0; i < np; i++) hidx_out[i] = B.hidx[i];
-    free(W.pt_active); free(W.S); free(W.Dinv); free(W.coef);
+    free(W.pt_active); free(W.S); free(W.Dinv); free(W.coef); env_free(&W.Senv);
     free(B.T); free(B.X); free(B.hidx); free(B.E);
     return ok;
 }

@@ -130,3 +130,24 @@ def run_two_branch_matches_oracle(lib, oracle, nkf, npt, solver_mode):
 
 def test_two_branch_solver_matches_oracle_emu(emu, oracle):
     run_two_branch_matches_oracle(emu, oracle, 160, 4000, 2)          # 954 unknowns = 30 tiles (forced: the automatic choice starts above 1 024 unknowns)
+
+
+def test_oracle_envelope_ldlt_equals_dense_ldlt(oracle):
+    """oracle/localba_oracle.c solves the reduced camera system with an envelope (skyline) LDL^T since round 4 (the reference's own solver is sparse,
+    linear_solver_eigen.h:94-124): it performs the dense row-oriented LDL^T's operations minus those on structural zeros, so poses, points, erase flags, the LM trace
+    and the iteration counts must be BIT-identical to the dense solver's (orc_ba_debug_set_dense(1)) — on a covisibility band, on a loop (wrap-around rows reach back
+    to column 0: the 'long rows' path) and on the small dense graphs of the other tests."""
+    from scenes import make_big_ba_problem
+    from oracle import oracle as orc
+    cases = [make_ba_problem(orc, seed=7)[0], make_ba_problem(orc, n_free=9, n_fixed=3, n_points=300, seed=8)[0],
+             make_big_ba_problem(90, 2200, seed=5)[0], open_trajectory(make_big_ba_problem(120, 3000, seed=6)[0], 120)]
+    for prob in cases:
+        outs = []
+        for dense in (1, 0):
+            orc.lib().orc_ba_debug_set_dense(dense)
+            try:
+                outs.append(orc.local_ba({k: (v.copy() if hasattr(v, 'copy') else v) for k, v in prob.items()}, CAM))
+            finally:
+                orc.lib().orc_ba_debug_set_dense(0)
+        for a, b in zip(*outs):
+            assert a.dtype == b.dtype and a.shape == b.shape and (a.view(np.uint8) == b.view(np.uint8)).all()
