@@ -1,6 +1,6 @@
 """Write the two PMC summaries kept under profiles/ (pmc_kernels.md, pmc_detector.md) from the per-kernel counter means tools/collect_profiles.sh leaves in a run directory.
 usage: pmc_markdown.py <run dir> <frames per launch>"""
-import re, json, sys, collections
+import os, re, json, sys, collections
 O, S = sys.argv[1], int(sys.argv[2])
 
 def parse(fn):
@@ -22,7 +22,8 @@ a, b, f, w = (parse(O + '/pmc_%s.txt' % n) for n in ('sq_a', 'sq_b', 'fetch', 'w
 try: st = json.load(open(O + '/standalone.json'))['avg_ms_per_launch']
 except Exception: st = {}
 issue = lambda valu: valu * 4.0 / (1024 * 2.4e9) * 1e3            # ms of pure issue time at 4 cycles per wave instruction on 1 024 SIMDs at 2.4 GHz
-out = ['# Round 2 — PMC evidence for the kernels of the tracking chain (MI355X, %d frames per launch)\n' % S,
+TAG = os.path.basename(os.path.normpath(sys.argv[1]))          # the collection's tag (tools/collect_profiles.sh <tag>) names the round: no round number hard-coded here
+out = ['# %s — PMC evidence for the kernels of the tracking chain (MI355X, %d frames per launch)\n' % (TAG, S),
        'Collected by `tools/collect_profiles.sh` with separate `rocprofv3 --pmc … --kernel-trace` passes over `bench.py --no-detector --no-config2 --steps 3 --warmup 1` (no sys / runtime trace',
        'domains; FETCH_SIZE and WRITE_SIZE each in a pass of their own), per the recipe in `MI355X_MICROARCH.md`.  Values are means per launch over the dispatches of the profiled steps (the',
        'tracking-stage kernels run in 3 of the 4 steps: the first frame of a run has no predecessor; `tools/pmc_insts.py` / `pmc_traffic.py` normalise per class by the steps in which it ran).',
@@ -49,7 +50,7 @@ is latency-bound, one wave per SIMD).''')
 open(O + '/pmc_kernels.md', 'w').write('\n'.join(out) + '\n')
 
 ds, dm, df, dw = (parse(O + '/pmc_%s.txt' % n) for n in ('det_sq', 'det_mfma', 'det_fetch', 'det_write'))
-out = ['# Round 2 — PMC evidence for the detector kernels (MI355X, batch %d, every plan step launched on its own: `tools/prof_det_ops.py %d 2`)\n' % (S, S),
+out = ['# %s — PMC evidence for the detector kernels (MI355X, batch %d, every plan step launched on its own: `tools/prof_det_ops.py %d 2`)\n' % (TAG, S, S),
        'Means per launch over all launches of a kernel instantiation (n = launches averaged; 3 launches per plan step).  MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 × SQ_BUSY_CU_CYCLES):',
        'share of the four matrix pipes of a CU that was busy while the CU was.  read MB = 2 × FETCH_SIZE (gfx950 correction), written MB = WRITE_SIZE.\n',
        '| kernel | n | waves | VALU | SALU | LDS | VMEM rd | MFMA MOPS f32 | MFMA busy | read MB | written MB |', '|---|---|---|---|---|---|---|---|---|---|---|']
