@@ -385,10 +385,10 @@ extern "C" int sgx_orb_extract_batch_dev(sgx_orb *h, const uint8_t *d_gray, int 
                        umax_packed, h->d_pattern, (uint8_t *)d_kps, d_desc, d_count, cap, batch, h->d_status);
     } else {
         static const int blur_threads = getenv("SGX_TUNE_BLUR_THREADS") ? atoi(getenv("SGX_TUNE_BLUR_THREADS")) : 256;   // env = tuning tap (64..512)
-        {   // persistent workgroups: four per CU (32 waves), each walks the (tile, frame) list with the grid as stride (frame fastest: a frame stays on its XCD when the grid is a multiple of 8)
-            const int blur_grid = getenv("SGX_TUNE_ORB_BLUR_GRID") ? atoi(getenv("SGX_TUNE_ORB_BLUR_GRID")) : 4096;          // measured at 512 frames: 0.59 / 0.48 / 0.46 ms at 1 024 / 2 048 / 4 096 workgroups (0.49 one tile per workgroup)
-            const int total = g.nblur_tiles * batch;
-            SGX_LAUNCH(k_blur_levels, dim3(std::min(total, std::max(8, blur_grid))), dim3(std::min(512, std::max(256, blur_threads))), stream, g, h->d_blur_tiles, d_gray, pitch, h->d_pyr, h->d_blur, batch);
+        {   // persistent workgroups: `parts` per frame, each walks a contiguous range of the frame's tiles (see k_blur_levels); about 4 096 workgroups = 16 per CU
+            const int blur_grid = getenv("SGX_TUNE_ORB_BLUR_GRID") ? atoi(getenv("SGX_TUNE_ORB_BLUR_GRID")) : 4096;          // tuning tap: target grid size (measured at 512 frames with the round-3 walk: 0.59 / 0.48 / 0.46 ms at 1 024 / 2 048 / 4 096)
+            const int parts = std::min(g.nblur_tiles, std::max(1, blur_grid / batch));
+            SGX_LAUNCH(k_blur_levels, dim3(parts * batch), dim3(std::min(512, std::max(256, blur_threads))), stream, g, h->d_blur_tiles, d_gray, pitch, h->d_pyr, h->d_blur, batch);
         }
         static const bool one_per_wave = getenv("SGX_TUNE_ORB_DESC_ONE_PER_WAVE") != nullptr;       // tuning tap: k_orient_desc2 (one keypoint per wave)
         if (one_per_wave)

@@ -972,9 +972,14 @@ struct SgxBlurTile { short level, x0, y0, w, h, pad0, pad1, pad2; };
 #define SGX_BT_IS 80            /* LDS row stride of the staged input (bytes): 3 lead + 3 + 64 + 3, dword aligned */
 #define SGX_BT_HS 66            /* COLUMN stride of the horizontal-pass buffer (u16): it is stored transposed, [column][row], 64 staged rows + 2 (33 dwords: odd -> the columns of a wave fall on different banks) */
 
-// Persistent and software-pipelined: a workgroup walks the work list with stride gridDim.x; the global loads of the NEXT tile are issued into registers right after the
+// Persistent and software-pipelined: a workgroup walks a list of tiles; the global loads of the NEXT tile are issued into registers right after the
 // horizontal pass (the staged input is dead from then on) and land in LDS after the vertical pass, so a tile costs its two passes and three barriers, not a load round trip
 // on top (the one-tile-per-workgroup form ran at 32 waves per CU that mostly waited: 6.8 us per tile).
+// Which tiles (round 4).  grid = parts x batch; workgroup b owns frame b % batch (XCD b % 8 = frame % 8 for batches that are multiples of 8: a frame's pyramid stays in one L2)
+// and the CONTIGUOUS tile range [k T / parts, (k + 1) T / parts) of that frame, k = b / batch, in table order = row-major inside a level.  A 64-byte-wide tile + halo straddles
+// two 128-byte lines, so x-neighbours share every second line: walking them back to back finds the shared line still in L2.  Round 3 walked tile = k, k + parts, k + 2 parts, ...
+// per workgroup: the x-neighbours of a tile were then other workgroups' work at unrelated times, every tile fetched its two lines per row from HBM and the kernel read 1 876 MB
+// per 512 frames for 487 MB of pyramid (one tile per workgroup in (tile, frame) order reads 520 MB but gives up the pipelining).
 #define SGX_BT_PRE 5            /* staged dwords per thread: 64 rows x 20 dwords / 256 threads (the smallest workgroup the host launches) */
 SGX_KERNEL(512) k_blur_levels(SgxOrbGeom g, const SgxBlurTile *tiles, const uint8_t *gray, int gray_pitch, const uint8_t *pyr, uint8_t *blur, int batch)
 {
@@ -1003,20 +1008,20 @@ SGX_KERNEL(512) k_blur_levels(SgxOrbGeom g, const SgxBlurTile *tiles, const uint
         }                                                                                                                                 \
     }
     if ((int)blockIdx.x >= total) return;
-    // work item w = tile * batch + frame (frame fastest); w advances by the grid size: (frame, tile) advance by its remainder / quotient — no division per tile
-    const int step_t = (int)gridDim.x / batch, step_f = (int)gridDim.x - step_t * batch;
-    int cur_t = (int)blockIdx.x / batch, cur_f = (int)blockIdx.x - cur_t * batch;
+    const int parts = (int)gridDim.x / batch, part = (int)blockIdx.x / batch;              // host: gridDim.x = parts * batch, 1 <= parts <= tiles per frame
+    const int cur_f = (int)blockIdx.x - part * batch;
+    const int t_end = (int)(((long long)(part + 1) * g.nblur_tiles) / parts);
+    int cur_t = (int)(((long long)part * g.nblur_tiles) / parts);
     SGX_THREADS_BEGIN(tid)
     SGX_PRIV_BIND(pre, tid);
     SGX_BLUR_FETCH(cur_f, cur_t, pre)
     for (int u = 0; u < SGX_BT_PRE; u++) { const int i = tid + u * (int)blockDim.x; if (i < (SGX_BT_H + 6) * (SGX_BT_IS / 4)) in_dw[i] = pre[u]; }
     SGX_THREADS_END
     SGX_SYNC();
-    for (int w = (int)blockIdx.x; w < total; w += (int)gridDim.x) {
-        const int frame = cur_f, wn = w + (int)gridDim.x;
+    for (; cur_t < t_end; cur_t++) {
+        const int frame = cur_f, nxt_f = cur_f, nxt_t = cur_t + 1;
+        const bool more = nxt_t < t_end;
         const SgxBlurTile t = tiles[cur_t];
-        int nxt_f = cur_f + step_f, nxt_t = cur_t + step_t;
-        if (nxt_f >= batch) { nxt_f -= batch; nxt_t++; }
         const SgxLevel L = g.lv[t.level];
         const int rows = t.h + 6, xs = t.x0 - 3;
         const int lead = xs & 3;
@@ -1056,7 +1061,7 @@ SGX_KERNEL(512) k_blur_levels(SgxOrbGeom g, const SgxBlurTile *tiles, const uint
         // the next tile's loads leave now; their latency hides behind the vertical pass
         SGX_THREADS_BEGIN(tid)
         SGX_PRIV_BIND(pre, tid);
-        if (wn < total) SGX_BLUR_FETCH(nxt_f, nxt_t, pre)
+        if (more) SGX_BLUR_FETCH(nxt_f, nxt_t, pre)
         SGX_THREADS_END
         SGX_SYNC();
         // vertical pass: task = (column, 8-row segment).  Rows r0 .. r0+15 of the column are 8 aligned dwords = the row pairs starting at even rows; the odd-start pairs come
@@ -1085,7 +1090,7 @@ SGX_KERNEL(512) k_blur_levels(SgxOrbGeom g, const SgxBlurTile *tiles, const uint
         SGX_THREADS_END
         SGX_THREADS_BEGIN(tid)
         SGX_PRIV_BIND(pre, tid);
-        if (wn < total) for (int u = 0; u < SGX_BT_PRE; u++) { const int i = tid + u * (int)blockDim.x; if (i < (SGX_BT_H + 6) * (SGX_BT_IS / 4)) in_dw[i] = pre[u]; }
+        if (more) for (int u = 0; u < SGX_BT_PRE; u++) { const int i = tid + u * (int)blockDim.x; if (i < (SGX_BT_H + 6) * (SGX_BT_IS / 4)) in_dw[i] = pre[u]; }
         SGX_THREADS_END
         SGX_SYNC();
         SGX_THREADS_BEGIN(tid)
@@ -1095,7 +1100,6 @@ SGX_KERNEL(512) k_blur_levels(SgxOrbGeom g, const SgxBlurTile *tiles, const uint
             if (4 * q < t.w) *(uint32_t *)(dst + (size_t)(t.y0 + r) * L.bstride + t.x0 + 4 * q) = o_dw[i];        // rows are padded to 64 bytes: the last dword may spill into the padding
         }
         SGX_THREADS_END
-        cur_f = nxt_f; cur_t = nxt_t;
     }
 #undef SGX_BLUR_FETCH
 }
