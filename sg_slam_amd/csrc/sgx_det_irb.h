@@ -608,7 +608,34 @@ __global__ void __launch_bounds__(768) k_irb3(SgxIrb p)
                     xpix = (unsigned)((size_t)(b0 + qi) * p.in_pitch + (size_t)iy * p.W + ix) * 4u;
                 }
                 float *Ew = E + ew;
-                if (EXPAND) {
+                if (EXPAND && (p.dbg & 64)) {
+                    // expand stage on the fp32 matrix cores exactly as k_irb (operand ring of 8 k2 steps): the variant "bf16x3 for the project / squeeze-excite GEMMs only"
+                    sgx_f32x16 e;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) e[r] = sgx_bld(r_b1, (unsigned)half * 16u, (unsigned)(ch1 + (r & 3) + 8 * (r >> 2)) * 4u);
+                    const sgx_rsrc r_w1 = sgx_mkrsrc(p.w1T);
+                    const unsigned aoff1 = (unsigned)(half * p.ld1 + l31) * 4u, xoff = xpix + (unsigned)half * sXrow, sXstep = 2u * sXrow;
+                    constexpr int D = 8;
+                    const int nks = p.Cin >> 1, nkp = (nks + D - 1) & ~(D - 1);
+                    const unsigned sA = (unsigned)ch1 * 4u, sAstep = (unsigned)(2 * p.ld1) * 4u;
+                    float ar[D], br[D];
+#pragma unroll
+                    for (int d = 0; d < D; d++) { ar[d] = sgx_bld(r_w1, aoff1, sA + d * sAstep); br[d] = sgx_bld(r_in, xoff, (unsigned)min(d, nks - 1) * sXstep); }
+                    for (int s0 = 0; s0 < nkp; s0 += D) {
+#pragma unroll
+                        for (int d = 0; d < D; d++) {
+                            e = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[d], br[d], e, 0, 0, 0);
+                            const int sn = min(s0 + d + D, nkp - 1);
+                            ar[d] = sgx_bld(r_w1, aoff1, sA + (unsigned)sn * sAstep); br[d] = sgx_bld(r_in, xoff, (unsigned)min(sn, nks - 1) * sXstep);
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; r++) e[r] = sgx_irb_act_fast(AMODE, e[r], p.a1c1, p.a1lo, p.a1hi, p.a1c2, rc1);
+                    if (ivalid) {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) Ew[(size_t)((r & 3) + 8 * (r >> 2) + 4 * half) * p.planeT] = e[r];
+                    }
+                } else if (EXPAND) {
                     sgx_f32x16 e;
 #pragma unroll
                     for (int r = 0; r < 16; r++) e[r] = sgx_bld(r_b1, (unsigned)half * 16u, (unsigned)(ch1 + (r & 3) + 8 * (r >> 2)) * 4u);

@@ -22,7 +22,7 @@ timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format cs
 # 4. detector: per-step table, then the same SQ counters over its launches (batch $S, 2 repetitions, steps launched one by one)
 timeout 200 python $R/tools/prof_det_ops.py $S 5 > $O/detector_ops.txt 2>/dev/null
 timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace --output-format csv -d $O/det_sq -o p -- python $R/tools/prof_det_ops.py $S 2 > /dev/null 2>&1
-timeout -s KILL 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/det_mfma -o p -- python $R/tools/prof_det_ops.py $S 2 > /dev/null 2>&1
+timeout -s KILL 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 --kernel-trace --output-format csv -d $O/det_mfma -o p -- python $R/tools/prof_det_ops.py $S 2 > /dev/null 2>&1
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/det_fetch -o p -- python $R/tools/prof_det_ops.py $S 2 > /dev/null 2>&1
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/det_write -o p -- python $R/tools/prof_det_ops.py $S 2 > /dev/null 2>&1
 cd $R

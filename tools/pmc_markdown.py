@@ -53,13 +53,13 @@ ds, dm, df, dw = (parse(O + '/pmc_%s.txt' % n) for n in ('det_sq', 'det_mfma', '
 out = ['# %s — PMC evidence for the detector kernels (MI355X, batch %d, every plan step launched on its own: `tools/prof_det_ops.py %d 2`)\n' % (TAG, S, S),
        'Means per launch over all launches of a kernel instantiation (n = launches averaged; 3 launches per plan step).  MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 × SQ_BUSY_CU_CYCLES):',
        'share of the four matrix pipes of a CU that was busy while the CU was.  read MB = 2 × FETCH_SIZE (gfx950 correction), written MB = WRITE_SIZE.\n',
-       '| kernel | n | waves | VALU | SALU | LDS | VMEM rd | MFMA MOPS f32 | MFMA busy | read MB | written MB |', '|---|---|---|---|---|---|---|---|---|---|---|']
+       '| kernel | n | waves | VALU | SALU | LDS | VMEM rd | MFMA MOPS f32 | MFMA MOPS bf16 | MFMA busy | read MB | written MB |', '|---|---|---|---|---|---|---|---|---|---|---|---|']
 for k in ds:
     if not (k.startswith('k_') or k.startswith('void k_')): continue
     A, Mx, F, W = ds[k], dm.get(k, {}), df.get(k, {}), dw.get(k, {})
     busy = g(Mx, 'SQ_VALU_MFMA_BUSY_CYCLES') / (4 * g(Mx, 'SQ_BUSY_CU_CYCLES')) if g(Mx, 'SQ_BUSY_CU_CYCLES') else 0
-    out.append('| `%s` | %d | %s | %s | %s | %s | %s | %s | %.0f %% | %.1f | %.1f |' % (k.replace('void ', ''), A.get('SQ_WAVES', (0, 0))[1], M(g(A, 'SQ_WAVES')), M(g(A, 'SQ_INSTS_VALU')), M(g(A, 'SQ_INSTS_SALU')),
-               M(g(A, 'SQ_INSTS_LDS')), M(g(A, 'SQ_INSTS_VMEM_RD')), M(g(A, 'SQ_INSTS_VALU_MFMA_MOPS_F32')), 100 * busy, 2 * g(F, 'FETCH_SIZE') / 1024, g(W, 'WRITE_SIZE') / 1024))
+    out.append('| `%s` | %d | %s | %s | %s | %s | %s | %s | %s | %.0f %% | %.1f | %.1f |' % (k.replace('void ', ''), A.get('SQ_WAVES', (0, 0))[1], M(g(A, 'SQ_WAVES')), M(g(A, 'SQ_INSTS_VALU')), M(g(A, 'SQ_INSTS_SALU')),
+               M(g(A, 'SQ_INSTS_LDS')), M(g(A, 'SQ_INSTS_VMEM_RD')), M(g(A, 'SQ_INSTS_VALU_MFMA_MOPS_F32')), M(g(Mx, 'SQ_INSTS_VALU_MFMA_MOPS_BF16')), 100 * busy, 2 * g(F, 'FETCH_SIZE') / 1024, g(W, 'WRITE_SIZE') / 1024))
 try: tj = json.load(open(O + '/traffic.json'))['bytes_per_launch']
 except Exception: tj = {}
 out.append('\nWhole forward (pre-processing + 102 plan steps), %d frames: %.1f GB of HBM-side traffic (`traffic.json`) against %.1f GB of algorithmic activation + weight bytes summed over the steps '
