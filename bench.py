@@ -518,7 +518,7 @@ def main():
                                   'order in LK, the device the exact-sum variant; RANSAC / mask decisions can differ on knife-edge points)'}
         if not args.no_cpu_all_cores:
             import subprocess, tempfile
-            P = max(1, min(os.cpu_count() or 1, 128)); n_per = max(12, args.cpu_sample // 10)
+            P = max(1, os.cpu_count() or 1); n_per = max(12, args.cpu_sample // 10)
             start = os.path.join(tempfile.mkdtemp(prefix='sgx_cpu_'), 'go')
             env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
             procs = [subprocess.Popen([sys.executable, '-m', 'oracle.cpu_chain', '--index', str(k), '--frames', str(T), '--n', str(n_per), '--start-file', start] +

@@ -459,7 +459,9 @@ int sgx_det_forward_batch_dev(sgx_det *h, const uint8_t *d_img, int pitch, int b
 int sgx_det_debug_read_blob(sgx_det *h, const char *blob_name, int image, float *dst, int cap, int *n);
 /* test tap: DetectionOutput + detect() filtering alone on caller-supplied head outputs (host arrays: loc batch x num_priors x 4, conf batch x num_priors x num_class) */
 int sgx_det_debug_detection_output(sgx_det *h, const float *loc, const float *conf, int batch, sgx_det_result *results);
-/* test / tuning taps.  set_fusion(0) makes the NEXT sgx_det_create build the unfused plan (one kernel per ncnn layer, every blob
+/* test / tuning taps.  Every sgx_*_debug_set_* setting is PER CALLING THREAD (thread_local): it affects the next create / call made by the same thread only, so the taps
+ * cannot leak into the Tracking, Detector2D or LocalMapping thread of a host program; the SGX_* environment switches are read once and never written.
+ * set_fusion(0) makes the NEXT sgx_det_create build the unfused plan (one kernel per ncnn layer, every blob
  * materialised) — the fused plan (default) must reproduce it bit for bit.  time_ops: HIP-event time per plan step (ms[0] = pre-processing). */
 int sgx_det_debug_set_fusion(int on);
 int sgx_det_debug_set_irb(int on);                 /* the NEXT sgx_det_create: matrix-core inverted-residual block kernels (sgx_det_irb.h) 0 off, 1 on the shapes where they beat the per-layer kernels, 2 on every supported shape, -1 = default (1, or SGX_DET_IRB); bit-identical either way */

@@ -53,7 +53,7 @@ struct Arena {
     template <class T> void take(T **p, size_t n) { off = (off + 255) & ~(size_t)255; if (base) *p = (T *)(base + off); off += (n ? n : 1) * sizeof(T); }
 };
 static Arena g_arena;
-static int g_ba_solver = -1;              // test / tuning tap (sgx_ba_debug_set_solver): -1 = SGX_BA_SOLVER or auto, 0 auto, 1 dense blocked Cholesky, 2 envelope solver
+static thread_local int g_ba_solver = -1;              // test / tuning tap (sgx_ba_debug_set_solver): -1 = SGX_BA_SOLVER or auto, 0 auto, 1 dense blocked Cholesky, 2 envelope solver
 
 struct BA {
     int np, nl, ne, nf, NP;
@@ -328,7 +328,7 @@ static int optimize(BA &B, int iterations, int *iters_done, double *final_chi)
 }
 }  // namespace
 
-static int g_ba_last_plan[4] = { 0, 0, 0, 0 };
+static thread_local int g_ba_last_plan[4] = { 0, 0, 0, 0 };
 extern "C" int sgx_ba_debug_last_plan(int32_t plan[4]) { if (!plan) return SGX_ERR_INVALID; for (int i = 0; i < 4; i++) plan[i] = g_ba_last_plan[i]; return SGX_OK; }
 extern "C" int sgx_ba_debug_set_solver(int mode) { g_ba_solver = mode < 0 ? -1 : (mode > 2 ? 2 : mode); return SGX_OK; }
 

@@ -72,19 +72,19 @@ struct sgx_det {
     template <class Tp> int alloc(Tp **p, size_t n) { void *q = nullptr; if (hipMalloc(&q, (n ? n : 1) * sizeof(Tp)) != hipSuccess) return SGX_ERR_NOMEM; dev.push_back(q); *p = (Tp *)q; return SGX_OK; }
 };
 
-static int g_det_fuse = 1;
-static int g_det_block_fusion = 0;       // test / tuning tap (read at sgx_det_create): fuse expand -> depthwise -> project triples into k_fused_block
-static int g_det_legacy = 0;             // test tap (read at sgx_det_create): run the simple reference kernels (k_conv_pw / k_conv_kxk) instead of the tuned ones
+static thread_local int g_det_fuse = 1;
+static thread_local int g_det_block_fusion = 0;       // test / tuning tap (read at sgx_det_create): fuse expand -> depthwise -> project triples into k_fused_block
+static thread_local int g_det_legacy = 0;             // test tap (read at sgx_det_create): run the simple reference kernels (k_conv_pw / k_conv_kxk) instead of the tuned ones
 extern "C" int sgx_det_debug_set_fusion(int on) { g_det_fuse = on ? 1 : 0; return SGX_OK; }
 extern "C" int sgx_det_debug_set_legacy_kernels(int on) { g_det_legacy = on ? 1 : 0; return SGX_OK; }
 extern "C" int sgx_det_debug_set_block_fusion(int on) { g_det_block_fusion = on ? 1 : 0; return SGX_OK; }
-static int g_det_irb = -1;               // test / tuning tap: inverted-residual blocks and SSD heads as one matrix-core kernel each (sgx_det_irb.h): 0 off, 1 the shapes where it beats
+static thread_local int g_det_irb = -1;               // test / tuning tap: inverted-residual blocks and SSD heads as one matrix-core kernel each (sgx_det_irb.h): 0 off, 1 the shapes where it beats
                                          // the per-layer kernels on MI355X (default), 2 every shape it supports (tests); -1 = SGX_DET_IRB or the default
 extern "C" int sgx_det_debug_set_irb(int on) { g_det_irb = on < 0 ? -1 : (on > 2 ? 2 : on); return SGX_OK; }
 // Matrix-product scheme of the pointwise / expand / project / squeeze-excite convolutions (read at sgx_det_create): 0 = exact fp32 on v_mfma_f32_32x32x2_f32 (bit-identical to the
 // per-layer reference kernels and to the emulator: the anchor of the plan-equality tests), 1 = bf16x3 on v_mfma_f32_32x32x16_bf16 (fp32-accurate products, fp32 accumulation,
 // another summation order; sgx_det_bf16.h), -1 = SGX_DET_GEMM (f32 | bf16x3) or the default.  The emulator build always runs 0.
-static int g_det_gemm = -1;
+static thread_local int g_det_gemm = -1;
 #ifndef SGX_DET_GEMM_DEFAULT
 #define SGX_DET_GEMM_DEFAULT 1
 #endif

@@ -46,7 +46,7 @@ struct sgx_orb {
     int oct_maxlim = 0;            // largest octree list capacity over the levels (quota + 3 or 4*nIni)
 };
 
-static int g_orb_unfused_pyramid = 0;      // test tap: 1 = one k_resize launch per level instead of the fused k_pyramid
+static thread_local int g_orb_unfused_pyramid = 0;      // test tap: 1 = one k_resize launch per level instead of the fused k_pyramid
 extern "C" int sgx_orb_debug_set_unfused_pyramid(int on) { g_orb_unfused_pyramid = on ? 1 : 0; return SGX_OK; }
 
 static inline int cvround_f(float v) { return (int)lrintf(v); }

@@ -15,7 +15,7 @@ def test_tracker_mask_gpu(gpulib):
 
 
 def test_tracker_full_batch_properties(gpulib):
-    """The bench's batch size (256 streams per launch): a stream's result must not depend on its slot or on the batch it runs in.  Eight distinct streams are
+    """A large batch (256 streams per launch; the bench runs 512): a stream's result must not depend on its slot or on the batch it runs in.  Eight distinct streams are
     tiled over the 256 slots; every copy must return the same bits as the first, slot results must equal a batch-of-one run of the same frames, and the
     trajectories must follow the synthetic ground truth."""
     import numpy as np
