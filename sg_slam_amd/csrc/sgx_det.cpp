@@ -620,6 +620,9 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                     static const int irb3_env = getenv("SGX_DET_IRB3") ? atoi(getenv("SGX_DET_IRB3")) : 0;
                     const bool ok3 = irb3_env != 0 && h->gemm == 1 && c.wS && (ai < 0 || ops[ai].wS) && (di < 0 || (ops[di].wS && ops[ei].wS && (ops[di].outc + 15) / 16 == nqs));
                     ib.gemm = ok3 ? 1 : 0;
+                    // mode 2: the fp32 block kernel with ONLY its expand GEMM as bf16x3 (SGX_DET_IRB_A3, tuning tap)
+                    static const int a3_env = getenv("SGX_DET_IRB_A3") ? atoi(getenv("SGX_DET_IRB_A3")) : 0;
+                    if (!ok3 && a3_env && h->gemm == 1 && ai >= 0 && ops[ai].wS) { ib.gemm = 2; ib.w1S = ops[ai].wS; }
                     if (ok3) { ib.w2S = c.wS; ib.w1S = ai >= 0 ? ops[ai].wS : nullptr; ib.wq1S = di >= 0 ? ops[di].wS : nullptr; ib.wq2S = di >= 0 ? ops[ei].wS : nullptr; }
                 }
                 {   // depthwise taps + bias, one padded row per channel

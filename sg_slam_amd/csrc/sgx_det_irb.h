@@ -83,7 +83,7 @@ SGX_DEV void sgx_bst(sgx_rsrc r, unsigned voff, unsigned soff, float v) { __buil
 // bias of accumulator register r of 32-row tile t: row = 32 t + (r & 3) + 8 (r >> 2) + 4 half; the descriptor ends at the last channel, so padded rows read 0
 #define SGX_IRB_BIAS(rs, t, r, half) sgx_bld(rs, (unsigned)(half) * 16u, (unsigned)(32 * (t) + ((r) & 3) + 8 * ((r) >> 2)) * 4u)
 
-template <int K, int S, int NT, int NQ, bool EXPAND, bool HS, int NT2>
+template <int K, int S, int NT, int NQ, bool EXPAND, bool HS, int NT2, bool A3 = false>
 __global__ void __launch_bounds__(768) k_irb(SgxIrb p)
 {
     extern __shared__ __attribute__((aligned(16))) float sgx_irb_smem[];
@@ -238,7 +238,51 @@ __global__ void __launch_bounds__(768) k_irb(SgxIrb p)
                     xoff = (unsigned)((size_t)(b0 + qi) * p.in_pitch + (size_t)iy * p.W + ix + (size_t)half * HW) * 4u;
                 }
                 float *Ew = E + ew;
-                if (EXPAND) {
+                if (EXPAND && A3) {
+                    // gemm mode 2: ONLY the expand GEMM on the bf16 matrix pipes (bf16x3, sgx_det_bf16.h): its 56 fp32 MFMAs per tile (3.6 k cycles of blocked vector issue) become
+                    // 42 bf16 MFMAs that run beside other waves' vector work, for 36 split instructions per k16 step; the depthwise / project / squeeze-excite stages stay as they are
+                    sgx_f32x16 e;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) e[r] = sgx_bld(r_b1, (unsigned)half * 16u, (unsigned)(ch1 + (r & 3) + 8 * (r >> 2)) * 4u);
+                    const int nks1 = (p.Cin + 15) >> 4;
+                    const unsigned sXrow = (unsigned)HW * 4u;
+                    const unsigned xh8 = xoff - (unsigned)half * sXrow + (unsigned)(8 * half) * sXrow;          // xoff carries + half rows (k2 layout): here the half-wave starts 8 rows down
+                    const unsigned xpix = xoff - (unsigned)half * sXrow;
+                    auto loadX = [&](int s_, float (&dst)[8]) {
+                        if (16 * s_ + 16 <= p.Cin) {
+#pragma unroll
+                            for (int j = 0; j < 8; j++) dst[j] = sgx_bld(r_in, xh8, (unsigned)(16 * s_ + j) * sXrow);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 8; j++) dst[j] = sgx_bld(r_in, xpix + (unsigned)min(16 * s_ + 8 * half + j, p.Cin - 1) * sXrow, 0u);
+                        }
+                    };
+                    const sgx_u32x4 *w1l = (const sgx_u32x4 *)p.w1S + (size_t)half * p.ld1 + l31 + ch1;
+                    auto loadW = [&](int s_, sgx_u32x4 (&dst)[3]) {
+#pragma unroll
+                        for (int q = 0; q < 3; q++) dst[q] = w1l[(size_t)(6 * s_ + 2 * q) * p.ld1];
+                    };
+                    float xr[2][8]; sgx_u32x4 wr[2][3];
+                    loadX(0, xr[0]); loadW(0, wr[0]);
+                    for (int s0 = 0; s0 < nks1; s0 += 2) {
+#pragma unroll
+                        for (int d = 0; d < 2; d++) {
+                            const int s_ = s0 + d;
+                            if (s_ < nks1) {
+                                loadX(min(s_ + 1, nks1 - 1), xr[d ^ 1]);
+                                loadW(min(s_ + 1, nks1 - 1), wr[d ^ 1]);
+                                const SgxB3 b = sgx_split3x8(xr[d]);
+                                e = sgx_mfma_bf16x3(wr[d][0], wr[d][1], wr[d][2], b, e);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; r++) e[r] = sgx_irb_act(AMODE, e[r], p.a1c1, p.a1lo, p.a1hi, p.a1c2);
+                    if (ivalid) {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) Ew[(size_t)((r & 3) + 8 * (r >> 2) + 4 * half) * p.planeT] = e[r];
+                    }
+                } else if (EXPAND) {
                     sgx_f32x16 e;
 #pragma unroll
                     for (int r = 0; r < 16; r++) e[r] = sgx_bld(r_b1, (unsigned)half * 16u, (unsigned)(ch1 + (r & 3) + 8 * (r >> 2)) * 4u);
@@ -901,6 +945,14 @@ static inline int sgx_irb_launch(const SgxIrb &p, int batch, sgx_stream_t st)
         SGX_IRB_INSTANCES(SGX_IRB_X)
 #undef SGX_IRB_X
         return SGX_ERR_UNSUPPORTED;
+    }
+    if (p.gemm == 2 && p.has_expand) {
+#define SGX_IRB_X(K_, S_, NT_, NQ_, E_, H_, N2_) if (E_ && p.K == K_ && p.S == S_ && NT == NT_ && NQ == NQ_ && (p.act2 == SGX_EMODE_HSWISH) == H_ && NT2 == N2_) { \
+        auto kfn = k_irb<K_, S_, NT_, NQ_, E_, H_, N2_, true>; static bool attr = false; \
+        if (!attr) { (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * nw), lds, st, q); return SGX_OK; }
+        SGX_IRB_INSTANCES(SGX_IRB_X)
+#undef SGX_IRB_X
     }
 #define SGX_IRB_X(K_, S_, NT_, NQ_, E_, H_, N2_) if (p.K == K_ && p.S == S_ && NT == NT_ && NQ == NQ_ && (p.has_expand != 0) == E_ && (p.act2 == SGX_EMODE_HSWISH) == H_ && NT2 == N2_) { \
         auto kfn = k_irb<K_, S_, NT_, NQ_, E_, H_, N2_>; static bool attr = false; \

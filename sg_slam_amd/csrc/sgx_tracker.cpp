@@ -20,6 +20,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <vector>
 
 #ifndef SGX_EMU
@@ -102,7 +103,7 @@ struct sgx_tracker {
     sgx_st last_stream = nullptr;           // non-pipelined mode: the caller stream of the last step (snapshots and the record pack are ordered behind it)
     bool pack_pending[3] = { false, false, false };
     int frame_idx = 0, cur = 0;
-    bool pipelined = false;
+    bool pipelined = false, shared_T = false;      // shared_T: sT aliases another stream (not destroyed separately)
 
     template <class Tp> int alloc(Tp **p, size_t count)
     {
@@ -126,7 +127,7 @@ extern "C" void sgx_tracker_destroy(sgx_tracker *t)
     ev_destroy(t->ev_step);
     for (int i = 0; i < 2; i++) { ev_destroy(t->ev_det[i]); ev_destroy(t->ev_up[i]); }
     ev_destroy(t->ev_in);
-    st_destroy(t->sE); st_destroy(t->sT); st_destroy(t->sD); st_destroy(t->sU);
+    st_destroy(t->sE); if (!t->shared_T) st_destroy(t->sT); st_destroy(t->sD); st_destroy(t->sU);
     delete t;
 }
 
@@ -175,7 +176,14 @@ extern "C" int sgx_tracker_create(const sgx_tracker_config *cfg, sgx_det *detect
     }
     t->pipelined = cfg->pipelined != 0;
     if (t->pipelined) {
-        if (st_create(&t->sE, 0) || st_create(&t->sT, 1) || st_create(&t->sD, 0)) FAIL(SGX_ERR_DEVICE);      // the tracking stream is the latency-critical one: dispatch it first
+        // stream priorities (bit 0 extraction, 1 tracking, 2 detector): the tracking stream is the latency-critical one for a single camera and gets the high priority by default;
+        // SGX_TRK_PRIO is the tuning tap
+        static const int prio = getenv("SGX_TRK_PRIO") ? atoi(getenv("SGX_TRK_PRIO")) : 2;
+        // SGX_TRK_SHARE (tuning tap): 1 = tracking on the DETECTOR's stream (det(t), then track(t) behind it), 2 = tracking on the EXTRACTION stream (the round-1 serial order)
+        static const int share = getenv("SGX_TRK_SHARE") ? atoi(getenv("SGX_TRK_SHARE")) : 0;
+        if (st_create(&t->sE, prio & 1) || st_create(&t->sD, (prio >> 2) & 1)) FAIL(SGX_ERR_DEVICE);
+        if (share == 1) { t->sT = t->sD; t->shared_T = true; } else if (share == 2) { t->sT = t->sE; t->shared_T = true; }
+        else if (st_create(&t->sT, (prio >> 1) & 1)) FAIL(SGX_ERR_DEVICE);
         for (int i = 0; i < 3; i++) if (ev_create(&t->ev_extract[i]) || ev_create(&t->ev_track[i]) || ev_create(&t->ev_pack[i]) || ev_create(&t->ev_consumed[i])) FAIL(SGX_ERR_DEVICE);
         for (int i = 0; i < 2; i++) if (ev_create(&t->ev_det[i]) || ev_create(&t->ev_up[i])) FAIL(SGX_ERR_DEVICE);
         if (ev_create(&t->ev_in)) FAIL(SGX_ERR_DEVICE);
