@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFS = 157.3        # fp32-input MFMA = fp32 vector peak
+MFMA_BF16_PEAK_TFS = 2516.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PFLOP/s); a bf16x3 product costs six bf16 MFMAs -> 419 TFLOP/s of fp32-equivalent flops
 FP64_PEAK_TFS = 78.6
 LEVELS = [(640, 480), (533, 400), (444, 333), (370, 278), (309, 231), (257, 193), (214, 161), (179, 134)]
 PIX = [w * h for w, h in LEVELS]
@@ -254,6 +255,15 @@ def main():
         if d_bgr is None:
             d_bgr = d_frames.unsqueeze(-1).expand(T, S, 480, 640, 3).contiguous()          # gray replicated to 3 channels (SURVEY §8(d) input 2)
         det_gflop = 2.0 * det.gmac
+        # share of the graph's multiply-adds that the plan runs as bf16x3 on the bf16 matrix pipes (k_conv_pw3 steps are marked in the plan's step descriptions); the roofline peak
+        # of det_forward is the harmonic blend of the two pipes' peaks over that split ("frac recomputed against the peak of the pipe actually used")
+        import re as _re
+        mac3 = 0.0
+        for desc, _ in ([] if det.gemm != 'bf16x3' else [(d, 0) for d in det.op_descriptions()]):
+            m = _re.match(r'pw \S+ c(\d+)->(\d+) k1 s1 (\d+)x(\d+)->', desc)
+            if m and desc.rstrip().endswith('bf16x3'): mac3 += int(m.group(1)) * int(m.group(2)) * int(m.group(3)) * int(m.group(4))
+        det_bf16x3_share = mac3 / (det.gmac * 1e9)
+        det_peak_tfs = 1.0 / (det_bf16x3_share / (MFMA_BF16_PEAK_TFS / 6.0) + (1.0 - det_bf16x3_share) / MFMA_F32_PEAK_TFS)
     tr = TrackerNative(lib, S, cam, pipelined=not args.no_pipeline, local_map=not args.no_local_map, dynamic_mask=True, max_boxes=MB, detector=det)
     tr.set_initial_pose(initial_poses())
 
@@ -446,10 +456,13 @@ def main():
     except Exception:
         traffic = None
     if dk['bound'] == 'mfma':
-        roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': dk['achieved_TFLOPs'], 'peak': MFMA_F32_PEAK_TFS, 'unit': 'TFLOP/s', 'frac': dk['achieved_TFLOPs'] / MFMA_F32_PEAK_TFS,
+        roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': dk['achieved_TFLOPs'], 'peak': round(det_peak_tfs, 1), 'unit': 'TFLOP/s', 'frac': dk['achieved_TFLOPs'] / det_peak_tfs,
+                    'peak_fp32_matrix': MFMA_F32_PEAK_TFS, 'frac_of_fp32_matrix_peak': dk['achieved_TFLOPs'] / MFMA_F32_PEAK_TFS, 'bf16x3_share_of_macs': round(det_bf16x3_share, 4),
                     'traffic': traffic, 'avg_launch_ms': dk['avg_ms_per_launch'], 'alg_gflop_per_launch': dk['alg_gflop_per_launch'],
-                    'note': f'det_forward = pre-processing + the {det.num_kernels}-launch hipGraph of the MobileNetV3-SSDLite plan (the pointwise convolutions on v_mfma_f32_32x32x2_f32 carry 0.50 of its '
-                            '0.557 GMAC); flops = 2 x MACs of the whole graph, priced against the fp32 matrix peak; per-launch rocprof table in profiles/'}
+                    'note': f'det_forward = pre-processing + the {det.num_kernels}-launch hipGraph of the MobileNetV3-SSDLite plan; flops = 2 x MACs of the whole graph.  Matrix products: {det.gemm} '
+                            f'({det_bf16x3_share:.0%} of the MACs as bf16x3 = six v_mfma_f32_32x32x16_bf16 per product on the bf16 pipes at {MFMA_BF16_PEAK_TFS / 6:.0f} TFLOP/s fp32-equivalent; the rest — the fused '
+                            'inverted-residual blocks and the short-k layers — as exact fp32 on v_mfma_f32_32x32x2_f32 or packed fp32 FMAs); peak = harmonic blend of the two pipes over that split; '
+                            'per-launch rocprof table in profiles/'}
     else:
         roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': dk['achieved_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': dk['achieved_GBs'] / HBM_PEAK_GBS, 'traffic': traffic,
                     'avg_launch_ms': dk['avg_ms_per_launch'], 'alg_bytes_per_launch': dk['alg_bytes_per_launch']}
@@ -475,7 +488,7 @@ def main():
             if nl and S == 512:
                 kms = tot_ns / nl / 1e6
                 roofline['graph_kernel_time'] = {'sum_of_node_kernel_ms_per_launch': round(kms, 3), 'achieved': round(dk['alg_gflop_per_launch'] / (kms * 1e-3) / 1e3, 3),
-                                                 'frac': dk['alg_gflop_per_launch'] / (kms * 1e-3) / 1e3 / MFMA_F32_PEAK_TFS, 'source': 'profiles/' + os.path.basename(ks_path) + ' (rocprofv3 --kernel-trace --stats of this command at 512 streams)'}
+                                                 'frac': dk['alg_gflop_per_launch'] / (kms * 1e-3) / 1e3 / det_peak_tfs, 'source': 'profiles/' + os.path.basename(ks_path) + ' (rocprofv3 --kernel-trace --stats of this command at 512 streams)'}
         except (OSError, ImportError, KeyError, StopIteration):
             pass
     roofline['traffic_source'] = ('profiles/' + os.path.basename(tj_path) + ' (separate rocprofv3 --pmc passes of this command)') if traffic is not None else None
@@ -544,7 +557,7 @@ def main():
     workload = ('Single MI355X: + NCNN detector fwd (MFMA convs) and dynamic-feature mask' if det is not None else 'Single MI355X: ORB extract+match HIP kernels + LK / RANSAC mask inputs') + \
                (f', TUM sequence {os.path.basename(os.path.normpath(args.tum))}' if args.tum else ', 640x480 synthetic streams') + ', 1000 feats/frame'
     # arithmetic types of the path: u8 / integer fixed point (ORB, LK, Hamming matching), f32 (detector forward; its scheme is named by the detector), f64 (LM pose / BA solvers)
-    DTYPE = 'u8/f32/f64' if det is not None else 'u8/f64'
+    DTYPE = ('u8/f32(bf16x3 matrix products)/f64' if det.gemm == 'bf16x3' else 'u8/f32/f64') if det is not None else 'u8/f64'
     out = {
         'metric': 'tracked frames/sec (640x480 RGB-D)', 'value': fps, 'unit': 'frames/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
@@ -554,7 +567,7 @@ def main():
                                     'fm_ransac (pair selection + findFundamentalMat)', 'wait for detector boxes', 'dynamic_mask + erase', 'stereo_from_rgbd', 'motion_model',
                                     'search_by_projection(cur,last)', 'pose_optimization'] + ([] if args.no_local_map else ['search_by_projection(cur,local_map th=3)', 'pose_optimization#2']) +
                                    ['unproject'] + ([] if args.no_local_map else ['make_map_points']) + (['gather of frame records to rank 0'] if dist else []),
-                   'detector': None if det is None else {'graph': os.path.basename(args.param), 'weights': weights_note, 'gflop_per_frame': det_gflop, 'mean_person_boxes_last_step': float(nbx.mean()),
+                   'detector': None if det is None else {'graph': os.path.basename(args.param), 'weights': weights_note, 'gflop_per_frame': det_gflop, 'matrix_products': det.gemm, 'mean_person_boxes_last_step': float(nbx.mean()),
                                                          'boxes_feed_mask_of_same_frame_and_ransac_selection_of_next': True},
                    'local_map_points': 0 if args.no_local_map else 2 * tr.cap, 'mean_local_map_matches': None if args.no_local_map else float(nmatch_local.mean()),
                    'streams_per_gpu': S, 'frames_per_step': S, 'distinct_frames_per_stream': T,

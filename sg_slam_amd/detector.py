@@ -84,6 +84,15 @@ class Detector2D:
             buf = C.create_string_buffer(256); self.lib.check(self.lib.dll.sgx_det_debug_op_desc(self.h, i, buf, 256)); out.append((buf.value.decode(), float(ms[i])))
         return out
 
+    def op_descriptions(self):
+        """one line per plan step (kind, layers, shapes, ' bf16x3' behind the steps that run on the bf16 matrix pipes)"""
+        out = []
+        for i in range(self.num_kernels):
+            buf = C.create_string_buffer(256)
+            if self.lib.dll.sgx_det_debug_op_desc(self.h, i, buf, 256) != 0: break
+            out.append(buf.value.decode())
+        return out
+
     def debug_blob(self, name, image=0):
         n = C.c_int(0)
         self.lib.check(self.lib.dll.sgx_det_debug_read_blob(self.h, name.encode(), image, None, 0, C.byref(n)))
