@@ -531,7 +531,8 @@ def main():
                                   'order in LK, the device the exact-sum variant; RANSAC / mask decisions can differ on knife-edge points)'}
         if not args.no_cpu_all_cores:
             import subprocess, tempfile
-            P = max(1, os.cpu_count() or 1); n_per = max(12, args.cpu_sample // 10)
+            # one worker per PHYSICAL core: the box reports 256 logical CPUs = 128 cores x 2 threads; measured in round 4: 256 workers give 115 frames/s, 128 give 166-168
+            P = max(1, min(os.cpu_count() or 1, 128)); n_per = max(12, args.cpu_sample // 10)
             start = os.path.join(tempfile.mkdtemp(prefix='sgx_cpu_'), 'go')
             env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
             procs = [subprocess.Popen([sys.executable, '-m', 'oracle.cpu_chain', '--index', str(k), '--frames', str(T), '--n', str(n_per), '--start-file', start] +
