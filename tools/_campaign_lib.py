@@ -7,6 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def campaign_lib():
     """(library, array flavour for the tracker harness)"""
     if os.environ.get('SGX_CAMPAIGN_LIB', '') == 'device':
+        import torch                      # torch first: its HIP runtime must be initialised before libsgx.so touches the device (the tracker harness allocates through torch)
+        torch.cuda.init()
         import sg_slam_amd
         lib = sg_slam_amd.load()
         assert 'gfx950' in lib.version()
