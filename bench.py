@@ -272,6 +272,7 @@ def main():
     traj = torch.zeros((NSTEP, S, 16), dtype=torch.float32, device='cuda')                     # pose snapshots per step (device copies on the tracking stream)
     NBOX = min(64, NSTEP)
     box_log = torch.zeros((NBOX, MB, 4), dtype=torch.float32, device='cuda'); nbox_log = torch.zeros((NBOX, 1), dtype=torch.int32, device='cuda')      # stream 0, for the oracle-chain comparison
+    torch.cuda.synchronize()          # the snapshot copies run on the tracker's own (non-blocking) streams: the zero-fills above must have landed first
 
     def step(i):
         fi = order[i % len(order)]
@@ -312,6 +313,7 @@ def main():
     tracked = int((ninl >= 10).sum())
     if det is not None:
         bx_last = torch.zeros((MB, 4), dtype=torch.float32, device='cuda'); nb_all = torch.zeros(S, dtype=torch.int32, device='cuda')
+        torch.cuda.synchronize()                                                                  # the fills above run on torch's stream, the snapshots on the tracker's detector stream
         for s_ in range(0, S, max(1, S // 64)):                                                   # person-box count of a sample of streams in the last step
             tr.snapshot_boxes(s_, bx_last, nb_all[s_:s_ + 1])
         tr.synchronize(); torch.cuda.synchronize()

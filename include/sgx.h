@@ -580,6 +580,7 @@ int sgx_tracker_read(sgx_tracker *t, float *Tcw, int32_t *nkeys, int32_t *nmatch
                      int32_t *f_ok, int32_t *f_stats);
 int sgx_tracker_snapshot_pose_dev(sgx_tracker *t, float *d_out /* streams x 16 */);                               /* async copy on the tracking stream */
 int sgx_tracker_snapshot_boxes_dev(sgx_tracker *t, int stream_index, float *d_boxes /* max_boxes x 4 */, int32_t *d_nboxes);   /* async copy on the detector stream */
+/* (both snapshots copy on the tracker's own non-blocking streams: the destination buffers must have no pending writes on other streams — e.g. a zero-fill — when they are called) */
 /* the frame records {n, cv::KeyPoint[cap], descriptors[cap][32], Tcw} of the frame tracked last, packed by one kernel into d_records (streams x record_bytes) on
  * `stream` after the frame's tracking event: what the RCCL gather of BASELINE config 5 sends */
 int sgx_tracker_pack_records_dev(sgx_tracker *t, uint8_t *d_records, void *stream);

@@ -193,7 +193,10 @@ __global__ void __launch_bounds__(768) k_irb(SgxIrb p)
             const unsigned sBb = (unsigned)(ch0 * p.ld2b) * 4u, sstepb = (unsigned)(2 * p.ld2b) * 4u;
             // project weights: a ring of R k-steps in flight, statically indexed (the loop advances R steps per trip; Cexp is a multiple of 8: planner), so a
             // load is only waited for R steps after it was issued
-            constexpr int R = 4;
+#ifndef SGX_IRB_R5
+#define SGX_IRB_R5 2
+#endif
+            constexpr int R = NT >= 5 ? SGX_IRB_R5 : 4;      // SGX_IRB_R5 / SGX_IRB_D5: A/B taps for the five-tile instantiations, whose 80 accumulator registers leave the least room (tools/ab_build.sh)
             float ar[R][NT], ar2[R][NT2A];
 #pragma unroll
             for (int d = 0; d < R; d++) {
@@ -288,7 +291,10 @@ __global__ void __launch_bounds__(768) k_irb(SgxIrb p)
                     for (int r = 0; r < 16; r++) e[r] = sgx_bld(r_b1, (unsigned)half * 16u, (unsigned)(ch1 + (r & 3) + 8 * (r >> 2)) * 4u);
                     // operand ring: D k-steps in flight.  The k loop runs over whole groups of D steps: steps past Cin / 2 meet zero weight rows (the host pads the
                     // transposed weights to a multiple of 32 rows) and a clamped, finite input row — the per-layer kernel k_conv_pw2 pads the same way
-                    constexpr int D = 8;
+#ifndef SGX_IRB_D5
+#define SGX_IRB_D5 8
+#endif
+                    constexpr int D = NT >= 5 ? SGX_IRB_D5 : 8;
                     const int nks = p.Cin >> 1, nkp = (nks + D - 1) & ~(D - 1);
                     const unsigned sA = (unsigned)ch1 * 4u, sAstep = (unsigned)(2 * p.ld1) * 4u;
                     float ar[D], br[D];

@@ -14,6 +14,18 @@
 
 #include "sgx_se3.h"
 
+// Sum of a double over groups of 8 consecutive lanes, as the pairwise tree ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7)); every lane of the group receives it.  On the device
+// three DPP steps (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror) on the two halves of the value; the emulator forms the same tree from the threads' stored values.
+#ifndef SGX_EMU
+template <int CTRL> SGX_DEV double sgx_dpp_add_f64(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return v + __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, true), __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, true));
+}
+SGX_DEV double sgx_sum8_f64(double v) { v = sgx_dpp_add_f64<0xB1>(v); v = sgx_dpp_add_f64<0x4E>(v); return sgx_dpp_add_f64<0x141>(v); }
+#endif
+SGX_DEV double sgx_tree8_f64(const double *a, int stride) { return ((a[0] + a[stride]) + (a[2 * stride] + a[3 * stride])) + ((a[4 * stride] + a[5 * stride]) + (a[6 * stride] + a[7 * stride])); }
+
 // ---------------------------------------------------------------------------------------------
 // k_pose_opt: one 256-thread workgroup per frame.  Edge e <-> keypoint i with a map point (ascending i, as the
 // reference inserts them, Optimizer.cc:280-360).  Threads own edges e = tid, tid+256, ...; the
@@ -42,11 +54,17 @@ SGX_KERNEL(NTT) k_pose_opt(int cap, const uint8_t *keys_raw, const float *uright
     SGX_LDS double e_err[SGX_PO_CAP * 3];
     SGX_LDS uint16_t e_kp[SGX_PO_CAP];
     SGX_LDS uint8_t e_flags[SGX_PO_CAP];          // bit0 stereo, bit1 level==1 (excluded), bit3 outlier flag
-    constexpr int NG = NTT / 32;                   // reduction groups (rows j, j+NG, j+2NG, ... of `part`)
-    SGX_LDS double part[NTT * SGX_PO_NRED];
+    // Reduction of the per-thread sums (round 4): first over groups of 8 lanes in registers (sgx_sum8_f64), then R8 = NTT / 8 rows through LDS in NG groups, then the groups.
+    // `part` used to hold one row per THREAD (55 KB at 256 threads): with it the kernel took 128 KB of LDS, i.e. ONE workgroup = one wave per SIMD per CU — and a wave issues
+    // a dependent fp64 FMA only every 7.3 cycles.  At 80 KB two frames share a CU and fill each other's issue gaps.
+    constexpr int R8 = NTT / 8, NG = R8 >= 8 ? R8 / 8 : 1, RPG = R8 / NG;      // rows, groups, rows per group (rows j, j + NG, ... belong to group j)
+    SGX_LDS double part[R8 * SGX_PO_NRED];
     SGX_LDS double part2[SGX_PO_NRED * NG];
     SGX_LDS double red[SGX_PO_NRED];
-    SGX_LDS double chi_part[NTT], chi_grp[SGX_PO_CG];
+    SGX_LDS double chi_part[R8], chi_grp[SGX_PO_CG];
+#ifdef SGX_EMU
+    static thread_local double part_thr[NTT * SGX_PO_NRED], chi_thr[NTT];         // the emulator's threads run one after the other: their values wait here for the 8-lane tree
+#endif
     SGX_LDS int scan[NTT];
     SGX_LDS int s_ne, s_nbad;
 
@@ -106,6 +124,13 @@ SGX_KERNEL(NTT) k_pose_opt(int cap, const uint8_t *keys_raw, const float *uright
     for (int i = 0; i < 16; i++) T0[i] = Tcw[16 * f + i];
     int nBad = 0;
 
+#ifndef SGX_EMU
+#define SGX_PO_STORE_CHI8(chi_) { const double c8_ = sgx_sum8_f64(chi_); if ((tid & 7) == 0) chi_part[tid >> 3] = c8_; }
+#define SGX_PO_EMU_CHI8()
+#else
+#define SGX_PO_STORE_CHI8(chi_) chi_thr[tid] = (chi_);
+#define SGX_PO_EMU_CHI8() for (int r_ = 0; r_ < R8; r_++) chi_part[r_] = sgx_tree8_f64(chi_thr + 8 * r_, 1);
+#endif
 // evaluates the errors of the edges at `est` and the robust chi2 of the active (level-0) ones -> chiTot.  Excluded edges are evaluated too
 // (their e_err is recomputed by the classification below before it is next read) but add an exact zero.
 #define SGX_PO_ERRORS()                                                                                     \
@@ -121,11 +146,12 @@ SGX_KERNEL(NTT) k_pose_opt(int cap, const uint8_t *keys_raw, const float *uright
         if (robust) r0 = sgx_huber_rho0((fl & 2) ? 0.0 : c2, (fl & 1) ? deltaStereo : deltaMono);           \
         chi += (fl & 2) ? 0.0 : r0;                                                                         \
     }                                                                                                       \
-    chi_part[tid] = chi;                                                                                    \
+    SGX_PO_STORE_CHI8(chi)                                                                                  \
     SGX_THREADS_END                                                                                         \
+    SGX_PO_EMU_CHI8()                                                                                       \
     SGX_SYNC();                                                                                             \
     SGX_THREADS_BEGIN(tid)                                                                                  \
-    if (tid < SGX_PO_CG) { double s = 0; for (int l = 0; l < NTT / SGX_PO_CG; l++) s += chi_part[l * SGX_PO_CG + tid]; chi_grp[tid] = s; } \
+    if (tid < SGX_PO_CG) { double s = 0; for (int l = 0; l * SGX_PO_CG + tid < R8; l++) s += chi_part[l * SGX_PO_CG + tid]; chi_grp[tid] = s; } \
     SGX_THREADS_END                                                                                         \
     SGX_SYNC();                                                                                             \
     { double s = 0; for (int l = 0; l < SGX_PO_CG; l++) s += chi_grp[l]; chiTot = s; }
@@ -177,12 +203,19 @@ SGX_KERNEL(NTT) k_pose_opt(int cap, const uint8_t *keys_raw, const float *uright
                     }
                 }
             }
+#ifndef SGX_EMU
 #pragma unroll
-            for (int k = 0; k < 27; k++) part[tid * SGX_PO_NRED + k] = acc[k];
+            for (int k = 0; k < 27; k++) { const double s8 = sgx_sum8_f64(acc[k]); if ((tid & 7) == 0) part[(tid >> 3) * SGX_PO_NRED + k] = s8; }
+#else
+            for (int k = 0; k < 27; k++) part_thr[tid * SGX_PO_NRED + k] = acc[k];
+#endif
             SGX_THREADS_END
+#ifdef SGX_EMU
+            for (int r_ = 0; r_ < R8; r_++) for (int k = 0; k < 27; k++) part[r_ * SGX_PO_NRED + k] = sgx_tree8_f64(part_thr + (8 * r_) * SGX_PO_NRED + k, SGX_PO_NRED);
+#endif
             SGX_SYNC();
             SGX_THREADS_BEGIN(tid)
-            if (tid < 27 * NG) { const int c = tid / NG, j = tid - c * NG; double s = 0; for (int l = 0; l < 32; l++) s += part[(l * NG + j) * SGX_PO_NRED + c]; part2[c * NG + j] = s; }
+            if (tid < 27 * NG) { const int c = tid / NG, j = tid - c * NG; double s = 0; for (int l = 0; l < RPG; l++) s += part[(l * NG + j) * SGX_PO_NRED + c]; part2[c * NG + j] = s; }
             SGX_THREADS_END
             SGX_SYNC();
             SGX_THREADS_BEGIN(tid)

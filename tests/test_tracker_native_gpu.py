@@ -62,6 +62,7 @@ def test_native_tracker_with_detector_equals_python_orchestration(gpulib):
         py.step(d_gray, d_depth, mask=dict(boxes=boxes[b], nboxes=nb[b], have_dynamic=have[b], event=ev[b]))
         nat.step(d_gray, d_depth, d_bgr=d_bgr, stream=torch.cuda.current_stream().cuda_stream)
         bx = torch.zeros((MB, 4), dtype=torch.float32, device='cuda'); bn = torch.zeros(1, dtype=torch.int32, device='cuda')
+        torch.cuda.current_stream().synchronize()      # the zero-fills run on torch's stream, the snapshot copies on the tracker's detector stream (non-blocking): without this the fill can land AFTER the copy
         nat.snapshot_boxes(1, bx, bn)
         r = nat.read(); py.synchronize(); sD.synchronize(); torch.cuda.synchronize()
         assert (bn.cpu().numpy()[0] == nb[b].cpu().numpy()[1]) and (bx.cpu().numpy() == boxes[b][1].cpu().numpy()).all()
