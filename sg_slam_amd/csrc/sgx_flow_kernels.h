@@ -899,7 +899,10 @@ struct SgxFmArgs {
     double *F; int *ok; int *stats;          /* F: 9 doubles per frame; ok: 1 / 0 (no model; F zeroed); stats (optional): 4 ints per frame */
 };
 
-SGX_KERNEL(256) k_fm_ransac(SgxFmArgs A)
+#ifndef SGX_FM_OCC
+#define SGX_FM_OCC 2      /* waves per SIMD the register allocation is held to: at 243 + 16 registers (round 3) one workgroup = one wave per SIMD had a CU to itself */
+#endif
+SGX_KERNEL_OCC(256, SGX_FM_OCC) k_fm_ransac(SgxFmArgs A)
 {
     SGX_DYN_LDS(lds_raw);
     // layout: m1 (cap float2) | m2 (cap float2) | scan (256 int) | flags (cap u8, padded)
