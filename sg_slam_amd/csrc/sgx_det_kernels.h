@@ -1186,10 +1186,14 @@ SGX_DEV bool sgx_iou_gt(float a0, float a1, float a2, float a3, float area_a, fl
 
 SGX_KERNEL(256) k_det_class_nms(SgxDetOut P, const float *loc, const float *conf, const float *priors, float *cls_rows, int *cls_count)
 {
-    SGX_LDS uint32_t sc[SGX_DO_SORT];                            // score pattern per prior, 0 = below the confidence threshold
-    SGX_LDS unsigned long long keys[SGX_DO_TOPK];
-    SGX_LDS float box[SGX_DO_TOPK][4];
-    SGX_LDS float area[SGX_DO_TOPK];
+    SGX_DYN_LDS(sc_pool);                                        // score pattern per prior (u32 view `sc`), 0 = below the confidence threshold: sized by the host to max(num_priors, 7 * SGX_DO_TOPK) words
+    unsigned long long *sc64 = (unsigned long long *)sc_pool;     // (a static SGX_DO_SORT-entry array cost 7 KB more than this graph's 2 268 priors need: six workgroups per CU instead of five)
+    uint32_t *sc = (uint32_t *)sc_pool;
+    // the sorted keys, the decoded boxes and their areas are written only after the last read of `sc` (the selection loop): they live in its storage — 31 KB instead of 40 KB
+    // of LDS, five workgroups per CU instead of four (round 4)
+    unsigned long long *keys = sc64;                              // [SGX_DO_TOPK]
+    float (*box)[4] = (float (*)[4])(sc + 2 * SGX_DO_TOPK);       // [SGX_DO_TOPK][4]
+    float *area = (float *)(sc + 6 * SGX_DO_TOPK);                // [SGX_DO_TOPK]
     SGX_LDS unsigned long long over[SGX_DO_TOPK][SGX_DO_WORDS];
     SGX_LDS unsigned long long kept[SGX_DO_WORDS];
     SGX_LDS int hist[256], eqc[256], sel[4];
