@@ -64,8 +64,17 @@ SGX_DEV sgx_f32x16 sgx_mfma_bf16x3(const sgx_u32x4 &a0, const sgx_u32x4 &a1, con
 // splits them once and multiplies them with OCB weight tiles; weights come straight from global memory (L2-resident, one dwordx4 per term and tile).  B operands are
 // requested two k16 steps ahead, A operands one.  grid / XCD order / tile shapes as k_conv_pw2.
 // ---------------------------------------------------------------------------------------------
+#ifndef SGX_PW3_BRING
+#define SGX_PW3_BRING 3      /* B-operand ring: k16 steps in flight (A/B taps, tools/ab_build.sh) */
+#endif
+#ifndef SGX_PW3_ARING
+#define SGX_PW3_ARING 2      /* A-operand ring */
+#endif
+#ifndef SGX_PW3_OCC4
+#define SGX_PW3_OCC4 2       /* waves per SIMD the four-tile shapes are compiled for */
+#endif
 template <int OCB, int PXB>
-SGX_KERNEL_OCC(256, (OCB * PXB == 1 ? 4 : (OCB * PXB <= 3 ? 3 : 2))) k_conv_pw3(int inc, int outc, int N, int total, const float *in, size_t in_pitch, const sgx_u32x4 *__restrict__ Ws, const float *bias,
+SGX_KERNEL_OCC(256, (OCB * PXB == 1 ? 4 : (OCB * PXB <= 3 ? 3 : (OCB * PXB == 4 ? SGX_PW3_OCC4 : 2)))) k_conv_pw3(int inc, int outc, int N, int total, const float *in, size_t in_pitch, const sgx_u32x4 *__restrict__ Ws, const float *bias,
                                                           float *out, size_t out_pitch, SgxEpi epi, int hwc, int hwc_off, int nxt, int noc, int ldw, int direct)
 {
     constexpr int OCT = 32 * OCB;
@@ -117,10 +126,11 @@ SGX_KERNEL_OCC(256, (OCB * PXB == 1 ? 4 : (OCB * PXB <= 3 ? 3 : 2))) k_conv_pw3(
 #pragma unroll
             for (int q = 0; q < 3; q++) dst[t][q] = ws[(size_t)(2 * q) * ldw + 32 * t];
     };
-    float braw[3][PXB][8];
-    sgx_u32x4 aw[2][OCB][3];                                             // weights one k16 step ahead
+    constexpr int BR = SGX_PW3_BRING, AR = SGX_PW3_ARING;
+    float braw[BR][PXB][8];
+    sgx_u32x4 aw[AR][OCB][3];
     loadB(0, braw[0]); loadA(0, aw[0]);
-    loadB(min(1, nks - 1), braw[1]);
+    if (BR == 3) loadB(min(1, nks - 1), braw[1]);
     __syncthreads();
     sgx_f32x16 acc[OCB][PXB];
 #pragma unroll
@@ -137,15 +147,16 @@ SGX_KERNEL_OCC(256, (OCB * PXB == 1 ? 4 : (OCB * PXB <= 3 ? 3 : 2))) k_conv_pw3(
         for (int d = 0; d < 6; d++) {
             const int s = s0 + d;
             if (s < nks) {                                                // uniform
-                loadB(min(s + 2, nks - 1), braw[(d + 2) % 3]);
-                loadA(min(s + 1, nks - 1), aw[(d + 1) & 1]);
+                loadB(min(s + BR - 1, nks - 1), braw[(d + BR - 1) % BR]);
+                if (AR == 2) loadA(min(s + 1, nks - 1), aw[(d + 1) & 1]);
                 SgxB3 bs[PXB];
 #pragma unroll
-                for (int m = 0; m < PXB; m++) bs[m] = sgx_split3x8(braw[d % 3][m]);
+                for (int m = 0; m < PXB; m++) bs[m] = sgx_split3x8(braw[d % BR][m]);
 #pragma unroll
                 for (int t = 0; t < OCB; t++)
 #pragma unroll
-                    for (int m = 0; m < PXB; m++) acc[t][m] = sgx_mfma_bf16x3(aw[d & 1][t][0], aw[d & 1][t][1], aw[d & 1][t][2], bs[m], acc[t][m]);
+                    for (int m = 0; m < PXB; m++) acc[t][m] = sgx_mfma_bf16x3(aw[d % AR][t][0], aw[d % AR][t][1], aw[d % AR][t][2], bs[m], acc[t][m]);
+                if (AR == 1) loadA(min(s + 1, nks - 1), aw[0]);          // single set: the next step's weights are requested behind this step's products
             }
         }
     }
