@@ -206,7 +206,7 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                 const float *wsrc = (const float *)(bp + bo);
                 const bool pw = (k == 1 && group == 1 && stride == 1 && pad == 0), stem = (group == 1 && k > 1 && outc <= 16);
                 if (pw || stem) {
-                    const int kk = inc * k * k, ldo = pw ? ((outc + 31) / 32) * 32 + 96 : 16;          // pointwise: zero-padded to [ceil32(inc)][ldo]
+                    const int kk = inc * k * k, ldo = pw ? ((outc + 31) / 32) * 32 + 128 : 16;          // pointwise: zero-padded to [ceil32(inc)][ldo] (ldo covers the last oc block of every tile shape: up to four padding tiles of 32)
                     op.ldw = ldo;
                     std::vector<float> wT((size_t)(pw ? ((kk + 31) / 32) * 32 : kk) * ldo, 0.f);
                     for (int o = 0; o < outc; o++) for (int q = 0; q < kk; q++) { float v; memcpy(&v, wsrc + (size_t)o * kk + q, 4); wT[(size_t)q * ldo + o] = v; }

@@ -74,7 +74,12 @@ SGX_DEV sgx_f32x16 sgx_mfma_bf16x3(const sgx_u32x4 &a0, const sgx_u32x4 &a1, con
 #define SGX_PW3_OCC4 2       /* waves per SIMD the four-tile shapes are compiled for */
 #endif
 template <int OCB, int PXB>
-SGX_KERNEL_OCC(256, (OCB * PXB == 1 ? 4 : (OCB * PXB <= 3 ? 3 : (OCB * PXB == 4 ? SGX_PW3_OCC4 : 2)))) k_conv_pw3(int inc, int outc, int N, int total, const float *in, size_t in_pitch, const sgx_u32x4 *__restrict__ Ws, const float *bias,
+#if !defined(SGX_PW3_V1)
+#define SGX_PW3_OCC(OCB_, PXB_) ((OCB_) * (PXB_) == 1 ? 4 : ((PXB_) == 1 || (OCB_) * (PXB_) <= 3 ? 3 : 2))      /* with the weights in LDS every single-pixel-tile shape fits three waves per SIMD */
+#else
+#define SGX_PW3_OCC(OCB_, PXB_) ((OCB_) * (PXB_) == 1 ? 4 : ((OCB_) * (PXB_) <= 3 ? 3 : ((OCB_) * (PXB_) == 4 ? SGX_PW3_OCC4 : 2)))
+#endif
+SGX_KERNEL_OCC(256, SGX_PW3_OCC(OCB, PXB)) k_conv_pw3(int inc, int outc, int N, int total, const float *in, size_t in_pitch, const sgx_u32x4 *__restrict__ Ws, const float *bias,
                                                           float *out, size_t out_pitch, SgxEpi epi, int hwc, int hwc_off, int nxt, int noc, int ldw, int direct)
 {
     constexpr int OCT = 32 * OCB;
@@ -126,6 +131,66 @@ SGX_KERNEL_OCC(256, (OCB * PXB == 1 ? 4 : (OCB * PXB <= 3 ? 3 : (OCB * PXB == 4 
 #pragma unroll
             for (int q = 0; q < 3; q++) dst[t][q] = ws[(size_t)(2 * q) * ldw + 32 * t];
     };
+#if !defined(SGX_PW3_V1)
+    // Round 4, second version: the weights of a k16 step go through LDS ONCE per workgroup (its four waves multiply different pixels by the same weights) instead of once per wave
+    // from L2: a quarter of the weight loads, and 12 operand registers per wave instead of the 24 OCB of a private double buffer — the (5,1) shape drops from 245 to ~150
+    // registers, i.e. from two to three waves per SIMD, on layers whose grids (10 x 10 and 19 x 19 maps) give a SIMD only two or three waves to hide a k loop of 10-60 steps behind.
+    // Double-buffered chunk of one k16 step, [term * 2 + half][oc] x 16 bytes = the global layout cut to the block's oc range; one barrier per step.
+    constexpr int BR = 3, ROWS = 6 * OCT, CP = (ROWS + 255) / 256;
+    SGX_LDS sgx_u32x4 Aw[2][ROWS];
+    float braw[BR][PXB][8];
+    sgx_u32x4 cpy[CP];
+    int cidx[CP]; unsigned coff[CP];                                   // this thread's slots of the chunk copy: LDS index and global offset inside a step (in 16-byte units)
+#pragma unroll
+    for (int i = 0; i < CP; i++) { const int idx = tid + 256 * i, row = idx / OCT, oc = idx - row * OCT; cidx[i] = idx; coff[i] = (unsigned)(row * ldw + oc0 + oc); }
+    auto fetchA = [&](int s_) {
+        const sgx_u32x4 *ws = Ws + (size_t)(6 * s_) * ldw;
+#pragma unroll
+        for (int i = 0; i < CP; i++) if (CP * 256 == ROWS || cidx[i] < ROWS) cpy[i] = ws[coff[i]];
+    };
+    auto storeA = [&](int buf_) {
+#pragma unroll
+        for (int i = 0; i < CP; i++) if (CP * 256 == ROWS || cidx[i] < ROWS) Aw[buf_][cidx[i]] = cpy[i];
+    };
+    fetchA(0); loadB(0, braw[0]); loadB(min(1, nks - 1), braw[1]);
+    storeA(0);
+    fetchA(min(1, nks - 1));
+    __syncthreads();
+    sgx_f32x16 acc[OCB][PXB];
+#pragma unroll
+    for (int t = 0; t < OCB; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float bz = Bs[32 * t + (r & 3) + 8 * (r >> 2) + 4 * half];
+#pragma unroll
+            for (int m = 0; m < PXB; m++) acc[t][m][r] = bz;
+        }
+    for (int s0 = 0; s0 < nks; s0 += 6) {
+#pragma unroll
+        for (int d = 0; d < 6; d++) {
+            const int s_ = s0 + d;
+            if (s_ < nks) {                                              // uniform
+                const int buf = s_ & 1;
+                loadB(min(s_ + 2, nks - 1), braw[(d + 2) % 3]);
+                SgxB3 bs[PXB];
+#pragma unroll
+                for (int m = 0; m < PXB; m++) bs[m] = sgx_split3x8(braw[d % 3][m]);
+                const sgx_u32x4 *al = &Aw[buf][half * OCT + l31];
+                // (issuing one cross term for every tile before the next term — OCB * PXB independent MFMAs between two dependent ones — was measured: equal on every shape
+                // but (5,1), where it spills and runs three times slower)
+#pragma unroll
+                for (int t = 0; t < OCB; t++) {
+                    const sgx_u32x4 a0 = al[32 * t], a1 = al[2 * OCT + 32 * t], a2 = al[4 * OCT + 32 * t];
+#pragma unroll
+                    for (int m = 0; m < PXB; m++) acc[t][m] = sgx_mfma_bf16x3(a0, a1, a2, bs[m], acc[t][m]);
+                }
+                storeA(buf ^ 1);                                         // the chunk of step s + 1 (in registers since the last step) -> the buffer read during step s - 1
+                fetchA(min(s_ + 2, nks - 1));
+                __syncthreads();
+            }
+        }
+    }
+#else
     constexpr int BR = SGX_PW3_BRING, AR = SGX_PW3_ARING;
     float braw[BR][PXB][8];
     sgx_u32x4 aw[AR][OCB][3];
@@ -160,6 +225,7 @@ SGX_KERNEL_OCC(256, (OCB * PXB == 1 ? 4 : (OCB * PXB <= 3 ? 3 : (OCB * PXB == 4 
             }
         }
     }
+#endif
     sgx_pw2_epilogue<OCB, PXB>(epi, acc, Es[wave], oc0, outc, N, total, g0, half, l31, out, out_pitch, ooff4, toff4, hwc, hwc_off, direct);
 }
 #endif
