@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun session of the round-4 detector work: parity of the bf16x3 plan, blob-by-blob diagnostic against the exact-fp32 plan, per-step timings of both plans, a short bench of both.
-#   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/gpu_trip.sh r4a'
+#   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/gpu_det_gemm.sh <tag>'
 set -u
 TAG=${1:-trip}; R=$PWD; O=$R/gpurun_out/$TAG; mkdir -p $O
 timeout 300 python tools/diag_gemm.py 3 > $O/diag_gemm.txt 2>&1
