@@ -613,6 +613,16 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                     ib.wq2T = ops[ei].wtT; ib.bq2 = ops[ei].bias; ib.ldq2 = ops[ei].ldw; ib.wq2 = ops[ei].wt;
                 }
                 ib.has_res = res_blob >= 0; ib.hwc = c.hwc; ib.hwc_off = c.hwc_off;
+                {   // tuning tap SGX_IRB_W1LDS=1: expand weights through LDS when the two slices fit beside the planes (the 5 x 5 blocks' planes leave no room).  OFF: measured 6 % slower
+                    // on every block (3.45 -> 3.65 ms over the seven expand blocks, bit-identical) — the per-wave loads with scalar offsets and an 8-deep ring hide their latency behind the
+                    // 64-cycle fp32 MFMAs already, and the LDS reads compete with the plane traffic
+                    static const int w1lds_env = getenv("SGX_IRB_W1LDS") ? atoi(getenv("SGX_IRB_W1LDS")) : 0;
+                    if (ai >= 0 && w1lds_env) {
+                        const int rows = (((ib.Cin >> 1) + 7) & ~7) * 2;
+                        ib.w1rows = rows;
+                        if (sgx_irb_lds_bytes(ib) > lds_max) ib.w1rows = 0;
+                    }
+                }
                 {   // bf16x3 plan: every GEMM of the block needs its split weights (and the squeeze width must span the k16 steps the instantiation unrolls)
                     const int nqs = NQ == 0 ? 1 : (NQ == 2 ? 3 : (NT == 2 ? 1 : 2));
                     // k_irb3 is OPT-IN (SGX_DET_IRB3=1) until its operand streams hide their latency: measured slower than k_irb on every expand block (r4 trips: 0.99 against 0.75 ms on

@@ -32,6 +32,7 @@ struct SgxIrb {
     int G, nbands, OH, batch;                   // images per workgroup (nbands == 1) or bands of OH output rows per image (G == 1)
     int Wp, HpWp, planeT, nbuf;                 // LDS plane geometry in floats: row pitch, per-image plane, per-channel plane (G images); 1 or 2 plane buffers
     int has_expand, stagger;
+    int w1rows;                                 // > 0: the expand weights of a chunk go through LDS once per workgroup ([2][w1rows][32] floats behind the depthwise weights; round 4), k_irb only
     int act1, act2;                             // SGX_EMODE_ACT / SGX_EMODE_HSWISH
     float a1c1, a1lo, a1hi, a1c2, a2c1, a2lo, a2hi, a2c2;
     float qlo, qhi;                             // squeeze activation
@@ -53,7 +54,7 @@ struct SgxIrb {
     const void *w1S, *w2S, *wq1S, *wq2S, *w2Sb;
 };
 #define SGX_IRB_KKP(K) (((K) * (K) + 1 + 3) & ~3)
-static inline size_t sgx_irb_lds_bytes(const SgxIrb &p) { return (size_t)p.nbuf * 32 * ((size_t)p.planeT + (p.Cout2 ? 2 : 1) * SGX_IRB_KKP(p.K)) * 4; }
+static inline size_t sgx_irb_lds_bytes(const SgxIrb &p) { return (size_t)p.nbuf * 32 * ((size_t)p.planeT + (p.Cout2 ? 2 : 1) * SGX_IRB_KKP(p.K)) * 4 + (size_t)2 * p.w1rows * 32 * 4; }
 
 SGX_DEV float sgx_irb_act(int mode, float v, float c1, float lo, float hi, float c2)
 {
@@ -112,6 +113,15 @@ __global__ void __launch_bounds__(768) k_irb(SgxIrb p)
         float4 *z = (float4 *)Eb; const int nz = p.nbuf * 8 * p.planeT;
         for (int i = tid; i < nz; i += nthreads) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    // Expand weights through LDS (round 4): the twelve waves of the workgroup multiply different pixels by the SAME 32 x Cin weight slice of a chunk; it is copied global -> LDS once
+    // per workgroup, one chunk ahead (two buffers), instead of being fetched by every wave from L2 (p.w1rows = 0: the per-wave loads of round 3)
+    float *W1s = Wds + (size_t)p.nbuf * 32 * KKP * (NT2 > 0 ? 2 : 1);
+    auto stageW1 = [&](int chunk) {
+        float4 *dst = (float4 *)(W1s + (size_t)(chunk & 1) * p.w1rows * 32);
+        for (int i = tid; i < p.w1rows * 8; i += nthreads) dst[i] = *(const float4 *)(p.w1T + (size_t)(i >> 3) * p.ld1 + chunk * 32 + 4 * (i & 7));
+    };
+    if (EXPAND && !A3 && p.w1rows) stageW1(0);
+    __syncthreads();                                                  // the zero-fill (and the first weight slice) before any wave writes a tile into the planes
     sgx_f32x16 acc[NT];
     {
         const sgx_rsrc r_b2 = sgx_mkrsrc_n(p.b2, p.Cout * 4);
@@ -171,6 +181,7 @@ __global__ void __launch_bounds__(768) k_irb(SgxIrb p)
     for (int c = -1; c < nchunks; c++) {
         const int ch1 = (c + 1) * 32, buf1 = (c + 1) & bmask;
         const bool more = c + 1 < nchunks;
+        if (EXPAND && !A3 && p.w1rows && c + 2 < nchunks) stageW1(c + 2);      // into the buffer stage A read one iteration ago; visible behind this iteration's barrier
         // ---- no expand stage: the next chunk's depthwise input (first tile of this wave) is requested before this chunk's stage B and parked in registers
         float pre[EXPAND ? 1 : 16];
         if (!EXPAND && more && p.nbuf == 2) {
@@ -298,6 +309,19 @@ __global__ void __launch_bounds__(768) k_irb(SgxIrb p)
                     const int nks = p.Cin >> 1, nkp = (nks + D - 1) & ~(D - 1);
                     const unsigned sA = (unsigned)ch1 * 4u, sAstep = (unsigned)(2 * p.ld1) * 4u;
                     float ar[D], br[D];
+                    if (p.w1rows) {                                       // uniform: weights from the chunk's LDS slice (row 2 s + half, column = the lane's channel)
+                        const float *W1c = W1s + (size_t)((c + 1) & 1) * p.w1rows * 32 + half * 32 + l31;
+#pragma unroll
+                        for (int d = 0; d < D; d++) { ar[d] = W1c[64 * d]; br[d] = sgx_bld(r_in, xoff, (unsigned)min(d, nks - 1) * sXstep); }
+                        for (int s0 = 0; s0 < nkp; s0 += D) {
+#pragma unroll
+                            for (int d = 0; d < D; d++) {
+                                e = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[d], br[d], e, 0, 0, 0);
+                                const int sn = min(s0 + d + D, nkp - 1);
+                                ar[d] = W1c[64 * sn]; br[d] = sgx_bld(r_in, xoff, (unsigned)min(sn, nks - 1) * sXstep);
+                            }
+                        }
+                    } else {
 #pragma unroll
                     for (int d = 0; d < D; d++) { ar[d] = sgx_bld(r_w1, aoff1, sA + d * sAstep); br[d] = sgx_bld(r_in, xoff, (unsigned)min(d, nks - 1) * sXstep); }
                     for (int s0 = 0; s0 < nkp; s0 += D) {
@@ -307,6 +331,7 @@ __global__ void __launch_bounds__(768) k_irb(SgxIrb p)
                             const int sn = min(s0 + d + D, nkp - 1);
                             ar[d] = sgx_bld(r_w1, aoff1, sA + (unsigned)sn * sAstep); br[d] = sgx_bld(r_in, xoff, (unsigned)min(sn, nks - 1) * sXstep);
                         }
+                    }
                     }
 #pragma unroll
                     for (int r = 0; r < 16; r++) e[r] = sgx_irb_act(AMODE, e[r], p.a1c1, p.a1lo, p.a1hi, p.a1c2);
@@ -515,6 +540,7 @@ __global__ void __launch_bounds__(768) k_irb3(SgxIrb p)
         float4 *z = (float4 *)Eb; const int nz = p.nbuf * 8 * p.planeT;
         for (int i = tid; i < nz; i += nthreads) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    __syncthreads();                                                  // the zero-fill before any wave writes a tile into the planes
     sgx_f32x16 acc[NT];
     {
         const sgx_rsrc r_b2 = sgx_mkrsrc_n(p.b2, p.Cout * 4);
