@@ -83,6 +83,13 @@ def test_detector_emu_matches_oracle(emu, model):
     run_compare(emu, model)
 
 
+def test_detector_emu_bf16x3_plan_matches_oracle(emu, model):
+    """The bf16x3 plan on the CPU tier: the planner's branch (host-split weights in the matrix-core layout, zero padding, the k >= 64 rule) with the pointwise layers run by a software
+    model of k_conv_pw3 that reads those very operands (sgx_det.cpp::sgx_pw3_emu) — same criterion as the exact-fp32 plan; the device kernel itself is checked on the GPU."""
+    run_compare(emu, model, seeds=(0,), gemm='bf16x3')
+    run_compare(emu, model, seeds=(1,), fuse=True, gemm='bf16x3')
+
+
 def test_detector_emu_fused_matches_oracle(emu, model):
     run_compare(emu, model, seeds=(0,), fuse=True)
 
