@@ -473,6 +473,14 @@ def main():
         ach = (dk['alg_gflop_per_launch'] / (sa * 1e-3) / 1e3) if dk['bound'] == 'mfma' else (dk['alg_bytes_per_launch'] / (sa * 1e-3) / 1e9)
         roofline['standalone'] = {'avg_launch_ms': sa, 'achieved': round(ach, 3), 'frac': ach / roofline['peak'], 'source': 'profiles/' + os.path.basename(sj_path)}
     if dom == 'det_forward':
+        try:        # both matrix-product schemes stand-alone, from one committed session ("report both in the line")
+            gj = json.load(open(latest_profile('detector_gemm_schemes.json')))
+            if gj['frames_per_launch'] == S:
+                roofline['standalone_by_scheme'] = {k: {'avg_launch_ms': v, 'achieved': round(dk['alg_gflop_per_launch'] / (v * 1e-3) / 1e3, 3),
+                                                        'frac_of_fp32_matrix_peak': dk['alg_gflop_per_launch'] / (v * 1e-3) / 1e3 / MFMA_F32_PEAK_TFS} for k, v in gj['det_forward_ms_per_launch'].items()}
+                roofline['standalone_by_scheme']['source'] = 'profiles/' + os.path.basename(latest_profile('detector_gemm_schemes.json'))
+        except (OSError, KeyError, ValueError):
+            pass
         # det_forward is a ~100-node hipGraph, timed as one HIP-event span; the sum of its node kernels' own durations from the committed rocprofv3 kernel statistics of this same
         # command (profiles/r2_bench_kernel_stats.csv) is reported next to it (the two agree when the graph's nodes run back to back).
         try:
