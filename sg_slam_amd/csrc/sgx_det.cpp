@@ -497,7 +497,7 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                 if (cc.mode != SGX_EMODE_NONE && cc.mode != SGX_EMODE_ADD_T) continue;
                 if (c.hwc && cc.mode != SGX_EMODE_NONE) continue;
                 // expand: pointwise producer of the depthwise input whose only reader is the depthwise convolution
-                int ai = -1; EpiClass ca; ca.mode = SGX_EMODE_NONE;
+                int ai = -1; EpiClass ca = { SGX_EMODE_NONE, 0.f, 0.f, INFINITY, 1.f, -1, -1 };
                 for (int i = 0; i < nops; i++) if (!ops[i].dead && ops[i].kind == OP_PW && ops[i].out == bq.in0 && !ops[i].hwc) ai = i;
                 if (ai >= 0) {
                     readers_all(bq.in0, R);
@@ -505,7 +505,7 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                     if (R.size() != 1 || !ops[ai].wtT || (ops[ai].inc & 1) || (ca.mode != SGX_EMODE_ACT && ca.mode != SGX_EMODE_HSWISH) || bq.in0 == h->loc_blob || bq.in0 == h->conf_blob) ai = -1;
                 }
                 // squeeze-excite behind the project convolution: readers of its output = { squeeze conv, excite conv's gate operand }
-                int di = -1, ei = -1; EpiClass cd, ce; int out_blob = c.out, res_blob = cc.mode == SGX_EMODE_ADD_T ? cc.t1 : -1;
+                int di = -1, ei = -1; EpiClass cd = { SGX_EMODE_NONE, 0.f, 0.f, INFINITY, 1.f, -1, -1 }, ce = cd; int out_blob = c.out, res_blob = cc.mode == SGX_EMODE_ADD_T ? cc.t1 : -1;
                 if (!c.hwc && cc.mode == SGX_EMODE_NONE && c.out != h->loc_blob && c.out != h->conf_blob) {
                     readers_all(c.out, R);
                     if (R.size() == 2) {
