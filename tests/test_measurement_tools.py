@@ -51,3 +51,28 @@ def test_bench_gpus_builds_a_torchrun_command():
     # under torchrun (WORLD_SIZE present) nothing is spawned
     assert b.needs_spawn(8, {'WORLD_SIZE': '8'}) is False and b.needs_spawn(8, {}) is True and b.needs_spawn(1, {}) is False
     assert b.needs_spawn(1, {'SGX_BENCH_FORCE_SPAWN': '1'}) is True
+
+
+def test_isa_census_counts_select_runs_and_lane_reads():
+    """tools/isa_census.py: a run of v_cndmask_b32_e32 is broken by a vector / memory instruction, not by scalar instructions or s_nop (profiles/r4_ubench_snop_cost*.txt)"""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import isa_census
+    asm = """_Z3foov:
+	v_cmp_lt_u32 vcc, v0, v1
+	s_nop 1
+	v_cndmask_b32_e32 v1, v1, v2, vcc
+	s_mov_b32 s0, 0
+	v_cndmask_b32_e32 v3, v3, v2, vcc
+	v_cndmask_b32_e32 v4, v4, v2, vcc
+	v_mov_b32_e32 v5, v1
+	v_cndmask_b32_e32 v4, v4, v2, vcc
+	v_readlane_b32 s1, v9, 3
+	s_cbranch_vccnz .LBB0_1
+	s_endpgm
+_Z3barv:
+	v_cndmask_b32_e64 v1, 0, v2, s[2:3]
+	s_endpgm
+"""
+    c = isa_census.census(asm)
+    assert c['_Z3foov'] == dict(valu=7, cnd_e32=4, runs={3: 1, 1: 1}, lanes=1, s_nop=1, branches=1)
+    assert c['_Z3barv']['cnd_e32'] == 0 and c['_Z3barv']['valu'] == 1 and not c['_Z3barv']['runs']
