@@ -77,14 +77,6 @@ int sgx_orb_extract(sgx_orb *h, const uint8_t *gray, int stride, sgx_keypoint *k
 /* device-side overflow/status word of the last batched call (synchronises `stream`) */
 int sgx_orb_last_status(sgx_orb *h, void *stream);
 
-/* test/diagnostic taps (synchronous, host destination) */
-int sgx_orb_debug_level_geometry(const sgx_orb *h, int level, int32_t *w, int32_t *hgt, int32_t *stride);
-int sgx_orb_debug_set_unfused_pyramid(int on);   /* test tap: 1 = per-level k_resize launches instead of the fused pyramid kernel (must give identical bytes) */
-int sgx_orb_debug_read_level(sgx_orb *h, int frame, int level, uint8_t *dst /* w*h, tight */);
-/* candidates of (frame, level) after per-cell FAST+NMS, unordered: x,y relative to the
- * (16,16) border origin exactly as pushed at ORBextractor.cc:823-825; returns count in *n */
-int sgx_orb_debug_read_candidates(sgx_orb *h, int frame, int level, int32_t *x, int32_t *y, int32_t *score, int cap, int *n);
-
 /* ---- ORB matcher ----------------------------------------------------------------------------
  * Replaces ORB_SLAM2::ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame,
  * const float th, const bool bMono)  (src/sg-slam/include/ORBmatcher.h:56, src/sg-slam/src/ORBmatcher.cc:1332-1472),
@@ -307,11 +299,6 @@ int sgx_voc_transform_batch_dev(sgx_voc *v, const uint8_t *d_desc, size_t desc_p
  * src/sg-slam/Thirdparty/DBoW2/DBoW2/ScoringObject.cpp:23-67; callers KeyFrameDatabase.cc:133,249, LoopClosing.cc:134); SGX_ERR_UNSUPPORTED for the other scoring types */
 int sgx_voc_score(const sgx_voc *v, int n1, const int32_t *ids1, const double *w1, int n2, const int32_t *ids2, const double *w2, double *score);
 
-/* Harness helper (bench.py / tests), NOT a reference entry point: the previous-frame position of every keypoint under a per-frame affine flow
- * (prev = A * (x, y, 1), A = 6 floats), optionally displaced by shift[2] inside the frame's first box.  Stands in for cv::calcOpticalFlowPyrLK
- * (Frame.cc:445, tier N1) when the dynamic-feature mask is exercised on synthetic streams whose flow is known exactly. */
-int sgx_debug_flow_affine_batch_dev(int batch, int cap, const sgx_keypoint *d_keys, const int32_t *d_n, const float *d_A, const float *d_shift, const float *d_boxes,
-                                    int max_boxes, float *d_prev_xy, void *stream);
 /* The colour conversion at the top of Tracking::GrabImageRGBD (src/sg-slam/src/Tracking.cc:214-227): cvtColor(CV_RGB2GRAY / CV_BGR2GRAY / CV_RGBA2GRAY / CV_BGRA2GRAY) on
  * 8-bit images, OpenCV's fixed point (R*4899 + G*9617 + B*1868 + 8192) >> 14.  blue_first = !mbRGB.  Pitches in bytes, multiples of 4; pointers 4-byte aligned. */
 int sgx_frame_gray_from_color_batch_dev(int batch, int width, int height, const uint8_t *d_src, int src_pitch, int channels, int blue_first,
@@ -359,7 +346,6 @@ int sgx_pose_optimization_batch_dev(int batch, int cap, const sgx_keypoint *d_ke
                                     const int32_t *d_mp_index, const uint8_t *d_has_mp, const float *d_mp_xw, int xw_pitch,
                                     const float *inv_level_sigma2, int nlevels, const sgx_camera *cam,
                                     float *d_Tcw, uint8_t *d_outlier, int32_t *d_n_inliers, void *stream);
-int sgx_pose_opt_debug_set_threads(int threads_per_frame);   /* tuning / test tap: 0 = default (256 threads = four waves per frame), 64 = one wave per frame, 256 */
 int sgx_pose_optimization(int n, const sgx_keypoint *keys_un, const float *uright, const uint8_t *has_mp, const float *mp_xw,
                           const float *inv_level_sigma2, int nlevels, const sgx_camera *cam,
                           float *Tcw, uint8_t *outlier, int32_t *n_inliers);
@@ -393,8 +379,6 @@ int sgx_local_bundle_adjustment(const sgx_ba_problem *problem, const sgx_camera 
  * landmark, one edge per observation in a keyframe of the problem; ONE optimizer.optimize(nIterations) with Huber kernels sqrt(5.99) / sqrt(7.815) when bRobust, no
  * outlier classification.  Out: every pose (the fixed one included, :200-214) and every point that has at least one edge (:216-236; the others are
  * vbNotIncludedMP) — the caller stores them with SetPose / SetWorldPos (nLoopKF == 0) or in mTcwGBA / mPosGBA.  stats: iterations_first, chi2_first. */
-int sgx_ba_debug_last_plan(int32_t plan[4]);    /* test tap: solver plan of the last bundle adjustment of this process: { 0 dense / 1 envelope, column steps of branch A, of branch B (0 = one branch), unknowns of their separator } */
-int sgx_ba_debug_set_solver(int mode);             /* test / tuning tap: reduced-camera-system solver of the bundle adjustments: -1 default (SGX_BA_SOLVER or auto), 0 auto, 1 dense blocked Cholesky, 2 envelope solver */
 int sgx_bundle_adjustment(const sgx_ba_problem *problem, const sgx_camera *cam, int n_iterations, const volatile int32_t *stop_flag, int robust, sgx_ba_stats *stats);
 
 /* int Optimizer::OptimizeSim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches1, g2o::Sim3 &g2oS12, const float th2, const bool bFixScale)
@@ -456,25 +440,14 @@ int sgx_det_detect_batch_dev(sgx_det *h, const uint8_t *d_img, int pitch, int ba
                              float *d_boxes, int32_t *d_nboxes, int max_boxes, int32_t *d_have_dynamic, void *stream);
 /* device-resident batched forward only: leaves mbox_loc (num_priors*4) and softmax conf (num_priors*num_class) per image in HBM */
 int sgx_det_forward_batch_dev(sgx_det *h, const uint8_t *d_img, int pitch, int batch, const float **d_loc, const float **d_conf, void *stream);
-int sgx_det_debug_read_blob(sgx_det *h, const char *blob_name, int image, float *dst, int cap, int *n);
-/* test tap: DetectionOutput + detect() filtering alone on caller-supplied head outputs (host arrays: loc batch x num_priors x 4, conf batch x num_priors x num_class) */
-int sgx_det_debug_detection_output(sgx_det *h, const float *loc, const float *conf, int batch, sgx_det_result *results);
-/* test / tuning taps.  Every sgx_*_debug_set_* setting is PER CALLING THREAD (thread_local): it affects the next create / call made by the same thread only, so the taps
- * cannot leak into the Tracking, Detector2D or LocalMapping thread of a host program; the SGX_* environment switches are read once and never written.
- * set_fusion(0) makes the NEXT sgx_det_create build the unfused plan (one kernel per ncnn layer, every blob
- * materialised) — the fused plan (default) must reproduce it bit for bit.  time_ops: HIP-event time per plan step (ms[0] = pre-processing). */
-int sgx_det_debug_set_fusion(int on);
-int sgx_det_debug_set_irb(int on);                 /* the NEXT sgx_det_create: matrix-core inverted-residual block kernels (sgx_det_irb.h) 0 off, 1 on the shapes where they beat the per-layer kernels, 2 on every supported shape, -1 = default (1, or SGX_DET_IRB); bit-identical either way */
-int sgx_det_debug_set_block_fusion(int on);        /* 1: the NEXT sgx_det_create also fuses every expand -> depthwise -> project triple into one kernel (bit-identical; opt-in: slower at batch 256) */
 /* Matrix-product scheme of the detector's 1x1 convolutions (pointwise / expand / project / squeeze-excite), read by the NEXT sgx_det_create: 0 = exact fp32
  * (v_mfma_f32_32x32x2_f32, an ascending-k fmaf chain: bit-identical to the per-layer reference kernels), 1 = bf16x3 (each fp32 operand split exactly into three
  * bf16 terms, the six leading cross products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: fp32-accurate products in another summation order), -1 = the
- * default (1, or SGX_DET_GEMM=f32|bf16x3).  sgx_det_gemm_mode reports what a detector was built with. */
-int sgx_det_debug_set_gemm(int mode);
+ * default (1).  Selected per detector by the test tap sgx_det_debug_set_gemm (include/sgx_debug.h); sgx_det_gemm_mode reports what a detector was built with. */
 int sgx_det_gemm_mode(const sgx_det *h);
-int sgx_det_debug_set_legacy_kernels(int on);      /* 1: run the simple reference kernels (one thread per output / 64x64 GEMM tile) instead of the tuned ones */
-int sgx_det_debug_time_ops(sgx_det *h, const uint8_t *d_img, int pitch, int batch, int reps, float *ms, int cap, int *nops);
-int sgx_det_debug_op_desc(const sgx_det *h, int i, char *buf, int cap);
+/* one line of text per plan step i in [0, num_kernels of sgx_det_info): kind, ncnn layers, shapes, ' bf16x3' behind the steps that run on the bf16 matrix pipes (introspection for
+ * profilers and the roofline accounting of bench.py); SGX_ERR_INVALID past the last step */
+int sgx_det_plan_step(const sgx_det *h, int i, char *buf, int cap);
 /* Frame::RmDynamicPointWithSemanticAndGeometry's keep/erase predicate (src/sg-slam/src/Frame.cc:556-597, :613-652): keep[i] = 1 when the
  * epipolar distance of (keypoint i, its LK-tracked previous position) under F (3x3 row-major fp64, cv::findFundamentalMat) is below
  * 0.2 px inside a person box / 1.0 px elsewhere (an all-zero F = "no fundamental matrix": the frame keeps every keypoint).  boxes: max_boxes x (x, y, w, h) per frame.  The caller applies the
@@ -522,8 +495,6 @@ int sgx_flow_lk_batch_dev(sgx_flow *h, const uint8_t *d_gray, int pitch, int bat
                           float *d_prev_xy, uint8_t *d_status, int32_t *have_prev, void *stream);
 /* cv::calcOpticalFlowPyrLK(gray_from, gray_to, pts, next_pts, status, ...) on one host image pair (n points, 2 floats each).  Synchronous; resets the streaming state. */
 int sgx_flow_lk(sgx_flow *h, const uint8_t *gray_from, const uint8_t *gray_to, int stride, const float *pts, int n, float *next_pts, uint8_t *status);
-int sgx_flow_debug_read_level(sgx_flow *h, int slot, int frame, int level, uint8_t *img);     /* test tap: pyramid level, w*h tight */
-int sgx_flow_debug_level_size(const sgx_flow *h, int level, int32_t *w, int32_t *hgt);
 /* Frame.cc:454-472 for `batch` frames: pair selection against the PREVIOUS frame's person boxes (d_pre_have_dynamic = bPreFrameHavePotentialDynamicObj,
  * d_pre_boxes / d_pre_nboxes = vPreFramePotentialDynamicBorder in the layout sgx_det_detect_batch_dev writes; all three may be NULL) and
  * cv::findFundamentalMat(FM_RANSAC, threshold, confidence): cv::RNG(-1) sampling, 7-point solver, symmetric epipolar error, adaptive iteration count,
@@ -586,10 +557,6 @@ int sgx_tracker_snapshot_boxes_dev(sgx_tracker *t, int stream_index, float *d_bo
 int sgx_tracker_pack_records_dev(sgx_tracker *t, uint8_t *d_records, void *stream);
 int sgx_tracker_frame_dev(sgx_tracker *t, const int32_t **d_n, const sgx_keypoint **d_keys, const uint8_t **d_desc, const float **d_Tcw, const float **d_xw, const uint8_t **d_has);
 sgx_orb *sgx_tracker_extractor(sgx_tracker *t);
-
-/* run the octree-distribution kernel alone on packed candidates (x | y<<12 | score<<24, coordinates
- * relative to the (16,16) border origin) for `level`; returns the selected packed entries in list order */
-int sgx_orb_debug_run_octree(sgx_orb *h, int level, const uint32_t *packed, int n, uint32_t *out_sel, int cap, int *nsel);
 
 /* ---- per-kernel HIP-event timing (process-wide) ---------------------------------------------------
  * When enabled, every batched entry point records a hipEvent pair on the caller's stream around each

@@ -166,6 +166,50 @@ def forward(layers, W, x, dt=np.float32):
     return blobs['detection_out'], blobs
 
 
+def eval_layer(L, W, args, dt=np.float32):
+    """one layer of forward() on explicit input arrays (same arithmetic; used by forward_cut)"""
+    t, p = L['type'], L['p']
+    a = args[0]
+    if t in ('Convolution', 'ConvolutionDepthWise'):
+        w, b = W[L['name']]
+        return conv2d(a, w, b, p[0], p[1], p.get(3, 1), p.get(4, 0), p.get(7, 1), dt)
+    if t == 'BinaryOp':
+        b = args[1]; op = p.get(0, 0)
+        if b.size == 1: b = b.reshape(())
+        return (a + b if op == 0 else a * b if op == 2 else a / b).astype(dt)
+    if t == 'Clip': return np.clip(a, dt(p[0]), dt(p[1]))
+    if t == 'ReLU': return np.maximum(a, dt(0))
+    if t == 'Permute': return np.ascontiguousarray(a.transpose(1, 2, 0))
+    if t == 'Flatten': return a.reshape(-1)
+    if t == 'Concat': return np.concatenate(args, 0) if p.get(0, 0) == 0 else np.concatenate(args, 1)
+    if t == 'Reshape': return a.reshape(-1, p[0])
+    if t == 'Softmax':
+        e = np.exp(a - a.max(1, keepdims=True)).astype(dt); return (e / e.sum(1, keepdims=True)).astype(dt)
+    raise NotImplementedError(t)
+
+
+def forward_cut(layers, W, given, shapes, targets, dt=np.float64):
+    """Per-step isolation (VERDICT r4 next #1c): every blob in `targets` is evaluated in `dt` from the NEAREST blobs of `given` upstream of it (given[target] itself is not
+    used for that target), i.e. exactly the layers one plan step of the device fuses, fed with the device's own step inputs.  given: name -> flat array (device blobs, plus
+    'input' from preprocess()); shapes: name -> shape (from one forward() run).  Returns name -> array."""
+    producer = {o: L for L in layers for o in L['outs']}
+    cache = {}
+
+    def value(name, root):
+        if not root:
+            if name in given: return np.asarray(given[name], dt).reshape(shapes[name])
+            if name in cache: return cache[name]
+        L = producer[name]
+        if L['type'] == 'MemoryData': v = W[L['name']].astype(dt)
+        elif L['type'] == 'Split': v = value(L['ins'][0], False)
+        elif L['type'] == 'Input': raise KeyError('the network input must be given')
+        else: v = eval_layer(L, W, [value(i, False) for i in L['ins']], dt)
+        if not root and name not in given: cache[name] = v
+        return v
+
+    return {t: value(t, True) for t in targets}
+
+
 def detect(layers, W, img_u8, det_th=0.90, dyn_th=0.01):
     """Detector2D::detect: returns (objects [(id, prob, x, y, w, h)], person boxes for mapping, person boxes for the dynamic-feature mask)."""
     img_h, img_w = img_u8.shape[:2]

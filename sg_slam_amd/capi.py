@@ -61,24 +61,33 @@ class OrbConfig(C.Structure):
 
 # every symbol include/sgx.h declares (tests/test_abi.py checks the export table against this list)
 SYMBOLS = [
-    'sgx_version', 'sgx_status_string',
-    'sgx_orb_create', 'sgx_orb_destroy', 'sgx_orb_keypoint_capacity', 'sgx_orb_get_tables',
-    'sgx_orb_extract_batch_dev', 'sgx_orb_extract', 'sgx_orb_last_status',
+    'sgx_version', 'sgx_status_string', 'sgx_orb_create', 'sgx_orb_destroy', 'sgx_orb_keypoint_capacity', 'sgx_orb_get_tables',
+    'sgx_orb_extract_batch_dev', 'sgx_orb_extract', 'sgx_orb_last_status', 'sgx_profile_enable', 'sgx_profile_num_classes', 'sgx_profile_class_name',
+    'sgx_profile_read', 'sgx_match_project_frame_batch_dev', 'sgx_match_project_frame', 'sgx_match_project_local_batch_dev',
+    'sgx_match_project_local', 'sgx_frame_stereo_from_rgbd_batch_dev', 'sgx_frame_unproject_batch_dev', 'sgx_frame_make_map_points_batch_dev',
+    'sgx_frame_merge_matches_batch_dev', 'sgx_pose_optimization_batch_dev', 'sgx_pose_optimization', 'sgx_frame_motion_model_batch_dev',
+    'sgx_local_bundle_adjustment', 'sgx_bundle_adjustment', 'sgx_det_create', 'sgx_det_destroy', 'sgx_det_info', 'sgx_det_detect',
+    'sgx_det_detect_batch_dev', 'sgx_det_forward_batch_dev', 'sgx_frame_compact_keys_batch_dev', 'sgx_frame_gray_from_color_batch_dev',
+    'sgx_det_gemm_mode', 'sgx_det_plan_step', 'sgx_dynamic_mask_batch_dev', 'sgx_tracker_create', 'sgx_tracker_destroy',
+    'sgx_tracker_keypoint_capacity', 'sgx_tracker_record_bytes', 'sgx_tracker_set_initial_pose', 'sgx_tracker_step_dev', 'sgx_tracker_host_buffers',
+    'sgx_tracker_step_host', 'sgx_tracker_wait_inputs', 'sgx_tracker_sync', 'sgx_tracker_read', 'sgx_tracker_snapshot_pose_dev',
+    'sgx_tracker_snapshot_boxes_dev', 'sgx_tracker_pack_records_dev', 'sgx_tracker_frame_dev', 'sgx_tracker_extractor', 'sgx_flow_create',
+    'sgx_flow_destroy', 'sgx_flow_reset', 'sgx_flow_levels', 'sgx_flow_lk_batch_dev', 'sgx_flow_lk', 'sgx_fundamental_ransac_batch_dev',
+    'sgx_find_fundamental_mat', 'sgx_hamming_matrix', 'sgx_hamming_matrix_dev', 'sgx_match_search_for_triangulation', 'sgx_match_search_by_bow',
+    'sgx_match_search_by_bow_kf', 'sgx_match_fuse_search', 'sgx_match_project_keyframe', 'sgx_match_fuse_search_sim3',
+    'sgx_triangulate_new_map_points', 'sgx_mappoint_update_normal_and_depth', 'sgx_mappoint_distinctive_descriptors', 'sgx_sim3_solver_create',
+    'sgx_sim3_solver_set_ransac_parameters', 'sgx_sim3_solver_iterate', 'sgx_sim3_solver_get_estimate', 'sgx_sim3_solver_destroy',
+    'sgx_match_search_for_initialization', 'sgx_voc_load', 'sgx_voc_create', 'sgx_voc_info', 'sgx_voc_destroy', 'sgx_voc_transform',
+    'sgx_voc_transform_batch_dev', 'sgx_voc_score', 'sgx_match_project_sim3', 'sgx_match_search_by_sim3', 'sgx_optimize_sim3',
+    'sgx_optimize_essential_graph', 'sgx_correct_map_points',
+]
+# the test / tuning taps include/sgx_debug.h declares: exported by tests/taps/libsgx_taps.so and the emulator (-DSGX_DEBUG_TAPS) only, never by the product library
+TAP_SYMBOLS = [
     'sgx_orb_debug_level_geometry', 'sgx_orb_debug_set_unfused_pyramid', 'sgx_orb_debug_read_level', 'sgx_orb_debug_read_candidates',
-    'sgx_orb_debug_run_octree', 'sgx_profile_enable', 'sgx_profile_num_classes', 'sgx_profile_class_name', 'sgx_profile_read',
-    'sgx_match_project_frame_batch_dev', 'sgx_match_project_frame', 'sgx_match_project_local_batch_dev', 'sgx_match_project_local',
-    'sgx_frame_stereo_from_rgbd_batch_dev', 'sgx_frame_unproject_batch_dev', 'sgx_frame_make_map_points_batch_dev', 'sgx_frame_merge_matches_batch_dev',
-    'sgx_pose_optimization_batch_dev', 'sgx_pose_opt_debug_set_threads', 'sgx_pose_optimization', 'sgx_frame_motion_model_batch_dev',
-    'sgx_local_bundle_adjustment', 'sgx_bundle_adjustment', 'sgx_ba_debug_set_solver', 'sgx_ba_debug_last_plan',
-    'sgx_det_create', 'sgx_det_destroy', 'sgx_det_info', 'sgx_det_detect', 'sgx_det_detect_batch_dev', 'sgx_det_forward_batch_dev', 'sgx_det_debug_read_blob', 'sgx_det_debug_detection_output',
-    'sgx_frame_compact_keys_batch_dev', 'sgx_frame_gray_from_color_batch_dev', 'sgx_debug_flow_affine_batch_dev', 'sgx_det_debug_set_fusion', 'sgx_det_debug_set_legacy_kernels', 'sgx_det_debug_set_block_fusion', 'sgx_det_debug_set_irb', 'sgx_det_debug_set_gemm', 'sgx_det_gemm_mode', 'sgx_det_debug_time_ops', 'sgx_det_debug_op_desc',
-    'sgx_dynamic_mask_batch_dev',
-    'sgx_tracker_create', 'sgx_tracker_destroy', 'sgx_tracker_keypoint_capacity', 'sgx_tracker_record_bytes', 'sgx_tracker_set_initial_pose', 'sgx_tracker_step_dev',
-    'sgx_tracker_host_buffers', 'sgx_tracker_step_host', 'sgx_tracker_wait_inputs', 'sgx_tracker_sync', 'sgx_tracker_read', 'sgx_tracker_snapshot_pose_dev', 'sgx_tracker_snapshot_boxes_dev',
-    'sgx_tracker_pack_records_dev', 'sgx_tracker_frame_dev', 'sgx_tracker_extractor',
-    'sgx_flow_create', 'sgx_flow_destroy', 'sgx_flow_reset', 'sgx_flow_levels', 'sgx_flow_lk_batch_dev', 'sgx_flow_lk', 'sgx_flow_debug_read_level', 'sgx_flow_debug_level_size',
-    'sgx_fundamental_ransac_batch_dev', 'sgx_find_fundamental_mat',
-    'sgx_hamming_matrix', 'sgx_hamming_matrix_dev', 'sgx_match_search_for_triangulation', 'sgx_match_search_by_bow', 'sgx_match_search_by_bow_kf', 'sgx_match_fuse_search', 'sgx_match_project_keyframe', 'sgx_match_fuse_search_sim3', 'sgx_triangulate_new_map_points', 'sgx_mappoint_update_normal_and_depth', 'sgx_mappoint_distinctive_descriptors', 'sgx_sim3_solver_create', 'sgx_sim3_solver_set_ransac_parameters', 'sgx_sim3_solver_iterate', 'sgx_sim3_solver_get_estimate', 'sgx_sim3_solver_destroy', 'sgx_match_search_for_initialization', 'sgx_voc_load', 'sgx_voc_create', 'sgx_voc_info', 'sgx_voc_destroy', 'sgx_voc_transform', 'sgx_voc_transform_batch_dev', 'sgx_voc_score', 'sgx_match_project_sim3', 'sgx_match_search_by_sim3', 'sgx_optimize_sim3', 'sgx_optimize_essential_graph', 'sgx_correct_map_points',
+    'sgx_orb_debug_run_octree', 'sgx_pose_opt_debug_set_threads', 'sgx_ba_debug_set_solver', 'sgx_ba_debug_last_plan', 'sgx_det_debug_read_blob',
+    'sgx_det_debug_detection_output', 'sgx_debug_flow_affine_batch_dev', 'sgx_det_debug_set_fusion', 'sgx_det_debug_set_legacy_kernels',
+    'sgx_det_debug_set_block_fusion', 'sgx_det_debug_set_irb', 'sgx_det_debug_set_gemm', 'sgx_det_debug_time_ops', 'sgx_flow_debug_read_level',
+    'sgx_flow_debug_level_size',
 ]
 
 
@@ -110,12 +119,7 @@ class SgxLib:
                                                 C.c_void_p, C.c_int, C.c_void_p]
         d.sgx_orb_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         d.sgx_orb_last_status.argtypes = [C.c_void_p, C.c_void_p]
-        d.sgx_orb_debug_level_geometry.argtypes = [C.c_void_p, C.c_int] + [C.POINTER(C.c_int32)] * 3
-        d.sgx_orb_debug_read_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
-        d.sgx_orb_debug_read_candidates.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                                    C.c_int, C.POINTER(C.c_int)]
 
-        d.sgx_orb_debug_run_octree.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         d.sgx_profile_enable.argtypes = [C.c_int]
         d.sgx_profile_class_name.restype = C.c_char_p
         d.sgx_profile_class_name.argtypes = [C.c_int]
@@ -130,22 +134,13 @@ class SgxLib:
         d.sgx_pose_optimization.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.c_int, C.POINTER(Camera), vp, vp, vp]
         d.sgx_frame_motion_model_batch_dev.argtypes = [C.c_int, vp, vp, vp, vp, vp]
         d.sgx_local_bundle_adjustment.argtypes = [C.POINTER(BaProblem), C.POINTER(Camera), vp, vp, C.POINTER(BaStats)]
-        d.sgx_ba_debug_set_solver.argtypes = [C.c_int]
-        d.sgx_ba_debug_last_plan.argtypes = [C.c_void_p]
         d.sgx_bundle_adjustment.argtypes = [C.POINTER(BaProblem), C.POINTER(Camera), C.c_int, vp, C.c_int, C.POINTER(BaStats)]
         d.sgx_det_create.argtypes = [C.c_char_p, vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.POINTER(vp)]
         d.sgx_det_destroy.argtypes = [vp]; d.sgx_det_destroy.restype = None
         d.sgx_det_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
         d.sgx_det_detect.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(DetResult)]
-        d.sgx_det_debug_detection_output.argtypes = [vp, vp, vp, C.c_int, C.POINTER(DetResult)]
         d.sgx_det_detect_batch_dev.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp]
         d.sgx_det_forward_batch_dev.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp), vp]
-        d.sgx_det_debug_read_blob.argtypes = [vp, C.c_char_p, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
-        d.sgx_det_debug_set_fusion.argtypes = [C.c_int]
-        d.sgx_det_debug_set_legacy_kernels.argtypes = [C.c_int]
-        d.sgx_det_debug_set_block_fusion.argtypes = [C.c_int]
-        d.sgx_det_debug_set_irb.argtypes = [C.c_int]
-        d.sgx_det_debug_set_gemm.argtypes = [C.c_int]
         d.sgx_det_gemm_mode.argtypes = [vp]
         d.sgx_tracker_create.argtypes = [C.POINTER(TrackerConfig), vp, C.POINTER(vp)]
         d.sgx_tracker_destroy.argtypes = [vp]; d.sgx_tracker_destroy.restype = None
@@ -163,11 +158,9 @@ class SgxLib:
         d.sgx_tracker_pack_records_dev.argtypes = [vp, vp, vp]
         d.sgx_tracker_frame_dev.argtypes = [vp] + [C.POINTER(vp)] * 6
         d.sgx_tracker_extractor.argtypes = [vp]; d.sgx_tracker_extractor.restype = vp
-        d.sgx_det_debug_time_ops.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
-        d.sgx_det_debug_op_desc.argtypes = [vp, C.c_int, C.c_char_p, C.c_int]
+        d.sgx_det_plan_step.argtypes = [vp, C.c_int, C.c_char_p, C.c_int]
         d.sgx_dynamic_mask_batch_dev.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp]
         d.sgx_frame_gray_from_color_batch_dev.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]
-        d.sgx_debug_flow_affine_batch_dev.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, vp]
         d.sgx_frame_compact_keys_batch_dev.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]
         d.sgx_match_project_local.argtypes = [C.c_int] + [vp] * 5 + [C.c_int] + [vp] * 7 + [C.POINTER(Camera), vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp, vp]
         d.sgx_match_project_local_batch_dev.argtypes = [C.c_int, C.c_int] + [vp] * 6 + [C.c_int] + [vp] * 8 + [C.POINTER(Camera), vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp, vp, vp]
@@ -179,8 +172,6 @@ class SgxLib:
         d.sgx_flow_levels.argtypes = [vp]
         d.sgx_flow_lk_batch_dev.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, C.POINTER(C.c_int32), vp]
         d.sgx_flow_lk.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, vp, vp]
-        d.sgx_flow_debug_read_level.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
-        d.sgx_flow_debug_level_size.argtypes = [vp, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         d.sgx_fundamental_ransac_batch_dev.argtypes = [C.c_int, C.c_int] + [vp] * 6 + [C.c_int, C.c_double, C.c_double, vp, vp, vp, vp]
         d.sgx_find_fundamental_mat.argtypes = [vp, vp, C.c_int, C.c_double, C.c_double, vp, vp, vp]
         d.sgx_hamming_matrix.argtypes = [vp, C.c_int, vp, C.c_int, vp]
@@ -212,6 +203,32 @@ class SgxLib:
         d.sgx_match_fuse_search.argtypes = [C.c_int] + [vp] * 4 + [C.c_int] + [vp] * 6 + [C.POINTER(Camera), vp, vp, C.c_int, C.c_float, C.c_float, vp, vp, vp]
         d.sgx_hamming_matrix_dev.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
         d.sgx_match_search_for_triangulation.argtypes = [C.c_int] + [vp] * 6 + [C.c_int] + [vp] * 6 + [vp, C.POINTER(Camera), vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
+
+        # test / tuning taps (include/sgx_debug.h): present in tests/taps/libsgx_taps.so and the emulator only
+        self.has_taps = hasattr(d, 'sgx_det_debug_read_blob')
+        if self.has_taps:
+            d.sgx_orb_debug_level_geometry.argtypes = [C.c_void_p, C.c_int] + [C.POINTER(C.c_int32)] * 3
+            d.sgx_orb_debug_read_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+            d.sgx_orb_debug_read_candidates.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+            d.sgx_orb_debug_run_octree.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+            d.sgx_orb_debug_set_unfused_pyramid.argtypes = [C.c_int]
+            d.sgx_pose_opt_debug_set_threads.argtypes = [C.c_int]
+            d.sgx_ba_debug_set_solver.argtypes = [C.c_int]
+            d.sgx_ba_debug_last_plan.argtypes = [C.c_void_p]
+            d.sgx_det_debug_detection_output.argtypes = [vp, vp, vp, C.c_int, C.POINTER(DetResult)]
+            d.sgx_det_debug_read_blob.argtypes = [vp, C.c_char_p, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
+            for nm in ('fusion', 'legacy_kernels', 'block_fusion', 'irb', 'gemm'):
+                getattr(d, 'sgx_det_debug_set_' + nm).argtypes = [C.c_int]
+            d.sgx_det_debug_time_ops.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
+            d.sgx_debug_flow_affine_batch_dev.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, vp]
+            d.sgx_flow_debug_read_level.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
+            d.sgx_flow_debug_level_size.argtypes = [vp, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+
+    def tap(self, name):
+        """a test / tuning tap entry (include/sgx_debug.h); the product library has none"""
+        if not self.has_taps:
+            raise SgxError(f'{name}: {self.path} is the product build and has no test taps; use tests/taps/libsgx_taps.so (make -C sg_slam_amd/csrc taps)')
+        return getattr(self.dll, name)
 
     def version(self):
         return self.dll.sgx_version().decode()

@@ -13,6 +13,9 @@
 #include "sgx_eg_kernels.h"
 #include "sgx_prof.h"
 #include "../../include/sgx.h"
+#ifdef SGX_DEBUG_TAPS
+#include "../../include/sgx_debug.h"      // test / tuning taps: compiled into tests/taps/libsgx_taps.so and the emulator only
+#endif
 #include <float.h>
 #include <math.h>
 #include <stdio.h>
@@ -192,7 +195,7 @@ static int chol_factor_solve(const Chol &C, const double **xout)
     *xout = C.xp;
     if (C.env_rstart && C.NP > 0) {                      // sparse covisibility: the whole factorisation + forward substitution as one persistent workgroup, then the backward pass
         const int nt = (C.NP + SGX_NB - 1) / SGX_NB;
-        static const int env_dbg = getenv("SGX_ENV_DBG") ? atoi(getenv("SGX_ENV_DBG")) : 0;      // timing tap: 1 skip the diagonal tiles, 2 skip panel + update, 4 skip the update
+        static const int env_dbg = sgx_getenv("SGX_ENV_DBG") ? atoi(sgx_getenv("SGX_ENV_DBG")) : 0;      // timing tap: 1 skip the diagonal tiles, 2 skip panel + update, 4 skip the update
         const int nA = C.env_nB > 0 ? C.env_nA : nt, nB = C.env_nB > 0 ? C.env_nB : 0;
         if (nB > 0) {                                    // the second branch's separator contributions start from zero
             const size_t ns = (size_t)(C.NP - (nA + nB) * SGX_NB);
@@ -208,23 +211,23 @@ static int chol_factor_solve(const Chol &C, const double **xout)
         return SGX_OK;
     }
     // workgroup sizes of the single-workgroup solver kernels (env = tuning taps): their phases are short, so fewer waves mean cheaper barriers
-    static const int t_small = getenv("SGX_TUNE_CHOL_SMALL_THREADS") ? atoi(getenv("SGX_TUNE_CHOL_SMALL_THREADS")) : 256;
-    static const int t_diag = getenv("SGX_TUNE_CHOL_DIAG_THREADS") ? atoi(getenv("SGX_TUNE_CHOL_DIAG_THREADS")) : 256;
-    static const int t_solve = getenv("SGX_TUNE_CHOL_SOLVE_THREADS") ? atoi(getenv("SGX_TUNE_CHOL_SOLVE_THREADS")) : 256;
+    static const int t_small = sgx_getenv("SGX_TUNE_CHOL_SMALL_THREADS") ? atoi(sgx_getenv("SGX_TUNE_CHOL_SMALL_THREADS")) : 256;
+    static const int t_diag = sgx_getenv("SGX_TUNE_CHOL_DIAG_THREADS") ? atoi(sgx_getenv("SGX_TUNE_CHOL_DIAG_THREADS")) : 256;
+    static const int t_solve = sgx_getenv("SGX_TUNE_CHOL_SOLVE_THREADS") ? atoi(sgx_getenv("SGX_TUNE_CHOL_SOLVE_THREADS")) : 256;
     if (C.NP > 0 && C.NP <= SGX_CHOL_SMALL) {
-        static const int small_lds = getenv("SGX_TUNE_CHOL_SMALL_LDS") ? atoi(getenv("SGX_TUNE_CHOL_SMALL_LDS")) : 0;     // 1 = the LDS-resident version (comparison tap)
+        static const int small_lds = sgx_getenv("SGX_TUNE_CHOL_SMALL_LDS") ? atoi(sgx_getenv("SGX_TUNE_CHOL_SMALL_LDS")) : 0;     // 1 = the LDS-resident version (comparison tap)
         if (small_lds) SGX_LAUNCH(k_chol_small, dim3(1), dim3(t_small), (sgx_stream_t)0, C.NP, C.S, C.bp, C.coef, C.xp, C.ok);
         else SGX_LAUNCH(k_chol_small_reg, dim3(1), dim3(256), (sgx_stream_t)0, C.NP, C.S, C.bp, C.coef, C.xp, C.ok);
     } else if (C.NP > 0) {                                   // blocked Cholesky of the reduced camera system
         const int nt = (C.NP + SGX_NB - 1) / SGX_NB;
         // tiles per outer panel; small systems keep one level (a rank-256 launch on the critical path costs them more than its eight rank-32 shares)
-        static const int wide_min = getenv("SGX_TUNE_CHOL_WIDE_MIN") ? atoi(getenv("SGX_TUNE_CHOL_WIDE_MIN")) : 1024;
+        static const int wide_min = sgx_getenv("SGX_TUNE_CHOL_WIDE_MIN") ? atoi(sgx_getenv("SGX_TUNE_CHOL_WIDE_MIN")) : 1024;
         const int OT = C.NP > wide_min ? SGX_OB / SGX_NB : (1 << 24);
         for (int kb = 0; kb < nt; kb++) {
             const int k0 = kb * SGX_NB, rem = nt - kb - 1;
             const int in_panel = OT - 1 - kb % OT;           // column tiles right of this one that still belong to the outer panel
 #ifndef SGX_EMU
-            static const int diag_lds = getenv("SGX_TUNE_CHOL_DIAG_LDS") ? atoi(getenv("SGX_TUNE_CHOL_DIAG_LDS")) : 0;      // 1 = the workgroup / LDS version (comparison tap)
+            static const int diag_lds = sgx_getenv("SGX_TUNE_CHOL_DIAG_LDS") ? atoi(sgx_getenv("SGX_TUNE_CHOL_DIAG_LDS")) : 0;      // 1 = the workgroup / LDS version (comparison tap)
             if (!diag_lds) SGX_LAUNCH(k_chol_diag_wave, dim3(1), dim3(64), (sgx_stream_t)0, C.NP, k0, C.S, C.Linv, C.ok, C.bp, C.coef, C.xp);
             else
 #endif
@@ -240,7 +243,7 @@ static int chol_factor_solve(const Chol &C, const double **xout)
                 }
             }
         }
-        static const int back_min = getenv("SGX_TUNE_CHOL_BACK_MIN") ? atoi(getenv("SGX_TUNE_CHOL_BACK_MIN")) : 0;     // measured: the per-block launches win at every blocked size (360 unknowns: 9.9 -> 9.5 ms per LocalBA, 12 000: 2.5 -> 1.1 s)
+        static const int back_min = sgx_getenv("SGX_TUNE_CHOL_BACK_MIN") ? atoi(sgx_getenv("SGX_TUNE_CHOL_BACK_MIN")) : 0;     // measured: the per-block launches win at every blocked size (360 unknowns: 9.9 -> 9.5 ms per LocalBA, 12 000: 2.5 -> 1.1 s)
         if (C.NP < back_min) {
             SGX_LAUNCH(k_chol_solve, dim3(1), dim3(t_solve), (sgx_stream_t)0, C.NP, C.S, C.Linv, C.bp, C.coef, C.xp, C.ok);
         } else {                                            // one launch per diagonal block, all CUs on the row panel (k_chol_back_step)
@@ -329,8 +332,8 @@ static int optimize(BA &B, int iterations, int *iters_done, double *final_chi)
 }  // namespace
 
 static thread_local int g_ba_last_plan[4] = { 0, 0, 0, 0 };
-extern "C" int sgx_ba_debug_last_plan(int32_t plan[4]) { if (!plan) return SGX_ERR_INVALID; for (int i = 0; i < 4; i++) plan[i] = g_ba_last_plan[i]; return SGX_OK; }
-extern "C" int sgx_ba_debug_set_solver(int mode) { g_ba_solver = mode < 0 ? -1 : (mode > 2 ? 2 : mode); return SGX_OK; }
+SGX_TAP int sgx_ba_debug_last_plan(int32_t plan[4]) { if (!plan) return SGX_ERR_INVALID; for (int i = 0; i < 4; i++) plan[i] = g_ba_last_plan[i]; return SGX_OK; }
+SGX_TAP int sgx_ba_debug_set_solver(int mode) { g_ba_solver = mode < 0 ? -1 : (mode > 2 ? 2 : mode); return SGX_OK; }
 
 // mode 0: Optimizer::LocalBundleAdjustment (Optimizer.cc:453-778); mode 1: Optimizer::BundleAdjustment (Optimizer.cc:49-237): one optimize(n_iterations) over
 // all edges, Huber deltas sqrt(5.99) / sqrt(7.815) only when `robust`, no classification, every pose rewritten
@@ -341,7 +344,7 @@ static int ba_run(const sgx_ba_problem *P, const sgx_camera *cam, const volatile
     // the device arena is one per process: calls from several threads (the reference has one LocalMapping thread, plus GlobalBundleAdjustment from LoopClosing) take turns
     static std::mutex arena_mutex;
     std::lock_guard<std::mutex> arena_lock(arena_mutex);
-    static const bool timing = getenv("SGX_BA_TIMING") != nullptr;          // tuning tap: wall-clock of the host phases on stderr
+    static const bool timing = sgx_getenv("SGX_BA_TIMING") != nullptr;          // tuning tap: wall-clock of the host phases on stderr
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tmark = now();
     auto lap = [&](const char *what) { if (timing) { (void)hipDeviceSynchronize(); const double t = now(); fprintf(stderr, "[sgx_ba] %-22s %8.3f ms\n", what, t - tmark); tmark = t; } };
@@ -385,7 +388,7 @@ static int ba_run(const sgx_ba_problem *P, const sgx_camera *cam, const volatile
     std::vector<int> env_rstart, env_rows;
     int env_nA = 0, env_nB = 0; size_t env_nsep = 0;
     {
-        static const char *solver_env = getenv("SGX_BA_SOLVER");
+        static const char *solver_env = sgx_getenv("SGX_BA_SOLVER");
         const int mode_env = !solver_env ? 0 : (strcmp(solver_env, "dense") == 0 ? 1 : (strcmp(solver_env, "env") == 0 ? 2 : 0));
         const int smode = g_ba_solver >= 0 ? g_ba_solver : mode_env;
         const bool want_env = smode != 1, force_env = smode == 2;
@@ -434,7 +437,7 @@ static int ba_run(const sgx_ba_problem *P, const sgx_camera *cam, const volatile
             // Two-branch ordering: [poses 0 .. a) ascending][poses t0-1 .. bs DEScending][separator: the rest, natural order]: the band is eliminated from both ends at once.
             // The separator must cut every coupling between the halves (no pose of [bs, t0) shares a landmark with a pose < a): it is the stretch [a, bs) behind the first
             // half plus — when the trajectory closes on itself — the tail [t0, nf) that sees the start again.  Branch sizes are multiples of 16 poses = 3 tiles.
-            const int twist_env = getenv("SGX_BA_TWIST") ? atoi(getenv("SGX_BA_TWIST")) : 1;          // read per call (tests switch it)
+            const int twist_env = sgx_getenv("SGX_BA_TWIST") ? atoi(sgx_getenv("SGX_BA_TWIST")) : 1;          // read per call (tests switch it)
             bool done = false;
             if (twist_env && nt >= 24) {
                 const int a = (B.nf / 2 / 16) * 16;

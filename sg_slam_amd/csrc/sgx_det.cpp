@@ -7,6 +7,9 @@
 #include "sgx_det_bf16.h"
 #include "sgx_prof.h"
 #include "../../include/sgx.h"
+#ifdef SGX_DEBUG_TAPS
+#include "../../include/sgx_debug.h"      // test / tuning taps: compiled into tests/taps/libsgx_taps.so and the emulator only
+#endif
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -44,6 +47,10 @@ struct Op {
 };
 }  // namespace
 
+#ifndef SGX_DET_FORK_LANES
+#define SGX_DET_FORK_LANES 1      // capture lanes of the plan's hipGraph (capture_forked): 1 = a chain
+#endif
+
 struct sgx_det {
     int T = 300, max_batch = 1, W = 0, H = 0, legacy = 0;
     int gemm = 0;                       // matrix products of the pointwise convolutions: 0 exact fp32 (v_mfma_f32_32x32x2_f32: an ascending-k fmaf chain), 1 bf16x3 (sgx_det_bf16.h)
@@ -62,10 +69,14 @@ struct sgx_det {
     double gmac = 0;
 #ifndef SGX_EMU
     std::map<int, hipGraphExec_t> graphs;     // captured plan per batch size (launch-bound tail of ~100 small kernels -> one graph launch)
+    std::vector<hipStream_t> fork_streams;    // side lanes of the forked capture (capture_forked): they only exist to give the graph its parallel branches
+    std::vector<hipEvent_t> fork_events;
 #endif
     ~sgx_det() {
 #ifndef SGX_EMU
         for (auto &g : graphs) (void)hipGraphExecDestroy(g.second);
+        for (hipEvent_t e : fork_events) (void)hipEventDestroy(e);
+        for (hipStream_t q : fork_streams) (void)hipStreamDestroy(q);
 #endif
         for (void *p : dev) (void)hipFree(p);
     }
@@ -75,12 +86,12 @@ struct sgx_det {
 static thread_local int g_det_fuse = 1;
 static thread_local int g_det_block_fusion = 0;       // test / tuning tap (read at sgx_det_create): fuse expand -> depthwise -> project triples into k_fused_block
 static thread_local int g_det_legacy = 0;             // test tap (read at sgx_det_create): run the simple reference kernels (k_conv_pw / k_conv_kxk) instead of the tuned ones
-extern "C" int sgx_det_debug_set_fusion(int on) { g_det_fuse = on ? 1 : 0; return SGX_OK; }
-extern "C" int sgx_det_debug_set_legacy_kernels(int on) { g_det_legacy = on ? 1 : 0; return SGX_OK; }
-extern "C" int sgx_det_debug_set_block_fusion(int on) { g_det_block_fusion = on ? 1 : 0; return SGX_OK; }
+SGX_TAP int sgx_det_debug_set_fusion(int on) { g_det_fuse = on ? 1 : 0; return SGX_OK; }
+SGX_TAP int sgx_det_debug_set_legacy_kernels(int on) { g_det_legacy = on ? 1 : 0; return SGX_OK; }
+SGX_TAP int sgx_det_debug_set_block_fusion(int on) { g_det_block_fusion = on ? 1 : 0; return SGX_OK; }
 static thread_local int g_det_irb = -1;               // test / tuning tap: inverted-residual blocks and SSD heads as one matrix-core kernel each (sgx_det_irb.h): 0 off, 1 the shapes where it beats
                                          // the per-layer kernels on MI355X (default), 2 every shape it supports (tests); -1 = SGX_DET_IRB or the default
-extern "C" int sgx_det_debug_set_irb(int on) { g_det_irb = on < 0 ? -1 : (on > 2 ? 2 : on); return SGX_OK; }
+SGX_TAP int sgx_det_debug_set_irb(int on) { g_det_irb = on < 0 ? -1 : (on > 2 ? 2 : on); return SGX_OK; }
 // Matrix-product scheme of the pointwise / expand / project / squeeze-excite convolutions (read at sgx_det_create): 0 = exact fp32 on v_mfma_f32_32x32x2_f32 (bit-identical to the
 // per-layer reference kernels and to the emulator: the anchor of the plan-equality tests), 1 = bf16x3 on v_mfma_f32_32x32x16_bf16 (fp32-accurate products, fp32 accumulation,
 // another summation order; sgx_det_bf16.h), -1 = SGX_DET_GEMM (f32 | bf16x3) or the default.  The emulator build always runs 0.
@@ -88,14 +99,14 @@ static thread_local int g_det_gemm = -1;
 #ifndef SGX_DET_GEMM_DEFAULT
 #define SGX_DET_GEMM_DEFAULT 1
 #endif
-extern "C" int sgx_det_debug_set_gemm(int mode) { g_det_gemm = mode < 0 ? -1 : (mode ? 1 : 0); return SGX_OK; }
+SGX_TAP int sgx_det_debug_set_gemm(int mode) { g_det_gemm = mode < 0 ? -1 : (mode ? 1 : 0); return SGX_OK; }
 extern "C" int sgx_det_gemm_mode(const sgx_det *h) { return h ? h->gemm : -1; }
 static int det_gemm_mode()
 {
     // the emulator build defaults to the exact-fp32 plan (its kernels ARE the ascending-k fmaf chains); asked for bf16x3 it runs the pointwise layers through a software model of
     // k_conv_pw3 (sgx_pw3_emu below) so that the planner's bf16x3 branch — split weights, their layout and padding, the k >= 64 rule — is covered by the CPU tier
     if (g_det_gemm >= 0) return g_det_gemm;
-    const char *e = getenv("SGX_DET_GEMM");
+    const char *e = sgx_getenv("SGX_DET_GEMM");
     if (e && *e) return (!strcmp(e, "f32") || !strcmp(e, "0")) ? 0 : 1;
 #ifdef SGX_EMU
     return 0;
@@ -118,7 +129,7 @@ static Stem2Geom stem2_geom(const Op &op)
 static bool stem2_epi_ok(const sgx_det *h, const Op &op);
 static bool stem2_ok(const sgx_det *h, const Op &op)
 {
-    static const int dw2_on = getenv("SGX_DW2") ? atoi(getenv("SGX_DW2")) : 1;
+    static const int dw2_on = sgx_getenv("SGX_DW2") ? atoi(sgx_getenv("SGX_DW2")) : 1;
     if (op.kind != OP_KXK || !dw2_on || h->legacy || op.depthwise || !op.wtT || op.outc > 16 || op.inc != 3 || op.k != 3 || op.stride != 2) return false;
     const Stem2Geom g = stem2_geom(op);
     return 3 * 5 * g.pitch4 * 4 <= 65536 && g.pitch4 < 4096 && stem2_epi_ok(h, op);
@@ -372,9 +383,9 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
         // sgx_det_debug_set_block_fusion): bit-identical, but measured SLOWER than the three tuned kernels on MI355X at batch 256 (13.7 vs 10.9 ms per forward: 30-60 k small
         // workgroups, each re-staging its weights and running five barrier-separated phases at 3 waves per SIMD) — see DESIGN.md §6.
         // k_fused_block2 (VALU-only, thread per pixel) takes the high-resolution few-channel blocks by default (SGX_DET_BLOCK2=0 turns it off); faster than the three kernels there.
-        static const int fb2_env = getenv("SGX_DET_BLOCK2") ? atoi(getenv("SGX_DET_BLOCK2")) : 1;
+        static const int fb2_env = sgx_getenv("SGX_DET_BLOCK2") ? atoi(sgx_getenv("SGX_DET_BLOCK2")) : 1;
         const bool fb2_on = fb2_env != 0 && !g_det_legacy && g_det_fuse;
-        const bool fb1_on = (g_det_block_fusion || getenv("SGX_DET_BLOCK_FUSION")) && !g_det_legacy;
+        const bool fb1_on = (g_det_block_fusion || sgx_getenv("SGX_DET_BLOCK_FUSION")) && !g_det_legacy;
         if (fb1_on || fb2_on) {
             auto act_only = [&](const Op &o, float *lo, float *hi) -> bool {
                 if (o.epi.size() != 1) return false;
@@ -442,7 +453,7 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                 fb.NPI = ((fb.TIH * fb.TIW + 31) / 32) * 32; fb.NPO = ((bth * btw + 31) / 32) * 32; fb.CMR = std::min(32, fb.Cmid); fb.ES = fb.NPI + 4;
                 { auto magic = [](int d) -> unsigned { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
                   fb.m_tiw = magic(fb.TIW); fb.m_tow = magic(btw); fb.m_npo = magic(bth * btw); fb.m_kk = magic(fb.K * fb.K); }
-                fb.tiles_x = (fb.Wo + btw - 1) / btw; fb.tiles_y = (fb.Ho + bth - 1) / bth; fb.dbg = getenv("SGX_FB_DBG") ? atoi(getenv("SGX_FB_DBG")) : 0;
+                fb.tiles_x = (fb.Wo + btw - 1) / btw; fb.tiles_y = (fb.Ho + bth - 1) / bth; fb.dbg = sgx_getenv("SGX_FB_DBG") ? atoi(sgx_getenv("SGX_FB_DBG")) : 0;
                 fb.w1 = a.wt; fb.b1 = a.bias; fb.wd = bq.wt; fb.bd = bq.bias; fb.w2 = c.wt; fb.b2 = c.bias;
                 Op f; f.kind = OP_FUSED_BLOCK; f.in0 = a.in0; f.out = c.out; f.name = a.name + "+" + bq.name + "+" + c.name; f.fb = fb; f.fb_res_blob = res;
                 f.inc = a.inc; f.outc = c.outc; f.H = a.H; f.W = a.W; f.Ho = bq.Ho; f.Wo = bq.Wo; f.k = bq.k; f.stride = bq.stride;
@@ -452,7 +463,7 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
         // ---- inverted-residual blocks on the matrix cores (sgx_det_irb.h): [pointwise expand + act ->] depthwise + act -> pointwise project
         // [-> squeeze (ReLU) -> excite -> hard-sigmoid gate x project output] [+ residual], one kernel, nothing but the block's input and output in HBM.
         // SGX_DET_IRB=0 keeps the per-layer plan (bit-identical either way).
-        static const int irb_env = getenv("SGX_DET_IRB") ? atoi(getenv("SGX_DET_IRB")) : 1;
+        static const int irb_env = sgx_getenv("SGX_DET_IRB") ? atoi(sgx_getenv("SGX_DET_IRB")) : 1;
         const int irb_mode = g_det_irb < 0 ? irb_env : g_det_irb;
         if (irb_mode != 0 && !g_det_legacy) {
             struct EpiClass { int mode; float c1, lo, hi, c2; int t0, t1; };
@@ -482,7 +493,7 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                     if (rd) r.push_back(i);
                 }
             };
-            static const int irb_mask = getenv("SGX_DET_IRB_MASK") ? atoi(getenv("SGX_DET_IRB_MASK")) : 0xff;      // tuning tap: 1 stride-1 blocks, 2 stride-2 blocks, 4 no-expand blocks, 8 heads
+            static const int irb_mask = sgx_getenv("SGX_DET_IRB_MASK") ? atoi(sgx_getenv("SGX_DET_IRB_MASK")) : 0xff;      // tuning tap: 1 stride-1 blocks, 2 stride-2 blocks, 4 no-expand blocks, 8 heads
             for (int bi = 0; bi < nops; bi++) {
                 Op &bq = ops[bi];
                 if (bq.dead || bq.kind != OP_KXK || !bq.depthwise || (bq.k != 3 && bq.k != 5) || (bq.stride != 1 && bq.stride != 2) || bq.pad != bq.k / 2 || bq.inc != bq.outc) continue;
@@ -522,7 +533,7 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                 // the 75 -> 38 block (24 -> 72 -> 40, 5 x 5 depthwise stride 2, squeeze-excite tail): a k loop of 24 is too short for the matrix-core kernel and the per-layer plan
                 // moves the 72-channel expansion through HBM twice; k_fused_block2 with the squeeze-excite tail in registers takes it
                 // (SGX_DET_BLOCK2_SE=0: per-layer kernels; irb mode 2 keeps k_irb on these shapes for its tests)
-                static const int fb2se_env = getenv("SGX_DET_BLOCK2_SE") ? atoi(getenv("SGX_DET_BLOCK2_SE")) : 1;
+                static const int fb2se_env = sgx_getenv("SGX_DET_BLOCK2_SE") ? atoi(sgx_getenv("SGX_DET_BLOCK2_SE")) : 1;
                 if (fb2_on && fb2se_env && irb_mode == 1 && ai >= 0 && di >= 0 && !c.hwc && ca.mode == SGX_EMODE_ACT && cb.mode == SGX_EMODE_ACT) {
                     Op &a = ops[ai]; const Op &d = ops[di], &e = ops[ei];
                     const int v2 = sgx_fb2_variant(a.inc, c.outc, bq.k, bq.stride, d.outc);
@@ -579,8 +590,8 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                 const size_t lds_max = 160 * 1024; const int kkp = SGX_IRB_KKP(bq.k), max_px = 384;
                 auto lds_of = [&](int g, int oh, int nb) { const int planeT = ((g * ((oh - 1) * bq.stride + bq.k) * ib.Wp + 3) / 4) * 4; return (size_t)nb * 32 * (planeT + kkp) * 4; };
                 int G = 0, OH = bq.Ho, nbands = 1, nbuf = 2;
-                static const int env_g = getenv("SGX_IRB_G") ? atoi(getenv("SGX_IRB_G")) : 0, env_nbuf = getenv("SGX_IRB_NBUF") ? atoi(getenv("SGX_IRB_NBUF")) : 0,
-                                 env_split = getenv("SGX_IRB_SPLIT") ? atoi(getenv("SGX_IRB_SPLIT")) : 0, env_minhw = getenv("SGX_IRB_MINHW") ? atoi(getenv("SGX_IRB_MINHW")) : 0;      // tuning taps
+                static const int env_g = sgx_getenv("SGX_IRB_G") ? atoi(sgx_getenv("SGX_IRB_G")) : 0, env_nbuf = sgx_getenv("SGX_IRB_NBUF") ? atoi(sgx_getenv("SGX_IRB_NBUF")) : 0,
+                                 env_split = sgx_getenv("SGX_IRB_SPLIT") ? atoi(sgx_getenv("SGX_IRB_SPLIT")) : 0, env_minhw = sgx_getenv("SGX_IRB_MINHW") ? atoi(sgx_getenv("SGX_IRB_MINHW")) : 0;      // tuning taps
                 if (bq.Ho * bq.Wo < env_minhw) continue;
                 const bool split = env_split > 0 && bq.Ho * bq.Wo >= env_split;          // force bands of about half the image
                 if (!split && bq.Ho * bq.Wo <= max_px && lds_of(1, bq.Ho, 1) <= lds_max) {
@@ -605,7 +616,7 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                     if (big >= 0xFFFFFFFFull) continue;
                 }
                 ib.has_expand = ai >= 0;
-                { static const int env_stagger = getenv("SGX_IRB_STAGGER") ? atoi(getenv("SGX_IRB_STAGGER")) : 1; ib.stagger = env_stagger; }
+                { static const int env_stagger = sgx_getenv("SGX_IRB_STAGGER") ? atoi(sgx_getenv("SGX_IRB_STAGGER")) : 1; ib.stagger = env_stagger; }
                 if (ai >= 0) { ib.act1 = ca.mode; ib.a1c1 = ca.c1; ib.a1lo = ca.lo; ib.a1hi = ca.hi; ib.a1c2 = ca.c2; ib.w1T = ops[ai].wtT; ib.b1 = ops[ai].bias; ib.ld1 = ops[ai].ldw; ib.w1 = ops[ai].wt; }
                 ib.act2 = cb.mode; ib.a2c1 = cb.c1; ib.a2lo = cb.lo; ib.a2hi = cb.hi; ib.a2c2 = cb.c2;
                 ib.w2T = c.wtT; ib.b2 = c.bias; ib.ld2 = c.ldw; ib.w2 = c.wt; ib.wd = bq.wt; ib.bd = bq.bias;
@@ -618,7 +629,7 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                 {   // tuning tap SGX_IRB_W1LDS=1: expand weights through LDS when the two slices fit beside the planes (the 5 x 5 blocks' planes leave no room).  OFF: measured 6 % slower
                     // on every block (3.45 -> 3.65 ms over the seven expand blocks, bit-identical) — the per-wave loads with scalar offsets and an 8-deep ring hide their latency behind the
                     // 64-cycle fp32 MFMAs already, and the LDS reads compete with the plane traffic
-                    static const int w1lds_env = getenv("SGX_IRB_W1LDS") ? atoi(getenv("SGX_IRB_W1LDS")) : 0;
+                    static const int w1lds_env = sgx_getenv("SGX_IRB_W1LDS") ? atoi(sgx_getenv("SGX_IRB_W1LDS")) : 0;
                     if (ai >= 0 && w1lds_env) {
                         const int rows = (((ib.Cin >> 1) + 7) & ~7) * 2;
                         ib.w1rows = rows;
@@ -629,11 +640,11 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                     const int nqs = NQ == 0 ? 1 : (NQ == 2 ? 3 : (NT == 2 ? 1 : 2));
                     // k_irb3 is OPT-IN (SGX_DET_IRB3=1) until its operand streams hide their latency: measured slower than k_irb on every expand block (r4 trips: 0.99 against 0.75 ms on
                     // 112 -> 672 -> 112), equal on the SSD heads; the pointwise layers take the bf16x3 path by default
-                    static const int irb3_env = getenv("SGX_DET_IRB3") ? atoi(getenv("SGX_DET_IRB3")) : 0;
+                    static const int irb3_env = sgx_getenv("SGX_DET_IRB3") ? atoi(sgx_getenv("SGX_DET_IRB3")) : 0;
                     const bool ok3 = irb3_env != 0 && h->gemm == 1 && c.wS && (ai < 0 || ops[ai].wS) && (di < 0 || (ops[di].wS && ops[ei].wS && (ops[di].outc + 15) / 16 == nqs));
                     ib.gemm = ok3 ? 1 : 0;
                     // mode 2: the fp32 block kernel with ONLY its expand GEMM as bf16x3 (SGX_DET_IRB_A3, tuning tap)
-                    static const int a3_env = getenv("SGX_DET_IRB_A3") ? atoi(getenv("SGX_DET_IRB_A3")) : 0;
+                    static const int a3_env = sgx_getenv("SGX_DET_IRB_A3") ? atoi(sgx_getenv("SGX_DET_IRB_A3")) : 0;
                     if (!ok3 && a3_env && h->gemm == 1 && ai >= 0 && ops[ai].wS) { ib.gemm = 2; ib.w1S = ops[ai].wS; }
                     if (ok3) { ib.w2S = c.wS; ib.w1S = ai >= 0 ? ops[ai].wS : nullptr; ib.wq1S = di >= 0 ? ops[di].wS : nullptr; ib.wq2S = di >= 0 ? ops[ei].wS : nullptr; }
                 }
@@ -657,7 +668,7 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
             }
         // ---- squeeze-excite tails that are still two pointwise launches (the 38 x 38 blocks: 40 -> 10 -> 40 channels on 1 444 pixels) as one k_se_gate each
         {
-            static const int seg_env = getenv("SGX_DET_SE_GATE") ? atoi(getenv("SGX_DET_SE_GATE")) : 1;
+            static const int seg_env = sgx_getenv("SGX_DET_SE_GATE") ? atoi(sgx_getenv("SGX_DET_SE_GATE")) : 1;
             for (int di = 0; seg_env && irb_mode == 1 && g_det_fuse && di < nops; di++) {
                 Op &d = ops[di];
                 if (d.dead || d.kind != OP_PW || d.hwc || d.in0 < 0) continue;
@@ -692,7 +703,7 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
         // ---- the two SSD heads of a feature map (loc and conf: depthwise 3x3 + ReLU -> pointwise, HWC store) read the same planes: one kernel stages them once, reads the
         // depthwise taps once and runs both heads' weights over them (k_irb with a second accumulator set).  SGX_DET_IRB_DUAL=0 keeps them apart.
         {
-            static const int dual_env = getenv("SGX_DET_IRB_DUAL") ? atoi(getenv("SGX_DET_IRB_DUAL")) : 1;
+            static const int dual_env = sgx_getenv("SGX_DET_IRB_DUAL") ? atoi(sgx_getenv("SGX_DET_IRB_DUAL")) : 1;
             for (int i = 0; dual_env && i < nops; i++) {
                 Op &a = ops[i];
                 if (a.dead || a.kind != OP_IRB || a.irb.has_expand || !a.irb.hwc || a.irb.Cq || a.irb.Cout2) continue;
@@ -722,7 +733,7 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
         if (o.irb_out2_blob >= 0) { Blob &o2 = h->blobs[o.irb_out2_blob]; if (!o2.d && o2.n) { if (h->alloc(&o2.d, o2.n * B)) FAIL(SGX_ERR_NOMEM); } }
     }
     {   // pre-processing fused into the stem (k_stem_pre) when the stem is the only reader of the network input and takes the k_conv_stem2 path (see run_op)
-        static const int prefuse_env = getenv("SGX_DET_PREFUSE") ? atoi(getenv("SGX_DET_PREFUSE")) : 1;
+        static const int prefuse_env = sgx_getenv("SGX_DET_PREFUSE") ? atoi(sgx_getenv("SGX_DET_PREFUSE")) : 1;
         const int in_id = h->blob_id.at("input");
         int readers = 0; for (const Op &o : h->ops) readers += (o.in0 == in_id) + (o.in1 == in_id);
         if (prefuse_env && g_det_fuse && !h->legacy && !h->ops.empty() && readers == 1 && stem2_ok(h, h->ops[0]) && h->ops[0].in0 == in_id) {
@@ -741,7 +752,7 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
         h->alloc(&h->d_cls_count, (size_t)B * (h->num_class - 1)) || h->alloc(&h->d_results, (size_t)B)) { delete h; return SGX_ERR_NOMEM; }
     if (hipMemcpy(h->d_priors, prior_boxes.data(), sizeof(float) * 4 * h->num_priors, hipMemcpyHostToDevice) != hipSuccess) { delete h; return SGX_ERR_DEVICE; }
     {   // A/B switch of the XCD-aware work order (sgx_xcd_order); on by default
-        const int xo = getenv("SGX_DET_XCD") ? atoi(getenv("SGX_DET_XCD")) : 1;
+        const int xo = sgx_getenv("SGX_DET_XCD") ? atoi(sgx_getenv("SGX_DET_XCD")) : 1;
 #ifndef SGX_EMU
         if (hipMemcpyToSymbol(HIP_SYMBOL(sgx_det_xcd_order), &xo, sizeof(int)) != hipSuccess) { delete h; return SGX_ERR_DEVICE; }
 #else
@@ -834,7 +845,7 @@ static void run_op(sgx_det *h, const Op &op, int batch, sgx_stream_t st)
                        make_epi(h, op, (size_t)op.outc * N), op.hwc, op.hwc_off);
             break;
         }
-        static const int pw3_mink = getenv("SGX_PW3_MINK") ? atoi(getenv("SGX_PW3_MINK")) : 64;      // measured: with fewer than four k16 steps the exact-fp32 kernel's shorter prologue wins (c40 -> 120 / 160: 0.14 against 0.17 ms)
+        static const int pw3_mink = sgx_getenv("SGX_PW3_MINK") ? atoi(sgx_getenv("SGX_PW3_MINK")) : 64;      // measured: with fewer than four k16 steps the exact-fp32 kernel's shorter prologue wins (c40 -> 120 / 160: 0.14 against 0.17 ms)
 #ifdef SGX_EMU
         if (h->gemm == 1 && op.wS && op.inc >= pw3_mink) {
             sgx_pw3_emu(op.inc, op.outc, N, batch, A.d, A.n, (const unsigned short *)op.wS, op.ldw, op.bias, O.d, O.n, make_epi(h, op, (size_t)op.outc * N), op.hwc, op.hwc_off);
@@ -845,7 +856,7 @@ static void run_op(sgx_det *h, const Op &op, int batch, sgx_stream_t st)
             // bf16x3 (k_conv_pw3): same decomposition; the accumulators + the split operands cap the wave tile at four 32 x 32 sub-tiles
             const int sub = (op.outc + 31) / 32, total = batch * N;
             static const int cand3[8][2] = { {2, 2}, {4, 1}, {3, 1}, {5, 1}, {1, 4}, {2, 1}, {1, 2}, {1, 1} };
-            static const int force3 = getenv("SGX_PW3_FORCE") ? atoi(getenv("SGX_PW3_FORCE")) : 0;      // tuning tap: OCB * 10 + PXB
+            static const int force3 = sgx_getenv("SGX_PW3_FORCE") ? atoi(sgx_getenv("SGX_PW3_FORCE")) : 0;      // tuning tap: OCB * 10 + PXB
             int ocb = 1, pxb = 1; long best_score = -1;
             for (int c = 0; c < 8; c++) {
                 const int cb = cand3[c][0], cp = cand3[c][1];
@@ -887,7 +898,7 @@ static void run_op(sgx_det *h, const Op &op, int batch, sgx_stream_t st)
         const int nxt = (total + 128 * pxb - 1) / (128 * pxb), noc = (sub + ocb - 1) / ocb;
         const int grid = ((nxt + 7) / 8) * 8 * noc;
         const SgxEpi e = make_epi(h, op, (size_t)op.outc * N);
-        static const int pw2_direct = getenv("SGX_PW2_DIRECT") ? atoi(getenv("SGX_PW2_DIRECT")) : 1;
+        static const int pw2_direct = sgx_getenv("SGX_PW2_DIRECT") ? atoi(sgx_getenv("SGX_PW2_DIRECT")) : 1;
 #define SGX_PW2(OCB_, PXB_) do { auto kfn = k_conv_pw2<OCB_, PXB_>; SGX_LAUNCH(kfn, dim3(grid), dim3(256), st, op.inc, op.outc, N, total, A.d, A.n, op.wtT, op.bias, \
                                                                                O.d, O.n, e, op.hwc, op.hwc_off, nxt, noc, op.ldw, pw2_direct); } while (0)
         switch (ocb * 10 + pxb) {
@@ -918,12 +929,12 @@ static void run_op(sgx_det *h, const Op &op, int batch, sgx_stream_t st)
         break; }
     case OP_KXK: {
         const SgxEpi e = make_epi(h, op, (size_t)op.outc * op.Ho * op.Wo);
-        static const int budget_env = getenv("SGX_DW_BUDGET") ? atoi(getenv("SGX_DW_BUDGET")) : 8192;
+        static const int budget_env = sgx_getenv("SGX_DW_BUDGET") ? atoi(sgx_getenv("SGX_DW_BUDGET")) : 8192;
         const int budget = budget_env;                                  // floats of LDS per workgroup for the staged input
         const int Wp = (op.Wo - 1) * op.stride + op.k;
         auto magic = [](int d) -> unsigned { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
         const int nbx4 = (op.Wo + 3) / 4, pitch4 = ((nbx4 - 1) * 4 * op.stride + 3 * op.stride + op.k + 3) & ~3;
-        static const int dw2_on = getenv("SGX_DW2") ? atoi(getenv("SGX_DW2")) : 1;
+        static const int dw2_on = sgx_getenv("SGX_DW2") ? atoi(sgx_getenv("SGX_DW2")) : 1;
         if (dw2_on && !h->legacy && op.depthwise && (op.k == 3 || op.k == 5) && (op.stride == 1 || op.stride == 2) && pitch4 * op.k <= budget) {
             // k_conv_dw2: P planes x a band of RB output rows per workgroup, LDS tile [P][(RB - 1) s + k][pitch4]
             const int nplanes = batch * op.outc, rin_full = (op.Ho - 1) * op.stride + op.k, KW = (op.k * op.k + 1 + 3) & ~3;
@@ -1010,6 +1021,76 @@ static void run_first_step(sgx_det *h, const uint8_t *d_img, int pitch, int batc
                    op.outc, op.Ho, op.Wo, op.pad, g.RB, g.pitch4, magic(g.pitch4), magic(g.nbx4), op.wtT, op.bias, O.d, O.n, e);
 }
 
+#ifndef SGX_EMU
+// The plan as a hipGraph WITH its parallel branches.  A one-stream capture turns the plan into a chain of nodes, so the SSD heads of a feature map (latency-bound: a few deep-k
+// workgroup chains per image) hold up the backbone layers behind them although nothing there reads their output, and the extra-layer tail (5 x 5 ... 1 x 1 maps) runs alone on the
+// chip.  Here the capture forks: dependencies between plan steps are derived from the blobs they read and write (read-after-write, write-after-read, write-after-write; the head
+// kernels' HWC stores into the shared concat buffers are disjoint slices and do not order each other), steps are dealt to `lanes` capture streams — a step continues the lane of
+// the producer whose longest remaining path runs through it (the backbone stays on lane 0), otherwise it takes a free side lane — and every cross-lane dependency becomes an
+// event edge.  All lanes rejoin lane 0 before the capture ends.  Same kernels, same arguments, same results; only the order constraints the hardware sees are fewer.
+static int capture_forked(sgx_det *h, size_t first, int batch, sgx_stream_t st, int lanes, hipGraph_t *graph)
+{
+    const int n = (int)h->ops.size();
+    auto root = [&](int b) { while (b >= 0 && h->blobs[b].alias >= 0) b = h->blobs[b].alias; return b; };
+    std::vector<std::vector<int>> rd(n), wr(n); std::vector<char> partial(n, 0);
+    for (int i = (int)first; i < n; i++) {
+        const Op &o = h->ops[i];
+        for (int b : { o.in0, o.in1, o.fb_res_blob, o.sg_res_blob, o.irb_res_blob }) if (b >= 0 && !h->blobs[b].scalar) rd[i].push_back(root(b));
+        for (const EpiStep &e : o.epi) if (e.tensor >= 0) rd[i].push_back(root(e.tensor));
+        wr[i].push_back(root(o.out)); if (o.irb_out2_blob >= 0) wr[i].push_back(root(o.irb_out2_blob));
+        partial[i] = (o.hwc || o.kind == OP_PERMUTE_INTO || o.kind == OP_COPY_INTO || (o.kind == OP_IRB && o.irb.hwc)) ? 1 : 0;
+    }
+    auto hits = [](const std::vector<int> &a, const std::vector<int> &b) { for (int x : a) for (int y : b) if (x == y) return true; return false; };
+    std::vector<std::vector<int>> deps(n), users(n);
+    for (int i = (int)first; i < n; i++)
+        for (int j = (int)first; j < i; j++)
+            if (hits(wr[j], rd[i]) || hits(rd[j], wr[i]) || (hits(wr[j], wr[i]) && !(partial[i] && partial[j]))) { deps[i].push_back(j); users[j].push_back(i); }
+    std::vector<int> prio(n, 1), heir(n, -1);                                   // longest remaining path in steps; the dependent that path runs through
+    for (int i = n - 1; i >= (int)first; i--)
+        for (int u : users[i]) if (prio[u] + 1 > prio[i]) { prio[i] = prio[u] + 1; heir[i] = u; }
+    lanes = std::max(1, std::min(lanes, 8));
+    while ((int)h->fork_streams.size() < lanes - 1) { hipStream_t q; SGX_CHECK_HIP(hipStreamCreateWithFlags(&q, hipStreamNonBlocking)); h->fork_streams.push_back(q); }
+    std::vector<hipStream_t> L(lanes); L[0] = st; for (int l = 1; l < lanes; l++) L[l] = h->fork_streams[l - 1];
+    std::vector<int> tail(lanes, -1), lane_of(n, 0); std::vector<char> started(lanes, 0); started[0] = 1;
+    std::vector<hipEvent_t> done(n, nullptr);
+    // every event the capture can need exists before it begins (no resource creation while the thread captures)
+    std::vector<hipEvent_t> pool((size_t)n + 2 * lanes); size_t next_ev = 0;
+    for (hipEvent_t &e : pool) { SGX_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->fork_events.push_back(e); }
+    SGX_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    // a failure inside the capture must not leave the caller's stream capturing
+#define CAP_CHECK(x) do { if ((x) != hipSuccess) { hipGraph_t g2 = nullptr; (void)hipStreamEndCapture(st, &g2); if (g2) (void)hipGraphDestroy(g2); return SGX_ERR_DEVICE; } } while (0)
+    for (int i = (int)first; i < n; i++) {
+        int lane = -1;
+        for (int j : deps[i]) if (tail[lane_of[j]] == j && heir[j] == i) { lane = lane_of[j]; break; }      // the critical successor keeps its producer's lane
+        if (lane < 0 && !deps[i].empty()) {
+            for (int l = 1; l < lanes && lane < 0; l++) {                                                       // a side lane whose tail has nothing critical left to wait for
+                const int t = tail[l];
+                if (t < 0 || heir[t] < 0 || heir[t] < i) lane = l;
+            }
+            if (lane < 0) for (int j : deps[i]) if (tail[lane_of[j]] == j) { lane = lane_of[j]; break; }      // no free lane: behind one of its producers
+        }
+        if (lane < 0) lane = 0;
+        for (int j : deps[i]) if (lane_of[j] != lane) { CAP_CHECK(hipStreamWaitEvent(L[lane], done[j], 0)); started[lane] = 1; }
+        if (!started[lane]) {                                                                                    // a side lane must enter the capture through an event of the origin stream
+            hipEvent_t e = pool[next_ev++];
+            CAP_CHECK(hipEventRecord(e, L[0])); CAP_CHECK(hipStreamWaitEvent(L[lane], e, 0)); started[lane] = 1;
+        }
+        run_op(h, h->ops[i], batch, L[lane]);
+        lane_of[i] = lane; tail[lane] = i;
+        if (!users[i].empty()) {                                                                                 // an event behind every step with dependents: the edge a later step on another lane waits on
+            hipEvent_t e = pool[next_ev++]; CAP_CHECK(hipEventRecord(e, L[lane])); done[i] = e;
+        }
+    }
+    for (int l = 1; l < lanes; l++) if (started[l] && tail[l] >= 0) {                                            // join: every side lane's tail before the capture ends on lane 0
+        hipEvent_t e = pool[next_ev++];
+        CAP_CHECK(hipEventRecord(e, L[l])); CAP_CHECK(hipStreamWaitEvent(L[0], e, 0));
+    }
+#undef CAP_CHECK
+    SGX_CHECK_HIP(hipStreamEndCapture(st, graph));
+    return SGX_OK;
+}
+#endif
+
 // Batched forward from device-resident interleaved 3-channel u8 images (B x H x W x 3, row pitch in bytes).
 // Leaves loc (num_priors*4) and softmax conf (num_priors*num_class) per image in device memory; returns their pointers.
 extern "C" int sgx_det_forward_batch_dev(sgx_det *h, const uint8_t *d_img, int pitch, int batch, const float **d_loc, const float **d_conf, void *stream_)
@@ -1022,14 +1103,18 @@ extern "C" int sgx_det_forward_batch_dev(sgx_det *h, const uint8_t *d_img, int p
 #ifndef SGX_EMU
     // The plan after pre-processing only touches the handle's own blobs, so it is captured once per batch size into a hipGraph and replayed
     // (needs a non-default stream; SGX_DET_NO_GRAPH=1 or the legacy stream falls back to individual launches).
-    static const bool no_graph = getenv("SGX_DET_NO_GRAPH") != nullptr;
+    static const bool no_graph = sgx_getenv("SGX_DET_NO_GRAPH") != nullptr;
     if (st != nullptr && !no_graph) {
         auto it = h->graphs.find(batch);
         if (it == h->graphs.end()) {
             hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
-            SGX_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            for (size_t i = first; i < h->ops.size(); i++) run_op(h, h->ops[i], batch, st);
-            SGX_CHECK_HIP(hipStreamEndCapture(st, &graph));
+            static const int fork_lanes = sgx_getenv("SGX_DET_FORK") ? atoi(sgx_getenv("SGX_DET_FORK")) : SGX_DET_FORK_LANES;      // A/B tap: 1 = the one-stream chain
+            if (fork_lanes > 1) { const int rc = capture_forked(h, first, batch, st, fork_lanes, &graph); if (rc != SGX_OK) return rc; }
+            else {
+                SGX_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+                for (size_t i = first; i < h->ops.size(); i++) run_op(h, h->ops[i], batch, st);
+                SGX_CHECK_HIP(hipStreamEndCapture(st, &graph));
+            }
             SGX_CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
             (void)hipGraphDestroy(graph);
             it = h->graphs.emplace(batch, exec).first;
@@ -1046,7 +1131,7 @@ extern "C" int sgx_det_forward_batch_dev(sgx_det *h, const uint8_t *d_img, int p
 }
 
 // test / tuning taps: per-launch HIP-event time of every step of the plan (ms[0] = pre-processing, ms[1 + i] = op i), and a description of op i
-extern "C" int sgx_det_debug_time_ops(sgx_det *h, const uint8_t *d_img, int pitch, int batch, int reps, float *ms, int cap, int *nops)
+SGX_TAP int sgx_det_debug_time_ops(sgx_det *h, const uint8_t *d_img, int pitch, int batch, int reps, float *ms, int cap, int *nops)
 {
     if (!h || !d_img || !ms || !nops || batch < 1 || batch > h->max_batch || reps < 1) return SGX_ERR_INVALID;
     const int skip = h->pre_fused;                                  // step 0 is then the stem itself; step i >= 1 is ops[i]
@@ -1071,7 +1156,7 @@ extern "C" int sgx_det_debug_time_ops(sgx_det *h, const uint8_t *d_img, int pitc
 #endif
 }
 
-extern "C" int sgx_det_debug_op_desc(const sgx_det *h, int i, char *buf, int cap)
+extern "C" int sgx_det_plan_step(const sgx_det *h, int i, char *buf, int cap)
 {
     if (!h || !buf || cap < 16 || i < 0 || i > (int)h->ops.size() - h->pre_fused) return SGX_ERR_INVALID;
     if (i == 0 && !h->pre_fused) { snprintf(buf, cap, "preprocess %dx%d->%d", h->W, h->H, h->T); return SGX_OK; }
@@ -1082,7 +1167,7 @@ extern "C" int sgx_det_debug_op_desc(const sgx_det *h, int i, char *buf, int cap
     if (o.kind == OP_SE_GATE) { snprintf(buf, cap, "se_gate %s c%d->%d->%d %dx%d%s", o.name.c_str(), o.sg.Cout, o.sg.Cq, o.sg.Cout, o.H, o.W, o.sg_res_blob >= 0 ? " +res" : ""); return SGX_OK; }
     if (o.kind == OP_PW || o.kind == OP_KXK)
         snprintf(buf, cap, "%s %s c%d->%d k%d s%d %s%dx%d->%dx%d epi%d%s%s", kn[o.kind], o.name.c_str(), o.inc, o.outc, o.k, o.stride, o.depthwise ? "dw " : "", o.H, o.W,
-                 o.kind == OP_PW ? o.H : o.Ho, o.kind == OP_PW ? o.W : o.Wo, (int)o.epi.size() + (o.act ? 1 : 0), o.hwc ? " hwc" : "", (o.kind == OP_PW && h->gemm == 1 && o.wS && o.inc >= (getenv("SGX_PW3_MINK") ? atoi(getenv("SGX_PW3_MINK")) : 64)) ? " bf16x3" : "");
+                 o.kind == OP_PW ? o.H : o.Ho, o.kind == OP_PW ? o.W : o.Wo, (int)o.epi.size() + (o.act ? 1 : 0), o.hwc ? " hwc" : "", (o.kind == OP_PW && h->gemm == 1 && o.wS && o.inc >= (sgx_getenv("SGX_PW3_MINK") ? atoi(sgx_getenv("SGX_PW3_MINK")) : 64)) ? " bf16x3" : "");
     else if (o.kind == OP_FUSED_BLOCK)
         snprintf(buf, cap, "block %s c%d->%d->%d k%d s%d %dx%d->%dx%d tile %dx%d%s%s", o.name.c_str(), o.fb.Cin, o.fb.Cmid, o.fb.Cout, o.fb.K, o.fb.stride, o.H, o.W, o.Ho, o.Wo, o.fb.TOH, o.fb.TOW,
                  o.fb.Cq ? " se" : "", o.fb_res_blob >= 0 ? " +res" : "");
@@ -1101,7 +1186,7 @@ extern "C" int sgx_det_info(const sgx_det *h, int32_t *num_priors, int32_t *num_
 }
 
 // test tap: copy one image's blob (by ncnn blob name) to the host; returns element count in *n
-extern "C" int sgx_det_debug_read_blob(sgx_det *h, const char *name, int image, float *dst, int cap, int *n)
+SGX_TAP int sgx_det_debug_read_blob(sgx_det *h, const char *name, int image, float *dst, int cap, int *n)
 {
     if (!h || !name || !n) return SGX_ERR_INVALID;
     auto it = h->blob_id.find(name); if (it == h->blob_id.end()) return SGX_ERR_INVALID;
@@ -1141,7 +1226,7 @@ static int run_detection_output(sgx_det *h, int batch, sgx_det_result *d_results
 }
 
 // test tap: DetectionOutput + detect() filtering alone on caller-supplied head outputs (loc: batch x num_priors x 4, conf: batch x num_priors x num_class)
-extern "C" int sgx_det_debug_detection_output(sgx_det *h, const float *loc, const float *conf, int batch, sgx_det_result *results)
+SGX_TAP int sgx_det_debug_detection_output(sgx_det *h, const float *loc, const float *conf, int batch, sgx_det_result *results)
 {
     if (!h || !loc || !conf || !results || batch < 1 || batch > h->max_batch) return SGX_ERR_INVALID;
     SGX_CHECK_HIP(hipMemcpy(h->blobs[h->loc_blob].d, loc, sizeof(float) * 4 * (size_t)h->num_priors * batch, hipMemcpyHostToDevice));

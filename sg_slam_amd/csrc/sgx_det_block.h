@@ -709,7 +709,7 @@ static inline int sgx_fb2_variant(int cin, int cout, int k, int stride, int cq =
         if (cin == 24 && cout == 40 && k == 5 && stride == 2 && cq == 10) return 4 * 16;
         return 0;
     }
-    static const int tile_env = getenv("SGX_FB2_TILE") ? atoi(getenv("SGX_FB2_TILE")) : -1;          // tuning tap: force 8 x 16 (0) or 16 x 16 (1) output tiles on the stride-1 blocks
+    static const int tile_env = sgx_getenv("SGX_FB2_TILE") ? atoi(sgx_getenv("SGX_FB2_TILE")) : -1;          // tuning tap: force 8 x 16 (0) or 16 x 16 (1) output tiles on the stride-1 blocks
     int shape = 0;
     if (cin == 16 && cout == 16 && k == 3 && stride == 1) shape = 1;
     else if (cin == 16 && cout == 24 && k == 3 && stride == 2) shape = 2;

@@ -966,7 +966,7 @@ static inline int sgx_irb_launch(const SgxIrb &p, int batch, sgx_stream_t st)
     const size_t lds = sgx_irb_lds_bytes(p);
     if (nw > 12 || lds > 160 * 1024) return SGX_ERR_UNSUPPORTED;
     SgxIrb q = p; q.batch = batch;
-    { static const int dbg_env = getenv("SGX_IRB3_DBG") ? atoi(getenv("SGX_IRB3_DBG")) : 0; q.dbg = dbg_env; }
+    { static const int dbg_env = sgx_getenv("SGX_IRB3_DBG") ? atoi(sgx_getenv("SGX_IRB3_DBG")) : 0; q.dbg = dbg_env; }
     if (p.gemm == 1) {
         const int nqs = NQ == 0 ? 1 : (NQ == 2 ? 3 : (NT == 2 ? 1 : 2));
         if (NQ > 0 && (p.Cq + 15) / 16 != nqs) return SGX_ERR_UNSUPPORTED;

@@ -5,6 +5,9 @@
 #pragma once
 #include "sgx_rt.h"
 #include "../../include/sgx.h"
+#ifdef SGX_DEBUG_TAPS
+#include "../../include/sgx_debug.h"      // test / tuning taps: compiled into tests/taps/libsgx_taps.so and the emulator only
+#endif
 
 // XCD-aware work order.  Workgroup w of a launch (linear id, x fastest) is dispatched to XCD w % 8, and every XCD has its own 4 MB L2: with the plain order
 // (work items of a frame on consecutive ids) neighbouring tiles of a frame land on eight different L2s and every halo / partial cache line they share is

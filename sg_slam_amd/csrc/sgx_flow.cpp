@@ -4,6 +4,9 @@
 #include "sgx_prof.h"
 #include "sgx_stage.h"
 #include "../../include/sgx.h"
+#ifdef SGX_DEBUG_TAPS
+#include "../../include/sgx_debug.h"      // test / tuning taps: compiled into tests/taps/libsgx_taps.so and the emulator only
+#endif
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -87,7 +90,7 @@ static int track(sgx_flow *h, int cur_slot, int prev_slot, int batch, const sgx_
     double eps = h->cfg.epsilon > 10. ? 10. : h->cfg.epsilon;
     A.eps2 = eps * eps; A.min_eig = (float)1e-4;
     sgx_prof_begin(SGX_K_LK_TRACK, st);
-    static const int kpw = getenv("SGX_LK_KPW") ? atoi(getenv("SGX_LK_KPW")) : 2;      // keypoints per wave: 2 (default) / 4 = k_lk_trackN, 1 = k_lk_track; same results
+    static const int kpw = sgx_getenv("SGX_LK_KPW") ? atoi(sgx_getenv("SGX_LK_KPW")) : 2;      // keypoints per wave: 2 (default) / 4 = k_lk_trackN, 1 = k_lk_track; same results
     A.batch = batch; A.kblocks = (cap + 4 * kpw - 1) / (4 * kpw);
     if (kpw == 4) { auto kfn = k_lk_trackN<4>; SGX_LAUNCH(kfn, dim3((unsigned)A.kblocks * (unsigned)batch), dim3(256), st, h->g, A); }
     else if (kpw == 2) { auto kfn = k_lk_trackN<2>; SGX_LAUNCH(kfn, dim3((unsigned)A.kblocks * (unsigned)batch), dim3(256), st, h->g, A); }
@@ -138,7 +141,7 @@ extern "C" int sgx_flow_lk(sgx_flow *h, const uint8_t *gray_from, const uint8_t 
     return SGX_OK;
 }
 
-extern "C" int sgx_flow_debug_read_level(sgx_flow *h, int slot, int frame, int level, uint8_t *img /* w*h tight */)
+SGX_TAP int sgx_flow_debug_read_level(sgx_flow *h, int slot, int frame, int level, uint8_t *img /* w*h tight */)
 {
     if (!h || slot < 0 || slot > 1 || frame < 0 || frame >= h->cfg.max_batch || level < 0 || level >= h->g.nl) return SGX_ERR_INVALID;
     const SgxLkGeom &g = h->g;
@@ -151,7 +154,7 @@ extern "C" int sgx_flow_debug_read_level(sgx_flow *h, int slot, int frame, int l
     }
     return SGX_OK;
 }
-extern "C" int sgx_flow_debug_level_size(const sgx_flow *h, int level, int32_t *w, int32_t *hh)
+SGX_TAP int sgx_flow_debug_level_size(const sgx_flow *h, int level, int32_t *w, int32_t *hh)
 {
     if (!h || level < 0 || level >= h->g.nl || !w || !hh) return SGX_ERR_INVALID;
     *w = h->g.w[level]; *hh = h->g.h[level];

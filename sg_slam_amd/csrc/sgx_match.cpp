@@ -4,6 +4,9 @@
 #include "sgx_prof.h"
 #include "sgx_stage.h"
 #include "../../include/sgx.h"
+#ifdef SGX_DEBUG_TAPS
+#include "../../include/sgx_debug.h"      // test / tuning taps: compiled into tests/taps/libsgx_taps.so and the emulator only
+#endif
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -28,7 +31,7 @@ extern "C" int sgx_match_project_frame_batch_dev(
     SgxScales sc; memset(&sc, 0, sizeof sc);
     for (int i = 0; i < nlevels; i++) sc.s[i] = scale_factors[i];
     sgx_prof_begin(SGX_K_MATCH, (sgx_stream_t)stream);
-    static const int mthreads = getenv("SGX_TUNE_MATCH_THREADS") ? atoi(getenv("SGX_TUNE_MATCH_THREADS")) : SGX_MATCH_THREADS;   // env = tuning tap (64..1024)
+    static const int mthreads = sgx_getenv("SGX_TUNE_MATCH_THREADS") ? atoi(sgx_getenv("SGX_TUNE_MATCH_THREADS")) : SGX_MATCH_THREADS;   // env = tuning tap (64..1024)
     SGX_LAUNCH(k_match_project_frame, dim3(batch), dim3(mthreads), (sgx_stream_t)stream, cap,
                (const uint8_t *)d_ckeys, d_cdesc, d_curight, d_cn, d_cTcw, (const uint8_t *)d_lkeys, d_ln, d_l_has_mp, d_l_outlier,
                d_l_xw, d_l_obs, d_l_mpdesc, d_lTcw, to_cam(cam), sc, th, b_mono, check_orientation, d_cur_match, d_nmatches);
@@ -222,7 +225,7 @@ extern "C" int sgx_frame_gray_from_color_batch_dev(int batch, int width, int hei
     return SGX_OK;
 }
 
-extern "C" int sgx_debug_flow_affine_batch_dev(int batch, int cap, const sgx_keypoint *d_keys, const int32_t *d_n, const float *d_A, const float *d_shift, const float *d_boxes,
+SGX_TAP int sgx_debug_flow_affine_batch_dev(int batch, int cap, const sgx_keypoint *d_keys, const int32_t *d_n, const float *d_A, const float *d_shift, const float *d_boxes,
                                                int max_boxes, float *d_prev_xy, void *stream)
 {
     if (batch < 1 || cap < 1 || !d_keys || !d_n || !d_A || !d_prev_xy) return SGX_ERR_INVALID;

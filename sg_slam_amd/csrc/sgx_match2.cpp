@@ -3,6 +3,9 @@
 #include "sgx_match2_kernels.h"
 #include "sgx_stage.h"
 #include "../../include/sgx.h"
+#ifdef SGX_DEBUG_TAPS
+#include "../../include/sgx_debug.h"      // test / tuning taps: compiled into tests/taps/libsgx_taps.so and the emulator only
+#endif
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>

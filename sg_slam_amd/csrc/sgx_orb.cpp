@@ -4,6 +4,9 @@
 #include "sgx_orb_kernels.h"
 #include "sgx_prof.h"
 #include "../../include/sgx.h"
+#ifdef SGX_DEBUG_TAPS
+#include "../../include/sgx_debug.h"      // test / tuning taps: compiled into tests/taps/libsgx_taps.so and the emulator only
+#endif
 #include "../../include/sgx_orb_pattern.h"
 #include <math.h>
 #include <stdio.h>
@@ -47,7 +50,7 @@ struct sgx_orb {
 };
 
 static thread_local int g_orb_unfused_pyramid = 0;      // test tap: 1 = one k_resize launch per level instead of the fused k_pyramid
-extern "C" int sgx_orb_debug_set_unfused_pyramid(int on) { g_orb_unfused_pyramid = on ? 1 : 0; return SGX_OK; }
+SGX_TAP int sgx_orb_debug_set_unfused_pyramid(int on) { g_orb_unfused_pyramid = on ? 1 : 0; return SGX_OK; }
 
 static inline int cvround_f(float v) { return (int)lrintf(v); }
 static inline int cvround_d(double v) { return (int)lrint(v); }
@@ -328,10 +331,10 @@ extern "C" int sgx_orb_get_tables(const sgx_orb *h, float *scale, float *inv_sca
 static void launch_octree(sgx_orb *h, int batch, sgx_stream_t stream)
 {
     const SgxOrbGeom &g = h->g; const int nl = g.nlevels;
-    static const int oct_threads = getenv("SGX_TUNE_OCT_THREADS") ? atoi(getenv("SGX_TUNE_OCT_THREADS")) : SGX_OCT_THREADS;   // env = tuning tap (64..SGX_OCT_THREADS)
+    static const int oct_threads = sgx_getenv("SGX_TUNE_OCT_THREADS") ? atoi(sgx_getenv("SGX_TUNE_OCT_THREADS")) : SGX_OCT_THREADS;   // env = tuning tap (64..SGX_OCT_THREADS)
     // (levels, frames) dispatch order.  The (frames, levels) order — all level-0 workgroups first, small levels in the tail; tap below — runs the kernel itself
     // 30 % faster at 256 frames (0.33 -> 0.22 ms) but the two-stream pipeline 1.5 % slower (A/B on one box: 112.5 k vs 114.1 k frames/s), so it is not the default
-    static const bool frame_fast = getenv("SGX_TUNE_OCT_FRAME_FAST") != nullptr;
+    static const bool frame_fast = sgx_getenv("SGX_TUNE_OCT_FRAME_FAST") != nullptr;
     const dim3 ogrid = frame_fast ? dim3(batch, nl) : dim3(nl, batch);
     if (h->oct_maxlim <= 256) {
         auto ka = k_octree<true, 256, 2048>; auto kb = k_octree<true, 256, SGX_CAND_LDS>; auto kc = k_octree<false, 256, 1>;
@@ -356,7 +359,7 @@ extern "C" int sgx_orb_extract_batch_dev(sgx_orb *h, const uint8_t *d_gray, int 
     h->last_batch = batch;
     SGX_CHECK_HIP(hipMemsetAsync(h->d_cand_count, 0, (size_t)batch * nl * 4, stream));
     sgx_prof_begin(SGX_K_RESIZE, stream);
-    static const int pyr_threads = getenv("SGX_TUNE_PYR_THREADS") ? atoi(getenv("SGX_TUNE_PYR_THREADS")) : 512;      // workgroup size (measured: 0.130 / 0.086 / 0.073 ms per 64 frames at 128 / 256 / 512); env = tuning tap (64..1024)
+    static const int pyr_threads = sgx_getenv("SGX_TUNE_PYR_THREADS") ? atoi(sgx_getenv("SGX_TUNE_PYR_THREADS")) : 512;      // workgroup size (measured: 0.130 / 0.086 / 0.073 ms per 64 frames at 128 / 256 / 512); env = tuning tap (64..1024)
     if (h->pyr_tiles > 0 && !g_orb_unfused_pyramid)
         SGX_LAUNCH_DYN(k_pyramid, dim3(h->pyr_tiles, batch), dim3(pyr_threads), h->pyr_lds, stream, g, h->pyr_tabs, d_gray, pitch, h->d_pyr, h->d_xt_all, h->d_yt_all, h->d_pyr_rects);
     else
@@ -366,8 +369,8 @@ extern "C" int sgx_orb_extract_batch_dev(sgx_orb *h, const uint8_t *d_gray, int 
         }
     sgx_prof_end(SGX_K_RESIZE, stream);
     sgx_prof_begin(SGX_K_FAST, stream);
-    static const int fast_threads = getenv("SGX_TUNE_FAST_THREADS") ? atoi(getenv("SGX_TUNE_FAST_THREADS")) : 128;      // workgroup size; env = tuning tap (64..SGX_FAST_THREADS)
-    static const int e_extra = getenv("SGX_TUNE_E_EXTRA_LDS") ? atoi(getenv("SGX_TUNE_E_EXTRA_LDS")) : 0;   // tuning tap: pad the extraction kernels' LDS to cap their occupancy
+    static const int fast_threads = sgx_getenv("SGX_TUNE_FAST_THREADS") ? atoi(sgx_getenv("SGX_TUNE_FAST_THREADS")) : 128;      // workgroup size; env = tuning tap (64..SGX_FAST_THREADS)
+    static const int e_extra = sgx_getenv("SGX_TUNE_E_EXTRA_LDS") ? atoi(sgx_getenv("SGX_TUNE_E_EXTRA_LDS")) : 0;   // tuning tap: pad the extraction kernels' LDS to cap their occupancy
     SGX_LAUNCH_DYN(k_fast_cells, dim3(g.ncells * batch), dim3(fast_threads), g.fast_lds_bytes + e_extra, stream, g, h->d_cells, d_gray, pitch, h->d_pyr, batch,
                h->d_cand, h->d_cand_count, h->d_status);
     sgx_prof_end(SGX_K_FAST, stream);
@@ -379,18 +382,18 @@ extern "C" int sgx_orb_extract_batch_dev(sgx_orb *h, const uint8_t *d_gray, int 
     for (int i = 0; i < 16; i++) umax_packed |= (unsigned long long)(h->umax_h[i] & 15) << (4 * i);
     // default: blur whole levels once (k_blur_levels), then a light per-keypoint kernel; SGX_TUNE_ORB_PATCH_BLUR=1 selects the first design (blur of a
     // 37x37 window per keypoint inside k_orient_desc) — identical bytes (tests), ~45 vs ~20+ VALU operations per pixel-equivalent
-    static const bool patch_blur = getenv("SGX_TUNE_ORB_PATCH_BLUR") != nullptr;
+    static const bool patch_blur = sgx_getenv("SGX_TUNE_ORB_PATCH_BLUR") != nullptr;
     if (patch_blur) {
         SGX_LAUNCH_DYN(k_orient_desc, dim3(g.kp_cap * batch), dim3(64), e_extra / 2, stream, g, d_gray, pitch, h->d_pyr, h->d_sel, h->d_sel_count,
                        umax_packed, h->d_pattern, (uint8_t *)d_kps, d_desc, d_count, cap, batch, h->d_status);
     } else {
-        static const int blur_threads = getenv("SGX_TUNE_BLUR_THREADS") ? atoi(getenv("SGX_TUNE_BLUR_THREADS")) : 256;   // env = tuning tap (64..512)
+        static const int blur_threads = sgx_getenv("SGX_TUNE_BLUR_THREADS") ? atoi(sgx_getenv("SGX_TUNE_BLUR_THREADS")) : 256;   // env = tuning tap (64..512)
         {   // persistent workgroups: `parts` per frame, each walks a contiguous range of the frame's tiles (see k_blur_levels); about 4 096 workgroups = 16 per CU
-            const int blur_grid = getenv("SGX_TUNE_ORB_BLUR_GRID") ? atoi(getenv("SGX_TUNE_ORB_BLUR_GRID")) : 4096;          // tuning tap: target grid size (measured at 512 frames with the round-3 walk: 0.59 / 0.48 / 0.46 ms at 1 024 / 2 048 / 4 096)
+            const int blur_grid = sgx_getenv("SGX_TUNE_ORB_BLUR_GRID") ? atoi(sgx_getenv("SGX_TUNE_ORB_BLUR_GRID")) : 4096;          // tuning tap: target grid size (measured at 512 frames with the round-3 walk: 0.59 / 0.48 / 0.46 ms at 1 024 / 2 048 / 4 096)
             const int parts = std::min(g.nblur_tiles, std::max(1, blur_grid / batch));
             SGX_LAUNCH(k_blur_levels, dim3(parts * batch), dim3(std::min(512, std::max(256, blur_threads))), stream, g, h->d_blur_tiles, d_gray, pitch, h->d_pyr, h->d_blur, batch);
         }
-        static const bool one_per_wave = getenv("SGX_TUNE_ORB_DESC_ONE_PER_WAVE") != nullptr;       // tuning tap: k_orient_desc2 (one keypoint per wave)
+        static const bool one_per_wave = sgx_getenv("SGX_TUNE_ORB_DESC_ONE_PER_WAVE") != nullptr;       // tuning tap: k_orient_desc2 (one keypoint per wave)
         if (one_per_wave)
             SGX_LAUNCH(k_orient_desc2, dim3(g.kp_cap * batch), dim3(64), stream, g, d_gray, pitch, h->d_pyr, h->d_blur, h->d_sel, h->d_sel_count,
                        umax_packed, h->d_pattern, (uint8_t *)d_kps, d_desc, d_count, cap, batch, h->d_status);
@@ -435,14 +438,14 @@ extern "C" int sgx_orb_extract(sgx_orb *h, const uint8_t *gray, int stride, sgx_
     return SGX_OK;
 }
 
-extern "C" int sgx_orb_debug_level_geometry(const sgx_orb *h, int level, int32_t *w, int32_t *hgt, int32_t *stride)
+SGX_TAP int sgx_orb_debug_level_geometry(const sgx_orb *h, int level, int32_t *w, int32_t *hgt, int32_t *stride)
 {
     if (!h || level < 0 || level >= h->g.nlevels) return SGX_ERR_INVALID;
     if (w) *w = h->g.lv[level].w; if (hgt) *hgt = h->g.lv[level].h; if (stride) *stride = h->g.lv[level].stride;
     return SGX_OK;
 }
 
-extern "C" int sgx_orb_debug_read_level(sgx_orb *h, int frame, int level, uint8_t *dst)
+SGX_TAP int sgx_orb_debug_read_level(sgx_orb *h, int frame, int level, uint8_t *dst)
 {
     if (!h || !dst || level < 1 || level >= h->g.nlevels || frame < 0 || frame >= h->cfg.max_batch) return SGX_ERR_INVALID;
     const SgxLevel &L = h->g.lv[level];
@@ -452,7 +455,7 @@ extern "C" int sgx_orb_debug_read_level(sgx_orb *h, int frame, int level, uint8_
     return SGX_OK;
 }
 
-extern "C" int sgx_orb_debug_read_candidates(sgx_orb *h, int frame, int level, int32_t *x, int32_t *y, int32_t *score, int cap, int *n)
+SGX_TAP int sgx_orb_debug_read_candidates(sgx_orb *h, int frame, int level, int32_t *x, int32_t *y, int32_t *score, int cap, int *n)
 {
     if (!h || !n || level < 0 || level >= h->g.nlevels || frame < 0 || frame >= h->cfg.max_batch) return SGX_ERR_INVALID;
     int cnt = 0;
@@ -468,7 +471,7 @@ extern "C" int sgx_orb_debug_read_candidates(sgx_orb *h, int frame, int level, i
 }
 
 // test tap: run k_octree alone on a caller-supplied candidate list for `level` (frame slot 0)
-extern "C" int sgx_orb_debug_run_octree(sgx_orb *h, int level, const uint32_t *packed, int n, uint32_t *out_sel, int cap, int *nsel)
+SGX_TAP int sgx_orb_debug_run_octree(sgx_orb *h, int level, const uint32_t *packed, int n, uint32_t *out_sel, int cap, int *nsel)
 {
     if (!h || !packed || !out_sel || !nsel || level < 0 || level >= h->g.nlevels || n < 0 || n > h->g.lv[level].cand_cap) return SGX_ERR_INVALID;
     const int nl = h->g.nlevels;

@@ -10,6 +10,9 @@
 #include "sgx_prof.h"
 #include "sgx_stage.h"
 #include "../../include/sgx.h"
+#ifdef SGX_DEBUG_TAPS
+#include "../../include/sgx_debug.h"      // test / tuning taps: compiled into tests/taps/libsgx_taps.so and the emulator only
+#endif
 #include <stdio.h>
 #include <string.h>
 #include <vector>
@@ -20,7 +23,7 @@
 static SgxCam po_cam(const sgx_camera *c) { SgxCam k; k.fx = c->fx; k.fy = c->fy; k.cx = c->cx; k.cy = c->cy; k.bf = c->bf; k.minX = c->min_x; k.maxX = c->max_x; k.minY = c->min_y; k.maxY = c->max_y; return k; }
 
 static thread_local int g_po_threads = 0;      // tuning / test tap: 0 = default (256), 64 or 256 = force
-extern "C" int sgx_pose_opt_debug_set_threads(int t) { if (t != 0 && t != 64 && t != 256) return SGX_ERR_INVALID; g_po_threads = t; return SGX_OK; }
+SGX_TAP int sgx_pose_opt_debug_set_threads(int t) { if (t != 0 && t != 64 && t != 256) return SGX_ERR_INVALID; g_po_threads = t; return SGX_OK; }
 
 extern "C" int sgx_pose_optimization_batch_dev(int batch, int cap, const sgx_keypoint *d_keys_un, const float *d_uright, const int32_t *d_n,
                                                 const int32_t *d_mp_index, const uint8_t *d_has_mp, const float *d_mp_xw, int xw_pitch,

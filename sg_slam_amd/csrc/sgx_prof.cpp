@@ -1,6 +1,9 @@
 // sgx_prof.cpp — per-kernel-class HIP-event timing (events recorded on the caller's stream around each launch).
 #include "sgx_prof.h"
 #include "../../include/sgx.h"
+#ifdef SGX_DEBUG_TAPS
+#include "../../include/sgx_debug.h"      // test / tuning taps: compiled into tests/taps/libsgx_taps.so and the emulator only
+#endif
 #include <vector>
 #include <mutex>
 

@@ -11,6 +11,17 @@
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
+
+// Test / tuning taps (include/sgx_debug.h) and the SGX_* environment switches exist only in builds with -DSGX_DEBUG_TAPS (tests/taps/libsgx_taps.so, the emulator):
+// in the product build a tap entry is a file-local function the linker drops and sgx_getenv() is a constant NULL, so every switch folds to its default.
+#ifdef SGX_DEBUG_TAPS
+#define SGX_TAP extern "C"
+static inline const char *sgx_getenv(const char *name) { return getenv(name); }
+#else
+#define SGX_TAP [[maybe_unused]] static
+static inline const char *sgx_getenv(const char *) { return nullptr; }
+#endif
 
 #ifndef SGX_EMU
 // ------------------------------------------------------------------ device build (gfx950)

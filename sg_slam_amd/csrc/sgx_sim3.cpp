@@ -2,6 +2,9 @@
 #include "sgx_sim3_kernels.h"
 #include "sgx_stage.h"
 #include "../../include/sgx.h"
+#ifdef SGX_DEBUG_TAPS
+#include "../../include/sgx_debug.h"      // test / tuning taps: compiled into tests/taps/libsgx_taps.so and the emulator only
+#endif
 #include <stdio.h>
 #include <string.h>
 

@@ -2,6 +2,9 @@
 // SetRansacParameters and the resumable iterate(); the hypotheses of a call run on the device (sgx_sim3solver_kernels.h).
 #include "sgx_sim3solver_kernels.h"
 #include "../../include/sgx.h"
+#ifdef SGX_DEBUG_TAPS
+#include "../../include/sgx_debug.h"      // test / tuning taps: compiled into tests/taps/libsgx_taps.so and the emulator only
+#endif
 #include <math.h>
 #include <stdio.h>
 #include <string.h>

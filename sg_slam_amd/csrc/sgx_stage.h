@@ -6,6 +6,9 @@
 #pragma once
 #include "sgx_rt.h"
 #include "../../include/sgx.h"
+#ifdef SGX_DEBUG_TAPS
+#include "../../include/sgx_debug.h"      // test / tuning taps: compiled into tests/taps/libsgx_taps.so and the emulator only
+#endif
 #include <vector>
 
 struct SgxStage {

@@ -17,6 +17,9 @@
 // ORB_SLAM2::Tracking's state machine (keyframe decisions, relocalisation and the map stay with the caller).
 #include "sgx_rt.h"
 #include "../../include/sgx.h"
+#ifdef SGX_DEBUG_TAPS
+#include "../../include/sgx_debug.h"      // test / tuning taps: compiled into tests/taps/libsgx_taps.so and the emulator only
+#endif
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -98,8 +101,10 @@ struct sgx_tracker {
     sgx_ev ev_extract[3] = {}, ev_track[3] = {}, ev_pack[3] = {}, ev_det[2] = {}, ev_up[2] = {}, ev_in = {};
     // ev_consumed[c]: every reader of the INPUT images of the step that used frame slot c (extraction stream: ORB, LK pyramid, stereo-from-RGBD; detector stream: the forward) is done.
     // ev_up[slot]: the H2D copies out of pinned staging slot `slot` are done (the caller may refill it).  ev_step: end of a non-pipelined step on the caller's stream.
-    sgx_ev ev_consumed[3] = {}, ev_step = {};
-    bool consumed_valid[3] = { false, false, false }, up_pending[2] = { false, false };
+    // ev_det_read[c]: the detector stream's reader of the same step (the forward reads d_bgr).  Kept apart from ev_consumed so that the extraction stream never waits for the
+    // detector only to publish "inputs consumed" (with dynamic_mask == 0 that serialised ORB / LK of frame i + 1 behind the forward of frame i).
+    sgx_ev ev_consumed[3] = {}, ev_det_read[3] = {}, ev_step = {};
+    bool consumed_valid[3] = { false, false, false }, det_read_valid[3] = { false, false, false }, up_pending[2] = { false, false };
     sgx_st last_stream = nullptr;           // non-pipelined mode: the caller stream of the last step (snapshots and the record pack are ordered behind it)
     bool pack_pending[3] = { false, false, false };
     int frame_idx = 0, cur = 0;
@@ -123,7 +128,7 @@ extern "C" void sgx_tracker_destroy(sgx_tracker *t)
     if (t->flow) sgx_flow_destroy(t->flow);
     for (void *p : t->dev) (void)hipFree(p);
     for (void *p : t->pinned) host_free(p);
-    for (int i = 0; i < 3; i++) { ev_destroy(t->ev_extract[i]); ev_destroy(t->ev_track[i]); ev_destroy(t->ev_pack[i]); ev_destroy(t->ev_consumed[i]); }
+    for (int i = 0; i < 3; i++) { ev_destroy(t->ev_extract[i]); ev_destroy(t->ev_track[i]); ev_destroy(t->ev_pack[i]); ev_destroy(t->ev_consumed[i]); ev_destroy(t->ev_det_read[i]); }
     ev_destroy(t->ev_step);
     for (int i = 0; i < 2; i++) { ev_destroy(t->ev_det[i]); ev_destroy(t->ev_up[i]); }
     ev_destroy(t->ev_in);
@@ -178,16 +183,17 @@ extern "C" int sgx_tracker_create(const sgx_tracker_config *cfg, sgx_det *detect
     if (t->pipelined) {
         // stream priorities (bit 0 extraction, 1 tracking, 2 detector): the tracking stream is the latency-critical one for a single camera and gets the high priority by default;
         // SGX_TRK_PRIO is the tuning tap
-        static const int prio = getenv("SGX_TRK_PRIO") ? atoi(getenv("SGX_TRK_PRIO")) : 2;
+        static const int prio = sgx_getenv("SGX_TRK_PRIO") ? atoi(sgx_getenv("SGX_TRK_PRIO")) : 2;
         // SGX_TRK_SHARE (tuning tap): 1 = tracking on the DETECTOR's stream (det(t), then track(t) behind it), 2 = tracking on the EXTRACTION stream (the round-1 serial order)
-        static const int share = getenv("SGX_TRK_SHARE") ? atoi(getenv("SGX_TRK_SHARE")) : 0;
+        static const int share = sgx_getenv("SGX_TRK_SHARE") ? atoi(sgx_getenv("SGX_TRK_SHARE")) : 0;
         if (st_create(&t->sE, prio & 1) || st_create(&t->sD, (prio >> 2) & 1)) FAIL(SGX_ERR_DEVICE);
         if (share == 1) { t->sT = t->sD; t->shared_T = true; } else if (share == 2) { t->sT = t->sE; t->shared_T = true; }
         else if (st_create(&t->sT, (prio >> 1) & 1)) FAIL(SGX_ERR_DEVICE);
-        for (int i = 0; i < 3; i++) if (ev_create(&t->ev_extract[i]) || ev_create(&t->ev_track[i]) || ev_create(&t->ev_pack[i]) || ev_create(&t->ev_consumed[i])) FAIL(SGX_ERR_DEVICE);
-        for (int i = 0; i < 2; i++) if (ev_create(&t->ev_det[i]) || ev_create(&t->ev_up[i])) FAIL(SGX_ERR_DEVICE);
+        for (int i = 0; i < 3; i++) if (ev_create(&t->ev_extract[i]) || ev_create(&t->ev_track[i]) || ev_create(&t->ev_pack[i]) || ev_create(&t->ev_consumed[i]) || ev_create(&t->ev_det_read[i])) FAIL(SGX_ERR_DEVICE);
+        for (int i = 0; i < 2; i++) if (ev_create(&t->ev_det[i])) FAIL(SGX_ERR_DEVICE);
         if (ev_create(&t->ev_in)) FAIL(SGX_ERR_DEVICE);
     } else if (ev_create(&t->ev_step)) FAIL(SGX_ERR_DEVICE);
+    for (int i = 0; i < 2; i++) if (ev_create(&t->ev_up[i])) FAIL(SGX_ERR_DEVICE);      // both modes: the refill contract of sgx_tracker_host_buffers
 #undef FAIL
     (void)hipDeviceSynchronize();           // the zero-fills above ran on the null stream, which the tracker's non-blocking streams do not wait for
     *out = t;
@@ -221,6 +227,7 @@ extern "C" int sgx_tracker_step_dev(sgx_tracker *t, const uint8_t *d_gray, int g
         st_wait(sE, t->ev_in); st_wait(sD, t->ev_in);
         if (i == 0) st_wait(sT, t->ev_in);
         if (t->consumed_valid[c]) st_wait((sgx_st)caller_stream, t->ev_consumed[c]);      // the inputs of step i - 3: later work on the caller's stream may overwrite them
+        if (t->det_read_valid[c]) { st_wait((sgx_st)caller_stream, t->ev_det_read[c]); t->det_read_valid[c] = false; }
         if (i >= 2) st_wait(sE, t->ev_track[(i - 2) % 3]);                // slot c was "last" of step i - 2 + 1: its readers must be done
         if (t->pack_pending[c]) { st_wait(sE, t->ev_pack[c]); t->pack_pending[c] = false; }      // ... and its record must have been packed for the gather
     }
@@ -230,7 +237,7 @@ extern "C" int sgx_tracker_step_dev(sgx_tracker *t, const uint8_t *d_gray, int g
     if (with_det) {
         if (t->pipelined && i >= 2) st_wait(sD, t->ev_extract[(i - 2) % 3]);      // result set b was last read by the mask / pre-box copy of step i - 2 (extraction stream)
         TRK_CHECK(sgx_det_detect_batch_dev(t->det, d_bgr, bgr_pitch, S, t->det_res[b], t->det_boxes[b], t->det_nb[b], MB, t->det_have[b], sD));
-        if (t->pipelined) ev_record(t->ev_det[b], sD);
+        if (t->pipelined) { ev_record(t->ev_det[b], sD); ev_record(t->ev_det_read[c], sD); t->det_read_valid[c] = true; }
     }
     const float *boxes = with_det ? t->det_boxes[b] : t->no_boxes; const int32_t *nboxes = with_det ? t->det_nb[b] : t->no_nboxes, *have = with_det ? t->det_have[b] : t->no_have;
     // ---- E: Frame::ExtractORB, then Frame::RmDynamicPointWithSemanticAndGeometry, then ComputeStereoFromRGBD
@@ -255,9 +262,8 @@ extern "C" int sgx_tracker_step_dev(sgx_tracker *t, const uint8_t *d_gray, int g
     TRK_CHECK(sgx_frame_stereo_from_rgbd_batch_dev(S, cap, t->keys[c], t->n[c], d_depth, cf.width, cf.height, cf.depth_map_factor, cf.cam.bf, t->uright[c], t->zdepth[c], sE));
     if (t->pipelined) {
         ev_record(t->ev_extract[c], sE); st_wait(sT, t->ev_extract[c]);
-        // "inputs consumed": the extraction stream's readers are behind us; the detector's forward read d_bgr on its own stream.  With the mask on, sE already waited for
-        // ev_det before the mask; otherwise (first frame, dynamic_mask == 0) the wait is added here, behind ev_extract so that the tracking stream is not held back.
-        if (with_det) st_wait(sE, t->ev_det[b]);
+        // "inputs consumed" by the extraction stream's readers; the detector's forward read d_bgr on its own stream and has its own event (ev_det_read[c]): whoever wants to
+        // overwrite the inputs waits for both, the extraction stream for neither
         ev_record(t->ev_consumed[c], sE); t->consumed_valid[c] = true;
     }
     // ---- T: Tracking::TrackWithMotionModel (Tracking.cc:906-967)
@@ -316,12 +322,12 @@ extern "C" int sgx_tracker_step_host(sgx_tracker *t, int slot, int rgb_order)
     if (!t || slot < 0 || slot > 1 || !t->h_bgr[0]) return SGX_ERR_INVALID;
     const int S = t->S, W = t->cfg.width, H = t->cfg.height;
     sgx_st sU = t->pipelined ? t->sU : (sgx_st) nullptr;
-    // the device staging slot was read by the step issued two calls ago, on the extraction AND the detector stream: ev_consumed covers both (ev_extract alone does not
-    // when that step ran without the mask's detector wait — first frame, dynamic_mask == 0)
-    if (t->pipelined && t->frame_idx >= 2) st_wait(sU, t->ev_consumed[(t->frame_idx - 2) % 3]);
+    // the device staging slot was read by the step issued two calls ago, on the extraction AND the detector stream: ev_consumed + ev_det_read (ev_extract alone does not
+    // cover the detector when that step ran without the mask's detector wait — first frame, dynamic_mask == 0)
+    if (t->pipelined && t->frame_idx >= 2) { const int p = (t->frame_idx - 2) % 3; st_wait(sU, t->ev_consumed[p]); if (t->det_read_valid[p]) st_wait(sU, t->ev_det_read[p]); }
     TRK_HIP(hipMemcpyAsync(t->d_bgr[slot], t->h_bgr[slot], (size_t)S * H * t->bgr_pitch, hipMemcpyHostToDevice, sU));
     TRK_HIP(hipMemcpyAsync(t->d_depth[slot], t->h_depth[slot], (size_t)S * H * W * 2, hipMemcpyHostToDevice, sU));
-    if (t->pipelined) { ev_record(t->ev_up[slot], sU); t->up_pending[slot] = true; }
+    ev_record(t->ev_up[slot], sU); t->up_pending[slot] = true;          // non-pipelined too: the copies out of pinned memory on the null stream are asynchronous to the host
     TRK_CHECK(sgx_frame_gray_from_color_batch_dev(S, W, H, t->d_bgr[slot], t->bgr_pitch, 3, rgb_order ? 0 : 1, t->d_gray[slot], W, sU));
     return sgx_tracker_step_dev(t, t->d_gray[slot], W, t->d_depth[slot], t->det ? t->d_bgr[slot] : nullptr, t->bgr_pitch, sU);
 }
@@ -335,6 +341,7 @@ extern "C" int sgx_tracker_wait_inputs(sgx_tracker *t, int steps_back)
     if (!t->pipelined) { TRK_HIP(hipDeviceSynchronize()); return SGX_OK; }
     const int c = (t->frame_idx - 1 - steps_back) % 3;
     if (t->consumed_valid[c]) ev_sync(t->ev_consumed[c]);
+    if (t->det_read_valid[c]) ev_sync(t->ev_det_read[c]);
     return SGX_OK;
 }
 

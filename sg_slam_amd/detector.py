@@ -21,15 +21,18 @@ class Detector2D:
             bin_bytes = open(bin_path or './Thirdparty/ncnn_model/mobilenetv3_ssdlite_voc.bin', 'rb').read()      # Detector2D.cc:25
         self._bin = bin_bytes
         h = C.c_void_p()
-        self.lib.dll.sgx_det_debug_set_fusion(1 if fuse else 0)      # fuse=False: one kernel per ncnn layer, every blob kept (tests)
-        self.lib.dll.sgx_det_debug_set_legacy_kernels(1 if legacy_kernels else 0)      # simple reference kernels instead of the tuned ones (tests)
-        self.lib.dll.sgx_det_debug_set_block_fusion(1 if block_fusion else 0)          # opt-in: expand -> depthwise -> project as one kernel (tests / tuning)
-        self.lib.dll.sgx_det_debug_set_irb(-1 if irb is None else (2 if irb is True else int(irb)))    # inverted-residual blocks / heads as one matrix-core kernel each: None = default (the shapes where it wins), True / 2 = every supported shape, False / 0 = off
-        # gemm: None = the library's default, 'f32' = exact fp32 matrix products (bit-identical to the per-layer reference kernels), 'bf16x3' = three-term bf16 split on the bf16 matrix pipes
-        self.lib.dll.sgx_det_debug_set_gemm(-1 if gemm is None else (0 if gemm in (0, 'f32') else 1))
+        # plan selection = test / tuning taps (include/sgx_debug.h, libsgx_taps.so / emulator only): fuse=False one kernel per ncnn layer with every blob kept; legacy_kernels the
+        # simple reference kernels; block_fusion the opt-in k_fused_block plan; irb None = default (the shapes where the matrix-core block kernel wins), True / 2 = every supported
+        # shape, False / 0 = off; gemm None = default, 'f32' = exact fp32 matrix products, 'bf16x3' = three-term bf16 split on the bf16 matrix pipes
+        taps = dict(fusion=1 if fuse else 0, legacy_kernels=1 if legacy_kernels else 0, block_fusion=1 if block_fusion else 0,
+                    irb=-1 if irb is None else (2 if irb is True else int(irb)), gemm=-1 if gemm is None else (0 if gemm in (0, 'f32') else 1))
+        default = dict(fusion=1, legacy_kernels=0, block_fusion=0, irb=-1, gemm=-1)
+        if taps != default or self.lib.has_taps:
+            for k, v in taps.items(): self.lib.tap('sgx_det_debug_set_' + k)(v)
         self.lib.check(self.lib.dll.sgx_det_create(param_text.encode(), bin_bytes, len(bin_bytes), width, height, max_batch,
                                                    float(detection_confidence_threshold), float(dynamic_detection_confidence_threshold), C.byref(h)), 'sgx_det_create')
-        self.lib.dll.sgx_det_debug_set_fusion(1); self.lib.dll.sgx_det_debug_set_legacy_kernels(0); self.lib.dll.sgx_det_debug_set_block_fusion(0); self.lib.dll.sgx_det_debug_set_irb(-1); self.lib.dll.sgx_det_debug_set_gemm(-1)
+        if self.lib.has_taps:
+            for k, v in default.items(): self.lib.tap('sgx_det_debug_set_' + k)(v)
         self.h = h; self.width, self.height, self.max_batch = width, height, max_batch
         npri, ncls, nk = C.c_int32(), C.c_int32(), C.c_int32(); g = C.c_double()
         self.lib.check(self.lib.dll.sgx_det_info(self.h, C.byref(npri), C.byref(ncls), C.byref(nk), C.byref(g)))
@@ -73,15 +76,15 @@ class Detector2D:
 
     def has_blob(self, name):
         n = C.c_int(0)
-        return self.lib.dll.sgx_det_debug_read_blob(self.h, name.encode(), 0, None, 0, C.byref(n)) == 0
+        return self.lib.tap('sgx_det_debug_read_blob')(self.h, name.encode(), 0, None, 0, C.byref(n)) == 0
 
     def time_ops(self, d_img, batch, reps=5):
         """[(description, ms per launch)] of every plan step on device images (tuning tap)"""
         ms = np.zeros(self.num_kernels, 'f4'); n = C.c_int(0)
-        self.lib.check(self.lib.dll.sgx_det_debug_time_ops(self.h, _vp(d_img), self.width * 3, batch, reps, _vp(ms), len(ms), C.byref(n)))
+        self.lib.check(self.lib.tap('sgx_det_debug_time_ops')(self.h, _vp(d_img), self.width * 3, batch, reps, _vp(ms), len(ms), C.byref(n)))
         out = []
         for i in range(n.value):
-            buf = C.create_string_buffer(256); self.lib.check(self.lib.dll.sgx_det_debug_op_desc(self.h, i, buf, 256)); out.append((buf.value.decode(), float(ms[i])))
+            buf = C.create_string_buffer(256); self.lib.check(self.lib.dll.sgx_det_plan_step(self.h, i, buf, 256)); out.append((buf.value.decode(), float(ms[i])))
         return out
 
     def op_descriptions(self):
@@ -89,13 +92,13 @@ class Detector2D:
         out = []
         for i in range(self.num_kernels):
             buf = C.create_string_buffer(256)
-            if self.lib.dll.sgx_det_debug_op_desc(self.h, i, buf, 256) != 0: break
+            if self.lib.dll.sgx_det_plan_step(self.h, i, buf, 256) != 0: break
             out.append(buf.value.decode())
         return out
 
     def debug_blob(self, name, image=0):
         n = C.c_int(0)
-        self.lib.check(self.lib.dll.sgx_det_debug_read_blob(self.h, name.encode(), image, None, 0, C.byref(n)))
+        self.lib.check(self.lib.tap('sgx_det_debug_read_blob')(self.h, name.encode(), image, None, 0, C.byref(n)))
         out = np.zeros(n.value, 'f4')
-        self.lib.check(self.lib.dll.sgx_det_debug_read_blob(self.h, name.encode(), image, _vp(out), n.value, C.byref(n)))
+        self.lib.check(self.lib.tap('sgx_det_debug_read_blob')(self.h, name.encode(), image, _vp(out), n.value, C.byref(n)))
         return out

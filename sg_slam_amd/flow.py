@@ -54,9 +54,9 @@ class OpticalFlowLK:
 
     def debug_level(self, slot, frame, level):
         w, h = C.c_int32(), C.c_int32()
-        self.lib.check(self.lib.dll.sgx_flow_debug_level_size(self.h, level, C.byref(w), C.byref(h)))
+        self.lib.check(self.lib.tap('sgx_flow_debug_level_size')(self.h, level, C.byref(w), C.byref(h)))
         img = np.zeros((h.value, w.value), np.uint8)
-        self.lib.check(self.lib.dll.sgx_flow_debug_read_level(self.h, slot, frame, level, _vp(img)), 'flow debug_read_level')
+        self.lib.check(self.lib.tap('sgx_flow_debug_read_level')(self.h, slot, frame, level, _vp(img)), 'flow debug_read_level')
         return img
 
 

@@ -65,20 +65,20 @@ class ORBextractor:
     # diagnostic taps
     def debug_level(self, frame, level):
         w, h, s = C.c_int32(), C.c_int32(), C.c_int32()
-        self.lib.check(self.lib.dll.sgx_orb_debug_level_geometry(self.h, level, C.byref(w), C.byref(h), C.byref(s)))
+        self.lib.check(self.lib.tap('sgx_orb_debug_level_geometry')(self.h, level, C.byref(w), C.byref(h), C.byref(s)))
         out = np.zeros((h.value, w.value), np.uint8)
-        self.lib.check(self.lib.dll.sgx_orb_debug_read_level(self.h, frame, level, _vp(out)), 'debug_read_level')
+        self.lib.check(self.lib.tap('sgx_orb_debug_read_level')(self.h, frame, level, _vp(out)), 'debug_read_level')
         return out
 
     def debug_candidates(self, frame, level, cap=8192):
         x = np.zeros(cap, 'i4'); y = np.zeros(cap, 'i4'); s = np.zeros(cap, 'i4'); n = C.c_int(0)
-        self.lib.check(self.lib.dll.sgx_orb_debug_read_candidates(self.h, frame, level, _vp(x), _vp(y), _vp(s), cap, C.byref(n)))
+        self.lib.check(self.lib.tap('sgx_orb_debug_read_candidates')(self.h, frame, level, _vp(x), _vp(y), _vp(s), cap, C.byref(n)))
         return x[:n.value].copy(), y[:n.value].copy(), s[:n.value].copy()
 
     def debug_run_octree(self, level, x, y, score):
         packed = (np.asarray(x, np.uint32) | (np.asarray(y, np.uint32) << 12) | (np.asarray(score, np.uint32) << 24)).astype(np.uint32)
         packed = np.ascontiguousarray(packed)
         out = np.zeros(2048, np.uint32); n = C.c_int(0)
-        self.lib.check(self.lib.dll.sgx_orb_debug_run_octree(self.h, level, _vp(packed), len(packed), _vp(out), 2048, C.byref(n)), 'debug_run_octree')
+        self.lib.check(self.lib.tap('sgx_orb_debug_run_octree')(self.h, level, _vp(packed), len(packed), _vp(out), 2048, C.byref(n)), 'debug_run_octree')
         o = out[:n.value]
         return (o & 0xFFF).astype('i4'), ((o >> 12) & 0xFFF).astype('i4'), (o >> 24).astype('i4')

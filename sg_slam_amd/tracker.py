@@ -116,7 +116,7 @@ class TrackerBatch:
         """prev_xy[s, i] = A[s] * (x, y, 1) of keypoint i: the stand-in for the LK tracker on synthetic streams (see synth.flow_affine);
         `shift` (S,2) moves the previous position of keypoints inside the first box of `boxes` (an independently moving object)."""
         L = self.lib
-        L.check(L.dll.sgx_debug_flow_affine_batch_dev(self.S, self.cap, _vp(keys_raw), _vp(self.rn), _vp(A), _vp(shift), _vp(boxes if shift is not None else None),
+        L.check(L.tap('sgx_debug_flow_affine_batch_dev')(self.S, self.cap, _vp(keys_raw), _vp(self.rn), _vp(A), _vp(shift), _vp(boxes if shift is not None else None),
                                                       self.max_boxes, _vp(self.prev_xy), st), 'flow affine')
 
     def step(self, d_gray, d_depth, stream=None, gray_pitch=None, mask=None):

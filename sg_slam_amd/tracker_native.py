@@ -87,3 +87,49 @@ class TrackerNative:
 
     def last_status(self, stream=None):
         self.lib.check(self.lib.dll.sgx_orb_last_status(self.lib.dll.sgx_tracker_extractor(self.h), None if stream is None else C.c_void_p(stream)))
+
+
+class TrackerGroups:
+    """G independent TrackerNative pipelines over contiguous slices of the S streams of a GPU, behind the interface of one: a step issues the G slices one after the other, each on
+    its own three HIP streams, so the detector graph of one slice runs beside the extraction / tracking kernels of another (streams are independent: SURVEY.md §8(e) shards at
+    stream granularity, inside a GPU as well as across GPUs).  Results are bit-identical to one pipeline over all S streams (every kernel works per frame)."""
+
+    def __init__(self, lib, streams, cam, groups, make_detector=None, **kw):
+        assert streams % groups == 0, 'streams must divide into equal groups'
+        self.lib, self.S, self.G, self.Sg = lib, int(streams), int(groups), int(streams) // int(groups)
+        self.detectors = [make_detector(self.Sg) if make_detector else None for _ in range(self.G)]
+        self.tr = [TrackerNative(lib, self.Sg, cam, detector=d, **kw) for d in self.detectors]
+        self.cap, self.rec_bytes, self.max_boxes = self.tr[0].cap, self.tr[0].rec_bytes, self.tr[0].max_boxes
+        self.W, self.H = self.tr[0].W, self.tr[0].H
+
+    def _sl(self, g, a):
+        return None if a is None else a[g * self.Sg:(g + 1) * self.Sg]
+
+    def set_initial_pose(self, Tcw_host):
+        T = np.ascontiguousarray(Tcw_host, 'f4').reshape(self.S, 16)
+        for g, t in enumerate(self.tr): t.set_initial_pose(T[g * self.Sg:(g + 1) * self.Sg])
+
+    def step(self, d_gray, d_depth, d_bgr=None, stream=None, **kw):
+        for g, t in enumerate(self.tr): t.step(self._sl(g, d_gray), self._sl(g, d_depth), d_bgr=self._sl(g, d_bgr), stream=stream, **kw)
+
+    def synchronize(self):
+        for t in self.tr: t.synchronize()
+
+    def read(self):
+        parts = [t.read() for t in self.tr]
+        return {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+
+    def snapshot_pose(self, d_out):
+        for g, t in enumerate(self.tr): t.snapshot_pose(self._sl(g, d_out))
+
+    def snapshot_boxes(self, stream_index, d_boxes, d_nboxes):
+        self.tr[stream_index // self.Sg].snapshot_boxes(stream_index % self.Sg, d_boxes, d_nboxes)
+
+    def pack_records(self, d_records, stream=None):
+        for g, t in enumerate(self.tr): t.pack_records(self._sl(g, d_records), stream=stream)
+
+    def last_status(self, stream=None):
+        for t in self.tr: t.last_status(stream=stream)
+
+    def close(self):
+        for t in self.tr: t.close()

@@ -48,7 +48,22 @@ def gpulib():
         pytest.skip('no GPU')
     import sg_slam_amd
     lib = sg_slam_amd.load()
-    assert 'gfx950' in lib.version()
+    assert 'gfx950' in lib.version() and not lib.has_taps
+    return lib
+
+
+@pytest.fixture(scope='session')
+def gpulib_taps():
+    """The product sources built with -DSGX_DEBUG_TAPS (tests/taps/libsgx_taps.so): the same kernels plus the entries of include/sgx_debug.h (blob / pyramid read-backs,
+    plan selection) and the SGX_* environment switches, which the product library does not have.  For the GPU tests that look INSIDE a stage; tests only."""
+    if not HAVE_GPU:
+        pytest.skip('no GPU')
+    from sg_slam_amd.capi import SgxLib
+    so = os.path.join(ROOT, 'tests', 'taps', 'libsgx_taps.so')
+    if not os.path.exists(so):
+        pytest.fail('tests/taps/libsgx_taps.so not built (make -C sg_slam_amd/csrc taps)')
+    lib = SgxLib(so)
+    assert 'gfx950' in lib.version() and lib.has_taps
     return lib
 
 

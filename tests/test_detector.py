@@ -1,10 +1,12 @@
 """Detector2D forward + post-processing + dynamic-feature mask: emulator vs the numpy oracle on the shipped graph with
 synthetic weights (the reference's .bin is absent).
 
-fp32 tolerance.  The reference computes in fp32 with ncnn's (unknowable) summation order; with synthetic weights the
-activations reach ~1e4 and pass through ~100 layers with clips and gates, so two correct fp32 implementations drift apart by far
-more than 1 ulp.  The yardstick is therefore a float64 run of the oracle: the device result must be as close to it as the
-oracle's own fp32 run is (within a factor 4), per tapped blob; the first layers (little accumulated drift) must agree to 1e-5."""
+Weights (round 5): the He draw followed by a synthetic batch-norm fold per convolution (sg_slam_amd.synth._calibrate) — unit-variance blobs, active gates,
+separated class scores.  On that network the oracle's own fp32 run is <= 1e-5 from its float64 run at every blob (asserted below), so the criteria have teeth:
+  * every tapped blob of the device is within max(2 x the oracle's own fp32 drift, 2e-6) of the float64 run (run_compare);
+  * DetectionOutput rows of the device equal the oracle's fp32 rows — same labels in the same order, scores / boxes to 1e-5 (run_compare, run_rows_identical);
+  * every plan step in isolation: the float64 oracle evaluated on the device's OWN step inputs gives the device's step output to 2e-6 (fp32 products) /
+    4e-6 (bf16x3 products) of the blob's magnitude (run_steps_isolated) — covers every k_conv_pw3 / k_irb / k_fused_block2 instantiation of the plan."""
 import os
 import numpy as np
 import pytest
@@ -64,7 +66,8 @@ def run_compare(lib, model, seeds=(0, 1), fuse=False, gemm=None, report=None):
             got = det.debug_blob(name, b); ref = np.asarray(blobs64[name]).reshape(-1); np32 = np.asarray(blobs[name], np.float64).reshape(-1)
             e_dev, e_np = rel_err(got.astype(np.float64), ref), rel_err(np32, ref)
             if report is not None: report[(s, name)] = (e_dev, e_np)
-            assert got.shape == ref.shape and e_dev <= max(4 * e_np, 1e-5), (name, e_dev, e_np)
+            assert e_np <= 1e-5, (name, e_np)                         # the calibrated network is well conditioned: the oracle's own fp32 run stays at rounding level
+            assert got.shape == ref.shape and e_dev <= max(2 * e_np, 2e-6), (name, e_dev, e_np)
         r = res[b]
         got_rows = np.array([[d.label, d.score, d.xmin, d.ymin, d.xmax, d.ymax] for d in r.raw[:r.n_raw]], np.float32).reshape(-1, 6)
         # post-processing (DetectionOutput + Detector2D::detect filtering) checked exactly on the DEVICE's own loc/conf
@@ -72,11 +75,78 @@ def run_compare(lib, model, seeds=(0, 1), fuse=False, gemm=None, report=None):
         exp_rows = D.detection_output(det.debug_blob('mbox_loc', b), det.debug_blob('mbox_conf_softmax', b), blobs['mbox_priorbox'], p)
         assert got_rows.shape == exp_rows.shape and (got_rows[:, 0] == exp_rows[:, 0]).all()
         assert np.abs(got_rows[:, 1:] - exp_rows[:, 1:]).max() < 1e-5
+        # ... and END TO END against the oracle's own fp32 run: same detections in the same order (what feeds Detector2D::detect's filter and the mask)
+        assert got_rows.shape == out.shape and len(out) > 0 and (got_rows[:, 0] == out[:, 0]).all() and np.abs(got_rows[:, 1:] - out[:, 1:]).max() < 1e-5
         keep = [v for v in exp_rows if v[1] > np.float32(0.90) or (v[1] > np.float32(0.01) and int(v[0]) == 15)]
         assert r.n_objects == sum(int(v[0]) != 15 for v in keep) and r.n_map_boxes == sum(int(v[0]) == 15 for v in keep)
         assert r.n_rm_boxes == sum(int(v[0]) == 15 and v[1] > np.float32(0.2) for v in keep)
         assert bool(r.have_dynamic_for_mapping) == (r.n_map_boxes > 0) and bool(r.have_dynamic_for_rm_feature) == (r.n_rm_boxes > 0)
     det.close()
+
+
+def device_rows(res, b):
+    r = res[b]
+    return np.array([[d.label, d.score, d.xmin, d.ymin, d.xmax, d.ymax] for d in r.raw[:r.n_raw]], np.float32).reshape(-1, 6)
+
+
+def rows_identical(a, b, tol=1e-5):
+    return a.shape == b.shape and bool((a[:, 0] == b[:, 0]).all()) and (len(a) == 0 or float(np.abs(a[:, 1:] - b[:, 1:]).max()) < tol)
+
+
+def run_rows_identical(lib, model, seeds=tuple(range(8)), gemms=('f32', 'bf16x3'), plans=(None,)):
+    """VERDICT r4 next #1b — the condition under which bf16x3 may be the default: DetectionOutput rows (label, order, score / box <= 1e-5) IDENTICAL between the oracle's
+    fp32 run, the device's exact-fp32 plan and the device's bf16x3 plan, on >= 8 images.  Also the filter outputs of Detector2D::detect (objects, person boxes)."""
+    layers, W, blob = model
+    imgs = np.stack([make_image(s) for s in seeds])
+    ref = [D.forward(layers, W, D.preprocess(im))[0] for im in imgs]
+    refd = [D.detect(layers, W, im) for im in imgs] if len(seeds) <= 2 else None
+    n_person = 0
+    for gemm in gemms:
+        for irb in plans:
+            det = Detector2D(0.90, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=len(seeds), lib=lib, fuse=True, irb=irb, gemm=gemm)
+            assert gemm is None or det.gemm == gemm
+            res = det.detect_batch(imgs)
+            for b in range(len(seeds)):
+                got = device_rows(res, b)
+                assert len(ref[b]) >= 20 and rows_identical(got, ref[b]), (gemm, irb, seeds[b], got[:4], ref[b][:4])
+                n_person += res[b].n_rm_boxes
+            det.close()
+    assert n_person > 0                         # person boxes (what the dynamic-feature mask consumes) are among the compared rows
+    return n_person
+
+
+def run_steps_isolated(lib, model, seed=2, gemm=None, irb=None, fuse=True, tol=None, block_fusion=False):
+    """VERDICT r4 next #1c: for EVERY plan step, the float64 oracle evaluated on the device's own step inputs (the nearest device-resident blobs upstream) must give the
+    device's step output to tol x max|out|: 2e-6 for fp32 matrix products, 4e-6 for bf16x3 (dropped terms <= 3 x 2^-24 |a||b|).  A kernel bug in ONE k_conv_pw3 / k_irb /
+    k_fused_block2 instantiation cannot hide behind accumulated drift: each step is judged on its own inputs."""
+    layers, W, blob = model
+    det = Detector2D(0.90, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=1, lib=lib, fuse=fuse, irb=irb, gemm=gemm, block_fusion=block_fusion)
+    if tol is None: tol = 4e-6 if det.gemm == 'bf16x3' else 2e-6
+    img = make_image(seed)
+    det.detect_batch(img[None])
+    x = D.preprocess(img)
+    _, blobs64 = D.forward(layers, W, x, dt=np.float64)
+    shapes = {k: np.asarray(v).shape for k, v in blobs64.items()}
+    names = [o for L in layers for o in L['outs'] if L['type'] not in ('Input', 'MemoryData', 'PriorBox', 'DetectionOutput')]
+    producer = {o: L for L in layers for o in L['outs']}
+    given = {'input': x}
+    for nm in names:
+        if producer[nm]['type'] in ('Permute', 'Flatten'): continue      # layout-only layers: in the fused plans the head kernels store HWC straight into the concat buffer and these names alias a slice of it
+        if det.has_blob(nm):
+            v = det.debug_blob(nm, 0)
+            if v.size == int(np.prod(shapes[nm])): given[nm] = v
+    targets = [nm for nm in given if nm != 'input' and producer[nm]['type'] not in ('Split', 'Reshape')]
+    assert len(targets) >= det.num_kernels - 13, (len(targets), det.num_kernels)       # 12 Permute steps + the pre-processing have no target of their own
+    ref = D.forward_cut(layers, W, given, shapes, targets)
+    worst = {}
+    for nm in targets:
+        r = np.asarray(ref[nm]).reshape(-1); g = given[nm].astype(np.float64)
+        worst[nm] = float(np.abs(g - r).max() / max(np.abs(r).max(), 1e-30))
+    descs = det.op_descriptions()
+    det.close()
+    bad = {nm: e for nm, e in worst.items() if not e <= tol}
+    assert not bad, (det.gemm, irb, tol, bad)            # every failing step at once (one GPU run names them all)
+    return worst, descs
 
 
 def test_detector_emu_matches_oracle(emu, model):
@@ -92,6 +162,18 @@ def test_detector_emu_bf16x3_plan_matches_oracle(emu, model):
 
 def test_detector_emu_fused_matches_oracle(emu, model):
     run_compare(emu, model, seeds=(0,), fuse=True)
+
+
+def test_detector_emu_rows_identical_to_oracle(emu, model):
+    run_rows_identical(emu, model, seeds=(0, 1), gemms=('f32', 'bf16x3'))
+
+
+def test_detector_emu_steps_isolated(emu, model):
+    """the emulator models the block kernels' arithmetic order on the host (no MFMA): the per-step criterion itself is exercised here, the device kernels on the GPU tier"""
+    for gemm, fuse in (('f32', True), ('bf16x3', True), ('f32', False)):
+        worst, _ = run_steps_isolated(emu, model, gemm=gemm, fuse=fuse)
+        assert len(worst) >= 30
+        print(gemm, fuse, len(worst), 'steps, worst', max(worst.items(), key=lambda kv: kv[1]))
 
 
 def run_fused_equals_unfused(lib, model):
@@ -114,19 +196,10 @@ def run_fused_equals_unfused(lib, model):
             assert (a == b).all()
 
 
-def matched_rows(ra, rb, tol=1e-3):
-    """share of the rows of ra (label, score, box) that have a counterpart in rb with the same label and score / box within tol"""
-    if len(ra) == 0: return 1.0 if len(rb) == 0 else 0.0
-    hit = 0
-    for r in ra:
-        c = rb[rb[:, 0] == r[0]]
-        if len(c) and (np.abs(c[:, 1:] - r[1:]).max(1) < tol).any(): hit += 1
-    return hit / len(ra)
-
-
 def run_bf16x3_against_f32(lib, model, seeds=(0, 1, 3, 4)):
-    """VERDICT r3 'next round' #2: bf16x3 may be the default only if, blob by blob, its drift against the oracle's float64 run is at most 1.5 x the exact-fp32 plan's (floor
-    1e-6: below that both are rounding noise of the comparison; geometric mean over the test images, no image above 3 x — see the comment at the end).  Device only."""
+    """bf16x3 is the default scheme of the pointwise layers only under these conditions: blob by blob its distance to the oracle's float64 run is at most
+    2 x the exact-fp32 plan's (floor 2e-6), and DetectionOutput rows are IDENTICAL (label, order, score / box <= 1e-5) between the two device plans and the oracle's fp32
+    run — for the default plan and for the plan with every supported shape on the matrix-core block kernel.  Device only."""
     layers, W, blob = model
     imgs = np.stack([make_image(s) for s in seeds])
     taps = ('603', '632', '672', '849', '908', '944', 'mbox_loc', 'mbox_conf_softmax')
@@ -138,37 +211,22 @@ def run_bf16x3_against_f32(lib, model, seeds=(0, 1, 3, 4)):
             assert det.gemm == gemm
             res = det.detect_batch(imgs)
             got[(gemm, fuse_irb)] = {nm: np.stack([det.debug_blob(nm, b) for b in range(len(seeds))]) for nm in taps if det.has_blob(nm)}
-            rows[(gemm, fuse_irb)] = [np.array([[d.label, d.score, d.xmin, d.ymin, d.xmax, d.ymax] for d in res[b].raw[:res[b].n_raw]], np.float32).reshape(-1, 6) for b in range(len(seeds))]
+            rows[(gemm, fuse_irb)] = [device_rows(res, b) for b in range(len(seeds))]
             det.close()
-    worst = {}; ratios = {}
+    worst = {}
     for b, s in enumerate(seeds):
         x = D.preprocess(imgs[b])
+        out32, _ = D.forward(layers, W, x)
         _, blobs64 = D.forward(layers, W, x, dt=np.float64)
         for plan in (None, True):
             for nm in taps:
                 if nm not in got[('f32', plan)] or nm not in got[('bf16x3', plan)]: continue
                 ref = np.asarray(blobs64[nm]).reshape(-1)
                 e32 = rel_err(got[('f32', plan)][nm][b].astype(np.float64), ref); e3 = rel_err(got[('bf16x3', plan)][nm][b].astype(np.float64), ref)
-                ratios.setdefault((plan, nm), []).append(max(e3, 1e-6) / max(e32, 1e-6))
-                assert e3 <= max(3.0 * e32, 1e-6), (plan, nm, s, e3, e32)          # no single image worse than 3 x
-            # DetectionOutput of the two plans.  With the synthetic weights the heads' logits are noise of magnitude 1e3: rows sit at near-tied scores and ANY other fp32
-            # summation order reshuffles them (the exact-fp32 plan differs from the oracle's own float32 run in the same way, measured below).  Row identity between two
-            # float32 evaluation orders is therefore not a property this weight draw has; the share of rows with a counterpart (same label, score and box within 1e-3) is
-            # returned for the log, next to the same share between the oracle's float32 run and either device plan.  What IS asserted: DetectionOutput is exact on the
-            # device's own loc / conf (run_compare) and loc / conf drift like float32 (above).
+                worst[(plan, nm)] = max(worst.get((plan, nm), (0, 0)), (e3, e32))
+                assert e3 <= max(2.0 * e32, 2e-6), (plan, nm, s, e3, e32)
             ra, rb = rows[('f32', plan)][b], rows[('bf16x3', plan)][b]
-            worst[(plan, 'rows_matched', s)] = matched_rows(ra, rb)
-        p = [L for L in layers if L['type'] == 'DetectionOutput'][0]['p']
-        out32, blobs32 = D.forward(layers, W, x)
-        orows = D.detection_output(np.asarray(blobs32['mbox_loc'], np.float32).reshape(-1), np.asarray(blobs32['mbox_conf_softmax'], np.float32).reshape(-1), blobs32['mbox_priorbox'], p)
-        worst[('oracle_f32_vs_device_f32', 'rows_matched', s)] = matched_rows(orows, rows[('f32', None)][b])
-        worst[('oracle_f32_vs_device_bf16x3', 'rows_matched', s)] = matched_rows(orows, rows[('bf16x3', None)][b])
-    # The 1.5 x bar is applied to the geometric mean over the images of a blob: behind the first clip / gate layers the synthetic network is chaotic (drifts of 1e-2 .. 2e-1 against
-    # float64 for EVERY float32 evaluation order, the oracle's own included), so the ratio of two such drifts on one image is a random variable around 1, not a measurement
-    for key, r in ratios.items():
-        g = float(np.exp(np.mean(np.log(r))))
-        worst[key] = (round(g, 3), round(max(r), 3))
-        assert g <= 1.5, (key, r)
+            assert rows_identical(ra, rb) and rows_identical(ra, out32) and len(out32) >= 20, (plan, s)
     return worst
 
 
@@ -279,7 +337,7 @@ def run_detection_output_stress(lib, model):
         if b == 1: raw[rng.rand(n) < 0.7] *= 0.001
         conf[b] = raw
     res = (DetResult * 2)()
-    lib.check(lib.dll.sgx_det_debug_detection_output(det.h, loc.ctypes.data, conf.ctypes.data, 2, res), 'detection_output')
+    lib.check(lib.tap('sgx_det_debug_detection_output')(det.h, loc.ctypes.data, conf.ctypes.data, 2, res), 'detection_output')
     for b in range(2):
         exp = D.detection_output(loc[b].reshape(-1), conf[b].reshape(-1), priors, p)
         r = res[b]

@@ -6,26 +6,49 @@ from test_detector import run_compare, run_mask, model   # noqa: F401  (fixture)
 pytestmark = pytest.mark.gpu
 
 
-def test_detector_gpu_matches_oracle(gpulib, model):
-    run_compare(gpulib, model)
+def test_detector_gpu_matches_oracle(gpulib_taps, model):
+    run_compare(gpulib_taps, model)
 
 
-def test_detector_gpu_exact_fp32_plan_matches_oracle(gpulib, model):
+def test_detector_gpu_exact_fp32_plan_matches_oracle(gpulib_taps, model):
     """the exact-fp32 matrix products (SGX_DET_GEMM=f32): the anchor plan of the plan-equality tests"""
-    run_compare(gpulib, model, seeds=(0,), gemm='f32')
-    run_compare(gpulib, model, seeds=(0,), fuse=True, gemm='f32')
+    run_compare(gpulib_taps, model, seeds=(0,), gemm='f32')
+    run_compare(gpulib_taps, model, seeds=(0,), fuse=True, gemm='f32')
 
 
-def test_detector_gpu_bf16x3_plan_matches_oracle(gpulib, model):
+def test_detector_gpu_bf16x3_plan_matches_oracle(gpulib_taps, model):
     """the bf16x3 matrix products (three-term bf16 split, six cross products on v_mfma_f32_32x32x16_bf16): same criterion as the fp32 plan, per-layer and fused"""
-    run_compare(gpulib, model, gemm='bf16x3')
-    run_compare(gpulib, model, fuse=True, gemm='bf16x3')
+    run_compare(gpulib_taps, model, gemm='bf16x3')
+    run_compare(gpulib_taps, model, fuse=True, gemm='bf16x3')
 
 
-def test_detector_gpu_bf16x3_drift_within_1p5x_of_fp32_and_same_detections(gpulib, model):
+def test_detector_gpu_bf16x3_same_detections_as_fp32_and_oracle(gpulib_taps, model):
     from test_detector import run_bf16x3_against_f32
-    worst = run_bf16x3_against_f32(gpulib, model)
-    print('bf16x3 drift / fp32 drift (geometric mean, max over the images) and DetectionOutput row agreement:', worst)
+    worst = run_bf16x3_against_f32(gpulib_taps, model)
+    print('worst (bf16x3, fp32) distance to the float64 run per blob:', worst)
+
+
+def test_detector_gpu_rows_identical_to_oracle_on_8_images(gpulib_taps, model):
+    """DetectionOutput rows: oracle fp32 == device f32 plan == device bf16x3 plan (label, order, score / box <= 1e-5) on eight images, default plan and all-shapes block plan"""
+    from test_detector import run_rows_identical
+    run_rows_identical(gpulib_taps, model, seeds=tuple(range(10, 18)), gemms=('f32', 'bf16x3'), plans=(None, True))
+
+
+@pytest.mark.parametrize('gemm,irb,block_fusion', [('bf16x3', None, False), ('f32', None, False), ('bf16x3', True, False), ('f32', True, False), ('f32', False, False), ('f32', None, True)])
+def test_detector_gpu_every_plan_step_isolated(gpulib_taps, model, gemm, irb, block_fusion):
+    """every plan step against the float64 oracle ON THE DEVICE'S OWN STEP INPUTS (2e-6 fp32 / 4e-6 bf16x3 of the blob's magnitude): each k_conv_pw3<*>, k_irb<*>,
+    k_fused_block2<*>, k_se_gate, depthwise and stem instantiation of the default plan, of the all-shapes block plan, of the plan without block kernels and of the
+    opt-in k_fused_block plan is judged on its own inputs"""
+    from test_detector import run_steps_isolated
+    worst, descs = run_steps_isolated(gpulib_taps, model, gemm=gemm, irb=irb, block_fusion=block_fusion)
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+    print(gemm, irb, block_fusion, len(worst), 'steps; largest step errors:', top)
+
+
+def test_detector_gpu_product_library_rows_identical_to_oracle(gpulib, model):
+    """the PRODUCT library (no taps: its one and only plan, the default bf16x3 scheme): DetectionOutput rows and person boxes equal the oracle's fp32 run on eight images"""
+    from test_detector import run_rows_identical
+    run_rows_identical(gpulib, model, seeds=tuple(range(20, 28)), gemms=(None,), plans=(None,))
 
 
 def test_dynamic_mask_gpu(gpulib):
@@ -33,13 +56,13 @@ def test_dynamic_mask_gpu(gpulib):
     run_mask(gpulib, to_dev=lambda a: torch.from_numpy(a.view(np.uint8) if a.dtype.fields else a).cuda(), to_host=lambda t: t.cpu().numpy())
 
 
-def test_detector_gpu_fused_matches_oracle(gpulib, model):
-    run_compare(gpulib, model, seeds=(0,), fuse=True)
+def test_detector_gpu_fused_matches_oracle(gpulib_taps, model):
+    run_compare(gpulib_taps, model, seeds=(0,), fuse=True)
 
 
-def test_detector_gpu_fused_equals_unfused(gpulib, model):
+def test_detector_gpu_fused_equals_unfused(gpulib_taps, model):
     from test_detector import run_fused_equals_unfused
-    run_fused_equals_unfused(gpulib, model)
+    run_fused_equals_unfused(gpulib_taps, model)
 
 
 def test_compact_gpu(gpulib):
@@ -86,12 +109,12 @@ def test_detect_dev_gpu(gpulib, model):
     run_detect_dev(gpulib, model, to_dev=lambda a: torch.from_numpy(a).cuda(), to_host=lambda t: t.cpu().numpy())
 
 
-def test_detection_output_stress_gpu(gpulib, model):
+def test_detection_output_stress_gpu(gpulib_taps, model):
     from test_detector import run_detection_output_stress
-    run_detection_output_stress(gpulib, model)
+    run_detection_output_stress(gpulib_taps, model)
 
 
-def test_xcd_work_order_is_a_permutation_of_the_work(gpulib, model):
+def test_xcd_work_order_is_a_permutation_of_the_work(gpulib_taps, model):
     """The tuned kernels deal frames out to the eight XCDs (sgx_xcd_order): a batch of 19 frames (two full groups of eight + three frames in the plain order)
     gives, frame by frame, the bytes the batch-of-two plan gives (which run_compare pins to the oracle), and the same with the plain order (SGX_DET_XCD=0)."""
     import os
@@ -105,7 +128,7 @@ def test_xcd_work_order_is_a_permutation_of_the_work(gpulib, model):
         if env is None: os.environ.pop('SGX_DET_XCD', None)
         else: os.environ['SGX_DET_XCD'] = env
         try:
-            det = Detector2D(0.90, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=batch, lib=gpulib, fuse=True)
+            det = Detector2D(0.90, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=batch, lib=gpulib_taps, fuse=True)
         finally:
             if old is None: os.environ.pop('SGX_DET_XCD', None)
             else: os.environ['SGX_DET_XCD'] = old

@@ -18,7 +18,7 @@ def test_tracker_with_device_detector_boxes(gpulib, oracle):
     from sg_slam_amd.tracker import TrackerBatch
     param = os.path.join(ROOT, 'tests', 'golden', 'mobilenetv3_ssdlite_voc.param')
     layers = synth.parse_ncnn_param(param)
-    _, blob = synth.synth_ncnn_weights(layers, seed=7, person_logit=2.0)       # a handful of "person" detections per frame
+    _, blob = synth.synth_ncnn_weights(layers, seed=7, person_logit=-0.5)       # a handful of "person" detections per frame
     S, MB, NF = 2, 100, 5
     det = Detector2D(0.9, 0.01, param_text=open(param).read(), bin_bytes=blob, max_batch=S, lib=gpulib)
     gen = synth.PlaneStream(seed=1234); offs = [3, 57]

@@ -12,7 +12,8 @@ def _xp(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-def test_pyramid_gpu(gpulib, oracle):
+def test_pyramid_gpu(gpulib_taps, oracle):
+    gpulib = gpulib_taps          # reads the LK pyramid levels back (include/sgx_debug.h)
     fc.check_pyramid(gpulib, oracle)
 
 

@@ -84,13 +84,13 @@ def run_envelope_solver_equals_dense(lib, nkf, npt, env_mode, two_branch=None, o
     nkf_free = int((np.asarray(prob['pose_fixed']) == 0).sum())
     try:
         for mode in (1, env_mode):
-            lib.dll.sgx_ba_debug_set_solver(mode)
+            lib.tap('sgx_ba_debug_set_solver')(mode)
             p = {k: (v.copy() if hasattr(v, 'copy') else v) for k, v in prob.items()}
             er, st = Optimizer.LocalBundleAdjustment(p, CAM, lib=lib)
             out[mode] = (p['poses'].astype('f8'), p['points'].astype('f8'), er.copy(), st)
-            pl = (C.c_int32 * 4)(); lib.check(lib.dll.sgx_ba_debug_last_plan(pl)); plans[mode] = tuple(pl)
+            pl = (C.c_int32 * 4)(); lib.check(lib.tap('sgx_ba_debug_last_plan')(pl)); plans[mode] = tuple(pl)
     finally:
-        lib.dll.sgx_ba_debug_set_solver(-1)
+        lib.tap('sgx_ba_debug_set_solver')(-1)
     a, b = out[1], out[env_mode]
     if two_branch is not None:
         assert (plans[1][0], plans[env_mode][0]) == (0, 1) and (plans[env_mode][2] > 0) == two_branch, plans      # the band eliminated from both ends at once (>= 24 tiles), or as one branch
@@ -114,12 +114,12 @@ def run_two_branch_matches_oracle(lib, oracle, nkf, npt, solver_mode):
     prob, _, _ = make_big_ba_problem(nkf, npt)
     eposes, epoints, eerase, etrace, eiters = oracle.local_ba(prob, CAM)
     p2 = {k: (v.copy() if hasattr(v, 'copy') else v) for k, v in prob.items()}
-    lib.dll.sgx_ba_debug_set_solver(solver_mode)
+    lib.tap('sgx_ba_debug_set_solver')(solver_mode)
     try:
         erase, stats = Optimizer.LocalBundleAdjustment(p2, CAM, lib=lib)
-        pl = (C.c_int32 * 4)(); lib.check(lib.dll.sgx_ba_debug_last_plan(pl))
+        pl = (C.c_int32 * 4)(); lib.check(lib.tap('sgx_ba_debug_last_plan')(pl))
     finally:
-        lib.dll.sgx_ba_debug_set_solver(-1)
+        lib.tap('sgx_ba_debug_set_solver')(-1)
     assert pl[0] == 1 and pl[1] > 0 and pl[2] > 0 and pl[3] > 0, tuple(pl)
     assert stats['iterations'] == tuple(eiters)
     assert (erase == eerase).all()

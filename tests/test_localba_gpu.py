@@ -22,13 +22,15 @@ def test_gpu_matches_oracle(gpulib, oracle, seed, n_free, n_fixed, n_points):
     assert abs(stats['chi2'][1] - ref) <= 1e-5 * max(1.0, ref)
 
 
-def test_envelope_solver_equals_dense_gpu(gpulib):
+def test_envelope_solver_equals_dense_gpu(gpulib_taps):
+    gpulib = gpulib_taps          # forces the solver plan (sgx_ba_debug_set_solver)
     from test_localba import run_envelope_solver_equals_dense
     run_envelope_solver_equals_dense(gpulib, 60, 1500, 2)        # forced on a small system (partial last tile, cyclic corner)
     run_envelope_solver_equals_dense(gpulib, 600, 15000, 0)      # automatic choice: 3 594 unknowns, narrow covisibility band
 
 
-def test_two_branch_solver_matches_oracle_gpu(gpulib, oracle):
+def test_two_branch_solver_matches_oracle_gpu(gpulib_taps, oracle):
+    gpulib = gpulib_taps
     from test_localba import run_two_branch_matches_oracle
     run_two_branch_matches_oracle(gpulib, oracle, 400, 10000, -1)    # 2 394 unknowns = 75 tiles, automatic solver choice; the oracle's dense solve takes ~20 s
 

@@ -124,7 +124,7 @@ def run_fused_pyramid_equals_per_level(lib, to_dev=lambda a: a):
         cap = e.capacity
         kps = to_dev(np.zeros((2, cap * 28), np.uint8)); desc = to_dev(np.zeros((2, cap, 32), np.uint8)); cnt = to_dev(np.zeros(2, 'i4')); dimg = to_dev(imgs)
         for unfused in (1, 0):
-            lib.dll.sgx_orb_debug_set_unfused_pyramid(unfused)
+            lib.tap('sgx_orb_debug_set_unfused_pyramid')(unfused)
             e.extract_batch_dev(dimg, w, 2, kps, desc, cnt)
             e.last_status()
             levels.append([[e.debug_level(f, l) for l in range(1, nl)] for f in range(2)])

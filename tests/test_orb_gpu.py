@@ -16,6 +16,15 @@ def ex(gpulib):
     e.close()
 
 
+@pytest.fixture(scope='module')
+def ex_taps(gpulib_taps):
+    """the tap build (include/sgx_debug.h): pyramid levels, per-cell FAST candidates and the octree kernel alone can be read back"""
+    from sg_slam_amd.orb import ORBextractor
+    e = ORBextractor(lib=gpulib_taps, max_batch=8)
+    yield e
+    e.close()
+
+
 def _same(ka, da, kb, db):
     return len(ka) == len(kb) and (ka == kb).all() and da.shape == db.shape and (da == db).all()
 
@@ -28,7 +37,8 @@ def test_extract_matches_oracle(ex, oracle, stream_frames, t):
     assert _same(k, d, ko, do)
 
 
-def test_stage_taps_match_oracle(ex, oracle, stream_frames):
+def test_stage_taps_match_oracle(ex_taps, oracle, stream_frames):
+    ex = ex_taps
     g, _, _ = stream_frames.frame(5)
     ex(g)
     _, _, pyr, nc = oracle.orb_extract(g, want_pyr=True)
@@ -73,7 +83,8 @@ def test_batched_device_call(ex, oracle, stream_frames):
 
 
 @pytest.mark.parametrize('seed', range(8))
-def test_octree_kernel_random_candidates(ex, oracle, seed):
+def test_octree_kernel_random_candidates(ex_taps, oracle, seed):
+    ex = ex_taps
     from test_orb_emu import test_octree_kernel_random_candidates as body
     body(ex, oracle, seed)
 
@@ -90,10 +101,10 @@ def test_full_size_properties(ex, stream_frames):
     assert (k1['angle'] >= 0).all() and (k1['angle'] < 360).all()
 
 
-def test_fused_pyramid_equals_per_level_gpu(gpulib):
+def test_fused_pyramid_equals_per_level_gpu(gpulib_taps):
     import torch
     from test_orb_emu import run_fused_pyramid_equals_per_level
-    run_fused_pyramid_equals_per_level(gpulib, to_dev=lambda a: torch.from_numpy(a).cuda())
+    run_fused_pyramid_equals_per_level(gpulib_taps, to_dev=lambda a: torch.from_numpy(a).cuda())
 
 
 def test_other_geometries_gpu(gpulib, oracle):

@@ -67,10 +67,10 @@ def test_threads_per_frame_variants_emu(emu, oracle, n, seed, threads):
     frame, _, _ = make_pose_problem(oracle, n=n, seed=seed)
     is2 = oracle.orb_params()['inv_sigma2']
     en, eT, eout = oracle.pose_optimization(frame, CAM, is2)
-    emu.dll.sgx_pose_opt_debug_set_threads(threads)
+    emu.tap('sgx_pose_opt_debug_set_threads')(threads)
     try:
         f2 = dict(frame)
         gn = Optimizer.PoseOptimization(f2, CAM, is2, lib=emu)
     finally:
-        emu.dll.sgx_pose_opt_debug_set_threads(0)
+        emu.tap('sgx_pose_opt_debug_set_threads')(0)
     assert gn == en and (f2['outlier'] == eout).all() and pose_close(f2['Tcw'], eT)

@@ -42,15 +42,16 @@ def test_gpu_mono_stereo(gpulib, oracle):
 
 @pytest.mark.parametrize('threads', [64, 256])
 @pytest.mark.parametrize('n,seed', [(400, 43), (1000, 47), (9, 46)])
-def test_threads_per_frame_variants_gpulib(gpulib, oracle, n, seed, threads):
+def test_threads_per_frame_variants_gpulib(gpulib_taps, oracle, n, seed, threads):
     """one wave per frame (large batches) and four waves per frame (small batches) both reproduce the oracle"""
     frame, _, _ = make_pose_problem(oracle, n=n, seed=seed)
     is2 = oracle.orb_params()['inv_sigma2']
     en, eT, eout = oracle.pose_optimization(frame, CAM, is2)
-    gpulib.dll.sgx_pose_opt_debug_set_threads(threads)
+    gpulib = gpulib_taps
+    gpulib.tap('sgx_pose_opt_debug_set_threads')(threads)
     try:
         f2 = dict(frame)
         gn = Optimizer.PoseOptimization(f2, CAM, is2, lib=gpulib)
     finally:
-        gpulib.dll.sgx_pose_opt_debug_set_threads(0)
+        gpulib.tap('sgx_pose_opt_debug_set_threads')(0)
     assert gn == en and (f2['outlier'] == eout).all() and pose_close(f2['Tcw'], eT)

@@ -9,9 +9,9 @@ def test_tracker_two_streams_gpu(gpulib, oracle):
     run_tracker(gpulib, oracle, 'torch')
 
 
-def test_tracker_mask_gpu(gpulib):
+def test_tracker_mask_gpu(gpulib_taps):
     from test_tracker_emu import run_tracker_mask
-    run_tracker_mask(gpulib, 'torch')
+    run_tracker_mask(gpulib_taps, 'torch')          # the synthetic affine flow stand-in (sgx_debug_flow_affine_batch_dev) is a tap
 
 
 def test_tracker_full_batch_properties(gpulib):

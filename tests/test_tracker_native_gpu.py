@@ -20,7 +20,7 @@ def test_native_tracker_full_chain_gpu(gpulib):
     run_native_equals_python(gpulib, 'torch', dynamic_mask=True, nframes=5)
 
 
-def _detector(gpulib, S, person_logit=2.0):
+def _detector(gpulib, S, person_logit=-0.5):
     from sg_slam_amd import synth
     from sg_slam_amd.detector import Detector2D
     param = os.path.join(ROOT, 'tests', 'golden', 'mobilenetv3_ssdlite_voc.param')
@@ -105,4 +105,37 @@ def test_native_tracker_host_input_equals_device_input(gpulib):
         for k in ra:
             assert (ra[k].view(np.uint32) == rb[k].view(np.uint32)).all(), (t, k)
     assert np.abs(ra['Tcw'].reshape(S, 4, 4) - np.stack([gen.Tcw(o + NF - 1) for o in offs])).max() < 0.05
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize('pipelined', [False, True])
+def test_host_slot_refill_contract_gpu(gpulib, pipelined):
+    """sgx_tracker_host_buffers(slot) returns once the slot's pending upload has left the pinned buffers — in the non-pipelined mode too (its copies out of pinned
+    memory on the null stream are asynchronous to the host).  The caller here scribbles over a slot IMMEDIATELY after asking for it again, without any other synchronisation,
+    while the same frames go through a second tracker that is synchronised after every step: identical results."""
+    from sg_slam_amd import synth
+    from sg_slam_amd.tracker_native import TrackerNative
+    S, NF = 8, 6
+    gen = synth.LayeredStream(seed=1234); offs = [3 + 11 * s for s in range(S)]
+    T0 = np.stack([gen.Tcw(o) for o in offs])
+    a = TrackerNative(gpulib, S, CAM, dynamic_mask=True, pipelined=pipelined); b = TrackerNative(gpulib, S, CAM, dynamic_mask=True, pipelined=pipelined)
+    a.set_initial_pose(T0); b.set_initial_pose(T0)
+    frames = []
+    for t in range(NF):
+        fr = [gen.frame(o + t) for o in offs]
+        frames.append((np.stack([f[0] for f in fr]), np.stack([f[1] for f in fr])))
+    ref = []
+    for t in range(NF):                      # b: one slot, full synchronisation after every step
+        hb, hd = b.host_buffers(0)
+        hb[:, :, :640 * 3] = np.repeat(frames[t][0][..., None], 3, 3).reshape(S, 480, 640 * 3); hd[...] = frames[t][1]
+        b.step_host(0); ref.append(b.read())
+    for t in range(NF):                      # a: refill slot t & 1 as soon as host_buffers hands it out again, then garbage into the OTHER slot's successor right away
+        hb, hd = a.host_buffers(t & 1)
+        hb[:, :, :640 * 3] = np.repeat(frames[t][0][..., None], 3, 3).reshape(S, 480, 640 * 3); hd[...] = frames[t][1]
+        a.step_host(t & 1)
+        hb2, hd2 = a.host_buffers(t & 1)     # must block until the upload just issued has been read out of the pinned buffers
+        hb2[...] = 0x5a; hd2[...] = 0x5a5a
+    got = a.read()
+    for k in got:
+        assert (got[k].view(np.uint32) == ref[-1][k].view(np.uint32)).all(), k
     a.close(); b.close()

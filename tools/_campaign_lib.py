@@ -4,11 +4,21 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def campaign_lib():
-    """(library, array flavour for the tracker harness)"""
+def taps_lib():
+    """tests/taps/libsgx_taps.so: the product sources with the test / tuning taps of include/sgx_debug.h and the SGX_* environment switches (make -C sg_slam_amd/csrc taps)"""
+    from sg_slam_amd.capi import SgxLib
+    lib = SgxLib(os.path.join(ROOT, 'tests', 'taps', 'libsgx_taps.so'))
+    assert 'gfx950' in lib.version() and lib.has_taps
+    return lib
+
+
+def campaign_lib(taps=False):
+    """(library, array flavour for the tracker harness); taps=True: the campaign drives a test tap, which on the device only the tap build has"""
     if os.environ.get('SGX_CAMPAIGN_LIB', '') == 'device':
         import torch                      # torch first: its HIP runtime must be initialised before libsgx.so touches the device (the tracker harness allocates through torch)
         torch.cuda.init()
+        if taps:
+            return taps_lib(), 'torch'
         import sg_slam_amd
         lib = sg_slam_amd.load()
         assert 'gfx950' in lib.version()

@@ -12,7 +12,10 @@ from sg_slam_amd.capi import _vp
 from oracle import detector_oracle as D          # only to synthesise the weight blob (the reference's .bin is absent)
 
 PARAM = os.path.join(ROOT, 'tests', 'golden', 'mobilenetv3_ssdlite_voc.param')
-lib = sg_slam_amd.load()
+if os.environ.get('SGX_BENCH_TAPS_LIB') == '1':          # A/B runs: the tap build honours the SGX_* switches (SGX_DET_FORK, SGX_DET_GEMM, ...)
+    sys.path.insert(0, os.path.join(ROOT, 'tools')); from _campaign_lib import taps_lib; lib = taps_lib()
+else:
+    lib = sg_slam_amd.load()
 layers = D.parse_param(PARAM); W, blob = D.synth_weights(layers)
 out = []
 BATCHES = [int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else [1, 16, 64]

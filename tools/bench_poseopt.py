@@ -6,7 +6,8 @@ from sg_slam_amd.capi import _vp, KP_DTYPE
 from sg_slam_amd.matcher import camera_struct
 from oracle import oracle as orc
 from scenes import make_pose_problem, CAM
-lib = sg_slam_amd.load()
+from _campaign_lib import taps_lib
+lib = taps_lib()          # the tap build (include/sgx_debug.h): plan selection / per-step timing / blob read-back are not in the product library
 is2 = np.asarray(orc.orb_params()['inv_sigma2'], 'f4')
 fr, _, _ = make_pose_problem(orc, n=800, seed=44)
 cap = 1024; n = len(fr['keys'])
@@ -21,7 +22,7 @@ for S in (64, 256, 512, 1024):
     dk, du, dh, dx = d(keys), d(ur), d(has), d(xw); dn = torch.full((S,), n, dtype=torch.int32, device='cuda')
     out = torch.zeros((S, cap), dtype=torch.uint8, device='cuda'); ninl = torch.zeros((S,), dtype=torch.int32, device='cuda')
     for thr in (256, 64):
-        lib.dll.sgx_pose_opt_debug_set_threads(thr)
+        lib.tap('sgx_pose_opt_debug_set_threads')(thr)
         def run():
             dT = torch.from_numpy(T0).cuda()
             lib.check(lib.dll.sgx_pose_optimization_batch_dev(S, cap, _vp(dk), _vp(du), _vp(dn), None, _vp(dh), _vp(dx), cap, _vp(is2), len(is2), C.byref(cs), _vp(dT), _vp(out), _vp(ninl), None))

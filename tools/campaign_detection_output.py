@@ -9,7 +9,7 @@ from oracle import detector_oracle as D
 from sg_slam_amd.detector import Detector2D
 from sg_slam_amd.capi import SgxLib, DetResult
 from _campaign_lib import campaign_lib
-lib, XP = campaign_lib()
+lib, XP = campaign_lib(taps=True)
 PARAM = ROOT + '/tests/golden/mobilenetv3_ssdlite_voc.param'
 layers = D.parse_param(PARAM); W, blob = D.synth_weights(layers, seed=7)
 det = Detector2D(0.90, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=1, lib=lib)
@@ -28,7 +28,7 @@ while time.time() - t0 < float(sys.argv[2]) and (MAXC is None or cases < MAXC):
     for c in rng.choice(nc, rng.randint(0, 6), replace=False): raw[:, c] = 0
     conf = np.ascontiguousarray(raw[None], 'f4')
     res = (DetResult * 1)()
-    lib.check(lib.dll.sgx_det_debug_detection_output(det.h, loc.ctypes.data, conf.ctypes.data, 1, res), 'do')
+    lib.check(lib.tap('sgx_det_debug_detection_output')(det.h, loc.ctypes.data, conf.ctypes.data, 1, res), 'do')
     exp = D.detection_output(loc[0].reshape(-1), conf[0].reshape(-1), priors, p)
     r = res[0]
     got = np.array([[d.label, d.score, d.xmin, d.ymin, d.xmax, d.ymax] for d in r.raw[:r.n_raw]], np.float32).reshape(-1, 6)

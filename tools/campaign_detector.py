@@ -11,7 +11,7 @@ from oracle import detector_oracle as D
 from sg_slam_amd.capi import SgxLib
 import test_detector as T
 from _campaign_lib import campaign_lib
-lib, XP = campaign_lib()
+lib, XP = campaign_lib(taps=True)
 layers = D.parse_param(T.PARAM)
 seed0 = int(sys.argv[1]); t0 = time.time(); n = bad = 0
 rng = np.random.RandomState(seed0)

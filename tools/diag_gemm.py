@@ -11,7 +11,8 @@ from sg_slam_amd import synth
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 PARAM = os.path.join(ROOT, 'tests', 'golden', 'mobilenetv3_ssdlite_voc.param')
-lib = sg_slam_amd.load()
+from _campaign_lib import taps_lib
+lib = taps_lib()          # the tap build (include/sgx_debug.h): plan selection / per-step timing / blob read-back are not in the product library
 layers = synth.parse_ncnn_param(PARAM); W, blob = synth.synth_ncnn_weights(layers)
 rng = np.random.RandomState(5)
 imgs = rng.randint(0, 256, (B, 480, 640, 3)).astype(np.uint8)

@@ -61,7 +61,8 @@ from sg_slam_amd import synth
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 PARAM = os.path.join(ROOT, 'tests', 'golden', 'mobilenetv3_ssdlite_voc.param')
-lib = sg_slam_amd.load()
+from _campaign_lib import taps_lib
+lib = taps_lib()          # the tap build (include/sgx_debug.h): plan selection / per-step timing / blob read-back are not in the product library
 layers = synth.parse_ncnn_param(PARAM); W, blob = synth.synth_ncnn_weights(layers)
 det = Detector2D(0.9, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=B, lib=lib, legacy_kernels=bool(int(os.environ.get('SGX_PROF_LEGACY', '0'))),
                  block_fusion=bool(int(os.environ.get('SGX_PROF_BLOCKS', '0'))))
