@@ -124,9 +124,9 @@ def main():
     ap.add_argument('--config2-only', action='store_true', help='measure only the configs[1] chain (no detector, no LK / RANSAC; mask inputs from the synthetic ground truth)')
     ap.add_argument('--param', default=os.path.join(ROOT, 'tests', 'golden', 'mobilenetv3_ssdlite_voc.param'), help='ncnn .param of the detector (the graph the reference ships)')
     ap.add_argument('--bin', default='', help='ncnn .bin weights of the detector (absent from the reference tree; default: synthetic weights in .bin order)')
-    ap.add_argument('--person-logit', type=float, default=-1.0, help='synthetic detector weights only: offset of the person-class logit of the calibrated synthetic network '
-                    '(sg_slam_amd.synth.synth_ncnn_weights).  0: three to six person boxes per frame; -0.5: one or two; -1 (default): a person box in every second frame, so the 0.2 px '
-                    'person-box branch of the mask runs in the timed region while the streams keep tracking; -3: none')
+    ap.add_argument('--person-logit', type=float, default=-0.5, help='synthetic detector weights only: offset of the person-class logit of the calibrated synthetic network '
+                    '(sg_slam_amd.synth.synth_ncnn_weights).  0: three to six person boxes per frame; -0.5 (default): one or two (measured on the bench streams: 1.4 per frame, each about a '
+                    'third of the image — what a walking person covers in TUM fr3/walking_xyz — and all 512 streams keep tracking); -1: a box in every second or third frame; -3: none')
     ap.add_argument('--tum', default='', help='TUM RGB-D sequence directory (rgb/ depth/ associations.txt [groundtruth.txt]): the streams are consecutive chunks of the sequence')
     ap.add_argument('--save-trajectory', default='', help='write stream 0 of rank 0 as a TUM trajectory file (System::SaveTrajectoryTUM format)')
     ap.add_argument('--cpu-sample', type=int, default=120, help='frames timed on the CPU oracle')
@@ -457,6 +457,7 @@ def main():
         e = {'avg_ms_per_launch': round(avg_ms, 5), 'launches': n, 'total_ms': round(ms, 3)}
         if k == 'det_forward':
             e.update({'bound': 'mfma', 'alg_gflop_per_launch': det_gflop * SL, 'achieved_TFLOPs': round(det_gflop * SL / (avg_ms * 1e-3) / 1e3, 3)})
+            e['frac'] = round(e['achieved_TFLOPs'] / det_peak_tfs, 4)
         else:
             e.update({'bound': 'hbm', 'alg_bytes_per_launch': alg[k] * SL, 'achieved_GBs': round(alg[k] * SL / (avg_ms * 1e-3) / 1e9, 3)})
             e['hbm_frac'] = round(e['achieved_GBs'] / HBM_PEAK_GBS, 4)

@@ -257,46 +257,51 @@ def _calibrate(layers, W, seed, person_logit, conf_gain=2.0, background_logit=2.
                 L = producer[L['ins'][0]]
             head_of[L['name']] = kind
     blobs = {'input': torch.from_numpy(_calibration_inputs(seed))}
-    with torch.no_grad():
-        for L in layers:
-            t, p, ins, outs = L['type'], L['p'], L['ins'], L['outs']
-            if t == 'Input': continue
-            if t == 'MemoryData': blobs[outs[0]] = torch.tensor(float(W[L['name']][0]), dtype=torch.float64); continue
-            if t == 'Split':
-                for o in outs: blobs[o] = blobs[ins[0]]
-                continue
-            if ins[0] not in blobs: continue                          # behind the heads (Permute .. DetectionOutput): nothing to calibrate
-            a = blobs[ins[0]]
-            if t in ('Convolution', 'ConvolutionDepthWise'):
-                w, b = W[L['name']]
-                outc, k, group = p[0], p[1], p.get(7, 1)
-                wt = torch.from_numpy(w.astype(np.float64).reshape(outc, -1, k, k))
-                y = F.conv2d(a, wt, torch.from_numpy(b.astype(np.float64)), stride=p.get(3, 1), padding=p.get(4, 0), groups=group)
-                kind = head_of.get(L['name'])
-                n = y.shape[0] * y.shape[2] * y.shape[3]
-                if n >= 32 and kind is None:
-                    mu = y.mean((0, 2, 3)).numpy(); sd = y.std((0, 2, 3), unbiased=False).numpy()
-                else:
-                    mu = np.full(outc, float(y.mean())); sd = np.full(outc, float(y.std(unbiased=False)))
-                sd = np.maximum(sd, 1e-3 * max(float(sd.max()), 1e-30))
-                if kind == 'conf':
-                    gain = np.full(outc, conf_gain); beta = np.zeros(outc); beta[0::21] += background_logit; beta[15::21] += person_logit
-                elif kind == 'loc':
-                    gain = np.ones(outc); beta = np.zeros(outc)
-                else:
-                    gain = rng.uniform(0.8, 1.25, outc); beta = rng.randn(outc) * 0.3
-                s = _quantise(gain / sd)
-                b2 = _quantise(beta + (b.astype(np.float64) - mu) * s)
-                w2 = (w.astype(np.float64).reshape(outc, -1) * s[:, None]).astype(np.float32).reshape(-1)
-                W[L['name']] = (w2, b2.astype(np.float32))
-                y = F.conv2d(a, torch.from_numpy(w2.astype(np.float64).reshape(outc, -1, k, k)), torch.from_numpy(b2.astype(np.float32).astype(np.float64)), stride=p.get(3, 1), padding=p.get(4, 0), groups=group)
-            elif t == 'BinaryOp':
-                b = blobs[ins[1]]; op = p.get(0, 0)
-                y = a + b if op == 0 else a * b if op == 2 else a / b
-            elif t == 'Clip': y = torch.clamp(a, float(p[0]), float(p[1]))
-            elif t == 'ReLU': y = torch.relu(a)
-            else: continue
-            blobs[outs[0]] = y
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)          # one thread: a few seconds, and no OpenMP oversubscription when several test workers calibrate at once (measured: 4 s alone, 700 s with 6 workers x 8 threads)
+    try:
+      with torch.no_grad():
+          for L in layers:
+              t, p, ins, outs = L['type'], L['p'], L['ins'], L['outs']
+              if t == 'Input': continue
+              if t == 'MemoryData': blobs[outs[0]] = torch.tensor(float(W[L['name']][0]), dtype=torch.float64); continue
+              if t == 'Split':
+                  for o in outs: blobs[o] = blobs[ins[0]]
+                  continue
+              if ins[0] not in blobs: continue                          # behind the heads (Permute .. DetectionOutput): nothing to calibrate
+              a = blobs[ins[0]]
+              if t in ('Convolution', 'ConvolutionDepthWise'):
+                  w, b = W[L['name']]
+                  outc, k, group = p[0], p[1], p.get(7, 1)
+                  wt = torch.from_numpy(w.astype(np.float64).reshape(outc, -1, k, k))
+                  y = F.conv2d(a, wt, torch.from_numpy(b.astype(np.float64)), stride=p.get(3, 1), padding=p.get(4, 0), groups=group)
+                  kind = head_of.get(L['name'])
+                  n = y.shape[0] * y.shape[2] * y.shape[3]
+                  if n >= 32 and kind is None:
+                      mu = y.mean((0, 2, 3)).numpy(); sd = y.std((0, 2, 3), unbiased=False).numpy()
+                  else:
+                      mu = np.full(outc, float(y.mean())); sd = np.full(outc, float(y.std(unbiased=False)))
+                  sd = np.maximum(sd, 1e-3 * max(float(sd.max()), 1e-30))
+                  if kind == 'conf':
+                      gain = np.full(outc, conf_gain); beta = np.zeros(outc); beta[0::21] += background_logit; beta[15::21] += person_logit
+                  elif kind == 'loc':
+                      gain = np.ones(outc); beta = np.zeros(outc)
+                  else:
+                      gain = rng.uniform(0.8, 1.25, outc); beta = rng.randn(outc) * 0.3
+                  s = _quantise(gain / sd)
+                  b2 = _quantise(beta + (b.astype(np.float64) - mu) * s)
+                  w2 = (w.astype(np.float64).reshape(outc, -1) * s[:, None]).astype(np.float32).reshape(-1)
+                  W[L['name']] = (w2, b2.astype(np.float32))
+                  y = F.conv2d(a, torch.from_numpy(w2.astype(np.float64).reshape(outc, -1, k, k)), torch.from_numpy(b2.astype(np.float32).astype(np.float64)), stride=p.get(3, 1), padding=p.get(4, 0), groups=group)
+              elif t == 'BinaryOp':
+                  b = blobs[ins[1]]; op = p.get(0, 0)
+                  y = a + b if op == 0 else a * b if op == 2 else a / b
+              elif t == 'Clip': y = torch.clamp(a, float(p[0]), float(p[1]))
+              elif t == 'ReLU': y = torch.relu(a)
+              else: continue
+              blobs[outs[0]] = y
+    finally:
+        torch.set_num_threads(nthreads)
     return W
 
 

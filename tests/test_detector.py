@@ -89,8 +89,21 @@ def device_rows(res, b):
     return np.array([[d.label, d.score, d.xmin, d.ymin, d.xmax, d.ymax] for d in r.raw[:r.n_raw]], np.float32).reshape(-1, 6)
 
 
-def rows_identical(a, b, tol=1e-5):
-    return a.shape == b.shape and bool((a[:, 0] == b[:, 0]).all()) and (len(a) == 0 or float(np.abs(a[:, 1:] - b[:, 1:]).max()) < tol)
+def rows_identical(a, b, tol=1e-5, tie=2e-6):
+    """DetectionOutput rows a (device) against b (oracle): 2 = identical — same labels in the same order, scores / boxes within tol; 1 = identical up to the order of rows whose
+    SCORES TIE within `tie` (fp32 noise: the device's softmax is within 5e-6 of the float64 run, so two rows 1e-7 apart may legitimately swap — the stable sort puts them
+    class-major in ncnn and oracle alike, but only for EXACT ties): every device row has its own oracle row (same label, score / box within tol) and the oracle row sitting at
+    the device row's position scores within `tie` of it; 0 = different detections."""
+    if a.shape != b.shape: return 0
+    if len(a) == 0 or ((a[:, 0] == b[:, 0]).all() and float(np.abs(a[:, 1:] - b[:, 1:]).max()) < tol): return 2
+    used = np.zeros(len(b), bool)
+    for i, r in enumerate(a):
+        cand = np.nonzero(~used & (b[:, 0] == r[0]) & (np.abs(b[:, 1:] - r[1:]).max(1) < tol))[0]
+        if len(cand) == 0: return 0
+        j = cand[np.argmin(np.abs(cand - i))]
+        if j != i and abs(float(b[j, 1]) - float(b[i, 1])) > tie: return 0
+        used[j] = True
+    return 1
 
 
 def run_rows_identical(lib, model, seeds=tuple(range(8)), gemms=('f32', 'bf16x3'), plans=(None,)):
@@ -100,7 +113,7 @@ def run_rows_identical(lib, model, seeds=tuple(range(8)), gemms=('f32', 'bf16x3'
     imgs = np.stack([make_image(s) for s in seeds])
     ref = [D.forward(layers, W, D.preprocess(im))[0] for im in imgs]
     refd = [D.detect(layers, W, im) for im in imgs] if len(seeds) <= 2 else None
-    n_person = 0
+    n_person = 0; n_tied = 0
     for gemm in gemms:
         for irb in plans:
             det = Detector2D(0.90, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=len(seeds), lib=lib, fuse=True, irb=irb, gemm=gemm)
@@ -108,10 +121,13 @@ def run_rows_identical(lib, model, seeds=tuple(range(8)), gemms=('f32', 'bf16x3'
             res = det.detect_batch(imgs)
             for b in range(len(seeds)):
                 got = device_rows(res, b)
-                assert len(ref[b]) >= 20 and rows_identical(got, ref[b]), (gemm, irb, seeds[b], got[:4], ref[b][:4])
+                same = rows_identical(got, ref[b])
+                assert len(ref[b]) >= 20 and same, (gemm, irb, seeds[b], got[:4], ref[b][:4])
+                n_tied += same == 1
                 n_person += res[b].n_rm_boxes
             det.close()
     assert n_person > 0                         # person boxes (what the dynamic-feature mask consumes) are among the compared rows
+    assert n_tied <= max(1, len(seeds) * len(gemms) * len(plans) // 8), n_tied      # the tie rule is the exception (seed 24: two rows 1.2e-7 apart), not the way the test passes
     return n_person
 
 
@@ -162,6 +178,18 @@ def test_detector_emu_bf16x3_plan_matches_oracle(emu, model):
 
 def test_detector_emu_fused_matches_oracle(emu, model):
     run_compare(emu, model, seeds=(0,), fuse=True)
+
+
+def test_rows_identical_rule():
+    """the comparison itself: identical -> 2; two rows whose scores tie within 2e-6 swapped -> 1; a swap of distinguishable rows, a moved box, a changed label -> 0"""
+    r = np.array([[4, 0.9, .1, .1, .5, .5], [7, 0.5275831, .2, .2, .4, .4], [1, 0.5275830, .4, .8, .7, .9], [15, 0.3, 0, 0, 1, 1]], np.float32)
+    assert rows_identical(r, r.copy()) == 2 and rows_identical(r + np.float32(3e-6) * (np.arange(6) > 0), r) == 2
+    assert rows_identical(r[[0, 2, 1, 3]], r) == 1
+    assert rows_identical(r[[1, 0, 2, 3]], r) == 0
+    q = r.copy(); q[3, 4] += 1e-3
+    assert rows_identical(q, r) == 0
+    q = r.copy(); q[3, 0] = 14
+    assert rows_identical(q, r) == 0 and rows_identical(r[:3], r) == 0
 
 
 def test_detector_emu_rows_identical_to_oracle(emu, model):
