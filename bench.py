@@ -568,11 +568,15 @@ def main():
         depth_img = [host_depth[t, 0] for t in range(T)]
         use_lm = not args.no_local_map
         stage = {}
-        cdt = cpu_chain.run_chain([host[t, 0] for t in range(T)], depth_img, cam, gen.Tcw(t0s[0]), order, n, use_lm, stage_times=stage)
-        cpu = {'value': n / cdt, 'unit': 'frames/s', 'cores': 1, 'kind': 'port',
-               'sample': f'{n} frames of one synthetic stream through the oracle chain (orb_extract + calcOpticalFlowPyrLK + findFundamentalMat RANSAC + dynamic mask + stereo + '
-                         f'SearchByProjection + PoseOptimization + {"local-map SearchByProjection + PoseOptimization + " if use_lm else ""}unproject), 1 thread; the detector forward is NOT '
-                         f'in this figure (the oracle detector is a numpy port, ~3 s per frame, not representative of ncnn; the reference runs it on a second thread); host has {os.cpu_count()} cores',
+        # the GPU figure includes Detector2D::detect, so the CPU figure does too — its forward runs on the same core per frame (pre-processing in numpy
+        # integers + the shipped graph on torch's float32 CPU operators, one thread: oracle.detector_oracle.TorchForward, checked against the numpy oracle in the tests)
+        det_fn = cpu_chain.make_detector_fn(args.param, person_logit=args.person_logit) if det is not None and not args.bin else None
+        cdt = cpu_chain.run_chain([host[t, 0] for t in range(T)], depth_img, cam, gen.Tcw(t0s[0]), order, n, use_lm, stage_times=stage, detector=det_fn)
+        det_s = stage.get('detector_forward', 0.0)
+        cpu = {'value': n / cdt, 'unit': 'frames/s', 'cores': 1, 'kind': 'port', 'value_without_detector': n / (cdt - det_s),
+               'sample': f'{n} frames of one synthetic stream through the oracle chain ({"Detector2D forward (from_pixels_resize + the shipped graph, float32 CPU operators of torch, no DetectionOutput) + " if det_fn else ""}'
+                         f'orb_extract + calcOpticalFlowPyrLK + findFundamentalMat RANSAC + dynamic mask + stereo + SearchByProjection + PoseOptimization + '
+                         f'{"local-map SearchByProjection + PoseOptimization + " if use_lm else ""}unproject), 1 thread; host has {os.cpu_count()} cores',
                'ms_per_frame_by_stage': {k: round(v / n * 1e3, 3) for k, v in stage.items()}}
         # trajectory of the device path against the oracle chain on the same frames and the same detector boxes ("ATE vs ref"): stream 0, first M frames
         M = min(N, 32, NBOX if det is not None else N)
@@ -591,7 +595,7 @@ def main():
             start = os.path.join(tempfile.mkdtemp(prefix='sgx_cpu_'), 'go')
             env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
             procs = [subprocess.Popen([sys.executable, '-m', 'oracle.cpu_chain', '--index', str(k), '--frames', str(T), '--n', str(n_per), '--start-file', start] +
-                                      (['--no-local-map'] if not use_lm else []), cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for k in range(P)]
+                                      (['--no-local-map'] if not use_lm else []) + (['--detector-param', args.param] if det_fn else []), cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for k in range(P)]
             try:
                 for pr in procs:
                     pr.stdout.readline()                                 # READY (frames synthesised, library loaded)
@@ -604,7 +608,7 @@ def main():
                 wall = time.perf_counter() - w0
                 if len(secs) == P:
                     cpu.update({'value_all_cores': P * n_per / wall, 'cores_all': P,
-                                'sample_all_cores': f'{P} worker processes (one per core, each its own stream) x {n_per} frames, started together; {P * n_per} frames / wall time'})
+                                'sample_all_cores': f'{P} worker processes (one per core, each its own stream{", detector forward included" if det_fn else ""}) x {n_per} frames, started together; {P * n_per} frames / wall time'})
             finally:
                 for pr in procs:
                     try: pr.wait(timeout=5)

@@ -15,12 +15,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def run_chain(frames, depth_img, cam, Tstart, order, n, use_lm=True, use_mask=True, boxes=None, want_traj=False, restart=True, stage_times=None):
+def run_chain(frames, depth_img, cam, Tstart, order, n, use_lm=True, use_mask=True, boxes=None, want_traj=False, restart=True, stage_times=None, detector=None):
     """frames: list/array of distinct gray frames of ONE stream (replayed in ping-pong `order`), depth_img: one u16 depth image or a list (one per distinct frame);
     returns seconds for n tracked frames
     (and the list of Tcw per frame when want_traj).  boxes (optional): per replayed frame index i a (k,4) array of person boxes (x, y, w, h) — the
     detector results of that frame; have_dynamic = k > 0.  restart: re-initialise the stream every 2*len(order) frames (bench timing) or run on.
-    stage_times (optional dict): accumulates seconds per stage."""
+    stage_times (optional dict): accumulates seconds per stage.  detector (optional callable gray -> anything): Detector2D::detect's forward of every frame on this core
+    (pre-processing + network; timing only — the boxes used are `boxes`)."""
     from oracle import oracle as orc
     sf = orc.orb_params()['scale']; is2 = orc.orb_params()['inv_sigma2']
     orc.orb_extract(frames[0])                                   # warm-up (library load, tables)
@@ -49,6 +50,10 @@ def run_chain(frames, depth_img, cam, Tstart, order, n, use_lm=True, use_mask=Tr
         for i in range(n - done if not restart else min(len(order) * 2, n - done)):
             g = frames[order[i % len(order)]]
             dimg = depth_img[order[i % len(order)]] if isinstance(depth_img, (list, tuple)) else depth_img
+            if detector is not None:
+                t0 = time.perf_counter()
+                detector(g)
+                tick('detector_forward', t0)
             t0 = time.perf_counter()
             k, d = orc.orb_extract(g)
             tick('orb_extract', t0)
@@ -107,6 +112,18 @@ def run_chain(frames, depth_img, cam, Tstart, order, n, use_lm=True, use_mask=Tr
     return (dt, traj) if want_traj else dt
 
 
+def make_detector_fn(param_path, seed=7, person_logit=-0.5):
+    """gray frame -> (loc, conf) of Detector2D::detect's forward on ONE CPU thread: from_pixels_resize + mean subtraction (numpy, integer) and the shipped graph with torch's
+    float32 CPU operators (oracle.detector_oracle.TorchForward) on the harness's synthetic weights.  DetectionOutput is not included (its numpy restatement is not a fair timing)."""
+    from oracle import detector_oracle as D
+    layers = D.parse_param(param_path); W, _ = D.synth_weights(layers, seed=seed, person_logit=person_logit)
+    tf = D.TorchForward(layers, W, threads=1)
+    def fn(gray):
+        return tf(D.preprocess(np.repeat(gray[:, :, None], 3, 2)))
+    fn(np.zeros((480, 640), np.uint8))
+    return fn
+
+
 def ping_pong(T):
     return list(range(T)) + list(range(T - 2, 0, -1)) if T > 1 else [0]
 
@@ -116,6 +133,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--index', type=int, default=0); ap.add_argument('--frames', type=int, default=6); ap.add_argument('--n', type=int, default=40)
     ap.add_argument('--no-local-map', action='store_true'); ap.add_argument('--no-mask', action='store_true'); ap.add_argument('--start-file', default='')
+    ap.add_argument('--detector-param', default='', help='ncnn .param: also run the detector forward of every frame (torch CPU float32, one thread; synthetic weights)')
     a = ap.parse_args()
     from sg_slam_amd import synth
     gen = synth.LayeredStream(seed=1234); cam = dict(synth.TUM3)
@@ -124,10 +142,11 @@ def main():
     frames = [f[0] for f in fr]; depth_img = [f[1] for f in fr]
     from oracle import oracle as orc
     orc.orb_extract(frames[0])
+    det_fn = make_detector_fn(a.detector_param) if a.detector_param else None
     print('READY', flush=True)
     while a.start_file and not os.path.exists(a.start_file):
         time.sleep(0.01)
-    dt = run_chain(frames, depth_img, cam, gen.Tcw(t0), ping_pong(a.frames), a.n, use_lm=not a.no_local_map, use_mask=not a.no_mask)
+    dt = run_chain(frames, depth_img, cam, gen.Tcw(t0), ping_pong(a.frames), a.n, use_lm=not a.no_local_map, use_mask=not a.no_mask, detector=det_fn)
     print(f'SECONDS {dt:.6f} {a.n}', flush=True)
 
 

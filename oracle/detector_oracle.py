@@ -23,10 +23,11 @@ from sg_slam_amd.synth import parse_ncnn_param as parse_param, synth_ncnn_weight
 
 
 # ---------------------------------------------------------------- pre-processing
-def resize_bilinear_c3(src, dw, dh):
-    """ncnn resize_bilinear_c3 (src/mat_pixel_resize.cpp): 11-bit fixed point, like OpenCV's but clamping to (n-2, 1.0)."""
-    sh, sw, _ = src.shape
-    def tabs(s, d):
+_RESIZE_TABS = {}
+
+
+def _resize_tabs(s, d):
+    if (s, d) not in _RESIZE_TABS:
         scale = float(s) / d
         ofs = np.zeros(d, np.int32); a = np.zeros((d, 2), np.int32)
         for i in range(d):
@@ -36,11 +37,19 @@ def resize_bilinear_c3(src, dw, dh):
             if si >= s - 1: si, f = s - 2, np.float32(1)
             ofs[i] = si
             a[i, 0] = int(np.rint(np.float32(np.float32(1) - f) * np.float32(2048))); a[i, 1] = int(np.rint(f * np.float32(2048)))
-        return ofs, a
-    xo, xa = tabs(sw, dw); yo, ya = tabs(sh, dh)
-    s = src.astype(np.int32)
-    rows = s[:, xo, :] * xa[None, :, 0, None] + s[:, xo + 1, :] * xa[None, :, 1, None]            # (sh, dw, 3)
-    r0 = rows[yo]; r1 = rows[yo + 1]
+        _RESIZE_TABS[(s, d)] = (ofs, a)
+    return _RESIZE_TABS[(s, d)]
+
+
+def resize_bilinear_c3(src, dw, dh):
+    """ncnn resize_bilinear_c3 (src/mat_pixel_resize.cpp): 11-bit fixed point, like OpenCV's but clamping to (n-2, 1.0).  Only the rows / columns the output touches are formed."""
+    sh, sw, _ = src.shape
+    xo, xa = _resize_tabs(sw, dw); yo, ya = _resize_tabs(sh, dh)
+    rows_needed = np.unique(np.concatenate([yo, yo + 1]))
+    s = src[rows_needed].astype(np.int32)
+    rows = s[:, xo, :] * xa[None, :, 0, None] + s[:, xo + 1, :] * xa[None, :, 1, None]            # (rows needed, dw, 3)
+    i0 = np.searchsorted(rows_needed, yo); i1 = np.searchsorted(rows_needed, yo + 1)
+    r0 = rows[i0]; r1 = rows[i1]
     out = (((ya[:, 0, None, None] * (r0 >> 4)) >> 16) + ((ya[:, 1, None, None] * (r1 >> 4)) >> 16) + 2) >> 2
     return out.astype(np.uint8)
 
@@ -164,6 +173,58 @@ def forward(layers, W, x, dt=np.float32):
             raise NotImplementedError(t)
         blobs[outs[0]] = y
     return blobs['detection_out'], blobs
+
+
+class TorchForward:
+    """The same graph with torch's CPU operators in float32 (MKL-DNN / oneDNN convolutions): the CPU-baseline leg's stand-in for ncnn's SIMD forward (bench.py cpu_baseline) —
+    the numpy forward() above is a readable restatement (~4 s per frame), not a fair CPU timing.  Checked against forward() in tests/test_detector.py (fp32 drift).  Runs up to
+    mbox_loc / mbox_conf_softmax; DetectionOutput stays the numpy routine.  TEST / BASELINE INFRASTRUCTURE like the rest of oracle/."""
+
+    def __init__(self, layers, W, threads=1):
+        import torch
+        self.torch, self.layers, self.threads = torch, layers, threads
+        self.P = {}
+        for L in layers:
+            if L['type'] in ('Convolution', 'ConvolutionDepthWise'):
+                w, b = W[L['name']]; p = L['p']
+                self.P[L['name']] = (torch.from_numpy(np.ascontiguousarray(w, np.float32).reshape(p[0], -1, p[1], p[1]).copy()), torch.from_numpy(np.ascontiguousarray(b, np.float32).copy()))
+            elif L['type'] == 'MemoryData':
+                self.P[L['name']] = float(W[L['name']][0])
+
+    def __call__(self, x):
+        """x: (3, 300, 300) float32 from preprocess() -> (mbox_loc flat, mbox_conf_softmax (n, 21)) as numpy float32"""
+        torch = self.torch; F = torch.nn.functional
+        old = torch.get_num_threads(); torch.set_num_threads(self.threads)
+        try:
+            with torch.no_grad():
+                blobs = {'input': torch.from_numpy(np.ascontiguousarray(x, np.float32))[None]}
+                for L in self.layers:
+                    t, p, ins, outs = L['type'], L['p'], L['ins'], L['outs']
+                    if t == 'Input': continue
+                    if t == 'MemoryData': blobs[outs[0]] = self.P[L['name']]; continue
+                    if t == 'Split':
+                        for o in outs: blobs[o] = blobs[ins[0]]
+                        continue
+                    if t in ('PriorBox', 'DetectionOutput') or ins[0] not in blobs: continue          # the prior-box branch is input-independent
+                    a = blobs[ins[0]]
+                    if t in ('Convolution', 'ConvolutionDepthWise'):
+                        w, b = self.P[L['name']]
+                        y = F.conv2d(a, w, b, stride=p.get(3, 1), padding=p.get(4, 0), groups=p.get(7, 1))
+                    elif t == 'BinaryOp':
+                        b = blobs[ins[1]]; op = p.get(0, 0)
+                        y = a + b if op == 0 else a * b if op == 2 else a / b
+                    elif t == 'Clip': y = torch.clamp(a, float(p[0]), float(p[1]))
+                    elif t == 'ReLU': y = torch.relu(a)
+                    elif t == 'Permute': y = a.permute(0, 2, 3, 1).contiguous()
+                    elif t == 'Flatten': y = a.reshape(1, -1)
+                    elif t == 'Concat': y = torch.cat([blobs[i] for i in ins], 1)
+                    elif t == 'Reshape': y = a.reshape(-1, p[0])
+                    elif t == 'Softmax': y = torch.softmax(a, 1)
+                    else: raise NotImplementedError(t)
+                    blobs[outs[0]] = y
+                return blobs['mbox_loc'].reshape(-1).numpy(), blobs['mbox_conf_softmax'].numpy()
+        finally:
+            torch.set_num_threads(old)
 
 
 def eval_layer(L, W, args, dt=np.float32):

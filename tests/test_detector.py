@@ -379,6 +379,22 @@ def test_detection_output_stress_emu(emu, model):
     run_detection_output_stress(emu, model)
 
 
+def test_oracle_torch_forward_matches_numpy_forward(model):
+    """oracle.detector_oracle.TorchForward (torch's float32 CPU operators: the detector leg of bench.py's cpu_baseline) computes the same network as the numpy oracle: head outputs
+    within fp32 drift of the float64 run, and the harness's per-frame callable runs"""
+    layers, W, _ = model
+    x = D.preprocess(make_image(6))
+    _, b64 = D.forward(layers, W, x, dt=np.float64)
+    loc, conf = D.TorchForward(layers, W, threads=1)(x)
+    for nm, g in (('mbox_loc', loc), ('mbox_conf_softmax', conf)):
+        r = np.asarray(b64[nm]).reshape(-1)
+        assert g.size == r.size and rel_err(g.reshape(-1).astype(np.float64), r) < 1e-5, nm
+    from oracle import cpu_chain
+    fn = cpu_chain.make_detector_fn(PARAM)
+    loc2, conf2 = fn(make_image(6)[:, :, 0])
+    assert loc2.size == loc.size and np.isfinite(conf2).all()
+
+
 def test_oracle_convolutions_match_torch(model):
     """pins the ORACLE's convolution semantics (padding, stride, depthwise grouping, ncnn weight order [outc][inc/group][kh][kw]) to an independent
     implementation: every convolution of the shipped graph is evaluated in float64 on the oracle's own input blob, once with the oracle's numpy routine and
