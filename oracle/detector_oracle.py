@@ -109,7 +109,10 @@ def prior_box(fh, fw, img, p):
     return np.stack([b.reshape(-1), var])
 
 
-def detection_output(loc, conf, priors, p):
+def detection_output(loc, conf, priors, p, margins=None):
+    """ncnn DetectionOutput.  margins (optional dict, filled): how far the decisions behind the returned rows are from flipping — 'order' = the smallest score gap between
+    consecutive rows of the final list (incl. the first row cut off by keep_top_k), 'iou' = the smallest |IoU - nms_threshold| over the suppression tests of candidates that score
+    at least as high as the last returned row.  An image whose margins are inside fp32 noise has no well-defined row list (tests/test_detector.py::run_rows_identical)."""
     ncls, nms_th, nms_topk, keep_topk, conf_th = p[0], np.float32(p[1]), p[2], p[3], np.float32(p[4])
     var = np.array([p.get(5, .1), p.get(6, .1), p.get(7, .2), p.get(8, .2)], np.float32)
     pb = priors[0].reshape(-1, 4); n = len(pb); loc = loc.reshape(n, 4); conf = conf.reshape(n, ncls)
@@ -117,7 +120,7 @@ def detection_output(loc, conf, priors, p):
     cx = var[0] * loc[:, 0] * pw + pcx; cy = var[1] * loc[:, 1] * ph + pcy
     w = np.exp(var[2] * loc[:, 2]).astype(np.float32) * pw; h = np.exp(var[3] * loc[:, 3]).astype(np.float32) * ph
     boxes = np.stack([cx - w * np.float32(0.5), cy - h * np.float32(0.5), cx + w * np.float32(0.5), cy + h * np.float32(0.5)], 1).astype(np.float32)
-    allr = []
+    allr = []; tests = []
     for c in range(1, ncls):
         sc = conf[:, c]; idx = np.nonzero(sc > conf_th)[0]
         idx = idx[np.argsort(-sc[idx], kind='stable')][:nms_topk]
@@ -129,10 +132,16 @@ def detection_output(loc, conf, priors, p):
                 iw = min(a[2], b[2]) - max(a[0], b[0]); ih = min(a[3], b[3]) - max(a[1], b[1])
                 inter = np.float32(iw * ih) if (iw > 0 and ih > 0) else np.float32(0)
                 union = (a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - inter
+                if margins is not None: tests.append((float(sc[i]), abs(float(inter / union) - float(nms_th))))
                 if inter / union > nms_th: ok = False; break
             if ok: keep.append(i)
         allr += [(c, sc[i], *boxes[i]) for i in keep]
     allr.sort(key=lambda r: -r[1])
+    if margins is not None:
+        top = [float(r[1]) for r in allr[:keep_topk + 1]]
+        margins['order'] = min([a_ - b_ for a_, b_ in zip(top, top[1:])], default=1.0)
+        cut = top[min(len(top), keep_topk) - 1] if top else 0.0
+        margins['iou'] = min([m for s_, m in tests if s_ >= cut], default=1.0)
     return np.array(allr[:keep_topk], np.float32).reshape(-1, 6)
 
 

@@ -25,3 +25,11 @@ def campaign_lib(taps=False):
         return lib, 'torch'
     from sg_slam_amd.capi import SgxLib
     return SgxLib(os.path.join(ROOT, 'tests', 'emu', 'libsgx_emu.so')), 'numpy'
+
+
+def tool_lib():
+    """the library a measurement tool drives: the product library, or — SGX_BENCH_TAPS_LIB=1, A/B runs of the SGX_* switches — the tap build"""
+    if os.environ.get('SGX_BENCH_TAPS_LIB') == '1':
+        return taps_lib()
+    import sg_slam_amd
+    return sg_slam_amd.load()

@@ -13,7 +13,7 @@ def main():
     from sg_slam_amd import synth
     from sg_slam_amd.orb import ORBextractor
     from sg_slam_amd.flow import OpticalFlowLK, fundamental_ransac_batch_dev
-    lib = sg_slam_amd.load()
+    from _campaign_lib import tool_lib; lib = tool_lib()
     S = a.streams
     gen = synth.PlaneStream(seed=1234)
     fr = np.stack([np.stack([gen.frame(37 * s + t)[0] for s in range(min(S, 16))]) for t in range(2)])

@@ -10,7 +10,7 @@ from sg_slam_amd.capi import _vp, KP_DTYPE
 from sg_slam_amd.matcher import camera_struct
 from oracle import oracle as orc
 from scenes import make_pair, CAM
-lib = sg_slam_amd.load()
+from _campaign_lib import tool_lib; lib = tool_lib()
 S = synth.PlaneStream(seed=1234)
 cur, last = make_pair(orc, S, 3, seed=1, obs_mode='zero')
 B, cap = 64, 1024

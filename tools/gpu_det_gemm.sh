@@ -7,7 +7,7 @@ timeout 300 python tools/diag_gemm.py 3 > $O/diag_gemm.txt 2>&1
 timeout 600 python -m pytest tests/test_detector_gpu.py -q -m gpu -s > $O/pytest_detector.txt 2>&1
 for g in f32 bf16x3; do
   SGX_DET_GEMM=$g timeout 200 python tools/prof_det_ops.py 512 5 > $O/detector_ops_$g.txt 2>$O/detector_ops_$g.err
-  SGX_DET_GEMM=$g timeout 300 python bench.py --steps 60 --warmup 6 --no-cpu-baseline --no-config2 --no-config4 --no-host-input > $O/bench_$g.json 2>$O/bench_$g.err
+  SGX_BENCH_TAPS_LIB=1 SGX_DET_GEMM=$g timeout 300 python bench.py --steps 60 --warmup 6 --no-cpu-baseline --no-config2 --no-config4 --no-host-input > $O/bench_$g.json 2>$O/bench_$g.err
 done
 tail -3 $O/pytest_detector.txt; tail -4 $O/diag_gemm.txt; head -1 $O/detector_ops_f32.txt; head -1 $O/detector_ops_bf16x3.txt
 python - <<PY

@@ -9,7 +9,7 @@ from sg_slam_amd import synth
 from sg_slam_amd.orb import ORBextractor
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-lib = sg_slam_amd.load()
+from _campaign_lib import tool_lib; lib = tool_lib()
 gen = synth.PlaneStream(seed=1234)
 host = np.stack([gen.frame(37 * s)[0] for s in range(B)])
 d = torch.from_numpy(host).cuda()
