@@ -47,6 +47,9 @@ struct Op {
 };
 }  // namespace
 
+#ifndef SGX_DET_GRAPH_EXECS
+#define SGX_DET_GRAPH_EXECS 2
+#endif
 #ifndef SGX_DET_FORK_LANES
 #define SGX_DET_FORK_LANES 3      // capture lanes of the plan's hipGraph (capture_forked); 1 = a chain.  Measured (profiles/r5_ab_concurrency.md): 3 lanes shorten the detector stream's
                                   // span per step 17.4 -> 16.1 ms in the pipeline (10.26 -> 10.11 ms alone) at unchanged throughput — latency for free
@@ -69,13 +72,14 @@ struct sgx_det {
     float *d_priors = nullptr, *d_cls_rows = nullptr; int *d_cls_count = nullptr; sgx_det_result *d_results = nullptr;      // DetectionOutput on the device
     double gmac = 0;
 #ifndef SGX_EMU
-    std::map<int, hipGraphExec_t> graphs;     // captured plan per batch size (launch-bound tail of ~100 small kernels -> one graph launch)
+    std::map<int, std::vector<hipGraphExec_t>> graphs;     // captured plan per batch size (launch-bound tail of ~100 small kernels -> one graph launch); SGX_DET_EXECS instances used in turn
+    std::map<int, unsigned> graph_turn;
     std::vector<hipStream_t> fork_streams;    // side lanes of the forked capture (capture_forked): they only exist to give the graph its parallel branches
     std::vector<hipEvent_t> fork_events;
 #endif
     ~sgx_det() {
 #ifndef SGX_EMU
-        for (auto &g : graphs) (void)hipGraphExecDestroy(g.second);
+        for (auto &g : graphs) for (hipGraphExec_t e : g.second) (void)hipGraphExecDestroy(e);
         for (hipEvent_t e : fork_events) (void)hipEventDestroy(e);
         for (hipStream_t q : fork_streams) (void)hipStreamDestroy(q);
 #endif
@@ -1116,11 +1120,16 @@ extern "C" int sgx_det_forward_batch_dev(sgx_det *h, const uint8_t *d_img, int p
                 for (size_t i = first; i < h->ops.size(); i++) run_op(h, h->ops[i], batch, st);
                 SGX_CHECK_HIP(hipStreamEndCapture(st, &graph));
             }
-            SGX_CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            // Two executable instances used in turn: a launch of an instance that is still running waits for it ON THE HOST in this runtime when the graph has parallel
+            // branches (measured, round 5: with one instance the host-input path lost its copy / compute overlap — the host could not enqueue the next step's uploads while the
+            // previous forward ran: 19.5 -> 32.2 ms per step); with two, launch i only meets launch i - 2, which has long finished.
+            static const int nexec_env = sgx_getenv("SGX_DET_EXECS") ? atoi(sgx_getenv("SGX_DET_EXECS")) : SGX_DET_GRAPH_EXECS;
+            std::vector<hipGraphExec_t> execs;
+            for (int e = 0; e < std::max(1, std::min(nexec_env, 4)); e++) { SGX_CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0)); execs.push_back(exec); }
             (void)hipGraphDestroy(graph);
-            it = h->graphs.emplace(batch, exec).first;
+            it = h->graphs.emplace(batch, execs).first;
         }
-        SGX_CHECK_HIP(hipGraphLaunch(it->second, st));
+        { unsigned &turn = h->graph_turn[batch]; SGX_CHECK_HIP(hipGraphLaunch(it->second[turn % it->second.size()], st)); turn++; }
     } else
 #endif
     for (size_t i = first; i < h->ops.size(); i++) run_op(h, h->ops[i], batch, st);
