@@ -110,6 +110,8 @@ def main():
     ap.add_argument('--streams', type=int, default=512, help='independent streams per GPU (frames per step)')
     ap.add_argument('--groups', type=int, default=1, help='independent pipelines per GPU: the streams of a GPU are cut into this many contiguous slices, each stepped by its own '
                     'C++ host (three HIP streams each), so one slice\'s detector graph runs beside another\'s extraction / tracking kernels; results are identical for any value')
+    ap.add_argument('--scene', choices=('layered', 'dynamic'), default='layered', help='synthetic scene: two static textured layers (parallax), or the same plus an independently moving textured '
+                    '"walker" at 1 m that crosses the view (sg_slam_amd.synth.DynamicStream): dynamic keypoints for LK + RANSAC + the mask to erase')
     ap.add_argument('--frames', type=int, default=6, help='distinct frames kept per stream (ping-pong replay)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-cpu-all-cores', action='store_true', help='skip the frames-parallel all-host-cores CPU baseline (keeps the 1-core figure)')
@@ -187,7 +189,8 @@ def main():
 
     S, T = args.streams, args.frames
     # synthetic scene: a textured background plane with a second textured layer in front of it (parallax, occlusion boundaries); ground-truth poses known
-    gen = synth.LayeredStream(seed=1234)
+    SCENE = 'DynamicStream' if args.scene == 'dynamic' else 'LayeredStream'
+    gen = getattr(synth, SCENE)(seed=1234)
     t0s = sdist.stream_offsets(rank, S)
     order = ping_pong(T)
     stamps = None; gt_tum = None
@@ -211,7 +214,7 @@ def main():
         if os.path.exists(gtp):
             gt_tum = tum.load_trajectory_tum(gtp)
     else:
-        host, host_depth = synth.synth_streams('LayeredStream', 1234, t0s, T, workers=max(1, min(32, (os.cpu_count() or 2) // (2 * world))))   # the ranks of a node share its cores
+        host, host_depth = synth.synth_streams(SCENE, 1234, t0s, T, workers=max(1, min(32, (os.cpu_count() or 2) // (2 * world))))   # the ranks of a node share its cores
         d_frames = torch.from_numpy(host).to(DEV)
         d_depth_t = torch.from_numpy(host_depth.view(np.int16)).to(DEV)          # raw u16 depth (DepthMapFactor 5000) as int16 bits
         d_bgr = None
@@ -594,7 +597,7 @@ def main():
             P = max(1, min(os.cpu_count() or 1, 128)); n_per = max(12, args.cpu_sample // 10)
             start = os.path.join(tempfile.mkdtemp(prefix='sgx_cpu_'), 'go')
             env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
-            procs = [subprocess.Popen([sys.executable, '-m', 'oracle.cpu_chain', '--index', str(k), '--frames', str(T), '--n', str(n_per), '--start-file', start] +
+            procs = [subprocess.Popen([sys.executable, '-m', 'oracle.cpu_chain', '--index', str(k), '--frames', str(T), '--n', str(n_per), '--start-file', start, '--scene', SCENE] +
                                       (['--no-local-map'] if not use_lm else []) + (['--detector-param', args.param] if det_fn else []), cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for k in range(P)]
             try:
                 for pr in procs:
@@ -615,7 +618,7 @@ def main():
                     except Exception: pr.kill()
 
     workload = ('Single MI355X: + NCNN detector fwd (MFMA convs) and dynamic-feature mask' if det is not None else 'Single MI355X: ORB extract+match HIP kernels + LK / RANSAC mask inputs') + \
-               (f', TUM sequence {os.path.basename(os.path.normpath(args.tum))}' if args.tum else ', 640x480 synthetic streams') + ', 1000 feats/frame'
+               (f', TUM sequence {os.path.basename(os.path.normpath(args.tum))}' if args.tum else f', 640x480 synthetic streams ({SCENE})') + ', 1000 feats/frame'
     # arithmetic types of the path: u8 / integer fixed point (ORB, LK, Hamming matching), f32 (detector forward; its scheme is named by the detector), f64 (LM pose / BA solvers)
     DTYPE = ('u8/f32(bf16x3 matrix products)/f64' if det.gemm == 'bf16x3' else 'u8/f32/f64') if det is not None else 'u8/f64'
     out = {

@@ -133,10 +133,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--index', type=int, default=0); ap.add_argument('--frames', type=int, default=6); ap.add_argument('--n', type=int, default=40)
     ap.add_argument('--no-local-map', action='store_true'); ap.add_argument('--no-mask', action='store_true'); ap.add_argument('--start-file', default='')
+    ap.add_argument('--scene', default='LayeredStream')
     ap.add_argument('--detector-param', default='', help='ncnn .param: also run the detector forward of every frame (torch CPU float32, one thread; synthetic weights)')
     a = ap.parse_args()
     from sg_slam_amd import synth
-    gen = synth.LayeredStream(seed=1234); cam = dict(synth.TUM3)
+    gen = getattr(synth, a.scene)(seed=1234); cam = dict(synth.TUM3)
     t0 = 37 * a.index
     fr = [gen.frame(t0 + t) for t in range(a.frames)]
     frames = [f[0] for f in fr]; depth_img = [f[1] for f in fr]

@@ -137,6 +137,32 @@ class LayeredStream(PlaneStream):
         return gray, depth, self.Tcw(t)
 
 
+class DynamicStream(LayeredStream):
+    """LayeredStream plus an independently moving "walker": a textured 110 x 230 rectangle at depth 1.0 m that crosses the image back and forth (3 - 6 px per frame against the
+    static scene, integer positions so frames stay byte-exact) — the dynamic content SG-SLAM's mask exists for (TUM fr3/walking_xyz: a person walking through the view).  Its
+    keypoints violate the epipolar geometry of the static scene, so LK + RANSAC + the 1.0 px / 0.2 px test have points to erase; poses and depth of the static scene are unchanged."""
+
+    def __init__(self, seed=1234, z_obj=1.0, **kw):
+        super().__init__(seed=seed, **kw)
+        self.z_obj = z_obj
+        self.obj_w, self.obj_h = 110, 230
+        self.obj_tex = world_texture(seed + 31337, 512, n_rect=500)[120:120 + self.obj_h, 80:80 + self.obj_w].copy()
+
+    def walker_box(self, t):
+        """(x, y, w, h) of the walker in frame t"""
+        x = 265 + int(round(230 * math.sin(2 * math.pi * t / 97.0 + 0.3)))          # |dx/dt| <= 15 px, typically 3 - 12
+        y = 120 + int(round(60 * math.sin(2 * math.pi * t / 41.0)))
+        return max(0, min(self.w - self.obj_w, x)), max(0, min(self.h - self.obj_h, y)), self.obj_w, self.obj_h
+
+    def frame(self, t):
+        gray, depth, T = super().frame(t)
+        x, y, w, h = self.walker_box(t)
+        gray = gray.copy(); depth = depth.copy()
+        gray[y:y + h, x:x + w] = self.obj_tex
+        depth[y:y + h, x:x + w] = int(round(self.z_obj * self.cam['depth_factor']))
+        return gray, depth, T
+
+
 def _texel_map(stream, t):
     """3x3 homogeneous map pixel (u, v) of frame t -> texel of the world texture (the float form of PlaneStream.frame's Q16 warp)."""
     cam, z0, ts = stream.cam, stream.z0, stream.ts

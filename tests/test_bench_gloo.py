@@ -51,8 +51,10 @@ def test_bench_two_ranks_gloo():
 
 def test_bench_rank_without_gpus_flag_adopts_world_size():
     """`torchrun --nproc-per-node N bench.py` without an explicit --gpus N is a valid launch (the default follows WORLD_SIZE)"""
-    out = _run(1, ARGS, gpus_flag=False)
+    out = _run(1, ARGS + ['--scene', 'dynamic'], gpus_flag=False)          # also: the scene with an independently moving object (synth.DynamicStream)
     assert out['n_gpus'] == 1 and out['config']['frame_record_gather'] is None
+    c = out['config']
+    assert 'DynamicStream' in c['workload'] and c['tracked_streams_last_frame'] == 2 and c['mean_keypoints'] < c['mean_keypoints_before_mask'] - 50      # the mask erased the walker's keypoints
 
 
 def test_bench_explicit_gpus_mismatch_fails_loudly():
