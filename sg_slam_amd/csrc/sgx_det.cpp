@@ -47,12 +47,16 @@ struct Op {
 };
 }  // namespace
 
+// Capture lanes of the plan's hipGraph (capture_forked) and executable instances used in turn.  DEFAULT 1 / 1 = the one-stream chain of rounds 1-4.  Round 5 built the forked
+// capture and measured it (profiles/r5_ab_concurrency.md): with 3 lanes the detector stream's span per step falls 17.4 -> 16.0 ms and the tracking stream's matchers run at their
+// stand-alone times, throughput unchanged — but on this runtime (ROCm 7.2) launching a graph WITH parallel branches blocks the calling host thread until the graph has run, so the
+// host-input path loses its copy / compute overlap (26.6 k -> 15.9 k frames/s, 40.8 -> 24.4 GB/s of PCIe; two instances used in turn recover only part: 18.6 k).  A gain that is a
+// side effect of a host-side serialisation is not kept as the default; SGX_DET_FORK / SGX_DET_EXECS remain as taps of the tap build.
 #ifndef SGX_DET_GRAPH_EXECS
-#define SGX_DET_GRAPH_EXECS 2
+#define SGX_DET_GRAPH_EXECS 1
 #endif
 #ifndef SGX_DET_FORK_LANES
-#define SGX_DET_FORK_LANES 3      // capture lanes of the plan's hipGraph (capture_forked); 1 = a chain.  Measured (profiles/r5_ab_concurrency.md): 3 lanes shorten the detector stream's
-                                  // span per step 17.4 -> 16.1 ms in the pipeline (10.26 -> 10.11 ms alone) at unchanged throughput — latency for free
+#define SGX_DET_FORK_LANES 1
 #endif
 
 struct sgx_det {
@@ -1120,9 +1124,7 @@ extern "C" int sgx_det_forward_batch_dev(sgx_det *h, const uint8_t *d_img, int p
                 for (size_t i = first; i < h->ops.size(); i++) run_op(h, h->ops[i], batch, st);
                 SGX_CHECK_HIP(hipStreamEndCapture(st, &graph));
             }
-            // Two executable instances used in turn: a launch of an instance that is still running waits for it ON THE HOST in this runtime when the graph has parallel
-            // branches (measured, round 5: with one instance the host-input path lost its copy / compute overlap — the host could not enqueue the next step's uploads while the
-            // previous forward ran: 19.5 -> 32.2 ms per step); with two, launch i only meets launch i - 2, which has long finished.
+            // (tap) several executable instances used in turn: measured with the forked capture, whose launches block the host on this runtime — see SGX_DET_FORK_LANES above
             static const int nexec_env = sgx_getenv("SGX_DET_EXECS") ? atoi(sgx_getenv("SGX_DET_EXECS")) : SGX_DET_GRAPH_EXECS;
             std::vector<hipGraphExec_t> execs;
             for (int e = 0; e < std::max(1, std::min(nexec_env, 4)); e++) { SGX_CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0)); execs.push_back(exec); }
