@@ -482,6 +482,11 @@ def main():
                 e['bound'] = 'valu'; e['frac'] = e['valu_frac']
                 e['valu_insts_per_frame'] = ik['valu_insts_per_frame']
         if e['bound'] == 'hbm': e['frac'] = e['hbm_frac']
+        # classes that neither stream memory nor saturate vector issue: name what they wait for instead of calling them HBM-bound with a fraction of 0.002
+        hint = {'pose_opt': 'fp64 issue of one wave per SIMD', 'match_project_frame': 'LDS / popcount + lock-sweep latency', 'match_project_local': 'LDS / popcount + lock-sweep latency',
+                'octree': 'latency (dependent list passes)', 'fm_ransac': 'latency (replayed sequential accept rule)', 'det_output': 'latency (per-class NMS chains)'}.get(k)
+        if hint and e['bound'] == 'hbm':
+            e['bound'] = hint; e['frac'] = e.get('fp64_frac', e.get('valu_frac', e['hbm_frac']))
         per_kernel[k] = e
     try:        # launch durations with nothing else on the GPU (the timed region above runs three streams at once: every kernel there shares CUs with the detector graph)
         sj_path = latest_profile('standalone.json')
