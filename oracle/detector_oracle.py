@@ -9,7 +9,8 @@ ncnn is NOT vendored in the reference tree (un-pinned git master, README.md:144-
 (SURVEY.md Appendix A.7): Convolution / ConvolutionDepthWise (0=outc 1=k 3=stride 4=pad 5=bias 6=weights 7=group),
 BinaryOp (0 add, 2 mul, 3 div), Clip, ReLU, Permute(order 3 = HWC), Flatten, Concat, Reshape, Softmax, PriorBox (Caffe-SSD
 style; the mmdetection flags 14/15 of the shipped graph are NOT modelled — noted in DESIGN.md), DetectionOutput.
-Weights are synthetic (the .bin is missing): N(0, 2/fan_in), seed 7, in ncnn .bin order.
+Weights are synthetic (the .bin is missing): N(0, 2/fan_in), seed 7, then a synthetic batch-norm fold per convolution (sg_slam_amd.synth._calibrate: unit-variance
+blobs, active gates, separated class scores — a network as well conditioned as a trained one), in ncnn .bin order.  They are INPUT data shared by harness, tests and oracle.
 """
 import numpy as np
 
