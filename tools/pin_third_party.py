@@ -82,7 +82,7 @@ def pin_ncnn(bin_path):
     if bin_path:
         blob = open(bin_path, 'rb').read(); wnote = os.path.basename(bin_path)
     else:
-        _, blob = synth.synth_ncnn_weights(layers, seed=7); wnote = 'synthetic N(0, 2/fan_in) seed 7 (sg_slam_amd.synth.synth_ncnn_weights)'
+        _, blob = synth.synth_ncnn_weights(layers, seed=7); wnote = 'synthetic N(0, 2/fan_in) seed 7 + batch-norm-style calibration fold (sg_slam_amd.synth.synth_ncnn_weights)'
     tmp = os.path.join(OUT, '_weights.bin'); os.makedirs(OUT, exist_ok=True)
     open(tmp, 'wb').write(blob)
     net = ncnn.Net(); net.opt.use_vulkan_compute = False; net.opt.num_threads = 1
