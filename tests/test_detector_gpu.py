@@ -145,3 +145,45 @@ def test_xcd_work_order_is_a_permutation_of_the_work(gpulib_taps, model):
         got = run(19, env)
         for f in range(19):
             assert (got[f][0] == ref[f][0]).all() and (got[f][1] == ref[f][1]).all(), (env, f)
+
+
+def test_forked_graph_capture_equals_plain_launches_gpu(gpulib_taps, model, tmp_path):
+    """capture_forked (sgx_det.cpp; a tap since round 5: SGX_DET_FORK=3, SGX_DET_EXECS=2): the plan captured with its parallel branches — dependencies from the blobs every step
+    reads and writes, cross-lane edges as capture events — replays to the same bytes as the plan launched step by step.  The switch is read once per process: a subprocess."""
+    import subprocess, sys, os
+    from test_detector import PARAM
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'fork.py'
+    script.write_text(f'''
+import sys, ctypes as C, numpy as np, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, "tests")!r}); sys.path.insert(0, {os.path.join(root, "tools")!r})
+from _campaign_lib import taps_lib
+from sg_slam_amd import synth
+from sg_slam_amd.capi import _vp
+from sg_slam_amd.detector import Detector2D
+from test_detector import make_image
+lib = taps_lib()
+layers = synth.parse_ncnn_param({PARAM!r}); _, blob = synth.synth_ncnn_weights(layers, seed=7)
+det = Detector2D(0.9, 0.01, param_text=open({PARAM!r}).read(), bin_bytes=blob, max_batch=3, lib=lib)
+imgs = torch.from_numpy(np.stack([make_image(s) for s in (5, 6, 7)])).cuda()
+dl, dc = C.c_void_p(), C.c_void_p()
+nl, nc = det.num_priors * 4, det.num_priors * det.num_class
+hip = C.cdll.LoadLibrary('libamdhip64.so')
+def grab():
+    torch.cuda.synchronize(); out = []
+    for ptr, n in ((dl, nl), (dc, nc)):
+        t = torch.zeros(3 * n, dtype=torch.float32, device='cuda'); hip.hipMemcpy(C.c_void_p(t.data_ptr()), ptr, C.c_size_t(12 * n), 3); out.append(t.cpu().numpy())
+    return out
+lib.check(lib.dll.sgx_det_forward_batch_dev(det.h, _vp(imgs), 640 * 3, 3, C.byref(dl), C.byref(dc), None))
+plain = grab()
+s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+for rep in range(3):
+    lib.check(lib.dll.sgx_det_forward_batch_dev(det.h, _vp(imgs), 640 * 3, 3, C.byref(dl), C.byref(dc), C.c_void_p(s.cuda_stream)))
+    s.synchronize()
+    g = grab()
+    assert all((a == b).all() for a, b in zip(plain, g)), rep
+print("FORK_OK", float(np.abs(plain[0]).max()))
+''')
+    env = dict(os.environ, SGX_DET_FORK='3', SGX_DET_EXECS='2')
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and 'FORK_OK' in out.stdout, (out.stdout[-500:], out.stderr[-2000:])

@@ -59,3 +59,24 @@ def test_native_tracker_config2_chain_emu(emu):
 
 def test_native_tracker_full_chain_emu(emu):
     run_native_equals_python(emu, 'numpy', dynamic_mask=True, nframes=3)
+
+
+def test_tracker_groups_equal_one_pipeline_emu(emu):
+    """TrackerGroups (bench.py --groups) = one pipeline, bit for bit (emulator: 2 streams as 2 groups of 1, 3 frames)"""
+    from sg_slam_amd.tracker_native import TrackerGroups
+    S, NF = 2, 3
+    gen = synth.LayeredStream(seed=1234); offs = [5, 14]
+    T0 = np.stack([gen.Tcw(o) for o in offs])
+    one = TrackerNative(emu, S, CAM, dynamic_mask=True, pipelined=False); grp = TrackerGroups(emu, S, CAM, 2, dynamic_mask=True, pipelined=False)
+    one.set_initial_pose(T0); grp.set_initial_pose(T0)
+    for t in range(NF):
+        fr = [gen.frame(o + t) for o in offs]
+        gray = np.stack([f[0] for f in fr]); depth = np.stack([f[1] for f in fr])
+        one.step(gray, depth); grp.step(gray, depth)
+        a, b = one.read(), grp.read()
+        for k in a:
+            assert (a[k].view(np.uint32) == b[k].view(np.uint32)).all(), (t, k)
+    ra = np.zeros((S, one.rec_bytes), np.uint8); rb = np.zeros_like(ra)
+    one.pack_records(ra); grp.pack_records(rb)
+    assert (ra == rb).all()
+    one.close(); grp.close()

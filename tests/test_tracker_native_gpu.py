@@ -139,3 +139,30 @@ def test_host_slot_refill_contract_gpu(gpulib, pipelined):
     for k in got:
         assert (got[k].view(np.uint32) == ref[-1][k].view(np.uint32)).all(), k
     a.close(); b.close()
+
+
+def test_tracker_groups_equal_one_pipeline_gpu(gpulib):
+    """TrackerGroups (bench.py --groups: several independent C++ pipelines over contiguous slices of a GPU's streams) returns the bits of ONE pipeline over all streams"""
+    import torch
+    from sg_slam_amd import synth
+    from sg_slam_amd.tracker_native import TrackerNative, TrackerGroups
+    S, NF = 8, 4
+    gen = synth.LayeredStream(seed=1234); offs = [5 + 9 * s for s in range(S)]
+    T0 = np.stack([gen.Tcw(o) for o in offs])
+    one = TrackerNative(gpulib, S, CAM, dynamic_mask=True); grp = TrackerGroups(gpulib, S, CAM, 4, dynamic_mask=True)
+    one.set_initial_pose(T0); grp.set_initial_pose(T0)
+    held = []
+    for t in range(NF):
+        fr = [gen.frame(o + t) for o in offs]
+        d_gray = torch.from_numpy(np.stack([f[0] for f in fr])).cuda(); d_depth = torch.from_numpy(np.stack([f[1] for f in fr]).view(np.int16)).cuda()
+        held.append((d_gray, d_depth))
+        st = torch.cuda.current_stream().cuda_stream
+        one.step(d_gray, d_depth, stream=st); grp.step(d_gray, d_depth, stream=st)
+        a, b = one.read(), grp.read()
+        for k in a:
+            assert (a[k].view(np.uint32) == b[k].view(np.uint32)).all(), (t, k)
+    rec_a = torch.zeros((S, one.rec_bytes), dtype=torch.uint8, device='cuda'); rec_b = torch.zeros_like(rec_a)
+    one.pack_records(rec_a, stream=torch.cuda.current_stream().cuda_stream); grp.pack_records(rec_b, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert (rec_a == rec_b).all()
+    one.close(); grp.close()
