@@ -43,6 +43,15 @@ while time.time() - t0 < float(sys.argv[2]) and (MAXC is None or cases < MAXC):
     o1, F, s1 = find_fundamental_mat(x1[:n], x2[:n], lib=lib)
     o2, rF, _, s2 = orc.find_fundamental_ransac(x1[:n], x2[:n])
     ok2 = o1 == (1 if o2 == 1 else 0) and (o1 == 0 or ((s1 == s2).all() and np.abs(F - rF).max() <= 1e-9 * max(np.abs(rF).max(), 1e-300)))
+    if not ok2 and 8 <= n <= 14 and o1 == 1 and o2 == 1:
+        # LMedS (8..14 pairs) on noise-free data: every sample drawn from inliers only yields the exact model, dozens of hypotheses tie at a median of ~1e-20 and the winner is decided
+        # by the last bit of the fp64 solver (round 5, device campaign seed 64 case 186: a ONE-ulp change of one input coordinate moves the oracle's own winner in 34 of 40 trials; the
+        # device build contracts multiply-adds).  Such a case is judged by the QUALITY of the model: the device's F must be as good a least-median solution as the oracle's.
+        def med(Fm):
+            p1 = np.c_[x1[:n].astype('f8'), np.ones(n)]; p2 = np.c_[x2[:n].astype('f8'), np.ones(n)]
+            l2 = p1 @ Fm.T; l1 = p2 @ Fm; d = (p2 * l2).sum(1)
+            return float(np.median(np.maximum(d * d / (l2[:, 0] ** 2 + l2[:, 1] ** 2), d * d / (l1[:, 0] ** 2 + l1[:, 1] ** 2))))
+        ok2 = s1[0] == s2[0] and med(np.asarray(F, 'f8').reshape(3, 3)) <= med(np.asarray(rF, 'f8').reshape(3, 3)) * (1 + 1e-6) + 1e-18
     cases += 1
     if not (ok and ok2): bad += 1; print('MISMATCH case', cases, type(gen).__name__, t, gap, 'lk', ok, 'ransac', ok2, n, flush=True)
 fl.close()
