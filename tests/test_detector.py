@@ -157,6 +157,35 @@ def run_rows_identical(lib, model, seeds=tuple(range(8)), gemms=('f32', 'bf16x3'
     return n_person, n_exact, n_cmp
 
 
+def steps_isolated_errors(layers, W, x, given):
+    """the judgement of run_steps_isolated on a set of device blobs: name -> |device - float64 oracle on the device's own inputs| / max|oracle|, for every blob that a plan step
+    produced (everything in `given` except the network input and pure aliases)"""
+    _, blobs64 = D.forward(layers, W, x, dt=np.float64)
+    shapes = {k: np.asarray(v).shape for k, v in blobs64.items()}
+    producer = {o: L for L in layers for o in L['outs']}
+    targets = [nm for nm in given if nm != 'input' and producer[nm]['type'] not in ('Split', 'Reshape')]
+    ref = D.forward_cut(layers, W, given, shapes, targets)
+    worst = {}
+    for nm in targets:
+        r = np.asarray(ref[nm]).reshape(-1); g = given[nm].astype(np.float64)
+        worst[nm] = float(np.abs(g - r).max() / max(np.abs(r).max(), 1e-30))
+    return worst
+
+
+def resident_blobs(det, layers, x, image=0):
+    """name -> flat array of every blob the plan keeps in device memory (plus the network input from the oracle's exact integer pre-processing)"""
+    producer = {o: L for L in layers for o in L['outs']}
+    sizes = {}
+    for L in layers:                                             # element counts from the graph's shapes are not needed: a blob whose device size differs from the oracle's is skipped below
+        pass
+    given = {'input': x}
+    for L in layers:
+        if L['type'] in ('Input', 'MemoryData', 'PriorBox', 'DetectionOutput', 'Permute', 'Flatten'): continue      # Permute / Flatten: layout-only, in the fused plans these names alias a slice of the concat buffer
+        for nm in L['outs']:
+            if det.has_blob(nm): given[nm] = det.debug_blob(nm, image)
+    return given
+
+
 def run_steps_isolated(lib, model, seed=2, gemm=None, irb=None, fuse=True, tol=None, block_fusion=False):
     """VERDICT r4 next #1c: for EVERY plan step, the float64 oracle evaluated on the device's own step inputs (the nearest device-resident blobs upstream) must give the
     device's step output to tol x max|out|: 2e-6 for fp32 matrix products, 4e-6 for bf16x3 (dropped terms <= 3 x 2^-24 |a||b|).  A kernel bug in ONE k_conv_pw3 / k_irb /
@@ -167,28 +196,41 @@ def run_steps_isolated(lib, model, seed=2, gemm=None, irb=None, fuse=True, tol=N
     img = make_image(seed)
     det.detect_batch(img[None])
     x = D.preprocess(img)
+    given = resident_blobs(det, layers, x)
     _, blobs64 = D.forward(layers, W, x, dt=np.float64)
-    shapes = {k: np.asarray(v).shape for k, v in blobs64.items()}
-    names = [o for L in layers for o in L['outs'] if L['type'] not in ('Input', 'MemoryData', 'PriorBox', 'DetectionOutput')]
-    producer = {o: L for L in layers for o in L['outs']}
-    given = {'input': x}
-    for nm in names:
-        if producer[nm]['type'] in ('Permute', 'Flatten'): continue      # layout-only layers: in the fused plans the head kernels store HWC straight into the concat buffer and these names alias a slice of it
-        if det.has_blob(nm):
-            v = det.debug_blob(nm, 0)
-            if v.size == int(np.prod(shapes[nm])): given[nm] = v
-    targets = [nm for nm in given if nm != 'input' and producer[nm]['type'] not in ('Split', 'Reshape')]
-    assert len(targets) >= det.num_kernels - 13, (len(targets), det.num_kernels)       # 12 Permute steps + the pre-processing have no target of their own
-    ref = D.forward_cut(layers, W, given, shapes, targets)
-    worst = {}
-    for nm in targets:
-        r = np.asarray(ref[nm]).reshape(-1); g = given[nm].astype(np.float64)
-        worst[nm] = float(np.abs(g - r).max() / max(np.abs(r).max(), 1e-30))
+    given = {k: v for k, v in given.items() if v.size == int(np.prod(np.asarray(blobs64[k]).shape))}
+    worst = steps_isolated_errors(layers, W, x, given)
+    assert len(worst) >= det.num_kernels - 13, (len(worst), det.num_kernels)       # 12 Permute steps + the pre-processing have no target of their own
     descs = det.op_descriptions()
     det.close()
     bad = {nm: e for nm, e in worst.items() if not e <= tol}
     assert not bad, (det.gemm, irb, tol, bad)            # every failing step at once (one GPU run names them all)
     return worst, descs
+
+
+def test_steps_isolated_criterion_has_teeth(emu, model):
+    """The per-step checker is itself checked: a fault of 1e-4 of a blob's magnitude injected into ONE element of ONE device blob (what a wrong lane, tap or k-step of one kernel
+    instantiation produces) is reported at that step — and at the steps that read the blob, whose device outputs no longer follow from their inputs — while every other step
+    stays below 2e-6; and the checker does not peek at the blob it judges (forward_cut never uses given[target] for the target)."""
+    layers, W, blob = model
+    det = Detector2D(0.90, 0.01, param_text=open(PARAM).read(), bin_bytes=blob, max_batch=1, lib=emu, fuse=True, gemm='f32')
+    img = make_image(2); det.detect_batch(img[None]); x = D.preprocess(img)
+    given = resident_blobs(det, layers, x); det.close()
+    clean = steps_isolated_errors(layers, W, x, given)
+    assert max(clean.values()) <= 2e-6
+    victim = '849' if '849' in given else sorted(k for k in given if k.isdigit())[len(given) // 2]
+    hurt = dict(given); v = hurt[victim].copy(); i = int(np.argmax(np.abs(v))) // 2; v[i] += 1e-4 * np.abs(v).max(); hurt[victim] = v
+    faulty = steps_isolated_errors(layers, W, x, hurt)
+    flagged = {nm for nm, e in faulty.items() if e > 2e-6}
+    assert victim in flagged and faulty[victim] > 5e-5, (victim, faulty[victim])
+    # (its readers see a one-element input fault of 1e-4 attenuated by their own weights: they may or may not cross 2e-6; nothing else may)
+    assert all(faulty[nm] <= 2e-6 for nm in faulty if nm not in flagged) and len(flagged) <= 8, sorted(flagged)
+    # a larger fault in a whole channel (a wrong weight row) must also surface downstream
+    hurt2 = dict(given); v = given[victim].copy(); v[:361] *= 1.01
+    for nm in given:                                             # the Split outputs are views of the same device buffer: a real fault shows under every name
+        if nm == victim or nm.startswith(victim + '_splitncnn'): hurt2[nm] = v
+    faulty2 = steps_isolated_errors(layers, W, x, hurt2)
+    assert faulty2[victim] > 1e-3 and len({nm for nm, e in faulty2.items() if e > 2e-6}) >= 2
 
 
 def test_detector_emu_matches_oracle(emu, model):
