@@ -187,3 +187,27 @@ print("FORK_OK", float(np.abs(plain[0]).max()))
     env = dict(os.environ, SGX_DET_FORK='3', SGX_DET_EXECS='2')
     out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and 'FORK_OK' in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+
+
+def test_detector_gpu_irb3_block_kernel_steps_isolated(gpulib_taps, tmp_path):
+    """k_irb3 — the inverted-residual block kernel with EVERY matrix product as bf16x3 (built in round 4, slower than k_irb, opt-in through the tap SGX_DET_IRB3=1; the product
+    never selects it): each of its plan steps against the float64 oracle on the device's own step inputs, like the default plans.  The switch is read once per process: a subprocess."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'irb3.py'
+    script.write_text(f'''
+import sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, "tests")!r}); sys.path.insert(0, {os.path.join(root, "tools")!r})
+import torch
+from _campaign_lib import taps_lib
+from oracle import detector_oracle as D
+import test_detector as T
+layers = D.parse_param(T.PARAM); W, blob = D.synth_weights(layers, seed=7)
+worst, descs = T.run_steps_isolated(taps_lib(), (layers, W, blob), gemm='bf16x3', irb=None)
+n3 = sum(1 for d in descs if d.startswith('irb') and d.rstrip().endswith('bf16x3'))
+print('IRB3_OK', n3, len(worst), max(worst.values()))
+assert n3 >= 6
+''')
+    env = dict(os.environ, SGX_DET_IRB3='1')
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and 'IRB3_OK' in out.stdout, (out.stdout[-800:], out.stderr[-2500:])
