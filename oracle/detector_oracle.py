@@ -110,10 +110,11 @@ def prior_box(fh, fw, img, p):
     return np.stack([b.reshape(-1), var])
 
 
-def detection_output(loc, conf, priors, p, margins=None):
+def detection_output(loc, conf, priors, p, margins=None, extra=0):
     """ncnn DetectionOutput.  margins (optional dict, filled): how far the decisions behind the returned rows are from flipping — 'order' = the smallest score gap between
     consecutive rows of the final list (incl. the first row cut off by keep_top_k), 'iou' = the smallest |IoU - nms_threshold| over the suppression tests of candidates that score
-    at least as high as the last returned row.  An image whose margins are inside fp32 noise has no well-defined row list (tests/test_detector.py::run_rows_identical)."""
+    at least as high as the last returned row.  An image whose margins are inside fp32 noise has no well-defined row list (tests/test_detector.py::run_rows_identical).
+    extra > 0 (tests): also return the first `extra` rows BEHIND the keep_top_k cut — a score tie across the cut decides which row is the last one."""
     ncls, nms_th, nms_topk, keep_topk, conf_th = p[0], np.float32(p[1]), p[2], p[3], np.float32(p[4])
     var = np.array([p.get(5, .1), p.get(6, .1), p.get(7, .2), p.get(8, .2)], np.float32)
     pb = priors[0].reshape(-1, 4); n = len(pb); loc = loc.reshape(n, 4); conf = conf.reshape(n, ncls)
@@ -143,7 +144,7 @@ def detection_output(loc, conf, priors, p, margins=None):
         margins['order'] = min([a_ - b_ for a_, b_ in zip(top, top[1:])], default=1.0)
         cut = top[min(len(top), keep_topk) - 1] if top else 0.0
         margins['iou'] = min([m for s_, m in tests if s_ >= cut], default=1.0)
-    return np.array(allr[:keep_topk], np.float32).reshape(-1, 6)
+    return np.array(allr[:keep_topk + extra], np.float32).reshape(-1, 6)
 
 
 def forward(layers, W, x, dt=np.float32):
