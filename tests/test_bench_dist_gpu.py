@@ -15,7 +15,7 @@ def test_bench_rccl_gather_path_single_rank(gpulib):
     env = dict(os.environ, SGX_BENCH_FORCE_DIST='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29600 + os.getpid() % 300), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
                HSA_ENABLE_IPC_MODE_LEGACY='0')
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '6', '--warmup', '3', '--streams', '8', '--no-cpu-baseline', '--no-config2', '--no-config4',
-                          '--no-host-input'], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+                          '--no-host-input'], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
     j = json.loads(line)
@@ -30,7 +30,7 @@ def test_bench_gpus_flag_spawns_the_ranks(gpulib):
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
     env.update(SGX_BENCH_FORCE_SPAWN='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '6', '--warmup', '3', '--streams', '8', '--no-cpu-baseline', '--no-config2',
-                          '--no-config4', '--no-host-input'], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+                          '--no-config4', '--no-host-input'], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     j = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
     assert j['n_gpus'] == 1 and j['value'] > 0 and j['config']['frame_record_gather'] is not None       # it ran as a torch.distributed rank
@@ -38,5 +38,5 @@ def test_bench_gpus_flag_spawns_the_ranks(gpulib):
     n = torch.cuda.device_count() + 1
     env.pop('SGX_BENCH_FORCE_SPAWN')
     bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n), '--steps', '2', '--warmup', '1', '--streams', '8', '--no-cpu-baseline', '--no-config2',
-                          '--no-config4', '--no-host-input'], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+                          '--no-config4', '--no-host-input'], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith('{')]

@@ -18,7 +18,7 @@ def test_campaign_slices_on_device(gpulib, oracle):
     procs = [(tool, subprocess.Popen([sys.executable, os.path.join(ROOT, 'tools', tool), SEED, '400', str(cases)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
              for tool, cases in SLICES]
     for tool, p in procs:
-        out, err = p.communicate(timeout=600)
+        out, err = p.communicate(timeout=300)
         assert p.returncode == 0, (tool, err[-2000:])
         last = out.strip().splitlines()[-1]
         assert last.startswith('seed') and last.endswith('bad 0'), (tool, out[-2000:])

@@ -185,7 +185,7 @@ for rep in range(3):
 print("FORK_OK", float(np.abs(plain[0]).max()))
 ''')
     env = dict(os.environ, SGX_DET_FORK='3', SGX_DET_EXECS='2')
-    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and 'FORK_OK' in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
 
 
@@ -209,5 +209,5 @@ print('IRB3_OK', n3, len(worst), max(worst.values()))
 assert n3 >= 6
 ''')
     env = dict(os.environ, SGX_DET_IRB3='1')
-    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and 'IRB3_OK' in out.stdout, (out.stdout[-800:], out.stderr[-2500:])
