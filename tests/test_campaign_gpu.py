@@ -15,7 +15,7 @@ SLICES = [('campaign_orb.py', 150), ('campaign_orb_geometry.py', 150), ('campaig
 
 def test_campaign_slices_on_device(gpulib, oracle):
     env = dict(os.environ, SGX_CAMPAIGN_LIB='device', OMP_NUM_THREADS='2', OPENBLAS_NUM_THREADS='2', MKL_NUM_THREADS='2')
-    procs = [(tool, subprocess.Popen([sys.executable, os.path.join(ROOT, 'tools', tool), SEED, '400', str(cases)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    procs = [(tool, subprocess.Popen([sys.executable, os.path.join(ROOT, 'tools', tool), SEED, '150', str(cases)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
              for tool, cases in SLICES]
     for tool, p in procs:
         out, err = p.communicate(timeout=300)
