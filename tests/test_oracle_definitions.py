@@ -1,0 +1,188 @@
+"""The oracle's restated third-party primitives against INDEPENDENT statements of their mathematical definitions (numpy / scipy / torch float64, nothing shared with oracle/*.c).
+This does not pin OpenCV's bits (absent here: DESIGN.md §2 — parity stays unpinned); it pins what each primitive MEANS, so that a mis-restated alignment, border rule, tap set,
+arc length or score definition cannot hide behind oracle == device agreement.  Fixed-point primitives must be within their own rounding of the exact real-valued result; the
+integer-exact ones must be equal."""
+import numpy as np
+import pytest
+from scipy import ndimage
+
+
+def _img(seed, h=97, w=131):
+    rng = np.random.RandomState(seed)
+    base = ndimage.gaussian_filter(rng.rand(h, w), 2.0) * 900 - 200 + rng.rand(h, w) * 60
+    return np.clip(base, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize('seed,dw,dh', [(1, 109, 81), (2, 110, 80), (3, 66, 49)])
+def test_resize_linear_is_pixel_centre_bilinear(oracle, seed, dw, dh):
+    """cv::resize(INTER_LINEAR): sample position (dx + 0.5) * sw / dw - 0.5, clamped at the borders, bilinear weights (11-bit fixed point in the restatement): against torch's float64
+    bilinear interpolation with align_corners=False (the same definition) the fixed-point result is within 1 grey level everywhere and equal almost everywhere."""
+    import torch
+    import torch.nn.functional as F
+    src = _img(seed)
+    got = oracle.resize_linear(src, dw, dh).astype(np.int32)
+    ref = F.interpolate(torch.from_numpy(src.astype(np.float64))[None, None], size=(dh, dw), mode='bilinear', align_corners=False)[0, 0].numpy()
+    d = np.abs(got - ref)
+    assert d.max() <= 1.0 + 1e-9 and (np.abs(got - np.rint(ref)) == 0).mean() > 0.9, (d.max(), (np.abs(got - np.rint(ref)) == 0).mean())
+
+
+def test_gaussian7_is_sigma2_gaussian_reflect101(oracle):
+    """cv::GaussianBlur(7 x 7, sigma 2, BORDER_REFLECT_101): against the exact normalised Gaussian taps exp(-x^2 / 8) convolved in float64 with scipy's 'mirror' border (= REFLECT_101)
+    the 8.8 fixed-point result ({18, 34, 48, 56, 48, 34, 18} / 256 for {17.96, 33.55, 48.82, 55.33, ...}) stays within 1.5 grey levels, mean error below 0.3, borders included."""
+    src = _img(4)
+    x = np.arange(-3, 4); k = np.exp(-x * x / 8.0); k /= k.sum()
+    ref = ndimage.convolve1d(ndimage.convolve1d(src.astype(np.float64), k, axis=0, mode='mirror'), k, axis=1, mode='mirror')
+    got = oracle.gaussian7(src).astype(np.float64)
+    d = np.abs(got - ref)
+    assert d.max() <= 1.5 and d.mean() < 0.3, (d.max(), d.mean())
+    assert np.abs((got - ref)[:3]).max() <= 1.5 and np.abs((got - ref)[:, -3:]).max() <= 1.5
+
+
+def test_pyr_down_is_binomial5_decimation(oracle):
+    """cv::pyrDown: [1 4 6 4 1]^2 / 256, REFLECT_101, every second sample, round half up — exact integers, so the independent statement must agree bit for bit"""
+    for seed, (h, w) in ((5, (96, 128)), (6, (97, 131))):
+        src = _img(seed, h, w)
+        k = np.array([1, 4, 6, 4, 1], np.int64)
+        full = ndimage.convolve1d(ndimage.convolve1d(src.astype(np.int64), k, axis=0, mode='mirror'), k, axis=1, mode='mirror')
+        ref = ((full[::2, ::2] + 128) >> 8).astype(np.uint8)
+        got = oracle.pyr_down(src)
+        assert got.shape == ref.shape and (got == ref).all()
+
+
+def test_scharr_deriv_is_3_10_3_central_difference(oracle):
+    """calcSharrDeriv: Ix = [3 10 3]^T x [-1 0 1], Iy = [-1 0 1]^T x [3 10 3] as int16 (interior; the border rule is checked by the LK tests)"""
+    src = _img(7).astype(np.int64)
+    sm = np.array([3, 10, 3], np.int64); df = np.array([-1, 0, 1], np.int64)
+    ix = ndimage.correlate1d(ndimage.correlate1d(src, sm, axis=0, mode='mirror'), df, axis=1, mode='mirror')
+    iy = ndimage.correlate1d(ndimage.correlate1d(src, df, axis=0, mode='mirror'), sm, axis=1, mode='mirror')
+    d = oracle.scharr_deriv(src.astype(np.uint8)).astype(np.int64)
+    assert (d[1:-1, 1:-1, 0] == ix[1:-1, 1:-1]).all() and (d[1:-1, 1:-1, 1] == iy[1:-1, 1:-1]).all()
+
+
+RING = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+
+
+def _fast_score_definition(img):
+    """S(p) = max over the 16 arcs of 9 contiguous ring pixels and both polarities of min over the arc of (v - ring) [darker ring] or (ring - v) [brighter ring], minus 1, floored at
+    -1: p is a FAST-9/16 corner at threshold t iff some arc is entirely brighter than v + t or entirely darker than v - t iff S(p) >= t (cv::FAST's segment test and cornerScore)."""
+    h, w = img.shape; v = img.astype(np.int64)
+    ring = np.stack([np.roll(np.roll(v, -dy, 0), -dx, 1) for dx, dy in RING])          # ring[k][y, x] = img[y + dy, x + dx]
+    dark = v[None] - ring; bright = ring - v[None]
+    best = np.full((h, w), -10 ** 9, np.int64)
+    for s in range(16):
+        idx = [(s + j) % 16 for j in range(9)]
+        best = np.maximum(best, np.maximum(dark[idx].min(0), bright[idx].min(0)))
+    return best - 1
+
+
+@pytest.mark.parametrize('seed', [11, 12])
+def test_fast_is_the_9_of_16_segment_test_with_the_arc_score(oracle, seed):
+    """cv::FAST(threshold, nonmax = false) returns exactly the interior pixels whose definition score is >= threshold, with that score as response, for both thresholds the
+    extractor uses; with nonmax = true exactly those of them that are strictly greater than their 8 neighbours' scores (non-corners count 0)"""
+    rng = np.random.RandomState(seed)
+    img = _img(seed, 64, 80)
+    img[rng.randint(4, 60, 60), rng.randint(4, 76, 60)] = rng.randint(0, 256, 60)          # isolated spikes: plenty of corners
+    S = _fast_score_definition(img)
+    inner = np.zeros_like(img, bool); inner[3:-3, 3:-3] = True
+    for t in (20, 7):
+        x, y, s = oracle.fast(img, t, nonmax=False)
+        ref = inner & (S >= t)
+        got = np.zeros_like(ref); got[y, x] = True
+        assert (got == ref).all(), t
+        assert (s == S[y, x]).all(), t
+        xs, ys, ss = oracle.fast(img, t, nonmax=True)
+        Sc = np.where(ref, S, 0)
+        pad = np.pad(Sc, 1)
+        nb = np.max(np.stack([pad[1 + dy:1 + dy + img.shape[0], 1 + dx:1 + dx + img.shape[1]] for dy in (-1, 0, 1) for dx in (-1, 0, 1) if (dx, dy) != (0, 0)]), 0)
+        refn = ref & (Sc > nb)
+        gotn = np.zeros_like(ref); gotn[ys, xs] = True
+        assert (gotn == refn).all() and refn.sum() > 10, t
+
+
+def test_fast_atan2_against_arctan2(oracle):
+    rng = np.random.RandomState(3)
+    for _ in range(400):
+        y, x = (float(v) for v in rng.uniform(-1000, 1000, 2))
+        ref = np.degrees(np.arctan2(y, x)) % 360.0
+        d = abs(oracle.fast_atan2(y, x) - ref)
+        assert min(d, 360 - d) < 0.02
+
+
+def test_ic_angle_is_the_intensity_centroid_direction(oracle):
+    """IC_Angle: atan2(m01, m10) of the radius-15 disc of half-widths umax[|v|] around the keypoint, in degrees"""
+    umax = oracle.orb_params()['umax']
+    img = _img(21, 80, 90)
+    for (x, y) in ((40, 40), (33, 47), (60, 25)):
+        m10 = m01 = 0
+        for v in range(-15, 16):
+            for u in range(-umax[abs(v)], umax[abs(v)] + 1):
+                p = int(img[y + v, x + u]); m10 += u * p; m01 += v * p
+        ref = np.degrees(np.arctan2(m01, m10)) % 360.0
+        d = abs(oracle.ic_angle(img, x, y, umax) - ref)
+        assert min(d, 360 - d) < 0.02
+
+
+def _bilinear(img, x, y):
+    """float64 bilinear sample with replicated borders"""
+    h, w = img.shape
+    x0 = np.floor(x).astype(int); y0 = np.floor(y).astype(int); fx = x - x0; fy = y - y0
+    c = lambda a, lo, hi: np.clip(a, lo, hi)
+    p = lambda yy, xx: img[c(yy, 0, h - 1), c(xx, 0, w - 1)]
+    return (1 - fy) * ((1 - fx) * p(y0, x0) + fx * p(y0, x0 + 1)) + fy * ((1 - fx) * p(y0 + 1, x0) + fx * p(y0 + 1, x0 + 1))
+
+
+def _lk_textbook(I, J, pts, levels=4, win=21, iters=30, eps=0.01):
+    """Pyramidal Lucas-Kanade in float64, straight from the definition (Bouguet): binomial-5 pyramids, Scharr gradients / 32 of the first image, the 21 x 21 window sampled
+    bilinearly, Gauss-Newton steps d = G^-1 b with G = sum [Ix^2 IxIy; IxIy Iy^2], b = sum (I - J) [Ix; Iy], from the coarsest level down.  No fixed point, no integer tricks."""
+    k = np.array([1, 4, 6, 4, 1], np.float64) / 16
+    def down(a):
+        f = ndimage.convolve1d(ndimage.convolve1d(a, k, axis=0, mode='mirror'), k, axis=1, mode='mirror')
+        return f[::2, ::2]
+    PI = [I.astype(np.float64)]; PJ = [J.astype(np.float64)]
+    for _ in range(levels - 1): PI.append(np.floor(down(PI[-1]) + 0.5)); PJ.append(np.floor(down(PJ[-1]) + 0.5))       # the u8 pyramid of the library
+    sm = np.array([3, 10, 3], np.float64) / 32; df = np.array([-1, 0, 1], np.float64)
+    out = []
+    half = (win - 1) / 2
+    wy, wx = np.mgrid[0:win, 0:win].astype(np.float64)
+    for (px, py) in pts:
+        g = np.zeros(2)
+        for l in range(levels - 1, -1, -1):
+            A, B = PI[l], PJ[l]
+            Ix = ndimage.correlate1d(ndimage.correlate1d(A, sm, axis=0, mode='mirror'), df, axis=1, mode='mirror')
+            Iy = ndimage.correlate1d(ndimage.correlate1d(A, df, axis=0, mode='mirror'), sm, axis=1, mode='mirror')
+            cx, cy = px / 2 ** l, py / 2 ** l
+            X = cx - half + wx; Y = cy - half + wy
+            a = _bilinear(A, X, Y); ix = _bilinear(Ix, X, Y); iy = _bilinear(Iy, X, Y)
+            G = np.array([[np.sum(ix * ix), np.sum(ix * iy)], [np.sum(ix * iy), np.sum(iy * iy)]])
+            v = np.zeros(2)
+            for _ in range(iters):
+                b_img = _bilinear(B, X + g[0] + v[0], Y + g[1] + v[1])
+                e = b_img - a
+                bb = np.array([np.sum(e * ix), np.sum(e * iy)])
+                d = -np.linalg.solve(G, bb)
+                v += d
+                if d @ d <= eps * eps: break
+            g = (g + v) * (2 if l > 0 else 1)
+        out.append((px + g[0], py + g[1]))
+    return np.array(out)
+
+
+def test_lk_agrees_with_a_textbook_float64_lucas_kanade(oracle):
+    """calcOpticalFlowPyrLK as restated (integer pyramids, 5-bit derivative scale, 14-bit bilinear weights, exact-sum accumulation) against a float64 Gauss-Newton LK written from
+    the definition: on textured points of a warped frame pair both land within 0.01 px of each other (measured 4e-5 px median) and within 0.2 px of the true displacement — the fixed-point pipeline
+    computes Lucas-Kanade flow, not something else that merely agrees with the device"""
+    from sg_slam_amd import synth
+    S = synth.PlaneStream(seed=1234)
+    cur, prev = S.frame(11)[0], S.frame(10)[0]
+    k, _ = oracle.orb_extract(cur)
+    lvl0 = k[k['octave'] == 0]
+    pts = np.stack([lvl0['x'], lvl0['y']], 1).astype('f4')
+    pts = pts[(pts[:, 0] > 60) & (pts[:, 0] < 580) & (pts[:, 1] > 60) & (pts[:, 1] < 420)][:40]
+    got, st = oracle.lk_pyr(cur, prev, pts, acc_mode=1)
+    ref = _lk_textbook(cur, prev, pts.astype(np.float64))
+    ok = st > 0
+    d = np.linalg.norm(got[ok].astype(np.float64) - ref[ok], axis=1)
+    assert ok.sum() >= 30 and np.median(d) < 2e-3 and d.max() < 1e-2, (ok.sum(), np.median(d), d.max())          # measured: median 4e-5 px, max 2e-4 px over 40 points
+    A = synth.flow_affine(S, 11, 10)                                  # the true map cur -> prev on the plane
+    truth = (A @ np.c_[pts.astype(np.float64), np.ones(len(pts))].T).T
+    assert np.median(np.linalg.norm(got[ok].astype(np.float64) - truth[ok], axis=1)) < 0.2
