@@ -186,3 +186,68 @@ def test_lk_agrees_with_a_textbook_float64_lucas_kanade(oracle):
     A = synth.flow_affine(S, 11, 10)                                  # the true map cur -> prev on the plane
     truth = (A @ np.c_[pts.astype(np.float64), np.ones(len(pts))].T).T
     assert np.median(np.linalg.norm(got[ok].astype(np.float64) - truth[ok], axis=1)) < 0.2
+
+
+@pytest.mark.parametrize('n,seed', [(400, 43), (800, 47)])
+def test_pose_optimization_returns_the_least_squares_pose_of_its_inliers(oracle, n, seed):
+    """Optimizer::PoseOptimization's last rounds run without the robust kernel on the edges still classified as inliers, so the pose it returns must be the weighted least-squares
+    optimum of the reprojection error over exactly those edges — checked with scipy's own Levenberg-Marquardt (MINPACK) on an independently written residual (mono: 2 rows per
+    edge, stereo: 3 with u_R = u - bf / z; weight 1 / sigma^2 of the octave): started from the returned pose it must not move (< 1e-5) nor lower chi^2 (< 1e-6 relative)."""
+    from scipy.optimize import least_squares
+    from scipy.spatial.transform import Rotation as Rot
+    from scenes import make_pose_problem, CAM
+    frame, Ttrue, _ = make_pose_problem(oracle, n=n, seed=seed)
+    is2 = oracle.orb_params()['inv_sigma2']
+    ninl, T, out = oracle.pose_optimization(frame, CAM, is2)
+    T = T.astype(np.float64)
+    sel = (frame['has_mp'] > 0) & (out == 0)
+    k = frame['keys']; X = frame['xw'].astype(np.float64)[sel]
+    u = k['x'].astype(np.float64)[sel]; v = k['y'].astype(np.float64)[sel]; ur = frame['uright'].astype(np.float64)[sel]
+    w = np.sqrt(is2[k['octave']].astype(np.float64)[sel]); stereo = ur >= 0
+
+    def resid(p):
+        R = Rot.from_rotvec(p[:3]).as_matrix() @ T[:3, :3]; t = T[:3, 3] + p[3:]
+        Xc = X @ R.T + t
+        pu = CAM['fx'] * Xc[:, 0] / Xc[:, 2] + CAM['cx']; pv = CAM['fy'] * Xc[:, 1] / Xc[:, 2] + CAM['cy']; pr = pu - CAM['bf'] / Xc[:, 2]
+        return np.concatenate([w * (u - pu), w * (v - pv), (w * (ur - pr))[stereo]])
+
+    c0 = float((resid(np.zeros(6)) ** 2).sum())
+    sol = least_squares(resid, np.zeros(6), method='lm', xtol=1e-14, ftol=1e-14)
+    assert ninl == sel.sum() and ninl > 0.5 * n
+    assert np.abs(sol.x).max() < 1e-5 and c0 - float((sol.fun ** 2).sum()) < 1e-6 * c0, (np.abs(sol.x).max(), c0, float((sol.fun ** 2).sum()))
+    assert np.abs(T - Ttrue).max() < 5e-3
+
+
+def test_local_bundle_adjustment_ends_at_the_least_squares_optimum_of_its_kept_edges(oracle):
+    """Optimizer::LocalBundleAdjustment's second pass (10 LM iterations, no robust kernel, erased edges excluded) on a LocalBA-sized graph: scipy's trust-region least squares on an
+    independently written residual over the free poses and the points of the kept edges, started from the returned estimate, gains < 1e-5 of chi^2 and moves no pose by 1e-4
+    (weakly observable point depths may still slide along their rays: not asserted)."""
+    from scipy.optimize import least_squares
+    from scipy.spatial.transform import Rotation as Rot
+    from scenes import make_ba_problem, CAM
+    prob, _, _ = make_ba_problem(oracle, n_free=4, n_fixed=3, n_points=120, seed=11)
+    poses, pts, erase, trace, iters = oracle.local_ba(prob, CAM)
+    poses = poses.astype(np.float64); pts = pts.astype(np.float64)
+    free = np.nonzero(prob['pose_fixed'] == 0)[0]
+    keep = erase == 0
+    ep, el = prob['edge_pose'][keep], prob['edge_point'][keep]
+    eo, ei = prob['edge_obs'].astype(np.float64)[keep], prob['edge_info'].astype(np.float64)[keep]
+    used = np.unique(el)
+    w = np.sqrt(ei); stereo = eo[:, 2] >= 0
+
+    def resid(p):
+        dp = p[:6 * len(free)].reshape(-1, 6); dx = p[6 * len(free):].reshape(-1, 3)
+        R = poses[:, :3, :3].copy(); t = poses[:, :3, 3].copy()
+        for j, i in enumerate(free):
+            R[i] = Rot.from_rotvec(dp[j, :3]).as_matrix() @ poses[i, :3, :3]; t[i] = poses[i, :3, 3] + dp[j, 3:]
+        X = pts.copy(); X[used] += dx
+        Xc = np.einsum('eij,ej->ei', R[ep], X[el]) + t[ep]
+        pu = CAM['fx'] * Xc[:, 0] / Xc[:, 2] + CAM['cx']; pv = CAM['fy'] * Xc[:, 1] / Xc[:, 2] + CAM['cy']; pr = pu - CAM['bf'] / Xc[:, 2]
+        return np.concatenate([w * (eo[:, 0] - pu), w * (eo[:, 1] - pv), (w * (eo[:, 2] - pr))[stereo]])
+
+    n0 = 6 * len(free) + 3 * len(used)
+    c0 = float((resid(np.zeros(n0)) ** 2).sum())
+    assert abs(c0 - trace[1, iters[1] - 1, 0]) <= 1e-6 * c0                 # the independent residual reproduces the oracle's own final chi^2 (float poses / points rounded at the boundary)
+    sol = least_squares(resid, np.zeros(n0), method='trf', xtol=1e-15, ftol=1e-15, gtol=1e-15)
+    c1 = float((sol.fun ** 2).sum())
+    assert (c0 - c1) < 1e-5 * c0 and np.abs(sol.x[:6 * len(free)]).max() < 1e-4, (c0, c1, np.abs(sol.x[:6 * len(free)]).max())
