@@ -251,3 +251,36 @@ def test_local_bundle_adjustment_ends_at_the_least_squares_optimum_of_its_kept_e
     sol = least_squares(resid, np.zeros(n0), method='trf', xtol=1e-15, ftol=1e-15, gtol=1e-15)
     c1 = float((sol.fun ** 2).sum())
     assert (c0 - c1) < 1e-5 * c0 and np.abs(sol.x[:6 * len(free)]).max() < 1e-4, (c0, c1, np.abs(sol.x[:6 * len(free)]).max())
+
+
+def _rot_cw(img):
+    """rotate the image content by +90 degrees in image coordinates (x to the right, y down; the sense in which IC_Angle / KeyPoint::angle grow): N[y', x'] = B[y, x] with
+    (x', y') = (H - 1 - y, x)"""
+    return np.ascontiguousarray(np.rot90(img, k=-1))
+
+
+def test_orientation_and_descriptor_are_rotation_equivariant(oracle):
+    """Geometric meaning of the steering: rotating the image by +90 degrees turns the intensity-centroid angle by +90 degrees and leaves the rBRIEF descriptor computed at the
+    rotated keypoint with the rotated angle UNCHANGED (angles 0 / 90 / 180 / 270: cos / sin are 0, +-1 up to 4e-8, so the rounded sample offsets are the exactly rotated ones);
+    FAST corners and scores rotate with the image."""
+    umax = oracle.orb_params()['umax']
+    img = _img(31, 101, 101)                                       # square: H - 1 - y stays inside
+    blur = oracle.gaussian7(img)
+    assert (oracle.gaussian7(_rot_cw(img)) == _rot_cw(blur)).all()                 # the symmetric blur commutes with the rotation
+    H = img.shape[0]
+    for (x, y) in ((50, 50), (40, 57), (61, 44)):
+        imgs = [img]; blurs = [blur]; pos = [(x, y)]
+        for _ in range(3):
+            imgs.append(_rot_cw(imgs[-1])); blurs.append(_rot_cw(blurs[-1])); px, py = pos[-1]; pos.append((H - 1 - py, px))
+        a0 = oracle.ic_angle(img, x, y, umax)
+        d0 = oracle.descriptor(blur, x, y, 0.0)
+        for q in range(1, 4):
+            aq = oracle.ic_angle(imgs[q], pos[q][0], pos[q][1], umax)
+            dd = (aq - a0 - 90.0 * q) % 360.0
+            assert min(dd, 360.0 - dd) < 0.02, (q, a0, aq)
+            assert (oracle.descriptor(blurs[q], pos[q][0], pos[q][1], 90.0 * q) == d0).all(), q
+        assert d0.any()
+    x0, y0, s0 = oracle.fast(img, 20, nonmax=True)
+    x1, y1, s1 = oracle.fast(_rot_cw(img), 20, nonmax=True)
+    a = sorted(zip((H - 1 - y0).tolist(), x0.tolist(), s0.tolist())); b = sorted(zip(x1.tolist(), y1.tolist(), s1.tolist()))
+    assert a == b and len(a) > 5
