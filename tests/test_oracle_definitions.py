@@ -284,3 +284,23 @@ def test_orientation_and_descriptor_are_rotation_equivariant(oracle):
     x1, y1, s1 = oracle.fast(_rot_cw(img), 20, nonmax=True)
     a = sorted(zip((H - 1 - y0).tolist(), x0.tolist(), s0.tolist())); b = sorted(zip(x1.tolist(), y1.tolist(), s1.tolist()))
     assert a == b and len(a) > 5
+
+
+def test_rgbd_stereo_and_unprojection_are_the_pinhole_model(oracle):
+    """ComputeStereoFromRGBD: z = raw / 5000 at the keypoint's TRUNCATED pixel (imDepth.at<float>(v, u) with float arguments, Frame.cc:903-906), u_R = u - bf / z; UnprojectStereo: the world point that the pose + pinhole model project back onto the
+    keypoint with that depth (float32 round trip)"""
+    from sg_slam_amd import synth
+    from scenes import CAM
+    S = synth.LayeredStream(seed=1234)
+    g, depth, T = S.frame(7)
+    k, _ = oracle.orb_extract(g)
+    ur, z = oracle.compute_stereo_from_rgbd(k, depth, CAM['bf'], CAM['depth_factor'])
+    xi = np.floor(k['x'].astype(np.float64)).astype(int); yi = np.floor(k['y'].astype(np.float64)).astype(int)
+    zr = depth[np.clip(yi, 0, 479), np.clip(xi, 0, 639)].astype(np.float64) / CAM['depth_factor']
+    good = z > 0
+    assert good.mean() > 0.9 and np.abs(z[good] - zr[good]).max() < 1e-6 and np.abs(ur[good] - (k['x'][good] - CAM['bf'] / zr[good])).max() < 1e-3
+    xw, has = oracle.unproject_stereo(k, z, T.astype('f4'), CAM)
+    assert (has.astype(bool) == good).all()
+    Xc = xw[good].astype(np.float64) @ T[:3, :3].T + T[:3, 3]
+    u = CAM['fx'] * Xc[:, 0] / Xc[:, 2] + CAM['cx']; v = CAM['fy'] * Xc[:, 1] / Xc[:, 2] + CAM['cy']
+    assert np.abs(u - k['x'][good]).max() < 2e-3 and np.abs(v - k['y'][good]).max() < 2e-3 and np.abs(Xc[:, 2] - z[good]).max() < 1e-5
