@@ -304,3 +304,16 @@ def test_rgbd_stereo_and_unprojection_are_the_pinhole_model(oracle):
     Xc = xw[good].astype(np.float64) @ T[:3, :3].T + T[:3, 3]
     u = CAM['fx'] * Xc[:, 0] / Xc[:, 2] + CAM['cx']; v = CAM['fy'] * Xc[:, 1] / Xc[:, 2] + CAM['cy']
     assert np.abs(u - k['x'][good]).max() < 2e-3 and np.abs(v - k['y'][good]).max() < 2e-3 and np.abs(Xc[:, 2] - z[good]).max() < 1e-5
+
+
+def test_detector_preprocessing_is_pixel_centre_bilinear_minus_mean():
+    """ncnn::Mat::from_pixels_resize (fixed-point bilinear, as restated in oracle/detector_oracle.py) + substract_mean_normalize: within one grey level of torch's float64
+    bilinear interpolation with align_corners = False, channel means removed"""
+    import torch
+    import torch.nn.functional as F
+    from oracle import detector_oracle as D
+    rng = np.random.RandomState(5)
+    img = np.clip(ndimage.gaussian_filter(rng.rand(480, 640, 3), (2, 2, 0)) * 700 - 150, 0, 255).astype(np.uint8)
+    x = D.preprocess(img)
+    ref = F.interpolate(torch.from_numpy(img.astype(np.float64)).permute(2, 0, 1)[None], size=(300, 300), mode='bilinear', align_corners=False)[0].numpy() - D.MEAN.astype(np.float64)[:, None, None]
+    assert x.shape == (3, 300, 300) and np.abs(x - ref).max() <= 1.0 + 1e-4
