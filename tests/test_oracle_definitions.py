@@ -317,3 +317,40 @@ def test_detector_preprocessing_is_pixel_centre_bilinear_minus_mean():
     x = D.preprocess(img)
     ref = F.interpolate(torch.from_numpy(img.astype(np.float64)).permute(2, 0, 1)[None], size=(300, 300), mode='bilinear', align_corners=False)[0].numpy() - D.MEAN.astype(np.float64)[:, None, None]
     assert x.shape == (3, 300, 300) and np.abs(x - ref).max() <= 1.0 + 1e-4
+
+
+def test_sim3_exp_is_the_matrix_exponential_and_log_inverts_it(oracle):
+    """g2o::Sim3(update) (types/sim3.h: omega, upsilon, sigma -> r = exp(omega), s = e^sigma, t = W upsilon) against scipy's matrix exponential of the 4 x 4 generator
+    [[omega^ + sigma I, upsilon], [0, 0]] = [[s R, t], [0, 1]], and Sim3::log as its inverse — the group the loop-closing optimisers (OptimizeSim3, OptimizeEssentialGraph) move in"""
+    import ctypes as C
+    from scipy.linalg import expm
+    from scipy.spatial.transform import Rotation as Rot
+    L = oracle.lib()
+    rng = np.random.RandomState(9)
+    for scale in (1e-3, 0.1, 1.0, 2.5):
+        for _ in range(6):
+            u = rng.randn(7) * scale; u[6] = rng.randn() * min(scale, 0.5)
+            out = np.zeros(8)
+            L.orc_kat_sim3_exp(u.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+            w = u[:3]
+            G = np.zeros((4, 4)); G[:3, :3] = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]) + u[6] * np.eye(3); G[:3, 3] = u[3:6]
+            M = expm(G)
+            s = out[7]; R = Rot.from_quat(out[:4]).as_matrix()
+            assert abs(s - np.exp(u[6])) < 1e-12 * max(1, s)
+            assert np.abs(s * R - M[:3, :3]).max() < 1e-9 * max(1.0, np.abs(M).max()) and np.abs(out[4:7] - M[:3, 3]).max() < 1e-9 * max(1.0, np.abs(M).max()), (scale, u)
+            back = np.zeros(7)
+            L.orc_kat_sim3_log(out.ctypes.data_as(C.c_void_p), back.ctypes.data_as(C.c_void_p))
+            th = np.linalg.norm(w)
+            if 0.01 < th < 3.0:                                   # the general branch of Sim3::log (cos(theta) <= 1 - 1e-5) inside the principal branch of the rotation logarithm
+                assert np.abs(back - u).max() < 1e-8 * max(1.0, np.abs(u).max()), (scale, u, back)
+            elif th < 4e-3 and abs(u[6]) >= 1e-5:
+                # REFERENCE QUIRK, reproduced on purpose: for cos(theta) > 1 - 1e-5 (theta < 4.5e-3) and |sigma| >= 1e-5, sim3.h:195-199 sets
+                # B = ((sigma^2 / 2 - sigma + 1) s) / sigma^3 — the "- 1" of the series is missing, B ~ 1 / sigma^3 instead of ~ 1 / 6 — so log() does NOT invert exp() there:
+                # the translation part comes back wrong.  (Sim3(update) has the same formula, but only below theta = 1e-5.)  The oracle must follow the reference, not the mathematics.
+                sg = u[6]; sc = np.exp(sg)
+                A_ = ((sg - 1) * sc + 1) / sg ** 2; B_ = ((0.5 * sg * sg - sg + 1) * sc) / sg ** 3; C_ = (sc - 1) / sg
+                Rm = Rot.from_quat(out[:4]).as_matrix(); om = 0.5 * np.array([Rm[2, 1] - Rm[1, 2], Rm[0, 2] - Rm[2, 0], Rm[1, 0] - Rm[0, 1]])
+                Om = np.array([[0, -om[2], om[1]], [om[2], 0, -om[0]], [-om[1], om[0], 0]])
+                ups = np.linalg.solve(A_ * Om + B_ * Om @ Om + C_ * np.eye(3), out[4:7])
+                assert np.abs(back[3:6] - ups).max() < 1e-6 * max(1e-3, np.abs(ups).max()) and np.abs(back[:3] - om).max() < 1e-12 and abs(back[6] - sg) < 1e-12
+                assert np.abs(back[3:6] - u[3:6]).max() > 1e-3 * np.abs(u[3:6]).max()                 # ... and that is not the inverse of exp
