@@ -354,3 +354,45 @@ def test_sim3_exp_is_the_matrix_exponential_and_log_inverts_it(oracle):
                 ups = np.linalg.solve(A_ * Om + B_ * Om @ Om + C_ * np.eye(3), out[4:7])
                 assert np.abs(back[3:6] - ups).max() < 1e-6 * max(1e-3, np.abs(ups).max()) and np.abs(back[:3] - om).max() < 1e-12 and abs(back[6] - sg) < 1e-12
                 assert np.abs(back[3:6] - u[3:6]).max() > 1e-3 * np.abs(u[3:6]).max()                 # ... and that is not the inverse of exp
+
+
+def test_detection_output_against_an_independent_vectorised_nms():
+    """ncnn DetectionOutput as restated in oracle/detector_oracle.py against a second implementation written differently (decoded boxes and the full IoU matrix by numpy
+    broadcasting in float32, greedy suppression as a boolean sweep): same rows on random head outputs with heavy overlaps"""
+    from oracle import detector_oracle as D
+    from test_detector import PARAM
+    layers = D.parse_param(PARAM)
+    p = [L for L in layers if L['type'] == 'DetectionOutput'][0]['p']
+    pri = [D.prior_box(fh, fh, 300, L['p']) for L, fh in zip([L for L in layers if L['type'] == 'PriorBox'], (19, 10, 5, 3, 2, 1))]
+    priors = np.concatenate(pri, 1)
+    n = priors.shape[1] // 4; nc = p[0]
+    rng = np.random.RandomState(4)
+    for trial in range(3):
+        loc = (rng.randn(n, 4) * (0.3, 1.0, 2.0)[trial]).astype(np.float32)
+        raw = rng.randn(n, nc).astype(np.float32) * 2; raw[:, 0] += 2
+        conf = np.exp(raw - raw.max(1, keepdims=True)); conf = (conf / conf.sum(1, keepdims=True)).astype(np.float32)
+        ref = D.detection_output(loc.reshape(-1), conf.reshape(-1), priors, p)
+        # independent implementation
+        var = np.array([p.get(5, .1), p.get(6, .1), p.get(7, .2), p.get(8, .2)], np.float32)
+        pb = priors[0].reshape(-1, 4)
+        pw = pb[:, 2] - pb[:, 0]; ph = pb[:, 3] - pb[:, 1]; pcx = (pb[:, 0] + pb[:, 2]) * np.float32(.5); pcy = (pb[:, 1] + pb[:, 3]) * np.float32(.5)
+        cx = var[0] * loc[:, 0] * pw + pcx; cy = var[1] * loc[:, 1] * ph + pcy
+        w = np.exp(var[2] * loc[:, 2]).astype(np.float32) * pw; h = np.exp(var[3] * loc[:, 3]).astype(np.float32) * ph
+        B = np.stack([cx - w * np.float32(.5), cy - h * np.float32(.5), cx + w * np.float32(.5), cy + h * np.float32(.5)], 1).astype(np.float32)
+        rows = []
+        for c in range(1, nc):
+            s = conf[:, c]; cand = np.nonzero(s > np.float32(p[4]))[0]
+            cand = cand[np.lexsort((cand, -s[cand]))][:p[2]]                      # score descending, prior index ascending
+            b = B[cand]; area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+            iw = np.minimum(b[:, None, 2], b[None, :, 2]) - np.maximum(b[:, None, 0], b[None, :, 0])
+            ih = np.minimum(b[:, None, 3], b[None, :, 3]) - np.maximum(b[:, None, 1], b[None, :, 1])
+            inter = np.where((iw > 0) & (ih > 0), (iw * ih).astype(np.float32), np.float32(0))
+            iou = inter / (area[:, None] + area[None, :] - inter)
+            alive = np.ones(len(cand), bool); kept = []
+            for i in range(len(cand)):
+                if not alive[i]: continue
+                kept.append(i); alive &= ~(iou[i] > np.float32(p[1])); alive[i] = False
+            rows += [(c, s[cand[i]], *b[i]) for i in kept]
+        rows.sort(key=lambda r: -r[1])
+        mine = np.array(rows[:p[3]], np.float32).reshape(-1, 6)
+        assert mine.shape == ref.shape and len(ref) == p[3] and (mine == ref).all(), trial
