@@ -11,8 +11,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0)); return so.getsockname()[1]
+
+
 def test_bench_rccl_gather_path_single_rank(gpulib):
-    env = dict(os.environ, SGX_BENCH_FORCE_DIST='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29600 + os.getpid() % 300), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+    env = dict(os.environ, SGX_BENCH_FORCE_DIST='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
                HSA_ENABLE_IPC_MODE_LEGACY='0')
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '6', '--warmup', '3', '--streams', '8', '--no-cpu-baseline', '--no-config2', '--no-config4',
                           '--no-host-input'], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
