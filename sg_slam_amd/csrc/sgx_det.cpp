@@ -5,6 +5,7 @@
 #include "sgx_det_block.h"
 #include "sgx_det_irb.h"
 #include "sgx_det_bf16.h"
+#include "sgx_det_hrb.h"
 #include "sgx_prof.h"
 #include "../../include/sgx.h"
 #ifdef SGX_DEBUG_TAPS
@@ -394,6 +395,8 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
         // k_fused_block2 (VALU-only, thread per pixel) takes the high-resolution few-channel blocks by default (SGX_DET_BLOCK2=0 turns it off); faster than the three kernels there.
         static const int fb2_env = sgx_getenv("SGX_DET_BLOCK2") ? atoi(sgx_getenv("SGX_DET_BLOCK2")) : 1;
         const bool fb2_on = fb2_env != 0 && !g_det_legacy && g_det_fuse;
+        static const int hrb_env = sgx_getenv("SGX_DET_HRB") ? atoi(sgx_getenv("SGX_DET_HRB")) : 1;
+        const bool hrb_on = hrb_env != 0;
         const bool fb1_on = (g_det_block_fusion || sgx_getenv("SGX_DET_BLOCK_FUSION")) && !g_det_legacy;
         if (fb1_on || fb2_on) {
             auto act_only = [&](const Op &o, float *lo, float *hi) -> bool {
@@ -434,6 +437,11 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                         float *dw2 = nullptr; if (h->alloc(&dw2, w2.size())) FAIL(SGX_ERR_NOMEM);
                         if (hipMemcpy(dw2, w2.data(), w2.size() * 4, hipMemcpyHostToDevice) != hipSuccess) FAIL(SGX_ERR_DEVICE);
                         fb.wd2 = dw2;
+                    }
+                    // round 6, bf16x3 plan: the same block with both pointwise convolutions on the bf16 matrix pipes (k_hrb, sgx_det_hrb.h); SGX_DET_HRB=0 (tap) keeps k_fused_block2
+                    if (hrb_on && h->gemm == 1 && a.wS && c.wS && sgx_hrb_variant(fb.Cin, fb.Cmid, fb.Cout, fb.K, fb.stride, 0, res >= 0, fb.lo1, fb.lo2, &fb.TOH, &fb.TOW)) {
+                        fb.hrb = 1; fb.w1S = a.wS; fb.ld1S = a.ldw; fb.w2S = c.wS; fb.ld2S = c.ldw;
+                        fb.tiles_x = (fb.Wo + fb.TOW - 1) / fb.TOW; fb.tiles_y = (fb.Ho + fb.TOH - 1) / fb.TOH;
                     }
                     Op f; f.kind = OP_FUSED_BLOCK; f.in0 = a.in0; f.out = c.out; f.name = a.name + "+" + bq.name + "+" + c.name; f.fb = fb; f.fb_res_blob = res;
                     f.inc = a.inc; f.outc = c.outc; f.H = a.H; f.W = a.W; f.Ho = bq.Ho; f.Wo = bq.Wo; f.k = bq.k; f.stride = bq.stride;
@@ -568,6 +576,10 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                             if (hipMemcpy(dw2, w2.data(), w2.size() * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dp1, p1.data(), p1.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
                                 hipMemcpy(dp2, p2.data(), p2.size() * 4, hipMemcpyHostToDevice) != hipSuccess) FAIL(SGX_ERR_DEVICE);
                             fb.wd2 = dw2; fb.wq1p = dp1; fb.wq2p = dp2;
+                        }
+                        if (hrb_on && h->gemm == 1 && a.wS && c.wS && d.wS && e.wS && sgx_hrb_variant(fb.Cin, fb.Cmid, fb.Cout, fb.K, fb.stride, fb.Cq, res_blob >= 0, fb.lo1, fb.lo2, &fb.TOH, &fb.TOW)) {
+                            fb.hrb = 1; fb.w1S = a.wS; fb.ld1S = a.ldw; fb.w2S = c.wS; fb.ld2S = c.ldw; fb.wq1S = d.wS; fb.ldq1S = d.ldw; fb.wq2S = e.wS; fb.ldq2S = e.ldw;
+                            fb.tiles_x = (fb.Wo + fb.TOW - 1) / fb.TOW; fb.tiles_y = (fb.Ho + fb.TOH - 1) / fb.TOH;
                         }
                         Op f; f.kind = OP_FUSED_BLOCK; f.in0 = a.in0; f.out = out_blob; f.fb = fb; f.fb_res_blob = res_blob;
                         f.name = a.name + "+" + bq.name + "+" + c.name + "+" + d.name + "+" + e.name;
@@ -920,6 +932,16 @@ static void run_op(sgx_det *h, const Op &op, int batch, sgx_stream_t st)
         SgxFusedBlk fb = op.fb;
         fb.in = A.d; fb.in_pitch = A.n; fb.out = O.d; fb.out_pitch = O.n;
         fb.res = op.fb_res_blob >= 0 ? h->blobs[op.fb_res_blob].d : nullptr; fb.res_pitch = op.fb_res_blob >= 0 ? h->blobs[op.fb_res_blob].n : 0;
+        if (fb.hrb) {
+            SgxHrb q; memset(&q, 0, sizeof q);
+            q.Cin = fb.Cin; q.Cmid = fb.Cmid; q.Cout = fb.Cout; q.Cq = fb.Cq; q.K = fb.K; q.S = fb.stride; q.pad = fb.pad; q.H = fb.H; q.W = fb.W; q.Ho = fb.Ho; q.Wo = fb.Wo;
+            q.TOH = fb.TOH; q.TOW = fb.TOW; q.tiles_x = fb.tiles_x; q.tiles_y = fb.tiles_y; q.lo1 = fb.lo1; q.hi1 = fb.hi1; q.lo2 = fb.lo2; q.hi2 = fb.hi2;
+            q.in = fb.in; q.in_pitch = fb.in_pitch; q.out = fb.out; q.out_pitch = fb.out_pitch; q.res = fb.res; q.res_pitch = fb.res_pitch;
+            q.w1S = (const sgx_q4 *)fb.w1S; q.ld1 = fb.ld1S; q.b1 = fb.b1; q.wd2 = fb.wd2; q.bd = fb.bd; q.w2S = (const sgx_q4 *)fb.w2S; q.ld2 = fb.ld2S; q.b2 = fb.b2;
+            q.wq1S = (const sgx_q4 *)fb.wq1S; q.wq2S = (const sgx_q4 *)fb.wq2S; q.ldq1 = fb.ldq1S; q.ldq2 = fb.ldq2S; q.bq1 = fb.bq1; q.bq2 = fb.bq2;
+            q.qlo = fb.qlo; q.qhi = fb.qhi; q.gc1 = fb.gc1; q.glo = fb.glo; q.ghi = fb.ghi; q.gc2 = fb.gc2;
+            (void)sgx_hrb_launch(q, batch, st); break;
+        }
         if (fb.v2) { (void)sgx_fb2_launch(fb, batch, st); break; }                      // the variant was validated when the plan was built
         SGX_LAUNCH_DYN(k_fused_block, dim3((unsigned)(fb.tiles_x * fb.tiles_y * batch)), dim3(256), sgx_fb_lds_floats(fb) * 4, st, fb);
         break; }
@@ -1181,8 +1203,8 @@ extern "C" int sgx_det_plan_step(const sgx_det *h, int i, char *buf, int cap)
         snprintf(buf, cap, "%s %s c%d->%d k%d s%d %s%dx%d->%dx%d epi%d%s%s", kn[o.kind], o.name.c_str(), o.inc, o.outc, o.k, o.stride, o.depthwise ? "dw " : "", o.H, o.W,
                  o.kind == OP_PW ? o.H : o.Ho, o.kind == OP_PW ? o.W : o.Wo, (int)o.epi.size() + (o.act ? 1 : 0), o.hwc ? " hwc" : "", (o.kind == OP_PW && h->gemm == 1 && o.wS && o.inc >= (sgx_getenv("SGX_PW3_MINK") ? atoi(sgx_getenv("SGX_PW3_MINK")) : 64)) ? " bf16x3" : "");
     else if (o.kind == OP_FUSED_BLOCK)
-        snprintf(buf, cap, "block %s c%d->%d->%d k%d s%d %dx%d->%dx%d tile %dx%d%s%s", o.name.c_str(), o.fb.Cin, o.fb.Cmid, o.fb.Cout, o.fb.K, o.fb.stride, o.H, o.W, o.Ho, o.Wo, o.fb.TOH, o.fb.TOW,
-                 o.fb.Cq ? " se" : "", o.fb_res_blob >= 0 ? " +res" : "");
+        snprintf(buf, cap, "block %s c%d->%d->%d k%d s%d %dx%d->%dx%d tile %dx%d%s%s%s", o.name.c_str(), o.fb.Cin, o.fb.Cmid, o.fb.Cout, o.fb.K, o.fb.stride, o.H, o.W, o.Ho, o.Wo, o.fb.TOH, o.fb.TOW,
+                 o.fb.Cq ? " se" : "", o.fb_res_blob >= 0 ? " +res" : "", o.fb.hrb ? " hrb bf16x3" : "");
     else if (o.kind == OP_IRB)
         snprintf(buf, cap, "irb %s c%d->%d->%d q%d k%d s%d %dx%d->%dx%d G%d bands%d buf%d%s%s%s%s", o.name.c_str(), o.irb.Cin, o.irb.Cexp, o.irb.Cout, o.irb.Cq, o.irb.K, o.irb.S, o.H, o.W, o.Ho, o.Wo,
                  o.irb.G, o.irb.nbands, o.irb.nbuf, o.irb.has_expand ? "" : " noexp", o.irb_res_blob >= 0 ? " +res" : "", o.hwc ? (o.irb.Cout2 ? " hwc dual" : " hwc") : "", o.irb.gemm == 1 ? " bf16x3" : "");
