@@ -439,7 +439,7 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                         fb.wd2 = dw2;
                     }
                     // round 6, bf16x3 plan: the same block with both pointwise convolutions on the bf16 matrix pipes (k_hrb, sgx_det_hrb.h); SGX_DET_HRB=0 (tap) keeps k_fused_block2
-                    if (hrb_on && h->gemm == 1 && a.wS && c.wS && sgx_hrb_variant(fb.Cin, fb.Cmid, fb.Cout, fb.K, fb.stride, 0, res >= 0, fb.lo1, fb.lo2, &fb.TOH, &fb.TOW)) {
+                    if (hrb_on && h->gemm == 1 && a.wS && c.wS && sgx_hrb_variant(fb.Cin, fb.Cmid, fb.Cout, fb.K, fb.stride, 0, res >= 0, fb.lo1, fb.lo2, &fb.TOH, &fb.TOW, &fb.hrb_occ)) {
                         fb.hrb = 1; fb.w1S = a.wS; fb.ld1S = a.ldw; fb.w2S = c.wS; fb.ld2S = c.ldw;
                         fb.tiles_x = (fb.Wo + fb.TOW - 1) / fb.TOW; fb.tiles_y = (fb.Ho + fb.TOH - 1) / fb.TOH;
                     }
@@ -577,7 +577,7 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                                 hipMemcpy(dp2, p2.data(), p2.size() * 4, hipMemcpyHostToDevice) != hipSuccess) FAIL(SGX_ERR_DEVICE);
                             fb.wd2 = dw2; fb.wq1p = dp1; fb.wq2p = dp2;
                         }
-                        if (hrb_on && h->gemm == 1 && a.wS && c.wS && d.wS && e.wS && sgx_hrb_variant(fb.Cin, fb.Cmid, fb.Cout, fb.K, fb.stride, fb.Cq, res_blob >= 0, fb.lo1, fb.lo2, &fb.TOH, &fb.TOW)) {
+                        if (hrb_on && h->gemm == 1 && a.wS && c.wS && d.wS && e.wS && sgx_hrb_variant(fb.Cin, fb.Cmid, fb.Cout, fb.K, fb.stride, fb.Cq, res_blob >= 0, fb.lo1, fb.lo2, &fb.TOH, &fb.TOW, &fb.hrb_occ)) {
                             fb.hrb = 1; fb.w1S = a.wS; fb.ld1S = a.ldw; fb.w2S = c.wS; fb.ld2S = c.ldw; fb.wq1S = d.wS; fb.ldq1S = d.ldw; fb.wq2S = e.wS; fb.ldq2S = e.ldw;
                             fb.tiles_x = (fb.Wo + fb.TOW - 1) / fb.TOW; fb.tiles_y = (fb.Ho + fb.TOH - 1) / fb.TOH;
                         }
@@ -935,7 +935,7 @@ static void run_op(sgx_det *h, const Op &op, int batch, sgx_stream_t st)
         if (fb.hrb) {
             SgxHrb q; memset(&q, 0, sizeof q);
             q.Cin = fb.Cin; q.Cmid = fb.Cmid; q.Cout = fb.Cout; q.Cq = fb.Cq; q.K = fb.K; q.S = fb.stride; q.pad = fb.pad; q.H = fb.H; q.W = fb.W; q.Ho = fb.Ho; q.Wo = fb.Wo;
-            q.TOH = fb.TOH; q.TOW = fb.TOW; q.tiles_x = fb.tiles_x; q.tiles_y = fb.tiles_y; q.lo1 = fb.lo1; q.hi1 = fb.hi1; q.lo2 = fb.lo2; q.hi2 = fb.hi2;
+            q.TOH = fb.TOH; q.TOW = fb.TOW; q.occ = fb.hrb_occ; q.tiles_x = fb.tiles_x; q.tiles_y = fb.tiles_y; q.lo1 = fb.lo1; q.hi1 = fb.hi1; q.lo2 = fb.lo2; q.hi2 = fb.hi2;
             q.in = fb.in; q.in_pitch = fb.in_pitch; q.out = fb.out; q.out_pitch = fb.out_pitch; q.res = fb.res; q.res_pitch = fb.res_pitch;
             q.w1S = (const sgx_q4 *)fb.w1S; q.ld1 = fb.ld1S; q.b1 = fb.b1; q.wd2 = fb.wd2; q.bd = fb.bd; q.w2S = (const sgx_q4 *)fb.w2S; q.ld2 = fb.ld2S; q.b2 = fb.b2;
             q.wq1S = (const sgx_q4 *)fb.wq1S; q.wq2S = (const sgx_q4 *)fb.wq2S; q.ldq1 = fb.ldq1S; q.ldq2 = fb.ldq2S; q.bq1 = fb.bq1; q.bq2 = fb.bq2;
@@ -1204,7 +1204,7 @@ extern "C" int sgx_det_plan_step(const sgx_det *h, int i, char *buf, int cap)
                  o.kind == OP_PW ? o.H : o.Ho, o.kind == OP_PW ? o.W : o.Wo, (int)o.epi.size() + (o.act ? 1 : 0), o.hwc ? " hwc" : "", (o.kind == OP_PW && h->gemm == 1 && o.wS && o.inc >= (sgx_getenv("SGX_PW3_MINK") ? atoi(sgx_getenv("SGX_PW3_MINK")) : 64)) ? " bf16x3" : "");
     else if (o.kind == OP_FUSED_BLOCK)
         snprintf(buf, cap, "block %s c%d->%d->%d k%d s%d %dx%d->%dx%d tile %dx%d%s%s%s", o.name.c_str(), o.fb.Cin, o.fb.Cmid, o.fb.Cout, o.fb.K, o.fb.stride, o.H, o.W, o.Ho, o.Wo, o.fb.TOH, o.fb.TOW,
-                 o.fb.Cq ? " se" : "", o.fb_res_blob >= 0 ? " +res" : "", o.fb.hrb ? " hrb bf16x3" : "");
+                 o.fb.Cq ? " se" : "", o.fb_res_blob >= 0 ? " +res" : "", o.fb.hrb ? (o.fb.hrb_occ == 4 ? " hrb4 bf16x3" : o.fb.hrb_occ == 3 ? " hrb3 bf16x3" : " hrb2 bf16x3") : "");
     else if (o.kind == OP_IRB)
         snprintf(buf, cap, "irb %s c%d->%d->%d q%d k%d s%d %dx%d->%dx%d G%d bands%d buf%d%s%s%s%s", o.name.c_str(), o.irb.Cin, o.irb.Cexp, o.irb.Cout, o.irb.Cq, o.irb.K, o.irb.S, o.H, o.W, o.Ho, o.Wo,
                  o.irb.G, o.irb.nbands, o.irb.nbuf, o.irb.has_expand ? "" : " noexp", o.irb_res_blob >= 0 ? " +res" : "", o.hwc ? (o.irb.Cout2 ? " hwc dual" : " hwc") : "", o.irb.gemm == 1 ? " bf16x3" : "");

@@ -28,7 +28,7 @@ struct SgxFusedBlk {
     const float *wq1, *bq1, *wq2, *bq2;                        // original layouts: wq1 [Cq][Cout], wq2 [Cout][Cq]
     const float *wq1p, *wq2p;                                  // pair-interleaved copies: wq1p [Cq / 2][Cout][2] = (wq1[2j][k], wq1[2j + 1][k]), wq2p [Cq][Cout / 2][2] = (wq2[2c][j], wq2[2c + 1][j])    // round 6: != 0 runs the block as k_hrb (sgx_det_hrb.h: both pointwise convolutions as bf16x3 on the matrix pipes; bf16x3 plan only) — split weights of the expand, project,
     // squeeze and excite convolutions in the MFMA operand layout (sgx_split_weights_bf16x3) with their leading dimensions
-    int hrb; const void *w1S, *w2S, *wq1S, *wq2S; int ld1S, ld2S, ldq1S, ldq2S;
+    int hrb, hrb_occ; const void *w1S, *w2S, *wq1S, *wq2S; int ld1S, ld2S, ldq1S, ldq2S;
 };
 struct SgxFb2Se { const float *wq1p, *bq1, *wq2p, *bq2; float qlo, qhi, gc1, glo, ghi, gc2; };
 #define SGX_FB_CM 32                                           /* expanded channels per chunk = one MFMA row block */

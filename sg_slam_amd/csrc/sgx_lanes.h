@@ -29,6 +29,7 @@ SGX_DEV vf v_sel(vb c, vf a, vf b) { return c ? a : b; }
 SGX_DEV vi v_seli(vb c, vi a, vi b) { return c ? a : b; }
 SGX_DEV vi v_min(vi a, vi b) { return a < b ? a : b; }
 SGX_DEV vu v_u(vi a) { return (unsigned)a; }
+SGX_DEV vf v_fma(vf a, vf b, vf c) { return fmaf(a, b, c); }
 SGX_DEV vf v_clip(vf v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
 SGX_DEV vf v_clipv(vf v, float lo, vf hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
 SGX_DEV vf v_ld(const float *base, vu byte_off) { return *(const float *)((const char *)base + byte_off); }            // uniform base + 32-bit lane offset: global_load with saddr
@@ -36,6 +37,8 @@ SGX_DEV void v_st(float *base, vu byte_off, vf v, vb m) { if (m) *(float *)((cha
 SGX_DEV vu4 v_ldq(const sgx_q4 *base, vi idx) { return base[idx]; }
 SGX_DEV vf2 v_lds_ld2(const sgx_f2 *E, vi idx) { return E[idx]; }
 SGX_DEV void v_lds_st2(sgx_f2 *E, vi idx, vf x, vf y, vb m) { if (m) E[idx] = sgx_mk2(x, y); }
+SGX_DEV vu4 v_lds_ldq(const sgx_q4 *E, vi idx) { return E[idx]; }
+SGX_DEV void v_lds_stq(sgx_q4 *E, vi idx, vu4 v, vb m) { if (m) E[idx] = v; }
 SGX_DEV vf v_lds_ld(const float *E, vi idx) { return E[idx]; }
 SGX_DEV void v_lds_st(float *E, vi idx, vf v) { E[idx] = v; }
 SGX_DEV vf2 v_mk2(vf x, vf y) { return sgx_mk2(x, y); }
@@ -86,6 +89,7 @@ static inline vf v_sel(const vb &c, const vf &a, const vf &b) { vf r; for (int l
 static inline vi v_seli(const vb &c, const vi &a, const vi &b) { vi r; for (int l = 0; l < 64; l++) r.v[l] = c.v[l] ? a.v[l] : b.v[l]; return r; }
 static inline vi v_min(const vi &a, const vi &b) { vi r; for (int l = 0; l < 64; l++) r.v[l] = a.v[l] < b.v[l] ? a.v[l] : b.v[l]; return r; }
 static inline vu v_u(const vi &a) { vu r; for (int l = 0; l < 64; l++) r.v[l] = (unsigned)a.v[l]; return r; }
+static inline vf v_fma(const vf &a, const vf &b, const vf &c) { vf r; for (int l = 0; l < 64; l++) r.v[l] = fmaf(a.v[l], b.v[l], c.v[l]); return r; }
 static inline vf v_clip(const vf &v, float lo, float hi) { vf r; for (int l = 0; l < 64; l++) r.v[l] = fminf(fmaxf(v.v[l], lo), hi); return r; }
 static inline vf v_clipv(const vf &v, float lo, const vf &hi) { vf r; for (int l = 0; l < 64; l++) r.v[l] = fminf(fmaxf(v.v[l], lo), hi.v[l]); return r; }
 static inline vf v_ld(const float *base, const vu &off) { vf r; for (int l = 0; l < 64; l++) r.v[l] = *(const float *)((const char *)base + off.v[l]); return r; }
@@ -93,6 +97,8 @@ static inline void v_st(float *base, const vu &off, const vf &v, const vb &m) { 
 static inline vu4 v_ldq(const sgx_q4 *base, const vi &idx) { vu4 r; for (int l = 0; l < 64; l++) for (int j = 0; j < 4; j++) r.c[j].v[l] = base[idx.v[l]].v[j]; return r; }
 static inline vf2 v_lds_ld2(const sgx_f2 *E, const vi &idx) { vf2 r; for (int l = 0; l < 64; l++) { r.x.v[l] = E[idx.v[l]].x; r.y.v[l] = E[idx.v[l]].y; } return r; }
 static inline void v_lds_st2(sgx_f2 *E, const vi &idx, const vf &x, const vf &y, const vb &m) { for (int l = 0; l < 64; l++) if (m.v[l]) { E[idx.v[l]].x = x.v[l]; E[idx.v[l]].y = y.v[l]; } }
+static inline vu4 v_lds_ldq(const sgx_q4 *E, const vi &idx) { return v_ldq(E, idx); }
+static inline void v_lds_stq(sgx_q4 *E, const vi &idx, const vu4 &v, const vb &m) { for (int l = 0; l < 64; l++) if (m.v[l]) for (int j = 0; j < 4; j++) E[idx.v[l]].v[j] = v.c[j].v[l]; }
 static inline vf v_lds_ld(const float *E, const vi &idx) { vf r; for (int l = 0; l < 64; l++) r.v[l] = E[idx.v[l]]; return r; }
 static inline void v_lds_st(float *E, const vi &idx, const vf &v) { for (int l = 0; l < 64; l++) E[idx.v[l]] = v.v[l]; }
 static inline vf2 v_mk2(const vf &x, const vf &y) { vf2 r; r.x = x; r.y = y; return r; }
