@@ -64,23 +64,24 @@ def ping_pong(T):
 
 def ate_pooled(est, ref):
     """est, ref: (N, S, 4, 4) Tcw; per-stream Horn alignment, pooled translational RMSE over all streams and frames.  A stream whose estimated poses are not finite (tracking
-    diverged: the harness has no relocalisation) is left out of the pool; the caller sees it in tracked_streams_last_frame"""
+    diverged: the harness has no relocalisation) is left out of the pool and COUNTED: the JSON line carries ate_streams_excluded (an ATE that silently improves when
+    tracking diverges is not a measurement)"""
     from sg_slam_amd import tum
-    sq = 0.0; cnt = 0
+    sq = 0.0; cnt = 0; excluded = 0
     for s in range(est.shape[1]):
-        if not np.isfinite(est[:, s]).all(): continue
+        if not np.isfinite(est[:, s]).all(): excluded += 1; continue
         a, b = tum.camera_centres(est[:, s]), tum.camera_centres(ref[:, s])
         try:
             r = tum.ate_rmse(a, b)
         except np.linalg.LinAlgError:
-            continue
+            excluded += 1; continue
         sq += r * r * len(a); cnt += len(a)
-    return float(np.sqrt(sq / max(cnt, 1))), sq, cnt
+    return float(np.sqrt(sq / max(cnt, 1))), sq, cnt, excluded
 
 
 def latest_profile(name):
     """newest committed profiles/rN_<name> (the PMC / standalone passes are collected by tools/collect_profiles.sh, not inside this run)"""
-    for r in ('r5', 'r4', 'r3', 'r2'):
+    for r in ('r6', 'r5', 'r4', 'r3', 'r2'):
         f = os.path.join(ROOT, 'profiles', f'{r}_{name}')
         if os.path.exists(f): return f
     raise FileNotFoundError(name)
@@ -281,7 +282,7 @@ def main():
             weights_note = f'synthetic weights (N(0, 2/fan_in) seed 7 + per-layer batch-norm-style calibration fold, ncnn .bin order), person-class logit {args.person_logit:+g} (the reference tree does not contain the .bin)'
         _param_text = open(args.param).read()
         make_det = lambda n: Detector2D(0.9, 0.01, param_text=_param_text, bin_bytes=blob, max_batch=n, lib=lib)
-        det = make_det(S)
+        det = make_det(S // max(1, args.groups) if args.groups > 1 else S)      # with --groups G > 1 this instance only answers metadata questions (TrackerGroups builds its own per pipeline): no S-batch of activations for it
         if d_bgr is None:
             d_bgr = d_frames.unsqueeze(-1).expand(T, S, 480, 640, 3).contiguous()          # gray replicated to 3 channels (SURVEY §8(d) input 2)
         det_gflop = 2.0 * det.gmac
@@ -292,6 +293,8 @@ def main():
         for desc, _ in ([] if det.gemm != 'bf16x3' else [(d, 0) for d in det.op_descriptions()]):
             m = _re.match(r'pw \S+ c(\d+)->(\d+) k1 s1 (\d+)x(\d+)->', desc)
             if m and desc.rstrip().endswith('bf16x3'): mac3 += int(m.group(1)) * int(m.group(2)) * int(m.group(3)) * int(m.group(4))
+            m = _re.match(r'block \S+ c(\d+)->(\d+)->(\d+) k\d+ s\d+ (\d+)x(\d+)->(\d+)x(\d+)', desc)      # k_hrb (round 6): the block's expand and project convolutions are bf16x3, its depthwise is vector fp32
+            if m and ' hrb' in desc: mac3 += int(m.group(1)) * int(m.group(2)) * int(m.group(4)) * int(m.group(5)) + int(m.group(2)) * int(m.group(3)) * int(m.group(6)) * int(m.group(7))
         det_bf16x3_share = mac3 / (det.gmac * 1e9)
         det_peak_tfs = 1.0 / (det_bf16x3_share / (MFMA_BF16_PEAK_TFS / 6.0) + (1.0 - det_bf16x3_share) / MFMA_F32_PEAK_TFS)
     G = max(1, args.groups); SL = S // G          # frames per kernel launch
@@ -359,10 +362,10 @@ def main():
     # ---- accuracy over the WHOLE run (warm-up + timed steps): per-stream Horn-aligned ATE against the synthetic ground truth (or groundtruth.txt)
     N = NSTEP
     est = traj.cpu().numpy().reshape(N, S, 4, 4).astype('f8')
-    ate_gt = None; ate_sq = 0.0; ate_cnt = 0
+    ate_gt = None; ate_sq = 0.0; ate_cnt = 0; ate_excl = 0
     if not args.tum:
         gt = np.stack([np.stack([gen.Tcw(t0 + order[i % len(order)]) for t0 in t0s]) for i in range(N)])
-        ate_gt, ate_sq, ate_cnt = ate_pooled(est, gt)
+        ate_gt, ate_sq, ate_cnt, ate_excl = ate_pooled(est, gt)
     elif gt_tum is not None:
         gst, gxyz, _ = gt_tum
         for s in range(S):
@@ -375,8 +378,8 @@ def main():
 
     if dist:
         dt = sdist.max_over_ranks(dist, dt, DEV)
-        sq = sdist.sum_over_ranks(dist, [ate_sq, float(ate_cnt), float(tracked)], DEV)
-        ate_gt = float(np.sqrt(sq[0] / sq[1])) if sq[1] else None; tracked = int(sq[2])
+        sq = sdist.sum_over_ranks(dist, [ate_sq, float(ate_cnt), float(tracked), float(ate_excl)], DEV)
+        ate_gt = float(np.sqrt(sq[0] / sq[1])) if sq[1] else None; tracked = int(sq[2]); ate_excl = int(sq[3])
         assert (gather.recv[0] is None and gather.recv[1] is None) == (rank != 0)      # only the destination rank holds receive buffers (gather, not all_gather)
         if rank == 0:
             last_rec = gather.unpack(gather.last())
@@ -517,7 +520,7 @@ def main():
                                 'inverted-residual blocks and the short-k layers — as exact fp32 on v_mfma_f32_32x32x2_f32 or packed fp32 FMAs); peak = harmonic blend of the two pipes over that split; '
                                 'per-launch rocprof table in profiles/'}
         else:
-            roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': dk['achieved_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': dk['achieved_GBs'] / HBM_PEAK_GBS, 'traffic': traffic,
+            roofline = {'bound': dk.get('bound', 'hbm'), 'kernel': dom, 'achieved': dk['achieved_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': dk['achieved_GBs'] / HBM_PEAK_GBS, 'traffic': traffic,
                         'avg_launch_ms': dk['avg_ms_per_launch'], 'alg_bytes_per_launch': dk['alg_bytes_per_launch']}
         if 'standalone_avg_ms_per_launch' in dk:      # the same kernel class with nothing else on the GPU (committed profile, not measured in this run)
             sa = dk['standalone_avg_ms_per_launch']
@@ -649,12 +652,13 @@ def main():
                    'mean_keypoints': float(nkp.mean()), 'mean_keypoints_before_mask': float(n_raw.mean()), 'mean_matches': float(nmatch.mean()), 'mean_inliers': float(ninl.mean()),
                    'fundamental_ok_frac': float(f_ok.mean()), 'mean_ransac_iterations': float(f_stats[:, 0].mean()),
                    'tracked_streams_last_frame': tracked, 'trajectory_frames_per_stream': N,
-                   'ate_rmse_m_vs_ground_truth': ate_gt, 'ate_vs_oracle_chain': ate_oracle,
+                   'ate_rmse_m_vs_ground_truth': ate_gt, 'ate_streams_excluded': ate_excl, 'ate_vs_oracle_chain': ate_oracle,
                    'frame_record_gather': None if gather is None else {'collective': 'gather to rank 0 (torch.distributed over RCCL), one per step, records packed by one kernel (sgx_tracker_pack_records_dev)',
                                                                        'bytes_per_step': gather._step_bytes(), 'record_bytes': gather.rec_bytes, 'records_per_step': gather.world * S,
                                                                        'GBs_into_rank0_over_xgmi': (gather.bytes_moved - gather_bytes0) / dt / 1e9, 'inside_timed_region': True},
                    'nfeatures': 1000, 'nlevels': 8, 'scale_factor': 1.2, 'parallelism': f'streams-sharded x{world}', 'hip_streams': 1 if args.no_pipeline else (3 if det is not None else 2), 'host': 'C++ pipelined host behind the C-ABI (sgx_tracker_step_dev): one ctypes call per step',
                    'pose_dtype': 'f64 LM, f32 boundary'},
+        'value_host_input': None if host_in is None else host_in['value'],      # the same step with BGR + depth uploaded from pinned host memory inside the timed region (never `value`)
         'roofline': roofline, 'cpu_baseline': cpu, 'config2': c2, 'host_input': host_in, 'config4': c4,
         'library': os.path.relpath(lib.path, ROOT) + ('' if not lib.has_taps else ' (TAP BUILD: A/B tool run, switches: ' + ' '.join(f'{k}={v}' for k, v in sorted(os.environ.items()) if k.startswith(('SGX_DET', 'SGX_IRB', 'SGX_TUNE', 'SGX_TRK', 'SGX_LK', 'SGX_PW', 'SGX_DW', 'SGX_FB')) and k != 'SGX_BENCH_TAPS_LIB') + ')'),
     }

@@ -554,11 +554,15 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                 if (fb2_on && fb2se_env && irb_mode == 1 && ai >= 0 && di >= 0 && !c.hwc && ca.mode == SGX_EMODE_ACT && cb.mode == SGX_EMODE_ACT) {
                     Op &a = ops[ai]; const Op &d = ops[di], &e = ops[ei];
                     const int v2 = sgx_fb2_variant(a.inc, c.outc, bq.k, bq.stride, d.outc);
-                    if (v2 && (a.outc % sgx_fb2_cm(v2)) == 0 && a.outc == bq.outc && d.inc == c.outc && e.inc == d.outc) {
+                    // round 6: k_hrb also takes the two 40 -> 120 -> 40 blocks at 38 x 38 (5 x 5, squeeze-excite, + residual) that k_fused_block2 lost to the per-layer kernels
+                    int h_toh = 0, h_tow = 0, h_occ = 0;
+                    const bool hrb_ok = hrb_on && h->gemm == 1 && a.wS && c.wS && d.wS && e.wS && bq.pad == bq.k / 2 &&
+                                        sgx_hrb_variant(a.inc, a.outc, c.outc, bq.k, bq.stride, d.outc, res_blob >= 0, ca.lo, cb.lo, &h_toh, &h_tow, &h_occ);
+                    if ((hrb_ok || (v2 && (a.outc % sgx_fb2_cm(v2)) == 0)) && a.outc == bq.outc && d.inc == c.outc && e.inc == d.outc) {
                         SgxFusedBlk fb; memset(&fb, 0, sizeof fb);
                         fb.Cin = a.inc; fb.Cmid = a.outc; fb.Cout = c.outc; fb.K = bq.k; fb.stride = bq.stride; fb.pad = bq.pad; fb.H = a.H; fb.W = a.W; fb.Ho = bq.Ho; fb.Wo = bq.Wo;
                         fb.lo1 = ca.lo; fb.hi1 = ca.hi; fb.lo2 = cb.lo; fb.hi2 = cb.hi; fb.v2 = v2;
-                        sgx_fb2_tile(v2, &fb.TOH, &fb.TOW);
+                        if (v2) sgx_fb2_tile(v2, &fb.TOH, &fb.TOW); else { fb.TOH = h_toh; fb.TOW = h_tow; }
                         fb.tiles_x = (fb.Wo + fb.TOW - 1) / fb.TOW; fb.tiles_y = (fb.Ho + fb.TOH - 1) / fb.TOH;
                         fb.w1 = a.wt; fb.b1 = a.bias; fb.wd = bq.wt; fb.bd = bq.bias; fb.w2 = c.wt; fb.b2 = c.bias; fb.w2t = c.wtT; fb.ldw2 = c.ldw;
                         fb.Cq = d.outc; fb.qlo = cd.lo; fb.qhi = cd.hi; fb.gc1 = ce.c1; fb.glo = ce.lo; fb.ghi = ce.hi; fb.gc2 = ce.c2;

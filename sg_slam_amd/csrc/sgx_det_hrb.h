@@ -437,6 +437,8 @@ SGX_KERNEL_OCC(256, OCC) k_hrb(SgxHrb p)
     X(24, 72, 24, 3, 1, 16, 16, 0, true, 2)   /* 605+608+611: 75 x 75, + residual            */  \
     X(24, 72, 40, 5, 2, 5, 19, 1, false, 2)   /* 614+617+620+622+625: 75 -> 38, squeeze-excite */ \
     SGX_HRB_ALTERNATIVES(X)
+// (measured and dropped, session r6c: the two 40 -> 120 -> 40 blocks at 38 x 38 (5 x 5, squeeze-excite, + residual) as X(40, 120, 40, 5, 1, 6, 19, 1, true, 2): 0.65 ms each against 0.52 for
+// their four per-layer launches — two output tiles of accumulators + 25 taps in flight do not fit 256 registers: 31 - 78 spilled)
 // alternative tiles / occupancies of the same blocks (tap build: SGX_HRB_PICK=n takes the n-th instantiation that fits a block; the product plans the first)
 #ifdef SGX_DEBUG_TAPS
 #define SGX_HRB_ALTERNATIVES(X) \

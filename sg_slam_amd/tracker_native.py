@@ -92,7 +92,9 @@ class TrackerNative:
 class TrackerGroups:
     """G independent TrackerNative pipelines over contiguous slices of the S streams of a GPU, behind the interface of one: a step issues the G slices one after the other, each on
     its own three HIP streams, so the detector graph of one slice runs beside the extraction / tracking kernels of another (streams are independent: SURVEY.md §8(e) shards at
-    stream granularity, inside a GPU as well as across GPUs).  Results are bit-identical to one pipeline over all S streams (every kernel works per frame)."""
+    stream granularity, inside a GPU as well as across GPUs).  Results are bit-identical to one pipeline over all S streams (every kernel works per frame).
+    Reduced interface: step / synchronize / read / snapshot_* / pack_records / last_status with device-resident inputs (what bench.py --groups uses); the host-input
+    entries of TrackerNative (host_buffers, step_host, wait_inputs) and frame_dev are not offered."""
 
     def __init__(self, lib, streams, cam, groups, make_detector=None, **kw):
         assert streams % groups == 0, 'streams must divide into equal groups'
@@ -103,7 +105,13 @@ class TrackerGroups:
         self.W, self.H = self.tr[0].W, self.tr[0].H
 
     def _sl(self, g, a):
-        return None if a is None else a[g * self.Sg:(g + 1) * self.Sg]
+        """slice g of a per-stream input.  Inputs are tensors / arrays with the stream axis first and contiguous in it (a raw device pointer or a strided view would give the
+        pipelines wrong addresses without any error: ADVICE r5)"""
+        if a is None: return None
+        assert hasattr(a, 'shape') and len(a.shape) >= 1 and a.shape[0] == self.S, 'TrackerGroups takes tensors / arrays of shape (streams, ...), not raw pointers'
+        contiguous = a.is_contiguous() if hasattr(a, 'is_contiguous') else a.flags['C_CONTIGUOUS']
+        assert contiguous, 'TrackerGroups inputs must be contiguous'
+        return a[g * self.Sg:(g + 1) * self.Sg]
 
     def set_initial_pose(self, Tcw_host):
         T = np.ascontiguousarray(Tcw_host, 'f4').reshape(self.S, 16)

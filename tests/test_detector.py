@@ -228,7 +228,15 @@ def test_steps_isolated_criterion_has_teeth(emu, model):
     flagged = {nm for nm, e in faulty.items() if e > 2e-6}
     assert victim in flagged and faulty[victim] > 5e-5, (victim, faulty[victim])
     # (its readers see a one-element input fault of 1e-4 attenuated by their own weights: they may or may not cross 2e-6; nothing else may)
-    assert all(faulty[nm] <= 2e-6 for nm in faulty if nm not in flagged) and len(flagged) <= 8, sorted(flagged)
+    # ... i.e. every flagged step must lie DOWNSTREAM of the victim in the graph (the former check "everything not flagged is below the threshold" was true by
+    # construction); a step upstream of the victim or on a sibling branch that crossed the threshold would be the checker peeking at the wrong blob
+    down = {victim}; grew = True
+    while grew:
+        grew = False
+        for L in layers:
+            if any(i in down for i in L['ins']) and not all(o in down for o in L['outs']): down.update(L['outs']); grew = True
+    assert flagged <= down and len(flagged) <= 8, (sorted(flagged), sorted(flagged - down))
+    assert all(faulty[nm] <= 2e-6 for nm in faulty if nm not in down), sorted(nm for nm in faulty if nm not in down and faulty[nm] > 2e-6)
     # a larger fault in a whole channel (a wrong weight row) must also surface downstream
     hurt2 = dict(given); v = given[victim].copy(); v[:361] *= 1.01
     for nm in given:                                             # the Split outputs are views of the same device buffer: a real fault shows under every name
