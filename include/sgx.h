@@ -555,6 +555,18 @@ int sgx_tracker_snapshot_boxes_dev(sgx_tracker *t, int stream_index, float *d_bo
 /* the frame records {n, cv::KeyPoint[cap], descriptors[cap][32], Tcw} of the frame tracked last, packed by one kernel into d_records (streams x record_bytes) on
  * `stream` after the frame's tracking event: what the RCCL gather of BASELINE config 5 sends */
 int sgx_tracker_pack_records_dev(sgx_tracker *t, uint8_t *d_records, void *stream);
+/* ---- the collective of BASELINE config 5 from the C++ host (round 6): gather of every rank's packed frame records to `root` over RCCL / xGMI ------------------------
+ * One process per GPU.  Rank 0 calls sgx_dist_unique_id and hands the 128 bytes to the other ranks (the caller's launcher: MPI, a file, a socket); every rank then calls
+ * sgx_dist_create on its own device.  sgx_dist_gather_records enqueues a grouped ncclSend / ncclRecv on `stream` — the stream sgx_tracker_pack_records_dev packed on — and
+ * returns without synchronising: every rank sends bytes_per_rank = streams x record_bytes from d_send; root receives world such blocks side by side in d_recv (block r =
+ * rank r's), the other ranks pass d_recv = NULL.  RCCL is loaded on first use (dlopen): a single-GPU program never needs it; SGX_ERR_UNSUPPORTED if it is absent.
+ * Replaces nothing in the reference (it is single-GPU); the Python harness uses torch.distributed for the same pattern (sg_slam_amd/dist.py). */
+typedef struct sgx_dist sgx_dist;
+int sgx_dist_unique_id(void *id128 /* 128 bytes out */);
+int sgx_dist_create(const void *id128, int world, int rank, sgx_dist **out);
+void sgx_dist_destroy(sgx_dist *d);
+int sgx_dist_world(const sgx_dist *d, int32_t *world, int32_t *rank);
+int sgx_dist_gather_records(sgx_dist *d, const void *d_send, size_t bytes_per_rank, void *d_recv, int root, void *stream);
 int sgx_tracker_frame_dev(sgx_tracker *t, const int32_t **d_n, const sgx_keypoint **d_keys, const uint8_t **d_desc, const float **d_Tcw, const float **d_xw, const uint8_t **d_has);
 sgx_orb *sgx_tracker_extractor(sgx_tracker *t);
 

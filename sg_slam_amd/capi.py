@@ -72,6 +72,7 @@ SYMBOLS = [
     'sgx_tracker_keypoint_capacity', 'sgx_tracker_record_bytes', 'sgx_tracker_set_initial_pose', 'sgx_tracker_step_dev', 'sgx_tracker_host_buffers',
     'sgx_tracker_step_host', 'sgx_tracker_wait_inputs', 'sgx_tracker_sync', 'sgx_tracker_read', 'sgx_tracker_snapshot_pose_dev',
     'sgx_tracker_snapshot_boxes_dev', 'sgx_tracker_pack_records_dev', 'sgx_tracker_frame_dev', 'sgx_tracker_extractor', 'sgx_flow_create',
+    'sgx_dist_unique_id', 'sgx_dist_create', 'sgx_dist_destroy', 'sgx_dist_world', 'sgx_dist_gather_records',
     'sgx_flow_destroy', 'sgx_flow_reset', 'sgx_flow_levels', 'sgx_flow_lk_batch_dev', 'sgx_flow_lk', 'sgx_fundamental_ransac_batch_dev',
     'sgx_find_fundamental_mat', 'sgx_hamming_matrix', 'sgx_hamming_matrix_dev', 'sgx_match_search_for_triangulation', 'sgx_match_search_by_bow',
     'sgx_match_search_by_bow_kf', 'sgx_match_fuse_search', 'sgx_match_project_keyframe', 'sgx_match_fuse_search_sim3',
@@ -156,6 +157,11 @@ class SgxLib:
         d.sgx_tracker_snapshot_pose_dev.argtypes = [vp, vp]
         d.sgx_tracker_snapshot_boxes_dev.argtypes = [vp, C.c_int, vp, vp]
         d.sgx_tracker_pack_records_dev.argtypes = [vp, vp, vp]
+        d.sgx_dist_unique_id.argtypes = [vp]
+        d.sgx_dist_create.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
+        d.sgx_dist_destroy.argtypes = [vp]; d.sgx_dist_destroy.restype = None
+        d.sgx_dist_world.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        d.sgx_dist_gather_records.argtypes = [vp, vp, C.c_size_t, vp, C.c_int, vp]
         d.sgx_tracker_frame_dev.argtypes = [vp] + [C.POINTER(vp)] * 6
         d.sgx_tracker_extractor.argtypes = [vp]; d.sgx_tracker_extractor.restype = vp
         d.sgx_det_plan_step.argtypes = [vp, C.c_int, C.c_char_p, C.c_int]

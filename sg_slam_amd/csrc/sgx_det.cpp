@@ -397,7 +397,11 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
         const bool fb2_on = fb2_env != 0 && !g_det_legacy && g_det_fuse;
         static const int hrb_env = sgx_getenv("SGX_DET_HRB") ? atoi(sgx_getenv("SGX_DET_HRB")) : 1;
         const bool hrb_on = hrb_env != 0;
+#ifdef SGX_DEBUG_TAPS
         const bool fb1_on = (g_det_block_fusion || sgx_getenv("SGX_DET_BLOCK_FUSION")) && !g_det_legacy;
+#else
+        const bool fb1_on = false;                                  // k_fused_block exists in the tap build only
+#endif
         if (fb1_on || fb2_on) {
             auto act_only = [&](const Op &o, float *lo, float *hi) -> bool {
                 if (o.epi.size() != 1) return false;
@@ -947,7 +951,9 @@ static void run_op(sgx_det *h, const Op &op, int batch, sgx_stream_t st)
             (void)sgx_hrb_launch(q, batch, st); break;
         }
         if (fb.v2) { (void)sgx_fb2_launch(fb, batch, st); break; }                      // the variant was validated when the plan was built
+#ifdef SGX_DEBUG_TAPS
         SGX_LAUNCH_DYN(k_fused_block, dim3((unsigned)(fb.tiles_x * fb.tiles_y * batch)), dim3(256), sgx_fb_lds_floats(fb) * 4, st, fb);
+#endif
         break; }
     case OP_SE_GATE: {
         SgxSeGate sg = op.sg;

@@ -39,6 +39,7 @@ static inline size_t sgx_fb_lds_floats(const SgxFusedBlk &p)
            (size_t)p.CMR * coP;
 }
 
+#ifdef SGX_DEBUG_TAPS      /* the first fused-block kernel (fp32 MFMA, 13.7 against 10.9 ms per forward): superseded, tap build only (sgx_det_debug_set_block_fusion / SGX_DET_BLOCK_FUSION) */
 SGX_KERNEL(256) k_fused_block(SgxFusedBlk p)
 {
     SGX_DYN_LDS(smem);
@@ -227,6 +228,7 @@ SGX_KERNEL(256) k_fused_block(SgxFusedBlk p)
     SGX_THREADS_END
 #endif
 }
+#endif      /* SGX_DEBUG_TAPS */
 
 // ---------------------------------------------------------------------------------------------
 // k_fused_block2 — the same inverted-residual block for the HIGH-RESOLUTION, FEW-CHANNEL blocks at the head of the backbone (150 x 150 and 75 x 75, Cin / Cout <= 24),

@@ -482,7 +482,7 @@ __global__ void __launch_bounds__(768) k_irb(SgxIrb p)
 }
 #endif
 
-#ifndef SGX_EMU
+#if !defined(SGX_EMU) && defined(SGX_DEBUG_TAPS)      /* k_irb3: built, correct, slower than k_irb (profiles/HISTORY_r1-r4.md): tap build only (SGX_DET_IRB3=1) */
 // ---------------------------------------------------------------------------------------------
 // k_irb3: the block of k_irb with every matrix product on v_mfma_f32_32x32x16_bf16 (bf16x3, sgx_det_bf16.h).  Same work decomposition, LDS planes, barriers, depthwise
 // arithmetic (fmaf in tap order) and epilogue; what changes is the operand shape of the three GEMMs:
@@ -967,6 +967,7 @@ static inline int sgx_irb_launch(const SgxIrb &p, int batch, sgx_stream_t st)
     if (nw > 12 || lds > 160 * 1024) return SGX_ERR_UNSUPPORTED;
     SgxIrb q = p; q.batch = batch;
     { static const int dbg_env = sgx_getenv("SGX_IRB3_DBG") ? atoi(sgx_getenv("SGX_IRB3_DBG")) : 0; q.dbg = dbg_env; }
+#ifdef SGX_DEBUG_TAPS
     if (p.gemm == 1) {
         const int nqs = NQ == 0 ? 1 : (NQ == 2 ? 3 : (NT == 2 ? 1 : 2));
         if (NQ > 0 && (p.Cq + 15) / 16 != nqs) return SGX_ERR_UNSUPPORTED;
@@ -986,6 +987,7 @@ static inline int sgx_irb_launch(const SgxIrb &p, int batch, sgx_stream_t st)
         SGX_IRB_INSTANCES(SGX_IRB_X)
 #undef SGX_IRB_X
     }
+#endif      /* SGX_DEBUG_TAPS: k_irb3 and the bf16x3-expand variant of k_irb */
 #define SGX_IRB_X(K_, S_, NT_, NQ_, E_, H_, N2_) if (p.K == K_ && p.S == S_ && NT == NT_ && NQ == NQ_ && (p.has_expand != 0) == E_ && (p.act2 == SGX_EMODE_HSWISH) == H_ && NT2 == N2_) { \
         auto kfn = k_irb<K_, S_, NT_, NQ_, E_, H_, N2_>; static bool attr = false; \
         if (!attr) { (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \

@@ -92,9 +92,12 @@ static int track(sgx_flow *h, int cur_slot, int prev_slot, int batch, const sgx_
     sgx_prof_begin(SGX_K_LK_TRACK, st);
     static const int kpw = sgx_getenv("SGX_LK_KPW") ? atoi(sgx_getenv("SGX_LK_KPW")) : 2;      // keypoints per wave: 2 (default) / 4 = k_lk_trackN, 1 = k_lk_track; same results
     A.batch = batch; A.kblocks = (cap + 4 * kpw - 1) / (4 * kpw);
+#ifdef SGX_DEBUG_TAPS      // the one- and four-keypoints-per-wave mappings exist in the tap build only (same results; kept as the A/B arms of SGX_LK_KPW)
     if (kpw == 4) { auto kfn = k_lk_trackN<4>; SGX_LAUNCH(kfn, dim3((unsigned)A.kblocks * (unsigned)batch), dim3(256), st, h->g, A); }
-    else if (kpw == 2) { auto kfn = k_lk_trackN<2>; SGX_LAUNCH(kfn, dim3((unsigned)A.kblocks * (unsigned)batch), dim3(256), st, h->g, A); }
-    else { A.kblocks = (cap + 3) / 4; SGX_LAUNCH(k_lk_track, dim3((unsigned)A.kblocks * (unsigned)batch), dim3(256), st, h->g, A); }
+    else if (kpw != 2) { A.kblocks = (cap + 3) / 4; SGX_LAUNCH(k_lk_track, dim3((unsigned)A.kblocks * (unsigned)batch), dim3(256), st, h->g, A); }
+    else
+#endif
+    { auto kfn = k_lk_trackN<2>; SGX_LAUNCH(kfn, dim3((unsigned)A.kblocks * (unsigned)batch), dim3(256), st, h->g, A); }
     sgx_prof_end(SGX_K_LK_TRACK, st);
     SGX_CHECK_HIP(hipGetLastError());
     return SGX_OK;

@@ -319,6 +319,7 @@ SGX_DEV void sgx_lk_stage(uint32_t *tile, const uint8_t *img, int w, int h, int 
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
 }
 
+#ifdef SGX_DEBUG_TAPS      /* one keypoint per wave: superseded by k_lk_trackN<2>, kept in the tap build as the A/B arm SGX_LK_KPW=1 */
 SGX_KERNEL(256) k_lk_track(SgxLkGeom g, SgxLkArgs A)
 {
     __shared__ uint32_t tiles[4][35 * SGX_LK_TILE_PITCH / 4 + 5];
@@ -473,6 +474,7 @@ SGX_KERNEL(256) k_lk_track(SgxLkGeom g, SgxLkArgs A)
         if (A.status) A.status[(size_t)f * A.cap + kp] = (uint8_t)status;
     }
 }
+#endif      /* SGX_DEBUG_TAPS */
 #endif
 
 // ---------------------------------------------------------------------------------------------

@@ -382,22 +382,27 @@ extern "C" int sgx_orb_extract_batch_dev(sgx_orb *h, const uint8_t *d_gray, int 
     for (int i = 0; i < 16; i++) umax_packed |= (unsigned long long)(h->umax_h[i] & 15) << (4 * i);
     // default: blur whole levels once (k_blur_levels), then a light per-keypoint kernel; SGX_TUNE_ORB_PATCH_BLUR=1 selects the first design (blur of a
     // 37x37 window per keypoint inside k_orient_desc) — identical bytes (tests), ~45 vs ~20+ VALU operations per pixel-equivalent
+#ifdef SGX_DEBUG_TAPS      // the superseded descriptor kernels (k_orient_desc: blur per keypoint window; k_orient_desc2: one keypoint per wave) exist in the tap build only
     static const bool patch_blur = sgx_getenv("SGX_TUNE_ORB_PATCH_BLUR") != nullptr;
     if (patch_blur) {
         SGX_LAUNCH_DYN(k_orient_desc, dim3(g.kp_cap * batch), dim3(64), e_extra / 2, stream, g, d_gray, pitch, h->d_pyr, h->d_sel, h->d_sel_count,
                        umax_packed, h->d_pattern, (uint8_t *)d_kps, d_desc, d_count, cap, batch, h->d_status);
-    } else {
+    } else
+#endif
+    {
         static const int blur_threads = sgx_getenv("SGX_TUNE_BLUR_THREADS") ? atoi(sgx_getenv("SGX_TUNE_BLUR_THREADS")) : 256;   // env = tuning tap (64..512)
         {   // persistent workgroups: `parts` per frame, each walks a contiguous range of the frame's tiles (see k_blur_levels); about 4 096 workgroups = 16 per CU
             const int blur_grid = sgx_getenv("SGX_TUNE_ORB_BLUR_GRID") ? atoi(sgx_getenv("SGX_TUNE_ORB_BLUR_GRID")) : 4096;          // tuning tap: target grid size (measured at 512 frames with the round-3 walk: 0.59 / 0.48 / 0.46 ms at 1 024 / 2 048 / 4 096)
             const int parts = std::min(g.nblur_tiles, std::max(1, blur_grid / batch));
             SGX_LAUNCH(k_blur_levels, dim3(parts * batch), dim3(std::min(512, std::max(256, blur_threads))), stream, g, h->d_blur_tiles, d_gray, pitch, h->d_pyr, h->d_blur, batch);
         }
+#ifdef SGX_DEBUG_TAPS
         static const bool one_per_wave = sgx_getenv("SGX_TUNE_ORB_DESC_ONE_PER_WAVE") != nullptr;       // tuning tap: k_orient_desc2 (one keypoint per wave)
         if (one_per_wave)
             SGX_LAUNCH(k_orient_desc2, dim3(g.kp_cap * batch), dim3(64), stream, g, d_gray, pitch, h->d_pyr, h->d_blur, h->d_sel, h->d_sel_count,
                        umax_packed, h->d_pattern, (uint8_t *)d_kps, d_desc, d_count, cap, batch, h->d_status);
         else
+#endif
             SGX_LAUNCH(k_orient_desc4, dim3(((g.kp_cap + 3) / 4) * batch), dim3(64), stream, g, d_gray, pitch, h->d_pyr, h->d_blur, h->d_sel, h->d_sel_count,
                        umax_packed, h->d_pattern, (uint8_t *)d_kps, d_desc, d_count, cap, batch, h->d_status);
     }

@@ -828,6 +828,7 @@ SGX_DEV int sgx_reflect101(int i, int n)
 #define SGX_PS 48                  /* LDS row stride of the staged patch (bytes) */
 #define SGX_HS 40                  /* LDS row stride of the horizontal-pass buffer (u16) */
 
+#ifdef SGX_DEBUG_TAPS      /* the first design (blur of a 37 x 37 window per keypoint); superseded by k_blur_levels + k_orient_desc4; tap build only: SGX_TUNE_ORB_PATCH_BLUR */
 SGX_KERNEL(64) k_orient_desc(SgxOrbGeom g, const uint8_t *gray, int gray_pitch, const uint8_t *pyr,
                              const uint32_t *sel, const int *sel_count, unsigned long long umax_packed, const signed char *pattern,
                              uint8_t *kps_raw, uint8_t *desc, int *count, int cap, int batch, uint32_t *status)
@@ -988,6 +989,7 @@ SGX_KERNEL(64) k_orient_desc(SgxOrbGeom g, const uint8_t *gray, int gray_pitch, 
     }
     SGX_THREADS_END
 }
+#endif      /* SGX_DEBUG_TAPS */
 
 // ---------------------------------------------------------------------------------------------
 // k_blur_levels: GaussianBlur(level, 7x7, sigma 2, BORDER_REFLECT_101) of every pyramid level (ORBextractor.cc:1086-1087), whole levels like the
@@ -1140,6 +1142,7 @@ SGX_KERNEL(512) k_blur_levels(SgxOrbGeom g, const SgxBlurTile *tiles, const uint
 // reaches 18 px, so neither the 31x31 moment patch nor the samples ever leave the level: no border path.
 // ---------------------------------------------------------------------------------------------
 #define SGX_MS 36              /* LDS row stride of the staged 31x31 moment patch (bytes) */
+#ifdef SGX_DEBUG_TAPS      /* superseded by k_orient_desc4 (four keypoints per wave); tap build only: SGX_TUNE_ORB_DESC_ONE_PER_WAVE */
 SGX_KERNEL(64) k_orient_desc2(SgxOrbGeom g, const uint8_t *gray, int gray_pitch, const uint8_t *pyr, const uint8_t *blur,
                               const uint32_t *sel, const int *sel_count, unsigned long long umax_packed, const signed char *pattern,
                               uint8_t *kps_raw, uint8_t *desc, int *count, int cap, int batch, uint32_t *status)
@@ -1234,6 +1237,7 @@ SGX_KERNEL(64) k_orient_desc2(SgxOrbGeom g, const uint8_t *gray, int gray_pitch,
     }
     SGX_THREADS_END
 }
+#endif      /* SGX_DEBUG_TAPS */
 
 // ---------------------------------------------------------------------------------------------
 // k_orient_desc4: k_orient_desc2 with FOUR keypoints per wave (16 lanes each).  The serial part of a keypoint (fastAtan2 + the bit-exact sincosf, ~250

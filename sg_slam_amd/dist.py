@@ -132,3 +132,35 @@ class FrameRecordGather:
         desc = a[:, :, o:o + cap * 32].reshape(a.shape[0], a.shape[1], cap, 32); o += cap * 32
         T = a[:, :, o:o + 64].copy().view(np.float32)
         return dict(n=n, keys=keys, desc=desc, Tcw=T)
+
+
+class NativeRecordGather:
+    """The same gather issued by the LIBRARY (sgx_dist_gather_records: grouped ncclSend / ncclRecv of RCCL loaded by libsgx.so itself) — the path a C++ host uses for BASELINE
+    config 5 without Python (include/sgx.h).  The 128-byte RCCL id of rank 0 reaches the other ranks through `broadcast_id` (a callable bytes -> bytes; with
+    torch.distributed: a broadcast of a uint8 tensor; a single rank passes None).  Synchronous interface for tests and examples; the production overlap (side stream, double
+    buffer) is FrameRecordGather's, which this class does not replace in bench.py."""
+
+    def __init__(self, lib, streams, cap, device, world=1, rank=0, broadcast_id=None, dst=0):
+        import ctypes as C
+        import torch
+        self.lib, self.S, self.cap, self.world, self.rank, self.dst = lib, streams, cap, world, rank, dst
+        self.rec_bytes = 16 + cap * 28 + cap * 32 + 64
+        ident = (C.c_char * 128)()
+        if rank == 0: lib.check(lib.dll.sgx_dist_unique_id(ident))
+        raw = bytes(ident) if broadcast_id is None else broadcast_id(bytes(ident))
+        h = C.c_void_p()
+        lib.check(lib.dll.sgx_dist_create(C.c_char_p(raw), world, rank, C.byref(h)))
+        self.h = h
+        self.send = torch.zeros((streams, self.rec_bytes), dtype=torch.uint8, device=device)
+        self.recv = torch.zeros((world, streams, self.rec_bytes), dtype=torch.uint8, device=device) if rank == dst else None
+
+    def gather_tracker(self, tracker, stream=None):
+        """pack the records of the frame the tracker tracked last and gather them to `dst` on `stream` (a raw hipStream_t; None = the legacy stream); asynchronous to the host"""
+        import ctypes as C
+        tracker.pack_records(self.send, stream=stream)
+        self.lib.check(self.lib.dll.sgx_dist_gather_records(self.h, C.c_void_p(self.send.data_ptr()), self.S * self.rec_bytes,
+                                                            None if self.recv is None else C.c_void_p(self.recv.data_ptr()), self.dst, None if stream is None else C.c_void_p(stream)))
+        return self.recv
+
+    def close(self):
+        if self.h: self.lib.dll.sgx_dist_destroy(self.h); self.h = None

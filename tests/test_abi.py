@@ -46,6 +46,22 @@ def test_product_library_has_no_taps_and_reads_no_environment():
     assert not re.findall(rb'SGX_(?:TUNE|DET|IRB|BA|PW|DW|LK|TRK|FB|ENV)[A-Z0-9_]*\x00', text)      # no switch name survives as a string
 
 
+def test_collective_entry_needs_no_rccl_at_load_time():
+    """sgx_dist_* (BASELINE config 5 from the C++ host) load RCCL on first use: the library itself must not depend on it (single-GPU programs, this CPU container), and
+    the emulator reports the entry as unsupported instead of pretending"""
+    import subprocess
+    so = os.path.join(ROOT, 'sg_slam_amd', 'libsgx.so')
+    needed = subprocess.check_output(['readelf', '-d', so]).decode()
+    assert 'rccl' not in needed.lower() and 'nccl' not in needed.lower()
+    emu = os.path.join(ROOT, 'tests', 'emu', 'libsgx_emu.so')
+    if os.path.exists(emu):
+        dll = ctypes.CDLL(emu)
+        buf = ctypes.create_string_buffer(128)
+        assert dll.sgx_dist_unique_id(buf) != 0
+        h = ctypes.c_void_p()
+        assert dll.sgx_dist_create(buf, 1, 0, ctypes.byref(h)) != 0 and not h.value
+
+
 def test_tap_builds_export_the_taps():
     for so in (os.path.join(ROOT, 'tests', 'taps', 'libsgx_taps.so'), os.path.join(ROOT, 'tests', 'emu', 'libsgx_emu.so')):
         if not os.path.exists(so):
