@@ -259,12 +259,12 @@ SGX_DEV int sgx_wave_sum_i32(int v)
     return __builtin_amdgcn_readlane(v, 63);
 }
 /* exact wave sum of per-lane int32 partials, returned as the correctly rounded float of the exact integer: the low 16 bits and the signed high
- * part are reduced separately (each fits 32 bits); hi * 65536 + lo is exact in fp64 (< 2^53), one rounding in the conversion to float —
- * identical to (float)(int64) of the oracle */
+ * part are reduced separately (each fits 32 bits); hi * 65536 + lo is rounded ONCE (fused multiply-add on exact float operands; round 6: was a detour through fp64,
+ * four double-rate instructions per sum) — identical to (float)(int64) of the oracle */
 SGX_DEV float sgx_wave_sum_f32(int v)
 {
     const int lo = sgx_wave_sum_i32(v & 0xFFFF), hi = sgx_wave_sum_i32(v >> 16);
-    return (float)((double)hi * 65536.0 + (double)lo);
+    return fmaf((float)hi, 65536.0f, (float)lo);       /* |hi| <= 2^21, lo < 2^22: both conversions and the product are exact, the fused add rounds the exact integer once */
 }
 SGX_DEV int sgx_mul24(int a, int b) { return __mul24(a, b); }          /* both operands fit 24 bits at every call site */
 /* REFLECT_101 for indices at most one image length outside, clamped (the clamp only ever acts on tile bytes no window uses) */
@@ -502,7 +502,7 @@ SGX_DEV float sgx_group_sum_f32(int v)                              /* exact sum
 {
     int lo = sgx_row_sum_i32(v & 0xFFFF), hi = sgx_row_sum_i32(v >> 16);
     if (LPK == 32) { lo += __shfl_xor(lo, 16, 64); hi += __shfl_xor(hi, 16, 64); }      /* the other row of the half-wave */
-    return (float)((double)hi * 65536.0 + (double)lo);
+    return fmaf((float)hi, 65536.0f, (float)lo);       /* |hi| <= 2^21, lo < 2^22: both conversions and the product are exact, the fused add rounds the exact integer once */
 }
 
 /* stage the NROWS x 32-byte patch of `img` whose top-left corner is (ox, oy) (ox a multiple of 4) into a keypoint's tile with the LPK lanes of its group (LPK / 8 tile rows of
@@ -701,8 +701,15 @@ SGX_KERNEL_OCC(256, (KPW == 4 ? 3 : 5)) k_lk_trackN(SgxLkGeom g, SgxLkArgs A)
                 const float dx = (A12 * b2 - A22 * b1) * D, dy = (A12 * b1 - A11 * b2) * D;
                 nextx += dx; nexty += dy;
                 outx = nextx + half; outy = nexty + half;
-                if ((double)dx * dx + (double)dy * dy <= A.eps2) act = false;
-                else if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) { outx -= dx * 0.5f; outy -= dy * 0.5f; act = false; }
+                // delta.ddot(delta) <= epsilon is a DOUBLE comparison in lkpyramid.cpp.  The float estimate f2 is within 2e-7 (relative) of the double value, so outside a 1e-5 band
+                // around the threshold it decides the same way; inside the band (any lane of the wave: wave-uniform branch) the double expression itself decides.  Round 6: the
+                // five double-rate instructions ran in every iteration of every lane.
+                const float f2 = dx * dx + dy * dy, e2f = (float)A.eps2;
+                bool conv = f2 <= e2f;
+                if (__any(fabsf(f2 - e2f) <= 1e-5f * e2f)) { asm volatile("" ::: "memory"); conv = (double)dx * dx + (double)dy * dy <= A.eps2; }      /* (the empty asm keeps the compiler from speculating the double path) */
+                if (conv) act = false;
+                // fabs((double)(float sum)) < 0.01  <=>  |sum| <= 0.01f: 0.01f = 0.00999999977648 is the largest float below the double 0.01
+                else if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) { outx -= dx * 0.5f; outy -= dy * 0.5f; act = false; }
                 pdx = dx; pdy = dy;
             }
         }
