@@ -72,6 +72,10 @@ template <int CIN, int CMID, int COUT, int K, int S, int TOH, int TOW> struct Sg
     static_assert(NPO <= 256 && (CMID % 8) == 0 && (CIN % 8) == 0 && (COUT % 8) == 0, "tile / channel constraints");
 };
 
+// Output pixel slot o of a tile -> (row, column).  Stride-2 blocks with 8 x 16 tiles deal the rows so that the two 16-lane halves of a 32-lane LDS access group sit FOUR tile rows
+// apart: the E words of rows r and r + 4 are 4 * 2 * TIWP = 272 float2 = 32 (mod 64) banks apart, so the 32 lanes of a ds_read_b64 touch 64 distinct banks; with adjacent rows
+// (r, r + 1: 8 banks apart) three quarters of every depthwise tap read were two-way bank conflicts (round 6, session B: 27 % of the block's LDS cycles).
+#define SGX_HRB_OROW(o_) ((S == 2 && TOW == 16 && TOH == 8) ? vi(((((o_) >> 4) & 1) << 2) + (((o_) >> 5) & 1) + (((o_) >> 6) << 1)) : vi((o_) / TOW))
 // NQS: k16 steps of the squeeze width (0 = no squeeze-excite tail); RES: residual tensor added to the output; OCC: waves per SIMD the instantiation is compiled for
 // (256-thread workgroups per CU: LDS and registers permitting).  Both activations are ReLU / Clip(0, hi) (lo1 = lo2 = 0: the planner checks).
 template <int CIN, int CMID, int COUT, int K, int S, int TOH, int TOW, int NQS, bool RES, int OCC>
@@ -224,7 +228,7 @@ SGX_KERNEL_OCC(256, OCC) k_hrb(SgxHrb p)
         SGX_WPRIV_BIND(acc, w); SGX_WPRIV_BIND(a2r, w); SGX_WPRIV_BIND(resr, w);
         const vi lane = v_lane(), l31 = lane & 31, half = lane >> 5;
         const int pw = w % G::NWP, ks = w / G::NWP;
-        const vi o = v_min(pw * 64 + lane, vi(G::NPO - 1)), oy = o / TOW, ox = o - oy * TOW;
+        const vi o = v_min(pw * 64 + lane, vi(G::NPO - 1)), oy = SGX_HRB_OROW(o), ox = o - (o / TOW) * TOW;
         const vi ebase = (oy * S) * G::TIWP + ox;                  // tap (a, c): + a TIWP + (S == 2 ? (c & 1) HALF + (c >> 1) : c)
 #pragma unroll
         for (int sl = 0; sl < 2; sl++) {
@@ -287,7 +291,7 @@ SGX_KERNEL_OCC(256, OCC) k_hrb(SgxHrb p)
                 if (RES && SGX_HRB_RESPRE && c == G::NCH - 1 && ks == 0 && sl == (G::KSPLIT == 2 || !(CMID % 32 == 0 || 16 * (2 * c + 1) < CMID) ? 0 : 1)) {
         #pragma unroll
                     for (int g = 0; g < 2; g++) {
-                        const vi o_ = pw * 64 + 32 * g + l31, oc_ = v_min(o_, vi(G::NPO - 1)), oy_ = oc_ / TOW, ox_ = oc_ - oy_ * TOW, gy_ = oy0 + oy_, gx_ = ox0 + ox_;
+                        const vi o_ = pw * 64 + 32 * g + l31, oc_ = v_min(o_, vi(G::NPO - 1)), oy_ = SGX_HRB_OROW(oc_), ox_ = oc_ - (oc_ / TOW) * TOW, gy_ = oy0 + oy_, gx_ = ox0 + ox_;
                         const vb live_ = (o_ < G::NPO) & (gy_ < p.Ho) & (gx_ < p.Wo);
                         const vu pix4_ = v_u(v_seli(live_, gy_ * p.Wo + gx_, vi(0))) * 4u + v_u(4 * half) * ((unsigned)(p.Ho * p.Wo) * 4u);
         #pragma unroll
@@ -402,7 +406,7 @@ SGX_KERNEL_OCC(256, OCC) k_hrb(SgxHrb p)
     const unsigned oplane4 = (unsigned)(p.Ho * p.Wo) * 4u;
 #pragma unroll
     for (int g = 0; g < 2; g++) {
-        const vi o = pw * 64 + 32 * g + l31, oc = v_min(o, vi(G::NPO - 1)), oy = oc / TOW, ox = oc - oy * TOW, gy = oy0 + oy, gx = ox0 + ox;
+        const vi o = pw * 64 + 32 * g + l31, oc = v_min(o, vi(G::NPO - 1)), oy = SGX_HRB_OROW(oc), ox = oc - (oc / TOW) * TOW, gy = oy0 + oy, gx = ox0 + ox;
         const vb live = (o < G::NPO) & (gy < p.Ho) & (gx < p.Wo);
         const vu pix4 = v_u(v_seli(live, gy * p.Wo + gx, vi(0))) * 4u + v_u(4 * half) * oplane4;
         if (RES && !SGX_HRB_RESPRE) {
@@ -442,8 +446,8 @@ SGX_KERNEL_OCC(256, OCC) k_hrb(SgxHrb p)
 // alternative tiles / occupancies of the same blocks (tap build: SGX_HRB_PICK=n takes the n-th instantiation that fits a block; the product plans the first)
 #ifdef SGX_DEBUG_TAPS
 #define SGX_HRB_ALTERNATIVES(X) \
-    X(16, 16, 16, 3, 1, 8, 16, 0, true, 4) X(16, 64, 24, 3, 2, 7, 16, 0, false, 2) X(24, 72, 24, 3, 1, 16, 16, 0, true, 3) \
-    X(16, 16, 16, 3, 1, 16, 16, 0, true, 2) X(24, 72, 24, 3, 1, 8, 16, 0, true, 3)
+    X(16, 16, 16, 3, 1, 16, 16, 0, true, 5) X(16, 64, 24, 3, 2, 7, 16, 0, false, 2) X(24, 72, 24, 3, 1, 16, 16, 0, true, 3) \
+    X(16, 16, 16, 3, 1, 16, 16, 0, true, 6) X(24, 72, 24, 3, 1, 8, 16, 0, true, 3)
 #else
 #define SGX_HRB_ALTERNATIVES(X)
 #endif
