@@ -675,6 +675,11 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                     // mode 2: the fp32 block kernel with ONLY its expand GEMM as bf16x3 (SGX_DET_IRB_A3, tuning tap)
                     static const int a3_env = sgx_getenv("SGX_DET_IRB_A3") ? atoi(sgx_getenv("SGX_DET_IRB_A3")) : 0;
                     if (!ok3 && a3_env && h->gemm == 1 && ai >= 0 && ops[ai].wS) { ib.gemm = 2; ib.w1S = ops[ai].wS; }
+                    if (ib.gemm == 2 && a3_env >= 2 && (a3_env == 2 || bq.outc == a3_env)) {      // experiment: pre-split input (SGX_DET_IRB_A3=2: every block; = Cexp: that block only)
+                        ib.ldS = ((bq.H * bq.W + 31) / 32) * 32;
+                        unsigned *sh = nullptr; if (h->alloc(&sh, (size_t)B * ((ops[ai].inc + 15) / 16) * 6 * ib.ldS * 4)) FAIL(SGX_ERR_NOMEM);      // 16 bytes per entry
+                        ib.inS = sh;
+                    } else if (ib.gemm == 2 && a3_env > 2 && bq.outc != a3_env) ib.gemm = 0;
                     if (ok3) { ib.w2S = c.wS; ib.w1S = ai >= 0 ? ops[ai].wS : nullptr; ib.wq1S = di >= 0 ? ops[di].wS : nullptr; ib.wq2S = di >= 0 ? ops[ei].wS : nullptr; }
                 }
                 {   // depthwise taps + bias, one padded row per channel

@@ -52,6 +52,9 @@ struct SgxIrb {
     // ld = the ld of the fp32 copy.  gemm = 1 selects k_irb3
     int gemm, dbg;                              // dbg: timing taps of k_irb3 (SGX_IRB3_DBG, wrong results): 1 no depthwise arithmetic, 2 no stage-B MFMAs, 4 no stage-A MFMAs, 8 no stage-A split, 16 no stage B at all, 32 no stage A tiles
     const void *w1S, *w2S, *wq1S, *wq2S, *w2Sb;
+    // experiment (round 6, tap build): the block input ALSO as three bf16 terms in B-operand layout [k16 step][term][half][ldS pixels][8] per image (k_presplit): the bf16x3 expand
+    // stage then loads operands (three 16-byte loads per k16 step) instead of eight dwords + a 44-instruction split
+    const void *inS; int ldS;
 };
 #define SGX_IRB_KKP(K) (((K) * (K) + 1 + 3) & ~3)
 static inline size_t sgx_irb_lds_bytes(const SgxIrb &p) { return (size_t)p.nbuf * 32 * ((size_t)p.planeT + (p.Cout2 ? 2 : 1) * SGX_IRB_KKP(p.K)) * 4 + (size_t)2 * p.w1rows * 32 * 4; }
@@ -276,6 +279,23 @@ __global__ void __launch_bounds__(768) k_irb(SgxIrb p)
 #pragma unroll
                         for (int q = 0; q < 3; q++) dst[q] = w1l[(size_t)(6 * s_ + 2 * q) * p.ld1];
                     };
+                    if (p.inS) {                                           // uniform: pre-split operands, two k16 steps in flight
+                        const int qq = min(tile * 32 + l31, PI - 1), qi_ = qq / (IH * p.W), qr_ = qq - qi_ * (IH * p.W), ry_ = qr_ / p.W, ix_ = qr_ - ry_ * p.W;
+                        const sgx_u32x4 *xl = (const sgx_u32x4 *)p.inS + (size_t)(b0 + qi_) * (size_t)(nks1 * 6 * p.ldS) + (size_t)half * p.ldS + (size_t)((iyA + ry_) * p.W + ix_);
+                        auto loadXS = [&](int s_, SgxB3 &dst) { const sgx_u32x4 *xs_ = xl + (size_t)(6 * s_) * p.ldS; dst.t0 = xs_[0]; dst.t1 = xs_[(size_t)2 * p.ldS]; dst.t2 = xs_[(size_t)4 * p.ldS]; };
+                        SgxB3 xb[3]; sgx_u32x4 wr[3][3];
+                        loadXS(0, xb[0]); loadW(0, wr[0]); loadXS(min(1, nks1 - 1), xb[1]); loadW(min(1, nks1 - 1), wr[1]);
+                        for (int s0 = 0; s0 < nks1; s0 += 3) {
+#pragma unroll
+                            for (int d = 0; d < 3; d++) {
+                                const int s_ = s0 + d;
+                                if (s_ < nks1) {
+                                    loadXS(min(s_ + 2, nks1 - 1), xb[(d + 2) % 3]); loadW(min(s_ + 2, nks1 - 1), wr[(d + 2) % 3]);
+                                    e = sgx_mfma_bf16x3(wr[d][0], wr[d][1], wr[d][2], xb[d], e);
+                                }
+                            }
+                        }
+                    } else {
                     float xr[2][8]; sgx_u32x4 wr[2][3];
                     loadX(0, xr[0]); loadW(0, wr[0]);
                     for (int s0 = 0; s0 < nks1; s0 += 2) {
@@ -289,6 +309,7 @@ __global__ void __launch_bounds__(768) k_irb(SgxIrb p)
                                 e = sgx_mfma_bf16x3(wr[d][0], wr[d][1], wr[d][2], b, e);
                             }
                         }
+                    }
                     }
 #pragma unroll
                     for (int r = 0; r < 16; r++) e[r] = sgx_irb_act(AMODE, e[r], p.a1c1, p.a1lo, p.a1hi, p.a1c2);
@@ -951,6 +972,22 @@ static inline bool sgx_irb_supported(int K, int S, int NT, int NQ, bool expand, 
     return false;
 }
 
+#if !defined(SGX_EMU) && defined(SGX_DEBUG_TAPS)
+// experiment (round 6): fp32 blob [C][HW] per image -> three bf16 terms in B-operand layout [k16 step][term][half][ldS][8] per image; a thread = (pixel, k16 step, half)
+__global__ void __launch_bounds__(256) k_presplit(int C, int HW, int ldS, int nks, int total, const float *in, size_t in_pitch, sgx_u32x4 *out)
+{
+    const int g = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (g >= total) return;
+    const int px = g % HW, r = g / HW, hf = r & 1, s = (r >> 1) % nks, b = (r >> 1) / nks;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { const int k = 16 * s + 8 * hf + j; v[j] = k < C ? in[(size_t)b * in_pitch + (size_t)k * HW + px] : 0.f; }
+    const SgxB3 t = sgx_split3x8(v);
+    sgx_u32x4 *o = out + (size_t)b * (size_t)(nks * 6 * ldS) + (size_t)(6 * s + hf) * ldS + px;
+    o[0] = t.t0; o[(size_t)2 * ldS] = t.t1; o[(size_t)4 * ldS] = t.t2;
+}
+#endif
+
 #ifndef SGX_IRB_NO_LAUNCH
 static inline int sgx_irb_launch(const SgxIrb &p, int batch, sgx_stream_t st)
 {
@@ -978,6 +1015,10 @@ static inline int sgx_irb_launch(const SgxIrb &p, int batch, sgx_stream_t st)
         SGX_IRB_INSTANCES(SGX_IRB_X)
 #undef SGX_IRB_X
         return SGX_ERR_UNSUPPORTED;
+    }
+    if (p.gemm == 2 && p.has_expand && p.inS) {
+        const int nks = (p.Cin + 15) / 16, total = batch * nks * 2 * p.H * p.W;
+        hipLaunchKernelGGL(k_presplit, dim3((total + 255) / 256), dim3(256), 0, st, p.Cin, p.H * p.W, p.ldS, nks, total, p.in, p.in_pitch, (sgx_u32x4 *)p.inS);
     }
     if (p.gemm == 2 && p.has_expand) {
 #define SGX_IRB_X(K_, S_, NT_, NQ_, E_, H_, N2_) if (E_ && p.K == K_ && p.S == S_ && NT == NT_ && NQ == NQ_ && (p.act2 == SGX_EMODE_HSWISH) == H_ && NT2 == N2_) { \
