@@ -40,7 +40,8 @@ struct Op {
     OpKind kind; int in0 = -1, in1 = -1, out = -1;
     std::vector<EpiStep> epi; int hwc = 0, hwc_off = 0; bool dead = false; std::string name;
     int inc = 0, outc = 0, H = 0, W = 0, Ho = 0, Wo = 0, k = 1, stride = 1, pad = 0, depthwise = 0, act = 0; float lo = 0, hi = 0;
-    float *wt = nullptr, *bias = nullptr, *wtT = nullptr; int ldw = 0; int bop = 0; int off = 0; int rows = 0, C = 0;
+    float *wt = nullptr, *bias = nullptr, *wtT = nullptr, *wtP = nullptr; int ldw = 0;      // wtP: depthwise weights with the channels of a pair interleaved [C / 2][k * k][2] (k_conv_dw3)
+    int bop = 0; int off = 0; int rows = 0, C = 0;
     void *wS = nullptr;                         // pointwise weights split into three bf16 terms in the MFMA operand layout (sgx_det_bf16.h), ld = ldw; NULL in the exact-fp32 plan
     SgxFusedBlk fb; int fb_res_blob = -1;      // OP_FUSED_BLOCK: expand -> depthwise -> project (+ residual) in one kernel (sgx_det_block.h)
     SgxSeGate sg; int sg_res_blob = -1;                            // OP_SE_GATE: squeeze -> excite -> gate x input [+ residual] as one kernel (k_se_gate, sgx_det_block.h)
@@ -245,6 +246,13 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                         op.wS = dws;
                     }
                 }
+            }
+            if (group == inc && group != 1 && (outc & 1) == 0 && inc == outc) {      // depthwise: pair-interleaved copy for k_conv_dw3
+                const float *wsrc = (const float *)(bp + bo); const int kk = k * k;
+                std::vector<float> w2((size_t)outc * kk);
+                for (int m = 0; m < outc; m++) for (int t = 0; t < kk; t++) memcpy(&w2[((size_t)(m >> 1) * kk + t) * 2 + (m & 1)], wsrc + (size_t)m * kk + t, 4);
+                if (h->alloc(&op.wtP, w2.size())) FAIL(SGX_ERR_NOMEM);
+                if (hipMemcpy(op.wtP, w2.data(), w2.size() * 4, hipMemcpyHostToDevice) != hipSuccess) FAIL(SGX_ERR_DEVICE);
             }
             bo += (size_t)wsize * 4;
             std::vector<float> bz(outc, 0.f);
@@ -981,6 +989,15 @@ static void run_op(sgx_det *h, const Op &op, int batch, sgx_stream_t st)
         auto magic = [](int d) -> unsigned { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
         const int nbx4 = (op.Wo + 3) / 4, pitch4 = ((nbx4 - 1) * 4 * op.stride + 3 * op.stride + op.k + 3) & ~3;
         static const int dw2_on = sgx_getenv("SGX_DW2") ? atoi(sgx_getenv("SGX_DW2")) : 1;
+        static const int dw3_on = sgx_getenv("SGX_DW3") ? atoi(sgx_getenv("SGX_DW3")) : 0;      // round 6 experiment: k_conv_dw3 (channel pairs, packed FMAs) measured SLOWER than k_conv_dw2 (0.26 vs 0.18 ms on the 38 x 38 planes): tap only
+        if (dw3_on && !h->legacy && op.depthwise && op.wtP) {
+            SgxDw3 d; int px = 1; size_t lds3 = 0;
+            if (sgx_dw3_plan(op.outc, op.H, op.W, op.Ho, op.Wo, op.k, op.stride, op.pad, e.mode, &d, &px, &lds3)) {
+                d.in = A.d; d.in_pitch = A.n; d.wd2 = op.wtP; d.bias = op.bias; d.out = O.d; d.out_pitch = O.n; d.epi = e;
+                sgx_dw3_launch(d, op.k, op.stride, px, lds3, batch, st);
+                break;
+            }
+        }
         if (dw2_on && !h->legacy && op.depthwise && (op.k == 3 || op.k == 5) && (op.stride == 1 || op.stride == 2) && pitch4 * op.k <= budget) {
             // k_conv_dw2: P planes x a band of RB output rows per workgroup, LDS tile [P][(RB - 1) s + k][pitch4]
             const int nplanes = batch * op.outc, rin_full = (op.Ho - 1) * op.stride + op.k, KW = (op.k * op.k + 1 + 3) & ~3;

@@ -703,6 +703,124 @@ static inline int sgx_se_gate_launch(const SgxSeGate &p, int batch, sgx_stream_t
     return SGX_ERR_INVALID;
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_conv_dw3<K, S, PX>: depthwise K x K convolution (+ ReLU / Clip / h-swish epilogue) in the arithmetic of k_fused_block2 / k_hrb (round 6).
+// k_conv_dw2 spends 2.7 lane-instructions per multiply-add (round-6 census: the 100 fp32 FMAs of a four-pixel task are a quarter of its cycles; the rest is the weight vector
+// read from LDS per task, index arithmetic, a scalar epilogue per pixel).  Here the CHANNEL PAIR is the unit:
+//   stage    the input planes of NP channel pairs of one image -> LDS, pair-interleaved [pair][padded row][padded column] float2 with the zero border in place
+//            (two coalesced global loads + one ds_write_b64 per pixel and pair)
+//   compute  wave w takes pairs w, w + 4, ...; the K x K weight pairs of a pair sit in SCALAR registers (wave-uniform), a lane takes PX horizontally adjacent output pixels
+//            (S = 1: their tap windows overlap, (PX + K - 1) x K ds_read_b64 serve PX K K v_pk_fma_f32), taps (i, j) ascending from the bias — per output the same fmaf chain as
+//            k_conv_dw2 / k_conv_kxk, so the results are BIT-IDENTICAL to them — and the epilogue program runs on both halves of the pair
+// Used by both plans (exact fp32 and bf16x3).  grid = images x ceil(pairs / NP); LDS = NP * HP * WP * 8 bytes.
+// ---------------------------------------------------------------------------------------------
+struct SgxDw3 { int C, H, W, Ho, Wo, pad, NP, HP, WP, nchunks, WU, NU; unsigned m_wu, m_wp, m_cells; const float *in; size_t in_pitch; const float *wd2, *bias; float *out; size_t out_pitch; SgxEpi epi; };
+template <int K, int S, int PX, int MODE>
+SGX_DEV void sgx_dw3_body(const SgxDw3 &p, sgx_f2 *Es, int tid)
+{
+    constexpr int KK = K * K, NC = (PX - 1) * S + K;                     // tap columns a lane reads per tap row
+    const int chunk = (int)blockIdx.x % p.nchunks, b = (int)blockIdx.x / p.nchunks;
+    const int pair0 = chunk * p.NP, np = min(p.NP, p.C / 2 - pair0);
+    const int wave = tid >> 6, lane = tid & 63;
+    const size_t ohw = (size_t)p.Ho * p.Wo;
+    float *Y = p.out + (size_t)b * p.out_pitch;
+    for (int pl = wave; pl < np; pl += 4) {                              // wave-uniform
+        const int gp = pair0 + pl;
+        const sgx_f2 *wt = (const sgx_f2 *)p.wd2 + (size_t)gp * KK;
+        sgx_f2 wk[KK];
+#pragma unroll
+        for (int t = 0; t < KK; t++) wk[t] = wt[t];
+        const sgx_f2 bz = sgx_mk2(p.bias[2 * gp], p.bias[2 * gp + 1]);
+        const sgx_f2 *E = Es + (size_t)pl * p.HP * p.WP;
+        for (int u0 = 0; u0 < p.NU; u0 += 64) {
+            const int u = min(u0 + lane, p.NU - 1), oy = (int)sgx_fastdiv((unsigned)u, p.m_wu), oxu = u - oy * p.WU, ox = oxu * PX;      // NU < 2^20, WU < 2^12
+            const sgx_f2 *e = E + (oy * S) * p.WP + ox * S;
+            sgx_f2 sv[PX];
+#pragma unroll
+            for (int i = 0; i < PX; i++) sv[i] = bz;
+#pragma unroll
+            for (int a = 0; a < K; a++) {
+                sgx_f2 tp[NC];
+#pragma unroll
+                for (int c = 0; c < NC; c++) tp[c] = e[a * p.WP + c];
+#pragma unroll
+                for (int c = 0; c < K; c++)
+#pragma unroll
+                    for (int i = 0; i < PX; i++) sv[i] = sgx_fma2_w(wk[a * K + c], tp[c + i * S], sv[i]);
+            }
+            if (u0 + lane < p.NU) {
+#pragma unroll
+                for (int i = 0; i < PX; i++)
+                    if (ox + i < p.Wo) {
+                        const size_t o = (size_t)oy * p.Wo + ox + i;
+                        Y[(size_t)(2 * gp) * ohw + o] = sgx_epi_mode<MODE>(p.epi, sv[i].x, 0, 0);
+                        Y[(size_t)(2 * gp + 1) * ohw + o] = sgx_epi_mode<MODE>(p.epi, sv[i].y, 0, 0);
+                    }
+            }
+        }
+    }
+}
+template <int K, int S, int PX>
+SGX_KERNEL(256) k_conv_dw3(SgxDw3 p)
+{
+    SGX_DYN_LDS(smem);
+    sgx_f2 *Es = (sgx_f2 *)smem;
+    const int chunk = (int)blockIdx.x % p.nchunks, b = (int)blockIdx.x / p.nchunks;
+    const int pair0 = chunk * p.NP, np = min(p.NP, p.C / 2 - pair0);
+    const float *X = p.in + (size_t)b * p.in_pitch;
+    const size_t hw = (size_t)p.H * p.W;
+    const int cells = p.HP * p.WP, total = np * cells;
+    SGX_THREADS_BEGIN(tid)
+    for (int i0 = tid; i0 < total; i0 += 256 * 4) {                      // four cells per thread and round: eight independent loads in flight
+        sgx_f2 v[4]; int idx[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int i = min(i0 + 256 * q, total - 1), pl = p.m_cells ? (int)sgx_fastdiv((unsigned)i, p.m_cells) : i / cells, r = i - pl * cells, yy = (int)sgx_fastdiv((unsigned)r, p.m_wp), xx = r - yy * p.WP, iy = yy - p.pad, ix = xx - p.pad;
+            const bool in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const float *src = X + (size_t)(2 * (pair0 + pl)) * hw + (size_t)(in ? iy : 0) * p.W + (in ? ix : 0);
+            const float x0 = src[0], x1 = src[hw];
+            v[q] = sgx_mk2(in ? x0 : 0.f, in ? x1 : 0.f); idx[q] = i0 + 256 * q < total ? i : -1;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) if (idx[q] >= 0) Es[idx[q]] = v[q];
+    }
+    SGX_THREADS_END
+    SGX_SYNC();
+    SGX_THREADS_BEGIN(tid)
+    switch (p.epi.mode) {
+    case SGX_EMODE_NONE: sgx_dw3_body<K, S, PX, SGX_EMODE_NONE>(p, Es, tid); break;
+    case SGX_EMODE_ACT: sgx_dw3_body<K, S, PX, SGX_EMODE_ACT>(p, Es, tid); break;
+    default: sgx_dw3_body<K, S, PX, SGX_EMODE_HSWISH>(p, Es, tid); break;      // the host launches this kernel for these three programs only
+    }
+    SGX_THREADS_END
+}
+static inline bool sgx_dw3_plan(int C, int H, int W, int Ho, int Wo, int k, int stride, int pad, int mode, SgxDw3 *p, int *px, size_t *lds)
+{
+    if ((C & 1) || (k != 3 && k != 5) || (stride != 1 && stride != 2) || pad != k / 2 || (mode != SGX_EMODE_NONE && mode != SGX_EMODE_ACT && mode != SGX_EMODE_HSWISH)) return false;
+    const int HP = H + 2 * pad, WP = W + 2 * pad + 3;                   // + 3: the tap window of the last (partial) pixel group stays inside the row
+    const size_t per_pair = (size_t)HP * WP * 8;
+    if (per_pair > 60 * 1024) return false;
+    int NP = (int)((56 * 1024) / per_pair); NP = NP > 16 ? 16 : NP; NP = NP > C / 2 ? C / 2 : NP; NP = NP < 1 ? 1 : NP;
+    if (NP >= 4) NP &= ~3;                                               // whole rounds of the four waves
+    *px = (stride == 1 && Wo >= 16) ? 2 : 1;
+    p->C = C; p->H = H; p->W = W; p->Ho = Ho; p->Wo = Wo; p->pad = pad; p->NP = NP; p->HP = HP; p->WP = WP; p->nchunks = (C / 2 + NP - 1) / NP;
+    p->WU = (Wo + *px - 1) / *px; p->NU = Ho * p->WU;
+    { auto magic = [](int d) -> unsigned { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
+      p->m_wu = magic(p->WU); p->m_wp = magic(WP); p->m_cells = (HP * WP < 4096 && NP * HP * WP < (1 << 20)) ? magic(HP * WP) : 0u; }
+    *lds = (size_t)NP * per_pair;
+    return true;
+}
+static inline void sgx_dw3_launch(const SgxDw3 &p, int k, int stride, int px, size_t lds, int batch, sgx_stream_t st)
+{
+    const unsigned grid = (unsigned)(batch * p.nchunks);
+#define SGX_DW3(K_, S_, PX_) do { auto kfn = k_conv_dw3<K_, S_, PX_>; SGX_LAUNCH_DYN(kfn, dim3(grid), dim3(256), lds, st, p); } while (0)
+    if (k == 3 && stride == 1) { if (px == 2) SGX_DW3(3, 1, 2); else SGX_DW3(3, 1, 1); }
+    else if (k == 3) SGX_DW3(3, 2, 1);
+    else if (stride == 1) { if (px == 2) SGX_DW3(5, 1, 2); else SGX_DW3(5, 1, 1); }
+    else SGX_DW3(5, 2, 1);
+#undef SGX_DW3
+}
+
 // ---- k_fused_block2 dispatch: (Cin, Cout, K, stride) -> instantiation; the tile variant comes from SGX_FB2_TILE (tuning tap) --------------------------------------
 static inline int sgx_fb2_cm(int v2) { return (v2 >> 4) == 1 ? 16 : 8; }       /* expanded channels per chunk of the instantiation (Cmid must be a multiple) */
 static inline int sgx_fb2_variant(int cin, int cout, int k, int stride, int cq = 0)

@@ -447,7 +447,7 @@ SGX_KERNEL_OCC(256, OCC) k_hrb(SgxHrb p)
 #ifdef SGX_DEBUG_TAPS
 #define SGX_HRB_ALTERNATIVES(X) \
     X(16, 16, 16, 3, 1, 16, 16, 0, true, 5) X(16, 64, 24, 3, 2, 7, 16, 0, false, 2) X(24, 72, 24, 3, 1, 16, 16, 0, true, 3) \
-    X(16, 16, 16, 3, 1, 16, 16, 0, true, 6) X(24, 72, 24, 3, 1, 8, 16, 0, true, 3)
+    X(16, 16, 16, 3, 1, 16, 16, 0, true, 6) X(24, 72, 24, 3, 1, 8, 16, 0, true, 3) X(24, 72, 40, 5, 2, 4, 19, 1, false, 2) X(24, 72, 40, 5, 2, 6, 19, 1, false, 2)
 #else
 #define SGX_HRB_ALTERNATIVES(X)
 #endif

@@ -279,18 +279,13 @@ SGX_DEV uint32_t sgx_as_u32(sgx_i16x2 v) { return __builtin_bit_cast(uint32_t, v
 /* (high half of p, low half of q): the pair one 16-bit element further along a row of pairs */
 SGX_DEV sgx_i16x2 sgx_lk_next(sgx_i16x2 p, sgx_i16x2 q) { return sgx_as_i16x2(__builtin_amdgcn_alignbit(sgx_as_u32(q), sgx_as_u32(p), 16)); }
 #define SGX_LK_DOT2(a, b, c) __builtin_amdgcn_sdot2((a), (b), (c), false)
-/* the same dot product with a SEPARATE destination (v_dot2_i32_i16, the VOP3P form): for an accumulator operand that must survive — the compiler picks the two-address
- * v_dot2c and copies the operand first (one v_mov per window sample and iteration in the tracker's inner loop) */
-SGX_DEV int sgx_lk_dot2_keep(sgx_i16x2 a, sgx_i16x2 b, int c)
-{
-#ifndef SGX_EMU
-    int d;
-    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-#else
-    return SGX_LK_DOT2(a, b, c);
-#endif
-}
+/* the first dot product of a window sample, whose accumulator operand (the sample's start value) must survive.  Rounds 4-6 issued it as inline assembly in the three-address
+ * VOP3P form (v_dot2_i32_i16) to spare the v_mov the compiler puts in front of its two-address v_dot2c.  That was a HARDWARE HAZARD: on gfx940 / gfx950 a DOT result needs
+ * 3 wait states before a VALU instruction of a different opcode reads it (4 before one overwrites it) and the compiler inserts them only for instructions it can see — not for
+ * the contents of an asm statement.  The following v_dot2c read its accumulator one wait state after the asm: harmless while other waves fill the issue slots, but with few
+ * waves on the SIMD (kernel tails, other kernels co-resident) about one keypoint in 10^4 got a stale value (found in round 6 by two trackers running side by side:
+ * tools/diag_two_trackers.py).  The builtin costs the v_mov (0.7 % of the kernel) and is handled by the compiler's hazard recogniser. */
+SGX_DEV int sgx_lk_dot2_keep(sgx_i16x2 a, sgx_i16x2 b, int c) { return SGX_LK_DOT2(a, b, c); }
 
 /* stage the ROWS x 36-byte patch of `img` whose top-left corner is (ox, oy) (ox a multiple of 4) into the wave's LDS tile: REFLECT_101 outside the
  * image, aligned dwords wherever the image allows.  Lane -> (row within a group of seven, dword column): 63 lanes move seven tile rows per pass. */

@@ -1,0 +1,43 @@
+"""diagnostic (round 6): the LK tracker on the SAME frame pair and keypoints over and over, beside a second instance on another stream; any change of the output between repetitions
+is a race inside the kernel (or its pyramid).  usage: python tools/diag_lk_repeat.py [reps] [taps]      env: SGX_LK_KPW (tap build), POLLUTE=KB"""
+import os, sys, ctypes as C
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import sg_slam_amd
+from sg_slam_amd import synth
+from sg_slam_amd.capi import SgxLib
+from sg_slam_amd.flow import OpticalFlowLK
+from sg_slam_amd.orb import ORBextractor
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+lib = SgxLib(os.path.join(ROOT, 'tests', 'taps', 'libsgx_taps.so')) if len(sys.argv) > 2 else sg_slam_amd.load()
+pol = C.CDLL(os.path.join(ROOT, 'tools', 'lds_pollute', 'liblds_pollute.so')) if int(os.environ.get('POLLUTE', '0')) else None
+S = 2; gen = synth.PlaneStream(seed=1234); offs = [3, 57]
+f0 = torch.from_numpy(np.stack([gen.frame(o + 1)[0] for o in offs])).cuda(); f1 = torch.from_numpy(np.stack([gen.frame(o + 2)[0] for o in offs])).cuda()
+ex = ORBextractor(nfeatures=1000, width=640, height=480, max_batch=S, lib=lib); cap = ex.capacity
+keys = torch.zeros((S, cap, 28), dtype=torch.uint8, device='cuda'); desc = torch.zeros((S, cap, 32), dtype=torch.uint8, device='cuda'); n = torch.zeros(S, dtype=torch.int32, device='cuda')
+ex.extract_batch_dev(f1, 640, S, keys, desc, n); torch.cuda.synchronize()
+nn = n.cpu().numpy(); print('keys', nn)
+class Inst:
+    def __init__(self):
+        self.fl = OpticalFlowLK(width=640, height=480, max_batch=S, lib=lib); self.st = torch.cuda.Stream()
+        self.xy = torch.zeros((S, cap, 2), dtype=torch.float32, device='cuda'); self.status = torch.zeros((S, cap), dtype=torch.uint8, device='cuda')
+    def run(self):
+        self.fl.reset()
+        self.fl.lk_batch_dev(f0, 640, S, None, None, cap, None, None, stream=self.st.cuda_stream)
+        self.fl.lk_batch_dev(f1, 640, S, keys, n, cap, self.xy, self.status, stream=self.st.cuda_stream)
+    def out(self):
+        return [np.concatenate([self.xy[s, :nn[s]].cpu().numpy().view(np.uint32), self.status[s, :nn[s], None].cpu().numpy().astype(np.uint32)], 1) for s in range(S)]
+A, B = Inst(), Inst()
+A.run(); torch.cuda.synchronize(); ref = A.out()
+bad = 0
+for r in range(reps):
+    if pol: pol.lds_pollute(C.c_uint32(0x7fc00000 + r), int(os.environ['POLLUTE']), 50, 1024)
+    A.run(); B.run(); torch.cuda.synchronize()
+    for name, I in (('A', A), ('B', B)):
+        o = I.out()
+        for s in range(S):
+            w = np.argwhere((o[s] != ref[s]).any(1))
+            if len(w):
+                bad += 1; i = int(w[0][0]); k = keys[s, i].cpu().numpy().view(np.float32)
+                print('rep %d %s stream %d: %d keys differ; key %d at (%.2f, %.2f) octave %d: %s vs quiet %s' % (r, name, s, len(w), i, k[0], k[1], keys[s, i].cpu().numpy().view(np.int32)[5], o[s][i, :2].view(np.float32), ref[s][i, :2].view(np.float32)), flush=True)
+print('reps', reps, 'bad', bad)

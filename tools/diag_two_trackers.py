@@ -1,0 +1,84 @@
+"""diagnostic (round 6): two identical Python-orchestrated trackers + detectors side by side on the same frames (optionally beside the LDS polluter); every intermediate buffer of the
+extraction stage is compared after each step.  usage: POLLUTE=64 python tools/diag_two_trackers.py [reps]"""
+import os, sys, ctypes as C
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import sg_slam_amd
+from sg_slam_amd import synth
+from sg_slam_amd.capi import DetResult
+from sg_slam_amd.detector import Detector2D
+from sg_slam_amd.tracker import TrackerBatch
+from test_tracker_native_gpu import CAM
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+pol = C.CDLL(os.path.join(ROOT, 'tools', 'lds_pollute', 'liblds_pollute.so')) if int(os.environ.get('POLLUTE', '0')) else None
+from sg_slam_amd.capi import SgxLib
+lib = SgxLib(os.path.join(ROOT, 'tests', 'taps', 'libsgx_taps.so')) if len(sys.argv) > 2 else sg_slam_amd.load()
+param = os.path.join(ROOT, 'tests', 'golden', 'mobilenetv3_ssdlite_voc.param')
+layers = synth.parse_ncnn_param(param); _, blob = synth.synth_ncnn_weights(layers, seed=7, person_logit=-0.5)
+S, MB, NF = 2, 100, 5
+gen = synth.PlaneStream(seed=1234); offs = [3, 57]
+frames = [[gen.frame(o + t) for o in offs] for t in range(NF)]
+T0 = np.stack([gen.Tcw(o) for o in offs])
+class Side:
+    def __init__(self):
+        self.det = Detector2D(0.9, 0.01, param_text=open(param).read(), bin_bytes=blob, max_batch=S, lib=lib)
+        self.tr = TrackerBatch(lib, S, CAM, xp='torch', lk=True, max_boxes=MB); self.tr.set_initial_pose(T0)
+        self.sD = torch.cuda.Stream()
+        self.res = [torch.zeros((S, C.sizeof(DetResult)), dtype=torch.uint8, device='cuda') for _ in range(2)]
+        self.boxes = [torch.zeros((S, MB, 4), dtype=torch.float32, device='cuda') for _ in range(2)]
+        self.nb = [torch.zeros(S, dtype=torch.int32, device='cuda') for _ in range(2)]; self.have = [torch.zeros(S, dtype=torch.int32, device='cuda') for _ in range(2)]
+        self.ev = [torch.cuda.Event() for _ in range(2)]
+    def step(self, t, d_gray, d_depth, d_bgr):
+        b = t & 1
+        self.sD.wait_stream(torch.cuda.current_stream())
+        if t >= 2: self.sD.wait_event(self.tr.ev_extract[(t - 2) % 3])
+        self.det.detect_batch_dev(d_bgr, 640 * 3, S, self.res[b], self.boxes[b], self.nb[b], MB, self.have[b], stream=self.sD.cuda_stream)
+        self.ev[b].record(self.sD)
+        self.tr.step(d_gray, d_depth, mask=dict(boxes=self.boxes[b], nboxes=self.nb[b], have_dynamic=self.have[b], event=self.ev[b]))
+    def snap(self, t):
+        tr = self.tr; b = t & 1; c = tr.cur
+        g = lambda x: x.cpu().numpy().copy()
+        rn = g(tr.rn); d = dict(nb=g(self.nb[b]), boxes=g(self.boxes[b]), have=g(self.have[b]), rn=rn, n=g(tr.n[c]))
+        for s in range(S):
+            k = int(rn[s]); d['rkeys%d' % s] = g(tr.rkeys[s, :k]); d['prev_xy%d' % s] = g(tr.prev_xy[s, :k]).view(np.uint32); d['lk_status%d' % s] = g(tr.lk_status[s, :k]); d['keep%d' % s] = g(tr.keep[s, :k])
+            d['keys%d' % s] = g(tr.keys[c][s, :int(d['n'][s])])
+        d['F'] = g(tr.F).view(np.uint64); d['f_ok'] = g(tr.f_ok); d['f_stats'] = g(tr.f_stats); d['pre_boxes'] = g(tr.pre_boxes); d['pre_nboxes'] = g(tr.pre_nboxes); d['pre_have'] = g(tr.pre_have)
+        d['Tcw'] = g(tr.Tcw[1]).view(np.uint32)
+        return d
+order = ['nb', 'boxes', 'have', 'rn', 'rkeys0', 'rkeys1', 'prev_xy0', 'prev_xy1', 'lk_status0', 'lk_status1', 'pre_nboxes', 'pre_boxes', 'pre_have', 'f_ok', 'F', 'f_stats', 'keep0', 'keep1', 'n', 'keys0', 'keys1', 'Tcw']
+nbad = 0
+for rep in range(reps):
+    A, B = Side(), Side(); held = []
+    for t in range(NF):
+        fr = frames[t]
+        d_gray = torch.from_numpy(np.stack([f[0] for f in fr])).cuda(); d_depth = torch.from_numpy(np.stack([f[1] for f in fr]).view(np.int16)).cuda()
+        d_bgr = d_gray.unsqueeze(-1).expand(S, 480, 640, 3).contiguous(); held.append((d_gray, d_depth, d_bgr))
+        if pol: assert pol.lds_pollute(C.c_uint32(0x7fc00000 + 977 * t + 31 * rep), int(os.environ['POLLUTE']), 400, 1024) == 0
+        A.step(t, d_gray, d_depth, d_bgr); B.step(t, d_gray, d_depth, d_bgr)
+        torch.cuda.synchronize()
+        if t == 0: continue
+        a, b = A.snap(t), B.snap(t)
+        diff = [k for k in order if a[k].shape != b[k].shape or not (a[k] == b[k]).all()]
+        if diff:
+            nbad += 1; k = diff[0]; print('rep %d t %d: differ %s; first: %s' % (rep, t, diff, k), flush=True)
+            if a[k].shape == b[k].shape:
+                w = np.argwhere(a[k] != b[k]); print('   where', w[:6].tolist(), 'A', a[k][tuple(w[0])], 'B', b[k][tuple(w[0])], 'count', len(w))
+                if k.startswith('prev_xy'):
+                    s = int(k[-1]); i = int(w[0][0]); print('   key', a['rkeys%d' % s][i].view(np.float32)[:2], 'A xy', a[k][i].view(np.float32), 'B xy', b[k][i].view(np.float32), 'status', a['lk_status%d' % s][i], b['lk_status%d' % s][i])
+            if k.startswith('prev_xy'):      # which side is right: the host entry (fresh handle, alone) on the same frame pair and keypoints
+                from sg_slam_amd.flow import OpticalFlowLK
+                s_ = int(k[-1]); fl = OpticalFlowLK(width=640, height=480, max_batch=1, lib=lib)
+                pts = a['rkeys%d' % s_].view(np.float32).reshape(len(a['rkeys%d' % s_]), 7)[:, :2].copy()
+                truth, st_ = fl(frames[t][s_][0], frames[t - 1][s_][0], pts)
+                tv = truth.view(np.uint32)
+                wa = np.argwhere((a[k] != tv).any(1)).ravel().tolist(); wb = np.argwhere((b[k] != tv).any(1)).ravel().tolist()
+                print('   against the host entry alone: A differs at', wa, ' B differs at', wb)
+                for i_ in sorted(set(wa + wb))[:4]: print('      key %d truth %s A %s B %s' % (i_, truth[i_], a[k][i_].view(np.float32), b[k][i_].view(np.float32)))
+            if lib.has_taps:
+                for slot in range(2):
+                    for fr_ in range(S):
+                        for lv in range(A.tr.flow.levels):
+                            pa, pb = A.tr.flow.debug_level(slot, fr_, lv), B.tr.flow.debug_level(slot, fr_, lv)
+                            if not (pa == pb).all(): print('   pyramid slot %d frame %d level %d differs at %d pixels, first %s' % (slot, fr_, lv, int((pa != pb).sum()), np.argwhere(pa != pb)[0].tolist()))
+            break
+print('reps', reps, 'bad', nbad)
