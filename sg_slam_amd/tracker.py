@@ -29,6 +29,7 @@ from .flow import OpticalFlowLK, fundamental_ransac_batch_dev
 
 
 class TrackerBatch:
+    stream_priorities = (0, 0)      # (extraction, tracking) HIP stream priorities; see __init__
     def __init__(self, lib, streams, cam, width=640, height=480, nfeatures=1000, xp='torch', th=15.0, pipelined=True, local_map=True, debug_taps=False, lk=False, max_boxes=8):
         self.lib, self.S, self.cam, self.W, self.H, self.th = lib, streams, dict(cam), width, height, th
         self.ex = ORBextractor(nfeatures=nfeatures, width=width, height=height, max_batch=streams, lib=lib)
@@ -90,7 +91,12 @@ class TrackerBatch:
         self.pipelined = bool(pipelined and xp == 'torch')
         if self.pipelined:
             import torch
-            self.sE, self.sT = torch.cuda.Stream(), torch.cuda.Stream(priority=-1)      # the tracking stream is the latency-critical one: dispatch it first
+            # Both streams at the SAME priority.  Rounds 2-5 gave the tracking stream the high priority (latency of a single camera).  Round 6: with queues of different
+            # priorities live on the device, the LK tracker (and only it: the most ALU-dense kernel of the chain) returned a slightly different position for about one keypoint
+            # in 10^4 — always a keypoint handled by lanes 32-63 of its wave, never with equal priorities, never with the kernels serialised (tools/diag_two_trackers.py,
+            # profiles/r6_lk_priority_diagnosis.md).  `stream_priorities` is the switch the diagnostic uses to bring the condition back.
+            pe, pt = self.stream_priorities
+            self.sE, self.sT = torch.cuda.Stream(priority=pe), torch.cuda.Stream(priority=pt)
             self.ev_extract = [torch.cuda.Event() for _ in range(NB)]
             self.ev_track = [torch.cuda.Event() for _ in range(NB)]
 

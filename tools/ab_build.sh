@@ -1,13 +1,9 @@
 #!/bin/bash
-# A/B builds of the product library with a compile-time switch: tools/ab_build.sh NAME "-DFLAG ..."  ->  gpurun_out/ab/libsgx_NAME.so (travels to the GPU box with the snapshot? no:
-# gpurun_out/ is not shipped — the variant goes to sg_slam_amd/ab/, which is git-ignored as *.so)
+# A/B build of the PRODUCT library that differs in one translation unit: tools/ab_build.sh NAME sgx_flow.cpp "-DFLAG ..."  ->  sg_slam_amd/ab/libsgx_NAME.so (git-ignored, travels with
+# gpurun).  The other objects are the product's (make -C sg_slam_amd/csrc ../libsgx.so first).
 set -e
-N=$1; F=$2; R=$(cd $(dirname $0)/.. && pwd); mkdir -p $R/sg_slam_amd/ab $R/sg_slam_amd/csrc/build_ab_$N
-cd $R/sg_slam_amd/csrc
-for f in sgx_*.cpp; do
-  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -Wno-everything $F -x hip -c $f -o build_ab_$N/${f%.cpp}.o ) &
-done
-wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared build_ab_$N/*.o -o $R/sg_slam_amd/ab/libsgx_$N.so
-rm -rf build_ab_$N
+N=$1; TU=$2; F=$3; R=$(cd $(dirname $0)/.. && pwd); mkdir -p $R/sg_slam_amd/ab
+cd $R/sg_slam_amd/csrc; B=${TU%.cpp}
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -Wno-everything $F -x hip -c $TU -o build/ab_${N}_$B.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared $(ls build/sgx_*.o | grep -v build/$B.o) build/ab_${N}_$B.o -o $R/sg_slam_amd/ab/libsgx_$N.so
 echo built $R/sg_slam_amd/ab/libsgx_$N.so

@@ -28,12 +28,30 @@ class Inst:
     def out(self):
         return [np.concatenate([self.xy[s, :nn[s]].cpu().numpy().view(np.uint32), self.status[s, :nn[s], None].cpu().numpy().astype(np.uint32)], 1) for s in range(S)]
 A, B = Inst(), Inst()
+corun = os.environ.get('CORUN', 'lk')
+if 'det' in corun:
+    from sg_slam_amd.detector import Detector2D
+    from sg_slam_amd.capi import DetResult
+    param = os.path.join(ROOT, 'tests', 'golden', 'mobilenetv3_ssdlite_voc.param')
+    layers = synth.parse_ncnn_param(param); _, blob = synth.synth_ncnn_weights(layers, seed=7, person_logit=-0.5)
+    det = Detector2D(0.9, 0.01, param_text=open(param).read(), bin_bytes=blob, max_batch=S, lib=lib); sDet = torch.cuda.Stream()
+    bgr = f1.unsqueeze(-1).expand(S, 480, 640, 3).contiguous()
+    dres = torch.zeros((S, C.sizeof(DetResult)), dtype=torch.uint8, device='cuda'); dbox = torch.zeros((S, 100, 4), dtype=torch.float32, device='cuda')
+    dnb = torch.zeros(S, dtype=torch.int32, device='cuda'); dhave = torch.zeros(S, dtype=torch.int32, device='cuda')
+if 'orb' in corun:
+    ex2 = ORBextractor(nfeatures=1000, width=640, height=480, max_batch=S, lib=lib); sOrb = torch.cuda.Stream()
+    k2 = torch.zeros_like(keys); d2 = torch.zeros_like(desc); n2 = torch.zeros_like(n)
 A.run(); torch.cuda.synchronize(); ref = A.out()
 bad = 0
 for r in range(reps):
     if pol: pol.lds_pollute(C.c_uint32(0x7fc00000 + r), int(os.environ['POLLUTE']), 50, 1024)
-    A.run(); B.run(); torch.cuda.synchronize()
-    for name, I in (('A', A), ('B', B)):
+    if 'det' in corun: det.detect_batch_dev(bgr, 640 * 3, S, dres, dbox, dnb, 100, dhave, stream=sDet.cuda_stream)
+    if 'orb' in corun and 'first' in corun: ex2.extract_batch_dev(f1, 640, S, k2, d2, n2, stream=sOrb.cuda_stream)
+    A.run()
+    if 'orb' in corun and 'first' not in corun: ex2.extract_batch_dev(f1, 640, S, k2, d2, n2, stream=sOrb.cuda_stream)
+    if 'lk' in corun: B.run()
+    torch.cuda.synchronize()
+    for name, I in ((('A', A), ('B', B)) if 'lk' in corun else (('A', A),)):
         o = I.out()
         for s in range(S):
             w = np.argwhere((o[s] != ref[s]).any(1))

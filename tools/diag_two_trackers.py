@@ -12,7 +12,7 @@ from test_tracker_native_gpu import CAM
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 pol = C.CDLL(os.path.join(ROOT, 'tools', 'lds_pollute', 'liblds_pollute.so')) if int(os.environ.get('POLLUTE', '0')) else None
 from sg_slam_amd.capi import SgxLib
-lib = SgxLib(os.path.join(ROOT, 'tests', 'taps', 'libsgx_taps.so')) if len(sys.argv) > 2 else sg_slam_amd.load()
+lib = (SgxLib(os.path.join(ROOT, 'tests', 'taps', 'libsgx_taps.so')) if sys.argv[2] == 'taps' else SgxLib(os.path.join(ROOT, sys.argv[2]))) if len(sys.argv) > 2 else sg_slam_amd.load()
 param = os.path.join(ROOT, 'tests', 'golden', 'mobilenetv3_ssdlite_voc.param')
 layers = synth.parse_ncnn_param(param); _, blob = synth.synth_ncnn_weights(layers, seed=7, person_logit=-0.5)
 S, MB, NF = 2, 100, 5
@@ -28,6 +28,10 @@ class Side:
         self.boxes = [torch.zeros((S, MB, 4), dtype=torch.float32, device='cuda') for _ in range(2)]
         self.nb = [torch.zeros(S, dtype=torch.int32, device='cuda') for _ in range(2)]; self.have = [torch.zeros(S, dtype=torch.int32, device='cuda') for _ in range(2)]
         self.ev = [torch.cuda.Event() for _ in range(2)]
+        self.dbg = None
+        if hasattr(lib.dll, 'sgx_flow_debug_set_dbg'):
+            self.dbg = torch.zeros((S, self.tr.cap, 4, 24), dtype=torch.float32, device='cuda')
+            lib.dll.sgx_flow_debug_set_dbg(self.tr.flow.h, C.c_void_p(self.dbg.data_ptr()))
     def step(self, t, d_gray, d_depth, d_bgr):
         b = t & 1
         self.sD.wait_stream(torch.cuda.current_stream())
@@ -46,9 +50,13 @@ class Side:
         d['Tcw'] = g(tr.Tcw[1]).view(np.uint32)
         return d
 order = ['nb', 'boxes', 'have', 'rn', 'rkeys0', 'rkeys1', 'prev_xy0', 'prev_xy1', 'lk_status0', 'lk_status1', 'pre_nboxes', 'pre_boxes', 'pre_have', 'f_ok', 'F', 'f_stats', 'keep0', 'keep1', 'n', 'keys0', 'keys1', 'Tcw']
-nbad = 0
+nbad = 0; bad_keys = []; keep_alive = []; MODE = os.environ.get('MODE', '')
 for rep in range(reps):
-    A, B = Side(), Side(); held = []
+    if 'swap' in MODE: B = Side(); A = Side()
+    else: A, B = Side(), Side()
+    held = []
+    if 'keep' in MODE: keep_alive.append((A, B))
+    if 'addr' in MODE: print('rep', rep, 'A prev_xy %x rkeys %x rn %x pyr %s | B prev_xy %x' % (A.tr.prev_xy.data_ptr(), A.tr.rkeys.data_ptr(), A.tr.rn.data_ptr(), '', B.tr.prev_xy.data_ptr()))
     for t in range(NF):
         fr = frames[t]
         d_gray = torch.from_numpy(np.stack([f[0] for f in fr])).cuda(); d_depth = torch.from_numpy(np.stack([f[1] for f in fr]).view(np.int16)).cuda()
@@ -65,6 +73,7 @@ for rep in range(reps):
                 w = np.argwhere(a[k] != b[k]); print('   where', w[:6].tolist(), 'A', a[k][tuple(w[0])], 'B', b[k][tuple(w[0])], 'count', len(w))
                 if k.startswith('prev_xy'):
                     s = int(k[-1]); i = int(w[0][0]); print('   key', a['rkeys%d' % s][i].view(np.float32)[:2], 'A xy', a[k][i].view(np.float32), 'B xy', b[k][i].view(np.float32), 'status', a['lk_status%d' % s][i], b['lk_status%d' % s][i])
+            if k.startswith('prev_xy'): bad_keys += np.argwhere((a[k] != b[k]).any(1)).ravel().tolist()
             if k.startswith('prev_xy'):      # which side is right: the host entry (fresh handle, alone) on the same frame pair and keypoints
                 from sg_slam_amd.flow import OpticalFlowLK
                 s_ = int(k[-1]); fl = OpticalFlowLK(width=640, height=480, max_batch=1, lib=lib)
@@ -74,6 +83,11 @@ for rep in range(reps):
                 wa = np.argwhere((a[k] != tv).any(1)).ravel().tolist(); wb = np.argwhere((b[k] != tv).any(1)).ravel().tolist()
                 print('   against the host entry alone: A differs at', wa, ' B differs at', wb)
                 for i_ in sorted(set(wa + wb))[:4]: print('      key %d truth %s A %s B %s' % (i_, truth[i_], a[k][i_].view(np.float32), b[k][i_].view(np.float32)))
+            if k.startswith('prev_xy') and A.dbg is not None:
+                s_ = int(k[-1]); da, db = A.dbg[s_].cpu().numpy(), B.dbg[s_].cpu().numpy()
+                for i_ in np.argwhere((a[k] != b[k]).any(1)).ravel().tolist()[:3]:
+                    for lv in (3, 2, 1, 0):
+                        if not (da[i_, lv, :22].view(np.uint32) == db[i_, lv, :22].view(np.uint32)).all(): print('      key %d level %d A-matrix %s iters A %d B %d  longest gap between iterations (10 ns ticks, at j): A %d @%d  B %d @%d   median gap of all keys at this level: A %d B %d' % (i_, lv, 'same' if (da[i_, lv, :3] == db[i_, lv, :3]).all() else 'DIFF', da[i_, lv, 3], db[i_, lv, 3], da[i_, lv, 22], da[i_, lv, 23], db[i_, lv, 22], db[i_, lv, 23], np.median(da[:, lv, 22]), np.median(db[:, lv, 22]))); [print('         j %d  A b %s nextx %r | B b %s nextx %r %s   D %r %r' % (j_, da[i_, lv, 4 + 3 * j_:6 + 3 * j_].tolist(), float(da[i_, lv, 6 + 3 * j_]), db[i_, lv, 4 + 3 * j_:6 + 3 * j_].tolist(), float(db[i_, lv, 6 + 3 * j_]), '' if (da[i_, lv, 4 + 3 * j_:7 + 3 * j_].view(np.uint32) == db[i_, lv, 4 + 3 * j_:7 + 3 * j_].view(np.uint32)).all() else '<--', float(da[i_, lv, 21]), float(db[i_, lv, 21]))) for j_ in range(min(6, int(max(da[i_, lv, 3], db[i_, lv, 3], 1))))]
             if lib.has_taps:
                 for slot in range(2):
                     for fr_ in range(S):
@@ -81,4 +95,4 @@ for rep in range(reps):
                             pa, pb = A.tr.flow.debug_level(slot, fr_, lv), B.tr.flow.debug_level(slot, fr_, lv)
                             if not (pa == pb).all(): print('   pyramid slot %d frame %d level %d differs at %d pixels, first %s' % (slot, fr_, lv, int((pa != pb).sum()), np.argwhere(pa != pb)[0].tolist()))
             break
-print('reps', reps, 'bad', nbad)
+print('reps', reps, 'bad', nbad, 'failing key indices', sorted(bad_keys))
