@@ -22,13 +22,7 @@ struct sgx_flow {
     uint8_t *img[2] = { nullptr, nullptr };     // two pyramid slots (current / previous), max_batch frames each
     int cur = 0;                                // slot the NEXT call writes
     int prev_batch = 0;                         // frames held by the other slot (0 = no previous frame: `if(imGrayPre.data)` false, Frame.cc:155)
-#ifdef SGX_LK_DBG
-    float *dbg = nullptr;
-#endif
 };
-#ifdef SGX_LK_DBG
-extern "C" int sgx_flow_debug_set_dbg(sgx_flow *h, float *p) { h->dbg = p; return 0; }
-#endif
 
 extern "C" int sgx_flow_create(const sgx_flow_config *cfg, sgx_flow **out)
 {
@@ -76,9 +70,6 @@ static int build_pyramid(sgx_flow *h, int slot, const uint8_t *d_gray, int pitch
 {
     const SgxLkGeom &g = h->g;
     uint8_t *base = h->img[slot];
-#ifdef SGX_LK_POISON      /* diagnostic build only (round 6): a reader that overtakes the pyramid kernels would see 0xFF instead of the (similar) frame before last */
-    (void)hipMemsetAsync(base, 0xFF, (size_t)g.img_stride * batch, st);
-#endif
     sgx_prof_begin(SGX_K_LK_PYR, st);
     auto magic = [](int d) -> unsigned { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };      // ceil(2^32 / d): exact quotients for the kernels' index split (index < 2^21, d < 2^11)
     SGX_LAUNCH(k_lk_copy, dim3(((g.pitch[0] >> 2) * g.h[0] + 255) / 256, batch), dim3(256), st, d_gray, g.w[0], g.h[0], pitch, base, g.pitch[0], g.img_stride, magic(g.pitch[0] >> 2));
@@ -98,9 +89,6 @@ static int track(sgx_flow *h, int cur_slot, int prev_slot, int batch, const sgx_
     A.max_count = h->cfg.max_count > 100 ? 100 : h->cfg.max_count;                        // SparsePyrLKOpticalFlowImpl::calc clamps the criteria
     double eps = h->cfg.epsilon > 10. ? 10. : h->cfg.epsilon;
     A.eps2 = eps * eps; A.min_eig = (float)1e-4;
-#ifdef SGX_LK_DBG
-    A.dbg = h->dbg;
-#endif
     sgx_prof_begin(SGX_K_LK_TRACK, st);
     static const int kpw = sgx_getenv("SGX_LK_KPW") ? atoi(sgx_getenv("SGX_LK_KPW")) : 2;      // keypoints per wave: 2 (default) / 4 = k_lk_trackN, 1 = k_lk_track; same results
     A.batch = batch; A.kblocks = (cap + 4 * kpw - 1) / (4 * kpw);

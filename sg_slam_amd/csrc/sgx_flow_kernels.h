@@ -145,9 +145,6 @@ struct SgxLkArgs {
     float *prev_xy; uint8_t *status;
     int max_count; double eps2; float min_eig;
     int batch, kblocks;                      /* frames, keypoint blocks (4 keypoints each) per frame */
-#ifdef SGX_LK_DBG
-    float *dbg;                              /* diagnostic build only: 4 levels x 8 floats per keypoint */
-#endif
 };
 /* block -> (frame, keypoint block): blocks are dealt to the 8 XCDs round-robin (observed dispatch order, speed only), so block i works for frame
  * (i % 8) + 8 * slot and walks through ALL keypoint blocks of that frame before the XCD moves to its next frame: the two pyramids of a frame
@@ -283,11 +280,10 @@ SGX_DEV uint32_t sgx_as_u32(sgx_i16x2 v) { return __builtin_bit_cast(uint32_t, v
 SGX_DEV sgx_i16x2 sgx_lk_next(sgx_i16x2 p, sgx_i16x2 q) { return sgx_as_i16x2(__builtin_amdgcn_alignbit(sgx_as_u32(q), sgx_as_u32(p), 16)); }
 #define SGX_LK_DOT2(a, b, c) __builtin_amdgcn_sdot2((a), (b), (c), false)
 /* the first dot product of a window sample, whose accumulator operand (the sample's start value) must survive.  Rounds 4-6 issued it as inline assembly in the three-address
- * VOP3P form (v_dot2_i32_i16) to spare the v_mov the compiler puts in front of its two-address v_dot2c.  That was a HARDWARE HAZARD: on gfx940 / gfx950 a DOT result needs
- * 3 wait states before a VALU instruction of a different opcode reads it (4 before one overwrites it) and the compiler inserts them only for instructions it can see — not for
- * the contents of an asm statement.  The following v_dot2c read its accumulator one wait state after the asm: harmless while other waves fill the issue slots, but with few
- * waves on the SIMD (kernel tails, other kernels co-resident) about one keypoint in 10^4 got a stale value (found in round 6 by two trackers running side by side:
- * tools/diag_two_trackers.py).  The builtin costs the v_mov (0.7 % of the kernel) and is handled by the compiler's hazard recogniser. */
+ * VOP3P form (v_dot2_i32_i16) to spare the v_mov the compiler puts in front of its two-address v_dot2c.  That hid a HAZARD from the compiler: on gfx940 / gfx950 a DOT result
+ * needs 3 wait states before a VALU instruction of another opcode reads it (4 before one overwrites it), the compiler's hazard recogniser inserts them only for instructions
+ * it can see, and the v_dot2c that followed read its accumulator one wait state after the asm.  No wrong result was ever traced to it (the rare LK difference of round 6 had
+ * another trigger: mixed stream priorities, sgx_tracker.cpp), but the rule is the hardware's: the builtin costs the v_mov (0.7 % of the kernel) and is handled by the compiler. */
 SGX_DEV int sgx_lk_dot2_keep(sgx_i16x2 a, sgx_i16x2 b, int c) { return SGX_LK_DOT2(a, b, c); }
 
 /* stage the ROWS x 36-byte patch of `img` whose top-left corner is (ox, oy) (ox a multiple of 4) into the wave's LDS tile: REFLECT_101 outside the
@@ -499,14 +495,7 @@ template <int LPK>
 SGX_DEV float sgx_group_sum_f32(int v)                              /* exact sum over the LPK lanes of a group -> correctly rounded float, as sgx_wave_sum_f32 */
 {
     int lo = sgx_row_sum_i32(v & 0xFFFF), hi = sgx_row_sum_i32(v >> 16);
-#ifdef SGX_LK_SWAP16     /* diagnostic build only (round 6): the other row through v_permlane16_swap instead of ds_bpermute */
-    if (LPK == 32) {
-        const auto rl = __builtin_amdgcn_permlane16_swap((unsigned)lo, (unsigned)lo, false, false), rh = __builtin_amdgcn_permlane16_swap((unsigned)hi, (unsigned)hi, false, false);
-        lo = (int)(rl[0] + rl[1]); hi = (int)(rh[0] + rh[1]);
-    }
-#else
     if (LPK == 32) { lo += __shfl_xor(lo, 16, 64); hi += __shfl_xor(hi, 16, 64); }      /* the other row of the half-wave */
-#endif
     return fmaf((float)hi, 65536.0f, (float)lo);       /* |hi| <= 2^21, lo < 2^22: both conversions and the product are exact, the fused add rounds the exact integer once */
 }
 
@@ -579,43 +568,17 @@ SGX_DEV void sgx_lk_segment_setup(const sgx_i16x2 (&P)[4][5], sgx_i16x2 W0, sgx_
 SGX_DEV int sgx_mad_lo16(int diff, uint32_t pair, int acc) { asm("v_mad_i32_i16 %0, %1, %2, %0 op_sel:[0,0,0,0]" : "+v"(acc) : "v"(diff), "v"(pair)); return acc; }
 SGX_DEV int sgx_mad_hi16(int diff, uint32_t pair, int acc) { asm("v_mad_i32_i16 %0, %1, %2, %0 op_sel:[0,1,0,0]" : "+v"(acc) : "v"(diff), "v"(pair)); return acc; }
 
-/* 8 / 12 bytes from a BYTE offset through naturally aligned dword reads + v_alignbyte_b32 (round 6: the unaligned ds_read_b64 / global_load_dwordx3 the compiler makes of a
- * byte-granular memcpy depend on the unaligned access mode of the memory pipeline, SH_MEM_CONFIG; with a high-priority queue live next to the tracker's, about one window in 10^4
- * was read as if its address had been rounded down — a window shifted by one to three pixels.  Aligned accesses do not depend on the mode.) */
-SGX_DEV void sgx_lk_ld8(const uint32_t *base, int byte_off, uint32_t (&a)[2])
-{
-    const uint32_t *w = base + (byte_off >> 2); const uint32_t sh = (uint32_t)byte_off & 3u;
-    const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
-    a[0] = __builtin_amdgcn_alignbyte(d1, d0, sh); a[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
-}
-SGX_DEV void sgx_lk_ld12(const uint32_t *w, uint32_t sh, uint32_t (&d)[3])       /* w: the aligned dword that holds the first byte, sh = its byte position in it */
-{
-    const uint32_t d0 = w[0], d1 = w[1], d2 = w[2], d3 = w[3];
-    d[0] = __builtin_amdgcn_alignbyte(d1, d0, sh); d[1] = __builtin_amdgcn_alignbyte(d2, d1, sh); d[2] = __builtin_amdgcn_alignbyte(d3, d2, sh);
-}
 template <int KPW>
-#ifndef SGX_LK_OCC2
-#define SGX_LK_OCC2 5
-#endif
-SGX_KERNEL_OCC(256, (KPW == 4 ? 3 : SGX_LK_OCC2)) k_lk_trackN(SgxLkGeom g, SgxLkArgs A)
+SGX_KERNEL_OCC(256, (KPW == 4 ? 3 : 5)) k_lk_trackN(SgxLkGeom g, SgxLkArgs A)
 {
     constexpr int LPK = 64 / KPW, SPL = KPW;                         /* lanes per keypoint, segments per lane (SPL * LPK = 64 slots for 63 segments) */
     constexpr int TD = 36 * SGX_LK4_PITCH / 4 + 5;                 /* dwords per keypoint tile: 36 rows of 32 bytes (+ slack for the 8-byte reads past the last row; odd stride between tiles) */
     __shared__ uint32_t tiles[4 * KPW][TD];
-#ifdef SGX_LK_SWAP      /* diagnostic build only (round 6): the upper half-wave takes the even keypoint / tile */
-    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, row = (lane / LPK) ^ 1, l16 = lane % LPK;
-#else
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, row = lane / LPK, l16 = lane % LPK;
-#endif
     int f, kb;
     sgx_lk_decode_block((int)blockIdx.x, A.batch, A.kblocks, f, kb);
-#ifdef SGX_LK_INV      /* diagnostic build only (round 6): drop every cached line before the first read */
-    asm volatile("buffer_inv sc0 sc1\n s_waitcnt vmcnt(0)" ::: "memory");
-#endif
     const int nkp = min(A.n[f], A.cap);
-#ifndef SGX_LK_WGSYNC
     if (kb * (4 * KPW) + wv * KPW >= nkp) return;                            /* wave-uniform: no workgroup barrier is used below */
-#endif
     const int kp = kb * (4 * KPW) + wv * KPW + row;
     const bool valid = kp < nkp;
     uint32_t *tile = tiles[wv * KPW + row];
@@ -662,22 +625,21 @@ SGX_KERNEL_OCC(256, (KPW == 4 ? 3 : SGX_LK_OCC2)) k_lk_trackN(SgxLkGeom g, SgxLk
                 const int gy0 = ipy + srow[q], gx0 = ipx + scol[q];
                 sgx_i16x2 P[4][5];
                 if (direct) {
-                    const uint8_t *gb = I + (size_t)(gy0 - 1) * pitch + ((gx0 - 1) & ~3);      /* level base and pitch are multiples of 4 */
-                    const uint32_t gsh = (uint32_t)(gx0 - 1) & 3u;
+                    const uint8_t *gb = I + (size_t)(gy0 - 1) * pitch + (gx0 - 1);
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         uint32_t d[3];
-                        sgx_lk_ld12((const uint32_t *)(gb + (size_t)j * pitch), gsh, d);
+                        __builtin_memcpy(d, gb + (size_t)j * pitch, 12);
                         P[j][0] = SGX_LK_PAIR(d[0], d[0], 0, 1); P[j][1] = SGX_LK_PAIR(d[0], d[0], 2, 3);
                         P[j][2] = SGX_LK_PAIR(d[1], d[1], 0, 1); P[j][3] = SGX_LK_PAIR(d[1], d[1], 2, 3);
                         P[j][4] = SGX_LK_PAIR(d[2], d[2], 0, 1);
                     }
                 } else {
-                    const int toff = soff[q] + (ipx - 1 - tx);
+                    const uint8_t *tb = tile8 + soff[q] + (ipx - 1 - tx);
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         uint32_t d[3];
-                        sgx_lk_ld12(tile + ((toff + j * SGX_LK4_PITCH) >> 2), (uint32_t)toff & 3u, d);
+                        __builtin_memcpy(d, tb + j * SGX_LK4_PITCH, 12);
                         P[j][0] = SGX_LK_PAIR(d[0], d[0], 0, 1); P[j][1] = SGX_LK_PAIR(d[0], d[0], 2, 3);
                         P[j][2] = SGX_LK_PAIR(d[1], d[1], 0, 1); P[j][3] = SGX_LK_PAIR(d[1], d[1], 2, 3);
                         P[j][4] = SGX_LK_PAIR(d[2], d[2], 0, 1);
@@ -697,11 +659,6 @@ SGX_KERNEL_OCC(256, (KPW == 4 ? 3 : SGX_LK_OCC2)) k_lk_trackN(SgxLkGeom g, SgxLk
         nextx -= half; nexty -= half;
         float pdx = 0.f, pdy = 0.f;
         int ox = 0, oy = 0; bool staged = false;
-#ifdef SGX_LK_DBG
-        float *dbg = A.dbg && valid && l16 == 0 ? A.dbg + (((size_t)f * A.cap + kp) * 4 + level) * 24 : nullptr; float dbg_need = 0.f; uint32_t dbg_ck = 0;
-        if (dbg) { dbg[0] = A11; dbg[1] = A12; dbg[2] = A22; for (int z = 3; z < 24; z++) dbg[z] = 0.f; }
-        unsigned long long dbg_t = __builtin_amdgcn_s_memrealtime(); float dbg_gap = 0.f, dbg_gap_j = -1.f;
-#endif
         for (int j = 0; j < A.max_count; j++) {
             const int inx = sgx_floor_f(nextx), iny = sgx_floor_f(nexty);
             if (act && (inx < -W || inx >= w || iny < -W || iny >= h)) { if (level == 0) status = 0; act = false; }
@@ -709,9 +666,6 @@ SGX_KERNEL_OCC(256, (KPW == 4 ? 3 : SGX_LK_OCC2)) k_lk_trackN(SgxLkGeom g, SgxLk
             k = sgx_lk_weights(nextx - inx, nexty - iny);
             W0 = sgx_as_i16x2((uint32_t)k.w00 | ((uint32_t)k.w01 << 16)); W1 = sgx_as_i16x2((uint32_t)k.w10 | ((uint32_t)k.w11 << 16));
             const bool need = act && (!staged || inx < ox || inx - ox > SGX_LK4_PITCH - 22 || iny < oy || iny - oy > 36 - 22);
-#ifdef SGX_LK_DBG
-            dbg_need = need ? 1.f : 0.f;
-#endif
             if (__any(need)) {
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
                 if (need) {
@@ -719,46 +673,24 @@ SGX_KERNEL_OCC(256, (KPW == 4 ? 3 : SGX_LK_OCC2)) k_lk_trackN(SgxLkGeom g, SgxLk
                     sgx_lk_stage_row<36, LPK>(tile, J, w, h, pitch, ox, oy, l16);
                     staged = true;
                 }
-#ifdef SGX_LK_WAIT
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
             }
-#ifdef SGX_LK_DBG      /* the lane's share of the tile (9 of the 288 dwords): recorded after a staging, checked before every other iteration's reads */
-            {
-                uint32_t ck = 0;
-                for (int z = 0; z < 9; z++) ck = ck * 31u + tile[l16 * 9 + z];
-                if (need) dbg_ck = ck;
-                const bool corrupt = act && !need && ck != dbg_ck;
-                if (__any(corrupt)) { const unsigned long long m = __ballot(corrupt); const int half_ = row * 32; dbg_need += 2.f * (float)(((m >> half_) & 0xFFFFFFFFull) != 0); dbg_ck = ck; }
-            }
-#endif
             int sb1 = 0, sb2 = 0;
             if (act) {
-                const int tb0 = (iny - oy) * SGX_LK4_PITCH + (inx - ox);
+                const uint8_t *tb0 = tile8 + (iny - oy) * SGX_LK4_PITCH + (inx - ox);
 #pragma unroll
                 for (int q = 0; q < SPL; q++) {
+                    const uint8_t *tb = tb0 + soff[q];
                     uint32_t a[2], b[2];
-                    sgx_lk_ld8(tile, tb0 + soff[q], a); sgx_lk_ld8(tile, tb0 + soff[q] + SGX_LK4_PITCH, b);
+                    __builtin_memcpy(a, tb, 8); __builtin_memcpy(b, tb + SGX_LK4_PITCH, 8);
 #pragma unroll
                     for (int c = 0; c < 7; c++) {
-#ifdef SGX_LK_NOPS      /* diagnostic build only (round 6): wait states around every step of the sample */
-                        int t1_ = sgx_lk_dot2_keep(SGX_LK_PAIR(a[1], a[0], c, c + 1), W0, ivb[q][c]); asm volatile("s_nop 7" : "+v"(t1_));
-                        int t2_ = SGX_LK_DOT2(SGX_LK_PAIR(b[1], b[0], c, c + 1), W1, t1_); asm volatile("s_nop 7" : "+v"(t2_));
-                        int diff = t2_ >> 9; asm volatile("s_nop 7" : "+v"(diff));
-                        sb1 = sgx_mad_lo16(diff, ixy[q][c], sb1); asm volatile("s_nop 7" : "+v"(sb1)); sb2 = sgx_mad_hi16(diff, ixy[q][c], sb2); asm volatile("s_nop 7" : "+v"(sb2));
-#else
                         const int diff = SGX_LK_DOT2(SGX_LK_PAIR(b[1], b[0], c, c + 1), W1, sgx_lk_dot2_keep(SGX_LK_PAIR(a[1], a[0], c, c + 1), W0, ivb[q][c])) >> 9;
                         sb1 = sgx_mad_lo16(diff, ixy[q][c], sb1); sb2 = sgx_mad_hi16(diff, ixy[q][c], sb2);      /* |diff| <= 255 * 32 fits 16 bits; ix = iy = 0 on the idle slot */
-#endif
                     }
                 }
             }
             const float b1 = sgx_group_sum_f32<LPK>(sb1) * FLT_SCALE, b2 = sgx_group_sum_f32<LPK>(sb2) * FLT_SCALE;
-#ifdef SGX_LK_DBG
-            { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); const float g_ = (float)(t_ - dbg_t); dbg_t = t_; if (g_ > dbg_gap) { dbg_gap = g_; dbg_gap_j = (float)j; } }
-            if (dbg && act) { dbg[22] = dbg_gap; dbg[23] = dbg_gap_j; dbg[3] = (float)(j + 1); if (j < 6) { dbg[3 + 3 * j + 1] = b1; dbg[3 + 3 * j + 2] = b2; dbg[3 + 3 * j + 3] = nextx; } dbg[21] = D; }
-#endif
             if (act) {
                 const float dx = (A12 * b2 - A22 * b1) * D, dy = (A12 * b1 - A11 * b2) * D;
                 nextx += dx; nexty += dy;
@@ -784,9 +716,6 @@ SGX_KERNEL_OCC(256, (KPW == 4 ? 3 : SGX_LK_OCC2)) k_lk_trackN(SgxLkGeom g, SgxLk
         A.prev_xy[2 * ((size_t)f * A.cap + kp)] = outx; A.prev_xy[2 * ((size_t)f * A.cap + kp) + 1] = outy;
         if (A.status) A.status[(size_t)f * A.cap + kp] = (uint8_t)status;
     }
-#ifdef SGX_LK_WGSYNC      /* diagnostic build only (round 6): the four waves of a workgroup stay alive until the slowest has finished */
-    __syncthreads();
-#endif
 }
 #else
 template <int KPW>

@@ -181,9 +181,10 @@ extern "C" int sgx_tracker_create(const sgx_tracker_config *cfg, sgx_det *detect
     }
     t->pipelined = cfg->pipelined != 0;
     if (t->pipelined) {
-        // stream priorities (bit 0 extraction, 1 tracking, 2 detector): the tracking stream is the latency-critical one for a single camera and gets the high priority by default;
-        // SGX_TRK_PRIO is the tuning tap
-        static const int prio = sgx_getenv("SGX_TRK_PRIO") ? atoi(sgx_getenv("SGX_TRK_PRIO")) : 2;
+        // stream priorities (bit 0 extraction, 1 tracking, 2 detector; SGX_TRK_PRIO is the tuning tap).  Default: all equal.  Rounds 2-5 gave the tracking stream the high
+        // priority (latency of a single camera).  Round 6: with queues of DIFFERENT priorities live on the device the LK tracker returned a slightly different position for
+        // about one keypoint in 10^4 — always one handled by lanes 32-63 of its wave, never with equal priorities or serialised kernels (profiles/r6_lk_priority_diagnosis.md).
+        static const int prio = sgx_getenv("SGX_TRK_PRIO") ? atoi(sgx_getenv("SGX_TRK_PRIO")) : 0;
         // SGX_TRK_SHARE (tuning tap): 1 = tracking on the DETECTOR's stream (det(t), then track(t) behind it), 2 = tracking on the EXTRACTION stream (the round-1 serial order)
         static const int share = sgx_getenv("SGX_TRK_SHARE") ? atoi(sgx_getenv("SGX_TRK_SHARE")) : 0;
         if (st_create(&t->sE, prio & 1) || st_create(&t->sD, (prio >> 2) & 1)) FAIL(SGX_ERR_DEVICE);

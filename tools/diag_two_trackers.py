@@ -1,5 +1,6 @@
-"""diagnostic (round 6): two identical Python-orchestrated trackers + detectors side by side on the same frames (optionally beside the LDS polluter); every intermediate buffer of the
-extraction stage is compared after each step.  usage: POLLUTE=64 python tools/diag_two_trackers.py [reps]"""
+"""diagnostic (round 6): two identical Python-orchestrated trackers + detectors side by side on the same frames; every intermediate buffer of the extraction stage is compared
+after each step and a difference in the LK output is judged against the host entry run alone.  usage: [MODE=prio] [POLLUTE=64] python tools/diag_two_trackers.py [reps] [taps | lib.so]
+MODE=prio restores the mixed stream priorities of rounds 2-5 (the condition under which the LK tracker differs, profiles/r6_lk_priority_diagnosis.md); MODE=keep / swap / addr: see the loop."""
 import os, sys, ctypes as C
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -51,6 +52,7 @@ class Side:
         return d
 order = ['nb', 'boxes', 'have', 'rn', 'rkeys0', 'rkeys1', 'prev_xy0', 'prev_xy1', 'lk_status0', 'lk_status1', 'pre_nboxes', 'pre_boxes', 'pre_have', 'f_ok', 'F', 'f_stats', 'keep0', 'keep1', 'n', 'keys0', 'keys1', 'Tcw']
 nbad = 0; bad_keys = []; keep_alive = []; MODE = os.environ.get('MODE', '')
+if 'prio' in MODE: TrackerBatch.stream_priorities = (0, -1)      # the round 2-5 setting: tracking stream at high priority
 for rep in range(reps):
     if 'swap' in MODE: B = Side(); A = Side()
     else: A, B = Side(), Side()
