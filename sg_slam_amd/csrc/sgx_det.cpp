@@ -247,6 +247,7 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                     }
                 }
             }
+#ifdef SGX_DEBUG_TAPS      // k_conv_dw3 (round-6 experiment, slower than k_conv_dw2) exists in the tap build only
             if (group == inc && group != 1 && (outc & 1) == 0 && inc == outc) {      // depthwise: pair-interleaved copy for k_conv_dw3
                 const float *wsrc = (const float *)(bp + bo); const int kk = k * k;
                 std::vector<float> w2((size_t)outc * kk);
@@ -254,6 +255,7 @@ extern "C" int sgx_det_create(const char *param_text, const void *bin, size_t bi
                 if (h->alloc(&op.wtP, w2.size())) FAIL(SGX_ERR_NOMEM);
                 if (hipMemcpy(op.wtP, w2.data(), w2.size() * 4, hipMemcpyHostToDevice) != hipSuccess) FAIL(SGX_ERR_DEVICE);
             }
+#endif
             bo += (size_t)wsize * 4;
             std::vector<float> bz(outc, 0.f);
             if (L.geti(5, 0)) { memcpy(bz.data(), bp + bo, (size_t)outc * 4); bo += (size_t)outc * 4; }
@@ -989,6 +991,7 @@ static void run_op(sgx_det *h, const Op &op, int batch, sgx_stream_t st)
         auto magic = [](int d) -> unsigned { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
         const int nbx4 = (op.Wo + 3) / 4, pitch4 = ((nbx4 - 1) * 4 * op.stride + 3 * op.stride + op.k + 3) & ~3;
         static const int dw2_on = sgx_getenv("SGX_DW2") ? atoi(sgx_getenv("SGX_DW2")) : 1;
+#ifdef SGX_DEBUG_TAPS
         static const int dw3_on = sgx_getenv("SGX_DW3") ? atoi(sgx_getenv("SGX_DW3")) : 0;      // round 6 experiment: k_conv_dw3 (channel pairs, packed FMAs) measured SLOWER than k_conv_dw2 (0.26 vs 0.18 ms on the 38 x 38 planes): tap only
         if (dw3_on && !h->legacy && op.depthwise && op.wtP) {
             SgxDw3 d; int px = 1; size_t lds3 = 0;
@@ -998,6 +1001,7 @@ static void run_op(sgx_det *h, const Op &op, int batch, sgx_stream_t st)
                 break;
             }
         }
+#endif
         if (dw2_on && !h->legacy && op.depthwise && (op.k == 3 || op.k == 5) && (op.stride == 1 || op.stride == 2) && pitch4 * op.k <= budget) {
             // k_conv_dw2: P planes x a band of RB output rows per workgroup, LDS tile [P][(RB - 1) s + k][pitch4]
             const int nplanes = batch * op.outc, rin_full = (op.Ho - 1) * op.stride + op.k, KW = (op.k * op.k + 1 + 3) & ~3;

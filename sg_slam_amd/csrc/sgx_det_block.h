@@ -703,6 +703,7 @@ static inline int sgx_se_gate_launch(const SgxSeGate &p, int batch, sgx_stream_t
     return SGX_ERR_INVALID;
 }
 
+#ifdef SGX_DEBUG_TAPS
 // ---------------------------------------------------------------------------------------------
 // k_conv_dw3<K, S, PX>: depthwise K x K convolution (+ ReLU / Clip / h-swish epilogue) in the arithmetic of k_fused_block2 / k_hrb (round 6).
 // k_conv_dw2 spends 2.7 lane-instructions per multiply-add (round-6 census: the 100 fp32 FMAs of a four-pixel task are a quarter of its cycles; the rest is the weight vector
@@ -712,7 +713,9 @@ static inline int sgx_se_gate_launch(const SgxSeGate &p, int batch, sgx_stream_t
 //   compute  wave w takes pairs w, w + 4, ...; the K x K weight pairs of a pair sit in SCALAR registers (wave-uniform), a lane takes PX horizontally adjacent output pixels
 //            (S = 1: their tap windows overlap, (PX + K - 1) x K ds_read_b64 serve PX K K v_pk_fma_f32), taps (i, j) ascending from the bias — per output the same fmaf chain as
 //            k_conv_dw2 / k_conv_kxk, so the results are BIT-IDENTICAL to them — and the epilogue program runs on both halves of the pair
-// Used by both plans (exact fp32 and bf16x3).  grid = images x ceil(pairs / NP); LDS = NP * HP * WP * 8 bytes.
+// grid = images x ceil(pairs / NP); LDS = NP * HP * WP * 8 bytes.
+// MEASURED SLOWER than k_conv_dw2 (0.259 / 0.254 / 0.266 / 0.222 ms against 0.181 / 0.181 / 0.253 / 0.181 on the four big depthwise steps, 512 frames): 15 KB of LDS per channel
+// pair leave three pairs per workgroup (one wave idle, three workgroups per CU) and the stage / compute phases do not overlap.  Tap build only (SGX_DW3=1).
 // ---------------------------------------------------------------------------------------------
 struct SgxDw3 { int C, H, W, Ho, Wo, pad, NP, HP, WP, nchunks, WU, NU; unsigned m_wu, m_wp, m_cells; const float *in; size_t in_pitch; const float *wd2, *bias; float *out; size_t out_pitch; SgxEpi epi; };
 template <int K, int S, int PX, int MODE>
@@ -820,6 +823,8 @@ static inline void sgx_dw3_launch(const SgxDw3 &p, int k, int stride, int px, si
     else SGX_DW3(5, 2, 1);
 #undef SGX_DW3
 }
+
+#endif
 
 // ---- k_fused_block2 dispatch: (Cin, Cout, K, stride) -> instantiation; the tile variant comes from SGX_FB2_TILE (tuning tap) --------------------------------------
 static inline int sgx_fb2_cm(int v2) { return (v2 >> 4) == 1 ? 16 : 8; }       /* expanded channels per chunk of the instantiation (Cmid must be a multiple) */
