@@ -31,5 +31,8 @@ def tool_lib():
     """the library a measurement tool drives: the product library, or — SGX_BENCH_TAPS_LIB=1, A/B runs of the SGX_* switches — the tap build"""
     if os.environ.get('SGX_BENCH_TAPS_LIB') == '1':
         return taps_lib()
+    if os.environ.get('SGX_BENCH_AB_LIB'):      # an A/B build of tools/ab_build.sh
+        from sg_slam_amd.capi import SgxLib
+        return SgxLib(os.path.join(ROOT, os.environ['SGX_BENCH_AB_LIB']))
     import sg_slam_amd
     return sg_slam_amd.load()
