@@ -523,6 +523,7 @@ static __device__ __attribute__((noinline)) bool sgx_chol_diag_wave_body(int lan
         a[j] = (row == j) ? (j < nb ? sdj : 0.0) : sgx_div_by_recip(a[j], sdj, rj);
     }
     // ---- explicit inverse: lane t computes column t of L^-1 by forward substitution (same order as k_chol_diag)
+    // (round 6: an LDS copy of the finished factor read back as broadcasts instead of the readlane pairs measured SLOWER: 16 -> 19 us per tile)
     double xc[SGX_NB];
 #pragma unroll
     for (int r = 0; r < SGX_NB; r++) {
@@ -753,7 +754,8 @@ SGX_KERNEL(256) k_chol_update_wide(int n, int p0, int pw, double *S, const int *
 // k_chol_env_factor runs the WHOLE factorisation (and the forward substitution) as ONE persistent workgroup: per step, wave 0 factors and inverts the diagonal tile
 // in registers (sgx_chol_diag_wave_body), then the 256-thread groups of the workgroup take the panel tiles L_rk = A_rk Linv_kk^T (+ x_r -= L_rk y_k) and the
 // update pairs A_rc -= L_rk L_ck^T, r >= c in R(k), with workgroup barriers in between; k_chol_env_back is the backward pass in the same shape.
-// Same tile arithmetic as k_chol_diag / k_chol_panel / k_chol_update (the update of a tile sums over k in ascending order, as the rank-32 path does).
+// The diagonal tile has the arithmetic of k_chol_diag (bit-identical); the tile products of the panel and the updates run on the fp64 matrix cores since round 6 (sgx_wave_gemm_nt_mfma:
+// the matrix core's own summation order, last-bit differences against the emulator's k-ascending sums — as the dense path's k_chol_update_wide).
 // The dense two-level path remains for systems whose envelope is not narrow.
 // ---------------------------------------------------------------------------------------------
 #define SGX_ENV_THREADS 512                       /* 8 waves: two per SIMD, so the diagonal-tile wave keeps its 32 x 32 tile + inverse in registers (no scratch) */
@@ -776,6 +778,29 @@ SGX_DEV void sgx_wave_gemm_nt(const double (*PT)[SGX_NB + 4], const double (*QT)
             for (int j = 0; j < 4; j++) acc[4 * i + j] += a[i] * b[j];
     }
 }
+
+#ifndef SGX_EMU
+// the same product on the fp64 matrix cores (round 6): 2 x 2 tiles of v_mfma_f64_16x16x4f64, eight k-steps each — 32 MFMAs instead of 512 double FMAs per lane.  Operands straight
+// from the transposed LDS tiles ([k][row]: lane (k = lane >> 4, row = lane & 15) of a k-step).  acc[a][b][i] = entry (16 a + 4 i + (lane >> 4), 16 b + (lane & 15)).
+// The matrix core sums k in its own order: last-bit differences against sgx_wave_gemm_nt (as the dense path's k_chol_update_wide against its emulator form).
+typedef double sgx_env_f64x4 __attribute__((ext_vector_type(4)));
+SGX_DEV void sgx_wave_gemm_nt_mfma(const double (*PT)[SGX_NB + 4], const double (*QT)[SGX_NB + 4], int lane, sgx_env_f64x4 (&acc)[2][2])
+{
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = sgx_env_f64x4{0.0, 0.0, 0.0, 0.0};
+    const int kq = lane >> 4, rr = lane & 15;
+#pragma unroll
+    for (int k4 = 0; k4 < SGX_NB; k4 += 4) {
+        const double a0 = PT[k4 + kq][rr], a1 = PT[k4 + kq][16 + rr], b0 = QT[k4 + kq][rr], b1 = QT[k4 + kq][16 + rr];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+}
+#endif
 
 #ifdef SGX_EMU
 // the workgroup / LDS form of the diagonal-tile factorisation (k_chol_diag) for tile kd: what sgx_chol_diag_wave_body does on the device, same arithmetic.  Sets *fail on a non-positive pivot.
@@ -838,6 +863,22 @@ SGX_DEV void sgx_env_update_pair(int pidx, int lane, int n, int q0, const int *r
     int bi = (int)((sqrt(8.0 * pidx + 1.0) - 1.0) * 0.5); while ((bi + 1) * (bi + 2) / 2 <= pidx) bi++; while (bi * (bi + 1) / 2 > pidx) bi--;
     const int bj = pidx - bi * (bi + 1) / 2;
     const int r0 = rows[q0 + bi] * SGX_NB, c0 = rows[q0 + bj] * SGX_NB, nr = min(SGX_NB, n - r0), nc = min(SGX_NB, n - c0);
+#ifndef SGX_EMU
+    sgx_env_f64x4 u4[2][2];
+    sgx_wave_gemm_nt_mfma(pool[bi], pool[bj], lane, u4);
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int r = 16 * a + 4 * i + (lane >> 4), c = 16 * b + (lane & 15);
+                if (r < nr && c < nc && !(bi == bj && c > r)) {
+                    if (c0 >= sep0) S2[(size_t)(r0 - sep0 + r) * (n - sep0) + (c0 - sep0 + c)] -= u4[a][b][i];
+                    else S[(size_t)(r0 + r) * n + c0 + c] -= u4[a][b][i];
+                }
+            }
+#else
     const int ty = lane >> 3, tx = lane & 7;
     double u[16];
     sgx_wave_gemm_nt(pool[bi], pool[bj], ty, tx, u);
@@ -851,7 +892,66 @@ SGX_DEV void sgx_env_update_pair(int pidx, int lane, int n, int q0, const int *r
                 else S[(size_t)(r0 + r) * n + c0 + c] -= u[4 * i + j];
             }
         }
+#endif
 }
+
+#ifndef SGX_EMU
+// The update pairs of one wave, software-pipelined (round 6): a pair is a read-modify-write of one 32 x 32 tile of S in global memory around a 0.5 us matrix-core product — done one
+// after the other, the load latency of every tile (1-3 us, the band is larger than L2) was the step time of waves 1-7.  The target tile of the NEXT pair is fetched into
+// registers before the current product starts.  Same arithmetic and the same tile -> wave assignment as a loop over sgx_env_update_pair.
+struct SgxEnvUpd { int bi, bj, nr, nc; double *base; size_t ld; };
+SGX_DEV void sgx_env_upd_target(int pidx, int n, int q0, const int *rows, double *S, int sep0, double *S2, SgxEnvUpd &u)
+{
+    int bi = (int)((sqrt(8.0 * pidx + 1.0) - 1.0) * 0.5); while ((bi + 1) * (bi + 2) / 2 <= pidx) bi++; while (bi * (bi + 1) / 2 > pidx) bi--;
+    const int bj = pidx - bi * (bi + 1) / 2;
+    const int r0 = rows[q0 + bi] * SGX_NB, c0 = rows[q0 + bj] * SGX_NB;
+    u.bi = bi; u.bj = bj; u.nr = min(SGX_NB, n - r0); u.nc = min(SGX_NB, n - c0);
+    if (c0 >= sep0) { u.ld = (size_t)(n - sep0); u.base = S2 + (size_t)(r0 - sep0) * u.ld + (c0 - sep0); }
+    else { u.ld = (size_t)n; u.base = S + (size_t)r0 * n + c0; }
+}
+SGX_DEV bool sgx_env_upd_mine(const SgxEnvUpd &u, int a, int b, int i, int lane, int &r, int &c)
+{
+    r = 16 * a + 4 * i + (lane >> 4); c = 16 * b + (lane & 15);
+    return r < u.nr && c < u.nc && !(u.bi == u.bj && c > r);
+}
+SGX_DEV void sgx_env_upd_load(const SgxEnvUpd &u, int lane, sgx_env_f64x4 (&v)[2][2])
+{
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) { int r, c; v[a][b][i] = sgx_env_upd_mine(u, a, b, i, lane, r, c) ? u.base[(size_t)r * u.ld + c] : 0.0; }
+}
+SGX_DEV void sgx_env_upd_store(const SgxEnvUpd &u, int lane, const sgx_env_f64x4 (&v)[2][2], const sgx_env_f64x4 (&p)[2][2])
+{
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) { int r, c; if (sgx_env_upd_mine(u, a, b, i, lane, r, c)) u.base[(size_t)r * u.ld + c] = v[a][b][i] - p[a][b][i]; }
+}
+SGX_DEV void sgx_env_update_pairs(int first, int stride, int npairs, int lane, int n, int q0, const int *rows, const double (*pool)[SGX_NB][SGX_NB + 4], double *S, int sep0, double *S2)
+{
+    if (first >= npairs) return;
+    SgxEnvUpd uc, un; sgx_env_f64x4 cur[2][2], nxt[2][2], prod[2][2];
+    sgx_env_upd_target(first, n, q0, rows, S, sep0, S2, uc); sgx_env_upd_load(uc, lane, cur);
+    for (int p = first; p < npairs; p += stride) {
+        const bool more = p + stride < npairs;
+        if (more) { sgx_env_upd_target(p + stride, n, q0, rows, S, sep0, S2, un); sgx_env_upd_load(un, lane, nxt); }
+        sgx_wave_gemm_nt_mfma(pool[uc.bi], pool[uc.bj], lane, prod);
+        sgx_env_upd_store(uc, lane, cur, prod);
+        if (more) {
+            uc = un;
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++) cur[a][b] = nxt[a][b];
+        }
+    }
+}
+#endif
 
 // Schedule.  The diagonal tile is the sequential spine (about 10 us on one wave); the updates of a step are up to 36 tile products.  Both run at the same time:
 // after the panel of step k, wave 0 takes the FIRST update pair — rows ascend inside a step, so that is tile (k + 1, k + 1) whenever row k + 1 belongs to R(k) — and then
@@ -926,18 +1026,19 @@ SGX_KERNEL(SGX_ENV_THREADS) k_chol_env_factor(int n, int nt, const int *rstart, 
                 }
                 __syncthreads();
                 if (g < m) {
-                    double a16[16];
-                    sgx_wave_gemm_nt(pool[g], LiT, lane >> 3, lane & 7, a16);                                          // out[r][c] = sum_q A[r][q] Linv[c][q]
+                    sgx_env_f64x4 a4[2][2];
+                    sgx_wave_gemm_nt_mfma(pool[g], LiT, lane, a4);                                                      // out[r][c] = sum_q A[r][q] Linv[c][q]
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();            // every lane has read A_rk before L_rk replaces it
-                    const int ty = lane >> 3, tx = lane & 7;
 #pragma unroll
-                    for (int i = 0; i < 4; i++)
+                    for (int a = 0; a < 2; a++)
 #pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const int r = 4 * ty + i, c = 4 * tx + j;
-                            pool[g][c][r] = a16[4 * i + j];
-                            if (r < nr && c < nb) S[(size_t)(r0 + r) * n + k0 + c] = a16[4 * i + j];
-                        }
+                        for (int b = 0; b < 2; b++)
+#pragma unroll
+                            for (int i = 0; i < 4; i++) {
+                                const int r = 16 * a + 4 * i + (lane >> 4), c = 16 * b + (lane & 15);
+                                pool[g][c][r] = a4[a][b][i];
+                                if (r < nr && c < nb) S[(size_t)(r0 + r) * n + k0 + c] = a4[a][b][i];
+                            }
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
                     double *xr = r0 >= sep0 ? xs : x;                                                                   // second branch: separator rows accumulate in x2
                     if (lane < nr) { double vv = xr[r0 + lane]; for (int q = 0; q < nb; q++) vv -= pool[g][q][lane] * yk[q]; xr[r0 + lane] = vv; }      // forward substitution
@@ -999,7 +1100,7 @@ SGX_KERNEL(SGX_ENV_THREADS) k_chol_env_factor(int n, int nt, const int *rstart, 
                 if (npairs > 0) { sgx_env_update_pair(0, lane, n, q0, rows, pool, S, sep0, S2); __threadfence_block(); }         // tile (k + 1, k + 1) when row k + 1 is in R(k): stored before it is read back
                 if (k + 1 < kend && !(dbg & 1)) { if (!sgx_chol_diag_wave_body(lane, n, (k + 1) * SGX_NB, S, Linv, nullptr, coef, x) && lane == 0) s_fail = 1; }
             } else {
-                for (int pidx = g; pidx < npairs; pidx += SGX_ENV_GROUPS - 1) sgx_env_update_pair(pidx, lane, n, q0, rows, pool, S, sep0, S2);
+                sgx_env_update_pairs(g, SGX_ENV_GROUPS - 1, npairs, lane, n, q0, rows, pool, S, sep0, S2);
             }
         }
 #else
