@@ -29,6 +29,7 @@ int sgx_ba_debug_set_solver(int mode);             /* test / tuning tap: reduced
 int sgx_det_debug_read_blob(sgx_det *h, const char *blob_name, int image, float *dst, int cap, int *n);
 int sgx_flow_debug_read_level(sgx_flow *h, int slot, int frame, int level, uint8_t *img);     /* test tap: pyramid level, w*h tight */
 int sgx_flow_debug_level_size(const sgx_flow *h, int level, int32_t *w, int32_t *hgt);
+int sgx_debug_corun_bf16(int blocks, int iters, int launches, void *stream);      /* test tap: `launches` launches of a kernel that only issues bf16 matrix products, asynchronous on `stream` (co-runner of the packed-fp32 regression test) */
 /* test tap: DetectionOutput + detect() filtering alone on caller-supplied head outputs (host arrays: loc batch x num_priors x 4, conf batch x num_priors x num_class) */
 int sgx_det_debug_detection_output(sgx_det *h, const float *loc, const float *conf, int batch, sgx_det_result *results);
 /* test / tuning taps.  Every sgx_*_debug_set_* setting is PER CALLING THREAD (thread_local): it affects the next create / call made by the same thread only, so the taps
@@ -41,6 +42,7 @@ int sgx_det_debug_set_block_fusion(int on);        /* 1: the NEXT sgx_det_create
 int sgx_det_debug_set_gemm(int mode);
 int sgx_det_debug_set_legacy_kernels(int on);      /* 1: run the simple reference kernels (one thread per output / 64x64 GEMM tile) instead of the tuned ones */
 int sgx_det_debug_time_ops(sgx_det *h, const uint8_t *d_img, int pitch, int batch, int reps, float *ms, int cap, int *nops);
+int sgx_det_debug_run_step(sgx_det *h, const uint8_t *d_img, int pitch, int batch, int step, int reps, void *stream);      /* plan step `step` launched reps times on `stream`, asynchronously (interference experiments) */
 /* run the octree-distribution kernel alone on packed candidates (x | y<<12 | score<<24, coordinates
  * relative to the (16,16) border origin) for `level`; returns the selected packed entries in list order */
 int sgx_orb_debug_run_octree(sgx_orb *h, int level, const uint32_t *packed, int n, uint32_t *out_sel, int cap, int *nsel);

@@ -87,8 +87,8 @@ TAP_SYMBOLS = [
     'sgx_orb_debug_level_geometry', 'sgx_orb_debug_set_unfused_pyramid', 'sgx_orb_debug_read_level', 'sgx_orb_debug_read_candidates',
     'sgx_orb_debug_run_octree', 'sgx_pose_opt_debug_set_threads', 'sgx_ba_debug_set_solver', 'sgx_ba_debug_last_plan', 'sgx_det_debug_read_blob',
     'sgx_det_debug_detection_output', 'sgx_debug_flow_affine_batch_dev', 'sgx_det_debug_set_fusion', 'sgx_det_debug_set_legacy_kernels',
-    'sgx_det_debug_set_block_fusion', 'sgx_det_debug_set_irb', 'sgx_det_debug_set_gemm', 'sgx_det_debug_time_ops', 'sgx_flow_debug_read_level',
-    'sgx_flow_debug_level_size',
+    'sgx_det_debug_set_block_fusion', 'sgx_det_debug_set_irb', 'sgx_det_debug_set_gemm', 'sgx_det_debug_time_ops', 'sgx_det_debug_run_step', 'sgx_flow_debug_read_level',
+    'sgx_flow_debug_level_size', 'sgx_debug_corun_bf16',
 ]
 
 
@@ -226,8 +226,10 @@ class SgxLib:
             for nm in ('fusion', 'legacy_kernels', 'block_fusion', 'irb', 'gemm'):
                 getattr(d, 'sgx_det_debug_set_' + nm).argtypes = [C.c_int]
             d.sgx_det_debug_time_ops.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
+            d.sgx_det_debug_run_step.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
             d.sgx_debug_flow_affine_batch_dev.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, vp]
             d.sgx_flow_debug_read_level.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
+            d.sgx_debug_corun_bf16.argtypes = [C.c_int, C.c_int, C.c_int, vp]
             d.sgx_flow_debug_level_size.argtypes = [vp, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
 
     def tap(self, name):

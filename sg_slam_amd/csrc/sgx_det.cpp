@@ -1226,6 +1226,16 @@ SGX_TAP int sgx_det_debug_time_ops(sgx_det *h, const uint8_t *d_img, int pitch, 
 #endif
 }
 
+// plan step i launched `reps` times on `stream` (asynchronous): a co-runner for interference experiments (round 6, tools/diag_lk_repeat.py)
+SGX_TAP int sgx_det_debug_run_step(sgx_det *h, const uint8_t *d_img, int pitch, int batch, int i, int reps, void *stream)
+{
+    if (!h || !d_img || batch < 1 || batch > h->max_batch || reps < 1) return SGX_ERR_INVALID;
+    const int skip = h->pre_fused, nops = (int)h->ops.size() + 1 - skip;
+    if (i < 0 || i >= nops) return SGX_ERR_INVALID;
+    for (int r = 0; r < reps; r++) { if (i == 0) run_first_step(h, d_img, pitch, batch, (sgx_stream_t)stream); else run_op(h, h->ops[i - 1 + skip], batch, (sgx_stream_t)stream); }
+    return SGX_OK;
+}
+
 extern "C" int sgx_det_plan_step(const sgx_det *h, int i, char *buf, int cap)
 {
     if (!h || !buf || cap < 16 || i < 0 || i > (int)h->ops.size() - h->pre_fused) return SGX_ERR_INVALID;

@@ -164,6 +164,37 @@ SGX_TAP int sgx_flow_debug_level_size(const sgx_flow *h, int level, int32_t *w, 
     return SGX_OK;
 }
 
+// Test tap (round 6): a co-runner that does nothing but bf16 matrix products (v_mfma_f32_32x32x16_bf16 back to back, two waves per SIMD, every CU), `launches` launches on `stream`,
+// asynchronous.  Beside it, compiler-generated PACKED fp32 instructions of a co-resident wave returned wrong values in lanes 48-63 (profiles/r6_lk_priority_diagnosis.md): the library
+// is built without them (-fno-slp-vectorize, Makefile), and tests/test_flow_gpu.py runs the LK tracker beside this kernel to keep it that way.
+#if defined(SGX_DEBUG_TAPS) && !defined(SGX_EMU)
+typedef float sgx_dbg_f16v __attribute__((ext_vector_type(16)));
+typedef __bf16 sgx_dbg_bf8 __attribute__((ext_vector_type(8)));
+SGX_KERNEL_OCC(256, 2) k_dbg_corun_bf16(float *o, int iters)
+{
+    const uint32_t x = threadIdx.x * 2654435761u + blockIdx.x, y = x ^ 0x9e3779b9u;
+    sgx_dbg_f16v acc = {0}; sgx_dbg_bf8 a, b;
+    for (int i = 0; i < 8; i++) { a[i] = (__bf16)(float)((x >> i) & 7); b[i] = (__bf16)(float)((y >> i) & 3); }
+    for (int i = 0; i < iters; i++) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    float s = 0.f; for (int i = 0; i < 16; i++) s += acc[i];
+    o[(blockIdx.x & 1023) * 256 + threadIdx.x] = s;
+}
+#endif
+SGX_TAP int sgx_debug_corun_bf16(int blocks, int iters, int launches, void *stream)
+{
+#if defined(SGX_DEBUG_TAPS) && !defined(SGX_EMU)
+    static float *sink = nullptr;
+    if (blocks < 1 || iters < 1 || launches < 1) return SGX_ERR_INVALID;
+    if (!sink) SGX_CHECK_HIP(hipMalloc((void **)&sink, 1024 * 256 * sizeof(float)));
+    for (int l = 0; l < launches; l++) SGX_LAUNCH(k_dbg_corun_bf16, dim3((unsigned)blocks), dim3(256), (sgx_stream_t)stream, sink, iters);
+    SGX_CHECK_HIP(hipGetLastError());
+    return SGX_OK;
+#else
+    (void)blocks; (void)iters; (void)launches; (void)stream;
+    return SGX_ERR_UNSUPPORTED;
+#endif
+}
+
 extern "C" int sgx_fundamental_ransac_batch_dev(int batch, int cap, const sgx_keypoint *d_keys, const int32_t *d_n, const float *d_prev_xy,
                                                 const int32_t *d_pre_have_dynamic, const float *d_pre_boxes, const int32_t *d_pre_nboxes, int max_boxes,
                                                 double threshold, double confidence, double *d_F, int32_t *d_ok, int32_t *d_stats, void *stream)

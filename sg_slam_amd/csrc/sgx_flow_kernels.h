@@ -278,7 +278,18 @@ SGX_DEV uint32_t sgx_as_u32(sgx_i16x2 v) { return __builtin_bit_cast(uint32_t, v
 #define SGX_LK_PAIR(hi, lo, a, b) sgx_as_i16x2(__builtin_amdgcn_perm((hi), (lo), (uint32_t)(a) | 0x0c00u | ((uint32_t)(b) << 16) | 0x0c000000u))
 /* (high half of p, low half of q): the pair one 16-bit element further along a row of pairs */
 SGX_DEV sgx_i16x2 sgx_lk_next(sgx_i16x2 p, sgx_i16x2 q) { return sgx_as_i16x2(__builtin_amdgcn_alignbit(sgx_as_u32(q), sgx_as_u32(p), 16)); }
+#if defined(SGX_LK_NODOT) && !defined(SGX_EMU)      /* diagnostic build (round 6): the two products of a dot as two v_mad_i32_i16 — no instruction of the DOT / matrix pipe in the kernel */
+SGX_DEV int sgx_lk_dot2_mad(sgx_i16x2 a, sgx_i16x2 b, int c)
+{
+    const uint32_t ua = __builtin_bit_cast(uint32_t, a), ub = __builtin_bit_cast(uint32_t, b);
+    asm("v_mad_i32_i16 %0, %1, %2, %0 op_sel:[0,0,0,0]" : "+v"(c) : "v"(ua), "v"(ub));
+    asm("v_mad_i32_i16 %0, %1, %2, %0 op_sel:[1,1,0,0]" : "+v"(c) : "v"(ua), "v"(ub));
+    return c;
+}
+#define SGX_LK_DOT2(a, b, c) sgx_lk_dot2_mad((a), (b), (c))
+#else
 #define SGX_LK_DOT2(a, b, c) __builtin_amdgcn_sdot2((a), (b), (c), false)
+#endif
 /* the first dot product of a window sample, whose accumulator operand (the sample's start value) must survive.  Rounds 4-6 issued it as inline assembly in the three-address
  * VOP3P form (v_dot2_i32_i16) to spare the v_mov the compiler puts in front of its two-address v_dot2c.  That hid a HAZARD from the compiler: on gfx940 / gfx950 a DOT result
  * needs 3 wait states before a VALU instruction of another opcode reads it (4 before one overwrites it), the compiler's hazard recogniser inserts them only for instructions

@@ -26,9 +26,11 @@ HAVE_GPU = _have_gpu()
 @pytest.fixture(scope='session', autouse=True)
 def _lds_polluter():
     """SGX_TEST_POLLUTE=<KB> (GPU box, optional): a side stream keeps overwriting the LDS of every CU with changing garbage while the tests run (tools/lds_pollute).  LDS is not
-    cleared between kernels, so a kernel that reads LDS it never wrote only shows as a difference when the leftovers change; round 6 found one that way."""
-    kb = os.environ.get('SGX_TEST_POLLUTE')
-    if not kb or not HAVE_GPU:
+    cleared between kernels, so a kernel that reads LDS it never wrote only shows as a difference when the leftovers change; round 6 found one that way.
+    SGX_TEST_CORUN=<kind bits> (GPU box, optional): the side stream runs tools/lds_pollute's k_corun instead (2 = dense bf16 matrix products on every CU): round 6 found that
+    compiler-generated packed fp32 instructions of a co-resident wave go wrong beside them (profiles/r6_lk_priority_diagnosis.md); the whole tier must pass with it on."""
+    kb = os.environ.get('SGX_TEST_POLLUTE'); kind = os.environ.get('SGX_TEST_CORUN')
+    if not (kb or kind) or not HAVE_GPU:
         yield; return
     import ctypes, threading
     so = os.path.join(ROOT, 'tools', 'lds_pollute', 'liblds_pollute.so')
@@ -39,7 +41,9 @@ def _lds_polluter():
         import torch
         torch.cuda.set_device(0); i = 0
         while not stop.is_set():
-            lib.lds_pollute(ctypes.c_uint32(0x7fc00000 + 7919 * i), int(kb), 64, 1024); lib.lds_pollute_sync(); i += 1
+            if kind: lib.corun_launch(1024, 2000, int(kind), 8, 3); lib.corun_sync()      # k_corun: SGX_TEST_CORUN=2 is a dense stream of bf16 matrix products on every CU
+            else: lib.lds_pollute(ctypes.c_uint32(0x7fc00000 + 7919 * i), int(kb), 64, 1024); lib.lds_pollute_sync()
+            i += 1
     th = threading.Thread(target=run, daemon=True); th.start()
     yield
     stop.set(); th.join(timeout=10)

@@ -62,3 +62,37 @@ def test_ransac_degenerate_gpu(gpulib, oracle):
     ok, F, st = find_fundamental_mat(p1, p2, lib=gpulib)
     rok, _, _, _ = oracle.find_fundamental_ransac(p1, p2)
     assert ok == rok == 0 and (F == 0).all()
+
+
+def test_lk_beside_bf16_matrix_products_gpu(gpulib, gpulib_taps):
+    """Round 6: beside a co-resident wave that issues bf16 matrix products back to back (the detector's k_hrb blocks do, on their own stream), compiler-generated PACKED fp32
+    instructions returned wrong values in lanes 48-63 — the LK tracker's step arithmetic had been paired into v_pk_fma_f32 / v_pk_mul_f32 by the SLP vectoriser and 50-100 of
+    2 000 keypoints per run came out different (20 of 20 runs; profiles/r6_lk_priority_diagnosis.md).  The library is built with -fno-slp-vectorize; this runs the PRODUCT
+    library's tracker beside the tap library's co-runner (sgx_debug_corun_bf16: 1024 workgroups of nothing but v_mfma_f32_32x32x16_bf16) and demands the quiet run's bits."""
+    import ctypes as C
+    import torch
+    from sg_slam_amd import synth
+    from sg_slam_amd.flow import OpticalFlowLK
+    from sg_slam_amd.orb import ORBextractor
+    S = 2; gen = synth.PlaneStream(seed=1234); offs = [3, 57]
+    f0 = _xp(np.stack([gen.frame(o + 1)[0] for o in offs])); f1 = _xp(np.stack([gen.frame(o + 2)[0] for o in offs]))
+    ex = ORBextractor(nfeatures=1000, width=640, height=480, max_batch=S, lib=gpulib); cap = ex.capacity
+    keys = torch.zeros((S, cap, 28), dtype=torch.uint8, device='cuda'); desc = torch.zeros((S, cap, 32), dtype=torch.uint8, device='cuda'); n = torch.zeros(S, dtype=torch.int32, device='cuda')
+    ex.extract_batch_dev(f1, 640, S, keys, desc, n); torch.cuda.synchronize(); nn = n.cpu().numpy()
+    assert nn.min() > 500
+    fl = OpticalFlowLK(width=640, height=480, max_batch=S, lib=gpulib); sV, sC = torch.cuda.Stream(), torch.cuda.Stream()
+    xy = torch.zeros((S, cap, 2), dtype=torch.float32, device='cuda'); status = torch.zeros((S, cap), dtype=torch.uint8, device='cuda')
+
+    def run(co):
+        torch.cuda.synchronize()
+        if co: gpulib_taps.check(gpulib_taps.tap('sgx_debug_corun_bf16')(1024, 2000, 3, C.c_void_p(sC.cuda_stream)))
+        fl.reset(); fl.lk_batch_dev(f0, 640, S, None, None, cap, None, None, stream=sV.cuda_stream); fl.lk_batch_dev(f1, 640, S, keys, n, cap, xy, status, stream=sV.cuda_stream)
+        torch.cuda.synchronize()
+        return [np.concatenate([xy[s, :nn[s]].cpu().numpy().view(np.uint32), status[s, :nn[s], None].cpu().numpy().astype(np.uint32)], 1) for s in range(S)]
+    ref = run(False)
+    for r in range(10):
+        out = run(True)
+        for s in range(S):
+            differ = int((out[s] != ref[s]).any(1).sum())
+            assert differ == 0, 'repetition %d stream %d: %d of %d keypoints differ from the quiet run' % (r, s, differ, nn[s])
+    fl.close(); ex.close()

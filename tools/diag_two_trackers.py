@@ -20,10 +20,12 @@ S, MB, NF = 2, 100, 5
 gen = synth.PlaneStream(seed=1234); offs = [3, 57]
 frames = [[gen.frame(o + t) for o in offs] for t in range(NF)]
 T0 = np.stack([gen.Tcw(o) for o in offs])
+ABL = os.environ.get('ABL', '')      # ablations: nodet (no detector forward at all), anodet / bnodet (only for the first / second tracker), nolocal (no local-map stage), bextract (second tracker: no step, only its detector)
+FIRST = [None]
 class Side:
     def __init__(self):
         self.det = Detector2D(0.9, 0.01, param_text=open(param).read(), bin_bytes=blob, max_batch=S, lib=lib)
-        self.tr = TrackerBatch(lib, S, CAM, xp='torch', lk=True, max_boxes=MB); self.tr.set_initial_pose(T0)
+        self.tr = TrackerBatch(lib, S, CAM, xp='torch', lk=True, max_boxes=MB, local_map='nolocal' not in ABL); self.tr.set_initial_pose(T0)
         self.sD = torch.cuda.Stream()
         self.res = [torch.zeros((S, C.sizeof(DetResult)), dtype=torch.uint8, device='cuda') for _ in range(2)]
         self.boxes = [torch.zeros((S, MB, 4), dtype=torch.float32, device='cuda') for _ in range(2)]
@@ -37,7 +39,8 @@ class Side:
         b = t & 1
         self.sD.wait_stream(torch.cuda.current_stream())
         if t >= 2: self.sD.wait_event(self.tr.ev_extract[(t - 2) % 3])
-        self.det.detect_batch_dev(d_bgr, 640 * 3, S, self.res[b], self.boxes[b], self.nb[b], MB, self.have[b], stream=self.sD.cuda_stream)
+        if 'nodet' not in ABL and not ('bnodet' in ABL and self is not FIRST[0]) and not ('anodet' in ABL and self is FIRST[0]):
+            self.det.detect_batch_dev(d_bgr, 640 * 3, S, self.res[b], self.boxes[b], self.nb[b], MB, self.have[b], stream=self.sD.cuda_stream)
         self.ev[b].record(self.sD)
         self.tr.step(d_gray, d_depth, mask=dict(boxes=self.boxes[b], nboxes=self.nb[b], have_dynamic=self.have[b], event=self.ev[b]))
     def snap(self, t):
@@ -64,6 +67,7 @@ for rep in range(reps):
         d_gray = torch.from_numpy(np.stack([f[0] for f in fr])).cuda(); d_depth = torch.from_numpy(np.stack([f[1] for f in fr]).view(np.int16)).cuda()
         d_bgr = d_gray.unsqueeze(-1).expand(S, 480, 640, 3).contiguous(); held.append((d_gray, d_depth, d_bgr))
         if pol: assert pol.lds_pollute(C.c_uint32(0x7fc00000 + 977 * t + 31 * rep), int(os.environ['POLLUTE']), 400, 1024) == 0
+        FIRST[0] = A
         A.step(t, d_gray, d_depth, d_bgr); B.step(t, d_gray, d_depth, d_bgr)
         torch.cuda.synchronize()
         if t == 0: continue

@@ -1,5 +1,8 @@
 #!/bin/bash
-# round 6, GPU session M: micro-reproducer of the mixed-stream-priority effect outside the library (tools/ubench/prio_lanes.hip)
+# round 6, GPU session M: every detector plan step as the only co-runner of the LK tracker (tap build, 20 launches of the step beside 4 LK runs, 60 repetitions each)
 set -u
-O=gpurun_out/r6m; mkdir -p $O
-for m in 5 1 2 3 4; do for p in 1 0; do timeout 120 tools/ubench/prio_lanes $m 300 $p 1024 2>&1 | tail -1 | tee -a $O/prio_lanes.txt; done; done
+O=gpurun_out/r6m; mkdir -p $O; : > $O/steps.txt
+for i in $(seq 0 51); do
+  r=$(LKRUNS=4 CORUN=step STEP=$i STEP_REPS=${STEP_REPS:-20} STEP_BATCH=${STEP_BATCH:-2} timeout 120 python tools/diag_lk_repeat.py 60 taps 2>&1 | grep -v amdgpu.ids | grep -E "^co-runner|^reps" | tr '\n' ' ')
+  echo "step $i: $r" | cut -c1-200 | tee -a $O/steps.txt
+done

@@ -4,7 +4,7 @@ usage: python tools/isa_census.py [sgx_det sgx_flow ...]     (default: every sg_
 import os, re, subprocess, sys, tempfile
 from collections import Counter
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); CSRC = os.path.join(ROOT, 'sg_slam_amd', 'csrc')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fhip-fp32-correctly-rounded-divide-sqrt', '-Wno-everything', '-x', 'hip', '--cuda-device-only', '-S']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fhip-fp32-correctly-rounded-divide-sqrt', '-fno-slp-vectorize', '-Wno-everything', '-x', 'hip', '--cuda-device-only', '-S']
 
 def census(asm_text):
     """{kernel: dict(valu, cnd_e32, runs{len: count}, lanes, s_nop, branches)} from the text of a gfx950 assembly file"""
