@@ -56,6 +56,7 @@ struct Arena {
     template <class T> void take(T **p, size_t n) { off = (off + 255) & ~(size_t)255; if (base) *p = (T *)(base + off); off += (n ? n : 1) * sizeof(T); }
 };
 static Arena g_arena;
+static thread_local int g_ba_jobs_host = 0;            // test tap (sgx_ba_debug_set_jobs): 1 = build the Schur job list on the host (the emulator's path; A/B arm of the device builder)
 static thread_local int g_ba_solver = -1;              // test / tuning tap (sgx_ba_debug_set_solver): -1 = SGX_BA_SOLVER or auto, 0 auto, 1 dense blocked Cholesky, 2 envelope solver
 
 struct BA {
@@ -66,6 +67,7 @@ struct BA {
     SgxBaEdge *E; SgxSE3 *T, *Tb; double *X, *Xb, *err, *Hll, *bl, *Hpl, *Hpp, *bp, *S, *coef, *xp, *xl, *Dinv, *dwork, *partial;
     int *pt_start, *pt_edges, *pose_start, *pose_edges, *hidx, *free_pose, *ok; uint8_t *pt_active;
     SgxBaJob *jobs; int *blk_start; double *Linv, *xsol; long long njobs, nblk; size_t jobs_cap;
+    int *pose_edges_l, *row_jobs, *row_blks, *job_off, *blk_off, *jtot;      // device-side job list build (k_ba_jobs_*): a pose's edges in ascending landmark order; per-row counts and their exclusive sums; { jobs, blocks }
     double *part_chi, *part_scale;      // device scalars block: [ok | part_scale[nblk_v] | part_chi[nblk_e]] read back with ONE copy per trial
     int nblk_e, nblk_v;
     int *env_rstart, *env_rows;          // narrow-envelope solver: rows of column step k = env_rows[env_rstart[k] .. env_rstart[k+1]) (NULL: dense solver)
@@ -184,6 +186,31 @@ static int build_jobs(BA &B, const std::vector<int> &pt_start, const std::vector
     SGX_CHECK_HIP(hipMemcpy(B.jobs, sorted.data(), sizeof(SgxBaJob) * sorted.size(), hipMemcpyHostToDevice));
     SGX_CHECK_HIP(hipMemcpy(B.blk_start, blk_start.data(), sizeof(int) * blk_start.size(), hipMemcpyHostToDevice));
     return SGX_OK;
+}
+
+// The same list built on the device (k_ba_jobs_row / k_ba_jobs_scan, sgx_ba_kernels.h): no host pass over the edges, no 25 MB upload at 2 000 keyframes, and after the
+// classification pass no download of the edge records either — the kernels read the levels where k_ba_classify wrote them.  One 8-byte read-back (jobs, blocks) per build.
+static int build_jobs_dev(BA &B)
+{
+#ifndef SGX_EMU
+    B.njobs = 0; B.nblk = 0;
+    if (B.nf < 1) return SGX_OK;
+    const size_t lds = sizeof(int) * (size_t)B.nf;
+    hipLaunchKernelGGL((k_ba_jobs_row<0>), dim3((unsigned)B.nf), dim3(64), lds, (sgx_stream_t)0, B.nf, B.free_pose, B.pose_start, B.pose_edges_l, B.pt_start, B.pt_edges, B.E, B.hidx,
+                       B.row_jobs, B.row_blks, (const int *)nullptr, (const int *)nullptr, (SgxBaJob *)nullptr, (int *)nullptr);
+    SGX_LAUNCH(k_ba_jobs_scan, dim3(1), dim3(256), (sgx_stream_t)0, B.nf, B.row_jobs, B.row_blks, B.job_off, B.blk_off, B.jtot, B.blk_start);
+    int tot[2] = { 0, 0 };
+    SGX_CHECK_HIP(hipMemcpy(tot, B.jtot, sizeof tot, hipMemcpyDeviceToHost));
+    if ((size_t)tot[0] > B.jobs_cap) return SGX_ERR_NOMEM;
+    B.njobs = tot[0]; B.nblk = tot[1];
+    if (tot[0] == 0) return SGX_OK;
+    hipLaunchKernelGGL((k_ba_jobs_row<1>), dim3((unsigned)B.nf), dim3(64), lds, (sgx_stream_t)0, B.nf, B.free_pose, B.pose_start, B.pose_edges_l, B.pt_start, B.pt_edges, B.E, B.hidx,
+                       B.row_jobs, B.row_blks, B.job_off, B.blk_off, B.jobs, B.blk_start);
+    SGX_CHECK_HIP(hipGetLastError());
+    return SGX_OK;
+#else
+    (void)B; return SGX_ERR_UNSUPPORTED;
+#endif
 }
 
 // Dense symmetric positive definite solve  S x = bp - coef  on the device (in place: S is overwritten by its factor): register / LDS kernels for small systems, the blocked
@@ -333,6 +360,7 @@ static int optimize(BA &B, int iterations, int *iters_done, double *final_chi)
 
 static thread_local int g_ba_last_plan[4] = { 0, 0, 0, 0 };
 SGX_TAP int sgx_ba_debug_last_plan(int32_t plan[4]) { if (!plan) return SGX_ERR_INVALID; for (int i = 0; i < 4; i++) plan[i] = g_ba_last_plan[i]; return SGX_OK; }
+SGX_TAP int sgx_ba_debug_set_jobs(int host) { g_ba_jobs_host = host ? 1 : 0; return SGX_OK; }
 SGX_TAP int sgx_ba_debug_set_solver(int mode) { g_ba_solver = mode < 0 ? -1 : (mode > 2 ? 2 : mode); return SGX_OK; }
 
 // mode 0: Optimizer::LocalBundleAdjustment (Optimizer.cc:453-778); mode 1: Optimizer::BundleAdjustment (Optimizer.cc:49-237): one optimize(n_iterations) over
@@ -481,8 +509,9 @@ static int ba_run(const sgx_ba_problem *P, const sgx_camera *cam, const volatile
         A.take(&B.E, B.ne); A.take(&B.X, 3 * (size_t)B.nl); A.take(&B.pt_start, B.nl + 1); A.take(&B.pt_edges, B.ne);
         A.take(&B.pose_start, B.np + 1); A.take(&B.pose_edges, B.ne); A.take(&B.hidx, B.np); A.take(&B.free_pose, B.nf);
         A.take(&dTcw, 16 * (size_t)B.np); A.take(&dfixed, B.np);
-        A.take(&B.env_rstart, env_rstart.size()); A.take(&B.env_rows, env_rows.size());
+        A.take(&B.env_rstart, env_rstart.size()); A.take(&B.env_rows, env_rows.size()); A.take(&B.pose_edges_l, B.ne);
         in_bytes = A.off;
+        A.take(&B.row_jobs, B.nf); A.take(&B.row_blks, B.nf); A.take(&B.job_off, B.nf + 1); A.take(&B.blk_off, B.nf + 1); A.take(&B.jtot, 2);
         A.take(&B.T, B.np); A.take(&B.Tb, B.np); A.take(&B.Xb, 3 * (size_t)B.nl); A.take(&B.err, 3 * (size_t)B.ne);
         A.take(&B.Hll, 9 * (size_t)B.nl); A.take(&B.bl, 3 * (size_t)B.nl); A.take(&B.Hpl, 18 * (size_t)B.ne); A.take(&B.Hpp, 36 * (size_t)B.nf);
         A.take(&B.bp, B.NP); A.take(&B.S, (size_t)B.NP * B.NP); A.take(&B.coef, B.NP); A.take(&B.xp, B.NP); A.take(&B.xsol, B.NP); A.take(&B.xl, 3 * (size_t)B.nl);
@@ -501,6 +530,7 @@ static int ba_run(const sgx_ba_problem *P, const sgx_camera *cam, const volatile
         put(B.E, E.data(), sizeof(SgxBaEdge) * B.ne); put(B.X, Xd.data(), sizeof(double) * Xd.size());
         put(B.pt_start, pt_start.data(), 4 * (size_t)(B.nl + 1)); put(B.pt_edges, pt_edges.data(), 4 * (size_t)B.ne);
         put(B.pose_start, pose_start.data(), 4 * (size_t)(B.np + 1)); put(B.pose_edges, pose_edges.data(), 4 * (size_t)B.ne);
+        put(B.pose_edges_l, pose_edges_l.data(), 4 * (size_t)B.ne);
         put(B.hidx, hidx.data(), 4 * (size_t)B.np); if (B.nf) put(B.free_pose, free_pose.data(), 4 * (size_t)B.nf);
         put(dTcw, P->poses, 64 * (size_t)B.np);
         if (!env_rstart.empty()) { put(B.env_rstart, env_rstart.data(), 4 * env_rstart.size()); put(B.env_rows, env_rows.data(), 4 * env_rows.size()); }
@@ -520,13 +550,19 @@ static int ba_run(const sgx_ba_problem *P, const sgx_camera *cam, const volatile
     lap("arena + upload");
     int it1 = 0, it2 = 0; double chi1 = 0, chi2 = 0;
     std::vector<uint8_t> level1(B.ne, 0);
-    rc = build_jobs(B, pt_start, pt_edges, pose_start, pose_edges_l, E, nullptr, hidx, free_pose); if (rc != SGX_OK) return rc;
+#ifdef SGX_EMU
+    const bool jobs_on_host = true;
+#else
+    const bool jobs_on_host = g_ba_jobs_host != 0;
+#endif
+    rc = jobs_on_host ? build_jobs(B, pt_start, pt_edges, pose_start, pose_edges_l, E, nullptr, hidx, free_pose) : build_jobs_dev(B); if (rc != SGX_OK) return rc;
     lap("schur job list 1");
     rc = optimize(B, mode == 1 ? n_iterations : 5, &it1, &chi1); if (rc != SGX_OK) return rc;   // Optimizer.cc:659-660 / :187-188
     lap("optimize 1");
     if (mode == 0 && !stopped(B)) {                                                                      // :662-707
         SGX_LAUNCH(k_ba_classify, dim3(B.nblk_e), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.ne, B.E, B.T, B.X, B.err, 0, derase);
-        {   // mirror the new levels on the host to rebuild the Schur job list (the active edge set changed)
+        if (!jobs_on_host) { rc = build_jobs_dev(B); if (rc != SGX_OK) return rc; }      // the active edge set changed: the kernels read the new levels in place
+        else {   // mirror the new levels on the host to rebuild the Schur job list
             std::vector<SgxBaEdge> Eh(B.ne);
             SGX_CHECK_HIP(hipMemcpy(Eh.data(), B.E, sizeof(SgxBaEdge) * B.ne, hipMemcpyDeviceToHost));
             for (int k = 0; k < B.ne; k++) level1[k] = (Eh[k].flags & 2) ? 1 : 0;

@@ -1237,6 +1237,90 @@ SGX_KERNEL(SGX_BA_THREADS) k_ba_dinv(int nl, const uint8_t *pt_active, const dou
 
 struct SgxBaJob { int k1, k2; };
 
+#ifndef SGX_EMU
+// ---------------------------------------------------------------------------------------------
+// Schur job list built on the device (round 6; the host builder — build_jobs_host in sgx_ba.cpp — stays as the emulator's path and as the A/B arm of the tap build).
+// The list is: all ordered pairs (k1, k2) of active free-pose edges of one landmark, grouped by destination block (i1, i2) of the reduced system, block rows ascending, i2 ascending
+// inside a row, and inside a block the order in which the reference subtracts them (block_solver.hpp:380-433): the edges k1 of pose i1 in ascending landmark order, for each the edges
+// k2 of its landmark in edge order.  One wave per block row i1:
+//   count  lanes over the row's edges, LDS counters per i2                                      -> jobs and non-empty blocks of the row
+//   scan   (k_ba_jobs_scan, one workgroup) exclusive sums over the rows                          -> where the row's jobs / block starts begin; totals for the host
+//   fill   the same counters, scanned over i2 into cursors; then the row's edges ONE AFTER THE OTHER (64 of them fetched at a time), lanes over the landmark's edges: a job goes
+//          to cursor[i2] + (lower lanes with the same i2), the last lane of an i2 group advances the cursor — a stable counting sort without atomics, so the list, hence
+//          the reduced system, is the same bits as the host-built one.
+// An edge is active when its level is 0 (flags bit 1 clear: k_ba_classify sets it) and its pose is free (hidx >= 0).
+// ---------------------------------------------------------------------------------------------
+SGX_DEV int sgx_ba_edge_row(const SgxBaEdge *E, const int *hidx, int k) { const int fl = E[k].flags, p = E[k].pose; return (fl & 2) ? -1 : hidx[p]; }
+
+template <int FILL>
+__global__ void __launch_bounds__(64) k_ba_jobs_row(int nf, const int *free_pose, const int *pose_start, const int *pose_edges_l, const int *pt_start, const int *pt_edges,
+                                                    const SgxBaEdge *E, const int *hidx, int *row_jobs, int *row_blks, const int *job_off, const int *blk_off,
+                                                    SgxBaJob *jobs, int *blk_start)
+{
+    extern __shared__ int sgx_ba_cnt[];                           /* nf counters, then cursors */
+    int *cnt = sgx_ba_cnt;
+    const int h1 = (int)blockIdx.x, lane = (int)threadIdx.x, p = free_pose[h1];
+    for (int i = lane; i < nf; i += 64) cnt[i] = 0;
+    __syncthreads();
+    const int q0 = pose_start[p], q1 = pose_start[p + 1];
+    for (int q = q0 + lane; q < q1; q += 64) {
+        const int k1 = pose_edges_l[q];
+        if (E[k1].flags & 2) continue;
+        const int l = E[k1].point;
+        for (int q2 = pt_start[l]; q2 < pt_start[l + 1]; q2++) { const int h2 = sgx_ba_edge_row(E, hidx, pt_edges[q2]); if (h2 >= 0) atomicAdd(&cnt[h2], 1); }
+    }
+    __syncthreads();
+    int run = 0, nb = 0;                                          /* jobs / non-empty blocks of the row before this chunk of 64 columns */
+    const int jo = FILL ? job_off[h1] : 0, bo = FILL ? blk_off[h1] : 0;
+    for (int base = 0; base < nf; base += 64) {
+        const int i = base + lane, c = i < nf ? cnt[i] : 0;
+        int s = c, b = c > 0 ? 1 : 0;
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(s, d, 64), u = __shfl_up(b, d, 64); if (lane >= d) { s += t; b += u; } }
+        if (FILL && i < nf) { if (c > 0) blk_start[bo + nb + b - 1] = jo + run + s - c; cnt[i] = run + s - c; }
+        run += __shfl(s, 63, 64); nb += __shfl(b, 63, 64);
+    }
+    if (!FILL) { if (lane == 0) { row_jobs[h1] = run; row_blks[h1] = nb; } return; }
+    __syncthreads();
+    SgxBaJob *out = jobs + jo;
+    for (int qb = q0; qb < q1; qb += 64) {
+        int my_k1 = -1, my_a0 = 0, my_a1 = 0;                     /* 64 edges of the row fetched side by side, then visited in order */
+        if (qb + lane < q1) { my_k1 = pose_edges_l[qb + lane]; if (E[my_k1].flags & 2) my_k1 = -1; else { const int l = E[my_k1].point; my_a0 = pt_start[l]; my_a1 = pt_start[l + 1]; } }
+        const int nq = min(64, q1 - qb);
+        for (int j = 0; j < nq; j++) {
+            const int k1 = __shfl(my_k1, j, 64), a0 = __shfl(my_a0, j, 64), a1 = __shfl(my_a1, j, 64);
+            if (k1 < 0) continue;
+            for (int t0 = a0; t0 < a1; t0 += 64) {
+                const int q2 = t0 + lane, nt = min(64, a1 - t0);
+                int k2 = -1, h2 = -1;
+                if (q2 < a1) { k2 = pt_edges[q2]; h2 = sgx_ba_edge_row(E, hidx, k2); }
+                int rank = 0, tot = 0;
+                for (int i = 0; i < nt; i++) { const int v = __shfl(h2, i, 64); if (v == h2) { tot++; if (i < lane) rank++; } }
+                int cur = 0;
+                if (h2 >= 0) { cur = cnt[h2]; SgxBaJob jb; jb.k1 = k1; jb.k2 = k2; out[cur + rank] = jb; }
+                __syncthreads();                                  /* one wave: orders the cursor reads above before the updates below */
+                if (h2 >= 0 && rank == tot - 1) cnt[h2] = cur + tot;
+                __syncthreads();
+            }
+        }
+    }
+}
+
+// exclusive sums of the rows' job and block counts; tot = { jobs, blocks }; the end marker of the block list
+__global__ void __launch_bounds__(256) k_ba_jobs_scan(int nf, const int *row_jobs, const int *row_blks, int *job_off, int *blk_off, int *tot, int *blk_start)
+{
+    __shared__ int sj[256], sb[256];
+    const int tid = (int)threadIdx.x, per = (nf + 255) / 256, lo = min(nf, tid * per), hi = min(nf, lo + per);
+    int aj = 0, ab = 0;
+    for (int i = lo; i < hi; i++) { aj += row_jobs[i]; ab += row_blks[i]; }
+    sj[tid] = aj; sb[tid] = ab;
+    __syncthreads();
+    if (tid == 0) { int rj = 0, rb = 0; for (int i = 0; i < 256; i++) { const int tj = sj[i], tb = sb[i]; sj[i] = rj; sb[i] = rb; rj += tj; rb += tb; } tot[0] = rj; tot[1] = rb; blk_start[rb] = rj; }
+    __syncthreads();
+    aj = sj[tid]; ab = sb[tid];
+    for (int i = lo; i < hi; i++) { job_off[i] = aj; blk_off[i] = ab; aj += row_jobs[i]; ab += row_blks[i]; }
+}
+#endif
+
 // Jobs arrive sorted by destination block (i1, i2) of the reduced system, landmark order inside a block (host: stable counting sort, once per active edge set).
 // One thread per (destination block, entry): it starts from the value k_ba_schur_init left in S and subtracts the block's contributions ONE BY ONE IN LANDMARK
 // ORDER — the order in which block_solver.hpp:380-433 visits them — and writes the entry once.  No atomics: the reduced system, hence the whole optimisation,

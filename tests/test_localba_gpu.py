@@ -70,3 +70,27 @@ def test_ba_config4_matches_oracle_fixture(gpulib, oracle):
     assert e1.mean() < 0.5 * e0.mean() and e1.max() < e0.max()
     # run-to-run: bit-identical (the Schur complement is summed per destination block in landmark order, no atomics)
     assert (runs[1][0] == poses).all() and (runs[1][1] == points).all() and (runs[1][2] == erase).all() and runs[1][3]['iterations'] == stats['iterations']
+
+
+@pytest.mark.parametrize('case', ['small', 'fixed_poses', 'band'])
+def test_device_job_list_equals_host_built_gpu(gpulib_taps, oracle, case):
+    """Round 6: the Schur job list (which pairs of edges feed which 6 x 6 block of the reduced camera system, in the reference's subtraction order) is built by kernels
+    (k_ba_jobs_row / k_ba_jobs_scan) instead of a host pass + 25 MB upload.  Same list -> same sums in the same order -> the whole bundle adjustment must come out with the
+    SAME BITS as with the host builder (sgx_ba_debug_set_jobs), including the second build after the classification pass switched edges off."""
+    from scenes import make_big_ba_problem
+    lib = gpulib_taps
+    if case == 'band': prob, _, _ = make_big_ba_problem(600, 15000)
+    else: prob, _, _ = make_ba_problem(oracle, n_free=30 if case == 'small' else 20, n_fixed=0 if case == 'small' else 40, n_points=1500 if case == 'small' else 2000, seed=21)
+    out = []
+    try:
+        for host in (1, 0):
+            lib.tap('sgx_ba_debug_set_jobs')(host)
+            p = {k: (v.copy() if hasattr(v, 'copy') else v) for k, v in prob.items()}
+            er, st = Optimizer.LocalBundleAdjustment(p, CAM, lib=lib)
+            out.append((np.ascontiguousarray(p['poses']).copy(), np.ascontiguousarray(p['points']).copy(), er.copy(), st))
+    finally:
+        lib.tap('sgx_ba_debug_set_jobs')(0)
+    a, b = out
+    assert a[3]['iterations'] == b[3]['iterations'] and a[3]['chi2'] == b[3]['chi2']
+    assert (a[2] == b[2]).all() and a[2].sum() > 0          # edges were switched off, so the second list differs from the first
+    assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes()

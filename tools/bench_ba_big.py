@@ -18,6 +18,9 @@ ne = len(prob['edge_pose'])
 if os.environ.get('SGX_TOOL_EMU'):          # generator / plumbing check without a GPU (tests' kernel-logic emulator; never a measurement)
     from sg_slam_amd.capi import SgxLib
     lib = SgxLib(os.path.join(ROOT, 'tests', 'emu', 'libsgx_emu.so'))
+elif os.environ.get('SGX_TOOL_TAPS'):      # the tap build (SGX_BA_TIMING=1 prints the host phases on stderr)
+    from sg_slam_amd.capi import SgxLib
+    lib = SgxLib(os.path.join(ROOT, 'tests', 'taps', 'libsgx_taps.so'))
 else:
     lib = sg_slam_amd.load()
 # two calls on the same input: the first one also pays for loading the code objects and growing the process-wide device arena (a LocalMapping thread pays
