@@ -1297,6 +1297,7 @@ static int run_detection_output(sgx_det *h, int batch, sgx_det_result *d_results
 {
     SgxDetOut P; P.n = h->num_priors; P.nc = h->num_class; P.nms_top_k = h->nms_top_k; P.keep_top_k = h->keep_top_k; P.nms_th = h->nms_th; P.conf_th = h->conf_th;
     P.var0 = h->dvar[0]; P.var1 = h->dvar[1]; P.var2 = h->dvar[2]; P.var3 = h->dvar[3];
+    { static const bool skip = sgx_getenv("SGX_DET_SKIP_OUTPUT") != nullptr; if (skip) return SGX_OK; }      // timing tap (round 6): what the per-class NMS chains cost the detector stream's critical path
     sgx_prof_begin(SGX_K_DET_OUT, st);
     SGX_LAUNCH_DYN(k_det_class_nms, dim3(h->num_class - 1, batch), dim3(256), (size_t)std::max(h->num_priors, 7 * SGX_DO_TOPK) * 4 + 16, st, P, h->blobs[h->loc_blob].d, h->blobs[h->conf_blob].d, h->d_priors, h->d_cls_rows, h->d_cls_count);
     SGX_LAUNCH(k_det_merge, dim3(batch), dim3(256), st, P, h->d_cls_rows, h->d_cls_count, h->det_th, h->dyn_th, h->W, h->H, h->T, d_results, d_boxes, d_nboxes, max_boxes, d_have_dynamic);
