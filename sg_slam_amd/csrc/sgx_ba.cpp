@@ -56,6 +56,20 @@ struct Arena {
     template <class T> void take(T **p, size_t n) { off = (off + 255) & ~(size_t)255; if (base) *p = (T *)(base + off); off += (n ? n : 1) * sizeof(T); }
 };
 static Arena g_arena;
+// pinned staging buffer of the packed host->device inputs, kept like the arena (grow-only): no 17 MB zero-fill + pageable copy per call at 2 000 keyframes
+static char *g_stage = nullptr; static size_t g_stage_cap = 0;
+static char *stage_reserve(size_t bytes)
+{
+    if (bytes <= g_stage_cap) return g_stage;
+#ifndef SGX_EMU
+    if (g_stage) (void)hipHostFree(g_stage);
+    g_stage = nullptr; g_stage_cap = 0;
+    if (hipHostMalloc((void **)&g_stage, bytes + bytes / 4, hipHostMallocPortable) != hipSuccess) { g_stage = nullptr; return nullptr; }
+#else
+    free(g_stage); g_stage = (char *)malloc(bytes + bytes / 4); if (!g_stage) { g_stage_cap = 0; return nullptr; }
+#endif
+    g_stage_cap = bytes + bytes / 4; return g_stage;
+}
 static thread_local int g_ba_jobs_host = 0;            // test tap (sgx_ba_debug_set_jobs): 1 = build the Schur job list on the host (the emulator's path; A/B arm of the device builder)
 static thread_local int g_ba_solver = -1;              // test / tuning tap (sgx_ba_debug_set_solver): -1 = SGX_BA_SOLVER or auto, 0 auto, 1 dense blocked Cholesky, 2 envelope solver
 
@@ -403,7 +417,10 @@ static int ba_run(const sgx_ba_problem *P, const sgx_camera *cam, const volatile
     { std::vector<int> f1(B.nl, 0), f2(B.np, 0);
       for (int k = 0; k < B.ne; k++) { pt_edges[pt_start[E[k].point] + f1[E[k].point]++] = k; pose_edges[pose_start[E[k].pose] + f2[E[k].pose]++] = k; } }
     std::vector<int> pose_edges_l(pose_edges);                                     // the edges of a pose in ascending landmark order (ties: edge order) for the Schur job list
-    for (int p = 0; p < B.np; p++) std::sort(pose_edges_l.begin() + pose_start[p], pose_edges_l.begin() + pose_start[p + 1], [&](int x, int y) { return E[x].point != E[y].point ? E[x].point < E[y].point : x < y; });
+    for (int p = 0; p < B.np; p++) {      // (a caller that adds its edges landmark by landmark — Optimizer.cc:573-640 does — hands every pose its edges already in this order)
+        const auto lt = [&](int x, int y) { return E[x].point != E[y].point ? E[x].point < E[y].point : x < y; };
+        if (!std::is_sorted(pose_edges_l.begin() + pose_start[p], pose_edges_l.begin() + pose_start[p + 1], lt)) std::sort(pose_edges_l.begin() + pose_start[p], pose_edges_l.begin() + pose_start[p + 1], lt);
+    }
     std::vector<double> Xd(3 * (size_t)B.nl);
     for (size_t i = 0; i < Xd.size(); i++) Xd[i] = (double)P->points[i];
     // upper bound of the Schur job list: sum over landmarks of (edges with a free pose)^2
@@ -524,9 +541,9 @@ static int ba_run(const sgx_ba_problem *P, const sgx_camera *cam, const volatile
         if (pass == 0) { if ((rc = A.reserve(total)) != SGX_OK) return rc; }
     }
     {
-        std::vector<char> stage(in_bytes, 0);
+        char *stage = stage_reserve(in_bytes); if (!stage) return SGX_ERR_NOMEM;       // (the 256-byte alignment gaps between the arrays are never read)
         char *base = g_arena.base;
-        auto put = [&](const void *dst_dev, const void *src, size_t bytes) { memcpy(stage.data() + ((const char *)dst_dev - base), src, bytes); };
+        auto put = [&](const void *dst_dev, const void *src, size_t bytes) { memcpy(stage + ((const char *)dst_dev - base), src, bytes); };
         put(B.E, E.data(), sizeof(SgxBaEdge) * B.ne); put(B.X, Xd.data(), sizeof(double) * Xd.size());
         put(B.pt_start, pt_start.data(), 4 * (size_t)(B.nl + 1)); put(B.pt_edges, pt_edges.data(), 4 * (size_t)B.ne);
         put(B.pose_start, pose_start.data(), 4 * (size_t)(B.np + 1)); put(B.pose_edges, pose_edges.data(), 4 * (size_t)B.ne);
@@ -534,8 +551,8 @@ static int ba_run(const sgx_ba_problem *P, const sgx_camera *cam, const volatile
         put(B.hidx, hidx.data(), 4 * (size_t)B.np); if (B.nf) put(B.free_pose, free_pose.data(), 4 * (size_t)B.nf);
         put(dTcw, P->poses, 64 * (size_t)B.np);
         if (!env_rstart.empty()) { put(B.env_rstart, env_rstart.data(), 4 * env_rstart.size()); put(B.env_rows, env_rows.data(), 4 * env_rows.size()); }
-        if (mode == 0) put(dfixed, P->pose_fixed, B.np);           // mode 1: every keyframe is rewritten from its vertex (Optimizer.cc:200-214) -> flags stay 0
-        SGX_CHECK_HIP(hipMemcpy(base, stage.data(), in_bytes, hipMemcpyHostToDevice));
+        if (mode == 0) put(dfixed, P->pose_fixed, B.np); else memset(stage + ((const char *)dfixed - base), 0, (size_t)B.np);           // mode 1: every keyframe is rewritten from its vertex (Optimizer.cc:200-214) -> flags stay 0
+        SGX_CHECK_HIP(hipMemcpy(base, stage, in_bytes, hipMemcpyHostToDevice));
     }
     if (env_rstart.empty()) { B.env_rstart = nullptr; B.env_rows = nullptr; }
     B.env_nA = env_nA; B.env_nB = env_nB; B.env_x2 = B.env_S2 + env_nsep * env_nsep;
