@@ -78,7 +78,7 @@ struct BA {
     SgxCam cam; double dMono, dStereo;
     const volatile int32_t *stop;
     // device
-    SgxBaEdge *E; SgxSE3 *T, *Tb; double *X, *Xb, *err, *Hll, *bl, *Hpl, *Hpp, *bp, *S, *coef, *xp, *xl, *Dinv, *dwork, *partial;
+    SgxBaEdge *E; SgxSE3 *T, *Tb; double *X, *Xb, *err, *Hll, *bl, *Hpl, *W, *Hpp, *bp, *S, *coef, *xp, *xl, *Dinv, *dwork, *partial;
     int *pt_start, *pt_edges, *pose_start, *pose_edges, *hidx, *free_pose, *ok; uint8_t *pt_active;
     SgxBaJob *jobs; int *blk_start; double *Linv, *xsol; long long njobs, nblk; size_t jobs_cap;
     int *pose_edges_l, *row_jobs, *row_blks, *job_off, *blk_off, *jtot;      // device-side job list build (k_ba_jobs_*): a pose's edges in ascending landmark order; per-row counts and their exclusive sums; { jobs, blocks }
@@ -331,9 +331,10 @@ static int optimize(BA &B, int iterations, int *iters_done, double *final_chi)
             }
             SGX_LAUNCH(k_ba_dinv, dim3((B.nl + SGX_BA_THREADS - 1) / SGX_BA_THREADS), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.nl, B.pt_active, B.Hll, lambda, B.Dinv);
             if (B.njobs > 0) {
-                const long long n36 = B.nblk * 36;
+                const long long n36 = B.nblk * 36, n6 = (long long)B.ne * 6;
+                SGX_LAUNCH(k_ba_hpl_dinv, dim3((unsigned)((n6 + SGX_BA_THREADS - 1) / SGX_BA_THREADS)), dim3(SGX_BA_THREADS), (sgx_stream_t)0, n6, B.E, B.hidx, B.Hpl, B.Dinv, B.W);
                 SGX_LAUNCH(k_ba_schur_pairs, dim3((unsigned)((n36 + SGX_BA_THREADS - 1) / SGX_BA_THREADS)), dim3(SGX_BA_THREADS), (sgx_stream_t)0, n36, B.nf, B.blk_start, B.jobs, B.E,
-                           B.hidx, B.bl, B.Hpl, B.Dinv, B.S, B.coef);
+                           B.hidx, B.bl, B.Hpl, B.W, B.S, B.coef);
             }
             sgx_prof_end(SGX_K_BA_SCHUR, (sgx_stream_t)0);
             sgx_prof_begin(SGX_K_BA_SOLVE, (sgx_stream_t)0);
@@ -530,7 +531,7 @@ static int ba_run(const sgx_ba_problem *P, const sgx_camera *cam, const volatile
         in_bytes = A.off;
         A.take(&B.row_jobs, B.nf); A.take(&B.row_blks, B.nf); A.take(&B.job_off, B.nf + 1); A.take(&B.blk_off, B.nf + 1); A.take(&B.jtot, 2);
         A.take(&B.T, B.np); A.take(&B.Tb, B.np); A.take(&B.Xb, 3 * (size_t)B.nl); A.take(&B.err, 3 * (size_t)B.ne);
-        A.take(&B.Hll, 9 * (size_t)B.nl); A.take(&B.bl, 3 * (size_t)B.nl); A.take(&B.Hpl, 18 * (size_t)B.ne); A.take(&B.Hpp, 36 * (size_t)B.nf);
+        A.take(&B.Hll, 9 * (size_t)B.nl); A.take(&B.bl, 3 * (size_t)B.nl); A.take(&B.Hpl, 18 * (size_t)B.ne); A.take(&B.W, 18 * (size_t)B.ne); A.take(&B.Hpp, 36 * (size_t)B.nf);
         A.take(&B.bp, B.NP); A.take(&B.S, (size_t)B.NP * B.NP); A.take(&B.coef, B.NP); A.take(&B.xp, B.NP); A.take(&B.xsol, B.NP); A.take(&B.xl, 3 * (size_t)B.nl);
         A.take(&B.Dinv, 9 * (size_t)B.nl); A.take(&B.dwork, B.NP); A.take(&B.partial, B.nblk_v);
         { double *blk = nullptr; A.take(&blk, 1 + (size_t)B.nblk_v + B.nblk_e); B.ok = (int *)blk; B.part_scale = blk ? blk + 1 : nullptr; B.part_chi = blk ? blk + 1 + B.nblk_v : nullptr; }

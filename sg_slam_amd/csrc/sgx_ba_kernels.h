@@ -1321,12 +1321,33 @@ __global__ void __launch_bounds__(256) k_ba_jobs_scan(int nf, const int *row_job
 }
 #endif
 
+// k_ba_hpl_dinv (round 6): W_k = Hpl_k Dinv_l, once per active edge and trial (6 x 3 per edge) instead of once per job and destination column inside k_ba_schur_pairs (every job of
+// edge k1 — about eight per edge, six columns each — recomputed the same three sums and fetched Dinv and the edge record for them).  The sums are the expressions k_ba_schur_pairs
+// evaluated, in the same order, so the reduced system keeps its bits.
+SGX_KERNEL(SGX_BA_THREADS) k_ba_hpl_dinv(long long n6, const SgxBaEdge *E, const int *hidx, const double *Hpl, const double *Dinv, double *W)
+{
+    SGX_THREADS_BEGIN(tid)
+    const long long g = (long long)blockIdx.x * SGX_BA_THREADS + tid;
+    if (g < n6) {
+        const int k = (int)(g / 6), a = (int)(g % 6);
+        const SgxBaEdge e = E[k];
+        if (!(e.flags & 2) && hidx[e.pose] >= 0) {
+            const double *Di = Dinv + (size_t)e.point * 9, *B1 = Hpl + (size_t)k * 18 + 3 * a;
+            double *w = W + (size_t)k * 18 + 3 * a;
+            w[0] = B1[0] * Di[0] + B1[1] * Di[3] + B1[2] * Di[6];
+            w[1] = B1[0] * Di[1] + B1[1] * Di[4] + B1[2] * Di[7];
+            w[2] = B1[0] * Di[2] + B1[1] * Di[5] + B1[2] * Di[8];
+        }
+    }
+    SGX_THREADS_END
+}
+
 // Jobs arrive sorted by destination block (i1, i2) of the reduced system, landmark order inside a block (host: stable counting sort, once per active edge set).
 // One thread per (destination block, entry): it starts from the value k_ba_schur_init left in S and subtracts the block's contributions ONE BY ONE IN LANDMARK
 // ORDER — the order in which block_solver.hpp:380-433 visits them — and writes the entry once.  No atomics: the reduced system, hence the whole optimisation,
 // is bit-reproducible from run to run.  The diagonal jobs (k1 == k2) of a diagonal block also accumulate coef(i1) += Hpl_1 (Dinv bl), same order.
 SGX_KERNEL(SGX_BA_THREADS) k_ba_schur_pairs(long long nblk36, int nf, const int *blk_start, const SgxBaJob *jobs, const SgxBaEdge *E, const int *hidx,
-                                            const double *bl, const double *Hpl, const double *Dinv, double *S, double *coef)
+                                            const double *bl, const double *Hpl, const double *W, double *S, double *coef)
 {
     SGX_THREADS_BEGIN(tid)
     const long long g = (long long)blockIdx.x * SGX_BA_THREADS + tid;
@@ -1339,14 +1360,11 @@ SGX_KERNEL(SGX_BA_THREADS) k_ba_schur_pairs(long long nblk36, int nf, const int 
         double cacc = (i1 == i2 && c == 0) ? coef[6 * i1 + a] : 0.0;
         for (int q = q0; q < q1; q++) {
             const SgxBaJob jb = jobs[q];
-            const int l = E[jb.k1].point;
-            const double *Di = Dinv + (size_t)l * 9;
-            const double *B1 = Hpl + (size_t)jb.k1 * 18 + 3 * a, *B2 = Hpl + (size_t)jb.k2 * 18 + 3 * c;
-            const double bd0 = B1[0] * Di[0] + B1[1] * Di[3] + B1[2] * Di[6];
-            const double bd1 = B1[0] * Di[1] + B1[1] * Di[4] + B1[2] * Di[7];
-            const double bd2 = B1[0] * Di[2] + B1[1] * Di[5] + B1[2] * Di[8];
+            const double *W1 = W + (size_t)jb.k1 * 18 + 3 * a, *B2 = Hpl + (size_t)jb.k2 * 18 + 3 * c;      // W1 = row a of Hpl_1 Dinv (k_ba_hpl_dinv)
+            const double bd0 = W1[0], bd1 = W1[1], bd2 = W1[2];
             acc += -(bd0 * B2[0] + bd1 * B2[1] + bd2 * B2[2]);
             if (jb.k1 == jb.k2 && c == 0) {
+                const int l = E[jb.k1].point;
                 const double b0 = bl[3 * (size_t)l], b1 = bl[3 * (size_t)l + 1], b2 = bl[3 * (size_t)l + 2];
                 cacc += bd0 * b0 + bd1 * b1 + bd2 * b2;               // Hpl_1 Dinv bl
             }
