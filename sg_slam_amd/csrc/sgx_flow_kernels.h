@@ -294,7 +294,7 @@ SGX_DEV int sgx_lk_dot2_mad(sgx_i16x2 a, sgx_i16x2 b, int c)
  * VOP3P form (v_dot2_i32_i16) to spare the v_mov the compiler puts in front of its two-address v_dot2c.  That hid a HAZARD from the compiler: on gfx940 / gfx950 a DOT result
  * needs 3 wait states before a VALU instruction of another opcode reads it (4 before one overwrites it), the compiler's hazard recogniser inserts them only for instructions
  * it can see, and the v_dot2c that followed read its accumulator one wait state after the asm.  No wrong result was ever traced to it (the rare LK difference of round 6 had
- * another trigger: mixed stream priorities, sgx_tracker.cpp), but the rule is the hardware's: the builtin costs the v_mov (0.7 % of the kernel) and is handled by the compiler. */
+ * another cause: compiler-generated packed fp32 beside another wave's bf16 matrix products, profiles/r6_lk_priority_diagnosis.md), but the rule is the hardware's: the builtin costs the v_mov (0.7 % of the kernel) and is handled by the compiler. */
 SGX_DEV int sgx_lk_dot2_keep(sgx_i16x2 a, sgx_i16x2 b, int c) { return SGX_LK_DOT2(a, b, c); }
 
 /* stage the ROWS x 36-byte patch of `img` whose top-left corner is (ox, oy) (ox a multiple of 4) into the wave's LDS tile: REFLECT_101 outside the

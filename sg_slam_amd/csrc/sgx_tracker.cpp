@@ -182,8 +182,8 @@ extern "C" int sgx_tracker_create(const sgx_tracker_config *cfg, sgx_det *detect
     t->pipelined = cfg->pipelined != 0;
     if (t->pipelined) {
         // stream priorities (bit 0 extraction, 1 tracking, 2 detector; SGX_TRK_PRIO is the tuning tap).  Default: all equal.  Rounds 2-5 gave the tracking stream the high
-        // priority (latency of a single camera).  Round 6: with queues of DIFFERENT priorities live on the device the LK tracker returned a slightly different position for
-        // about one keypoint in 10^4 — always one handled by lanes 32-63 of its wave, never with equal priorities or serialised kernels (profiles/r6_lk_priority_diagnosis.md).
+        // priority (latency of a single camera); no throughput difference was ever measured.  Round 6 first blamed mixed priorities for a rare LK difference between co-running
+        // trackers; they only changed how often the LK kernel met the detector's bf16 blocks on a CU — the cause was compiler-generated packed fp32 (profiles/r6_lk_priority_diagnosis.md).
         static const int prio = sgx_getenv("SGX_TRK_PRIO") ? atoi(sgx_getenv("SGX_TRK_PRIO")) : 0;
         // SGX_TRK_SHARE (tuning tap): 1 = tracking on the DETECTOR's stream (det(t), then track(t) behind it), 2 = tracking on the EXTRACTION stream (the round-1 serial order)
         static const int share = sgx_getenv("SGX_TRK_SHARE") ? atoi(sgx_getenv("SGX_TRK_SHARE")) : 0;

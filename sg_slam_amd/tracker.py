@@ -91,10 +91,9 @@ class TrackerBatch:
         self.pipelined = bool(pipelined and xp == 'torch')
         if self.pipelined:
             import torch
-            # Both streams at the SAME priority.  Rounds 2-5 gave the tracking stream the high priority (latency of a single camera).  Round 6: with queues of different
-            # priorities live on the device, the LK tracker (and only it: the most ALU-dense kernel of the chain) returned a slightly different position for about one keypoint
-            # in 10^4 — always a keypoint handled by lanes 32-63 of its wave, never with equal priorities, never with the kernels serialised (tools/diag_two_trackers.py,
-            # profiles/r6_lk_priority_diagnosis.md).  `stream_priorities` is the switch the diagnostic uses to bring the condition back.
+            # Both streams at the same priority.  Rounds 2-5 gave the tracking stream the high priority (latency of a single camera).  Round 6 first blamed mixed priorities for a
+            # rare LK difference between co-running trackers; they only changed how often the LK kernel met the detector's bf16 blocks on a CU — the cause was compiler-generated
+            # packed fp32 (profiles/r6_lk_priority_diagnosis.md).  `stream_priorities` is the switch tools/diag_two_trackers.py uses (MODE=prio).
             pe, pt = self.stream_priorities
             self.sE, self.sT = torch.cuda.Stream(priority=pe), torch.cuda.Stream(priority=pt)
             self.ev_extract = [torch.cuda.Event() for _ in range(NB)]

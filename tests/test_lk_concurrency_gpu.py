@@ -1,6 +1,8 @@
-"""Two identical trackers + detectors side by side on the same frames must agree bit for bit in every buffer of the extraction stage (round 6: with HIP streams of different
-priorities in the process the LK tracker differed for about one keypoint in 10^4, profiles/r6_lk_priority_diagnosis.md; the library and TrackerBatch now create all their
-streams at the default priority).  The comparison itself is tools/diag_two_trackers.py, which also serves as the reproducer (MODE=prio)."""
+"""Two identical trackers + detectors side by side on the same frames must agree bit for bit in every buffer of the extraction stage.  Round 6: the LK tracker differed for a few
+keypoints whenever its kernel shared a CU with the detector's bf16 blocks — compiler-generated packed fp32 with a half select goes wrong in lanes 48-63 beside another wave's bf16
+matrix products (profiles/r6_lk_priority_diagnosis.md; the library is built with -fno-slp-vectorize, tests/test_isa_rules.py and test_flow_gpu.py guard it).  Mixed stream priorities,
+the first suspect, only made the two kernels meet more often; the library and TrackerBatch create all their streams at the default priority.  The comparison itself is
+tools/diag_two_trackers.py (MODE=prio: the round 2-5 priorities)."""
 import os
 import subprocess
 import sys
