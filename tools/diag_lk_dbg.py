@@ -1,5 +1,7 @@
 """diagnostic (round 6): per-keypoint, per-level records of the LK tracker (debug build sg_slam_amd/ab/libsgx_lkdbg.so: gradient matrix, 1 / det, b and position of the first six
-iterations) from a quiet run against a run beside tools/lds_pollute's k_corun (EXT_KIND: instruction classes): which quantity goes wrong first?"""
+iterations) from a quiet run against a run beside tools/lds_pollute's k_corun (EXT_KIND: instruction classes): which quantity goes wrong first?
+The debug build's record macro (SGX_LK_DBG) lived in the diagnostic tree of commit d376699 and is not in the sources any more; the output that mattered is kept as
+profiles/r6_lk_dbg_values.txt (per-lane partial sums differ in the last 16-lane row only: how the packed-fp32 cause was found)."""
 import os, sys, ctypes as C
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
