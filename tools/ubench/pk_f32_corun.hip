@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
 }
 // ---- single instruction forms (mode > 0): a dependent chain of ONE packed-fp32 form in inline assembly, every lane on the same values; `W` = the s_nop operand between two links
 // (the compiler puts s_nop 0 = one wait state between dependent packed ops).  mode 1: v_pk_mul_f32 v, v, v   2: v_pk_fma_f32 v, v, s[..] op_sel_hi:[1,0,1], v   3: v_pk_add_f32 v, v, v
-// 4: v_pk_mul_f32 links separated by eight independent single-rate instructions instead of s_nop   5: v_mul_f32 pairs (not packed)   6: v_pk_mul_f32 with op_sel:[0,1] op_sel_hi:[1,0] (crossed halves)   7 / 8: the detector's tap forms (v_pk_fma_f32 s, v, v with the vector operand's high / low half broadcast)   9: broadcasts in v_pk_mul_f32
+// 4: v_pk_mul_f32 links separated by eight independent single-rate instructions instead of s_nop   5: v_mul_f32 pairs (not packed)   6: v_pk_mul_f32 with op_sel:[0,1] op_sel_hi:[1,0] (crossed halves)   7 / 8: the detector's tap forms (v_pk_fma_f32 s, v, v with the vector operand's high / low half broadcast)   9: broadcasts in v_pk_mul_f32   10: v_pk_mul_f32 with neg_lo / neg_hi only
 typedef float vf2 __attribute__((ext_vector_type(2)));
 template <int MODE, int W>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) k_form(int iters, float k1, float k2, unsigned *bad, float *sink)
@@ -67,6 +67,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
         if (MODE == 7) { asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n s_nop %4\n v_pk_fma_f32 %0, %1, %3, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n s_nop %4" : "+v"(x) : "s"(ks), "v"(c), "v"(cn), "n"(W)); }      /* the detector's depthwise tap: scalar weight pair x one pixel (high half broadcast) */
         if (MODE == 8) { asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]\n s_nop %4\n v_pk_fma_f32 %0, %1, %3, %0 op_sel_hi:[1,0,1]\n s_nop %4" : "+v"(x) : "s"(ks), "v"(c), "v"(cn), "n"(W)); }      /* ... low half broadcast */
         if (MODE == 9) { asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,1]\n s_nop %3\n v_pk_mul_f32 %0, %0, %2 op_sel:[0,0] op_sel_hi:[1,0]\n s_nop %3" : "+v"(x) : "v"(ka), "v"(kb), "n"(W)); }      /* broadcasts of a vector-register operand, not crossed */
+        if (MODE == 10) { asm volatile("v_pk_mul_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]\n s_nop %3\n v_pk_mul_f32 %0, %0, %2 neg_lo:[0,1] neg_hi:[0,1]\n s_nop %3" : "+v"(x) : "v"(ka), "v"(kb), "n"(W)); }      /* sign modifiers only (the ORB descriptor kernel's rotation): no half select */
         if (MODE == 6) { asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,0]\n s_nop %3\n v_pk_mul_f32 %0, %0, %2 op_sel:[0,1] op_sel_hi:[1,0]\n s_nop %3" : "+v"(x) : "v"(ka), "v"(kb), "n"(W)); }
     }
     const uint32_t ux = __float_as_uint(x[0]), uy = __float_as_uint(x[1]);
@@ -96,6 +97,7 @@ int main(int argc, char **argv)
         case 30: FORM(3, 0); break; case 31: FORM(3, 1); break; case 33: FORM(3, 3); break;
         case 40: FORM(4, 0); break; case 50: FORM(5, 0); break;
         case 70: FORM(7, 0); break; case 80: FORM(8, 0); break; case 90: FORM(9, 0); break;
+        case 100: FORM(10, 0); break;
         case 60: FORM(6, 0); break; case 61: FORM(6, 1); break; case 63: FORM(6, 3); break;
         default: printf("no such mode / wait\n"); return 1;
         }
