@@ -249,30 +249,7 @@ SGX_KERNEL(256) k_fused_block(SgxFusedBlk p)
 #else
 #define SGX_SCHED_FENCE() do { } while (0)
 #endif
-// Two fp32 lanes of one v_pk_fma_f32: a wave64 v_fma_f32 occupies the SIMD for 4 cycles, the packed form does two FMAs in the same slot (that is how gfx950 reaches its
-// 157 TFLOP/s fp32 vector peak).  Each half is an ordinary fused multiply-add, so results equal the scalar chain bit for bit.  The weights stay in SCALAR registers:
-// gfx950 reads an SGPR pair as a packed source with full pair and op_sel semantics (checked on hardware, tools/ubench/pk_fma_sgpr.hip); the compiler never emits that form
-// (it copies scalars into VGPRs first, one v_mov per use), hence the inline assembly.
-#ifndef SGX_EMU
-typedef float sgx_f2 __attribute__((ext_vector_type(2)));
-SGX_DEV sgx_f2 sgx_mk2(float a, float b) { sgx_f2 r; r.x = a; r.y = b; return r; }
-// c + (w.x, w.x) * b   and   c + (w.y, w.y) * b, w in scalar registers
-SGX_DEV sgx_f2 sgx_fma2_wlo(sgx_f2 w, sgx_f2 b, sgx_f2 c) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(c) : "s"(w), "v"(b)); return c; }
-SGX_DEV sgx_f2 sgx_fma2_whi(sgx_f2 w, sgx_f2 b, sgx_f2 c) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(c) : "s"(w), "v"(b)); return c; }
-// c + w * b, w a scalar-register pair
-SGX_DEV sgx_f2 sgx_fma2_w(sgx_f2 w, sgx_f2 b, sgx_f2 c) { asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(c) : "s"(w), "v"(b)); return c; }
-// c + w * (d.x, d.x)   and   c + w * (d.y, d.y), w a scalar-register pair
-SGX_DEV sgx_f2 sgx_fma2_w_dlo(sgx_f2 w, sgx_f2 d, sgx_f2 c) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(c) : "s"(w), "v"(d)); return c; }
-SGX_DEV sgx_f2 sgx_fma2_w_dhi(sgx_f2 w, sgx_f2 d, sgx_f2 c) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(c) : "s"(w), "v"(d)); return c; }
-#else
-struct sgx_f2 { float x, y; };
-static inline sgx_f2 sgx_mk2(float a, float b) { sgx_f2 r; r.x = a; r.y = b; return r; }
-static inline sgx_f2 sgx_fma2_w(sgx_f2 a, sgx_f2 b, sgx_f2 c) { sgx_f2 r; r.x = fmaf(a.x, b.x, c.x); r.y = fmaf(a.y, b.y, c.y); return r; }
-static inline sgx_f2 sgx_fma2_wlo(sgx_f2 w, sgx_f2 b, sgx_f2 c) { return sgx_fma2_w(sgx_mk2(w.x, w.x), b, c); }
-static inline sgx_f2 sgx_fma2_whi(sgx_f2 w, sgx_f2 b, sgx_f2 c) { return sgx_fma2_w(sgx_mk2(w.y, w.y), b, c); }
-static inline sgx_f2 sgx_fma2_w_dlo(sgx_f2 w, sgx_f2 d, sgx_f2 c) { return sgx_fma2_w(w, sgx_mk2(d.x, d.x), c); }
-static inline sgx_f2 sgx_fma2_w_dhi(sgx_f2 w, sgx_f2 d, sgx_f2 c) { return sgx_fma2_w(w, sgx_mk2(d.y, d.y), c); }
-#endif
+// (the packed multiply-add helpers sgx_f2 / sgx_fma2_* live in sgx_det_kernels.h since round 6: the stem uses them too)
 template <int CIN, int COUT, int K, int S, int TOH, int TOW, int CM> struct SgxFb2Geom {
     static constexpr int TIH = (TOH - 1) * S + K, TIW = (TOW - 1) * S + K, NPI = TIH * TIW, NPO = TOH * TOW;
     static constexpr int SLOTS_IN = (NPI + SGX_FB2_THREADS - 1) / SGX_FB2_THREADS, SLOTS_OUT = (NPO + SGX_FB2_THREADS - 1) / SGX_FB2_THREADS;

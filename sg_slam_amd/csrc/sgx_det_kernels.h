@@ -692,6 +692,31 @@ SGX_KERNEL(256) k_conv_dw2(int C, int H, int W, int Ho, int Wo, int pad, int P, 
     SGX_THREADS_END
 }
 
+// Two fp32 lanes of one v_pk_fma_f32: a wave64 v_fma_f32 occupies the SIMD for 4 cycles, the packed form does two FMAs in the same slot (that is how gfx950 reaches its
+// 157 TFLOP/s fp32 vector peak).  Each half is an ordinary fused multiply-add, so results equal the scalar chain bit for bit.  The weights stay in SCALAR registers:
+// gfx950 reads an SGPR pair as a packed source with full pair and op_sel semantics (checked on hardware, tools/ubench/pk_fma_sgpr.hip); the compiler never emits that form
+// (it copies scalars into VGPRs first, one v_mov per use), hence the inline assembly.
+#ifndef SGX_EMU
+typedef float sgx_f2 __attribute__((ext_vector_type(2)));
+SGX_DEV sgx_f2 sgx_mk2(float a, float b) { sgx_f2 r; r.x = a; r.y = b; return r; }
+// c + (w.x, w.x) * b   and   c + (w.y, w.y) * b, w in scalar registers
+SGX_DEV sgx_f2 sgx_fma2_wlo(sgx_f2 w, sgx_f2 b, sgx_f2 c) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(c) : "s"(w), "v"(b)); return c; }
+SGX_DEV sgx_f2 sgx_fma2_whi(sgx_f2 w, sgx_f2 b, sgx_f2 c) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(c) : "s"(w), "v"(b)); return c; }
+// c + w * b, w a scalar-register pair
+SGX_DEV sgx_f2 sgx_fma2_w(sgx_f2 w, sgx_f2 b, sgx_f2 c) { asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(c) : "s"(w), "v"(b)); return c; }
+// c + w * (d.x, d.x)   and   c + w * (d.y, d.y), w a scalar-register pair
+SGX_DEV sgx_f2 sgx_fma2_w_dlo(sgx_f2 w, sgx_f2 d, sgx_f2 c) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(c) : "s"(w), "v"(d)); return c; }
+SGX_DEV sgx_f2 sgx_fma2_w_dhi(sgx_f2 w, sgx_f2 d, sgx_f2 c) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(c) : "s"(w), "v"(d)); return c; }
+#else
+struct sgx_f2 { float x, y; };
+static inline sgx_f2 sgx_mk2(float a, float b) { sgx_f2 r; r.x = a; r.y = b; return r; }
+static inline sgx_f2 sgx_fma2_w(sgx_f2 a, sgx_f2 b, sgx_f2 c) { sgx_f2 r; r.x = fmaf(a.x, b.x, c.x); r.y = fmaf(a.y, b.y, c.y); return r; }
+static inline sgx_f2 sgx_fma2_wlo(sgx_f2 w, sgx_f2 b, sgx_f2 c) { return sgx_fma2_w(sgx_mk2(w.x, w.x), b, c); }
+static inline sgx_f2 sgx_fma2_whi(sgx_f2 w, sgx_f2 b, sgx_f2 c) { return sgx_fma2_w(sgx_mk2(w.y, w.y), b, c); }
+static inline sgx_f2 sgx_fma2_w_dlo(sgx_f2 w, sgx_f2 d, sgx_f2 c) { return sgx_fma2_w(w, sgx_mk2(d.x, d.x), c); }
+static inline sgx_f2 sgx_fma2_w_dhi(sgx_f2 w, sgx_f2 d, sgx_f2 c) { return sgx_fma2_w(w, sgx_mk2(d.y, d.y), c); }
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // k_conv_stem2<INC>: the 3 x 3, stride-2 stem (INC input channels -> up to 16 output channels), lean version of k_conv_stem: a workgroup owns a band of RB output rows of
 // one image, the INC padded input bands staged by sgx_stage_planes4; one task = 4 consecutive output pixels x ALL output channels (64 accumulators): per (c, i) row three
@@ -709,24 +734,32 @@ SGX_DEV void sgx_stem2_tasks(int tid, int outc, int nrows, int nbx, int Wo, int 
 #ifndef SGX_EMU
         asm volatile("" : "+s"(zoff));                            // opaque (but scalar) zero: keeps the 27 x 16 weight loads inside the task loop as scalar loads instead of 432 hoisted VGPRs
 #endif
-        float acc[16][4];
+        // Round 6: the 16 output channels as eight PAIRS per pixel — one v_pk_fma_f32 per pair and tap with the two weights as a scalar-register pair and the pixel's value
+        // broadcast from its half of a vector-register pair (sgx_fma2_w_dlo / _dhi: the forms of the detector's depthwise taps) — 216 instead of 432 multiply-add instructions
+        // per output pixel; per output the same fmaf chain in the same order, so the same bits.
+        sgx_f2 acc[8][4];
 #pragma unroll
-        for (int oc = 0; oc < 16; oc++) { const float bz = bias[min(oc, outc - 1)]; acc[oc][0] = bz; acc[oc][1] = bz; acc[oc][2] = bz; acc[oc][3] = bz; }
+        for (int op = 0; op < 8; op++) { const sgx_f2 bz = sgx_mk2(bias[min(2 * op, outc - 1)], bias[min(2 * op + 1, outc - 1)]); acc[op][0] = bz; acc[op][1] = bz; acc[op][2] = bz; acc[op][3] = bz; }
 #pragma unroll 1
         for (int c = 0; c < INC; c++)                               // run-time loops over (c, i): 3 taps x 16 scalar weights live at a time
 #pragma unroll 1
             for (int i = 0; i < 3; i++) {
-                float v[12];
+                sgx_f2 v[6];                                           // twelve consecutive input columns as six register pairs
                 const sgx_f4 *row = (const sgx_f4 *)(tile + c * plane_stride + (2 * oy + i) * pitch + 8 * bx);
 #pragma unroll
-                for (int g = 0; g < 3; g++) { const sgx_f4 x = row[g]; v[4 * g] = x.v[0]; v[4 * g + 1] = x.v[1]; v[4 * g + 2] = x.v[2]; v[4 * g + 3] = x.v[3]; }
+                for (int g = 0; g < 3; g++) { const sgx_f4 x = row[g]; v[2 * g] = sgx_mk2(x.v[0], x.v[1]); v[2 * g + 1] = sgx_mk2(x.v[2], x.v[3]); }
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
                     const float *w = WtT + zoff + ((c * 3 + i) * 3 + j) * 16;
 #pragma unroll
-                    for (int oc = 0; oc < 16; oc++)
+                    for (int op = 0; op < 8; op++) {
+                        const sgx_f2 wp = sgx_mk2(w[2 * op], w[2 * op + 1]);
 #pragma unroll
-                        for (int x = 0; x < 4; x++) acc[oc][x] = fmaf(w[oc], v[2 * x + j], acc[oc][x]);
+                        for (int x = 0; x < 4; x++) {                       // input column 2 x + j: the low or the high half of pair (2 x + j) / 2
+                            if (((2 * x + j) & 1) == 0) acc[op][x] = sgx_fma2_w_dlo(wp, v[(2 * x + j) >> 1], acc[op][x]);
+                            else acc[op][x] = sgx_fma2_w_dhi(wp, v[(2 * x + j) >> 1], acc[op][x]);
+                        }
+                    }
                 }
             }
         const size_t pix = (size_t)(r0 + oy) * Wo + (size_t)(4 * bx);
@@ -737,7 +770,7 @@ SGX_DEV void sgx_stem2_tasks(int tid, int outc, int nrows, int nbx, int Wo, int 
                 const size_t idx = (size_t)oc * Ho * Wo + pix;
                 float res[4];
 #pragma unroll
-                for (int x = 0; x < 4; x++) res[x] = sgx_epi_mode<MODE>(epi, acc[oc][x], tbase + idx + (size_t)min(x, nx - 1), 0);
+                for (int x = 0; x < 4; x++) res[x] = sgx_epi_mode<MODE>(epi, (oc & 1) ? acc[oc >> 1][x].y : acc[oc >> 1][x].x, tbase + idx + (size_t)min(x, nx - 1), 0);
                 if (nx == 4) { sgx_f4 pk; pk.v[0] = res[0]; pk.v[1] = res[1]; pk.v[2] = res[2]; pk.v[3] = res[3]; memcpy(out + idx, &pk, 16); }
                 else for (int x = 0; x < nx; x++) out[idx + x] = res[x];
             }
