@@ -132,7 +132,8 @@ static Stem2Geom stem2_geom(const Op &op)
 {
     Stem2Geom g;
     g.nbx4 = (op.Wo + 3) / 4; g.pitch4 = ((g.nbx4 - 1) * 4 * op.stride + 3 * op.stride + op.k + 3) & ~3;
-    g.RB = std::max(1, std::min(op.Ho, ((10240 / (3 * g.pitch4)) - 3) / 2 + 1));       // LDS = 3 x ((RB - 1) 2 + 3) x pitch4 floats, about 40 KB (3-4 workgroups per CU)
+    static const int env_words = sgx_getenv("SGX_DET_STEM_WORDS") ? atoi(sgx_getenv("SGX_DET_STEM_WORDS")) : 13824;      // tuning tap: LDS budget of the band tile in floats.  Round 6 sweep at 512 frames (k_stem_pre, ms): 4608 0.66, 6400 0.57, 8192 0.47, 10240 0.48-0.49 (rounds 3-6), 12000 0.49, 13824 0.44-0.45 (seven output rows per band), 17408 0.60, 24000 0.83
+    g.RB = std::max(1, std::min(op.Ho, ((env_words / (3 * g.pitch4)) - 3) / 2 + 1));       // LDS = 3 x ((RB - 1) 2 + 3) x pitch4 floats, about 54 KB
     g.nbands = (op.Ho + g.RB - 1) / g.RB;
     g.lds = (size_t)3 * ((g.RB - 1) * 2 + 3) * g.pitch4 * 4;
     return g;
