@@ -829,7 +829,10 @@ SGX_KERNEL(256) k_stem_pre(const uint8_t *__restrict__ img, int H, int ipitch, c
     SGX_THREADS_BEGIN(tid)
     const uint8_t *base = img + (size_t)b * H * ipitch;
     const float mean[3] = { m0, m1, m2 };
-    constexpr int U = 4;                                            // independent elements per thread and round: their loads are in flight together (no divergent control flow)
+#ifndef SGX_STEM_U
+#define SGX_STEM_U 4
+#endif
+    constexpr int U = SGX_STEM_U;                                   // independent elements per thread and round: their loads are in flight together (no divergent control flow)
     const int total = Rin * pitch;
     for (int t0 = tid; t0 < total; t0 += 256 * U) {
         unsigned long long ra[U], rb[U]; SgxDetTab tx[U], ty[U]; int dst[U];

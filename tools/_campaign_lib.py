@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def taps_lib():
     """tests/taps/libsgx_taps.so: the product sources with the test / tuning taps of include/sgx_debug.h and the SGX_* environment switches (make -C sg_slam_amd/csrc taps)"""
     from sg_slam_amd.capi import SgxLib
-    lib = SgxLib(os.path.join(ROOT, 'tests', 'taps', 'libsgx_taps.so'))
+    lib = SgxLib(os.path.join(ROOT, os.environ.get('SGX_TOOL_TAPS_LIB', os.path.join('tests', 'taps', 'libsgx_taps.so'))))      # SGX_TOOL_TAPS_LIB: an A/B variant (tools/ab_build_det.sh)
     assert 'gfx950' in lib.version() and lib.has_taps
     return lib
 
