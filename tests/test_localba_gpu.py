@@ -72,7 +72,7 @@ def test_ba_config4_matches_oracle_fixture(gpulib, oracle):
     assert (runs[1][0] == poses).all() and (runs[1][1] == points).all() and (runs[1][2] == erase).all() and runs[1][3]['iterations'] == stats['iterations']
 
 
-@pytest.mark.parametrize('case', ['small', 'fixed_poses', 'band'])
+@pytest.mark.parametrize('case', ['small', 'fixed_poses', 'band', 'wide_landmark'])
 def test_device_job_list_equals_host_built_gpu(gpulib_taps, oracle, case):
     """Round 6: the Schur job list (which pairs of edges feed which 6 x 6 block of the reduced camera system, in the reference's subtraction order) is built by kernels
     (k_ba_jobs_row / k_ba_jobs_scan) instead of a host pass + 25 MB upload.  Same list -> same sums in the same order -> the whole bundle adjustment must come out with the
@@ -80,6 +80,15 @@ def test_device_job_list_equals_host_built_gpu(gpulib_taps, oracle, case):
     from scenes import make_big_ba_problem
     lib = gpulib_taps
     if case == 'band': prob, _, _ = make_big_ba_problem(600, 15000)
+    elif case == 'wide_landmark':
+        # one landmark seen by 150 keyframes (the fill pass walks a landmark's edges 64 at a time) and twice by one of them (two jobs of one landmark in the same block: the
+        # in-tile rank), spliced into the middle of the edge list; the copied observations are inconsistent with the landmark, so these edges also exercise the classification pass
+        prob, _, _ = make_big_ba_problem(300, 6000)
+        ep, el, eo, ei = (np.asarray(prob[k]) for k in ('edge_pose', 'edge_point', 'edge_obs', 'edge_info'))
+        src = [int(np.flatnonzero(ep == q)[0]) for q in list(range(40, 190)) + [77]]
+        at = len(ep) // 2
+        prob['edge_pose'] = np.concatenate([ep[:at], ep[src], ep[at:]]).astype('i4'); prob['edge_point'] = np.concatenate([el[:at], np.full(len(src), 5, 'i4'), el[at:]]).astype('i4')
+        prob['edge_obs'] = np.concatenate([eo[:at], eo[src], eo[at:]]).astype('f4'); prob['edge_info'] = np.concatenate([ei[:at], ei[src], ei[at:]]).astype('f4')
     else: prob, _, _ = make_ba_problem(oracle, n_free=30 if case == 'small' else 20, n_fixed=0 if case == 'small' else 40, n_points=1500 if case == 'small' else 2000, seed=21)
     out = []
     try:
