@@ -25,6 +25,7 @@ int sgx_debug_flow_affine_batch_dev(int batch, int cap, const sgx_keypoint *d_ke
                                     int max_boxes, float *d_prev_xy, void *stream);
 int sgx_pose_opt_debug_set_threads(int threads_per_frame);   /* tuning / test tap: 0 = default (256 threads = four waves per frame), 64 = one wave per frame, 256 */
 int sgx_ba_debug_last_plan(int32_t plan[4]);    /* test tap: solver plan of the last bundle adjustment of this process: { 0 dense / 1 envelope, column steps of branch A, of branch B (0 = one branch), unknowns of their separator } */
+int sgx_ba_debug_set_init(int mode);               /* test tap: initialisation of the reduced camera system when the envelope solver runs: 0 only the solver's tiles (default), 1 the whole matrix, 2 the whole matrix NaN first, then the tiles */
 int sgx_ba_debug_set_jobs(int host);               /* test tap: 1 = the bundle adjustments of this thread build their Schur job list on the host (A/B arm of the device builder), 0 = on the device (default) */
 int sgx_ba_debug_set_solver(int mode);             /* test / tuning tap: reduced-camera-system solver of the bundle adjustments: -1 default (SGX_BA_SOLVER or auto), 0 auto, 1 dense blocked Cholesky, 2 envelope solver */
 int sgx_det_debug_read_blob(sgx_det *h, const char *blob_name, int image, float *dst, int cap, int *n);

@@ -85,7 +85,7 @@ SYMBOLS = [
 # the test / tuning taps include/sgx_debug.h declares: exported by tests/taps/libsgx_taps.so and the emulator (-DSGX_DEBUG_TAPS) only, never by the product library
 TAP_SYMBOLS = [
     'sgx_orb_debug_level_geometry', 'sgx_orb_debug_set_unfused_pyramid', 'sgx_orb_debug_read_level', 'sgx_orb_debug_read_candidates',
-    'sgx_orb_debug_run_octree', 'sgx_pose_opt_debug_set_threads', 'sgx_ba_debug_set_solver', 'sgx_ba_debug_set_jobs', 'sgx_ba_debug_last_plan', 'sgx_det_debug_read_blob',
+    'sgx_orb_debug_run_octree', 'sgx_pose_opt_debug_set_threads', 'sgx_ba_debug_set_solver', 'sgx_ba_debug_set_jobs', 'sgx_ba_debug_set_init', 'sgx_ba_debug_last_plan', 'sgx_det_debug_read_blob',
     'sgx_det_debug_detection_output', 'sgx_debug_flow_affine_batch_dev', 'sgx_det_debug_set_fusion', 'sgx_det_debug_set_legacy_kernels',
     'sgx_det_debug_set_block_fusion', 'sgx_det_debug_set_irb', 'sgx_det_debug_set_gemm', 'sgx_det_debug_time_ops', 'sgx_det_debug_run_step', 'sgx_flow_debug_read_level',
     'sgx_flow_debug_level_size', 'sgx_debug_corun_bf16',
@@ -221,6 +221,7 @@ class SgxLib:
             d.sgx_pose_opt_debug_set_threads.argtypes = [C.c_int]
             d.sgx_ba_debug_set_solver.argtypes = [C.c_int]
             d.sgx_ba_debug_set_jobs.argtypes = [C.c_int]
+            d.sgx_ba_debug_set_init.argtypes = [C.c_int]
             d.sgx_ba_debug_last_plan.argtypes = [C.c_void_p]
             d.sgx_det_debug_detection_output.argtypes = [vp, vp, vp, C.c_int, C.POINTER(DetResult)]
             d.sgx_det_debug_read_blob.argtypes = [vp, C.c_char_p, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]

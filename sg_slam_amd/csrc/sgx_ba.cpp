@@ -70,6 +70,7 @@ static char *stage_reserve(size_t bytes)
 #endif
     g_stage_cap = bytes + bytes / 4; return g_stage;
 }
+static thread_local int g_ba_init_mode = 0;            // test tap (sgx_ba_debug_set_init): 0 = envelope solver: only its tiles are initialised (default), 1 = the whole matrix, 2 = the whole matrix NaN, then the tiles
 static thread_local int g_ba_jobs_host = 0;            // test tap (sgx_ba_debug_set_jobs): 1 = build the Schur job list on the host (the emulator's path; A/B arm of the device builder)
 static thread_local int g_ba_solver = -1;              // test / tuning tap (sgx_ba_debug_set_solver): -1 = SGX_BA_SOLVER or auto, 0 auto, 1 dense blocked Cholesky, 2 envelope solver
 
@@ -85,6 +86,7 @@ struct BA {
     double *part_chi, *part_scale;      // device scalars block: [ok | part_scale[nblk_v] | part_chi[nblk_e]] read back with ONE copy per trial
     int nblk_e, nblk_v;
     int *env_rstart, *env_rows;          // narrow-envelope solver: rows of column step k = env_rows[env_rstart[k] .. env_rstart[k+1]) (NULL: dense solver)
+    int env_nrows = 0;                   // entries of env_rows
     int env_nA, env_nB;                  // two-branch elimination: column steps [0, nA) and [nA, nA + nB) are independent, the rest is their separator (nB = 0: one branch)
     double *env_S2, *env_x2;             // the second branch's contributions to the separator (nsep x nsep, nsep)
     std::vector<double> hpart;
@@ -327,6 +329,11 @@ static int optimize(BA &B, int iterations, int *iters_done, double *final_chi)
             sgx_prof_begin(SGX_K_BA_SCHUR, (sgx_stream_t)0);
             if (B.NP > 0) {
                 const int g = (int)(((size_t)B.NP * B.NP + SGX_BA_THREADS - 1) / SGX_BA_THREADS);
+                if (B.env_rstart && g_ba_init_mode != 1) {       // envelope solver: only the tiles it reads
+                    if (g_ba_init_mode == 2) SGX_CHECK_HIP(hipMemsetAsync(B.S, 0xFF, sizeof(double) * (size_t)B.NP * B.NP, 0));      // (test tap) all ones = NaN everywhere first
+                    const int nt = (B.NP + SGX_NB - 1) / SGX_NB;
+                    SGX_LAUNCH(k_ba_schur_init_env, dim3((unsigned)(nt + B.env_nrows)), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.nf, B.Hpp, lambda, B.S, B.coef, nt, B.env_rstart, B.env_rows);
+                } else
                 SGX_LAUNCH(k_ba_schur_init, dim3(g > 4096 ? 4096 : g), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.nf, B.Hpp, lambda, B.S, B.coef);
             }
             SGX_LAUNCH(k_ba_dinv, dim3((B.nl + SGX_BA_THREADS - 1) / SGX_BA_THREADS), dim3(SGX_BA_THREADS), (sgx_stream_t)0, B.nl, B.pt_active, B.Hll, lambda, B.Dinv);
@@ -375,6 +382,7 @@ static int optimize(BA &B, int iterations, int *iters_done, double *final_chi)
 
 static thread_local int g_ba_last_plan[4] = { 0, 0, 0, 0 };
 SGX_TAP int sgx_ba_debug_last_plan(int32_t plan[4]) { if (!plan) return SGX_ERR_INVALID; for (int i = 0; i < 4; i++) plan[i] = g_ba_last_plan[i]; return SGX_OK; }
+SGX_TAP int sgx_ba_debug_set_init(int mode) { g_ba_init_mode = mode < 0 ? 0 : (mode > 2 ? 2 : mode); return SGX_OK; }
 SGX_TAP int sgx_ba_debug_set_jobs(int host) { g_ba_jobs_host = host ? 1 : 0; return SGX_OK; }
 SGX_TAP int sgx_ba_debug_set_solver(int mode) { g_ba_solver = mode < 0 ? -1 : (mode > 2 ? 2 : mode); return SGX_OK; }
 
@@ -556,6 +564,7 @@ static int ba_run(const sgx_ba_problem *P, const sgx_camera *cam, const volatile
         SGX_CHECK_HIP(hipMemcpy(base, stage, in_bytes, hipMemcpyHostToDevice));
     }
     if (env_rstart.empty()) { B.env_rstart = nullptr; B.env_rows = nullptr; }
+    B.env_nrows = env_rstart.empty() ? 0 : env_rstart.back();
     B.env_nA = env_nA; B.env_nB = env_nB; B.env_x2 = B.env_S2 + env_nsep * env_nsep;
     g_ba_last_plan[0] = B.env_rstart ? 1 : 0; g_ba_last_plan[1] = env_nB > 0 ? env_nA : (B.env_rstart ? (B.NP + SGX_NB - 1) / SGX_NB : 0); g_ba_last_plan[2] = env_nB; g_ba_last_plan[3] = (int)env_nsep;
     SGX_CHECK_HIP(hipMemsetAsync(B.xp, 0, sizeof(double) * (B.NP ? B.NP : 1), 0));

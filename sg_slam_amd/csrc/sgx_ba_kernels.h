@@ -1321,6 +1321,32 @@ __global__ void __launch_bounds__(256) k_ba_jobs_scan(int nf, const int *row_job
 }
 #endif
 
+// k_ba_schur_init_env (round 6): the same values, written only where the envelope solver looks — the diagonal tiles and the tiles (r, k), r in R(k), of its column steps (the
+// symbolic factorisation's pattern, which contains every coupled pose pair and every pose that straddles two tiles).  At 2 000 keyframes that is 16 MB instead of the 1.15 GB of the
+// full 11 994 x 11 994 matrix, per LM trial.  Everything else in S stays undefined: k_ba_schur_pairs read-modify-writes the mirrored (upper) blocks there, nobody reads them
+// (tests: the whole matrix poisoned with NaN first — sgx_ba_debug_set_init(2) — gives the same bits).  One workgroup per tile.
+SGX_KERNEL(SGX_BA_THREADS) k_ba_schur_init_env(int nf, const double *Hpp, double lambda, double *S, double *coef, int nt, const int *rstart, const int *rows)
+{
+    SGX_THREADS_BEGIN(tid)
+    const int NP = 6 * nf, t = (int)blockIdx.x;
+    int tr = t, tc = t;
+    if (t >= nt) {
+        const int q = t - nt; int lo = 0, hi = nt;                // the column step of list entry q: the last k with rstart[k] <= q
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (rstart[mid] <= q) lo = mid; else hi = mid; }
+        tc = lo; tr = rows[q];
+    }
+    for (int e = tid; e < SGX_NB * SGX_NB; e += SGX_BA_THREADS) {
+        const int r = tr * SGX_NB + e / SGX_NB, c = tc * SGX_NB + e % SGX_NB;
+        if (r < NP && c < NP) {
+            double v = 0;
+            if (r / 6 == c / 6) v = Hpp[(size_t)(r / 6) * 36 + 6 * (r % 6) + (c % 6)] + (r == c ? lambda : 0.0);
+            S[(size_t)r * NP + c] = v;
+        }
+    }
+    if (t == 0) for (int i = tid; i < NP; i += SGX_BA_THREADS) coef[i] = 0;
+    SGX_THREADS_END
+}
+
 // k_ba_hpl_dinv (round 6): W_k = Hpl_k Dinv_l, once per active edge and trial (6 x 3 per edge) instead of once per job and destination column inside k_ba_schur_pairs (every job of
 // edge k1 — about eight per edge, six columns each — recomputed the same three sums and fetched Dinv and the edge record for them).  The sums are the expressions k_ba_schur_pairs
 // evaluated, in the same order, so the reduced system keeps its bits.

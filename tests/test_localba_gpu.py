@@ -103,3 +103,24 @@ def test_device_job_list_equals_host_built_gpu(gpulib_taps, oracle, case):
     assert a[3]['iterations'] == b[3]['iterations'] and a[3]['chi2'] == b[3]['chi2']
     assert (a[2] == b[2]).all() and a[2].sum() > 0          # edges were switched off, so the second list differs from the first
     assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes()
+
+
+def test_envelope_tiles_only_initialisation_gpu(gpulib_taps):
+    """Round 6: with the envelope solver only the tiles of its column steps are initialised per LM trial (k_ba_schur_init_env: 16 MB instead of the 1.15 GB dense matrix at 2 000
+    keyframes).  Same bits as the full initialisation — also when the whole matrix is NaN before the tiles are written (mode 2): nothing outside the tiles is ever read."""
+    from scenes import make_big_ba_problem
+    lib = gpulib_taps
+    prob, _, _ = make_big_ba_problem(600, 15000)
+    out = {}
+    try:
+        for mode in (1, 0, 2):
+            lib.tap('sgx_ba_debug_set_init')(mode)
+            p = {k: (v.copy() if hasattr(v, 'copy') else v) for k, v in prob.items()}
+            er, st = Optimizer.LocalBundleAdjustment(p, CAM, lib=lib)
+            import ctypes as C
+            pl = (C.c_int32 * 4)(); lib.check(lib.tap('sgx_ba_debug_last_plan')(pl)); assert pl[0] == 1, 'the envelope solver must have run'
+            out[mode] = (np.ascontiguousarray(p['poses']).tobytes(), np.ascontiguousarray(p['points']).tobytes(), er.tobytes(), st['iterations'], st['chi2'])
+    finally:
+        lib.tap('sgx_ba_debug_set_init')(0)
+    assert np.isfinite(out[1][4]).all()
+    assert out[0] == out[1] and out[2] == out[1]
